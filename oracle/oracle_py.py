@@ -1,0 +1,194 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes binding of oracle/libx265oracle_{8,10}.so.
+
+All buffers are flat numpy arrays (pixel dtype = uint8 for depth 8, uint16 above; int16 for
+shorts); offsets/strides are in elements.  Methods that write return a modified COPY of the
+destination buffer that was passed in, so callers can check untouched bytes as well.
+The same method vocabulary is implemented by tests/backends.py for the reference process and the
+HIP library.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_P = C.c_void_p
+_IP = C.c_ssize_t
+
+
+def _ptr(a, off=0):
+    return C.c_void_p(a.ctypes.data + off * a.itemsize)
+
+
+class Oracle:
+    def __init__(self, depth):
+        self.depth = depth
+        self.pixel = np.uint8 if depth == 8 else np.uint16
+        path = os.path.join(HERE, "libx265oracle_%d.so" % depth)
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.xo_sse_pp.restype = C.c_uint64
+        L.xo_sse_ss.restype = C.c_uint64
+        L.xo_ssd_s.restype = C.c_uint64
+        L.xo_quant.restype = C.c_uint32
+        L.xo_nquant.restype = C.c_uint32
+        L.xo_copy_count.restype = C.c_uint32
+        L.xo_dct_matrix.restype = C.c_void_p
+        assert L.xo_bit_depth() == depth
+
+    # ---- pixel compare ----
+    def sad(self, w, h, A, sa, oa, B, sb, ob):
+        return self.lib.xo_sad(w, h, _ptr(A, oa), _IP(sa), _ptr(B, ob), _IP(sb))
+
+    def satd(self, w, h, A, sa, oa, B, sb, ob):
+        return self.lib.xo_satd(w, h, _ptr(A, oa), _IP(sa), _ptr(B, ob), _IP(sb))
+
+    def sa8d(self, n, A, sa, oa, B, sb, ob):
+        return self.lib.xo_sa8d(n, _ptr(A, oa), _IP(sa), _ptr(B, ob), _IP(sb))
+
+    def psy_cost_pp(self, n, A, sa, oa, B, sb, ob):
+        return self.lib.xo_psy_cost_pp(n, _ptr(A, oa), _IP(sa), _ptr(B, ob), _IP(sb))
+
+    def sse_pp(self, n, A, sa, oa, B, sb, ob):
+        return self.lib.xo_sse_pp(n, n, _ptr(A, oa), _IP(sa), _ptr(B, ob), _IP(sb))
+
+    def sse_ss(self, n, A, sa, oa, B, sb, ob):
+        return self.lib.xo_sse_ss(n, n, _ptr(A, oa), _IP(sa), _ptr(B, ob), _IP(sb))
+
+    def ssd_s(self, n, A, sa, oa):
+        return self.lib.xo_ssd_s(n, _ptr(A, oa), _IP(sa))
+
+    def sad_x3(self, w, h, F, of, R, rs, offs):
+        res = np.zeros(4, np.int32)
+        self.lib.xo_sad_x3(w, h, _ptr(F, of), _ptr(R, offs[0]), _ptr(R, offs[1]), _ptr(R, offs[2]), _IP(rs), _ptr(res))
+        return res[:3].copy()
+
+    def sad_x4(self, w, h, F, of, R, rs, offs):
+        res = np.zeros(4, np.int32)
+        self.lib.xo_sad_x4(w, h, _ptr(F, of), _ptr(R, offs[0]), _ptr(R, offs[1]), _ptr(R, offs[2]), _ptr(R, offs[3]), _IP(rs), _ptr(res))
+        return res
+
+    # ---- block ops ----
+    def calcresidual(self, n, fenc, pred, resi, stride):
+        r = resi.copy(); self.lib.xo_calcresidual(n, _ptr(fenc), _ptr(pred), _ptr(r), _IP(stride)); return r
+
+    def sub_ps(self, n, dst, ds, s0, s1, ss0, ss1):
+        d = dst.copy(); self.lib.xo_sub_ps(n, n, _ptr(d), _IP(ds), _ptr(s0), _ptr(s1), _IP(ss0), _IP(ss1)); return d
+
+    def add_ps(self, n, dst, ds, s0, s1, ss0, ss1):
+        d = dst.copy(); self.lib.xo_add_ps(n, n, _ptr(d), _IP(ds), _ptr(s0), _ptr(s1), _IP(ss0), _IP(ss1)); return d
+
+    def copy_pp(self, w, h, dst, ds, src, ss):
+        d = dst.copy(); self.lib.xo_copy_pp(w, h, _ptr(d), _IP(ds), _ptr(src), _IP(ss)); return d
+
+    def copy_ss(self, n, dst, ds, src, ss):
+        d = dst.copy(); self.lib.xo_copy_ss(n, n, _ptr(d), _IP(ds), _ptr(src), _IP(ss)); return d
+
+    def copy_sp(self, n, dst, ds, src, ss):
+        d = dst.copy(); self.lib.xo_copy_sp(n, n, _ptr(d), _IP(ds), _ptr(src), _IP(ss)); return d
+
+    def copy_ps(self, n, dst, ds, src, ss):
+        d = dst.copy(); self.lib.xo_copy_ps(n, n, _ptr(d), _IP(ds), _ptr(src), _IP(ss)); return d
+
+    def blockfill_s(self, n, dst, ds, val):
+        d = dst.copy(); self.lib.xo_blockfill_s(n, _ptr(d), _IP(ds), C.c_int16(val)); return d
+
+    def cpy2Dto1D_shl(self, n, dst, src, ss, shift):
+        d = dst.copy(); self.lib.xo_cpy2Dto1D_shl(n, _ptr(d), _ptr(src), _IP(ss), shift); return d
+
+    def cpy2Dto1D_shr(self, n, dst, src, ss, shift):
+        d = dst.copy(); self.lib.xo_cpy2Dto1D_shr(n, _ptr(d), _ptr(src), _IP(ss), shift); return d
+
+    def cpy1Dto2D_shl(self, n, dst, src, ds, shift):
+        d = dst.copy(); self.lib.xo_cpy1Dto2D_shl(n, _ptr(d), _ptr(src), _IP(ds), shift); return d
+
+    def cpy1Dto2D_shr(self, n, dst, src, ds, shift):
+        d = dst.copy(); self.lib.xo_cpy1Dto2D_shr(n, _ptr(d), _ptr(src), _IP(ds), shift); return d
+
+    def transpose(self, n, dst, src, ss):
+        d = dst.copy(); self.lib.xo_transpose(n, _ptr(d), _ptr(src), _IP(ss)); return d
+
+    def addAvg(self, w, h, s0, s1, dst, ss0, ss1, ds):
+        d = dst.copy(); self.lib.xo_addAvg(w, h, _ptr(s0), _ptr(s1), _ptr(d), _IP(ss0), _IP(ss1), _IP(ds)); return d
+
+    def pixelavg_pp(self, w, h, dst, ds, s0, ss0, s1, ss1):
+        d = dst.copy(); self.lib.xo_pixelavg_pp(w, h, _ptr(d), _IP(ds), _ptr(s0), _IP(ss0), _ptr(s1), _IP(ss1)); return d
+
+    def weight_sp(self, src, dst, ss, ds, w, h, w0, rnd, shift, offset):
+        d = dst.copy(); self.lib.xo_weight_sp(_ptr(src), _ptr(d), _IP(ss), _IP(ds), w, h, w0, rnd, shift, offset); return d
+
+    def weight_pp(self, src, dst, stride, w, h, w0, rnd, shift, offset):
+        d = dst.copy(); self.lib.xo_weight_pp(_ptr(src), _ptr(d), _IP(stride), w, h, w0, rnd, shift, offset); return d
+
+    def scale1D_128to64(self, dst, src):
+        d = dst.copy(); self.lib.xo_scale1D_128to64(_ptr(d), _ptr(src)); return d
+
+    def scale2D_64to32(self, dst, src, stride):
+        d = dst.copy(); self.lib.xo_scale2D_64to32(_ptr(d), _ptr(src), _IP(stride)); return d
+
+    # ---- transforms ----
+    def dct(self, n, src, stride):
+        d = np.zeros(n * n, np.int16); self.lib.xo_dct(n, _ptr(src), _ptr(d), _IP(stride)); return d
+
+    def dst4(self, src, stride):
+        d = np.zeros(16, np.int16); self.lib.xo_dst4(_ptr(src), _ptr(d), _IP(stride)); return d
+
+    def idct(self, n, src, dst, stride):
+        d = dst.copy(); self.lib.xo_idct(n, _ptr(src), _ptr(d), _IP(stride)); return d
+
+    def idst4(self, src, dst, stride):
+        d = dst.copy(); self.lib.xo_idst4(_ptr(src), _ptr(d), _IP(stride)); return d
+
+    def quant(self, coef, qc, qbits, add, num):
+        du = np.zeros(num, np.int32); q = np.zeros(num, np.int16)
+        ns = self.lib.xo_quant(_ptr(coef), _ptr(qc), _ptr(du), _ptr(q), qbits, add, num)
+        return ns, q, du
+
+    def nquant(self, coef, qc, qbits, add, num):
+        q = np.zeros(num, np.int16)
+        ns = self.lib.xo_nquant(_ptr(coef), _ptr(qc), _ptr(q), qbits, add, num)
+        return ns, q
+
+    def dequant_normal(self, q, num, scale, shift):
+        c = np.zeros(num, np.int16); self.lib.xo_dequant_normal(_ptr(q), _ptr(c), num, scale, shift); return c
+
+    def dequant_scaling(self, q, deq, num, per, shift):
+        c = np.zeros(num, np.int16); self.lib.xo_dequant_scaling(_ptr(q), _ptr(deq), _ptr(c), num, per, shift); return c
+
+    def count_nonzero(self, n, q):
+        return self.lib.xo_count_nonzero(n, _ptr(q))
+
+    def copy_cnt(self, n, resi, rs):
+        c = np.zeros(n * n, np.int16); ns = self.lib.xo_copy_count(n, _ptr(c), _ptr(resi), _IP(rs)); return ns, c
+
+    def denoise_dct(self, coef, ressum, offset, num):
+        c = coef.copy(); r = ressum.copy(); self.lib.xo_denoise_dct(_ptr(c), _ptr(r), _ptr(offset), num); return c, r
+
+    def dct_matrix(self, n):
+        p = self.lib.xo_dct_matrix(n)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), (n * n,)).copy()
+
+    # ---- interpolation (taps 8 luma / 4 chroma) ----
+    def interp(self, kind, taps, w, h, src, ss, so, dst, ds, idx, idx2=0):
+        d = dst.copy()
+        L = self.lib
+        if kind == "hpp": L.xo_interp_hpp(taps, w, h, _ptr(src, so), _IP(ss), _ptr(d), _IP(ds), idx)
+        elif kind == "hps": L.xo_interp_hps(taps, w, h, _ptr(src, so), _IP(ss), _ptr(d), _IP(ds), idx, idx2)
+        elif kind == "vpp": L.xo_interp_vpp(taps, w, h, _ptr(src, so), _IP(ss), _ptr(d), _IP(ds), idx)
+        elif kind == "vps": L.xo_interp_vps(taps, w, h, _ptr(src, so), _IP(ss), _ptr(d), _IP(ds), idx)
+        elif kind == "vsp": L.xo_interp_vsp(taps, w, h, _ptr(src, so), _IP(ss), _ptr(d), _IP(ds), idx)
+        elif kind == "vss": L.xo_interp_vss(taps, w, h, _ptr(src, so), _IP(ss), _ptr(d), _IP(ds), idx)
+        elif kind == "hvpp": L.xo_interp_hvpp(taps, w, h, _ptr(src, so), _IP(ss), _ptr(d), _IP(ds), idx, idx2)
+        elif kind == "p2s": L.xo_p2s(w, h, _ptr(src, so), _IP(ss), _ptr(d), _IP(ds))
+        else: raise ValueError(kind)
+        return d
+
+    # ---- intra ----
+    def intra_filter(self, n, samples, filt):
+        f = filt.copy(); self.lib.xo_intra_filter(n, _ptr(samples), _ptr(f)); return f
+
+    def intra_pred(self, n, src, dst, ds, mode, bfilter):
+        d = dst.copy(); self.lib.xo_intra_pred(n, _ptr(d), _IP(ds), _ptr(src), mode, bfilter); return d
+
+    def intra_allangs(self, n, ref, filt, bluma):
+        d = np.zeros(33 * n * n, self.pixel); self.lib.xo_intra_allangs(n, _ptr(d), _ptr(ref), _ptr(filt), bluma); return d

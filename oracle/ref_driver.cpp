@@ -1,0 +1,347 @@
+/*
+ * ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Our own driver (no reference code in here) that is compiled TOGETHER WITH the
+ * reference's primitive sources where they lie under /root/reference
+ * (common/pixel.cpp, dct.cpp, ipfilter.cpp, intrapred.cpp, constants.cpp,
+ * lowpassdct.cpp) into oracle/_ref/x265ref_{8,10}.  It fills a real
+ * EncoderPrimitives table through the reference's own setup*Primitives_c()
+ * functions (primitives.cpp:56-75 lists them) and executes slot calls requested
+ * over stdin/stdout, so the Python tests can compare oracle/x265_oracle.c (and
+ * generate tests/golden) against the REAL reference arithmetic.
+ *
+ * Wire format (little endian), request:
+ *   u32 oplen, op bytes, u32 n_ints, i64 ints[], u32 n_bufs, { u64 len, bytes }[]
+ * response:
+ *   u32 n_bufs, { u64 len, bytes }[]          (n_bufs = 0xFFFFFFFF on unknown op)
+ */
+#include "common.h"
+#include "primitives.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <chrono>
+
+namespace X265_NS {
+void setupPixelPrimitives_c(EncoderPrimitives& p);
+void setupDCTPrimitives_c(EncoderPrimitives& p);
+void setupFilterPrimitives_c(EncoderPrimitives& p);
+void setupIntraPrimitives_c(EncoderPrimitives& p);
+void setupLowPassPrimitives_c(EncoderPrimitives& p);
+extern const int16_t g_t4[4][4];
+extern const int16_t g_t8[8][8];
+extern const int16_t g_t16[16][16];
+extern const int16_t g_t32[32][32];
+}
+using namespace X265_NS;
+
+static EncoderPrimitives T;
+
+typedef std::vector<uint8_t> Buf;
+struct Req { std::string op; std::vector<int64_t> I; std::vector<Buf> B; };
+
+static bool rd(void* p, size_t n) { return fread(p, 1, n, stdin) == n; }
+static void wr(const void* p, size_t n) { fwrite(p, 1, n, stdout); }
+
+static bool readReq(Req& r)
+{
+    uint32_t n;
+    if (!rd(&n, 4)) return false;
+    r.op.resize(n); if (n && !rd(&r.op[0], n)) return false;
+    if (!rd(&n, 4)) return false;
+    r.I.resize(n); if (n && !rd(r.I.data(), 8 * (size_t)n)) return false;
+    if (!rd(&n, 4)) return false;
+    r.B.resize(n);
+    for (uint32_t i = 0; i < n; i++)
+    {
+        uint64_t l; if (!rd(&l, 8)) return false;
+        r.B[i].resize(l); if (l && !rd(r.B[i].data(), l)) return false;
+    }
+    return true;
+}
+static void writeResp(const std::vector<Buf>& out)
+{
+    uint32_t n = (uint32_t)out.size(); wr(&n, 4);
+    for (auto& b : out) { uint64_t l = b.size(); wr(&l, 8); if (l) wr(b.data(), l); }
+    fflush(stdout);
+}
+template<class V> static Buf scalar(V v) { Buf b(sizeof(V)); memcpy(b.data(), &v, sizeof(V)); return b; }
+
+/* map (w,h) to LumaPU without primitives.cpp's table */
+static int puIndex(int w, int h)
+{
+    static const int dims[25][2] = { {4,4},{8,8},{16,16},{32,32},{64,64},{8,4},{4,8},{16,8},{8,16},{32,16},{16,32},{64,32},{32,64},
+        {16,12},{12,16},{16,4},{4,16},{32,24},{24,32},{32,8},{8,32},{64,48},{48,64},{64,16},{16,64} };
+    for (int i = 0; i < 25; i++) if (dims[i][0] == w && dims[i][1] == h) return i;
+    return -1;
+}
+static int cuIndex(int n) { int i = 0; while ((4 << i) < n) i++; return i; }
+
+#define PX(b, off) (reinterpret_cast<pixel*>((b).data()) + (off))
+#define S16(b, off) (reinterpret_cast<int16_t*>((b).data()) + (off))
+#define I32(b) (reinterpret_cast<int32_t*>((b).data()))
+
+static bool dispatch(Req& r, std::vector<Buf>& out)
+{
+    const std::string& op = r.op;
+    auto& I = r.I; auto& B = r.B;
+    if (op == "info")
+    {
+        out.push_back(scalar<int32_t>(X265_DEPTH));
+        out.push_back(scalar<int32_t>((int32_t)sizeof(EncoderPrimitives)));
+        out.push_back(scalar<int32_t>((int32_t)sizeof(sse_t)));
+        return true;
+    }
+    if (op == "layout")
+    {   /* byte offsets of the slots the HIP back end fills; checked against include/x265hip.h */
+        EncoderPrimitives* z = 0; (void)z;
+        std::vector<int32_t> v;
+#define OFF(m) v.push_back((int32_t)offsetof(EncoderPrimitives, m))
+        OFF(pu); OFF(pu[1]); OFF(pu[0].sad); OFF(pu[0].sad_x3); OFF(pu[0].sad_x4); OFF(pu[0].ads); OFF(pu[0].satd);
+        OFF(pu[0].luma_hpp); OFF(pu[0].luma_hps); OFF(pu[0].luma_vpp); OFF(pu[0].luma_vps); OFF(pu[0].luma_vsp); OFF(pu[0].luma_vss);
+        OFF(pu[0].luma_hvpp); OFF(pu[0].pixelavg_pp); OFF(pu[0].addAvg); OFF(pu[0].copy_pp); OFF(pu[0].convert_p2s);
+        OFF(cu); OFF(cu[1]); OFF(cu[0].dct); OFF(cu[0].idct); OFF(cu[0].standard_dct); OFF(cu[0].lowpass_dct); OFF(cu[0].calcresidual);
+        OFF(cu[0].sub_ps); OFF(cu[0].add_ps); OFF(cu[0].blockfill_s); OFF(cu[0].copy_cnt); OFF(cu[0].count_nonzero);
+        OFF(cu[0].cpy2Dto1D_shl); OFF(cu[0].cpy2Dto1D_shr); OFF(cu[0].cpy1Dto2D_shl); OFF(cu[0].cpy1Dto2D_shr);
+        OFF(cu[0].copy_sp); OFF(cu[0].copy_ps); OFF(cu[0].copy_ss); OFF(cu[0].copy_pp); OFF(cu[0].var);
+        OFF(cu[0].sse_pp); OFF(cu[0].sse_ss); OFF(cu[0].psy_cost_pp); OFF(cu[0].ssd_s); OFF(cu[0].sa8d); OFF(cu[0].transpose);
+        OFF(cu[0].intra_pred_allangs); OFF(cu[0].intra_filter); OFF(cu[0].intra_pred);
+        OFF(dst4x4); OFF(idst4x4); OFF(quant); OFF(nquant); OFF(dequant_scaling); OFF(dequant_normal); OFF(denoiseDct);
+        OFF(scale1D_128to64); OFF(scale2D_64to32); OFF(weight_sp); OFF(weight_pp);
+        OFF(chroma); OFF(chroma[1]); OFF(chroma[0].pu[1]); OFF(chroma[0].pu[0].satd); OFF(chroma[0].pu[0].filter_vpp);
+        OFF(chroma[0].pu[0].filter_vps); OFF(chroma[0].pu[0].filter_vsp); OFF(chroma[0].pu[0].filter_vss); OFF(chroma[0].pu[0].filter_hpp);
+        OFF(chroma[0].pu[0].filter_hps); OFF(chroma[0].pu[0].addAvg); OFF(chroma[0].pu[0].copy_pp); OFF(chroma[0].pu[0].p2s);
+        OFF(chroma[0].cu); OFF(chroma[0].cu[1]); OFF(chroma[0].cu[0].sa8d); OFF(chroma[0].cu[0].sse_pp); OFF(chroma[0].cu[0].sub_ps);
+        OFF(chroma[0].cu[0].add_ps); OFF(chroma[0].cu[0].copy_ps); OFF(chroma[0].cu[0].copy_sp); OFF(chroma[0].cu[0].copy_ss); OFF(chroma[0].cu[0].copy_pp);
+#undef OFF
+        v.push_back((int32_t)sizeof(EncoderPrimitives));
+        Buf b(v.size() * 4); memcpy(b.data(), v.data(), b.size()); out.push_back(b);
+        return true;
+    }
+    if (op == "dct_matrix")
+    {
+        int n = (int)I[0];
+        const int16_t* m = n == 4 ? &g_t4[0][0] : n == 8 ? &g_t8[0][0] : n == 16 ? &g_t16[0][0] : &g_t32[0][0];
+        Buf b(n * n * 2); memcpy(b.data(), m, b.size()); out.push_back(b);
+        return true;
+    }
+    /* ---- pixel compare: ints = w,h,strideA,strideB,offA,offB ; bufs = A,B ---- */
+    if (op == "sad" || op == "satd")
+    {
+        int pu = puIndex((int)I[0], (int)I[1]);
+        pixelcmp_t f = op == "sad" ? T.pu[pu].sad : T.pu[pu].satd;
+        out.push_back(scalar<int32_t>(f(PX(B[0], I[4]), I[2], PX(B[1], I[5]), I[3])));
+        return true;
+    }
+    if (op == "sa8d" || op == "psy_cost_pp")
+    {
+        int cu = cuIndex((int)I[0]);
+        pixelcmp_t f = op == "sa8d" ? T.cu[cu].sa8d : T.cu[cu].psy_cost_pp;
+        out.push_back(scalar<int32_t>(f(PX(B[0], I[4]), I[2], PX(B[1], I[5]), I[3])));
+        return true;
+    }
+    if (op == "sse_pp")
+    {
+        out.push_back(scalar<uint64_t>((uint64_t)T.cu[cuIndex((int)I[0])].sse_pp(PX(B[0], I[4]), I[2], PX(B[1], I[5]), I[3])));
+        return true;
+    }
+    if (op == "sse_ss")
+    {
+        out.push_back(scalar<uint64_t>((uint64_t)T.cu[cuIndex((int)I[0])].sse_ss(S16(B[0], I[4]), I[2], S16(B[1], I[5]), I[3])));
+        return true;
+    }
+    if (op == "ssd_s")
+    {   /* ints = size, stride, off */
+        out.push_back(scalar<uint64_t>((uint64_t)T.cu[cuIndex((int)I[0])].ssd_s[0](S16(B[0], I[2]), I[1])));
+        return true;
+    }
+    if (op == "sad_x3" || op == "sad_x4")
+    {   /* ints = w,h,refStride,offFenc,off0,off1,off2[,off3]; bufs = fenc(stride 64), ref */
+        int pu = puIndex((int)I[0], (int)I[1]);
+        int32_t res[4] = { 0, 0, 0, 0 };
+        if (op == "sad_x3") T.pu[pu].sad_x3(PX(B[0], I[3]), PX(B[1], I[4]), PX(B[1], I[5]), PX(B[1], I[6]), I[2], res);
+        else T.pu[pu].sad_x4(PX(B[0], I[3]), PX(B[1], I[4]), PX(B[1], I[5]), PX(B[1], I[6]), PX(B[1], I[7]), I[2], res);
+        Buf b(16); memcpy(b.data(), res, 16); out.push_back(b);
+        return true;
+    }
+    /* ---- block ops; output buffers are passed in pre-filled (so untouched bytes are checked too) ---- */
+    if (op == "calcresidual")
+    {   /* ints = size, stride ; bufs = fenc, pred, resi(out) */
+        T.cu[cuIndex((int)I[0])].calcresidual[0](PX(B[0], 0), PX(B[1], 0), S16(B[2], 0), I[1]);
+        out.push_back(B[2]); return true;
+    }
+    if (op == "sub_ps")
+    {   /* ints = size, ds, ss0, ss1 ; bufs = dst(out), s0, s1 */
+        T.cu[cuIndex((int)I[0])].sub_ps(S16(B[0], 0), I[1], PX(B[1], 0), PX(B[2], 0), I[2], I[3]);
+        out.push_back(B[0]); return true;
+    }
+    if (op == "add_ps")
+    {   /* ints = size, ds, ss0, ss1 ; bufs = dst(out), s0(pixel), s1(int16) */
+        T.cu[cuIndex((int)I[0])].add_ps[0](PX(B[0], 0), I[1], PX(B[1], 0), S16(B[2], 0), I[2], I[3]);
+        out.push_back(B[0]); return true;
+    }
+    if (op == "copy_pp")
+    {   /* ints = w,h,ds,ss */
+        T.pu[puIndex((int)I[0], (int)I[1])].copy_pp(PX(B[0], 0), I[2], PX(B[1], 0), I[3]);
+        out.push_back(B[0]); return true;
+    }
+    if (op == "copy_ss") { T.cu[cuIndex((int)I[0])].copy_ss(S16(B[0], 0), I[2], S16(B[1], 0), I[3]); out.push_back(B[0]); return true; }
+    if (op == "copy_sp") { T.cu[cuIndex((int)I[0])].copy_sp(PX(B[0], 0), I[2], S16(B[1], 0), I[3]); out.push_back(B[0]); return true; }
+    if (op == "copy_ps") { T.cu[cuIndex((int)I[0])].copy_ps(S16(B[0], 0), I[2], PX(B[1], 0), I[3]); out.push_back(B[0]); return true; }
+    if (op == "blockfill_s") { T.cu[cuIndex((int)I[0])].blockfill_s[0](S16(B[0], 0), I[1], (int16_t)I[2]); out.push_back(B[0]); return true; }
+    if (op == "cpy2Dto1D_shl") { T.cu[cuIndex((int)I[0])].cpy2Dto1D_shl(S16(B[0], 0), S16(B[1], 0), I[1], (int)I[2]); out.push_back(B[0]); return true; }
+    if (op == "cpy2Dto1D_shr") { T.cu[cuIndex((int)I[0])].cpy2Dto1D_shr(S16(B[0], 0), S16(B[1], 0), I[1], (int)I[2]); out.push_back(B[0]); return true; }
+    if (op == "cpy1Dto2D_shl") { T.cu[cuIndex((int)I[0])].cpy1Dto2D_shl[0](S16(B[0], 0), S16(B[1], 0), I[1], (int)I[2]); out.push_back(B[0]); return true; }
+    if (op == "cpy1Dto2D_shr") { T.cu[cuIndex((int)I[0])].cpy1Dto2D_shr(S16(B[0], 0), S16(B[1], 0), I[1], (int)I[2]); out.push_back(B[0]); return true; }
+    if (op == "transpose") { T.cu[cuIndex((int)I[0])].transpose(PX(B[0], 0), PX(B[1], 0), I[1]); out.push_back(B[0]); return true; }
+    if (op == "addAvg")
+    {   /* ints = w,h,ss0,ss1,ds ; bufs = s0,s1,dst(out) */
+        T.pu[puIndex((int)I[0], (int)I[1])].addAvg[0](S16(B[0], 0), S16(B[1], 0), PX(B[2], 0), I[2], I[3], I[4]);
+        out.push_back(B[2]); return true;
+    }
+    if (op == "pixelavg_pp")
+    {   /* ints = w,h,ds,ss0,ss1 ; bufs = dst(out), s0, s1 */
+        T.pu[puIndex((int)I[0], (int)I[1])].pixelavg_pp[0](PX(B[0], 0), I[2], PX(B[1], 0), I[3], PX(B[2], 0), I[4], 32);
+        out.push_back(B[0]); return true;
+    }
+    if (op == "weight_sp")
+    {   /* ints = ss, ds, w, h, w0, round, shift, offset ; bufs = src, dst(out) */
+        T.weight_sp(S16(B[0], 0), PX(B[1], 0), I[0], I[1], (int)I[2], (int)I[3], (int)I[4], (int)I[5], (int)I[6], (int)I[7]);
+        out.push_back(B[1]); return true;
+    }
+    if (op == "weight_pp")
+    {   /* ints = stride, w, h, w0, round, shift, offset ; bufs = src, dst(out) */
+        T.weight_pp(PX(B[0], 0), PX(B[1], 0), I[0], (int)I[1], (int)I[2], (int)I[3], (int)I[4], (int)I[5], (int)I[6]);
+        out.push_back(B[1]); return true;
+    }
+    if (op == "scale1D_128to64") { T.scale1D_128to64[0](PX(B[0], 0), PX(B[1], 0)); out.push_back(B[0]); return true; }
+    if (op == "scale2D_64to32") { T.scale2D_64to32(PX(B[0], 0), PX(B[1], 0), I[0]); out.push_back(B[0]); return true; }
+    /* ---- transforms ---- */
+    if (op == "dct")
+    {   /* ints = n, srcStride ; bufs = src ; dst dense */
+        int n = (int)I[0]; Buf d(n * n * 2 + 64); int16_t* dp = (int16_t*)(((uintptr_t)d.data() + 31) & ~(uintptr_t)31);
+        T.cu[cuIndex(n)].dct(S16(B[0], 0), dp, I[1]);
+        Buf o(n * n * 2); memcpy(o.data(), dp, o.size()); out.push_back(o); return true;
+    }
+    if (op == "dst4")
+    {
+        Buf d(32 + 64); int16_t* dp = (int16_t*)(((uintptr_t)d.data() + 31) & ~(uintptr_t)31);
+        T.dst4x4(S16(B[0], 0), dp, I[0]);
+        Buf o(32); memcpy(o.data(), dp, 32); out.push_back(o); return true;
+    }
+    if (op == "idct")
+    {   /* ints = n, dstStride ; bufs = src dense, dst(out, pre-filled) */
+        T.cu[cuIndex((int)I[0])].idct(S16(B[0], 0), S16(B[1], 0), I[1]);
+        out.push_back(B[1]); return true;
+    }
+    if (op == "idst4") { T.idst4x4(S16(B[0], 0), S16(B[1], 0), I[0]); out.push_back(B[1]); return true; }
+    if (op == "quant")
+    {   /* ints = qBits, add, numCoeff ; bufs = coef, quantCoeff */
+        int n = (int)I[2]; Buf du(n * 4), q(n * 2);
+        uint32_t ns = T.quant(S16(B[0], 0), I32(B[1]), (int32_t*)du.data(), (int16_t*)q.data(), (int)I[0], (int)I[1], n);
+        out.push_back(scalar<uint32_t>(ns)); out.push_back(q); out.push_back(du); return true;
+    }
+    if (op == "nquant")
+    {
+        int n = (int)I[2]; Buf q(n * 2);
+        uint32_t ns = T.nquant(S16(B[0], 0), I32(B[1]), (int16_t*)q.data(), (int)I[0], (int)I[1], n);
+        out.push_back(scalar<uint32_t>(ns)); out.push_back(q); return true;
+    }
+    if (op == "dequant_normal")
+    {   /* ints = num, scale, shift ; bufs = q */
+        int n = (int)I[0]; Buf c(n * 2);
+        T.dequant_normal(S16(B[0], 0), (int16_t*)c.data(), n, (int)I[1], (int)I[2]);
+        out.push_back(c); return true;
+    }
+    if (op == "dequant_scaling")
+    {   /* ints = num, per, shift ; bufs = q, deq */
+        int n = (int)I[0]; Buf c(n * 2);
+        T.dequant_scaling(S16(B[0], 0), I32(B[1]), (int16_t*)c.data(), n, (int)I[1], (int)I[2]);
+        out.push_back(c); return true;
+    }
+    if (op == "count_nonzero") { out.push_back(scalar<int32_t>(T.cu[cuIndex((int)I[0])].count_nonzero(S16(B[0], 0)))); return true; }
+    if (op == "copy_cnt")
+    {   /* ints = n, resiStride ; bufs = resi */
+        int n = (int)I[0]; Buf c(n * n * 2);
+        uint32_t ns = T.cu[cuIndex(n)].copy_cnt((int16_t*)c.data(), S16(B[0], 0), I[1]);
+        out.push_back(scalar<uint32_t>(ns)); out.push_back(c); return true;
+    }
+    if (op == "denoise_dct")
+    {   /* ints = num ; bufs = coef(inout), resSum(inout u32), offset(u16) */
+        T.denoiseDct(S16(B[0], 0), (uint32_t*)B[1].data(), (const uint16_t*)B[2].data(), (int)I[0]);
+        out.push_back(B[0]); out.push_back(B[1]); return true;
+    }
+    /* ---- interpolation: ints = taps,w,h,ss,ds,srcOff,idx[,idx2/isRowExt] ; bufs = src, dst(out, pre-filled) ---- */
+    if (op.compare(0, 7, "interp_") == 0 || op == "p2s")
+    {
+        int taps = (int)I[0], w = (int)I[1], h = (int)I[2];
+        intptr_t ss = I[3], ds = I[4], so = I[5]; int idx = (int)I[6]; int idx2 = I.size() > 7 ? (int)I[7] : 0;
+        bool luma = taps == 8;
+        /* chroma tables are indexed by the LUMA partition enum; 4:2:0 chroma block is (w,h) = luma/2 */
+        int pu = luma ? puIndex(w, h) : puIndex(w * 2, h * 2);
+        EncoderPrimitives::PU& L = T.pu[pu];
+        EncoderPrimitives::Chroma::PUChroma& C = T.chroma[X265_CSP_I420].pu[pu];
+        if (op == "interp_hpp") (luma ? L.luma_hpp : C.filter_hpp)(PX(B[0], so), ss, PX(B[1], 0), ds, idx);
+        else if (op == "interp_hps") (luma ? L.luma_hps : C.filter_hps)(PX(B[0], so), ss, S16(B[1], 0), ds, idx, idx2);
+        else if (op == "interp_vpp") (luma ? L.luma_vpp : C.filter_vpp)(PX(B[0], so), ss, PX(B[1], 0), ds, idx);
+        else if (op == "interp_vps") (luma ? L.luma_vps : C.filter_vps)(PX(B[0], so), ss, S16(B[1], 0), ds, idx);
+        else if (op == "interp_vsp") (luma ? L.luma_vsp : C.filter_vsp)(S16(B[0], so), ss, PX(B[1], 0), ds, idx);
+        else if (op == "interp_vss") (luma ? L.luma_vss : C.filter_vss)(S16(B[0], so), ss, S16(B[1], 0), ds, idx);
+        else if (op == "interp_hvpp") L.luma_hvpp(PX(B[0], so), ss, PX(B[1], 0), ds, idx, idx2);
+        else if (op == "p2s") (luma ? L.convert_p2s[0] : C.p2s[0])(PX(B[0], so), ss, S16(B[1], 0), ds);
+        else return false;
+        out.push_back(B[1]); return true;
+    }
+    /* ---- intra ---- */
+    if (op == "intra_filter")
+    {   /* ints = size ; bufs = samples, filtered(out, pre-filled) */
+        T.cu[cuIndex((int)I[0])].intra_filter(PX(B[0], 0), PX(B[1], 0)); out.push_back(B[1]); return true;
+    }
+    if (op == "intra_pred")
+    {   /* ints = size, ds, mode, bFilter ; bufs = srcPix, dst(out) */
+        T.cu[cuIndex((int)I[0])].intra_pred[I[2]](PX(B[1], 0), I[1], PX(B[0], 0), (int)I[2], (int)I[3]); out.push_back(B[1]); return true;
+    }
+    if (op == "intra_allangs")
+    {   /* ints = size, bLuma ; bufs = ref, filt */
+        int n = (int)I[0]; Buf d(33 * n * n * sizeof(pixel));
+        T.cu[cuIndex(n)].intra_pred_allangs((pixel*)d.data(), PX(B[0], 0), PX(B[1], 0), (int)I[1]); out.push_back(d); return true;
+    }
+    /* ---- timing helper for bench.py cpu_baseline(kind="reference"): ints = family, reps, w/h... ---- */
+    if (op == "time_tu")
+    {   /* residual -> dct32 -> quant over `I[0]` TUs of B[0] (int16 residual, dense 32x32 each); returns ns */
+        int ntu = (int)I[0], qBits = (int)I[1], add = (int)I[2];
+        int16_t* coef = (int16_t*)aligned_alloc(64, 2048); int16_t* q = (int16_t*)aligned_alloc(64, 2048);
+        int32_t* du = (int32_t*)aligned_alloc(64, 4096); uint32_t acc = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < ntu; i++)
+        {
+            T.cu[3].dct(S16(B[0], (size_t)i * 1024), coef, 32);
+            acc += T.quant(coef, I32(B[1]), du, q, qBits, add, 1024);
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        free(coef); free(q); free(du);
+        out.push_back(scalar<int64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count()));
+        out.push_back(scalar<uint32_t>(acc)); return true;
+    }
+    return false;
+}
+
+int main()
+{
+    memset(&T, 0, sizeof(T));
+    setupPixelPrimitives_c(T);
+    setupDCTPrimitives_c(T);
+    setupLowPassPrimitives_c(T);
+    setupFilterPrimitives_c(T);
+    setupIntraPrimitives_c(T);
+    Req r;
+    while (readReq(r))
+    {
+        std::vector<Buf> out;
+        if (!dispatch(r, out)) { uint32_t bad = 0xFFFFFFFFu; wr(&bad, 4); fflush(stdout); continue; }
+        writeResp(out);
+    }
+    return 0;
+}

@@ -1,0 +1,708 @@
+/*
+ * x265_oracle.c -- TEST INFRASTRUCTURE ONLY (see x265_oracle.h).
+ *
+ * Plain-C restatement of the arithmetic of the reference's C primitives.  It is
+ * written from the algorithm (what each slot computes, with the reference's
+ * rounding/clipping/cast points), not from the reference's SWAR/butterfly code.
+ * Every function cites the reference location whose results it must reproduce.
+ * Pinned by tests/test_oracle_vs_ref.py (against oracle/_ref built from the real
+ * sources) and tests/golden/ (vectors captured from that build).
+ */
+#include "x265_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define PIXEL_MAX ((1 << X265_DEPTH) - 1)
+#define IF_INTERNAL_PREC 14   /* common.h:304-310 */
+#define IF_FILTER_PREC 6
+#define IF_INTERNAL_OFFS (1 << (IF_INTERNAL_PREC - 1))
+
+static inline int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline xo_pixel clip_pixel(int v) { return (xo_pixel)clip3i(0, PIXEL_MAX, v); }
+static inline int16_t clip16(int v) { return (int16_t)clip3i(-32768, 32767, v); }
+
+int xo_bit_depth(void) { return X265_DEPTH; }
+
+/* ------------------------------------------------------------------ */
+/* pixel compare family                                                */
+/* ------------------------------------------------------------------ */
+
+/* pixel.cpp:40-55 sad<lx,ly> */
+int xo_sad(int w, int h, const xo_pixel* a, intptr_t sa, const xo_pixel* b, intptr_t sb)
+{
+    int sum = 0;
+    for (int y = 0; y < h; y++, a += sa, b += sb)
+        for (int x = 0; x < w; x++)
+            sum += abs((int)a[x] - (int)b[x]);
+    return sum;
+}
+
+/* pixel.cpp:74-95 sad_x3: fenc stride is the fixed FENC_STRIDE = 64 (common.h:71) */
+void xo_sad_x3(int w, int h, const xo_pixel* fenc, const xo_pixel* r0, const xo_pixel* r1, const xo_pixel* r2, intptr_t rs, int32_t* res)
+{
+    res[0] = xo_sad(w, h, fenc, 64, r0, rs);
+    res[1] = xo_sad(w, h, fenc, 64, r1, rs);
+    res[2] = xo_sad(w, h, fenc, 64, r2, rs);
+}
+
+/* pixel.cpp:97-119 sad_x4 */
+void xo_sad_x4(int w, int h, const xo_pixel* fenc, const xo_pixel* r0, const xo_pixel* r1, const xo_pixel* r2, const xo_pixel* r3, intptr_t rs, int32_t* res)
+{
+    res[0] = xo_sad(w, h, fenc, 64, r0, rs);
+    res[1] = xo_sad(w, h, fenc, 64, r1, rs);
+    res[2] = xo_sad(w, h, fenc, 64, r2, rs);
+    res[3] = xo_sad(w, h, fenc, 64, r3, rs);
+}
+
+/* 4-point Hadamard butterfly, in place on d[0..3] with stride st */
+static inline void had4(int* d, int st)
+{
+    int t0 = d[0] + d[st], t1 = d[0] - d[st], t2 = d[2 * st] + d[3 * st], t3 = d[2 * st] - d[3 * st];
+    d[0] = t0 + t2; d[2 * st] = t0 - t2; d[st] = t1 + t3; d[3 * st] = t1 - t3;
+}
+
+/* sum of |4x4 Hadamard coefficients| of (a-b), NOT yet halved (pixel.cpp:210-238) */
+static int had4x4_abs(const xo_pixel* a, intptr_t sa, const xo_pixel* b, intptr_t sb)
+{
+    int d[16];
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++)
+            d[y * 4 + x] = (int)a[y * sa + x] - (int)b[y * sb + x];
+    for (int y = 0; y < 4; y++) had4(d + 4 * y, 1);
+    for (int x = 0; x < 4; x++) had4(d + x, 4);
+    int s = 0;
+    for (int i = 0; i < 16; i++) s += abs(d[i]);
+    return s;
+}
+
+/* pixel.cpp:1148-1172: which decomposition each PU's satd slot uses.
+ *   4x4 -> satd_4x4 (>>1 per 4x4); 8x4 -> satd_8x4 (>>1 per 8x4 pair);
+ *   4x8, 4x16, 12x16 -> satd4<w,h> (sum of per-4x4 halved values);
+ *   everything else -> satd8<w,h> (sum of per-8x4 halved values). */
+int xo_satd(int w, int h, const xo_pixel* a, intptr_t sa, const xo_pixel* b, intptr_t sb)
+{
+    int total = 0;
+    int use4 = (w == 4) || (w == 12);
+    if (use4)
+    {
+        for (int y = 0; y < h; y += 4)
+            for (int x = 0; x < w; x += 4)
+                total += had4x4_abs(a + y * sa + x, sa, b + y * sb + x, sb) >> 1;
+    }
+    else
+    {
+        for (int y = 0; y < h; y += 4)
+            for (int x = 0; x < w; x += 8)
+                total += (had4x4_abs(a + y * sa + x, sa, b + y * sb + x, sb) +
+                          had4x4_abs(a + y * sa + x + 4, sa, b + y * sb + x + 4, sb)) >> 1;
+    }
+    return total;
+}
+
+/* raw 8x8 Hadamard |coef| sum (pixel.cpp:291-326 _sa8d_8x8) */
+static int had8x8_abs(const xo_pixel* a, intptr_t sa, const xo_pixel* b, intptr_t sb)
+{
+    int d[64];
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++)
+            d[y * 8 + x] = (int)a[y * sa + x] - (int)b[y * sb + x];
+    /* 8-point Hadamard along rows then columns (order of +/- outputs is irrelevant for sum of abs) */
+    for (int pass = 0; pass < 2; pass++)
+    {
+        int st = pass ? 8 : 1, ln = pass ? 1 : 8;
+        for (int l = 0; l < 8; l++)
+        {
+            int* p = d + l * ln;
+            for (int half = 4; half >= 1; half >>= 1)
+                for (int base = 0; base < 8; base += 2 * half)
+                    for (int k = 0; k < half; k++)
+                    {
+                        int u = p[(base + k) * st], v = p[(base + k + half) * st];
+                        p[(base + k) * st] = u + v;
+                        p[(base + k + half) * st] = u - v;
+                    }
+        }
+    }
+    int s = 0;
+    for (int i = 0; i < 64; i++) s += abs(d[i]);
+    return s;
+}
+
+/* pixel.cpp:328-369,1180-1184: 4 -> satd_4x4; 8 -> (raw+2)>>2; 16 -> (sum of four raw +2)>>2;
+ * 32/64 -> sum of sa8d_16x16 values */
+int xo_sa8d(int size, const xo_pixel* a, intptr_t sa, const xo_pixel* b, intptr_t sb)
+{
+    if (size == 4) return had4x4_abs(a, sa, b, sb) >> 1;
+    if (size == 8) return (had8x8_abs(a, sa, b, sb) + 2) >> 2;
+    int cost = 0;
+    for (int y = 0; y < size; y += 16)
+        for (int x = 0; x < size; x += 16)
+        {
+            const xo_pixel* p = a + y * sa + x; const xo_pixel* q = b + y * sb + x;
+            int s = had8x8_abs(p, sa, q, sb) + had8x8_abs(p + 8, sa, q + 8, sb) +
+                    had8x8_abs(p + 8 * sa, sa, q + 8 * sb, sb) + had8x8_abs(p + 8 * sa + 8, sa, q + 8 * sb + 8, sb);
+            cost += (s + 2) >> 2;
+        }
+    return cost;
+}
+
+/* pixel.cpp:167-186 sse<>; sse_t is u32 below 10-bit, u64 from 10-bit (common.h:145-149) */
+static inline uint64_t sse_wrap(uint64_t v)
+{
+#if X265_DEPTH < 10
+    return (uint32_t)v;
+#else
+    return v;
+#endif
+}
+uint64_t xo_sse_pp(int w, int h, const xo_pixel* a, intptr_t sa, const xo_pixel* b, intptr_t sb)
+{
+    uint64_t sum = 0;
+    for (int y = 0; y < h; y++, a += sa, b += sb)
+        for (int x = 0; x < w; x++) { int t = (int)a[x] - (int)b[x]; sum += (uint64_t)(int64_t)(int32_t)((uint32_t)t * (uint32_t)t); }
+    return sse_wrap(sum);
+}
+uint64_t xo_sse_ss(int w, int h, const int16_t* a, intptr_t sa, const int16_t* b, intptr_t sb)
+{
+    uint64_t sum = 0;
+    for (int y = 0; y < h; y++, a += sa, b += sb)
+        for (int x = 0; x < w; x++) { int t = (int)a[x] - (int)b[x]; sum += (uint64_t)(int64_t)(int32_t)((uint32_t)t * (uint32_t)t); }
+    return sse_wrap(sum);
+}
+/* pixel.cpp:371-383 pixel_ssd_s_c */
+uint64_t xo_ssd_s(int size, const int16_t* a, intptr_t sa)
+{
+    uint64_t sum = 0;
+    for (int y = 0; y < size; y++, a += sa)
+        for (int x = 0; x < size; x++) sum += (uint64_t)(int64_t)((int)a[x] * (int)a[x]);
+    return sse_wrap(sum);
+}
+
+/* pixel.cpp:718-749 psyCost_pp: per 8x8, |(sa8d(src,0) - sum(src)>>2) - (sa8d(rec,0) - sum(rec)>>2)|; 4x4 uses satd */
+int xo_psy_cost_pp(int size, const xo_pixel* src, intptr_t ss, const xo_pixel* rec, intptr_t rs)
+{
+    static const xo_pixel zero[8] = { 0 };
+    if (size == 4)
+    {
+        int se = (had4x4_abs(src, ss, zero, 0) >> 1) - (xo_sad(4, 4, src, ss, zero, 0) >> 2);
+        int re = (had4x4_abs(rec, rs, zero, 0) >> 1) - (xo_sad(4, 4, rec, rs, zero, 0) >> 2);
+        return abs(se - re);
+    }
+    uint32_t tot = 0;
+    for (int i = 0; i < size; i += 8)
+        for (int j = 0; j < size; j += 8)
+        {
+            int se = ((had8x8_abs(src + i * ss + j, ss, zero, 0) + 2) >> 2) - (xo_sad(8, 8, src + i * ss + j, ss, zero, 0) >> 2);
+            int re = ((had8x8_abs(rec + i * rs + j, rs, zero, 0) + 2) >> 2) - (xo_sad(8, 8, rec + i * rs + j, rs, zero, 0) >> 2);
+            tot += (uint32_t)abs(se - re);
+        }
+    return (int)tot;
+}
+
+/* ------------------------------------------------------------------ */
+/* block ops                                                           */
+/* ------------------------------------------------------------------ */
+
+/* pixel.cpp:463-475 getResidual: ONE stride shared by fenc, pred and residual */
+void xo_calcresidual(int size, const xo_pixel* fenc, const xo_pixel* pred, int16_t* resi, intptr_t stride)
+{
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++)
+            resi[y * stride + x] = (int16_t)((int)fenc[y * stride + x] - (int)pred[y * stride + x]);
+}
+/* pixel.cpp:806-818 */
+void xo_sub_ps(int w, int h, int16_t* dst, intptr_t ds, const xo_pixel* s0, const xo_pixel* s1, intptr_t ss0, intptr_t ss1)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            dst[y * ds + x] = (int16_t)((int)s0[y * ss0 + x] - (int)s1[y * ss1 + x]);
+}
+/* pixel.cpp:820-832 */
+void xo_add_ps(int w, int h, xo_pixel* dst, intptr_t ds, const xo_pixel* s0, const int16_t* s1, intptr_t ss0, intptr_t ss1)
+{
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            dst[y * ds + x] = clip_pixel((int)s0[y * ss0 + x] + (int)s1[y * ss1 + x]);
+}
+/* pixel.cpp:751-804 blockcopy_{pp,ss,sp,ps}_c */
+void xo_copy_pp(int w, int h, xo_pixel* dst, intptr_t ds, const xo_pixel* src, intptr_t ss)
+{ for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) dst[y * ds + x] = src[y * ss + x]; }
+void xo_copy_ss(int w, int h, int16_t* dst, intptr_t ds, const int16_t* src, intptr_t ss)
+{ for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) dst[y * ds + x] = src[y * ss + x]; }
+void xo_copy_sp(int w, int h, xo_pixel* dst, intptr_t ds, const int16_t* src, intptr_t ss)
+{ for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) dst[y * ds + x] = (xo_pixel)src[y * ss + x]; }
+void xo_copy_ps(int w, int h, int16_t* dst, intptr_t ds, const xo_pixel* src, intptr_t ss)
+{ for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) dst[y * ds + x] = (int16_t)src[y * ss + x]; }
+/* pixel.cpp:385-391 */
+void xo_blockfill_s(int size, int16_t* dst, intptr_t ds, int16_t val)
+{ for (int y = 0; y < size; y++) for (int x = 0; x < size; x++) dst[y * ds + x] = val; }
+/* pixel.cpp:393-461 */
+void xo_cpy2Dto1D_shl(int size, int16_t* dst, const int16_t* src, intptr_t ss, int shift)
+{ for (int i = 0; i < size; i++) for (int j = 0; j < size; j++) dst[i * size + j] = (int16_t)((uint32_t)(int32_t)src[i * ss + j] << shift); }
+void xo_cpy2Dto1D_shr(int size, int16_t* dst, const int16_t* src, intptr_t ss, int shift)
+{ int16_t round = (int16_t)(1 << (shift - 1)); for (int i = 0; i < size; i++) for (int j = 0; j < size; j++) dst[i * size + j] = (int16_t)(((int)src[i * ss + j] + round) >> shift); }
+void xo_cpy1Dto2D_shl(int size, int16_t* dst, const int16_t* src, intptr_t ds, int shift)
+{ for (int i = 0; i < size; i++) for (int j = 0; j < size; j++) dst[i * ds + j] = (int16_t)((uint32_t)(int32_t)src[i * size + j] << shift); }
+void xo_cpy1Dto2D_shr(int size, int16_t* dst, const int16_t* src, intptr_t ds, int shift)
+{ int16_t round = (int16_t)(1 << (shift - 1)); for (int i = 0; i < size; i++) for (int j = 0; j < size; j++) dst[i * ds + j] = (int16_t)(((int)src[i * size + j] + round) >> shift); }
+/* pixel.cpp:477-483: dst dense size x size */
+void xo_transpose(int size, xo_pixel* dst, const xo_pixel* src, intptr_t ss)
+{ for (int k = 0; k < size; k++) for (int l = 0; l < size; l++) dst[k * size + l] = src[l * ss + k]; }
+/* pixel.cpp:834-854 addAvg */
+void xo_addAvg(int w, int h, const int16_t* s0, const int16_t* s1, xo_pixel* dst, intptr_t ss0, intptr_t ss1, intptr_t ds)
+{
+    int shift = IF_INTERNAL_PREC + 1 - X265_DEPTH;
+    int offset = (1 << (shift - 1)) + 2 * IF_INTERNAL_OFFS;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            dst[y * ds + x] = clip_pixel(((int)s0[y * ss0 + x] + (int)s1[y * ss1 + x] + offset) >> shift);
+}
+/* pixel.cpp:537-549 */
+void xo_pixelavg_pp(int w, int h, xo_pixel* dst, intptr_t ds, const xo_pixel* s0, intptr_t ss0, const xo_pixel* s1, intptr_t ss1)
+{ for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) dst[y * ds + x] = (xo_pixel)(((int)s0[y * ss0 + x] + (int)s1[y * ss1 + x] + 1) >> 1); }
+/* pixel.cpp:485-508 */
+void xo_weight_sp(const int16_t* src, xo_pixel* dst, intptr_t ss, intptr_t ds, int w, int h, int w0, int round, int shift, int offset)
+{ for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) dst[y * ds + x] = clip_pixel(((w0 * ((int)src[y * ss + x] + IF_INTERNAL_OFFS) + round) >> shift) + offset); }
+/* pixel.cpp:510-535 */
+void xo_weight_pp(const xo_pixel* src, xo_pixel* dst, intptr_t stride, int w, int h, int w0, int round, int shift, int offset)
+{
+    int correction = IF_INTERNAL_PREC - X265_DEPTH;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+        {
+            int16_t val = (int16_t)((int)src[y * stride + x] << correction);
+            dst[y * stride + x] = clip_pixel(((w0 * (int)val + round) >> shift) + offset);
+        }
+}
+/* pixel.cpp:551-577: src = two rows of 128 (at src and src+128), dst = two rows of 64 */
+void xo_scale1D_128to64(xo_pixel* dst, const xo_pixel* src)
+{
+    for (int x = 0; x < 128; x += 2)
+    {
+        dst[x >> 1] = (xo_pixel)(((int)src[x] + (int)src[x + 1] + 1) >> 1);
+        dst[64 + (x >> 1)] = (xo_pixel)(((int)src[128 + x] + (int)src[128 + x + 1] + 1) >> 1);
+    }
+}
+/* pixel.cpp:579-594 */
+void xo_scale2D_64to32(xo_pixel* dst, const xo_pixel* src, intptr_t stride)
+{
+    for (int y = 0; y < 64; y += 2)
+        for (int x = 0; x < 64; x += 2)
+            dst[(y / 2) * 32 + x / 2] = (xo_pixel)(((int)src[y * stride + x] + (int)src[y * stride + x + 1] +
+                                                    (int)src[(y + 1) * stride + x] + (int)src[(y + 1) * stride + x + 1] + 2) >> 2);
+}
+
+/* ------------------------------------------------------------------ */
+/* transforms                                                          */
+/* ------------------------------------------------------------------ */
+
+/* HEVC core transform coefficients by angle index a: round-ish 64*sqrt2*cos(pi*a/64) as
+ * fixed by the standard (the numbers in constants.cpp:270-344 g_t4..g_t32). */
+static const int8_t k_cos[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                  61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+static int16_t g_mat[4][32 * 32];
+static int g_mat_ready;
+static void build_mats(void)
+{
+    if (g_mat_ready) return;
+    for (int li = 0; li < 4; li++)
+    {
+        int n = 4 << li, step = 32 / n;
+        for (int k = 0; k < n; k++)
+            for (int j = 0; j < n; j++)
+            {
+                int th = ((k * step) * (2 * j + 1)) & 127, v;
+                if (th <= 32) v = k_cos[th];
+                else if (th <= 64) v = -k_cos[64 - th];
+                else if (th <= 96) v = -k_cos[th - 64];
+                else v = k_cos[128 - th];
+                g_mat[li][k * n + j] = (int16_t)v;
+            }
+    }
+    g_mat_ready = 1;
+}
+static int log2i(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+const int16_t* xo_dct_matrix(int n) { build_mats(); return g_mat[log2i(n) - 2]; }
+
+/* DST-VII 4x4 basis (the matrix fastForwardDst/inversedst factor, dct.cpp:43-81) */
+static const int16_t k_dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
+
+/* forward stage: dst[k*n + j] = (sum_m M[k][m]*src[j*n+m] + add) >> shift, int16 cast, no clip
+ * (dct.cpp:83-240,418-440 partialButterfly*, exact as a matrix product) */
+static void fwd_stage(const int16_t* M, int n, const int16_t* src, int16_t* dst, int shift)
+{
+    int add = 1 << (shift - 1);
+    for (int j = 0; j < n; j++)
+        for (int k = 0; k < n; k++)
+        {
+            int s = 0;
+            for (int m = 0; m < n; m++) s += (int)M[k * n + m] * (int)src[j * n + m];
+            dst[k * n + j] = (int16_t)((s + add) >> shift);
+        }
+}
+/* inverse stage: dst[j*n + k] = clip16((sum_m M[m][k]*src[m*n+j] + add) >> shift)
+ * (dct.cpp:242-416 partialButterflyInverse*) */
+static void inv_stage(const int16_t* M, int n, const int16_t* src, int16_t* dst, int shift)
+{
+    int add = 1 << (shift - 1);
+    for (int j = 0; j < n; j++)
+        for (int k = 0; k < n; k++)
+        {
+            int s = 0;
+            for (int m = 0; m < n; m++) s += (int)M[m * n + k] * (int)src[m * n + j];
+            dst[j * n + k] = clip16((s + add) >> shift);
+        }
+}
+
+/* dct.cpp:443-526: shift1 = log2N - 1 + (depth-8), shift2 = log2N + 6 */
+void xo_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride)
+{
+    int16_t blk[1024], tmp[1024];
+    int lg = log2i(n);
+    for (int i = 0; i < n; i++) memcpy(blk + i * n, src + i * srcStride, n * sizeof(int16_t));
+    const int16_t* M = xo_dct_matrix(n);
+    fwd_stage(M, n, blk, tmp, lg - 1 + X265_DEPTH - 8);
+    fwd_stage(M, n, tmp, dst, lg + 6);
+}
+/* dct.cpp:528-611: shift1 = 7, shift2 = 12 - (depth-8), clip to int16 after each stage */
+void xo_idct(int n, const int16_t* src, int16_t* dst, intptr_t dstStride)
+{
+    int16_t tmp[1024], blk[1024];
+    const int16_t* M = xo_dct_matrix(n);
+    inv_stage(M, n, src, tmp, 7);
+    inv_stage(M, n, tmp, blk, 12 - (X265_DEPTH - 8));
+    for (int i = 0; i < n; i++) memcpy(dst + i * dstStride, blk + i * n, n * sizeof(int16_t));
+}
+/* dct.cpp:443-459 dst4_c */
+void xo_dst4(const int16_t* src, int16_t* dst, intptr_t srcStride)
+{
+    int16_t blk[16], tmp[16];
+    for (int i = 0; i < 4; i++) memcpy(blk + i * 4, src + i * srcStride, 4 * sizeof(int16_t));
+    fwd_stage(k_dst4, 4, blk, tmp, 1 + X265_DEPTH - 8);
+    fwd_stage(k_dst4, 4, tmp, dst, 8);
+}
+/* dct.cpp:528-544 idst4_c */
+void xo_idst4(const int16_t* src, int16_t* dst, intptr_t dstStride)
+{
+    int16_t tmp[16], blk[16];
+    inv_stage(k_dst4, 4, src, tmp, 7);
+    inv_stage(k_dst4, 4, tmp, blk, 12 - (X265_DEPTH - 8));
+    for (int i = 0; i < 4; i++) memcpy(dst + i * dstStride, blk + i * 4, 4 * sizeof(int16_t));
+}
+
+/* dct.cpp:666-688 quant_c.  int arithmetic wraps like the reference's int32 (done in uint32 to stay defined). */
+uint32_t xo_quant(const int16_t* coef, const int32_t* quantCoeff, int32_t* deltaU, int16_t* qCoef, int qBits, int add, int numCoeff)
+{
+    int qBits8 = qBits - 8;
+    uint32_t numSig = 0;
+    for (int i = 0; i < numCoeff; i++)
+    {
+        int level = coef[i];
+        int sign = level < 0 ? -1 : 1;
+        int32_t tmplevel = (int32_t)((uint32_t)abs(level) * (uint32_t)quantCoeff[i]);
+        level = (int32_t)((uint32_t)tmplevel + (uint32_t)add) >> qBits;
+        deltaU[i] = (int32_t)((uint32_t)tmplevel - ((uint32_t)level << qBits)) >> qBits8;
+        if (level) ++numSig;
+        level *= sign;
+        qCoef[i] = clip16(level);
+    }
+    return numSig;
+}
+/* dct.cpp:690-715 nquant_c: stores ABSOLUTE levels */
+uint32_t xo_nquant(const int16_t* coef, const int32_t* quantCoeff, int16_t* qCoef, int qBits, int add, int numCoeff)
+{
+    uint32_t numSig = 0;
+    for (int i = 0; i < numCoeff; i++)
+    {
+        int level = coef[i];
+        int sign = level < 0 ? -1 : 1;
+        int32_t tmplevel = (int32_t)((uint32_t)abs(level) * (uint32_t)quantCoeff[i]);
+        level = (int32_t)((uint32_t)tmplevel + (uint32_t)add) >> qBits;
+        if (level) ++numSig;
+        level *= sign;
+        qCoef[i] = (int16_t)abs(clip3i(-32768, 32767, level));
+    }
+    return numSig;
+}
+/* dct.cpp:614-636 */
+void xo_dequant_normal(const int16_t* q, int16_t* coef, int num, int scale, int shift)
+{
+    int add = 1 << (shift - 1);
+    for (int n = 0; n < num; n++)
+        coef[n] = clip16((int32_t)((uint32_t)((int)q[n] * scale) + (uint32_t)add) >> shift);
+}
+/* dct.cpp:638-664 */
+void xo_dequant_scaling(const int16_t* q, const int32_t* deq, int16_t* coef, int num, int per, int shift)
+{
+    shift += 4;
+    if (shift > per)
+    {
+        int add = 1 << (shift - per - 1);
+        for (int n = 0; n < num; n++)
+            coef[n] = clip16((int32_t)((uint32_t)((int)q[n] * deq[n]) + (uint32_t)add) >> (shift - per));
+    }
+    else
+    {
+        for (int n = 0; n < num; n++)
+        {
+            int c = clip3i(-32768, 32767, (int)q[n] * deq[n]);
+            coef[n] = clip16((int32_t)((uint32_t)c * (1u << (per - shift))));
+        }
+    }
+}
+/* dct.cpp:716-728 */
+int xo_count_nonzero(int n, const int16_t* q)
+{ int c = 0; for (int i = 0; i < n * n; i++) c += q[i] != 0; return c; }
+/* dct.cpp:730-744 */
+uint32_t xo_copy_count(int n, int16_t* coef, const int16_t* resi, intptr_t rs)
+{
+    uint32_t c = 0;
+    for (int k = 0; k < n; k++) for (int j = 0; j < n; j++) { coef[k * n + j] = resi[k * rs + j]; c += resi[k * rs + j] != 0; }
+    return c;
+}
+/* dct.cpp:746-757 */
+void xo_denoise_dct(int16_t* coef, uint32_t* resSum, const uint16_t* offset, int num)
+{
+    for (int i = 0; i < num; i++)
+    {
+        int level = coef[i];
+        int sign = level >> 31;
+        level = (level + sign) ^ sign;
+        resSum[i] += (uint32_t)level;
+        level -= offset[i];
+        coef[i] = (int16_t)(level < 0 ? 0 : (level ^ sign) - sign);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* interpolation                                                       */
+/* ------------------------------------------------------------------ */
+/* constants.cpp:250-268 (the HEVC interpolation taps) */
+static const int16_t k_luma[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+                                      { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+static const int16_t k_chroma[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+                                        { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+static const int16_t* taps_of(int taps, int idx) { return taps == 8 ? k_luma[idx] : k_chroma[idx]; }
+
+/* generic FIR; `step` is the element distance between taps (1 = horizontal, stride = vertical) */
+#define FIR(src, pos, step, c, taps, sum) do { sum = 0; for (int t_ = 0; t_ < (taps); t_++) sum += (int)(src)[(pos) + t_ * (step)] * (int)(c)[t_]; } while (0)
+
+/* ipfilter.cpp:79-118 */
+void xo_interp_hpp(int taps, int w, int h, const xo_pixel* src, intptr_t ss, xo_pixel* dst, intptr_t ds, int coeffIdx)
+{
+    const int16_t* c = taps_of(taps, coeffIdx);
+    src -= taps / 2 - 1;
+    for (int y = 0; y < h; y++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum; FIR(src, x, 1, c, taps, sum);
+            int16_t v = (int16_t)((sum + 32) >> 6);
+            dst[x] = clip_pixel(v);
+        }
+}
+/* ipfilter.cpp:120-162 */
+void xo_interp_hps(int taps, int w, int h, const xo_pixel* src, intptr_t ss, int16_t* dst, intptr_t ds, int coeffIdx, int isRowExt)
+{
+    const int16_t* c = taps_of(taps, coeffIdx);
+    int headRoom = IF_INTERNAL_PREC - X265_DEPTH, shift = IF_FILTER_PREC - headRoom;
+    int offset = (int)((unsigned)-IF_INTERNAL_OFFS << shift);
+    int rows = h;
+    src -= taps / 2 - 1;
+    if (isRowExt) { src -= (taps / 2 - 1) * ss; rows += taps - 1; }
+    for (int y = 0; y < rows; y++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum; FIR(src, x, 1, c, taps, sum);
+            dst[x] = (int16_t)((sum + offset) >> shift);
+        }
+}
+/* ipfilter.cpp:164-203 */
+void xo_interp_vpp(int taps, int w, int h, const xo_pixel* src, intptr_t ss, xo_pixel* dst, intptr_t ds, int coeffIdx)
+{
+    const int16_t* c = taps_of(taps, coeffIdx);
+    src -= (taps / 2 - 1) * ss;
+    for (int y = 0; y < h; y++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum; FIR(src, x, ss, c, taps, sum);
+            int16_t v = (int16_t)((sum + 32) >> 6);
+            dst[x] = clip_pixel(v);
+        }
+}
+/* ipfilter.cpp:205-239 */
+void xo_interp_vps(int taps, int w, int h, const xo_pixel* src, intptr_t ss, int16_t* dst, intptr_t ds, int coeffIdx)
+{
+    const int16_t* c = taps_of(taps, coeffIdx);
+    int headRoom = IF_INTERNAL_PREC - X265_DEPTH, shift = IF_FILTER_PREC - headRoom;
+    int offset = (int)((unsigned)-IF_INTERNAL_OFFS << shift);
+    src -= (taps / 2 - 1) * ss;
+    for (int y = 0; y < h; y++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum; FIR(src, x, ss, c, taps, sum);
+            dst[x] = (int16_t)((sum + offset) >> shift);
+        }
+}
+/* ipfilter.cpp:241-282 (and filterVertical_sp_c :319-360) */
+void xo_interp_vsp(int taps, int w, int h, const int16_t* src, intptr_t ss, xo_pixel* dst, intptr_t ds, int coeffIdx)
+{
+    const int16_t* c = taps_of(taps, coeffIdx);
+    int headRoom = IF_INTERNAL_PREC - X265_DEPTH, shift = IF_FILTER_PREC + headRoom;
+    int offset = (1 << (shift - 1)) + (IF_INTERNAL_OFFS << IF_FILTER_PREC);
+    src -= (taps / 2 - 1) * ss;
+    for (int y = 0; y < h; y++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum; FIR(src, x, ss, c, taps, sum);
+            int16_t v = (int16_t)((sum + offset) >> shift);
+            dst[x] = clip_pixel(v);
+        }
+}
+/* ipfilter.cpp:284-317 */
+void xo_interp_vss(int taps, int w, int h, const int16_t* src, intptr_t ss, int16_t* dst, intptr_t ds, int coeffIdx)
+{
+    const int16_t* c = taps_of(taps, coeffIdx);
+    src -= (taps / 2 - 1) * ss;
+    for (int y = 0; y < h; y++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int sum; FIR(src, x, ss, c, taps, sum);
+            dst[x] = (int16_t)(sum >> IF_FILTER_PREC);
+        }
+}
+/* ipfilter.cpp:362-369: hps with row extension into a w-strided int16 buffer, then vertical sp */
+void xo_interp_hvpp(int taps, int w, int h, const xo_pixel* src, intptr_t ss, xo_pixel* dst, intptr_t ds, int idxX, int idxY)
+{
+    int16_t immed[64 * (64 + 7)];
+    xo_interp_hps(taps, w, h, src, ss, immed, w, idxX, 1);
+    xo_interp_vsp(taps, w, h, immed + (taps / 2 - 1) * w, w, dst, ds, idxY);
+}
+/* ipfilter.cpp:40-57 filterPixelToShort_c */
+void xo_p2s(int w, int h, const xo_pixel* src, intptr_t ss, int16_t* dst, intptr_t ds)
+{
+    int shift = IF_INTERNAL_PREC - X265_DEPTH;
+    for (int y = 0; y < h; y++, src += ss, dst += ds)
+        for (int x = 0; x < w; x++)
+        {
+            int16_t v = (int16_t)((int)src[x] << shift);
+            dst[x] = (int16_t)(v - (int16_t)IF_INTERNAL_OFFS);
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* intra                                                               */
+/* ------------------------------------------------------------------ */
+/* constants.cpp:561 g_intraFilterFlags */
+static const uint8_t k_intraFilterFlags[35] = {
+    0x38, 0x00, 0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x38 };
+
+/* intrapred.cpp:31-51. Layout: [0]=top-left, [1..2N]=above+above-right, [2N+1..4N]=left+below-left */
+void xo_intra_filter(int size, const xo_pixel* s, xo_pixel* f)
+{
+    int n2 = size * 2;
+    int tl = s[0];
+    for (int i = 1; i < n2; i++) f[i] = (xo_pixel)((2 * s[i] + s[i - 1] + s[i + 1] + 2) >> 2);
+    f[n2] = s[n2];
+    f[0] = (xo_pixel)((2 * tl + s[1] + s[n2 + 1] + 2) >> 2);
+    f[n2 + 1] = (xo_pixel)((2 * s[n2 + 1] + tl + s[n2 + 2] + 2) >> 2);
+    for (int i = n2 + 2; i < 2 * n2; i++) f[i] = (xo_pixel)((2 * s[i] + s[i - 1] + s[i + 1] + 2) >> 2);
+    f[2 * n2] = s[2 * n2];
+}
+
+/* angular prediction into a DENSE size x size buffer `out`, WITHOUT the final transpose of
+ * horizontal modes (intrapred.cpp:102-189) */
+static void ang_core(int size, xo_pixel* out, const xo_pixel* srcPix0, int dirMode, int bFilter)
+{
+    static const int8_t angleTable[17] = { -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+    static const int16_t invAngleTable[8] = { 4096, 1638, 910, 630, 482, 390, 315, 256 };
+    int n2 = size * 2, horMode = dirMode < 18;
+    xo_pixel nb[129];
+    const xo_pixel* sp = srcPix0;
+    if (horMode)
+    {
+        nb[0] = srcPix0[0];
+        for (int i = 0; i < n2; i++) { nb[1 + i] = srcPix0[n2 + 1 + i]; nb[n2 + 1 + i] = srcPix0[1 + i]; }
+        sp = nb;
+    }
+    int angleOffset = horMode ? 10 - dirMode : dirMode - 26;
+    int angle = angleTable[8 + angleOffset];
+    if (!angle)
+    {
+        for (int y = 0; y < size; y++) for (int x = 0; x < size; x++) out[y * size + x] = sp[1 + x];
+        if (bFilter)
+        {
+            int tl = sp[0], top = sp[1];
+            for (int y = 0; y < size; y++)
+                out[y * size] = clip_pixel((int16_t)(top + (((int)sp[n2 + 1 + y] - tl) >> 1)));
+        }
+        return;
+    }
+    xo_pixel refBuf[64 + 2];
+    const xo_pixel* ref;
+    if (angle < 0)
+    {
+        int nbProjected = -((size * angle) >> 5) - 1;
+        xo_pixel* rp = refBuf + nbProjected + 1;
+        int invAngle = invAngleTable[-angleOffset - 1], invAngleSum = 128;
+        for (int i = 0; i < nbProjected; i++) { invAngleSum += invAngle; rp[-2 - i] = sp[n2 + (invAngleSum >> 8)]; }
+        for (int i = 0; i < size + 1; i++) rp[-1 + i] = sp[i];
+        ref = rp;
+    }
+    else
+        ref = sp + 1;
+    int angleSum = 0;
+    for (int y = 0; y < size; y++)
+    {
+        angleSum += angle;
+        int off = angleSum >> 5, frac = angleSum & 31;
+        for (int x = 0; x < size; x++)
+            out[y * size + x] = frac ? (xo_pixel)(((32 - frac) * ref[off + x] + frac * ref[off + x + 1] + 16) >> 5) : ref[off + x];
+    }
+}
+
+/* intrapred.cpp:53-100 (DC=1, planar=0) and :102-204 (angular 2..34) */
+void xo_intra_pred(int size, xo_pixel* dst, intptr_t ds, const xo_pixel* srcPix, int dirMode, int bFilter)
+{
+    const xo_pixel* above = srcPix + 1;
+    const xo_pixel* left = srcPix + 2 * size + 1;
+    if (dirMode == 0)
+    {
+        int lg = log2i(size), tr = above[size], bl = left[size];
+        for (int y = 0; y < size; y++)
+            for (int x = 0; x < size; x++)
+                dst[y * ds + x] = (xo_pixel)(((size - 1 - x) * left[y] + (size - 1 - y) * above[x] + (x + 1) * tr + (y + 1) * bl + size) >> (lg + 1));
+        return;
+    }
+    if (dirMode == 1)
+    {
+        int dc = size;
+        for (int i = 0; i < size; i++) dc += above[i] + left[i];
+        dc /= 2 * size;
+        for (int y = 0; y < size; y++) for (int x = 0; x < size; x++) dst[y * ds + x] = (xo_pixel)dc;
+        if (bFilter)
+        {
+            dst[0] = (xo_pixel)((above[0] + left[0] + 2 * dc + 2) >> 2);
+            for (int x = 1; x < size; x++) dst[x] = (xo_pixel)((above[x] + 3 * dc + 2) >> 2);
+            for (int y = 1; y < size; y++) dst[y * ds] = (xo_pixel)((left[y] + 3 * dc + 2) >> 2);
+        }
+        return;
+    }
+    xo_pixel tmp[32 * 32];
+    ang_core(size, tmp, srcPix, dirMode, bFilter);
+    int hor = dirMode < 18;
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++)
+            dst[y * ds + x] = hor ? tmp[x * size + y] : tmp[y * size + x];
+}
+
+/* intrapred.cpp:206-234: 33 dense blocks, modes < 18 left un-transposed (i.e. predicted on flipped
+ * neighbours); source = filtPix when g_intraFilterFlags[mode] & size */
+void xo_intra_allangs(int size, xo_pixel* dst, const xo_pixel* refPix, const xo_pixel* filtPix, int bLuma)
+{
+    for (int mode = 2; mode <= 34; mode++)
+    {
+        const xo_pixel* sp = (k_intraFilterFlags[mode] & size) ? filtPix : refPix;
+        ang_core(size, dst + (mode - 2) * size * size, sp, mode, bLuma);
+    }
+}
