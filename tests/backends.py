@@ -101,3 +101,165 @@ class Ref:
     def intra_filter(self, n, samples, filt): return self._o(self.r.call("intra_filter", [n], [samples, filt])[0], filt)
     def intra_pred(self, n, src, dst, ds, mode, bfilter): return self._o(self.r.call("intra_pred", [n, ds, mode, bfilter], [src, dst])[0], dst)
     def intra_allangs(self, n, ref, filt, bluma): return np.frombuffer(self.r.call("intra_allangs", [n, bluma], [ref, filt])[0], self.pixel).copy()
+
+
+# --------------------------------------------------------------------------------------
+# The product, called through the drop-in table it fills (reference per-slot C signatures).
+# --------------------------------------------------------------------------------------
+import ctypes as _C  # noqa: E402
+
+_VP, _IP, _I = _C.c_void_p, _C.c_ssize_t, _C.c_int
+
+
+def _p(a, off=0):
+    return _C.c_void_p(a.ctypes.data + off * a.itemsize)
+
+
+class Hip:
+    def __init__(self, depth):
+        import x265hip
+        self.depth = depth
+        self.pixel = np.uint8 if depth == 8 else np.uint16
+        self.h = x265hip.HipLib(depth)
+        self.sse_t = _C.c_uint32 if depth == 8 else _C.c_uint64
+
+    _CMP = (_VP, _IP, _VP, _IP)
+
+    def sad(self, w, h, A, sa, oa, B, sb, ob): return self.h.pu(w, h, "sad", _I, self._CMP)(_p(A, oa), sa, _p(B, ob), sb)
+    def satd(self, w, h, A, sa, oa, B, sb, ob): return self.h.pu(w, h, "satd", _I, self._CMP)(_p(A, oa), sa, _p(B, ob), sb)
+    def sa8d(self, n, A, sa, oa, B, sb, ob): return self.h.cu(n, "sa8d", _I, self._CMP)(_p(A, oa), sa, _p(B, ob), sb)
+    def psy_cost_pp(self, n, A, sa, oa, B, sb, ob): return self.h.cu(n, "psy_cost_pp", _I, self._CMP)(_p(A, oa), sa, _p(B, ob), sb)
+    def sse_pp(self, n, A, sa, oa, B, sb, ob): return self.h.cu(n, "sse_pp", self.sse_t, self._CMP)(_p(A, oa), sa, _p(B, ob), sb)
+    def sse_ss(self, n, A, sa, oa, B, sb, ob): return self.h.cu(n, "sse_ss", self.sse_t, self._CMP)(_p(A, oa), sa, _p(B, ob), sb)
+    def ssd_s(self, n, A, sa, oa): return self.h.cu(n, "ssd_s", self.sse_t, (_VP, _IP))(_p(A, oa), sa)
+
+    def sad_x3(self, w, h, F, of, R, rs, offs):
+        res = np.zeros(4, np.int32)
+        self.h.pu(w, h, "sad_x3", None, (_VP, _VP, _VP, _VP, _IP, _VP))(_p(F, of), _p(R, offs[0]), _p(R, offs[1]), _p(R, offs[2]), rs, _p(res))
+        return res[:3].copy()
+
+    def sad_x4(self, w, h, F, of, R, rs, offs):
+        res = np.zeros(4, np.int32)
+        self.h.pu(w, h, "sad_x4", None, (_VP, _VP, _VP, _VP, _VP, _IP, _VP))(_p(F, of), _p(R, offs[0]), _p(R, offs[1]), _p(R, offs[2]), _p(R, offs[3]), rs, _p(res))
+        return res
+
+    # ---- block ops ----
+    def calcresidual(self, n, fenc, pred, resi, stride):
+        r = resi.copy(); self.h.cu(n, "calcresidual", None, (_VP, _VP, _VP, _IP))(_p(fenc), _p(pred), _p(r), stride); return r
+
+    def sub_ps(self, n, dst, ds, s0, s1, ss0, ss1):
+        d = dst.copy(); self.h.cu(n, "sub_ps", None, (_VP, _IP, _VP, _VP, _IP, _IP))(_p(d), ds, _p(s0), _p(s1), ss0, ss1); return d
+
+    def add_ps(self, n, dst, ds, s0, s1, ss0, ss1):
+        d = dst.copy(); self.h.cu(n, "add_ps", None, (_VP, _IP, _VP, _VP, _IP, _IP))(_p(d), ds, _p(s0), _p(s1), ss0, ss1); return d
+
+    def copy_pp(self, w, h, dst, ds, src, ss):
+        d = dst.copy(); self.h.pu(w, h, "copy_pp", None, (_VP, _IP, _VP, _IP))(_p(d), ds, _p(src), ss); return d
+
+    def _cucopy(self, name, n, dst, ds, src, ss):
+        d = dst.copy(); self.h.cu(n, name, None, (_VP, _IP, _VP, _IP))(_p(d), ds, _p(src), ss); return d
+
+    def copy_ss(self, n, dst, ds, src, ss): return self._cucopy("copy_ss", n, dst, ds, src, ss)
+    def copy_sp(self, n, dst, ds, src, ss): return self._cucopy("copy_sp", n, dst, ds, src, ss)
+    def copy_ps(self, n, dst, ds, src, ss): return self._cucopy("copy_ps", n, dst, ds, src, ss)
+
+    def blockfill_s(self, n, dst, ds, val):
+        d = dst.copy(); self.h.cu(n, "blockfill_s", None, (_VP, _IP, _C.c_int16))(_p(d), ds, val); return d
+
+    def _cpy(self, name, n, dst, src, st, sh):
+        d = dst.copy(); self.h.cu(n, name, None, (_VP, _VP, _IP, _I))(_p(d), _p(src), st, sh); return d
+
+    def cpy2Dto1D_shl(self, n, dst, src, ss, sh): return self._cpy("cpy2Dto1D_shl", n, dst, src, ss, sh)
+    def cpy2Dto1D_shr(self, n, dst, src, ss, sh): return self._cpy("cpy2Dto1D_shr", n, dst, src, ss, sh)
+    def cpy1Dto2D_shl(self, n, dst, src, ds, sh): return self._cpy("cpy1Dto2D_shl", n, dst, src, ds, sh)
+    def cpy1Dto2D_shr(self, n, dst, src, ds, sh): return self._cpy("cpy1Dto2D_shr", n, dst, src, ds, sh)
+
+    def transpose(self, n, dst, src, ss):
+        d = dst.copy(); self.h.cu(n, "transpose", None, (_VP, _VP, _IP))(_p(d), _p(src), ss); return d
+
+    def addAvg(self, w, h, s0, s1, dst, ss0, ss1, ds):
+        d = dst.copy(); self.h.pu(w, h, "addAvg", None, (_VP, _VP, _VP, _IP, _IP, _IP))(_p(s0), _p(s1), _p(d), ss0, ss1, ds); return d
+
+    def pixelavg_pp(self, w, h, dst, ds, s0, ss0, s1, ss1):
+        d = dst.copy(); self.h.pu(w, h, "pixelavg_pp", None, (_VP, _IP, _VP, _IP, _VP, _IP, _I))(_p(d), ds, _p(s0), ss0, _p(s1), ss1, 32); return d
+
+    def weight_sp(self, src, dst, ss, ds, w, h, w0, rnd, sh, off):
+        d = dst.copy(); self.h.scalar("weight_sp", None, (_VP, _VP, _IP, _IP, _I, _I, _I, _I, _I, _I))(_p(src), _p(d), ss, ds, w, h, w0, rnd, sh, off); return d
+
+    def weight_pp(self, src, dst, st, w, h, w0, rnd, sh, off):
+        d = dst.copy(); self.h.scalar("weight_pp", None, (_VP, _VP, _IP, _I, _I, _I, _I, _I, _I))(_p(src), _p(d), st, w, h, w0, rnd, sh, off); return d
+
+    def scale1D_128to64(self, dst, src):
+        d = dst.copy(); self.h.scalar("scale1D_128to64", None, (_VP, _VP))(_p(d), _p(src)); return d
+
+    def scale2D_64to32(self, dst, src, stride):
+        d = dst.copy(); self.h.scalar("scale2D_64to32", None, (_VP, _VP, _IP))(_p(d), _p(src), stride); return d
+
+    # ---- transforms ----
+    def dct(self, n, src, stride):
+        d = np.zeros(n * n, np.int16); self.h.cu(n, "dct", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def dst4(self, src, stride):
+        d = np.zeros(16, np.int16); self.h.scalar("dst4x4", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def idct(self, n, src, dst, stride):
+        d = dst.copy(); self.h.cu(n, "idct", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def idst4(self, src, dst, stride):
+        d = dst.copy(); self.h.scalar("idst4x4", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def quant(self, coef, qc, qbits, add, num):
+        du = np.zeros(num, np.int32); q = np.zeros(num, np.int16)
+        ns = self.h.scalar("quant", _C.c_uint32, (_VP, _VP, _VP, _VP, _I, _I, _I))(_p(coef), _p(qc), _p(du), _p(q), qbits, add, num)
+        return ns, q, du
+
+    def nquant(self, coef, qc, qbits, add, num):
+        q = np.zeros(num, np.int16)
+        ns = self.h.scalar("nquant", _C.c_uint32, (_VP, _VP, _VP, _I, _I, _I))(_p(coef), _p(qc), _p(q), qbits, add, num)
+        return ns, q
+
+    def dequant_normal(self, q, num, scale, shift):
+        c = np.zeros(num, np.int16); self.h.scalar("dequant_normal", None, (_VP, _VP, _I, _I, _I))(_p(q), _p(c), num, scale, shift); return c
+
+    def dequant_scaling(self, q, deq, num, per, shift):
+        c = np.zeros(num, np.int16); self.h.scalar("dequant_scaling", None, (_VP, _VP, _VP, _I, _I, _I))(_p(q), _p(deq), _p(c), num, per, shift); return c
+
+    def count_nonzero(self, n, q): return self.h.cu(n, "count_nonzero", _I, (_VP,))(_p(q))
+
+    def copy_cnt(self, n, resi, rs):
+        c = np.zeros(n * n, np.int16); ns = self.h.cu(n, "copy_cnt", _C.c_uint32, (_VP, _VP, _IP))(_p(c), _p(resi), rs); return ns, c
+
+    def denoise_dct(self, coef, ressum, offset, num):
+        c = coef.copy(); r = ressum.copy(); self.h.scalar("denoiseDct", None, (_VP, _VP, _VP, _I))(_p(c), _p(r), _p(offset), num); return c, r
+
+    # ---- interpolation ----
+    def interp(self, kind, taps, w, h, src, ss, so, dst, ds, idx, idx2=0):
+        d = dst.copy()
+        luma = taps == 8
+        if luma:
+            name = {"hpp": "luma_hpp", "hps": "luma_hps", "vpp": "luma_vpp", "vps": "luma_vps", "vsp": "luma_vsp",
+                    "vss": "luma_vss", "hvpp": "luma_hvpp", "p2s": "convert_p2s"}[kind]
+            get = lambda rt, at: self.h.pu(w, h, name, rt, at)  # noqa: E731
+        else:
+            name = {"hpp": "filter_hpp", "hps": "filter_hps", "vpp": "filter_vpp", "vps": "filter_vps",
+                    "vsp": "filter_vsp", "vss": "filter_vss", "p2s": "p2s"}[kind]
+            get = lambda rt, at: self.h.chroma_pu(2 * w, 2 * h, name, rt, at)  # noqa: E731
+        if kind == "hps":
+            get(None, (_VP, _IP, _VP, _IP, _I, _I))(_p(src, so), ss, _p(d), ds, idx, idx2)
+        elif kind == "hvpp":
+            get(None, (_VP, _IP, _VP, _IP, _I, _I))(_p(src, so), ss, _p(d), ds, idx, idx2)
+        elif kind == "p2s":
+            get(None, (_VP, _IP, _VP, _IP))(_p(src, so), ss, _p(d), ds)
+        else:
+            get(None, (_VP, _IP, _VP, _IP, _I))(_p(src, so), ss, _p(d), ds, idx)
+        return d
+
+    # ---- intra ----
+    def intra_filter(self, n, samples, filt):
+        f = filt.copy(); self.h.cu(n, "intra_filter", None, (_VP, _VP))(_p(samples), _p(f)); return f
+
+    def intra_pred(self, n, src, dst, ds, mode, bfilter):
+        d = dst.copy(); self.h.cu(n, "intra_pred", None, (_VP, _IP, _VP, _I, _I), extra=mode)(_p(d), ds, _p(src), mode, bfilter); return d
+
+    def intra_allangs(self, n, ref, filt, bluma):
+        d = np.zeros(33 * n * n, self.pixel); self.h.cu(n, "intra_pred_allangs", None, (_VP, _VP, _VP, _I))(_p(d), _p(ref), _p(filt), bluma); return d

@@ -1,0 +1,66 @@
+// xh_common.h -- shared definitions for the gfx950 back end (device + host side).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/x265hip.h"
+
+#ifndef X265_DEPTH
+#error "build with -DX265_DEPTH=8 or 10"
+#endif
+#if X265_DEPTH > 8
+typedef uint16_t pixel;
+typedef uint64_t sse_t;
+#else
+typedef uint8_t pixel;
+typedef uint32_t sse_t;
+#endif
+
+#define XH_PIXEL_MAX ((1 << X265_DEPTH) - 1)
+#define XH_IF_INTERNAL_PREC 14     // reference common.h:304-310
+#define XH_IF_FILTER_PREC 6
+#define XH_IF_INTERNAL_OFFS (1 << (XH_IF_INTERNAL_PREC - 1))
+#define XH_FENC_STRIDE 64          // reference common.h:71
+#define XH_WAVE 64
+
+namespace xh {
+
+// ---- error plumbing ----
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);          // records + returns X265HIP_EDEVICE
+[[noreturn]] void fatal(const char* what);             // slot functions cannot return errors
+
+#define XH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return xh::hip_fail(e_, #call); } while (0)
+#define XH_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return xh::hip_fail(e_, "kernel launch"); } while (0)
+
+// ---- device helpers ----
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ pixel clip_pixel(int v) { return (pixel)clip3(0, XH_PIXEL_MAX, v); }
+__device__ __forceinline__ int16_t clip16(int v) { return (int16_t)clip3(-32768, 32767, v); }
+
+// full-wave (64 lane) integer sum; result valid in every lane
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// HEVC core-transform coefficient by angle index (the numbers of constants.cpp:270-344)
+static __device__ const int8_t k_cos33[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                              61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+__device__ __forceinline__ int dct_coef(int kfull, int j)   // kfull = k * (32 / N)
+{
+    int th = (kfull * (2 * j + 1)) & 127;
+    int a = th <= 32 ? th : th <= 64 ? 64 - th : th <= 96 ? th - 64 : 128 - th;
+    int v = k_cos33[a];
+    return (th > 32 && th <= 96) ? -v : v;
+}
+
+} // namespace xh

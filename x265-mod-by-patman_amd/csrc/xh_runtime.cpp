@@ -1,0 +1,102 @@
+// xh_runtime.cpp -- error plumbing, per-thread stream/arena, host<->device staging.
+#include "xh_runtime.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace xh {
+
+static thread_local char g_err[512];
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what)
+{
+    set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+    return X265HIP_EDEVICE;
+}
+void fatal(const char* what)
+{
+    fprintf(stderr, "x265hip: FATAL: %s -- %s\n(no CPU fallback exists in this library)\n", what, g_err);
+    abort();
+}
+
+static thread_local ThreadCtx* t_ctx = nullptr;
+static const size_t kArena = 8u << 20;     // enough for any single slot call (64x64 blocks, 33 intra modes ...)
+
+ThreadCtx& ThreadCtx::get()
+{
+    if (t_ctx) return *t_ctx;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { hip_fail(e, "hipGetDeviceCount"); fatal("no HIP device available"); }
+    ThreadCtx* c = new ThreadCtx();
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) fatal("hipStreamCreate failed");
+    if (hipMalloc((void**)&c->arena, kArena) != hipSuccess) fatal("hipMalloc(arena) failed");
+    c->arenaSize = kArena;
+    if (hipHostMalloc((void**)&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) fatal("hipHostMalloc failed");
+    t_ctx = c;
+    // zero offsets live at the very start of the arena, outside the bump region
+    if (hipMemsetAsync(c->arena, 0, 256, c->stream) != hipSuccess) fatal("hipMemset failed");
+    return *c;
+}
+
+void* ThreadCtx::dalloc(size_t bytes)
+{
+    size_t off = 256 + ((arenaUsed + 255) & ~(size_t)255);
+    if (off + bytes > arenaSize) { set_error("slot arena exhausted (%zu bytes requested)", bytes); fatal("arena"); }
+    arenaUsed = off - 256 + bytes;
+    return arena + off;
+}
+void ThreadCtx::sync()
+{
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { hip_fail(e, "hipStreamSynchronize"); fatal("kernel execution failed"); }
+}
+const int32_t* dev_zero_offsets(ThreadCtx& c) { return (const int32_t*)c.arena; }
+
+DevBlock stage_in(ThreadCtx& c, const void* host, intptr_t stride, int w, int h, int es)
+{
+    DevBlock b;
+    if (stride >= w)
+    {
+        b.ptr = c.dalloc((size_t)w * h * es); b.stride = w;
+        if (hipMemcpy2DAsync(b.ptr, (size_t)w * es, host, (size_t)stride * es, (size_t)w * es, h, hipMemcpyHostToDevice, c.stream) != hipSuccess)
+            fatal("hipMemcpy2DAsync H2D failed");
+    }
+    else
+    {   // overlapping rows: copy the span [first element, last element]
+        size_t span = ((size_t)(h - 1) * (stride < 0 ? 0 : stride) + w) * es;
+        b.ptr = c.dalloc(span); b.stride = stride;
+        if (hipMemcpyAsync(b.ptr, host, span, hipMemcpyHostToDevice, c.stream) != hipSuccess) fatal("hipMemcpyAsync H2D failed");
+    }
+    return b;
+}
+void* stage_out_alloc(ThreadCtx& c, int w, int h, int es) { return c.dalloc((size_t)w * h * es); }
+void stage_out_copy(ThreadCtx& c, void* host, intptr_t stride, const void* dev, int w, int h, int es)
+{
+    if (hipMemcpy2DAsync(host, (size_t)stride * es, dev, (size_t)w * es, (size_t)w * es, h, hipMemcpyDeviceToHost, c.stream) != hipSuccess)
+        fatal("hipMemcpy2DAsync D2H failed");
+}
+
+} // namespace xh
+
+extern "C" const char* x265hip_last_error(void) { return xh::g_err; }
+extern "C" int x265hip_bit_depth(void) { return X265_DEPTH; }
+extern "C" int x265hip_device_init(int device)
+{
+    int n = 0;
+    XH_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { xh::set_error("device %d out of range (%d devices)", device, n); return X265HIP_EDEVICE; }
+    XH_HIP(hipSetDevice(device));
+    return X265HIP_OK;
+}
+extern "C" int x265hip_abi_check(size_t sizeof_table, int bit_depth)
+{
+    if (sizeof_table != X265HIP_SIZEOF_TABLE) { xh::set_error("sizeof(EncoderPrimitives) %zu != %d", sizeof_table, X265HIP_SIZEOF_TABLE); return X265HIP_EABI; }
+    if (bit_depth != X265_DEPTH) { xh::set_error("bit depth %d requested, library built for %d", bit_depth, X265_DEPTH); return X265HIP_EABI; }
+    return X265HIP_OK;
+}
