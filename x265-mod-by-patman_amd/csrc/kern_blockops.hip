@@ -1,0 +1,122 @@
+// kern_blockops.hip -- batched element-wise block primitives: residual / reconstruction / copies /
+// shifts / transpose / bi-pred averaging / weighted prediction / down-scaling
+// (reference pixel.cpp:385-483, 485-594, 751-854).  One 256-thread workgroup per block; lanes walk
+// the block row-major so global accesses are coalesced along rows.
+#include "xh_common.h"
+using namespace xh;
+
+namespace {
+
+struct BlkArgs
+{
+    void* dst; intptr_t ds; const int32_t* dOff;
+    const void* s0; intptr_t ss0; const int32_t* s0Off;
+    const void* s1; intptr_t ss1; const int32_t* s1Off;
+    int p0, p1, p2, p3;
+};
+
+template<int OP>
+__global__ __launch_bounds__(256) void blockop_kernel(int w, int h, BlkArgs a, int n)
+{
+    const int item = blockIdx.x;
+    const intptr_t dO = a.dOff ? a.dOff[item] : 0, o0 = a.s0Off ? a.s0Off[item] : 0, o1 = a.s1Off ? a.s1Off[item] : 0;
+    const int ow = (OP == X265HIP_BLK_SCALE2D) ? 32 : (OP == X265HIP_BLK_SCALE1D ? 64 : w);
+    const int oh = (OP == X265HIP_BLK_SCALE2D) ? 32 : (OP == X265HIP_BLK_SCALE1D ? 2 : h);
+    for (int i = threadIdx.x; i < ow * oh; i += 256)
+    {
+        const int y = i / ow, x = i - y * ow;
+        if (OP == X265HIP_BLK_CALCRESIDUAL || OP == X265HIP_BLK_SUB_PS)
+        {   // residual = fenc - pred (pixel.cpp:463-475, 806-818)
+            const pixel* f = (const pixel*)a.s0 + o0; const pixel* p = (const pixel*)a.s1 + o1;
+            ((int16_t*)a.dst + dO)[y * a.ds + x] = (int16_t)((int)f[y * a.ss0 + x] - (int)p[y * a.ss1 + x]);
+        }
+        else if (OP == X265HIP_BLK_ADD_PS)
+        {   // recon = clip(pred + resid) (pixel.cpp:820-832)
+            const pixel* p = (const pixel*)a.s0 + o0; const int16_t* r = (const int16_t*)a.s1 + o1;
+            ((pixel*)a.dst + dO)[y * a.ds + x] = clip_pixel((int)p[y * a.ss0 + x] + (int)r[y * a.ss1 + x]);
+        }
+        else if (OP == X265HIP_BLK_COPY_PP)
+            ((pixel*)a.dst + dO)[y * a.ds + x] = ((const pixel*)a.s0 + o0)[y * a.ss0 + x];
+        else if (OP == X265HIP_BLK_COPY_SS)
+            ((int16_t*)a.dst + dO)[y * a.ds + x] = ((const int16_t*)a.s0 + o0)[y * a.ss0 + x];
+        else if (OP == X265HIP_BLK_COPY_SP)
+            ((pixel*)a.dst + dO)[y * a.ds + x] = (pixel)((const int16_t*)a.s0 + o0)[y * a.ss0 + x];
+        else if (OP == X265HIP_BLK_COPY_PS)
+            ((int16_t*)a.dst + dO)[y * a.ds + x] = (int16_t)((const pixel*)a.s0 + o0)[y * a.ss0 + x];
+        else if (OP == X265HIP_BLK_FILL_S)
+            ((int16_t*)a.dst + dO)[y * a.ds + x] = (int16_t)a.p0;
+        else if (OP == X265HIP_BLK_2DTO1D_SHL || OP == X265HIP_BLK_1DTO2D_SHL)
+        {   // pixel.cpp:393-409, 427-443
+            int v = ((const int16_t*)a.s0 + o0)[y * a.ss0 + x];
+            ((int16_t*)a.dst + dO)[y * a.ds + x] = (int16_t)((uint32_t)v << a.p0);
+        }
+        else if (OP == X265HIP_BLK_2DTO1D_SHR || OP == X265HIP_BLK_1DTO2D_SHR)
+        {   // pixel.cpp:411-425, 445-461: round is an int16 (1 << (shift-1))
+            int v = ((const int16_t*)a.s0 + o0)[y * a.ss0 + x];
+            int16_t round = (int16_t)(1 << (a.p0 - 1));
+            ((int16_t*)a.dst + dO)[y * a.ds + x] = (int16_t)((v + round) >> a.p0);
+        }
+        else if (OP == X265HIP_BLK_TRANSPOSE)
+            ((pixel*)a.dst + dO)[y * a.ds + x] = ((const pixel*)a.s0 + o0)[x * a.ss0 + y];
+        else if (OP == X265HIP_BLK_ADDAVG)
+        {   // pixel.cpp:834-854
+            const int shift = XH_IF_INTERNAL_PREC + 1 - X265_DEPTH, offset = (1 << (shift - 1)) + 2 * XH_IF_INTERNAL_OFFS;
+            int v = (int)((const int16_t*)a.s0 + o0)[y * a.ss0 + x] + (int)((const int16_t*)a.s1 + o1)[y * a.ss1 + x];
+            ((pixel*)a.dst + dO)[y * a.ds + x] = clip_pixel((v + offset) >> shift);
+        }
+        else if (OP == X265HIP_BLK_PIXELAVG)
+        {   // pixel.cpp:537-549
+            int v = (int)((const pixel*)a.s0 + o0)[y * a.ss0 + x] + (int)((const pixel*)a.s1 + o1)[y * a.ss1 + x];
+            ((pixel*)a.dst + dO)[y * a.ds + x] = (pixel)((v + 1) >> 1);
+        }
+        else if (OP == X265HIP_BLK_WEIGHT_SP)
+        {   // pixel.cpp:485-508: p0=w0 p1=round p2=shift p3=offset
+            int v = ((const int16_t*)a.s0 + o0)[y * a.ss0 + x];
+            ((pixel*)a.dst + dO)[y * a.ds + x] = clip_pixel(((a.p0 * (v + XH_IF_INTERNAL_OFFS) + a.p1) >> a.p2) + a.p3);
+        }
+        else if (OP == X265HIP_BLK_WEIGHT_PP)
+        {   // pixel.cpp:510-535
+            int16_t v = (int16_t)((int)((const pixel*)a.s0 + o0)[y * a.ss0 + x] << (XH_IF_INTERNAL_PREC - X265_DEPTH));
+            ((pixel*)a.dst + dO)[y * a.ds + x] = clip_pixel(((a.p0 * (int)v + a.p1) >> a.p2) + a.p3);
+        }
+        else if (OP == X265HIP_BLK_SCALE1D)
+        {   // pixel.cpp:551-577: rows at src and src+128 -> rows at dst and dst+64
+            const pixel* s = (const pixel*)a.s0 + o0 + 128 * y;
+            ((pixel*)a.dst + dO)[64 * y + x] = (pixel)(((int)s[2 * x] + (int)s[2 * x + 1] + 1) >> 1);
+        }
+        else if (OP == X265HIP_BLK_SCALE2D)
+        {   // pixel.cpp:579-594
+            const pixel* s = (const pixel*)a.s0 + o0 + 2 * y * a.ss0 + 2 * x;
+            ((pixel*)a.dst + dO)[32 * y + x] = (pixel)(((int)s[0] + (int)s[1] + (int)s[a.ss0] + (int)s[a.ss0 + 1] + 2) >> 2);
+        }
+    }
+}
+
+template<int OP> int launch(hipStream_t st, int w, int h, const BlkArgs& a, int n)
+{
+    hipLaunchKernelGGL(blockop_kernel<OP>, dim3(n), dim3(256), 0, st, w, h, a, n);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+} // namespace
+
+extern "C" int x265hip_blockop_batch(void* stream, int op, int w, int h, const x265hip_blk_args* args, int n)
+{
+    if (n <= 0) return X265HIP_OK;
+    if (!args || w < 1 || h < 1 || w > 128 || h > 128) { set_error("blockop_batch: bad arguments"); return X265HIP_EARG; }
+    BlkArgs a = { args->dst, args->dstStride, args->dstOff, args->src0, args->src0Stride, args->src0Off,
+                  args->src1, args->src1Stride, args->src1Off, args->p0, args->p1, args->p2, args->p3 };
+    hipStream_t st = (hipStream_t)stream;
+    switch (op)
+    {
+#define C(O) case O: return launch<O>(st, w, h, a, n);
+    C(X265HIP_BLK_CALCRESIDUAL) C(X265HIP_BLK_SUB_PS) C(X265HIP_BLK_ADD_PS) C(X265HIP_BLK_COPY_PP) C(X265HIP_BLK_COPY_SS)
+    C(X265HIP_BLK_COPY_SP) C(X265HIP_BLK_COPY_PS) C(X265HIP_BLK_FILL_S) C(X265HIP_BLK_2DTO1D_SHL) C(X265HIP_BLK_2DTO1D_SHR)
+    C(X265HIP_BLK_1DTO2D_SHL) C(X265HIP_BLK_1DTO2D_SHR) C(X265HIP_BLK_TRANSPOSE) C(X265HIP_BLK_ADDAVG) C(X265HIP_BLK_PIXELAVG)
+    C(X265HIP_BLK_WEIGHT_SP) C(X265HIP_BLK_WEIGHT_PP) C(X265HIP_BLK_SCALE1D) C(X265HIP_BLK_SCALE2D)
+#undef C
+    }
+    set_error("blockop_batch: unknown op %d", op);
+    return X265HIP_EARG;
+}

@@ -1,0 +1,12 @@
+// xh_internal.h -- launchers shared between translation units but not part of the public C ABI.
+#pragma once
+#include "xh_common.h"
+
+int xh_count_nonzero(hipStream_t st, int N, const int16_t* q, int n, uint32_t* out);
+int xh_copy_count(hipStream_t st, int N, const int16_t* resi, intptr_t rs, int16_t* coef, uint32_t* out);
+int xh_denoise(hipStream_t st, int16_t* coef, uint32_t* resSum, const uint16_t* offset, int num);
+
+// 32x32 forward DCT: MFMA (i8 x i8 -> i32, two byte planes) and VALU/LDS variants
+bool xh_dct32_mfma_enabled();
+int xh_dct32_mfma(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t* sOff, int16_t* dst, const int32_t* dOff, int n);
+int xh_dct32_valu(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t* sOff, int16_t* dst, const int32_t* dOff, int n);

@@ -3,6 +3,7 @@
 // for ONE item and copy the result back.  Reentrant: all state is per calling thread.
 // x265hip_setup_primitives() is the "one more overwrite pass" of primitives.cpp:336-376.
 #include "xh_runtime.h"
+#include "xh_internal.h"
 #include <cstring>
 
 using namespace xh;
@@ -109,7 +110,10 @@ template<int W, int H> void s_sad_x3(const pixel* f, const pixel* r0, const pixe
 template<int W, int H> void s_sad_x4(const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
 { const pixel* r[4] = { r0, r1, r2, r3 }; slot_sad_xn(4, W, H, f, r, rs, res); }
 
-#include "xh_slots_more.inc"
+#include "xh_slots_blk.inc"
+#include "xh_slots_tr.inc"
+#include "xh_slots_ip.inc"
+#include "xh_slots_intra.inc"
 
 } // namespace
 
@@ -136,6 +140,9 @@ extern "C" int x265hip_setup_primitives(void* encoder_primitives, int bit_depth,
     CU(i, X265HIP_CU_SSE_PP) = (void*)s_sse_pp<N>; CU(i, X265HIP_CU_SSE_SS) = (void*)s_sse_ss<N>; \
     CU(i, X265HIP_CU_SSD_S) = (void*)s_ssd_s<N>; CU(i, X265HIP_CU_SSD_S_ALIGNED) = (void*)s_ssd_s<N>;
     XH_FOR_EACH_CU(FILL_CU)
-    fill_more(t, flags);
+    fill_blk(t);
+    fill_transform(t);
+    fill_interp(t);
+    fill_intra(t, flags);
     return X265HIP_OK;
 }
