@@ -35,6 +35,8 @@ class Oracle:
         L.xo_copy_count.restype = C.c_uint32
         L.xo_dct_matrix.restype = C.c_void_p
         assert L.xo_bit_depth() == depth
+        self.me_lib = C.CDLL(os.path.join(HERE, "libx265oracle_me_%d.so" % depth))
+        self.me_lib.xo_lambda.restype = C.c_double
 
     # ---- pixel compare ----
     def sad(self, w, h, A, sa, oa, B, sb, ob):
@@ -192,3 +194,22 @@ class Oracle:
 
     def intra_allangs(self, n, ref, filt, bluma):
         d = np.zeros(33 * n * n, self.pixel); self.lib.xo_intra_allangs(n, _ptr(d), _ptr(ref), _ptr(filt), bluma); return d
+
+    # ---- motion search driver (x265_oracle_me.c) ----
+    def mvcost_row(self, qp, half):
+        out = np.zeros(2 * half + 1, np.uint16)
+        self.me_lib.xo_mvcost_row(qp, half, _ptr(out))
+        return out
+
+    def lambda_tab(self):
+        return np.array([self.me_lib.xo_lambda(q) for q in range(70)])
+
+    def me(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, mvc, merange, method, subme, costrow):
+        """costrow: centred uint16 row (as returned by mvcost_row); returns (mvx, mvy, cost)."""
+        b = np.asarray(bounds, np.int32); c = np.asarray(mvc, np.int32).reshape(-1)
+        out = np.zeros(2, np.int32)
+        half = (len(costrow) - 1) // 2
+        cost = self.me_lib.xo_motion_estimate(_ptr(cur, coff), _IP(cstride), w, h, _ptr(ref, roff), _IP(rstride), _ptr(b),
+                                              int(qmvp[0]), int(qmvp[1]), len(c) // 2, _ptr(c) if len(c) else None,
+                                              merange, method, subme, _ptr(costrow, half), _ptr(out))
+        return int(out[0]), int(out[1]), int(cost)

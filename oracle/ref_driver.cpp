@@ -3,8 +3,9 @@
  *
  * Our own driver (no reference code in here) that is compiled TOGETHER WITH the
  * reference's primitive sources where they lie under /root/reference
- * (common/pixel.cpp, dct.cpp, ipfilter.cpp, intrapred.cpp, constants.cpp,
- * lowpassdct.cpp) into oracle/_ref/x265ref_{8,10}.  It fills a real
+ * (common/pixel.cpp, dct.cpp, ipfilter.cpp, intrapred.cpp, constants.cpp, lowpassdct.cpp,
+ * primitives.cpp, common.cpp, yuv.cpp, encoder/bitcost.cpp, encoder/motion.cpp) into
+ * oracle/_ref/x265ref_{8,10}.  It fills a real
  * EncoderPrimitives table through the reference's own setup*Primitives_c()
  * functions (primitives.cpp:56-75 lists them) and executes slot calls requested
  * over stdin/stdout, so the Python tests can compare oracle/x265_oracle.c (and
@@ -17,6 +18,8 @@
  */
 #include "common.h"
 #include "primitives.h"
+#include "motion.h"
+#include "lowres.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -37,7 +40,14 @@ extern const int16_t g_t32[32][32];
 }
 using namespace X265_NS;
 
-static EncoderPrimitives T;
+static EncoderPrimitives& T = X265_NS::primitives;   /* the reference's own global table (primitives.cpp:54) */
+
+/* exposes the protected lambda-scaled MVD cost row of BitCost (bitcost.h:54-67) */
+struct MEx : public MotionEstimate
+{
+    const uint16_t* costRow() const { return m_cost; }
+};
+static MEx* g_me;
 
 typedef std::vector<uint8_t> Buf;
 struct Req { std::string op; std::vector<int64_t> I; std::vector<Buf> B; };
@@ -309,6 +319,38 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         T.cu[cuIndex(n)].intra_pred_allangs((pixel*)d.data(), PX(B[0], 0), PX(B[1], 0), (int)I[1]); out.push_back(d); return true;
     }
     /* ---- timing helper for bench.py cpu_baseline(kind="reference"): ints = family, reps, w/h... ---- */
+    if (op == "lambda_tab")
+    {
+        Buf b((QP_MAX_MAX + 1) * 8); memcpy(b.data(), x265_lambda_tab, b.size()); out.push_back(b); return true;
+    }
+    if (op == "mvcost_row")
+    {   /* ints = qp, halfRange ; returns u16 cost[-halfRange..halfRange] (bitcost.cpp:30-56) */
+        g_me->setQP((unsigned)I[0]);
+        int hr = (int)I[1]; Buf b((2 * hr + 1) * 2);
+        memcpy(b.data(), g_me->costRow() - hr, b.size()); out.push_back(b); return true;
+    }
+    if (op == "me")
+    {   /* ints = w,h, fencStride,fencOff, refStride,refOff, mvmin.x,mvmin.y,mvmax.x,mvmax.y, qmvp.x,qmvp.y,
+                  merange, searchMethod, subpelRefine, qp, numCand, (mvc.x,mvc.y)* ; bufs = fenc plane, ref plane.
+           Runs the reference's MotionEstimate::motionEstimate (motion.cpp:923-1773) with the luma-only
+           setSourcePU (motion.cpp:203-231). */
+        int w = (int)I[0], h = (int)I[1];
+        ReferencePlanes rp;
+        rp.fpelPlane[0] = PX(B[1], I[5]);
+        rp.lumaStride = I[4];
+        rp.isLowres = false; rp.isHMELowres = false;
+        g_me->setQP((unsigned)I[15]);
+        g_me->setSourcePU(PX(B[0], 0), I[2], I[3], w, h, (int)I[13], (int)I[14]);
+        MV mvmin((int)I[6], (int)I[7]), mvmax((int)I[8], (int)I[9]), qmvp((int)I[10], (int)I[11]), outmv;
+        int nc = (int)I[16]; MV mvc[16];
+        for (int i = 0; i < nc && i < 16; i++) mvc[i] = MV((int)I[17 + 2 * i], (int)I[18 + 2 * i]);
+        /* blockOffset is the PU offset inside the fenc plane; the reference plane pointer is pre-offset so the
+           same blockOffset addresses the co-located block (lookahead calling convention, slicetype.cpp:4484) */
+        rp.fpelPlane[0] = PX(B[1], I[5]) - I[3];
+        int cost = g_me->motionEstimate(&rp, mvmin, mvmax, qmvp, nc, mvc, (int)I[12], outmv, 1, false);
+        int32_t r[3] = { outmv.x, outmv.y, cost };
+        Buf b(12); memcpy(b.data(), r, 12); out.push_back(b); return true;
+    }
     if (op == "time_tu")
     {   /* residual -> dct32 -> quant over `I[0]` TUs of B[0] (int16 residual, dense 32x32 each); returns ns */
         int ntu = (int)I[0], qBits = (int)I[1], add = (int)I[2];
@@ -336,6 +378,10 @@ int main()
     setupLowPassPrimitives_c(T);
     setupFilterPrimitives_c(T);
     setupIntraPrimitives_c(T);
+    setupAliasPrimitives(T);           /* primitives.cpp:178-284 */
+    MotionEstimate::initScales();
+    g_me = new MEx();
+    g_me->init(X265_CSP_I400);
     Req r;
     while (readReq(r))
     {

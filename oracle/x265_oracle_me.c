@@ -1,0 +1,418 @@
+/*
+ * x265_oracle_me.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference's motion-search DRIVER for one PU and one reference:
+ *   - BitCost::setQP / CalculateLogs  (encoder/bitcost.cpp:30-105): lambda-scaled MVD cost row
+ *   - MotionEstimate::motionEstimate  (encoder/motion.cpp:923-1773): start-point selection,
+ *     DIA / HEX / STAR / FULL integer search, sub-pel refinement per workload[subme], final zero-MV check
+ *   - MotionEstimate::subpelCompare   (encoder/motion.cpp:1775-1803, luma part)
+ * built on the primitive restatements of x265_oracle.c.  Pinned against the REAL reference driver
+ * (oracle/_ref, op "me" / "mvcost_row") by tests/test_me_oracle_vs_ref.py.
+ */
+#include "x265_oracle_me.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { int x, y; } mv_t;
+
+/* constants.cpp:28-116: x265_lambda_tab[q] = pow(2, q/6 - 2) * (1 << (depth-8)), tabulated to 4 decimals */
+double xo_lambda(int qp)
+{
+    double v = pow(2.0, (double)qp / 6.0 - 2.0) * (double)(1 << (X265_DEPTH - 8));
+    return floor(v * 10000.0 + 0.5) / 10000.0;
+}
+
+/* bitcost.cpp:87-100 CalculateLogs (float storage, double log) + :51-56 the uint16 cost row */
+void xo_mvcost_row(int qp, int halfRange, uint16_t* out)
+{
+    double lambda = xo_lambda(qp);
+    float log2_2 = (float)(2.0f / log(2.0f));
+    for (int i = 0; i <= halfRange; i++)
+    {
+        float bits = i ? (float)(log((double)(float)(i + 1)) * log2_2 + 1.718f) : 0.718f;
+        double c = bits * lambda + 0.5f;
+        if (c > (double)((1 << 15) - 1)) c = (double)((1 << 15) - 1);
+        out[halfRange + i] = out[halfRange - i] = (uint16_t)c;
+    }
+}
+
+typedef struct
+{
+    const xo_pixel* fref; intptr_t stride;       /* co-located block origin in the reference plane */
+    xo_pixel fenc[64 * 64];                        /* PU cached at FENC_STRIDE (motion.cpp:223-229) */
+    int w, h;
+    const uint16_t* cost;                          /* centred cost row */
+    mv_t mvp;
+} me_t;
+
+static inline int mvcost(const me_t* m, int qx, int qy)
+{   /* bitcost.h:57: uint16_t sum of the two table entries */
+    return (uint16_t)(m->cost[qx - m->mvp.x] + m->cost[qy - m->mvp.y]);
+}
+static inline int sad_at(const me_t* m, int mx, int my)
+{
+    return xo_sad(m->w, m->h, m->fenc, 64, m->fref + mx + my * m->stride, m->stride);
+}
+/* motion.cpp:1775-1803 */
+static int subpel_compare(const me_t* m, int qx, int qy, int useSatd)
+{
+    const xo_pixel* fref = m->fref + (qx >> 2) + (qy >> 2) * m->stride;
+    int xf = qx & 3, yf = qy & 3;
+    xo_pixel buf[64 * 64];
+    const xo_pixel* p = fref; intptr_t ps = m->stride;
+    if (xf | yf)
+    {
+        if (!yf) xo_interp_hpp(8, m->w, m->h, fref, m->stride, buf, m->w, xf);
+        else if (!xf) xo_interp_vpp(8, m->w, m->h, fref, m->stride, buf, m->w, yf);
+        else xo_interp_hvpp(8, m->w, m->h, fref, m->stride, buf, m->w, xf, yf);
+        p = buf; ps = m->w;
+    }
+    return useSatd ? xo_satd(m->w, m->h, m->fenc, 64, p, ps) : xo_sad(m->w, m->h, m->fenc, 64, p, ps);
+}
+
+static const mv_t hex2[8] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
+static const uint8_t mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+static const mv_t square1[9] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
+static const mv_t offsets2[16] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {-1,-1},
+                                   {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1} };
+/* motion.cpp:48-58 workload[]: hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd */
+static const int workload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
+
+static inline int in_range(mv_t v, mv_t mn, mv_t mx) { return v.x >= mn.x && v.x <= mx.x && v.y >= mn.y && v.y <= mx.y; }
+
+typedef struct { mv_t bmv; int bcost, bPointNr, bDistance; } star_t;
+
+#define PT_DIST(mx_, my_, point, dist) do { int c_ = sad_at(m, (mx_), (my_)) + mvcost(m, (mx_) * 4, (my_) * 4); \
+    if (c_ < s->bcost) { s->bcost = c_; s->bmv.x = (mx_); s->bmv.y = (my_); s->bPointNr = (point); s->bDistance = (dist); } } while (0)
+
+/* motion.cpp:387-629 */
+static void star_pattern(const me_t* m, mv_t mvmin, mv_t mvmax, star_t* s, int earlyExitIters, int merange)
+{
+    mv_t omv = s->bmv;
+    int saved = s->bcost, rounds = 0;
+    {
+        int dist = 1;
+        int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        /* the x4 form and the guarded scalar form visit the same points in the same order */
+        if (top >= mvmin.y) PT_DIST(omv.x, top, 2, dist);
+        if (left >= mvmin.x) PT_DIST(left, omv.y, 4, dist);
+        if (right <= mvmax.x) PT_DIST(right, omv.y, 5, dist);
+        if (bottom <= mvmax.y) PT_DIST(omv.x, bottom, 7, dist);
+        if (s->bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 2; dist <= 8; dist <<= 1)
+    {
+        int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        int top2 = omv.y - (dist >> 1), bottom2 = omv.y + (dist >> 1), left2 = omv.x - (dist >> 1), right2 = omv.x + (dist >> 1);
+        saved = s->bcost;
+        if (top >= mvmin.y && left >= mvmin.x && right <= mvmax.x && bottom <= mvmax.y)
+        {   /* x4 order: (2, 1, 3, 4) then (5, 6, 8, 7) */
+            PT_DIST(omv.x, top, 2, dist); PT_DIST(left2, top2, 1, dist >> 1); PT_DIST(right2, top2, 3, dist >> 1); PT_DIST(left, omv.y, 4, dist);
+            PT_DIST(right, omv.y, 5, dist); PT_DIST(left2, bottom2, 6, dist >> 1); PT_DIST(right2, bottom2, 8, dist >> 1); PT_DIST(omv.x, bottom, 7, dist);
+        }
+        else
+        {
+            if (top >= mvmin.y) PT_DIST(omv.x, top, 2, dist);
+            if (top2 >= mvmin.y)
+            {
+                if (left2 >= mvmin.x) PT_DIST(left2, top2, 1, dist >> 1);
+                if (right2 <= mvmax.x) PT_DIST(right2, top2, 3, dist >> 1);
+            }
+            if (left >= mvmin.x) PT_DIST(left, omv.y, 4, dist);
+            if (right <= mvmax.x) PT_DIST(right, omv.y, 5, dist);
+            if (bottom2 <= mvmax.y)
+            {
+                if (left2 >= mvmin.x) PT_DIST(left2, bottom2, 6, dist >> 1);
+                if (right2 <= mvmax.x) PT_DIST(right2, bottom2, 8, dist >> 1);
+            }
+            if (bottom <= mvmax.y) PT_DIST(omv.x, bottom, 7, dist);
+        }
+        if (s->bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 16; dist <= (int16_t)merange; dist <<= 1)
+    {
+        int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        saved = s->bcost;
+        int all = top >= mvmin.y && left >= mvmin.x && right <= mvmax.x && bottom <= mvmax.y;
+        if (all || top >= mvmin.y) PT_DIST(omv.x, top, 0, dist);
+        if (all || left >= mvmin.x) PT_DIST(left, omv.y, 0, dist);
+        if (all || right <= mvmax.x) PT_DIST(right, omv.y, 0, dist);
+        if (all || bottom <= mvmax.y) PT_DIST(omv.x, bottom, 0, dist);
+        for (int index = 1; index < 4; index++)
+        {
+            int posYT = top + ((dist >> 2) * index), posYB = bottom - ((dist >> 2) * index);
+            int posXL = omv.x - ((dist >> 2) * index), posXR = omv.x + ((dist >> 2) * index);
+            if (all)
+            {
+                PT_DIST(posXL, posYT, 0, dist); PT_DIST(posXR, posYT, 0, dist); PT_DIST(posXL, posYB, 0, dist); PT_DIST(posXR, posYB, 0, dist);
+            }
+            else
+            {
+                if (posYT >= mvmin.y)
+                {
+                    if (posXL >= mvmin.x) PT_DIST(posXL, posYT, 0, dist);
+                    if (posXR <= mvmax.x) PT_DIST(posXR, posYT, 0, dist);
+                }
+                if (posYB <= mvmax.y)
+                {
+                    if (posXL >= mvmin.x) PT_DIST(posXL, posYB, 0, dist);
+                    if (posXR <= mvmax.x) PT_DIST(posXR, posYB, 0, dist);
+                }
+            }
+        }
+        if (s->bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+}
+
+#define COST_MV(mx_, my_) do { int c_ = sad_at(m, (mx_), (my_)) + mvcost(m, (mx_) * 4, (my_) * 4); \
+    if (c_ < bcost) { bcost = c_; bmv.x = (mx_); bmv.y = (my_); } } while (0)
+
+int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h,
+                       const xo_pixel* fref, intptr_t refStride,
+                       const int32_t* bounds /* mvmin.x, mvmin.y, mvmax.x, mvmax.y (full-pel) */,
+                       int qmvpx, int qmvpy, int numCand, const int32_t* mvc /* qpel x,y pairs */,
+                       int merange, int method, int subme, const uint16_t* costRowCentre, int32_t* outQMv)
+{
+    me_t me, *m = &me;
+    m->fref = fref; m->stride = refStride; m->w = w; m->h = h; m->cost = costRowCentre;
+    m->mvp.x = qmvpx; m->mvp.y = qmvpy;
+    for (int y = 0; y < h; y++) memcpy(m->fenc + 64 * y, fencPlane + y * fencStride, w * sizeof(xo_pixel));
+    const mv_t mvmin = { bounds[0], bounds[1] }, mvmax = { bounds[2], bounds[3] };
+    const mv_t qmvmin = { mvmin.x * 4, mvmin.y * 4 }, qmvmax = { mvmax.x * 4, mvmax.y * 4 };
+    int costs[4];
+
+    /* motion.cpp:955-1012: start point */
+    mv_t pmv = { qmvpx > qmvmax.x ? qmvmax.x : qmvpx, qmvpy > qmvmax.y ? qmvmax.y : qmvpy };
+    if (pmv.x < qmvmin.x) pmv.x = qmvmin.x;
+    if (pmv.y < qmvmin.y) pmv.y = qmvmin.y;
+    mv_t bestpre = pmv;
+    int bprecost = subpel_compare(m, pmv.x, pmv.y, 0);           /* no mvcost on the MVP itself (:970) */
+    mv_t bmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };
+    int bcost = bprecost;
+    if ((pmv.x | pmv.y) & 3)
+        bcost = sad_at(m, bmv.x, bmv.y) + mvcost(m, bmv.x * 4, bmv.y * 4);
+    if (pmv.x | pmv.y)
+    {
+        int cost = sad_at(m, 0, 0) + mvcost(m, 0, 0);
+        if (cost < bcost)
+        {
+            bcost = cost; bmv.x = 0;
+            int t = 0 < mvmax.y ? 0 : mvmax.y;
+            bmv.y = t > mvmin.y ? t : mvmin.y;
+        }
+    }
+    for (int i = 0; i < numCand; i++)
+    {
+        mv_t c = { mvc[2 * i], mvc[2 * i + 1] };
+        if (c.x > qmvmax.x) c.x = qmvmax.x; if (c.y > qmvmax.y) c.y = qmvmax.y;
+        if (c.x < qmvmin.x) c.x = qmvmin.x; if (c.y < qmvmin.y) c.y = qmvmin.y;
+        if ((c.x | c.y) && !(c.x == pmv.x && c.y == pmv.y) && !(c.x == bestpre.x && c.y == bestpre.y))
+        {
+            int cost = subpel_compare(m, c.x, c.y, 0) + mvcost(m, c.x, c.y);
+            if (cost < bprecost) { bprecost = cost; bestpre = c; }
+        }
+    }
+    pmv.x = (pmv.x + 2) >> 2; pmv.y = (pmv.y + 2) >> 2;
+    if (bcost == 0)
+    {
+        outQMv[0] = bmv.x * 4; outQMv[1] = bmv.y * 4;
+        return mvcost(m, bmv.x * 4, bmv.y * 4);
+    }
+
+    switch (method)
+    {
+    case XO_ME_DIA:
+    {   /* motion.cpp:1016-1039 */
+        unsigned ubcost = (unsigned)bcost << 4;
+        int i = merange;
+        do
+        {
+            static const mv_t d[4] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
+            for (int k = 0; k < 4; k++) costs[k] = sad_at(m, bmv.x + d[k].x, bmv.y + d[k].y) + mvcost(m, (bmv.x + d[k].x) * 4, (bmv.y + d[k].y) * 4);
+            int bc = (int)ubcost;
+            if ((bmv.y - 1 >= mvmin.y) & (bmv.y - 1 <= mvmax.y)) { if ((costs[0] << 4) + 1 < bc) bc = (costs[0] << 4) + 1; }
+            if ((bmv.y + 1 >= mvmin.y) & (bmv.y + 1 <= mvmax.y)) { if ((costs[1] << 4) + 3 < bc) bc = (costs[1] << 4) + 3; }
+            if ((costs[2] << 4) + 4 < bc) bc = (costs[2] << 4) + 4;
+            if ((costs[3] << 4) + 12 < bc) bc = (costs[3] << 4) + 12;
+            ubcost = (unsigned)bc;
+            if (!(bc & 15)) break;
+            bmv.x -= (int32_t)((uint32_t)bc << 28) >> 30;
+            bmv.y -= (int32_t)((uint32_t)bc << 30) >> 30;
+            ubcost &= ~15u;
+        }
+        while (--i && in_range(bmv, mvmin, mvmax));
+        bcost = (int)ubcost >> 4;
+        break;
+    }
+    case XO_ME_HEX:
+    {   /* motion.cpp:1041-1140 */
+#define X3_DIR(a, b, c) do { const mv_t d_[3] = { a, b, c }; for (int k_ = 0; k_ < 3; k_++) \
+        costs[k_] = sad_at(m, bmv.x + d_[k_].x, bmv.y + d_[k_].y) + mvcost(m, (bmv.x + d_[k_].x) * 4, (bmv.y + d_[k_].y) * 4); } while (0)
+#define LT1(x, y) do { if ((y) < (x)) (x) = (y); } while (0)
+        { const mv_t a = {-2,0}, b = {-1,2}, c = {1,2}; X3_DIR(a, b, c); }
+        bcost <<= 3;
+        if ((bmv.y >= mvmin.y) & (bmv.y <= mvmax.y)) LT1(bcost, (costs[0] << 3) + 2);
+        if ((bmv.y + 2 >= mvmin.y) & (bmv.y + 2 <= mvmax.y)) { LT1(bcost, (costs[1] << 3) + 3); LT1(bcost, (costs[2] << 3) + 4); }
+        { const mv_t a = {2,0}, b = {1,-2}, c = {-1,-2}; X3_DIR(a, b, c); }
+        if ((bmv.y >= mvmin.y) & (bmv.y <= mvmax.y)) LT1(bcost, (costs[0] << 3) + 5);
+        if ((bmv.y - 2 >= mvmin.y) & (bmv.y - 2 <= mvmax.y)) { LT1(bcost, (costs[1] << 3) + 6); LT1(bcost, (costs[2] << 3) + 7); }
+        if (bcost & 7)
+        {
+            int dir = (bcost & 7) - 2;
+            if ((bmv.y + hex2[dir + 1].y >= mvmin.y) & (bmv.y + hex2[dir + 1].y <= mvmax.y))
+            {
+                bmv.x += hex2[dir + 1].x; bmv.y += hex2[dir + 1].y;
+                for (int i = (merange >> 1) - 1; i > 0 && in_range(bmv, mvmin, mvmax); i--)
+                {
+                    X3_DIR(hex2[dir + 0], hex2[dir + 1], hex2[dir + 2]);
+                    bcost &= ~7;
+                    if ((bmv.y + hex2[dir + 0].y >= mvmin.y) & (bmv.y + hex2[dir + 0].y <= mvmax.y)) LT1(bcost, (costs[0] << 3) + 1);
+                    if ((bmv.y + hex2[dir + 1].y >= mvmin.y) & (bmv.y + hex2[dir + 1].y <= mvmax.y)) LT1(bcost, (costs[1] << 3) + 2);
+                    if ((bmv.y + hex2[dir + 2].y >= mvmin.y) & (bmv.y + hex2[dir + 2].y <= mvmax.y)) LT1(bcost, (costs[2] << 3) + 3);
+                    if (!(bcost & 7)) break;
+                    dir += (bcost & 7) - 2;
+                    dir = mod6m1[dir + 1];
+                    bmv.x += hex2[dir + 1].x; bmv.y += hex2[dir + 1].y;
+                }
+            }
+        }
+        bcost >>= 3;
+        /* square refine */
+        int dir = 0;
+        static const mv_t sq[8] = { {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
+        int c8[8];
+        for (int k = 0; k < 8; k++) c8[k] = sad_at(m, bmv.x + sq[k].x, bmv.y + sq[k].y) + mvcost(m, (bmv.x + sq[k].x) * 4, (bmv.y + sq[k].y) * 4);
+        int upOk = (bmv.y - 1 >= mvmin.y) & (bmv.y - 1 <= mvmax.y), dnOk = (bmv.y + 1 >= mvmin.y) & (bmv.y + 1 <= mvmax.y);
+        if (upOk && c8[0] < bcost) { bcost = c8[0]; dir = 1; }
+        if (dnOk && c8[1] < bcost) { bcost = c8[1]; dir = 2; }
+        if (c8[2] < bcost) { bcost = c8[2]; dir = 3; }
+        if (c8[3] < bcost) { bcost = c8[3]; dir = 4; }
+        if (upOk && c8[4] < bcost) { bcost = c8[4]; dir = 5; }
+        if (dnOk && c8[5] < bcost) { bcost = c8[5]; dir = 6; }
+        if (upOk && c8[6] < bcost) { bcost = c8[6]; dir = 7; }
+        if (dnOk && c8[7] < bcost) { bcost = c8[7]; dir = 8; }
+        bmv.x += square1[dir].x; bmv.y += square1[dir].y;
+        break;
+    }
+    case XO_ME_STAR:
+    {   /* motion.cpp:1328-1436 */
+        star_t st = { bmv, bcost, 0, 0 }, *s = &st;
+        star_pattern(m, mvmin, mvmax, s, 3, merange);
+        bmv = s->bmv; bcost = s->bcost;
+        int done = 0;
+        if (s->bDistance == 1)
+        {
+            if (s->bPointNr)
+            {
+                int saved = bcost;
+                mv_t mv1 = { bmv.x + offsets2[(s->bPointNr - 1) * 2].x, bmv.y + offsets2[(s->bPointNr - 1) * 2].y };
+                mv_t mv2 = { bmv.x + offsets2[(s->bPointNr - 1) * 2 + 1].x, bmv.y + offsets2[(s->bPointNr - 1) * 2 + 1].y };
+                if (in_range(mv1, mvmin, mvmax)) COST_MV(mv1.x, mv1.y);
+                if (in_range(mv2, mvmin, mvmax)) COST_MV(mv2.x, mv2.y);
+                if (bcost == saved) done = 1;
+            }
+            else done = 1;
+        }
+        if (done) break;
+        const int RasterDistance = 5;
+        if (s->bDistance > RasterDistance)
+        {
+            mv_t t;
+            for (t.y = mvmin.y; t.y <= mvmax.y; t.y += RasterDistance)
+                for (t.x = mvmin.x; t.x <= mvmax.x; t.x += RasterDistance)
+                {
+                    if (t.x + RasterDistance * 3 <= mvmax.x)
+                    {
+                        for (int k = 0; k < 4; k++) costs[k] = sad_at(m, t.x + RasterDistance * k, t.y);
+                        for (int k = 0; k < 4; k++)
+                        {
+                            if (k) t.x += RasterDistance;
+                            /* reference quirk (:1392): the 4th candidate's mv cost is taken at tmv << 3 */
+                            int c = costs[k] + (k == 3 ? mvcost(m, t.x * 8, t.y * 8) : mvcost(m, t.x * 4, t.y * 4));
+                            if (c < bcost) { bcost = c; bmv = t; }
+                        }
+                    }
+                    else
+                        COST_MV(t.x, t.y);
+                }
+        }
+        int bDistance = s->bDistance;
+        while (bDistance > 0)
+        {
+            st.bmv = bmv; st.bcost = bcost; st.bPointNr = 0; st.bDistance = 0;
+            star_pattern(m, mvmin, mvmax, s, 32, merange);
+            bmv = s->bmv; bcost = s->bcost; bDistance = s->bDistance;
+            if (bDistance == 1)
+            {
+                if (!s->bPointNr) break;
+                mv_t mv1 = { bmv.x + offsets2[(s->bPointNr - 1) * 2].x, bmv.y + offsets2[(s->bPointNr - 1) * 2].y };
+                mv_t mv2 = { bmv.x + offsets2[(s->bPointNr - 1) * 2 + 1].x, bmv.y + offsets2[(s->bPointNr - 1) * 2 + 1].y };
+                if (in_range(mv1, mvmin, mvmax)) COST_MV(mv1.x, mv1.y);
+                if (in_range(mv2, mvmin, mvmax)) COST_MV(mv2.x, mv2.y);
+                break;
+            }
+        }
+        break;
+    }
+    case XO_ME_FULL:
+    {   /* motion.cpp:1593-1637 (visiting order == plain raster) */
+        mv_t t;
+        for (t.y = mvmin.y; t.y <= mvmax.y; t.y++)
+            for (t.x = mvmin.x; t.x <= mvmax.x; t.x++)
+                COST_MV(t.x, t.y);
+        break;
+    }
+    default:
+        return -1;
+    }
+
+    /* motion.cpp:1644-1768 */
+    if (bprecost < bcost) { bmv = bestpre; bcost = bprecost; }
+    else { bmv.x *= 4; bmv.y *= 4; }
+    const int* wl = workload[subme];
+    if (!bcost)
+        bcost = mvcost(m, bmv.x, bmv.y);
+    else
+    {
+        int hpelSatd = wl[4];
+        if (hpelSatd) bcost = subpel_compare(m, bmv.x, bmv.y, 1) + mvcost(m, bmv.x, bmv.y);
+        for (int iter = 0; iter < wl[0]; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[1]; i++)
+            {
+                int qx = bmv.x + square1[i].x * 2, qy = bmv.y + square1[i].y * 2;
+                if ((qy < qmvmin.y) | (qy > qmvmax.y)) continue;
+                int cost = subpel_compare(m, qx, qy, hpelSatd) + mvcost(m, qx, qy);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bmv.x += square1[bdir].x * 2; bmv.y += square1[bdir].y * 2; }
+            else break;
+        }
+        if (!hpelSatd) bcost = subpel_compare(m, bmv.x, bmv.y, 1) + mvcost(m, bmv.x, bmv.y);
+        for (int iter = 0; iter < wl[2]; iter++)
+        {
+            int bdir = 0;
+            for (int i = 1; i <= wl[3]; i++)
+            {
+                int qx = bmv.x + square1[i].x, qy = bmv.y + square1[i].y;
+                if ((qy < qmvmin.y) | (qy > qmvmax.y)) continue;
+                int cost = subpel_compare(m, qx, qy, 1) + mvcost(m, qx, qy);
+                if (cost < bcost) { bcost = cost; bdir = i; }
+            }
+            if (bdir) { bmv.x += square1[bdir].x; bmv.y += square1[bdir].y; }
+            else break;
+        }
+    }
+    if (bmv.x | bmv.y)
+    {
+        int cost = subpel_compare(m, 0, 0, 1) + mvcost(m, 0, 0);
+        if (cost <= bcost) { bmv.x = 0; bmv.y = 0; }
+    }
+    outQMv[0] = bmv.x; outQMv[1] = bmv.y;
+    return bcost;
+}

@@ -102,6 +102,17 @@ class Ref:
     def intra_pred(self, n, src, dst, ds, mode, bfilter): return self._o(self.r.call("intra_pred", [n, ds, mode, bfilter], [src, dst])[0], dst)
     def intra_allangs(self, n, ref, filt, bluma): return np.frombuffer(self.r.call("intra_allangs", [n, bluma], [ref, filt])[0], self.pixel).copy()
 
+    # ---- the reference's own MotionEstimate / BitCost (motion.cpp, bitcost.cpp) ----
+    def mvcost_row(self, qp, half): return np.frombuffer(self.r.call("mvcost_row", [qp, half])[0], np.uint16).copy()
+    def lambda_tab(self): return np.frombuffer(self.r.call("lambda_tab")[0], np.float64)[:70].copy()
+
+    def me(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, mvc, merange, method, subme, qp):
+        mvc = [int(v) for v in np.asarray(mvc).reshape(-1)]
+        ints = [w, h, cstride, coff, rstride, roff] + [int(b) for b in bounds] + [int(qmvp[0]), int(qmvp[1]), merange, method, subme, qp,
+                                                                                  len(mvc) // 2] + mvc
+        o = np.frombuffer(self.r.call("me", ints, [cur, ref])[0], np.int32)
+        return int(o[0]), int(o[1]), int(o[2])
+
 
 # --------------------------------------------------------------------------------------
 # The product, called through the drop-in table it fills (reference per-slot C signatures).
