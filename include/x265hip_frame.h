@@ -1,0 +1,82 @@
+/*
+ * x265hip_frame.h -- frame/CTU-granular batched entry points (device-resident planes).
+ *
+ * These are the throughput path: what the per-call table slots of x265hip.h compute one block at a
+ * time, computed for every PU / TU of a frame in one launch.  The contracts mirror the reference's
+ * own decoupled-ME seam (encoder/threadedme.h:122-130 `MEData`, search.cpp:226-560
+ * `puMotionEstimation`): per (PU, reference) a search window, a predictor and candidates go in, a
+ * quarter-pel MV and its cost come out in a flat array.
+ *
+ * All pointers are DEVICE memory; `stream` is a hipStream_t.  Planes are padded like the reference's
+ * PicYuv (picyuv.cpp:91-111): every address the search can touch -- block + mv range + 8 pixels of
+ * interpolation / pattern overshoot -- must be inside the allocation.
+ */
+#ifndef X265HIP_FRAME_H
+#define X265HIP_FRAME_H
+#include "x265hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* search methods, numbered like X265_*_SEARCH (reference x265.h:511-518) */
+enum x265hip_me_method { X265HIP_ME_DIA = 0, X265HIP_ME_HEX = 1, X265HIP_ME_UMH = 2, X265HIP_ME_STAR = 3,
+                         X265HIP_ME_SEA = 4, X265HIP_ME_FULL = 5 };
+
+/* one (PU, reference) search; all PUs of one x265hip_me_batch call share (w, h).
+ * replaces: MotionEstimate::setSourcePU + motionEstimate (motion.cpp:203-231, 923-1773) */
+typedef struct x265hip_me_task {
+    int32_t curOff;              /* element offset of the PU's top-left pixel in the source plane   */
+    int32_t refOff;              /* element offset of the co-located pixel in the reference plane   */
+    int16_t mvmin[2], mvmax[2];  /* full-pel search bounds (x, y), inclusive (motion.cpp:925-926)    */
+    int16_t qmvp[2];             /* quarter-pel MV predictor                                         */
+    int16_t mvc[8];              /* up to 4 quarter-pel candidates (x, y)                            */
+    int32_t numCand;             /* 0..4                                                             */
+} x265hip_me_task;               /* 40 bytes */
+
+typedef struct x265hip_me_result {
+    int16_t mv[2];               /* chosen quarter-pel MV (outQMv)                                   */
+    int32_t cost;                /* return value of motionEstimate: distortion + lambda * MVD bits   */
+    int32_t mvcost;              /* the lambda-scaled MVD cost of mv (BitCost::mvcost)               */
+    int32_t reserved;
+} x265hip_me_result;             /* 16 bytes */
+
+/* costRow: device uint16 table of 2*costHalfRange+1 entries, entry [costHalfRange + d] = lambda-scaled cost
+ * of an MVD component d in quarter-pels -- the row BitCost::setQP builds (bitcost.cpp:30-56); it is an
+ * INPUT so that host and device use the very same table.  costHalfRange must cover |mv - mvp| (and
+ * 8 * mv for the STAR raster quirk, motion.cpp:1392). */
+int x265hip_me_batch(void* stream, int w, int h,
+                     const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                     const x265hip_me_task* tasks, int n,
+                     const uint16_t* costRow, int costHalfRange,
+                     int merange, int method, int subpelRefine, x265hip_me_result* results);
+
+/* one transform unit of the inter residual path; all TUs of one call share log2 size.
+ * replaces the chain Predict::predInterLumaPixel (predict.cpp:279-300: copy_pp | luma_hpp | luma_vpp |
+ * luma_hvpp by MV fraction) -> cu[].sub_ps -> Quant::transformNxN (quant.cpp:397-480: cu[].dct -> quant)
+ * and, when recon is requested, Quant::invtransformNxN (quant.cpp:543-605: dequant_normal -> cu[].idct,
+ * DC shortcut :588-597) -> cu[].add_ps -> cu[].sse_pp (search.cpp:5563-5575). */
+typedef struct x265hip_tu_task {
+    int32_t curOff;              /* TU top-left in the source plane                                   */
+    int32_t refOff;              /* co-located pixel in the reference plane                           */
+    int16_t mv[2];               /* quarter-pel MV used for motion compensation                       */
+    int32_t reconOff;            /* TU top-left in the recon plane (ignored without recon)            */
+} x265hip_tu_task;               /* 16 bytes */
+
+typedef struct x265hip_tq_params {
+    int qp;                      /* 0..51: per = qp/6, rem = qp%6 (quant.cpp:465-469,555-568)         */
+    int add;                     /* quant rounding numerator: 171 (intra) or 85 (inter), << (qBits-9) */
+    const int32_t* quantCoeff;   /* numCoeff-long table or NULL = flat s_quantScales[rem] (scalinglist.cpp:129) */
+    int32_t* deltaU;             /* optional: n * N*N int32 (quant_c's deltaU) or NULL                */
+} x265hip_tq_params;
+
+int x265hip_tq_batch(void* stream, int log2TrSize,
+                     const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                     const x265hip_tu_task* tasks, int n, const x265hip_tq_params* params,
+                     int16_t* coeff /* n x N*N dense */, uint32_t* numSig /* n */,
+                     void* reconPlane /* NULL = forward path only */, intptr_t reconStride, uint64_t* sse /* n, with recon */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+"""GPU parity of the batched motion search (x265hip_me_batch) against the restated reference driver
+(oracle/x265_oracle_me.c, itself pinned to the real motion.cpp): MV and cost must be identical."""
+import numpy as np
+import pytest
+
+import x265hip  # noqa: F401
+from x265hip_pkg.synth import frame_pair
+from x265hip_pkg.frame import FrameApi, ME_TASK, ME_RESULT
+from backends import Oracle
+
+pytestmark = pytest.mark.gpu
+
+PUS = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64), (16, 12), (12, 16),
+       (16, 4), (4, 16), (32, 24), (24, 32), (32, 8), (8, 32), (64, 48), (48, 64), (64, 16), (16, 64), (8, 4), (4, 8)]
+
+
+def make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange):
+    t = np.zeros(n, ME_TASK)
+    for i in range(n):
+        px = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+        py = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        off = (margin + py) * stride + margin + px
+        r = rng.random()
+        if r < 0.6:
+            qmvp = (4 * dx + int(rng.integers(-9, 10)), 4 * dy + int(rng.integers(-9, 10)))
+        elif r < 0.8:
+            qmvp = (0, 0)
+        else:
+            qmvp = (int(rng.integers(-120, 121)), int(rng.integers(-120, 121)))
+        lim = margin - 16
+        fx, fy = qmvp[0] >> 2, qmvp[1] >> 2
+        t[i]["curOff"] = off; t[i]["refOff"] = off
+        t[i]["mvmin"] = (max(fx - merange, -px - lim), max(fy - merange, -py - lim))
+        t[i]["mvmax"] = (min(fx + merange, W - px - w + lim), min(fy + merange, H - py - h + lim))
+        t[i]["qmvp"] = qmvp
+        nc = int(rng.integers(0, 5))
+        t[i]["numCand"] = nc
+        t[i]["mvc"][:2 * nc] = rng.integers(-80, 81, 2 * nc)
+    return t
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method", [0, 1, 3])      # DIA, HEX, STAR
+def test_me_batch_matches_oracle(depth, method):
+    api, ora = FrameApi(depth), Oracle(depth)
+    rng = np.random.default_rng(77 * depth + method)
+    W, H, margin = 320, 192, 96
+    half = 1 << 13
+    for seed in range(2):
+        cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 10 + seed, margin=margin, max_shift=10 if seed else 28)
+        cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
+        d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+        for (w, h) in PUS:
+            merange = int(rng.choice([8, 16, 57]))
+            qp = int(rng.choice([22, 28, 37]))
+            subme = int(rng.integers(0, 8))
+            n = 24 if w * h <= 1024 else 10
+            tasks = make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange)
+            row = ora.mvcost_row(qp, half)
+            d_tasks, d_row = api.to_device(tasks), api.to_device(row.view(np.int16))
+            d_res = api.torch.zeros(n * ME_RESULT.itemsize, dtype=api.torch.uint8, device="cuda")
+            api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, merange, method, subme, d_res)
+            api.torch.cuda.synchronize()
+            res = d_res.cpu().numpy().view(ME_RESULT)
+            for i in range(n):
+                tk = tasks[i]
+                bounds = [int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])]
+                mvc = [int(v) for v in tk["mvc"][:2 * int(tk["numCand"])]]
+                exp = ora.me(w, h, cur_f, stride, int(tk["curOff"]), ref_f, stride, int(tk["refOff"]), bounds,
+                             (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc, merange, method, subme, row)
+                got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
+                assert got == exp, "PU %dx%d task %d method %d subme %d merange %d: hip %s oracle %s (mvp %s)" % (
+                    w, h, i, method, subme, merange, got, exp, tk["qmvp"])

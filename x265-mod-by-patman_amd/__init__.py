@@ -5,3 +5,4 @@ C ABI in include/x265hip.h).  This package only locates/builds/loads them for te
 tooling; it contains no arithmetic and no CPU fallback.
 """
 from .binding import HipLib, build_libraries, lib_path  # noqa: F401
+from . import synth  # noqa: F401

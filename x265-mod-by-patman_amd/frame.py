@@ -1,0 +1,57 @@
+"""Python-side plumbing for the frame-level C ABI (include/x265hip_frame.h).
+
+torch supplies device memory and streams only; every computation is a call into libx265hip_<depth>.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .binding import HipLib
+
+ME_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mvmin", "<i2", 2), ("mvmax", "<i2", 2), ("qmvp", "<i2", 2),
+                    ("mvc", "<i2", 8), ("numCand", "<i4")])
+ME_RESULT = np.dtype([("mv", "<i2", 2), ("cost", "<i4"), ("mvcost", "<i4"), ("reserved", "<i4")])
+TU_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv", "<i2", 2), ("reconOff", "<i4")])
+assert ME_TASK.itemsize == 40 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 16
+
+
+class TqParams(C.Structure):
+    _fields_ = [("qp", C.c_int), ("add", C.c_int), ("quantCoeff", C.c_void_p), ("deltaU", C.c_void_p)]
+
+
+def _dp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class FrameApi:
+    def __init__(self, depth):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("x265hip: no GPU visible -- the HIP path has no CPU fallback")
+        self.depth = depth
+        self.h = HipLib(depth, fill_table=False)
+        self.lib = self.h.lib
+        self.pixel_t = torch.uint8 if depth == 8 else torch.int16   # 16-bit pixels travel as int16 bit patterns
+
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def to_device(self, arr):
+        a = np.ascontiguousarray(arr)
+        if a.dtype == np.uint16:
+            a = a.view(np.int16)
+        elif a.dtype.fields is not None or a.dtype not in (np.uint8, np.int16, np.int32, np.int64, np.uint8):
+            a = a.view(np.uint8)
+        return self.torch.from_numpy(a.reshape(-1)).cuda()
+
+    def me_batch(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half, merange, method, subme, results):
+        self.h.check(self.lib.x265hip_me_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
+                                               _dp(tasks), n, _dp(cost_row), half, merange, method, subme, _dp(results)))
+
+    def tq_batch(self, log2n, cur, cstride, ref, rstride, tasks, n, qp, add, coeff, numsig, quant_coeff=None, delta_u=None,
+                 recon=None, recon_stride=0, sse=None):
+        p = TqParams(qp, add, _dp(quant_coeff), _dp(delta_u))
+        self.h.check(self.lib.x265hip_tq_batch(self.stream(), log2n, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
+                                               _dp(tasks), n, C.byref(p), _dp(coeff), _dp(numsig),
+                                               _dp(recon), C.c_ssize_t(recon_stride), _dp(sse)))
