@@ -11,6 +11,7 @@
 // cache, motion.cpp:223-229); interpolated candidates and the 14-bit hv intermediate live in LDS too.
 #include "xh_common.h"
 #include "../../include/x265hip_frame.h"
+#include <cstdlib>
 using namespace xh;
 
 namespace {
@@ -24,12 +25,23 @@ __device__ const int8_t k_offsets[16][2] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-
                                              {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1} };
 __device__ const int8_t k_workload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
 
+// LDS pointers carry their address space explicitly so that every access is a ds_* instruction.  (With generic
+// pointers the compiler mixes ds_* at inlined sites with flat_* inside non-inlined helpers; a ds_write followed by
+// a flat_load of the same LDS word is not ordered by the hardware and returned stale candidate lists.)
+#define XH_LDS __attribute__((address_space(3)))
+typedef XH_LDS pixel lpixel;
+typedef XH_LDS int16_t lshort;
+typedef XH_LDS int lint;
+typedef XH_LDS uint32_t lu32;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef XH_LDS u32x2 lu2;
+
 struct Ctx
 {
     const pixel* fref; intptr_t rs;      // co-located block origin in the reference plane
-    pixel* fenc; pixel* pred; int16_t* immed; int* cl;   // per-wave LDS: source PU, candidate block, hv intermediate, candidate list
+    lpixel* fenc; lpixel* pred; lshort* immed; lint* cl;   // per-wave LDS: source PU, candidate block, hv intermediate, candidate list
     const uint16_t* cost; int mvpx, mvpy;
-    int w, h, lane, qpr, nquads, qdivm;
+    int w, h, lane, qpr, nquads, qdivm, dbg;
 };
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -41,13 +53,13 @@ __device__ __forceinline__ int mvcost(const Ctx& c, int qx, int qy)
 }
 
 // ---- 4-pixel helpers -------------------------------------------------------------------------
-__device__ __forceinline__ void load4(const pixel* p, int* v)      // p aligned to 4 pixels (LDS)
+__device__ __forceinline__ void load4(const lpixel* p, int* v)      // p aligned to 4 pixels (LDS)
 {
 #if X265_DEPTH == 8
-    uint32_t a = *(const uint32_t*)p;
+    uint32_t a = *(const lu32*)p;
     v[0] = a & 0xFF; v[1] = (a >> 8) & 0xFF; v[2] = (a >> 16) & 0xFF; v[3] = a >> 24;
 #else
-    uint2 a = *(const uint2*)p;
+    u32x2 a = *(const lu2*)p;
     v[0] = a.x & 0xFFFF; v[1] = a.x >> 16; v[2] = a.y & 0xFFFF; v[3] = a.y >> 16;
 #endif
 }
@@ -57,26 +69,31 @@ __device__ __forceinline__ void load4u(const pixel* p, int* v)     // unaligned 
     uint32_t a; __builtin_memcpy(&a, p, 4);
     v[0] = a & 0xFF; v[1] = (a >> 8) & 0xFF; v[2] = (a >> 16) & 0xFF; v[3] = a >> 24;
 #else
-    uint2 a; __builtin_memcpy(&a, p, 8);
+    u32x2 a; __builtin_memcpy(&a, p, 8);
     v[0] = a.x & 0xFFFF; v[1] = a.x >> 16; v[2] = a.y & 0xFFFF; v[3] = a.y >> 16;
 #endif
 }
-__device__ __forceinline__ void store4(pixel* p, const int* v)     // aligned (LDS)
+__device__ __forceinline__ void store4(lpixel* p, const int* v)     // aligned (LDS)
 {
 #if X265_DEPTH == 8
-    *(uint32_t*)p = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    // ROCm 7.2 / gfx950: clamp(x >> s, 0, 255) pairs feeding a byte pack are selected as v_ashr_pk_u8_i32, whose
+    // result the compiler then ORs with bytes 2-3 as if its upper 16 bits were zero -- they keep the old register
+    // contents (observed: bytes 2/3 of every packed quad corrupted).  Materialise the four values first.
+    int v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+    *(lu32*)p = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
 #else
-    uint2 a; a.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); a.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
-    *(uint2*)p = a;
+    u32x2 a; a.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); a.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+    *(lu2*)p = a;
 #endif
 }
-__device__ __forceinline__ unsigned sad4(const pixel* f /*LDS aligned*/, const pixel* r /*global*/, unsigned acc)
+__device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const pixel* r /*global*/, unsigned acc)
 {
 #if X265_DEPTH == 8
-    uint32_t a = *(const uint32_t*)f, b; __builtin_memcpy(&b, r, 4);
+    uint32_t a = *(const lu32*)f, b; __builtin_memcpy(&b, r, 4);
     return __builtin_amdgcn_sad_u8(a, b, acc);
 #else
-    uint2 a = *(const uint2*)f, b; __builtin_memcpy(&b, r, 8);
+    u32x2 a = *(const lu2*)f, b; __builtin_memcpy(&b, r, 8);
     acc = __builtin_amdgcn_sad_u16(a.x, b.x, acc);
     return __builtin_amdgcn_sad_u16(a.y, b.y, acc);
 #endif
@@ -102,6 +119,7 @@ __device__ __forceinline__ void load11u(const pixel* p, int* v)
 // cl layout: [0..15] x, [16..31] y, [32..47] cost
 __device__ void eval_list(const Ctx& c, int n)
 {
+    wave_sync();
     for (int base = 0; base < n; base += 4)
     {
         const int k = n - base < 4 ? n - base : 4;
@@ -114,7 +132,7 @@ __device__ void eval_list(const Ctx& c, int n)
         }
         unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;
         QUAD_LOOP(c, q, y, x4)
-            const pixel* f = c.fenc + y * c.w + x4;
+            const lpixel* f = c.fenc + y * c.w + x4;
             const pixel* r = c.fref + (intptr_t)y * c.rs + x4;
             p0 = sad4(f, r + off[0], p0);
             if (k > 1) p1 = sad4(f, r + off[1], p1);
@@ -130,11 +148,11 @@ __device__ void eval_list(const Ctx& c, int n)
             if (k > 3) c.cl[32 + base + 3] = s3 + mvcost(c, c.cl[base + 3] * 4, c.cl[16 + base + 3] * 4);
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
 }
 __device__ __forceinline__ void put(const Ctx& c, int i, int x, int y)
 {
-    if (c.lane == 0) { c.cl[i] = x; c.cl[16 + i] = y; }
+    c.cl[i] = x; c.cl[16 + i] = y;     // every lane stores the same (wave-uniform) value
 }
 __device__ __forceinline__ int costOf(const Ctx& c, int i) { return uni(c.cl[32 + i]); }
 
@@ -219,10 +237,10 @@ __device__ void build_pred(const Ctx& c, int qx, int qy)
                 for (int i = 0; i < 8; i++) s += px[e + i] * t[i];
                 o[e] = (int16_t)((s + offset1) >> shift1);
             }
-            uint2 pk; pk.x = (uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16); pk.y = (uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
-            *(uint2*)(c.immed + y * c.w + x4) = pk;
+            u32x2 pk; pk.x = (uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16); pk.y = (uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+            *(lu2*)(c.immed + y * c.w + x4) = pk;
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
 #pragma unroll
         for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[yf][i];
         const int shift2 = XH_IF_FILTER_PREC + headRoom, offset2 = (1 << (shift2 - 1)) + (XH_IF_INTERNAL_OFFS << XH_IF_FILTER_PREC);
@@ -231,7 +249,7 @@ __device__ void build_pred(const Ctx& c, int qx, int qy)
 #pragma unroll
             for (int i = 0; i < 8; i++)
             {
-                uint2 a = *(const uint2*)(c.immed + (y + i) * c.w + x4);
+                u32x2 a = *(const lu2*)(c.immed + (y + i) * c.w + x4);
                 s[0] += (int)(int16_t)(a.x & 0xFFFF) * t[i]; s[1] += (int)(int16_t)(a.x >> 16) * t[i];
                 s[2] += (int)(int16_t)(a.y & 0xFFFF) * t[i]; s[3] += (int)(int16_t)(a.y >> 16) * t[i];
             }
@@ -240,7 +258,7 @@ __device__ void build_pred(const Ctx& c, int qx, int qy)
             store4(c.pred + y * c.w + x4, o);
         QUAD_END
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
 }
 
 __device__ __forceinline__ void had4(int& a, int& b, int& cc, int& d)
@@ -248,7 +266,7 @@ __device__ __forceinline__ void had4(int& a, int& b, int& cc, int& d)
     int t0 = a + b, t1 = a - b, t2 = cc + d, t3 = cc - d;
     a = t0 + t2; cc = t0 - t2; b = t1 + t3; d = t1 - t3;
 }
-__device__ __forceinline__ int had4x4_lds(const pixel* f, const pixel* p, int w)
+__device__ __forceinline__ int had4x4_lds(const lpixel* f, const lpixel* p, int w)
 {
     int d[16];
 #pragma unroll
@@ -277,9 +295,9 @@ __device__ int cmp_pred(const Ctx& c, bool satd)
         unsigned p = 0;
         QUAD_LOOP(c, q, y, x4)
 #if X265_DEPTH == 8
-            p = __builtin_amdgcn_sad_u8(*(const uint32_t*)(c.fenc + y * c.w + x4), *(const uint32_t*)(c.pred + y * c.w + x4), p);
+            p = __builtin_amdgcn_sad_u8(*(const lu32*)(c.fenc + y * c.w + x4), *(const lu32*)(c.pred + y * c.w + x4), p);
 #else
-            uint2 a = *(const uint2*)(c.fenc + y * c.w + x4), b = *(const uint2*)(c.pred + y * c.w + x4);
+            u32x2 a = *(const lu2*)(c.fenc + y * c.w + x4), b = *(const lu2*)(c.pred + y * c.w + x4);
             p = __builtin_amdgcn_sad_u16(a.x, b.x, p); p = __builtin_amdgcn_sad_u16(a.y, b.y, p);
 #endif
         QUAD_END
@@ -292,7 +310,7 @@ __device__ int cmp_pred(const Ctx& c, bool satd)
         for (int u = c.lane; u < nunits; u += 64)
         {
             int uy = u / ux, x0 = (u - uy * ux) * uw, y0 = uy * 4;
-            const pixel* f = c.fenc + y0 * c.w + x0; const pixel* p = c.pred + y0 * c.w + x0;
+            const lpixel* f = c.fenc + y0 * c.w + x0; const lpixel* p = c.pred + y0 * c.w + x0;
             int v = had4x4_lds(f, p, c.w);
             if (!use4) v += had4x4_lds(f + 4, p + 4, c.w);
             s += v >> 1;
@@ -324,7 +342,7 @@ __device__ void star_apply(const Ctx& c, Star& s, int n)
         }
     }
 }
-#define SPUT(i, X, Y, P, D) do { if (c.lane == 0) { c.cl[i] = (X); c.cl[16 + (i)] = (Y); c.cl[48 + (i)] = (P) | ((D) << 8); } } while (0)
+#define SPUT(i, X, Y, P, D) do { c.cl[i] = (X); c.cl[16 + (i)] = (Y); c.cl[48 + (i)] = (P) | ((D) << 8); } while (0)
 
 // motion.cpp:387-629 StarPatternSearch
 __device__ void star_pattern(const Ctx& c, int mnx, int mny, int mxx, int mxy, Star& s, int earlyExitIters, int merange)
@@ -401,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                                                         const pixel* __restrict__ ref, intptr_t rs,
                                                         const x265hip_me_task* __restrict__ tasks, int n,
                                                         const uint16_t* __restrict__ costCentre,
-                                                        int merange, int method, int subme, x265hip_me_result* __restrict__ results)
+                                                        int merange, int method, int subme, x265hip_me_result* __restrict__ results, int dbg)
 {
     __shared__ __attribute__((aligned(16))) pixel s_fenc[WAVES][MAXPIX];
     __shared__ __attribute__((aligned(16))) pixel s_pred[WAVES][MAXPIX];
@@ -415,8 +433,8 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
 
     Ctx c;
     c.lane = threadIdx.x & 63; c.w = w; c.h = h; c.qpr = w >> 2; c.nquads = c.qpr * h; c.qdivm = ((1 << 20) / c.qpr) + 1;
-    c.fenc = s_fenc[wave]; c.pred = s_pred[wave]; c.immed = s_immed[wave]; c.cl = s_cl[wave];
-    c.fref = ref + tk.refOff; c.rs = rs; c.cost = costCentre; c.mvpx = tk.qmvp[0]; c.mvpy = tk.qmvp[1];
+    c.fenc = (lpixel*)s_fenc[wave]; c.pred = (lpixel*)s_pred[wave]; c.immed = (lshort*)s_immed[wave]; c.cl = (lint*)s_cl[wave];
+    c.dbg = dbg; c.fref = ref + tk.refOff; c.rs = rs; c.cost = costCentre; c.mvpx = tk.qmvp[0]; c.mvpy = tk.qmvp[1];
 
     // cache the source PU (motion.cpp:223-229)
     {
@@ -424,7 +442,20 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
         QUAD_LOOP(c, q, y, x4)
             int v[4]; load4u(src + (intptr_t)y * cs + x4, v); store4(c.fenc + y * w + x4, v);
         QUAD_END
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
+    }
+    if (dbg == 1) return;
+    if (dbg == 7)
+    {   // debug: dump the interpolated block at the predictor position
+        build_pred(c, tk.qmvp[0], tk.qmvp[1]);
+        for (int i = c.lane; i < w * h; i += 64) ((pixel*)results)[i] = c.pred[i];
+        return;
+    }
+    if (dbg == 5 || dbg == 6)
+    {   // debug: raw sub-pel cost of the predictor position (SATD for 5, SAD for 6)
+        int v = subpel_cost(c, tk.qmvp[0], tk.qmvp[1], dbg == 5);
+        if (c.lane == 0) { x265hip_me_result r; r.mv[0] = tk.qmvp[0]; r.mv[1] = tk.qmvp[1]; r.cost = v; r.mvcost = 0; r.reserved = 0; results[item] = r; }
+        return;
     }
     const int mnx = tk.mvmin[0], mny = tk.mvmin[1], mxx = tk.mvmax[0], mxy = tk.mvmax[1];
     const int qmnx = mnx * 4, qmny = mny * 4, qmxx = mxx * 4, qmxy = mxy * 4;
@@ -450,6 +481,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
             if (cost < bprecost) { bprecost = cost; bestprex = mx; bestprey = my; }
         }
     }
+    if (dbg == 2) return;
     bool finished = false;
     int outx = 0, outy = 0, outcost = 0;
     if (bcost == 0)
@@ -600,6 +632,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
             bx = s.bx; by = s.by; bcost = s.bcost;
         }
 
+        if (dbg == 3) return;
         // ---- sub-pel refinement, motion.cpp:1644-1768 ----
         int qx, qy;
         if (bprecost < bcost) { qx = bestprex; qy = bestprey; bcost = bprecost; }
@@ -659,7 +692,7 @@ int launch_me(hipStream_t st, int w, int h, const pixel* cur, intptr_t cs, const
               const uint16_t* costCentre, int merange, int method, int subme, x265hip_me_result* results)
 {
     hipLaunchKernelGGL((me_kernel<MAXPIX, MAXW, WAVES>), dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, st,
-                       w, h, cur, cs, ref, rs, tasks, n, costCentre, merange, method, subme, results);
+                       w, h, cur, cs, ref, rs, tasks, n, costCentre, merange, method, subme, results, getenv("X265HIP_ME_DBG") ? atoi(getenv("X265HIP_ME_DBG")) : 0);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void pixelcmp_kernel(int op, int w, int h,
             else
             {
                 lds[wave][lane] = raw;
-                __builtin_amdgcn_wave_barrier();
+                wave_sync();
                 int ng = nb >> 1, v = 0;
                 if (lane < ng * ng)
                 {

@@ -38,6 +38,17 @@ __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo
 __device__ __forceinline__ pixel clip_pixel(int v) { return (pixel)clip3(0, XH_PIXEL_MAX, v); }
 __device__ __forceinline__ int16_t clip16(int v) { return (int16_t)clip3(-32768, 32767, v); }
 
+// Wave-level synchronisation point for data exchanged between lanes through LDS.  Lanes are independent
+// threads to the compiler: without a CONVERGENT barrier plus release/acquire fences it may order one lane's
+// LDS store after another lane's load of the same word (e.g. by threading the load into both arms of a
+// divergent `if (lane == 0)` store).  Costs no instruction beyond the waitcnt the hardware needs anyway.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // full-wave (64 lane) integer sum; result valid in every lane
 __device__ __forceinline__ int wave_sum(int v)
 {
