@@ -213,3 +213,15 @@ class Oracle:
                                               int(qmvp[0]), int(qmvp[1]), len(c) // 2, _ptr(c) if len(c) else None,
                                               merange, method, subme, _ptr(costrow, half), _ptr(out))
         return int(out[0]), int(out[1]), int(cost)
+
+    # ---- inter TU pipeline (x265_oracle_me.c xo_tq_tu) ----
+    def tq_tu(self, log2n, cur, cstride, coff, ref, rstride, roff, mv, qp, add, quant_coeff=None, want_recon=False):
+        n = 1 << log2n
+        coeff = np.zeros(n * n, np.int16); du = np.zeros(n * n, np.int32)
+        recon = np.zeros(n * n, self.pixel) if want_recon else None
+        sse = C.c_uint64(0)
+        self.me_lib.xo_tq_tu.restype = C.c_uint32
+        ns = self.me_lib.xo_tq_tu(log2n, _ptr(cur, coff), _IP(cstride), _ptr(ref, roff), _IP(rstride), int(mv[0]), int(mv[1]), qp, add,
+                                  _ptr(quant_coeff) if quant_coeff is not None else None, _ptr(coeff), _ptr(du),
+                                  _ptr(recon) if want_recon else None, _IP(n), C.byref(sse))
+        return int(ns), coeff, du, recon, int(sse.value)

@@ -416,3 +416,62 @@ int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, in
     outQMv[0] = bmv.x; outQMv[1] = bmv.y;
     return bcost;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* inter TU pipeline                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref, intptr_t refStride,
+                  int qmvx, int qmvy, int qp, int addNumerator, const int32_t* quantCoeff,
+                  int16_t* coeff, int32_t* deltaU, xo_pixel* recon, intptr_t reconStride, uint64_t* sse)
+{
+    static const int quantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };   /* scalinglist.cpp:129 */
+    static const int invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                  /* scalinglist.cpp:130 */
+    const int N = 1 << log2TrSize, num = N * N;
+    xo_pixel pred[32 * 32];
+    int16_t resi[32 * 32], dct[32 * 32];
+    int32_t du[32 * 32], flat[32 * 32];
+
+    /* predict.cpp:279-300: copy_pp | luma_hpp | luma_vpp | luma_hvpp by MV fraction */
+    const xo_pixel* src = fref + (qmvx >> 2) + (qmvy >> 2) * refStride;
+    int xf = qmvx & 3, yf = qmvy & 3;
+    if (!(xf | yf)) xo_copy_pp(N, N, pred, N, src, refStride);
+    else if (!yf) xo_interp_hpp(8, N, N, src, refStride, pred, N, xf);
+    else if (!xf) xo_interp_vpp(8, N, N, src, refStride, pred, N, yf);
+    else xo_interp_hvpp(8, N, N, src, refStride, pred, N, xf, yf);
+
+    xo_sub_ps(N, N, resi, N, cur, pred, curStride, N);
+    xo_dct(N, resi, dct, N);
+
+    /* quant.cpp:458-469 */
+    const int per = qp / 6, rem = qp % 6;
+    const int transformShift = 15 - X265_DEPTH - log2TrSize;
+    const int qbits = 14 + per + transformShift;
+    const int add = addNumerator << (qbits - 9);
+    if (!quantCoeff) { for (int i = 0; i < num; i++) flat[i] = quantScales[rem]; quantCoeff = flat; }
+    uint32_t numSig = xo_quant(dct, quantCoeff, deltaU ? deltaU : du, coeff, qbits, add, num);
+
+    if (recon)
+    {
+        int16_t deq[32 * 32], res2[32 * 32];
+        if (!numSig)
+            memset(res2, 0, sizeof(res2));              /* search.cpp:5630 blockfill_s(curResi, 0) */
+        else
+        {
+            /* quant.cpp:555-568 */
+            const int shift = 20 - 14 - transformShift;
+            xo_dequant_normal(coeff, deq, num, invQuantScales[rem] << per, shift);
+            if (numSig == 1 && coeff[0] != 0)
+            {   /* DC shortcut, quant.cpp:588-597 */
+                const int shift_1st = 7 - 6, add_1st = 1 << (shift_1st - 1);
+                const int shift_2nd = 12 - (X265_DEPTH - 8) - 3, add_2nd = 1 << (shift_2nd - 1);
+                int dc_val = (((deq[0] * (64 >> 6) + add_1st) >> shift_1st) * (64 >> 3) + add_2nd) >> shift_2nd;
+                xo_blockfill_s(N, res2, N, (int16_t)dc_val);
+            }
+            else
+                xo_idct(N, deq, res2, N);
+        }
+        xo_add_ps(N, N, recon, reconStride, pred, res2, N, N);
+        if (sse) *sse = xo_sse_pp(N, N, cur, curStride, recon, reconStride);
+    }
+    return numSig;
+}

@@ -22,3 +22,19 @@ int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, in
 }
 #endif
 #endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* One luma TU of the inter residual path, restating the caller chain
+ *   Predict::predInterLumaPixel (predict.cpp:279-300) -> sub_ps -> Quant::transformNxN (quant.cpp:397-480, rdoq off)
+ *   [-> Quant::invtransformNxN (quant.cpp:543-605, flat lists) -> add_ps -> sse_pp   when recon != NULL]
+ * cur / fref point at the TU's top-left source pixel and the co-located reference pixel.
+ * quantCoeff may be NULL (flat s_quantScales[qp%6], scalinglist.cpp:129).  Returns numSig. */
+uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref, intptr_t refStride,
+                  int qmvx, int qmvy, int qp, int addNumerator /*171 or 85*/, const int32_t* quantCoeff,
+                  int16_t* coeff /*N*N*/, int32_t* deltaU /*N*N or NULL*/,
+                  xo_pixel* recon /*or NULL*/, intptr_t reconStride, uint64_t* sse);
+#ifdef __cplusplus
+}
+#endif

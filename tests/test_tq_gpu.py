@@ -1,0 +1,61 @@
+"""GPU parity of the fused inter-TU pipeline (x265hip_tq_batch) against the oracle (xo_tq_tu):
+quantised coefficients, numSig, deltaU, reconstruction and SSE must be bit-identical."""
+import numpy as np
+import pytest
+
+import x265hip  # noqa: F401
+from x265hip_pkg.synth import frame_pair
+from x265hip_pkg.frame import FrameApi, TU_TASK
+from backends import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("log2n", [2, 3, 4, 5])
+def test_tq_batch_matches_oracle(depth, log2n):
+    api, ora = FrameApi(depth), Oracle(depth)
+    torch = api.torch
+    rng = np.random.default_rng(31 * depth + log2n)
+    W, H, margin = 256, 128, 48
+    N = 1 << log2n
+    cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 20 + log2n, margin=margin, max_shift=8)
+    cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
+    d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+    for (qp, add, recon, flat) in [(28, 85, True, True), (22, 171, True, True), (37, 85, False, True), (45, 85, True, True),
+                                   (51, 85, True, True), (30, 85, True, False), (4, 171, True, True)]:
+        n = 40
+        t = np.zeros(n, TU_TASK)
+        for i in range(n):
+            px = int(rng.integers(0, (W - N) // 4 + 1)) * 4; py = int(rng.integers(0, (H - N) // 4 + 1)) * 4
+            off = (margin + py) * stride + margin + px
+            t[i]["curOff"] = off; t[i]["refOff"] = off; t[i]["reconOff"] = off
+            if rng.random() < 0.8:
+                t[i]["mv"] = (4 * dx + int(rng.integers(-6, 7)), 4 * dy + int(rng.integers(-6, 7)))
+            else:
+                t[i]["mv"] = (int(rng.integers(-60, 61)), int(rng.integers(-60, 61)))
+        qc = None if flat else (rng.integers(8, 64, N * N) * 1024).astype(np.int32)
+        d_t = api.to_device(t)
+        d_coeff = torch.zeros(n * N * N, dtype=torch.int16, device="cuda")
+        d_ns = torch.zeros(n, dtype=torch.int32, device="cuda")
+        d_du = torch.zeros(n * N * N, dtype=torch.int32, device="cuda")
+        d_rec = torch.zeros_like(d_cur) if recon else None
+        d_sse = torch.zeros(n, dtype=torch.int64, device="cuda") if recon else None
+        d_qc = api.to_device(qc) if qc is not None else None
+        api.tq_batch(log2n, d_cur, stride, d_ref, stride, d_t, n, qp, add, d_coeff, d_ns, quant_coeff=d_qc, delta_u=d_du,
+                     recon=d_rec, recon_stride=stride, sse=d_sse)
+        torch.cuda.synchronize()
+        coeff = d_coeff.cpu().numpy().reshape(n, N * N); ns = d_ns.cpu().numpy(); du = d_du.cpu().numpy().reshape(n, N * N)
+        rec = d_rec.cpu().numpy().view(cur_f.dtype) if recon else None
+        sse = d_sse.cpu().numpy() if recon else None
+        kinds = set()
+        for i in range(n):
+            off = int(t[i]["curOff"]); mv = (int(t[i]["mv"][0]), int(t[i]["mv"][1]))
+            e_ns, e_coeff, e_du, e_rec, e_sse = ora.tq_tu(log2n, cur_f, stride, off, ref_f, stride, off, mv, qp, add, quant_coeff=qc, want_recon=recon)
+            assert int(ns[i]) == e_ns and np.array_equal(coeff[i], e_coeff), "coeff: N=%d qp=%d task %d mv %s" % (N, qp, i, mv)
+            assert np.array_equal(du[i], e_du), "deltaU: N=%d qp=%d task %d" % (N, qp, i)
+            if recon:
+                got = np.array([rec[off + y * stride: off + y * stride + N] for y in range(N)]).reshape(-1)
+                assert np.array_equal(got, e_rec), "recon: N=%d qp=%d task %d numSig %d" % (N, qp, i, e_ns)
+                assert int(sse[i]) == e_sse, "sse: N=%d qp=%d task %d" % (N, qp, i)
+            kinds.add(0 if e_ns == 0 else (1 if e_ns == 1 else 2))

@@ -19,56 +19,11 @@
 //           ordering gives the exact sum.
 #include "xh_common.h"
 #include "xh_internal.h"
+#include "xh_dct32.h"
 #include <cstdlib>
 using namespace xh;
 
 namespace {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ int pack_lo(int d0, int d1) { return __builtin_amdgcn_perm(d1, d0, 0x06040200); }   // bytes 0,2 of d0, d1
-__device__ __forceinline__ int pack_hi(int d0, int d1) { return __builtin_amdgcn_perm(d1, d0, 0x07050301); }   // bytes 1,3 of d0, d1
-
-// three exact planes of 16 int16 values held as 8 dwords (2 per dword)
-__device__ __forceinline__ void split_planes(const int* d, v4i& lo, v4i& hi, v4i& bb)
-{
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-    {
-        int L = pack_lo(d[2 * q], d[2 * q + 1]);
-        lo[q] = L;
-        hi[q] = pack_hi(d[2 * q], d[2 * q + 1]);
-        bb[q] = (int)(((unsigned)L >> 7) & 0x01010101u);
-    }
-}
-
-__device__ __forceinline__ v16i mm3(const v4i& lo, const v4i& hi, const v4i& bb, const v4i& t, v16i& accLo)
-{
-    v16i z = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    return z; (void)lo; (void)hi; (void)bb; (void)t; (void)accLo;
-}
-
-template<bool XT_IS_A>
-__device__ __forceinline__ void product(const v4i& lo, const v4i& hi, const v4i& bb, const v4i& t, v16i& out)
-{
-    v16i z = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    v16i aLo, aHb;
-    if (XT_IS_A)
-    {   // data matrix is the A operand, T the B operand
-        aLo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, t, z, 0, 0, 0);
-        aHb = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, t, z, 0, 0, 0);
-        aHb = __builtin_amdgcn_mfma_i32_32x32x32_i8(bb, t, aHb, 0, 0, 0);
-    }
-    else
-    {
-        aLo = __builtin_amdgcn_mfma_i32_32x32x32_i8(t, lo, z, 0, 0, 0);
-        aHb = __builtin_amdgcn_mfma_i32_32x32x32_i8(t, hi, z, 0, 0, 0);
-        aHb = __builtin_amdgcn_mfma_i32_32x32x32_i8(t, bb, aHb, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; i++) out[i] = aHb[i] * 256 + aLo[i];
-}
 
 __global__ __launch_bounds__(256) void dct32_mfma_kernel(const int16_t* __restrict__ src, intptr_t ss, const int32_t* __restrict__ sOff,
                                                          int16_t* __restrict__ dst, const int32_t* __restrict__ dOff, int n)
@@ -76,25 +31,9 @@ __global__ __launch_bounds__(256) void dct32_mfma_kernel(const int16_t* __restri
     const int lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5;
     const int wavesTotal = gridDim.x * 4;
     int tu = blockIdx.x * 4 + (threadIdx.x >> 6);
-
-    // constant operands, built once per wave
-    v4i tB1, tA2;   // stage-1 B = T[r][16g + s]; stage-2 A = T[r][n(s,g)]
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-    {
-        unsigned b1 = 0, a2 = 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-        {
-            int s = 4 * q + e;
-            b1 |= ((unsigned)dct_coef(r, 16 * g + s) & 0xFFu) << (8 * e);
-            a2 |= ((unsigned)dct_coef(r, (s & 3) + 8 * (s >> 2) + 4 * g) & 0xFFu) << (8 * e);
-        }
-        tB1[q] = (int)b1; tA2[q] = (int)a2;
-    }
-    const int shift1 = 4 + X265_DEPTH - 8, add1 = 1 << (shift1 - 1);
+    v4i tB1, tA2;
+    dct32_operands(r, g, tB1, tA2);       // built once per wave, amortised over the grid-stride loop
     const int shift2 = 11, add2 = 1 << (shift2 - 1);
-
     for (; tu < n; tu += wavesTotal)
     {
         const intptr_t so = sOff ? (intptr_t)sOff[tu] : (intptr_t)tu * 1024;
@@ -110,20 +49,8 @@ __global__ __launch_bounds__(256) void dct32_mfma_kernel(const int16_t* __restri
 #pragma unroll
             for (int q = 0; q < 8; q++) d[q] = (int)(((unsigned)(uint16_t)p[2 * q]) | ((unsigned)(uint16_t)p[2 * q + 1] << 16));
         }
-        v4i lo, hi, bb;
-        split_planes(d, lo, hi, bb);
         v16i acc;
-        product<true>(lo, hi, bb, tB1, acc);          // D1[n][j], lane: col j = r, rows n(i,g)
-        // round stage 1, cast to int16, repack as the stage-2 B operand (k-slot i <-> n(i,g))
-        int t16[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-        {
-            int v0 = (acc[2 * q] + add1) >> shift1, v1 = (acc[2 * q + 1] + add1) >> shift1;
-            t16[q] = __builtin_amdgcn_perm(v1, v0, 0x05040100);   // two int16 per dword
-        }
-        split_planes(t16, lo, hi, bb);
-        product<false>(lo, hi, bb, tA2, acc);         // D2[k][j], lane: col j = r, rows k(i,g)
+        dct32_forward(d, tB1, tA2, acc);
         int16_t* o = dst + (dOff ? (intptr_t)dOff[tu] : (intptr_t)tu * 1024);
 #pragma unroll
         for (int i = 0; i < 16; i++)

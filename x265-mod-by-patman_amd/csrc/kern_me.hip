@@ -9,15 +9,13 @@
 // Hadamard over the PU) is spread over the 64 lanes in units of 4 horizontally adjacent pixels
 // (v_sad_u8 / v_sad_u16 on packed pixels).  The source PU is cached in LDS (the reference's FENC_STRIDE
 // cache, motion.cpp:223-229); interpolated candidates and the 14-bit hv intermediate live in LDS too.
-#include "xh_common.h"
+#include "xh_mc.h"
 #include "../../include/x265hip_frame.h"
 #include <cstdlib>
 using namespace xh;
 
 namespace {
 
-__device__ const int8_t k_lumaTaps[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
-                                             { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
 __device__ const int8_t k_hex2[8][2] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
 __device__ const uint8_t k_mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
 __device__ const int8_t k_square1[9][2] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
@@ -25,95 +23,17 @@ __device__ const int8_t k_offsets[16][2] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-
                                              {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1} };
 __device__ const int8_t k_workload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
 
-// LDS pointers carry their address space explicitly so that every access is a ds_* instruction.  (With generic
-// pointers the compiler mixes ds_* at inlined sites with flat_* inside non-inlined helpers; a ds_write followed by
-// a flat_load of the same LDS word is not ordered by the hardware and returned stale candidate lists.)
-#define XH_LDS __attribute__((address_space(3)))
-typedef XH_LDS pixel lpixel;
-typedef XH_LDS int16_t lshort;
-typedef XH_LDS int lint;
-typedef XH_LDS uint32_t lu32;
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef XH_LDS u32x2 lu2;
-
-struct Ctx
+struct Ctx : McCtx
 {
-    const pixel* fref; intptr_t rs;      // co-located block origin in the reference plane
-    lpixel* fenc; lpixel* pred; lshort* immed; lint* cl;   // per-wave LDS: source PU, candidate block, hv intermediate, candidate list
+    lpixel* fenc; lint* cl;              // per-wave LDS: source PU (stride w), candidate list
     const uint16_t* cost; int mvpx, mvpy;
-    int w, h, lane, qpr, nquads, qdivm, dbg;
+    int dbg;
 };
-
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int wsum_u(int v) { return uni(wave_sum(v)); }
 
 __device__ __forceinline__ int mvcost(const Ctx& c, int qx, int qy)
 {   // bitcost.h:57 -- uint16_t sum
     return (uint16_t)(c.cost[qx - c.mvpx] + c.cost[qy - c.mvpy]);
 }
-
-// ---- 4-pixel helpers -------------------------------------------------------------------------
-__device__ __forceinline__ void load4(const lpixel* p, int* v)      // p aligned to 4 pixels (LDS)
-{
-#if X265_DEPTH == 8
-    uint32_t a = *(const lu32*)p;
-    v[0] = a & 0xFF; v[1] = (a >> 8) & 0xFF; v[2] = (a >> 16) & 0xFF; v[3] = a >> 24;
-#else
-    u32x2 a = *(const lu2*)p;
-    v[0] = a.x & 0xFFFF; v[1] = a.x >> 16; v[2] = a.y & 0xFFFF; v[3] = a.y >> 16;
-#endif
-}
-__device__ __forceinline__ void load4u(const pixel* p, int* v)     // unaligned (global)
-{
-#if X265_DEPTH == 8
-    uint32_t a; __builtin_memcpy(&a, p, 4);
-    v[0] = a & 0xFF; v[1] = (a >> 8) & 0xFF; v[2] = (a >> 16) & 0xFF; v[3] = a >> 24;
-#else
-    u32x2 a; __builtin_memcpy(&a, p, 8);
-    v[0] = a.x & 0xFFFF; v[1] = a.x >> 16; v[2] = a.y & 0xFFFF; v[3] = a.y >> 16;
-#endif
-}
-__device__ __forceinline__ void store4(lpixel* p, const int* v)     // aligned (LDS)
-{
-#if X265_DEPTH == 8
-    // ROCm 7.2 / gfx950: clamp(x >> s, 0, 255) pairs feeding a byte pack are selected as v_ashr_pk_u8_i32, whose
-    // result the compiler then ORs with bytes 2-3 as if its upper 16 bits were zero -- they keep the old register
-    // contents (observed: bytes 2/3 of every packed quad corrupted).  Materialise the four values first.
-    int v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
-    *(lu32*)p = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
-#else
-    u32x2 a; a.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); a.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
-    *(lu2*)p = a;
-#endif
-}
-__device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const pixel* r /*global*/, unsigned acc)
-{
-#if X265_DEPTH == 8
-    uint32_t a = *(const lu32*)f, b; __builtin_memcpy(&b, r, 4);
-    return __builtin_amdgcn_sad_u8(a, b, acc);
-#else
-    u32x2 a = *(const lu2*)f, b; __builtin_memcpy(&b, r, 8);
-    acc = __builtin_amdgcn_sad_u16(a.x, b.x, acc);
-    return __builtin_amdgcn_sad_u16(a.y, b.y, acc);
-#endif
-}
-// 11 consecutive pixels starting at p (unaligned, global): what a 4-wide 8-tap horizontal filter needs
-__device__ __forceinline__ void load11u(const pixel* p, int* v)
-{
-#if X265_DEPTH == 8
-    uint32_t a[3]; __builtin_memcpy(a, p, 12);
-#pragma unroll
-    for (int i = 0; i < 11; i++) v[i] = (a[i >> 2] >> (8 * (i & 3))) & 0xFF;
-#else
-    uint32_t a[6]; __builtin_memcpy(a, p, 24);
-#pragma unroll
-    for (int i = 0; i < 11; i++) v[i] = (a[i >> 1] >> (16 * (i & 1))) & 0xFFFF;
-#endif
-}
-
-#define QUAD_LOOP(c, q, y, x4) for (int q = (c).lane; q < (c).nquads; q += 64) { const int y = (q * (c).qdivm) >> 20; const int x4 = (q - y * (c).qpr) * 4;
-#define QUAD_END }
 
 // ---- integer-pel SAD of up to 4 candidates listed in LDS; costs (SAD + mvcost) go back to the list ----
 // cl layout: [0..15] x, [16..31] y, [32..47] cost
@@ -164,101 +84,6 @@ __device__ int sad_fpel(const Ctx& c, int mx, int my)      // plain SAD (no mv c
         p = sad4(c.fenc + y * c.w + x4, c.fref + off + (intptr_t)y * c.rs + x4, p);
     QUAD_END
     return wsum_u((int)p);
-}
-
-// ---- sub-pel candidate: build the interpolated block in LDS (motion.cpp:1797-1801 dispatch) ----
-__device__ void build_pred(const Ctx& c, int qx, int qy)
-{
-    const pixel* src = c.fref + (qx >> 2) + (intptr_t)(qy >> 2) * c.rs;
-    const int xf = qx & 3, yf = qy & 3;
-    const int headRoom = XH_IF_INTERNAL_PREC - X265_DEPTH;
-    if (!(xf | yf))
-    {
-        QUAD_LOOP(c, q, y, x4)
-            int v[4]; load4u(src + (intptr_t)y * c.rs + x4, v); store4(c.pred + y * c.w + x4, v);
-        QUAD_END
-    }
-    else if (!yf)
-    {   // luma_hpp, ipfilter.cpp:79-118
-        int t[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[xf][i];
-        QUAD_LOOP(c, q, y, x4)
-            int px[11], o[4];
-            load11u(src + (intptr_t)y * c.rs + x4 - 3, px);
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-            {
-                int s = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) s += px[e + i] * t[i];
-                o[e] = clip3(0, XH_PIXEL_MAX, (int)(int16_t)((s + 32) >> 6));
-            }
-            store4(c.pred + y * c.w + x4, o);
-        QUAD_END
-    }
-    else if (!xf)
-    {   // luma_vpp, ipfilter.cpp:164-203
-        int t[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[yf][i];
-        QUAD_LOOP(c, q, y, x4)
-            int s[4] = { 0, 0, 0, 0 }, o[4];
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-            {
-                int v[4]; load4u(src + (intptr_t)(y - 3 + i) * c.rs + x4, v);
-#pragma unroll
-                for (int e = 0; e < 4; e++) s[e] += v[e] * t[i];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = clip3(0, XH_PIXEL_MAX, (int)(int16_t)((s[e] + 32) >> 6));
-            store4(c.pred + y * c.w + x4, o);
-        QUAD_END
-    }
-    else
-    {   // luma_hvpp = hps(row-extended) into the 14-bit intermediate, then vertical sp; ipfilter.cpp:120-162,319-369
-        int t[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[xf][i];
-        const int shift1 = XH_IF_FILTER_PREC - headRoom, offset1 = (int)((unsigned)-XH_IF_INTERNAL_OFFS << shift1);
-        const int rows = c.h + 7, nq = c.qpr * rows;
-        for (int q = c.lane; q < nq; q += 64)
-        {
-            const int y = (q * c.qdivm) >> 20, x4 = (q - y * c.qpr) * 4;
-            int px[11];
-            load11u(src + (intptr_t)(y - 3) * c.rs + x4 - 3, px);
-            int16_t o[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-            {
-                int s = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) s += px[e + i] * t[i];
-                o[e] = (int16_t)((s + offset1) >> shift1);
-            }
-            u32x2 pk; pk.x = (uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16); pk.y = (uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
-            *(lu2*)(c.immed + y * c.w + x4) = pk;
-        }
-        wave_sync();
-#pragma unroll
-        for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[yf][i];
-        const int shift2 = XH_IF_FILTER_PREC + headRoom, offset2 = (1 << (shift2 - 1)) + (XH_IF_INTERNAL_OFFS << XH_IF_FILTER_PREC);
-        QUAD_LOOP(c, q, y, x4)
-            int s[4] = { 0, 0, 0, 0 }, o[4];
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-            {
-                u32x2 a = *(const lu2*)(c.immed + (y + i) * c.w + x4);
-                s[0] += (int)(int16_t)(a.x & 0xFFFF) * t[i]; s[1] += (int)(int16_t)(a.x >> 16) * t[i];
-                s[2] += (int)(int16_t)(a.y & 0xFFFF) * t[i]; s[3] += (int)(int16_t)(a.y >> 16) * t[i];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = clip3(0, XH_PIXEL_MAX, (int)(int16_t)((s[e] + offset2) >> shift2));
-            store4(c.pred + y * c.w + x4, o);
-        QUAD_END
-    }
-    wave_sync();
 }
 
 __device__ __forceinline__ void had4(int& a, int& b, int& cc, int& d)

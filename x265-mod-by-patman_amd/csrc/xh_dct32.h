@@ -1,0 +1,89 @@
+// xh_dct32.h -- exact 32x32x32 integer products on the gfx950 matrix cores (see kern_dct32_mfma.hip for the
+// derivation): byte-plane split of int16 operands and the two constant T operands of the forward DCT.
+#pragma once
+#include "xh_common.h"
+
+namespace xh {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int pack_lo(int d0, int d1) { return __builtin_amdgcn_perm(d1, d0, 0x06040200); }   // bytes 0,2 of d0, d1
+__device__ __forceinline__ int pack_hi(int d0, int d1) { return __builtin_amdgcn_perm(d1, d0, 0x07050301); }   // bytes 1,3 of d0, d1
+
+// three exact planes of 16 int16 values held as 8 dwords (2 per dword)
+__device__ __forceinline__ void split_planes(const int* d, v4i& lo, v4i& hi, v4i& bb)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        int L = pack_lo(d[2 * q], d[2 * q + 1]);
+        lo[q] = L;
+        hi[q] = pack_hi(d[2 * q], d[2 * q + 1]);
+        bb[q] = (int)(((unsigned)L >> 7) & 0x01010101u);
+    }
+}
+
+template<bool XT_IS_A>
+__device__ __forceinline__ void product(const v4i& lo, const v4i& hi, const v4i& bb, const v4i& t, v16i& out)
+{
+    v16i z = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    v16i aLo, aHb;
+    if (XT_IS_A)
+    {   // data matrix is the A operand, T the B operand
+        aLo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, t, z, 0, 0, 0);
+        aHb = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, t, z, 0, 0, 0);
+        aHb = __builtin_amdgcn_mfma_i32_32x32x32_i8(bb, t, aHb, 0, 0, 0);
+    }
+    else
+    {
+        aLo = __builtin_amdgcn_mfma_i32_32x32x32_i8(t, lo, z, 0, 0, 0);
+        aHb = __builtin_amdgcn_mfma_i32_32x32x32_i8(t, hi, z, 0, 0, 0);
+        aHb = __builtin_amdgcn_mfma_i32_32x32x32_i8(t, bb, aHb, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = aHb[i] * 256 + aLo[i];
+}
+
+
+// constant operands for lane (r = lane & 31, g = lane >> 5):
+//   tB1: stage-1 B = T[r][16g + s]           (k-slot s = 0..15)
+//   tA2: stage-2 A = T[r][n(s,g)],  n(s,g) = (s & 3) + 8 * (s >> 2) + 4 * g   (the C/D row order of stage 1)
+__device__ __forceinline__ void dct32_operands(int r, int g, v4i& tB1, v4i& tA2)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        unsigned b1 = 0, a2 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            int s = 4 * q + e;
+            b1 |= ((unsigned)dct_coef(r, 16 * g + s) & 0xFFu) << (8 * e);
+            a2 |= ((unsigned)dct_coef(r, (s & 3) + 8 * (s >> 2) + 4 * g) & 0xFFu) << (8 * e);
+        }
+        tB1[q] = (int)b1; tA2[q] = (int)a2;
+    }
+}
+
+// Forward 32x32 DCT of one TU held as 8 dwords per lane (row r, columns 16g..16g+15, two int16 per dword).
+// Result: acc[i] = UNROUNDED stage-2 sum for coefficient (k = (i & 3) + 8 * (i >> 2) + 4 * g, j = r);
+// the caller applies (acc + (1 << 10)) >> 11 (dct.cpp:511-526 shift_2nd = 11).
+__device__ __forceinline__ void dct32_forward(const int* d, const v4i& tB1, const v4i& tA2, v16i& acc)
+{
+    const int shift1 = 4 + X265_DEPTH - 8, add1 = 1 << (shift1 - 1);
+    v4i lo, hi, bb;
+    split_planes(d, lo, hi, bb);
+    product<true>(lo, hi, bb, tB1, acc);
+    int t16[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+    {
+        int v0 = (acc[2 * q] + add1) >> shift1, v1 = (acc[2 * q + 1] + add1) >> shift1;
+        t16[q] = __builtin_amdgcn_perm(v1, v0, 0x05040100);
+    }
+    split_planes(t16, lo, hi, bb);
+    product<false>(lo, hi, bb, tA2, acc);
+}
+
+} // namespace xh
