@@ -29,7 +29,7 @@ def test_tq_batch_matches_oracle(depth, log2n):
         for i in range(n):
             px = int(rng.integers(0, (W - N) // 4 + 1)) * 4; py = int(rng.integers(0, (H - N) // 4 + 1)) * 4
             off = (margin + py) * stride + margin + px
-            t[i]["curOff"] = off; t[i]["refOff"] = off; t[i]["reconOff"] = off
+            t[i]["curOff"] = off; t[i]["refOff"] = off; t[i]["reconOff"] = i * N * N      # dense, non-overlapping recon blocks
             if rng.random() < 0.8:
                 t[i]["mv"] = (4 * dx + int(rng.integers(-6, 7)), 4 * dy + int(rng.integers(-6, 7)))
             else:
@@ -39,11 +39,11 @@ def test_tq_batch_matches_oracle(depth, log2n):
         d_coeff = torch.zeros(n * N * N, dtype=torch.int16, device="cuda")
         d_ns = torch.zeros(n, dtype=torch.int32, device="cuda")
         d_du = torch.zeros(n * N * N, dtype=torch.int32, device="cuda")
-        d_rec = torch.zeros_like(d_cur) if recon else None
+        d_rec = torch.zeros(n * N * N, dtype=d_cur.dtype, device="cuda") if recon else None
         d_sse = torch.zeros(n, dtype=torch.int64, device="cuda") if recon else None
         d_qc = api.to_device(qc) if qc is not None else None
         api.tq_batch(log2n, d_cur, stride, d_ref, stride, d_t, n, qp, add, d_coeff, d_ns, quant_coeff=d_qc, delta_u=d_du,
-                     recon=d_rec, recon_stride=stride, sse=d_sse)
+                     recon=d_rec, recon_stride=N, sse=d_sse)
         torch.cuda.synchronize()
         coeff = d_coeff.cpu().numpy().reshape(n, N * N); ns = d_ns.cpu().numpy(); du = d_du.cpu().numpy().reshape(n, N * N)
         rec = d_rec.cpu().numpy().view(cur_f.dtype) if recon else None
@@ -55,7 +55,7 @@ def test_tq_batch_matches_oracle(depth, log2n):
             assert int(ns[i]) == e_ns and np.array_equal(coeff[i], e_coeff), "coeff: N=%d qp=%d task %d mv %s" % (N, qp, i, mv)
             assert np.array_equal(du[i], e_du), "deltaU: N=%d qp=%d task %d" % (N, qp, i)
             if recon:
-                got = np.array([rec[off + y * stride: off + y * stride + N] for y in range(N)]).reshape(-1)
+                got = rec[i * N * N:(i + 1) * N * N]
                 assert np.array_equal(got, e_rec), "recon: N=%d qp=%d task %d numSig %d" % (N, qp, i, e_ns)
                 assert int(sse[i]) == e_sse, "sse: N=%d qp=%d task %d" % (N, qp, i)
             kinds.add(0 if e_ns == 0 else (1 if e_ns == 1 else 2))

@@ -42,6 +42,26 @@ def build_libraries(jobs=8):
     subprocess.check_call(["make", "-s", "-j%d" % jobs, "-C", HERE])
 
 
+_runtime_pinned = False
+
+
+def _pin_hip_runtime():
+    """torch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever copy is mapped first serves
+    every later user in the process, and torch stops seeing the GPU when the system copy got there first.  Inside
+    Python we therefore always map torch's runtime before libx265hip (a C/C++ host simply uses the system one)."""
+    global _runtime_pinned
+    if _runtime_pinned:
+        return
+    _runtime_pinned = True
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except ImportError:
+        pass
+
+
 class HipLib:
     """One loaded libx265hip_<depth>.so plus an EncoderPrimitives-sized table it has filled."""
 
@@ -50,6 +70,7 @@ class HipLib:
         if not os.path.exists(path):
             raise RuntimeError("x265hip: %s missing -- run `make -C %s` (no fallback exists)" % (path, HERE))
         self.depth = depth
+        _pin_hip_runtime()
         self.lib = C.CDLL(path)
         self.lib.x265hip_last_error.restype = C.c_char_p
         if self.lib.x265hip_bit_depth() != depth:
