@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- ME + DCT + quant throughput of the x265 encoder-primitives hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of F synthetic (source, reference) frame pairs that are
+already resident in HBM: integer + sub-pel motion search for the 2Nx2N PU pyramid of every CTU (85 PUs / CTU64),
+then motion compensation -> residual -> DCT -> quant of every 32x32 TU with the MVs just found.
+Metric (BASELINE.json): Mpixels/s of luma source pixels through that pipeline, whole job over all ranks.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Ranks process independent frames (weak scaling, no data-path collective; RCCL is used only for the barrier and the
+max-over-ranks time).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E nominal (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+METHODS = {"dia": 0, "hex": 1, "star": 3}
+WORKLOADS = {
+    # BASELINE.json configs[1]: 1080p 8-bit, preset medium (me hex, subme 2, merange 57 -- param.cpp:188,238-256)
+    "1080p8_medium": dict(depth=8, width=1920, height=1088, method="hex", subme=2, merange=57),
+    # configs[2]: 2160p 10-bit Main10, preset slow (me star, subme 3)
+    "2160p10_slow": dict(depth=10, width=3840, height=2176, method="star", subme=3, merange=57),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="1080p8_medium", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=8, help="frame pairs per step per GPU")
+    ap.add_argument("--qp", type=int, default=28)
+    ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
+    ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
+    ap.add_argument("--cpu-ctus", type=int, default=1020, help="CTUs in the CPU-baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(pipe, depth, n_ctus):
+    """The reference's own C primitives + motionEstimate (oracle/_ref, built from /root/reference sources) on the same
+    tasks the GPU just processed, one process per host core; falls back to the restated oracle when the binary is
+    missing.  Also cross-checks the sample's results against the GPU's (parity in the same run)."""
+    from refproc import RefProc, ref_available
+    from x265hip_pkg.pipeline import LEVELS
+    cores = min(os.cpu_count() or 1, 64)
+    ctus_per_frame = (pipe.W // 64) * (pipe.H // 64)
+    n_ctus = min(n_ctus, ctus_per_frame * pipe.F)
+    n_frames = (n_ctus + ctus_per_frame - 1) // ctus_per_frame
+    elems = n_frames * pipe.plane
+    cur, ref = pipe.cur_host[:elems], pipe.ref_host[:elems]
+    res = {lv: pipe.results(lv) for lv in LEVELS}
+    # work list: (kind, level, task index) limited to the sampled CTUs, split round-robin over processes
+    jobs = []
+    for lv in LEVELS:
+        t = pipe.tasks_host[lv]
+        per_frame = (pipe.W // lv) * (pipe.H // lv)
+        keep = []
+        for f in range(n_frames):
+            cnt = per_frame if (f + 1) * ctus_per_frame <= n_ctus else int(per_frame * (n_ctus - f * ctus_per_frame) / ctus_per_frame)
+            keep.extend(range(f * per_frame, f * per_frame + cnt))
+        keep = np.asarray(keep)
+        qmvp = np.zeros((len(keep), 2), np.int64)
+        if lv != 64:
+            qmvp = res[2 * lv][t["mvpFrom"][keep]]["mv"].astype(np.int64)
+        d = pipe.merange << 2
+        lo, hi = t["mvmin"][keep].astype(np.int64), t["mvmax"][keep].astype(np.int64)
+        mn = np.minimum(hi, np.maximum(lo, qmvp - d)) >> 2
+        mx = np.minimum(hi, np.maximum(lo, qmvp + d)) >> 2
+        mx[:, 1] = np.maximum(mx[:, 1], mn[:, 1])
+        rows = np.concatenate([t["curOff"][keep].astype(np.int64)[:, None], mn, mx, qmvp], axis=1)
+        jobs.append((lv, keep, rows))
+    n_tu = 1 << pipe.tu_log2
+    tu = pipe.tu_host
+    tu_per_frame = (pipe.W // n_tu) * (pipe.H // n_tu)
+    tu_keep = np.arange(min(len(tu), int(tu_per_frame * n_ctus / ctus_per_frame)))
+    tu_rows = np.concatenate([tu["curOff"][tu_keep].astype(np.int64)[:, None],
+                              res[pipe.mv_level][tu["mvFrom"][tu_keep]]["mv"].astype(np.int64)], axis=1)
+    sample_px = n_ctus * 4096
+
+    if ref_available(depth):
+        kind = "reference"
+        procs = [RefProc(depth) for _ in range(cores)]
+        pending = []
+        t0 = time.time()
+        for p_i, p in enumerate(procs):
+            reqs = []
+            for lv, keep, rows in jobs:
+                sl = rows[p_i::cores]
+                if len(sl):
+                    ints = [lv, lv, pipe.stride, pipe.merange, pipe.method, pipe.subme, pipe.qp, len(sl)] + sl.reshape(-1).tolist()
+                    reqs.append(("bench_me", ints, (lv, keep[p_i::cores])))
+            sl = tu_rows[p_i::cores]
+            if len(sl):
+                reqs.append(("bench_tq", [pipe.tu_log2, pipe.stride, pipe.qp, 85, len(sl)] + sl.reshape(-1).tolist(), ("tq", tu_keep[p_i::cores])))
+            pending.append(reqs)
+        # issue every process its first request before collecting anything, so all cores work concurrently
+        import threading
+        ns_per_proc = [0] * cores
+        mismatches = []
+        coeff = pipe.d_coeff.cpu().numpy().reshape(-1, n_tu * n_tu)
+        numsig = pipe.d_numsig.cpu().numpy()
+
+        def worker(i):
+            for op, ints, tag in pending[i]:
+                out = procs[i].call(op, ints, [cur, ref])
+                ns_per_proc[i] += int(np.frombuffer(out[0], np.int64)[0])
+                if op == "bench_me":
+                    lv, idx = tag
+                    r = np.frombuffer(out[1], np.int32).reshape(-1, 3)
+                    g = res[lv][idx]
+                    ok = (r[:, 0] == g["mv"][:, 0]) & (r[:, 1] == g["mv"][:, 1]) & (r[:, 2] == g["cost"])
+                    if not ok.all():
+                        mismatches.append(("me", lv, int((~ok).sum())))
+                else:
+                    _, idx = tag
+                    ns = np.frombuffer(out[1], np.uint32)
+                    w = (np.arange(n_tu * n_tu, dtype=np.int64) + 1)
+                    cs = int((coeff[idx].astype(np.int64) * w).sum() & 0xFFFFFFFF)
+                    if not (np.array_equal(ns, numsig[idx].astype(np.uint32)) and cs == int(np.frombuffer(out[2], np.uint32)[0])):
+                        mismatches.append(("tq", n_tu, 1))
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        wall = time.time() - t0
+        for p in procs:
+            p.close()
+        busy = max(ns_per_proc) / 1e9
+        parity = "identical" if not mismatches else "MISMATCH %s" % mismatches[:3]
+    else:
+        kind = "port"
+        from oracle_py import Oracle
+        ora = Oracle(depth)
+        cores = 1
+        n_ctus = min(n_ctus, 32)
+        sample_px = n_ctus * 4096
+        t0 = time.time()
+        rng = np.random.default_rng(0)
+        checked = 0
+        for lv, keep, rows in jobs:
+            per_ctu = (64 // lv) ** 2
+            for j in range(min(len(rows), n_ctus * per_ctu)):
+                r = rows[j]
+                ora.me(lv, lv, cur, pipe.stride, int(r[0]), ref, pipe.stride, int(r[0]), [int(v) for v in r[1:5]], (int(r[5]), int(r[6])), [],
+                       pipe.merange, pipe.method, pipe.subme, pipe.cost_row_host)
+                checked += 1
+        for j in range(min(len(tu_rows), n_ctus * (64 // n_tu) ** 2)):
+            r = tu_rows[j]
+            ora.tq_tu(pipe.tu_log2, cur, pipe.stride, int(r[0]), ref, pipe.stride, int(r[0]), (int(r[1]), int(r[2])), pipe.qp, 85)
+        wall = busy = time.time() - t0
+        parity = "not cross-checked"
+    return {"value": round(sample_px / busy / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+            "sample": "%d CTU64 (%d luma px) of the same batch: ME pyramid (85 PUs/CTU) + %dx%d DCT+quant, %s; busiest core %.2f s, wall %.2f s; "
+                      "results vs GPU: %s" % (n_ctus, sample_px, n_tu, n_tu,
+                                               "reference C primitives + motionEstimate (no asm), one process per core" if kind == "reference"
+                                               else "restated oracle, single thread", busy, wall, parity)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import x265hip  # noqa: F401
+    from x265hip_pkg.frame import FrameApi, mvcost_row
+    from x265hip_pkg.pipeline import FramePipeline, LEVELS
+    from x265hip_pkg.synth import frame_pair
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    wl = WORKLOADS[args.workload]
+    depth, W, H = wl["depth"], wl["width"], wl["height"]
+    api = FrameApi(depth)
+    half = 1 << 15
+    cost_row = mvcost_row(depth, args.qp, half)
+    pipe = FramePipeline(depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"],
+                         tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api)
+    pairs = []
+    for f in range(args.frames):
+        cur, ref, stride, _ = frame_pair(W, H, depth, seed=rank * args.frames + f, margin=pipe.margin, max_shift=24)
+        pairs.append((cur, ref))
+    pipe.upload(pairs)                      # inputs are resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pipe.step()
+    barrier()
+    names = ["me64", "me32", "me16", "me8", "tq%d" % (1 << args.tu)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev = events[k]
+        ev[0].record()
+        for i, lv in enumerate(LEVELS):
+            pipe.launch_me(lv)
+            ev[i + 1].record()
+        pipe.launch_tq()
+        ev[len(names)].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        kms = {n: float(np.mean([events[k][i].elapsed_time(events[k][i + 1]) for k in range(args.steps)])) for i, n in enumerate(names)}
+        bpp = 1 if depth == 8 else 2
+        px = pipe.pixels_per_step
+        # algorithmic (compulsory) bytes per launch: SURVEY 8(d) -- each plane byte once + 16 B result per PU / 2 B coeff per pixel
+        alg = {}
+        for lv in LEVELS:
+            alg["me%d" % lv] = px * 2 * bpp + len(pipe.tasks_host[lv]) * 16
+        n_tu = 1 << args.tu
+        alg[names[-1]] = px * (2 * bpp + 2) + len(pipe.tu_host) * 4
+        dom = max(kms, key=kms.get)
+        achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        value = world * px * args.steps / dt / 1e6
+        out = {
+            "metric": "Mpixels/s ME+DCT+quant on CTU batches (luma source pixels through ME pyramid + MC/DCT/quant)",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
+            "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames,
+                       "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "qp": args.qp,
+                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "sharding": "independent frames per GPU, no collectives"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
+                         "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()},
+                         "all_kernels_GBps": {k: round(alg[k] / (v * 1e-3) / 1e9, 2) for k, v in kms.items()}},
+        }
+        if world == 1 and args.cpu_ctus > 0:
+            out["cpu_baseline"] = cpu_baseline(pipe, depth, args.cpu_ctus)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,11 +28,19 @@ enum x265hip_me_method { X265HIP_ME_DIA = 0, X265HIP_ME_HEX = 1, X265HIP_ME_UMH 
 typedef struct x265hip_me_task {
     int32_t curOff;              /* element offset of the PU's top-left pixel in the source plane   */
     int32_t refOff;              /* element offset of the co-located pixel in the reference plane   */
-    int16_t mvmin[2], mvmax[2];  /* full-pel search bounds (x, y), inclusive (motion.cpp:925-926)    */
-    int16_t qmvp[2];             /* quarter-pel MV predictor                                         */
+    int16_t mvmin[2], mvmax[2];  /* full-pel search bounds (x, y), inclusive (motion.cpp:925-926);
+                                    with X265HIP_ME_WINDOW: QUARTER-pel clip limits (CUData::clipMv)   */
+    int16_t qmvp[2];             /* quarter-pel MV predictor (ignored when mvpFrom >= 0)             */
     int16_t mvc[8];              /* up to 4 quarter-pel candidates (x, y)                            */
-    int32_t numCand;             /* 0..4                                                             */
-} x265hip_me_task;               /* 40 bytes */
+    int16_t numCand;             /* 0..4                                                             */
+    int16_t flags;               /* X265HIP_ME_*                                                     */
+    int32_t mvpFrom;             /* >= 0: predictor = mvpSource[mvpFrom].mv (e.g. the parent CU's MV, the way
+                                    Analysis::deriveMVsForCTU seeds PUs from m_areaBestMV, analysis.cpp:248-306) */
+} x265hip_me_task;               /* 44 bytes */
+
+/* flags: derive the search window on the device the way Search::setSearchRange does (search.cpp:4969-5021):
+ * [mvp - 4*merange, mvp + 4*merange] clipped to the task's quarter-pel limits, >> 2, mvmax.y >= mvmin.y */
+#define X265HIP_ME_WINDOW 1
 
 typedef struct x265hip_me_result {
     int16_t mv[2];               /* chosen quarter-pel MV (outQMv)                                   */
@@ -40,6 +48,12 @@ typedef struct x265hip_me_result {
     int32_t mvcost;              /* the lambda-scaled MVD cost of mv (BitCost::mvcost)               */
     int32_t reserved;
 } x265hip_me_result;             /* 16 bytes */
+
+/* Host helper: the lambda-scaled MVD cost row of BitCost::setQP / CalculateLogs (bitcost.cpp:30-105) for this
+ * library's bit depth: out[halfRange + d] = min(uint16(bits(|d|) * lambda(qp) + 0.5), 32767), d in quarter-pels,
+ * bits(0) = 0.718, bits(i) = log(i+1) * 2/log(2) + 1.718 in the reference's float/double mix, lambda =
+ * x265_lambda_tab[qp] (constants.cpp:28-116).  Pure host code (no GPU needed); upload the row for x265hip_me_batch. */
+int x265hip_mvcost_row(int qp, int halfRange, uint16_t* out /* 2*halfRange+1 */);
 
 /* costRow: device uint16 table of 2*costHalfRange+1 entries, entry [costHalfRange + d] = lambda-scaled cost
  * of an MVD component d in quarter-pels -- the row BitCost::setQP builds (bitcost.cpp:30-56); it is an
@@ -49,7 +63,8 @@ int x265hip_me_batch(void* stream, int w, int h,
                      const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                      const x265hip_me_task* tasks, int n,
                      const uint16_t* costRow, int costHalfRange,
-                     int merange, int method, int subpelRefine, x265hip_me_result* results);
+                     int merange, int method, int subpelRefine, x265hip_me_result* results,
+                     const x265hip_me_result* mvpSource /* may be NULL */);
 
 /* one transform unit of the inter residual path; all TUs of one call share log2 size.
  * replaces the chain Predict::predInterLumaPixel (predict.cpp:279-300: copy_pp | luma_hpp | luma_vpp |
@@ -61,7 +76,8 @@ typedef struct x265hip_tu_task {
     int32_t refOff;              /* co-located pixel in the reference plane                           */
     int16_t mv[2];               /* quarter-pel MV used for motion compensation                       */
     int32_t reconOff;            /* TU top-left in the recon plane (ignored without recon)            */
-} x265hip_tu_task;               /* 16 bytes */
+    int32_t mvFrom;              /* >= 0: mv = mvSource[mvFrom].mv (device-side hand-over from x265hip_me_batch) */
+} x265hip_tu_task;               /* 20 bytes */
 
 typedef struct x265hip_tq_params {
     int qp;                      /* 0..51: per = qp/6, rem = qp%6 (quant.cpp:465-469,555-568)         */
@@ -74,7 +90,8 @@ int x265hip_tq_batch(void* stream, int log2TrSize,
                      const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                      const x265hip_tu_task* tasks, int n, const x265hip_tq_params* params,
                      int16_t* coeff /* n x N*N dense */, uint32_t* numSig /* n */,
-                     void* reconPlane /* NULL = forward path only */, intptr_t reconStride, uint64_t* sse /* n, with recon */);
+                     void* reconPlane /* NULL = forward path only */, intptr_t reconStride, uint64_t* sse /* n, with recon */,
+                     const x265hip_me_result* mvSource /* may be NULL */);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ t = np.zeros(1, ME_TASK)
 px, py = 64, 48
 off = (margin + py) * stride + margin + px
 qmvp = (4 * dx, 4 * dy)
-t[0]["curOff"] = off; t[0]["refOff"] = off
+t[0]["mvpFrom"] = -1; t[0]["curOff"] = off; t[0]["refOff"] = off
 t[0]["mvmin"] = (-40, -40); t[0]["mvmax"] = (40, 40); t[0]["qmvp"] = qmvp
 d_t = api.to_device(t)
 d_res = api.torch.zeros(16, dtype=api.torch.uint8, device="cuda")

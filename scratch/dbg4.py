@@ -19,7 +19,7 @@ for (qx, qy) in [(-8, -7), (-7, -8), (-7, -7), (0, 0)]:
     t = np.zeros(1, ME_TASK)
     px, py = 64, 48
     off = (margin + py) * stride + margin + px
-    t[0]["curOff"] = off; t[0]["refOff"] = off; t[0]["mvmin"] = (-40, -40); t[0]["mvmax"] = (40, 40); t[0]["qmvp"] = (qx, qy)
+    t[0]["mvpFrom"] = -1; t[0]["curOff"] = off; t[0]["refOff"] = off; t[0]["mvmin"] = (-40, -40); t[0]["mvmax"] = (40, 40); t[0]["qmvp"] = (qx, qy)
     d_t = api.to_device(t); d_res = api.torch.zeros(8192, dtype=api.torch.uint8, device="cuda")
     api.me_batch(w, h, d_cur, stride, d_ref, stride, d_t, 1, d_row, half, 4, 0, 7, d_res)
     api.torch.cuda.synchronize()

@@ -34,7 +34,7 @@ def make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange):
         t[i]["mvmax"] = (min(fx + merange, W - px - w + lim), min(fy + merange, H - py - h + lim))
         t[i]["qmvp"] = qmvp
         nc = int(rng.integers(0, 5))
-        t[i]["numCand"] = nc
+        t[i]["numCand"] = nc; t[i]["mvpFrom"] = -1
         t[i]["mvc"][:2 * nc] = rng.integers(-80, 81, 2 * nc)
     return t
 

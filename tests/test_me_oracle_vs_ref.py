@@ -70,3 +70,20 @@ def test_motion_estimate_matches_reference(depth, method):
     finally:
         ref.close()
     assert n >= 70
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_library_cost_row_matches_oracle_and_reference(depth):
+    """x265hip_mvcost_row is host code of the PRODUCT (no GPU needed): it must reproduce BitCost::setQP."""
+    from x265hip_pkg.frame import mvcost_row
+    ora = Oracle(depth)
+    ref = Ref(depth) if ref_available(depth) else None
+    try:
+        for qp in (0, 7, 22, 28, 37, 51):
+            row = mvcost_row(depth, qp, 3000)
+            assert np.array_equal(row, ora.mvcost_row(qp, 3000))
+            if ref:
+                assert np.array_equal(row, ref.mvcost_row(qp, 3000))
+    finally:
+        if ref:
+            ref.close()

@@ -1,0 +1,60 @@
+"""Frame pipeline on the GPU: sampled oracle parity on small frames for every search method, and -- at the
+bench's full 1080p size -- size-independent properties plus a random sample against the oracle."""
+import numpy as np
+import pytest
+
+import x265hip  # noqa: F401
+from x265hip_pkg.frame import mvcost_row
+from x265hip_pkg.pipeline import FramePipeline, LEVELS
+from x265hip_pkg.synth import frame_pair
+from backends import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method,subme,tu", [(1, 2, 5), (3, 3, 4), (0, 0, 3), (1, 7, 2)])
+def test_small_frames_match_oracle(depth, method, subme, tu):
+    row = mvcost_row(depth, 28, 1 << 15)
+    pipe = FramePipeline(depth, 256, 128, 2, qp=28, merange=24, method=method, subme=subme, tu_log2=tu, recon=True, cost_row=row)
+    pipe.upload([frame_pair(256, 128, depth, 40 + s, margin=pipe.margin, max_shift=14)[:2] for s in range(2)])
+    pipe.step()
+    pipe.torch.cuda.synchronize()
+    assert pipe.check_sample(Oracle(depth), np.random.default_rng(depth + method), per_level=12, n_tu=16) >= 40
+
+
+def test_full_size_properties_and_sample():
+    """BASELINE configs[1] size: 1920x1088 8-bit, HEX, subme 2, merange 57."""
+    depth, W, H = 8, 1920, 1088
+    row = mvcost_row(depth, 28, 1 << 15)
+    pipe = FramePipeline(depth, W, H, 2, qp=28, merange=57, method=1, subme=2, tu_log2=5, recon=True, cost_row=row)
+    T = pipe.torch
+    cur0, ref0, _, (dx, dy) = frame_pair(W, H, depth, 1, margin=pipe.margin, max_shift=24)
+    # frame 1: reference identical to the source -> the search must return zero MVs, zero residual, zero SSE
+    pipe.upload([(cur0, ref0), (cur0, cur0)])
+    pipe.step(); T.cuda.synchronize()
+    first = {lv: pipe.results(lv).copy() for lv in LEVELS}
+    coeff1 = pipe.d_coeff.clone(); sse1 = pipe.d_sse.clone(); rec1 = pipe.d_recon.clone()
+    # determinism / idempotence: a second pass over the same planes gives identical bytes
+    pipe.step(); T.cuda.synchronize()
+    for lv in LEVELS:
+        assert np.array_equal(first[lv], pipe.results(lv))
+    assert T.equal(coeff1, pipe.d_coeff) and T.equal(sse1, pipe.d_sse) and T.equal(rec1, pipe.d_recon)
+    # identical frames
+    for lv in LEVELS:
+        r = first[lv]; n = len(r) // 2
+        assert not r["mv"][n:].any(), "identical frames must give zero motion at level %d" % lv
+    ntu = len(pipe.tu_host) // 2
+    assert int(pipe.d_numsig[ntu:].abs().sum()) == 0 and int(pipe.d_coeff.view(-1, 1024)[ntu:].abs().sum()) == 0
+    assert int(pipe.d_sse[ntu:].sum()) == 0
+    # the global motion is found by the bulk of the large PUs of frame 0
+    r64 = first[64][:len(first[64]) // 2]
+    hit = np.mean((np.abs(r64["mv"][:, 0] - 4 * dx) <= 4) & (np.abs(r64["mv"][:, 1] - 4 * dy) <= 4))
+    assert hit > 0.8, "only %.0f%% of the 64x64 PUs found the synthetic motion (%d,%d)" % (100 * hit, dx, dy)
+    # checksum of checksums: per-TU SSE must add up to the plane-level squared error of the reconstruction
+    m, s = pipe.margin, pipe.stride
+    cur = pipe.d_cur.view(2, H + 2 * m, s)[:, m:m + H, m:m + W].to(T.int64)
+    rec = pipe.d_recon.view(2, H + 2 * m, s)[:, m:m + H, m:m + W].to(T.int64)
+    assert int(((cur - rec) ** 2).sum()) == int(pipe.d_sse.sum())
+    # and a random sample of PUs / TUs bit-exact against the oracle
+    assert pipe.check_sample(Oracle(depth), np.random.default_rng(3), per_level=25, n_tu=25) == 125

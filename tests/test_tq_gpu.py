@@ -29,7 +29,7 @@ def test_tq_batch_matches_oracle(depth, log2n):
         for i in range(n):
             px = int(rng.integers(0, (W - N) // 4 + 1)) * 4; py = int(rng.integers(0, (H - N) // 4 + 1)) * 4
             off = (margin + py) * stride + margin + px
-            t[i]["curOff"] = off; t[i]["refOff"] = off; t[i]["reconOff"] = i * N * N      # dense, non-overlapping recon blocks
+            t[i]["mvFrom"] = -1; t[i]["curOff"] = off; t[i]["refOff"] = off; t[i]["reconOff"] = i * N * N      # dense, non-overlapping recon blocks
             if rng.random() < 0.8:
                 t[i]["mv"] = (4 * dx + int(rng.integers(-6, 7)), 4 * dy + int(rng.integers(-6, 7)))
             else:

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                                                         const pixel* __restrict__ ref, intptr_t rs,
                                                         const x265hip_me_task* __restrict__ tasks, int n,
                                                         const uint16_t* __restrict__ costCentre,
-                                                        int merange, int method, int subme, x265hip_me_result* __restrict__ results, int dbg)
+                                                        int merange, int method, int subme, x265hip_me_result* __restrict__ results,
+                                                        const x265hip_me_result* __restrict__ mvpSource, int dbg)
 {
     __shared__ __attribute__((aligned(16))) pixel s_fenc[WAVES][MAXPIX];
     __shared__ __attribute__((aligned(16))) pixel s_pred[WAVES][MAXPIX];
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
     const int wave = threadIdx.x >> 6;
     const int item = blockIdx.x * WAVES + wave;
     if (item >= n) return;            // wave-granular exit; no block barriers are used
-    const x265hip_me_task tk = tasks[item];
+    x265hip_me_task tk = tasks[item];
+    if (tk.mvpFrom >= 0 && mvpSource) { tk.qmvp[0] = mvpSource[tk.mvpFrom].mv[0]; tk.qmvp[1] = mvpSource[tk.mvpFrom].mv[1]; }
 
     Ctx c;
     c.lane = threadIdx.x & 63; c.w = w; c.h = h; c.qpr = w >> 2; c.nquads = c.qpr * h; c.qdivm = ((1 << 20) / c.qpr) + 1;
@@ -282,7 +284,14 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
         if (c.lane == 0) { x265hip_me_result r; r.mv[0] = tk.qmvp[0]; r.mv[1] = tk.qmvp[1]; r.cost = v; r.mvcost = 0; r.reserved = 0; results[item] = r; }
         return;
     }
-    const int mnx = tk.mvmin[0], mny = tk.mvmin[1], mxx = tk.mvmax[0], mxy = tk.mvmax[1];
+    int mnx = tk.mvmin[0], mny = tk.mvmin[1], mxx = tk.mvmax[0], mxy = tk.mvmax[1];
+    if (tk.flags & X265HIP_ME_WINDOW)
+    {   // search.cpp:4969-5021 setSearchRange: clip mvp -/+ 4*merange to the quarter-pel limits, then to full-pel
+        const int lx0 = mnx, ly0 = mny, lx1 = mxx, ly1 = mxy, d = merange << 2;
+        mnx = min(lx1, max(lx0, tk.qmvp[0] - d)) >> 2; mny = min(ly1, max(ly0, tk.qmvp[1] - d)) >> 2;
+        mxx = min(lx1, max(lx0, tk.qmvp[0] + d)) >> 2; mxy = min(ly1, max(ly0, tk.qmvp[1] + d)) >> 2;
+        mxy = max(mxy, mny);
+    }
     const int qmnx = mnx * 4, qmny = mny * 4, qmxx = mxx * 4, qmxy = mxy * 4;
 
     // ---- start point, motion.cpp:955-1012 ----
@@ -514,10 +523,10 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
 
 template<int MAXPIX, int MAXW, int WAVES>
 int launch_me(hipStream_t st, int w, int h, const pixel* cur, intptr_t cs, const pixel* ref, intptr_t rs, const x265hip_me_task* tasks, int n,
-              const uint16_t* costCentre, int merange, int method, int subme, x265hip_me_result* results)
+              const uint16_t* costCentre, int merange, int method, int subme, x265hip_me_result* results, const x265hip_me_result* mvpSource)
 {
     hipLaunchKernelGGL((me_kernel<MAXPIX, MAXW, WAVES>), dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, st,
-                       w, h, cur, cs, ref, rs, tasks, n, costCentre, merange, method, subme, results, getenv("X265HIP_ME_DBG") ? atoi(getenv("X265HIP_ME_DBG")) : 0);
+                       w, h, cur, cs, ref, rs, tasks, n, costCentre, merange, method, subme, results, mvpSource, getenv("X265HIP_ME_DBG") ? atoi(getenv("X265HIP_ME_DBG")) : 0);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -526,7 +535,7 @@ int launch_me(hipStream_t st, int w, int h, const pixel* cur, intptr_t cs, const
 
 extern "C" int x265hip_me_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                                 const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
-                                int merange, int method, int subpelRefine, x265hip_me_result* results)
+                                int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource)
 {
     if (n <= 0) return X265HIP_OK;
     if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !tasks || !results || !costRow || costHalfRange < 1)
@@ -538,8 +547,8 @@ extern "C" int x265hip_me_batch(void* stream, int w, int h, const void* curPlane
     const pixel* cur = (const pixel*)curPlane; const pixel* ref = (const pixel*)refPlane;
     const uint16_t* centre = costRow + costHalfRange;
     const int area = w * h;
-    if (area <= 64 && w <= 16) return launch_me<64, 16, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results);
-    if (area <= 256 && w <= 32) return launch_me<256, 32, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results);
-    if (area <= 1024) return launch_me<1024, 64, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results);
-    return launch_me<4096, 64, 2>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results);
+    if (area <= 64 && w <= 16) return launch_me<64, 16, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
+    if (area <= 256 && w <= 32) return launch_me<256, 32, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
+    if (area <= 1024) return launch_me<1024, 64, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
+    return launch_me<4096, 64, 2>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
 }

@@ -23,6 +23,7 @@ struct TqArgs
     int qp, add; const int32_t* quantCoeff; int32_t* deltaU;
     int16_t* coeff; uint32_t* numSig;
     pixel* recon; intptr_t reconStride; uint64_t* sse;
+    const x265hip_me_result* mvSource;
 };
 
 template<int N> struct Lg { static const int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5; };
@@ -60,7 +61,8 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + wave;
     if (item >= a.n) return;
-    const x265hip_tu_task tk = a.tasks[item];
+    x265hip_tu_task tk = a.tasks[item];
+    if (tk.mvFrom >= 0 && a.mvSource) { tk.mv[0] = a.mvSource[tk.mvFrom].mv[0]; tk.mv[1] = a.mvSource[tk.mvFrom].mv[1]; }
 
     McCtx c;
     c.setGeometry(N, N, lane);
@@ -251,7 +253,8 @@ template<int N> int launch_tq(hipStream_t st, const TqArgs& a)
 
 extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                                 const x265hip_tu_task* tasks, int n, const x265hip_tq_params* params,
-                                int16_t* coeff, uint32_t* numSig, void* reconPlane, intptr_t reconStride, uint64_t* sse)
+                                int16_t* coeff, uint32_t* numSig, void* reconPlane, intptr_t reconStride, uint64_t* sse,
+                                const x265hip_me_result* mvSource)
 {
     if (n <= 0) return X265HIP_OK;
     if (!tasks || !params || !coeff || !numSig || log2TrSize < 2 || log2TrSize > 5 || params->qp < 0 || params->qp > 51 ||
@@ -259,7 +262,7 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
     { set_error("tq_batch: bad arguments"); return X265HIP_EARG; }
     TqArgs a = { (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride, tasks, n,
                  params->qp, params->add, params->quantCoeff, params->deltaU, coeff, numSig,
-                 (pixel*)reconPlane, reconStride, sse };
+                 (pixel*)reconPlane, reconStride, sse, mvSource };
     hipStream_t st = (hipStream_t)stream;
     switch (log2TrSize)
     {

@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include "../../include/x265hip_frame.h"
 
 namespace xh {
 
@@ -98,5 +100,22 @@ extern "C" int x265hip_abi_check(size_t sizeof_table, int bit_depth)
 {
     if (sizeof_table != X265HIP_SIZEOF_TABLE) { xh::set_error("sizeof(EncoderPrimitives) %zu != %d", sizeof_table, X265HIP_SIZEOF_TABLE); return X265HIP_EABI; }
     if (bit_depth != X265_DEPTH) { xh::set_error("bit depth %d requested, library built for %d", bit_depth, X265_DEPTH); return X265HIP_EABI; }
+    return X265HIP_OK;
+}
+
+// BitCost::CalculateLogs + setQP (bitcost.cpp:30-105): float table of bit sizes from a DOUBLE log, scaled by the
+// 4-decimal lambda table (constants.cpp:28-116: pow(2, qp/6 - 2) * (1 << (depth - 8))), + 0.5f, capped at 2^15 - 1.
+extern "C" int x265hip_mvcost_row(int qp, int halfRange, uint16_t* out)
+{
+    if (qp < 0 || qp > 69 || halfRange < 0 || !out) { xh::set_error("mvcost_row: bad arguments"); return X265HIP_EARG; }
+    const double lambda = std::floor(std::pow(2.0, (double)qp / 6.0 - 2.0) * (double)(1 << (X265_DEPTH - 8)) * 10000.0 + 0.5) / 10000.0;
+    const float log2_2 = (float)(2.0f / std::log((double)2.0f));
+    for (int i = 0; i <= halfRange; i++)
+    {
+        const float bits = i ? (float)(std::log((double)(float)(i + 1)) * log2_2 + 1.718f) : 0.718f;
+        double c = bits * lambda + 0.5f;
+        if (c > 32767.0) c = 32767.0;
+        out[halfRange + i] = out[halfRange - i] = (uint16_t)c;
+    }
     return X265HIP_OK;
 }

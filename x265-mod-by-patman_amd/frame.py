@@ -9,14 +9,23 @@ import numpy as np
 from .binding import HipLib
 
 ME_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mvmin", "<i2", 2), ("mvmax", "<i2", 2), ("qmvp", "<i2", 2),
-                    ("mvc", "<i2", 8), ("numCand", "<i4")])
+                    ("mvc", "<i2", 8), ("numCand", "<i2"), ("flags", "<i2"), ("mvpFrom", "<i4")])
+ME_WINDOW = 1
 ME_RESULT = np.dtype([("mv", "<i2", 2), ("cost", "<i4"), ("mvcost", "<i4"), ("reserved", "<i4")])
-TU_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv", "<i2", 2), ("reconOff", "<i4")])
-assert ME_TASK.itemsize == 40 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 16
+TU_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv", "<i2", 2), ("reconOff", "<i4"), ("mvFrom", "<i4")])
+assert ME_TASK.itemsize == 44 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 20
 
 
 class TqParams(C.Structure):
     _fields_ = [("qp", C.c_int), ("add", C.c_int), ("quantCoeff", C.c_void_p), ("deltaU", C.c_void_p)]
+
+
+def mvcost_row(depth, qp, half):
+    """Host-side cost row from the library (x265hip_mvcost_row); needs no GPU."""
+    lib = HipLib(depth, fill_table=False)
+    out = np.zeros(2 * half + 1, np.uint16)
+    lib.check(lib.lib.x265hip_mvcost_row(qp, half, C.c_void_p(out.ctypes.data)))
+    return out
 
 
 def _dp(t):
@@ -45,13 +54,13 @@ class FrameApi:
             a = a.view(np.uint8)
         return self.torch.from_numpy(a.reshape(-1)).cuda()
 
-    def me_batch(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half, merange, method, subme, results):
+    def me_batch(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half, merange, method, subme, results, mvp_source=None):
         self.h.check(self.lib.x265hip_me_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
-                                               _dp(tasks), n, _dp(cost_row), half, merange, method, subme, _dp(results)))
+                                               _dp(tasks), n, _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source)))
 
     def tq_batch(self, log2n, cur, cstride, ref, rstride, tasks, n, qp, add, coeff, numsig, quant_coeff=None, delta_u=None,
-                 recon=None, recon_stride=0, sse=None):
+                 recon=None, recon_stride=0, sse=None, mv_source=None):
         p = TqParams(qp, add, _dp(quant_coeff), _dp(delta_u))
         self.h.check(self.lib.x265hip_tq_batch(self.stream(), log2n, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
                                                _dp(tasks), n, C.byref(p), _dp(coeff), _dp(numsig),
-                                               _dp(recon), C.c_ssize_t(recon_stride), _dp(sse)))
+                                               _dp(recon), C.c_ssize_t(recon_stride), _dp(sse), _dp(mv_source)))

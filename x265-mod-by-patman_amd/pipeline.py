@@ -1,0 +1,159 @@
+"""Frame-batched ME -> MC/DCT/quant pipeline on device-resident planes (the bench / smoke workload).
+
+One step over a batch of F (source, reference) frame pairs:
+  S1+S2  x265hip_me_batch for the 2Nx2N PU pyramid of every CTU (64, 32, 16, 8 -> 85 PUs / CTU64), each level
+         seeded with its parent's MV the way Analysis::deriveMVsForCTU / computeMVForPUs seed PUs from
+         m_areaBestMV (analysis.cpp:161-306); search window per Search::setSearchRange (search.cpp:4969-5021)
+         with CUData::clipMv limits (cudata.cpp:2094-2107).
+  S3     x265hip_tq_batch on the 2^tu_log2 grid with the MVs of the matching pyramid level:
+         MC -> residual -> DCT -> quant (inter rounding 85), coefficients + numSig out.
+  S4     optional (recon=True): dequant -> IDCT -> reconstruction + SSE.
+All launches go to torch's current stream; nothing is synchronised inside step().
+"""
+import numpy as np
+
+from .frame import FrameApi, ME_TASK, ME_RESULT, TU_TASK, ME_WINDOW
+
+LEVELS = (64, 32, 16, 8)
+CTU = 64
+
+
+class FramePipeline:
+    def __init__(self, depth, width, height, frames, qp=28, merange=57, method=1, subme=2, tu_log2=5, margin=96,
+                 recon=False, cost_row=None, api=None):
+        assert width % CTU == 0 and height % CTU == 0, "pad the picture to whole CTUs"
+        self.api = api or FrameApi(depth)
+        self.torch = self.api.torch
+        self.depth, self.W, self.H, self.F = depth, width, height, frames
+        self.qp, self.merange, self.method, self.subme, self.tu_log2, self.margin = qp, merange, method, subme, tu_log2, margin
+        self.recon = recon
+        self.stride = width + 2 * margin
+        self.plane = self.stride * (height + 2 * margin)        # elements per padded plane
+        self.half = 1 << 15
+        if cost_row is None:
+            raise ValueError("cost_row (uint16, centred, 2*half+1 entries) must be supplied by the caller")
+        assert len(cost_row) == 2 * self.half + 1
+        self.cost_row_host = cost_row
+        self.d_cost = self.api.to_device(cost_row.view(np.int16))
+        self.d_cur = self.d_ref = None
+        self._build_tasks()
+
+    # ---- host-side task construction (once) ----
+    def _origin(self, f, x, y):
+        return f * self.plane + (self.margin + y) * self.stride + self.margin + x
+
+    def _build_tasks(self):
+        W, H, F = self.W, self.H, self.F
+        self.tasks_host, self.index = {}, {}
+        for lv in LEVELS:
+            nx, ny = W // lv, H // lv
+            t = np.zeros(F * nx * ny, ME_TASK)
+            f, by, bx = np.meshgrid(np.arange(F), np.arange(ny), np.arange(nx), indexing="ij")
+            x, y = (bx * lv).reshape(-1), (by * lv).reshape(-1)
+            f = f.reshape(-1)
+            off = f * self.plane + (self.margin + y) * self.stride + self.margin + x
+            t["curOff"] = off
+            t["refOff"] = off
+            # CUData::clipMv limits in quarter-pels (offset 8, maxCUSize 64)
+            t["mvmin"][:, 0] = -((CTU + 8 + x - 1) << 2)
+            t["mvmin"][:, 1] = -((CTU + 8 + y - 1) << 2)
+            t["mvmax"][:, 0] = (W + 8 - x - 1) << 2
+            t["mvmax"][:, 1] = (H + 8 - y - 1) << 2
+            t["flags"] = ME_WINDOW
+            if lv == CTU:
+                t["mvpFrom"] = -1
+            else:
+                pnx, pny = W // (2 * lv), H // (2 * lv)
+                t["mvpFrom"] = f * (pnx * pny) + (by.reshape(-1) // 2) * pnx + (bx.reshape(-1) // 2)
+            self.tasks_host[lv] = t
+        n = 1 << self.tu_log2
+        nx, ny = W // n, H // n
+        tu = np.zeros(F * nx * ny, TU_TASK)
+        f, by, bx = np.meshgrid(np.arange(F), np.arange(ny), np.arange(nx), indexing="ij")
+        x, y, f = (bx * n).reshape(-1), (by * n).reshape(-1), f.reshape(-1)
+        off = f * self.plane + (self.margin + y) * self.stride + self.margin + x
+        tu["curOff"] = off; tu["refOff"] = off; tu["reconOff"] = off
+        self.mv_level = max(n, 8)                                # pyramid level whose MVs drive the TUs
+        lnx, lny = W // self.mv_level, H // self.mv_level
+        tu["mvFrom"] = f * (lnx * lny) + (y // self.mv_level) * lnx + (x // self.mv_level)
+        self.tu_host = tu
+        T = self.torch
+        self.d_tasks = {lv: self.api.to_device(t) for lv, t in self.tasks_host.items()}
+        self.d_results = {lv: T.zeros(len(t) * ME_RESULT.itemsize, dtype=T.uint8, device="cuda") for lv, t in self.tasks_host.items()}
+        self.d_tu = self.api.to_device(tu)
+        self.d_coeff = T.zeros(len(tu) * n * n, dtype=T.int16, device="cuda")
+        self.d_numsig = T.zeros(len(tu), dtype=T.int32, device="cuda")
+        self.d_sse = T.zeros(len(tu), dtype=T.int64, device="cuda") if self.recon else None
+        self.d_recon = None
+
+    @property
+    def pixels_per_step(self):
+        return self.F * self.W * self.H
+
+    def upload(self, pairs):
+        """pairs: F tuples (cur_padded, ref_padded) of shape (H + 2*margin, W + 2*margin)."""
+        assert len(pairs) == self.F
+        cur = np.concatenate([c.reshape(-1) for c, _ in pairs])
+        ref = np.concatenate([r.reshape(-1) for _, r in pairs])
+        assert cur.size == self.F * self.plane
+        self.cur_host, self.ref_host = cur, ref
+        self.d_cur, self.d_ref = self.api.to_device(cur), self.api.to_device(ref)
+        if self.recon:
+            self.d_recon = self.torch.zeros_like(self.d_cur)
+
+    # ---- device work ----
+    def launch_me(self, lv):
+        parent = None if lv == CTU else self.d_results[2 * lv]
+        self.api.me_batch(lv, lv, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tasks[lv], len(self.tasks_host[lv]),
+                          self.d_cost, self.half, self.merange, self.method, self.subme, self.d_results[lv], mvp_source=parent)
+
+    def launch_tq(self):
+        self.api.tq_batch(self.tu_log2, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tu, len(self.tu_host), self.qp, 85,
+                          self.d_coeff, self.d_numsig, recon=self.d_recon, recon_stride=self.stride, sse=self.d_sse,
+                          mv_source=self.d_results[self.mv_level])
+
+    def step(self):
+        for lv in LEVELS:
+            self.launch_me(lv)
+        self.launch_tq()
+
+    # ---- read-back / checking helpers (tests, smoke) ----
+    def results(self, lv):
+        return self.d_results[lv].cpu().numpy().view(ME_RESULT)
+
+    def check_sample(self, oracle, rng, per_level=40, n_tu=40):
+        """Compare randomly sampled PUs / TUs of the last step() with the oracle (bit-exact). Returns #checked."""
+        res = {lv: self.results(lv) for lv in LEVELS}
+        checked = 0
+        for lv in LEVELS:
+            t = self.tasks_host[lv]
+            for i in rng.choice(len(t), size=min(per_level, len(t)), replace=False):
+                tk = t[i]
+                qmvp = (0, 0) if tk["mvpFrom"] < 0 else tuple(int(v) for v in res[2 * lv][tk["mvpFrom"]]["mv"])
+                d = self.merange << 2
+                lx0, ly0, lx1, ly1 = int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])
+                b = [min(lx1, max(lx0, qmvp[0] - d)) >> 2, min(ly1, max(ly0, qmvp[1] - d)) >> 2,
+                     min(lx1, max(lx0, qmvp[0] + d)) >> 2, min(ly1, max(ly0, qmvp[1] + d)) >> 2]
+                b[3] = max(b[3], b[1])
+                exp = oracle.me(lv, lv, self.cur_host, self.stride, int(tk["curOff"]), self.ref_host, self.stride, int(tk["refOff"]),
+                                b, qmvp, [], self.merange, self.method, self.subme, self.cost_row_host)
+                got = (int(res[lv][i]["mv"][0]), int(res[lv][i]["mv"][1]), int(res[lv][i]["cost"]))
+                assert got == exp, "ME level %d task %d: hip %s oracle %s" % (lv, i, got, exp)
+                checked += 1
+        n = 1 << self.tu_log2
+        coeff = self.d_coeff.cpu().numpy().reshape(-1, n * n)
+        numsig = self.d_numsig.cpu().numpy()
+        sse = self.d_sse.cpu().numpy() if self.recon else None
+        rec = self.d_recon.cpu().numpy().view(self.cur_host.dtype) if self.recon else None
+        for i in rng.choice(len(self.tu_host), size=min(n_tu, len(self.tu_host)), replace=False):
+            tk = self.tu_host[i]
+            mv = tuple(int(v) for v in res[self.mv_level][tk["mvFrom"]]["mv"])
+            e_ns, e_coeff, _, e_rec, e_sse = oracle.tq_tu(self.tu_log2, self.cur_host, self.stride, int(tk["curOff"]), self.ref_host, self.stride,
+                                                          int(tk["refOff"]), mv, self.qp, 85, want_recon=self.recon)
+            assert int(numsig[i]) == e_ns and np.array_equal(coeff[i], e_coeff), "TU %d: coefficients differ from the oracle" % i
+            if self.recon:
+                o = int(tk["reconOff"])
+                got = np.concatenate([rec[o + y * self.stride: o + y * self.stride + n] for y in range(n)])
+                assert np.array_equal(got, e_rec) and int(sse[i]) == e_sse, "TU %d: reconstruction differs from the oracle" % i
+            checked += 1
+        return checked
