@@ -353,18 +353,19 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
     }
     if (op == "bench_me")
     {   /* many PUs of one size through the reference's motionEstimate, timed inside the process (no IPC in the
-           timed region).  ints = w,h,stride,merange,method,subme,qp,n, then n x (off, mvmin.x,mvmin.y,mvmax.x,mvmax.y,
+           timed region).  ints = w,h,stride,merange,method,subme,qp,n,reps, then n x (off, mvmin.x,mvmin.y,mvmax.x,mvmax.y,
            qmvp.x,qmvp.y); bufs = cur plane, ref plane.  returns elapsed ns, n x (mvx, mvy, cost). */
         int w = (int)I[0], h = (int)I[1]; intptr_t stride = I[2];
-        int merange = (int)I[3], method = (int)I[4], subme = (int)I[5], qp = (int)I[6], n = (int)I[7];
+        int merange = (int)I[3], method = (int)I[4], subme = (int)I[5], qp = (int)I[6], n = (int)I[7], reps = (int)I[8];
         std::vector<int32_t> res(3 * (size_t)n);
         g_me->setQP((unsigned)qp);
         ReferencePlanes rp; rp.lumaStride = stride; rp.isLowres = false; rp.isHMELowres = false;
         rp.fpelPlane[0] = PX(B[1], 0);
         auto t0 = std::chrono::steady_clock::now();
+        for (int rep = 0; rep < reps; rep++)
         for (int i = 0; i < n; i++)
         {
-            const int64_t* a = &I[8 + 7 * (size_t)i];
+            const int64_t* a = &I[9 + 7 * (size_t)i];
             g_me->setSourcePU(PX(B[0], 0), stride, a[0], w, h, method, subme);
             MV mvmin((int)a[1], (int)a[2]), mvmax((int)a[3], (int)a[4]), qmvp((int)a[5], (int)a[6]), outmv;
             int cost = g_me->motionEstimate(&rp, mvmin, mvmax, qmvp, 0, NULL, merange, outmv, 1, false);
@@ -377,10 +378,10 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
     if (op == "bench_tq")
     {   /* many inter TUs through the reference's primitives in the order of predict.cpp:279-300 and
            quant.cpp:397-480 (rdoq off, flat lists): copy_pp|luma_hpp|luma_vpp|luma_hvpp -> sub_ps -> dct -> quant.
-           ints = log2n, stride, qp, addNumerator, n, then n x (off, mvx, mvy); bufs = cur, ref.
+           ints = log2n, stride, qp, addNumerator, n, reps, then n x (off, mvx, mvy); bufs = cur, ref.
            returns elapsed ns, numSig[n], coefficient checksum (sum of coef * (index+1) mod 2^32). */
         static const int qs[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };
-        int lg = (int)I[0], N = 1 << lg; intptr_t stride = I[1]; int qp = (int)I[2], addNum = (int)I[3], n = (int)I[4];
+        int lg = (int)I[0], N = 1 << lg; intptr_t stride = I[1]; int qp = (int)I[2], addNum = (int)I[3], n = (int)I[4], reps = (int)I[5];
         int pu = puIndex(N, N), cu = cuIndex(N);
         pixel* pred = (pixel*)aligned_alloc(64, 32 * 32 * sizeof(pixel));
         int16_t* resi = (int16_t*)aligned_alloc(64, 2048); int16_t* dctc = (int16_t*)aligned_alloc(64, 2048);
@@ -390,9 +391,10 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         const int tshift = 15 - X265_DEPTH - lg, qbits = 14 + qp / 6 + tshift, add = addNum << (qbits - 9);
         std::vector<uint32_t> ns(n); uint32_t csum = 0;
         auto t0 = std::chrono::steady_clock::now();
+        for (int rep = 0; rep < reps; rep++)
         for (int i = 0; i < n; i++)
         {
-            const int64_t* a = &I[5 + 3 * (size_t)i];
+            const int64_t* a = &I[6 + 3 * (size_t)i];
             const pixel* cur = PX(B[0], a[0]);
             int mvx = (int)a[1], mvy = (int)a[2];
             const pixel* src = PX(B[1], a[0]) + (mvx >> 2) + (mvy >> 2) * stride;
@@ -404,7 +406,7 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
             T.cu[cu].sub_ps(resi, N, cur, pred, stride, N);
             T.cu[cu].dct(resi, dctc, N);
             ns[i] = T.quant(dctc, qc, du, q, qbits, add, N * N);
-            for (int k = 0; k < N * N; k++) csum += (uint32_t)(int32_t)q[k] * (uint32_t)(k + 1);
+            if (rep == 0) for (int k = 0; k < N * N; k++) csum += (uint32_t)(int32_t)q[k] * (uint32_t)(k + 1);
         }
         auto t1 = std::chrono::steady_clock::now();
         free(pred); free(resi); free(dctc); free(q); free(du); free(qc);

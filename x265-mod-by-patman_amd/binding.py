@@ -54,6 +54,12 @@ def _pin_hip_runtime():
         return
     _runtime_pinned = True
     try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return                      # some copy is already mapped: never map a second one
+    except OSError:
+        pass
+    try:
         import torch
         cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
         if os.path.exists(cand):

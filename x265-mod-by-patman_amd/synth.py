@@ -1,8 +1,8 @@
 """Deterministic synthetic frames for parity tests and bench.py (SURVEY 8d / BASELINE.md section 4).
 
 cur = low-pass filtered noise texture scaled to the full pixel range (+ small noise);
-ref = cur displaced by a known global full-pel motion (dx, dy) plus independent small noise, so a
-motion search has something real to find.  Planes are returned PADDED (edge replicated, like the
+ref = cur displaced by a known global full-pel motion plus independent small noise, so a motion search has
+something real to find: the block at (x, y) of cur sits at (x + dx, y + dy) in ref, i.e. the true MV is (dx, dy).  Planes are returned PADDED (edge replicated, like the
 reference's extendPicBorder, pixel.cpp:1044-1058) with `margin` pixels on every side.
 """
 import numpy as np
@@ -20,15 +20,22 @@ def frame_pair(width, height, depth, seed, margin=96, max_shift=24, noise=2.0):
     pm = (1 << depth) - 1
     dt = np.uint8 if depth == 8 else np.uint16
     ext = max_shift + 8
-    big = rng.random((height + 2 * ext, width + 2 * ext))
-    big = _box3(_box3(big))
+    bh, bw = height + 2 * ext, width + 2 * ext
+    # multi-octave value noise: structure at 64/32/16/8-pixel scales (so every PU size has gradients and the SAD
+    # surface has a basin around the true motion) plus a little fine texture
+    big = np.zeros((bh, bw))
+    for cell, amp in ((64, 0.40), (32, 0.25), (16, 0.18), (8, 0.12)):
+        g = rng.random((bh // cell + 3, bw // cell + 3))
+        up = np.kron(g, np.ones((cell, cell)))
+        for _ in range(2):                      # two box passes of the cell size ~ quadratic B-spline smoothing
+            c = np.cumsum(np.cumsum(np.pad(up, ((cell, 0), (cell, 0))), 0), 1)
+            up = (c[cell:, cell:] - c[:-cell, cell:] - c[cell:, :-cell] + c[:-cell, :-cell]) / (cell * cell)
+        big += amp * up[cell:cell + bh, cell:cell + bw]
+    big += 0.05 * _box3(rng.random((bh, bw)))
     big = (big - big.min()) / (big.max() - big.min() + 1e-12)
-    # add coarse structure so large PUs have gradients too
-    yy, xx = np.mgrid[0:big.shape[0], 0:big.shape[1]]
-    big = 0.75 * big + 0.25 * (0.5 + 0.5 * np.sin(xx / 37.0 + seed) * np.cos(yy / 53.0))
     dx, dy = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
     cur = big[ext:ext + height, ext:ext + width]
-    ref = big[ext + dy:ext + dy + height, ext + dx:ext + dx + width]   # ref(x, y) = cur(x + dx, y + dy)
+    ref = big[ext - dy:ext - dy + height, ext - dx:ext - dx + width]   # ref(x + dx, y + dy) = cur(x, y): true MV = (dx, dy)
     scale = pm * (1 << 0)
     cur = np.clip(cur * scale + rng.normal(0, noise * (1 << (depth - 8)), cur.shape), 0, pm).astype(dt)
     ref = np.clip(ref * scale + rng.normal(0, noise * (1 << (depth - 8)), ref.shape), 0, pm).astype(dt)
