@@ -37,7 +37,7 @@ __device__ __forceinline__ int mvcost(const Ctx& c, int qx, int qy)
 
 // ---- integer-pel SAD of up to 4 candidates listed in LDS; costs (SAD + mvcost) go back to the list ----
 // cl layout: [0..15] x, [16..31] y, [32..47] cost
-__device__ void eval_list(const Ctx& c, int n)
+template<int G> __device__ void eval_list(const Ctx& c, int n)
 {
     wave_sync();
     for (int base = 0; base < n; base += 4)
@@ -59,7 +59,7 @@ __device__ void eval_list(const Ctx& c, int n)
             if (k > 2) p2 = sad4(f, r + off[2], p2);
             if (k > 3) p3 = sad4(f, r + off[3], p3);
         QUAD_END
-        int s0 = wsum_u((int)p0), s1 = k > 1 ? wsum_u((int)p1) : 0, s2 = k > 2 ? wsum_u((int)p2) : 0, s3 = k > 3 ? wsum_u((int)p3) : 0;
+        int s0 = group_sum<G>((int)p0), s1 = k > 1 ? group_sum<G>((int)p1) : 0, s2 = k > 2 ? group_sum<G>((int)p2) : 0, s3 = k > 3 ? group_sum<G>((int)p3) : 0;
         if (c.lane == 0)
         {
             c.cl[32 + base] = s0 + mvcost(c, c.cl[base] * 4, c.cl[16 + base] * 4);
@@ -74,16 +74,16 @@ __device__ __forceinline__ void put(const Ctx& c, int i, int x, int y)
 {
     c.cl[i] = x; c.cl[16 + i] = y;     // every lane stores the same (wave-uniform) value
 }
-__device__ __forceinline__ int costOf(const Ctx& c, int i) { return uni(c.cl[32 + i]); }
+__device__ __forceinline__ int costOf(const Ctx& c, int i) { return c.cl[32 + i]; }
 
-__device__ int sad_fpel(const Ctx& c, int mx, int my)      // plain SAD (no mv cost)
+template<int G> __device__ int sad_fpel(const Ctx& c, int mx, int my)      // plain SAD (no mv cost)
 {
     unsigned p = 0;
     const intptr_t off = (intptr_t)my * c.rs + mx;
     QUAD_LOOP(c, q, y, x4)
         p = sad4(c.fenc + y * c.w + x4, c.fref + off + (intptr_t)y * c.rs + x4, p);
     QUAD_END
-    return wsum_u((int)p);
+    return group_sum<G>((int)p);
 }
 
 __device__ __forceinline__ void had4(int& a, int& b, int& cc, int& d)
@@ -112,7 +112,7 @@ __device__ __forceinline__ int had4x4_lds(const lpixel* f, const lpixel* p, int 
     return s;
 }
 // SAD or SATD between the cached source PU and the candidate block in LDS (SATD rounding per pixel.cpp:1148-1172)
-__device__ int cmp_pred(const Ctx& c, bool satd)
+template<int G> __device__ int cmp_pred(const Ctx& c, bool satd)
 {
     int s = 0;
     if (!satd)
@@ -132,7 +132,7 @@ __device__ int cmp_pred(const Ctx& c, bool satd)
     {
         const bool use4 = (c.w == 4) || (c.w == 12);
         const int uw = use4 ? 4 : 8, ux = c.w / uw, nunits = ux * (c.h >> 2);
-        for (int u = c.lane; u < nunits; u += 64)
+        for (int u = c.lane; u < nunits; u += G)
         {
             int uy = u / ux, x0 = (u - uy * ux) * uw, y0 = uy * 4;
             const lpixel* f = c.fenc + y0 * c.w + x0; const lpixel* p = c.pred + y0 * c.w + x0;
@@ -141,36 +141,36 @@ __device__ int cmp_pred(const Ctx& c, bool satd)
             s += v >> 1;
         }
     }
-    return wsum_u(s);
+    return group_sum<G>(s);
 }
 // motion.cpp:1775-1803 subpelCompare (luma)
-__device__ int subpel_cost(const Ctx& c, int qx, int qy, bool satd)
+template<int G> __device__ int subpel_cost(const Ctx& c, int qx, int qy, bool satd)
 {
-    if (!satd && !((qx | qy) & 3)) return sad_fpel(c, qx >> 2, qy >> 2);
+    if (!satd && !((qx | qy) & 3)) return sad_fpel<G>(c, qx >> 2, qy >> 2);
     build_pred(c, qx, qy);
-    return cmp_pred(c, satd);
+    return cmp_pred<G>(c, satd);
 }
 
 struct Star { int bx, by, bcost, bPointNr, bDistance; };
 
 // Evaluate the listed points in order with strict-< updates (COST_MV_PT_DIST semantics); pt/dist packed in cl[48..63]
-__device__ void star_apply(const Ctx& c, Star& s, int n)
+template<int G> __device__ void star_apply(const Ctx& c, Star& s, int n)
 {
-    eval_list(c, n);
+    eval_list<G>(c, n);
     for (int i = 0; i < n; i++)
     {
         int cost = costOf(c, i);
         if (cost < s.bcost)
         {
-            s.bcost = cost; s.bx = uni(c.cl[i]); s.by = uni(c.cl[16 + i]);
-            int pd = uni(c.cl[48 + i]); s.bPointNr = pd & 0xFF; s.bDistance = pd >> 8;
+            s.bcost = cost; s.bx = c.cl[i]; s.by = c.cl[16 + i];
+            int pd = c.cl[48 + i]; s.bPointNr = pd & 0xFF; s.bDistance = pd >> 8;
         }
     }
 }
 #define SPUT(i, X, Y, P, D) do { c.cl[i] = (X); c.cl[16 + (i)] = (Y); c.cl[48 + (i)] = (P) | ((D) << 8); } while (0)
 
 // motion.cpp:387-629 StarPatternSearch
-__device__ void star_pattern(const Ctx& c, int mnx, int mny, int mxx, int mxy, Star& s, int earlyExitIters, int merange)
+template<int G> __device__ void star_pattern(const Ctx& c, int mnx, int mny, int mxx, int mxy, Star& s, int earlyExitIters, int merange)
 {
     const int ox = s.bx, oy = s.by;
     int saved = s.bcost, rounds = 0;
@@ -181,7 +181,7 @@ __device__ void star_pattern(const Ctx& c, int mnx, int mny, int mxx, int mxy, S
         if (left >= mnx) { SPUT(n, left, oy, 4, dist); n++; }
         if (right <= mxx) { SPUT(n, right, oy, 5, dist); n++; }
         if (bottom <= mxy) { SPUT(n, ox, bottom, 7, dist); n++; }
-        star_apply(c, s, n);
+        star_apply<G>(c, s, n);
         if (s.bcost < saved) rounds = 0;
         else if (++rounds >= earlyExitIters) return;
     }
@@ -205,7 +205,7 @@ __device__ void star_pattern(const Ctx& c, int mnx, int mny, int mxx, int mxy, S
             if (right2 <= mxx) { SPUT(n, right2, bottom2, 8, dist >> 1); n++; }
         }
         if (bottom <= mxy) { SPUT(n, ox, bottom, 7, dist); n++; }
-        star_apply(c, s, n);
+        star_apply<G>(c, s, n);
         if (s.bcost < saved) rounds = 0;
         else if (++rounds >= earlyExitIters) return;
     }
@@ -233,13 +233,13 @@ __device__ void star_pattern(const Ctx& c, int mnx, int mny, int mxx, int mxy, S
                 if (posXR <= mxx) { SPUT(n, posXR, posYB, 0, dist); n++; }
             }
         }
-        star_apply(c, s, n);
+        star_apply<G>(c, s, n);
         if (s.bcost < saved) rounds = 0;
         else if (++rounds >= earlyExitIters) return;
     }
 }
 
-template<int MAXPIX, int MAXW, int WAVES>
+template<int G, int MAXPIX, int MAXW, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixel* __restrict__ cur, intptr_t cs,
                                                         const pixel* __restrict__ ref, intptr_t rs,
                                                         const x265hip_me_task* __restrict__ tasks, int n,
@@ -247,19 +247,20 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                                                         int merange, int method, int subme, x265hip_me_result* __restrict__ results,
                                                         const x265hip_me_result* __restrict__ mvpSource, int dbg)
 {
-    __shared__ __attribute__((aligned(16))) pixel s_fenc[WAVES][MAXPIX];
-    __shared__ __attribute__((aligned(16))) pixel s_pred[WAVES][MAXPIX];
-    __shared__ __attribute__((aligned(16))) int16_t s_immed[WAVES][MAXPIX + 7 * MAXW];
-    __shared__ int s_cl[WAVES][64];
+    constexpr int GROUPS = WAVES * (64 / G);          // PUs per workgroup: 64/G lane groups per wavefront
+    __shared__ __attribute__((aligned(16))) pixel s_fenc[GROUPS][MAXPIX];
+    __shared__ __attribute__((aligned(16))) pixel s_pred[GROUPS][MAXPIX];
+    __shared__ __attribute__((aligned(16))) int16_t s_immed[GROUPS][MAXPIX + 7 * MAXW];
+    __shared__ int s_cl[GROUPS][64];
 
-    const int wave = threadIdx.x >> 6;
-    const int item = blockIdx.x * WAVES + wave;
-    if (item >= n) return;            // wave-granular exit; no block barriers are used
+    const int wave = threadIdx.x / G;                 // index of this lane group inside the workgroup
+    const int item = blockIdx.x * GROUPS + wave;
+    if (item >= n) return;            // group-granular exit; no block barriers are used
     x265hip_me_task tk = tasks[item];
     if (tk.mvpFrom >= 0 && mvpSource) { tk.qmvp[0] = mvpSource[tk.mvpFrom].mv[0]; tk.qmvp[1] = mvpSource[tk.mvpFrom].mv[1]; }
 
     Ctx c;
-    c.lane = threadIdx.x & 63; c.w = w; c.h = h; c.qpr = w >> 2; c.nquads = c.qpr * h; c.qdivm = ((1 << 20) / c.qpr) + 1;
+    c.setGeometry(w, h, threadIdx.x & (G - 1), G);
     c.fenc = (lpixel*)s_fenc[wave]; c.pred = (lpixel*)s_pred[wave]; c.immed = (lshort*)s_immed[wave]; c.cl = (lint*)s_cl[wave];
     c.dbg = dbg; c.fref = ref + tk.refOff; c.rs = rs; c.cost = costCentre; c.mvpx = tk.qmvp[0]; c.mvpy = tk.qmvp[1];
 
@@ -275,12 +276,12 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
     if (dbg == 7)
     {   // debug: dump the interpolated block at the predictor position
         build_pred(c, tk.qmvp[0], tk.qmvp[1]);
-        for (int i = c.lane; i < w * h; i += 64) ((pixel*)results)[i] = c.pred[i];
+        for (int i = c.lane; i < w * h; i += G) ((pixel*)results)[i] = c.pred[i];
         return;
     }
     if (dbg == 5 || dbg == 6)
     {   // debug: raw sub-pel cost of the predictor position (SATD for 5, SAD for 6)
-        int v = subpel_cost(c, tk.qmvp[0], tk.qmvp[1], dbg == 5);
+        int v = subpel_cost<G>(c, tk.qmvp[0], tk.qmvp[1], dbg == 5);
         if (c.lane == 0) { x265hip_me_result r; r.mv[0] = tk.qmvp[0]; r.mv[1] = tk.qmvp[1]; r.cost = v; r.mvcost = 0; r.reserved = 0; results[item] = r; }
         return;
     }
@@ -297,13 +298,13 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
     // ---- start point, motion.cpp:955-1012 ----
     int pmx = min(max((int)tk.qmvp[0], qmnx), qmxx), pmy = min(max((int)tk.qmvp[1], qmny), qmxy);
     int bestprex = pmx, bestprey = pmy;
-    int bprecost = subpel_cost(c, pmx, pmy, false);
+    int bprecost = subpel_cost<G>(c, pmx, pmy, false);
     int bx = (pmx + 2) >> 2, by = (pmy + 2) >> 2;
     int bcost = bprecost;
-    if ((pmx | pmy) & 3) bcost = sad_fpel(c, bx, by) + mvcost(c, bx * 4, by * 4);
+    if ((pmx | pmy) & 3) bcost = sad_fpel<G>(c, bx, by) + mvcost(c, bx * 4, by * 4);
     if (pmx | pmy)
     {
-        int cost = sad_fpel(c, 0, 0) + mvcost(c, 0, 0);
+        int cost = sad_fpel<G>(c, 0, 0) + mvcost(c, 0, 0);
         if (cost < bcost) { bcost = cost; bx = 0; by = max(min(0, mxy), mny); }
     }
     for (int i = 0; i < tk.numCand; i++)
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
         int mx = min(max((int)tk.mvc[2 * i], qmnx), qmxx), my = min(max((int)tk.mvc[2 * i + 1], qmny), qmxy);
         if ((mx | my) && !(mx == pmx && my == pmy) && !(mx == bestprex && my == bestprey))
         {
-            int cost = subpel_cost(c, mx, my, false) + mvcost(c, mx, my);
+            int cost = subpel_cost<G>(c, mx, my, false) + mvcost(c, mx, my);
             if (cost < bprecost) { bprecost = cost; bestprex = mx; bestprey = my; }
         }
     }
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
             do
             {
                 put(c, 0, bx, by - 1); put(c, 1, bx, by + 1); put(c, 2, bx - 1, by); put(c, 3, bx + 1, by);
-                eval_list(c, 4);
+                eval_list<G>(c, 4);
                 if ((by - 1 >= mny) & (by - 1 <= mxy)) bc = min(bc, (costOf(c, 0) << 4) + 1);
                 if ((by + 1 >= mny) & (by + 1 <= mxy)) bc = min(bc, (costOf(c, 1) << 4) + 3);
                 bc = min(bc, (costOf(c, 2) << 4) + 4);
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
         {   // motion.cpp:1041-1140
             put(c, 0, bx - 2, by); put(c, 1, bx - 1, by + 2); put(c, 2, bx + 1, by + 2);
             put(c, 3, bx + 2, by); put(c, 4, bx + 1, by - 2); put(c, 5, bx - 1, by - 2);
-            eval_list(c, 6);
+            eval_list<G>(c, 6);
             bcost <<= 3;
             if ((by >= mny) & (by <= mxy)) bcost = min(bcost, (costOf(c, 0) << 3) + 2);
             if ((by + 2 >= mny) & (by + 2 <= mxy)) { bcost = min(bcost, (costOf(c, 1) << 3) + 3); bcost = min(bcost, (costOf(c, 2) << 3) + 4); }
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                         put(c, 0, bx + k_hex2[dir][0], by + k_hex2[dir][1]);
                         put(c, 1, bx + k_hex2[dir + 1][0], by + k_hex2[dir + 1][1]);
                         put(c, 2, bx + k_hex2[dir + 2][0], by + k_hex2[dir + 2][1]);
-                        eval_list(c, 3);
+                        eval_list<G>(c, 3);
                         bcost &= ~7;
                         if ((by + k_hex2[dir][1] >= mny) & (by + k_hex2[dir][1] <= mxy)) bcost = min(bcost, (costOf(c, 0) << 3) + 1);
                         if ((by + k_hex2[dir + 1][1] >= mny) & (by + k_hex2[dir + 1][1] <= mxy)) bcost = min(bcost, (costOf(c, 1) << 3) + 2);
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
             // square refine
             put(c, 0, bx, by - 1); put(c, 1, bx, by + 1); put(c, 2, bx - 1, by); put(c, 3, bx + 1, by);
             put(c, 4, bx - 1, by - 1); put(c, 5, bx - 1, by + 1); put(c, 6, bx + 1, by - 1); put(c, 7, bx + 1, by + 1);
-            eval_list(c, 8);
+            eval_list<G>(c, 8);
             const bool upOk = (by - 1 >= mny) & (by - 1 <= mxy), dnOk = (by + 1 >= mny) & (by + 1 <= mxy);
             int dir = 0, cc;
             if (upOk && (cc = costOf(c, 0)) < bcost) { bcost = cc; dir = 1; }
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
         else if (method == X265HIP_ME_STAR)
         {   // motion.cpp:1328-1436
             Star s = { bx, by, bcost, 0, 0 };
-            star_pattern(c, mnx, mny, mxx, mxy, s, 3, merange);
+            star_pattern<G>(c, mnx, mny, mxx, mxy, s, 3, merange);
             bool done = false;
             if (s.bDistance == 1)
             {
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                     const int x2 = s.bx + k_offsets[(s.bPointNr - 1) * 2 + 1][0], y2 = s.by + k_offsets[(s.bPointNr - 1) * 2 + 1][1];
                     if (x1 >= mnx && x1 <= mxx && y1 >= mny && y1 <= mxy) { SPUT(n, x1, y1, s.bPointNr, s.bDistance); n++; }
                     if (x2 >= mnx && x2 <= mxx && y2 >= mny && y2 <= mxy) { SPUT(n, x2, y2, s.bPointNr, s.bDistance); n++; }
-                    star_apply(c, s, n);      // COST_MV keeps bPointNr/bDistance: the packed values re-store the current ones
+                    star_apply<G>(c, s, n);      // COST_MV keeps bPointNr/bDistance: the packed values re-store the current ones
                     if (s.bcost == saved) done = true;
                 }
                 else done = true;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                             if (tx + RasterDistance * 3 <= mxx)
                             {
                                 put(c, 0, tx, ty); put(c, 1, tx + 5, ty); put(c, 2, tx + 10, ty); put(c, 3, tx + 15, ty);
-                                eval_list(c, 4);
+                                eval_list<G>(c, 4);
                                 for (int k = 0; k < 4; k++)
                                 {
                                     int cost = costOf(c, k);
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                             else
                             {
                                 put(c, 0, tx, ty);
-                                eval_list(c, 1);
+                                eval_list<G>(c, 1);
                                 int cost = costOf(c, 0);
                                 if (cost < s.bcost) { s.bcost = cost; s.bx = tx; s.by = ty; }
                             }
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                 while (bDistance > 0)
                 {
                     s.bPointNr = 0; s.bDistance = 0;
-                    star_pattern(c, mnx, mny, mxx, mxy, s, 32, merange);
+                    star_pattern<G>(c, mnx, mny, mxx, mxy, s, 32, merange);
                     bDistance = s.bDistance;
                     if (bDistance == 1)
                     {
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                         const int x2 = s.bx + k_offsets[(s.bPointNr - 1) * 2 + 1][0], y2 = s.by + k_offsets[(s.bPointNr - 1) * 2 + 1][1];
                         if (x1 >= mnx && x1 <= mxx && y1 >= mny && y1 <= mxy) { SPUT(n, x1, y1, 0, 0); n++; }
                         if (x2 >= mnx && x2 <= mxx && y2 >= mny && y2 <= mxy) { SPUT(n, x2, y2, 0, 0); n++; }
-                        star_apply(c, s, n);
+                        star_apply<G>(c, s, n);
                         break;
                     }
                 }
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
         {
             const int hpelIters = k_workload[subme][0], hpelDirs = k_workload[subme][1], qpelIters = k_workload[subme][2], qpelDirs = k_workload[subme][3];
             const bool hpelSatd = k_workload[subme][4] != 0;
-            if (hpelSatd) bcost = subpel_cost(c, qx, qy, true) + mvcost(c, qx, qy);
+            if (hpelSatd) bcost = subpel_cost<G>(c, qx, qy, true) + mvcost(c, qx, qy);
             for (int iter = 0; iter < hpelIters; iter++)
             {
                 int bdir = 0;
@@ -485,13 +486,13 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                 {
                     const int tx = qx + k_square1[i][0] * 2, ty = qy + k_square1[i][1] * 2;
                     if ((ty < qmny) | (ty > qmxy)) continue;
-                    int cost = subpel_cost(c, tx, ty, hpelSatd) + mvcost(c, tx, ty);
+                    int cost = subpel_cost<G>(c, tx, ty, hpelSatd) + mvcost(c, tx, ty);
                     if (cost < bcost) { bcost = cost; bdir = i; }
                 }
                 if (bdir) { qx += k_square1[bdir][0] * 2; qy += k_square1[bdir][1] * 2; }
                 else break;
             }
-            if (!hpelSatd) bcost = subpel_cost(c, qx, qy, true) + mvcost(c, qx, qy);
+            if (!hpelSatd) bcost = subpel_cost<G>(c, qx, qy, true) + mvcost(c, qx, qy);
             for (int iter = 0; iter < qpelIters; iter++)
             {
                 int bdir = 0;
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
                 {
                     const int tx = qx + k_square1[i][0], ty = qy + k_square1[i][1];
                     if ((ty < qmny) | (ty > qmxy)) continue;
-                    int cost = subpel_cost(c, tx, ty, true) + mvcost(c, tx, ty);
+                    int cost = subpel_cost<G>(c, tx, ty, true) + mvcost(c, tx, ty);
                     if (cost < bcost) { bcost = cost; bdir = i; }
                 }
                 if (bdir) { qx += k_square1[bdir][0]; qy += k_square1[bdir][1]; }
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
         }
         if (qx | qy)
         {
-            int cost = subpel_cost(c, 0, 0, true) + mvcost(c, 0, 0);
+            int cost = subpel_cost<G>(c, 0, 0, true) + mvcost(c, 0, 0);
             if (cost <= bcost) { qx = 0; qy = 0; }
         }
         outx = qx; outy = qy; outcost = bcost;
@@ -521,11 +522,12 @@ __global__ __launch_bounds__(64 * WAVES) void me_kernel(int w, int h, const pixe
     }
 }
 
-template<int MAXPIX, int MAXW, int WAVES>
+template<int G, int MAXPIX, int MAXW, int WAVES>
 int launch_me(hipStream_t st, int w, int h, const pixel* cur, intptr_t cs, const pixel* ref, intptr_t rs, const x265hip_me_task* tasks, int n,
               const uint16_t* costCentre, int merange, int method, int subme, x265hip_me_result* results, const x265hip_me_result* mvpSource)
 {
-    hipLaunchKernelGGL((me_kernel<MAXPIX, MAXW, WAVES>), dim3((n + WAVES - 1) / WAVES), dim3(64 * WAVES), 0, st,
+    constexpr int GROUPS = WAVES * (64 / G);
+    hipLaunchKernelGGL((me_kernel<G, MAXPIX, MAXW, WAVES>), dim3((n + GROUPS - 1) / GROUPS), dim3(64 * WAVES), 0, st,
                        w, h, cur, cs, ref, rs, tasks, n, costCentre, merange, method, subme, results, mvpSource, getenv("X265HIP_ME_DBG") ? atoi(getenv("X265HIP_ME_DBG")) : 0);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -547,8 +549,11 @@ extern "C" int x265hip_me_batch(void* stream, int w, int h, const void* curPlane
     const pixel* cur = (const pixel*)curPlane; const pixel* ref = (const pixel*)refPlane;
     const uint16_t* centre = costRow + costHalfRange;
     const int area = w * h;
-    if (area <= 64 && w <= 16) return launch_me<64, 16, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
-    if (area <= 256 && w <= 32) return launch_me<256, 32, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
-    if (area <= 1024) return launch_me<1024, 64, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
-    return launch_me<4096, 64, 2>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
+    const int nquads = area / 4;
+    if (nquads <= 8) return launch_me<8, 32, 8, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);   // 8x4, 4x8
+    if (area <= 64 && w <= 16) return launch_me<16, 64, 16, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);   // 8x8, 16x4, 4x16
+    if (nquads <= 32 && w <= 16) return launch_me<32, 128, 16, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);   // 16x8, 8x16
+    if (area <= 256 && w <= 32) return launch_me<64, 256, 32, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
+    if (area <= 1024) return launch_me<64, 1024, 64, 4>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
+    return launch_me<64, 4096, 64, 2>(st, w, h, cur, curStride, ref, refStride, tasks, n, centre, merange, method, subpelRefine, results, mvpSource);
 }

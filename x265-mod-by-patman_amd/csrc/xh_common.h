@@ -49,18 +49,28 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// full-wave (64 lane) integer sum; result valid in every lane
-__device__ __forceinline__ int wave_sum(int v)
+// Full-wave (64 lane) integer sum, result valid in every lane.  Four DPP steps (quad_perm x2, row_half_mirror,
+// row_mirror: VALU-rate cross-lane moves inside each 16-lane row) leave the row sum in every lane of the row; the
+// four row sums are then combined through v_readlane (SGPRs).  The ds_bpermute butterfly (__shfl_xor) it replaces
+// costs a dependent LDS-crossbar round trip per step and dominated the first ME kernel.
+__device__ __forceinline__ int row_sum16(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);    // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);    // row_mirror
     return v;
 }
-__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
+__device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = row_sum16(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
+{   // callers' partial sums are < 2^26 * 64 lanes: reduce as 16-bit-safe halves
+    unsigned lo = (unsigned)(v & 0xFFFFFFu), mid = (unsigned)((v >> 24) & 0xFFFFFFu), hi = (unsigned)(v >> 48);
+    return (unsigned long long)(unsigned)wave_sum((int)lo) + ((unsigned long long)(unsigned)wave_sum((int)mid) << 24) +
+           ((unsigned long long)(unsigned)wave_sum((int)hi) << 48);
 }
 
 // HEVC core-transform coefficient by angle index (the numbers of constants.cpp:270-344)

@@ -26,13 +26,27 @@ struct McCtx
 {
     const pixel* fref; intptr_t rs;      // co-located block origin in the reference plane
     lpixel* pred; lshort* immed;         // per-wave LDS: candidate / predicted block (stride w), 14-bit hv intermediate
-    int w, h, lane, qpr, nquads, qdivm;
-    __device__ __forceinline__ void setGeometry(int w_, int h_, int lane_)
-    { w = w_; h = h_; lane = lane_; qpr = w_ >> 2; nquads = qpr * h_; qdivm = ((1 << 20) / qpr) + 1; }
+    int w, h, lane, gsize, qpr, nquads, qdivm;   // lane = index inside the lane GROUP that owns this block; gsize = lanes per group
+    __device__ __forceinline__ void setGeometry(int w_, int h_, int lane_, int gsize_ = 64)
+    { w = w_; h = h_; lane = lane_; gsize = gsize_; qpr = w_ >> 2; nquads = qpr * h_; qdivm = ((1 << 20) / qpr) + 1; }
 };
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int wsum_u(int v) { return uni(wave_sum(v)); }
+
+// Sum over an aligned group of G lanes (G = 8, 16, 32 or 64); every lane of the group gets the group's sum.
+// Small PUs are packed 64/G per wavefront: each group runs its own search (its lanes hold identical control
+// state and therefore take identical branches), only these reductions and the LDS exchanges are cooperative.
+template<int G> __device__ __forceinline__ int group_sum(int v)
+{
+    if (G == 64) return wsum_u(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);    // row_half_mirror: 8 lanes
+    if (G >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);   // row_mirror: 16 lanes
+    if (G == 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
 
 // ---- 4-pixel helpers -------------------------------------------------------------------------
 __device__ __forceinline__ void load4(const lpixel* p, int* v)      // p aligned to 4 pixels (LDS)
@@ -94,7 +108,7 @@ __device__ __forceinline__ void load11u(const pixel* p, int* v)
 #endif
 }
 
-#define QUAD_LOOP(c, q, y, x4) for (int q = (c).lane; q < (c).nquads; q += 64) { const int y = (q * (c).qdivm) >> 20; const int x4 = (q - y * (c).qpr) * 4;
+#define QUAD_LOOP(c, q, y, x4) for (int q = (c).lane; q < (c).nquads; q += (c).gsize) { const int y = (q * (c).qdivm) >> 20; const int x4 = (q - y * (c).qpr) * 4;
 #define QUAD_END }
 
 // ---- sub-pel candidate: build the interpolated block in LDS (motion.cpp:1797-1801 dispatch) ----
@@ -154,7 +168,7 @@ template<class C> __device__ void build_pred(const C& c, int qx, int qy)
         for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[xf][i];
         const int shift1 = XH_IF_FILTER_PREC - headRoom, offset1 = (int)((unsigned)-XH_IF_INTERNAL_OFFS << shift1);
         const int rows = c.h + 7, nq = c.qpr * rows;
-        for (int q = c.lane; q < nq; q += 64)
+        for (int q = c.lane; q < nq; q += c.gsize)
         {
             const int y = (q * c.qdivm) >> 20, x4 = (q - y * c.qpr) * 4;
             int px[11];
