@@ -190,6 +190,7 @@ def main():
     from x265hip_pkg.frame import FrameApi, mvcost_row
     from x265hip_pkg.pipeline import FramePipeline, LEVELS
     from x265hip_pkg.synth import frame_pair
+    from x265hip_pkg.sharding import rank_frame_seeds, max_over_ranks, whole_job_mpixels_per_s
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -209,8 +210,8 @@ def main():
     pipe = FramePipeline(depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"],
                          tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api)
     pairs = []
-    for f in range(args.frames):
-        cur, ref, stride, _ = frame_pair(W, H, depth, seed=rank * args.frames + f, margin=pipe.margin, max_shift=24)
+    for seed in rank_frame_seeds(rank, args.frames):          # independent frames per rank, no overlap
+        cur, ref, stride, _ = frame_pair(W, H, depth, seed=seed, margin=pipe.margin, max_shift=24)
         pairs.append((cur, ref))
     pipe.upload(pairs)                      # inputs are resident in HBM before the timed region
 
@@ -236,10 +237,7 @@ def main():
         ev[len(names)].record()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda")
 
     if rank == 0:
         kms = {n: float(np.mean([events[k][i].elapsed_time(events[k][i + 1]) for k in range(args.steps)])) for i, n in enumerate(names)}
@@ -260,7 +258,7 @@ def main():
                 traffic = json.load(open(tpath)).get(dom)
             except Exception:
                 traffic = None
-        value = world * px * args.steps / dt / 1e6
+        value = whole_job_mpixels_per_s(world, px, args.steps, dt)
         out = {
             "metric": "Mpixels/s ME+DCT+quant on CTU batches (luma source pixels through ME pyramid + MC/DCT/quant)",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

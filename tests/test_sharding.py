@@ -1,0 +1,66 @@
+"""N>1 path on CPU: world_size-2 gloo.  Ranks own disjoint frames, generate different deterministic pictures,
+need no data exchange, and the bench bookkeeping (barrier, MAX-over-ranks time, whole-job aggregate) is consistent."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import x265hip  # noqa: F401
+from x265hip_pkg.sharding import rank_frame_seeds, max_over_ranks, whole_job_mpixels_per_s
+from x265hip_pkg.synth import frame_pair
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, frames, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from oracle_py import Oracle
+    seeds = rank_frame_seeds(rank, frames)
+    ora = Oracle(8)
+    row = ora.mvcost_row(28, 4096)
+    sums = []
+    for s in seeds:                                    # each rank's own frames through the (CPU) oracle: no peer data needed
+        cur, ref, stride, (dx, dy) = frame_pair(64, 64, 8, s, margin=40, max_shift=6)
+        off = 40 * stride + 40
+        mv = ora.me(64, 64, cur.reshape(-1), stride, off, ref.reshape(-1), stride, off, [-16, -16, 16, 16], (0, 0), [], 16, 1, 2, row)
+        sums.append((s, int(cur.sum()), mv[0], mv[1], 4 * dx, 4 * dy))
+    dist.barrier()
+    dt = max_over_ranks(0.5 + 0.25 * rank, dist)       # slowest rank defines the job time
+    gathered = [None] * world
+    dist.all_gather_object(gathered, sums)             # test-only: collect for the assertions (not a data-path collective)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "res.npy"), np.array([dt, whole_job_mpixels_per_s(world, 64 * 64 * frames, 3, dt)]))
+        import json
+        json.dump(gathered, open(os.path.join(out_dir, "g.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding(tmp_path):
+    world, frames = 2, 3
+    mp.spawn(_worker, args=(world, _free_port(), frames, str(tmp_path)), nprocs=world, join=True)
+    dt, value = np.load(tmp_path / "res.npy")
+    assert dt == 0.75                                   # MAX over ranks
+    assert abs(value - 2 * 64 * 64 * frames * 3 / 0.75 / 1e6) < 1e-9
+    import json
+    g = json.load(open(tmp_path / "g.json"))
+    seeds = [r[0] for part in g for r in part]
+    assert sorted(seeds) == list(range(world * frames))            # disjoint and complete
+    assert len({r[1] for part in g for r in part}) == world * frames   # every frame is a different picture
+    for part in g:
+        for (_, _, mvx, mvy, tx, ty) in part:                       # each rank found its own frames' motion
+            assert abs(mvx - tx) <= 4 and abs(mvy - ty) <= 4
+
+
+def test_rank_seeds_are_disjoint_for_eight_gpus():
+    allseeds = [s for r in range(8) for s in rank_frame_seeds(r, 8)]
+    assert sorted(allseeds) == list(range(64))
+    assert max_over_ranks(1.25) == 1.25
