@@ -1,0 +1,9 @@
+// kern_me_star.hip -- the STAR-search instantiations of me_body.inc (reference motion.cpp:387-629, 1328-1436)
+#include "me_body.inc"
+
+int xh_me_star(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+               const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
+               int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource)
+{
+    return dispatch_me<true>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource);
+}

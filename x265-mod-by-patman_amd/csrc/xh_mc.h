@@ -108,19 +108,64 @@ __device__ __forceinline__ void load11u(const pixel* p, int* v)
 #endif
 }
 
+
+// ---- unaligned reads from an LDS-staged reference window ----------------------------------------
+// 32-bit DS reads at byte-granular addresses are native on gfx950 (unaligned DS access mode); wider misaligned DS
+// reads are replayed slowly, so every wide read is issued as separate (volatile => never merged) dwords.
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+typedef const XH_LDS u32_unaligned lu32u;
+__device__ __forceinline__ uint32_t lds_u32(const lpixel* p, int byteOff) { return *(lu32u*)((const XH_LDS char*)p + byteOff); }
+__device__ __forceinline__ void load4u(const lpixel* p, int* v)
+{
+#if X265_DEPTH == 8
+    uint32_t a = lds_u32(p, 0);
+    v[0] = a & 0xFF; v[1] = (a >> 8) & 0xFF; v[2] = (a >> 16) & 0xFF; v[3] = a >> 24;
+#else
+    uint32_t a = lds_u32(p, 0), b = lds_u32(p, 4);
+    v[0] = a & 0xFFFF; v[1] = a >> 16; v[2] = b & 0xFFFF; v[3] = b >> 16;
+#endif
+}
+__device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const lpixel* r /*LDS window, unaligned*/, unsigned acc)
+{
+#if X265_DEPTH == 8
+    return __builtin_amdgcn_sad_u8(*(const lu32*)f, lds_u32(r, 0), acc);
+#else
+    u32x2 a = *(const lu2*)f;
+    acc = __builtin_amdgcn_sad_u16(a.x, lds_u32(r, 0), acc);
+    return __builtin_amdgcn_sad_u16(a.y, lds_u32(r, 4), acc);
+#endif
+}
+__device__ __forceinline__ void load11u(const lpixel* p, int* v)
+{
+#if X265_DEPTH == 8
+    uint32_t a[3] = { lds_u32(p, 0), lds_u32(p, 4), lds_u32(p, 8) };
+#pragma unroll
+    for (int i = 0; i < 11; i++) v[i] = (a[i >> 2] >> (8 * (i & 3))) & 0xFF;
+#else
+    uint32_t a[6] = { lds_u32(p, 0), lds_u32(p, 4), lds_u32(p, 8), lds_u32(p, 12), lds_u32(p, 16), lds_u32(p, 20) };
+#pragma unroll
+    for (int i = 0; i < 11; i++) v[i] = (a[i >> 1] >> (16 * (i & 1))) & 0xFFFF;
+#endif
+}
+
+// A reference "view": pointer to the pixel co-located with the block's top-left corner + row stride, either in
+// global memory (the padded plane) or in LDS (a staged window).  at(x, y) is the pixel x right / y below.
+struct GView { const pixel* p; intptr_t s; __device__ __forceinline__ const pixel* at(int x, int y) const { return p + (intptr_t)y * s + x; } };
+struct LView { const lpixel* p; int s; __device__ __forceinline__ const lpixel* at(int x, int y) const { return p + y * s + x; } };
+
 #define QUAD_LOOP(c, q, y, x4) for (int q = (c).lane; q < (c).nquads; q += (c).gsize) { const int y = (q * (c).qdivm) >> 20; const int x4 = (q - y * (c).qpr) * 4;
 #define QUAD_END }
 
 // ---- sub-pel candidate: build the interpolated block in LDS (motion.cpp:1797-1801 dispatch) ----
-template<class C> __device__ void build_pred(const C& c, int qx, int qy)
+template<class C, class V> __device__ __forceinline__ void build_pred(const C& c, const V& ref, int qx, int qy)
 {
-    const pixel* src = c.fref + (qx >> 2) + (intptr_t)(qy >> 2) * c.rs;
+    const int ix = qx >> 2, iy = qy >> 2;
     const int xf = qx & 3, yf = qy & 3;
     const int headRoom = XH_IF_INTERNAL_PREC - X265_DEPTH;
     if (!(xf | yf))
     {
         QUAD_LOOP(c, q, y, x4)
-            int v[4]; load4u(src + (intptr_t)y * c.rs + x4, v); store4(c.pred + y * c.w + x4, v);
+            int v[4]; load4u(ref.at(ix + x4, iy + y), v); store4(c.pred + y * c.w + x4, v);
         QUAD_END
     }
     else if (!yf)
@@ -130,7 +175,7 @@ template<class C> __device__ void build_pred(const C& c, int qx, int qy)
         for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[xf][i];
         QUAD_LOOP(c, q, y, x4)
             int px[11], o[4];
-            load11u(src + (intptr_t)y * c.rs + x4 - 3, px);
+            load11u(ref.at(ix + x4 - 3, iy + y), px);
 #pragma unroll
             for (int e = 0; e < 4; e++)
             {
@@ -152,7 +197,7 @@ template<class C> __device__ void build_pred(const C& c, int qx, int qy)
 #pragma unroll
             for (int i = 0; i < 8; i++)
             {
-                int v[4]; load4u(src + (intptr_t)(y - 3 + i) * c.rs + x4, v);
+                int v[4]; load4u(ref.at(ix + x4, iy + y - 3 + i), v);
 #pragma unroll
                 for (int e = 0; e < 4; e++) s[e] += v[e] * t[i];
             }
@@ -172,7 +217,7 @@ template<class C> __device__ void build_pred(const C& c, int qx, int qy)
         {
             const int y = (q * c.qdivm) >> 20, x4 = (q - y * c.qpr) * 4;
             int px[11];
-            load11u(src + (intptr_t)(y - 3) * c.rs + x4 - 3, px);
+            load11u(ref.at(ix + x4 - 3, iy + y - 3), px);
             int16_t o[4];
 #pragma unroll
             for (int e = 0; e < 4; e++)
@@ -207,3 +252,9 @@ template<class C> __device__ void build_pred(const C& c, int qx, int qy)
 }
 
 } // namespace xh
+
+namespace xh {
+// convenience: the whole-plane (global memory) view of a context
+template<class C> __device__ __forceinline__ GView plane_view(const C& c) { GView v; v.p = c.fref; v.s = c.rs; return v; }
+template<class C> __device__ __forceinline__ void build_pred(const C& c, int qx, int qy) { build_pred(c, plane_view(c), qx, qy); }
+}
