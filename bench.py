@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="frame pairs per step per GPU")
     ap.add_argument("--qp", type=int, default=28)
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
+    ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
@@ -208,7 +209,7 @@ def main():
     half = 1 << 15
     cost_row = mvcost_row(depth, args.qp, half)
     pipe = FramePipeline(depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"],
-                         tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api)
+                         tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api, use_planes=not args.no_planes)
     pairs = []
     for seed in rank_frame_seeds(rank, args.frames):          # independent frames per rank, no overlap
         cur, ref, stride, _ = frame_pair(W, H, depth, seed=seed, margin=pipe.margin, max_shift=24)
@@ -224,17 +225,19 @@ def main():
     for _ in range(args.warmup):
         pipe.step()
     barrier()
-    names = ["me64", "me32", "me16", "me8", "tq%d" % (1 << args.tu)]
+    names = (["planes"] if pipe.use_planes else []) + ["me64", "me32", "me16", "me8", "tq%d" % (1 << args.tu)]
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev = events[k]
         ev[0].record()
-        for i, lv in enumerate(LEVELS):
-            pipe.launch_me(lv)
-            ev[i + 1].record()
+        j = 0
+        if pipe.use_planes:
+            pipe.launch_planes(); j += 1; ev[j].record()
+        for lv in LEVELS:
+            pipe.launch_me(lv); j += 1; ev[j].record()
         pipe.launch_tq()
-        ev[len(names)].record()
+        ev[j + 1].record()
     barrier()
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda")
@@ -249,6 +252,8 @@ def main():
             alg["me%d" % lv] = px * 2 * bpp + len(pipe.tasks_host[lv]) * 16
         n_tu = 1 << args.tu
         alg[names[-1]] = px * (2 * bpp + 2) + len(pipe.tu_host) * 4
+        if pipe.use_planes:
+            alg["planes"] = pipe.F * pipe.plane * bpp * 16          # 1 plane read + 15 written (padded planes)
         dom = max(kms, key=kms.get)
         achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
         traffic = None
@@ -266,7 +271,7 @@ def main():
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames,
                        "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "qp": args.qp,
-                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "sharding": "independent frames per GPU, no collectives"},
+                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "sharding": "independent frames per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),

@@ -64,7 +64,18 @@ int x265hip_me_batch(void* stream, int w, int h,
                      const x265hip_me_task* tasks, int n,
                      const uint16_t* costRow, int costHalfRange,
                      int merange, int method, int subpelRefine, x265hip_me_result* results,
-                     const x265hip_me_result* mvpSource /* may be NULL */);
+                     const x265hip_me_result* mvpSource /* may be NULL */,
+                     const void* subpelPlanes /* may be NULL: interpolate inside the kernel */, int64_t planeElems);
+
+/* Pre-interpolate a padded reference plane (or a stack of planes: `rows` counts every row of the allocation) into
+ * its 15 quarter-pel phase planes: outPlanes + f*planeElems for f = yFrac*4 + xFrac = 1..15 holds, at the same
+ * (stride, row) addressing as refPlane, exactly luma_hpp / luma_vpp / luma_hvpp of the pixel (ipfilter.cpp:79-118,
+ * 164-203, 362-369).  Slot f = 0 is not written (it is refPlane itself).  With the planes, x265hip_me_batch costs
+ * every sub-pel candidate as a plain SAD/SATD at an integer offset -- the device-memory-rich version of the
+ * reference lookahead's half-pel planes (lowres.h:104-124).  Values within 4 pixels of the allocation border are
+ * computed from clamped coordinates and must not be used (they lie in the picture margins).
+ * stride and planeElems must be multiples of 4 pixels, planeElems >= stride*rows, 16 planes of planeElems allocated. */
+int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems);
 
 /* one transform unit of the inter residual path; all TUs of one call share log2 size.
  * replaces the chain Predict::predInterLumaPixel (predict.cpp:279-300: copy_pp | luma_hpp | luma_vpp |

@@ -39,9 +39,10 @@ def make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange):
     return t
 
 
+@pytest.mark.parametrize("planes", [False, True])
 @pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("method", [0, 1, 3])      # DIA, HEX, STAR
-def test_me_batch_matches_oracle(depth, method):
+def test_me_batch_matches_oracle(depth, method, planes):
     api, ora = FrameApi(depth), Oracle(depth)
     rng = np.random.default_rng(77 * depth + method)
     W, H, margin = 320, 192, 96
@@ -50,6 +51,11 @@ def test_me_batch_matches_oracle(depth, method):
         cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 10 + seed, margin=margin, max_shift=10 if seed else 28)
         cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
         d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+        d_pl, pe = None, 0
+        if planes:
+            pe = cur_f.size
+            d_pl = api.torch.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
+            api.subpel_planes(d_ref, stride, cur.shape[0], d_pl, pe)
         for (w, h) in PUS:
             merange = int(rng.choice([8, 16, 57]))
             qp = int(rng.choice([22, 28, 37]))
@@ -59,7 +65,7 @@ def test_me_batch_matches_oracle(depth, method):
             row = ora.mvcost_row(qp, half)
             d_tasks, d_row = api.to_device(tasks), api.to_device(row.view(np.int16))
             d_res = api.torch.zeros(n * ME_RESULT.itemsize, dtype=api.torch.uint8, device="cuda")
-            api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, merange, method, subme, d_res)
+            api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, merange, method, subme, d_res, planes=d_pl, plane_elems=pe)
             api.torch.cuda.synchronize()
             res = d_res.cpu().numpy().view(ME_RESULT)
             for i in range(n):

@@ -12,11 +12,13 @@ from backends import Oracle
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("planes", [True, False])
 @pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("method,subme,tu", [(1, 2, 5), (3, 3, 4), (0, 0, 3), (1, 7, 2)])
-def test_small_frames_match_oracle(depth, method, subme, tu):
+def test_small_frames_match_oracle(depth, method, subme, tu, planes):
     row = mvcost_row(depth, 28, 1 << 15)
-    pipe = FramePipeline(depth, 256, 128, 2, qp=28, merange=24, method=method, subme=subme, tu_log2=tu, recon=True, cost_row=row)
+    pipe = FramePipeline(depth, 256, 128, 2, qp=28, merange=24, method=method, subme=subme, tu_log2=tu, recon=True, cost_row=row,
+                         use_planes=planes)
     pipe.upload([frame_pair(256, 128, depth, 40 + s, margin=pipe.margin, max_shift=14)[:2] for s in range(2)])
     pipe.step()
     pipe.torch.cuda.synchronize()
@@ -58,3 +60,31 @@ def test_full_size_properties_and_sample():
     assert int(((cur - rec) ** 2).sum()) == int(pipe.d_sse.sum())
     # and a random sample of PUs / TUs bit-exact against the oracle
     assert pipe.check_sample(Oracle(depth), np.random.default_rng(3), per_level=25, n_tu=25) == 125
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_phase_planes_equal_the_interpolation_primitives(depth):
+    """x265hip_subpel_planes: every phase plane equals luma_hpp / luma_vpp / luma_hvpp of the oracle, block by block."""
+    from x265hip_pkg.frame import FrameApi
+    api, ora = FrameApi(depth), Oracle(depth)
+    T = api.torch
+    rng = np.random.default_rng(depth)
+    W, H, m = 192, 96, 32
+    _, ref, stride, _ = frame_pair(W, H, depth, 9, margin=m, max_shift=4)
+    rows = H + 2 * m
+    ref_f = ref.reshape(-1)
+    d_ref = api.to_device(ref_f)
+    pe = stride * rows
+    d_pl = T.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
+    api.subpel_planes(d_ref, stride, rows, d_pl, pe)
+    T.cuda.synchronize()
+    pl = d_pl.cpu().numpy().view(ref_f.dtype).reshape(16, rows, stride)
+    for f in range(1, 16):
+        xf, yf = f & 3, f >> 2
+        for _ in range(6):
+            w, h = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 4), (4, 16)][int(rng.integers(0, 6))]
+            x = int(rng.integers(8, stride - w - 8)); y = int(rng.integers(8, rows - h - 8))
+            buf = np.zeros(w * h, ref_f.dtype)
+            kind = "hpp" if yf == 0 else ("vpp" if xf == 0 else "hvpp")
+            exp = ora.interp(kind, 8, w, h, ref_f, stride, y * stride + x, buf, w, xf if kind != "vpp" else yf, yf).reshape(h, w)
+            assert np.array_equal(pl[f, y:y + h, x:x + w], exp), "phase (%d,%d) block %dx%d at (%d,%d)" % (xf, yf, w, h, x, y)

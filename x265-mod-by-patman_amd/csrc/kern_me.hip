@@ -4,11 +4,13 @@
 
 int xh_me_star(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
-               int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource);
+               int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+               const void* subpelPlanes, int64_t planeElems);
 
 extern "C" int x265hip_me_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                                 const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
-                                int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource)
+                                int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+               const void* subpelPlanes, int64_t planeElems)
 {
     if (n <= 0) return X265HIP_OK;
     if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !tasks || !results || !costRow || costHalfRange < 1)
@@ -16,7 +18,8 @@ extern "C" int x265hip_me_batch(void* stream, int w, int h, const void* curPlane
     if (method != X265HIP_ME_DIA && method != X265HIP_ME_HEX && method != X265HIP_ME_STAR)
     { set_error("me_batch: search method %d is not offloaded (DIA/HEX/STAR are)", method); return X265HIP_EARG; }
     if (subpelRefine < 0 || subpelRefine > 7 || merange < 1) { set_error("me_batch: bad subme/merange"); return X265HIP_EARG; }
+    if (subpelPlanes && (planeElems <= 0 || ((uintptr_t)subpelPlanes & 7))) { set_error("me_batch: bad subpel planes"); return X265HIP_EARG; }
     if (method == X265HIP_ME_STAR)
-        return xh_me_star(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource);
-    return dispatch_me<false>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource);
+        return xh_me_star(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
+    return dispatch_me<false>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
 }

@@ -3,7 +3,8 @@
 
 int xh_me_star(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
-               int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource)
+               int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+               const void* subpelPlanes, int64_t planeElems)
 {
-    return dispatch_me<true>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource);
+    return dispatch_me<true>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
 }

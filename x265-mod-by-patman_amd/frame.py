@@ -54,9 +54,14 @@ class FrameApi:
             a = a.view(np.uint8)
         return self.torch.from_numpy(a.reshape(-1)).cuda()
 
-    def me_batch(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half, merange, method, subme, results, mvp_source=None):
+    def me_batch(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half, merange, method, subme, results, mvp_source=None,
+                 planes=None, plane_elems=0):
         self.h.check(self.lib.x265hip_me_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
-                                               _dp(tasks), n, _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source)))
+                                               _dp(tasks), n, _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source),
+                                               _dp(planes), C.c_int64(plane_elems)))
+
+    def subpel_planes(self, ref, stride, rows, out_planes, plane_elems):
+        self.h.check(self.lib.x265hip_subpel_planes(self.stream(), _dp(ref), C.c_ssize_t(stride), rows, _dp(out_planes), C.c_int64(plane_elems)))
 
     def tq_batch(self, log2n, cur, cstride, ref, rstride, tasks, n, qp, add, coeff, numsig, quant_coeff=None, delta_u=None,
                  recon=None, recon_stride=0, sse=None, mv_source=None):

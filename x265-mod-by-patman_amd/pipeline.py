@@ -5,6 +5,8 @@ One step over a batch of F (source, reference) frame pairs:
          seeded with its parent's MV the way Analysis::deriveMVsForCTU / computeMVForPUs seed PUs from
          m_areaBestMV (analysis.cpp:161-306); search window per Search::setSearchRange (search.cpp:4969-5021)
          with CUData::clipMv limits (cudata.cpp:2094-2107).
+  S0     (use_planes) x265hip_subpel_planes: the 15 quarter-pel phase planes of the reference stack, so that
+         every sub-pel candidate of S2 is a plain SATD at an integer offset.
   S3     x265hip_tq_batch on the 2^tu_log2 grid with the MVs of the matching pyramid level:
          MC -> residual -> DCT -> quant (inter rounding 85), coefficients + numSig out.
   S4     optional (recon=True): dequant -> IDCT -> reconstruction + SSE.
@@ -20,13 +22,15 @@ CTU = 64
 
 class FramePipeline:
     def __init__(self, depth, width, height, frames, qp=28, merange=57, method=1, subme=2, tu_log2=5, margin=96,
-                 recon=False, cost_row=None, api=None):
+                 recon=False, cost_row=None, api=None, use_planes=True):
         assert width % CTU == 0 and height % CTU == 0, "pad the picture to whole CTUs"
         self.api = api or FrameApi(depth)
         self.torch = self.api.torch
         self.depth, self.W, self.H, self.F = depth, width, height, frames
         self.qp, self.merange, self.method, self.subme, self.tu_log2, self.margin = qp, merange, method, subme, tu_log2, margin
         self.recon = recon
+        self.use_planes = use_planes
+        self.d_planes = None
         self.stride = width + 2 * margin
         self.plane = self.stride * (height + 2 * margin)        # elements per padded plane
         self.half = 1 << 15
@@ -100,12 +104,21 @@ class FramePipeline:
         self.d_cur, self.d_ref = self.api.to_device(cur), self.api.to_device(ref)
         if self.recon:
             self.d_recon = self.torch.zeros_like(self.d_cur)
+        if self.use_planes and self.d_planes is None:
+            # 16 phase-plane slots (slot 0 unused) with the reference stack's own addressing
+            self.plane_elems = self.F * self.plane
+            self.d_planes = self.torch.empty(16 * self.plane_elems, dtype=self.d_ref.dtype, device="cuda")
 
     # ---- device work ----
+    def launch_planes(self):
+        """Quarter-pel phase planes of the whole reference stack (once per reference picture in an encoder)."""
+        self.api.subpel_planes(self.d_ref, self.stride, self.F * (self.H + 2 * self.margin), self.d_planes, self.plane_elems)
+
     def launch_me(self, lv):
         parent = None if lv == CTU else self.d_results[2 * lv]
         self.api.me_batch(lv, lv, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tasks[lv], len(self.tasks_host[lv]),
-                          self.d_cost, self.half, self.merange, self.method, self.subme, self.d_results[lv], mvp_source=parent)
+                          self.d_cost, self.half, self.merange, self.method, self.subme, self.d_results[lv], mvp_source=parent,
+                          planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
 
     def launch_tq(self):
         self.api.tq_batch(self.tu_log2, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tu, len(self.tu_host), self.qp, 85,
@@ -113,6 +126,8 @@ class FramePipeline:
                           mv_source=self.d_results[self.mv_level])
 
     def step(self):
+        if self.use_planes:
+            self.launch_planes()
         for lv in LEVELS:
             self.launch_me(lv)
         self.launch_tq()
