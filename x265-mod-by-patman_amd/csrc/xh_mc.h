@@ -94,6 +94,20 @@ __device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const 
     return __builtin_amdgcn_sad_u16(a.y, b.y, acc);
 #endif
 }
+// a quad (4 horizontally adjacent pixels) as packed register data
+#if X265_DEPTH == 8
+typedef uint32_t fquad;
+__device__ __forceinline__ fquad ldq(const pixel* p) { uint32_t a; __builtin_memcpy(&a, p, 4); return a; }           // unaligned, global
+__device__ __forceinline__ fquad ldf(const lpixel* p) { return *(const lu32*)p; }                                  // aligned, LDS
+__device__ __forceinline__ unsigned sadq(fquad f, fquad r, unsigned acc) { return __builtin_amdgcn_sad_u8(f, r, acc); }
+__device__ __forceinline__ void unpackq(fquad a, int* v) { v[0] = a & 0xFF; v[1] = (a >> 8) & 0xFF; v[2] = (a >> 16) & 0xFF; v[3] = a >> 24; }
+#else
+typedef u32x2 fquad;
+__device__ __forceinline__ fquad ldq(const pixel* p) { u32x2 a; __builtin_memcpy(&a, p, 8); return a; }
+__device__ __forceinline__ fquad ldf(const lpixel* p) { return *(const lu2*)p; }
+__device__ __forceinline__ unsigned sadq(fquad f, fquad r, unsigned acc) { return __builtin_amdgcn_sad_u16(f.y, r.y, __builtin_amdgcn_sad_u16(f.x, r.x, acc)); }
+__device__ __forceinline__ void unpackq(fquad a, int* v) { v[0] = a.x & 0xFFFF; v[1] = a.x >> 16; v[2] = a.y & 0xFFFF; v[3] = a.y >> 16; }
+#endif
 // 11 consecutive pixels starting at p (unaligned, global): what a 4-wide 8-tap horizontal filter needs
 __device__ __forceinline__ void load11u(const pixel* p, int* v)
 {
