@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     __syncthreads();                   // the only block-level barrier; waves are independent from here on
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + wave;
+    const int item = xcd_contiguous_block(blockIdx.x, gridDim.x) * 4 + wave;
     if (item >= a.n) return;
     x265hip_tu_task tk = a.tasks[item];
     if (tk.mvFrom >= 0 && a.mvSource) { tk.mv[0] = a.mvSource[tk.mvFrom].mv[0]; tk.mv[1] = a.mvSource[tk.mvFrom].mv[1]; }

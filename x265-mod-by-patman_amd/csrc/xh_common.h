@@ -73,6 +73,25 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
            ((unsigned long long)(unsigned)wave_sum((int)hi) << 48);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2.
+// Renumbering gives XCD k the k-th CONTIGUOUS eighth of the work list, so neighbouring blocks of a picture -- which
+// share reference rows and search aprons -- meet in one L2 instead of being replicated in all eight.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nblocks)
+{
+    const int xcd = b & 7, idx = b >> 3, q = nblocks >> 3, r = nblocks & 7;
+    return xcd * q + min(xcd, r) + idx;
+}
+
+// The same in chunks of C consecutive blocks per XCD (keeps neighbours together without handing whole pictures --
+// whose search effort differs -- to single XCDs).  Blocks past the last full round of 8*C keep their number.
+__device__ __forceinline__ int xcd_chunked_block(int b, int nblocks, int C)
+{
+    const int round = 8 * C, full = (nblocks / round) * round;
+    if (b >= full) return b;
+    const int base = (b / round) * round, o = b - base;
+    return base + (o & 7) * C + (o >> 3);
+}
+
 // HEVC core-transform coefficient by angle index (the numbers of constants.cpp:270-344)
 static __device__ const int8_t k_cos33[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
                                               61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
