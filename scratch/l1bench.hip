@@ -8,6 +8,7 @@ template<int BYTES> __device__ __forceinline__ uint32_t ld(const char* p)
 {
     if (BYTES == 4) { uint32_t a; __builtin_memcpy(&a, p, 4); return a; }
     if (BYTES == 8) { uint2 a; __builtin_memcpy(&a, p, 8); return a.x ^ a.y; }
+    if (BYTES == 12) { struct { uint32_t x, y, z; } a; __builtin_memcpy(&a, __builtin_assume_aligned(p, 4), 12); return a.x ^ a.y ^ a.z; }
     uint4 a; __builtin_memcpy(&a, p, 16); return a.x ^ a.y ^ a.z ^ a.w;
 }
 template<int BYTES>
@@ -32,7 +33,7 @@ int main()
     const int iters = 2000, blocks = 256 * 8;
     struct P { int bytes, lpr, stride, mis; };
     std::vector<P> ps;
-    for (int bytes : {4, 8, 16}) for (int lpr : {64, 16, 8, 4, 2, 1}) for (int mis : {0, 1}) ps.push_back({bytes, lpr, 2112, mis});
+    for (int bytes : {8, 12, 16}) for (int lpr : {16, 4, 2, 1}) for (int mis : {0, 2, 4, 8, 12}) ps.push_back({bytes, lpr, 2112, mis});
     for (auto& q : ps)
     {
         float ms = 0;
@@ -41,6 +42,7 @@ int main()
             hipEventRecord(e0);
             if (q.bytes == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, d, q.lpr, q.stride, q.mis, iters, 4, o);
             else if (q.bytes == 8) hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(256), 0, 0, d, q.lpr, q.stride, q.mis, iters, 4, o);
+            else if (q.bytes == 12) hipLaunchKernelGGL(k<12>, dim3(blocks), dim3(256), 0, 0, d, q.lpr, q.stride, q.mis, iters, 4, o);
             else hipLaunchKernelGGL(k<16>, dim3(blocks), dim3(256), 0, 0, d, q.lpr, q.stride, q.mis, iters, 4, o);
             hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
         }

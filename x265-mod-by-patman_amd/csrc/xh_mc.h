@@ -94,17 +94,31 @@ __device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const 
     return __builtin_amdgcn_sad_u16(a.y, b.y, acc);
 #endif
 }
-// a quad (4 horizontally adjacent pixels) as packed register data
-#if X265_DEPTH == 8
-typedef uint32_t fquad;
-__device__ __forceinline__ fquad ldq(const pixel* p) { uint32_t a; __builtin_memcpy(&a, p, 4); return a; }           // unaligned, global
-__device__ __forceinline__ fquad ldf(const lpixel* p) { return *(const lu32*)p; }                                  // aligned, LDS
-__device__ __forceinline__ unsigned sadq(fquad f, fquad r, unsigned acc) { return __builtin_amdgcn_sad_u8(f, r, acc); }
-__device__ __forceinline__ void unpackq(fquad a, int* v) { v[0] = a & 0xFF; v[1] = (a >> 8) & 0xFF; v[2] = (a >> 16) & 0xFF; v[3] = a >> 24; }
-#else
+// The lane unit of the size-specialised kernels: 8 bytes of one row (8 pixels at 8 bit, 4 pixels at 16 bit) as packed
+// register data.  8-byte units keep row chunks >= 16 bytes for every PU width >= 16, which is what the L1/TA front end
+// needs to stay at 4 lanes per clock (scratch/l1bench.hip: 4-byte lanes on 8-byte rows cost 1 lane per clock).
 typedef u32x2 fquad;
-__device__ __forceinline__ fquad ldq(const pixel* p) { u32x2 a; __builtin_memcpy(&a, p, 8); return a; }
-__device__ __forceinline__ fquad ldf(const lpixel* p) { return *(const lu2*)p; }
+#define XH_UNITPX (8 / (int)sizeof(pixel))
+__device__ __forceinline__ fquad ldq(const pixel* p) { u32x2 a; __builtin_memcpy(&a, p, 8); return a; }              // unaligned, global
+__device__ __forceinline__ fquad ldf(const lpixel* p) { return *(const lu2*)p; }                                     // 8-byte aligned, LDS
+// The same unit at a byte-misaligned address: one DWORD-ALIGNED 12-byte load + two funnel shifts.  The L1/TA front end
+// splits a sub-dword-misaligned wide load into dwords at twice the cost, while dword-aligned x2/x3/x4 loads run at the
+// full 4 lanes per clock whatever their 8/16-byte alignment (scratch/l1bench.hip).  a = address rounded down to 4, m = address & 3.
+__device__ __forceinline__ fquad ldq_a(const char* a, unsigned m)
+{
+    struct W3 { uint32_t x, y, z; } w;
+    __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 12);
+    fquad r; r.x = __builtin_amdgcn_alignbyte(w.y, w.x, m); r.y = __builtin_amdgcn_alignbyte(w.z, w.y, m);
+    return r;
+}
+#if X265_DEPTH == 8
+__device__ __forceinline__ unsigned sadq(fquad f, fquad r, unsigned acc) { return __builtin_amdgcn_sad_u8(f.y, r.y, __builtin_amdgcn_sad_u8(f.x, r.x, acc)); }
+__device__ __forceinline__ void unpackq(fquad a, int* v)
+{
+    v[0] = a.x & 0xFF; v[1] = (a.x >> 8) & 0xFF; v[2] = (a.x >> 16) & 0xFF; v[3] = a.x >> 24;
+    v[4] = a.y & 0xFF; v[5] = (a.y >> 8) & 0xFF; v[6] = (a.y >> 16) & 0xFF; v[7] = a.y >> 24;
+}
+#else
 __device__ __forceinline__ unsigned sadq(fquad f, fquad r, unsigned acc) { return __builtin_amdgcn_sad_u16(f.y, r.y, __builtin_amdgcn_sad_u16(f.x, r.x, acc)); }
 __device__ __forceinline__ void unpackq(fquad a, int* v) { v[0] = a.x & 0xFFFF; v[1] = a.x >> 16; v[2] = a.y & 0xFFFF; v[3] = a.y >> 16; }
 #endif
