@@ -8,6 +8,8 @@
 // plane[yFrac*4 + xFrac] at an integer offset.  Arithmetic per phase is exactly the primitive's:
 //   yFrac == 0: luma_hpp (ipfilter.cpp:79-118)     xFrac == 0: luma_vpp (:164-203)
 //   else:       luma_hvpp = hps (row extended, :120-162) -> vsp (:319-369)
+// Slot 0 of the output receives a copy of the reference plane, so that the motion search addresses every candidate --
+// integer or sub-pel -- as one buffer base plus a 32-bit offset.
 // One workgroup produces a 64x16 tile of all 15 planes: source tile + apron in LDS, the three horizontal 14-bit
 // intermediates in LDS, then nine vertical passes.  Streaming kernel: 1 plane read, 15 written.
 #include "xh_mc.h"
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
         int col[8][4];
 #pragma unroll
         for (int k = 0; k < 8; k++) load4u(src + (y + k) * SSTRIDE + x4 + 4, col[k]);
+        store4g(o0, col[3]);                                          // slot 0: the reference plane itself (one base for every candidate)
 #pragma unroll
         for (int yf = 1; yf < 4; yf++)
         {
