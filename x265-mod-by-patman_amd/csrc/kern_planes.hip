@@ -13,6 +13,7 @@
 // One workgroup produces a 64x16 tile of all 15 planes: source tile + apron in LDS, the three horizontal 14-bit
 // intermediates in LDS, then nine vertical passes.  Streaming kernel: 1 plane read, 15 written.
 #include "xh_mc.h"
+#include <cstdlib>
 #include "../../include/x265hip_frame.h"
 using namespace xh;
 
@@ -33,6 +34,232 @@ __device__ __forceinline__ void store4g(pixel* p, const int* v)      // 4 pixels
 #endif
 }
 
+#if X265_DEPTH == 8
+// ---- 8-bit build: the filters as packed dot products -------------------------------------------------------------
+// Pixels are kept as signed bytes q = p - 128, so an 8-tap sum is two v_dot4_i32_i8 (taps are int8):
+//   sum(t*p) = dot(t, q) + 128*64, hence the 14-bit intermediate of luma_hps (sum - 8192, shift 0 at 8 bit) IS the dot
+// and the vertical pass over intermediates is four v_dot2_i32_i16 on vertically packed pairs.  Horizontal windows come
+// from the row-major tile, vertical windows from a byte-transposed copy (v_perm 4x4 transposes), both realigned with
+// v_alignbyte/v_alignbit.  ~2x fewer vector instructions per pixel than the scalar-MAC form below.
+constexpr int SROW = 20;                    // dwords per row of the row-major tile (19 used)
+constexpr int TCOL = 7;                     // dwords per column of the transposed tile (6 used; odd -> banks)
+constexpr int NT = 4;                       // tiles per workgroup (vertical walk)
+constexpr int ICOL = 13;                    // dwords per column of the transposed intermediates (12 used)
+__device__ __forceinline__ constexpr uint32_t pk4(int a, int b, int c, int d) { return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24); }
+__device__ __forceinline__ constexpr uint32_t pk2(int a, int b) { return (uint32_t)(uint16_t)a | ((uint32_t)(uint16_t)b << 16); }
+// (Builtins, not inline asm: dot results have read-after-write hazards against other VALU opcodes that the compiler
+// only pads with wait states when it can see both instructions.)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot8(uint32_t lo, uint32_t hi, uint32_t tlo, uint32_t thi, int acc)
+{
+    return __builtin_amdgcn_sdot4((int)lo, (int)tlo, __builtin_amdgcn_sdot4((int)hi, (int)thi, acc, false), false);
+}
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t t, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, t), acc, false);
+}
+// four pixels clip(v[i] >> SH, 0, 255) packed into a dword: v_ashr_pk_u8_i32 shifts, saturates and packs two at a time
+template<int SH> __device__ __forceinline__ uint32_t sat_pack4(int a, int b, int c, int d)
+{
+    u16x2 v = { __builtin_amdgcn_ashr_pk_u8_i32(a, b, SH), __builtin_amdgcn_ashr_pk_u8_i32(c, d, SH) };
+    return __builtin_bit_cast(uint32_t, v);
+}
+// Plane stores: the plane / row part of the address is wave-uniform (an SGPR base), the thread part a 32-bit offset.
+__device__ __forceinline__ void store_px4(pixel* uniformBase, uint32_t threadOff, uint32_t v)
+{
+    *(uint32_t*)((char*)uniformBase + (size_t)threadOff) = v;
+}
+__device__ __forceinline__ uint32_t pack_u8(int a, int b, int c, int d)
+{
+    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));          // see xh_mc.h store4(): v_ashr_pk_u8_i32 miscompile
+    return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+// the 8 bytes starting `sh` bytes into the 12-byte window (w0, w1, w2), sh = 0..3 (compile-time)
+template<int SH> __device__ __forceinline__ void window8(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t& lo, uint32_t& hi)
+{
+    if (SH == 0) { lo = w0; hi = w1; }
+    else { lo = __builtin_amdgcn_alignbyte(w1, w0, SH); hi = __builtin_amdgcn_alignbyte(w2, w1, SH); }
+}
+
+__global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restrict__ ref, intptr_t stride, int rows,
+                                                            pixel* __restrict__ out, int64_t planeElems)
+{
+    __shared__ uint32_t s_src[24 * SROW];            // rows y0-3 .. y0+20, bytes x0-4 .. x0+71, as q = p - 128
+    __shared__ uint32_t s_srcT[TW * TCOL];           // [column][row]: the same pixels for columns x0 .. x0+63
+    __shared__ uint32_t s_imT[3][TW * ICOL];         // [xFrac-1][column][row pair]: 14-bit intermediates, int16 pairs (row 2i | row 2i+1)
+    const int x0 = blockIdx.x * TW, t = threadIdx.x;
+    constexpr uint32_t TLO[4] = { 0, pk4(-1, 4, -10, 58), pk4(-1, 4, -11, 40), pk4(0, 1, -5, 17) };
+    constexpr uint32_t THI[4] = { 0, pk4(17, -5, 1, 0), pk4(40, -11, 4, -1), pk4(58, -10, 4, -1) };
+    constexpr uint32_t TP[4][4] = { { 0, 0, 0, 0 }, { pk2(-1, 4), pk2(-10, 58), pk2(17, -5), pk2(1, 0) },
+                                    { pk2(-1, 4), pk2(-11, 40), pk2(40, -11), pk2(4, -1) }, { pk2(0, 1), pk2(-5, 17), pk2(58, -10), pk2(4, -1) } };
+
+    // A workgroup walks NT vertically adjacent tiles; the source rows of tile i+1 are fetched into registers while tile i is
+    // being filtered, so the HBM latency of the only read of this kernel hides behind the arithmetic.
+    const int rbA = t / 19, dcA = t - rbA * 19, gxA = x0 - 4 + 4 * dcA;           // loader role (t < 6*19): 4 rows x 1 dword
+    auto fetch = [&](int y0_, uint32_t (&v)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int gy = min(max(y0_ - 3 + 4 * rbA + r, 0), rows - 1);
+            const pixel* row = ref + (intptr_t)gy * stride;
+            if (gxA >= 0 && gxA + 3 < (int)stride) v[r] = *(const uint32_t*)(row + gxA);
+            else
+            {
+                v[r] = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[r] |= (uint32_t)row[min(max(gxA + e, 0), (int)stride - 1)] << (8 * e);
+            }
+        }
+    };
+    uint32_t nxt[4] = { 0, 0, 0, 0 };
+    if (t < 6 * 19 && (int)blockIdx.y * NT * TH < rows) fetch(blockIdx.y * NT * TH, nxt);
+    for (int it = 0; it < NT; it++)
+    {
+    const int y0 = (blockIdx.y * NT + it) * TH;
+    if (y0 >= rows) break;                                                          // uniform
+    // ---- A: slot-0 copy, signed bytes, transposed copy (coordinates were clamped into the allocation by fetch) ----
+    if (t < 6 * 19)
+    {
+        const int rb = rbA, dc = dcA, gx = gxA;
+        uint32_t v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+            const int gyu = y0 - 3 + 4 * rb + r;
+            v[r] = nxt[r];
+            if (dc >= 1 && dc <= 16 && 4 * rb + r >= 3 && 4 * rb + r < 3 + TH && gyu < rows && gx < (int)stride)
+                *(uint32_t*)(out + (intptr_t)gyu * stride + gx) = v[r];            // slot 0: the reference plane itself
+            v[r] ^= 0x80808080u;
+            s_src[(4 * rb + r) * SROW + dc] = v[r];
+        }
+        if (dc >= 1 && dc <= 16)
+        {   // 4x4 byte transpose: c_i = (v0.b_i, v1.b_i, v2.b_i, v3.b_i)
+            const uint32_t t0 = __builtin_amdgcn_perm(v[1], v[0], 0x05010400), t1 = __builtin_amdgcn_perm(v[1], v[0], 0x07030602);
+            const uint32_t t2 = __builtin_amdgcn_perm(v[3], v[2], 0x05010400), t3 = __builtin_amdgcn_perm(v[3], v[2], 0x07030602);
+            const int col = 4 * (dc - 1);
+            s_srcT[(col + 0) * TCOL + rb] = __builtin_amdgcn_perm(t2, t0, 0x05040100);
+            s_srcT[(col + 1) * TCOL + rb] = __builtin_amdgcn_perm(t2, t0, 0x07060302);
+            s_srcT[(col + 2) * TCOL + rb] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
+            s_srcT[(col + 3) * TCOL + rb] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
+        }
+        if (it + 1 < NT && y0 + TH < rows) fetch(y0 + TH, nxt);                     // in flight during H / V / HV
+    }
+    __syncthreads();
+
+    if (t < 96)
+    {   // ---- H: 4 rows x 4 pixels per thread: intermediates for the three xFracs + the yFrac == 0 planes ----
+        const int rb = t >> 4, q = t & 15;
+        const int gx = x0 + 4 * q;
+        const uint32_t hoff = (uint32_t)(4 * rb) * (uint32_t)stride + 4 * q;         // thread part of the store address (bytes = pixels)
+#pragma unroll
+        for (int pb = 0; pb < 2; pb++)
+        {
+            uint32_t lo[2][4], hi[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+            {
+                const uint32_t* w = s_src + (4 * rb + 2 * pb + r) * SROW + q;
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+                window8<1>(w0, w1, w2, lo[r][0], hi[r][0]); window8<2>(w0, w1, w2, lo[r][1], hi[r][1]);
+                window8<3>(w0, w1, w2, lo[r][2], hi[r][2]); lo[r][3] = w1; hi[r][3] = w2;
+            }
+#pragma unroll
+            for (int xf = 1; xf < 4; xf++)
+            {
+                // d = sum(t*p) + 32 = intermediate + 8224: the bias rides along into the LDS copy and is absorbed by the
+                // rounding constant of the second pass (64 * 8224 == (1 << 11) + (8192 << 6))
+                int d[2][4];
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) d[r][e] = dot8(lo[r][e], hi[r][e], TLO[xf], THI[xf], 8192 + 32);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    s_imT[xf - 1][(4 * q + e) * ICOL + 2 * rb + pb] = __builtin_amdgcn_perm((uint32_t)d[1][e], (uint32_t)d[0][e], 0x05040100);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                {
+                    const int tr = 4 * rb + 2 * pb + r, gy = y0 + tr - 3;
+                    if (tr >= 3 && tr < 3 + TH && gy < rows && gx < (int)stride)
+                        store_px4(out + (int64_t)xf * planeElems, (uint32_t)((y0 - 3 + 2 * pb + r) * (int)stride + x0) + hoff, sat_pack4<6>(d[r][0], d[r][1], d[r][2], d[r][3]));
+                }
+            }
+        }
+    }
+    else if (t >= 128 && t < 192)
+    {   // ---- V: 4 columns x 4 rows per thread straight from the pixels: the xFrac == 0 planes ----
+        const int i = t - 128, rq = i >> 4, cq = i & 15;
+        const int gx = x0 + 4 * cq;
+        const uint32_t voff = (uint32_t)(4 * rq) * (uint32_t)stride + 4 * cq;
+        uint32_t lo[4][4], hi[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+            const uint32_t* w = s_srcT + (4 * cq + c) * TCOL + rq;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            window8<0>(w0, w1, w2, lo[c][0], hi[c][0]); window8<1>(w0, w1, w2, lo[c][1], hi[c][1]);
+            window8<2>(w0, w1, w2, lo[c][2], hi[c][2]); window8<3>(w0, w1, w2, lo[c][3], hi[c][3]);
+        }
+#pragma unroll
+        for (int yf = 1; yf < 4; yf++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                const int gy = y0 + 4 * rq + e;
+                int o[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) o[c] = dot8(lo[c][e], hi[c][e], TLO[yf], THI[yf], 8192 + 32);
+                if (gy < rows && gx < (int)stride)
+                    store_px4(out + (int64_t)(yf * 4) * planeElems, (uint32_t)((y0 + e) * (int)stride + x0) + voff, sat_pack4<6>(o[0], o[1], o[2], o[3]));
+            }
+    }
+    __syncthreads();
+
+    if (t < 192)
+    {   // ---- HV: 4 columns x 4 rows per thread and xFrac: vertical taps over the intermediates ----
+        const int xf = __builtin_amdgcn_readfirstlane(t >> 6), i = t & 63, rq = i >> 4, cq = i & 15;   // one xFrac per wavefront
+        const int gx = x0 + 4 * cq;
+        const uint32_t voff = (uint32_t)(4 * rq) * (uint32_t)stride + 4 * cq;
+        pixel* xbase = out + (int64_t)(xf + 1) * planeElems;
+        uint32_t P[4][5], Q[4][5];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+            const uint32_t* w = s_imT[xf] + (4 * cq + c) * ICOL + 2 * rq;
+            uint32_t p5 = w[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) P[c][k] = w[k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) Q[c][k] = __builtin_amdgcn_alignbit(P[c][k + 1], P[c][k], 16);
+            Q[c][4] = __builtin_amdgcn_alignbit(p5, P[c][4], 16);
+        }
+        const int offset2 = (1 << 11) + (XH_IF_INTERNAL_OFFS << XH_IF_FILTER_PREC);
+#pragma unroll
+        for (int yf = 1; yf < 4; yf++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                const int gy = y0 + 4 * rq + e;
+                int o[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                {
+                    const uint32_t* a = (e & 1) ? Q[c] + (e >> 1) : P[c] + (e >> 1);
+                    int sum = offset2 - 64 * (8192 + 32);                              // == 0: the bias of the intermediates is the rounding term
+#pragma unroll
+                    for (int k = 0; k < 4; k++) sum = dot2(a[k], TP[yf][k], sum);
+                    o[c] = sum;
+                }
+                if (gy < rows && gx < (int)stride)
+                    store_px4(xbase + (int64_t)(yf * 4) * planeElems, (uint32_t)((y0 + e) * (int)stride + x0) + voff, sat_pack4<12>(o[0], o[1], o[2], o[3]));
+            }
+    }
+    // no third barrier: the next tile's A only writes s_src / s_srcT (last read before the barrier above), and s_imT is
+    // rewritten after the next tile's first barrier, which every wavefront reaches after its HV reads
+    }
+}
+#else
 __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restrict__ ref, intptr_t stride, int rows,
                                                             pixel* __restrict__ out, int64_t planeElems)
 {
@@ -153,6 +380,8 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
     }
 }
 
+#endif
+
 } // namespace
 
 extern "C" int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems)
@@ -160,7 +389,11 @@ extern "C" int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_
     if (!refPlane || !outPlanes || stride < 16 || rows < 8 || (stride & 3) || planeElems < (int64_t)stride * rows || (planeElems & 3))
     { set_error("subpel_planes: bad arguments (stride and planeElems must be multiples of 4)"); return X265HIP_EARG; }
     if (((uintptr_t)refPlane | (uintptr_t)outPlanes) & 7) { set_error("subpel_planes: planes must be 8-byte aligned"); return X265HIP_EARG; }
+#if X265_DEPTH == 8
+    dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH * NT - 1) / (TH * NT)));
+#else
     dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
+#endif
     hipLaunchKernelGGL(subpel_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                        (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
     XH_LAUNCH_CHECK();
