@@ -24,12 +24,17 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E nominal (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
-METHODS = {"dia": 0, "hex": 1, "star": 3}
+METHODS = {"dia": 0, "hex": 1, "star": 3, "full": 5}
 WORKLOADS = {
     # BASELINE.json configs[1]: 1080p 8-bit, preset medium (me hex, subme 2, merange 57 -- param.cpp:188,238-256)
     "1080p8_medium": dict(depth=8, width=1920, height=1088, method="hex", subme=2, merange=57),
     # configs[2]: 2160p 10-bit Main10, preset slow (me star, subme 3)
     "2160p10_slow": dict(depth=10, width=3840, height=2176, method="star", subme=3, merange=57),
+    # configs[4]: 8K 10-bit, preset slower (me star, subme 4), --merange 128 (run with --frames 2: 16 phase planes of one
+    # 8K10 frame pair are 1.1 GB and the size-specialised kernels address the plane buffer with 32-bit byte offsets)
+    "4320p10_slower": dict(depth=10, width=7680, height=4352, method="star", subme=4, merange=128),
+    # the exhaustive integer search (VALU-bound by construction), reported next to the pattern searches
+    "1080p8_full": dict(depth=8, width=1920, height=1088, method="full", subme=2, merange=16),
 }
 
 

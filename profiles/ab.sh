@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of ME kernel variants inside ONE box (box-to-box variance is ~15%): scratch/ab.sh "<env assignments>" ...
+# A/B of ME kernel variants inside ONE box (box-to-box variance is ~15%): profiles/ab.sh "<env assignments>" ...
 for v in "$@"; do
   for wl in 1080p8_medium 2160p10_slow; do
     st=20; [ $wl = 2160p10_slow ] && st=5

@@ -1,5 +1,5 @@
 // L1/TA micro-benchmark: cost of one wave-wide load instruction for the address patterns the ME kernels use.
-// usage: l1bench  (prints cycles per wave-instruction per CU at full occupancy)
+// build: hipcc --offload-arch=gfx950 -O3 -o l1bench l1bench.hip ; usage: l1bench  (prints cycles per wave-instruction per CU at full occupancy)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

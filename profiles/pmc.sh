@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch/pmc.sh <tag> "<counters pass 1>" "<counters pass 2>" ... : one rocprofv3 --pmc run per counter set, summary to gpurun_out/<tag>.txt
+# profiles/pmc.sh <tag> "<counters pass 1>" "<counters pass 2>" ... : one rocprofv3 --pmc run per counter set, summary to gpurun_out/<tag>.txt
 tag=$1; shift
 export TMPDIR=/tmp
 i=0

@@ -41,7 +41,7 @@ def make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange):
 
 @pytest.mark.parametrize("planes", [False, True])
 @pytest.mark.parametrize("depth", [8, 10])
-@pytest.mark.parametrize("method", [0, 1, 3])      # DIA, HEX, STAR
+@pytest.mark.parametrize("method", [0, 1, 3, 5])      # DIA, HEX, STAR, FULL
 def test_me_batch_matches_oracle(depth, method, planes):
     api, ora = FrameApi(depth), Oracle(depth)
     rng = np.random.default_rng(77 * depth + method)
@@ -57,7 +57,7 @@ def test_me_batch_matches_oracle(depth, method, planes):
             d_pl = api.torch.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
             api.subpel_planes(d_ref, stride, cur.shape[0], d_pl, pe)
         for (w, h) in PUS:
-            merange = int(rng.choice([8, 16, 57]))
+            merange = int(rng.choice([4, 9, 16] if method == 5 else [8, 16, 57]))
             qp = int(rng.choice([22, 28, 37]))
             subme = int(rng.integers(0, 8))
             n = 24 if w * h <= 1024 else 10

@@ -1,4 +1,4 @@
-// kern_me.hip -- x265hip_me_batch: DIA / HEX kernels live in this translation unit, the STAR kernels (whose pattern
+// kern_me.hip -- x265hip_me_batch: DIA / HEX / FULL kernels live in this translation unit, the STAR kernels (whose pattern
 // code is large and kept out of line) in kern_me_star.hip; both are generated from me_body.inc.
 #include "me_body.inc"
 
@@ -15,8 +15,8 @@ extern "C" int x265hip_me_batch(void* stream, int w, int h, const void* curPlane
     if (n <= 0) return X265HIP_OK;
     if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !tasks || !results || !costRow || costHalfRange < 1)
     { set_error("me_batch: bad arguments"); return X265HIP_EARG; }
-    if (method != X265HIP_ME_DIA && method != X265HIP_ME_HEX && method != X265HIP_ME_STAR)
-    { set_error("me_batch: search method %d is not offloaded (DIA/HEX/STAR are)", method); return X265HIP_EARG; }
+    if (method != X265HIP_ME_DIA && method != X265HIP_ME_HEX && method != X265HIP_ME_STAR && method != X265HIP_ME_FULL)
+    { set_error("me_batch: search method %d is not offloaded (DIA/HEX/STAR/FULL are)", method); return X265HIP_EARG; }
     if (subpelRefine < 0 || subpelRefine > 7 || merange < 1) { set_error("me_batch: bad subme/merange"); return X265HIP_EARG; }
     if (subpelPlanes && (planeElems <= 0 || ((uintptr_t)subpelPlanes & 7))) { set_error("me_batch: bad subpel planes"); return X265HIP_EARG; }
     if (method == X265HIP_ME_STAR)

@@ -96,14 +96,14 @@ __device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const 
 }
 // The lane unit of the size-specialised kernels: 8 bytes of one row (8 pixels at 8 bit, 4 pixels at 16 bit) as packed
 // register data.  8-byte units keep row chunks >= 16 bytes for every PU width >= 16, which is what the L1/TA front end
-// needs to stay at 4 lanes per clock (scratch/l1bench.hip: 4-byte lanes on 8-byte rows cost 1 lane per clock).
+// needs to stay at 4 lanes per clock (profiles/micro/l1bench.hip: 4-byte lanes on 8-byte rows cost 1 lane per clock).
 typedef u32x2 fquad;
 #define XH_UNITPX (8 / (int)sizeof(pixel))
 __device__ __forceinline__ fquad ldq(const pixel* p) { u32x2 a; __builtin_memcpy(&a, p, 8); return a; }              // unaligned, global
 __device__ __forceinline__ fquad ldf(const lpixel* p) { return *(const lu2*)p; }                                     // 8-byte aligned, LDS
 // The same unit at a byte-misaligned address: one DWORD-ALIGNED 12-byte load + two funnel shifts.  The L1/TA front end
 // splits a sub-dword-misaligned wide load into dwords at twice the cost, while dword-aligned x2/x3/x4 loads run at the
-// full 4 lanes per clock whatever their 8/16-byte alignment (scratch/l1bench.hip).  a = address rounded down to 4, m = address & 3.
+// full 4 lanes per clock whatever their 8/16-byte alignment (profiles/micro/l1bench.hip).  a = address rounded down to 4, m = address & 3.
 __device__ __forceinline__ fquad ldq_a(const char* a, unsigned m)
 {
     struct W3 { uint32_t x, y, z; } w;
