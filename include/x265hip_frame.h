@@ -66,13 +66,16 @@ int x265hip_me_batch(void* stream, int w, int h,
                      int merange, int method, int subpelRefine, x265hip_me_result* results,
                      const x265hip_me_result* mvpSource /* may be NULL */,
                      const void* subpelPlanes /* may be NULL: interpolate inside the kernel */, int64_t planeElems);
+/* subpelPlanes, when given, must be the 16-slot buffer x265hip_subpel_planes produced from refPlane (slot 0 == refPlane,
+ * same stride / offsets).  method: DIA, HEX, STAR or FULL (UMH and SEA are not offloaded -> X265HIP_EARG). */
 
 /* Pre-interpolate a padded reference plane (or a stack of planes: `rows` counts every row of the allocation) into
  * its 15 quarter-pel phase planes: outPlanes + f*planeElems for f = yFrac*4 + xFrac = 1..15 holds, at the same
  * (stride, row) addressing as refPlane, exactly luma_hpp / luma_vpp / luma_hvpp of the pixel (ipfilter.cpp:79-118,
- * 164-203, 362-369).  Slot f = 0 is not written (it is refPlane itself).  With the planes, x265hip_me_batch costs
- * every sub-pel candidate as a plain SAD/SATD at an integer offset -- the device-memory-rich version of the
- * reference lookahead's half-pel planes (lowres.h:104-124).  Values within 4 pixels of the allocation border are
+ * 164-203, 362-369).  Slot f = 0 receives a copy of refPlane, so that x265hip_me_batch can address every candidate --
+ * integer or sub-pel -- as "buffer base + 32-bit offset".  With the planes, x265hip_me_batch costs every sub-pel
+ * candidate as a plain SAD/SATD at an integer offset -- the device-memory-rich version of the reference lookahead's
+ * half-pel planes (lowres.h:104-124).  Values within 4 pixels of the allocation border are
  * computed from clamped coordinates and must not be used (they lie in the picture margins).
  * stride and planeElems must be multiples of 4 pixels, planeElems >= stride*rows, 16 planes of planeElems allocated. */
 int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems);
