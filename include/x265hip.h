@@ -141,10 +141,17 @@ int x265hip_blockop_batch(void* stream, int op, int w, int h, const x265hip_blk_
 
 /* transforms (dct.cpp:443-611): n TUs of size N; src item i at src + srcOff[i] with srcStride,
  * dst dense N*N at dst + i*N*N (forward) / the mirror image for inverse. dst4 = DST-VII 4x4. */
-enum x265hip_tr_op { X265HIP_TR_DCT, X265HIP_TR_IDCT, X265HIP_TR_DST4, X265HIP_TR_IDST4 };
+enum x265hip_tr_op { X265HIP_TR_DCT, X265HIP_TR_IDCT, X265HIP_TR_DST4, X265HIP_TR_IDST4,
+                     X265HIP_TR_LOWPASS /* lowPassDct8/16/32_c, lowpassdct.cpp:34-116; N = full block size */ };
 int x265hip_transform_batch(void* stream, int op, int N,
                             const int16_t* src, intptr_t srcStride, const int32_t* srcOff,
                             int16_t* dst, intptr_t dstStride, const int32_t* dstOff, int n);
+
+/* SEA pre-filter pu[].ads (pixel.cpp:121-165; which PU uses x1 / x2 / x4: pixel.cpp:1122-1146): for i in [0, width)
+ * ads = sum |encDC[k] - sums[i + off_k]| + costMvX[i]; positions with ads < thresh are appended, in order, to mvs.
+ * parts = 1, 2 or 4; lx = PU width.  All pointers are device pointers; *nmv receives the count. */
+int x265hip_ads(void* stream, int parts, int lx, const int32_t* encDC, const uint32_t* sums, int delta,
+                const uint16_t* costMvX, int16_t* mvs, int width, int thresh, int32_t* nmv);
 
 /* quant family (dct.cpp:614-715): n dense blocks of numCoeff coefficients each.
  * quantCoeff is ONE numCoeff-long table shared by all blocks (per-TU-size scaling list). */

@@ -132,6 +132,22 @@ class Oracle:
     def dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.lib.xo_dct(n, _ptr(src), _ptr(d), _IP(stride)); return d
 
+    def lowpass_dct(self, n, src, stride):
+        d = np.zeros(n * n, np.int16); self.lib.xo_lowpass_dct(n, _ptr(src), _ptr(d), _IP(stride)); return d
+
+    ADS_X1 = {(4, 4), (8, 8), (16, 12), (12, 16), (16, 4), (4, 16)}
+    ADS_X2 = {(8, 4), (4, 8), (16, 8), (8, 16), (32, 16), (16, 32), (64, 32), (32, 64)}
+
+    @classmethod
+    def ads_parts(cls, w, h):
+        """which ads variant the reference assigns to a PU (pixel.cpp:1122-1146)"""
+        return 1 if (w, h) in cls.ADS_X1 else 2 if (w, h) in cls.ADS_X2 else 4
+
+    def ads(self, w, h, enc, sums, delta, cost, width, thresh):
+        mvs = np.zeros(max(width, 1), np.int16)
+        n = self.lib.xo_ads(self.ads_parts(w, h), w, _ptr(enc), _ptr(sums), delta, _ptr(cost), _ptr(mvs), width, thresh)
+        return int(n), mvs[:n].copy()
+
     def dst4(self, src, stride):
         d = np.zeros(16, np.int16); self.lib.xo_dst4(_ptr(src), _ptr(d), _IP(stride)); return d
 

@@ -235,6 +235,20 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         T.cu[cuIndex(n)].dct(S16(B[0], 0), dp, I[1]);
         Buf o(n * n * 2); memcpy(o.data(), dp, o.size()); out.push_back(o); return true;
     }
+    if (op == "lowpass_dct")
+    {   /* ints = n, srcStride ; bufs = src ; dst dense (cu[].lowpass_dct, lowpassdct.cpp) */
+        int n = (int)I[0]; Buf d(n * n * 2 + 64); int16_t* dp = (int16_t*)(((uintptr_t)d.data() + 31) & ~(uintptr_t)31);
+        T.cu[cuIndex(n)].lowpass_dct(S16(B[0], 0), dp, I[1]);
+        Buf o(n * n * 2); memcpy(o.data(), dp, o.size()); out.push_back(o); return true;
+    }
+    if (op == "ads")
+    {   /* ints = w, h, delta, width, thresh ; bufs = encDC (int32[4]), sums (uint32[]), costMvX (uint16[]) -> nmv, mvs */
+        int width = (int)I[3];
+        Buf mv((size_t)(width > 0 ? width : 1) * 2);
+        int n = T.pu[puIndex((int)I[0], (int)I[1])].ads((int*)B[0].data(), (uint32_t*)B[1].data(), (int)I[2], (uint16_t*)B[2].data(),
+                                                         (int16_t*)mv.data(), width, (int)I[4]);
+        out.push_back(scalar<int32_t>(n)); out.push_back(mv); return true;
+    }
     if (op == "dst4")
     {
         Buf d(32 + 64); int16_t* dp = (int16_t*)(((uintptr_t)d.data() + 31) & ~(uintptr_t)31);
@@ -438,6 +452,7 @@ int main()
     memset(&T, 0, sizeof(T));
     setupPixelPrimitives_c(T);
     setupDCTPrimitives_c(T);
+    for (int i = 0; i < 4; i++) T.cu[i].standard_dct = T.cu[i].dct;      /* enableLowpassDCTPrimitives, primitives.cpp:77-83 (without its dct <- lowpass_dct switch) */
     setupLowPassPrimitives_c(T);
     setupFilterPrimitives_c(T);
     setupIntraPrimitives_c(T);

@@ -364,6 +364,49 @@ void xo_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride)
     fwd_stage(M, n, blk, tmp, lg - 1 + X265_DEPTH - 8);
     fwd_stage(M, n, tmp, dst, lg + 6);
 }
+/* lowpassdct.cpp:34-116: 2x2 means (int16 arithmetic) -> half-size dct -> top-left embed, DC = scaled block sum.
+ * n = size of the full block (8, 16, 32).  The 8x8 variant accumulates the block sum in int16 (:37), the others in int32. */
+void xo_lowpass_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride)
+{
+    const int h = n / 2;
+    int16_t avg[256], coef[256];
+    int32_t total32 = 0; int16_t total16 = 0;
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < h; j++)
+        {
+            int16_t sum = (int16_t)(src[2 * i * srcStride + 2 * j] + src[2 * i * srcStride + 2 * j + 1]
+                                    + src[(2 * i + 1) * srcStride + 2 * j] + src[(2 * i + 1) * srcStride + 2 * j + 1]);
+            avg[i * h + j] = (int16_t)(sum >> 2);
+            total32 += sum; total16 = (int16_t)(total16 + sum);
+        }
+    xo_dct(h, avg, coef, h);
+    memset(dst, 0, (size_t)n * n * sizeof(int16_t));
+    for (int i = 0; i < h; i++) memcpy(dst + i * n, coef + i * h, h * sizeof(int16_t));
+    if (n == 8)
+#if X265_DEPTH == 8
+        dst[0] = (int16_t)(total16 << 1);
+#else
+        dst[0] = (int16_t)(total16 >> (X265_DEPTH - 9));
+#endif
+    else
+        dst[0] = (int16_t)(total32 >> ((n == 16 ? 1 : 3) + (X265_DEPTH - 8)));
+}
+/* pixel.cpp:121-165 ads_x1 / x2 / x4 (SEA pre-filter): which of them a PU uses is the slot map pixel.cpp:1122-1146.
+ * parts = 1, 2 or 4; lx = PU width (the x4 variant reads sums[lx >> 1]). */
+int xo_ads(int parts, int lx, const int* encDC, const uint32_t* sums, int delta, const uint16_t* costMvX, int16_t* mvs, int width, int thresh)
+{
+    int nmv = 0;
+    for (int i = 0; i < width; i++, sums++)
+    {
+        long a = labs((long)encDC[0] - (long)sums[0]);
+        if (parts == 2) a += labs((long)encDC[1] - (long)sums[delta]);
+        if (parts == 4)
+            a += labs((long)encDC[1] - (long)sums[lx >> 1]) + labs((long)encDC[2] - (long)sums[delta]) + labs((long)encDC[3] - (long)sums[delta + (lx >> 1)]);
+        int ads = (int)(a + costMvX[i]);
+        if (ads < thresh) mvs[nmv++] = (int16_t)i;
+    }
+    return nmv;
+}
 /* dct.cpp:528-611: shift1 = 7, shift2 = 12 - (depth-8), clip to int16 after each stage */
 void xo_idct(int n, const int16_t* src, int16_t* dst, intptr_t dstStride)
 {

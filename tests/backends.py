@@ -69,6 +69,13 @@ class Ref:
     def scale2D_64to32(self, dst, src, stride): return self._o(self.r.call("scale2D_64to32", [stride], [dst, src])[0], dst)
 
     def dct(self, n, src, stride): return np.frombuffer(self.r.call("dct", [n, stride], [src])[0], np.int16).copy()
+    def lowpass_dct(self, n, src, stride): return np.frombuffer(self.r.call("lowpass_dct", [n, stride], [src])[0], np.int16).copy()
+
+    def ads(self, w, h, enc, sums, delta, cost, width, thresh):
+        o = self.r.call("ads", [w, h, delta, width, thresh], [enc, sums, cost])
+        n = RefProc.i32(o[0])
+        return n, np.frombuffer(o[1], np.int16)[:n].copy()
+
     def dst4(self, src, stride): return np.frombuffer(self.r.call("dst4", [stride], [src])[0], np.int16).copy()
     def idct(self, n, src, dst, stride): return self._o(self.r.call("idct", [n, stride], [src, dst])[0], dst)
     def idst4(self, src, dst, stride): return self._o(self.r.call("idst4", [stride], [src, dst])[0], dst)
@@ -209,6 +216,15 @@ class Hip:
     # ---- transforms ----
     def dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.h.cu(n, "dct", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def lowpass_dct(self, n, src, stride):
+        d = np.zeros(n * n, np.int16); self.h.cu(n, "lowpass_dct", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def ads(self, w, h, enc, sums, delta, cost, width, thresh):
+        mvs = np.zeros(max(width, 1), np.int16)
+        e = enc.copy()
+        n = self.h.pu(w, h, "ads", _I, (_VP, _VP, _I, _VP, _VP, _I, _I))(_p(e), _p(sums), delta, _p(cost), _p(mvs), width, thresh)
+        return int(n), mvs[:n].copy()
 
     def dst4(self, src, stride):
         d = np.zeros(16, np.int16); self.h.scalar("dst4x4", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d

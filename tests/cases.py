@@ -218,7 +218,32 @@ def cases_intra(depth, rng, reps=2):
                 yield ("allangs %d %s" % (n, kind), "intra_allangs", (n, nb, nb2, int(n <= 16)))
 
 
+def cases_extras(depth, rng, reps=2):
+    """cu[].lowpass_dct (lowpassdct.cpp:34-116) and pu[].ads (pixel.cpp:121-165; the reference's harness has no test for ads)."""
+    pm = (1 << depth) - 1
+    for kind in KINDS:
+        for n in (8, 16, 32):
+            for _ in range(reps):
+                st = int(rng.integers(n, 70))
+                src = short_buf(rng, 70 * 32, kind, -pm, pm)
+                yield ("lowpass_dct %d %s" % (n, kind), "lowpass_dct", (n, src, st))
+    for n in (8, 16, 32):      # full int16 range: the 2x2 sums and the 8x8 block sum wrap in int16 like the reference's
+        yield ("lowpass_dct %d wide" % n, "lowpass_dct", (n, short_buf(rng, 70 * 32, "rand", -32768, 32767), 40))
+    for (w, h) in LUMA_PU:
+        for _ in range(reps):
+            width = int(rng.integers(1, 140))
+            delta = int(rng.integers(8, 300))
+            base = int(rng.integers(0, w * h * pm + 1))
+            span = width + delta + w
+            sums = (base + rng.integers(-4000, 4000, span)).clip(0, None).astype(np.uint32)
+            enc = (base + rng.integers(-3000, 3000, 4)).clip(0, None).astype(np.int32)
+            cost = rng.integers(0, 600, width).astype(np.uint16)
+            thresh = int(rng.integers(500, 9000))
+            yield ("ads %dx%d" % (w, h), "ads", (w, h, enc, sums, delta, cost, width, thresh))
+
+
 FAMILIES = {
+    "extras": cases_extras,
     "pixelcmp": cases_pixelcmp,
     "blockops": cases_blockops,
     "transform": cases_transform,

@@ -19,7 +19,7 @@ from backends import Ref  # noqa: E402
 from cases import FAMILIES, run_case  # noqa: E402
 
 SEED = 0x5EED0000
-KEEP_EVERY = {"pixelcmp": 9, "blockops": 4, "transform": 3, "interp": 11, "intra": 13}
+KEEP_EVERY = {"pixelcmp": 9, "blockops": 4, "transform": 3, "interp": 11, "intra": 13, "extras": 1}
 
 
 def pack(obj, arrays, ids):
@@ -38,9 +38,12 @@ def pack(obj, arrays, ids):
 
 
 def main():
+    only = set(sys.argv[1:])                      # optional: regenerate just the named families
     for depth in (8, 10):
         ref = Ref(depth)
         for fam, gen in sorted(FAMILIES.items()):
+            if only and fam not in only:
+                continue
             rng = np.random.default_rng(SEED + depth)
             arrays, ids, manifest = {}, {}, []
             keep = []  # keep argument arrays alive so id() stays unique

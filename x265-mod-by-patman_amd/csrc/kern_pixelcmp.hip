@@ -209,6 +209,43 @@ __global__ __launch_bounds__(256) void pixelcmp_kernel(int op, int w, int h,
 
 } // namespace
 
+
+namespace {
+// pu[].ads (pixel.cpp:121-165): one wavefront scans the row of candidate x positions 64 at a time; survivors are appended
+// in ascending order through a ballot prefix count.
+__global__ __launch_bounds__(64) void ads_kernel(int parts, int half, const int32_t* __restrict__ encDC, const uint32_t* __restrict__ sums, int delta,
+                                                 const uint16_t* __restrict__ costMvX, int16_t* __restrict__ mvs, int width, int thresh, int32_t* __restrict__ nmvOut)
+{
+    const int lane = threadIdx.x;
+    int nmv = 0;
+    const long long e0 = encDC[0], e1 = parts > 1 ? encDC[1] : 0, e2 = parts > 2 ? encDC[2] : 0, e3 = parts > 2 ? encDC[3] : 0;
+    for (int base = 0; base < width; base += 64)
+    {
+        const int i = base + lane;
+        bool keep = false;
+        if (i < width)
+        {
+            long long a = llabs(e0 - (long long)sums[i]);
+            if (parts == 2) a += llabs(e1 - (long long)sums[i + delta]);
+            if (parts == 4) a += llabs(e1 - (long long)sums[i + half]) + llabs(e2 - (long long)sums[i + delta]) + llabs(e3 - (long long)sums[i + delta + half]);
+            keep = (int)(a + costMvX[i]) < thresh;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) mvs[nmv + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int16_t)i;
+        nmv += __builtin_popcountll(m);
+    }
+    if (lane == 0) *nmvOut = nmv;
+}
+} // namespace
+extern "C" int x265hip_ads(void* stream, int parts, int lx, const int32_t* encDC, const uint32_t* sums, int delta,
+                           const uint16_t* costMvX, int16_t* mvs, int width, int thresh, int32_t* nmv)
+{
+    if ((parts != 1 && parts != 2 && parts != 4) || width < 0 || !encDC || !sums || !costMvX || !mvs || !nmv) { set_error("ads: bad arguments"); return X265HIP_EARG; }
+    hipLaunchKernelGGL(ads_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, parts, lx >> 1, encDC, sums, delta, costMvX, mvs, width, thresh, nmv);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
 extern "C" int x265hip_pixelcmp_batch(void* stream, int op, int w, int h,
                                       const void* a, intptr_t strideA, const int32_t* offA,
                                       const void* b, intptr_t strideB, const int32_t* offB, int n, void* out)

@@ -91,6 +91,66 @@ __global__ __launch_bounds__(256) void transform_kernel(const int16_t* __restric
     }
 }
 
+
+// lowPassDct8/16/32_c (lowpassdct.cpp:34-116): 2x2 means of the residual (int16 arithmetic like the reference), forward DCT
+// of the half-size block, embedded top-left in a zeroed full-size block, DC replaced by the scaled block sum.
+// One workgroup per TU; H = half size (4, 8, 16).
+template<int H>
+__global__ __launch_bounds__(256) void lowpass_kernel(const int16_t* __restrict__ src, intptr_t ss, const int32_t* __restrict__ sOff,
+                                                      int16_t* __restrict__ dst, const int32_t* __restrict__ dOff, int n)
+{
+    constexpr int N = 2 * H, HH = H * H;
+    __shared__ int16_t sA[HH], sB[HH];
+    __shared__ int8_t sM[HH];
+    __shared__ int sSum;
+    const int tu = blockIdx.x, t = threadIdx.x;
+    if (tu >= n) return;
+    const intptr_t so = sOff ? (intptr_t)sOff[tu] : (intptr_t)tu * N * N;
+    const intptr_t dofs = dOff ? (intptr_t)dOff[tu] : (intptr_t)tu * N * N;
+    if (t == 0) sSum = 0;
+    for (int i = t; i < HH; i += 256) sM[i] = (int8_t)dct_coef((i / H) * (32 / H), i % H);
+    __syncthreads();
+    for (int i = t; i < HH; i += 256)
+    {
+        const int r = i / H, c = i % H;
+        const int16_t* p = src + so + (2 * r) * ss + 2 * c;
+        const int16_t sum = (int16_t)(p[0] + p[1] + p[ss] + p[ss + 1]);
+        sA[i] = (int16_t)(sum >> 2);
+        atomicAdd(&sSum, (int)sum);
+    }
+    __syncthreads();
+    constexpr int LG = H == 4 ? 2 : H == 8 ? 3 : 4;
+    const int shift1 = LG - 1 + X265_DEPTH - 8, shift2 = LG + 6;
+#pragma unroll
+    for (int stage = 0; stage < 2; stage++)
+    {
+        const int shift = stage ? shift2 : shift1, add = 1 << (shift - 1);
+        const int16_t* in = stage ? sB : sA;
+        int16_t* outp = stage ? sA : sB;
+        for (int i = t; i < HH; i += 256)
+        {
+            const int pp = i / H, q = i % H;
+            int s = 0;
+#pragma unroll
+            for (int m = 0; m < H; m++) s += (int)sM[pp * H + m] * (int)in[q * H + m];
+            outp[i] = (int16_t)((s + add) >> shift);
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < N * N; i += 256)
+    {
+        const int r = i / N, c = i % N;
+        int16_t v = (r < H && c < H) ? sA[r * H + c] : (int16_t)0;
+        if (i == 0)
+        {
+            const int total = sSum;
+            if (N == 8) v = X265_DEPTH == 8 ? (int16_t)((int16_t)total << 1) : (int16_t)((int16_t)total >> (X265_DEPTH - 9 > 0 ? X265_DEPTH - 9 : 0));   // int16 block sum (:37)
+            else v = (int16_t)(total >> ((N == 16 ? 1 : 3) + (X265_DEPTH - 8)));
+        }
+        dst[dofs + i] = v;
+    }
+}
+
 template<int N, int OP> int launch_tr(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t* sOff,
                                       int16_t* dst, intptr_t ds, const int32_t* dOff, int n)
 {
@@ -206,6 +266,15 @@ extern "C" int x265hip_transform_batch(void* stream, int op, int N, const int16_
         if (N != 4) { set_error("DST exists for 4x4 only"); return X265HIP_EARG; }
         return op == X265HIP_TR_DST4 ? launch_tr<4, X265HIP_TR_DST4>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n)
                                      : launch_tr<4, X265HIP_TR_IDST4>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n);
+    }
+    if (op == X265HIP_TR_LOWPASS)
+    {
+        if (N == 8) hipLaunchKernelGGL(lowpass_kernel<4>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
+        else if (N == 16) hipLaunchKernelGGL(lowpass_kernel<8>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
+        else if (N == 32) hipLaunchKernelGGL(lowpass_kernel<16>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
+        else { set_error("lowpass dct exists for 8, 16 and 32"); return X265HIP_EARG; }
+        XH_LAUNCH_CHECK();
+        return X265HIP_OK;
     }
     if (op != X265HIP_TR_DCT && op != X265HIP_TR_IDCT) { set_error("transform_batch: unknown op %d", op); return X265HIP_EARG; }
     const bool f = op == X265HIP_TR_DCT;

@@ -110,6 +110,31 @@ template<int W, int H> void s_sad_x3(const pixel* f, const pixel* r0, const pixe
 template<int W, int H> void s_sad_x4(const pixel* f, const pixel* r0, const pixel* r1, const pixel* r2, const pixel* r3, intptr_t rs, int32_t* res)
 { const pixel* r[4] = { r0, r1, r2, r3 }; slot_sad_xn(4, W, H, f, r, rs, res); }
 
+// pu[].ads (pixel.cpp:121-165); which variant a PU gets is the reference's slot map (pixel.cpp:1122-1146)
+constexpr int ads_parts(int w, int h)
+{
+    return ((w == 4 && h == 4) || (w == 8 && h == 8) || (w == 16 && h == 12) || (w == 12 && h == 16) || (w == 16 && h == 4) || (w == 4 && h == 16)) ? 1
+         : ((w == 8 && h == 4) || (w == 4 && h == 8) || (w == 16 && h == 8) || (w == 8 && h == 16) || (w == 32 && h == 16) || (w == 16 && h == 32) ||
+            (w == 64 && h == 32) || (w == 32 && h == 64)) ? 2 : 4;
+}
+template<int W, int H> int s_ads(int* encDC, uint32_t* sums, int delta, uint16_t* costMvX, int16_t* mvs, int width, int thresh)
+{
+    constexpr int P = ads_parts(W, H);
+    ThreadCtx& c = ThreadCtx::get(); c.reset();
+    if (width <= 0) return 0;
+    const int span = width + (P > 1 ? delta : 0) + (P == 4 ? (W >> 1) : 0);
+    DevBlock E = stage_in(c, encDC, 4, P, 1, 4), S = stage_in(c, sums, span, span, 1, 4), M = stage_in(c, costMvX, width, width, 1, 2);
+    int16_t* dm = (int16_t*)c.dalloc((size_t)width * 2); int32_t* dn = (int32_t*)c.dalloc(8);
+    XH_OK(x265hip_ads(c.stream, P, W, (const int32_t*)E.ptr, (const uint32_t*)S.ptr, delta, (const uint16_t*)M.ptr, dm, width, thresh, dn));
+    const int nmv = fetch_scalar<int32_t>(c, dn);
+    if (nmv > 0)
+    {
+        if (hipMemcpyAsync(mvs, dm, (size_t)nmv * 2, hipMemcpyDeviceToHost, c.stream) != hipSuccess) fatal("ads D2H");
+        c.sync();
+    }
+    return nmv;
+}
+
 #include "xh_slots_blk.inc"
 #include "xh_slots_tr.inc"
 #include "xh_slots_ip.inc"
@@ -133,7 +158,7 @@ extern "C" int x265hip_setup_primitives(void* encoder_primitives, int bit_depth,
 
 #define FILL_PU(i, W, H) \
     PU(i, X265HIP_PU_SAD) = (void*)s_sad<W, H>; PU(i, X265HIP_PU_SAD_X3) = (void*)s_sad_x3<W, H>; \
-    PU(i, X265HIP_PU_SAD_X4) = (void*)s_sad_x4<W, H>; PU(i, X265HIP_PU_SATD) = (void*)s_satd<W, H>;
+    PU(i, X265HIP_PU_SAD_X4) = (void*)s_sad_x4<W, H>; PU(i, X265HIP_PU_SATD) = (void*)s_satd<W, H>; PU(i, X265HIP_PU_ADS) = (void*)s_ads<W, H>;
     XH_FOR_EACH_PU(FILL_PU)
 #define FILL_CU(i, N) \
     CU(i, X265HIP_CU_SA8D) = (void*)s_sa8d<N>; CU(i, X265HIP_CU_PSY_COST_PP) = (void*)s_psy<N>; \
