@@ -122,6 +122,20 @@ __device__ __forceinline__ void unpackq(fquad a, int* v)
 __device__ __forceinline__ unsigned sadq(fquad f, fquad r, unsigned acc) { return __builtin_amdgcn_sad_u16(f.y, r.y, __builtin_amdgcn_sad_u16(f.x, r.x, acc)); }
 __device__ __forceinline__ void unpackq(fquad a, int* v) { v[0] = a.x & 0xFFFF; v[1] = a.x >> 16; v[2] = a.y & 0xFFFF; v[3] = a.y >> 16; }
 #endif
+// 4 pixels at byte offset `bo` from a (wave-uniform) base: dword-aligned load(s) + funnel shift, like ldq_a
+__device__ __forceinline__ void load4a(const char* base, uint32_t bo, int* v)
+{
+    const uint32_t m = bo & 3u;
+    const char* a = base + (size_t)(bo - m);
+#if X265_DEPTH == 8
+    u32x2 w; __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 8);
+    const uint32_t x = __builtin_amdgcn_alignbyte(w.y, w.x, m);
+    v[0] = x & 0xFF; v[1] = (x >> 8) & 0xFF; v[2] = (x >> 16) & 0xFF; v[3] = x >> 24;
+#else
+    const fquad q = ldq_a(a, m);
+    v[0] = q.x & 0xFFFF; v[1] = q.x >> 16; v[2] = q.y & 0xFFFF; v[3] = q.y >> 16;
+#endif
+}
 // 11 consecutive pixels starting at p (unaligned, global): what a 4-wide 8-tap horizontal filter needs
 __device__ __forceinline__ void load11u(const pixel* p, int* v)
 {
