@@ -147,13 +147,11 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
     }
     __syncthreads();
 
-    if (t < 96)
-    {   // ---- H: 4 rows x 4 pixels per thread: intermediates for the three xFracs + the yFrac == 0 planes ----
-        const int rb = t >> 4, q = t & 15;
+    if (t < 192)
+    {   // ---- H: 2 rows x 4 pixels per thread: intermediates for the three xFracs + the yFrac == 0 planes ----
+        const int rb = t >> 5, pb = (t >> 4) & 1, q = t & 15;
         const int gx = x0 + 4 * q;
         const uint32_t hoff = (uint32_t)(4 * rb) * (uint32_t)stride + 4 * q;         // thread part of the store address (bytes = pixels)
-#pragma unroll
-        for (int pb = 0; pb < 2; pb++)
         {
             uint32_t lo[2][4], hi[2][4];
 #pragma unroll
@@ -187,9 +185,9 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
             }
         }
     }
-    else if (t >= 128 && t < 192)
+    else
     {   // ---- V: 4 columns x 4 rows per thread straight from the pixels: the xFrac == 0 planes ----
-        const int i = t - 128, rq = i >> 4, cq = i & 15;
+        const int i = t - 192, rq = i >> 4, cq = i & 15;
         const int gx = x0 + 4 * cq;
         const uint32_t voff = (uint32_t)(4 * rq) * (uint32_t)stride + 4 * cq;
         uint32_t lo[4][4], hi[4][4];
