@@ -81,6 +81,7 @@ enum x265hip_cu_slot {
 #define X265HIP_OFF_DENOISEDCT 6768
 #define X265HIP_OFF_SCALE1D_128TO64 6776   /* [2] */
 #define X265HIP_OFF_SCALE2D_64TO32 6792
+#define X265HIP_OFF_EXTENDROWBORDER 6968
 #define X265HIP_OFF_WEIGHT_SP 7016
 #define X265HIP_OFF_WEIGHT_PP 7024
 /* pointer index inside Chroma::PUChroma / CUChroma (primitives.h:399-428) */
@@ -146,6 +147,13 @@ enum x265hip_tr_op { X265HIP_TR_DCT, X265HIP_TR_IDCT, X265HIP_TR_DST4, X265HIP_T
 int x265hip_transform_batch(void* stream, int op, int N,
                             const int16_t* src, intptr_t srcStride, const int32_t* srcOff,
                             int16_t* dst, intptr_t dstStride, const int32_t* dstOff, int n);
+
+/* Reference-plane preparation: extendPicBorder (pixel.cpp:1044-1058) on nPictures padded pictures of one
+ * device allocation -- picOrg = pixel (0,0) of picture 0, picture i at picOrg + i*pictureElems.  Rows are widened first
+ * (p.extendRowBorder, ipfilter.cpp:59-77), then the widened top / bottom rows are replicated into the vertical margins,
+ * so a reconstructed frame becomes a searchable reference without leaving HBM. */
+int x265hip_extend_pic_border(void* stream, void* picOrg, intptr_t stride, int width, int height, int marginX, int marginY,
+                              int nPictures, int64_t pictureElems);
 
 /* SEA pre-filter pu[].ads (pixel.cpp:121-165; which PU uses x1 / x2 / x4: pixel.cpp:1122-1146): for i in [0, width)
  * ads = sum |encDC[k] - sums[i + off_k]| + costMvX[i]; positions with ads < thresh are appended, in order, to mvs.

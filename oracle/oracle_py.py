@@ -132,6 +132,12 @@ class Oracle:
     def dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.lib.xo_dct(n, _ptr(src), _ptr(d), _IP(stride)); return d
 
+    def extend_pic_border(self, plane, stride, width, height, mx, my):
+        d = plane.copy(); self.lib.xo_extend_pic_border(_ptr(d, my * stride + mx), _IP(stride), width, height, mx, my); return d
+
+    def extend_row_border(self, rows, stride, width, height, mx):
+        d = rows.copy(); self.lib.xo_extend_row_border(_ptr(d, mx), _IP(stride), width, height, mx); return d
+
     def lowpass_dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.lib.xo_lowpass_dct(n, _ptr(src), _ptr(d), _IP(stride)); return d
 

@@ -125,6 +125,7 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         OFF(chroma[0].pu[0].filter_hps); OFF(chroma[0].pu[0].addAvg); OFF(chroma[0].pu[0].copy_pp); OFF(chroma[0].pu[0].p2s);
         OFF(chroma[0].cu); OFF(chroma[0].cu[1]); OFF(chroma[0].cu[0].sa8d); OFF(chroma[0].cu[0].sse_pp); OFF(chroma[0].cu[0].sub_ps);
         OFF(chroma[0].cu[0].add_ps); OFF(chroma[0].cu[0].copy_ps); OFF(chroma[0].cu[0].copy_sp); OFF(chroma[0].cu[0].copy_ss); OFF(chroma[0].cu[0].copy_pp);
+        OFF(extendRowBorder);
 #undef OFF
         v.push_back((int32_t)sizeof(EncoderPrimitives));
         Buf b(v.size() * 4); memcpy(b.data(), v.data(), b.size()); out.push_back(b);
@@ -234,6 +235,17 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         int n = (int)I[0]; Buf d(n * n * 2 + 64); int16_t* dp = (int16_t*)(((uintptr_t)d.data() + 31) & ~(uintptr_t)31);
         T.cu[cuIndex(n)].dct(S16(B[0], 0), dp, I[1]);
         Buf o(n * n * 2); memcpy(o.data(), dp, o.size()); out.push_back(o); return true;
+    }
+    if (op == "extend_pic_border")
+    {   /* ints = stride, width, height, marginX, marginY ; bufs = padded plane (in/out), picture origin at (marginX, marginY) */
+        pixel* pic = PX(B[0], 0) + I[4] * I[0] + I[3];
+        extendPicBorder(pic, I[0], (int)I[1], (int)I[2], (int)I[3], (int)I[4]);          /* pixel.cpp:1044-1058 */
+        out.push_back(B[0]); return true;
+    }
+    if (op == "extend_row_border")
+    {   /* the table slot alone (ipfilter.cpp:59-77): ints = stride, width, height, marginX ; bufs = rows (in/out), origin at x = marginX */
+        T.extendRowBorder(PX(B[0], 0) + I[3], I[0], (int)I[1], (int)I[2], (int)I[3]);
+        out.push_back(B[0]); return true;
     }
     if (op == "lowpass_dct")
     {   /* ints = n, srcStride ; bufs = src ; dst dense (cu[].lowpass_dct, lowpassdct.cpp) */

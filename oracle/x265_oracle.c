@@ -364,6 +364,24 @@ void xo_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride)
     fwd_stage(M, n, blk, tmp, lg - 1 + X265_DEPTH - 8);
     fwd_stage(M, n, tmp, dst, lg + 6);
 }
+/* ipfilter.cpp:59-77 extendCURowColBorder (the p.extendRowBorder slot): replicate the first / last pixel of each row into the margins */
+void xo_extend_row_border(xo_pixel* txt, intptr_t stride, int width, int height, int marginX)
+{
+    for (int y = 0; y < height; y++, txt += stride)
+        for (int x = 0; x < marginX; x++) { txt[-marginX + x] = txt[0]; txt[width + x] = txt[width - 1]; }
+}
+/* pixel.cpp:1044-1058 extendPicBorder: rows first, then the (already widened) top / bottom rows into the vertical margins */
+void xo_extend_pic_border(xo_pixel* pic, intptr_t stride, int width, int height, int marginX, int marginY)
+{
+    xo_extend_row_border(pic, stride, width, height, marginX);
+    xo_pixel* top = pic - marginX;
+    xo_pixel* bot = pic - marginX + (intptr_t)(height - 1) * stride;
+    for (int y = 0; y < marginY; y++)
+    {
+        memcpy(top - (intptr_t)(y + 1) * stride, top, (size_t)stride * sizeof(xo_pixel));
+        memcpy(bot + (intptr_t)(y + 1) * stride, bot, (size_t)stride * sizeof(xo_pixel));
+    }
+}
 /* lowpassdct.cpp:34-116: 2x2 means (int16 arithmetic) -> half-size dct -> top-left embed, DC = scaled block sum.
  * n = size of the full block (8, 16, 32).  The 8x8 variant accumulates the block sum in int16 (:37), the others in int32. */
 void xo_lowpass_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride)

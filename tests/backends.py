@@ -69,6 +69,12 @@ class Ref:
     def scale2D_64to32(self, dst, src, stride): return self._o(self.r.call("scale2D_64to32", [stride], [dst, src])[0], dst)
 
     def dct(self, n, src, stride): return np.frombuffer(self.r.call("dct", [n, stride], [src])[0], np.int16).copy()
+    def extend_pic_border(self, plane, stride, width, height, mx, my):
+        return self._o(self.r.call("extend_pic_border", [stride, width, height, mx, my], [plane])[0], plane)
+
+    def extend_row_border(self, rows, stride, width, height, mx):
+        return self._o(self.r.call("extend_row_border", [stride, width, height, mx], [rows])[0], rows)
+
     def lowpass_dct(self, n, src, stride): return np.frombuffer(self.r.call("lowpass_dct", [n, stride], [src])[0], np.int16).copy()
 
     def ads(self, w, h, enc, sums, delta, cost, width, thresh):
@@ -216,6 +222,20 @@ class Hip:
     # ---- transforms ----
     def dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.h.cu(n, "dct", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def extend_pic_border(self, plane, stride, width, height, mx, my):
+        # device entry point (planes live in HBM); host staging here only for the comparison
+        import torch
+        d = torch.from_numpy(plane.view(np.uint8 if plane.dtype == np.uint8 else np.int16).copy()).cuda()
+        org = d.data_ptr() + (my * stride + mx) * plane.dtype.itemsize
+        self.h.check(self.h.lib.x265hip_extend_pic_border(None, _C.c_void_p(org), _C.c_ssize_t(stride), width, height, mx, my, 1, _C.c_int64(0)))
+        torch.cuda.synchronize()
+        return d.cpu().numpy().view(plane.dtype)
+
+    def extend_row_border(self, rows, stride, width, height, mx):
+        d = rows.copy()
+        self.h.scalar("extendRowBorder", None, (_VP, _IP, _I, _I, _I))(_p(d, mx), stride, width, height, mx)
+        return d
 
     def lowpass_dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.h.cu(n, "lowpass_dct", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d

@@ -229,6 +229,15 @@ def cases_extras(depth, rng, reps=2):
                 yield ("lowpass_dct %d %s" % (n, kind), "lowpass_dct", (n, src, st))
     for n in (8, 16, 32):      # full int16 range: the 2x2 sums and the 8x8 block sum wrap in int16 like the reference's
         yield ("lowpass_dct %d wide" % n, "lowpass_dct", (n, short_buf(rng, 70 * 32, "rand", -32768, 32767), 40))
+    for kind in KINDS:         # reference-plane preparation: extendPicBorder (pixel.cpp:1044-1058) and its row slot (ipfilter.cpp:59-77)
+        for _ in range(reps):
+            w, h = int(rng.integers(8, 90)), int(rng.integers(4, 40))
+            mx, my = int(rng.choice([4, 16, 40, 96])), int(rng.integers(1, 20))
+            stride = w + 2 * mx + 4 * int(rng.integers(0, 3))
+            plane = pix_buf(rng, depth, stride * (h + 2 * my), kind if kind != "rand" else "rand")
+            yield ("extend_pic_border %dx%d %s" % (w, h, kind), "extend_pic_border", (plane, stride, w, h, mx, my))
+            rows = pix_buf(rng, depth, stride * h, "rand")
+            yield ("extend_row_border %dx%d" % (w, h), "extend_row_border", (rows, stride, w, h, mx))
     for (w, h) in LUMA_PU:
         for _ in range(reps):
             width = int(rng.integers(1, 140))

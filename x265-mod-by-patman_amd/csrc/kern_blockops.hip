@@ -101,6 +101,44 @@ template<int OP> int launch(hipStream_t st, int w, int h, const BlkArgs& a, int 
 
 } // namespace
 
+// ---- extendPicBorder (pixel.cpp:1044-1058) / p.extendRowBorder (ipfilter.cpp:59-77) on pictures resident in HBM ----
+// grid.x walks the rows of the padded picture (height + 2*marginY), grid.y the pictures.  A row of the picture proper gets
+// its two margins; a margin row is a copy of the widened first / last picture row, built from that row's end pixels so
+// that the launch has no ordering between rows.
+namespace {
+__global__ __launch_bounds__(256) void extend_border_kernel(pixel* __restrict__ picOrg, intptr_t stride, int width, int height, int marginX, int marginY,
+                                                            int64_t pictureElems)
+{
+    pixel* pic = picOrg + (int64_t)blockIdx.y * pictureElems;
+    const int row = (int)blockIdx.x - marginY;                          // -marginY .. height + marginY - 1
+    const int srcRow = min(max(row, 0), height - 1);
+    const pixel* src = pic + (intptr_t)srcRow * stride;
+    pixel* dst = pic + (intptr_t)row * stride;
+    const pixel left = src[0], right = src[width - 1];
+    if (row == srcRow)
+    {   // picture row: only the margins are written
+        for (int x = threadIdx.x; x < marginX; x += 256) { dst[-marginX + x] = left; dst[width + x] = right; }
+    }
+    else
+    {   // margin row: the whole widened row -- `stride` elements from the row start like the reference's memcpy, i.e.
+        // including whatever lies between the right margin and the next row (pixel.cpp:1050-1057)
+        for (int x = threadIdx.x - marginX; x < (int)stride - marginX; x += 256)
+            dst[x] = x < 0 ? left : (x < width ? src[x] : (x < width + marginX ? right : src[x]));
+    }
+}
+} // namespace
+extern "C" int x265hip_extend_pic_border(void* stream, void* picOrg, intptr_t stride, int width, int height, int marginX, int marginY,
+                                         int nPictures, int64_t pictureElems)
+{
+    if (nPictures <= 0) return X265HIP_OK;
+    if (!picOrg || width <= 0 || height <= 0 || marginX < 0 || marginY < 0 || stride < width + 2 * marginX)
+    { set_error("extend_pic_border: bad arguments"); return X265HIP_EARG; }
+    hipLaunchKernelGGL(extend_border_kernel, dim3((unsigned)(height + 2 * marginY), (unsigned)nPictures), dim3(256), 0, (hipStream_t)stream,
+                       (pixel*)picOrg, stride, width, height, marginX, marginY, pictureElems);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
 extern "C" int x265hip_blockop_batch(void* stream, int op, int w, int h, const x265hip_blk_args* args, int n)
 {
     if (n <= 0) return X265HIP_OK;
