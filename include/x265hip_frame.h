@@ -98,6 +98,8 @@ typedef struct x265hip_tq_params {
     int add;                     /* quant rounding numerator: 171 (intra) or 85 (inter), << (qBits-9) */
     const int32_t* quantCoeff;   /* numCoeff-long table or NULL = flat s_quantScales[rem] (scalinglist.cpp:129) */
     int32_t* deltaU;             /* optional: n * N*N int32 (quant_c's deltaU) or NULL                */
+    const void* subpelPlanes;    /* optional: the 16-slot buffer x265hip_subpel_planes made from refPlane -> motion     */
+    int64_t planeElems;          /*           compensation is a copy out of slot 4*yFrac + xFrac instead of a filter    */
 } x265hip_tq_params;
 
 int x265hip_tq_batch(void* stream, int log2TrSize,

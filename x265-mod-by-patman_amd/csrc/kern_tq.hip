@@ -24,6 +24,7 @@ struct TqArgs
     int16_t* coeff; uint32_t* numSig;
     pixel* recon; intptr_t reconStride; uint64_t* sse;
     const x265hip_me_result* mvSource;
+    const pixel* planes; int64_t planeElems;
 };
 
 template<int N> struct Lg { static const int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5; };
@@ -72,8 +73,19 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     lshort* sb = (lshort*)s_b[wave];
     const lpixel* pred = c.pred;
 
-    // ---- motion compensation into LDS (ends with a wave_sync) ----
-    build_pred(c, tk.mv[0], tk.mv[1]);
+    // ---- motion compensation into LDS (ends with a wave_sync): the reference's copy_pp | hpp | vpp | hvpp dispatch, or -- with
+    //      the phase planes of this reference -- a copy of the block at the integer part of the MV out of plane 4*yFrac + xFrac ----
+    if (a.planes)
+    {
+        const int f = (tk.mv[1] & 3) * 4 + (tk.mv[0] & 3);
+        const pixel* src = (f ? a.planes + (int64_t)f * a.planeElems : a.ref) + tk.refOff + (intptr_t)(tk.mv[1] >> 2) * a.rs + (tk.mv[0] >> 2);
+        QUAD_LOOP(c, q, y, x4)
+            int v[4]; load4u(src + (intptr_t)y * a.rs + x4, v); store4(c.pred + y * N + x4, v);
+        QUAD_END
+        wave_sync();
+    }
+    else
+        build_pred(c, tk.mv[0], tk.mv[1]);
 
     // ---- residual (kept in LDS; the source quad is re-read from L2 for the SSE only when recon is requested) ----
     const pixel* cur = a.cur + tk.curOff;
@@ -262,7 +274,7 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
     { set_error("tq_batch: bad arguments"); return X265HIP_EARG; }
     TqArgs a = { (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride, tasks, n,
                  params->qp, params->add, params->quantCoeff, params->deltaU, coeff, numSig,
-                 (pixel*)reconPlane, reconStride, sse, mvSource };
+                 (pixel*)reconPlane, reconStride, sse, mvSource, (const pixel*)params->subpelPlanes, params->planeElems };
     hipStream_t st = (hipStream_t)stream;
     switch (log2TrSize)
     {

@@ -17,7 +17,8 @@ assert ME_TASK.itemsize == 44 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize 
 
 
 class TqParams(C.Structure):
-    _fields_ = [("qp", C.c_int), ("add", C.c_int), ("quantCoeff", C.c_void_p), ("deltaU", C.c_void_p)]
+    _fields_ = [("qp", C.c_int), ("add", C.c_int), ("quantCoeff", C.c_void_p), ("deltaU", C.c_void_p),
+                ("subpelPlanes", C.c_void_p), ("planeElems", C.c_int64)]
 
 
 def mvcost_row(depth, qp, half):
@@ -64,8 +65,8 @@ class FrameApi:
         self.h.check(self.lib.x265hip_subpel_planes(self.stream(), _dp(ref), C.c_ssize_t(stride), rows, _dp(out_planes), C.c_int64(plane_elems)))
 
     def tq_batch(self, log2n, cur, cstride, ref, rstride, tasks, n, qp, add, coeff, numsig, quant_coeff=None, delta_u=None,
-                 recon=None, recon_stride=0, sse=None, mv_source=None):
-        p = TqParams(qp, add, _dp(quant_coeff), _dp(delta_u))
+                 recon=None, recon_stride=0, sse=None, mv_source=None, planes=None, plane_elems=0):
+        p = TqParams(qp, add, _dp(quant_coeff), _dp(delta_u), _dp(planes), plane_elems if planes is not None else 0)
         self.h.check(self.lib.x265hip_tq_batch(self.stream(), log2n, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
                                                _dp(tasks), n, C.byref(p), _dp(coeff), _dp(numsig),
                                                _dp(recon), C.c_ssize_t(recon_stride), _dp(sse), _dp(mv_source)))

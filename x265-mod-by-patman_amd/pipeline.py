@@ -123,7 +123,8 @@ class FramePipeline:
     def launch_tq(self):
         self.api.tq_batch(self.tu_log2, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tu, len(self.tu_host), self.qp, 85,
                           self.d_coeff, self.d_numsig, recon=self.d_recon, recon_stride=self.stride, sse=self.d_sse,
-                          mv_source=self.d_results[self.mv_level])
+                          mv_source=self.d_results[self.mv_level],
+                          planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
 
     def step(self):
         if self.use_planes:
