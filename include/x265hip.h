@@ -81,6 +81,8 @@ enum x265hip_cu_slot {
 #define X265HIP_OFF_DENOISEDCT 6768
 #define X265HIP_OFF_SCALE1D_128TO64 6776   /* [2] */
 #define X265HIP_OFF_SCALE2D_64TO32 6792
+#define X265HIP_OFF_FRAMEINITLOWRES 6928
+#define X265HIP_OFF_FRAMEINITLOWERRES 6936
 #define X265HIP_OFF_EXTENDROWBORDER 6968
 #define X265HIP_OFF_WEIGHT_SP 7016
 #define X265HIP_OFF_WEIGHT_PP 7024
@@ -147,6 +149,12 @@ enum x265hip_tr_op { X265HIP_TR_DCT, X265HIP_TR_IDCT, X265HIP_TR_DST4, X265HIP_T
 int x265hip_transform_batch(void* stream, int op, int N,
                             const int16_t* src, intptr_t srcStride, const int32_t* srcOff,
                             int16_t* dst, intptr_t dstStride, const int32_t* dstOff, int n);
+
+/* Lookahead plane preparation: frame_init_lowres_core (pixel.cpp:596-622) -- the half-resolution plane and its
+ * three half-pel companions of a width x height LOWRES picture; reads source rows 0 .. 2*height and columns 0 .. 2*width.
+ * Device pointers. */
+int x265hip_frame_init_lowres(void* stream, const void* src, intptr_t srcStride, void* dst0, void* dsth, void* dstv, void* dstc,
+                              intptr_t dstStride, int width, int height);
 
 /* Reference-plane preparation: extendPicBorder (pixel.cpp:1044-1058) on nPictures padded pictures of one
  * device allocation -- picOrg = pixel (0,0) of picture 0, picture i at picOrg + i*pictureElems.  Rows are widened first

@@ -132,6 +132,11 @@ class Oracle:
     def dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.lib.xo_dct(n, _ptr(src), _ptr(d), _IP(stride)); return d
 
+    def frame_init_lowres(self, src, ss, d0, dh, dv, dc, ds, width, height):
+        o = [d.copy() for d in (d0, dh, dv, dc)]
+        self.lib.xo_frame_init_lowres(_ptr(src), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3]), _IP(ss), _IP(ds), width, height)
+        return tuple(o)
+
     def extend_pic_border(self, plane, stride, width, height, mx, my):
         d = plane.copy(); self.lib.xo_extend_pic_border(_ptr(d, my * stride + mx), _IP(stride), width, height, mx, my); return d
 

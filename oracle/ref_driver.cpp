@@ -125,7 +125,7 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         OFF(chroma[0].pu[0].filter_hps); OFF(chroma[0].pu[0].addAvg); OFF(chroma[0].pu[0].copy_pp); OFF(chroma[0].pu[0].p2s);
         OFF(chroma[0].cu); OFF(chroma[0].cu[1]); OFF(chroma[0].cu[0].sa8d); OFF(chroma[0].cu[0].sse_pp); OFF(chroma[0].cu[0].sub_ps);
         OFF(chroma[0].cu[0].add_ps); OFF(chroma[0].cu[0].copy_ps); OFF(chroma[0].cu[0].copy_sp); OFF(chroma[0].cu[0].copy_ss); OFF(chroma[0].cu[0].copy_pp);
-        OFF(extendRowBorder);
+        OFF(extendRowBorder); OFF(frameInitLowres); OFF(frameInitLowerRes);
 #undef OFF
         v.push_back((int32_t)sizeof(EncoderPrimitives));
         Buf b(v.size() * 4); memcpy(b.data(), v.data(), b.size()); out.push_back(b);
@@ -235,6 +235,11 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         int n = (int)I[0]; Buf d(n * n * 2 + 64); int16_t* dp = (int16_t*)(((uintptr_t)d.data() + 31) & ~(uintptr_t)31);
         T.cu[cuIndex(n)].dct(S16(B[0], 0), dp, I[1]);
         Buf o(n * n * 2); memcpy(o.data(), dp, o.size()); out.push_back(o); return true;
+    }
+    if (op == "frame_init_lowres")
+    {   /* ints = srcStride, dstStride, width, height (lowres size) ; bufs = src, dst0, dsth, dstv, dstc (outs pre-filled) */
+        T.frameInitLowres(PX(B[0], 0), PX(B[1], 0), PX(B[2], 0), PX(B[3], 0), PX(B[4], 0), I[0], I[1], (int)I[2], (int)I[3]);
+        out.push_back(B[1]); out.push_back(B[2]); out.push_back(B[3]); out.push_back(B[4]); return true;
     }
     if (op == "extend_pic_border")
     {   /* ints = stride, width, height, marginX, marginY ; bufs = padded plane (in/out), picture origin at (marginX, marginY) */

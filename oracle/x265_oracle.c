@@ -364,6 +364,25 @@ void xo_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride)
     fwd_stage(M, n, blk, tmp, lg - 1 + X265_DEPTH - 8);
     fwd_stage(M, n, tmp, dst, lg + 6);
 }
+/* pixel.cpp:596-622 frame_init_lowres_core (p.frameInitLowres / frameInitLowerRes): half-resolution plane + its three
+ * half-pel companions, each a rounded average of rounded vertical averages ("slower than naive bilinear, but matches asm") */
+void xo_frame_init_lowres(const xo_pixel* src0, xo_pixel* dst0, xo_pixel* dsth, xo_pixel* dstv, xo_pixel* dstc,
+                          intptr_t srcStride, intptr_t dstStride, int width, int height)
+{
+#define XO_F(a, b, c, d) ((((a + b + 1) >> 1) + ((c + d + 1) >> 1) + 1) >> 1)
+    for (int y = 0; y < height; y++)
+    {
+        const xo_pixel* s0 = src0 + (intptr_t)(2 * y) * srcStride; const xo_pixel* s1 = s0 + srcStride; const xo_pixel* s2 = s1 + srcStride;
+        for (int x = 0; x < width; x++)
+        {
+            dst0[y * dstStride + x] = (xo_pixel)XO_F(s0[2 * x], s1[2 * x], s0[2 * x + 1], s1[2 * x + 1]);
+            dsth[y * dstStride + x] = (xo_pixel)XO_F(s0[2 * x + 1], s1[2 * x + 1], s0[2 * x + 2], s1[2 * x + 2]);
+            dstv[y * dstStride + x] = (xo_pixel)XO_F(s1[2 * x], s2[2 * x], s1[2 * x + 1], s2[2 * x + 1]);
+            dstc[y * dstStride + x] = (xo_pixel)XO_F(s1[2 * x + 1], s2[2 * x + 1], s1[2 * x + 2], s2[2 * x + 2]);
+        }
+    }
+#undef XO_F
+}
 /* ipfilter.cpp:59-77 extendCURowColBorder (the p.extendRowBorder slot): replicate the first / last pixel of each row into the margins */
 void xo_extend_row_border(xo_pixel* txt, intptr_t stride, int width, int height, int marginX)
 {

@@ -68,6 +68,8 @@ void xo_scale2D_64to32(xo_pixel* dst, const xo_pixel* src, intptr_t stride);
 
 /* ---- transform / quant family (dct.cpp:43-757) ---- */
 void     xo_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride);   /* n = 4,8,16,32 */
+void     xo_frame_init_lowres(const xo_pixel* src0, xo_pixel* dst0, xo_pixel* dsth, xo_pixel* dstv, xo_pixel* dstc,
+                              intptr_t srcStride, intptr_t dstStride, int width, int height);                      /* pixel.cpp:596-622 */
 void     xo_extend_row_border(xo_pixel* txt, intptr_t stride, int width, int height, int marginX);                  /* ipfilter.cpp:59-77 */
 void     xo_extend_pic_border(xo_pixel* pic, intptr_t stride, int width, int height, int marginX, int marginY);    /* pixel.cpp:1044-1058 */
 void     xo_lowpass_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride);   /* n = 8,16,32 (lowpassdct.cpp:34-116) */

@@ -69,6 +69,10 @@ class Ref:
     def scale2D_64to32(self, dst, src, stride): return self._o(self.r.call("scale2D_64to32", [stride], [dst, src])[0], dst)
 
     def dct(self, n, src, stride): return np.frombuffer(self.r.call("dct", [n, stride], [src])[0], np.int16).copy()
+    def frame_init_lowres(self, src, ss, d0, dh, dv, dc, ds, width, height):
+        o = self.r.call("frame_init_lowres", [ss, ds, width, height], [src, d0, dh, dv, dc])
+        return tuple(self._o(o[i], d0) for i in range(4))
+
     def extend_pic_border(self, plane, stride, width, height, mx, my):
         return self._o(self.r.call("extend_pic_border", [stride, width, height, mx, my], [plane])[0], plane)
 
@@ -222,6 +226,11 @@ class Hip:
     # ---- transforms ----
     def dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.h.cu(n, "dct", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def frame_init_lowres(self, src, ss, d0, dh, dv, dc, ds, width, height):
+        o = [d.copy() for d in (d0, dh, dv, dc)]
+        self.h.scalar("frameInitLowres", None, (_VP,) * 5 + (_IP, _IP, _I, _I))(_p(src), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), ss, ds, width, height)
+        return tuple(o)
 
     def extend_pic_border(self, plane, stride, width, height, mx, my):
         # device entry point (planes live in HBM); host staging here only for the comparison

@@ -238,6 +238,14 @@ def cases_extras(depth, rng, reps=2):
             yield ("extend_pic_border %dx%d %s" % (w, h, kind), "extend_pic_border", (plane, stride, w, h, mx, my))
             rows = pix_buf(rng, depth, stride * h, "rand")
             yield ("extend_row_border %dx%d" % (w, h), "extend_row_border", (rows, stride, w, h, mx))
+    dt = np.uint8 if depth == 8 else np.uint16
+    for kind in KINDS:         # lookahead plane preparation: frame_init_lowres_core (pixel.cpp:596-622)
+        for _ in range(reps):
+            w, h = int(rng.integers(4, 70)), int(rng.integers(2, 30))
+            ss, ds = 2 * w + 2 + int(rng.integers(0, 9)), w + int(rng.integers(0, 9))
+            src = pix_buf(rng, depth, ss * (2 * h + 2), kind)
+            outs = [np.full(ds * h, 0xCD, dt) for _ in range(4)]
+            yield ("frame_init_lowres %dx%d %s" % (w, h, kind), "frame_init_lowres", (src, ss, outs[0], outs[1], outs[2], outs[3], ds, w, h))
     for (w, h) in LUMA_PU:
         for _ in range(reps):
             width = int(rng.integers(1, 140))

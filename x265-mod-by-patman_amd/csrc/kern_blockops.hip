@@ -101,6 +101,33 @@ template<int OP> int launch(hipStream_t st, int w, int h, const BlkArgs& a, int 
 
 } // namespace
 
+// ---- frame_init_lowres_core (pixel.cpp:596-622): one thread per lowres pixel, 3x3 source neighbourhood -> 4 outputs ----
+namespace {
+__global__ __launch_bounds__(256) void lowres_kernel(const pixel* __restrict__ src, intptr_t ss, pixel* __restrict__ d0, pixel* __restrict__ dh,
+                                                     pixel* __restrict__ dv, pixel* __restrict__ dc, intptr_t ds, int width, int height)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= width || y >= height) return;
+    const pixel* s0 = src + (intptr_t)(2 * y) * ss + 2 * x; const pixel* s1 = s0 + ss; const pixel* s2 = s1 + ss;
+    const int a0 = s0[0], a1 = s0[1], a2 = s0[2], b0 = s1[0], b1 = s1[1], b2 = s1[2], c0 = s2[0], c1 = s2[1], c2 = s2[2];
+    const int v00 = (a0 + b0 + 1) >> 1, v01 = (a1 + b1 + 1) >> 1, v02 = (a2 + b2 + 1) >> 1;      // rows 0/1, columns 0..2
+    const int v10 = (b0 + c0 + 1) >> 1, v11 = (b1 + c1 + 1) >> 1, v12 = (b2 + c2 + 1) >> 1;      // rows 1/2
+    const intptr_t o = (intptr_t)y * ds + x;
+    d0[o] = (pixel)((v00 + v01 + 1) >> 1); dh[o] = (pixel)((v01 + v02 + 1) >> 1);
+    dv[o] = (pixel)((v10 + v11 + 1) >> 1); dc[o] = (pixel)((v11 + v12 + 1) >> 1);
+}
+} // namespace
+extern "C" int x265hip_frame_init_lowres(void* stream, const void* src, intptr_t srcStride, void* dst0, void* dsth, void* dstv, void* dstc,
+                                         intptr_t dstStride, int width, int height)
+{
+    if (width <= 0 || height <= 0) return X265HIP_OK;
+    if (!src || !dst0 || !dsth || !dstv || !dstc) { set_error("frame_init_lowres: NULL plane"); return X265HIP_EARG; }
+    hipLaunchKernelGGL(lowres_kernel, dim3((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const pixel*)src, srcStride, (pixel*)dst0, (pixel*)dsth, (pixel*)dstv, (pixel*)dstc, dstStride, width, height);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
 // ---- extendPicBorder (pixel.cpp:1044-1058) / p.extendRowBorder (ipfilter.cpp:59-77) on pictures resident in HBM ----
 // grid.x walks the rows of the padded picture (height + 2*marginY), grid.y the pictures.  A row of the picture proper gets
 // its two margins; a margin row is a copy of the widened first / last picture row, built from that row's end pixels so
