@@ -88,3 +88,43 @@ def test_phase_planes_equal_the_interpolation_primitives(depth):
             kind = "hpp" if yf == 0 else ("vpp" if xf == 0 else "hvpp")
             exp = ora.interp(kind, 8, w, h, ref_f, stride, y * stride + x, buf, w, xf if kind != "vpp" else yf, yf).reshape(h, w)
             assert np.array_equal(pl[f, y:y + h, x:x + w], exp), "phase (%d,%d) block %dx%d at (%d,%d)" % (xf, yf, w, h, x, y)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_reconstruction_becomes_the_next_reference_on_device(depth):
+    """TQ recon -> extendPicBorder -> phase planes, all in HBM, equals the oracle's chain on the host copy."""
+    from x265hip_pkg.frame import FrameApi
+    ora = Oracle(depth)
+    row = mvcost_row(depth, 30, 1 << 15)
+    W, H, F = 192, 128, 2
+    pipe = FramePipeline(depth, W, H, F, qp=30, merange=16, method=1, subme=2, tu_log2=4, recon=True, cost_row=row)
+    pairs = [frame_pair(W, H, depth, 70 + s, margin=pipe.margin, max_shift=9)[:2] for s in range(F)]
+    pipe.upload(pairs)
+    # the recon plane starts as garbage everywhere (margins included): only the F pictures proper get written by the TQ stage
+    pipe.d_recon.fill_(0x55)
+    pipe.step()
+    api, T, m = pipe.api, pipe.torch, pipe.margin
+    T.cuda.synchronize()
+    rec_before = pipe.d_recon.cpu().numpy().view(pipe.cur_host.dtype).copy()
+    api.extend_pic_border(pipe.d_recon, m * pipe.stride + m, pipe.stride, W, H, m, m, n_pictures=F, picture_elems=pipe.plane)
+    T.cuda.synchronize()
+    got = pipe.d_recon.cpu().numpy().view(pipe.cur_host.dtype)
+    exp = rec_before.copy()
+    for f in range(F):
+        exp[f * pipe.plane:(f + 1) * pipe.plane] = ora.extend_pic_border(rec_before[f * pipe.plane:(f + 1) * pipe.plane], pipe.stride, W, H, m, m)
+    assert np.array_equal(got, exp)
+    # ... and its phase planes are the interpolation primitives of that reconstructed, extended picture
+    rows = F * (H + 2 * m)
+    d_pl = T.zeros(16 * pipe.plane * F, dtype=pipe.d_recon.dtype, device="cuda")
+    api.subpel_planes(pipe.d_recon, pipe.stride, rows, d_pl, pipe.plane * F)
+    T.cuda.synchronize()
+    pl = d_pl.cpu().numpy().view(got.dtype).reshape(16, rows, pipe.stride)
+    assert np.array_equal(pl[0].reshape(-1), got)
+    rng = np.random.default_rng(depth)
+    for f in (2, 7, 9, 15):
+        xf, yf = f & 3, f >> 2
+        x, y = int(rng.integers(8, pipe.stride - 40)), int(rng.integers(8, rows - 40))
+        kind = "hpp" if yf == 0 else ("vpp" if xf == 0 else "hvpp")
+        buf = np.zeros(32 * 32, got.dtype)
+        e = ora.interp(kind, 8, 32, 32, got, pipe.stride, y * pipe.stride + x, buf, 32, xf if kind != "vpp" else yf, yf).reshape(32, 32)
+        assert np.array_equal(pl[f, y:y + 32, x:x + 32], e)

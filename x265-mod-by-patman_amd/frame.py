@@ -64,6 +64,16 @@ class FrameApi:
     def subpel_planes(self, ref, stride, rows, out_planes, plane_elems):
         self.h.check(self.lib.x265hip_subpel_planes(self.stream(), _dp(ref), C.c_ssize_t(stride), rows, _dp(out_planes), C.c_int64(plane_elems)))
 
+    def extend_pic_border(self, plane, origin_elems, stride, width, height, margin_x, margin_y, n_pictures=1, picture_elems=0):
+        """extendPicBorder on pictures resident in HBM; `origin_elems` = element index of pixel (0,0) of picture 0 inside `plane`."""
+        org = C.c_void_p(plane.data_ptr() + origin_elems * plane.element_size())
+        self.h.check(self.lib.x265hip_extend_pic_border(self.stream(), org, C.c_ssize_t(stride), width, height, margin_x, margin_y,
+                                                        n_pictures, C.c_int64(picture_elems)))
+
+    def frame_init_lowres(self, src, src_stride, d0, dh, dv, dc, dst_stride, width, height):
+        self.h.check(self.lib.x265hip_frame_init_lowres(self.stream(), _dp(src), C.c_ssize_t(src_stride), _dp(d0), _dp(dh), _dp(dv), _dp(dc),
+                                                        C.c_ssize_t(dst_stride), width, height))
+
     def tq_batch(self, log2n, cur, cstride, ref, rstride, tasks, n, qp, add, coeff, numsig, quant_coeff=None, delta_u=None,
                  recon=None, recon_stride=0, sse=None, mv_source=None, planes=None, plane_elems=0):
         p = TqParams(qp, add, _dp(quant_coeff), _dp(delta_u), _dp(planes), plane_elems if planes is not None else 0)
