@@ -23,7 +23,7 @@ int main()
     const size_t planeBytes = (size_t)stride * rows; const int nplanes = 16;
     char* d; hipMalloc(&d, planeBytes * nplanes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    struct P { int bytes, tw, th; } ps[] = { {4, 64, 16}, {4, 128, 8}, {4, 256, 4}, {8, 128, 16}, {8, 256, 8}, {16, 256, 16}, {16, 512, 8}, {4, 64, 64}, {16, 1024, 4} };
+    struct P { int bytes, tw, th; } ps[] = { {4, 64, 16}, {4, 128, 8}, {4, 256, 4}, {8, 128, 16}, {8, 256, 8}, {16, 256, 16}, {16, 512, 8}, {4, 64, 64}, {16, 1024, 4}, {8, 64, 16}, {16, 64, 16}, {8, 64, 32}, {16, 64, 64} };
     for (auto& q : ps)
     {
         float ms = 0;

@@ -41,10 +41,13 @@ __device__ __forceinline__ void store4g(pixel* p, const int* v)      // 4 pixels
 // and the vertical pass over intermediates is four v_dot2_i32_i16 on vertically packed pairs.  Horizontal windows come
 // from the row-major tile, vertical windows from a byte-transposed copy (v_perm 4x4 transposes), both realigned with
 // v_alignbyte/v_alignbit.  ~2x fewer vector instructions per pixel than the scalar-MAC form below.
-constexpr int SROW = 20;                    // dwords per row of the row-major tile (19 used)
-constexpr int TCOL = 7;                     // dwords per column of the transposed tile (6 used; odd -> banks)
-constexpr int NT = 4;                       // tiles per workgroup (vertical walk)
-constexpr int ICOL = 13;                    // dwords per column of the transposed intermediates (12 used)
+// Tile of the 8-bit kernel: 128 x 8 outputs (128-byte row segments: full-line stores, profiles/micro/RESULTS.md), 16 source rows,
+// 256 work items in each of its two compute phases.
+constexpr int TW8 = 128, TH8 = 8, TROWS8 = 16, DW8 = TW8 / 4 + 3;
+constexpr int SROW = 48;                    // dwords per row of the row-major tile (35 used; 2 rows = 32 banks apart)
+constexpr int TCOL = 5;                     // dwords per column of the transposed tile (4 used)
+constexpr int NT = 8;                       // tiles per workgroup (vertical walk)
+constexpr int ICOL = 9;                     // dwords per column of the transposed intermediates (8 used)
 __device__ __forceinline__ constexpr uint32_t pk4(int a, int b, int c, int d) { return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24); }
 __device__ __forceinline__ constexpr uint32_t pk2(int a, int b) { return (uint32_t)(uint16_t)a | ((uint32_t)(uint16_t)b << 16); }
 // (Builtins, not inline asm: dot results have read-after-write hazards against other VALU opcodes that the compiler
@@ -85,10 +88,10 @@ template<int SH> __device__ __forceinline__ void window8(uint32_t w0, uint32_t w
 __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restrict__ ref, intptr_t stride, int rows,
                                                             pixel* __restrict__ out, int64_t planeElems)
 {
-    __shared__ uint32_t s_src[24 * SROW];            // rows y0-3 .. y0+20, bytes x0-4 .. x0+71, as q = p - 128
-    __shared__ uint32_t s_srcT[TW * TCOL];           // [column][row]: the same pixels for columns x0 .. x0+63
-    __shared__ uint32_t s_imT[3][TW * ICOL];         // [xFrac-1][column][row pair]: 14-bit intermediates, int16 pairs (row 2i | row 2i+1)
-    const int x0 = blockIdx.x * TW, t = threadIdx.x;
+    __shared__ uint32_t s_src[TROWS8 * SROW];        // rows y0-3 .. y0+12, bytes x0-4 .. x0+135, as q = p - 128
+    __shared__ uint32_t s_srcT[TW8 * TCOL];          // [column][row]: the same pixels for columns x0 .. x0+127
+    __shared__ uint32_t s_imT[3][TW8 * ICOL];         // [xFrac-1][column][row pair]: 14-bit intermediates, int16 pairs (row 2i | row 2i+1)
+    const int x0 = blockIdx.x * TW8, t = threadIdx.x;
     constexpr uint32_t TLO[4] = { 0, pk4(-1, 4, -10, 58), pk4(-1, 4, -11, 40), pk4(0, 1, -5, 17) };
     constexpr uint32_t THI[4] = { 0, pk4(17, -5, 1, 0), pk4(40, -11, 4, -1), pk4(58, -10, 4, -1) };
     constexpr uint32_t TP[4][4] = { { 0, 0, 0, 0 }, { pk2(-1, 4), pk2(-10, 58), pk2(17, -5), pk2(1, 0) },
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
 
     // A workgroup walks NT vertically adjacent tiles; the source rows of tile i+1 are fetched into registers while tile i is
     // being filtered, so the HBM latency of the only read of this kernel hides behind the arithmetic.
-    const int rbA = t / 19, dcA = t - rbA * 19, gxA = x0 - 4 + 4 * dcA;           // loader role (t < 6*19): 4 rows x 1 dword
+    const int rbA = t / DW8, dcA = t - rbA * DW8, gxA = x0 - 4 + 4 * dcA;         // loader role (t < 4*DW8): 4 rows x 1 dword
     auto fetch = [&](int y0_, uint32_t (&v)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -113,13 +116,13 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
         }
     };
     uint32_t nxt[4] = { 0, 0, 0, 0 };
-    if (t < 6 * 19 && (int)blockIdx.y * NT * TH < rows) fetch(blockIdx.y * NT * TH, nxt);
+    if (t < 4 * DW8 && (int)blockIdx.y * NT * TH8 < rows) fetch(blockIdx.y * NT * TH8, nxt);
     for (int it = 0; it < NT; it++)
     {
-    const int y0 = (blockIdx.y * NT + it) * TH;
+    const int y0 = (blockIdx.y * NT + it) * TH8;
     if (y0 >= rows) break;                                                          // uniform
     // ---- A: slot-0 copy, signed bytes, transposed copy (coordinates were clamped into the allocation by fetch) ----
-    if (t < 6 * 19)
+    if (t < 4 * DW8)
     {
         const int rb = rbA, dc = dcA, gx = gxA;
         uint32_t v[4];
@@ -128,12 +131,12 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
         {
             const int gyu = y0 - 3 + 4 * rb + r;
             v[r] = nxt[r];
-            if (dc >= 1 && dc <= 16 && 4 * rb + r >= 3 && 4 * rb + r < 3 + TH && gyu < rows && gx < (int)stride)
+            if (dc >= 1 && dc <= TW8 / 4 && 4 * rb + r >= 3 && 4 * rb + r < 3 + TH8 && gyu < rows && gx < (int)stride)
                 *(uint32_t*)(out + (intptr_t)gyu * stride + gx) = v[r];            // slot 0: the reference plane itself
             v[r] ^= 0x80808080u;
             s_src[(4 * rb + r) * SROW + dc] = v[r];
         }
-        if (dc >= 1 && dc <= 16)
+        if (dc >= 1 && dc <= TW8 / 4)
         {   // 4x4 byte transpose: c_i = (v0.b_i, v1.b_i, v2.b_i, v3.b_i)
             const uint32_t t0 = __builtin_amdgcn_perm(v[1], v[0], 0x05010400), t1 = __builtin_amdgcn_perm(v[1], v[0], 0x07030602);
             const uint32_t t2 = __builtin_amdgcn_perm(v[3], v[2], 0x05010400), t3 = __builtin_amdgcn_perm(v[3], v[2], 0x07030602);
@@ -143,13 +146,12 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
             s_srcT[(col + 2) * TCOL + rb] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
             s_srcT[(col + 3) * TCOL + rb] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
         }
-        if (it + 1 < NT && y0 + TH < rows) fetch(y0 + TH, nxt);                     // in flight during H / V / HV
+        if (it + 1 < NT && y0 + TH8 < rows) fetch(y0 + TH8, nxt);                     // in flight during H / V / HV
     }
     __syncthreads();
 
-    if (t < 192)
-    {   // ---- H: 2 rows x 4 pixels per thread: intermediates for the three xFracs + the yFrac == 0 planes ----
-        const int rb = t >> 5, pb = (t >> 4) & 1, q = t & 15;
+    {   // ---- H (all 256 threads): 2 rows x 4 pixels per thread: intermediates for the three xFracs + the yFrac == 0 planes ----
+        const int rb = t >> 6, pb = (t >> 5) & 1, q = t & 31;
         const int gx = x0 + 4 * q;
         const uint32_t hoff = (uint32_t)(4 * rb) * (uint32_t)stride + 4 * q;         // thread part of the store address (bytes = pixels)
         {
@@ -179,44 +181,17 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                 for (int r = 0; r < 2; r++)
                 {
                     const int tr = 4 * rb + 2 * pb + r, gy = y0 + tr - 3;
-                    if (tr >= 3 && tr < 3 + TH && gy < rows && gx < (int)stride)
+                    if (tr >= 3 && tr < 3 + TH8 && gy < rows && gx < (int)stride)
                         store_px4(out + (int64_t)xf * planeElems, (uint32_t)((y0 - 3 + 2 * pb + r) * (int)stride + x0) + hoff, sat_pack4<6>(d[r][0], d[r][1], d[r][2], d[r][3]));
                 }
             }
         }
     }
-    else
-    {   // ---- V: 4 columns x 4 rows per thread straight from the pixels: the xFrac == 0 planes ----
-        const int i = t - 192, rq = i >> 4, cq = i & 15;
-        const int gx = x0 + 4 * cq;
-        const uint32_t voff = (uint32_t)(4 * rq) * (uint32_t)stride + 4 * cq;
-        uint32_t lo[4][4], hi[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-        {
-            const uint32_t* w = s_srcT + (4 * cq + c) * TCOL + rq;
-            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-            window8<0>(w0, w1, w2, lo[c][0], hi[c][0]); window8<1>(w0, w1, w2, lo[c][1], hi[c][1]);
-            window8<2>(w0, w1, w2, lo[c][2], hi[c][2]); window8<3>(w0, w1, w2, lo[c][3], hi[c][3]);
-        }
-#pragma unroll
-        for (int yf = 1; yf < 4; yf++)
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-            {
-                const int gy = y0 + 4 * rq + e;
-                int o[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) o[c] = dot8(lo[c][e], hi[c][e], TLO[yf], THI[yf], 8192 + 32);
-                if (gy < rows && gx < (int)stride)
-                    store_px4(out + (int64_t)(yf * 4) * planeElems, (uint32_t)((y0 + e) * (int)stride + x0) + voff, sat_pack4<6>(o[0], o[1], o[2], o[3]));
-            }
-    }
     __syncthreads();
 
     if (t < 192)
     {   // ---- HV: 4 columns x 4 rows per thread and xFrac: vertical taps over the intermediates ----
-        const int xf = __builtin_amdgcn_readfirstlane(t >> 6), i = t & 63, rq = i >> 4, cq = i & 15;   // one xFrac per wavefront
+        const int xf = __builtin_amdgcn_readfirstlane(t >> 6), i = t & 63, rq = i >> 5, cq = i & 31;   // one xFrac per wavefront
         const int gx = x0 + 4 * cq;
         const uint32_t voff = (uint32_t)(4 * rq) * (uint32_t)stride + 4 * cq;
         pixel* xbase = out + (int64_t)(xf + 1) * planeElems;
@@ -253,8 +228,34 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                     store_px4(xbase + (int64_t)(yf * 4) * planeElems, (uint32_t)((y0 + e) * (int)stride + x0) + voff, sat_pack4<12>(o[0], o[1], o[2], o[3]));
             }
     }
-    // no third barrier: the next tile's A only writes s_src / s_srcT (last read before the barrier above), and s_imT is
-    // rewritten after the next tile's first barrier, which every wavefront reaches after its HV reads
+    else
+    {   // ---- V (the fourth wavefront): 4 columns x 4 rows per thread straight from the pixels: the xFrac == 0 planes ----
+        const int i = t - 192, rq = i >> 5, cq = i & 31;
+        const int gx = x0 + 4 * cq;
+        const uint32_t voff = (uint32_t)(4 * rq) * (uint32_t)stride + 4 * cq;
+        uint32_t lo[4][4], hi[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+        {
+            const uint32_t* w = s_srcT + (4 * cq + c) * TCOL + rq;
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            window8<0>(w0, w1, w2, lo[c][0], hi[c][0]); window8<1>(w0, w1, w2, lo[c][1], hi[c][1]);
+            window8<2>(w0, w1, w2, lo[c][2], hi[c][2]); window8<3>(w0, w1, w2, lo[c][3], hi[c][3]);
+        }
+#pragma unroll
+        for (int yf = 1; yf < 4; yf++)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                const int gy = y0 + 4 * rq + e;
+                int o[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) o[c] = dot8(lo[c][e], hi[c][e], TLO[yf], THI[yf], 8192 + 32);
+                if (gy < rows && gx < (int)stride)
+                    store_px4(out + (int64_t)(yf * 4) * planeElems, (uint32_t)((y0 + e) * (int)stride + x0) + voff, sat_pack4<6>(o[0], o[1], o[2], o[3]));
+            }
+    }
+    __syncthreads();                         // the next tile's A rewrites s_src / s_srcT, which V has just read
     }
 }
 #else
@@ -388,7 +389,7 @@ extern "C" int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_
     { set_error("subpel_planes: bad arguments (stride and planeElems must be multiples of 4)"); return X265HIP_EARG; }
     if (((uintptr_t)refPlane | (uintptr_t)outPlanes) & 7) { set_error("subpel_planes: planes must be 8-byte aligned"); return X265HIP_EARG; }
 #if X265_DEPTH == 8
-    dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH * NT - 1) / (TH * NT)));
+    dim3 grid((unsigned)((stride + TW8 - 1) / TW8), (unsigned)((rows + TH8 * NT - 1) / (TH8 * NT)));
 #else
     dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
 #endif
