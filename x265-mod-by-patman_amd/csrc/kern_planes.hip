@@ -46,7 +46,7 @@ __device__ __forceinline__ void store4g(pixel* p, const int* v)      // 4 pixels
 constexpr int TW8 = 128, TH8 = 8, TROWS8 = 16, DW8 = TW8 / 4 + 3;
 constexpr int SROW = 48;                    // dwords per row of the row-major tile (35 used; 2 rows = 32 banks apart)
 constexpr int TCOL = 5;                     // dwords per column of the transposed tile (4 used)
-constexpr int NT = 8;                       // tiles per workgroup (vertical walk)
+constexpr int NT = 4;                       // tiles per workgroup (vertical walk)
 constexpr int ICOL = 9;                     // dwords per column of the transposed intermediates (8 used)
 __device__ __forceinline__ constexpr uint32_t pk4(int a, int b, int c, int d) { return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24); }
 __device__ __forceinline__ constexpr uint32_t pk2(int a, int b) { return (uint32_t)(uint16_t)a | ((uint32_t)(uint16_t)b << 16); }
