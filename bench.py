@@ -264,7 +264,7 @@ def main():
         n_tu = 1 << args.tu
         alg[names[-1]] = px * (2 * bpp + 2) + len(pipe.tu_host) * 4
         if pipe.use_planes:
-            alg["planes"] = pipe.F * pipe.plane * bpp * 16          # 1 plane read + 15 written (padded planes)
+            alg["planes"] = pipe.F * pipe.plane * bpp * 17          # 1 plane read + 16 written (15 phases + the slot-0 copy; padded planes)
         dom = max(kms, key=kms.get)
         achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
         traffic = None
