@@ -45,9 +45,7 @@ __device__ __forceinline__ void store4g(pixel* p, const int* v)      // 4 pixels
 // 256 work items in each of its two compute phases.
 constexpr int TW8 = 128, TH8 = 8, TROWS8 = 16, DW8 = TW8 / 4 + 3;
 constexpr int SROW = 48;                    // dwords per row of the row-major tile (35 used; 2 rows = 32 banks apart)
-constexpr int TCOL = 5;                     // dwords per column of the transposed tile (4 used)
 constexpr int NT = 4;                       // tiles per workgroup (vertical walk)
-constexpr int ICOL = 9;                     // dwords per column of the transposed intermediates (8 used)
 __device__ __forceinline__ constexpr uint32_t pk4(int a, int b, int c, int d) { return (uint32_t)(uint8_t)a | ((uint32_t)(uint8_t)b << 8) | ((uint32_t)(uint8_t)c << 16) | ((uint32_t)(uint8_t)d << 24); }
 __device__ __forceinline__ constexpr uint32_t pk2(int a, int b) { return (uint32_t)(uint16_t)a | ((uint32_t)(uint16_t)b << 16); }
 // (Builtins, not inline asm: dot results have read-after-write hazards against other VALU opcodes that the compiler
@@ -89,8 +87,9 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                                                             pixel* __restrict__ out, int64_t planeElems)
 {
     __shared__ uint32_t s_src[TROWS8 * SROW];        // rows y0-3 .. y0+12, bytes x0-4 .. x0+135, as q = p - 128
-    __shared__ uint32_t s_srcT[TW8 * TCOL];          // [column][row]: the same pixels for columns x0 .. x0+127
-    __shared__ uint32_t s_imT[3][TW8 * ICOL];         // [xFrac-1][column][row pair]: 14-bit intermediates, int16 pairs (row 2i | row 2i+1)
+    // vertically packed copies, [row group][column]: a thread's four adjacent columns are one 16-byte LDS access
+    __shared__ __attribute__((aligned(16))) uint32_t s_srcT[(TROWS8 / 4) * TW8];     // dword = rows 4g .. 4g+3 of one column (bytes)
+    __shared__ __attribute__((aligned(16))) uint32_t s_imT[3][(TROWS8 / 2) * TW8];   // [xFrac-1]: dword = rows 2p, 2p+1 of one column (14-bit intermediates, int16)
     const int x0 = blockIdx.x * TW8, t = threadIdx.x;
     constexpr uint32_t TLO[4] = { 0, pk4(-1, 4, -10, 58), pk4(-1, 4, -11, 40), pk4(0, 1, -5, 17) };
     constexpr uint32_t THI[4] = { 0, pk4(17, -5, 1, 0), pk4(40, -11, 4, -1), pk4(58, -10, 4, -1) };
@@ -141,10 +140,10 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
             const uint32_t t0 = __builtin_amdgcn_perm(v[1], v[0], 0x05010400), t1 = __builtin_amdgcn_perm(v[1], v[0], 0x07030602);
             const uint32_t t2 = __builtin_amdgcn_perm(v[3], v[2], 0x05010400), t3 = __builtin_amdgcn_perm(v[3], v[2], 0x07030602);
             const int col = 4 * (dc - 1);
-            s_srcT[(col + 0) * TCOL + rb] = __builtin_amdgcn_perm(t2, t0, 0x05040100);
-            s_srcT[(col + 1) * TCOL + rb] = __builtin_amdgcn_perm(t2, t0, 0x07060302);
-            s_srcT[(col + 2) * TCOL + rb] = __builtin_amdgcn_perm(t3, t1, 0x05040100);
-            s_srcT[(col + 3) * TCOL + rb] = __builtin_amdgcn_perm(t3, t1, 0x07060302);
+            uint4 cols;
+            cols.x = __builtin_amdgcn_perm(t2, t0, 0x05040100); cols.y = __builtin_amdgcn_perm(t2, t0, 0x07060302);
+            cols.z = __builtin_amdgcn_perm(t3, t1, 0x05040100); cols.w = __builtin_amdgcn_perm(t3, t1, 0x07060302);
+            *(uint4*)(s_srcT + rb * TW8 + col) = cols;
         }
         if (it + 1 < NT && y0 + TH8 < rows) fetch(y0 + TH8, nxt);                     // in flight during H / V / HV
     }
@@ -174,9 +173,12 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int e = 0; e < 4; e++) d[r][e] = dot8(lo[r][e], hi[r][e], TLO[xf], THI[xf], 8192 + 32);
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    s_imT[xf - 1][(4 * q + e) * ICOL + 2 * rb + pb] = __builtin_amdgcn_perm((uint32_t)d[1][e], (uint32_t)d[0][e], 0x05040100);
+                {
+                    uint4 pr;
+                    pr.x = __builtin_amdgcn_perm((uint32_t)d[1][0], (uint32_t)d[0][0], 0x05040100); pr.y = __builtin_amdgcn_perm((uint32_t)d[1][1], (uint32_t)d[0][1], 0x05040100);
+                    pr.z = __builtin_amdgcn_perm((uint32_t)d[1][2], (uint32_t)d[0][2], 0x05040100); pr.w = __builtin_amdgcn_perm((uint32_t)d[1][3], (uint32_t)d[0][3], 0x05040100);
+                    *(uint4*)(s_imT[xf - 1] + (2 * rb + pb) * TW8 + 4 * q) = pr;
+                }
 #pragma unroll
                 for (int r = 0; r < 2; r++)
                 {
@@ -196,16 +198,20 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
         const uint32_t voff = (uint32_t)(4 * rq) * (uint32_t)stride + 4 * cq;
         pixel* xbase = out + (int64_t)(xf + 1) * planeElems;
         uint32_t P[4][5], Q[4][5];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
         {
-            const uint32_t* w = s_imT[xf] + (4 * cq + c) * ICOL + 2 * rq;
-            uint32_t p5 = w[5];
+            uint4 w[6];
 #pragma unroll
-            for (int k = 0; k < 5; k++) P[c][k] = w[k];
+            for (int k = 0; k < 6; k++) w[k] = *(const uint4*)(s_imT[xf] + (2 * rq + k) * TW8 + 4 * cq);
 #pragma unroll
-            for (int k = 0; k < 4; k++) Q[c][k] = __builtin_amdgcn_alignbit(P[c][k + 1], P[c][k], 16);
-            Q[c][4] = __builtin_amdgcn_alignbit(p5, P[c][4], 16);
+            for (int k = 0; k < 5; k++) { P[0][k] = w[k].x; P[1][k] = w[k].y; P[2][k] = w[k].z; P[3][k] = w[k].w; }
+            const uint32_t p5[4] = { w[5].x, w[5].y, w[5].z, w[5].w };
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+            {
+#pragma unroll
+                for (int k = 0; k < 4; k++) Q[c][k] = __builtin_amdgcn_alignbit(P[c][k + 1], P[c][k], 16);
+                Q[c][4] = __builtin_amdgcn_alignbit(p5[c], P[c][4], 16);
+            }
         }
         const int offset2 = (1 << 11) + (XH_IF_INTERNAL_OFFS << XH_IF_FILTER_PREC);
 #pragma unroll
@@ -234,13 +240,17 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
         const int gx = x0 + 4 * cq;
         const uint32_t voff = (uint32_t)(4 * rq) * (uint32_t)stride + 4 * cq;
         uint32_t lo[4][4], hi[4][4];
-#pragma unroll
-        for (int c = 0; c < 4; c++)
         {
-            const uint32_t* w = s_srcT + (4 * cq + c) * TCOL + rq;
-            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-            window8<0>(w0, w1, w2, lo[c][0], hi[c][0]); window8<1>(w0, w1, w2, lo[c][1], hi[c][1]);
-            window8<2>(w0, w1, w2, lo[c][2], hi[c][2]); window8<3>(w0, w1, w2, lo[c][3], hi[c][3]);
+            uint4 g[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) g[k] = *(const uint4*)(s_srcT + (rq + k) * TW8 + 4 * cq);
+            const uint32_t W[4][3] = { { g[0].x, g[1].x, g[2].x }, { g[0].y, g[1].y, g[2].y }, { g[0].z, g[1].z, g[2].z }, { g[0].w, g[1].w, g[2].w } };
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+            {
+                window8<0>(W[c][0], W[c][1], W[c][2], lo[c][0], hi[c][0]); window8<1>(W[c][0], W[c][1], W[c][2], lo[c][1], hi[c][1]);
+                window8<2>(W[c][0], W[c][1], W[c][2], lo[c][2], hi[c][2]); window8<3>(W[c][0], W[c][1], W[c][2], lo[c][3], hi[c][3]);
+            }
         }
 #pragma unroll
         for (int yf = 1; yf < 4; yf++)
