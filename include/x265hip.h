@@ -195,6 +195,17 @@ int x265hip_intra_pred_batch(void* stream, int N, const void* nb, const int32_t*
 int x265hip_intra_allangs_batch(void* stream, int N, const void* ref, const int32_t* refOff,
                                 const void* filt, const int32_t* filtOff, void* dst /* n x 33*N*N dense */, int bLuma, int n);
 
+/* Intra mode scan of n square CUs -- the data-parallel half of Search::estIntraPredQT (encoder/search.cpp:1655-1745):
+ * costs[i*35 + mode] = sa8d(source block, prediction of `mode`) for mode 0 (planar), 1 (DC) and the 33 angular modes, with the
+ * reference's choices of neighbour array (g_intraFilterFlags), edge filter (size <= 16) and 64x64 handling (source and neighbours
+ * scaled to 32x32 by scale2D_64to32 / scale1D_128to64, no filtered neighbours, costs << 2).  nbRef / nbFilt: per CU the 4*size+1
+ * pixels of Predict::intraNeighbourBuf[0] / [1] after initAdiPattern (predict.h:75), CU i at + i*nbPitch.  Mode bits, MPMs and
+ * the RD comparison stay on the host.  64x64 needs x265hip_intra_cost_workspace() bytes of device workspace. */
+size_t x265hip_intra_cost_workspace(int log2Size, int n);
+int x265hip_intra_cost_batch(void* stream, int log2Size, const void* srcPlane, intptr_t srcStride, const int32_t* srcOff,
+                             const void* nbRef, const void* nbFilt, int nbPitch, int n, int32_t* costs,
+                             void* workspace, size_t workspaceBytes);
+
 #ifdef __cplusplus
 }
 #endif

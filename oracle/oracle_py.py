@@ -132,6 +132,11 @@ class Oracle:
     def dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.lib.xo_dct(n, _ptr(src), _ptr(d), _IP(stride)); return d
 
+    def intra_costs(self, size, src, stride, off, nb_ref, nb_filt):
+        c = np.zeros(35, np.int32)
+        self.lib.xo_intra_costs(size, _ptr(src, off), _IP(stride), _ptr(nb_ref), _ptr(nb_filt), _ptr(c))
+        return c
+
     def frame_init_lowres(self, src, ss, d0, dh, dv, dc, ds, width, height):
         o = [d.copy() for d in (d0, dh, dv, dc)]
         self.lib.xo_frame_init_lowres(_ptr(src), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3]), _IP(ss), _IP(ds), width, height)

@@ -236,6 +236,43 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         T.cu[cuIndex(n)].dct(S16(B[0], 0), dp, I[1]);
         Buf o(n * n * 2); memcpy(o.data(), dp, o.size()); out.push_back(o); return true;
     }
+    if (op == "intra_costs")
+    {   /* ints = size, stride, off ; bufs = src plane, nbRef (4*size+1), nbFilt -> int32 costs[35].
+         * The reference's own primitives in the order of Search::estIntraPredQT (search.cpp:1655-1745, allangs branch). */
+        int tuSize = (int)I[0]; intptr_t stride = I[1];
+        const pixel* fenc = PX(B[0], 0) + I[2];
+        static pixel fencScaled[32 * 32], fencT[32 * 32], predBuf[33 * 32 * 32], nb[2][258];
+        memcpy(nb[0], B[1].data(), (4 * tuSize + 1) * sizeof(pixel)); memcpy(nb[1], B[2].data(), (4 * tuSize + 1) * sizeof(pixel));
+        int scaleTuSize = tuSize, scaleStride = (int)stride, costShift = 0, sizeIdx = cuIndex(tuSize);
+        if (tuSize > 32)
+        {
+            T.scale2D_64to32(fencScaled, fenc, stride); fenc = fencScaled;
+            pixel nScale[129];
+            nb[1][0] = nb[0][0];
+            T.scale1D_128to64[0](nScale + 1, nb[0] + 1);
+            memcpy(&nb[0][1], &nScale[1], 2 * 64 * sizeof(pixel)); memcpy(&nb[1][1], &nScale[1], 2 * 64 * sizeof(pixel));
+            scaleTuSize = 32; scaleStride = 32; costShift = 2; sizeIdx = 3;
+        }
+        pixelcmp_t sa8d = T.cu[sizeIdx].sa8d;
+        int predsize = scaleTuSize * scaleTuSize;
+        std::vector<int32_t> c(35);
+        T.cu[sizeIdx].intra_pred[DC_IDX](predBuf, scaleStride, nb[0], 0, (scaleTuSize <= 16));
+        c[DC_IDX] = sa8d(fenc, scaleStride, predBuf, scaleStride) << costShift;
+        pixel* planar = nb[0];
+        if (tuSize & (8 | 16 | 32)) planar = nb[1];
+        T.cu[sizeIdx].intra_pred[PLANAR_IDX](predBuf, scaleStride, planar, 0, 0);
+        c[PLANAR_IDX] = sa8d(fenc, scaleStride, predBuf, scaleStride) << costShift;
+        T.cu[sizeIdx].transpose(fencT, fenc, scaleStride);
+        /* the C table leaves intra_pred_allangs NULL (primitives.cpp:348); all_angs_pred_c is what the asm slot computes */
+        for (int mode = 2; mode < 35; mode++)
+        {
+            int filter = !!(g_intraFilterFlags[mode] & scaleTuSize);
+            T.cu[sizeIdx].intra_pred[mode](predBuf, scaleTuSize, nb[filter], mode, scaleTuSize <= 16);
+            c[mode] = sa8d(fenc, scaleStride, predBuf, scaleTuSize) << costShift;     /* the !allangs arm of TRY_ANGLE */
+        }
+        (void)fencT; (void)predsize;
+        Buf o(35 * 4); memcpy(o.data(), c.data(), o.size()); out.push_back(o); return true;
+    }
     if (op == "frame_init_lowres")
     {   /* ints = srcStride, dstStride, width, height (lowres size) ; bufs = src, dst0, dsth, dstv, dstc (outs pre-filled) */
         T.frameInitLowres(PX(B[0], 0), PX(B[1], 0), PX(B[2], 0), PX(B[3], 0), PX(B[4], 0), I[0], I[1], (int)I[2], (int)I[3]);

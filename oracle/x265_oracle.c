@@ -364,6 +364,37 @@ void xo_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride)
     fwd_stage(M, n, blk, tmp, lg - 1 + X265_DEPTH - 8);
     fwd_stage(M, n, tmp, dst, lg + 6);
 }
+/* The data-parallel half of Search::estIntraPredQT's mode scan (encoder/search.cpp:1655-1745): sa8d of the source block
+ * against the DC, planar and 33 angular predictions.  size 4..64; 64x64 is scaled to 32x32 like the reference
+ * (scale2D_64to32 / scale1D_128to64, no filtered neighbours, costs << 2).  nbRef / nbFilt = intraNeighbourBuf[0] / [1] as
+ * Predict::initAdiPattern leaves them (4*size+1 pixels).  costs[mode], mode 0 = planar, 1 = DC, 2..34 angular. */
+void xo_intra_costs(int size, const xo_pixel* fenc, intptr_t stride, const xo_pixel* nbRef, const xo_pixel* nbFilt, int32_t* costs)
+{
+    static const unsigned char flags[35] = { 0x38, 0x00, 0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+                                             0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x38 };
+    xo_pixel scaled[32 * 32], nb0[129], nb1[129], fencT[32 * 32], pred[32 * 32];
+    static xo_pixel angs[33 * 32 * 32];
+    const xo_pixel* ref = nbRef; const xo_pixel* flt = nbFilt;
+    int n = size, shift = 0; (void)flags;
+    if (size > 32)
+    {   /* search.cpp:1670-1688 */
+        xo_scale2D_64to32(scaled, fenc, stride);
+        fenc = scaled; stride = 32;
+        nb0[0] = nbRef[0];
+        xo_scale1D_128to64(nb0 + 1, nbRef + 1);
+        memcpy(nb1, nb0, sizeof(nb0));
+        ref = nb0; flt = nb1; n = 32; shift = 2;
+    }
+    const int bLuma = n <= 16;
+    xo_intra_pred(n, pred, n, ref, 1, bLuma);                                              /* DC (:1702) */
+    costs[1] = xo_sa8d(n, fenc, stride, pred, n) << shift;
+    xo_intra_pred(n, pred, n, (size & (8 | 16 | 32)) ? flt : ref, 0, 0);                   /* planar (:1708-1713) */
+    costs[0] = xo_sa8d(n, fenc, stride, pred, n) << shift;
+    xo_transpose(n, fencT, fenc, stride);                                                  /* :1721-1723 */
+    xo_intra_allangs(n, angs, ref, flt, bLuma);
+    for (int mode = 2; mode < 35; mode++)                                                  /* TRY_ANGLE, :1728-1735 */
+        costs[mode] = (mode < 18 ? xo_sa8d(n, fencT, n, angs + (mode - 2) * n * n, n) : xo_sa8d(n, fenc, stride, angs + (mode - 2) * n * n, n)) << shift;
+}
 /* pixel.cpp:596-622 frame_init_lowres_core (p.frameInitLowres / frameInitLowerRes): half-resolution plane + its three
  * half-pel companions, each a rounded average of rounded vertical averages ("slower than naive bilinear, but matches asm") */
 void xo_frame_init_lowres(const xo_pixel* src0, xo_pixel* dst0, xo_pixel* dsth, xo_pixel* dstv, xo_pixel* dstc,

@@ -68,6 +68,7 @@ void xo_scale2D_64to32(xo_pixel* dst, const xo_pixel* src, intptr_t stride);
 
 /* ---- transform / quant family (dct.cpp:43-757) ---- */
 void     xo_dct(int n, const int16_t* src, int16_t* dst, intptr_t srcStride);   /* n = 4,8,16,32 */
+void     xo_intra_costs(int size, const xo_pixel* fenc, intptr_t stride, const xo_pixel* nbRef, const xo_pixel* nbFilt, int32_t* costs);   /* search.cpp:1655-1745 */
 void     xo_frame_init_lowres(const xo_pixel* src0, xo_pixel* dst0, xo_pixel* dsth, xo_pixel* dstv, xo_pixel* dstc,
                               intptr_t srcStride, intptr_t dstStride, int width, int height);                      /* pixel.cpp:596-622 */
 void     xo_extend_row_border(xo_pixel* txt, intptr_t stride, int width, int height, int marginX);                  /* ipfilter.cpp:59-77 */

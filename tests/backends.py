@@ -69,6 +69,9 @@ class Ref:
     def scale2D_64to32(self, dst, src, stride): return self._o(self.r.call("scale2D_64to32", [stride], [dst, src])[0], dst)
 
     def dct(self, n, src, stride): return np.frombuffer(self.r.call("dct", [n, stride], [src])[0], np.int16).copy()
+    def intra_costs(self, size, src, stride, off, nb_ref, nb_filt):
+        return np.frombuffer(self.r.call("intra_costs", [size, stride, off], [src, nb_ref, nb_filt])[0], np.int32).copy()
+
     def frame_init_lowres(self, src, ss, d0, dh, dv, dc, ds, width, height):
         o = self.r.call("frame_init_lowres", [ss, ds, width, height], [src, d0, dh, dv, dc])
         return tuple(self._o(o[i], d0) for i in range(4))
@@ -226,6 +229,23 @@ class Hip:
     # ---- transforms ----
     def dct(self, n, src, stride):
         d = np.zeros(n * n, np.int16); self.h.cu(n, "dct", None, (_VP, _VP, _IP))(_p(src), _p(d), stride); return d
+
+    def intra_costs(self, size, src, stride, off, nb_ref, nb_filt):
+        # batched device entry point (one CU here); host staging only for the comparison
+        import torch
+        lg = {4: 2, 8: 3, 16: 4, 32: 5, 64: 6}[size]
+        view = lambda a: a.view(np.uint8 if a.dtype == np.uint8 else np.int16)  # noqa: E731
+        d_src, d_ref, d_flt = (torch.from_numpy(view(a).copy()).cuda() for a in (src, nb_ref, nb_filt))
+        d_off = torch.tensor([off], dtype=torch.int32, device="cuda")
+        d_cost = torch.zeros(35, dtype=torch.int32, device="cuda")
+        self.h.lib.x265hip_intra_cost_workspace.restype = _C.c_size_t
+        wsb = int(self.h.lib.x265hip_intra_cost_workspace(lg, 1))
+        d_ws = torch.zeros(max(wsb, 8), dtype=torch.uint8, device="cuda")
+        P = lambda t: _C.c_void_p(t.data_ptr())  # noqa: E731
+        self.h.check(self.h.lib.x265hip_intra_cost_batch(None, lg, P(d_src), _C.c_ssize_t(stride), P(d_off), P(d_ref), P(d_flt), 4 * size + 1, 1,
+                                                         P(d_cost), P(d_ws), _C.c_size_t(wsb)))
+        torch.cuda.synchronize()
+        return d_cost.cpu().numpy()
 
     def frame_init_lowres(self, src, ss, d0, dh, dv, dc, ds, width, height):
         o = [d.copy() for d in (d0, dh, dv, dc)]

@@ -238,6 +238,15 @@ def cases_extras(depth, rng, reps=2):
             yield ("extend_pic_border %dx%d %s" % (w, h, kind), "extend_pic_border", (plane, stride, w, h, mx, my))
             rows = pix_buf(rng, depth, stride * h, "rand")
             yield ("extend_row_border %dx%d" % (w, h), "extend_row_border", (rows, stride, w, h, mx))
+    for kind in KINDS:         # intra mode scan: sa8d of 35 predictions per CU (search.cpp:1655-1745)
+        for n in (4, 8, 16, 32, 64):
+            for _ in range(reps):
+                stride = n + int(rng.integers(0, 40))
+                src = pix_buf(rng, depth, stride * n + 64, kind)
+                off = int(rng.integers(0, 32))
+                nb_ref = pix_buf(rng, depth, 4 * n + 1, "rand" if kind == "rand" else kind)
+                nb_filt = pix_buf(rng, depth, 4 * n + 1, "rand")
+                yield ("intra_costs %d %s" % (n, kind), "intra_costs", (n, src, stride, off, nb_ref, nb_filt))
     dt = np.uint8 if depth == 8 else np.uint16
     for kind in KINDS:         # lookahead plane preparation: frame_init_lowres_core (pixel.cpp:596-622)
         for _ in range(reps):

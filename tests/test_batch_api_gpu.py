@@ -148,3 +148,30 @@ def test_argument_validation_and_empty_batches(env):
     assert lib.x265hip_me_batch(api.stream(), 16, 16, z, _IP(0), z, _IP(0), z, 5, z, 0, 16, 1, 2, z, z, z, C.c_int64(0)) == -3
     assert b"me_batch" in lib.x265hip_last_error()
     assert lib.x265hip_abi_check(C.c_size_t(18240), depth) == 0 and lib.x265hip_abi_check(C.c_size_t(18240), 12) == -1
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_intra_cost_batch_matches_oracle(depth):
+    """x265hip_intra_cost_batch over many CUs of one plane (offset addressing, 64x64 workspace path)."""
+    from x265hip_pkg.frame import FrameApi
+    from backends import Oracle
+    api, ora = FrameApi(depth), Oracle(depth)
+    T = api.torch
+    rng = np.random.default_rng(5 + depth)
+    dt = np.uint8 if depth == 8 else np.uint16
+    W = H = 256
+    plane = rng.integers(0, 1 << depth, W * H).astype(dt)
+    d_plane = api.to_device(plane)
+    for lg in (2, 3, 4, 5, 6):
+        n, size = 24, 1 << lg
+        offs = np.array([int(rng.integers(0, H - size)) * W + int(rng.integers(0, W - size)) for _ in range(n)], np.int32)
+        pitch = 4 * size + 1 + 3
+        nb_ref = rng.integers(0, 1 << depth, n * pitch).astype(dt)
+        nb_flt = rng.integers(0, 1 << depth, n * pitch).astype(dt)
+        d_cost = T.zeros(n * 35, dtype=T.int32, device="cuda")
+        api.intra_cost_batch(lg, d_plane, W, api.to_device(offs), api.to_device(nb_ref), api.to_device(nb_flt), pitch, n, d_cost)
+        T.cuda.synchronize()
+        got = d_cost.cpu().numpy().reshape(n, 35)
+        for i in range(n):
+            exp = ora.intra_costs(size, plane, W, int(offs[i]), nb_ref[i * pitch:(i + 1) * pitch], nb_flt[i * pitch:(i + 1) * pitch])
+            assert np.array_equal(got[i], exp), "size %d CU %d" % (size, i)

@@ -140,6 +140,132 @@ __global__ __launch_bounds__(256) void intra_allangs_kernel(int N, const pixel* 
     predict_block(N, src, mode, bLuma, dst + ((intptr_t)item * 33 + (mode - 2)) * N * N, N, true, sp, refBuf);
 }
 
+
+// ---- intra mode scan: the data-parallel half of Search::estIntraPredQT (encoder/search.cpp:1655-1745) -------------------
+// One workgroup per (mode, CU): the prediction is built in LDS (never stored), the source block is staged beside it
+// (transposed for the horizontal modes, which the all-angs layout keeps flipped -- search.cpp:1721-1731 compares those
+// with the transposed source), and the workgroup returns sa8d(source, prediction) << costShift.
+// sa8d per size as the table slots are composed (pixel.cpp:291-369, 1180-1184): 4x4 -> satd_4x4 = sum >> 1;
+// 8x8 -> (sum + 2) >> 2; 16x16 -> (four raw 8x8 sums + 2) >> 2; 32x32 -> sum of its four 16x16 values.
+__device__ int had8x8_lds(const pixel* a, const pixel* b, int N)
+{   // raw 8x8 Hadamard |sum| of (a - b), rows N apart
+    int d[8][8];
+#pragma unroll
+    for (int y = 0; y < 8; y++)
+    {
+#pragma unroll
+        for (int x = 0; x < 8; x++) d[y][x] = (int)a[y * N + x] - (int)b[y * N + x];
+#pragma unroll
+        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+            for (int x = 0; x < 8; x++)
+                if (!(x & st)) { int u = d[y][x], v = d[y][x + st]; d[y][x] = u + v; d[y][x + st] = u - v; }
+    }
+    int s = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++)
+    {
+#pragma unroll
+        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+            for (int y = 0; y < 8; y++)
+                if (!(y & st)) { int u = d[y][x], v = d[y + st][x]; d[y][x] = u + v; d[y + st][x] = u - v; }
+#pragma unroll
+        for (int y = 0; y < 8; y++) s += abs(d[y][x]);
+    }
+    return s;
+}
+__global__ __launch_bounds__(256) void intra_cost_kernel(int N, int origSize, const pixel* __restrict__ src, intptr_t ss, const int32_t* __restrict__ srcOff,
+                                                         intptr_t srcItemStride, const pixel* __restrict__ nbRef, const pixel* __restrict__ nbFilt, int nbPitch,
+                                                         int costShift, int32_t* __restrict__ costs, int n)
+{
+    __shared__ pixel sp[132];
+    __shared__ pixel refBuf[68];
+    __shared__ pixel s_pred[32 * 32];
+    __shared__ pixel s_fenc[32 * 32];
+    __shared__ int s_part[16];
+    const int mode = blockIdx.x, item = blockIdx.y, tid = threadIdx.x;
+    const bool hor = mode >= 2 && mode < 18;
+    // which neighbour array, which edge filter (search.cpp:1702-1735)
+    bool useFilt;
+    if (mode == 1) useFilt = false;
+    else if (mode == 0) useFilt = (origSize & (8 | 16 | 32)) != 0;
+    else useFilt = (k_intraFilterFlags[mode] & N) != 0;
+    const int bFilter = mode == 0 ? 0 : (N <= 16);
+    const pixel* nb = (useFilt ? nbFilt : nbRef) + (intptr_t)item * nbPitch;
+    predict_block(N, nb, mode, bFilter, s_pred, N, true, sp, refBuf);
+    const pixel* f = src + (srcOff ? (intptr_t)srcOff[item] : (intptr_t)item * srcItemStride);
+    const int lg = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+    for (int i = tid; i < N * N; i += 256)
+    {
+        const int y = i >> lg, x = i & (N - 1);
+        s_fenc[i] = hor ? f[(intptr_t)x * ss + y] : f[(intptr_t)y * ss + x];
+    }
+    __syncthreads();
+    int cost = 0;
+    if (N == 4)
+    {
+        if (tid == 0)
+        {   // satd_4x4 (pixel.cpp:210-231)
+            int d[4][4], s = 0;
+            for (int y = 0; y < 4; y++)
+            {
+                for (int x = 0; x < 4; x++) d[y][x] = (int)s_fenc[y * 4 + x] - (int)s_pred[y * 4 + x];
+                int a0 = d[y][0] + d[y][1], a1 = d[y][0] - d[y][1], a2 = d[y][2] + d[y][3], a3 = d[y][2] - d[y][3];
+                d[y][0] = a0 + a2; d[y][2] = a0 - a2; d[y][1] = a1 + a3; d[y][3] = a1 - a3;
+            }
+            for (int x = 0; x < 4; x++)
+            {
+                int a0 = d[0][x] + d[1][x], a1 = d[0][x] - d[1][x], a2 = d[2][x] + d[3][x], a3 = d[2][x] - d[3][x];
+                s += abs(a0 + a2) + abs(a0 - a2) + abs(a1 + a3) + abs(a1 - a3);
+            }
+            cost = s >> 1;
+        }
+    }
+    else
+    {
+        const int per = N >> 3, nsub = per * per;                 // 8x8 sub-blocks
+        if (tid < nsub)
+        {
+            const int by = tid / per, bx = tid - by * per;
+            s_part[tid] = had8x8_lds(s_fenc + (by * 8) * N + bx * 8, s_pred + (by * 8) * N + bx * 8, N);
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            if (N == 8) cost = (s_part[0] + 2) >> 2;
+            else
+            {   // per 16x16: four raw sums, one rounding (pixel.cpp:330-345); 32x32 adds its four 16x16 values
+                for (int qy = 0; qy < per; qy += 2)
+                    for (int qx = 0; qx < per; qx += 2)
+                        cost += (s_part[qy * per + qx] + s_part[qy * per + qx + 1] + s_part[(qy + 1) * per + qx] + s_part[(qy + 1) * per + qx + 1] + 2) >> 2;
+            }
+        }
+    }
+    if (tid == 0) costs[(intptr_t)item * 35 + mode] = cost << costShift;
+}
+// 64x64 CUs: the reference scales source and neighbours to 32x32 first (search.cpp:1670-1688; pixel.cpp:551-594)
+__global__ __launch_bounds__(256) void intra_scale64_kernel(const pixel* __restrict__ src, intptr_t ss, const int32_t* __restrict__ srcOff,
+                                                            const pixel* __restrict__ nbRef, int nbPitch, pixel* __restrict__ fencS /* n x 1024 */,
+                                                            pixel* __restrict__ nbS /* n x 129 */, int n)
+{
+    const int item = blockIdx.x, tid = threadIdx.x;
+    const pixel* f = src + srcOff[item];
+    for (int i = tid; i < 1024; i += 256)
+    {   // scale2D_64to32: rounded mean of 2x2
+        const int y = i >> 5, x = i & 31;
+        const pixel* p = f + (intptr_t)(2 * y) * ss + 2 * x;
+        fencS[(intptr_t)item * 1024 + i] = (pixel)((p[0] + p[1] + p[ss] + p[ss + 1] + 2) >> 2);
+    }
+    const pixel* r = nbRef + (intptr_t)item * nbPitch;
+    pixel* o = nbS + (intptr_t)item * 129;
+    if (tid == 0) o[0] = r[0];
+    for (int i = tid; i < 128; i += 256)
+    {   // scale1D_128to64 on both halves: dst[x] = (src[2x] + src[2x+1] + 1) >> 1 for the 64 above and the 64 left samples
+        o[1 + i] = (pixel)((r[1 + 2 * i] + r[1 + 2 * i + 1] + 1) >> 1);
+    }
+}
+
 bool bad_n(int N) { return N != 4 && N != 8 && N != 16 && N != 32; }
 
 } // namespace
@@ -167,6 +293,36 @@ extern "C" int x265hip_intra_allangs_batch(void* stream, int N, const void* ref,
     if (n <= 0) return X265HIP_OK;
     if (bad_n(N)) { set_error("intra_allangs_batch: N must be 4/8/16/32"); return X265HIP_EARG; }
     hipLaunchKernelGGL(intra_allangs_kernel, dim3(33, n), dim3(256), 0, (hipStream_t)stream, N, (const pixel*)ref, refOff, (const pixel*)filt, filtOff, (pixel*)dst, bLuma, n);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" size_t x265hip_intra_cost_workspace(int log2Size, int n)
+{
+    return log2Size == 6 ? (size_t)n * (1024 + 129 + 3) * sizeof(pixel) : 0;
+}
+extern "C" int x265hip_intra_cost_batch(void* stream, int log2Size, const void* srcPlane, intptr_t srcStride, const int32_t* srcOff,
+                                        const void* nbRef, const void* nbFilt, int nbPitch, int n, int32_t* costs,
+                                        void* workspace, size_t workspaceBytes)
+{
+    if (n <= 0) return X265HIP_OK;
+    if (log2Size < 2 || log2Size > 6 || !srcPlane || !srcOff || !nbRef || !nbFilt || !costs || nbPitch < 4 * (1 << log2Size) + 1)
+    { set_error("intra_cost_batch: bad arguments"); return X265HIP_EARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int size = 1 << log2Size;
+    if (size == 64)
+    {
+        if (!workspace || workspaceBytes < x265hip_intra_cost_workspace(6, n)) { set_error("intra_cost_batch: workspace too small for 64x64 CUs"); return X265HIP_EARG; }
+        pixel* fencS = (pixel*)workspace; pixel* nbS = fencS + (size_t)n * 1024;
+        hipLaunchKernelGGL(intra_scale64_kernel, dim3(n), dim3(256), 0, st, (const pixel*)srcPlane, srcStride, srcOff, (const pixel*)nbRef, nbPitch, fencS, nbS, n);
+        XH_LAUNCH_CHECK();
+        // "we do not estimate filtering for downscaled samples": both neighbour arrays are the scaled unfiltered one
+        hipLaunchKernelGGL(intra_cost_kernel, dim3(35, n), dim3(256), 0, st, 32, 64, (const pixel*)fencS, (intptr_t)32, (const int32_t*)nullptr, (intptr_t)1024,
+                           (const pixel*)nbS, (const pixel*)nbS, 129, 2, costs, n);
+    }
+    else
+        hipLaunchKernelGGL(intra_cost_kernel, dim3(35, n), dim3(256), 0, st, size, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+                           (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -70,6 +70,16 @@ class FrameApi:
         self.h.check(self.lib.x265hip_extend_pic_border(self.stream(), org, C.c_ssize_t(stride), width, height, margin_x, margin_y,
                                                         n_pictures, C.c_int64(picture_elems)))
 
+    def intra_cost_batch(self, log2_size, src, src_stride, src_off, nb_ref, nb_filt, nb_pitch, n, costs, workspace=None):
+        """sa8d of the 35 intra predictions of n CUs (the mode scan of Search::estIntraPredQT); costs: int32 tensor n x 35."""
+        self.lib.x265hip_intra_cost_workspace.restype = C.c_size_t
+        need = int(self.lib.x265hip_intra_cost_workspace(log2_size, n))
+        if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+            workspace = self.torch.empty(need, dtype=self.torch.uint8, device="cuda")
+        self.h.check(self.lib.x265hip_intra_cost_batch(self.stream(), log2_size, _dp(src), C.c_ssize_t(src_stride), _dp(src_off), _dp(nb_ref), _dp(nb_filt),
+                                                       nb_pitch, n, _dp(costs), _dp(workspace), C.c_size_t(need)))
+        return workspace
+
     def frame_init_lowres(self, src, src_stride, d0, dh, dv, dc, dst_stride, width, height):
         self.h.check(self.lib.x265hip_frame_init_lowres(self.stream(), _dp(src), C.c_ssize_t(src_stride), _dp(d0), _dp(dh), _dp(dv), _dp(dc),
                                                         C.c_ssize_t(dst_stride), width, height))
