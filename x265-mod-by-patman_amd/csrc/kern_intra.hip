@@ -266,6 +266,117 @@ __global__ __launch_bounds__(256) void intra_scale64_kernel(const pixel* __restr
     }
 }
 
+// ---- the same scan with one WAVEFRONT per (mode, CU) pass: lane = pixel of an 8x8 sub-block ---------------------------------
+// A workgroup owns one CU (neighbour arrays and source block staged in LDS once); its four wavefronts take the 35 modes
+// round-robin.  Per 8x8 sub-block every lane predicts ITS pixel straight from the LDS neighbour arrays (the projected
+// reference of negative angles is evaluated on the fly, intrapred.cpp:136-150) and the 64 differences go through a
+// 64-point Walsh-Hadamard transform across the lanes (six butterfly stages: DPP quad_perm / bank-masked row shifts /
+// row_ror:8, then v_permlane16_swap and v_permlane32_swap) -- the 2-D 8x8 Hadamard of sa8d up to coefficient order.
+#define XI_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+__device__ __forceinline__ int wht64_abs_sum(int d, int lane)
+{
+    const int s1 = (lane & 1) ? -1 : 1, s2 = (lane & 2) ? -1 : 1, s4 = (lane & 4) ? -1 : 1, s8 = (lane & 8) ? -1 : 1, s16 = (lane & 16) ? -1 : 1, s32 = (lane & 32) ? -1 : 1;
+    d = XI_DPP(d, 0xB1) + __mul24(d, s1);                                     // lane ^ 1
+    d = XI_DPP(d, 0x4E) + __mul24(d, s2);                                     // lane ^ 2
+    {   // lane ^ 4: row_shl:4 into banks 0/2, row_shr:4 into banks 1/3
+        int o = __builtin_amdgcn_update_dpp(0, d, 0x104, 0xF, 0x5, false);
+        o = __builtin_amdgcn_update_dpp(o, d, 0x114, 0xF, 0xA, false);
+        d = o + __mul24(d, s4);
+    }
+    d = XI_DPP(d, 0x128) + __mul24(d, s8);                                    // row_ror:8 = lane ^ 8
+    { auto r = __builtin_amdgcn_permlane16_swap((unsigned)d, (unsigned)d, false, false); d = (int)((lane & 16) ? r[0] : r[1]) + __mul24(d, s16); }
+    { auto r = __builtin_amdgcn_permlane32_swap((unsigned)d, (unsigned)d, false, false); d = (int)((lane & 32) ? r[0] : r[1]) + __mul24(d, s32); }
+    return wave_sum(abs(d));
+}
+// neighbour sample i of the array a mode works on: the array itself, or "flipped" (above <-> left) for horizontal modes
+__device__ __forceinline__ int nb_at(const pixel* a, int i, bool flip, int n2) { return a[flip && i >= 1 ? (i <= n2 ? i + n2 : i - n2) : i]; }
+
+template<int N>
+__global__ __launch_bounds__(256) void intra_scan_kernel(int origSize, const pixel* __restrict__ src, intptr_t ss, const int32_t* __restrict__ srcOff, intptr_t srcItemStride,
+                                                         const pixel* __restrict__ nbRef, const pixel* __restrict__ nbFilt, int nbPitch,
+                                                         int costShift, int32_t* __restrict__ costs, int n)
+{
+    constexpr int n2 = 2 * N, NB = 4 * N + 1, LG = N == 8 ? 3 : N == 16 ? 4 : 5, PER = N / 8;
+    __shared__ pixel s_nb[2][NB + 3];
+    __shared__ pixel s_fenc[N * N];
+    const int item = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (item >= n) return;
+    {
+        const pixel* r = nbRef + (intptr_t)item * nbPitch; const pixel* fl = nbFilt + (intptr_t)item * nbPitch;
+        for (int i = tid; i < NB; i += 256) { s_nb[0][i] = r[i]; s_nb[1][i] = fl[i]; }
+        const pixel* f = src + (srcOff ? (intptr_t)srcOff[item] : (intptr_t)item * srcItemStride);
+        for (int i = tid; i < N * N; i += 256) s_fenc[i] = f[(intptr_t)(i >> LG) * ss + (i & (N - 1))];
+    }
+    __syncthreads();
+    const int px = lane & 7, py = lane >> 3;
+    for (int mode = wave; mode < 35; mode += 4)
+    {
+        const bool hor = mode >= 2 && mode < 18;
+        const bool useFilt = mode == 1 ? false : mode == 0 ? (origSize & (8 | 16 | 32)) != 0 : (k_intraFilterFlags[mode] & N) != 0;
+        const bool bFilter = mode != 0 && N <= 16;
+        const pixel* a = s_nb[useFilt ? 1 : 0];
+        int dc = 0, angle = 0, invAngle = 0;
+        if (mode == 1)
+        {   // DC value (intrapred.cpp:58-64): N above + N left samples, one or two per lane
+            int v = 0;
+            for (int i = lane; i < n2; i += 64) v += i < N ? a[1 + i] : a[n2 + 1 + i - N];
+            dc = (wave_sum(v) + N) / n2;
+        }
+        else if (mode >= 2)
+        {
+            const int angleOffset = hor ? 10 - mode : mode - 26;
+            angle = k_angleTable[8 + angleOffset];
+            if (angle < 0) invAngle = k_invAngleTable[-angleOffset - 1];
+        }
+        int total = 0, sum16 = 0;
+        for (int sb = 0; sb < PER * PER; sb++)
+        {
+            // sub-block order: the four 8x8 of a 16x16 are consecutive (sa8d rounds per 16x16, pixel.cpp:330-345)
+            const int q = sb >> 2, r4 = sb & 3;
+            const int bx = PER == 1 ? 0 : ((q % (PER / 2 > 0 ? PER / 2 : 1)) * 2 + (r4 & 1)), by = PER == 1 ? 0 : ((q / (PER / 2 > 0 ? PER / 2 : 1)) * 2 + (r4 >> 1));
+            const int x = bx * 8 + px, y = by * 8 + py;
+            int p;
+            if (mode == 0)
+            {   // planar (intrapred.cpp:87-100)
+                const int tr = a[1 + N], bl = a[n2 + 1 + N];
+                p = ((N - 1 - x) * a[n2 + 1 + y] + (N - 1 - y) * a[1 + x] + (x + 1) * tr + (y + 1) * bl + N) >> (LG + 1);
+            }
+            else if (mode == 1)
+            {   // DC + edge filter (intrapred.cpp:66-85)
+                p = dc;
+                if (bFilter)
+                {
+                    if (x == 0 && y == 0) p = (a[1] + a[n2 + 1] + 2 * dc + 2) >> 2;
+                    else if (y == 0) p = (a[1 + x] + 3 * dc + 2) >> 2;
+                    else if (x == 0) p = (a[n2 + 1 + y] + 3 * dc + 2) >> 2;
+                }
+            }
+            else if (!angle)
+            {   // pure vertical (or horizontal, on the flipped array): copy + optional edge filter (intrapred.cpp:152-166)
+                p = nb_at(a, 1 + x, hor, n2);
+                if (bFilter && x == 0) p = clip_pixel((int16_t)(nb_at(a, 1, hor, n2) + ((nb_at(a, n2 + 1 + y, hor, n2) - (int)a[0]) >> 1)));
+            }
+            else
+            {   // 1/32-pel two-tap interpolation along the (possibly projected) reference row (intrapred.cpp:168-190)
+                const int angleSum = (y + 1) * angle, off = angleSum >> 5, frac = angleSum & 31;
+                auto ref = [&](int j) -> int {          // ref[j], j >= -1: the main array; j < -1: projected from the side array
+                    return j >= -1 ? nb_at(a, 1 + j, hor, n2) : nb_at(a, n2 + ((128 + (-1 - j) * invAngle) >> 8), hor, n2);
+                };
+                p = frac ? ((32 - frac) * ref(off + x) + frac * ref(off + x + 1) + 16) >> 5 : ref(off + x);
+            }
+            const int f = hor ? s_fenc[x * N + y] : s_fenc[y * N + x];
+            const int raw = wht64_abs_sum(f - p, lane);
+            if (N == 8) total = (raw + 2) >> 2;
+            else
+            {
+                sum16 += raw;
+                if (r4 == 3) { total += (sum16 + 2) >> 2; sum16 = 0; }
+            }
+        }
+        if (lane == 0) costs[(intptr_t)item * 35 + mode] = total << costShift;
+    }
+}
+
 bool bad_n(int N) { return N != 4 && N != 8 && N != 16 && N != 32; }
 
 } // namespace
@@ -317,11 +428,20 @@ extern "C" int x265hip_intra_cost_batch(void* stream, int log2Size, const void* 
         hipLaunchKernelGGL(intra_scale64_kernel, dim3(n), dim3(256), 0, st, (const pixel*)srcPlane, srcStride, srcOff, (const pixel*)nbRef, nbPitch, fencS, nbS, n);
         XH_LAUNCH_CHECK();
         // "we do not estimate filtering for downscaled samples": both neighbour arrays are the scaled unfiltered one
-        hipLaunchKernelGGL(intra_cost_kernel, dim3(35, n), dim3(256), 0, st, 32, 64, (const pixel*)fencS, (intptr_t)32, (const int32_t*)nullptr, (intptr_t)1024,
+        hipLaunchKernelGGL(intra_scan_kernel<32>, dim3(n), dim3(256), 0, st, 64, (const pixel*)fencS, (intptr_t)32, (const int32_t*)nullptr, (intptr_t)1024,
                            (const pixel*)nbS, (const pixel*)nbS, 129, 2, costs, n);
     }
-    else
+    else if (size == 4)     // 16 pixels: the workgroup-per-(mode, CU) form
         hipLaunchKernelGGL(intra_cost_kernel, dim3(35, n), dim3(256), 0, st, size, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+                           (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
+    else if (size == 8)
+        hipLaunchKernelGGL(intra_scan_kernel<8>, dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+                           (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
+    else if (size == 16)
+        hipLaunchKernelGGL(intra_scan_kernel<16>, dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+                           (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
+    else
+        hipLaunchKernelGGL(intra_scan_kernel<32>, dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
