@@ -49,8 +49,66 @@ def parse():
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
+    ap.add_argument("--intra", action="store_true", help="also time the intra mode scan (35 sa8d costs per CU, sizes 64..8) over the same frames; reported under \"intra_scan\", not part of value")
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
+
+
+def intra_scan_leg(pipe, depth, steps):
+    """Intra mode scan (x265hip_intra_cost_batch) of every CU of sizes 64, 32, 16, 8 of the step's source frames.  The neighbour
+    arrays are taken from the source picture (like the lookahead, slicetype.cpp:800-831): above row, left column, top-left;
+    the filtered arrays come from x265hip_intra_filter_batch.  A sample of CUs is checked against the reference's primitives."""
+    import torch
+    from refproc import RefProc, ref_available
+    api, T = pipe.api, torch
+    W, H, F, m, st = pipe.W, pipe.H, pipe.F, pipe.margin, pipe.stride
+    cur = pipe.cur_host
+    legs, total_ms, checked = {}, 0.0, 0
+    rng = np.random.default_rng(3)
+    for lg in (6, 5, 4, 3):
+        n_ = 1 << lg
+        nx, ny = W // n_, H // n_
+        f, by, bx = np.meshgrid(np.arange(F), np.arange(ny), np.arange(nx), indexing="ij")
+        org = (f * pipe.plane + (m + by * n_) * st + m + bx * n_).reshape(-1).astype(np.int64)
+        n = len(org)
+        pitch = 4 * n_ + 1
+        nb = np.empty((n, pitch), cur.dtype)
+        nb[:, 0] = cur[org - st - 1]
+        nb[:, 1:2 * n_ + 1] = cur[(org - st)[:, None] + np.arange(2 * n_)[None, :]]
+        nb[:, 2 * n_ + 1:] = cur[(org - 1)[:, None] + (np.arange(2 * n_) * st)[None, :]]
+        d_nb = api.to_device(nb.reshape(-1))
+        d_flt = T.empty_like(d_nb)
+        if n_ <= 32:
+            import ctypes
+            api.h.check(api.lib.x265hip_intra_filter_batch(api.stream(), n_, ctypes.c_void_p(d_nb.data_ptr()), None, ctypes.c_void_p(d_flt.data_ptr()), None, n))
+        else:
+            d_flt.copy_(d_nb)
+        d_off = api.to_device(org.astype(np.int32))
+        d_cost = T.zeros(n * 35, dtype=T.int32, device="cuda")
+        ws = api.intra_cost_batch(lg, pipe.d_cur, st, d_off, d_nb, d_flt, pitch, n, d_cost)
+        T.cuda.synchronize()
+        e0, e1 = T.cuda.Event(enable_timing=True), T.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            api.intra_cost_batch(lg, pipe.d_cur, st, d_off, d_nb, d_flt, pitch, n, d_cost, workspace=ws)
+        e1.record(); T.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        legs["intra%d" % n_] = round(ms, 4); total_ms += ms
+        if ref_available(depth):
+            got = d_cost.cpu().numpy().reshape(n, 35)
+            flt = d_flt.cpu().numpy().view(cur.dtype).reshape(n, pitch)
+            r = RefProc(depth)
+            try:
+                for i in rng.choice(n, size=min(12, n), replace=False):
+                    exp = np.frombuffer(r.call("intra_costs", [n_, st, int(org[i])], [cur, nb[i], flt[i]])[0], np.int32)
+                    assert np.array_equal(got[i], exp), "intra scan: CU %d of size %d differs from the reference" % (i, n_)
+                    checked += 1
+            finally:
+                r.close()
+    px = pipe.pixels_per_step
+    return {"ms_per_step": round(total_ms, 4), "Mpixels/s": round(px / (total_ms * 1e-3) / 1e6, 1), "kernels_ms": legs,
+            "what": "sa8d of the 35 intra predictions of every CU of sizes 64/32/16/8 (4 launches; mode bits and RD decision stay on the host)",
+            "checked_vs_reference": "%d CUs identical" % checked if checked else "reference binary not present"}
 
 
 def cpu_baseline(pipe, depth, n_ctus):
@@ -289,6 +347,8 @@ def main():
                          "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()},
                          "all_kernels_GBps": {k: round(alg[k] / (v * 1e-3) / 1e9, 2) for k, v in kms.items()}},
         }
+        if args.intra:
+            out["intra_scan"] = intra_scan_leg(pipe, depth, max(2, min(args.steps, 10)))
         if world == 1 and args.cpu_ctus > 0:
             out["cpu_baseline"] = cpu_baseline(pipe, depth, args.cpu_ctus)
         else:

@@ -256,12 +256,13 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         pixelcmp_t sa8d = T.cu[sizeIdx].sa8d;
         int predsize = scaleTuSize * scaleTuSize;
         std::vector<int32_t> c(35);
-        T.cu[sizeIdx].intra_pred[DC_IDX](predBuf, scaleStride, nb[0], 0, (scaleTuSize <= 16));
-        c[DC_IDX] = sa8d(fenc, scaleStride, predBuf, scaleStride) << costShift;
+        /* (in search.cpp fenc is a compact CU buffer, so its stride doubles as the prediction stride; here fenc lives in a plane) */
+        T.cu[sizeIdx].intra_pred[DC_IDX](predBuf, scaleTuSize, nb[0], 0, (scaleTuSize <= 16));
+        c[DC_IDX] = sa8d(fenc, scaleStride, predBuf, scaleTuSize) << costShift;
         pixel* planar = nb[0];
         if (tuSize & (8 | 16 | 32)) planar = nb[1];
-        T.cu[sizeIdx].intra_pred[PLANAR_IDX](predBuf, scaleStride, planar, 0, 0);
-        c[PLANAR_IDX] = sa8d(fenc, scaleStride, predBuf, scaleStride) << costShift;
+        T.cu[sizeIdx].intra_pred[PLANAR_IDX](predBuf, scaleTuSize, planar, 0, 0);
+        c[PLANAR_IDX] = sa8d(fenc, scaleStride, predBuf, scaleTuSize) << costShift;
         T.cu[sizeIdx].transpose(fencT, fenc, scaleStride);
         /* the C table leaves intra_pred_allangs NULL (primitives.cpp:348); all_angs_pred_c is what the asm slot computes */
         for (int mode = 2; mode < 35; mode++)
