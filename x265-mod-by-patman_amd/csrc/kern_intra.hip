@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void intra_scale64_kernel(const pixel* __restr
 // 64-point Walsh-Hadamard transform across the lanes (six butterfly stages: DPP quad_perm / bank-masked row shifts /
 // row_ror:8, then v_permlane16_swap and v_permlane32_swap) -- the 2-D 8x8 Hadamard of sa8d up to coefficient order.
 #define XI_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
-__device__ __forceinline__ int wht64_abs_sum(int d, int lane)
+__device__ __forceinline__ int wht64_abs(int d, int lane)      // |coefficient| held by this lane; the caller sums over lanes
 {
     const int s1 = (lane & 1) ? -1 : 1, s2 = (lane & 2) ? -1 : 1, s4 = (lane & 4) ? -1 : 1, s8 = (lane & 8) ? -1 : 1, s16 = (lane & 16) ? -1 : 1, s32 = (lane & 32) ? -1 : 1;
     d = XI_DPP(d, 0xB1) + __mul24(d, s1);                                     // lane ^ 1
@@ -286,7 +286,7 @@ __device__ __forceinline__ int wht64_abs_sum(int d, int lane)
     d = XI_DPP(d, 0x128) + __mul24(d, s8);                                    // row_ror:8 = lane ^ 8
     { auto r = __builtin_amdgcn_permlane16_swap((unsigned)d, (unsigned)d, false, false); d = (int)((lane & 16) ? r[0] : r[1]) + __mul24(d, s16); }
     { auto r = __builtin_amdgcn_permlane32_swap((unsigned)d, (unsigned)d, false, false); d = (int)((lane & 32) ? r[0] : r[1]) + __mul24(d, s32); }
-    return wave_sum(abs(d));
+    return abs(d);
 }
 // neighbour sample i of the array a mode works on: the array itself, or "flipped" (above <-> left) for horizontal modes
 __device__ __forceinline__ int nb_at(const pixel* a, int i, bool flip, int n2) { return a[flip && i >= 1 ? (i <= n2 ? i + n2 : i - n2) : i]; }
@@ -365,13 +365,9 @@ __global__ __launch_bounds__(256) void intra_scan_kernel(int origSize, const pix
                 p = frac ? ((32 - frac) * ref(off + x) + frac * ref(off + x + 1) + 16) >> 5 : ref(off + x);
             }
             const int f = hor ? s_fenc[x * N + y] : s_fenc[y * N + x];
-            const int raw = wht64_abs_sum(f - p, lane);
-            if (N == 8) total = (raw + 2) >> 2;
-            else
-            {
-                sum16 += raw;
-                if (r4 == 3) { total += (sum16 + 2) >> 2; sum16 = 0; }
-            }
+            sum16 += wht64_abs(f - p, lane);                                   // per-lane partial of the current 8x8 / 16x16
+            if (N == 8) total = (wave_sum(sum16) + 2) >> 2;
+            else if (r4 == 3) { total += (wave_sum(sum16) + 2) >> 2; sum16 = 0; }
         }
         if (lane == 0) costs[(intptr_t)item * 35 + mode] = total << costShift;
     }
