@@ -291,25 +291,30 @@ __device__ __forceinline__ int wht64_abs(int d, int lane)      // |coefficient| 
 // neighbour sample i of the array a mode works on: the array itself, or "flipped" (above <-> left) for horizontal modes
 __device__ __forceinline__ int nb_at(const pixel* a, int i, bool flip, int n2) { return a[flip && i >= 1 ? (i <= n2 ? i + n2 : i - n2) : i]; }
 
-template<int N>
+template<int N, int CPB>      // CPB = CUs per workgroup: 1 (the four wavefronts share one CU's modes) or 4 (one wavefront per CU, all 35 modes)
 __global__ __launch_bounds__(256) void intra_scan_kernel(int origSize, const pixel* __restrict__ src, intptr_t ss, const int32_t* __restrict__ srcOff, intptr_t srcItemStride,
                                                          const pixel* __restrict__ nbRef, const pixel* __restrict__ nbFilt, int nbPitch,
                                                          int costShift, int32_t* __restrict__ costs, int n)
 {
     constexpr int n2 = 2 * N, NB = 4 * N + 1, LG = N == 8 ? 3 : N == 16 ? 4 : 5, PER = N / 8;
-    __shared__ pixel s_nb[2][NB + 3];
-    __shared__ pixel s_fenc[N * N];
-    const int item = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    if (item >= n) return;
+    __shared__ pixel s_nbAll[CPB][2][NB + 3];
+    __shared__ pixel s_fencAll[CPB][N * N];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int item = CPB == 1 ? (int)blockIdx.x : (int)blockIdx.x * CPB + wave;
+    if (item >= n) return;                                      // wave-granular for CPB == 4 (no workgroup barrier below in that case)
+    pixel (*s_nb)[NB + 3] = s_nbAll[CPB == 1 ? 0 : wave];
+    pixel* s_fenc = s_fencAll[CPB == 1 ? 0 : wave];
     {
+        constexpr int T = CPB == 1 ? 256 : 64;
+        const int t = CPB == 1 ? tid : lane;
         const pixel* r = nbRef + (intptr_t)item * nbPitch; const pixel* fl = nbFilt + (intptr_t)item * nbPitch;
-        for (int i = tid; i < NB; i += 256) { s_nb[0][i] = r[i]; s_nb[1][i] = fl[i]; }
+        for (int i = t; i < NB; i += T) { s_nb[0][i] = r[i]; s_nb[1][i] = fl[i]; }
         const pixel* f = src + (srcOff ? (intptr_t)srcOff[item] : (intptr_t)item * srcItemStride);
-        for (int i = tid; i < N * N; i += 256) s_fenc[i] = f[(intptr_t)(i >> LG) * ss + (i & (N - 1))];
+        for (int i = t; i < N * N; i += T) s_fenc[i] = f[(intptr_t)(i >> LG) * ss + (i & (N - 1))];
     }
-    __syncthreads();
+    if (CPB == 1) __syncthreads(); else wave_sync();
     const int px = lane & 7, py = lane >> 3;
-    for (int mode = wave; mode < 35; mode += 4)
+    for (int mode = CPB == 1 ? wave : 0; mode < 35; mode += CPB == 1 ? 4 : 1)
     {
         const bool hor = mode >= 2 && mode < 18;
         const bool useFilt = mode == 1 ? false : mode == 0 ? (origSize & (8 | 16 | 32)) != 0 : (k_intraFilterFlags[mode] & N) != 0;
@@ -424,20 +429,20 @@ extern "C" int x265hip_intra_cost_batch(void* stream, int log2Size, const void* 
         hipLaunchKernelGGL(intra_scale64_kernel, dim3(n), dim3(256), 0, st, (const pixel*)srcPlane, srcStride, srcOff, (const pixel*)nbRef, nbPitch, fencS, nbS, n);
         XH_LAUNCH_CHECK();
         // "we do not estimate filtering for downscaled samples": both neighbour arrays are the scaled unfiltered one
-        hipLaunchKernelGGL(intra_scan_kernel<32>, dim3(n), dim3(256), 0, st, 64, (const pixel*)fencS, (intptr_t)32, (const int32_t*)nullptr, (intptr_t)1024,
+        hipLaunchKernelGGL((intra_scan_kernel<32, 1>), dim3(n), dim3(256), 0, st, 64, (const pixel*)fencS, (intptr_t)32, (const int32_t*)nullptr, (intptr_t)1024,
                            (const pixel*)nbS, (const pixel*)nbS, 129, 2, costs, n);
     }
     else if (size == 4)     // 16 pixels: the workgroup-per-(mode, CU) form
         hipLaunchKernelGGL(intra_cost_kernel, dim3(35, n), dim3(256), 0, st, size, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     else if (size == 8)
-        hipLaunchKernelGGL(intra_scan_kernel<8>, dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+        hipLaunchKernelGGL((intra_scan_kernel<8, 4>), dim3((n + 3) / 4), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     else if (size == 16)
-        hipLaunchKernelGGL(intra_scan_kernel<16>, dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+        hipLaunchKernelGGL((intra_scan_kernel<16, 1>), dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     else
-        hipLaunchKernelGGL(intra_scan_kernel<32>, dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+        hipLaunchKernelGGL((intra_scan_kernel<32, 1>), dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
