@@ -439,7 +439,7 @@ extern "C" int x265hip_intra_cost_batch(void* stream, int log2Size, const void* 
         hipLaunchKernelGGL((intra_scan_kernel<8, 4>), dim3((n + 3) / 4), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     else if (size == 16)
-        hipLaunchKernelGGL((intra_scan_kernel<16, 1>), dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+        hipLaunchKernelGGL((intra_scan_kernel<16, 4>), dim3((n + 3) / 4), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     else
         hipLaunchKernelGGL((intra_scan_kernel<32, 1>), dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
