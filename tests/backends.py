@@ -335,7 +335,8 @@ class Hip:
         f = filt.copy(); self.h.cu(n, "intra_filter", None, (_VP, _VP))(_p(samples), _p(f)); return f
 
     def intra_pred(self, n, src, dst, ds, mode, bfilter):
-        d = dst.copy(); self.h.cu(n, "intra_pred", None, (_VP, _IP, _VP, _I, _I), extra=mode)(_p(d), ds, _p(src), mode, bfilter); return d
+        # planar / DC slots get dirMode 0 like the reference's callers and its harness (search.cpp:1702,1713; intrapredharness.cpp:62,98)
+        d = dst.copy(); self.h.cu(n, "intra_pred", None, (_VP, _IP, _VP, _I, _I), extra=mode)(_p(d), ds, _p(src), mode if mode >= 2 else 0, bfilter); return d
 
     def intra_allangs(self, n, ref, filt, bluma):
         d = np.zeros(33 * n * n, self.pixel); self.h.cu(n, "intra_pred_allangs", None, (_VP, _VP, _VP, _I))(_p(d), _p(ref), _p(filt), bluma); return d

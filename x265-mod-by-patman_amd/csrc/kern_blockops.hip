@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void blockop_kernel(int w, int h, BlkArgs a, i
     const intptr_t dO = a.dOff ? a.dOff[item] : 0, o0 = a.s0Off ? a.s0Off[item] : 0, o1 = a.s1Off ? a.s1Off[item] : 0;
     const int ow = (OP == X265HIP_BLK_SCALE2D) ? 32 : (OP == X265HIP_BLK_SCALE1D ? 64 : w);
     const int oh = (OP == X265HIP_BLK_SCALE2D) ? 32 : (OP == X265HIP_BLK_SCALE1D ? 2 : h);
-    for (int i = threadIdx.x; i < ow * oh; i += 256)
+    // blockIdx.y spreads big blocks (weight_pp / weight_sp run over whole reference planes, reference.cpp:161-163)
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < ow * oh; i += 256 * gridDim.y)
     {
         const int y = i / ow, x = i - y * ow;
         if (OP == X265HIP_BLK_CALCRESIDUAL || OP == X265HIP_BLK_SUB_PS)
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(256) void blockop_kernel(int w, int h, BlkArgs a, i
 
 template<int OP> int launch(hipStream_t st, int w, int h, const BlkArgs& a, int n)
 {
-    hipLaunchKernelGGL(blockop_kernel<OP>, dim3(n), dim3(256), 0, st, w, h, a, n);
+    const long long elems = (long long)w * h;
+    const unsigned gy = (unsigned)(elems <= 4096 ? 1 : (elems + 4095) / 4096 > 2048 ? 2048 : (elems + 4095) / 4096);
+    hipLaunchKernelGGL(blockop_kernel<OP>, dim3(n, gy), dim3(256), 0, st, w, h, a, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -169,7 +172,7 @@ extern "C" int x265hip_extend_pic_border(void* stream, void* picOrg, intptr_t st
 extern "C" int x265hip_blockop_batch(void* stream, int op, int w, int h, const x265hip_blk_args* args, int n)
 {
     if (n <= 0) return X265HIP_OK;
-    if (!args || w < 1 || h < 1 || w > 128 || h > 128) { set_error("blockop_batch: bad arguments"); return X265HIP_EARG; }
+    if (!args || w < 1 || h < 1 || w > 16384 || h > 16384) { set_error("blockop_batch: bad arguments (op %d, %dx%d)", op, w, h); return X265HIP_EARG; }
     BlkArgs a = { args->dst, args->dstStride, args->dstOff, args->src0, args->src0Stride, args->src0Off,
                   args->src1, args->src1Stride, args->src1Off, args->p0, args->p1, args->p2, args->p3 };
     hipStream_t st = (hipStream_t)stream;
