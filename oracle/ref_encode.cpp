@@ -13,7 +13,7 @@
  * Both modes must produce the SAME BITSTREAM: that is the drop-in claim, checked end to end through the untouched
  * RDO / entropy coder.  (The per-slot path stages every block over PCIe -- it is a parity vehicle, not the fast path.)
  *
- * usage: x265enc_<depth> c|hip <libx265hip.so or -> <width> <height> <frames> <preset> <out.hevc>
+ * usage: x265enc_<depth> c|hip <libx265hip.so or -> <width> <height> <frames> <preset> <out.hevc> [option=value ...]   (x265_param_parse names)
  */
 #include "x265.h"
 #include "common.h"
@@ -26,6 +26,7 @@
 #include <vector>
 
 using namespace X265_NS;
+namespace X265_NS { void enableLowpassDCTPrimitives(EncoderPrimitives& p); }     /* primitives.cpp:77-88 */
 
 static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixel>& v, int w, int h, int f)
 {   // moving smooth texture + deterministic noise (fixed LCG), so that inter and intra tools both have work
@@ -60,6 +61,12 @@ int main(int argc, char** argv)
     p->frameNumThreads = 1; p->bEnableWavefront = 0; p->lookaheadSlices = 0;
     x265_param_parse(p, "pools", "none");
     x265_param_parse(p, "hash", "1");                 // decoded-picture MD5 SEI: the reconstruction is part of the bitstream
+    for (int i = 8; i < argc; i++)
+    {
+        char* eq = strchr(argv[i], '=');
+        if (eq) *eq = 0;
+        if (x265_param_parse(p, argv[i], eq ? eq + 1 : NULL) < 0) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
+    }
 
     x265_setup_primitives(p);
     if (hip)
@@ -82,6 +89,7 @@ int main(int argc, char** argv)
                 if ((long)(i * 8) < lo || (long)(i * 8) >= hi) t[i] = c[i];
         }
         setupAliasPrimitives(primitives);
+        if (p->bLowPassDct) enableLowpassDCTPrimitives(primitives);          /* the step after the alias pass (primitives.cpp:369-372) */
     }
     x265_encoder* enc = x265_encoder_open(p);
     if (!enc) { fprintf(stderr, "encoder_open failed\n"); return 2; }

@@ -20,8 +20,14 @@ def _env():
     return env
 
 
-@pytest.mark.parametrize("depth,w,h,frames,preset", [(8, 64, 64, 2, "ultrafast"), (8, 128, 64, 2, "medium"), (10, 64, 64, 2, "slow")])
-def test_reference_encoder_emits_identical_bitstream_with_the_hip_table(tmp_path, depth, w, h, frames, preset):
+@pytest.mark.parametrize("depth,w,h,frames,preset,extra", [
+    (8, 64, 64, 2, "ultrafast", []),
+    (8, 128, 64, 2, "medium", []),
+    (10, 64, 64, 2, "slow", []),
+    (8, 72, 40, 2, "medium", ["lowpass-dct=1", "weightb=1", "bframes=2"]),       # non-CTU-multiple picture, cu[].lowpass_dct, weight_pp on planes
+    (8, 64, 64, 2, "medium", ["tskip=1", "nr-inter=100", "me=full", "merange=6"]),   # transform skip, denoiseDct, exhaustive search
+])
+def test_reference_encoder_emits_identical_bitstream_with_the_hip_table(tmp_path, depth, w, h, frames, preset, extra):
     enc = os.path.join(ROOT, "oracle", "_ref", "x265enc_%d" % depth)
     lib = os.path.join(ROOT, "x265-mod-by-patman_amd", "libx265hip_%d.so" % depth)
     if not os.path.exists(enc):
@@ -29,7 +35,7 @@ def test_reference_encoder_emits_identical_bitstream_with_the_hip_table(tmp_path
     outs = {}
     for mode in ("c", "hip"):
         out = str(tmp_path / ("%s.hevc" % mode))
-        r = subprocess.run([enc, mode, lib, str(w), str(h), str(frames), preset, out], env=_env(), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([enc, mode, lib, str(w), str(h), str(frames), preset, out] + extra, env=_env(), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         outs[mode] = (out, json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs["c"][1]["bytes"] > 500
