@@ -24,7 +24,7 @@ def _env():
     (8, 64, 64, 2, "ultrafast", []),
     (8, 128, 64, 2, "medium", []),
     (10, 64, 64, 2, "slow", []),
-    (8, 72, 40, 2, "medium", ["lowpass-dct=1", "weightb=1", "bframes=2"]),       # non-CTU-multiple picture, cu[].lowpass_dct, weight_pp on planes
+    (8, 136, 72, 2, "medium", ["lowpass-dct=1", "weightb=1", "bframes=2"]),       # non-CTU-multiple picture, cu[].lowpass_dct, weight_pp on planes
     (8, 64, 64, 2, "medium", ["tskip=1", "nr-inter=100", "me=full", "merange=6"]),   # transform skip, denoiseDct, exhaustive search
 ])
 def test_reference_encoder_emits_identical_bitstream_with_the_hip_table(tmp_path, depth, w, h, frames, preset, extra):
