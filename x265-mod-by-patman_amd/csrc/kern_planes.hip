@@ -10,8 +10,8 @@
 //   else:       luma_hvpp = hps (row extended, :120-162) -> vsp (:319-369)
 // Slot 0 of the output receives a copy of the reference plane, so that the motion search addresses every candidate --
 // integer or sub-pel -- as one buffer base plus a 32-bit offset.
-// One workgroup produces a 64x16 tile of all 15 planes: source tile + apron in LDS, the three horizontal 14-bit
-// intermediates in LDS, then nine vertical passes.  Streaming kernel: 1 plane read, 15 written.
+// Streaming kernel: 1 plane read, 16 written.  Two forms: the 8-bit build filters with packed dot products on 128x8 tiles
+// (below), the 16-bit builds with scalar MACs on 64x16 tiles (at the end of the file; already at the store ceiling).
 #include "xh_mc.h"
 #include <cstdlib>
 #include "../../include/x265hip_frame.h"
