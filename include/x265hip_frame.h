@@ -67,7 +67,7 @@ int x265hip_me_batch(void* stream, int w, int h,
                      const x265hip_me_result* mvpSource /* may be NULL */,
                      const void* subpelPlanes /* may be NULL: interpolate inside the kernel */, int64_t planeElems);
 /* subpelPlanes, when given, must be the 16-slot buffer x265hip_subpel_planes produced from refPlane (slot 0 == refPlane,
- * same stride / offsets).  method: DIA, HEX, STAR or FULL (UMH and SEA are not offloaded -> X265HIP_EARG). */
+ * same stride / offsets).  method: DIA, HEX, UMH, STAR or FULL (SEA is not offloaded -> X265HIP_EARG). */
 
 /* Pre-interpolate a padded reference plane (or a stack of planes: `rows` counts every row of the allocation) into
  * its 15 quarter-pel phase planes: outPlanes + f*planeElems for f = yFrac*4 + xFrac = 1..15 holds, at the same

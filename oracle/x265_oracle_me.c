@@ -4,7 +4,7 @@
  * CPU restatement of the reference's motion-search DRIVER for one PU and one reference:
  *   - BitCost::setQP / CalculateLogs  (encoder/bitcost.cpp:30-105): lambda-scaled MVD cost row
  *   - MotionEstimate::motionEstimate  (encoder/motion.cpp:923-1773): start-point selection,
- *     DIA / HEX / STAR / FULL integer search, sub-pel refinement per workload[subme], final zero-MV check
+ *     DIA / HEX / UMH / STAR / FULL integer search, sub-pel refinement per workload[subme], final zero-MV check
  *   - MotionEstimate::subpelCompare   (encoder/motion.cpp:1775-1803, luma part)
  * built on the primitive restatements of x265_oracle.c.  Pinned against the REAL reference driver
  * (oracle/_ref, op "me" / "mvcost_row") by tests/test_me_oracle_vs_ref.py.
@@ -79,6 +79,7 @@ static const mv_t offsets2[16] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-1,0}, {1,0
 /* motion.cpp:48-58 workload[]: hpel_iters, hpel_dirs, qpel_iters, qpel_dirs, hpel_satd */
 static const int workload[8][5] = { {1,4,0,4,0}, {1,4,1,4,0}, {1,4,1,4,1}, {2,4,1,4,1}, {2,4,2,4,1}, {1,8,1,8,1}, {2,8,1,8,1}, {2,8,2,8,1} };
 
+static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int in_range(mv_t v, mv_t mn, mv_t mx) { return v.x >= mn.x && v.x <= mx.x && v.y >= mn.y && v.y <= mx.y; }
 
 typedef struct { mv_t bmv; int bcost, bPointNr, bDistance; } star_t;
@@ -248,6 +249,89 @@ int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, in
         bcost = (int)ubcost >> 4;
         break;
     }
+    case XO_ME_UMH:
+    {   /* motion.cpp:1142-1326 (uneven multi-hexagon); candidates relative to omv, strict `<` in the order written there */
+        static const mv_t hex4[16] = { {0,-4}, {0,4}, {-2,-3}, {2,-3}, {-4,-2}, {4,-2}, {-4,-1}, {4,-1},
+                                       {-4,0}, {4,0}, {-4,1}, {4,1}, {-4,2}, {4,2}, {-2,3}, {2,3} };   /* motion.cpp:67-73 */
+        const int scale = (h * h) >> 4;                                                                /* sizeScale, :60-61,123-153 */
+#define SAD_THRESH(v) (bcost < (((v) >> 4) * scale))
+        /* COST_MV_X4 (:296-317): all four measured, only the vertical range is tested */
+#define X4(ax, ay, bx_, by_, cx, cy, dx, dy) do { const mv_t d_[4] = { {ax, ay}, {bx_, by_}, {cx, cy}, {dx, dy} }; \
+        for (int k_ = 0; k_ < 4; k_++) { \
+            int c_ = sad_at(m, omv.x + d_[k_].x, omv.y + d_[k_].y) + mvcost(m, (omv.x + d_[k_].x) * 4, (omv.y + d_[k_].y) * 4); \
+            if ((omv.y + d_[k_].y >= mvmin.y) & (omv.y + d_[k_].y <= mvmax.y)) \
+                if (c_ < bcost) { bcost = c_; bmv.x = omv.x + d_[k_].x; bmv.y = omv.y + d_[k_].y; } } } while (0)
+#define DIA1(mx_, my_) do { omv.x = (mx_); omv.y = (my_); X4(0, -1, 0, 1, -1, 0, 1, 0); } while (0)
+        /* CROSS (:361-385) */
+#define CROSS(start, x_max, y_max) do { int i_ = (start); \
+        if ((x_max) <= imin(mvmax.x - omv.x, omv.x - mvmin.x)) for (; i_ < (x_max) - 2; i_ += 4) X4(i_, 0, -i_, 0, i_ + 2, 0, -i_ - 2, 0); \
+        for (; i_ < (x_max); i_ += 2) { if (omv.x + i_ <= mvmax.x) COST_MV(omv.x + i_, omv.y); if (omv.x - i_ >= mvmin.x) COST_MV(omv.x - i_, omv.y); } \
+        i_ = (start); \
+        if ((y_max) <= imin(mvmax.y - omv.y, omv.y - mvmin.y)) for (; i_ < (y_max) - 2; i_ += 4) X4(0, i_, 0, -i_, 0, i_ + 2, 0, -i_ - 2); \
+        for (; i_ < (y_max); i_ += 2) { if (omv.y + i_ <= mvmax.y) COST_MV(omv.x, omv.y + i_); if (omv.y - i_ >= mvmin.y) COST_MV(omv.x, omv.y - i_); } } while (0)
+        mv_t omv = bmv;
+        int ucost1 = bcost, ucost2, cross_start = 1, done = 0;
+        DIA1(pmv.x, pmv.y);
+        if (pmv.x | pmv.y) DIA1(0, 0);
+        ucost2 = bcost;
+        if ((bmv.x | bmv.y) && !(bmv.x == pmv.x && bmv.y == pmv.y)) DIA1(bmv.x, bmv.y);
+        if (bcost == ucost2) cross_start = 3;
+        omv = bmv;
+        if (bcost == ucost2 && SAD_THRESH(2000))
+        {   /* early termination (:1161-1180) */
+            X4(0, -2, -1, -1, 1, -1, -2, 0);
+            X4(2, 0, -1, 1, 1, 1, 0, 2);
+            if (bcost == ucost1 && SAD_THRESH(500)) done = 1;
+            else if (bcost == ucost2)
+            {
+                int range = (int16_t)((merange >> 1) | 1);
+                CROSS(3, range, range);
+                X4(-1, -2, 1, -2, -2, -1, 2, -1);
+                X4(-2, 1, 2, 1, -1, 2, 1, 2);
+                if (bcost == ucost2) done = 1;
+                cross_start = range + 2;
+            }
+        }
+        if (done) break;
+        if (numCand)
+        {   /* adaptive range from the agreement of the predictors (:1186-1236) */
+            static const uint8_t range_mul[4][4] = { {3,3,4,4}, {3,4,4,4}, {4,4,4,5}, {4,4,5,6} };
+            const int is64 = (w == 64 && h == 64);
+            int mvd, denom = 1;
+            if (numCand == 1)
+                mvd = is64 ? 25 : abs(qmvpx - mvc[0]) + abs(qmvpy - mvc[1]);
+            else
+            {
+                denom = numCand - 1; mvd = 0;
+                if (!is64) { mvd = abs(qmvpx - mvc[0]) + abs(qmvpy - mvc[1]); denom++; }
+                for (int i = 0; i < numCand - 1; i++)                       /* predictorDifference (:87-98) */
+                    mvd += abs(mvc[2 * i] - mvc[2 * i + 2]) + abs(mvc[2 * i + 1] - mvc[2 * i + 3]);
+            }
+            int sad_ctx = SAD_THRESH(1000) ? 0 : SAD_THRESH(2000) ? 1 : SAD_THRESH(4000) ? 2 : 3;
+            int mvd_ctx = mvd < 10 * denom ? 0 : mvd < 20 * denom ? 1 : mvd < 40 * denom ? 2 : 3;
+            merange = (merange * range_mul[mvd_ctx][sad_ctx]) >> 2;
+        }
+        CROSS(cross_start, merange, merange >> 1);
+        X4(-2, -2, -2, 2, 2, -2, 2, 2);
+        /* hexagon grid (:1243-1320): rings of 16 points at radius i */
+        omv = bmv;
+        int i = 1;
+        do
+        {
+            for (int j = 0; j < 16; j++)
+            {
+                mv_t mv = { omv.x + hex4[j].x * i, omv.y + hex4[j].y * i };
+                if (in_range(mv, mvmin, mvmax)) COST_MV(mv.x, mv.y);       /* the sad_x4 branch has every point in range */
+            }
+        }
+        while (++i <= merange >> 2);
+        if (!in_range(bmv, mvmin, mvmax)) break;
+#undef SAD_THRESH
+#undef X4
+#undef DIA1
+#undef CROSS
+    }
+    /* fall through: `goto me_hex2` (motion.cpp:1323-1324) with the adapted merange */
     case XO_ME_HEX:
     {   /* motion.cpp:1041-1140 */
 #define X3_DIR(a, b, c) do { const mv_t d_[3] = { a, b, c }; for (int k_ = 0; k_ < 3; k_++) \

@@ -41,7 +41,7 @@ def make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange):
 
 @pytest.mark.parametrize("planes", [False, True])
 @pytest.mark.parametrize("depth", [8, 10])
-@pytest.mark.parametrize("method", [0, 1, 3, 5])      # DIA, HEX, STAR, FULL
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 5])      # DIA, HEX, UMH, STAR, FULL
 def test_me_batch_matches_oracle(depth, method, planes):
     api, ora = FrameApi(depth), Oracle(depth)
     rng = np.random.default_rng(77 * depth + method)

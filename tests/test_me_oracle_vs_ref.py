@@ -25,7 +25,7 @@ def test_lambda_and_mvcost_tables(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
-@pytest.mark.parametrize("method", [0, 1, 3, 5])      # DIA, HEX, STAR, FULL
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 5])      # DIA, HEX, UMH, STAR, FULL
 def test_motion_estimate_matches_reference(depth, method):
     if not ref_available(depth):
         pytest.skip("no reference binary")
@@ -38,7 +38,7 @@ def test_motion_estimate_matches_reference(depth, method):
             cur, rf, stride, (dx, dy) = frame_pair(W, H, depth, seed, margin=margin, max_shift=12 if seed else 30)
             cur, rf = cur.reshape(-1), rf.reshape(-1)
             for (w, h) in PUS:
-                reps = 1 if method == 5 else 3
+                reps = 1 if method == 5 else 6 if method == 2 else 3
                 for _ in range(reps):
                     px = int(rng.integers(0, (W - w) // 4 + 1)) * 4
                     py = int(rng.integers(0, (H - h) // 4 + 1)) * 4

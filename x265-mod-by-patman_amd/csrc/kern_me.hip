@@ -1,8 +1,13 @@
-// kern_me.hip -- x265hip_me_batch: DIA / HEX / FULL kernels live in this translation unit, the STAR kernels (whose pattern
-// code is large and kept out of line) in kern_me_star.hip; both are generated from me_body.inc.
+// kern_me.hip -- x265hip_me_batch: DIA / HEX / FULL kernels live in this translation unit, the STAR and UMH kernels (whose
+// pattern code is large and kept out of line) in kern_me_star.hip / kern_me_umh.hip; all are generated from me_body.inc.
 #include "me_body.inc"
 
 int xh_me_star(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+               const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
+               int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+               const void* subpelPlanes, int64_t planeElems);
+
+int xh_me_umh(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
                int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
                const void* subpelPlanes, int64_t planeElems);
@@ -15,11 +20,13 @@ extern "C" int x265hip_me_batch(void* stream, int w, int h, const void* curPlane
     if (n <= 0) return X265HIP_OK;
     if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !tasks || !results || !costRow || costHalfRange < 1)
     { set_error("me_batch: bad arguments"); return X265HIP_EARG; }
-    if (method != X265HIP_ME_DIA && method != X265HIP_ME_HEX && method != X265HIP_ME_STAR && method != X265HIP_ME_FULL)
-    { set_error("me_batch: search method %d is not offloaded (DIA/HEX/STAR/FULL are)", method); return X265HIP_EARG; }
+    if (method != X265HIP_ME_DIA && method != X265HIP_ME_HEX && method != X265HIP_ME_UMH && method != X265HIP_ME_STAR && method != X265HIP_ME_FULL)
+    { set_error("me_batch: search method %d is not offloaded (DIA/HEX/UMH/STAR/FULL are)", method); return X265HIP_EARG; }
     if (subpelRefine < 0 || subpelRefine > 7 || merange < 1) { set_error("me_batch: bad subme/merange"); return X265HIP_EARG; }
     if (subpelPlanes && (planeElems <= 0 || ((uintptr_t)subpelPlanes & 7))) { set_error("me_batch: bad subpel planes"); return X265HIP_EARG; }
     if (method == X265HIP_ME_STAR)
         return xh_me_star(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
-    return dispatch_me<false>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
+    if (method == X265HIP_ME_UMH)
+        return xh_me_umh(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
+    return dispatch_me<0>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
 }

@@ -6,5 +6,5 @@ int xh_me_star(void* stream, int w, int h, const void* curPlane, intptr_t curStr
                int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
                const void* subpelPlanes, int64_t planeElems)
 {
-    return dispatch_me<true>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
+    return dispatch_me<1>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
 }
