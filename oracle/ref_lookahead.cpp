@@ -1,0 +1,161 @@
+/*
+ * ref_lookahead.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * The reference's LOOKAHEAD frame-cost path, compiled from its own sources (oracle/Makefile target "la", whole
+ * source/common + source/encoder, no asm), driven directly on its own classes:
+ *
+ *     PicYuv (full-resolution source, borders replicated with the reference's extendPicBorder)
+ *       -> Lowres::create / Lowres::init              (lowres.cpp:79-250, 349-407: frameInitLowres + 4x extendPicBorder)
+ *       -> LookaheadTLD::lowresIntraEstimate          (slicetype.cpp:755-870)
+ *       -> CostEstimateGroup::singleCost(p0, p1, b)   (slicetype.cpp:4230-4234 -> estimateFrameCost :4365-4463
+ *                                                      -> estimateCUCost :4467-4640 -> MotionEstimate::motionEstimate, lowres mode)
+ *
+ * It pins oracle/x265_oracle_la.c (and through it the HIP batch of x265hip_lookahead_cost_batch).  No thread pool, no HME,
+ * no weighted prediction, no lookahead slices: the serial loops of estimateFrameCost.
+ *
+ * usage: x265la_<depth> <width> <height> <nframes> <in.raw> <out.bin> <aq 0|1> [p0,b,p1[,keep] ...]
+ *   in.raw  : nframes luma planes, width x height pixels each (u8 / u16), no padding
+ *   triples : indices into the frame list, p0 <= b <= p1; "keep" = 1 leaves the MV caches of frame b as the previous
+ *             triples left them (bDoSearch then follows the reference's own rule, slicetype.cpp:4376-4377), 0 resets them
+ *   out.bin : records of [int64 count][count x int32], in the order written below
+ */
+#include "common.h"
+#include "primitives.h"
+#include "picyuv.h"
+#include "lowres.h"
+#include "slicetype.h"
+#include "motion.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace X265_NS;
+
+static FILE* g_out;
+static void rec(const std::vector<int32_t>& v)
+{
+    int64_t n = (int64_t)v.size();
+    fwrite(&n, 8, 1, g_out);
+    if (n) fwrite(v.data(), 4, (size_t)n, g_out);
+}
+
+/* estimateFrameCost is reached through the public singleCost; the group only needs the frame list */
+struct Group : public CostEstimateGroup
+{
+    Group(Lookahead& l, Lowres** f) : CostEstimateGroup(l, f) {}
+};
+
+static void resetCaches(Lowres& f, int bframes)
+{   /* the per-frame cache state Lowres::init establishes (lowres.cpp:359-376) */
+    memset(f.costEst, -1, sizeof(f.costEst));
+    if (f.qpAqOffset && f.invQscaleFactor) memset(f.costEstAq, -1, sizeof(f.costEstAq));
+    for (int y = 0; y < bframes + 2; y++)
+        for (int x = 0; x < bframes + 2; x++)
+            f.rowSatds[y][x][0] = -1;
+    for (int i = 0; i < bframes + 2; i++)
+    {
+        f.lowresMvs[0][i][0].x = 0x7FFF;
+        f.lowresMvs[1][i][0].x = 0x7FFF;
+        f.intraMbs[i] = 0;
+    }
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 7) { fprintf(stderr, "usage: %s width height nframes in.raw out.bin aq [p0,b,p1[,keep] ...]\n", argv[0]); return 2; }
+    const int W = atoi(argv[1]), H = atoi(argv[2]), N = atoi(argv[3]), aq = atoi(argv[6]);
+    x265_param* p = x265_param_alloc();
+    x265_param_default_preset(p, "medium", NULL);
+    p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = X265_CSP_I400;
+    p->bEnableWeightedPred = 0; p->bEnableWeightedBiPred = 0; p->bEnableHME = 0; p->lookaheadSlices = 0;
+    p->rc.aqMode = aq ? X265_AQ_VARIANCE : X265_AQ_NONE; p->rc.cuTree = 0; p->bEnableTemporalFilter = 0;
+    p->bHistBasedSceneCut = 0; p->bAQMotion = 0;
+    x265_setup_primitives(p);
+    MotionEstimate::initScales();
+
+    FILE* in = fopen(argv[4], "rb");
+    g_out = fopen(argv[5], "wb");
+    if (!in || !g_out) { fprintf(stderr, "cannot open files\n"); return 2; }
+
+    Lookahead la(p, NULL);
+    if (!la.create()) { fprintf(stderr, "Lookahead::create failed\n"); return 2; }
+    LookaheadTLD& tld = la.m_tld[0];
+
+    std::vector<PicYuv*> pics(N);
+    std::vector<Lowres*> low(N);
+    std::vector<pixel> row(W);
+    for (int f = 0; f < N; f++)
+    {
+        PicYuv* pic = pics[f] = new PicYuv;
+        if (!pic->create(p, true, NULL)) { fprintf(stderr, "PicYuv::create failed\n"); return 2; }
+        /* the allocation is larger than the picture when the size is no multiple of the CTU: clear it, then fill and replicate */
+        const uint32_t ctuRows = (H + p->maxCUSize - 1) / p->maxCUSize;
+        memset(pic->m_picBuf[0], 0, sizeof(pixel) * pic->m_stride * (ctuRows * p->maxCUSize + 2 * pic->m_lumaMarginY));
+        for (int y = 0; y < H; y++)
+        {
+            if (fread(row.data(), sizeof(pixel), W, in) != (size_t)W) { fprintf(stderr, "short input\n"); return 2; }
+            memcpy(pic->m_picOrg[0] + (intptr_t)y * pic->m_stride, row.data(), W * sizeof(pixel));
+        }
+        extendPicBorder(pic->m_picOrg[0], pic->m_stride, W, H, pic->m_lumaMarginX, pic->m_lumaMarginY);
+        Lowres* l = low[f] = new Lowres;
+        memset((void*)l, 0, sizeof(Lowres));
+        if (!l->create(p, pic, p->rc.qgSize)) { fprintf(stderr, "Lowres::create failed\n"); return 2; }
+        l->init(pic, f, false);
+        const int ncu = l->maxBlocksInRow * l->maxBlocksInCol;
+        if (aq && l->invQscaleFactor)
+        {   /* synthetic AQ factors (the AQ analysis itself is floating-point host code outside the path): 8.8 fixed point around 1.0 */
+            const int nfull = (p->rc.qgSize > 8) ? ncu : ncu << 2;
+            for (int i = 0; i < nfull; i++) l->invQscaleFactor[i] = 160 + ((i * 37 + f * 11) % 200);
+            if (l->invQscaleFactor8x8) for (int i = 0; i < ncu; i++) l->invQscaleFactor8x8[i] = 160 + ((i * 37 + f * 11) % 200);
+        }
+        tld.lowresIntraEstimate(*l, p->rc.qgSize);
+    }
+    Lowres* L0 = low[0];
+    const int wcu = L0->maxBlocksInRow, hcu = L0->maxBlocksInCol, ncu = wcu * hcu;
+    const int marginX = pics[0]->m_lumaMarginX, marginY = pics[0]->m_lumaMarginY;
+    rec({ W, H, N, (int32_t)L0->lumaStride, L0->width, L0->lines, wcu, hcu, marginX, marginY, X265_DEPTH, (int32_t)p->rc.qgSize, p->bframes });
+    for (int f = 0; f < N; f++)
+    {   /* the four padded lowres planes, then the intra results */
+        Lowres* l = low[f];
+        const size_t planesize = (size_t)l->lumaStride * (l->lines + 2 * marginY);
+        for (int k = 0; k < 4; k++)
+        {
+            const pixel* base = l->lowresPlane[k] - ((intptr_t)l->lumaStride * marginY + marginX);
+            std::vector<int32_t> v(planesize);
+            for (size_t i = 0; i < planesize; i++) v[i] = base[i];
+            rec(v);
+        }
+        std::vector<int32_t> ic(l->intraCost, l->intraCost + ncu), im(ncu), rs(hcu), lc(ncu), q(ncu);
+        for (int i = 0; i < ncu; i++) { im[i] = l->intraMode[i]; lc[i] = l->lowresCosts[0][0][i]; }
+        for (int i = 0; i < hcu; i++) rs[i] = l->rowSatds[0][0][i];
+        for (int i = 0; i < ncu; i++) q[i] = !(aq && l->invQscaleFactor) ? 256 : (p->rc.qgSize == 8 ? l->invQscaleFactor8x8[i] : l->invQscaleFactor[i]);
+        rec(ic); rec(im); rec(lc); rec(rs); rec(q);
+    }
+    for (int a = 7; a < argc; a++)
+    {
+        int p0, b, p1, keep = 0;
+        if (sscanf(argv[a], "%d,%d,%d,%d", &p0, &b, &p1, &keep) < 3) { fprintf(stderr, "bad triple %s\n", argv[a]); return 2; }
+        Lowres* fenc = low[b];
+        if (!keep) resetCaches(*fenc, p->bframes);
+        const int doSearch0 = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF, doSearch1 = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
+        Group g(la, low.data());
+        const int64_t score = g.singleCost(p0, p1, b, false);
+        rec({ p0, b, p1, keep, doSearch0, doSearch1, (int32_t)score, (int32_t)fenc->costEst[b - p0][p1 - b], (int32_t)fenc->costEstAq[b - p0][p1 - b],
+              fenc->intraMbs[b - p0] });
+        for (int l = 0; l < 2; l++)
+        {
+            const int d = l ? p1 - b : b - p0;
+            std::vector<int32_t> mv(2 * (size_t)ncu, 0), mc(ncu, 0);
+            if (l == 0 || p1 > b)
+                for (int i = 0; i < ncu; i++) { mv[2 * i] = fenc->lowresMvs[l][d][i].x; mv[2 * i + 1] = fenc->lowresMvs[l][d][i].y; mc[i] = fenc->lowresMvCosts[l][d][i]; }
+            rec(mv); rec(mc);
+        }
+        std::vector<int32_t> lc(ncu), rs(hcu);
+        for (int i = 0; i < ncu; i++) lc[i] = fenc->lowresCosts[b - p0][p1 - b][i];
+        for (int i = 0; i < hcu; i++) rs[i] = fenc->rowSatds[b - p0][p1 - b][i];
+        rec(lc); rec(rs);
+    }
+    fclose(g_out); fclose(in);
+    return 0;
+}

@@ -1,0 +1,330 @@
+/*
+ * x265_oracle_la.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference's LOOKAHEAD frame-cost path on half-resolution ("lowres") pictures:
+ *   - LookaheadTLD::lowresIntraEstimate              (encoder/slicetype.cpp:755-864)
+ *   - CostEstimateGroup::estimateFrameCost, serial   (encoder/slicetype.cpp:4365-4463; no HME, no weightp, no slices)
+ *   - CostEstimateGroup::estimateCUCost              (encoder/slicetype.cpp:4467-4640)
+ *   - MotionEstimate::motionEstimate, ref->isLowres  (encoder/motion.cpp:923-1140 HEX, :1644-1773 with the lowres branch :1667-1699)
+ *   - ReferencePlanes::lowresMC / lowresQPelCost     (common/lowres.h:75-124)
+ * built on the primitive restatements of x265_oracle.c.  Pinned against the REAL reference classes
+ * (oracle/_ref/x265la_*, oracle/ref_lookahead.cpp) by tests/test_lookahead_oracle_vs_ref.py.
+ */
+#include "x265_oracle_la.h"
+#include "x265_oracle_me.h"
+#include <limits.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CU 8                                   /* X265_LOWRES_CU_SIZE (common.h) */
+#define COST_MAX (1 << 28)                     /* MotionEstimate::COST_MAX (motion.h) */
+#define LOWRES_COST_MASK ((1 << 14) - 1)       /* slicetype.h:42-43 */
+#define LOWRES_COST_SHIFT 14
+
+typedef struct { int x, y; } mv_t;
+
+int xo_lookahead_qp(void) { return 12 + 6 * (X265_DEPTH - 8); }          /* X265_LOOKAHEAD_QP, common.h:223 */
+
+static const unsigned char k_filterFlags[35] = {                           /* constants.cpp:561 g_intraFilterFlags */
+    0x38, 0x00, 0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x38 };
+
+static int frame_score_cu(int cuX, int cuY, int wcu, int hcu)
+{   /* edge blocks are left out of the frame totals (slicetype.cpp:843-844, 4607-4608) */
+    return (cuX > 0 && cuX < wcu - 1 && cuY > 0 && cuY < hcu - 1) || wcu <= 2 || hcu <= 2;
+}
+
+/* slicetype.cpp:755-864 */
+void xo_lowres_intra_estimate(const xo_pixel* plane0, intptr_t stride, int wcu, int hcu, const int32_t* invQscale,
+                              int32_t* intraCost, int32_t* intraMode, int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
+{
+    const int lambda = (int)xo_lambda(xo_lookahead_qp());
+    const int intraPenalty = 5 * lambda, lowresPenalty = 4;
+    int64_t costEst = 0, costEstAq = 0;
+    for (int cuY = 0; cuY < hcu; cuY++)
+    {
+        rowSatds[cuY] = 0;
+        for (int cuX = 0; cuX < wcu; cuX++)
+        {
+            const int cuXY = cuX + cuY * wcu;
+            const xo_pixel* cur = plane0 + CU * cuX + (intptr_t)CU * cuY * stride;
+            xo_pixel fenc[CU * CU], pred[CU * CU], nb[2][4 * CU + 1];
+            for (int y = 0; y < CU; y++) memcpy(fenc + CU * y, cur + y * stride, CU * sizeof(xo_pixel));
+            const xo_pixel* tl = cur - stride - 1;
+            memcpy(nb[0], tl, (2 * CU + 1) * sizeof(xo_pixel));                                   /* top-left, top, top-right */
+            for (int i = 1; i <= 2 * CU; i++) nb[0][2 * CU + i] = tl[i * stride];                /* left, below-left */
+            xo_intra_filter(CU, nb[0], nb[1]);
+            int icost = COST_MAX, ilow = 0, cost;
+            xo_intra_pred(CU, pred, CU, nb[0], 1, 1);                                             /* DC, edge filter on (cuSize <= 16) */
+            cost = xo_satd(CU, CU, fenc, CU, pred, CU);
+            if (cost < icost) { icost = cost; ilow = 1; }
+            xo_intra_pred(CU, pred, CU, nb[1], 0, 0);                                             /* planar on the filtered neighbours (cuSize >= 8) */
+            cost = xo_satd(CU, CU, fenc, CU, pred, CU);
+            if (cost < icost) { icost = cost; ilow = 0; }
+            int acost = COST_MAX, alow = 4;
+            for (int mode = 5; mode < 35; mode += 5)
+            {
+                xo_intra_pred(CU, pred, CU, nb[!!(k_filterFlags[mode] & CU)], mode, 1);
+                cost = xo_satd(CU, CU, fenc, CU, pred, CU);
+                if (cost < acost) { acost = cost; alow = mode; }
+            }
+            for (int dist = 2; dist >= 1; dist--)
+            {
+                const int two[2] = { alow - dist, alow + dist };
+                for (int k = 0; k < 2; k++)
+                {
+                    const int mode = two[k];
+                    xo_intra_pred(CU, pred, CU, nb[!!(k_filterFlags[mode] & CU)], mode, 1);
+                    cost = xo_satd(CU, CU, fenc, CU, pred, CU);
+                    if (cost < acost) { acost = cost; alow = mode; }
+                }
+            }
+            if (acost < icost) { icost = acost; ilow = alow; }
+            icost += intraPenalty + lowresPenalty;
+            lowresCosts[cuXY] = (uint16_t)(icost < LOWRES_COST_MASK ? icost : LOWRES_COST_MASK);
+            intraCost[cuXY] = icost; intraMode[cuXY] = ilow;
+            const int score = frame_score_cu(cuX, cuY, wcu, hcu);
+            const int icostAq = (score && invQscale) ? ((icost * invQscale[cuXY] + 128) >> 8) : icost;
+            if (score) { costEst += icost; costEstAq += icostAq; }
+            rowSatds[cuY] += icostAq;
+        }
+    }
+    sums[0] = costEst; sums[1] = costEstAq;
+}
+
+/* ---- lowres reference access (lowres.h:75-124) ---- */
+typedef struct
+{
+    const xo_pixel* plane[4]; intptr_t stride;    /* block origin inside the four half-pel planes (0 = full, 1 = H, 2 = V, 3 = HV) */
+    xo_pixel fenc[CU * CU];
+    const uint16_t* cost; mv_t mvp;
+} la_t;
+
+static const xo_pixel* lowres_mc(const la_t* m, int qx, int qy, xo_pixel* buf, intptr_t* outStride)
+{
+    if ((qx | qy) & 1)
+    {
+        const int hpelA = (qy & 2) | ((qx & 2) >> 1);
+        const xo_pixel* a = m->plane[hpelA] + (qx >> 2) + (qy >> 2) * m->stride;
+        const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
+        const int hpelB = (qy2 & 2) | ((qx2 & 2) >> 1);
+        const xo_pixel* b = m->plane[hpelB] + (qx2 >> 2) + (qy2 >> 2) * m->stride;
+        xo_pixelavg_pp(CU, CU, buf, CU, a, m->stride, b, m->stride);
+        *outStride = CU;
+        return buf;
+    }
+    *outStride = m->stride;
+    return m->plane[(qy & 2) | ((qx & 2) >> 1)] + (qx >> 2) + (qy >> 2) * m->stride;
+}
+static int qpel_cost(const la_t* m, int qx, int qy, int useSatd)
+{
+    xo_pixel buf[CU * CU]; intptr_t s;
+    const xo_pixel* p = lowres_mc(m, qx, qy, buf, &s);
+    return useSatd ? xo_satd(CU, CU, m->fenc, CU, p, s) : xo_sad(CU, CU, m->fenc, CU, p, s);
+}
+static inline int mvcost(const la_t* m, int qx, int qy) { return (uint16_t)(m->cost[qx - m->mvp.x] + m->cost[qy - m->mvp.y]); }
+static inline int sad_at(const la_t* m, int mx, int my) { return xo_sad(CU, CU, m->fenc, CU, m->plane[0] + mx + my * m->stride, m->stride); }
+
+static const mv_t hex2[8] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
+static const unsigned char mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
+static const mv_t square1[9] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
+
+/* motionEstimate for a lowres reference: no candidates, hexagon search, subme 1 (slicetype.cpp:4496-4499 setSourcePU) */
+static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, mv_t* out)
+{
+    m->mvp = qmvp;
+    const mv_t qmin = { mvmin.x * 4, mvmin.y * 4 }, qmax = { mvmax.x * 4, mvmax.y * 4 };
+    mv_t pmv = { qmvp.x < qmin.x ? qmin.x : qmvp.x > qmax.x ? qmax.x : qmvp.x, qmvp.y < qmin.y ? qmin.y : qmvp.y > qmax.y ? qmax.y : qmvp.y };
+    const mv_t bestpre = pmv;
+    int bprecost = qpel_cost(m, pmv.x, pmv.y, 0);                                             /* motion.cpp:967-968 */
+    mv_t bmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };
+    int bcost = bprecost, costs[3];
+    if ((pmv.x | pmv.y) & 3) bcost = sad_at(m, bmv.x, bmv.y) + mvcost(m, bmv.x * 4, bmv.y * 4);
+    if (pmv.x | pmv.y)
+    {
+        const int cost = sad_at(m, 0, 0) + mvcost(m, 0, 0);
+        if (cost < bcost) { bcost = cost; bmv.x = 0; int t = 0 < mvmax.y ? 0 : mvmax.y; bmv.y = t > mvmin.y ? t : mvmin.y; }
+    }
+    if (bcost == 0) { out->x = bmv.x * 4; out->y = bmv.y * 4; return mvcost(m, out->x, out->y); }
+    /* hexagon search, motion.cpp:1041-1140 */
+#define INY(v) (((v) >= mvmin.y) & ((v) <= mvmax.y))
+#define X3(a, b, c) do { const mv_t d_[3] = { a, b, c }; for (int k_ = 0; k_ < 3; k_++) \
+        costs[k_] = sad_at(m, bmv.x + d_[k_].x, bmv.y + d_[k_].y) + mvcost(m, (bmv.x + d_[k_].x) * 4, (bmv.y + d_[k_].y) * 4); } while (0)
+#define LT(x, y) do { if ((y) < (x)) (x) = (y); } while (0)
+    { const mv_t a = {-2,0}, b = {-1,2}, c = {1,2}; X3(a, b, c); }
+    bcost <<= 3;
+    if (INY(bmv.y)) LT(bcost, (costs[0] << 3) + 2);
+    if (INY(bmv.y + 2)) { LT(bcost, (costs[1] << 3) + 3); LT(bcost, (costs[2] << 3) + 4); }
+    { const mv_t a = {2,0}, b = {1,-2}, c = {-1,-2}; X3(a, b, c); }
+    if (INY(bmv.y)) LT(bcost, (costs[0] << 3) + 5);
+    if (INY(bmv.y - 2)) { LT(bcost, (costs[1] << 3) + 6); LT(bcost, (costs[2] << 3) + 7); }
+    if (bcost & 7)
+    {
+        int dir = (bcost & 7) - 2;
+        if (INY(bmv.y + hex2[dir + 1].y))
+        {
+            bmv.x += hex2[dir + 1].x; bmv.y += hex2[dir + 1].y;
+            for (int i = (merange >> 1) - 1; i > 0 && bmv.x >= mvmin.x && bmv.x <= mvmax.x && INY(bmv.y); i--)
+            {
+                X3(hex2[dir + 0], hex2[dir + 1], hex2[dir + 2]);
+                bcost &= ~7;
+                if (INY(bmv.y + hex2[dir + 0].y)) LT(bcost, (costs[0] << 3) + 1);
+                if (INY(bmv.y + hex2[dir + 1].y)) LT(bcost, (costs[1] << 3) + 2);
+                if (INY(bmv.y + hex2[dir + 2].y)) LT(bcost, (costs[2] << 3) + 3);
+                if (!(bcost & 7)) break;
+                dir += (bcost & 7) - 2;
+                dir = mod6m1[dir + 1];
+                bmv.x += hex2[dir + 1].x; bmv.y += hex2[dir + 1].y;
+            }
+        }
+    }
+    bcost >>= 3;
+    {
+        int dir = 0, c8[8];
+        for (int k = 0; k < 8; k++) c8[k] = sad_at(m, bmv.x + square1[k + 1].x, bmv.y + square1[k + 1].y) + mvcost(m, (bmv.x + square1[k + 1].x) * 4, (bmv.y + square1[k + 1].y) * 4);
+        const int upOk = INY(bmv.y - 1), dnOk = INY(bmv.y + 1);
+        if (upOk && c8[0] < bcost) { bcost = c8[0]; dir = 1; }
+        if (dnOk && c8[1] < bcost) { bcost = c8[1]; dir = 2; }
+        if (c8[2] < bcost) { bcost = c8[2]; dir = 3; }
+        if (c8[3] < bcost) { bcost = c8[3]; dir = 4; }
+        if (upOk && c8[4] < bcost) { bcost = c8[4]; dir = 5; }
+        if (dnOk && c8[5] < bcost) { bcost = c8[5]; dir = 6; }
+        if (upOk && c8[6] < bcost) { bcost = c8[6]; dir = 7; }
+        if (dnOk && c8[7] < bcost) { bcost = c8[7]; dir = 8; }
+        bmv.x += square1[dir].x; bmv.y += square1[dir].y;
+    }
+#undef X3
+#undef LT
+    /* motion.cpp:1644-1699 */
+    if (bprecost < bcost) { bmv = bestpre; bcost = bprecost; }
+    else { bmv.x *= 4; bmv.y *= 4; }
+    if (!bcost)
+        bcost = mvcost(m, bmv.x, bmv.y);
+    else
+    {   /* the lowres branch: 4 half-pel directions at SAD, re-measure at SATD, 4 quarter-pel directions at SATD (workload[1]) */
+        int bdir = 0;
+        for (int i = 1; i <= 4; i++)
+        {
+            const int qx = bmv.x + square1[i].x * 2, qy = bmv.y + square1[i].y * 2;
+            if ((qy < qmin.y) | (qy > qmax.y)) continue;
+            const int cost = qpel_cost(m, qx, qy, 0) + mvcost(m, qx, qy);
+            if (cost < bcost) { bcost = cost; bdir = i; }
+        }
+        bmv.x += square1[bdir].x * 2; bmv.y += square1[bdir].y * 2;
+        bcost = qpel_cost(m, bmv.x, bmv.y, 1) + mvcost(m, bmv.x, bmv.y);
+        bdir = 0;
+        for (int i = 1; i <= 4; i++)
+        {
+            const int qx = bmv.x + square1[i].x, qy = bmv.y + square1[i].y;
+            if ((qy < qmin.y) | (qy > qmax.y)) continue;
+            const int cost = qpel_cost(m, qx, qy, 1) + mvcost(m, qx, qy);
+            if (cost < bcost) { bcost = cost; bdir = i; }
+        }
+        bmv.x += square1[bdir].x; bmv.y += square1[bdir].y;
+    }
+    if (bmv.x | bmv.y)
+    {   /* motion.cpp:1763-1768: subpelCompare at MV 0 = SATD against the full-pel plane */
+        const int cost = xo_satd(CU, CU, m->fenc, CU, m->plane[0], m->stride) + mvcost(m, 0, 0);
+        if (cost <= bcost) { bmv.x = 0; bmv.y = 0; }
+    }
+#undef INY
+    *out = bmv;
+    return bcost;
+}
+
+/* slicetype.cpp:4365-4463 (serial branch) + :4467-4640 */
+void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, intptr_t stride,
+                          int wcu, int hcu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
+                          int doSearch0, int doSearch1, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                          int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
+{
+    const int bBidir = ref1 != NULL;
+    const int doSearch[2] = { doSearch0, doSearch1 };
+    int32_t* const mvs[2] = { mvs0, mvs1 };
+    int32_t* const mvCosts[2] = { mvCosts0, mvCosts1 };
+    const xo_pixel* const* const refs[2] = { ref0, ref1 };
+    int64_t costEst = 0, costEstAq = 0, intraMbs = 0;
+    const int lowresPenalty = 4, merange = 16;                                                   /* slicetype.h:337 s_merange */
+    for (int cuY = hcu - 1; cuY >= 0; cuY--)
+    {
+        const int lastRow = cuY == hcu - 1;
+        rowSatds[cuY] = 0;
+        for (int cuX = wcu - 1; cuX >= 0; cuX--)
+        {
+            const int cuXY = cuX + cuY * wcu;
+            const intptr_t pel = CU * cuX + (intptr_t)CU * cuY * stride;
+            la_t me;
+            me.stride = stride; me.cost = costRowCentre;
+            for (int y = 0; y < CU; y++) memcpy(me.fenc + CU * y, fencPlane0 + pel + y * stride, CU * sizeof(xo_pixel));
+            const mv_t mvmin = { -cuX * CU - 8, -cuY * CU - 8 }, mvmax = { (wcu - cuX - 1) * CU + 8, (hcu - cuY - 1) * CU + 8 };
+            int bcost = COST_MAX, listused = 0;
+            for (int i = 0; i < 1 + bBidir; i++)
+            {
+                int32_t* fencCost = &mvCosts[i][cuXY];
+                int32_t* fencMV = &mvs[i][2 * cuXY];
+                if (!doSearch[i])
+                {
+                    if (*fencCost < bcost) { bcost = *fencCost; listused = i + 1; }
+                    continue;
+                }
+                for (int k = 0; k < 4; k++) me.plane[k] = refs[i][k] + pel;
+                /* reverse-order MV prediction (:4520-4536): right, below, below-left, below-right */
+                mv_t mvc[5], mvp = { 0, 0 }; int numc = 0, skipCost = INT_MAX;
+#define MVC(o) do { mvc[numc].x = fencMV[2 * (o)]; mvc[numc].y = fencMV[2 * (o) + 1]; numc++; } while (0)
+                if (cuX < wcu - 1) MVC(1);
+                if (!lastRow)
+                {
+                    MVC(wcu);
+                    if (cuX > 0) MVC(wcu - 1);
+                    if (cuX < wcu - 1) MVC(wcu + 1);
+                }
+#undef MVC
+                if (numc)
+                {   /* the candidate with the lowest SATD becomes the MVP (:4541-4556) */
+                    int mvpcost = COST_MAX;
+                    for (int idx = 0; idx < numc; idx++)
+                    {
+                        const int cost = qpel_cost(&me, mvc[idx].x, mvc[idx].y, 1);
+                        if (cost < mvpcost) { mvpcost = cost; mvp = mvc[idx]; }
+                        if (!(mvp.x | mvp.y) && bBidir) skipCost = cost;
+                    }
+                }
+                mv_t out;
+                *fencCost = lowres_me(&me, mvmin, mvmax, mvp, merange, &out);
+                fencMV[0] = out.x; fencMV[1] = out.y;
+                if (skipCost < 64 && skipCost < *fencCost && bBidir) { *fencCost = skipCost; fencMV[0] = 0; fencMV[1] = 0; }
+                if (*fencCost < bcost) { bcost = *fencCost; listused = i + 1; }
+            }
+            if (bBidir)
+            {   /* :4574-4592 */
+                xo_pixel b0[CU * CU], b1[CU * CU], avg[CU * CU]; intptr_t s0, s1;
+                la_t r0 = me, r1 = me;
+                for (int k = 0; k < 4; k++) { r0.plane[k] = ref0[k] + pel; r1.plane[k] = ref1[k] + pel; }
+                const xo_pixel* src0 = lowres_mc(&r0, mvs0[2 * cuXY], mvs0[2 * cuXY + 1], b0, &s0);
+                const xo_pixel* src1 = lowres_mc(&r1, mvs1[2 * cuXY], mvs1[2 * cuXY + 1], b1, &s1);
+                xo_pixelavg_pp(CU, CU, avg, CU, src0, s0, src1, s1);
+                int bicost = xo_satd(CU, CU, me.fenc, CU, avg, CU);
+                if (bicost < bcost) { bcost = bicost; listused = 3; }
+                xo_pixelavg_pp(CU, CU, avg, CU, ref0[0] + pel, stride, ref1[0] + pel, stride);
+                bicost = xo_satd(CU, CU, me.fenc, CU, avg, CU);
+                if (bicost < bcost) { bcost = bicost; listused = 3; }
+                bcost += lowresPenalty;
+            }
+            else
+            {
+                bcost += lowresPenalty;
+                if (intraCost[cuXY] < bcost) { bcost = intraCost[cuXY]; listused = 0; }
+            }
+            const int score = frame_score_cu(cuX, cuY, wcu, hcu);
+            const int bcostAq = (score && invQscale) ? ((bcost * invQscale[cuXY] + 128) >> 8) : bcost;
+            if (score)
+            {
+                costEst += bcost; costEstAq += bcostAq;
+                if (!listused && !bBidir) intraMbs++;
+            }
+            rowSatds[cuY] += bcostAq;
+            lowresCosts[cuXY] = (uint16_t)((bcost < LOWRES_COST_MASK ? bcost : LOWRES_COST_MASK) | (listused << LOWRES_COST_SHIFT));
+        }
+    }
+    sums[0] = costEst; sums[1] = costEstAq; sums[2] = intraMbs;
+}

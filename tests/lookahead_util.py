@@ -1,0 +1,139 @@
+"""Shared plumbing of the lookahead frame-cost tests: synthetic clips, the lowres picture geometry of the reference
+(picyuv.cpp:88-93, lowres.cpp:84-103), the oracle-side drivers and the parser of oracle/_ref/x265la_* output."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CTU = 64
+MARGIN_X, MARGIN_Y = CTU + 32, CTU + 16          # PicYuv::create (picyuv.cpp:91-92); the lowres planes reuse them (lowres.cpp:87,102-103)
+
+
+def la_bin(depth):
+    return os.path.join(ROOT, "oracle", "_ref", "x265la_%d" % depth)
+
+
+def la_available(depth):
+    return os.path.exists(la_bin(depth))
+
+
+def synth_clip(W, H, n, depth, seed, shift=(3, 2), noise=2):
+    """n frames of a smooth texture panning by `shift` full-res pixels per frame, plus noise and one local change"""
+    rng = np.random.default_rng(seed)
+    pad = 16 + max(abs(shift[0]), abs(shift[1])) * n
+    base = rng.integers(0, 256, (H + 2 * pad, W + 2 * pad)).astype(np.float32)
+    for _ in range(3):
+        base = (base + np.roll(base, 1, 0) + np.roll(base, 1, 1) + np.roll(np.roll(base, 1, 0), 1, 1)) / 4
+    base = (base - base.min()) / (base.max() - base.min())
+    pm = (1 << depth) - 1
+    frames = []
+    for f in range(n):
+        y0, x0 = pad + shift[1] * f, pad + shift[0] * f
+        fr = base[y0:y0 + H, x0:x0 + W] * pm + rng.normal(0, noise * (1 << (depth - 8)), (H, W))
+        if f == n // 2:                                        # a patch of new content: intra wins there
+            fr[H // 4:H // 4 + 24, W // 3:W // 3 + 40] = rng.integers(0, pm + 1, (24, 40))
+        frames.append(np.clip(np.rint(fr), 0, pm).astype(np.uint8 if depth == 8 else np.uint16))
+    return frames
+
+
+class Geometry:
+    def __init__(self, W, H):
+        self.W, self.H = W, H
+        self.full_stride = (W + CTU - 1) // CTU * CTU + 2 * MARGIN_X
+        self.full_rows = (H + CTU - 1) // CTU * CTU + 2 * MARGIN_Y
+        self.wcu, self.hcu = (W // 2 + 7) >> 3, (H // 2 + 7) >> 3
+        self.lw, self.lh = self.wcu * 8, self.hcu * 8
+        s = W // 2 + 2 * MARGIN_X
+        self.stride = s + (32 - (s & 31)) % 32 if (s & 31) else s
+        self.rows = self.lh + 2 * MARGIN_Y
+        self.plane_elems = self.stride * self.rows
+        self.origin = self.stride * MARGIN_Y + MARGIN_X
+        self.ncu = self.wcu * self.hcu
+
+
+def pad_full(ora, frame, g):
+    """the source picture inside its padded allocation, borders replicated (what ref_lookahead.cpp builds with the reference's extendPicBorder)"""
+    buf = np.zeros((g.full_rows, g.full_stride), frame.dtype)
+    buf[MARGIN_Y:MARGIN_Y + g.H, MARGIN_X:MARGIN_X + g.W] = frame
+    return ora.extend_pic_border(buf.reshape(-1), g.full_stride, g.W, g.H, MARGIN_X, MARGIN_Y)
+
+
+def lowres_planes_oracle(ora, frame, g):
+    """Lowres::init (lowres.cpp:381-391): frameInitLowres + extendPicBorder on the four planes -> array [4, plane_elems]"""
+    full = pad_full(ora, frame, g)
+    z = [np.zeros(g.plane_elems, frame.dtype) for _ in range(4)]
+    src = full[g.full_stride * MARGIN_Y + MARGIN_X:]
+    dst = [p[g.origin:] for p in z]
+    L = ora.lib
+    ip = C.c_ssize_t
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    L.xo_frame_init_lowres(P(src), P(dst[0]), P(dst[1]), P(dst[2]), P(dst[3]), ip(g.full_stride), ip(g.stride), g.lw, g.lh)
+    return np.stack([ora.extend_pic_border(p, g.stride, g.lw, g.lh, MARGIN_X, MARGIN_Y) for p in z])
+
+
+def _P(a, off=0):
+    return C.c_void_p(a.ctypes.data + off * a.itemsize)
+
+
+def oracle_intra(ora, planes, g, inv_q=None):
+    L = ora.me_lib
+    ic, im, lc = (np.zeros(g.ncu, np.int32) for _ in range(3))
+    rs = np.zeros(g.hcu, np.int32); sums = np.zeros(2, np.int64)
+    L.xo_lowres_intra_estimate(_P(planes[0], g.origin), C.c_ssize_t(g.stride), g.wcu, g.hcu, _P(inv_q) if inv_q is not None else None,
+                               _P(ic), _P(im), _P(lc), _P(rs), _P(sums))
+    return dict(intraCost=ic, intraMode=im, lowresCosts=lc, rowSatds=rs, costEst=int(sums[0]), costEstAq=int(sums[1]))
+
+
+def lookahead_cost_row(ora, half=1 << 13):
+    return ora.mvcost_row(int(ora.me_lib.xo_lookahead_qp()), half), half
+
+
+def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost, inv_q, state=None, do_search=(1, 1)):
+    """state = dict(mvs0, mvc0, mvs1, mvc1) carried between estimates that share a reference distance (in/out)"""
+    L = ora.me_lib
+    row, half = lookahead_cost_row(ora)
+    st = state if state is not None else {}
+    for k, n in (("mvs0", 2 * g.ncu), ("mvc0", g.ncu), ("mvs1", 2 * g.ncu), ("mvc1", g.ncu)):
+        st.setdefault(k, np.zeros(n, np.int32))
+    lc = np.zeros(g.ncu, np.int32); rs = np.zeros(g.hcu, np.int32); sums = np.zeros(3, np.int64)
+    VP = C.c_void_p * 4
+    r0 = VP(*[ref0_planes[k].ctypes.data + g.origin * ref0_planes.itemsize for k in range(4)])
+    r1 = VP(*[ref1_planes[k].ctypes.data + g.origin * ref1_planes.itemsize for k in range(4)]) if ref1_planes is not None else None
+    L.xo_lowres_frame_cost(_P(fenc_planes[0], g.origin), r0, r1, C.c_ssize_t(g.stride), g.wcu, g.hcu, _P(intra_cost),
+                           _P(inv_q) if inv_q is not None else None, _P(row, half), int(do_search[0]), int(do_search[1]),
+                           _P(st["mvs0"]), _P(st["mvc0"]), _P(st["mvs1"]), _P(st["mvc1"]), _P(lc), _P(rs), _P(sums))
+    return dict(mvs0=st["mvs0"].copy(), mvc0=st["mvc0"].copy(), mvs1=st["mvs1"].copy(), mvc1=st["mvc1"].copy(), lowresCosts=lc, rowSatds=rs,
+                costEst=int(sums[0]), costEstAq=int(sums[1]), intraMbs=int(sums[2]))
+
+
+def run_reference(depth, frames, triples, aq):
+    """oracle/_ref/x265la_<depth> on the clip -> (header dict, per-frame dicts, per-triple dicts)"""
+    H, W = frames[0].shape
+    with tempfile.TemporaryDirectory() as td:
+        inp, out = os.path.join(td, "in.raw"), os.path.join(td, "out.bin")
+        np.stack(frames).tofile(inp)
+        args = [la_bin(depth), str(W), str(H), str(len(frames)), inp, out, "1" if aq else "0"] + [",".join(str(v) for v in t) for t in triples]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = open(out, "rb").read()
+    recs, off = [], 0
+    while off < len(d):
+        n = int(np.frombuffer(d, np.int64, 1, off)[0]); off += 8
+        recs.append(np.frombuffer(d, np.int32, n, off).copy()); off += 4 * n
+    h = recs[0]
+    hdr = dict(W=h[0], H=h[1], N=h[2], stride=h[3], lw=h[4], lh=h[5], wcu=h[6], hcu=h[7], mx=h[8], my=h[9], depth=h[10], qg=h[11], bframes=h[12])
+    i, per_frame, per_triple = 1, [], []
+    for _ in frames:
+        per_frame.append(dict(planes=np.stack(recs[i:i + 4]), intraCost=recs[i + 4], intraMode=recs[i + 5], lowresCosts=recs[i + 6], rowSatds=recs[i + 7],
+                              invQ=recs[i + 8]))
+        i += 9
+    for _ in triples:
+        t = recs[i]
+        per_triple.append(dict(p0=t[0], b=t[1], p1=t[2], keep=t[3], doSearch=(t[4], t[5]), score=t[6], costEstNorm=t[7], costEstAq=t[8], intraMbs=t[9],
+                               mvs0=recs[i + 1], mvc0=recs[i + 2], mvs1=recs[i + 3], mvc1=recs[i + 4], lowresCosts=recs[i + 5], rowSatds=recs[i + 6]))
+        i += 7
+    return hdr, per_frame, per_triple

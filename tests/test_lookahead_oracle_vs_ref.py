@@ -1,0 +1,55 @@
+"""The restated lookahead frame-cost path (oracle/x265_oracle_la.c) against the REAL reference classes
+(oracle/_ref/x265la_*: Lowres::init, LookaheadTLD::lowresIntraEstimate, CostEstimateGroup::estimateFrameCost)."""
+import numpy as np
+import pytest
+
+from backends import Oracle
+from lookahead_util import (Geometry, la_available, lowres_planes_oracle, oracle_frame_cost, oracle_intra, run_reference, synth_clip)
+
+# (p0, b, p1, keep): P estimates, B estimates, and one B estimate that reuses the list-0 search a P estimate cached
+TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3, 0), (0, 2, 3, 1), (0, 3, 3, 0), (0, 1, 3, 0)]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,aq,shift", [((192, 144), 0, (3, 2)), ((208, 120), 1, (-6, 4)), ((64, 48), 1, (1, 0))])
+def test_lookahead_cost_matches_reference(depth, size, aq, shift):
+    if not la_available(depth):
+        pytest.skip("no reference lookahead binary")
+    W, H = size
+    frames = synth_clip(W, H, 4, depth, seed=100 + depth + W, shift=shift)
+    hdr, ref_frames, ref_triples = run_reference(depth, frames, TRIPLES, aq)
+    ora = Oracle(depth)
+    g = Geometry(W, H)
+    assert (g.stride, g.lw, g.lh, g.wcu, g.hcu) == (hdr["stride"], hdr["lw"], hdr["lh"], hdr["wcu"], hdr["hcu"])
+    planes, intra = [], []
+    for f, fr in enumerate(frames):
+        pl = lowres_planes_oracle(ora, fr, g)
+        assert np.array_equal(pl.astype(np.int32), ref_frames[f]["planes"]), "lowres planes of frame %d" % f
+        inv_q = ref_frames[f]["invQ"] if aq else None
+        it = oracle_intra(ora, pl, g, inv_q)
+        for k in ("intraCost", "intraMode", "lowresCosts", "rowSatds"):
+            assert np.array_equal(it[k], ref_frames[f][k]), "intra %s of frame %d" % (k, f)
+        planes.append(pl); intra.append(it)
+    cache = {}                                                  # (b, list, distance) -> (mvs, mvCosts), the reference's per-frame MV caches
+    for t, rt in zip(TRIPLES, ref_triples):
+        p0, b, p1, keep = t
+        if not keep:
+            cache = {k: v for k, v in cache.items() if k[0] != b}
+        do = tuple(int(v) for v in rt["doSearch"])
+        assert do == (int((b, 0, b - p0) not in cache), int(p1 > b and (b, 1, p1 - b) not in cache))
+        st = {}
+        if not do[0]:
+            st["mvs0"], st["mvc0"] = (a.copy() for a in cache[(b, 0, b - p0)])
+        if p1 > b and not do[1]:
+            st["mvs1"], st["mvc1"] = (a.copy() for a in cache[(b, 1, p1 - b)])
+        inv_q = ref_frames[b]["invQ"] if aq else None
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], inv_q, st, do)
+        for k in ("mvs0", "mvc0", "lowresCosts", "rowSatds") + (("mvs1", "mvc1") if p1 > b else ()):
+            assert np.array_equal(o[k], rt[k]), "%s of estimate %s" % (k, t)
+        norm = o["costEst"] * 100 // (130 + 0) if p1 > b else o["costEst"]          # slicetype.cpp:4456-4457, bFrameBias 0
+        assert (norm, o["costEstAq"]) == (rt["costEstNorm"], rt["costEstAq"]), "totals of estimate %s" % (t,)
+        if p1 == b:                                                              # intraMbs[b - p0] only counts in P estimates (:4619-4620)
+            assert o["intraMbs"] == rt["intraMbs"], "intraMbs of estimate %s" % (t,)
+        cache[(b, 0, b - p0)] = (o["mvs0"], o["mvc0"])
+        if p1 > b:
+            cache[(b, 1, p1 - b)] = (o["mvs1"], o["mvc1"])
