@@ -109,6 +109,39 @@ int x265hip_tq_batch(void* stream, int log2TrSize,
                      void* reconPlane /* NULL = forward path only */, intptr_t reconStride, uint64_t* sse /* n, with recon */,
                      const x265hip_me_result* mvSource /* may be NULL */);
 
+/* ---- lookahead frame costs on half-resolution pictures ------------------------------------------------
+ * The lowres buffer holds F pictures x 4 planes (full-pel, H, V, HV half-pel: what x265hip_frame_init_lowres +
+ * x265hip_extend_pic_border produce, the layout of Lowres::lowresPlane[0..3], lowres.cpp:381-391), each plane planeElems
+ * long with pixel (0,0) at element `origin`; plane k of picture f starts at ((f * 4 + k) * planeElems).  Blocks are the
+ * lookahead's 8x8 (X265_LOWRES_CU_SIZE); widthInCU x heightInCU of them per picture; margins >= 8 + 8 + 1 pixels.
+ *
+ * x265hip_lookahead_intra_batch  replaces LookaheadTLD::lowresIntraEstimate (slicetype.cpp:755-864) for nFrames pictures:
+ *   intraCost / intraMode / lowresCosts are nFrames x ncu, rowSatds nFrames x heightInCU, sums nFrames x { costEst, costEstAq }.
+ * x265hip_lookahead_cost_batch   replaces CostEstimateGroup::estimateFrameCost (slicetype.cpp:4365-4463, serial branch; no
+ *   HME, no weighted reference, no slices) with estimateCUCost (:4467-4640) for nTasks (p0, b, p1) choices at once.
+ *   invQscale: nFrames x ncu 8.8 fixed-point AQ factors (Lowres::invQscaleFactor / invQscaleFactor8x8) or NULL.
+ *   costRow: the row of x265hip_mvcost_row(x265hip_lookahead_qp(), ...), costHalfRange >= 4 * (8 * max(wcu, hcu) + 16).
+ *   mvs (int16 x, y per block) and mvCosts are arrays of ncu-long SLOTS, the device form of Lowres::lowresMvs[list][dist] /
+ *   lowresMvCosts[list][dist]: a task searches into its slot when doSearch[list] != 0 and reads it otherwise (the
+ *   reference's bDoSearch caching, :4376-4377).  Two tasks of one call must not search the same slot.
+ *   Outputs per outSlot: lowresCosts (ncu, cost | listused << 14), rowSatds (heightInCU), sums { costEst before the
+ *   B-frame normalisation (:4456-4457), costEstAq, intraMbs }. */
+typedef struct x265hip_la_task {
+    int32_t b, p0, p1;           /* picture indices in the lowres buffer, p0 <= b <= p1; p1 == b: P estimate        */
+    int32_t doSearch[2];         /* per list: run the motion search (else the slot already holds its result)          */
+    int32_t mvSlot[2];           /* per list: slot of mvs / mvCosts (mvSlot[1] unused for a P estimate)               */
+    int32_t outSlot;             /* slot of lowresCosts / rowSatds / sums                                             */
+} x265hip_la_task;               /* 32 bytes */
+
+int x265hip_lookahead_qp(void);  /* X265_LOOKAHEAD_QP of this library's bit depth (common.h:223) */
+int x265hip_lookahead_intra_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
+                                  int nFrames, const int32_t* invQscale, int32_t* intraCost, uint8_t* intraMode, uint16_t* lowresCosts,
+                                  int32_t* rowSatds, int64_t* sums);
+int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
+                                 const x265hip_la_task* tasks, int nTasks, const int32_t* intraCost, const int32_t* invQscale,
+                                 const uint16_t* costRow, int costHalfRange, int16_t* mvs, int32_t* mvCosts,
+                                 uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,109 @@
+"""GPU parity of the lookahead frame-cost batch (x265hip_lookahead_intra_batch / _cost_batch, with the lowres pictures built
+on the device by x265hip_frame_init_lowres + x265hip_extend_pic_border) against the restated reference path
+(oracle/x265_oracle_la.c, itself pinned to the reference's Lowres / Lookahead classes): every MV, cost and total identical."""
+import numpy as np
+import pytest
+
+import x265hip  # noqa: F401
+from x265hip_pkg.frame import FrameApi, LA_TASK
+from backends import Oracle
+from lookahead_util import (MARGIN_X, MARGIN_Y, Geometry, lookahead_cost_row, lowres_planes_oracle, oracle_frame_cost, oracle_intra, pad_full,
+                            synth_clip)
+
+pytestmark = pytest.mark.gpu
+
+
+def device_lowres(api, ora, frames, g):
+    """Lowres::init on the device: full-res padded pictures -> 4 half-pel planes per picture, borders extended"""
+    t = api.torch
+    n = len(frames)
+    full = np.stack([pad_full(ora, f, g) for f in frames])
+    d_full = api.to_device(full.reshape(-1))
+    d_low = t.zeros(n * 4 * g.plane_elems, dtype=api.pixel_t, device="cuda")
+    esz = d_low.element_size()
+    import ctypes as C
+    for f in range(n):
+        src = C.c_void_p(d_full.data_ptr() + (f * full.shape[1] + g.full_stride * MARGIN_Y + MARGIN_X) * esz)
+        dst = [C.c_void_p(d_low.data_ptr() + ((f * 4 + k) * g.plane_elems + g.origin) * esz) for k in range(4)]
+        api.h.check(api.lib.x265hip_frame_init_lowres(api.stream(), src, C.c_ssize_t(g.full_stride), dst[0], dst[1], dst[2], dst[3],
+                                                      C.c_ssize_t(g.stride), g.lw, g.lh))
+    api.extend_pic_border(d_low, g.origin, g.stride, g.lw, g.lh, MARGIN_X, MARGIN_Y, n_pictures=4 * n, picture_elems=g.plane_elems)
+    return d_low
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,aq,shift", [((192, 144), 0, (3, 2)), ((208, 120), 1, (-6, 4)), ((64, 48), 1, (1, 0)), ((640, 368), 1, (5, -3))])
+def test_lookahead_batch_matches_oracle(depth, size, aq, shift):
+    api, ora = FrameApi(depth), Oracle(depth)
+    t = api.torch
+    W, H = size
+    N = 4
+    frames = synth_clip(W, H, N, depth, seed=300 + depth + W, shift=shift)
+    g = Geometry(W, H)
+    d_low = device_lowres(api, ora, frames, g)
+    planes = [lowres_planes_oracle(ora, f, g) for f in frames]
+    got = d_low.cpu().numpy().view(planes[0].dtype).reshape(N, 4, g.plane_elems)
+    for f in range(N):
+        assert np.array_equal(got[f], planes[f]), "lowres planes of picture %d" % f
+    rng = np.random.default_rng(7 + W)
+    inv_q = rng.integers(160, 360, (N, g.ncu)).astype(np.int32) if aq else None
+    d_invq = api.to_device(inv_q.reshape(-1)) if aq else None
+    # ---- intra ----
+    d_ic = t.zeros(N * g.ncu, dtype=t.int32, device="cuda"); d_im = t.zeros(N * g.ncu, dtype=t.uint8, device="cuda")
+    d_lc = t.zeros(N * g.ncu, dtype=t.int16, device="cuda"); d_rs = t.full((N * g.hcu,), -7, dtype=t.int32, device="cuda")
+    d_sm = t.full((N * 2,), -7, dtype=t.int64, device="cuda")
+    api.lookahead_intra_batch(d_low, g.plane_elems, g.stride, g.origin, g.wcu, g.hcu, N, d_invq, d_ic, d_im, d_lc, d_rs, d_sm)
+    t.cuda.synchronize()
+    intra = [oracle_intra(ora, planes[f], g, inv_q[f] if aq else None) for f in range(N)]
+    ic = d_ic.cpu().numpy().reshape(N, g.ncu); im = d_im.cpu().numpy().reshape(N, g.ncu)
+    lc = d_lc.cpu().numpy().view(np.uint16).reshape(N, g.ncu); rs = d_rs.cpu().numpy().reshape(N, g.hcu); sm = d_sm.cpu().numpy().reshape(N, 2)
+    for f in range(N):
+        assert np.array_equal(ic[f], intra[f]["intraCost"]) and np.array_equal(im[f], intra[f]["intraMode"]), "intra costs / modes of picture %d" % f
+        assert np.array_equal(lc[f], intra[f]["lowresCosts"]) and np.array_equal(rs[f], intra[f]["rowSatds"]), "intra lowresCosts / rowSatds %d" % f
+        assert (int(sm[f][0]), int(sm[f][1])) == (intra[f]["costEst"], intra[f]["costEstAq"])
+    # ---- frame costs: one batch of independent estimates, then a second batch that reuses cached list-0 searches ----
+    row, half = lookahead_cost_row(ora)
+    d_row = api.to_device(row.view(np.int16))
+    est = [(0, 1, 1), (0, 2, 2), (0, 3, 3), (0, 1, 2), (1, 2, 3), (0, 1, 3), (2, 3, 3)]
+    tasks = np.zeros(len(est), LA_TASK)
+    nslot = 0
+    for i, (p0, b, p1) in enumerate(est):
+        tasks[i]["p0"], tasks[i]["b"], tasks[i]["p1"] = p0, b, p1
+        tasks[i]["doSearch"] = (1, 1 if p1 > b else 0)
+        tasks[i]["mvSlot"] = (nslot, nslot + 1 if p1 > b else 0)
+        nslot += 2 if p1 > b else 1
+        tasks[i]["outSlot"] = i
+    # second batch: B estimates (0,2,3) and (1,3,... no: reuse the list-0 result the P estimate (0,2,2) left in its slot
+    est2 = [(0, 2, 3)]
+    tasks2 = np.zeros(len(est2), LA_TASK)
+    tasks2[0]["p0"], tasks2[0]["b"], tasks2[0]["p1"] = est2[0]
+    tasks2[0]["doSearch"] = (0, 1); tasks2[0]["mvSlot"] = (int(tasks[1]["mvSlot"][0]), nslot); tasks2[0]["outSlot"] = len(est)
+    nslot += 1
+    nout = len(est) + len(est2)
+    d_mvs = t.full((nslot * g.ncu * 2,), 0x7fff, dtype=t.int16, device="cuda"); d_mvc = t.full((nslot * g.ncu,), -1, dtype=t.int32, device="cuda")
+    d_lc2 = t.zeros(nout * g.ncu, dtype=t.int16, device="cuda"); d_rs2 = t.full((nout * g.hcu,), -7, dtype=t.int32, device="cuda")
+    d_sm2 = t.full((nout * 3,), -7, dtype=t.int64, device="cuda")
+    for tk in (tasks, tasks2):
+        d_tasks = api.to_device(tk)
+        api.lookahead_cost_batch(d_low, g.plane_elems, g.stride, g.origin, g.wcu, g.hcu, d_tasks, len(tk), d_ic, d_invq, d_row, half, d_mvs, d_mvc, d_lc2, d_rs2, d_sm2)
+        t.cuda.synchronize()
+    mvs = d_mvs.cpu().numpy().reshape(nslot, g.ncu * 2).astype(np.int32); mvc = d_mvc.cpu().numpy().reshape(nslot, g.ncu)
+    lc2 = d_lc2.cpu().numpy().view(np.uint16).reshape(nout, g.ncu); rs2 = d_rs2.cpu().numpy().reshape(nout, g.hcu); sm2 = d_sm2.cpu().numpy().reshape(nout, 3)
+    results = {}
+    for tk in list(tasks) + list(tasks2):
+        p0, b, p1 = int(tk["p0"]), int(tk["b"]), int(tk["p1"])
+        st = {}
+        if not tk["doSearch"][0]:
+            prev = results[(0, 2, 2)]
+            st["mvs0"], st["mvc0"] = prev["mvs0"].copy(), prev["mvc0"].copy()
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], inv_q[b] if aq else None, st,
+                              (int(tk["doSearch"][0]), int(tk["doSearch"][1])))
+        results[(p0, b, p1)] = o
+        s0, s1, out = int(tk["mvSlot"][0]), int(tk["mvSlot"][1]), int(tk["outSlot"])
+        what = "estimate (%d,%d,%d)" % (p0, b, p1)
+        assert np.array_equal(mvs[s0], o["mvs0"]) and np.array_equal(mvc[s0], o["mvc0"]), "list-0 MVs / costs of " + what
+        if p1 > b:
+            assert np.array_equal(mvs[s1], o["mvs1"]) and np.array_equal(mvc[s1], o["mvc1"]), "list-1 MVs / costs of " + what
+        assert np.array_equal(lc2[out], o["lowresCosts"]), "lowresCosts of " + what
+        assert np.array_equal(rs2[out], o["rowSatds"]), "rowSatds of " + what
+        assert [int(v) for v in sm2[out]] == [o["costEst"], o["costEstAq"], o["intraMbs"]], "totals of " + what

@@ -1,0 +1,583 @@
+// kern_lookahead.hip -- the lookahead's frame-cost path on half-resolution ("lowres") pictures resident in HBM:
+//   la_intra_kernel   LookaheadTLD::lowresIntraEstimate           (reference encoder/slicetype.cpp:755-864)
+//   la_search_kernel  the motion-search half of estimateCUCost     (slicetype.cpp:4467-4572; motion.cpp:923-1140, 1644-1773, lowres branch)
+//   la_finish_kernel  the decision half of estimateCUCost          (slicetype.cpp:4574-4640)
+//
+// estimateFrameCost walks the 8x8 blocks of a picture in REVERSE raster order because every block takes its MV
+// predictor from the blocks to its right and below (right, below, below-left, below-right).  That is a wavefront
+// dependency, not a serial one: block (x, y) can start once step (W-1-x) + 2*(H-1-y) - 1 is done.  One workgroup owns
+// one (estimate, list) pair and sweeps the wavefront with one barrier per step; an 8-lane group (lane = block row)
+// runs the complete lowres motionEstimate of a block.  Independent estimates -- the lookahead asks for O(bframes^2)
+// per mini-GOP, and list 0 / list 1 of one estimate are independent too -- fill the machine.
+#include "xh_common.h"
+#include "../../include/x265hip_frame.h"
+#include <cmath>
+using namespace xh;
+
+namespace {
+
+constexpr int CU = 8;                      // X265_LOWRES_CU_SIZE
+constexpr int COST_MAX = 1 << 28;          // MotionEstimate::COST_MAX (motion.h:65)
+constexpr int LOWRES_COST_MASK = (1 << 14) - 1, LOWRES_COST_SHIFT = 14;   // slicetype.h:42-43
+constexpr int LA_MERANGE = 16;             // CostEstimateGroup::s_merange (slicetype.h:337)
+
+#define LA_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+__device__ __forceinline__ int quad_sum(int v) { v += LA_DPP(v, 0xB1); v += LA_DPP(v, 0x4E); return v; }          // quad_perm [1,0,3,2], [2,3,0,1]
+__device__ __forceinline__ int xor4(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x101F); }                      // lane ^ 4 (bit mode: and 0x1f, xor 4)
+__device__ __forceinline__ int group8_sum(int v) { v = quad_sum(v); return v + xor4(v); }
+
+// one row of eight pixels
+#if X265_DEPTH == 8
+struct Row { uint32_t w[2]; };
+__device__ __forceinline__ uint32_t avg_word(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu); }   // (a + b + 1) >> 1 per byte
+__device__ __forceinline__ int sad_row(const Row& a, const Row& b)
+{
+    return (int)__builtin_amdgcn_sad_u8(a.w[1], b.w[1], __builtin_amdgcn_sad_u8(a.w[0], b.w[0], 0));
+}
+__device__ __forceinline__ void diff_row(const Row& a, const Row& b, int (&d)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = (int)((a.w[i >> 2] >> (8 * (i & 3))) & 255) - (int)((b.w[i >> 2] >> (8 * (i & 3))) & 255);
+}
+constexpr int ROW_WORDS = 2;
+#else
+struct Row { uint32_t w[4]; };
+__device__ __forceinline__ uint32_t avg_word(uint32_t a, uint32_t b) { return (a | b) - (((a ^ b) >> 1) & 0x7fff7fffu); }
+__device__ __forceinline__ int sad_row(const Row& a, const Row& b)
+{
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s = __builtin_amdgcn_sad_u16(a.w[i], b.w[i], s);
+    return (int)s;
+}
+__device__ __forceinline__ void diff_row(const Row& a, const Row& b, int (&d)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = (int)((a.w[i >> 1] >> (16 * (i & 1))) & 0xffff) - (int)((b.w[i >> 1] >> (16 * (i & 1))) & 0xffff);
+}
+constexpr int ROW_WORDS = 4;
+#endif
+__device__ __forceinline__ Row ld_row(const pixel* p) { Row r; __builtin_memcpy(&r, p, sizeof(Row)); return r; }                  // any alignment, global
+__device__ __forceinline__ Row avg_rows(const Row& a, const Row& b)
+{   // pixelavg_pp (pixel.cpp:537-549) with the 32/32 weights the lookahead passes
+    Row r;
+#pragma unroll
+    for (int i = 0; i < ROW_WORDS; i++) r.w[i] = avg_word(a.w[i], b.w[i]);
+    return r;
+}
+
+// SATD of the 8x8 block whose row `lane & 7` differences are d[]: two satd_8x4 (pixel.cpp:237-265), each >> 1.
+// Horizontal 4-point Hadamards in registers, vertical ones across the four lanes of a quad (two DPP butterflies).
+__device__ __forceinline__ int satd_rows(const int (&d)[8], int lane)
+{
+    int h[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 4)
+    {
+        const int a0 = d[k] + d[k + 1], a1 = d[k] - d[k + 1], a2 = d[k + 2] + d[k + 3], a3 = d[k + 2] - d[k + 3];
+        h[k] = a0 + a2; h[k + 1] = a1 + a3; h[k + 2] = a0 - a2; h[k + 3] = a1 - a3;
+    }
+    const int s1 = (lane & 1) ? -1 : 1, s2 = (lane & 2) ? -1 : 1;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+        int v = h[k];
+        v = LA_DPP(v, 0xB1) + s1 * v;
+        v = LA_DPP(v, 0x4E) + s2 * v;
+        s += abs(v);
+    }
+    const int half = quad_sum(s) >> 1;           // one 8x4
+    return half + xor4(half);
+}
+
+// ---- per-block context of the search / finish kernels ----
+struct Blk
+{
+    Row fenc;
+    const pixel* ref0; int64_t pe;  // the lane's row at MV 0 in the full-pel plane of the reference; the H / V / HV half-pel planes follow pe elements apart (lowres.h:75-124)
+    intptr_t stride;
+    const uint16_t* cost; int mvpx, mvpy;
+    int lane;
+};
+__device__ __forceinline__ int mvcost(const Blk& c, int qx, int qy) { return (uint16_t)((int)c.cost[qx - c.mvpx] + (int)c.cost[qy - c.mvpy]); }   // bitcost.h:57
+// ReferencePlanes::lowresMC: half-pel positions are planes, quarter-pel positions the rounded average of two of them
+__device__ __forceinline__ Row mc_row(const Blk& c, int qx, int qy)
+{
+    const int hpelA = (qy & 2) | ((qx & 2) >> 1);
+    const Row a = ld_row(c.ref0 + hpelA * c.pe + (qx >> 2) + (intptr_t)(qy >> 2) * c.stride);
+    if (!((qx | qy) & 1)) return a;
+    const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
+    const int hpelB = (qy2 & 2) | ((qx2 & 2) >> 1);
+    const Row b = ld_row(c.ref0 + hpelB * c.pe + (qx2 >> 2) + (intptr_t)(qy2 >> 2) * c.stride);
+    return avg_rows(a, b);
+}
+// K candidates (quarter-pel coordinates) costed in one pass: loads first, then the reductions
+template<int K, bool SATD>
+__device__ __forceinline__ void eval(const Blk& c, const int (&qx)[K], const int (&qy)[K], int (&out)[K])
+{
+    Row r[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) r[k] = mc_row(c, qx[k], qy[k]);
+#pragma unroll
+    for (int k = 0; k < K; k++)
+    {
+        if (SATD) { int d[8]; diff_row(c.fenc, r[k], d); out[k] = satd_rows(d, c.lane); }
+        else out[k] = group8_sum(sad_row(c.fenc, r[k]));
+    }
+}
+
+__device__ __forceinline__ int k_hex2(int i, int col)
+{   // motion.cpp:64: {-1,-2} {-2,0} {-1,2} {1,2} {2,0} {1,-2} {-1,-2} {-2,0}, packed (value + 2) in 3 bits
+    const unsigned v = col ? 0x402910u /* y */ : 0x05c641u /* x */;
+    return (int)((v >> (3 * i)) & 7) - 2;
+}
+__device__ __forceinline__ int k_mod6m1(int i) { return (int)((0x05432105u >> (4 * i)) & 15); }   // motion.cpp:65
+__device__ __forceinline__ int k_sq(int i, int col)
+{   // square1 (motion.cpp:66): {0,0} {0,-1} {0,1} {-1,0} {1,0} {-1,-1} {-1,1} {1,-1} {1,1}, packed (value + 1) in 2 bits
+    const unsigned v = col ? 0x22161u /* y */ : 0x28215u /* x */;
+    return (int)((v >> (2 * i)) & 3) - 1;
+}
+
+// MotionEstimate::motionEstimate for a lowres reference (no candidates, hexagon search, subme 1): returns the cost, MV in (ox, oy)
+__device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int mxy, int mvpx, int mvpy, int& ox, int& oy)
+{
+    c.mvpx = mvpx; c.mvpy = mvpy;
+    const int qmnx = mnx * 4, qmny = mny * 4, qmxx = mxx * 4, qmxy = mxy * 4;
+    const int pmx = min(max(mvpx, qmnx), qmxx), pmy = min(max(mvpy, qmny), qmxy);
+    int bx = (pmx + 2) >> 2, by = (pmy + 2) >> 2, bcost, bprecost;
+    {   // motion.cpp:966-988: clipped MVP (sub-pel SAD, no mv cost), rounded MVP, zero MV
+        const int X[3] = { pmx, bx * 4, 0 }, Y[3] = { pmy, by * 4, 0 };
+        int C[3];
+        eval<3, false>(c, X, Y, C);
+        bprecost = bcost = C[0];
+        if ((pmx | pmy) & 3) bcost = C[1] + mvcost(c, bx * 4, by * 4);
+        if (pmx | pmy)
+        {
+            const int cost = C[2] + mvcost(c, 0, 0);
+            if (cost < bcost) { bcost = cost; bx = 0; by = max(min(0, mxy), mny); }
+        }
+    }
+    if (bcost == 0) { ox = bx * 4; oy = by * 4; return mvcost(c, ox, oy); }
+    auto inY = [&](int y) { return (y >= mny) & (y <= mxy); };
+    {   // hexagon search (motion.cpp:1041-1140)
+        int X[6], Y[6], C[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { X[k] = (bx + k_hex2(k + 1, 0)) * 4; Y[k] = (by + k_hex2(k + 1, 1)) * 4; }     // (-2,0) (-1,2) (1,2) (2,0) (1,-2) (-1,-2)
+        eval<6, false>(c, X, Y, C);
+#pragma unroll
+        for (int k = 0; k < 6; k++) C[k] += mvcost(c, X[k], Y[k]);
+        bcost <<= 3;
+        if (inY(by)) bcost = min(bcost, (C[0] << 3) + 2);
+        if (inY(by + 2)) { bcost = min(bcost, (C[1] << 3) + 3); bcost = min(bcost, (C[2] << 3) + 4); }
+        if (inY(by)) bcost = min(bcost, (C[3] << 3) + 5);
+        if (inY(by - 2)) { bcost = min(bcost, (C[4] << 3) + 6); bcost = min(bcost, (C[5] << 3) + 7); }
+    }
+    if (bcost & 7)
+    {
+        int dir = (bcost & 7) - 2;
+        if (inY(by + k_hex2(dir + 1, 1)))
+        {
+            bx += k_hex2(dir + 1, 0); by += k_hex2(dir + 1, 1);
+            for (int i = (LA_MERANGE >> 1) - 1; i > 0 && bx >= mnx && bx <= mxx && inY(by); i--)
+            {
+                int X[3], Y[3], C[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { X[k] = (bx + k_hex2(dir + k, 0)) * 4; Y[k] = (by + k_hex2(dir + k, 1)) * 4; }
+                eval<3, false>(c, X, Y, C);
+                bcost &= ~7;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (inY(by + k_hex2(dir + k, 1))) bcost = min(bcost, ((C[k] + mvcost(c, X[k], Y[k])) << 3) + k + 1);
+                if (!(bcost & 7)) break;
+                dir += (bcost & 7) - 2;
+                dir = k_mod6m1(dir + 1);
+                bx += k_hex2(dir + 1, 0); by += k_hex2(dir + 1, 1);
+            }
+        }
+    }
+    bcost >>= 3;
+    {   // square refine (:1116-1138)
+        int X[8], Y[8], C[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { X[k] = (bx + k_sq(k + 1, 0)) * 4; Y[k] = (by + k_sq(k + 1, 1)) * 4; }
+        eval<8, false>(c, X, Y, C);
+        int dir = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            const int cost = C[k] + mvcost(c, X[k], Y[k]);
+            if ((k_sq(k + 1, 1) == 0 || inY(by + k_sq(k + 1, 1))) && cost < bcost) { bcost = cost; dir = k + 1; }
+        }
+        bx += k_sq(dir, 0); by += k_sq(dir, 1);
+    }
+    // motion.cpp:1644-1699
+    int qx, qy;
+    if (bprecost < bcost) { qx = pmx; qy = pmy; bcost = bprecost; }
+    else { qx = bx * 4; qy = by * 4; }
+    int zeroSatd = -1;
+    if (!bcost)
+        bcost = mvcost(c, qx, qy);
+    else
+    {   // lowres branch: 4 half-pel directions at SAD, re-measure at SATD, 4 quarter-pel directions at SATD
+        int X[4], Y[4], C[4], bdir = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { X[k] = qx + k_sq(k + 1, 0) * 2; Y[k] = qy + k_sq(k + 1, 1) * 2; }
+        eval<4, false>(c, X, Y, C);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            if ((Y[k] < qmny) | (Y[k] > qmxy)) continue;
+            const int cost = C[k] + mvcost(c, X[k], Y[k]);
+            if (cost < bcost) { bcost = cost; bdir = k + 1; }
+        }
+        qx += k_sq(bdir, 0) * 2; qy += k_sq(bdir, 1) * 2;
+        {   // the zero-MV SATD of the final check rides along
+            const int X2[2] = { qx, 0 }, Y2[2] = { qy, 0 };
+            int C2[2];
+            eval<2, true>(c, X2, Y2, C2);
+            bcost = C2[0] + mvcost(c, qx, qy); zeroSatd = C2[1];
+        }
+        bdir = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { X[k] = qx + k_sq(k + 1, 0); Y[k] = qy + k_sq(k + 1, 1); }
+        eval<4, true>(c, X, Y, C);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            if ((Y[k] < qmny) | (Y[k] > qmxy)) continue;
+            const int cost = C[k] + mvcost(c, X[k], Y[k]);
+            if (cost < bcost) { bcost = cost; bdir = k + 1; }
+        }
+        qx += k_sq(bdir, 0); qy += k_sq(bdir, 1);
+    }
+    if (qx | qy)
+    {   // motion.cpp:1763-1768 (the cost is NOT replaced when the zero MV wins)
+        if (zeroSatd < 0)
+        {
+            const int X1[1] = { 0 }, Y1[1] = { 0 };
+            int C1[1];
+            eval<1, true>(c, X1, Y1, C1);
+            zeroSatd = C1[0];
+        }
+        if (zeroSatd + mvcost(c, 0, 0) <= bcost) { qx = 0; qy = 0; }
+    }
+    ox = qx; oy = qy;
+    return bcost;
+}
+
+struct LaGeom { const pixel* lowres; int64_t planeElems; intptr_t stride; int64_t origin; int wcu, hcu; };
+
+__device__ __forceinline__ const pixel* plane_of(const LaGeom& g, int frame, int k) { return g.lowres + ((int64_t)frame * 4 + k) * g.planeElems + g.origin; }
+
+// packed MV (x low, y high 16 bits), exchanged between the wavefronts of a workgroup through global memory
+__device__ __forceinline__ uint32_t ld_mv(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_mv(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint16_t* __restrict__ costCentre,
+                                                         uint32_t* mvs, int32_t* mvCosts)
+{
+    const x265hip_la_task* tp = tasks + (blockIdx.x >> 1);
+    const int list = blockIdx.x & 1;
+    const int tb = tp->b, tp0 = tp->p0, tp1 = tp->p1;
+    const bool bidir = tp1 > tb;
+    if ((list && !bidir) || !tp->doSearch[list]) return;
+    const int W = g.wcu, H = g.hcu, ncu = W * H;
+    const int grp = threadIdx.x >> 3, ngrp = blockDim.x >> 3, lane = threadIdx.x & 7;
+    const int slot = tp->mvSlot[list];
+    uint32_t* mv = mvs + (int64_t)slot * ncu;
+    int32_t* mvCost = mvCosts + (int64_t)slot * ncu;
+    const int refFrame = list ? tp1 : tp0;
+    const pixel* fencPlane = plane_of(g, tb, 0);
+    const pixel* rp = plane_of(g, refFrame, 0);
+
+    const int steps = W + 2 * (H - 1);
+    for (int s = 0; s < steps; s++)
+    {
+        const int jmin = max(0, (s - W + 2) >> 1), jmax = min(H - 1, s >> 1);
+        for (int j = jmin + grp; j <= jmax; j += ngrp)
+        {
+            const int cuY = H - 1 - j, cuX = W - 1 - (s - 2 * j), cuXY = cuX + cuY * W;
+            const bool lastRow = cuY == H - 1;
+            const intptr_t pel = (intptr_t)CU * cuX + ((intptr_t)CU * cuY + lane) * g.stride;
+            Blk c;
+            c.lane = lane; c.stride = g.stride; c.cost = costCentre; c.mvpx = 0; c.mvpy = 0;
+            c.fenc = ld_row(fencPlane + pel);
+            c.ref0 = rp + pel; c.pe = g.planeElems;
+            const int mnx = -cuX * CU - 8, mny = -cuY * CU - 8, mxx = (W - cuX - 1) * CU + 8, mxy = (H - cuY - 1) * CU + 8;
+            // reverse-order MV prediction (slicetype.cpp:4520-4536): right, below, below-left, below-right
+            const bool valid[4] = { cuX < W - 1, !lastRow, !lastRow && cuX > 0, !lastRow && cuX < W - 1 };
+            const int where[4] = { 1, W, W - 1, W + 1 };
+            int X[4], Y[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const uint32_t v = valid[k] ? ld_mv(mv + cuXY + where[k]) : 0u;
+                X[k] = (int16_t)(v & 0xffff); Y[k] = (int16_t)(v >> 16);
+            }
+            int mvpx = 0, mvpy = 0, skipCost = 0x7fffffff;
+            if (valid[0] | valid[1])
+            {   // the candidate with the lowest SATD becomes the predictor (:4541-4556)
+                int C[4];
+                eval<4, true>(c, X, Y, C);
+                int mvpcost = COST_MAX;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    if (!valid[k]) continue;
+                    if (C[k] < mvpcost) { mvpcost = C[k]; mvpx = X[k]; mvpy = Y[k]; }
+                    if (!(mvpx | mvpy) && bidir) skipCost = C[k];
+                }
+            }
+            int ox, oy;
+            int fencCost = lowres_me(c, mnx, mny, mxx, mxy, mvpx, mvpy, ox, oy);
+            if (skipCost < 64 && skipCost < fencCost && bidir) { fencCost = skipCost; ox = 0; oy = 0; }
+            if (lane == 0)
+            {
+                st_mv(mv + cuXY, (uint32_t)(uint16_t)ox | ((uint32_t)(uint16_t)oy << 16));
+                mvCost[cuXY] = fencCost;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void la_zero_kernel(const x265hip_la_task* __restrict__ tasks, int nTasks, int hcu, int32_t* rowSatds, unsigned long long* sums)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, per = hcu + 3;
+    if (i >= nTasks * per) return;
+    const int t = i / per, k = i % per, slot = tasks[t].outSlot;
+    if (k < hcu) rowSatds[(int64_t)slot * hcu + k] = 0;
+    else sums[(int64_t)slot * 3 + (k - hcu)] = 0;
+}
+
+// the decision half of estimateCUCost (:4574-4640); 8 lanes per block, 32 blocks per workgroup
+__global__ __launch_bounds__(256) void la_finish_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint32_t* __restrict__ mvs,
+                                                        const int32_t* __restrict__ mvCosts, const int32_t* __restrict__ intraCost,
+                                                        const int32_t* __restrict__ invQscale, uint16_t* __restrict__ lowresCosts,
+                                                        int32_t* rowSatds, unsigned long long* sums)
+{
+    const x265hip_la_task tk = tasks[blockIdx.y];
+    const int W = g.wcu, H = g.hcu, ncu = W * H;
+    const int cuXY = blockIdx.x * 32 + (threadIdx.x >> 3), lane = threadIdx.x & 7;
+    if (cuXY >= ncu) return;
+    const int cuX = cuXY % W, cuY = cuXY / W;
+    const bool bidir = tk.p1 > tk.b;
+    const intptr_t pel = (intptr_t)CU * cuX + ((intptr_t)CU * cuY + lane) * g.stride;
+    int bcost = COST_MAX, listused = 0;
+    for (int i = 0; i < 1 + (bidir ? 1 : 0); i++)
+    {
+        const int fencCost = mvCosts[(int64_t)tk.mvSlot[i] * ncu + cuXY];
+        if (fencCost < bcost) { bcost = fencCost; listused = i + 1; }
+    }
+    if (bidir)
+    {
+        Blk c0, c1;
+        c0.lane = c1.lane = lane; c0.stride = c1.stride = g.stride;
+        c0.fenc = ld_row(plane_of(g, tk.b, 0) + pel);
+        c0.ref0 = plane_of(g, tk.p0, 0) + pel; c1.ref0 = plane_of(g, tk.p1, 0) + pel; c0.pe = c1.pe = g.planeElems;
+        const uint32_t m0 = mvs[(int64_t)tk.mvSlot[0] * ncu + cuXY], m1 = mvs[(int64_t)tk.mvSlot[1] * ncu + cuXY];
+        const Row a = avg_rows(mc_row(c0, (int16_t)(m0 & 0xffff), (int16_t)(m0 >> 16)), mc_row(c1, (int16_t)(m1 & 0xffff), (int16_t)(m1 >> 16)));   // avg(l0-mv, l1-mv)
+        const Row z = avg_rows(ld_row(c0.ref0), ld_row(c1.ref0));                                                                              // co-located
+        int d[8];
+        diff_row(c0.fenc, a, d);
+        int bicost = satd_rows(d, lane);
+        if (bicost < bcost) { bcost = bicost; listused = 3; }
+        diff_row(c0.fenc, z, d);
+        bicost = satd_rows(d, lane);
+        if (bicost < bcost) { bcost = bicost; listused = 3; }
+        bcost += 4;                                        // lowresPenalty
+    }
+    else
+    {
+        bcost += 4;
+        const int ic = intraCost[(int64_t)tk.b * ncu + cuXY];
+        if (ic < bcost) { bcost = ic; listused = 0; }
+    }
+    if (lane) return;
+    const bool score = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+    const int bcostAq = (score && invQscale) ? ((bcost * invQscale[(int64_t)tk.b * ncu + cuXY] + 128) >> 8) : bcost;
+    unsigned long long* sm = sums + (int64_t)tk.outSlot * 3;
+    if (score)
+    {
+        atomicAdd(sm, (unsigned long long)bcost);
+        atomicAdd(sm + 1, (unsigned long long)bcostAq);
+        if (!listused && !bidir) atomicAdd(sm + 2, 1ull);
+    }
+    atomicAdd(rowSatds + (int64_t)tk.outSlot * H + cuY, bcostAq);
+    lowresCosts[(int64_t)tk.outSlot * ncu + cuXY] = (uint16_t)(min(bcost, LOWRES_COST_MASK) | (listused << LOWRES_COST_SHIFT));
+}
+
+// ---- intra cost of every 8x8 block (slicetype.cpp:755-864): one wavefront per block, lane = pixel ----
+__device__ const int8_t k_angleTable[17] = { -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+__device__ const int16_t k_invAngleTable[8] = { 4096, 1638, 910, 630, 482, 390, 315, 256 };
+__device__ const uint8_t k_intraFilterFlags[35] = {   // constants.cpp:561
+    0x38, 0x00, 0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30,
+    0x38, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x20, 0x00, 0x20, 0x30, 0x30, 0x30, 0x30, 0x30, 0x30, 0x38 };
+
+// satd of an 8x8 whose pixel (lane & 7, lane >> 3) difference is d: 4x4 Hadamards across lane bits 0,1 (x) and 3,4 (y)
+__device__ __forceinline__ int satd8x8_px(int d, int lane)
+{
+    int v = d;
+    v = LA_DPP(v, 0xB1) + ((lane & 1) ? -v : v);
+    v = LA_DPP(v, 0x4E) + ((lane & 2) ? -v : v);
+    v = LA_DPP(v, 0x128) + ((lane & 8) ? -v : v);                                   // row_ror:8 = lane ^ 8 inside a row of 16
+    v = __builtin_amdgcn_ds_swizzle(v, 0x401F) + ((lane & 16) ? -v : v);            // lane ^ 16
+    const int a = abs(v);
+    const int top = wave_sum(lane < 32 ? a : 0), bot = wave_sum(lane < 32 ? 0 : a); // the two 8x4 halves
+    return (top >> 1) + (bot >> 1);
+}
+
+__global__ __launch_bounds__(256) void la_intra_kernel(LaGeom g, int nFrames, const int32_t* __restrict__ invQscale, int penalty,
+                                                       int32_t* __restrict__ intraCost, uint8_t* __restrict__ intraMode, uint16_t* __restrict__ lowresCosts,
+                                                       int32_t* rowSatds, unsigned long long* sums)
+{
+    constexpr int N = CU, n2 = 2 * N, NB = 4 * N + 1;
+    __shared__ pixel s_nbAll[4][2][NB + 3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int W = g.wcu, H = g.hcu, ncu = W * H;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= nFrames * ncu) return;                         // wave-granular; no workgroup barrier below
+    const int frame = item / ncu, cuXY = item % ncu, cuX = cuXY % W, cuY = cuXY / W;
+    pixel (*s_nb)[NB + 3] = s_nbAll[wave];
+    const pixel* cur = plane_of(g, frame, 0) + (intptr_t)CU * cuX + (intptr_t)CU * cuY * g.stride;
+    const int x = lane & 7, y = lane >> 3;
+    const int f = cur[(intptr_t)y * g.stride + x];
+    {   // reference samples straight from the source plane (:795-799), then the [1 2 1] smoothing (intrapred.cpp:31-51)
+        const pixel* tl = cur - g.stride - 1;
+        if (lane <= 4 * N) s_nb[0][lane] = lane <= n2 ? tl[lane] : tl[(intptr_t)(lane - n2) * g.stride];
+        wave_sync();
+        if (lane <= 4 * N)
+        {
+            const pixel* s = s_nb[0];
+            const int i = lane, t = s[0];
+            int v;
+            if (i == 0) v = (2 * t + s[1] + s[n2 + 1] + 2) >> 2;
+            else if (i == n2 || i == 2 * n2) v = s[i];
+            else if (i == n2 + 1) v = (2 * s[i] + t + s[i + 1] + 2) >> 2;
+            else v = (2 * s[i] + s[i - 1] + s[i + 1] + 2) >> 2;
+            s_nb[1][i] = (pixel)v;
+        }
+        wave_sync();
+    }
+    auto nbAt = [&](const pixel* a, int i, bool flip) -> int { return a[flip && i >= 1 ? (i <= n2 ? i + n2 : i - n2) : i]; };
+    auto modeCost = [&](int mode) -> int {
+        // the prediction of pixel (x, y); horizontal modes (< 18) are the transpose of the vertical construction on the
+        // flipped neighbour array (intrapred.cpp:111-120, 192-203): evaluate that construction at (y, x)
+        const bool hor = mode >= 2 && mode < 18;
+        const int px = hor ? y : x, py = hor ? x : y;
+        int p;
+        if (mode == 0)
+        {   // planar on the filtered samples (intrapred.cpp:87-100; :812)
+            const pixel* a = s_nb[1];
+            p = ((N - 1 - x) * a[n2 + 1 + y] + (N - 1 - y) * a[1 + x] + (x + 1) * a[1 + N] + (y + 1) * a[n2 + 1 + N] + N) >> 4;
+        }
+        else if (mode == 1)
+        {   // DC with the edge filter (intrapred.cpp:53-85; :808)
+            const pixel* a = s_nb[0];
+            int v = lane < n2 ? (lane < N ? a[1 + lane] : a[n2 + 1 + lane - N]) : 0;
+            const int dc = (wave_sum(v) + N) / n2;
+            p = dc;
+            if (x == 0 && y == 0) p = (a[1] + a[n2 + 1] + 2 * dc + 2) >> 2;
+            else if (y == 0) p = (a[1 + x] + 3 * dc + 2) >> 2;
+            else if (x == 0) p = (a[n2 + 1 + y] + 3 * dc + 2) >> 2;
+        }
+        else
+        {
+            const pixel* a = s_nb[(k_intraFilterFlags[mode] & N) ? 1 : 0];
+            const int angleOffset = hor ? 10 - mode : mode - 26;
+            const int angle = k_angleTable[8 + angleOffset];
+            if (!angle)
+            {   // pure vertical / horizontal with the edge filter (intrapred.cpp:152-166)
+                p = nbAt(a, 1 + px, hor);
+                if (px == 0) p = clip_pixel((int16_t)(nbAt(a, 1, hor) + ((nbAt(a, n2 + 1 + py, hor) - (int)a[0]) >> 1)));
+            }
+            else
+            {
+                const int invAngle = angle < 0 ? k_invAngleTable[-angleOffset - 1] : 0;
+                const int angleSum = (py + 1) * angle, off = angleSum >> 5, frac = angleSum & 31;
+                auto ref = [&](int j) -> int { return j >= -1 ? nbAt(a, 1 + j, hor) : nbAt(a, n2 + ((128 + (-1 - j) * invAngle) >> 8), hor); };
+                p = frac ? ((32 - frac) * ref(off + px) + frac * ref(off + px + 1) + 16) >> 5 : ref(off + px);
+            }
+        }
+        return satd8x8_px(f - p, lane);
+    };
+    int icost = COST_MAX, ilow = 0, cost;
+    cost = modeCost(1); if (cost < icost) { icost = cost; ilow = 1; }
+    cost = modeCost(0); if (cost < icost) { icost = cost; ilow = 0; }
+    int acost = COST_MAX, alow = 4;
+    for (int mode = 5; mode < 35; mode += 5) { cost = modeCost(mode); if (cost < acost) { acost = cost; alow = mode; } }
+    for (int dist = 2; dist >= 1; dist--)
+    {
+        const int minus = alow - dist, plus = alow + dist;
+        cost = modeCost(minus); if (cost < acost) { acost = cost; alow = minus; }
+        cost = modeCost(plus); if (cost < acost) { acost = cost; alow = plus; }
+    }
+    if (acost < icost) { icost = acost; ilow = alow; }
+    icost += penalty;
+    if (lane) return;
+    intraCost[item] = icost; intraMode[item] = (uint8_t)ilow;
+    lowresCosts[item] = (uint16_t)min(icost, LOWRES_COST_MASK);
+    const bool score = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+    const int icostAq = (score && invQscale) ? ((icost * invQscale[item] + 128) >> 8) : icost;
+    if (score) { atomicAdd(sums + 2 * frame, (unsigned long long)icost); atomicAdd(sums + 2 * frame + 1, (unsigned long long)icostAq); }
+    atomicAdd(rowSatds + (int64_t)frame * H + cuY, icostAq);
+}
+
+bool bad_geom(const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int wcu, int hcu)
+{
+    return !lowres || planeElems <= 0 || stride < wcu * CU || origin < 0 || wcu < 1 || hcu < 1 || origin >= planeElems;
+}
+
+} // namespace
+
+extern "C" int x265hip_lookahead_qp(void) { return 12 + 6 * (X265_DEPTH - 8); }      // X265_LOOKAHEAD_QP (common.h:223)
+
+extern "C" int x265hip_lookahead_intra_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
+                                             int nFrames, const int32_t* invQscale, int32_t* intraCost, uint8_t* intraMode, uint16_t* lowresCosts,
+                                             int32_t* rowSatds, int64_t* sums)
+{
+    if (nFrames <= 0) return X265HIP_OK;
+    if (bad_geom(lowres, planeElems, stride, origin, widthInCU, heightInCU) || !intraCost || !intraMode || !lowresCosts || !rowSatds || !sums)
+    { set_error("lookahead_intra_batch: bad arguments"); return X265HIP_EARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int qp = x265hip_lookahead_qp();
+    const double lambda = std::floor(std::pow(2.0, (double)qp / 6.0 - 2.0) * (double)(1 << (X265_DEPTH - 8)) * 10000.0 + 0.5) / 10000.0;   // x265_lambda_tab[qp]
+    const int penalty = 5 * (int)lambda + 4;                                           // intraPenalty + lowresPenalty (:762-764)
+    XH_HIP(hipMemsetAsync(rowSatds, 0, sizeof(int32_t) * (size_t)nFrames * heightInCU, st));
+    XH_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * 2 * (size_t)nFrames, st));
+    const LaGeom g = { (const pixel*)lowres, planeElems, stride, origin, widthInCU, heightInCU };
+    const int64_t items = (int64_t)nFrames * widthInCU * heightInCU;
+    hipLaunchKernelGGL(la_intra_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, g, nFrames, invQscale, penalty, intraCost, intraMode, lowresCosts, rowSatds,
+                       (unsigned long long*)sums);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
+                                            const x265hip_la_task* tasks, int nTasks, const int32_t* intraCost, const int32_t* invQscale,
+                                            const uint16_t* costRow, int costHalfRange, int16_t* mvs, int32_t* mvCosts,
+                                            uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
+{
+    if (nTasks <= 0) return X265HIP_OK;
+    if (bad_geom(lowres, planeElems, stride, origin, widthInCU, heightInCU) || !tasks || !intraCost || !costRow || !mvs || !mvCosts || !lowresCosts || !rowSatds || !sums)
+    { set_error("lookahead_cost_batch: bad arguments"); return X265HIP_EARG; }
+    // every MV and predictor lies within the picture + 8 + one block: |mvd| <= 4 * (size + 16) quarter-pels
+    if (costHalfRange < 4 * (max(widthInCU, heightInCU) * CU + 16))
+    { set_error("lookahead_cost_batch: cost row too short for this picture size (need >= %d)", 4 * (max(widthInCU, heightInCU) * CU + 16)); return X265HIP_EARG; }
+    if (((uintptr_t)mvs & 3)) { set_error("lookahead_cost_batch: mvs must be 4-byte aligned"); return X265HIP_EARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const LaGeom g = { (const pixel*)lowres, planeElems, stride, origin, widthInCU, heightInCU };
+    hipLaunchKernelGGL(la_zero_kernel, dim3((unsigned)((nTasks * (heightInCU + 3) + 255) / 256)), dim3(256), 0, st, tasks, nTasks, heightInCU, rowSatds, (unsigned long long*)sums);
+    XH_LAUNCH_CHECK();
+    // one 8-lane group per block of the widest wavefront step, in whole wavefronts, at most 1024 threads
+    const int widest = min(heightInCU, (widthInCU + 1) / 2);
+    const int threads = min(1024, max(64, (widest * 8 + 63) / 64 * 64));
+    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks), dim3(threads), 0, st, g, tasks, costRow + costHalfRange, (uint32_t*)mvs, mvCosts);
+    XH_LAUNCH_CHECK();
+    const int ncu = widthInCU * heightInCU;
+    hipLaunchKernelGGL(la_finish_kernel, dim3((ncu + 31) / 32, nTasks), dim3(256), 0, st, g, tasks, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
+                       (unsigned long long*)sums);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}

@@ -13,7 +13,8 @@ ME_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mvmin", "<i2", 2), (
 ME_WINDOW = 1
 ME_RESULT = np.dtype([("mv", "<i2", 2), ("cost", "<i4"), ("mvcost", "<i4"), ("reserved", "<i4")])
 TU_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv", "<i2", 2), ("reconOff", "<i4"), ("mvFrom", "<i4")])
-assert ME_TASK.itemsize == 44 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 20
+LA_TASK = np.dtype([("b", "<i4"), ("p0", "<i4"), ("p1", "<i4"), ("doSearch", "<i4", 2), ("mvSlot", "<i4", 2), ("outSlot", "<i4")])
+assert ME_TASK.itemsize == 44 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 20 and LA_TASK.itemsize == 32
 
 
 class TqParams(C.Structure):
@@ -79,6 +80,21 @@ class FrameApi:
         self.h.check(self.lib.x265hip_intra_cost_batch(self.stream(), log2_size, _dp(src), C.c_ssize_t(src_stride), _dp(src_off), _dp(nb_ref), _dp(nb_filt),
                                                        nb_pitch, n, _dp(costs), _dp(workspace), C.c_size_t(need)))
         return workspace
+
+    def lookahead_qp(self):
+        return int(self.lib.x265hip_lookahead_qp())
+
+    def lookahead_intra_batch(self, lowres, plane_elems, stride, origin, wcu, hcu, n_frames, inv_qscale, intra_cost, intra_mode, lowres_costs, row_satds, sums):
+        """LookaheadTLD::lowresIntraEstimate for n_frames lowres pictures (4 planes each) resident in `lowres`."""
+        self.h.check(self.lib.x265hip_lookahead_intra_batch(self.stream(), _dp(lowres), C.c_int64(plane_elems), C.c_ssize_t(stride), C.c_int64(origin), wcu, hcu,
+                                                            n_frames, _dp(inv_qscale), _dp(intra_cost), _dp(intra_mode), _dp(lowres_costs), _dp(row_satds), _dp(sums)))
+
+    def lookahead_cost_batch(self, lowres, plane_elems, stride, origin, wcu, hcu, tasks, n_tasks, intra_cost, inv_qscale, cost_row, half,
+                             mvs, mv_costs, lowres_costs, row_satds, sums):
+        """CostEstimateGroup::estimateFrameCost for n_tasks (p0, b, p1) choices (LA_TASK records on the device)."""
+        self.h.check(self.lib.x265hip_lookahead_cost_batch(self.stream(), _dp(lowres), C.c_int64(plane_elems), C.c_ssize_t(stride), C.c_int64(origin), wcu, hcu,
+                                                           _dp(tasks), n_tasks, _dp(intra_cost), _dp(inv_qscale), _dp(cost_row), half,
+                                                           _dp(mvs), _dp(mv_costs), _dp(lowres_costs), _dp(row_satds), _dp(sums)))
 
     def frame_init_lowres(self, src, src_stride, d0, dh, dv, dc, dst_stride, width, height):
         self.h.check(self.lib.x265hip_frame_init_lowres(self.stream(), _dp(src), C.c_ssize_t(src_stride), _dp(d0), _dp(dh), _dp(dv), _dp(dc),
