@@ -49,9 +49,75 @@ def parse():
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
+    ap.add_argument("--lookahead", action="store_true", help="also time the lookahead frame-cost batch (lowres init, intra estimate, estimateFrameCost of a 32-picture window); reported under \"lookahead\", not part of value")
     ap.add_argument("--intra", action="store_true", help="also time the intra mode scan (35 sa8d costs per CU, sizes 64..8) over the same frames; reported under \"intra_scan\", not part of value")
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
+
+
+def lookahead_leg(depth, steps):
+    """Lookahead frame costs: 32 source pictures of 1920x1080 resident in HBM -> half-resolution planes, intra
+    costs and every (p0, b, p1) estimate a bframes=3 lookahead asks about inside that window, in one batch.  Two of the
+    estimates are run through the REFERENCE's own Lookahead classes (oracle/_ref/x265la_*, when present) on the same pictures:
+    results must be identical, and its clock gives the host number next to ours."""
+    import subprocess, tempfile
+    import torch
+    from x265hip_pkg.lookahead import LookaheadBatch, minigop_estimates, pan_clip
+    W, H, N = 1920, 1080, 32
+    est = minigop_estimates(N, 3)
+    lb = LookaheadBatch(depth, W, H, N, len(est))
+    frames = pan_clip(W, H, N, depth, seed=11)
+    lb.upload(frames)
+    lb.set_estimates(est)
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_low = timed(lb.build_lowres, steps)
+    ms_intra = timed(lb.intra, steps)
+    ms_cost = timed(lb.costs, steps)
+    nb = sum(1 for (p0, b, p1) in est if p1 > b)
+    out = {"what": "Lowres::init + lowresIntraEstimate of %d pictures, then estimateFrameCost of %d estimates (%d P, %d B = %d list searches) in one batch"
+                   % (N, len(est), len(est) - nb, nb, len(est) + nb),
+           "frame": "%dx%d -> lowres %dx%d blocks of 8x8" % (W, H, lb.g.wcu, lb.g.hcu), "pictures": N, "estimates": len(est),
+           "lowres_init_ms": round(ms_low, 4), "intra_ms": round(ms_intra, 4), "cost_batch_ms": round(ms_cost, 4),
+           "estimates_per_s": round(len(est) / (ms_cost * 1e-3), 1),
+           "mpixels_per_s": round(len(est) * W * H / (ms_cost * 1e-3) / 1e6, 1)}
+    ref = os.path.join(ROOT, "oracle", "_ref", "x265la_%d" % depth)
+    if os.path.exists(ref):
+        sample = [next(e for e in est if e[2] == e[1] and e[1] == 16), next(e for e in est if e[2] > e[1] and e[1] == 16)]
+        with tempfile.TemporaryDirectory() as td:
+            inp, outp = os.path.join(td, "in.raw"), os.path.join(td, "out.bin")
+            np.stack(frames).tofile(inp)
+            r = subprocess.run([ref, str(W), str(H), str(N), inp, outp, "0"] + ["%d,%d,%d" % e for e in sample], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-1000:]
+            d = open(outp, "rb").read()
+        recs, off = [], 0
+        while off < len(d):
+            n = int(np.frombuffer(d, np.int64, 1, off)[0]); off += 8
+            recs.append(np.frombuffer(d, np.int32, n, off)); off += 4 * n
+        scores = lb.frame_scores()
+        lc = lb.d_lc.cpu().numpy().view(np.uint16).reshape(-1, lb.g.ncu)
+        ic = lb.d_intra_cost.cpu().numpy().reshape(N, lb.g.ncu)
+        for f in range(N):
+            assert np.array_equal(ic[f], recs[1 + 9 * f + 4]), "lookahead: intra costs of picture %d differ from the reference" % f
+        base = 1 + 9 * N
+        for k, e in enumerate(sample):
+            i = est.index(e)
+            hdr = recs[base + 7 * k]
+            assert int(hdr[6]) == int(scores[i]) and np.array_equal(lc[i], recs[base + 7 * k + 5].astype(np.uint16)), "lookahead: estimate %s differs from the reference" % (e,)
+        tm = recs[-1].astype(np.int64) & 0xffffffff
+        ns_intra, ns_cost = int(tm[0] | (tm[1] << 32)), int(tm[2] | (tm[3] << 32))
+        cpu_est_s = len(sample) / (ns_cost * 1e-9)
+        out["reference"] = {"kind": "reference", "cores": 1, "sample": "%d estimates (one P, one B) and %d intra pictures through the reference's Lookahead classes, results identical" % (len(sample), N),
+                            "estimates_per_s": round(cpu_est_s, 2), "intra_pictures_per_s": round(N / (ns_intra * 1e-9), 2),
+                            "gpu_over_one_core": round(len(est) / (ms_cost * 1e-3) / cpu_est_s, 1)}
+    return out
 
 
 def intra_scan_leg(pipe, depth, steps):
@@ -349,6 +415,8 @@ def main():
         }
         if args.intra:
             out["intra_scan"] = intra_scan_leg(pipe, depth, max(2, min(args.steps, 10)))
+        if args.lookahead:
+            out["lookahead"] = lookahead_leg(depth, max(2, min(args.steps, 10)))
         if world == 1 and args.cpu_ctus > 0:
             out["cpu_baseline"] = cpu_baseline(pipe, depth, args.cpu_ctus)
         else:

@@ -17,7 +17,8 @@
  *   in.raw  : nframes luma planes, width x height pixels each (u8 / u16), no padding
  *   triples : indices into the frame list, p0 <= b <= p1; "keep" = 1 leaves the MV caches of frame b as the previous
  *             triples left them (bDoSearch then follows the reference's own rule, slicetype.cpp:4376-4377), 0 resets them
- *   out.bin : records of [int64 count][count x int32], in the order written below
+ *   out.bin : records of [int64 count][count x int32], in the order written below; the last record holds the time spent in
+ *             lowresIntraEstimate (all frames) and in singleCost (all estimates), nanoseconds as (lo, hi) int32 pairs
  */
 #include "common.h"
 #include "primitives.h"
@@ -25,6 +26,7 @@
 #include "lowres.h"
 #include "slicetype.h"
 #include "motion.h"
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -82,6 +84,7 @@ int main(int argc, char** argv)
     if (!la.create()) { fprintf(stderr, "Lookahead::create failed\n"); return 2; }
     LookaheadTLD& tld = la.m_tld[0];
 
+    int64_t nsIntra = 0, nsCost = 0;
     std::vector<PicYuv*> pics(N);
     std::vector<Lowres*> low(N);
     std::vector<pixel> row(W);
@@ -109,7 +112,7 @@ int main(int argc, char** argv)
             for (int i = 0; i < nfull; i++) l->invQscaleFactor[i] = 160 + ((i * 37 + f * 11) % 200);
             if (l->invQscaleFactor8x8) for (int i = 0; i < ncu; i++) l->invQscaleFactor8x8[i] = 160 + ((i * 37 + f * 11) % 200);
         }
-        tld.lowresIntraEstimate(*l, p->rc.qgSize);
+        { const auto t0 = std::chrono::steady_clock::now(); tld.lowresIntraEstimate(*l, p->rc.qgSize); nsIntra += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
     }
     Lowres* L0 = low[0];
     const int wcu = L0->maxBlocksInRow, hcu = L0->maxBlocksInCol, ncu = wcu * hcu;
@@ -140,7 +143,9 @@ int main(int argc, char** argv)
         if (!keep) resetCaches(*fenc, p->bframes);
         const int doSearch0 = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF, doSearch1 = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
         Group g(la, low.data());
+        const auto t0 = std::chrono::steady_clock::now();
         const int64_t score = g.singleCost(p0, p1, b, false);
+        nsCost += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         rec({ p0, b, p1, keep, doSearch0, doSearch1, (int32_t)score, (int32_t)fenc->costEst[b - p0][p1 - b], (int32_t)fenc->costEstAq[b - p0][p1 - b],
               fenc->intraMbs[b - p0] });
         for (int l = 0; l < 2; l++)
@@ -156,6 +161,7 @@ int main(int argc, char** argv)
         for (int i = 0; i < hcu; i++) rs[i] = fenc->rowSatds[b - p0][p1 - b][i];
         rec(lc); rec(rs);
     }
+    rec({ (int32_t)(nsIntra & 0xffffffff), (int32_t)(nsIntra >> 32), (int32_t)(nsCost & 0xffffffff), (int32_t)(nsCost >> 32) });
     fclose(g_out); fclose(in);
     return 0;
 }

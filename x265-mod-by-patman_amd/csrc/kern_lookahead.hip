@@ -57,7 +57,28 @@ __device__ __forceinline__ void diff_row(const Row& a, const Row& b, int (&d)[8]
 }
 constexpr int ROW_WORDS = 4;
 #endif
-__device__ __forceinline__ Row ld_row(const pixel* p) { Row r; __builtin_memcpy(&r, p, sizeof(Row)); return r; }                  // any alignment, global
+// A row at any pixel alignment, fetched as DWORD-ALIGNED loads + funnel shifts: one lane per cache line is already the
+// slowest pattern for the L1/TA front end (profiles/micro/RESULTS.md: ~37 clk per wave load), and a sub-dword-misaligned
+// address would split every lane's load again (2-4x).  Reads up to 3 bytes past the row (inside the plane margins).
+__device__ __forceinline__ Row ld_row(const pixel* p)
+{
+    const uintptr_t A = (uintptr_t)p;
+    const char* a = (const char*)(A & ~(uintptr_t)3);
+    const unsigned m = (unsigned)A & 3u;
+    Row r;
+#if X265_DEPTH == 8
+    struct W3 { uint32_t x, y, z; } w;
+    __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 12);
+    r.w[0] = __builtin_amdgcn_alignbyte(w.y, w.x, m); r.w[1] = __builtin_amdgcn_alignbyte(w.z, w.y, m);
+#else
+    struct W4 { uint32_t x, y, z, t; } w; uint32_t e;
+    __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 16);
+    __builtin_memcpy(&e, __builtin_assume_aligned(a + 16, 4), 4);
+    r.w[0] = __builtin_amdgcn_alignbyte(w.y, w.x, m); r.w[1] = __builtin_amdgcn_alignbyte(w.z, w.y, m);
+    r.w[2] = __builtin_amdgcn_alignbyte(w.t, w.z, m); r.w[3] = __builtin_amdgcn_alignbyte(e, w.t, m);
+#endif
+    return r;
+}
 __device__ __forceinline__ Row avg_rows(const Row& a, const Row& b)
 {   // pixelavg_pp (pixel.cpp:537-549) with the 32/32 weights the lookahead passes
     Row r;
@@ -83,8 +104,8 @@ __device__ __forceinline__ int satd_rows(const int (&d)[8], int lane)
     for (int k = 0; k < 8; k++)
     {
         int v = h[k];
-        v = LA_DPP(v, 0xB1) + s1 * v;
-        v = LA_DPP(v, 0x4E) + s2 * v;
+        v = LA_DPP(v, 0xB1) + __mul24(v, s1);         // full-rate 24-bit multiply: |v| < 2^15
+        v = LA_DPP(v, 0x4E) + __mul24(v, s2);
         s += abs(v);
     }
     const int half = quad_sum(s) >> 1;           // one 8x4
@@ -97,10 +118,12 @@ struct Blk
     Row fenc;
     const pixel* ref0; int64_t pe;  // the lane's row at MV 0 in the full-pel plane of the reference; the H / V / HV half-pel planes follow pe elements apart (lowres.h:75-124)
     intptr_t stride;
-    const uint16_t* cost; int mvpx, mvpy;
+    const uint16_t* cost; const uint16_t* lcost; int mvpx, mvpy;   // MVD cost row: global (full) and its LDS slice [-LA_COST_R, LA_COST_R] (both centred)
     int lane;
 };
-__device__ __forceinline__ int mvcost(const Blk& c, int qx, int qy) { return (uint16_t)((int)c.cost[qx - c.mvpx] + (int)c.cost[qy - c.mvpy]); }   // bitcost.h:57
+constexpr int LA_COST_R = 255;
+__device__ __forceinline__ int cost1(const Blk& c, int d) { return (unsigned)(d + LA_COST_R) <= 2u * LA_COST_R ? (int)c.lcost[d] : (int)c.cost[d]; }
+__device__ __forceinline__ int mvcost(const Blk& c, int qx, int qy) { return (uint16_t)(cost1(c, qx - c.mvpx) + cost1(c, qy - c.mvpy)); }   // bitcost.h:57
 // ReferencePlanes::lowresMC: half-pel positions are planes, quarter-pel positions the rounded average of two of them
 __device__ __forceinline__ Row mc_row(const Blk& c, int qx, int qy)
 {
@@ -288,6 +311,9 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
     uint32_t* mv = mvs + (int64_t)slot * ncu;
     int32_t* mvCost = mvCosts + (int64_t)slot * ncu;
     const int refFrame = list ? tp1 : tp0;
+    __shared__ uint16_t s_cost[2 * LA_COST_R + 2];
+    for (int i = threadIdx.x; i <= 2 * LA_COST_R; i += blockDim.x) s_cost[i] = costCentre[i - LA_COST_R];
+    __syncthreads();
     const pixel* fencPlane = plane_of(g, tb, 0);
     const pixel* rp = plane_of(g, refFrame, 0);
 
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
             const bool lastRow = cuY == H - 1;
             const intptr_t pel = (intptr_t)CU * cuX + ((intptr_t)CU * cuY + lane) * g.stride;
             Blk c;
-            c.lane = lane; c.stride = g.stride; c.cost = costCentre; c.mvpx = 0; c.mvpy = 0;
+            c.lane = lane; c.stride = g.stride; c.cost = costCentre; c.lcost = s_cost + LA_COST_R; c.mvpx = 0; c.mvpy = 0;
             c.fenc = ld_row(fencPlane + pel);
             c.ref0 = rp + pel; c.pe = g.planeElems;
             const int mnx = -cuX * CU - 8, mny = -cuY * CU - 8, mxx = (W - cuX - 1) * CU + 8, mxy = (H - cuY - 1) * CU + 8;
@@ -342,70 +368,98 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
     }
 }
 
-__global__ __launch_bounds__(256) void la_zero_kernel(const x265hip_la_task* __restrict__ tasks, int nTasks, int hcu, int32_t* rowSatds, unsigned long long* sums)
+__global__ __launch_bounds__(256) void la_zero_kernel(const x265hip_la_task* __restrict__ tasks, int nTasks, unsigned long long* sums)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, per = hcu + 3;
-    if (i >= nTasks * per) return;
-    const int t = i / per, k = i % per, slot = tasks[t].outSlot;
-    if (k < hcu) rowSatds[(int64_t)slot * hcu + k] = 0;
-    else sums[(int64_t)slot * 3 + (k - hcu)] = 0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nTasks * 3) sums[(int64_t)tasks[i / 3].outSlot * 3 + i % 3] = 0;
 }
 
-// the decision half of estimateCUCost (:4574-4640); 8 lanes per block, 32 blocks per workgroup
+// workgroup-wide sum of three per-thread values -> out[0..2] valid in thread 0 (the totals of one block row)
+__device__ __forceinline__ void row_totals(int a, int b, int c, int (&out)[3])
+{
+    __shared__ int s_red[4][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    if (lane == 0) { s_red[wave][0] = a; s_red[wave][1] = b; s_red[wave][2] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 3; k++) out[k] = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
+}
+
+// the decision half of estimateCUCost (:4574-4640): one workgroup per (block row, estimate), 8 lanes per block; the row's
+// totals are reduced inside the workgroup, so the frame sums see one atomic per row instead of one per block
 __global__ __launch_bounds__(256) void la_finish_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint32_t* __restrict__ mvs,
                                                         const int32_t* __restrict__ mvCosts, const int32_t* __restrict__ intraCost,
                                                         const int32_t* __restrict__ invQscale, uint16_t* __restrict__ lowresCosts,
-                                                        int32_t* rowSatds, unsigned long long* sums)
+                                                        int32_t* __restrict__ rowSatds, unsigned long long* sums)
 {
-    const x265hip_la_task tk = tasks[blockIdx.y];
+    const x265hip_la_task* tp = tasks + blockIdx.y;
+    const int tb = tp->b, tp0 = tp->p0, tp1 = tp->p1, slot0 = tp->mvSlot[0], slot1 = tp->mvSlot[1], outSlot = tp->outSlot;
     const int W = g.wcu, H = g.hcu, ncu = W * H;
-    const int cuXY = blockIdx.x * 32 + (threadIdx.x >> 3), lane = threadIdx.x & 7;
-    if (cuXY >= ncu) return;
-    const int cuX = cuXY % W, cuY = cuXY / W;
-    const bool bidir = tk.p1 > tk.b;
-    const intptr_t pel = (intptr_t)CU * cuX + ((intptr_t)CU * cuY + lane) * g.stride;
-    int bcost = COST_MAX, listused = 0;
-    for (int i = 0; i < 1 + (bidir ? 1 : 0); i++)
+    const int cuY = blockIdx.x, lane = threadIdx.x & 7;
+    const bool bidir = tp1 > tb;
+    int accCost = 0, accAq = 0, accRow = 0, accIntra = 0;
+    for (int cuX = threadIdx.x >> 3; cuX < W; cuX += 32)
     {
-        const int fencCost = mvCosts[(int64_t)tk.mvSlot[i] * ncu + cuXY];
-        if (fencCost < bcost) { bcost = fencCost; listused = i + 1; }
+        const int cuXY = cuX + cuY * W;
+        const intptr_t pel = (intptr_t)CU * cuX + ((intptr_t)CU * cuY + lane) * g.stride;
+        int bcost = COST_MAX, listused = 0;
+        {
+            const int c0 = mvCosts[(int64_t)slot0 * ncu + cuXY];
+            if (c0 < bcost) { bcost = c0; listused = 1; }
+            if (bidir)
+            {
+                const int c1 = mvCosts[(int64_t)slot1 * ncu + cuXY];
+                if (c1 < bcost) { bcost = c1; listused = 2; }
+            }
+        }
+        if (bidir)
+        {
+            Blk c0, c1;
+            c0.lane = c1.lane = lane; c0.stride = c1.stride = g.stride;
+            c0.fenc = ld_row(plane_of(g, tb, 0) + pel);
+            c0.ref0 = plane_of(g, tp0, 0) + pel; c1.ref0 = plane_of(g, tp1, 0) + pel; c0.pe = c1.pe = g.planeElems;
+            const uint32_t m0 = mvs[(int64_t)slot0 * ncu + cuXY], m1 = mvs[(int64_t)slot1 * ncu + cuXY];
+            const Row a = avg_rows(mc_row(c0, (int16_t)(m0 & 0xffff), (int16_t)(m0 >> 16)), mc_row(c1, (int16_t)(m1 & 0xffff), (int16_t)(m1 >> 16)));   // avg(l0-mv, l1-mv)
+            const Row z = avg_rows(ld_row(c0.ref0), ld_row(c1.ref0));                                                                              // co-located
+            int d[8];
+            diff_row(c0.fenc, a, d);
+            int bicost = satd_rows(d, lane);
+            if (bicost < bcost) { bcost = bicost; listused = 3; }
+            diff_row(c0.fenc, z, d);
+            bicost = satd_rows(d, lane);
+            if (bicost < bcost) { bcost = bicost; listused = 3; }
+            bcost += 4;                                        // lowresPenalty
+        }
+        else
+        {
+            bcost += 4;
+            const int ic = intraCost[(int64_t)tb * ncu + cuXY];
+            if (ic < bcost) { bcost = ic; listused = 0; }
+        }
+        if (lane == 0)
+        {
+            const bool score = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+            const int bcostAq = (score && invQscale) ? ((bcost * invQscale[(int64_t)tb * ncu + cuXY] + 128) >> 8) : bcost;
+            if (score) { accCost += bcost; accAq += bcostAq; accIntra += (!listused && !bidir) ? 1 : 0; }
+            accRow += bcostAq;
+            lowresCosts[(int64_t)outSlot * ncu + cuXY] = (uint16_t)(min(bcost, LOWRES_COST_MASK) | (listused << LOWRES_COST_SHIFT));
+        }
     }
-    if (bidir)
+    // a row holds at most a few thousand blocks of cost < 2^18: 32-bit partial sums are safe
+    int t3[3];
+    row_totals(accCost, accAq, accRow, t3);
+    __syncthreads();
+    int t1[3];
+    row_totals(accIntra, 0, 0, t1);
+    if (threadIdx.x == 0)
     {
-        Blk c0, c1;
-        c0.lane = c1.lane = lane; c0.stride = c1.stride = g.stride;
-        c0.fenc = ld_row(plane_of(g, tk.b, 0) + pel);
-        c0.ref0 = plane_of(g, tk.p0, 0) + pel; c1.ref0 = plane_of(g, tk.p1, 0) + pel; c0.pe = c1.pe = g.planeElems;
-        const uint32_t m0 = mvs[(int64_t)tk.mvSlot[0] * ncu + cuXY], m1 = mvs[(int64_t)tk.mvSlot[1] * ncu + cuXY];
-        const Row a = avg_rows(mc_row(c0, (int16_t)(m0 & 0xffff), (int16_t)(m0 >> 16)), mc_row(c1, (int16_t)(m1 & 0xffff), (int16_t)(m1 >> 16)));   // avg(l0-mv, l1-mv)
-        const Row z = avg_rows(ld_row(c0.ref0), ld_row(c1.ref0));                                                                              // co-located
-        int d[8];
-        diff_row(c0.fenc, a, d);
-        int bicost = satd_rows(d, lane);
-        if (bicost < bcost) { bcost = bicost; listused = 3; }
-        diff_row(c0.fenc, z, d);
-        bicost = satd_rows(d, lane);
-        if (bicost < bcost) { bcost = bicost; listused = 3; }
-        bcost += 4;                                        // lowresPenalty
+        rowSatds[(int64_t)outSlot * H + cuY] = t3[2];
+        unsigned long long* sm = sums + (int64_t)outSlot * 3;
+        if (t3[0]) atomicAdd(sm, (unsigned long long)t3[0]);
+        if (t3[1]) atomicAdd(sm + 1, (unsigned long long)t3[1]);
+        if (t1[0]) atomicAdd(sm + 2, (unsigned long long)t1[0]);
     }
-    else
-    {
-        bcost += 4;
-        const int ic = intraCost[(int64_t)tk.b * ncu + cuXY];
-        if (ic < bcost) { bcost = ic; listused = 0; }
-    }
-    if (lane) return;
-    const bool score = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
-    const int bcostAq = (score && invQscale) ? ((bcost * invQscale[(int64_t)tk.b * ncu + cuXY] + 128) >> 8) : bcost;
-    unsigned long long* sm = sums + (int64_t)tk.outSlot * 3;
-    if (score)
-    {
-        atomicAdd(sm, (unsigned long long)bcost);
-        atomicAdd(sm + 1, (unsigned long long)bcostAq);
-        if (!listused && !bidir) atomicAdd(sm + 2, 1ull);
-    }
-    atomicAdd(rowSatds + (int64_t)tk.outSlot * H + cuY, bcostAq);
-    lowresCosts[(int64_t)tk.outSlot * ncu + cuXY] = (uint16_t)(min(bcost, LOWRES_COST_MASK) | (listused << LOWRES_COST_SHIFT));
 }
 
 // ---- intra cost of every 8x8 block (slicetype.cpp:755-864): one wavefront per block, lane = pixel ----
@@ -428,7 +482,7 @@ __device__ __forceinline__ int satd8x8_px(int d, int lane)
     return (top >> 1) + (bot >> 1);
 }
 
-__global__ __launch_bounds__(256) void la_intra_kernel(LaGeom g, int nFrames, const int32_t* __restrict__ invQscale, int penalty,
+__global__ __launch_bounds__(256) void la_intra_kernel(LaGeom g, const int32_t* __restrict__ invQscale, int penalty,
                                                        int32_t* __restrict__ intraCost, uint8_t* __restrict__ intraMode, uint16_t* __restrict__ lowresCosts,
                                                        int32_t* rowSatds, unsigned long long* sums)
 {
@@ -436,10 +490,12 @@ __global__ __launch_bounds__(256) void la_intra_kernel(LaGeom g, int nFrames, co
     __shared__ pixel s_nbAll[4][2][NB + 3];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int W = g.wcu, H = g.hcu, ncu = W * H;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= nFrames * ncu) return;                         // wave-granular; no workgroup barrier below
-    const int frame = item / ncu, cuXY = item % ncu, cuX = cuXY % W, cuY = cuXY / W;
+    const int frame = blockIdx.y, cuY = blockIdx.x;            // one workgroup per block row: its four wavefronts take every fourth block
     pixel (*s_nb)[NB + 3] = s_nbAll[wave];
+    int accCost = 0, accAq = 0, accRow = 0;
+    for (int cuX = wave; cuX < W; cuX += 4)
+    {
+    const int cuXY = cuX + cuY * W, item = frame * ncu + cuXY;
     const pixel* cur = plane_of(g, frame, 0) + (intptr_t)CU * cuX + (intptr_t)CU * cuY * g.stride;
     const int x = lane & 7, y = lane >> 3;
     const int f = cur[(intptr_t)y * g.stride + x];
@@ -515,13 +571,25 @@ __global__ __launch_bounds__(256) void la_intra_kernel(LaGeom g, int nFrames, co
     }
     if (acost < icost) { icost = acost; ilow = alow; }
     icost += penalty;
-    if (lane) return;
-    intraCost[item] = icost; intraMode[item] = (uint8_t)ilow;
-    lowresCosts[item] = (uint16_t)min(icost, LOWRES_COST_MASK);
-    const bool score = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
-    const int icostAq = (score && invQscale) ? ((icost * invQscale[item] + 128) >> 8) : icost;
-    if (score) { atomicAdd(sums + 2 * frame, (unsigned long long)icost); atomicAdd(sums + 2 * frame + 1, (unsigned long long)icostAq); }
-    atomicAdd(rowSatds + (int64_t)frame * H + cuY, icostAq);
+    if (lane == 0)
+    {
+        intraCost[item] = icost; intraMode[item] = (uint8_t)ilow;
+        lowresCosts[item] = (uint16_t)min(icost, LOWRES_COST_MASK);
+        const bool score = (cuX > 0 && cuX < W - 1 && cuY > 0 && cuY < H - 1) || W <= 2 || H <= 2;
+        const int icostAq = (score && invQscale) ? ((icost * invQscale[item] + 128) >> 8) : icost;
+        if (score) { accCost += icost; accAq += icostAq; }
+        accRow += icostAq;
+    }
+    wave_sync();                                               // the next block overwrites this wavefront's neighbour arrays
+    }
+    int t3[3];
+    row_totals(accCost, accAq, accRow, t3);
+    if (threadIdx.x == 0)
+    {
+        rowSatds[(int64_t)frame * H + cuY] = t3[2];
+        if (t3[0]) atomicAdd(sums + 2 * frame, (unsigned long long)t3[0]);
+        if (t3[1]) atomicAdd(sums + 2 * frame + 1, (unsigned long long)t3[1]);
+    }
 }
 
 bool bad_geom(const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int wcu, int hcu)
@@ -544,11 +612,9 @@ extern "C" int x265hip_lookahead_intra_batch(void* stream, const void* lowres, i
     const int qp = x265hip_lookahead_qp();
     const double lambda = std::floor(std::pow(2.0, (double)qp / 6.0 - 2.0) * (double)(1 << (X265_DEPTH - 8)) * 10000.0 + 0.5) / 10000.0;   // x265_lambda_tab[qp]
     const int penalty = 5 * (int)lambda + 4;                                           // intraPenalty + lowresPenalty (:762-764)
-    XH_HIP(hipMemsetAsync(rowSatds, 0, sizeof(int32_t) * (size_t)nFrames * heightInCU, st));
     XH_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * 2 * (size_t)nFrames, st));
     const LaGeom g = { (const pixel*)lowres, planeElems, stride, origin, widthInCU, heightInCU };
-    const int64_t items = (int64_t)nFrames * widthInCU * heightInCU;
-    hipLaunchKernelGGL(la_intra_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, g, nFrames, invQscale, penalty, intraCost, intraMode, lowresCosts, rowSatds,
+    hipLaunchKernelGGL(la_intra_kernel, dim3(heightInCU, nFrames), dim3(256), 0, st, g, invQscale, penalty, intraCost, intraMode, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -568,15 +634,14 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     if (((uintptr_t)mvs & 3)) { set_error("lookahead_cost_batch: mvs must be 4-byte aligned"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     const LaGeom g = { (const pixel*)lowres, planeElems, stride, origin, widthInCU, heightInCU };
-    hipLaunchKernelGGL(la_zero_kernel, dim3((unsigned)((nTasks * (heightInCU + 3) + 255) / 256)), dim3(256), 0, st, tasks, nTasks, heightInCU, rowSatds, (unsigned long long*)sums);
+    hipLaunchKernelGGL(la_zero_kernel, dim3((unsigned)((nTasks * 3 + 255) / 256)), dim3(256), 0, st, tasks, nTasks, (unsigned long long*)sums);
     XH_LAUNCH_CHECK();
     // one 8-lane group per block of the widest wavefront step, in whole wavefronts, at most 1024 threads
     const int widest = min(heightInCU, (widthInCU + 1) / 2);
     const int threads = min(1024, max(64, (widest * 8 + 63) / 64 * 64));
     hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks), dim3(threads), 0, st, g, tasks, costRow + costHalfRange, (uint32_t*)mvs, mvCosts);
     XH_LAUNCH_CHECK();
-    const int ncu = widthInCU * heightInCU;
-    hipLaunchKernelGGL(la_finish_kernel, dim3((ncu + 31) / 32, nTasks), dim3(256), 0, st, g, tasks, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
+    hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
