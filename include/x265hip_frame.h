@@ -120,7 +120,7 @@ int x265hip_tq_batch(void* stream, int log2TrSize,
  * x265hip_lookahead_cost_batch   replaces CostEstimateGroup::estimateFrameCost (slicetype.cpp:4365-4463, serial branch; no
  *   HME, no weighted reference, no slices) with estimateCUCost (:4467-4640) for nTasks (p0, b, p1) choices at once.
  *   invQscale: nFrames x ncu 8.8 fixed-point AQ factors (Lowres::invQscaleFactor / invQscaleFactor8x8) or NULL.
- *   costRow: the row of x265hip_mvcost_row(x265hip_lookahead_qp(), ...), costHalfRange >= 4 * (8 * max(wcu, hcu) + 16).
+ *   costRow: the row of x265hip_mvcost_row(x265hip_lookahead_qp(), ...), costHalfRange >= 4 * (8 * max(wcu, hcu) + 32).
  *   mvs (int16 x, y per block) and mvCosts are arrays of ncu-long SLOTS, the device form of Lowres::lowresMvs[list][dist] /
  *   lowresMvCosts[list][dist]: a task searches into its slot when doSearch[list] != 0 and reads it otherwise (the
  *   reference's bDoSearch caching, :4376-4377).  Two tasks of one call must not search the same slot.

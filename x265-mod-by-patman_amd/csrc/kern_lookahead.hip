@@ -11,7 +11,9 @@
 // per mini-GOP, and list 0 / list 1 of one estimate are independent too -- fill the machine.
 #include "xh_common.h"
 #include "../../include/x265hip_frame.h"
+#include <algorithm>
 #include <cmath>
+#include <vector>
 using namespace xh;
 
 namespace {
@@ -60,22 +62,23 @@ constexpr int ROW_WORDS = 4;
 // A row at any pixel alignment, fetched as DWORD-ALIGNED loads + funnel shifts: one lane per cache line is already the
 // slowest pattern for the L1/TA front end (profiles/micro/RESULTS.md: ~37 clk per wave load), and a sub-dword-misaligned
 // address would split every lane's load again (2-4x).  Reads up to 3 bytes past the row (inside the plane margins).
-__device__ __forceinline__ Row ld_row(const pixel* p)
+// The address is "uniform 4-byte-aligned buffer base + 32-bit element offset": SGPR-base addressing, no 64-bit VALU math.
+__device__ __forceinline__ Row ld_row(const pixel* base, uint32_t e)
 {
-    const uintptr_t A = (uintptr_t)p;
-    const char* a = (const char*)(A & ~(uintptr_t)3);
-    const unsigned m = (unsigned)A & 3u;
+    const uint32_t boff = e * (uint32_t)sizeof(pixel);
+    const char* a = (const char*)base + (boff & ~3u);
+    const unsigned m = boff & 3u;
     Row r;
 #if X265_DEPTH == 8
     struct W3 { uint32_t x, y, z; } w;
     __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 12);
     r.w[0] = __builtin_amdgcn_alignbyte(w.y, w.x, m); r.w[1] = __builtin_amdgcn_alignbyte(w.z, w.y, m);
 #else
-    struct W4 { uint32_t x, y, z, t; } w; uint32_t e;
+    struct W4 { uint32_t x, y, z, t; } w; uint32_t w4;
     __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 16);
-    __builtin_memcpy(&e, __builtin_assume_aligned(a + 16, 4), 4);
+    __builtin_memcpy(&w4, __builtin_assume_aligned(a + 16, 4), 4);
     r.w[0] = __builtin_amdgcn_alignbyte(w.y, w.x, m); r.w[1] = __builtin_amdgcn_alignbyte(w.z, w.y, m);
-    r.w[2] = __builtin_amdgcn_alignbyte(w.t, w.z, m); r.w[3] = __builtin_amdgcn_alignbyte(e, w.t, m);
+    r.w[2] = __builtin_amdgcn_alignbyte(w.t, w.z, m); r.w[3] = __builtin_amdgcn_alignbyte(w4, w.t, m);
 #endif
     return r;
 }
@@ -116,23 +119,21 @@ __device__ __forceinline__ int satd_rows(const int (&d)[8], int lane)
 struct Blk
 {
     Row fenc;
-    const pixel* ref0; int64_t pe;  // the lane's row at MV 0 in the full-pel plane of the reference; the H / V / HV half-pel planes follow pe elements apart (lowres.h:75-124)
-    intptr_t stride;
-    const uint16_t* cost; const uint16_t* lcost; int mvpx, mvpy;   // MVD cost row: global (full) and its LDS slice [-LA_COST_R, LA_COST_R] (both centred)
+    const pixel* base; uint32_t ref0, pe;   // lowres buffer; element offset of the lane's row at MV 0 in the reference's full-pel plane; the H / V / HV half-pel planes follow pe elements apart (lowres.h:75-124)
+    int stride;
+    const uint16_t* lcost; int mvpx, mvpy;   // MVD cost row in LDS (centred); it covers every |mv - mvp| a picture of this size can produce
     int lane;
 };
-constexpr int LA_COST_R = 255;
-__device__ __forceinline__ int cost1(const Blk& c, int d) { return (unsigned)(d + LA_COST_R) <= 2u * LA_COST_R ? (int)c.lcost[d] : (int)c.cost[d]; }
-__device__ __forceinline__ int mvcost(const Blk& c, int qx, int qy) { return (uint16_t)(cost1(c, qx - c.mvpx) + cost1(c, qy - c.mvpy)); }   // bitcost.h:57
+__device__ __forceinline__ int mvcost(const Blk& c, int qx, int qy) { return (uint16_t)((int)c.lcost[qx - c.mvpx] + (int)c.lcost[qy - c.mvpy]); }   // bitcost.h:57
 // ReferencePlanes::lowresMC: half-pel positions are planes, quarter-pel positions the rounded average of two of them
 __device__ __forceinline__ Row mc_row(const Blk& c, int qx, int qy)
 {
     const int hpelA = (qy & 2) | ((qx & 2) >> 1);
-    const Row a = ld_row(c.ref0 + hpelA * c.pe + (qx >> 2) + (intptr_t)(qy >> 2) * c.stride);
+    const Row a = ld_row(c.base, c.ref0 + __umul24(hpelA, c.pe) + (uint32_t)((qx >> 2) + __mul24(qy >> 2, c.stride)));
     if (!((qx | qy) & 1)) return a;
     const int qx2 = qx + (qx & 1), qy2 = qy + (qy & 1);
     const int hpelB = (qy2 & 2) | ((qx2 & 2) >> 1);
-    const Row b = ld_row(c.ref0 + hpelB * c.pe + (qx2 >> 2) + (intptr_t)(qy2 >> 2) * c.stride);
+    const Row b = ld_row(c.base, c.ref0 + __umul24(hpelB, c.pe) + (uint32_t)((qx2 >> 2) + __mul24(qy2 >> 2, c.stride)));
     return avg_rows(a, b);
 }
 // K candidates (quarter-pel coordinates) costed in one pass: loads first, then the reductions
@@ -292,12 +293,14 @@ __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int 
 struct LaGeom { const pixel* lowres; int64_t planeElems; intptr_t stride; int64_t origin; int wcu, hcu; };
 
 __device__ __forceinline__ const pixel* plane_of(const LaGeom& g, int frame, int k) { return g.lowres + ((int64_t)frame * 4 + k) * g.planeElems + g.origin; }
+// element offset of pixel (0,0) of plane 0 of a picture inside the lowres buffer (the whole buffer is < 2^31 elements, checked on the host)
+__device__ __forceinline__ uint32_t plane0_off(const LaGeom& g, int frame) { return (uint32_t)((int64_t)frame * 4 * g.planeElems + g.origin); }
 
 // packed MV (x low, y high 16 bits), exchanged between the wavefronts of a workgroup through global memory
 __device__ __forceinline__ uint32_t ld_mv(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void st_mv(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint16_t* __restrict__ costCentre,
+__global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint16_t* __restrict__ costCentre, int costR,
                                                          uint32_t* mvs, int32_t* mvCosts)
 {
     const x265hip_la_task* tp = tasks + (blockIdx.x >> 1);
@@ -311,11 +314,11 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
     uint32_t* mv = mvs + (int64_t)slot * ncu;
     int32_t* mvCost = mvCosts + (int64_t)slot * ncu;
     const int refFrame = list ? tp1 : tp0;
-    __shared__ uint16_t s_cost[2 * LA_COST_R + 2];
-    for (int i = threadIdx.x; i <= 2 * LA_COST_R; i += blockDim.x) s_cost[i] = costCentre[i - LA_COST_R];
+    extern __shared__ uint16_t s_cost[];                       // 2 * costR + 1 entries of the cost row
+    for (int i = threadIdx.x; i <= 2 * costR; i += blockDim.x) s_cost[i] = costCentre[i - costR];
     __syncthreads();
-    const pixel* fencPlane = plane_of(g, tb, 0);
-    const pixel* rp = plane_of(g, refFrame, 0);
+    const uint32_t fencPlane = plane0_off(g, tb), rp = plane0_off(g, refFrame);
+    const int stride = (int)g.stride;
 
     const int steps = W + 2 * (H - 1);
     for (int s = 0; s < steps; s++)
@@ -325,11 +328,11 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
         {
             const int cuY = H - 1 - j, cuX = W - 1 - (s - 2 * j), cuXY = cuX + cuY * W;
             const bool lastRow = cuY == H - 1;
-            const intptr_t pel = (intptr_t)CU * cuX + ((intptr_t)CU * cuY + lane) * g.stride;
+            const uint32_t pel = (uint32_t)(CU * cuX + __mul24(CU * cuY + lane, stride));
             Blk c;
-            c.lane = lane; c.stride = g.stride; c.cost = costCentre; c.lcost = s_cost + LA_COST_R; c.mvpx = 0; c.mvpy = 0;
-            c.fenc = ld_row(fencPlane + pel);
-            c.ref0 = rp + pel; c.pe = g.planeElems;
+            c.lane = lane; c.stride = stride; c.base = g.lowres; c.lcost = s_cost + costR; c.mvpx = 0; c.mvpy = 0;
+            c.fenc = ld_row(g.lowres, fencPlane + pel);
+            c.ref0 = rp + pel; c.pe = (uint32_t)g.planeElems;
             const int mnx = -cuX * CU - 8, mny = -cuY * CU - 8, mxx = (W - cuX - 1) * CU + 8, mxy = (H - cuY - 1) * CU + 8;
             // reverse-order MV prediction (slicetype.cpp:4520-4536): right, below, below-left, below-right
             const bool valid[4] = { cuX < W - 1, !lastRow, !lastRow && cuX > 0, !lastRow && cuX < W - 1 };
@@ -343,9 +346,26 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
             }
             int mvpx = 0, mvpy = 0, skipCost = 0x7fffffff;
             if (valid[0] | valid[1])
-            {   // the candidate with the lowest SATD becomes the predictor (:4541-4556)
-                int C[4];
-                eval<4, true>(c, X, Y, C);
+            {   // the candidate with the lowest SATD becomes the predictor (:4541-4556).  Neighbours mostly agree: a candidate
+                // equal to an earlier one reuses its cost, and a slot nobody in the wavefront needs is skipped (uniform branches)
+                int C[4] = { 0, 0, 0, 0 };
+                bool need[4]; Row r[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    bool dup = false;
+#pragma unroll
+                    for (int j = 0; j < k; j++) dup |= valid[j] && X[j] == X[k] && Y[j] == Y[k];
+                    need[k] = __builtin_amdgcn_ballot_w64(valid[k] && !dup) != 0;
+                    if (need[k]) r[k] = mc_row(c, X[k], Y[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    if (need[k]) { int d[8]; diff_row(c.fenc, r[k], d); C[k] = satd_rows(d, lane); }
+#pragma unroll
+                    for (int j = k - 1; j >= 0; j--) if (valid[j] && X[j] == X[k] && Y[j] == Y[k]) C[k] = C[j];
+                }
                 int mvpcost = COST_MAX;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(256) void la_finish_kernel(LaGeom g, const x265hip_
     for (int cuX = threadIdx.x >> 3; cuX < W; cuX += 32)
     {
         const int cuXY = cuX + cuY * W;
-        const intptr_t pel = (intptr_t)CU * cuX + ((intptr_t)CU * cuY + lane) * g.stride;
+        const uint32_t pel = (uint32_t)(CU * cuX + __mul24(CU * cuY + lane, (int)g.stride));
         int bcost = COST_MAX, listused = 0;
         {
             const int c0 = mvCosts[(int64_t)slot0 * ncu + cuXY];
@@ -416,12 +436,12 @@ __global__ __launch_bounds__(256) void la_finish_kernel(LaGeom g, const x265hip_
         if (bidir)
         {
             Blk c0, c1;
-            c0.lane = c1.lane = lane; c0.stride = c1.stride = g.stride;
-            c0.fenc = ld_row(plane_of(g, tb, 0) + pel);
-            c0.ref0 = plane_of(g, tp0, 0) + pel; c1.ref0 = plane_of(g, tp1, 0) + pel; c0.pe = c1.pe = g.planeElems;
+            c0.lane = c1.lane = lane; c0.stride = c1.stride = (int)g.stride; c0.base = c1.base = g.lowres;
+            c0.fenc = ld_row(g.lowres, plane0_off(g, tb) + pel);
+            c0.ref0 = plane0_off(g, tp0) + pel; c1.ref0 = plane0_off(g, tp1) + pel; c0.pe = c1.pe = (uint32_t)g.planeElems;
             const uint32_t m0 = mvs[(int64_t)slot0 * ncu + cuXY], m1 = mvs[(int64_t)slot1 * ncu + cuXY];
             const Row a = avg_rows(mc_row(c0, (int16_t)(m0 & 0xffff), (int16_t)(m0 >> 16)), mc_row(c1, (int16_t)(m1 & 0xffff), (int16_t)(m1 >> 16)));   // avg(l0-mv, l1-mv)
-            const Row z = avg_rows(ld_row(c0.ref0), ld_row(c1.ref0));                                                                              // co-located
+            const Row z = avg_rows(ld_row(c0.base, c0.ref0), ld_row(c1.base, c1.ref0));                                                                              // co-located
             int d[8];
             diff_row(c0.fenc, a, d);
             int bicost = satd_rows(d, lane);
@@ -594,7 +614,7 @@ __global__ __launch_bounds__(256) void la_intra_kernel(LaGeom g, const int32_t* 
 
 bool bad_geom(const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int wcu, int hcu)
 {
-    return !lowres || planeElems <= 0 || stride < wcu * CU || origin < 0 || wcu < 1 || hcu < 1 || origin >= planeElems;
+    return !lowres || ((uintptr_t)lowres & 3) || planeElems <= 0 || planeElems >= (1 << 24) || stride < wcu * CU || stride >= (1 << 23) || origin < 0 || wcu < 1 || hcu < 1 || origin >= planeElems;
 }
 
 } // namespace
@@ -628,10 +648,22 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     if (nTasks <= 0) return X265HIP_OK;
     if (bad_geom(lowres, planeElems, stride, origin, widthInCU, heightInCU) || !tasks || !intraCost || !costRow || !mvs || !mvCosts || !lowresCosts || !rowSatds || !sums)
     { set_error("lookahead_cost_batch: bad arguments"); return X265HIP_EARG; }
-    // every MV and predictor lies within the picture + 8 + one block: |mvd| <= 4 * (size + 16) quarter-pels
-    if (costHalfRange < 4 * (max(widthInCU, heightInCU) * CU + 16))
-    { set_error("lookahead_cost_batch: cost row too short for this picture size (need >= %d)", 4 * (max(widthInCU, heightInCU) * CU + 16)); return X265HIP_EARG; }
+    // every MV and predictor lies within the picture + 8, + one block for the neighbour's own window, + 3 of pattern overshoot: |mvd| < 4 * (size + 32) quarter-pels
+    if (costHalfRange < 4 * (max(widthInCU, heightInCU) * CU + 32))
+    { set_error("lookahead_cost_batch: cost row too short for this picture size (need >= %d)", 4 * (max(widthInCU, heightInCU) * CU + 32)); return X265HIP_EARG; }
     if (((uintptr_t)mvs & 3)) { set_error("lookahead_cost_batch: mvs must be 4-byte aligned"); return X265HIP_EARG; }
+    int maxFrame = 0;
+    {   // the kernels address the lowres buffer with 32-bit element offsets: all referenced pictures must lie below 2^31 elements
+        std::vector<x265hip_la_task> h((size_t)nTasks);
+        XH_HIP(hipMemcpyAsync(h.data(), tasks, sizeof(x265hip_la_task) * (size_t)nTasks, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        XH_HIP(hipStreamSynchronize((hipStream_t)stream));
+        for (const auto& t : h)
+        {
+            if (t.p0 < 0 || t.p0 > t.b || t.b > t.p1) { set_error("lookahead_cost_batch: estimate (%d, %d, %d) is not ordered p0 <= b <= p1", t.p0, t.b, t.p1); return X265HIP_EARG; }
+            maxFrame = std::max(maxFrame, t.p1);
+        }
+    }
+    if (((int64_t)maxFrame + 1) * 4 * planeElems >= ((int64_t)1 << 31)) { set_error("lookahead_cost_batch: lowres buffer beyond 2^31 elements"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     const LaGeom g = { (const pixel*)lowres, planeElems, stride, origin, widthInCU, heightInCU };
     hipLaunchKernelGGL(la_zero_kernel, dim3((unsigned)((nTasks * 3 + 255) / 256)), dim3(256), 0, st, tasks, nTasks, (unsigned long long*)sums);
@@ -639,7 +671,8 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     // one 8-lane group per block of the widest wavefront step, in whole wavefronts, at most 1024 threads
     const int widest = min(heightInCU, (widthInCU + 1) / 2);
     const int threads = min(1024, max(64, (widest * 8 + 63) / 64 * 64));
-    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks), dim3(threads), 0, st, g, tasks, costRow + costHalfRange, (uint32_t*)mvs, mvCosts);
+    const int costR = 4 * (max(widthInCU, heightInCU) * CU + 32);               // the bound checked above; 2 bytes per entry of LDS
+    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks), dim3(threads), sizeof(uint16_t) * (2 * costR + 2), st, g, tasks, costRow + costHalfRange, costR, (uint32_t*)mvs, mvCosts);
     XH_LAUNCH_CHECK();
     hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
