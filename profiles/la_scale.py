@@ -5,7 +5,10 @@ import x265hip  # noqa
 import torch
 from x265hip_pkg.lookahead import LookaheadBatch, minigop_estimates, pan_clip
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-W, H, N = 1920, 1080, 32
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+print("depth %d, %dx%d, %d pictures" % (depth, W, H, N))
 est = minigop_estimates(N, 3)
 lb = LookaheadBatch(depth, W, H, N, 4 * len(est))
 lb.upload(pan_clip(W, H, N, depth, seed=11)); lb.build_lowres(); lb.intra()
