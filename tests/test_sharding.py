@@ -9,7 +9,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import x265hip  # noqa: F401
-from x265hip_pkg.sharding import rank_frame_seeds, max_over_ranks, whole_job_mpixels_per_s
+from x265hip_pkg.sharding import rank_frame_seeds, max_over_ranks, whole_job_mpixels_per_s, rank_estimates
 from x265hip_pkg.synth import frame_pair
 
 
@@ -64,3 +64,43 @@ def test_rank_seeds_are_disjoint_for_eight_gpus():
     allseeds = [s for r in range(8) for s in rank_frame_seeds(r, 8)]
     assert sorted(allseeds) == list(range(64))
     assert max_over_ranks(1.25) == 1.25
+
+
+def _la_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "oracle")); sys.path.insert(0, os.path.join(root, "tests"))
+    from oracle_py import Oracle
+    from lookahead_util import Geometry, lowres_planes_oracle, oracle_frame_cost, oracle_intra, synth_clip
+    from x265hip_pkg.lookahead import minigop_estimates
+    ora = Oracle(8)
+    frames = synth_clip(96, 64, 5, 8, seed=5)             # every rank holds the (small) window of pictures
+    g = Geometry(96, 64)
+    planes = [lowres_planes_oracle(ora, f, g) for f in frames]
+    intra = [oracle_intra(ora, p, g) for p in planes]
+    est = minigop_estimates(5, 2)
+    mine = rank_estimates(rank, world, est) if world > 1 else est
+    res = {}
+    for (p0, b, p1) in mine:                               # the rank's own estimates through the (CPU) oracle: no peer data needed
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], None)
+        res[(p0, b, p1)] = (o["costEst"], o["costEstAq"], o["intraMbs"], int(o["mvs0"].astype(np.int64).sum()))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)                  # test-only collection
+    if rank == 0:
+        import pickle
+        pickle.dump((est, gathered), open(os.path.join(out_dir, "la.pkl"), "wb"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lookahead_estimates_shard_without_exchange(tmp_path):
+    import pickle
+    mp.spawn(_la_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    est, two = pickle.load(open(tmp_path / "la.pkl", "rb"))
+    assert not (set(two[0]) & set(two[1])) and set(two[0]) | set(two[1]) == set(est) and two[0] and two[1]
+    mp.spawn(_la_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    _, one = pickle.load(open(tmp_path / "la.pkl", "rb"))
+    merged = dict(two[0]); merged.update(two[1])
+    assert merged == one[0]

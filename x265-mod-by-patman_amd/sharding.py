@@ -23,3 +23,12 @@ def max_over_ranks(value, dist=None, device="cpu"):
 def whole_job_mpixels_per_s(world, pixels_per_step_per_rank, steps, seconds):
     """Aggregate throughput of the whole job: every rank processed the same amount (weak scaling)."""
     return world * pixels_per_step_per_rank * steps / seconds / 1e6
+
+
+def rank_estimates(rank, world, estimates):
+    """Lookahead frame-cost estimates (p0, b, p1) are independent given the pictures (which every rank holds -- a lookahead window of
+    half-resolution pictures is a few MB): rank r takes every world-th estimate, no exchange.  Estimates that share a (b, list,
+    distance) search are kept on one rank so that the reference's search reuse (bDoSearch) stays local: the key is (b, b - p0)."""
+    keys = sorted({(b, b - p0) for (p0, b, p1) in estimates})
+    owner = {k: i % world for i, k in enumerate(keys)}
+    return [e for e in estimates if owner[(e[1], e[1] - e[0])] == rank]
