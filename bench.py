@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
+    ap.add_argument("--overlap-tq", action="store_true", help="launch the TQ kernel beside me16/me8 on a side stream (it needs the me32 MVs only); measured gain 2 %, off by default so that per-kernel durations are those of kernels that own the GPU")
     ap.add_argument("--lookahead", action="store_true", help="also time the lookahead frame-cost batch (lowres init, intra estimate, estimateFrameCost of a 32-picture window); reported under \"lookahead\", not part of value")
     ap.add_argument("--intra", action="store_true", help="also time the intra mode scan (35 sa8d costs per CU, sizes 64..8) over the same frames; reported under \"intra_scan\", not part of value")
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
@@ -358,27 +359,18 @@ def main():
     # per-kernel HIP events on every 4th step only: an event between two launches keeps the tail of one kernel from
     # overlapping the head of the next (measured: ~5 % of the step time when every launch is bracketed)
     sampled = [k for k in range(args.steps) if k % 4 == 0]
-    events = {k: [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for k in sampled}
+    evname = {n: ("tq" if n.startswith("tq") else n) for n in names}
+    events = {k: {evname[n]: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for k in sampled}
+    pipe.overlap_tq = args.overlap_tq
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev = events.get(k)
-        if ev is None:
-            pipe.step()
-            continue
-        ev[0].record()
-        j = 0
-        if pipe.use_planes:
-            pipe.launch_planes(); j += 1; ev[j].record()
-        for lv in LEVELS:
-            pipe.launch_me(lv); j += 1; ev[j].record()
-        pipe.launch_tq()
-        ev[j + 1].record()
+        pipe.step(events.get(k))                    # events (when given) are recorded on the stream each kernel is launched on
     barrier()
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda")
 
     if rank == 0:
-        kms = {n: float(np.mean([events[k][i].elapsed_time(events[k][i + 1]) for k in sampled])) for i, n in enumerate(names)}
+        kms = {n: float(np.mean([events[k][evname[n]][0].elapsed_time(events[k][evname[n]][1]) for k in sampled])) for n in names}
         bpp = 1 if depth == 8 else 2
         px = pipe.pixels_per_step
         # algorithmic (compulsory) bytes per launch: SURVEY 8(d) -- each plane byte once + 16 B result per PU / 2 B coeff per pixel
@@ -406,7 +398,7 @@ def main():
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames,
                        "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "qp": args.qp,
-                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": "kernel by kernel, per-kernel events on every 4th step", "sharding": "independent frames per GPU, no collectives"},
+                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": ("TQ on a side stream beside the me16/me8 launches (it needs the me32 MVs only), joined per step" if pipe.overlap_tq else "kernel by kernel") + "; per-kernel events on every 4th step", "sharding": "independent frames per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),

@@ -78,6 +78,7 @@ class FramePipeline:
         off = f * self.plane + (self.margin + y) * self.stride + self.margin + x
         tu["curOff"] = off; tu["refOff"] = off; tu["reconOff"] = off
         self.mv_level = max(n, 8)                                # pyramid level whose MVs drive the TUs
+        self.overlap_tq = False                                  # step(): TQ on a side stream beside the smaller-PU searches (measured: 2 %, 0.644 vs 0.657 ms)
         lnx, lny = W // self.mv_level, H // self.mv_level
         tu["mvFrom"] = f * (lnx * lny) + (y // self.mv_level) * lnx + (x // self.mv_level)
         self.tu_host = tu
@@ -126,12 +127,38 @@ class FramePipeline:
                           mv_source=self.d_results[self.mv_level],
                           planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
 
-    def step(self):
+    def step(self, ev=None):
+        """One pass of the hot path.  The TQ launch depends on the MVs of one ME level only (mv_level), so it runs on a side
+        stream next to the remaining (smaller-PU) ME launches -- a memory/MFMA-side kernel beside VALU-side ones -- and is joined
+        before the step ends.  ev: optional {name: (start_event, end_event)} recorded around each launch on the stream it runs on."""
+        t = self.torch
+        main = t.cuda.current_stream()
+        if getattr(self, "side", None) is None:
+            self.side = t.cuda.Stream()
+            self.ev_fork, self.ev_join = t.cuda.Event(), t.cuda.Event()
+
+        def run(name, fn, stream):
+            if ev is not None:
+                ev[name][0].record(stream)
+            fn()
+            if ev is not None:
+                ev[name][1].record(stream)
         if self.use_planes:
-            self.launch_planes()
+            run("planes", self.launch_planes, main)
+        forked = False
         for lv in LEVELS:
-            self.launch_me(lv)
-        self.launch_tq()
+            run("me%d" % lv, lambda: self.launch_me(lv), main)
+            if lv == self.mv_level and self.overlap_tq:
+                self.ev_fork.record(main)
+                self.side.wait_event(self.ev_fork)
+                with t.cuda.stream(self.side):
+                    run("tq", self.launch_tq, self.side)
+                    self.ev_join.record(self.side)
+                forked = True
+        if forked:
+            main.wait_event(self.ev_join)
+        else:
+            run("tq", self.launch_tq, main)
 
     # ---- read-back / checking helpers (tests, smoke) ----
     def results(self, lv):
