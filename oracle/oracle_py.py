@@ -236,14 +236,23 @@ class Oracle:
     def lambda_tab(self):
         return np.array([self.me_lib.xo_lambda(q) for q in range(70)])
 
-    def me(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, mvc, merange, method, subme, costrow):
-        """costrow: centred uint16 row (as returned by mvcost_row); returns (mvx, mvy, cost)."""
+    def sea_integral_planes(self, ref, stride, origin, max_height, pad_x, pad_y):
+        """the 12 SEA integral planes of a padded picture (framefilter.cpp:740-833): uint32 array [12, len(ref)], same layout as ref"""
+        planes = np.full((12, ref.size), 0xdeadbeef, np.uint32)
+        ptrs = (C.c_void_p * 12)(*[planes[k].ctypes.data + origin * 4 for k in range(12)])
+        self.me_lib.xo_sea_integral_planes(_ptr(ref, origin), _IP(stride), max_height, pad_x, pad_y, ptrs)
+        return planes
+
+    def me(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, mvc, merange, method, subme, costrow, integral=None):
+        """costrow: centred uint16 row (as returned by mvcost_row); integral: [12, len(ref)] planes of sea_integral_planes (method 4);
+        returns (mvx, mvy, cost)."""
         b = np.asarray(bounds, np.int32); c = np.asarray(mvc, np.int32).reshape(-1)
         out = np.zeros(2, np.int32)
         half = (len(costrow) - 1) // 2
-        cost = self.me_lib.xo_motion_estimate(_ptr(cur, coff), _IP(cstride), w, h, _ptr(ref, roff), _IP(rstride), _ptr(b),
-                                              int(qmvp[0]), int(qmvp[1]), len(c) // 2, _ptr(c) if len(c) else None,
-                                              merange, method, subme, _ptr(costrow, half), _ptr(out))
+        ip = (C.c_void_p * 12)(*[integral[k].ctypes.data + roff * 4 for k in range(12)]) if integral is not None else None
+        cost = self.me_lib.xo_motion_estimate_sea(_ptr(cur, coff), _IP(cstride), w, h, _ptr(ref, roff), _IP(rstride), _ptr(b),
+                                                  int(qmvp[0]), int(qmvp[1]), len(c) // 2, _ptr(c) if len(c) else None,
+                                                  merange, method, subme, _ptr(costrow, half), _ptr(out), ip)
         return int(out[0]), int(out[1]), int(cost)
 
     # ---- inter TU pipeline (x265_oracle_me.c xo_tq_tu) ----

@@ -33,6 +33,7 @@ void setupDCTPrimitives_c(EncoderPrimitives& p);
 void setupFilterPrimitives_c(EncoderPrimitives& p);
 void setupIntraPrimitives_c(EncoderPrimitives& p);
 void setupLowPassPrimitives_c(EncoderPrimitives& p);
+void setupSeaIntegralPrimitives_c(EncoderPrimitives& p);   /* framefilter.cpp:142-157 */
 extern const int16_t g_t4[4][4];
 extern const int16_t g_t8[8][8];
 extern const int16_t g_t16[16][16];
@@ -416,6 +417,32 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         /* blockOffset is the PU offset inside the fenc plane; the reference plane pointer is pre-offset so the
            same blockOffset addresses the co-located block (lookahead calling convention, slicetype.cpp:4484) */
         rp.fpelPlane[0] = PX(B[1], I[5]) - I[3];
+        std::vector<std::vector<uint32_t> > integ;
+        if ((int)I[13] == X265_SEA)
+        {   /* ints after the candidates: element index of pixel (0,0) in the reference buffer, CTU-aligned picture height, padX, padY.
+               The 12 integral planes are built by the reference's integral_init primitives in the order FrameFilter::processPostRow
+               calls them (framefilter.cpp:757-833), then handed to the search at the PU's co-located offset (search.cpp:2153-2157). */
+            const int64_t org = I[17 + 2 * nc]; const int maxHeight = (int)I[18 + 2 * nc], padX = (int)I[19 + 2 * nc], padY = (int)I[20 + 2 * nc];
+            const intptr_t stride = I[4];
+            const size_t elems = B[1].size() / sizeof(pixel);
+            static const int Wk[12] = { INTEGRAL_32, INTEGRAL_32, INTEGRAL_32, INTEGRAL_24, INTEGRAL_16, INTEGRAL_16, INTEGRAL_16, INTEGRAL_12, INTEGRAL_8, INTEGRAL_8, INTEGRAL_4, INTEGRAL_4 };
+            static const int Hk[12] = { INTEGRAL_32, INTEGRAL_24, INTEGRAL_8, INTEGRAL_32, INTEGRAL_16, INTEGRAL_12, INTEGRAL_4, INTEGRAL_16, INTEGRAL_32, INTEGRAL_8, INTEGRAL_16, INTEGRAL_4 };
+            static const int Hn[12] = { 32, 24, 8, 32, 16, 12, 4, 16, 32, 8, 16, 4 };
+            integ.assign(12, std::vector<uint32_t>(elems + 64, 0xdeadbeefu));
+            for (int k = 0; k < 12; k++)
+            {
+                uint32_t* Iorg = integ[k].data() + org;
+                memset(Iorg - padY * stride - padX, 0, stride * sizeof(uint32_t));
+                for (int y = -padY; y < maxHeight + padY - 1; y++)
+                {
+                    pixel* pix = PX(B[1], org) + y * stride - padX;
+                    uint32_t* sum = Iorg + (y + 1) * stride - padX;
+                    T.integral_inith[Wk[k]](sum, pix, stride);
+                    if (y >= Hn[k] - padY) T.integral_initv[Hk[k]](sum - Hn[k] * stride, stride);
+                }
+                g_me->integral[k] = Iorg + (I[5] - org);             /* the plane at the PU's co-located position (search.cpp:355) */
+            }
+        }
         int cost = g_me->motionEstimate(&rp, mvmin, mvmax, qmvp, nc, mvc, (int)I[12], outmv, 1, false);
         int32_t r[3] = { outmv.x, outmv.y, cost };
         Buf b(12); memcpy(b.data(), r, 12); out.push_back(b); return true;
@@ -511,6 +538,7 @@ int main()
     setupLowPassPrimitives_c(T);
     setupFilterPrimitives_c(T);
     setupIntraPrimitives_c(T);
+    setupSeaIntegralPrimitives_c(T);
     setupAliasPrimitives(T);           /* primitives.cpp:178-284 */
     MotionEstimate::initScales();
     g_me = new MEx();

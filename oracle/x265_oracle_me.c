@@ -4,7 +4,7 @@
  * CPU restatement of the reference's motion-search DRIVER for one PU and one reference:
  *   - BitCost::setQP / CalculateLogs  (encoder/bitcost.cpp:30-105): lambda-scaled MVD cost row
  *   - MotionEstimate::motionEstimate  (encoder/motion.cpp:923-1773): start-point selection,
- *     DIA / HEX / UMH / STAR / FULL integer search, sub-pel refinement per workload[subme], final zero-MV check
+ *     DIA / HEX / UMH / STAR / SEA / FULL integer search, sub-pel refinement per workload[subme], final zero-MV check
  *   - MotionEstimate::subpelCompare   (encoder/motion.cpp:1775-1803, luma part)
  * built on the primitive restatements of x265_oracle.c.  Pinned against the REAL reference driver
  * (oracle/_ref, op "me" / "mvcost_row") by tests/test_me_oracle_vs_ref.py.
@@ -172,11 +172,57 @@ static void star_pattern(const me_t* m, mv_t mvmin, mv_t mvmax, star_t* s, int e
 #define COST_MV(mx_, my_) do { int c_ = sad_at(m, (mx_), (my_)) + mvcost(m, (mx_) * 4, (my_) * 4); \
     if (c_ < bcost) { bcost = c_; bmv.x = (mx_); bmv.y = (my_); } } while (0)
 
+/* encoder/framefilter.cpp:38-139 (integral_init{4,8,12,16,24,32}{h,v}_c) driven the way FrameFilter::processPostRow drives them
+ * (:740-833) over a whole padded picture: plane k holds, at every position whose box lies inside the padded picture, the sum of
+ * the W x H pixels whose top-left corner is that position.  planes[k] and pic point at pixel (0,0); rows -padY .. maxHeight+padY-1. */
+static const int k_seaW[12] = { 32, 32, 32, 24, 16, 16, 16, 12, 8, 8, 4, 4 }, k_seaH[12] = { 32, 24, 8, 32, 16, 12, 4, 16, 32, 8, 16, 4 };
+void xo_sea_integral_planes(const xo_pixel* pic, intptr_t stride, int maxHeight, int padX, int padY, uint32_t* const* planes)
+{
+    for (int k = 0; k < 12; k++)
+    {
+        const int W = k_seaW[k], H = k_seaH[k];
+        uint32_t* I = planes[k];
+        memset(I - padY * stride - padX, 0, stride * sizeof(uint32_t));                              /* :768-769 */
+        for (int y = -padY; y < maxHeight + padY - 1; y++)
+        {
+            const xo_pixel* pix = pic + y * stride - padX;
+            uint32_t* sum = I + (y + 1) * stride - padX;
+            int32_t v = 0;
+            for (int i = 0; i < W; i++) v += pix[i];
+            for (int x = 0; x < stride - W; x++) { sum[x] = v + sum[x - stride]; v += pix[x + W] - pix[x]; }   /* integral_initNh_c */
+            if (y >= H - padY)
+            {
+                uint32_t* s2 = sum - H * stride;
+                for (int x = 0; x < stride; x++) s2[x] = s2[x + H * stride] - s2[x];                /* integral_initNv_c */
+            }
+        }
+    }
+}
+
+static int ads_parts(int w, int h)
+{   /* which ads variant a PU's slot holds (pixel.cpp:1122-1146) */
+    static const int x1[6][2] = { {4,4}, {8,8}, {16,12}, {12,16}, {16,4}, {4,16} };
+    static const int x2[8][2] = { {8,4}, {4,8}, {16,8}, {8,16}, {32,16}, {16,32}, {64,32}, {32,64} };
+    for (int i = 0; i < 6; i++) if (x1[i][0] == w && x1[i][1] == h) return 1;
+    for (int i = 0; i < 8; i++) if (x2[i][0] == w && x2[i][1] == h) return 2;
+    return 4;
+}
+static int is_pu(int w, int h, const int (*set)[2], int n) { for (int i = 0; i < n; i++) if (set[i][0] == w && set[i][1] == h) return 1; return 0; }
+
 int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h,
                        const xo_pixel* fref, intptr_t refStride,
                        const int32_t* bounds /* mvmin.x, mvmin.y, mvmax.x, mvmax.y (full-pel) */,
                        int qmvpx, int qmvpy, int numCand, const int32_t* mvc /* qpel x,y pairs */,
                        int merange, int method, int subme, const uint16_t* costRowCentre, int32_t* outQMv)
+{
+    return xo_motion_estimate_sea(fencPlane, fencStride, w, h, fref, refStride, bounds, qmvpx, qmvpy, numCand, mvc, merange, method, subme, costRowCentre, outQMv, NULL);
+}
+
+/* the same with the 12 SEA integral planes of the reference picture (pointers at the PU's co-located position), needed by XO_ME_SEA */
+int xo_motion_estimate_sea(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h,
+                           const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
+                           int qmvpx, int qmvpy, int numCand, const int32_t* mvc,
+                           int merange, int method, int subme, const uint16_t* costRowCentre, int32_t* outQMv, const uint32_t* const* integral)
 {
     me_t me, *m = &me;
     m->fref = fref; m->stride = refStride; m->w = w; m->h = h; m->cost = costRowCentre;
@@ -440,6 +486,77 @@ int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, in
                 break;
             }
         }
+        break;
+    }
+    case XO_ME_SEA:
+    {   /* motion.cpp:1438-1591: successive elimination -- the ads pre-filter on the integral planes decides which positions of
+           each row get a SAD.  Costs are restated literally, including the doubled-MVP indexing of p_cost_mvx / p_cost_mvy. */
+        if (!integral) return -1;
+        const mv_t omv = bmv;
+        const int minX = omv.x - merange > mvmin.x ? omv.x - merange : mvmin.x, minY = omv.y - merange > mvmin.y ? omv.y - merange : mvmin.y;
+        const int maxX = omv.x + merange < mvmax.x ? omv.x + merange : mvmax.x, maxY = omv.y + merange < mvmax.y ? omv.y + merange : mvmax.y;
+        const uint16_t* p_cost_mvx = m->cost - 2 * qmvpx;       /* m_cost_mvx - qmvp.x, with m_cost_mvx = m_cost - mvp.x (bitcost.h:49-52) */
+        const uint16_t* p_cost_mvy = m->cost - 2 * qmvpy;
+        const int meRangeWidth = (maxX - minX + 3) & ~3;
+        int16_t* scratch = (int16_t*)calloc((size_t)(merange * 2 + 4 > meRangeWidth ? merange * 2 + 4 : meRangeWidth) + 4, sizeof(int16_t));
+        uint16_t* costMvX = (uint16_t*)malloc((size_t)(meRangeWidth + 4) * sizeof(uint16_t));
+        for (int i = 0; i < meRangeWidth; i++) costMvX[i] = m->cost[4 * (minX + i) - qmvpx];     /* m_fpelMvCosts[-qmvp.x & 3] + (-qmvp.x >> 2) + minX (bitcost.cpp:57-80) */
+        int deltaX = w <= 8 ? w : w >> 1, deltaY = h <= 8 ? h : h >> 1;
+        static const int smallRect[5][2] = { {4,4}, {16,12}, {12,16}, {16,4}, {4,16} };
+        static const int vertRect[4][2] = { {32,64}, {16,32}, {8,16}, {4,8} }, horRect[4][2] = { {64,32}, {32,16}, {16,8}, {8,4} };
+        static const int asymV[6][2] = { {12,16}, {4,16}, {24,32}, {8,32}, {48,64}, {16,64} }, asymH[6][2] = { {16,12}, {16,4}, {32,24}, {32,8}, {64,48}, {64,16} };
+        static const int mulStride[13][2] = { {64,64}, {32,32}, {16,16}, {32,64}, {16,32}, {8,16}, {4,8}, {12,16}, {4,16}, {24,32}, {8,32}, {48,64}, {16,64} };
+        const int verticalRect = is_pu(w, h, vertRect, 4), horizontalRect = is_pu(w, h, horRect, 4);
+        int tw, th;                                              /* the sub-block whose DC the pre-filter compares (:1485-1502) */
+        if (verticalRect) { tw = w; th = h >> 1; }
+        else if (horizontalRect) { tw = w >> 1; th = h; }
+        else if (is_pu(w, h, asymV, 6) || is_pu(w, h, asymH, 6)) { if (is_pu(w, h, smallRect, 5)) { tw = w; th = h; } else { tw = w >> 1; th = h >> 1; } }
+        else if (w <= 8) { tw = w; th = h; }
+        else { tw = w >> 1; th = h >> 1; }
+        int encDC[4];
+        {
+            const xo_pixel* f4[4] = { m->fenc, m->fenc + deltaX, m->fenc + deltaY * 64, m->fenc + deltaX + deltaY * 64 };
+            for (int k = 0; k < 4; k++)
+            {
+                int sum = 0;
+                for (int y = 0; y < th; y++) for (int x = 0; x < tw; x++) sum += f4[k][y * 64 + x];
+                encDC[k] = sum;
+            }
+        }
+        int plane;
+        switch (deltaX)
+        {
+        case 32: plane = deltaY % 24 == 0 ? 1 : deltaY == 8 ? 2 : 0; break;
+        case 24: plane = 3; break;
+        case 16: plane = deltaY % 12 == 0 ? 5 : deltaY == 4 ? 6 : 4; break;
+        case 12: plane = 7; break;
+        case 8: plane = deltaY == 32 ? 8 : 9; break;
+        case 4: plane = deltaY == 16 ? 10 : 11; break;
+        default: plane = 11; break;
+        }
+        const uint32_t* sumsBase = integral[plane];
+        if (is_pu(w, h, mulStride, 13)) deltaY *= (int)refStride;
+        if (verticalRect) encDC[1] = encDC[2];
+        if (horizontalRect) deltaY = deltaX;
+        const int parts = ads_parts(w, h);
+        for (int ty = minY; ty <= maxY; ty++)
+        {
+            const int ycost = p_cost_mvy[ty] << 2;
+            if (bcost <= ycost) continue;
+            bcost -= ycost;
+            const int xn = xo_ads(parts, w, encDC, sumsBase + minX + ty * refStride, deltaY, costMvX, scratch, meRangeWidth, bcost);
+            int i;
+            for (i = 0; i < xn - 2; i += 3)
+                for (int k = 0; k < 3; k++)
+                {   /* COST_MV_X3_ABS (:319-332) */
+                    const int mx = minX + scratch[i + k];
+                    const int c = sad_at(m, mx, ty) + p_cost_mvx[mx * 4];
+                    if (c < bcost) { bcost = c; bmv.x = mx; bmv.y = ty; }
+                }
+            bcost += ycost;
+            for (; i < xn; i++) COST_MV(minX + scratch[i], ty);
+        }
+        free(scratch); free(costMvX);
         break;
     }
     case XO_ME_FULL:

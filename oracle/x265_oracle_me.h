@@ -18,6 +18,13 @@ int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, in
                        const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
                        int qmvpx, int qmvpy, int numCand, const int32_t* mvc,
                        int merange, int method, int subme, const uint16_t* costRowCentre, int32_t* outQMv);
+/* SEA (XO_ME_SEA): the 12 integral planes of the reference picture (framefilter.cpp:740-833; order 32x32, 32x24, 32x8, 24x32, 16x16,
+ * 16x12, 16x4, 12x16, 8x32, 8x8, 4x16, 4x4) and the search with them; integral[k] points at the PU's co-located position. */
+void xo_sea_integral_planes(const xo_pixel* pic, intptr_t stride, int maxHeight, int padX, int padY, uint32_t* const* planes);
+int xo_motion_estimate_sea(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h,
+                           const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
+                           int qmvpx, int qmvpy, int numCand, const int32_t* mvc,
+                           int merange, int method, int subme, const uint16_t* costRowCentre, int32_t* outQMv, const uint32_t* const* integral);
 #ifdef __cplusplus
 }
 #endif

@@ -126,10 +126,11 @@ class Ref:
     def mvcost_row(self, qp, half): return np.frombuffer(self.r.call("mvcost_row", [qp, half])[0], np.uint16).copy()
     def lambda_tab(self): return np.frombuffer(self.r.call("lambda_tab")[0], np.float64)[:70].copy()
 
-    def me(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, mvc, merange, method, subme, qp):
+    def me(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, mvc, merange, method, subme, qp, sea=None):
+        """sea = (element index of pixel (0,0) in ref, CTU-aligned picture height, padX, padY): needed by method 4 (SEA)"""
         mvc = [int(v) for v in np.asarray(mvc).reshape(-1)]
         ints = [w, h, cstride, coff, rstride, roff] + [int(b) for b in bounds] + [int(qmvp[0]), int(qmvp[1]), merange, method, subme, qp,
-                                                                                  len(mvc) // 2] + mvc
+                                                                                  len(mvc) // 2] + mvc + ([int(v) for v in sea] if sea else [])
         o = np.frombuffer(self.r.call("me", ints, [cur, ref])[0], np.int32)
         return int(o[0]), int(o[1]), int(o[2])
 

@@ -24,8 +24,14 @@ def test_lambda_and_mvcost_tables(depth):
         ref.close()
 
 
+# SEA on these PU shapes reads fenc rows / columns OUTSIDE the PU for its DC terms (motion.cpp:1467-1468: deltaX = w, deltaY = h for
+# sizes <= 8, then sad_x4 at fenc + deltaX / + deltaY * FENC_STRIDE :1504-1510): the reference's result depends on what earlier PUs
+# left in MotionEstimate::fencPUYuv, i.e. it is not a function of the inputs.  They are excluded from parity (and not offloaded).
+SEA_UNDEFINED = {(8, 4), (4, 8), (8, 32), (32, 8)}
+
+
 @pytest.mark.parametrize("depth", [8, 10])
-@pytest.mark.parametrize("method", [0, 1, 2, 3, 5])      # DIA, HEX, UMH, STAR, FULL
+@pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])      # DIA, HEX, UMH, STAR, SEA, FULL
 def test_motion_estimate_matches_reference(depth, method):
     if not ref_available(depth):
         pytest.skip("no reference binary")
@@ -37,13 +43,19 @@ def test_motion_estimate_matches_reference(depth, method):
             W, H, margin = 256, 192, 96
             cur, rf, stride, (dx, dy) = frame_pair(W, H, depth, seed, margin=margin, max_shift=12 if seed else 30)
             cur, rf = cur.reshape(-1), rf.reshape(-1)
+            integral = None
             for (w, h) in PUS:
+                if method == 4 and (w, h) in SEA_UNDEFINED:
+                    continue
                 reps = 1 if method == 5 else 6 if method == 2 else 3
+                if method == 4 and integral is None:
+                    # SEA: the 12 integral planes of this reference picture (the synthetic planes are H + 2*margin rows, margin on every side)
+                    integral = ora.sea_integral_planes(rf, stride, margin * stride + margin, H, margin, margin)
                 for _ in range(reps):
                     px = int(rng.integers(0, (W - w) // 4 + 1)) * 4
                     py = int(rng.integers(0, (H - h) // 4 + 1)) * 4
                     off = (margin + py) * stride + margin + px
-                    merange = int(rng.choice([8, 16, 57])) if method != 5 else 6
+                    merange = int(rng.choice([8, 16, 57])) if method not in (4, 5) else int(rng.choice([6, 12])) if method == 4 else 6
                     qp = int(rng.choice([22, 28, 37]))
                     subme = int(rng.integers(0, 8))
                     # MVP near the true motion most of the time, sometimes far/zero
@@ -61,9 +73,10 @@ def test_motion_estimate_matches_reference(depth, method):
                               min(mvp_f[0] + merange, W - px - w + lim), min(mvp_f[1] + merange, H - py - h + lim)]
                     nc = int(rng.integers(0, 4))
                     mvc = [int(v) for v in rng.integers(-80, 81, 2 * nc)]
-                    a = ref.me(w, h, cur, stride, off, rf, stride, off, bounds, qmvp, mvc, merange, method, subme, qp)
+                    a = ref.me(w, h, cur, stride, off, rf, stride, off, bounds, qmvp, mvc, merange, method, subme, qp,
+                               sea=(margin * stride + margin, H, margin, margin) if method == 4 else None)
                     row = ora.mvcost_row(qp, 1 << 13)
-                    b = ora.me(w, h, cur, stride, off, rf, stride, off, bounds, qmvp, mvc, merange, method, subme, row)
+                    b = ora.me(w, h, cur, stride, off, rf, stride, off, bounds, qmvp, mvc, merange, method, subme, row, integral=integral)
                     assert a == b, "PU %dx%d method %d subme %d qp %d mvp %s bounds %s: ref %s oracle %s" % (
                         w, h, method, subme, qp, qmvp, bounds, a, b)
                     n += 1
