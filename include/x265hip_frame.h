@@ -67,7 +67,7 @@ int x265hip_me_batch(void* stream, int w, int h,
                      const x265hip_me_result* mvpSource /* may be NULL */,
                      const void* subpelPlanes /* may be NULL: interpolate inside the kernel */, int64_t planeElems);
 /* subpelPlanes, when given, must be the 16-slot buffer x265hip_subpel_planes produced from refPlane (slot 0 == refPlane,
- * same stride / offsets).  method: DIA, HEX, UMH, STAR or FULL (SEA is not offloaded -> X265HIP_EARG). */
+ * same stride / offsets).  method: DIA, HEX, UMH, STAR or FULL (SEA needs integral planes: x265hip_me_batch_sea). */
 
 /* Pre-interpolate a padded reference plane (or a stack of planes: `rows` counts every row of the allocation) into
  * its 15 quarter-pel phase planes: outPlanes + f*planeElems for f = yFrac*4 + xFrac = 1..15 holds, at the same
@@ -108,6 +108,23 @@ int x265hip_tq_batch(void* stream, int log2TrSize,
                      int16_t* coeff /* n x N*N dense */, uint32_t* numSig /* n */,
                      void* reconPlane /* NULL = forward path only */, intptr_t reconStride, uint64_t* sse /* n, with recon */,
                      const x265hip_me_result* mvSource /* may be NULL */);
+
+/* ---- SEA search (motion.cpp:1438-1591) ---------------------------------------------------------------------------------
+ * x265hip_sea_integral_planes builds the 12 integral planes FrameFilter::processPostRow builds per reconstructed picture
+ * (encoder/framefilter.cpp:38-139, 740-833; order 32x32, 32x24, 32x8, 24x32, 16x16, 16x12, 16x4, 12x16, 8x32, 8x8, 4x16, 4x4):
+ * plane k, at every position whose W x H box lies inside the padded picture, holds the sum of the box whose top-left pixel is that
+ * position.  picPadded = FIRST element of the padded picture (row -marginY, column -marginX), rows = all its rows; plane k starts at
+ * planes + k * planeElems with the same layout, so the planes take the tasks' refOff unchanged.  workspace: device scratch of
+ * x265hip_sea_integral_workspace(stride, rows) bytes.
+ * x265hip_me_batch_sea = x265hip_me_batch with method SEA.  The PU shapes 8x4, 4x8, 8x32 and 32x8 are refused (X265HIP_EARG): for them
+ * the reference's result depends on stale contents of MotionEstimate::fencPUYuv (its DC terms read outside the PU, :1467-1468). */
+size_t x265hip_sea_integral_workspace(intptr_t stride, int rows);
+int x265hip_sea_integral_planes(void* stream, const void* picPadded, intptr_t stride, int rows, uint32_t* planes, int64_t planeElems,
+                                void* workspace, size_t workspaceBytes);
+int x265hip_me_batch_sea(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                         const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
+                         int merange, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+                         const void* subpelPlanes, int64_t planeElems, const uint32_t* integralPlanes, int64_t integralPlaneElems);
 
 /* ---- lookahead frame costs on half-resolution pictures ------------------------------------------------
  * The lowres buffer holds F pictures x 4 planes (full-pel, H, V, HV half-pel: what x265hip_frame_init_lowres +

@@ -77,3 +77,56 @@ def test_me_batch_matches_oracle(depth, method, planes):
                 got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
                 assert got == exp, "PU %dx%d task %d method %d subme %d merange %d: hip %s oracle %s (mvp %s)" % (
                     w, h, i, method, subme, merange, got, exp, tk["qmvp"])
+
+
+SEA_UNDEFINED = {(8, 4), (4, 8), (8, 32), (32, 8)}      # the reference's own result is not a function of the inputs (see test_me_oracle_vs_ref.py)
+
+
+@pytest.mark.parametrize("planes", [False, True])
+@pytest.mark.parametrize("depth", [8, 10])
+def test_me_batch_sea_matches_oracle(depth, planes):
+    """SEA: integral planes built on the device (x265hip_sea_integral_planes) + x265hip_me_batch_sea against the oracle"""
+    api, ora = FrameApi(depth), Oracle(depth)
+    rng = np.random.default_rng(401 * depth)
+    W, H, margin = 320, 192, 96
+    half = 1 << 13
+    cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 21, margin=margin, max_shift=12)
+    rows = cur.shape[0]
+    cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
+    d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+    d_int, ie = api.sea_integral_planes(d_ref, stride, rows)
+    integral = ora.sea_integral_planes(ref_f, stride, margin * stride + margin, H, margin, margin)
+    got = d_int.cpu().numpy().view(np.uint32).reshape(12, ie)
+    BW = [32, 32, 32, 24, 16, 16, 16, 12, 8, 8, 4, 4]; BH = [32, 24, 8, 32, 16, 12, 4, 16, 32, 8, 16, 4]
+    for k in range(12):                                   # compare where the reference defines the plane: rows 1 .. rows-BH, columns 0 .. stride-BW-1
+        a = got[k].reshape(rows, stride)[1:rows - BH[k], :stride - BW[k]]
+        b = integral[k].reshape(rows, stride)[1:rows - BH[k], :stride - BW[k]]
+        assert np.array_equal(a, b), "integral plane %d" % k
+    d_pl, pe = None, 0
+    if planes:
+        pe = cur_f.size
+        d_pl = api.torch.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
+        api.subpel_planes(d_ref, stride, rows, d_pl, pe)
+    for (w, h) in PUS:
+        if (w, h) in SEA_UNDEFINED:
+            with pytest.raises(RuntimeError):
+                api.me_batch_sea(w, h, d_cur, stride, d_ref, stride, d_cur, 1, d_cur, half, 8, 2, d_cur, d_int, ie)
+            continue
+        merange = int(rng.choice([6, 12, 20]))
+        qp = int(rng.choice([22, 28, 37])); subme = int(rng.integers(0, 8))
+        n = 12 if w * h <= 1024 else 6
+        tasks = make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange)
+        row = ora.mvcost_row(qp, half)
+        d_tasks, d_row = api.to_device(tasks), api.to_device(row.view(np.int16))
+        d_res = api.torch.zeros(n * ME_RESULT.itemsize, dtype=api.torch.uint8, device="cuda")
+        api.me_batch_sea(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, merange, subme, d_res, d_int, ie, planes=d_pl, plane_elems=pe)
+        api.torch.cuda.synchronize()
+        res = d_res.cpu().numpy().view(ME_RESULT)
+        for i in range(n):
+            tk = tasks[i]
+            bounds = [int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])]
+            mvc = [int(v) for v in tk["mvc"][:2 * int(tk["numCand"])]]
+            exp = ora.me(w, h, cur_f, stride, int(tk["curOff"]), ref_f, stride, int(tk["refOff"]), bounds,
+                         (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc, merange, 4, subme, row, integral=integral)
+            got_i = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
+            assert got_i == exp, "SEA PU %dx%d task %d subme %d merange %d: hip %s oracle %s (mvp %s)" % (w, h, i, subme, merange, got_i, exp, tk["qmvp"])

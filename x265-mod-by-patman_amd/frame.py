@@ -62,6 +62,23 @@ class FrameApi:
                                                _dp(tasks), n, _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source),
                                                _dp(planes), C.c_int64(plane_elems)))
 
+    def sea_integral_planes(self, pic_padded, stride, rows):
+        """12 SEA integral planes (uint32, laid out like the padded picture) of a picture resident in HBM -> int32 tensor [12 * rows * stride]"""
+        t = self.torch
+        elems = stride * rows
+        planes = t.zeros(12 * elems, dtype=t.int32, device="cuda")
+        self.lib.x265hip_sea_integral_workspace.restype = C.c_size_t
+        need = int(self.lib.x265hip_sea_integral_workspace(C.c_ssize_t(stride), rows))
+        ws = t.empty(need, dtype=t.uint8, device="cuda")
+        self.h.check(self.lib.x265hip_sea_integral_planes(self.stream(), _dp(pic_padded), C.c_ssize_t(stride), rows, _dp(planes), C.c_int64(elems), _dp(ws), C.c_size_t(need)))
+        return planes, elems
+
+    def me_batch_sea(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half, merange, subme, results, integral, integral_elems, mvp_source=None,
+                     planes=None, plane_elems=0):
+        self.h.check(self.lib.x265hip_me_batch_sea(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
+                                                   _dp(tasks), n, _dp(cost_row), half, merange, subme, _dp(results), _dp(mvp_source),
+                                                   _dp(planes), C.c_int64(plane_elems), _dp(integral), C.c_int64(integral_elems)))
+
     def subpel_planes(self, ref, stride, rows, out_planes, plane_elems):
         self.h.check(self.lib.x265hip_subpel_planes(self.stream(), _dp(ref), C.c_ssize_t(stride), rows, _dp(out_planes), C.c_int64(plane_elems)))
 
