@@ -159,6 +159,15 @@ int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t plane
                                  const uint16_t* costRow, int costHalfRange, int16_t* mvs, int32_t* mvCosts,
                                  uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
 
+/* cuTree: one propagation step (Lookahead::estimateCUPropagate, slicetype.cpp:3850-3953, with primitives.propagateCost, pixel.cpp:906-931)
+ * on the arrays the calls above left in HBM: intraCost / invQscale of picture b, the lowresCosts and the two MV slots of its estimate,
+ * and the three pictures' propagateCost arrays (uint16, ncu each; prop1 may be NULL for a P picture).  distP0 = b - p0, distP1 = p1 - b;
+ * fpsFactor = CLIP_DURATION(frame duration) / CLIP_DURATION(average duration) (:3863).  Double arithmetic as in the reference; the
+ * saturating adds are order-independent (non-negative addends).  workspace: 16 * ncu bytes of device scratch. */
+int x265hip_cutree_propagate(void* stream, int widthInCU, int heightInCU, int distP0, int distP1, int weightedBiPred, double fpsFactor, int referenced,
+                             const int32_t* intraCost, const uint16_t* lowresCosts, const int32_t* invQscale, const int16_t* mvs0, const int16_t* mvs1,
+                             uint16_t* propB, uint16_t* prop0, uint16_t* prop1, void* workspace, size_t workspaceBytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,10 +13,12 @@
  * It pins oracle/x265_oracle_la.c (and through it the HIP batch of x265hip_lookahead_cost_batch).  No thread pool, no HME,
  * no weighted prediction, no lookahead slices: the serial loops of estimateFrameCost.
  *
- * usage: x265la_<depth> <width> <height> <nframes> <in.raw> <out.bin> <aq 0|1> [p0,b,p1[,keep] ...]
+ * usage: x265la_<depth> <width> <height> <nframes> <in.raw> <out.bin> <aq 0|1> [p0,b,p1[,keep] | prop:p0,b,p1,referenced,seed ...]
  *   in.raw  : nframes luma planes, width x height pixels each (u8 / u16), no padding
  *   triples : indices into the frame list, p0 <= b <= p1; "keep" = 1 leaves the MV caches of frame b as the previous
  *             triples left them (bDoSearch then follows the reference's own rule, slicetype.cpp:4376-4377), 0 resets them
+ *   prop:   : the estimate (caches reset), then Lookahead::estimateCUPropagate(frames, 0.05, p0, p1, b, referenced) (slicetype.cpp:3850-3953)
+ *             on propagateCost arrays of the three pictures pre-filled from `seed`; needs aq = 1 (the AQ factor array must exist)
  *   out.bin : records of [int64 count][count x int32], in the order written below; the last record holds the time spent in
  *             lowresIntraEstimate (all frames) and in singleCost (all estimates), nanoseconds as (lo, hi) int32 pairs
  */
@@ -26,6 +28,7 @@
 #include "lowres.h"
 #include "slicetype.h"
 #include "motion.h"
+#include "ratecontrol.h"
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +44,13 @@ static void rec(const std::vector<int32_t>& v)
     fwrite(&n, 8, 1, g_out);
     if (n) fwrite(v.data(), 4, (size_t)n, g_out);
 }
+
+/* the cuTree propagation step is a protected member */
+struct LA : public Lookahead
+{
+    LA(x265_param* p) : Lookahead(p, NULL) {}
+    using Lookahead::estimateCUPropagate;
+};
 
 /* estimateFrameCost is reached through the public singleCost; the group only needs the frame list */
 struct Group : public CostEstimateGroup
@@ -80,7 +90,7 @@ int main(int argc, char** argv)
     g_out = fopen(argv[5], "wb");
     if (!in || !g_out) { fprintf(stderr, "cannot open files\n"); return 2; }
 
-    Lookahead la(p, NULL);
+    LA la(p);
     if (!la.create()) { fprintf(stderr, "Lookahead::create failed\n"); return 2; }
     LookaheadTLD& tld = la.m_tld[0];
 
@@ -137,8 +147,10 @@ int main(int argc, char** argv)
     }
     for (int a = 7; a < argc; a++)
     {
-        int p0, b, p1, keep = 0;
-        if (sscanf(argv[a], "%d,%d,%d,%d", &p0, &b, &p1, &keep) < 3) { fprintf(stderr, "bad triple %s\n", argv[a]); return 2; }
+        int p0, b, p1, keep = 0, referenced = 0, seed = 0;
+        const bool prop = !strncmp(argv[a], "prop:", 5);
+        if (prop) { if (sscanf(argv[a] + 5, "%d,%d,%d,%d,%d", &p0, &b, &p1, &referenced, &seed) < 5) { fprintf(stderr, "bad prop %s\n", argv[a]); return 2; } }
+        else if (sscanf(argv[a], "%d,%d,%d,%d", &p0, &b, &p1, &keep) < 3) { fprintf(stderr, "bad triple %s\n", argv[a]); return 2; }
         Lowres* fenc = low[b];
         if (!keep) resetCaches(*fenc, p->bframes);
         const int doSearch0 = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF, doSearch1 = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
@@ -160,6 +172,29 @@ int main(int argc, char** argv)
         for (int i = 0; i < ncu; i++) lc[i] = fenc->lowresCosts[b - p0][p1 - b][i];
         for (int i = 0; i < hcu; i++) rs[i] = fenc->rowSatds[b - p0][p1 - b][i];
         rec(lc); rec(rs);
+        if (prop)
+        {
+            uint32_t st = 2463534242u + 7919u * (uint32_t)seed;
+            Lowres* three[3] = { fenc, low[p0], low[p1] };
+            std::vector<int32_t> before[3], after[3];
+            for (int k = 0; k < 3; k++)
+            {
+                if (k == 2 && p1 == b) { before[k] = before[0]; continue; }
+                if (k == 1 && p0 == b) { before[k] = before[0]; continue; }
+                for (int i = 0; i < ncu; i++)
+                {   /* xorshift32; mostly moderate values, some close to saturation */
+                    st ^= st << 13; st ^= st >> 17; st ^= st << 5;
+                    three[k]->propagateCost[i] = (uint16_t)((st & 15) == 0 ? 65000 + (st >> 8) % 536 : (st >> 8) % 6000);
+                }
+                before[k].assign(three[k]->propagateCost, three[k]->propagateCost + ncu);
+            }
+            la.estimateCUPropagate(low.data(), 0.05, p0, p1, b, referenced);
+            for (int k = 0; k < 3; k++) after[k].assign(three[k]->propagateCost, three[k]->propagateCost + ncu);
+            const double fpsFactor = CLIP_DURATION((double)p->fpsDenom / p->fpsNum) / CLIP_DURATION(0.05);
+            int32_t bits[2]; memcpy(bits, &fpsFactor, 8);
+            rec({ referenced, seed, bits[0], bits[1], p->bEnableWeightedBiPred });
+            for (int k = 0; k < 3; k++) { rec(before[k]); rec(after[k]); }
+        }
     }
     rec({ (int32_t)(nsIntra & 0xffffffff), (int32_t)(nsIntra >> 32), (int32_t)(nsCost & 0xffffffff), (int32_t)(nsCost >> 32) });
     fclose(g_out); fclose(in);

@@ -7,6 +7,7 @@
  *   - CostEstimateGroup::estimateCUCost              (encoder/slicetype.cpp:4467-4640)
  *   - MotionEstimate::motionEstimate, ref->isLowres  (encoder/motion.cpp:923-1140 HEX, :1644-1773 with the lowres branch :1667-1699)
  *   - ReferencePlanes::lowresMC / lowresQPelCost     (common/lowres.h:75-124)
+ *   - Lookahead::estimateCUPropagate + propagateCost  (encoder/slicetype.cpp:3850-3953, common/pixel.cpp:906-931)
  * built on the primitive restatements of x265_oracle.c.  Pinned against the REAL reference classes
  * (oracle/_ref/x265la_*, oracle/ref_lookahead.cpp) by tests/test_lookahead_oracle_vs_ref.py.
  */
@@ -327,4 +328,80 @@ void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref
         }
     }
     sums[0] = costEst; sums[1] = costEstAq; sums[2] = intraMbs;
+}
+
+/* ---- cuTree cost propagation of one picture (slicetype.cpp:3850-3953 estimateCUPropagate; pixel.cpp:906-931 propagateCost) ----
+ * fpsFactor = CLIP_DURATION(frame duration) / CLIP_DURATION(average duration) as the caller computes it (:3863); the per-block
+ * arithmetic is the reference's double arithmetic, operation by operation.  prop0 / prop1 / propB are the pictures'
+ * Lowres::propagateCost arrays (uint16, saturating adds). */
+void xo_cu_propagate_cost(int32_t* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,
+                          const int32_t* invQscales, double fpsFactor, int len)
+{
+    const double fps = fpsFactor / 256;
+    for (int i = 0; i < len; i++)
+    {
+        const int intraCost = intraCosts[i];
+        const int inter = interCosts[i] & LOWRES_COST_MASK;
+        const int interCost = intraCost < inter ? intraCost : inter;
+        const double propagateIntra = intraCost * invQscales[i];
+        const double propagateAmount = (double)propagateIn[i] + propagateIntra * fps;
+        const double propagateNum = (double)(intraCost - interCost);
+        const double propagateDenom = (double)intraCost;
+        dst[i] = (int)(propagateAmount * propagateNum / propagateDenom + 0.5);
+    }
+}
+
+void xo_estimate_cu_propagate(int wcu, int hcu, int distP0 /* b - p0 */, int distP1 /* p1 - b */, int weightedBiPred, double fpsFactor, int referenced,
+                              const int32_t* intraCost, const uint16_t* lowresCosts, const int32_t* invQscale,
+                              const int32_t* mvs0, const int32_t* mvs1, uint16_t* propB, uint16_t* prop0, uint16_t* prop1)
+{
+    uint16_t* refCosts[2] = { prop0, prop1 };
+    const int32_t* mvsL[2] = { mvs0, mvs1 };
+    const int span = distP0 + distP1;
+    const int distScaleFactor = ((distP0 << 8) + (span >> 1)) / span;
+    const int bipredWeight = weightedBiPred ? 64 - (distScaleFactor >> 2) : 32;
+    const int bipredWeights[2] = { bipredWeight, 64 - bipredWeight };
+    int32_t* scratch = (int32_t*)calloc((size_t)wcu, sizeof(int32_t));
+    const uint16_t* propagateIn = propB;
+    if (!referenced) memset(propB, 0, wcu * sizeof(uint16_t));
+    for (int blocky = 0; blocky < hcu; blocky++)
+    {
+        int cuIndex = blocky * wcu;
+        xo_cu_propagate_cost(scratch, propagateIn, intraCost + cuIndex, lowresCosts + cuIndex, invQscale + cuIndex, fpsFactor, wcu);
+        if (referenced) propagateIn += wcu;
+        for (int blockx = 0; blockx < wcu; blockx++, cuIndex++)
+        {
+            const int amount = scratch[blockx];
+            if (amount <= 0) continue;                                               /* intra blocks do not propagate */
+            const int listsUsed = lowresCosts[cuIndex] >> LOWRES_COST_SHIFT;
+            for (int list = 0; list < 2; list++)
+            {
+                if (!((listsUsed >> list) & 1)) continue;
+#define CLIP_ADD(s, x) (s) = (uint16_t)((s) + (x) < (1 << 16) - 1 ? (s) + (x) : (1 << 16) - 1)
+                int listamount = amount;
+                if (listsUsed == 3) listamount = (listamount * bipredWeights[list] + 32) >> 6;
+                int x = mvsL[list][2 * cuIndex], y = mvsL[list][2 * cuIndex + 1];
+                uint16_t* rc = refCosts[list];
+                if (!(x | y)) { CLIP_ADD(rc[cuIndex], listamount); continue; }
+                const int cux = (x >> 5) + blockx, cuy = (y >> 5) + blocky;
+                const int idx0 = cux + cuy * wcu, idx1 = idx0 + 1, idx2 = idx0 + wcu, idx3 = idx0 + wcu + 1;
+                x &= 31; y &= 31;
+                const int w0 = (32 - y) * (32 - x), w1 = (32 - y) * x, w2 = y * (32 - x), w3 = y * x;
+                if (cux < wcu - 1 && cuy < hcu - 1 && cux >= 0 && cuy >= 0)
+                {
+                    CLIP_ADD(rc[idx0], (listamount * w0 + 512) >> 10); CLIP_ADD(rc[idx1], (listamount * w1 + 512) >> 10);
+                    CLIP_ADD(rc[idx2], (listamount * w2 + 512) >> 10); CLIP_ADD(rc[idx3], (listamount * w3 + 512) >> 10);
+                }
+                else
+                {   /* offsets checked individually: blocks outside the picture receive nothing */
+                    if (cux < wcu && cuy < hcu && cux >= 0 && cuy >= 0) CLIP_ADD(rc[idx0], (listamount * w0 + 512) >> 10);
+                    if (cux + 1 < wcu && cuy < hcu && cux + 1 >= 0 && cuy >= 0) CLIP_ADD(rc[idx1], (listamount * w1 + 512) >> 10);
+                    if (cux < wcu && cuy + 1 < hcu && cux >= 0 && cuy + 1 >= 0) CLIP_ADD(rc[idx2], (listamount * w2 + 512) >> 10);
+                    if (cux + 1 < wcu && cuy + 1 < hcu && cux + 1 >= 0 && cuy + 1 >= 0) CLIP_ADD(rc[idx3], (listamount * w3 + 512) >> 10);
+                }
+#undef CLIP_ADD
+            }
+        }
+    }
+    free(scratch);
 }

@@ -22,6 +22,12 @@ void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref
                           int widthInCU, int heightInCU, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
                           int doSearch0, int doSearch1, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
                           int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
+/* cuTree (slicetype.cpp:3850-3953): propagate the cost of picture b into its references; see x265_oracle_la.c */
+void xo_cu_propagate_cost(int32_t* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,
+                          const int32_t* invQscales, double fpsFactor, int len);
+void xo_estimate_cu_propagate(int widthInCU, int heightInCU, int distP0, int distP1, int weightedBiPred, double fpsFactor, int referenced,
+                              const int32_t* intraCost, const uint16_t* lowresCosts, const int32_t* invQscale,
+                              const int32_t* mvs0, const int32_t* mvs1, uint16_t* propB, uint16_t* prop0, uint16_t* prop1);
 #ifdef __cplusplus
 }
 #endif

@@ -35,7 +35,8 @@ def synth_clip(W, H, n, depth, seed, shift=(3, 2), noise=2):
         y0, x0 = pad + shift[1] * f, pad + shift[0] * f
         fr = base[y0:y0 + H, x0:x0 + W] * pm + rng.normal(0, noise * (1 << (depth - 8)), (H, W))
         if f == n // 2:                                        # a patch of new content: intra wins there
-            fr[H // 4:H // 4 + 24, W // 3:W // 3 + 40] = rng.integers(0, pm + 1, (24, 40))
+            ph, pw = min(24, H - H // 4), min(40, W - W // 3)
+            fr[H // 4:H // 4 + ph, W // 3:W // 3 + pw] = rng.integers(0, pm + 1, (ph, pw))
         frames.append(np.clip(np.rint(fr), 0, pm).astype(np.uint8 if depth == 8 else np.uint16))
     return frames
 
@@ -116,7 +117,8 @@ def run_reference(depth, frames, triples, aq):
     with tempfile.TemporaryDirectory() as td:
         inp, out = os.path.join(td, "in.raw"), os.path.join(td, "out.bin")
         np.stack(frames).tofile(inp)
-        args = [la_bin(depth), str(W), str(H), str(len(frames)), inp, out, "1" if aq else "0"] + [",".join(str(v) for v in t) for t in triples]
+        args = [la_bin(depth), str(W), str(H), str(len(frames)), inp, out, "1" if aq else "0"] + \
+               [("prop:" + ",".join(str(v) for v in t[1:])) if t[0] == "prop" else ",".join(str(v) for v in t) for t in triples]
         r = subprocess.run(args, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         d = open(out, "rb").read()
@@ -131,9 +133,29 @@ def run_reference(depth, frames, triples, aq):
         per_frame.append(dict(planes=np.stack(recs[i:i + 4]), intraCost=recs[i + 4], intraMode=recs[i + 5], lowresCosts=recs[i + 6], rowSatds=recs[i + 7],
                               invQ=recs[i + 8]))
         i += 9
-    for _ in triples:
+    for tr in triples:
         t = recs[i]
-        per_triple.append(dict(p0=t[0], b=t[1], p1=t[2], keep=t[3], doSearch=(t[4], t[5]), score=t[6], costEstNorm=t[7], costEstAq=t[8], intraMbs=t[9],
-                               mvs0=recs[i + 1], mvc0=recs[i + 2], mvs1=recs[i + 3], mvc1=recs[i + 4], lowresCosts=recs[i + 5], rowSatds=recs[i + 6]))
+        d = dict(p0=t[0], b=t[1], p1=t[2], keep=t[3], doSearch=(t[4], t[5]), score=t[6], costEstNorm=t[7], costEstAq=t[8], intraMbs=t[9],
+                 mvs0=recs[i + 1], mvc0=recs[i + 2], mvs1=recs[i + 3], mvc1=recs[i + 4], lowresCosts=recs[i + 5], rowSatds=recs[i + 6])
         i += 7
+        if tr[0] == "prop":                      # + header (referenced, seed, fpsFactor bits, weightb) and before / after of propB, prop0, prop1
+            ph = recs[i]
+            d["prop"] = dict(referenced=int(ph[0]), seed=int(ph[1]), fpsFactor=float(np.array([ph[2], ph[3]], np.int32).view(np.float64)[0]), weightb=int(ph[4]),
+                             before=[recs[i + 1], recs[i + 3], recs[i + 5]], after=[recs[i + 2], recs[i + 4], recs[i + 6]])
+            i += 7
+        per_triple.append(d)
     return hdr, per_frame, per_triple
+
+
+def oracle_propagate(ora, g, dist_p0, dist_p1, weightb, fps_factor, referenced, intra_cost, lowres_costs, inv_q, mvs0, mvs1, prop_b, prop0, prop1):
+    """xo_estimate_cu_propagate on copies of the three propagateCost arrays (uint16); when p1 == b pass prop1 = prop_b (same array, like
+    the reference's refCosts[1] = frames[p1]->propagateCost).  Returns the arrays after the step."""
+    L = ora.me_lib
+    L.xo_estimate_cu_propagate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int] + [C.c_void_p] * 8
+    pb = prop_b.astype(np.uint16).copy(); p0 = pb if prop0 is prop_b else prop0.astype(np.uint16).copy()
+    p1 = pb if prop1 is prop_b else (p0 if prop1 is prop0 else prop1.astype(np.uint16).copy())
+    lc = lowres_costs.astype(np.uint16)
+    m1 = mvs1 if mvs1 is not None else np.zeros(2 * g.ncu, np.int32)
+    L.xo_estimate_cu_propagate(g.wcu, g.hcu, dist_p0, dist_p1, weightb, fps_factor, referenced, _P(intra_cost), _P(lc), _P(inv_q),
+                               _P(mvs0), _P(m1), _P(pb), _P(p0), _P(p1))
+    return pb, p0, p1

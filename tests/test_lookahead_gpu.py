@@ -32,7 +32,7 @@ def device_lowres(api, ora, frames, g):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
-@pytest.mark.parametrize("size,aq,shift", [((192, 144), 0, (3, 2)), ((208, 120), 1, (-6, 4)), ((64, 48), 1, (1, 0)), ((640, 368), 1, (5, -3))])
+@pytest.mark.parametrize("size,aq,shift", [((192, 144), 0, (3, 2)), ((208, 120), 1, (-6, 4)), ((64, 48), 1, (1, 0)), ((32, 16), 0, (1, 1)), ((16, 48), 1, (0, 1)), ((640, 368), 1, (5, -3))])
 def test_lookahead_batch_matches_oracle(depth, size, aq, shift):
     api, ora = FrameApi(depth), Oracle(depth)
     t = api.torch
@@ -107,3 +107,42 @@ def test_lookahead_batch_matches_oracle(depth, size, aq, shift):
         assert np.array_equal(lc2[out], o["lowresCosts"]), "lowresCosts of " + what
         assert np.array_equal(rs2[out], o["rowSatds"]), "rowSatds of " + what
         assert [int(v) for v in sm2[out]] == [o["costEst"], o["costEstAq"], o["intraMbs"]], "totals of " + what
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_cutree_propagate_matches_oracle(depth):
+    """x265hip_cutree_propagate on the arrays the lookahead batch left in HBM against the oracle's estimateCUPropagate (pinned to the reference)"""
+    from x265hip_pkg.lookahead import LookaheadBatch
+    from lookahead_util import oracle_propagate
+    ora = Oracle(depth)
+    W, H, N = 208, 136, 4
+    frames = synth_clip(W, H, N, depth, seed=77 + depth, shift=(-7, 5))
+    est = [(0, 1, 1), (0, 2, 3), (1, 2, 3), (0, 3, 3), (0, 1, 3)]
+    lb = LookaheadBatch(depth, W, H, N, len(est))
+    t, g = lb.t, lb.g
+    rng = np.random.default_rng(5 + depth)
+    inv_q = rng.integers(160, 360, (N, g.ncu)).astype(np.int32)
+    lb.d_invq = lb.api.to_device(inv_q.reshape(-1))
+    lb.upload(frames); lb.build_lowres(); lb.intra(); lb.set_estimates(est); lb.costs(); t.cuda.synchronize()
+    ic = lb.d_intra_cost.cpu().numpy().reshape(N, g.ncu)
+    lc = lb.d_lc.cpu().numpy().view(np.uint16).reshape(-1, g.ncu)
+    mvs = lb.d_mvs.cpu().numpy().reshape(-1, 2 * g.ncu).astype(np.int32)
+    ws = t.zeros(2 * g.ncu, dtype=t.int64, device="cuda")
+    for i, (p0, b, p1) in enumerate(est):
+        for referenced, fps in ((1, 0.8), (0, 1.0)):
+            prop = np.where(rng.random((N, g.ncu)) < 0.06, rng.integers(65000, 65536, (N, g.ncu)), rng.integers(0, 6000, (N, g.ncu))).astype(np.uint16)
+            d_prop = lb.api.to_device(prop.view(np.int16).reshape(-1)).view(N, g.ncu)
+            lb.api.cutree_propagate(g.wcu, g.hcu, b - p0, p1 - b, 1, fps, referenced, lb.d_intra_cost[b * g.ncu:(b + 1) * g.ncu], lb.d_lc[i * g.ncu:(i + 1) * g.ncu],
+                                    lb.d_invq[b * g.ncu:(b + 1) * g.ncu], lb.d_mvs[2 * i * 2 * g.ncu:(2 * i + 1) * 2 * g.ncu],
+                                    lb.d_mvs[(2 * i + 1) * 2 * g.ncu:(2 * i + 2) * 2 * g.ncu] if p1 > b else None,
+                                    d_prop[b], d_prop[p0], d_prop[p1] if p1 > b else None, ws)
+            t.cuda.synchronize()
+            got = d_prop.cpu().numpy().view(np.uint16)
+            pb = prop[b].copy()
+            exp = oracle_propagate(ora, g, b - p0, p1 - b, 1, fps, referenced, ic[b], lc[i].astype(np.int32), inv_q[b], mvs[2 * i], mvs[2 * i + 1] if p1 > b else None,
+                                   pb, prop[p0].copy(), prop[p1].copy() if p1 > b else pb)
+            assert np.array_equal(got[b], exp[0]) and np.array_equal(got[p0], exp[1]), "cuTree step of %s (referenced %d)" % ((p0, b, p1), referenced)
+            if p1 > b:
+                assert np.array_equal(got[p1], exp[2]), "cuTree step of %s: list-1 reference" % ((p0, b, p1),)
+            untouched = [f for f in range(N) if f not in (p0, b, p1)]
+            assert all(np.array_equal(got[f], prop[f]) for f in untouched)

@@ -4,14 +4,14 @@ import numpy as np
 import pytest
 
 from backends import Oracle
-from lookahead_util import (Geometry, la_available, lowres_planes_oracle, oracle_frame_cost, oracle_intra, run_reference, synth_clip)
+from lookahead_util import (Geometry, la_available, lowres_planes_oracle, oracle_frame_cost, oracle_intra, oracle_propagate, run_reference, synth_clip)
 
 # (p0, b, p1, keep): P estimates, B estimates, and one B estimate that reuses the list-0 search a P estimate cached
 TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3, 0), (0, 2, 3, 1), (0, 3, 3, 0), (0, 1, 3, 0)]
 
 
 @pytest.mark.parametrize("depth", [8, 10])
-@pytest.mark.parametrize("size,aq,shift", [((192, 144), 0, (3, 2)), ((208, 120), 1, (-6, 4)), ((64, 48), 1, (1, 0))])
+@pytest.mark.parametrize("size,aq,shift", [((192, 144), 0, (3, 2)), ((208, 120), 1, (-6, 4)), ((64, 48), 1, (1, 0)), ((32, 16), 0, (1, 1)), ((16, 48), 1, (0, 1))])
 def test_lookahead_cost_matches_reference(depth, size, aq, shift):
     if not la_available(depth):
         pytest.skip("no reference lookahead binary")
@@ -53,3 +53,29 @@ def test_lookahead_cost_matches_reference(depth, size, aq, shift):
         cache[(b, 0, b - p0)] = (o["mvs0"], o["mvc0"])
         if p1 > b:
             cache[(b, 1, p1 - b)] = (o["mvs1"], o["mvc1"])
+
+
+# ("prop", p0, b, p1, referenced, seed): the estimate, then one cuTree propagation step with pre-filled propagateCost arrays
+PROPS = [("prop", 0, 1, 1, 1, 1), ("prop", 0, 2, 3, 1, 2), ("prop", 1, 2, 3, 0, 3), ("prop", 0, 3, 3, 0, 4), ("prop", 0, 1, 3, 1, 5)]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,shift", [((192, 144), (3, 2)), ((208, 120), (-9, 7)), ((64, 48), (1, 0))])
+def test_cutree_propagate_matches_reference(depth, size, shift):
+    if not la_available(depth):
+        pytest.skip("no reference lookahead binary")
+    W, H = size
+    frames = synth_clip(W, H, 4, depth, seed=500 + depth + W, shift=shift)
+    hdr, ref_frames, ref_triples = run_reference(depth, frames, PROPS, 1)
+    ora = Oracle(depth)
+    g = Geometry(W, H)
+    for t, rt in zip(PROPS, ref_triples):
+        _, p0, b, p1, referenced, seed = t
+        pr = rt["prop"]
+        assert pr["referenced"] == referenced
+        before = [a.astype(np.uint16) for a in pr["before"]]
+        pb = before[0]; a0 = pb if p0 == b else before[1]; a1 = pb if p1 == b else before[2]
+        got = oracle_propagate(ora, g, b - p0, p1 - b, pr["weightb"], pr["fpsFactor"], referenced, ref_frames[b]["intraCost"], rt["lowresCosts"],
+                               ref_frames[b]["invQ"], rt["mvs0"], rt["mvs1"] if p1 > b else None, pb, a0, a1)
+        for k, name in enumerate(("b", "p0", "p1")):
+            assert np.array_equal(got[k].astype(np.int32), pr["after"][k]), "propagateCost of %s after %s" % (name, t)

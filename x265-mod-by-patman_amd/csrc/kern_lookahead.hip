@@ -612,6 +612,63 @@ __global__ __launch_bounds__(256) void la_intra_kernel(LaGeom g, const int32_t* 
     }
 }
 
+// ---- cuTree: propagate the cost of picture b into its references (slicetype.cpp:3850-3953; pixel.cpp:906-931) ----
+// The reference walks the blocks in raster order and adds into the references' uint16 arrays with saturation.  All addends are
+// non-negative, so "saturating add after saturating add" equals min(start + sum, 65535): the sums are gathered with 64-bit atomics
+// in any order and folded in afterwards.  The per-block amount is the reference's DOUBLE arithmetic operation by operation (no
+// contraction into fused multiply-adds, IEEE division), so the truncated integer is the same.
+__global__ __launch_bounds__(256) void cutree_scatter_kernel(int W, int H, int bipredWeight0, double fps, int referenced,
+                                                             const int32_t* __restrict__ intraCost, const uint16_t* __restrict__ lowresCosts,
+                                                             const int32_t* __restrict__ invQscale, const uint32_t* __restrict__ mvs0,
+                                                             const uint32_t* __restrict__ mvs1, uint16_t* propB, unsigned long long* acc)
+{
+#pragma clang fp contract(off)
+    const int cuIndex = blockIdx.x * 256 + threadIdx.x, ncu = W * H;
+    if (cuIndex >= ncu) return;
+    const int blockx = cuIndex % W, blocky = cuIndex / W;
+    const int propagateIn = referenced ? (int)propB[cuIndex] : 0;             // unreferenced pictures use (and leave) a zeroed first row (:3866-3867)
+    if (!referenced && blocky == 0) propB[cuIndex] = 0;
+    const int intra = intraCost[cuIndex];
+    const int lc = lowresCosts[cuIndex];
+    const int inter = min(intra, lc & LOWRES_COST_MASK);
+    const double propagateIntra = (double)(intra * invQscale[cuIndex]);
+    const double propagateAmount = (double)propagateIn + propagateIntra * fps;
+    const double propagateNum = (double)(intra - inter);
+    const double propagateDenom = (double)intra;
+    const int amount = (int)(propagateAmount * propagateNum / propagateDenom + 0.5);
+    if (amount <= 0) return;                                                  // intra blocks do not propagate
+    const int listsUsed = lc >> LOWRES_COST_SHIFT;
+    for (int list = 0; list < 2; list++)
+    {
+        if (!((listsUsed >> list) & 1)) continue;
+        int listamount = amount;
+        if (listsUsed == 3) listamount = (listamount * (list ? 64 - bipredWeight0 : bipredWeight0) + 32) >> 6;
+        const uint32_t mv = (list ? mvs1 : mvs0)[cuIndex];
+        unsigned long long* rc = acc + (int64_t)list * ncu;
+        if (!mv) { atomicAdd(rc + cuIndex, (unsigned long long)listamount); continue; }
+        int x = (int16_t)(mv & 0xffff), y = (int16_t)(mv >> 16);
+        const int cux = (x >> 5) + blockx, cuy = (y >> 5) + blocky;
+        const int idx0 = cux + cuy * W;
+        x &= 31; y &= 31;
+        const int wgt[4] = { (32 - y) * (32 - x), (32 - y) * x, y * (32 - x), y * x };
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {   // blocks outside the picture receive nothing (:3930-3947)
+            const int tx = cux + (k & 1), ty = cuy + (k >> 1);
+            if (tx >= 0 && tx < W && ty >= 0 && ty < H)
+                atomicAdd(rc + idx0 + (k & 1) + (k >> 1) * W, (unsigned long long)((listamount * wgt[k] + 512) >> 10));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void cutree_fold_kernel(int ncu, const unsigned long long* __restrict__ acc, uint16_t* prop0, uint16_t* prop1)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ncu) return;
+    const unsigned long long a0 = acc[i], a1 = acc[ncu + i];
+    if (a0) prop0[i] = (uint16_t)min((unsigned long long)prop0[i] + a0, 65535ull);
+    if (a1) prop1[i] = (uint16_t)min((unsigned long long)prop1[i] + a1, 65535ull);
+}
+
 bool bad_geom(const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int wcu, int hcu)
 {
     return !lowres || ((uintptr_t)lowres & 3) || planeElems <= 0 || planeElems >= (1 << 24) || stride < wcu * CU || stride >= (1 << 23) || origin < 0 || wcu < 1 || hcu < 1 || origin >= planeElems;
@@ -676,6 +733,27 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     XH_LAUNCH_CHECK();
     hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_cutree_propagate(void* stream, int widthInCU, int heightInCU, int distP0, int distP1, int weightedBiPred, double fpsFactor, int referenced,
+                                        const int32_t* intraCost, const uint16_t* lowresCosts, const int32_t* invQscale, const int16_t* mvs0, const int16_t* mvs1,
+                                        uint16_t* propB, uint16_t* prop0, uint16_t* prop1, void* workspace, size_t workspaceBytes)
+{
+    const int ncu = widthInCU * heightInCU;
+    if (widthInCU < 1 || heightInCU < 1 || distP0 < 1 || distP1 < 0 || !intraCost || !lowresCosts || !invQscale || !mvs0 || (distP1 > 0 && !mvs1) || !propB || !prop0 ||
+        (distP1 > 0 && !prop1) || !workspace || workspaceBytes < sizeof(uint64_t) * 2 * (size_t)ncu || ((uintptr_t)mvs0 & 3) || ((uintptr_t)mvs1 & 3))
+    { set_error("cutree_propagate: bad arguments"); return X265HIP_EARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int span = distP0 + distP1;
+    const int distScaleFactor = ((distP0 << 8) + (span >> 1)) / span;                    // slicetype.cpp:3853-3855
+    const int bipredWeight = weightedBiPred ? 64 - (distScaleFactor >> 2) : 32;
+    XH_HIP(hipMemsetAsync(workspace, 0, sizeof(uint64_t) * 2 * (size_t)ncu, st));
+    hipLaunchKernelGGL(cutree_scatter_kernel, dim3((ncu + 255) / 256), dim3(256), 0, st, widthInCU, heightInCU, bipredWeight, fpsFactor / 256, referenced,
+                       intraCost, lowresCosts, invQscale, (const uint32_t*)mvs0, (const uint32_t*)(mvs1 ? mvs1 : mvs0), propB, (unsigned long long*)workspace);
+    XH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cutree_fold_kernel, dim3((ncu + 255) / 256), dim3(256), 0, st, ncu, (const unsigned long long*)workspace, prop0, prop1 ? prop1 : prop0);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

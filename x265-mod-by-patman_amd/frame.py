@@ -113,6 +113,12 @@ class FrameApi:
                                                            _dp(tasks), n_tasks, _dp(intra_cost), _dp(inv_qscale), _dp(cost_row), half,
                                                            _dp(mvs), _dp(mv_costs), _dp(lowres_costs), _dp(row_satds), _dp(sums)))
 
+    def cutree_propagate(self, wcu, hcu, dist_p0, dist_p1, weightb, fps_factor, referenced, intra_cost, lowres_costs, inv_q, mvs0, mvs1, prop_b, prop0, prop1, workspace):
+        """one cuTree propagation step (Lookahead::estimateCUPropagate); tensors may be views into the lookahead batch's arrays"""
+        self.h.check(self.lib.x265hip_cutree_propagate(self.stream(), wcu, hcu, dist_p0, dist_p1, weightb, C.c_double(fps_factor), referenced,
+                                                       _dp(intra_cost), _dp(lowres_costs), _dp(inv_q), _dp(mvs0), _dp(mvs1), _dp(prop_b), _dp(prop0), _dp(prop1),
+                                                       _dp(workspace), C.c_size_t(workspace.numel() * workspace.element_size())))
+
     def frame_init_lowres(self, src, src_stride, d0, dh, dv, dc, dst_stride, width, height):
         self.h.check(self.lib.x265hip_frame_init_lowres(self.stream(), _dp(src), C.c_ssize_t(src_stride), _dp(d0), _dp(dh), _dp(dv), _dp(dc),
                                                         C.c_ssize_t(dst_stride), width, height))
