@@ -115,6 +115,51 @@ __device__ __forceinline__ int satd_rows(const int (&d)[8], int lane)
     return half + xor4(half);
 }
 
+// The same SATD on PACKED 16-bit lanes (|coefficient| <= 16 * 1023 fits int16): the left and the right 4x4 block of the row travel in
+// the low and the high half of one register -- the pairing of the reference's SWAR satd_8x4 (pixel.cpp:237-265) -- so the horizontal
+// butterflies are four v_pk_add/sub pairs between registers and the two vertical (cross-lane) stages one DPP move + one packed
+// multiply-add per register instead of two scalar pairs.  About half the vector instructions of satd_rows.
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ int satd_rows_pk(const Row& a, const Row& b, int lane)
+{
+    s2 r[4];                                          // r[k] = (d[k], d[k + 4]): column k of the left block, column k of the right block
+#if X265_DEPTH == 8
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {   // v_perm_b32: bytes (w0.b[k], 0, w1.b[k], 0); selector 0-3 = second operand, 4-7 = first, 0x0C = zero
+        const uint32_t sel = 0x0C040C00u + 0x00010001u * (uint32_t)k;
+        r[k] = as_s2(__builtin_amdgcn_perm(a.w[1], a.w[0], sel)) - as_s2(__builtin_amdgcn_perm(b.w[1], b.w[0], sel));
+    }
+#else
+    {
+        const s2 d01 = as_s2(a.w[0]) - as_s2(b.w[0]), d23 = as_s2(a.w[1]) - as_s2(b.w[1]), d45 = as_s2(a.w[2]) - as_s2(b.w[2]), d67 = as_s2(a.w[3]) - as_s2(b.w[3]);
+        r[0] = as_s2(__builtin_amdgcn_perm(as_u32(d45), as_u32(d01), 0x05040100u)); r[1] = as_s2(__builtin_amdgcn_perm(as_u32(d45), as_u32(d01), 0x07060302u));
+        r[2] = as_s2(__builtin_amdgcn_perm(as_u32(d67), as_u32(d23), 0x05040100u)); r[3] = as_s2(__builtin_amdgcn_perm(as_u32(d67), as_u32(d23), 0x07060302u));
+    }
+#endif
+    const s2 a0 = r[0] + r[1], a1 = r[0] - r[1], a2 = r[2] + r[3], a3 = r[2] - r[3];
+    s2 h[4] = { a0 + a2, a1 + a3, a0 - a2, a1 - a3 };
+    const short m1 = (lane & 1) ? -1 : 1, m2 = (lane & 2) ? -1 : 1;
+    const s2 s1 = { m1, m1 }, sg2 = { m2, m2 };
+    u2 acc = { 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        s2 v = h[k];
+        v = as_s2((uint32_t)LA_DPP((int)as_u32(v), 0xB1)) + v * s1;
+        v = as_s2((uint32_t)LA_DPP((int)as_u32(v), 0x4E)) + v * sg2;
+        const s2 n = -v;
+        acc += __builtin_bit_cast(u2, __builtin_elementwise_max(v, n));      // |v|; four of them stay below 2^16 as UNSIGNED 16-bit
+    }
+    const uint32_t u = __builtin_bit_cast(uint32_t, acc);
+    const int s = (int)(u & 0xffffu) + (int)(u >> 16);
+    const int half = quad_sum(s) >> 1;                // one 8x4
+    return half + xor4(half);
+}
+
 // ---- per-block context of the search / finish kernels ----
 struct Blk
 {
@@ -146,7 +191,7 @@ __device__ __forceinline__ void eval(const Blk& c, const int (&qx)[K], const int
 #pragma unroll
     for (int k = 0; k < K; k++)
     {
-        if (SATD) { int d[8]; diff_row(c.fenc, r[k], d); out[k] = satd_rows(d, c.lane); }
+        if (SATD) out[k] = satd_rows_pk(c.fenc, r[k], c.lane);
         else out[k] = group8_sum(sad_row(c.fenc, r[k]));
     }
 }
@@ -362,7 +407,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                 {
-                    if (need[k]) { int d[8]; diff_row(c.fenc, r[k], d); C[k] = satd_rows(d, lane); }
+                    if (need[k]) C[k] = satd_rows_pk(c.fenc, r[k], lane);
 #pragma unroll
                     for (int j = k - 1; j >= 0; j--) if (valid[j] && X[j] == X[k] && Y[j] == Y[k]) C[k] = C[j];
                 }
@@ -442,12 +487,9 @@ __global__ __launch_bounds__(256) void la_finish_kernel(LaGeom g, const x265hip_
             const uint32_t m0 = mvs[(int64_t)slot0 * ncu + cuXY], m1 = mvs[(int64_t)slot1 * ncu + cuXY];
             const Row a = avg_rows(mc_row(c0, (int16_t)(m0 & 0xffff), (int16_t)(m0 >> 16)), mc_row(c1, (int16_t)(m1 & 0xffff), (int16_t)(m1 >> 16)));   // avg(l0-mv, l1-mv)
             const Row z = avg_rows(ld_row(c0.base, c0.ref0), ld_row(c1.base, c1.ref0));                                                                              // co-located
-            int d[8];
-            diff_row(c0.fenc, a, d);
-            int bicost = satd_rows(d, lane);
+            int bicost = satd_rows_pk(c0.fenc, a, lane);
             if (bicost < bcost) { bcost = bicost; listused = 3; }
-            diff_row(c0.fenc, z, d);
-            bicost = satd_rows(d, lane);
+            bicost = satd_rows_pk(c0.fenc, z, lane);
             if (bicost < bcost) { bcost = bicost; listused = 3; }
             bcost += 4;                                        // lowresPenalty
         }
@@ -729,7 +771,12 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     const int widest = min(heightInCU, (widthInCU + 1) / 2);
     const int threads = min(1024, max(64, (widest * 8 + 63) / 64 * 64));
     const int costR = 4 * (max(widthInCU, heightInCU) * CU + 32);               // the bound checked above; 2 bytes per entry of LDS
-    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks), dim3(threads), sizeof(uint16_t) * (2 * costR + 2), st, g, tasks, costRow + costHalfRange, costR, (uint32_t*)mvs, mvCosts);
+    // Workgroup placement: a CU accepts four of these 8-wavefront workgroups, and the dispatcher fills CUs one after the other, so a
+    // batch of ~2 workgroups per CU ends up four deep on some CUs and absent on others -- and four interleaved wavefront sweeps take
+    // four times as long as one.  Asking for 56 KB of LDS (of 160 KB per CU) caps the depth at two.
+    static const size_t ldsPad = getenv("X265HIP_LA_LDS") ? (size_t)atoi(getenv("X265HIP_LA_LDS")) : 56 * 1024;
+    const size_t lds = std::max(sizeof(uint16_t) * (size_t)(2 * costR + 2), ldsPad);
+    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks), dim3(threads), lds, st, g, tasks, costRow + costHalfRange, costR, (uint32_t*)mvs, mvCosts);
     XH_LAUNCH_CHECK();
     hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
