@@ -83,7 +83,12 @@ enum x265hip_cu_slot {
 #define X265HIP_OFF_SCALE2D_64TO32 6792
 #define X265HIP_OFF_FRAMEINITLOWRES 6928
 #define X265HIP_OFF_FRAMEINITLOWERRES 6936
+#define X265HIP_OFF_PROPAGATECOST 6944
+#define X265HIP_OFF_FIX8UNPACK 6952
+#define X265HIP_OFF_FIX8PACK 6960
 #define X265HIP_OFF_EXTENDROWBORDER 6968
+#define X265HIP_OFF_INTEGRAL_INITV 7104     /* [6]: 4, 8, 12, 16, 24, 32 rows (primitives.h:122-131) */
+#define X265HIP_OFF_INTEGRAL_INITH 7152     /* [6]: 4, 8, 12, 16, 24, 32 columns */
 #define X265HIP_OFF_WEIGHT_SP 7016
 #define X265HIP_OFF_WEIGHT_PP 7024
 /* pointer index inside Chroma::PUChroma / CUChroma (primitives.h:399-428) */
@@ -162,6 +167,17 @@ int x265hip_frame_init_lowres(void* stream, const void* src, intptr_t srcStride,
  * so a reconstructed frame becomes a searchable reference without leaving HBM. */
 int x265hip_extend_pic_border(void* stream, void* picOrg, intptr_t stride, int width, int height, int marginX, int marginY,
                               int nPictures, int64_t pictureElems);
+
+/* Row-granular helpers behind the slots propagateCost, fix8Pack / fix8Unpack (cuTree; pixel.cpp:906-948) and integral_init{4..32}{h,v}
+ * (SEA; encoder/framefilter.cpp:38-139).  Device pointers.  The frame-level forms are x265hip_cutree_propagate and
+ * x265hip_sea_integral_planes (x265hip_frame.h).
+ *   integral_init_h: sum[x] = (pix[x] + ... + pix[x + boxWidth - 1]) + above[x] for x in [0, positions); above = the row before sum
+ *   integral_init_v: top[x] = below[x] - top[x]                                  for x in [0, positions); below = top + N rows */
+int x265hip_propagate_cost_row(void* stream, int32_t* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,
+                               const int32_t* invQscales, double fpsFactor, int len);
+int x265hip_fix8_convert(void* stream, int pack, void* dst, const void* src, int count);     /* pack: double -> Q8.8 uint16; else the reverse */
+int x265hip_integral_init_h(void* stream, uint32_t* sum, const uint32_t* above, const void* pix, int boxWidth, int positions);
+int x265hip_integral_init_v(void* stream, uint32_t* top, const uint32_t* below, int positions);
 
 /* SEA pre-filter pu[].ads (pixel.cpp:121-165; which PU uses x1 / x2 / x4: pixel.cpp:1122-1146): for i in [0, width)
  * ads = sum |encDC[k] - sums[i + off_k]| + costMvX[i]; positions with ads < thresh are appended, in order, to mvs.

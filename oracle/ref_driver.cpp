@@ -127,6 +127,7 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         OFF(chroma[0].cu); OFF(chroma[0].cu[1]); OFF(chroma[0].cu[0].sa8d); OFF(chroma[0].cu[0].sse_pp); OFF(chroma[0].cu[0].sub_ps);
         OFF(chroma[0].cu[0].add_ps); OFF(chroma[0].cu[0].copy_ps); OFF(chroma[0].cu[0].copy_sp); OFF(chroma[0].cu[0].copy_ss); OFF(chroma[0].cu[0].copy_pp);
         OFF(extendRowBorder); OFF(frameInitLowres); OFF(frameInitLowerRes);
+        OFF(propagateCost); OFF(fix8Unpack); OFF(fix8Pack); OFF(integral_initv); OFF(integral_inith);
 #undef OFF
         v.push_back((int32_t)sizeof(EncoderPrimitives));
         Buf b(v.size() * 4); memcpy(b.data(), v.data(), b.size()); out.push_back(b);

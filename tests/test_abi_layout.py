@@ -37,7 +37,8 @@ def expected_layout():
                            "addAvg", "copy_pp", "p2s")]
     v += [ccu0, ccu0 + B.CHROMA_CU_PTRS * 8]
     v += [ccu(s) for s in ("sa8d", "sse_pp", "sub_ps", "add_ps", "copy_ps", "copy_sp", "copy_ss", "copy_pp")]
-    v += [B.SCALAR_OFF["extendRowBorder"], B.SCALAR_OFF["frameInitLowres"], B.SCALAR_OFF["frameInitLowerRes"], B.SIZEOF_TABLE]
+    v += [B.SCALAR_OFF["extendRowBorder"], B.SCALAR_OFF["frameInitLowres"], B.SCALAR_OFF["frameInitLowerRes"]]
+    v += [B.SCALAR_OFF[s] for s in ("propagateCost", "fix8Unpack", "fix8Pack", "integral_initv", "integral_inith")] + [B.SIZEOF_TABLE]
     return v
 
 
@@ -65,7 +66,8 @@ def test_header_constants_agree_with_binding():
     for name, key in (("dst4x4", "DST4X4"), ("quant", "QUANT"), ("nquant", "NQUANT"), ("dequant_normal", "DEQUANT_NORMAL"),
                       ("dequant_scaling", "DEQUANT_SCALING"), ("weight_sp", "WEIGHT_SP"), ("weight_pp", "WEIGHT_PP"),
                       ("scale2D_64to32", "SCALE2D_64TO32"), ("denoiseDct", "DENOISEDCT"), ("extendRowBorder", "EXTENDROWBORDER"), ("frameInitLowres", "FRAMEINITLOWRES"),
-                      ("frameInitLowerRes", "FRAMEINITLOWERRES")):
+                      ("frameInitLowerRes", "FRAMEINITLOWERRES"), ("propagateCost", "PROPAGATECOST"), ("fix8Unpack", "FIX8UNPACK"), ("fix8Pack", "FIX8PACK"),
+                      ("integral_initv", "INTEGRAL_INITV"), ("integral_inith", "INTEGRAL_INITH")):
         assert int(d["X265HIP_OFF_" + key]) == B.SCALAR_OFF[name]
 
 

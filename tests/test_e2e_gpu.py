@@ -26,6 +26,8 @@ def _env():
     (10, 64, 64, 2, "slow", []),
     (8, 136, 72, 2, "medium", ["lowpass-dct=1", "weightb=1", "bframes=2"]),       # non-CTU-multiple picture, cu[].lowpass_dct, weight_pp on planes
     (8, 64, 64, 2, "medium", ["tskip=1", "nr-inter=100", "me=full", "merange=6"]),   # transform skip, denoiseDct, exhaustive search
+    (8, 64, 64, 3, "medium", ["me=sea", "merange=8", "bframes=1"]),                  # SEA: the ads slot + the 12 integral_init slots; cuTree: propagateCost, fix8
+    (10, 64, 64, 2, "medium", ["me=umh", "merange=12"]),
 ])
 def test_reference_encoder_emits_identical_bitstream_with_the_hip_table(tmp_path, depth, w, h, frames, preset, extra):
     enc = os.path.join(ROOT, "oracle", "_ref", "x265enc_%d" % depth)

@@ -711,6 +711,32 @@ __global__ __launch_bounds__(256) void cutree_fold_kernel(int ncu, const unsigne
     if (a1) prop1[i] = (uint16_t)min((unsigned long long)prop1[i] + a1, 65535ull);
 }
 
+// primitives.propagateCost on one row of blocks (pixel.cpp:906-931) and the Q8.8 converters cuTree stores its offsets with (:935-948)
+__global__ __launch_bounds__(256) void propagate_row_kernel(int32_t* __restrict__ dst, const uint16_t* __restrict__ propagateIn, const int32_t* __restrict__ intraCosts,
+                                                            const uint16_t* __restrict__ interCosts, const int32_t* __restrict__ invQscales, double fps, int len)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    const int intra = intraCosts[i];
+    const int inter = min(intra, (int)interCosts[i] & LOWRES_COST_MASK);
+    const double propagateIntra = (double)(intra * invQscales[i]);
+    const double propagateAmount = (double)propagateIn[i] + propagateIntra * fps;
+    const double propagateNum = (double)(intra - inter);
+    const double propagateDenom = (double)intra;
+    dst[i] = (int)(propagateAmount * propagateNum / propagateDenom + 0.5);
+}
+__global__ __launch_bounds__(256) void fix8_pack_kernel(uint16_t* __restrict__ dst, const double* __restrict__ src, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (uint16_t)(int16_t)(src[i] * 256.0);
+}
+__global__ __launch_bounds__(256) void fix8_unpack_kernel(double* __restrict__ dst, const uint16_t* __restrict__ src, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (double)(int16_t)src[i] / 256.0;
+}
+
 bool bad_geom(const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int wcu, int hcu)
 {
     return !lowres || ((uintptr_t)lowres & 3) || planeElems <= 0 || planeElems >= (1 << 24) || stride < wcu * CU || stride >= (1 << 23) || origin < 0 || wcu < 1 || hcu < 1 || origin >= planeElems;
@@ -801,6 +827,25 @@ extern "C" int x265hip_cutree_propagate(void* stream, int widthInCU, int heightI
                        intraCost, lowresCosts, invQscale, (const uint32_t*)mvs0, (const uint32_t*)(mvs1 ? mvs1 : mvs0), propB, (unsigned long long*)workspace);
     XH_LAUNCH_CHECK();
     hipLaunchKernelGGL(cutree_fold_kernel, dim3((ncu + 255) / 256), dim3(256), 0, st, ncu, (const unsigned long long*)workspace, prop0, prop1 ? prop1 : prop0);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_propagate_cost_row(void* stream, int32_t* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,
+                                          const int32_t* invQscales, double fpsFactor, int len)
+{
+    if (len <= 0) return X265HIP_OK;
+    if (!dst || !propagateIn || !intraCosts || !interCosts || !invQscales) { set_error("propagate_cost_row: bad arguments"); return X265HIP_EARG; }
+    hipLaunchKernelGGL(propagate_row_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream, dst, propagateIn, intraCosts, interCosts, invQscales, fpsFactor / 256, len);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+extern "C" int x265hip_fix8_convert(void* stream, int pack, void* dst, const void* src, int count)
+{
+    if (count <= 0) return X265HIP_OK;
+    if (!dst || !src) { set_error("fix8_convert: bad arguments"); return X265HIP_EARG; }
+    if (pack) hipLaunchKernelGGL(fix8_pack_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dst, (const double*)src, count);
+    else hipLaunchKernelGGL(fix8_unpack_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double*)dst, (const uint16_t*)src, count);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

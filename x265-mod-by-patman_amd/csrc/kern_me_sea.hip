@@ -38,7 +38,37 @@ __global__ __launch_bounds__(256) void sea_box_kernel(const uint16_t* __restrict
     out[k * outElems + (int64_t)y * stride + x] = s;
 }
 
+// the row-granular primitives integral_initNh / integral_initNv themselves (framefilter.cpp:38-139), for the table slots
+__global__ __launch_bounds__(256) void integral_h_kernel(uint32_t* __restrict__ sum, const uint32_t* __restrict__ above, const pixel* __restrict__ pix, int W, int n)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= n) return;                               // n = stride - W positions
+    uint32_t v = 0;
+    for (int i = 0; i < W; i++) v += pix[x + i];
+    sum[x] = v + above[x];
+}
+__global__ __launch_bounds__(256) void integral_v_kernel(uint32_t* __restrict__ top, const uint32_t* __restrict__ below, int n)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x < n) top[x] = below[x] - top[x];
+}
+
 } // namespace
+
+extern "C" int x265hip_integral_init_h(void* stream, uint32_t* sum, const uint32_t* above, const void* pix, int boxWidth, int positions)
+{
+    if (positions <= 0) return X265HIP_OK;
+    hipLaunchKernelGGL(integral_h_kernel, dim3((positions + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, above, (const pixel*)pix, boxWidth, positions);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+extern "C" int x265hip_integral_init_v(void* stream, uint32_t* top, const uint32_t* below, int positions)
+{
+    if (positions <= 0) return X265HIP_OK;
+    hipLaunchKernelGGL(integral_v_kernel, dim3((positions + 255) / 256), dim3(256), 0, (hipStream_t)stream, top, below, positions);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
 
 extern "C" size_t x265hip_sea_integral_workspace(intptr_t stride, int rows) { return sizeof(uint16_t) * (size_t)SEA_NW * (size_t)stride * (size_t)rows; }
 
