@@ -26,16 +26,24 @@ __global__ __launch_bounds__(256) void sea_rowsum_kernel(const pixel* __restrict
 }
 __device__ const int8_t k_seaW[12] = { 5, 5, 5, 4, 3, 3, 3, 2, 1, 1, 0, 0 };      // index into k_seaWidths: 32 32 32 24 16 16 16 12 8 8 4 4
 __device__ const int8_t k_seaH[12] = { 32, 24, 8, 32, 16, 12, 4, 16, 32, 8, 16, 4 };
+constexpr int SEA_STRIP = 32;          // rows per thread: a vertical sliding window costs (H + 2 * 31) reads per 32 outputs instead of 32 * H
 __global__ __launch_bounds__(256) void sea_box_kernel(const uint16_t* __restrict__ rs, int64_t rsElems, intptr_t stride, int rows, int cols,
                                                       uint32_t* __restrict__ out, int64_t outElems)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * SEA_STRIP, k = blockIdx.z;
     const int H = k_seaH[k];
-    if (x >= cols || y + H > rows) return;                                         // boxes that leave the padded picture stay undefined
-    const uint16_t* r = rs + k_seaW[k] * rsElems + (int64_t)y * stride + x;
+    if (x >= cols || y0 + H > rows) return;                                        // boxes that leave the padded picture stay undefined
+    const uint16_t* r = rs + k_seaW[k] * rsElems + (int64_t)y0 * stride + x;
+    uint32_t* o = out + k * outElems + (int64_t)y0 * stride + x;
     uint32_t s = 0;
     for (int j = 0; j < H; j++) s += r[(intptr_t)j * stride];
-    out[k * outElems + (int64_t)y * stride + x] = s;
+    o[0] = s;
+    const int n = min(SEA_STRIP, rows - H + 1 - y0);                               // outputs of this strip
+    for (int t = 1; t < n; t++)
+    {
+        s += (uint32_t)r[(intptr_t)(H - 1 + t) * stride] - (uint32_t)r[(intptr_t)(t - 1) * stride];
+        o[(intptr_t)t * stride] = s;
+    }
 }
 
 // the row-granular primitives integral_initNh / integral_initNv themselves (framefilter.cpp:38-139), for the table slots
@@ -83,7 +91,7 @@ extern "C" int x265hip_sea_integral_planes(void* stream, const void* picPadded, 
     hipLaunchKernelGGL(sea_rowsum_kernel, dim3((unsigned)((stride + 255) / 256), rows), dim3(256), 0, st, (const pixel*)picPadded, stride, rows, (int)stride,
                        (uint16_t*)workspace, rsElems);
     XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sea_box_kernel, dim3((unsigned)((stride + 255) / 256), rows, 12), dim3(256), 0, st, (const uint16_t*)workspace, rsElems, stride, rows, (int)stride,
+    hipLaunchKernelGGL(sea_box_kernel, dim3((unsigned)((stride + 255) / 256), (rows + SEA_STRIP - 1) / SEA_STRIP, 12), dim3(256), 0, st, (const uint16_t*)workspace, rsElems, stride, rows, (int)stride,
                        planes, planeElems);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
