@@ -795,7 +795,8 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     XH_LAUNCH_CHECK();
     // one 8-lane group per block of the widest wavefront step, in whole wavefronts, at most 1024 threads
     const int widest = min(heightInCU, (widthInCU + 1) / 2);
-    const int threads = min(1024, max(64, (widest * 8 + 63) / 64 * 64));
+    static const int threadCap = getenv("X265HIP_LA_THREADS") ? atoi(getenv("X265HIP_LA_THREADS")) : 1024;   // A/B switch: lane groups per workgroup
+    const int threads = min(min(1024, threadCap), max(64, (widest * 8 + 63) / 64 * 64));
     const int costR = 4 * (max(widthInCU, heightInCU) * CU + 32);               // the bound checked above; 2 bytes per entry of LDS
     // Workgroup placement: a CU accepts four of these 8-wavefront workgroups, and the dispatcher fills CUs one after the other, so a
     // batch of ~2 workgroups per CU ends up four deep on some CUs and absent on others -- and four interleaved wavefront sweeps take
