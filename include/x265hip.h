@@ -81,6 +81,7 @@ enum x265hip_cu_slot {
 #define X265HIP_OFF_DENOISEDCT 6768
 #define X265HIP_OFF_SCALE1D_128TO64 6776   /* [2] */
 #define X265HIP_OFF_SCALE2D_64TO32 6792
+#define X265HIP_OFF_SAOCUSTATSBO 6888          /* then saoCuStatsE0..E3 at +8, +16, +24, +32 */
 #define X265HIP_OFF_FRAMEINITLOWRES 6928
 #define X265HIP_OFF_FRAMEINITLOWERRES 6936
 #define X265HIP_OFF_PROPAGATECOST 6944
@@ -178,6 +179,14 @@ int x265hip_propagate_cost_row(void* stream, int32_t* dst, const uint16_t* propa
 int x265hip_fix8_convert(void* stream, int pack, void* dst, const void* src, int count);     /* pack: double -> Q8.8 uint16; else the reverse */
 int x265hip_integral_init_h(void* stream, uint32_t* sum, const uint32_t* above, const void* pix, int boxWidth, int positions);
 int x265hip_integral_init_v(void* stream, uint32_t* top, const uint32_t* below, int positions);
+
+/* SAO statistics of one block (encoder/sao.cpp:1774-1937): type 0..3 = saoCuStatsE0..E3, 4 = saoCuStatsBO.  diff has stride 64;
+ * rec points at the block's first pixel (the edge classes read one pixel / row around it).  out[0..31] = per-class sums of diff, out[32..63] =
+ * counts (edge classes in SAO::s_eoTable order) -- deltas, the caller adds them.  upIn = the reference's upBuff1 on entry (types 1-3); upOutA /
+ * upOutB receive what the reference leaves in upBuff1 / upBufft (type 1: [0, endX); type 2: A = [0, endX] of the last odd row, B = of the last even
+ * row; type 3: upOutA[0] stands for upBuff1[-1], [1 .. endX] for [0 .. endX - 1]).  Device pointers. */
+int x265hip_sao_stats(void* stream, int type, const int16_t* diff, const void* rec, intptr_t stride, const int8_t* upIn, int endX, int endY,
+                      int32_t* out, int8_t* upOutA, int8_t* upOutB);
 
 /* SEA pre-filter pu[].ads (pixel.cpp:121-165; which PU uses x1 / x2 / x4: pixel.cpp:1122-1146): for i in [0, width)
  * ads = sum |encDC[k] - sums[i + off_k]| + costMvX[i]; positions with ads < thresh are appended, in order, to mvs.

@@ -34,6 +34,7 @@ void setupFilterPrimitives_c(EncoderPrimitives& p);
 void setupIntraPrimitives_c(EncoderPrimitives& p);
 void setupLowPassPrimitives_c(EncoderPrimitives& p);
 void setupSeaIntegralPrimitives_c(EncoderPrimitives& p);   /* framefilter.cpp:142-157 */
+void setupSaoPrimitives_c(EncoderPrimitives& p);           /* sao.cpp:1939-1950 */
 extern const int16_t g_t4[4][4];
 extern const int16_t g_t8[8][8];
 extern const int16_t g_t16[16][16];
@@ -128,6 +129,7 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         OFF(chroma[0].cu[0].add_ps); OFF(chroma[0].cu[0].copy_ps); OFF(chroma[0].cu[0].copy_sp); OFF(chroma[0].cu[0].copy_ss); OFF(chroma[0].cu[0].copy_pp);
         OFF(extendRowBorder); OFF(frameInitLowres); OFF(frameInitLowerRes);
         OFF(propagateCost); OFF(fix8Unpack); OFF(fix8Pack); OFF(integral_initv); OFF(integral_inith);
+        OFF(saoCuStatsBO); OFF(saoCuStatsE0); OFF(saoCuStatsE1); OFF(saoCuStatsE2); OFF(saoCuStatsE3);
 #undef OFF
         v.push_back((int32_t)sizeof(EncoderPrimitives));
         Buf b(v.size() * 4); memcpy(b.data(), v.data(), b.size()); out.push_back(b);
@@ -394,6 +396,21 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
     {
         Buf b((QP_MAX_MAX + 1) * 8); memcpy(b.data(), x265_lambda_tab, b.size()); out.push_back(b); return true;
     }
+    if (op == "sao_stats")
+    {   /* ints = type (0..3 = E0..E3, 4 = BO), stride, recOff, endX, endY, upOff ; bufs = diff (int16, stride 64), rec plane, upBuff1, upBufft,
+           stats (int32), count (int32).  returns stats, count, upBuff1, upBufft after the reference's primitive (sao.cpp:1774-1937). */
+        const int type = (int)I[0]; const intptr_t stride = I[1]; const int endX = (int)I[3], endY = (int)I[4];
+        Buf st = B[4], ct = B[5], u1 = B[2], ut = B[3];
+        const int16_t* diff = (const int16_t*)B[0].data(); const pixel* rec = PX(B[1], I[2]);
+        int8_t* up1 = (int8_t*)u1.data() + I[5]; int8_t* upt = (int8_t*)ut.data() + I[5];
+        int32_t* s = (int32_t*)st.data(); int32_t* c = (int32_t*)ct.data();
+        if (type == 4) T.saoCuStatsBO(diff, rec, stride, endX, endY, s, c);
+        else if (type == 0) T.saoCuStatsE0(diff, rec, stride, endX, endY, s, c);
+        else if (type == 1) T.saoCuStatsE1(diff, rec, stride, up1, endX, endY, s, c);
+        else if (type == 2) T.saoCuStatsE2(diff, rec, stride, up1, upt, endX, endY, s, c);
+        else T.saoCuStatsE3(diff, rec, stride, up1, endX, endY, s, c);
+        out.push_back(st); out.push_back(ct); out.push_back(u1); out.push_back(ut); return true;
+    }
     if (op == "mvcost_row")
     {   /* ints = qp, halfRange ; returns u16 cost[-halfRange..halfRange] (bitcost.cpp:30-56) */
         g_me->setQP((unsigned)I[0]);
@@ -540,6 +557,7 @@ int main()
     setupFilterPrimitives_c(T);
     setupIntraPrimitives_c(T);
     setupSeaIntegralPrimitives_c(T);
+    setupSaoPrimitives_c(T);
     setupAliasPrimitives(T);           /* primitives.cpp:178-284 */
     MotionEstimate::initScales();
     g_me = new MEx();

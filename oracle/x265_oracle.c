@@ -817,3 +817,71 @@ void xo_intra_allangs(int size, xo_pixel* dst, const xo_pixel* refPix, const xo_
         ang_core(size, dst + (mode - 2) * size * size, sp, mode, bLuma);
     }
 }
+
+/* ---- SAO statistics (encoder/sao.cpp:1774-1937): per offset class, sum of (source - reconstruction) and pixel count ----
+ * diff has the fixed stride MAX_CU_SIZE = 64; stats / count accumulate (+=).  type 0..3 = edge classes EO_0..EO_3 (neighbour
+ * pairs left/right, up/down, up-left/down-right, up-right/down-left), 4 = band offset.  The sign buffers carry the "upper
+ * neighbour" signs of the first row in and those of the row after the last one out, exactly like the reference's in-place updates. */
+static inline int sgn(int v) { return (v > 0) - (v < 0); }
+static const int k_eoTable[5] = { 1, 2, 0, 3, 4 };                                /* SAO::s_eoTable, sao.cpp:59-66 */
+void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t stride, int8_t* upBuff1, int8_t* upBufft,
+                  int endX, int endY, int32_t* stats, int32_t* count)
+{
+    if (type == 4)
+    {   /* saoCuStatsBO_c */
+        const int boShift = X265_DEPTH - 5;
+        for (int y = 0; y < endY; y++, diff += 64, rec += stride)
+            for (int x = 0; x < endX; x++) { const int c = rec[x] >> boShift; stats[c] += diff[x]; count[c]++; }
+        return;
+    }
+    int32_t ts[5] = { 0, 0, 0, 0, 0 }, tc[5] = { 0, 0, 0, 0, 0 };
+    for (int y = 0; y < endY; y++)
+    {
+        if (type == 0)
+        {   /* saoCuStatsE0_c */
+            int signLeft = sgn(rec[0] - rec[-1]);
+            for (int x = 0; x < endX; x++)
+            {
+                const int signRight = sgn(rec[x] - rec[x + 1]);
+                const int e = signRight + signLeft + 2;
+                signLeft = -signRight;
+                ts[e] += diff[x]; tc[e]++;
+            }
+        }
+        else if (type == 1)
+        {   /* saoCuStatsE1_c */
+            for (int x = 0; x < endX; x++)
+            {
+                const int signDown = sgn(rec[x] - rec[x + stride]);
+                const int e = signDown + upBuff1[x] + 2;
+                upBuff1[x] = (int8_t)(-signDown);
+                ts[e] += diff[x]; tc[e]++;
+            }
+        }
+        else if (type == 2)
+        {   /* saoCuStatsE2_c: the two sign buffers swap roles every row */
+            upBufft[0] = (int8_t)sgn(rec[stride] - rec[-1]);
+            for (int x = 0; x < endX; x++)
+            {
+                const int signDown = sgn(rec[x] - rec[x + stride + 1]);
+                const int e = signDown + upBuff1[x] + 2;
+                upBufft[x + 1] = (int8_t)(-signDown);
+                ts[e] += diff[x]; tc[e]++;
+            }
+            int8_t* t = upBuff1; upBuff1 = upBufft; upBufft = t;
+        }
+        else
+        {   /* saoCuStatsE3_c */
+            for (int x = 0; x < endX; x++)
+            {
+                const int signDown = sgn(rec[x] - rec[x + stride - 1]);
+                const int e = signDown + upBuff1[x] + 2;
+                upBuff1[x - 1] = (int8_t)(-signDown);
+                ts[e] += diff[x]; tc[e]++;
+            }
+            upBuff1[endX - 1] = (int8_t)sgn(rec[endX - 1 + stride] - rec[endX]);
+        }
+        rec += stride; diff += 64;
+    }
+    for (int x = 0; x < 5; x++) { stats[k_eoTable[x]] += ts[x]; count[k_eoTable[x]] += tc[x]; }
+}

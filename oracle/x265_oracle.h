@@ -87,6 +87,10 @@ uint32_t xo_copy_count(int n, int16_t* coef, const int16_t* resi, intptr_t rs);
 void     xo_denoise_dct(int16_t* coef, uint32_t* resSum, const uint16_t* offset, int num);
 const int16_t* xo_dct_matrix(int n);   /* n x n, row-major (constants.cpp:270-344) */
 
+/* ---- SAO statistics (encoder/sao.cpp:1774-1937): type 0..3 = saoCuStatsE0..E3, 4 = saoCuStatsBO; diff stride 64 ---- */
+void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t stride, int8_t* upBuff1, int8_t* upBufft,
+                  int endX, int endY, int32_t* stats, int32_t* count);
+
 /* ---- interpolation family (ipfilter.cpp:40-369); taps = 8 (luma) or 4 (chroma) ---- */
 void xo_interp_hpp(int taps, int w, int h, const xo_pixel* src, intptr_t ss, xo_pixel* dst, intptr_t ds, int coeffIdx);
 void xo_interp_hps(int taps, int w, int h, const xo_pixel* src, intptr_t ss, int16_t* dst, intptr_t ds, int coeffIdx, int isRowExt);

@@ -38,7 +38,8 @@ def expected_layout():
     v += [ccu0, ccu0 + B.CHROMA_CU_PTRS * 8]
     v += [ccu(s) for s in ("sa8d", "sse_pp", "sub_ps", "add_ps", "copy_ps", "copy_sp", "copy_ss", "copy_pp")]
     v += [B.SCALAR_OFF["extendRowBorder"], B.SCALAR_OFF["frameInitLowres"], B.SCALAR_OFF["frameInitLowerRes"]]
-    v += [B.SCALAR_OFF[s] for s in ("propagateCost", "fix8Unpack", "fix8Pack", "integral_initv", "integral_inith")] + [B.SIZEOF_TABLE]
+    v += [B.SCALAR_OFF[s] for s in ("propagateCost", "fix8Unpack", "fix8Pack", "integral_initv", "integral_inith")]
+    v += [B.SCALAR_OFF[s] for s in ("saoCuStatsBO", "saoCuStatsE0", "saoCuStatsE1", "saoCuStatsE2", "saoCuStatsE3")] + [B.SIZEOF_TABLE]
     return v
 
 
@@ -67,7 +68,7 @@ def test_header_constants_agree_with_binding():
                       ("dequant_scaling", "DEQUANT_SCALING"), ("weight_sp", "WEIGHT_SP"), ("weight_pp", "WEIGHT_PP"),
                       ("scale2D_64to32", "SCALE2D_64TO32"), ("denoiseDct", "DENOISEDCT"), ("extendRowBorder", "EXTENDROWBORDER"), ("frameInitLowres", "FRAMEINITLOWRES"),
                       ("frameInitLowerRes", "FRAMEINITLOWERRES"), ("propagateCost", "PROPAGATECOST"), ("fix8Unpack", "FIX8UNPACK"), ("fix8Pack", "FIX8PACK"),
-                      ("integral_initv", "INTEGRAL_INITV"), ("integral_inith", "INTEGRAL_INITH")):
+                      ("integral_initv", "INTEGRAL_INITV"), ("integral_inith", "INTEGRAL_INITH"), ("saoCuStatsBO", "SAOCUSTATSBO")):
         assert int(d["X265HIP_OFF_" + key]) == B.SCALAR_OFF[name]
 
 

@@ -22,6 +22,7 @@ CU_SLOT = {n: i for i, n in enumerate(
      "intra_pred_allangs", "intra_filter", "intra_pred"])}
 SCALAR_OFF = {"dst4x4": 6720, "idst4x4": 6728, "quant": 6736, "nquant": 6744, "dequant_scaling": 6752,
               "dequant_normal": 6760, "denoiseDct": 6768, "scale1D_128to64": 6776, "scale2D_64to32": 6792,
+              "saoCuStatsBO": 6888, "saoCuStatsE0": 6896, "saoCuStatsE1": 6904, "saoCuStatsE2": 6912, "saoCuStatsE3": 6920,
               "frameInitLowres": 6928, "frameInitLowerRes": 6936, "propagateCost": 6944, "fix8Unpack": 6952, "fix8Pack": 6960, "extendRowBorder": 6968,
               "integral_initv": 7104, "integral_inith": 7152, "weight_sp": 7016, "weight_pp": 7024}
 CHROMA_PU_SLOT = {n: i for i, n in enumerate(

@@ -102,6 +102,65 @@ template<int OP> int launch(hipStream_t st, int w, int h, const BlkArgs& a, int 
     return X265HIP_OK;
 }
 
+
+// ---- SAO statistics (encoder/sao.cpp:1774-1937): saoCuStatsE0..E3 (type 0..3) and saoCuStatsBO (type 4) of one block ----
+// Per pixel the class is sign(c - a) + sign(c - b) + 2 for the two neighbours of the edge direction (band: c >> (depth - 5)); the
+// reference's rolling sign buffers are the same signs carried from row to row, so every pixel is independent here.  Row 0 takes
+// its "upper neighbour" signs from upIn, the signs the reference would leave behind for the next block go to upOutA / upOutB.
+// out[0..31] = sums of diff per class, out[32..63] = counts (edge classes already mapped through SAO::s_eoTable).
+__global__ __launch_bounds__(256) void sao_stats_kernel(int type, const int16_t* __restrict__ diff, const pixel* __restrict__ rec, intptr_t stride,
+                                                        const int8_t* __restrict__ upIn, int endX, int endY, int32_t* __restrict__ out,
+                                                        int8_t* __restrict__ upOutA, int8_t* __restrict__ upOutB)
+{
+    __shared__ int s_sum[32], s_cnt[32];
+    const int t = threadIdx.x;
+    if (t < 32) { s_sum[t] = 0; s_cnt[t] = 0; }
+    __syncthreads();
+    auto sgn = [](int v) { return (v > 0) - (v < 0); };
+    // neighbour offsets (a = the one the sign buffer stands for, b = the opposite one)
+    const int ax = type == 0 ? -1 : type == 2 ? -1 : type == 3 ? 1 : 0, ay = type == 0 ? 0 : -1;
+    const int bx = -ax, by = -ay;
+    for (int i = t; i < endX * endY; i += 256)
+    {
+        const int y = i / endX, x = i - y * endX;
+        const int c = rec[(intptr_t)y * stride + x];
+        int cls;
+        if (type == 4) cls = c >> (X265_DEPTH - 5);
+        else
+        {
+            const int sa = (ay == -1 && y == 0) ? (int)upIn[x] : sgn(c - (int)rec[(intptr_t)(y + ay) * stride + x + ax]);
+            const int sb = sgn(c - (int)rec[(intptr_t)(y + by) * stride + x + bx]);
+            const int e = sa + sb + 2;
+            cls = (int)((0x43021u >> (4 * e)) & 15);                            // s_eoTable = { 1, 2, 0, 3, 4 }
+        }
+        atomicAdd(&s_sum[cls], (int)diff[y * 64 + x]);
+        atomicAdd(&s_cnt[cls], 1);
+    }
+    // the sign buffers after the last row (only the entries the reference writes)
+    const int L = endY - 1;
+    if (type == 1)
+        for (int x = t; x < endX; x += 256) upOutA[x] = (int8_t)(-sgn((int)rec[(intptr_t)L * stride + x] - (int)rec[(intptr_t)(L + 1) * stride + x]));
+    else if (type == 2)
+    {   // row y writes buffer (y even ? upBufft : upBuff1): [0] = sign(rec[y+1][0] - rec[y][-1]), [x + 1] = -sign(rec[y][x] - rec[y+1][x+1])
+        for (int k = 0; k < 2; k++)
+        {
+            const int y = L - k;                                                  // last row and the one before it
+            if (y < 0) break;
+            int8_t* dst = (y & 1) ? upOutA : upOutB;
+            for (int x = t; x <= endX; x += 256)
+                dst[x] = x == 0 ? (int8_t)sgn((int)rec[(intptr_t)(y + 1) * stride] - (int)rec[(intptr_t)y * stride - 1])
+                                : (int8_t)(-sgn((int)rec[(intptr_t)y * stride + x - 1] - (int)rec[(intptr_t)(y + 1) * stride + x]));
+        }
+    }
+    else if (type == 3)
+    {   // upOutA[0] stands for upBuff1[-1]
+        for (int x = t; x < endX; x += 256) upOutA[x] = (int8_t)(-sgn((int)rec[(intptr_t)L * stride + x] - (int)rec[(intptr_t)(L + 1) * stride + x - 1]));
+        if (t == 0) upOutA[endX] = (int8_t)sgn((int)rec[(intptr_t)(L + 1) * stride + endX - 1] - (int)rec[(intptr_t)L * stride + endX]);
+    }
+    __syncthreads();
+    if (t < 32) { out[t] = s_sum[t]; out[32 + t] = s_cnt[t]; }
+}
+
 } // namespace
 
 // ---- frame_init_lowres_core (pixel.cpp:596-622): one thread per lowres pixel, 3x3 source neighbourhood -> 4 outputs ----
@@ -187,4 +246,15 @@ extern "C" int x265hip_blockop_batch(void* stream, int op, int w, int h, const x
     }
     set_error("blockop_batch: unknown op %d", op);
     return X265HIP_EARG;
+}
+
+extern "C" int x265hip_sao_stats(void* stream, int type, const int16_t* diff, const void* rec, intptr_t stride, const int8_t* upIn, int endX, int endY,
+                                 int32_t* out, int8_t* upOutA, int8_t* upOutB)
+{
+    if (endX <= 0 || endY <= 0) return X265HIP_OK;
+    if (type < 0 || type > 4 || endX > 64 || endY > 64 || !diff || !rec || !out || (type >= 1 && type <= 3 && (!upIn || !upOutA)) || (type == 2 && !upOutB))
+    { set_error("sao_stats: bad arguments"); return X265HIP_EARG; }
+    hipLaunchKernelGGL(sao_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, type, diff, (const pixel*)rec, stride, upIn, endX, endY, out, upOutA, upOutB);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
 }
