@@ -16,6 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _env():
     import torch
     env = dict(os.environ)
+    # The reference encoder reads uninitialised heap memory in some configurations (its own output changes with MALLOC_PERTURB_, e.g. rd=1
+    # on a 64x64 clip); a process that has loaded the HIP runtime has a different heap history than one that has not.  Both modes therefore run
+    # with the same glibc fill byte for fresh and freed chunks, which makes "same inputs" true for the two runs.
+    env["MALLOC_PERTURB_"] = "85"
     env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(os.path.dirname(torch.__file__), "lib"), "/opt/rocm/lib", env.get("LD_LIBRARY_PATH", "")])
     return env
 
