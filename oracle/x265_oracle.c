@@ -885,3 +885,59 @@ void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t s
     }
     for (int x = 0; x < 5; x++) { stats[k_eoTable[x]] += ts[x]; count[k_eoTable[x]] += tc[x]; }
 }
+
+/* SAO::calcSaoStatsCTU for the luma plane of every CTU of a picture (encoder/sao.cpp:729-905; one slice, bLimitSAO off): which pixels
+ * of a CTU each offset class counts (the rows / columns the deblocking of the neighbours has not finalised are skipped: skipB / skipR),
+ * composed from the primitives above.  out: per CTU [2][5][32] = offsetOrg then count, types in the order SAO_EO_0..3, SAO_BO. */
+void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int32_t* out)
+{
+    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
+    for (int addr = 0; addr < nx * ny; addr++)
+    {
+        const int lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;
+        const int firstRow = addr < nx, lastRow = addr >= nx * ny - nx;
+        const int bAboveUnavail = (!tpely) | firstRow;
+        const int rpelx = lpelx + ctuSize < picWidth ? lpelx + ctuSize : picWidth, bpely = tpely + ctuSize < picHeight ? tpely + ctuSize : picHeight;
+        const int ctuWidth = rpelx - lpelx, ctuHeight = bpely - tpely;
+        const int picH = lastRow ? bpely : picHeight;
+        const xo_pixel* fenc0 = fenc + tpely * stride + lpelx; const xo_pixel* rec0 = recon + tpely * stride + lpelx;
+        int32_t* stats = out + (size_t)addr * 320; int32_t* count = stats + 160;
+        memset(stats, 0, 320 * sizeof(int32_t));
+        int16_t diff[64 * 64];
+        for (int y = 0; y < ctuHeight; y++) for (int x = 0; x < ctuWidth; x++) diff[y * 64 + x] = (int16_t)(fenc0[y * stride + x] - rec0[y * stride + x]);
+        int8_t buf[2 * (64 + 32)], *upBuff1 = buf + 16, *upBufft = upBuff1 + (64 + 32);
+        int skipB = 4, skipR = 5, startX, startY, endX, endY;
+        const xo_pixel* rec;
+        /* SAO_BO (:800-812) */
+        if (nonDeblocked) { skipB = 3; skipR = 4; }
+        endX = rpelx == picWidth ? ctuWidth : ctuWidth - skipR;
+        endY = bpely == picH ? ctuHeight : ctuHeight - skipB;
+        xo_sao_stats(4, diff, rec0, stride, NULL, NULL, endX, endY, stats + 4 * 32, count + 4 * 32);
+        /* SAO_EO_0 (:816-828) */
+        if (nonDeblocked) { skipB = 3; skipR = 5; }
+        startX = !lpelx;
+        endX = rpelx == picWidth ? ctuWidth - 1 : ctuWidth - skipR;
+        xo_sao_stats(0, diff + startX, rec0 + startX, stride, NULL, NULL, endX - startX, ctuHeight - skipB, stats, count);
+        /* SAO_EO_1 (:831-851) */
+        if (nonDeblocked) { skipB = 4; skipR = 4; }
+        rec = rec0; startY = bAboveUnavail;
+        endX = rpelx == picWidth ? ctuWidth : ctuWidth - skipR;
+        endY = bpely == picH ? ctuHeight - 1 : ctuHeight - skipB;
+        if (startY) rec += stride;
+        for (int i = 0; i < ctuWidth; i++) upBuff1[i] = (int8_t)sgn(rec[i] - rec[i - stride]);
+        xo_sao_stats(1, diff + startY * 64, rec0 + startY * stride, stride, upBuff1, NULL, endX, endY - startY, stats + 32, count + 32);
+        /* SAO_EO_2 (:856-878) */
+        if (nonDeblocked) { skipB = 4; skipR = 5; }
+        rec = rec0; startX = !lpelx;
+        endX = rpelx == picWidth ? ctuWidth - 1 : ctuWidth - skipR;
+        startY = bAboveUnavail;
+        endY = bpely == picH ? ctuHeight - 1 : ctuHeight - skipB;
+        if (startY) rec += stride;
+        for (int i = 0; i < endX - startX; i++) upBuff1[i] = (int8_t)sgn(rec[startX + i] - rec[startX + i - stride - 1]);
+        xo_sao_stats(2, diff + startX + startY * 64, rec0 + startX + startY * stride, stride, upBuff1, upBufft, endX - startX, endY - startY, stats + 64, count + 64);
+        /* SAO_EO_3 (:880-901) */
+        rec = rec0; if (startY) rec += stride;
+        for (int i = 0; i < endX - startX + 1; i++) upBuff1[i] = (int8_t)sgn(rec[startX - 1 + i] - rec[startX + i - stride]);
+        xo_sao_stats(3, diff + startX + startY * 64, rec0 + startX + startY * stride, stride, upBuff1 + 1, NULL, endX - startX, endY - startY, stats + 96, count + 96);
+    }
+}
