@@ -17,3 +17,26 @@ def test_sao_stats_slots_match_oracle(depth):
         a, b = run_hip(lib, c), run_oracle(ora, c)
         for x, y, what in zip(a, b, ("stats", "count", "upBuff1", "upBufft")):
             assert np.array_equal(x, y), "case %d type %d endX %d endY %d: %s" % (i, c[0], c[5], c[6], what)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu,nd", [((200, 136), 64, 0), ((192, 128), 64, 0), ((72, 40), 32, 0), ((130, 70), 16, 0), ((200, 136), 64, 1), ((64, 64), 64, 0),
+                                         ((1920, 1080), 64, 0)])
+def test_sao_frame_stats_match_oracle(depth, size, ctu, nd):
+    """x265hip_sao_stats_frame (all CTUs of a picture in one launch) against the oracle's calcSaoStatsCTU (pinned to the reference's SAO class)"""
+    import ctypes as C
+    from x265hip_pkg.frame import FrameApi
+    from test_sao_oracle_vs_ref import sao_frame_oracle, sao_frame_pair
+    api = FrameApi(depth)
+    t = api.torch
+    W, H = size
+    fenc, rec = sao_frame_pair(depth, W, H, 170 + depth + W)
+    exp = sao_frame_oracle(Oracle(depth), fenc, rec, ctu, nd)
+    d_f, d_r = api.to_device(fenc.reshape(-1)), api.to_device(rec.reshape(-1))
+    d_out = t.full((exp.size,), -7, dtype=t.int32, device="cuda")
+    P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    api.h.check(api.lib.x265hip_sao_stats_frame(api.stream(), P(d_f), P(d_r), C.c_ssize_t(W), W, H, ctu, nd, P(d_out)))
+    t.cuda.synchronize()
+    got = d_out.cpu().numpy().reshape(exp.shape)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, "first mismatch (ctu, which, type, class) %s: hip %d oracle %d" % (bad[0], got[tuple(bad[0])], exp[tuple(bad[0])])

@@ -161,6 +161,82 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(int type, const int16_t*
     if (t < 32) { out[t] = s_sum[t]; out[32 + t] = s_cnt[t]; }
 }
 
+
+// ---- SAO statistics of a whole picture (SAO::calcSaoStatsCTU, encoder/sao.cpp:729-905, luma, one slice): one workgroup per CTU ----
+// Every pixel is classified against its real neighbours (the reference's sign buffers hold exactly those signs); which pixels of a CTU
+// each class counts is a rectangle per type (skipB / skipR keep away from rows / columns the neighbours' deblocking has not finalised).
+// Edge classes accumulate in registers (5 classes x 4 types, compile-time indexed), the 32 bands through LDS atomics (one copy per wavefront).
+__global__ __launch_bounds__(256) void sao_frame_kernel(const pixel* __restrict__ fenc, const pixel* __restrict__ recon, intptr_t stride, int picWidth, int picHeight,
+                                                        int ctuSize, int nonDeblocked, int32_t* __restrict__ out)
+{
+    __shared__ int s_bo[4][2][32];
+    __shared__ int s_eo[4][40];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    for (int i = t; i < 4 * 2 * 32; i += 256) (&s_bo[0][0][0])[i] = 0;
+    __syncthreads();
+    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
+    const int addr = blockIdx.x, lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;
+    const bool lastRow = addr >= nx * ny - nx;
+    const int above = (!tpely) | (addr < nx);
+    const int rpelx = min(lpelx + ctuSize, picWidth), bpely = min(tpely + ctuSize, picHeight);
+    const int cw = rpelx - lpelx, ch = bpely - tpely;
+    const int picH = lastRow ? bpely : picHeight;
+    const bool atRight = rpelx == picWidth, atBottom = bpely == picH;
+    const int startX = !lpelx;
+    // regions (:800-901); deblocked statistics: skipB 4 / skipR 5 throughout, non-deblocked: per class
+    const int boX = atRight ? cw : cw - (nonDeblocked ? 4 : 5), boY = atBottom ? ch : ch - (nonDeblocked ? 3 : 4);
+    const int e0X = atRight ? cw - 1 : cw - 5, e0Y = ch - (nonDeblocked ? 3 : 4);
+    const int e1X = atRight ? cw : cw - (nonDeblocked ? 4 : 5), e1Y = atBottom ? ch - 1 : ch - 4;
+    const int e2X = atRight ? cw - 1 : cw - 5, e2Y = atBottom ? ch - 1 : ch - 4;
+    const pixel* f0 = fenc + (intptr_t)tpely * stride + lpelx;
+    const pixel* r0 = recon + (intptr_t)tpely * stride + lpelx;
+    int sum[4][5], cnt[4][5];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int c = 0; c < 5; c++) { sum[k][c] = 0; cnt[k][c] = 0; }
+    auto sgn = [](int v) { return (v > 0) - (v < 0); };
+    for (int i = t; i < cw * ch; i += 256)
+    {
+        const int y = i / cw, x = i - y * cw;
+        const pixel* r = r0 + (intptr_t)y * stride + x;
+        const int c = r[0], d = (int)f0[(intptr_t)y * stride + x] - c;
+        if (x < boX && y < boY) { atomicAdd(&s_bo[wave][0][c >> (X265_DEPTH - 5)], d); atomicAdd(&s_bo[wave][1][c >> (X265_DEPTH - 5)], 1); }
+        const bool in[4] = { x >= startX && x < e0X && y < e0Y, x < e1X && y >= above && y < e1Y,
+                             x >= startX && x < e2X && y >= above && y < e2Y, x >= startX && x < e2X && y >= above && y < e2Y };
+        // neighbour pairs of the four edge directions: (-1,0)/(1,0), (0,-1)/(0,1), (-1,-1)/(1,1), (1,-1)/(-1,1)
+        const int ax[4] = { -1, 0, -1, 1 }, ay[4] = { 0, -1, -1, -1 };
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            if (!in[k]) continue;
+            const int e = sgn(c - (int)r[(intptr_t)ay[k] * stride + ax[k]]) + sgn(c - (int)r[-(intptr_t)ay[k] * stride - ax[k]]) + 2;
+#pragma unroll
+            for (int q = 0; q < 5; q++) { const bool hit = e == q; sum[k][q] += hit ? d : 0; cnt[k][q] += hit ? 1 : 0; }
+        }
+    }
+    // per-wavefront totals of the edge classes, mapped through s_eoTable = { 1, 2, 0, 3, 4 }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int q = 0; q < 5; q++)
+        {
+            const int cls = (int)((0x43021u >> (4 * q)) & 15);
+            const int a = wave_sum(sum[k][q]), b = wave_sum(cnt[k][q]);
+            if (lane == 0) { s_eo[wave][k * 10 + cls] = a; s_eo[wave][k * 10 + 5 + cls] = b; }
+        }
+    __syncthreads();
+    int32_t* o = out + (int64_t)addr * 320;                        // [2][5][32]: offsetOrg, count; types EO_0..3, BO
+    for (int i = t; i < 320; i += 256)
+    {
+        const int which = i / 160, type = (i % 160) / 32, cls = i % 32;
+        int v = 0;
+        if (type == 4) v = s_bo[0][which][cls] + s_bo[1][which][cls] + s_bo[2][which][cls] + s_bo[3][which][cls];
+        else if (cls < 5) v = s_eo[0][type * 10 + which * 5 + cls] + s_eo[1][type * 10 + which * 5 + cls] + s_eo[2][type * 10 + which * 5 + cls] + s_eo[3][type * 10 + which * 5 + cls];
+        o[i] = v;
+    }
+}
+
 } // namespace
 
 // ---- frame_init_lowres_core (pixel.cpp:596-622): one thread per lowres pixel, 3x3 source neighbourhood -> 4 outputs ----
@@ -255,6 +331,17 @@ extern "C" int x265hip_sao_stats(void* stream, int type, const int16_t* diff, co
     if (type < 0 || type > 4 || endX > 64 || endY > 64 || !diff || !rec || !out || (type >= 1 && type <= 3 && (!upIn || !upOutA)) || (type == 2 && !upOutB))
     { set_error("sao_stats: bad arguments"); return X265HIP_EARG; }
     hipLaunchKernelGGL(sao_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, type, diff, (const pixel*)rec, stride, upIn, endX, endY, out, upOutA, upOutB);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                                       int32_t* out)
+{
+    if (!fenc || !recon || !out || picWidth < 1 || picHeight < 1 || (ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth)
+    { set_error("sao_stats_frame: bad arguments"); return X265HIP_EARG; }
+    const int n = ((picWidth + ctuSize - 1) / ctuSize) * ((picHeight + ctuSize - 1) / ctuSize);
+    hipLaunchKernelGGL(sao_frame_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
