@@ -168,11 +168,12 @@ int x265hip_cutree_propagate(void* stream, int widthInCU, int heightInCU, int di
                              const int32_t* intraCost, const uint16_t* lowresCosts, const int32_t* invQscale, const int16_t* mvs0, const int16_t* mvs1,
                              uint16_t* propB, uint16_t* prop0, uint16_t* prop1, void* workspace, size_t workspaceBytes);
 
-/* SAO statistics of a whole deblocked picture: SAO::calcSaoStatsCTU (encoder/sao.cpp:729-905) for the luma plane of every CTU, one slice,
- * bLimitSAO off.  fenc / recon point at pixel (0,0) of the source and the reconstructed plane (same stride).  out: per CTU (raster order)
+/* SAO statistics of a whole deblocked picture: SAO::calcSaoStatsCTU (encoder/sao.cpp:729-905) for one plane of every CTU, one slice,
+ * bLimitSAO off.  fenc / recon point at pixel (0,0) of the source and the reconstructed plane (same stride).  Luma: planeOffset 0; a 4:2:0 chroma
+ * plane: its own width / height / CTU size (picture and CTU sizes halved, sao.cpp:748-756) and planeOffset 2 (:773).  out: per CTU (raster order)
  * [2][5][32] int32 = m_offsetOrg then m_count, types in the order SAO_EO_0..3, SAO_BO (sao.h:43-50).  nonDeblocked = param bSaoNonDeblocked. */
 int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
-                            int32_t* out);
+                            int planeOffset, int32_t* out);
 
 #ifdef __cplusplus
 }

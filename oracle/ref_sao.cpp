@@ -6,9 +6,9 @@
  * (position, first / last row flags) the function reads.  It pins the frame-level restatement xo_sao_stats_frame (region rules of
  * every offset class) and through it the HIP batch x265hip_sao_stats_frame.  Luma plane, one slice, deblocked statistics (the default).
  *
- * usage: x265sao_<depth> <width> <height> <ctu> <in.raw> <out.bin> [sao-non-deblock 0|1]
- *   in.raw  : source plane then reconstructed plane, width x height pixels each
- *   out.bin : per CTU 5 x 32 int32 offsetOrg then 5 x 32 int32 count (types SAO_EO_0..3, SAO_BO as in sao.h:43-50)
+ * usage: x265sao_<depth> <width> <height> <ctu> <in.raw> <out.bin> [sao-non-deblock 0|1] [planes 1|3]
+ *   in.raw  : per plane (Y, then Cb, Cr of a 4:2:0 picture when planes = 3) the source plane then the reconstructed plane, tightly packed
+ *   out.bin : per plane, per CTU 5 x 32 int32 offsetOrg then 5 x 32 int32 count (types SAO_EO_0..3, SAO_BO as in sao.h:43-50)
  */
 #include "common.h"
 #include "primitives.h"
@@ -38,7 +38,8 @@ int main(int argc, char** argv)
     const int W = atoi(argv[1]), H = atoi(argv[2]), ctu = atoi(argv[3]);
     x265_param* p = x265_param_alloc();
     x265_param_default_preset(p, "medium", NULL);
-    p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = X265_CSP_I400; p->maxCUSize = ctu;
+    const int nplanes = argc > 7 ? atoi(argv[7]) : 1;
+    p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = nplanes == 3 ? X265_CSP_I420 : X265_CSP_I400; p->maxCUSize = ctu;
     p->maxLog2CUSize = ctu == 64 ? 6 : ctu == 32 ? 5 : 4; p->unitSizeDepth = p->maxLog2CUSize - 2;       /* Encoder::configure */
     p->bSaoNonDeblocked = argc > 6 ? atoi(argv[6]) : 0; p->bLimitSAO = 0;
     x265_setup_primitives(p);
@@ -54,13 +55,21 @@ int main(int argc, char** argv)
     if (!in || !out) { fprintf(stderr, "cannot open files\n"); return 2; }
     PicYuv* pics[2] = { frame.m_fencPic, frame.m_reconPic[0] };
     for (int k = 0; k < 2; k++)
-    {
+    {   /* the allocations are larger than the picture: clear them first */
         PicYuv* pic = pics[k];
-        const uint32_t rowsAlloc = sps.numCuInHeight * ctu + 2 * pic->m_lumaMarginY;
-        memset(pic->m_picBuf[0], 0, sizeof(pixel) * pic->m_stride * rowsAlloc);
-        for (int y = 0; y < H; y++)
-            if (fread(pic->m_picOrg[0] + (intptr_t)y * pic->m_stride, sizeof(pixel), W, in) != (size_t)W) { fprintf(stderr, "short input\n"); return 2; }
+        memset(pic->m_picBuf[0], 0, sizeof(pixel) * pic->m_stride * (sps.numCuInHeight * ctu + 2 * pic->m_lumaMarginY));
+        for (int c = 1; c < nplanes; c++)
+            memset(pic->m_picBuf[c], 0, sizeof(pixel) * pic->m_strideC * (((sps.numCuInHeight * ctu) >> pic->m_vChromaShift) + 2 * pic->m_chromaMarginY));
     }
+    for (int plane = 0; plane < nplanes; plane++)
+        for (int k = 0; k < 2; k++)
+        {
+            PicYuv* pic = pics[k];
+            const int w = plane ? W >> 1 : W, h = plane ? H >> 1 : H;
+            const intptr_t st = plane ? pic->m_strideC : pic->m_stride;
+            for (int y = 0; y < h; y++)
+                if (fread(pic->m_picOrg[plane] + (intptr_t)y * st, sizeof(pixel), w, in) != (size_t)w) { fprintf(stderr, "short input\n"); return 2; }
+        }
     FrameData* fd = frame.m_encData = new FrameData;
     fd->m_slice = new Slice; fd->m_slice->m_sliceType = P_SLICE;
     fd->m_picCTU = new CUData[sps.numCUsInFrame];
@@ -73,13 +82,14 @@ int main(int argc, char** argv)
     SaoX sao;
     if (!sao.create(p, 1)) { fprintf(stderr, "SAO::create failed\n"); return 2; }
     sao.m_frame = &frame;
-    for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
-    {
-        sao.clear();
-        sao.calcSaoStatsCTU((int)a, 0);
-        fwrite(sao.sums(), 4, 5 * 32, out);
-        fwrite(sao.counts(), 4, 5 * 32, out);
-    }
+    for (int plane = 0; plane < nplanes; plane++)
+        for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
+        {
+            sao.clear();
+            sao.calcSaoStatsCTU((int)a, plane);
+            fwrite(sao.sums() + plane * 5 * 32, 4, 5 * 32, out);
+            fwrite(sao.counts() + plane * 5 * 32, 4, 5 * 32, out);
+        }
     fclose(out); fclose(in);
     return 0;
 }

@@ -889,8 +889,9 @@ void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t s
 /* SAO::calcSaoStatsCTU for the luma plane of every CTU of a picture (encoder/sao.cpp:729-905; one slice, bLimitSAO off): which pixels
  * of a CTU each offset class counts (the rows / columns the deblocking of the neighbours has not finalised are skipped: skipB / skipR),
  * composed from the primitives above.  out: per CTU [2][5][32] = offsetOrg then count, types in the order SAO_EO_0..3, SAO_BO. */
-void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int32_t* out)
-{
+void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out)
+{   /* chroma planes: pass the PLANE's width / height / CTU size (already shifted, :748-756) and planeOffset = 2 (:773) */
+    const int po = planeOffset;
     const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
     for (int addr = 0; addr < nx * ny; addr++)
     {
@@ -910,28 +911,28 @@ void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t st
         const xo_pixel* rec;
         /* SAO_BO (:800-812) */
         if (nonDeblocked) { skipB = 3; skipR = 4; }
-        endX = rpelx == picWidth ? ctuWidth : ctuWidth - skipR;
-        endY = bpely == picH ? ctuHeight : ctuHeight - skipB;
+        endX = rpelx == picWidth ? ctuWidth : ctuWidth - skipR + po;
+        endY = bpely == picH ? ctuHeight : ctuHeight - skipB + po;
         xo_sao_stats(4, diff, rec0, stride, NULL, NULL, endX, endY, stats + 4 * 32, count + 4 * 32);
         /* SAO_EO_0 (:816-828) */
         if (nonDeblocked) { skipB = 3; skipR = 5; }
         startX = !lpelx;
-        endX = rpelx == picWidth ? ctuWidth - 1 : ctuWidth - skipR;
-        xo_sao_stats(0, diff + startX, rec0 + startX, stride, NULL, NULL, endX - startX, ctuHeight - skipB, stats, count);
+        endX = rpelx == picWidth ? ctuWidth - 1 : ctuWidth - skipR + po;
+        xo_sao_stats(0, diff + startX, rec0 + startX, stride, NULL, NULL, endX - startX, ctuHeight - skipB + po, stats, count);
         /* SAO_EO_1 (:831-851) */
         if (nonDeblocked) { skipB = 4; skipR = 4; }
         rec = rec0; startY = bAboveUnavail;
-        endX = rpelx == picWidth ? ctuWidth : ctuWidth - skipR;
-        endY = bpely == picH ? ctuHeight - 1 : ctuHeight - skipB;
+        endX = rpelx == picWidth ? ctuWidth : ctuWidth - skipR + po;
+        endY = bpely == picH ? ctuHeight - 1 : ctuHeight - skipB + po;
         if (startY) rec += stride;
         for (int i = 0; i < ctuWidth; i++) upBuff1[i] = (int8_t)sgn(rec[i] - rec[i - stride]);
         xo_sao_stats(1, diff + startY * 64, rec0 + startY * stride, stride, upBuff1, NULL, endX, endY - startY, stats + 32, count + 32);
         /* SAO_EO_2 (:856-878) */
         if (nonDeblocked) { skipB = 4; skipR = 5; }
         rec = rec0; startX = !lpelx;
-        endX = rpelx == picWidth ? ctuWidth - 1 : ctuWidth - skipR;
+        endX = rpelx == picWidth ? ctuWidth - 1 : ctuWidth - skipR + po;
         startY = bAboveUnavail;
-        endY = bpely == picH ? ctuHeight - 1 : ctuHeight - skipB;
+        endY = bpely == picH ? ctuHeight - 1 : ctuHeight - skipB + po;
         if (startY) rec += stride;
         for (int i = 0; i < endX - startX; i++) upBuff1[i] = (int8_t)sgn(rec[startX + i] - rec[startX + i - stride - 1]);
         xo_sao_stats(2, diff + startX + startY * 64, rec0 + startX + startY * stride, stride, upBuff1, upBufft, endX - startX, endY - startY, stats + 64, count + 64);

@@ -91,8 +91,8 @@ const int16_t* xo_dct_matrix(int n);   /* n x n, row-major (constants.cpp:270-34
 void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t stride, int8_t* upBuff1, int8_t* upBufft,
                   int endX, int endY, int32_t* stats, int32_t* count);
 
-/* SAO::calcSaoStatsCTU, luma, every CTU of a picture (sao.cpp:729-905); out: per CTU [2][5][32] int32 (offsetOrg, count; EO_0..3, BO) */
-void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int32_t* out);
+/* SAO::calcSaoStatsCTU, every CTU of one plane of a picture (sao.cpp:729-905; chroma: the plane's own sizes + planeOffset 2); out: per CTU [2][5][32] int32 (offsetOrg, count; EO_0..3, BO) */
+void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out);
 
 /* ---- interpolation family (ipfilter.cpp:40-369); taps = 8 (luma) or 4 (chroma) ---- */
 void xo_interp_hpp(int taps, int w, int h, const xo_pixel* src, intptr_t ss, xo_pixel* dst, intptr_t ds, int coeffIdx);

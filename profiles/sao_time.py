@@ -16,7 +16,7 @@ for depth in (8, 10):
         n = ((W + 63) // 64) * ((H + 63) // 64)
         d_out = torch.zeros(n * 320, dtype=torch.int32, device="cuda")
         P = lambda x: C.c_void_p(x.data_ptr())
-        def run(): api.h.check(api.lib.x265hip_sao_stats_frame(api.stream(), P(d_f), P(d_r), C.c_ssize_t(W), W, H, 64, 0, P(d_out)))
+        def run(): api.h.check(api.lib.x265hip_sao_stats_frame(api.stream(), P(d_f), P(d_r), C.c_ssize_t(W), W, H, 64, 0, 0, P(d_out)))
         run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

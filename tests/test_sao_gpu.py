@@ -20,9 +20,9 @@ def test_sao_stats_slots_match_oracle(depth):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
-@pytest.mark.parametrize("size,ctu,nd", [((200, 136), 64, 0), ((192, 128), 64, 0), ((72, 40), 32, 0), ((130, 70), 16, 0), ((200, 136), 64, 1), ((64, 64), 64, 0),
-                                         ((1920, 1080), 64, 0)])
-def test_sao_frame_stats_match_oracle(depth, size, ctu, nd):
+@pytest.mark.parametrize("size,ctu,nd,po", [((200, 136), 64, 0, 0), ((192, 128), 64, 0, 0), ((72, 40), 32, 0, 0), ((130, 70), 16, 0, 0), ((200, 136), 64, 1, 0),
+                                            ((64, 64), 64, 0, 0), ((1920, 1080), 64, 0, 0), ((100, 68), 32, 0, 2), ((960, 540), 32, 1, 2), ((36, 20), 8, 0, 2)])
+def test_sao_frame_stats_match_oracle(depth, size, ctu, nd, po):
     """x265hip_sao_stats_frame (all CTUs of a picture in one launch) against the oracle's calcSaoStatsCTU (pinned to the reference's SAO class)"""
     import ctypes as C
     from x265hip_pkg.frame import FrameApi
@@ -31,11 +31,11 @@ def test_sao_frame_stats_match_oracle(depth, size, ctu, nd):
     t = api.torch
     W, H = size
     fenc, rec = sao_frame_pair(depth, W, H, 170 + depth + W)
-    exp = sao_frame_oracle(Oracle(depth), fenc, rec, ctu, nd)
+    exp = sao_frame_oracle(Oracle(depth), fenc, rec, ctu, nd, po)
     d_f, d_r = api.to_device(fenc.reshape(-1)), api.to_device(rec.reshape(-1))
     d_out = t.full((exp.size,), -7, dtype=t.int32, device="cuda")
     P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
-    api.h.check(api.lib.x265hip_sao_stats_frame(api.stream(), P(d_f), P(d_r), C.c_ssize_t(W), W, H, ctu, nd, P(d_out)))
+    api.h.check(api.lib.x265hip_sao_stats_frame(api.stream(), P(d_f), P(d_r), C.c_ssize_t(W), W, H, ctu, nd, po, P(d_out)))
     t.cuda.synchronize()
     got = d_out.cpu().numpy().reshape(exp.shape)
     bad = np.argwhere(got != exp)

@@ -20,26 +20,30 @@ def test_sao_stats_match_reference(depth):
         ref.close()
 
 
-def sao_frame_reference(depth, fenc, rec, ctu, non_deblock=0):
+def sao_frame_reference(depth, fenc, rec, ctu, non_deblock=0, chroma=None):
+    """chroma = [(fencCb, recCb), (fencCr, recCr)] of a 4:2:0 picture -> array [planes, ctus, 2, 5, 32]; luma only -> [ctus, 2, 5, 32]"""
     import os, subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     H, W = fenc.shape
     with tempfile.TemporaryDirectory() as td:
         inp, out = os.path.join(td, "in.raw"), os.path.join(td, "out.bin")
-        np.concatenate([fenc.reshape(-1), rec.reshape(-1)]).tofile(inp)
-        r = subprocess.run([os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth), str(W), str(H), str(ctu), inp, out, str(non_deblock)], capture_output=True, text=True)
+        parts = [fenc.reshape(-1), rec.reshape(-1)] + ([a.reshape(-1) for pr in chroma for a in pr] if chroma else [])
+        np.concatenate(parts).tofile(inp)
+        r = subprocess.run([os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth), str(W), str(H), str(ctu), inp, out, str(non_deblock), "3" if chroma else "1"],
+                           capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1000:]
-        return np.fromfile(out, np.int32).reshape(-1, 2, 5, 32)
+        o = np.fromfile(out, np.int32)
+        return o.reshape(3, -1, 2, 5, 32) if chroma else o.reshape(-1, 2, 5, 32)
 
 
-def sao_frame_oracle(ora, fenc, rec, ctu, non_deblock=0):
+def sao_frame_oracle(ora, fenc, rec, ctu, non_deblock=0, plane_offset=0):
     import ctypes as C
     H, W = fenc.shape
     n = ((W + ctu - 1) // ctu) * ((H + ctu - 1) // ctu)
     out = np.zeros((n, 2, 5, 32), np.int32)
     P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
     f, r = np.ascontiguousarray(fenc), np.ascontiguousarray(rec)
-    ora.lib.xo_sao_stats_frame(P(f), P(r), C.c_ssize_t(W), W, H, ctu, non_deblock, P(out))
+    ora.lib.xo_sao_stats_frame(P(f), P(r), C.c_ssize_t(W), W, H, ctu, non_deblock, plane_offset, P(out))
     return out
 
 
@@ -67,3 +71,20 @@ def test_sao_frame_stats_match_reference(depth, size, ctu, nd):
     for addr in range(a.shape[0]):
         for t in range(5):
             assert np.array_equal(a[addr, :, t], b[addr, :, t]), "CTU %d type %d" % (addr, t)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu,nd", [((200, 136), 64, 0), ((192, 128), 64, 1), ((72, 40), 32, 0), ((136, 72), 16, 0)])
+def test_sao_frame_stats_chroma_match_reference(depth, size, ctu, nd):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth)):
+        pytest.skip("no reference SAO binary")
+    W, H = size
+    y = sao_frame_pair(depth, W, H, 7 + depth + W)
+    cb, cr = sao_frame_pair(depth, W // 2, H // 2, 8 + depth + W), sao_frame_pair(depth, W // 2, H // 2, 9 + depth + W)
+    a = sao_frame_reference(depth, y[0], y[1], ctu, nd, chroma=[cb, cr])
+    ora = Oracle(depth)
+    exp = [sao_frame_oracle(ora, y[0], y[1], ctu, nd, 0), sao_frame_oracle(ora, cb[0], cb[1], ctu // 2, nd, 2), sao_frame_oracle(ora, cr[0], cr[1], ctu // 2, nd, 2)]
+    for plane in range(3):
+        assert np.array_equal(a[plane], exp[plane]), "plane %d" % plane

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(int type, const int16_t*
 // each class counts is a rectangle per type (skipB / skipR keep away from rows / columns the neighbours' deblocking has not finalised).
 // Edge classes accumulate in registers (5 classes x 4 types, compile-time indexed), the 32 bands through LDS atomics (one copy per wavefront).
 __global__ __launch_bounds__(256) void sao_frame_kernel(const pixel* __restrict__ fenc, const pixel* __restrict__ recon, intptr_t stride, int picWidth, int picHeight,
-                                                        int ctuSize, int nonDeblocked, int32_t* __restrict__ out)
+                                                        int ctuSize, int nonDeblocked, int po, int32_t* __restrict__ out)
 {
     __shared__ int s_bo[4][2][32];
     __shared__ int s_eo[4][40];
@@ -184,10 +184,11 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const pixel* __restrict_
     const bool atRight = rpelx == picWidth, atBottom = bpely == picH;
     const int startX = !lpelx;
     // regions (:800-901); deblocked statistics: skipB 4 / skipR 5 throughout, non-deblocked: per class
-    const int boX = atRight ? cw : cw - (nonDeblocked ? 4 : 5), boY = atBottom ? ch : ch - (nonDeblocked ? 3 : 4);
-    const int e0X = atRight ? cw - 1 : cw - 5, e0Y = ch - (nonDeblocked ? 3 : 4);
-    const int e1X = atRight ? cw : cw - (nonDeblocked ? 4 : 5), e1Y = atBottom ? ch - 1 : ch - 4;
-    const int e2X = atRight ? cw - 1 : cw - 5, e2Y = atBottom ? ch - 1 : ch - 4;
+    // po = plane_offset (:773): 0 for luma, 2 for the chroma planes (whose sizes the caller passes already shifted)
+    const int boX = atRight ? cw : cw - (nonDeblocked ? 4 : 5) + po, boY = atBottom ? ch : ch - (nonDeblocked ? 3 : 4) + po;
+    const int e0X = atRight ? cw - 1 : cw - 5 + po, e0Y = ch - (nonDeblocked ? 3 : 4) + po;
+    const int e1X = atRight ? cw : cw - (nonDeblocked ? 4 : 5) + po, e1Y = atBottom ? ch - 1 : ch - 4 + po;
+    const int e2X = atRight ? cw - 1 : cw - 5 + po, e2Y = atBottom ? ch - 1 : ch - 4 + po;
     const pixel* f0 = fenc + (intptr_t)tpely * stride + lpelx;
     const pixel* r0 = recon + (intptr_t)tpely * stride + lpelx;
     int sum[4][5], cnt[4][5];
@@ -336,12 +337,13 @@ extern "C" int x265hip_sao_stats(void* stream, int type, const int16_t* diff, co
 }
 
 extern "C" int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
-                                       int32_t* out)
+                                       int planeOffset, int32_t* out)
 {
-    if (!fenc || !recon || !out || picWidth < 1 || picHeight < 1 || (ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth)
+    if (!fenc || !recon || !out || picWidth < 1 || picHeight < 1 || (ctuSize != 8 && ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth ||
+        (planeOffset != 0 && planeOffset != 2))
     { set_error("sao_stats_frame: bad arguments"); return X265HIP_EARG; }
     const int n = ((picWidth + ctuSize - 1) / ctuSize) * ((picHeight + ctuSize - 1) / ctuSize);
-    hipLaunchKernelGGL(sao_frame_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, out);
+    hipLaunchKernelGGL(sao_frame_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
