@@ -148,7 +148,10 @@ typedef struct x265hip_la_task {
     int32_t doSearch[2];         /* per list: run the motion search (else the slot already holds its result)          */
     int32_t mvSlot[2];           /* per list: slot of mvs / mvCosts (mvSlot[1] unused for a P estimate)               */
     int32_t outSlot;             /* slot of lowresCosts / rowSatds / sums                                             */
-} x265hip_la_task;               /* 32 bytes */
+    int32_t weighted0;           /* 0, or 1 + index of the picture list 0 is SEARCHED in: the weighted copy of p0 that
+                                    LookaheadTLD::weightsAnalyse made (slicetype.cpp:919-1020, wfref0 :4474; x265hip blockop
+                                    weight_pp on the four planes); the bidirectional average always uses p0 itself      */
+} x265hip_la_task;               /* 36 bytes */
 
 int x265hip_lookahead_qp(void);  /* X265_LOOKAHEAD_QP of this library's bit depth (common.h:223) */
 int x265hip_lookahead_intra_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,

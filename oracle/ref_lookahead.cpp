@@ -80,8 +80,9 @@ int main(int argc, char** argv)
     x265_param* p = x265_param_alloc();
     x265_param_default_preset(p, "medium", NULL);
     p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = X265_CSP_I400;
-    p->bEnableWeightedPred = 0; p->bEnableWeightedBiPred = 0; p->bEnableHME = 0; p->lookaheadSlices = 0;
-    p->rc.aqMode = aq ? X265_AQ_VARIANCE : X265_AQ_NONE; p->rc.cuTree = 0; p->bEnableTemporalFilter = 0;
+    const bool weightp = (aq & 2) != 0;            /* aq argument: bit 0 = AQ factors, bit 1 = weighted prediction analysis (weightsAnalyse) */
+    p->bEnableWeightedPred = weightp; p->bEnableWeightedBiPred = 0; p->bEnableHME = 0; p->lookaheadSlices = 0;
+    p->rc.aqMode = (aq & 1) ? X265_AQ_VARIANCE : X265_AQ_NONE; p->rc.cuTree = 0; p->bEnableTemporalFilter = 0;
     p->bHistBasedSceneCut = 0; p->bAQMotion = 0;
     x265_setup_primitives(p);
     MotionEstimate::initScales();
@@ -116,7 +117,15 @@ int main(int argc, char** argv)
         if (!l->create(p, pic, p->rc.qgSize)) { fprintf(stderr, "Lowres::create failed\n"); return 2; }
         l->init(pic, f, false);
         const int ncu = l->maxBlocksInRow * l->maxBlocksInCol;
-        if (aq && l->invQscaleFactor)
+        {   /* what calcAdaptiveQuantFrame leaves for weightsAnalyse (slicetype.cpp:49-57, 727-734): pixel sum and the sum of squares about the mean */
+            uint64_t sum = 0, ssd = 0;
+            for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) { const uint64_t v = pic->m_picOrg[0][(intptr_t)y * pic->m_stride + x]; sum += v; ssd += v * v; }
+            l->wp_sum[0] = sum; l->wp_ssd[0] = ssd - (sum * sum + ((uint64_t)W * H) / 2) / ((uint64_t)W * H);
+            /* weightsAnalyse divides the FULL-resolution sum by the LOWRES area (slicetype.cpp:951-952), which makes its offsets four times too
+               large and weights a rarity; aq bit 2 hands it a quarter of the sum instead so that the weighted search path gets exercised */
+            if (aq & 4) l->wp_sum[0] = sum / 4;
+        }
+        if ((aq & 1) && l->invQscaleFactor)
         {   /* synthetic AQ factors (the AQ analysis itself is floating-point host code outside the path): 8.8 fixed point around 1.0 */
             const int nfull = (p->rc.qgSize > 8) ? ncu : ncu << 2;
             for (int i = 0; i < nfull; i++) l->invQscaleFactor[i] = 160 + ((i * 37 + f * 11) % 200);
@@ -142,7 +151,7 @@ int main(int argc, char** argv)
         std::vector<int32_t> ic(l->intraCost, l->intraCost + ncu), im(ncu), rs(hcu), lc(ncu), q(ncu);
         for (int i = 0; i < ncu; i++) { im[i] = l->intraMode[i]; lc[i] = l->lowresCosts[0][0][i]; }
         for (int i = 0; i < hcu; i++) rs[i] = l->rowSatds[0][0][i];
-        for (int i = 0; i < ncu; i++) q[i] = !(aq && l->invQscaleFactor) ? 256 : (p->rc.qgSize == 8 ? l->invQscaleFactor8x8[i] : l->invQscaleFactor[i]);
+        for (int i = 0; i < ncu; i++) q[i] = !l->invQscaleFactor ? -1 /* no AQ array: costs are not scaled */ : (p->rc.qgSize == 8 ? l->invQscaleFactor8x8[i] : l->invQscaleFactor[i]);
         rec(ic); rec(im); rec(lc); rec(rs); rec(q);
     }
     for (int a = 7; a < argc; a++)
@@ -172,6 +181,23 @@ int main(int argc, char** argv)
         for (int i = 0; i < ncu; i++) lc[i] = fenc->lowresCosts[b - p0][p1 - b][i];
         for (int i = 0; i < hcu; i++) rs[i] = fenc->rowSatds[b - p0][p1 - b][i];
         rec(lc); rec(rs);
+        if (weightp)
+        {   /* did weightsAnalyse (slicetype.cpp:919-1020) weight the list-0 reference, and with which planes */
+            ReferencePlanes& wr = fenc->weightedRef[b - p0];
+            const int isW = wr.isWeighted ? 1 : 0;
+            rec({ isW });
+            if (isW)
+            {
+                const size_t planesize = (size_t)fenc->lumaStride * (fenc->lines + 2 * marginY);
+                for (int k = 0; k < 4; k++)
+                {
+                    const pixel* base = wr.lowresPlane[k] - ((intptr_t)fenc->lumaStride * marginY + marginX);
+                    std::vector<int32_t> v(planesize);
+                    for (size_t i = 0; i < planesize; i++) v[i] = base[i];
+                    rec(v);
+                }
+            }
+        }
         if (prop)
         {
             uint32_t st = 2463534242u + 7919u * (uint32_t)seed;

@@ -234,7 +234,7 @@ static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, mv
 }
 
 /* slicetype.cpp:4365-4463 (serial branch) + :4467-4640 */
-void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, intptr_t stride,
+void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, const xo_pixel* const* ref0w, intptr_t stride,
                           int wcu, int hcu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
                           int doSearch0, int doSearch1, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
                           int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
@@ -243,7 +243,8 @@ void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref
     const int doSearch[2] = { doSearch0, doSearch1 };
     int32_t* const mvs[2] = { mvs0, mvs1 };
     int32_t* const mvCosts[2] = { mvCosts0, mvCosts1 };
-    const xo_pixel* const* const refs[2] = { ref0, ref1 };
+    /* list 0 is SEARCHED in the weighted copy of p0 when weightsAnalyse made one (wfref0, :4474); the bidirectional average uses p0 itself */
+    const xo_pixel* const* const refs[2] = { ref0w ? ref0w : ref0, ref1 };
     int64_t costEst = 0, costEstAq = 0, intraMbs = 0;
     const int lowresPenalty = 4, merange = 16;                                                   /* slicetype.h:337 s_merange */
     for (int cuY = hcu - 1; cuY >= 0; cuY--)

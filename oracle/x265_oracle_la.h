@@ -14,11 +14,12 @@ void xo_lowres_intra_estimate(const xo_pixel* plane0, intptr_t stride, int width
                               int32_t* intraCost, int32_t* intraMode, int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
 
 /* Frame cost of one (p0, b, p1) choice (slicetype.cpp:4365-4640, serial loops, no HME / weightp / slices).
- * ref0 / ref1 = the four half-pel planes (pixel (0,0) each) of frames p0 / p1; ref1 = NULL for a P estimate (b == p1).
+ * ref0 / ref1 = the four half-pel planes (pixel (0,0) each) of frames p0 / p1; ref1 = NULL for a P estimate (b == p1);
+ * ref0w = the weighted copy of p0's planes list 0 is searched in (LookaheadTLD::weightsAnalyse, slicetype.cpp:919-1020) or NULL.
  * mvsN (x,y pairs, quarter-pel) and mvCostsN are in/out: read when doSearchN == 0 (results cached by an earlier estimate
  * with the same reference distance), written otherwise.  sums = { costEst (before the B normalisation :4456-4457),
  * costEstAq, intraMbs }. */
-void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, intptr_t stride,
+void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, const xo_pixel* const* ref0w, intptr_t stride,
                           int widthInCU, int heightInCU, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
                           int doSearch0, int doSearch1, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
                           int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums);

@@ -93,7 +93,7 @@ def lookahead_cost_row(ora, half=1 << 13):
     return ora.mvcost_row(int(ora.me_lib.xo_lookahead_qp()), half), half
 
 
-def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost, inv_q, state=None, do_search=(1, 1)):
+def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost, inv_q, state=None, do_search=(1, 1), ref0w_planes=None):
     """state = dict(mvs0, mvc0, mvs1, mvc1) carried between estimates that share a reference distance (in/out)"""
     L = ora.me_lib
     row, half = lookahead_cost_row(ora)
@@ -104,7 +104,8 @@ def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost,
     VP = C.c_void_p * 4
     r0 = VP(*[ref0_planes[k].ctypes.data + g.origin * ref0_planes.itemsize for k in range(4)])
     r1 = VP(*[ref1_planes[k].ctypes.data + g.origin * ref1_planes.itemsize for k in range(4)]) if ref1_planes is not None else None
-    L.xo_lowres_frame_cost(_P(fenc_planes[0], g.origin), r0, r1, C.c_ssize_t(g.stride), g.wcu, g.hcu, _P(intra_cost),
+    rw = VP(*[ref0w_planes[k].ctypes.data + g.origin * ref0w_planes.itemsize for k in range(4)]) if ref0w_planes is not None else None
+    L.xo_lowres_frame_cost(_P(fenc_planes[0], g.origin), r0, r1, rw, C.c_ssize_t(g.stride), g.wcu, g.hcu, _P(intra_cost),
                            _P(inv_q) if inv_q is not None else None, _P(row, half), int(do_search[0]), int(do_search[1]),
                            _P(st["mvs0"]), _P(st["mvc0"]), _P(st["mvs1"]), _P(st["mvc1"]), _P(lc), _P(rs), _P(sums))
     return dict(mvs0=st["mvs0"].copy(), mvc0=st["mvc0"].copy(), mvs1=st["mvs1"].copy(), mvc1=st["mvc1"].copy(), lowresCosts=lc, rowSatds=rs,
@@ -117,7 +118,7 @@ def run_reference(depth, frames, triples, aq):
     with tempfile.TemporaryDirectory() as td:
         inp, out = os.path.join(td, "in.raw"), os.path.join(td, "out.bin")
         np.stack(frames).tofile(inp)
-        args = [la_bin(depth), str(W), str(H), str(len(frames)), inp, out, "1" if aq else "0"] + \
+        args = [la_bin(depth), str(W), str(H), str(len(frames)), inp, out, str(int(aq))] + \
                [("prop:" + ",".join(str(v) for v in t[1:])) if t[0] == "prop" else ",".join(str(v) for v in t) for t in triples]
         r = subprocess.run(args, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -138,6 +139,10 @@ def run_reference(depth, frames, triples, aq):
         d = dict(p0=t[0], b=t[1], p1=t[2], keep=t[3], doSearch=(t[4], t[5]), score=t[6], costEstNorm=t[7], costEstAq=t[8], intraMbs=t[9],
                  mvs0=recs[i + 1], mvc0=recs[i + 2], mvs1=recs[i + 3], mvc1=recs[i + 4], lowresCosts=recs[i + 5], rowSatds=recs[i + 6])
         i += 7
+        if int(aq) & 2:                          # weightp: flag, then the four weighted planes when weightsAnalyse chose weights
+            d["isWeighted"] = int(recs[i][0]); i += 1
+            if d["isWeighted"]:
+                d["wplanes"] = np.stack(recs[i:i + 4]); i += 4
         if tr[0] == "prop":                      # + header (referenced, seed, fpsFactor bits, weightb) and before / after of propB, prop0, prop1
             ph = recs[i]
             d["prop"] = dict(referenced=int(ph[0]), seed=int(ph[1]), fpsFactor=float(np.array([ph[2], ph[3]], np.int32).view(np.float64)[0]), weightb=int(ph[4]),

@@ -146,3 +146,44 @@ def test_cutree_propagate_matches_oracle(depth):
                 assert np.array_equal(got[p1], exp[2]), "cuTree step of %s: list-1 reference" % ((p0, b, p1),)
             untouched = [f for f in range(N) if f not in (p0, b, p1)]
             assert all(np.array_equal(got[f], prop[f]) for f in untouched)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_lookahead_weighted_list0_reference(depth):
+    """x265hip_la_task.weighted0: list 0 searched in a weighted copy of p0 (an extra picture of the lowres buffer), the bidirectional average in p0 itself"""
+    api, ora = FrameApi(depth), Oracle(depth)
+    t = api.torch
+    W, H, N = 208, 136, 3
+    frames = synth_clip(W, H, N, depth, seed=11 + depth, shift=(4, -2))
+    g = Geometry(W, H)
+    planes = [lowres_planes_oracle(ora, f, g) for f in frames]
+    pm = (1 << depth) - 1
+    wplanes = np.clip(planes[0].astype(np.int64) * 3 // 4 + 9 * (1 << (depth - 8)), 0, pm).astype(planes[0].dtype)     # stands for weight_pp(scale 96/128, offset 9)
+    allp = np.stack(planes + [wplanes])                                                                                  # picture N = the weighted copy of picture 0
+    d_low = api.to_device(allp.reshape(-1))
+    intra = [oracle_intra(ora, planes[f], g, None) for f in range(N)]
+    d_ic = api.to_device(np.stack([i["intraCost"] for i in intra]).reshape(-1))
+    row, half = lookahead_cost_row(ora)
+    d_row = api.to_device(row.view(np.int16))
+    est = [(0, 1, 1), (0, 1, 2), (0, 2, 2)]
+    tasks = np.zeros(len(est), LA_TASK)
+    for i, (p0, b, p1) in enumerate(est):
+        tasks[i]["p0"], tasks[i]["b"], tasks[i]["p1"] = p0, b, p1
+        tasks[i]["doSearch"] = (1, 1 if p1 > b else 0); tasks[i]["mvSlot"] = (2 * i, 2 * i + 1); tasks[i]["outSlot"] = i
+        tasks[i]["weighted0"] = N + 1
+    d_tasks = api.to_device(tasks)
+    d_mvs = t.zeros(2 * len(est) * g.ncu * 2, dtype=t.int16, device="cuda"); d_mvc = t.zeros(2 * len(est) * g.ncu, dtype=t.int32, device="cuda")
+    d_lc = t.zeros(len(est) * g.ncu, dtype=t.int16, device="cuda"); d_rs = t.zeros(len(est) * g.hcu, dtype=t.int32, device="cuda")
+    d_sm = t.zeros(len(est) * 3, dtype=t.int64, device="cuda")
+    api.lookahead_cost_batch(d_low, g.plane_elems, g.stride, g.origin, g.wcu, g.hcu, d_tasks, len(est), d_ic, None, d_row, half, d_mvs, d_mvc, d_lc, d_rs, d_sm)
+    t.cuda.synchronize()
+    mvs = d_mvs.cpu().numpy().reshape(-1, g.ncu * 2).astype(np.int32); mvc = d_mvc.cpu().numpy().reshape(-1, g.ncu)
+    lc = d_lc.cpu().numpy().view(np.uint16).reshape(-1, g.ncu); sm = d_sm.cpu().numpy().reshape(-1, 3)
+    for i, (p0, b, p1) in enumerate(est):
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], None, {}, (1, 1), ref0w_planes=wplanes)
+        plain = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], None, {}, (1, 1))
+        assert not np.array_equal(o["mvc0"], plain["mvc0"])                      # the weighted copy really changes the search
+        assert np.array_equal(mvs[2 * i], o["mvs0"]) and np.array_equal(mvc[2 * i], o["mvc0"]) and np.array_equal(lc[i], o["lowresCosts"])
+        if p1 > b:
+            assert np.array_equal(mvs[2 * i + 1], o["mvs1"]) and np.array_equal(mvc[2 * i + 1], o["mvc1"])
+        assert [int(v) for v in sm[i]] == [o["costEst"], o["costEstAq"], o["intraMbs"]]

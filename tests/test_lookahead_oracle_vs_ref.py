@@ -79,3 +79,47 @@ def test_cutree_propagate_matches_reference(depth, size, shift):
                                ref_frames[b]["invQ"], rt["mvs0"], rt["mvs1"] if p1 > b else None, pb, a0, a1)
         for k, name in enumerate(("b", "p0", "p1")):
             assert np.array_equal(got[k].astype(np.int32), pr["after"][k]), "propagateCost of %s after %s" % (name, t)
+
+
+def fade_clip(W, H, n, depth, seed):
+    """a static rough texture (expensive to predict intra) fading towards a flat grey, scale AND offset changing per picture, plus a little
+    noise: LookaheadTLD::weightsAnalyse (slicetype.cpp:919-1020) chooses weights for most reference distances"""
+    rng = np.random.default_rng(seed)
+    pm = (1 << depth) - 1
+    tex = rng.random((H, W))
+    tex = (tex + np.roll(tex, 1, 0) + np.roll(tex, 1, 1)) / 3
+    out = []
+    for f in range(n):
+        a = 1.0 - 0.2 * f
+        fr = (tex * a + (1 - a) * 0.55) * pm + rng.normal(0, 1.0 * (1 << (depth - 8)), (H, W))
+        out.append(np.clip(np.rint(fr), 0, pm).astype(np.uint8 if depth == 8 else np.uint16))
+    return out
+
+
+WP_TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 1, 2, 0), (1, 2, 3, 0), (0, 3, 3, 0), (1, 3, 3, 0)]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size", [(192, 144), (208, 120)])
+def test_lookahead_cost_with_weighted_reference_matches_reference(depth, size):
+    """--weightp (on by default): P and B estimates whose list-0 search runs in the weighted copy of p0 the reference built"""
+    if not la_available(depth):
+        pytest.skip("no reference lookahead binary")
+    W, H = size
+    frames = fade_clip(W, H, 4, depth, seed=40 + depth + W)
+    hdr, ref_frames, ref_triples = run_reference(depth, frames, WP_TRIPLES, 6)      # weightp + the quarter-sum input (see ref_lookahead.cpp)
+    assert sum(rt["isWeighted"] for rt in ref_triples) >= 3, "the clip must make the reference choose weights"
+    ora = Oracle(depth)
+    g = Geometry(W, H)
+    planes = [lowres_planes_oracle(ora, fr, g) for fr in frames]
+    # with weightp the reference allocates the AQ factor array (all zero without an AQ pass): the AQ-scaled outputs use it as it is
+    inv_q = [f["invQ"] if f["invQ"][0] >= 0 else None for f in ref_frames]
+    intra = [oracle_intra(ora, pl, g, q) for pl, q in zip(planes, inv_q)]
+    for t, rt in zip(WP_TRIPLES, ref_triples):
+        p0, b, p1, _ = t
+        wpl = rt["wplanes"].astype(planes[0].dtype) if rt["isWeighted"] else None
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], inv_q[b], {}, (1, 1), ref0w_planes=wpl)
+        for k in ("mvs0", "mvc0", "lowresCosts", "rowSatds") + (("mvs1", "mvc1") if p1 > b else ()):
+            assert np.array_equal(o[k], rt[k]), "%s of estimate %s (weighted %d)" % (k, t, rt["isWeighted"])
+        norm = o["costEst"] * 100 // 130 if p1 > b else o["costEst"]
+        assert (norm, o["costEstAq"]) == (rt["costEstNorm"], rt["costEstAq"])

@@ -358,7 +358,8 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
     const int slot = tp->mvSlot[list];
     uint32_t* mv = mvs + (int64_t)slot * ncu;
     int32_t* mvCost = mvCosts + (int64_t)slot * ncu;
-    const int refFrame = list ? tp1 : tp0;
+    const int w0 = tp->weighted0;
+    const int refFrame = list ? tp1 : (w0 > 0 ? w0 - 1 : tp0);
     extern __shared__ uint16_t s_cost[];                       // 2 * costR + 1 entries of the cost row
     for (int i = threadIdx.x; i <= 2 * costR; i += blockDim.x) s_cost[i] = costCentre[i - costR];
     __syncthreads();
@@ -785,7 +786,8 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
         for (const auto& t : h)
         {
             if (t.p0 < 0 || t.p0 > t.b || t.b > t.p1) { set_error("lookahead_cost_batch: estimate (%d, %d, %d) is not ordered p0 <= b <= p1", t.p0, t.b, t.p1); return X265HIP_EARG; }
-            maxFrame = std::max(maxFrame, t.p1);
+            if (t.weighted0 < 0) { set_error("lookahead_cost_batch: bad weighted0"); return X265HIP_EARG; }
+            maxFrame = std::max(maxFrame, std::max(t.p1, t.weighted0 - 1));
         }
     }
     if (((int64_t)maxFrame + 1) * 4 * planeElems >= ((int64_t)1 << 31)) { set_error("lookahead_cost_batch: lowres buffer beyond 2^31 elements"); return X265HIP_EARG; }
