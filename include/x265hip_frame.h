@@ -135,7 +135,7 @@ int x265hip_me_batch_sea(void* stream, int w, int h, const void* curPlane, intpt
  * x265hip_lookahead_intra_batch  replaces LookaheadTLD::lowresIntraEstimate (slicetype.cpp:755-864) for nFrames pictures:
  *   intraCost / intraMode / lowresCosts are nFrames x ncu, rowSatds nFrames x heightInCU, sums nFrames x { costEst, costEstAq }.
  * x265hip_lookahead_cost_batch   replaces CostEstimateGroup::estimateFrameCost (slicetype.cpp:4365-4463, serial branch; no
- *   HME, no weighted reference, no slices) with estimateCUCost (:4467-4640) for nTasks (p0, b, p1) choices at once.
+ *   HME, no slices; weighted list-0 reference through x265hip_la_task.weighted0) with estimateCUCost (:4467-4640) for nTasks (p0, b, p1) choices at once.
  *   invQscale: nFrames x ncu 8.8 fixed-point AQ factors (Lowres::invQscaleFactor / invQscaleFactor8x8) or NULL.
  *   costRow: the row of x265hip_mvcost_row(x265hip_lookahead_qp(), ...), costHalfRange >= 4 * (8 * max(wcu, hcu) + 32).
  *   mvs (int16 x, y per block) and mvCosts are arrays of ncu-long SLOTS, the device form of Lowres::lowresMvs[list][dist] /

@@ -3,7 +3,7 @@
  *
  * CPU restatement of the reference's LOOKAHEAD frame-cost path on half-resolution ("lowres") pictures:
  *   - LookaheadTLD::lowresIntraEstimate              (encoder/slicetype.cpp:755-864)
- *   - CostEstimateGroup::estimateFrameCost, serial   (encoder/slicetype.cpp:4365-4463; no HME, no weightp, no slices)
+ *   - CostEstimateGroup::estimateFrameCost, serial   (encoder/slicetype.cpp:4365-4463; no HME, no slices; weightsAnalyse itself stays outside, its weighted planes come in as ref0w)
  *   - CostEstimateGroup::estimateCUCost              (encoder/slicetype.cpp:4467-4640)
  *   - MotionEstimate::motionEstimate, ref->isLowres  (encoder/motion.cpp:923-1140 HEX, :1644-1773 with the lowres branch :1667-1699)
  *   - ReferencePlanes::lowresMC / lowresQPelCost     (common/lowres.h:75-124)
