@@ -136,6 +136,8 @@ int x265hip_me_batch_sea(void* stream, int w, int h, const void* curPlane, intpt
  *   intraCost / intraMode / lowresCosts are nFrames x ncu, rowSatds nFrames x heightInCU, sums nFrames x { costEst, costEstAq }.
  * x265hip_lookahead_cost_batch   replaces CostEstimateGroup::estimateFrameCost (slicetype.cpp:4365-4463, serial branch; no
  *   HME, no slices; weighted list-0 reference through x265hip_la_task.weighted0) with estimateCUCost (:4467-4640) for nTasks (p0, b, p1) choices at once.
+ *   rowsPerSlice: 0 = the serial sweep of estimateFrameCost; > 0 = Lookahead::m_numRowsPerSlice of the cooperative --lookahead-slices branch
+ *   (slicetype.cpp:1173-1176, 4347-4357, 4394-4426): each slice of that many block rows (the last one with the remainder) is swept on its own.
  *   invQscale: nFrames x ncu 8.8 fixed-point AQ factors (Lowres::invQscaleFactor / invQscaleFactor8x8) or NULL.
  *   costRow: the row of x265hip_mvcost_row(x265hip_lookahead_qp(), ...), costHalfRange >= 4 * (8 * max(wcu, hcu) + 32).
  *   mvs (int16 x, y per block) and mvCosts are arrays of ncu-long SLOTS, the device form of Lowres::lowresMvs[list][dist] /
@@ -159,7 +161,7 @@ int x265hip_lookahead_intra_batch(void* stream, const void* lowres, int64_t plan
                                   int32_t* rowSatds, int64_t* sums);
 int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
                                  const x265hip_la_task* tasks, int nTasks, const int32_t* intraCost, const int32_t* invQscale,
-                                 const uint16_t* costRow, int costHalfRange, int16_t* mvs, int32_t* mvCosts,
+                                 const uint16_t* costRow, int costHalfRange, int rowsPerSlice, int16_t* mvs, int32_t* mvCosts,
                                  uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
 
 /* cuTree: one propagation step (Lookahead::estimateCUPropagate, slicetype.cpp:3850-3953, with primitives.propagateCost, pixel.cpp:906-931)

@@ -15,6 +15,7 @@
  *
  * usage: x265la_<depth> <width> <height> <nframes> <in.raw> <out.bin> <aq 0|1> [p0,b,p1[,keep] | prop:p0,b,p1,referenced,seed ...]
  *   in.raw  : nframes luma planes, width x height pixels each (u8 / u16), no padding
+ *   p0,b,p1,keep,rows : a fifth value > 0 = cooperative lookahead slices of that many block rows (--lookahead-slices, slicetype.cpp:1173-1176)
  *   triples : indices into the frame list, p0 <= b <= p1; "keep" = 1 leaves the MV caches of frame b as the previous
  *             triples left them (bDoSearch then follows the reference's own rule, slicetype.cpp:4376-4377), 0 resets them
  *   prop:   : the estimate (caches reset), then Lookahead::estimateCUPropagate(frames, 0.05, p0, p1, b, referenced) (slicetype.cpp:3850-3953)
@@ -56,6 +57,38 @@ struct LA : public Lookahead
 struct Group : public CostEstimateGroup
 {
     Group(Lookahead& l, Lowres** f) : CostEstimateGroup(l, f) {}
+    /* The cooperative-slices branch of estimateFrameCost (slicetype.cpp:4394-4426) with its per-slice row loops (processTasks, :4347-4357) run in
+     * this thread: the reference distributes the slices over pool workers, which this harness does not have; every block goes through the
+     * reference's own estimateCUCost.  rowsPerSlice = Lookahead::m_numRowsPerSlice (:1173-1176). */
+    int64_t slicedCost(LookaheadTLD& tld, int p0, int p1, int b, int rowsPerSlice)
+    {
+        Lowres* fenc = m_frames[b];
+        bool bDoSearch[2] = { fenc->lowresMvs[0][b - p0][0].x == 0x7FFF, p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF };
+        fenc->weightedRef[b - p0].isWeighted = false;
+        fenc->costEst[b - p0][p1 - b] = 0; fenc->costEstAq[b - p0][p1 - b] = 0;
+        const int H = m_lookahead.m_8x8Height, W = m_lookahead.m_8x8Width, nslices = H / rowsPerSlice;
+        memset(&m_slice, 0, sizeof(Slice) * nslices);
+        for (int i = 0; i < nslices; i++)
+        {
+            const int firstY = rowsPerSlice * i, lastY = (i == nslices - 1) ? H - 1 : rowsPerSlice * (i + 1) - 1;
+            bool lastRow = true;
+            for (int cuY = lastY; cuY >= firstY; cuY--)
+            {
+                fenc->rowSatds[b - p0][p1 - b][cuY] = 0;
+                for (int cuX = W - 1; cuX >= 0; cuX--) estimateCUCost(tld, cuX, cuY, p0, p1, b, bDoSearch, lastRow, i, 0);
+                lastRow = false;
+            }
+        }
+        for (int i = 0; i < nslices; i++)
+        {
+            fenc->costEst[b - p0][p1 - b] += m_slice[i].costEst; fenc->costEstAq[b - p0][p1 - b] += m_slice[i].costEstAq;
+            if (p1 == b) fenc->intraMbs[b - p0] += m_slice[i].intraMbs;
+        }
+        int64_t score = fenc->costEst[b - p0][p1 - b];
+        if (b != p1) score = score * 100 / (130 + m_lookahead.m_param->bFrameBias);
+        fenc->costEst[b - p0][p1 - b] = score;
+        return score;
+    }
 };
 
 static void resetCaches(Lowres& f, int bframes)
@@ -156,16 +189,16 @@ int main(int argc, char** argv)
     }
     for (int a = 7; a < argc; a++)
     {
-        int p0, b, p1, keep = 0, referenced = 0, seed = 0;
+        int p0, b, p1, keep = 0, referenced = 0, seed = 0, sliceRows = 0;
         const bool prop = !strncmp(argv[a], "prop:", 5);
         if (prop) { if (sscanf(argv[a] + 5, "%d,%d,%d,%d,%d", &p0, &b, &p1, &referenced, &seed) < 5) { fprintf(stderr, "bad prop %s\n", argv[a]); return 2; } }
-        else if (sscanf(argv[a], "%d,%d,%d,%d", &p0, &b, &p1, &keep) < 3) { fprintf(stderr, "bad triple %s\n", argv[a]); return 2; }
+        else if (sscanf(argv[a], "%d,%d,%d,%d,%d", &p0, &b, &p1, &keep, &sliceRows) < 3) { fprintf(stderr, "bad triple %s\n", argv[a]); return 2; }
         Lowres* fenc = low[b];
         if (!keep) resetCaches(*fenc, p->bframes);
         const int doSearch0 = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF, doSearch1 = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
         Group g(la, low.data());
         const auto t0 = std::chrono::steady_clock::now();
-        const int64_t score = g.singleCost(p0, p1, b, false);
+        const int64_t score = sliceRows > 0 ? g.slicedCost(tld, p0, p1, b, sliceRows) : g.singleCost(p0, p1, b, false);
         nsCost += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         rec({ p0, b, p1, keep, doSearch0, doSearch1, (int32_t)score, (int32_t)fenc->costEst[b - p0][p1 - b], (int32_t)fenc->costEstAq[b - p0][p1 - b],
               fenc->intraMbs[b - p0] });

@@ -236,7 +236,7 @@ static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, mv
 /* slicetype.cpp:4365-4463 (serial branch) + :4467-4640 */
 void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, const xo_pixel* const* ref0w, intptr_t stride,
                           int wcu, int hcu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
-                          int doSearch0, int doSearch1, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                          int doSearch0, int doSearch1, int rowsPerSlice, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
                           int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
 {
     const int bBidir = ref1 != NULL;
@@ -247,9 +247,13 @@ void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref
     const xo_pixel* const* const refs[2] = { ref0w ? ref0w : ref0, ref1 };
     int64_t costEst = 0, costEstAq = 0, intraMbs = 0;
     const int lowresPenalty = 4, merange = 16;                                                   /* slicetype.h:337 s_merange */
+    /* cooperative slices (--lookahead-slices, :1173-1176, 4347-4357): slice i covers rowsPerSlice block rows (the last one the remainder too) and
+       starts its reverse sweep with lastRow = true, i.e. no predictor crosses its lower edge; the frame totals are the sums over the slices */
+    const int rps = rowsPerSlice > 0 ? rowsPerSlice : hcu, nslices = hcu / rps;
     for (int cuY = hcu - 1; cuY >= 0; cuY--)
     {
-        const int lastRow = cuY == hcu - 1;
+        const int sl = cuY / rps < nslices - 1 ? cuY / rps : nslices - 1;
+        const int lastRow = cuY == (sl == nslices - 1 ? hcu - 1 : rps * (sl + 1) - 1);
         rowSatds[cuY] = 0;
         for (int cuX = wcu - 1; cuX >= 0; cuX--)
         {

@@ -21,7 +21,7 @@ void xo_lowres_intra_estimate(const xo_pixel* plane0, intptr_t stride, int width
  * costEstAq, intraMbs }. */
 void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, const xo_pixel* const* ref0w, intptr_t stride,
                           int widthInCU, int heightInCU, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
-                          int doSearch0, int doSearch1, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                          int doSearch0, int doSearch1, int rowsPerSlice /* 0 = one slice; Lookahead::m_numRowsPerSlice */, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
                           int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
 /* cuTree (slicetype.cpp:3850-3953): propagate the cost of picture b into its references; see x265_oracle_la.c */
 void xo_cu_propagate_cost(int32_t* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,

@@ -93,7 +93,7 @@ def lookahead_cost_row(ora, half=1 << 13):
     return ora.mvcost_row(int(ora.me_lib.xo_lookahead_qp()), half), half
 
 
-def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost, inv_q, state=None, do_search=(1, 1), ref0w_planes=None):
+def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost, inv_q, state=None, do_search=(1, 1), ref0w_planes=None, rows_per_slice=0):
     """state = dict(mvs0, mvc0, mvs1, mvc1) carried between estimates that share a reference distance (in/out)"""
     L = ora.me_lib
     row, half = lookahead_cost_row(ora)
@@ -106,7 +106,7 @@ def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost,
     r1 = VP(*[ref1_planes[k].ctypes.data + g.origin * ref1_planes.itemsize for k in range(4)]) if ref1_planes is not None else None
     rw = VP(*[ref0w_planes[k].ctypes.data + g.origin * ref0w_planes.itemsize for k in range(4)]) if ref0w_planes is not None else None
     L.xo_lowres_frame_cost(_P(fenc_planes[0], g.origin), r0, r1, rw, C.c_ssize_t(g.stride), g.wcu, g.hcu, _P(intra_cost),
-                           _P(inv_q) if inv_q is not None else None, _P(row, half), int(do_search[0]), int(do_search[1]),
+                           _P(inv_q) if inv_q is not None else None, _P(row, half), int(do_search[0]), int(do_search[1]), int(rows_per_slice),
                            _P(st["mvs0"]), _P(st["mvc0"]), _P(st["mvs1"]), _P(st["mvc1"]), _P(lc), _P(rs), _P(sums))
     return dict(mvs0=st["mvs0"].copy(), mvc0=st["mvc0"].copy(), mvs1=st["mvs1"].copy(), mvc1=st["mvc1"].copy(), lowresCosts=lc, rowSatds=rs,
                 costEst=int(sums[0]), costEstAq=int(sums[1]), intraMbs=int(sums[2]))

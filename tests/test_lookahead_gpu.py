@@ -187,3 +187,29 @@ def test_lookahead_weighted_list0_reference(depth):
         if p1 > b:
             assert np.array_equal(mvs[2 * i + 1], o["mvs1"]) and np.array_equal(mvc[2 * i + 1], o["mvc1"])
         assert [int(v) for v in sm[i]] == [o["costEst"], o["costEstAq"], o["intraMbs"]]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,rows", [((208, 184), 5), ((320, 256), 10), ((192, 144), 3), ((192, 144), 9)])
+def test_lookahead_slices_match_oracle(depth, size, rows):
+    """cooperative lookahead slices (rowsPerSlice): every slice swept by its own workgroup"""
+    from x265hip_pkg.lookahead import LookaheadBatch
+    ora = Oracle(depth)
+    W, H = size
+    N = 3
+    frames = synth_clip(W, H, N, depth, seed=21 + depth + W + rows, shift=(-3, 5))
+    est = [(0, 1, 1), (0, 1, 2), (0, 2, 2), (1, 2, 2)]
+    lb = LookaheadBatch(depth, W, H, N, len(est))
+    t, g = lb.t, lb.g
+    lb.upload(frames); lb.build_lowres(); lb.intra(); lb.set_estimates(est); lb.costs(rows_per_slice=rows); t.cuda.synchronize()
+    planes = [lowres_planes_oracle(ora, f, g) for f in frames]
+    ic = lb.d_intra_cost.cpu().numpy().reshape(N, g.ncu)
+    mvs = lb.d_mvs.cpu().numpy().reshape(-1, 2 * g.ncu).astype(np.int32); mvc = lb.d_mv_costs.cpu().numpy().reshape(-1, g.ncu)
+    lc = lb.d_lc.cpu().numpy().view(np.uint16).reshape(-1, g.ncu); rs = lb.d_rows.cpu().numpy().reshape(-1, g.hcu); sm = lb.d_sums.cpu().numpy().reshape(-1, 3)
+    for i, (p0, b, p1) in enumerate(est):
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, ic[b], None, {}, (1, 1), rows_per_slice=rows)
+        assert np.array_equal(mvs[2 * i], o["mvs0"]) and np.array_equal(mvc[2 * i], o["mvc0"]), "list 0 of %s" % ((p0, b, p1),)
+        if p1 > b:
+            assert np.array_equal(mvs[2 * i + 1], o["mvs1"]) and np.array_equal(mvc[2 * i + 1], o["mvc1"])
+        assert np.array_equal(lc[i], o["lowresCosts"]) and np.array_equal(rs[i], o["rowSatds"])
+        assert [int(v) for v in sm[i]] == [o["costEst"], o["costEstAq"], o["intraMbs"]]

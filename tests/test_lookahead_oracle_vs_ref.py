@@ -123,3 +123,32 @@ def test_lookahead_cost_with_weighted_reference_matches_reference(depth, size):
             assert np.array_equal(o[k], rt[k]), "%s of estimate %s (weighted %d)" % (k, t, rt["isWeighted"])
         norm = o["costEst"] * 100 // 130 if p1 > b else o["costEst"]
         assert (norm, o["costEstAq"]) == (rt["costEstNorm"], rt["costEstAq"])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,rows,aq", [((192, 144), 3, 0), ((208, 184), 5, 1), ((320, 256), 10, 1), ((192, 144), 9, 0)])
+def test_lookahead_cost_with_slices_matches_reference(depth, size, rows, aq):
+    """--lookahead-slices: every slice of `rows` block rows is its own reverse sweep (no predictor crosses its lower edge)"""
+    if not la_available(depth):
+        pytest.skip("no reference lookahead binary")
+    W, H = size
+    frames = synth_clip(W, H, 3, depth, seed=60 + depth + W + rows, shift=(3, -4))
+    triples = [(0, 1, 1, 0, rows), (0, 1, 2, 0, rows), (0, 2, 2, 0, rows)]
+    hdr, ref_frames, ref_triples = run_reference(depth, frames, triples, aq)
+    ora = Oracle(depth)
+    g = Geometry(W, H)
+    planes = [lowres_planes_oracle(ora, fr, g) for fr in frames]
+    inv_q = [f["invQ"] if aq else None for f in ref_frames]
+    intra = [oracle_intra(ora, pl, g, q) for pl, q in zip(planes, inv_q)]
+    for t, rt in zip(triples, ref_triples):
+        p0, b, p1 = t[:3]
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], inv_q[b], {}, (1, 1), rows_per_slice=rows)
+        whole = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], inv_q[b], {}, (1, 1))
+        if g.hcu // rows > 1:
+            assert not np.array_equal(o["mvc0"], whole["mvc0"])                 # the slicing changes predictors at the slice edges
+        for k in ("mvs0", "mvc0", "lowresCosts", "rowSatds") + (("mvs1", "mvc1") if p1 > b else ()):
+            assert np.array_equal(o[k], rt[k]), "%s of estimate %s in slices of %d rows" % (k, t, rows)
+        norm = o["costEst"] * 100 // 130 if p1 > b else o["costEst"]
+        assert (norm, o["costEstAq"]) == (rt["costEstNorm"], rt["costEstAq"])
+        if p1 == b:
+            assert o["intraMbs"] == rt["intraMbs"]

@@ -345,7 +345,7 @@ __device__ __forceinline__ uint32_t plane0_off(const LaGeom& g, int frame) { ret
 __device__ __forceinline__ uint32_t ld_mv(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void st_mv(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint16_t* __restrict__ costCentre, int costR,
+__global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint16_t* __restrict__ costCentre, int costR, int rowsPerSlice,
                                                          uint32_t* mvs, int32_t* mvCosts)
 {
     const x265hip_la_task* tp = tasks + (blockIdx.x >> 1);
@@ -366,14 +366,18 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
     const uint32_t fencPlane = plane0_off(g, tb), rp = plane0_off(g, refFrame);
     const int stride = (int)g.stride;
 
-    const int steps = W + 2 * (H - 1);
+    // cooperative slices (--lookahead-slices, slicetype.cpp:1173-1176, 4347-4357): blockIdx.y = slice; a slice is its own sweep, its bottom row
+    // takes no predictors from below (lastRow), the last slice also takes the remainder rows
+    const int nslices = H / rowsPerSlice, sl = blockIdx.y;
+    const int firstY = sl * rowsPerSlice, lastY = sl == nslices - 1 ? H - 1 : firstY + rowsPerSlice - 1, HS = lastY - firstY + 1;
+    const int steps = W + 2 * (HS - 1);
     for (int s = 0; s < steps; s++)
     {
-        const int jmin = max(0, (s - W + 2) >> 1), jmax = min(H - 1, s >> 1);
+        const int jmin = max(0, (s - W + 2) >> 1), jmax = min(HS - 1, s >> 1);
         for (int j = jmin + grp; j <= jmax; j += ngrp)
         {
-            const int cuY = H - 1 - j, cuX = W - 1 - (s - 2 * j), cuXY = cuX + cuY * W;
-            const bool lastRow = cuY == H - 1;
+            const int cuY = lastY - j, cuX = W - 1 - (s - 2 * j), cuXY = cuX + cuY * W;
+            const bool lastRow = j == 0;
             const uint32_t pel = (uint32_t)(CU * cuX + __mul24(CU * cuY + lane, stride));
             Blk c;
             c.lane = lane; c.stride = stride; c.base = g.lowres; c.lcost = s_cost + costR; c.mvpx = 0; c.mvpy = 0;
@@ -768,10 +772,11 @@ extern "C" int x265hip_lookahead_intra_batch(void* stream, const void* lowres, i
 
 extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
                                             const x265hip_la_task* tasks, int nTasks, const int32_t* intraCost, const int32_t* invQscale,
-                                            const uint16_t* costRow, int costHalfRange, int16_t* mvs, int32_t* mvCosts,
+                                            const uint16_t* costRow, int costHalfRange, int rowsPerSlice, int16_t* mvs, int32_t* mvCosts,
                                             uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
 {
     if (nTasks <= 0) return X265HIP_OK;
+    if (rowsPerSlice <= 0 || rowsPerSlice > heightInCU) rowsPerSlice = heightInCU;          // one slice
     if (bad_geom(lowres, planeElems, stride, origin, widthInCU, heightInCU) || !tasks || !intraCost || !costRow || !mvs || !mvCosts || !lowresCosts || !rowSatds || !sums)
     { set_error("lookahead_cost_batch: bad arguments"); return X265HIP_EARG; }
     // every MV and predictor lies within the picture + 8, + one block for the neighbour's own window, + 3 of pattern overshoot: |mvd| < 4 * (size + 32) quarter-pels
@@ -796,7 +801,8 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     hipLaunchKernelGGL(la_zero_kernel, dim3((unsigned)((nTasks * 3 + 255) / 256)), dim3(256), 0, st, tasks, nTasks, (unsigned long long*)sums);
     XH_LAUNCH_CHECK();
     // one 8-lane group per block of the widest wavefront step, in whole wavefronts, at most 1024 threads
-    const int widest = min(heightInCU, (widthInCU + 1) / 2);
+    const int nslices = heightInCU / rowsPerSlice;
+    const int widest = min(rowsPerSlice + heightInCU % rowsPerSlice, (widthInCU + 1) / 2);
     static const int threadCap = getenv("X265HIP_LA_THREADS") ? atoi(getenv("X265HIP_LA_THREADS")) : 1024;   // A/B switch: lane groups per workgroup
     const int threads = min(min(1024, threadCap), max(64, (widest * 8 + 63) / 64 * 64));
     const int costR = 4 * (max(widthInCU, heightInCU) * CU + 32);               // the bound checked above; 2 bytes per entry of LDS
@@ -805,7 +811,7 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     // four times as long as one.  Asking for 56 KB of LDS (of 160 KB per CU) caps the depth at two.
     static const size_t ldsPad = getenv("X265HIP_LA_LDS") ? (size_t)atoi(getenv("X265HIP_LA_LDS")) : 56 * 1024;
     const size_t lds = std::max(sizeof(uint16_t) * (size_t)(2 * costR + 2), ldsPad);
-    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks), dim3(threads), lds, st, g, tasks, costRow + costHalfRange, costR, (uint32_t*)mvs, mvCosts);
+    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts);
     XH_LAUNCH_CHECK();
     hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);

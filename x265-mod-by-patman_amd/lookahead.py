@@ -99,10 +99,12 @@ class LookaheadBatch:
         self.tasks_host = tk
         self.d_tasks = self.api.to_device(tk)
 
-    def costs(self):
+    def costs(self, rows_per_slice=0):
+        """rows_per_slice > 0: the cooperative --lookahead-slices form (every slice its own sweep)"""
         g = self.g
         self.api.lookahead_cost_batch(self.d_low, g.plane_elems, g.stride, g.origin, g.wcu, g.hcu, self.d_tasks, self.n_tasks, self.d_intra_cost,
-                                      self.d_invq, self.d_row, self.half, self.d_mvs, self.d_mv_costs, self.d_lc, self.d_rows, self.d_sums)
+                                      self.d_invq, self.d_row, self.half, self.d_mvs, self.d_mv_costs, self.d_lc, self.d_rows, self.d_sums,
+                                      rows_per_slice=rows_per_slice)
 
     def frame_scores(self, frame_bias=0):
         """int64 scores as estimateFrameCost returns them: costEst, normalised for B estimates (slicetype.cpp:4454-4459)"""
