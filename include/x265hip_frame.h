@@ -180,6 +180,10 @@ int x265hip_cutree_propagate(void* stream, int widthInCU, int heightInCU, int di
 int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
                             int planeOffset, int32_t* out);
 
+/* PSNR numerator of one plane: Encoder::computeSSD (encoder/encoder.cpp:1203-1270), the exact 64-bit sum of squared differences of the source and
+ * the reconstructed plane (width <= 16384).  *out is a device uint64. */
+int x265hip_plane_ssd(void* stream, const void* fenc, const void* recon, intptr_t stride, int width, int height, uint64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -942,3 +942,13 @@ void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t st
         xo_sao_stats(3, diff + startX + startY * 64, rec0 + startX + startY * stride, stride, upBuff1 + 1, NULL, endX - startX, endY - startY, stats + 96, count + 96);
     }
 }
+
+/* Encoder::computeSSD (encoder/encoder.cpp:1203-1270): the sum of squared differences of two planes -- what PSNR is computed from.  Its
+ * block-wise fast path adds the same integers as the "slow path" loop restated here. */
+uint64_t xo_plane_ssd(const xo_pixel* fenc, const xo_pixel* rec, intptr_t stride, int width, int height)
+{
+    uint64_t ssd = 0;
+    for (int y = 0; y < height; y++, fenc += stride, rec += stride)
+        for (int x = 0; x < width; x++) { const int d = (int)fenc[x] - (int)rec[x]; ssd += (uint64_t)(d * d); }
+    return ssd;
+}

@@ -40,3 +40,26 @@ def test_sao_frame_stats_match_oracle(depth, size, ctu, nd, po):
     got = d_out.cpu().numpy().reshape(exp.shape)
     bad = np.argwhere(got != exp)
     assert bad.size == 0, "first mismatch (ctu, which, type, class) %s: hip %d oracle %d" % (bad[0], got[tuple(bad[0])], exp[tuple(bad[0])])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_plane_ssd_matches_oracle(depth):
+    """x265hip_plane_ssd = Encoder::computeSSD (the PSNR numerator): exact 64-bit sums, incl. all-extreme planes"""
+    import ctypes as C
+    from x265hip_pkg.frame import FrameApi
+    api, ora = FrameApi(depth), Oracle(depth)
+    t = api.torch
+    rng = np.random.default_rng(depth)
+    pm = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    ora.lib.xo_plane_ssd.restype = C.c_uint64
+    for (W, H, stride, kind) in ((1920, 1080, 1920, 0), (37, 19, 40, 0), (3840, 2160, 3904, 1), (64, 64, 64, 1), (1, 1, 4, 0)):
+        a = rng.integers(0, pm + 1, stride * H).astype(dt) if kind == 0 else np.zeros(stride * H, dt)
+        b = rng.integers(0, pm + 1, stride * H).astype(dt) if kind == 0 else np.full(stride * H, pm, dt)
+        exp = int(ora.lib.xo_plane_ssd(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), C.c_ssize_t(stride), W, H))
+        assert exp == int(((a.reshape(H, stride)[:, :W].astype(np.int64) - b.reshape(H, stride)[:, :W].astype(np.int64)) ** 2).sum())
+        d_a, d_b = api.to_device(a), api.to_device(b)
+        d_o = t.full((1,), -1, dtype=t.int64, device="cuda")
+        api.h.check(api.lib.x265hip_plane_ssd(api.stream(), C.c_void_p(d_a.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_ssize_t(stride), W, H, C.c_void_p(d_o.data_ptr())))
+        t.cuda.synchronize()
+        assert int(d_o.cpu().numpy().view(np.uint64)[0]) == exp, (W, H)

@@ -238,6 +238,25 @@ __global__ __launch_bounds__(256) void sao_frame_kernel(const pixel* __restrict_
     }
 }
 
+
+// Encoder::computeSSD (encoder/encoder.cpp:1203-1270): sum of squared differences of two planes (PSNR numerator), exact in 64 bits
+__global__ __launch_bounds__(256) void plane_ssd_kernel(const pixel* __restrict__ a, const pixel* __restrict__ b, intptr_t stride, int width, int height, unsigned long long* out)
+{
+    __shared__ unsigned long long s_part[4];
+    unsigned long long acc = 0;
+    for (int y = blockIdx.x; y < height; y += gridDim.x)
+    {
+        const pixel* pa = a + (intptr_t)y * stride; const pixel* pb = b + (intptr_t)y * stride;
+        unsigned rowAcc = 0;                                   // one thread's share of a row: < 2^32 (<= 64 pixels of < 2^20 each for rows up to 16 K pixels)
+        for (int x = threadIdx.x; x < width; x += 256) { const int d = (int)pa[x] - (int)pb[x]; rowAcc += (unsigned)(d * d); }
+        acc += rowAcc;
+    }
+    acc = wave_sum64(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
 } // namespace
 
 // ---- frame_init_lowres_core (pixel.cpp:596-622): one thread per lowres pixel, 3x3 source neighbourhood -> 4 outputs ----
@@ -344,6 +363,16 @@ extern "C" int x265hip_sao_stats_frame(void* stream, const void* fenc, const voi
     { set_error("sao_stats_frame: bad arguments"); return X265HIP_EARG; }
     const int n = ((picWidth + ctuSize - 1) / ctuSize) * ((picHeight + ctuSize - 1) / ctuSize);
     hipLaunchKernelGGL(sao_frame_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_plane_ssd(void* stream, const void* fenc, const void* recon, intptr_t stride, int width, int height, uint64_t* out)
+{
+    if (!fenc || !recon || !out || width < 1 || height < 1 || stride < width || width > 16384) { set_error("plane_ssd: bad arguments"); return X265HIP_EARG; }
+    hipStream_t st = (hipStream_t)stream;
+    XH_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), st));
+    hipLaunchKernelGGL(plane_ssd_kernel, dim3(min(height, 2048)), dim3(256), 0, st, (const pixel*)fenc, (const pixel*)recon, stride, width, height, (unsigned long long*)out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
