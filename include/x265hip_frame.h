@@ -180,6 +180,12 @@ int x265hip_cutree_propagate(void* stream, int widthInCU, int heightInCU, int di
 int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
                             int planeOffset, int32_t* out);
 
+/* SAO of a whole luma plane, OUT OF PLACE (in != out): SAO::generateLumaOffsets + applyPixelOffsets (encoder/sao.cpp:268-623) for every CTU.  The
+ * reference filters in place and classifies against saved unmodified neighbours (m_tmpU, m_tmpL); reading the input plane is the same thing.
+ * params (device): per CTU in raster order 6 int32 = typeIdx (-1 = off, 0..3 = SAO_EO_0..3, 4 = SAO_BO), bandPos, offset[4], with SAO_MERGE_LEFT / UP
+ * already resolved to the merged CTU's values.  One slice (the picture's first / last rows are the slice's). */
+int x265hip_sao_apply_frame(void* stream, const void* in, void* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params);
+
 /* PSNR numerator of one plane: Encoder::computeSSD (encoder/encoder.cpp:1203-1270), the exact 64-bit sum of squared differences of the source and
  * the reconstructed plane (width <= 16384).  *out is a device uint64. */
 int x265hip_plane_ssd(void* stream, const void* fenc, const void* recon, intptr_t stride, int width, int height, uint64_t* out);

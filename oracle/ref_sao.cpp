@@ -9,6 +9,9 @@
  * usage: x265sao_<depth> <width> <height> <ctu> <in.raw> <out.bin> [sao-non-deblock 0|1] [planes 1|3]
  *   in.raw  : per plane (Y, then Cb, Cr of a 4:2:0 picture when planes = 3) the source plane then the reconstructed plane, tightly packed
  *   out.bin : per plane, per CTU 5 x 32 int32 offsetOrg then 5 x 32 int32 count (types SAO_EO_0..3, SAO_BO as in sao.h:43-50)
+ * apply mode (argv[8] = params.bin: per CTU 6 int32 = typeIdx (-1 = off), bandPos, offset[4]): the luma SAO of the picture the way the frame filter runs
+ *   it -- SAO::generateLumaOffsets CTU by CTU in raster order (sao.cpp:566-623 -> applyPixelOffsets :268-563), m_tmpU holding the unmodified last row
+ *   of the CTU row above (FrameFilter::ParallelFilter::copySaoAboveRef, framefilter.cpp:303-311); out.bin = the reconstructed plane afterwards (int32 per pixel)
  */
 #include "common.h"
 #include "primitives.h"
@@ -30,6 +33,7 @@ struct SaoX : public SAO
     void clear() { memset(m_count, 0, sizeof(m_count)); memset(m_offsetOrg, 0, sizeof(m_offsetOrg)); }
     const int32_t* counts() const { return &m_count[0][0][0]; }
     const int32_t* sums() const { return &m_offsetOrg[0][0][0]; }
+    pixel* aboveRow() { return m_tmpU[0]; }
 };
 
 int main(int argc, char** argv)
@@ -82,6 +86,33 @@ int main(int argc, char** argv)
     SaoX sao;
     if (!sao.create(p, 1)) { fprintf(stderr, "SAO::create failed\n"); return 2; }
     sao.m_frame = &frame;
+    if (argc > 8)
+    {
+        FILE* pf = fopen(argv[8], "rb");
+        std::vector<int32_t> raw(6 * (size_t)sps.numCUsInFrame);
+        if (!pf || fread(raw.data(), 4, raw.size(), pf) != raw.size()) { fprintf(stderr, "bad params file\n"); return 2; }
+        fclose(pf);
+        std::vector<SaoCtuParam> prm(sps.numCUsInFrame);
+        for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
+        {
+            prm[a].reset(); prm[a].typeIdx = raw[6 * a]; prm[a].bandPos = (uint32_t)raw[6 * a + 1];
+            for (int i = 0; i < 4; i++) prm[a].offset[i] = raw[6 * a + 2 + i];
+        }
+        PicYuv* rp = frame.m_reconPic[0];
+        std::vector<pixel> pristine((size_t)rp->m_stride * H);
+        for (int y = 0; y < H; y++) memcpy(&pristine[(size_t)y * rp->m_stride], rp->m_picOrg[0] + (intptr_t)y * rp->m_stride, W * sizeof(pixel));
+        for (uint32_t row = 0; row < sps.numCuInHeight; row++)
+        {
+            /* copySaoAboveRef: the unmodified row above the CTU row -- for the first CTU row its own first row (framefilter.cpp:307) */
+            memcpy(sao.aboveRow(), &pristine[(size_t)(row ? row * ctu - 1 : 0) * rp->m_stride], W * sizeof(pixel));
+            for (uint32_t col = 0; col < sps.numCuInWidth; col++) sao.generateLumaOffsets(prm.data(), (int)row, (int)col);
+        }
+        std::vector<int32_t> o((size_t)W * H);
+        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) o[(size_t)y * W + x] = rp->m_picOrg[0][(intptr_t)y * rp->m_stride + x];
+        fwrite(o.data(), 4, o.size(), out);
+        fclose(out); fclose(in);
+        return 0;
+    }
     for (int plane = 0; plane < nplanes; plane++)
         for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
         {

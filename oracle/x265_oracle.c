@@ -952,3 +952,39 @@ uint64_t xo_plane_ssd(const xo_pixel* fenc, const xo_pixel* rec, intptr_t stride
         for (int x = 0; x < width; x++) { const int d = (int)fenc[x] - (int)rec[x]; ssd += (uint64_t)(d * d); }
     return ssd;
 }
+
+/* SAO of a whole luma plane (SAO::generateLumaOffsets + applyPixelOffsets, encoder/sao.cpp:268-623) restated OUT OF PLACE: the reference works in
+ * place CTU by CTU and keeps unmodified copies of the neighbouring row / column (m_tmpU, m_tmpL), i.e. every pixel is classified on the
+ * picture as it was before SAO.  params: per CTU { typeIdx (-1 off, 0..3 EO, 4 BO), bandPos, offset[4] } with merges already resolved. */
+void xo_sao_apply_frame(const xo_pixel* in, xo_pixel* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params)
+{
+    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize, pm = (1 << X265_DEPTH) - 1;
+    for (int y = 0; y < picHeight; y++) memcpy(out + y * stride, in + y * stride, picWidth * sizeof(xo_pixel));
+    static const int ax[4] = { -1, 0, -1, 1 }, ay[4] = { 0, -1, -1, -1 };
+    for (int addr = 0; addr < nx * ny; addr++)
+    {
+        const int32_t* p = params + 6 * addr;
+        const int type = p[0];
+        if (type < 0) continue;
+        const int lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;
+        const int above = (!tpely) | (addr < nx), lastRow = addr >= nx * ny - nx;
+        const int picH = lastRow ? (picHeight < tpely + ctuSize ? picHeight : tpely + ctuSize) : picHeight;
+        const int rpelx = lpelx + ctuSize < picWidth ? lpelx + ctuSize : picWidth, bpely = tpely + ctuSize < picH ? tpely + ctuSize : picH;
+        const int cw = rpelx - lpelx, ch = bpely - tpely;
+        int offEo[5];                                                   /* m_offsetEo: by edge type through s_eoTable, class 0 = no offset (:609-618) */
+        { const int off[5] = { 0, p[2], p[3], p[4], p[5] }; for (int e = 0; e < 5; e++) offEo[e] = (int8_t)off[k_eoTable[e]]; }
+        int8_t offBo[32]; memset(offBo, 0, sizeof(offBo));
+        for (int i = 0; i < 4; i++) offBo[(p[1] + i) & 31] = (int8_t)p[2 + i];
+        const int startX = (type == 1 || type == 4) ? 0 : !lpelx, endX = (type == 1 || type == 4) ? cw : (rpelx == picWidth ? cw - 1 : cw);
+        const int startY = (type == 0 || type == 4) ? 0 : above, endY = (type == 0 || type == 4) ? ch : (bpely == picH ? ch - 1 : ch);
+        for (int y = startY; y < endY; y++)
+            for (int x = startX; x < endX; x++)
+            {
+                const xo_pixel* r = in + (tpely + y) * stride + lpelx + x;
+                int v;
+                if (type == 4) v = r[0] + offBo[r[0] >> (X265_DEPTH - 5)];
+                else v = r[0] + offEo[sgn(r[0] - r[ay[type] * stride + ax[type]]) + sgn(r[0] - r[-ay[type] * stride - ax[type]]) + 2];
+                out[(tpely + y) * stride + lpelx + x] = (xo_pixel)(v < 0 ? 0 : v > pm ? pm : v);
+            }
+    }
+}

@@ -63,3 +63,37 @@ def test_plane_ssd_matches_oracle(depth):
         api.h.check(api.lib.x265hip_plane_ssd(api.stream(), C.c_void_p(d_a.data_ptr()), C.c_void_p(d_b.data_ptr()), C.c_ssize_t(stride), W, H, C.c_void_p(d_o.data_ptr())))
         t.cuda.synchronize()
         assert int(d_o.cpu().numpy().view(np.uint64)[0]) == exp, (W, H)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((72, 40), 32), ((130, 70), 16), ((64, 64), 64), ((1920, 1080), 64), ((3, 5), 16)])
+def test_sao_apply_frame_matches_oracle(depth, size, ctu):
+    """x265hip_sao_apply_frame against the oracle (pinned to the reference's in-place SAO::generateLumaOffsets sequence)"""
+    import ctypes as C
+    import time
+    from x265hip_pkg.frame import FrameApi
+    from test_sao_oracle_vs_ref import sao_apply_oracle, sao_frame_pair, sao_params
+    api = FrameApi(depth)
+    t = api.torch
+    W, H = size
+    _, rec = sao_frame_pair(depth, max(W, 8), max(H, 8), 55 + depth + W)
+    rec = np.ascontiguousarray(rec[:H, :W])
+    n = ((W + ctu - 1) // ctu) * ((H + ctu - 1) // ctu)
+    prm = sao_params(np.random.default_rng(3 * W + depth), n, depth)
+    exp = sao_apply_oracle(Oracle(depth), rec, ctu, prm)
+    d_in, d_prm = api.to_device(rec.reshape(-1)), api.to_device(prm.reshape(-1))
+    d_out = t.zeros_like(d_in)
+    P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    api.h.check(api.lib.x265hip_sao_apply_frame(api.stream(), P(d_in), P(d_out), C.c_ssize_t(W), W, H, ctu, P(d_prm)))
+    t.cuda.synchronize()
+    got = d_out.cpu().numpy().view(rec.dtype).reshape(H, W)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, "first differing pixel %s: hip %d oracle %d" % (bad[0], got[tuple(bad[0])], exp[tuple(bad[0])])
+    if W >= 1920:
+        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            api.lib.x265hip_sao_apply_frame(api.stream(), P(d_in), P(d_out), C.c_ssize_t(W), W, H, ctu, P(d_prm))
+        e1.record(); t.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print("sao_apply %d bit %dx%d: %.4f ms, %.0f GB/s algorithmic (plane read + written)" % (depth, W, H, ms, 2 * W * H * rec.itemsize / ms / 1e6))

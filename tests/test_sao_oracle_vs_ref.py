@@ -88,3 +88,55 @@ def test_sao_frame_stats_chroma_match_reference(depth, size, ctu, nd):
     exp = [sao_frame_oracle(ora, y[0], y[1], ctu, nd, 0), sao_frame_oracle(ora, cb[0], cb[1], ctu // 2, nd, 2), sao_frame_oracle(ora, cr[0], cr[1], ctu // 2, nd, 2)]
     for plane in range(3):
         assert np.array_equal(a[plane], exp[plane]), "plane %d" % plane
+
+
+def sao_params(rng, n_ctu, depth):
+    """per CTU { typeIdx (-1 off, 0..3 EO, 4 BO), bandPos, offset[4] }: EO offsets with the standard's signs, BO offsets any sign"""
+    p = np.zeros((n_ctu, 6), np.int32)
+    for a in range(n_ctu):
+        t = int(rng.integers(-1, 5))
+        p[a, 0] = t
+        if t == 4:
+            p[a, 1] = rng.integers(0, 32); p[a, 2:] = rng.integers(-7, 8, 4)
+        elif t >= 0:
+            p[a, 2:] = (rng.integers(0, 8), rng.integers(0, 8), -rng.integers(0, 8), -rng.integers(0, 8))
+    return p
+
+
+def sao_apply_reference(depth, fenc, rec, ctu, params):
+    import os, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    H, W = rec.shape
+    with tempfile.TemporaryDirectory() as td:
+        inp, out, prm = os.path.join(td, "in.raw"), os.path.join(td, "out.bin"), os.path.join(td, "p.bin")
+        np.concatenate([fenc.reshape(-1), rec.reshape(-1)]).tofile(inp); params.astype(np.int32).tofile(prm)
+        r = subprocess.run([os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth), str(W), str(H), str(ctu), inp, out, "0", "1", prm], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1000:]
+        return np.fromfile(out, np.int32).reshape(H, W)
+
+
+def sao_apply_oracle(ora, rec, ctu, params):
+    import ctypes as C
+    H, W = rec.shape
+    src = np.ascontiguousarray(rec); dst = np.zeros_like(src); prm = np.ascontiguousarray(params.astype(np.int32))
+    P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    ora.lib.xo_sao_apply_frame(P(src), P(dst), C.c_ssize_t(W), W, H, ctu, P(prm))
+    return dst
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((192, 128), 64), ((72, 40), 32), ((130, 70), 16), ((64, 64), 64), ((256, 64), 32)])
+def test_sao_apply_frame_matches_reference(depth, size, ctu):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth)):
+        pytest.skip("no reference SAO binary")
+    W, H = size
+    fenc, rec = sao_frame_pair(depth, W, H, 31 + depth + W)
+    n = ((W + ctu - 1) // ctu) * ((H + ctu - 1) // ctu)
+    prm = sao_params(np.random.default_rng(W + depth), n, depth)
+    a = sao_apply_reference(depth, fenc, rec, ctu, prm)
+    b = sao_apply_oracle(Oracle(depth), rec, ctu, prm)
+    bad = np.argwhere(a != b.astype(np.int32))
+    assert bad.size == 0, "first differing pixel (y, x) %s: reference %d oracle %d, CTU params %s" % (bad[0], a[tuple(bad[0])], b[tuple(bad[0])], prm[(bad[0][0] // ctu) * ((W + ctu - 1) // ctu) + bad[0][1] // ctu])
+    assert (a != rec.astype(np.int32)).sum() > 0

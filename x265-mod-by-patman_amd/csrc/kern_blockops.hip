@@ -257,6 +257,50 @@ __global__ __launch_bounds__(256) void plane_ssd_kernel(const pixel* __restrict_
     if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 
+
+// SAO of a whole luma plane, out of place (SAO::generateLumaOffsets + applyPixelOffsets, encoder/sao.cpp:268-623): the reference filters in place
+// CTU by CTU and classifies against saved copies of the unmodified neighbours (m_tmpU / m_tmpL) -- i.e. against the picture before SAO, which is
+// simply the input here.  params: per CTU { typeIdx (-1 off, 0..3 EO, 4 BO), bandPos, offset[4] }.  Each thread filters four neighbouring pixels.
+__global__ __launch_bounds__(256) void sao_apply_kernel(const pixel* __restrict__ in, pixel* __restrict__ out, intptr_t stride, int picWidth, int picHeight,
+                                                        int ctuSize, int lgCtu, const int32_t* __restrict__ params)
+{
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= picWidth || y >= picHeight) return;
+    const int nx = (picWidth + ctuSize - 1) >> lgCtu, ny = (picHeight + ctuSize - 1) >> lgCtu;
+    const int cy = y >> lgCtu;
+    auto sgn = [](int v) { return (v > 0) - (v < 0); };
+    const pixel* r = in + (intptr_t)y * stride;
+    pixel* o = out + (intptr_t)y * stride;
+    const bool bottomRowOfPic = y == picHeight - 1;               // (bpely == picHeight) and the last row of that CTU
+    for (int i = 0; i < 4; i++)
+    {
+        const int x = x0 + i;
+        if (x >= picWidth) break;
+        const int32_t* p = params + 6 * (cy * nx + (x >> lgCtu));
+        const int type = p[0], c = r[x];
+        int v = c;
+        if (type == 4)
+        {
+            const int band = c >> (X265_DEPTH - 5), k = (band - p[1]) & 31;
+            if (k < 4) v = c + (int8_t)p[2 + k];
+        }
+        else if (type >= 0)
+        {
+            const bool horiz = type != 1, vert = type != 0;        // which picture edges make the pixel ineligible (:318-320, 372-374, 408-412, 474-478)
+            const bool ok = !(horiz && (x == 0 || x == picWidth - 1)) && !(vert && (y == 0 || bottomRowOfPic));
+            if (ok)
+            {
+                const int ax = type == 0 ? -1 : type == 1 ? 0 : type == 2 ? -1 : 1, ay = type == 0 ? 0 : -1;
+                const int e = sgn(c - (int)r[(intptr_t)ay * stride + x + ax]) + sgn(c - (int)r[-(intptr_t)ay * stride + x - ax]) + 2;
+                const int cls = (int)((0x43021u >> (4 * e)) & 15);  // s_eoTable; class 0 carries no offset
+                if (cls) v = c + (int8_t)p[1 + cls];
+            }
+        }
+        o[x] = (pixel)min(max(v, 0), XH_PIXEL_MAX);
+    }
+    (void)ny;
+}
+
 } // namespace
 
 // ---- frame_init_lowres_core (pixel.cpp:596-622): one thread per lowres pixel, 3x3 source neighbourhood -> 4 outputs ----
@@ -373,6 +417,17 @@ extern "C" int x265hip_plane_ssd(void* stream, const void* fenc, const void* rec
     hipStream_t st = (hipStream_t)stream;
     XH_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), st));
     hipLaunchKernelGGL(plane_ssd_kernel, dim3(min(height, 2048)), dim3(256), 0, st, (const pixel*)fenc, (const pixel*)recon, stride, width, height, (unsigned long long*)out);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_sao_apply_frame(void* stream, const void* in, void* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params)
+{
+    if (!in || !out || in == out || !params || picWidth < 1 || picHeight < 1 || (ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth)
+    { set_error("sao_apply_frame: bad arguments (out of place only)"); return X265HIP_EARG; }
+    const int lg = ctuSize == 64 ? 6 : ctuSize == 32 ? 5 : 4;
+    hipLaunchKernelGGL(sao_apply_kernel, dim3((picWidth + 255) / 256, (picHeight + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const pixel*)in, (pixel*)out, stride,
+                       picWidth, picHeight, ctuSize, lg, params);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
