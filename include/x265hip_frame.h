@@ -190,6 +190,16 @@ int x265hip_sao_apply_frame(void* stream, const void* in, void* out, intptr_t st
  * the reconstructed plane (width <= 16384).  *out is a device uint64. */
 int x265hip_plane_ssd(void* stream, const void* fenc, const void* recon, intptr_t stride, int width, int height, uint64_t* out);
 
+/* SSIM of the reconstructed picture against the source as the frame filter accumulates it (FrameFilter::processPostRow, encoder/framefilter.cpp:704-722 ->
+ * calculateSSIM :839-865 -> ssim_4x4x2_core / ssim_end_4, common/pixel.cpp:623-693): rowSsim[r] / rowCnt[r] = what CTU row r adds to
+ * FrameEncoder::m_ssim / m_ssimCnt (float sum of its windows in the reference's order of additions, number of windows); frame[0] = the double sum of the
+ * rows in row order, frame[1] = the window count: the picture's SSIM is frame[0] / frame[1] (Encoder::finishFrameStats, encoder.cpp:3193-3198).  Float
+ * arithmetic, but the order of operations is the reference's, so the result is IDENTICAL to the single-threaded reference (the tests use tolerance 0).
+ * workspace: x265hip_ssim_workspace(width, height) bytes of device memory.  width, height >= 10, width <= 16384. */
+size_t x265hip_ssim_workspace(int width, int height);
+int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stride1, const void* fenc, intptr_t stride2, int width, int height, int ctuSize,
+                       void* workspace, float* rowSsim, uint32_t* rowCnt, double* frame);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,28 @@ int main(int argc, char** argv)
     pic->planes[0] = Y.data(); pic->planes[1] = U.data(); pic->planes[2] = V.data();
     pic->stride[0] = w * (int)sizeof(pixel); pic->stride[1] = pic->stride[2] = (w / 2) * (int)sizeof(pixel);
     pic->bitDepth = X265_DEPTH; pic->colorSpace = X265_CSP_I420;
+    /* X265ENC_DUMP=<file>: every output picture as  int32 poc, double ssim, psnrY, psnrU, psnrV  then the source Y and the reconstructed Y, U, V planes
+     * (16-bit samples, tightly packed) -- the pin of the frame-level SSIM / SSD restatements against the encoder's own per-frame statistics */
+    FILE* dump = getenv("X265ENC_DUMP") ? fopen(getenv("X265ENC_DUMP"), "wb") : NULL;
+    x265_picture* rec = x265_picture_alloc();
+    auto dumpPic = [&](int got)
+    {
+        if (!dump || got <= 0) return;
+        const int32_t poc = rec->poc;
+        const double st[4] = { rec->frameData.ssim, rec->frameData.psnrY, rec->frameData.psnrU, rec->frameData.psnrV };
+        fwrite(&poc, 4, 1, dump); fwrite(st, 8, 4, dump);
+        std::vector<pixel> sy((size_t)w * h), su((size_t)w * h / 4), sv((size_t)w * h / 4);
+        synth(sy, su, sv, w, h, poc);
+        std::vector<uint16_t> line;
+        auto put = [&](const pixel* src, intptr_t stride, int pw, int ph)
+        {
+            line.resize(pw);
+            for (int y = 0; y < ph; y++) { for (int x = 0; x < pw; x++) line[x] = src[y * stride + x]; fwrite(line.data(), 2, pw, dump); }
+        };
+        put(sy.data(), w, w, h); put(su.data(), w / 2, w / 2, h / 2); put(sv.data(), w / 2, w / 2, h / 2);
+        for (int c = 0; c < 3; c++)
+            put((const pixel*)rec->planes[c], rec->stride[c] / (int)sizeof(pixel), c ? w / 2 : w, c ? h / 2 : h);
+    };
     size_t bytes = 0;
     const auto t0 = std::chrono::steady_clock::now();
     x265_nal* nal; uint32_t nnal;
@@ -108,11 +130,17 @@ int main(int argc, char** argv)
     {
         synth(Y, U, V, w, h, f);
         pic->pts = f;
-        if (x265_encoder_encode(enc, &nal, &nnal, pic, NULL) < 0) { fprintf(stderr, "encode failed\n"); return 2; }
+        const int got = x265_encoder_encode(enc, &nal, &nnal, pic, dump ? rec : NULL);
+        if (got < 0) { fprintf(stderr, "encode failed\n"); return 2; }
+        dumpPic(got);
         for (uint32_t i = 0; i < nnal; i++) { fwrite(nal[i].payload, 1, nal[i].sizeBytes, out); bytes += nal[i].sizeBytes; }
     }
-    while (x265_encoder_encode(enc, &nal, &nnal, NULL, NULL) > 0)
+    for (int got; (got = x265_encoder_encode(enc, &nal, &nnal, NULL, dump ? rec : NULL)) > 0;)
+    {
+        dumpPic(got);
         for (uint32_t i = 0; i < nnal; i++) { fwrite(nal[i].payload, 1, nal[i].sizeBytes, out); bytes += nal[i].sizeBytes; }
+    }
+    if (dump) fclose(dump);
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fclose(out);
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);

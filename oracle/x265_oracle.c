@@ -988,3 +988,72 @@ void xo_sao_apply_frame(const xo_pixel* in, xo_pixel* out, intptr_t stride, int 
             }
     }
 }
+
+/* SSIM of a picture as the frame filter accumulates it (FrameFilter::processPostRow, encoder/framefilter.cpp:704-722; calculateSSIM :839-865;
+ * ssim_4x4x2_core / ssim_end_1 / ssim_end_4, common/pixel.cpp:623-693).  The 4x4 blocks sit on a grid shifted by (2,2); a window is 2x2 blocks;
+ * every CTU row r accumulates its window rows in FLOAT, four windows at a time (the ssim_end_4 partial) added to the row's running sum, and the
+ * frame total is the DOUBLE sum of the row results (m_ssim += ...).  Restated on the global block grid instead of the reference's two rolling
+ * sum rows: CTU row r starts at block row B0 = 0 (r = 0) or r*ctu/4 - 3 and holds hb block rows.  Float expressions keep the reference's
+ * order of operations (this file must be compiled without FMA contraction: x86-64 baseline has none). */
+static void ssim_block(const xo_pixel* a, intptr_t sa, const xo_pixel* b, intptr_t sb, uint32_t s[4])
+{
+    s[0] = s[1] = s[2] = s[3] = 0;
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++)
+        {
+            const uint32_t p = a[y * sa + x], q = b[y * sb + x];
+            s[0] += p; s[1] += q; s[2] += p * p + q * q; s[3] += p * q;
+        }
+}
+
+static float ssim_window(int s1, int s2, int ss, int s12)
+{
+#if X265_DEPTH > 8
+    const float c1 = (float)(.01 * .01 * ((1 << X265_DEPTH) - 1) * ((1 << X265_DEPTH) - 1) * 64), c2 = (float)(.03 * .03 * ((1 << X265_DEPTH) - 1) * ((1 << X265_DEPTH) - 1) * 64 * 63);
+    const float f1 = (float)s1, f2 = (float)s2, fss = (float)ss, f12 = (float)s12;
+    const float vars = fss * 64 - f1 * f1 - f2 * f2, covar = f12 * 64 - f1 * f2;
+#else
+    const int c1 = (int)(.01 * .01 * ((1 << X265_DEPTH) - 1) * ((1 << X265_DEPTH) - 1) * 64 + .5), c2 = (int)(.03 * .03 * ((1 << X265_DEPTH) - 1) * ((1 << X265_DEPTH) - 1) * 64 * 63 + .5);
+    const int f1 = s1, f2 = s2;
+    const int vars = ss * 64 - f1 * f1 - f2 * f2, covar = s12 * 64 - f1 * f2;
+#endif
+    return (float)(2 * f1 * f2 + c1) * (float)(2 * covar + c2) / ((float)(f1 * f1 + f2 * f2 + c1) * (float)(vars + c2));
+}
+
+/* rowSsim / rowCnt: one entry per CTU row; *total = sum of rowSsim in row order (double), *cnt = sum of rowCnt: the frame's SSIM is total / cnt
+ * (Encoder::finishFrameStats, encoder.cpp:3193-3198) */
+void xo_ssim_frame(const xo_pixel* rec, intptr_t stride1, const xo_pixel* fenc, intptr_t stride2, int width, int height, int ctuSize,
+                   float* rowSsim, uint32_t* rowCnt, double* total, uint32_t* cnt)
+{
+    const int numRows = (height + ctuSize - 1) / ctuSize;
+    const uint32_t wb = (uint32_t)(width - 2) >> 2;
+    *total = 0; *cnt = 0;
+    for (int r = 0; r < numRows; r++)
+    {
+        const int start = r == 0, end = r == numRows - 1;
+        uint32_t minY = r * ctuSize - 4 * !start, maxY = (r + 1) * ctuSize - 4 * !end;
+        if (maxY > (uint32_t)height) maxY = height;
+        minY += start ? 2 : -6;
+        const uint32_t hb = (maxY - minY) >> 2;
+        float ssim = 0.0f;
+        for (uint32_t y = 1; y < hb; y++)
+            for (uint32_t x = 0; x + 1 < wb; x += 4)
+            {
+                float part = 0.0f;
+                for (uint32_t i = x; i < x + 4 && i + 1 < wb; i++)
+                {
+                    uint32_t s[4] = { 0, 0, 0, 0 }, t[4];
+                    for (int k = 0; k < 4; k++)
+                    {
+                        const intptr_t py = minY + 4 * (y - 1 + (k >> 1)), px = 2 + 4 * (i + (k & 1));
+                        ssim_block(rec + py * stride1 + px, stride1, fenc + py * stride2 + px, stride2, t);
+                        for (int c = 0; c < 4; c++) s[c] += t[c];
+                    }
+                    part += ssim_window((int)s[0], (int)s[1], (int)s[2], (int)s[3]);
+                }
+                ssim += part;
+            }
+        rowSsim[r] = ssim; rowCnt[r] = (hb - 1) * (wb - 1);
+        *total += ssim; *cnt += rowCnt[r];
+    }
+}

@@ -97,6 +97,9 @@ void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t st
 /* SAO of a luma plane, out of place (sao.cpp:268-623); params: per CTU { typeIdx, bandPos, offset[4] } */
 void xo_sao_apply_frame(const xo_pixel* in, xo_pixel* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params);
 uint64_t xo_plane_ssd(const xo_pixel* fenc, const xo_pixel* rec, intptr_t stride, int width, int height);   /* encoder.cpp:1203-1270 computeSSD */
+/* framefilter.cpp:704-722, 839-865 + pixel.cpp:623-693: per CTU row float sums and window counts, frame total in double */
+void xo_ssim_frame(const xo_pixel* rec, intptr_t stride1, const xo_pixel* fenc, intptr_t stride2, int width, int height, int ctuSize,
+                   float* rowSsim, uint32_t* rowCnt, double* total, uint32_t* cnt);
 
 /* ---- interpolation family (ipfilter.cpp:40-369); taps = 8 (luma) or 4 (chroma) ---- */
 void xo_interp_hpp(int taps, int w, int h, const xo_pixel* src, intptr_t ss, xo_pixel* dst, intptr_t ds, int coeffIdx);

@@ -258,6 +258,87 @@ __global__ __launch_bounds__(256) void plane_ssd_kernel(const pixel* __restrict_
 }
 
 
+// SSIM of a picture as the frame filter accumulates it (FrameFilter::processPostRow, encoder/framefilter.cpp:704-722; calculateSSIM :839-865; ssim_4x4x2_core /
+// ssim_end_1 / ssim_end_4, common/pixel.cpp:623-693).  4x4 blocks on a grid shifted by (2,2), a window = 2x2 blocks.  The window values are computed in
+// parallel; what makes the float result identical to the reference's is the ORDER of the additions, kept literally: four windows -> a partial, partials
+// added to the CTU row's running float sum left to right, top to bottom; CTU rows added in double.  No FMA contraction anywhere in these functions.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float ssim_window(int s1, int s2, int ss, int s12)
+{
+#if X265_DEPTH > 8
+    constexpr float c1 = (float)(.01 * .01 * XH_PIXEL_MAX * XH_PIXEL_MAX * 64), c2 = (float)(.03 * .03 * XH_PIXEL_MAX * XH_PIXEL_MAX * 64 * 63);
+    const float f1 = (float)s1, f2 = (float)s2, fss = (float)ss, f12 = (float)s12;
+    const float vars = fss * 64 - f1 * f1 - f2 * f2, covar = f12 * 64 - f1 * f2;
+#else
+    constexpr int c1 = (int)(.01 * .01 * XH_PIXEL_MAX * XH_PIXEL_MAX * 64 + .5), c2 = (int)(.03 * .03 * XH_PIXEL_MAX * XH_PIXEL_MAX * 64 * 63 + .5);
+    const int f1 = s1, f2 = s2;
+    const int vars = ss * 64 - f1 * f1 - f2 * f2, covar = s12 * 64 - f1 * f2;
+#endif
+    return (float)(2 * f1 * f2 + c1) * (float)(2 * covar + c2) / ((float)(f1 * f1 + f2 * f2 + c1) * (float)(vars + c2));
+}
+
+// one workgroup: a tile of 32 x 8 windows = 33 x 9 block sums in LDS; E[wy * nwx + wx] = the window's ssim_end_1 value
+__global__ __launch_bounds__(256) void ssim_window_kernel(const pixel* __restrict__ rec, intptr_t stride1, const pixel* __restrict__ fenc, intptr_t stride2,
+                                                          int nwx, int nwy, float* __restrict__ E)
+{
+    __shared__ uint4 s_blk[9][33];
+    const int bx0 = blockIdx.x * 32, by0 = blockIdx.y * 8;
+    for (int t = threadIdx.x; t < 9 * 33; t += 256)
+    {
+        const int ly = t / 33, lx = t - ly * 33, bx = bx0 + lx, by = by0 + ly;
+        uint4 s = make_uint4(0, 0, 0, 0);
+        if (bx <= nwx && by <= nwy)
+        {
+            const pixel* a = rec + (intptr_t)(2 + 4 * by) * stride1 + 2 + 4 * bx;
+            const pixel* b = fenc + (intptr_t)(2 + 4 * by) * stride2 + 2 + 4 * bx;
+            for (int y = 0; y < 4; y++, a += stride1, b += stride2)
+                for (int x = 0; x < 4; x++) { const uint32_t p = a[x], q = b[x]; s.x += p; s.y += q; s.z += p * p + q * q; s.w += p * q; }
+        }
+        s_blk[ly][lx] = s;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5, wx = bx0 + lx, wy = by0 + ly;
+    if (wx >= nwx || wy >= nwy) return;
+    const uint4 a = s_blk[ly][lx], b = s_blk[ly][lx + 1], c = s_blk[ly + 1][lx], d = s_blk[ly + 1][lx + 1];
+    E[(size_t)wy * nwx + wx] = ssim_window((int)(a.x + b.x + c.x + d.x), (int)(a.y + b.y + c.y + d.y), (int)(a.z + b.z + c.z + d.z), (int)(a.w + b.w + c.w + d.w));
+}
+
+// one wavefront per CTU row: lanes form the four-window partials of a window row (ssim_end_4), lane 0 adds them to the running sum in order
+__global__ __launch_bounds__(64) void ssim_rows_kernel(const float* __restrict__ E, int nwx, int width, int height, int ctuSize, int numRows,
+                                                       float* __restrict__ rowSsim, uint32_t* __restrict__ rowCnt)
+{
+    __shared__ float s_part[1024];                                 // (16384 / 4 - 1 + 3) / 4 groups at most
+    const int r = blockIdx.x, start = r == 0, end = r == numRows - 1;
+    uint32_t minY = r * ctuSize - 4 * !start, maxY = min((uint32_t)((r + 1) * ctuSize - 4 * !end), (uint32_t)height);
+    minY += start ? 2 : -6;
+    const uint32_t hb = (maxY - minY) >> 2, wy0 = (minY - 2) >> 2;
+    const int groups = (nwx + 3) >> 2;
+    float ssim = 0.0f;
+    for (uint32_t y = 1; y < hb; y++)
+    {
+        const float* e = E + (size_t)(wy0 + y - 1) * nwx;
+        for (int g = threadIdx.x; g < groups; g += 64)
+        {
+            float part = 0.0f;
+            for (int i = 4 * g; i < 4 * g + 4 && i < nwx; i++) part += e[i];
+            s_part[g] = part;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int g = 0; g < groups; g++) ssim += s_part[g];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { rowSsim[r] = ssim; rowCnt[r] = (hb - 1) * (uint32_t)nwx; }
+}
+
+__global__ void ssim_total_kernel(const float* __restrict__ rowSsim, const uint32_t* __restrict__ rowCnt, int numRows, double* __restrict__ frame)
+{
+    double t = 0; uint32_t c = 0;
+    for (int r = 0; r < numRows; r++) { t += rowSsim[r]; c += rowCnt[r]; }
+    frame[0] = t; frame[1] = (double)c;
+}
+#pragma clang fp contract(fast)
+
 // SAO of a whole luma plane, out of place (SAO::generateLumaOffsets + applyPixelOffsets, encoder/sao.cpp:268-623): the reference filters in place
 // CTU by CTU and classifies against saved copies of the unmodified neighbours (m_tmpU / m_tmpL) -- i.e. against the picture before SAO, which is
 // simply the input here.  params: per CTU { typeIdx (-1 off, 0..3 EO, 4 BO), bandPos, offset[4] }.  Each thread filters four neighbouring pixels.
@@ -417,6 +498,39 @@ extern "C" int x265hip_plane_ssd(void* stream, const void* fenc, const void* rec
     hipStream_t st = (hipStream_t)stream;
     XH_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), st));
     hipLaunchKernelGGL(plane_ssd_kernel, dim3(min(height, 2048)), dim3(256), 0, st, (const pixel*)fenc, (const pixel*)recon, stride, width, height, (unsigned long long*)out);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" size_t x265hip_ssim_workspace(int width, int height)
+{
+    if (width < 10 || height < 10) return 0;
+    return (size_t)((width - 2) >> 2) * ((height - 2) >> 2) * sizeof(float);
+}
+
+extern "C" int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stride1, const void* fenc, intptr_t stride2, int width, int height, int ctuSize,
+                                  void* workspace, float* rowSsim, uint32_t* rowCnt, double* frame)
+{
+    if (!recon || !fenc || !workspace || !rowSsim || !rowCnt || !frame || width < 10 || height < 10 || width > 16384 || (ctuSize != 16 && ctuSize != 32 && ctuSize != 64) ||
+        stride1 < width || stride2 < width)
+    { set_error("ssim_frame: bad arguments"); return X265HIP_EARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int numRows = (height + ctuSize - 1) / ctuSize;
+    const int nwx = ((width - 2) >> 2) - 1;                              // windows per row; block columns 0..nwx
+    /* block rows the CTU rows cover: the last CTU row ends at block row B0 + hb - 1 (the arithmetic of ssim_rows_kernel) */
+    const int lastMin = numRows == 1 ? 2 : (numRows - 1) * ctuSize - 10;
+    const int nby = ((lastMin - 2) >> 2) + ((height - lastMin) >> 2);
+    const int nwy = nby - 1;
+    if (nwx < 1 || nwy < 1)
+    {   /* no complete window: the reference reports zero windows (single CTU row pictures lower than 10 rows cannot get here) */
+        XH_HIP(hipMemsetAsync(rowSsim, 0, numRows * sizeof(float), st)); XH_HIP(hipMemsetAsync(rowCnt, 0, numRows * sizeof(uint32_t), st));
+        XH_HIP(hipMemsetAsync(frame, 0, 2 * sizeof(double), st));
+        return X265HIP_OK;
+    }
+    hipLaunchKernelGGL(ssim_window_kernel, dim3((nwx + 31) / 32, (nwy + 7) / 8), dim3(256), 0, st, (const pixel*)recon, stride1, (const pixel*)fenc, stride2, nwx, nwy,
+                       (float*)workspace);
+    hipLaunchKernelGGL(ssim_rows_kernel, dim3(numRows), dim3(64), 0, st, (const float*)workspace, nwx, width, height, ctuSize, numRows, rowSsim, rowCnt);
+    hipLaunchKernelGGL(ssim_total_kernel, dim3(1), dim3(1), 0, st, (const float*)rowSsim, (const uint32_t*)rowCnt, numRows, frame);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
