@@ -1057,3 +1057,147 @@ void xo_ssim_frame(const xo_pixel* rec, intptr_t stride1, const xo_pixel* fenc, 
         *total += ssim; *cnt += rowCnt[r];
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------------
+ * Deblocking of a whole 4:2:0 picture (Deblock::deblockCTU / deblockCU / setEdgefilter* / getBoundaryStrength / edgeFilterLuma / edgeFilterChroma,
+ * common/deblock.cpp:37-497; pelFilterLumaStrong_c / pelFilterChroma_*_c, common/loopfilter.cpp:136-232), restated per 4x4 unit instead of as the
+ * reference's recursive walk over the CU quadtree: a unit knows its CU size, so "is this unit's left / top side a transform edge, a prediction edge,
+ * a CU edge" is arithmetic on its position inside the CU.  The per-partition arrays are the reference's own (CUData, CTU after CTU, z-scan order).
+ * One slice; all vertical edges first, then all horizontal edges.
+ * --------------------------------------------------------------------------------------------------------------------------------------------- */
+static const uint8_t k_dbkTc[54] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9,
+                                     10, 11, 13, 14, 16, 18, 20, 22, 24 };                       /* HEVC table 8-12 (deblock.cpp:499-503) */
+static const uint8_t k_dbkBeta[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36,
+                                       38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };  /* deblock.cpp:505-509 */
+
+static inline int dbk_clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+static inline int dbk_pix(int v) { return dbk_clip3(0, (1 << X265_DEPTH) - 1, v); }
+
+static uint32_t dbk_part(const xo_deblock_pic* d, int ux, int uy)          /* index of unit (ux, uy) in the CTU-major z-scan arrays */
+{
+    const int upc = d->ctuSize >> 2, nx = (d->width + d->ctuSize - 1) / d->ctuSize;
+    const int lx = ux % upc, ly = uy % upc;
+    uint32_t z = 0;
+    for (int b = 0; b < 4; b++) z |= ((lx >> b) & 1u) << (2 * b) | ((ly >> b) & 1u) << (2 * b + 1);
+    return (uint32_t)((uy / upc) * nx + ux / upc) * (uint32_t)(upc * upc) + z;
+}
+
+static int dbk_mv_far(const int32_t* a, const int32_t* b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+
+/* boundary strength of the edge on the left (dir 0) / top (dir 1) side of unit (ux, uy); deblock.cpp:46-70, 72-101, 125-247 */
+int xo_deblock_bs(const xo_deblock_pic* d, int ux, int uy, int dir)
+{
+    const uint32_t q = dbk_part(d, ux, uy);
+    if (!d->predMode[q]) return 0;
+    const int pos = (dir ? uy : ux) * 4, cuSize = 1 << d->log2CUSize[q], rel = pos & (cuSize - 1);
+    int bs;
+    if (!rel) bs = pos > 0 ? 2 : 0;                                                   /* CU edge: 2 when the neighbour exists (bsCuEdge) */
+    else if (!(rel & ((cuSize >> d->tuDepth[q]) - 1))) bs = 2;                         /* transform edge (setEdgefilterTU) */
+    else
+    {                                                                                 /* prediction edge inside the CU (setEdgefilterPU) */
+        const int ps = d->partSize[q];
+        const int at = dir ? (ps == 1 || ps == 3 ? cuSize >> 1 : ps == 4 ? cuSize >> 2 : ps == 5 ? cuSize - (cuSize >> 2) : -1)
+                           : (ps == 2 || ps == 3 ? cuSize >> 1 : ps == 6 ? cuSize >> 2 : ps == 7 ? cuSize - (cuSize >> 2) : -1);
+        bs = rel == at ? 1 : 0;
+    }
+    if (!bs || ((dir ? uy : ux) & 1)) return bs;                                       /* only the 8x8 grid is examined further (bsCheck) */
+    const uint32_t p = dir ? dbk_part(d, ux, uy - 1) : dbk_part(d, ux - 1, uy);
+    if (d->predMode[p] == 2 || d->predMode[q] == 2) return 2;
+    if (bs > 1 && (((d->cbfLuma[q] >> d->tuDepth[q]) & 1) || ((d->cbfLuma[p] >> d->tuDepth[p]) & 1))) return 1;
+    static const int32_t zero[2] = { 0, 0 };
+    const int rp0 = d->refIdx0[p] >= 0 ? d->refPic[0][d->refIdx0[p]] : -1, rq0 = d->refIdx0[q] >= 0 ? d->refPic[0][d->refIdx0[q]] : -1;
+    const int32_t* mp0 = rp0 >= 0 ? d->mv0 + 2 * p : zero; const int32_t* mq0 = rq0 >= 0 ? d->mv0 + 2 * q : zero;
+    if (d->sliceIsP) return rp0 != rq0 || dbk_mv_far(mq0, mp0);
+    const int rp1 = d->refIdx1[p] >= 0 ? d->refPic[1][d->refIdx1[p]] : -1, rq1 = d->refIdx1[q] >= 0 ? d->refPic[1][d->refIdx1[q]] : -1;
+    const int32_t* mp1 = rp1 >= 0 ? d->mv1 + 2 * p : zero; const int32_t* mq1 = rq1 >= 0 ? d->mv1 + 2 * q : zero;
+    if ((rp0 == rq0 && rp1 == rq1) || (rp0 == rq1 && rp1 == rq0))
+    {
+        if (rp0 != rp1)
+            return rp0 == rq0 ? (dbk_mv_far(mq0, mp0) || dbk_mv_far(mq1, mp1)) : (dbk_mv_far(mq1, mp0) || dbk_mv_far(mq0, mp1));
+        return (dbk_mv_far(mq0, mp0) || dbk_mv_far(mq1, mp1)) && (dbk_mv_far(mq1, mp0) || dbk_mv_far(mq0, mp1));
+    }
+    return 1;
+}
+
+/* one 4-sample luma edge segment; src = first sample on the Q side, offset = across the edge, step = along it (deblock.cpp:249-415) */
+static void dbk_luma_segment(xo_pixel* src, intptr_t step, intptr_t offset, int bs, int qp, int betaOffset, int tcOffset, int maskP, int maskQ)
+{
+    const int sh = X265_DEPTH - 8;
+    const int beta = k_dbkBeta[dbk_clip3(0, 51, qp + betaOffset)] << sh;
+#define S(line, k) ((int)src[(line) * step + (k) * offset])
+    const int dp0 = abs(S(0, -3) - 2 * S(0, -2) + S(0, -1)), dq0 = abs(S(0, 0) - 2 * S(0, 1) + S(0, 2));
+    const int dp3 = abs(S(3, -3) - 2 * S(3, -2) + S(3, -1)), dq3 = abs(S(3, 0) - 2 * S(3, 1) + S(3, 2));
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta) return;
+    const int tc = k_dbkTc[dbk_clip3(0, 53, qp + 2 * (bs - 1) + tcOffset)] << sh;
+    int strong = 2 * d0 < (beta >> 2) && 2 * d3 < (beta >> 2);
+    for (int line = 0; line < 4 && strong; line += 3)
+        strong = abs(S(line, -4) - S(line, -1)) + abs(S(line, 3) - S(line, 0)) < (beta >> 3) && abs(S(line, -1) - S(line, 0)) < ((tc * 5 + 1) >> 1);
+    const int side = (beta + (beta >> 1)) >> 3;
+    const int maskP1 = (dp0 + dp3 < side ? -1 : 0) & maskP, maskQ1 = (dq0 + dq3 < side ? -1 : 0) & maskQ;
+    for (int i = 0; i < 4; i++)
+    {
+        const int m0 = S(i, -4), m1 = S(i, -3), m2 = S(i, -2), m3 = S(i, -1), m4 = S(i, 0), m5 = S(i, 1), m6 = S(i, 2), m7 = S(i, 3);
+        xo_pixel* s = src + i * step;
+        if (strong)
+        {   /* pelFilterLumaStrong_c: no clip to the pixel range, the result is cast */
+            const int tcP = (2 * tc) & maskP, tcQ = (2 * tc) & maskQ;
+            s[-3 * offset] = (xo_pixel)(dbk_clip3(-tcP, tcP, ((2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3) - m1) + m1);
+            s[-2 * offset] = (xo_pixel)(dbk_clip3(-tcP, tcP, ((m1 + m2 + m3 + m4 + 2) >> 2) - m2) + m2);
+            s[-offset] = (xo_pixel)(dbk_clip3(-tcP, tcP, ((m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3) - m3) + m3);
+            s[0] = (xo_pixel)(dbk_clip3(-tcQ, tcQ, ((m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3) - m4) + m4);
+            s[offset] = (xo_pixel)(dbk_clip3(-tcQ, tcQ, ((m3 + m4 + m5 + m6 + 2) >> 2) - m5) + m5);
+            s[2 * offset] = (xo_pixel)(dbk_clip3(-tcQ, tcQ, ((m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3) - m6) + m6);
+            continue;
+        }
+        int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+        if (abs(delta) >= tc * 10) continue;
+        delta = dbk_clip3(-tc, tc, delta);
+        s[-offset] = (xo_pixel)dbk_pix(m3 + (delta & maskP));
+        s[0] = (xo_pixel)dbk_pix(m4 - (delta & maskQ));
+        if (maskP1) s[-2 * offset] = (xo_pixel)dbk_pix(m2 + dbk_clip3(-(tc >> 1), tc >> 1, (((m1 + m3 + 1) >> 1) - m2 + delta) >> 1));
+        if (maskQ1) s[offset] = (xo_pixel)dbk_pix(m5 + dbk_clip3(-(tc >> 1), tc >> 1, (((m6 + m4 + 1) >> 1) - m5 - delta) >> 1));
+    }
+#undef S
+}
+
+static const uint8_t k_dbkChromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33,
+                                              34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };   /* constants.cpp:346-350 (g_chromaScale) */
+
+void xo_deblock_frame(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_pixel* Cb, xo_pixel* Cr, intptr_t strideC, uint8_t* bsOut)
+{
+    const int uw = d->width >> 2, uh = d->height >> 2;
+    for (int dir = 0; dir < 2; dir++)
+        for (int uy = 0; uy < uh; uy++)
+            for (int ux = 0; ux < uw; ux++)
+            {
+                const int bs = xo_deblock_bs(d, ux, uy, dir);
+                if (bsOut) bsOut[((size_t)dir * uh + uy) * uw + ux] = (uint8_t)bs;
+                if (!bs || ((dir ? uy : ux) & 1)) continue;                             /* edges on the 8x8 grid only (DEBLOCK_SMALLEST_BLOCK) */
+                const uint32_t q = dbk_part(d, ux, uy), p = dir ? dbk_part(d, ux, uy - 1) : dbk_part(d, ux - 1, uy);
+                int maskP = -1, maskQ = -1;
+                if (d->tqBypassEnabled)
+                {
+                    maskP = d->tqBypass[p] ? 0 : -1; maskQ = d->tqBypass[q] ? 0 : -1;
+                    if (!(maskP | maskQ)) continue;
+                }
+                const int qp = (d->qp[p] + d->qp[q] + 1) >> 1;
+                dbk_luma_segment(Y + (intptr_t)uy * 4 * strideY + ux * 4, dir ? 1 : strideY, dir ? strideY : 1, bs, qp, 2 * d->betaOffsetDiv2, 2 * d->tcOffsetDiv2, maskP, maskQ);
+                /* chroma (4:2:0): edges on the 16-sample luma grid, intra strength only, one 4-sample chroma segment per TWO luma units along the edge */
+                if (bs < 2 || ((dir ? uy : ux) & 3) || ((dir ? ux : uy) & 1)) continue;
+                for (int c = 0; c < 2; c++)
+                {
+                    int cqp = qp + (c ? d->crQpOffset : d->cbQpOffset);
+                    if (cqp >= 30) cqp = k_dbkChromaScale[cqp > 57 ? 57 : cqp];
+                    const int tc = k_dbkTc[dbk_clip3(0, 53, cqp + 2 + 2 * d->tcOffsetDiv2)] << (X265_DEPTH - 8);
+                    xo_pixel* s = (c ? Cr : Cb) + (intptr_t)uy * 2 * strideC + ux * 2;
+                    const intptr_t step = dir ? 1 : strideC, off = dir ? strideC : 1;
+                    for (int i = 0; i < 4; i++, s += step)
+                    {
+                        const int m2 = s[-2 * off], m3 = s[-off], m4 = s[0], m5 = s[off];
+                        const int delta = dbk_clip3(-tc, tc, ((m4 - m3) * 4 + m2 - m5 + 4) >> 3);
+                        s[-off] = (xo_pixel)dbk_pix(m3 + (delta & maskP)); s[0] = (xo_pixel)dbk_pix(m4 - (delta & maskQ));
+                    }
+                }
+            }
+}

@@ -97,6 +97,19 @@ void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t st
 /* SAO of a luma plane, out of place (sao.cpp:268-623); params: per CTU { typeIdx, bandPos, offset[4] } */
 void xo_sao_apply_frame(const xo_pixel* in, xo_pixel* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params);
 uint64_t xo_plane_ssd(const xo_pixel* fenc, const xo_pixel* rec, intptr_t stride, int width, int height);   /* encoder.cpp:1203-1270 computeSSD */
+/* deblocking of a 4:2:0 picture, common/deblock.cpp:37-497 + common/loopfilter.cpp:136-232.  The per-partition arrays are CUData's (CTU after CTU,
+ * z-scan order inside a CTU): m_log2CUSize, m_partSize, m_tuDepth, m_predMode, m_cbf[0], m_tqBypass, m_qp, m_refIdx[0..1], m_mv[0..1] (int32 x, y);
+ * refPic[list][refIdx] identifies the picture (what the reference compares as Frame pointers). */
+typedef struct xo_deblock_pic
+{
+    int width, height, ctuSize, sliceIsP, betaOffsetDiv2, tcOffsetDiv2, cbQpOffset, crQpOffset, tqBypassEnabled;
+    const uint8_t *log2CUSize, *partSize, *tuDepth, *predMode, *cbfLuma, *tqBypass;
+    const int8_t *qp, *refIdx0, *refIdx1;
+    const int32_t *mv0, *mv1;
+    int32_t refPic[2][16];
+} xo_deblock_pic;
+int xo_deblock_bs(const xo_deblock_pic* d, int ux, int uy, int dir);
+void xo_deblock_frame(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_pixel* Cb, xo_pixel* Cr, intptr_t strideC, uint8_t* bsOut);
 /* framefilter.cpp:704-722, 839-865 + pixel.cpp:623-693: per CTU row float sums and window counts, frame total in double */
 void xo_ssim_frame(const xo_pixel* rec, intptr_t stride1, const xo_pixel* fenc, intptr_t stride2, int width, int height, int ctuSize,
                    float* rowSsim, uint32_t* rowCnt, double* total, uint32_t* cnt);

@@ -1,0 +1,30 @@
+"""Deblocking: the per-unit restatement xo_deblock_frame against the reference's Deblock::deblockCTU run on its own CUData objects
+(oracle/_ref/x265deblock_*, oracle/ref_deblock.cpp) -- random coded pictures: every CU size / partition shape / transform depth, intra / inter / skip,
+P and B slices with repeated reference pictures, QP extremes, PPS offsets, lossless CUs, pictures that are no CTU multiple.  Bit-exact, all three planes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+from oracle_py import Oracle  # noqa: E402
+from deblock_util import coded_picture, dbk_bin, run_oracle, run_reference  # noqa: E402
+
+CASES = [(8, 64, 64, 64, 1, False, False), (8, 136, 72, 64, 2, True, False), (8, 200, 152, 32, 3, False, True), (8, 96, 80, 16, 4, False, False),
+         (10, 136, 104, 64, 5, False, False), (10, 64, 64, 32, 6, True, True), (8, 320, 192, 64, 7, False, False), (10, 264, 136, 16, 8, False, True)]
+
+
+@pytest.mark.parametrize("depth,W,H,ctu,seed,slice_p,bypass", CASES)
+def test_deblock_frame_matches_reference(depth, W, H, ctu, seed, slice_p, bypass):
+    if not os.path.exists(dbk_bin(depth)):
+        pytest.skip("oracle/_ref/x265deblock_%d not built (needs /root/reference at build time)" % depth)
+    pic = coded_picture(depth, W, H, ctu, seed, slice_p, bypass)
+    ref = run_reference(pic)
+    got = run_oracle(Oracle(depth), pic)
+    changed = sum(int((r != p).sum()) for r, p in zip(ref, pic["planes"]))
+    assert changed > W * H // 50, "the picture hardly exercises the filter (%d samples changed)" % changed
+    for c in range(3):
+        bad = np.argwhere(got[c] != ref[c])
+        assert bad.size == 0, "plane %d: %d samples differ, first at (y, x) %s: oracle %d reference %d" % (c, len(bad), bad[0], got[c][tuple(bad[0])], ref[c][tuple(bad[0])])
