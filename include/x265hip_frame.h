@@ -200,6 +200,27 @@ size_t x265hip_ssim_workspace(int width, int height);
 int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stride1, const void* fenc, intptr_t stride2, int width, int height, int ctuSize,
                        void* workspace, float* rowSsim, uint32_t* rowCnt, double* frame);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------------------
+ * Deblocking of a reconstructed 4:2:0 picture, in place in HBM: replaces the Deblock::deblockCTU(ctu, geom, EDGE_VER / EDGE_HOR) calls of the frame
+ * filter (FrameFilter::ParallelFilter::processTasks, encoder/framefilter.cpp:383-443 -> common/deblock.cpp:37-497 -> primitives.pelFilterLumaStrong /
+ * pelFilterChroma, common/loopfilter.cpp:136-232).  The picture is described by CUData's own per-partition arrays, copied to the device as they are:
+ * CTU after CTU (raster order of CTUs), numPartitions = (ctuSize / 4)^2 entries per CTU in z-scan order -- m_log2CUSize, m_partSize, m_tuDepth,
+ * m_predMode (0 = not coded / outside the picture), m_cbf[0], m_tqBypass (may be NULL when !tqBypassEnabled), m_qp, m_refIdx[0], m_refIdx[1] (B slices),
+ * m_mv[0], m_mv[1] (int32 x, y pairs).  refPic[list][refIdx] = any integer identifying the picture behind slice->m_refFrameList[list][refIdx] (the reference
+ * compares Frame pointers; POCs do).  betaOffsetDiv2 / tcOffsetDiv2 / cb / crQpOffset / tqBypassEnabled are the PPS fields.  width and height are
+ * multiples of 8 (the minimum CU size); one slice (no slice / tile boundaries inside the picture).
+ * bsOut (optional, device, 2 * (height/4) * (width/4) bytes): the boundary strength of every examined edge segment, [dir][unitY][unitX].
+ * --------------------------------------------------------------------------------------------------------------------------------------------- */
+typedef struct x265hip_deblock_pic
+{
+    int width, height, ctuSize, sliceIsP, betaOffsetDiv2, tcOffsetDiv2, cbQpOffset, crQpOffset, tqBypassEnabled;
+    const uint8_t *log2CUSize, *partSize, *tuDepth, *predMode, *cbfLuma, *tqBypass;
+    const int8_t *qp, *refIdx0, *refIdx1;
+    const int32_t *mv0, *mv1;
+    int32_t refPic[2][16];
+} x265hip_deblock_pic;
+int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut);
+
 #ifdef __cplusplus
 }
 #endif
