@@ -183,7 +183,9 @@ int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, i
 /* SAO of a whole luma plane, OUT OF PLACE (in != out): SAO::generateLumaOffsets + applyPixelOffsets (encoder/sao.cpp:268-623) for every CTU.  The
  * reference filters in place and classifies against saved unmodified neighbours (m_tmpU, m_tmpL); reading the input plane is the same thing.
  * params (device): per CTU in raster order 6 int32 = typeIdx (-1 = off, 0..3 = SAO_EO_0..3, 4 = SAO_BO), bandPos, offset[4], with SAO_MERGE_LEFT / UP
- * already resolved to the merged CTU's values.  One slice (the picture's first / last rows are the slice's). */
+ * already resolved to the merged CTU's values.  One slice (the picture's first / last rows are the slice's).
+ * Chroma (SAO::generateChromaOffsets, sao.cpp:626-730): call it on the Cb / Cr plane with the plane's width, height and CTU size (ctuSize / 2 for 4:2:0, so 8..32);
+ * the two chroma planes share one typeIdx per CTU (the reference applies Cr with Cb's type, sao.cpp:721) -- pass Cb's typeIdx in Cr's records. */
 int x265hip_sao_apply_frame(void* stream, const void* in, void* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params);
 
 /* PSNR numerator of one plane: Encoder::computeSSD (encoder/encoder.cpp:1203-1270), the exact 64-bit sum of squared differences of the source and

@@ -9,9 +9,10 @@
  * usage: x265sao_<depth> <width> <height> <ctu> <in.raw> <out.bin> [sao-non-deblock 0|1] [planes 1|3]
  *   in.raw  : per plane (Y, then Cb, Cr of a 4:2:0 picture when planes = 3) the source plane then the reconstructed plane, tightly packed
  *   out.bin : per plane, per CTU 5 x 32 int32 offsetOrg then 5 x 32 int32 count (types SAO_EO_0..3, SAO_BO as in sao.h:43-50)
- * apply mode (argv[8] = params.bin: per CTU 6 int32 = typeIdx (-1 = off), bandPos, offset[4]): the luma SAO of the picture the way the frame filter runs
+ * apply mode (argv[8] = params.bin: per plane, per CTU 6 int32 = typeIdx (-1 = off), bandPos, offset[4]): the SAO of the picture (luma, and Cb / Cr through
+ *   SAO::generateChromaOffsets, sao.cpp:626-730, when planes = 3) the way the frame filter runs
  *   it -- SAO::generateLumaOffsets CTU by CTU in raster order (sao.cpp:566-623 -> applyPixelOffsets :268-563), m_tmpU holding the unmodified last row
- *   of the CTU row above (FrameFilter::ParallelFilter::copySaoAboveRef, framefilter.cpp:303-311); out.bin = the reconstructed plane afterwards (int32 per pixel)
+ *   of the CTU row above (FrameFilter::ParallelFilter::copySaoAboveRef, framefilter.cpp:303-311); out.bin = the reconstructed plane(s) afterwards (int32 per pixel)
  */
 #include "common.h"
 #include "primitives.h"
@@ -33,7 +34,7 @@ struct SaoX : public SAO
     void clear() { memset(m_count, 0, sizeof(m_count)); memset(m_offsetOrg, 0, sizeof(m_offsetOrg)); }
     const int32_t* counts() const { return &m_count[0][0][0]; }
     const int32_t* sums() const { return &m_offsetOrg[0][0][0]; }
-    pixel* aboveRow() { return m_tmpU[0]; }
+    pixel* aboveRow(int plane = 0) { return m_tmpU[plane]; }
 };
 
 int main(int argc, char** argv)
@@ -89,27 +90,53 @@ int main(int argc, char** argv)
     if (argc > 8)
     {
         FILE* pf = fopen(argv[8], "rb");
-        std::vector<int32_t> raw(6 * (size_t)sps.numCUsInFrame);
+        std::vector<int32_t> raw(6 * (size_t)sps.numCUsInFrame * nplanes);
         if (!pf || fread(raw.data(), 4, raw.size(), pf) != raw.size()) { fprintf(stderr, "bad params file\n"); return 2; }
         fclose(pf);
-        std::vector<SaoCtuParam> prm(sps.numCUsInFrame);
-        for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
+        std::vector<SaoCtuParam> prm[3];
+        for (int c = 0; c < nplanes; c++)
         {
-            prm[a].reset(); prm[a].typeIdx = raw[6 * a]; prm[a].bandPos = (uint32_t)raw[6 * a + 1];
-            for (int i = 0; i < 4; i++) prm[a].offset[i] = raw[6 * a + 2 + i];
+            prm[c].resize(sps.numCUsInFrame);
+            for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
+            {
+                const int32_t* r = &raw[6 * ((size_t)c * sps.numCUsInFrame + a)];
+                prm[c][a].reset(); prm[c][a].typeIdx = r[0]; prm[c][a].bandPos = (uint32_t)r[1];
+                for (int i = 0; i < 4; i++) prm[c][a].offset[i] = r[2 + i];
+            }
         }
         PicYuv* rp = frame.m_reconPic[0];
-        std::vector<pixel> pristine((size_t)rp->m_stride * H);
-        for (int y = 0; y < H; y++) memcpy(&pristine[(size_t)y * rp->m_stride], rp->m_picOrg[0] + (intptr_t)y * rp->m_stride, W * sizeof(pixel));
+        std::vector<pixel> pristine[3];
+        for (int c = 0; c < nplanes; c++)
+        {
+            const int w = c ? W >> 1 : W, h = c ? H >> 1 : H;
+            const intptr_t st = c ? rp->m_strideC : rp->m_stride;
+            pristine[c].resize((size_t)st * h);
+            for (int y = 0; y < h; y++) memcpy(&pristine[c][(size_t)y * st], rp->m_picOrg[c] + (intptr_t)y * st, w * sizeof(pixel));
+        }
+        SaoCtuParam* prm3[3] = { prm[0].data(), nplanes == 3 ? prm[1].data() : NULL, nplanes == 3 ? prm[2].data() : NULL };
         for (uint32_t row = 0; row < sps.numCuInHeight; row++)
         {
-            /* copySaoAboveRef: the unmodified row above the CTU row -- for the first CTU row its own first row (framefilter.cpp:307) */
-            memcpy(sao.aboveRow(), &pristine[(size_t)(row ? row * ctu - 1 : 0) * rp->m_stride], W * sizeof(pixel));
-            for (uint32_t col = 0; col < sps.numCuInWidth; col++) sao.generateLumaOffsets(prm.data(), (int)row, (int)col);
+            /* copySaoAboveRef: the unmodified row above the CTU row -- for the first CTU row its own first row (framefilter.cpp:303-325) */
+            for (int c = 0; c < nplanes; c++)
+            {
+                const int w = c ? W >> 1 : W, ch = c ? ctu >> 1 : ctu;
+                const intptr_t st = c ? rp->m_strideC : rp->m_stride;
+                memcpy(sao.aboveRow(c), &pristine[c][(size_t)(row ? row * ch - 1 : 0) * st], w * sizeof(pixel));
+            }
+            for (uint32_t col = 0; col < sps.numCuInWidth; col++)
+            {
+                sao.generateLumaOffsets(prm3[0], (int)row, (int)col);
+                if (nplanes == 3) sao.generateChromaOffsets(prm3, (int)row, (int)col);
+            }
         }
-        std::vector<int32_t> o((size_t)W * H);
-        for (int y = 0; y < H; y++) for (int x = 0; x < W; x++) o[(size_t)y * W + x] = rp->m_picOrg[0][(intptr_t)y * rp->m_stride + x];
-        fwrite(o.data(), 4, o.size(), out);
+        for (int c = 0; c < nplanes; c++)
+        {
+            const int w = c ? W >> 1 : W, h = c ? H >> 1 : H;
+            const intptr_t st = c ? rp->m_strideC : rp->m_stride;
+            std::vector<int32_t> o((size_t)w * h);
+            for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) o[(size_t)y * w + x] = rp->m_picOrg[c][(intptr_t)y * st + x];
+            fwrite(o.data(), 4, o.size(), out);
+        }
         fclose(out); fclose(in);
         return 0;
     }

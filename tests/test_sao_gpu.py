@@ -97,3 +97,25 @@ def test_sao_apply_frame_matches_oracle(depth, size, ctu):
         e1.record(); t.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         print("sao_apply %d bit %dx%d: %.4f ms, %.0f GB/s algorithmic (plane read + written)" % (depth, W, H, ms, 2 * W * H * rec.itemsize / ms / 1e6))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((72, 40), 32), ((136, 72), 16), ((1920, 1080), 64)])
+def test_sao_apply_chroma_planes_match_oracle(depth, size, ctu):
+    """Cb / Cr of a 4:2:0 picture = x265hip_sao_apply_frame on the chroma plane with its dimensions and CTU size (oracle pinned to generateChromaOffsets)"""
+    import ctypes as C
+    from x265hip_pkg.frame import FrameApi
+    from test_sao_oracle_vs_ref import sao_apply_oracle, sao_frame_pair, sao_params
+    api, ora = FrameApi(depth), Oracle(depth)
+    t = api.torch
+    W, H = size[0] // 2, size[1] // 2
+    n = ((size[0] + ctu - 1) // ctu) * ((size[1] + ctu - 1) // ctu)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    for c in (1, 2):
+        _, rec = sao_frame_pair(depth, W, H, 50 + c + depth + W)
+        prm = sao_params(np.random.default_rng(W + depth + c), n, depth)
+        exp = sao_apply_oracle(ora, rec, ctu // 2, prm)
+        d_in = api.to_device(np.ascontiguousarray(rec).reshape(-1)); d_out = t.zeros_like(d_in); d_prm = api.to_device(prm.astype(np.int32).reshape(-1))
+        api.h.check(api.lib.x265hip_sao_apply_frame(api.stream(), P(d_in), P(d_out), C.c_ssize_t(W), W, H, ctu // 2, P(d_prm)))
+        got = d_out.cpu().numpy().reshape(H, W)
+        assert np.array_equal(got, exp)

@@ -140,3 +140,47 @@ def test_sao_apply_frame_matches_reference(depth, size, ctu):
     bad = np.argwhere(a != b.astype(np.int32))
     assert bad.size == 0, "first differing pixel (y, x) %s: reference %d oracle %d, CTU params %s" % (bad[0], a[tuple(bad[0])], b[tuple(bad[0])], prm[(bad[0][0] // ctu) * ((W + ctu - 1) // ctu) + bad[0][1] // ctu])
     assert (a != rec.astype(np.int32)).sum() > 0
+
+
+def sao_apply_reference_420(depth, planes, ctu, params3):
+    """planes: [(fenc, rec)] * 3 (Y, Cb, Cr); params3: [3, nCtu, 6] -> the three planes after SAO::generateLumaOffsets / generateChromaOffsets"""
+    import os, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    H, W = planes[0][1].shape
+    with tempfile.TemporaryDirectory() as td:
+        inp, out, prm = os.path.join(td, "in.raw"), os.path.join(td, "out.bin"), os.path.join(td, "p.bin")
+        np.concatenate([a.reshape(-1) for pair in planes for a in pair]).tofile(inp); params3.astype(np.int32).tofile(prm)
+        r = subprocess.run([os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth), str(W), str(H), str(ctu), inp, out, "0", "3", prm], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1000:]
+        d = np.fromfile(out, np.int32)
+    return [d[:W * H].reshape(H, W), d[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), d[W * H + W * H // 4:].reshape(H // 2, W // 2)]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((192, 128), 64), ((72, 40), 32), ((136, 72), 16)])
+def test_sao_apply_chroma_matches_reference(depth, size, ctu):
+    """Cb / Cr through SAO::generateChromaOffsets (sao.cpp:626-730) = the plane-level restatement called with the chroma plane's dimensions and CTU size"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth)):
+        pytest.skip("no reference SAO binary")
+    W, H = size
+    planes = [sao_frame_pair(depth, W, H, 41 + depth + W), sao_frame_pair(depth, W // 2, H // 2, 42 + depth + W), sao_frame_pair(depth, W // 2, H // 2, 43 + depth + W)]
+    n = ((W + ctu - 1) // ctu) * ((H + ctu - 1) // ctu)
+    rng = np.random.default_rng(W * 3 + depth)
+    prm = np.stack([sao_params(rng, n, depth) for _ in range(3)])
+    # Cb and Cr share one type per CTU (sao_type_idx_chroma; generateChromaOffsets applies Cr with Cb's type, sao.cpp:721): own band position and offsets only
+    prm[2, :, 0] = prm[1, :, 0]
+    for a in range(n):
+        t = prm[1, a, 0]
+        if t == 4:
+            prm[2, a, 1] = rng.integers(0, 32); prm[2, a, 2:] = rng.integers(-7, 8, 4)
+        elif t >= 0:
+            prm[2, a, 2:] = (rng.integers(0, 8), rng.integers(0, 8), -rng.integers(0, 8), -rng.integers(0, 8))
+    ref = sao_apply_reference_420(depth, planes, ctu, prm)
+    ora = Oracle(depth)
+    for c in range(3):
+        got = sao_apply_oracle(ora, planes[c][1], ctu if c == 0 else ctu // 2, prm[c])
+        bad = np.argwhere(ref[c] != got.astype(np.int32))
+        assert bad.size == 0, "plane %d first differing pixel (y, x) %s: reference %d oracle %d" % (c, bad[0], ref[c][tuple(bad[0])], got[tuple(bad[0])])
+        assert (ref[c] != planes[c][1].astype(np.int32)).sum() > 0

@@ -537,9 +537,9 @@ extern "C" int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stri
 
 extern "C" int x265hip_sao_apply_frame(void* stream, const void* in, void* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params)
 {
-    if (!in || !out || in == out || !params || picWidth < 1 || picHeight < 1 || (ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth)
+    if (!in || !out || in == out || !params || picWidth < 1 || picHeight < 1 || (ctuSize != 8 && ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth)
     { set_error("sao_apply_frame: bad arguments (out of place only)"); return X265HIP_EARG; }
-    const int lg = ctuSize == 64 ? 6 : ctuSize == 32 ? 5 : 4;
+    const int lg = ctuSize == 64 ? 6 : ctuSize == 32 ? 5 : ctuSize == 16 ? 4 : 3;        // 8: the chroma plane of a 4:2:0 picture with 16x16 CTUs
     hipLaunchKernelGGL(sao_apply_kernel, dim3((picWidth + 255) / 256, (picHeight + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const pixel*)in, (pixel*)out, stride,
                        picWidth, picHeight, ctuSize, lg, params);
     XH_LAUNCH_CHECK();
