@@ -53,7 +53,174 @@ def parse():
     ap.add_argument("--lookahead", action="store_true", help="also time the lookahead frame-cost batch (lowres init, intra estimate, estimateFrameCost of a 32-picture window); reported under \"lookahead\", not part of value")
     ap.add_argument("--intra", action="store_true", help="also time the intra mode scan (35 sa8d costs per CU, sizes 64..8) over the same frames; reported under \"intra_scan\", not part of value")
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--filters", action="store_true", help="also time the in-loop filter chain after reconstruction (deblock, SAO statistics, SAO apply, SSIM, SSD) on 8 coded 1080p pictures; reported under \"filters\", not part of value")
     return ap.parse_args()
+
+
+def filters_leg(depth, steps):
+    """In-loop filters and picture statistics after reconstruction: 8 coded 4:2:0 pictures of 1920x1080 resident in HBM ->
+    deblocking (in place), SAO statistics of the three planes, SAO of the three planes (out of place), SSIM of the luma plane and the SSD of the
+    three planes against the source.  Every stage of picture 0 is compared with the oracle (the CPU restatement pinned to the reference's own
+    Deblock / SAO classes and to the encoder's reported SSIM / PSNR); the oracle's clock on that picture is the host number (one core, a port)."""
+    import ctypes as C
+    import time
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from deblock_util import I8, U8, coded_picture, descriptor, run_oracle
+    from oracle_py import Oracle
+    from x265hip_pkg.frame import FrameApi
+    api, ora = FrameApi(depth), Oracle(depth)
+    W, H, ctu, F = 1920, 1080 - 1080 % 8, 64, 8
+    pic = coded_picture(depth, W, H, ctu, 21)
+    rng = np.random.default_rng(5)
+    pm = (1 << depth) - 1
+    src = [np.clip(p.astype(np.int64) + rng.integers(-3, 4, p.shape) * (1 << (depth - 8)), 0, pm).astype(p.dtype) for p in pic["planes"]]   # the "source" the statistics compare with
+    n_ctu = ((W + ctu - 1) // ctu) * ((H + ctu - 1) // ctu)
+    prm = np.zeros((3, n_ctu, 6), np.int32)
+    for c in range(3):
+        for a in range(n_ctu):
+            t = int(rng.integers(-1, 5)) if c != 2 else int(prm[1, a, 0])
+            prm[c, a, 0] = t
+            if t == 4:
+                prm[c, a, 1] = rng.integers(0, 32); prm[c, a, 2:] = rng.integers(-7, 8, 4)
+            elif t >= 0:
+                prm[c, a, 2:] = (rng.integers(0, 8), rng.integers(0, 8), -rng.integers(0, 8), -rng.integers(0, 8))
+    P = lambda x: C.c_void_p(x.data_ptr())
+    shapes = [(H, W), (H // 2, W // 2), (H // 2, W // 2)]
+    d_pristine = [api.to_device(p.reshape(-1)) for p in pic["planes"]]
+    d_src = [api.to_device(p.reshape(-1)) for p in src]
+    d_rec = [[torch.empty_like(x) for x in d_pristine] for _ in range(F)]
+    d_out = [[torch.empty_like(x) for x in d_pristine] for _ in range(F)]
+    arrs = {k: api.to_device(np.ascontiguousarray(pic[k]).reshape(-1)) for k in U8 + I8 + ("mv0", "mv1")}
+    desc = descriptor(pic, lambda k: arrs[k].data_ptr())
+    d_prm = [api.to_device(prm[c].reshape(-1)) for c in range(3)]
+    d_stats = [[torch.zeros(n_ctu * 2 * 5 * 32, dtype=torch.int32, device="cuda") for _ in range(3)] for _ in range(F)]
+    api.lib.x265hip_ssim_workspace.restype = C.c_size_t
+    d_ws = torch.zeros(api.lib.x265hip_ssim_workspace(W, H) // 4, dtype=torch.float32, device="cuda")
+    nrows = (H + ctu - 1) // ctu
+    d_rs = [torch.zeros(nrows, dtype=torch.float32, device="cuda") for _ in range(F)]; d_rc = [torch.zeros(nrows, dtype=torch.int32, device="cuda") for _ in range(F)]
+    d_fr = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(F)]
+    d_ssd = [torch.zeros(3, dtype=torch.int64, device="cuda") for _ in range(F)]
+    st, L, esz = api.stream(), api.lib, d_pristine[0].element_size()
+
+    def restore():
+        for f in range(F):
+            for c in range(3):
+                d_rec[f][c].copy_(d_pristine[c])
+
+    def deblock():
+        for f in range(F):
+            api.h.check(L.x265hip_deblock_frame(st, C.byref(desc), P(d_rec[f][0]), C.c_ssize_t(W), P(d_rec[f][1]), P(d_rec[f][2]), C.c_ssize_t(W // 2), None))
+
+    def sao_stats():
+        for f in range(F):
+            for c in range(3):
+                h, w = shapes[c]
+                api.h.check(L.x265hip_sao_stats_frame(st, P(d_src[c]), P(d_rec[f][c]), C.c_ssize_t(w), w, h, ctu if c == 0 else ctu // 2, 0, 0 if c == 0 else 2, P(d_stats[f][c])))
+
+    def sao_apply():
+        for f in range(F):
+            for c in range(3):
+                h, w = shapes[c]
+                api.h.check(L.x265hip_sao_apply_frame(st, P(d_rec[f][c]), P(d_out[f][c]), C.c_ssize_t(w), w, h, ctu if c == 0 else ctu // 2, P(d_prm[c])))
+
+    def quality():
+        for f in range(F):
+            api.h.check(L.x265hip_ssim_frame(st, P(d_out[f][0]), C.c_ssize_t(W), P(d_src[0]), C.c_ssize_t(W), W, H, ctu, P(d_ws), P(d_rs[f]), P(d_rc[f]), P(d_fr[f])))
+            for c in range(3):
+                h, w = shapes[c]
+                api.h.check(L.x265hip_plane_ssd(st, P(d_src[c]), P(d_out[f][c]), C.c_ssize_t(w), w, h, C.c_void_p(d_ssd[f].data_ptr() + 8 * c)))
+
+    def timed(fn, reps, before=None):
+        tot = 0.0
+        for _ in range(reps + 1):
+            if before:
+                before()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1) if _ else 0.0
+        return tot / reps
+    ms = {"deblock": timed(deblock, steps, restore), "sao_stats": timed(sao_stats, steps), "sao_apply": timed(sao_apply, steps), "ssim_ssd": timed(quality, steps)}
+    total = sum(ms.values())
+    px = F * W * H
+
+    # the same work with every picture's chain on its own HIP stream: the kernels are small (a 1080p plane does not fill 256 CUs), so chains of
+    # different pictures overlap instead of queueing behind each other's launch gaps
+    streams = [torch.cuda.Stream() for _ in range(F)]
+
+    def chain(f, sh):
+        h_ = C.c_void_p(sh)
+        api.h.check(L.x265hip_deblock_frame(h_, C.byref(desc), P(d_rec[f][0]), C.c_ssize_t(W), P(d_rec[f][1]), P(d_rec[f][2]), C.c_ssize_t(W // 2), None))
+        for c in range(3):
+            h, w = shapes[c]
+            cs = ctu if c == 0 else ctu // 2
+            api.h.check(L.x265hip_sao_stats_frame(h_, P(d_src[c]), P(d_rec[f][c]), C.c_ssize_t(w), w, h, cs, 0, 0 if c == 0 else 2, P(d_stats[f][c])))
+            api.h.check(L.x265hip_sao_apply_frame(h_, P(d_rec[f][c]), P(d_out[f][c]), C.c_ssize_t(w), w, h, cs, P(d_prm[c])))
+            api.h.check(L.x265hip_plane_ssd(h_, P(d_src[c]), P(d_out[f][c]), C.c_ssize_t(w), w, h, C.c_void_p(d_ssd[f].data_ptr() + 8 * c)))
+        api.h.check(L.x265hip_ssim_frame(h_, P(d_out[f][0]), C.c_ssize_t(W), P(d_src[0]), C.c_ssize_t(W), W, H, ctu, P(d_wsf[f]), P(d_rs[f]), P(d_rc[f]), P(d_fr[f])))
+
+    d_wsf = [torch.zeros_like(d_ws) for _ in range(F)]
+    def all_chains():
+        here = torch.cuda.current_stream()
+        for f in range(F):
+            streams[f].wait_stream(here)
+            chain(f, streams[f].cuda_stream)
+        for f in range(F):
+            here.wait_stream(streams[f])
+    ms_streams = timed(all_chains, steps, restore)
+    # ... and captured once as a hipGraph (fork into the per-picture streams, join), replayed: the ~170 launches cost no host time any more
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        all_chains()
+    ms_graph = timed(graph.replay, steps, restore)
+    nbytes = sum(p.nbytes for p in pic["planes"])
+    out = {"what": "deblock (in place) -> SAO statistics -> SAO (out of place) -> SSIM + SSD, 3 planes of %d coded 4:2:0 pictures, one call per picture and plane" % F,
+           "frame": "%dx%d" % (W, H), "pictures": F, "ms": {k: round(v, 4) for k, v in ms.items()}, "ms_per_picture": round(total / F, 4),
+           "mpixels_per_s": round(px / (total * 1e-3) / 1e6, 1),
+           "one_stream_per_picture": {"ms": round(ms_streams, 4), "ms_per_picture": round(ms_streams / F, 4), "mpixels_per_s": round(px / (ms_streams * 1e-3) / 1e6, 1)},
+           "hipgraph_of_the_streams": {"ms": round(ms_graph, 4), "ms_per_picture": round(ms_graph / F, 4), "mpixels_per_s": round(px / (ms_graph * 1e-3) / 1e6, 1)},
+           "algorithmic_GBps": {"deblock": round(4 * nbytes * F / (ms["deblock"] * 1e-3) / 1e9, 1), "sao_stats": round(2 * nbytes * F / (ms["sao_stats"] * 1e-3) / 1e9, 1),
+                                "sao_apply": round(2 * nbytes * F / (ms["sao_apply"] * 1e-3) / 1e9, 1), "ssim_ssd": round((2 * nbytes + 2 * pic["planes"][0].nbytes) * F / (ms["ssim_ssd"] * 1e-3) / 1e9, 1)}}
+    # the same chain through the oracle on one picture: results identical, its clock = the host number
+    LO = ora.lib
+    N = lambda a: C.c_void_p(a.ctypes.data)
+    t0 = time.perf_counter()
+    o_rec = run_oracle(ora, pic)
+    t1 = time.perf_counter()
+    o_stats = []
+    for c in range(3):
+        h, w = shapes[c]
+        o = np.zeros(n_ctu * 2 * 5 * 32, np.int32)
+        LO.xo_sao_stats_frame(N(src[c]), N(o_rec[c]), C.c_ssize_t(w), w, h, ctu if c == 0 else ctu // 2, 0, 0 if c == 0 else 2, N(o))
+        o_stats.append(o)
+    t2 = time.perf_counter()
+    o_out = []
+    for c in range(3):
+        h, w = shapes[c]
+        o = np.zeros_like(o_rec[c]); pc = np.ascontiguousarray(prm[c])
+        LO.xo_sao_apply_frame(N(o_rec[c]), N(o), C.c_ssize_t(w), w, h, ctu if c == 0 else ctu // 2, N(pc))
+        o_out.append(o)
+    t3 = time.perf_counter()
+    rs, rc = np.zeros(nrows, np.float32), np.zeros(nrows, np.uint32)
+    tot, cnt = C.c_double(0), C.c_uint32(0)
+    LO.xo_ssim_frame(N(o_out[0]), C.c_ssize_t(W), N(src[0]), C.c_ssize_t(W), W, H, ctu, N(rs), N(rc), C.byref(tot), C.byref(cnt))
+    LO.xo_plane_ssd.restype = C.c_uint64
+    o_ssd = [int(LO.xo_plane_ssd(N(src[c]), N(o_out[c]), C.c_ssize_t(shapes[c][1]), shapes[c][1], shapes[c][0])) for c in range(3)]
+    t4 = time.perf_counter()
+    restore(); deblock(); sao_stats(); sao_apply(); quality(); torch.cuda.synchronize()
+    for c in range(3):
+        assert np.array_equal(d_rec[0][c].cpu().numpy().view(o_rec[c].dtype).reshape(shapes[c]), o_rec[c]), "filters: deblocked plane %d differs from the oracle" % c
+        assert np.array_equal(d_stats[0][c].cpu().numpy(), o_stats[c]), "filters: SAO statistics of plane %d differ from the oracle" % c
+        assert np.array_equal(d_out[0][c].cpu().numpy().view(o_out[c].dtype).reshape(shapes[c]), o_out[c]), "filters: SAO output plane %d differs from the oracle" % c
+    fr = d_fr[0].cpu().numpy()
+    assert fr[0] == tot.value and int(fr[1]) == cnt.value, "filters: SSIM differs from the oracle"
+    assert [int(v) for v in d_ssd[0].cpu().numpy()] == o_ssd, "filters: SSD differs from the oracle"
+    cpu_ms = {"deblock": (t1 - t0) * 1e3, "sao_stats": (t2 - t1) * 1e3, "sao_apply": (t3 - t2) * 1e3, "ssim_ssd": (t4 - t3) * 1e3}
+    out["ssim"] = fr[0] / fr[1]
+    out["cpu_port"] = {"kind": "port", "cores": 1, "sample": "the same chain on one of the pictures through the oracle (C, -O2), every plane / statistic / SSIM identical to the GPU's",
+                       "ms_per_picture": {k: round(v, 2) for k, v in cpu_ms.items()}, "mpixels_per_s": round(W * H / (sum(cpu_ms.values()) * 1e-3) / 1e6, 1),
+                       "gpu_over_one_core": round((px / (min(total, ms_streams, ms_graph) * 1e-3)) / (W * H / (sum(cpu_ms.values()) * 1e-3)), 1)}
+    return out
 
 
 def lookahead_leg(depth, steps):
@@ -381,10 +548,10 @@ def main():
         alg[names[-1]] = px * (2 * bpp + 2) + len(pipe.tu_host) * 4
         if pipe.use_planes:
             alg["planes"] = pipe.F * pipe.plane * bpp * 17          # 1 plane read + 16 written (15 phases + the slot-0 copy; padded planes)
-        # dominant kernel = longest average launch; planes and me64 run within a few percent of each other, so launches within 5 % of the
+        # dominant kernel = longest average launch; planes and me64 run within a few percent of each other, so launches within 10 % of the
         # longest are treated as tied and the tie goes to the one that moves the most algorithmic bytes (the HBM-relevant one)
         longest = max(kms.values())
-        dom = max((k for k in kms if kms[k] >= 0.95 * longest), key=lambda k: alg[k])
+        dom = max((k for k in kms if kms[k] >= 0.90 * longest), key=lambda k: alg[k])
         achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
@@ -402,7 +569,7 @@ def main():
             "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames,
                        "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "qp": args.qp,
                        "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": ("TQ on a side stream beside the me16/me8 launches (it needs the me32 MVs only), joined per step" if pipe.overlap_tq else "kernel by kernel") + "; per-kernel events on every 4th step", "sharding": "independent frames per GPU, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "longest average launch; ties within 5 % go to the larger algorithmic byte count", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "longest average launch; launches within 10 % of the longest count as tied (planes, me64 and me8 swap places from box to box) and the tie goes to the larger algorithmic byte count, i.e. to the kernel an HBM roofline means something for; every kernel's GB/s is in all_kernels_GBps", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
                          "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()},
@@ -412,6 +579,8 @@ def main():
             out["intra_scan"] = intra_scan_leg(pipe, depth, max(2, min(args.steps, 10)))
         if args.lookahead:
             out["lookahead"] = lookahead_leg(depth, max(2, min(args.steps, 10)))
+        if args.filters:
+            out["filters"] = filters_leg(depth, max(2, min(args.steps, 10)))
         if world == 1 and args.cpu_ctus > 0:
             out["cpu_baseline"] = cpu_baseline(pipe, depth, args.cpu_ctus)
         else:
