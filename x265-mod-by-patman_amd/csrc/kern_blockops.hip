@@ -303,12 +303,12 @@ __global__ __launch_bounds__(256) void ssim_window_kernel(const pixel* __restric
     E[(size_t)wy * nwx + wx] = ssim_window((int)(a.x + b.x + c.x + d.x), (int)(a.y + b.y + c.y + d.y), (int)(a.z + b.z + c.z + d.z), (int)(a.w + b.w + c.w + d.w));
 }
 
-// one wavefront per CTU row: the lanes form the four-window partials (ssim_end_4) of as many window rows as fit in 32 KB of LDS (all 16 of a 64-row
-// CTU row up to 2K-wide pictures) with every global load in flight at once, then lane 0 adds them to the running sum in order, 16 partials per step
-// fetched as four 16-byte LDS reads.  Measured at 1080p (17 wavefronts, 1920 ordered additions each): 40 us, the same as one window row per barrier with
-// one LDS read per addition -- what remains is the chain of dependent additions on a single lane of an otherwise idle chip; taking the partials out of
-// the lanes with v_readlane instead of LDS was slower (60 us).
-__global__ __launch_bounds__(64) void ssim_rows_kernel(const float* __restrict__ E, int nwx, int width, int height, int ctuSize, int numRows,
+// one workgroup per CTU row: 1024 threads form the four-window partials (ssim_end_4) of as many window rows as fit in 32 KB of LDS (all 16 of a 64-row
+// CTU row up to 2K-wide pictures), then thread 0 adds them to the running sum in order, 16 partials per step fetched as four 16-byte LDS reads.
+// What bounds it is the latency of the global loads of the window values (written by the previous launch, i.e. not in this XCD's L2): with 64 threads
+// every thread walked 32 groups one load-wait after the other (40 us per 1080p picture, however the additions were fed -- LDS scalar / vector reads or
+// v_readlane, 60 us); 1024 threads take two groups each.
+__global__ __launch_bounds__(1024) void ssim_rows_kernel(const float* __restrict__ E, int nwx, int width, int height, int ctuSize, int numRows,
                                                        float* __restrict__ rowSsim, uint32_t* __restrict__ rowCnt)
 {
     constexpr int CAP = 8192;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void ssim_rows_kernel(const float* __restrict__
     for (uint32_t y = 1; y < hb; y += chunk)
     {
         const int rows = min((uint32_t)chunk, hb - y);
-        for (int t = threadIdx.x; t < rows * padded; t += 64)
+        for (int t = threadIdx.x; t < rows * padded; t += 1024)
         {
             const int k = t / padded, g = t - k * padded;
             const float* e = E + (size_t)(wy0 + y + k - 1) * nwx;
@@ -548,7 +548,7 @@ extern "C" int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stri
     }
     hipLaunchKernelGGL(ssim_window_kernel, dim3((nwx + 31) / 32, (nwy + 7) / 8), dim3(256), 0, st, (const pixel*)recon, stride1, (const pixel*)fenc, stride2, nwx, nwy,
                        (float*)workspace);
-    hipLaunchKernelGGL(ssim_rows_kernel, dim3(numRows), dim3(64), 0, st, (const float*)workspace, nwx, width, height, ctuSize, numRows, rowSsim, rowCnt);
+    hipLaunchKernelGGL(ssim_rows_kernel, dim3(numRows), dim3(1024), 0, st, (const float*)workspace, nwx, width, height, ctuSize, numRows, rowSsim, rowCnt);
     hipLaunchKernelGGL(ssim_total_kernel, dim3(1), dim3(1), 0, st, (const float*)rowSsim, (const uint32_t*)rowCnt, numRows, frame);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
