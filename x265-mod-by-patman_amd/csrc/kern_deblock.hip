@@ -33,33 +33,42 @@ __device__ __forceinline__ uint32_t part_index(int ux, int uy, int lgUpc, int nx
 
 __device__ __forceinline__ bool mv_far(int2 a, int2 b) { return abs(a.x - b.x) >= 4 || abs(a.y - b.y) >= 4; }
 
-template<int DIR>
-__device__ __forceinline__ int boundary_strength(const x265hip_deblock_pic& d, int ux, int uy, uint32_t q, uint32_t p)
+// everything the strength derivation reads about one unit, fetched in one go (all loads independent of each other)
+struct UnitInfo { int log2CU, part, tu, mode, cbf, ref0, ref1, qp, bypass; int2 mv0, mv1; };
+
+__device__ __forceinline__ UnitInfo load_unit(const x265hip_deblock_pic& d, uint32_t i, bool needL1)
 {
-    const int pos = (DIR ? uy : ux) * 4, cuSize = 1 << d.log2CUSize[q], rel = pos & (cuSize - 1);
-    const int tuQ = d.tuDepth[q];
+    UnitInfo u;
+    u.log2CU = d.log2CUSize[i]; u.part = d.partSize[i]; u.tu = d.tuDepth[i]; u.mode = d.predMode[i]; u.cbf = d.cbfLuma[i]; u.qp = d.qp[i];
+    u.ref0 = d.refIdx0[i]; u.mv0 = ((const int2*)d.mv0)[i];
+    u.ref1 = needL1 ? (int)d.refIdx1[i] : -1; u.mv1 = needL1 ? ((const int2*)d.mv1)[i] : make_int2(0, 0);
+    u.bypass = d.tqBypassEnabled ? (int)d.tqBypass[i] : 0;
+    return u;
+}
+
+template<int DIR>
+__device__ __forceinline__ int boundary_strength(const x265hip_deblock_pic& d, int ux, int uy, const UnitInfo& Q, const UnitInfo& P)
+{
+    const int pos = (DIR ? uy : ux) * 4, cuSize = 1 << Q.log2CU, rel = pos & (cuSize - 1);
     int bs;
     if (!rel) bs = pos > 0 ? 2 : 0;                                                    // CU edge (bsCuEdge): the neighbour exists except at the picture border
-    else if (!(rel & ((cuSize >> tuQ) - 1))) bs = 2;                                    // transform edge
+    else if (!(rel & ((cuSize >> Q.tu) - 1))) bs = 2;                                   // transform edge
     else
     {
-        const int ps = d.partSize[q];
+        const int ps = Q.part;
         const int at = DIR ? (ps == 1 || ps == 3 ? cuSize >> 1 : ps == 4 ? cuSize >> 2 : ps == 5 ? cuSize - (cuSize >> 2) : -1)
                            : (ps == 2 || ps == 3 ? cuSize >> 1 : ps == 6 ? cuSize >> 2 : ps == 7 ? cuSize - (cuSize >> 2) : -1);
         bs = rel == at ? 1 : 0;                                                        // prediction edge inside the CU
     }
     if (!bs) return 0;
-    if (d.predMode[p] == 2 || d.predMode[q] == 2) return 2;
-    if (bs > 1 && (((d.cbfLuma[q] >> tuQ) & 1) || ((d.cbfLuma[p] >> d.tuDepth[p]) & 1))) return 1;
-    const int ip0 = d.refIdx0[p], iq0 = d.refIdx0[q];
-    const int rp0 = ip0 >= 0 ? d.refPic[0][ip0 & 15] : -1, rq0 = iq0 >= 0 ? d.refPic[0][iq0 & 15] : -1;
-    const int2* mv0 = (const int2*)d.mv0; const int2* mv1 = (const int2*)d.mv1;
+    if (P.mode == 2 || Q.mode == 2) return 2;
+    if (bs > 1 && (((Q.cbf >> Q.tu) & 1) || ((P.cbf >> P.tu) & 1))) return 1;
+    const int rp0 = P.ref0 >= 0 ? d.refPic[0][P.ref0 & 15] : -1, rq0 = Q.ref0 >= 0 ? d.refPic[0][Q.ref0 & 15] : -1;
     const int2 zero = make_int2(0, 0);
-    const int2 mp0 = rp0 >= 0 ? mv0[p] : zero, mq0 = rq0 >= 0 ? mv0[q] : zero;
+    const int2 mp0 = rp0 >= 0 ? P.mv0 : zero, mq0 = rq0 >= 0 ? Q.mv0 : zero;
     if (d.sliceIsP) return rp0 != rq0 || mv_far(mq0, mp0);
-    const int ip1 = d.refIdx1[p], iq1 = d.refIdx1[q];
-    const int rp1 = ip1 >= 0 ? d.refPic[1][ip1 & 15] : -1, rq1 = iq1 >= 0 ? d.refPic[1][iq1 & 15] : -1;
-    const int2 mp1 = rp1 >= 0 ? mv1[p] : zero, mq1 = rq1 >= 0 ? mv1[q] : zero;
+    const int rp1 = P.ref1 >= 0 ? d.refPic[1][P.ref1 & 15] : -1, rq1 = Q.ref1 >= 0 ? d.refPic[1][Q.ref1 & 15] : -1;
+    const int2 mp1 = rp1 >= 0 ? P.mv1 : zero, mq1 = rq1 >= 0 ? Q.mv1 : zero;
     if ((rp0 == rq0 && rp1 == rq1) || (rp0 == rq1 && rp1 == rq0))
     {
         if (rp0 != rp1)
@@ -77,19 +86,29 @@ __global__ __launch_bounds__(256) void deblock_kernel(x265hip_deblock_pic d, pix
     const int a = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int ux = DIR ? a : 2 * a, uy = DIR ? 2 * b : b;                               // the 8x8 grid: even units across the edge
     if (ux >= uw || uy >= uh || !(DIR ? uy : ux)) return;
+    // one round of independent loads: the two units' records and the segment's 4 lines x 8 luma samples (wasted where the strength turns out 0, but a
+    // segment that is filtered no longer waits for the records, then the strength inputs, then the samples one round trip after the other)
     const uint32_t q = part_index(ux, uy, lgUpc, nx);
-    if (!d.predMode[q]) return;
     const uint32_t p = DIR ? part_index(ux, uy - 1, lgUpc, nx) : part_index(ux - 1, uy, lgUpc, nx);
-    const int bs = boundary_strength<DIR>(d, ux, uy, q, p);
+    const UnitInfo Q = load_unit(d, q, !d.sliceIsP), P = load_unit(d, p, !d.sliceIsP);
+    pixel* src = Y + (intptr_t)uy * 4 * strideY + ux * 4;
+    const intptr_t step = DIR ? 1 : strideY, off = DIR ? strideY : 1;
+    int m[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) m[i][k] = src[i * step + (k - 4) * off];
+    if (!Q.mode) return;
+    const int bs = boundary_strength<DIR>(d, ux, uy, Q, P);
     if (bsOut) bsOut[((size_t)DIR * uh + uy) * uw + ux] = (uint8_t)bs;
     if (!bs) return;
     int maskP = -1, maskQ = -1;
     if (d.tqBypassEnabled)
     {
-        maskP = d.tqBypass[p] ? 0 : -1; maskQ = d.tqBypass[q] ? 0 : -1;
+        maskP = P.bypass ? 0 : -1; maskQ = Q.bypass ? 0 : -1;
         if (!(maskP | maskQ)) return;
     }
-    const int qp = ((int)d.qp[p] + (int)d.qp[q] + 1) >> 1;
+    const int qp = (P.qp + Q.qp + 1) >> 1;
     constexpr int sh = X265_DEPTH - 8;
     const int tcOffset = 2 * d.tcOffsetDiv2;
 
@@ -114,14 +133,7 @@ __global__ __launch_bounds__(256) void deblock_kernel(x265hip_deblock_pic d, pix
         }
     }
 
-    // luma: the segment's 4 lines x 8 samples in registers
-    pixel* src = Y + (intptr_t)uy * 4 * strideY + ux * 4;
-    const intptr_t step = DIR ? 1 : strideY, off = DIR ? strideY : 1;
-    int m[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) m[i][k] = src[i * step + (k - 4) * off];
+    // luma: the segment's 4 lines x 8 samples are in registers already
     const int beta = c_beta[clip3(0, 51, qp + 2 * d.betaOffsetDiv2)] << sh;
     const int dp0 = abs(m[0][1] - 2 * m[0][2] + m[0][3]), dq0 = abs(m[0][4] - 2 * m[0][5] + m[0][6]);
     const int dp3 = abs(m[3][1] - 2 * m[3][2] + m[3][3]), dq3 = abs(m[3][4] - 2 * m[3][5] + m[3][6]);
