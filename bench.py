@@ -6,10 +6,15 @@ already resident in HBM: integer + sub-pel motion search for the 2Nx2N PU pyrami
 then motion compensation -> residual -> DCT -> quant of every 32x32 TU with the MVs just found.
 Metric (BASELINE.json): Mpixels/s of luma source pixels through that pipeline, whole job over all ranks.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
+N > 1: one rank per GPU.  Under torch.distributed.run (WORLD_SIZE set) this process IS a rank; started plainly with
+--gpus N it launches the N ranks itself (x265hip_pkg.sharding.spawn_ranks -> python -m torch.distributed.run).
 Ranks process independent frames (weak scaling, no data-path collective; RCCL is used only for the barrier and the
 max-over-ranks time).  Rank 0 prints ONE JSON line.
+
+Default workload = BASELINE.json configs[2], the configuration the metric is quoted on that fits one GPU: 4K 10-bit
+Main10, preset slow (STAR search, subme 3).  `--workload 1080p8_medium` is configs[1].
 """
 import argparse
 import json
@@ -24,6 +29,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E nominal (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+# vector-instruction issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per SIMD every VALU_CYCLES clocks at 2.4 GHz.
+# profiles/micro/valu_rate.hip measures it for the search kernels' own instruction (v_sad_u16 / v_sad_u8); see profiles/micro/RESULTS.md
+GPU_CLOCK_HZ, N_SIMD, VALU_CYCLES = 2.4e9, 1024, 4
 METHODS = {"dia": 0, "hex": 1, "star": 3, "full": 5}
 WORKLOADS = {
     # BASELINE.json configs[1]: 1080p 8-bit, preset medium (me hex, subme 2, merange 57 -- param.cpp:188,238-256)
@@ -43,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="1080p8_medium", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="2160p10_slow", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=8, help="frame pairs per step per GPU")
     ap.add_argument("--qp", type=int, default=28)
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
@@ -53,6 +61,7 @@ def parse():
     ap.add_argument("--lookahead", action="store_true", help="also time the lookahead frame-cost batch (lowres init, intra estimate, estimateFrameCost of a 32-picture window); reported under \"lookahead\", not part of value")
     ap.add_argument("--intra", action="store_true", help="also time the intra mode scan (35 sa8d costs per CU, sizes 64..8) over the same frames; reported under \"intra_scan\", not part of value")
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-dry-run", action="store_true", help="launcher / bookkeeping check without a GPU: gloo ranks, a sleep in place of the step (tests/test_sharding.py); prints a line marked data=dry-run")
     ap.add_argument("--filters", action="store_true", help="also time the in-loop filter chain after reconstruction (deblock, SAO statistics, SAO apply, SSIM, SSD) on 8 coded 1080p pictures; reported under \"filters\", not part of value")
     return ap.parse_args()
 
@@ -480,37 +489,119 @@ def cpu_baseline(pipe, depth, n_ctus):
                                                else "restated oracle, single thread", reps, total_cpu, busy, parity)}
 
 
+MARGIN = 96                  # PicYuv-style padding of the synthetic planes (FramePipeline's default)
+
+
+def _make_pair(W, H, depth, seed):
+    from x265hip_pkg.synth import frame_pair
+    cur, ref, _, _ = frame_pair(W, H, depth, seed=seed, margin=MARGIN, max_shift=24)
+    return cur, ref
+
+
+def asm_probe():
+    """north_star asks for the reference's AVX2 / AVX-512 asm path beside ours.  It needs nasm to build and the GPU box receives only this
+    repository, so look for what the host offers at run time and say what was found."""
+    import ctypes.util
+    import shutil
+    found = {"nasm": shutil.which("nasm") or shutil.which("yasm"), "x265_cli": shutil.which("x265"), "libx265": ctypes.util.find_library("x265")}
+    if found["x265_cli"]:
+        note = "a system x265 CLI exists (%s) but exposes no primitive-level entry; its whole-encoder fps is not this metric" % found["x265_cli"]
+    elif found["libx265"]:
+        note = "a system libx265 exists (%s) but the EncoderPrimitives table is not part of its public API" % found["libx265"]
+    elif found["nasm"]:
+        note = "nasm is present (%s) but /root/reference is not on this box, so there is nothing to assemble" % found["nasm"]
+    else:
+        note = "no nasm/yasm, no system x265/libx265 on this host: the x86 asm table cannot be built or found; the C (no-asm) table of the reference is what ran"
+    return {"found": found, "asm_baseline": None, "note": note}
+
+
+def profile_figure(workload, which):
+    """Per-launch counter figures that cannot be collected inside an untraced run (HBM bytes, SQ_INSTS_VALU): read from the committed
+    rocprofv3 summaries, labelled with where they come from.  {} when no summary exists for the workload."""
+    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (which, workload))
+    if not os.path.exists(path):
+        return {}, None
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return {}, None
+    src = d.pop("_source", None) if isinstance(d, dict) else None
+    return d, "profiles/%s_%s.json (rocprofv3 --pmc pass%s)" % (which, workload, ", " + src if src else "")
+
+
+def dry_run(args):
+    """Launcher and bookkeeping without a GPU (world_size-2 gloo test): the same rank set-up, barrier, MAX-over-ranks time and
+    whole-job aggregate as the real run, with a sleep standing in for the step."""
+    import torch.distributed as dist
+    import x265hip  # noqa: F401
+    from x265hip_pkg.sharding import init_ranks, max_over_ranks, whole_job_mpixels_per_s, rank_frame_seeds
+    rank, local_rank, world = init_ranks(args.gpus, "gloo")
+    wl = WORKLOADS[args.workload]
+    px = args.frames * wl["width"] * wl["height"]
+    seeds = rank_frame_seeds(rank, args.frames)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
+    owned = [seeds]
+    if world > 1:
+        owned = [None] * world
+        dist.all_gather_object(owned, seeds)
+    if rank == 0:
+        print(json.dumps({"metric": "Mpixels/s ME+DCT+quant on 4K CTU batches", "value": round(whole_job_mpixels_per_s(world, px, args.steps, dt), 2), "unit": "Mpixels/s",
+                          "n_gpus": world, "rccl_ranks": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run",
+                          "config": {"workload": args.workload, "backend": "gloo", "frames_owned": owned}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: become the launcher of N ranks (one per GPU), hand their exit status back
+        import x265hip  # noqa: F401  (registers the package under an importable name)
+        from x265hip_pkg.sharding import spawn_ranks
+        if not args.cpu_dry_run:
+            import torch
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this host (one rank per GPU, no oversubscription)" % (args.gpus, have))
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if args.cpu_dry_run:
+        return dry_run(args)
+    # the rank's synthetic frames first, in worker processes (a 4K pair takes ~9 s of numpy; forked before torch / HIP are initialised)
+    import x265hip  # noqa: F401
+    from x265hip_pkg.sharding import rank_frame_seeds
+    wl = WORKLOADS[args.workload]
+    depth, W, H = wl["depth"], wl["width"], wl["height"]
+    seeds = rank_frame_seeds(int(os.environ.get("RANK", "0")), args.frames)          # independent frames per rank, no overlap
+    import multiprocessing
+    with multiprocessing.get_context("fork").Pool(min(len(seeds), max(1, (os.cpu_count() or 1) // max(1, args.gpus)))) as pool:
+        pairs = pool.starmap(_make_pair, [(W, H, depth, sd) for sd in seeds])
     import torch
     import torch.distributed as dist
     import x265hip  # noqa: F401
     from x265hip_pkg.frame import FrameApi, mvcost_row
     from x265hip_pkg.pipeline import FramePipeline, LEVELS
-    from x265hip_pkg.synth import frame_pair
-    from x265hip_pkg.sharding import rank_frame_seeds, max_over_ranks, whole_job_mpixels_per_s
+    from x265hip_pkg.sharding import init_ranks, max_over_ranks, whole_job_mpixels_per_s
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    rank, local_rank, world = init_ranks(args.gpus, "nccl", torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    wl = WORKLOADS[args.workload]
-    depth, W, H = wl["depth"], wl["width"], wl["height"]
     api = FrameApi(depth)
     half = 1 << 15
     cost_row = mvcost_row(depth, args.qp, half)
     pipe = FramePipeline(depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"],
                          tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api, use_planes=not args.no_planes)
-    pairs = []
-    for seed in rank_frame_seeds(rank, args.frames):          # independent frames per rank, no overlap
-        cur, ref, stride, _ = frame_pair(W, H, depth, seed=seed, margin=pipe.margin, max_shift=24)
-        pairs.append((cur, ref))
+    assert pipe.margin == MARGIN
     pipe.upload(pairs)                      # inputs are resident in HBM before the timed region
 
     def barrier():
@@ -522,12 +613,11 @@ def main():
     for _ in range(args.warmup):
         pipe.step()
     barrier()
-    names = (["planes"] if pipe.use_planes else []) + ["me64", "me32", "me16", "me8", "tq%d" % (1 << args.tu)]
+    names = pipe.kernel_names()
     # per-kernel HIP events on every 4th step only: an event between two launches keeps the tail of one kernel from
     # overlapping the head of the next (measured: ~5 % of the step time when every launch is bracketed)
     sampled = [k for k in range(args.steps) if k % 4 == 0]
-    evname = {n: ("tq" if n.startswith("tq") else n) for n in names}
-    events = {k: {evname[n]: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for k in sampled}
+    events = {k: {n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for k in sampled}
     pipe.overlap_tq = args.overlap_tq
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -535,54 +625,68 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda")
+    devices = [torch.cuda.get_device_name(local_rank)]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, "%d:%s" % (local_rank, torch.cuda.get_device_name(local_rank)))
 
     if rank == 0:
-        kms = {n: float(np.mean([events[k][evname[n]][0].elapsed_time(events[k][evname[n]][1]) for k in sampled])) for n in names}
+        kms = {n: float(np.mean([events[k][n][0].elapsed_time(events[k][n][1]) for k in sampled])) for n in names}
         bpp = 1 if depth == 8 else 2
         px = pipe.pixels_per_step
-        # algorithmic (compulsory) bytes per launch: SURVEY 8(d) -- each plane byte once + 16 B result per PU / 2 B coeff per pixel
-        alg = {}
-        for lv in LEVELS:
-            alg["me%d" % lv] = px * 2 * bpp + len(pipe.tasks_host[lv]) * 16
         n_tu = 1 << args.tu
-        alg[names[-1]] = px * (2 * bpp + 2) + len(pipe.tu_host) * 4
-        if pipe.use_planes:
-            alg["planes"] = pipe.F * pipe.plane * bpp * 17          # 1 plane read + 16 written (15 phases + the slot-0 copy; padded planes)
-        # dominant kernel = longest average launch; planes and me64 run within a few percent of each other, so launches within 10 % of the
-        # longest are treated as tied and the tie goes to the one that moves the most algorithmic bytes (the HBM-relevant one)
-        longest = max(kms.values())
-        dom = max((k for k in kms if kms[k] >= 0.90 * longest), key=lambda k: alg[k])
+        alg = pipe.algorithmic_bytes()              # each plane byte once per launch + the records it writes
+        # dominant kernel = strictly the longest average launch of the step, whatever it is bound by
+        dom = max(kms, key=lambda k: kms[k])
         achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:
-                traffic = None
+        traffic_all, traffic_src = profile_figure(args.workload, "traffic")
+        valu_all, valu_src = profile_figure(args.workload, "valu")
+        valu_peak = N_SIMD * GPU_CLOCK_HZ / VALU_CYCLES
+        step_bytes = px * (2 * bpp + 2) + sum(len(pipe.tasks_host[lv]) for lv in LEVELS) * 16       # SURVEY 8(d) fused S1-S3: source + reference once, MVs + coefficients out
+        step_gbs = step_bytes / (dt / args.steps) / 1e9
         value = whole_job_mpixels_per_s(world, px, args.steps, dt)
         out = {
-            "metric": "Mpixels/s ME+DCT+quant on CTU batches (luma source pixels through ME pyramid + MC/DCT/quant)",
-            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "Mpixels/s ME+DCT+quant on 4K CTU batches (luma source pixels through ME pyramid + MC/DCT/quant)",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": dist.get_world_size() if world > 1 else 1, "rccl_ranks": world, "devices": devices,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames,
-                       "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "qp": args.qp,
+                       "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": 1, "qp": args.qp,
                        "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": ("TQ on a side stream beside the me16/me8 launches (it needs the me32 MVs only), joined per step" if pipe.overlap_tq else "kernel by kernel") + "; per-kernel events on every 4th step", "sharding": "independent frames per GPU, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "longest average launch; launches within 10 % of the longest count as tied (planes, me64 and me8 swap places from box to box) and the tie goes to the larger algorithmic byte count, i.e. to the kernel an HBM roofline means something for; every kernel's GB/s is in all_kernels_GBps", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "strictly the longest average launch of the step", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(dom), "traffic_source": traffic_src if traffic_all.get(dom) is not None else None,
                          "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
                          "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()},
                          "all_kernels_GBps": {k: round(alg[k] / (v * 1e-3) / 1e9, 2) for k, v in kms.items()}},
+            # the search kernels are vector-issue bound, not bandwidth bound: instructions per launch (SQ_INSTS_VALU of the committed counter pass)
+            # over the live launch time, against the chip's wave-instruction issue rate
+            "roofline_valu": {"bound": "valu issue", "unit": "G wave-instr/s", "peak": round(valu_peak / 1e9, 1),
+                              "peak_rule": "%d SIMDs x %.1f GHz / %d clocks per wave64 instruction" % (N_SIMD, GPU_CLOCK_HZ / 1e9, VALU_CYCLES),
+                              "insts_source": valu_src,
+                              "kernels": {k: {"insts": int(valu_all[k]), "achieved": round(valu_all[k] / (kms[k] * 1e-3) / 1e9, 1), "frac": round(valu_all[k] / (kms[k] * 1e-3) / valu_peak, 4)}
+                                          for k in kms if k in valu_all}},
+            # the whole step against the HBM bound of SURVEY 8(d): source and reference read once, MVs and coefficients written
+            "roofline_step": {"bound": "hbm", "bytes_rule": "pixels x (2*bpp + 2) + 16 B per PU", "bytes": int(step_bytes), "achieved": round(step_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(step_gbs / HBM_PEAK_GBS, 5),
+                              "traffic_per_step": (sum(v for k, v in traffic_all.items() if k in kms) or None) if traffic_all else None, "traffic_source": traffic_src},
+            "e2e_fps": None,
         }
+        e2e_path = os.path.join(ROOT, "profiles", "e2e_fps.json")
+        if os.path.exists(e2e_path):
+            try:
+                out["e2e_fps"] = json.load(open(e2e_path))
+            except Exception:
+                pass
         if args.intra:
             out["intra_scan"] = intra_scan_leg(pipe, depth, max(2, min(args.steps, 10)))
         if args.lookahead:
             out["lookahead"] = lookahead_leg(depth, max(2, min(args.steps, 10)))
         if args.filters:
             out["filters"] = filters_leg(depth, max(2, min(args.steps, 10)))
-        if world == 1 and args.cpu_ctus > 0:
-            out["cpu_baseline"] = cpu_baseline(pipe, depth, args.cpu_ctus)
+        if args.cpu_ctus > 0:
+            out["cpu_baseline"] = cpu_baseline(pipe, depth, args.cpu_ctus)     # rank 0's host cores, after the timed region (the other ranks wait at the barrier below)
+            out["cpu_baseline"]["asm"] = asm_probe()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

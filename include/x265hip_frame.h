@@ -140,6 +140,8 @@ int x265hip_me_batch_sea(void* stream, int w, int h, const void* curPlane, intpt
  *   (slicetype.cpp:1173-1176, 4347-4357, 4394-4426): each slice of that many block rows (the last one with the remainder) is swept on its own.
  *   invQscale: nFrames x ncu 8.8 fixed-point AQ factors (Lowres::invQscaleFactor / invQscaleFactor8x8) or NULL.
  *   costRow: the row of x265hip_mvcost_row(x265hip_lookahead_qp(), ...), costHalfRange >= 4 * (8 * max(wcu, hcu) + 32).
+ *   The call is fully asynchronous (no copy back, no synchronisation: it may be captured into a hipGraph); tasks whose pictures are out of order
+ *   or not among the nFrames pictures of the buffer are skipped on the device (their outputs keep their previous contents).
  *   mvs (int16 x, y per block) and mvCosts are arrays of ncu-long SLOTS, the device form of Lowres::lowresMvs[list][dist] /
  *   lowresMvCosts[list][dist]: a task searches into its slot when doSearch[list] != 0 and reads it otherwise (the
  *   reference's bDoSearch caching, :4376-4377).  Two tasks of one call must not search the same slot.
@@ -160,7 +162,7 @@ int x265hip_lookahead_intra_batch(void* stream, const void* lowres, int64_t plan
                                   int nFrames, const int32_t* invQscale, int32_t* intraCost, uint8_t* intraMode, uint16_t* lowresCosts,
                                   int32_t* rowSatds, int64_t* sums);
 int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
-                                 const x265hip_la_task* tasks, int nTasks, const int32_t* intraCost, const int32_t* invQscale,
+                                 const x265hip_la_task* tasks, int nTasks, int nFrames /* pictures in the lowres buffer */, const int32_t* intraCost, const int32_t* invQscale,
                                  const uint16_t* costRow, int costHalfRange, int rowsPerSlice, int16_t* mvs, int32_t* mvCosts,
                                  uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
 

@@ -130,3 +130,96 @@ def test_me_batch_sea_matches_oracle(depth, planes):
                          (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc, merange, 4, subme, row, integral=integral)
             got_i = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
             assert got_i == exp, "SEA PU %dx%d task %d subme %d merange %d: hip %s oracle %s (mvp %s)" % (w, h, i, subme, merange, got_i, exp, tk["qmvp"])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method", [1, 3])               # HEX, STAR (with its raster over the whole +-128 window)
+def test_me_batch_merange_128(depth, method):
+    """BASELINE configs[4] searches with --merange 128: MVDs reach the edge of (and leave) the +-512 quarter-pel cost slice the kernels keep
+    in LDS, the STAR raster covers 52 x 52 placements, and the `tmv << 3` quirk indexes the cost row far outside the slice."""
+    api, ora = FrameApi(depth), Oracle(depth)
+    rng = np.random.default_rng(1280 + depth + method)
+    W, H, margin, merange = 448, 320, 160, 128
+    half = 1 << 14
+    cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 55, margin=margin, max_shift=40)
+    cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
+    d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+    pe = cur_f.size
+    row = ora.mvcost_row(28, half)
+    d_row = api.to_device(row.view(np.int16))
+    for planes in (True, False):
+        d_pl = None
+        if planes:
+            d_pl = api.torch.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
+            api.subpel_planes(d_ref, stride, cur.shape[0], d_pl, pe)
+        for (w, h) in [(64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (16, 64)]:
+            if not planes and w * h < 1024:
+                continue
+            n = 10 if planes else 4
+            subme = int(rng.integers(2, 5))
+            tasks = make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange)
+            for i in range(0, n, 2):                      # every other task: a far-off predictor, so the first STAR pass lands far away and the raster runs
+                px_, py_ = (int(tasks[i]["curOff"]) % stride) - margin, (int(tasks[i]["curOff"]) // stride) - margin
+                q = (int(rng.integers(-300, 301)), int(rng.integers(-300, 301)))
+                lim = margin - 16
+                tasks[i]["qmvp"] = q
+                tasks[i]["mvmin"] = (max((q[0] >> 2) - merange, -px_ - lim), max((q[1] >> 2) - merange, -py_ - lim))
+                tasks[i]["mvmax"] = (min((q[0] >> 2) + merange, W - px_ - w + lim), min((q[1] >> 2) + merange, H - py_ - h + lim))
+            d_tasks = api.to_device(tasks)
+            d_res = api.torch.zeros(n * ME_RESULT.itemsize, dtype=api.torch.uint8, device="cuda")
+            api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, merange, method, subme, d_res, planes=d_pl, plane_elems=pe if planes else 0)
+            api.torch.cuda.synchronize()
+            res = d_res.cpu().numpy().view(ME_RESULT)
+            for i in range(n):
+                tk = tasks[i]
+                bounds = [int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])]
+                mvc = [int(v) for v in tk["mvc"][:2 * int(tk["numCand"])]]
+                exp = ora.me(w, h, cur_f, stride, int(tk["curOff"]), ref_f, stride, int(tk["refOff"]), bounds,
+                             (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc, merange, method, subme, row)
+                got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
+                assert got == exp, "merange 128: PU %dx%d task %d method %d subme %d planes %s: hip %s oracle %s (mvp %s)" % (
+                    w, h, i, method, subme, planes, got, exp, tk["qmvp"])
+
+
+def test_me_batch_plane_buffer_beyond_4gb():
+    """A reference stack whose 16-slot phase-plane buffer is larger than 4 GB (4 padded 8K 10-bit pictures: 4.6 GB) cannot be addressed
+    with the 32-bit byte offsets of the size-specialised kernels; x265hip_me_batch must take the generic kernels and still be exact.
+    The searched picture is the LAST of the stack, so every address lies beyond 2^32 bytes in the higher slots."""
+    depth = 10
+    api, ora = FrameApi(depth), Oracle(depth)
+    T = api.torch
+    rng = np.random.default_rng(4096)
+    W, H, margin, F = 7680, 4352, 96, 4
+    c4, r4, _, (dx, dy) = frame_pair(W // 4, H // 4, depth, 77, margin=0, max_shift=20)      # one quarter-size pair, tiled 4 x 4: same motion everywhere
+    cur = np.pad(np.tile(c4, (4, 4)), margin, mode="edge"); ref = np.pad(np.tile(r4, (4, 4)), margin, mode="edge")
+    stride, rows = W + 2 * margin, H + 2 * margin
+    plane = stride * rows
+    cur_f, ref_f = np.ascontiguousarray(cur).reshape(-1), np.ascontiguousarray(ref).reshape(-1)
+    d_cur = api.to_device(cur_f)
+    d_ref = T.zeros(F * plane, dtype=d_cur.dtype, device="cuda")
+    d_ref[(F - 1) * plane:].copy_(api.to_device(ref_f))
+    pe = F * plane
+    assert 16 * pe * 2 >= 1 << 32
+    d_pl = T.empty(16 * pe, dtype=d_ref.dtype, device="cuda")
+    api.subpel_planes(d_ref, stride, F * rows, d_pl, pe)
+    half = 1 << 13
+    row = ora.mvcost_row(28, half)
+    d_row = api.to_device(row.view(np.int16))
+    for (w, h) in [(64, 64), (32, 32), (16, 16), (8, 8)]:
+        n = 12
+        tasks = make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, 57)
+        host = tasks.copy()
+        tasks["refOff"] += (F - 1) * plane
+        d_tasks = api.to_device(tasks)
+        d_res = T.zeros(n * ME_RESULT.itemsize, dtype=T.uint8, device="cuda")
+        api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, 57, 3, 3, d_res, planes=d_pl, plane_elems=pe)
+        T.cuda.synchronize()
+        res = d_res.cpu().numpy().view(ME_RESULT)
+        for i in range(n):
+            tk = host[i]
+            bounds = [int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])]
+            mvc = [int(v) for v in tk["mvc"][:2 * int(tk["numCand"])]]
+            exp = ora.me(w, h, cur_f, stride, int(tk["curOff"]), ref_f, stride, int(tk["refOff"]), bounds,
+                         (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc, 57, 3, 3, row)
+            got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
+            assert got == exp, ">4GB planes: PU %dx%d task %d: hip %s oracle %s" % (w, h, i, got, exp)

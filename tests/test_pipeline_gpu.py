@@ -8,6 +8,7 @@ from x265hip_pkg.frame import mvcost_row
 from x265hip_pkg.pipeline import FramePipeline, LEVELS
 from x265hip_pkg.synth import frame_pair
 from backends import Oracle
+from pipeline_check import check_sample
 
 pytestmark = pytest.mark.gpu
 
@@ -22,7 +23,7 @@ def test_small_frames_match_oracle(depth, method, subme, tu, planes):
     pipe.upload([frame_pair(256, 128, depth, 40 + s, margin=pipe.margin, max_shift=14)[:2] for s in range(2)])
     pipe.step()
     pipe.torch.cuda.synchronize()
-    assert pipe.check_sample(Oracle(depth), np.random.default_rng(depth + method), per_level=12, n_tu=16) >= 40
+    assert check_sample(pipe, Oracle(depth), np.random.default_rng(depth + method), per_level=12, n_tu=16) >= 40
 
 
 def test_full_size_properties_and_sample():
@@ -59,7 +60,56 @@ def test_full_size_properties_and_sample():
     rec = pipe.d_recon.view(2, H + 2 * m, s)[:, m:m + H, m:m + W].to(T.int64)
     assert int(((cur - rec) ** 2).sum()) == int(pipe.d_sse.sum())
     # and a random sample of PUs / TUs bit-exact against the oracle
-    assert pipe.check_sample(Oracle(depth), np.random.default_rng(3), per_level=25, n_tu=25) == 125
+    assert check_sample(pipe, Oracle(depth), np.random.default_rng(3), per_level=25, n_tu=25) == 125
+
+
+def _full_size(depth, W, H, method, subme, merange, pair0, min_hit):
+    """Size-independent properties of one step at a BASELINE configuration's own size (2 frame pairs: a moving one and an identical one)
+    plus >= 100 randomly sampled PUs / TUs bit-exact against the oracle."""
+    row = mvcost_row(depth, 28, 1 << 15)
+    pipe = FramePipeline(depth, W, H, 2, qp=28, merange=merange, method=method, subme=subme, tu_log2=5, recon=True, cost_row=row)
+    T = pipe.torch
+    cur0, ref0, (dx, dy) = pair0(pipe.margin)
+    pipe.upload([(cur0, ref0), (cur0, cur0)])
+    pipe.step(); T.cuda.synchronize()
+    first = {lv: pipe.results(lv).copy() for lv in LEVELS}
+    coeff1 = pipe.d_coeff.clone(); sse1 = pipe.d_sse.clone(); rec1 = pipe.d_recon.clone()
+    pipe.step(); T.cuda.synchronize()                      # idempotence: a second pass over the same planes gives identical bytes
+    for lv in LEVELS:
+        assert np.array_equal(first[lv], pipe.results(lv))
+    assert T.equal(coeff1, pipe.d_coeff) and T.equal(sse1, pipe.d_sse) and T.equal(rec1, pipe.d_recon)
+    for lv in LEVELS:                                      # identical frames: zero motion, zero residual, zero error
+        r = first[lv]; n = len(r) // 2
+        assert not r["mv"][n:].any(), "identical frames must give zero motion at level %d" % lv
+    ntu = len(pipe.tu_host) // 2
+    assert int(pipe.d_numsig[ntu:].abs().sum()) == 0 and int(pipe.d_coeff.view(-1, 1024)[ntu:].abs().sum()) == 0
+    assert int(pipe.d_sse[ntu:].sum()) == 0
+    r64 = first[64][:len(first[64]) // 2]                  # the synthetic global motion is found by the bulk of the large PUs
+    hit = np.mean((np.abs(r64["mv"][:, 0] - 4 * dx) <= 4) & (np.abs(r64["mv"][:, 1] - 4 * dy) <= 4))
+    assert hit > min_hit, "only %.0f%% of the 64x64 PUs found the synthetic motion (%d,%d)" % (100 * hit, dx, dy)
+    m, s = pipe.margin, pipe.stride                        # checksum of checksums: per-TU SSE adds up to the plane-level squared error
+    cur = pipe.d_cur.view(2, H + 2 * m, s)[:, m:m + H, m:m + W].to(T.int64)
+    rec = pipe.d_recon.view(2, H + 2 * m, s)[:, m:m + H, m:m + W].to(T.int64)
+    assert int(((cur - rec) ** 2).sum()) == int(pipe.d_sse.sum())
+    assert check_sample(pipe, Oracle(depth), np.random.default_rng(W), per_level=25, n_tu=25) == 125
+
+
+def test_full_size_4k_10bit_slow():
+    """BASELINE configs[2]: 3840x2176 (CTU-aligned 2160p) 10-bit, preset slow = STAR, subme 3, merange 57."""
+    def pair0(margin):
+        cur, ref, _, mv = frame_pair(3840, 2176, 10, 1, margin=margin, max_shift=24)
+        return cur, ref, mv
+    _full_size(10, 3840, 2176, 3, 3, 57, pair0, 0.8)
+
+
+def test_full_size_8k_10bit_slower_merange_128():
+    """BASELINE configs[4]: 7680x4352 10-bit, preset slower = STAR, subme 4, --merange 128.  The picture is a 4K synthetic pair tiled
+    2 x 2 (the same global motion in every tile), which keeps the host-side generation short."""
+    def pair0(margin):
+        c, r, _, mv = frame_pair(3840, 2176, 10, 2, margin=0, max_shift=40)
+        return (np.ascontiguousarray(np.pad(np.tile(c, (2, 2)), margin, mode="edge")),
+                np.ascontiguousarray(np.pad(np.tile(r, (2, 2)), margin, mode="edge")), mv)
+    _full_size(10, 7680, 4352, 3, 4, 128, pair0, 0.7)
 
 
 @pytest.mark.parametrize("depth", [8, 10])

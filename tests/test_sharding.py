@@ -104,3 +104,39 @@ def test_lookahead_estimates_shard_without_exchange(tmp_path):
     _, one = pickle.load(open(tmp_path / "la.pkl", "rb"))
     merged = dict(two[0]); merged.update(two[1])
     assert merged == one[0]
+
+
+def _bench(*argv, env=None):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, env=e, timeout=600)
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` (no launcher around it) starts two ranks through torch.distributed.run; on the CPU they run the
+    dry-run step over gloo: same rank set-up, barrier, MAX-over-ranks time and whole-job aggregate as the GPU run."""
+    import json
+    r = _bench("--gpus", "2", "--steps", "3", "--warmup", "0", "--cpu-dry-run", "--workload", "1080p8_medium", "--frames", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["scaling"] == "weak" and d["data"] == "dry-run"
+    assert d["config"]["frames_owned"] == [[0, 1], [2, 3]]             # disjoint frames per rank
+    # whole-job value = 2 ranks x their pixels over the SLOWEST rank's time (rank 1 sleeps twice as long as rank 0)
+    assert d["ms_per_step"] >= 4.0
+    assert abs(d["value"] - 2 * 2 * 1920 * 1088 * 3 / (d["ms_per_step"] * 3e-3) / 1e6) / d["value"] < 1e-3
+
+
+def test_bench_gpus_flag_fails_loudly_without_enough_gpus():
+    """The real (non dry-run) path must refuse N ranks on fewer than N GPUs instead of running one rank and printing n_gpus 1."""
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", env={"HIP_VISIBLE_DEVICES": "0", "CUDA_VISIBLE_DEVICES": "0"})
+    assert r.returncode != 0
+    assert "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_world_size_must_match_gpus_flag():
+    r = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--cpu-dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

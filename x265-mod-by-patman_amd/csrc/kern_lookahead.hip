@@ -345,10 +345,18 @@ __device__ __forceinline__ uint32_t plane0_off(const LaGeom& g, int frame) { ret
 __device__ __forceinline__ uint32_t ld_mv(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void st_mv(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-__global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint16_t* __restrict__ costCentre, int costR, int rowsPerSlice,
+// a task the host could not look at (the list lives in device memory): pictures in order and inside the buffer, else the estimate is skipped
+__device__ __forceinline__ bool la_task_ok(const x265hip_la_task* tp, int nFrames)
+{
+    const int w0 = tp->weighted0;
+    return tp->p0 >= 0 && tp->p0 <= tp->b && tp->b <= tp->p1 && tp->p1 < nFrames && w0 >= 0 && w0 <= nFrames;
+}
+
+__global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, int nFrames, const uint16_t* __restrict__ costCentre, int costR, int rowsPerSlice,
                                                          uint32_t* mvs, int32_t* mvCosts)
 {
     const x265hip_la_task* tp = tasks + (blockIdx.x >> 1);
+    if (!la_task_ok(tp, nFrames)) return;
     const int list = blockIdx.x & 1;
     const int tb = tp->b, tp0 = tp->p0, tp1 = tp->p1;
     const bool bidir = tp1 > tb;
@@ -458,12 +466,13 @@ __device__ __forceinline__ void row_totals(int a, int b, int c, int (&out)[3])
 
 // the decision half of estimateCUCost (:4574-4640): one workgroup per (block row, estimate), 8 lanes per block; the row's
 // totals are reduced inside the workgroup, so the frame sums see one atomic per row instead of one per block
-__global__ __launch_bounds__(256) void la_finish_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, const uint32_t* __restrict__ mvs,
+__global__ __launch_bounds__(256) void la_finish_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, int nFrames, const uint32_t* __restrict__ mvs,
                                                         const int32_t* __restrict__ mvCosts, const int32_t* __restrict__ intraCost,
                                                         const int32_t* __restrict__ invQscale, uint16_t* __restrict__ lowresCosts,
                                                         int32_t* __restrict__ rowSatds, unsigned long long* sums)
 {
     const x265hip_la_task* tp = tasks + blockIdx.y;
+    if (!la_task_ok(tp, nFrames)) return;
     const int tb = tp->b, tp0 = tp->p0, tp1 = tp->p1, slot0 = tp->mvSlot[0], slot1 = tp->mvSlot[1], outSlot = tp->outSlot;
     const int W = g.wcu, H = g.hcu, ncu = W * H;
     const int cuY = blockIdx.x, lane = threadIdx.x & 7;
@@ -771,11 +780,12 @@ extern "C" int x265hip_lookahead_intra_batch(void* stream, const void* lowres, i
 }
 
 extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
-                                            const x265hip_la_task* tasks, int nTasks, const int32_t* intraCost, const int32_t* invQscale,
+                                            const x265hip_la_task* tasks, int nTasks, int nFrames, const int32_t* intraCost, const int32_t* invQscale,
                                             const uint16_t* costRow, int costHalfRange, int rowsPerSlice, int16_t* mvs, int32_t* mvCosts,
                                             uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
 {
     if (nTasks <= 0) return X265HIP_OK;
+    if (nFrames <= 0) { set_error("lookahead_cost_batch: nFrames must be the number of pictures in the lowres buffer"); return X265HIP_EARG; }
     if (rowsPerSlice <= 0 || rowsPerSlice > heightInCU) rowsPerSlice = heightInCU;          // one slice
     if (bad_geom(lowres, planeElems, stride, origin, widthInCU, heightInCU) || !tasks || !intraCost || !costRow || !mvs || !mvCosts || !lowresCosts || !rowSatds || !sums)
     { set_error("lookahead_cost_batch: bad arguments"); return X265HIP_EARG; }
@@ -783,18 +793,10 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     if (costHalfRange < 4 * (max(widthInCU, heightInCU) * CU + 32))
     { set_error("lookahead_cost_batch: cost row too short for this picture size (need >= %d)", 4 * (max(widthInCU, heightInCU) * CU + 32)); return X265HIP_EARG; }
     if (((uintptr_t)mvs & 3)) { set_error("lookahead_cost_batch: mvs must be 4-byte aligned"); return X265HIP_EARG; }
-    int maxFrame = 0;
-    {   // the kernels address the lowres buffer with 32-bit element offsets: all referenced pictures must lie below 2^31 elements
-        std::vector<x265hip_la_task> h((size_t)nTasks);
-        XH_HIP(hipMemcpyAsync(h.data(), tasks, sizeof(x265hip_la_task) * (size_t)nTasks, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        XH_HIP(hipStreamSynchronize((hipStream_t)stream));
-        for (const auto& t : h)
-        {
-            if (t.p0 < 0 || t.p0 > t.b || t.b > t.p1) { set_error("lookahead_cost_batch: estimate (%d, %d, %d) is not ordered p0 <= b <= p1", t.p0, t.b, t.p1); return X265HIP_EARG; }
-            if (t.weighted0 < 0) { set_error("lookahead_cost_batch: bad weighted0"); return X265HIP_EARG; }
-            maxFrame = std::max(maxFrame, std::max(t.p1, t.weighted0 - 1));
-        }
-    }
+    // Nothing is copied back or synchronised here (the call can be captured into a hipGraph): the task list stays on the device, the kernels
+    // skip estimates whose pictures are out of order or outside the nFrames pictures of the buffer.  The kernels address the lowres buffer
+    // with 32-bit element offsets: all of it must lie below 2^31 elements.
+    const int maxFrame = nFrames - 1;
     if (((int64_t)maxFrame + 1) * 4 * planeElems >= ((int64_t)1 << 31)) { set_error("lookahead_cost_batch: lowres buffer beyond 2^31 elements"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     const LaGeom g = { (const pixel*)lowres, planeElems, stride, origin, widthInCU, heightInCU };
@@ -803,17 +805,18 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     // one 8-lane group per block of the widest wavefront step, in whole wavefronts, at most 1024 threads
     const int nslices = heightInCU / rowsPerSlice;
     const int widest = min(rowsPerSlice + heightInCU % rowsPerSlice, (widthInCU + 1) / 2);
-    static const int threadCap = getenv("X265HIP_LA_THREADS") ? atoi(getenv("X265HIP_LA_THREADS")) : 1024;   // A/B switch: lane groups per workgroup
+    // A/B switches of the profiling scripts, clamped to what the kernel can run with (whole wavefronts, 64..1024 threads; LDS within the CU's 160 KB)
+    static const int threadCap = [] { const char* e = getenv("X265HIP_LA_THREADS"); int v = e ? atoi(e) : 1024; v = v / 64 * 64; return v < 64 ? 64 : v > 1024 ? 1024 : v; }();
     const int threads = min(min(1024, threadCap), max(64, (widest * 8 + 63) / 64 * 64));
     const int costR = 4 * (max(widthInCU, heightInCU) * CU + 32);               // the bound checked above; 2 bytes per entry of LDS
     // Workgroup placement: a CU accepts four of these 8-wavefront workgroups, and the dispatcher fills CUs one after the other, so a
     // batch of ~2 workgroups per CU ends up four deep on some CUs and absent on others -- and four interleaved wavefront sweeps take
     // four times as long as one.  Asking for 56 KB of LDS (of 160 KB per CU) caps the depth at two.
-    static const size_t ldsPad = getenv("X265HIP_LA_LDS") ? (size_t)atoi(getenv("X265HIP_LA_LDS")) : 56 * 1024;
+    static const size_t ldsPad = [] { const char* e = getenv("X265HIP_LA_LDS"); long v = e ? atol(e) : 56 * 1024; return (size_t)(v < 0 ? 0 : v > 160 * 1024 ? 160 * 1024 : v); }();
     const size_t lds = std::max(sizeof(uint16_t) * (size_t)(2 * costR + 2), ldsPad);
-    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts);
+    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts);
     XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
+    hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, nFrames, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <atomic>
 #include "../../include/x265hip_frame.h"
 
 namespace xh {
@@ -26,39 +27,76 @@ void fatal(const char* what)
     abort();
 }
 
-static thread_local ThreadCtx* t_ctx = nullptr;
-static const size_t kArena = 8u << 20;     // enough for any single slot call (64x64 blocks, 33 intra modes ...)
+static const size_t kArena = 8u << 20;     // first arena; plane-sized slots (frameInitLowres, weight_pp on 4K / 8K planes) grow it on demand
+static std::atomic<int> g_device{-1};      // device chosen by x265hip_device_init; the reference's pool threads inherit it here
+
+// The context of a thread dies with the thread (the reference's pool workers come and go with the encoder).
+struct CtxHolder
+{
+    ThreadCtx* c = nullptr;
+    ~CtxHolder()
+    {
+        if (!c) return;
+        (void)hipStreamSynchronize(c->stream);
+        for (char* p : c->retired) (void)hipFree(p);
+        (void)hipFree(c->arena); (void)hipFree(c->zeros); (void)hipHostFree(c->pinned); (void)hipStreamDestroy(c->stream);
+        delete c;
+    }
+};
+static thread_local CtxHolder t_ctx;
 
 ThreadCtx& ThreadCtx::get()
 {
-    if (t_ctx) return *t_ctx;
+    if (t_ctx.c) return *t_ctx.c;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) { hip_fail(e, "hipGetDeviceCount"); fatal("no HIP device available"); }
+    const int dev = g_device.load();
+    if (dev >= 0 && hipSetDevice(dev) != hipSuccess) fatal("hipSetDevice failed");     // a new host thread starts on device 0 otherwise
     ThreadCtx* c = new ThreadCtx();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) fatal("hipStreamCreate failed");
     if (hipMalloc((void**)&c->arena, kArena) != hipSuccess) fatal("hipMalloc(arena) failed");
     c->arenaSize = kArena;
+    if (hipMalloc((void**)&c->zeros, 256) != hipSuccess) fatal("hipMalloc(zeros) failed");
     if (hipHostMalloc((void**)&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) fatal("hipHostMalloc failed");
-    t_ctx = c;
-    // zero offsets live at the very start of the arena, outside the bump region
-    if (hipMemsetAsync(c->arena, 0, 256, c->stream) != hipSuccess) fatal("hipMemset failed");
+    t_ctx.c = c;
+    if (hipMemsetAsync(c->zeros, 0, 256, c->stream) != hipSuccess) fatal("hipMemset failed");
     return *c;
 }
 
+// A slot call that needs more than the arena holds gets a new, larger chunk; blocks handed out earlier in the same call stay valid
+// (their chunk is retired, not freed) until the next call's reset(), which runs after that call's sync().
 void* ThreadCtx::dalloc(size_t bytes)
 {
-    size_t off = 256 + ((arenaUsed + 255) & ~(size_t)255);
-    if (off + bytes > arenaSize) { set_error("slot arena exhausted (%zu bytes requested)", bytes); fatal("arena"); }
-    arenaUsed = off - 256 + bytes;
+    size_t off = (arenaUsed + 255) & ~(size_t)255;
+    if (off + bytes > arenaSize)
+    {
+        size_t want = arenaSize * 2;
+        while (want < bytes + 256) want *= 2;
+        char* bigger = nullptr;
+        if (hipMalloc((void**)&bigger, want) != hipSuccess) { set_error("device memory exhausted growing the slot arena to %zu bytes", want); fatal("arena"); }
+        retired.push_back(arena);
+        arena = bigger; arenaSize = want; off = 0;
+    }
+    arenaUsed = off + bytes;
     return arena + off;
+}
+void ThreadCtx::reset()
+{
+    arenaUsed = 0;
+    if (!retired.empty())
+    {   // every slot call ends with sync(), so nothing queued on the stream still reads the retired chunks
+        (void)hipStreamSynchronize(stream);
+        for (char* p : retired) (void)hipFree(p);
+        retired.clear();
+    }
 }
 void ThreadCtx::sync()
 {
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) { hip_fail(e, "hipStreamSynchronize"); fatal("kernel execution failed"); }
 }
-const int32_t* dev_zero_offsets(ThreadCtx& c) { return (const int32_t*)c.arena; }
+const int32_t* dev_zero_offsets(ThreadCtx& c) { return (const int32_t*)c.zeros; }
 
 DevBlock stage_in(ThreadCtx& c, const void* host, intptr_t stride, int w, int h, int es)
 {
@@ -94,6 +132,7 @@ extern "C" int x265hip_device_init(int device)
     XH_HIP(hipGetDeviceCount(&n));
     if (device < 0 || device >= n) { xh::set_error("device %d out of range (%d devices)", device, n); return X265HIP_EDEVICE; }
     XH_HIP(hipSetDevice(device));
+    xh::g_device.store(device);          // the table slots run on the caller's pool threads: ThreadCtx::get() selects this device there
     return X265HIP_OK;
 }
 extern "C" int x265hip_abi_check(size_t sizeof_table, int bit_depth)

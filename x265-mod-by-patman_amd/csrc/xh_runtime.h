@@ -3,17 +3,20 @@
 // every pool worker concurrently and the slots must be reentrant: SURVEY 8b / threadpool.cpp).
 #pragma once
 #include "xh_common.h"
+#include <vector>
 
 namespace xh {
 
 struct ThreadCtx
 {
     hipStream_t stream = nullptr;
-    char* arena = nullptr;       // device scratch
+    char* arena = nullptr;       // device scratch (bump allocated per slot call; grows on demand)
     size_t arenaSize = 0, arenaUsed = 0;
+    std::vector<char*> retired;  // smaller chunks replaced during the current call, freed by the next reset()
+    char* zeros = nullptr;       // 256 zero bytes (offsets of single-item batches)
     char* pinned = nullptr;      // small pinned host block for scalar results / offsets
     static ThreadCtx& get();     // creates on first use; fatal() if there is no usable GPU
-    void reset() { arenaUsed = 0; }
+    void reset();
     void* dalloc(size_t bytes);  // bump allocation, 256-B aligned
     void sync();
 };

@@ -110,7 +110,7 @@ class FrameApi:
                              mvs, mv_costs, lowres_costs, row_satds, sums, rows_per_slice=0):
         """CostEstimateGroup::estimateFrameCost for n_tasks (p0, b, p1) choices (LA_TASK records on the device)."""
         self.h.check(self.lib.x265hip_lookahead_cost_batch(self.stream(), _dp(lowres), C.c_int64(plane_elems), C.c_ssize_t(stride), C.c_int64(origin), wcu, hcu,
-                                                           _dp(tasks), n_tasks, _dp(intra_cost), _dp(inv_qscale), _dp(cost_row), half, rows_per_slice,
+                                                           _dp(tasks), n_tasks, int(lowres.numel() // (4 * plane_elems)), _dp(intra_cost), _dp(inv_qscale), _dp(cost_row), half, rows_per_slice,
                                                            _dp(mvs), _dp(mv_costs), _dp(lowres_costs), _dp(row_satds), _dp(sums)))
 
     def cutree_propagate(self, wcu, hcu, dist_p0, dist_p1, weightb, fps_factor, referenced, intra_cost, lowres_costs, inv_q, mvs0, mvs1, prop_b, prop0, prop1, workspace):

@@ -160,43 +160,22 @@ class FramePipeline:
         else:
             run("tq", self.launch_tq, main)
 
-    # ---- read-back / checking helpers (tests, smoke) ----
+    # ---- what bench.py reports about a step ----
+    def kernel_names(self):
+        """names of the launches of one step, in order (the keys of step()'s event dictionary)"""
+        return (["planes"] if self.use_planes else []) + ["me%d" % lv for lv in LEVELS] + ["tq"]
+
+    def algorithmic_bytes(self):
+        """SURVEY 8(d) compulsory bytes per launch: each plane byte once + the records the launch writes (16 B per PU, 2 B per
+        coefficient + 4 B per TU); the phase-plane launch reads one padded plane stack and writes 16."""
+        bpp = 1 if self.depth == 8 else 2
+        px = self.pixels_per_step
+        alg = {"me%d" % lv: px * 2 * bpp + len(self.tasks_host[lv]) * 16 for lv in LEVELS}
+        alg["tq"] = px * (2 * bpp + 2) + len(self.tu_host) * 4 + (px * bpp if self.recon else 0)
+        if self.use_planes:
+            alg["planes"] = self.F * self.plane * bpp * 17
+        return alg
+
+    # ---- read-back ----
     def results(self, lv):
         return self.d_results[lv].cpu().numpy().view(ME_RESULT)
-
-    def check_sample(self, oracle, rng, per_level=40, n_tu=40):
-        """Compare randomly sampled PUs / TUs of the last step() with the oracle (bit-exact). Returns #checked."""
-        res = {lv: self.results(lv) for lv in LEVELS}
-        checked = 0
-        for lv in LEVELS:
-            t = self.tasks_host[lv]
-            for i in rng.choice(len(t), size=min(per_level, len(t)), replace=False):
-                tk = t[i]
-                qmvp = (0, 0) if tk["mvpFrom"] < 0 else tuple(int(v) for v in res[2 * lv][tk["mvpFrom"]]["mv"])
-                d = self.merange << 2
-                lx0, ly0, lx1, ly1 = int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])
-                b = [min(lx1, max(lx0, qmvp[0] - d)) >> 2, min(ly1, max(ly0, qmvp[1] - d)) >> 2,
-                     min(lx1, max(lx0, qmvp[0] + d)) >> 2, min(ly1, max(ly0, qmvp[1] + d)) >> 2]
-                b[3] = max(b[3], b[1])
-                exp = oracle.me(lv, lv, self.cur_host, self.stride, int(tk["curOff"]), self.ref_host, self.stride, int(tk["refOff"]),
-                                b, qmvp, [], self.merange, self.method, self.subme, self.cost_row_host)
-                got = (int(res[lv][i]["mv"][0]), int(res[lv][i]["mv"][1]), int(res[lv][i]["cost"]))
-                assert got == exp, "ME level %d task %d: hip %s oracle %s" % (lv, i, got, exp)
-                checked += 1
-        n = 1 << self.tu_log2
-        coeff = self.d_coeff.cpu().numpy().reshape(-1, n * n)
-        numsig = self.d_numsig.cpu().numpy()
-        sse = self.d_sse.cpu().numpy() if self.recon else None
-        rec = self.d_recon.cpu().numpy().view(self.cur_host.dtype) if self.recon else None
-        for i in rng.choice(len(self.tu_host), size=min(n_tu, len(self.tu_host)), replace=False):
-            tk = self.tu_host[i]
-            mv = tuple(int(v) for v in res[self.mv_level][tk["mvFrom"]]["mv"])
-            e_ns, e_coeff, _, e_rec, e_sse = oracle.tq_tu(self.tu_log2, self.cur_host, self.stride, int(tk["curOff"]), self.ref_host, self.stride,
-                                                          int(tk["refOff"]), mv, self.qp, 85, want_recon=self.recon)
-            assert int(numsig[i]) == e_ns and np.array_equal(coeff[i], e_coeff), "TU %d: coefficients differ from the oracle" % i
-            if self.recon:
-                o = int(tk["reconOff"])
-                got = np.concatenate([rec[o + y * self.stride: o + y * self.stride + n] for y in range(n)])
-                assert np.array_equal(got, e_rec) and int(sse[i]) == e_sse, "TU %d: reconstruction differs from the oracle" % i
-            checked += 1
-        return checked

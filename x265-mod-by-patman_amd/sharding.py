@@ -5,6 +5,40 @@ segments); the only communication is the barrier around the timed region and a M
 """
 
 
+def spawn_ranks(script, argv, n, port=None, env=None):
+    """`python script --gpus N ...` started without a launcher: run the N ranks (one process per GPU) the way the driver does --
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv -- and return
+    its exit status.  The rendezvous is on 127.0.0.1 (a container hostname may not resolve)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    if port is None:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    e = dict(os.environ if env is None else env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # this pool's driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd, env=e)
+
+
+def init_ranks(gpus_arg, backend, device_count=None):
+    """Rank set-up of a process started by torch.distributed.run (or alone): returns (rank, local_rank, world).  WORLD_SIZE must
+    agree with --gpus, and with backend nccl (= RCCL) every rank needs its own GPU."""
+    import os
+    rank, local_rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if gpus_arg != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (gpus_arg, world))
+    if device_count is not None and device_count < world:
+        raise SystemExit("%d ranks but only %d GPU(s) visible: one rank per GPU, no oversubscription" % (world, device_count))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world
+    return rank, local_rank, world
+
+
 def rank_frame_seeds(rank, frames_per_rank):
     """Global frame indices (also the synthetic-frame seeds) owned by `rank`."""
     return list(range(rank * frames_per_rank, (rank + 1) * frames_per_rank))
