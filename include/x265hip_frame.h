@@ -31,12 +31,13 @@ typedef struct x265hip_me_task {
     int16_t mvmin[2], mvmax[2];  /* full-pel search bounds (x, y), inclusive (motion.cpp:925-926);
                                     with X265HIP_ME_WINDOW: QUARTER-pel clip limits (CUData::clipMv)   */
     int16_t qmvp[2];             /* quarter-pel MV predictor (ignored when mvpFrom >= 0)             */
-    int16_t mvc[8];              /* up to 4 quarter-pel candidates (x, y)                            */
-    int16_t numCand;             /* 0..4                                                             */
+    int16_t mvc[24];             /* up to 12 quarter-pel candidates (x, y): the mvc[(MD_ABOVE_LEFT + 1) * 2 + 2] list of
+                                    Search::puMotionEstimation / predInterSearch (search.cpp:237, 2599)              */
+    int16_t numCand;             /* 0..12                                                            */
     int16_t flags;               /* X265HIP_ME_*                                                     */
     int32_t mvpFrom;             /* >= 0: predictor = mvpSource[mvpFrom].mv (e.g. the parent CU's MV, the way
                                     Analysis::deriveMVsForCTU seeds PUs from m_areaBestMV, analysis.cpp:248-306) */
-} x265hip_me_task;               /* 44 bytes */
+} x265hip_me_task;               /* 76 bytes */
 
 /* flags: derive the search window on the device the way Search::setSearchRange does (search.cpp:4969-5021):
  * [mvp - 4*merange, mvp + 4*merange] clipped to the task's quarter-pel limits, >> 2, mvmax.y >= mvmin.y */

@@ -1,0 +1,170 @@
+/*
+ * ref_tme.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * The reference encoder run with --threaded-me (decoupled motion estimation: ThreadedME::findJob -> Analysis::deriveMVsForCTU ->
+ * Search::puMotionEstimation, encoder/threadedme.cpp:207-261, analysis.cpp:161-306, search.cpp:226-560) on a synthetic clip, with every
+ * call of MotionEstimate::motionEstimate on a full-resolution reference RECORDED: the PU's source pixels, the reference plane, the search
+ * window, predictor and candidates exactly as puMotionEstimation / predInterSearch built them, and what the reference returned.  The records
+ * are the fixture of tests/golden/tme_*.npz: the same task list goes through x265hip_me_batch (GPU) and the oracle (CPU) and must give the
+ * same MV and cost -- the data-level form of SURVEY 8(f1).
+ *
+ * How the calls are seen without touching the reference's sources: oracle/Makefile compiles encoder/motion.cpp a second time with
+ * -DmotionEstimate=motionEstimate_ref (the member keeps its body, under another name) and links that object instead of the regular one;
+ * the definition of MotionEstimate::motionEstimate below is what every caller in the encoder then reaches: it forwards to the renamed member
+ * and writes the record.
+ *
+ * usage: x265tme_<depth> <width> <height> <frames> <preset> <out.bin> [option=value ...]
+ * record stream (little endian):  int32 kind, int32 nInts, int32 ints[nInts], then kind-specific pixels as uint16
+ *   kind 1 (reference plane snapshot): ints = { id, stride, rows, originOffset, width, height }, pixels = stride * rows
+ *   kind 2 (call): ints = { planeId, w, h, blockOffset, mvmin.x, .y, mvmax.x, .y, qmvp.x, .y, numCand, merange, searchMethod, subpelRefine, qp,
+ *                           bChromaSATD, maxSlices, vertRestriction, srcPlaneGiven, out.x, out.y, cost, mvcost(out), mvc[2 * numCand] }, pixels = w * h (source PU)
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+#define protected public
+#define private public
+#include "x265.h"
+#include "common.h"
+#include "primitives.h"
+#include "picyuv.h"
+#include "motion.h"
+#undef protected
+#undef private
+
+using namespace X265_NS;
+
+static FILE* g_out;
+static std::mutex g_lock;
+struct Snap { int id; uint64_t sum; };
+static std::map<const pixel*, Snap> g_planes;
+static int g_nextPlane, g_calls, g_skipped;
+/* heights of enum LumaPU (primitives.h:52-64), in its order */
+static const int g_lumaH[25] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 12, 16, 4, 16, 24, 32, 8, 32, 48, 64, 16, 64 };
+
+static void put(int kind, const std::vector<int32_t>& ints, const std::vector<uint16_t>& px)
+{
+    const int32_t hdr[2] = { kind, (int32_t)ints.size() };
+    fwrite(hdr, 4, 2, g_out); fwrite(ints.data(), 4, ints.size(), g_out); fwrite(px.data(), 2, px.size(), g_out);
+}
+
+/* the reference's own body, compiled from encoder/motion.cpp as the member motionEstimate_ref (see the header comment); a member cannot be declared
+ * outside its class, so it is reached as a function with `this` as first argument under the member's mangled name (Itanium ABI) */
+#if X265_DEPTH == 8
+#define XTME_REAL "_ZN4x26514MotionEstimate18motionEstimate_refEPNS_15ReferencePlanesERKNS_2MVES5_S5_iPS4_iRS3_jbPh"
+#else
+#define XTME_REAL "_ZN4x26514MotionEstimate18motionEstimate_refEPNS_15ReferencePlanesERKNS_2MVES5_S5_iPS4_iRS3_jbPt"
+#endif
+int motionEstimate_ref(MotionEstimate* self, ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, const MV& qmvp, int numCandidates, const MV* mvc, int merange,
+                       MV& outQMv, uint32_t maxSlices, bool m_vertRestriction, pixel* srcReferencePlane) __asm__(XTME_REAL);
+
+namespace X265_NS {
+int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, const MV& qmvp, int numCandidates, const MV* mvc, int merange,
+                                   MV& outQMv, uint32_t maxSlices, bool m_vertRestriction, pixel* srcReferencePlane)
+{
+    const int cost = ::motionEstimate_ref(this, ref, mvmin, mvmax, qmvp, numCandidates, mvc, merange, outQMv, maxSlices, m_vertRestriction, srcReferencePlane);
+    if (!g_out || ref->isLowres || ref->isHMELowres) return cost;         /* the lookahead's searches on half-resolution pictures are another path */
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (srcReferencePlane || !ref->reconPic) { g_skipped++; return cost; }
+    const PicYuv* rp = ref->reconPic;
+    const intptr_t stride = ref->lumaStride;
+    const int rows = rp->m_picHeight + 2 * rp->m_lumaMarginY;
+    const pixel* top = ref->fpelPlane[0] - (intptr_t)rp->m_lumaMarginY * stride - rp->m_lumaMarginX;
+    uint64_t sum = 1469598103934665603ull;
+    for (intptr_t i = 0; i < stride * rows; i++) sum = (sum ^ top[i]) * 1099511628211ull;
+    auto it = g_planes.find(ref->fpelPlane[0]);
+    if (it == g_planes.end() || it->second.sum != sum)
+    {   /* first sight of this plane (or its buffer holds another picture now): snapshot */
+        Snap s = { g_nextPlane++, sum };
+        g_planes[ref->fpelPlane[0]] = s;
+        std::vector<uint16_t> px((size_t)stride * rows);
+        for (size_t i = 0; i < px.size(); i++) px[i] = top[i];
+        put(1, { s.id, (int32_t)stride, rows, (int32_t)(rp->m_lumaMarginY * stride + rp->m_lumaMarginX), (int32_t)rp->m_picWidth, (int32_t)rp->m_picHeight }, px);
+        it = g_planes.find(ref->fpelPlane[0]);
+    }
+    int qp = -1;
+    for (int q = 0; q < BC_MAX_QP; q++)
+        if (s_costs[q] && s_costs[q] == m_cost) qp = q;
+    const int blockh = (int)(g_lumaH[partEnum]);     /* setSourcePU never sets blockheight (motion.cpp:167-247): the height follows from the partition enum */
+    std::vector<int32_t> ints = { it->second.id, blockwidth, blockh, (int32_t)blockOffset, mvmin.x, mvmin.y, mvmax.x, mvmax.y, qmvp.x, qmvp.y, numCandidates, merange,
+                                  searchMethod, subpelRefine, qp, (int32_t)bChromaSATD, (int32_t)maxSlices, (int32_t)m_vertRestriction, srcReferencePlane ? 1 : 0,
+                                  outQMv.x, outQMv.y, cost, (int32_t)mvcost(outQMv) };
+    for (int i = 0; i < numCandidates; i++) { ints.push_back(mvc[i].x); ints.push_back(mvc[i].y); }
+    std::vector<uint16_t> px((size_t)blockwidth * blockh);
+    for (int y = 0; y < blockh; y++)
+        for (int x = 0; x < blockwidth; x++) px[(size_t)y * blockwidth + x] = fencPUYuv.m_buf[0][y * FENC_STRIDE + x];
+    put(2, ints, px);
+    g_calls++;
+    return cost;
+}
+}
+
+static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixel>& v, int w, int h, int f)
+{   /* textured picture in (not purely translational) motion + deterministic noise: predictors, candidates and search paths vary from PU to PU */
+    uint32_t s = 4242u + 733u * (uint32_t)f;
+    const int pm = (1 << X265_DEPTH) - 1;
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++)
+        {
+            const int x = i + 5 * f + ((j >> 5) & 1) * f, yy = j + 3 * f;
+            const int t = (((x * x) / 9 + yy * 7 + (x * yy) / 13 + ((x >> 3) ^ (yy >> 3)) * 11) & 255) * (pm + 1) / 256;
+            s = s * 1664525u + 1013904223u;
+            const int val = t + (int)((s >> 24) & 7) - 3;
+            y[(size_t)j * w + i] = (pixel)(val < 0 ? 0 : val > pm ? pm : val);
+        }
+    for (int j = 0; j < h / 2; j++)
+        for (int i = 0; i < w / 2; i++)
+        {
+            u[(size_t)j * (w / 2) + i] = (pixel)((((i + f) * 3 + j) & 127) * (pm + 1) / 256 + (pm + 1) / 4);
+            v[(size_t)j * (w / 2) + i] = (pixel)((((j + 2 * f) * 5 + i) & 127) * (pm + 1) / 256 + (pm + 1) / 4);
+        }
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 6) { fprintf(stderr, "usage: %s width height frames preset out.bin [option=value ...]\n", argv[0]); return 2; }
+    const int w = atoi(argv[1]), h = atoi(argv[2]), frames = atoi(argv[3]);
+    x265_param* p = x265_param_alloc();
+    if (x265_param_default_preset(p, argv[4], NULL) < 0) { fprintf(stderr, "bad preset\n"); return 2; }
+    p->sourceWidth = w; p->sourceHeight = h; p->fpsNum = 25; p->fpsDenom = 1; p->internalCsp = X265_CSP_I420;
+    p->totalFrames = frames; p->logLevel = X265_LOG_WARNING; p->bRepeatHeaders = 1;
+    p->frameNumThreads = 1; p->bEnableWavefront = 0; p->lookaheadSlices = 0;
+    x265_param_parse(p, "pools", "32");                /* ThreadedME needs a worker pool of at least MIN_TME_THREADS threads (encoder.cpp:273-306, threadpool.cpp:288-296) */
+    x265_param_parse(p, "threaded-me", "1");
+    for (int i = 6; i < argc; i++)
+    {
+        char* eq = strchr(argv[i], '=');
+        if (eq) *eq = 0;
+        if (x265_param_parse(p, argv[i], eq ? eq + 1 : NULL) < 0) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
+    }
+    g_out = fopen(argv[5], "wb");
+    if (!g_out) { fprintf(stderr, "cannot write %s\n", argv[5]); return 2; }
+    x265_encoder* enc = x265_encoder_open(p);
+    if (!enc) { fprintf(stderr, "encoder_open failed\n"); return 2; }
+    x265_picture* pic = x265_picture_alloc();
+    x265_picture_init(p, pic);
+    std::vector<pixel> Y((size_t)w * h), U((size_t)w * h / 4), V((size_t)w * h / 4);
+    pic->planes[0] = Y.data(); pic->planes[1] = U.data(); pic->planes[2] = V.data();
+    pic->stride[0] = w * (int)sizeof(pixel); pic->stride[1] = pic->stride[2] = (w / 2) * (int)sizeof(pixel);
+    pic->bitDepth = X265_DEPTH; pic->colorSpace = X265_CSP_I420;
+    x265_nal* nal; uint32_t nnal;
+    for (int f = 0; f < frames; f++)
+    {
+        synth(Y, U, V, w, h, f);
+        pic->pts = f;
+        if (x265_encoder_encode(enc, &nal, &nnal, pic, NULL) < 0) { fprintf(stderr, "encode failed\n"); return 2; }
+    }
+    while (x265_encoder_encode(enc, &nal, &nnal, NULL, NULL) > 0) {}
+    x265_param* live = x265_param_alloc();
+    x265_encoder_parameters(enc, live);                /* the encoder's own copy: threaded-me is switched off there when the pool is too small */
+    const int tme = live->bThreadedME;
+    x265_param_free(live);
+    x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
+    fclose(g_out);
+    printf("{\"calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_nextPlane, g_skipped, tme);
+    return 0;
+}

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""tests/make_golden_tme.py -- fixtures tests/golden/tme_{8,10}.npz: every MotionEstimate::motionEstimate call of a reference encode run with
+--threaded-me (oracle/_ref/x265tme_*, oracle/ref_tme.cpp): source PU, reference plane, window, predictor, candidates -> MV and cost.
+Run here (needs /root/reference for `make -C oracle tme`); the .npz files are committed and replayed on the CPU (oracle) and the GPU box."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NI = 23          # ints of a call record in front of the candidates (ref_tme.cpp)
+CALL_FIELDS = ("plane w h blockOffset mnx mny mxx mxy qmvpx qmvpy numCand merange method subme qp chromaSatd maxSlices vertRestriction "
+               "srcPlane outx outy cost mvcost").split()
+
+
+def parse(path):
+    d = np.fromfile(path, np.uint8).tobytes()
+    off, planes, calls, mvcs, blocks = 0, {}, [], [], []
+    while off < len(d):
+        kind, n = np.frombuffer(d, np.int32, 2, off); off += 8
+        ints = np.frombuffer(d, np.int32, n, off).copy(); off += 4 * n
+        if kind == 1:
+            pid, stride, rows = int(ints[0]), int(ints[1]), int(ints[2])
+            px = np.frombuffer(d, np.uint16, stride * rows, off).copy(); off += 2 * stride * rows
+            planes[pid] = (ints, px)
+        else:
+            w, h = int(ints[1]), int(ints[2])
+            px = np.frombuffer(d, np.uint16, w * h, off).copy(); off += 2 * w * h
+            calls.append(ints[:NI]); mvcs.append(ints[NI:]); blocks.append(px)
+    return planes, calls, mvcs, blocks
+
+
+def build(depth, args, out):
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265tme_%d" % depth)
+    with tempfile.TemporaryDirectory() as td:
+        raw = os.path.join(td, "tme.bin")
+        subprocess.check_call([exe] + args[:4] + [raw] + args[4:], stdout=subprocess.DEVNULL)
+        planes, calls, mvcs, blocks = parse(raw)
+    dt = np.uint8 if depth == 8 else np.uint16
+    calls = np.stack(calls).astype(np.int32)
+    mvc = np.zeros((len(calls), 24), np.int16)
+    for i, m in enumerate(mvcs):
+        assert len(m) <= 24, "more than 12 candidates"
+        mvc[i, :len(m)] = m
+    starts = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.int64)
+    data = {"fields": np.array(CALL_FIELDS), "calls": calls, "mvc": mvc, "fenc": np.concatenate(blocks).astype(dt), "fenc_start": starts,
+            "cmdline": np.array(" ".join(args))}
+    for pid, (ints, px) in planes.items():
+        data["plane%d_geom" % pid] = ints
+        data["plane%d" % pid] = px.astype(dt)
+    np.savez_compressed(out, **data)
+    return calls
+
+
+if __name__ == "__main__":
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "tme"])
+    for depth, args in ((8, ["128", "128", "3", "medium"]), (10, ["128", "128", "3", "slow", "amp=0"])):
+        out = os.path.join(ROOT, "tests", "golden", "tme_%d.npz" % depth)
+        c = build(depth, args, out)
+        f = {n: c[:, i] for i, n in enumerate(CALL_FIELDS)}
+        print(depth, "calls", len(c), "size", os.path.getsize(out), "methods", np.unique(f["method"]), "subme", np.unique(f["subme"]), "chromaSatd", np.unique(f["chromaSatd"]),
+              "numCand max", f["numCand"].max(), "shapes", sorted({(int(a), int(b)) for a, b in zip(f["w"], f["h"])}), "qp", np.unique(f["qp"]),
+              "vert/slices/src", np.unique(f["vertRestriction"]), np.unique(f["maxSlices"]), np.unique(f["srcPlane"]))

@@ -1,0 +1,31 @@
+"""SURVEY 8(f1) at the data level, CPU side: the oracle's motionEstimate restatement replays the calls a reference encode with --threaded-me
+made (Search::puMotionEstimation's window, predictor and candidate lists; fixtures from oracle/ref_tme.cpp) and must return the reference's MV and cost."""
+import numpy as np
+import pytest
+
+from backends import Oracle
+from tme_util import TmeFixture
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_replays_the_threaded_me_calls_of_a_reference_encode(depth):
+    fx, ora = TmeFixture(depth), Oracle(depth)
+    assert len(fx) > 1500
+    c = fx.col
+    assert not c["chromaSatd"].any() and not c["vertRestriction"].any() and not c["srcPlane"].any() and (c["maxSlices"] == 1).all()
+    rows = {}
+    step = 1
+    n = 0
+    for i in range(0, len(fx), step):
+        qp = int(c["qp"][i])
+        if qp not in rows:
+            rows[qp] = ora.mvcost_row(qp, 1 << 14)
+        pl = fx.planes[int(c["plane"][i])]
+        w, h, nc = int(c["w"][i]), int(c["h"][i]), int(c["numCand"][i])
+        got = ora.me(w, h, fx.block(i), w, 0, pl["px"], pl["stride"], pl["origin"] + int(c["blockOffset"][i]),
+                     [int(c["mnx"][i]), int(c["mny"][i]), int(c["mxx"][i]), int(c["mxy"][i])], (int(c["qmvpx"][i]), int(c["qmvpy"][i])),
+                     [int(v) for v in fx.mvc[i, :2 * nc]], int(c["merange"][i]), int(c["method"][i]), int(c["subme"][i]), rows[qp])
+        assert got == (int(c["outx"][i]), int(c["outy"][i]), int(c["cost"][i])), "call %d (%dx%d, %d candidates): oracle %s reference %s" % (
+            i, w, h, nc, got, (int(c["outx"][i]), int(c["outy"][i]), int(c["cost"][i])))
+        n += 1
+    assert n == len(fx)

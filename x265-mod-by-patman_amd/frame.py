@@ -9,12 +9,12 @@ import numpy as np
 from .binding import HipLib
 
 ME_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mvmin", "<i2", 2), ("mvmax", "<i2", 2), ("qmvp", "<i2", 2),
-                    ("mvc", "<i2", 8), ("numCand", "<i2"), ("flags", "<i2"), ("mvpFrom", "<i4")])
+                    ("mvc", "<i2", 24), ("numCand", "<i2"), ("flags", "<i2"), ("mvpFrom", "<i4")])
 ME_WINDOW = 1
 ME_RESULT = np.dtype([("mv", "<i2", 2), ("cost", "<i4"), ("mvcost", "<i4"), ("reserved", "<i4")])
 TU_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv", "<i2", 2), ("reconOff", "<i4"), ("mvFrom", "<i4")])
 LA_TASK = np.dtype([("b", "<i4"), ("p0", "<i4"), ("p1", "<i4"), ("doSearch", "<i4", 2), ("mvSlot", "<i4", 2), ("outSlot", "<i4"), ("weighted0", "<i4")])
-assert ME_TASK.itemsize == 44 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 20 and LA_TASK.itemsize == 36
+assert ME_TASK.itemsize == 76 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 20 and LA_TASK.itemsize == 36
 
 
 class TqParams(C.Structure):
