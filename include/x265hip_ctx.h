@@ -1,0 +1,70 @@
+/*
+ * x265hip_ctx.h -- the host side of the frame-batched path for a C / C++ caller (an encoder): device context, resident planes and the
+ * CTU-pyramid batch "motion search -> motion compensation / DCT / quant" of x265hip_frame.h, without any Python or torch in the process.
+ *
+ * This is the `x265hip_ctx_create / upload_plane / me_batch / tq_batch / sync` surface of SURVEY 8(b)(3).  What it replaces on the encoder
+ * side: the per-CTU producer of the decoupled-ME seam (ThreadedME::findJob -> Analysis::deriveMVsForCTU, encoder/threadedme.cpp:207-261,
+ * analysis.cpp:248-306) and the inter-residual chain of Search::estimateResidualQT (search.cpp:5515-5636) for whole frames:
+ *
+ *   x265hip_ctx_create(device)                    one device, one stream
+ *   x265hip_batch_create(ctx, desc)               planes, phase planes, pyramid task lists, result / coefficient arrays for F frame pairs
+ *   x265hip_batch_upload_plane(...)               source / reference picture -> padded device plane (borders replicated on the device:
+ *                                                 extendPicBorder, common/pixel.cpp:1044-1058)
+ *   x265hip_batch_step(batch)                     phase planes -> ME 64 / 32 / 16 / 8 (each level seeded by its parent CU's MV the way
+ *                                                 computeMVForPUs seeds PUs from m_areaBestMV) -> TQ; asynchronous on the context's stream
+ *   x265hip_batch_read_results / read_coeffs      MVs + costs per pyramid level (the flat MEData array of threadedme.h:122-130), coefficients
+ *
+ * All functions return X265HIP_OK or a negative X265HIP_E* code (x265hip_last_error() has the text).  Nothing here has a CPU fallback.
+ */
+#ifndef X265HIP_CTX_H
+#define X265HIP_CTX_H
+#include "x265hip_frame.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct x265hip_ctx x265hip_ctx;
+typedef struct x265hip_batch x265hip_batch;
+
+int   x265hip_ctx_create(int device, x265hip_ctx** ctx);
+void  x265hip_ctx_destroy(x265hip_ctx* ctx);
+void* x265hip_ctx_stream(x265hip_ctx* ctx);          /* hipStream_t: every call on this context is ordered on it */
+int   x265hip_ctx_sync(x265hip_ctx* ctx);
+
+typedef struct x265hip_batch_desc
+{
+    int width, height;      /* luma picture size, multiples of the CTU size 64 (pad the picture as the encoder does, picyuv.cpp:91-111) */
+    int frames;             /* (source, reference) picture pairs processed per step                                                    */
+    int margin;             /* padding on every side of a plane; >= 64 + 16 + 8 (PicYuv uses maxCUSize + 32 = 96)                         */
+    int qp;                 /* lambda of the MVD cost row (BitCost::setQP) and quantiser of the TQ stage                               */
+    int merange, method, subme;   /* param->searchRange, X265_*_SEARCH (x265hip_me_method), param->subpelRefine                        */
+    int tuLog2;             /* transform size of the TQ stage: 2..5                                                                    */
+    int recon;              /* != 0: also dequant -> IDCT -> reconstruction + SSE (S4)                                                 */
+    int usePlanes;          /* != 0: quarter-pel phase planes of the reference stack (x265hip_subpel_planes)                           */
+} x265hip_batch_desc;
+
+/* Pure host code (no GPU needed): the task lists x265hip_batch_create uploads.  level = 64, 32, 16 or 8.  Task k of a level is PU
+ * (frame, row, column) in raster order; mvpFrom of a level below 64 = index of the parent CU's task in the level above; limits are
+ * CUData::clipMv's (cudata.cpp:2094-2107) with the search window derived on the device (X265HIP_ME_WINDOW). */
+int   x265hip_batch_task_count(const x265hip_batch_desc* desc, int level);
+int   x265hip_batch_build_me_tasks(const x265hip_batch_desc* desc, int level, x265hip_me_task* out);
+int   x265hip_batch_tu_count(const x265hip_batch_desc* desc);
+int   x265hip_batch_build_tu_tasks(const x265hip_batch_desc* desc, x265hip_tu_task* out);
+
+int   x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* desc, x265hip_batch** batch);
+void  x265hip_batch_destroy(x265hip_batch* batch);
+/* which: 0 = source, 1 = reference.  pixels: the unpadded width x height picture in HOST memory (pixel = uint8_t / uint16_t by library),
+ * strideElems its row pitch.  The padded plane is assembled on the device. */
+int   x265hip_batch_upload_plane(x265hip_batch* batch, int which, int frame, const void* pixels, intptr_t strideElems);
+int   x265hip_batch_step(x265hip_batch* batch);
+int   x265hip_batch_read_results(x265hip_batch* batch, int level, x265hip_me_result* out /* x265hip_batch_task_count entries */);
+int   x265hip_batch_read_coeffs(x265hip_batch* batch, int16_t* coeff /* tu_count << (2 * tuLog2) */, uint32_t* numSig /* tu_count */);
+/* device pointers for consumers that stay on the GPU: what = 0 source planes, 1 reference planes, 2 phase planes, 3 coefficients, 4 numSig,
+ * 5 reconstruction, 10 + log2(level) - 3 = results of a pyramid level (10: 8x8 ... 13: 64x64) */
+void* x265hip_batch_device_ptr(x265hip_batch* batch, int what);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -20,6 +20,46 @@ LEVELS = (64, 32, 16, 8)
 CTU = 64
 
 
+def pyramid_tasks(W, H, F, margin, tu_log2):
+    """Host-side task lists of a batch of F padded W x H frame pairs (the numpy twin of x265hip_batch_build_me_tasks / _tu_tasks in
+    csrc/xh_ctx.cpp): {level: ME_TASK array}, TU_TASK array, the pyramid level whose MVs drive the TUs."""
+    stride = W + 2 * margin
+    plane = stride * (H + 2 * margin)
+    tasks = {}
+    for lv in LEVELS:
+        nx, ny = W // lv, H // lv
+        t = np.zeros(F * nx * ny, ME_TASK)
+        f, by, bx = np.meshgrid(np.arange(F), np.arange(ny), np.arange(nx), indexing="ij")
+        x, y = (bx * lv).reshape(-1), (by * lv).reshape(-1)
+        f = f.reshape(-1)
+        off = f * plane + (margin + y) * stride + margin + x
+        t["curOff"] = off
+        t["refOff"] = off
+        # CUData::clipMv limits in quarter-pels (offset 8, maxCUSize 64)
+        t["mvmin"][:, 0] = -((CTU + 8 + x - 1) << 2)
+        t["mvmin"][:, 1] = -((CTU + 8 + y - 1) << 2)
+        t["mvmax"][:, 0] = (W + 8 - x - 1) << 2
+        t["mvmax"][:, 1] = (H + 8 - y - 1) << 2
+        t["flags"] = ME_WINDOW
+        if lv == CTU:
+            t["mvpFrom"] = -1
+        else:
+            pnx, pny = W // (2 * lv), H // (2 * lv)
+            t["mvpFrom"] = f * (pnx * pny) + (by.reshape(-1) // 2) * pnx + (bx.reshape(-1) // 2)
+        tasks[lv] = t
+    n = 1 << tu_log2
+    nx, ny = W // n, H // n
+    tu = np.zeros(F * nx * ny, TU_TASK)
+    f, by, bx = np.meshgrid(np.arange(F), np.arange(ny), np.arange(nx), indexing="ij")
+    x, y, f = (bx * n).reshape(-1), (by * n).reshape(-1), f.reshape(-1)
+    off = f * plane + (margin + y) * stride + margin + x
+    tu["curOff"] = off; tu["refOff"] = off; tu["reconOff"] = off
+    mv_level = max(n, 8)                                     # pyramid level whose MVs drive the TUs
+    lnx, lny = W // mv_level, H // mv_level
+    tu["mvFrom"] = f * (lnx * lny) + (y // mv_level) * lnx + (x // mv_level)
+    return tasks, tu, mv_level
+
+
 class FramePipeline:
     def __init__(self, depth, width, height, frames, qp=28, merange=57, method=1, subme=2, tu_log2=5, margin=96,
                  recon=False, cost_row=None, api=None, use_planes=True):
@@ -47,41 +87,10 @@ class FramePipeline:
         return f * self.plane + (self.margin + y) * self.stride + self.margin + x
 
     def _build_tasks(self):
-        W, H, F = self.W, self.H, self.F
-        self.tasks_host, self.index = {}, {}
-        for lv in LEVELS:
-            nx, ny = W // lv, H // lv
-            t = np.zeros(F * nx * ny, ME_TASK)
-            f, by, bx = np.meshgrid(np.arange(F), np.arange(ny), np.arange(nx), indexing="ij")
-            x, y = (bx * lv).reshape(-1), (by * lv).reshape(-1)
-            f = f.reshape(-1)
-            off = f * self.plane + (self.margin + y) * self.stride + self.margin + x
-            t["curOff"] = off
-            t["refOff"] = off
-            # CUData::clipMv limits in quarter-pels (offset 8, maxCUSize 64)
-            t["mvmin"][:, 0] = -((CTU + 8 + x - 1) << 2)
-            t["mvmin"][:, 1] = -((CTU + 8 + y - 1) << 2)
-            t["mvmax"][:, 0] = (W + 8 - x - 1) << 2
-            t["mvmax"][:, 1] = (H + 8 - y - 1) << 2
-            t["flags"] = ME_WINDOW
-            if lv == CTU:
-                t["mvpFrom"] = -1
-            else:
-                pnx, pny = W // (2 * lv), H // (2 * lv)
-                t["mvpFrom"] = f * (pnx * pny) + (by.reshape(-1) // 2) * pnx + (bx.reshape(-1) // 2)
-            self.tasks_host[lv] = t
-        n = 1 << self.tu_log2
-        nx, ny = W // n, H // n
-        tu = np.zeros(F * nx * ny, TU_TASK)
-        f, by, bx = np.meshgrid(np.arange(F), np.arange(ny), np.arange(nx), indexing="ij")
-        x, y, f = (bx * n).reshape(-1), (by * n).reshape(-1), f.reshape(-1)
-        off = f * self.plane + (self.margin + y) * self.stride + self.margin + x
-        tu["curOff"] = off; tu["refOff"] = off; tu["reconOff"] = off
-        self.mv_level = max(n, 8)                                # pyramid level whose MVs drive the TUs
-        self.overlap_tq = False                                  # step(): TQ on a side stream beside the smaller-PU searches (measured: 2 %, 0.644 vs 0.657 ms)
-        lnx, lny = W // self.mv_level, H // self.mv_level
-        tu["mvFrom"] = f * (lnx * lny) + (y // self.mv_level) * lnx + (x // self.mv_level)
+        self.tasks_host, tu, self.mv_level = pyramid_tasks(self.W, self.H, self.F, self.margin, self.tu_log2)
         self.tu_host = tu
+        self.overlap_tq = False                                  # step(): TQ on a side stream beside the smaller-PU searches (measured: 2 %, 0.644 vs 0.657 ms)
+        n = 1 << self.tu_log2
         T = self.torch
         self.d_tasks = {lv: self.api.to_device(t) for lv, t in self.tasks_host.items()}
         self.d_results = {lv: T.zeros(len(t) * ME_RESULT.itemsize, dtype=T.uint8, device="cuda") for lv, t in self.tasks_host.items()}
