@@ -70,6 +70,23 @@ int x265hip_me_batch(void* stream, int w, int h,
 /* subpelPlanes, when given, must be the 16-slot buffer x265hip_subpel_planes produced from refPlane (slot 0 == refPlane,
  * same stride / offsets).  method: DIA, HEX, UMH, STAR or FULL (SEA needs integral planes: x265hip_me_batch_sea). */
 
+/* x265hip_me_batch with the chroma SATD terms of MotionEstimate::subpelCompare (motion.cpp:1805-1865): the search Search::predInterSearch runs
+ * (setSourcePU's Yuv overload with bChroma, motion.cpp:218-247; search.cpp:2582).  4:2:0.  At subpelRefine >= 3, for PUs whose chroma block is a
+ * multiple of 4x4 (the reference's chromaSatd exists: primitives.cpp:213-234), EVERY sub-pel cost -- clipped MVP and candidates, half / quarter-pel
+ * refinement, zero-MV check -- carries SATD(Cb) + SATD(Cr) of the prediction at the eighth-pel chroma MV (4-tap filters); otherwise the result
+ * equals x265hip_me_batch's.  subpelPlanes is required.  Methods DIA, HEX, STAR, FULL. */
+typedef struct x265hip_me_chroma {
+    const void *curCb, *curCr; intptr_t curStrideC;   /* source chroma planes                                                              */
+    const void *refCb, *refCr; intptr_t refStrideC;   /* reference chroma planes, padded like the luma plane (half the margins)            */
+    const int32_t* curOffC;                           /* device array, per task: element offset of the PU's chroma block in curCb / curCr  */
+    const int32_t* refOffC;                           /* device array, per task: the co-located offset in refCb / refCr                    */
+} x265hip_me_chroma;
+int x265hip_me_batch_chroma(void* stream, int w, int h,
+                            const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                            const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
+                            int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+                            const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* chroma);
+
 /* Pre-interpolate a padded reference plane (or a stack of planes: `rows` counts every row of the allocation) into
  * its 15 quarter-pel phase planes: outPlanes + f*planeElems for f = yFrac*4 + xFrac = 1..15 holds, at the same
  * (stride, row) addressing as refPlane, exactly luma_hpp / luma_vpp / luma_hvpp of the pixel (ipfilter.cpp:79-118,

@@ -255,6 +255,16 @@ class Oracle:
                                                   merange, method, subme, _ptr(costrow, half), _ptr(out), ip)
         return int(out[0]), int(out[1]), int(cost)
 
+    def me_chroma(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, mvc, merange, method, subme, costrow, cur_c, cstride_c, coff_c, ref_c, rstride_c, roff_c):
+        """me() with the chroma SATD terms (4:2:0): cur_c / ref_c = (Cb, Cr) arrays, coff_c / roff_c = element offset of the PU's chroma block in both"""
+        b = np.asarray(bounds, np.int32); c = np.asarray(mvc, np.int32).reshape(-1)
+        out = np.zeros(2, np.int32)
+        half = (len(costrow) - 1) // 2
+        cost = self.me_lib.xo_motion_estimate_chroma(_ptr(cur, coff), _IP(cstride), w, h, _ptr(ref, roff), _IP(rstride), _ptr(b), int(qmvp[0]), int(qmvp[1]), len(c) // 2,
+                                                     _ptr(c) if len(c) else None, merange, method, subme, _ptr(costrow, half), _ptr(out),
+                                                     _ptr(cur_c[0], coff_c), _ptr(cur_c[1], coff_c), _IP(cstride_c), _ptr(ref_c[0], roff_c), _ptr(ref_c[1], roff_c), _IP(rstride_c))
+        return int(out[0]), int(out[1]), int(cost)
+
     # ---- inter TU pipeline (x265_oracle_me.c xo_tq_tu) ----
     def tq_tu(self, log2n, cur, cstride, coff, ref, rstride, roff, mv, qp, add, quant_coeff=None, want_recon=False):
         n = 1 << log2n

@@ -17,7 +17,12 @@
  * record stream (little endian):  int32 kind, int32 nInts, int32 ints[nInts], then kind-specific pixels as uint16
  *   kind 1 (reference plane snapshot): ints = { id, stride, rows, originOffset, width, height }, pixels = stride * rows
  *   kind 2 (call): ints = { planeId, w, h, blockOffset, mvmin.x, .y, mvmax.x, .y, qmvp.x, .y, numCand, merange, searchMethod, subpelRefine, qp,
- *                           bChromaSATD, maxSlices, vertRestriction, srcPlaneGiven, out.x, out.y, cost, mvcost(out), mvc[2 * numCand] }, pixels = w * h (source PU)
+ *                           bChromaSATD, maxSlices, vertRestriction, srcPlaneGiven, out.x, out.y, cost, mvcost(out),
+ *                           cbPlaneId, crPlaneId, chromaOffset, chromaStride, cw, ch  (-1, -1, 0, 0, 0, 0 without chroma SATD),  mvc[2 * numCand] },
+ *                  pixels = w * h (source PU) [+ cw * ch Cb + cw * ch Cr of the source PU]
+ *   kind 3 (chroma plane snapshot of a reference picture, 4:2:0): ints and pixels as kind 1
+ * With threaded-me=0 on the command line the calls are those of Search::predInterSearch (search.cpp:2582-2700), whose setSourcePU overload enables
+ * the chroma SATD terms of subpelCompare (motion.cpp:218-247, 1805-1865) at subme >= 3.
  */
 #include <chrono>
 #include <cstdio>
@@ -86,17 +91,45 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
         put(1, { s.id, (int32_t)stride, rows, (int32_t)(rp->m_lumaMarginY * stride + rp->m_lumaMarginX), (int32_t)rp->m_picWidth, (int32_t)rp->m_picHeight }, px);
         it = g_planes.find(ref->fpelPlane[0]);
     }
+    int cbId = -1, crId = -1, chromaOff = 0, strideC = 0, cw = 0, ch = 0;
+    if (bChromaSATD)
+    {   /* the chroma planes of the reference picture, snapshot like the luma plane */
+        strideC = (int)rp->m_strideC; cw = blockwidth >> fencPUYuv.m_hChromaShift; ch = g_lumaH[partEnum] >> fencPUYuv.m_vChromaShift;
+        chromaOff = (int)rp->getChromaAddrOffset(ctuAddr, absPartIdx);
+        const int rowsC = (rp->m_picHeight >> rp->m_vChromaShift) + 2 * rp->m_chromaMarginY;
+        for (int c = 1; c <= 2; c++)
+        {
+            const pixel* topC = ref->fpelPlane[c] - (intptr_t)rp->m_chromaMarginY * strideC - rp->m_chromaMarginX;
+            uint64_t sc = 1469598103934665603ull;
+            for (intptr_t i = 0; i < (intptr_t)strideC * rowsC; i++) sc = (sc ^ topC[i]) * 1099511628211ull;
+            auto ic = g_planes.find(ref->fpelPlane[c]);
+            if (ic == g_planes.end() || ic->second.sum != sc)
+            {
+                Snap sn = { g_nextPlane++, sc };
+                g_planes[ref->fpelPlane[c]] = sn;
+                std::vector<uint16_t> pc((size_t)strideC * rowsC);
+                for (size_t i = 0; i < pc.size(); i++) pc[i] = topC[i];
+                put(3, { sn.id, strideC, rowsC, (int32_t)(rp->m_chromaMarginY * strideC + rp->m_chromaMarginX), (int32_t)(rp->m_picWidth >> rp->m_hChromaShift),
+                         (int32_t)(rp->m_picHeight >> rp->m_vChromaShift) }, pc);
+                ic = g_planes.find(ref->fpelPlane[c]);
+            }
+            (c == 1 ? cbId : crId) = ic->second.id;
+        }
+    }
     int qp = -1;
     for (int q = 0; q < BC_MAX_QP; q++)
         if (s_costs[q] && s_costs[q] == m_cost) qp = q;
     const int blockh = (int)(g_lumaH[partEnum]);     /* setSourcePU never sets blockheight (motion.cpp:167-247): the height follows from the partition enum */
     std::vector<int32_t> ints = { it->second.id, blockwidth, blockh, (int32_t)blockOffset, mvmin.x, mvmin.y, mvmax.x, mvmax.y, qmvp.x, qmvp.y, numCandidates, merange,
                                   searchMethod, subpelRefine, qp, (int32_t)bChromaSATD, (int32_t)maxSlices, (int32_t)m_vertRestriction, srcReferencePlane ? 1 : 0,
-                                  outQMv.x, outQMv.y, cost, (int32_t)mvcost(outQMv) };
+                                  outQMv.x, outQMv.y, cost, (int32_t)mvcost(outQMv), cbId, crId, chromaOff, strideC, cw, ch };
     for (int i = 0; i < numCandidates; i++) { ints.push_back(mvc[i].x); ints.push_back(mvc[i].y); }
     std::vector<uint16_t> px((size_t)blockwidth * blockh);
     for (int y = 0; y < blockh; y++)
         for (int x = 0; x < blockwidth; x++) px[(size_t)y * blockwidth + x] = fencPUYuv.m_buf[0][y * FENC_STRIDE + x];
+    for (int c = 1; c <= 2 && bChromaSATD; c++)
+        for (int y = 0; y < ch; y++)
+            for (int x = 0; x < cw; x++) px.push_back(fencPUYuv.m_buf[c][y * fencPUYuv.m_csize + x]);
     put(2, ints, px);
     g_calls++;
     return cost;

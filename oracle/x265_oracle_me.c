@@ -44,6 +44,10 @@ typedef struct
     int w, h;
     const uint16_t* cost;                          /* centred cost row */
     mv_t mvp;
+    /* chroma SATD terms of subpelCompare (motion.cpp:218-247, 1805-1865), 4:2:0: the PU's Cb / Cr source blocks and the co-located reference pixels */
+    int chroma, cw, ch;
+    xo_pixel fencC[2][32 * 32];                    /* cached at stride 32 */
+    const xo_pixel* frefC[2]; intptr_t strideC;
 } me_t;
 
 static inline int mvcost(const me_t* m, int qx, int qy)
@@ -68,7 +72,32 @@ static int subpel_compare(const me_t* m, int qx, int qy, int useSatd)
         else xo_interp_hvpp(8, m->w, m->h, fref, m->stride, buf, m->w, xf, yf);
         p = buf; ps = m->w;
     }
-    return useSatd ? xo_satd(m->w, m->h, m->fenc, 64, p, ps) : xo_sad(m->w, m->h, m->fenc, 64, p, ps);
+    int cost = useSatd ? xo_satd(m->w, m->h, m->fenc, 64, p, ps) : xo_sad(m->w, m->h, m->fenc, 64, p, ps);
+    if (m->chroma)
+    {   /* motion.cpp:1805-1865 with hshift = vshift = 1: the quarter-pel luma MV is the eighth-pel chroma MV; 4-tap filters, SATD whatever `cmp` is */
+        const int mvx = qx, mvy = qy, cxf = mvx & 7, cyf = mvy & 7;
+        const intptr_t off = (mvx >> 3) + (mvy >> 3) * m->strideC;
+        for (int c = 0; c < 2; c++)
+        {
+            const xo_pixel* r = m->frefC[c] + off;
+            xo_pixel cb[32 * 32];
+            const xo_pixel* q = r; intptr_t qs = m->strideC;
+            if (cxf | cyf)
+            {
+                if (!cyf) xo_interp_hpp(4, m->cw, m->ch, r, m->strideC, cb, m->cw, cxf);
+                else if (!cxf) xo_interp_vpp(4, m->cw, m->ch, r, m->strideC, cb, m->cw, cyf);
+                else
+                {
+                    int16_t immed[32 * (32 + 3)];
+                    xo_interp_hps(4, m->cw, m->ch, r, m->strideC, immed, m->cw, cxf, 1);
+                    xo_interp_vsp(4, m->cw, m->ch, immed + m->cw, m->cw, cb, m->cw, cyf);
+                }
+                q = cb; qs = m->cw;
+            }
+            cost += xo_satd(m->cw, m->ch, m->fencC[c], 32, q, qs);
+        }
+    }
+    return cost;
 }
 
 static const mv_t hex2[8] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1,-2}, {-2,0} };
@@ -218,6 +247,19 @@ int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, in
     return xo_motion_estimate_sea(fencPlane, fencStride, w, h, fref, refStride, bounds, qmvpx, qmvpy, numCand, mvc, merange, method, subme, costRowCentre, outQMv, NULL);
 }
 
+/* the search of Search::predInterSearch (search.cpp:2582): setSourcePU's Yuv overload with bChroma -- at subme >= 3, and when the 4:2:0 chroma block
+ * is a multiple of 4x4, every subpelCompare adds the SATD of the Cb and Cr predictions (motion.cpp:236-238, 1805-1865) */
+static const xo_pixel* g_fencC[2]; static const xo_pixel* g_refC[2]; static intptr_t g_fencStrideC, g_refStrideC;
+int xo_motion_estimate_chroma(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h, const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
+                              int qmvpx, int qmvpy, int numCand, const int32_t* mvc, int merange, int method, int subme, const uint16_t* costRowCentre, int32_t* outQMv,
+                              const xo_pixel* fencCb, const xo_pixel* fencCr, intptr_t fencStrideC, const xo_pixel* refCb, const xo_pixel* refCr, intptr_t refStrideC)
+{
+    g_fencC[0] = fencCb; g_fencC[1] = fencCr; g_refC[0] = refCb; g_refC[1] = refCr; g_fencStrideC = fencStrideC; g_refStrideC = refStrideC;
+    const int r = xo_motion_estimate_sea(fencPlane, fencStride, w, h, fref, refStride, bounds, qmvpx, qmvpy, numCand, mvc, merange, method, subme, costRowCentre, outQMv, NULL);
+    g_fencC[0] = g_fencC[1] = NULL;
+    return r;
+}
+
 /* the same with the 12 SEA integral planes of the reference picture (pointers at the PU's co-located position), needed by XO_ME_SEA */
 int xo_motion_estimate_sea(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h,
                            const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
@@ -228,6 +270,16 @@ int xo_motion_estimate_sea(const xo_pixel* fencPlane, intptr_t fencStride, int w
     m->fref = fref; m->stride = refStride; m->w = w; m->h = h; m->cost = costRowCentre;
     m->mvp.x = qmvpx; m->mvp.y = qmvpy;
     for (int y = 0; y < h; y++) memcpy(m->fenc + 64 * y, fencPlane + y * fencStride, w * sizeof(xo_pixel));
+    m->chroma = 0;
+    if (g_fencC[0] && subme > 2 && !((w >> 1) & 3) && !((h >> 1) & 3))
+    {   /* bChromaSATD (motion.cpp:236-238): chromaSatd exists for 4:2:0 blocks that are multiples of 4x4 (primitives.cpp:213-234) */
+        m->chroma = 1; m->cw = w >> 1; m->ch = h >> 1; m->strideC = g_refStrideC;
+        for (int c = 0; c < 2; c++)
+        {
+            m->frefC[c] = g_refC[c];
+            for (int y = 0; y < m->ch; y++) memcpy(m->fencC[c] + 32 * y, g_fencC[c] + y * g_fencStrideC, m->cw * sizeof(xo_pixel));
+        }
+    }
     const mv_t mvmin = { bounds[0], bounds[1] }, mvmax = { bounds[2], bounds[3] };
     const mv_t qmvmin = { mvmin.x * 4, mvmin.y * 4 }, qmvmax = { mvmax.x * 4, mvmax.y * 4 };
     int costs[4];

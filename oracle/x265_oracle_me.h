@@ -18,6 +18,11 @@ int xo_motion_estimate(const xo_pixel* fencPlane, intptr_t fencStride, int w, in
                        const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
                        int qmvpx, int qmvpy, int numCand, const int32_t* mvc,
                        int merange, int method, int subme, const uint16_t* costRowCentre, int32_t* outQMv);
+/* the same with the chroma SATD terms of subpelCompare (the Yuv overload of setSourcePU with bChroma, 4:2:0): fencCb / fencCr point at the PU's
+ * chroma source blocks, refCb / refCr at the co-located reference chroma pixels.  Not reentrant (test infrastructure). */
+int xo_motion_estimate_chroma(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h, const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
+                              int qmvpx, int qmvpy, int numCand, const int32_t* mvc, int merange, int method, int subme, const uint16_t* costRowCentre, int32_t* outQMv,
+                              const xo_pixel* fencCb, const xo_pixel* fencCr, intptr_t fencStrideC, const xo_pixel* refCb, const xo_pixel* refCr, intptr_t refStrideC);
 /* SEA (XO_ME_SEA): the 12 integral planes of the reference picture (framefilter.cpp:740-833; order 32x32, 32x24, 32x8, 24x32, 16x16,
  * 16x12, 16x4, 12x16, 8x32, 8x8, 4x16, 4x4) and the search with them; integral[k] points at the PU's co-located position. */
 void xo_sea_integral_planes(const xo_pixel* pic, intptr_t stride, int maxHeight, int padX, int padY, uint32_t* const* planes);

@@ -10,9 +10,9 @@ import tempfile
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NI = 23          # ints of a call record in front of the candidates (ref_tme.cpp)
+NI = 29          # ints of a call record in front of the candidates (ref_tme.cpp)
 CALL_FIELDS = ("plane w h blockOffset mnx mny mxx mxy qmvpx qmvpy numCand merange method subme qp chromaSatd maxSlices vertRestriction "
-               "srcPlane outx outy cost mvcost").split()
+               "srcPlane outx outy cost mvcost cbPlane crPlane chromaOffset chromaStride cw ch").split()
 
 
 def parse(path):
@@ -21,13 +21,14 @@ def parse(path):
     while off < len(d):
         kind, n = np.frombuffer(d, np.int32, 2, off); off += 8
         ints = np.frombuffer(d, np.int32, n, off).copy(); off += 4 * n
-        if kind == 1:
+        if kind in (1, 3):
             pid, stride, rows = int(ints[0]), int(ints[1]), int(ints[2])
             px = np.frombuffer(d, np.uint16, stride * rows, off).copy(); off += 2 * stride * rows
             planes[pid] = (ints, px)
         else:
             w, h = int(ints[1]), int(ints[2])
-            px = np.frombuffer(d, np.uint16, w * h, off).copy(); off += 2 * w * h
+            npx = w * h + 2 * int(ints[27]) * int(ints[28])          # luma block [+ Cb + Cr blocks of the source PU]
+            px = np.frombuffer(d, np.uint16, npx, off).copy(); off += 2 * npx
             calls.append(ints[:NI]); mvcs.append(ints[NI:]); blocks.append(px)
     return planes, calls, mvcs, blocks
 
@@ -56,10 +57,14 @@ def build(depth, args, out):
 
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "tme"])
-    for depth, args in ((8, ["128", "128", "3", "medium"]), (10, ["128", "128", "3", "slow", "amp=0"])):
-        out = os.path.join(ROOT, "tests", "golden", "tme_%d.npz" % depth)
+    # tme_*: --threaded-me encodes (luma-only searches of puMotionEstimation); mec_*: regular encodes whose predInterSearch searches carry the chroma
+    # SATD terms (subme >= 3), incl. weighted / several references and B pictures
+    for name, depth, args in (("tme", 8, ["128", "128", "3", "medium"]), ("tme", 10, ["128", "128", "3", "slow", "amp=0"]),
+                              ("mec", 8, ["128", "64", "4", "slow", "threaded-me=0", "rect=0", "amp=0", "bframes=1"]),
+                              ("mec", 10, ["128", "64", "4", "slower", "threaded-me=0", "rect=0", "amp=0", "bframes=1", "me=hex"])):
+        out = os.path.join(ROOT, "tests", "golden", "%s_%d.npz" % (name, depth))
         c = build(depth, args, out)
         f = {n: c[:, i] for i, n in enumerate(CALL_FIELDS)}
-        print(depth, "calls", len(c), "size", os.path.getsize(out), "methods", np.unique(f["method"]), "subme", np.unique(f["subme"]), "chromaSatd", np.unique(f["chromaSatd"]),
+        print(name, depth, "calls", len(c), "size", os.path.getsize(out), "methods", np.unique(f["method"]), "subme", np.unique(f["subme"]), "chromaSatd", np.unique(f["chromaSatd"]),
               "numCand max", f["numCand"].max(), "shapes", sorted({(int(a), int(b)) for a, b in zip(f["w"], f["h"])}), "qp", np.unique(f["qp"]),
               "vert/slices/src", np.unique(f["vertRestriction"]), np.unique(f["maxSlices"]), np.unique(f["srcPlane"]))

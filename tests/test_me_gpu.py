@@ -223,3 +223,53 @@ def test_me_batch_plane_buffer_beyond_4gb():
                          (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc, 57, 3, 3, row)
             got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
             assert got == exp, ">4GB planes: PU %dx%d task %d: hip %s oracle %s" % (w, h, i, got, exp)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method", [0, 1, 3, 5])        # DIA, HEX, STAR, FULL
+def test_me_batch_chroma_matches_oracle(depth, method):
+    """x265hip_me_batch_chroma (the predInterSearch call form: chroma SATD terms in every sub-pel cost, motion.cpp:1805-1865) against the oracle, which
+    is pinned on recorded reference searches (test_tme_golden.py): all 24 PU shapes (the terms apply where the 4:2:0 block is a multiple of 4x4),
+    subme 3..7 (and 2, where bChromaSATD stays off), random predictors and candidates."""
+    api, ora = FrameApi(depth), Oracle(depth)
+    T = api.torch
+    rng = np.random.default_rng(911 * depth + method)
+    W, H, margin = 320, 192, 96
+    half = 1 << 13
+    cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 31, margin=margin, max_shift=12)
+    # chroma planes: any content does for parity; half-size pictures with half the margin, the same layout rule
+    cm = margin // 2
+    ccb, rcb, cstr, _ = frame_pair(W // 2, H // 2, depth, 32, margin=cm, max_shift=6)
+    ccr, rcr, _, _ = frame_pair(W // 2, H // 2, depth, 33, margin=cm, max_shift=6)
+    cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
+    cc = (ccb.reshape(-1), ccr.reshape(-1)); rc = (rcb.reshape(-1), rcr.reshape(-1))
+    d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+    d_cc = [api.to_device(x) for x in cc]; d_rc = [api.to_device(x) for x in rc]
+    pe = cur_f.size
+    d_pl = T.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
+    api.subpel_planes(d_ref, stride, cur.shape[0], d_pl, pe)
+    for (w, h) in PUS:
+        merange = int(rng.choice([4, 9] if method == 5 else [8, 16, 57]))
+        qp = int(rng.choice([22, 28, 37]))
+        subme = int(rng.integers(2, 8))
+        n = 16 if w * h <= 1024 else 8
+        tasks = make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange)
+        offc = np.zeros(n, np.int32)
+        for i in range(n):
+            px, py = (int(tasks[i]["curOff"]) % stride) - margin, (int(tasks[i]["curOff"]) // stride) - margin
+            offc[i] = (cm + py // 2) * cstr + cm + px // 2
+        row = ora.mvcost_row(qp, half)
+        d_tasks, d_row, d_off = api.to_device(tasks), api.to_device(row.view(np.int16)), api.to_device(offc)
+        d_res = T.zeros(n * ME_RESULT.itemsize, dtype=T.uint8, device="cuda")
+        api.me_batch_chroma(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, merange, method, subme, d_res, d_pl, pe,
+                            d_cc[0], d_cc[1], cstr, d_rc[0], d_rc[1], cstr, d_off, d_off)
+        T.cuda.synchronize()
+        res = d_res.cpu().numpy().view(ME_RESULT)
+        for i in range(n):
+            tk = tasks[i]
+            bounds = [int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])]
+            mvc = [int(v) for v in tk["mvc"][:2 * int(tk["numCand"])]]
+            exp = ora.me_chroma(w, h, cur_f, stride, int(tk["curOff"]), ref_f, stride, int(tk["refOff"]), bounds, (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc,
+                                merange, method, subme, row, cc, cstr, int(offc[i]), rc, cstr, int(offc[i]))
+            got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
+            assert got == exp, "chroma: PU %dx%d task %d method %d subme %d merange %d: hip %s oracle %s (mvp %s)" % (w, h, i, method, subme, merange, got, exp, tk["qmvp"])

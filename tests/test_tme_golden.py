@@ -29,3 +29,27 @@ def test_oracle_replays_the_threaded_me_calls_of_a_reference_encode(depth):
             i, w, h, nc, got, (int(c["outx"][i]), int(c["outy"][i]), int(c["cost"][i])))
         n += 1
     assert n == len(fx)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_replays_the_chroma_satd_searches_of_a_reference_encode(depth):
+    """Search::predInterSearch's call form (the Yuv overload of setSourcePU with bChroma, search.cpp:2582): at subme 3 / 4 every sub-pel cost carries
+    the SATD of the Cb and Cr predictions (motion.cpp:1805-1865).  Fixtures: a regular (not threaded-me) encode, P and B pictures, up to 12 candidates."""
+    from tme_util import MecFixture
+    fx, ora = MecFixture(depth), Oracle(depth)
+    c = fx.col
+    assert len(fx) > 800 and c["chromaSatd"].all() and (c["subme"] >= 3).all()
+    rows = {}
+    for i in range(len(fx)):
+        qp = int(c["qp"][i])
+        if qp not in rows:
+            rows[qp] = ora.mvcost_row(qp, 1 << 14)
+        pl, cb, cr = fx.planes[int(c["plane"][i])], fx.planes[int(c["cbPlane"][i])], fx.planes[int(c["crPlane"][i])]
+        w, h, nc, cw = int(c["w"][i]), int(c["h"][i]), int(c["numCand"][i]), int(c["cw"][i])
+        y, u, v = fx.blocks(i)
+        got = ora.me_chroma(w, h, y, w, 0, pl["px"], pl["stride"], pl["origin"] + int(c["blockOffset"][i]),
+                            [int(c["mnx"][i]), int(c["mny"][i]), int(c["mxx"][i]), int(c["mxy"][i])], (int(c["qmvpx"][i]), int(c["qmvpy"][i])),
+                            [int(x) for x in fx.mvc[i, :2 * nc]], int(c["merange"][i]), int(c["method"][i]), int(c["subme"][i]), rows[qp],
+                            (u, v), cw, 0, (cb["px"], cr["px"]), cb["stride"], cb["origin"] + int(c["chromaOffset"][i]))
+        exp = (int(c["outx"][i]), int(c["outy"][i]), int(c["cost"][i]))
+        assert got == exp, "call %d (%dx%d, subme %d): oracle %s reference %s" % (i, w, h, int(c["subme"][i]), got, exp)

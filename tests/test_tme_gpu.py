@@ -50,3 +50,51 @@ def test_me_batch_replays_the_threaded_me_task_list(depth, planes):
             w, h, pid, qp, len(bad), n, idx[bad[0]], r[bad[0]], c["outx"][idx[bad[0]]], c["outy"][idx[bad[0]]], c["cost"][idx[bad[0]]])
         checked += n
     assert checked > 600
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_me_batch_chroma_replays_the_searches_of_pred_inter_search(depth):
+    """The predInterSearch call form: chroma SATD terms in every sub-pel cost (subme 3 / 4, 4:2:0).  Fixtures from a regular reference encode
+    (P and B pictures, several references, up to 12 candidates): x265hip_me_batch_chroma must return the reference's MV, cost and MV cost."""
+    from tme_util import MecFixture
+    fx, api = MecFixture(depth), FrameApi(depth)
+    T = api.torch
+    c = fx.col
+    half = 1 << 14
+    d_planes, d_phase, rows = {}, {}, {}
+    for pid, pl in fx.planes.items():
+        d_planes[pid] = api.to_device(pl["px"])
+    checked = 0
+    keys = {}
+    for i in range(len(fx)):
+        keys.setdefault((int(c["plane"][i]), int(c["cbPlane"][i]), int(c["crPlane"][i]), int(c["w"][i]), int(c["h"][i]), int(c["qp"][i]), int(c["method"][i]),
+                         int(c["subme"][i]), int(c["merange"][i])), []).append(i)
+    for (pid, cbid, crid, w, h, qp, method, subme, merange), idx in keys.items():
+        pl, cb = fx.planes[pid], fx.planes[cbid]
+        if pid not in d_phase:
+            d_phase[pid] = T.zeros(16 * pl["px"].size, dtype=d_planes[pid].dtype, device="cuda")
+            api.subpel_planes(d_planes[pid], pl["stride"], pl["rows"], d_phase[pid], pl["px"].size)
+        n, cw, ch = len(idx), w // 2, h // 2
+        t = np.zeros(n, ME_TASK)
+        blocks = [fx.blocks(i) for i in idx]
+        cur = np.concatenate([b[0] for b in blocks]); cur_cb = np.concatenate([b[1] for b in blocks]); cur_cr = np.concatenate([b[2] for b in blocks])
+        t["curOff"] = np.arange(n) * (w * h)
+        t["refOff"] = pl["origin"] + c["blockOffset"][idx]
+        t["mvmin"][:, 0] = c["mnx"][idx]; t["mvmin"][:, 1] = c["mny"][idx]; t["mvmax"][:, 0] = c["mxx"][idx]; t["mvmax"][:, 1] = c["mxy"][idx]
+        t["qmvp"][:, 0] = c["qmvpx"][idx]; t["qmvp"][:, 1] = c["qmvpy"][idx]
+        t["mvc"] = fx.mvc[idx]; t["numCand"] = c["numCand"][idx]; t["mvpFrom"] = -1
+        if qp not in rows:
+            rows[qp] = api.to_device(mvcost_row(depth, qp, half).view(np.int16))
+        d_t, d_cur, d_ccb, d_ccr = api.to_device(t), api.to_device(cur), api.to_device(cur_cb), api.to_device(cur_cr)
+        d_co = api.to_device((np.arange(n) * (cw * ch)).astype(np.int32))
+        d_ro = api.to_device((cb["origin"] + c["chromaOffset"][idx]).astype(np.int32))
+        d_res = T.zeros(n * ME_RESULT.itemsize, dtype=T.uint8, device="cuda")
+        api.me_batch_chroma(w, h, d_cur, w, d_planes[pid], pl["stride"], d_t, n, rows[qp], half, merange, method, subme, d_res, d_phase[pid], pl["px"].size,
+                            d_ccb, d_ccr, cw, d_planes[cbid], d_planes[crid], cb["stride"], d_co, d_ro)
+        T.cuda.synchronize()
+        r = d_res.cpu().numpy().view(ME_RESULT)
+        bad = np.nonzero((r["mv"][:, 0] != c["outx"][idx]) | (r["mv"][:, 1] != c["outy"][idx]) | (r["cost"] != c["cost"][idx]) | (r["mvcost"] != c["mvcost"][idx]))[0]
+        assert len(bad) == 0, "%dx%d method %d subme %d: %d of %d tasks differ, first: call %d hip %s reference (%d, %d, %d)" % (
+            w, h, method, subme, len(bad), n, idx[bad[0]], r[bad[0]], c["outx"][idx[bad[0]]], c["outy"][idx[bad[0]]], c["cost"][idx[bad[0]]])
+        checked += n
+    assert checked == len(fx)

@@ -34,3 +34,28 @@ class TmeFixture:
             c = self.col
             keys.setdefault((int(c["plane"][i]), int(c["w"][i]), int(c["h"][i]), int(c["qp"][i]), int(c["method"][i]), int(c["subme"][i]), int(c["merange"][i])), []).append(i)
         return keys
+
+
+class MecFixture(TmeFixture):
+    """tests/golden/mec_{8,10}.npz: the searches of Search::predInterSearch in a regular encode (several references, B pictures, candidates),
+    with the chroma SATD terms of subpelCompare (subme >= 3); per call also the Cb / Cr source blocks and reference chroma planes."""
+    def __init__(self, depth):
+        d = np.load(os.path.join(GOLD, "mec_%d.npz" % depth))
+        self.depth = depth
+        self.fields = [str(f) for f in d["fields"]]
+        self.calls = d["calls"]
+        self.col = {n: self.calls[:, i] for i, n in enumerate(self.fields)}
+        self.mvc, self.fenc, self.start = d["mvc"], d["fenc"], d["fenc_start"]
+        self.planes = {}
+        for k in d.files:
+            if k.startswith("plane") and k.endswith("_geom"):
+                pid = int(k[5:-5])
+                g = d[k]
+                self.planes[pid] = dict(stride=int(g[1]), rows=int(g[2]), origin=int(g[3]), width=int(g[4]), height=int(g[5]), px=d["plane%d" % pid])
+
+    def blocks(self, i):
+        """(luma, Cb, Cr) source blocks of call i"""
+        c = self.col
+        w, h, cw, ch = int(c["w"][i]), int(c["h"][i]), int(c["cw"][i]), int(c["ch"][i])
+        b = self.fenc[self.start[i]:self.start[i + 1]]
+        return b[:w * h], b[w * h:w * h + cw * ch], b[w * h + cw * ch:]

@@ -17,6 +17,35 @@ int xh_me_sea(void* stream, int w, int h, const void* curPlane, intptr_t curStri
               int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
               const void* subpelPlanes, int64_t planeElems, const uint32_t* integral, int64_t integralElems);
 
+int xh_me_chroma(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                 const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
+                 int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+                 const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* ch);
+int xh_me_star_chroma(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                      const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
+                      int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+                      const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* ch);
+
+// the search of Search::predInterSearch: chroma SATD terms in every sub-pel cost (4:2:0)
+extern "C" int x265hip_me_batch_chroma(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                                       const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
+                                       int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+                                       const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* chroma)
+{
+    if (n <= 0) return X265HIP_OK;
+    if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !tasks || !results || !costRow || costHalfRange < 1)
+    { set_error("me_batch_chroma: bad arguments"); return X265HIP_EARG; }
+    if (!chroma || !chroma->curCb || !chroma->curCr || !chroma->refCb || !chroma->refCr || !chroma->curOffC || !chroma->refOffC)
+    { set_error("me_batch_chroma: chroma planes and per-task chroma offsets are required"); return X265HIP_EARG; }
+    if (method != X265HIP_ME_DIA && method != X265HIP_ME_HEX && method != X265HIP_ME_STAR && method != X265HIP_ME_FULL)
+    { set_error("me_batch_chroma: search method %d is not offered with chroma terms (DIA / HEX / STAR / FULL are)", method); return X265HIP_EARG; }
+    if (subpelRefine < 0 || subpelRefine > 7 || merange < 1) { set_error("me_batch_chroma: bad subme/merange"); return X265HIP_EARG; }
+    if (!subpelPlanes || planeElems <= 0 || ((uintptr_t)subpelPlanes & 7)) { set_error("me_batch_chroma: the phase planes of the reference picture are required"); return X265HIP_EARG; }
+    if (method == X265HIP_ME_STAR)
+        return xh_me_star_chroma(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems, chroma);
+    return xh_me_chroma(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems, chroma);
+}
+
 // SEA: the search needs the 12 integral planes of the reference picture (x265hip_sea_integral_planes), laid out like the reference plane
 extern "C" int x265hip_me_batch_sea(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                                     const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,

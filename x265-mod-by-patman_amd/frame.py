@@ -17,6 +17,11 @@ LA_TASK = np.dtype([("b", "<i4"), ("p0", "<i4"), ("p1", "<i4"), ("doSearch", "<i
 assert ME_TASK.itemsize == 76 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 20 and LA_TASK.itemsize == 36
 
 
+class MeChroma(C.Structure):
+    _fields_ = [("curCb", C.c_void_p), ("curCr", C.c_void_p), ("curStrideC", C.c_ssize_t), ("refCb", C.c_void_p), ("refCr", C.c_void_p), ("refStrideC", C.c_ssize_t),
+                ("curOffC", C.c_void_p), ("refOffC", C.c_void_p)]
+
+
 class TqParams(C.Structure):
     _fields_ = [("qp", C.c_int), ("add", C.c_int), ("quantCoeff", C.c_void_p), ("deltaU", C.c_void_p),
                 ("subpelPlanes", C.c_void_p), ("planeElems", C.c_int64)]
@@ -97,6 +102,13 @@ class FrameApi:
         self.h.check(self.lib.x265hip_intra_cost_batch(self.stream(), log2_size, _dp(src), C.c_ssize_t(src_stride), _dp(src_off), _dp(nb_ref), _dp(nb_filt),
                                                        nb_pitch, n, _dp(costs), _dp(workspace), C.c_size_t(need)))
         return workspace
+
+    def me_batch_chroma(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half, merange, method, subme, results, planes, plane_elems,
+                        cur_cb, cur_cr, cstride_c, ref_cb, ref_cr, rstride_c, cur_off_c, ref_off_c, mvp_source=None):
+        """x265hip_me_batch_chroma: the search with the chroma SATD terms of subpelCompare (the predInterSearch call form), 4:2:0."""
+        ch = MeChroma(_dp(cur_cb), _dp(cur_cr), cstride_c, _dp(ref_cb), _dp(ref_cr), rstride_c, _dp(cur_off_c), _dp(ref_off_c))
+        self.h.check(self.lib.x265hip_me_batch_chroma(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride), _dp(tasks), n,
+                                                      _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source), _dp(planes), C.c_int64(plane_elems), C.byref(ch)))
 
     def lookahead_qp(self):
         return int(self.lib.x265hip_lookahead_qp())
