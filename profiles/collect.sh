@@ -13,9 +13,12 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 "$@" > /dev/null 2> $out/write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $out/sq1 -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 "$@" > /dev/null 2> $out/sq1.err
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $out/sq2 -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 "$@" > /dev/null 2> $out/sq2.err
-python profiles/summarize_pmc.py --traffic $out/fetch $out/write > $out/traffic.json
+src="$tag, code $(cat profiles/.commit 2>/dev/null || echo unknown)"
+python profiles/summarize_pmc.py --traffic $out/fetch $out/write "$src" > $out/traffic.json
+python profiles/summarize_pmc.py --valu $out/sq1 "$src" > $out/valu.json
 python profiles/summarize_pmc.py $out/sq1 $out/sq2 > $out/sq.txt
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
+find $out/stats -name "*kernel_trace.csv" | head -1 | xargs -I{} python profiles/kstats.py $out/kernel_stats.csv {} > $out/kstats.txt
 # keep the merged-back payload small: the raw traces are not needed once summarised
 find $out -name "*kernel_trace.csv" -delete; find $out -name "*counter_collection.csv" -delete
-cat $out/bench.json; cat $out/traffic.json; cat $out/sq.txt
+cat $out/bench.json; cat $out/traffic.json; cat $out/valu.json; cat $out/kstats.txt

@@ -28,28 +28,53 @@ def load(d):
 
 
 def bench_name(kernel):
-    """me_kernel<G, MAXPIX, ...> / tq_kernel<N> / subpel_planes_kernel -> the names bench.py uses."""
+    """me_kernel<G, MAXPIX, ...> / star64_kernel / tq_kernel<N> / subpel_planes_kernel -> the names bench.py uses (one name per launch GROUP of a
+    step: me64 = the two halves of the split 64x64 kernel + star64_kernel)."""
     if kernel.startswith("subpel_planes_kernel"):
         return "planes"
-    m = re.match(r"tq_kernel<(\d+)", kernel)
-    if m:
-        return "tq%s" % m.group(1)
+    if kernel.startswith("star64_kernel"):
+        return "me64"
+    if re.match(r"tq_kernel<(\d+)", kernel):
+        return "tq"
     m = re.match(r"me_kernel<(\d+), (\d+)", kernel)
     if m:
         return {4096: "me64", 1024: "me32", 256: "me16", 64: "me8"}.get(int(m.group(2)))
     return None
 
 
+def per_step(d):
+    """{bench name: {counter: total per step}}: counter values summed over ALL dispatches of the kernels behind a bench name, divided by the number
+    of steps of the run (= dispatches of the phase-plane kernel, launched once per step)."""
+    tot, steps = defaultdict(lambda: defaultdict(float)), 0
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        rows = list(csv.DictReader(open(f)))
+        first = rows[0]["Counter_Name"] if rows else None
+        for r in rows:
+            k = short(r["Kernel_Name"])
+            b = bench_name(k)
+            if b:
+                tot[b][r["Counter_Name"]] += float(r["Counter_Value"])
+            if k.startswith("subpel_planes_kernel") and r["Counter_Name"] == first:
+                steps += 1
+    return {b: {c: v / max(steps, 1) for c, v in cs.items()} for b, cs in tot.items()}
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "--traffic":
-        fetch, write = load(sys.argv[2]), load(sys.argv[3])
-        out = {}
-        for k in fetch:
-            b = bench_name(k)
-            if b and "FETCH_SIZE" in fetch[k] and k in write:
-                out[b] = int((fetch[k]["FETCH_SIZE"] + write[k].get("WRITE_SIZE", 0.0)) * 1024)
-                out[b + "_read"] = int(fetch[k]["FETCH_SIZE"] * 1024)
-                out[b + "_write"] = int(write[k].get("WRITE_SIZE", 0.0) * 1024)
+        fetch, write = per_step(sys.argv[2]), per_step(sys.argv[3])
+        out = {"_source": sys.argv[4] if len(sys.argv) > 4 else "FETCH_SIZE + WRITE_SIZE (KiB) per step"}
+        for b in fetch:
+            if "FETCH_SIZE" in fetch[b] and b in write:
+                out[b] = int((fetch[b]["FETCH_SIZE"] + write[b].get("WRITE_SIZE", 0.0)) * 1024)
+                out[b + "_read"] = int(fetch[b]["FETCH_SIZE"] * 1024)
+                out[b + "_write"] = int(write[b].get("WRITE_SIZE", 0.0) * 1024)
+        print(json.dumps(out, indent=1, sort_keys=True))
+    elif sys.argv[1] == "--valu":
+        sq = per_step(sys.argv[2])
+        out = {"_source": sys.argv[3] if len(sys.argv) > 3 else "SQ_INSTS_VALU per step"}
+        for b in sq:
+            if "SQ_INSTS_VALU" in sq[b]:
+                out[b] = int(sq[b]["SQ_INSTS_VALU"])
         print(json.dumps(out, indent=1, sort_keys=True))
     else:
         for d in sys.argv[1:]:
