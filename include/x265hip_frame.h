@@ -87,6 +87,38 @@ int x265hip_me_batch_chroma(void* stream, int w, int h,
                             int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
                             const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* chroma);
 
+/* ---- several references, two lists: the per-PU choice after the per-reference searches --------------------------------------------------
+ * x265hip_inter_merge_batch replaces the tail of Search::puMotionEstimation / predInterSearch for 2Nx2N PUs (search.cpp:258-556): bits and cost of every
+ * (list, reference) search -- listSelBits + MVP_IDX_BITS + getTUBits(ref) + BitCost::bitcost(mv - mvp), (satd - mvcost) + RDCost::getCost(bits) --, the best
+ * reference of each list, for B slices the bidirectional candidate (predInterLumaPixel of both bests -> pixelavg_pp -> SATD, and the same with both MVs zero),
+ * and the final choice, as a record like MEData (encoder/threadedme.h:122-130).  There is no AMVP list here: the MVP of a search is its predictor (the task's
+ * qmvp, or mvpSource[list][ref][task.mvpFrom].mv) and checkBestMVP / updateMVP have nothing to choose from.
+ * results[list][ref]: the x265hip_me_batch outputs of the same task list searched in that reference.  subpelPlanes[list][ref]: the 16-slot phase-plane buffer
+ * of that reference (needed when bidir != 0 and list 1 is not empty); all references share refStride / planeElems and the tasks' refOff. */
+typedef struct x265hip_inter_choice {
+    int16_t  mv[2][2];           /* per list: quarter-pel MV (0 when the list is unused)                */
+    int16_t  mvp[2][2];          /* per list: the predictor the bits were counted against               */
+    uint32_t mvCost[2];          /* per list: lambda-scaled MVD cost of the chosen search (MEData.mvCost) */
+    int8_t   ref[2];             /* per list: reference index, -1 = list unused (REF_NOT_VALID)          */
+    int16_t  reserved;
+    int32_t  bits;               /* MEData.bits                                                          */
+    uint32_t cost;               /* MEData.cost                                                          */
+} x265hip_inter_choice;          /* 36 bytes */
+typedef struct x265hip_merge_params {
+    int numRef[2];                                   /* references searched per list: 1..4 and 0..4 (0: P slice)            */
+    const x265hip_me_result* results[2][4];
+    const x265hip_me_result* mvpSource[2][4];        /* per (list, ref): the array task.mvpFrom indexes, or NULL             */
+    const void* subpelPlanes[2][4]; int64_t planeElems;
+    const float* bitsRow; int bitsHalfRange;         /* device copy of x265hip_mvbits_row: entry [bitsHalfRange + d] = s_bitsizes[|d|] */
+    uint64_t lambda;                                 /* x265hip_rd_lambda(qp) = RDCost::m_lambda                            */
+    int bidir;                                       /* != 0: evaluate the bidirectional candidate (B slices)               */
+    int sourceMaxDim;                                /* max(param->sourceWidth, sourceHeight): range of the zero-MV try     */
+} x265hip_merge_params;
+int x265hip_mvbits_row(int halfRange, float* out /* 2 * halfRange + 1 */);      /* host: BitCost::CalculateLogs (bitcost.cpp:72-86)        */
+uint64_t x265hip_rd_lambda(int qp);                                             /* host: RDCost::setLambda on x265_lambda_tab[qp]          */
+int x265hip_inter_merge_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, intptr_t refStride,
+                              const x265hip_me_task* tasks, int n, const x265hip_merge_params* params, x265hip_inter_choice* out);
+
 /* Pre-interpolate a padded reference plane (or a stack of planes: `rows` counts every row of the allocation) into
  * its 15 quarter-pel phase planes: outPlanes + f*planeElems for f = yFrac*4 + xFrac = 1..15 holds, at the same
  * (stride, row) addressing as refPlane, exactly luma_hpp / luma_vpp / luma_hvpp of the pixel (ipfilter.cpp:79-118,

@@ -265,6 +265,27 @@ class Oracle:
                                                      _ptr(cur_c[0], coff_c), _ptr(cur_c[1], coff_c), _IP(cstride_c), _ptr(ref_c[0], roff_c), _ptr(ref_c[1], roff_c), _IP(rstride_c))
         return int(out[0]), int(out[1]), int(cost)
 
+    # ---- choice among references + bidirectional candidate (x265_oracle_me.c xo_inter_merge) ----
+    def mvbits_row(self, half):
+        out = np.zeros(2 * half + 1, np.float32)
+        self.me_lib.xo_mvbits_row(half, _ptr(out))
+        return out
+
+    def rd_lambda(self, qp):
+        self.me_lib.xo_rd_lambda.restype = C.c_uint64
+        return int(self.me_lib.xo_rd_lambda(qp))
+
+    def inter_merge(self, w, h, num_ref, mv, mvp, cost, mvcost, bits_row, lam, bidir, source_max_dim, clip, cur, cstride, coff, refs, rstride, roff):
+        """mv / mvp: int arrays [8][2] (list * 4 + ref), cost / mvcost [8]; refs: 8 reference planes (or None); returns (out[12], mvCost[2])"""
+        nr = np.asarray(num_ref, np.int32); m = np.asarray(mv, np.int32).reshape(-1); p = np.asarray(mvp, np.int32).reshape(-1)
+        c = np.asarray(cost, np.int32); mc = np.asarray(mvcost, np.int32); cl = np.asarray(clip, np.int32)
+        half = (len(bits_row) - 1) // 2
+        ptrs = (C.c_void_p * 8)(*[(r.ctypes.data + roff * r.itemsize) if r is not None else None for r in refs])
+        out = np.zeros(12, np.int32); mco = np.zeros(2, np.uint32)
+        self.me_lib.xo_inter_merge(w, h, _ptr(nr), _ptr(m), _ptr(p), _ptr(c), _ptr(mc), _ptr(bits_row, half), C.c_uint64(lam), int(bidir), source_max_dim, _ptr(cl),
+                                   _ptr(cur, coff), _IP(cstride), ptrs, _IP(rstride), _ptr(out), _ptr(mco))
+        return out, mco
+
     # ---- inter TU pipeline (x265_oracle_me.c xo_tq_tu) ----
     def tq_tu(self, log2n, cur, cstride, coff, ref, rstride, roff, mv, qp, add, quant_coeff=None, want_recon=False):
         n = 1 << log2n

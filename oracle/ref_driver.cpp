@@ -20,6 +20,7 @@
 #include "primitives.h"
 #include "motion.h"
 #include "lowres.h"
+#include "rdcost.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -416,6 +417,19 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         g_me->setQP((unsigned)I[0]);
         int hr = (int)I[1]; Buf b((2 * hr + 1) * 2);
         memcpy(b.data(), g_me->costRow() - hr, b.size()); out.push_back(b); return true;
+    }
+    if (op == "bits_cost")
+    {   /* ints = qp, n, then n x (mv.x, mv.y, mvp.x, mvp.y, bits): returns u32[n] BitCost::bitcost(mv, mvp) (bitcost.h:66-70) and u32[n] RDCost::getCost(bits)
+           for the slice-independent lambda of that qp (rdcost.h:88-92,164-169) */
+        g_me->setQP((unsigned)I[0]);
+        RDCost rd; rd.setLambda(x265_lambda2_tab[I[0]], x265_lambda_tab[I[0]]);
+        int n = (int)I[1]; Buf a(4 * n), b(4 * n);
+        for (int i = 0; i < n; i++)
+        {
+            ((uint32_t*)a.data())[i] = g_me->bitcost(MV((int)I[2 + 5 * i], (int)I[3 + 5 * i]), MV((int)I[4 + 5 * i], (int)I[5 + 5 * i]));
+            ((uint32_t*)b.data())[i] = rd.getCost((uint32_t)I[6 + 5 * i]);
+        }
+        out.push_back(a); out.push_back(b); return true;
     }
     if (op == "me")
     {   /* ints = w,h, fencStride,fencOff, refStride,refOff, mvmin.x,mvmin.y,mvmax.x,mvmax.y, qmvp.x,qmvp.y,

@@ -728,3 +728,116 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
     }
     return numSig;
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------------------------
+ * The tail of Search::puMotionEstimation / predInterSearch for one 2Nx2N PU after its per-reference searches (encoder/search.cpp:258-556):
+ * bits and cost of every (list, reference), best reference per list, the bidirectional candidate (average of the two best predictions at
+ * SATD, and the same with both MVs zero), final choice.  No AMVP list (the search predictor is the MVP): checkBestMVP / updateMVP do nothing.
+ * --------------------------------------------------------------------------------------------------------------------------------------- */
+void xo_mvbits_row(int halfRange, float* out)
+{   /* BitCost::CalculateLogs (bitcost.cpp:72-86): s_bitsizes, symmetric; out[halfRange + d] */
+    float log2_2 = (float)(2.0f / log(2.0f));
+    for (int i = 0; i <= halfRange; i++)
+        out[halfRange + i] = out[halfRange - i] = i ? (float)(log((double)(float)(i + 1)) * log2_2 + 1.718f) : 0.718f;
+}
+static uint32_t mv_bitcost(const float* bitsCentre, int mvx, int mvy, int px, int py)
+{   /* bitcost.h:60-70 */
+    return (uint32_t)(bitsCentre[mvx - px] + bitsCentre[mvy - py] + 0.5f);
+}
+uint64_t xo_rd_lambda(int qp) { return (uint64_t)floor(256.0 * xo_lambda(qp)); }          /* RDCost::setLambda, rdcost.h:88-92 */
+static uint32_t rd_getcost(uint64_t lambda, uint32_t bits) { return (uint32_t)((bits * lambda + 128) >> 8); }   /* rdcost.h:164-169 */
+
+/* luma motion compensation of one block (Predict::predInterLumaPixel, predict.cpp:279-300) */
+static void mc_luma(const xo_pixel* fref, intptr_t stride, int w, int h, int qx, int qy, xo_pixel* dst)
+{
+    const xo_pixel* src = fref + (qx >> 2) + (qy >> 2) * stride;
+    const int xf = qx & 3, yf = qy & 3;
+    if (!(xf | yf)) xo_copy_pp(w, h, dst, w, src, stride);
+    else if (!yf) xo_interp_hpp(8, w, h, src, stride, dst, w, xf);
+    else if (!xf) xo_interp_vpp(8, w, h, src, stride, dst, w, yf);
+    else xo_interp_hvpp(8, w, h, src, stride, dst, w, xf, yf);
+}
+int xo_bidir_satd(int w, int h, const xo_pixel* fenc, intptr_t fencStride, const xo_pixel* ref0, intptr_t stride0, int mv0x, int mv0y,
+                  const xo_pixel* ref1, intptr_t stride1, int mv1x, int mv1y)
+{   /* search.cpp:436-446: predInterLumaPixel twice, pixelavg_pp, SATD */
+    xo_pixel p0[64 * 64], p1[64 * 64], avg[64 * 64];
+    mc_luma(ref0, stride0, w, h, mv0x, mv0y, p0); mc_luma(ref1, stride1, w, h, mv1x, mv1y, p1);
+    xo_pixelavg_pp(w, h, avg, w, p0, w, p1, w);
+    return xo_satd(w, h, fenc, fencStride, avg, w);
+}
+
+/* numRef[l] references per list (numRef[1] = 0: P slice).  Per (list, ref) k = l * 4 + r: mv / mvp (quarter-pel), cost (motionEstimate's return value) and
+ * mvcost.  clip[4] = the PU's quarter-pel MV limits (CUData::clipMv: xmin, ymin, xmax, ymax).  fenc / refs[k] point at the PU in the source and co-located in
+ * each reference.  out[12] = { mv0x, mv0y, mv1x, mv1y, mvp0x, mvp0y, mvp1x, mvp1y, ref0, ref1 (-1 = list unused), bits, cost }, mvCostOut[2]. */
+void xo_inter_merge(int w, int h, const int32_t* numRef, const int32_t* mv, const int32_t* mvp, const int32_t* cost, const int32_t* mvcost,
+                    const float* bitsCentre, uint64_t lambda, int bidir, int sourceMaxDim, const int32_t* clip,
+                    const xo_pixel* fenc, intptr_t fencStride, const xo_pixel* const* refs, intptr_t refStride, int32_t* out, uint32_t* mvCostOut)
+{
+    const int isP = numRef[1] == 0;
+    const uint32_t listSelBits[3] = { isP ? 1u : 3u, 3u, 5u };                    /* getBlkBits, SIZE_2Nx2N (search.cpp:4896-4901) */
+    struct { int mvx, mvy, px, py, ref; uint32_t cost, bits, mvCost; } best[2];
+    best[0].cost = best[1].cost = 0xFFFFFFFFu; best[0].ref = best[1].ref = -1;
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < numRef[l]; r++)
+        {
+            const int k = l * 4 + r;
+            uint32_t bits = listSelBits[l] + 1 /* MVP_IDX_BITS */ + (uint32_t)(r + (r < numRef[l] - 1));      /* getTUBits, search.h:252-255 */
+            bits += mv_bitcost(bitsCentre, mv[2 * k], mv[2 * k + 1], mvp[2 * k], mvp[2 * k + 1]);
+            const uint32_t c = (uint32_t)(cost[k] - mvcost[k]) + rd_getcost(lambda, bits);                    /* search.cpp:372-374 */
+            if (c < best[l].cost)
+            {
+                best[l].cost = c; best[l].bits = bits; best[l].mvCost = (uint32_t)mvcost[k]; best[l].ref = r;
+                best[l].mvx = mv[2 * k]; best[l].mvy = mv[2 * k + 1]; best[l].px = mvp[2 * k]; best[l].py = mvp[2 * k + 1];
+            }
+        }
+    uint32_t bidirCost = 0xFFFFFFFFu; int bidirBits = 0;
+    int b0x = 0, b0y = 0, b1x = 0, b1y = 0;
+    if (!isP && bidir && best[0].cost != 0xFFFFFFFFu && best[1].cost != 0xFFFFFFFFu)
+    {   /* search.cpp:420-503 */
+        b0x = best[0].mvx; b0y = best[0].mvy; b1x = best[1].mvx; b1y = best[1].mvy;
+        int satd = xo_bidir_satd(w, h, fenc, fencStride, refs[best[0].ref], refStride, b0x, b0y, refs[4 + best[1].ref], refStride, b1x, b1y);
+        bidirBits = (int)(best[0].bits + best[1].bits + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
+        bidirCost = (uint32_t)satd + rd_getcost(lambda, (uint32_t)bidirBits);
+        int tryZero = (b0x | b0y | b1x | b1y) != 0;
+        if (tryZero)
+        {   /* setSearchRange(cu, mvzero, max(sourceWidth, sourceHeight)) (search.cpp:4969-5021), mvmax.y += 2, << 2; both MVPs inside */
+            int mnx = -(sourceMaxDim << 2), mny = mnx, mxx = sourceMaxDim << 2, mxy = mxx;
+            mnx = mnx < clip[0] ? clip[0] : mnx > clip[2] ? clip[2] : mnx; mxx = mxx < clip[0] ? clip[0] : mxx > clip[2] ? clip[2] : mxx;
+            mny = mny < clip[1] ? clip[1] : mny > clip[3] ? clip[3] : mny; mxy = mxy < clip[1] ? clip[1] : mxy > clip[3] ? clip[3] : mxy;
+            mnx >>= 2; mny >>= 2; mxx >>= 2; mxy >>= 2;
+            if (mxy < mny) mxy = mny;
+            mxy += 2;
+            mnx <<= 2; mny <<= 2; mxx <<= 2; mxy <<= 2;
+            for (int l = 0; l < 2; l++)
+                tryZero &= best[l].px >= mnx && best[l].px <= mxx && best[l].py >= mny && best[l].py <= mxy;
+        }
+        if (tryZero)
+        {
+            satd = xo_bidir_satd(w, h, fenc, fencStride, refs[best[0].ref], refStride, 0, 0, refs[4 + best[1].ref], refStride, 0, 0);
+            const uint32_t bits0 = best[0].bits - mv_bitcost(bitsCentre, best[0].mvx, best[0].mvy, best[0].px, best[0].py) + mv_bitcost(bitsCentre, 0, 0, best[0].px, best[0].py);
+            const uint32_t bits1 = best[1].bits - mv_bitcost(bitsCentre, best[1].mvx, best[1].mvy, best[1].px, best[1].py) + mv_bitcost(bitsCentre, 0, 0, best[1].px, best[1].py);
+            const uint32_t c = (uint32_t)satd + rd_getcost(lambda, bits0) + rd_getcost(lambda, bits1);
+            if (c < bidirCost)
+            {
+                b0x = b0y = b1x = b1y = 0; bidirCost = c;
+                bidirBits = (int)(bits0 + bits1 + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
+            }
+        }
+    }
+    /* search.cpp:504-555 */
+    for (int i = 0; i < 12; i++) out[i] = 0;
+    out[8] = out[9] = -1; mvCostOut[0] = mvCostOut[1] = 0;
+    if (bidirCost < best[0].cost && bidirCost < best[1].cost)
+    {
+        out[0] = b0x; out[1] = b0y; out[2] = b1x; out[3] = b1y;
+        out[4] = best[0].px; out[5] = best[0].py; out[6] = best[1].px; out[7] = best[1].py;
+        out[8] = best[0].ref; out[9] = best[1].ref; out[10] = bidirBits; out[11] = (int32_t)bidirCost;
+        mvCostOut[0] = best[0].mvCost; mvCostOut[1] = best[1].mvCost;
+    }
+    else
+    {
+        const int l = best[0].cost <= best[1].cost ? 0 : 1;
+        out[2 * l] = best[l].mvx; out[2 * l + 1] = best[l].mvy; out[4 + 2 * l] = best[l].px; out[5 + 2 * l] = best[l].py;
+        out[8 + l] = best[l].ref; out[10] = (int32_t)best[l].bits; out[11] = (int32_t)best[l].cost; mvCostOut[l] = best[l].mvCost;
+    }
+}

@@ -50,3 +50,18 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
 #ifdef __cplusplus
 }
 #endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* the per-PU choice among references and the bidirectional candidate (tail of Search::puMotionEstimation, search.cpp:258-556; see x265_oracle_me.c) */
+void xo_mvbits_row(int halfRange, float* out);
+uint64_t xo_rd_lambda(int qp);
+int xo_bidir_satd(int w, int h, const xo_pixel* fenc, intptr_t fencStride, const xo_pixel* ref0, intptr_t stride0, int mv0x, int mv0y,
+                  const xo_pixel* ref1, intptr_t stride1, int mv1x, int mv1y);
+void xo_inter_merge(int w, int h, const int32_t* numRef, const int32_t* mv, const int32_t* mvp, const int32_t* cost, const int32_t* mvcost,
+                    const float* bitsCentre, uint64_t lambda, int bidir, int sourceMaxDim, const int32_t* clip,
+                    const xo_pixel* fenc, intptr_t fencStride, const xo_pixel* const* refs, intptr_t refStride, int32_t* out, uint32_t* mvCostOut);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,202 @@
+// kern_merge.hip -- the per-PU choice among references and the bidirectional candidate: the tail of Search::puMotionEstimation / predInterSearch
+// (reference encoder/search.cpp:258-556) after the per-reference searches of x265hip_me_batch, for every 2Nx2N PU of a batch in one launch:
+//   bits and cost of each (list, reference):  listSelBits + MVP_IDX_BITS + getTUBits(ref) + BitCost::bitcost(mv - mvp); (satd - mvcost) + RDCost::getCost(bits)
+//   best reference per list (strict `<` in reference order),
+//   bidirectional candidate (B slices): predInterLumaPixel of both bests -> pixelavg_pp -> SATD (search.cpp:436-446), and the same with both MVs zero
+//   (:449-502), final choice (:504-555) -> a record like MEData (encoder/threadedme.h:122-130).
+// One wavefront per PU: the decision arithmetic is uniform (every lane computes it), the two averaged predictions are built from the references'
+// phase planes (a prediction at any quarter-pel MV is a block of plane 4 * yFrac + xFrac) into LDS and compared with the cached source PU at SATD.
+#include "xh_mc.h"
+#include "../../include/x265hip_frame.h"
+#include <cmath>
+using namespace xh;
+
+namespace {
+
+struct MergeArgs
+{
+    int w, h, n, isP, bidir, sourceMaxDim, numRef[2];
+    const pixel* cur; intptr_t cs; intptr_t rs;
+    const x265hip_me_task* tasks;
+    const x265hip_me_result* res[8]; const x265hip_me_result* mvpSrc[8];      // [list * 4 + ref]
+    const pixel* planes[8]; int64_t planeElems;                                // 16-slot phase-plane buffer of each reference
+    const float* bitsCentre; int bitsHalf; unsigned long long lambda;
+    x265hip_inter_choice* out;
+};
+
+__device__ __forceinline__ uint32_t bitcost(const MergeArgs& a, int mvx, int mvy, int px, int py)
+{
+    const int dx = min(max(mvx - px, -a.bitsHalf), a.bitsHalf), dy = min(max(mvy - py, -a.bitsHalf), a.bitsHalf);
+    return (uint32_t)(a.bitsCentre[dx] + a.bitsCentre[dy] + 0.5f);               // bitcost.h:66-70 (float sum, truncation)
+}
+__device__ __forceinline__ uint32_t getcost(const MergeArgs& a, uint32_t bits) { return (uint32_t)(((unsigned long long)bits * a.lambda + 128) >> 8); }   // rdcost.h:164-169
+
+// SATD of the cached source PU (LDS, stride w) against the average of two predictions (planes of reference a / b at quarter-pel MVs)
+__device__ int bidir_satd(const MergeArgs& a, const lpixel* fenc, lpixel* avg, int refOff, const pixel* pa, int ax, int ay, const pixel* pb, int bx, int by, int lane)
+{
+    const int w = a.w, h = a.h, qpr = w >> 2, nquads = qpr * h;
+    const pixel* s0 = pa + (int64_t)((ay & 3) * 4 + (ax & 3)) * a.planeElems + refOff + (intptr_t)(ay >> 2) * a.rs + (ax >> 2);
+    const pixel* s1 = pb + (int64_t)((by & 3) * 4 + (bx & 3)) * a.planeElems + refOff + (intptr_t)(by >> 2) * a.rs + (bx >> 2);
+    for (int q = lane; q < nquads; q += 64)
+    {
+        const int y = q / qpr, x4 = (q - y * qpr) * 4;
+        int u[4], v[4], o[4];
+        load4u(s0 + (intptr_t)y * a.rs + x4, u); load4u(s1 + (intptr_t)y * a.rs + x4, v);
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = (u[e] + v[e] + 1) >> 1;             // pixelavg_pp (pixel.cpp:375-388)
+        store4(avg + y * w + x4, o);
+    }
+    wave_sync();
+    const bool use4 = w == 4 || w == 12;
+    const int uw = use4 ? 4 : 8, ux = w / uw, nunits = ux * (h >> 2);
+    int s = 0;
+    LView pv; pv.p = avg; pv.s = w;
+    for (int u = lane; u < nunits; u += 64)
+    {
+        const int uy = u / ux, x0 = (u - uy * ux) * uw, y0 = uy * 4;
+        const lpixel* f = fenc + y0 * w + x0;
+        int d[16], t = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+        {
+            if (half && use4) break;
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++)
+            {
+                int p[4], r[4]; load4(f + half * 4 + yy * w, p); load4u(pv.at(x0 + half * 4, y0 + yy), r);
+                const int a0 = p[0] - r[0], a1 = p[1] - r[1], a2 = p[2] - r[2], a3 = p[3] - r[3];
+                const int t0 = a0 + a1, t1 = a0 - a1, t2 = a2 + a3, t3 = a2 - a3;
+                d[4 * yy] = t0 + t2; d[4 * yy + 2] = t0 - t2; d[4 * yy + 1] = t1 + t3; d[4 * yy + 3] = t1 - t3;
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+            {
+                const int t0 = d[x] + d[4 + x], t1 = d[x] - d[4 + x], t2 = d[8 + x] + d[12 + x], t3 = d[8 + x] - d[12 + x];
+                t += abs(t0 + t2) + abs(t0 - t2) + abs(t1 + t3) + abs(t1 - t3);
+            }
+        }
+        s += t >> 1;                                                            // satd4: per 4x4; satd8: per 8x4 (pixel.cpp:262-289)
+    }
+    wave_sync();
+    return wsum_u(s);
+}
+
+__global__ __launch_bounds__(256) void inter_merge_kernel(MergeArgs a)
+{
+    __shared__ __attribute__((aligned(16))) pixel s_fenc[4][64 * 64];
+    __shared__ __attribute__((aligned(16))) pixel s_avg[4][64 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= a.n) return;
+    const x265hip_me_task* tp = a.tasks + item;
+    const uint32_t listSelBits[3] = { a.isP ? 1u : 3u, 3u, 5u };                // getBlkBits, SIZE_2Nx2N (search.cpp:4896-4901)
+    struct Best { int mvx, mvy, px, py, ref; uint32_t cost, bits, mvCost; } best[2];
+    best[0].cost = best[1].cost = 0xFFFFFFFFu; best[0].ref = best[1].ref = -1;
+#pragma unroll
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < a.numRef[l]; r++)
+        {
+            const int k = l * 4 + r;
+            const x265hip_me_result m = a.res[k][item];
+            int px = tp->qmvp[0], py = tp->qmvp[1];
+            if (tp->mvpFrom >= 0 && a.mvpSrc[k]) { px = a.mvpSrc[k][tp->mvpFrom].mv[0]; py = a.mvpSrc[k][tp->mvpFrom].mv[1]; }
+            uint32_t bits = listSelBits[l] + 1u + (uint32_t)(r + (r < a.numRef[l] - 1));      // MVP_IDX_BITS, getTUBits (search.h:252-255)
+            bits += bitcost(a, m.mv[0], m.mv[1], px, py);
+            const uint32_t c = (uint32_t)(m.cost - m.mvcost) + getcost(a, bits);               // search.cpp:372-374
+            if (c < best[l].cost) { best[l].cost = c; best[l].bits = bits; best[l].mvCost = (uint32_t)m.mvcost; best[l].ref = r; best[l].mvx = m.mv[0]; best[l].mvy = m.mv[1]; best[l].px = px; best[l].py = py; }
+        }
+    uint32_t bidirCost = 0xFFFFFFFFu; int bidirBits = 0, b0x = 0, b0y = 0, b1x = 0, b1y = 0;
+    if (!a.isP && a.bidir && best[0].cost != 0xFFFFFFFFu && best[1].cost != 0xFFFFFFFFu)
+    {   // search.cpp:420-503
+        lpixel* fenc = (lpixel*)s_fenc[wave]; lpixel* avg = (lpixel*)s_avg[wave];
+        const int qpr = a.w >> 2, nquads = qpr * a.h;
+        for (int q = lane; q < nquads; q += 64)
+        {
+            const int y = q / qpr, x4 = (q - y * qpr) * 4;
+            int v[4]; load4u(a.cur + tp->curOff + (intptr_t)y * a.cs + x4, v); store4(fenc + y * a.w + x4, v);
+        }
+        wave_sync();
+        b0x = best[0].mvx; b0y = best[0].mvy; b1x = best[1].mvx; b1y = best[1].mvy;
+        const pixel* pa = a.planes[best[0].ref]; const pixel* pb = a.planes[4 + best[1].ref];
+        int satd = bidir_satd(a, fenc, avg, tp->refOff, pa, b0x, b0y, pb, b1x, b1y, lane);
+        bidirBits = (int)(best[0].bits + best[1].bits + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
+        bidirCost = (uint32_t)satd + getcost(a, (uint32_t)bidirBits);
+        bool tryZero = (b0x | b0y | b1x | b1y) != 0;
+        if (tryZero)
+        {   // setSearchRange(cu, mvzero, max(sourceWidth, sourceHeight)) (search.cpp:4969-5021), mvmax.y += 2, << 2: both MVPs inside
+            const int cx0 = tp->mvmin[0], cy0 = tp->mvmin[1], cx1 = tp->mvmax[0], cy1 = tp->mvmax[1], d = a.sourceMaxDim << 2;
+            int mnx = min(max(-d, cx0), cx1) >> 2, mny = min(max(-d, cy0), cy1) >> 2, mxx = min(max(d, cx0), cx1) >> 2, mxy = min(max(d, cy0), cy1) >> 2;
+            mxy = max(mxy, mny) + 2;
+            mnx <<= 2; mny <<= 2; mxx <<= 2; mxy <<= 2;
+#pragma unroll
+            for (int l = 0; l < 2; l++) tryZero &= best[l].px >= mnx && best[l].px <= mxx && best[l].py >= mny && best[l].py <= mxy;
+        }
+        if (tryZero)
+        {
+            satd = bidir_satd(a, fenc, avg, tp->refOff, pa, 0, 0, pb, 0, 0, lane);
+            const uint32_t bits0 = best[0].bits - bitcost(a, best[0].mvx, best[0].mvy, best[0].px, best[0].py) + bitcost(a, 0, 0, best[0].px, best[0].py);
+            const uint32_t bits1 = best[1].bits - bitcost(a, best[1].mvx, best[1].mvy, best[1].px, best[1].py) + bitcost(a, 0, 0, best[1].px, best[1].py);
+            const uint32_t c = (uint32_t)satd + getcost(a, bits0) + getcost(a, bits1);
+            if (c < bidirCost) { b0x = b0y = b1x = b1y = 0; bidirCost = c; bidirBits = (int)(bits0 + bits1 + listSelBits[2] - (listSelBits[0] + listSelBits[1])); }
+        }
+    }
+    if (lane == 0)
+    {   // search.cpp:504-555
+        x265hip_inter_choice o;
+        o.mv[0][0] = o.mv[0][1] = o.mv[1][0] = o.mv[1][1] = 0; o.mvp[0][0] = o.mvp[0][1] = o.mvp[1][0] = o.mvp[1][1] = 0;
+        o.mvCost[0] = o.mvCost[1] = 0; o.ref[0] = o.ref[1] = -1; o.reserved = 0;
+        if (bidirCost < best[0].cost && bidirCost < best[1].cost)
+        {
+            o.mv[0][0] = (int16_t)b0x; o.mv[0][1] = (int16_t)b0y; o.mv[1][0] = (int16_t)b1x; o.mv[1][1] = (int16_t)b1y;
+#pragma unroll
+            for (int l = 0; l < 2; l++) { o.mvp[l][0] = (int16_t)best[l].px; o.mvp[l][1] = (int16_t)best[l].py; o.mvCost[l] = best[l].mvCost; o.ref[l] = (int8_t)best[l].ref; }
+            o.bits = bidirBits; o.cost = bidirCost;
+        }
+        else
+        {
+            const int l = best[0].cost <= best[1].cost ? 0 : 1;
+            o.mv[l][0] = (int16_t)best[l].mvx; o.mv[l][1] = (int16_t)best[l].mvy; o.mvp[l][0] = (int16_t)best[l].px; o.mvp[l][1] = (int16_t)best[l].py;
+            o.mvCost[l] = best[l].mvCost; o.ref[l] = (int8_t)best[l].ref; o.bits = (int32_t)best[l].bits; o.cost = best[l].cost;
+        }
+        a.out[item] = o;
+    }
+}
+
+} // namespace
+
+extern "C" int x265hip_mvbits_row(int halfRange, float* out)
+{   // BitCost::CalculateLogs (bitcost.cpp:72-86): s_bitsizes, out[halfRange + d]; pure host code
+    if (halfRange < 0 || !out) { set_error("mvbits_row: bad arguments"); return X265HIP_EARG; }
+    const float log2_2 = (float)(2.0f / std::log((double)2.0f));
+    for (int i = 0; i <= halfRange; i++)
+        out[halfRange + i] = out[halfRange - i] = i ? (float)(std::log((double)(float)(i + 1)) * log2_2 + 1.718f) : 0.718f;
+    return X265HIP_OK;
+}
+extern "C" uint64_t x265hip_rd_lambda(int qp)
+{   // RDCost::setLambda (rdcost.h:88-92) on x265_lambda_tab[qp] (constants.cpp:28-116)
+    const double lambda = std::floor(std::pow(2.0, (double)qp / 6.0 - 2.0) * (double)(1 << (X265_DEPTH - 8)) * 10000.0 + 0.5) / 10000.0;
+    return (uint64_t)std::floor(256.0 * lambda);
+}
+
+extern "C" int x265hip_inter_merge_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, intptr_t refStride,
+                                         const x265hip_me_task* tasks, int n, const x265hip_merge_params* p, x265hip_inter_choice* out)
+{
+    if (n <= 0) return X265HIP_OK;
+    if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !tasks || !p || !out || !curPlane || !p->bitsRow || p->bitsHalfRange < 1)
+    { set_error("inter_merge_batch: bad arguments"); return X265HIP_EARG; }
+    if (p->numRef[0] < 1 || p->numRef[0] > 4 || p->numRef[1] < 0 || p->numRef[1] > 4) { set_error("inter_merge_batch: 1..4 references in list 0, 0..4 in list 1"); return X265HIP_EARG; }
+    MergeArgs a{};
+    a.w = w; a.h = h; a.n = n; a.isP = p->numRef[1] == 0; a.bidir = p->bidir; a.sourceMaxDim = p->sourceMaxDim; a.numRef[0] = p->numRef[0]; a.numRef[1] = p->numRef[1];
+    a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.tasks = tasks; a.planeElems = p->planeElems;
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < p->numRef[l]; r++)
+        {
+            if (!p->results[l][r]) { set_error("inter_merge_batch: results of list %d reference %d missing", l, r); return X265HIP_EARG; }
+            if (p->bidir && p->numRef[1] && !p->subpelPlanes[l][r]) { set_error("inter_merge_batch: the bidirectional candidate needs the phase planes of every reference"); return X265HIP_EARG; }
+            a.res[l * 4 + r] = p->results[l][r]; a.mvpSrc[l * 4 + r] = p->mvpSource[l][r]; a.planes[l * 4 + r] = (const pixel*)p->subpelPlanes[l][r];
+        }
+    a.bitsCentre = p->bitsRow + p->bitsHalfRange; a.bitsHalf = p->bitsHalfRange; a.lambda = p->lambda; a.out = out;
+    hipLaunchKernelGGL(inter_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}

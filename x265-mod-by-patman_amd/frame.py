@@ -13,6 +13,8 @@ ME_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mvmin", "<i2", 2), (
 ME_WINDOW = 1
 ME_RESULT = np.dtype([("mv", "<i2", 2), ("cost", "<i4"), ("mvcost", "<i4"), ("reserved", "<i4")])
 TU_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv", "<i2", 2), ("reconOff", "<i4"), ("mvFrom", "<i4")])
+INTER_CHOICE = np.dtype([("mv", "<i2", (2, 2)), ("mvp", "<i2", (2, 2)), ("mvCost", "<u4", 2), ("ref", "i1", 2), ("reserved", "<i2"), ("bits", "<i4"), ("cost", "<u4")])
+assert INTER_CHOICE.itemsize == 36
 LA_TASK = np.dtype([("b", "<i4"), ("p0", "<i4"), ("p1", "<i4"), ("doSearch", "<i4", 2), ("mvSlot", "<i4", 2), ("outSlot", "<i4"), ("weighted0", "<i4")])
 assert ME_TASK.itemsize == 76 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 20 and LA_TASK.itemsize == 36
 
@@ -20,6 +22,27 @@ assert ME_TASK.itemsize == 76 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize 
 class MeChroma(C.Structure):
     _fields_ = [("curCb", C.c_void_p), ("curCr", C.c_void_p), ("curStrideC", C.c_ssize_t), ("refCb", C.c_void_p), ("refCr", C.c_void_p), ("refStrideC", C.c_ssize_t),
                 ("curOffC", C.c_void_p), ("refOffC", C.c_void_p)]
+
+
+class MergeParams(C.Structure):
+    _fields_ = [("numRef", C.c_int * 2), ("results", (C.c_void_p * 4) * 2), ("mvpSource", (C.c_void_p * 4) * 2), ("subpelPlanes", (C.c_void_p * 4) * 2), ("planeElems", C.c_int64),
+                ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int), ("lambda_", C.c_uint64), ("bidir", C.c_int), ("sourceMaxDim", C.c_int)]
+
+
+def mvbits_row(depth, half):
+    """Host-side MVD bit-size row (x265hip_mvbits_row = BitCost::CalculateLogs); needs no GPU."""
+    from .binding import HipLib
+    lib = HipLib(depth, fill_table=False)
+    out = np.zeros(2 * half + 1, np.float32)
+    lib.check(lib.lib.x265hip_mvbits_row(half, C.c_void_p(out.ctypes.data)))
+    return out
+
+
+def rd_lambda(depth, qp):
+    from .binding import HipLib
+    lib = HipLib(depth, fill_table=False).lib
+    lib.x265hip_rd_lambda.restype = C.c_uint64
+    return int(lib.x265hip_rd_lambda(qp))
 
 
 class TqParams(C.Structure):
@@ -109,6 +132,18 @@ class FrameApi:
         ch = MeChroma(_dp(cur_cb), _dp(cur_cr), cstride_c, _dp(ref_cb), _dp(ref_cr), rstride_c, _dp(cur_off_c), _dp(ref_off_c))
         self.h.check(self.lib.x265hip_me_batch_chroma(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride), _dp(tasks), n,
                                                       _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source), _dp(planes), C.c_int64(plane_elems), C.byref(ch)))
+
+    def inter_merge_batch(self, w, h, cur, cstride, rstride, tasks, n, results, mvp_sources, planes, plane_elems, bits_row, bits_half, lam, bidir, source_max_dim, out):
+        """x265hip_inter_merge_batch; results / mvp_sources / planes: [list][ref] nested lists of tensors (or None)."""
+        p = MergeParams()
+        for l in range(2):
+            p.numRef[l] = len(results[l])
+            for r in range(len(results[l])):
+                p.results[l][r] = results[l][r].data_ptr()
+                p.mvpSource[l][r] = mvp_sources[l][r].data_ptr() if mvp_sources and mvp_sources[l][r] is not None else None
+                p.subpelPlanes[l][r] = planes[l][r].data_ptr() if planes and planes[l][r] is not None else None
+        p.planeElems = plane_elems; p.bitsRow = bits_row.data_ptr(); p.bitsHalfRange = bits_half; p.lambda_ = lam; p.bidir = int(bidir); p.sourceMaxDim = source_max_dim
+        self.h.check(self.lib.x265hip_inter_merge_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), C.c_ssize_t(rstride), _dp(tasks), n, C.byref(p), _dp(out)))
 
     def lookahead_qp(self):
         return int(self.lib.x265hip_lookahead_qp())
