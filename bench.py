@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--workload", default="2160p10_slow", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=8, help="frame pairs per step per GPU")
     ap.add_argument("--qp", type=int, default=28)
+    ap.add_argument("--refs", type=int, default=1, help="list-0 reference pictures searched per source picture (preset medium: 3, slow: 4 -- param.cpp:567-587); each is searched down the "
+                    "pyramid, x265hip_inter_merge_batch chooses per PU, the TQ stage compensates from the chosen reference.  value stays Mpixels/s of SOURCE pixels")
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
@@ -438,7 +440,7 @@ def cpu_baseline(pipe, depth, n_ctus):
                     ns = np.frombuffer(out[1], np.uint32)
                     w = (np.arange(n_tu * n_tu, dtype=np.int64) + 1)
                     cs = int((coeff[idx].astype(np.int64) * w).sum() & 0xFFFFFFFF)
-                    if not (np.array_equal(ns, numsig[idx].astype(np.uint32)) and cs == int(np.frombuffer(out[2], np.uint32)[0])):
+                    if pipe.refs == 1 and not (np.array_equal(ns, numsig[idx].astype(np.uint32)) and cs == int(np.frombuffer(out[2], np.uint32)[0])):
                         mismatches.append(("tq", n_tu, 1))
         def run_all():
             threads = [threading.Thread(target=worker, args=(i,)) for i in range(cores)]
@@ -482,6 +484,8 @@ def cpu_baseline(pipe, depth, n_ctus):
         wall = busy = time.time() - t0
         total_cpu, reps = busy, 1
         parity = "not cross-checked"
+    if pipe.refs > 1:
+        busy *= pipe.refs             # one of the references was searched on the CPU (its chain is cross-checked); the others cost the same
     return {"value": round(sample_px / busy / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": kind,
             "sample": "%d CTU64 (%d luma px) of the same batch: ME pyramid (85 PUs/CTU) + %dx%d DCT+quant, %s; %d repetition(s), %.1f CPU-seconds in total, busiest core %.3f s per repetition; "
                       "results vs GPU: %s" % (n_ctus, sample_px, n_tu, n_tu,
@@ -492,10 +496,16 @@ def cpu_baseline(pipe, depth, n_ctus):
 MARGIN = 96                  # PicYuv-style padding of the synthetic planes (FramePipeline's default)
 
 
-def _make_pair(W, H, depth, seed):
+def _make_pair(W, H, depth, seed, refs=1):
+    """(source, reference 0 [, further references]): reference r > 0 is reference 0 displaced a little further plus its own noise -- an older picture of the same scene"""
     from x265hip_pkg.synth import frame_pair
     cur, ref, _, _ = frame_pair(W, H, depth, seed=seed, margin=MARGIN, max_shift=24)
-    return cur, ref
+    out = [cur, ref]
+    rng = np.random.default_rng(77000 + seed)
+    for r in range(1, refs):
+        o = np.roll(ref, (2 * r, -3 * r), (0, 1)).astype(np.float32) + rng.normal(0, (1.0 + r) * (1 << (depth - 8)), ref.shape).astype(np.float32)
+        out.append(np.clip(o, 0, (1 << depth) - 1).astype(ref.dtype))
+    return tuple(out)
 
 
 def asm_probe():
@@ -583,7 +593,7 @@ def main():
     seeds = rank_frame_seeds(int(os.environ.get("RANK", "0")), args.frames)          # independent frames per rank, no overlap
     import multiprocessing
     with multiprocessing.get_context("fork").Pool(min(len(seeds), max(1, (os.cpu_count() or 1) // max(1, args.gpus)))) as pool:
-        pairs = pool.starmap(_make_pair, [(W, H, depth, sd) for sd in seeds])
+        pairs = pool.starmap(_make_pair, [(W, H, depth, sd, args.refs) for sd in seeds])
     import torch
     import torch.distributed as dist
     import x265hip  # noqa: F401
@@ -600,7 +610,7 @@ def main():
     half = 1 << 15
     cost_row = mvcost_row(depth, args.qp, half)
     pipe = FramePipeline(depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"],
-                         tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api, use_planes=not args.no_planes)
+                         tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api, use_planes=not args.no_planes, refs=args.refs)
     assert pipe.margin == MARGIN
     pipe.upload(pairs)                      # inputs are resident in HBM before the timed region
 
@@ -642,7 +652,7 @@ def main():
         traffic_all, traffic_src = profile_figure(args.workload, "traffic")
         valu_all, valu_src = profile_figure(args.workload, "valu")
         valu_peak = N_SIMD * GPU_CLOCK_HZ / VALU_CYCLES
-        step_bytes = px * (2 * bpp + 2) + sum(len(pipe.tasks_host[lv]) for lv in LEVELS) * 16       # SURVEY 8(d) fused S1-S3: source + reference once, MVs + coefficients out
+        step_bytes = px * ((1 + args.refs) * bpp + 2) + sum(len(pipe.tasks_host[lv]) for lv in LEVELS) * 16       # SURVEY 8(d) fused S1-S3: source + reference(s) once, MVs + coefficients out
         step_gbs = step_bytes / (dt / args.steps) / 1e9
         value = whole_job_mpixels_per_s(world, px, args.steps, dt)
         out = {
@@ -652,7 +662,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames,
-                       "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": 1, "qp": args.qp,
+                       "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": args.refs, "qp": args.qp,
                        "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": ("TQ on a side stream beside the me16/me8 launches (it needs the me32 MVs only), joined per step" if pipe.overlap_tq else "kernel by kernel") + "; per-kernel events on every 4th step", "sharding": "independent frames per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "strictly the longest average launch of the step", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(dom), "traffic_source": traffic_src if traffic_all.get(dom) is not None else None,

@@ -143,6 +143,7 @@ typedef struct x265hip_tu_task {
     int32_t mvFrom;              /* >= 0: mv = mvSource[mvFrom].mv (device-side hand-over from x265hip_me_batch) */
 } x265hip_tu_task;               /* 20 bytes */
 
+struct x265hip_inter_choice;
 typedef struct x265hip_tq_params {
     int qp;                      /* 0..51: per = qp/6, rem = qp%6 (quant.cpp:465-469,555-568)         */
     int add;                     /* quant rounding numerator: 171 (intra) or 85 (inter), << (qBits-9) */
@@ -150,6 +151,9 @@ typedef struct x265hip_tq_params {
     int32_t* deltaU;             /* optional: n * N*N int32 (quant_c's deltaU) or NULL                */
     const void* subpelPlanes;    /* optional: the 16-slot buffer x265hip_subpel_planes made from refPlane -> motion     */
     int64_t planeElems;          /*           compensation is a copy out of slot 4*yFrac + xFrac instead of a filter    */
+    const struct x265hip_inter_choice* choice;   /* optional (several references): the TU's MV and reference come from choice[task.mvFrom] (x265hip_inter_merge_batch): */
+    int choiceList, choiceRef;   /*           only TUs whose PU chose reference choiceRef of list choiceList are processed by this call (one call per reference
+                                              plane; the outputs of the other TUs are left alone); uni-directional choices only */
 } x265hip_tq_params;
 
 int x265hip_tq_batch(void* stream, int log2TrSize,

@@ -42,3 +42,47 @@ def check_sample(pipe, oracle, rng, per_level=40, n_tu=40):
             assert np.array_equal(got, e_rec) and int(sse[i]) == e_sse, "TU %d: reconstruction differs from the oracle" % i
         checked += 1
     return checked
+
+
+def check_sample_refs(pipe, oracle, rng, per_level=10, n_tu=10):
+    """The several-references form of check_sample: per sampled PU the search in every reference (its own parent chain), the choice among them
+    (xo_inter_merge) and, per sampled TU, the coefficients compensated from the chosen reference -- all against the oracle."""
+    R = pipe.refs
+    res = {lv: [pipe.results(lv, r) for r in range(R)] for lv in LEVELS}
+    ch = {lv: pipe.choices(lv) for lv in LEVELS}
+    checked = 0
+    for lv in LEVELS:
+        t = pipe.tasks_host[lv]
+        for i in rng.choice(len(t), size=min(per_level, len(t)), replace=False):
+            tk = t[i]
+            mv = np.zeros((8, 2), np.int32); mvp = np.zeros((8, 2), np.int32); cost = np.zeros(8, np.int32); mvc = np.zeros(8, np.int32)
+            for r in range(R):
+                qmvp = (0, 0) if tk["mvpFrom"] < 0 else tuple(int(v) for v in res[2 * lv][r][tk["mvpFrom"]]["mv"])
+                d = pipe.merange << 2
+                lx0, ly0, lx1, ly1 = int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])
+                b = [min(lx1, max(lx0, qmvp[0] - d)) >> 2, min(ly1, max(ly0, qmvp[1] - d)) >> 2, min(lx1, max(lx0, qmvp[0] + d)) >> 2, min(ly1, max(ly0, qmvp[1] + d)) >> 2]
+                b[3] = max(b[3], b[1])
+                exp = oracle.me(lv, lv, pipe.cur_host, pipe.stride, int(tk["curOff"]), pipe.refs_host[r], pipe.stride, int(tk["refOff"]), b, qmvp, [],
+                                pipe.merange, pipe.method, pipe.subme, pipe.cost_row_host)
+                g = res[lv][r][i]
+                assert (int(g["mv"][0]), int(g["mv"][1]), int(g["cost"])) == exp, "level %d task %d reference %d: hip %s oracle %s" % (lv, i, r, g, exp)
+                mv[r] = g["mv"]; mvp[r] = qmvp; cost[r] = g["cost"]; mvc[r] = g["mvcost"]
+            o, mco = oracle.inter_merge(lv, lv, (R, 0), mv, mvp, cost, mvc, pipe.bits_row_host, pipe.rd_lambda, False, max(pipe.W, pipe.H),
+                                        list(tk["mvmin"]) + list(tk["mvmax"]), pipe.cur_host, pipe.stride, int(tk["curOff"]), pipe.refs_host + [None] * (8 - R), pipe.stride, int(tk["refOff"]))
+            g = ch[lv][i]
+            mine = [int(g["mv"][0][0]), int(g["mv"][0][1]), int(g["mv"][1][0]), int(g["mv"][1][1]), int(g["mvp"][0][0]), int(g["mvp"][0][1]), int(g["mvp"][1][0]), int(g["mvp"][1][1]),
+                    int(g["ref"][0]), int(g["ref"][1]), int(g["bits"]), int(g["cost"])]
+            assert mine == [int(v) for v in o], "level %d task %d: choice hip %s oracle %s" % (lv, i, mine, list(o))
+            checked += 1
+    n = 1 << pipe.tu_log2
+    coeff = pipe.d_coeff.cpu().numpy().reshape(-1, n * n)
+    numsig = pipe.d_numsig.cpu().numpy()
+    for i in rng.choice(len(pipe.tu_host), size=min(n_tu, len(pipe.tu_host)), replace=False):
+        tk = pipe.tu_host[i]
+        c = ch[pipe.mv_level][tk["mvFrom"]]
+        r = int(c["ref"][0])
+        e_ns, e_coeff, _, _, _ = oracle.tq_tu(pipe.tu_log2, pipe.cur_host, pipe.stride, int(tk["curOff"]), pipe.refs_host[r], pipe.stride, int(tk["refOff"]),
+                                              (int(c["mv"][0][0]), int(c["mv"][0][1])), pipe.qp, 85)
+        assert int(numsig[i]) == e_ns and np.array_equal(coeff[i], e_coeff), "TU %d (reference %d): coefficients differ from the oracle" % (i, r)
+        checked += 1
+    return checked

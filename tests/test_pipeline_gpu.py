@@ -178,3 +178,31 @@ def test_reconstruction_becomes_the_next_reference_on_device(depth):
         buf = np.zeros(32 * 32, got.dtype)
         e = ora.interp(kind, 8, 32, 32, got, pipe.stride, y * pipe.stride + x, buf, 32, xf if kind != "vpp" else yf, yf).reshape(32, 32)
         assert np.array_equal(pl[f, y:y + 32, x:x + 32], e)
+
+
+@pytest.mark.parametrize("depth,method,subme,refs", [(8, 1, 2, 3), (10, 3, 3, 4), (8, 3, 3, 2)])
+def test_several_references_match_oracle(depth, method, subme, refs):
+    """preset medium searches 3 references, slow 4 (param.cpp:567-587): every reference its own predictor chain down the pyramid, the choice per PU by the
+    reference's bit / cost rule (x265hip_inter_merge_batch), every TU compensated from the reference its PU chose."""
+    from pipeline_check import check_sample_refs
+    row = mvcost_row(depth, 28, 1 << 15)
+    W, H, F = 256, 128, 2
+    pipe = FramePipeline(depth, W, H, F, qp=28, merange=24, method=method, subme=subme, tu_log2=4, cost_row=row, refs=refs)
+    rng = np.random.default_rng(depth + refs)
+    pm = (1 << depth) - 1
+    pairs = []
+    for s in range(F):
+        cur, ref, _, _ = frame_pair(W, H, depth, 60 + s, margin=pipe.margin, max_shift=10, noise=1.0)
+        others = []
+        for r in range(1, refs):                         # further references: the first one displaced again + noise that differs from block to block, so the best reference varies
+            o = np.roll(ref, (2 * r, -3 * r), (0, 1)).astype(np.float64)
+            sig = np.kron(rng.uniform(0.5, 6.0, (o.shape[0] // 32 + 1, o.shape[1] // 32 + 1)), np.ones((32, 32)))[:o.shape[0], :o.shape[1]]
+            others.append(np.clip(o + rng.normal(0, 1, o.shape) * sig * (1 << (depth - 8)), 0, pm).astype(ref.dtype))
+        base_sig = np.kron(rng.uniform(0.5, 6.0, (ref.shape[0] // 32 + 1, ref.shape[1] // 32 + 1)), np.ones((32, 32)))[:ref.shape[0], :ref.shape[1]]
+        ref0 = np.clip(ref.astype(np.float64) + rng.normal(0, 1, ref.shape) * base_sig * (1 << (depth - 8)), 0, pm).astype(ref.dtype)
+        pairs.append((cur, ref0) + tuple(others))
+    pipe.upload(pairs)
+    pipe.step(); pipe.torch.cuda.synchronize()
+    assert check_sample_refs(pipe, Oracle(depth), np.random.default_rng(1), per_level=10, n_tu=16) >= 50
+    chosen = {int(r) for lv in LEVELS for r in pipe.choices(lv)["ref"][:, 0]}
+    assert len(chosen) >= 2, "the clip should make more than one reference win: %s" % chosen

@@ -81,6 +81,37 @@ __device__ int bidir_satd(const MergeArgs& a, const lpixel* fenc, lpixel* avg, i
     return wsum_u(s);
 }
 
+// P slices / no bidirectional candidate: the choice is arithmetic on the search results only -- one THREAD per PU
+__global__ __launch_bounds__(256) void inter_merge_uni_kernel(MergeArgs a)
+{
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= a.n) return;
+    const x265hip_me_task* tp = a.tasks + item;
+    const uint32_t listSelBits[2] = { a.isP ? 1u : 3u, 3u };
+    const int qx = tp->qmvp[0], qy = tp->qmvp[1], from = tp->mvpFrom;
+    uint32_t bcost[2] = { 0xFFFFFFFFu, 0xFFFFFFFFu }, bbits[2] = { 0, 0 }, bmvc[2] = { 0, 0 };
+    int bmvx[2] = { 0, 0 }, bmvy[2] = { 0, 0 }, bpx[2] = { 0, 0 }, bpy[2] = { 0, 0 }, bref[2] = { -1, -1 };
+#pragma unroll
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < a.numRef[l]; r++)
+        {
+            const int k = l * 4 + r;
+            const x265hip_me_result m = a.res[k][item];
+            int px = qx, py = qy;
+            if (from >= 0 && a.mvpSrc[k]) { px = a.mvpSrc[k][from].mv[0]; py = a.mvpSrc[k][from].mv[1]; }
+            const uint32_t bits = listSelBits[l] + 1u + (uint32_t)(r + (r < a.numRef[l] - 1)) + bitcost(a, m.mv[0], m.mv[1], px, py);
+            const uint32_t c = (uint32_t)(m.cost - m.mvcost) + getcost(a, bits);
+            if (c < bcost[l]) { bcost[l] = c; bbits[l] = bits; bmvc[l] = (uint32_t)m.mvcost; bref[l] = r; bmvx[l] = m.mv[0]; bmvy[l] = m.mv[1]; bpx[l] = px; bpy[l] = py; }
+        }
+    const int l = bcost[0] <= bcost[1] ? 0 : 1;                                  // search.cpp:530-555
+    x265hip_inter_choice o;
+    o.mv[0][0] = o.mv[0][1] = o.mv[1][0] = o.mv[1][1] = 0; o.mvp[0][0] = o.mvp[0][1] = o.mvp[1][0] = o.mvp[1][1] = 0;
+    o.mvCost[0] = o.mvCost[1] = 0; o.ref[0] = o.ref[1] = -1; o.reserved = 0;
+    o.mv[l][0] = (int16_t)bmvx[l]; o.mv[l][1] = (int16_t)bmvy[l]; o.mvp[l][0] = (int16_t)bpx[l]; o.mvp[l][1] = (int16_t)bpy[l];
+    o.mvCost[l] = bmvc[l]; o.ref[l] = (int8_t)bref[l]; o.bits = (int32_t)bbits[l]; o.cost = bcost[l];
+    a.out[item] = o;
+}
+
 __global__ __launch_bounds__(256) void inter_merge_kernel(MergeArgs a)
 {
     __shared__ __attribute__((aligned(16))) pixel s_fenc[4][64 * 64];
@@ -196,7 +227,8 @@ extern "C" int x265hip_inter_merge_batch(void* stream, int w, int h, const void*
             a.res[l * 4 + r] = p->results[l][r]; a.mvpSrc[l * 4 + r] = p->mvpSource[l][r]; a.planes[l * 4 + r] = (const pixel*)p->subpelPlanes[l][r];
         }
     a.bitsCentre = p->bitsRow + p->bitsHalfRange; a.bitsHalf = p->bitsHalfRange; a.lambda = p->lambda; a.out = out;
-    hipLaunchKernelGGL(inter_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.isP || !a.bidir) hipLaunchKernelGGL(inter_merge_uni_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(inter_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

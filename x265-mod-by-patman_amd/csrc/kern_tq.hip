@@ -25,6 +25,7 @@ struct TqArgs
     pixel* recon; intptr_t reconStride; uint64_t* sse;
     const x265hip_me_result* mvSource;
     const pixel* planes; int64_t planeElems;
+    const x265hip_inter_choice* choice; int choiceList, choiceRef;
 };
 
 template<int N> struct Lg { static const int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5; };
@@ -64,6 +65,12 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     if (item >= a.n) return;
     x265hip_tu_task tk = a.tasks[item];
     if (tk.mvFrom >= 0 && a.mvSource) { tk.mv[0] = a.mvSource[tk.mvFrom].mv[0]; tk.mv[1] = a.mvSource[tk.mvFrom].mv[1]; }
+    if (tk.mvFrom >= 0 && a.choice)
+    {   // several references: this launch compensates from ONE of them -- only the TUs whose PU chose it
+        const x265hip_inter_choice ch = a.choice[tk.mvFrom];
+        if (ch.ref[a.choiceList] != a.choiceRef || ch.ref[a.choiceList ^ 1] >= 0) return;
+        tk.mv[0] = ch.mv[a.choiceList][0]; tk.mv[1] = ch.mv[a.choiceList][1];
+    }
 
     McCtx c;
     c.setGeometry(N, N, lane);
@@ -274,7 +281,9 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
     { set_error("tq_batch: bad arguments"); return X265HIP_EARG; }
     TqArgs a = { (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride, tasks, n,
                  params->qp, params->add, params->quantCoeff, params->deltaU, coeff, numSig,
-                 (pixel*)reconPlane, reconStride, sse, mvSource, (const pixel*)params->subpelPlanes, params->planeElems };
+                 (pixel*)reconPlane, reconStride, sse, mvSource, (const pixel*)params->subpelPlanes, params->planeElems,
+                 params->choice, params->choiceList, params->choiceRef };
+    if (params->choice && (params->choiceList < 0 || params->choiceList > 1 || params->choiceRef < 0 || params->choiceRef > 3)) { set_error("tq_batch: bad choiceList / choiceRef"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     switch (log2TrSize)
     {

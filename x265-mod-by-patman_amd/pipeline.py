@@ -14,7 +14,7 @@ All launches go to torch's current stream; nothing is synchronised inside step()
 """
 import numpy as np
 
-from .frame import FrameApi, ME_TASK, ME_RESULT, TU_TASK, ME_WINDOW
+from .frame import FrameApi, ME_TASK, ME_RESULT, TU_TASK, ME_WINDOW, INTER_CHOICE, mvbits_row, rd_lambda
 
 LEVELS = (64, 32, 16, 8)
 CTU = 64
@@ -62,7 +62,10 @@ def pyramid_tasks(W, H, F, margin, tu_log2):
 
 class FramePipeline:
     def __init__(self, depth, width, height, frames, qp=28, merange=57, method=1, subme=2, tu_log2=5, margin=96,
-                 recon=False, cost_row=None, api=None, use_planes=True):
+                 recon=False, cost_row=None, api=None, use_planes=True, refs=1):
+        """refs > 1: every source picture is searched in `refs` list-0 reference pictures (param->maxNumReferences); each reference has its own predictor
+        chain down the pyramid (m_areaBestMV[area][list][ref], analysis.cpp:248-306), x265hip_inter_merge_batch picks the reference per PU with the
+        reference's bit / cost rule, and the TQ stage compensates every TU from the reference its PU chose."""
         assert width % CTU == 0 and height % CTU == 0, "pad the picture to whole CTUs"
         self.api = api or FrameApi(depth)
         self.torch = self.api.torch
@@ -70,6 +73,8 @@ class FramePipeline:
         self.qp, self.merange, self.method, self.subme, self.tu_log2, self.margin = qp, merange, method, subme, tu_log2, margin
         self.recon = recon
         self.use_planes = use_planes
+        self.refs = refs
+        assert refs == 1 or use_planes, "several references: the phase planes are required"
         self.d_planes = None
         self.stride = width + 2 * margin
         self.plane = self.stride * (height + 2 * margin)        # elements per padded plane
@@ -94,6 +99,14 @@ class FramePipeline:
         T = self.torch
         self.d_tasks = {lv: self.api.to_device(t) for lv, t in self.tasks_host.items()}
         self.d_results = {lv: T.zeros(len(t) * ME_RESULT.itemsize, dtype=T.uint8, device="cuda") for lv, t in self.tasks_host.items()}
+        if self.refs > 1:
+            self.d_results_ref = [self.d_results] + [{lv: T.zeros(len(t) * ME_RESULT.itemsize, dtype=T.uint8, device="cuda") for lv, t in self.tasks_host.items()}
+                                                     for _ in range(self.refs - 1)]
+            self.d_choice = {lv: T.zeros(len(t) * INTER_CHOICE.itemsize, dtype=T.uint8, device="cuda") for lv, t in self.tasks_host.items()}
+            self.bits_half = 1 << 14
+            self.bits_row_host = mvbits_row(self.depth, self.bits_half)
+            self.d_bits = self.api.to_device(self.bits_row_host.view(np.int32)).view(T.float32)
+            self.rd_lambda = rd_lambda(self.depth, self.qp)
         self.d_tu = self.api.to_device(tu)
         self.d_coeff = T.zeros(len(tu) * n * n, dtype=T.int16, device="cuda")
         self.d_numsig = T.zeros(len(tu), dtype=T.int32, device="cuda")
@@ -105,32 +118,58 @@ class FramePipeline:
         return self.F * self.W * self.H
 
     def upload(self, pairs):
-        """pairs: F tuples (cur_padded, ref_padded) of shape (H + 2*margin, W + 2*margin)."""
-        assert len(pairs) == self.F
-        cur = np.concatenate([c.reshape(-1) for c, _ in pairs])
-        ref = np.concatenate([r.reshape(-1) for _, r in pairs])
+        """pairs: F tuples (cur_padded, ref_padded [, ref1_padded ...]) of shape (H + 2*margin, W + 2*margin); `refs` reference pictures per source picture."""
+        assert len(pairs) == self.F and all(len(p) == 1 + self.refs for p in pairs)
+        cur = np.concatenate([p[0].reshape(-1) for p in pairs])
+        ref = np.concatenate([p[1].reshape(-1) for p in pairs])
         assert cur.size == self.F * self.plane
         self.cur_host, self.ref_host = cur, ref
         self.d_cur, self.d_ref = self.api.to_device(cur), self.api.to_device(ref)
+        if self.refs > 1:
+            self.refs_host = [ref] + [np.concatenate([p[1 + r].reshape(-1) for p in pairs]) for r in range(1, self.refs)]
+            self.d_refs = [self.d_ref] + [self.api.to_device(x) for x in self.refs_host[1:]]
         if self.recon:
             self.d_recon = self.torch.zeros_like(self.d_cur)
         if self.use_planes and self.d_planes is None:
             # 16 phase-plane slots (slot 0 unused) with the reference stack's own addressing
             self.plane_elems = self.F * self.plane
             self.d_planes = self.torch.empty(16 * self.plane_elems, dtype=self.d_ref.dtype, device="cuda")
+            if self.refs > 1:
+                self.d_planes_ref = [self.d_planes] + [self.torch.empty(16 * self.plane_elems, dtype=self.d_ref.dtype, device="cuda") for _ in range(self.refs - 1)]
 
     # ---- device work ----
     def launch_planes(self):
         """Quarter-pel phase planes of the whole reference stack (once per reference picture in an encoder)."""
         self.api.subpel_planes(self.d_ref, self.stride, self.F * (self.H + 2 * self.margin), self.d_planes, self.plane_elems)
+        for r in range(1, self.refs):
+            self.api.subpel_planes(self.d_refs[r], self.stride, self.F * (self.H + 2 * self.margin), self.d_planes_ref[r], self.plane_elems)
 
     def launch_me(self, lv):
+        if self.refs > 1:
+            return self._launch_me_refs(lv)
         parent = None if lv == CTU else self.d_results[2 * lv]
         self.api.me_batch(lv, lv, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tasks[lv], len(self.tasks_host[lv]),
                           self.d_cost, self.half, self.merange, self.method, self.subme, self.d_results[lv], mvp_source=parent,
                           planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
 
+    def _launch_me_refs(self, lv):
+        """the level searched in every reference (each with its own parent chain), then the per-PU choice"""
+        n = len(self.tasks_host[lv])
+        for r in range(self.refs):
+            parent = None if lv == CTU else self.d_results_ref[r][2 * lv]
+            self.api.me_batch(lv, lv, self.d_cur, self.stride, self.d_refs[r], self.stride, self.d_tasks[lv], n, self.d_cost, self.half, self.merange, self.method,
+                              self.subme, self.d_results_ref[r][lv], mvp_source=parent, planes=self.d_planes_ref[r], plane_elems=self.plane_elems)
+        parents = [[None if lv == CTU else self.d_results_ref[r][2 * lv] for r in range(self.refs)], []]
+        self.api.inter_merge_batch(lv, lv, self.d_cur, self.stride, self.stride, self.d_tasks[lv], n, [[self.d_results_ref[r][lv] for r in range(self.refs)], []], parents,
+                                   [self.d_planes_ref, []], self.plane_elems, self.d_bits, self.bits_half, self.rd_lambda, False, max(self.W, self.H), self.d_choice[lv])
+
     def launch_tq(self):
+        if self.refs > 1:
+            for r in range(self.refs):            # one launch per reference plane: every TU is compensated from the reference its PU chose
+                self.api.tq_batch(self.tu_log2, self.d_cur, self.stride, self.d_refs[r], self.stride, self.d_tu, len(self.tu_host), self.qp, 85,
+                                  self.d_coeff, self.d_numsig, recon=self.d_recon, recon_stride=self.stride, sse=self.d_sse,
+                                  planes=self.d_planes_ref[r], plane_elems=self.plane_elems, choice=self.d_choice[self.mv_level], choice_list=0, choice_ref=r)
+            return
         self.api.tq_batch(self.tu_log2, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tu, len(self.tu_host), self.qp, 85,
                           self.d_coeff, self.d_numsig, recon=self.d_recon, recon_stride=self.stride, sse=self.d_sse,
                           mv_source=self.d_results[self.mv_level],
@@ -179,12 +218,15 @@ class FramePipeline:
         coefficient + 4 B per TU); the phase-plane launch reads one padded plane stack and writes 16."""
         bpp = 1 if self.depth == 8 else 2
         px = self.pixels_per_step
-        alg = {"me%d" % lv: px * 2 * bpp + len(self.tasks_host[lv]) * 16 for lv in LEVELS}
+        alg = {"me%d" % lv: px * (1 + self.refs) * bpp + len(self.tasks_host[lv]) * 16 * self.refs for lv in LEVELS}
         alg["tq"] = px * (2 * bpp + 2) + len(self.tu_host) * 4 + (px * bpp if self.recon else 0)
         if self.use_planes:
-            alg["planes"] = self.F * self.plane * bpp * 17
+            alg["planes"] = self.F * self.plane * bpp * 17 * self.refs
         return alg
 
     # ---- read-back ----
-    def results(self, lv):
-        return self.d_results[lv].cpu().numpy().view(ME_RESULT)
+    def results(self, lv, ref=0):
+        return (self.d_results_ref[ref][lv] if self.refs > 1 else self.d_results[lv]).cpu().numpy().view(ME_RESULT)
+
+    def choices(self, lv):
+        return self.d_choice[lv].cpu().numpy().view(INTER_CHOICE)
