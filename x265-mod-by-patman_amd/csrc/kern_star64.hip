@@ -465,6 +465,125 @@ __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict_
     }
 }
 
+// ---- raster mode: windows beyond the band (merange up to 128: 52 x 52 placements in a (256 + 64)^2 window) ---------------------------------
+// The split 64x64 kernel parks a PU where the raster refinement is due (me_body.inc, phase 3: mvcost = 2 in its record); here the raster is costed as
+// SAD surfaces chunk by chunk -- 23 vertical x 24 horizontal placements per pass, each pass with its own (174 x 179)-pixel piece of the window in the
+// band -- and the minimum in raster order over all passes replaces the parked position if it is cheaper (phase 4 resumes behind it).
+__global__ __launch_bounds__(256, 2) void star64_raster_kernel(const pixel* __restrict__ cur, intptr_t cs, const pixel* __restrict__ ref, intptr_t rs,
+                                                               const x265hip_me_task* __restrict__ tasks, int n, const uint16_t* __restrict__ costCentre, int chr,
+                                                               int merange, x265hip_me_result* __restrict__ results, const x265hip_me_result* __restrict__ mvpSource)
+{
+    __shared__ __attribute__((aligned(16))) Shared s;
+    const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (item >= n) return;
+    const x265hip_me_result st = results[item];
+    if (st.reserved != XH_PARKED || st.mvcost != 2) return;
+    const x265hip_me_task* __restrict__ tp = tasks + item;
+    Mv mv; mv.centre = costCentre; mv.lcentre = (const lu16*)s.mvc + COST_R; mv.chr = chr;
+    mv.mvpx = tp->qmvp[0]; mv.mvpy = tp->qmvp[1];
+    { const int from = tp->mvpFrom; if (from >= 0 && mvpSource) { mv.mvpx = mvpSource[from].mv[0]; mv.mvpy = mvpSource[from].mv[1]; } }
+    int mnx = tp->mvmin[0], mny = tp->mvmin[1], mxx = tp->mvmax[0], mxy = tp->mvmax[1];
+    if (tp->flags & X265HIP_ME_WINDOW)
+    {
+        const int lx0 = mnx, ly0 = mny, lx1 = mxx, ly1 = mxy, d = merange << 2;
+        mnx = min(lx1, max(lx0, mv.mvpx - d)) >> 2; mny = min(ly1, max(ly0, mv.mvpy - d)) >> 2;
+        mxx = min(lx1, max(lx0, mv.mvpx + d)) >> 2; mxy = min(ly1, max(ly0, mv.mvpy + d)) >> 2;
+        mxy = max(mxy, mny);
+    }
+    const int NX = mxx >= mnx ? (mxx - mnx) / RD + 1 : 0, NY = mxy >= mny ? (mxy - mny) / RD + 1 : 0;
+    const int groupEnd = NX >= 4 ? ((NX - 4) & ~3) + 4 : 0;
+    {
+        const pixel* src = cur + tp->curOff;
+        for (int q = tid; q < PH * (PW / XH_UNITPX); q += 256)
+        {
+            const int y = q / (PW / XH_UNITPX), x = (q % (PW / XH_UNITPX)) * XH_UNITPX;
+            *(lu2*)((lpixel*)s.fenc + y * PW + x) = ldq(src + (intptr_t)y * cs + x);
+        }
+        for (int k = tid; k < 2 * COST_R + 1; k += 256) s.mvc[k] = costCentre[k - COST_R];
+        if (tid == 0) s.best = ~0ull;
+    }
+    __syncthreads();
+    const int h = wave & 1, u = lane % LPI;
+    fquad f[HR];
+    {
+        const lpixel* fp = (const lpixel*)s.fenc + (h * HR) * PW + u * XH_UNITPX;
+#pragma unroll
+        for (int y = 0; y < HR; y++) f[y] = ldf(fp + y * PW);
+    }
+    const int rowB = (int)rs * (int)sizeof(pixel);
+    for (int j0 = 0; j0 < NY; j0 += NJ)
+    {
+        const int nj = min(NJ, NY - j0);
+        for (int i0 = 0; i0 < NX; i0 += NIC)
+        {
+            const int ni = min(NIC, NX - i0);
+            const pixel* org = ref + tp->refOff + (intptr_t)(mny + RD * j0) * rs + (mnx + RD * i0);
+            const int m0 = (int)((uintptr_t)org & 3u);
+            const char* src = (const char*)org - m0;
+            const int rows = RD * (nj - 1) + PH, nd = (((RD * (ni - 1) + PW) * (int)sizeof(pixel) + m0 + 3) >> 2) + 2;
+            __syncthreads();                                                        // the previous pass is done with the band and the sums
+            for (int k = tid; k < NJ * NIC; k += 256) s.psum[k] = 0;
+            {
+                const int q = tid % LOADQ, r0 = tid / LOADQ;
+                if (r0 < LOADROWS && 4 * q < nd)
+                {
+#pragma unroll
+                    for (int p = 0; p < LOADPASSES; p++)
+                    {
+                        const int r = r0 + p * LOADROWS;
+                        if (r < rows)
+                        {
+                            const u32x4 v = *(const u32x4a4*)(src + (size_t)r * (size_t)rowB + 16u * (unsigned)q);
+                            lu32* dst = (lu32*)s.band + (4 * q) * BRP + r;
+                            dst[0] = v.x;
+                            if (4 * q + 1 < BCDW) dst[BRP] = v.y;
+                            if (4 * q + 2 < BCDW) dst[2 * BRP] = v.z;
+                            if (4 * q + 3 < BCDW) dst[3 * BRP] = v.w;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            const int ngroups = (ni + IPW - 1) / IPW;
+            for (int g = wave >> 1; g < ngroups; g += 2)
+                raster_task((const lu32*)s.band, f, (lu32*)s.psum, g, h, lane, m0);
+            __syncthreads();
+            unsigned long long best = ~0ull;
+            for (int k = tid; k < nj * ni; k += 256)
+            {
+                const int j = k / ni, i = k - j * ni, gi = i0 + i, gj = j0 + j;
+                const int tx = mnx + RD * gi, ty = mny + RD * gj;
+                const int sad = (int)s.psum[j * NIC + i];
+                const bool quirk = gi < groupEnd && (gi & 3) == 3;                   // the fourth of a sad_x4 group: mvcost(tmv << 3) (:1392)
+                const int cost = sad + (quirk ? mvcost(mv, tx * 8, ty * 8) : mvcost(mv, tx * 4, ty * 4));
+                const unsigned long long key = ((unsigned long long)(unsigned)cost << 16) | (unsigned)(gj * NX + gi);
+                best = key < best ? key : best;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+            {
+                const unsigned lo = __shfl_xor((unsigned)best, off, 64), hi = __shfl_xor((unsigned)(best >> 32), off, 64);
+                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                best = o < best ? o : best;
+            }
+            if (lane == 0) __hip_atomic_fetch_min(&s.best, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        const unsigned long long bb = s.best;
+        x265hip_me_result r = st;
+        r.mvcost = 3;                                                              // raster done
+        if (bb != ~0ull && (int)(bb >> 16) < st.cost)
+        {   // COPY2_IF_LT in raster order against the best of the pattern pass
+            const int k = (int)(bb & 0xFFFFu), gj = k / NX, gi = k - gj * NX;
+            r.mv[0] = (int16_t)(mnx + RD * gi); r.mv[1] = (int16_t)(mny + RD * gj); r.cost = (int)(bb >> 16);
+        }
+        results[item] = r;
+    }
+}
+
 } // namespace
 
 // Can the full-pel STAR search of this call run here?  64x64 PUs, row pitch a multiple of 4 bytes (the band is the dword image of the rows),
@@ -478,6 +597,20 @@ int xh_star64(void* stream, const void* curPlane, intptr_t curStride, const void
               const uint16_t* costCentre, int costHalfRange, int merange, x265hip_me_result* results, const x265hip_me_result* mvpSource)
 {
     hipLaunchKernelGGL(star64_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride,
+                       tasks, n, costCentre, costHalfRange, merange, results, mvpSource);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+// the raster-only mode: any window whose placements per row / column fit the 16-bit order field (merange <= 160)
+bool xh_star64_raster_ok(intptr_t refStride, int merange)
+{
+    return ((refStride * (intptr_t)sizeof(pixel)) & 3) == 0 && merange > MAXR && (2 * merange) / RD + 1 <= 255;
+}
+int xh_star64_raster(void* stream, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride, const x265hip_me_task* tasks, int n,
+                     const uint16_t* costCentre, int costHalfRange, int merange, x265hip_me_result* results, const x265hip_me_result* mvpSource)
+{
+    hipLaunchKernelGGL(star64_raster_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride,
                        tasks, n, costCentre, costHalfRange, merange, results, mvpSource);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
