@@ -28,6 +28,7 @@
 #include "xh_mc.h"
 #include "../../include/x265hip_frame.h"
 #include <utility>
+#include <cstdlib>
 using namespace xh;
 
 #define XH_PARKED 0x5041524B               // me_body.inc: x265hip_me_result.reserved of a parked PU
@@ -270,7 +271,7 @@ __device__ __forceinline__ uint32_t cost_batch(Shared& s, const fquad (&f)[HR], 
 
 __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict__ cur, intptr_t cs, const pixel* __restrict__ ref, intptr_t rs,
                                                         const x265hip_me_task* __restrict__ tasks, int n, const uint16_t* __restrict__ costCentre, int chr,
-                                                        int merange, x265hip_me_result* __restrict__ results, const x265hip_me_result* __restrict__ mvpSource)
+                                                        int merange, x265hip_me_result* __restrict__ results, const x265hip_me_result* __restrict__ mvpSource, int dbg)
 {
     __shared__ __attribute__((aligned(16))) Shared s;
     const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict_
     }
 
     int bx = st.mv[0], by = st.mv[1], bcost = st.cost, bPointNr = 0, bDistance = 0;
+    if (dbg == 5) return;                                                           // timing experiments: window load only
 
     // motion.cpp:387-629 with all points of the pass costed up front; the first pass (3 idle rounds end it) costs distances 1-4 first
     auto star_pass = [&](int earlyExitIters) {
@@ -432,8 +434,10 @@ __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict_
     for (;;)
     {
         if (!first) { bPointNr = 0; bDistance = 0; }
+        if (dbg == 4 && !first) break;                                              // timing experiments: no re-centred passes
         star_pass(first ? 3 : 32);
         __syncthreads();
+        if (dbg == 1) break;                                                        // timing experiments: the first pass only
         if (first)
         {
             first = false;
@@ -444,7 +448,8 @@ __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict_
                 two_point();
                 if (bcost == saved) break;
             }
-            if (bDistance > RD) raster();
+            if (bDistance > RD && dbg != 3) raster();
+            if (dbg == 2) break;                                                    // timing experiments: first pass + raster
             if (!(bDistance > 0)) break;
         }
         else
@@ -596,8 +601,9 @@ bool xh_star64_ok(intptr_t refStride, int merange)
 int xh_star64(void* stream, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride, const x265hip_me_task* tasks, int n,
               const uint16_t* costCentre, int costHalfRange, int merange, x265hip_me_result* results, const x265hip_me_result* mvpSource)
 {
+    static const int dbg = getenv("X265HIP_STAR64_DBG") ? atoi(getenv("X265HIP_STAR64_DBG")) : 0;      // timing experiments only (results are wrong with it)
     hipLaunchKernelGGL(star64_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride,
-                       tasks, n, costCentre, costHalfRange, merange, results, mvpSource);
+                       tasks, n, costCentre, costHalfRange, merange, results, mvpSource, dbg);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
