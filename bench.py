@@ -603,8 +603,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))      # before the process group exists: RCCL binds its communicator to the current device
     rank, local_rank, world = init_ranks(args.gpus, "nccl", torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
 
     api = FrameApi(depth)
     half = 1 << 15
