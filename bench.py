@@ -155,6 +155,39 @@ def filters_leg(depth, steps):
     total = sum(ms.values())
     px = F * W * H
 
+    # ... and through the picture-batched entry points: ONE launch per stage (and plane) for all F pictures
+    from deblock_util import DeblockPic
+    class Job(C.Structure):
+        _fields_ = [("pic", DeblockPic), ("Y", C.c_void_p), ("Cb", C.c_void_p), ("Cr", C.c_void_p), ("bsOut", C.c_void_p)]
+    elems = [h * w for h, w in shapes]
+    s_pristine = [torch.cat([d_pristine[c]] * F) for c in range(3)]
+    s_src = [torch.cat([d_src[c]] * F) for c in range(3)]
+    s_rec = [torch.empty_like(x) for x in s_pristine]; s_out = [torch.empty_like(x) for x in s_pristine]
+    jobs = (Job * F)()
+    for f in range(F):
+        jobs[f].pic = desc
+        jobs[f].Y = s_rec[0].data_ptr() + f * elems[0] * esz; jobs[f].Cb = s_rec[1].data_ptr() + f * elems[1] * esz; jobs[f].Cr = s_rec[2].data_ptr() + f * elems[2] * esz
+    d_jobs = api.to_device(np.frombuffer(bytes(jobs), np.uint8).copy())
+    s_prm = [torch.cat([d_prm[c]] * F) for c in range(3)]
+    s_stats = [torch.zeros(F * n_ctu * 320, dtype=torch.int32, device="cuda") for _ in range(3)]
+    s_ws = torch.zeros(F * d_ws.numel(), dtype=torch.float32, device="cuda")
+    s_rs = torch.zeros(F * nrows, dtype=torch.float32, device="cuda"); s_rc = torch.zeros(F * nrows, dtype=torch.int32, device="cuda")
+    s_fr = torch.zeros(2 * F, dtype=torch.float64, device="cuda"); s_ssd = torch.zeros(3 * F, dtype=torch.int64, device="cuda")
+
+    def restore_stack():
+        for c in range(3):
+            s_rec[c].copy_(s_pristine[c])
+
+    def batched():
+        api.h.check(L.x265hip_deblock_pictures(st, P(d_jobs), jobs, F, C.c_ssize_t(W), C.c_ssize_t(W // 2)))
+        for c in range(3):
+            h, w = shapes[c]
+            cs = ctu if c == 0 else ctu // 2
+            api.h.check(L.x265hip_sao_stats_pictures(st, P(s_src[c]), P(s_rec[c]), C.c_ssize_t(w), w, h, cs, 0, 0 if c == 0 else 2, P(s_stats[c]), F, C.c_int64(elems[c])))
+            api.h.check(L.x265hip_sao_apply_pictures(st, P(s_rec[c]), P(s_out[c]), C.c_ssize_t(w), w, h, cs, P(s_prm[c]), F, C.c_int64(elems[c])))
+            api.h.check(L.x265hip_plane_ssd_pictures(st, P(s_src[c]), P(s_out[c]), C.c_ssize_t(w), w, h, C.c_void_p(s_ssd.data_ptr() + 8 * F * c), F, C.c_int64(elems[c]), C.c_int64(elems[c])))
+        api.h.check(L.x265hip_ssim_pictures(st, P(s_out[0]), C.c_ssize_t(W), P(s_src[0]), C.c_ssize_t(W), W, H, ctu, P(s_ws), P(s_rs), P(s_rc), P(s_fr), F, C.c_int64(elems[0]), C.c_int64(elems[0])))
+    ms_batched = timed(batched, steps, restore_stack)
     # the same work with every picture's chain on its own HIP stream: the kernels are small (a 1080p plane does not fill 256 CUs), so chains of
     # different pictures overlap instead of queueing behind each other's launch gaps
     streams = [torch.cuda.Stream() for _ in range(F)]
@@ -190,6 +223,8 @@ def filters_leg(depth, steps):
            "mpixels_per_s": round(px / (total * 1e-3) / 1e6, 1),
            "one_stream_per_picture": {"ms": round(ms_streams, 4), "ms_per_picture": round(ms_streams / F, 4), "mpixels_per_s": round(px / (ms_streams * 1e-3) / 1e6, 1)},
            "hipgraph_of_the_streams": {"ms": round(ms_graph, 4), "ms_per_picture": round(ms_graph / F, 4), "mpixels_per_s": round(px / (ms_graph * 1e-3) / 1e6, 1)},
+           "picture_batched_entry_points": {"ms": round(ms_batched, 4), "ms_per_picture": round(ms_batched / F, 4), "mpixels_per_s": round(px / (ms_batched * 1e-3) / 1e6, 1),
+                                            "launches": "one per stage and plane for all %d pictures (x265hip_*_pictures)" % F},
            "algorithmic_GBps": {"deblock": round(4 * nbytes * F / (ms["deblock"] * 1e-3) / 1e9, 1), "sao_stats": round(2 * nbytes * F / (ms["sao_stats"] * 1e-3) / 1e9, 1),
                                 "sao_apply": round(2 * nbytes * F / (ms["sao_apply"] * 1e-3) / 1e9, 1), "ssim_ssd": round((2 * nbytes + 2 * pic["planes"][0].nbytes) * F / (ms["ssim_ssd"] * 1e-3) / 1e9, 1)}}
     # the same chain through the oracle on one picture: results identical, its clock = the host number
@@ -225,12 +260,18 @@ def filters_leg(depth, steps):
         assert np.array_equal(d_out[0][c].cpu().numpy().view(o_out[c].dtype).reshape(shapes[c]), o_out[c]), "filters: SAO output plane %d differs from the oracle" % c
     fr = d_fr[0].cpu().numpy()
     assert fr[0] == tot.value and int(fr[1]) == cnt.value, "filters: SSIM differs from the oracle"
+    restore_stack(); batched(); torch.cuda.synchronize()                # the batched forms: every picture of the stack = the per-picture results
+    for c in range(3):
+        for f in (0, F - 1):
+            assert torch.equal(s_rec[c][f * elems[c]:(f + 1) * elems[c]], d_rec[0][c]) and torch.equal(s_out[c][f * elems[c]:(f + 1) * elems[c]], d_out[0][c]), "filters: batched plane differs"
+        assert torch.equal(s_stats[c][:n_ctu * 320], d_stats[0][c]), "filters: batched statistics differ"
+    assert torch.equal(s_fr[:2], d_fr[0]) and [int(v) for v in s_ssd.cpu().numpy()[::F]] == o_ssd, "filters: batched SSIM / SSD differ"
     assert [int(v) for v in d_ssd[0].cpu().numpy()] == o_ssd, "filters: SSD differs from the oracle"
     cpu_ms = {"deblock": (t1 - t0) * 1e3, "sao_stats": (t2 - t1) * 1e3, "sao_apply": (t3 - t2) * 1e3, "ssim_ssd": (t4 - t3) * 1e3}
     out["ssim"] = fr[0] / fr[1]
     out["cpu_port"] = {"kind": "port", "cores": 1, "sample": "the same chain on one of the pictures through the oracle (C, -O2), every plane / statistic / SSIM identical to the GPU's",
                        "ms_per_picture": {k: round(v, 2) for k, v in cpu_ms.items()}, "mpixels_per_s": round(W * H / (sum(cpu_ms.values()) * 1e-3) / 1e6, 1),
-                       "gpu_over_one_core": round((px / (min(total, ms_streams, ms_graph) * 1e-3)) / (W * H / (sum(cpu_ms.values()) * 1e-3)), 1)}
+                       "gpu_over_one_core": round((px / (min(total, ms_streams, ms_graph, ms_batched) * 1e-3)) / (W * H / (sum(cpu_ms.values()) * 1e-3)), 1)}
     return out
 
 

@@ -279,6 +279,22 @@ typedef struct x265hip_deblock_pic
 } x265hip_deblock_pic;
 int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut);
 
+/* ---- the same stages for a BATCH of pictures of one size in one launch per stage (a 1080p plane does not fill 256 CUs: per-picture launches of 7-20 us
+ * on <= 17 workgroups are launch-latency bound; a batch is not).  Pictures are `pictureElems` elements apart in their buffers; per-picture outputs are
+ * consecutive (statistics: nCtu x 320 int32 per picture; SAO parameters: nCtu x 6 int32; SSD: one uint64; SSIM: rowSsim / rowCnt numRows each, frame 2 doubles,
+ * workspace x265hip_ssim_workspace bytes each).  Deblocking takes one description + plane pointers per picture: the job list both as a host copy (checked,
+ * sizes the launch) and as its device copy (read by the kernels). */
+typedef struct x265hip_deblock_job { x265hip_deblock_pic pic; void *Y, *Cb, *Cr; uint8_t* bsOut; } x265hip_deblock_job;
+int x265hip_deblock_pictures(void* stream, const x265hip_deblock_job* jobsDevice, const x265hip_deblock_job* jobsHost, int nPictures, intptr_t strideY, intptr_t strideC);
+int x265hip_sao_stats_pictures(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                               int planeOffset, int32_t* out, int nPictures, int64_t pictureElems);
+int x265hip_sao_apply_pictures(void* stream, const void* in, void* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params,
+                               int nPictures, int64_t pictureElems);
+int x265hip_plane_ssd_pictures(void* stream, const void* fenc, const void* recon, intptr_t stride, int width, int height, uint64_t* out, int nPictures,
+                               int64_t fencPictureElems, int64_t reconPictureElems);
+int x265hip_ssim_pictures(void* stream, const void* recon, intptr_t stride1, const void* fenc, intptr_t stride2, int width, int height, int ctuSize,
+                          void* workspace, float* rowSsim, uint32_t* rowCnt, double* frame, int nPictures, int64_t reconPictureElems, int64_t fencPictureElems);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,8 +167,9 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(int type, const int16_t*
 // each class counts is a rectangle per type (skipB / skipR keep away from rows / columns the neighbours' deblocking has not finalised).
 // Edge classes accumulate in registers (5 classes x 4 types, compile-time indexed), the 32 bands through LDS atomics (one copy per wavefront).
 __global__ __launch_bounds__(1024) void sao_frame_kernel(const pixel* __restrict__ fenc, const pixel* __restrict__ recon, intptr_t stride, int picWidth, int picHeight,
-                                                        int ctuSize, int nonDeblocked, int po, int32_t* __restrict__ out)
+                                                        int ctuSize, int nonDeblocked, int po, int32_t* __restrict__ out, int64_t picElems, int64_t outPicInts)
 {
+    fenc += blockIdx.z * picElems; recon += blockIdx.z * picElems; out += blockIdx.z * outPicInts;      // picture of a batch (grid z)
     constexpr int NW = 16;                                         // wavefronts of the workgroup: a 64x64 CTU is 4 pixels per thread
     __shared__ int s_bo[NW][2][32];
     __shared__ int s_eo[NW][40];
@@ -247,8 +248,10 @@ __global__ __launch_bounds__(1024) void sao_frame_kernel(const pixel* __restrict
 // Encoder::computeSSD (encoder/encoder.cpp:1203-1270): sum of squared differences of two planes (PSNR numerator), exact in 64 bits.
 // A workgroup takes a 256 x 8 tile: a thread's 16 loads are independent and issued together (a per-thread loop along the row waited for one load
 // round trip per step: 10.7 us per 1080p plane).
-__global__ __launch_bounds__(256) void plane_ssd_kernel(const pixel* __restrict__ a, const pixel* __restrict__ b, intptr_t stride, int width, int height, unsigned long long* out)
+__global__ __launch_bounds__(256) void plane_ssd_kernel(const pixel* __restrict__ a, const pixel* __restrict__ b, intptr_t stride, int width, int height, unsigned long long* out,
+                                                        int64_t aPicElems, int64_t bPicElems, int outPicStride)
 {
+    a += blockIdx.z * aPicElems; b += blockIdx.z * bPicElems; out += blockIdx.z * outPicStride;         // picture of a batch (grid z)
     __shared__ unsigned long long s_part[4];
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * 8;
     int va[8], vb[8];
@@ -290,8 +293,9 @@ __device__ __forceinline__ float ssim_window(int s1, int s2, int ss, int s12)
 
 // one workgroup: a tile of 32 x 8 windows = 33 x 9 block sums in LDS; E[wy * nwx + wx] = the window's ssim_end_1 value
 __global__ __launch_bounds__(256) void ssim_window_kernel(const pixel* __restrict__ rec, intptr_t stride1, const pixel* __restrict__ fenc, intptr_t stride2,
-                                                          int nwx, int nwy, float* __restrict__ E)
+                                                          int nwx, int nwy, float* __restrict__ E, int64_t recPicElems, int64_t fencPicElems, int64_t ePicFloats)
 {
+    rec += blockIdx.z * recPicElems; fenc += blockIdx.z * fencPicElems; E += blockIdx.z * ePicFloats;   // picture of a batch (grid z)
     __shared__ uint4 s_blk[9][33];
     const int bx0 = blockIdx.x * 32, by0 = blockIdx.y * 8;
     for (int t = threadIdx.x; t < 9 * 33; t += 256)
@@ -320,8 +324,9 @@ __global__ __launch_bounds__(256) void ssim_window_kernel(const pixel* __restric
 // every thread walked 32 groups one load-wait after the other (40 us per 1080p picture, however the additions were fed -- LDS scalar / vector reads or
 // v_readlane, 60 us); 1024 threads take two groups each.
 __global__ __launch_bounds__(1024) void ssim_rows_kernel(const float* __restrict__ E, int nwx, int width, int height, int ctuSize, int numRows,
-                                                       float* __restrict__ rowSsim, uint32_t* __restrict__ rowCnt)
+                                                       float* __restrict__ rowSsim, uint32_t* __restrict__ rowCnt, int64_t ePicFloats)
 {
+    E += blockIdx.y * ePicFloats; rowSsim += blockIdx.y * numRows; rowCnt += blockIdx.y * numRows;      // picture of a batch (grid y)
     constexpr int CAP = 8192;
     __shared__ __attribute__((aligned(16))) float s_part[CAP];
     const int r = blockIdx.x, start = r == 0, end = r == numRows - 1;
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(1024) void ssim_rows_kernel(const float* __restrict
 
 __global__ void ssim_total_kernel(const float* __restrict__ rowSsim, const uint32_t* __restrict__ rowCnt, int numRows, double* __restrict__ frame)
 {
+    rowSsim += blockIdx.x * numRows; rowCnt += blockIdx.x * numRows; frame += 2 * blockIdx.x;           // picture of a batch (grid x)
     double t = 0; uint32_t c = 0;
     for (int r = 0; r < numRows; r++) { t += rowSsim[r]; c += rowCnt[r]; }
     frame[0] = t; frame[1] = (double)c;
@@ -373,8 +379,9 @@ __global__ void ssim_total_kernel(const float* __restrict__ rowSsim, const uint3
 // CTU by CTU and classifies against saved copies of the unmodified neighbours (m_tmpU / m_tmpL) -- i.e. against the picture before SAO, which is
 // simply the input here.  params: per CTU { typeIdx (-1 off, 0..3 EO, 4 BO), bandPos, offset[4] }.  Each thread filters four neighbouring pixels.
 __global__ __launch_bounds__(256) void sao_apply_kernel(const pixel* __restrict__ in, pixel* __restrict__ out, intptr_t stride, int picWidth, int picHeight,
-                                                        int ctuSize, int lgCtu, const int32_t* __restrict__ params)
+                                                        int ctuSize, int lgCtu, const int32_t* __restrict__ params, int64_t inPicElems, int64_t outPicElems, int64_t paramPicInts)
 {
+    in += blockIdx.z * inPicElems; out += blockIdx.z * outPicElems; params += blockIdx.z * paramPicInts;   // picture of a batch (grid z)
     const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x0 >= picWidth || y >= picHeight) return;
     const int nx = (picWidth + ctuSize - 1) >> lgCtu, ny = (picHeight + ctuSize - 1) >> lgCtu;
@@ -510,26 +517,38 @@ extern "C" int x265hip_sao_stats(void* stream, int type, const int16_t* diff, co
     return X265HIP_OK;
 }
 
-extern "C" int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
-                                       int planeOffset, int32_t* out)
+extern "C" int x265hip_sao_stats_pictures(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                                          int planeOffset, int32_t* out, int nPictures, int64_t pictureElems)
 {
     if (!fenc || !recon || !out || picWidth < 1 || picHeight < 1 || (ctuSize != 8 && ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth ||
-        (planeOffset != 0 && planeOffset != 2))
-    { set_error("sao_stats_frame: bad arguments"); return X265HIP_EARG; }
+        (planeOffset != 0 && planeOffset != 2) || nPictures < 1 || nPictures > 65535 || (nPictures > 1 && pictureElems < stride * (intptr_t)picHeight))
+    { set_error("sao_stats: bad arguments"); return X265HIP_EARG; }
     const int n = ((picWidth + ctuSize - 1) / ctuSize) * ((picHeight + ctuSize - 1) / ctuSize);
-    hipLaunchKernelGGL(sao_frame_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out);
+    hipLaunchKernelGGL(sao_frame_kernel, dim3(n, 1, nPictures), dim3(1024), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize,
+                       nonDeblocked, planeOffset, out, pictureElems, (int64_t)n * 320);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
-
-extern "C" int x265hip_plane_ssd(void* stream, const void* fenc, const void* recon, intptr_t stride, int width, int height, uint64_t* out)
+extern "C" int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                                       int planeOffset, int32_t* out)
 {
-    if (!fenc || !recon || !out || width < 1 || height < 1 || stride < width || width > 16384) { set_error("plane_ssd: bad arguments"); return X265HIP_EARG; }
+    return x265hip_sao_stats_pictures(stream, fenc, recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out, 1, 0);
+}
+
+extern "C" int x265hip_plane_ssd_pictures(void* stream, const void* fenc, const void* recon, intptr_t stride, int width, int height, uint64_t* out, int nPictures,
+                                          int64_t fencPictureElems, int64_t reconPictureElems)
+{
+    if (!fenc || !recon || !out || width < 1 || height < 1 || stride < width || width > 16384 || nPictures < 1 || nPictures > 65535) { set_error("plane_ssd: bad arguments"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
-    XH_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t), st));
-    hipLaunchKernelGGL(plane_ssd_kernel, dim3((width + 255) / 256, (height + 7) / 8), dim3(256), 0, st, (const pixel*)fenc, (const pixel*)recon, stride, width, height, (unsigned long long*)out);
+    XH_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t) * nPictures, st));
+    hipLaunchKernelGGL(plane_ssd_kernel, dim3((width + 255) / 256, (height + 7) / 8, nPictures), dim3(256), 0, st, (const pixel*)fenc, (const pixel*)recon, stride, width, height,
+                       (unsigned long long*)out, fencPictureElems, reconPictureElems, 1);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
+}
+extern "C" int x265hip_plane_ssd(void* stream, const void* fenc, const void* recon, intptr_t stride, int width, int height, uint64_t* out)
+{
+    return x265hip_plane_ssd_pictures(stream, fenc, recon, stride, width, height, out, 1, 0, 0);
 }
 
 extern "C" size_t x265hip_ssim_workspace(int width, int height)
@@ -538,11 +557,11 @@ extern "C" size_t x265hip_ssim_workspace(int width, int height)
     return (size_t)((width - 2) >> 2) * ((height - 2) >> 2) * sizeof(float);
 }
 
-extern "C" int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stride1, const void* fenc, intptr_t stride2, int width, int height, int ctuSize,
-                                  void* workspace, float* rowSsim, uint32_t* rowCnt, double* frame)
+extern "C" int x265hip_ssim_pictures(void* stream, const void* recon, intptr_t stride1, const void* fenc, intptr_t stride2, int width, int height, int ctuSize,
+                                     void* workspace, float* rowSsim, uint32_t* rowCnt, double* frame, int nPictures, int64_t reconPictureElems, int64_t fencPictureElems)
 {
     if (!recon || !fenc || !workspace || !rowSsim || !rowCnt || !frame || width < 10 || height < 10 || width > 16384 || (ctuSize != 16 && ctuSize != 32 && ctuSize != 64) ||
-        stride1 < width || stride2 < width)
+        stride1 < width || stride2 < width || nPictures < 1 || nPictures > 65535)
     { set_error("ssim_frame: bad arguments"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     const int numRows = (height + ctuSize - 1) / ctuSize;
@@ -553,25 +572,38 @@ extern "C" int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stri
     const int nwy = nby - 1;
     if (nwx < 1 || nwy < 1)
     {   /* no complete window: the reference reports zero windows (single CTU row pictures lower than 10 rows cannot get here) */
-        XH_HIP(hipMemsetAsync(rowSsim, 0, numRows * sizeof(float), st)); XH_HIP(hipMemsetAsync(rowCnt, 0, numRows * sizeof(uint32_t), st));
-        XH_HIP(hipMemsetAsync(frame, 0, 2 * sizeof(double), st));
+        XH_HIP(hipMemsetAsync(rowSsim, 0, (size_t)nPictures * numRows * sizeof(float), st)); XH_HIP(hipMemsetAsync(rowCnt, 0, (size_t)nPictures * numRows * sizeof(uint32_t), st));
+        XH_HIP(hipMemsetAsync(frame, 0, (size_t)nPictures * 2 * sizeof(double), st));
         return X265HIP_OK;
     }
-    hipLaunchKernelGGL(ssim_window_kernel, dim3((nwx + 31) / 32, (nwy + 7) / 8), dim3(256), 0, st, (const pixel*)recon, stride1, (const pixel*)fenc, stride2, nwx, nwy,
-                       (float*)workspace);
-    hipLaunchKernelGGL(ssim_rows_kernel, dim3(numRows), dim3(1024), 0, st, (const float*)workspace, nwx, width, height, ctuSize, numRows, rowSsim, rowCnt);
-    hipLaunchKernelGGL(ssim_total_kernel, dim3(1), dim3(1), 0, st, (const float*)rowSsim, (const uint32_t*)rowCnt, numRows, frame);
+    const int64_t ePic = (int64_t)(x265hip_ssim_workspace(width, height) / sizeof(float));
+    hipLaunchKernelGGL(ssim_window_kernel, dim3((nwx + 31) / 32, (nwy + 7) / 8, nPictures), dim3(256), 0, st, (const pixel*)recon, stride1, (const pixel*)fenc, stride2, nwx, nwy,
+                       (float*)workspace, reconPictureElems, fencPictureElems, ePic);
+    hipLaunchKernelGGL(ssim_rows_kernel, dim3(numRows, nPictures), dim3(1024), 0, st, (const float*)workspace, nwx, width, height, ctuSize, numRows, rowSsim, rowCnt, ePic);
+    hipLaunchKernelGGL(ssim_total_kernel, dim3(nPictures), dim3(1), 0, st, (const float*)rowSsim, (const uint32_t*)rowCnt, numRows, frame);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
-
-extern "C" int x265hip_sao_apply_frame(void* stream, const void* in, void* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params)
+extern "C" int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stride1, const void* fenc, intptr_t stride2, int width, int height, int ctuSize,
+                                  void* workspace, float* rowSsim, uint32_t* rowCnt, double* frame)
 {
-    if (!in || !out || in == out || !params || picWidth < 1 || picHeight < 1 || (ctuSize != 8 && ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth)
-    { set_error("sao_apply_frame: bad arguments (out of place only)"); return X265HIP_EARG; }
+    return x265hip_ssim_pictures(stream, recon, stride1, fenc, stride2, width, height, ctuSize, workspace, rowSsim, rowCnt, frame, 1, 0, 0);
+}
+
+extern "C" int x265hip_sao_apply_pictures(void* stream, const void* in, void* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params,
+                                          int nPictures, int64_t pictureElems)
+{
+    if (!in || !out || in == out || !params || picWidth < 1 || picHeight < 1 || (ctuSize != 8 && ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth ||
+        nPictures < 1 || nPictures > 65535)
+    { set_error("sao_apply: bad arguments (out of place only)"); return X265HIP_EARG; }
     const int lg = ctuSize == 64 ? 6 : ctuSize == 32 ? 5 : ctuSize == 16 ? 4 : 3;        // 8: the chroma plane of a 4:2:0 picture with 16x16 CTUs
-    hipLaunchKernelGGL(sao_apply_kernel, dim3((picWidth + 255) / 256, (picHeight + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const pixel*)in, (pixel*)out, stride,
-                       picWidth, picHeight, ctuSize, lg, params);
+    const int n = ((picWidth + ctuSize - 1) / ctuSize) * ((picHeight + ctuSize - 1) / ctuSize);
+    hipLaunchKernelGGL(sao_apply_kernel, dim3((picWidth + 255) / 256, (picHeight + 3) / 4, nPictures), dim3(256), 0, (hipStream_t)stream, (const pixel*)in, (pixel*)out, stride,
+                       picWidth, picHeight, ctuSize, lg, params, pictureElems, pictureElems, (int64_t)n * 6);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
+}
+extern "C" int x265hip_sao_apply_frame(void* stream, const void* in, void* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params)
+{
+    return x265hip_sao_apply_pictures(stream, in, out, stride, picWidth, picHeight, ctuSize, params, 1, 0);
 }

@@ -79,8 +79,8 @@ __device__ __forceinline__ int boundary_strength(const x265hip_deblock_pic& d, i
 }
 
 template<int DIR>
-__global__ __launch_bounds__(256) void deblock_kernel(x265hip_deblock_pic d, pixel* __restrict__ Y, intptr_t strideY, pixel* __restrict__ Cb, pixel* __restrict__ Cr,
-                                                      intptr_t strideC, int lgUpc, int nx, uint8_t* __restrict__ bsOut)
+__device__ __forceinline__ void deblock_body(const x265hip_deblock_pic& d, pixel* __restrict__ Y, intptr_t strideY, pixel* __restrict__ Cb, pixel* __restrict__ Cr,
+                                             intptr_t strideC, int lgUpc, int nx, uint8_t* __restrict__ bsOut)
 {
     const int uw = d.width >> 2, uh = d.height >> 2;
     const int a = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -178,7 +178,48 @@ __global__ __launch_bounds__(256) void deblock_kernel(x265hip_deblock_pic d, pix
     }
 }
 
+template<int DIR>
+__global__ __launch_bounds__(256) void deblock_kernel(x265hip_deblock_pic d, pixel* __restrict__ Y, intptr_t strideY, pixel* __restrict__ Cb, pixel* __restrict__ Cr,
+                                                      intptr_t strideC, int lgUpc, int nx, uint8_t* __restrict__ bsOut)
+{
+    deblock_body<DIR>(d, Y, strideY, Cb, Cr, strideC, lgUpc, nx, bsOut);
+}
+// a batch of pictures of one size: picture = grid z, its description and planes from the device copy of the job list
+template<int DIR>
+__global__ __launch_bounds__(256) void deblock_pictures_kernel(const x265hip_deblock_job* __restrict__ jobs, intptr_t strideY, intptr_t strideC, int lgUpc, int nx)
+{
+    const x265hip_deblock_job& j = jobs[blockIdx.z];              // left in memory (uniform address: scalar loads); a local copy would put refPic[][] in scratch
+    deblock_body<DIR>(j.pic, (pixel*)j.Y, strideY, (pixel*)j.Cb, (pixel*)j.Cr, strideC, lgUpc, nx, j.bsOut);
+}
+
 } // namespace
+
+static bool deblock_desc_ok(const x265hip_deblock_pic& d, intptr_t strideY, intptr_t strideC)
+{
+    return !(d.width < 8 || d.height < 8 || (d.width & 7) || (d.height & 7) || (d.ctuSize != 16 && d.ctuSize != 32 && d.ctuSize != 64) || strideY < d.width || strideC < d.width / 2 ||
+             !d.log2CUSize || !d.partSize || !d.tuDepth || !d.predMode || !d.cbfLuma || !d.qp || !d.refIdx0 || !d.mv0 || (!d.sliceIsP && (!d.refIdx1 || !d.mv1)) ||
+             (d.tqBypassEnabled && !d.tqBypass));
+}
+
+extern "C" int x265hip_deblock_pictures(void* stream, const x265hip_deblock_job* jobsDevice, const x265hip_deblock_job* jobsHost, int nPictures, intptr_t strideY, intptr_t strideC)
+{
+    if (!jobsDevice || !jobsHost || nPictures < 1 || nPictures > 65535) { set_error("deblock_pictures: bad arguments"); return X265HIP_EARG; }
+    const x265hip_deblock_pic& d0 = jobsHost[0].pic;
+    for (int i = 0; i < nPictures; i++)
+    {
+        const x265hip_deblock_job& j = jobsHost[i];
+        if (!j.Y || !j.Cb || !j.Cr || !deblock_desc_ok(j.pic, strideY, strideC) || j.pic.width != d0.width || j.pic.height != d0.height || j.pic.ctuSize != d0.ctuSize)
+        { set_error("deblock_pictures: bad description of picture %d (all pictures of a batch share width, height and CTU size)", i); return X265HIP_EARG; }
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int lgUpc = d0.ctuSize == 64 ? 4 : d0.ctuSize == 32 ? 3 : 2, nx = (d0.width + d0.ctuSize - 1) / d0.ctuSize, uw = d0.width >> 2, uh = d0.height >> 2;
+    for (int i = 0; i < nPictures; i++)
+        if (jobsHost[i].bsOut) XH_HIP(hipMemsetAsync(jobsHost[i].bsOut, 0, (size_t)2 * uw * uh, st));
+    hipLaunchKernelGGL(deblock_pictures_kernel<0>, dim3((uw / 2 + 63) / 64, (uh + 3) / 4, nPictures), dim3(256), 0, st, jobsDevice, strideY, strideC, lgUpc, nx);
+    hipLaunchKernelGGL(deblock_pictures_kernel<1>, dim3((uw + 63) / 64, (uh / 2 + 3) / 4, nPictures), dim3(256), 0, st, jobsDevice, strideY, strideC, lgUpc, nx);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
 
 extern "C" int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut)
 {
