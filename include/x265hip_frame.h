@@ -229,6 +229,14 @@ int x265hip_cutree_propagate(void* stream, int widthInCU, int heightInCU, int di
                              const int32_t* intraCost, const uint16_t* lowresCosts, const int32_t* invQscale, const int16_t* mvs0, const int16_t* mvs1,
                              uint16_t* propB, uint16_t* prop0, uint16_t* prop1, void* workspace, size_t workspaceBytes);
 
+/* cuTree: the last step for a picture (Lookahead::cuTreeFinish, slicetype.cpp:4098-4150; default configuration: no --hevc-aq, qg-size above 8): the qp offset of every
+ * block of the half-resolution picture from its accumulated propagateCost: qpCuTreeOffset = qpAqOffset - strength * (log2(intra + propagate) - log2(intra) + weightdelta),
+ * intra = (intraCost * invQscale + 128) >> 8, propagate = (propagateCost * fpsFactor + 128) >> 8, fpsFactor = (int)(CLIP_DURATION(averageDuration) / CLIP_DURATION(frame
+ * duration) * 256), weightdelta = 1 - weightedCostDelta when ref0Distance != 0 and weightedCostDelta > 0, strength = Lookahead::m_cuTreeStrength = 5 * (1 - qcomp).
+ * Blocks without intra cost keep their qpCuTreeOffset.  Doubles; the two log2 come from the device math library (tolerance 1e-12 against the host's). */
+int x265hip_cutree_finish(void* stream, int ncu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost, const double* qpAqOffset,
+                          int fpsFactor, double weightedCostDelta, int ref0Distance, double cuTreeStrength, double* qpCuTreeOffset);
+
 /* SAO statistics of a whole deblocked picture: SAO::calcSaoStatsCTU (encoder/sao.cpp:729-905) for one plane of every CTU, one slice,
  * bLimitSAO off.  fenc / recon point at pixel (0,0) of the source and the reconstructed plane (same stride).  Luma: planeOffset 0; a 4:2:0 chroma
  * plane: its own width / height / CTU size (picture and CTU sizes halved, sao.cpp:748-756) and planeOffset 2 (:773).  out: per CTU (raster order)

@@ -51,6 +51,7 @@ struct LA : public Lookahead
 {
     LA(x265_param* p) : Lookahead(p, NULL) {}
     using Lookahead::estimateCUPropagate;
+    using Lookahead::cuTreeFinish;
 };
 
 /* estimateFrameCost is reached through the public singleCost; the group only needs the frame list */
@@ -253,6 +254,14 @@ int main(int argc, char** argv)
             int32_t bits[2]; memcpy(bits, &fpsFactor, 8);
             rec({ referenced, seed, bits[0], bits[1], p->bEnableWeightedBiPred });
             for (int k = 0; k < 3; k++) { rec(before[k]); rec(after[k]); }
+            /* ... then Lookahead::cuTreeFinish on picture b (slicetype.cpp:4098-4150, the qgSize != 8, non-hevc-aq branch): qp offsets from the propagated costs.
+               Recorded as int32 pairs of the doubles: { strength, weightedCostDelta used, ref0Distance }, qpAqOffset (input), qpCuTreeOffset (output). */
+            const int ref0Distance = b == p1 ? b - p0 : 0;
+            if (ref0Distance) fenc->weightedCostDelta[ref0Distance - 1] = (seed & 1) ? 0.25 + 0.01 * (seed % 7) : 0.0;     /* both branches of weightdelta */
+            la.cuTreeFinish(fenc, 0.05, ref0Distance);
+            auto dbl = [&](const double* v, int n) { std::vector<int32_t> o(2 * n); memcpy(o.data(), v, 8 * (size_t)n); rec(o); };
+            const double hdr3[3] = { la.m_cuTreeStrength, ref0Distance ? fenc->weightedCostDelta[ref0Distance - 1] : 0.0, (double)ref0Distance };
+            dbl(hdr3, 3); dbl(fenc->qpAqOffset, ncu); dbl(fenc->qpCuTreeOffset, ncu);
         }
     }
     rec({ (int32_t)(nsIntra & 0xffffffff), (int32_t)(nsIntra >> 32), (int32_t)(nsCost & 0xffffffff), (int32_t)(nsCost >> 32) });

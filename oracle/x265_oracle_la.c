@@ -410,3 +410,21 @@ void xo_estimate_cu_propagate(int wcu, int hcu, int distP0 /* b - p0 */, int dis
     }
     free(scratch);
 }
+
+/* Lookahead::cuTreeFinish (slicetype.cpp:4098-4150), the branch of the default configuration (no hevc-aq, qgSize != 8): per block of the half-resolution picture
+ * the qp offset that follows from how much later pictures inherit from it.  fpsFactor = (int)(CLIP_DURATION(averageDuration) / CLIP_DURATION(frame duration) * 256);
+ * weightdelta = 1 - weightedCostDelta[ref0Distance - 1] when that is > 0, else 0.  Blocks with no intra cost keep their previous qpCuTreeOffset. */
+void xo_cutree_finish(int ncu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost, const double* qpAqOffset, int fpsFactor,
+                      double weightdelta, double strength, double* qpCuTreeOffset)
+{
+    for (int i = 0; i < ncu; i++)
+    {
+        const int intracost = (intraCost[i] * invQscale[i] + 128) >> 8;
+        if (intracost)
+        {
+            const int propagate = (propagateCost[i] * fpsFactor + 128) >> 8;
+            const double log2_ratio = log2((double)(intracost + propagate)) - log2((double)intracost) + weightdelta;
+            qpCuTreeOffset[i] = qpAqOffset[i] - strength * log2_ratio;
+        }
+    }
+}

@@ -29,6 +29,8 @@ void xo_cu_propagate_cost(int32_t* dst, const uint16_t* propagateIn, const int32
 void xo_estimate_cu_propagate(int widthInCU, int heightInCU, int distP0, int distP1, int weightedBiPred, double fpsFactor, int referenced,
                               const int32_t* intraCost, const uint16_t* lowresCosts, const int32_t* invQscale,
                               const int32_t* mvs0, const int32_t* mvs1, uint16_t* propB, uint16_t* prop0, uint16_t* prop1);
+void xo_cutree_finish(int ncu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost, const double* qpAqOffset, int fpsFactor,
+                      double weightdelta, double strength, double* qpCuTreeOffset);
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,10 @@ def run_reference(depth, frames, triples, aq):
             d["prop"] = dict(referenced=int(ph[0]), seed=int(ph[1]), fpsFactor=float(np.array([ph[2], ph[3]], np.int32).view(np.float64)[0]), weightb=int(ph[4]),
                              before=[recs[i + 1], recs[i + 3], recs[i + 5]], after=[recs[i + 2], recs[i + 4], recs[i + 6]])
             i += 7
+            dbl = lambda r: np.ascontiguousarray(r, np.int32).view(np.float64)
+            fh = dbl(recs[i])                    # Lookahead::cuTreeFinish on picture b: strength, weightedCostDelta, ref0Distance; qpAqOffset in, qpCuTreeOffset out
+            d["finish"] = dict(strength=float(fh[0]), weightedCostDelta=float(fh[1]), ref0Distance=int(fh[2]), qpAq=dbl(recs[i + 1]), qpCuTree=dbl(recs[i + 2]))
+            i += 3
         per_triple.append(d)
     return hdr, per_frame, per_triple
 

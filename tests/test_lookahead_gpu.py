@@ -213,3 +213,32 @@ def test_lookahead_slices_match_oracle(depth, size, rows):
             assert np.array_equal(mvs[2 * i + 1], o["mvs1"]) and np.array_equal(mvc[2 * i + 1], o["mvc1"])
         assert np.array_equal(lc[i], o["lowresCosts"]) and np.array_equal(rs[i], o["rowSatds"])
         assert [int(v) for v in sm[i]] == [o["costEst"], o["costEstAq"], o["intraMbs"]]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_cutree_finish_matches_oracle(depth):
+    """x265hip_cutree_finish (Lookahead::cuTreeFinish) against the oracle, which equals the reference's doubles exactly on the CPU (test_lookahead_oracle_vs_ref.py).
+    The integer part is exact; the device's log2 is allowed 1e-12 against the host's (stated tolerance: float accounting, the one place it applies in this path)."""
+    import ctypes as C
+    from x265hip_pkg.frame import FrameApi
+    api, ora = FrameApi(depth), Oracle(depth)
+    t = api.torch
+    rng = np.random.default_rng(31 + depth)
+    ncu = 34 * 60 + 7
+    ic = rng.integers(0, 20000, ncu).astype(np.int32); ic[rng.random(ncu) < 0.05] = 0          # blocks without intra cost are left alone
+    iq = rng.integers(100, 400, ncu).astype(np.int32)
+    prop = np.where(rng.random(ncu) < 0.1, rng.integers(60000, 65536, ncu), rng.integers(0, 8000, ncu)).astype(np.uint16)
+    aq = rng.normal(0, 2.0, ncu)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    for fps, wcd, dist, strength in ((12, 0.26, 1, 2.0), (320, 0.0, 2, 2.0), (256, 0.4, 0, 1.5)):
+        d_out = t.full((ncu,), -777.0, dtype=t.float64, device="cuda")
+        d_ic, d_iq, d_prop, d_aq = api.to_device(ic), api.to_device(iq), api.to_device(prop.view(np.int16)), api.to_device(aq)      # kept alive until the launch has run
+        api.h.check(api.lib.x265hip_cutree_finish(api.stream(), ncu, P(d_ic), P(d_iq), P(d_prop), P(d_aq), fps, C.c_double(wcd), dist, C.c_double(strength), P(d_out)))
+        t.cuda.synchronize()
+        exp = np.full(ncu, -777.0)
+        wd = 1.0 - wcd if dist and wcd > 0 else 0.0
+        ora.me_lib.xo_cutree_finish(ncu, C.c_void_p(ic.ctypes.data), C.c_void_p(iq.ctypes.data), C.c_void_p(prop.ctypes.data), C.c_void_p(aq.ctypes.data), fps,
+                                    C.c_double(wd), C.c_double(strength), C.c_void_p(exp.ctypes.data))
+        got = d_out.cpu().numpy()
+        assert np.array_equal(got == -777.0, exp == -777.0) and (exp == -777.0).sum() > 20
+        assert np.max(np.abs(got - exp)) <= 1e-12, np.max(np.abs(got - exp))

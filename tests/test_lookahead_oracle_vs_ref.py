@@ -1,5 +1,7 @@
 """The restated lookahead frame-cost path (oracle/x265_oracle_la.c) against the REAL reference classes
 (oracle/_ref/x265la_*: Lowres::init, LookaheadTLD::lowresIntraEstimate, CostEstimateGroup::estimateFrameCost)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -59,6 +61,16 @@ def test_lookahead_cost_matches_reference(depth, size, aq, shift):
 PROPS = [("prop", 0, 1, 1, 1, 1), ("prop", 0, 2, 3, 1, 2), ("prop", 1, 2, 3, 0, 3), ("prop", 0, 3, 3, 0, 4), ("prop", 0, 1, 3, 1, 5)]
 
 
+def _keep(a, dt):
+    a = np.ascontiguousarray(a, dt); _keep.live.append(a); return C.c_void_p(a.ctypes.data)
+_keep.live = []
+_P32 = lambda a: _keep(a, np.int32)
+_P16 = lambda a: _keep(a, np.uint16)
+def _PD(a):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return C.c_void_p(a.ctypes.data)
+
+
 @pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("size,shift", [((192, 144), (3, 2)), ((208, 120), (-9, 7)), ((64, 48), (1, 0))])
 def test_cutree_propagate_matches_reference(depth, size, shift):
@@ -79,6 +91,15 @@ def test_cutree_propagate_matches_reference(depth, size, shift):
                                ref_frames[b]["invQ"], rt["mvs0"], rt["mvs1"] if p1 > b else None, pb, a0, a1)
         for k, name in enumerate(("b", "p0", "p1")):
             assert np.array_equal(got[k].astype(np.int32), pr["after"][k]), "propagateCost of %s after %s" % (name, t)
+        # ... and Lookahead::cuTreeFinish on picture b with the propagated costs: the qp offsets as doubles, identical
+        fin = rt["finish"]
+        fps = int(256.0 / pr["fpsFactor"])            # (int)(CLIP_DURATION(averageDuration) / CLIP_DURATION(frame duration) * 256): the inverse of the propagate step's factor
+        wd = 1.0 - fin["weightedCostDelta"] if fin["ref0Distance"] and fin["weightedCostDelta"] > 0 else 0.0
+        out = np.full(g.ncu, -777.0)
+        ora.me_lib.xo_cutree_finish(g.ncu, _P32(ref_frames[b]["intraCost"]), _P32(ref_frames[b]["invQ"]), _P16(pr["after"][0].astype(np.uint16)), _PD(fin["qpAq"]), fps,
+                                    C.c_double(wd), C.c_double(fin["strength"]), _PD(out))
+        touched = out != -777.0
+        assert touched.any() and np.array_equal(out[touched], fin["qpCuTree"][touched]), "cuTreeFinish after %s" % (t,)
 
 
 def fade_clip(W, H, n, depth, seed):

@@ -843,6 +843,31 @@ extern "C" int x265hip_cutree_propagate(void* stream, int widthInCU, int heightI
     return X265HIP_OK;
 }
 
+// Lookahead::cuTreeFinish (slicetype.cpp:4098-4150, default configuration: no hevc-aq, qgSize != 8): qp offset of every block from its propagated cost.
+// Integer part exact; the two log2 of doubles are the device math library's (not guaranteed to round like the host's libm: tests state 1e-12).
+__global__ __launch_bounds__(256) void cutree_finish_kernel(int ncu, const int32_t* __restrict__ intraCost, const int32_t* __restrict__ invQscale, const uint16_t* __restrict__ prop,
+                                                            const double* __restrict__ qpAq, int fpsFactor, double weightdelta, double strength, double* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ncu) return;
+    const int intracost = (intraCost[i] * invQscale[i] + 128) >> 8;
+    if (!intracost) return;                                       // the reference leaves qpCuTreeOffset of such blocks alone
+    const int propagate = ((int)prop[i] * fpsFactor + 128) >> 8;
+    const double log2_ratio = log2((double)(intracost + propagate)) - log2((double)intracost) + weightdelta;
+    out[i] = qpAq[i] - strength * log2_ratio;
+}
+extern "C" int x265hip_cutree_finish(void* stream, int ncu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* propagateCost, const double* qpAqOffset,
+                                     int fpsFactor, double weightedCostDelta, int ref0Distance, double cuTreeStrength, double* qpCuTreeOffset)
+{
+    if (ncu <= 0) return X265HIP_OK;
+    if (!intraCost || !invQscale || !propagateCost || !qpAqOffset || !qpCuTreeOffset) { set_error("cutree_finish: bad arguments"); return X265HIP_EARG; }
+    const double weightdelta = ref0Distance && weightedCostDelta > 0 ? 1.0 - weightedCostDelta : 0.0;          // slicetype.cpp:4107-4110
+    hipLaunchKernelGGL(cutree_finish_kernel, dim3((ncu + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncu, intraCost, invQscale, propagateCost, qpAqOffset, fpsFactor, weightdelta,
+                       cuTreeStrength, qpCuTreeOffset);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
 extern "C" int x265hip_propagate_cost_row(void* stream, int32_t* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,
                                           const int32_t* invQscales, double fpsFactor, int len)
 {
