@@ -154,6 +154,9 @@ typedef struct x265hip_tq_params {
     const struct x265hip_inter_choice* choice;   /* optional (several references): the TU's MV and reference come from choice[task.mvFrom] (x265hip_inter_merge_batch): */
     int choiceList, choiceRef;   /*           only TUs whose PU chose reference choiceRef of list choiceList are processed by this call (one call per reference
                                               plane; the outputs of the other TUs are left alone); uni-directional choices only */
+    int chroma;                  /* != 0: the planes are a Cb or Cr plane of a 4:2:0 picture and the TUs chroma TUs (2^log2TrSize chroma samples): motion
+                                    compensation is Predict::predInterChromaPixel (predict.cpp:340-380: the quarter-pel luma MV read as an eighth-pel chroma MV,
+                                    4-tap filters); qp must be the CHROMA qp of the plane (the caller maps it, as Quant::setChromaQP does); subpelPlanes unused */
 } x265hip_tq_params;
 
 int x265hip_tq_batch(void* stream, int log2TrSize,

@@ -287,13 +287,14 @@ class Oracle:
         return out, mco
 
     # ---- inter TU pipeline (x265_oracle_me.c xo_tq_tu) ----
-    def tq_tu(self, log2n, cur, cstride, coff, ref, rstride, roff, mv, qp, add, quant_coeff=None, want_recon=False):
+    def tq_tu(self, log2n, cur, cstride, coff, ref, rstride, roff, mv, qp, add, quant_coeff=None, want_recon=False, chroma=False):
         n = 1 << log2n
         coeff = np.zeros(n * n, np.int16); du = np.zeros(n * n, np.int32)
         recon = np.zeros(n * n, self.pixel) if want_recon else None
         sse = C.c_uint64(0)
-        self.me_lib.xo_tq_tu.restype = C.c_uint32
-        ns = self.me_lib.xo_tq_tu(log2n, _ptr(cur, coff), _IP(cstride), _ptr(ref, roff), _IP(rstride), int(mv[0]), int(mv[1]), qp, add,
+        fn = self.me_lib.xo_tq_tu_chroma if chroma else self.me_lib.xo_tq_tu
+        fn.restype = C.c_uint32
+        ns = fn(log2n, _ptr(cur, coff), _IP(cstride), _ptr(ref, roff), _IP(rstride), int(mv[0]), int(mv[1]), qp, add,
                                   _ptr(quant_coeff) if quant_coeff is not None else None, _ptr(coeff), _ptr(du),
                                   _ptr(recon) if want_recon else None, _IP(n), C.byref(sse))
         return int(ns), coeff, du, recon, int(sse.value)

@@ -14,6 +14,7 @@
 #include "x265_oracle_la.h"
 #include "x265_oracle_me.h"
 #include <limits.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 

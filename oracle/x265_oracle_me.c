@@ -673,6 +673,17 @@ int xo_motion_estimate_sea(const xo_pixel* fencPlane, intptr_t fencStride, int w
 /* ------------------------------------------------------------------------------------------ */
 /* inter TU pipeline                                                                           */
 /* ------------------------------------------------------------------------------------------ */
+static int g_tqChroma;
+/* the same chain for a chroma TU of a 4:2:0 picture: Predict::predInterChromaPixel (predict.cpp:340-380) in place of the luma motion compensation; qp = the plane's chroma qp */
+uint32_t xo_tq_tu_chroma(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref, intptr_t refStride,
+                         int qmvx, int qmvy, int qp, int addNumerator, const int32_t* quantCoeff,
+                         int16_t* coeff, int32_t* deltaU, xo_pixel* recon, intptr_t reconStride, uint64_t* sse)
+{
+    g_tqChroma = 1;
+    const uint32_t r = xo_tq_tu(log2TrSize, cur, curStride, fref, refStride, qmvx, qmvy, qp, addNumerator, quantCoeff, coeff, deltaU, recon, reconStride, sse);
+    g_tqChroma = 0;
+    return r;
+}
 uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref, intptr_t refStride,
                   int qmvx, int qmvy, int qp, int addNumerator, const int32_t* quantCoeff,
                   int16_t* coeff, int32_t* deltaU, xo_pixel* recon, intptr_t reconStride, uint64_t* sse)
@@ -685,9 +696,24 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
     int32_t du[32 * 32], flat[32 * 32];
 
     /* predict.cpp:279-300: copy_pp | luma_hpp | luma_vpp | luma_hvpp by MV fraction */
+    if (g_tqChroma)
+    {   /* predict.cpp:340-380 (4:2:0: mvx = mv.x, mvy = mv.y in eighth-pels): copy | filter_hpp | filter_vpp | filter_hps (row-extended) + filter_vsp */
+        const xo_pixel* csrc = fref + (qmvx >> 3) + (qmvy >> 3) * refStride;
+        const int cxf = qmvx & 7, cyf = qmvy & 7;
+        if (!(cxf | cyf)) xo_copy_pp(N, N, pred, N, csrc, refStride);
+        else if (!cyf) xo_interp_hpp(4, N, N, csrc, refStride, pred, N, cxf);
+        else if (!cxf) xo_interp_vpp(4, N, N, csrc, refStride, pred, N, cyf);
+        else
+        {
+            int16_t immed[32 * (32 + 3)];
+            xo_interp_hps(4, N, N, csrc, refStride, immed, N, cxf, 1);
+            xo_interp_vsp(4, N, N, immed + N, N, pred, N, cyf);
+        }
+    }
     const xo_pixel* src = fref + (qmvx >> 2) + (qmvy >> 2) * refStride;
     int xf = qmvx & 3, yf = qmvy & 3;
-    if (!(xf | yf)) xo_copy_pp(N, N, pred, N, src, refStride);
+    if (g_tqChroma) { }
+    else if (!(xf | yf)) xo_copy_pp(N, N, pred, N, src, refStride);
     else if (!yf) xo_interp_hpp(8, N, N, src, refStride, pred, N, xf);
     else if (!xf) xo_interp_vpp(8, N, N, src, refStride, pred, N, yf);
     else xo_interp_hvpp(8, N, N, src, refStride, pred, N, xf, yf);

@@ -59,3 +59,55 @@ def test_tq_batch_matches_oracle(depth, log2n):
                 assert np.array_equal(got, e_rec), "recon: N=%d qp=%d task %d numSig %d" % (N, qp, i, e_ns)
                 assert int(sse[i]) == e_sse, "sse: N=%d qp=%d task %d" % (N, qp, i)
             kinds.add(0 if e_ns == 0 else (1 if e_ns == 1 else 2))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("log2n", [2, 3, 4, 5])
+def test_tq_batch_chroma_matches_oracle(depth, log2n):
+    """Chroma TUs of a 4:2:0 picture: motion compensation = predInterChromaPixel (predict.cpp:340-380) with the luma MV
+    read in eighth-pels; the rest of the chain is unchanged."""
+    api, ora = FrameApi(depth), Oracle(depth)
+    torch = api.torch
+    rng = np.random.default_rng(77 * depth + log2n)
+    W, H, margin = 160, 96, 40                        # the chroma plane of a 320x192 picture
+    N = 1 << log2n
+    cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 60 + log2n, margin=margin, max_shift=5)
+    cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
+    d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+    for (qp, add, recon) in [(29, 85, True), (20, 171, True), (39, 85, False), (6, 85, True)]:
+        n = 48
+        t = np.zeros(n, TU_TASK)
+        for i in range(n):
+            px = int(rng.integers(0, (W - N) // 2 + 1)) * 2; py = int(rng.integers(0, (H - N) // 2 + 1)) * 2
+            off = (margin + py) * stride + margin + px
+            t[i]["mvFrom"] = -1; t[i]["curOff"] = off; t[i]["refOff"] = off; t[i]["reconOff"] = i * N * N
+            kind = i % 6
+            if kind == 0:   mv = (8 * dx, 8 * dy)                                                    # full-pel
+            elif kind == 1: mv = (8 * dx + int(rng.integers(1, 8)), 8 * dy)                           # horizontal only
+            elif kind == 2: mv = (8 * dx, 8 * dy + int(rng.integers(1, 8)))                           # vertical only
+            elif kind == 3: mv = (int(rng.integers(-100, 101)), int(rng.integers(-100, 101)))
+            else:           mv = (8 * dx + int(rng.integers(-12, 13)), 8 * dy + int(rng.integers(-12, 13)))
+            t[i]["mv"] = mv
+        d_t = api.to_device(t)
+        d_coeff = torch.zeros(n * N * N, dtype=torch.int16, device="cuda")
+        d_ns = torch.zeros(n, dtype=torch.int32, device="cuda")
+        d_du = torch.zeros(n * N * N, dtype=torch.int32, device="cuda")
+        d_rec = torch.zeros(n * N * N, dtype=d_cur.dtype, device="cuda") if recon else None
+        d_sse = torch.zeros(n, dtype=torch.int64, device="cuda") if recon else None
+        api.tq_batch(log2n, d_cur, stride, d_ref, stride, d_t, n, qp, add, d_coeff, d_ns, delta_u=d_du,
+                     recon=d_rec, recon_stride=N, sse=d_sse, chroma=True)
+        torch.cuda.synchronize()
+        coeff = d_coeff.cpu().numpy().reshape(n, N * N); ns = d_ns.cpu().numpy(); du = d_du.cpu().numpy().reshape(n, N * N)
+        rec = d_rec.cpu().numpy().view(cur_f.dtype) if recon else None
+        sse = d_sse.cpu().numpy() if recon else None
+        coded = 0
+        for i in range(n):
+            off = int(t[i]["curOff"]); mv = (int(t[i]["mv"][0]), int(t[i]["mv"][1]))
+            e_ns, e_coeff, e_du, e_rec, e_sse = ora.tq_tu(log2n, cur_f, stride, off, ref_f, stride, off, mv, qp, add, want_recon=recon, chroma=True)
+            assert int(ns[i]) == e_ns and np.array_equal(coeff[i], e_coeff), "chroma coeff: N=%d qp=%d task %d mv %s" % (N, qp, i, mv)
+            assert np.array_equal(du[i], e_du), "chroma deltaU: N=%d qp=%d task %d" % (N, qp, i)
+            if recon:
+                assert np.array_equal(rec[i * N * N:(i + 1) * N * N], e_rec), "chroma recon: N=%d qp=%d task %d mv %s" % (N, qp, i, mv)
+                assert int(sse[i]) == e_sse, "chroma sse: N=%d qp=%d task %d" % (N, qp, i)
+            coded += e_ns > 0
+        assert coded or qp > 35

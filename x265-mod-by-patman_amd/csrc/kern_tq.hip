@@ -26,6 +26,7 @@ struct TqArgs
     const x265hip_me_result* mvSource;
     const pixel* planes; int64_t planeElems;
     const x265hip_inter_choice* choice; int choiceList, choiceRef;
+    int chroma;
 };
 
 template<int N> struct Lg { static const int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5; };
@@ -82,7 +83,13 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
 
     // ---- motion compensation into LDS (ends with a wave_sync): the reference's copy_pp | hpp | vpp | hvpp dispatch, or -- with
     //      the phase planes of this reference -- a copy of the block at the integer part of the MV out of plane 4*yFrac + xFrac ----
-    if (a.planes)
+    if (a.chroma)
+    {   // chroma TU of a 4:2:0 picture: predInterChromaPixel (4-tap filters at the eighth-pel chroma MV = the quarter-pel luma MV)
+        CCtx cc; cc.ref[0] = a.ref + tk.refOff; cc.ref[1] = cc.ref[0]; cc.rs = a.rs; cc.fenc[0] = cc.fenc[1] = nullptr; cc.pred = c.pred; cc.immed = c.immed;      // (N + 3) intermediate rows fit the luma path's (N + 7)-row buffer
+        cc.w = N; cc.h = N; cc.qpr = N >> 2; cc.nquads = (N >> 2) * N; cc.lane = lane; cc.on = true;
+        chroma_pred<64>(cc, 0, tk.mv[0], tk.mv[1]);
+    }
+    else if (a.planes)
     {
         const int f = (tk.mv[1] & 3) * 4 + (tk.mv[0] & 3);
         const pixel* src = (f ? a.planes + (int64_t)f * a.planeElems : a.ref) + tk.refOff + (intptr_t)(tk.mv[1] >> 2) * a.rs + (tk.mv[0] >> 2);
@@ -282,7 +289,7 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
     TqArgs a = { (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride, tasks, n,
                  params->qp, params->add, params->quantCoeff, params->deltaU, coeff, numSig,
                  (pixel*)reconPlane, reconStride, sse, mvSource, (const pixel*)params->subpelPlanes, params->planeElems,
-                 params->choice, params->choiceList, params->choiceRef };
+                 params->choice, params->choiceList, params->choiceRef, params->chroma };
     if (params->choice && (params->choiceList < 0 || params->choiceList > 1 || params->choiceRef < 0 || params->choiceRef > 3)) { set_error("tq_batch: bad choiceList / choiceRef"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     switch (log2TrSize)

@@ -296,6 +296,95 @@ template<class C, class V> __device__ __forceinline__ void build_pred(const C& c
 } // namespace xh
 
 namespace xh {
+// ---- chroma motion compensation of one 4:2:0 block into LDS (Predict::predInterChromaPixel, predict.cpp:340-380: copy | filter_hpp | filter_vpp |
+// filter_hps + filter_vsp by the eighth-pel MV's fractions), shared by the chroma SATD terms of the search (me_body.inc) and the chroma TUs of the TQ chain ----
+struct CCtx { const pixel* ref[2]; intptr_t rs; lpixel* fenc[2]; lpixel* pred; lshort* immed; int w, h, qpr, nquads, lane; bool on; };
+__device__ const int8_t k_chromaTaps[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+                                               { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };   // constants.cpp:258-268
+template<int G> __device__ __forceinline__ void gsync() { if (G > 64) __syncthreads(); else wave_sync(); }
+
+template<int G> __device__ __forceinline__ void chroma_pred(const CCtx& cc, int plane, int mvx, int mvy)
+{
+    const pixel* r = cc.ref[plane] + (mvx >> 3) + (intptr_t)(mvy >> 3) * cc.rs;
+    const int xf = mvx & 7, yf = mvy & 7, w = cc.w;
+    const int headRoom = XH_IF_INTERNAL_PREC - X265_DEPTH;
+    int t[4];
+    if (!(xf | yf))
+    {
+        for (int q = cc.lane; q < cc.nquads; q += G)
+        {
+            const int y = q / cc.qpr, x4 = (q - y * cc.qpr) * 4;
+            int v[4]; load4u(r + (intptr_t)y * cc.rs + x4, v); store4(cc.pred + y * w + x4, v);
+        }
+    }
+    else if (!yf || !xf)
+    {   // filter_hpp / filter_vpp (ipfilter.cpp:79-118, 164-203 with N = 4)
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = k_chromaTaps[yf ? yf : xf][i];
+        const intptr_t step = yf ? cc.rs : 1;
+        for (int q = cc.lane; q < cc.nquads; q += G)
+        {
+            const int y = q / cc.qpr, x4 = (q - y * cc.qpr) * 4;
+            const pixel* p = r + (intptr_t)y * cc.rs + x4 - step;
+            int o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) sum += (int)p[e + i * step] * t[i];
+                o[e] = clip3(0, XH_PIXEL_MAX, (int)(int16_t)((sum + 32) >> 6));
+            }
+            store4(cc.pred + y * w + x4, o);
+        }
+    }
+    else
+    {   // filter_hps (row-extended) into the 14-bit intermediate, then filter_vsp (ipfilter.cpp:120-162, 319-360 with N = 4)
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = k_chromaTaps[xf][i];
+        const int shift1 = XH_IF_FILTER_PREC - headRoom, offset1 = (int)((unsigned)-XH_IF_INTERNAL_OFFS << shift1);
+        const int nq = cc.qpr * (cc.h + 3);
+        for (int q = cc.lane; q < nq; q += G)
+        {
+            const int y = q / cc.qpr, x4 = (q - y * cc.qpr) * 4;
+            const pixel* p = r + (intptr_t)(y - 1) * cc.rs + x4 - 1;
+            int16_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                int sum = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) sum += (int)p[e + i] * t[i];
+                o[e] = (int16_t)((sum + offset1) >> shift1);
+            }
+            u32x2 pk; pk.x = (uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16); pk.y = (uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+            *(lu2*)(cc.immed + y * w + x4) = pk;
+        }
+        gsync<G>();
+#pragma unroll
+        for (int i = 0; i < 4; i++) t[i] = k_chromaTaps[yf][i];
+        const int shift2 = XH_IF_FILTER_PREC + headRoom, offset2 = (1 << (shift2 - 1)) + (XH_IF_INTERNAL_OFFS << XH_IF_FILTER_PREC);
+        for (int q = cc.lane; q < cc.nquads; q += G)
+        {
+            const int y = q / cc.qpr, x4 = (q - y * cc.qpr) * 4;
+            int sum[4] = { 0, 0, 0, 0 }, o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+            {
+                const u32x2 a = *(const lu2*)(cc.immed + (y + i) * w + x4);
+                sum[0] += (int)(int16_t)(a.x & 0xFFFF) * t[i]; sum[1] += (int)(int16_t)(a.x >> 16) * t[i];
+                sum[2] += (int)(int16_t)(a.y & 0xFFFF) * t[i]; sum[3] += (int)(int16_t)(a.y >> 16) * t[i];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = clip3(0, XH_PIXEL_MAX, (int)(int16_t)((sum[e] + offset2) >> shift2));
+            store4(cc.pred + y * w + x4, o);
+        }
+    }
+    gsync<G>();
+}
+} // namespace xh
+
+namespace xh {
 // convenience: the whole-plane (global memory) view of a context
 template<class C> __device__ __forceinline__ GView plane_view(const C& c) { GView v; v.p = c.fref; v.s = c.rs; return v; }
 template<class C> __device__ __forceinline__ void build_pred(const C& c, int qx, int qy) { build_pred(c, plane_view(c), qx, qy); }
