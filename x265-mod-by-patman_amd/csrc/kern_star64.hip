@@ -271,10 +271,11 @@ __device__ __forceinline__ uint32_t cost_batch(Shared& s, const fquad (&f)[HR], 
 
 __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict__ cur, intptr_t cs, const pixel* __restrict__ ref, intptr_t rs,
                                                         const x265hip_me_task* __restrict__ tasks, int n, const uint16_t* __restrict__ costCentre, int chr,
-                                                        int merange, x265hip_me_result* __restrict__ results, const x265hip_me_result* __restrict__ mvpSource, int dbg)
+                                                        int merange, x265hip_me_result* __restrict__ results, const x265hip_me_result* __restrict__ mvpSource, int dbgAll)
 {
+    const int dbg = dbgAll & 15;
     __shared__ __attribute__((aligned(16))) Shared s;
-    const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int item = (dbgAll & 32) ? xcd_contiguous_block(blockIdx.x, gridDim.x) : (dbgAll & 64) ? xcd_chunked_block(blockIdx.x, gridDim.x, 60) : (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (item >= n) return;
     const x265hip_me_result st = results[item];
     if (st.reserved != XH_PARKED) return;                                           // only PUs the first half parked (start stage done, search pending)

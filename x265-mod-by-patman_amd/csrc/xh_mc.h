@@ -167,6 +167,59 @@ __device__ __forceinline__ void load4u(const lpixel* p, int* v)
     v[0] = a & 0xFFFF; v[1] = a >> 16; v[2] = b & 0xFFFF; v[3] = b >> 16;
 #endif
 }
+// ---- 4x4 Hadamard of a difference block in packed 16-bit lanes (satd_4x4 / satd_8x4's transform, pixel.cpp:210-260) --------
+// Four pixels of a row travel as packed data (px4); their differences are two registers of two int16 (U, V).  Every butterfly
+// between rows and the first butterfly along the row are whole-register v_pk_add/sub_i16; the last butterfly along the row pairs the
+// halves of one register, and only sum |coef| is wanted, so it is |a + b| + |a - b| = 2 max(|a|, |b|).  10 bit: |difference| <= 1023,
+// three butterfly stages <= 8184 < 2^15; the eight maxima of a 4x4 add up to <= 65472 < 2^16.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk16(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+#if X265_DEPTH == 8
+typedef uint32_t px4;
+__device__ __forceinline__ px4 ld4p(const lpixel* p) { return *(const lu32*)p; }                                       // aligned to 4 pixels (LDS)
+__device__ __forceinline__ px4 ld4pu(const pixel* p) { uint32_t a; __builtin_memcpy(&a, p, 4); return a; }             // unaligned (global)
+__device__ __forceinline__ px4 ld4pu(const lpixel* p) { return lds_u32(p, 0); }                                         // unaligned (LDS)
+__device__ __forceinline__ px4 ld4pa(const char* base, uint32_t bo)                                                    // byte offset off a uniform base: aligned loads + funnel shift
+{
+    const uint32_t m = bo & 3u;
+    u32x2 w; __builtin_memcpy(&w, __builtin_assume_aligned(base + (size_t)(bo - m), 4), 8);
+    return __builtin_amdgcn_alignbyte(w.y, w.x, m);
+}
+// pixels (0, 2) and (1, 3) of the four, zero-extended to 16 bits
+__device__ __forceinline__ void px4_split(px4 a, s16x2& e, s16x2& o) { e = pk16(a & 0x00FF00FFu); o = pk16(__builtin_amdgcn_perm(0u, a, 0x0C030C01u)); }
+#else
+typedef u32x2 px4;
+__device__ __forceinline__ px4 ld4p(const lpixel* p) { return *(const lu2*)p; }
+__device__ __forceinline__ px4 ld4pu(const pixel* p) { u32x2 a; __builtin_memcpy(&a, p, 8); return a; }
+__device__ __forceinline__ px4 ld4pu(const lpixel* p) { u32x2 a; a.x = lds_u32(p, 0); a.y = lds_u32(p, 4); return a; }
+__device__ __forceinline__ px4 ld4pa(const char* base, uint32_t bo) { const uint32_t m = bo & 3u; return ldq_a(base + (size_t)(bo - m), m); }
+__device__ __forceinline__ void px4_split(px4 a, s16x2& e, s16x2& o) { e = pk16(a.x); o = pk16(a.y); }                  // pixels (0, 1) and (2, 3)
+#endif
+__device__ __forceinline__ void px4_diff(px4 a, px4 b, s16x2& u, s16x2& v) { s16x2 ae, ao, be, bo; px4_split(a, ae, ao); px4_split(b, be, bo); u = ae - be; v = ao - bo; }
+// max(|lo|, |hi|) of a register, in its low half
+__device__ __forceinline__ u16x2 pk_absmax(s16x2 v)
+{
+    const s16x2 a = __builtin_elementwise_abs(v), sw = a.yx;
+    return __builtin_bit_cast(u16x2, __builtin_elementwise_max(a, sw));
+}
+__device__ __forceinline__ void had4p(s16x2& a, s16x2& b, s16x2& c, s16x2& d)
+{
+    const s16x2 t0 = a + b, t1 = a - b, t2 = c + d, t3 = c - d;
+    a = t0 + t2; c = t0 - t2; b = t1 + t3; d = t1 - t3;
+}
+// sum |coef| of the 4x4 Hadamard transform of a - b, rows given as packed pixels
+__device__ __forceinline__ int had4x4_pk(const px4 (&a)[4], const px4 (&b)[4])
+{
+    s16x2 u[4], v[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) px4_diff(a[y], b[y], u[y], v[y]);
+    had4p(u[0], u[1], u[2], u[3]); had4p(v[0], v[1], v[2], v[3]);
+    u16x2 acc = 0;
+#pragma unroll
+    for (int y = 0; y < 4; y++) { acc += pk_absmax(u[y] + v[y]); acc += pk_absmax(u[y] - v[y]); }
+    return 2 * (int)acc.x;
+}
 __device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const lpixel* r /*LDS window, unaligned*/, unsigned acc)
 {
 #if X265_DEPTH == 8
