@@ -295,25 +295,46 @@ __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict_
     // searches it the general way
     if (mxx - mnx > 2 * MAXR || mxy - mny > 2 * MAXR || mxx < mnx || mxy < mny) return;
 
-    // ---- source PU, MVD cost slice, the window ----
-    {
-        const pixel* src = cur + tp->curOff;
-        for (int q = tid; q < PH * (PW / XH_UNITPX); q += 256)
-        {
-            const int y = q / (PW / XH_UNITPX), x = (q % (PW / XH_UNITPX)) * XH_UNITPX;
-            *(lu2*)((lpixel*)s.fenc + y * PW + x) = ldq(src + (intptr_t)y * cs + x);
-        }
-        for (int k = tid; k < NJ * NIC; k += 256) s.psum[k] = 0;
-        for (int k = tid; k < 2 * COST_R + 1; k += 256) s.mvc[k] = costCentre[k - COST_R];
-    }
+    // ---- source PU, MVD cost slice, the window: every global load of the set-up is issued before the first LDS store (the loads sit behind
+    //      no per-pass branch: rows past the window are clamped, not skipped -- a conditional load per pass made the 17 passes 17 exposed
+    //      round trips: 2.59 -> 2.49 ms for the launch at 4K 10 bit) ----
     const pixel* org = ref + tp->refOff + (intptr_t)mny * rs + mnx;
     const int m0 = (int)((uintptr_t)org & 3u);
     {
-        const char* src = (const char*)org - m0;
+        constexpr int FQ = PH * (PW / XH_UNITPX) / 256, MQ = (2 * COST_R + 1 + 255) / 256;
+        const pixel* src = cur + tp->curOff;
+        fquad fq[FQ];
+#pragma unroll
+        for (int i = 0; i < FQ; i++)
+        {
+            const int q = tid + 256 * i, y = q / (PW / XH_UNITPX), x = (q % (PW / XH_UNITPX)) * XH_UNITPX;
+            fq[i] = ldq(src + (intptr_t)y * cs + x);
+        }
+        const char* wsrc = (const char*)org - m0;
         const int rowB = (int)rs * (int)sizeof(pixel);
         const int rows = (mxy - mny) + PH, nd = ((((mxx - mnx) + PW) * (int)sizeof(pixel) + m0 + 3) >> 2) + 2;
-        const int q = tid % LOADQ, r0 = tid / LOADQ;
-        if (r0 < LOADROWS && 4 * q < nd)
+        const int wq = tid % LOADQ, r0 = tid / LOADQ;
+        const bool loader = r0 < LOADROWS && 4 * wq < nd;
+        u32x4 wv[LOADPASSES];
+#pragma unroll
+        for (int p = 0; p < LOADPASSES; p++)
+        {
+            const int r = min(r0 + p * LOADROWS, rows - 1);
+            wv[p] = *(const u32x4a4*)(wsrc + (size_t)r * (size_t)rowB + 16u * (unsigned)(loader ? wq : 0));
+        }
+        uint16_t mc[MQ];
+#pragma unroll
+        for (int i = 0; i < MQ; i++) mc[i] = costCentre[min(tid + 256 * i, 2 * COST_R) - COST_R];
+#pragma unroll
+        for (int i = 0; i < FQ; i++)
+        {
+            const int q = tid + 256 * i, y = q / (PW / XH_UNITPX), x = (q % (PW / XH_UNITPX)) * XH_UNITPX;
+            *(lu2*)((lpixel*)s.fenc + y * PW + x) = fq[i];
+        }
+        for (int k = tid; k < NJ * NIC; k += 256) s.psum[k] = 0;
+#pragma unroll
+        for (int i = 0; i < MQ; i++) if (tid + 256 * i < 2 * COST_R + 1) s.mvc[tid + 256 * i] = mc[i];
+        if (loader)
         {
 #pragma unroll
             for (int p = 0; p < LOADPASSES; p++)
@@ -321,12 +342,11 @@ __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict_
                 const int r = r0 + p * LOADROWS;
                 if (r < rows)
                 {
-                    const u32x4 v = *(const u32x4a4*)(src + (size_t)r * (size_t)rowB + 16u * (unsigned)q);
-                    lu32* dst = (lu32*)s.band + (4 * q) * BRP + r;
-                    dst[0] = v.x;
-                    if (4 * q + 1 < BCDW) dst[BRP] = v.y;
-                    if (4 * q + 2 < BCDW) dst[2 * BRP] = v.z;
-                    if (4 * q + 3 < BCDW) dst[3 * BRP] = v.w;
+                    lu32* dst = (lu32*)s.band + (4 * wq) * BRP + r;
+                    dst[0] = wv[p].x;
+                    if (4 * wq + 1 < BCDW) dst[BRP] = wv[p].y;
+                    if (4 * wq + 2 < BCDW) dst[2 * BRP] = wv[p].z;
+                    if (4 * wq + 3 < BCDW) dst[3 * BRP] = wv[p].w;
                 }
             }
         }
