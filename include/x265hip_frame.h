@@ -87,6 +87,15 @@ int x265hip_me_batch_chroma(void* stream, int w, int h,
                             int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
                             const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* chroma);
 
+/* MotionEstimate::diamondSearch (motion.cpp:631-773) for n PUs of one size: the full-pel predictor search of ThreadedME's first stage
+ * (Search::puMotionEstimation with isMVP, search.cpp:355-363 -- the CTU and its four sub-CUs at search range 32; the results seed m_areaBestMV for
+ * the PU searches, analysis.cpp:248-306).  Uses of x265hip_me_task: curOff, refOff, mvmin / mvmax (full pel), qmvp (the MVD origin setMVP was
+ * given; (0,0) in the reference's use); the other fields are ignored.  results[i]: mv = FULL-pel outMV, cost = the return value, mvcost = the
+ * lambda-scaled MVD cost of mv << 2.  The reference's COST_MV_X4 offsets the second loop's points twice (kern_diamond.hip header): positions up to
+ * twice the window's half-width from the PU are read, inside the plane's padding as in the reference. */
+int x265hip_diamond_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                          const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange, x265hip_me_result* results);
+
 /* ---- several references, two lists: the per-PU choice after the per-reference searches --------------------------------------------------
  * x265hip_inter_merge_batch replaces the tail of Search::puMotionEstimation / predInterSearch for 2Nx2N PUs (search.cpp:258-556): bits and cost of every
  * (list, reference) search -- listSelBits + MVP_IDX_BITS + getTUBits(ref) + BitCost::bitcost(mv - mvp), (satd - mvcost) + RDCost::getCost(bits) --, the best

@@ -255,6 +255,14 @@ class Oracle:
                                                   merange, method, subme, _ptr(costrow, half), _ptr(out), ip)
         return int(out[0]), int(out[1]), int(cost)
 
+    def diamond(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, costrow):
+        """MotionEstimate::diamondSearch (xo_diamond_search): returns (full-pel mvx, mvy, cost)"""
+        b = np.asarray(bounds, np.int32)
+        out = np.zeros(2, np.int32)
+        half = (len(costrow) - 1) // 2
+        cost = self.me_lib.xo_diamond_search(_ptr(cur, coff), _IP(cstride), w, h, _ptr(ref, roff), _IP(rstride), _ptr(b), int(qmvp[0]), int(qmvp[1]), _ptr(costrow, half), _ptr(out))
+        return int(out[0]), int(out[1]), int(cost)
+
     def me_chroma(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, mvc, merange, method, subme, costrow, cur_c, cstride_c, coff_c, ref_c, rstride_c, roff_c):
         """me() with the chroma SATD terms (4:2:0): cur_c / ref_c = (Cb, Cr) arrays, coff_c / roff_c = element offset of the PU's chroma block in both"""
         b = np.asarray(bounds, np.int32); c = np.asarray(mvc, np.int32).reshape(-1)

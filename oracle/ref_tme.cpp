@@ -21,6 +21,9 @@
  *                           cbPlaneId, crPlaneId, chromaOffset, chromaStride, cw, ch  (-1, -1, 0, 0, 0, 0 without chroma SATD),  mvc[2 * numCand] },
  *                  pixels = w * h (source PU) [+ cw * ch Cb + cw * ch Cr of the source PU]
  *   kind 3 (chroma plane snapshot of a reference picture, 4:2:0): ints and pixels as kind 1
+ *   kind 4 (MotionEstimate::diamondSearch call, motion.cpp:631-773 -- the predictor stage of ThreadedME, search.cpp:362; recorded through the same
+ *           renaming trick, -DdiamondSearch=diamondSearch_ref): ints = { planeId, w, h, blockOffset, mvmin.x, .y, mvmax.x, .y, mvp.x, .y (what setMVP
+ *           was given: the MVD origin of mvcost), qp, out.x, out.y, cost }, pixels = w * h (source PU)
  * With threaded-me=0 on the command line the calls are those of Search::predInterSearch (search.cpp:2582-2700), whose setSourcePU overload enables
  * the chroma SATD terms of subpelCompare (motion.cpp:218-247, 1805-1865) at subme >= 3.
  */
@@ -57,6 +60,30 @@ static void put(int kind, const std::vector<int32_t>& ints, const std::vector<ui
     fwrite(hdr, 4, 2, g_out); fwrite(ints.data(), 4, ints.size(), g_out); fwrite(px.data(), 2, px.size(), g_out);
 }
 
+
+/* id of the luma plane of a reference picture, snapshotting it at first sight (or when its buffer holds another picture now); g_lock held */
+static int luma_plane_id(const ReferencePlanes* ref)
+{
+    const PicYuv* rp = ref->reconPic;
+    const intptr_t stride = ref->lumaStride;
+    const int rows = rp->m_picHeight + 2 * rp->m_lumaMarginY;
+    const pixel* top = ref->fpelPlane[0] - (intptr_t)rp->m_lumaMarginY * stride - rp->m_lumaMarginX;
+    uint64_t sum = 1469598103934665603ull;
+    for (intptr_t i = 0; i < stride * rows; i++) sum = (sum ^ top[i]) * 1099511628211ull;
+    auto it = g_planes.find(ref->fpelPlane[0]);
+    if (it == g_planes.end() || it->second.sum != sum)
+    {
+        Snap s = { g_nextPlane++, sum };
+        g_planes[ref->fpelPlane[0]] = s;
+        std::vector<uint16_t> px((size_t)stride * rows);
+        for (size_t i = 0; i < px.size(); i++) px[i] = top[i];
+        put(1, { s.id, (int32_t)stride, rows, (int32_t)(rp->m_lumaMarginY * stride + rp->m_lumaMarginX), (int32_t)rp->m_picWidth, (int32_t)rp->m_picHeight }, px);
+        return s.id;
+    }
+    return it->second.id;
+}
+static int g_diamonds;
+
 /* the reference's own body, compiled from encoder/motion.cpp as the member motionEstimate_ref (see the header comment); a member cannot be declared
  * outside its class, so it is reached as a function with `this` as first argument under the member's mangled name (Itanium ABI) */
 #if X265_DEPTH == 8
@@ -76,21 +103,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     std::lock_guard<std::mutex> guard(g_lock);
     if (srcReferencePlane || !ref->reconPic) { g_skipped++; return cost; }
     const PicYuv* rp = ref->reconPic;
-    const intptr_t stride = ref->lumaStride;
-    const int rows = rp->m_picHeight + 2 * rp->m_lumaMarginY;
-    const pixel* top = ref->fpelPlane[0] - (intptr_t)rp->m_lumaMarginY * stride - rp->m_lumaMarginX;
-    uint64_t sum = 1469598103934665603ull;
-    for (intptr_t i = 0; i < stride * rows; i++) sum = (sum ^ top[i]) * 1099511628211ull;
-    auto it = g_planes.find(ref->fpelPlane[0]);
-    if (it == g_planes.end() || it->second.sum != sum)
-    {   /* first sight of this plane (or its buffer holds another picture now): snapshot */
-        Snap s = { g_nextPlane++, sum };
-        g_planes[ref->fpelPlane[0]] = s;
-        std::vector<uint16_t> px((size_t)stride * rows);
-        for (size_t i = 0; i < px.size(); i++) px[i] = top[i];
-        put(1, { s.id, (int32_t)stride, rows, (int32_t)(rp->m_lumaMarginY * stride + rp->m_lumaMarginX), (int32_t)rp->m_picWidth, (int32_t)rp->m_picHeight }, px);
-        it = g_planes.find(ref->fpelPlane[0]);
-    }
+    const int lumaId = luma_plane_id(ref);
     int cbId = -1, crId = -1, chromaOff = 0, strideC = 0, cw = 0, ch = 0;
     if (bChromaSATD)
     {   /* the chroma planes of the reference picture, snapshot like the luma plane */
@@ -120,7 +133,7 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
     for (int q = 0; q < BC_MAX_QP; q++)
         if (s_costs[q] && s_costs[q] == m_cost) qp = q;
     const int blockh = (int)(g_lumaH[partEnum]);     /* setSourcePU never sets blockheight (motion.cpp:167-247): the height follows from the partition enum */
-    std::vector<int32_t> ints = { it->second.id, blockwidth, blockh, (int32_t)blockOffset, mvmin.x, mvmin.y, mvmax.x, mvmax.y, qmvp.x, qmvp.y, numCandidates, merange,
+    std::vector<int32_t> ints = { lumaId, blockwidth, blockh, (int32_t)blockOffset, mvmin.x, mvmin.y, mvmax.x, mvmax.y, qmvp.x, qmvp.y, numCandidates, merange,
                                   searchMethod, subpelRefine, qp, (int32_t)bChromaSATD, (int32_t)maxSlices, (int32_t)m_vertRestriction, srcReferencePlane ? 1 : 0,
                                   outQMv.x, outQMv.y, cost, (int32_t)mvcost(outQMv), cbId, crId, chromaOff, strideC, cw, ch };
     for (int i = 0; i < numCandidates; i++) { ints.push_back(mvc[i].x); ints.push_back(mvc[i].y); }
@@ -132,6 +145,30 @@ int MotionEstimate::motionEstimate(ReferencePlanes* ref, const MV& mvmin, const 
             for (int x = 0; x < cw; x++) px.push_back(fencPUYuv.m_buf[c][y * fencPUYuv.m_csize + x]);
     put(2, ints, px);
     g_calls++;
+    return cost;
+}
+}
+
+
+#define XTME_DIAMOND "_ZN4x26514MotionEstimate17diamondSearch_refEPNS_15ReferencePlanesERKNS_2MVES5_RS3_"
+int diamondSearch_ref(MotionEstimate* self, ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, MV& outMV) __asm__(XTME_DIAMOND);
+namespace X265_NS {
+int MotionEstimate::diamondSearch(ReferencePlanes* ref, const MV& mvmin, const MV& mvmax, MV& outMV)
+{
+    const int cost = ::diamondSearch_ref(this, ref, mvmin, mvmax, outMV);
+    if (!g_out || ref->isLowres || ref->isHMELowres || !ref->reconPic) return cost;
+    std::lock_guard<std::mutex> guard(g_lock);
+    const int lumaId = luma_plane_id(ref);
+    int qp = -1;
+    for (int q = 0; q < BC_MAX_QP; q++)
+        if (s_costs[q] && s_costs[q] == m_cost) qp = q;
+    const int blockh = (int)(g_lumaH[partEnum]);
+    std::vector<int32_t> ints = { lumaId, blockwidth, blockh, (int32_t)blockOffset, mvmin.x, mvmin.y, mvmax.x, mvmax.y, m_mvp.x, m_mvp.y, qp, outMV.x, outMV.y, cost };
+    std::vector<uint16_t> px((size_t)blockwidth * blockh);
+    for (int y = 0; y < blockh; y++)
+        for (int x = 0; x < blockwidth; x++) px[(size_t)y * blockwidth + x] = fencPUYuv.m_buf[0][y * FENC_STRIDE + x];
+    put(4, ints, px);
+    g_diamonds++;
     return cost;
 }
 }
@@ -198,6 +235,6 @@ int main(int argc, char** argv)
     x265_param_free(live);
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(g_out);
-    printf("{\"calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_nextPlane, g_skipped, tme);
+    printf("{\"calls\": %d, \"diamond_calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_diamonds, g_nextPlane, g_skipped, tme);
     return 0;
 }

@@ -10,6 +10,7 @@
  * (oracle/_ref, op "me" / "mvcost_row") by tests/test_me_oracle_vs_ref.py.
  */
 #include "x265_oracle_me.h"
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -200,6 +201,99 @@ static void star_pattern(const me_t* m, mv_t mvmin, mv_t mvmax, star_t* s, int e
 
 #define COST_MV(mx_, my_) do { int c_ = sad_at(m, (mx_), (my_)) + mvcost(m, (mx_) * 4, (my_) * 4); \
     if (c_ < bcost) { bcost = c_; bmv.x = (mx_); bmv.y = (my_); } } while (0)
+
+/* MotionEstimate::diamondSearch (motion.cpp:631-773): the full-pel predictor search of ThreadedME's first stage (search.cpp:355-363, range 32, MVP (0,0)).
+ * It starts from bmv = (0,0) with bcost = INT_MAX WITHOUT costing (0,0); a first loop of distances 1, 2, 4 always around omv = (0,0) (omv is
+ * not moved inside it), then distances 8 .. 64 around the best so far, each ending when the best did not move.  Away from the window's edge the
+ * points go through COST_MV_X4 (:307-328), whose arguments are OFFSETS from omv -- but diamondSearch passes absolute coordinates (omv.x, top ...),
+ * so in the second loop, where omv != 0, the measured positions are omv + (absolute coordinate): the restatement keeps that, and the macro's
+ * vertical range test `omv.y + my in [mvmin.y, mvmax.y]` with no horizontal one.  Returns bcost, outMv = full-pel MV. */
+int xo_diamond_search(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h, const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
+                      int qmvpx, int qmvpy, const uint16_t* costRowCentre, int32_t* outMv)
+{
+    me_t mm; me_t* m = &mm;
+    m->fref = fref; m->stride = refStride; m->w = w; m->h = h; m->cost = costRowCentre; m->mvp.x = qmvpx; m->mvp.y = qmvpy; m->chroma = 0;
+    for (int y = 0; y < h; y++) memcpy(m->fenc + y * 64, fencPlane + y * fencStride, w * sizeof(xo_pixel));
+    const mv_t mvmin = { bounds[0], bounds[1] }, mvmax = { bounds[2], bounds[3] };
+    int bcost = INT_MAX;
+    mv_t bmv = { 0, 0 }, omv = bmv;
+#define DX4(a0, a1, b0, b1, c0, c1, d0, d1) do { const int o_[4][2] = { { a0, a1 }, { b0, b1 }, { c0, c1 }, { d0, d1 } }; int c_[4]; \
+        for (int k_ = 0; k_ < 4; k_++) c_[k_] = sad_at(m, omv.x + o_[k_][0], omv.y + o_[k_][1]) + mvcost(m, (omv.x + o_[k_][0]) * 4, (omv.y + o_[k_][1]) * 4); \
+        for (int k_ = 0; k_ < 4; k_++) if (omv.y + o_[k_][1] >= mvmin.y && omv.y + o_[k_][1] <= mvmax.y && c_[k_] < bcost) \
+            { bcost = c_[k_]; bmv.x = omv.x + o_[k_][0]; bmv.y = omv.y + o_[k_][1]; } } while (0)
+    for (int dist = 1; dist <= 4; dist <<= 1)
+    {
+        const mv_t bmv0 = bmv;
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        const int top2 = omv.y - (dist >> 1), bottom2 = omv.y + (dist >> 1), left2 = omv.x - (dist >> 1), right2 = omv.x + (dist >> 1);
+        if (top >= mvmin.y && left >= mvmin.x && right <= mvmax.x && bottom <= mvmax.y)
+        {
+            DX4(omv.x, top, omv.x, bottom, left, omv.y, right, omv.y);
+            DX4(left2, top2, right2, top2, left2, bottom2, right2, bottom2);
+        }
+        else
+        {
+            if (top >= mvmin.y) COST_MV(omv.x, top);
+            if (top2 >= mvmin.y)
+            {
+                if (left2 >= mvmin.x) COST_MV(left2, top2);
+                if (right2 <= mvmax.x) COST_MV(right2, top2);
+            }
+            if (left >= mvmin.x) COST_MV(left, omv.y);
+            if (right <= mvmax.x) COST_MV(right, omv.y);
+            if (bottom2 <= mvmax.y)
+            {
+                if (left2 >= mvmin.x) COST_MV(left2, bottom2);
+                if (right2 <= mvmax.x) COST_MV(right2, bottom2);
+            }
+            if (bottom <= mvmax.y) COST_MV(omv.x, bottom);
+        }
+        if (bmv.x == bmv0.x && bmv.y == bmv0.y) break;
+    }
+    omv = bmv;
+    for (int dist = 8; dist <= 64; dist += 8)
+    {
+        const mv_t bmv0 = bmv;
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        if (top >= mvmin.y && left >= mvmin.x && right <= mvmax.x && bottom <= mvmax.y)
+        {
+            DX4(omv.x, top, left, omv.y, right, omv.y, omv.x, bottom);
+            for (int index = 1; index < 4; index++)
+            {
+                const int posYT = top + ((dist >> 2) * index), posYB = bottom - ((dist >> 2) * index);
+                const int posXL = omv.x - ((dist >> 2) * index), posXR = omv.x + ((dist >> 2) * index);
+                DX4(posXL, posYT, posXR, posYT, posXL, posYB, posXR, posYB);
+            }
+        }
+        else
+        {
+            if (top >= mvmin.y) COST_MV(omv.x, top);
+            if (left >= mvmin.x) COST_MV(left, omv.y);
+            if (right <= mvmax.x) COST_MV(right, omv.y);
+            if (bottom <= mvmax.y) COST_MV(omv.x, bottom);
+            for (int index = 1; index < 4; index++)
+            {
+                const int posYT = top + ((dist >> 2) * index), posYB = bottom - ((dist >> 2) * index);
+                const int posXL = omv.x - ((dist >> 2) * index), posXR = omv.x + ((dist >> 2) * index);
+                if (posYT >= mvmin.y)
+                {
+                    if (posXL >= mvmin.x) COST_MV(posXL, posYT);
+                    if (posXR <= mvmax.x) COST_MV(posXR, posYT);
+                }
+                if (posYB <= mvmax.y)
+                {
+                    if (posXL >= mvmin.x) COST_MV(posXL, posYB);
+                    if (posXR <= mvmax.x) COST_MV(posXR, posYB);
+                }
+            }
+        }
+        if (bmv.x == bmv0.x && bmv.y == bmv0.y) break;
+        omv = bmv;
+    }
+#undef DX4
+    outMv[0] = bmv.x; outMv[1] = bmv.y;
+    return bcost;
+}
 
 /* encoder/framefilter.cpp:38-139 (integral_init{4,8,12,16,24,32}{h,v}_c) driven the way FrameFilter::processPostRow drives them
  * (:740-833) over a whole padded picture: plane k holds, at every position whose box lies inside the padded picture, the sum of

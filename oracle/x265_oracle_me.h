@@ -47,6 +47,9 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
                   int qmvx, int qmvy, int qp, int addNumerator /*171 or 85*/, const int32_t* quantCoeff,
                   int16_t* coeff /*N*N*/, int32_t* deltaU /*N*N or NULL*/,
                   xo_pixel* recon /*or NULL*/, intptr_t reconStride, uint64_t* sse);
+/* MotionEstimate::diamondSearch (motion.cpp:631-773); bounds and outMv in full pels; qmvp = the MVD origin of mvcost (setMVP) */
+int xo_diamond_search(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h, const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
+                      int qmvpx, int qmvpy, const uint16_t* costRowCentre, int32_t* outMv);
 uint32_t xo_tq_tu_chroma(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref, intptr_t refStride,
                          int qmvx, int qmvy, int qp, int addNumerator, const int32_t* quantCoeff,
                          int16_t* coeff, int32_t* deltaU, xo_pixel* recon, intptr_t reconStride, uint64_t* sse);

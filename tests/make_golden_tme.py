@@ -15,7 +15,10 @@ CALL_FIELDS = ("plane w h blockOffset mnx mny mxx mxy qmvpx qmvpy numCand merang
                "srcPlane outx outy cost mvcost cbPlane crPlane chromaOffset chromaStride cw ch").split()
 
 
-def parse(path):
+DIA_FIELDS = "plane w h blockOffset mnx mny mxx mxy mvpx mvpy qp outx outy cost".split()
+
+
+def parse(path, dias=None):
     d = np.fromfile(path, np.uint8).tobytes()
     off, planes, calls, mvcs, blocks = 0, {}, [], [], []
     while off < len(d):
@@ -25,6 +28,10 @@ def parse(path):
             pid, stride, rows = int(ints[0]), int(ints[1]), int(ints[2])
             px = np.frombuffer(d, np.uint16, stride * rows, off).copy(); off += 2 * stride * rows
             planes[pid] = (ints, px)
+        elif kind == 4:
+            npx = int(ints[1]) * int(ints[2])
+            px = np.frombuffer(d, np.uint16, npx, off).copy(); off += 2 * npx
+            if dias is not None: dias.append((ints, px))
         else:
             w, h = int(ints[1]), int(ints[2])
             npx = w * h + 2 * int(ints[27]) * int(ints[28])          # luma block [+ Cb + Cr blocks of the source PU]
@@ -55,10 +62,38 @@ def build(depth, args, out):
     return calls
 
 
+def build_dia(depth, args, out):
+    """dia_{8,10}.npz: the MotionEstimate::diamondSearch calls (ThreadedME's predictor stage, search.cpp:355-363) of a --threaded-me encode"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265tme_%d" % depth)
+    dias = []
+    with tempfile.TemporaryDirectory() as td:
+        raw = os.path.join(td, "tme.bin")
+        subprocess.check_call([exe] + args[:4] + [raw] + args[4:], stdout=subprocess.DEVNULL)
+        planes, _, _, _ = parse(raw, dias)
+    dt = np.uint8 if depth == 8 else np.uint16
+    calls = np.stack([i for i, _ in dias]).astype(np.int32)
+    used = set(int(v) for v in calls[:, 0])
+    starts = np.concatenate([[0], np.cumsum([len(b) for _, b in dias])]).astype(np.int64)
+    data = {"fields": np.array(DIA_FIELDS), "calls": calls, "fenc": np.concatenate([b for _, b in dias]).astype(dt), "fenc_start": starts, "cmdline": np.array(" ".join(args))}
+    for pid, (ints, px) in planes.items():
+        if pid in used:
+            data["plane%d_geom" % pid] = ints
+            data["plane%d" % pid] = px.astype(dt)
+    np.savez_compressed(out, **data)
+    return calls
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "tme"])
     # tme_*: --threaded-me encodes (luma-only searches of puMotionEstimation); mec_*: regular encodes whose predInterSearch searches carry the chroma
     # SATD terms (subme >= 3), incl. weighted / several references and B pictures
+    for depth, args in ((8, ["256", "192", "4", "medium"]), (10, ["256", "192", "4", "slow", "amp=0", "rect=0"])):
+        out = os.path.join(ROOT, "tests", "golden", "dia_%d.npz" % depth)
+        c = build_dia(depth, args, out)
+        f = {n: c[:, i] for i, n in enumerate(DIA_FIELDS)}
+        print("dia", depth, "calls", len(c), "size", os.path.getsize(out), "shapes", sorted({(int(a), int(b)) for a, b in zip(f["w"], f["h"])}), "out range", f["outx"].min(), f["outx"].max(), f["outy"].min(), f["outy"].max(),
+              "mvp", np.unique(f["mvpx"]), np.unique(f["mvpy"]))
+    if "--dia-only" in sys.argv: sys.exit(0)
     for name, depth, args in (("tme", 8, ["128", "128", "3", "medium"]), ("tme", 10, ["128", "128", "3", "slow", "amp=0"]),
                               ("mec", 8, ["128", "64", "4", "slow", "threaded-me=0", "rect=0", "amp=0", "bframes=1"]),
                               ("mec", 10, ["128", "64", "4", "slower", "threaded-me=0", "rect=0", "amp=0", "bframes=1", "me=hex"])):

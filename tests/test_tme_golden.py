@@ -53,3 +53,26 @@ def test_oracle_replays_the_chroma_satd_searches_of_a_reference_encode(depth):
                             (u, v), cw, 0, (cb["px"], cr["px"]), cb["stride"], cb["origin"] + int(c["chromaOffset"][i]))
         exp = (int(c["outx"][i]), int(c["outy"][i]), int(c["cost"][i]))
         assert got == exp, "call %d (%dx%d, subme %d): oracle %s reference %s" % (i, w, h, int(c["subme"][i]), got, exp)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_replays_the_diamond_searches_of_a_reference_encode(depth):
+    """MotionEstimate::diamondSearch (motion.cpp:631-773), the predictor stage of ThreadedME (search.cpp:355-363): every recorded call, including the
+    second loop's positions that COST_MV_X4 offsets twice (xo_diamond_search's header)."""
+    from tme_util import DiaFixture
+    fx, ora = DiaFixture(depth), Oracle(depth)
+    c = fx.col
+    assert len(fx) >= 300
+    rows, moved, far = {}, 0, 0
+    for i in range(len(fx)):
+        qp = int(c["qp"][i])
+        if qp not in rows:
+            rows[qp] = ora.mvcost_row(qp, 1 << 14)
+        pl = fx.planes[int(c["plane"][i])]
+        w, h = int(c["w"][i]), int(c["h"][i])
+        got = ora.diamond(w, h, fx.block(i), w, 0, pl["px"], pl["stride"], pl["origin"] + int(c["blockOffset"][i]),
+                          [int(c["mnx"][i]), int(c["mny"][i]), int(c["mxx"][i]), int(c["mxy"][i])], (int(c["mvpx"][i]), int(c["mvpy"][i])), rows[qp])
+        exp = (int(c["outx"][i]), int(c["outy"][i]), int(c["cost"][i]))
+        assert got == exp, "call %d (%dx%d): oracle %s reference %s" % (i, w, h, got, exp)
+        moved += exp[:2] != (0, 0); far += max(abs(exp[0]), abs(exp[1])) > 8
+    assert moved > 100 and far > 20          # the second loop (distances 8..64 around a moved centre) is exercised

@@ -98,3 +98,58 @@ def test_me_batch_chroma_replays_the_searches_of_pred_inter_search(depth):
             w, h, method, subme, len(bad), n, idx[bad[0]], r[bad[0]], c["outx"][idx[bad[0]]], c["outy"][idx[bad[0]]], c["cost"][idx[bad[0]]])
         checked += n
     assert checked == len(fx)
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_diamond_batch_replays_the_predictor_searches_of_threaded_me(depth):
+    """MotionEstimate::diamondSearch (motion.cpp:631-773): the recorded calls of ThreadedME's first stage (the CTU and its four sub-CUs, range 32)
+    through x265hip_diamond_batch -- full-pel MV and cost must be the reference's; plus synthetic windows cut by the picture edge (the per-point
+    branches) against the oracle, which the golden test pins to the same records."""
+    from tme_util import DiaFixture
+    from backends import Oracle
+    fx, api, ora = DiaFixture(depth), FrameApi(depth), Oracle(depth)
+    T = api.torch
+    c = fx.col
+    half = 1 << 14
+    rows, rows_h = {}, {}
+    checked = 0
+    keys = {}
+    for i in range(len(fx)):
+        keys.setdefault((int(c["plane"][i]), int(c["w"][i]), int(c["h"][i]), int(c["qp"][i])), []).append(i)
+    for (pid, w, h, qp), idx in keys.items():
+        pl = fx.planes[pid]
+        n = len(idx)
+        t = np.zeros(n, ME_TASK)
+        cur = np.concatenate([fx.block(i) for i in idx])
+        t["curOff"] = np.arange(n) * (w * h)
+        t["refOff"] = pl["origin"] + c["blockOffset"][idx]
+        t["mvmin"][:, 0] = c["mnx"][idx]; t["mvmin"][:, 1] = c["mny"][idx]; t["mvmax"][:, 0] = c["mxx"][idx]; t["mvmax"][:, 1] = c["mxy"][idx]
+        t["qmvp"][:, 0] = c["mvpx"][idx]; t["qmvp"][:, 1] = c["mvpy"][idx]
+        if qp not in rows:
+            rows_h[qp] = mvcost_row(depth, qp, half)
+            rows[qp] = api.to_device(rows_h[qp].view(np.int16))
+        d_t, d_cur, d_ref = api.to_device(t), api.to_device(cur), api.to_device(pl["px"])
+        d_res = T.zeros(n * ME_RESULT.itemsize, dtype=T.uint8, device="cuda")
+        api.diamond_batch(w, h, d_cur, w, d_ref, pl["stride"], d_t, n, rows[qp], half, d_res)
+        T.cuda.synchronize()
+        r = d_res.cpu().numpy().view(ME_RESULT)
+        bad = np.nonzero((r["mv"][:, 0] != c["outx"][idx]) | (r["mv"][:, 1] != c["outy"][idx]) | (r["cost"] != c["cost"][idx]))[0]
+        assert len(bad) == 0, "%dx%d plane %d: %d of %d differ, first: call %d hip %s reference (%d, %d, %d)" % (
+            w, h, pid, len(bad), n, idx[bad[0]], r[bad[0]], c["outx"][idx[bad[0]]], c["outy"][idx[bad[0]]], c["cost"][idx[bad[0]]])
+        checked += n
+        # the same PUs with narrow / lopsided windows and a non-zero MVD origin: oracle as the expectation
+        rng = np.random.default_rng(depth * 100 + w)
+        t2 = t.copy()
+        for k in range(n):
+            t2["mvmin"][k] = (-int(rng.integers(0, 20)), -int(rng.integers(0, 20))); t2["mvmax"][k] = (int(rng.integers(0, 20)), int(rng.integers(0, 20)))
+            t2["qmvp"][k] = (int(rng.integers(-40, 41)), int(rng.integers(-40, 41)))
+        d_t2 = api.to_device(t2)
+        api.diamond_batch(w, h, d_cur, w, d_ref, pl["stride"], d_t2, n, rows[qp], half, d_res)
+        T.cuda.synchronize()
+        r = d_res.cpu().numpy().view(ME_RESULT)
+        for k in range(0, n, 3):
+            exp = ora.diamond(w, h, cur, w, int(t2["curOff"][k]), pl["px"], pl["stride"], int(t2["refOff"][k]),
+                              [int(t2["mvmin"][k][0]), int(t2["mvmin"][k][1]), int(t2["mvmax"][k][0]), int(t2["mvmax"][k][1])], (int(t2["qmvp"][k][0]), int(t2["qmvp"][k][1])), rows_h[qp])
+            got = (int(r["mv"][k][0]), int(r["mv"][k][1]), int(r["cost"][k]))
+            assert got == exp, "edge window, task %d: hip %s oracle %s (bounds %s %s)" % (k, got, exp, t2["mvmin"][k], t2["mvmax"][k])
+    assert checked >= 300

@@ -59,3 +59,26 @@ class MecFixture(TmeFixture):
         w, h, cw, ch = int(c["w"][i]), int(c["h"][i]), int(c["cw"][i]), int(c["ch"][i])
         b = self.fenc[self.start[i]:self.start[i + 1]]
         return b[:w * h], b[w * h:w * h + cw * ch], b[w * h + cw * ch:]
+
+
+class DiaFixture:
+    """tests/golden/dia_{8,10}.npz: the MotionEstimate::diamondSearch calls of a --threaded-me encode (ThreadedME's predictor stage)"""
+    def __init__(self, depth):
+        d = np.load(os.path.join(GOLD, "dia_%d.npz" % depth))
+        self.depth = depth
+        self.fields = [str(f) for f in d["fields"]]
+        self.calls = d["calls"]
+        self.col = {n: self.calls[:, i] for i, n in enumerate(self.fields)}
+        self.fenc, self.start = d["fenc"], d["fenc_start"]
+        self.planes = {}
+        for k in d.files:
+            if k.startswith("plane") and k.endswith("_geom"):
+                pid = int(k[5:-5])
+                g = d[k]
+                self.planes[pid] = dict(stride=int(g[1]), rows=int(g[2]), origin=int(g[3]), width=int(g[4]), height=int(g[5]), px=d["plane%d" % pid])
+
+    def __len__(self):
+        return len(self.calls)
+
+    def block(self, i):
+        return self.fenc[self.start[i]:self.start[i + 1]]

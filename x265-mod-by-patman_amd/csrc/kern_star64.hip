@@ -550,8 +550,14 @@ __global__ __launch_bounds__(256, 2) void star64_raster_kernel(const pixel* __re
             __syncthreads();                                                        // the previous pass is done with the band and the sums
             for (int k = tid; k < NJ * NIC; k += 256) s.psum[k] = 0;
             {
+                // as in star64_kernel: all loads of the chunk's window in flight before the first LDS store
                 const int q = tid % LOADQ, r0 = tid / LOADQ;
-                if (r0 < LOADROWS && 4 * q < nd)
+                const bool loader = r0 < LOADROWS && 4 * q < nd;
+                u32x4 wv[LOADPASSES];
+#pragma unroll
+                for (int p = 0; p < LOADPASSES; p++)
+                    wv[p] = *(const u32x4a4*)(src + (size_t)min(r0 + p * LOADROWS, rows - 1) * (size_t)rowB + 16u * (unsigned)(loader ? q : 0));
+                if (loader)
                 {
 #pragma unroll
                     for (int p = 0; p < LOADPASSES; p++)
@@ -559,12 +565,11 @@ __global__ __launch_bounds__(256, 2) void star64_raster_kernel(const pixel* __re
                         const int r = r0 + p * LOADROWS;
                         if (r < rows)
                         {
-                            const u32x4 v = *(const u32x4a4*)(src + (size_t)r * (size_t)rowB + 16u * (unsigned)q);
                             lu32* dst = (lu32*)s.band + (4 * q) * BRP + r;
-                            dst[0] = v.x;
-                            if (4 * q + 1 < BCDW) dst[BRP] = v.y;
-                            if (4 * q + 2 < BCDW) dst[2 * BRP] = v.z;
-                            if (4 * q + 3 < BCDW) dst[3 * BRP] = v.w;
+                            dst[0] = wv[p].x;
+                            if (4 * q + 1 < BCDW) dst[BRP] = wv[p].y;
+                            if (4 * q + 2 < BCDW) dst[2 * BRP] = wv[p].z;
+                            if (4 * q + 3 < BCDW) dst[3 * BRP] = wv[p].w;
                         }
                     }
                 }

@@ -133,6 +133,11 @@ class FrameApi:
         self.h.check(self.lib.x265hip_me_batch_chroma(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride), _dp(tasks), n,
                                                       _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source), _dp(planes), C.c_int64(plane_elems), C.byref(ch)))
 
+    def diamond_batch(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half_range, results):
+        """x265hip_diamond_batch: MotionEstimate::diamondSearch for n PUs (full-pel MV, cost)"""
+        self.h.check(self.lib.x265hip_diamond_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride), _dp(tasks), n,
+                                                    _dp(cost_row), half_range, _dp(results)))
+
     def inter_merge_batch(self, w, h, cur, cstride, rstride, tasks, n, results, mvp_sources, planes, plane_elems, bits_row, bits_half, lam, bidir, source_max_dim, out):
         """x265hip_inter_merge_batch; results / mvp_sources / planes: [list][ref] nested lists of tensors (or None)."""
         p = MergeParams()
