@@ -166,6 +166,10 @@ typedef struct x265hip_tq_params {
     int chroma;                  /* != 0: the planes are a Cb or Cr plane of a 4:2:0 picture and the TUs chroma TUs (2^log2TrSize chroma samples): motion
                                     compensation is Predict::predInterChromaPixel (predict.cpp:340-380: the quarter-pel luma MV read as an eighth-pel chroma MV,
                                     4-tap filters); qp must be the CHROMA qp of the plane (the caller maps it, as Quant::setChromaQP does); subpelPlanes unused */
+    const void* refPlane1;       /* != NULL: a BI-DIRECTIONAL launch (needs choice): refPlane is reference choiceRef of list 0, refPlane1 reference choiceRef1 of
+                                    list 1 (same stride, the tasks' refOff); only TUs whose PU chose exactly that pair are processed; motion compensation is
+                                    the B-slice branch of Predict::motionCompensation (predict.cpp:186-211): predInterLumaShort of both (14-bit) -> addAvg */
+    int choiceRef1;
 } x265hip_tq_params;
 
 int x265hip_tq_batch(void* stream, int log2TrSize,

@@ -295,6 +295,17 @@ class Oracle:
         return out, mco
 
     # ---- inter TU pipeline (x265_oracle_me.c xo_tq_tu) ----
+    def tq_tu_bi(self, log2n, cur, cstride, coff, ref0, ref1, rstride, roff, mv0, mv1, qp, add, want_recon=False):
+        n = 1 << log2n
+        coeff = np.zeros(n * n, np.int16); du = np.zeros(n * n, np.int32)
+        recon = np.zeros(n * n, self.pixel) if want_recon else None
+        sse = C.c_uint64(0)
+        fn = self.me_lib.xo_tq_tu_bi
+        fn.restype = C.c_uint32
+        ns = fn(log2n, _ptr(cur, coff), _IP(cstride), _ptr(ref0, roff), _ptr(ref1, roff), _IP(rstride), int(mv0[0]), int(mv0[1]), int(mv1[0]), int(mv1[1]), qp, add,
+                None, _ptr(coeff), _ptr(du), _ptr(recon) if want_recon else None, _IP(n), C.byref(sse))
+        return int(ns), coeff, du, recon, int(sse.value)
+
     def tq_tu(self, log2n, cur, cstride, coff, ref, rstride, roff, mv, qp, add, quant_coeff=None, want_recon=False, chroma=False):
         n = 1 << log2n
         coeff = np.zeros(n * n, np.int16); du = np.zeros(n * n, np.int32)

@@ -768,6 +768,32 @@ int xo_motion_estimate_sea(const xo_pixel* fencPlane, intptr_t fencStride, int w
 /* inter TU pipeline                                                                           */
 /* ------------------------------------------------------------------------------------------ */
 static int g_tqChroma;
+static const xo_pixel* g_tqRef1; static int g_tqMv1x, g_tqMv1y;
+/* Predict::predInterLumaShort (predict.cpp:302-338) */
+static void mc_luma_short(const xo_pixel* fref, intptr_t stride, int N, int qx, int qy, int16_t* dst)
+{
+    const xo_pixel* src = fref + (qx >> 2) + (qy >> 2) * stride;
+    const int xf = qx & 3, yf = qy & 3;
+    if (!(xf | yf)) xo_p2s(N, N, src, stride, dst, N);
+    else if (!yf) xo_interp_hps(8, N, N, src, stride, dst, N, xf, 0);
+    else if (!xf) xo_interp_vps(8, N, N, src, stride, dst, N, yf);
+    else
+    {
+        int16_t immed[32 * (32 + 7)];
+        xo_interp_hps(8, N, N, src, stride, immed, N, xf, 1);
+        xo_interp_vss(8, N, N, immed + 3 * N, N, dst, N, yf);
+    }
+}
+/* the same chain for a bi-directionally predicted TU: the B-slice branch of Predict::motionCompensation (predict.cpp:186-211) -- two 14-bit predictions, addAvg */
+uint32_t xo_tq_tu_bi(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref0, const xo_pixel* fref1, intptr_t refStride,
+                     int qmv0x, int qmv0y, int qmv1x, int qmv1y, int qp, int addNumerator, const int32_t* quantCoeff,
+                     int16_t* coeff, int32_t* deltaU, xo_pixel* recon, intptr_t reconStride, uint64_t* sse)
+{
+    g_tqRef1 = fref1; g_tqMv1x = qmv1x; g_tqMv1y = qmv1y;
+    const uint32_t r = xo_tq_tu(log2TrSize, cur, curStride, fref0, refStride, qmv0x, qmv0y, qp, addNumerator, quantCoeff, coeff, deltaU, recon, reconStride, sse);
+    g_tqRef1 = NULL;
+    return r;
+}
 /* the same chain for a chroma TU of a 4:2:0 picture: Predict::predInterChromaPixel (predict.cpp:340-380) in place of the luma motion compensation; qp = the plane's chroma qp */
 uint32_t xo_tq_tu_chroma(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref, intptr_t refStride,
                          int qmvx, int qmvy, int qp, int addNumerator, const int32_t* quantCoeff,
@@ -790,7 +816,14 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
     int32_t du[32 * 32], flat[32 * 32];
 
     /* predict.cpp:279-300: copy_pp | luma_hpp | luma_vpp | luma_hvpp by MV fraction */
-    if (g_tqChroma)
+    if (g_tqRef1)
+    {
+        int16_t s0[32 * 32], s1[32 * 32];
+        mc_luma_short(fref, refStride, N, qmvx, qmvy, s0);
+        mc_luma_short(g_tqRef1, refStride, N, g_tqMv1x, g_tqMv1y, s1);
+        xo_addAvg(N, N, s0, s1, pred, N, N, N);
+    }
+    else if (g_tqChroma)
     {   /* predict.cpp:340-380 (4:2:0: mvx = mv.x, mvy = mv.y in eighth-pels): copy | filter_hpp | filter_vpp | filter_hps (row-extended) + filter_vsp */
         const xo_pixel* csrc = fref + (qmvx >> 3) + (qmvy >> 3) * refStride;
         const int cxf = qmvx & 7, cyf = qmvy & 7;
@@ -806,7 +839,7 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
     }
     const xo_pixel* src = fref + (qmvx >> 2) + (qmvy >> 2) * refStride;
     int xf = qmvx & 3, yf = qmvy & 3;
-    if (g_tqChroma) { }
+    if (g_tqChroma || g_tqRef1) { }
     else if (!(xf | yf)) xo_copy_pp(N, N, pred, N, src, refStride);
     else if (!yf) xo_interp_hpp(8, N, N, src, refStride, pred, N, xf);
     else if (!xf) xo_interp_vpp(8, N, N, src, refStride, pred, N, yf);

@@ -111,3 +111,60 @@ def test_tq_batch_chroma_matches_oracle(depth, log2n):
                 assert int(sse[i]) == e_sse, "chroma sse: N=%d qp=%d task %d" % (N, qp, i)
             coded += e_ns > 0
         assert coded or qp > 35
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("log2n", [2, 3, 4, 5])
+def test_tq_batch_bidirectional_matches_oracle(depth, log2n):
+    """Bi-directionally predicted TUs: two 14-bit predictions (Predict::predInterLumaShort: p2s | hps | vps | hps + vss) -> addAvg (predict.cpp:186-211).
+    The launch takes the TUs whose PU chose exactly (list-0 reference 1, list-1 reference 0); TUs of other choices keep their output untouched."""
+    from x265hip_pkg.frame import INTER_CHOICE
+    api, ora = FrameApi(depth), Oracle(depth)
+    torch = api.torch
+    rng = np.random.default_rng(500 * depth + log2n)
+    W, H, margin = 256, 128, 48
+    N = 1 << log2n
+    cur, ref0, stride, (dx, dy) = frame_pair(W, H, depth, 70 + log2n, margin=margin, max_shift=6)
+    _, ref1, _, (ex, ey) = frame_pair(W, H, depth, 70 + log2n, margin=margin, max_shift=6)      # same source picture, another displacement draw
+    ref1 = np.ascontiguousarray(ref1[::-1, ::-1]) if np.array_equal(ref0, ref1) else ref1     # (identical draws would make the average trivial)
+    cur_f, r0_f, r1_f = cur.reshape(-1), ref0.reshape(-1), ref1.reshape(-1)
+    d_cur, d_r0, d_r1 = api.to_device(cur_f), api.to_device(r0_f), api.to_device(r1_f)
+    for (qp, recon) in [(27, True), (35, False), (12, True)]:
+        n = 48
+        t = np.zeros(n, TU_TASK); ch = np.zeros(n, INTER_CHOICE)
+        for i in range(n):
+            px = int(rng.integers(0, (W - N) // 4 + 1)) * 4; py = int(rng.integers(0, (H - N) // 4 + 1)) * 4
+            off = (margin + py) * stride + margin + px
+            t[i]["mvFrom"] = i; t[i]["curOff"] = off; t[i]["refOff"] = off; t[i]["reconOff"] = i * N * N
+            kind = i % 8
+            mv0 = [(0, 0), (4 * dx, 4 * dy), (4 * dx + 2, 4 * dy), (4 * dx, 4 * dy + 1), (4 * dx + 3, 4 * dy + 2)][kind % 5] if kind < 5 else (int(rng.integers(-30, 31)), int(rng.integers(-30, 31)))
+            mv1 = (int(rng.integers(-30, 31)), int(rng.integers(-30, 31))) if kind % 2 else (4 * int(rng.integers(-5, 6)), 4 * int(rng.integers(-5, 6)))
+            ch[i]["mv"][0] = mv0; ch[i]["mv"][1] = mv1
+            ch[i]["ref"] = (1, 0) if i % 6 else ((1, -1) if i % 12 else (0, 0))                   # every sixth PU chose something else
+        d_t, d_ch = api.to_device(t), api.to_device(ch)
+        d_coeff = torch.full((n * N * N,), 7, dtype=torch.int16, device="cuda")
+        d_ns = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        d_du = torch.zeros(n * N * N, dtype=torch.int32, device="cuda")
+        d_rec = torch.zeros(n * N * N, dtype=d_cur.dtype, device="cuda") if recon else None
+        d_sse = torch.zeros(n, dtype=torch.int64, device="cuda") if recon else None
+        api.tq_batch(log2n, d_cur, stride, d_r0, stride, d_t, n, qp, 85, d_coeff, d_ns, delta_u=d_du, recon=d_rec, recon_stride=N, sse=d_sse,
+                     choice=d_ch, choice_list=0, choice_ref=1, ref1=d_r1, choice_ref1=0)
+        torch.cuda.synchronize()
+        coeff = d_coeff.cpu().numpy().reshape(n, N * N); ns = d_ns.cpu().numpy(); du = d_du.cpu().numpy().reshape(n, N * N)
+        rec = d_rec.cpu().numpy().view(cur_f.dtype) if recon else None
+        sse = d_sse.cpu().numpy() if recon else None
+        done = 0
+        for i in range(n):
+            if tuple(ch[i]["ref"]) != (1, 0):
+                assert int(ns[i]) == -1 and (coeff[i] == 7).all(), "a TU of another choice was touched (task %d)" % i
+                continue
+            off = int(t[i]["curOff"])
+            mv0 = (int(ch[i]["mv"][0][0]), int(ch[i]["mv"][0][1])); mv1 = (int(ch[i]["mv"][1][0]), int(ch[i]["mv"][1][1]))
+            e_ns, e_coeff, e_du, e_rec, e_sse = ora.tq_tu_bi(log2n, cur_f, stride, off, r0_f, r1_f, stride, off, mv0, mv1, qp, 85, want_recon=recon)
+            assert int(ns[i]) == e_ns and np.array_equal(coeff[i], e_coeff), "bi coeff: N=%d qp=%d task %d mv %s %s" % (N, qp, i, mv0, mv1)
+            assert np.array_equal(du[i], e_du)
+            if recon:
+                assert np.array_equal(rec[i * N * N:(i + 1) * N * N], e_rec), "bi recon: N=%d qp=%d task %d mv %s %s" % (N, qp, i, mv0, mv1)
+                assert int(sse[i]) == e_sse
+            done += 1
+        assert done >= 36

@@ -27,6 +27,7 @@ struct TqArgs
     const pixel* planes; int64_t planeElems;
     const x265hip_inter_choice* choice; int choiceList, choiceRef;
     int chroma;
+    const pixel* ref1; int choiceRef1;          // bi-directional launch: list-1 reference plane and index
 };
 
 template<int N> struct Lg { static const int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5; };
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     __shared__ __attribute__((aligned(16))) int16_t s_a[4][NN];
     __shared__ __attribute__((aligned(16))) int16_t s_b[4][(N + 7) * N];
     __shared__ int8_t s_m[NN];
+    __shared__ __attribute__((aligned(16))) int16_t s_c[4][NN];                        // second 14-bit prediction of a bi-directional TU
 
     if (N < 32)
     {
@@ -66,11 +68,20 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     if (item >= a.n) return;
     x265hip_tu_task tk = a.tasks[item];
     if (tk.mvFrom >= 0 && a.mvSource) { tk.mv[0] = a.mvSource[tk.mvFrom].mv[0]; tk.mv[1] = a.mvSource[tk.mvFrom].mv[1]; }
+    int mv1x = 0, mv1y = 0;
     if (tk.mvFrom >= 0 && a.choice)
-    {   // several references: this launch compensates from ONE of them -- only the TUs whose PU chose it
+    {   // several references: this launch compensates from ONE of them (or one PAIR, a.ref1) -- only the TUs whose PU chose it
         const x265hip_inter_choice ch = a.choice[tk.mvFrom];
-        if (ch.ref[a.choiceList] != a.choiceRef || ch.ref[a.choiceList ^ 1] >= 0) return;
-        tk.mv[0] = ch.mv[a.choiceList][0]; tk.mv[1] = ch.mv[a.choiceList][1];
+        if (a.ref1)
+        {
+            if (ch.ref[0] != a.choiceRef || ch.ref[1] != a.choiceRef1) return;
+            tk.mv[0] = ch.mv[0][0]; tk.mv[1] = ch.mv[0][1]; mv1x = ch.mv[1][0]; mv1y = ch.mv[1][1];
+        }
+        else
+        {
+            if (ch.ref[a.choiceList] != a.choiceRef || ch.ref[a.choiceList ^ 1] >= 0) return;
+            tk.mv[0] = ch.mv[a.choiceList][0]; tk.mv[1] = ch.mv[a.choiceList][1];
+        }
     }
 
     McCtx c;
@@ -83,7 +94,14 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
 
     // ---- motion compensation into LDS (ends with a wave_sync): the reference's copy_pp | hpp | vpp | hvpp dispatch, or -- with
     //      the phase planes of this reference -- a copy of the block at the integer part of the MV out of plane 4*yFrac + xFrac ----
-    if (a.chroma)
+    if (a.ref1)
+    {   // bi-directional TU: Predict::motionCompensation's B-slice branch (predict.cpp:186-196, 211): two 14-bit predictions, addAvg
+        build_pred_short(c, plane_view(c), tk.mv[0], tk.mv[1], sa);
+        McCtx c1 = c; c1.fref = a.ref1 + tk.refOff;
+        build_pred_short(c1, plane_view(c1), mv1x, mv1y, (lshort*)s_c[wave]);
+        add_avg(c, sa, (const lshort*)s_c[wave]);
+    }
+    else if (a.chroma)
     {   // chroma TU of a 4:2:0 picture: predInterChromaPixel (4-tap filters at the eighth-pel chroma MV = the quarter-pel luma MV)
         CCtx cc; cc.ref[0] = a.ref + tk.refOff; cc.ref[1] = cc.ref[0]; cc.rs = a.rs; cc.fenc[0] = cc.fenc[1] = nullptr; cc.pred = c.pred; cc.immed = c.immed;      // (N + 3) intermediate rows fit the luma path's (N + 7)-row buffer
         cc.w = N; cc.h = N; cc.qpr = N >> 2; cc.nquads = (N >> 2) * N; cc.lane = lane; cc.on = true;
@@ -289,7 +307,8 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
     TqArgs a = { (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride, tasks, n,
                  params->qp, params->add, params->quantCoeff, params->deltaU, coeff, numSig,
                  (pixel*)reconPlane, reconStride, sse, mvSource, (const pixel*)params->subpelPlanes, params->planeElems,
-                 params->choice, params->choiceList, params->choiceRef, params->chroma };
+                 params->choice, params->choiceList, params->choiceRef, params->chroma, (const pixel*)params->refPlane1, params->choiceRef1 };
+    if (params->refPlane1 && (!params->choice || params->chroma || params->choiceRef1 < 0 || params->choiceRef1 > 3)) { set_error("tq_batch: a bi-directional launch needs choice records, luma planes and choiceRef1 in 0..3"); return X265HIP_EARG; }
     if (params->choice && (params->choiceList < 0 || params->choiceList > 1 || params->choiceRef < 0 || params->choiceRef > 3)) { set_error("tq_batch: bad choiceList / choiceRef"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     switch (log2TrSize)

@@ -351,6 +351,112 @@ template<class C, class V> __device__ __forceinline__ void build_pred(const C& c
 namespace xh {
 // ---- chroma motion compensation of one 4:2:0 block into LDS (Predict::predInterChromaPixel, predict.cpp:340-380: copy | filter_hpp | filter_vpp |
 // filter_hps + filter_vsp by the eighth-pel MV's fractions), shared by the chroma SATD terms of the search (me_body.inc) and the chroma TUs of the TQ chain ----
+// ---- 14-bit prediction for bi-directional averaging: Predict::predInterLumaShort (predict.cpp:302-338) = convert_p2s | luma_hps | luma_vps |
+// luma_hps (row-extended) + luma_vss (ipfilter.cpp:40-57, 120-162, 205-239, 284-317) into `dst` (stride c.w), then addAvg (pixel.cpp:834-854) ----
+template<class C, class V> __device__ __forceinline__ void build_pred_short(const C& c, const V& ref, int qx, int qy, lshort* dst)
+{
+    const int ix = qx >> 2, iy = qy >> 2, xf = qx & 3, yf = qy & 3;
+    const int headRoom = XH_IF_INTERNAL_PREC - X265_DEPTH;
+    const int shift1 = XH_IF_FILTER_PREC - headRoom, offset1 = (int)((unsigned)-XH_IF_INTERNAL_OFFS << shift1);
+    auto put4 = [&](lshort* p, const int (&o)[4]) {
+        u32x2 pk; pk.x = (uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16); pk.y = (uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+        *(lu2*)p = pk;
+    };
+    if (!(xf | yf))
+    {
+        QUAD_LOOP(c, q, y, x4)
+            int v[4], o[4]; load4u(ref.at(ix + x4, iy + y), v);
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (int16_t)((v[e] << headRoom) - XH_IF_INTERNAL_OFFS);
+            put4(dst + y * c.w + x4, o);
+        QUAD_END
+    }
+    else if (!yf || !xf)
+    {
+        int t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[yf ? yf : xf][i];
+        QUAD_LOOP(c, q, y, x4)
+            int s[4] = { 0, 0, 0, 0 }, o[4];
+            if (!yf)
+            {
+                int px[11]; load11u(ref.at(ix + x4 - 3, iy + y), px);
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+#pragma unroll
+                    for (int i = 0; i < 8; i++) s[e] += px[e + i] * t[i];
+            }
+            else
+            {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                {
+                    int v[4]; load4u(ref.at(ix + x4, iy + y - 3 + i), v);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) s[e] += v[e] * t[i];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (int16_t)((s[e] + offset1) >> shift1);
+            put4(dst + y * c.w + x4, o);
+        QUAD_END
+    }
+    else
+    {
+        int t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[xf][i];
+        const int rows = c.h + 7, nq = c.qpr * rows;
+        for (int q = c.lane; q < nq; q += c.gsize)
+        {
+            const int y = (q * c.qdivm) >> 20, x4 = (q - y * c.qpr) * 4;
+            int px[11], o[4];
+            load11u(ref.at(ix + x4 - 3, iy + y - 3), px);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                int s = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) s += px[e + i] * t[i];
+                o[e] = (int16_t)((s + offset1) >> shift1);
+            }
+            put4(c.immed + y * c.w + x4, o);
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = k_lumaTaps[yf][i];
+        QUAD_LOOP(c, q, y, x4)
+            int s[4] = { 0, 0, 0, 0 }, o[4];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                u32x2 a = *(const lu2*)(c.immed + (y + i) * c.w + x4);
+                s[0] += (int)(int16_t)(a.x & 0xFFFF) * t[i]; s[1] += (int)(int16_t)(a.x >> 16) * t[i];
+                s[2] += (int)(int16_t)(a.y & 0xFFFF) * t[i]; s[3] += (int)(int16_t)(a.y >> 16) * t[i];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (int16_t)(s[e] >> XH_IF_FILTER_PREC);        // filterVertical_ss: no offset (ipfilter.cpp:284-317)
+            put4(dst + y * c.w + x4, o);
+        QUAD_END
+    }
+    wave_sync();
+}
+// addAvg (pixel.cpp:834-854): c.pred = clip((a + b + offset) >> shift), shift = 15 - depth, offset = (1 << (shift - 1)) + 2 * 8192
+template<class C> __device__ __forceinline__ void add_avg(const C& c, const lshort* a, const lshort* b)
+{
+    const int shiftNum = XH_IF_INTERNAL_PREC + 1 - X265_DEPTH, offset = (1 << (shiftNum - 1)) + 2 * XH_IF_INTERNAL_OFFS;
+    QUAD_LOOP(c, q, y, x4)
+        const u32x2 u = *(const lu2*)(a + y * c.w + x4), v = *(const lu2*)(b + y * c.w + x4);
+        int o[4];
+        o[0] = clip3(0, XH_PIXEL_MAX, ((int)(int16_t)(u.x & 0xFFFF) + (int)(int16_t)(v.x & 0xFFFF) + offset) >> shiftNum);
+        o[1] = clip3(0, XH_PIXEL_MAX, ((int)(int16_t)(u.x >> 16) + (int)(int16_t)(v.x >> 16) + offset) >> shiftNum);
+        o[2] = clip3(0, XH_PIXEL_MAX, ((int)(int16_t)(u.y & 0xFFFF) + (int)(int16_t)(v.y & 0xFFFF) + offset) >> shiftNum);
+        o[3] = clip3(0, XH_PIXEL_MAX, ((int)(int16_t)(u.y >> 16) + (int)(int16_t)(v.y >> 16) + offset) >> shiftNum);
+        store4(c.pred + y * c.w + x4, o);
+    QUAD_END
+    wave_sync();
+}
+
 struct CCtx { const pixel* ref[2]; intptr_t rs; lpixel* fenc[2]; lpixel* pred; lshort* immed; int w, h, qpr, nquads, lane; bool on; };
 __device__ const int8_t k_chromaTaps[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
                                                { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };   // constants.cpp:258-268
