@@ -170,6 +170,9 @@ typedef struct x265hip_tq_params {
                                     list 1 (same stride, the tasks' refOff); only TUs whose PU chose exactly that pair are processed; motion compensation is
                                     the B-slice branch of Predict::motionCompensation (predict.cpp:186-211): predInterLumaShort of both (14-bit) -> addAvg */
     int choiceRef1;
+    int dst4;                    /* != 0 with log2TrSize 2: the 4x4 transform pair is DST-VII (dst4x4 / idst4x4, dct.cpp:43-81, 443-456, 528-541) and the DC-only
+                                    shortcut of the inverse is off -- Quant's choice for intra luma 4x4 TUs (quant.cpp:429-432, 585-603).  With refPlane = a plane
+                                    holding the caller's intra predictions, MVs zero and add = 171 the chain is the intra TU's */
 } x265hip_tq_params;
 
 int x265hip_tq_batch(void* stream, int log2TrSize,

@@ -295,6 +295,15 @@ class Oracle:
         return out, mco
 
     # ---- inter TU pipeline (x265_oracle_me.c xo_tq_tu) ----
+    def tq_tu_dst4(self, cur, cstride, coff, pred, pstride, poff, qp, add, want_recon=False):
+        coeff = np.zeros(16, np.int16); du = np.zeros(16, np.int32)
+        recon = np.zeros(16, self.pixel) if want_recon else None
+        sse = C.c_uint64(0)
+        fn = self.me_lib.xo_tq_tu_dst4
+        fn.restype = C.c_uint32
+        ns = fn(_ptr(cur, coff), _IP(cstride), _ptr(pred, poff), _IP(pstride), qp, add, _ptr(coeff), _ptr(du), _ptr(recon) if want_recon else None, _IP(4), C.byref(sse))
+        return int(ns), coeff, du, recon, int(sse.value)
+
     def tq_tu_bi(self, log2n, cur, cstride, coff, ref0, ref1, rstride, roff, mv0, mv1, qp, add, want_recon=False):
         n = 1 << log2n
         coeff = np.zeros(n * n, np.int16); du = np.zeros(n * n, np.int32)

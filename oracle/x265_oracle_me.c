@@ -769,6 +769,16 @@ int xo_motion_estimate_sea(const xo_pixel* fencPlane, intptr_t fencStride, int w
 /* ------------------------------------------------------------------------------------------ */
 static int g_tqChroma;
 static const xo_pixel* g_tqRef1; static int g_tqMv1x, g_tqMv1y;
+static int g_tqDst4;
+/* the chain of an intra luma 4x4 TU (quant.cpp:429-432, 585-603): DST-VII pair, no DC shortcut; the prediction is whatever `fref` holds at MV (0,0) */
+uint32_t xo_tq_tu_dst4(const xo_pixel* cur, intptr_t curStride, const xo_pixel* predPlane, intptr_t predStride, int qp, int addNumerator,
+                       int16_t* coeff, int32_t* deltaU, xo_pixel* recon, intptr_t reconStride, uint64_t* sse)
+{
+    g_tqDst4 = 1;
+    const uint32_t r = xo_tq_tu(2, cur, curStride, predPlane, predStride, 0, 0, qp, addNumerator, NULL, coeff, deltaU, recon, reconStride, sse);
+    g_tqDst4 = 0;
+    return r;
+}
 /* Predict::predInterLumaShort (predict.cpp:302-338) */
 static void mc_luma_short(const xo_pixel* fref, intptr_t stride, int N, int qx, int qy, int16_t* dst)
 {
@@ -846,7 +856,7 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
     else xo_interp_hvpp(8, N, N, src, refStride, pred, N, xf, yf);
 
     xo_sub_ps(N, N, resi, N, cur, pred, curStride, N);
-    xo_dct(N, resi, dct, N);
+    if (g_tqDst4 && N == 4) xo_dst4(resi, dct, N); else xo_dct(N, resi, dct, N);
 
     /* quant.cpp:458-469 */
     const int per = qp / 6, rem = qp % 6;
@@ -866,13 +876,15 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
             /* quant.cpp:555-568 */
             const int shift = 20 - 14 - transformShift;
             xo_dequant_normal(coeff, deq, num, invQuantScales[rem] << per, shift);
-            if (numSig == 1 && coeff[0] != 0)
+            if (numSig == 1 && coeff[0] != 0 && !(g_tqDst4 && N == 4))
             {   /* DC shortcut, quant.cpp:588-597 */
                 const int shift_1st = 7 - 6, add_1st = 1 << (shift_1st - 1);
                 const int shift_2nd = 12 - (X265_DEPTH - 8) - 3, add_2nd = 1 << (shift_2nd - 1);
                 int dc_val = (((deq[0] * (64 >> 6) + add_1st) >> shift_1st) * (64 >> 3) + add_2nd) >> shift_2nd;
                 xo_blockfill_s(N, res2, N, (int16_t)dc_val);
             }
+            else if (g_tqDst4 && N == 4)
+                xo_idst4(deq, res2, N);
             else
                 xo_idct(N, deq, res2, N);
         }

@@ -53,6 +53,8 @@ int xo_diamond_search(const xo_pixel* fencPlane, intptr_t fencStride, int w, int
 uint32_t xo_tq_tu_bi(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref0, const xo_pixel* fref1, intptr_t refStride,
                      int qmv0x, int qmv0y, int qmv1x, int qmv1y, int qp, int addNumerator, const int32_t* quantCoeff,
                      int16_t* coeff, int32_t* deltaU, xo_pixel* recon /*or NULL*/, intptr_t reconStride, uint64_t* sse);
+uint32_t xo_tq_tu_dst4(const xo_pixel* cur, intptr_t curStride, const xo_pixel* predPlane, intptr_t predStride, int qp, int addNumerator,
+                       int16_t* coeff, int32_t* deltaU, xo_pixel* recon /*or NULL*/, intptr_t reconStride, uint64_t* sse);
 uint32_t xo_tq_tu_chroma(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const xo_pixel* fref, intptr_t refStride,
                          int qmvx, int qmvy, int qp, int addNumerator, const int32_t* quantCoeff,
                          int16_t* coeff, int32_t* deltaU, xo_pixel* recon, intptr_t reconStride, uint64_t* sse);

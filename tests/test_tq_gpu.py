@@ -168,3 +168,35 @@ def test_tq_batch_bidirectional_matches_oracle(depth, log2n):
                 assert int(sse[i]) == e_sse
             done += 1
         assert done >= 36
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_tq_batch_intra_4x4_dst_matches_oracle(depth):
+    """The chain of an intra luma 4x4 TU (quant.cpp:429-432, 585-603): prediction from a plane the caller filled (MV 0), rounding 171, the DST-VII
+    pair instead of the DCT, no DC-only shortcut in the inverse."""
+    api, ora = FrameApi(depth), Oracle(depth)
+    torch = api.torch
+    rng = np.random.default_rng(9 + depth)
+    W, H, margin = 128, 64, 16
+    cur, pred, stride, _ = frame_pair(W, H, depth, 91, margin=margin, max_shift=2)       # "pred": any plane close to the source does
+    cur_f, pred_f = cur.reshape(-1), pred.reshape(-1)
+    d_cur, d_pred = api.to_device(cur_f), api.to_device(pred_f)
+    for qp in (10, 24, 33, 44):
+        n = 96
+        t = np.zeros(n, TU_TASK)
+        for i in range(n):
+            px = int(rng.integers(0, (W - 4) // 4 + 1)) * 4; py = int(rng.integers(0, (H - 4) // 4 + 1)) * 4
+            off = (margin + py) * stride + margin + px
+            t[i]["mvFrom"] = -1; t[i]["curOff"] = off; t[i]["refOff"] = off; t[i]["reconOff"] = i * 16
+        d_t = api.to_device(t)
+        d_coeff = torch.zeros(n * 16, dtype=torch.int16, device="cuda"); d_ns = torch.zeros(n, dtype=torch.int32, device="cuda")
+        d_du = torch.zeros(n * 16, dtype=torch.int32, device="cuda")
+        d_rec = torch.zeros(n * 16, dtype=d_cur.dtype, device="cuda"); d_sse = torch.zeros(n, dtype=torch.int64, device="cuda")
+        api.tq_batch(2, d_cur, stride, d_pred, stride, d_t, n, qp, 171, d_coeff, d_ns, delta_u=d_du, recon=d_rec, recon_stride=4, sse=d_sse, dst4=True)
+        torch.cuda.synchronize()
+        coeff = d_coeff.cpu().numpy().reshape(n, 16); ns = d_ns.cpu().numpy(); rec = d_rec.cpu().numpy().view(cur_f.dtype); sse = d_sse.cpu().numpy()
+        for i in range(n):
+            off = int(t[i]["curOff"])
+            e_ns, e_coeff, e_du, e_rec, e_sse = ora.tq_tu_dst4(cur_f, stride, off, pred_f, stride, off, qp, 171, want_recon=True)
+            assert int(ns[i]) == e_ns and np.array_equal(coeff[i], e_coeff), "dst4 coeff: qp=%d task %d" % (qp, i)
+            assert np.array_equal(rec[i * 16:(i + 1) * 16], e_rec) and int(sse[i]) == e_sse, "dst4 recon: qp=%d task %d numSig %d" % (qp, i, e_ns)

@@ -15,6 +15,7 @@ namespace {
 
 __device__ const int k_quantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };   // scalinglist.cpp:129
 __device__ const int k_invQuantScales[6] = { 40, 45, 51, 57, 64, 72 };                  // scalinglist.cpp:130
+__device__ const int8_t k_dst4m[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };   // dct.cpp:43-81 (fastForwardDst / inversedst as a matrix)
 
 struct TqArgs
 {
@@ -28,6 +29,7 @@ struct TqArgs
     const x265hip_inter_choice* choice; int choiceList, choiceRef;
     int chroma;
     const pixel* ref1; int choiceRef1;          // bi-directional launch: list-1 reference plane and index
+    int dst4;                                   // 4x4 TUs: DST-VII instead of the DCT (intra luma, quant.cpp:429-432, 585-603)
 };
 
 template<int N> struct Lg { static const int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5; };
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
 
     if (N < 32)
     {
-        for (int i = threadIdx.x; i < NN; i += 256) s_m[i] = (int8_t)dct_coef((i / N) * (32 / N), i % N);
+        for (int i = threadIdx.x; i < NN; i += 256) s_m[i] = (N == 4 && a.dst4) ? k_dst4m[i & 15] : (int8_t)dct_coef((i / N) * (32 / N), i % N);
     }
     else if (a.recon)
     {
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     else
     {
         const int shift = 20 - 14 - transformShift, scale = k_invQuantScales[rem] << per, dqAdd = 1 << (shift - 1);
-        if (numSig == 1 && q0 != 0)
-        {   // DC shortcut (quant.cpp:588-597)
+        if (numSig == 1 && q0 != 0 && !(N == 4 && a.dst4))
+        {   // DC shortcut (quant.cpp:588-597; not with the DST)
             const int deq0 = clip3(-32768, 32767, (int32_t)((uint32_t)(q0 * scale) + (uint32_t)dqAdd) >> shift);
             const int shift_2nd = 12 - (X265_DEPTH - 8) - 3;
             dcVal = (int)(int16_t)(((((deq0 + 1) >> 1) * 8) + (1 << (shift_2nd - 1))) >> shift_2nd);
@@ -307,7 +309,7 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
     TqArgs a = { (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride, tasks, n,
                  params->qp, params->add, params->quantCoeff, params->deltaU, coeff, numSig,
                  (pixel*)reconPlane, reconStride, sse, mvSource, (const pixel*)params->subpelPlanes, params->planeElems,
-                 params->choice, params->choiceList, params->choiceRef, params->chroma, (const pixel*)params->refPlane1, params->choiceRef1 };
+                 params->choice, params->choiceList, params->choiceRef, params->chroma, (const pixel*)params->refPlane1, params->choiceRef1, params->dst4 };
     if (params->refPlane1 && (!params->choice || params->chroma || params->choiceRef1 < 0 || params->choiceRef1 > 3)) { set_error("tq_batch: a bi-directional launch needs choice records, luma planes and choiceRef1 in 0..3"); return X265HIP_EARG; }
     if (params->choice && (params->choiceList < 0 || params->choiceList > 1 || params->choiceRef < 0 || params->choiceRef > 3)) { set_error("tq_batch: bad choiceList / choiceRef"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;

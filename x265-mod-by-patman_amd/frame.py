@@ -47,7 +47,7 @@ def rd_lambda(depth, qp):
 
 class TqParams(C.Structure):
     _fields_ = [("qp", C.c_int), ("add", C.c_int), ("quantCoeff", C.c_void_p), ("deltaU", C.c_void_p),
-                ("subpelPlanes", C.c_void_p), ("planeElems", C.c_int64), ("choice", C.c_void_p), ("choiceList", C.c_int), ("choiceRef", C.c_int), ("chroma", C.c_int), ("refPlane1", C.c_void_p), ("choiceRef1", C.c_int)]
+                ("subpelPlanes", C.c_void_p), ("planeElems", C.c_int64), ("choice", C.c_void_p), ("choiceList", C.c_int), ("choiceRef", C.c_int), ("chroma", C.c_int), ("refPlane1", C.c_void_p), ("choiceRef1", C.c_int), ("dst4", C.c_int)]
 
 
 def mvcost_row(depth, qp, half):
@@ -176,9 +176,9 @@ class FrameApi:
                                                         C.c_ssize_t(dst_stride), width, height))
 
     def tq_batch(self, log2n, cur, cstride, ref, rstride, tasks, n, qp, add, coeff, numsig, quant_coeff=None, delta_u=None,
-                 recon=None, recon_stride=0, sse=None, mv_source=None, planes=None, plane_elems=0, choice=None, choice_list=0, choice_ref=0, chroma=False, ref1=None, choice_ref1=0):
+                 recon=None, recon_stride=0, sse=None, mv_source=None, planes=None, plane_elems=0, choice=None, choice_list=0, choice_ref=0, chroma=False, ref1=None, choice_ref1=0, dst4=False):
         p = TqParams(qp, add, _dp(quant_coeff), _dp(delta_u), _dp(planes), plane_elems if planes is not None else 0, _dp(choice), choice_list, choice_ref, int(chroma),
-                     _dp(ref1), choice_ref1)
+                     _dp(ref1), choice_ref1, int(dst4))
         self.h.check(self.lib.x265hip_tq_batch(self.stream(), log2n, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
                                                _dp(tasks), n, C.byref(p), _dp(coeff), _dp(numsig),
                                                _dp(recon), C.c_ssize_t(recon_stride), _dp(sse), _dp(mv_source)))
