@@ -87,6 +87,22 @@ int x265hip_me_batch_chroma(void* stream, int w, int h,
                             int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
                             const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* chroma);
 
+/* ---- AMVP: CUData::getPMV (common/cudata.cpp:1806-1990) for a batch of (PU, list, reference) --------------------------------------------------------------
+ * In: the PU's neighbour records in MVP_DIR order (cudata.h:67-75: LEFT, ABOVE, ABOVE_RIGHT, BELOW_LEFT, ABOVE_LEFT, COLLOCATED) as CUData::getNeighbourMV /
+ * Search::puMotionEstimation (search.cpp:283-305) fill InterNeighbourMV: per list an MV and a reference index (-1 = none); for COLLOCATED refIdx[list] is the
+ * unified index (bit 4 = list of the collocated block's reference, low bits = index; -1 = no temporal candidate) and colPOC / colRefPOC are the POCs
+ * :1962-1967 looks up in the collocated picture (the host resolves them).  Out: the two AMVP candidates (zero-filled) and the motion-candidate list handed to
+ * motionEstimate (at most 11 entries).  Replaces getPMV + getDirectPMV + getIndirectPMV + scaleMvByPOCDist. */
+typedef struct x265hip_amvp_neighbour { int16_t mv[2][2]; int8_t refIdx[2]; int8_t available; int8_t reserved; } x265hip_amvp_neighbour;   /* 12 bytes */
+typedef struct x265hip_amvp_task {
+    x265hip_amvp_neighbour nb[6];
+    int8_t  list, refIdx; int16_t reserved;
+    int32_t colPOC, colRefPOC;
+} x265hip_amvp_task;                /* 84 bytes */
+typedef struct x265hip_amvp_params { int curPOC; int temporalMvp; int refPOC[2][16]; } x265hip_amvp_params;   /* Slice::m_poc, SPS::bTemporalMVPEnabled, Slice::m_refPOCList */
+typedef struct x265hip_amvp_result { int16_t amvp[2][2]; int16_t numMvc; int16_t mvc[11][2]; int16_t reserved; } x265hip_amvp_result;   /* 56 bytes */
+int x265hip_amvp_batch(void* stream, const x265hip_amvp_task* tasks, int n, const x265hip_amvp_params* params, x265hip_amvp_result* out);
+
 /* MotionEstimate::diamondSearch (motion.cpp:631-773) for n PUs of one size: the full-pel predictor search of ThreadedME's first stage
  * (Search::puMotionEstimation with isMVP, search.cpp:355-363 -- the CTU and its four sub-CUs at search range 32; the results seed m_areaBestMV for
  * the PU searches, analysis.cpp:248-306).  Uses of x265hip_me_task: curOff, refOff, mvmin / mvmax (full pel), qmvp (the MVD origin setMVP was

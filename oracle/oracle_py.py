@@ -255,6 +255,13 @@ class Oracle:
                                                   merange, method, subme, _ptr(costrow, half), _ptr(out), ip)
         return int(out[0]), int(out[1]), int(cost)
 
+    def get_pmv(self, nb, lst, ref_idx, cur_poc, temporal, ref_poc, col_poc, col_ref_poc):
+        """CUData::getPMV (xo_get_pmv): nb = 54 ints (6 neighbours x 9, the recorder's layout), ref_poc = 32 ints; returns (amvp[4], mvc pairs)"""
+        nb = np.ascontiguousarray(nb, np.int32); rp = np.ascontiguousarray(ref_poc, np.int32)
+        amvp = np.zeros(4, np.int32); mvc = np.zeros(32, np.int32)
+        n = self.me_lib.xo_get_pmv(_ptr(nb), int(lst), int(ref_idx), int(cur_poc), int(temporal), _ptr(rp), int(col_poc), int(col_ref_poc), _ptr(amvp), _ptr(mvc))
+        return amvp, mvc[:2 * n]
+
     def diamond(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, costrow):
         """MotionEstimate::diamondSearch (xo_diamond_search): returns (full-pel mvx, mvy, cost)"""
         b = np.asarray(bounds, np.int32)

@@ -24,6 +24,10 @@
  *   kind 4 (MotionEstimate::diamondSearch call, motion.cpp:631-773 -- the predictor stage of ThreadedME, search.cpp:362; recorded through the same
  *           renaming trick, -DdiamondSearch=diamondSearch_ref): ints = { planeId, w, h, blockOffset, mvmin.x, .y, mvmax.x, .y, mvp.x, .y (what setMVP
  *           was given: the MVD origin of mvcost), qp, out.x, out.y, cost }, pixels = w * h (source PU)
+ *   kind 5 (CUData::getPMV call, cudata.cpp:1806-1990 -- the AMVP candidates and the motion-candidate list of a PU; recorded through -DgetPMV=getPMV_ref on
+ *           common/cudata.cpp; at most X265TME_PMV calls, default 0 = none): ints = { list, refIdx, curPOC, temporalMvpEnabled, numRefIdx[2], refPOCList[2][16],
+ *           6 neighbours x { mv0.x, mv0.y, mv1.x, mv1.y, refIdx0, refIdx1, cuAddr0, cuAddr1, isAvailable }, colPOC, colRefPOC (of the temporal candidate, 0 when unused),
+ *           amvp0.x, .y, amvp1.x, .y, numMvc, mvc[2 * numMvc] }, no pixels
  * With threaded-me=0 on the command line the calls are those of Search::predInterSearch (search.cpp:2582-2700), whose setSourcePU overload enables
  * the chroma SATD terms of subpelCompare (motion.cpp:218-247, 1805-1865) at subme >= 3.
  */
@@ -41,6 +45,10 @@
 #include "primitives.h"
 #include "picyuv.h"
 #include "motion.h"
+#include "cudata.h"
+#include "slice.h"
+#include "frame.h"
+#include "framedata.h"
 #undef protected
 #undef private
 
@@ -173,6 +181,46 @@ int MotionEstimate::diamondSearch(ReferencePlanes* ref, const MV& mvmin, const M
 }
 }
 
+/* CUData::getPMV under the recorder (common/cudata.cpp compiled with -DgetPMV=getPMV_ref, oracle/Makefile) */
+static int g_pmvCalls, g_pmvMax;
+int getPMV_ref(const CUData* self, InterNeighbourMV* neighbours, uint32_t picList, uint32_t refIdx, MV* amvpCand, MV* pmv) __asm__("_ZNK4x2656CUData10getPMV_refEPNS_16InterNeighbourMVEjjPNS_2MVES4_");
+namespace X265_NS {
+int CUData::getPMV(InterNeighbourMV* neighbours, uint32_t picList, uint32_t refIdx, MV* amvpCand, MV* pmv) const
+{
+    InterNeighbourMV in[6];
+    memcpy(in, neighbours, sizeof(in));
+    const int numMvc = ::getPMV_ref(this, neighbours, picList, refIdx, amvpCand, pmv);
+    if (!g_out || g_pmvCalls >= g_pmvMax) return numMvc;
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (g_pmvCalls >= g_pmvMax) return numMvc;
+    std::vector<int32_t> ints = { (int32_t)picList, (int32_t)refIdx, m_slice->m_poc, (int32_t)m_slice->m_sps->bTemporalMVPEnabled, m_slice->m_numRefIdx[0], m_slice->m_numRefIdx[1] };
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < 16; r++) ints.push_back(m_slice->m_refPOCList[l][r]);
+    for (int d = 0; d < 6; d++)
+    {
+        ints.push_back(in[d].mv[0].x); ints.push_back(in[d].mv[0].y); ints.push_back(in[d].mv[1].x); ints.push_back(in[d].mv[1].y);
+        ints.push_back(in[d].refIdx[0]); ints.push_back(in[d].refIdx[1]); ints.push_back((int32_t)in[d].cuAddr[0]); ints.push_back((int32_t)in[d].cuAddr[1]);
+        ints.push_back(in[d].isAvailable ? 1 : 0);
+    }
+    int colPOC = 0, colRefPOC = 0;
+    const int tempRefIdx = in[MD_COLLOCATED].refIdx[picList];
+    if (m_slice->m_sps->bTemporalMVPEnabled && tempRefIdx != -1)
+    {   /* what :1962-1970 reads for the scaling of the temporal candidate */
+        const Frame* colPic = m_slice->m_refFrameList[m_slice->isInterB() && !m_slice->m_colFromL0Flag][m_slice->m_colRefIdx];
+        const CUData* colCU = colPic->m_encData->getPicCTU(in[MD_COLLOCATED].cuAddr[picList]);
+        colRefPOC = colCU->m_slice->m_refPOCList[tempRefIdx >> 4][tempRefIdx & 0xf];
+        colPOC = colCU->m_slice->m_poc;
+    }
+    ints.push_back(colPOC); ints.push_back(colRefPOC);
+    ints.push_back(amvpCand[0].x); ints.push_back(amvpCand[0].y); ints.push_back(amvpCand[1].x); ints.push_back(amvpCand[1].y);
+    ints.push_back(numMvc);
+    for (int i = 0; i < numMvc; i++) { ints.push_back(pmv[i].x); ints.push_back(pmv[i].y); }
+    put(5, ints, {});
+    g_pmvCalls++;
+    return numMvc;
+}
+}
+
 static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixel>& v, int w, int h, int f)
 {   /* textured picture in (not purely translational) motion + deterministic noise: predictors, candidates and search paths vary from PU to PU */
     uint32_t s = 4242u + 733u * (uint32_t)f;
@@ -211,6 +259,7 @@ int main(int argc, char** argv)
         if (eq) *eq = 0;
         if (x265_param_parse(p, argv[i], eq ? eq + 1 : NULL) < 0) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
     }
+    g_pmvMax = getenv("X265TME_PMV") ? atoi(getenv("X265TME_PMV")) : 0;
     g_out = fopen(argv[5], "wb");
     if (!g_out) { fprintf(stderr, "cannot write %s\n", argv[5]); return 2; }
     x265_encoder* enc = x265_encoder_open(p);
@@ -235,6 +284,6 @@ int main(int argc, char** argv)
     x265_param_free(live);
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(g_out);
-    printf("{\"calls\": %d, \"diamond_calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_diamonds, g_nextPlane, g_skipped, tme);
+    printf("{\"calls\": %d, \"diamond_calls\": %d, \"pmv_calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_diamonds, g_pmvCalls, g_nextPlane, g_skipped, tme);
     return 0;
 }

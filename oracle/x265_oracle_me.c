@@ -202,6 +202,88 @@ static void star_pattern(const me_t* m, mv_t mvmin, mv_t mvmax, star_t* s, int e
 #define COST_MV(mx_, my_) do { int c_ = sad_at(m, (mx_), (my_)) + mvcost(m, (mx_) * 4, (my_) * 4); \
     if (c_ < bcost) { bcost = c_; bmv.x = (mx_); bmv.y = (my_); } } while (0)
 
+/* ---- CUData::getPMV (common/cudata.cpp:1806-1990, the build without multiview / SCC): the two AMVP candidates and the motion-candidate list of a PU ----
+ * nb = 6 neighbours in MVP_DIR order (cudata.h:67-75: LEFT, ABOVE, ABOVE_RIGHT, BELOW_LEFT, ABOVE_LEFT, COLLOCATED) x { mv[0].x, .y, mv[1].x, .y, refIdx[0], refIdx[1],
+ * cuAddr[0], cuAddr[1], isAvailable }; refPOC = m_refPOCList[2][16]; colPOC / colRefPOC = the POCs :1962-1967 looks up for the temporal candidate.
+ * amvp = { c0.x, c0.y, c1.x, c1.y }; returns numMvc, mvc = x, y pairs. */
+static void scale_mv_poc(const int32_t* in, int curPOC, int curRefPOC, int colPOC, int colRefPOC, int32_t* out)
+{   /* scaleMvByPOCDist (cudata.cpp:2229-2244), scaleMv (:104-110) */
+    const int diffPocD = colPOC - colRefPOC, diffPocB = curPOC - curRefPOC;
+    if (diffPocD == diffPocB) { out[0] = in[0]; out[1] = in[1]; return; }
+    const int tdb = diffPocB < -128 ? -128 : diffPocB > 127 ? 127 : diffPocB, tdd = diffPocD < -128 ? -128 : diffPocD > 127 ? 127 : diffPocD;
+    const int x = (0x4000 + abs(tdd / 2)) / tdd;
+    int scale = (tdb * x + 32) >> 6;
+    scale = scale < -4096 ? -4096 : scale > 4095 ? 4095 : scale;
+    for (int k = 0; k < 2; k++)
+    {
+        int v = (scale * in[k] + 127 + (scale * in[k] < 0)) >> 8;
+        out[k] = v < -32768 ? -32768 : v > 32767 ? 32767 : v;
+    }
+}
+int xo_get_pmv(const int32_t* nb, int list, int refIdx, int curPOC, int temporalEnabled, const int32_t* refPOC, int colPOC, int colRefPOC, int32_t* amvp, int32_t* mvc)
+{
+    enum { LEFT, ABOVE, ABOVE_RIGHT, BELOW_LEFT, ABOVE_LEFT, COLLOCATED };
+    int32_t direct[5][2], indirect[5][2];
+    int validD[5], validI[5];
+    const int curRefPOC = refPOC[list * 16 + refIdx];
+    for (int d = 0; d < 5; d++)
+    {
+        const int32_t* n = nb + 9 * d;
+        validD[d] = validI[d] = 0;
+        /* getDirectPMV (:2110-2123): same reference picture, either list, the asked-for list first */
+        for (int i = 0, l = list; i < 2; i++, l = !l)
+        {
+            const int r = n[4 + l];
+            if (r >= 0 && curRefPOC == refPOC[l * 16 + r]) { direct[d][0] = n[2 * l]; direct[d][1] = n[2 * l + 1]; validD[d] = 1; break; }
+        }
+        /* getIndirectPMV (:2126-2156): any reference, scaled by the POC distances (the neighbour belongs to the current picture) */
+        for (int i = 0, l = list; i < 2; i++, l = !l)
+        {
+            const int r = n[4 + l];
+            if (r >= 0) { scale_mv_poc(n + 2 * l, curPOC, curRefPOC, curPOC, refPOC[l * 16 + r], indirect[d]); validI[d] = 1; break; }
+        }
+    }
+    int num = 0;
+#define PUT(v) do { amvp[2 * num] = (v)[0]; amvp[2 * num + 1] = (v)[1]; num++; } while (0)
+    if (validD[BELOW_LEFT]) PUT(direct[BELOW_LEFT]);
+    else if (validD[LEFT]) PUT(direct[LEFT]);
+    else if (validI[BELOW_LEFT]) PUT(indirect[BELOW_LEFT]);
+    else if (validI[LEFT]) PUT(indirect[LEFT]);
+    const int bAddedSmvp = num > 0;
+    if (validD[ABOVE_RIGHT]) PUT(direct[ABOVE_RIGHT]);
+    else if (validD[ABOVE]) PUT(direct[ABOVE]);
+    else if (validD[ABOVE_LEFT]) PUT(direct[ABOVE_LEFT]);
+    if (!bAddedSmvp)
+    {
+        if (validI[ABOVE_RIGHT]) PUT(indirect[ABOVE_RIGHT]);
+        else if (validI[ABOVE]) PUT(indirect[ABOVE]);
+        else if (validI[ABOVE_LEFT]) PUT(indirect[ABOVE_LEFT]);
+    }
+    /* (at most two entries so far: left group <= 1; above group: a direct one, and an indirect one only when the left group gave none) */
+    int numMvc = 0;
+    for (int d = LEFT; d <= ABOVE_LEFT; d++)
+    {
+        if (validD[d] && (direct[d][0] | direct[d][1])) { mvc[2 * numMvc] = direct[d][0]; mvc[2 * numMvc + 1] = direct[d][1]; numMvc++; }
+        if (validI[d] && (indirect[d][0] | indirect[d][1])) { mvc[2 * numMvc] = indirect[d][0]; mvc[2 * numMvc + 1] = indirect[d][1]; numMvc++; }
+    }
+    if (num == 2) num -= (amvp[0] == amvp[2] && amvp[1] == amvp[3]);
+    if (temporalEnabled && num < 2)
+    {
+        const int32_t* n = nb + 9 * COLLOCATED;
+        const int tempRefIdx = n[4 + list];
+        if (tempRefIdx != -1)
+        {
+            int32_t t[2];
+            scale_mv_poc(n + 2 * list, curPOC, curRefPOC, colPOC, colRefPOC, t);
+            mvc[2 * numMvc] = t[0]; mvc[2 * numMvc + 1] = t[1]; numMvc++;
+            PUT(t);
+        }
+    }
+#undef PUT
+    while (num < 2) { amvp[2 * num] = 0; amvp[2 * num + 1] = 0; num++; }
+    return numMvc;
+}
+
 /* MotionEstimate::diamondSearch (motion.cpp:631-773): the full-pel predictor search of ThreadedME's first stage (search.cpp:355-363, range 32, MVP (0,0)).
  * It starts from bmv = (0,0) with bcost = INT_MAX WITHOUT costing (0,0); a first loop of distances 1, 2, 4 always around omv = (0,0) (omv is
  * not moved inside it), then distances 8 .. 64 around the best so far, each ending when the best did not move.  Away from the window's edge the

@@ -47,6 +47,8 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
                   int qmvx, int qmvy, int qp, int addNumerator /*171 or 85*/, const int32_t* quantCoeff,
                   int16_t* coeff /*N*N*/, int32_t* deltaU /*N*N or NULL*/,
                   xo_pixel* recon /*or NULL*/, intptr_t reconStride, uint64_t* sse);
+/* CUData::getPMV (cudata.cpp:1806-1990); see x265_oracle_me.c */
+int xo_get_pmv(const int32_t* nb, int list, int refIdx, int curPOC, int temporalEnabled, const int32_t* refPOC, int colPOC, int colRefPOC, int32_t* amvp, int32_t* mvc);
 /* MotionEstimate::diamondSearch (motion.cpp:631-773); bounds and outMv in full pels; qmvp = the MVD origin of mvcost (setMVP) */
 int xo_diamond_search(const xo_pixel* fencPlane, intptr_t fencStride, int w, int h, const xo_pixel* fref, intptr_t refStride, const int32_t* bounds,
                       int qmvpx, int qmvpy, const uint16_t* costRowCentre, int32_t* outMv);

@@ -18,7 +18,7 @@ CALL_FIELDS = ("plane w h blockOffset mnx mny mxx mxy qmvpx qmvpy numCand merang
 DIA_FIELDS = "plane w h blockOffset mnx mny mxx mxy mvpx mvpy qp outx outy cost".split()
 
 
-def parse(path, dias=None):
+def parse(path, dias=None, pmvs=None):
     d = np.fromfile(path, np.uint8).tobytes()
     off, planes, calls, mvcs, blocks = 0, {}, [], [], []
     while off < len(d):
@@ -28,6 +28,8 @@ def parse(path, dias=None):
             pid, stride, rows = int(ints[0]), int(ints[1]), int(ints[2])
             px = np.frombuffer(d, np.uint16, stride * rows, off).copy(); off += 2 * stride * rows
             planes[pid] = (ints, px)
+        elif kind == 5:
+            if pmvs is not None: pmvs.append(ints)
         elif kind == 4:
             npx = int(ints[1]) * int(ints[2])
             px = np.frombuffer(d, np.uint16, npx, off).copy(); off += 2 * npx
@@ -83,6 +85,27 @@ def build_dia(depth, args, out):
     return calls
 
 
+def build_amvp(out):
+    """amvp.npz: CUData::getPMV calls (ref_tme.cpp kind 5) of a --threaded-me encode and of a regular encode with B pictures and several references; the records
+    are bit-depth independent (8-bit harness); identical records are kept once.  Row layout = the recorder's (fixed 99 ints + 22 mvc ints, zero padded)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265tme_8")
+    rows = []
+    for args in (["192", "128", "6", "slow", "bframes=2"], ["192", "128", "8", "slow", "bframes=3", "threaded-me=0", "ref=3"], ["192", "128", "5", "medium", "bframes=0", "threaded-me=0", "ref=2"]):
+        pm = []
+        with tempfile.TemporaryDirectory() as td:
+            raw = os.path.join(td, "tme.bin")
+            subprocess.check_call([exe] + args[:4] + [raw] + args[4:], stdout=subprocess.DEVNULL, env=dict(os.environ, X265TME_PMV="200000"))
+            parse(raw, None, pm)
+        for r in pm:
+            row = np.zeros(99 + 22, np.int32); row[:len(r)] = r
+            rows.append(row)
+    rows = np.unique(np.stack(rows), axis=0)
+    if len(rows) > 24000:
+        rows = rows[np.random.default_rng(5).permutation(len(rows))[:24000]]
+    np.savez_compressed(out, calls=rows)
+    return rows
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "tme"])
     # tme_*: --threaded-me encodes (luma-only searches of puMotionEstimation); mec_*: regular encodes whose predInterSearch searches carry the chroma
@@ -93,6 +116,9 @@ if __name__ == "__main__":
         f = {n: c[:, i] for i, n in enumerate(DIA_FIELDS)}
         print("dia", depth, "calls", len(c), "size", os.path.getsize(out), "shapes", sorted({(int(a), int(b)) for a, b in zip(f["w"], f["h"])}), "out range", f["outx"].min(), f["outx"].max(), f["outy"].min(), f["outy"].max(),
               "mvp", np.unique(f["mvpx"]), np.unique(f["mvpy"]))
+    r = build_amvp(os.path.join(ROOT, "tests", "golden", "amvp.npz"))
+    print("amvp calls", len(r), "size", os.path.getsize(os.path.join(ROOT, "tests", "golden", "amvp.npz")), "numMvc", np.bincount(r[:, 98]), "temporal used", int((r[:, 93] != 0).sum() + (r[:, 92] != 0).sum()),
+          "lists", np.bincount(r[:, 0]), "refs", np.bincount(r[:, 1]))
     if "--dia-only" in sys.argv: sys.exit(0)
     for name, depth, args in (("tme", 8, ["128", "128", "3", "medium"]), ("tme", 10, ["128", "128", "3", "slow", "amp=0"]),
                               ("mec", 8, ["128", "64", "4", "slow", "threaded-me=0", "rect=0", "amp=0", "bframes=1"]),

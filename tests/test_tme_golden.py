@@ -76,3 +76,21 @@ def test_oracle_replays_the_diamond_searches_of_a_reference_encode(depth):
         assert got == exp, "call %d (%dx%d): oracle %s reference %s" % (i, w, h, got, exp)
         moved += exp[:2] != (0, 0); far += max(abs(exp[0]), abs(exp[1])) > 8
     assert moved > 100 and far > 20          # the second loop (distances 8..64 around a moved centre) is exercised
+
+
+def test_oracle_replays_the_get_pmv_calls_of_reference_encodes():
+    """CUData::getPMV (cudata.cpp:1806-1990): 24,000 distinct recorded calls (threaded-me and regular encodes, P and B pictures, up to three references,
+    temporal candidates) -- AMVP candidates and the motion-candidate list must be the reference's."""
+    import os
+    from tme_util import GOLD
+    rows = np.load(os.path.join(GOLD, "amvp.npz"))["calls"]
+    ora = Oracle(8)
+    assert len(rows) >= 20000
+    scaled = 0
+    for r in rows:
+        amvp, mvc = ora.get_pmv(r[38:92], r[0], r[1], r[2], r[3], r[6:38], r[92], r[93])
+        nm = int(r[98])
+        assert np.array_equal(amvp, r[94:98]) and len(mvc) == 2 * nm and np.array_equal(mvc, r[99:99 + 2 * nm]), "getPMV: list %d ref %d: oracle %s %s reference %s %s" % (
+            r[0], r[1], amvp, mvc, r[94:98], r[99:99 + 2 * nm])
+        scaled += r[92] != r[93]
+    assert scaled > 1000

@@ -153,3 +153,38 @@ def test_diamond_batch_replays_the_predictor_searches_of_threaded_me(depth):
             got = (int(r["mv"][k][0]), int(r["mv"][k][1]), int(r["cost"][k]))
             assert got == exp, "edge window, task %d: hip %s oracle %s (bounds %s %s)" % (k, got, exp, t2["mvmin"][k], t2["mvmax"][k])
     assert checked >= 300
+
+
+def test_amvp_batch_replays_the_get_pmv_calls_of_reference_encodes():
+    """x265hip_amvp_batch against the recorded CUData::getPMV calls (tests/golden/amvp.npz): both AMVP candidates, numMvc and the candidate list."""
+    import os
+    from tme_util import GOLD
+    from x265hip_pkg.frame import AMVP_TASK, AMVP_RESULT
+    rows = np.load(os.path.join(GOLD, "amvp.npz"))["calls"]
+    api = FrameApi(8)
+    T = api.torch
+    # one launch per slice context (current POC, temporal flag, POC lists)
+    ctx = {}
+    for i, r in enumerate(rows):
+        ctx.setdefault((int(r[2]), int(r[3])) + tuple(int(v) for v in r[6:38]), []).append(i)
+    checked = 0
+    for key, idx in ctx.items():
+        n = len(idx)
+        t = np.zeros(n, AMVP_TASK)
+        R = rows[idx]
+        nb = R[:, 38:92].reshape(n, 6, 9)
+        t["nb"]["mv"][:, :, 0, 0] = nb[:, :, 0]; t["nb"]["mv"][:, :, 0, 1] = nb[:, :, 1]; t["nb"]["mv"][:, :, 1, 0] = nb[:, :, 2]; t["nb"]["mv"][:, :, 1, 1] = nb[:, :, 3]
+        t["nb"]["refIdx"][:, :, 0] = nb[:, :, 4]; t["nb"]["refIdx"][:, :, 1] = nb[:, :, 5]; t["nb"]["available"] = nb[:, :, 8]
+        t["list"] = R[:, 0]; t["refIdx"] = R[:, 1]; t["colPOC"] = R[:, 92]; t["colRefPOC"] = R[:, 93]
+        d_t = api.to_device(t)
+        d_out = T.zeros(n * AMVP_RESULT.itemsize, dtype=T.uint8, device="cuda")
+        api.amvp_batch(d_t, n, key[0], key[1], [key[2:18], key[18:34]], d_out)
+        T.cuda.synchronize()
+        o = d_out.cpu().numpy().view(AMVP_RESULT)
+        exp_amvp = R[:, 94:98].reshape(n, 2, 2)
+        assert np.array_equal(o["amvp"], exp_amvp), "AMVP candidates differ (POC %d)" % key[0]
+        assert np.array_equal(o["numMvc"], R[:, 98])
+        exp_mvc = R[:, 99:121].reshape(n, 11, 2)
+        assert np.array_equal(o["mvc"], exp_mvc), "candidate lists differ (POC %d)" % key[0]
+        checked += n
+    assert checked == len(rows) >= 20000

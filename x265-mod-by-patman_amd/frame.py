@@ -13,6 +13,10 @@ ME_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mvmin", "<i2", 2), (
 ME_WINDOW = 1
 ME_RESULT = np.dtype([("mv", "<i2", 2), ("cost", "<i4"), ("mvcost", "<i4"), ("reserved", "<i4")])
 TU_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv", "<i2", 2), ("reconOff", "<i4"), ("mvFrom", "<i4")])
+AMVP_NB = np.dtype([("mv", "<i2", (2, 2)), ("refIdx", "i1", 2), ("available", "i1"), ("reserved", "i1")])
+AMVP_TASK = np.dtype([("nb", AMVP_NB, 6), ("list", "i1"), ("refIdx", "i1"), ("reserved", "<i2"), ("colPOC", "<i4"), ("colRefPOC", "<i4")])
+AMVP_RESULT = np.dtype([("amvp", "<i2", (2, 2)), ("numMvc", "<i2"), ("mvc", "<i2", (11, 2)), ("reserved", "<i2")])
+assert AMVP_NB.itemsize == 12 and AMVP_TASK.itemsize == 84 and AMVP_RESULT.itemsize == 56
 INTER_CHOICE = np.dtype([("mv", "<i2", (2, 2)), ("mvp", "<i2", (2, 2)), ("mvCost", "<u4", 2), ("ref", "i1", 2), ("reserved", "<i2"), ("bits", "<i4"), ("cost", "<u4")])
 assert INTER_CHOICE.itemsize == 36
 LA_TASK = np.dtype([("b", "<i4"), ("p0", "<i4"), ("p1", "<i4"), ("doSearch", "<i4", 2), ("mvSlot", "<i4", 2), ("outSlot", "<i4"), ("weighted0", "<i4")])
@@ -132,6 +136,15 @@ class FrameApi:
         ch = MeChroma(_dp(cur_cb), _dp(cur_cr), cstride_c, _dp(ref_cb), _dp(ref_cr), rstride_c, _dp(cur_off_c), _dp(ref_off_c))
         self.h.check(self.lib.x265hip_me_batch_chroma(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride), _dp(tasks), n,
                                                       _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source), _dp(planes), C.c_int64(plane_elems), C.byref(ch)))
+
+    def amvp_batch(self, tasks, n, cur_poc, temporal, ref_poc, out):
+        """x265hip_amvp_batch: CUData::getPMV for n (PU, list, reference) records; ref_poc = [2][16] ints"""
+        class P(C.Structure):
+            _fields_ = [("curPOC", C.c_int), ("temporalMvp", C.c_int), ("refPOC", (C.c_int * 16) * 2)]
+        p = P(); p.curPOC = int(cur_poc); p.temporalMvp = int(temporal)
+        for l in range(2):
+            for r in range(16): p.refPOC[l][r] = int(ref_poc[l][r])
+        self.h.check(self.lib.x265hip_amvp_batch(self.stream(), _dp(tasks), n, C.byref(p), _dp(out)))
 
     def diamond_batch(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half_range, results):
         """x265hip_diamond_batch: MotionEstimate::diamondSearch for n PUs (full-pel MV, cost)"""
