@@ -103,6 +103,18 @@ typedef struct x265hip_amvp_params { int curPOC; int temporalMvp; int refPOC[2][
 typedef struct x265hip_amvp_result { int16_t amvp[2][2]; int16_t numMvc; int16_t mvc[11][2]; int16_t reserved; } x265hip_amvp_result;   /* 56 bytes */
 int x265hip_amvp_batch(void* stream, const x265hip_amvp_task* tasks, int n, const x265hip_amvp_params* params, x265hip_amvp_result* out);
 
+/* Search::selectMVP (search.cpp:2347-2382) for n PUs of one size: both AMVP candidates clipped to `clip` (CUData::clipMv's limits of the CU: xmin, ymin, xmax, ymax in
+ * quarter-pels, cudata.cpp:2094-2107), motion compensated out of the reference's phase planes and compared with the source PU at SAD; mvpIdx = 0 on a tie or when the
+ * candidates are equal (then no cost is measured).  The m_bFrameParallel exclusions (:2360-2371) are the caller's (they do not depend on pixels). */
+typedef struct x265hip_select_task { int32_t curOff, refOff; int16_t amvp[2][2]; int32_t clip[4]; } x265hip_select_task;        /* 32 bytes */
+typedef struct x265hip_select_result { int32_t mvpIdx; int32_t cost[2]; } x265hip_select_result;
+int x265hip_select_mvp_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* subpelPlanes, int64_t planeElems, intptr_t refStride,
+                             const x265hip_select_task* tasks, int n, x265hip_select_result* out);
+/* Search::updateMVP + checkBestMVP (search.cpp:4947-4967) on n records, in place: with useAlter the bits / cost (counted against `alter`, e.g. the lookahead's MV the
+ * search started from, search.cpp:395-398) are re-based to amvp[mvpIdx]; then the other AMVP candidate takes over if it codes mv in fewer bits. */
+typedef struct x265hip_mvp_bits { int16_t amvp[2][2]; int16_t mv[2]; int16_t alter[2]; int16_t mvpIdx; int16_t useAlter; uint32_t bits; uint32_t cost; } x265hip_mvp_bits;   /* 28 bytes */
+int x265hip_mvp_bits_batch(void* stream, x265hip_mvp_bits* records, int n, const float* bitsRow /* x265hip_mvbits_row, device */, int bitsHalfRange, uint64_t lambda);
+
 /* MotionEstimate::diamondSearch (motion.cpp:631-773) for n PUs of one size: the full-pel predictor search of ThreadedME's first stage
  * (Search::puMotionEstimation with isMVP, search.cpp:355-363 -- the CTU and its four sub-CUs at search range 32; the results seed m_areaBestMV for
  * the PU searches, analysis.cpp:248-306).  Uses of x265hip_me_task: curOff, refOff, mvmin / mvmax (full pel), qmvp (the MVD origin setMVP was

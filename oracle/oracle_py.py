@@ -262,6 +262,27 @@ class Oracle:
         n = self.me_lib.xo_get_pmv(_ptr(nb), int(lst), int(ref_idx), int(cur_poc), int(temporal), _ptr(rp), int(col_poc), int(col_ref_poc), _ptr(amvp), _ptr(mvc))
         return amvp, mvc[:2 * n]
 
+    def select_mvp(self, w, h, fenc, ref, rstride, roff, amvp, clip):
+        a = np.ascontiguousarray(amvp, np.int32); c = np.ascontiguousarray(clip, np.int32); costs = np.zeros(2, np.int32)
+        idx = self.me_lib.xo_select_mvp(w, h, _ptr(fenc), _IP(w), _ptr(ref, roff), _IP(rstride), _ptr(a), _ptr(c), _ptr(costs))
+        return int(idx), costs
+
+    def _bits_centre(self):
+        if not hasattr(self, "_bits"):
+            self._bits = np.zeros(2 * 32768 + 1, np.float32)
+            self.me_lib.xo_mvbits_row(32768, _ptr(self._bits))
+        return _ptr(self._bits, 32768)
+
+    def check_best_mvp(self, lam, amvp, mv, mvp_idx, bits, cost):
+        a = np.ascontiguousarray(amvp, np.int32); io = np.array([mvp_idx, bits, cost], np.uint32)
+        self.me_lib.xo_check_best_mvp(self._bits_centre(), C.c_uint64(lam), _ptr(a), int(mv[0]), int(mv[1]), _ptr(io))
+        return int(io[0]), int(io[1]), int(io[2])
+
+    def update_mvp(self, lam, amvp, mv, alter, bits, cost):
+        io = np.array([bits, cost], np.uint32)
+        self.me_lib.xo_update_mvp(self._bits_centre(), C.c_uint64(lam), int(amvp[0]), int(amvp[1]), int(mv[0]), int(mv[1]), int(alter[0]), int(alter[1]), _ptr(io))
+        return int(io[0]), int(io[1])
+
     def diamond(self, w, h, cur, cstride, coff, ref, rstride, roff, bounds, qmvp, costrow):
         """MotionEstimate::diamondSearch (xo_diamond_search): returns (full-pel mvx, mvy, cost)"""
         b = np.asarray(bounds, np.int32)

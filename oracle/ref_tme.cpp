@@ -28,6 +28,12 @@
  *           common/cudata.cpp; at most X265TME_PMV calls, default 0 = none): ints = { list, refIdx, curPOC, temporalMvpEnabled, numRefIdx[2], refPOCList[2][16],
  *           6 neighbours x { mv0.x, mv0.y, mv1.x, mv1.y, refIdx0, refIdx1, cuAddr0, cuAddr1, isAvailable }, colPOC, colRefPOC (of the temporal candidate, 0 when unused),
  *           amvp0.x, .y, amvp1.x, .y, numMvc, mvc[2 * numMvc] }, no pixels
+ *   kind 6 (Search::selectMVP call, search.cpp:2347-2382; at most X265TME_SEL calls): ints = { planeId, w, h, blockOffset, amvp0.x, .y, amvp1.x, .y, CUData::clipMv's xmin, ymin,
+ *           xmax, ymax for this CU, frameParallel, result }, pixels = w * h (source PU as setSourcePU cached it)
+ *   kind 7 (Search::checkBestMVP, search.cpp:4947-4958): ints = { amvp0.x, .y, amvp1.x, .y, mv.x, .y, mvpIdx, bits, cost, lambda lo, lambda hi, -> mvpIdx, bits, cost }
+ *   kind 8 (Search::updateMVP, search.cpp:4961-4967): ints = { amvp.x, .y, mv.x, .y, alter.x, .y, bits, cost, lambda lo, lambda hi, -> bits, cost }
+ *   (kinds 6-8: the callers live in search.cpp itself, so instead of a renamed second compile the regular search.o gets its three definitions weakened and
+ *   aliased with objcopy -- oracle/Makefile -- and the strong definitions below take every call)
  * With threaded-me=0 on the command line the calls are those of Search::predInterSearch (search.cpp:2582-2700), whose setSourcePU overload enables
  * the chroma SATD terms of subpelCompare (motion.cpp:218-247, 1805-1865) at subme >= 3.
  */
@@ -49,6 +55,7 @@
 #include "slice.h"
 #include "frame.h"
 #include "framedata.h"
+#include "search.h"
 #undef protected
 #undef private
 
@@ -221,6 +228,77 @@ int CUData::getPMV(InterNeighbourMV* neighbours, uint32_t picList, uint32_t refI
 }
 }
 
+/* id of a reconstructed picture's luma plane (as luma_plane_id, keyed by the plane pointer) */
+static int recon_plane_id(const PicYuv* rp)
+{
+    const intptr_t stride = rp->m_stride;
+    const int rows = rp->m_picHeight + 2 * rp->m_lumaMarginY;
+    const pixel* org = rp->m_picOrg[0];
+    const pixel* top = org - (intptr_t)rp->m_lumaMarginY * stride - rp->m_lumaMarginX;
+    uint64_t sum = 1469598103934665603ull;
+    for (intptr_t i = 0; i < stride * rows; i++) sum = (sum ^ top[i]) * 1099511628211ull;
+    auto it = g_planes.find(org);
+    if (it == g_planes.end() || it->second.sum != sum)
+    {
+        Snap s = { g_nextPlane++, sum };
+        g_planes[org] = s;
+        std::vector<uint16_t> px((size_t)stride * rows);
+        for (size_t i = 0; i < px.size(); i++) px[i] = top[i];
+        put(1, { s.id, (int32_t)stride, rows, (int32_t)(rp->m_lumaMarginY * stride + rp->m_lumaMarginX), (int32_t)rp->m_picWidth, (int32_t)rp->m_picHeight }, px);
+        return s.id;
+    }
+    return it->second.id;
+}
+static int g_selCalls, g_selMax, g_chkCalls, g_updCalls, g_dbgMask = 7;
+int selectMVP_ref(Search* self, const CUData& cu, const PredictionUnit& pu, const MV* amvp, int list, int ref) __asm__("xtme_selectMVP");
+const MV& checkBestMVP_ref(const Search* self, const MV* amvpCand, const MV& mv, int& mvpIdx, uint32_t& outBits, uint32_t& outCost) __asm__("xtme_checkBestMVP");
+void updateMVP_ref(Search* self, const MV amvp, const MV& mv, uint32_t& outBits, uint32_t& outCost, const MV& alterMVP) __asm__("xtme_updateMVP");
+namespace X265_NS {
+int Search::selectMVP(const CUData& cu, const PredictionUnit& pu, const MV amvp[AMVP_NUM_CANDS], int list, int ref)
+{
+    const int idx = ::selectMVP_ref(this, cu, pu, amvp, list, ref);
+    if (!g_out || g_selCalls >= g_selMax || amvp[0] == amvp[1] || !(g_dbgMask & 1)) return idx;
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (g_selCalls >= g_selMax) return idx;
+    const PicYuv* rp = m_slice->m_refReconPicList[list][ref];
+    const int planeId = recon_plane_id(rp);
+    const int blockOffset = (int)(rp->getLumaAddr(pu.ctuAddr, pu.cuAbsPartIdx + pu.puAbsPartIdx) - rp->getLumaAddr(0));
+    MV lo(-0x40000000, -0x40000000), hi(0x3fffffff, 0x3fffffff);
+    cu.clipMv(lo); cu.clipMv(hi);                       /* the limits CUData::clipMv applies for this CU */
+    std::vector<int32_t> ints = { planeId, pu.width, pu.height, blockOffset, amvp[0].x, amvp[0].y, amvp[1].x, amvp[1].y, lo.x, lo.y, hi.x, hi.y, (int32_t)m_bFrameParallel, idx };
+    std::vector<uint16_t> px((size_t)pu.width * pu.height);
+    for (int y = 0; y < pu.height; y++)
+        for (int x = 0; x < pu.width; x++) px[(size_t)y * pu.width + x] = m_me.fencPUYuv.m_buf[0][y * FENC_STRIDE + x];
+    put(6, ints, px);
+    g_selCalls++;
+    return idx;
+}
+const MV& Search::checkBestMVP(const MV* amvpCand, const MV& mv, int& mvpIdx, uint32_t& outBits, uint32_t& outCost) const
+{
+    const int i0 = mvpIdx; const uint32_t b0 = outBits, c0 = outCost;
+    const MV& r = ::checkBestMVP_ref(this, amvpCand, mv, mvpIdx, outBits, outCost);
+    if (g_out && g_chkCalls < g_selMax && (g_dbgMask & 2))
+    {
+        std::lock_guard<std::mutex> guard(g_lock);
+        put(7, { amvpCand[0].x, amvpCand[0].y, amvpCand[1].x, amvpCand[1].y, mv.x, mv.y, i0, (int32_t)b0, (int32_t)c0, (int32_t)(m_rdCost.m_lambda & 0xffffffffu), (int32_t)(m_rdCost.m_lambda >> 32),
+                 mvpIdx, (int32_t)outBits, (int32_t)outCost }, {});
+        g_chkCalls++;
+    }
+    return r;
+}
+void Search::updateMVP(const MV amvp, const MV& mv, uint32_t& outBits, uint32_t& outCost, const MV& alterMVP)
+{
+    const uint32_t b0 = outBits, c0 = outCost;
+    ::updateMVP_ref(this, amvp, mv, outBits, outCost, alterMVP);
+    if (g_out && g_updCalls < g_selMax && (g_dbgMask & 4))
+    {
+        std::lock_guard<std::mutex> guard(g_lock);
+        put(8, { amvp.x, amvp.y, mv.x, mv.y, alterMVP.x, alterMVP.y, (int32_t)b0, (int32_t)c0, (int32_t)(m_rdCost.m_lambda & 0xffffffffu), (int32_t)(m_rdCost.m_lambda >> 32), (int32_t)outBits, (int32_t)outCost }, {});
+        g_updCalls++;
+    }
+}
+}
+
 static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixel>& v, int w, int h, int f)
 {   /* textured picture in (not purely translational) motion + deterministic noise: predictors, candidates and search paths vary from PU to PU */
     uint32_t s = 4242u + 733u * (uint32_t)f;
@@ -259,6 +337,8 @@ int main(int argc, char** argv)
         if (eq) *eq = 0;
         if (x265_param_parse(p, argv[i], eq ? eq + 1 : NULL) < 0) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
     }
+    g_selMax = getenv("X265TME_SEL") ? atoi(getenv("X265TME_SEL")) : 0;
+    g_dbgMask = getenv("X265TME_DBG") ? atoi(getenv("X265TME_DBG")) : 7;
     g_pmvMax = getenv("X265TME_PMV") ? atoi(getenv("X265TME_PMV")) : 0;
     g_out = fopen(argv[5], "wb");
     if (!g_out) { fprintf(stderr, "cannot write %s\n", argv[5]); return 2; }
@@ -284,6 +364,6 @@ int main(int argc, char** argv)
     x265_param_free(live);
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(g_out);
-    printf("{\"calls\": %d, \"diamond_calls\": %d, \"pmv_calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_diamonds, g_pmvCalls, g_nextPlane, g_skipped, tme);
+    printf("{\"calls\": %d, \"diamond_calls\": %d, \"pmv_calls\": %d, \"select_calls\": %d, \"check_calls\": %d, \"update_calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_diamonds, g_pmvCalls, g_selCalls, g_chkCalls, g_updCalls, g_nextPlane, g_skipped, tme);
     return 0;
 }

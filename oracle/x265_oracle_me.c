@@ -1004,6 +1004,46 @@ static void mc_luma(const xo_pixel* fref, intptr_t stride, int w, int h, int qx,
     else if (!xf) xo_interp_vpp(8, w, h, src, stride, dst, w, yf);
     else xo_interp_hvpp(8, w, h, src, stride, dst, w, xf, yf);
 }
+/* Search::selectMVP (search.cpp:2347-2382; m_bFrameParallel off): which of the two AMVP candidates predicts the PU better -- each is clipped like CUData::clipMv
+ * (clip = xmin, ymin, xmax, ymax in quarter-pels), the block is motion compensated (predInterLumaPixel) and compared at SAD; ties go to candidate 0.
+ * costs (optional) receives the two SADs. */
+int xo_select_mvp(int w, int h, const xo_pixel* fenc, intptr_t fencStride, const xo_pixel* fref, intptr_t refStride, const int32_t* amvp, const int32_t* clip, int32_t* costs)
+{
+    if (amvp[0] == amvp[2] && amvp[1] == amvp[3]) return 0;
+    xo_pixel pred[64 * 64];
+    int c[2];
+    for (int i = 0; i < 2; i++)
+    {
+        int mx = amvp[2 * i], my = amvp[2 * i + 1];
+        mx = mx < clip[0] ? clip[0] : mx > clip[2] ? clip[2] : mx;            /* X265_MIN(xmax, X265_MAX(xmin, mv.x)), cudata.cpp:2105-2106 */
+        my = my < clip[1] ? clip[1] : my > clip[3] ? clip[3] : my;
+        mc_luma(fref, refStride, w, h, mx, my, pred);
+        c[i] = xo_sad(w, h, fenc, fencStride, pred, w);
+        if (costs) costs[i] = c[i];
+    }
+    return c[0] <= c[1] ? 0 : 1;
+}
+/* Search::checkBestMVP (search.cpp:4947-4958): would the other AMVP candidate code this MV in fewer bits?  io = { mvpIdx, bits, cost } */
+void xo_check_best_mvp(const float* bitsCentre, uint64_t lambda, const int32_t* amvp, int mvx, int mvy, uint32_t* io)
+{
+    const int idx = (int)io[0];
+    const int diffBits = (int)mv_bitcost(bitsCentre, mvx, mvy, amvp[2 * !idx], amvp[2 * !idx + 1]) - (int)mv_bitcost(bitsCentre, mvx, mvy, amvp[2 * idx], amvp[2 * idx + 1]);
+    if (diffBits < 0)
+    {
+        const uint32_t orig = io[1];
+        io[0] = !idx;
+        io[1] = orig + diffBits;
+        io[2] = (io[2] - rd_getcost(lambda, orig)) + rd_getcost(lambda, io[1]);
+    }
+}
+/* Search::updateMVP (search.cpp:4961-4967): bits / cost of the MV against `amvp` when they were counted against `alter`; io = { bits, cost } */
+void xo_update_mvp(const float* bitsCentre, uint64_t lambda, int amvpx, int amvpy, int mvx, int mvy, int alterx, int altery, uint32_t* io)
+{
+    const int diffBits = (int)mv_bitcost(bitsCentre, mvx, mvy, amvpx, amvpy) - (int)mv_bitcost(bitsCentre, mvx, mvy, alterx, altery);
+    const uint32_t orig = io[0];
+    io[0] = orig + diffBits;
+    io[1] = (io[1] - rd_getcost(lambda, orig)) + rd_getcost(lambda, io[0]);
+}
 int xo_bidir_satd(int w, int h, const xo_pixel* fenc, intptr_t fencStride, const xo_pixel* ref0, intptr_t stride0, int mv0x, int mv0y,
                   const xo_pixel* ref1, intptr_t stride1, int mv1x, int mv1y)
 {   /* search.cpp:436-446: predInterLumaPixel twice, pixelavg_pp, SATD */

@@ -47,6 +47,10 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
                   int qmvx, int qmvy, int qp, int addNumerator /*171 or 85*/, const int32_t* quantCoeff,
                   int16_t* coeff /*N*N*/, int32_t* deltaU /*N*N or NULL*/,
                   xo_pixel* recon /*or NULL*/, intptr_t reconStride, uint64_t* sse);
+/* Search::selectMVP / checkBestMVP / updateMVP (search.cpp:2347-2382, 4947-4967); see x265_oracle_me.c */
+int xo_select_mvp(int w, int h, const xo_pixel* fenc, intptr_t fencStride, const xo_pixel* fref, intptr_t refStride, const int32_t* amvp, const int32_t* clip, int32_t* costs);
+void xo_check_best_mvp(const float* bitsCentre, uint64_t lambda, const int32_t* amvp, int mvx, int mvy, uint32_t* io);
+void xo_update_mvp(const float* bitsCentre, uint64_t lambda, int amvpx, int amvpy, int mvx, int mvy, int alterx, int altery, uint32_t* io);
 /* CUData::getPMV (cudata.cpp:1806-1990); see x265_oracle_me.c */
 int xo_get_pmv(const int32_t* nb, int list, int refIdx, int curPOC, int temporalEnabled, const int32_t* refPOC, int colPOC, int colRefPOC, int32_t* amvp, int32_t* mvc);
 /* MotionEstimate::diamondSearch (motion.cpp:631-773); bounds and outMv in full pels; qmvp = the MVD origin of mvcost (setMVP) */

@@ -18,7 +18,7 @@ CALL_FIELDS = ("plane w h blockOffset mnx mny mxx mxy qmvpx qmvpy numCand merang
 DIA_FIELDS = "plane w h blockOffset mnx mny mxx mxy mvpx mvpy qp outx outy cost".split()
 
 
-def parse(path, dias=None, pmvs=None):
+def parse(path, dias=None, pmvs=None, sels=None, chks=None, upds=None):
     d = np.fromfile(path, np.uint8).tobytes()
     off, planes, calls, mvcs, blocks = 0, {}, [], [], []
     while off < len(d):
@@ -30,6 +30,14 @@ def parse(path, dias=None, pmvs=None):
             planes[pid] = (ints, px)
         elif kind == 5:
             if pmvs is not None: pmvs.append(ints)
+        elif kind == 6:
+            npx = int(ints[1]) * int(ints[2])
+            px = np.frombuffer(d, np.uint16, npx, off).copy(); off += 2 * npx
+            if sels is not None: sels.append((ints, px))
+        elif kind == 7:
+            if chks is not None: chks.append(ints)
+        elif kind == 8:
+            if upds is not None: upds.append(ints)
         elif kind == 4:
             npx = int(ints[1]) * int(ints[2])
             px = np.frombuffer(d, np.uint16, npx, off).copy(); off += 2 * npx
@@ -85,6 +93,32 @@ def build_dia(depth, args, out):
     return calls
 
 
+def build_mvpsel(depth, args, out):
+    """mvpsel_{8,10}.npz: Search::selectMVP calls (source PU, reference plane, both AMVP candidates, clipMv limits -> index) and the checkBestMVP / updateMVP
+    records of a --threaded-me encode (ref_tme.cpp kinds 6-8)"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265tme_%d" % depth)
+    sels, chks, upds = [], [], []
+    with tempfile.TemporaryDirectory() as td:
+        raw = os.path.join(td, "tme.bin")
+        subprocess.check_call([exe] + args[:4] + [raw] + args[4:], stdout=subprocess.DEVNULL, env=dict(os.environ, X265TME_SEL="1000000"))
+        planes, _, _, _ = parse(raw, None, None, sels, chks, upds)
+    dt = np.uint8 if depth == 8 else np.uint16
+    rng = np.random.default_rng(11)
+    keep = sorted(rng.permutation(len(sels))[:2400].tolist())
+    sels = [sels[i] for i in keep]
+    calls = np.stack([i for i, _ in sels]).astype(np.int32)
+    starts = np.concatenate([[0], np.cumsum([len(b) for _, b in sels])]).astype(np.int64)
+    chk = np.unique(np.stack(chks), axis=0); upd = np.unique(np.stack(upds), axis=0)
+    data = {"select": calls, "fenc": np.concatenate([b for _, b in sels]).astype(dt), "fenc_start": starts, "check": chk[rng.permutation(len(chk))[:6000]], "update": upd[rng.permutation(len(upd))[:3000]],
+            "cmdline": np.array(" ".join(args))}
+    for pid in set(int(v) for v in calls[:, 0]):
+        ints, px = planes[pid]
+        data["plane%d_geom" % pid] = ints
+        data["plane%d" % pid] = px.astype(dt)
+    np.savez_compressed(out, **data)
+    return calls, data["check"], data["update"]
+
+
 def build_amvp(out):
     """amvp.npz: CUData::getPMV calls (ref_tme.cpp kind 5) of a --threaded-me encode and of a regular encode with B pictures and several references; the records
     are bit-depth independent (8-bit harness); identical records are kept once.  Row layout = the recorder's (fixed 99 ints + 22 mvc ints, zero padded)."""
@@ -116,6 +150,11 @@ if __name__ == "__main__":
         f = {n: c[:, i] for i, n in enumerate(DIA_FIELDS)}
         print("dia", depth, "calls", len(c), "size", os.path.getsize(out), "shapes", sorted({(int(a), int(b)) for a, b in zip(f["w"], f["h"])}), "out range", f["outx"].min(), f["outx"].max(), f["outy"].min(), f["outy"].max(),
               "mvp", np.unique(f["mvpx"]), np.unique(f["mvpy"]))
+    for depth in (8, 10):
+        out = os.path.join(ROOT, "tests", "golden", "mvpsel_%d.npz" % depth)
+        c, k, u = build_mvpsel(depth, ["128", "128", "5", "slow", "bframes=2"], out)
+        print("mvpsel", depth, "select", len(c), "picked", np.bincount(c[:, 13]), "shapes", len({(int(a), int(b)) for a, b in zip(c[:, 1], c[:, 2])}), "check", len(k), "switched", int((k[:, 11] != k[:, 6]).sum()),
+              "update", len(u), "size", os.path.getsize(out))
     r = build_amvp(os.path.join(ROOT, "tests", "golden", "amvp.npz"))
     print("amvp calls", len(r), "size", os.path.getsize(os.path.join(ROOT, "tests", "golden", "amvp.npz")), "numMvc", np.bincount(r[:, 98]), "temporal used", int((r[:, 93] != 0).sum() + (r[:, 92] != 0).sum()),
           "lists", np.bincount(r[:, 0]), "refs", np.bincount(r[:, 1]))

@@ -94,3 +94,21 @@ def test_oracle_replays_the_get_pmv_calls_of_reference_encodes():
             r[0], r[1], amvp, mvc, r[94:98], r[99:99 + 2 * nm])
         scaled += r[92] != r[93]
     assert scaled > 1000
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_oracle_replays_select_check_update_mvp(depth):
+    """Search::selectMVP, checkBestMVP, updateMVP (search.cpp:2347-2382, 4947-4967) on the records of a --threaded-me encode"""
+    from tme_util import MvpSelFixture, u32, lam64
+    fx, ora = MvpSelFixture(depth), Oracle(depth)
+    assert len(fx.select) >= 2000
+    for i, r in enumerate(fx.select):
+        pl = fx.planes[int(r[0])]
+        idx, _ = ora.select_mvp(int(r[1]), int(r[2]), fx.block(i), pl["px"], pl["stride"], pl["origin"] + int(r[3]), r[4:8], r[8:12])
+        assert idx == int(r[13]), "selectMVP call %d (%dx%d): oracle %d reference %d" % (i, r[1], r[2], idx, r[13])
+    for r in fx.check:
+        got = ora.check_best_mvp(lam64(r[9], r[10]), r[0:4], (r[4], r[5]), int(r[6]), u32(r[7]), u32(r[8]))
+        assert got == (int(r[11]), u32(r[12]), u32(r[13]))
+    for r in fx.update:
+        got = ora.update_mvp(lam64(r[8], r[9]), (r[0], r[1]), (r[2], r[3]), (r[4], r[5]), u32(r[6]), u32(r[7]))
+        assert got == (u32(r[10]), u32(r[11]))

@@ -188,3 +188,68 @@ def test_amvp_batch_replays_the_get_pmv_calls_of_reference_encodes():
         assert np.array_equal(o["mvc"], exp_mvc), "candidate lists differ (POC %d)" % key[0]
         checked += n
     assert checked == len(rows) >= 20000
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_select_mvp_and_mvp_bits_replay_the_reference_records(depth):
+    """x265hip_select_mvp_batch against the recorded Search::selectMVP calls (index; the two SADs against the oracle's), x265hip_mvp_bits_batch against the
+    recorded checkBestMVP and updateMVP calls."""
+    from tme_util import MvpSelFixture, u32, lam64
+    from backends import Oracle
+    from x265hip_pkg.frame import SELECT_TASK, SELECT_RESULT, MVP_BITS
+    fx, api, ora = MvpSelFixture(depth), FrameApi(depth), Oracle(depth)
+    T = api.torch
+    S = fx.select
+    groups = {}
+    for i, r in enumerate(S):
+        groups.setdefault((int(r[0]), int(r[1]), int(r[2])), []).append(i)
+    d_phase = {}
+    checked = 0
+    for (pid, w, h), idx in groups.items():
+        pl = fx.planes[pid]
+        if pid not in d_phase:
+            d_ref = api.to_device(pl["px"])
+            d_phase[pid] = T.zeros(16 * pl["px"].size, dtype=d_ref.dtype, device="cuda")
+            api.subpel_planes(d_ref, pl["stride"], pl["rows"], d_phase[pid], pl["px"].size)
+        n = len(idx)
+        t = np.zeros(n, SELECT_TASK)
+        cur = np.concatenate([fx.block(i) for i in idx])
+        t["curOff"] = np.arange(n) * (w * h); t["refOff"] = pl["origin"] + S[idx, 3]
+        t["amvp"] = S[idx, 4:8].reshape(n, 2, 2); t["clip"] = S[idx, 8:12]
+        d_t, d_cur = api.to_device(t), api.to_device(cur)
+        d_out = T.zeros(n * SELECT_RESULT.itemsize, dtype=T.uint8, device="cuda")
+        api.select_mvp_batch(w, h, d_cur, w, d_phase[pid], pl["px"].size, pl["stride"], d_t, n, d_out)
+        T.cuda.synchronize()
+        o = d_out.cpu().numpy().view(SELECT_RESULT)
+        assert np.array_equal(o["mvpIdx"], S[idx, 13]), "selectMVP %dx%d plane %d" % (w, h, pid)
+        for k in range(0, n, 7):
+            _, costs = ora.select_mvp(w, h, fx.block(idx[k]), pl["px"], pl["stride"], pl["origin"] + int(S[idx[k], 3]), S[idx[k], 4:8], S[idx[k], 8:12])
+            assert tuple(o["cost"][k]) == tuple(int(v) for v in costs)
+        checked += n
+    assert checked == len(S)
+    bits_row = np.zeros(2 * 32768 + 1, np.float32)
+    api.h.check(api.lib.x265hip_mvbits_row(32768, bits_row.ctypes.data_as(__import__("ctypes").c_void_p)))
+    d_bits = api.to_device(bits_row.view(np.int32))
+    for rows, upd in ((fx.check, False), (fx.update, True)):
+        lams = {}
+        for i, r in enumerate(rows):
+            lams.setdefault(lam64(r[8], r[9]) if upd else lam64(r[9], r[10]), []).append(i)
+        for lam, idx in lams.items():
+            R = rows[idx]; n = len(idx)
+            rec = np.zeros(n, MVP_BITS)
+            if upd:
+                # updateMVP alone: make both AMVP candidates the new base so that the checkBestMVP step that follows changes nothing
+                rec["amvp"][:, 0, 0] = R[:, 0]; rec["amvp"][:, 0, 1] = R[:, 1]; rec["amvp"][:, 1] = rec["amvp"][:, 0]
+                rec["mv"][:, 0] = R[:, 2]; rec["mv"][:, 1] = R[:, 3]; rec["alter"][:, 0] = R[:, 4]; rec["alter"][:, 1] = R[:, 5]
+                rec["useAlter"] = 1; rec["bits"] = R[:, 6].astype(np.uint32); rec["cost"] = R[:, 7].astype(np.uint32)
+            else:
+                rec["amvp"] = R[:, 0:4].reshape(n, 2, 2); rec["mv"][:, 0] = R[:, 4]; rec["mv"][:, 1] = R[:, 5]
+                rec["mvpIdx"] = R[:, 6]; rec["bits"] = R[:, 7].astype(np.uint32); rec["cost"] = R[:, 8].astype(np.uint32)
+            d_rec = api.to_device(rec)
+            api.mvp_bits_batch(d_rec, n, d_bits, 32768, lam)
+            T.cuda.synchronize()
+            o = d_rec.cpu().numpy().view(MVP_BITS)
+            if upd:
+                assert np.array_equal(o["bits"], R[:, 10].astype(np.uint32)) and np.array_equal(o["cost"], R[:, 11].astype(np.uint32))
+            else:
+                assert np.array_equal(o["mvpIdx"], R[:, 11]) and np.array_equal(o["bits"], R[:, 12].astype(np.uint32)) and np.array_equal(o["cost"], R[:, 13].astype(np.uint32))

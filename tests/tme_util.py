@@ -82,3 +82,29 @@ class DiaFixture:
 
     def block(self, i):
         return self.fenc[self.start[i]:self.start[i + 1]]
+
+
+class MvpSelFixture:
+    """tests/golden/mvpsel_{8,10}.npz: Search::selectMVP calls and checkBestMVP / updateMVP records of a --threaded-me encode"""
+    def __init__(self, depth):
+        d = np.load(os.path.join(GOLD, "mvpsel_%d.npz" % depth))
+        self.depth = depth
+        self.select, self.check, self.update = d["select"], d["check"], d["update"]
+        self.fenc, self.start = d["fenc"], d["fenc_start"]
+        self.planes = {}
+        for k in d.files:
+            if k.startswith("plane") and k.endswith("_geom"):
+                pid = int(k[5:-5])
+                g = d[k]
+                self.planes[pid] = dict(stride=int(g[1]), rows=int(g[2]), origin=int(g[3]), px=d["plane%d" % pid])
+
+    def block(self, i):
+        return self.fenc[self.start[i]:self.start[i + 1]]
+
+
+def u32(v):
+    return int(v) & 0xFFFFFFFF
+
+
+def lam64(lo, hi):
+    return u32(lo) | (u32(hi) << 32)

@@ -17,6 +17,10 @@ AMVP_NB = np.dtype([("mv", "<i2", (2, 2)), ("refIdx", "i1", 2), ("available", "i
 AMVP_TASK = np.dtype([("nb", AMVP_NB, 6), ("list", "i1"), ("refIdx", "i1"), ("reserved", "<i2"), ("colPOC", "<i4"), ("colRefPOC", "<i4")])
 AMVP_RESULT = np.dtype([("amvp", "<i2", (2, 2)), ("numMvc", "<i2"), ("mvc", "<i2", (11, 2)), ("reserved", "<i2")])
 assert AMVP_NB.itemsize == 12 and AMVP_TASK.itemsize == 84 and AMVP_RESULT.itemsize == 56
+SELECT_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("amvp", "<i2", (2, 2)), ("clip", "<i4", 4)])
+SELECT_RESULT = np.dtype([("mvpIdx", "<i4"), ("cost", "<i4", 2)])
+MVP_BITS = np.dtype([("amvp", "<i2", (2, 2)), ("mv", "<i2", 2), ("alter", "<i2", 2), ("mvpIdx", "<i2"), ("useAlter", "<i2"), ("bits", "<u4"), ("cost", "<u4")])
+assert SELECT_TASK.itemsize == 32 and SELECT_RESULT.itemsize == 12 and MVP_BITS.itemsize == 28
 INTER_CHOICE = np.dtype([("mv", "<i2", (2, 2)), ("mvp", "<i2", (2, 2)), ("mvCost", "<u4", 2), ("ref", "i1", 2), ("reserved", "<i2"), ("bits", "<i4"), ("cost", "<u4")])
 assert INTER_CHOICE.itemsize == 36
 LA_TASK = np.dtype([("b", "<i4"), ("p0", "<i4"), ("p1", "<i4"), ("doSearch", "<i4", 2), ("mvSlot", "<i4", 2), ("outSlot", "<i4"), ("weighted0", "<i4")])
@@ -145,6 +149,12 @@ class FrameApi:
         for l in range(2):
             for r in range(16): p.refPOC[l][r] = int(ref_poc[l][r])
         self.h.check(self.lib.x265hip_amvp_batch(self.stream(), _dp(tasks), n, C.byref(p), _dp(out)))
+
+    def select_mvp_batch(self, w, h, cur, cstride, planes, plane_elems, rstride, tasks, n, out):
+        self.h.check(self.lib.x265hip_select_mvp_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(planes), C.c_int64(plane_elems), C.c_ssize_t(rstride), _dp(tasks), n, _dp(out)))
+
+    def mvp_bits_batch(self, records, n, bits_row, half_range, lam):
+        self.h.check(self.lib.x265hip_mvp_bits_batch(self.stream(), _dp(records), n, _dp(bits_row), half_range, C.c_uint64(lam)))
 
     def diamond_batch(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_row, half_range, results):
         """x265hip_diamond_batch: MotionEstimate::diamondSearch for n PUs (full-pel MV, cost)"""
