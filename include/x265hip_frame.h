@@ -287,7 +287,9 @@ int x265hip_cutree_finish(void* stream, int ncu, const int32_t* intraCost, const
 /* SAO statistics of a whole deblocked picture: SAO::calcSaoStatsCTU (encoder/sao.cpp:729-905) for one plane of every CTU, one slice,
  * bLimitSAO off.  fenc / recon point at pixel (0,0) of the source and the reconstructed plane (same stride).  Luma: planeOffset 0; a 4:2:0 chroma
  * plane: its own width / height / CTU size (picture and CTU sizes halved, sao.cpp:748-756) and planeOffset 2 (:773).  out: per CTU (raster order)
- * [2][5][32] int32 = m_offsetOrg then m_count, types in the order SAO_EO_0..3, SAO_BO (sao.h:43-50).  nonDeblocked = param bSaoNonDeblocked. */
+ * [2][5][32] int32 = m_offsetOrg then m_count, types in the order SAO_EO_0..3, SAO_BO (sao.h:43-50).  nonDeblocked = param bSaoNonDeblocked (0 / 1);
+ * nonDeblocked = 2: the statistics SAO::calcSaoStatsCu_BeforeDblk collects instead (sao.cpp:908-1207) -- the bottom / right border of every CTU that the deblocked
+ * statistics leave out under sao-non-deblock, with `recon` = the picture BEFORE deblocking (m_offsetOrgPreDblk / m_countPreDblk of each CTU, same layout). */
 int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
                             int planeOffset, int32_t* out);
 

@@ -6,7 +6,9 @@
  * (position, first / last row flags) the function reads.  It pins the frame-level restatement xo_sao_stats_frame (region rules of
  * every offset class) and through it the HIP batch x265hip_sao_stats_frame.  Luma plane, one slice, deblocked statistics (the default).
  *
- * usage: x265sao_<depth> <width> <height> <ctu> <in.raw> <out.bin> [sao-non-deblock 0|1] [planes 1|3]
+ * usage: x265sao_<depth> <width> <height> <ctu> <in.raw> <out.bin> [sao-non-deblock 0|1|2] [planes 1|3]
+ *   sao-non-deblock 2: the statistics SAO::calcSaoStatsCu_BeforeDblk collects (sao.cpp:908-1207) -- the bottom / right border of every CTU, on the picture as it is BEFORE
+ *   deblocking (in.raw's reconstructed planes are taken as that picture); same output layout
  *   in.raw  : per plane (Y, then Cb, Cr of a 4:2:0 picture when planes = 3) the source plane then the reconstructed plane, tightly packed
  *   out.bin : per plane, per CTU 5 x 32 int32 offsetOrg then 5 x 32 int32 count (types SAO_EO_0..3, SAO_BO as in sao.h:43-50)
  * apply mode (argv[8] = params.bin: per plane, per CTU 6 int32 = typeIdx (-1 = off), bandPos, offset[4]): the SAO of the picture (luma, and Cb / Cr through
@@ -34,6 +36,8 @@ struct SaoX : public SAO
     void clear() { memset(m_count, 0, sizeof(m_count)); memset(m_offsetOrg, 0, sizeof(m_offsetOrg)); }
     const int32_t* counts() const { return &m_count[0][0][0]; }
     const int32_t* sums() const { return &m_offsetOrg[0][0][0]; }
+    const int32_t* preCounts(int addr) const { return &m_countPreDblk[addr][0][0][0]; }
+    const int32_t* preSums(int addr) const { return &m_offsetOrgPreDblk[addr][0][0][0]; }
     pixel* aboveRow(int plane = 0) { return m_tmpU[plane]; }
 };
 
@@ -46,7 +50,8 @@ int main(int argc, char** argv)
     const int nplanes = argc > 7 ? atoi(argv[7]) : 1;
     p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = nplanes == 3 ? X265_CSP_I420 : X265_CSP_I400; p->maxCUSize = ctu;
     p->maxLog2CUSize = ctu == 64 ? 6 : ctu == 32 ? 5 : 4; p->unitSizeDepth = p->maxLog2CUSize - 2;       /* Encoder::configure */
-    p->bSaoNonDeblocked = argc > 6 ? atoi(argv[6]) : 0; p->bLimitSAO = 0;
+    const int statMode = argc > 6 ? atoi(argv[6]) : 0;
+    p->bSaoNonDeblocked = statMode ? 1 : 0; p->bLimitSAO = 0;
     x265_setup_primitives(p);
     SPS sps; memset(&sps, 0, sizeof(sps));
     sps.numCuInWidth = (W + ctu - 1) / ctu; sps.numCuInHeight = (H + ctu - 1) / ctu; sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
@@ -137,6 +142,18 @@ int main(int argc, char** argv)
             for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) o[(size_t)y * w + x] = rp->m_picOrg[c][(intptr_t)y * st + x];
             fwrite(o.data(), 4, o.size(), out);
         }
+        fclose(out); fclose(in);
+        return 0;
+    }
+    if (statMode == 2)
+    {
+        for (uint32_t a = 0; a < sps.numCUsInFrame; a++) sao.calcSaoStatsCu_BeforeDblk(&frame, (int)(a % sps.numCuInWidth), (int)(a / sps.numCuInWidth));
+        for (int plane = 0; plane < nplanes; plane++)
+            for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
+            {
+                fwrite(sao.preSums((int)a) + plane * 5 * 32, 4, 5 * 32, out);
+                fwrite(sao.preCounts((int)a) + plane * 5 * 32, 4, 5 * 32, out);
+            }
         fclose(out); fclose(in);
         return 0;
     }

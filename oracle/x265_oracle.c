@@ -943,6 +943,50 @@ void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t st
     }
 }
 
+/* SAO::calcSaoStatsCu_BeforeDblk (encoder/sao.cpp:908-1207) for every CTU of one plane: the statistics of the bottom / right border the deblocked statistics
+ * leave out (--sao-non-deblock), taken on the picture BEFORE deblocking.  Restated per pixel: every pixel is classified against its real neighbours (what the
+ * reference's sign buffers hold, including the entries its comments say it recomputes), and a class counts it when it lies in the class's window
+ * [firstX, endX) x [firstY, endY) and right of startX or below startY.  Same output layout and plane conventions as xo_sao_stats_frame. */
+void xo_sao_stats_frame_predeblock(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int planeOffset, int32_t* out)
+{
+    static const int eoTable[5] = { 1, 2, 0, 3, 4 };
+    const int po = planeOffset, boShift = X265_DEPTH - 5;
+    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
+    for (int addr = 0; addr < nx * ny; addr++)
+    {
+        const int lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;
+        const int firstRow = addr < nx, lastRow = addr >= nx * ny - nx;
+        const int above = (!tpely) | firstRow;
+        const int rpelx = lpelx + ctuSize < picWidth ? lpelx + ctuSize : picWidth, bpely = tpely + ctuSize < picHeight ? tpely + ctuSize : picHeight;
+        const int cw = rpelx - lpelx, ch = bpely - tpely;
+        const int picH = lastRow ? bpely : picHeight;
+        const int atRight = rpelx == picWidth, atBottom = bpely == picH, firstX = !lpelx;
+        int32_t* stats = out + (size_t)addr * 320; int32_t* count = stats + 160;
+        memset(stats, 0, 320 * sizeof(int32_t));
+        /* per type: startX, startY (:985-986, 1008-1009, 1040-1041, 1084-1085, 1138-1139) */
+        const int boX = atRight ? cw : cw - (4 - po), boY = atBottom ? ch : ch - (3 - po);
+        const int e0X = atRight ? cw - 1 : cw - (5 - po), e0Y = atBottom ? ch : ch - (3 - po);
+        const int e1X = atRight ? cw : cw - (4 - po), e1Y = atBottom ? ch - 1 : ch - (4 - po);
+        const int e2X = atRight ? cw - 1 : cw - (5 - po), e2Y = atBottom ? ch - 1 : ch - (4 - po);
+        for (int y = 0; y < ch; y++)
+            for (int x = 0; x < cw; x++)
+            {
+                const xo_pixel* r = recon + (tpely + y) * stride + lpelx + x;
+                const int c = r[0], d = (int)fenc[(tpely + y) * stride + lpelx + x] - c;
+                if (x >= boX || y >= boY) { stats[4 * 32 + (c >> boShift)] += d; count[4 * 32 + (c >> boShift)]++; }
+                if (x < cw - 1 && x >= (y < e0Y ? e0X : firstX))
+                { const int e = eoTable[sgn(c - r[-1]) + sgn(c - r[1]) + 2]; stats[e] += d; count[e]++; }
+                if (y >= above && y < ch - 1 && (x >= e1X || y >= e1Y))
+                { const int e = eoTable[sgn(c - r[-stride]) + sgn(c - r[stride]) + 2]; stats[32 + e] += d; count[32 + e]++; }
+                if (y >= above && y < ch - 1 && x >= firstX && x < cw - 1 && (x >= e2X || y >= e2Y))
+                {
+                    const int e2 = eoTable[sgn(c - r[-stride - 1]) + sgn(c - r[stride + 1]) + 2]; stats[64 + e2] += d; count[64 + e2]++;
+                    const int e3 = eoTable[sgn(c - r[-stride + 1]) + sgn(c - r[stride - 1]) + 2]; stats[96 + e3] += d; count[96 + e3]++;
+                }
+            }
+    }
+}
+
 /* Encoder::computeSSD (encoder/encoder.cpp:1203-1270): the sum of squared differences of two planes -- what PSNR is computed from.  Its
  * block-wise fast path adds the same integers as the "slow path" loop restated here. */
 uint64_t xo_plane_ssd(const xo_pixel* fenc, const xo_pixel* rec, intptr_t stride, int width, int height)

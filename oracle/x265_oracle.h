@@ -93,6 +93,7 @@ void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t s
 
 /* SAO::calcSaoStatsCTU, every CTU of one plane of a picture (sao.cpp:729-905; chroma: the plane's own sizes + planeOffset 2); out: per CTU [2][5][32] int32 (offsetOrg, count; EO_0..3, BO) */
 void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out);
+void xo_sao_stats_frame_predeblock(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int planeOffset, int32_t* out);
 
 /* SAO of a luma plane, out of place (sao.cpp:268-623); params: per CTU { typeIdx, bandPos, offset[4] } */
 void xo_sao_apply_frame(const xo_pixel* in, xo_pixel* out, intptr_t stride, int picWidth, int picHeight, int ctuSize, const int32_t* params);

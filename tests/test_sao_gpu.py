@@ -21,17 +21,19 @@ def test_sao_stats_slots_match_oracle(depth):
 
 @pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("size,ctu,nd,po", [((200, 136), 64, 0, 0), ((192, 128), 64, 0, 0), ((72, 40), 32, 0, 0), ((130, 70), 16, 0, 0), ((200, 136), 64, 1, 0),
-                                            ((64, 64), 64, 0, 0), ((1920, 1080), 64, 0, 0), ((100, 68), 32, 0, 2), ((960, 540), 32, 1, 2), ((36, 20), 8, 0, 2)])
+                                            ((64, 64), 64, 0, 0), ((1920, 1080), 64, 0, 0), ((100, 68), 32, 0, 2), ((960, 540), 32, 1, 2), ((36, 20), 8, 0, 2),
+                                            ((200, 136), 64, 2, 0), ((1920, 1080), 64, 2, 0), ((130, 70), 16, 2, 0), ((960, 540), 32, 2, 2), ((100, 68), 32, 2, 2), ((64, 64), 64, 2, 0)])
 def test_sao_frame_stats_match_oracle(depth, size, ctu, nd, po):
     """x265hip_sao_stats_frame (all CTUs of a picture in one launch) against the oracle's calcSaoStatsCTU (pinned to the reference's SAO class)"""
     import ctypes as C
     from x265hip_pkg.frame import FrameApi
-    from test_sao_oracle_vs_ref import sao_frame_oracle, sao_frame_pair
+    from test_sao_oracle_vs_ref import sao_frame_oracle, sao_frame_oracle_pre, sao_frame_pair
     api = FrameApi(depth)
     t = api.torch
     W, H = size
     fenc, rec = sao_frame_pair(depth, W, H, 170 + depth + W)
-    exp = sao_frame_oracle(Oracle(depth), fenc, rec, ctu, nd, po)
+    # nd = 2: SAO::calcSaoStatsCu_BeforeDblk's border statistics (rec = the picture before deblocking)
+    exp = sao_frame_oracle_pre(Oracle(depth), fenc, rec, ctu, po) if nd == 2 else sao_frame_oracle(Oracle(depth), fenc, rec, ctu, nd, po)
     d_f, d_r = api.to_device(fenc.reshape(-1)), api.to_device(rec.reshape(-1))
     d_out = t.full((exp.size,), -7, dtype=t.int32, device="cuda")
     P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731

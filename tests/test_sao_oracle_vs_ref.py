@@ -184,3 +184,36 @@ def test_sao_apply_chroma_matches_reference(depth, size, ctu):
         bad = np.argwhere(ref[c] != got.astype(np.int32))
         assert bad.size == 0, "plane %d first differing pixel (y, x) %s: reference %d oracle %d" % (c, bad[0], ref[c][tuple(bad[0])], got[tuple(bad[0])])
         assert (ref[c] != planes[c][1].astype(np.int32)).sum() > 0
+
+
+def sao_frame_oracle_pre(ora, fenc, rec, ctu, plane_offset=0):
+    import ctypes as C
+    H, W = fenc.shape
+    n = ((W + ctu - 1) // ctu) * ((H + ctu - 1) // ctu)
+    out = np.zeros((n, 2, 5, 32), np.int32)
+    P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+    f, r = np.ascontiguousarray(fenc), np.ascontiguousarray(rec)
+    ora.lib.xo_sao_stats_frame_predeblock(P(f), P(r), C.c_ssize_t(W), W, H, ctu, plane_offset, P(out))
+    return out
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((192, 128), 64), ((72, 40), 32), ((136, 72), 16), ((64, 64), 64)])
+def test_sao_predeblock_stats_match_reference(depth, size, ctu):
+    """SAO::calcSaoStatsCu_BeforeDblk (sao.cpp:908-1207): the border statistics on the not yet deblocked picture, luma and 4:2:0 chroma, against the
+    reference's SAO class (oracle/ref_sao.cpp, mode 2)"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth)):
+        pytest.skip("no reference SAO binary")
+    W, H = size
+    y = sao_frame_pair(depth, W, H, 17 + depth + W)
+    cb, cr = sao_frame_pair(depth, W // 2, H // 2, 18 + depth + W), sao_frame_pair(depth, W // 2, H // 2, 19 + depth + W)
+    a = sao_frame_reference(depth, y[0], y[1], ctu, 2, chroma=[cb, cr])
+    ora = Oracle(depth)
+    exp = [sao_frame_oracle_pre(ora, y[0], y[1], ctu, 0), sao_frame_oracle_pre(ora, cb[0], cb[1], ctu // 2, 2), sao_frame_oracle_pre(ora, cr[0], cr[1], ctu // 2, 2)]
+    for plane in range(3):
+        for addr in range(a.shape[1]):
+            for t in range(5):
+                assert np.array_equal(a[plane, addr, :, t], exp[plane][addr, :, t]), "plane %d CTU %d type %d" % (plane, addr, t)
+    assert a[0, :, 1].sum() > 0 or (W <= ctu and H <= ctu)            # a picture of one CTU has no border left out

@@ -191,6 +191,10 @@ __global__ __launch_bounds__(1024) void sao_frame_kernel(const pixel* __restrict
     const int e0X = atRight ? cw - 1 : cw - 5 + po, e0Y = ch - (nonDeblocked ? 3 : 4) + po;
     const int e1X = atRight ? cw : cw - (nonDeblocked ? 4 : 5) + po, e1Y = atBottom ? ch - 1 : ch - 4 + po;
     const int e2X = atRight ? cw - 1 : cw - 5 + po, e2Y = atBottom ? ch - 1 : ch - 4 + po;
+    // nonDeblocked == 2: the border statistics before deblocking (skipB / skipR per class: BO 3 / 4, EO_0 3 / 5, EO_1 4 / 4, EO_2 and EO_3 4 / 5)
+    const bool pre = nonDeblocked == 2;
+    const int pBoX = atRight ? cw : cw - 4 + po, pBoY = atBottom ? ch : ch - 3 + po;            // BO startX / startY; EO_0 shares startY, EO_1 startX
+    const int pE2X = atRight ? cw - 1 : cw - 5 + po, pE2Y = atBottom ? ch - 1 : ch - 4 + po;    // EO_0 / EO_2 / EO_3 startX; EO_1 / EO_2 / EO_3 startY
     int sum[4][5], cnt[4][5];
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -211,9 +215,15 @@ __global__ __launch_bounds__(1024) void sao_frame_kernel(const pixel* __restrict
         const int c = rc[gx], d = (int)fenc[(intptr_t)gy * stride + gx] - c;
         const int nA[4] = { (int)rc[xm], (int)rm[gx], (int)rm[xm], (int)rm[xp] };      // (-1,0) (0,-1) (-1,-1) (1,-1)
         const int nB[4] = { (int)rc[xp], (int)rp[gx], (int)rp[xp], (int)rp[xm] };      // (1,0)  (0,1)  (1,1)   (-1,1)
-        if (x < boX && y < boY) { atomicAdd(&s_bo[wave][0][c >> (X265_DEPTH - 5)], d); atomicAdd(&s_bo[wave][1][c >> (X265_DEPTH - 5)], 1); }
-        const bool in[4] = { x >= startX && x < e0X && y < e0Y, x < e1X && y >= above && y < e1Y,
-                             x >= startX && x < e2X && y >= above && y < e2Y, x >= startX && x < e2X && y >= above && y < e2Y };
+        // pre: SAO::calcSaoStatsCu_BeforeDblk (:908-1207) -- the complement, the CTU's bottom / right border on the picture before deblocking: inside the
+        // class's window [firstX, cw - 1) x [above, ch - 1) and right of its startX or below its startY
+        const bool boHit = pre ? (x >= pBoX || y >= pBoY) : (x < boX && y < boY);
+        if (boHit) { atomicAdd(&s_bo[wave][0][c >> (X265_DEPTH - 5)], d); atomicAdd(&s_bo[wave][1][c >> (X265_DEPTH - 5)], 1); }
+        const bool inD[4] = { x >= startX && x < e0X && y < e0Y, x < e1X && y >= above && y < e1Y,
+                              x >= startX && x < e2X && y >= above && y < e2Y, x >= startX && x < e2X && y >= above && y < e2Y };
+        const bool diagP = y >= above && y < ch - 1 && x >= startX && x < cw - 1 && (x >= pE2X || y >= pE2Y);
+        const bool inP[4] = { x < cw - 1 && x >= (y < pBoY ? pE2X : startX), y >= above && y < ch - 1 && (x >= pBoX || y >= pE2Y), diagP, diagP };
+        const bool in[4] = { pre ? inP[0] : inD[0], pre ? inP[1] : inD[1], pre ? inP[2] : inD[2], pre ? inP[3] : inD[3] };
 #pragma unroll
         for (int k = 0; k < 4; k++)
         {
