@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--qp", type=int, default=28)
     ap.add_argument("--refs", type=int, default=1, help="list-0 reference pictures searched per source picture (preset medium: 3, slow: 4 -- param.cpp:567-587); each is searched down the "
                     "pyramid, x265hip_inter_merge_batch chooses per PU, the TQ stage compensates from the chosen reference.  value stays Mpixels/s of SOURCE pixels")
+    ap.add_argument("--rect", action="store_true", help="also search the 2NxN / Nx2N PUs of every CU (bEnableRectInter, preset slow and up): 425 PUs per CTU instead of 85; one reference")
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
@@ -651,7 +652,7 @@ def main():
     half = 1 << 15
     cost_row = mvcost_row(depth, args.qp, half)
     pipe = FramePipeline(depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"],
-                         tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api, use_planes=not args.no_planes, refs=args.refs)
+                         tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api, use_planes=not args.no_planes, refs=args.refs, rect=args.rect)
     assert pipe.margin == MARGIN
     pipe.upload(pairs)                      # inputs are resident in HBM before the timed region
 
@@ -703,7 +704,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames,
-                       "ctu": 64, "pus_per_ctu": 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": args.refs, "qp": args.qp,
+                       "ctu": 64, "pus_per_ctu": 425 if args.rect else 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": args.refs, "qp": args.qp,
                        "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": ("TQ on a side stream beside the me16/me8 launches (it needs the me32 MVs only), joined per step" if pipe.overlap_tq else "kernel by kernel") + "; per-kernel events on every 4th step", "sharding": "independent frames per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "strictly the longest average launch of the step", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(dom), "traffic_source": traffic_src if traffic_all.get(dom) is not None else None,

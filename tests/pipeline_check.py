@@ -25,6 +25,22 @@ def check_sample(pipe, oracle, rng, per_level=40, n_tu=40):
             got = (int(res[lv][i]["mv"][0]), int(res[lv][i]["mv"][1]), int(res[lv][i]["cost"]))
             assert got == exp, "ME level %d task %d: hip %s oracle %s" % (lv, i, got, exp)
             checked += 1
+    if getattr(pipe, "rect", False):
+        for (w, h), t in pipe.rect_host.items():
+            lv = max(w, h)
+            rr = pipe.rect_results(w, h)
+            for i in rng.choice(len(t), size=min(max(per_level // 2, 4), len(t)), replace=False):
+                tk = t[i]
+                qmvp = tuple(int(v) for v in res[lv][tk["mvpFrom"]]["mv"])
+                d = pipe.merange << 2
+                lx0, ly0, lx1, ly1 = int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])
+                b = [min(lx1, max(lx0, qmvp[0] - d)) >> 2, min(ly1, max(ly0, qmvp[1] - d)) >> 2, min(lx1, max(lx0, qmvp[0] + d)) >> 2, min(ly1, max(ly0, qmvp[1] + d)) >> 2]
+                b[3] = max(b[3], b[1])
+                exp = oracle.me(w, h, pipe.cur_host, pipe.stride, int(tk["curOff"]), pipe.ref_host, pipe.stride, int(tk["refOff"]), b, qmvp, [], pipe.merange, pipe.method,
+                                pipe.subme, pipe.cost_row_host)
+                got = (int(rr[i]["mv"][0]), int(rr[i]["mv"][1]), int(rr[i]["cost"]))
+                assert got == exp, "rect PU %dx%d task %d: hip %s oracle %s" % (w, h, i, got, exp)
+                checked += 1
     n = 1 << pipe.tu_log2
     coeff = pipe.d_coeff.cpu().numpy().reshape(-1, n * n)
     numsig = pipe.d_numsig.cpu().numpy()

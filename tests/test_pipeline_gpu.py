@@ -206,3 +206,17 @@ def test_several_references_match_oracle(depth, method, subme, refs):
     assert check_sample_refs(pipe, Oracle(depth), np.random.default_rng(1), per_level=10, n_tu=16) >= 50
     chosen = {int(r) for lv in LEVELS for r in pipe.choices(lv)["ref"][:, 0]}
     assert len(chosen) >= 2, "the clip should make more than one reference win: %s" % chosen
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method,subme", [(1, 2), (3, 3)])
+def test_rectangular_partitions_match_oracle(depth, method, subme):
+    """param bEnableRectInter (preset slow and up): the 2NxN / Nx2N PUs of every CU of the pyramid (64x32 ... 4x8, 425 PUs per CTU with the squares), each
+    seeded by its CU's 2Nx2N result -- sampled PUs of every shape against the oracle."""
+    row = mvcost_row(depth, 28, 1 << 15)
+    pipe = FramePipeline(depth, 256, 128, 2, qp=28, merange=24, method=method, subme=subme, tu_log2=4, cost_row=row, rect=True)
+    assert sum(len(t) for t in pipe.rect_host.values()) + sum(len(t) for t in pipe.tasks_host.values()) == 2 * (256 // 64) * (128 // 64) * 425
+    pipe.upload([frame_pair(256, 128, depth, 140 + s, margin=pipe.margin, max_shift=14)[:2] for s in range(2)])
+    pipe.step()
+    pipe.torch.cuda.synchronize()
+    assert check_sample(pipe, Oracle(depth), np.random.default_rng(3 * depth + method), per_level=12, n_tu=8) >= 8 * 6 + 40

@@ -60,9 +60,36 @@ def pyramid_tasks(W, H, F, margin, tu_log2):
     return tasks, tu, mv_level
 
 
+RECT_SHAPES = tuple((w, h) for lv in LEVELS for (w, h) in ((lv, lv // 2), (lv // 2, lv)))     # 2NxN and Nx2N of every CU size: 64x32 ... 4x8
+
+
+def rect_tasks(W, H, F, margin):
+    """Task lists of the rectangular partitions (param bEnableRectInter: preset slow and up, param.cpp:572-587): for every CU of the pyramid its two 2NxN and two
+    Nx2N PUs (g_puLookup, encoder/threadedme.h:67-92), each seeded with the MV of its own CU's 2Nx2N search (mvpFrom indexes that level's results).
+    {(w, h): ME_TASK array}"""
+    stride = W + 2 * margin
+    plane = stride * (H + 2 * margin)
+    out = {}
+    for lv in LEVELS:
+        for (w, h) in ((lv, lv // 2), (lv // 2, lv)):
+            nx, ny = W // w, H // h
+            t = np.zeros(F * nx * ny, ME_TASK)
+            f, by, bx = np.meshgrid(np.arange(F), np.arange(ny), np.arange(nx), indexing="ij")
+            x, y, f = (bx * w).reshape(-1), (by * h).reshape(-1), f.reshape(-1)
+            off = f * plane + (margin + y) * stride + margin + x
+            t["curOff"] = off; t["refOff"] = off
+            cx, cy = (x // lv) * lv, (y // lv) * lv                 # CUData::clipMv works on the CU's position (cudata.cpp:2094-2107)
+            t["mvmin"][:, 0] = -((CTU + 8 + cx - 1) << 2); t["mvmin"][:, 1] = -((CTU + 8 + cy - 1) << 2)
+            t["mvmax"][:, 0] = (W + 8 - cx - 1) << 2; t["mvmax"][:, 1] = (H + 8 - cy - 1) << 2
+            t["flags"] = ME_WINDOW
+            t["mvpFrom"] = f * ((W // lv) * (H // lv)) + (y // lv) * (W // lv) + (x // lv)
+            out[(w, h)] = t
+    return out
+
+
 class FramePipeline:
     def __init__(self, depth, width, height, frames, qp=28, merange=57, method=1, subme=2, tu_log2=5, margin=96,
-                 recon=False, cost_row=None, api=None, use_planes=True, refs=1):
+                 recon=False, cost_row=None, api=None, use_planes=True, refs=1, rect=False):
         """refs > 1: every source picture is searched in `refs` list-0 reference pictures (param->maxNumReferences); each reference has its own predictor
         chain down the pyramid (m_areaBestMV[area][list][ref], analysis.cpp:248-306), x265hip_inter_merge_batch picks the reference per PU with the
         reference's bit / cost rule, and the TQ stage compensates every TU from the reference its PU chose."""
@@ -74,6 +101,8 @@ class FramePipeline:
         self.recon = recon
         self.use_planes = use_planes
         self.refs = refs
+        self.rect = rect                                         # also search the 2NxN / Nx2N PUs of every CU (425 PUs per CTU instead of 85)
+        assert not rect or refs == 1, "rect: one reference"
         assert refs == 1 or use_planes, "several references: the phase planes are required"
         self.d_planes = None
         self.stride = width + 2 * margin
@@ -107,6 +136,10 @@ class FramePipeline:
             self.bits_row_host = mvbits_row(self.depth, self.bits_half)
             self.d_bits = self.api.to_device(self.bits_row_host.view(np.int32)).view(T.float32)
             self.rd_lambda = rd_lambda(self.depth, self.qp)
+        if self.rect:
+            self.rect_host = rect_tasks(self.W, self.H, self.F, self.margin)
+            self.d_rect_tasks = {k: self.api.to_device(t) for k, t in self.rect_host.items()}
+            self.d_rect_results = {k: T.zeros(len(t) * ME_RESULT.itemsize, dtype=T.uint8, device="cuda") for k, t in self.rect_host.items()}
         self.d_tu = self.api.to_device(tu)
         self.d_coeff = T.zeros(len(tu) * n * n, dtype=T.int16, device="cuda")
         self.d_numsig = T.zeros(len(tu), dtype=T.int32, device="cuda")
@@ -152,6 +185,13 @@ class FramePipeline:
                           self.d_cost, self.half, self.merange, self.method, self.subme, self.d_results[lv], mvp_source=parent,
                           planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
 
+    def launch_rect(self, lv):
+        """the 2NxN and Nx2N PUs of the CUs of size lv, seeded by the 2Nx2N results of the same CUs"""
+        for k in ((lv, lv // 2), (lv // 2, lv)):
+            self.api.me_batch(k[0], k[1], self.d_cur, self.stride, self.d_ref, self.stride, self.d_rect_tasks[k], len(self.rect_host[k]), self.d_cost, self.half, self.merange,
+                              self.method, self.subme, self.d_rect_results[k], mvp_source=self.d_results[lv],
+                              planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
+
     def _launch_me_refs(self, lv):
         """the level searched in every reference (each with its own parent chain), then the per-PU choice"""
         n = len(self.tasks_host[lv])
@@ -196,6 +236,8 @@ class FramePipeline:
         forked = False
         for lv in LEVELS:
             run("me%d" % lv, lambda: self.launch_me(lv), main)
+            if self.rect:
+                run("rect%d" % lv, lambda: self.launch_rect(lv), main)
             if lv == self.mv_level and self.overlap_tq:
                 self.ev_fork.record(main)
                 self.side.wait_event(self.ev_fork)
@@ -211,7 +253,8 @@ class FramePipeline:
     # ---- what bench.py reports about a step ----
     def kernel_names(self):
         """names of the launches of one step, in order (the keys of step()'s event dictionary)"""
-        return (["planes"] if self.use_planes else []) + ["me%d" % lv for lv in LEVELS] + ["tq"]
+        me = [n for lv in LEVELS for n in (["me%d" % lv, "rect%d" % lv] if self.rect else ["me%d" % lv])]
+        return (["planes"] if self.use_planes else []) + me + ["tq"]
 
     def algorithmic_bytes(self):
         """SURVEY 8(d) compulsory bytes per launch: each plane byte once + the records the launch writes (16 B per PU, 2 B per
@@ -219,6 +262,9 @@ class FramePipeline:
         bpp = 1 if self.depth == 8 else 2
         px = self.pixels_per_step
         alg = {"me%d" % lv: px * (1 + self.refs) * bpp + len(self.tasks_host[lv]) * 16 * self.refs for lv in LEVELS}
+        if self.rect:
+            for lv in LEVELS:
+                alg["rect%d" % lv] = 2 * (px * 2 * bpp) + sum(len(self.rect_host[k]) for k in ((lv, lv // 2), (lv // 2, lv))) * 16
         alg["tq"] = px * (2 * bpp + 2) + len(self.tu_host) * 4 + (px * bpp if self.recon else 0)
         if self.use_planes:
             alg["planes"] = self.F * self.plane * bpp * 17 * self.refs
@@ -227,6 +273,9 @@ class FramePipeline:
     # ---- read-back ----
     def results(self, lv, ref=0):
         return (self.d_results_ref[ref][lv] if self.refs > 1 else self.d_results[lv]).cpu().numpy().view(ME_RESULT)
+
+    def rect_results(self, w, h):
+        return self.d_rect_results[(w, h)].cpu().numpy().view(ME_RESULT)
 
     def choices(self, lv):
         return self.d_choice[lv].cpu().numpy().view(INTER_CHOICE)
