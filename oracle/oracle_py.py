@@ -273,6 +273,13 @@ class Oracle:
             self.me_lib.xo_mvbits_row(32768, _ptr(self._bits))
         return _ptr(self._bits, 32768)
 
+    def mv_bitcost(self, mv, mvp):
+        fn = self.me_lib.xo_mv_bitcost; fn.restype = C.c_uint32
+        return int(fn(self._bits_centre(), int(mv[0]), int(mv[1]), int(mvp[0]), int(mvp[1])))
+
+    def bidir_satd(self, w, h, fenc, ref0, ref1, rstride, roff, mv0, mv1):
+        return int(self.me_lib.xo_bidir_satd(w, h, _ptr(fenc), _IP(w), _ptr(ref0, roff), _IP(rstride), int(mv0[0]), int(mv0[1]), _ptr(ref1, roff), _IP(rstride), int(mv1[0]), int(mv1[1])))
+
     def check_best_mvp(self, lam, amvp, mv, mvp_idx, bits, cost):
         a = np.ascontiguousarray(amvp, np.int32); io = np.array([mvp_idx, bits, cost], np.uint32)
         self.me_lib.xo_check_best_mvp(self._bits_centre(), C.c_uint64(lam), _ptr(a), int(mv[0]), int(mv[1]), _ptr(io))

@@ -34,6 +34,7 @@
  *   kind 8 (Search::updateMVP, search.cpp:4961-4967): ints = { amvp.x, .y, mv.x, .y, alter.x, .y, bits, cost, lambda lo, lambda hi, -> bits, cost }
  *   (kinds 6-8: the callers live in search.cpp itself, so instead of a renamed second compile the regular search.o gets its three definitions weakened and
  *   aliased with objcopy -- oracle/Makefile -- and the strong definitions below take every call)
+ *   kind 9 / 10: a whole Search::puMotionEstimation call with everything under it (see below; at most X265TME_PU calls)
  * With threaded-me=0 on the command line the calls are those of Search::predInterSearch (search.cpp:2582-2700), whose setSourcePU overload enables
  * the chroma SATD terms of subpelCompare (motion.cpp:218-247, 1805-1865) at subme >= 3.
  */
@@ -56,6 +57,7 @@
 #include "frame.h"
 #include "framedata.h"
 #include "search.h"
+#include "threadedme.h"
 #undef protected
 #undef private
 
@@ -69,8 +71,13 @@ static int g_nextPlane, g_calls, g_skipped;
 /* heights of enum LumaPU (primitives.h:52-64), in its order */
 static const int g_lumaH[25] = { 4, 8, 16, 32, 64, 4, 8, 8, 16, 16, 32, 32, 64, 12, 16, 4, 16, 24, 32, 8, 32, 48, 64, 16, 64 };
 
+/* a Search::puMotionEstimation call being recorded on this thread (kind 9): what the functions under it record is collected here and written behind the
+ * call's own record, in call order */
+struct Composite { std::vector<int> kinds; std::vector<std::vector<int32_t>> ints; std::vector<std::vector<uint16_t>> px; };
+static thread_local Composite* t_cur;
 static void put(int kind, const std::vector<int32_t>& ints, const std::vector<uint16_t>& px)
 {
+    if (t_cur && kind != 1 && kind != 3) { t_cur->kinds.push_back(kind); t_cur->ints.push_back(ints); t_cur->px.push_back(px); return; }
     const int32_t hdr[2] = { kind, (int32_t)ints.size() };
     fwrite(hdr, 4, 2, g_out); fwrite(ints.data(), 4, ints.size(), g_out); fwrite(px.data(), 2, px.size(), g_out);
 }
@@ -197,9 +204,8 @@ int CUData::getPMV(InterNeighbourMV* neighbours, uint32_t picList, uint32_t refI
     InterNeighbourMV in[6];
     memcpy(in, neighbours, sizeof(in));
     const int numMvc = ::getPMV_ref(this, neighbours, picList, refIdx, amvpCand, pmv);
-    if (!g_out || g_pmvCalls >= g_pmvMax) return numMvc;
+    if (!g_out || (g_pmvCalls >= g_pmvMax && !t_cur)) return numMvc;
     std::lock_guard<std::mutex> guard(g_lock);
-    if (g_pmvCalls >= g_pmvMax) return numMvc;
     std::vector<int32_t> ints = { (int32_t)picList, (int32_t)refIdx, m_slice->m_poc, (int32_t)m_slice->m_sps->bTemporalMVPEnabled, m_slice->m_numRefIdx[0], m_slice->m_numRefIdx[1] };
     for (int l = 0; l < 2; l++)
         for (int r = 0; r < 16; r++) ints.push_back(m_slice->m_refPOCList[l][r]);
@@ -257,9 +263,8 @@ namespace X265_NS {
 int Search::selectMVP(const CUData& cu, const PredictionUnit& pu, const MV amvp[AMVP_NUM_CANDS], int list, int ref)
 {
     const int idx = ::selectMVP_ref(this, cu, pu, amvp, list, ref);
-    if (!g_out || g_selCalls >= g_selMax || amvp[0] == amvp[1] || !(g_dbgMask & 1)) return idx;
+    if (!g_out || (g_selCalls >= g_selMax && !t_cur) || amvp[0] == amvp[1] || !(g_dbgMask & 1)) return idx;
     std::lock_guard<std::mutex> guard(g_lock);
-    if (g_selCalls >= g_selMax) return idx;
     const PicYuv* rp = m_slice->m_refReconPicList[list][ref];
     const int planeId = recon_plane_id(rp);
     const int blockOffset = (int)(rp->getLumaAddr(pu.ctuAddr, pu.cuAbsPartIdx + pu.puAbsPartIdx) - rp->getLumaAddr(0));
@@ -277,7 +282,7 @@ const MV& Search::checkBestMVP(const MV* amvpCand, const MV& mv, int& mvpIdx, ui
 {
     const int i0 = mvpIdx; const uint32_t b0 = outBits, c0 = outCost;
     const MV& r = ::checkBestMVP_ref(this, amvpCand, mv, mvpIdx, outBits, outCost);
-    if (g_out && g_chkCalls < g_selMax && (g_dbgMask & 2))
+    if (g_out && (g_chkCalls < g_selMax || t_cur) && (g_dbgMask & 2))
     {
         std::lock_guard<std::mutex> guard(g_lock);
         put(7, { amvpCand[0].x, amvpCand[0].y, amvpCand[1].x, amvpCand[1].y, mv.x, mv.y, i0, (int32_t)b0, (int32_t)c0, (int32_t)(m_rdCost.m_lambda & 0xffffffffu), (int32_t)(m_rdCost.m_lambda >> 32),
@@ -290,12 +295,111 @@ void Search::updateMVP(const MV amvp, const MV& mv, uint32_t& outBits, uint32_t&
 {
     const uint32_t b0 = outBits, c0 = outCost;
     ::updateMVP_ref(this, amvp, mv, outBits, outCost, alterMVP);
-    if (g_out && g_updCalls < g_selMax && (g_dbgMask & 4))
+    if (g_out && (g_updCalls < g_selMax || t_cur) && (g_dbgMask & 4))
     {
         std::lock_guard<std::mutex> guard(g_lock);
         put(8, { amvp.x, amvp.y, mv.x, mv.y, alterMVP.x, alterMVP.y, (int32_t)b0, (int32_t)c0, (int32_t)(m_rdCost.m_lambda & 0xffffffffu), (int32_t)(m_rdCost.m_lambda >> 32), (int32_t)outBits, (int32_t)outCost }, {});
         g_updCalls++;
     }
+}
+}
+
+/* ---- kind 9: a whole Search::puMotionEstimation call of the PU stage (isMVP = false), search.cpp:226-556 ----
+ * ints = { 1 (layout version), isInterP, numRefIdx[2], curPOC, temporalMvpEnabled, refPOCList[2][16], part, log2CUSize, cuPelX, cuPelY (the CU), puOffset, areaIdx, finalIdx,
+ *          neighborIdx[5], searchRange, searchMethod, subpelRefine, lambda lo, lambda hi, picWidth, picHeight, maxCUSize, numPart, maxSlices,
+ *          m_areaBestMV[areaIdx][list][ref] x, y for list 0..1, ref 0..3 (16 ints),
+ *          the 5 neighbour MEData records as the call finds them: mv[0].x, .y, mv[1].x, .y, ref[0], ref[1] (30 ints; -2 in ref[0] = no such neighbour),
+ *          per partition: pos, then the MEData the call left at pos: mv[0], mv[1], mvp[0], mvp[1] (8 ints), mvCost[2], ref[2], bits, cost,
+ *          per partition, list, reference 0..3: the reference FRAME's MEData at pos (mv[0].x, .y, mv[1].x, .y, ref[0], ref[1]; ref[0] = -3: that frame is intra / absent),
+ *          per partition: x, y (luma position in the picture), w, h;  per list, reference 0..3: id of the plane motionEstimate searches (slice->m_mref[l][r], weighted or not) and of the
+ *          reconstructed picture selectMVP / the bidirectional candidate read (m_refReconPicList[l][r]); -1 = no such reference,
+ *          number of records that follow }, pixels = the partitions' source blocks (w * h each)
+ * followed by that many records of kinds 2, 5, 6, 7, 8, 10 in call order -- everything the call did.  kind 10 = Search::getLowresMV: { list, ref, result.x, .y } */
+static int g_puCalls, g_puMax;
+void puMotionEstimation_real(Search* self, const Slice* slice, const CUGeom& cuGeom, CUData& cu, PicYuv* fencPic, int puOffset, PartSize part, int areaIdx, int finalIdx, bool isMVP,
+                             const int* neighborIdx) __asm__("xtme_puMotionEstimation");
+MV getLowresMV_real(Search* self, const CUData& cu, const PredictionUnit& pu, int list, int ref) __asm__("xtme_getLowresMV");
+namespace X265_NS {
+MV Search::getLowresMV(const CUData& cu, const PredictionUnit& pu, int list, int ref)
+{
+    const MV r = ::getLowresMV_real(this, cu, pu, list, ref);
+    if (t_cur) { std::lock_guard<std::mutex> guard(g_lock); put(10, { list, ref, r.x, r.y }, {}); }
+    return r;
+}
+void Search::puMotionEstimation(const Slice* slice, const CUGeom& cuGeom, CUData& cu, PicYuv* fencPic, int puOffset, PartSize part, int areaIdx, int finalIdx, bool isMVP, const int* neighborIdx)
+{
+    if (isMVP || !g_out || g_puCalls >= g_puMax) { ::puMotionEstimation_real(this, slice, cuGeom, cu, fencPic, puOffset, part, areaIdx, finalIdx, isMVP, neighborIdx); return; }
+    const int numCols = m_slice->m_sps->numCuInWidth;
+    const int slotIdx = (cu.m_cuAddr / numCols) * numCols + cu.m_cuAddr % numCols;
+    std::vector<int32_t> ints = { 1, (int32_t)slice->isInterP(), slice->m_numRefIdx[0], slice->m_numRefIdx[1], slice->m_poc, (int32_t)slice->m_sps->bTemporalMVPEnabled };
+    for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) ints.push_back(slice->m_refPOCList[l][r]);
+    const int numPart = (int)cu.getNumPartInter(0);
+    for (int32_t v : { (int32_t)part, (int32_t)cuGeom.log2CUSize, (int32_t)(cu.m_cuPelX), (int32_t)(cu.m_cuPelY), puOffset, areaIdx, finalIdx,
+                       neighborIdx[0], neighborIdx[1], neighborIdx[2], neighborIdx[3], neighborIdx[4], m_param->searchRange, m_param->searchMethod, m_param->subpelRefine,
+                       (int32_t)(m_rdCost.m_lambda & 0xffffffffu), (int32_t)(m_rdCost.m_lambda >> 32), (int32_t)m_slice->m_sps->picWidthInLumaSamples, (int32_t)m_slice->m_sps->picHeightInLumaSamples,
+                       (int32_t)m_param->maxCUSize, numPart, (int32_t)m_param->maxSlices }) ints.push_back(v);
+    for (int l = 0; l < 2; l++) for (int r = 0; r < 4; r++) { ints.push_back(m_areaBestMV[areaIdx][l][r].x); ints.push_back(m_areaBestMV[areaIdx][l][r].y); }
+    for (int d = 0; d < 5; d++)
+    {
+        if (neighborIdx[d] >= 0)
+        {
+            const MEData& nd = slice->m_ctuMV[slotIdx * MAX_NUM_PUS_PER_CTU + neighborIdx[d]];
+            for (int32_t v : { nd.mv[0].x, nd.mv[0].y, nd.mv[1].x, nd.mv[1].y, nd.ref[0], nd.ref[1] }) ints.push_back(v);
+        }
+        else for (int32_t v : { 0, 0, 0, 0, -2, -2 }) ints.push_back(v);
+    }
+    /* the reference frames' own records at the partitions' slots (the fallback predictor of :313-330), read before the call */
+    std::vector<int32_t> refRec;
+    for (int pi = 0; pi < numPart; pi++)
+        for (int l = 0; l < 2; l++)
+            for (int r = 0; r < 4; r++)
+            {
+                const Frame* rf = (l < (slice->isInterP() ? 1 : 2) && r < slice->m_numRefIdx[l]) ? slice->m_refFrameList[l][r] : NULL;
+                if (rf && rf->m_encData->m_slice->m_sliceType != I_SLICE && rf->m_encData->m_slice->m_ctuMV)
+                {
+                    const MEData& md = rf->m_encData->m_slice->m_ctuMV[slotIdx * MAX_NUM_PUS_PER_CTU + finalIdx + pi * puOffset];
+                    for (int32_t v : { md.mv[0].x, md.mv[0].y, md.mv[1].x, md.mv[1].y, md.ref[0], md.ref[1] }) refRec.push_back(v);
+                }
+                else for (int32_t v : { 0, 0, 0, 0, -3, -3 }) refRec.push_back(v);
+            }
+    std::vector<int32_t> geo; std::vector<uint16_t> blocks;
+    for (int pi = 0; pi < numPart; pi++)
+    {
+        PredictionUnit pu(cu, cuGeom, pi);
+        const int x = cu.m_cuPelX + g_zscanToPelX[pu.puAbsPartIdx], y = cu.m_cuPelY + g_zscanToPelY[pu.puAbsPartIdx];
+        for (int32_t v : { x, y, pu.width, pu.height }) geo.push_back(v);
+        const pixel* src = fencPic->m_picOrg[0] + (intptr_t)y * fencPic->m_stride + x;
+        for (int yy = 0; yy < pu.height; yy++) for (int xx = 0; xx < pu.width; xx++) blocks.push_back(src[(intptr_t)yy * fencPic->m_stride + xx]);
+    }
+    {
+        std::lock_guard<std::mutex> guard(g_lock);
+        for (int l = 0; l < 2; l++)
+            for (int r = 0; r < 4; r++)
+            {
+                const bool on = l < (slice->isInterP() ? 1 : 2) && r < slice->m_numRefIdx[l];
+                geo.push_back(on ? luma_plane_id(&slice->m_mref[l][r]) : -1);
+                geo.push_back(on ? recon_plane_id(slice->m_refReconPicList[l][r]) : -1);
+            }
+    }
+    Composite c;
+    t_cur = &c;
+    ::puMotionEstimation_real(this, slice, cuGeom, cu, fencPic, puOffset, part, areaIdx, finalIdx, isMVP, neighborIdx);
+    t_cur = nullptr;
+    for (int pi = 0; pi < numPart; pi++)
+    {
+        const int pos = finalIdx + pi * puOffset;
+        const MEData& o = slice->m_ctuMV[slotIdx * MAX_NUM_PUS_PER_CTU + pos];
+        for (int32_t v : { pos, o.mv[0].x, o.mv[0].y, o.mv[1].x, o.mv[1].y, o.mvp[0].x, o.mvp[0].y, o.mvp[1].x, o.mvp[1].y, (int32_t)o.mvCost[0], (int32_t)o.mvCost[1], o.ref[0], o.ref[1], o.bits, (int32_t)o.cost })
+            ints.push_back(v);
+    }
+    ints.insert(ints.end(), refRec.begin(), refRec.end());
+    ints.insert(ints.end(), geo.begin(), geo.end());
+    ints.push_back((int32_t)c.kinds.size());
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (g_puCalls >= g_puMax) return;
+    put(9, ints, blocks);
+    for (size_t i = 0; i < c.kinds.size(); i++) put(c.kinds[i], c.ints[i], c.px[i]);
+    g_puCalls++;
 }
 }
 
@@ -337,6 +441,7 @@ int main(int argc, char** argv)
         if (eq) *eq = 0;
         if (x265_param_parse(p, argv[i], eq ? eq + 1 : NULL) < 0) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
     }
+    g_puMax = getenv("X265TME_PU") ? atoi(getenv("X265TME_PU")) : 0;
     g_selMax = getenv("X265TME_SEL") ? atoi(getenv("X265TME_SEL")) : 0;
     g_dbgMask = getenv("X265TME_DBG") ? atoi(getenv("X265TME_DBG")) : 7;
     g_pmvMax = getenv("X265TME_PMV") ? atoi(getenv("X265TME_PMV")) : 0;
@@ -364,6 +469,6 @@ int main(int argc, char** argv)
     x265_param_free(live);
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(g_out);
-    printf("{\"calls\": %d, \"diamond_calls\": %d, \"pmv_calls\": %d, \"select_calls\": %d, \"check_calls\": %d, \"update_calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_diamonds, g_pmvCalls, g_selCalls, g_chkCalls, g_updCalls, g_nextPlane, g_skipped, tme);
+    printf("{\"calls\": %d, \"diamond_calls\": %d, \"pmv_calls\": %d, \"select_calls\": %d, \"check_calls\": %d, \"update_calls\": %d, \"pu_calls\": %d, \"planes\": %d, \"skipped\": %d, \"threaded_me\": %d}\n", g_calls, g_diamonds, g_pmvCalls, g_selCalls, g_chkCalls, g_updCalls, g_puCalls, g_nextPlane, g_skipped, tme);
     return 0;
 }

@@ -991,6 +991,7 @@ static uint32_t mv_bitcost(const float* bitsCentre, int mvx, int mvy, int px, in
 {   /* bitcost.h:60-70 */
     return (uint32_t)(bitsCentre[mvx - px] + bitsCentre[mvy - py] + 0.5f);
 }
+uint32_t xo_mv_bitcost(const float* bitsCentre, int mvx, int mvy, int px, int py) { return mv_bitcost(bitsCentre, mvx, mvy, px, py); }
 uint64_t xo_rd_lambda(int qp) { return (uint64_t)floor(256.0 * xo_lambda(qp)); }          /* RDCost::setLambda, rdcost.h:88-92 */
 static uint32_t rd_getcost(uint64_t lambda, uint32_t bits) { return (uint32_t)((bits * lambda + 128) >> 8); }   /* rdcost.h:164-169 */
 

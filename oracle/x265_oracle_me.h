@@ -47,6 +47,7 @@ uint32_t xo_tq_tu(int log2TrSize, const xo_pixel* cur, intptr_t curStride, const
                   int qmvx, int qmvy, int qp, int addNumerator /*171 or 85*/, const int32_t* quantCoeff,
                   int16_t* coeff /*N*N*/, int32_t* deltaU /*N*N or NULL*/,
                   xo_pixel* recon /*or NULL*/, intptr_t reconStride, uint64_t* sse);
+uint32_t xo_mv_bitcost(const float* bitsCentre, int mvx, int mvy, int px, int py);   /* BitCost::bitcost(mv, mvp), bitcost.h:66-70 */
 /* Search::selectMVP / checkBestMVP / updateMVP (search.cpp:2347-2382, 4947-4967); see x265_oracle_me.c */
 int xo_select_mvp(int w, int h, const xo_pixel* fenc, intptr_t fencStride, const xo_pixel* fref, intptr_t refStride, const int32_t* amvp, const int32_t* clip, int32_t* costs);
 void xo_check_best_mvp(const float* bitsCentre, uint64_t lambda, const int32_t* amvp, int mvx, int mvy, uint32_t* io);

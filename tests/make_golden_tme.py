@@ -119,6 +119,38 @@ def build_mvpsel(depth, args, out):
     return calls, data["check"], data["update"]
 
 
+def build_pu(depth, args, out, n_keep=700):
+    """pu_{8,10}.npz: whole Search::puMotionEstimation calls of a --threaded-me encode (ref_tme.cpp kind 9) with the records of everything under them (ints only: the
+    source blocks travel with the call record), P and B pictures; a sample of n_keep calls that keeps every bidirectional / list-1 outcome"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tme_pu
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265tme_%d" % depth)
+    with tempfile.TemporaryDirectory() as td:
+        raw = os.path.join(td, "tme.bin")
+        subprocess.check_call([exe] + args[:4] + [raw] + args[4:], stdout=subprocess.DEVNULL, env=dict(os.environ, X265TME_PU="1000000"))
+        planes, calls = tme_pu.parse_stream(raw)
+    rng = np.random.default_rng(3)
+    special = [i for i, c in enumerate(calls) if any(tme_pu.decode(c)["out"][p][12] >= 0 for p in range(int(c["ints"][58])))]
+    keep = sorted(set(special[:250]) | set(rng.permutation(len(calls))[:n_keep].tolist()))
+    calls = [calls[i] for i in keep]
+    dt = np.uint8 if depth == 8 else np.uint16
+    data = {"call_ints": np.concatenate([c["ints"] for c in calls]), "call_ints_start": np.concatenate([[0], np.cumsum([len(c["ints"]) for c in calls])]),
+            "call_px": np.concatenate([c["px"] for c in calls]).astype(dt), "call_px_start": np.concatenate([[0], np.cumsum([len(c["px"]) for c in calls])]),
+            "sub_kind": np.array([k for c in calls for (k, _, _) in c["subs"]], np.int32), "sub_ints": np.concatenate([i for c in calls for (_, i, _) in c["subs"]]),
+            "sub_ints_start": np.concatenate([[0], np.cumsum([len(i) for c in calls for (_, i, _) in c["subs"]])]),
+            "call_sub_start": np.concatenate([[0], np.cumsum([len(c["subs"]) for c in calls])]), "cmdline": np.array(" ".join(args))}
+    used = set()
+    for c in calls:
+        d = tme_pu.decode(c)
+        used |= set(int(v) for v in d["planeIds"].reshape(-1) if v >= 0)
+    for pid in used:
+        ints, px = planes[pid]
+        data["plane%d_geom" % pid] = ints
+        data["plane%d" % pid] = px.astype(dt)
+    np.savez_compressed(out, **data)
+    return calls
+
+
 def build_amvp(out):
     """amvp.npz: CUData::getPMV calls (ref_tme.cpp kind 5) of a --threaded-me encode and of a regular encode with B pictures and several references; the records
     are bit-depth independent (8-bit harness); identical records are kept once.  Row layout = the recorder's (fixed 99 ints + 22 mvc ints, zero padded)."""
@@ -150,6 +182,10 @@ if __name__ == "__main__":
         f = {n: c[:, i] for i, n in enumerate(DIA_FIELDS)}
         print("dia", depth, "calls", len(c), "size", os.path.getsize(out), "shapes", sorted({(int(a), int(b)) for a, b in zip(f["w"], f["h"])}), "out range", f["outx"].min(), f["outx"].max(), f["outy"].min(), f["outy"].max(),
               "mvp", np.unique(f["mvpx"]), np.unique(f["mvpy"]))
+    for depth in (8, 10):
+        out = os.path.join(ROOT, "tests", "golden", "pu_%d.npz" % depth)
+        c = build_pu(depth, ["128", "128", "6", "slow", "bframes=2", "ref=2"], out)
+        print("pu", depth, "calls", len(c), "size", os.path.getsize(out))
     for depth in (8, 10):
         out = os.path.join(ROOT, "tests", "golden", "mvpsel_%d.npz" % depth)
         c, k, u = build_mvpsel(depth, ["128", "128", "5", "slow", "bframes=2"], out)

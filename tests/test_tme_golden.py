@@ -112,3 +112,24 @@ def test_oracle_replays_select_check_update_mvp(depth):
     for r in fx.update:
         got = ora.update_mvp(lam64(r[8], r[9]), (r[0], r[1]), (r[2], r[3]), (r[4], r[5]), u32(r[6]), u32(r[7]))
         assert got == (u32(r[10]), u32(r[11]))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_whole_pu_motion_estimation_calls_replay_to_the_references_medata(depth):
+    """SURVEY 8(f1), one level up from the single functions: whole Search::puMotionEstimation calls of ThreadedME's PU stage (search.cpp:226-556; 2Nx2N, 2NxN and
+    Nx2N partitions, P and B pictures, two references per list) -- the neighbour records of the CTU's table, AMVP, the choice of the predictor, the lookahead's MV as
+    candidate and second search, both searches, the bit / cost bookkeeping, the bidirectional candidate -- composed from the oracle's pieces by tests/tme_pu.py must
+    leave the MEData record the reference left (threadedme.h:122-130), including what the second partition of a CU inherits from the first."""
+    import tme_pu
+    planes, calls = tme_pu.load_fixture(depth)
+    be = tme_pu.OracleBackend(Oracle(depth), depth)
+    assert len(calls) > 800
+    n, kinds = 0, set()
+    for ci, call in enumerate(calls):
+        c = tme_pu.decode(call)
+        outs = tme_pu.replay(c, be, planes, be.dt)
+        for pi, o in enumerate(outs):
+            e = tme_pu.expected(c, pi)
+            assert tme_pu.same(o, e), "call %d partition %d (part %d, %s): glue %s reference %s" % (ci, pi, c["part"], list(c["geo"][pi]), o, e)
+            kinds.add((e["ref"][0] >= 0, e["ref"][1] >= 0)); n += 1
+    assert n > 1300 and kinds == {(True, False), (False, True), (True, True)}
