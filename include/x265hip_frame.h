@@ -87,6 +87,12 @@ int x265hip_me_batch_chroma(void* stream, int w, int h,
                             int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
                             const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* chroma);
 
+/* The distortion of the bidirectional candidate alone (search.cpp:436-446): predInterLumaPixel of the list-0 and the list-1 reference at the given quarter-pel MVs (blocks
+ * of their phase planes), pixelavg_pp, SATD against the source PU.  What x265hip_inter_merge_batch computes inside, for callers that keep the bit bookkeeping. */
+typedef struct x265hip_bidir_task { int32_t curOff, refOff; int16_t mv0[2], mv1[2]; } x265hip_bidir_task;   /* 16 bytes */
+int x265hip_bidir_satd_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* subpelPlanes0, const void* subpelPlanes1, int64_t planeElems,
+                             intptr_t refStride, const x265hip_bidir_task* tasks, int n, int32_t* satd);
+
 /* ---- AMVP: CUData::getPMV (common/cudata.cpp:1806-1990) for a batch of (PU, list, reference) --------------------------------------------------------------
  * In: the PU's neighbour records in MVP_DIR order (cudata.h:67-75: LEFT, ABOVE, ABOVE_RIGHT, BELOW_LEFT, ABOVE_LEFT, COLLOCATED) as CUData::getNeighbourMV /
  * Search::puMotionEstimation (search.cpp:283-305) fill InterNeighbourMV: per list an MV and a reference index (-1 = none); for COLLOCATED refIdx[list] is the

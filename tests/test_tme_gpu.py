@@ -253,3 +253,24 @@ def test_select_mvp_and_mvp_bits_replay_the_reference_records(depth):
                 assert np.array_equal(o["bits"], R[:, 10].astype(np.uint32)) and np.array_equal(o["cost"], R[:, 11].astype(np.uint32))
             else:
                 assert np.array_equal(o["mvpIdx"], R[:, 11]) and np.array_equal(o["bits"], R[:, 12].astype(np.uint32)) and np.array_equal(o["cost"], R[:, 13].astype(np.uint32))
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_whole_pu_motion_estimation_calls_through_the_hip_entry_points(depth):
+    """The recorded Search::puMotionEstimation calls (tests/golden/pu_*.npz) with every piece of the PU's chain on the GPU -- x265hip_amvp_batch,
+    x265hip_select_mvp_batch, x265hip_me_batch (both searches), x265hip_mvp_bits_batch, x265hip_bidir_satd_batch -- each as one batch over all calls that wait for
+    it, composed by the glue of tests/tme_pu.py: the MEData records must be the reference's."""
+    import tme_pu
+    planes, calls = tme_pu.load_fixture(depth)
+    api = FrameApi(depth)
+    ex = tme_pu.HipExecutor(api, depth, planes)
+    cs = [tme_pu.decode(c) for c in calls]
+    outs = tme_pu.replay_batched(cs, planes, np.uint8 if depth == 8 else np.uint16, ex.execute)
+    n, kinds = 0, set()
+    for ci, (c, res) in enumerate(zip(cs, outs)):
+        for pi, o in enumerate(res):
+            e = tme_pu.expected(c, pi)
+            assert tme_pu.same(o, e), "call %d partition %d (part %d): hip chain %s reference %s" % (ci, pi, c["part"], o, e)
+            kinds.add((e["ref"][0] >= 0, e["ref"][1] >= 0)); n += 1
+    assert n > 1300 and kinds == {(True, False), (False, True), (True, True)}
+    assert ex.launches["me"] < 40 and ex.launches["get_pmv"] < 20, "the requests were not batched: %s" % ex.launches

@@ -112,9 +112,9 @@ def decode(call):
     return c
 
 
-def replay(c, be, planes, dt):
-    """-> per partition the MEData the glue produces: dict(mv, mvp, mvCost, ref, bits, cost).  be: backend with get_pmv / select_mvp / me / bidir_satd / bits / getcost /
-    mvcost / check_best_mvp / update_mvp (see OracleBackend in test_tme_golden.py)."""
+def replay_gen(c, planes, dt):
+    """Generator form of the glue: every heavy piece is a request `yield (op, args)` answered by send(result); returns (StopIteration.value) per partition the MEData
+    the glue produces: dict(mv, mvp, mvCost, ref, bits, cost).  ops: get_pmv / select_mvp / me / bidir_satd / bits / getcost / mvcost / check_best_mvp / update_mvp."""
     subs = list(c["subs"])
     nlist = 1 if c["isP"] else 2
     clip = clip_limits(c)
@@ -147,7 +147,7 @@ def replay(c, be, planes, dt):
                         nb[d, 4] = nb[d, 5] = -1
                 k5 = take(5)[1]                       # temporal neighbour + its POCs: inputs
                 nb[5] = k5[38 + 45:38 + 54]
-                amvp, mvc = be.get_pmv(nb.reshape(-1), l, r, c["curPOC"], c["temporal"], c["refPOC"], int(k5[92]), int(k5[93]))
+                amvp, mvc = (yield ("get_pmv", (nb.reshape(-1), l, r, c["curPOC"], c["temporal"], c["refPOC"], int(k5[92]), int(k5[93]))))
                 given = k5[38:38 + 45].reshape(5, 9)                 # what the reference handed to getPMV: only the reference indices, and the MVs of used lists, are initialised
                 for d in range(5):
                     assert nb[d, 4] == given[d, 4] and nb[d, 5] == given[d, 5], "neighbour %d: reference indices differ from what getPMV was given" % d
@@ -159,7 +159,7 @@ def replay(c, be, planes, dt):
                 me_plane, rec_plane = planes[int(c["planeIds"][l][r][0])], planes[int(c["planeIds"][l][r][1])]
                 boff = int(me_plane[0][3]) + y * int(me_plane[0][1]) + x
                 if len(mvc):
-                    mvp_idx = 0 if amvp[0] == amvp[1] else be.select_mvp(w, h, fenc, rec_plane, boff, amvp, clip)
+                    mvp_idx = 0 if amvp[0] == amvp[1] else (yield ("select_mvp", (w, h, fenc, rec_plane, boff, amvp, clip)))
                     mvp = amvp[mvp_idx]
                 else:
                     amvp = [(0, 0), (0, 0)]
@@ -179,21 +179,21 @@ def replay(c, be, planes, dt):
                 k2 = take(2)[1]
                 qp = int(k2[14])
                 bounds = search_range(clip, mvp, c["merange"])
-                out, satd = be.me(w, h, fenc, me_plane, boff, bounds, mvp, mvc, c["merange"], c["method"], c["subme"], qp)
+                out, satd = (yield ("me", (w, h, fenc, me_plane, boff, bounds, mvp, mvc, c["merange"], c["method"], c["subme"], qp)))
                 last_mvp = mvp
                 if b_low and low != mvp:
                     take(2)
                     b_low = False
-                    out2, satd2 = be.me(w, h, fenc, me_plane, boff, search_range(clip, low, c["merange"]), low, mvc, c["merange"], c["method"], c["subme"], qp)
+                    out2, satd2 = (yield ("me", (w, h, fenc, me_plane, boff, search_range(clip, low, c["merange"]), low, mvc, c["merange"], c["method"], c["subme"], qp)))
                     last_mvp = low
                     if satd2 < satd:
                         out, satd, b_low = out2, satd2, True
-                bits += be.bits(out, last_mvp)
-                mv_cost = be.mvcost(qp, out, last_mvp)
-                cost = ((satd - mv_cost) + be.getcost(c["lam"], bits)) & 0xFFFFFFFF
+                bits += (yield ("bits", (out, last_mvp)))
+                mv_cost = (yield ("mvcost", (qp, out, last_mvp)))
+                cost = ((satd - mv_cost) + (yield ("getcost", (c["lam"], bits)))) & 0xFFFFFFFF
                 if b_low:
-                    bits, cost = be.update_mvp(c["lam"], mvp, out, low, bits, cost)
-                mvp_idx, bits, cost = be.check_best_mvp(c["lam"], amvp, out, mvp_idx, bits, cost)
+                    bits, cost = (yield ("update_mvp", (c["lam"], mvp, out, low, bits, cost)))
+                mvp_idx, bits, cost = (yield ("check_best_mvp", (c["lam"], amvp, out, mvp_idx, bits, cost)))
                 mvp = amvp[mvp_idx]
                 if cost < best[l]["cost"]:
                     best[l] = dict(mv=out, mvp=mvp, cost=cost, bits=bits, mvCost=mv_cost, ref=r, rec_plane=rec_plane)
@@ -202,9 +202,9 @@ def replay(c, be, planes, dt):
         restricted = c["log2CU"] == 3 and c["part"] != SIZE_2Nx2N
         if not c["isP"] and not restricted and c["part"] != SIZE_2Nx2N and best[0]["cost"] != 0xFFFFFFFF and best[1]["cost"] != 0xFFFFFFFF:
             boff = int(best[0]["rec_plane"][0][3]) + y * int(best[0]["rec_plane"][0][1]) + x
-            satd = be.bidir_satd(w, h, fenc, best[0]["rec_plane"], best[1]["rec_plane"], boff, best[0]["mv"], best[1]["mv"])
+            satd = (yield ("bidir_satd", (w, h, fenc, best[0]["rec_plane"], best[1]["rec_plane"], boff, best[0]["mv"], best[1]["mv"])))
             bidir_bits = best[0]["bits"] + best[1]["bits"] + sel_bits[2] - (sel_bits[0] + sel_bits[1])
-            bidir_cost = satd + be.getcost(c["lam"], bidir_bits)
+            bidir_cost = satd + (yield ("getcost", (c["lam"], bidir_bits)))
             bmv = [best[0]["mv"], best[1]["mv"]]
             try_zero = best[0]["mv"] != (0, 0) or best[1]["mv"] != (0, 0)
             if try_zero:
@@ -215,10 +215,10 @@ def replay(c, be, planes, dt):
                     p = best[l]["mvp"]
                     try_zero = try_zero and zb[0] <= p[0] <= zb[2] and zb[1] <= p[1] <= zb[3]
             if try_zero:
-                satd = be.bidir_satd(w, h, fenc, best[0]["rec_plane"], best[1]["rec_plane"], boff, (0, 0), (0, 0))
-                b0 = best[0]["bits"] - be.bits(best[0]["mv"], best[0]["mvp"]) + be.bits((0, 0), best[0]["mvp"])
-                b1 = best[1]["bits"] - be.bits(best[1]["mv"], best[1]["mvp"]) + be.bits((0, 0), best[1]["mvp"])
-                cz = satd + be.getcost(c["lam"], b0) + be.getcost(c["lam"], b1)
+                satd = (yield ("bidir_satd", (w, h, fenc, best[0]["rec_plane"], best[1]["rec_plane"], boff, (0, 0), (0, 0))))
+                b0 = best[0]["bits"] - (yield ("bits", (best[0]["mv"], best[0]["mvp"]))) + (yield ("bits", ((0, 0), best[0]["mvp"])))
+                b1 = best[1]["bits"] - (yield ("bits", (best[1]["mv"], best[1]["mvp"]))) + (yield ("bits", ((0, 0), best[1]["mvp"])))
+                cz = satd + (yield ("getcost", (c["lam"], b0))) + (yield ("getcost", (c["lam"], b1)))
                 if cz < bidir_cost:
                     bmv = [(0, 0), (0, 0)]; bidir_cost = cz; bidir_bits = b0 + b1 + sel_bits[2] - (sel_bits[0] + sel_bits[1])
         if bidir_cost < best[0]["cost"] and bidir_cost < best[1]["cost"]:
@@ -232,6 +232,43 @@ def replay(c, be, planes, dt):
             o["mv"][1] = best[1]["mv"]; o["mvp"][1] = best[1]["mvp"]; o["mvCost"][1] = best[1]["mvCost"]; o["ref"][1] = best[1]["ref"]; o["bits"] = best[1]["bits"]; o["cost"] = best[1]["cost"]
         outs.append(o)
     return outs
+
+
+def replay(c, be, planes, dt):
+    """the glue with a backend that answers every request at once (the oracle)"""
+    g = replay_gen(c, planes, dt)
+    try:
+        op, args = next(g)
+        while True:
+            op, args = g.send(getattr(be, op)(*args))
+    except StopIteration as st:
+        return st.value
+
+
+def replay_batched(cs, planes, dt, execute):
+    """the glue of many calls side by side: the pending requests of all calls are handed to execute(op, [args, ...]) -> [result, ...] one op at a time, so that a
+    backend can run each of them as ONE batch (the HIP entry points).  -> list of per-call results"""
+    gens = [replay_gen(c, planes, dt) for c in cs]
+    pending, results = {}, [None] * len(cs)
+    for i, g in enumerate(gens):
+        try:
+            pending[i] = next(g)
+        except StopIteration as st:
+            results[i] = st.value
+    while pending:
+        # the op with the most waiting calls first
+        ops = {}
+        for i, (op, args) in pending.items():
+            ops.setdefault(op, []).append(i)
+        op = max(ops, key=lambda k: len(ops[k]))
+        idx = ops[op]
+        answers = execute(op, [pending[i][1] for i in idx])
+        for i, a in zip(idx, answers):
+            try:
+                pending[i] = gens[i].send(a)
+            except StopIteration as st:
+                results[i] = st.value; del pending[i]
+    return results
 
 
 def expected(c, pi):
@@ -288,3 +325,174 @@ class OracleBackend:
 
     def bidir_satd(self, w, h, fenc, p0, p1, boff, mv0, mv1):
         return self.o.bidir_satd(w, h, fenc, p0[1], p1[1], int(p0[0][1]), boff, mv0, mv1)
+
+
+class HipExecutor:
+    """execute(op, [args...]) for replay_batched: every op of the glue through the library -- x265hip_amvp_batch, x265hip_select_mvp_batch, x265hip_me_batch,
+    x265hip_bidir_satd_batch, x265hip_mvp_bits_batch on the GPU, one launch per group of like requests; the MVD bit / cost tables and RDCost::getCost through the
+    library's own host helpers (x265hip_mvbits_row, x265hip_mvcost_row).  Nothing here touches the oracle."""
+    def __init__(self, api, depth, planes):
+        import ctypes as C
+        from x265hip_pkg import frame as F
+        self.api, self.F, self.T, self.depth = api, F, api.torch, depth
+        self.planes, self.d_plane, self.d_phase = planes, {}, {}
+        self.half = 1 << 15
+        self.rows, self.d_rows = {}, {}
+        self.bits_row = np.zeros(2 * 32768 + 1, np.float32)
+        api.h.check(api.lib.x265hip_mvbits_row(32768, self.bits_row.ctypes.data_as(C.c_void_p)))
+        self.d_bits = api.to_device(self.bits_row.view(np.int32))
+        self.launches = {}
+
+    def _plane(self, p):
+        pid = int(p[0][0])
+        if pid not in self.d_plane:
+            self.d_plane[pid] = self.api.to_device(p[1])
+            self.d_phase[pid] = self.T.zeros(16 * p[1].size, dtype=self.d_plane[pid].dtype, device="cuda")
+            self.api.subpel_planes(self.d_plane[pid], int(p[0][1]), int(p[0][2]), self.d_phase[pid], p[1].size)
+        return pid
+
+    def _row(self, qp):
+        if qp not in self.rows:
+            self.rows[qp] = self.F.mvcost_row(self.depth, qp, self.half)
+            self.d_rows[qp] = self.api.to_device(self.rows[qp].view(np.int16))
+        return self.rows[qp]
+
+    def execute(self, op, reqs):
+        self.launches[op] = self.launches.get(op, 0) + 1
+        return getattr(self, "x_" + op)(reqs)
+
+    # ---- host table lookups (library helpers) ----
+    def x_bits(self, reqs):
+        b = self.bits_row
+        return [int(np.float32(b[32768 + mv[0] - p[0]]) + np.float32(b[32768 + mv[1] - p[1]]) + np.float32(0.5)) for (mv, p) in reqs]
+
+    def x_mvcost(self, reqs):
+        out = []
+        for (qp, mv, p) in reqs:
+            row = self._row(qp)
+            out.append((int(row[self.half + mv[0] - p[0]]) + int(row[self.half + mv[1] - p[1]])) & 0xFFFF)
+        return out
+
+    def x_getcost(self, reqs):
+        return [((bits * lam + 128) >> 8) & 0xFFFFFFFF for (lam, bits) in reqs]
+
+    # ---- device batches ----
+    def x_get_pmv(self, reqs):
+        F, T = self.F, self.T
+        out = [None] * len(reqs)
+        groups = {}
+        for i, (nb, l, r, cur, temp, refpoc, cp, crp) in enumerate(reqs):
+            groups.setdefault((int(cur), int(temp)) + tuple(int(v) for v in refpoc), []).append(i)
+        for key, idx in groups.items():
+            n = len(idx)
+            t = np.zeros(n, F.AMVP_TASK)
+            for k, i in enumerate(idx):
+                nb = np.asarray(reqs[i][0]).reshape(6, 9)
+                t["nb"]["mv"][k, :, 0, 0] = nb[:, 0]; t["nb"]["mv"][k, :, 0, 1] = nb[:, 1]; t["nb"]["mv"][k, :, 1, 0] = nb[:, 2]; t["nb"]["mv"][k, :, 1, 1] = nb[:, 3]
+                t["nb"]["refIdx"][k, :, 0] = nb[:, 4]; t["nb"]["refIdx"][k, :, 1] = nb[:, 5]
+                t["list"][k] = reqs[i][1]; t["refIdx"][k] = reqs[i][2]; t["colPOC"][k] = reqs[i][6]; t["colRefPOC"][k] = reqs[i][7]
+            d_t = self.api.to_device(t)
+            d_o = T.zeros(n * F.AMVP_RESULT.itemsize, dtype=T.uint8, device="cuda")
+            self.api.amvp_batch(d_t, n, key[0], key[1], [key[2:18], key[18:34]], d_o)
+            o = d_o.cpu().numpy().view(F.AMVP_RESULT)
+            for k, i in enumerate(idx):
+                nm = int(o["numMvc"][k])
+                out[i] = (o["amvp"][k].reshape(-1).astype(np.int32), o["mvc"][k][:nm].reshape(-1).astype(np.int32))
+        return out
+
+    def x_select_mvp(self, reqs):
+        F, T = self.F, self.T
+        out = [None] * len(reqs)
+        groups = {}
+        for i, (w, h, fenc, plane, boff, amvp, clip) in enumerate(reqs):
+            groups.setdefault((self._plane(plane), w, h), []).append(i)
+        for (pid, w, h), idx in groups.items():
+            n = len(idx)
+            t = np.zeros(n, F.SELECT_TASK)
+            cur = np.concatenate([reqs[i][2] for i in idx])
+            t["curOff"] = np.arange(n) * (w * h)
+            for k, i in enumerate(idx):
+                t["refOff"][k] = reqs[i][4]; t["amvp"][k] = reqs[i][5]; t["clip"][k] = reqs[i][6]
+            d_t, d_cur = self.api.to_device(t), self.api.to_device(cur)
+            d_o = T.zeros(n * F.SELECT_RESULT.itemsize, dtype=T.uint8, device="cuda")
+            pl = self.planes[pid]
+            self.api.select_mvp_batch(w, h, d_cur, w, self.d_phase[pid], pl[1].size, int(pl[0][1]), d_t, n, d_o)
+            o = d_o.cpu().numpy().view(F.SELECT_RESULT)
+            for k, i in enumerate(idx):
+                out[i] = int(o["mvpIdx"][k])
+        return out
+
+    def x_me(self, reqs):
+        F, T = self.F, self.T
+        out = [None] * len(reqs)
+        groups = {}
+        for i, (w, h, fenc, plane, boff, bounds, mvp, mvc, merange, method, subme, qp) in enumerate(reqs):
+            groups.setdefault((self._plane(plane), w, h, merange, method, subme, qp), []).append(i)
+        for (pid, w, h, merange, method, subme, qp), idx in groups.items():
+            n = len(idx)
+            self._row(qp)
+            t = np.zeros(n, F.ME_TASK)
+            cur = np.concatenate([reqs[i][2] for i in idx])
+            t["curOff"] = np.arange(n) * (w * h); t["mvpFrom"] = -1
+            for k, i in enumerate(idx):
+                _, _, _, _, boff, bounds, mvp, mvc, *_ = reqs[i]
+                t["refOff"][k] = boff; t["mvmin"][k] = bounds[0:2]; t["mvmax"][k] = bounds[2:4]; t["qmvp"][k] = mvp
+                t["numCand"][k] = len(mvc) // 2; t["mvc"][k][:len(mvc)] = mvc
+            d_t, d_cur = self.api.to_device(t), self.api.to_device(cur)
+            d_r = T.zeros(n * F.ME_RESULT.itemsize, dtype=T.uint8, device="cuda")
+            pl = self.planes[pid]
+            self.api.me_batch(w, h, d_cur, w, self.d_plane[pid], int(pl[0][1]), d_t, n, self.d_rows[qp], self.half, merange, method, subme, d_r,
+                              planes=self.d_phase[pid], plane_elems=pl[1].size)
+            r = d_r.cpu().numpy().view(F.ME_RESULT)
+            for k, i in enumerate(idx):
+                out[i] = ((int(r["mv"][k][0]), int(r["mv"][k][1])), int(r["cost"][k]))
+        return out
+
+    def x_bidir_satd(self, reqs):
+        F, T = self.F, self.T
+        out = [None] * len(reqs)
+        groups = {}
+        for i, (w, h, fenc, p0, p1, boff, mv0, mv1) in enumerate(reqs):
+            groups.setdefault((self._plane(p0), self._plane(p1), w, h), []).append(i)
+        for (a, b, w, h), idx in groups.items():
+            n = len(idx)
+            t = np.zeros(n, F.BIDIR_TASK)
+            cur = np.concatenate([reqs[i][2] for i in idx])
+            t["curOff"] = np.arange(n) * (w * h)
+            for k, i in enumerate(idx):
+                t["refOff"][k] = reqs[i][5]; t["mv0"][k] = reqs[i][6]; t["mv1"][k] = reqs[i][7]
+            d_t, d_cur = self.api.to_device(t), self.api.to_device(cur)
+            d_o = T.zeros(n, dtype=T.int32, device="cuda")
+            pl = self.planes[a]
+            self.api.bidir_satd_batch(w, h, d_cur, w, self.d_phase[a], self.d_phase[b], pl[1].size, int(pl[0][1]), d_t, n, d_o)
+            o = d_o.cpu().numpy()
+            for k, i in enumerate(idx):
+                out[i] = int(o[k])
+        return out
+
+    def _mvp_bits(self, recs, lams):
+        F = self.F
+        out = [None] * len(recs)
+        groups = {}
+        for i, lam in enumerate(lams):
+            groups.setdefault(lam, []).append(i)
+        for lam, idx in groups.items():
+            rec = np.zeros(len(idx), F.MVP_BITS)
+            for k, i in enumerate(idx):
+                for f, v in recs[i].items():
+                    rec[f][k] = v
+            d = self.api.to_device(rec)
+            self.api.mvp_bits_batch(d, len(idx), self.d_bits, 32768, lam)
+            o = d.cpu().numpy().view(F.MVP_BITS)
+            for k, i in enumerate(idx):
+                out[i] = (int(o["mvpIdx"][k]), int(o["bits"][k]), int(o["cost"][k]))
+        return out
+
+    def x_check_best_mvp(self, reqs):
+        recs = [dict(amvp=np.array(a, np.int16), mv=mv, mvpIdx=idx, bits=bits, cost=cost) for (lam, a, mv, idx, bits, cost) in reqs]
+        return self._mvp_bits(recs, [r[0] for r in reqs])
+
+    def x_update_mvp(self, reqs):
+        # updateMVP alone: both AMVP slots = the new base, so the checkBestMVP step of the record changes nothing
+        recs = [dict(amvp=np.array([a, a], np.int16), mv=mv, alter=alter, useAlter=1, bits=bits, cost=cost) for (lam, a, mv, alter, bits, cost) in reqs]
+        return [(b, c) for (_, b, c) in self._mvp_bits(recs, [r[0] for r in reqs])]

@@ -193,6 +193,26 @@ __global__ __launch_bounds__(256) void inter_merge_kernel(MergeArgs a)
     }
 }
 
+// the bidirectional candidate's distortion alone (search.cpp:436-446) for a batch of PUs: predInterLumaPixel of both references at the given MVs -> pixelavg_pp -> SATD
+__global__ __launch_bounds__(256) void bidir_satd_kernel(MergeArgs a, const x265hip_bidir_task* __restrict__ bt, int32_t* __restrict__ satd)
+{
+    __shared__ __attribute__((aligned(16))) pixel s_fenc[4][64 * 64];
+    __shared__ __attribute__((aligned(16))) pixel s_avg[4][64 * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, item = blockIdx.x * 4 + wave;
+    if (item >= a.n) return;
+    const x265hip_bidir_task t = bt[item];
+    lpixel* fenc = (lpixel*)s_fenc[wave]; lpixel* avg = (lpixel*)s_avg[wave];
+    const int qpr = a.w >> 2, nquads = qpr * a.h;
+    for (int q = lane; q < nquads; q += 64)
+    {
+        const int y = q / qpr, x4 = (q - y * qpr) * 4;
+        int v[4]; load4u(a.cur + t.curOff + (intptr_t)y * a.cs + x4, v); store4(fenc + y * a.w + x4, v);
+    }
+    wave_sync();
+    const int s = bidir_satd(a, fenc, avg, t.refOff, a.planes[0], t.mv0[0], t.mv0[1], a.planes[4], t.mv1[0], t.mv1[1], lane);
+    if (lane == 0) satd[item] = s;
+}
+
 } // namespace
 
 extern "C" int x265hip_mvbits_row(int halfRange, float* out)
@@ -229,6 +249,19 @@ extern "C" int x265hip_inter_merge_batch(void* stream, int w, int h, const void*
     a.bitsCentre = p->bitsRow + p->bitsHalfRange; a.bitsHalf = p->bitsHalfRange; a.lambda = p->lambda; a.out = out;
     if (a.isP || !a.bidir) hipLaunchKernelGGL(inter_merge_uni_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(inter_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_bidir_satd_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* subpelPlanes0, const void* subpelPlanes1, int64_t planeElems,
+                                        intptr_t refStride, const x265hip_bidir_task* tasks, int n, int32_t* satd)
+{
+    if (n <= 0) return X265HIP_OK;
+    if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !curPlane || !subpelPlanes0 || !subpelPlanes1 || !tasks || !satd) { set_error("bidir_satd_batch: bad arguments"); return X265HIP_EARG; }
+    MergeArgs a{};
+    a.w = w; a.h = h; a.n = n; a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.planeElems = planeElems;
+    a.planes[0] = (const pixel*)subpelPlanes0; a.planes[4] = (const pixel*)subpelPlanes1;
+    hipLaunchKernelGGL(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -17,6 +17,7 @@ AMVP_NB = np.dtype([("mv", "<i2", (2, 2)), ("refIdx", "i1", 2), ("available", "i
 AMVP_TASK = np.dtype([("nb", AMVP_NB, 6), ("list", "i1"), ("refIdx", "i1"), ("reserved", "<i2"), ("colPOC", "<i4"), ("colRefPOC", "<i4")])
 AMVP_RESULT = np.dtype([("amvp", "<i2", (2, 2)), ("numMvc", "<i2"), ("mvc", "<i2", (11, 2)), ("reserved", "<i2")])
 assert AMVP_NB.itemsize == 12 and AMVP_TASK.itemsize == 84 and AMVP_RESULT.itemsize == 56
+BIDIR_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv0", "<i2", 2), ("mv1", "<i2", 2)])
 SELECT_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("amvp", "<i2", (2, 2)), ("clip", "<i4", 4)])
 SELECT_RESULT = np.dtype([("mvpIdx", "<i4"), ("cost", "<i4", 2)])
 MVP_BITS = np.dtype([("amvp", "<i2", (2, 2)), ("mv", "<i2", 2), ("alter", "<i2", 2), ("mvpIdx", "<i2"), ("useAlter", "<i2"), ("bits", "<u4"), ("cost", "<u4")])
@@ -149,6 +150,9 @@ class FrameApi:
         for l in range(2):
             for r in range(16): p.refPOC[l][r] = int(ref_poc[l][r])
         self.h.check(self.lib.x265hip_amvp_batch(self.stream(), _dp(tasks), n, C.byref(p), _dp(out)))
+
+    def bidir_satd_batch(self, w, h, cur, cstride, planes0, planes1, plane_elems, rstride, tasks, n, out):
+        self.h.check(self.lib.x265hip_bidir_satd_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(planes0), _dp(planes1), C.c_int64(plane_elems), C.c_ssize_t(rstride), _dp(tasks), n, _dp(out)))
 
     def select_mvp_batch(self, w, h, cur, cstride, planes, plane_elems, rstride, tasks, n, out):
         self.h.check(self.lib.x265hip_select_mvp_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(planes), C.c_int64(plane_elems), C.c_ssize_t(rstride), _dp(tasks), n, _dp(out)))
