@@ -87,6 +87,23 @@ int x265hip_me_batch_chroma(void* stream, int w, int h,
                             int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
                             const void* subpelPlanes, int64_t planeElems, const x265hip_me_chroma* chroma);
 
+/* ---- the order of ThreadedME's PU stage --------------------------------------------------------------------------------------------------------------------
+ * x265hip_tme_schedule (host, no GPU): the calls Analysis::computeMVForPUs makes for one CTU (analysis.cpp:161-246), in its order -- sub-CUs first, then every PU
+ * shape of the CU in g_puLookup's order (threadedme.h:67-92) -- each with the slot of its first partition in the CTU's MEData table (finalIdx, from
+ * ThreadedME::initPuStartIdx, threadedme.cpp:86-107), the slot distance of the second partition, the neighbour slots Search::puMotionEstimation reads
+ * (MVP_DIR order; -1 = none) and the partitions' rectangles inside the CTU.  The schedule is the same for every CTU (CTUs cut by the picture edge skip the
+ * entries whose CU lies outside).  The area index of an entry is position dependent in the reference (analysis.cpp:175-179 compares the CU's ABSOLUTE
+ * position with half a CTU): areaIdx = cuSize == ctuSize ? 0 : (ctuX + cuX >= ctuSize / 2) + 2 * (ctuY + cuY >= ctuSize / 2) + 1.
+ * Returns the number of entries (also when maxSteps is smaller: call with 0 to size the array). */
+typedef struct x265hip_tme_step {
+    int16_t part, cuSize, cuX, cuY;        /* enum PartSize (2Nx2N 0, 2NxN 1, Nx2N 2, 2NxnU 4, 2NxnD 5, nLx2N 6, nRx2N 7); CU size and position inside the CTU */
+    int16_t puOffset, finalIdx;            /* MEData slot of partition i = finalIdx + i * puOffset                                                           */
+    int16_t neighbor[5];                   /* slots of the left, above, above-right, below-left (never), above-left neighbour of the same shape              */
+    int16_t numPart;
+    int16_t pu[2][4];                      /* per partition: x, y inside the CTU, width, height                                                              */
+} x265hip_tme_step;                        /* 40 bytes */
+int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int amp, x265hip_tme_step* steps, int maxSteps);
+
 /* The distortion of the bidirectional candidate alone (search.cpp:436-446): predInterLumaPixel of the list-0 and the list-1 reference at the given quarter-pel MVs (blocks
  * of their phase planes), pixelavg_pp, SATD against the source PU.  What x265hip_inter_merge_batch computes inside, for callers that keep the bit bookkeeping. */
 typedef struct x265hip_bidir_task { int32_t curOff, refOff; int16_t mv0[2], mv1[2]; } x265hip_bidir_task;   /* 16 bytes */

@@ -151,6 +151,31 @@ def build_pu(depth, args, out, n_keep=700):
     return calls
 
 
+def build_sched(out):
+    """tme_sched.npz: the order of Search::puMotionEstimation calls inside a CTU (Analysis::computeMVForPUs) with slots, neighbour slots, area index and partition
+    rectangles, for three presets (rect / amp off, rect on, rect + amp on): per config an int array [call][cols], CTU by CTU of the first P picture"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import tme_pu
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265tme_8")
+    data = {}
+    for name, args in (("medium", ["128", "128", "2", "medium"]), ("slow", ["128", "128", "2", "slow"]), ("slower", ["128", "128", "2", "slower", "bframes=0"])):
+        with tempfile.TemporaryDirectory() as td:
+            raw = os.path.join(td, "tme.bin")
+            subprocess.check_call([exe] + args[:4] + [raw] + args[4:], stdout=subprocess.DEVNULL, env=dict(os.environ, X265TME_PU="10000000"))
+            _, calls = tme_pu.parse_stream(raw)
+        rows = []
+        for c in calls:
+            d = tme_pu.decode(c)
+            ctu = (d["cuY"] // 64) * 2 + d["cuX"] // 64
+            geo = np.zeros(8, np.int32); geo[:4 * d["numPart"]] = d["geo"].reshape(-1)
+            rows.append([d["curPOC"], ctu, d["part"], 1 << d["log2CU"], d["cuX"], d["cuY"], d["puOffset"], d["area"], d["finalIdx"]] + d["nbIdx"] + [d["numPart"]] + list(geo))
+        rows = np.array(rows, np.int32)
+        poc = rows[0, 0]
+        data[name] = rows[rows[:, 0] == poc]
+    np.savez_compressed(out, **data)
+    return {k: len(v) for k, v in data.items()}
+
+
 def build_amvp(out):
     """amvp.npz: CUData::getPMV calls (ref_tme.cpp kind 5) of a --threaded-me encode and of a regular encode with B pictures and several references; the records
     are bit-depth independent (8-bit harness); identical records are kept once.  Row layout = the recorder's (fixed 99 ints + 22 mvc ints, zero padded)."""
@@ -176,12 +201,14 @@ if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "tme"])
     # tme_*: --threaded-me encodes (luma-only searches of puMotionEstimation); mec_*: regular encodes whose predInterSearch searches carry the chroma
     # SATD terms (subme >= 3), incl. weighted / several references and B pictures
-    for depth, args in ((8, ["256", "192", "4", "medium"]), (10, ["256", "192", "4", "slow", "amp=0", "rect=0"])):
+    for depth, args in (() if "--sched-only" in sys.argv else ((8, ["256", "192", "4", "medium"]), (10, ["256", "192", "4", "slow", "amp=0", "rect=0"]))):
         out = os.path.join(ROOT, "tests", "golden", "dia_%d.npz" % depth)
         c = build_dia(depth, args, out)
         f = {n: c[:, i] for i, n in enumerate(DIA_FIELDS)}
         print("dia", depth, "calls", len(c), "size", os.path.getsize(out), "shapes", sorted({(int(a), int(b)) for a, b in zip(f["w"], f["h"])}), "out range", f["outx"].min(), f["outx"].max(), f["outy"].min(), f["outy"].max(),
               "mvp", np.unique(f["mvpx"]), np.unique(f["mvpy"]))
+    print("sched", build_sched(os.path.join(ROOT, "tests", "golden", "tme_sched.npz")))
+    if "--sched-only" in sys.argv: sys.exit(0)
     for depth in (8, 10):
         out = os.path.join(ROOT, "tests", "golden", "pu_%d.npz" % depth)
         c = build_pu(depth, ["128", "128", "6", "slow", "bframes=2", "ref=2"], out)
