@@ -634,8 +634,11 @@ def main():
     depth, W, H = wl["depth"], wl["width"], wl["height"]
     seeds = rank_frame_seeds(int(os.environ.get("RANK", "0")), args.frames)          # independent frames per rank, no overlap
     import multiprocessing
-    with multiprocessing.get_context("fork").Pool(min(len(seeds), max(1, (os.cpu_count() or 1) // max(1, args.gpus)))) as pool:
-        pairs = pool.starmap(_make_pair, [(W, H, depth, sd, args.refs) for sd in seeds])
+    # close() + join(), not the context manager: its terminate() sends SIGTERM to the workers, and under rocprofv3 (whose signal handler is inherited by the forked
+    # workers) a worker then never exits and the run hangs in wait4 (seen in the r02 counter passes)
+    pool = multiprocessing.get_context("fork").Pool(min(len(seeds), max(1, (os.cpu_count() or 1) // max(1, args.gpus))))
+    pairs = pool.starmap(_make_pair, [(W, H, depth, sd, args.refs) for sd in seeds])
+    pool.close(); pool.join()
     import torch
     import torch.distributed as dist
     import x265hip  # noqa: F401

@@ -138,6 +138,40 @@ int x265hip_select_mvp_batch(void* stream, int w, int h, const void* curPlane, i
 typedef struct x265hip_mvp_bits { int16_t amvp[2][2]; int16_t mv[2]; int16_t alter[2]; int16_t mvpIdx; int16_t useAlter; uint32_t bits; uint32_t cost; } x265hip_mvp_bits;   /* 28 bytes */
 int x265hip_mvp_bits_batch(void* stream, x265hip_mvp_bits* records, int n, const float* bitsRow /* x265hip_mvbits_row, device */, int bitsHalfRange, uint64_t lambda);
 
+/* x265hip_tme_frame: the PU stage of ThreadedME for every CTU of one picture (Analysis::computeMVForPUs -> Search::puMotionEstimation, analysis.cpp:161-246,
+ * search.cpp:226-556), stepped through the schedule: per entry, partition, list and reference one launch sequence over all CTUs -- neighbour records out of the
+ * MEData table, getPMV, selectMVP, the search (and the second one from the lookahead's MV), the bit / cost bookkeeping with updateMVP / checkBestMVP, the
+ * bidirectional candidate, the MEData record written back into the table (kern_tme.hip).  The table is read and written in the reference's order, so entries that a
+ * PU reads before this picture wrote them (the reference reads whatever the FrameData held) are the caller's: pass the table as it was.
+ * Host-supplied per PU: the temporal (collocated) neighbour CUData::getNeighbourMV finds in the collocated picture's motion (cudata.cpp:1992-2075) with the two POCs
+ * getPMV scales it by.  Pictures of whole CTUs; the bidirectional candidate with one reference per list.  All planes share stride, origin and planeElems. */
+typedef struct x265hip_tme_temporal { x265hip_amvp_neighbour nb; int32_t colPOC[2], colRefPOC[2]; } x265hip_tme_temporal;      /* 28 bytes; per (ctu, entry, partition) */
+typedef struct x265hip_tme_ref {
+    const void* mePlane;                       /* the plane motionEstimate searches (slice->m_mref[l][r].fpelPlane[0]: weighted or not), first element of the padded allocation */
+    const void* mePhase;                       /* its 16-slot phase planes (x265hip_subpel_planes)                                              */
+    const void* reconPhase;                    /* phase planes of the reconstructed reference picture (selectMVP, bidirectional candidate)      */
+    const struct x265hip_inter_choice* refTable;   /* that reference picture's own MEData table, or NULL (intra picture / none): the fallback predictor of search.cpp:313-330 */
+    const int16_t* lowresMv;                   /* the lookahead's MVs of this (list, distance), x / y per 16x16 block of the picture (Lowres::lowresMvs), or NULL = not estimated / out of range */
+} x265hip_tme_ref;
+typedef struct x265hip_tme_args {
+    int isP, numRef[2], curPOC, temporalMvp, refPOC[2][16];
+    int searchRange, searchMethod, subpelRefine;
+    int picWidth, picHeight, ctuSize, lowresBlocksX;
+    const void* curPlane; intptr_t stride; int64_t origin /* element offset of pixel (0,0) in every plane */, planeElems;
+    x265hip_tme_ref refs[2][4];
+    struct x265hip_inter_choice* table;        /* [numCtu][593] MEData records, in / out                                                         */
+    const int16_t* areaBest;                   /* [numCtu][5][2][4][2]: m_areaBestMV after deriveMVsForCTU's first stage (x265hip_diamond_batch + the median of the collocated MVs) */
+    const x265hip_tme_temporal* temporal;      /* [numCtu][nSteps][2]                                                                            */
+    int nQp;                                   /* distinct qps of the picture's CUs, 1..8 (Analysis::setLambdaFromQP runs per CU: AQ / cuTree)   */
+    const uint8_t* qpIndex;                    /* [numCtu][nSteps]: which of them the CU of an entry uses; NULL with nQp == 1                     */
+    const uint16_t* costRows[8]; int costHalfRange; uint64_t lambdas[8];    /* per qp: device x265hip_mvcost_row(qp), x265hip_rd_lambda(qp)          */
+    const float* bitsRow; int bitsHalfRange;   /* device x265hip_mvbits_row                                                                      */
+    const x265hip_tme_step* steps; int nSteps; /* HOST array (x265hip_tme_schedule)                                                              */
+    void* workspace; size_t workspaceBytes;    /* device scratch of x265hip_tme_workspace(numCtu) bytes                                          */
+} x265hip_tme_args;
+size_t x265hip_tme_workspace(int nCtu);
+int x265hip_tme_frame(void* stream, const x265hip_tme_args* args);
+
 /* MotionEstimate::diamondSearch (motion.cpp:631-773) for n PUs of one size: the full-pel predictor search of ThreadedME's first stage
  * (Search::puMotionEstimation with isMVP, search.cpp:355-363 -- the CTU and its four sub-CUs at search range 32; the results seed m_areaBestMV for
  * the PU searches, analysis.cpp:248-306).  Uses of x265hip_me_task: curOff, refOff, mvmin / mvmax (full pel), qmvp (the MVD origin setMVP was

@@ -119,7 +119,7 @@ def build_mvpsel(depth, args, out):
     return calls, data["check"], data["update"]
 
 
-def build_pu(depth, args, out, n_keep=700):
+def build_pu(depth, args, out, n_keep=700, keep_all=False):
     """pu_{8,10}.npz: whole Search::puMotionEstimation calls of a --threaded-me encode (ref_tme.cpp kind 9) with the records of everything under them (ints only: the
     source blocks travel with the call record), P and B pictures; a sample of n_keep calls that keeps every bidirectional / list-1 outcome"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -131,7 +131,7 @@ def build_pu(depth, args, out, n_keep=700):
         planes, calls = tme_pu.parse_stream(raw)
     rng = np.random.default_rng(3)
     special = [i for i, c in enumerate(calls) if any(tme_pu.decode(c)["out"][p][12] >= 0 for p in range(int(c["ints"][58])))]
-    keep = sorted(set(special[:250]) | set(rng.permutation(len(calls))[:n_keep].tolist()))
+    keep = list(range(len(calls))) if keep_all else sorted(set(special[:250]) | set(rng.permutation(len(calls))[:n_keep].tolist()))
     calls = [calls[i] for i in keep]
     dt = np.uint8 if depth == 8 else np.uint16
     data = {"call_ints": np.concatenate([c["ints"] for c in calls]), "call_ints_start": np.concatenate([[0], np.cumsum([len(c["ints"]) for c in calls])]),
@@ -207,6 +207,11 @@ if __name__ == "__main__":
         f = {n: c[:, i] for i, n in enumerate(DIA_FIELDS)}
         print("dia", depth, "calls", len(c), "size", os.path.getsize(out), "shapes", sorted({(int(a), int(b)) for a, b in zip(f["w"], f["h"])}), "out range", f["outx"].min(), f["outx"].max(), f["outy"].min(), f["outy"].max(),
               "mvp", np.unique(f["mvpx"]), np.unique(f["mvpy"]))
+    for depth in (8, 10):
+        # every puMotionEstimation call of every CTU of a P and a B picture, in order: what x265hip_tme_frame steps through (one reference per list)
+        out = os.path.join(ROOT, "tests", "golden", "tmectu_%d.npz" % depth)
+        c = build_pu(depth, ["128", "128", "3", "slow", "bframes=1", "ref=1"], out, keep_all=True)
+        print("tmectu", depth, "calls", len(c), "size", os.path.getsize(out))
     print("sched", build_sched(os.path.join(ROOT, "tests", "golden", "tme_sched.npz")))
     if "--sched-only" in sys.argv: sys.exit(0)
     for depth in (8, 10):

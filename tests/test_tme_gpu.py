@@ -274,3 +274,125 @@ def test_whole_pu_motion_estimation_calls_through_the_hip_entry_points(depth):
             kinds.add((e["ref"][0] >= 0, e["ref"][1] >= 0)); n += 1
     assert n > 1300 and kinds == {(True, False), (False, True), (True, True)}
     assert ex.launches["me"] < 40 and ex.launches["get_pmv"] < 20, "the requests were not batched: %s" % ex.launches
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_tme_frame_steps_whole_pictures_to_the_references_tables(depth):
+    """x265hip_tme_frame: every puMotionEstimation call of every CTU of a P and a B picture (tests/golden/tmectu_*.npz: 4 CTUs x 255 schedule entries x 2 pictures),
+    stepped on the device through x265hip_tme_schedule -- the MEData table after the run must hold, at every slot the reference wrote, what the reference wrote.
+    Inputs assembled from the records: the table entries the reference found where this picture had not written yet, m_areaBestMV, the lookahead's MVs, the
+    reference picture's own table, the temporal neighbour of every PU."""
+    import tme_pu
+    from x265hip_pkg.frame import INTER_CHOICE, TME_TEMPORAL
+    planes, calls = tme_pu.load_fixture(depth, "tmectu")
+    api = FrameApi(depth)
+    T = api.torch
+    steps = api.tme_schedule(64, 8, rect=True, amp=False)
+    nS = len(steps)
+    cs = [tme_pu.decode(c) for c in calls]
+    W = H = 128
+    bits_row = np.zeros(2 * 32768 + 1, np.float32)
+    api.h.check(api.lib.x265hip_mvbits_row(32768, bits_row.ctypes.data_as(__import__("ctypes").c_void_p)))
+    d_bits = api.to_device(bits_row.view(np.int32))
+    d_plane, d_phase = {}, {}
+    def dev_plane(pid):
+        if pid not in d_plane:
+            g, px = planes[pid]
+            d_plane[pid] = api.to_device(px)
+            d_phase[pid] = T.zeros(16 * px.size, dtype=d_plane[pid].dtype, device="cuda")
+            api.subpel_planes(d_plane[pid], int(g[1]), int(g[2]), d_phase[pid], px.size)
+        return d_plane[pid], d_phase[pid]
+    checked = 0
+    for poc in sorted({c["curPOC"] for c in cs}):
+        fc = [c for c in cs if c["curPOC"] == poc]
+        assert len(fc) == 4 * nS
+        c0 = fc[0]
+        g = planes[int(c0["planeIds"][0][0][0])][0]
+        stride, rows, origin = int(g[1]), int(g[2]), int(g[3])
+        # the source picture: rebuilt from the PU blocks of the 2Nx2N 64x64 calls
+        cur = np.zeros(stride * rows, planes[int(c0["planeIds"][0][0][0])][1].dtype)
+        table = np.zeros((4, 593), INTER_CHOICE); table["ref"] = -1
+        written = np.zeros((4, 593), bool)
+        area = np.zeros((4, 5, 2, 4, 2), np.int16)
+        temporal = np.zeros((4, nS, 2), TME_TEMPORAL); temporal["nb"]["refIdx"] = -1
+        nlist = 1 if c0["isP"] else 2
+        ref_tab = [[np.zeros((4, 593), INTER_CHOICE) for _ in range(4)] for _ in range(2)]
+        ref_tab_on = [[False] * 4 for _ in range(2)]
+        for l in range(2):
+            for r in range(4): ref_tab[l][r]["ref"] = -1
+        low = [[np.zeros((H // 16) * (W // 16) * 2, np.int16) for _ in range(4)] for _ in range(2)]
+        qps, qp_of = [], np.zeros((4, nS), np.uint8)
+        per_ctu = {k: [c for c in fc if (c["cuY"] // 64) * 2 + c["cuX"] // 64 == k] for k in range(4)}
+        for ctu, lst in per_ctu.items():
+            assert len(lst) == nS
+            for k, c in enumerate(lst):
+                st = steps[k]
+                assert (c["part"], c["finalIdx"], c["puOffset"]) == (int(st["part"]), int(st["finalIdx"]), int(st["puOffset"]))
+                area[ctu, c["area"]] = c["areaBest"]
+                for d in range(5):
+                    slot = c["nbIdx"][d]
+                    if slot >= 0 and not written[ctu, slot]:
+                        rec = c["nbRec"][d]
+                        table[ctu, slot]["mv"] = rec[0:4].reshape(2, 2); table[ctu, slot]["ref"] = rec[4:6]
+                subs = list(c["subs"])
+                for pi in range(c["numPart"]):
+                    x, y, w, h = (int(v) for v in c["geo"][pi])
+                    if c["part"] == 0 and w == 64:
+                        for yy in range(64):
+                            cur[origin + (y + yy) * stride + x: origin + (y + yy) * stride + x + 64] = c["blocks"][pi][yy * 64:(yy + 1) * 64]
+                    for l in range(nlist):
+                        for r in range(c["numRef"][l]):
+                            k5 = next(s for s in subs if s[0] == 5); subs.remove(k5); k5 = k5[1]
+                            assert (int(k5[0]), int(k5[1])) == (l, r)
+                            nb5 = k5[38 + 45:38 + 54]
+                            tp = temporal[ctu, k, pi]
+                            tp["nb"]["refIdx"] = (nb5[4], nb5[5])
+                            for ll in range(2):
+                                if nb5[4 + ll] != -1:
+                                    tp["nb"]["mv"][ll] = (nb5[2 * ll], nb5[2 * ll + 1])
+                            tp["colPOC"][l] = k5[92]; tp["colRefPOC"][l] = k5[93]
+                            rr = c["refRec"][pi][l][r]
+                            if rr[4] != -3:
+                                ref_tab_on[l][r] = True
+                                e = ref_tab[l][r][ctu, c["finalIdx"] + pi * c["puOffset"]]
+                                e["mv"] = rr[0:4].reshape(2, 2); e["ref"] = rr[4:6]
+                            k10 = [s for s in subs if s[0] == 10]
+                            if x + (w >> 1) < W and y + (h >> 1) < H:
+                                k10 = k10[0]; subs.remove(k10); k10 = k10[1]
+                                idx = ((y + h // 2) >> 4) * (W // 16) + ((x + w // 2) >> 4)
+                                assert int(k10[2]) % 2 == 0 and int(k10[3]) % 2 == 0
+                                low[l][r][2 * idx] = int(k10[2]) // 2; low[l][r][2 * idx + 1] = int(k10[3]) // 2
+                            k2 = next(s for s in subs if s[0] == 2); subs.remove(k2)
+                            qp = int(k2[1][14])
+                            if (qp, c["lam"]) not in qps: qps.append((qp, c["lam"]))
+                            qp_of[ctu, k] = qps.index((qp, c["lam"]))
+                            nxt = [s for s in subs if s[0] in (2, 5)]
+                            if nxt and nxt[0][0] == 2: subs.remove(nxt[0])          # the second search
+                    written[ctu, c["finalIdx"] + pi * c["puOffset"]] = True
+        d_rows = [api.to_device(mvcost_row(depth, q, 1 << 15).view(np.int16)) for (q, _) in qps]
+        refs = [[], []]
+        for l in range(nlist):
+            for r in range(c0["numRef"][l]):
+                me_p, me_ph = dev_plane(int(c0["planeIds"][l][r][0])); _, rec_ph = dev_plane(int(c0["planeIds"][l][r][1]))
+                refs[l].append(dict(me_plane=me_p, me_phase=me_ph, recon_phase=rec_ph, ref_table=api.to_device(ref_tab[l][r].reshape(-1)) if ref_tab_on[l][r] else None,
+                                    lowres_mv=api.to_device(low[l][r])))
+        d_table = api.to_device(table.reshape(-1))
+        api.tme_frame(is_p=c0["isP"], num_ref=c0["numRef"], cur_poc=poc, temporal_mvp=c0["temporal"], ref_poc=[c0["refPOC"][:16], c0["refPOC"][16:]], merange=c0["merange"],
+                      method=c0["method"], subme=c0["subme"], lams=[lm for (_, lm) in qps], qp_index=api.to_device(qp_of.reshape(-1)), width=W, height=H, ctu=64, lowres_blocks_x=W // 16, cur=api.to_device(cur), stride=stride, origin=origin,
+                      plane_elems=stride * rows, refs=refs, table=d_table, area_best=api.to_device(area.reshape(-1)), temporal=api.to_device(temporal.reshape(-1)),
+                      cost_rows=d_rows, cost_half=1 << 15, bits_row=d_bits, bits_half=32768, steps=steps)
+        out = d_table.cpu().numpy().view(INTER_CHOICE).reshape(4, 593)
+        # the LAST write of a slot is what the table holds
+        last = {}
+        for ctu, lst in per_ctu.items():
+            for c in lst:
+                for pi in range(c["numPart"]):
+                    last[(ctu, c["finalIdx"] + pi * c["puOffset"])] = tme_pu.expected(c, pi)
+        kinds = set()
+        for (ctu, slot), e in last.items():
+            o = out[ctu, slot]
+            got = dict(mv=[(int(o["mv"][0][0]), int(o["mv"][0][1])), (int(o["mv"][1][0]), int(o["mv"][1][1]))], mvp=[(int(o["mvp"][0][0]), int(o["mvp"][0][1])), (int(o["mvp"][1][0]), int(o["mvp"][1][1]))],
+                       mvCost=[int(o["mvCost"][0]), int(o["mvCost"][1])], ref=[int(o["ref"][0]), int(o["ref"][1])], bits=int(o["bits"]), cost=int(o["cost"]))
+            assert tme_pu.same(got, e), "POC %d CTU %d slot %d: device %s reference %s" % (poc, ctu, slot, got, e)
+            kinds.add((e["ref"][0] >= 0, e["ref"][1] >= 0)); checked += 1
+    assert checked >= 2 * 4 * 400

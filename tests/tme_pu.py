@@ -43,10 +43,10 @@ def parse_stream(path):
     return planes, calls
 
 
-def load_fixture(depth):
-    """tests/golden/pu_{8,10}.npz (tests/make_golden_tme.py) -> planes, calls as parse_stream returns them (records under a call: ints only)"""
+def load_fixture(depth, name="pu"):
+    """tests/golden/pu_{8,10}.npz / tmectu_{8,10}.npz (tests/make_golden_tme.py) -> planes, calls as parse_stream returns them (records under a call: ints only)"""
     import os
-    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pu_%d.npz" % depth))
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "%s_%d.npz" % (name, depth)))
     planes = {}
     for k in d.files:
         if k.startswith("plane") and k.endswith("_geom"):

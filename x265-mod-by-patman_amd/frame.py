@@ -17,6 +17,10 @@ AMVP_NB = np.dtype([("mv", "<i2", (2, 2)), ("refIdx", "i1", 2), ("available", "i
 AMVP_TASK = np.dtype([("nb", AMVP_NB, 6), ("list", "i1"), ("refIdx", "i1"), ("reserved", "<i2"), ("colPOC", "<i4"), ("colRefPOC", "<i4")])
 AMVP_RESULT = np.dtype([("amvp", "<i2", (2, 2)), ("numMvc", "<i2"), ("mvc", "<i2", (11, 2)), ("reserved", "<i2")])
 assert AMVP_NB.itemsize == 12 and AMVP_TASK.itemsize == 84 and AMVP_RESULT.itemsize == 56
+TME_STEP = np.dtype([("part", "<i2"), ("cuSize", "<i2"), ("cuX", "<i2"), ("cuY", "<i2"), ("puOffset", "<i2"), ("finalIdx", "<i2"), ("neighbor", "<i2", 5), ("numPart", "<i2"),
+                     ("pu", "<i2", (2, 4))])
+TME_TEMPORAL = np.dtype([("nb", AMVP_NB), ("colPOC", "<i4", 2), ("colRefPOC", "<i4", 2)])
+assert TME_STEP.itemsize == 40 and TME_TEMPORAL.itemsize == 28
 BIDIR_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("mv0", "<i2", 2), ("mv1", "<i2", 2)])
 SELECT_TASK = np.dtype([("curOff", "<i4"), ("refOff", "<i4"), ("amvp", "<i2", (2, 2)), ("clip", "<i4", 4)])
 SELECT_RESULT = np.dtype([("mvpIdx", "<i4"), ("cost", "<i4", 2)])
@@ -150,6 +154,53 @@ class FrameApi:
         for l in range(2):
             for r in range(16): p.refPOC[l][r] = int(ref_poc[l][r])
         self.h.check(self.lib.x265hip_amvp_batch(self.stream(), _dp(tasks), n, C.byref(p), _dp(out)))
+
+    def tme_schedule(self, ctu=64, min_cu=8, rect=True, amp=False):
+        n = self.lib.x265hip_tme_schedule(ctu, min_cu, int(rect), int(amp), None, 0)
+        steps = np.zeros(n, TME_STEP)
+        assert self.lib.x265hip_tme_schedule(ctu, min_cu, int(rect), int(amp), steps.ctypes.data_as(C.c_void_p), n) == n
+        return steps
+
+    def tme_frame(self, *, is_p, num_ref, cur_poc, temporal_mvp, ref_poc, merange, method, subme, lams, qp_index, width, height, ctu, lowres_blocks_x, cur, stride, origin, plane_elems,
+                  refs, table, area_best, temporal, cost_rows, cost_half, bits_row, bits_half, steps):
+        """x265hip_tme_frame; refs[l][r] = dict(me_plane, me_phase, recon_phase, ref_table or None, lowres_mv or None) of device tensors; steps: host TME_STEP array"""
+        class Ref(C.Structure):
+            _fields_ = [("mePlane", C.c_void_p), ("mePhase", C.c_void_p), ("reconPhase", C.c_void_p), ("refTable", C.c_void_p), ("lowresMv", C.c_void_p)]
+        class Args(C.Structure):
+            _fields_ = [("isP", C.c_int), ("numRef", C.c_int * 2), ("curPOC", C.c_int), ("temporalMvp", C.c_int), ("refPOC", (C.c_int * 16) * 2),
+                        ("searchRange", C.c_int), ("searchMethod", C.c_int), ("subpelRefine", C.c_int),
+                        ("picWidth", C.c_int), ("picHeight", C.c_int), ("ctuSize", C.c_int), ("lowresBlocksX", C.c_int),
+                        ("curPlane", C.c_void_p), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("planeElems", C.c_int64),
+                        ("refs", (Ref * 4) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
+                        ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p * 8), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 8), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
+                        ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t)]
+        a = Args()
+        a.isP = int(is_p); a.numRef[0], a.numRef[1] = int(num_ref[0]), int(num_ref[1]); a.curPOC = int(cur_poc); a.temporalMvp = int(temporal_mvp)
+        for l in range(2):
+            for r in range(16): a.refPOC[l][r] = int(ref_poc[l][r])
+        a.searchRange, a.searchMethod, a.subpelRefine = int(merange), int(method), int(subme)
+        a.nQp = len(lams); a.qpIndex = _dp(qp_index)
+        for q in range(len(lams)):
+            a.costRows[q] = cost_rows[q].data_ptr(); a.lambdas[q] = int(lams[q])
+        a.picWidth, a.picHeight, a.ctuSize, a.lowresBlocksX = int(width), int(height), int(ctu), int(lowres_blocks_x)
+        a.curPlane = _dp(cur); a.stride = int(stride); a.origin = int(origin); a.planeElems = int(plane_elems)
+        for l in range(2):
+            for r in range(4):
+                d = refs[l][r] if l < len(refs) and r < len(refs[l]) else None
+                if d:
+                    a.refs[l][r].mePlane = _dp(d["me_plane"]); a.refs[l][r].mePhase = _dp(d["me_phase"]); a.refs[l][r].reconPhase = _dp(d["recon_phase"])
+                    a.refs[l][r].refTable = _dp(d.get("ref_table")); a.refs[l][r].lowresMv = _dp(d.get("lowres_mv"))
+        a.table = _dp(table); a.areaBest = _dp(area_best); a.temporal = _dp(temporal)
+        a.costHalfRange = int(cost_half); a.bitsRow = _dp(bits_row); a.bitsHalfRange = int(bits_half)
+        steps = np.ascontiguousarray(steps)
+        a.steps = steps.ctypes.data; a.nSteps = len(steps)
+        n_ctu = (width // ctu) * (height // ctu)
+        self.lib.x265hip_tme_workspace.restype = C.c_size_t
+        ws_bytes = self.lib.x265hip_tme_workspace(n_ctu)
+        ws = self.torch.zeros(ws_bytes, dtype=self.torch.uint8, device="cuda")
+        a.workspace = _dp(ws); a.workspaceBytes = ws_bytes
+        self.h.check(self.lib.x265hip_tme_frame(self.stream(), C.byref(a)))
+        self.torch.cuda.synchronize()           # `steps` and the workspace must outlive the launches
 
     def bidir_satd_batch(self, w, h, cur, cstride, planes0, planes1, plane_elems, rstride, tasks, n, out):
         self.h.check(self.lib.x265hip_bidir_satd_batch(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(planes0), _dp(planes1), C.c_int64(plane_elems), C.c_ssize_t(rstride), _dp(tasks), n, _dp(out)))
