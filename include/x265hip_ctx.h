@@ -64,6 +64,40 @@ int   x265hip_batch_read_coeffs(x265hip_batch* batch, int16_t* coeff /* tu_count
  * 5 reconstruction, 10 + log2(level) - 3 = results of a pyramid level (10: 8x8 ... 13: 64x64) */
 void* x265hip_batch_device_ptr(x265hip_batch* batch, int what);
 
+/* ---- ThreadedME producer for a C++ encoder: one picture's MEData table from HOST data ------------------------------------------------------------------
+ * What ThreadedME::findJob -> Analysis::deriveMVsForCTU does for every CTU of a picture (threadedme.cpp:207-261, analysis.cpp:248-306): the diamond searches of the
+ * CTU and its four sub-CUs per reference (m_areaBestMV), the collocated-median override, then every PU of the schedule (x265hip_tme_frame).  The caller hands over
+ * host pointers -- the padded planes as PicYuv holds them (first element of the allocation; all planes of one geometry), the picture's MEData table
+ * (slice->m_ctuMV, as x265hip_inter_choice records) as it is before the picture, per reference that reference picture's table and the lookahead's MVs -- and what only
+ * the encoder's own state yields: per CTU and reference the median of the collocated MVs (CUData::getMedianColMV, cudata.cpp:1744-1790), per (CTU, entry, partition)
+ * the temporal neighbour (CUData::getNeighbourMV's collocated part), and the qp of every CU (Analysis::calculateQpforCuSize).  Pictures of whole CTUs; one
+ * reference per list when B pictures use rectangular / AMP partitions (x265hip_tme_frame's limit). */
+typedef struct x265hip_tme x265hip_tme;
+typedef struct x265hip_tme_host_ref {
+    const void* mePlane;                       /* slice->m_mref[l][r].fpelPlane[0] allocation (weighted or not)                                  */
+    const void* reconPlane;                    /* the reconstructed reference picture's plane (== mePlane without weighting)                     */
+    const struct x265hip_inter_choice* refTable;   /* that picture's own table or NULL (intra picture)                                           */
+    const int16_t* lowresMv;                   /* Lowres::lowresMvs[l][dist] as x, y per 16x16 block, or NULL (not estimated / distance out of range) */
+} x265hip_tme_host_ref;
+typedef struct x265hip_tme_picture_desc {
+    int isP, numRef[2], curPOC, temporalMvp, refPOC[2][16];
+    int searchRange, searchMethod, subpelRefine;
+    int width, height, lowresBlocksX;
+    const void* curPlane; intptr_t stride; int64_t origin, planeElems;
+    x265hip_tme_host_ref refs[2][4];
+    struct x265hip_inter_choice* table;        /* [numCtu][593], in / out                                                                        */
+    const int16_t* median;                     /* [numCtu][2][4][3]: valid, x, y of getMedianColMV; NULL = none                                  */
+    const x265hip_tme_temporal* temporal;      /* [numCtu][entries][2]                                                                           */
+    int nQp, qps[8];                           /* the distinct qps of the picture's CUs                                                          */
+    const uint8_t* qpIndex;                    /* [numCtu][entries]: index into qps of the entry's CU                                            */
+    const uint8_t* areaQpIndex;                /* [numCtu][5]: index into qps of the CTU (area 0) and its four sub-CUs (the diamond searches)    */
+    int16_t* areaBestOut;                      /* optional [numCtu][5][2][4][2]: m_areaBestMV as computed                                        */
+} x265hip_tme_picture_desc;
+int  x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** tme);
+void x265hip_tme_destroy(x265hip_tme* tme);
+int  x265hip_tme_entries(const x265hip_tme* tme, const x265hip_tme_step** steps);     /* the schedule (x265hip_tme_schedule) this producer steps through */
+int  x265hip_tme_picture(x265hip_tme* tme, const x265hip_tme_picture_desc* desc);     /* synchronous: desc->table holds the picture's records on return   */
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,3 +89,197 @@ extern "C" int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int am
     b.visit(0, 0, ctuSize);
     return b.n;
 }
+
+// ---- host-level producer: one picture's MEData table from HOST inputs (include/x265hip_ctx.h: x265hip_tme_*) ----------------------------------------------
+// Uploads the picture's planes, builds the phase planes, runs deriveMVsForCTU's first stage (x265hip_diamond_batch for the CTU and its four sub-CUs per reference,
+// then the caller's collocated-median override), steps x265hip_tme_frame through the schedule and copies the table back.
+#include "../../include/x265hip_ctx.h"
+#include <cstring>
+#include <map>
+#include <new>
+#include <vector>
+using namespace xh;
+
+struct x265hip_tme
+{
+    x265hip_ctx* ctx = nullptr;
+    int width = 0, height = 0, ctu = 64, nCtu = 0, nCtuX = 0, depthBytes = (int)sizeof(pixel);
+    std::vector<x265hip_tme_step> steps;
+    std::vector<void*> owned;
+    std::map<int, uint16_t*> costRows;         // per qp, device
+    float* bitsRow = nullptr;
+    pixel* cur = nullptr; pixel* plane[2][4][2] = {}; pixel* phase[2][4][2] = {};       // [list][ref][0 = searched plane, 1 = reconstructed picture]
+    int64_t planeElems = 0;
+    x265hip_inter_choice* table = nullptr; x265hip_inter_choice* refTable[2][4] = {}; int16_t* lowres[2][4] = {};
+    int16_t* areaBest = nullptr; x265hip_tme_temporal* temporal = nullptr; uint8_t* qpIndex = nullptr; void* workspace = nullptr; size_t workspaceBytes = 0;
+    x265hip_me_task* dTasks = nullptr; x265hip_me_result* dResults = nullptr;
+    template<class T> int alloc(T*& p, size_t n)
+    {
+        void* v = nullptr;
+        XH_HIP(hipMalloc(&v, n * sizeof(T)));
+        owned.push_back(v); p = (T*)v;
+        return X265HIP_OK;
+    }
+};
+
+namespace {
+constexpr int kHalf = 1 << 15, kBitsHalf = 1 << 15;
+}
+
+extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** out)
+{
+    if (!ctx || !out || width < ctuSize || height < ctuSize || width % ctuSize || height % ctuSize) { set_error("tme_create: pictures of whole CTUs"); return X265HIP_EARG; }
+    const int n = x265hip_tme_schedule(ctuSize, minCuSize, rect, amp, nullptr, 0);
+    if (n <= 0) { set_error("tme_create: bad CTU / CU sizes"); return X265HIP_EARG; }
+    x265hip_tme* t = new (std::nothrow) x265hip_tme();
+    if (!t) return X265HIP_EARG;
+    t->ctx = ctx; t->width = width; t->height = height; t->ctu = ctuSize; t->nCtuX = width / ctuSize; t->nCtu = t->nCtuX * (height / ctuSize);
+    t->steps.resize(n);
+    x265hip_tme_schedule(ctuSize, minCuSize, rect, amp, t->steps.data(), n);
+    int rc;
+    std::vector<float> bits(2 * kBitsHalf + 1);
+    x265hip_mvbits_row(kBitsHalf, bits.data());
+    if ((rc = t->alloc(t->bitsRow, bits.size()))) { x265hip_tme_destroy(t); return rc; }
+    if (hipMemcpy(t->bitsRow, bits.data(), bits.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { x265hip_tme_destroy(t); return X265HIP_EDEVICE; }
+    t->workspaceBytes = x265hip_tme_workspace(t->nCtu);
+    char* ws = nullptr;
+    if ((rc = t->alloc(ws, t->workspaceBytes)) || (rc = t->alloc(t->table, (size_t)t->nCtu * 593)) || (rc = t->alloc(t->areaBest, (size_t)t->nCtu * 5 * 2 * 4 * 2)) ||
+        (rc = t->alloc(t->temporal, (size_t)t->nCtu * n * 2)) || (rc = t->alloc(t->qpIndex, (size_t)t->nCtu * n)) || (rc = t->alloc(t->dTasks, (size_t)t->nCtu * 5)) ||
+        (rc = t->alloc(t->dResults, (size_t)t->nCtu * 5)))
+    { x265hip_tme_destroy(t); return rc; }
+    t->workspace = ws;
+    *out = t;
+    return X265HIP_OK;
+}
+extern "C" void x265hip_tme_destroy(x265hip_tme* t)
+{
+    if (!t) return;
+    for (void* p : t->owned) (void)hipFree(p);
+    for (auto& kv : t->costRows) (void)hipFree(kv.second);
+    delete t;
+}
+extern "C" int x265hip_tme_entries(const x265hip_tme* t, const x265hip_tme_step** steps) { if (!t) return 0; if (steps) *steps = t->steps.data(); return (int)t->steps.size(); }
+
+extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_desc* d)
+{
+    if (!t || !d || !d->curPlane || !d->table || !d->temporal || d->nQp < 1 || d->nQp > 8 || !d->qpIndex || !d->areaQpIndex) { set_error("tme_picture: bad arguments"); return X265HIP_EARG; }
+    hipStream_t st = (hipStream_t)x265hip_ctx_stream(t->ctx);
+    const int nl = d->isP ? 1 : 2, nS = (int)t->steps.size(), nCtu = t->nCtu;
+    const int64_t elems = d->planeElems;
+    int rc;
+    if (t->planeElems != elems)
+    {   // first picture (or another plane geometry): the device planes
+        if (t->planeElems) { set_error("tme_picture: the plane geometry changed"); return X265HIP_EARG; }
+        t->planeElems = elems;
+        if ((rc = t->alloc(t->cur, (size_t)elems))) return rc;
+    }
+    XH_HIP(hipMemcpyAsync(t->cur, d->curPlane, (size_t)elems * sizeof(pixel), hipMemcpyHostToDevice, st));
+    const int rows = (int)(elems / d->stride);
+    for (int l = 0; l < nl; l++)
+        for (int r = 0; r < d->numRef[l]; r++)
+        {
+            const x265hip_tme_host_ref& R = d->refs[l][r];
+            if (!R.mePlane || !R.reconPlane) { set_error("tme_picture: planes of list %d reference %d missing", l, r); return X265HIP_EARG; }
+            for (int k = 0; k < 2; k++)
+            {
+                if (k == 1 && R.reconPlane == R.mePlane) { t->plane[l][r][1] = t->plane[l][r][0]; t->phase[l][r][1] = t->phase[l][r][0]; continue; }
+                if (!t->plane[l][r][k] || (k == 1 && t->plane[l][r][1] == t->plane[l][r][0]))
+                { if ((rc = t->alloc(t->plane[l][r][k], (size_t)elems)) || (rc = t->alloc(t->phase[l][r][k], (size_t)elems * 16))) return rc; }
+                XH_HIP(hipMemcpyAsync(t->plane[l][r][k], k ? R.reconPlane : R.mePlane, (size_t)elems * sizeof(pixel), hipMemcpyHostToDevice, st));
+                if ((rc = x265hip_subpel_planes(st, t->plane[l][r][k], d->stride, rows, t->phase[l][r][k], elems))) return rc;
+            }
+            if (R.refTable)
+            {
+                if (!t->refTable[l][r] && (rc = t->alloc(t->refTable[l][r], (size_t)nCtu * 593))) return rc;
+                XH_HIP(hipMemcpyAsync(t->refTable[l][r], R.refTable, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
+            }
+            if (R.lowresMv)
+            {
+                const size_t nb = (size_t)d->lowresBlocksX * ((d->height + 15) / 16) * 2;
+                if (!t->lowres[l][r] && (rc = t->alloc(t->lowres[l][r], nb))) return rc;
+                XH_HIP(hipMemcpyAsync(t->lowres[l][r], R.lowresMv, nb * sizeof(int16_t), hipMemcpyHostToDevice, st));
+            }
+        }
+    for (int q = 0; q < d->nQp; q++)
+        if (!t->costRows.count(d->qps[q]))
+        {
+            std::vector<uint16_t> row(2 * kHalf + 1);
+            if ((rc = x265hip_mvcost_row(d->qps[q], kHalf, row.data()))) return rc;
+            void* v = nullptr;
+            XH_HIP(hipMalloc(&v, row.size() * sizeof(uint16_t)));
+            XH_HIP(hipMemcpy(v, row.data(), row.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            t->costRows[d->qps[q]] = (uint16_t*)v;
+        }
+    // ---- deriveMVsForCTU's first stage (analysis.cpp:262-299): diamondSearch at range 32 around (0,0) for the CTU (area 0) and its four sub-CUs (areas 1..4), per reference;
+    //      m_areaBestMV starts as zero for every area a search does not write; the collocated median, where there is one, replaces all five ----
+    std::vector<int16_t> area((size_t)nCtu * 5 * 2 * 4 * 2, 0);
+    std::vector<x265hip_me_task> tasks; std::vector<int> where;
+    std::vector<x265hip_me_result> res;
+    for (int l = 0; l < nl; l++)
+        for (int r = 0; r < d->numRef[l]; r++)
+            for (int size = t->ctu; size >= t->ctu / 2; size >>= 1)
+                for (int q = 0; q < d->nQp; q++)
+                {
+                    tasks.clear(); where.clear();
+                    for (int c = 0; c < nCtu; c++)
+                        for (int a = (size == t->ctu ? 0 : 1); a < (size == t->ctu ? 1 : 5); a++)
+                        {
+                            if (d->areaQpIndex[c * 5 + a] != q) continue;
+                            const int cx = (c % t->nCtuX) * t->ctu + (a ? ((a - 1) & 1) * size : 0), cy = (c / t->nCtuX) * t->ctu + (a ? ((a - 1) >> 1) * size : 0);
+                            x265hip_me_task k{};
+                            k.curOff = k.refOff = (int32_t)(d->origin + (int64_t)cy * d->stride + cx);
+                            // Search::setSearchRange(cu, MV(0,0), 32) >> 2 (search.cpp:4969-5021) with CUData::clipMv's limits of this CU
+                            const int xmin = -((t->ctu + 8 + cx - 1) << 2), ymin = -((t->ctu + 8 + cy - 1) << 2), xmax = (d->width + 8 - cx - 1) << 2, ymax = (d->height + 8 - cy - 1) << 2;
+                            const int dd = 32 << 2;
+                            k.mvmin[0] = (int16_t)(std::min(xmax, std::max(xmin, -dd)) >> 2); k.mvmin[1] = (int16_t)(std::min(ymax, std::max(ymin, -dd)) >> 2);
+                            k.mvmax[0] = (int16_t)(std::min(xmax, std::max(xmin, dd)) >> 2); k.mvmax[1] = (int16_t)(std::max(std::min(ymax, std::max(ymin, dd)) >> 2, (int)k.mvmin[1]));
+                            k.mvpFrom = -1;
+                            tasks.push_back(k); where.push_back(c * 5 + a);
+                        }
+                    if (tasks.empty()) continue;
+                    XH_HIP(hipMemcpyAsync(t->dTasks, tasks.data(), tasks.size() * sizeof(x265hip_me_task), hipMemcpyHostToDevice, st));
+                    if ((rc = x265hip_diamond_batch(st, size, size, t->cur, d->stride, t->plane[l][r][0], d->stride, t->dTasks, (int)tasks.size(), t->costRows[d->qps[q]], kHalf, t->dResults))) return rc;
+                    res.resize(tasks.size());
+                    XH_HIP(hipMemcpyAsync(res.data(), t->dResults, tasks.size() * sizeof(x265hip_me_result), hipMemcpyDeviceToHost, st));
+                    XH_HIP(hipStreamSynchronize(st));
+                    for (size_t i = 0; i < tasks.size(); i++)
+                    {
+                        int16_t* o = &area[(((size_t)where[i] * 2 + l) * 4 + r) * 2];
+                        o[0] = res[i].mv[0]; o[1] = res[i].mv[1];                      // the full-pel MV as the reference stores it (search.cpp:363)
+                    }
+                }
+    if (d->median)
+        for (int c = 0; c < nCtu; c++)
+            for (int l = 0; l < nl; l++)
+                for (int r = 0; r < d->numRef[l]; r++)
+                {
+                    const int16_t* m = &d->median[(((size_t)c * 2 + l) * 4 + r) * 3];
+                    if (!m[0]) continue;
+                    for (int a = 0; a < 5; a++) { int16_t* o = &area[((((size_t)c * 5 + a) * 2 + l) * 4 + r) * 2]; o[0] = m[1]; o[1] = m[2]; }
+                }
+    XH_HIP(hipMemcpyAsync(t->areaBest, area.data(), area.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(t->table, d->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(t->temporal, d->temporal, (size_t)nCtu * nS * 2 * sizeof(x265hip_tme_temporal), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(t->qpIndex, d->qpIndex, (size_t)nCtu * nS, hipMemcpyHostToDevice, st));
+    x265hip_tme_args a{};
+    a.isP = d->isP; a.numRef[0] = d->numRef[0]; a.numRef[1] = d->numRef[1]; a.curPOC = d->curPOC; a.temporalMvp = d->temporalMvp;
+    std::memcpy(a.refPOC, d->refPOC, sizeof(a.refPOC));
+    a.searchRange = d->searchRange; a.searchMethod = d->searchMethod; a.subpelRefine = d->subpelRefine;
+    a.picWidth = d->width; a.picHeight = d->height; a.ctuSize = t->ctu; a.lowresBlocksX = d->lowresBlocksX;
+    a.curPlane = t->cur; a.stride = d->stride; a.origin = d->origin; a.planeElems = elems;
+    for (int l = 0; l < nl; l++)
+        for (int r = 0; r < d->numRef[l]; r++)
+        {
+            a.refs[l][r].mePlane = t->plane[l][r][0]; a.refs[l][r].mePhase = t->phase[l][r][0]; a.refs[l][r].reconPhase = t->phase[l][r][1];
+            a.refs[l][r].refTable = d->refs[l][r].refTable ? t->refTable[l][r] : nullptr; a.refs[l][r].lowresMv = d->refs[l][r].lowresMv ? t->lowres[l][r] : nullptr;
+        }
+    a.table = t->table; a.areaBest = t->areaBest; a.temporal = t->temporal;
+    a.nQp = d->nQp; a.qpIndex = t->qpIndex; a.costHalfRange = kHalf;
+    for (int q = 0; q < d->nQp; q++) { a.costRows[q] = t->costRows[d->qps[q]]; a.lambdas[q] = x265hip_rd_lambda(d->qps[q]); }
+    a.bitsRow = t->bitsRow; a.bitsHalfRange = kBitsHalf; a.steps = t->steps.data(); a.nSteps = nS; a.workspace = t->workspace; a.workspaceBytes = t->workspaceBytes;
+    if ((rc = x265hip_tme_frame(st, &a))) return rc;
+    XH_HIP(hipMemcpyAsync(d->table, t->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
+    if (d->areaBestOut) std::memcpy(d->areaBestOut, area.data(), area.size() * sizeof(int16_t));
+    XH_HIP(hipStreamSynchronize(st));
+    return X265HIP_OK;
+}
