@@ -70,8 +70,7 @@ void* x265hip_batch_device_ptr(x265hip_batch* batch, int what);
  * host pointers -- the padded planes as PicYuv holds them (first element of the allocation; all planes of one geometry), the picture's MEData table
  * (slice->m_ctuMV, as x265hip_inter_choice records) as it is before the picture, per reference that reference picture's table and the lookahead's MVs -- and what only
  * the encoder's own state yields: per CTU and reference the median of the collocated MVs (CUData::getMedianColMV, cudata.cpp:1744-1790), per (CTU, entry, partition)
- * the temporal neighbour (CUData::getNeighbourMV's collocated part), and the qp of every CU (Analysis::calculateQpforCuSize).  Pictures of whole CTUs; one
- * reference per list when B pictures use rectangular / AMP partitions (x265hip_tme_frame's limit). */
+ * the temporal neighbour (CUData::getNeighbourMV's collocated part), and the qp of every CU (Analysis::calculateQpforCuSize).  Pictures of whole CTUs. */
 typedef struct x265hip_tme x265hip_tme;
 typedef struct x265hip_tme_host_ref {
     const void* mePlane;                       /* slice->m_mref[l][r].fpelPlane[0] allocation (weighted or not)                                  */
@@ -88,7 +87,7 @@ typedef struct x265hip_tme_picture_desc {
     struct x265hip_inter_choice* table;        /* [numCtu][593], in / out                                                                        */
     const int16_t* median;                     /* [numCtu][2][4][3]: valid, x, y of getMedianColMV; NULL = none                                  */
     const x265hip_tme_temporal* temporal;      /* [numCtu][entries][2]                                                                           */
-    int nQp, qps[8];                           /* the distinct qps of the picture's CUs                                                          */
+    int nQp, qps[64];                           /* the distinct qps of the picture's CUs                                                          */
     const uint8_t* qpIndex;                    /* [numCtu][entries]: index into qps of the entry's CU                                            */
     const uint8_t* areaQpIndex;                /* [numCtu][5]: index into qps of the CTU (area 0) and its four sub-CUs (the diamond searches)    */
     int16_t* areaBestOut;                      /* optional [numCtu][5][2][4][2]: m_areaBestMV as computed                                        */

@@ -109,6 +109,9 @@ int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int amp, x265hip_
 typedef struct x265hip_bidir_task { int32_t curOff, refOff; int16_t mv0[2], mv1[2]; } x265hip_bidir_task;   /* 16 bytes */
 int x265hip_bidir_satd_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* subpelPlanes0, const void* subpelPlanes1, int64_t planeElems,
                              intptr_t refStride, const x265hip_bidir_task* tasks, int n, int32_t* satd);
+/* ... with the references chosen per task: subpelPlanes0[r] / subpelPlanes1[r] (r = 0..3, unused entries NULL) and device arrays ref0[i] / ref1[i] */
+int x265hip_bidir_satd_batch_refs(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* const* subpelPlanes0, const void* const* subpelPlanes1,
+                                  int64_t planeElems, intptr_t refStride, const x265hip_bidir_task* tasks, const int8_t* ref0, const int8_t* ref1, int n, int32_t* satd);
 
 /* ---- AMVP: CUData::getPMV (common/cudata.cpp:1806-1990) for a batch of (PU, list, reference) --------------------------------------------------------------
  * In: the PU's neighbour records in MVP_DIR order (cudata.h:67-75: LEFT, ABOVE, ABOVE_RIGHT, BELOW_LEFT, ABOVE_LEFT, COLLOCATED) as CUData::getNeighbourMV /
@@ -144,7 +147,7 @@ int x265hip_mvp_bits_batch(void* stream, x265hip_mvp_bits* records, int n, const
  * bidirectional candidate, the MEData record written back into the table (kern_tme.hip).  The table is read and written in the reference's order, so entries that a
  * PU reads before this picture wrote them (the reference reads whatever the FrameData held) are the caller's: pass the table as it was.
  * Host-supplied per PU: the temporal (collocated) neighbour CUData::getNeighbourMV finds in the collocated picture's motion (cudata.cpp:1992-2075) with the two POCs
- * getPMV scales it by.  Pictures of whole CTUs; the bidirectional candidate with one reference per list.  All planes share stride, origin and planeElems. */
+ * getPMV scales it by.  Pictures of whole CTUs.  All planes share stride, origin and planeElems. */
 typedef struct x265hip_tme_temporal { x265hip_amvp_neighbour nb; int32_t colPOC[2], colRefPOC[2]; } x265hip_tme_temporal;      /* 28 bytes; per (ctu, entry, partition) */
 typedef struct x265hip_tme_ref {
     const void* mePlane;                       /* the plane motionEstimate searches (slice->m_mref[l][r].fpelPlane[0]: weighted or not), first element of the padded allocation */
@@ -162,9 +165,9 @@ typedef struct x265hip_tme_args {
     struct x265hip_inter_choice* table;        /* [numCtu][593] MEData records, in / out                                                         */
     const int16_t* areaBest;                   /* [numCtu][5][2][4][2]: m_areaBestMV after deriveMVsForCTU's first stage (x265hip_diamond_batch + the median of the collocated MVs) */
     const x265hip_tme_temporal* temporal;      /* [numCtu][nSteps][2]                                                                            */
-    int nQp;                                   /* distinct qps of the picture's CUs, 1..8 (Analysis::setLambdaFromQP runs per CU: AQ / cuTree)   */
+    int nQp;                                   /* distinct qps of the picture's CUs, 1..64 (Analysis::setLambdaFromQP runs per CU: AQ / cuTree)   */
     const uint8_t* qpIndex;                    /* [numCtu][nSteps]: which of them the CU of an entry uses; NULL with nQp == 1                     */
-    const uint16_t* costRows[8]; int costHalfRange; uint64_t lambdas[8];    /* per qp: device x265hip_mvcost_row(qp), x265hip_rd_lambda(qp)          */
+    const uint16_t* costRows[64]; int costHalfRange; uint64_t lambdas[64];    /* per qp: device x265hip_mvcost_row(qp), x265hip_rd_lambda(qp)          */
     const float* bitsRow; int bitsHalfRange;   /* device x265hip_mvbits_row                                                                      */
     const x265hip_tme_step* steps; int nSteps; /* HOST array (x265hip_tme_schedule)                                                              */
     void* workspace; size_t workspaceBytes;    /* device scratch of x265hip_tme_workspace(numCtu) bytes                                          */

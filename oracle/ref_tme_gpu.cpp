@@ -1,0 +1,349 @@
+/*
+ * ref_tme_gpu.cpp -- TEST INFRASTRUCTURE ONLY.
+ *
+ * The reference encoder run with --threaded-me where the producer of the MEData tables is the GPU: Analysis::deriveMVsForCTU (encoder/analysis.cpp:248-306,
+ * what ThreadedME::findJob calls per CTU, threadedme.cpp:207-261) is replaced -- oracle/Makefile compiles encoder/analysis.cpp a second time with
+ * -DderiveMVsForCTU=deriveMVsForCTU_ref and links that object instead of the regular one -- by the definition below: the first call for a picture hands the WHOLE
+ * picture to libx265hip's x265hip_tme_picture (include/x265hip_ctx.h) and copies the table it returns into slice->m_ctuMV; the calls for the picture's other CTUs
+ * find their records there already.  Everything else -- slice decision, rate control, RDO (Search::predInterSearch consuming the records, search.cpp:2607-3090),
+ * entropy coding -- is the reference.  With X265TMEGPU=0 the definition forwards every call to the reference's own body: the same binary, CPU producer.
+ * The bitstream of the two runs must be identical (tests/test_e2e_tme_gpu.py); the printed frames-per-second are the end-to-end figures of DESIGN section 6.
+ *
+ * What the adapter reads out of the reference's state for the picture, and how: the planes (PicYuv allocations), the table as FrameData::reinit left it, per
+ * reference the reference picture's own table and the lookahead's MVs (Lowres::lowresMvs), and -- through the reference's own member functions, on its own CUData
+ * objects, in computeMVForPUs' order -- the qp of every CU (Analysis::calculateQpforCuSize), the collocated neighbour of every PU (CUData::getNeighbourMV), the
+ * collocated median of every CTU (CUData::getMedianColMV).
+ *
+ * usage: x265tmegpu_<depth> <libx265hip.so> <width> <height> <frames> <preset> <out.hevc> [option=value ...]     (width, height: multiples of 64)
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <map>
+#include <mutex>
+#include <vector>
+#define protected public
+#define private public
+#include "x265.h"
+#include "common.h"
+#include "primitives.h"
+#include "picyuv.h"
+#include "frame.h"
+#include "framedata.h"
+#include "slice.h"
+#include "cudata.h"
+#include "lowres.h"
+#include "search.h"
+#include "analysis.h"
+#include "threadedme.h"
+#undef protected
+#undef private
+#include "../include/x265hip_ctx.h"
+
+using namespace X265_NS;
+
+static struct Api
+{
+    int (*ctx_create)(int, x265hip_ctx**);
+    int (*tme_create)(x265hip_ctx*, int, int, int, int, int, int, x265hip_tme**);
+    int (*tme_entries)(const x265hip_tme*, const x265hip_tme_step**);
+    int (*tme_picture)(x265hip_tme*, const x265hip_tme_picture_desc*);
+    const char* (*last_error)();
+} g_api;
+static x265hip_ctx* g_ctx;
+static x265hip_tme* g_tme;
+static int g_useGpu = 1, g_pictures;
+static double g_gpuSeconds;
+static std::mutex g_lock;
+static std::map<const Frame*, int> g_done;          /* picture -> POC + 1 whose table is complete */
+
+void deriveMVsForCTU_ref(Analysis* self, CUData& ctu, const CUGeom& cuGeom, Frame& frame) __asm__("_ZN4x2658Analysis19deriveMVsForCTU_refERNS_6CUDataERKNS_6CUGeomERNS_5FrameE");
+
+namespace {
+
+struct Harvest
+{
+    Analysis& an; const Slice* slice; Frame& frame; const x265hip_tme_step* steps; int nSteps;
+    std::vector<x265hip_tme_temporal>& temporal; std::vector<int>& entryQp;
+    int ctuAddr, k;
+    void collocated(const CUData& cu, int puIdx, uint32_t puAbsPartIdx, x265hip_tme_temporal& t)
+    {
+        InterNeighbourMV nb[6];
+        cu.getNeighbourMV(puIdx, puAbsPartIdx, nb);
+        memset(&t, 0, sizeof(t));
+        t.nb.refIdx[0] = t.nb.refIdx[1] = -1;
+        if (nb[MD_COLLOCATED].unifiedRef == -1) return;
+        for (int l = 0; l < 2; l++)
+        {
+            t.nb.mv[l][0] = (int16_t)nb[MD_COLLOCATED].mv[l].x; t.nb.mv[l][1] = (int16_t)nb[MD_COLLOCATED].mv[l].y;
+            const int tempRefIdx = nb[MD_COLLOCATED].refIdx[l];
+            t.nb.refIdx[l] = (int8_t)tempRefIdx;
+            if (tempRefIdx != -1)
+            {   /* what CUData::getPMV looks up to scale the candidate (cudata.cpp:1962-1967) */
+                const Frame* colPic = slice->m_refFrameList[slice->isInterB() && !slice->m_colFromL0Flag][slice->m_colRefIdx];
+                const CUData* colCU = colPic->m_encData->getPicCTU(nb[MD_COLLOCATED].cuAddr[l]);
+                t.colRefPOC[l] = colCU->m_slice->m_refPOCList[tempRefIdx >> 4][tempRefIdx & 0xf];
+                t.colPOC[l] = colCU->m_slice->m_poc;
+            }
+        }
+    }
+    /* Analysis::computeMVForPUs' walk (analysis.cpp:161-246): sub-CUs first, then the CU's own PU shapes -- here only to harvest per entry the CU's qp and the partitions' collocated neighbours */
+    void walk(CUData& ctu, const CUGeom& geom, int qp)
+    {
+        const uint32_t cuSize = 1u << geom.log2CUSize;
+        if (cuSize > an.m_param->minCUSize)
+        {
+            int nextQP = qp;
+            for (uint32_t sub = 0; sub < 4; sub++)
+            {
+                const CUGeom& child = *(&geom + geom.childOffset + sub);
+                if (slice->m_pps->bUseDQP && geom.depth + 1 <= slice->m_pps->maxCuDQPDepth)
+                    nextQP = x265_clip3(QP_MIN, QP_MAX_SPEC, an.calculateQpforCuSize(ctu, child));
+                walk(ctu, child, nextQP);
+            }
+        }
+        CUData& cu = an.m_modeDepth[geom.depth].pred[Analysis::PRED_2Nx2N].cu;
+        while (k < nSteps && steps[k].cuSize == (int)cuSize && steps[k].cuX == (int)g_zscanToPelX[geom.absPartIdx] && steps[k].cuY == (int)g_zscanToPelY[geom.absPartIdx])
+        {
+            const x265hip_tme_step& e = steps[k];
+            entryQp[(size_t)ctuAddr * nSteps + k] = qp;
+            cu.initSubCU(ctu, geom, qp);
+            cu.setPartSizeSubParts((PartSize)e.part);
+            for (int pi = 0; pi < e.numPart; pi++)
+            {
+                PredictionUnit pu(cu, geom, pi);
+                collocated(cu, pi, pu.puAbsPartIdx, temporal[((size_t)ctuAddr * nSteps + k) * 2 + pi]);
+            }
+            k++;
+        }
+    }
+};
+
+void to_choice(const MEData& m, x265hip_inter_choice& o)
+{
+    for (int l = 0; l < 2; l++)
+    {
+        o.mv[l][0] = (int16_t)m.mv[l].x; o.mv[l][1] = (int16_t)m.mv[l].y; o.mvp[l][0] = (int16_t)m.mvp[l].x; o.mvp[l][1] = (int16_t)m.mvp[l].y;
+        o.mvCost[l] = m.mvCost[l]; o.ref[l] = (int8_t)m.ref[l];
+    }
+    o.reserved = 0; o.bits = m.bits; o.cost = m.cost;
+}
+void from_choice(const x265hip_inter_choice& o, MEData& m)
+{
+    for (int l = 0; l < 2; l++)
+    {
+        m.mv[l] = MV(o.mv[l][0], o.mv[l][1]); m.mvp[l] = MV(o.mvp[l][0], o.mvp[l][1]); m.mvCost[l] = o.mvCost[l]; m.ref[l] = o.ref[l];
+    }
+    m.bits = o.bits; m.cost = o.cost;
+}
+
+int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
+{
+    const Slice* slice = an.m_slice;
+    const x265_param* p = an.m_param;
+    const int W = slice->m_sps->picWidthInLumaSamples, H = slice->m_sps->picHeightInLumaSamples, ctuSize = p->maxCUSize;
+    const int nCtuX = slice->m_sps->numCuInWidth, nCtuY = slice->m_sps->numCuInHeight, nCtu = nCtuX * nCtuY;
+    if (!g_tme)
+    {
+        if (W % ctuSize || H % ctuSize) { fprintf(stderr, "picture not a multiple of the CTU size\n"); return -1; }
+        if (g_api.ctx_create(0, &g_ctx) || g_api.tme_create(g_ctx, W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme))
+        { fprintf(stderr, "x265hip_tme_create: %s\n", g_api.last_error()); return -1; }
+    }
+    const x265hip_tme_step* steps; const int nS = g_api.tme_entries(g_tme, &steps);
+    const int nl = slice->isInterP() ? 1 : 2;
+    x265hip_tme_picture_desc d;
+    memset(&d, 0, sizeof(d));
+    d.isP = slice->isInterP(); d.numRef[0] = slice->m_numRefIdx[0]; d.numRef[1] = nl > 1 ? slice->m_numRefIdx[1] : 0; d.curPOC = slice->m_poc;
+    d.temporalMvp = slice->m_sps->bTemporalMVPEnabled;
+    for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) d.refPOC[l][r] = slice->m_refPOCList[l][r];
+    d.searchRange = p->searchRange; d.searchMethod = p->searchMethod; d.subpelRefine = p->subpelRefine;
+    d.width = W; d.height = H;
+    const PicYuv* fenc = frame.m_fencPic;
+    d.curPlane = fenc->m_picBuf[0]; d.stride = fenc->m_stride; d.origin = fenc->m_picOrg[0] - fenc->m_picBuf[0];
+    d.planeElems = (int64_t)fenc->m_stride * (fenc->m_picHeight + 2 * fenc->m_lumaMarginY);
+    /* per CTU: what findJob sets up before the call (threadedme.cpp:238-246), then the harvest */
+    std::vector<x265hip_tme_temporal> temporal((size_t)nCtu * nS * 2);
+    std::vector<int> entryQp((size_t)nCtu * nS), areaQp((size_t)nCtu * 5);
+    std::vector<int16_t> median((size_t)nCtu * 2 * 4 * 3, 0);
+    const Frame* colPic = slice->m_refFrameList[slice->isInterB() && !slice->m_colFromL0Flag][slice->m_colRefIdx];
+    for (int c = 0; c < nCtu; c++)
+    {
+        CUData* ctu = frame.m_encData->getPicCTU(c);
+        ctu->m_slice = frame.m_encData->m_slice;
+        const int row = c / nCtuX, col = c % nCtuX;
+        frame.m_encData->m_cuStat[c].baseQp = frame.m_encData->m_avgQpRc;
+        ctu->initCTU(frame, c, slice->m_sliceQp, row == 0, row == nCtuY - 1, row == nCtuY - 1 && col == nCtuX - 1);     /* one slice */
+        const int rawBase = slice->m_pps->bUseDQP ? an.calculateQpforCuSize(*ctu, ctuGeom) : slice->m_sliceQp;
+        areaQp[c * 5] = rawBase;
+        for (int sub = 0; sub < 4; sub++)
+            areaQp[c * 5 + 1 + sub] = slice->m_pps->bUseDQP ? an.calculateQpforCuSize(*ctu, *(&ctuGeom + ctuGeom.childOffset + sub)) : slice->m_sliceQp;
+        Harvest h{ an, slice, frame, steps, nS, temporal, entryQp, c, 0 };
+        h.walk(*ctu, ctuGeom, x265_clip3(QP_MIN, QP_MAX_SPEC, rawBase));
+        if (h.k != nS) { fprintf(stderr, "schedule mismatch: %d of %d entries\n", h.k, nS); return -1; }
+        const CUData* colCU = colPic->m_encData->getPicCTU(c);
+        for (int l = 0; l < nl; l++)
+            for (int r = 0; r < slice->m_numRefIdx[l]; r++)
+            {
+                MV m;
+                if (ctu->getMedianColMV(colCU, colPic, l, r, m)) { int16_t* o = &median[(((size_t)c * 2 + l) * 4 + r) * 3]; o[0] = 1; o[1] = (int16_t)m.x; o[2] = (int16_t)m.y; }
+            }
+    }
+    /* the distinct qps */
+    std::vector<int> qps;
+    auto qidx = [&](int qp) { if (qp > QP_MAX_SPEC) { fprintf(stderr, "qp %d above 51: not handled\n", qp); exit(3); }
+                              for (size_t i = 0; i < qps.size(); i++) if (qps[i] == qp) return (int)i; qps.push_back(qp); return (int)qps.size() - 1; };
+    std::vector<uint8_t> qpIndex(entryQp.size()), areaQpIndex(areaQp.size());
+    for (size_t i = 0; i < entryQp.size(); i++) qpIndex[i] = (uint8_t)qidx(entryQp[i]);
+    for (size_t i = 0; i < areaQp.size(); i++) areaQpIndex[i] = (uint8_t)qidx(areaQp[i]);
+    if (qps.size() > 64) { fprintf(stderr, "more than 64 distinct qps\n"); return -1; }
+    d.nQp = (int)qps.size();
+    for (int i = 0; i < d.nQp; i++) d.qps[i] = qps[i];
+    d.qpIndex = qpIndex.data(); d.areaQpIndex = areaQpIndex.data(); d.temporal = temporal.data(); d.median = median.data();
+    /* references: planes, their own tables, the lookahead's MVs */
+    std::vector<std::vector<x265hip_inter_choice>> refTables;
+    std::vector<std::vector<int16_t>> lowres;
+    refTables.reserve(8); lowres.reserve(8);
+    d.lowresBlocksX = frame.m_lowres.maxBlocksInRow;
+    for (int l = 0; l < nl; l++)
+        for (int r = 0; r < slice->m_numRefIdx[l]; r++)
+        {
+            x265hip_tme_host_ref& R = d.refs[l][r];
+            const MotionReference& mr = slice->m_mref[l][r];
+            const PicYuv* rec = slice->m_refReconPicList[l][r];
+            R.mePlane = mr.fpelPlane[0] - d.origin;
+            R.reconPlane = rec->m_picBuf[0];
+            const Frame* rf = slice->m_refFrameList[l][r];
+            if (rf->m_encData->m_slice->m_sliceType != I_SLICE)
+            {
+                refTables.emplace_back((size_t)nCtu * 593);
+                const MEData* src = rf->m_encData->m_slice->m_ctuMV;
+                for (size_t i = 0; i < refTables.back().size(); i++) to_choice(src[i], refTables.back()[i]);
+                R.refTable = refTables.back().data();
+            }
+            const int diffPoc = abs(slice->m_poc - slice->m_refPOCList[l][r]);
+            if (diffPoc <= p->bframes + 1)
+            {
+                const MV* mvs = frame.m_lowres.lowresMvs[l][diffPoc];
+                if (mvs[0].x != 0x7FFF)
+                {
+                    const size_t nb = (size_t)frame.m_lowres.maxBlocksInRow * ((H + 15) / 16);
+                    lowres.emplace_back(nb * 2);
+                    for (size_t i = 0; i < nb; i++) { lowres.back()[2 * i] = (int16_t)mvs[i].x; lowres.back()[2 * i + 1] = (int16_t)mvs[i].y; }
+                    R.lowresMv = lowres.back().data();
+                }
+            }
+        }
+    std::vector<x265hip_inter_choice> table((size_t)nCtu * 593);
+    MEData* dst = frame.m_encData->m_slice->m_ctuMV;
+    for (size_t i = 0; i < table.size(); i++) to_choice(dst[i], table[i]);
+    d.table = table.data();
+    const auto t0 = std::chrono::steady_clock::now();
+    { const int rc = g_api.tme_picture(g_tme, &d); if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", slice->m_poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; } }
+    g_gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t i = 0; i < table.size(); i++) from_choice(table[i], dst[i]);
+    g_pictures++;
+    return 0;
+}
+
+} // namespace
+
+namespace X265_NS {
+void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
+{
+    if (!g_useGpu) { ::deriveMVsForCTU_ref(this, ctu, cuGeom, frame); return; }
+    std::lock_guard<std::mutex> guard(g_lock);
+    const int poc = ctu.m_slice->m_poc;
+    auto it = g_done.find(&frame);
+    if (it != g_done.end() && it->second == poc + 1) return;              /* this picture's table is there already */
+    m_slice = ctu.m_slice; m_frame = &frame; m_param = m_frame->m_param;  /* as the reference's body starts (analysis.cpp:250-252) */
+    if (run_picture(*this, cuGeom, frame)) exit(3);
+    g_done[&frame] = poc + 1;
+}
+}
+
+static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixel>& v, int w, int h, int f)
+{   /* the clip of ref_tme.cpp: textured picture in (not purely translational) motion + deterministic noise */
+    uint32_t s = 4242u + 733u * (uint32_t)f;
+    const int pm = (1 << X265_DEPTH) - 1;
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++)
+        {
+            const int x = i + 5 * f + ((j >> 5) & 1) * f, yy = j + 3 * f;
+            const int t = (((x * x) / 9 + yy * 7 + (x * yy) / 13 + ((x >> 3) ^ (yy >> 3)) * 11) & 255) * (pm + 1) / 256;
+            s = s * 1664525u + 1013904223u;
+            const int val = t + (int)((s >> 24) & 7) - 3;
+            y[(size_t)j * w + i] = (pixel)(val < 0 ? 0 : val > pm ? pm : val);
+        }
+    for (int j = 0; j < h / 2; j++)
+        for (int i = 0; i < w / 2; i++)
+        {
+            u[(size_t)j * (w / 2) + i] = (pixel)((((i + f) * 3 + j) & 127) * (pm + 1) / 256 + (pm + 1) / 4);
+            v[(size_t)j * (w / 2) + i] = (pixel)((((j + 2 * f) * 5 + i) & 127) * (pm + 1) / 256 + (pm + 1) / 4);
+        }
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 7) { fprintf(stderr, "usage: %s libx265hip.so width height frames preset out.hevc [option=value ...]\n", argv[0]); return 2; }
+    g_useGpu = getenv("X265TMEGPU") ? atoi(getenv("X265TMEGPU")) : 1;
+    if (g_useGpu)
+    {
+        void* lib = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+        g_api.ctx_create = (int (*)(int, x265hip_ctx**))dlsym(lib, "x265hip_ctx_create");
+        g_api.tme_create = (int (*)(x265hip_ctx*, int, int, int, int, int, int, x265hip_tme**))dlsym(lib, "x265hip_tme_create");
+        g_api.tme_entries = (int (*)(const x265hip_tme*, const x265hip_tme_step**))dlsym(lib, "x265hip_tme_entries");
+        g_api.tme_picture = (int (*)(x265hip_tme*, const x265hip_tme_picture_desc*))dlsym(lib, "x265hip_tme_picture");
+        g_api.last_error = (const char* (*)())dlsym(lib, "x265hip_last_error");
+        if (!g_api.ctx_create || !g_api.tme_create || !g_api.tme_entries || !g_api.tme_picture || !g_api.last_error) { fprintf(stderr, "missing symbols\n"); return 2; }
+    }
+    const int w = atoi(argv[2]), h = atoi(argv[3]), frames = atoi(argv[4]);
+    x265_param* p = x265_param_alloc();
+    if (x265_param_default_preset(p, argv[5], NULL) < 0) { fprintf(stderr, "bad preset\n"); return 2; }
+    p->sourceWidth = w; p->sourceHeight = h; p->fpsNum = 25; p->fpsDenom = 1; p->internalCsp = X265_CSP_I420;
+    p->totalFrames = frames; p->logLevel = X265_LOG_WARNING; p->bRepeatHeaders = 1;
+    p->frameNumThreads = 1; p->bEnableWavefront = 0; p->lookaheadSlices = 0;
+    x265_param_parse(p, "pools", "32");
+    x265_param_parse(p, "threaded-me", "1");
+    for (int i = 7; i < argc; i++)
+    {
+        char* eq = strchr(argv[i], '=');
+        if (eq) *eq = 0;
+        if (x265_param_parse(p, argv[i], eq ? eq + 1 : NULL) < 0) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
+    }
+    FILE* out = fopen(argv[6], "wb");
+    if (!out) { fprintf(stderr, "cannot write %s\n", argv[6]); return 2; }
+    x265_encoder* enc = x265_encoder_open(p);
+    if (!enc) { fprintf(stderr, "encoder_open failed\n"); return 2; }
+    x265_picture* pic = x265_picture_alloc();
+    x265_picture_init(p, pic);
+    std::vector<pixel> Y((size_t)w * h), U((size_t)w * h / 4), V((size_t)w * h / 4);
+    pic->planes[0] = Y.data(); pic->planes[1] = U.data(); pic->planes[2] = V.data();
+    pic->stride[0] = w * (int)sizeof(pixel); pic->stride[1] = pic->stride[2] = (w / 2) * (int)sizeof(pixel);
+    pic->bitDepth = X265_DEPTH; pic->colorSpace = X265_CSP_I420;
+    x265_nal* nal; uint32_t nnal;
+    size_t bytes = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int f = 0; f < frames; f++)
+    {
+        synth(Y, U, V, w, h, f);
+        pic->pts = f;
+        const int r = x265_encoder_encode(enc, &nal, &nnal, pic, NULL);
+        if (r < 0) { fprintf(stderr, "encode failed\n"); return 2; }
+        for (uint32_t i = 0; i < nnal; i++) { fwrite(nal[i].payload, 1, nal[i].sizeBytes, out); bytes += nal[i].sizeBytes; }
+    }
+    while (x265_encoder_encode(enc, &nal, &nnal, NULL, NULL) > 0)
+        for (uint32_t i = 0; i < nnal; i++) { fwrite(nal[i].payload, 1, nal[i].sizeBytes, out); bytes += nal[i].sizeBytes; }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    x265_param* live = x265_param_alloc();
+    x265_encoder_parameters(enc, live);
+    const int tme = live->bThreadedME;
+    x265_param_free(live);
+    x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
+    fclose(out);
+    printf("{\"producer\": \"%s\", \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f}\n",
+           g_useGpu ? "gpu" : "cpu", frames, secs, frames / secs, bytes, tme, g_pictures, g_gpuSeconds);
+    return 0;
+}

@@ -1,0 +1,37 @@
+"""SURVEY 8(f1) end to end: the reference encoder run with --threaded-me whose MEData tables come from libx265hip (oracle/ref_tme_gpu.cpp: Analysis::deriveMVsForCTU
+replaced by one x265hip_tme_picture call per picture) must write the bitstream it writes with its own CPU producer."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+import x265hip
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def encode(depth, producer, args, out):
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265tmegpu_%d" % depth)
+    if not os.path.exists(exe):
+        pytest.skip("no oracle/_ref/x265tmegpu_%d (built where the reference is present)" % depth)
+    env = dict(os.environ, X265TMEGPU="1" if producer == "gpu" else "0")
+    r = subprocess.run([exe, x265hip.lib_path(depth)] + args[:4] + [out] + args[4:], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["threaded_me"] == 1
+    return info, hashlib.md5(open(out, "rb").read()).hexdigest()
+
+
+@pytest.mark.parametrize("depth,args", [(8, ["128", "128", "6", "medium", "ref=1", "weightp=0", "weightb=0"]),
+                                        (8, ["192", "128", "6", "slow", "ref=1", "weightp=0", "weightb=0", "bframes=2"]),
+                                        (10, ["128", "128", "5", "slow", "ref=1", "weightp=0", "weightb=0"]),
+                                        (8, ["256", "192", "5", "medium", "ref=2", "bframes=0", "weightp=0"])])
+def test_bitstream_identical_with_gpu_producer(depth, args, tmp_path):
+    cpu, h_cpu = encode(depth, "cpu", args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(depth, "gpu", args, str(tmp_path / "gpu.hevc"))
+    assert gpu["gpu_pictures"] >= 3, "the GPU producer did not run: %s" % gpu
+    assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
+    print("e2e", depth, args, "cpu fps %.2f gpu fps %.2f (gpu producer %.3f s for %d pictures)" % (cpu["fps"], gpu["fps"], gpu["gpu_seconds"], gpu["gpu_pictures"]))

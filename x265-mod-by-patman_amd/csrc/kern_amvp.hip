@@ -98,7 +98,7 @@ extern "C" int x265hip_select_mvp_batch(void* stream, int w, int h, const void* 
                                         const x265hip_select_task* tasks, int n, x265hip_select_result* out)
 {
     if (n <= 0) return X265HIP_OK;
-    if (!curPlane || !subpelPlanes || !tasks || !out || w < 4 || h < 4 || w > 64 || h > 64 || (w & 3)) return X265HIP_EARG;
+    if (!curPlane || !subpelPlanes || !tasks || !out || w < 4 || h < 4 || w > 64 || h > 64 || (w & 3)) { set_error("select_mvp_batch: bad arguments (%dx%d)", w, h); return X265HIP_EARG; }
     hipLaunchKernelGGL(select_mvp_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, h, (const pixel*)curPlane, curStride, (const pixel*)subpelPlanes, planeElems, refStride, tasks, n, out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

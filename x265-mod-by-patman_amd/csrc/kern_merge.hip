@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void inter_merge_kernel(MergeArgs a)
 }
 
 // the bidirectional candidate's distortion alone (search.cpp:436-446) for a batch of PUs: predInterLumaPixel of both references at the given MVs -> pixelavg_pp -> SATD
-__global__ __launch_bounds__(256) void bidir_satd_kernel(MergeArgs a, const x265hip_bidir_task* __restrict__ bt, int32_t* __restrict__ satd)
+__global__ __launch_bounds__(256) void bidir_satd_kernel(MergeArgs a, const x265hip_bidir_task* __restrict__ bt, int32_t* __restrict__ satd, const int8_t* __restrict__ ref0, const int8_t* __restrict__ ref1)
 {
     __shared__ __attribute__((aligned(16))) pixel s_fenc[4][64 * 64];
     __shared__ __attribute__((aligned(16))) pixel s_avg[4][64 * 64];
@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256) void bidir_satd_kernel(MergeArgs a, const x265
         int v[4]; load4u(a.cur + t.curOff + (intptr_t)y * a.cs + x4, v); store4(fenc + y * a.w + x4, v);
     }
     wave_sync();
-    const int s = bidir_satd(a, fenc, avg, t.refOff, a.planes[0], t.mv0[0], t.mv0[1], a.planes[4], t.mv1[0], t.mv1[1], lane);
+    // per-task references (ref0 / ref1 given): the planes of the list-0 / list-1 reference this PU chose
+    const pixel* pa = a.planes[ref0 ? uni((int)ref0[item]) & 3 : 0]; const pixel* pb = a.planes[4 + (ref1 ? uni((int)ref1[item]) & 3 : 0)];
+    const int s = bidir_satd(a, fenc, avg, t.refOff, pa, t.mv0[0], t.mv0[1], pb, t.mv1[0], t.mv1[1], lane);
     if (lane == 0) satd[item] = s;
 }
 
@@ -261,7 +263,21 @@ extern "C" int x265hip_bidir_satd_batch(void* stream, int w, int h, const void* 
     MergeArgs a{};
     a.w = w; a.h = h; a.n = n; a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.planeElems = planeElems;
     a.planes[0] = (const pixel*)subpelPlanes0; a.planes[4] = (const pixel*)subpelPlanes1;
-    hipLaunchKernelGGL(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd);
+    hipLaunchKernelGGL(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd, (const int8_t*)nullptr, (const int8_t*)nullptr);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+// the same with the references chosen per task: subpelPlanes0[r] / subpelPlanes1[r] = phase planes of reference r of list 0 / 1, ref0[i] / ref1[i] = task i's choice
+extern "C" int x265hip_bidir_satd_batch_refs(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* const* subpelPlanes0, const void* const* subpelPlanes1,
+                                             int64_t planeElems, intptr_t refStride, const x265hip_bidir_task* tasks, const int8_t* ref0, const int8_t* ref1, int n, int32_t* satd)
+{
+    if (n <= 0) return X265HIP_OK;
+    if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !curPlane || !subpelPlanes0 || !subpelPlanes1 || !tasks || !satd || !ref0 || !ref1) { set_error("bidir_satd_batch_refs: bad arguments"); return X265HIP_EARG; }
+    MergeArgs a{};
+    a.w = w; a.h = h; a.n = n; a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.planeElems = planeElems;
+    for (int r = 0; r < 4; r++) { a.planes[r] = (const pixel*)(subpelPlanes0[r] ? subpelPlanes0[r] : subpelPlanes0[0]); a.planes[4 + r] = (const pixel*)(subpelPlanes1[r] ? subpelPlanes1[r] : subpelPlanes1[0]); }
+    hipLaunchKernelGGL(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd, ref0, ref1);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

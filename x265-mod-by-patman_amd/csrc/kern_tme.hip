@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void tme_cost_kernel(Slice s, x265hip_tme_step
 
 // ---- the bidirectional candidate's tasks (search.cpp:418-450) ----
 __global__ __launch_bounds__(256) void tme_bidir_kernel(Slice s, x265hip_tme_step st, int pi, int nCtu, TmeState* __restrict__ state, x265hip_bidir_task* __restrict__ t0,
-                                                        x265hip_bidir_task* __restrict__ t1)
+                                                        x265hip_bidir_task* __restrict__ t1, int8_t* __restrict__ ref0, int8_t* __restrict__ ref1)
 {
     const int ctu = blockIdx.x * 256 + threadIdx.x;
     if (ctu >= nCtu) return;
@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void tme_bidir_kernel(Slice s, x265hip_tme_ste
         S.tryZero = tz;
     }
     t0[ctu] = a;
+    ref0[ctu] = (int8_t)(S.bidirOn ? S.bestRef[0] : 0); ref1[ctu] = (int8_t)(S.bidirOn ? S.bestRef[1] : 0);
 }
 
 // ---- finish: the bidirectional decision and the MEData record (search.cpp:440-556) ----
@@ -292,22 +293,22 @@ __global__ __launch_bounds__(256) void tme_finish_kernel(Slice s, x265hip_tme_st
 extern "C" size_t x265hip_tme_workspace(int nCtu)
 {
     const size_t per = sizeof(TmeState) + sizeof(x265hip_select_task) + sizeof(x265hip_select_result) + 2 * sizeof(x265hip_me_task) + 2 * sizeof(x265hip_me_result) +
-                       2 * sizeof(x265hip_bidir_task) + 2 * sizeof(int32_t);
+                       2 * sizeof(x265hip_bidir_task) + 2 * sizeof(int32_t) + 2;
     return (size_t)nCtu * per + 16 * 256;
 }
 
 extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
 {
-    if (!a || !a->steps || a->nSteps < 1 || !a->curPlane || !a->table || !a->areaBest || !a->temporal || !a->bitsRow || !a->workspace || a->nQp < 1 || a->nQp > 8 || (a->nQp > 1 && !a->qpIndex)) return X265HIP_EARG;
-    for (int q = 0; q < a->nQp; q++) if (!a->costRows[q]) return X265HIP_EARG;
-    if (a->ctuSize < 16 || a->picWidth % a->ctuSize || a->picHeight % a->ctuSize) return X265HIP_EARG;       // whole CTUs only (CUs outside the picture are not handled yet)
+    if (!a || !a->steps || a->nSteps < 1 || !a->curPlane || !a->table || !a->areaBest || !a->temporal || !a->bitsRow || !a->workspace || a->nQp < 1 || a->nQp > 64 || (a->nQp > 1 && !a->qpIndex)) { set_error("tme_frame: missing arguments"); return X265HIP_EARG; }
+    for (int q = 0; q < a->nQp; q++) if (!a->costRows[q]) { set_error("tme_frame: cost row %d missing", q); return X265HIP_EARG; }
+    if (a->ctuSize < 16 || a->picWidth % a->ctuSize || a->picHeight % a->ctuSize) { set_error("tme_frame: pictures of whole CTUs only"); return X265HIP_EARG; }       // whole CTUs only (CUs outside the picture are not handled yet)
     const int nCtuX = a->picWidth / a->ctuSize, nCtuY = a->picHeight / a->ctuSize, nCtu = nCtuX * nCtuY;
-    if (a->workspaceBytes < x265hip_tme_workspace(nCtu)) return X265HIP_EARG;
+    if (a->workspaceBytes < x265hip_tme_workspace(nCtu)) { set_error("tme_frame: workspace too small"); return X265HIP_EARG; }
     const int nl = a->isP ? 1 : 2;
     for (int l = 0; l < nl; l++)
     {
-        if (a->numRef[l] < 1 || a->numRef[l] > 4) return X265HIP_EARG;
-        for (int r = 0; r < a->numRef[l]; r++) if (!a->refs[l][r].mePlane || !a->refs[l][r].mePhase || !a->refs[l][r].reconPhase) return X265HIP_EARG;
+        if (a->numRef[l] < 1 || a->numRef[l] > 4) { set_error("tme_frame: %d references in list %d", a->numRef[l], l); return X265HIP_EARG; }
+        for (int r = 0; r < a->numRef[l]; r++) if (!a->refs[l][r].mePlane || !a->refs[l][r].mePhase || !a->refs[l][r].reconPhase) { set_error("tme_frame: planes of list %d reference %d missing", l, r); return X265HIP_EARG; }
     }
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)a->workspace;
@@ -318,7 +319,9 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
     x265hip_me_task* tA = (x265hip_me_task*)take(sizeof(x265hip_me_task) * nCtu); x265hip_me_task* tB = (x265hip_me_task*)take(sizeof(x265hip_me_task) * nCtu);
     x265hip_me_result* rA = (x265hip_me_result*)take(sizeof(x265hip_me_result) * nCtu); x265hip_me_result* rB = (x265hip_me_result*)take(sizeof(x265hip_me_result) * nCtu);
     x265hip_bidir_task* b0 = (x265hip_bidir_task*)take(sizeof(x265hip_bidir_task) * nCtu); x265hip_bidir_task* b1 = (x265hip_bidir_task*)take(sizeof(x265hip_bidir_task) * nCtu);
-    int32_t* s0 = (int32_t*)take(4 * nCtu); int32_t* s1 = (int32_t*)take(4 * nCtu);
+    int32_t* s0 = (int32_t*)take(4 * nCtu); int32_t* s1 = (int32_t*)take(4 * nCtu); int8_t* br0 = (int8_t*)take(nCtu); int8_t* br1 = (int8_t*)take(nCtu);
+    const void* ph0[4] = {}; const void* ph1[4] = {};
+    for (int r = 0; r < 4; r++) { ph0[r] = r < a->numRef[0] ? a->refs[0][r].reconPhase : nullptr; ph1[r] = (!a->isP && r < a->numRef[1]) ? a->refs[1][r].reconPhase : nullptr; }
     Slice s{};
     s.isP = a->isP; s.numRef[0] = a->numRef[0]; s.numRef[1] = a->isP ? 0 : a->numRef[1]; s.searchRange = a->searchRange; s.picW = a->picWidth; s.picH = a->picHeight;
     s.ctuSize = a->ctuSize; s.numCtuX = nCtuX; s.lowresBlocksX = a->lowresBlocksX; s.stride = a->stride; s.origin = a->origin;
@@ -338,7 +341,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
                     const x265hip_tme_ref& R = a->refs[l][r];
                     hipLaunchKernelGGL(tme_gather_kernel, grid, block, 0, st, s, e, k, a->nSteps, pi, l, r, nCtu, a->table, a->areaBest, a->temporal, R.refTable, R.lowresMv, state, sel);
                     int rc = x265hip_select_mvp_batch(stream, pw, ph, a->curPlane, a->stride, R.reconPhase, a->planeElems, a->stride, sel, nCtu, selRes);
-                    if (rc) return rc;
+                    if (rc) { set_error("tme_frame: select_mvp_batch %dx%d failed", pw, ph); return rc; }
                     for (int q = 0; q < a->nQp; q++)
                     {   // one round per qp of the picture: the searches take ONE cost row per launch; the CUs of another qp get a degenerate task in this round
                         hipLaunchKernelGGL(tme_build_kernel, grid, block, 0, st, s, e, pi, nCtu, selRes, state, tA, tB, a->qpIndex, k, a->nSteps, q);
@@ -352,13 +355,12 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
                                            a->qpIndex, k, a->nSteps, q, (unsigned long long)a->lambdas[q]);
                     }
                 }
-            hipLaunchKernelGGL(tme_bidir_kernel, grid, block, 0, st, s, e, pi, nCtu, state, b0, b1);
+            hipLaunchKernelGGL(tme_bidir_kernel, grid, block, 0, st, s, e, pi, nCtu, state, b0, b1, br0, br1);
             if (!a->isP && e.part != 0 && e.cuSize != 8)
-            {   // the bidirectional candidate exists for this shape: its two distortions.  One reference per list in this form (the chosen reference varies per CTU otherwise)
-                if (a->numRef[0] != 1 || a->numRef[1] != 1) return X265HIP_EARG;
-                int rc = x265hip_bidir_satd_batch(stream, pw, ph, a->curPlane, a->stride, a->refs[0][0].reconPhase, a->refs[1][0].reconPhase, a->planeElems, a->stride, b0, nCtu, s0);
+            {   // the bidirectional candidate exists for this shape: its two distortions, each PU against the references it chose per list
+                int rc = x265hip_bidir_satd_batch_refs(stream, pw, ph, a->curPlane, a->stride, ph0, ph1, a->planeElems, a->stride, b0, br0, br1, nCtu, s0);
                 if (rc) return rc;
-                rc = x265hip_bidir_satd_batch(stream, pw, ph, a->curPlane, a->stride, a->refs[0][0].reconPhase, a->refs[1][0].reconPhase, a->planeElems, a->stride, b1, nCtu, s1);
+                rc = x265hip_bidir_satd_batch_refs(stream, pw, ph, a->curPlane, a->stride, ph0, ph1, a->planeElems, a->stride, b1, br0, br1, nCtu, s1);
                 if (rc) return rc;
             }
             hipLaunchKernelGGL(tme_finish_kernel, grid, block, 0, st, s, e, pi, nCtu, s0, s1, bitsCentre, a->bitsHalfRange, state, a->table);

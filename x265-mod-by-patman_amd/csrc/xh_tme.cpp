@@ -162,7 +162,7 @@ extern "C" int x265hip_tme_entries(const x265hip_tme* t, const x265hip_tme_step*
 
 extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_desc* d)
 {
-    if (!t || !d || !d->curPlane || !d->table || !d->temporal || d->nQp < 1 || d->nQp > 8 || !d->qpIndex || !d->areaQpIndex) { set_error("tme_picture: bad arguments"); return X265HIP_EARG; }
+    if (!t || !d || !d->curPlane || !d->table || !d->temporal || d->nQp < 1 || d->nQp > 64 || !d->qpIndex || !d->areaQpIndex) { set_error("tme_picture: bad arguments"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)x265hip_ctx_stream(t->ctx);
     const int nl = d->isP ? 1 : 2, nS = (int)t->steps.size(), nCtu = t->nCtu;
     const int64_t elems = d->planeElems;
