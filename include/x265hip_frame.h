@@ -42,6 +42,10 @@ typedef struct x265hip_me_task {
 /* flags: derive the search window on the device the way Search::setSearchRange does (search.cpp:4969-5021):
  * [mvp - 4*merange, mvp + 4*merange] clipped to the task's quarter-pel limits, >> 2, mvmax.y >= mvmin.y */
 #define X265HIP_ME_WINDOW 1
+/* flags: the task has its own MVD cost row (CUs of different qp in one launch: Analysis::setLambdaFromQP runs per CU).  costRow of the call is then a TABLE of
+ * rows, 2 * costHalfRange + 1 entries each, and bits 8..15 of flags are the task's row index.  (The searches then read the row from memory, not from the
+ * workgroup's LDS slice.) */
+#define X265HIP_ME_ROWS 2
 
 typedef struct x265hip_me_result {
     int16_t mv[2];               /* chosen quarter-pel MV (outQMv)                                   */
@@ -167,7 +171,8 @@ typedef struct x265hip_tme_args {
     const x265hip_tme_temporal* temporal;      /* [numCtu][nSteps][2]                                                                            */
     int nQp;                                   /* distinct qps of the picture's CUs, 1..64 (Analysis::setLambdaFromQP runs per CU: AQ / cuTree)   */
     const uint8_t* qpIndex;                    /* [numCtu][nSteps]: which of them the CU of an entry uses; NULL with nQp == 1                     */
-    const uint16_t* costRows[64]; int costHalfRange; uint64_t lambdas[64];    /* per qp: device x265hip_mvcost_row(qp), x265hip_rd_lambda(qp)          */
+    const uint16_t* costRows; int costHalfRange;   /* device table [nQp][2 * costHalfRange + 1]: row q = x265hip_mvcost_row(qp q) (X265HIP_ME_ROWS)  */
+    uint64_t lambdas[64];                      /* per qp: x265hip_rd_lambda(qp)                                                                  */
     const float* bitsRow; int bitsHalfRange;   /* device x265hip_mvbits_row                                                                      */
     const x265hip_tme_step* steps; int nSteps; /* HOST array (x265hip_tme_schedule)                                                              */
     void* workspace; size_t workspaceBytes;    /* device scratch of x265hip_tme_workspace(numCtu) bytes                                          */

@@ -273,3 +273,41 @@ def test_me_batch_chroma_matches_oracle(depth, method):
                                 merange, method, subme, row, cc, cstr, int(offc[i]), rc, cstr, int(offc[i]))
             got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
             assert got == exp, "chroma: PU %dx%d task %d method %d subme %d merange %d: hip %s oracle %s (mvp %s)" % (w, h, i, method, subme, merange, got, exp, tk["qmvp"])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("method", [1, 3])
+def test_me_batch_cost_row_per_task(depth, method):
+    """X265HIP_ME_ROWS: PUs of CUs with different qps in one launch -- every task names its row of a cost table; the results must be those of the oracle searching
+    with that qp's row (sizes incl. 64x64, whose STAR search goes through the window kernel)."""
+    from x265hip_pkg.frame import mvcost_row
+    api, ora = FrameApi(depth), Oracle(depth)
+    T = api.torch
+    rng = np.random.default_rng(17 * depth + method)
+    W, H, margin, half = 320, 192, 96, 1 << 14
+    cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 77, margin=margin, max_shift=12)
+    cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
+    d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+    pe = cur_f.size
+    d_pl = T.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
+    api.subpel_planes(d_ref, stride, cur.shape[0], d_pl, pe)
+    qps = [22, 30, 37, 45]
+    rows = [mvcost_row(depth, q, half) for q in qps]
+    d_table = api.to_device(np.concatenate(rows).view(np.int16))
+    for (w, h) in [(64, 64), (32, 32), (16, 8), (8, 8)]:
+        n = 24
+        tasks = make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, 24)
+        which = rng.integers(0, len(qps), n)
+        tasks["flags"] = 2 | (which.astype(np.int16) << 8)                  # X265HIP_ME_ROWS | row << 8
+        d_tasks = api.to_device(tasks)
+        d_res = T.zeros(n * ME_RESULT.itemsize, dtype=T.uint8, device="cuda")
+        api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_table, half, 24, method, 3, d_res, planes=d_pl, plane_elems=pe)
+        T.cuda.synchronize()
+        res = d_res.cpu().numpy().view(ME_RESULT)
+        for i in range(n):
+            tk = tasks[i]
+            bounds = [int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])]
+            mvc = [int(v) for v in tk["mvc"][:2 * int(tk["numCand"])]]
+            exp = ora.me(w, h, cur_f, stride, int(tk["curOff"]), ref_f, stride, int(tk["refOff"]), bounds, (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc, 24, method, 3, rows[int(which[i])])
+            got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
+            assert got == exp, "row per task: PU %dx%d task %d qp %d: hip %s oracle %s" % (w, h, i, qps[int(which[i])], got, exp)

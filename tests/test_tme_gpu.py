@@ -369,7 +369,7 @@ def test_tme_frame_steps_whole_pictures_to_the_references_tables(depth):
                             nxt = [s for s in subs if s[0] in (2, 5)]
                             if nxt and nxt[0][0] == 2: subs.remove(nxt[0])          # the second search
                     written[ctu, c["finalIdx"] + pi * c["puOffset"]] = True
-        d_rows = [api.to_device(mvcost_row(depth, q, 1 << 15).view(np.int16)) for (q, _) in qps]
+        d_rows = api.to_device(np.concatenate([mvcost_row(depth, q, 1 << 15) for (q, _) in qps]).view(np.int16))       # the cost table: one row per qp of the picture
         refs = [[], []]
         for l in range(nlist):
             for r in range(c0["numRef"][l]):

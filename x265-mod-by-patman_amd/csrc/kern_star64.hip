@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void star64_kernel(const pixel* __restrict_
     const x265hip_me_result st = results[item];
     if (st.reserved != XH_PARKED) return;                                           // only PUs the first half parked (start stage done, search pending)
     const x265hip_me_task* __restrict__ tp = tasks + item;
+    if (tp->flags & X265HIP_ME_ROWS) costCentre += (size_t)((tp->flags >> 8) & 0xFF) * (size_t)(2 * chr + 1);      // the task's own MVD cost row (one PU per workgroup: its LDS slice too)
     Mv mv; mv.centre = costCentre; mv.lcentre = (const lu16*)s.mvc + COST_R; mv.chr = chr;
     mv.mvpx = tp->qmvp[0]; mv.mvpy = tp->qmvp[1];
     { const int from = tp->mvpFrom; if (from >= 0 && mvpSource) { mv.mvpx = mvpSource[from].mv[0]; mv.mvpy = mvpSource[from].mv[1]; } }
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(256, 2) void star64_raster_kernel(const pixel* __re
     const x265hip_me_result st = results[item];
     if (st.reserved != XH_PARKED || st.mvcost != 2) return;
     const x265hip_me_task* __restrict__ tp = tasks + item;
+    if (tp->flags & X265HIP_ME_ROWS) costCentre += (size_t)((tp->flags >> 8) & 0xFF) * (size_t)(2 * chr + 1);      // the task's own MVD cost row (one PU per workgroup: its LDS slice too)
     Mv mv; mv.centre = costCentre; mv.lcentre = (const lu16*)s.mvc + COST_R; mv.chr = chr;
     mv.mvpx = tp->qmvp[0]; mv.mvpy = tp->qmvp[1];
     { const int from = tp->mvpFrom; if (from >= 0 && mvpSource) { mv.mvpx = mvpSource[from].mv[0]; mv.mvpy = mvpSource[from].mv[1]; } }

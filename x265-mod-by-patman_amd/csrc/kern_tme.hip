@@ -25,6 +25,8 @@ struct TmeState
     unsigned long long lambda;               // of the CU's qp (Analysis::setLambdaFromQP per CU: AQ / cuTree move the qp inside a picture)
 };
 
+struct Lambdas { unsigned long long v[64]; };
+
 struct Slice
 {
     int isP, numRef[2], searchRange, picW, picH, ctuSize, numCtuX, lowresBlocksX;
@@ -123,12 +125,12 @@ __global__ __launch_bounds__(256) void tme_gather_kernel(Slice s, x265hip_tme_st
 
 // ---- build: the predictor and the two search tasks (search.cpp:309-390) ----
 __global__ __launch_bounds__(256) void tme_build_kernel(Slice s, x265hip_tme_step st, int pi, int nCtu, const x265hip_select_result* __restrict__ selRes, TmeState* __restrict__ state,
-                                                        x265hip_me_task* __restrict__ taskA, x265hip_me_task* __restrict__ taskB, const uint8_t* __restrict__ qpIndex, int stepIdx, int nSteps, int q)
+                                                        x265hip_me_task* __restrict__ taskA, x265hip_me_task* __restrict__ taskB, const uint8_t* __restrict__ qpIndex, int stepIdx, int nSteps)
 {
     const int ctu = blockIdx.x * 256 + threadIdx.x;
     if (ctu >= nCtu) return;
     TmeState& S = state[ctu];
-    const bool mine = !qpIndex || qpIndex[(int64_t)ctu * nSteps + stepIdx] == q;          // this launch round searches with the cost row of qp index q
+    const int q = qpIndex ? qpIndex[(int64_t)ctu * nSteps + stepIdx] : 0;                  // the CU's qp: the row of the cost table this PU's searches price MVDs with
     const int ctuX = (ctu % s.numCtuX) * s.ctuSize, ctuY = (ctu / s.numCtuX) * s.ctuSize;
     int mvp[2] = { S.mvpBase[0], S.mvpBase[1] };
     S.mvpIdx = 0;
@@ -145,11 +147,10 @@ __global__ __launch_bounds__(256) void tme_build_kernel(Slice s, x265hip_tme_ste
     a.qmvp[0] = (int16_t)mvp[0]; a.qmvp[1] = (int16_t)mvp[1];
 #pragma unroll
     for (int k = 0; k < 12; k++) { a.mvc[2 * k] = S.mvc[k][0]; a.mvc[2 * k + 1] = S.mvc[k][1]; }
-    a.numCand = (int16_t)numCand; a.flags = X265HIP_ME_WINDOW; a.mvpFrom = -1;
+    a.numCand = (int16_t)numCand; a.flags = (int16_t)(X265HIP_ME_WINDOW | X265HIP_ME_ROWS | (q << 8)); a.mvpFrom = -1;
     x265hip_me_task b = a;
-    if (!mine) { a.mvmin[0] = a.mvmin[1] = a.mvmax[0] = a.mvmax[1] = 0; a.qmvp[0] = a.qmvp[1] = 0; a.numCand = 0; }    // searched in another round: next to nothing here
     taskA[ctu] = a;
-    if (S.ranB && mine) { b.qmvp[0] = (int16_t)S.lowres[0]; b.qmvp[1] = (int16_t)S.lowres[1]; }
+    if (S.ranB) { b.qmvp[0] = (int16_t)S.lowres[0]; b.qmvp[1] = (int16_t)S.lowres[1]; }
     else
     {   // no second search for this PU: a search that costs next to nothing (window of one position, no candidates); its result is not read
         b.mvmin[0] = b.mvmin[1] = b.mvmax[0] = b.mvmax[1] = 0; b.qmvp[0] = b.qmvp[1] = 0; b.numCand = 0;
@@ -159,13 +160,15 @@ __global__ __launch_bounds__(256) void tme_build_kernel(Slice s, x265hip_tme_ste
 
 // ---- cost: search.cpp:392-416 ----
 __global__ __launch_bounds__(256) void tme_cost_kernel(Slice s, x265hip_tme_step st, int pi, int l, int r, int nCtu, const x265hip_me_result* __restrict__ resA,
-                                                       const x265hip_me_result* __restrict__ resB, const uint16_t* __restrict__ costCentre, int costHalf,
+                                                       const x265hip_me_result* __restrict__ resB, const uint16_t* __restrict__ costTable, int costHalf,
                                                        const float* __restrict__ bitsCentre, int bitsHalf, TmeState* __restrict__ state, const uint8_t* __restrict__ qpIndex, int stepIdx, int nSteps,
-                                                       int q, unsigned long long lambda)
+                                                       Lambdas lambdas)
 {
     const int ctu = blockIdx.x * 256 + threadIdx.x;
     if (ctu >= nCtu) return;
-    if (qpIndex && qpIndex[(int64_t)ctu * nSteps + stepIdx] != q) return;
+    const int q = qpIndex ? qpIndex[(int64_t)ctu * nSteps + stepIdx] : 0;
+    const uint16_t* costCentre = costTable + (size_t)q * (size_t)(2 * costHalf + 1) + costHalf;
+    const unsigned long long lambda = lambdas.v[q];
     TmeState& S = state[ctu];
     S.lambda = lambda;
     blk_bits(st.part, s.isP != 0, pi, S.lastMode, S.selBits);
@@ -288,19 +291,23 @@ __global__ __launch_bounds__(256) void tme_finish_kernel(Slice s, x265hip_tme_st
     }
 }
 
+// Entries of different PU shapes never read each other's slots (a PU's neighbours are PUs of its own shape, search.cpp:283-305), so every shape is its own chain of
+// dependent launches: the chains run side by side on their own streams, each with its own slice of the workspace.
+constexpr int XH_TME_CHAINS = 24;
+
 } // namespace
 
 extern "C" size_t x265hip_tme_workspace(int nCtu)
 {
     const size_t per = sizeof(TmeState) + sizeof(x265hip_select_task) + sizeof(x265hip_select_result) + 2 * sizeof(x265hip_me_task) + 2 * sizeof(x265hip_me_result) +
                        2 * sizeof(x265hip_bidir_task) + 2 * sizeof(int32_t) + 2;
-    return (size_t)nCtu * per + 16 * 256;
+    return ((size_t)nCtu * per + 16 * 256) * XH_TME_CHAINS;
 }
 
 extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
 {
     if (!a || !a->steps || a->nSteps < 1 || !a->curPlane || !a->table || !a->areaBest || !a->temporal || !a->bitsRow || !a->workspace || a->nQp < 1 || a->nQp > 64 || (a->nQp > 1 && !a->qpIndex)) { set_error("tme_frame: missing arguments"); return X265HIP_EARG; }
-    for (int q = 0; q < a->nQp; q++) if (!a->costRows[q]) { set_error("tme_frame: cost row %d missing", q); return X265HIP_EARG; }
+    if (!a->costRows) { set_error("tme_frame: cost table missing"); return X265HIP_EARG; }
     if (a->ctuSize < 16 || a->picWidth % a->ctuSize || a->picHeight % a->ctuSize) { set_error("tme_frame: pictures of whole CTUs only"); return X265HIP_EARG; }       // whole CTUs only (CUs outside the picture are not handled yet)
     const int nCtuX = a->picWidth / a->ctuSize, nCtuY = a->picHeight / a->ctuSize, nCtu = nCtuX * nCtuY;
     if (a->workspaceBytes < x265hip_tme_workspace(nCtu)) { set_error("tme_frame: workspace too small"); return X265HIP_EARG; }
@@ -310,8 +317,28 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
         if (a->numRef[l] < 1 || a->numRef[l] > 4) { set_error("tme_frame: %d references in list %d", a->numRef[l], l); return X265HIP_EARG; }
         for (int r = 0; r < a->numRef[l]; r++) if (!a->refs[l][r].mePlane || !a->refs[l][r].mePhase || !a->refs[l][r].reconPhase) { set_error("tme_frame: planes of list %d reference %d missing", l, r); return X265HIP_EARG; }
     }
-    hipStream_t st = (hipStream_t)stream;
-    char* w = (char*)a->workspace;
+    hipStream_t mainStream = (hipStream_t)stream;
+    // the chains: entries grouped by shape (CU size, partition type), order kept
+    int chainOf[24 * 4]; int nChains = 0; int key[XH_TME_CHAINS];
+    (void)chainOf;
+    static thread_local hipStream_t side[XH_TME_CHAINS] = {};
+    static thread_local hipEvent_t evFork = nullptr, evJoin[XH_TME_CHAINS] = {};
+    if (!evFork) XH_HIP(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
+    for (int k = 0; k < a->nSteps; k++)
+    {
+        const int kk = a->steps[k].cuSize * 8 + a->steps[k].part;
+        int c = 0; while (c < nChains && key[c] != kk) c++;
+        if (c == nChains) { if (nChains == XH_TME_CHAINS) { set_error("tme_frame: more than %d PU shapes", XH_TME_CHAINS); return X265HIP_EARG; } key[nChains++] = kk; }
+    }
+    XH_HIP(hipEventRecord(evFork, mainStream));
+    const size_t chainBytes = x265hip_tme_workspace(nCtu) / XH_TME_CHAINS;
+    for (int chain = 0; chain < nChains; chain++)
+    {
+    if (!side[chain]) { XH_HIP(hipStreamCreateWithFlags(&side[chain], hipStreamNonBlocking)); XH_HIP(hipEventCreateWithFlags(&evJoin[chain], hipEventDisableTiming)); }
+    hipStream_t st = side[chain];
+    void* stream = (void*)st;                                                         // the batch entry points of this chain launch on its stream
+    XH_HIP(hipStreamWaitEvent(st, evFork, 0));
+    char* w = (char*)a->workspace + (size_t)chain * chainBytes;
     auto take = [&](size_t bytes) { char* p = w; w += (bytes + 255) & ~(size_t)255; return p; };
     TmeState* state = (TmeState*)take(sizeof(TmeState) * nCtu);
     x265hip_select_task* sel = (x265hip_select_task*)take(sizeof(x265hip_select_task) * nCtu);
@@ -329,9 +356,12 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
     for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) s.amvp.refPOC[l][r] = a->refPOC[l][r];
     const dim3 grid((nCtu + 255) / 256), block(256);
     const float* bitsCentre = a->bitsRow + a->bitsHalfRange;
+    Lambdas lambdas{};
+    for (int q = 0; q < a->nQp; q++) lambdas.v[q] = a->lambdas[q];
     for (int k = 0; k < a->nSteps; k++)
     {
         const x265hip_tme_step& e = a->steps[k];
+        if (e.cuSize * 8 + e.part != key[chain]) continue;
         for (int pi = 0; pi < e.numPart; pi++)
         {
             const int pw = e.pu[pi][2], ph = e.pu[pi][3];
@@ -342,18 +372,15 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
                     hipLaunchKernelGGL(tme_gather_kernel, grid, block, 0, st, s, e, k, a->nSteps, pi, l, r, nCtu, a->table, a->areaBest, a->temporal, R.refTable, R.lowresMv, state, sel);
                     int rc = x265hip_select_mvp_batch(stream, pw, ph, a->curPlane, a->stride, R.reconPhase, a->planeElems, a->stride, sel, nCtu, selRes);
                     if (rc) { set_error("tme_frame: select_mvp_batch %dx%d failed", pw, ph); return rc; }
-                    for (int q = 0; q < a->nQp; q++)
-                    {   // one round per qp of the picture: the searches take ONE cost row per launch; the CUs of another qp get a degenerate task in this round
-                        hipLaunchKernelGGL(tme_build_kernel, grid, block, 0, st, s, e, pi, nCtu, selRes, state, tA, tB, a->qpIndex, k, a->nSteps, q);
-                        rc = x265hip_me_batch(stream, pw, ph, a->curPlane, a->stride, R.mePlane, a->stride, tA, nCtu, a->costRows[q], a->costHalfRange, a->searchRange, a->searchMethod,
-                                              a->subpelRefine, rA, nullptr, R.mePhase, a->planeElems);
-                        if (rc) return rc;
-                        rc = x265hip_me_batch(stream, pw, ph, a->curPlane, a->stride, R.mePlane, a->stride, tB, nCtu, a->costRows[q], a->costHalfRange, a->searchRange, a->searchMethod,
-                                              a->subpelRefine, rB, nullptr, R.mePhase, a->planeElems);
-                        if (rc) return rc;
-                        hipLaunchKernelGGL(tme_cost_kernel, grid, block, 0, st, s, e, pi, l, r, nCtu, rA, rB, a->costRows[q] + a->costHalfRange, a->costHalfRange, bitsCentre, a->bitsHalfRange, state,
-                                           a->qpIndex, k, a->nSteps, q, (unsigned long long)a->lambdas[q]);
-                    }
+                    hipLaunchKernelGGL(tme_build_kernel, grid, block, 0, st, s, e, pi, nCtu, selRes, state, tA, tB, a->qpIndex, k, a->nSteps);
+                    rc = x265hip_me_batch(stream, pw, ph, a->curPlane, a->stride, R.mePlane, a->stride, tA, nCtu, a->costRows, a->costHalfRange, a->searchRange, a->searchMethod,
+                                          a->subpelRefine, rA, nullptr, R.mePhase, a->planeElems);
+                    if (rc) return rc;
+                    rc = x265hip_me_batch(stream, pw, ph, a->curPlane, a->stride, R.mePlane, a->stride, tB, nCtu, a->costRows, a->costHalfRange, a->searchRange, a->searchMethod,
+                                          a->subpelRefine, rB, nullptr, R.mePhase, a->planeElems);
+                    if (rc) return rc;
+                    hipLaunchKernelGGL(tme_cost_kernel, grid, block, 0, st, s, e, pi, l, r, nCtu, rA, rB, a->costRows, a->costHalfRange, bitsCentre, a->bitsHalfRange, state,
+                                       a->qpIndex, k, a->nSteps, lambdas);
                 }
             hipLaunchKernelGGL(tme_bidir_kernel, grid, block, 0, st, s, e, pi, nCtu, state, b0, b1, br0, br1);
             if (!a->isP && e.part != 0 && e.cuSize != 8)
@@ -365,6 +392,9 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
             }
             hipLaunchKernelGGL(tme_finish_kernel, grid, block, 0, st, s, e, pi, nCtu, s0, s1, bitsCentre, a->bitsHalfRange, state, a->table);
         }
+    }
+    XH_HIP(hipEventRecord(evJoin[chain], st));
+    XH_HIP(hipStreamWaitEvent(mainStream, evJoin[chain], 0));
     }
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

@@ -106,7 +106,9 @@ struct x265hip_tme
     int width = 0, height = 0, ctu = 64, nCtu = 0, nCtuX = 0, depthBytes = (int)sizeof(pixel);
     std::vector<x265hip_tme_step> steps;
     std::vector<void*> owned;
-    std::map<int, uint16_t*> costRows;         // per qp, device
+    std::map<int, uint16_t*> costRows;         // per qp, device (the diamond stage)
+    std::map<int, std::vector<uint16_t>> hostRows;
+    uint16_t* costTable = nullptr;             // [64][2 * kHalf + 1]: the rows of the picture's qps, in the order of desc->qps
     float* bitsRow = nullptr;
     pixel* cur = nullptr; pixel* plane[2][4][2] = {}; pixel* phase[2][4][2] = {};       // [list][ref][0 = searched plane, 1 = reconstructed picture]
     int64_t planeElems = 0;
@@ -145,7 +147,7 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
     char* ws = nullptr;
     if ((rc = t->alloc(ws, t->workspaceBytes)) || (rc = t->alloc(t->table, (size_t)t->nCtu * 593)) || (rc = t->alloc(t->areaBest, (size_t)t->nCtu * 5 * 2 * 4 * 2)) ||
         (rc = t->alloc(t->temporal, (size_t)t->nCtu * n * 2)) || (rc = t->alloc(t->qpIndex, (size_t)t->nCtu * n)) || (rc = t->alloc(t->dTasks, (size_t)t->nCtu * 5)) ||
-        (rc = t->alloc(t->dResults, (size_t)t->nCtu * 5)))
+        (rc = t->alloc(t->dResults, (size_t)t->nCtu * 5)) || (rc = t->alloc(t->costTable, (size_t)64 * (2 * kHalf + 1))))
     { x265hip_tme_destroy(t); return rc; }
     t->workspace = ws;
     *out = t;
@@ -209,7 +211,10 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
             XH_HIP(hipMalloc(&v, row.size() * sizeof(uint16_t)));
             XH_HIP(hipMemcpy(v, row.data(), row.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             t->costRows[d->qps[q]] = (uint16_t*)v;
+            t->hostRows[d->qps[q]] = row;
         }
+    for (int q = 0; q < d->nQp; q++)
+        XH_HIP(hipMemcpyAsync(t->costTable + (size_t)q * (2 * kHalf + 1), t->hostRows[d->qps[q]].data(), (size_t)(2 * kHalf + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, st));
     // ---- deriveMVsForCTU's first stage (analysis.cpp:262-299): diamondSearch at range 32 around (0,0) for the CTU (area 0) and its four sub-CUs (areas 1..4), per reference;
     //      m_areaBestMV starts as zero for every area a search does not write; the collocated median, where there is one, replaces all five ----
     std::vector<int16_t> area((size_t)nCtu * 5 * 2 * 4 * 2, 0);
@@ -275,7 +280,8 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
         }
     a.table = t->table; a.areaBest = t->areaBest; a.temporal = t->temporal;
     a.nQp = d->nQp; a.qpIndex = t->qpIndex; a.costHalfRange = kHalf;
-    for (int q = 0; q < d->nQp; q++) { a.costRows[q] = t->costRows[d->qps[q]]; a.lambdas[q] = x265hip_rd_lambda(d->qps[q]); }
+    a.costRows = t->costTable;
+    for (int q = 0; q < d->nQp; q++) a.lambdas[q] = x265hip_rd_lambda(d->qps[q]);
     a.bitsRow = t->bitsRow; a.bitsHalfRange = kBitsHalf; a.steps = t->steps.data(); a.nSteps = nS; a.workspace = t->workspace; a.workspaceBytes = t->workspaceBytes;
     if ((rc = x265hip_tme_frame(st, &a))) return rc;
     XH_HIP(hipMemcpyAsync(d->table, t->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));

@@ -172,7 +172,7 @@ class FrameApi:
                         ("picWidth", C.c_int), ("picHeight", C.c_int), ("ctuSize", C.c_int), ("lowresBlocksX", C.c_int),
                         ("curPlane", C.c_void_p), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("planeElems", C.c_int64),
                         ("refs", (Ref * 4) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
-                        ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p * 64), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 64), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
+                        ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 64), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
                         ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t)]
         a = Args()
         a.isP = int(is_p); a.numRef[0], a.numRef[1] = int(num_ref[0]), int(num_ref[1]); a.curPOC = int(cur_poc); a.temporalMvp = int(temporal_mvp)
@@ -181,7 +181,8 @@ class FrameApi:
         a.searchRange, a.searchMethod, a.subpelRefine = int(merange), int(method), int(subme)
         a.nQp = len(lams); a.qpIndex = _dp(qp_index)
         for q in range(len(lams)):
-            a.costRows[q] = cost_rows[q].data_ptr(); a.lambdas[q] = int(lams[q])
+            a.lambdas[q] = int(lams[q])
+        a.costRows = _dp(cost_rows)
         a.picWidth, a.picHeight, a.ctuSize, a.lowresBlocksX = int(width), int(height), int(ctu), int(lowres_blocks_x)
         a.curPlane = _dp(cur); a.stride = int(stride); a.origin = int(origin); a.planeElems = int(plane_elems)
         for l in range(2):
