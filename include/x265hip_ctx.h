@@ -70,7 +70,7 @@ void* x265hip_batch_device_ptr(x265hip_batch* batch, int what);
  * host pointers -- the padded planes as PicYuv holds them (first element of the allocation; all planes of one geometry), the picture's MEData table
  * (slice->m_ctuMV, as x265hip_inter_choice records) as it is before the picture, per reference that reference picture's table and the lookahead's MVs -- and what only
  * the encoder's own state yields: per CTU and reference the median of the collocated MVs (CUData::getMedianColMV, cudata.cpp:1744-1790), per (CTU, entry, partition)
- * the temporal neighbour (CUData::getNeighbourMV's collocated part), and the qp of every CU (Analysis::calculateQpforCuSize).  Pictures of whole CTUs. */
+ * the temporal neighbour (CUData::getNeighbourMV's collocated part), and the qp of every CU (Analysis::calculateQpforCuSize). */
 typedef struct x265hip_tme x265hip_tme;
 typedef struct x265hip_tme_host_ref {
     const void* mePlane;                       /* slice->m_mref[l][r].fpelPlane[0] allocation (weighted or not)                                  */

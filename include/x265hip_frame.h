@@ -151,7 +151,8 @@ int x265hip_mvp_bits_batch(void* stream, x265hip_mvp_bits* records, int n, const
  * bidirectional candidate, the MEData record written back into the table (kern_tme.hip).  The table is read and written in the reference's order, so entries that a
  * PU reads before this picture wrote them (the reference reads whatever the FrameData held) are the caller's: pass the table as it was.
  * Host-supplied per PU: the temporal (collocated) neighbour CUData::getNeighbourMV finds in the collocated picture's motion (cudata.cpp:1992-2075) with the two POCs
- * getPMV scales it by.  Pictures of whole CTUs.  All planes share stride, origin and planeElems. */
+ * getPMV scales it by.  All planes share stride, origin and planeElems; CTUs cut by the picture edge run the
+ * whole schedule (as in the reference), their PUs beyond the edge read the planes' padding. */
 typedef struct x265hip_tme_temporal { x265hip_amvp_neighbour nb; int32_t colPOC[2], colRefPOC[2]; } x265hip_tme_temporal;      /* 28 bytes; per (ctu, entry, partition) */
 typedef struct x265hip_tme_ref {
     const void* mePlane;                       /* the plane motionEstimate searches (slice->m_mref[l][r].fpelPlane[0]: weighted or not), first element of the padded allocation */

@@ -14,7 +14,7 @@
  * objects, in computeMVForPUs' order -- the qp of every CU (Analysis::calculateQpforCuSize), the collocated neighbour of every PU (CUData::getNeighbourMV), the
  * collocated median of every CTU (CUData::getMedianColMV).
  *
- * usage: x265tmegpu_<depth> <libx265hip.so> <width> <height> <frames> <preset> <out.hevc> [option=value ...]     (width, height: multiples of 64)
+ * usage: x265tmegpu_<depth> <libx265hip.so> <width> <height> <frames> <preset> <out.hevc> [option=value ...]
  */
 #include <chrono>
 #include <cstdio>
@@ -147,7 +147,6 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
     const int nCtuX = slice->m_sps->numCuInWidth, nCtuY = slice->m_sps->numCuInHeight, nCtu = nCtuX * nCtuY;
     if (!g_tme)
     {
-        if (W % ctuSize || H % ctuSize) { fprintf(stderr, "picture not a multiple of the CTU size\n"); return -1; }
         if (g_api.ctx_create(0, &g_ctx) || g_api.tme_create(g_ctx, W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme))
         { fprintf(stderr, "x265hip_tme_create: %s\n", g_api.last_error()); return -1; }
     }

@@ -28,7 +28,9 @@ def encode(depth, producer, args, out):
 @pytest.mark.parametrize("depth,args", [(8, ["128", "128", "6", "medium", "ref=1", "weightp=0", "weightb=0"]),
                                         (8, ["192", "128", "6", "slow", "ref=1", "weightp=0", "weightb=0", "bframes=2"]),
                                         (10, ["128", "128", "5", "slow", "ref=1", "weightp=0", "weightb=0"]),
-                                        (8, ["256", "192", "5", "medium", "ref=2", "bframes=0", "weightp=0"])])
+                                        (8, ["256", "192", "5", "medium", "ref=2", "bframes=0", "weightp=0"]),
+                                        (8, ["200", "120", "5", "medium", "ref=1", "weightp=0", "weightb=0"]),          # CTUs cut by the picture edge
+                                        (10, ["176", "144", "4", "slow", "ref=1", "weightp=0", "weightb=0"])])
 def test_bitstream_identical_with_gpu_producer(depth, args, tmp_path):
     cpu, h_cpu = encode(depth, "cpu", args, str(tmp_path / "cpu.hevc"))
     gpu, h_gpu = encode(depth, "gpu", args, str(tmp_path / "gpu.hevc"))

@@ -308,8 +308,9 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
 {
     if (!a || !a->steps || a->nSteps < 1 || !a->curPlane || !a->table || !a->areaBest || !a->temporal || !a->bitsRow || !a->workspace || a->nQp < 1 || a->nQp > 64 || (a->nQp > 1 && !a->qpIndex)) { set_error("tme_frame: missing arguments"); return X265HIP_EARG; }
     if (!a->costRows) { set_error("tme_frame: cost table missing"); return X265HIP_EARG; }
-    if (a->ctuSize < 16 || a->picWidth % a->ctuSize || a->picHeight % a->ctuSize) { set_error("tme_frame: pictures of whole CTUs only"); return X265HIP_EARG; }       // whole CTUs only (CUs outside the picture are not handled yet)
-    const int nCtuX = a->picWidth / a->ctuSize, nCtuY = a->picHeight / a->ctuSize, nCtu = nCtuX * nCtuY;
+    if (a->ctuSize < 16 || a->picWidth < 8 || a->picHeight < 8) { set_error("tme_frame: bad picture / CTU size"); return X265HIP_EARG; }
+    // CTUs cut by the picture edge run the whole schedule like the others -- computeMVForPUs does not look at the picture size; PUs beyond the edge read the planes' padding
+    const int nCtuX = (a->picWidth + a->ctuSize - 1) / a->ctuSize, nCtuY = (a->picHeight + a->ctuSize - 1) / a->ctuSize, nCtu = nCtuX * nCtuY;
     if (a->workspaceBytes < x265hip_tme_workspace(nCtu)) { set_error("tme_frame: workspace too small"); return X265HIP_EARG; }
     const int nl = a->isP ? 1 : 2;
     for (int l = 0; l < nl; l++)

@@ -130,12 +130,12 @@ constexpr int kHalf = 1 << 15, kBitsHalf = 1 << 15;
 
 extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** out)
 {
-    if (!ctx || !out || width < ctuSize || height < ctuSize || width % ctuSize || height % ctuSize) { set_error("tme_create: pictures of whole CTUs"); return X265HIP_EARG; }
+    if (!ctx || !out || width < 8 || height < 8) { set_error("tme_create: bad picture size"); return X265HIP_EARG; }
     const int n = x265hip_tme_schedule(ctuSize, minCuSize, rect, amp, nullptr, 0);
     if (n <= 0) { set_error("tme_create: bad CTU / CU sizes"); return X265HIP_EARG; }
     x265hip_tme* t = new (std::nothrow) x265hip_tme();
     if (!t) return X265HIP_EARG;
-    t->ctx = ctx; t->width = width; t->height = height; t->ctu = ctuSize; t->nCtuX = width / ctuSize; t->nCtu = t->nCtuX * (height / ctuSize);
+    t->ctx = ctx; t->width = width; t->height = height; t->ctu = ctuSize; t->nCtuX = (width + ctuSize - 1) / ctuSize; t->nCtu = t->nCtuX * ((height + ctuSize - 1) / ctuSize);
     t->steps.resize(n);
     x265hip_tme_schedule(ctuSize, minCuSize, rect, amp, t->steps.data(), n);
     int rc;
