@@ -54,7 +54,7 @@ static struct Api
 } g_api;
 static x265hip_ctx* g_ctx;
 static x265hip_tme* g_tme;
-static int g_useGpu = 1, g_pictures;
+static int g_useGpu = 1, g_pictures, g_weighted;
 static double g_gpuSeconds;
 static std::mutex g_lock;
 static std::map<const Frame*, int> g_done;          /* picture -> POC + 1 whose table is complete */
@@ -210,6 +210,12 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
         {
             x265hip_tme_host_ref& R = d.refs[l][r];
             const MotionReference& mr = slice->m_mref[l][r];
+            if (mr.isWeighted)
+            {   /* the frame encoder weights the reference's rows as it releases them to the row encoders (frameencoder.cpp:1029-1036); the producer takes the whole
+                   picture at once: finish the plane now (same values, the later calls find nothing left to do) */
+                const_cast<MotionReference&>(mr).applyWeight(nCtuY - 1, nCtuY, nCtuY, 0);
+                g_weighted++;
+            }
             const PicYuv* rec = slice->m_refReconPicList[l][r];
             R.mePlane = mr.fpelPlane[0] - d.origin;
             R.reconPlane = rec->m_picBuf[0];
@@ -272,7 +278,8 @@ static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixe
             const int x = i + 5 * f + ((j >> 5) & 1) * f, yy = j + 3 * f;
             const int t = (((x * x) / 9 + yy * 7 + (x * yy) / 13 + ((x >> 3) ^ (yy >> 3)) * 11) & 255) * (pm + 1) / 256;
             s = s * 1664525u + 1013904223u;
-            const int val = t + (int)((s >> 24) & 7) - 3;
+            int val = t + (int)((s >> 24) & 7) - 3;
+            if (getenv("X265TME_FADE")) val = val * (16 - 2 * (f < 6 ? f : 6)) / 16 + 4 * f * (pm + 1) / 256;      /* a fade: weighted prediction gets something to do */
             y[(size_t)j * w + i] = (pixel)(val < 0 ? 0 : val > pm ? pm : val);
         }
     for (int j = 0; j < h / 2; j++)
@@ -342,7 +349,7 @@ int main(int argc, char** argv)
     x265_param_free(live);
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(out);
-    printf("{\"producer\": \"%s\", \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f}\n",
-           g_useGpu ? "gpu" : "cpu", frames, secs, frames / secs, bytes, tme, g_pictures, g_gpuSeconds);
+    printf("{\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f}\n",
+           g_useGpu ? "gpu" : "cpu", g_weighted, frames, secs, frames / secs, bytes, tme, g_pictures, g_gpuSeconds);
     return 0;
 }

@@ -18,7 +18,10 @@ def encode(depth, producer, args, out):
     if not os.path.exists(exe):
         pytest.skip("no oracle/_ref/x265tmegpu_%d (built where the reference is present)" % depth)
     env = dict(os.environ, X265TMEGPU="1" if producer == "gpu" else "0")
-    r = subprocess.run([exe, x265hip.lib_path(depth)] + args[:4] + [out] + args[4:], capture_output=True, text=True, env=env, timeout=900)
+    extra = [a for a in args[4:] if a != "fades=1"]
+    if "fades=1" in args:
+        env["X265TME_FADE"] = "1"
+    r = subprocess.run([exe, x265hip.lib_path(depth)] + args[:4] + [out] + extra, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["threaded_me"] == 1
@@ -30,10 +33,14 @@ def encode(depth, producer, args, out):
                                         (10, ["128", "128", "5", "slow", "ref=1", "weightp=0", "weightb=0"]),
                                         (8, ["256", "192", "5", "medium", "ref=2", "bframes=0", "weightp=0"]),
                                         (8, ["200", "120", "5", "medium", "ref=1", "weightp=0", "weightb=0"]),          # CTUs cut by the picture edge
-                                        (10, ["176", "144", "4", "slow", "ref=1", "weightp=0", "weightb=0"])])
+                                        (10, ["176", "144", "4", "slow", "ref=1", "weightp=0", "weightb=0"]),
+                                        (8, ["256", "128", "8", "medium", "ref=2", "weightp=1", "bframes=0", "fades=1"]),      # weighted reference planes (the clip fades)
+                                        (8, ["192", "128", "6", "slow"])])                                                      # the preset as it is
 def test_bitstream_identical_with_gpu_producer(depth, args, tmp_path):
     cpu, h_cpu = encode(depth, "cpu", args, str(tmp_path / "cpu.hevc"))
     gpu, h_gpu = encode(depth, "gpu", args, str(tmp_path / "gpu.hevc"))
     assert gpu["gpu_pictures"] >= 3, "the GPU producer did not run: %s" % gpu
     assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
-    print("e2e", depth, args, "cpu fps %.2f gpu fps %.2f (gpu producer %.3f s for %d pictures)" % (cpu["fps"], gpu["fps"], gpu["gpu_seconds"], gpu["gpu_pictures"]))
+    if "fades=1" in args:
+        assert gpu["weighted_refs"] > 0, "the clip did not make the encoder weight a reference: %s" % gpu
+    print("e2e", depth, args, "weighted refs %d" % gpu["weighted_refs"], "cpu fps %.2f gpu fps %.2f (gpu producer %.3f s for %d pictures)" % (cpu["fps"], gpu["fps"], gpu["gpu_seconds"], gpu["gpu_pictures"]))
