@@ -42,9 +42,8 @@ typedef struct x265hip_me_task {
 /* flags: derive the search window on the device the way Search::setSearchRange does (search.cpp:4969-5021):
  * [mvp - 4*merange, mvp + 4*merange] clipped to the task's quarter-pel limits, >> 2, mvmax.y >= mvmin.y */
 #define X265HIP_ME_WINDOW 1
-/* flags: the task has its own MVD cost row (CUs of different qp in one launch: Analysis::setLambdaFromQP runs per CU).  costRow of the call is then a TABLE of
- * rows, 2 * costHalfRange + 1 entries each, and bits 8..15 of flags are the task's row index.  (The searches then read the row from memory, not from the
- * workgroup's LDS slice.) */
+/* flags, honoured by x265hip_me_batch_rows only: the task has its own MVD cost row (CUs of different qp in one launch: Analysis::setLambdaFromQP runs per CU).
+ * costRows of that call is a TABLE of rows, 2 * costHalfRange + 1 entries each, and bits 8..15 of flags are the task's row index. */
 #define X265HIP_ME_ROWS 2
 
 typedef struct x265hip_me_result {
@@ -71,6 +70,14 @@ int x265hip_me_batch(void* stream, int w, int h,
                      int merange, int method, int subpelRefine, x265hip_me_result* results,
                      const x265hip_me_result* mvpSource /* may be NULL */,
                      const void* subpelPlanes /* may be NULL: interpolate inside the kernel */, int64_t planeElems);
+/* The same search with a cost row per task (X265HIP_ME_ROWS above; DIA / HEX / UMH / STAR / FULL).  Its own kernels: such tasks read their row from memory instead of the
+ * workgroup's LDS slice, and the plain entry point does not carry that test (it costs its small-PU kernels a third of their speed). */
+int x265hip_me_batch_rows(void* stream, int w, int h,
+                          const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                          const x265hip_me_task* tasks, int n,
+                          const uint16_t* costRows, int costHalfRange,
+                          int merange, int method, int subpelRefine, x265hip_me_result* results,
+                          const x265hip_me_result* mvpSource, const void* subpelPlanes, int64_t planeElems);
 /* subpelPlanes, when given, must be the 16-slot buffer x265hip_subpel_planes produced from refPlane (slot 0 == refPlane,
  * same stride / offsets).  method: DIA, HEX, UMH, STAR or FULL (SEA needs integral planes: x265hip_me_batch_sea). */
 

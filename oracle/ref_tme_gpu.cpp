@@ -48,6 +48,7 @@ static struct Api
 {
     int (*ctx_create)(int, x265hip_ctx**);
     int (*tme_create)(x265hip_ctx*, int, int, int, int, int, int, x265hip_tme**);
+    void (*tme_destroy)(x265hip_tme*);
     int (*tme_entries)(const x265hip_tme*, const x265hip_tme_step**);
     int (*tme_picture)(x265hip_tme*, const x265hip_tme_picture_desc*);
     const char* (*last_error)();
@@ -300,6 +301,7 @@ int main(int argc, char** argv)
         if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
         g_api.ctx_create = (int (*)(int, x265hip_ctx**))dlsym(lib, "x265hip_ctx_create");
         g_api.tme_create = (int (*)(x265hip_ctx*, int, int, int, int, int, int, x265hip_tme**))dlsym(lib, "x265hip_tme_create");
+        g_api.tme_destroy = (void (*)(x265hip_tme*))dlsym(lib, "x265hip_tme_destroy");
         g_api.tme_entries = (int (*)(const x265hip_tme*, const x265hip_tme_step**))dlsym(lib, "x265hip_tme_entries");
         g_api.tme_picture = (int (*)(x265hip_tme*, const x265hip_tme_picture_desc*))dlsym(lib, "x265hip_tme_picture");
         g_api.last_error = (const char* (*)())dlsym(lib, "x265hip_last_error");
@@ -349,6 +351,7 @@ int main(int argc, char** argv)
     x265_param_free(live);
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(out);
+    if (g_tme && g_api.tme_destroy) { g_api.tme_destroy(g_tme); g_tme = nullptr; }
     printf("{\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f}\n",
            g_useGpu ? "gpu" : "cpu", g_weighted, frames, secs, frames / secs, bytes, tme, g_pictures, g_gpuSeconds);
     return 0;

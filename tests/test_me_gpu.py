@@ -301,7 +301,7 @@ def test_me_batch_cost_row_per_task(depth, method):
         tasks["flags"] = 2 | (which.astype(np.int16) << 8)                  # X265HIP_ME_ROWS | row << 8
         d_tasks = api.to_device(tasks)
         d_res = T.zeros(n * ME_RESULT.itemsize, dtype=T.uint8, device="cuda")
-        api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_table, half, 24, method, 3, d_res, planes=d_pl, plane_elems=pe)
+        api.me_batch_rows(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_table, half, 24, method, 3, d_res, planes=d_pl, plane_elems=pe)
         T.cuda.synchronize()
         res = d_res.cpu().numpy().view(ME_RESULT)
         for i in range(n):

@@ -84,3 +84,31 @@ extern "C" int x265hip_me_batch(void* stream, int w, int h, const void* curPlane
         return xh_me_umh(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
     return dispatch_me<0>(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRow, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
 }
+
+// ... the same search for tasks of different qp in one launch (Analysis::setLambdaFromQP runs per CU): costRows is a TABLE of rows, 2 * costHalfRange + 1 entries each, and
+// a task with X265HIP_ME_ROWS in its flags prices its MVDs with row (flags >> 8) & 0xFF.  Kernels built for it (kern_me*_rows.hip): the cost lookups of such tasks go to
+// memory, which the plain kernels do not pay for.
+int xh_me_rows(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride, const x265hip_me_task* tasks, int n, const uint16_t* costRow,
+               int costHalfRange, int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource, const void* subpelPlanes, int64_t planeElems);
+int xh_me_star_rows(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride, const x265hip_me_task* tasks, int n, const uint16_t* costRow,
+                    int costHalfRange, int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource, const void* subpelPlanes, int64_t planeElems);
+int xh_me_umh_rows(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride, const x265hip_me_task* tasks, int n, const uint16_t* costRow,
+                   int costHalfRange, int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource, const void* subpelPlanes, int64_t planeElems);
+extern "C" int x265hip_me_batch_rows(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                                     const x265hip_me_task* tasks, int n, const uint16_t* costRows, int costHalfRange,
+                                     int merange, int method, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+                                     const void* subpelPlanes, int64_t planeElems)
+{
+    if (n <= 0) return X265HIP_OK;
+    if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !tasks || !results || !costRows || costHalfRange < 1)
+    { set_error("me_batch_rows: bad arguments"); return X265HIP_EARG; }
+    if (method != X265HIP_ME_DIA && method != X265HIP_ME_HEX && method != X265HIP_ME_UMH && method != X265HIP_ME_STAR && method != X265HIP_ME_FULL)
+    { set_error("me_batch_rows: search method %d is not offloaded here (DIA/HEX/UMH/STAR/FULL are)", method); return X265HIP_EARG; }
+    if (subpelRefine < 0 || subpelRefine > 7 || merange < 1) { set_error("me_batch_rows: bad subme/merange"); return X265HIP_EARG; }
+    if (subpelPlanes && (planeElems <= 0 || ((uintptr_t)subpelPlanes & 7))) { set_error("me_batch_rows: bad subpel planes"); return X265HIP_EARG; }
+    if (method == X265HIP_ME_STAR)
+        return xh_me_star_rows(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRows, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
+    if (method == X265HIP_ME_UMH)
+        return xh_me_umh_rows(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRows, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
+    return xh_me_rows(stream, w, h, curPlane, curStride, refPlane, refStride, tasks, n, costRows, costHalfRange, merange, method, subpelRefine, results, mvpSource, subpelPlanes, planeElems);
+}

@@ -6,7 +6,7 @@
 //   (:449-502), final choice (:504-555) -> a record like MEData (encoder/threadedme.h:122-130).
 // One wavefront per PU: the decision arithmetic is uniform (every lane computes it), the two averaged predictions are built from the references'
 // phase planes (a prediction at any quarter-pel MV is a block of plane 4 * yFrac + xFrac) into LDS and compared with the cached source PU at SATD.
-#include "xh_mc.h"
+#include "xh_bidir.h"
 #include "../../include/x265hip_frame.h"
 #include <cmath>
 using namespace xh;
@@ -31,54 +31,9 @@ __device__ __forceinline__ uint32_t bitcost(const MergeArgs& a, int mvx, int mvy
 }
 __device__ __forceinline__ uint32_t getcost(const MergeArgs& a, uint32_t bits) { return (uint32_t)(((unsigned long long)bits * a.lambda + 128) >> 8); }   // rdcost.h:164-169
 
-// SATD of the cached source PU (LDS, stride w) against the average of two predictions (planes of reference a / b at quarter-pel MVs)
 __device__ int bidir_satd(const MergeArgs& a, const lpixel* fenc, lpixel* avg, int refOff, const pixel* pa, int ax, int ay, const pixel* pb, int bx, int by, int lane)
 {
-    const int w = a.w, h = a.h, qpr = w >> 2, nquads = qpr * h;
-    const pixel* s0 = pa + (int64_t)((ay & 3) * 4 + (ax & 3)) * a.planeElems + refOff + (intptr_t)(ay >> 2) * a.rs + (ax >> 2);
-    const pixel* s1 = pb + (int64_t)((by & 3) * 4 + (bx & 3)) * a.planeElems + refOff + (intptr_t)(by >> 2) * a.rs + (bx >> 2);
-    for (int q = lane; q < nquads; q += 64)
-    {
-        const int y = q / qpr, x4 = (q - y * qpr) * 4;
-        int u[4], v[4], o[4];
-        load4u(s0 + (intptr_t)y * a.rs + x4, u); load4u(s1 + (intptr_t)y * a.rs + x4, v);
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = (u[e] + v[e] + 1) >> 1;             // pixelavg_pp (pixel.cpp:375-388)
-        store4(avg + y * w + x4, o);
-    }
-    wave_sync();
-    const bool use4 = w == 4 || w == 12;
-    const int uw = use4 ? 4 : 8, ux = w / uw, nunits = ux * (h >> 2);
-    int s = 0;
-    LView pv; pv.p = avg; pv.s = w;
-    for (int u = lane; u < nunits; u += 64)
-    {
-        const int uy = u / ux, x0 = (u - uy * ux) * uw, y0 = uy * 4;
-        const lpixel* f = fenc + y0 * w + x0;
-        int d[16], t = 0;
-#pragma unroll
-        for (int half = 0; half < 2; half++)
-        {
-            if (half && use4) break;
-#pragma unroll
-            for (int yy = 0; yy < 4; yy++)
-            {
-                int p[4], r[4]; load4(f + half * 4 + yy * w, p); load4u(pv.at(x0 + half * 4, y0 + yy), r);
-                const int a0 = p[0] - r[0], a1 = p[1] - r[1], a2 = p[2] - r[2], a3 = p[3] - r[3];
-                const int t0 = a0 + a1, t1 = a0 - a1, t2 = a2 + a3, t3 = a2 - a3;
-                d[4 * yy] = t0 + t2; d[4 * yy + 2] = t0 - t2; d[4 * yy + 1] = t1 + t3; d[4 * yy + 3] = t1 - t3;
-            }
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-            {
-                const int t0 = d[x] + d[4 + x], t1 = d[x] - d[4 + x], t2 = d[8 + x] + d[12 + x], t3 = d[8 + x] - d[12 + x];
-                t += abs(t0 + t2) + abs(t0 - t2) + abs(t1 + t3) + abs(t1 - t3);
-            }
-        }
-        s += t >> 1;                                                            // satd4: per 4x4; satd8: per 8x4 (pixel.cpp:262-289)
-    }
-    wave_sync();
-    return wsum_u(s);
+    return bidir_satd_core(a.w, a.h, a.rs, a.planeElems, fenc, avg, refOff, pa, ax, ay, pb, bx, by, lane);
 }
 
 // P slices / no bidirectional candidate: the choice is arithmetic on the search results only -- one THREAD per PU

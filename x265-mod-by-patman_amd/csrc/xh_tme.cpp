@@ -98,6 +98,9 @@ extern "C" int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int am
 #include <map>
 #include <new>
 #include <vector>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 using namespace xh;
 
 struct x265hip_tme
@@ -115,6 +118,7 @@ struct x265hip_tme
     x265hip_inter_choice* table = nullptr; x265hip_inter_choice* refTable[2][4] = {}; int16_t* lowres[2][4] = {};
     int16_t* areaBest = nullptr; x265hip_tme_temporal* temporal = nullptr; uint8_t* qpIndex = nullptr; void* workspace = nullptr; size_t workspaceBytes = 0;
     x265hip_me_task* dTasks = nullptr; x265hip_me_result* dResults = nullptr;
+    bool prof = false, first = false; double sec[5] = {}; int pictures = 0;      // X265HIP_TME_PROF: upload, diamond stage, submit, drain, (total)
     template<class T> int alloc(T*& p, size_t n)
     {
         void* v = nullptr;
@@ -135,6 +139,7 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
     if (n <= 0) { set_error("tme_create: bad CTU / CU sizes"); return X265HIP_EARG; }
     x265hip_tme* t = new (std::nothrow) x265hip_tme();
     if (!t) return X265HIP_EARG;
+    t->prof = getenv("X265HIP_TME_PROF") != nullptr;
     t->ctx = ctx; t->width = width; t->height = height; t->ctu = ctuSize; t->nCtuX = (width + ctuSize - 1) / ctuSize; t->nCtu = t->nCtuX * ((height + ctuSize - 1) / ctuSize);
     t->steps.resize(n);
     x265hip_tme_schedule(ctuSize, minCuSize, rect, amp, t->steps.data(), n);
@@ -156,6 +161,9 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
 extern "C" void x265hip_tme_destroy(x265hip_tme* t)
 {
     if (!t) return;
+    if (t->prof && t->pictures)
+        fprintf(stderr, "x265hip_tme: %d pictures, per picture: upload + phase planes %.2f ms, diamond stage %.2f ms, submit %.2f ms, drain + table down %.2f ms\n", t->pictures,
+                1e3 * t->sec[0] / t->pictures, 1e3 * t->sec[1] / t->pictures, 1e3 * t->sec[2] / t->pictures, 1e3 * t->sec[3] / t->pictures);
     for (void* p : t->owned) (void)hipFree(p);
     for (auto& kv : t->costRows) (void)hipFree(kv.second);
     delete t;
@@ -169,6 +177,9 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     const int nl = d->isP ? 1 : 2, nS = (int)t->steps.size(), nCtu = t->nCtu;
     const int64_t elems = d->planeElems;
     int rc;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](int k, bool sync) { if (!t->prof) return; if (sync) (void)hipStreamSynchronize(st); const double t1 = now(); if (t->first) t->sec[k] += t1 - t0; t0 = t1; };      // the first picture (streams, code objects) is not counted
     if (t->planeElems != elems)
     {   // first picture (or another plane geometry): the device planes
         if (t->planeElems) { set_error("tme_picture: the plane geometry changed"); return X265HIP_EARG; }
@@ -215,6 +226,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
         }
     for (int q = 0; q < d->nQp; q++)
         XH_HIP(hipMemcpyAsync(t->costTable + (size_t)q * (2 * kHalf + 1), t->hostRows[d->qps[q]].data(), (size_t)(2 * kHalf + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    lap(0, true);
     // ---- deriveMVsForCTU's first stage (analysis.cpp:262-299): diamondSearch at range 32 around (0,0) for the CTU (area 0) and its four sub-CUs (areas 1..4), per reference;
     //      m_areaBestMV starts as zero for every area a search does not write; the collocated median, where there is one, replaces all five ----
     std::vector<int16_t> area((size_t)nCtu * 5 * 2 * 4 * 2, 0);
@@ -266,6 +278,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     XH_HIP(hipMemcpyAsync(t->table, d->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
     XH_HIP(hipMemcpyAsync(t->temporal, d->temporal, (size_t)nCtu * nS * 2 * sizeof(x265hip_tme_temporal), hipMemcpyHostToDevice, st));
     XH_HIP(hipMemcpyAsync(t->qpIndex, d->qpIndex, (size_t)nCtu * nS, hipMemcpyHostToDevice, st));
+    lap(1, true);
     x265hip_tme_args a{};
     a.isP = d->isP; a.numRef[0] = d->numRef[0]; a.numRef[1] = d->numRef[1]; a.curPOC = d->curPOC; a.temporalMvp = d->temporalMvp;
     std::memcpy(a.refPOC, d->refPOC, sizeof(a.refPOC));
@@ -284,8 +297,10 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     for (int q = 0; q < d->nQp; q++) a.lambdas[q] = x265hip_rd_lambda(d->qps[q]);
     a.bitsRow = t->bitsRow; a.bitsHalfRange = kBitsHalf; a.steps = t->steps.data(); a.nSteps = nS; a.workspace = t->workspace; a.workspaceBytes = t->workspaceBytes;
     if ((rc = x265hip_tme_frame(st, &a))) return rc;
+    lap(2, false);
     XH_HIP(hipMemcpyAsync(d->table, t->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
     if (d->areaBestOut) std::memcpy(d->areaBestOut, area.data(), area.size() * sizeof(int16_t));
     XH_HIP(hipStreamSynchronize(st));
+    lap(3, false); if (t->first) t->pictures++; t->first = true;
     return X265HIP_OK;
 }

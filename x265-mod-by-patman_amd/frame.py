@@ -103,6 +103,13 @@ class FrameApi:
                                                _dp(tasks), n, _dp(cost_row), half, merange, method, subme, _dp(results), _dp(mvp_source),
                                                _dp(planes), C.c_int64(plane_elems)))
 
+    def me_batch_rows(self, w, h, cur, cstride, ref, rstride, tasks, n, cost_rows, half, merange, method, subme, results, mvp_source=None,
+                      planes=None, plane_elems=0):
+        """x265hip_me_batch_rows: cost_rows is a table of rows, tasks with X265HIP_ME_ROWS choose theirs (flags bits 8..15)"""
+        self.h.check(self.lib.x265hip_me_batch_rows(self.stream(), w, h, _dp(cur), C.c_ssize_t(cstride), _dp(ref), C.c_ssize_t(rstride),
+                                                    _dp(tasks), n, _dp(cost_rows), half, merange, method, subme, _dp(results), _dp(mvp_source),
+                                                    _dp(planes), C.c_int64(plane_elems)))
+
     def sea_integral_planes(self, pic_padded, stride, rows):
         """12 SEA integral planes (uint32, laid out like the padded picture) of a picture resident in HBM -> int32 tensor [12 * rows * stride]"""
         t = self.torch
