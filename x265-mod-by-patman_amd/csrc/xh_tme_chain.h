@@ -24,6 +24,7 @@ struct xh_chain_args
     x265hip_inter_choice* table; const int16_t* areaBest; const x265hip_tme_temporal* temporal; const uint8_t* qpIndex;
     const uint16_t* costRows; int costHalf; const float* bitsCentre; int bitsHalf;
     int searchRange, method, subme;
+    int dbg;                                               // me_one's debug exits; 0
 };
 
 constexpr int XH_CHAIN_LEVELS = 64, XH_CHAIN_WIDTH = 4;
