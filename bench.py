@@ -65,8 +65,49 @@ def parse():
     ap.add_argument("--intra", action="store_true", help="also time the intra mode scan (35 sa8d costs per CU, sizes 64..8) over the same frames; reported under \"intra_scan\", not part of value")
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-dry-run", action="store_true", help="launcher / bookkeeping check without a GPU: gloo ranks, a sleep in place of the step (tests/test_sharding.py); prints a line marked data=dry-run")
+    ap.add_argument("--no-tme", action="store_true", help="skip the ThreadedME producer leg (x265hip_tme_picture on synthetic 1080p pictures: medium- and slow-like partition sets); reported under \"tme_producer\", not part of value")
     ap.add_argument("--filters", action="store_true", help="also time the in-loop filter chain after reconstruction (deblock, SAO statistics, SAO apply, SSIM, SSD) on 8 coded 1080p pictures; reported under \"filters\", not part of value")
     return ap.parse_args()
+
+
+def tme_producer_leg(depth):
+    """the MEData tables of whole pictures through x265hip_tme_picture (include/x265hip_ctx.h), the call the reference encoder makes per picture in
+    place of its CPU producer (oracle/ref_tme_gpu.cpp; bitstream-identical there, tests/test_e2e_tme_gpu.py).  Host planes in, host table out -- PCIe inclusive.
+    Synthetic 1920x1080 P pictures (a shifted, noisy copy of the reference; one reference, no temporal neighbours), the partition sets of presets medium and slow."""
+    import ctypes as C
+    import importlib
+    import numpy as np
+    import x265hip
+    TmeProducer = importlib.import_module("x265-mod-by-patman_amd.tme_host").TmeProducer
+    lib = C.CDLL(x265hip.lib_path(depth))
+    W, H, margin = 1920, 1080, 96
+    stride, rows = W + 2 * margin, ((H + 63) // 64) * 64 + 2 * margin
+    rng = np.random.default_rng(7)
+    dt = np.uint8 if depth == 8 else np.uint16
+    base = rng.integers(0, 1 << depth, (rows // 8 + 2, stride // 8 + 2)).astype(np.int32)
+    ref = np.kron(base, np.ones((8, 8), dtype=np.int32))[:rows, :stride]
+    ref = np.clip(ref + rng.integers(-6, 7, ref.shape), 0, (1 << depth) - 1).astype(dt)
+    cur = np.clip(np.roll(ref, (3, -5), axis=(0, 1)).astype(np.int32) + rng.integers(-4, 5, ref.shape), 0, (1 << depth) - 1).astype(dt)
+    ref, cur = np.ascontiguousarray(ref).reshape(-1), np.ascontiguousarray(cur).reshape(-1)
+    out = {"unit": "ms per picture", "picture": "%dx%d P picture, 1 reference, host planes in / host table out" % (W, H), "presets": {}}
+    for name, rect, amp, method, subme in (("medium", False, False, 1, 2), ("slow", True, True, 3, 3)):
+        prod = TmeProducer(lib, W, H, 64, 8, rect, amp)
+        try:
+            table = prod.empty_table()
+            times = []
+            for it in range(5):
+                table["ref"] = -1
+                t0 = time.perf_counter()
+                prod.picture(cur, [[ref], []], stride, margin * stride + margin, table, qp=28, merange=57, method=method, subme=subme)
+                times.append(time.perf_counter() - t0)
+            used = int((table["ref"][:, 0] >= 0).sum())
+            assert used > 0, "the producer wrote no record"
+            ms = sorted(times[1:])[len(times[1:]) // 2] * 1e3                                   # the first picture pays for streams and code objects
+            out["presets"][name] = {"ms": round(ms, 2), "pictures_per_s": round(1e3 / ms, 1), "entries_per_ctu": prod.entries, "records_written": used,
+                                    "search": {1: "hex", 3: "star"}[method], "subme": subme, "rect": rect, "amp": amp}
+        finally:
+            prod.close()
+    return out
 
 
 def filters_leg(depth, steps):
@@ -733,6 +774,8 @@ def main():
                 out["e2e_fps"] = json.load(open(e2e_path))
             except Exception:
                 pass
+        if not args.no_tme:
+            out["tme_producer"] = tme_producer_leg(depth)
         if args.intra:
             out["intra_scan"] = intra_scan_leg(pipe, depth, max(2, min(args.steps, 10)))
         if args.lookahead:

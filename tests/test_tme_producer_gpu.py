@@ -1,0 +1,32 @@
+"""The host producer x265hip_tme_picture (include/x265hip_ctx.h) on synthetic pictures: the chain kernels (tme_chain.inc: a PU shape's entries inside one kernel, entries of a
+level side by side, a placement per lane in the STAR rounds) must write the table the one-launch-per-stage path writes (kern_tme.hip, pinned to the reference's recorded
+calls in test_tme_gpu.py and to its bitstreams in test_e2e_tme_gpu.py) -- record for record, P and B pictures, with the partition sets of presets medium and slow."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(depth, preset, kind, **env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "tme_producer_run.py"), str(depth), preset, kind], capture_output=True, text=True, env=e, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("table ")][-1].split()
+    return line[1], int(line[2]), int(line[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,preset,kind", [(8, "medium", "P"), (8, "slow", "B"), (10, "slow", "P"), (10, "medium", "B")])
+def test_chain_kernels_write_the_table_of_the_launch_path(depth, preset, kind):
+    chains = run(depth, preset, kind)
+    launches = run(depth, preset, kind, X265HIP_TME_LAUNCHES="1")
+    packed = run(depth, preset, kind, X265HIP_TME_PACKED="1")            # the small shapes in the batched kernels' lane packing (several PUs per wavefront)
+    assert chains[1] > 1000, "hardly any record written: %s" % (chains,)
+    if kind == "B" and preset == "slow":
+        assert chains[2] > 0, "no bidirectional record in a B picture"
+    assert chains == launches, "chain kernels %s != launch path %s" % (chains, launches)
+    assert packed == launches, "packed chain kernels %s != launch path %s" % (packed, launches)
