@@ -312,3 +312,23 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
+
+// ---- table transfers of the host producer: a schedule touches some of the 593 slots of a CTU (85 with preset medium's partitions); only those cross the bus ----
+namespace {
+__global__ __launch_bounds__(256) void tme_slots_kernel(x265hip_inter_choice* __restrict__ table, x265hip_inter_choice* __restrict__ packed, const int32_t* __restrict__ slots, int nUsed, int total, int toTable)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ctu = i / nUsed, k = i - ctu * nUsed;
+    x265hip_inter_choice* a = table + (int64_t)ctu * 593 + slots[k];
+    if (toTable) *a = packed[i]; else packed[i] = *a;
+}
+}
+int xh_tme_slots(void* stream, x265hip_inter_choice* table, x265hip_inter_choice* packed, const int32_t* slots, int nUsed, int nCtu, int toTable)
+{
+    const int total = nUsed * nCtu;
+    if (total <= 0) return X265HIP_OK;
+    hipLaunchKernelGGL(tme_slots_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, packed, slots, nUsed, total, toTable);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}

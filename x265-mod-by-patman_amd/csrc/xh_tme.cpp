@@ -103,6 +103,8 @@ extern "C" int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int am
 #include <cstdlib>
 using namespace xh;
 
+int xh_tme_slots(void* stream, x265hip_inter_choice* table, x265hip_inter_choice* packed, const int32_t* slots, int nUsed, int nCtu, int toTable);      // kern_tme.hip
+
 struct x265hip_tme
 {
     x265hip_ctx* ctx = nullptr;
@@ -118,6 +120,8 @@ struct x265hip_tme
     x265hip_inter_choice* table = nullptr; x265hip_inter_choice* refTable[2][4] = {}; int16_t* lowres[2][4] = {};
     int16_t* areaBest = nullptr; x265hip_tme_temporal* temporal = nullptr; uint8_t* qpIndex = nullptr; void* workspace = nullptr; size_t workspaceBytes = 0;
     x265hip_me_task* dTasks = nullptr; x265hip_me_result* dResults = nullptr;
+    // the slots of a CTU's table the schedule writes (and reads: neighbours are PUs of the same shape); sparse schedules move only these (pinned staging, packed [ctu][slot])
+    std::vector<int32_t> slots; int32_t* dSlots = nullptr; x265hip_inter_choice* dPacked = nullptr; x265hip_inter_choice* hPacked = nullptr; bool sparse = false;
     bool prof = false, first = false; double sec[5] = {}; int pictures = 0;      // X265HIP_TME_PROF: upload, diamond stage, submit, drain, (total)
     template<class T> int alloc(T*& p, size_t n)
     {
@@ -144,6 +148,19 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
     t->steps.resize(n);
     x265hip_tme_schedule(ctuSize, minCuSize, rect, amp, t->steps.data(), n);
     int rc;
+    {
+        std::vector<char> used(593, 0);
+        for (const x265hip_tme_step& e : t->steps) for (int pi = 0; pi < e.numPart; pi++) { const int sl = e.finalIdx + pi * e.puOffset; if (sl >= 0 && sl < 593) used[sl] = 1; }
+        for (int sl = 0; sl < 593; sl++) if (used[sl]) t->slots.push_back(sl);
+        t->sparse = t->slots.size() * 2 < 593;
+        if (t->sparse)
+        {
+            const size_t nrec = (size_t)t->nCtu * t->slots.size();
+            if ((rc = t->alloc(t->dSlots, t->slots.size())) || (rc = t->alloc(t->dPacked, nrec))) { x265hip_tme_destroy(t); return rc; }
+            if (hipMemcpy(t->dSlots, t->slots.data(), t->slots.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+                hipHostMalloc((void**)&t->hPacked, nrec * sizeof(x265hip_inter_choice), hipHostMallocDefault) != hipSuccess) { x265hip_tme_destroy(t); return X265HIP_EDEVICE; }
+        }
+    }
     std::vector<float> bits(2 * kBitsHalf + 1);
     x265hip_mvbits_row(kBitsHalf, bits.data());
     if ((rc = t->alloc(t->bitsRow, bits.size()))) { x265hip_tme_destroy(t); return rc; }
@@ -164,6 +181,7 @@ extern "C" void x265hip_tme_destroy(x265hip_tme* t)
     if (t->prof && t->pictures)
         fprintf(stderr, "x265hip_tme: %d pictures, per picture: upload + phase planes %.2f ms, diamond stage %.2f ms, submit %.2f ms, drain + table down %.2f ms\n", t->pictures,
                 1e3 * t->sec[0] / t->pictures, 1e3 * t->sec[1] / t->pictures, 1e3 * t->sec[2] / t->pictures, 1e3 * t->sec[3] / t->pictures);
+    if (t->hPacked) (void)hipHostFree(t->hPacked);
     for (void* p : t->owned) (void)hipFree(p);
     for (auto& kv : t->costRows) (void)hipFree(kv.second);
     delete t;
@@ -180,6 +198,16 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     auto lap = [&](int k, bool sync) { if (!t->prof) return; if (sync) (void)hipStreamSynchronize(st); const double t1 = now(); if (t->first) t->sec[k] += t1 - t0; t0 = t1; };      // the first picture (streams, code objects) is not counted
+    // host table -> device table: whole, or the schedule's slots through the pinned buffer (the stream is drained before the buffer is reused)
+    auto table_up = [&](x265hip_inter_choice* dev, const x265hip_inter_choice* host) -> int
+    {
+        if (!t->sparse) { XH_HIP(hipMemcpyAsync(dev, host, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st)); return X265HIP_OK; }
+        const int nU = (int)t->slots.size();
+        XH_HIP(hipStreamSynchronize(st));
+        for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) t->hPacked[(size_t)c * nU + k] = host[(size_t)c * 593 + t->slots[k]];
+        XH_HIP(hipMemcpyAsync(t->dPacked, t->hPacked, (size_t)nCtu * nU * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
+        return xh_tme_slots(st, dev, t->dPacked, t->dSlots, nU, nCtu, 1);
+    };
     if (t->planeElems != elems)
     {   // first picture (or another plane geometry): the device planes
         if (t->planeElems) { set_error("tme_picture: the plane geometry changed"); return X265HIP_EARG; }
@@ -204,7 +232,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
             if (R.refTable)
             {
                 if (!t->refTable[l][r] && (rc = t->alloc(t->refTable[l][r], (size_t)nCtu * 593))) return rc;
-                XH_HIP(hipMemcpyAsync(t->refTable[l][r], R.refTable, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
+                if ((rc = table_up(t->refTable[l][r], R.refTable))) return rc;
             }
             if (R.lowresMv)
             {
@@ -275,7 +303,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                     for (int a = 0; a < 5; a++) { int16_t* o = &area[((((size_t)c * 5 + a) * 2 + l) * 4 + r) * 2]; o[0] = m[1]; o[1] = m[2]; }
                 }
     XH_HIP(hipMemcpyAsync(t->areaBest, area.data(), area.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
-    XH_HIP(hipMemcpyAsync(t->table, d->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
+    if ((rc = table_up(t->table, d->table))) return rc;
     XH_HIP(hipMemcpyAsync(t->temporal, d->temporal, (size_t)nCtu * nS * 2 * sizeof(x265hip_tme_temporal), hipMemcpyHostToDevice, st));
     XH_HIP(hipMemcpyAsync(t->qpIndex, d->qpIndex, (size_t)nCtu * nS, hipMemcpyHostToDevice, st));
     lap(1, true);
@@ -298,9 +326,20 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     a.bitsRow = t->bitsRow; a.bitsHalfRange = kBitsHalf; a.steps = t->steps.data(); a.nSteps = nS; a.workspace = t->workspace; a.workspaceBytes = t->workspaceBytes;
     if ((rc = x265hip_tme_frame(st, &a))) return rc;
     lap(2, false);
-    XH_HIP(hipMemcpyAsync(d->table, t->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
+    if (!t->sparse) XH_HIP(hipMemcpyAsync(d->table, t->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
+    else
+    {
+        const int nU = (int)t->slots.size();
+        if ((rc = xh_tme_slots(st, t->table, t->dPacked, t->dSlots, nU, nCtu, 0))) return rc;
+        XH_HIP(hipMemcpyAsync(t->hPacked, t->dPacked, (size_t)nCtu * nU * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
+    }
     if (d->areaBestOut) std::memcpy(d->areaBestOut, area.data(), area.size() * sizeof(int16_t));
     XH_HIP(hipStreamSynchronize(st));
+    if (t->sparse)
+    {
+        const int nU = (int)t->slots.size();
+        for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) d->table[(size_t)c * 593 + t->slots[k]] = t->hPacked[(size_t)c * nU + k];
+    }
     lap(3, false); if (t->first) t->pictures++; t->first = true;
     return X265HIP_OK;
 }

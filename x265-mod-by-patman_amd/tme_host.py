@@ -38,6 +38,7 @@ class TmeProducer:
         self.entries = int(lib.x265hip_tme_entries(self.tme, None))
         self.width, self.height, self.ctu = width, height, ctu
         self.n_ctu = ((width + ctu - 1) // ctu) * ((height + ctu - 1) // ctu)
+        self._keep = None
 
     def close(self):
         if self.tme:
@@ -70,13 +71,13 @@ class TmeProducer:
         for l in range(2):
             for r, p in enumerate(refs[l]):
                 d.refs[l][r].mePlane = p.ctypes.data; d.refs[l][r].reconPlane = p.ctypes.data
-        temporal = np.zeros(self.n_ctu * self.entries * 2, dtype=TME_TEMPORAL)
-        temporal["nb"]["refIdx"] = -1
-        qp_index = np.zeros(self.n_ctu * self.entries, dtype=np.uint8)
-        area_qp = np.zeros(self.n_ctu * 5, dtype=np.uint8)
+        if self._keep is None:                                  # no temporal neighbour anywhere, one qp: the same arrays for every picture
+            temporal = np.zeros(self.n_ctu * self.entries * 2, dtype=TME_TEMPORAL)
+            temporal["nb"]["refIdx"] = -1
+            self._keep = (temporal, np.zeros(self.n_ctu * self.entries, dtype=np.uint8), np.zeros(self.n_ctu * 5, dtype=np.uint8))
+        temporal, qp_index, area_qp = self._keep
         d.table = table.ctypes.data; d.temporal = temporal.ctypes.data; d.nQp = 1; d.qps[0] = int(qp)
         d.qpIndex = qp_index.ctypes.data; d.areaQpIndex = area_qp.ctypes.data
-        self._keep = (temporal, qp_index, area_qp)
         rc = self.lib.x265hip_tme_picture(self.tme, C.byref(d))
         if rc:
             self.lib.x265hip_last_error.restype = C.c_char_p
