@@ -107,6 +107,28 @@ def tme_producer_leg(depth):
                                     "search": {1: "hex", 3: "star"}[method], "subme": subme, "rect": rect, "amp": amp}
         finally:
             prod.close()
+        # frame threads: independent pictures in flight, one producer (context, stream, buffers) per host thread, as an encoder's frame encoders would hold them
+        import threading
+        NT, PER = 4, 4
+        prods = [TmeProducer(lib, W, H, 64, 8, rect, amp) for _ in range(NT)]
+        tables = [p.empty_table() for p in prods]
+        try:
+            for p, tb in zip(prods, tables):
+                p.picture(cur, [[ref], []], stride, margin * stride + margin, tb, qp=28, merange=57, method=method, subme=subme)       # streams, code objects
+            def work(i):
+                for _ in range(PER):                         # (the table is not reset between pictures: a numpy pass would hold the interpreter lock of all four threads)
+                    prods[i].picture(cur, [[ref], []], stride, margin * stride + margin, tables[i], qp=28, merange=57, method=method, subme=subme)
+            th = [threading.Thread(target=work, args=(i,)) for i in range(NT)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            dt = time.perf_counter() - t0
+            out["presets"][name]["pictures_per_s_4_threads"] = round(NT * PER / dt, 1)
+        finally:
+            for p in prods:
+                p.close()
     return out
 
 

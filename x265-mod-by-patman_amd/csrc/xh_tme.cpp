@@ -122,6 +122,7 @@ struct x265hip_tme
     x265hip_me_task* dTasks = nullptr; x265hip_me_result* dResults = nullptr;
     // the slots of a CTU's table the schedule writes (and reads: neighbours are PUs of the same shape); sparse schedules move only these (pinned staging, packed [ctu][slot])
     std::vector<int32_t> slots; int32_t* dSlots = nullptr; x265hip_inter_choice* dPacked = nullptr; x265hip_inter_choice* hPacked = nullptr; bool sparse = false;
+    int rowQp[64];                                                // the qp whose MVD cost row sits in row q of costTable (rows are kept across pictures)
     bool prof = false, first = false; double sec[5] = {}; int pictures = 0;      // X265HIP_TME_PROF: upload, diamond stage, submit, drain, (total)
     template<class T> int alloc(T*& p, size_t n)
     {
@@ -144,6 +145,7 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
     x265hip_tme* t = new (std::nothrow) x265hip_tme();
     if (!t) return X265HIP_EARG;
     t->prof = getenv("X265HIP_TME_PROF") != nullptr;
+    for (int q = 0; q < 64; q++) t->rowQp[q] = -1;
     t->ctx = ctx; t->width = width; t->height = height; t->ctu = ctuSize; t->nCtuX = (width + ctuSize - 1) / ctuSize; t->nCtu = t->nCtuX * ((height + ctuSize - 1) / ctuSize);
     t->steps.resize(n);
     x265hip_tme_schedule(ctuSize, minCuSize, rect, amp, t->steps.data(), n);
@@ -253,7 +255,11 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
             t->hostRows[d->qps[q]] = row;
         }
     for (int q = 0; q < d->nQp; q++)
-        XH_HIP(hipMemcpyAsync(t->costTable + (size_t)q * (2 * kHalf + 1), t->hostRows[d->qps[q]].data(), (size_t)(2 * kHalf + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+        if (t->rowQp[q] != d->qps[q])
+        {   // device to device: the row of this qp exists on the device since the first picture that used it
+            XH_HIP(hipMemcpyAsync(t->costTable + (size_t)q * (2 * kHalf + 1), t->costRows[d->qps[q]], (size_t)(2 * kHalf + 1) * sizeof(uint16_t), hipMemcpyDeviceToDevice, st));
+            t->rowQp[q] = d->qps[q];
+        }
     lap(0, true);
     // ---- deriveMVsForCTU's first stage (analysis.cpp:262-299): diamondSearch at range 32 around (0,0) for the CTU (area 0) and its four sub-CUs (areas 1..4), per reference;
     //      m_areaBestMV starts as zero for every area a search does not write; the collocated median, where there is one, replaces all five ----
