@@ -332,3 +332,26 @@ int xh_tme_slots(void* stream, x265hip_inter_choice* table, x265hip_inter_choice
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
+
+// ---- m_areaBestMV from the diamond stage's results, on the device (analysis.cpp:262-299): result i of (list l, reference r) belongs to area where[i] = ctu * 5 + area;
+//      the collocated median, where the caller found one, replaces the five areas of its CTU ----
+namespace {
+__global__ __launch_bounds__(256) void tme_area_kernel(const x265hip_me_result* __restrict__ res, const int32_t* __restrict__ where, int nTasks, int nl, int numRef0, int numRef1,
+                                                       const int16_t* __restrict__ median, int16_t* __restrict__ areaBest)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, lr = blockIdx.y, l = lr >> 2, r = lr & 3;
+    if (i >= nTasks || l >= nl || r >= (l ? numRef1 : numRef0)) return;
+    const int ca = where[i], c = ca / 5;
+    int mx = res[(int64_t)lr * nTasks + i].mv[0], my = res[(int64_t)lr * nTasks + i].mv[1];                 // the full-pel MV as the reference stores it (search.cpp:363)
+    if (median) { const int16_t* m = median + (((int64_t)c * 2 + l) * 4 + r) * 3; if (m[0]) { mx = m[1]; my = m[2]; } }
+    int16_t* o = areaBest + (((int64_t)ca * 2 + l) * 4 + r) * 2;
+    o[0] = (int16_t)mx; o[1] = (int16_t)my;
+}
+}
+int xh_tme_area(void* stream, const x265hip_me_result* res, const int32_t* where, int nTasks, int nl, int numRef0, int numRef1, const int16_t* median, int16_t* areaBest)
+{
+    if (nTasks <= 0) return X265HIP_OK;
+    hipLaunchKernelGGL(tme_area_kernel, dim3((nTasks + 255) / 256, 8), dim3(256), 0, (hipStream_t)stream, res, where, nTasks, nl, numRef0, numRef1, median, areaBest);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}

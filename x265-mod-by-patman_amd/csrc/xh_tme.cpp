@@ -103,6 +103,7 @@ extern "C" int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int am
 #include <cstdlib>
 using namespace xh;
 
+int xh_tme_area(void* stream, const x265hip_me_result* res, const int32_t* where, int nTasks, int nl, int numRef0, int numRef1, const int16_t* median, int16_t* areaBest);      // kern_tme.hip
 int xh_tme_slots(void* stream, x265hip_inter_choice* table, x265hip_inter_choice* packed, const int32_t* slots, int nUsed, int nCtu, int toTable);      // kern_tme.hip
 
 struct x265hip_tme
@@ -119,7 +120,8 @@ struct x265hip_tme
     int64_t planeElems = 0;
     x265hip_inter_choice* table = nullptr; x265hip_inter_choice* refTable[2][4] = {}; int16_t* lowres[2][4] = {};
     int16_t* areaBest = nullptr; x265hip_tme_temporal* temporal = nullptr; uint8_t* qpIndex = nullptr; void* workspace = nullptr; size_t workspaceBytes = 0;
-    x265hip_me_task* dTasks = nullptr; x265hip_me_result* dResults = nullptr;
+    x265hip_me_task* dTasks = nullptr; x265hip_me_result* dResults = nullptr; int32_t* dWhere = nullptr; int16_t* dMedian = nullptr;
+    std::vector<x265hip_me_task> hTasks; std::vector<int32_t> hWhere;      // kept: the copies read them after the call that filled them returned
     // the slots of a CTU's table the schedule writes (and reads: neighbours are PUs of the same shape); sparse schedules move only these (pinned staging, packed [ctu][slot])
     std::vector<int32_t> slots; int32_t* dSlots = nullptr; x265hip_inter_choice* dPacked = nullptr; x265hip_inter_choice* hPacked = nullptr; bool sparse = false;
     int rowQp[64];                                                // the qp whose MVD cost row sits in row q of costTable (rows are kept across pictures)
@@ -171,7 +173,7 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
     char* ws = nullptr;
     if ((rc = t->alloc(ws, t->workspaceBytes)) || (rc = t->alloc(t->table, (size_t)t->nCtu * 593)) || (rc = t->alloc(t->areaBest, (size_t)t->nCtu * 5 * 2 * 4 * 2)) ||
         (rc = t->alloc(t->temporal, (size_t)t->nCtu * n * 2)) || (rc = t->alloc(t->qpIndex, (size_t)t->nCtu * n)) || (rc = t->alloc(t->dTasks, (size_t)t->nCtu * 5)) ||
-        (rc = t->alloc(t->dResults, (size_t)t->nCtu * 5)) || (rc = t->alloc(t->costTable, (size_t)64 * (2 * kHalf + 1))))
+        (rc = t->alloc(t->dResults, (size_t)t->nCtu * 5 * 8)) || (rc = t->alloc(t->dWhere, (size_t)t->nCtu * 5)) || (rc = t->alloc(t->dMedian, (size_t)t->nCtu * 2 * 4 * 3)) || (rc = t->alloc(t->costTable, (size_t)64 * (2 * kHalf + 1))))
     { x265hip_tme_destroy(t); return rc; }
     t->workspace = ws;
     *out = t;
@@ -263,52 +265,44 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     lap(0, true);
     // ---- deriveMVsForCTU's first stage (analysis.cpp:262-299): diamondSearch at range 32 around (0,0) for the CTU (area 0) and its four sub-CUs (areas 1..4), per reference;
     //      m_areaBestMV starts as zero for every area a search does not write; the collocated median, where there is one, replaces all five ----
-    std::vector<int16_t> area((size_t)nCtu * 5 * 2 * 4 * 2, 0);
-    std::vector<x265hip_me_task> tasks; std::vector<int> where;
-    std::vector<x265hip_me_result> res;
+    // The tasks do not depend on the reference: built once (grouped by CU size and qp: a launch has one PU size and one cost row), uploaded once; every
+    // (reference, group) is a launch into its own part of the result array, and m_areaBestMV is assembled on the device -- no round trip inside the picture.
+    std::vector<x265hip_me_task>& tasks = t->hTasks; std::vector<int32_t>& where = t->hWhere;
+    tasks.clear(); where.clear();
+    struct Group { int size, q, first, n; };
+    std::vector<Group> groups;
+    for (int size = t->ctu; size >= t->ctu / 2; size >>= 1)
+        for (int q = 0; q < d->nQp; q++)
+        {
+            const int first = (int)tasks.size();
+            for (int c = 0; c < nCtu; c++)
+                for (int a = (size == t->ctu ? 0 : 1); a < (size == t->ctu ? 1 : 5); a++)
+                {
+                    if (d->areaQpIndex[c * 5 + a] != q) continue;
+                    const int cx = (c % t->nCtuX) * t->ctu + (a ? ((a - 1) & 1) * size : 0), cy = (c / t->nCtuX) * t->ctu + (a ? ((a - 1) >> 1) * size : 0);
+                    x265hip_me_task k{};
+                    k.curOff = k.refOff = (int32_t)(d->origin + (int64_t)cy * d->stride + cx);
+                    // Search::setSearchRange(cu, MV(0,0), 32) >> 2 (search.cpp:4969-5021) with CUData::clipMv's limits of this CU
+                    const int xmin = -((t->ctu + 8 + cx - 1) << 2), ymin = -((t->ctu + 8 + cy - 1) << 2), xmax = (d->width + 8 - cx - 1) << 2, ymax = (d->height + 8 - cy - 1) << 2;
+                    const int dd = 32 << 2;
+                    k.mvmin[0] = (int16_t)(std::min(xmax, std::max(xmin, -dd)) >> 2); k.mvmin[1] = (int16_t)(std::min(ymax, std::max(ymin, -dd)) >> 2);
+                    k.mvmax[0] = (int16_t)(std::min(xmax, std::max(xmin, dd)) >> 2); k.mvmax[1] = (int16_t)(std::max(std::min(ymax, std::max(ymin, dd)) >> 2, (int)k.mvmin[1]));
+                    k.mvpFrom = -1;
+                    tasks.push_back(k); where.push_back(c * 5 + a);
+                }
+            if ((int)tasks.size() > first) groups.push_back(Group{ size, q, first, (int)tasks.size() - first });
+        }
+    const int nTasks = (int)tasks.size();                                                 // nCtu * 5
+    XH_HIP(hipMemcpyAsync(t->dTasks, tasks.data(), (size_t)nTasks * sizeof(x265hip_me_task), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(t->dWhere, where.data(), (size_t)nTasks * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (d->median) XH_HIP(hipMemcpyAsync(t->dMedian, d->median, (size_t)nCtu * 2 * 4 * 3 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemsetAsync(t->areaBest, 0, (size_t)nCtu * 5 * 2 * 4 * 2 * sizeof(int16_t), st));
     for (int l = 0; l < nl; l++)
         for (int r = 0; r < d->numRef[l]; r++)
-            for (int size = t->ctu; size >= t->ctu / 2; size >>= 1)
-                for (int q = 0; q < d->nQp; q++)
-                {
-                    tasks.clear(); where.clear();
-                    for (int c = 0; c < nCtu; c++)
-                        for (int a = (size == t->ctu ? 0 : 1); a < (size == t->ctu ? 1 : 5); a++)
-                        {
-                            if (d->areaQpIndex[c * 5 + a] != q) continue;
-                            const int cx = (c % t->nCtuX) * t->ctu + (a ? ((a - 1) & 1) * size : 0), cy = (c / t->nCtuX) * t->ctu + (a ? ((a - 1) >> 1) * size : 0);
-                            x265hip_me_task k{};
-                            k.curOff = k.refOff = (int32_t)(d->origin + (int64_t)cy * d->stride + cx);
-                            // Search::setSearchRange(cu, MV(0,0), 32) >> 2 (search.cpp:4969-5021) with CUData::clipMv's limits of this CU
-                            const int xmin = -((t->ctu + 8 + cx - 1) << 2), ymin = -((t->ctu + 8 + cy - 1) << 2), xmax = (d->width + 8 - cx - 1) << 2, ymax = (d->height + 8 - cy - 1) << 2;
-                            const int dd = 32 << 2;
-                            k.mvmin[0] = (int16_t)(std::min(xmax, std::max(xmin, -dd)) >> 2); k.mvmin[1] = (int16_t)(std::min(ymax, std::max(ymin, -dd)) >> 2);
-                            k.mvmax[0] = (int16_t)(std::min(xmax, std::max(xmin, dd)) >> 2); k.mvmax[1] = (int16_t)(std::max(std::min(ymax, std::max(ymin, dd)) >> 2, (int)k.mvmin[1]));
-                            k.mvpFrom = -1;
-                            tasks.push_back(k); where.push_back(c * 5 + a);
-                        }
-                    if (tasks.empty()) continue;
-                    XH_HIP(hipMemcpyAsync(t->dTasks, tasks.data(), tasks.size() * sizeof(x265hip_me_task), hipMemcpyHostToDevice, st));
-                    if ((rc = x265hip_diamond_batch(st, size, size, t->cur, d->stride, t->plane[l][r][0], d->stride, t->dTasks, (int)tasks.size(), t->costRows[d->qps[q]], kHalf, t->dResults))) return rc;
-                    res.resize(tasks.size());
-                    XH_HIP(hipMemcpyAsync(res.data(), t->dResults, tasks.size() * sizeof(x265hip_me_result), hipMemcpyDeviceToHost, st));
-                    XH_HIP(hipStreamSynchronize(st));
-                    for (size_t i = 0; i < tasks.size(); i++)
-                    {
-                        int16_t* o = &area[(((size_t)where[i] * 2 + l) * 4 + r) * 2];
-                        o[0] = res[i].mv[0]; o[1] = res[i].mv[1];                      // the full-pel MV as the reference stores it (search.cpp:363)
-                    }
-                }
-    if (d->median)
-        for (int c = 0; c < nCtu; c++)
-            for (int l = 0; l < nl; l++)
-                for (int r = 0; r < d->numRef[l]; r++)
-                {
-                    const int16_t* m = &d->median[(((size_t)c * 2 + l) * 4 + r) * 3];
-                    if (!m[0]) continue;
-                    for (int a = 0; a < 5; a++) { int16_t* o = &area[((((size_t)c * 5 + a) * 2 + l) * 4 + r) * 2]; o[0] = m[1]; o[1] = m[2]; }
-                }
-    XH_HIP(hipMemcpyAsync(t->areaBest, area.data(), area.size() * sizeof(int16_t), hipMemcpyHostToDevice, st));
+            for (const Group& g : groups)
+                if ((rc = x265hip_diamond_batch(st, g.size, g.size, t->cur, d->stride, t->plane[l][r][0], d->stride, t->dTasks + g.first, g.n, t->costRows[d->qps[g.q]], kHalf,
+                                                t->dResults + (size_t)(l * 4 + r) * nTasks + g.first))) return rc;
+    if ((rc = xh_tme_area(st, t->dResults, t->dWhere, nTasks, nl, d->numRef[0], d->isP ? 0 : d->numRef[1], d->median ? t->dMedian : nullptr, t->areaBest))) return rc;
     if ((rc = table_up(t->table, d->table))) return rc;
     XH_HIP(hipMemcpyAsync(t->temporal, d->temporal, (size_t)nCtu * nS * 2 * sizeof(x265hip_tme_temporal), hipMemcpyHostToDevice, st));
     XH_HIP(hipMemcpyAsync(t->qpIndex, d->qpIndex, (size_t)nCtu * nS, hipMemcpyHostToDevice, st));
@@ -339,7 +333,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
         if ((rc = xh_tme_slots(st, t->table, t->dPacked, t->dSlots, nU, nCtu, 0))) return rc;
         XH_HIP(hipMemcpyAsync(t->hPacked, t->dPacked, (size_t)nCtu * nU * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
     }
-    if (d->areaBestOut) std::memcpy(d->areaBestOut, area.data(), area.size() * sizeof(int16_t));
+    if (d->areaBestOut) XH_HIP(hipMemcpyAsync(d->areaBestOut, t->areaBest, (size_t)nCtu * 5 * 2 * 4 * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     XH_HIP(hipStreamSynchronize(st));
     if (t->sparse)
     {
