@@ -105,6 +105,21 @@ def tme_producer_leg(depth):
             ms = sorted(times[1:])[len(times[1:]) // 2] * 1e3                                   # the first picture pays for streams and code objects
             out["presets"][name] = {"ms": round(ms, 2), "pictures_per_s": round(1e3 / ms, 1), "entries_per_ctu": prod.entries, "records_written": used,
                                     "search": {1: "hex", 3: "star"}[method], "subme": subme, "rect": rect, "amp": amp}
+            # the same with the caller's long-lived buffers page-locked once (x265hip_host_register: PicYuv planes and FrameData tables live as long as the encoder)
+            pinned = [cur, ref, table]
+            for a in pinned:
+                prod.pin(a)
+            try:
+                times = []
+                for it in range(5):
+                    table["ref"] = -1
+                    t0 = time.perf_counter()
+                    prod.picture(cur, [[ref], []], stride, margin * stride + margin, table, qp=28, merange=57, method=method, subme=subme)
+                    times.append(time.perf_counter() - t0)
+                out["presets"][name]["ms_host_buffers_registered"] = round(sorted(times[1:])[len(times[1:]) // 2] * 1e3, 2)
+            finally:
+                for a in pinned:
+                    prod.unpin(a)
         finally:
             prod.close()
         # frame threads: independent pictures in flight, one producer (context, stream, buffers) per host thread, as an encoder's frame encoders would hold them

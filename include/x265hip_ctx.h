@@ -95,6 +95,9 @@ typedef struct x265hip_tme_picture_desc {
 int  x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** tme);
 void x265hip_tme_destroy(x265hip_tme* tme);
 int  x265hip_tme_entries(const x265hip_tme* tme, const x265hip_tme_step** steps);     /* the schedule (x265hip_tme_schedule) this producer steps through */
+/* optional: page-lock a long-lived host buffer of the caller (a PicYuv plane allocation, a FrameData table) once; copies from / to it are then DMA transfers */
+int  x265hip_host_register(void* p, size_t bytes);
+int  x265hip_host_unregister(void* p);
 int  x265hip_tme_picture(x265hip_tme* tme, const x265hip_tme_picture_desc* desc);     /* synchronous: desc->table holds the picture's records on return   */
 
 #ifdef __cplusplus

@@ -8,11 +8,11 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 python bench.py --steps 20 --warmup 3 "$@" > $out/bench.json 2> $out/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 10 --warmup 2 --cpu-ctus 0 "$@" > $out/stats_bench.json 2> $out/stats.err
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 "$@" > /dev/null 2> $out/fetch.err
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 "$@" > /dev/null 2> $out/write.err
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $out/sq1 -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 "$@" > /dev/null 2> $out/sq1.err
-timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $out/sq2 -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 "$@" > /dev/null 2> $out/sq2.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --steps 10 --warmup 2 --cpu-ctus 0 --no-tme "$@" > $out/stats_bench.json 2> $out/stats.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 --no-tme "$@" > /dev/null 2> $out/fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 --no-tme "$@" > /dev/null 2> $out/write.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d $out/sq1 -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 --no-tme "$@" > /dev/null 2> $out/sq1.err
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --output-format csv -d $out/sq2 -- python bench.py --steps 3 --warmup 1 --cpu-ctus 0 --no-tme "$@" > /dev/null 2> $out/sq2.err
 src="$tag, code $(cat profiles/.commit 2>/dev/null || echo unknown)"
 python profiles/summarize_pmc.py --traffic $out/fetch $out/write "$src" > $out/traffic.json
 python profiles/summarize_pmc.py --valu $out/sq1 "$src" > $out/valu.json

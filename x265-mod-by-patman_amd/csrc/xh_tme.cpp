@@ -343,3 +343,18 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     lap(3, false); if (t->first) t->pictures++; t->first = true;
     return X265HIP_OK;
 }
+
+// Long-lived host buffers of the caller (PicYuv planes, the FrameData tables) can be page-locked once: the producer's copies from / to them are then DMA transfers
+// instead of the runtime's staged pageable copies (which bound x265hip_tme_picture at preset medium: ~9 MB per 1080p picture).
+extern "C" int x265hip_host_register(void* p, size_t bytes)
+{
+    if (!p || !bytes) { set_error("host_register: bad arguments"); return X265HIP_EARG; }
+    XH_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return X265HIP_OK;
+}
+extern "C" int x265hip_host_unregister(void* p)
+{
+    if (!p) return X265HIP_EARG;
+    XH_HIP(hipHostUnregister(p));
+    return X265HIP_OK;
+}

@@ -50,6 +50,17 @@ class TmeProducer:
             self.lib.x265hip_ctx_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
+    def pin(self, arr):
+        """page-lock a long-lived numpy buffer (x265hip_host_register); undone by unpin"""
+        self.lib.x265hip_host_register.argtypes = [C.c_void_p, C.c_size_t]
+        rc = self.lib.x265hip_host_register(arr.ctypes.data, arr.nbytes)
+        if rc:
+            raise RuntimeError("x265hip_host_register: %d" % rc)
+
+    def unpin(self, arr):
+        self.lib.x265hip_host_unregister.argtypes = [C.c_void_p]
+        self.lib.x265hip_host_unregister(arr.ctypes.data)
+
     def empty_table(self):
         """the table of a picture before its first record: every slot unavailable (FrameData::reinit)"""
         t = np.zeros(self.n_ctu * 593, dtype=INTER_CHOICE)
