@@ -77,6 +77,8 @@ typedef struct x265hip_tme_host_ref {
     const void* reconPlane;                    /* the reconstructed reference picture's plane (== mePlane without weighting)                     */
     const struct x265hip_inter_choice* refTable;   /* that picture's own table or NULL (intra picture)                                           */
     const int16_t* lowresMv;                   /* Lowres::lowresMvs[l][dist] as x, y per 16x16 block, or NULL (not estimated / distance out of range) */
+    uint64_t reconKey;                         /* identity of the reconstructed picture (e.g. Frame::m_encodeOrder + 1): the producer keeps the planes of the last
+                                                  pictures it saw on the device and uploads / phase-interpolates a picture once; 0 = no identity, upload every time */
 } x265hip_tme_host_ref;
 typedef struct x265hip_tme_picture_desc {
     int isP, numRef[2], curPOC, temporalMvp, refPOC[2][16];

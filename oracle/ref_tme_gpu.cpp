@@ -55,7 +55,7 @@ static struct Api
 } g_api;
 static x265hip_ctx* g_ctx;
 static x265hip_tme* g_tme;
-static int g_useGpu = 1, g_pictures, g_weighted;
+static int g_useGpu = 1, g_pictures, g_weighted, g_keepPlanes = 1;
 static double g_gpuSeconds;
 static std::mutex g_lock;
 static std::map<const Frame*, int> g_done;          /* picture -> POC + 1 whose table is complete */
@@ -221,6 +221,7 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
             R.mePlane = mr.fpelPlane[0] - d.origin;
             R.reconPlane = rec->m_picBuf[0];
             const Frame* rf = slice->m_refFrameList[l][r];
+            R.reconKey = g_keepPlanes ? (uint64_t)rf->m_encodeOrder + 1 : 0;      /* a finished picture: its planes stay on the device for the pictures that reference it */
             if (rf->m_encData->m_slice->m_sliceType != I_SLICE)
             {
                 refTables.emplace_back((size_t)nCtu * 593);
@@ -293,6 +294,7 @@ static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixe
 
 int main(int argc, char** argv)
 {
+    if (getenv("X265TME_NOKEEP")) g_keepPlanes = 0;
     if (argc < 7) { fprintf(stderr, "usage: %s libx265hip.so width height frames preset out.hevc [option=value ...]\n", argv[0]); return 2; }
     g_useGpu = getenv("X265TMEGPU") ? atoi(getenv("X265TMEGPU")) : 1;
     if (g_useGpu)

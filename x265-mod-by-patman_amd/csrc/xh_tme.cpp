@@ -116,7 +116,8 @@ struct x265hip_tme
     std::map<int, std::vector<uint16_t>> hostRows;
     uint16_t* costTable = nullptr;             // [64][2 * kHalf + 1]: the rows of the picture's qps, in the order of desc->qps
     float* bitsRow = nullptr;
-    pixel* cur = nullptr; pixel* plane[2][4][2] = {}; pixel* phase[2][4][2] = {};       // [list][ref][0 = searched plane, 1 = reconstructed picture]
+    pixel* cur = nullptr; pixel* plane[2][4][2] = {}; pixel* phase[2][4][2] = {};      // this picture's: kept buffers or the slot's own ones
+    pixel* ownPlane[2][4][2] = {}; pixel* ownPhase[2][4][2] = {}; bool own[2][4][2] = {};       // [list][ref][0 = searched plane, 1 = reconstructed picture]
     int64_t planeElems = 0;
     x265hip_inter_choice* table = nullptr; x265hip_inter_choice* refTable[2][4] = {}; int16_t* lowres[2][4] = {};
     int16_t* areaBest = nullptr; x265hip_tme_temporal* temporal = nullptr; uint8_t* qpIndex = nullptr; void* workspace = nullptr; size_t workspaceBytes = 0;
@@ -124,6 +125,9 @@ struct x265hip_tme
     std::vector<x265hip_me_task> hTasks; std::vector<int32_t> hWhere;      // kept: the copies read them after the call that filled them returned
     // the slots of a CTU's table the schedule writes (and reads: neighbours are PUs of the same shape); sparse schedules move only these (pinned staging, packed [ctu][slot])
     std::vector<int32_t> slots; int32_t* dSlots = nullptr; x265hip_inter_choice* dPacked = nullptr; x265hip_inter_choice* hPacked = nullptr; bool sparse = false;
+    // reconstructed reference pictures stay on the device (plane + its 16 phase planes) under the caller's key; the least recently used of kKeep makes room
+    struct Kept { uint64_t key = 0; pixel* plane = nullptr; pixel* phase = nullptr; uint64_t used = 0; };
+    std::vector<Kept> kept; uint64_t tick = 0;
     int rowQp[64];                                                // the qp whose MVD cost row sits in row q of costTable (rows are kept across pictures)
     bool prof = false, first = false; double sec[5] = {}; int pictures = 0;      // X265HIP_TME_PROF: upload, diamond stage, submit, drain, (total)
     template<class T> int alloc(T*& p, size_t n)
@@ -137,6 +141,7 @@ struct x265hip_tme
 
 namespace {
 constexpr int kHalf = 1 << 15, kBitsHalf = 1 << 15;
+constexpr int kKeep = 20;                  // reconstructed pictures kept on the device (16 references + the ones just replaced); 17 planes each
 }
 
 extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** out)
@@ -228,8 +233,36 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
             for (int k = 0; k < 2; k++)
             {
                 if (k == 1 && R.reconPlane == R.mePlane) { t->plane[l][r][1] = t->plane[l][r][0]; t->phase[l][r][1] = t->phase[l][r][0]; continue; }
-                if (!t->plane[l][r][k] || (k == 1 && t->plane[l][r][1] == t->plane[l][r][0]))
-                { if ((rc = t->alloc(t->plane[l][r][k], (size_t)elems)) || (rc = t->alloc(t->phase[l][r][k], (size_t)elems * 16))) return rc; }
+                const bool recon = k == 1 || R.reconPlane == R.mePlane;                      // a weighted plane belongs to the current picture: never kept
+                if (recon && R.reconKey)
+                {
+                    x265hip_tme::Kept* slot = nullptr;
+                    for (auto& kp : t->kept) if (kp.key == R.reconKey) slot = &kp;
+                    const bool hit = slot != nullptr;
+                    if (!slot)
+                    {
+                        if ((int)t->kept.size() < kKeep)
+                        {
+                            t->kept.emplace_back(); slot = &t->kept.back();
+                            if ((rc = t->alloc(slot->plane, (size_t)elems)) || (rc = t->alloc(slot->phase, (size_t)elems * 16))) { t->kept.pop_back(); return rc; }
+                        }
+                        else
+                        {   // least recently used, not one this picture already took
+                            for (auto& kp : t->kept) if (kp.used != t->tick + 1 && (!slot || kp.used < slot->used)) slot = &kp;
+                            if (!slot) { set_error("tme_picture: more distinct reference pictures than kept planes"); return X265HIP_EARG; }
+                        }
+                        slot->key = R.reconKey;
+                    }
+                    slot->used = t->tick + 1;
+                    t->plane[l][r][k] = slot->plane; t->phase[l][r][k] = slot->phase;
+                    if (hit) continue;
+                }
+                else if (!t->own[l][r][k])
+                {
+                    if ((rc = t->alloc(t->ownPlane[l][r][k], (size_t)elems)) || (rc = t->alloc(t->ownPhase[l][r][k], (size_t)elems * 16))) return rc;
+                    t->own[l][r][k] = true;
+                }
+                if (!(recon && R.reconKey)) { t->plane[l][r][k] = t->ownPlane[l][r][k]; t->phase[l][r][k] = t->ownPhase[l][r][k]; }
                 XH_HIP(hipMemcpyAsync(t->plane[l][r][k], k ? R.reconPlane : R.mePlane, (size_t)elems * sizeof(pixel), hipMemcpyHostToDevice, st));
                 if ((rc = x265hip_subpel_planes(st, t->plane[l][r][k], d->stride, rows, t->phase[l][r][k], elems))) return rc;
             }
@@ -340,6 +373,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
         const int nU = (int)t->slots.size();
         for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) d->table[(size_t)c * 593 + t->slots[k]] = t->hPacked[(size_t)c * nU + k];
     }
+    t->tick++;
     lap(3, false); if (t->first) t->pictures++; t->first = true;
     return X265HIP_OK;
 }

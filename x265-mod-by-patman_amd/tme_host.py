@@ -8,7 +8,7 @@ from .frame import INTER_CHOICE, TME_TEMPORAL
 
 
 class HostRef(C.Structure):
-    _fields_ = [("mePlane", C.c_void_p), ("reconPlane", C.c_void_p), ("refTable", C.c_void_p), ("lowresMv", C.c_void_p)]
+    _fields_ = [("mePlane", C.c_void_p), ("reconPlane", C.c_void_p), ("refTable", C.c_void_p), ("lowresMv", C.c_void_p), ("reconKey", C.c_uint64)]
 
 
 class PictureDesc(C.Structure):
@@ -67,7 +67,7 @@ class TmeProducer:
         t["ref"] = -1
         return t
 
-    def picture(self, cur, refs, stride, origin, table, qp=28, is_p=True, merange=57, method=1, subme=2, cur_poc=1, ref_pocs=((0,), ())):
+    def picture(self, cur, refs, stride, origin, table, qp=28, is_p=True, merange=57, method=1, subme=2, cur_poc=1, ref_pocs=((0,), ()), ref_keys=None):
         """cur: padded plane (numpy, pixel dtype); refs: [[plane, ...] of list 0, [...] of list 1]; table: INTER_CHOICE[n_ctu * 593] in / out.
         No temporal neighbours, no lookahead MVs, one qp: what a first P picture after an intra picture looks like."""
         d = PictureDesc()
@@ -82,6 +82,7 @@ class TmeProducer:
         for l in range(2):
             for r, p in enumerate(refs[l]):
                 d.refs[l][r].mePlane = p.ctypes.data; d.refs[l][r].reconPlane = p.ctypes.data
+                d.refs[l][r].reconKey = int(ref_keys[l][r]) if ref_keys else 0          # 0: uploaded and phase-interpolated with every picture
         if self._keep is None:                                  # no temporal neighbour anywhere, one qp: the same arrays for every picture
             temporal = np.zeros(self.n_ctu * self.entries * 2, dtype=TME_TEMPORAL)
             temporal["nb"]["refIdx"] = -1
