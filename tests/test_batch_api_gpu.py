@@ -175,3 +175,32 @@ def test_intra_cost_batch_matches_oracle(depth):
         for i in range(n):
             exp = ora.intra_costs(size, plane, W, int(offs[i]), nb_ref[i * pitch:(i + 1) * pitch], nb_flt[i * pitch:(i + 1) * pitch])
             assert np.array_equal(got[i], exp), "size %d CU %d" % (size, i)
+
+
+def test_idct32_on_the_matrix_cores_is_exact_for_every_int16(env):
+    """The 32x32 inverse transform runs as two int8 MFMA products per stage (csrc/xh_dct32.h: three exact byte planes of an int16 operand): full-range coefficients incl.
+    -32768 / 32767, sparse blocks, a strided destination with odd offsets -- all equal to the oracle (partialButterflyInverse32, dct.cpp:242-416, both clip16 points)."""
+    depth, api, ora, rng = env
+    T = api.torch
+    n, N = 67, 32
+    coef = rng.integers(-32768, 32768, n * N * N).astype(np.int16)
+    coef[:N * N] = -32768; coef[N * N:2 * N * N] = 32767                                  # saturating blocks
+    coef[2 * N * N:3 * N * N] = 0; coef[2 * N * N] = 32767                                 # DC only
+    coef[3 * N * N:4 * N * N] = np.where(rng.random(N * N) < 0.05, coef[3 * N * N:4 * N * N], 0)
+    stride = 48
+    d_off = (np.arange(n, dtype=np.int32) * (N * stride + 8) + (np.arange(n, dtype=np.int32) % 4)).astype(np.int32)       # odd element offsets: the unaligned store path
+    total = int(d_off[-1]) + N * stride + 8
+    d_coef = api.to_device(coef); dd_off = api.to_device(d_off)
+    d_rec = T.full((total,), 1234, dtype=T.int16, device="cuda")
+    api.h.check(api.lib.x265hip_transform_batch(api.stream(), 1, N, _dp(d_coef), _IP(N), None, _dp(d_rec), _IP(stride), _dp(dd_off), n))
+    T.cuda.synchronize()
+    rec = d_rec.cpu().numpy()
+    for i in range(n):
+        exp = ora.idct(N, coef[i * N * N:(i + 1) * N * N], np.zeros(N * N, np.int16), N).reshape(N, N)
+        got = np.lib.stride_tricks.as_strided(rec[int(d_off[i]):], shape=(N, N), strides=(stride * 2, 2))
+        assert np.array_equal(got, exp), "TU %d" % i
+    touched = np.zeros(total, bool)
+    for i in range(n):
+        for y in range(N):
+            touched[int(d_off[i]) + y * stride:int(d_off[i]) + y * stride + N] = True
+    assert np.all(rec[~touched] == 1234), "the kernel wrote outside its blocks"

@@ -20,6 +20,10 @@
 #include "xh_common.h"
 #include "xh_internal.h"
 #include "xh_dct32.h"
+#include <cstdint>
+#ifndef XH_LDS
+#define XH_LDS __attribute__((address_space(3)))
+#endif
 #include <cstdlib>
 using namespace xh;
 
@@ -61,6 +65,59 @@ __global__ __launch_bounds__(256) void dct32_mfma_kernel(const int16_t* __restri
     }
 }
 
+// Inverse: one wavefront per TU; the coefficient block is read row by row (32 bytes per lane) and handed over through LDS so that every lane gets its column.
+__global__ __launch_bounds__(256) void idct32_mfma_kernel(const int16_t* __restrict__ src, const int32_t* __restrict__ sOff, int16_t* __restrict__ dst, intptr_t ds,
+                                                          const int32_t* __restrict__ dOff, int n)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_c[4][32 * 34];                        // rows of 34: the column reads of a wavefront spread over the banks
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5;
+    const int wavesTotal = gridDim.x * 4;
+    int tu = blockIdx.x * 4 + wave;
+    v4i tB1, tA2;
+    idct32_operands(r, g, tB1, tA2);
+    const int shift2 = 12 - (X265_DEPTH - 8), add2 = 1 << (shift2 - 1);
+    XH_LDS int16_t* tile = (XH_LDS int16_t*)s_c[wave];
+    for (; tu < n; tu += wavesTotal)
+    {
+        const int16_t* p = src + (sOff ? (intptr_t)sOff[tu] : (intptr_t)tu * 1024) + r * 32 + 16 * g;
+        int u[8];
+        if (((uintptr_t)p & 15) == 0)
+        {
+            const int4 u0 = *(const int4*)p, u1 = *(const int4*)(p + 8);
+            u[0] = u0.x; u[1] = u0.y; u[2] = u0.z; u[3] = u0.w; u[4] = u1.x; u[5] = u1.y; u[6] = u1.z; u[7] = u1.w;
+        }
+        else
+        {
+#pragma unroll
+            for (int q = 0; q < 8; q++) u[q] = (int)(((unsigned)(uint16_t)p[2 * q]) | ((unsigned)(uint16_t)p[2 * q + 1] << 16));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) *(XH_LDS int*)(tile + r * 34 + 16 * g + 2 * q) = u[q];
+        wave_sync();
+        int d[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+        {
+            const unsigned a = (uint16_t)tile[(16 * g + 2 * q) * 34 + r], b = (uint16_t)tile[(16 * g + 2 * q + 1) * 34 + r];
+            d[q] = (int)(a | (b << 16));
+        }
+        wave_sync();                                                                          // the next TU of this wavefront overwrites the tile
+        v16i acc;
+        idct32_inverse(d, tB1, tA2, acc);
+        int16_t* o = dst + (dOff ? (intptr_t)dOff[tu] : (intptr_t)tu * 1024) + (intptr_t)r * ds;
+#pragma unroll
+        for (int i4 = 0; i4 < 4; i4++)
+        {   // columns q(i,g) = 8 * i4 + 4 * g + (0 .. 3): four neighbours per step
+            int v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = min(max((acc[4 * i4 + e] + add2) >> shift2, -32768), 32767);
+            int16_t* q = o + 8 * i4 + 4 * g;
+            if (((uintptr_t)q & 7) == 0) { int2 w; w.x = __builtin_amdgcn_perm(v[1], v[0], 0x05040100); w.y = __builtin_amdgcn_perm(v[3], v[2], 0x05040100); *(int2*)q = w; }
+            else { q[0] = (int16_t)v[0]; q[1] = (int16_t)v[1]; q[2] = (int16_t)v[2]; q[3] = (int16_t)v[3]; }
+        }
+    }
+}
+
 } // namespace
 
 bool xh_dct32_mfma_enabled()
@@ -75,6 +132,15 @@ int xh_dct32_mfma(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t
     int blocks = (n + 3) / 4;
     if (blocks > 4096) blocks = 4096;       // grid-stride: constant operands are amortised over many TUs
     hipLaunchKernelGGL(dct32_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, ss, sOff, dst, dOff, n);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+int xh_idct32_mfma(hipStream_t st, const int16_t* src, const int32_t* sOff, int16_t* dst, intptr_t ds, const int32_t* dOff, int n)
+{
+    int blocks = (n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(idct32_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, sOff, dst, ds, dOff, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -86,4 +86,44 @@ __device__ __forceinline__ void dct32_forward(const int* d, const v4i& tB1, cons
     product<false>(lo, hi, bb, tA2, acc);
 }
 
+// ---- inverse 32x32 DCT (dct.cpp:242-416, 579-594): X = T^T C T with the reference's two rounding points --------------------------------------------------
+// stage 1  D1T[j][k] = sum_m C[m][j] T[m][k]  (the reference's first pass, stored transposed there too), rounded (v + 64) >> 7 and clipped to int16:
+//          A = C^T (lane: row j = r, k-slots m = 16g .. 16g+15 -> the lane needs a COLUMN of the coefficient block: one trip through LDS), B = T (lane: col k = r,
+//          k-slot m -> T[16g + s][r]).  C/D: lane holds col k = r, rows j(i,g) = (i & 3) + 8 * (i >> 2) + 4 * g.
+// stage 2  X[p][q] = sum_j D1T'[j][p] T[j][q]: the rounded stage-1 registers are the B operand as they stand (col p = r, k-slot i <-> j(i,g)); A = T^T with its
+//          k-slots in the same order (lane: row q = r, k-slot s -> T[j(s,g)][r]).  C/D: lane holds col p = r, rows q(i,g): row r of the residual block.
+__device__ __forceinline__ void idct32_operands(int r, int g, v4i& tB1, v4i& tA2)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        unsigned b1 = 0, a2 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            int s = 4 * q + e;
+            b1 |= ((unsigned)dct_coef(16 * g + s, r) & 0xFFu) << (8 * e);
+            a2 |= ((unsigned)dct_coef((s & 3) + 8 * (s >> 2) + 4 * g, r) & 0xFFu) << (8 * e);
+        }
+        tB1[q] = (int)b1; tA2[q] = (int)a2;
+    }
+}
+// d: the lane's column of the coefficient block, C[16g + s][r] for s = 0 .. 15 (two per dword).  Result: acc[i] = UNROUNDED stage-2 sum of X[r][q(i,g)];
+// the caller applies clip16((acc + add2) >> shift2), shift2 = 12 - (X265_DEPTH - 8).
+__device__ __forceinline__ void idct32_inverse(const int* d, const v4i& tB1, const v4i& tA2, v16i& acc)
+{
+    v4i lo, hi, bb;
+    split_planes(d, lo, hi, bb);
+    product<true>(lo, hi, bb, tB1, acc);
+    int t16[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+    {
+        const int v0 = min(max((acc[2 * q] + 64) >> 7, -32768), 32767), v1 = min(max((acc[2 * q + 1] + 64) >> 7, -32768), 32767);
+        t16[q] = __builtin_amdgcn_perm(v1, v0, 0x05040100);
+    }
+    split_planes(t16, lo, hi, bb);
+    product<false>(lo, hi, bb, tA2, acc);
+}
+
 } // namespace xh
