@@ -237,6 +237,26 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
             for (int i = lane; i < NN; i += 64)
                 sa[i] = (int16_t)clip3(-32768, 32767, (int32_t)((uint32_t)((int)sb[i] * scale) + (uint32_t)dqAdd) >> shift);
             wave_sync();
+            if constexpr (N == 32)
+            {   // both inverse stages on the matrix cores (xh_dct32.h): the lane's column of the dequantised block in, row r of the residual out
+                const int r = lane & 31, g = lane >> 5;
+                v4i tB1, tA2;
+                idct32_operands(r, g, tB1, tA2);
+                int d[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    d[q] = (int)((unsigned)(uint16_t)sa[(16 * g + 2 * q) * 32 + r] | ((unsigned)(uint16_t)sa[(16 * g + 2 * q + 1) * 32 + r] << 16));
+                v16i acc;
+                idct32_inverse(d, tB1, tA2, acc);
+                wave_sync();                                   // every lane has its column: sa becomes the residual
+                const int shift2 = 12 - (X265_DEPTH - 8);
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    sa[r * 32 + (i & 3) + 8 * (i >> 2) + 4 * g] = (int16_t)clip3(-32768, 32767, (acc[i] + (1 << (shift2 - 1))) >> shift2);
+                wave_sync();
+            }
+            else
+            {
             // inverse stage 1: sb[j*N + k] = clip16((sum_m M[m][k] * sa[m*N + j] + 64) >> 7)   (dct.cpp:242-416)
             for (int i = lane; i < NN; i += 64)
             {
@@ -270,6 +290,7 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
                 if (i < NN) sa[i] = (int16_t)resReg[e];
             }
             wave_sync();
+            }
         }
     }
     // recon = clip(pred + resid), SSE against the source (pixel.cpp:820-832, 167-186)
