@@ -177,6 +177,40 @@ def test_intra_cost_batch_matches_oracle(depth):
             assert np.array_equal(got[i], exp), "size %d CU %d" % (size, i)
 
 
+def test_dct16_pairs_on_the_matrix_cores(env):
+    """16x16 forward and inverse transforms run two TUs per 32x32x32 MFMA product (block-diagonal operands, csrc/xh_dct32.h): odd TU counts (a wavefront with one TU),
+    full-range int16 inputs, strided sources / destinations with odd offsets."""
+    depth, api, ora, rng = env
+    T = api.torch
+    N = 16
+    for n in (1, 2, 67):
+        stride = 40
+        off = (np.arange(n, dtype=np.int32) * (N * stride + 8) + (np.arange(n, dtype=np.int32) % 4)).astype(np.int32)
+        total = int(off[-1]) + N * stride + 8
+        src = rng.integers(-32768, 32768, total).astype(np.int16)
+        src[:N * stride] = -32768
+        d_src = api.to_device(src); d_off = api.to_device(off)
+        d_coef = T.full((n * N * N,), 77, dtype=T.int16, device="cuda")
+        api.h.check(api.lib.x265hip_transform_batch(api.stream(), 0, N, _dp(d_src), _IP(stride), _dp(d_off), _dp(d_coef), _IP(N), None, n))
+        coef_in = rng.integers(-32768, 32768, n * N * N).astype(np.int16)
+        coef_in[:N * N] = 32767
+        d_cin = api.to_device(coef_in)
+        d_rec = T.full((total,), 1234, dtype=T.int16, device="cuda")
+        api.h.check(api.lib.x265hip_transform_batch(api.stream(), 1, N, _dp(d_cin), _IP(N), None, _dp(d_rec), _IP(stride), _dp(d_off), n))
+        T.cuda.synchronize()
+        coef, rec = d_coef.cpu().numpy(), d_rec.cpu().numpy()
+        touched = np.zeros(total, bool)
+        for i in range(n):
+            blk = np.lib.stride_tricks.as_strided(src[int(off[i]):], shape=(N, N), strides=(stride * 2, 2))
+            assert np.array_equal(coef[i * N * N:(i + 1) * N * N], ora.dct(N, np.ascontiguousarray(blk).reshape(-1), N)), "forward TU %d of %d" % (i, n)
+            exp = ora.idct(N, coef_in[i * N * N:(i + 1) * N * N], np.zeros(N * N, np.int16), N).reshape(N, N)
+            got = np.lib.stride_tricks.as_strided(rec[int(off[i]):], shape=(N, N), strides=(stride * 2, 2))
+            assert np.array_equal(got, exp), "inverse TU %d of %d" % (i, n)
+            for y in range(N):
+                touched[int(off[i]) + y * stride:int(off[i]) + y * stride + N] = True
+        assert np.all(rec[~touched] == 1234), "the inverse kernel wrote outside its blocks"
+
+
 def test_idct32_on_the_matrix_cores_is_exact_for_every_int16(env):
     """The 32x32 inverse transform runs as two int8 MFMA products per stage (csrc/xh_dct32.h: three exact byte planes of an int16 operand): full-range coefficients incl.
     -32768 / 32767, sparse blocks, a strided destination with odd offsets -- all equal to the oracle (partialButterflyInverse32, dct.cpp:242-416, both clip16 points)."""

@@ -118,6 +118,106 @@ __global__ __launch_bounds__(256) void idct32_mfma_kernel(const int16_t* __restr
     }
 }
 
+// ---- 16x16: two TUs per wavefront pass (xh_dct32.h) ----
+__global__ __launch_bounds__(256) void dct16_mfma_kernel(const int16_t* __restrict__ src, intptr_t ss, const int32_t* __restrict__ sOff,
+                                                         int16_t* __restrict__ dst, const int32_t* __restrict__ dOff, int n)
+{
+    const int lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5, half = r >> 4;
+    const int pairsTotal = gridDim.x * 4, nPairs = (n + 1) >> 1;
+    v4i tB1, tA2;
+    dct16_operands(r, g, tB1, tA2);
+    for (int pair = blockIdx.x * 4 + (threadIdx.x >> 6); pair < nPairs; pair += pairsTotal)
+    {
+        const int tu = 2 * pair + half;
+        int d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (g == half && tu < n)
+        {
+            const int16_t* p = src + (sOff ? (intptr_t)sOff[tu] : (intptr_t)tu * 256) + (intptr_t)(r & 15) * ss;
+            if (((uintptr_t)p & 15) == 0)
+            {
+                const int4 u0 = *(const int4*)p, u1 = *(const int4*)(p + 8);
+                d[0] = u0.x; d[1] = u0.y; d[2] = u0.z; d[3] = u0.w; d[4] = u1.x; d[5] = u1.y; d[6] = u1.z; d[7] = u1.w;
+            }
+            else
+            {
+#pragma unroll
+                for (int q = 0; q < 8; q++) d[q] = (int)(((unsigned)(uint16_t)p[2 * q]) | ((unsigned)(uint16_t)p[2 * q + 1] << 16));
+            }
+        }
+        v16i acc;
+        dct16_forward(d, tB1, tA2, acc);
+        if (tu < n)
+        {
+            int16_t* o = dst + (dOff ? (intptr_t)dOff[tu] : (intptr_t)tu * 256);
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+            {
+                const int k = (i & 3) + 8 * (i >> 2) + 4 * g;
+                if ((k >> 4) == half) o[(k & 15) * 16 + (r & 15)] = (int16_t)((acc[i] + (1 << 9)) >> 10);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void idct16_mfma_kernel(const int16_t* __restrict__ src, const int32_t* __restrict__ sOff, int16_t* __restrict__ dst, intptr_t ds,
+                                                          const int32_t* __restrict__ dOff, int n)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_c[4][2][16 * 18];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5, half = r >> 4;
+    const int pairsTotal = gridDim.x * 4, nPairs = (n + 1) >> 1;
+    v4i tB1, tA2;
+    idct16_operands(r, g, tB1, tA2);
+    const int shift2 = 12 - (X265_DEPTH - 8), add2 = 1 << (shift2 - 1);
+    XH_LDS int16_t* tile = (XH_LDS int16_t*)s_c[wave][half];
+    for (int pair = blockIdx.x * 4 + wave; pair < nPairs; pair += pairsTotal)
+    {
+        const int tu = 2 * pair + half;
+        // the lanes with g == half bring in row (r & 15) of their TU; every lane of that TU then takes its column
+        if (g == half && tu < n)
+        {
+            const int16_t* p = src + (sOff ? (intptr_t)sOff[tu] : (intptr_t)tu * 256) + (r & 15) * 16;
+            int u[8];
+            if (((uintptr_t)p & 15) == 0)
+            {
+                const int4 u0 = *(const int4*)p, u1 = *(const int4*)(p + 8);
+                u[0] = u0.x; u[1] = u0.y; u[2] = u0.z; u[3] = u0.w; u[4] = u1.x; u[5] = u1.y; u[6] = u1.z; u[7] = u1.w;
+            }
+            else
+            {
+#pragma unroll
+                for (int q = 0; q < 8; q++) u[q] = (int)(((unsigned)(uint16_t)p[2 * q]) | ((unsigned)(uint16_t)p[2 * q + 1] << 16));
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) *(XH_LDS int*)(tile + (r & 15) * 18 + 2 * q) = u[q];
+        }
+        wave_sync();
+        int d[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (g == half && tu < n)
+        {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                d[q] = (int)((unsigned)(uint16_t)tile[(2 * q) * 18 + (r & 15)] | ((unsigned)(uint16_t)tile[(2 * q + 1) * 18 + (r & 15)] << 16));
+        }
+        wave_sync();
+        v16i acc;
+        idct16_inverse(d, tB1, tA2, acc);
+        if (tu < n)
+        {
+            int16_t* o = dst + (dOff ? (intptr_t)dOff[tu] : (intptr_t)tu * 256) + (intptr_t)(r & 15) * ds;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; i4++)
+            {   // columns q(i,g) = 8 * i4 + 4 * g + (0 .. 3): the lane's TU owns i4 = 2 * half, 2 * half + 1
+                if ((i4 >> 1) != half) continue;
+                int v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = min(max((acc[4 * i4 + e] + add2) >> shift2, -32768), 32767);
+                int16_t* q = o + ((8 * i4 + 4 * g) & 15);
+                if (((uintptr_t)q & 7) == 0) { int2 w; w.x = __builtin_amdgcn_perm(v[1], v[0], 0x05040100); w.y = __builtin_amdgcn_perm(v[3], v[2], 0x05040100); *(int2*)q = w; }
+                else { q[0] = (int16_t)v[0]; q[1] = (int16_t)v[1]; q[2] = (int16_t)v[2]; q[3] = (int16_t)v[3]; }
+            }
+        }
+    }
+}
+
 } // namespace
 
 bool xh_dct32_mfma_enabled()
@@ -141,6 +241,23 @@ int xh_idct32_mfma(hipStream_t st, const int16_t* src, const int32_t* sOff, int1
     int blocks = (n + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(idct32_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, sOff, dst, ds, dOff, n);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+int xh_dct16_mfma(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t* sOff, int16_t* dst, const int32_t* dOff, int n)
+{
+    int blocks = ((n + 1) / 2 + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dct16_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, ss, sOff, dst, dOff, n);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+int xh_idct16_mfma(hipStream_t st, const int16_t* src, const int32_t* sOff, int16_t* dst, intptr_t ds, const int32_t* dOff, int n)
+{
+    int blocks = ((n + 1) / 2 + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(idct16_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, sOff, dst, ds, dOff, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -282,7 +282,9 @@ extern "C" int x265hip_transform_batch(void* stream, int op, int N, const int16_
     {
     case 4: return f ? launch_tr<4, X265HIP_TR_DCT>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n) : launch_tr<4, X265HIP_TR_IDCT>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n);
     case 8: return f ? launch_tr<8, X265HIP_TR_DCT>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n) : launch_tr<8, X265HIP_TR_IDCT>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n);
-    case 16: return f ? launch_tr<16, X265HIP_TR_DCT>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n) : launch_tr<16, X265HIP_TR_IDCT>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n);
+    case 16:
+        if (xh_dct32_mfma_enabled()) return f ? xh_dct16_mfma(st, src, srcStride, srcOff, dst, dstOff, n) : xh_idct16_mfma(st, src, srcOff, dst, dstStride, dstOff, n);
+        return f ? launch_tr<16, X265HIP_TR_DCT>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n) : launch_tr<16, X265HIP_TR_IDCT>(st, src, srcStride, srcOff, dst, dstStride, dstOff, n);
     case 32:
         if (f && xh_dct32_mfma_enabled()) return xh_dct32_mfma(st, src, srcStride, srcOff, dst, dstOff, n);
         if (!f && xh_dct32_mfma_enabled()) return xh_idct32_mfma(st, src, srcOff, dst, dstStride, dstOff, n);

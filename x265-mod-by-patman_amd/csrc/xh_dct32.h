@@ -126,4 +126,66 @@ __device__ __forceinline__ void idct32_inverse(const int* d, const v4i& tB1, con
     product<false>(lo, hi, bb, tA2, acc);
 }
 
+// ---- 16x16 transforms on the same instruction: TWO TUs per 32x32x32 product, as the diagonal blocks of block-diagonal operands (rows / columns 0..15 = the first
+// TU, 16..31 = the second; the off-diagonal blocks are exact zeros in, exact zeros out -- rounding keeps them zero).  A quarter of the multiplier array does useful work;
+// the kernels are bound by memory either way.  T16[k][m] = dct_coef(2k, m).
+// lane (r, g): `mine` = the half of the k-slots (16g .. 16g+15) that belongs to the lane's TU (r >> 4).
+__device__ __forceinline__ void dct16_operands(int r, int g, v4i& tB1, v4i& tA2)
+{
+    const bool mine = g == (r >> 4);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        unsigned b1 = 0, a2 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            const int s = 4 * q + e, n = (s & 3) + 8 * (s >> 2) + 4 * g;
+            if (mine) b1 |= ((unsigned)dct_coef(2 * (r & 15), s) & 0xFFu) << (8 * e);                        // stage-1 B = T16^T: col j = r, k-slot m = s
+            if ((n >> 4) == (r >> 4)) a2 |= ((unsigned)dct_coef(2 * (r & 15), n & 15) & 0xFFu) << (8 * e);    // stage-2 A = T16: row k = r, k-slot n(s,g)
+        }
+        tB1[q] = (int)b1; tA2[q] = (int)a2;
+    }
+}
+__device__ __forceinline__ void idct16_operands(int r, int g, v4i& tB1, v4i& tA2)
+{
+    const bool mine = g == (r >> 4);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        unsigned b1 = 0, a2 = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            const int s = 4 * q + e, j = (s & 3) + 8 * (s >> 2) + 4 * g;
+            if (mine) b1 |= ((unsigned)dct_coef(2 * s, r & 15) & 0xFFu) << (8 * e);                            // stage-1 B = T16: col k = r, k-slot m = s
+            if ((j >> 4) == (r >> 4)) a2 |= ((unsigned)dct_coef(2 * (j & 15), r & 15) & 0xFFu) << (8 * e);    // stage-2 A = T16^T: row q = r, k-slot j(s,g)
+        }
+        tB1[q] = (int)b1; tA2[q] = (int)a2;
+    }
+}
+// d: forward -- row (r & 15) of the lane's TU (zeros on the lanes whose k-slots are not the TU's); acc[i] = unrounded stage-2 sum of coefficient (k(i,g) & 15, r & 15)
+// of TU r >> 4, valid where k(i,g) >> 4 == r >> 4; the caller applies (acc + (1 << 9)) >> 10 (dct.cpp:528-543).
+__device__ __forceinline__ void dct16_forward(const int* d, const v4i& tB1, const v4i& tA2, v16i& acc)
+{
+    const int shift1 = 3 + X265_DEPTH - 8, add1 = 1 << (shift1 - 1);
+    v4i lo, hi, bb;
+    split_planes(d, lo, hi, bb);
+    product<true>(lo, hi, bb, tB1, acc);
+    int t16[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+    {
+        const int v0 = (acc[2 * q] + add1) >> shift1, v1 = (acc[2 * q + 1] + add1) >> shift1;
+        t16[q] = __builtin_amdgcn_perm(v1, v0, 0x05040100);
+    }
+    split_planes(t16, lo, hi, bb);
+    product<false>(lo, hi, bb, tA2, acc);
+}
+// d: inverse -- column (r & 15) of the lane's TU's coefficient block (zeros on the other lanes); acc[i] = unrounded stage-2 sum of residual (r & 15, q(i,g) & 15)
+__device__ __forceinline__ void idct16_inverse(const int* d, const v4i& tB1, const v4i& tA2, v16i& acc)
+{
+    idct32_inverse(d, tB1, tA2, acc);                  // the same two products and the same rounding / clipping between them
+}
+
 } // namespace xh

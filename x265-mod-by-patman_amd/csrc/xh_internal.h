@@ -9,5 +9,7 @@ int xh_denoise(hipStream_t st, int16_t* coef, uint32_t* resSum, const uint16_t* 
 // 32x32 forward DCT: MFMA (i8 x i8 -> i32, two byte planes) and VALU/LDS variants
 bool xh_dct32_mfma_enabled();
 int xh_dct32_mfma(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t* sOff, int16_t* dst, const int32_t* dOff, int n);
+int xh_dct16_mfma(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t* sOff, int16_t* dst, const int32_t* dOff, int n);
+int xh_idct16_mfma(hipStream_t st, const int16_t* src, const int32_t* sOff, int16_t* dst, intptr_t ds, const int32_t* dOff, int n);
 int xh_idct32_mfma(hipStream_t st, const int16_t* src, const int32_t* sOff, int16_t* dst, intptr_t ds, const int32_t* dOff, int n);
 int xh_dct32_valu(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t* sOff, int16_t* dst, const int32_t* dOff, int n);
