@@ -10,10 +10,10 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run(depth, preset, kind, **env):
+def run(depth, preset, kind, extra=(), **env):
     e = dict(os.environ)
     e.update(env)
-    r = subprocess.run([sys.executable, os.path.join(HERE, "tme_producer_run.py"), str(depth), preset, kind], capture_output=True, text=True, env=e, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "tme_producer_run.py"), str(depth), preset, kind] + [str(x) for x in extra], capture_output=True, text=True, env=e, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("table ")][-1].split()
     return line[1], int(line[2]), int(line[3])
@@ -30,3 +30,13 @@ def test_chain_kernels_write_the_table_of_the_launch_path(depth, preset, kind):
         assert chains[2] > 0, "no bidirectional record in a B picture"
     assert chains == launches, "chain kernels %s != launch path %s" % (chains, launches)
     assert packed == launches, "packed chain kernels %s != launch path %s" % (packed, launches)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,preset,kind,method,merange", [(8, "slow", "P", 0, 57),      # DIA
+                                                              (10, "medium", "B", 5, 5),    # FULL (a small window: every position is costed)
+                                                              (8, "medium", "P", 2, 24)])   # UMH: no chain kernels, the launch path either way (the rows build of the UMH kernels)
+def test_other_search_methods_through_the_producer(depth, preset, kind, method, merange):
+    chains = run(depth, preset, kind, extra=(method, merange))
+    launches = run(depth, preset, kind, extra=(method, merange), X265HIP_TME_LAUNCHES="1")
+    assert chains[1] > 1000 and chains == launches, "method %d: %s != %s" % (method, chains, launches)

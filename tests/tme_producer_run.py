@@ -1,5 +1,5 @@
 """Helper of test_tme_producer_gpu.py: one picture through x265hip_tme_picture on synthetic planes, prints the SHA-1 of the table.  Run as a script so that the switches
-the library reads once (X265HIP_TME_LAUNCHES, X265HIP_TME_PACKED) can differ between runs.   python tests/tme_producer_run.py depth preset P|B"""
+the library reads once (X265HIP_TME_LAUNCHES, X265HIP_TME_PACKED) can differ between runs.   python tests/tme_producer_run.py depth preset P|B [method merange]"""
 import ctypes as C
 import hashlib
 import importlib
@@ -27,12 +27,15 @@ def main():
     cur = np.clip(np.roll(ref0, (3, -5), axis=(0, 1)) + rng.integers(-4, 5, ref0.shape), 0, (1 << depth) - 1)
     ref0, ref1, cur = (np.ascontiguousarray(a.astype(dt)).reshape(-1) for a in (ref0, ref1, cur))
     rect, amp, method, subme = {"medium": (False, False, 1, 2), "slow": (True, True, 3, 3)}[preset]
+    merange = 57
+    if len(sys.argv) > 5:
+        method, merange = int(sys.argv[4]), int(sys.argv[5])
     prod = TmeProducer(lib, W, H, 64, 8, rect, amp)
     table = prod.empty_table()
     if kind == "P":
-        prod.picture(cur, [[ref0, ref1], []], stride, margin * stride + margin, table, method=method, subme=subme, cur_poc=2, ref_pocs=((1, 0), ()))
+        prod.picture(cur, [[ref0, ref1], []], stride, margin * stride + margin, table, method=method, subme=subme, merange=merange, cur_poc=2, ref_pocs=((1, 0), ()))
     else:
-        prod.picture(cur, [[ref0], [ref1]], stride, margin * stride + margin, table, is_p=False, method=method, subme=subme, cur_poc=1, ref_pocs=((0,), (2,)))
+        prod.picture(cur, [[ref0], [ref1]], stride, margin * stride + margin, table, is_p=False, method=method, subme=subme, merange=merange, cur_poc=1, ref_pocs=((0,), (2,)))
     used = int((table["ref"] >= 0).any(axis=1).sum())
     bi = int(((table["ref"][:, 0] >= 0) & (table["ref"][:, 1] >= 0)).sum())
     prod.close()
