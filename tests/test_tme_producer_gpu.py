@@ -35,7 +35,7 @@ def test_chain_kernels_write_the_table_of_the_launch_path(depth, preset, kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("depth,preset,kind,method,merange", [(8, "slow", "P", 0, 57),      # DIA
                                                               (10, "medium", "B", 5, 5),    # FULL (a small window: every position is costed)
-                                                              (8, "medium", "P", 2, 24)])   # UMH: no chain kernels, the launch path either way (the rows build of the UMH kernels)
+                                                              (8, "medium", "P", 2, 24)])   # UMH
 def test_other_search_methods_through_the_producer(depth, preset, kind, method, merange):
     chains = run(depth, preset, kind, extra=(method, merange))
     launches = run(depth, preset, kind, extra=(method, merange), X265HIP_TME_LAUNCHES="1")

@@ -175,7 +175,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
     }
     hipStream_t mainStream = (hipStream_t)stream;
     static const bool launches = getenv("X265HIP_TME_LAUNCHES") != nullptr;             // A/B switch: every stage of every entry its own launch (below)
-    if (!launches && (a->searchMethod == X265HIP_ME_DIA || a->searchMethod == X265HIP_ME_HEX || a->searchMethod == X265HIP_ME_STAR || a->searchMethod == X265HIP_ME_FULL))
+    if (!launches && (a->searchMethod == X265HIP_ME_DIA || a->searchMethod == X265HIP_ME_HEX || a->searchMethod == X265HIP_ME_STAR || a->searchMethod == X265HIP_ME_FULL || a->searchMethod == X265HIP_ME_UMH))
     {   // ---- the chains inside the kernels (tme_chain.inc): one launch per kernel configuration, side by side on their own streams ----
         ChainStreams* side = chain_streams(mainStream);                                 // one set per caller's stream, whichever thread calls
         if (!side) { set_error("tme_frame: could not create the chain streams"); return X265HIP_EDEVICE; }
@@ -224,7 +224,8 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
             }
             if (!nKeys) continue;
             XH_HIP(hipStreamWaitEvent(cs[config], cFork, 0));
-            const int rc = a->searchMethod == X265HIP_ME_STAR ? xh_tme_chain_star(cs[config], config, &A, nKeys) : xh_tme_chain_hex(cs[config], config, &A, nKeys);
+            const int rc = a->searchMethod == X265HIP_ME_STAR ? xh_tme_chain_star(cs[config], config, &A, nKeys) : a->searchMethod == X265HIP_ME_UMH ? xh_tme_chain_umh(cs[config], config, &A, nKeys)
+                                                              : xh_tme_chain_hex(cs[config], config, &A, nKeys);
             if (rc) return rc;
             XH_HIP(hipEventRecord(cJoin[config], cs[config]));
             XH_HIP(hipStreamWaitEvent(mainStream, cJoin[config], 0));

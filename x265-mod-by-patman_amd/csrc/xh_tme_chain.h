@@ -41,3 +41,4 @@ inline int xh_chain_config(int cuSize, int part)
 }
 int xh_tme_chain_hex(void* stream, int config, const xh_chain_args* args, int nKeys);     // DIA / HEX / FULL
 int xh_tme_chain_star(void* stream, int config, const xh_chain_args* args, int nKeys);    // STAR
+int xh_tme_chain_umh(void* stream, int config, const xh_chain_args* args, int nKeys);     // UMH
