@@ -56,7 +56,7 @@ static struct Api
 static x265hip_ctx* g_ctx;
 static x265hip_tme* g_tme;
 static int g_useGpu = 1, g_pictures, g_weighted, g_keepPlanes = 1;
-static double g_gpuSeconds;
+static double g_gpuSeconds, g_pictureSeconds;      /* inside x265hip_tme_picture; the whole producer call incl. the adapter's harvest and write-back */
 static std::mutex g_lock;
 static std::map<const Frame*, int> g_done;          /* picture -> POC + 1 whose table is complete */
 
@@ -265,7 +265,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     auto it = g_done.find(&frame);
     if (it != g_done.end() && it->second == poc + 1) return;              /* this picture's table is there already */
     m_slice = ctu.m_slice; m_frame = &frame; m_param = m_frame->m_param;  /* as the reference's body starts (analysis.cpp:250-252) */
-    if (run_picture(*this, cuGeom, frame)) exit(3);
+    { const auto tp0 = std::chrono::steady_clock::now(); if (run_picture(*this, cuGeom, frame)) exit(3); g_pictureSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count(); }
     g_done[&frame] = poc + 1;
 }
 }
@@ -354,7 +354,7 @@ int main(int argc, char** argv)
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(out);
     if (g_tme && g_api.tme_destroy) { g_api.tme_destroy(g_tme); g_tme = nullptr; }
-    printf("{\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f}\n",
-           g_useGpu ? "gpu" : "cpu", g_weighted, frames, secs, frames / secs, bytes, tme, g_pictures, g_gpuSeconds);
+    printf("{\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f}\n",
+           g_useGpu ? "gpu" : "cpu", g_weighted, frames, secs, frames / secs, bytes, tme, g_pictures, g_gpuSeconds, g_pictureSeconds);
     return 0;
 }
