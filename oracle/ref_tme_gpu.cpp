@@ -153,6 +153,12 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
     }
     const x265hip_tme_step* steps; const int nS = g_api.tme_entries(g_tme, &steps);
     const int nl = slice->isInterP() ? 1 : 2;
+    std::vector<int> used;                                         /* the MEData slots of a CTU the schedule writes (and reads) */
+    {
+        std::vector<char> mark(593, 0);
+        for (int k = 0; k < nS; k++) for (int pi = 0; pi < steps[k].numPart; pi++) { const int sl = steps[k].finalIdx + pi * steps[k].puOffset; if (sl >= 0 && sl < 593) mark[sl] = 1; }
+        for (int sl = 0; sl < 593; sl++) if (mark[sl]) used.push_back(sl);
+    }
     x265hip_tme_picture_desc d;
     memset(&d, 0, sizeof(d));
     d.isP = slice->isInterP(); d.numRef[0] = slice->m_numRefIdx[0]; d.numRef[1] = nl > 1 ? slice->m_numRefIdx[1] : 0; d.curPOC = slice->m_poc;
@@ -223,11 +229,12 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
             const Frame* rf = slice->m_refFrameList[l][r];
             R.reconKey = g_keepPlanes ? (uint64_t)rf->m_encodeOrder + 1 : 0;      /* a finished picture: its planes stay on the device for the pictures that reference it */
             if (rf->m_encData->m_slice->m_sliceType != I_SLICE)
-            {
+            {   /* only the slots the schedule names are ever read */
                 refTables.emplace_back((size_t)nCtu * 593);
                 const MEData* src = rf->m_encData->m_slice->m_ctuMV;
-                for (size_t i = 0; i < refTables.back().size(); i++) to_choice(src[i], refTables.back()[i]);
-                R.refTable = refTables.back().data();
+                x265hip_inter_choice* o = refTables.back().data();
+                for (int c = 0; c < nCtu; c++) for (int sl : used) to_choice(src[(size_t)c * 593 + sl], o[(size_t)c * 593 + sl]);
+                R.refTable = o;
             }
             const int diffPoc = abs(slice->m_poc - slice->m_refPOCList[l][r]);
             if (diffPoc <= p->bframes + 1)
@@ -244,12 +251,12 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
         }
     std::vector<x265hip_inter_choice> table((size_t)nCtu * 593);
     MEData* dst = frame.m_encData->m_slice->m_ctuMV;
-    for (size_t i = 0; i < table.size(); i++) to_choice(dst[i], table[i]);
+    for (int c = 0; c < nCtu; c++) for (int sl : used) to_choice(dst[(size_t)c * 593 + sl], table[(size_t)c * 593 + sl]);
     d.table = table.data();
     const auto t0 = std::chrono::steady_clock::now();
     { const int rc = g_api.tme_picture(g_tme, &d); if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", slice->m_poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; } }
     g_gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    for (size_t i = 0; i < table.size(); i++) from_choice(table[i], dst[i]);
+    for (int c = 0; c < nCtu; c++) for (int sl : used) from_choice(table[(size_t)c * 593 + sl], dst[(size_t)c * 593 + sl]);
     g_pictures++;
     return 0;
 }
