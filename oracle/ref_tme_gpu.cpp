@@ -106,11 +106,12 @@ struct Harvest
             }
         }
         CUData& cu = an.m_modeDepth[geom.depth].pred[Analysis::PRED_2Nx2N].cu;
+        bool inited = false;
         while (k < nSteps && steps[k].cuSize == (int)cuSize && steps[k].cuX == (int)g_zscanToPelX[geom.absPartIdx] && steps[k].cuY == (int)g_zscanToPelY[geom.absPartIdx])
         {
             const x265hip_tme_step& e = steps[k];
             entryQp[(size_t)ctuAddr * nSteps + k] = qp;
-            cu.initSubCU(ctu, geom, qp);
+            if (!inited) { cu.initSubCU(ctu, geom, qp); inited = true; }          /* once per CU: the entries of a CU differ in the partition size only */
             cu.setPartSizeSubParts((PartSize)e.part);
             for (int pi = 0; pi < e.numPart; pi++)
             {
