@@ -56,6 +56,7 @@ static struct Api
 static x265hip_ctx* g_ctx;
 static x265hip_tme* g_tme;
 static int g_useGpu = 1, g_pictures, g_weighted, g_keepPlanes = 1;
+static double g_sec[4];      /* adapter sections: CTU set-up + area qps, the entry walk (qps, collocated neighbours), medians, references + tables */
 static double g_gpuSeconds, g_pictureSeconds;      /* inside x265hip_tme_picture; the whole producer call incl. the adapter's harvest and write-back */
 static std::mutex g_lock;
 static std::map<const Frame*, int> g_done;          /* picture -> POC + 1 whose table is complete */
@@ -171,12 +172,14 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
     d.curPlane = fenc->m_picBuf[0]; d.stride = fenc->m_stride; d.origin = fenc->m_picOrg[0] - fenc->m_picBuf[0];
     d.planeElems = (int64_t)fenc->m_stride * (fenc->m_picHeight + 2 * fenc->m_lumaMarginY);
     /* per CTU: what findJob sets up before the call (threadedme.cpp:238-246), then the harvest */
-    std::vector<x265hip_tme_temporal> temporal((size_t)nCtu * nS * 2);
-    std::vector<int> entryQp((size_t)nCtu * nS), areaQp((size_t)nCtu * 5);
-    std::vector<int16_t> median((size_t)nCtu * 2 * 4 * 3, 0);
+    /* buffers kept across pictures (the call runs under g_lock): fresh 10 MB vectors per picture cost more in page faults than the work on them */
+    static std::vector<x265hip_tme_temporal> temporal; static std::vector<int> entryQp, areaQp; static std::vector<int16_t> median;
+    temporal.resize((size_t)nCtu * nS * 2); entryQp.resize((size_t)nCtu * nS); areaQp.resize((size_t)nCtu * 5); median.assign((size_t)nCtu * 2 * 4 * 3, 0);
     const Frame* colPic = slice->m_refFrameList[slice->isInterB() && !slice->m_colFromL0Flag][slice->m_colRefIdx];
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (int c = 0; c < nCtu; c++)
     {
+        double ts = now();
         CUData* ctu = frame.m_encData->getPicCTU(c);
         ctu->m_slice = frame.m_encData->m_slice;
         const int row = c / nCtuX, col = c % nCtuX;
@@ -186,8 +189,10 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
         areaQp[c * 5] = rawBase;
         for (int sub = 0; sub < 4; sub++)
             areaQp[c * 5 + 1 + sub] = slice->m_pps->bUseDQP ? an.calculateQpforCuSize(*ctu, *(&ctuGeom + ctuGeom.childOffset + sub)) : slice->m_sliceQp;
+        g_sec[0] += now() - ts; ts = now();
         Harvest h{ an, slice, frame, steps, nS, temporal, entryQp, c, 0 };
         h.walk(*ctu, ctuGeom, x265_clip3(QP_MIN, QP_MAX_SPEC, rawBase));
+        g_sec[1] += now() - ts; ts = now();
         if (h.k != nS) { fprintf(stderr, "schedule mismatch: %d of %d entries\n", h.k, nS); return -1; }
         const CUData* colCU = colPic->m_encData->getPicCTU(c);
         for (int l = 0; l < nl; l++)
@@ -196,12 +201,15 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
                 MV m;
                 if (ctu->getMedianColMV(colCU, colPic, l, r, m)) { int16_t* o = &median[(((size_t)c * 2 + l) * 4 + r) * 3]; o[0] = 1; o[1] = (int16_t)m.x; o[2] = (int16_t)m.y; }
             }
+        g_sec[2] += now() - ts;
     }
+    const double tRefs = now();
     /* the distinct qps */
     std::vector<int> qps;
     auto qidx = [&](int qp) { if (qp > QP_MAX_SPEC) { fprintf(stderr, "qp %d above 51: not handled\n", qp); exit(3); }
                               for (size_t i = 0; i < qps.size(); i++) if (qps[i] == qp) return (int)i; qps.push_back(qp); return (int)qps.size() - 1; };
-    std::vector<uint8_t> qpIndex(entryQp.size()), areaQpIndex(areaQp.size());
+    static std::vector<uint8_t> qpIndex, areaQpIndex;
+    qpIndex.resize(entryQp.size()); areaQpIndex.resize(areaQp.size());
     for (size_t i = 0; i < entryQp.size(); i++) qpIndex[i] = (uint8_t)qidx(entryQp[i]);
     for (size_t i = 0; i < areaQp.size(); i++) areaQpIndex[i] = (uint8_t)qidx(areaQp[i]);
     if (qps.size() > 64) { fprintf(stderr, "more than 64 distinct qps\n"); return -1; }
@@ -209,9 +217,9 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
     for (int i = 0; i < d.nQp; i++) d.qps[i] = qps[i];
     d.qpIndex = qpIndex.data(); d.areaQpIndex = areaQpIndex.data(); d.temporal = temporal.data(); d.median = median.data();
     /* references: planes, their own tables, the lookahead's MVs */
-    std::vector<std::vector<x265hip_inter_choice>> refTables;
-    std::vector<std::vector<int16_t>> lowres;
-    refTables.reserve(8); lowres.reserve(8);
+    static std::vector<std::vector<x265hip_inter_choice>> refTables(8);
+    static std::vector<std::vector<int16_t>> lowres(8);
+    int nRefTables = 0, nLowres = 0;
     d.lowresBlocksX = frame.m_lowres.maxBlocksInRow;
     for (int l = 0; l < nl; l++)
         for (int r = 0; r < slice->m_numRefIdx[l]; r++)
@@ -231,9 +239,10 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
             R.reconKey = g_keepPlanes ? (uint64_t)rf->m_encodeOrder + 1 : 0;      /* a finished picture: its planes stay on the device for the pictures that reference it */
             if (rf->m_encData->m_slice->m_sliceType != I_SLICE)
             {   /* only the slots the schedule names are ever read */
-                refTables.emplace_back((size_t)nCtu * 593);
+                std::vector<x265hip_inter_choice>& rt = refTables[nRefTables++];
+                rt.resize((size_t)nCtu * 593);
                 const MEData* src = rf->m_encData->m_slice->m_ctuMV;
-                x265hip_inter_choice* o = refTables.back().data();
+                x265hip_inter_choice* o = rt.data();
                 for (int c = 0; c < nCtu; c++) for (int sl : used) to_choice(src[(size_t)c * 593 + sl], o[(size_t)c * 593 + sl]);
                 R.refTable = o;
             }
@@ -244,16 +253,19 @@ int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
                 if (mvs[0].x != 0x7FFF)
                 {
                     const size_t nb = (size_t)frame.m_lowres.maxBlocksInRow * ((H + 15) / 16);
-                    lowres.emplace_back(nb * 2);
-                    for (size_t i = 0; i < nb; i++) { lowres.back()[2 * i] = (int16_t)mvs[i].x; lowres.back()[2 * i + 1] = (int16_t)mvs[i].y; }
-                    R.lowresMv = lowres.back().data();
+                    std::vector<int16_t>& lm = lowres[nLowres++];
+                    lm.resize(nb * 2);
+                    for (size_t i = 0; i < nb; i++) { lm[2 * i] = (int16_t)mvs[i].x; lm[2 * i + 1] = (int16_t)mvs[i].y; }
+                    R.lowresMv = lm.data();
                 }
             }
         }
-    std::vector<x265hip_inter_choice> table((size_t)nCtu * 593);
+    static std::vector<x265hip_inter_choice> table;
+    table.resize((size_t)nCtu * 593);
     MEData* dst = frame.m_encData->m_slice->m_ctuMV;
     for (int c = 0; c < nCtu; c++) for (int sl : used) to_choice(dst[(size_t)c * 593 + sl], table[(size_t)c * 593 + sl]);
     d.table = table.data();
+    g_sec[3] += now() - tRefs;
     const auto t0 = std::chrono::steady_clock::now();
     { const int rc = g_api.tme_picture(g_tme, &d); if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", slice->m_poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; } }
     g_gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -362,7 +374,7 @@ int main(int argc, char** argv)
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(out);
     if (g_tme && g_api.tme_destroy) { g_api.tme_destroy(g_tme); g_tme = nullptr; }
-    printf("{\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f}\n",
-           g_useGpu ? "gpu" : "cpu", g_weighted, frames, secs, frames / secs, bytes, tme, g_pictures, g_gpuSeconds, g_pictureSeconds);
+    printf("{\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
+           g_useGpu ? "gpu" : "cpu", g_weighted, frames, secs, frames / secs, bytes, tme, g_pictures, g_gpuSeconds, g_pictureSeconds, g_sec[0], g_sec[1], g_sec[2], g_sec[3]);
     return 0;
 }
