@@ -58,6 +58,8 @@ def parse():
                     "pyramid, x265hip_inter_merge_batch chooses per PU, the TQ stage compensates from the chosen reference.  value stays Mpixels/s of SOURCE pixels")
     ap.add_argument("--rect", action="store_true", help="also search the 2NxN / Nx2N PUs of every CU (bEnableRectInter, preset slow and up): 425 PUs per CTU instead of 85; one reference")
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
+    ap.add_argument("--splits", type=int, default=1, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
+    ap.add_argument("--skew", type=int, default=1, help="with --splits: stream s is issued this many stages behind stream s - 1")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
     ap.add_argument("--overlap-tq", action="store_true", help="launch the TQ kernel beside me16/me8 on a side stream (it needs the me32 MVs only); measured gain 2 %, off by default so that per-kernel durations are those of kernels that own the GPU")
@@ -66,6 +68,7 @@ def parse():
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-dry-run", action="store_true", help="launcher / bookkeeping check without a GPU: gloo ranks, a sleep in place of the step (tests/test_sharding.py); prints a line marked data=dry-run")
     ap.add_argument("--no-tme", action="store_true", help="skip the ThreadedME producer leg (x265hip_tme_picture on synthetic 1080p pictures: medium- and slow-like partition sets); reported under \"tme_producer\", not part of value")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the live end-to-end leg (reference encoder, 1920x1088 medium, CPU producer vs GPU producer of the MEData tables, ~20 s); reported under \"e2e_fps\"")
     ap.add_argument("--filters", action="store_true", help="also time the in-loop filter chain after reconstruction (deblock, SAO statistics, SAO apply, SSIM, SSD) on 8 coded 1080p pictures; reported under \"filters\", not part of value")
     return ap.parse_args()
 
@@ -90,7 +93,8 @@ def tme_producer_leg(depth):
     cur = np.clip(np.roll(ref, (3, -5), axis=(0, 1)).astype(np.int32) + rng.integers(-4, 5, ref.shape), 0, (1 << depth) - 1).astype(dt)
     ref, cur = np.ascontiguousarray(ref).reshape(-1), np.ascontiguousarray(cur).reshape(-1)
     out = {"unit": "ms per picture", "picture": "%dx%d P picture, 1 reference, host planes in / host table out" % (W, H), "presets": {}}
-    for name, rect, amp, method, subme in (("medium", False, False, 1, 2), ("slow", True, True, 3, 3)):
+    # preset medium: 85 entries per CTU, HEX, subme 2; preset slow: rect but no AMP (param.cpp:572-587), STAR, subme 3; preset slower adds AMP and subme 4 (param.cpp:588-608)
+    for name, rect, amp, method, subme in (("medium", False, False, 1, 2), ("slow", True, False, 3, 3), ("slower", True, True, 3, 4)):
         prod = TmeProducer(lib, W, H, 64, 8, rect, amp)
         try:
             table = prod.empty_table()
@@ -145,6 +149,37 @@ def tme_producer_leg(depth):
             for p in prods:
                 p.close()
     return out
+
+
+def e2e_fps_leg(frames=8):
+    """BASELINE's M2 measured in THIS run: the reference encoder (oracle/_ref/x265tmegpu_8 = all of source/common + source/encoder compiled from where they lie, C
+    primitives, no asm; it travels with the repository) on BASELINE configs[1] -- 1920x1088 8-bit, preset medium with the preset's own defaults, --threaded-me -- once
+    with its own CPU producer of the MEData tables and once with x265hip_tme_picture as the producer (integration/tme_adapter.cpp).  Both runs must write the same bitstream.
+    None when the binary is not there (then the committed figure of profiles/e2e_fps.json is reported, labelled as such)."""
+    import hashlib, subprocess, tempfile
+    import x265hip
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265tmegpu_8")
+    if not os.path.exists(exe):
+        return None
+    runs = {}
+    with tempfile.TemporaryDirectory() as td:
+        for prod in ("cpu", "gpu"):
+            outp = os.path.join(td, prod + ".hevc")
+            env = dict(os.environ, X265TMEGPU="1" if prod == "gpu" else "0", MALLOC_PERTURB_="85")
+            r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(frames), "medium", outp], capture_output=True, text=True, env=env, timeout=600)
+            if r.returncode != 0:
+                return {"measured": "this run: FAILED", "producer": prod, "stderr": r.stderr[-500:]}
+            info = json.loads(r.stdout.strip().splitlines()[-1])
+            info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
+            runs[prod] = info
+    g, c = runs["gpu"], runs["cpu"]
+    return {"value": g["fps"], "unit": "frames/s", "measured": "this run",
+            "config": "BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults (ref=3, weightp, bframes=4), --threaded-me, %d frames" % frames,
+            "host": "the reference encoder with C primitives (no asm; no nasm on this box) -- its RDO bounds the encode; the MEData tables come from x265hip_tme_picture (integration/tme_adapter.cpp)",
+            "same_encoder_cpu_producer_fps": c["fps"], "bitstream_identical": g["md5"] == c["md5"] and g["bytes"] == c["bytes"], "bytes": g["bytes"],
+            "gpu_pictures": g["gpu_pictures"], "producer_seconds": g["gpu_seconds"], "adapter_seconds": g["adapter_seconds"], "adapter_sections_s": g["adapter_sections"],
+            "producer_ms_per_picture": round(1e3 * g["gpu_seconds"] / max(1, g["gpu_pictures"]), 2),
+            "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"]) / max(1, g["gpu_pictures"]), 2)}
 
 
 def filters_leg(depth, steps):
@@ -743,6 +778,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    pipe.splits, pipe.skew = args.splits, args.skew
     for _ in range(args.warmup):
         pipe.step()
     barrier()
@@ -806,7 +842,12 @@ def main():
             "e2e_fps": None,
         }
         e2e_path = os.path.join(ROOT, "profiles", "e2e_fps.json")
-        if os.path.exists(e2e_path):
+        if not args.no_e2e:
+            try:
+                out["e2e_fps"] = e2e_fps_leg()
+            except Exception as ex:                  # the leg runs an external binary: a failure there must not lose the line
+                out["e2e_fps"] = {"measured": "this run: FAILED", "error": repr(ex)[:300]}
+        if out["e2e_fps"] is None and os.path.exists(e2e_path):
             try:
                 out["e2e_fps"] = json.load(open(e2e_path))
             except Exception:

@@ -31,6 +31,9 @@ int   x265hip_ctx_create(int device, x265hip_ctx** ctx);
 void  x265hip_ctx_destroy(x265hip_ctx* ctx);
 void* x265hip_ctx_stream(x265hip_ctx* ctx);          /* hipStream_t: every call on this context is ordered on it */
 int   x265hip_ctx_sync(x265hip_ctx* ctx);
+int   x265hip_ctx_device(const x265hip_ctx* ctx);    /* the device the context was created on; every entry point that takes a context selects it for the calling thread */
+
+#define X265HIP_MAX_PIC_DIM 8184                 /* (dim + 8 - 1) << 2 must fit the int16 quarter-pel limits of the task records */
 
 typedef struct x265hip_batch_desc
 {
@@ -78,21 +81,26 @@ typedef struct x265hip_tme_host_ref {
     const struct x265hip_inter_choice* refTable;   /* that picture's own table or NULL (intra picture)                                           */
     const int16_t* lowresMv;                   /* Lowres::lowresMvs[l][dist] as x, y per 16x16 block, or NULL (not estimated / distance out of range) */
     uint64_t reconKey;                         /* identity of the reconstructed picture (e.g. Frame::m_encodeOrder + 1): the producer keeps the planes of the last
-                                                  pictures it saw on the device and uploads / phase-interpolates a picture once; 0 = no identity, upload every time */
+                                                  pictures it saw on the device and uploads / phase-interpolates a picture once; 0 = no identity, upload every time.  Precondition: a keyed picture is
+                                                  COMPLETE (fully reconstructed, borders extended) when first seen -- it is never uploaded again */
 } x265hip_tme_host_ref;
 typedef struct x265hip_tme_picture_desc {
     int isP, numRef[2], curPOC, temporalMvp, refPOC[2][16];
     int searchRange, searchMethod, subpelRefine;
     int width, height, lowresBlocksX;
     const void* curPlane; intptr_t stride; int64_t origin, planeElems;
-    x265hip_tme_host_ref refs[2][4];
+    x265hip_tme_host_ref refs[2][X265HIP_MAX_REF];      /* numRef[l] <= X265HIP_MAX_REF = 16 (MAX_NUM_REF); more is X265HIP_EARG */
     struct x265hip_inter_choice* table;        /* [numCtu][593], in / out                                                                        */
-    const int16_t* median;                     /* [numCtu][2][4][3]: valid, x, y of getMedianColMV; NULL = none                                  */
+    const int16_t* median;                     /* [numCtu][2][X265HIP_MAX_REF][3]: valid, x, y of getMedianColMV; NULL = none                   */
     const x265hip_tme_temporal* temporal;      /* [numCtu][entries][2]                                                                           */
     int nQp, qps[64];                           /* the distinct qps of the picture's CUs                                                          */
     const uint8_t* qpIndex;                    /* [numCtu][entries]: index into qps of the entry's CU                                            */
     const uint8_t* areaQpIndex;                /* [numCtu][5]: index into qps of the CTU (area 0) and its four sub-CUs (the diamond searches)    */
-    int16_t* areaBestOut;                      /* optional [numCtu][5][2][4][2]: m_areaBestMV as computed                                        */
+    int sourceHeight;                          /* param->sourceHeight (the unpadded picture); 0 = height                                         */
+    int frameThreads;                          /* param->frameNumThreads; 0 or 1: reference pictures are complete.  > 1 models the encoder's window and selectMVP restrictions
+                                                  (m_refLagPixels = searchRange, m_bFrameParallel); the caller must still hand over finished reference rows only            */
+    int flags;                                 /* X265HIP_TME_LAUNCH_PER_STAGE / X265HIP_TME_PACKED_GROUPS (x265hip_frame.h); 0 for production   */
+    int16_t* areaBestOut;                      /* optional [numCtu][5][2][X265HIP_MAX_REF][2]: m_areaBestMV as computed                         */
 } x265hip_tme_picture_desc;
 int  x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** tme);
 void x265hip_tme_destroy(x265hip_tme* tme);

@@ -15,6 +15,8 @@
 #define X265HIP_FRAME_H
 #include "x265hip.h"
 
+#define X265HIP_MAX_REF 16                     /* references per list: MAX_NUM_REF (common/common.h:329; m_areaBestMV[5][2][MAX_NUM_REF], encoder/search.h:297) */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -120,7 +122,7 @@ int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int amp, x265hip_
 typedef struct x265hip_bidir_task { int32_t curOff, refOff; int16_t mv0[2], mv1[2]; } x265hip_bidir_task;   /* 16 bytes */
 int x265hip_bidir_satd_batch(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* subpelPlanes0, const void* subpelPlanes1, int64_t planeElems,
                              intptr_t refStride, const x265hip_bidir_task* tasks, int n, int32_t* satd);
-/* ... with the references chosen per task: subpelPlanes0[r] / subpelPlanes1[r] (r = 0..3, unused entries NULL) and device arrays ref0[i] / ref1[i] */
+/* ... with the references chosen per task: subpelPlanes0[r] / subpelPlanes1[r] (r = 0..X265HIP_MAX_REF-1, unused entries NULL) and device arrays ref0[i] / ref1[i] */
 int x265hip_bidir_satd_batch_refs(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* const* subpelPlanes0, const void* const* subpelPlanes1,
                                   int64_t planeElems, intptr_t refStride, const x265hip_bidir_task* tasks, const int8_t* ref0, const int8_t* ref1, int n, int32_t* satd);
 
@@ -168,14 +170,16 @@ typedef struct x265hip_tme_ref {
     const struct x265hip_inter_choice* refTable;   /* that reference picture's own MEData table, or NULL (intra picture / none): the fallback predictor of search.cpp:313-330 */
     const int16_t* lowresMv;                   /* the lookahead's MVs of this (list, distance), x / y per 16x16 block of the picture (Lowres::lowresMvs), or NULL = not estimated / out of range */
 } x265hip_tme_ref;
+#define X265HIP_TME_LAUNCH_PER_STAGE 1         /* every stage of every entry as its own launch over all CTUs (the first implementation; kept as the form the chain kernels are checked against) */
+#define X265HIP_TME_PACKED_GROUPS 2            /* chain kernels with several PUs per wavefront for the small shapes                              */
 typedef struct x265hip_tme_args {
     int isP, numRef[2], curPOC, temporalMvp, refPOC[2][16];
     int searchRange, searchMethod, subpelRefine;
     int picWidth, picHeight, ctuSize, lowresBlocksX;
     const void* curPlane; intptr_t stride; int64_t origin /* element offset of pixel (0,0) in every plane */, planeElems;
-    x265hip_tme_ref refs[2][4];
+    x265hip_tme_ref refs[2][X265HIP_MAX_REF];
     struct x265hip_inter_choice* table;        /* [numCtu][593] MEData records, in / out                                                         */
-    const int16_t* areaBest;                   /* [numCtu][5][2][4][2]: m_areaBestMV after deriveMVsForCTU's first stage (x265hip_diamond_batch + the median of the collocated MVs) */
+    const int16_t* areaBest;                   /* [numCtu][5][2][X265HIP_MAX_REF][2]: m_areaBestMV after deriveMVsForCTU's first stage (x265hip_diamond_batch + the median of the collocated MVs) */
     const x265hip_tme_temporal* temporal;      /* [numCtu][nSteps][2]                                                                            */
     int nQp;                                   /* distinct qps of the picture's CUs, 1..64 (Analysis::setLambdaFromQP runs per CU: AQ / cuTree)   */
     const uint8_t* qpIndex;                    /* [numCtu][nSteps]: which of them the CU of an entry uses; NULL with nQp == 1                     */
@@ -184,9 +188,14 @@ typedef struct x265hip_tme_args {
     const float* bitsRow; int bitsHalfRange;   /* device x265hip_mvbits_row                                                                      */
     const x265hip_tme_step* steps; int nSteps; /* HOST array (x265hip_tme_schedule)                                                              */
     void* workspace; size_t workspaceBytes;    /* device scratch of x265hip_tme_workspace(numCtu) bytes                                          */
+    int refLagPixels;                          /* Search::m_refLagPixels (search.cpp:96): param.sourceHeight with one frame thread, param.searchRange with several; full-pel upper
+                                                  bound of both ends of every search window (search.cpp:5017-5018).  0 = picHeight                                                 */
+    int flags;                                 /* X265HIP_TME_* below; 0 = the chain kernels                                                     */
+    int frameParallel;                         /* != 0: m_bFrameParallel -- selectMVP does not cost a candidate with y >= (searchRange + 1) * 4 (search.cpp:2360-2365)           */
 } x265hip_tme_args;
 size_t x265hip_tme_workspace(int nCtu);
 int x265hip_tme_frame(void* stream, const x265hip_tme_args* args);
+void x265hip_tme_release_stream(void* stream);      /* drops the side streams x265hip_tme_frame keeps per caller stream; call before destroying that stream */
 
 /* MotionEstimate::diamondSearch (motion.cpp:631-773) for n PUs of one size: the full-pel predictor search of ThreadedME's first stage
  * (Search::puMotionEstimation with isMVP, search.cpp:355-363 -- the CTU and its four sub-CUs at search range 32; the results seed m_areaBestMV for
@@ -215,10 +224,10 @@ typedef struct x265hip_inter_choice {
     uint32_t cost;               /* MEData.cost                                                          */
 } x265hip_inter_choice;          /* 36 bytes */
 typedef struct x265hip_merge_params {
-    int numRef[2];                                   /* references searched per list: 1..4 and 0..4 (0: P slice)            */
-    const x265hip_me_result* results[2][4];
-    const x265hip_me_result* mvpSource[2][4];        /* per (list, ref): the array task.mvpFrom indexes, or NULL             */
-    const void* subpelPlanes[2][4]; int64_t planeElems;
+    int numRef[2];                                   /* references searched per list: 1..16 and 0..16 (0: P slice)          */
+    const x265hip_me_result* results[2][X265HIP_MAX_REF];
+    const x265hip_me_result* mvpSource[2][X265HIP_MAX_REF];        /* per (list, ref): the array task.mvpFrom indexes, or NULL             */
+    const void* subpelPlanes[2][X265HIP_MAX_REF]; int64_t planeElems;
     const float* bitsRow; int bitsHalfRange;         /* device copy of x265hip_mvbits_row: entry [bitsHalfRange + d] = s_bitsizes[|d|] */
     uint64_t lambda;                                 /* x265hip_rd_lambda(qp) = RDCost::m_lambda                            */
     int bidir;                                       /* != 0: evaluate the bidirectional candidate (B slices)               */

@@ -1,0 +1,319 @@
+/*
+ * tme_adapter.cpp -- Analysis::deriveMVsForCTU with the GPU as ThreadedME's producer (see tme_adapter.h).
+ *
+ * What the adapter reads out of the encoder's state for the picture, and how: the planes (PicYuv allocations), the table as FrameData::reinit left it, per
+ * reference the reference picture's own table and the lookahead's MVs (Lowres::lowresMvs), and -- through the encoder's own member functions, on its own CUData
+ * objects, in computeMVForPUs' order -- the qp of every CU (Analysis::calculateQpforCuSize), the collocated neighbour of every PU (CUData::getNeighbourMV), the
+ * collocated median of every CTU (CUData::getMedianColMV).
+ *
+ * Preconditions (checked where they can be): one slice per picture; frame threads = 1 or complete reference pictures (the producer takes whole planes; the row-lag
+ * clamp of Search::setSearchRange, search.cpp:5017-5018, is not modelled); numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF.
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <map>
+#include <mutex>
+#include <vector>
+#include "x265.h"
+#include "common.h"
+#include "primitives.h"
+#include "picyuv.h"
+#include "frame.h"
+#include "framedata.h"
+#include "slice.h"
+#include "cudata.h"
+#include "lowres.h"
+#include "search.h"
+#include "analysis.h"
+#include "threadedme.h"
+#include "../include/x265hip_ctx.h"
+#include "tme_adapter.h"
+
+using namespace X265_NS;
+
+namespace {
+struct Api
+{
+    int (*ctx_create)(int, x265hip_ctx**);
+    void (*ctx_destroy)(x265hip_ctx*);
+    int (*tme_create)(x265hip_ctx*, int, int, int, int, int, int, x265hip_tme**);
+    void (*tme_destroy)(x265hip_tme*);
+    int (*tme_entries)(const x265hip_tme*, const x265hip_tme_step**);
+    int (*tme_picture)(x265hip_tme*, const x265hip_tme_picture_desc*);
+    const char* (*last_error)();
+} g_api;
+void* g_lib;
+x265hip_ctx* g_ctx;
+x265hip_tme* g_tme;
+int g_useGpu, g_device, g_pictures, g_weighted, g_keepPlanes = 1;
+double g_sec[4];      /* adapter sections: CTU set-up + area qps, the entry walk (qps, collocated neighbours), medians, references + tables */
+double g_gpuSeconds, g_pictureSeconds;      /* inside x265hip_tme_picture; the whole producer call incl. the adapter's harvest and write-back */
+std::mutex g_lock;
+std::map<const Frame*, int> g_done;          /* picture -> POC + 1 whose table is complete */
+
+void to_choice(const MEData& m, x265hip_inter_choice& o)
+{
+    for (int l = 0; l < 2; l++)
+    {
+        o.mv[l][0] = (int16_t)m.mv[l].x; o.mv[l][1] = (int16_t)m.mv[l].y; o.mvp[l][0] = (int16_t)m.mvp[l].x; o.mvp[l][1] = (int16_t)m.mvp[l].y;
+        o.mvCost[l] = m.mvCost[l]; o.ref[l] = (int8_t)m.ref[l];
+    }
+    o.reserved = 0; o.bits = m.bits; o.cost = m.cost;
+}
+void from_choice(const x265hip_inter_choice& o, MEData& m)
+{
+    for (int l = 0; l < 2; l++)
+    {
+        m.mv[l] = MV(o.mv[l][0], o.mv[l][1]); m.mvp[l] = MV(o.mvp[l][0], o.mvp[l][1]); m.mvCost[l] = o.mvCost[l]; m.ref[l] = o.ref[l];
+    }
+    m.bits = o.bits; m.cost = o.cost;
+}
+} // namespace
+
+void deriveMVsForCTU_cpu(Analysis* self, CUData& ctu, const CUGeom& cuGeom, Frame& frame) __asm__("_ZN4x2658Analysis19deriveMVsForCTU_cpuERNS_6CUDataERKNS_6CUGeomERNS_5FrameE");      /* the encoder's own body, under its second name */
+
+namespace X265_NS {
+void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
+{
+    if (!g_useGpu) { ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame); return; }
+    /* local classes of a member function have the member's access: calculateQpforCuSize (protected) is reached without touching analysis.h */
+    struct Harvest
+    {
+        Analysis& an; const Slice* slice; Frame& frame; const x265hip_tme_step* steps; int nSteps;
+        std::vector<x265hip_tme_temporal>& temporal; std::vector<int>& entryQp;
+        int ctuAddr, k;
+        void collocated(const CUData& cu, int puIdx, uint32_t puAbsPartIdx, x265hip_tme_temporal& t)
+        {
+            InterNeighbourMV nb[6];
+            cu.getNeighbourMV(puIdx, puAbsPartIdx, nb);
+            memset(&t, 0, sizeof(t));
+            t.nb.refIdx[0] = t.nb.refIdx[1] = -1;
+            if (nb[MD_COLLOCATED].unifiedRef == -1) return;
+            for (int l = 0; l < 2; l++)
+            {
+                t.nb.mv[l][0] = (int16_t)nb[MD_COLLOCATED].mv[l].x; t.nb.mv[l][1] = (int16_t)nb[MD_COLLOCATED].mv[l].y;
+                const int tempRefIdx = nb[MD_COLLOCATED].refIdx[l];
+                t.nb.refIdx[l] = (int8_t)tempRefIdx;
+                if (tempRefIdx != -1)
+                {   /* what CUData::getPMV looks up to scale the candidate (cudata.cpp:1962-1967) */
+                    const Frame* colPic = slice->m_refFrameList[slice->isInterB() && !slice->m_colFromL0Flag][slice->m_colRefIdx];
+                    const CUData* colCU = colPic->m_encData->getPicCTU(nb[MD_COLLOCATED].cuAddr[l]);
+                    t.colRefPOC[l] = colCU->m_slice->m_refPOCList[tempRefIdx >> 4][tempRefIdx & 0xf];
+                    t.colPOC[l] = colCU->m_slice->m_poc;
+                }
+            }
+        }
+        /* Analysis::computeMVForPUs' walk (analysis.cpp:161-246): sub-CUs first, then the CU's own PU shapes -- here only to harvest per entry the CU's qp and the partitions' collocated neighbours */
+        void walk(CUData& ctu, const CUGeom& geom, int qp)
+        {
+            const uint32_t cuSize = 1u << geom.log2CUSize;
+            if (cuSize > an.m_param->minCUSize)
+            {
+                int nextQP = qp;
+                for (uint32_t sub = 0; sub < 4; sub++)
+                {
+                    const CUGeom& child = *(&geom + geom.childOffset + sub);
+                    if (slice->m_pps->bUseDQP && geom.depth + 1 <= slice->m_pps->maxCuDQPDepth)
+                        nextQP = x265_clip3(QP_MIN, QP_MAX_SPEC, an.calculateQpforCuSize(ctu, child));
+                    walk(ctu, child, nextQP);
+                }
+            }
+            CUData& cu = an.m_modeDepth[geom.depth].pred[Analysis::PRED_2Nx2N].cu;
+            bool inited = false;
+            while (k < nSteps && steps[k].cuSize == (int)cuSize && steps[k].cuX == (int)g_zscanToPelX[geom.absPartIdx] && steps[k].cuY == (int)g_zscanToPelY[geom.absPartIdx])
+            {
+                const x265hip_tme_step& e = steps[k];
+                entryQp[(size_t)ctuAddr * nSteps + k] = qp;
+                if (!inited) { cu.initSubCU(ctu, geom, qp); inited = true; }          /* once per CU: the entries of a CU differ in the partition size only */
+                cu.setPartSizeSubParts((PartSize)e.part);
+                for (int pi = 0; pi < e.numPart; pi++)
+                {
+                    PredictionUnit pu(cu, geom, pi);
+                    collocated(cu, pi, pu.puAbsPartIdx, temporal[((size_t)ctuAddr * nSteps + k) * 2 + pi]);
+                }
+                k++;
+            }
+        }
+    };
+    struct Picture
+    {
+    static int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
+    {
+        const Slice* slice = an.m_slice;
+        const x265_param* p = an.m_param;
+        const int W = slice->m_sps->picWidthInLumaSamples, H = slice->m_sps->picHeightInLumaSamples, ctuSize = p->maxCUSize;
+        const int nCtuX = slice->m_sps->numCuInWidth, nCtuY = slice->m_sps->numCuInHeight, nCtu = nCtuX * nCtuY;
+        if (!g_tme)
+        {
+            if (g_api.ctx_create(g_device, &g_ctx) || g_api.tme_create(g_ctx, W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme))
+            { fprintf(stderr, "x265hip_tme_create: %s\n", g_api.last_error()); return -1; }
+        }
+        const x265hip_tme_step* steps; const int nS = g_api.tme_entries(g_tme, &steps);
+        const int nl = slice->isInterP() ? 1 : 2;
+        for (int l = 0; l < nl; l++)
+            if (slice->m_numRefIdx[l] < 1 || slice->m_numRefIdx[l] > X265HIP_MAX_REF) { fprintf(stderr, "tme_adapter: %d references in list %d (1..%d)\n", slice->m_numRefIdx[l], l, X265HIP_MAX_REF); return -1; }
+        if (p->maxSlices > 1) { fprintf(stderr, "tme_adapter: --slices %d: one slice per picture only\n", p->maxSlices); return -1; }
+        std::vector<int> used;                                         /* the MEData slots of a CTU the schedule writes (and reads) */
+        {
+            std::vector<char> mark(593, 0);
+            for (int k = 0; k < nS; k++) for (int pi = 0; pi < steps[k].numPart; pi++) { const int sl = steps[k].finalIdx + pi * steps[k].puOffset; if (sl >= 0 && sl < 593) mark[sl] = 1; }
+            for (int sl = 0; sl < 593; sl++) if (mark[sl]) used.push_back(sl);
+        }
+        x265hip_tme_picture_desc d;
+        memset(&d, 0, sizeof(d));
+        d.isP = slice->isInterP(); d.numRef[0] = slice->m_numRefIdx[0]; d.numRef[1] = nl > 1 ? slice->m_numRefIdx[1] : 0; d.curPOC = slice->m_poc;
+        d.temporalMvp = slice->m_sps->bTemporalMVPEnabled;
+        for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) d.refPOC[l][r] = slice->m_refPOCList[l][r];
+        d.searchRange = p->searchRange; d.searchMethod = p->searchMethod; d.subpelRefine = p->subpelRefine;
+        d.width = W; d.height = H;
+        const PicYuv* fenc = frame.m_fencPic;
+        d.curPlane = fenc->m_picBuf[0]; d.stride = fenc->m_stride; d.origin = fenc->m_picOrg[0] - fenc->m_picBuf[0];
+        d.planeElems = (int64_t)fenc->m_stride * (fenc->m_picHeight + 2 * fenc->m_lumaMarginY);
+        /* per CTU: what findJob sets up before the call (threadedme.cpp:238-246), then the harvest */
+        /* buffers kept across pictures (the call runs under g_lock): fresh 10 MB vectors per picture cost more in page faults than the work on them */
+        static std::vector<x265hip_tme_temporal> temporal; static std::vector<int> entryQp, areaQp; static std::vector<int16_t> median;
+        temporal.resize((size_t)nCtu * nS * 2); entryQp.resize((size_t)nCtu * nS); areaQp.resize((size_t)nCtu * 5); median.assign((size_t)nCtu * 2 * X265HIP_MAX_REF * 3, 0);
+        const Frame* colPic = slice->m_refFrameList[slice->isInterB() && !slice->m_colFromL0Flag][slice->m_colRefIdx];
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (int c = 0; c < nCtu; c++)
+        {
+            double ts = now();
+            CUData* ctu = frame.m_encData->getPicCTU(c);
+            ctu->m_slice = frame.m_encData->m_slice;
+            const int row = c / nCtuX, col = c % nCtuX;
+            frame.m_encData->m_cuStat[c].baseQp = frame.m_encData->m_avgQpRc;
+            ctu->initCTU(frame, c, slice->m_sliceQp, row == 0, row == nCtuY - 1, row == nCtuY - 1 && col == nCtuX - 1);     /* one slice */
+            const int rawBase = slice->m_pps->bUseDQP ? an.calculateQpforCuSize(*ctu, ctuGeom) : slice->m_sliceQp;
+            areaQp[c * 5] = rawBase;
+            for (int sub = 0; sub < 4; sub++)
+                areaQp[c * 5 + 1 + sub] = slice->m_pps->bUseDQP ? an.calculateQpforCuSize(*ctu, *(&ctuGeom + ctuGeom.childOffset + sub)) : slice->m_sliceQp;
+            g_sec[0] += now() - ts; ts = now();
+            Harvest h{ an, slice, frame, steps, nS, temporal, entryQp, c, 0 };
+            h.walk(*ctu, ctuGeom, x265_clip3(QP_MIN, QP_MAX_SPEC, rawBase));
+            g_sec[1] += now() - ts; ts = now();
+            if (h.k != nS) { fprintf(stderr, "schedule mismatch: %d of %d entries\n", h.k, nS); return -1; }
+            const CUData* colCU = colPic->m_encData->getPicCTU(c);
+            for (int l = 0; l < nl; l++)
+                for (int r = 0; r < slice->m_numRefIdx[l]; r++)
+                {
+                    MV m;
+                    if (ctu->getMedianColMV(colCU, colPic, l, r, m)) { int16_t* o = &median[(((size_t)c * 2 + l) * X265HIP_MAX_REF + r) * 3]; o[0] = 1; o[1] = (int16_t)m.x; o[2] = (int16_t)m.y; }
+                }
+            g_sec[2] += now() - ts;
+        }
+        const double tRefs = now();
+        /* the distinct qps */
+        std::vector<int> qps;
+        auto qidx = [&](int qp) { if (qp > QP_MAX_SPEC) { fprintf(stderr, "qp %d above 51: not handled\n", qp); exit(3); }
+                                  for (size_t i = 0; i < qps.size(); i++) if (qps[i] == qp) return (int)i; qps.push_back(qp); return (int)qps.size() - 1; };
+        static std::vector<uint8_t> qpIndex, areaQpIndex;
+        qpIndex.resize(entryQp.size()); areaQpIndex.resize(areaQp.size());
+        for (size_t i = 0; i < entryQp.size(); i++) qpIndex[i] = (uint8_t)qidx(entryQp[i]);
+        for (size_t i = 0; i < areaQp.size(); i++) areaQpIndex[i] = (uint8_t)qidx(areaQp[i]);
+        if (qps.size() > 64) { fprintf(stderr, "more than 64 distinct qps\n"); return -1; }
+        d.nQp = (int)qps.size();
+        for (int i = 0; i < d.nQp; i++) d.qps[i] = qps[i];
+        d.qpIndex = qpIndex.data(); d.areaQpIndex = areaQpIndex.data(); d.temporal = temporal.data(); d.median = median.data();
+        /* references: planes, their own tables, the lookahead's MVs */
+        static std::vector<std::vector<x265hip_inter_choice>> refTables(2 * X265HIP_MAX_REF);
+        static std::vector<std::vector<int16_t>> lowres(2 * X265HIP_MAX_REF);
+        int nRefTables = 0, nLowres = 0;
+        d.lowresBlocksX = frame.m_lowres.maxBlocksInRow;
+        for (int l = 0; l < nl; l++)
+            for (int r = 0; r < slice->m_numRefIdx[l]; r++)
+            {
+                x265hip_tme_host_ref& R = d.refs[l][r];
+                const MotionReference& mr = slice->m_mref[l][r];
+                if (mr.isWeighted)
+                {   /* the frame encoder weights the reference's rows as it releases them to the row encoders (frameencoder.cpp:1029-1036); the producer takes the whole
+                       picture at once: finish the plane now (same values, the later calls find nothing left to do) */
+                    const_cast<MotionReference&>(mr).applyWeight(nCtuY - 1, nCtuY, nCtuY, 0);
+                    g_weighted++;
+                }
+                const PicYuv* rec = slice->m_refReconPicList[l][r];
+                R.mePlane = mr.fpelPlane[0] - d.origin;
+                R.reconPlane = rec->m_picBuf[0];
+                const Frame* rf = slice->m_refFrameList[l][r];
+                R.reconKey = g_keepPlanes ? (uint64_t)rf->m_encodeOrder + 1 : 0;      /* a finished picture: its planes stay on the device for the pictures that reference it */
+                if (rf->m_encData->m_slice->m_sliceType != I_SLICE)
+                {   /* only the slots the schedule names are ever read */
+                    std::vector<x265hip_inter_choice>& rt = refTables[nRefTables++];
+                    rt.resize((size_t)nCtu * 593);
+                    const MEData* src = rf->m_encData->m_slice->m_ctuMV;
+                    x265hip_inter_choice* o = rt.data();
+                    for (int c = 0; c < nCtu; c++) for (int sl : used) to_choice(src[(size_t)c * 593 + sl], o[(size_t)c * 593 + sl]);
+                    R.refTable = o;
+                }
+                const int diffPoc = abs(slice->m_poc - slice->m_refPOCList[l][r]);
+                if (diffPoc <= p->bframes + 1)
+                {
+                    const MV* mvs = frame.m_lowres.lowresMvs[l][diffPoc];
+                    if (mvs[0].x != 0x7FFF)
+                    {
+                        const size_t nb = (size_t)frame.m_lowres.maxBlocksInRow * ((H + 15) / 16);
+                        std::vector<int16_t>& lm = lowres[nLowres++];
+                        lm.resize(nb * 2);
+                        for (size_t i = 0; i < nb; i++) { lm[2 * i] = (int16_t)mvs[i].x; lm[2 * i + 1] = (int16_t)mvs[i].y; }
+                        R.lowresMv = lm.data();
+                    }
+                }
+            }
+        static std::vector<x265hip_inter_choice> table;
+        table.resize((size_t)nCtu * 593);
+        MEData* dst = frame.m_encData->m_slice->m_ctuMV;
+        for (int c = 0; c < nCtu; c++) for (int sl : used) to_choice(dst[(size_t)c * 593 + sl], table[(size_t)c * 593 + sl]);
+        d.table = table.data();
+        g_sec[3] += now() - tRefs;
+        const auto t0 = std::chrono::steady_clock::now();
+        { const int rc = g_api.tme_picture(g_tme, &d); if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", slice->m_poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; } }
+        g_gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int c = 0; c < nCtu; c++) for (int sl : used) from_choice(table[(size_t)c * 593 + sl], dst[(size_t)c * 593 + sl]);
+        g_pictures++;
+        return 0;
+    }
+    };
+    std::lock_guard<std::mutex> guard(g_lock);
+    const int poc = ctu.m_slice->m_poc;
+    auto it = g_done.find(&frame);
+    if (it != g_done.end() && it->second == poc + 1) return;              /* this picture's table is there already */
+    m_slice = ctu.m_slice; m_frame = &frame; m_param = m_frame->m_param;  /* as the encoder's body starts (analysis.cpp:250-252) */
+    const auto tp0 = std::chrono::steady_clock::now();
+    if (Picture::run_picture(*this, cuGeom, frame)) exit(3);
+    g_pictureSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
+    g_done[&frame] = poc + 1;
+}
+}
+
+extern "C" int x265hip_tme_adapter_load(const char* libraryPath, int device)
+{
+    if (getenv("X265TME_NOKEEP")) g_keepPlanes = 0;
+    g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
+    if (!g_lib) { fprintf(stderr, "tme_adapter: dlopen: %s\n", dlerror()); return -1; }
+    g_api.ctx_create = (int (*)(int, x265hip_ctx**))dlsym(g_lib, "x265hip_ctx_create");
+    g_api.ctx_destroy = (void (*)(x265hip_ctx*))dlsym(g_lib, "x265hip_ctx_destroy");
+    g_api.tme_create = (int (*)(x265hip_ctx*, int, int, int, int, int, int, x265hip_tme**))dlsym(g_lib, "x265hip_tme_create");
+    g_api.tme_destroy = (void (*)(x265hip_tme*))dlsym(g_lib, "x265hip_tme_destroy");
+    g_api.tme_entries = (int (*)(const x265hip_tme*, const x265hip_tme_step**))dlsym(g_lib, "x265hip_tme_entries");
+    g_api.tme_picture = (int (*)(x265hip_tme*, const x265hip_tme_picture_desc*))dlsym(g_lib, "x265hip_tme_picture");
+    g_api.last_error = (const char* (*)())dlsym(g_lib, "x265hip_last_error");
+    if (!g_api.ctx_create || !g_api.ctx_destroy || !g_api.tme_create || !g_api.tme_destroy || !g_api.tme_entries || !g_api.tme_picture || !g_api.last_error)
+    { fprintf(stderr, "tme_adapter: %s lacks the producer's entry points\n", libraryPath); return -1; }
+    g_device = device; g_useGpu = 1;
+    return 0;
+}
+extern "C" void x265hip_tme_adapter_enable(int on) { g_useGpu = on && g_lib; }
+extern "C" void x265hip_tme_adapter_close(void)
+{
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (g_tme) { g_api.tme_destroy(g_tme); g_tme = nullptr; }
+    if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
+    g_done.clear(); g_useGpu = 0;
+}
+extern "C" void x265hip_tme_adapter_get_stats(x265hip_tme_adapter_stats* o)
+{
+    o->pictures = g_pictures; o->weightedRefs = g_weighted; o->producerSeconds = g_gpuSeconds; o->adapterSeconds = g_pictureSeconds;
+    for (int i = 0; i < 4; i++) o->sections[i] = g_sec[i];
+}

@@ -1,0 +1,37 @@
+/*
+ * tme_adapter.h -- the binding of libx265hip's ThreadedME producer into the reference encoder.
+ *
+ * x265's decoupled motion estimation (--threaded-me) has a producer / consumer contract: ThreadedME::findJob calls Analysis::deriveMVsForCTU(ctu, geom, frame) per CTU
+ * (encoder/threadedme.cpp:207-261), which fills that CTU's MEData records in slice->m_ctuMV (encoder/analysis.cpp:248-306); Search::predInterSearch consumes them.
+ * tme_adapter.cpp defines Analysis::deriveMVsForCTU: the first call for a picture hands the WHOLE picture to x265hip_tme_picture (include/x265hip_ctx.h) and copies the
+ * table it returns into slice->m_ctuMV; the calls for the picture's other CTUs find their records there.  The encoder's own body of that member stays available under the
+ * name deriveMVsForCTU_cpu (a maintainer renames it in analysis.cpp / analysis.h; a build without source changes compiles analysis.cpp with
+ * -DderiveMVsForCTU=deriveMVsForCTU_cpu, oracle/Makefile target tmegpu) and is what runs when the adapter is not loaded.
+ *
+ * No reference header is patched and no private member is reached from outside: everything the adapter needs beyond public data (Analysis::calculateQpforCuSize is
+ * protected) is used from inside the member function it defines.
+ */
+#ifndef X265HIP_TME_ADAPTER_H
+#define X265HIP_TME_ADAPTER_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* dlopen libx265hip_<depth>.so and bind the producer; 0 on success.  Before x265_encoder_open.  Without it (or after tme_adapter_enable(0)) deriveMVsForCTU runs the encoder's own body. */
+int  x265hip_tme_adapter_load(const char* libraryPath, int device);
+void x265hip_tme_adapter_enable(int on);
+void x265hip_tme_adapter_close(void);          /* after x265_encoder_close: destroys the producer and its context */
+
+typedef struct x265hip_tme_adapter_stats
+{
+    int pictures, weightedRefs;
+    double producerSeconds;        /* inside x265hip_tme_picture                                                        */
+    double adapterSeconds;         /* the whole per-picture call: harvest + producer + write-back                       */
+    double sections[4];            /* CTU set-up + area qps; entry walk (qps, collocated neighbours); medians; references + tables */
+} x265hip_tme_adapter_stats;
+void x265hip_tme_adapter_get_stats(x265hip_tme_adapter_stats* out);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

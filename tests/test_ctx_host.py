@@ -53,3 +53,38 @@ def test_context_needs_a_device():
     lib = x265hip.HipLib(8, fill_table=False).lib
     ctx = C.c_void_p()
     assert lib.x265hip_ctx_create(0, C.byref(ctx)) < 0 and not ctx.value      # no CPU fallback: fails loudly
+
+
+def test_reference_count_and_picture_size_limits_are_argument_errors():
+    """Host-side validation, no GPU: x265hip_tme_frame refuses more than X265HIP_MAX_REF = 16 references per list (MAX_NUM_REF, common/common.h:329) before it looks at a
+    device; pictures whose quarter-pel clip limits would not fit int16 are refused by the batch descriptor."""
+    from x265hip_pkg.frame import MAX_REF
+    lib = x265hip.HipLib(8, fill_table=False).lib
+    lib.x265hip_last_error.restype = C.c_char_p
+    assert MAX_REF == 16
+
+    class Ref(C.Structure):
+        _fields_ = [(n, C.c_void_p) for n in ("mePlane", "mePhase", "reconPhase", "refTable", "lowresMv")]
+
+    class Args(C.Structure):
+        _fields_ = [("isP", C.c_int), ("numRef", C.c_int * 2), ("curPOC", C.c_int), ("temporalMvp", C.c_int), ("refPOC", (C.c_int * 16) * 2),
+                    ("searchRange", C.c_int), ("searchMethod", C.c_int), ("subpelRefine", C.c_int),
+                    ("picWidth", C.c_int), ("picHeight", C.c_int), ("ctuSize", C.c_int), ("lowresBlocksX", C.c_int),
+                    ("curPlane", C.c_void_p), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("planeElems", C.c_int64),
+                    ("refs", (Ref * MAX_REF) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
+                    ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 64), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
+                    ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t),
+                    ("refLagPixels", C.c_int), ("flags", C.c_int), ("frameParallel", C.c_int)]
+    lib.x265hip_tme_workspace.restype = C.c_size_t
+    buf = np.zeros(4096, np.uint8)
+    a = Args()
+    a.isP = 1; a.numRef[0] = 17; a.picWidth = a.picHeight = 64; a.ctuSize = 64; a.nQp = 1; a.nSteps = 1
+    for f in ("curPlane", "table", "areaBest", "temporal", "costRows", "bitsRow", "steps", "workspace"):
+        setattr(a, f, buf.ctypes.data)
+    a.workspaceBytes = lib.x265hip_tme_workspace(1)
+    assert lib.x265hip_tme_frame(None, C.byref(a)) == -3 and b"17 references" in lib.x265hip_last_error()
+    a.numRef[0] = 0
+    assert lib.x265hip_tme_frame(None, C.byref(a)) == -3
+    for w, h in ((8192, 64), (64, 8192)):
+        assert lib.x265hip_batch_task_count(C.byref(Desc(w, h, 1, 96, 28, 57, 1, 2, 5, 0, 1)), 64) < 0
+    assert lib.x265hip_batch_task_count(C.byref(Desc(8128, 64, 1, 96, 28, 57, 1, 2, 5, 0, 1)), 64) == 127

@@ -313,7 +313,7 @@ def test_tme_frame_steps_whole_pictures_to_the_references_tables(depth):
         cur = np.zeros(stride * rows, planes[int(c0["planeIds"][0][0][0])][1].dtype)
         table = np.zeros((4, 593), INTER_CHOICE); table["ref"] = -1
         written = np.zeros((4, 593), bool)
-        area = np.zeros((4, 5, 2, 4, 2), np.int16)
+        area = np.zeros((4, 5, 2, 16, 2), np.int16)                   # [ctu][area][list][X265HIP_MAX_REF][x, y]
         temporal = np.zeros((4, nS, 2), TME_TEMPORAL); temporal["nb"]["refIdx"] = -1
         nlist = 1 if c0["isP"] else 2
         ref_tab = [[np.zeros((4, 593), INTER_CHOICE) for _ in range(4)] for _ in range(2)]
@@ -328,7 +328,7 @@ def test_tme_frame_steps_whole_pictures_to_the_references_tables(depth):
             for k, c in enumerate(lst):
                 st = steps[k]
                 assert (c["part"], c["finalIdx"], c["puOffset"]) == (int(st["part"]), int(st["finalIdx"]), int(st["puOffset"]))
-                area[ctu, c["area"]] = c["areaBest"]
+                area[ctu, c["area"], :, :4] = c["areaBest"]
                 for d in range(5):
                     slot = c["nbIdx"][d]
                     if slot >= 0 and not written[ctu, slot]:

@@ -20,23 +20,23 @@ def run(depth, preset, kind, extra=(), **env):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("depth,preset,kind", [(8, "medium", "P"), (8, "slow", "B"), (10, "slow", "P"), (10, "medium", "B")])
+@pytest.mark.parametrize("depth,preset,kind", [(8, "medium", "P"), (8, "slower", "B"), (10, "slow", "P"), (10, "medium", "B"), (10, "slower", "B")])
 def test_chain_kernels_write_the_table_of_the_launch_path(depth, preset, kind):
     chains = run(depth, preset, kind)
-    launches = run(depth, preset, kind, X265HIP_TME_LAUNCHES="1")
-    packed = run(depth, preset, kind, X265HIP_TME_PACKED="1")            # the small shapes in the batched kernels' lane packing (several PUs per wavefront)
+    launches = run(depth, preset, kind, TME_RUN_FLAGS="1")
+    packed = run(depth, preset, kind, TME_RUN_FLAGS="2")            # the small shapes in the batched kernels' lane packing (several PUs per wavefront)
     assert chains[1] > 1000, "hardly any record written: %s" % (chains,)
-    if kind == "B" and preset == "slow":
+    if kind == "B" and preset == "slower":
         assert chains[2] > 0, "no bidirectional record in a B picture"
     assert chains == launches, "chain kernels %s != launch path %s" % (chains, launches)
     assert packed == launches, "packed chain kernels %s != launch path %s" % (packed, launches)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("depth,preset,kind,method,merange", [(8, "slow", "P", 0, 57),      # DIA
+@pytest.mark.parametrize("depth,preset,kind,method,merange", [(8, "slower", "P", 0, 57),      # DIA
                                                               (10, "medium", "B", 5, 5),    # FULL (a small window: every position is costed)
                                                               (8, "medium", "P", 2, 24)])   # UMH
 def test_other_search_methods_through_the_producer(depth, preset, kind, method, merange):
     chains = run(depth, preset, kind, extra=(method, merange))
-    launches = run(depth, preset, kind, extra=(method, merange), X265HIP_TME_LAUNCHES="1")
+    launches = run(depth, preset, kind, extra=(method, merange), TME_RUN_FLAGS="1")
     assert chains[1] > 1000 and chains == launches, "method %d: %s != %s" % (method, chains, launches)

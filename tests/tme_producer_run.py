@@ -1,5 +1,5 @@
 """Helper of test_tme_producer_gpu.py: one picture through x265hip_tme_picture on synthetic planes, prints the SHA-1 of the table.  Run as a script so that the switches
-the library reads once (X265HIP_TME_LAUNCHES, X265HIP_TME_PACKED) can differ between runs.   python tests/tme_producer_run.py depth preset P|B [method merange]"""
+the caller sets (TME_RUN_FLAGS = x265hip_tme_picture_desc.flags: 1 one launch per stage, 2 packed lane groups) differ between runs, each in a fresh process.   python tests/tme_producer_run.py depth preset P|B [method merange]"""
 import ctypes as C
 import hashlib
 import importlib
@@ -26,16 +26,17 @@ def main():
     ref1 = np.clip(np.roll(ref0, (-2, 7), axis=(0, 1)) + rng.integers(-5, 6, ref0.shape), 0, (1 << depth) - 1)
     cur = np.clip(np.roll(ref0, (3, -5), axis=(0, 1)) + rng.integers(-4, 5, ref0.shape), 0, (1 << depth) - 1)
     ref0, ref1, cur = (np.ascontiguousarray(a.astype(dt)).reshape(-1) for a in (ref0, ref1, cur))
-    rect, amp, method, subme = {"medium": (False, False, 1, 2), "slow": (True, True, 3, 3)}[preset]
+    rect, amp, method, subme = {"medium": (False, False, 1, 2), "slow": (True, False, 3, 3), "slower": (True, True, 3, 4)}[preset]      # rect / amp / method / subme of the presets (param.cpp:567-608)
     merange = 57
     if len(sys.argv) > 5:
         method, merange = int(sys.argv[4]), int(sys.argv[5])
     prod = TmeProducer(lib, W, H, 64, 8, rect, amp)
+    flags = int(os.environ.get("TME_RUN_FLAGS", "0"))
     table = prod.empty_table()
     if kind == "P":
-        prod.picture(cur, [[ref0, ref1], []], stride, margin * stride + margin, table, method=method, subme=subme, merange=merange, cur_poc=2, ref_pocs=((1, 0), ()))
+        prod.picture(cur, [[ref0, ref1], []], stride, margin * stride + margin, table, method=method, subme=subme, merange=merange, cur_poc=2, ref_pocs=((1, 0), ()), flags=flags)
     else:
-        prod.picture(cur, [[ref0], [ref1]], stride, margin * stride + margin, table, is_p=False, method=method, subme=subme, merange=merange, cur_poc=1, ref_pocs=((0,), (2,)))
+        prod.picture(cur, [[ref0], [ref1]], stride, margin * stride + margin, table, is_p=False, method=method, subme=subme, merange=merange, cur_poc=1, ref_pocs=((0,), (2,)), flags=flags)
     used = int((table["ref"] >= 0).any(axis=1).sum())
     bi = int(((table["ref"][:, 0] >= 0) & (table["ref"][:, 1] >= 0)).sum())
     prod.close()

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void idct16_mfma_kernel(const int16_t* __restr
 bool xh_dct32_mfma_enabled()
 {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("X265HIP_DCT32_VALU"); on = (e && e[0] == '1') ? 0 : 1; }
+    if (on < 0) { const char* e = xh_experiment("X265HIP_DCT32_VALU"); on = (e && e[0] == '1') ? 0 : 1; }
     return on == 1;
 }
 

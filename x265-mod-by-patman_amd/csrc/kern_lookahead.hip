@@ -806,13 +806,13 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     const int nslices = heightInCU / rowsPerSlice;
     const int widest = min(rowsPerSlice + heightInCU % rowsPerSlice, (widthInCU + 1) / 2);
     // A/B switches of the profiling scripts, clamped to what the kernel can run with (whole wavefronts, 64..1024 threads; LDS within the CU's 160 KB)
-    static const int threadCap = [] { const char* e = getenv("X265HIP_LA_THREADS"); int v = e ? atoi(e) : 1024; v = v / 64 * 64; return v < 64 ? 64 : v > 1024 ? 1024 : v; }();
+    static const int threadCap = [] { const char* e = xh_experiment("X265HIP_LA_THREADS"); int v = e ? atoi(e) : 1024; v = v / 64 * 64; return v < 64 ? 64 : v > 1024 ? 1024 : v; }();
     const int threads = min(min(1024, threadCap), max(64, (widest * 8 + 63) / 64 * 64));
     const int costR = 4 * (max(widthInCU, heightInCU) * CU + 32);               // the bound checked above; 2 bytes per entry of LDS
     // Workgroup placement: a CU accepts four of these 8-wavefront workgroups, and the dispatcher fills CUs one after the other, so a
     // batch of ~2 workgroups per CU ends up four deep on some CUs and absent on others -- and four interleaved wavefront sweeps take
     // four times as long as one.  Asking for 56 KB of LDS (of 160 KB per CU) caps the depth at two.
-    static const size_t ldsPad = [] { const char* e = getenv("X265HIP_LA_LDS"); long v = e ? atol(e) : 56 * 1024; return (size_t)(v < 0 ? 0 : v > 160 * 1024 ? 160 * 1024 : v); }();
+    static const size_t ldsPad = [] { const char* e = xh_experiment("X265HIP_LA_LDS"); long v = e ? atol(e) : 56 * 1024; return (size_t)(v < 0 ? 0 : v > 160 * 1024 ? 160 * 1024 : v); }();
     const size_t lds = std::max(sizeof(uint16_t) * (size_t)(2 * costR + 2), ldsPad);
     hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts);
     XH_LAUNCH_CHECK();

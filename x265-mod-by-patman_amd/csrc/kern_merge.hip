@@ -18,8 +18,8 @@ struct MergeArgs
     int w, h, n, isP, bidir, sourceMaxDim, numRef[2];
     const pixel* cur; intptr_t cs; intptr_t rs;
     const x265hip_me_task* tasks;
-    const x265hip_me_result* res[8]; const x265hip_me_result* mvpSrc[8];      // [list * 4 + ref]
-    const pixel* planes[8]; int64_t planeElems;                                // 16-slot phase-plane buffer of each reference
+    const x265hip_me_result* res[2 * X265HIP_MAX_REF]; const x265hip_me_result* mvpSrc[2 * X265HIP_MAX_REF];      // [list * X265HIP_MAX_REF + ref]
+    const pixel* planes[2 * X265HIP_MAX_REF]; int64_t planeElems;                                // 16-slot phase-plane buffer of each reference
     const float* bitsCentre; int bitsHalf; unsigned long long lambda;
     x265hip_inter_choice* out;
 };
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void inter_merge_uni_kernel(MergeArgs a)
     for (int l = 0; l < 2; l++)
         for (int r = 0; r < a.numRef[l]; r++)
         {
-            const int k = l * 4 + r;
+            const int k = l * X265HIP_MAX_REF + r;
             const x265hip_me_result m = a.res[k][item];
             int px = qx, py = qy;
             if (from >= 0 && a.mvpSrc[k]) { px = a.mvpSrc[k][from].mv[0]; py = a.mvpSrc[k][from].mv[1]; }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void inter_merge_kernel(MergeArgs a)
     for (int l = 0; l < 2; l++)
         for (int r = 0; r < a.numRef[l]; r++)
         {
-            const int k = l * 4 + r;
+            const int k = l * X265HIP_MAX_REF + r;
             const x265hip_me_result m = a.res[k][item];
             int px = tp->qmvp[0], py = tp->qmvp[1];
             if (tp->mvpFrom >= 0 && a.mvpSrc[k]) { px = a.mvpSrc[k][tp->mvpFrom].mv[0]; py = a.mvpSrc[k][tp->mvpFrom].mv[1]; }
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void inter_merge_kernel(MergeArgs a)
         }
         wave_sync();
         b0x = best[0].mvx; b0y = best[0].mvy; b1x = best[1].mvx; b1y = best[1].mvy;
-        const pixel* pa = a.planes[best[0].ref]; const pixel* pb = a.planes[4 + best[1].ref];
+        const pixel* pa = a.planes[best[0].ref]; const pixel* pb = a.planes[X265HIP_MAX_REF + best[1].ref];
         int satd = bidir_satd(a, fenc, avg, tp->refOff, pa, b0x, b0y, pb, b1x, b1y, lane);
         bidirBits = (int)(best[0].bits + best[1].bits + listSelBits[2] - (listSelBits[0] + listSelBits[1]));
         bidirCost = (uint32_t)satd + getcost(a, (uint32_t)bidirBits);
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void bidir_satd_kernel(MergeArgs a, const x265
     }
     wave_sync();
     // per-task references (ref0 / ref1 given): the planes of the list-0 / list-1 reference this PU chose
-    const pixel* pa = a.planes[ref0 ? uni((int)ref0[item]) & 3 : 0]; const pixel* pb = a.planes[4 + (ref1 ? uni((int)ref1[item]) & 3 : 0)];
+    const pixel* pa = a.planes[ref0 ? uni((int)ref0[item]) & (X265HIP_MAX_REF - 1) : 0]; const pixel* pb = a.planes[X265HIP_MAX_REF + (ref1 ? uni((int)ref1[item]) & (X265HIP_MAX_REF - 1) : 0)];
     const int s = bidir_satd(a, fenc, avg, t.refOff, pa, t.mv0[0], t.mv0[1], pb, t.mv1[0], t.mv1[1], lane);
     if (lane == 0) satd[item] = s;
 }
@@ -192,7 +192,7 @@ extern "C" int x265hip_inter_merge_batch(void* stream, int w, int h, const void*
     if (n <= 0) return X265HIP_OK;
     if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !tasks || !p || !out || !curPlane || !p->bitsRow || p->bitsHalfRange < 1)
     { set_error("inter_merge_batch: bad arguments"); return X265HIP_EARG; }
-    if (p->numRef[0] < 1 || p->numRef[0] > 4 || p->numRef[1] < 0 || p->numRef[1] > 4) { set_error("inter_merge_batch: 1..4 references in list 0, 0..4 in list 1"); return X265HIP_EARG; }
+    if (p->numRef[0] < 1 || p->numRef[0] > X265HIP_MAX_REF || p->numRef[1] < 0 || p->numRef[1] > X265HIP_MAX_REF) { set_error("inter_merge_batch: 1..%d references in list 0, 0..%d in list 1", X265HIP_MAX_REF, X265HIP_MAX_REF); return X265HIP_EARG; }
     MergeArgs a{};
     a.w = w; a.h = h; a.n = n; a.isP = p->numRef[1] == 0; a.bidir = p->bidir; a.sourceMaxDim = p->sourceMaxDim; a.numRef[0] = p->numRef[0]; a.numRef[1] = p->numRef[1];
     a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.tasks = tasks; a.planeElems = p->planeElems;
@@ -201,7 +201,7 @@ extern "C" int x265hip_inter_merge_batch(void* stream, int w, int h, const void*
         {
             if (!p->results[l][r]) { set_error("inter_merge_batch: results of list %d reference %d missing", l, r); return X265HIP_EARG; }
             if (p->bidir && p->numRef[1] && !p->subpelPlanes[l][r]) { set_error("inter_merge_batch: the bidirectional candidate needs the phase planes of every reference"); return X265HIP_EARG; }
-            a.res[l * 4 + r] = p->results[l][r]; a.mvpSrc[l * 4 + r] = p->mvpSource[l][r]; a.planes[l * 4 + r] = (const pixel*)p->subpelPlanes[l][r];
+            a.res[l * X265HIP_MAX_REF + r] = p->results[l][r]; a.mvpSrc[l * X265HIP_MAX_REF + r] = p->mvpSource[l][r]; a.planes[l * X265HIP_MAX_REF + r] = (const pixel*)p->subpelPlanes[l][r];
         }
     a.bitsCentre = p->bitsRow + p->bitsHalfRange; a.bitsHalf = p->bitsHalfRange; a.lambda = p->lambda; a.out = out;
     if (a.isP || !a.bidir) hipLaunchKernelGGL(inter_merge_uni_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
@@ -217,7 +217,7 @@ extern "C" int x265hip_bidir_satd_batch(void* stream, int w, int h, const void* 
     if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !curPlane || !subpelPlanes0 || !subpelPlanes1 || !tasks || !satd) { set_error("bidir_satd_batch: bad arguments"); return X265HIP_EARG; }
     MergeArgs a{};
     a.w = w; a.h = h; a.n = n; a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.planeElems = planeElems;
-    a.planes[0] = (const pixel*)subpelPlanes0; a.planes[4] = (const pixel*)subpelPlanes1;
+    a.planes[0] = (const pixel*)subpelPlanes0; a.planes[X265HIP_MAX_REF] = (const pixel*)subpelPlanes1;
     hipLaunchKernelGGL(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd, (const int8_t*)nullptr, (const int8_t*)nullptr);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -231,7 +231,7 @@ extern "C" int x265hip_bidir_satd_batch_refs(void* stream, int w, int h, const v
     if (w < 4 || h < 4 || w > 64 || h > 64 || ((w | h) & 3) || !curPlane || !subpelPlanes0 || !subpelPlanes1 || !tasks || !satd || !ref0 || !ref1) { set_error("bidir_satd_batch_refs: bad arguments"); return X265HIP_EARG; }
     MergeArgs a{};
     a.w = w; a.h = h; a.n = n; a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.planeElems = planeElems;
-    for (int r = 0; r < 4; r++) { a.planes[r] = (const pixel*)(subpelPlanes0[r] ? subpelPlanes0[r] : subpelPlanes0[0]); a.planes[4 + r] = (const pixel*)(subpelPlanes1[r] ? subpelPlanes1[r] : subpelPlanes1[0]); }
+    for (int r = 0; r < X265HIP_MAX_REF; r++) { a.planes[r] = (const pixel*)(subpelPlanes0[r] ? subpelPlanes0[r] : subpelPlanes0[0]); a.planes[X265HIP_MAX_REF + r] = (const pixel*)(subpelPlanes1[r] ? subpelPlanes1[r] : subpelPlanes1[0]); }
     hipLaunchKernelGGL(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd, ref0, ref1);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

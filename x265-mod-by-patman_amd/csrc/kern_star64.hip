@@ -629,7 +629,7 @@ bool xh_star64_ok(intptr_t refStride, int merange)
 int xh_star64(void* stream, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride, const x265hip_me_task* tasks, int n,
               const uint16_t* costCentre, int costHalfRange, int merange, x265hip_me_result* results, const x265hip_me_result* mvpSource)
 {
-    static const int dbg = getenv("X265HIP_STAR64_DBG") ? atoi(getenv("X265HIP_STAR64_DBG")) : 0;      // timing experiments only (results are wrong with it)
+    static const int dbg = xh_experiment("X265HIP_STAR64_DBG") ? atoi(xh_experiment("X265HIP_STAR64_DBG")) : 0;      // timing experiments only (results are wrong with it)
     hipLaunchKernelGGL(star64_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride,
                        tasks, n, costCentre, costHalfRange, merange, results, mvpSource, dbg);
     XH_LAUNCH_CHECK();

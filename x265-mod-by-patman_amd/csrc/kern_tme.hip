@@ -79,18 +79,21 @@ size_t launch_workspace(int nCtu)
 }
 // Side streams of the chain launches of one caller stream (the kernel configurations run side by side)
 struct ChainStreams { hipStream_t cs[8]; hipEvent_t fork, join[8]; };
-ChainStreams* chain_streams(hipStream_t mainStream)
+std::mutex g_chainMu;
+std::map<std::pair<int, hipStream_t>, std::unique_ptr<ChainStreams>> g_chainSets;      // keyed by (device, caller's stream); dropped by x265hip_tme_release_stream
+ChainStreams* chain_streams(int device, hipStream_t mainStream)
 {
-    static std::mutex mu;
-    static std::map<hipStream_t, std::unique_ptr<ChainStreams>> sets;
+    std::mutex& mu = g_chainMu;
+    auto& sets = g_chainSets;
+    const std::pair<int, hipStream_t> key(device, mainStream);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = sets.find(mainStream);
+    auto it = sets.find(key);
     if (it != sets.end()) return it->second.get();
     std::unique_ptr<ChainStreams> up(new ChainStreams());
     if (hipEventCreateWithFlags(&up->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
     for (int i = 0; i < 8; i++)
         if (hipStreamCreateWithFlags(&up->cs[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&up->join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-    return (sets[mainStream] = std::move(up)).get();
+    return (sets[key] = std::move(up)).get();
 }
 // The level lists of a schedule (built once per schedule, kept: the copies to the device read them asynchronously)
 struct ChainPlan { std::vector<int16_t> sched; std::vector<uint8_t> later; std::vector<int> shapeKeys, nLevels, firstStep; };
@@ -159,6 +162,21 @@ extern "C" size_t x265hip_tme_workspace(int nCtu)
     return ((size_t)nCtu * per + 16 * 256) * XH_TME_CHAINS + chain_workspace(nCtu);
 }
 
+// the side streams x265hip_tme_frame keeps for a caller's stream: to be released before that stream is destroyed (x265hip_ctx_destroy does it), so that a recycled
+// handle never finds another stream's set
+extern "C" void x265hip_tme_release_stream(void* stream)
+{
+    std::lock_guard<std::mutex> lock(g_chainMu);
+    for (auto it = g_chainSets.begin(); it != g_chainSets.end();)
+        if (it->first.second == (hipStream_t)stream)
+        {
+            for (int i = 0; i < 8; i++) { (void)hipStreamSynchronize(it->second->cs[i]); (void)hipStreamDestroy(it->second->cs[i]); (void)hipEventDestroy(it->second->join[i]); }
+            (void)hipEventDestroy(it->second->fork);
+            it = g_chainSets.erase(it);
+        }
+        else ++it;
+}
+
 extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
 {
     if (!a || !a->steps || a->nSteps < 1 || !a->curPlane || !a->table || !a->areaBest || !a->temporal || !a->bitsRow || !a->workspace || a->nQp < 1 || a->nQp > 64 || (a->nQp > 1 && !a->qpIndex)) { set_error("tme_frame: missing arguments"); return X265HIP_EARG; }
@@ -170,14 +188,19 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
     const int nl = a->isP ? 1 : 2;
     for (int l = 0; l < nl; l++)
     {
-        if (a->numRef[l] < 1 || a->numRef[l] > 4) { set_error("tme_frame: %d references in list %d", a->numRef[l], l); return X265HIP_EARG; }
+        if (a->numRef[l] < 1 || a->numRef[l] > X265HIP_MAX_REF) { set_error("tme_frame: %d references in list %d", a->numRef[l], l); return X265HIP_EARG; }
         for (int r = 0; r < a->numRef[l]; r++) if (!a->refs[l][r].mePlane || !a->refs[l][r].mePhase || !a->refs[l][r].reconPhase) { set_error("tme_frame: planes of list %d reference %d missing", l, r); return X265HIP_EARG; }
     }
+    // the launches, side streams and events below belong to the device of the caller's stream, whatever device the calling thread had selected
+    int device = 0;
+    if (stream) { hipDevice_t dv = 0; XH_HIP(hipStreamGetDevice((hipStream_t)stream, &dv)); device = (int)dv; } else XH_HIP(hipGetDevice(&device));
+    XH_HIP(hipSetDevice(device));
     hipStream_t mainStream = (hipStream_t)stream;
-    static const bool launches = getenv("X265HIP_TME_LAUNCHES") != nullptr;             // A/B switch: every stage of every entry its own launch (below)
+    const bool launches = (a->flags & X265HIP_TME_LAUNCH_PER_STAGE) != 0;               // the diagnostic form: every stage of every entry its own launch (below)
     if (!launches && (a->searchMethod == X265HIP_ME_DIA || a->searchMethod == X265HIP_ME_HEX || a->searchMethod == X265HIP_ME_STAR || a->searchMethod == X265HIP_ME_FULL || a->searchMethod == X265HIP_ME_UMH))
     {   // ---- the chains inside the kernels (tme_chain.inc): one launch per kernel configuration, side by side on their own streams ----
-        ChainStreams* side = chain_streams(mainStream);                                 // one set per caller's stream, whichever thread calls
+        const bool packed = (a->flags & X265HIP_TME_PACKED_GROUPS) != 0;
+        ChainStreams* side = chain_streams(device, mainStream);                                 // one set per caller's stream, whichever thread calls
         if (!side) { set_error("tme_frame: could not create the chain streams"); return X265HIP_EDEVICE; }
         hipStream_t* cs = side->cs; hipEvent_t cFork = side->fork; hipEvent_t* cJoin = side->join;
         if (a->nSteps > 1024) { set_error("tme_frame: more than 1024 schedule entries"); return X265HIP_EARG; }
@@ -197,6 +220,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
         xh_chain_args A{};
         A.s.isP = a->isP; A.s.numRef[0] = a->numRef[0]; A.s.numRef[1] = a->isP ? 0 : a->numRef[1]; A.s.searchRange = a->searchRange; A.s.picW = a->picWidth; A.s.picH = a->picHeight;
         A.s.ctuSize = a->ctuSize; A.s.numCtuX = nCtuX; A.s.lowresBlocksX = a->lowresBlocksX; A.s.stride = a->stride; A.s.origin = a->origin;
+        A.s.frameParallel = a->frameParallel != 0; A.s.refLag = a->refLagPixels > 0 ? a->refLagPixels : a->picHeight;
         A.s.amvp.curPOC = a->curPOC; A.s.amvp.temporalMvp = a->temporalMvp;
         for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) A.s.amvp.refPOC[l][r] = a->refPOC[l][r];
         for (int q = 0; q < a->nQp; q++) A.lambdas.v[q] = a->lambdas[q];
@@ -224,8 +248,8 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
             }
             if (!nKeys) continue;
             XH_HIP(hipStreamWaitEvent(cs[config], cFork, 0));
-            const int rc = a->searchMethod == X265HIP_ME_STAR ? xh_tme_chain_star(cs[config], config, &A, nKeys) : a->searchMethod == X265HIP_ME_UMH ? xh_tme_chain_umh(cs[config], config, &A, nKeys)
-                                                              : xh_tme_chain_hex(cs[config], config, &A, nKeys);
+            const int rc = a->searchMethod == X265HIP_ME_STAR ? xh_tme_chain_star(cs[config], config, &A, nKeys, packed) : a->searchMethod == X265HIP_ME_UMH ? xh_tme_chain_umh(cs[config], config, &A, nKeys, packed)
+                                                              : xh_tme_chain_hex(cs[config], config, &A, nKeys, packed);
             if (rc) return rc;
             XH_HIP(hipEventRecord(cJoin[config], cs[config]));
             XH_HIP(hipStreamWaitEvent(mainStream, cJoin[config], 0));
@@ -261,11 +285,12 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
     x265hip_me_result* rA = (x265hip_me_result*)take(sizeof(x265hip_me_result) * nCtu); x265hip_me_result* rB = (x265hip_me_result*)take(sizeof(x265hip_me_result) * nCtu);
     x265hip_bidir_task* b0 = (x265hip_bidir_task*)take(sizeof(x265hip_bidir_task) * nCtu); x265hip_bidir_task* b1 = (x265hip_bidir_task*)take(sizeof(x265hip_bidir_task) * nCtu);
     int32_t* s0 = (int32_t*)take(4 * nCtu); int32_t* s1 = (int32_t*)take(4 * nCtu); int8_t* br0 = (int8_t*)take(nCtu); int8_t* br1 = (int8_t*)take(nCtu);
-    const void* ph0[4] = {}; const void* ph1[4] = {};
-    for (int r = 0; r < 4; r++) { ph0[r] = r < a->numRef[0] ? a->refs[0][r].reconPhase : nullptr; ph1[r] = (!a->isP && r < a->numRef[1]) ? a->refs[1][r].reconPhase : nullptr; }
+    const void* ph0[X265HIP_MAX_REF] = {}; const void* ph1[X265HIP_MAX_REF] = {};
+    for (int r = 0; r < X265HIP_MAX_REF; r++) { ph0[r] = r < a->numRef[0] ? a->refs[0][r].reconPhase : nullptr; ph1[r] = (!a->isP && r < a->numRef[1]) ? a->refs[1][r].reconPhase : nullptr; }
     Slice s{};
     s.isP = a->isP; s.numRef[0] = a->numRef[0]; s.numRef[1] = a->isP ? 0 : a->numRef[1]; s.searchRange = a->searchRange; s.picW = a->picWidth; s.picH = a->picHeight;
     s.ctuSize = a->ctuSize; s.numCtuX = nCtuX; s.lowresBlocksX = a->lowresBlocksX; s.stride = a->stride; s.origin = a->origin;
+    s.frameParallel = a->frameParallel != 0; s.refLag = a->refLagPixels > 0 ? a->refLagPixels : a->picHeight;
     s.amvp.curPOC = a->curPOC; s.amvp.temporalMvp = a->temporalMvp;
     for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) s.amvp.refPOC[l][r] = a->refPOC[l][r];
     const dim3 grid((nCtu + 255) / 256), block(256);
@@ -340,19 +365,19 @@ namespace {
 __global__ __launch_bounds__(256) void tme_area_kernel(const x265hip_me_result* __restrict__ res, const int32_t* __restrict__ where, int nTasks, int nl, int numRef0, int numRef1,
                                                        const int16_t* __restrict__ median, int16_t* __restrict__ areaBest)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, lr = blockIdx.y, l = lr >> 2, r = lr & 3;
+    const int i = blockIdx.x * 256 + threadIdx.x, lr = blockIdx.y, l = lr / X265HIP_MAX_REF, r = lr % X265HIP_MAX_REF;
     if (i >= nTasks || l >= nl || r >= (l ? numRef1 : numRef0)) return;
     const int ca = where[i], c = ca / 5;
     int mx = res[(int64_t)lr * nTasks + i].mv[0], my = res[(int64_t)lr * nTasks + i].mv[1];                 // the full-pel MV as the reference stores it (search.cpp:363)
-    if (median) { const int16_t* m = median + (((int64_t)c * 2 + l) * 4 + r) * 3; if (m[0]) { mx = m[1]; my = m[2]; } }
-    int16_t* o = areaBest + (((int64_t)ca * 2 + l) * 4 + r) * 2;
+    if (median) { const int16_t* m = median + (((int64_t)c * 2 + l) * X265HIP_MAX_REF + r) * 3; if (m[0]) { mx = m[1]; my = m[2]; } }
+    int16_t* o = areaBest + (((int64_t)ca * 2 + l) * X265HIP_MAX_REF + r) * 2;
     o[0] = (int16_t)mx; o[1] = (int16_t)my;
 }
 }
 int xh_tme_area(void* stream, const x265hip_me_result* res, const int32_t* where, int nTasks, int nl, int numRef0, int numRef1, const int16_t* median, int16_t* areaBest)
 {
     if (nTasks <= 0) return X265HIP_OK;
-    hipLaunchKernelGGL(tme_area_kernel, dim3((nTasks + 255) / 256, 8), dim3(256), 0, (hipStream_t)stream, res, where, nTasks, nl, numRef0, numRef1, median, areaBest);
+    hipLaunchKernelGGL(tme_area_kernel, dim3((nTasks + 255) / 256, 2 * X265HIP_MAX_REF), dim3(256), 0, (hipStream_t)stream, res, where, nTasks, nl, numRef0, numRef1, median, areaBest);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

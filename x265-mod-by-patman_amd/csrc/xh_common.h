@@ -23,6 +23,15 @@ typedef uint32_t sse_t;
 #define XH_FENC_STRIDE 64          // reference common.h:71
 #define XH_WAVE 64
 
+// Experiment switches (environment variables of the A/B runs under profiles/) exist only in builds with -DX265HIP_EXPERIMENTS; a release library never reads
+// the environment, so a stray variable cannot change which kernel runs.
+#include <cstdlib>
+#ifdef X265HIP_EXPERIMENTS
+inline const char* xh_experiment(const char* name) { return getenv(name); }
+#else
+inline const char* xh_experiment(const char*) { return nullptr; }
+#endif
+
 namespace xh {
 
 // ---- error plumbing ----

@@ -21,7 +21,7 @@ constexpr int kHalf = 1 << 15;                 // MVD cost row: d in [-32768, 32
 
 bool desc_ok(const x265hip_batch_desc* d)
 {
-    return d && d->width >= CTU && d->height >= CTU && d->width % CTU == 0 && d->height % CTU == 0 && d->frames >= 1 && d->margin >= CTU + 16 + 8 &&
+    return d && d->width >= CTU && d->height >= CTU && d->width <= X265HIP_MAX_PIC_DIM && d->height <= X265HIP_MAX_PIC_DIM && d->width % CTU == 0 && d->height % CTU == 0 && d->frames >= 1 && d->margin >= CTU + 16 + 8 &&
            d->margin % 4 == 0 && d->qp >= 0 && d->qp <= 51 && d->merange >= 1 && d->subme >= 0 && d->subme <= 7 && d->tuLog2 >= 2 && d->tuLog2 <= 5;
 }
 int level_index(int level) { for (int i = 0; i < 4; i++) if (kLevels[i] == level) return i; return -1; }
@@ -67,10 +67,12 @@ extern "C" int x265hip_ctx_create(int device, x265hip_ctx** out)
 extern "C" void x265hip_ctx_destroy(x265hip_ctx* c)
 {
     if (!c) return;
-    (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream); x265hip_tme_release_stream(c->stream); (void)hipStreamDestroy(c->stream);
     delete c;
 }
 extern "C" void* x265hip_ctx_stream(x265hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int x265hip_ctx_device(const x265hip_ctx* c) { return c ? c->device : -1; }
 extern "C" int x265hip_ctx_sync(x265hip_ctx* c)
 {
     if (!c) { set_error("ctx_sync: null context"); return X265HIP_EARG; }

@@ -116,10 +116,10 @@ struct x265hip_tme
     std::map<int, std::vector<uint16_t>> hostRows;
     uint16_t* costTable = nullptr;             // [64][2 * kHalf + 1]: the rows of the picture's qps, in the order of desc->qps
     float* bitsRow = nullptr;
-    pixel* cur = nullptr; pixel* plane[2][4][2] = {}; pixel* phase[2][4][2] = {};      // this picture's: kept buffers or the slot's own ones
-    pixel* ownPlane[2][4][2] = {}; pixel* ownPhase[2][4][2] = {}; bool own[2][4][2] = {};       // [list][ref][0 = searched plane, 1 = reconstructed picture]
+    pixel* cur = nullptr; pixel* plane[2][X265HIP_MAX_REF][2] = {}; pixel* phase[2][X265HIP_MAX_REF][2] = {};      // this picture's: kept buffers or the slot's own ones
+    pixel* ownPlane[2][X265HIP_MAX_REF][2] = {}; pixel* ownPhase[2][X265HIP_MAX_REF][2] = {}; bool own[2][X265HIP_MAX_REF][2] = {};       // [list][ref][0 = searched plane, 1 = reconstructed picture]
     int64_t planeElems = 0;
-    x265hip_inter_choice* table = nullptr; x265hip_inter_choice* refTable[2][4] = {}; int16_t* lowres[2][4] = {};
+    x265hip_inter_choice* table = nullptr; x265hip_inter_choice* refTable[2][X265HIP_MAX_REF] = {}; int16_t* lowres[2][X265HIP_MAX_REF] = {};
     int16_t* areaBest = nullptr; x265hip_tme_temporal* temporal = nullptr; uint8_t* qpIndex = nullptr; void* workspace = nullptr; size_t workspaceBytes = 0;
     x265hip_me_task* dTasks = nullptr; x265hip_me_result* dResults = nullptr; int32_t* dWhere = nullptr; int16_t* dMedian = nullptr;
     std::vector<x265hip_me_task> hTasks; std::vector<int32_t> hWhere;      // kept: the copies read them after the call that filled them returned
@@ -147,11 +147,14 @@ constexpr int kKeep = 20;                  // reconstructed pictures kept on the
 extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** out)
 {
     if (!ctx || !out || width < 8 || height < 8) { set_error("tme_create: bad picture size"); return X265HIP_EARG; }
+    // CUData::clipMv's quarter-pel limits, (size + 8 - pos - 1) << 2, travel as int16 in the task records
+    if (width > X265HIP_MAX_PIC_DIM || height > X265HIP_MAX_PIC_DIM) { set_error("tme_create: %dx%d: pictures up to %d pixels a side", width, height, X265HIP_MAX_PIC_DIM); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(x265hip_ctx_device(ctx)));
     const int n = x265hip_tme_schedule(ctuSize, minCuSize, rect, amp, nullptr, 0);
     if (n <= 0) { set_error("tme_create: bad CTU / CU sizes"); return X265HIP_EARG; }
     x265hip_tme* t = new (std::nothrow) x265hip_tme();
     if (!t) return X265HIP_EARG;
-    t->prof = getenv("X265HIP_TME_PROF") != nullptr;
+    t->prof = xh_experiment("X265HIP_TME_PROF") != nullptr;
     for (int q = 0; q < 64; q++) t->rowQp[q] = -1;
     t->ctx = ctx; t->width = width; t->height = height; t->ctu = ctuSize; t->nCtuX = (width + ctuSize - 1) / ctuSize; t->nCtu = t->nCtuX * ((height + ctuSize - 1) / ctuSize);
     t->steps.resize(n);
@@ -176,9 +179,9 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
     if (hipMemcpy(t->bitsRow, bits.data(), bits.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { x265hip_tme_destroy(t); return X265HIP_EDEVICE; }
     t->workspaceBytes = x265hip_tme_workspace(t->nCtu);
     char* ws = nullptr;
-    if ((rc = t->alloc(ws, t->workspaceBytes)) || (rc = t->alloc(t->table, (size_t)t->nCtu * 593)) || (rc = t->alloc(t->areaBest, (size_t)t->nCtu * 5 * 2 * 4 * 2)) ||
+    if ((rc = t->alloc(ws, t->workspaceBytes)) || (rc = t->alloc(t->table, (size_t)t->nCtu * 593)) || (rc = t->alloc(t->areaBest, (size_t)t->nCtu * 5 * 2 * X265HIP_MAX_REF * 2)) ||
         (rc = t->alloc(t->temporal, (size_t)t->nCtu * n * 2)) || (rc = t->alloc(t->qpIndex, (size_t)t->nCtu * n)) || (rc = t->alloc(t->dTasks, (size_t)t->nCtu * 5)) ||
-        (rc = t->alloc(t->dResults, (size_t)t->nCtu * 5 * 8)) || (rc = t->alloc(t->dWhere, (size_t)t->nCtu * 5)) || (rc = t->alloc(t->dMedian, (size_t)t->nCtu * 2 * 4 * 3)) || (rc = t->alloc(t->costTable, (size_t)64 * (2 * kHalf + 1))))
+        (rc = t->alloc(t->dResults, (size_t)t->nCtu * 5 * 2 * X265HIP_MAX_REF)) || (rc = t->alloc(t->dWhere, (size_t)t->nCtu * 5)) || (rc = t->alloc(t->dMedian, (size_t)t->nCtu * 2 * X265HIP_MAX_REF * 3)) || (rc = t->alloc(t->costTable, (size_t)64 * (2 * kHalf + 1))))
     { x265hip_tme_destroy(t); return rc; }
     t->workspace = ws;
     *out = t;
@@ -200,8 +203,13 @@ extern "C" int x265hip_tme_entries(const x265hip_tme* t, const x265hip_tme_step*
 extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_desc* d)
 {
     if (!t || !d || !d->curPlane || !d->table || !d->temporal || d->nQp < 1 || d->nQp > 64 || !d->qpIndex || !d->areaQpIndex) { set_error("tme_picture: bad arguments"); return X265HIP_EARG; }
-    hipStream_t st = (hipStream_t)x265hip_ctx_stream(t->ctx);
     const int nl = d->isP ? 1 : 2, nS = (int)t->steps.size(), nCtu = t->nCtu;
+    for (int l = 0; l < nl; l++)      // before anything is indexed by it: refs[][] and every per-reference array here hold X265HIP_MAX_REF entries
+        if (d->numRef[l] < 1 || d->numRef[l] > X265HIP_MAX_REF) { set_error("tme_picture: %d references in list %d (1..%d)", d->numRef[l], l, X265HIP_MAX_REF); return X265HIP_EARG; }
+    if (d->width != t->width || d->height != t->height) { set_error("tme_picture: %dx%d picture on a %dx%d producer", d->width, d->height, t->width, t->height); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(x265hip_ctx_device(t->ctx)));      // the caller may be any thread of the encoder's pool (a new thread starts on device 0)
+    hipStream_t st = (hipStream_t)x265hip_ctx_stream(t->ctx);
+    const int refLag = d->frameThreads > 1 ? d->searchRange : (d->sourceHeight > 0 ? d->sourceHeight : d->height);
     const int64_t elems = d->planeElems;
     int rc;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -234,6 +242,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
             {
                 if (k == 1 && R.reconPlane == R.mePlane) { t->plane[l][r][1] = t->plane[l][r][0]; t->phase[l][r][1] = t->phase[l][r][0]; continue; }
                 const bool recon = k == 1 || R.reconPlane == R.mePlane;                      // a weighted plane belongs to the current picture: never kept
+                uint64_t* pendingKey = nullptr;
                 if (recon && R.reconKey)
                 {
                     x265hip_tme::Kept* slot = nullptr;
@@ -251,7 +260,8 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                             for (auto& kp : t->kept) if (kp.used != t->tick + 1 && (!slot || kp.used < slot->used)) slot = &kp;
                             if (!slot) { set_error("tme_picture: more distinct reference pictures than kept planes"); return X265HIP_EARG; }
                         }
-                        slot->key = R.reconKey;
+                        slot->key = 0;                      // named only once its planes are on their way (below): a failed call must not leave a keyed slot with stale planes
+                        pendingKey = &slot->key;
                     }
                     slot->used = t->tick + 1;
                     t->plane[l][r][k] = slot->plane; t->phase[l][r][k] = slot->phase;
@@ -265,6 +275,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                 if (!(recon && R.reconKey)) { t->plane[l][r][k] = t->ownPlane[l][r][k]; t->phase[l][r][k] = t->ownPhase[l][r][k]; }
                 XH_HIP(hipMemcpyAsync(t->plane[l][r][k], k ? R.reconPlane : R.mePlane, (size_t)elems * sizeof(pixel), hipMemcpyHostToDevice, st));
                 if ((rc = x265hip_subpel_planes(st, t->plane[l][r][k], d->stride, rows, t->phase[l][r][k], elems))) return rc;
+                if (pendingKey) *pendingKey = R.reconKey;
             }
             if (R.refTable)
             {
@@ -319,7 +330,8 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                     const int xmin = -((t->ctu + 8 + cx - 1) << 2), ymin = -((t->ctu + 8 + cy - 1) << 2), xmax = (d->width + 8 - cx - 1) << 2, ymax = (d->height + 8 - cy - 1) << 2;
                     const int dd = 32 << 2;
                     k.mvmin[0] = (int16_t)(std::min(xmax, std::max(xmin, -dd)) >> 2); k.mvmin[1] = (int16_t)(std::min(ymax, std::max(ymin, -dd)) >> 2);
-                    k.mvmax[0] = (int16_t)(std::min(xmax, std::max(xmin, dd)) >> 2); k.mvmax[1] = (int16_t)(std::max(std::min(ymax, std::max(ymin, dd)) >> 2, (int)k.mvmin[1]));
+                    k.mvmin[1] = (int16_t)std::min((int)k.mvmin[1], refLag);                                  // m_refLagPixels on both ends (search.cpp:5017-5018)
+                    k.mvmax[0] = (int16_t)(std::min(xmax, std::max(xmin, dd)) >> 2); k.mvmax[1] = (int16_t)(std::max(std::min(std::min(ymax, std::max(ymin, dd)) >> 2, refLag), (int)k.mvmin[1]));
                     k.mvpFrom = -1;
                     tasks.push_back(k); where.push_back(c * 5 + a);
                 }
@@ -328,13 +340,13 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     const int nTasks = (int)tasks.size();                                                 // nCtu * 5
     XH_HIP(hipMemcpyAsync(t->dTasks, tasks.data(), (size_t)nTasks * sizeof(x265hip_me_task), hipMemcpyHostToDevice, st));
     XH_HIP(hipMemcpyAsync(t->dWhere, where.data(), (size_t)nTasks * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (d->median) XH_HIP(hipMemcpyAsync(t->dMedian, d->median, (size_t)nCtu * 2 * 4 * 3 * sizeof(int16_t), hipMemcpyHostToDevice, st));
-    XH_HIP(hipMemsetAsync(t->areaBest, 0, (size_t)nCtu * 5 * 2 * 4 * 2 * sizeof(int16_t), st));
+    if (d->median) XH_HIP(hipMemcpyAsync(t->dMedian, d->median, (size_t)nCtu * 2 * X265HIP_MAX_REF * 3 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemsetAsync(t->areaBest, 0, (size_t)nCtu * 5 * 2 * X265HIP_MAX_REF * 2 * sizeof(int16_t), st));
     for (int l = 0; l < nl; l++)
         for (int r = 0; r < d->numRef[l]; r++)
             for (const Group& g : groups)
                 if ((rc = x265hip_diamond_batch(st, g.size, g.size, t->cur, d->stride, t->plane[l][r][0], d->stride, t->dTasks + g.first, g.n, t->costRows[d->qps[g.q]], kHalf,
-                                                t->dResults + (size_t)(l * 4 + r) * nTasks + g.first))) return rc;
+                                                t->dResults + (size_t)(l * X265HIP_MAX_REF + r) * nTasks + g.first))) return rc;
     if ((rc = xh_tme_area(st, t->dResults, t->dWhere, nTasks, nl, d->numRef[0], d->isP ? 0 : d->numRef[1], d->median ? t->dMedian : nullptr, t->areaBest))) return rc;
     if ((rc = table_up(t->table, d->table))) return rc;
     XH_HIP(hipMemcpyAsync(t->temporal, d->temporal, (size_t)nCtu * nS * 2 * sizeof(x265hip_tme_temporal), hipMemcpyHostToDevice, st));
@@ -345,6 +357,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     std::memcpy(a.refPOC, d->refPOC, sizeof(a.refPOC));
     a.searchRange = d->searchRange; a.searchMethod = d->searchMethod; a.subpelRefine = d->subpelRefine;
     a.picWidth = d->width; a.picHeight = d->height; a.ctuSize = t->ctu; a.lowresBlocksX = d->lowresBlocksX;
+    a.refLagPixels = refLag; a.frameParallel = d->frameThreads > 1; a.flags = d->flags;
     a.curPlane = t->cur; a.stride = d->stride; a.origin = d->origin; a.planeElems = elems;
     for (int l = 0; l < nl; l++)
         for (int r = 0; r < d->numRef[l]; r++)
@@ -366,7 +379,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
         if ((rc = xh_tme_slots(st, t->table, t->dPacked, t->dSlots, nU, nCtu, 0))) return rc;
         XH_HIP(hipMemcpyAsync(t->hPacked, t->dPacked, (size_t)nCtu * nU * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
     }
-    if (d->areaBestOut) XH_HIP(hipMemcpyAsync(d->areaBestOut, t->areaBest, (size_t)nCtu * 5 * 2 * 4 * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    if (d->areaBestOut) XH_HIP(hipMemcpyAsync(d->areaBestOut, t->areaBest, (size_t)nCtu * 5 * 2 * X265HIP_MAX_REF * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     XH_HIP(hipStreamSynchronize(st));
     if (t->sparse)
     {

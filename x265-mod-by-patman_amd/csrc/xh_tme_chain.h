@@ -20,7 +20,7 @@ struct xh_chain_args
     const uint8_t* later;                                  // per entry: bit d = neighbour d comes later in the schedule (its record is read from tableInit)
     const x265hip_inter_choice* tableInit;                 // the table as it was when the picture started
     const pixel* cur; int64_t planeElems;
-    xh_chain_ref refs[2][4];
+    xh_chain_ref refs[2][X265HIP_MAX_REF];
     x265hip_inter_choice* table; const int16_t* areaBest; const x265hip_tme_temporal* temporal; const uint8_t* qpIndex;
     const uint16_t* costRows; int costHalf; const float* bitsCentre; int bitsHalf;
     int searchRange, method, subme;
@@ -39,6 +39,6 @@ inline int xh_chain_config(int cuSize, int part)
     if (cuSize == 32) return part == 0 ? 5 : 6;
     return 7;
 }
-int xh_tme_chain_hex(void* stream, int config, const xh_chain_args* args, int nKeys);     // DIA / HEX / FULL
-int xh_tme_chain_star(void* stream, int config, const xh_chain_args* args, int nKeys);    // STAR
-int xh_tme_chain_umh(void* stream, int config, const xh_chain_args* args, int nKeys);     // UMH
+int xh_tme_chain_hex(void* stream, int config, const xh_chain_args* args, int nKeys, bool packed);     // DIA / HEX / FULL
+int xh_tme_chain_star(void* stream, int config, const xh_chain_args* args, int nKeys, bool packed);    // STAR
+int xh_tme_chain_umh(void* stream, int config, const xh_chain_args* args, int nKeys, bool packed);     // UMH

@@ -23,6 +23,7 @@ struct Lambdas { unsigned long long v[64]; };
 struct Slice
 {
     int isP, numRef[2], searchRange, picW, picH, ctuSize, numCtuX, lowresBlocksX;
+    int refLag, frameParallel;               // Search::m_refLagPixels (full pel; search.cpp:96) and m_bFrameParallel
     x265hip_amvp_params amvp;
     intptr_t stride; int64_t origin;
 };
@@ -62,7 +63,7 @@ __device__ __forceinline__ void tme_gather(const Slice& s, const x265hip_tme_ste
         S.bestCost[0] = S.bestCost[1] = 0xFFFFFFFFu; S.bestRef[0] = S.bestRef[1] = -1; S.lastMode = 0;
     }
     const int area = st.cuSize == s.ctuSize ? 0 : (cuAbsX >= (s.ctuSize >> 1)) + 2 * (cuAbsY >= (s.ctuSize >> 1)) + 1;     // analysis.cpp:175-179 (absolute position, as there)
-    const int16_t* ab = areaBest + ((((int64_t)ctu * 5 + area) * 2 + l) * 4 + r) * 2;
+    const int16_t* ab = areaBest + ((((int64_t)ctu * 5 + area) * 2 + l) * X265HIP_MAX_REF + r) * 2;
     S.mvpBase[0] = ab[0]; S.mvpBase[1] = ab[1];
     x265hip_amvp_task t;
 #pragma unroll
@@ -123,7 +124,17 @@ __device__ __forceinline__ void tme_build(const Slice& s, const x265hip_tme_step
     const int ctuX = (ctu % s.numCtuX) * s.ctuSize, ctuY = (ctu / s.numCtuX) * s.ctuSize;
     int mvp[2] = { S.mvpBase[0], S.mvpBase[1] };
     S.mvpIdx = 0;
-    if (S.numMvc > 0) { S.mvpIdx = selRes.mvpIdx; mvp[0] = S.amvp[S.mvpIdx][0]; mvp[1] = S.amvp[S.mvpIdx][1]; }
+    if (S.numMvc > 0)
+    {
+        S.mvpIdx = selRes.mvpIdx;
+        if (s.frameParallel && (S.amvp[0][0] != S.amvp[1][0] || S.amvp[0][1] != S.amvp[1][1]))
+        {   // selectMVP with frame threads: a candidate pointing below the rows the reference has finished is not costed (COST_MAX; search.cpp:2360-2365)
+            const int lim = (s.searchRange + 1) * 4;
+            const bool skip0 = S.amvp[0][1] >= lim, skip1 = S.amvp[1][1] >= lim;          // a costed candidate always beats COST_MAX; two skipped ones tie -> 0
+            if (skip0 || skip1) S.mvpIdx = (skip0 && !skip1) ? 1 : 0;
+        }
+        mvp[0] = S.amvp[S.mvpIdx][0]; mvp[1] = S.amvp[S.mvpIdx][1];
+    }
     S.mvpA[0] = mvp[0]; S.mvpA[1] = mvp[1];
     int numCand = S.numMvc;
     if (S.hasLowres) { S.mvc[numCand][0] = (int16_t)S.lowres[0]; S.mvc[numCand][1] = (int16_t)S.lowres[1]; numCand++; }
@@ -132,6 +143,9 @@ __device__ __forceinline__ void tme_build(const Slice& s, const x265hip_tme_step
     const int px = ctuX + st.pu[pi][0], py = ctuY + st.pu[pi][1];
     a.curOff = (int32_t)(s.origin + (int64_t)py * s.stride + px); a.refOff = a.curOff;
     int32_t c[4]; clip_limits(s, ctuX + st.cuX, ctuY + st.cuY, c);
+    // the window is derived on the device as clamp(mvp -+ range, limits) >> 2; setSearchRange's last clamp, min(full-pel y, m_refLagPixels) on both ends
+    // (search.cpp:5017-5018), is the same as an upper quarter-pel limit of 4 * lag + 3
+    c[3] = min(c[3], (s.refLag << 2) + 3);
     a.mvmin[0] = (int16_t)c[0]; a.mvmin[1] = (int16_t)c[1]; a.mvmax[0] = (int16_t)c[2]; a.mvmax[1] = (int16_t)c[3];
     a.qmvp[0] = (int16_t)mvp[0]; a.qmvp[1] = (int16_t)mvp[1];
 #pragma unroll
@@ -217,6 +231,7 @@ __device__ __forceinline__ void tme_bidir(const Slice& s, const x265hip_tme_step
             int32_t c[4]; clip_limits(s, ctuX + st.cuX, ctuY + st.cuY, c);
             const int d = max(s.picW, s.picH) << 2;
             int mnx = min(c[2], max(c[0], -d)) >> 2, mny = min(c[3], max(c[1], -d)) >> 2, mxx = min(c[2], max(c[0], d)) >> 2, mxy = min(c[3], max(c[1], d)) >> 2;
+            mny = min(mny, s.refLag); mxy = min(mxy, s.refLag);
             mxy = max(mxy, mny) + 2;
             mnx <<= 2; mny <<= 2; mxx <<= 2; mxy <<= 2;
 #pragma unroll

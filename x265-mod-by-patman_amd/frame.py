@@ -32,13 +32,16 @@ LA_TASK = np.dtype([("b", "<i4"), ("p0", "<i4"), ("p1", "<i4"), ("doSearch", "<i
 assert ME_TASK.itemsize == 76 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize == 20 and LA_TASK.itemsize == 36
 
 
+MAX_REF = 16                   # X265HIP_MAX_REF (include/x265hip_frame.h)
+
+
 class MeChroma(C.Structure):
     _fields_ = [("curCb", C.c_void_p), ("curCr", C.c_void_p), ("curStrideC", C.c_ssize_t), ("refCb", C.c_void_p), ("refCr", C.c_void_p), ("refStrideC", C.c_ssize_t),
                 ("curOffC", C.c_void_p), ("refOffC", C.c_void_p)]
 
 
 class MergeParams(C.Structure):
-    _fields_ = [("numRef", C.c_int * 2), ("results", (C.c_void_p * 4) * 2), ("mvpSource", (C.c_void_p * 4) * 2), ("subpelPlanes", (C.c_void_p * 4) * 2), ("planeElems", C.c_int64),
+    _fields_ = [("numRef", C.c_int * 2), ("results", (C.c_void_p * MAX_REF) * 2), ("mvpSource", (C.c_void_p * MAX_REF) * 2), ("subpelPlanes", (C.c_void_p * MAX_REF) * 2), ("planeElems", C.c_int64),
                 ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int), ("lambda_", C.c_uint64), ("bidir", C.c_int), ("sourceMaxDim", C.c_int)]
 
 
@@ -169,7 +172,7 @@ class FrameApi:
         return steps
 
     def tme_frame(self, *, is_p, num_ref, cur_poc, temporal_mvp, ref_poc, merange, method, subme, lams, qp_index, width, height, ctu, lowres_blocks_x, cur, stride, origin, plane_elems,
-                  refs, table, area_best, temporal, cost_rows, cost_half, bits_row, bits_half, steps):
+                  refs, table, area_best, temporal, cost_rows, cost_half, bits_row, bits_half, steps, flags=0, ref_lag=0, frame_parallel=False):
         """x265hip_tme_frame; refs[l][r] = dict(me_plane, me_phase, recon_phase, ref_table or None, lowres_mv or None) of device tensors; steps: host TME_STEP array"""
         class Ref(C.Structure):
             _fields_ = [("mePlane", C.c_void_p), ("mePhase", C.c_void_p), ("reconPhase", C.c_void_p), ("refTable", C.c_void_p), ("lowresMv", C.c_void_p)]
@@ -178,9 +181,10 @@ class FrameApi:
                         ("searchRange", C.c_int), ("searchMethod", C.c_int), ("subpelRefine", C.c_int),
                         ("picWidth", C.c_int), ("picHeight", C.c_int), ("ctuSize", C.c_int), ("lowresBlocksX", C.c_int),
                         ("curPlane", C.c_void_p), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("planeElems", C.c_int64),
-                        ("refs", (Ref * 4) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
+                        ("refs", (Ref * MAX_REF) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
                         ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 64), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
-                        ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t)]
+                        ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t),
+                        ("refLagPixels", C.c_int), ("flags", C.c_int), ("frameParallel", C.c_int)]
         a = Args()
         a.isP = int(is_p); a.numRef[0], a.numRef[1] = int(num_ref[0]), int(num_ref[1]); a.curPOC = int(cur_poc); a.temporalMvp = int(temporal_mvp)
         for l in range(2):
@@ -193,7 +197,7 @@ class FrameApi:
         a.picWidth, a.picHeight, a.ctuSize, a.lowresBlocksX = int(width), int(height), int(ctu), int(lowres_blocks_x)
         a.curPlane = _dp(cur); a.stride = int(stride); a.origin = int(origin); a.planeElems = int(plane_elems)
         for l in range(2):
-            for r in range(4):
+            for r in range(MAX_REF):
                 d = refs[l][r] if l < len(refs) and r < len(refs[l]) else None
                 if d:
                     a.refs[l][r].mePlane = _dp(d["me_plane"]); a.refs[l][r].mePhase = _dp(d["me_phase"]); a.refs[l][r].reconPhase = _dp(d["recon_phase"])
@@ -207,6 +211,7 @@ class FrameApi:
         ws_bytes = self.lib.x265hip_tme_workspace(n_ctu)
         ws = self.torch.zeros(ws_bytes, dtype=self.torch.uint8, device="cuda")
         a.workspace = _dp(ws); a.workspaceBytes = ws_bytes
+        a.flags, a.refLagPixels, a.frameParallel = int(flags), int(ref_lag), int(frame_parallel)
         self.h.check(self.lib.x265hip_tme_frame(self.stream(), C.byref(a)))
         self.torch.cuda.synchronize()           # `steps` and the workspace must outlive the launches
 

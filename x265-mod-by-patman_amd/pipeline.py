@@ -215,11 +215,81 @@ class FramePipeline:
                           mv_source=self.d_results[self.mv_level],
                           planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
 
+    # ---- sub-batches on their own streams ----
+    def _chunks(self, S):
+        """frame ranges of S sub-batches (independent pictures: nothing of one chunk reads anything of another)"""
+        b = [self.F * i // S for i in range(S + 1)]
+        return [(b[i], b[i + 1]) for i in range(S) if b[i + 1] > b[i]]
+
+    def launch_planes_chunk(self, f0, f1):
+        esz = self.d_ref.element_size()
+        rows = self.H + 2 * self.margin
+        for r in range(self.refs):
+            src = self.d_ref if r == 0 else self.d_refs[r]
+            dst = self.d_planes if r == 0 else self.d_planes_ref[r]
+            self.api.subpel_planes(src[f0 * self.plane:], self.stride, (f1 - f0) * rows, dst[f0 * self.plane:], self.plane_elems)
+
+    def launch_me_chunk(self, lv, f0, f1):
+        assert self.refs == 1
+        per = (self.W // lv) * (self.H // lv)
+        a, n = f0 * per, (f1 - f0) * per
+        parent = None if lv == CTU else self.d_results[2 * lv]
+        self.api.me_batch(lv, lv, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tasks[lv][a * ME_TASK.itemsize:], n,
+                          self.d_cost, self.half, self.merange, self.method, self.subme, self.d_results[lv][a * ME_RESULT.itemsize:], mvp_source=parent,
+                          planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
+
+    def launch_tq_chunk(self, f0, f1):
+        n_ = 1 << self.tu_log2
+        per = (self.W // n_) * (self.H // n_)
+        a, n = f0 * per, (f1 - f0) * per
+        self.api.tq_batch(self.tu_log2, self.d_cur, self.stride, self.d_ref, self.stride, self.d_tu[a * TU_TASK.itemsize:], n, self.qp, 85,
+                          self.d_coeff[a * n_ * n_:], self.d_numsig[a:], recon=self.d_recon, recon_stride=self.stride, sse=self.d_sse[a:] if self.d_sse is not None else None,
+                          mv_source=self.d_results[self.mv_level],
+                          planes=self.d_planes if self.use_planes else None, plane_elems=self.plane_elems if self.use_planes else 0)
+
+    def step_split(self, S, ev=None, skew=1):
+        """One pass of the hot path with the batch cut into S sub-batches of whole pictures, each on its own stream: the levels of one picture depend on
+        each other (a level's predictor is its parent CU's MV), pictures do not, so the LDS-bound 64x64 search of one sub-batch runs beside the latency-bound
+        16x16 / 8x8 searches of another.  Issue order is a software pipeline (stream s is `skew` stages behind stream s - 1)."""
+        t = self.torch
+        main = t.cuda.current_stream()
+        chunks = self._chunks(S)
+        if getattr(self, "sub_streams", None) is None or len(self.sub_streams) < len(chunks):
+            self.sub_streams = [t.cuda.Stream() for _ in chunks]
+            self.ev_sub = [t.cuda.Event() for _ in chunks]
+            self.ev_start = t.cuda.Event()
+        stages = (["planes"] if self.use_planes else []) + ["me%d" % lv for lv in LEVELS] + ["tq"]
+        self.ev_start.record(main)
+        for st in self.sub_streams[:len(chunks)]:
+            st.wait_event(self.ev_start)
+        for tick in range(len(stages) + skew * (len(chunks) - 1)):
+            for s, (f0, f1) in enumerate(chunks):
+                k = tick - skew * s
+                if k < 0 or k >= len(stages):
+                    continue
+                name, st = stages[k], self.sub_streams[s]
+                with t.cuda.stream(st):
+                    if ev is not None and s == 0:
+                        ev[name][0].record(st)
+                    if name == "planes":
+                        self.launch_planes_chunk(f0, f1)
+                    elif name == "tq":
+                        self.launch_tq_chunk(f0, f1)
+                    else:
+                        self.launch_me_chunk(int(name[2:]), f0, f1)
+                    if ev is not None and s == 0:
+                        ev[name][1].record(st)
+        for s in range(len(chunks)):
+            self.ev_sub[s].record(self.sub_streams[s])
+            main.wait_event(self.ev_sub[s])
+
     def step(self, ev=None):
         """One pass of the hot path.  The TQ launch depends on the MVs of one ME level only (mv_level), so it runs on a side
         stream next to the remaining (smaller-PU) ME launches -- a memory/MFMA-side kernel beside VALU-side ones -- and is joined
         before the step ends.  ev: optional {name: (start_event, end_event)} recorded around each launch on the stream it runs on."""
         t = self.torch
+        if getattr(self, "splits", 1) > 1:
+            return self.step_split(self.splits, ev, getattr(self, "skew", 1))
         main = t.cuda.current_stream()
         if getattr(self, "side", None) is None:
             self.side = t.cuda.Stream()

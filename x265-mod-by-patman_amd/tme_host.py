@@ -16,9 +16,10 @@ class PictureDesc(C.Structure):
                 ("searchRange", C.c_int), ("searchMethod", C.c_int), ("subpelRefine", C.c_int),
                 ("width", C.c_int), ("height", C.c_int), ("lowresBlocksX", C.c_int),
                 ("curPlane", C.c_void_p), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("planeElems", C.c_int64),
-                ("refs", (HostRef * 4) * 2),
+                ("refs", (HostRef * 16) * 2),
                 ("table", C.c_void_p), ("median", C.c_void_p), ("temporal", C.c_void_p),
-                ("nQp", C.c_int), ("qps", C.c_int * 64), ("qpIndex", C.c_void_p), ("areaQpIndex", C.c_void_p), ("areaBestOut", C.c_void_p)]
+                ("nQp", C.c_int), ("qps", C.c_int * 64), ("qpIndex", C.c_void_p), ("areaQpIndex", C.c_void_p),
+                ("sourceHeight", C.c_int), ("frameThreads", C.c_int), ("flags", C.c_int), ("areaBestOut", C.c_void_p)]
 
 
 class TmeProducer:
@@ -67,7 +68,7 @@ class TmeProducer:
         t["ref"] = -1
         return t
 
-    def picture(self, cur, refs, stride, origin, table, qp=28, is_p=True, merange=57, method=1, subme=2, cur_poc=1, ref_pocs=((0,), ()), ref_keys=None):
+    def picture(self, cur, refs, stride, origin, table, qp=28, is_p=True, merange=57, method=1, subme=2, cur_poc=1, ref_pocs=((0,), ()), ref_keys=None, flags=0, frame_threads=1):
         """cur: padded plane (numpy, pixel dtype); refs: [[plane, ...] of list 0, [...] of list 1]; table: INTER_CHOICE[n_ctu * 593] in / out.
         No temporal neighbours, no lookahead MVs, one qp: what a first P picture after an intra picture looks like."""
         d = PictureDesc()
@@ -90,6 +91,7 @@ class TmeProducer:
         temporal, qp_index, area_qp = self._keep
         d.table = table.ctypes.data; d.temporal = temporal.ctypes.data; d.nQp = 1; d.qps[0] = int(qp)
         d.qpIndex = qp_index.ctypes.data; d.areaQpIndex = area_qp.ctypes.data
+        d.flags = int(flags); d.frameThreads = int(frame_threads); d.sourceHeight = self.height
         rc = self.lib.x265hip_tme_picture(self.tme, C.byref(d))
         if rc:
             self.lib.x265hip_last_error.restype = C.c_char_p
