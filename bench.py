@@ -58,11 +58,10 @@ def parse():
                     "pyramid, x265hip_inter_merge_batch chooses per PU, the TQ stage compensates from the chosen reference.  value stays Mpixels/s of SOURCE pixels")
     ap.add_argument("--rect", action="store_true", help="also search the 2NxN / Nx2N PUs of every CU (bEnableRectInter, preset slow and up): 425 PUs per CTU instead of 85; one reference")
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
-    ap.add_argument("--splits", type=int, default=1, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
-    ap.add_argument("--skew", type=int, default=1, help="with --splits: stream s is issued this many stages behind stream s - 1")
+    ap.add_argument("--inner", type=int, default=5, help="passes over the resident batch per step (a step of the driver's --steps 20 then lasts long enough for the whole timed region to be >= 0.5 s)")
+    ap.add_argument("--splits", type=int, default=2, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
-    ap.add_argument("--overlap-tq", action="store_true", help="launch the TQ kernel beside me16/me8 on a side stream (it needs the me32 MVs only); measured gain 2 %, off by default so that per-kernel durations are those of kernels that own the GPU")
     ap.add_argument("--lookahead", action="store_true", help="also time the lookahead frame-cost batch (lowres init, intra estimate, estimateFrameCost of a 32-picture window); reported under \"lookahead\", not part of value")
     ap.add_argument("--intra", action="store_true", help="also time the intra mode scan (35 sa8d costs per CU, sizes 64..8) over the same frames; reported under \"intra_scan\", not part of value")
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
@@ -511,12 +510,22 @@ def intra_scan_leg(pipe, depth, steps):
             "checked_vs_reference": "%d CUs identical" % checked if checked else "reference binary not present"}
 
 
+def python_pipeline(args, wl, depth, W, H, pairs):
+    """the torch-tensor plumbing of the same step (x265hip_pkg.pipeline.FramePipeline): what the optional legs that work on torch tensors use"""
+    from x265hip_pkg.frame import FrameApi, mvcost_row
+    from x265hip_pkg.pipeline import FramePipeline
+    pp = FramePipeline(depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, recon=args.recon,
+                       cost_row=mvcost_row(depth, args.qp, 1 << 15), api=FrameApi(depth), use_planes=not args.no_planes, refs=1)
+    pp.upload([p[:2] for p in pairs])
+    return pp
+
+
 def cpu_baseline(pipe, depth, n_ctus):
     """The reference's own C primitives + motionEstimate (oracle/_ref, built from /root/reference sources) on the same
     tasks the GPU just processed, one process per host core; falls back to the restated oracle when the binary is
     missing.  Also cross-checks the sample's results against the GPU's (parity in the same run)."""
     from refproc import RefProc, ref_available
-    from x265hip_pkg.pipeline import LEVELS
+    from x265hip_pkg.host_batch import LEVELS
     cores = min(os.cpu_count() or 1, 64)
     ctus_per_frame = (pipe.W // 64) * (pipe.H // 64)
     n_ctus = min(n_ctus, ctus_per_frame * pipe.F)
@@ -576,8 +585,8 @@ def cpu_baseline(pipe, depth, n_ctus):
         import threading
         ns_per_proc = [0] * cores
         mismatches = []
-        coeff = pipe.d_coeff.cpu().numpy().reshape(-1, n_tu * n_tu)
-        numsig = pipe.d_numsig.cpu().numpy()
+        coeff, numsig = pipe.coeffs()
+        coeff = coeff.reshape(-1, n_tu * n_tu)
 
         def worker(i):
             for op, ints, tag in pending[i]:
@@ -755,8 +764,8 @@ def main():
     import torch
     import torch.distributed as dist
     import x265hip  # noqa: F401
-    from x265hip_pkg.frame import FrameApi, mvcost_row
-    from x265hip_pkg.pipeline import FramePipeline, LEVELS
+    from x265hip_pkg.frame import mvcost_row
+    from x265hip_pkg.host_batch import HostBatch, LEVELS
     from x265hip_pkg.sharding import init_ranks, max_over_ranks, whole_job_mpixels_per_s
 
     if not torch.cuda.is_available():
@@ -764,13 +773,14 @@ def main():
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))      # before the process group exists: RCCL binds its communicator to the current device
     rank, local_rank, world = init_ranks(args.gpus, "nccl", torch.cuda.device_count())
 
-    api = FrameApi(depth)
-    half = 1 << 15
-    cost_row = mvcost_row(depth, args.qp, half)
-    pipe = FramePipeline(depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"],
-                         tu_log2=args.tu, recon=args.recon, cost_row=cost_row, api=api, use_planes=not args.no_planes, refs=args.refs, rect=args.rect)
-    assert pipe.margin == MARGIN
-    pipe.upload(pairs)                      # inputs are resident in HBM before the timed region
+    # The step is driven by the C++ host of the path (include/x265hip_ctx.h: x265hip_batch_*, csrc/xh_ctx.cpp) -- what a C++ encoder links; Python only calls it.
+    # torch is here for the process group (barrier, max over ranks) and the device-wide synchronisation around the timed region.
+    lib = x265hip.HipLib(depth, fill_table=False).lib
+    pipe = HostBatch(lib, depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, margin=MARGIN,
+                     recon=args.recon, use_planes=not args.no_planes, refs=args.refs, rect=args.rect, streams=args.splits, device=local_rank)
+    pipe.cost_row_host = mvcost_row(depth, args.qp, 1 << 15)
+    pipe.upload([p[:1 + args.refs] for p in pairs])                      # inputs are resident in HBM before the timed region
+    assert np.array_equal(pipe.device_plane(1, 0), pairs[0][1].reshape(-1)), "the device's border extension differs from the host-padded plane"
 
     def barrier():
         torch.cuda.synchronize()
@@ -778,19 +788,17 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    pipe.splits, pipe.skew = args.splits, args.skew
-    for _ in range(args.warmup):
+    for _ in range(args.warmup * args.inner):
         pipe.step()
     barrier()
     names = pipe.kernel_names()
-    # per-kernel HIP events on every 4th step only: an event between two launches keeps the tail of one kernel from
-    # overlapping the head of the next (measured: ~5 % of the step time when every launch is bracketed)
-    sampled = [k for k in range(args.steps) if k % 4 == 0]
-    events = {k: {n: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for n in names} for k in sampled}
-    pipe.overlap_tq = args.overlap_tq
+    # per-stage HIP events (recorded by the host on the stream each stage runs on, x265hip_batch_set_timing) on every 4th step only: an event between two launches
+    # keeps the tail of one kernel from overlapping the head of the next (measured: ~5 % of the step time when every launch is bracketed)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        pipe.step(events.get(k))                    # events (when given) are recorded on the stream each kernel is launched on
+        pipe.set_timing(k % 4 == 0)
+        for _ in range(args.inner):                 # one step = `inner` passes of the hot path over the resident batch (the timed region of the driver's 20 steps is >= 0.5 s)
+            pipe.step()
     barrier()
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda")
@@ -800,9 +808,10 @@ def main():
         dist.all_gather_object(devices, "%d:%s" % (local_rank, torch.cuda.get_device_name(local_rank)))
 
     if rank == 0:
-        kms = {n: float(np.mean([events[k][n][0].elapsed_time(events[k][n][1]) for k in sampled])) for n in names}
+        kms = pipe.read_timing()                    # mean over the sampled passes; stages of sub-batch 0
         bpp = 1 if depth == 8 else 2
-        px = pipe.pixels_per_step
+        px = pipe.pixels_per_step * args.inner      # pixels of one step
+        share = pipe.sub_batch_pictures() / args.frames      # the part of the batch one timed launch group covers
         n_tu = 1 << args.tu
         alg = pipe.algorithmic_bytes()              # each plane byte once per launch + the records it writes
         # dominant kernel = strictly the longest average launch of the step, whatever it is bound by
@@ -811,7 +820,7 @@ def main():
         traffic_all, traffic_src = profile_figure(args.workload, "traffic")
         valu_all, valu_src = profile_figure(args.workload, "valu")
         valu_peak = N_SIMD * GPU_CLOCK_HZ / VALU_CYCLES
-        step_bytes = px * ((1 + args.refs) * bpp + 2) + sum(len(pipe.tasks_host[lv]) for lv in LEVELS) * 16       # SURVEY 8(d) fused S1-S3: source + reference(s) once, MVs + coefficients out
+        step_bytes = px * ((1 + args.refs) * bpp + 2) + args.inner * sum(len(pipe.tasks_host[lv]) for lv in LEVELS) * 16       # SURVEY 8(d) fused S1-S3: source + reference(s) once, MVs + coefficients out
         step_gbs = step_bytes / (dt / args.steps) / 1e9
         value = whole_job_mpixels_per_s(world, px, args.steps, dt)
         out = {
@@ -820,11 +829,13 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
-            "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames,
+            "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames * args.inner,
+                       "step": "%d passes of the hot path over a resident batch of %d frame pairs" % (args.inner, args.frames), "host": "C++ (x265hip_batch_step, csrc/xh_ctx.cpp)",
+                       "streams": "%d sub-batches of whole pictures on their own streams" % args.splits if args.splits > 1 else "one stream",
                        "ctu": 64, "pus_per_ctu": 425 if args.rect else 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": args.refs, "qp": args.qp,
-                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": ("TQ on a side stream beside the me16/me8 launches (it needs the me32 MVs only), joined per step" if pipe.overlap_tq else "kernel by kernel") + "; per-kernel events on every 4th step", "sharding": "independent frames per GPU, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "strictly the longest average launch of the step", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_all.get(dom), "traffic_source": traffic_src if traffic_all.get(dom) is not None else None,
+                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": "stage by stage per sub-batch; per-stage events on every 4th step (sub-batch 0)", "sharding": "independent frames per GPU, no collectives"},
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "strictly the longest average launch group of the step" + ("; a launch covers one of %d sub-batches, stages of different sub-batches run concurrently (their times do not add up to ms_per_step)" % args.splits if args.splits > 1 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": (traffic_all.get(dom) * share if traffic_all.get(dom) is not None else None), "traffic_source": traffic_src if traffic_all.get(dom) is not None else None,
                          "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
                          "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()},
                          "all_kernels_GBps": {k: round(alg[k] / (v * 1e-3) / 1e9, 2) for k, v in kms.items()}},
@@ -833,12 +844,14 @@ def main():
             "roofline_valu": {"bound": "valu issue", "unit": "G wave-instr/s", "peak": round(valu_peak / 1e9, 1),
                               "peak_rule": "%d SIMDs x %.1f GHz / %d clocks per wave64 instruction" % (N_SIMD, GPU_CLOCK_HZ / 1e9, VALU_CYCLES),
                               "insts_source": valu_src,
-                              "kernels": {k: {"insts": int(valu_all[k]), "achieved": round(valu_all[k] / (kms[k] * 1e-3) / 1e9, 1), "frac": round(valu_all[k] / (kms[k] * 1e-3) / valu_peak, 4)}
-                                          for k in kms if k in valu_all}},
+                              "kernels": {k: {"insts": int(valu_all[k] * share), "achieved": round(valu_all[k] * share / (kms[k] * 1e-3) / 1e9, 1), "frac": round(valu_all[k] * share / (kms[k] * 1e-3) / valu_peak, 4)}
+                                          for k in kms if k in valu_all},
+                              "step": ({"insts": int(sum(valu_all[k] for k in kms if k in valu_all) * args.inner), "achieved": round(sum(valu_all[k] for k in kms if k in valu_all) * args.inner / (dt / args.steps) / 1e9, 1),
+                                        "frac": round(sum(valu_all[k] for k in kms if k in valu_all) * args.inner / (dt / args.steps) / valu_peak, 4)} if valu_all else None)},
             # the whole step against the HBM bound of SURVEY 8(d): source and reference read once, MVs and coefficients written
             "roofline_step": {"bound": "hbm", "bytes_rule": "pixels x (2*bpp + 2) + 16 B per PU", "bytes": int(step_bytes), "achieved": round(step_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(step_gbs / HBM_PEAK_GBS, 5),
-                              "traffic_per_step": (sum(v for k, v in traffic_all.items() if k in kms) or None) if traffic_all else None, "traffic_source": traffic_src},
+                              "traffic_per_step": (sum(v for k, v in traffic_all.items() if k in kms) * args.inner or None) if traffic_all else None, "traffic_source": traffic_src},
             "e2e_fps": None,
         }
         e2e_path = os.path.join(ROOT, "profiles", "e2e_fps.json")
@@ -855,7 +868,7 @@ def main():
         if not args.no_tme:
             out["tme_producer"] = tme_producer_leg(depth)
         if args.intra:
-            out["intra_scan"] = intra_scan_leg(pipe, depth, max(2, min(args.steps, 10)))
+            out["intra_scan"] = intra_scan_leg(python_pipeline(args, wl, depth, W, H, pairs), depth, max(2, min(args.steps, 10)))
         if args.lookahead:
             out["lookahead"] = lookahead_leg(depth, max(2, min(args.steps, 10)))
         if args.filters:

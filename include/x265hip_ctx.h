@@ -45,6 +45,13 @@ typedef struct x265hip_batch_desc
     int tuLog2;             /* transform size of the TQ stage: 2..5                                                                    */
     int recon;              /* != 0: also dequant -> IDCT -> reconstruction + SSE (S4)                                                 */
     int usePlanes;          /* != 0: quarter-pel phase planes of the reference stack (x265hip_subpel_planes)                           */
+    int refs;               /* list-0 reference pictures searched per source picture: 1..X265HIP_MAX_REF (0 = 1; param->maxNumReferences: medium 3, slow 4,
+                               slower 5 -- param.cpp:567-608).  Every reference is searched down the pyramid with its own predictor chain (m_areaBestMV[area][list][ref],
+                               analysis.cpp:248-306), x265hip_inter_merge_batch chooses per PU, the TQ stage compensates each TU from the chosen reference.  > 1 needs usePlanes */
+    int rect;               /* != 0: also the 2NxN and Nx2N PUs of every CU (param->bEnableRectInter: preset slow and up): 425 PUs per CTU instead of 85, each seeded
+                               by its own CU's 2Nx2N result in the same reference                                                       */
+    int streams;            /* 1..8 (0 = 1): the batch is cut into this many sub-batches of whole pictures, each stepped on its own stream (pictures are independent,
+                               the levels of one picture are not); x265hip_batch_step stays ordered on the context's stream               */
 } x265hip_batch_desc;
 
 /* Pure host code (no GPU needed): the task lists x265hip_batch_create uploads.  level = 64, 32, 16 or 8.  Task k of a level is PU
@@ -52,19 +59,32 @@ typedef struct x265hip_batch_desc
  * CUData::clipMv's (cudata.cpp:2094-2107) with the search window derived on the device (X265HIP_ME_WINDOW). */
 int   x265hip_batch_task_count(const x265hip_batch_desc* desc, int level);
 int   x265hip_batch_build_me_tasks(const x265hip_batch_desc* desc, int level, x265hip_me_task* out);
+/* the rectangular partitions w x h (2NxN: w = 2h = CU size; Nx2N: h = 2w): task k = PU (frame, row, column) in raster order of the w x h grid, mvpFrom = its CU's 2Nx2N task */
+int   x265hip_batch_rect_task_count(const x265hip_batch_desc* desc, int w, int h);
+int   x265hip_batch_build_rect_tasks(const x265hip_batch_desc* desc, int w, int h, x265hip_me_task* out);
 int   x265hip_batch_tu_count(const x265hip_batch_desc* desc);
 int   x265hip_batch_build_tu_tasks(const x265hip_batch_desc* desc, x265hip_tu_task* out);
 
 int   x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* desc, x265hip_batch** batch);
 void  x265hip_batch_destroy(x265hip_batch* batch);
-/* which: 0 = source, 1 = reference.  pixels: the unpadded width x height picture in HOST memory (pixel = uint8_t / uint16_t by library),
+/* which: 0 = source, 1 + r = list-0 reference r.  pixels: the unpadded width x height picture in HOST memory (pixel = uint8_t / uint16_t by library),
  * strideElems its row pitch.  The padded plane is assembled on the device. */
 int   x265hip_batch_upload_plane(x265hip_batch* batch, int which, int frame, const void* pixels, intptr_t strideElems);
 int   x265hip_batch_step(x265hip_batch* batch);
-int   x265hip_batch_read_results(x265hip_batch* batch, int level, x265hip_me_result* out /* x265hip_batch_task_count entries */);
+int   x265hip_batch_read_results(x265hip_batch* batch, int level, x265hip_me_result* out /* x265hip_batch_task_count entries */);       /* reference 0, 2Nx2N */
+int   x265hip_batch_read_results_ref(x265hip_batch* batch, int w, int h, int ref, x265hip_me_result* out);      /* any searched shape (square or, with rect, 2NxN / Nx2N), any reference */
+int   x265hip_batch_read_choices(x265hip_batch* batch, int w, int h, struct x265hip_inter_choice* out);         /* refs > 1: the per-PU choice among the references */
+/* per-stage timing of sub-batch 0 (HIP events on the stream the stage runs on): while set_timing is 1 every step records its own event set (the last 64 are kept);
+ * read_timing synchronises the batch's streams, returns the number of steps averaged (> 0) and the mean milliseconds of every stage over them, in
+ * x265hip_batch_stage_name order ("planes", "me64", ["rect64",] ..., "tq"), and starts a new record */
+int   x265hip_batch_set_timing(x265hip_batch* batch, int on);
+int   x265hip_batch_stage_count(const x265hip_batch* batch);
+const char* x265hip_batch_stage_name(const x265hip_batch* batch, int i);
+int   x265hip_batch_read_timing(x265hip_batch* batch, float* msPerStage);
+int   x265hip_batch_read_plane(x265hip_batch* batch, int which, int frame, void* out /* the padded plane as it sits on the device: (width + 2 margin) x (height + 2 margin) pixels */);
 int   x265hip_batch_read_coeffs(x265hip_batch* batch, int16_t* coeff /* tu_count << (2 * tuLog2) */, uint32_t* numSig /* tu_count */);
 /* device pointers for consumers that stay on the GPU: what = 0 source planes, 1 reference planes, 2 phase planes, 3 coefficients, 4 numSig,
- * 5 reconstruction, 10 + log2(level) - 3 = results of a pyramid level (10: 8x8 ... 13: 64x64) */
+ * 5 reconstruction, 10 + log2(level) - 3 = results of a pyramid level (10: 8x8 ... 13: 64x64; reference 0), 100 + r = plane stack of reference r, 200 + r = its phase planes */
 void* x265hip_batch_device_ptr(x265hip_batch* batch, int what);
 
 /* ---- ThreadedME producer for a C++ encoder: one picture's MEData table from HOST data ------------------------------------------------------------------

@@ -11,7 +11,7 @@ from x265hip_pkg.pipeline import pyramid_tasks, LEVELS
 
 
 class Desc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes")]
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes", "refs", "rect", "streams")]
 
 
 @pytest.mark.parametrize("depth", [8, 10])
@@ -88,3 +88,23 @@ def test_reference_count_and_picture_size_limits_are_argument_errors():
     for w, h in ((8192, 64), (64, 8192)):
         assert lib.x265hip_batch_task_count(C.byref(Desc(w, h, 1, 96, 28, 57, 1, 2, 5, 0, 1)), 64) < 0
     assert lib.x265hip_batch_task_count(C.byref(Desc(8128, 64, 1, 96, 28, 57, 1, 2, 5, 0, 1)), 64) == 127
+
+
+@pytest.mark.parametrize("geom", [(128, 64, 2, 96), (256, 192, 3, 96)])
+def test_rect_task_lists_equal_the_python_pipeline(geom):
+    """the 2NxN / Nx2N task lists of the C++ host (x265hip_batch_build_rect_tasks) are, byte for byte, pipeline.rect_tasks'"""
+    from x265hip_pkg.pipeline import rect_tasks
+    W, H, F, margin = geom
+    lib = x265hip.HipLib(8, fill_table=False).lib
+    d = Desc(W, H, F, margin, 28, 57, 3, 3, 5, 0, 1, 4, 1, 2)
+    exp = rect_tasks(W, H, F, margin)
+    assert len(exp) == 8
+    for (w, h), t in exp.items():
+        n = lib.x265hip_batch_rect_task_count(C.byref(d), w, h)
+        assert n == len(t)
+        out = np.zeros(n, ME_TASK)
+        assert lib.x265hip_batch_build_rect_tasks(C.byref(d), w, h, C.c_void_p(out.ctypes.data)) == 0
+        assert out.tobytes() == t.tobytes(), "%dx%d" % (w, h)
+    assert lib.x265hip_batch_rect_task_count(C.byref(d), 64, 64) < 0 and lib.x265hip_batch_rect_task_count(C.byref(d), 64, 16) < 0
+    for bad in (Desc(W, H, F, margin, 28, 57, 3, 3, 5, 0, 1, 17, 0, 1), Desc(W, H, F, margin, 28, 57, 3, 3, 5, 0, 1, 1, 0, 9), Desc(W, H, F, margin, 28, 57, 3, 3, 5, 0, 0, 2, 0, 1)):
+        assert lib.x265hip_batch_task_count(C.byref(bad), 64) < 0        # too many references / streams; several references without phase planes

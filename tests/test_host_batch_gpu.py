@@ -1,0 +1,103 @@
+"""The C++ host of the frame-batched path (include/x265hip_ctx.h: x265hip_batch_*, csrc/xh_ctx.cpp) with everything preset slow asks of the motion search in ONE run:
+several list-0 references, the rectangular PUs of every CU, sub-batches of whole pictures on their own streams -- sampled against the oracle, equal to the Python
+plumbing (FramePipeline) where that can run the same configuration, and independent of how the batch is cut into streams."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import x265hip
+from x265hip_pkg.frame import mvcost_row, mvbits_row, rd_lambda
+from x265hip_pkg.host_batch import HostBatch, LEVELS
+from x265hip_pkg.pipeline import FramePipeline
+from x265hip_pkg.synth import frame_pair
+from backends import Oracle
+from pipeline_check import check_host_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def pairs_for(W, H, depth, F, refs, seed0=300):
+    out = []
+    for s in range(F):
+        cur, ref, _, _ = frame_pair(W, H, depth, seed=seed0 + s, margin=96, max_shift=14)
+        p = [cur, ref]
+        rng = np.random.default_rng(9000 + s)
+        for r in range(1, refs):
+            # an older picture of the same scene: the picture area displaced a little further + its own noise, borders replicated as extendPicBorder does
+            inner = np.roll(ref[96:96 + H, 96:96 + W], (2 * r, -3 * r), (0, 1)).astype(np.int32) + rng.integers(-3 * r, 3 * r + 1, (H, W)) * (1 << (depth - 8))
+            inner = np.clip(inner, 0, (1 << depth) - 1).astype(ref.dtype)
+            p.append(np.pad(inner, 96, mode="edge"))
+        out.append(tuple(p))
+    return out
+
+
+def make(depth, W, H, F, **kw):
+    lib = C.CDLL(x265hip.lib_path(depth))
+    return HostBatch(lib, depth, W, H, F, **kw)
+
+
+@pytest.mark.parametrize("depth,method,subme,refs,rect,streams", [(8, 1, 2, 1, False, 1), (10, 3, 3, 1, True, 1), (8, 3, 3, 3, False, 2), (10, 3, 3, 4, True, 2), (8, 1, 2, 2, True, 3),
+                                                                  (8, 3, 4, 5, True, 1)])
+def test_host_batch_matches_oracle(depth, method, subme, refs, rect, streams):
+    W, H, F, qp, merange = 256, 128, 3, 28, 24
+    hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=4, refs=refs, rect=rect, streams=streams)
+    try:
+        pairs = pairs_for(W, H, depth, F, refs)
+        hb.upload(pairs)
+        for f in (0, F - 1):        # the device pads the picture the way the host-padded planes are padded
+            for which in range(1 + refs):
+                assert np.array_equal(hb.device_plane(which, f), pairs[f][which].reshape(-1)), "plane %d of picture %d" % (which, f)
+        hb.step(); hb.sync()
+        n = check_host_batch(hb, Oracle(depth), np.random.default_rng(depth + refs), mvcost_row(depth, qp, 1 << 15), mvbits_row(depth, 1 << 14), rd_lambda(depth, qp))
+        assert n >= (12 if rect else 4) * 8
+    finally:
+        hb.close()
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+def test_streams_do_not_change_the_bytes_and_python_plumbing_agrees(depth):
+    """pictures are independent: 1, 2, 3 and 5 sub-batches of a 5-picture batch give the same records and coefficients; so does the Python pipeline (torch tensors, one stream)"""
+    W, H, F, qp, merange, method, subme = 192, 128, 5, 30, 20, 3, 3
+    pairs = pairs_for(W, H, depth, F, 2)
+    ref_out = None
+    for streams in (1, 2, 3, 5):
+        hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, refs=2, rect=True, streams=streams)
+        try:
+            hb.upload(pairs)
+            hb.step(); hb.step(); hb.sync()                     # twice: a second pass over the resident planes gives the same bytes
+            out = [hb.results(lv, r).tobytes() for lv in LEVELS for r in range(2)] + [hb.rect_results(w, h, r).tobytes() for (w, h) in sorted(hb.rect_host) for r in range(2)]
+            out += [hb.choices(lv).tobytes() for lv in LEVELS] + [hb.choices(w, h).tobytes() for (w, h) in sorted(hb.rect_host)]
+            co, ns = hb.coeffs()
+            out += [co.tobytes(), ns.tobytes()]
+        finally:
+            hb.close()
+        if ref_out is None:
+            ref_out = out
+        else:
+            assert out == ref_out, "%d streams change the results" % streams
+    pipe = FramePipeline(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, cost_row=mvcost_row(depth, qp, 1 << 15), refs=2)
+    pipe.upload(pairs); pipe.step(); pipe.torch.cuda.synchronize()
+    k = 0
+    for lv in LEVELS:
+        for r in range(2):
+            assert pipe.results(lv, r).tobytes() == ref_out[k], "level %d reference %d" % (lv, r)
+            k += 1
+    assert pipe.d_coeff.cpu().numpy().tobytes() == ref_out[-2] and pipe.d_numsig.cpu().numpy().astype(np.uint32).tobytes() == ref_out[-1]
+
+
+def test_stage_timing_and_names():
+    hb = make(8, 256, 128, 4, method=3, subme=3, merange=24, rect=True, streams=2)
+    try:
+        hb.upload(pairs_for(256, 128, 8, 4, 1))
+        assert hb.kernel_names() == ["planes", "me64", "rect64", "me32", "rect32", "me16", "rect16", "me8", "rect8", "tq"]
+        hb.set_timing(True)
+        for _ in range(3):
+            hb.step()
+        t = hb.read_timing()
+        assert set(t) == set(hb.kernel_names()) and all(0 < v < 50 for v in t.values()), t
+        hb.set_timing(False); hb.step(); hb.sync()
+        with pytest.raises(RuntimeError):
+            hb.read_timing()                                     # nothing was timed since the last read
+    finally:
+        hb.close()

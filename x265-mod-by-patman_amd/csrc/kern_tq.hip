@@ -331,8 +331,8 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
                  params->qp, params->add, params->quantCoeff, params->deltaU, coeff, numSig,
                  (pixel*)reconPlane, reconStride, sse, mvSource, (const pixel*)params->subpelPlanes, params->planeElems,
                  params->choice, params->choiceList, params->choiceRef, params->chroma, (const pixel*)params->refPlane1, params->choiceRef1, params->dst4 };
-    if (params->refPlane1 && (!params->choice || params->chroma || params->choiceRef1 < 0 || params->choiceRef1 > 3)) { set_error("tq_batch: a bi-directional launch needs choice records, luma planes and choiceRef1 in 0..3"); return X265HIP_EARG; }
-    if (params->choice && (params->choiceList < 0 || params->choiceList > 1 || params->choiceRef < 0 || params->choiceRef > 3)) { set_error("tq_batch: bad choiceList / choiceRef"); return X265HIP_EARG; }
+    if (params->refPlane1 && (!params->choice || params->chroma || params->choiceRef1 < 0 || params->choiceRef1 >= X265HIP_MAX_REF)) { set_error("tq_batch: a bi-directional launch needs choice records, luma planes and choiceRef1 in 0..15"); return X265HIP_EARG; }
+    if (params->choice && (params->choiceList < 0 || params->choiceList > 1 || params->choiceRef < 0 || params->choiceRef >= X265HIP_MAX_REF)) { set_error("tq_batch: bad choiceList / choiceRef"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     switch (log2TrSize)
     {

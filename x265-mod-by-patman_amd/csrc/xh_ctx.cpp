@@ -4,6 +4,7 @@
 #include "../../include/x265hip_ctx.h"
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 using namespace xh;
@@ -18,11 +19,14 @@ namespace {
 constexpr int CTU = 64;
 const int kLevels[4] = { 64, 32, 16, 8 };
 constexpr int kHalf = 1 << 15;                 // MVD cost row: d in [-32768, 32768] quarter-pels
+constexpr int kTimingSets = 64;                // event sets kept between two x265hip_batch_read_timing calls
+constexpr int kBitsHalf = 1 << 14;             // MVD bit-size row of the per-PU choice among references
 
 bool desc_ok(const x265hip_batch_desc* d)
 {
     return d && d->width >= CTU && d->height >= CTU && d->width <= X265HIP_MAX_PIC_DIM && d->height <= X265HIP_MAX_PIC_DIM && d->width % CTU == 0 && d->height % CTU == 0 && d->frames >= 1 && d->margin >= CTU + 16 + 8 &&
-           d->margin % 4 == 0 && d->qp >= 0 && d->qp <= 51 && d->merange >= 1 && d->subme >= 0 && d->subme <= 7 && d->tuLog2 >= 2 && d->tuLog2 <= 5;
+           d->margin % 4 == 0 && d->qp >= 0 && d->qp <= 51 && d->merange >= 1 && d->subme >= 0 && d->subme <= 7 && d->tuLog2 >= 2 && d->tuLog2 <= 5 &&
+           d->refs >= 0 && d->refs <= X265HIP_MAX_REF && d->streams >= 0 && d->streams <= 8 && (d->refs <= 1 || d->usePlanes);
 }
 int level_index(int level) { for (int i = 0; i < 4; i++) if (kLevels[i] == level) return i; return -1; }
 int64_t stride_of(const x265hip_batch_desc* d) { return d->width + 2 * d->margin; }
@@ -33,12 +37,21 @@ struct x265hip_batch
 {
     x265hip_ctx* ctx = nullptr;
     x265hip_batch_desc d{};
+    int refs = 1, nsub = 1;
     int64_t stride = 0, plane = 0;
-    pixel *cur = nullptr, *ref = nullptr, *planes = nullptr, *recon = nullptr;
-    x265hip_me_task* tasks[4] = {}; x265hip_me_result* results[4] = {}; int ntasks[4] = {};
+    pixel *cur = nullptr, *recon = nullptr;
+    pixel* ref[X265HIP_MAX_REF] = {}; pixel* planes[X265HIP_MAX_REF] = {};                      // per list-0 reference: the plane stack and its 16-slot phase planes
+    x265hip_me_task* tasks[4] = {}; x265hip_me_result* results[X265HIP_MAX_REF][4] = {}; int ntasks[4] = {};      // results[r][level]: reference r's own chain down the pyramid
+    x265hip_inter_choice* choice[4] = {};                                                      // refs > 1: the per-PU choice among the references
+    // rectangular partitions (desc.rect): shape k = 2 * level + (0: 2NxN, 1: Nx2N)
+    x265hip_me_task* rtasks[8] = {}; x265hip_me_result* rresults[X265HIP_MAX_REF][8] = {}; x265hip_inter_choice* rchoice[8] = {}; int nrtasks[8] = {};
     x265hip_tu_task* tu = nullptr; int ntu = 0, mvLevel = 0;
     int16_t* coeff = nullptr; uint32_t* numSig = nullptr; uint64_t* sse = nullptr;
-    uint16_t* costRow = nullptr;
+    uint16_t* costRow = nullptr; float* bitsRow = nullptr; uint64_t lambda = 0;
+    // sub-batches of whole pictures on their own streams (desc.streams): stream 0 is the context's
+    hipStream_t sub[8] = {}; hipEvent_t evFork = nullptr, evJoin[8] = {};
+    // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
+    bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
     std::vector<void*> owned;
     template<class T> int alloc(T*& p, size_t n)
     {
@@ -131,10 +144,46 @@ extern "C" int x265hip_batch_build_tu_tasks(const x265hip_batch_desc* d, x265hip
     return X265HIP_OK;
 }
 
+// ---- rectangular partitions: for every CU of a pyramid level its two 2NxN and its two Nx2N PUs (g_puLookup, encoder/threadedme.h:67-92), each seeded with the MV of
+//      its own CU's 2Nx2N search (mvpFrom indexes that level's results); limits = CUData::clipMv on the CU's position (cudata.cpp:2094-2107) ----
+namespace {
+void rect_shape(int k, int& w, int& h) { const int lv = kLevels[k >> 1]; if (k & 1) { w = lv >> 1; h = lv; } else { w = lv; h = lv >> 1; } }
+}
+extern "C" int x265hip_batch_rect_task_count(const x265hip_batch_desc* d, int w, int h)
+{
+    if (!desc_ok(d) || level_index(w > h ? w : h) < 0 || (w != 2 * h && h != 2 * w)) return X265HIP_EARG;
+    return d->frames * (d->width / w) * (d->height / h);
+}
+extern "C" int x265hip_batch_build_rect_tasks(const x265hip_batch_desc* d, int w, int h, x265hip_me_task* out)
+{
+    if (x265hip_batch_rect_task_count(d, w, h) < 0 || !out) { set_error("batch_build_rect_tasks: bad arguments"); return X265HIP_EARG; }
+    const int W = d->width, H = d->height, lv = w > h ? w : h, nx = W / w, ny = H / h;
+    const int64_t stride = stride_of(d), plane = plane_of(d);
+    x265hip_me_task* t = out;
+    for (int f = 0; f < d->frames; f++)
+        for (int by = 0; by < ny; by++)
+            for (int bx = 0; bx < nx; bx++, t++)
+            {
+                const int x = bx * w, y = by * h, cx = (x / lv) * lv, cy = (y / lv) * lv;
+                memset(t, 0, sizeof(*t));
+                t->curOff = t->refOff = (int32_t)(f * plane + (int64_t)(d->margin + y) * stride + d->margin + x);
+                t->mvmin[0] = (int16_t)(-((CTU + 8 + cx - 1) << 2)); t->mvmin[1] = (int16_t)(-((CTU + 8 + cy - 1) << 2));
+                t->mvmax[0] = (int16_t)((W + 8 - cx - 1) << 2);      t->mvmax[1] = (int16_t)((H + 8 - cy - 1) << 2);
+                t->flags = X265HIP_ME_WINDOW;
+                t->mvpFrom = f * ((W / lv) * (H / lv)) + (y / lv) * (W / lv) + (x / lv);
+            }
+    return X265HIP_OK;
+}
+
 extern "C" void x265hip_batch_destroy(x265hip_batch* b)
 {
     if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
+    for (int i = 1; i < 8; i++) if (b->sub[i]) { (void)hipStreamSynchronize(b->sub[i]); x265hip_tme_release_stream(b->sub[i]); (void)hipStreamDestroy(b->sub[i]); }
+    for (int i = 0; i < 8; i++) if (b->evJoin[i]) (void)hipEventDestroy(b->evJoin[i]);
+    if (b->evFork) (void)hipEventDestroy(b->evFork);
+    for (hipEvent_t e : b->evStage) (void)hipEventDestroy(e);
     for (void* p : b->owned) (void)hipFree(p);
     delete b;
 }
@@ -146,12 +195,26 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
     x265hip_batch* b = new (std::nothrow) x265hip_batch();
     if (!b) { set_error("batch_create: out of host memory"); return X265HIP_EARG; }
     b->ctx = ctx; b->d = *d; b->stride = stride_of(d); b->plane = plane_of(d);
+    b->refs = d->refs > 1 ? d->refs : 1;
+    b->nsub = d->streams > 1 ? (d->streams < d->frames ? d->streams : d->frames) : 1;
+    b->sub[0] = ctx->stream;
     const size_t elems = (size_t)b->plane * d->frames;
     int rc = X265HIP_OK;
     auto fail = [&](int code) { x265hip_batch_destroy(b); return code; };
 #define XB(call) do { rc = (call); if (rc != X265HIP_OK) return fail(rc); } while (0)
-    XB(b->alloc(b->cur, elems)); XB(b->alloc(b->ref, elems));
-    if (d->usePlanes) XB(b->alloc(b->planes, 16 * elems));
+#define XBH(call, what) do { if ((call) != hipSuccess) return fail(hip_fail(hipErrorUnknown, what)); } while (0)
+    XBH(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming), "hipEventCreate");
+    for (int i = 0; i < b->nsub; i++)
+    {
+        if (i) XBH(hipStreamCreateWithFlags(&b->sub[i], hipStreamNonBlocking), "hipStreamCreate");
+        XBH(hipEventCreateWithFlags(&b->evJoin[i], hipEventDisableTiming), "hipEventCreate");
+    }
+    XB(b->alloc(b->cur, elems));
+    for (int r = 0; r < b->refs; r++)
+    {
+        XB(b->alloc(b->ref[r], elems));
+        if (d->usePlanes) XB(b->alloc(b->planes[r], 16 * elems));
+    }
     if (d->recon) { XB(b->alloc(b->recon, elems)); XB(b->alloc(b->sse, (size_t)x265hip_batch_tu_count(d))); }
     std::vector<x265hip_me_task> host;
     for (int i = 0; i < 4; i++)
@@ -159,32 +222,71 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
         b->ntasks[i] = x265hip_batch_task_count(d, kLevels[i]);
         host.resize((size_t)b->ntasks[i]);
         XB(x265hip_batch_build_me_tasks(d, kLevels[i], host.data()));
-        XB(b->alloc(b->tasks[i], host.size())); XB(b->alloc(b->results[i], host.size()));
-        if (hipMemcpy(b->tasks[i], host.data(), host.size() * sizeof(x265hip_me_task), hipMemcpyHostToDevice) != hipSuccess) return fail(hip_fail(hipErrorUnknown, "hipMemcpy(tasks)"));
-        if (hipMemset(b->results[i], 0, host.size() * sizeof(x265hip_me_result)) != hipSuccess) return fail(hip_fail(hipErrorUnknown, "hipMemset(results)"));
+        XB(b->alloc(b->tasks[i], host.size()));
+        XBH(hipMemcpy(b->tasks[i], host.data(), host.size() * sizeof(x265hip_me_task), hipMemcpyHostToDevice), "hipMemcpy(tasks)");
+        for (int r = 0; r < b->refs; r++)
+        {
+            XB(b->alloc(b->results[r][i], host.size()));
+            XBH(hipMemset(b->results[r][i], 0, host.size() * sizeof(x265hip_me_result)), "hipMemset(results)");
+        }
+        if (b->refs > 1) XB(b->alloc(b->choice[i], host.size()));
     }
+    if (d->rect)
+        for (int k = 0; k < 8; k++)
+        {
+            int w, h; rect_shape(k, w, h);
+            b->nrtasks[k] = x265hip_batch_rect_task_count(d, w, h);
+            host.resize((size_t)b->nrtasks[k]);
+            XB(x265hip_batch_build_rect_tasks(d, w, h, host.data()));
+            XB(b->alloc(b->rtasks[k], host.size()));
+            XBH(hipMemcpy(b->rtasks[k], host.data(), host.size() * sizeof(x265hip_me_task), hipMemcpyHostToDevice), "hipMemcpy(rect tasks)");
+            for (int r = 0; r < b->refs; r++)
+            {
+                XB(b->alloc(b->rresults[r][k], host.size()));
+                XBH(hipMemset(b->rresults[r][k], 0, host.size() * sizeof(x265hip_me_result)), "hipMemset(rect results)");
+            }
+            if (b->refs > 1) XB(b->alloc(b->rchoice[k], host.size()));
+        }
     b->ntu = x265hip_batch_tu_count(d);
     b->mvLevel = (1 << d->tuLog2) < 8 ? 8 : (1 << d->tuLog2);
     std::vector<x265hip_tu_task> tu((size_t)b->ntu);
     XB(x265hip_batch_build_tu_tasks(d, tu.data()));
     XB(b->alloc(b->tu, tu.size()));
-    if (hipMemcpy(b->tu, tu.data(), tu.size() * sizeof(x265hip_tu_task), hipMemcpyHostToDevice) != hipSuccess) return fail(hip_fail(hipErrorUnknown, "hipMemcpy(tu tasks)"));
+    XBH(hipMemcpy(b->tu, tu.data(), tu.size() * sizeof(x265hip_tu_task), hipMemcpyHostToDevice), "hipMemcpy(tu tasks)");
     XB(b->alloc(b->coeff, (size_t)b->ntu << (2 * d->tuLog2))); XB(b->alloc(b->numSig, (size_t)b->ntu));
     std::vector<uint16_t> row(2 * kHalf + 1);
     XB(x265hip_mvcost_row(d->qp, kHalf, row.data()));
     XB(b->alloc(b->costRow, row.size()));
-    if (hipMemcpy(b->costRow, row.data(), row.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) return fail(hip_fail(hipErrorUnknown, "hipMemcpy(cost row)"));
+    XBH(hipMemcpy(b->costRow, row.data(), row.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "hipMemcpy(cost row)");
+    if (b->refs > 1)
+    {   // the per-PU choice among references prices MVDs in bits (BitCost::bitcost) and weighs them with the RD lambda (RDCost::getCost)
+        std::vector<float> bits(2 * kBitsHalf + 1);
+        XB(x265hip_mvbits_row(kBitsHalf, bits.data()));
+        XB(b->alloc(b->bitsRow, bits.size()));
+        XBH(hipMemcpy(b->bitsRow, bits.data(), bits.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(bits row)");
+        b->lambda = x265hip_rd_lambda(d->qp);
+    }
+    // the stages of one sub-batch, in launch order
+    if (d->usePlanes) b->stageNames.push_back("planes");
+    for (int i = 0; i < 4; i++)
+    {
+        b->stageNames.push_back("me" + std::to_string(kLevels[i]));
+        if (d->rect) b->stageNames.push_back("rect" + std::to_string(kLevels[i]));
+    }
+    b->stageNames.push_back("tq");
 #undef XB
+#undef XBH
     *out = b;
     return X265HIP_OK;
 }
 
 extern "C" int x265hip_batch_upload_plane(x265hip_batch* b, int which, int frame, const void* pixels, intptr_t strideElems)
 {
-    if (!b || (which != 0 && which != 1) || frame < 0 || frame >= b->d.frames || !pixels || strideElems < b->d.width)
+    if (!b || which < 0 || which > b->refs || frame < 0 || frame >= b->d.frames || !pixels || strideElems < b->d.width)
     { set_error("batch_upload_plane: bad arguments"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(b->ctx->device));
     const x265hip_batch_desc& d = b->d;
-    pixel* plane = (which ? b->ref : b->cur) + (size_t)frame * b->plane;
+    pixel* plane = (which ? b->ref[which - 1] : b->cur) + (size_t)frame * b->plane;
     pixel* org = plane + (size_t)d.margin * b->stride + d.margin;
     hipStream_t st = b->ctx->stream;
     // host rows -> straight into the padded plane, then the borders on the device (extendPicBorder)
@@ -192,50 +294,191 @@ extern "C" int x265hip_batch_upload_plane(x265hip_batch* b, int which, int frame
     return x265hip_extend_pic_border(st, org, b->stride, d.width, d.height, d.margin, d.margin, 1, 0);
 }
 
+namespace {
+// one sub-batch (pictures f0 .. f1 - 1) on stream st; ev != nullptr: events around every stage (2 per stage)
+int step_range(x265hip_batch* b, int f0, int f1, hipStream_t st, hipEvent_t* ev)
+{
+    const x265hip_batch_desc& d = b->d;
+    const int64_t planeElems = b->plane * d.frames;                  // the 16 phase-plane slots are planeElems apart; a sub-batch addresses its pictures inside them
+    const int nf = f1 - f0, rowsPerPic = d.height + 2 * d.margin;
+    const bool up = d.usePlanes != 0;
+    int rc, stage = 0;
+    auto mark = [&](int end) -> int { if (ev) XH_HIP(hipEventRecord(ev[2 * stage + end], st)); if (end) stage++; return X265HIP_OK; };
+    if (up)
+    {
+        if ((rc = mark(0))) return rc;
+        for (int r = 0; r < b->refs; r++)
+            if ((rc = x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, nf * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems)) != X265HIP_OK) return rc;
+        if ((rc = mark(1))) return rc;
+    }
+    // one task list searched in every reference (each with its own parent chain), then the per-PU choice (Search::puMotionEstimation's tail, search.cpp:258-556)
+    auto search = [&](int w, int h, const x265hip_me_task* tasks, int first, int n, x265hip_me_result* const* res, x265hip_me_result* const* parent, x265hip_inter_choice* choice) -> int
+    {
+        for (int r = 0; r < b->refs; r++)
+        {
+            rc = x265hip_me_batch(st, w, h, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.method, d.subme,
+                                  res[r] + first, parent ? parent[r] : nullptr, up ? b->planes[r] : nullptr, up ? planeElems : 0);
+            if (rc != X265HIP_OK) return rc;
+        }
+        if (b->refs > 1)
+        {
+            x265hip_merge_params p{};
+            p.numRef[0] = b->refs; p.numRef[1] = 0;
+            for (int r = 0; r < b->refs; r++) { p.results[0][r] = res[r] + first; p.mvpSource[0][r] = parent ? parent[r] : nullptr; p.subpelPlanes[0][r] = b->planes[r]; }
+            p.planeElems = planeElems; p.bitsRow = b->bitsRow; p.bitsHalfRange = kBitsHalf; p.lambda = b->lambda; p.bidir = 0; p.sourceMaxDim = d.width > d.height ? d.width : d.height;
+            if ((rc = x265hip_inter_merge_batch(st, w, h, b->cur, b->stride, b->stride, tasks + first, n, &p, choice + first)) != X265HIP_OK) return rc;
+        }
+        return X265HIP_OK;
+    };
+    for (int i = 0; i < 4; i++)
+    {
+        const int lv = kLevels[i], per = (d.width / lv) * (d.height / lv);
+        x265hip_me_result* res[X265HIP_MAX_REF]; x265hip_me_result* par[X265HIP_MAX_REF];
+        for (int r = 0; r < b->refs; r++) { res[r] = b->results[r][i]; par[r] = i ? b->results[r][i - 1] : nullptr; }
+        if ((rc = mark(0))) return rc;
+        if ((rc = search(lv, lv, b->tasks[i], f0 * per, nf * per, res, i ? par : nullptr, b->choice[i]))) return rc;
+        if ((rc = mark(1))) return rc;
+        if (d.rect)
+        {
+            if ((rc = mark(0))) return rc;
+            for (int k = 2 * i; k < 2 * i + 2; k++)
+            {
+                int w, h; rect_shape(k, w, h);
+                const int rper = (d.width / w) * (d.height / h);
+                x265hip_me_result* rres[X265HIP_MAX_REF];
+                for (int r = 0; r < b->refs; r++) rres[r] = b->rresults[r][k];
+                if ((rc = search(w, h, b->rtasks[k], f0 * rper, nf * rper, rres, res, b->rchoice[k]))) return rc;      // seeded by the CU's own 2Nx2N result in the same reference
+            }
+            if ((rc = mark(1))) return rc;
+        }
+    }
+    const int n = 1 << d.tuLog2, tper = (d.width / n) * (d.height / n), t0 = f0 * tper, nt = nf * tper, mi = level_index(b->mvLevel);
+    if ((rc = mark(0))) return rc;
+    for (int r = 0; r < b->refs; r++)
+    {   // one launch per reference plane: every TU is compensated from the reference its PU chose
+        x265hip_tq_params p{};
+        p.qp = d.qp; p.add = 85; p.subpelPlanes = up ? b->planes[r] : nullptr; p.planeElems = up ? planeElems : 0;
+        if (b->refs > 1) { p.choice = b->choice[mi]; p.choiceList = 0; p.choiceRef = r; }
+        rc = x265hip_tq_batch(st, d.tuLog2, b->cur, b->stride, b->ref[r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
+                              d.recon ? b->recon : nullptr, b->stride, d.recon ? b->sse + t0 : nullptr, b->refs > 1 ? nullptr : b->results[0][mi]);
+        if (rc != X265HIP_OK) return rc;
+    }
+    return mark(1);
+}
+}
+
 extern "C" int x265hip_batch_step(x265hip_batch* b)
 {
     if (!b) { set_error("batch_step: null batch"); return X265HIP_EARG; }
-    const x265hip_batch_desc& d = b->d;
-    hipStream_t st = b->ctx->stream;
-    const int64_t planeElems = b->plane * d.frames;
-    int rc;
-    if (d.usePlanes && (rc = x265hip_subpel_planes(st, b->ref, b->stride, d.frames * (d.height + 2 * d.margin), b->planes, planeElems)) != X265HIP_OK) return rc;
-    for (int i = 0; i < 4; i++)
+    XH_HIP(hipSetDevice(b->ctx->device));
+    const int F = b->d.frames, S = b->nsub;
+    hipEvent_t* ev = nullptr;
+    if (b->timing)
+    {   // the next event set (the sets of the steps since the last read_timing; beyond kTimingSets the oldest are overwritten)
+        const size_t per = 2 * b->stageNames.size(), set = (size_t)(b->timedSteps % kTimingSets);
+        while (b->evStage.size() < (set + 1) * per) { hipEvent_t e; XH_HIP(hipEventCreate(&e)); b->evStage.push_back(e); }
+        ev = b->evStage.data() + set * per;
+        b->timedSteps++;
+    }
+    if (S == 1) return step_range(b, 0, F, b->sub[0], ev);
+    // Independent pictures: the levels of one picture depend on each other (a level's predictor is its parent CU's MV), pictures do not.  Sub-batch s runs on its own
+    // stream, so the LDS-bound 64x64 search of one runs beside the latency-bound 16x16 / 8x8 searches of another.  Everything is ordered after the work already queued
+    // on the context's stream and joined back into it.
+    XH_HIP(hipEventRecord(b->evFork, b->sub[0]));
+    for (int s = 0; s < S; s++)
     {
-        const int lv = kLevels[i];
-        rc = x265hip_me_batch(st, lv, lv, b->cur, b->stride, b->ref, b->stride, b->tasks[i], b->ntasks[i], b->costRow, kHalf, d.merange, d.method, d.subme,
-                              b->results[i], i ? b->results[i - 1] : nullptr, d.usePlanes ? b->planes : nullptr, d.usePlanes ? planeElems : 0);
+        if (s) XH_HIP(hipStreamWaitEvent(b->sub[s], b->evFork, 0));
+        const int rc = step_range(b, F * s / S, F * (s + 1) / S, b->sub[s], s == 0 ? ev : nullptr);
         if (rc != X265HIP_OK) return rc;
     }
-    x265hip_tq_params p{};
-    p.qp = d.qp; p.add = 85; p.quantCoeff = nullptr; p.deltaU = nullptr; p.subpelPlanes = d.usePlanes ? b->planes : nullptr; p.planeElems = d.usePlanes ? planeElems : 0;
-    return x265hip_tq_batch(st, d.tuLog2, b->cur, b->stride, b->ref, b->stride, b->tu, b->ntu, &p, b->coeff, b->numSig, d.recon ? b->recon : nullptr, b->stride,
-                            d.recon ? b->sse : nullptr, b->results[level_index(b->mvLevel)]);
+    for (int s = 1; s < S; s++)
+    {
+        XH_HIP(hipEventRecord(b->evJoin[s], b->sub[s]));
+        XH_HIP(hipStreamWaitEvent(b->sub[0], b->evJoin[s], 0));
+    }
+    return X265HIP_OK;
 }
 
-extern "C" int x265hip_batch_read_results(x265hip_batch* b, int level, x265hip_me_result* out)
+extern "C" int x265hip_batch_set_timing(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->timing = on != 0; return X265HIP_OK; }
+extern "C" int x265hip_batch_stage_count(const x265hip_batch* b) { return b ? (int)b->stageNames.size() : 0; }
+extern "C" const char* x265hip_batch_stage_name(const x265hip_batch* b, int i) { return (b && i >= 0 && i < (int)b->stageNames.size()) ? b->stageNames[i].c_str() : nullptr; }
+extern "C" int x265hip_batch_read_timing(x265hip_batch* b, float* ms)
 {
-    const int i = level_index(level);
-    if (!b || i < 0 || !out) { set_error("batch_read_results: bad arguments"); return X265HIP_EARG; }
-    XH_HIP(hipMemcpyAsync(out, b->results[i], (size_t)b->ntasks[i] * sizeof(x265hip_me_result), hipMemcpyDeviceToHost, b->ctx->stream));
+    if (!b || !ms || b->timedSteps < 1) { set_error("batch_read_timing: no timed step"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(b->ctx->device));
+    for (int s = 0; s < b->nsub; s++) XH_HIP(hipStreamSynchronize(b->sub[s]));
+    const size_t per = 2 * b->stageNames.size();
+    const int sets = b->timedSteps < kTimingSets ? b->timedSteps : kTimingSets;
+    for (size_t i = 0; i < b->stageNames.size(); i++)
+    {
+        double sum = 0;
+        for (int k = 0; k < sets; k++) { float t = 0; XH_HIP(hipEventElapsedTime(&t, b->evStage[k * per + 2 * i], b->evStage[k * per + 2 * i + 1])); sum += t; }
+        ms[i] = (float)(sum / sets);
+    }
+    b->timedSteps = 0;
+    return sets;
+}
+
+namespace {
+int shape_slot(const x265hip_batch* b, int w, int h, bool& rect)
+{
+    rect = w != h;
+    if (!rect) return level_index(w);
+    if (!b->d.rect || level_index(w > h ? w : h) < 0 || (w != 2 * h && h != 2 * w)) return -1;
+    return 2 * level_index(w > h ? w : h) + (h > w ? 1 : 0);
+}
+}
+extern "C" int x265hip_batch_read_results(x265hip_batch* b, int level, x265hip_me_result* out) { return x265hip_batch_read_results_ref(b, level, level, 0, out); }
+extern "C" int x265hip_batch_read_results_ref(x265hip_batch* b, int w, int h, int ref, x265hip_me_result* out)
+{
+    bool rect = false;
+    const int i = b ? shape_slot(b, w, h, rect) : -1;
+    if (!b || i < 0 || ref < 0 || ref >= b->refs || !out) { set_error("batch_read_results: bad arguments"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(b->ctx->device));
+    const x265hip_me_result* src = rect ? b->rresults[ref][i] : b->results[ref][i];
+    const int n = rect ? b->nrtasks[i] : b->ntasks[i];
+    XH_HIP(hipMemcpyAsync(out, src, (size_t)n * sizeof(x265hip_me_result), hipMemcpyDeviceToHost, b->ctx->stream));
+    XH_HIP(hipStreamSynchronize(b->ctx->stream));
+    return X265HIP_OK;
+}
+extern "C" int x265hip_batch_read_choices(x265hip_batch* b, int w, int h, x265hip_inter_choice* out)
+{
+    bool rect = false;
+    const int i = b ? shape_slot(b, w, h, rect) : -1;
+    if (!b || i < 0 || b->refs < 2 || !out) { set_error("batch_read_choices: bad arguments (choices exist with refs > 1)"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(b->ctx->device));
+    const int n = rect ? b->nrtasks[i] : b->ntasks[i];
+    XH_HIP(hipMemcpyAsync(out, rect ? b->rchoice[i] : b->choice[i], (size_t)n * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, b->ctx->stream));
     XH_HIP(hipStreamSynchronize(b->ctx->stream));
     return X265HIP_OK;
 }
 extern "C" int x265hip_batch_read_coeffs(x265hip_batch* b, int16_t* coeff, uint32_t* numSig)
 {
     if (!b || (!coeff && !numSig)) { set_error("batch_read_coeffs: bad arguments"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(b->ctx->device));
     if (coeff) XH_HIP(hipMemcpyAsync(coeff, b->coeff, ((size_t)b->ntu << (2 * b->d.tuLog2)) * sizeof(int16_t), hipMemcpyDeviceToHost, b->ctx->stream));
     if (numSig) XH_HIP(hipMemcpyAsync(numSig, b->numSig, (size_t)b->ntu * sizeof(uint32_t), hipMemcpyDeviceToHost, b->ctx->stream));
+    XH_HIP(hipStreamSynchronize(b->ctx->stream));
+    return X265HIP_OK;
+}
+extern "C" int x265hip_batch_read_plane(x265hip_batch* b, int which, int frame, void* out)
+{
+    if (!b || which < 0 || which > b->refs || frame < 0 || frame >= b->d.frames || !out) { set_error("batch_read_plane: bad arguments"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(b->ctx->device));
+    const pixel* plane = (which ? b->ref[which - 1] : b->cur) + (size_t)frame * b->plane;
+    XH_HIP(hipMemcpyAsync(out, plane, (size_t)b->plane * sizeof(pixel), hipMemcpyDeviceToHost, b->ctx->stream));
     XH_HIP(hipStreamSynchronize(b->ctx->stream));
     return X265HIP_OK;
 }
 extern "C" void* x265hip_batch_device_ptr(x265hip_batch* b, int what)
 {
     if (!b) return nullptr;
+    if (what >= 100 && what < 100 + b->refs) return b->ref[what - 100];
+    if (what >= 200 && what < 200 + b->refs) return b->planes[what - 200];
     switch (what)
     {
-    case 0: return b->cur; case 1: return b->ref; case 2: return b->planes; case 3: return b->coeff; case 4: return b->numSig; case 5: return b->recon;
-    case 10: return b->results[3]; case 11: return b->results[2]; case 12: return b->results[1]; case 13: return b->results[0];
+    case 0: return b->cur; case 1: return b->ref[0]; case 2: return b->planes[0]; case 3: return b->coeff; case 4: return b->numSig; case 5: return b->recon;
+    case 10: return b->results[0][3]; case 11: return b->results[0][2]; case 12: return b->results[0][1]; case 13: return b->results[0][0];
     default: return nullptr;
     }
 }
