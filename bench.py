@@ -151,34 +151,48 @@ def tme_producer_leg(depth):
 
 
 def e2e_fps_leg(frames=8):
-    """BASELINE's M2 measured in THIS run: the reference encoder (oracle/_ref/x265tmegpu_8 = all of source/common + source/encoder compiled from where they lie, C
-    primitives, no asm; it travels with the repository) on BASELINE configs[1] -- 1920x1088 8-bit, preset medium with the preset's own defaults, --threaded-me -- once
-    with its own CPU producer of the MEData tables and once with x265hip_tme_picture as the producer (integration/tme_adapter.cpp).  Both runs must write the same bitstream.
-    None when the binary is not there (then the committed figure of profiles/e2e_fps.json is reported, labelled as such)."""
+    """BASELINE's M2 measured in THIS run: the reference encoder (oracle/_ref/x265e2e_8 = all of source/common + source/encoder compiled from where they lie, C
+    primitives, no asm; it travels with the repository) on BASELINE configs[1] -- 1920x1088 8-bit, preset medium with the preset's own defaults, --threaded-me -- with its
+    own CPU producers, with x265hip_tme_picture producing the MEData tables (integration/tme_adapter.cpp), with x265hip_la_intra / x265hip_la_estimate producing the
+    lookahead's costs (integration/lookahead_adapter.cpp), and with both.  Every run must write the same bitstream.
+    None when no binary is there (then the committed figure of profiles/e2e_fps.json is reported, labelled as such)."""
     import hashlib, subprocess, tempfile
     import x265hip
-    exe = os.path.join(ROOT, "oracle", "_ref", "x265tmegpu_8")
-    if not os.path.exists(exe):
-        return None
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265e2e_8")
+    both = os.path.exists(exe)
+    if not both:
+        exe = os.path.join(ROOT, "oracle", "_ref", "x265tmegpu_8")
+        if not os.path.exists(exe):
+            return None
     runs = {}
+    modes = (("cpu", 0, 0), ("tme_gpu", 1, 0)) + ((("la_gpu", 0, 1), ("tme_la_gpu", 1, 1)) if both else ())
     with tempfile.TemporaryDirectory() as td:
-        for prod in ("cpu", "gpu"):
-            outp = os.path.join(td, prod + ".hevc")
-            env = dict(os.environ, X265TMEGPU="1" if prod == "gpu" else "0", MALLOC_PERTURB_="85")
+        for name, tme, la in modes:
+            outp = os.path.join(td, name + ".hevc")
+            env = dict(os.environ, X265TMEGPU=str(tme), X265LAGPU=str(la), MALLOC_PERTURB_="85")
             r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(frames), "medium", outp], capture_output=True, text=True, env=env, timeout=600)
             if r.returncode != 0:
-                return {"measured": "this run: FAILED", "producer": prod, "stderr": r.stderr[-500:]}
+                return {"measured": "this run: FAILED", "producer": name, "stderr": r.stderr[-500:]}
             info = json.loads(r.stdout.strip().splitlines()[-1])
             info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
-            runs[prod] = info
-    g, c = runs["gpu"], runs["cpu"]
-    return {"value": g["fps"], "unit": "frames/s", "measured": "this run",
-            "config": "BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults (ref=3, weightp, bframes=4), --threaded-me, %d frames" % frames,
-            "host": "the reference encoder with C primitives (no asm; no nasm on this box) -- its RDO bounds the encode; the MEData tables come from x265hip_tme_picture (integration/tme_adapter.cpp)",
-            "same_encoder_cpu_producer_fps": c["fps"], "bitstream_identical": g["md5"] == c["md5"] and g["bytes"] == c["bytes"], "bytes": g["bytes"],
-            "gpu_pictures": g["gpu_pictures"], "producer_seconds": g["gpu_seconds"], "adapter_seconds": g["adapter_seconds"], "adapter_sections_s": g["adapter_sections"],
-            "producer_ms_per_picture": round(1e3 * g["gpu_seconds"] / max(1, g["gpu_pictures"]), 2),
-            "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"]) / max(1, g["gpu_pictures"]), 2)}
+            runs[name] = info
+    g, c = runs["tme_gpu"], runs["cpu"]
+    best = runs.get("tme_la_gpu", g)
+    out = {"value": best["fps"], "unit": "frames/s", "measured": "this run",
+           "config": "BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults (ref=3, weightp, bframes=4, b-adapt 2), --threaded-me, %d frames" % frames,
+           "host": "the reference encoder with C primitives (no asm; no nasm on this box) -- its RDO bounds the encode; value = GPU producers on every seam that is bound (%s)"
+                   % ("ThreadedME + lookahead" if both else "ThreadedME"),
+           "fps": {k: v["fps"] for k, v in runs.items()}, "same_encoder_cpu_producer_fps": c["fps"],
+           "bitstream_identical": all(v["md5"] == c["md5"] and v["bytes"] == c["bytes"] for v in runs.values()), "bytes": c["bytes"],
+           "tme": {"gpu_pictures": g["gpu_pictures"], "producer_ms_per_picture": round(1e3 * g["gpu_seconds"] / max(1, g["gpu_pictures"]), 2),
+                   "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"]) / max(1, g["gpu_pictures"]), 2), "adapter_sections_s": g["adapter_sections"]}}
+    if both:
+        l = runs["la_gpu"]
+        out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "estimates_left_to_the_cpu": l["la_cpu_estimates"],
+                            "ms_per_estimate": round(1e3 * l["la_estimate_seconds"] / max(1, l["la_estimates"]), 3),
+                            "ms_per_intra_picture": round(1e3 * l["la_intra_seconds"] / max(1, l["la_intra_pictures"]), 3),
+                            "producer_seconds": l["la_producer_seconds"]}
+    return out
 
 
 def filters_leg(depth, steps):

@@ -130,6 +130,37 @@ int  x265hip_host_register(void* p, size_t bytes);
 int  x265hip_host_unregister(void* p);
 int  x265hip_tme_picture(x265hip_tme* tme, const x265hip_tme_picture_desc* desc);     /* synchronous: desc->table holds the picture's records on return   */
 
+/* ---- lookahead producer for a C++ encoder: lowres intra costs and frame-cost estimates from HOST data ------------------------------------------------------------
+ * What the lookahead's workers do per picture and per (p0, b, p1) choice: LookaheadTLD::lowresIntraEstimate (slicetype.cpp:755-864) and CostEstimateGroup::estimateFrameCost
+ * (:4366-4463; estimateCUCost :4467-4640).  The half-resolution pictures (Lowres::buffer[0]: four planes of planeElems pixels back to back, lowres.cpp:84-140) stay on
+ * the device under the caller's key (e.g. Lowres::frameNum + 1; the least recently used of maxPictures makes room, a missing picture is uploaded again from `planes`).
+ * Arrays are the reference's own: MVs as int16 x, y per 8x8 block (Lowres::lowresMvs[list][dist], MV = two int32 there), costs int32 (lowresMvCosts), lowresCosts uint16
+ * (cost | listused << 14), rowSatds int32 per block row; sums = { costEst before the B-frame normalisation (:4456-4457), costEstAq, intraMbs }.  Calls are synchronous
+ * and serialised inside the producer (the lookahead's workers may call concurrently).  HME is not offered (the caller keeps its own path for --hme). */
+typedef struct x265hip_la x265hip_la;
+int  x265hip_la_create(x265hip_ctx* ctx, int widthInCU, int heightInCU, intptr_t stride /* Lowres::lumaStride */, int64_t planeElems /* buffer[1] - buffer[0] */,
+                       int64_t origin /* lowresPlane[0] - buffer[0] */, int maxPictures, x265hip_la** la);
+void x265hip_la_destroy(x265hip_la* la);
+/* make a picture resident (no-op when it is): planes4 = Lowres::buffer[0]; invQscale = Lowres::invQscaleFactor (or ...8x8 with qgSize 8) or NULL; intraCost: optional,
+ * for callers that ran the intra estimate themselves */
+int  x265hip_la_picture(x265hip_la* la, uint64_t key, const void* planes4, const int32_t* invQscale, const int32_t* intraCost);
+int  x265hip_la_forget(x265hip_la* la, uint64_t key);         /* the picture left the lookahead: its slot is free */
+/* lowresIntraEstimate of one picture (made resident on the way): intraCost / intraMode / lowresCosts[0][0] per block, rowSatds[0][0], sums2 = { costEst[0][0], costEstAq[0][0] } */
+int  x265hip_la_intra(x265hip_la* la, uint64_t key, const void* planes4, const int32_t* invQscale, int32_t* intraCost, uint8_t* intraMode, uint16_t* lowresCosts,
+                      int32_t* rowSatds, int64_t* sums2);
+typedef struct x265hip_la_estimate_desc {
+    uint64_t key[3];                 /* p0, b, p1; key[2] == key[1]: P estimate                                                                       */
+    const void* planes[3];           /* Lowres::buffer[0] of each, used when the picture is not resident (may be NULL when it certainly is)           */
+    const int32_t* invQscale;        /* of b, used with planes[1]                                                                                     */
+    const int32_t* intraCost;        /* of b, used with planes[1] (a resident b holds the costs x265hip_la_intra / x265hip_la_picture left)          */
+    const void* weightedPlanes;      /* NULL, or the four planes of the weighted copy of p0 (LookaheadTLD::wbuffer[0], slicetype.cpp:919-1020): list 0 is searched there */
+    int doSearch[2];                 /* per list: search (mvs / mvCosts are outputs) or reuse the list's earlier result (inputs) -- bDoSearch, :4376-4377 */
+    int rowsPerSlice;                /* 0 = the serial sweep; > 0 = Lookahead::m_numRowsPerSlice of the cooperative --lookahead-slices sweep          */
+    int16_t* mvs[2]; int32_t* mvCosts[2];       /* per list, ncu entries (list 1 unused for a P estimate)                                              */
+    uint16_t* lowresCosts; int32_t* rowSatds; int64_t* sums;      /* ncu, heightInCU, 3                                                                 */
+} x265hip_la_estimate_desc;
+int  x265hip_la_estimate(x265hip_la* la, const x265hip_la_estimate_desc* desc);
+
 #ifdef __cplusplus
 }
 #endif

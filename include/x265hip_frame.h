@@ -323,15 +323,15 @@ int x265hip_me_batch_sea(void* stream, int w, int h, const void* curPlane, intpt
  *   (slicetype.cpp:1173-1176, 4347-4357, 4394-4426): each slice of that many block rows (the last one with the remainder) is swept on its own.
  *   invQscale: nFrames x ncu 8.8 fixed-point AQ factors (Lowres::invQscaleFactor / invQscaleFactor8x8) or NULL.
  *   costRow: the row of x265hip_mvcost_row(x265hip_lookahead_qp(), ...), costHalfRange >= 4 * (8 * max(wcu, hcu) + 32).
- *   The call is fully asynchronous (no copy back, no synchronisation: it may be captured into a hipGraph); tasks whose pictures are out of order
- *   or not among the nFrames pictures of the buffer are skipped on the device (their outputs keep their previous contents).
+ *   The call is fully asynchronous (no copy back, no synchronisation: it may be captured into a hipGraph); tasks with p0 == b
+ *   or pictures not among the nFrames pictures of the buffer are skipped on the device (their outputs keep their previous contents).
  *   mvs (int16 x, y per block) and mvCosts are arrays of ncu-long SLOTS, the device form of Lowres::lowresMvs[list][dist] /
  *   lowresMvCosts[list][dist]: a task searches into its slot when doSearch[list] != 0 and reads it otherwise (the
  *   reference's bDoSearch caching, :4376-4377).  Two tasks of one call must not search the same slot.
  *   Outputs per outSlot: lowresCosts (ncu, cost | listused << 14), rowSatds (heightInCU), sums { costEst before the
  *   B-frame normalisation (:4456-4457), costEstAq, intraMbs }. */
 typedef struct x265hip_la_task {
-    int32_t b, p0, p1;           /* picture indices in the lowres buffer, p0 <= b <= p1; p1 == b: P estimate        */
+    int32_t b, p0, p1;           /* picture indices in the lowres buffer (places, not display order); p1 == b: P estimate */
     int32_t doSearch[2];         /* per list: run the motion search (else the slot already holds its result)          */
     int32_t mvSlot[2];           /* per list: slot of mvs / mvCosts (mvSlot[1] unused for a P estimate)               */
     int32_t outSlot;             /* slot of lowresCosts / rowSatds / sums                                             */

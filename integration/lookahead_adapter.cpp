@@ -1,0 +1,176 @@
+/*
+ * lookahead_adapter.cpp -- LookaheadTLD::lowresIntraEstimate and CostEstimateGroup::estimateFrameCost with the GPU as the lookahead's cost producer
+ * (see lookahead_adapter.h).
+ *
+ * Per call the adapter hands over what the encoder's state holds for the pictures involved -- the Lowres planes (buffer[0]: four half-pel planes back to back), the AQ
+ * factors, for a list that was searched before its MVs and costs (the encoder's own bDoSearch caching) -- and writes the results where the encoder's body writes them.
+ * LookaheadTLD::weightsAnalyse stays host code (it is a handful of SATD sums); when it weights the list-0 reference its weighted copy (wbuffer) goes along.
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <vector>
+#include "x265.h"
+#include "common.h"
+#include "primitives.h"
+#include "lowres.h"
+#include "mv.h"
+#include "slicetype.h"
+#include "../include/x265hip_ctx.h"
+#include "lookahead_adapter.h"
+
+using namespace X265_NS;
+
+namespace {
+struct Api
+{
+    int (*ctx_create)(int, x265hip_ctx**);
+    void (*ctx_destroy)(x265hip_ctx*);
+    int (*la_create)(x265hip_ctx*, int, int, intptr_t, int64_t, int64_t, int, x265hip_la**);
+    void (*la_destroy)(x265hip_la*);
+    int (*la_intra)(x265hip_la*, uint64_t, const void*, const int32_t*, int32_t*, uint8_t*, uint16_t*, int32_t*, int64_t*);
+    int (*la_estimate)(x265hip_la*, const x265hip_la_estimate_desc*);
+    const char* (*last_error)();
+} g_api;
+void* g_lib;
+x265hip_ctx* g_ctx;
+x265hip_la* g_la;
+int g_on, g_device;
+std::mutex g_lock;                       /* creation of the producer; the producer serialises its own calls */
+x265hip_la_adapter_stats g_stats;
+std::mutex g_statLock;
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+uint64_t key_of(const Lowres& f) { return (uint64_t)(int64_t)f.frameNum + 2; }      /* frameNum starts at 0; 0 is "no key" */
+
+/* one producer per encoder: the geometry of the first picture seen (all Lowres of an encoder share it) */
+x265hip_la* producer(const Lowres& f, int widthInCU, int heightInCU)
+{
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (g_la) return g_la;
+    const int64_t planeElems = f.buffer[1] - f.buffer[0], origin = f.lowresPlane[0] - f.buffer[0];
+    if (g_api.ctx_create(g_device, &g_ctx) || g_api.la_create(g_ctx, widthInCU, heightInCU, f.lumaStride, planeElems, origin, 96, &g_la))
+    {
+        fprintf(stderr, "lookahead_adapter: x265hip_la_create: %s -- the encoder's own lookahead runs\n", g_api.last_error());
+        g_on = 0; g_la = nullptr;
+    }
+    return g_la;
+}
+}
+
+int64_t estimateFrameCost_cpu(CostEstimateGroup* self, LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty) __asm__("xla_estimateFrameCost_cpu");
+void lowresIntraEstimate_cpu(LookaheadTLD* self, Lowres& fenc, uint32_t qgSize) __asm__("xla_lowresIntraEstimate_cpu");
+
+namespace X265_NS {
+
+void LookaheadTLD::lowresIntraEstimate(Lowres& fenc, uint32_t qgSize)
+{
+    x265hip_la* la = g_on ? producer(fenc, widthInCU, heightInCU) : nullptr;
+    if (!la) { ::lowresIntraEstimate_cpu(this, fenc, qgSize); return; }
+    const double t0 = now();
+    /* slicetype.cpp:755-864: per block intraCost / intraMode / lowresCosts[0][0], per row rowSatds[0][0], the frame's costEst[0][0] / costEstAq[0][0].  The AQ factors
+       the estimate weighs with are invQscaleFactor8x8 with qgSize 8, invQscaleFactor otherwise, and none at all when invQscaleFactor is NULL (:851-854) */
+    const int32_t* invq = fenc.invQscaleFactor ? (qgSize == 8 ? fenc.invQscaleFactor8x8 : fenc.invQscaleFactor) : nullptr;
+    int64_t sums[2] = { 0, 0 };
+    const double t1 = now();
+    const int rc = g_api.la_intra(la, key_of(fenc), fenc.buffer[0], invq, fenc.intraCost, fenc.intraMode, fenc.lowresCosts[0][0], fenc.rowSatds[0][0], sums);
+    const double t2 = now();
+    if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_intra (frame %d): %d %s\n", fenc.frameNum, rc, g_api.last_error()); exit(3); }
+    fenc.costEst[0][0] = sums[0];
+    fenc.costEstAq[0][0] = sums[1];
+    std::lock_guard<std::mutex> guard(g_statLock);
+    g_stats.intraPictures++; g_stats.intraSeconds += now() - t0; g_stats.producerSeconds += t2 - t1;
+}
+
+int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty)
+{
+    Lowres* fenc = m_frames[b];
+    x265_param* param = m_lookahead.m_param;
+    x265hip_la* la = (g_on && !param->bEnableHME) ? producer(*fenc, m_lookahead.m_8x8Width, m_lookahead.m_8x8Height) : nullptr;
+    if (!la)
+    {
+        if (g_on) { std::lock_guard<std::mutex> guard(g_statLock); g_stats.cpuEstimates++; }
+        return ::estimateFrameCost_cpu(this, tld, p0, p1, b, bIntraPenalty);
+    }
+    int64_t score = 0;
+    if (fenc->costEst[b - p0][p1 - b] >= 0 && fenc->rowSatds[b - p0][p1 - b][0] != -1)      /* estimated before (slicetype.cpp:4372-4373) */
+        score = fenc->costEst[b - p0][p1 - b];
+    else
+    {
+        const double t0 = now();
+        const int ncu = m_lookahead.m_8x8Width * m_lookahead.m_8x8Height;
+        bool bDoSearch[2];
+        bDoSearch[0] = fenc->lowresMvs[0][b - p0][0].x == 0x7FFF;
+        bDoSearch[1] = p1 > b && fenc->lowresMvs[1][p1 - b][0].x == 0x7FFF;
+        fenc->weightedRef[b - p0].isWeighted = false;
+        if (param->bEnableWeightedPred && bDoSearch[0])
+            tld.weightsAnalyse(*m_frames[b], *m_frames[p0]);
+        x265hip_la_estimate_desc d;
+        memset(&d, 0, sizeof(d));
+        Lowres* fr[3] = { m_frames[p0], fenc, m_frames[p1] };
+        for (int k = 0; k < 3; k++) { d.key[k] = key_of(*fr[k]); d.planes[k] = fr[k]->buffer[0]; }
+        d.invQscale = fenc->invQscaleFactor ? (param->rc.qgSize == 8 ? fenc->invQscaleFactor8x8 : fenc->invQscaleFactor) : nullptr;
+        d.intraCost = fenc->intraCost;
+        if (fenc->weightedRef[b - p0].isWeighted) d.weightedPlanes = tld.wbuffer[0];
+        d.doSearch[0] = bDoSearch[0]; d.doSearch[1] = bDoSearch[1];
+        /* the cooperative sweep (a slice of block rows per worker, slicetype.cpp:4394-4426) gives other MV predictors at the slice borders than the serial one: same rule here */
+        const bool coop = !m_batchMode && m_lookahead.m_numCoopSlices > 1 && ((p1 > b) || bDoSearch[0] || bDoSearch[1]);
+        d.rowsPerSlice = coop ? m_lookahead.m_numRowsPerSlice : 0;
+        /* MVs travel as int16 pairs; the encoder keeps int32 pairs (MV) */
+        std::vector<int16_t> mv[2]; 
+        const int nl = p1 > b ? 2 : 1;
+        const int dist[2] = { b - p0, p1 - b };
+        for (int l = 0; l < nl; l++)
+        {
+            mv[l].resize((size_t)ncu * 2);
+            if (!bDoSearch[l]) { const MV* src = fenc->lowresMvs[l][dist[l]]; for (int i = 0; i < ncu; i++) { mv[l][2 * i] = (int16_t)src[i].x; mv[l][2 * i + 1] = (int16_t)src[i].y; } }
+            d.mvs[l] = mv[l].data(); d.mvCosts[l] = fenc->lowresMvCosts[l][dist[l]];
+        }
+        int64_t sums[3] = { 0, 0, 0 };
+        d.lowresCosts = fenc->lowresCosts[b - p0][p1 - b]; d.rowSatds = fenc->rowSatds[b - p0][p1 - b]; d.sums = sums;
+        const double t1 = now();
+        const int rc = g_api.la_estimate(la, &d);
+        const double t2 = now();
+        if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_estimate (%d, %d, %d): %d %s\n", p0, b, p1, rc, g_api.last_error()); exit(3); }
+        for (int l = 0; l < nl; l++)
+            if (bDoSearch[l]) { MV* dst = fenc->lowresMvs[l][dist[l]]; for (int i = 0; i < ncu; i++) { dst[i].x = mv[l][2 * i]; dst[i].y = mv[l][2 * i + 1]; } }
+        fenc->costEstAq[b - p0][p1 - b] = sums[1];
+        if (p1 == b) fenc->intraMbs[b - p0] += (int)sums[2];
+        score = sums[0];
+        if (b != p1)
+            score = score * 100 / (130 + param->bFrameBias);
+        fenc->costEst[b - p0][p1 - b] = score;
+        std::lock_guard<std::mutex> guard(g_statLock);
+        g_stats.estimates++; g_stats.estimateSeconds += now() - t0; g_stats.producerSeconds += t2 - t1; g_stats.weighted += d.weightedPlanes != nullptr;
+    }
+    if (bIntraPenalty)
+        // arbitrary penalty for I-blocks after B-frames
+        score += score * fenc->intraMbs[b - p0] / (tld.ncu * 8);
+    return score;
+}
+
+}
+
+extern "C" int x265hip_la_adapter_load(const char* libraryPath, int device)
+{
+    g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
+    if (!g_lib) { fprintf(stderr, "lookahead_adapter: dlopen: %s\n", dlerror()); return -1; }
+#define SYM(field, name) *(void**)&g_api.field = dlsym(g_lib, name); if (!g_api.field) { fprintf(stderr, "lookahead_adapter: %s lacks %s\n", libraryPath, name); return -1; }
+    SYM(ctx_create, "x265hip_ctx_create") SYM(ctx_destroy, "x265hip_ctx_destroy") SYM(la_create, "x265hip_la_create") SYM(la_destroy, "x265hip_la_destroy")
+    SYM(la_intra, "x265hip_la_intra") SYM(la_estimate, "x265hip_la_estimate") SYM(last_error, "x265hip_last_error")
+#undef SYM
+    g_device = device; g_on = 1;
+    return 0;
+}
+extern "C" void x265hip_la_adapter_enable(int on) { g_on = on && g_lib; }
+extern "C" void x265hip_la_adapter_close(void)
+{
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (g_la) { g_api.la_destroy(g_la); g_la = nullptr; }
+    if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
+    g_on = 0;
+}
+extern "C" void x265hip_la_adapter_get_stats(x265hip_la_adapter_stats* o) { std::lock_guard<std::mutex> guard(g_statLock); *o = g_stats; }

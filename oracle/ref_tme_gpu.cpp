@@ -6,6 +6,9 @@
  * the encoder's own body: the same binary, CPU producer.  The bitstream of the two runs must be identical (tests/test_e2e_tme_gpu.py); the printed frames-per-second are
  * the end-to-end figures of DESIGN section 6 and bench.py's e2e_fps.
  *
+ * Built a second time as x265e2e_<depth> (-DWITH_LA_ADAPTER, make -C oracle e2e2) with integration/lookahead_adapter.cpp linked in as well: X265LAGPU=1 makes the GPU the
+ * producer of the lookahead's intra costs and frame-cost estimates (x265hip_la_intra / x265hip_la_estimate), X265TME=0 runs without --threaded-me (lookahead seam alone).
+ *
  * usage: x265tmegpu_<depth> <libx265hip.so> <width> <height> <frames> <preset> <out.hevc> [option=value ...]
  */
 #include <chrono>
@@ -16,6 +19,9 @@
 #include "x265.h"
 #include "common.h"
 #include "../integration/tme_adapter.h"
+#ifdef WITH_LA_ADAPTER
+#include "../integration/lookahead_adapter.h"
+#endif
 
 using namespace X265_NS;
 
@@ -46,6 +52,11 @@ int main(int argc, char** argv)
     if (argc < 7) { fprintf(stderr, "usage: %s libx265hip.so width height frames preset out.hevc [option=value ...]\n", argv[0]); return 2; }
     const int useGpu = getenv("X265TMEGPU") ? atoi(getenv("X265TMEGPU")) : 1;
     if (useGpu && x265hip_tme_adapter_load(argv[1], getenv("X265TME_DEVICE") ? atoi(getenv("X265TME_DEVICE")) : 0)) return 2;
+    int useLa = 0;
+#ifdef WITH_LA_ADAPTER
+    useLa = getenv("X265LAGPU") ? atoi(getenv("X265LAGPU")) : 0;
+    if (useLa && x265hip_la_adapter_load(argv[1], getenv("X265TME_DEVICE") ? atoi(getenv("X265TME_DEVICE")) : 0)) return 2;
+#endif
     const int w = atoi(argv[2]), h = atoi(argv[3]), frames = atoi(argv[4]);
     x265_param* p = x265_param_alloc();
     if (x265_param_default_preset(p, argv[5], NULL) < 0) { fprintf(stderr, "bad preset\n"); return 2; }
@@ -53,7 +64,8 @@ int main(int argc, char** argv)
     p->totalFrames = frames; p->logLevel = X265_LOG_WARNING; p->bRepeatHeaders = 1;
     p->frameNumThreads = 1; p->bEnableWavefront = 0; p->lookaheadSlices = 0;
     x265_param_parse(p, "pools", "32");
-    x265_param_parse(p, "threaded-me", "1");
+    const int tmeOn = getenv("X265TME") ? atoi(getenv("X265TME")) : 1;
+    if (tmeOn) x265_param_parse(p, "threaded-me", "1");
     for (int i = 7; i < argc; i++)
     {
         char* eq = strchr(argv[i], '=');
@@ -93,7 +105,17 @@ int main(int argc, char** argv)
     x265hip_tme_adapter_stats s;
     x265hip_tme_adapter_get_stats(&s);
     x265hip_tme_adapter_close();
-    printf("{\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
-           useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.producerSeconds, s.adapterSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
+    char la[512] = "";
+#ifdef WITH_LA_ADAPTER
+    {
+        x265hip_la_adapter_stats ls;
+        x265hip_la_adapter_get_stats(&ls);
+        x265hip_la_adapter_close();
+        snprintf(la, sizeof(la), "\"lookahead_producer\": \"%s\", \"la_intra_pictures\": %d, \"la_estimates\": %d, \"la_cpu_estimates\": %d, \"la_weighted\": %d, \"la_intra_seconds\": %.3f, \"la_estimate_seconds\": %.3f, \"la_producer_seconds\": %.3f, ",
+                 useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds);
+    }
+#endif
+    printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
+           la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.producerSeconds, s.adapterSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
     return 0;
 }

@@ -1,0 +1,64 @@
+"""SURVEY 8(f2) end to end: the reference encoder whose lookahead costs come from libx265hip (the binding integration/lookahead_adapter.cpp: LookaheadTLD::lowresIntraEstimate
+and CostEstimateGroup::estimateFrameCost = one x265hip_la_intra / x265hip_la_estimate call each) must take the decisions -- slice types, scene cuts, cuTree offsets, rate
+control -- it takes with its own CPU lookahead, i.e. write the same bitstream; alone, and together with the ThreadedME binding."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+import x265hip
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def encode(depth, la, tme, tme_gpu, args, out, fade=False):
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265e2e_%d" % depth)
+    if not os.path.exists(exe):
+        pytest.skip("no oracle/_ref/x265e2e_%d (built where the reference is present)" % depth)
+    env = dict(os.environ, X265LAGPU="1" if la else "0", X265TME="1" if tme else "0", X265TMEGPU="1" if tme_gpu else "0", MALLOC_PERTURB_="85")
+    if fade:
+        env["X265TME_FADE"] = "1"
+    r = subprocess.run([exe, x265hip.lib_path(depth)] + args[:4] + [out] + args[4:], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), hashlib.md5(open(out, "rb").read()).hexdigest()
+
+
+@pytest.mark.parametrize("depth,args,fade", [(8, ["256", "192", "12", "medium"], False),                               # preset defaults: b-adapt 2, bframes 4, weightp, cuTree, AQ
+                                             (8, ["256", "192", "12", "medium", "b-adapt=1"], False),
+                                             (8, ["200", "120", "10", "medium", "bframes=2", "aq-mode=0", "cutree=0"], False),      # lowres pictures that are no block multiple, no AQ factors
+                                             (10, ["256", "192", "10", "slow"], False),
+                                             (8, ["256", "128", "12", "medium", "weightp=1"], True),                    # a fade: weightsAnalyse weights list 0
+                                             (8, ["256", "192", "12", "medium", "lookahead-slices=4"], False),          # the cooperative sweep
+                                             (8, ["256", "192", "10", "medium", "qg-size=8"], False),
+                                             (8, ["256", "192", "16", "fast", "rc-lookahead=10", "scenecut=40"], False)])
+def test_bitstream_identical_with_gpu_lookahead(depth, args, fade, tmp_path):
+    cpu, h_cpu = encode(depth, False, False, False, args, str(tmp_path / "cpu.hevc"), fade)
+    gpu, h_gpu = encode(depth, True, False, False, args, str(tmp_path / "gpu.hevc"), fade)
+    assert gpu["lookahead_producer"] == "gpu" and gpu["la_intra_pictures"] == int(args[2]) and gpu["la_estimates"] > 0, "the GPU lookahead did not run: %s" % gpu
+    assert gpu["la_cpu_estimates"] == 0
+    assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
+    if fade:
+        assert gpu["la_weighted"] > 0, "the fade did not make the lookahead weight a reference: %s" % gpu
+    print("e2e la", depth, args, "estimates %d, %.2f ms each (producer %.2f)" % (gpu["la_estimates"], 1e3 * gpu["la_estimate_seconds"] / gpu["la_estimates"],
+                                                                                  1e3 * gpu["la_producer_seconds"] / (gpu["la_estimates"] + gpu["la_intra_pictures"])))
+
+
+@pytest.mark.parametrize("depth,args", [(8, ["256", "192", "10", "medium"]), (10, ["192", "128", "8", "slow"])])
+def test_both_seams_together(depth, args, tmp_path):
+    """--threaded-me with the GPU producing the MEData tables AND the lookahead's costs: the bitstream of the all-CPU run"""
+    cpu, h_cpu = encode(depth, False, True, False, args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(depth, True, True, True, args, str(tmp_path / "gpu.hevc"))
+    assert gpu["gpu_pictures"] >= 3 and gpu["la_estimates"] > 0
+    assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
+
+
+def test_hme_keeps_the_encoders_own_lookahead(tmp_path):
+    """--hme is not offered by the producer: the adapter forwards those estimates to the encoder's own body (counted), the intra estimates still come from the GPU"""
+    args = ["960", "544", "5", "superfast", "hme=1"]          # (the encoder switches HME off below 540 lines, encoder.cpp:4799-4806)
+    cpu, h_cpu = encode(8, False, False, False, args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(8, True, False, False, args, str(tmp_path / "gpu.hevc"))
+    assert gpu["la_estimates"] == 0 and gpu["la_cpu_estimates"] > 0
+    assert h_cpu == h_gpu

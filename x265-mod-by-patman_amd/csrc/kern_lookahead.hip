@@ -345,11 +345,12 @@ __device__ __forceinline__ uint32_t plane0_off(const LaGeom& g, int frame) { ret
 __device__ __forceinline__ uint32_t ld_mv(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void st_mv(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// a task the host could not look at (the list lives in device memory): pictures in order and inside the buffer, else the estimate is skipped
+// a task the host could not look at (the list lives in device memory): pictures inside the buffer and b not its own list-0 reference, else the estimate is skipped.
+// The indices are places in the lowres buffer, not display order (a caller that keeps pictures in reusable slots has none): p1 == b marks a P estimate.
 __device__ __forceinline__ bool la_task_ok(const x265hip_la_task* tp, int nFrames)
 {
     const int w0 = tp->weighted0;
-    return tp->p0 >= 0 && tp->p0 <= tp->b && tp->b <= tp->p1 && tp->p1 < nFrames && w0 >= 0 && w0 <= nFrames;
+    return tp->p0 >= 0 && tp->p0 < nFrames && tp->b >= 0 && tp->b < nFrames && tp->p1 >= 0 && tp->p1 < nFrames && tp->p0 != tp->b && w0 >= 0 && w0 <= nFrames;
 }
 
 __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, int nFrames, const uint16_t* __restrict__ costCentre, int costR, int rowsPerSlice,
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
     if (!la_task_ok(tp, nFrames)) return;
     const int list = blockIdx.x & 1;
     const int tb = tp->b, tp0 = tp->p0, tp1 = tp->p1;
-    const bool bidir = tp1 > tb;
+    const bool bidir = tp1 != tb;
     if ((list && !bidir) || !tp->doSearch[list]) return;
     const int W = g.wcu, H = g.hcu, ncu = W * H;
     const int grp = threadIdx.x >> 3, ngrp = blockDim.x >> 3, lane = threadIdx.x & 7;
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void la_finish_kernel(LaGeom g, const x265hip_
     const int tb = tp->b, tp0 = tp->p0, tp1 = tp->p1, slot0 = tp->mvSlot[0], slot1 = tp->mvSlot[1], outSlot = tp->outSlot;
     const int W = g.wcu, H = g.hcu, ncu = W * H;
     const int cuY = blockIdx.x, lane = threadIdx.x & 7;
-    const bool bidir = tp1 > tb;
+    const bool bidir = tp1 != tb;
     int accCost = 0, accAq = 0, accRow = 0, accIntra = 0;
     for (int cuX = threadIdx.x >> 3; cuX < W; cuX += 32)
     {

@@ -1,0 +1,190 @@
+// xh_la.cpp -- host side of the lookahead frame-cost path for a C / C++ caller (include/x265hip_ctx.h: x265hip_la_*): the half-resolution pictures of the frames in the
+// lookahead stay on the device under the caller's key; LookaheadTLD::lowresIntraEstimate (encoder/slicetype.cpp:755-864) of one picture and
+// CostEstimateGroup::estimateFrameCost (:4366-4463, with estimateCUCost :4467-4640) of one (p0, b, p1) choice are one call each, host arrays in / out, on top of
+// x265hip_lookahead_intra_batch / x265hip_lookahead_cost_batch (kern_lookahead.hip).  What integration/lookahead_adapter.cpp binds inside the reference encoder.
+#include "xh_common.h"
+#include "../../include/x265hip_ctx.h"
+#include <mutex>
+#include <new>
+#include <vector>
+using namespace xh;
+
+struct x265hip_la
+{
+    x265hip_ctx* ctx = nullptr;
+    int wcu = 0, hcu = 0, ncu = 0, maxPics = 0;
+    intptr_t stride = 0; int64_t planeElems = 0, origin = 0;
+    pixel* low = nullptr;                        // (maxPics + 1) pictures x 4 planes; the last picture slot holds a weighted copy for the duration of one estimate
+    int32_t* intraCost = nullptr; int32_t* invq = nullptr; bool haveInvq = false;      // per picture slot
+    uint8_t* intraMode = nullptr; uint16_t* intraLc = nullptr; int32_t* intraRows = nullptr; int64_t* intraSums = nullptr;      // one picture's worth (the one being estimated)
+    uint16_t* costRow = nullptr;
+    int16_t* mvs = nullptr; int32_t* mvCosts = nullptr; uint16_t* lc = nullptr; int32_t* rows = nullptr; int64_t* sums = nullptr; x265hip_la_task* task = nullptr;
+    struct Slot { uint64_t key = 0; uint64_t used = 0; };
+    std::vector<Slot> slots; uint64_t tick = 0;
+    std::mutex mu;                                // the lookahead's workers call concurrently; one estimate at a time on the context's stream
+    std::vector<void*> owned;
+    template<class T> int alloc(T*& p, size_t n)
+    {
+        void* v = nullptr;
+        XH_HIP(hipMalloc(&v, n * sizeof(T)));
+        owned.push_back(v); p = (T*)v;
+        return X265HIP_OK;
+    }
+    int find(uint64_t key) const { for (int i = 0; i < (int)slots.size(); i++) if (slots[i].key == key) return i; return -1; }
+};
+
+namespace { constexpr int kLaHalf = 1 << 14; }
+
+extern "C" int x265hip_la_create(x265hip_ctx* ctx, int widthInCU, int heightInCU, intptr_t stride, int64_t planeElems, int64_t origin, int maxPictures, x265hip_la** out)
+{
+    if (!ctx || !out || widthInCU < 1 || heightInCU < 1 || stride < widthInCU * 8 || planeElems < stride * heightInCU * 8 || origin < 0 || origin >= planeElems || maxPictures < 3 || maxPictures > 1024)
+    { set_error("la_create: bad geometry"); return X265HIP_EARG; }
+    if (kLaHalf < 4 * (8 * (widthInCU > heightInCU ? widthInCU : heightInCU) + 32)) { set_error("la_create: picture too large for the MVD cost row"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(x265hip_ctx_device(ctx)));
+    x265hip_la* a = new (std::nothrow) x265hip_la();
+    if (!a) return X265HIP_EARG;
+    a->ctx = ctx; a->wcu = widthInCU; a->hcu = heightInCU; a->ncu = widthInCU * heightInCU; a->stride = stride; a->planeElems = planeElems; a->origin = origin; a->maxPics = maxPictures;
+    a->slots.resize((size_t)maxPictures);
+    const size_t np = (size_t)maxPictures + 1, ncu = (size_t)a->ncu;
+    int rc;
+    if ((rc = a->alloc(a->low, np * 4 * (size_t)planeElems)) || (rc = a->alloc(a->intraCost, np * ncu)) || (rc = a->alloc(a->invq, np * ncu)) || (rc = a->alloc(a->intraMode, ncu)) ||
+        (rc = a->alloc(a->intraLc, ncu)) || (rc = a->alloc(a->intraRows, (size_t)heightInCU)) || (rc = a->alloc(a->intraSums, 2)) || (rc = a->alloc(a->costRow, (size_t)2 * kLaHalf + 1)) ||
+        (rc = a->alloc(a->mvs, 2 * ncu * 2)) || (rc = a->alloc(a->mvCosts, 2 * ncu)) || (rc = a->alloc(a->lc, ncu)) || (rc = a->alloc(a->rows, (size_t)heightInCU)) || (rc = a->alloc(a->sums, 3)) ||
+        (rc = a->alloc(a->task, 1)))
+    { x265hip_la_destroy(a); return rc; }
+    std::vector<uint16_t> row((size_t)2 * kLaHalf + 1);
+    if ((rc = x265hip_mvcost_row(x265hip_lookahead_qp(), kLaHalf, row.data()))) { x265hip_la_destroy(a); return rc; }
+    if (hipMemcpy(a->costRow, row.data(), row.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { x265hip_la_destroy(a); return X265HIP_EDEVICE; }
+    *out = a;
+    return X265HIP_OK;
+}
+extern "C" void x265hip_la_destroy(x265hip_la* a)
+{
+    if (!a) return;
+    (void)hipSetDevice(x265hip_ctx_device(a->ctx));
+    (void)hipStreamSynchronize((hipStream_t)x265hip_ctx_stream(a->ctx));
+    for (void* p : a->owned) (void)hipFree(p);
+    delete a;
+}
+
+namespace {
+// the picture's slot, uploading its planes (and AQ factors / intra costs when given) if it is not on the device yet; `pinned`: slots this call must not evict
+int ensure_picture(x265hip_la* a, hipStream_t st, uint64_t key, const void* planes4, const int32_t* invQscale, const int32_t* intraCost, const int* pinned, int nPinned, int* slotOut)
+{
+    if (!key) { set_error("la: picture key 0"); return X265HIP_EARG; }
+    int s = a->find(key);
+    if (s < 0)
+    {
+        if (!planes4) { set_error("la: picture %llu is not on the device and no planes were given", (unsigned long long)key); return X265HIP_EARG; }
+        for (int i = 0; i < (int)a->slots.size(); i++)
+        {
+            bool pin = false;
+            for (int k = 0; k < nPinned; k++) pin |= pinned[k] == i;
+            if (!pin && (s < 0 || a->slots[i].used < a->slots[s].used)) s = i;
+        }
+        a->slots[s].key = 0;
+        XH_HIP(hipMemcpyAsync(a->low + (size_t)s * 4 * a->planeElems, planes4, (size_t)4 * a->planeElems * sizeof(pixel), hipMemcpyHostToDevice, st));
+        if (invQscale) { XH_HIP(hipMemcpyAsync(a->invq + (size_t)s * a->ncu, invQscale, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st)); a->haveInvq = true; }
+        if (intraCost) XH_HIP(hipMemcpyAsync(a->intraCost + (size_t)s * a->ncu, intraCost, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        XH_HIP(hipStreamSynchronize(st));                    // the caller's buffers are free again (and pageable copies are staged anyway)
+        a->slots[s].key = key;                               // named once its planes are there
+    }
+    else if (invQscale)
+    {   // the factors of a resident picture may have moved since (--aq-motion rewrites them during the slice-type analysis): they are small, send them again
+        XH_HIP(hipMemcpyAsync(a->invq + (size_t)s * a->ncu, invQscale, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st)); a->haveInvq = true;
+        XH_HIP(hipStreamSynchronize(st));
+    }
+    a->slots[s].used = ++a->tick;
+    *slotOut = s;
+    return X265HIP_OK;
+}
+}
+
+extern "C" int x265hip_la_picture(x265hip_la* a, uint64_t key, const void* planes4, const int32_t* invQscale, const int32_t* intraCost)
+{
+    if (!a) { set_error("la_picture: null"); return X265HIP_EARG; }
+    std::lock_guard<std::mutex> g(a->mu);
+    XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
+    int s;
+    return ensure_picture(a, (hipStream_t)x265hip_ctx_stream(a->ctx), key, planes4, invQscale, intraCost, nullptr, 0, &s);
+}
+extern "C" int x265hip_la_forget(x265hip_la* a, uint64_t key)
+{
+    if (!a) return X265HIP_EARG;
+    std::lock_guard<std::mutex> g(a->mu);
+    const int s = a->find(key);
+    if (s >= 0) a->slots[s].key = 0;
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_la_intra(x265hip_la* a, uint64_t key, const void* planes4, const int32_t* invQscale, int32_t* intraCost, uint8_t* intraMode, uint16_t* lowresCosts,
+                                int32_t* rowSatds, int64_t* sums2)
+{
+    if (!a || !intraCost || !intraMode || !lowresCosts || !rowSatds || !sums2) { set_error("la_intra: bad arguments"); return X265HIP_EARG; }
+    std::lock_guard<std::mutex> g(a->mu);
+    XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
+    hipStream_t st = (hipStream_t)x265hip_ctx_stream(a->ctx);
+    int s, rc;
+    if ((rc = ensure_picture(a, st, key, planes4, invQscale, nullptr, nullptr, 0, &s))) return rc;
+    const size_t ncu = (size_t)a->ncu;
+    if ((rc = x265hip_lookahead_intra_batch(st, a->low + (size_t)s * 4 * a->planeElems, a->planeElems, a->stride, a->origin, a->wcu, a->hcu, 1, a->haveInvq ? a->invq + (size_t)s * ncu : nullptr,
+                                            a->intraCost + (size_t)s * ncu, a->intraMode, a->intraLc, a->intraRows, a->intraSums))) return rc;
+    XH_HIP(hipMemcpyAsync(intraCost, a->intraCost + (size_t)s * ncu, ncu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    XH_HIP(hipMemcpyAsync(intraMode, a->intraMode, ncu, hipMemcpyDeviceToHost, st));
+    XH_HIP(hipMemcpyAsync(lowresCosts, a->intraLc, ncu * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+    XH_HIP(hipMemcpyAsync(rowSatds, a->intraRows, (size_t)a->hcu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    XH_HIP(hipMemcpyAsync(sums2, a->intraSums, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    XH_HIP(hipStreamSynchronize(st));
+    return X265HIP_OK;
+}
+
+extern "C" int x265hip_la_estimate(x265hip_la* a, const x265hip_la_estimate_desc* d)
+{
+    if (!a || !d || !d->lowresCosts || !d->rowSatds || !d->sums || !d->mvs[0] || !d->mvCosts[0] || (d->key[2] != d->key[1] && (!d->mvs[1] || !d->mvCosts[1])))
+    { set_error("la_estimate: bad arguments"); return X265HIP_EARG; }
+    std::lock_guard<std::mutex> g(a->mu);
+    XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
+    hipStream_t st = (hipStream_t)x265hip_ctx_stream(a->ctx);
+    const bool isB = d->key[2] != d->key[1];
+    const size_t ncu = (size_t)a->ncu;
+    int slot[3] = { -1, -1, -1 }, rc;
+    // b first (its intra costs and AQ factors are read), then the references; a picture already taken is not evicted for the next one
+    const int order[3] = { 1, 0, 2 };
+    int pinned[3], nPinned = 0;
+    for (int k : order)
+    {
+        if (k == 2 && !isB) { slot[2] = slot[1]; continue; }
+        if ((rc = ensure_picture(a, st, d->key[k], d->planes[k], k == 1 ? d->invQscale : nullptr, k == 1 ? d->intraCost : nullptr, pinned, nPinned, &slot[k]))) return rc;
+        pinned[nPinned++] = slot[k];
+    }
+    if (slot[0] == slot[1] || (isB && slot[2] == slot[1])) { set_error("la_estimate: the estimated picture is its own reference"); return X265HIP_EARG; }
+    x265hip_la_task t{};
+    t.b = slot[1]; t.p0 = slot[0]; t.p1 = slot[2];
+    // the batch call addresses pictures by their place in the lowres buffer; p1 == b marks the P estimate
+    t.doSearch[0] = d->doSearch[0] != 0; t.doSearch[1] = isB && d->doSearch[1] != 0; t.mvSlot[0] = 0; t.mvSlot[1] = 1; t.outSlot = 0; t.weighted0 = 0;
+    if (d->weightedPlanes)
+    {   // list 0 is searched in the weighted copy LookaheadTLD::weightsAnalyse made (slicetype.cpp:4474); the bidirectional average uses p0 itself
+        XH_HIP(hipMemcpyAsync(a->low + (size_t)a->maxPics * 4 * a->planeElems, d->weightedPlanes, (size_t)4 * a->planeElems * sizeof(pixel), hipMemcpyHostToDevice, st));
+        t.weighted0 = 1 + a->maxPics;
+    }
+    for (int l = 0; l < (isB ? 2 : 1); l++)
+        if (!t.doSearch[l])
+        {   // the list's earlier result (the reference's bDoSearch caching, :4376-4377): MVs and costs are read
+            XH_HIP(hipMemcpyAsync(a->mvs + (size_t)l * ncu * 2, d->mvs[l], ncu * 2 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+            XH_HIP(hipMemcpyAsync(a->mvCosts + (size_t)l * ncu, d->mvCosts[l], ncu * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        }
+    XH_HIP(hipMemcpyAsync(a->task, &t, sizeof(t), hipMemcpyHostToDevice, st));
+    if ((rc = x265hip_lookahead_cost_batch(st, a->low, a->planeElems, a->stride, a->origin, a->wcu, a->hcu, a->task, 1, a->maxPics + 1, a->intraCost, a->haveInvq ? a->invq : nullptr,
+                                           a->costRow, kLaHalf, d->rowsPerSlice, a->mvs, a->mvCosts, a->lc, a->rows, a->sums))) return rc;
+    for (int l = 0; l < (isB ? 2 : 1); l++)
+        if (t.doSearch[l])
+        {
+            XH_HIP(hipMemcpyAsync(d->mvs[l], a->mvs + (size_t)l * ncu * 2, ncu * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+            XH_HIP(hipMemcpyAsync(d->mvCosts[l], a->mvCosts + (size_t)l * ncu, ncu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        }
+    XH_HIP(hipMemcpyAsync(d->lowresCosts, a->lc, ncu * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+    XH_HIP(hipMemcpyAsync(d->rowSatds, a->rows, (size_t)a->hcu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    XH_HIP(hipMemcpyAsync(d->sums, a->sums, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    XH_HIP(hipStreamSynchronize(st));
+    return X265HIP_OK;
+}
