@@ -188,7 +188,7 @@ def e2e_fps_leg(frames=8):
                    "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"]) / max(1, g["gpu_pictures"]), 2), "adapter_sections_s": g["adapter_sections"]}}
     if both:
         l = runs["la_gpu"]
-        out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "estimates_left_to_the_cpu": l["la_cpu_estimates"],
+        out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "device_launches": l.get("la_launches"), "estimates_left_to_the_cpu": l["la_cpu_estimates"],
                             "ms_per_estimate": round(1e3 * l["la_estimate_seconds"] / max(1, l["la_estimates"]), 3),
                             "ms_per_intra_picture": round(1e3 * l["la_intra_seconds"] / max(1, l["la_intra_pictures"]), 3),
                             "producer_seconds": l["la_producer_seconds"]}

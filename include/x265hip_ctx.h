@@ -136,7 +136,7 @@ int  x265hip_tme_picture(x265hip_tme* tme, const x265hip_tme_picture_desc* desc)
  * the device under the caller's key (e.g. Lowres::frameNum + 1; the least recently used of maxPictures makes room, a missing picture is uploaded again from `planes`).
  * Arrays are the reference's own: MVs as int16 x, y per 8x8 block (Lowres::lowresMvs[list][dist], MV = two int32 there), costs int32 (lowresMvCosts), lowresCosts uint16
  * (cost | listused << 14), rowSatds int32 per block row; sums = { costEst before the B-frame normalisation (:4456-4457), costEstAq, intraMbs }.  Calls are synchronous
- * and serialised inside the producer (the lookahead's workers may call concurrently).  HME is not offered (the caller keeps its own path for --hme). */
+ * (the lookahead's workers may call concurrently).  HME is not offered (the caller keeps its own path for --hme). */
 typedef struct x265hip_la x265hip_la;
 int  x265hip_la_create(x265hip_ctx* ctx, int widthInCU, int heightInCU, intptr_t stride /* Lowres::lumaStride */, int64_t planeElems /* buffer[1] - buffer[0] */,
                        int64_t origin /* lowresPlane[0] - buffer[0] */, int maxPictures, x265hip_la** la);
@@ -160,6 +160,9 @@ typedef struct x265hip_la_estimate_desc {
     uint16_t* lowresCosts; int32_t* rowSatds; int64_t* sums;      /* ncu, heightInCU, 3                                                                 */
 } x265hip_la_estimate_desc;
 int  x265hip_la_estimate(x265hip_la* la, const x265hip_la_estimate_desc* desc);
+/* x265hip_la_estimate is synchronous for its caller, but estimates that arrive from other threads while a launch is in flight go up TOGETHER as the next launch (up to 16):
+ * the lookahead's batched frame costs (b-adapt 2 with a thread pool) become batches on the device.  launches / estimates so far: */
+int  x265hip_la_batch_stats(const x265hip_la* la, int64_t* launches, int64_t* estimates);
 
 #ifdef __cplusplus
 }

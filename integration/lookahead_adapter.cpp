@@ -33,6 +33,7 @@ struct Api
     void (*la_destroy)(x265hip_la*);
     int (*la_intra)(x265hip_la*, uint64_t, const void*, const int32_t*, int32_t*, uint8_t*, uint16_t*, int32_t*, int64_t*);
     int (*la_estimate)(x265hip_la*, const x265hip_la_estimate_desc*);
+    int (*la_batch_stats)(const x265hip_la*, int64_t*, int64_t*);
     const char* (*last_error)();
 } g_api;
 void* g_lib;
@@ -52,7 +53,11 @@ x265hip_la* producer(const Lowres& f, int widthInCU, int heightInCU)
     std::lock_guard<std::mutex> guard(g_lock);
     if (g_la) return g_la;
     const int64_t planeElems = f.buffer[1] - f.buffer[0], origin = f.lowresPlane[0] - f.buffer[0];
-    if (g_api.ctx_create(g_device, &g_ctx) || g_api.la_create(g_ctx, widthInCU, heightInCU, f.lumaStride, planeElems, origin, 96, &g_la))
+    /* pictures kept on the device: the lookahead's depth and then some; the producer addresses its lowres buffer with 32-bit element offsets (16 more places hold the
+       weighted copies of a launch), which bounds the count for very large pictures -- fewer places only mean more uploads */
+    int64_t keep = (((int64_t)1 << 31) - 1) / (4 * planeElems) - 17;
+    if (keep > 96) keep = 96;
+    if (keep < 8 || g_api.ctx_create(g_device, &g_ctx) || g_api.la_create(g_ctx, widthInCU, heightInCU, f.lumaStride, planeElems, origin, (int)keep, &g_la))
     {
         fprintf(stderr, "lookahead_adapter: x265hip_la_create: %s -- the encoder's own lookahead runs\n", g_api.last_error());
         g_on = 0; g_la = nullptr;
@@ -160,7 +165,7 @@ extern "C" int x265hip_la_adapter_load(const char* libraryPath, int device)
     if (!g_lib) { fprintf(stderr, "lookahead_adapter: dlopen: %s\n", dlerror()); return -1; }
 #define SYM(field, name) *(void**)&g_api.field = dlsym(g_lib, name); if (!g_api.field) { fprintf(stderr, "lookahead_adapter: %s lacks %s\n", libraryPath, name); return -1; }
     SYM(ctx_create, "x265hip_ctx_create") SYM(ctx_destroy, "x265hip_ctx_destroy") SYM(la_create, "x265hip_la_create") SYM(la_destroy, "x265hip_la_destroy")
-    SYM(la_intra, "x265hip_la_intra") SYM(la_estimate, "x265hip_la_estimate") SYM(last_error, "x265hip_last_error")
+    SYM(la_intra, "x265hip_la_intra") SYM(la_estimate, "x265hip_la_estimate") SYM(la_batch_stats, "x265hip_la_batch_stats") SYM(last_error, "x265hip_last_error")
 #undef SYM
     g_device = device; g_on = 1;
     return 0;
@@ -169,7 +174,13 @@ extern "C" void x265hip_la_adapter_enable(int on) { g_on = on && g_lib; }
 extern "C" void x265hip_la_adapter_close(void)
 {
     std::lock_guard<std::mutex> guard(g_lock);
-    if (g_la) { g_api.la_destroy(g_la); g_la = nullptr; }
+    if (g_la)
+    {
+        int64_t l = 0, e = 0;
+        g_api.la_batch_stats(g_la, &l, &e);
+        { std::lock_guard<std::mutex> sg(g_statLock); g_stats.launches = (int)l; }
+        g_api.la_destroy(g_la); g_la = nullptr;
+    }
     if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
     g_on = 0;
 }

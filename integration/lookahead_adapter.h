@@ -19,6 +19,7 @@ void x265hip_la_adapter_close(void);                                      /* aft
 typedef struct x265hip_la_adapter_stats
 {
     int intraPictures, estimates, cpuEstimates /* fell through to the encoder's own body */, weighted;
+    int launches;                              /* device launches the estimates went up in (concurrent callers share one); filled by x265hip_la_adapter_close */
     double intraSeconds, estimateSeconds;      /* whole calls, harvest and write-back included */
     double producerSeconds;                    /* inside x265hip_la_intra / x265hip_la_estimate */
 } x265hip_la_adapter_stats;

@@ -109,10 +109,10 @@ int main(int argc, char** argv)
 #ifdef WITH_LA_ADAPTER
     {
         x265hip_la_adapter_stats ls;
-        x265hip_la_adapter_get_stats(&ls);
         x265hip_la_adapter_close();
-        snprintf(la, sizeof(la), "\"lookahead_producer\": \"%s\", \"la_intra_pictures\": %d, \"la_estimates\": %d, \"la_cpu_estimates\": %d, \"la_weighted\": %d, \"la_intra_seconds\": %.3f, \"la_estimate_seconds\": %.3f, \"la_producer_seconds\": %.3f, ",
-                 useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds);
+        x265hip_la_adapter_get_stats(&ls);
+        snprintf(la, sizeof(la), "\"lookahead_producer\": \"%s\", \"la_intra_pictures\": %d, \"la_estimates\": %d, \"la_launches\": %d, \"la_cpu_estimates\": %d, \"la_weighted\": %d, \"la_intra_seconds\": %.3f, \"la_estimate_seconds\": %.3f, \"la_producer_seconds\": %.3f, ",
+                 useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.launches, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds);
     }
 #endif
     printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",

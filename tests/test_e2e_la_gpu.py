@@ -42,7 +42,8 @@ def test_bitstream_identical_with_gpu_lookahead(depth, args, fade, tmp_path):
     assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
     if fade:
         assert gpu["la_weighted"] > 0, "the fade did not make the lookahead weight a reference: %s" % gpu
-    print("e2e la", depth, args, "estimates %d, %.2f ms each (producer %.2f)" % (gpu["la_estimates"], 1e3 * gpu["la_estimate_seconds"] / gpu["la_estimates"],
+    assert 0 < gpu["la_launches"] <= gpu["la_estimates"]
+    print("e2e la", depth, args, "estimates %d in %d launches, %.2f ms each (producer %.2f)" % (gpu["la_estimates"], gpu["la_launches"], 1e3 * gpu["la_estimate_seconds"] / gpu["la_estimates"],
                                                                                   1e3 * gpu["la_producer_seconds"] / (gpu["la_estimates"] + gpu["la_intra_pictures"])))
 
 

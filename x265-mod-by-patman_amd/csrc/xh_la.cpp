@@ -4,24 +4,32 @@
 // x265hip_lookahead_intra_batch / x265hip_lookahead_cost_batch (kern_lookahead.hip).  What integration/lookahead_adapter.cpp binds inside the reference encoder.
 #include "xh_common.h"
 #include "../../include/x265hip_ctx.h"
+#include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <vector>
 using namespace xh;
+
+namespace { struct Req; constexpr int kLaBatch = 16; }      // estimates per launch at most
 
 struct x265hip_la
 {
     x265hip_ctx* ctx = nullptr;
     int wcu = 0, hcu = 0, ncu = 0, maxPics = 0;
     intptr_t stride = 0; int64_t planeElems = 0, origin = 0;
-    pixel* low = nullptr;                        // (maxPics + 1) pictures x 4 planes; the last picture slot holds a weighted copy for the duration of one estimate
+    pixel* low = nullptr;                        // (maxPics + kLaBatch) pictures x 4 planes; the last kLaBatch places hold the weighted copies of the estimates of one launch
     int32_t* intraCost = nullptr; int32_t* invq = nullptr; bool haveInvq = false;      // per picture slot
     uint8_t* intraMode = nullptr; uint16_t* intraLc = nullptr; int32_t* intraRows = nullptr; int64_t* intraSums = nullptr;      // one picture's worth (the one being estimated)
     uint16_t* costRow = nullptr;
     int16_t* mvs = nullptr; int32_t* mvCosts = nullptr; uint16_t* lc = nullptr; int32_t* rows = nullptr; int64_t* sums = nullptr; x265hip_la_task* task = nullptr;
     struct Slot { uint64_t key = 0; uint64_t used = 0; };
     std::vector<Slot> slots; uint64_t tick = 0;
-    std::mutex mu;                                // the lookahead's workers call concurrently; one estimate at a time on the context's stream
+    std::mutex mu;                                // the device side: one call at a time on the context's stream
+    // estimates that arrive while a launch is in flight are queued and go up together (x265hip_la_estimate)
+    std::mutex qmu; std::condition_variable qcv; bool leader = false;
+    std::vector<Req*> queue;
+    int64_t batches = 0, batched = 0;
     std::vector<void*> owned;
     template<class T> int alloc(T*& p, size_t n)
     {
@@ -45,12 +53,13 @@ extern "C" int x265hip_la_create(x265hip_ctx* ctx, int widthInCU, int heightInCU
     if (!a) return X265HIP_EARG;
     a->ctx = ctx; a->wcu = widthInCU; a->hcu = heightInCU; a->ncu = widthInCU * heightInCU; a->stride = stride; a->planeElems = planeElems; a->origin = origin; a->maxPics = maxPictures;
     a->slots.resize((size_t)maxPictures);
-    const size_t np = (size_t)maxPictures + 1, ncu = (size_t)a->ncu;
+    const size_t np = (size_t)maxPictures + kLaBatch, ncu = (size_t)a->ncu;      // + one weighted copy per estimate of a batch
+    if ((int64_t)np * 4 * planeElems >= ((int64_t)1 << 31)) { set_error("la_create: %d pictures of this size do not fit the 2^31-element lowres buffer", maxPictures); delete a; return X265HIP_EARG; }
     int rc;
     if ((rc = a->alloc(a->low, np * 4 * (size_t)planeElems)) || (rc = a->alloc(a->intraCost, np * ncu)) || (rc = a->alloc(a->invq, np * ncu)) || (rc = a->alloc(a->intraMode, ncu)) ||
         (rc = a->alloc(a->intraLc, ncu)) || (rc = a->alloc(a->intraRows, (size_t)heightInCU)) || (rc = a->alloc(a->intraSums, 2)) || (rc = a->alloc(a->costRow, (size_t)2 * kLaHalf + 1)) ||
-        (rc = a->alloc(a->mvs, 2 * ncu * 2)) || (rc = a->alloc(a->mvCosts, 2 * ncu)) || (rc = a->alloc(a->lc, ncu)) || (rc = a->alloc(a->rows, (size_t)heightInCU)) || (rc = a->alloc(a->sums, 3)) ||
-        (rc = a->alloc(a->task, 1)))
+        (rc = a->alloc(a->mvs, (size_t)kLaBatch * 2 * ncu * 2)) || (rc = a->alloc(a->mvCosts, (size_t)kLaBatch * 2 * ncu)) || (rc = a->alloc(a->lc, (size_t)kLaBatch * ncu)) ||
+        (rc = a->alloc(a->rows, (size_t)kLaBatch * heightInCU)) || (rc = a->alloc(a->sums, (size_t)kLaBatch * 3)) || (rc = a->alloc(a->task, (size_t)kLaBatch)))
     { x265hip_la_destroy(a); return rc; }
     std::vector<uint16_t> row((size_t)2 * kLaHalf + 1);
     if ((rc = x265hip_mvcost_row(x265hip_lookahead_qp(), kLaHalf, row.data()))) { x265hip_la_destroy(a); return rc; }
@@ -138,53 +147,104 @@ extern "C" int x265hip_la_intra(x265hip_la* a, uint64_t key, const void* planes4
     return X265HIP_OK;
 }
 
+namespace {
+// One launch for every estimate that is waiting: the lookahead's workers ask concurrently (b-adapt 2 batches its frame costs, slicetype.cpp:1960-1990, 4236-4283), and a
+// batch of estimates costs the device little more than one (the sweep over a picture's block wavefronts is a serial depth that a batch pays once).
+struct Req { const x265hip_la_estimate_desc* d; int rc; bool done; };
+
+int run_batch(x265hip_la* a, Req* const* reqs, int n)
+{
+    std::lock_guard<std::mutex> g(a->mu);
+    XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
+    hipStream_t st = (hipStream_t)x265hip_ctx_stream(a->ctx);
+    const size_t ncu = (size_t)a->ncu;
+    std::vector<int> pinned;
+    x265hip_la_task tasks[kLaBatch];
+    int rc;
+    for (int i = 0; i < n; i++)
+    {
+        const x265hip_la_estimate_desc* d = reqs[i]->d;
+        const bool isB = d->key[2] != d->key[1];
+        int slot[3] = { -1, -1, -1 };
+        const int order[3] = { 1, 0, 2 };      // b first (its intra costs and AQ factors are read), then the references; a picture this batch uses is not evicted for another
+        for (int k : order)
+        {
+            if (k == 2 && !isB) { slot[2] = slot[1]; continue; }
+            if ((rc = ensure_picture(a, st, d->key[k], d->planes[k], k == 1 ? d->invQscale : nullptr, k == 1 ? d->intraCost : nullptr, pinned.data(), (int)pinned.size(), &slot[k]))) return rc;
+            pinned.push_back(slot[k]);
+        }
+        if (slot[0] == slot[1] || (isB && slot[2] == slot[1])) { set_error("la_estimate: the estimated picture is its own reference"); return X265HIP_EARG; }
+        x265hip_la_task& t = tasks[i];
+        t = x265hip_la_task{};
+        t.b = slot[1]; t.p0 = slot[0]; t.p1 = slot[2];      // places in the lowres buffer; p1 == b marks the P estimate
+        t.doSearch[0] = d->doSearch[0] != 0; t.doSearch[1] = isB && d->doSearch[1] != 0; t.mvSlot[0] = 2 * i; t.mvSlot[1] = 2 * i + 1; t.outSlot = i; t.weighted0 = 0;
+        if (d->weightedPlanes)
+        {   // list 0 is searched in the weighted copy LookaheadTLD::weightsAnalyse made (slicetype.cpp:4474); the bidirectional average uses p0 itself
+            XH_HIP(hipMemcpyAsync(a->low + (size_t)(a->maxPics + i) * 4 * a->planeElems, d->weightedPlanes, (size_t)4 * a->planeElems * sizeof(pixel), hipMemcpyHostToDevice, st));
+            t.weighted0 = 1 + a->maxPics + i;
+        }
+        for (int l = 0; l < (isB ? 2 : 1); l++)
+            if (!t.doSearch[l])
+            {   // the list's earlier result (the reference's bDoSearch caching, :4376-4377): MVs and costs are read
+                XH_HIP(hipMemcpyAsync(a->mvs + (size_t)(2 * i + l) * ncu * 2, d->mvs[l], ncu * 2 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+                XH_HIP(hipMemcpyAsync(a->mvCosts + (size_t)(2 * i + l) * ncu, d->mvCosts[l], ncu * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            }
+    }
+    // all estimates of a batch sweep the same way (the caller's workers belong to one lookahead)
+    const int rowsPerSlice = reqs[0]->d->rowsPerSlice;
+    for (int i = 1; i < n; i++) if (reqs[i]->d->rowsPerSlice != rowsPerSlice) { set_error("la_estimate: concurrent estimates with different slice heights"); return X265HIP_EARG; }
+    XH_HIP(hipMemcpyAsync(a->task, tasks, (size_t)n * sizeof(x265hip_la_task), hipMemcpyHostToDevice, st));
+    if ((rc = x265hip_lookahead_cost_batch(st, a->low, a->planeElems, a->stride, a->origin, a->wcu, a->hcu, a->task, n, a->maxPics + kLaBatch, a->intraCost, a->haveInvq ? a->invq : nullptr,
+                                           a->costRow, kLaHalf, rowsPerSlice, a->mvs, a->mvCosts, a->lc, a->rows, a->sums))) return rc;
+    for (int i = 0; i < n; i++)
+    {
+        const x265hip_la_estimate_desc* d = reqs[i]->d;
+        const bool isB = d->key[2] != d->key[1];
+        for (int l = 0; l < (isB ? 2 : 1); l++)
+            if (tasks[i].doSearch[l])
+            {
+                XH_HIP(hipMemcpyAsync(d->mvs[l], a->mvs + (size_t)(2 * i + l) * ncu * 2, ncu * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+                XH_HIP(hipMemcpyAsync(d->mvCosts[l], a->mvCosts + (size_t)(2 * i + l) * ncu, ncu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            }
+        XH_HIP(hipMemcpyAsync(d->lowresCosts, a->lc + (size_t)i * ncu, ncu * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+        XH_HIP(hipMemcpyAsync(d->rowSatds, a->rows + (size_t)i * a->hcu, (size_t)a->hcu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        XH_HIP(hipMemcpyAsync(d->sums, a->sums + (size_t)i * 3, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    }
+    XH_HIP(hipStreamSynchronize(st));
+    a->batches++; a->batched += n;
+    return X265HIP_OK;
+}
+}
+
 extern "C" int x265hip_la_estimate(x265hip_la* a, const x265hip_la_estimate_desc* d)
 {
     if (!a || !d || !d->lowresCosts || !d->rowSatds || !d->sums || !d->mvs[0] || !d->mvCosts[0] || (d->key[2] != d->key[1] && (!d->mvs[1] || !d->mvCosts[1])))
     { set_error("la_estimate: bad arguments"); return X265HIP_EARG; }
-    std::lock_guard<std::mutex> g(a->mu);
-    XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
-    hipStream_t st = (hipStream_t)x265hip_ctx_stream(a->ctx);
-    const bool isB = d->key[2] != d->key[1];
-    const size_t ncu = (size_t)a->ncu;
-    int slot[3] = { -1, -1, -1 }, rc;
-    // b first (its intra costs and AQ factors are read), then the references; a picture already taken is not evicted for the next one
-    const int order[3] = { 1, 0, 2 };
-    int pinned[3], nPinned = 0;
-    for (int k : order)
+    Req r{ d, X265HIP_OK, false };
+    std::unique_lock<std::mutex> lk(a->qmu);
+    a->queue.push_back(&r);
+    while (!r.done)
     {
-        if (k == 2 && !isB) { slot[2] = slot[1]; continue; }
-        if ((rc = ensure_picture(a, st, d->key[k], d->planes[k], k == 1 ? d->invQscale : nullptr, k == 1 ? d->intraCost : nullptr, pinned, nPinned, &slot[k]))) return rc;
-        pinned[nPinned++] = slot[k];
+        if (a->leader) { a->qcv.wait(lk); continue; }
+        // become the leader: everything that is waiting now (this request among it, unless more than a batch was ahead of it) goes up as one launch
+        a->leader = true;
+        Req* batch[kLaBatch];
+        const int n = (int)std::min<size_t>(a->queue.size(), (size_t)kLaBatch);
+        for (int i = 0; i < n; i++) batch[i] = a->queue[i];
+        a->queue.erase(a->queue.begin(), a->queue.begin() + n);
+        lk.unlock();
+        const int rc = run_batch(a, batch, n);
+        lk.lock();
+        for (int i = 0; i < n; i++) { batch[i]->rc = rc; batch[i]->done = true; }      // (an error text belongs to the thread that ran the batch; the code reaches every caller)
+        a->leader = false;
+        a->qcv.notify_all();
     }
-    if (slot[0] == slot[1] || (isB && slot[2] == slot[1])) { set_error("la_estimate: the estimated picture is its own reference"); return X265HIP_EARG; }
-    x265hip_la_task t{};
-    t.b = slot[1]; t.p0 = slot[0]; t.p1 = slot[2];
-    // the batch call addresses pictures by their place in the lowres buffer; p1 == b marks the P estimate
-    t.doSearch[0] = d->doSearch[0] != 0; t.doSearch[1] = isB && d->doSearch[1] != 0; t.mvSlot[0] = 0; t.mvSlot[1] = 1; t.outSlot = 0; t.weighted0 = 0;
-    if (d->weightedPlanes)
-    {   // list 0 is searched in the weighted copy LookaheadTLD::weightsAnalyse made (slicetype.cpp:4474); the bidirectional average uses p0 itself
-        XH_HIP(hipMemcpyAsync(a->low + (size_t)a->maxPics * 4 * a->planeElems, d->weightedPlanes, (size_t)4 * a->planeElems * sizeof(pixel), hipMemcpyHostToDevice, st));
-        t.weighted0 = 1 + a->maxPics;
-    }
-    for (int l = 0; l < (isB ? 2 : 1); l++)
-        if (!t.doSearch[l])
-        {   // the list's earlier result (the reference's bDoSearch caching, :4376-4377): MVs and costs are read
-            XH_HIP(hipMemcpyAsync(a->mvs + (size_t)l * ncu * 2, d->mvs[l], ncu * 2 * sizeof(int16_t), hipMemcpyHostToDevice, st));
-            XH_HIP(hipMemcpyAsync(a->mvCosts + (size_t)l * ncu, d->mvCosts[l], ncu * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        }
-    XH_HIP(hipMemcpyAsync(a->task, &t, sizeof(t), hipMemcpyHostToDevice, st));
-    if ((rc = x265hip_lookahead_cost_batch(st, a->low, a->planeElems, a->stride, a->origin, a->wcu, a->hcu, a->task, 1, a->maxPics + 1, a->intraCost, a->haveInvq ? a->invq : nullptr,
-                                           a->costRow, kLaHalf, d->rowsPerSlice, a->mvs, a->mvCosts, a->lc, a->rows, a->sums))) return rc;
-    for (int l = 0; l < (isB ? 2 : 1); l++)
-        if (t.doSearch[l])
-        {
-            XH_HIP(hipMemcpyAsync(d->mvs[l], a->mvs + (size_t)l * ncu * 2, ncu * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
-            XH_HIP(hipMemcpyAsync(d->mvCosts[l], a->mvCosts + (size_t)l * ncu, ncu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        }
-    XH_HIP(hipMemcpyAsync(d->lowresCosts, a->lc, ncu * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
-    XH_HIP(hipMemcpyAsync(d->rowSatds, a->rows, (size_t)a->hcu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    XH_HIP(hipMemcpyAsync(d->sums, a->sums, 3 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    XH_HIP(hipStreamSynchronize(st));
+    return r.rc;
+}
+extern "C" int x265hip_la_batch_stats(const x265hip_la* a, int64_t* launches, int64_t* estimates)
+{
+    if (!a) return X265HIP_EARG;
+    if (launches) *launches = a->batches;
+    if (estimates) *estimates = a->batched;
     return X265HIP_OK;
 }
