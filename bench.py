@@ -185,7 +185,10 @@ def e2e_fps_leg(frames=8):
            "fps": {k: v["fps"] for k, v in runs.items()}, "same_encoder_cpu_producer_fps": c["fps"],
            "bitstream_identical": all(v["md5"] == c["md5"] and v["bytes"] == c["bytes"] for v in runs.values()), "bytes": c["bytes"],
            "tme": {"gpu_pictures": g["gpu_pictures"], "producer_ms_per_picture": round(1e3 * g["gpu_seconds"] / max(1, g["gpu_pictures"]), 2),
-                   "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"]) / max(1, g["gpu_pictures"]), 2), "adapter_sections_s": g["adapter_sections"]}}
+                   "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"] - g.get("adapter_create_seconds", 0.0)) / max(1, g["gpu_pictures"]), 2),
+                   "adapter_note": "host work around the producer call (qps, collocated neighbours, medians, table conversions), spread over the encoder's ThreadedME workers; creating the producer (%.0f ms, once) not included"
+                                   % (1e3 * g.get("adapter_create_seconds", 0.0)),
+                   "ctus_harvested_by_helper_workers": int(g["adapter_sections"][2])}}
     if both:
         l = runs["la_gpu"]
         out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "device_launches": l.get("la_launches"), "estimates_left_to_the_cpu": l["la_cpu_estimates"],

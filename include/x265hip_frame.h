@@ -171,6 +171,7 @@ typedef struct x265hip_tme_ref {
     const int16_t* lowresMv;                   /* the lookahead's MVs of this (list, distance), x / y per 16x16 block of the picture (Lowres::lowresMvs), or NULL = not estimated / out of range */
 } x265hip_tme_ref;
 #define X265HIP_TME_LAUNCH_PER_STAGE 1         /* every stage of every entry as its own launch over all CTUs (the first implementation; kept as the form the chain kernels are checked against) */
+#define X265HIP_TME_PROFILE 4                  /* x265hip_tme_picture: time its sections (with a stream synchronisation after each) and print the averages when the producer is destroyed */
 #define X265HIP_TME_PACKED_GROUPS 2            /* chain kernels with several PUs per wavefront for the small shapes                              */
 typedef struct x265hip_tme_args {
     int isP, numRef[2], curPOC, temporalMvp, refPOC[2][16];

@@ -9,13 +9,16 @@
  * Preconditions (checked where they can be): one slice per picture; frame threads = 1 or complete reference pictures (the producer takes whole planes; the row-lag
  * clamp of Search::setSearchRange, search.cpp:5017-5018, is not modelled); numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF.
  */
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "x265.h"
 #include "common.h"
@@ -49,7 +52,9 @@ void* g_lib;
 x265hip_ctx* g_ctx;
 x265hip_tme* g_tme;
 int g_useGpu, g_device, g_pictures, g_weighted, g_keepPlanes = 1;
-double g_sec[4];      /* adapter sections: CTU set-up + area qps, the entry walk (qps, collocated neighbours), medians, references + tables */
+double g_sec[4];      /* per encode: [0] job set-up seconds (incl. creating the producer on the first picture), [1] wall seconds up to the producer call (set-up + harvest: qps,
+                         collocated neighbours, medians, table conversions -- spread over the workers), [2] CTUs harvested by workers other than the leader, [3] write-back seconds */
+double g_createSeconds;                     /* creating the producer (context, streams, device buffers) on the first picture */
 double g_gpuSeconds, g_pictureSeconds;      /* inside x265hip_tme_picture; the whole producer call incl. the adapter's harvest and write-back */
 std::mutex g_lock;
 std::map<const Frame*, int> g_done;          /* picture -> POC + 1 whose table is complete */
@@ -138,63 +143,135 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             }
         }
     };
-    struct Picture
+    /* One picture = one job.  The first worker that arrives for a picture sets the job up; every worker that arrives while it runs (ThreadedME's workers are waiting for
+       this picture's records anyway) takes CTUs of the host-side passes -- the harvest before the producer call, the write-back after it -- with its OWN Analysis object,
+       so the per-picture host work is spread over the encoder's ThreadedME workers instead of sitting on one of them. */
+    struct Job
     {
-    static int run_picture(Analysis& an, const CUGeom& ctuGeom, Frame& frame)
-    {
-        const Slice* slice = an.m_slice;
-        const x265_param* p = an.m_param;
-        const int W = slice->m_sps->picWidthInLumaSamples, H = slice->m_sps->picHeightInLumaSamples, ctuSize = p->maxCUSize;
-        const int nCtuX = slice->m_sps->numCuInWidth, nCtuY = slice->m_sps->numCuInHeight, nCtu = nCtuX * nCtuY;
-        if (!g_tme)
-        {
-            if (g_api.ctx_create(g_device, &g_ctx) || g_api.tme_create(g_ctx, W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme))
-            { fprintf(stderr, "x265hip_tme_create: %s\n", g_api.last_error()); return -1; }
-        }
-        const x265hip_tme_step* steps; const int nS = g_api.tme_entries(g_tme, &steps);
-        const int nl = slice->isInterP() ? 1 : 2;
-        for (int l = 0; l < nl; l++)
-            if (slice->m_numRefIdx[l] < 1 || slice->m_numRefIdx[l] > X265HIP_MAX_REF) { fprintf(stderr, "tme_adapter: %d references in list %d (1..%d)\n", slice->m_numRefIdx[l], l, X265HIP_MAX_REF); return -1; }
-        if (p->maxSlices > 1) { fprintf(stderr, "tme_adapter: --slices %d: one slice per picture only\n", p->maxSlices); return -1; }
-        std::vector<int> used;                                         /* the MEData slots of a CTU the schedule writes (and reads) */
-        {
-            std::vector<char> mark(593, 0);
-            for (int k = 0; k < nS; k++) for (int pi = 0; pi < steps[k].numPart; pi++) { const int sl = steps[k].finalIdx + pi * steps[k].puOffset; if (sl >= 0 && sl < 593) mark[sl] = 1; }
-            for (int sl = 0; sl < 593; sl++) if (mark[sl]) used.push_back(sl);
-        }
+        Frame* frame; int poc, nCtu, nCtuX, nCtuY, nS, nl;
+        const x265hip_tme_step* steps;
+        std::vector<int> used;                                     /* the MEData slots of a CTU the schedule writes (and reads) */
+        std::vector<x265hip_tme_temporal> temporal; std::vector<int> entryQp, areaQp; std::vector<int16_t> median;
+        std::vector<x265hip_inter_choice> table; std::vector<std::vector<x265hip_inter_choice>> refTables; std::vector<const MEData*> refSrc;
+        std::vector<std::vector<int16_t>> lowres; size_t nRefTables = 0, nLowres = 0;      /* (the outer vectors only grow: their inner buffers are reused) */
+        std::vector<uint8_t> qpIndex, areaQpIndex;
         x265hip_tme_picture_desc d;
-        memset(&d, 0, sizeof(d));
-        d.isP = slice->isInterP(); d.numRef[0] = slice->m_numRefIdx[0]; d.numRef[1] = nl > 1 ? slice->m_numRefIdx[1] : 0; d.curPOC = slice->m_poc;
-        d.temporalMvp = slice->m_sps->bTemporalMVPEnabled;
-        for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) d.refPOC[l][r] = slice->m_refPOCList[l][r];
-        d.searchRange = p->searchRange; d.searchMethod = p->searchMethod; d.subpelRefine = p->subpelRefine;
-        d.width = W; d.height = H;
-        const PicYuv* fenc = frame.m_fencPic;
-        d.curPlane = fenc->m_picBuf[0]; d.stride = fenc->m_stride; d.origin = fenc->m_picOrg[0] - fenc->m_picBuf[0];
-        d.planeElems = (int64_t)fenc->m_stride * (fenc->m_picHeight + 2 * fenc->m_lumaMarginY);
-        /* per CTU: what findJob sets up before the call (threadedme.cpp:238-246), then the harvest */
-        /* buffers kept across pictures (the call runs under g_lock): fresh 10 MB vectors per picture cost more in page faults than the work on them */
-        static std::vector<x265hip_tme_temporal> temporal; static std::vector<int> entryQp, areaQp; static std::vector<int16_t> median;
-        temporal.resize((size_t)nCtu * nS * 2); entryQp.resize((size_t)nCtu * nS); areaQp.resize((size_t)nCtu * 5); median.assign((size_t)nCtu * 2 * X265HIP_MAX_REF * 3, 0);
-        const Frame* colPic = slice->m_refFrameList[slice->isInterB() && !slice->m_colFromL0Flag][slice->m_colRefIdx];
-        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        for (int c = 0; c < nCtu; c++)
+        std::atomic<int> nextA{0}, doneA{0}, nextB{0}, doneB{0}, failed{0}, helped{0};
+        int phase = 0, users = 0;                                  /* 0 harvest, 1 producer call, 2 write-back, 3 done; workers inside the job (both under g_lock) */
+
+        static Job* create(Analysis& an, Frame& frame)
         {
-            double ts = now();
-            CUData* ctu = frame.m_encData->getPicCTU(c);
-            ctu->m_slice = frame.m_encData->m_slice;
+            const Slice* slice = an.m_slice;
+            const x265_param* p = an.m_param;
+            const int W = slice->m_sps->picWidthInLumaSamples, H = slice->m_sps->picHeightInLumaSamples, ctuSize = p->maxCUSize;
+            if (!g_tme)
+            {
+                const auto t0 = std::chrono::steady_clock::now();
+                if (g_api.ctx_create(g_device, &g_ctx) || g_api.tme_create(g_ctx, W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme))
+                { fprintf(stderr, "x265hip_tme_create: %s\n", g_api.last_error()); return nullptr; }
+                g_createSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            /* the job's arrays are kept from picture to picture: fresh 10 MB vectors per picture cost more in page faults than the work on them */
+            static Job storage;
+            Job* j = &storage;
+            j->nextA = 0; j->doneA = 0; j->nextB = 0; j->doneB = 0; j->failed = 0; j->helped = 0; j->phase = 0; j->users = 0;
+            j->used.clear(); j->refSrc.clear(); j->nRefTables = 0; j->nLowres = 0;
+            j->frame = &frame; j->poc = slice->m_poc;
+            j->nCtuX = slice->m_sps->numCuInWidth; j->nCtuY = slice->m_sps->numCuInHeight; j->nCtu = j->nCtuX * j->nCtuY;
+            j->nS = g_api.tme_entries(g_tme, &j->steps);
+            j->nl = slice->isInterP() ? 1 : 2;
+            const int nCtu = j->nCtu, nS = j->nS, nl = j->nl;
+            for (int l = 0; l < nl; l++)
+                if (slice->m_numRefIdx[l] < 1 || slice->m_numRefIdx[l] > X265HIP_MAX_REF) { fprintf(stderr, "tme_adapter: %d references in list %d (1..%d)\n", slice->m_numRefIdx[l], l, X265HIP_MAX_REF); return nullptr; }
+            if (p->maxSlices > 1) { fprintf(stderr, "tme_adapter: --slices %d: one slice per picture only\n", p->maxSlices); return nullptr; }
+            {
+                std::vector<char> mark(593, 0);
+                for (int k = 0; k < nS; k++) for (int pi = 0; pi < j->steps[k].numPart; pi++) { const int sl = j->steps[k].finalIdx + pi * j->steps[k].puOffset; if (sl >= 0 && sl < 593) mark[sl] = 1; }
+                for (int sl = 0; sl < 593; sl++) if (mark[sl]) j->used.push_back(sl);
+            }
+            x265hip_tme_picture_desc& d = j->d;
+            memset(&d, 0, sizeof(d));
+            d.isP = slice->isInterP(); d.numRef[0] = slice->m_numRefIdx[0]; d.numRef[1] = nl > 1 ? slice->m_numRefIdx[1] : 0; d.curPOC = slice->m_poc;
+            d.temporalMvp = slice->m_sps->bTemporalMVPEnabled;
+            for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) d.refPOC[l][r] = slice->m_refPOCList[l][r];
+            d.searchRange = p->searchRange; d.searchMethod = p->searchMethod; d.subpelRefine = p->subpelRefine;
+            d.flags = getenv("X265TME_PROF") ? X265HIP_TME_PROFILE : 0;
+            d.width = W; d.height = H; d.sourceHeight = p->sourceHeight; d.frameThreads = p->frameNumThreads;
+            const PicYuv* fenc = frame.m_fencPic;
+            d.curPlane = fenc->m_picBuf[0]; d.stride = fenc->m_stride; d.origin = fenc->m_picOrg[0] - fenc->m_picBuf[0];
+            d.planeElems = (int64_t)fenc->m_stride * (fenc->m_picHeight + 2 * fenc->m_lumaMarginY);
+            j->temporal.resize((size_t)nCtu * nS * 2); j->entryQp.resize((size_t)nCtu * nS); j->areaQp.resize((size_t)nCtu * 5); j->median.assign((size_t)nCtu * 2 * X265HIP_MAX_REF * 3, 0);
+            j->table.resize((size_t)nCtu * 593);
+            /* references: planes, the lookahead's MVs; their own tables are converted CTU by CTU in the harvest */
+            d.lowresBlocksX = frame.m_lowres.maxBlocksInRow;
+            for (int l = 0; l < nl; l++)
+                for (int r = 0; r < slice->m_numRefIdx[l]; r++)
+                {
+                    x265hip_tme_host_ref& R = d.refs[l][r];
+                    const MotionReference& mr = slice->m_mref[l][r];
+                    if (mr.isWeighted)
+                    {   /* the frame encoder weights the reference's rows as it releases them to the row encoders (frameencoder.cpp:1029-1036); the producer takes the whole
+                           picture at once: finish the plane now (same values, the later calls find nothing left to do) */
+                        const_cast<MotionReference&>(mr).applyWeight(j->nCtuY - 1, j->nCtuY, j->nCtuY, 0);
+                        g_weighted++;
+                    }
+                    const PicYuv* rec = slice->m_refReconPicList[l][r];
+                    R.mePlane = mr.fpelPlane[0] - d.origin;
+                    R.reconPlane = rec->m_picBuf[0];
+                    const Frame* rf = slice->m_refFrameList[l][r];
+                    R.reconKey = g_keepPlanes ? (uint64_t)rf->m_encodeOrder + 1 : 0;      /* a finished picture: its planes stay on the device for the pictures that reference it */
+                    if (rf->m_encData->m_slice->m_sliceType != I_SLICE)
+                    {   /* only the slots the schedule names are ever read */
+                        if (j->refTables.size() <= j->nRefTables) j->refTables.emplace_back();
+                        j->refTables[j->nRefTables++].resize((size_t)nCtu * 593);
+                        j->refSrc.push_back(rf->m_encData->m_slice->m_ctuMV);
+                    }
+                    const int diffPoc = abs(slice->m_poc - slice->m_refPOCList[l][r]);
+                    if (diffPoc <= p->bframes + 1)
+                    {
+                        const MV* mvs = frame.m_lowres.lowresMvs[l][diffPoc];
+                        if (mvs[0].x != 0x7FFF)
+                        {
+                            const size_t nb = (size_t)frame.m_lowres.maxBlocksInRow * ((H + 15) / 16);
+                            if (j->lowres.size() <= j->nLowres) j->lowres.emplace_back();
+                            std::vector<int16_t>& lm = j->lowres[j->nLowres++];
+                            lm.resize(nb * 2);
+                            for (size_t i = 0; i < nb; i++) { lm[2 * i] = (int16_t)mvs[i].x; lm[2 * i + 1] = (int16_t)mvs[i].y; }
+                        }
+                    }
+                }
+            /* (the vectors above do not move any more: hand their storage to the descriptor) */
+            size_t rt = 0, lw = 0;
+            for (int l = 0; l < nl; l++)
+                for (int r = 0; r < slice->m_numRefIdx[l]; r++)
+                {
+                    const Frame* rf = slice->m_refFrameList[l][r];
+                    if (rf->m_encData->m_slice->m_sliceType != I_SLICE) d.refs[l][r].refTable = j->refTables[rt++].data();
+                    const int diffPoc = abs(slice->m_poc - slice->m_refPOCList[l][r]);
+                    if (diffPoc <= p->bframes + 1 && frame.m_lowres.lowresMvs[l][diffPoc][0].x != 0x7FFF) d.refs[l][r].lowresMv = j->lowres[lw++].data();
+                }
+            return j;
+        }
+
+        /* per CTU, by whichever worker takes it: what findJob sets up before the call (threadedme.cpp:238-246), the qps, the collocated neighbours and medians, and this
+           CTU's part of the table conversions */
+        void harvest(Analysis& an, const CUGeom& ctuGeom, int c)
+        {
+            const Slice* slice = an.m_slice;
+            Frame& fr = *frame;
+            CUData* ctu = fr.m_encData->getPicCTU(c);
+            ctu->m_slice = fr.m_encData->m_slice;
             const int row = c / nCtuX, col = c % nCtuX;
-            frame.m_encData->m_cuStat[c].baseQp = frame.m_encData->m_avgQpRc;
-            ctu->initCTU(frame, c, slice->m_sliceQp, row == 0, row == nCtuY - 1, row == nCtuY - 1 && col == nCtuX - 1);     /* one slice */
+            fr.m_encData->m_cuStat[c].baseQp = fr.m_encData->m_avgQpRc;
+            ctu->initCTU(fr, c, slice->m_sliceQp, row == 0, row == nCtuY - 1, row == nCtuY - 1 && col == nCtuX - 1);     /* one slice */
             const int rawBase = slice->m_pps->bUseDQP ? an.calculateQpforCuSize(*ctu, ctuGeom) : slice->m_sliceQp;
             areaQp[c * 5] = rawBase;
             for (int sub = 0; sub < 4; sub++)
                 areaQp[c * 5 + 1 + sub] = slice->m_pps->bUseDQP ? an.calculateQpforCuSize(*ctu, *(&ctuGeom + ctuGeom.childOffset + sub)) : slice->m_sliceQp;
-            g_sec[0] += now() - ts; ts = now();
-            Harvest h{ an, slice, frame, steps, nS, temporal, entryQp, c, 0 };
+            Harvest h{ an, slice, fr, steps, nS, temporal, entryQp, c, 0 };
             h.walk(*ctu, ctuGeom, x265_clip3(QP_MIN, QP_MAX_SPEC, rawBase));
-            g_sec[1] += now() - ts; ts = now();
-            if (h.k != nS) { fprintf(stderr, "schedule mismatch: %d of %d entries\n", h.k, nS); return -1; }
+            if (h.k != nS) { fprintf(stderr, "schedule mismatch: %d of %d entries\n", h.k, nS); failed = 1; return; }
+            const Frame* colPic = slice->m_refFrameList[slice->isInterB() && !slice->m_colFromL0Flag][slice->m_colRefIdx];
             const CUData* colCU = colPic->m_encData->getPicCTU(c);
             for (int l = 0; l < nl; l++)
                 for (int r = 0; r < slice->m_numRefIdx[l]; r++)
@@ -202,88 +279,116 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
                     MV m;
                     if (ctu->getMedianColMV(colCU, colPic, l, r, m)) { int16_t* o = &median[(((size_t)c * 2 + l) * X265HIP_MAX_REF + r) * 3]; o[0] = 1; o[1] = (int16_t)m.x; o[2] = (int16_t)m.y; }
                 }
-            g_sec[2] += now() - ts;
+            const MEData* dst = fr.m_encData->m_slice->m_ctuMV;
+            for (int sl : used) to_choice(dst[(size_t)c * 593 + sl], table[(size_t)c * 593 + sl]);
+            for (size_t t = 0; t < nRefTables; t++)
+                for (int sl : used) to_choice(refSrc[t][(size_t)c * 593 + sl], refTables[t][(size_t)c * 593 + sl]);
         }
-        const double tRefs = now();
-        /* the distinct qps */
-        std::vector<int> qps;
-        auto qidx = [&](int qp) { if (qp > QP_MAX_SPEC) { fprintf(stderr, "qp %d above 51: not handled\n", qp); exit(3); }
-                                  for (size_t i = 0; i < qps.size(); i++) if (qps[i] == qp) return (int)i; qps.push_back(qp); return (int)qps.size() - 1; };
-        static std::vector<uint8_t> qpIndex, areaQpIndex;
-        qpIndex.resize(entryQp.size()); areaQpIndex.resize(areaQp.size());
-        for (size_t i = 0; i < entryQp.size(); i++) qpIndex[i] = (uint8_t)qidx(entryQp[i]);
-        for (size_t i = 0; i < areaQp.size(); i++) areaQpIndex[i] = (uint8_t)qidx(areaQp[i]);
-        if (qps.size() > 64) { fprintf(stderr, "more than 64 distinct qps\n"); return -1; }
-        d.nQp = (int)qps.size();
-        for (int i = 0; i < d.nQp; i++) d.qps[i] = qps[i];
-        d.qpIndex = qpIndex.data(); d.areaQpIndex = areaQpIndex.data(); d.temporal = temporal.data(); d.median = median.data();
-        /* references: planes, their own tables, the lookahead's MVs */
-        static std::vector<std::vector<x265hip_inter_choice>> refTables(2 * X265HIP_MAX_REF);
-        static std::vector<std::vector<int16_t>> lowres(2 * X265HIP_MAX_REF);
-        int nRefTables = 0, nLowres = 0;
-        d.lowresBlocksX = frame.m_lowres.maxBlocksInRow;
-        for (int l = 0; l < nl; l++)
-            for (int r = 0; r < slice->m_numRefIdx[l]; r++)
-            {
-                x265hip_tme_host_ref& R = d.refs[l][r];
-                const MotionReference& mr = slice->m_mref[l][r];
-                if (mr.isWeighted)
-                {   /* the frame encoder weights the reference's rows as it releases them to the row encoders (frameencoder.cpp:1029-1036); the producer takes the whole
-                       picture at once: finish the plane now (same values, the later calls find nothing left to do) */
-                    const_cast<MotionReference&>(mr).applyWeight(nCtuY - 1, nCtuY, nCtuY, 0);
-                    g_weighted++;
-                }
-                const PicYuv* rec = slice->m_refReconPicList[l][r];
-                R.mePlane = mr.fpelPlane[0] - d.origin;
-                R.reconPlane = rec->m_picBuf[0];
-                const Frame* rf = slice->m_refFrameList[l][r];
-                R.reconKey = g_keepPlanes ? (uint64_t)rf->m_encodeOrder + 1 : 0;      /* a finished picture: its planes stay on the device for the pictures that reference it */
-                if (rf->m_encData->m_slice->m_sliceType != I_SLICE)
-                {   /* only the slots the schedule names are ever read */
-                    std::vector<x265hip_inter_choice>& rt = refTables[nRefTables++];
-                    rt.resize((size_t)nCtu * 593);
-                    const MEData* src = rf->m_encData->m_slice->m_ctuMV;
-                    x265hip_inter_choice* o = rt.data();
-                    for (int c = 0; c < nCtu; c++) for (int sl : used) to_choice(src[(size_t)c * 593 + sl], o[(size_t)c * 593 + sl]);
-                    R.refTable = o;
-                }
-                const int diffPoc = abs(slice->m_poc - slice->m_refPOCList[l][r]);
-                if (diffPoc <= p->bframes + 1)
-                {
-                    const MV* mvs = frame.m_lowres.lowresMvs[l][diffPoc];
-                    if (mvs[0].x != 0x7FFF)
-                    {
-                        const size_t nb = (size_t)frame.m_lowres.maxBlocksInRow * ((H + 15) / 16);
-                        std::vector<int16_t>& lm = lowres[nLowres++];
-                        lm.resize(nb * 2);
-                        for (size_t i = 0; i < nb; i++) { lm[2 * i] = (int16_t)mvs[i].x; lm[2 * i + 1] = (int16_t)mvs[i].y; }
-                        R.lowresMv = lm.data();
-                    }
-                }
-            }
-        static std::vector<x265hip_inter_choice> table;
-        table.resize((size_t)nCtu * 593);
-        MEData* dst = frame.m_encData->m_slice->m_ctuMV;
-        for (int c = 0; c < nCtu; c++) for (int sl : used) to_choice(dst[(size_t)c * 593 + sl], table[(size_t)c * 593 + sl]);
-        d.table = table.data();
-        g_sec[3] += now() - tRefs;
-        const auto t0 = std::chrono::steady_clock::now();
-        { const int rc = g_api.tme_picture(g_tme, &d); if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", slice->m_poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; } }
-        g_gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        for (int c = 0; c < nCtu; c++) for (int sl : used) from_choice(table[(size_t)c * 593 + sl], dst[(size_t)c * 593 + sl]);
-        g_pictures++;
-        return 0;
-    }
+
+        int call()
+        {   /* the distinct qps, then the producer */
+            std::vector<int> qps;
+            auto qidx = [&](int qp) { if (qp > QP_MAX_SPEC) { fprintf(stderr, "qp %d above 51: not handled\n", qp); exit(3); }
+                                      for (size_t i = 0; i < qps.size(); i++) if (qps[i] == qp) return (int)i; qps.push_back(qp); return (int)qps.size() - 1; };
+            qpIndex.resize(entryQp.size()); areaQpIndex.resize(areaQp.size());
+            for (size_t i = 0; i < entryQp.size(); i++) qpIndex[i] = (uint8_t)qidx(entryQp[i]);
+            for (size_t i = 0; i < areaQp.size(); i++) areaQpIndex[i] = (uint8_t)qidx(areaQp[i]);
+            if (qps.size() > 64) { fprintf(stderr, "more than 64 distinct qps\n"); return -1; }
+            d.nQp = (int)qps.size();
+            for (int i = 0; i < d.nQp; i++) d.qps[i] = qps[i];
+            d.qpIndex = qpIndex.data(); d.areaQpIndex = areaQpIndex.data(); d.temporal = temporal.data(); d.median = median.data(); d.table = table.data();
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = g_api.tme_picture(g_tme, &d);
+            if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; }
+            g_gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            return 0;
+        }
+
+        void writeback(int c)
+        {
+            MEData* dst = frame->m_encData->m_slice->m_ctuMV;
+            for (int sl : used) from_choice(table[(size_t)c * 593 + sl], dst[(size_t)c * 593 + sl]);
+        }
     };
-    std::lock_guard<std::mutex> guard(g_lock);
+    static Job* s_job = nullptr;
+    static std::condition_variable s_cv;
+
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::unique_lock<std::mutex> lk(g_lock);
     const int poc = ctu.m_slice->m_poc;
-    auto it = g_done.find(&frame);
-    if (it != g_done.end() && it->second == poc + 1) return;              /* this picture's table is there already */
-    m_slice = ctu.m_slice; m_frame = &frame; m_param = m_frame->m_param;  /* as the encoder's body starts (analysis.cpp:250-252) */
-    const auto tp0 = std::chrono::steady_clock::now();
-    if (Picture::run_picture(*this, cuGeom, frame)) exit(3);
-    g_pictureSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count();
-    g_done[&frame] = poc + 1;
+    m_slice = ctu.m_slice; m_frame = &frame; m_param = m_frame->m_param;      /* as the encoder's body starts (analysis.cpp:250-252) */
+    bool leader = false;
+    const double tStart = now();
+    for (;;)
+    {
+        auto it = g_done.find(&frame);
+        if (it != g_done.end() && it->second == poc + 1) return;              /* this picture's table is there already */
+        if (s_job && s_job->frame == &frame && s_job->poc == poc) break;      /* the picture's job is running: help */
+        if (!s_job)
+        {
+            s_job = Job::create(*this, frame);
+            if (!s_job) exit(3);
+            g_sec[0] += now() - tStart;                                       /* job set-up (the first picture also creates the producer: context, streams, code objects) */
+            leader = true;
+            break;
+        }
+        s_cv.wait(lk);                                                        /* another picture's job is still running (frame threads) */
+    }
+    Job* job = s_job;
+    job->users++;
+    lk.unlock();
+    for (;;)
+    {   /* pass A */
+        const int c = job->nextA.fetch_add(1);
+        if (c >= job->nCtu) break;
+        job->harvest(*this, cuGeom, c);
+        job->doneA.fetch_add(1);
+        if (!leader) job->helped.fetch_add(1);
+    }
+    if (leader)
+    {
+        while (job->doneA.load() < job->nCtu) std::this_thread::yield();      /* the helpers' last CTUs */
+        const double tCall = now();
+        g_sec[1] += tCall - tStart;                                           /* wall time up to the producer call: set-up + harvest (qps, collocated neighbours, medians, table conversions) */
+        g_sec[2] += job->helped.load();                                       /* CTUs other workers harvested */
+        if (job->failed.load() || job->call()) exit(3);
+        g_sec[3] -= now();                                                    /* write-back wall time, closed below */
+        lk.lock(); job->phase = 2; lk.unlock();
+        s_cv.notify_all();
+    }
+    else
+    {
+        lk.lock();
+        while (job->phase < 2) s_cv.wait(lk);
+        lk.unlock();
+    }
+    for (;;)
+    {   /* pass B */
+        const int c = job->nextB.fetch_add(1);
+        if (c >= job->nCtu) break;
+        job->writeback(c);
+        job->doneB.fetch_add(1);
+    }
+    lk.lock();
+    if (leader)
+    {
+        while (job->doneB.load() < job->nCtu) { lk.unlock(); std::this_thread::yield(); lk.lock(); }
+        g_sec[3] += now();
+        g_done[&frame] = poc + 1;
+        g_pictures++;
+        g_pictureSeconds += now() - tStart;
+        job->phase = 3;
+        s_cv.notify_all();
+        while (job->users > 1) s_cv.wait(lk);                                 /* every helper has left the job */
+        s_job = nullptr;
+        s_cv.notify_all();
+    }
+    else
+    {
+        while (job->phase < 3) s_cv.wait(lk);
+        job->users--;
+        s_cv.notify_all();
+    }
 }
 }
 
@@ -314,6 +419,6 @@ extern "C" void x265hip_tme_adapter_close(void)
 }
 extern "C" void x265hip_tme_adapter_get_stats(x265hip_tme_adapter_stats* o)
 {
-    o->pictures = g_pictures; o->weightedRefs = g_weighted; o->producerSeconds = g_gpuSeconds; o->adapterSeconds = g_pictureSeconds;
+    o->pictures = g_pictures; o->weightedRefs = g_weighted; o->producerSeconds = g_gpuSeconds; o->adapterSeconds = g_pictureSeconds; o->createSeconds = g_createSeconds;
     for (int i = 0; i < 4; i++) o->sections[i] = g_sec[i];
 }

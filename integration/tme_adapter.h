@@ -27,7 +27,9 @@ typedef struct x265hip_tme_adapter_stats
     int pictures, weightedRefs;
     double producerSeconds;        /* inside x265hip_tme_picture                                                        */
     double adapterSeconds;         /* the whole per-picture call: harvest + producer + write-back                       */
-    double sections[4];            /* CTU set-up + area qps; entry walk (qps, collocated neighbours); medians; references + tables */
+    double createSeconds;          /* creating the producer, once (inside adapterSeconds and sections[0..1])                */
+    double sections[4];            /* [0] job set-up, [1] wall time up to the producer call (set-up + harvest, spread over the ThreadedME workers), [2] CTUs harvested by workers
+                                      other than the one that opened the job, [3] write-back */
 } x265hip_tme_adapter_stats;
 void x265hip_tme_adapter_get_stats(x265hip_tme_adapter_stats* out);
 #ifdef __cplusplus

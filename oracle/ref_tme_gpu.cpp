@@ -115,7 +115,7 @@ int main(int argc, char** argv)
                  useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.launches, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds);
     }
 #endif
-    printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
-           la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.producerSeconds, s.adapterSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
+    printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
+           la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.producerSeconds, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
     return 0;
 }

@@ -4,6 +4,6 @@
 W=${1:-1280}; H=${2:-704}; F=${3:-16}; P=${4:-medium}; shift 4
 lib=$(python -c "import x265hip; print(x265hip.lib_path(8))")
 for prod in 0 1 1; do
-  X265HIP_TME_PROF=1 X265TMEGPU=$prod timeout -k 10 600 oracle/_ref/x265tmegpu_8 $lib $W $H $F $P /tmp/e2e_$prod.hevc "$@" 2>&1 | grep -E "^x265hip_tme:|^\{" 
+  X265TME_PROF=1 X265TMEGPU=$prod timeout -k 10 600 oracle/_ref/x265tmegpu_8 $lib $W $H $F $P /tmp/e2e_$prod.hevc "$@" 2>&1 | grep -E "^x265hip_tme:|^\{" 
 done
 md5sum /tmp/e2e_0.hevc /tmp/e2e_1.hevc

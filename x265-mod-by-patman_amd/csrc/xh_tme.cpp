@@ -154,7 +154,6 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
     if (n <= 0) { set_error("tme_create: bad CTU / CU sizes"); return X265HIP_EARG; }
     x265hip_tme* t = new (std::nothrow) x265hip_tme();
     if (!t) return X265HIP_EARG;
-    t->prof = xh_experiment("X265HIP_TME_PROF") != nullptr;
     for (int q = 0; q < 64; q++) t->rowQp[q] = -1;
     t->ctx = ctx; t->width = width; t->height = height; t->ctu = ctuSize; t->nCtuX = (width + ctuSize - 1) / ctuSize; t->nCtu = t->nCtuX * ((height + ctuSize - 1) / ctuSize);
     t->steps.resize(n);
@@ -209,6 +208,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     if (d->width != t->width || d->height != t->height) { set_error("tme_picture: %dx%d picture on a %dx%d producer", d->width, d->height, t->width, t->height); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(x265hip_ctx_device(t->ctx)));      // the caller may be any thread of the encoder's pool (a new thread starts on device 0)
     hipStream_t st = (hipStream_t)x265hip_ctx_stream(t->ctx);
+    t->prof = (d->flags & X265HIP_TME_PROFILE) != 0;
     const int refLag = d->frameThreads > 1 ? d->searchRange : (d->sourceHeight > 0 ? d->sourceHeight : d->height);
     const int64_t elems = d->planeElems;
     int rc;
