@@ -106,7 +106,18 @@ def tme_producer_leg(depth):
             used = int((table["ref"][:, 0] >= 0).sum())
             assert used > 0, "the producer wrote no record"
             ms = sorted(times[1:])[len(times[1:]) // 2] * 1e3                                   # the first picture pays for streams and code objects
-            out["presets"][name] = {"ms": round(ms, 2), "pictures_per_s": round(1e3 / ms, 1), "entries_per_ctu": prod.entries, "records_written": used,
+            counters = {}
+            cpath = os.path.join(ROOT, "profiles", "r03_tme_%s_counters.json" % name)
+            if os.path.exists(cpath):
+                try:
+                    cj = json.load(open(cpath))
+                    counters = {"source": "profiles/r03_tme_%s_counters.json (%s)" % (name, cj.get("_source", "")),
+                                "bound": "valu issue, 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instr/s; the chain kernels are bound by the serial depth of one PU chain (few strands per picture), not by issue or bandwidth",
+                                "kernels": {k: {f: v[f] for f in ("avg_us", "calls", "valu_insts", "valu_frac_of_issue_peak", "hbm_read_MB", "hbm_write_MB") if f in v}
+                                            for k, v in cj["kernels"].items() if k.startswith("tme_chain_kernel") or k.startswith("diamond") or k.startswith("subpel")}}
+                except Exception:
+                    counters = {}
+            out["presets"][name] = {"ms": round(ms, 2), "pictures_per_s": round(1e3 / ms, 1), "entries_per_ctu": prod.entries, "records_written": used, "roofline_valu": counters or None,
                                     "search": {1: "hex", 3: "star"}[method], "subme": subme, "rect": rect, "amp": amp}
             # the same with the caller's long-lived buffers page-locked once (x265hip_host_register: PicYuv planes and FrameData tables live as long as the encoder)
             pinned = [cur, ref, table]
