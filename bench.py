@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--inner", type=int, default=5, help="passes over the resident batch per step (a step of the driver's --steps 20 then lasts long enough for the whole timed region to be >= 0.5 s)")
     ap.add_argument("--splits", type=int, default=2, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
+    ap.add_argument("--band-rows", type=int, default=0, help="band-major schedule: bands of this many CTU rows go through all levels + TQ before the stream takes the next band (x265hip_batch_desc.bandRows); 0 = sub-batches of whole pictures")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
     ap.add_argument("--lookahead", action="store_true", help="also time the lookahead frame-cost batch (lowres init, intra estimate, estimateFrameCost of a 32-picture window); reported under \"lookahead\", not part of value")
@@ -805,7 +806,7 @@ def main():
     # torch is here for the process group (barrier, max over ranks) and the device-wide synchronisation around the timed region.
     lib = x265hip.HipLib(depth, fill_table=False).lib
     pipe = HostBatch(lib, depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, margin=MARGIN,
-                     recon=args.recon, use_planes=not args.no_planes, refs=args.refs, rect=args.rect, streams=args.splits, device=local_rank)
+                     recon=args.recon, use_planes=not args.no_planes, refs=args.refs, rect=args.rect, streams=args.splits, device=local_rank, band_rows=args.band_rows)
     pipe.cost_row_host = mvcost_row(depth, args.qp, 1 << 15)
     pipe.upload([p[:1 + args.refs] for p in pairs])                      # inputs are resident in HBM before the timed region
     assert np.array_equal(pipe.device_plane(1, 0), pairs[0][1].reshape(-1)), "the device's border extension differs from the host-padded plane"
@@ -859,7 +860,7 @@ def main():
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames * args.inner,
                        "step": "%d passes of the hot path over a resident batch of %d frame pairs" % (args.inner, args.frames), "host": "C++ (x265hip_batch_step, csrc/xh_ctx.cpp)",
-                       "streams": "%d sub-batches of whole pictures on their own streams" % args.splits if args.splits > 1 else "one stream",
+                       "streams": ("bands of %d CTU rows through all levels, round-robin on %d streams" % (args.band_rows, args.splits)) if args.band_rows > 0 else ("%d sub-batches of whole pictures on their own streams" % args.splits if args.splits > 1 else "one stream"),
                        "ctu": 64, "pus_per_ctu": 425 if args.rect else 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": args.refs, "qp": args.qp,
                        "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": "stage by stage per sub-batch; per-stage events on every 4th step (sub-batch 0)", "sharding": "independent frames per GPU, no collectives"},
             "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "strictly the longest average launch group of the step" + ("; a launch covers one of %d sub-batches, stages of different sub-batches run concurrently (their times do not add up to ms_per_step)" % args.splits if args.splits > 1 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -52,6 +52,9 @@ typedef struct x265hip_batch_desc
                                by its own CU's 2Nx2N result in the same reference                                                       */
     int streams;            /* 1..8 (0 = 1): the batch is cut into this many sub-batches of whole pictures, each stepped on its own stream (pictures are independent,
                                the levels of one picture are not); x265hip_batch_step stays ordered on the context's stream               */
+    int bandRows;           /* 0: sub-batches are whole pictures.  > 0: band-major -- the phase planes of the whole batch first, then bands of this many CTU rows, each taken
+                               through all levels and the TQ stage before its stream takes the next band (bands dealt round-robin to the streams): the planes under a band
+                               are re-read while they are still in the last-level cache                                                   */
 } x265hip_batch_desc;
 
 /* Pure host code (no GPU needed): the task lists x265hip_batch_create uploads.  level = 64, 32, 16 or 8.  Task k of a level is PU

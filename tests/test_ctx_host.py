@@ -11,7 +11,7 @@ from x265hip_pkg.pipeline import pyramid_tasks, LEVELS
 
 
 class Desc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes", "refs", "rect", "streams")]
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes", "refs", "rect", "streams", "bandRows")]
 
 
 @pytest.mark.parametrize("depth", [8, 10])

@@ -33,7 +33,7 @@ def pairs_for(W, H, depth, F, refs, seed0=300):
 
 
 def make(depth, W, H, F, **kw):
-    lib = C.CDLL(x265hip.lib_path(depth))
+    lib = x265hip.HipLib(depth, fill_table=False).lib          # (maps torch's HIP runtime before the library: the Python plumbing of the same step runs in this process too)
     return HostBatch(lib, depth, W, H, F, **kw)
 
 
@@ -61,8 +61,8 @@ def test_streams_do_not_change_the_bytes_and_python_plumbing_agrees(depth):
     W, H, F, qp, merange, method, subme = 192, 128, 5, 30, 20, 3, 3
     pairs = pairs_for(W, H, depth, F, 2)
     ref_out = None
-    for streams in (1, 2, 3, 5):
-        hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, refs=2, rect=True, streams=streams)
+    for streams, band in ((1, 0), (2, 0), (3, 0), (5, 0), (1, 1), (2, 3), (4, 1), (3, 2)):        # band > 0: band-major, bands of that many CTU rows (they may span pictures)
+        hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, refs=2, rect=True, streams=streams, band_rows=band)
         try:
             hb.upload(pairs)
             hb.step(); hb.step(); hb.sync()                     # twice: a second pass over the resident planes gives the same bytes
@@ -75,7 +75,7 @@ def test_streams_do_not_change_the_bytes_and_python_plumbing_agrees(depth):
         if ref_out is None:
             ref_out = out
         else:
-            assert out == ref_out, "%d streams change the results" % streams
+            assert out == ref_out, "%d streams / bands of %d rows change the results" % (streams, band)
     pipe = FramePipeline(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, cost_row=mvcost_row(depth, qp, 1 << 15), refs=2)
     pipe.upload(pairs); pipe.step(); pipe.torch.cuda.synchronize()
     k = 0

@@ -2,6 +2,7 @@
 // lists, one step = phase planes -> ME 64 / 32 / 16 / 8 -> TQ.  Plain HIP runtime calls around the batch entry points of x265hip_frame.h.
 #include "xh_common.h"
 #include "../../include/x265hip_ctx.h"
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -26,7 +27,7 @@ bool desc_ok(const x265hip_batch_desc* d)
 {
     return d && d->width >= CTU && d->height >= CTU && d->width <= X265HIP_MAX_PIC_DIM && d->height <= X265HIP_MAX_PIC_DIM && d->width % CTU == 0 && d->height % CTU == 0 && d->frames >= 1 && d->margin >= CTU + 16 + 8 &&
            d->margin % 4 == 0 && d->qp >= 0 && d->qp <= 51 && d->merange >= 1 && d->subme >= 0 && d->subme <= 7 && d->tuLog2 >= 2 && d->tuLog2 <= 5 &&
-           d->refs >= 0 && d->refs <= X265HIP_MAX_REF && d->streams >= 0 && d->streams <= 8 && (d->refs <= 1 || d->usePlanes);
+           d->refs >= 0 && d->refs <= X265HIP_MAX_REF && d->streams >= 0 && d->streams <= 8 && d->bandRows >= 0 && (d->refs <= 1 || d->usePlanes);
 }
 int level_index(int level) { for (int i = 0; i < 4; i++) if (kLevels[i] == level) return i; return -1; }
 int64_t stride_of(const x265hip_batch_desc* d) { return d->width + 2 * d->margin; }
@@ -196,7 +197,7 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
     if (!b) { set_error("batch_create: out of host memory"); return X265HIP_EARG; }
     b->ctx = ctx; b->d = *d; b->stride = stride_of(d); b->plane = plane_of(d);
     b->refs = d->refs > 1 ? d->refs : 1;
-    b->nsub = d->streams > 1 ? (d->streams < d->frames ? d->streams : d->frames) : 1;
+    b->nsub = d->streams > 1 ? ((d->bandRows > 0 || d->streams < d->frames) ? d->streams : d->frames) : 1;
     b->sub[0] = ctx->stream;
     const size_t elems = (size_t)b->plane * d->frames;
     int rc = X265HIP_OK;
@@ -295,21 +296,40 @@ extern "C" int x265hip_batch_upload_plane(x265hip_batch* b, int which, int frame
 }
 
 namespace {
-// one sub-batch (pictures f0 .. f1 - 1) on stream st; ev != nullptr: events around every stage (2 per stage)
-int step_range(x265hip_batch* b, int f0, int f1, hipStream_t st, hipEvent_t* ev)
+// the phase planes of pictures f0 .. f1 - 1 (every reference)
+int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
 {
     const x265hip_batch_desc& d = b->d;
     const int64_t planeElems = b->plane * d.frames;                  // the 16 phase-plane slots are planeElems apart; a sub-batch addresses its pictures inside them
-    const int nf = f1 - f0, rowsPerPic = d.height + 2 * d.margin;
+    const int rowsPerPic = d.height + 2 * d.margin;
+    for (int r = 0; r < b->refs; r++)
+    {
+        const int rc = x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems);
+        if (rc != X265HIP_OK) return rc;
+    }
+    return X265HIP_OK;
+}
+
+// One sub-batch on stream st: the CTU rows g0 .. g1 - 1 of the batch, counted through the pictures (global row g = picture * ctuRows + row).  Tasks of every
+// shape are laid out picture-major, then raster: a range of global CTU rows is a contiguous range of every task list.  withPlanes: the range is whole pictures and
+// their phase planes are made first; ev != nullptr: events around every stage (2 per stage)
+int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev)
+{
+    const x265hip_batch_desc& d = b->d;
+    const int64_t planeElems = b->plane * d.frames;
+    const int ctuRows = d.height / CTU;
     const bool up = d.usePlanes != 0;
     int rc, stage = 0;
     auto mark = [&](int end) -> int { if (ev) XH_HIP(hipEventRecord(ev[2 * stage + end], st)); if (end) stage++; return X265HIP_OK; };
     if (up)
     {
-        if ((rc = mark(0))) return rc;
-        for (int r = 0; r < b->refs; r++)
-            if ((rc = x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, nf * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems)) != X265HIP_OK) return rc;
-        if ((rc = mark(1))) return rc;
+        if (withPlanes)
+        {
+            if ((rc = mark(0))) return rc;
+            if ((rc = planes_range(b, g0 / ctuRows, g1 / ctuRows, st)) != X265HIP_OK) return rc;
+            if ((rc = mark(1))) return rc;
+        }
+        else stage++;                                    // (band-major: the planes of the whole batch were made, and timed, before the bands)
     }
     // one task list searched in every reference (each with its own parent chain), then the per-PU choice (Search::puMotionEstimation's tail, search.cpp:258-556)
     auto search = [&](int w, int h, const x265hip_me_task* tasks, int first, int n, x265hip_me_result* const* res, x265hip_me_result* const* parent, x265hip_inter_choice* choice) -> int
@@ -332,11 +352,11 @@ int step_range(x265hip_batch* b, int f0, int f1, hipStream_t st, hipEvent_t* ev)
     };
     for (int i = 0; i < 4; i++)
     {
-        const int lv = kLevels[i], per = (d.width / lv) * (d.height / lv);
+        const int lv = kLevels[i], per = (d.width / lv) * (CTU / lv);               // PUs of this level per CTU row
         x265hip_me_result* res[X265HIP_MAX_REF]; x265hip_me_result* par[X265HIP_MAX_REF];
         for (int r = 0; r < b->refs; r++) { res[r] = b->results[r][i]; par[r] = i ? b->results[r][i - 1] : nullptr; }
         if ((rc = mark(0))) return rc;
-        if ((rc = search(lv, lv, b->tasks[i], f0 * per, nf * per, res, i ? par : nullptr, b->choice[i]))) return rc;
+        if ((rc = search(lv, lv, b->tasks[i], g0 * per, (g1 - g0) * per, res, i ? par : nullptr, b->choice[i]))) return rc;
         if ((rc = mark(1))) return rc;
         if (d.rect)
         {
@@ -344,15 +364,15 @@ int step_range(x265hip_batch* b, int f0, int f1, hipStream_t st, hipEvent_t* ev)
             for (int k = 2 * i; k < 2 * i + 2; k++)
             {
                 int w, h; rect_shape(k, w, h);
-                const int rper = (d.width / w) * (d.height / h);
+                const int rper = (d.width / w) * (CTU / h);
                 x265hip_me_result* rres[X265HIP_MAX_REF];
                 for (int r = 0; r < b->refs; r++) rres[r] = b->rresults[r][k];
-                if ((rc = search(w, h, b->rtasks[k], f0 * rper, nf * rper, rres, res, b->rchoice[k]))) return rc;      // seeded by the CU's own 2Nx2N result in the same reference
+                if ((rc = search(w, h, b->rtasks[k], g0 * rper, (g1 - g0) * rper, rres, res, b->rchoice[k]))) return rc;      // seeded by the CU's own 2Nx2N result in the same reference
             }
             if ((rc = mark(1))) return rc;
         }
     }
-    const int n = 1 << d.tuLog2, tper = (d.width / n) * (d.height / n), t0 = f0 * tper, nt = nf * tper, mi = level_index(b->mvLevel);
+    const int n = 1 << d.tuLog2, tper = (d.width / n) * (CTU / n), t0 = g0 * tper, nt = (g1 - g0) * tper, mi = level_index(b->mvLevel);
     if ((rc = mark(0))) return rc;
     for (int r = 0; r < b->refs; r++)
     {   // one launch per reference plane: every TU is compensated from the reference its PU chose
@@ -371,7 +391,7 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
 {
     if (!b) { set_error("batch_step: null batch"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
-    const int F = b->d.frames, S = b->nsub;
+    const int F = b->d.frames, S = b->nsub, ctuRows = b->d.height / CTU, G = F * ctuRows, band = b->d.bandRows;
     hipEvent_t* ev = nullptr;
     if (b->timing)
     {   // the next event set (the sets of the steps since the last read_timing; beyond kTimingSets the oldest are overwritten)
@@ -380,16 +400,40 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
         ev = b->evStage.data() + set * per;
         b->timedSteps++;
     }
-    if (S == 1) return step_range(b, 0, F, b->sub[0], ev);
-    // Independent pictures: the levels of one picture depend on each other (a level's predictor is its parent CU's MV), pictures do not.  Sub-batch s runs on its own
-    // stream, so the LDS-bound 64x64 search of one runs beside the latency-bound 16x16 / 8x8 searches of another.  Everything is ordered after the work already queued
-    // on the context's stream and joined back into it.
-    XH_HIP(hipEventRecord(b->evFork, b->sub[0]));
-    for (int s = 0; s < S; s++)
-    {
-        if (s) XH_HIP(hipStreamWaitEvent(b->sub[s], b->evFork, 0));
-        const int rc = step_range(b, F * s / S, F * (s + 1) / S, b->sub[s], s == 0 ? ev : nullptr);
-        if (rc != X265HIP_OK) return rc;
+    if (S == 1 && band <= 0) return step_range(b, 0, G, true, b->sub[0], ev);
+    int rc;
+    if (band > 0)
+    {   // Band-major: the phase planes of the whole batch first, then bands of CTU rows, each through ALL levels before the stream takes its next band -- the 16 phase
+        // planes under a band (tens of MB) are read by four levels and the TQ stage back to back instead of once per level-wide pass over the whole batch (GBs), so the
+        // re-reads find them in the last-level cache.  Bands are independent of each other (a level's predictor is its parent CU's MV, inside the band); they are dealt
+        // round-robin to the streams.
+        if (b->d.usePlanes)
+        {
+            if (ev) XH_HIP(hipEventRecord(ev[0], b->sub[0]));
+            if ((rc = planes_range(b, 0, F, b->sub[0])) != X265HIP_OK) return rc;
+            if (ev) XH_HIP(hipEventRecord(ev[1], b->sub[0]));
+        }
+        XH_HIP(hipEventRecord(b->evFork, b->sub[0]));
+        for (int s = 1; s < S; s++) XH_HIP(hipStreamWaitEvent(b->sub[s], b->evFork, 0));
+        int k = 0;
+        for (int g0 = 0; g0 < G; g0 += band, k++)
+        {
+            const int s = k % S;
+            // (the stage events bracket the first band of stream 0; its planes slot holds the whole-batch launch above)
+            // the stage events bracket the first band (stream 0); its "planes" pair was recorded around the whole-batch launch above, so the band records from stage 1 on
+            if ((rc = step_range(b, g0, std::min(G, g0 + band), false, b->sub[s], (ev && k == 0) ? ev : nullptr)) != X265HIP_OK) return rc;
+        }
+    }
+    else
+    {   // Independent pictures: the levels of one picture depend on each other (a level's predictor is its parent CU's MV), pictures do not.  Sub-batch s runs on its
+        // own stream, so the LDS-bound 64x64 search of one runs beside the latency-bound 16x16 / 8x8 searches of another.  Everything is ordered after the work already
+        // queued on the context's stream and joined back into it.
+        XH_HIP(hipEventRecord(b->evFork, b->sub[0]));
+        for (int s = 0; s < S; s++)
+        {
+            if (s) XH_HIP(hipStreamWaitEvent(b->sub[s], b->evFork, 0));
+            if ((rc = step_range(b, (F * s / S) * ctuRows, (F * (s + 1) / S) * ctuRows, true, b->sub[s], s == 0 ? ev : nullptr)) != X265HIP_OK) return rc;
+        }
     }
     for (int s = 1; s < S; s++)
     {

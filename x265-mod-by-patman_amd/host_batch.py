@@ -11,22 +11,22 @@ LEVELS = (64, 32, 16, 8)
 
 
 class BatchDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes", "refs", "rect", "streams")]
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes", "refs", "rect", "streams", "bandRows")]
 
 
 class HostBatch:
     def __init__(self, lib, depth, width, height, frames, qp=28, merange=57, method=1, subme=2, tu_log2=5, margin=96, recon=False, use_planes=True, refs=1, rect=False,
-                 streams=1, device=0):
+                 streams=1, device=0, band_rows=0):
         self.lib, self.depth = lib, depth
         self.W, self.H, self.F, self.margin = width, height, frames, margin
         self.qp, self.merange, self.method, self.subme, self.tu_log2, self.recon, self.use_planes = qp, merange, method, subme, tu_log2, recon, use_planes
-        self.refs, self.rect, self.streams = refs, rect, streams
+        self.refs, self.rect, self.streams, self.band_rows = refs, rect, streams, band_rows
         self.stride = width + 2 * margin
         self.plane = self.stride * (height + 2 * margin)
         self.pixel = np.uint8 if depth == 8 else np.uint16
         lib.x265hip_last_error.restype = C.c_char_p
         lib.x265hip_batch_stage_name.restype = C.c_char_p
-        self.desc = BatchDesc(width, height, frames, margin, qp, merange, method, subme, tu_log2, int(recon), int(use_planes), refs, int(rect), streams)
+        self.desc = BatchDesc(width, height, frames, margin, qp, merange, method, subme, tu_log2, int(recon), int(use_planes), refs, int(rect), streams, band_rows)
         self.ctx, self.batch = C.c_void_p(), C.c_void_p()
         self._ck(lib.x265hip_ctx_create(device, C.byref(self.ctx)), "ctx_create")
         self._ck(lib.x265hip_batch_create(self.ctx, C.byref(self.desc), C.byref(self.batch)), "batch_create")
@@ -128,6 +128,8 @@ class HostBatch:
 
     def sub_batch_pictures(self):
         """pictures of sub-batch 0 -- the one the stage events are recorded on"""
+        if self.band_rows > 0:
+            return self.band_rows * 64 / self.H                     # (a fraction of a picture: the first band)
         S = max(1, min(self.streams, self.F))
         return self.F * 1 // S if S > 1 else self.F
 
@@ -136,13 +138,14 @@ class HostBatch:
         and reference, 2 B per coefficient + 4 B per TU); the phase-plane stage reads one padded plane stack and writes 16, per reference."""
         bpp = 1 if self.depth == 8 else 2
         nf = self.sub_batch_pictures()
-        px = nf * self.W * self.H
+        px = int(nf * self.W * self.H)
         share = nf / self.F
         alg = {"me%d" % lv: px * (1 + self.refs) * bpp + int(len(self.tasks_host[lv]) * share) * 16 * self.refs for lv in LEVELS}
         if self.rect:
             for lv in LEVELS:
                 alg["rect%d" % lv] = 2 * px * (1 + self.refs) * bpp + int(sum(len(self.rect_host[k]) for k in ((lv, lv // 2), (lv // 2, lv))) * share) * 16 * self.refs
         alg["tq"] = px * (2 * bpp + 2) + int(len(self.tu_host) * share) * 4 + (px * bpp if self.recon else 0)
+        alg = {k: int(v) for k, v in alg.items()}
         if self.use_planes:
-            alg["planes"] = nf * self.plane * bpp * 17 * self.refs
+            alg["planes"] = int((self.F if self.band_rows > 0 else nf) * self.plane * bpp * 17 * self.refs)
         return alg
