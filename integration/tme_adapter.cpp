@@ -6,7 +6,7 @@
  * objects, in computeMVForPUs' order -- the qp of every CU (Analysis::calculateQpforCuSize), the collocated neighbour of every PU (CUData::getNeighbourMV), the
  * collocated median of every CTU (CUData::getMedianColMV).
  *
- * Preconditions (checked where they can be): one slice per picture; frame threads = 1 or complete reference pictures (the producer takes whole planes; the row-lag
+ * Preconditions (checked where they can be): frame threads = 1 or complete reference pictures (the producer takes whole planes; the row-lag
  * clamp of Search::setSearchRange, search.cpp:5017-5018, is not modelled); numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF.
  */
 #include <atomic>
@@ -151,6 +151,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         Frame* frame; int poc, nCtu, nCtuX, nCtuY, nS, nl;
         const x265hip_tme_step* steps;
         std::vector<int> used;                                     /* the MEData slots of a CTU the schedule writes (and reads) */
+        std::vector<int> sliceOfRow;
         std::vector<x265hip_tme_temporal> temporal; std::vector<int> entryQp, areaQp; std::vector<int16_t> median;
         std::vector<x265hip_inter_choice> table; std::vector<std::vector<x265hip_inter_choice>> refTables; std::vector<const MEData*> refSrc;
         std::vector<std::vector<int16_t>> lowres; size_t nRefTables = 0, nLowres = 0;      /* (the outer vectors only grow: their inner buffers are reused) */
@@ -183,7 +184,21 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             const int nCtu = j->nCtu, nS = j->nS, nl = j->nl;
             for (int l = 0; l < nl; l++)
                 if (slice->m_numRefIdx[l] < 1 || slice->m_numRefIdx[l] > X265HIP_MAX_REF) { fprintf(stderr, "tme_adapter: %d references in list %d (1..%d)\n", slice->m_numRefIdx[l], l, X265HIP_MAX_REF); return nullptr; }
-            if (p->maxSlices > 1) { fprintf(stderr, "tme_adapter: --slices %d: one slice per picture only\n", p->maxSlices); return nullptr; }
+            /* --slices: the rows of a slice as FrameEncoder::init deals them (frameencoder.cpp:131-146).  What a slice changes on this path with one frame thread: the
+               first / last-row flags initCTU gets (threadedme.cpp:298-308).  Search::setSearchRange and selectMVP look at slice bounds only with several frame threads
+               (search.cpp:2367-2369, 4999-5003), and motionEstimate's slice check (motion.cpp:1655-1659) tests an MV against the window it was searched in. */
+            j->sliceOfRow.assign((size_t)j->nCtuY, 0);
+            if (p->maxSlices > 1)
+            {
+                if (p->frameNumThreads > 1) { fprintf(stderr, "tme_adapter: --slices with several frame threads: the slice MV bounds are not modelled\n"); return nullptr; }
+                const uint32_t accu = ((uint32_t)j->nCtuY << 8) / p->maxSlices;
+                uint32_t rowSum = accu, sidx = 0;
+                for (uint32_t i = 0; i < (uint32_t)j->nCtuY; i++)
+                {
+                    if ((i >= (rowSum >> 8)) & (sidx != (uint32_t)p->maxSlices - 1)) { rowSum += accu; ++sidx; }
+                    j->sliceOfRow[i] = (int)sidx;
+                }
+            }
             {
                 std::vector<char> mark(593, 0);
                 for (int k = 0; k < nS; k++) for (int pi = 0; pi < j->steps[k].numPart; pi++) { const int sl = j->steps[k].finalIdx + pi * j->steps[k].puOffset; if (sl >= 0 && sl < 593) mark[sl] = 1; }
@@ -263,7 +278,8 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             ctu->m_slice = fr.m_encData->m_slice;
             const int row = c / nCtuX, col = c % nCtuX;
             fr.m_encData->m_cuStat[c].baseQp = fr.m_encData->m_avgQpRc;
-            ctu->initCTU(fr, c, slice->m_sliceQp, row == 0, row == nCtuY - 1, row == nCtuY - 1 && col == nCtuX - 1);     /* one slice */
+            const bool firstRow = row == 0 || sliceOfRow[row - 1] != sliceOfRow[row], lastRow = row == nCtuY - 1 || sliceOfRow[row + 1] != sliceOfRow[row];
+            ctu->initCTU(fr, c, slice->m_sliceQp, firstRow, lastRow, lastRow && col == nCtuX - 1);
             const int rawBase = slice->m_pps->bUseDQP ? an.calculateQpforCuSize(*ctu, ctuGeom) : slice->m_sliceQp;
             areaQp[c * 5] = rawBase;
             for (int sub = 0; sub < 4; sub++)

@@ -38,6 +38,8 @@ def encode(depth, producer, args, out):
                                         (8, ["192", "128", "6", "slow"]),                                                       # the preset as it is
                                         (8, ["192", "128", "6", "slower"]),                                                     # ref 5 (param.cpp:588-608): more than four references per list
                                         (10, ["192", "128", "7", "veryslow", "ref=6"]),
+                                        (8, ["256", "256", "6", "medium", "slices=2", "wpp=1"]),                                         # two slices of two CTU rows
+                                        (10, ["192", "320", "5", "slow", "slices=3", "wpp=1"]),
                                         (8, ["1920", "1080", "3", "medium"])])                                                  # BASELINE configs[1] at its own size
 def test_bitstream_identical_with_gpu_producer(depth, args, tmp_path):
     cpu, h_cpu = encode(depth, "cpu", args, str(tmp_path / "cpu.hevc"))
