@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--rect", action="store_true", help="also search the 2NxN / Nx2N PUs of every CU (bEnableRectInter, preset slow and up): 425 PUs per CTU instead of 85; one reference")
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--inner", type=int, default=5, help="passes over the resident batch per step (a step of the driver's --steps 20 then lasts long enough for the whole timed region to be >= 0.5 s)")
-    ap.add_argument("--splits", type=int, default=2, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
+    ap.add_argument("--no-streams-leg", action="store_true", help="skip the extra leg that steps the same batch as 2 and 3 sub-batches of whole pictures on their own streams (x265hip_batch_desc.streams); reported under \"streams\", not part of value")
+    ap.add_argument("--splits", type=int, default=1, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
     ap.add_argument("--band-rows", type=int, default=0, help="band-major schedule: bands of this many CTU rows go through all levels + TQ before the stream takes the next band (x265hip_batch_desc.bandRows); 0 = sub-batches of whole pictures")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
@@ -68,6 +69,7 @@ def parse():
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-dry-run", action="store_true", help="launcher / bookkeeping check without a GPU: gloo ranks, a sleep in place of the step (tests/test_sharding.py); prints a line marked data=dry-run")
     ap.add_argument("--no-tme", action="store_true", help="skip the ThreadedME producer leg (x265hip_tme_picture on synthetic 1080p pictures: medium- and slow-like partition sets); reported under \"tme_producer\", not part of value")
+    ap.add_argument("--no-preset-exact", action="store_true", help="skip the preset-exact leg (the preset's own reference count and, from preset slow on, the rectangular PUs, on 2 pictures of the batch); reported under \"preset_exact\", not part of value")
     ap.add_argument("--no-e2e", action="store_true", help="skip the live end-to-end leg (reference encoder, 1920x1088 medium, CPU producer vs GPU producer of the MEData tables, ~20 s); reported under \"e2e_fps\"")
     ap.add_argument("--filters", action="store_true", help="also time the in-loop filter chain after reconstruction (deblock, SAO statistics, SAO apply, SSIM, SSD) on 8 coded 1080p pictures; reported under \"filters\", not part of value")
     return ap.parse_args()
@@ -539,6 +541,66 @@ def intra_scan_leg(pipe, depth, steps):
             "checked_vs_reference": "%d CUs identical" % checked if checked else "reference binary not present"}
 
 
+def streams_leg(lib, depth, W, H, wl, args, pairs, headline_s_per_pass):
+    """The same batch stepped as sub-batches of whole pictures on their own streams (x265hip_batch_desc.streams = 2, 3): pictures are independent, so the LDS-bound 64x64
+    search of one sub-batch runs beside the latency-bound 16x16 / 8x8 searches of another.  The headline stays the one-stream schedule so that its per-stage times are
+    those of kernels that own the GPU; this leg says what the overlap is worth (measured: 3-4 %)."""
+    import torch
+    from x265hip_pkg.host_batch import HostBatch
+    res = {"what": "x265hip_batch_step, desc.streams = S: S sub-batches of whole pictures, each on its own stream; same batch, same results (tests/test_host_batch_gpu.py)", "one_stream_ms_per_pass": round(headline_s_per_pass * 1e3, 4)}
+    for S in (2, 3):
+        hb = HostBatch(lib, depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, margin=MARGIN,
+                       recon=args.recon, use_planes=not args.no_planes, refs=args.refs, rect=args.rect, streams=S, device=torch.cuda.current_device())
+        try:
+            hb.upload([p[:1 + args.refs] for p in pairs])
+            for _ in range(3):
+                hb.step()
+            hb.sync()
+            reps = max(10, 4 * args.inner)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                hb.step()
+            hb.sync()
+            dt = (time.perf_counter() - t0) / reps
+            res["streams_%d" % S] = {"ms_per_pass": round(dt * 1e3, 4), "Mpixels/s": round(hb.pixels_per_step / dt / 1e6, 1), "vs_one_stream": round(headline_s_per_pass / dt, 4)}
+        finally:
+            hb.close()
+    return res
+
+
+def preset_exact_leg(lib, depth, W, H, wl, args, pairs, refs, rect, headline_s_per_search):
+    """The search the preset really asks for, in ONE run of the C++ host: every list-0 reference of the preset (each down the pyramid with its own predictor chain), the
+    rectangular PUs of every CU where the preset has them, the per-PU choice among the references, TQ from the chosen reference -- on PRESET_F pictures of the batch.
+    `value` of the line stays the SURVEY 8(d) pipeline (85 PUs per CTU, one reference); this leg says what the preset's own load costs next to it."""
+    import torch
+    from x265hip_pkg.host_batch import HostBatch
+    F = PRESET_F
+    hb = HostBatch(lib, depth, W, H, F, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, margin=MARGIN,
+                   use_planes=True, refs=refs, rect=rect, streams=min(2, F), device=torch.cuda.current_device())
+    try:
+        hb.upload([p[:1 + refs] for p in pairs[:F]])
+        for _ in range(2):
+            hb.step()
+        hb.sync()
+        reps = 4
+        hb.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hb.step()
+        hb.sync()
+        dt = (time.perf_counter() - t0) / reps
+        kms = hb.read_timing()
+        searches = F * (W // 64) * (H // 64) * (425 if rect else 85) * refs
+        return {"config": {"refs": refs, "rect": bool(rect), "pus_per_ctu": 425 if rect else 85, "pictures": F, "preset_exact": True,
+                           "what": "x265hip_batch_step with desc.refs = %d%s: the preset's own motion-search load" % (refs, ", desc.rect = 1" if rect else "")},
+                "ms_per_pass": round(dt * 1e3, 3), "ms_per_picture": round(dt * 1e3 / F, 3), "Mpixels/s": round(F * W * H / dt / 1e6, 1),
+                "searched_pus_per_pass": searches, "ns_per_searched_pu": round(dt / searches * 1e9, 3),
+                "vs_headline_per_searched_pu": round((dt / searches) / headline_s_per_search, 3),
+                "stage_ms_sub_batch_0": {k: round(v, 4) for k, v in kms.items()}}
+    finally:
+        hb.close()
+
+
 def python_pipeline(args, wl, depth, W, H, pairs):
     """the torch-tensor plumbing of the same step (x265hip_pkg.pipeline.FramePipeline): what the optional legs that work on torch tensors use"""
     from x265hip_pkg.frame import FrameApi, mvcost_row
@@ -687,6 +749,10 @@ def cpu_baseline(pipe, depth, n_ctus):
 
 
 MARGIN = 96                  # PicYuv-style padding of the synthetic planes (FramePipeline's default)
+# the preset's own search: references per list-0 (param.cpp:567-608) and the rectangular PUs (preset slow and up); medium has no rect
+PRESET_REFS = {"1080p8_medium": 3, "2160p10_slow": 4, "4320p10_slower": 5}
+PRESET_RECT = {"1080p8_medium": False, "2160p10_slow": True, "4320p10_slower": True}
+PRESET_F = 2                 # pictures of the preset-exact leg
 
 
 def _make_pair(W, H, depth, seed, refs=1):
@@ -788,7 +854,9 @@ def main():
     # close() + join(), not the context manager: its terminate() sends SIGTERM to the workers, and under rocprofv3 (whose signal handler is inherited by the forked
     # workers) a worker then never exits and the run hangs in wait4 (seen in the r02 counter passes)
     pool = multiprocessing.get_context("fork").Pool(min(len(seeds), max(1, (os.cpu_count() or 1) // max(1, args.gpus))))
-    pairs = pool.starmap(_make_pair, [(W, H, depth, sd, args.refs) for sd in seeds])
+    # (the first PRESET_F pictures get the references of the preset-exact leg as well)
+    exact_refs = PRESET_REFS.get(args.workload, 0) if (not args.no_preset_exact and int(os.environ.get("RANK", "0")) == 0) else 0
+    pairs = pool.starmap(_make_pair, [(W, H, depth, sd, max(args.refs, exact_refs) if i < PRESET_F else args.refs) for i, sd in enumerate(seeds)])
     pool.close(); pool.join()
     import torch
     import torch.distributed as dist
@@ -858,7 +926,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
-            "config": {"workload": args.workload, "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames * args.inner,
+            "config": {"workload": args.workload, "preset_exact": bool(args.refs == PRESET_REFS.get(args.workload) and args.rect == PRESET_RECT.get(args.workload)),
+                       "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames * args.inner,
                        "step": "%d passes of the hot path over a resident batch of %d frame pairs" % (args.inner, args.frames), "host": "C++ (x265hip_batch_step, csrc/xh_ctx.cpp)",
                        "streams": ("bands of %d CTU rows through all levels, round-robin on %d streams" % (args.band_rows, args.splits)) if args.band_rows > 0 else ("%d sub-batches of whole pictures on their own streams" % args.splits if args.splits > 1 else "one stream"),
                        "ctu": 64, "pus_per_ctu": 425 if args.rect else 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": args.refs, "qp": args.qp,
@@ -883,6 +952,10 @@ def main():
                               "traffic_per_step": (sum(v for k, v in traffic_all.items() if k in kms) * args.inner or None) if traffic_all else None, "traffic_source": traffic_src},
             "e2e_fps": None,
         }
+        if not args.no_streams_leg and args.splits == 1 and args.band_rows == 0 and args.frames >= 2:
+            out["streams"] = streams_leg(lib, depth, W, H, wl, args, pairs, dt / args.steps / args.inner)
+        if exact_refs and not (args.refs == exact_refs and args.rect == PRESET_RECT[args.workload]):
+            out["preset_exact"] = preset_exact_leg(lib, depth, W, H, wl, args, pairs, exact_refs, PRESET_RECT[args.workload], (dt / args.steps / args.inner) / (args.frames * (W // 64) * (H // 64) * 85 * args.refs))
         e2e_path = os.path.join(ROOT, "profiles", "e2e_fps.json")
         if not args.no_e2e:
             try:

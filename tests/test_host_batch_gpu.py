@@ -101,3 +101,24 @@ def test_stage_timing_and_names():
             hb.read_timing()                                     # nothing was timed since the last read
     finally:
         hb.close()
+
+
+def test_preset_slow_search_at_4k_10bit_full_size():
+    """BASELINE configs[2] with the preset's own search load in one run of the C++ host: 3840x2176 10-bit, STAR, subme 3, merange 57, 4 list-0 references, the rectangular
+    PUs of every CU (425 PUs per CTU), 2 pictures on 2 streams: a second pass gives the same bytes, and PUs of every shape and reference, the choices among the
+    references and TUs, sampled at random, equal the oracle's."""
+    depth, W, H, F, refs = 10, 3840, 2176, 2, 4
+    hb = make(depth, W, H, F, qp=28, merange=57, method=3, subme=3, tu_log2=5, refs=refs, rect=True, streams=2)
+    try:
+        hb.upload(pairs_for(W, H, depth, F, refs, seed0=700))
+        hb.step(); hb.sync()
+        first = [hb.results(lv, r).tobytes() for lv in LEVELS for r in range(refs)] + [hb.choices(w, h).tobytes() for (w, h) in sorted(hb.rect_host)]
+        co1, ns1 = hb.coeffs()
+        hb.step(); hb.sync()
+        assert first == [hb.results(lv, r).tobytes() for lv in LEVELS for r in range(refs)] + [hb.choices(w, h).tobytes() for (w, h) in sorted(hb.rect_host)]
+        co2, ns2 = hb.coeffs()
+        assert np.array_equal(co1, co2) and np.array_equal(ns1, ns2)
+        n = check_host_batch(hb, Oracle(depth), np.random.default_rng(17), mvcost_row(depth, 28, 1 << 15), mvbits_row(depth, 1 << 14), rd_lambda(depth, 28), per_shape=5, n_tu=10)
+        assert n >= 12 * 5 + 10
+    finally:
+        hb.close()
