@@ -212,6 +212,25 @@ def e2e_fps_leg(frames=8):
     return out
 
 
+def c1_host_leg(frames=40):
+    """1080p 8-bit, preset ultrafast, the x265 encoder on the host CPU alone with the threading its CLI uses by default (frame threads, WPP, all cores).
+    The binary is the reference encoder compiled here from its sources WITHOUT assembly (no nasm in the image): a C-primitives figure, labelled so."""
+    import subprocess, tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265e2e_8")
+    if not os.path.exists(exe):
+        exe = os.path.join(ROOT, "oracle", "_ref", "x265tmegpu_8")
+        if not os.path.exists(exe):
+            return None
+    with tempfile.TemporaryDirectory() as td:
+        env = dict(os.environ, X265TMEGPU="0", X265LAGPU="0", X265TME="0", X265_CLI_THREADING="1")
+        r = subprocess.run([exe, "none", "1920", "1080", str(frames), "ultrafast", os.path.join(td, "c1.hevc")], capture_output=True, text=True, env=env, timeout=600)
+        if r.returncode != 0:
+            return {"measured": "this run: FAILED", "stderr": r.stderr[-300:]}
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+    return {"value": info["fps"], "unit": "frames/s", "measured": "this run", "config": "BASELINE C1: 1920x1080 8-bit synthetic clip, preset ultrafast, %d frames, host CPU only (%d cores), the CLI's default threading" % (frames, os.cpu_count() or 0),
+            "asm": False, "note": "the reference encoder built from its sources without assembly (no nasm / yasm on this box: cpu_baseline.asm); the x86 asm build would be faster"}
+
+
 def filters_leg(depth, steps):
     """In-loop filters and picture statistics after reconstruction: 8 coded 4:2:0 pictures of 1920x1080 resident in HBM ->
     deblocking (in place), SAO statistics of the three planes, SAO of the three planes (out of place), SSIM of the luma plane and the SSD of the
@@ -967,6 +986,11 @@ def main():
                 out["e2e_fps"] = json.load(open(e2e_path))
             except Exception:
                 pass
+        if not args.no_e2e:
+            try:
+                out["c1_host_fps"] = c1_host_leg()
+            except Exception as ex:
+                out["c1_host_fps"] = {"measured": "this run: FAILED", "error": repr(ex)[:300]}
         if not args.no_tme:
             out["tme_producer"] = tme_producer_leg(depth)
         if args.intra:

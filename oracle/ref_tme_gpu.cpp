@@ -62,8 +62,12 @@ int main(int argc, char** argv)
     if (x265_param_default_preset(p, argv[5], NULL) < 0) { fprintf(stderr, "bad preset\n"); return 2; }
     p->sourceWidth = w; p->sourceHeight = h; p->fpsNum = 25; p->fpsDenom = 1; p->internalCsp = X265_CSP_I420;
     p->totalFrames = frames; p->logLevel = X265_LOG_WARNING; p->bRepeatHeaders = 1;
-    p->frameNumThreads = 1; p->bEnableWavefront = 0; p->lookaheadSlices = 0;
-    x265_param_parse(p, "pools", "32");
+    if (!getenv("X265_CLI_THREADING"))
+    {   /* the seams are checked with one frame thread and no WPP (complete reference pictures); X265_CLI_THREADING=1 leaves the threading the x265 CLI would use by
+           default (frame threads, WPP, all cores): BASELINE.md's C1 "x265 CLI on host CPU" figure */
+        p->frameNumThreads = 1; p->bEnableWavefront = 0; p->lookaheadSlices = 0;
+        x265_param_parse(p, "pools", "32");
+    }
     const int tmeOn = getenv("X265TME") ? atoi(getenv("X265TME")) : 1;
     if (tmeOn) x265_param_parse(p, "threaded-me", "1");
     for (int i = 7; i < argc; i++)

@@ -36,7 +36,8 @@ LUMA_PU = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (8, 4), (4, 8), (16, 8)
 
 
 def lib_path(depth):
-    return os.path.join(HERE, "libx265hip_%d.so" % depth)
+    # X265HIP_LIBDIR: the experiment build of profiles/*.sh (make OUT=<dir>/ OBJ=<dir>/obj EXPERIMENTS=1), never set by the tests or the default bench
+    return os.path.join(os.environ.get("X265HIP_LIBDIR", HERE), "libx265hip_%d.so" % depth)
 
 
 def build_libraries(jobs=8):
