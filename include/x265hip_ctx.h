@@ -139,11 +139,14 @@ int  x265hip_tme_picture(x265hip_tme* tme, const x265hip_tme_picture_desc* desc)
  * the device under the caller's key (e.g. Lowres::frameNum + 1; the least recently used of maxPictures makes room, a missing picture is uploaded again from `planes`).
  * Arrays are the reference's own: MVs as int16 x, y per 8x8 block (Lowres::lowresMvs[list][dist], MV = two int32 there), costs int32 (lowresMvCosts), lowresCosts uint16
  * (cost | listused << 14), rowSatds int32 per block row; sums = { costEst before the B-frame normalisation (:4456-4457), costEstAq, intraMbs }.  Calls are synchronous
- * (the lookahead's workers may call concurrently).  HME is not offered (the caller keeps its own path for --hme). */
+ * (the lookahead's workers may call concurrently).  --hme is offered for the serial sweep (x265hip_la_enable_hme + desc.hme). */
 typedef struct x265hip_la x265hip_la;
 int  x265hip_la_create(x265hip_ctx* ctx, int widthInCU, int heightInCU, intptr_t stride /* Lowres::lumaStride */, int64_t planeElems /* buffer[1] - buffer[0] */,
                        int64_t origin /* lowresPlane[0] - buffer[0] */, int maxPictures, x265hip_la** la);
 void x265hip_la_destroy(x265hip_la* la);
+/* --hme: the quarter-resolution pictures (Lowres::lowerResBuffer[0], four planes of planeElems4 = lowerResBuffer[1] - lowerResBuffer[0] pixels; rows lumaStride / 2 apart;
+ * origin4 = lowerResPlane[0] - lowerResBuffer[0]) on the Lookahead::m_4x4Width x m_4x4Height grid of 8x8 blocks.  Once, before the first estimate with desc.hme. */
+int  x265hip_la_enable_hme(x265hip_la* la, int widthInCU4, int heightInCU4, intptr_t stride4, int64_t planeElems4, int64_t origin4);
 /* make a picture resident (no-op when it is): planes4 = Lowres::buffer[0]; invQscale = Lowres::invQscaleFactor (or ...8x8 with qgSize 8) or NULL; intraCost: optional,
  * for callers that ran the intra estimate themselves */
 int  x265hip_la_picture(x265hip_la* la, uint64_t key, const void* planes4, const int32_t* invQscale, const int32_t* intraCost);
@@ -161,6 +164,11 @@ typedef struct x265hip_la_estimate_desc {
     int rowsPerSlice;                /* 0 = the serial sweep; > 0 = Lookahead::m_numRowsPerSlice of the cooperative --lookahead-slices sweep          */
     int16_t* mvs[2]; int32_t* mvCosts[2];       /* per list, ncu entries (list 1 unused for a P estimate)                                              */
     uint16_t* lowresCosts; int32_t* rowSatds; int64_t* sums;      /* ncu, heightInCU, 3                                                                 */
+    /* --hme (after x265hip_la_enable_hme): the quarter-resolution sweep runs first and seeds the half-resolution one (x265hip_lookahead_cost_batch_hme) */
+    int hme;                         /* != 0: param->bEnableHME                                                                                       */
+    const void* lowerPlanes[3];      /* Lowres::lowerResBuffer[0] of p0, b, p1 (uploaded once per picture)                                            */
+    int hmeMethod[2], hmeRange[2];   /* param->hmeSearchMethod[0..1] (X265HIP_ME_HEX / X265HIP_ME_UMH), param->hmeRange[0..1]                          */
+    int16_t* lowerMvs[2]; int32_t* lowerMvCosts[2];      /* optional outputs per searched list: Lowres::lowerResMvs / lowerResMvCosts (m_4x4Width * m_4x4Height entries) */
 } x265hip_la_estimate_desc;
 int  x265hip_la_estimate(x265hip_la* la, const x265hip_la_estimate_desc* desc);
 /* x265hip_la_estimate is synchronous for its caller, but estimates that arrive from other threads while a launch is in flight go up TOGETHER as the next launch (up to 16):

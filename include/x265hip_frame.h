@@ -350,6 +350,21 @@ int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t plane
                                  const uint16_t* costRow, int costHalfRange, int rowsPerSlice, int16_t* mvs, int32_t* mvCosts,
                                  uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
 
+/* --hme (param->bEnableHME, slicetype.cpp:4430-4437, 4483-4575): the sweep runs first on the QUARTER-resolution pictures (Lowres::lowerResPlane[0..3], four planes per
+ * picture at the same picture indices as the lowres buffer; blocks of 8x8 on the Lookahead::m_4x4Width x m_4x4Height grid) with hmeRange[0] / hmeSearchMethod[0] into its own
+ * MV / cost slots (mvs / mvCosts below: the device form of Lowres::lowerResMvs / lowerResMvCosts, same slot numbers as the call's mvSlot), then on the half-resolution pictures
+ * with hmeRange[1] / hmeSearchMethod[1], where twice the quarter-resolution MV of the block above a block joins its predictor candidates.  Methods: X265HIP_ME_HEX or
+ * X265HIP_ME_UMH (the reference's default is hex, umh).  The serial sweep only (rowsPerSlice 0). */
+typedef struct x265hip_la_hme {
+    const void* lowerRes; int64_t planeElems; intptr_t stride; int64_t origin; int widthInCU, heightInCU;
+    int method[2], range[2];
+    int16_t* mvs; int32_t* mvCosts;            /* slots of widthInCU * heightInCU entries */
+} x265hip_la_hme;
+int x265hip_lookahead_cost_batch_hme(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
+                                     const x265hip_la_task* tasks, int nTasks, int nFrames, const int32_t* intraCost, const int32_t* invQscale,
+                                     const uint16_t* costRow, int costHalfRange, int rowsPerSlice, int16_t* mvs, int32_t* mvCosts,
+                                     uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums, const x265hip_la_hme* hme /* NULL: no HME */);
+
 /* cuTree: one propagation step (Lookahead::estimateCUPropagate, slicetype.cpp:3850-3953, with primitives.propagateCost, pixel.cpp:906-931)
  * on the arrays the calls above left in HBM: intraCost / invQscale of picture b, the lowresCosts and the two MV slots of its estimate,
  * and the three pictures' propagateCost arrays (uint16, ncu each; prop1 may be NULL for a P picture).  distP0 = b - p0, distP1 = p1 - b;

@@ -31,6 +31,7 @@ struct Api
     void (*ctx_destroy)(x265hip_ctx*);
     int (*la_create)(x265hip_ctx*, int, int, intptr_t, int64_t, int64_t, int, x265hip_la**);
     void (*la_destroy)(x265hip_la*);
+    int (*la_enable_hme)(x265hip_la*, int, int, intptr_t, int64_t, int64_t);
     int (*la_intra)(x265hip_la*, uint64_t, const void*, const int32_t*, int32_t*, uint8_t*, uint16_t*, int32_t*, int64_t*);
     int (*la_estimate)(x265hip_la*, const x265hip_la_estimate_desc*);
     int (*la_batch_stats)(const x265hip_la*, int64_t*, int64_t*);
@@ -40,6 +41,7 @@ void* g_lib;
 x265hip_ctx* g_ctx;
 x265hip_la* g_la;
 int g_on, g_device;
+int g_hme;                               /* 0 not tried yet, 1 the producer holds the quarter-resolution pictures, -1 it cannot: --hme estimates stay with the encoder */
 std::mutex g_lock;                       /* creation of the producer; the producer serialises its own calls */
 x265hip_la_adapter_stats g_stats;
 std::mutex g_statLock;
@@ -55,7 +57,7 @@ x265hip_la* producer(const Lowres& f, int widthInCU, int heightInCU)
     const int64_t planeElems = f.buffer[1] - f.buffer[0], origin = f.lowresPlane[0] - f.buffer[0];
     /* pictures kept on the device: the lookahead's depth and then some; the producer addresses its lowres buffer with 32-bit element offsets (16 more places hold the
        weighted copies of a launch), which bounds the count for very large pictures -- fewer places only mean more uploads */
-    int64_t keep = (((int64_t)1 << 31) - 1) / (4 * planeElems) - 17;
+    int64_t keep = (((int64_t)1 << 31) - 1) / (4 * planeElems) - 17;          /* (the quarter-resolution pictures of --hme are a quarter of that again: never the bound) */
     if (keep > 96) keep = 96;
     if (keep < 8 || g_api.ctx_create(g_device, &g_ctx) || g_api.la_create(g_ctx, widthInCU, heightInCU, f.lumaStride, planeElems, origin, (int)keep, &g_la))
     {
@@ -63,6 +65,21 @@ x265hip_la* producer(const Lowres& f, int widthInCU, int heightInCU)
         g_on = 0; g_la = nullptr;
     }
     return g_la;
+}
+/* --hme: the quarter-resolution level on the producer too (Lookahead::m_4x4Width x m_4x4Height blocks of Lowres::lowerResPlane, rows lumaStride / 2 apart, lowres.cpp:170-188).
+   Hexagon and uneven multi-hexagon levels (the default --hme-search hex,umh,umh) are offered; anything else keeps the encoder's own estimate. */
+bool hme_ready(x265hip_la* la, const Lowres& f, const x265_param& p, int w4, int h4)
+{
+    for (int l = 0; l < 2; l++)
+        if ((p.hmeSearchMethod[l] != X265_HEX_SEARCH && p.hmeSearchMethod[l] != X265_UMH_SEARCH) || p.hmeRange[l] < 1 || p.hmeRange[l] > 64) return false;
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (!g_hme)
+    {
+        const int rc = g_api.la_enable_hme(la, w4, h4, f.lumaStride / 2, f.lowerResBuffer[1] - f.lowerResBuffer[0], f.lowerResPlane[0] - f.lowerResBuffer[0]);
+        if (rc) fprintf(stderr, "lookahead_adapter: x265hip_la_enable_hme: %s -- the encoder's own estimate runs with --hme\n", g_api.last_error());
+        g_hme = rc ? -1 : 1;
+    }
+    return g_hme > 0;
 }
 }
 
@@ -94,7 +111,10 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
 {
     Lowres* fenc = m_frames[b];
     x265_param* param = m_lookahead.m_param;
-    x265hip_la* la = (g_on && !param->bEnableHME) ? producer(*fenc, m_lookahead.m_8x8Width, m_lookahead.m_8x8Height) : nullptr;
+    x265hip_la* la = g_on ? producer(*fenc, m_lookahead.m_8x8Width, m_lookahead.m_8x8Height) : nullptr;
+    /* with --hme the cooperative sweep reads quarter-resolution results of other slices while they are being written (slicetype.cpp:4332-4358, :4532): the encoder keeps it */
+    const bool hme = param->bEnableHME;
+    if (la && hme && ((m_lookahead.m_numCoopSlices > 1 && !m_batchMode) || !hme_ready(la, *fenc, *param, m_lookahead.m_4x4Width, m_lookahead.m_4x4Height))) la = nullptr;
     if (!la)
     {
         if (g_on) { std::lock_guard<std::mutex> guard(g_statLock); g_stats.cpuEstimates++; }
@@ -134,6 +154,16 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
             if (!bDoSearch[l]) { const MV* src = fenc->lowresMvs[l][dist[l]]; for (int i = 0; i < ncu; i++) { mv[l][2 * i] = (int16_t)src[i].x; mv[l][2 * i + 1] = (int16_t)src[i].y; } }
             d.mvs[l] = mv[l].data(); d.mvCosts[l] = fenc->lowresMvCosts[l][dist[l]];
         }
+        std::vector<int16_t> mv4[2];
+        const int ncu4 = m_lookahead.m_4x4Width * m_lookahead.m_4x4Height;
+        if (hme)
+        {
+            d.hme = 1;
+            for (int k = 0; k < 3; k++) d.lowerPlanes[k] = fr[k]->lowerResBuffer[0];
+            for (int l = 0; l < 2; l++) { d.hmeMethod[l] = param->hmeSearchMethod[l]; d.hmeRange[l] = param->hmeRange[l]; }
+            for (int l = 0; l < nl; l++)
+                if (bDoSearch[l]) { mv4[l].resize((size_t)ncu4 * 2); d.lowerMvs[l] = mv4[l].data(); d.lowerMvCosts[l] = fenc->lowerResMvCosts[l][dist[l]]; }
+        }
         int64_t sums[3] = { 0, 0, 0 };
         d.lowresCosts = fenc->lowresCosts[b - p0][p1 - b]; d.rowSatds = fenc->rowSatds[b - p0][p1 - b]; d.sums = sums;
         const double t1 = now();
@@ -141,7 +171,11 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
         const double t2 = now();
         if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_estimate (%d, %d, %d): %d %s\n", p0, b, p1, rc, g_api.last_error()); exit(3); }
         for (int l = 0; l < nl; l++)
-            if (bDoSearch[l]) { MV* dst = fenc->lowresMvs[l][dist[l]]; for (int i = 0; i < ncu; i++) { dst[i].x = mv[l][2 * i]; dst[i].y = mv[l][2 * i + 1]; } }
+            if (bDoSearch[l])
+            {
+                MV* dst = fenc->lowresMvs[l][dist[l]]; for (int i = 0; i < ncu; i++) { dst[i].x = mv[l][2 * i]; dst[i].y = mv[l][2 * i + 1]; }
+                if (hme) { MV* d4 = fenc->lowerResMvs[l][dist[l]]; for (int i = 0; i < ncu4; i++) { d4[i].x = mv4[l][2 * i]; d4[i].y = mv4[l][2 * i + 1]; } }
+            }
         fenc->costEstAq[b - p0][p1 - b] = sums[1];
         if (p1 == b) fenc->intraMbs[b - p0] += (int)sums[2];
         score = sums[0];
@@ -164,7 +198,7 @@ extern "C" int x265hip_la_adapter_load(const char* libraryPath, int device)
     g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
     if (!g_lib) { fprintf(stderr, "lookahead_adapter: dlopen: %s\n", dlerror()); return -1; }
 #define SYM(field, name) *(void**)&g_api.field = dlsym(g_lib, name); if (!g_api.field) { fprintf(stderr, "lookahead_adapter: %s lacks %s\n", libraryPath, name); return -1; }
-    SYM(ctx_create, "x265hip_ctx_create") SYM(ctx_destroy, "x265hip_ctx_destroy") SYM(la_create, "x265hip_la_create") SYM(la_destroy, "x265hip_la_destroy")
+    SYM(ctx_create, "x265hip_ctx_create") SYM(ctx_destroy, "x265hip_ctx_destroy") SYM(la_create, "x265hip_la_create") SYM(la_destroy, "x265hip_la_destroy") SYM(la_enable_hme, "x265hip_la_enable_hme")
     SYM(la_intra, "x265hip_la_intra") SYM(la_estimate, "x265hip_la_estimate") SYM(la_batch_stats, "x265hip_la_batch_stats") SYM(last_error, "x265hip_last_error")
 #undef SYM
     g_device = device; g_on = 1;
@@ -182,6 +216,6 @@ extern "C" void x265hip_la_adapter_close(void)
         g_api.la_destroy(g_la); g_la = nullptr;
     }
     if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
-    g_on = 0;
+    g_on = 0; g_hme = 0;
 }
 extern "C" void x265hip_la_adapter_get_stats(x265hip_la_adapter_stats* o) { std::lock_guard<std::mutex> guard(g_statLock); *o = g_stats; }

@@ -10,8 +10,9 @@
  *       -> CostEstimateGroup::singleCost(p0, p1, b)   (slicetype.cpp:4230-4234 -> estimateFrameCost :4365-4463
  *                                                      -> estimateCUCost :4467-4640 -> MotionEstimate::motionEstimate, lowres mode)
  *
- * It pins oracle/x265_oracle_la.c (and through it the HIP batch of x265hip_lookahead_cost_batch).  No thread pool, no HME,
- * no weighted prediction, no lookahead slices: the serial loops of estimateFrameCost.
+ * It pins oracle/x265_oracle_la.c (and through it the HIP batch of x265hip_lookahead_cost_batch).  No thread pool: the serial loops of estimateFrameCost
+ * (the cooperative slices through slicedCost below).  Environment X265LA_HME=method0,method1,range0,range1 turns --hme on (param->bEnableHME, hmeSearchMethod[0..1],
+ * hmeRange[0..1]; X265_HEX_SEARCH = 1, X265_UMH_SEARCH = 2): Lowres then carries the quarter-resolution planes and estimateFrameCost sweeps them first (slicetype.cpp:4430-4439).
  *
  * usage: x265la_<depth> <width> <height> <nframes> <in.raw> <out.bin> <aq 0|1> [p0,b,p1[,keep] | prop:p0,b,p1,referenced,seed ...]
  *   in.raw  : nframes luma planes, width x height pixels each (u8 / u16), no padding
@@ -20,6 +21,8 @@
  *             triples left them (bDoSearch then follows the reference's own rule, slicetype.cpp:4376-4377), 0 resets them
  *   prop:   : the estimate (caches reset), then Lookahead::estimateCUPropagate(frames, 0.05, p0, p1, b, referenced) (slicetype.cpp:3850-3953)
  *             on propagateCost arrays of the three pictures pre-filled from `seed`; needs aq = 1 (the AQ factor array must exist)
+ *   with X265LA_HME: the header record grows by { m_4x4Width, m_4x4Height }, every frame by its four lowerResBuffer planes (planesize / 2 pixels each, after the lowres planes),
+ *             every estimate by lowerResMvs / lowerResMvCosts of both lists (after rowSatds)
  *   out.bin : records of [int64 count][count x int32], in the order written below; the last record holds the time spent in
  *             lowresIntraEstimate (all frames) and in singleCost (all estimates), nanoseconds as (lo, hi) int32 pairs
  */
@@ -116,6 +119,13 @@ int main(int argc, char** argv)
     p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = X265_CSP_I400;
     const bool weightp = (aq & 2) != 0;            /* aq argument: bit 0 = AQ factors, bit 1 = weighted prediction analysis (weightsAnalyse) */
     p->bEnableWeightedPred = weightp; p->bEnableWeightedBiPred = 0; p->bEnableHME = 0; p->lookaheadSlices = 0;
+    const char* hmeEnv = getenv("X265LA_HME");
+    const bool hme = hmeEnv && *hmeEnv;
+    if (hme)
+    {
+        if (sscanf(hmeEnv, "%d,%d,%d,%d", &p->hmeSearchMethod[0], &p->hmeSearchMethod[1], &p->hmeRange[0], &p->hmeRange[1]) != 4) { fprintf(stderr, "bad X265LA_HME\n"); return 2; }
+        p->bEnableHME = 1;
+    }
     p->rc.aqMode = (aq & 1) ? X265_AQ_VARIANCE : X265_AQ_NONE; p->rc.cuTree = 0; p->bEnableTemporalFilter = 0;
     p->bHistBasedSceneCut = 0; p->bAQMotion = 0;
     x265_setup_primitives(p);
@@ -170,7 +180,9 @@ int main(int argc, char** argv)
     Lowres* L0 = low[0];
     const int wcu = L0->maxBlocksInRow, hcu = L0->maxBlocksInCol, ncu = wcu * hcu;
     const int marginX = pics[0]->m_lumaMarginX, marginY = pics[0]->m_lumaMarginY;
-    rec({ W, H, N, (int32_t)L0->lumaStride, L0->width, L0->lines, wcu, hcu, marginX, marginY, X265_DEPTH, (int32_t)p->rc.qgSize, p->bframes });
+    const int ncu4 = la.m_4x4Width * la.m_4x4Height;
+    if (hme) rec({ W, H, N, (int32_t)L0->lumaStride, L0->width, L0->lines, wcu, hcu, marginX, marginY, X265_DEPTH, (int32_t)p->rc.qgSize, p->bframes, la.m_4x4Width, la.m_4x4Height });
+    else rec({ W, H, N, (int32_t)L0->lumaStride, L0->width, L0->lines, wcu, hcu, marginX, marginY, X265_DEPTH, (int32_t)p->rc.qgSize, p->bframes });
     for (int f = 0; f < N; f++)
     {   /* the four padded lowres planes, then the intra results */
         Lowres* l = low[f];
@@ -182,6 +194,13 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < planesize; i++) v[i] = base[i];
             rec(v);
         }
+        if (hme)
+            for (int k = 0; k < 4; k++)
+            {   /* lowres.cpp:171-188: planesize / 2 pixels per plane, rows lumaStride / 2 apart, pixel (0,0) at padoffset / 2 */
+                std::vector<int32_t> v(planesize / 2);
+                for (size_t i = 0; i < planesize / 2; i++) v[i] = l->lowerResBuffer[k][i];
+                rec(v);
+            }
         std::vector<int32_t> ic(l->intraCost, l->intraCost + ncu), im(ncu), rs(hcu), lc(ncu), q(ncu);
         for (int i = 0; i < ncu; i++) { im[i] = l->intraMode[i]; lc[i] = l->lowresCosts[0][0][i]; }
         for (int i = 0; i < hcu; i++) rs[i] = l->rowSatds[0][0][i];
@@ -215,6 +234,15 @@ int main(int argc, char** argv)
         for (int i = 0; i < ncu; i++) lc[i] = fenc->lowresCosts[b - p0][p1 - b][i];
         for (int i = 0; i < hcu; i++) rs[i] = fenc->rowSatds[b - p0][p1 - b][i];
         rec(lc); rec(rs);
+        if (hme)
+            for (int l = 0; l < 2; l++)
+            {
+                const int d = l ? p1 - b : b - p0;
+                std::vector<int32_t> mv(2 * (size_t)ncu4, 0), mc(ncu4, 0);
+                if (l == 0 || p1 > b)
+                    for (int i = 0; i < ncu4; i++) { mv[2 * i] = fenc->lowerResMvs[l][d][i].x; mv[2 * i + 1] = fenc->lowerResMvs[l][d][i].y; mc[i] = fenc->lowerResMvCosts[l][d][i]; }
+                rec(mv); rec(mc);
+            }
         if (weightp)
         {   /* did weightsAnalyse (slicetype.cpp:919-1020) weight the list-0 reference, and with which planes */
             ReferencePlanes& wr = fenc->weightedRef[b - p0];

@@ -3,9 +3,10 @@
  *
  * CPU restatement of the reference's LOOKAHEAD frame-cost path on half-resolution ("lowres") pictures:
  *   - LookaheadTLD::lowresIntraEstimate              (encoder/slicetype.cpp:755-864)
- *   - CostEstimateGroup::estimateFrameCost, serial   (encoder/slicetype.cpp:4365-4463; no HME, no slices; weightsAnalyse itself stays outside, its weighted planes come in as ref0w)
+ *   - CostEstimateGroup::estimateFrameCost, serial   (encoder/slicetype.cpp:4365-4463; weightsAnalyse itself stays outside, its weighted planes come in as ref0w;
+ *                                                      with --hme the quarter-resolution sweep of :4430-4439 first, whose MVs seed the half-resolution one, :4532-4535)
  *   - CostEstimateGroup::estimateCUCost              (encoder/slicetype.cpp:4467-4640)
- *   - MotionEstimate::motionEstimate, ref->isLowres  (encoder/motion.cpp:923-1140 HEX, :1644-1773 with the lowres branch :1667-1699)
+ *   - MotionEstimate::motionEstimate, ref->isLowres  (encoder/motion.cpp:923-1140 HEX, :1142-1326 UMH as an --hme level runs it, :1644-1773 with the lowres branch :1667-1699)
  *   - ReferencePlanes::lowresMC / lowresQPelCost     (common/lowres.h:75-124)
  *   - Lookahead::estimateCUPropagate + propagateCost  (encoder/slicetype.cpp:3850-3953, common/pixel.cpp:906-931)
  * built on the primitive restatements of x265_oracle.c.  Pinned against the REAL reference classes
@@ -100,6 +101,9 @@ typedef struct
     const xo_pixel* plane[4]; intptr_t stride;    /* block origin inside the four half-pel planes (0 = full, 1 = H, 2 = V, 3 = HV) */
     xo_pixel fenc[CU * CU];
     const uint16_t* cost; mv_t mvp;
+    /* the final zero-MV check (motion.cpp:1763-1768) goes through subpelCompare, which reads ReferencePlanes::fpelPlane[0] with lumaStride whatever the level: on the
+       quarter-resolution level of --hme that is the HALF-resolution plane at the quarter-resolution block offset.  zero == NULL: plane[0] / stride. */
+    const xo_pixel* zero; intptr_t zeroStride;
 } la_t;
 
 static const xo_pixel* lowres_mc(const la_t* m, int qx, int qy, xo_pixel* buf, intptr_t* outStride)
@@ -131,8 +135,82 @@ static const mv_t hex2[8] = { {-1,-2}, {-2,0}, {-1,2}, {1,2}, {2,0}, {1,-2}, {-1
 static const unsigned char mod6m1[8] = { 5, 0, 1, 2, 3, 4, 5, 0 };
 static const mv_t square1[9] = { {0,0}, {0,-1}, {0,1}, {-1,0}, {1,0}, {-1,-1}, {-1,1}, {1,-1}, {1,1} };
 
-/* motionEstimate for a lowres reference: no candidates, hexagon search, subme 1 (slicetype.cpp:4496-4499 setSourcePU) */
-static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, mv_t* out)
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int in_range(mv_t v, mv_t mn, mv_t mx) { return v.x >= mn.x && v.x <= mx.x && v.y >= mn.y && v.y <= mx.y; }
+
+/* X265_UMH_SEARCH (motion.cpp:1142-1326) on an 8x8 lowres block: no motion candidates, so the range is never adapted (:1186).  Returns 0 when the search ends inside
+ * (the early terminations :1170-1183, or a best point out of range :1321-1322), 1 when it goes on into the hexagon search (`goto me_hex2`).
+ * The statement order, the strict `<` and the vertical-only range test of COST_MV_X4 follow x265_oracle_me.c's restatement of the same code. */
+static int lowres_umh(const la_t* m, mv_t mvmin, mv_t mvmax, mv_t pmv /* full-pel */, int merange, mv_t* bmvIO, int* bcostIO)
+{
+    static const mv_t hex4[16] = { {0,-4}, {0,4}, {-2,-3}, {2,-3}, {-4,-2}, {4,-2}, {-4,-1}, {4,-1},
+                                   {-4,0}, {4,0}, {-4,1}, {4,1}, {-4,2}, {4,2}, {-2,3}, {2,3} };       /* motion.cpp:67-73 */
+    const int scale = (CU * CU) >> 4;                                                              /* sizeScale[LUMA_8x8], :60-61,123-153 */
+    mv_t bmv = *bmvIO; int bcost = *bcostIO;
+#define SAD_THRESH(v) (bcost < (((v) >> 4) * scale))
+#define COST_MV(mx_, my_) do { const int c_ = sad_at(m, (mx_), (my_)) + mvcost(m, (mx_) * 4, (my_) * 4); if (c_ < bcost) { bcost = c_; bmv.x = (mx_); bmv.y = (my_); } } while (0)
+#define X4(ax, ay, bx_, by_, cx, cy, dx, dy) do { const mv_t d_[4] = { {ax, ay}, {bx_, by_}, {cx, cy}, {dx, dy} }; \
+        for (int k_ = 0; k_ < 4; k_++) { \
+            const int c_ = sad_at(m, omv.x + d_[k_].x, omv.y + d_[k_].y) + mvcost(m, (omv.x + d_[k_].x) * 4, (omv.y + d_[k_].y) * 4); \
+            if ((omv.y + d_[k_].y >= mvmin.y) & (omv.y + d_[k_].y <= mvmax.y)) \
+                if (c_ < bcost) { bcost = c_; bmv.x = omv.x + d_[k_].x; bmv.y = omv.y + d_[k_].y; } } } while (0)
+#define DIA1(mx_, my_) do { omv.x = (mx_); omv.y = (my_); X4(0, -1, 0, 1, -1, 0, 1, 0); } while (0)
+#define CROSS(start, x_max, y_max) do { int i_ = (start); \
+        if ((x_max) <= imin(mvmax.x - omv.x, omv.x - mvmin.x)) for (; i_ < (x_max) - 2; i_ += 4) X4(i_, 0, -i_, 0, i_ + 2, 0, -i_ - 2, 0); \
+        for (; i_ < (x_max); i_ += 2) { if (omv.x + i_ <= mvmax.x) COST_MV(omv.x + i_, omv.y); if (omv.x - i_ >= mvmin.x) COST_MV(omv.x - i_, omv.y); } \
+        i_ = (start); \
+        if ((y_max) <= imin(mvmax.y - omv.y, omv.y - mvmin.y)) for (; i_ < (y_max) - 2; i_ += 4) X4(0, i_, 0, -i_, 0, i_ + 2, 0, -i_ - 2); \
+        for (; i_ < (y_max); i_ += 2) { if (omv.y + i_ <= mvmax.y) COST_MV(omv.x, omv.y + i_); if (omv.y - i_ >= mvmin.y) COST_MV(omv.x, omv.y - i_); } } while (0)
+    mv_t omv = bmv;
+    int ucost1 = bcost, ucost2, cross_start = 1, done = 0, hexToo = 0;
+    DIA1(pmv.x, pmv.y);
+    if (pmv.x | pmv.y) DIA1(0, 0);
+    ucost2 = bcost;
+    if ((bmv.x | bmv.y) && !(bmv.x == pmv.x && bmv.y == pmv.y)) DIA1(bmv.x, bmv.y);
+    if (bcost == ucost2) cross_start = 3;
+    omv = bmv;
+    if (bcost == ucost2 && SAD_THRESH(2000))
+    {
+        X4(0, -2, -1, -1, 1, -1, -2, 0);
+        X4(2, 0, -1, 1, 1, 1, 0, 2);
+        if (bcost == ucost1 && SAD_THRESH(500)) done = 1;
+        else if (bcost == ucost2)
+        {
+            const int range = (int16_t)((merange >> 1) | 1);
+            CROSS(3, range, range);
+            X4(-1, -2, 1, -2, -2, -1, 2, -1);
+            X4(-2, 1, 2, 1, -1, 2, 1, 2);
+            if (bcost == ucost2) done = 1;
+            cross_start = range + 2;
+        }
+    }
+    if (!done)
+    {
+        CROSS(cross_start, merange, merange >> 1);
+        X4(-2, -2, -2, 2, 2, -2, 2, 2);
+        omv = bmv;
+        int i = 1;
+        do
+            for (int j = 0; j < 16; j++)
+            {
+                const mv_t mv = { omv.x + hex4[j].x * i, omv.y + hex4[j].y * i };
+                if (in_range(mv, mvmin, mvmax)) COST_MV(mv.x, mv.y);
+            }
+        while (++i <= merange >> 2);
+        hexToo = in_range(bmv, mvmin, mvmax);
+    }
+#undef SAD_THRESH
+#undef COST_MV
+#undef X4
+#undef DIA1
+#undef CROSS
+    *bmvIO = bmv; *bcostIO = bcost;
+    return hexToo;
+}
+
+/* motionEstimate for a lowres reference: no candidates, subme 1 (slicetype.cpp:4483-4486 setSourcePU); the hexagon search, or -- an --hme level whose
+ * hmeSearchMethod says so (motion.cpp:1013) -- the uneven multi-hexagon search in front of it */
+static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, int umh, mv_t* out)
 {
     m->mvp = qmvp;
     const mv_t qmin = { mvmin.x * 4, mvmin.y * 4 }, qmax = { mvmax.x * 4, mvmax.y * 4 };
@@ -148,6 +226,10 @@ static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, mv
         if (cost < bcost) { bcost = cost; bmv.x = 0; int t = 0 < mvmax.y ? 0 : mvmax.y; bmv.y = t > mvmin.y ? t : mvmin.y; }
     }
     if (bcost == 0) { out->x = bmv.x * 4; out->y = bmv.y * 4; return mvcost(m, out->x, out->y); }
+    {
+        const mv_t fpmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };                              /* motion.cpp:1005 */
+        if (umh && !lowres_umh(m, mvmin, mvmax, fpmv, merange, &bmv, &bcost)) goto refine;
+    }
     /* hexagon search, motion.cpp:1041-1140 */
 #define INY(v) (((v) >= mvmin.y) & ((v) <= mvmax.y))
 #define X3(a, b, c) do { const mv_t d_[3] = { a, b, c }; for (int k_ = 0; k_ < 3; k_++) \
@@ -197,6 +279,7 @@ static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, mv
     }
 #undef X3
 #undef LT
+refine:
     /* motion.cpp:1644-1699 */
     if (bprecost < bcost) { bmv = bestpre; bcost = bprecost; }
     else { bmv.x *= 4; bmv.y *= 4; }
@@ -226,7 +309,7 @@ static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, mv
     }
     if (bmv.x | bmv.y)
     {   /* motion.cpp:1763-1768: subpelCompare at MV 0 = SATD against the full-pel plane */
-        const int cost = xo_satd(CU, CU, m->fenc, CU, m->plane[0], m->stride) + mvcost(m, 0, 0);
+        const int cost = (m->zero ? xo_satd(CU, CU, m->fenc, CU, m->zero, m->zeroStride) : xo_satd(CU, CU, m->fenc, CU, m->plane[0], m->stride)) + mvcost(m, 0, 0);
         if (cost <= bcost) { bmv.x = 0; bmv.y = 0; }
     }
 #undef INY
@@ -234,20 +317,74 @@ static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, mv
     return bcost;
 }
 
+/* the motion search of one list of one block (slicetype.cpp:4504-4573): reverse-order MV prediction, the candidate with the lowest SATD as MVP, motionEstimate, the
+ * zero-MV skip rule of B estimates.  fencMV / fencCost address the block inside the list's arrays (widthInCU entries per row); extra = the fifth candidate or NULL. */
+static void list_search(la_t* me, int cuX, int wcu, int lastRow, int bBidir, mv_t mvmin, mv_t mvmax, const mv_t* extra, int merange, int umh,
+                        int32_t* fencMV, int32_t* fencCost)
+{
+    mv_t mvc[5], mvp = { 0, 0 }; int numc = 0, skipCost = INT_MAX;
+#define MVC(o) do { mvc[numc].x = fencMV[2 * (o)]; mvc[numc].y = fencMV[2 * (o) + 1]; numc++; } while (0)
+    if (cuX < wcu - 1) MVC(1);
+    if (!lastRow)
+    {
+        MVC(wcu);
+        if (cuX > 0) MVC(wcu - 1);
+        if (cuX < wcu - 1) MVC(wcu + 1);
+    }
+#undef MVC
+    if (extra) mvc[numc++] = *extra;
+    if (numc)
+    {   /* :4541-4557 */
+        int mvpcost = COST_MAX;
+        for (int idx = 0; idx < numc; idx++)
+        {
+            const int cost = qpel_cost(me, mvc[idx].x, mvc[idx].y, 1);
+            if (cost < mvpcost) { mvpcost = cost; mvp = mvc[idx]; }
+            if (!(mvp.x | mvp.y) && bBidir) skipCost = cost;
+        }
+    }
+    mv_t out;
+    *fencCost = lowres_me(me, mvmin, mvmax, mvp, merange, umh, &out);
+    fencMV[0] = out.x; fencMV[1] = out.y;
+    if (skipCost < 64 && skipCost < *fencCost && bBidir) { *fencCost = skipCost; fencMV[0] = 0; fencMV[1] = 0; }
+}
+
 /* slicetype.cpp:4365-4463 (serial branch) + :4467-4640 */
-void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, const xo_pixel* const* ref0w, intptr_t stride,
-                          int wcu, int hcu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
-                          int doSearch0, int doSearch1, int rowsPerSlice, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
-                          int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
+void xo_lowres_frame_cost_hme(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, const xo_pixel* const* ref0w, intptr_t stride,
+                              int wcu, int hcu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
+                              int doSearch0, int doSearch1, int rowsPerSlice, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                              int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums, const xo_la_hme* hme)
 {
     const int bBidir = ref1 != NULL;
     const int doSearch[2] = { doSearch0, doSearch1 };
     int32_t* const mvs[2] = { mvs0, mvs1 };
     int32_t* const mvCosts[2] = { mvCosts0, mvCosts1 };
-    /* list 0 is SEARCHED in the weighted copy of p0 when weightsAnalyse made one (wfref0, :4474); the bidirectional average uses p0 itself */
+    /* list 0 is SEARCHED in the weighted copy of p0 when weightsAnalyse made one (wfref0, :4473; never on the quarter-resolution level); the bidirectional average uses p0 itself */
     const xo_pixel* const* const refs[2] = { ref0w ? ref0w : ref0, ref1 };
     int64_t costEst = 0, costEstAq = 0, intraMbs = 0;
-    const int lowresPenalty = 4, merange = 16;                                                   /* slicetype.h:337 s_merange */
+    const int lowresPenalty = 4, merange = hme ? hme->range[1] : 16;                             /* slicetype.h:337 s_merange; :4560 */
+    if (hme)
+    {   /* :4430-4439, estimateCUCost(..., hme = 1): the searches only, on the quarter-resolution pictures, into Lowres::lowerResMvs / lowerResMvCosts */
+        const xo_pixel* const* const refs4[2] = { hme->ref0, hme->ref1 };
+        for (int cuY = hme->hcu - 1; cuY >= 0; cuY--)
+            for (int cuX = hme->wcu - 1; cuX >= 0; cuX--)
+            {
+                const int cuXY = cuX + cuY * hme->wcu;
+                const intptr_t pel = CU * cuX + (intptr_t)CU * cuY * hme->stride;
+                la_t me;
+                me.stride = hme->stride; me.cost = costRowCentre;
+                for (int y = 0; y < CU; y++) memcpy(me.fenc + CU * y, hme->fenc + pel + y * hme->stride, CU * sizeof(xo_pixel));
+                const mv_t mvmin = { -cuX * CU - 8, -cuY * CU - 8 }, mvmax = { (hme->wcu - cuX - 1) * CU + 8, (hme->hcu - cuY - 1) * CU + 8 };
+                for (int i = 0; i < 1 + bBidir; i++)
+                {
+                    if (!doSearch[i]) continue;
+                    for (int k = 0; k < 4; k++) me.plane[k] = refs4[i][k] + pel;
+                    me.zero = (i ? ref1 : ref0)[0] + pel; me.zeroStride = stride;
+                    list_search(&me, cuX, hme->wcu, cuY == hme->hcu - 1, bBidir, mvmin, mvmax, NULL, hme->range[0], hme->method[0] == XO_ME_UMH,
+                                &hme->mvs[i][2 * cuXY], &hme->mvCosts[i][cuXY]);
+                }
+            }
+    }
     /* cooperative slices (--lookahead-slices, :1173-1176, 4347-4357): slice i covers rowsPerSlice block rows (the last one the remainder too) and
        starts its reverse sweep with lastRow = true, i.e. no predictor crosses its lower edge; the frame totals are the sums over the slices */
     const int rps = rowsPerSlice > 0 ? rowsPerSlice : hcu, nslices = hcu / rps;
@@ -259,9 +396,10 @@ void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref
         for (int cuX = wcu - 1; cuX >= 0; cuX--)
         {
             const int cuXY = cuX + cuY * wcu;
+            const int cuXY_4x4 = (cuX / 2) + (cuY / 2) * wcu / 2;                                /* :4479, as written there (not a position on the quarter-resolution grid) */
             const intptr_t pel = CU * cuX + (intptr_t)CU * cuY * stride;
             la_t me;
-            me.stride = stride; me.cost = costRowCentre;
+            me.stride = stride; me.cost = costRowCentre; me.zero = NULL; me.zeroStride = 0;
             for (int y = 0; y < CU; y++) memcpy(me.fenc + CU * y, fencPlane0 + pel + y * stride, CU * sizeof(xo_pixel));
             const mv_t mvmin = { -cuX * CU - 8, -cuY * CU - 8 }, mvmax = { (wcu - cuX - 1) * CU + 8, (hcu - cuY - 1) * CU + 8 };
             int bcost = COST_MAX, listused = 0;
@@ -275,35 +413,14 @@ void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref
                     continue;
                 }
                 for (int k = 0; k < 4; k++) me.plane[k] = refs[i][k] + pel;
-                /* reverse-order MV prediction (:4520-4536): right, below, below-left, below-right */
-                mv_t mvc[5], mvp = { 0, 0 }; int numc = 0, skipCost = INT_MAX;
-#define MVC(o) do { mvc[numc].x = fencMV[2 * (o)]; mvc[numc].y = fencMV[2 * (o) + 1]; numc++; } while (0)
-                if (cuX < wcu - 1) MVC(1);
-                if (!lastRow)
-                {
-                    MVC(wcu);
-                    if (cuX > 0) MVC(wcu - 1);
-                    if (cuX < wcu - 1) MVC(wcu + 1);
-                }
-#undef MVC
-                if (numc)
-                {   /* the candidate with the lowest SATD becomes the MVP (:4541-4556) */
-                    int mvpcost = COST_MAX;
-                    for (int idx = 0; idx < numc; idx++)
-                    {
-                        const int cost = qpel_cost(&me, mvc[idx].x, mvc[idx].y, 1);
-                        if (cost < mvpcost) { mvpcost = cost; mvp = mvc[idx]; }
-                        if (!(mvp.x | mvp.y) && bBidir) skipCost = cost;
-                    }
-                }
-                mv_t out;
-                *fencCost = lowres_me(&me, mvmin, mvmax, mvp, merange, &out);
-                fencMV[0] = out.x; fencMV[1] = out.y;
-                if (skipCost < 64 && skipCost < *fencCost && bBidir) { *fencCost = skipCost; fencMV[0] = 0; fencMV[1] = 0; }
+                mv_t extra; int haveExtra = 0;
+                if (hme && hme->mvCosts[i][cuXY_4x4] > 0)                                        /* :4532-4535: twice the quarter-resolution MV */
+                { extra.x = hme->mvs[i][2 * cuXY_4x4] * 2; extra.y = hme->mvs[i][2 * cuXY_4x4 + 1] * 2; haveExtra = 1; }
+                list_search(&me, cuX, wcu, lastRow, bBidir, mvmin, mvmax, haveExtra ? &extra : NULL, merange, hme && hme->method[1] == XO_ME_UMH, fencMV, fencCost);
                 if (*fencCost < bcost) { bcost = *fencCost; listused = i + 1; }
             }
             if (bBidir)
-            {   /* :4574-4592 */
+            {   /* :4577-4597 */
                 xo_pixel b0[CU * CU], b1[CU * CU], avg[CU * CU]; intptr_t s0, s1;
                 la_t r0 = me, r1 = me;
                 for (int k = 0; k < 4; k++) { r0.plane[k] = ref0[k] + pel; r1.plane[k] = ref1[k] + pel; }
@@ -334,6 +451,14 @@ void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref
         }
     }
     sums[0] = costEst; sums[1] = costEstAq; sums[2] = intraMbs;
+}
+void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, const xo_pixel* const* ref0w, intptr_t stride,
+                          int wcu, int hcu, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
+                          int doSearch0, int doSearch1, int rowsPerSlice, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                          int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
+{
+    xo_lowres_frame_cost_hme(fencPlane0, ref0, ref1, ref0w, stride, wcu, hcu, intraCost, invQscale, costRowCentre, doSearch0, doSearch1, rowsPerSlice, mvs0, mvCosts0, mvs1, mvCosts1,
+                             lowresCosts, rowSatds, sums, NULL);
 }
 
 /* ---- cuTree cost propagation of one picture (slicetype.cpp:3850-3953 estimateCUPropagate; pixel.cpp:906-931 propagateCost) ----

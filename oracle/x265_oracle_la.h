@@ -23,6 +23,22 @@ void xo_lowres_frame_cost(const xo_pixel* fencPlane0, const xo_pixel* const* ref
                           int widthInCU, int heightInCU, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
                           int doSearch0, int doSearch1, int rowsPerSlice /* 0 = one slice; Lookahead::m_numRowsPerSlice */, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
                           int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums);
+/* The same with --hme (slicetype.cpp:4430-4439, 4483-4575): the searches run on the quarter-resolution pictures first (Lowres::lowerResPlane, rows stride apart; the
+ * Lookahead::m_4x4Width x m_4x4Height grid; hmeRange[0], hmeSearchMethod[0]) into mvs / mvCosts of the searched lists (Lowres::lowerResMvs / lowerResMvCosts), then on the
+ * half-resolution ones (hmeRange[1], hmeSearchMethod[1]) with twice the quarter-resolution MV of block (cuX / 2) + (cuY / 2) * widthInCU / 2 as a fifth predictor candidate.
+ * method: XO_ME_HEX or XO_ME_UMH (x265_oracle_me.h).  hme == NULL: xo_lowres_frame_cost. */
+typedef struct xo_la_hme
+{
+    const xo_pixel* fenc;                         /* lowerResPlane[0] of picture b, pixel (0,0) */
+    const xo_pixel* const* ref0; const xo_pixel* const* ref1;     /* the four lowerResPlane of p0 / p1 (ref1 unused in a P estimate) */
+    intptr_t stride; int wcu, hcu;
+    int method[2], range[2];
+    int32_t* mvs[2]; int32_t* mvCosts[2];
+} xo_la_hme;
+void xo_lowres_frame_cost_hme(const xo_pixel* fencPlane0, const xo_pixel* const* ref0, const xo_pixel* const* ref1, const xo_pixel* const* ref0w, intptr_t stride,
+                              int widthInCU, int heightInCU, const int32_t* intraCost, const int32_t* invQscale, const uint16_t* costRowCentre,
+                              int doSearch0, int doSearch1, int rowsPerSlice, int32_t* mvs0, int32_t* mvCosts0, int32_t* mvs1, int32_t* mvCosts1,
+                              int32_t* lowresCosts, int32_t* rowSatds, int64_t* sums, const xo_la_hme* hme);
 /* cuTree (slicetype.cpp:3850-3953): propagate the cost of picture b into its references; see x265_oracle_la.c */
 void xo_cu_propagate_cost(int32_t* dst, const uint16_t* propagateIn, const int32_t* intraCosts, const uint16_t* interCosts,
                           const int32_t* invQscales, double fpsFactor, int len);

@@ -54,6 +54,11 @@ class Geometry:
         self.plane_elems = self.stride * self.rows
         self.origin = self.stride * MARGIN_Y + MARGIN_X
         self.ncu = self.wcu * self.hcu
+        # --hme: the quarter-resolution planes (lowres.cpp:171-188: rows lumaStride / 2 apart, planesize / 2 pixels, pixel (0,0) at padoffset / 2) on the
+        # Lookahead::m_4x4Width x m_4x4Height grid (slicetype.cpp:1112-1113)
+        self.stride4, self.plane_elems4, self.origin4 = self.stride // 2, self.plane_elems // 2, self.origin // 2
+        self.wcu4, self.hcu4 = (W // 4 + 7) >> 3, (H // 4 + 7) >> 3
+        self.ncu4 = self.wcu4 * self.hcu4
 
 
 def pad_full(ora, frame, g):
@@ -76,6 +81,29 @@ def lowres_planes_oracle(ora, frame, g):
     return np.stack([ora.extend_pic_border(p, g.stride, g.lw, g.lh, MARGIN_X, MARGIN_Y) for p in z])
 
 
+def lowerres_planes_oracle(ora, planes, g):
+    """Lowres::init with --hme (lowres.cpp:393-403): frameInitLowerRes of the full-pel lowres plane + extendPicBorder by half the margins -> array [4, plane_elems4]"""
+    z = [np.zeros(g.plane_elems4, planes.dtype) for _ in range(4)]
+    dst = [p[g.origin4:] for p in z]
+    ip = C.c_ssize_t
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    ora.lib.xo_frame_init_lowres(P(planes[0][g.origin:]), P(dst[0]), P(dst[1]), P(dst[2]), P(dst[3]), ip(g.stride), ip(g.stride4), g.lw // 2, g.lh // 2)
+    # pixel (0,0) sits MARGIN_Y rows (not MARGIN_Y / 2) below the start of the plane: the rows above the extended border stay zero
+    skip = (MARGIN_Y - MARGIN_Y // 2) * g.stride4
+    assert g.origin4 == skip + (MARGIN_Y // 2) * g.stride4 + MARGIN_X // 2
+    out = []
+    for p in z:
+        q = p.copy()
+        q[skip:] = ora.extend_pic_border(p[skip:].copy(), g.stride4, g.lw // 2, g.lh // 2, MARGIN_X // 2, MARGIN_Y // 2)
+        out.append(q)
+    return np.stack(out)
+
+
+class XoLaHme(C.Structure):
+    _fields_ = [("fenc", C.c_void_p), ("ref0", C.c_void_p), ("ref1", C.c_void_p), ("stride", C.c_ssize_t), ("wcu", C.c_int), ("hcu", C.c_int),
+                ("method", C.c_int * 2), ("range", C.c_int * 2), ("mvs", C.c_void_p * 2), ("mvCosts", C.c_void_p * 2)]
+
+
 def _P(a, off=0):
     return C.c_void_p(a.ctypes.data + off * a.itemsize)
 
@@ -93,8 +121,10 @@ def lookahead_cost_row(ora, half=1 << 13):
     return ora.mvcost_row(int(ora.me_lib.xo_lookahead_qp()), half), half
 
 
-def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost, inv_q, state=None, do_search=(1, 1), ref0w_planes=None, rows_per_slice=0):
-    """state = dict(mvs0, mvc0, mvs1, mvc1) carried between estimates that share a reference distance (in/out)"""
+def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost, inv_q, state=None, do_search=(1, 1), ref0w_planes=None, rows_per_slice=0, hme=None):
+    """state = dict(mvs0, mvc0, mvs1, mvc1) carried between estimates that share a reference distance (in/out).
+    hme = dict(fenc, ref0, ref1 (quarter-resolution plane arrays [4, plane_elems4]; ref1 None in a P estimate), method (m0, m1), range (r0, r1)): the --hme sweep;
+    the result then carries lmvs0 / lmvc0 / lmvs1 / lmvc1 (Lowres::lowerResMvs / lowerResMvCosts of the searched lists)"""
     L = ora.me_lib
     row, half = lookahead_cost_row(ora)
     st = state if state is not None else {}
@@ -105,22 +135,35 @@ def oracle_frame_cost(ora, fenc_planes, ref0_planes, ref1_planes, g, intra_cost,
     r0 = VP(*[ref0_planes[k].ctypes.data + g.origin * ref0_planes.itemsize for k in range(4)])
     r1 = VP(*[ref1_planes[k].ctypes.data + g.origin * ref1_planes.itemsize for k in range(4)]) if ref1_planes is not None else None
     rw = VP(*[ref0w_planes[k].ctypes.data + g.origin * ref0w_planes.itemsize for k in range(4)]) if ref0w_planes is not None else None
-    L.xo_lowres_frame_cost(_P(fenc_planes[0], g.origin), r0, r1, rw, C.c_ssize_t(g.stride), g.wcu, g.hcu, _P(intra_cost),
-                           _P(inv_q) if inv_q is not None else None, _P(row, half), int(do_search[0]), int(do_search[1]), int(rows_per_slice),
-                           _P(st["mvs0"]), _P(st["mvc0"]), _P(st["mvs1"]), _P(st["mvc1"]), _P(lc), _P(rs), _P(sums))
-    return dict(mvs0=st["mvs0"].copy(), mvc0=st["mvc0"].copy(), mvs1=st["mvs1"].copy(), mvc1=st["mvc1"].copy(), lowresCosts=lc, rowSatds=rs,
+    hs, low = None, {}
+    if hme is not None:
+        for k, n in (("lmvs0", 2 * g.ncu4), ("lmvc0", g.ncu4), ("lmvs1", 2 * g.ncu4), ("lmvc1", g.ncu4)):
+            low[k] = np.zeros(n, np.int32)
+        q0 = VP(*[hme["ref0"][k].ctypes.data + g.origin4 * hme["ref0"].itemsize for k in range(4)])
+        q1 = VP(*[hme["ref1"][k].ctypes.data + g.origin4 * hme["ref1"].itemsize for k in range(4)]) if hme.get("ref1") is not None else None
+        hs = XoLaHme(hme["fenc"][0].ctypes.data + g.origin4 * hme["fenc"].itemsize, C.cast(q0, C.c_void_p), C.cast(q1, C.c_void_p) if q1 is not None else None, g.stride4, g.wcu4, g.hcu4,
+                     (C.c_int * 2)(*hme["method"]), (C.c_int * 2)(*hme["range"]), (C.c_void_p * 2)(low["lmvs0"].ctypes.data, low["lmvs1"].ctypes.data),
+                     (C.c_void_p * 2)(low["lmvc0"].ctypes.data, low["lmvc1"].ctypes.data))
+    L.xo_lowres_frame_cost_hme(_P(fenc_planes[0], g.origin), r0, r1, rw, C.c_ssize_t(g.stride), g.wcu, g.hcu, _P(intra_cost),
+                               _P(inv_q) if inv_q is not None else None, _P(row, half), int(do_search[0]), int(do_search[1]), int(rows_per_slice),
+                               _P(st["mvs0"]), _P(st["mvc0"]), _P(st["mvs1"]), _P(st["mvc1"]), _P(lc), _P(rs), _P(sums), C.byref(hs) if hs is not None else None)
+    return dict(low, mvs0=st["mvs0"].copy(), mvc0=st["mvc0"].copy(), mvs1=st["mvs1"].copy(), mvc1=st["mvc1"].copy(), lowresCosts=lc, rowSatds=rs,
                 costEst=int(sums[0]), costEstAq=int(sums[1]), intraMbs=int(sums[2]))
 
 
-def run_reference(depth, frames, triples, aq):
-    """oracle/_ref/x265la_<depth> on the clip -> (header dict, per-frame dicts, per-triple dicts)"""
+def run_reference(depth, frames, triples, aq, hme=None):
+    """oracle/_ref/x265la_<depth> on the clip -> (header dict, per-frame dicts, per-triple dicts); hme = (method0, method1, range0, range1) turns --hme on"""
     H, W = frames[0].shape
     with tempfile.TemporaryDirectory() as td:
         inp, out = os.path.join(td, "in.raw"), os.path.join(td, "out.bin")
         np.stack(frames).tofile(inp)
         args = [la_bin(depth), str(W), str(H), str(len(frames)), inp, out, str(int(aq))] + \
                [("prop:" + ",".join(str(v) for v in t[1:])) if t[0] == "prop" else ",".join(str(v) for v in t) for t in triples]
-        r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+        env = dict(os.environ)
+        env.pop("X265LA_HME", None)
+        if hme is not None:
+            env["X265LA_HME"] = ",".join(str(int(v)) for v in hme)
+        r = subprocess.run(args, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         d = open(out, "rb").read()
     recs, off = [], 0
@@ -129,16 +172,24 @@ def run_reference(depth, frames, triples, aq):
         recs.append(np.frombuffer(d, np.int32, n, off).copy()); off += 4 * n
     h = recs[0]
     hdr = dict(W=h[0], H=h[1], N=h[2], stride=h[3], lw=h[4], lh=h[5], wcu=h[6], hcu=h[7], mx=h[8], my=h[9], depth=h[10], qg=h[11], bframes=h[12])
+    if hme is not None:
+        hdr["wcu4"], hdr["hcu4"] = h[13], h[14]
     i, per_frame, per_triple = 1, [], []
     for _ in frames:
-        per_frame.append(dict(planes=np.stack(recs[i:i + 4]), intraCost=recs[i + 4], intraMode=recs[i + 5], lowresCosts=recs[i + 6], rowSatds=recs[i + 7],
-                              invQ=recs[i + 8]))
-        i += 9
+        fr = dict(planes=np.stack(recs[i:i + 4]))
+        i += 4
+        if hme is not None:
+            fr["lowerPlanes"] = np.stack(recs[i:i + 4]); i += 4
+        fr.update(intraCost=recs[i], intraMode=recs[i + 1], lowresCosts=recs[i + 2], rowSatds=recs[i + 3], invQ=recs[i + 4])
+        per_frame.append(fr)
+        i += 5
     for tr in triples:
         t = recs[i]
         d = dict(p0=t[0], b=t[1], p1=t[2], keep=t[3], doSearch=(t[4], t[5]), score=t[6], costEstNorm=t[7], costEstAq=t[8], intraMbs=t[9],
                  mvs0=recs[i + 1], mvc0=recs[i + 2], mvs1=recs[i + 3], mvc1=recs[i + 4], lowresCosts=recs[i + 5], rowSatds=recs[i + 6])
         i += 7
+        if hme is not None:
+            d.update(lmvs0=recs[i], lmvc0=recs[i + 1], lmvs1=recs[i + 2], lmvc1=recs[i + 3]); i += 4
         if int(aq) & 2:                          # weightp: flag, then the four weighted planes when weightsAnalyse chose weights
             d["isWeighted"] = int(recs[i][0]); i += 1
             if d["isWeighted"]:

@@ -56,9 +56,22 @@ def test_both_seams_together(depth, args, tmp_path):
     assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
 
 
-def test_hme_keeps_the_encoders_own_lookahead(tmp_path):
-    """--hme is not offered by the producer: the adapter forwards those estimates to the encoder's own body (counted), the intra estimates still come from the GPU"""
-    args = ["960", "544", "5", "superfast", "hme=1"]          # (the encoder switches HME off below 540 lines, encoder.cpp:4799-4806)
+# --hme: the encoder switches it off below 540 lines (encoder.cpp:4799-4806), and below 720 lines the lookahead has no cooperative slices (slicetype.cpp:1165-1169)
+@pytest.mark.parametrize("depth,args", [(8, ["960", "544", "6", "superfast", "hme=1"]),                                   # hme-search hex,umh,umh; hme-range 16,32,48
+                                        (8, ["960", "544", "6", "faster", "hme=1", "hme-search=umh,hex,hex", "hme-range=24,24,32", "bframes=3", "b-adapt=2"]),
+                                        (10, ["960", "544", "5", "superfast", "hme=1", "hme-search=hex"])])
+def test_bitstream_identical_with_gpu_hme_lookahead(depth, args, tmp_path):
+    """--hme: the quarter-resolution sweep runs on the GPU too (x265hip_la_enable_hme + x265hip_la_estimate_desc.hme); Lowres::lowerResMvs / lowerResMvCosts come back"""
+    cpu, h_cpu = encode(depth, False, False, False, args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(depth, True, False, False, args, str(tmp_path / "gpu.hevc"))
+    assert gpu["la_estimates"] > 0 and gpu["la_cpu_estimates"] == 0, "the GPU lookahead did not run: %s" % gpu
+    assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
+
+
+def test_hme_levels_the_producer_lacks_stay_with_the_encoder(tmp_path):
+    """an --hme level searched with a method the producer does not offer (star, sea, full, dia): the adapter forwards those estimates to the encoder's own body (counted), the
+    intra estimates still come from the GPU"""
+    args = ["960", "544", "4", "superfast", "hme=1", "hme-search=star,hex,hex"]
     cpu, h_cpu = encode(8, False, False, False, args, str(tmp_path / "cpu.hevc"))
     gpu, h_gpu = encode(8, True, False, False, args, str(tmp_path / "gpu.hevc"))
     assert gpu["la_estimates"] == 0 and gpu["la_cpu_estimates"] > 0

@@ -242,3 +242,75 @@ def test_cutree_finish_matches_oracle(depth):
         got = d_out.cpu().numpy()
         assert np.array_equal(got == -777.0, exp == -777.0) and (exp == -777.0).sum() > 20
         assert np.max(np.abs(got - exp)) <= 1e-12, np.max(np.abs(got - exp))
+
+
+# --hme: (method of the quarter-resolution level, method of the half-resolution level, their ranges); 1 = hexagon, 2 = uneven multi-hexagon (the reference's default: hex, umh, 16, 32)
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,aq,shift,hme", [((192, 144), 0, (3, 2), (1, 2, 16, 32)), ((208, 120), 1, (-6, 4), (2, 2, 16, 32)), ((320, 176), 1, (12, -8), (1, 1, 8, 12)),
+                                               ((136, 72), 0, (-5, 9), (2, 1, 24, 48)), ((64, 48), 1, (1, 0), (1, 2, 16, 32)), ((960, 544), 1, (14, -6), (1, 2, 16, 32))])
+def test_hme_lookahead_batch_matches_oracle(depth, size, aq, shift, hme):
+    """x265hip_lookahead_cost_batch_hme against the restated --hme sweep (oracle xo_lowres_frame_cost_hme, pinned to the reference by test_lookahead_oracle_vs_ref.py): the
+    quarter-resolution MVs / costs (Lowres::lowerResMvs / lowerResMvCosts) and everything the half-resolution sweep leaves, identical"""
+    from lookahead_util import lowerres_planes_oracle
+    api, ora = FrameApi(depth), Oracle(depth)
+    t = api.torch
+    W, H = size
+    N = 4
+    frames = synth_clip(W, H, N, depth, seed=700 + depth + W, shift=shift)
+    g = Geometry(W, H)
+    planes = [lowres_planes_oracle(ora, f, g) for f in frames]
+    lower = [lowerres_planes_oracle(ora, p, g) for p in planes]
+    view = np.uint8 if depth == 8 else np.int16
+    d_low = api.to_device(np.stack(planes).reshape(-1).view(view)); d_low4 = api.to_device(np.stack(lower).reshape(-1).view(view))
+    rng = np.random.default_rng(17 + W)
+    inv_q = rng.integers(160, 360, (N, g.ncu)).astype(np.int32) if aq else None
+    d_invq = api.to_device(inv_q.reshape(-1)) if aq else None
+    intra = [oracle_intra(ora, planes[f], g, inv_q[f] if aq else None) for f in range(N)]
+    d_ic = api.to_device(np.stack([it["intraCost"] for it in intra]).reshape(-1))
+    row, half = lookahead_cost_row(ora)
+    d_row = api.to_device(row.view(np.int16))
+    est = [(0, 1, 1), (0, 2, 2), (0, 1, 2), (1, 2, 3), (0, 1, 3), (2, 3, 3)]
+    tasks = np.zeros(len(est), LA_TASK)
+    nslot = 0
+    for i, (p0, b, p1) in enumerate(est):
+        tasks[i]["p0"], tasks[i]["b"], tasks[i]["p1"] = p0, b, p1
+        tasks[i]["doSearch"] = (1, 1 if p1 > b else 0)
+        tasks[i]["mvSlot"] = (nslot, nslot + 1 if p1 > b else 0)
+        nslot += 2 if p1 > b else 1
+        tasks[i]["outSlot"] = i
+    est2 = [(0, 2, 3)]                                  # list 0 (and its quarter-resolution MVs) as the P estimate (0,2,2) left them
+    tasks2 = np.zeros(1, LA_TASK)
+    tasks2[0]["p0"], tasks2[0]["b"], tasks2[0]["p1"] = est2[0]
+    tasks2[0]["doSearch"] = (0, 1); tasks2[0]["mvSlot"] = (int(tasks[1]["mvSlot"][0]), nslot); tasks2[0]["outSlot"] = len(est)
+    nslot += 1
+    nout = len(est) + 1
+    d_mvs = t.full((nslot * g.ncu * 2,), 0x7fff, dtype=t.int16, device="cuda"); d_mvc = t.full((nslot * g.ncu,), -1, dtype=t.int32, device="cuda")
+    d_mvs4 = t.full((nslot * g.ncu4 * 2,), 0x7fff, dtype=t.int16, device="cuda"); d_mvc4 = t.full((nslot * g.ncu4,), -1, dtype=t.int32, device="cuda")
+    d_lc = t.zeros(nout * g.ncu, dtype=t.int16, device="cuda"); d_rs = t.full((nout * g.hcu,), -7, dtype=t.int32, device="cuda"); d_sm = t.full((nout * 3,), -7, dtype=t.int64, device="cuda")
+    for tk in (tasks, tasks2):
+        d_tasks = api.to_device(tk)
+        api.lookahead_cost_batch_hme(d_low, g.plane_elems, g.stride, g.origin, g.wcu, g.hcu, d_tasks, len(tk), d_ic, d_invq, d_row, half, d_mvs, d_mvc, d_lc, d_rs, d_sm,
+                                     d_low4, g.plane_elems4, g.stride4, g.origin4, g.wcu4, g.hcu4, hme[:2], hme[2:], d_mvs4, d_mvc4)
+        t.cuda.synchronize()
+    mvs = d_mvs.cpu().numpy().reshape(nslot, g.ncu * 2).astype(np.int32); mvc = d_mvc.cpu().numpy().reshape(nslot, g.ncu)
+    mvs4 = d_mvs4.cpu().numpy().reshape(nslot, g.ncu4 * 2).astype(np.int32); mvc4 = d_mvc4.cpu().numpy().reshape(nslot, g.ncu4)
+    lc = d_lc.cpu().numpy().view(np.uint16).reshape(nout, g.ncu); rs = d_rs.cpu().numpy().reshape(nout, g.hcu); sm = d_sm.cpu().numpy().reshape(nout, 3)
+    results = {}
+    for tk in list(tasks) + list(tasks2):
+        p0, b, p1 = int(tk["p0"]), int(tk["b"]), int(tk["p1"])
+        do = (int(tk["doSearch"][0]), int(tk["doSearch"][1]))
+        st = {}
+        if not do[0]:
+            st["mvs0"], st["mvc0"] = results[(0, 2, 2)]["mvs0"].copy(), results[(0, 2, 2)]["mvc0"].copy()
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], inv_q[b] if aq else None, st, do,
+                              hme=dict(fenc=lower[b], ref0=lower[p0], ref1=lower[p1] if p1 > b else None, method=hme[:2], range=hme[2:]))
+        results[(p0, b, p1)] = o
+        what = "estimate (%d,%d,%d)" % (p0, b, p1)
+        for l in range(2 if p1 > b else 1):
+            s = int(tk["mvSlot"][l])
+            if do[l]:
+                assert np.array_equal(mvs4[s], o["lmvs%d" % l]) and np.array_equal(mvc4[s], o["lmvc%d" % l]), "quarter-resolution list %d of %s" % (l, what)
+            assert np.array_equal(mvs[s], o["mvs%d" % l]) and np.array_equal(mvc[s], o["mvc%d" % l]), "list-%d MVs / costs of %s" % (l, what)
+        out = int(tk["outSlot"])
+        assert np.array_equal(lc[out], o["lowresCosts"]) and np.array_equal(rs[out], o["rowSatds"]), "lowresCosts / rowSatds of " + what
+        assert [int(v) for v in sm[out]] == [o["costEst"], o["costEstAq"], o["intraMbs"]], "totals of " + what

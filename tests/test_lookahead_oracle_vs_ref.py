@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from backends import Oracle
-from lookahead_util import (Geometry, la_available, lowres_planes_oracle, oracle_frame_cost, oracle_intra, oracle_propagate, run_reference, synth_clip)
+from lookahead_util import (Geometry, la_available, lowerres_planes_oracle, lowres_planes_oracle, oracle_frame_cost, oracle_intra, oracle_propagate, run_reference, synth_clip)
 
 # (p0, b, p1, keep): P estimates, B estimates, and one B estimate that reuses the list-0 search a P estimate cached
 TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3, 0), (0, 2, 3, 1), (0, 3, 3, 0), (0, 1, 3, 0)]
@@ -173,3 +173,52 @@ def test_lookahead_cost_with_slices_matches_reference(depth, size, rows, aq):
         assert (norm, o["costEstAq"]) == (rt["costEstNorm"], rt["costEstAq"])
         if p1 == b:
             assert o["intraMbs"] == rt["intraMbs"]
+
+
+# --hme (slicetype.cpp:4430-4439, 4483-4575): (method of the quarter-resolution level, method of the half-resolution level, their ranges); 1 = hexagon, 2 = uneven multi-hexagon
+HME_TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3, 0), (0, 3, 3, 0), (0, 1, 3, 0)]
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,aq,shift,hme", [((192, 144), 0, (3, 2), (1, 2, 16, 32)), ((208, 120), 1, (-6, 4), (2, 2, 16, 32)), ((320, 176), 1, (12, -8), (1, 1, 8, 12)),
+                                               ((136, 72), 0, (-5, 9), (2, 1, 24, 48)), ((64, 48), 1, (1, 0), (1, 2, 16, 32))])
+def test_hme_lookahead_cost_matches_reference(depth, size, aq, shift, hme):
+    if not la_available(depth):
+        pytest.skip("no reference lookahead binary")
+    W, H = size
+    frames = synth_clip(W, H, 4, depth, seed=900 + depth + W, shift=shift)
+    hdr, ref_frames, ref_triples = run_reference(depth, frames, HME_TRIPLES, aq, hme=hme)
+    ora = Oracle(depth)
+    g = Geometry(W, H)
+    assert (g.wcu4, g.hcu4) == (hdr["wcu4"], hdr["hcu4"])
+    planes, lower, intra = [], [], []
+    for f, fr in enumerate(frames):
+        pl = lowres_planes_oracle(ora, fr, g)
+        lo = lowerres_planes_oracle(ora, pl, g)
+        assert np.array_equal(pl.astype(np.int32), ref_frames[f]["planes"]), "lowres planes of frame %d" % f
+        assert np.array_equal(lo.astype(np.int32), ref_frames[f]["lowerPlanes"]), "quarter-resolution planes of frame %d" % f
+        planes.append(pl); lower.append(lo)
+        intra.append(oracle_intra(ora, pl, g, ref_frames[f]["invQ"] if aq else None))
+    cache = {}
+    for t, rt in zip(HME_TRIPLES, ref_triples):
+        p0, b, p1, keep = t
+        if not keep:
+            cache = {k: v for k, v in cache.items() if k[0] != b}
+        do = tuple(int(v) for v in rt["doSearch"])
+        st = {}
+        if not do[0]:
+            st["mvs0"], st["mvc0"] = (a.copy() for a in cache[(b, 0, b - p0)])
+        if p1 > b and not do[1]:
+            st["mvs1"], st["mvc1"] = (a.copy() for a in cache[(b, 1, p1 - b)])
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], ref_frames[b]["invQ"] if aq else None, st, do,
+                              hme=dict(fenc=lower[b], ref0=lower[p0], ref1=lower[p1] if p1 > b else None, method=hme[:2], range=hme[2:]))
+        for l in range(2 if p1 > b else 1):
+            if do[l]:
+                assert np.array_equal(o["lmvs%d" % l], rt["lmvs%d" % l]) and np.array_equal(o["lmvc%d" % l], rt["lmvc%d" % l]), "quarter-resolution list %d of estimate %s" % (l, t)
+        for k in ("mvs0", "mvc0", "lowresCosts", "rowSatds") + (("mvs1", "mvc1") if p1 > b else ()):
+            assert np.array_equal(o[k], rt[k]), "%s of estimate %s" % (k, t)
+        norm = o["costEst"] * 100 // 130 if p1 > b else o["costEst"]
+        assert (norm, o["costEstAq"]) == (rt["costEstNorm"], rt["costEstAq"]), "totals of estimate %s" % (t,)
+        cache[(b, 0, b - p0)] = (o["mvs0"], o["mvc0"])
+        if p1 > b:
+            cache[(b, 1, p1 - b)] = (o["mvs1"], o["mvc1"])

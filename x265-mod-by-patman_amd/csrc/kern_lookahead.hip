@@ -168,6 +168,9 @@ struct Blk
     int stride;
     const uint16_t* lcost; int mvpx, mvpy;   // MVD cost row in LDS (centred); it covers every |mv - mvp| a picture of this size can produce
     int lane;
+    // the final zero-MV check of motionEstimate (motion.cpp:1763-1768) goes through subpelCompare, which always reads ReferencePlanes::fpelPlane[0] with lumaStride: on the
+    // quarter-resolution level of --hme that is the HALF-resolution plane, at the quarter-resolution block offset.  zbase != NULL: the lane's row of that block (element offset zref).
+    const pixel* zbase; uint32_t zref;
 };
 __device__ __forceinline__ int mvcost(const Blk& c, int qx, int qy) { return (uint16_t)((int)c.lcost[qx - c.mvpx] + (int)c.lcost[qy - c.mvpy]); }   // bitcost.h:57
 // ReferencePlanes::lowresMC: half-pel positions are planes, quarter-pel positions the rounded average of two of them
@@ -208,8 +211,105 @@ __device__ __forceinline__ int k_sq(int i, int col)
     return (int)((v >> (2 * i)) & 3) - 1;
 }
 
-// MotionEstimate::motionEstimate for a lowres reference (no candidates, hexagon search, subme 1): returns the cost, MV in (ox, oy)
-__device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int mxy, int mvpx, int mvpy, int& ox, int& oy)
+// hex4 of the uneven multi-hexagon search (motion.cpp:67-73), packed (value + 4) per nibble
+__device__ __forceinline__ int k_hex4(int j, int col)
+{
+    const unsigned long long v = col ? 0x7766554433221180ull : 0x6280808080806244ull;
+    return (int)((v >> (4 * j)) & 15) - 4;
+}
+// X265_UMH_SEARCH up to its `goto me_hex2` (motion.cpp:1142-1326) for an 8x8 lowres block (no motion candidates: the range is never adapted) -- what --hme runs on the
+// half-resolution level by default (hmeSearchMethod[1]).  The same sequence as umh_stage of me_body.inc, on this kernel's evaluator; candidates the reference skips are
+// measured at the origin and ignored.  Returns whether the hexagon refinement follows.
+__device__ __forceinline__ bool lowres_umh(Blk& c, int px, int py, int merange, int mnx, int mny, int mxx, int mxy, int& bx, int& by, int& bcost)
+{
+    int ox = bx, oy = by;
+    constexpr int scale = (CU * CU) >> 4;                                  // sizeScale of the 8x8 PU (:60-61, 123-153)
+    auto sadThresh = [&](int v) { return bcost < (v >> 4) * scale; };
+    auto x4 = [&](int ax, int ay, int bx_, int by_, int cx, int cy, int dx, int dy) {      // COST_MV_X4 (:296-317): only the vertical range is tested
+        const int X[4] = { ox + ax, ox + bx_, ox + cx, ox + dx }, Y[4] = { oy + ay, oy + by_, oy + cy, oy + dy };
+        const int QX[4] = { X[0] * 4, X[1] * 4, X[2] * 4, X[3] * 4 }, QY[4] = { Y[0] * 4, Y[1] * 4, Y[2] * 4, Y[3] * 4 };
+        int C[4];
+        eval<4, false>(c, QX, QY, C);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+            const int cost = C[k] + mvcost(c, QX[k], QY[k]);
+            if ((Y[k] >= mny) & (Y[k] <= mxy) && cost < bcost) { bcost = cost; bx = X[k]; by = Y[k]; }
+        }
+    };
+    auto pair = [&](int xa, int ya, bool oka, int xb, int yb, bool okb) {                  // two COST_MV of one CROSS step
+        const int QX[2] = { (oka ? xa : ox) * 4, (okb ? xb : ox) * 4 }, QY[2] = { (oka ? ya : oy) * 4, (okb ? yb : oy) * 4 };
+        int C[2];
+        eval<2, false>(c, QX, QY, C);
+        const int c0 = C[0] + mvcost(c, QX[0], QY[0]), c1 = C[1] + mvcost(c, QX[1], QY[1]);
+        if (oka && c0 < bcost) { bcost = c0; bx = xa; by = ya; }
+        if (okb && c1 < bcost) { bcost = c1; bx = xb; by = yb; }
+    };
+    auto cross = [&](int start, int xMax, int yMax) {                                        // CROSS (:361-385)
+        int i = start;
+        if (xMax <= min(mxx - ox, ox - mnx))
+            for (; i < xMax - 2; i += 4) x4(i, 0, -i, 0, i + 2, 0, -i - 2, 0);
+        for (; i < xMax; i += 2) pair(ox + i, oy, ox + i <= mxx, ox - i, oy, ox - i >= mnx);
+        i = start;
+        if (yMax <= min(mxy - oy, oy - mny))
+            for (; i < yMax - 2; i += 4) x4(0, i, 0, -i, 0, i + 2, 0, -i - 2);
+        for (; i < yMax; i += 2) pair(ox, oy + i, oy + i <= mxy, ox, oy - i, oy - i >= mny);
+    };
+    const int ucost1 = bcost;                                              // refine predictors (:1147-1159)
+    int crossStart = 1;
+    ox = px; oy = py; x4(0, -1, 0, 1, -1, 0, 1, 0);
+    if (px | py) { ox = 0; oy = 0; x4(0, -1, 0, 1, -1, 0, 1, 0); }
+    const int ucost2 = bcost;
+    if ((bx | by) && !(bx == px && by == py)) { ox = bx; oy = by; x4(0, -1, 0, 1, -1, 0, 1, 0); }
+    if (bcost == ucost2) crossStart = 3;
+    ox = bx; oy = by;
+    if (bcost == ucost2 && sadThresh(2000))
+    {   // early termination (:1161-1180)
+        x4(0, -2, -1, -1, 1, -1, -2, 0);
+        x4(2, 0, -1, 1, 1, 1, 0, 2);
+        if (bcost == ucost1 && sadThresh(500)) return false;
+        if (bcost == ucost2)
+        {
+            const int range = (int16_t)(merange >> 1) | 1;
+            cross(3, range, range);
+            x4(-1, -2, 1, -2, -2, -1, 2, -1);
+            x4(-2, 1, 2, 1, -1, 2, 1, 2);
+            if (bcost == ucost2) return false;
+            crossStart = range + 2;
+        }
+    }
+    cross(crossStart, merange, merange >> 1);
+    x4(-2, -2, -2, 2, 2, -2, 2, 2);
+    ox = bx; oy = by;                                                      // hexagon grid (:1243-1320)
+    int i = 1;
+    do
+    {
+        for (int j0 = 0; j0 < 16; j0 += 4)
+        {
+            int X[4], Y[4], QX[4], QY[4], C[4]; bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int x = ox + k_hex4(j0 + k, 0) * i, y = oy + k_hex4(j0 + k, 1) * i;
+                ok[k] = x >= mnx && x <= mxx && y >= mny && y <= mxy;
+                X[k] = ok[k] ? x : ox; Y[k] = ok[k] ? y : oy; QX[k] = X[k] * 4; QY[k] = Y[k] * 4;
+            }
+            eval<4, false>(c, QX, QY, C);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const int cost = C[k] + mvcost(c, QX[k], QY[k]);
+                if (ok[k] && cost < bcost) { bcost = cost; bx = X[k]; by = Y[k]; }
+            }
+        }
+    }
+    while (++i <= merange >> 2);
+    return bx >= mnx && bx <= mxx && by >= mny && by <= mxy;               // `goto me_hex2` (:1323-1324)
+}
+
+// MotionEstimate::motionEstimate for a lowres reference (no candidates, subme 1; the hexagon search, or -- with --hme -- the level's method: hexagon or uneven
+// multi-hexagon, motion.cpp:1013): returns the cost, MV in (ox, oy)
+__device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int mxy, int mvpx, int mvpy, int& ox, int& oy, int merange = LA_MERANGE, bool umh = false)
 {
     c.mvpx = mvpx; c.mvpy = mvpy;
     const int qmnx = mnx * 4, qmny = mny * 4, qmxx = mxx * 4, qmxy = mxy * 4;
@@ -229,6 +329,10 @@ __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int 
     }
     if (bcost == 0) { ox = bx * 4; oy = by * 4; return mvcost(c, ox, oy); }
     auto inY = [&](int y) { return (y >= mny) & (y <= mxy); };
+    bool hexToo = true;
+    if (umh) hexToo = lowres_umh(c, (pmx + 2) >> 2, (pmy + 2) >> 2, merange, mnx, mny, mxx, mxy, bx, by, bcost);
+    if (hexToo)
+    {
     {   // hexagon search (motion.cpp:1041-1140)
         int X[6], Y[6], C[6];
 #pragma unroll
@@ -248,7 +352,7 @@ __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int 
         if (inY(by + k_hex2(dir + 1, 1)))
         {
             bx += k_hex2(dir + 1, 0); by += k_hex2(dir + 1, 1);
-            for (int i = (LA_MERANGE >> 1) - 1; i > 0 && bx >= mnx && bx <= mxx && inY(by); i--)
+            for (int i = (merange >> 1) - 1; i > 0 && bx >= mnx && bx <= mxx && inY(by); i--)
             {
                 int X[3], Y[3], C[3];
 #pragma unroll
@@ -280,6 +384,7 @@ __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int 
         }
         bx += k_sq(dir, 0); by += k_sq(dir, 1);
     }
+    }
     // motion.cpp:1644-1699
     int qx, qy;
     if (bprecost < bcost) { qx = pmx; qy = pmy; bcost = bprecost; }
@@ -301,6 +406,14 @@ __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int 
             if (cost < bcost) { bcost = cost; bdir = k + 1; }
         }
         qx += k_sq(bdir, 0) * 2; qy += k_sq(bdir, 1) * 2;
+        if (c.zbase)
+        {
+            const int X1[1] = { qx }, Y1[1] = { qy };
+            int C1[1];
+            eval<1, true>(c, X1, Y1, C1);
+            bcost = C1[0] + mvcost(c, qx, qy);
+        }
+        else
         {   // the zero-MV SATD of the final check rides along
             const int X2[2] = { qx, 0 }, Y2[2] = { qy, 0 };
             int C2[2];
@@ -322,7 +435,8 @@ __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int 
     }
     if (qx | qy)
     {   // motion.cpp:1763-1768 (the cost is NOT replaced when the zero MV wins)
-        if (zeroSatd < 0)
+        if (c.zbase) zeroSatd = satd_rows_pk(c.fenc, ld_row(c.zbase, c.zref), c.lane);
+        else if (zeroSatd < 0)
         {
             const int X1[1] = { 0 }, Y1[1] = { 0 };
             int C1[1];
@@ -353,8 +467,13 @@ __device__ __forceinline__ bool la_task_ok(const x265hip_la_task* tp, int nFrame
     return tp->p0 >= 0 && tp->p0 < nFrames && tp->b >= 0 && tp->b < nFrames && tp->p1 >= 0 && tp->p1 < nFrames && tp->p0 != tp->b && w0 >= 0 && w0 <= nFrames;
 }
 
+// --hme (slicetype.cpp:4430-4437, 4483-4575): the same sweep runs first on the quarter-resolution pictures (level 0: its own geometry g, range hmeRange[0], method
+// hmeSearchMethod[0], never the weighted copy) into its own MV / cost slots; the half-resolution sweep (level 1: hmeRange[1], hmeSearchMethod[1]) then takes twice the
+// level-0 MV of the block above it as a fifth predictor candidate.  hme5Mvs == NULL: no such candidate (no HME, or level 0 itself).  gz.lowres != NULL on level 0 only: the
+// half-resolution pictures, for the zero-MV check (Blk::zbase).
 __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, int nFrames, const uint16_t* __restrict__ costCentre, int costR, int rowsPerSlice,
-                                                         uint32_t* mvs, int32_t* mvCosts)
+                                                         uint32_t* mvs, int32_t* mvCosts, int merange, int umh, int useWeighted,
+                                                         const uint32_t* __restrict__ hme5Mvs, const int32_t* __restrict__ hme5Costs, int hme5N, LaGeom gz)
 {
     const x265hip_la_task* tp = tasks + (blockIdx.x >> 1);
     if (!la_task_ok(tp, nFrames)) return;
@@ -368,7 +487,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
     uint32_t* mv = mvs + (int64_t)slot * ncu;
     int32_t* mvCost = mvCosts + (int64_t)slot * ncu;
     const int w0 = tp->weighted0;
-    const int refFrame = list ? tp1 : (w0 > 0 ? w0 - 1 : tp0);
+    const int refFrame = list ? tp1 : ((w0 > 0 && useWeighted) ? w0 - 1 : tp0);
     extern __shared__ uint16_t s_cost[];                       // 2 * costR + 1 entries of the cost row
     for (int i = threadIdx.x; i <= 2 * costR; i += blockDim.x) s_cost[i] = costCentre[i - costR];
     __syncthreads();
@@ -392,25 +511,37 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
             c.lane = lane; c.stride = stride; c.base = g.lowres; c.lcost = s_cost + costR; c.mvpx = 0; c.mvpy = 0;
             c.fenc = ld_row(g.lowres, fencPlane + pel);
             c.ref0 = rp + pel; c.pe = (uint32_t)g.planeElems;
+            c.zbase = gz.lowres; c.zref = gz.lowres ? plane0_off(gz, list ? tp1 : tp0) + (uint32_t)(CU * cuX + __mul24(CU * cuY, stride) + __mul24(lane, (int)gz.stride)) : 0u;
             const int mnx = -cuX * CU - 8, mny = -cuY * CU - 8, mxx = (W - cuX - 1) * CU + 8, mxy = (H - cuY - 1) * CU + 8;
-            // reverse-order MV prediction (slicetype.cpp:4520-4536): right, below, below-left, below-right
-            const bool valid[4] = { cuX < W - 1, !lastRow, !lastRow && cuX > 0, !lastRow && cuX < W - 1 };
+            // reverse-order MV prediction (slicetype.cpp:4520-4536): right, below, below-left, below-right; with --hme twice the quarter-resolution MV (:4537-4540)
+            constexpr int NC = 5;
+            bool valid[NC] = { cuX < W - 1, !lastRow, !lastRow && cuX > 0, !lastRow && cuX < W - 1, false };
             const int where[4] = { 1, W, W - 1, W + 1 };
-            int X[4], Y[4];
+            int X[NC], Y[NC];
 #pragma unroll
             for (int k = 0; k < 4; k++)
             {
                 const uint32_t v = valid[k] ? ld_mv(mv + cuXY + where[k]) : 0u;
                 X[k] = (int16_t)(v & 0xffff); Y[k] = (int16_t)(v >> 16);
             }
+            X[4] = Y[4] = 0;
+            if (hme5Mvs)
+            {   // cuXY_4x4 = (cuX / 2) + (cuY / 2) * widthInCU / 2 -- with the HALF-resolution width, as the reference writes it
+                const int i4 = (cuX / 2) + ((cuY / 2) * W) / 2;
+                if (i4 < hme5N && hme5Costs[(int64_t)slot * hme5N + i4] > 0)
+                {
+                    const uint32_t v = hme5Mvs[(int64_t)slot * hme5N + i4];
+                    valid[4] = true; X[4] = 2 * (int)(int16_t)(v & 0xffff); Y[4] = 2 * (int)(int16_t)(v >> 16);
+                }
+            }
             int mvpx = 0, mvpy = 0, skipCost = 0x7fffffff;
-            if (valid[0] | valid[1])
+            if (valid[0] | valid[1] | valid[4])
             {   // the candidate with the lowest SATD becomes the predictor (:4541-4556).  Neighbours mostly agree: a candidate
                 // equal to an earlier one reuses its cost, and a slot nobody in the wavefront needs is skipped (uniform branches)
-                int C[4] = { 0, 0, 0, 0 };
-                bool need[4]; Row r[4];
+                int C[NC] = { 0, 0, 0, 0, 0 };
+                bool need[NC]; Row r[NC];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
+                for (int k = 0; k < NC; k++)
                 {
                     bool dup = false;
 #pragma unroll
@@ -419,7 +550,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
                     if (need[k]) r[k] = mc_row(c, X[k], Y[k]);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; k++)
+                for (int k = 0; k < NC; k++)
                 {
                     if (need[k]) C[k] = satd_rows_pk(c.fenc, r[k], lane);
 #pragma unroll
@@ -427,7 +558,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
                 }
                 int mvpcost = COST_MAX;
 #pragma unroll
-                for (int k = 0; k < 4; k++)
+                for (int k = 0; k < NC; k++)
                 {
                     if (!valid[k]) continue;
                     if (C[k] < mvpcost) { mvpcost = C[k]; mvpx = X[k]; mvpy = Y[k]; }
@@ -435,7 +566,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
                 }
             }
             int ox, oy;
-            int fencCost = lowres_me(c, mnx, mny, mxx, mxy, mvpx, mvpy, ox, oy);
+            int fencCost = lowres_me(c, mnx, mny, mxx, mxy, mvpx, mvpy, ox, oy, merange, umh != 0);
             if (skipCost < 64 && skipCost < fencCost && bidir) { fencCost = skipCost; ox = 0; oy = 0; }
             if (lane == 0)
             {
@@ -785,7 +916,26 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
                                             const uint16_t* costRow, int costHalfRange, int rowsPerSlice, int16_t* mvs, int32_t* mvCosts,
                                             uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums)
 {
+    return x265hip_lookahead_cost_batch_hme(stream, lowres, planeElems, stride, origin, widthInCU, heightInCU, tasks, nTasks, nFrames, intraCost, invQscale, costRow, costHalfRange,
+                                            rowsPerSlice, mvs, mvCosts, lowresCosts, rowSatds, sums, nullptr);
+}
+
+extern "C" int x265hip_lookahead_cost_batch_hme(void* stream, const void* lowres, int64_t planeElems, intptr_t stride, int64_t origin, int widthInCU, int heightInCU,
+                                                const x265hip_la_task* tasks, int nTasks, int nFrames, const int32_t* intraCost, const int32_t* invQscale,
+                                                const uint16_t* costRow, int costHalfRange, int rowsPerSlice, int16_t* mvs, int32_t* mvCosts,
+                                                uint16_t* lowresCosts, int32_t* rowSatds, int64_t* sums, const x265hip_la_hme* hme)
+{
     if (nTasks <= 0) return X265HIP_OK;
+    if (hme)
+    {
+        if (bad_geom(hme->lowerRes, hme->planeElems, hme->stride, hme->origin, hme->widthInCU, hme->heightInCU) || !hme->mvs || !hme->mvCosts || ((uintptr_t)hme->mvs & 3))
+        { set_error("lookahead_cost_batch_hme: bad quarter-resolution arguments"); return X265HIP_EARG; }
+        for (int l = 0; l < 2; l++)
+            if ((hme->method[l] != X265HIP_ME_HEX && hme->method[l] != X265HIP_ME_UMH) || hme->range[l] < 1 || hme->range[l] > 64)
+            { set_error("lookahead_cost_batch_hme: level %d: hexagon or uneven multi-hexagon search, range 1..64", l); return X265HIP_EARG; }
+        if (rowsPerSlice > 0 && rowsPerSlice < heightInCU) { set_error("lookahead_cost_batch_hme: the cooperative sweep is not offered with HME"); return X265HIP_EARG; }
+        if (((int64_t)nFrames) * 4 * hme->planeElems >= ((int64_t)1 << 31)) { set_error("lookahead_cost_batch_hme: quarter-resolution buffer beyond 2^31 elements"); return X265HIP_EARG; }
+    }
     if (nFrames <= 0) { set_error("lookahead_cost_batch: nFrames must be the number of pictures in the lowres buffer"); return X265HIP_EARG; }
     if (rowsPerSlice <= 0 || rowsPerSlice > heightInCU) rowsPerSlice = heightInCU;          // one slice
     if (bad_geom(lowres, planeElems, stride, origin, widthInCU, heightInCU) || !tasks || !intraCost || !costRow || !mvs || !mvCosts || !lowresCosts || !rowSatds || !sums)
@@ -815,7 +965,19 @@ extern "C" int x265hip_lookahead_cost_batch(void* stream, const void* lowres, in
     // four times as long as one.  Asking for 56 KB of LDS (of 160 KB per CU) caps the depth at two.
     static const size_t ldsPad = [] { const char* e = xh_experiment("X265HIP_LA_LDS"); long v = e ? atol(e) : 56 * 1024; return (size_t)(v < 0 ? 0 : v > 160 * 1024 ? 160 * 1024 : v); }();
     const size_t lds = std::max(sizeof(uint16_t) * (size_t)(2 * costR + 2), ldsPad);
-    hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts);
+    if (hme)
+    {   // level 0: the quarter-resolution sweep into its own slots (same slot numbers), one slice, never the weighted copy
+        const LaGeom g0 = { (const pixel*)hme->lowerRes, hme->planeElems, hme->stride, hme->origin, hme->widthInCU, hme->heightInCU };
+        const int widest0 = min(hme->heightInCU, (hme->widthInCU + 1) / 2), threads0 = min(1024, max(64, (widest0 * 8 + 63) / 64 * 64));
+        hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, 1), dim3(threads0), lds, st, g0, tasks, nFrames, costRow + costHalfRange, costR, hme->heightInCU, (uint32_t*)hme->mvs, hme->mvCosts,
+                           hme->range[0], hme->method[0] == X265HIP_ME_UMH, 0, (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, g);
+        XH_LAUNCH_CHECK();
+        hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts,
+                           hme->range[1], hme->method[1] == X265HIP_ME_UMH, 1, (const uint32_t*)hme->mvs, (const int32_t*)hme->mvCosts, hme->widthInCU * hme->heightInCU, LaGeom{});
+    }
+    else
+        hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts,
+                           LA_MERANGE, 0, 1, (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, LaGeom{});
     XH_LAUNCH_CHECK();
     hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, nFrames, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);

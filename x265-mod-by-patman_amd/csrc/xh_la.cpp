@@ -6,6 +6,7 @@
 #include "../../include/x265hip_ctx.h"
 #include <algorithm>
 #include <condition_variable>
+#include <cstring>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -23,7 +24,10 @@ struct x265hip_la
     uint8_t* intraMode = nullptr; uint16_t* intraLc = nullptr; int32_t* intraRows = nullptr; int64_t* intraSums = nullptr;      // one picture's worth (the one being estimated)
     uint16_t* costRow = nullptr;
     int16_t* mvs = nullptr; int32_t* mvCosts = nullptr; uint16_t* lc = nullptr; int32_t* rows = nullptr; int64_t* sums = nullptr; x265hip_la_task* task = nullptr;
-    struct Slot { uint64_t key = 0; uint64_t used = 0; };
+    // --hme: the quarter-resolution pictures (Lowres::lowerResBuffer[0]: four planes) at the same places, the level-0 MV / cost slots of a launch
+    bool hme = false; int wcu4 = 0, hcu4 = 0, ncu4 = 0; intptr_t stride4 = 0; int64_t planeElems4 = 0, origin4 = 0;
+    pixel* low4 = nullptr; int16_t* mvs4 = nullptr; int32_t* mvCosts4 = nullptr;
+    struct Slot { uint64_t key = 0; uint64_t used = 0; bool lower = false; };
     std::vector<Slot> slots; uint64_t tick = 0;
     std::mutex mu;                                // the device side: one call at a time on the context's stream
     // estimates that arrive while a launch is in flight are queued and go up together (x265hip_la_estimate)
@@ -67,6 +71,21 @@ extern "C" int x265hip_la_create(x265hip_ctx* ctx, int widthInCU, int heightInCU
     *out = a;
     return X265HIP_OK;
 }
+extern "C" int x265hip_la_enable_hme(x265hip_la* a, int widthInCU4, int heightInCU4, intptr_t stride4, int64_t planeElems4, int64_t origin4)
+{
+    if (!a || widthInCU4 < 1 || heightInCU4 < 1 || stride4 < widthInCU4 * 8 || planeElems4 < stride4 * heightInCU4 * 8 || origin4 < 0 || origin4 >= planeElems4)
+    { set_error("la_enable_hme: bad geometry"); return X265HIP_EARG; }
+    std::lock_guard<std::mutex> g(a->mu);
+    if (a->hme) return X265HIP_OK;
+    XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
+    const size_t np = (size_t)a->maxPics + kLaBatch;
+    if ((int64_t)np * 4 * planeElems4 >= ((int64_t)1 << 31)) { set_error("la_enable_hme: the quarter-resolution buffer does not fit 2^31 elements"); return X265HIP_EARG; }
+    a->wcu4 = widthInCU4; a->hcu4 = heightInCU4; a->ncu4 = widthInCU4 * heightInCU4; a->stride4 = stride4; a->planeElems4 = planeElems4; a->origin4 = origin4;
+    int rc;
+    if ((rc = a->alloc(a->low4, np * 4 * (size_t)planeElems4)) || (rc = a->alloc(a->mvs4, (size_t)kLaBatch * 2 * a->ncu4 * 2)) || (rc = a->alloc(a->mvCosts4, (size_t)kLaBatch * 2 * a->ncu4))) return rc;
+    a->hme = true;
+    return X265HIP_OK;
+}
 extern "C" void x265hip_la_destroy(x265hip_la* a)
 {
     if (!a) return;
@@ -78,7 +97,8 @@ extern "C" void x265hip_la_destroy(x265hip_la* a)
 
 namespace {
 // the picture's slot, uploading its planes (and AQ factors / intra costs when given) if it is not on the device yet; `pinned`: slots this call must not evict
-int ensure_picture(x265hip_la* a, hipStream_t st, uint64_t key, const void* planes4, const int32_t* invQscale, const int32_t* intraCost, const int* pinned, int nPinned, int* slotOut)
+int ensure_picture(x265hip_la* a, hipStream_t st, uint64_t key, const void* planes4, const int32_t* invQscale, const int32_t* intraCost, const int* pinned, int nPinned, int* slotOut,
+                   const void* lowerPlanes4 = nullptr)
 {
     if (!key) { set_error("la: picture key 0"); return X265HIP_EARG; }
     int s = a->find(key);
@@ -91,7 +111,7 @@ int ensure_picture(x265hip_la* a, hipStream_t st, uint64_t key, const void* plan
             for (int k = 0; k < nPinned; k++) pin |= pinned[k] == i;
             if (!pin && (s < 0 || a->slots[i].used < a->slots[s].used)) s = i;
         }
-        a->slots[s].key = 0;
+        a->slots[s].key = 0; a->slots[s].lower = false;
         XH_HIP(hipMemcpyAsync(a->low + (size_t)s * 4 * a->planeElems, planes4, (size_t)4 * a->planeElems * sizeof(pixel), hipMemcpyHostToDevice, st));
         if (invQscale) { XH_HIP(hipMemcpyAsync(a->invq + (size_t)s * a->ncu, invQscale, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st)); a->haveInvq = true; }
         if (intraCost) XH_HIP(hipMemcpyAsync(a->intraCost + (size_t)s * a->ncu, intraCost, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -102,6 +122,12 @@ int ensure_picture(x265hip_la* a, hipStream_t st, uint64_t key, const void* plan
     {   // the factors of a resident picture may have moved since (--aq-motion rewrites them during the slice-type analysis): they are small, send them again
         XH_HIP(hipMemcpyAsync(a->invq + (size_t)s * a->ncu, invQscale, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st)); a->haveInvq = true;
         XH_HIP(hipStreamSynchronize(st));
+    }
+    if (a->hme && lowerPlanes4 && !a->slots[s].lower)
+    {   // (the intra estimate brought the picture up without its quarter-resolution planes)
+        XH_HIP(hipMemcpyAsync(a->low4 + (size_t)s * 4 * a->planeElems4, lowerPlanes4, (size_t)4 * a->planeElems4 * sizeof(pixel), hipMemcpyHostToDevice, st));
+        XH_HIP(hipStreamSynchronize(st));
+        a->slots[s].lower = true;
     }
     a->slots[s].used = ++a->tick;
     *slotOut = s;
@@ -170,7 +196,9 @@ int run_batch(x265hip_la* a, Req* const* reqs, int n)
         for (int k : order)
         {
             if (k == 2 && !isB) { slot[2] = slot[1]; continue; }
-            if ((rc = ensure_picture(a, st, d->key[k], d->planes[k], k == 1 ? d->invQscale : nullptr, k == 1 ? d->intraCost : nullptr, pinned.data(), (int)pinned.size(), &slot[k]))) return rc;
+            if ((rc = ensure_picture(a, st, d->key[k], d->planes[k], k == 1 ? d->invQscale : nullptr, k == 1 ? d->intraCost : nullptr, pinned.data(), (int)pinned.size(), &slot[k],
+                                     d->hme ? d->lowerPlanes[k] : nullptr))) return rc;
+            if (d->hme && (!a->hme || !a->slots[slot[k]].lower)) { set_error("la_estimate: --hme estimate without x265hip_la_enable_hme / quarter-resolution planes"); return X265HIP_EARG; }
             pinned.push_back(slot[k]);
         }
         if (slot[0] == slot[1] || (isB && slot[2] == slot[1])) { set_error("la_estimate: the estimated picture is its own reference"); return X265HIP_EARG; }
@@ -192,10 +220,20 @@ int run_batch(x265hip_la* a, Req* const* reqs, int n)
     }
     // all estimates of a batch sweep the same way (the caller's workers belong to one lookahead)
     const int rowsPerSlice = reqs[0]->d->rowsPerSlice;
-    for (int i = 1; i < n; i++) if (reqs[i]->d->rowsPerSlice != rowsPerSlice) { set_error("la_estimate: concurrent estimates with different slice heights"); return X265HIP_EARG; }
+    const x265hip_la_estimate_desc* d0 = reqs[0]->d;
+    for (int i = 1; i < n; i++)
+        if (reqs[i]->d->rowsPerSlice != rowsPerSlice || reqs[i]->d->hme != d0->hme || (d0->hme && (memcmp(reqs[i]->d->hmeMethod, d0->hmeMethod, sizeof(d0->hmeMethod)) || memcmp(reqs[i]->d->hmeRange, d0->hmeRange, sizeof(d0->hmeRange)))))
+        { set_error("la_estimate: concurrent estimates with different sweep parameters"); return X265HIP_EARG; }
+    x265hip_la_hme H{};
+    if (d0->hme)
+    {
+        H.lowerRes = a->low4; H.planeElems = a->planeElems4; H.stride = a->stride4; H.origin = a->origin4; H.widthInCU = a->wcu4; H.heightInCU = a->hcu4;
+        H.method[0] = d0->hmeMethod[0]; H.method[1] = d0->hmeMethod[1]; H.range[0] = d0->hmeRange[0]; H.range[1] = d0->hmeRange[1];
+        H.mvs = a->mvs4; H.mvCosts = a->mvCosts4;
+    }
     XH_HIP(hipMemcpyAsync(a->task, tasks, (size_t)n * sizeof(x265hip_la_task), hipMemcpyHostToDevice, st));
-    if ((rc = x265hip_lookahead_cost_batch(st, a->low, a->planeElems, a->stride, a->origin, a->wcu, a->hcu, a->task, n, a->maxPics + kLaBatch, a->intraCost, a->haveInvq ? a->invq : nullptr,
-                                           a->costRow, kLaHalf, rowsPerSlice, a->mvs, a->mvCosts, a->lc, a->rows, a->sums))) return rc;
+    if ((rc = x265hip_lookahead_cost_batch_hme(st, a->low, a->planeElems, a->stride, a->origin, a->wcu, a->hcu, a->task, n, a->maxPics + kLaBatch, a->intraCost, a->haveInvq ? a->invq : nullptr,
+                                               a->costRow, kLaHalf, rowsPerSlice, a->mvs, a->mvCosts, a->lc, a->rows, a->sums, d0->hme ? &H : nullptr))) return rc;
     for (int i = 0; i < n; i++)
     {
         const x265hip_la_estimate_desc* d = reqs[i]->d;
@@ -203,6 +241,11 @@ int run_batch(x265hip_la* a, Req* const* reqs, int n)
         for (int l = 0; l < (isB ? 2 : 1); l++)
             if (tasks[i].doSearch[l])
             {
+                if (d->hme && d->lowerMvs[l] && d->lowerMvCosts[l])
+                {   // Lowres::lowerResMvs / lowerResMvCosts of the list
+                    XH_HIP(hipMemcpyAsync(d->lowerMvs[l], a->mvs4 + (size_t)(2 * i + l) * a->ncu4 * 2, (size_t)a->ncu4 * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+                    XH_HIP(hipMemcpyAsync(d->lowerMvCosts[l], a->mvCosts4 + (size_t)(2 * i + l) * a->ncu4, (size_t)a->ncu4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                }
                 XH_HIP(hipMemcpyAsync(d->mvs[l], a->mvs + (size_t)(2 * i + l) * ncu * 2, ncu * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
                 XH_HIP(hipMemcpyAsync(d->mvCosts[l], a->mvCosts + (size_t)(2 * i + l) * ncu, ncu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             }

@@ -35,6 +35,11 @@ assert ME_TASK.itemsize == 76 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize 
 MAX_REF = 16                   # X265HIP_MAX_REF (include/x265hip_frame.h)
 
 
+class LaHme(C.Structure):                   # x265hip_la_hme (include/x265hip_frame.h)
+    _fields_ = [("lowerRes", C.c_void_p), ("planeElems", C.c_int64), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("widthInCU", C.c_int), ("heightInCU", C.c_int),
+                ("method", C.c_int * 2), ("range", C.c_int * 2), ("mvs", C.c_void_p), ("mvCosts", C.c_void_p)]
+
+
 class MeChroma(C.Structure):
     _fields_ = [("curCb", C.c_void_p), ("curCr", C.c_void_p), ("curStrideC", C.c_ssize_t), ("refCb", C.c_void_p), ("refCr", C.c_void_p), ("refStrideC", C.c_ssize_t),
                 ("curOffC", C.c_void_p), ("refOffC", C.c_void_p)]
@@ -255,6 +260,14 @@ class FrameApi:
         self.h.check(self.lib.x265hip_lookahead_cost_batch(self.stream(), _dp(lowres), C.c_int64(plane_elems), C.c_ssize_t(stride), C.c_int64(origin), wcu, hcu,
                                                            _dp(tasks), n_tasks, int(lowres.numel() // (4 * plane_elems)), _dp(intra_cost), _dp(inv_qscale), _dp(cost_row), half, rows_per_slice,
                                                            _dp(mvs), _dp(mv_costs), _dp(lowres_costs), _dp(row_satds), _dp(sums)))
+
+    def lookahead_cost_batch_hme(self, lowres, plane_elems, stride, origin, wcu, hcu, tasks, n_tasks, intra_cost, inv_qscale, cost_row, half,
+                                 mvs, mv_costs, lowres_costs, row_satds, sums, lower, plane_elems4, stride4, origin4, wcu4, hcu4, methods, ranges, lower_mvs, lower_mv_costs):
+        """the same with --hme (x265hip_la_hme): the quarter-resolution pictures `lower` (same places as `lowres`), the level methods / ranges, the level-0 MV / cost slots"""
+        hme = LaHme(lower.data_ptr(), plane_elems4, stride4, origin4, wcu4, hcu4, (C.c_int * 2)(*methods), (C.c_int * 2)(*ranges), lower_mvs.data_ptr(), lower_mv_costs.data_ptr())
+        self.h.check(self.lib.x265hip_lookahead_cost_batch_hme(self.stream(), _dp(lowres), C.c_int64(plane_elems), C.c_ssize_t(stride), C.c_int64(origin), wcu, hcu,
+                                                               _dp(tasks), n_tasks, int(lowres.numel() // (4 * plane_elems)), _dp(intra_cost), _dp(inv_qscale), _dp(cost_row), half, 0,
+                                                               _dp(mvs), _dp(mv_costs), _dp(lowres_costs), _dp(row_satds), _dp(sums), C.byref(hme)))
 
     def cutree_propagate(self, wcu, hcu, dist_p0, dist_p1, weightb, fps_factor, referenced, intra_cost, lowres_costs, inv_q, mvs0, mvs1, prop_b, prop0, prop1, workspace):
         """one cuTree propagation step (Lookahead::estimateCUPropagate); tensors may be views into the lookahead batch's arrays"""
