@@ -175,6 +175,30 @@ int  x265hip_la_estimate(x265hip_la* la, const x265hip_la_estimate_desc* desc);
  * the lookahead's batched frame costs (b-adapt 2 with a thread pool) become batches on the device.  launches / estimates so far: */
 int  x265hip_la_batch_stats(const x265hip_la* la, int64_t* launches, int64_t* estimates);
 
+/* ---------------------------------------------------------------------------------------------------------------------------------------------
+ * In-loop filter producer for a host caller: what FrameFilter does to one reconstructed 4:2:0 picture between its reconstruction and the SAO decision
+ * (encoder/framefilter.cpp:451-573 ParallelFilter::processTasks): the deblocking filter of the whole picture (Deblock::deblockCTU on every CTU, both edge directions)
+ * and the SAO statistics of every CTU on the deblocked picture (SAO::calcSaoStatsCTU for the three planes) -- one call, host arrays in and out, on top of
+ * x265hip_deblock_frame / x265hip_sao_stats_frame (include/x265hip_frame.h).  The SAO decision (rate-distortion search with the encoder's entropy coder) and what
+ * follows stay with the caller.  What integration/filter_adapter.cpp binds inside the reference encoder.
+ * The picture is described as for x265hip_deblock_frame (CUData's per-partition arrays, CTU after CTU -- here HOST arrays); planes are host pointers to pixel (0,0),
+ * rows strideY / strideC (given at creation) apart; the source planes have the same strides (PicYuv of one encoder).  One slice, 4:2:0, bLimitSAO off.
+ * --------------------------------------------------------------------------------------------------------------------------------------------- */
+typedef struct x265hip_ff x265hip_ff;
+int  x265hip_ff_create(x265hip_ctx* ctx, int width, int height, int ctuSize, intptr_t strideY, intptr_t strideC, x265hip_ff** out);
+void x265hip_ff_destroy(x265hip_ff* ff);
+typedef struct x265hip_ff_picture_desc
+{
+    x265hip_deblock_pic pic;                   /* width / height / ctuSize as at creation; the array pointers are HOST pointers (numCtu * numPartitions entries each)         */
+    void *reconY, *reconCb, *reconCr;          /* in: the reconstructed picture; out (deblock != 0): the deblocked picture (the picture area only, the borders are untouched) */
+    const void *fencY, *fencCb, *fencCr;       /* the source picture (saoStats != 0)                                                                                            */
+    int deblock;                               /* param->bEnableLoopFilter                                                                                                      */
+    int saoStats;                              /* bit 0: luma statistics, bit 1: the two chroma planes' (SAOParam::bSaoFlag[0] / [1])                                           */
+    int saoNonDeblocked;                       /* param->bSaoNonDeblocked (the skipped border widths of calcSaoStatsCTU)                                                         */
+    int32_t* stats[3];                         /* out, per plane: per CTU in raster order [2][5][32] int32 = m_offsetOrg then m_count of that plane (x265hip_sao_stats_frame) */
+} x265hip_ff_picture_desc;
+int  x265hip_ff_picture(x265hip_ff* ff, const x265hip_ff_picture_desc* desc);
+
 #ifdef __cplusplus
 }
 #endif

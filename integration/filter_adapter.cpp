@@ -1,0 +1,216 @@
+/*
+ * filter_adapter.cpp -- FrameFilter::processRow, Deblock::deblockCTU and SAO::calcSaoStatsCTU with the GPU as the producer of the deblocked picture and of the SAO
+ * statistics (see filter_adapter.h).
+ *
+ * Why the whole picture at its last row is the same thing as the reference's row pipeline: the deblocking of a CTU row touches no sample the analysis of later rows
+ * reads (that is what FrameEncoder::m_filterRowDelay arranges), the SAO statistics of a CTU leave out the samples later deblocking still changes (skipB / skipR of
+ * calcSaoStatsCTU) and are taken before the SAO of the neighbours is applied (the column delays of ParallelFilter::processTasks), and the bitstream is written after the
+ * last filter row (FrameEncoder::encodeSlice).  So deblocking everything first, then collecting all statistics, then deciding and applying SAO row by row in the
+ * reference's order gives the reference's picture and the reference's SAO parameters.
+ */
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <mutex>
+#include <vector>
+#include "x265.h"
+#include "common.h"
+#include "frame.h"
+#include "framedata.h"
+#include "cudata.h"
+#include "picyuv.h"
+#include "slice.h"
+#include "deblock.h"
+#include "sao.h"
+#include "framefilter.h"
+#include "../include/x265hip_ctx.h"
+#include "filter_adapter.h"
+
+using namespace X265_NS;
+
+namespace {
+struct Api
+{
+    int (*ctx_create)(int, x265hip_ctx**);
+    void (*ctx_destroy)(x265hip_ctx*);
+    int (*ff_create)(x265hip_ctx*, int, int, int, intptr_t, intptr_t, x265hip_ff**);
+    void (*ff_destroy)(x265hip_ff*);
+    int (*ff_picture)(x265hip_ff*, const x265hip_ff_picture_desc*);
+    const char* (*last_error)();
+} g_api;
+void* g_lib;
+x265hip_ctx* g_ctx;
+x265hip_ff* g_ff;
+int g_on, g_device, g_deferOnly;
+std::mutex g_lock;                        /* one picture at a time through the producer and its staging arrays */
+x265hip_ff_adapter_stats g_stats;
+std::mutex g_statLock;
+
+/* the picture whose rows are being replayed on this thread: deblocked already, statistics in the table */
+struct Replay { bool deblocked; const int32_t* stats[3]; long long skipped, served; };
+thread_local Replay* t_replay;
+
+/* staging: CUData's per-partition arrays of all CTUs back to back, the statistics of the three planes */
+struct Staging
+{
+    std::vector<uint8_t> log2CUSize, partSize, tuDepth, predMode, cbf, tqBypass;
+    std::vector<int8_t> qp, refIdx[2];
+    std::vector<int32_t> mv[2], stats[3];
+} g_st;
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+x265hip_ff* producer(const x265_param& p, const PicYuv& recon)
+{
+    if (g_ff) return g_ff;
+    if (g_api.ctx_create(g_device, &g_ctx) || g_api.ff_create(g_ctx, p.sourceWidth, p.sourceHeight, (int)p.maxCUSize, recon.m_stride, recon.m_strideC, &g_ff))
+    {
+        fprintf(stderr, "filter_adapter: x265hip_ff_create: %s -- the encoder's own filters run\n", g_api.last_error());
+        g_on = 0; g_ff = nullptr;
+    }
+    return g_ff;
+}
+}
+
+void processRow_cpu(FrameFilter* self, int row, int layer) __asm__("xff_processRow_cpu");
+void deblockCTU_cpu(const CUData* ctu, const CUGeom& cuGeom, int32_t dir) __asm__("xff_deblockCTU_cpu");
+void calcSaoStatsCTU_cpu(SAO* self, int addr, int plane) __asm__("xff_calcSaoStatsCTU_cpu");
+
+namespace X265_NS {
+
+void Deblock::deblockCTU(const CUData* ctu, const CUGeom& cuGeom, int32_t dir)
+{
+    if (t_replay && t_replay->deblocked) { t_replay->skipped++; return; }
+    ::deblockCTU_cpu(ctu, cuGeom, dir);
+}
+
+void SAO::calcSaoStatsCTU(int addr, int plane)
+{
+    const int32_t* tab = t_replay ? t_replay->stats[plane] : NULL;
+    if (!tab) { ::calcSaoStatsCTU_cpu(this, addr, plane); return; }
+    /* per CTU [2][5][32]: m_offsetOrg then m_count of the plane; the body ADDS to what rdoSaoUnitCu left there (zero, or the pre-deblock sums of --sao-non-deblock) */
+    const int32_t* s = tab + (size_t)addr * (2 * MAX_NUM_SAO_TYPE * MAX_NUM_SAO_CLASS);
+    for (int t = 0; t < MAX_NUM_SAO_TYPE; t++)
+        for (int c = 0; c < MAX_NUM_SAO_CLASS; c++)
+        {
+            m_offsetOrg[plane][t][c] += s[t * MAX_NUM_SAO_CLASS + c];
+            m_count[plane][t][c] += s[(MAX_NUM_SAO_TYPE + t) * MAX_NUM_SAO_CLASS + c];
+        }
+    t_replay->served++;
+}
+
+void FrameFilter::processRow(int row, int layer)
+{
+    const x265_param& p = *m_param;
+    bool mine = g_on && (p.bEnableLoopFilter || m_useSao) && m_parallelFilter && p.maxSlices == 1 && p.internalCsp == X265_CSP_I420 && !p.bLimitSAO;
+    if (mine)
+    {
+        const PicYuv& rp = *m_frame->m_reconPic[0]; const PicYuv& fp = *m_frame->m_fencPic;
+        mine = fp.m_picCsp == X265_CSP_I420 && rp.m_stride == fp.m_stride && rp.m_strideC == fp.m_strideC && !(p.sourceWidth & 7) && !(p.sourceHeight & 7);
+    }
+    if (!mine)
+    {
+        if (g_on && row == m_numRows - 1) { std::lock_guard<std::mutex> guard(g_statLock); g_stats.cpuPictures++; }
+        ::processRow_cpu(this, row, layer);
+        return;
+    }
+    if (row != m_numRows - 1) return;                  /* the rows wait for the picture */
+    if (g_deferOnly)
+    {   /* X265FF_DEFER_ONLY: the deferral alone, filters by the encoder's own bodies (separates the two things the binding changes; needs no GPU) */
+        for (int r = 0; r < m_numRows; r++) ::processRow_cpu(this, r, layer);
+        std::lock_guard<std::mutex> sg(g_statLock); g_stats.cpuPictures++;
+        return;
+    }
+
+    std::lock_guard<std::mutex> guard(g_lock);
+    FrameData& encData = *m_frame->m_encData;
+    Slice* slice = encData.m_slice;
+    PicYuv* recon = m_frame->m_reconPic[0];
+    PicYuv* fenc = m_frame->m_fencPic;
+    x265hip_ff* ff = producer(p, *recon);
+    if (!ff)
+    {
+        for (int r = 0; r < m_numRows; r++) ::processRow_cpu(this, r, layer);
+        return;
+    }
+    const double t0 = now();
+    const uint32_t nctu = slice->m_sps->numCUsInFrame, np = encData.getPicCTU(0)->m_numPartitions;
+    const size_t n = (size_t)nctu * np;
+    const bool isB = slice->m_sliceType == B_SLICE, bypass = slice->m_pps->bTransquantBypassEnabled;
+    Staging& S = g_st;
+    S.log2CUSize.resize(n); S.partSize.resize(n); S.tuDepth.resize(n); S.predMode.resize(n); S.cbf.resize(n); S.tqBypass.resize(n); S.qp.resize(n);
+    for (int l = 0; l < 2; l++) { S.refIdx[l].resize(n); S.mv[l].resize(2 * n); }
+    if (p.bEnableLoopFilter)
+        for (uint32_t a = 0; a < nctu; a++)
+        {
+            const CUData* c = encData.getPicCTU(a);
+            const size_t o = (size_t)a * np;
+            memcpy(&S.log2CUSize[o], c->m_log2CUSize, np); memcpy(&S.partSize[o], c->m_partSize, np); memcpy(&S.tuDepth[o], c->m_tuDepth, np);
+            memcpy(&S.predMode[o], c->m_predMode, np); memcpy(&S.cbf[o], c->m_cbf[0], np); memcpy(&S.qp[o], c->m_qp, np);
+            if (bypass) memcpy(&S.tqBypass[o], c->m_tqBypass, np);
+            for (int l = 0; l < (isB ? 2 : 1); l++)
+            {
+                memcpy(&S.refIdx[l][o], c->m_refIdx[l], np);
+                static_assert(sizeof(MV) == 2 * sizeof(int32_t), "MV is a pair of 32-bit components");
+                memcpy(&S.mv[l][2 * o], c->m_mv[l], np * sizeof(MV));
+            }
+        }
+    x265hip_ff_picture_desc d;
+    memset(&d, 0, sizeof(d));
+    d.pic.width = p.sourceWidth; d.pic.height = p.sourceHeight; d.pic.ctuSize = (int)p.maxCUSize; d.pic.sliceIsP = !isB;
+    d.pic.betaOffsetDiv2 = slice->m_pps->deblockingFilterBetaOffsetDiv2; d.pic.tcOffsetDiv2 = slice->m_pps->deblockingFilterTcOffsetDiv2;
+    d.pic.cbQpOffset = slice->m_pps->chromaQpOffset[0]; d.pic.crQpOffset = slice->m_pps->chromaQpOffset[1]; d.pic.tqBypassEnabled = bypass;
+    d.pic.log2CUSize = S.log2CUSize.data(); d.pic.partSize = S.partSize.data(); d.pic.tuDepth = S.tuDepth.data(); d.pic.predMode = S.predMode.data();
+    d.pic.cbfLuma = S.cbf.data(); d.pic.tqBypass = bypass ? S.tqBypass.data() : NULL; d.pic.qp = S.qp.data();
+    d.pic.refIdx0 = S.refIdx[0].data(); d.pic.mv0 = S.mv[0].data(); d.pic.refIdx1 = isB ? S.refIdx[1].data() : NULL; d.pic.mv1 = isB ? S.mv[1].data() : NULL;
+    /* the reference compares the Frame behind (list, refIdx) (deblock.cpp:getBoundaryStrength); the POC identifies it */
+    for (int l = 0; l < 2; l++) for (int i = 0; i < 16; i++) d.pic.refPic[l][i] = i < slice->m_numRefIdx[l] ? slice->m_refPOCList[l][i] : -1 - i - 16 * l;
+    d.reconY = recon->m_picOrg[0]; d.reconCb = recon->m_picOrg[1]; d.reconCr = recon->m_picOrg[2];
+    d.fencY = fenc->m_picOrg[0]; d.fencCb = fenc->m_picOrg[1]; d.fencCr = fenc->m_picOrg[2];
+    d.deblock = p.bEnableLoopFilter;
+    const SAOParam* sp = encData.m_saoParam;
+    d.saoStats = (m_useSao && sp) ? (sp->bSaoFlag[0] ? 1 : 0) | (sp->bSaoFlag[1] ? 2 : 0) : 0;
+    d.saoNonDeblocked = p.bSaoNonDeblocked;
+    for (int k = 0; k < 3; k++) { S.stats[k].resize((size_t)nctu * 320); d.stats[k] = S.stats[k].data(); }
+    const double t1 = now();
+    const int rc = g_api.ff_picture(ff, &d);
+    const double t2 = now();
+    if (rc) { fprintf(stderr, "filter_adapter: x265hip_ff_picture (POC %d): %d %s\n", slice->m_poc, rc, g_api.last_error()); exit(3); }
+    Replay rp;
+    rp.deblocked = p.bEnableLoopFilter != 0; rp.skipped = rp.served = 0;
+    rp.stats[0] = (d.saoStats & 1) ? S.stats[0].data() : NULL;
+    rp.stats[1] = (d.saoStats & 2) ? S.stats[1].data() : NULL; rp.stats[2] = (d.saoStats & 2) ? S.stats[2].data() : NULL;
+    t_replay = &rp;
+    for (int r = 0; r < m_numRows; r++) ::processRow_cpu(this, r, layer);
+    t_replay = NULL;
+    const double t3 = now();
+    std::lock_guard<std::mutex> sg(g_statLock);
+    g_stats.pictures++; g_stats.deblockSkipped += rp.skipped; g_stats.statsServed += rp.served;
+    g_stats.gatherSeconds += t1 - t0; g_stats.producerSeconds += t2 - t1; g_stats.replaySeconds += t3 - t2;
+}
+
+}
+
+extern "C" int x265hip_ff_adapter_load(const char* libraryPath, int device)
+{
+    g_deferOnly = getenv("X265FF_DEFER_ONLY") && atoi(getenv("X265FF_DEFER_ONLY"));
+    g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
+    if (!g_lib) { fprintf(stderr, "filter_adapter: dlopen: %s\n", dlerror()); return -1; }
+#define SYM(field, name) *(void**)&g_api.field = dlsym(g_lib, name); if (!g_api.field) { fprintf(stderr, "filter_adapter: %s lacks %s\n", libraryPath, name); return -1; }
+    SYM(ctx_create, "x265hip_ctx_create") SYM(ctx_destroy, "x265hip_ctx_destroy") SYM(ff_create, "x265hip_ff_create") SYM(ff_destroy, "x265hip_ff_destroy")
+    SYM(ff_picture, "x265hip_ff_picture") SYM(last_error, "x265hip_last_error")
+#undef SYM
+    g_device = device; g_on = 1;
+    return 0;
+}
+extern "C" void x265hip_ff_adapter_enable(int on) { g_on = on && g_lib; }
+extern "C" void x265hip_ff_adapter_close(void)
+{
+    std::lock_guard<std::mutex> guard(g_lock);
+    if (g_ff) { g_api.ff_destroy(g_ff); g_ff = nullptr; }
+    if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
+    g_on = 0;
+}
+extern "C" void x265hip_ff_adapter_get_stats(x265hip_ff_adapter_stats* o) { std::lock_guard<std::mutex> guard(g_statLock); *o = g_stats; }

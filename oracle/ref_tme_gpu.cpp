@@ -7,7 +7,8 @@
  * the end-to-end figures of DESIGN section 6 and bench.py's e2e_fps.
  *
  * Built a second time as x265e2e_<depth> (-DWITH_LA_ADAPTER, make -C oracle e2e2) with integration/lookahead_adapter.cpp linked in as well: X265LAGPU=1 makes the GPU the
- * producer of the lookahead's intra costs and frame-cost estimates (x265hip_la_intra / x265hip_la_estimate), X265TME=0 runs without --threaded-me (lookahead seam alone).
+ * producer of the lookahead's intra costs and frame-cost estimates (x265hip_la_intra / x265hip_la_estimate), X265TME=0 runs without --threaded-me (lookahead seam alone);
+ * and with integration/filter_adapter.cpp: X265FFGPU=1 makes the GPU deblock every picture and collect its SAO statistics (x265hip_ff_picture).
  *
  * usage: x265tmegpu_<depth> <libx265hip.so> <width> <height> <frames> <preset> <out.hevc> [option=value ...]
  */
@@ -21,6 +22,7 @@
 #include "../integration/tme_adapter.h"
 #ifdef WITH_LA_ADAPTER
 #include "../integration/lookahead_adapter.h"
+#include "../integration/filter_adapter.h"
 #endif
 
 using namespace X265_NS;
@@ -56,6 +58,8 @@ int main(int argc, char** argv)
 #ifdef WITH_LA_ADAPTER
     useLa = getenv("X265LAGPU") ? atoi(getenv("X265LAGPU")) : 0;
     if (useLa && x265hip_la_adapter_load(argv[1], getenv("X265TME_DEVICE") ? atoi(getenv("X265TME_DEVICE")) : 0)) return 2;
+    const int useFf = getenv("X265FFGPU") ? atoi(getenv("X265FFGPU")) : 0;
+    if (useFf && x265hip_ff_adapter_load(argv[1], getenv("X265TME_DEVICE") ? atoi(getenv("X265TME_DEVICE")) : 0)) return 2;
 #endif
     const int w = atoi(argv[2]), h = atoi(argv[3]), frames = atoi(argv[4]);
     x265_param* p = x265_param_alloc();
@@ -109,7 +113,7 @@ int main(int argc, char** argv)
     x265hip_tme_adapter_stats s;
     x265hip_tme_adapter_get_stats(&s);
     x265hip_tme_adapter_close();
-    char la[512] = "";
+    char la[1024] = "";
 #ifdef WITH_LA_ADAPTER
     {
         x265hip_la_adapter_stats ls;
@@ -117,6 +121,12 @@ int main(int argc, char** argv)
         x265hip_la_adapter_get_stats(&ls);
         snprintf(la, sizeof(la), "\"lookahead_producer\": \"%s\", \"la_intra_pictures\": %d, \"la_estimates\": %d, \"la_launches\": %d, \"la_cpu_estimates\": %d, \"la_weighted\": %d, \"la_intra_seconds\": %.3f, \"la_estimate_seconds\": %.3f, \"la_producer_seconds\": %.3f, ",
                  useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.launches, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds);
+        x265hip_ff_adapter_stats fs;
+        x265hip_ff_adapter_close();
+        x265hip_ff_adapter_get_stats(&fs);
+        const size_t at = strlen(la);
+        snprintf(la + at, sizeof(la) - at, "\"filter_producer\": \"%s\", \"ff_pictures\": %d, \"ff_cpu_pictures\": %d, \"ff_deblock_calls_skipped\": %lld, \"ff_stats_served\": %lld, \"ff_gather_seconds\": %.3f, \"ff_producer_seconds\": %.3f, \"ff_replay_seconds\": %.3f, ",
+                 useFf ? "gpu" : "cpu", fs.pictures, fs.cpuPictures, fs.deblockSkipped, fs.statsServed, fs.gatherSeconds, fs.producerSeconds, fs.replaySeconds);
     }
 #endif
     printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",

@@ -1,0 +1,114 @@
+// xh_ff.cpp -- host side of the in-loop filter path for a C / C++ caller (include/x265hip_ctx.h: x265hip_ff_*): one reconstructed picture goes up with CUData's
+// per-partition arrays, is deblocked on the device (x265hip_deblock_frame = Deblock::deblockCTU for every CTU, common/deblock.cpp:37-497), the SAO statistics of every
+// CTU are collected on the deblocked picture (x265hip_sao_stats_frame = SAO::calcSaoStatsCTU, encoder/sao.cpp:729-905), and the deblocked planes and the statistics come
+// back.  What integration/filter_adapter.cpp binds inside the reference encoder (FrameFilter::processRow / ParallelFilter::processTasks, encoder/framefilter.cpp:451-664).
+#include "xh_common.h"
+#include "../../include/x265hip_ctx.h"
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+using namespace xh;
+
+struct x265hip_ff
+{
+    x265hip_ctx* ctx = nullptr;
+    int width = 0, height = 0, ctu = 0, nctu = 0, npart = 0;
+    intptr_t strideY = 0, strideC = 0;
+    pixel *recon[3] = {}, *fenc[3] = {};                    // device planes, the host's pitches
+    uint8_t *log2CUSize = nullptr, *partSize = nullptr, *tuDepth = nullptr, *predMode = nullptr, *cbfLuma = nullptr, *tqBypass = nullptr;
+    int8_t *qp = nullptr, *refIdx0 = nullptr, *refIdx1 = nullptr;
+    int32_t *mv0 = nullptr, *mv1 = nullptr;
+    int32_t* stats[3] = {};
+    std::mutex mu;
+    std::vector<void*> owned;
+    template<class T> int alloc(T*& p, size_t n)
+    {
+        void* v = nullptr;
+        XH_HIP(hipMalloc(&v, n * sizeof(T)));
+        owned.push_back(v); p = (T*)v;
+        return X265HIP_OK;
+    }
+};
+
+extern "C" int x265hip_ff_create(x265hip_ctx* ctx, int width, int height, int ctuSize, intptr_t strideY, intptr_t strideC, x265hip_ff** out)
+{
+    if (!ctx || !out || width < 8 || height < 8 || (width & 7) || (height & 7) || width > X265HIP_MAX_PIC_DIM || height > X265HIP_MAX_PIC_DIM ||
+        (ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || strideY < width || strideC < width / 2)
+    { set_error("ff_create: bad geometry (dimensions are multiples of 8, CTU 16/32/64, 4:2:0)"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(x265hip_ctx_device(ctx)));
+    x265hip_ff* f = new (std::nothrow) x265hip_ff();
+    if (!f) return X265HIP_EARG;
+    f->ctx = ctx; f->width = width; f->height = height; f->ctu = ctuSize; f->strideY = strideY; f->strideC = strideC;
+    f->nctu = ((width + ctuSize - 1) / ctuSize) * ((height + ctuSize - 1) / ctuSize); f->npart = (ctuSize / 4) * (ctuSize / 4);
+    const size_t n = (size_t)f->nctu * f->npart, ly = (size_t)strideY * height, lc = (size_t)strideC * (height / 2);
+    int rc = 0;
+    for (int p = 0; p < 3 && !rc; p++)
+        if (!(rc = f->alloc(f->recon[p], p ? lc : ly)) && !(rc = f->alloc(f->fenc[p], p ? lc : ly))) rc = f->alloc(f->stats[p], (size_t)f->nctu * 320);
+    if (!rc) rc = f->alloc(f->log2CUSize, n); if (!rc) rc = f->alloc(f->partSize, n); if (!rc) rc = f->alloc(f->tuDepth, n); if (!rc) rc = f->alloc(f->predMode, n);
+    if (!rc) rc = f->alloc(f->cbfLuma, n); if (!rc) rc = f->alloc(f->tqBypass, n); if (!rc) rc = f->alloc(f->qp, n); if (!rc) rc = f->alloc(f->refIdx0, n);
+    if (!rc) rc = f->alloc(f->refIdx1, n); if (!rc) rc = f->alloc(f->mv0, 2 * n); if (!rc) rc = f->alloc(f->mv1, 2 * n);
+    if (rc) { x265hip_ff_destroy(f); return rc; }
+    *out = f;
+    return X265HIP_OK;
+}
+
+extern "C" void x265hip_ff_destroy(x265hip_ff* f)
+{
+    if (!f) return;
+    (void)hipSetDevice(x265hip_ctx_device(f->ctx));
+    (void)hipStreamSynchronize((hipStream_t)x265hip_ctx_stream(f->ctx));
+    for (void* p : f->owned) (void)hipFree(p);
+    delete f;
+}
+
+extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* d)
+{
+    if (!f || !d) { set_error("ff_picture: null argument"); return X265HIP_EARG; }
+    const x265hip_deblock_pic& P = d->pic;
+    if (P.width != f->width || P.height != f->height || P.ctuSize != f->ctu || !d->reconY || !d->reconCb || !d->reconCr)
+    { set_error("ff_picture: the picture is not the one the producer was created for"); return X265HIP_EARG; }
+    if (d->deblock && (!P.log2CUSize || !P.partSize || !P.tuDepth || !P.predMode || !P.cbfLuma || !P.qp || !P.refIdx0 || !P.mv0 || (!P.sliceIsP && (!P.refIdx1 || !P.mv1)) ||
+                       (P.tqBypassEnabled && !P.tqBypass)))
+    { set_error("ff_picture: incomplete picture description"); return X265HIP_EARG; }
+    if ((d->saoStats & 1) && (!d->fencY || !d->stats[0])) { set_error("ff_picture: luma statistics without the source plane / the output"); return X265HIP_EARG; }
+    if ((d->saoStats & 2) && (!d->fencCb || !d->fencCr || !d->stats[1] || !d->stats[2])) { set_error("ff_picture: chroma statistics without the source planes / the outputs"); return X265HIP_EARG; }
+    std::lock_guard<std::mutex> g(f->mu);
+    XH_HIP(hipSetDevice(x265hip_ctx_device(f->ctx)));
+    hipStream_t st = (hipStream_t)x265hip_ctx_stream(f->ctx);
+    const size_t n = (size_t)f->nctu * f->npart;
+    void* const hostRecon[3] = { d->reconY, d->reconCb, d->reconCr };
+    const void* const hostFenc[3] = { d->fencY, d->fencCb, d->fencCr };
+    auto pitch = [&](int p) { return (size_t)(p ? f->strideC : f->strideY) * sizeof(pixel); };
+    auto wbytes = [&](int p) { return (size_t)(p ? f->width / 2 : f->width) * sizeof(pixel); };
+    auto rows = [&](int p) { return (size_t)(p ? f->height / 2 : f->height); };
+    for (int p = 0; p < 3; p++)
+    {
+        XH_HIP(hipMemcpy2DAsync(f->recon[p], pitch(p), hostRecon[p], pitch(p), wbytes(p), rows(p), hipMemcpyHostToDevice, st));
+        if ((p == 0 && (d->saoStats & 1)) || (p > 0 && (d->saoStats & 2)))
+            XH_HIP(hipMemcpy2DAsync(f->fenc[p], pitch(p), hostFenc[p], pitch(p), wbytes(p), rows(p), hipMemcpyHostToDevice, st));
+    }
+    if (d->deblock)
+    {
+        x265hip_deblock_pic D = P;
+#define XF_UP(field, count) XH_HIP(hipMemcpyAsync(f->field, P.field, (count) * sizeof(*P.field), hipMemcpyHostToDevice, st)); D.field = f->field
+        XF_UP(log2CUSize, n); XF_UP(partSize, n); XF_UP(tuDepth, n); XF_UP(predMode, n); XF_UP(cbfLuma, n); XF_UP(qp, n); XF_UP(refIdx0, n); XF_UP(mv0, 2 * n);
+        if (P.tqBypassEnabled) { XF_UP(tqBypass, n); } else D.tqBypass = nullptr;
+        if (!P.sliceIsP) { XF_UP(refIdx1, n); XF_UP(mv1, 2 * n); } else { D.refIdx1 = nullptr; D.mv1 = nullptr; }
+#undef XF_UP
+        int rc = x265hip_deblock_frame(st, &D, f->recon[0], f->strideY, f->recon[1], f->recon[2], f->strideC, nullptr);
+        if (rc) return rc;
+        for (int p = 0; p < 3; p++) XH_HIP(hipMemcpy2DAsync(hostRecon[p], pitch(p), f->recon[p], pitch(p), wbytes(p), rows(p), hipMemcpyDeviceToHost, st));
+    }
+    for (int p = 0; p < 3; p++)
+    {
+        if (!((p == 0 && (d->saoStats & 1)) || (p > 0 && (d->saoStats & 2)))) continue;
+        // a 4:2:0 chroma plane: its own width / height / CTU size and planeOffset 2 (sao.cpp:748-756, :773)
+        int rc = x265hip_sao_stats_frame(st, f->fenc[p], f->recon[p], p ? f->strideC : f->strideY, p ? f->width / 2 : f->width, p ? f->height / 2 : f->height,
+                                         p ? f->ctu / 2 : f->ctu, d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, f->stats[p]);
+        if (rc) return rc;
+        XH_HIP(hipMemcpyAsync(d->stats[p], f->stats[p], (size_t)f->nctu * 320 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
+    XH_HIP(hipStreamSynchronize(st));
+    return X265HIP_OK;
+}
