@@ -168,7 +168,8 @@ def e2e_fps_leg(frames=8):
     """BASELINE's M2 measured in THIS run: the reference encoder (oracle/_ref/x265e2e_8 = all of source/common + source/encoder compiled from where they lie, C
     primitives, no asm; it travels with the repository) on BASELINE configs[1] -- 1920x1088 8-bit, preset medium with the preset's own defaults, --threaded-me -- with its
     own CPU producers, with x265hip_tme_picture producing the MEData tables (integration/tme_adapter.cpp), with x265hip_la_intra / x265hip_la_estimate producing the
-    lookahead's costs (integration/lookahead_adapter.cpp), and with both.  Every run must write the same bitstream.
+    lookahead's costs (integration/lookahead_adapter.cpp), with x265hip_ff_picture producing the deblocked picture and the SAO statistics (integration/filter_adapter.cpp),
+    and with all three.  Every run must write the same bitstream.
     None when no binary is there (then the committed figure of profiles/e2e_fps.json is reported, labelled as such)."""
     import hashlib, subprocess, tempfile
     import x265hip
@@ -179,11 +180,14 @@ def e2e_fps_leg(frames=8):
         if not os.path.exists(exe):
             return None
     runs = {}
-    modes = (("cpu", 0, 0), ("tme_gpu", 1, 0)) + ((("la_gpu", 0, 1), ("tme_la_gpu", 1, 1)) if both else ())
+    modes = (("cpu", 0, 0, 0), ("tme_gpu", 1, 0, 0)) + ((("la_gpu", 0, 1, 0), ("ff_gpu", 0, 0, 1), ("cpu_filters_timed", 0, 0, 2), ("all_gpu", 1, 1, 1)) if both else ())
     with tempfile.TemporaryDirectory() as td:
-        for name, tme, la in modes:
+        for name, tme, la, ff in modes:
             outp = os.path.join(td, name + ".hevc")
-            env = dict(os.environ, X265TMEGPU=str(tme), X265LAGPU=str(la), MALLOC_PERTURB_="85")
+            env = dict(os.environ, X265TMEGPU=str(tme), X265LAGPU=str(la), X265FFGPU="1" if ff else "0", MALLOC_PERTURB_="85")
+            env.pop("X265FF_DEFER_ONLY", None)
+            if ff == 2:
+                env["X265FF_DEFER_ONLY"] = "1"             # the binding's deferral with the encoder's own filters: times what the CPU spends on a picture's filters
             r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(frames), "medium", outp], capture_output=True, text=True, env=env, timeout=600)
             if r.returncode != 0:
                 return {"measured": "this run: FAILED", "producer": name, "stderr": r.stderr[-500:]}
@@ -191,11 +195,11 @@ def e2e_fps_leg(frames=8):
             info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
             runs[name] = info
     g, c = runs["tme_gpu"], runs["cpu"]
-    best = runs.get("tme_la_gpu", g)
+    best = runs.get("all_gpu", g)
     out = {"value": best["fps"], "unit": "frames/s", "measured": "this run",
            "config": "BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults (ref=3, weightp, bframes=4, b-adapt 2), --threaded-me, %d frames" % frames,
            "host": "the reference encoder with C primitives (no asm; no nasm on this box) -- its RDO bounds the encode; value = GPU producers on every seam that is bound (%s)"
-                   % ("ThreadedME + lookahead" if both else "ThreadedME"),
+                   % ("ThreadedME + lookahead + in-loop filters" if both else "ThreadedME"),
            "fps": {k: v["fps"] for k, v in runs.items()}, "same_encoder_cpu_producer_fps": c["fps"],
            "bitstream_identical": all(v["md5"] == c["md5"] and v["bytes"] == c["bytes"] for v in runs.values()), "bytes": c["bytes"],
            "tme": {"gpu_pictures": g["gpu_pictures"], "producer_ms_per_picture": round(1e3 * g["gpu_seconds"] / max(1, g["gpu_pictures"]), 2),
@@ -209,6 +213,13 @@ def e2e_fps_leg(frames=8):
                             "ms_per_estimate": round(1e3 * l["la_estimate_seconds"] / max(1, l["la_estimates"]), 3),
                             "ms_per_intra_picture": round(1e3 * l["la_intra_seconds"] / max(1, l["la_intra_pictures"]), 3),
                             "producer_seconds": l["la_producer_seconds"]}
+        f, ct = runs["ff_gpu"], runs["cpu_filters_timed"]
+        nf = max(1, f["ff_pictures"])
+        out["filters"] = {"pictures": f["ff_pictures"], "pictures_left_to_the_cpu": f["ff_cpu_pictures"],
+                          "ms_per_picture": {"gather": round(1e3 * f["ff_gather_seconds"] / nf, 2), "x265hip_ff_picture": round(1e3 * f["ff_producer_seconds"] / nf, 2),
+                                             "encoder_row_loop_behind_it": round(1e3 * f["ff_replay_seconds"] / nf, 2)},
+                          "encoder_own_filters_ms_per_picture": round(1e3 * ct["ff_replay_seconds"] / max(1, ct["ff_cpu_pictures"]), 2),
+                          "note": "x265hip_ff_picture = upload of the reconstructed and the source picture and of CUData's arrays, deblocking, SAO statistics of the three planes, download; the row loop behind it = SAO decision and SAO, border extension, PSNR / SSIM, hashes (the encoder's own code)"}
     return out
 
 

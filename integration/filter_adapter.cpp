@@ -119,8 +119,9 @@ void FrameFilter::processRow(int row, int layer)
     if (row != m_numRows - 1) return;                  /* the rows wait for the picture */
     if (g_deferOnly)
     {   /* X265FF_DEFER_ONLY: the deferral alone, filters by the encoder's own bodies (separates the two things the binding changes; needs no GPU) */
+        const double t0 = now();
         for (int r = 0; r < m_numRows; r++) ::processRow_cpu(this, r, layer);
-        std::lock_guard<std::mutex> sg(g_statLock); g_stats.cpuPictures++;
+        std::lock_guard<std::mutex> sg(g_statLock); g_stats.cpuPictures++; g_stats.replaySeconds += now() - t0;
         return;
     }
 
