@@ -108,3 +108,14 @@ def test_rect_task_lists_equal_the_python_pipeline(geom):
     assert lib.x265hip_batch_rect_task_count(C.byref(d), 64, 64) < 0 and lib.x265hip_batch_rect_task_count(C.byref(d), 64, 16) < 0
     for bad in (Desc(W, H, F, margin, 28, 57, 3, 3, 5, 0, 1, 17, 0, 1), Desc(W, H, F, margin, 28, 57, 3, 3, 5, 0, 1, 1, 0, 9), Desc(W, H, F, margin, 28, 57, 3, 3, 5, 0, 0, 2, 0, 1)):
         assert lib.x265hip_batch_task_count(C.byref(bad), 64) < 0        # too many references / streams; several references without phase planes
+
+
+def test_filter_producer_refuses_bad_geometry():
+    """x265hip_ff_create / x265hip_ff_picture validate before they look at a device: no context, dimensions that are no multiple of 8, CTU sizes HEVC does not have"""
+    lib = x265hip.HipLib(8, fill_table=False).lib
+    ff = C.c_void_p()
+    fake = C.c_void_p(1)                                         # never dereferenced: the geometry is refused first
+    assert lib.x265hip_ff_create(None, 128, 64, 64, C.c_ssize_t(320), C.c_ssize_t(160), C.byref(ff)) == -3 and not ff.value
+    for (w, h, ctu, sy, sc) in [(100, 64, 64, 320, 160), (128, 60, 64, 320, 160), (128, 64, 48, 320, 160), (128, 64, 64, 100, 160), (128, 64, 64, 320, 32), (8192, 64, 64, 9000, 4500)]:
+        assert lib.x265hip_ff_create(fake, w, h, ctu, C.c_ssize_t(sy), C.c_ssize_t(sc), C.byref(ff)) == -3 and not ff.value, (w, h, ctu, sy, sc)
+    assert lib.x265hip_ff_picture(None, None) == -3

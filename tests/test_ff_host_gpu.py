@@ -1,0 +1,73 @@
+"""x265hip_ff_picture (include/x265hip_ctx.h: the host-level in-loop filter producer integration/filter_adapter.cpp binds) against the oracle: a random coded picture goes in as
+HOST arrays with padded row pitches, the deblocked planes must equal xo_deblock_frame's and the SAO statistics of every CTU of the three planes xo_sao_stats_frame's on the
+deblocked picture (both pinned to the reference's Deblock / SAO classes: test_deblock_oracle_vs_ref.py, test_sao_oracle_vs_ref.py)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+sys.path.insert(0, HERE)
+import x265hip  # noqa: E402
+from oracle_py import Oracle  # noqa: E402
+from deblock_util import I8, U8, DeblockPic, coded_picture, descriptor, run_oracle  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+class FfDesc(C.Structure):
+    _fields_ = [("pic", DeblockPic), ("recon", C.c_void_p * 3), ("fenc", C.c_void_p * 3), ("deblock", C.c_int), ("saoStats", C.c_int), ("saoNonDeblocked", C.c_int),
+                ("stats", C.c_void_p * 3)]
+
+
+@pytest.mark.parametrize("depth,W,H,ctu,slice_p,bypass,deblock,sao,nd", [(8, 256, 192, 64, False, False, 1, 3, 0), (10, 200, 120, 64, True, True, 1, 3, 0), (8, 192, 128, 32, False, False, 1, 1, 1),
+                                                                       (8, 128, 128, 16, True, False, 0, 3, 0), (10, 1920, 1080, 64, False, False, 1, 3, 0), (8, 256, 192, 64, False, False, 1, 0, 0)])
+def test_ff_picture_matches_oracle(depth, W, H, ctu, slice_p, bypass, deblock, sao, nd):
+    H -= H % 8
+    ora = Oracle(depth)
+    lib = x265hip.HipLib(depth, fill_table=False).lib
+    lib.x265hip_last_error.restype = C.c_char_p
+    pic = coded_picture(depth, W, H, ctu, 77 + W + depth, slice_p, bypass)
+    rng = np.random.default_rng(5 + W)
+    dt = pic["planes"][0].dtype
+    sY, sC = W + 40, W // 2 + 24                                                        # padded pitches, as PicYuv has
+    src = [np.clip(p.astype(np.int32) + rng.integers(-6, 7, p.shape), 0, (1 << depth) - 1).astype(dt) for p in pic["planes"]]      # a "source" the picture is a coded version of
+    def padded(p, s):
+        b = np.full((p.shape[0], s), 3, dt); b[:, :p.shape[1]] = p
+        return b
+    recon = [padded(p, sC if c else sY) for c, p in enumerate(pic["planes"])]
+    fenc = [padded(p, sC if c else sY) for c, p in enumerate(src)]
+    before = [r.copy() for r in recon]
+    ctx, ff = C.c_void_p(), C.c_void_p()
+    assert lib.x265hip_ctx_create(0, C.byref(ctx)) == 0, lib.x265hip_last_error()
+    assert lib.x265hip_ff_create(ctx, W, H, ctu, C.c_ssize_t(sY), C.c_ssize_t(sC), C.byref(ff)) == 0, lib.x265hip_last_error()
+    keep = {k: np.ascontiguousarray(pic[k]) for k in U8 + I8 + ("mv0", "mv1")}
+    nctu = ((W + ctu - 1) // ctu) * ((H + ctu - 1) // ctu)
+    stats = [np.full(nctu * 320, -9, np.int32) for _ in range(3)]
+    d = FfDesc()
+    d.pic = descriptor(pic, lambda k: keep[k].ctypes.data)
+    d.recon[:] = [r.ctypes.data for r in recon]; d.fenc[:] = [f.ctypes.data for f in fenc]
+    d.deblock, d.saoStats, d.saoNonDeblocked = deblock, sao, nd
+    d.stats[:] = [s.ctypes.data for s in stats]
+    for rep in range(2):                                                                # twice: the producer keeps no state between pictures
+        for r, b in zip(recon, before):
+            r[:] = b
+        assert lib.x265hip_ff_picture(ff, C.byref(d)) == 0, lib.x265hip_last_error()
+        exp = run_oracle(ora, pic) if deblock else [p.copy() for p in pic["planes"]]
+        for c in range(3):
+            w = W if c == 0 else W // 2
+            assert np.array_equal(recon[c][:, :w], exp[c]), "plane %d after deblocking" % c
+            assert np.array_equal(recon[c][:, w:], before[c][:, w:]), "the padding of plane %d was touched" % c
+            if (c == 0 and sao & 1) or (c > 0 and sao & 2):
+                h, cs = (H, ctu) if c == 0 else (H // 2, ctu // 2)
+                want = np.zeros(nctu * 320, np.int32)
+                P = lambda a: C.c_void_p(a.ctypes.data)
+                f_c, r_c = np.ascontiguousarray(src[c]), np.ascontiguousarray(exp[c])
+                ora.lib.xo_sao_stats_frame(P(f_c), P(r_c), C.c_ssize_t(w), w, h, cs, nd, 0 if c == 0 else 2, P(want))
+                assert np.array_equal(stats[c], want), "SAO statistics of plane %d" % c
+            else:
+                assert (stats[c] == -9).all()
+    lib.x265hip_ff_destroy(ff); lib.x265hip_ctx_destroy(ctx)
