@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--inner", type=int, default=5, help="passes over the resident batch per step (a step of the driver's --steps 20 then lasts long enough for the whole timed region to be >= 0.5 s)")
     ap.add_argument("--no-streams-leg", action="store_true", help="skip the extra leg that steps the same batch as 2 and 3 sub-batches of whole pictures on their own streams (x265hip_batch_desc.streams); reported under \"streams\", not part of value")
-    ap.add_argument("--splits", type=int, default=1, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
+    ap.add_argument("--splits", type=int, default=2, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
     ap.add_argument("--band-rows", type=int, default=0, help="band-major schedule: bands of this many CTU rows go through all levels + TQ before the stream takes the next band (x265hip_batch_desc.bandRows); 0 = sub-batches of whole pictures")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
@@ -572,13 +572,14 @@ def intra_scan_leg(pipe, depth, steps):
 
 
 def streams_leg(lib, depth, W, H, wl, args, pairs, headline_s_per_pass):
-    """The same batch stepped as sub-batches of whole pictures on their own streams (x265hip_batch_desc.streams = 2, 3): pictures are independent, so the LDS-bound 64x64
-    search of one sub-batch runs beside the latency-bound 16x16 / 8x8 searches of another.  The headline stays the one-stream schedule so that its per-stage times are
-    those of kernels that own the GPU; this leg says what the overlap is worth (measured: 3-4 %)."""
+    """The same batch stepped as S sub-batches of whole pictures on their own streams (x265hip_batch_desc.streams): pictures are independent, so the LDS-bound 64x64 search
+    of one sub-batch runs beside the latency-bound 16x16 / 8x8 searches of another; with S = 2 the two streams alternate on the 64x64 level and are not joined between
+    passes.  The line's value is the schedule --splits names (default 2); this leg measures the others."""
     import torch
     from x265hip_pkg.host_batch import HostBatch
-    res = {"what": "x265hip_batch_step, desc.streams = S: S sub-batches of whole pictures, each on its own stream; same batch, same results (tests/test_host_batch_gpu.py)", "one_stream_ms_per_pass": round(headline_s_per_pass * 1e3, 4)}
-    for S in (2, 3):
+    res = {"what": "x265hip_batch_step, desc.streams = S: S sub-batches of whole pictures, each on its own stream; same batch, same results (tests/test_host_batch_gpu.py)",
+           "headline_streams": args.splits, "headline_ms_per_pass": round(headline_s_per_pass * 1e3, 4)}
+    for S in [v for v in (1, 2, 3) if v != args.splits]:
         hb = HostBatch(lib, depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, margin=MARGIN,
                        recon=args.recon, use_planes=not args.no_planes, refs=args.refs, rect=args.rect, streams=S, device=torch.cuda.current_device())
         try:
@@ -592,7 +593,7 @@ def streams_leg(lib, depth, W, H, wl, args, pairs, headline_s_per_pass):
                 hb.step()
             hb.sync()
             dt = (time.perf_counter() - t0) / reps
-            res["streams_%d" % S] = {"ms_per_pass": round(dt * 1e3, 4), "Mpixels/s": round(hb.pixels_per_step / dt / 1e6, 1), "vs_one_stream": round(headline_s_per_pass / dt, 4)}
+            res["streams_%d" % S] = {"ms_per_pass": round(dt * 1e3, 4), "Mpixels/s": round(hb.pixels_per_step / dt / 1e6, 1), "headline_vs_this": round(dt / headline_s_per_pass, 4)}
         finally:
             hb.close()
     return res
@@ -922,12 +923,25 @@ def main():
     # per-stage HIP events (recorded by the host on the stream each stage runs on, x265hip_batch_set_timing) on every 4th step only: an event between two launches
     # keeps the tail of one kernel from overlapping the head of the next (measured: ~5 % of the step time when every launch is bracketed)
     t0 = time.perf_counter()
+    serial_stage_times = args.splits > 1 and args.band_rows == 0       # sub-batches on their own streams overlap: the per-stage times then come from one-stream passes behind the timed region
     for k in range(args.steps):
-        pipe.set_timing(k % 4 == 0)
+        pipe.set_timing(k % 4 == 0 and not serial_stage_times)
         for _ in range(args.inner):                 # one step = `inner` passes of the hot path over the resident batch (the timed region of the driver's 20 steps is >= 0.5 s)
             pipe.step()
     barrier()
     dt = time.perf_counter() - t0
+    t_serial = None
+    if serial_stage_times and rank == 0:
+        # NOT part of the timed region: the same batch stepped as one sub-batch on one stream (x265hip_batch_step_one_stream, same results), every pass with per-stage events
+        pipe.set_timing(False)
+        pipe.step_one_stream(); pipe.sync()
+        pipe.set_timing(True)
+        ts0 = time.perf_counter()
+        for _ in range(4):
+            pipe.step_one_stream()
+        pipe.sync()
+        t_serial = (time.perf_counter() - ts0) / 4
+        pipe.set_timing(False)
     dt = max_over_ranks(dt, dist if world > 1 else None, device="cuda")
     devices = [torch.cuda.get_device_name(local_rank)]
     if world > 1:
@@ -935,10 +949,10 @@ def main():
         dist.all_gather_object(devices, "%d:%s" % (local_rank, torch.cuda.get_device_name(local_rank)))
 
     if rank == 0:
-        kms = pipe.read_timing()                    # mean over the sampled passes; stages of sub-batch 0
+        kms = pipe.read_timing()                    # mean over the sampled passes; stages of sub-batch 0 (one stream: the whole batch)
         bpp = 1 if depth == 8 else 2
         px = pipe.pixels_per_step * args.inner      # pixels of one step
-        share = pipe.sub_batch_pictures() / args.frames      # the part of the batch one timed launch group covers
+        share = 1.0 if serial_stage_times else pipe.sub_batch_pictures() / args.frames      # the part of the batch one timed launch group covers
         n_tu = 1 << args.tu
         alg = pipe.algorithmic_bytes()              # each plane byte once per launch + the records it writes
         # dominant kernel = strictly the longest average launch of the step, whatever it is bound by
@@ -959,10 +973,13 @@ def main():
             "config": {"workload": args.workload, "preset_exact": bool(args.refs == PRESET_REFS.get(args.workload) and args.rect == PRESET_RECT.get(args.workload)),
                        "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames * args.inner,
                        "step": "%d passes of the hot path over a resident batch of %d frame pairs" % (args.inner, args.frames), "host": "C++ (x265hip_batch_step, csrc/xh_ctx.cpp)",
-                       "streams": ("bands of %d CTU rows through all levels, round-robin on %d streams" % (args.band_rows, args.splits)) if args.band_rows > 0 else ("%d sub-batches of whole pictures on their own streams" % args.splits if args.splits > 1 else "one stream"),
+                       "streams": ("bands of %d CTU rows through all levels, round-robin on %d streams" % (args.band_rows, args.splits)) if args.band_rows > 0 else
+                                  ("2 sub-batches of whole pictures on their own streams, alternating on the 64x64 level, joined at the end of the timed region (x265hip_batch_desc.streams = 2)" if args.splits == 2 else
+                                   "%d sub-batches of whole pictures on their own streams" % args.splits if args.splits > 1 else "one stream"),
                        "ctu": 64, "pus_per_ctu": 425 if args.rect else 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": args.refs, "qp": args.qp,
-                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": "stage by stage per sub-batch; per-stage events on every 4th step (sub-batch 0)", "sharding": "independent frames per GPU, no collectives"},
-            "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "strictly the longest average launch group of the step" + ("; a launch covers one of %d sub-batches, stages of different sub-batches run concurrently (their times do not add up to ms_per_step)" % args.splits if args.splits > 1 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "tu": "%dx%d" % (n_tu, n_tu), "recon": bool(args.recon), "subpel": "phase planes" if pipe.use_planes else "in-kernel interpolation", "launch": "stage by stage per sub-batch" + ("; the per-stage times of roofline / roofline_valu are NOT from the timed region (its stages overlap): 4 one-stream passes of the same batch behind it, %.4f ms per pass" % (t_serial * 1e3) if serial_stage_times else "; per-stage events on every 4th step (sub-batch 0)"), "sharding": "independent frames per GPU, no collectives"},
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_rule": "strictly the longest average launch group of a pass" + ("; times of one-stream passes (the whole batch per launch, stages one after the other: they add up to the one-stream pass, %.4f ms, not to ms_per_step / %d = %.4f ms of the overlapped schedule)" % (t_serial * 1e3, args.inner, dt / args.steps / args.inner * 1e3) if serial_stage_times else
+                                                                                                      "; a launch covers one of %d sub-batches, stages of different sub-batches run concurrently (their times do not add up to ms_per_step)" % args.splits if args.splits > 1 else ""), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": (traffic_all.get(dom) * share if traffic_all.get(dom) is not None else None), "traffic_source": traffic_src if traffic_all.get(dom) is not None else None,
                          "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
                          "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()},
@@ -982,7 +999,7 @@ def main():
                               "traffic_per_step": (sum(v for k, v in traffic_all.items() if k in kms) * args.inner or None) if traffic_all else None, "traffic_source": traffic_src},
             "e2e_fps": None,
         }
-        if not args.no_streams_leg and args.splits == 1 and args.band_rows == 0 and args.frames >= 2:
+        if not args.no_streams_leg and args.band_rows == 0 and args.frames >= 2:
             out["streams"] = streams_leg(lib, depth, W, H, wl, args, pairs, dt / args.steps / args.inner)
         if exact_refs and not (args.refs == exact_refs and args.rect == PRESET_RECT[args.workload]):
             out["preset_exact"] = preset_exact_leg(lib, depth, W, H, wl, args, pairs, exact_refs, PRESET_RECT[args.workload], (dt / args.steps / args.inner) / (args.frames * (W // 64) * (H // 64) * 85 * args.refs))

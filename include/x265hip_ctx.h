@@ -30,7 +30,7 @@ typedef struct x265hip_batch x265hip_batch;
 int   x265hip_ctx_create(int device, x265hip_ctx** ctx);
 void  x265hip_ctx_destroy(x265hip_ctx* ctx);
 void* x265hip_ctx_stream(x265hip_ctx* ctx);          /* hipStream_t: every call on this context is ordered on it */
-int   x265hip_ctx_sync(x265hip_ctx* ctx);
+int   x265hip_ctx_sync(x265hip_ctx* ctx);              /* waits for everything queued through the context, the sub-streams of its batches included */
 int   x265hip_ctx_device(const x265hip_ctx* ctx);    /* the device the context was created on; every entry point that takes a context selects it for the calling thread */
 
 #define X265HIP_MAX_PIC_DIM 8184                 /* (dim + 8 - 1) << 2 must fit the int16 quarter-pel limits of the task records */
@@ -51,7 +51,10 @@ typedef struct x265hip_batch_desc
     int rect;               /* != 0: also the 2NxN and Nx2N PUs of every CU (param->bEnableRectInter: preset slow and up): 425 PUs per CTU instead of 85, each seeded
                                by its own CU's 2Nx2N result in the same reference                                                       */
     int streams;            /* 1..8 (0 = 1): the batch is cut into this many sub-batches of whole pictures, each stepped on its own stream (pictures are independent,
-                               the levels of one picture are not); x265hip_batch_step stays ordered on the context's stream               */
+                               the levels of one picture are not); x265hip_batch_step stays ordered behind the context's stream.
+                               2: the two streams ALTERNATE on the 64x64 level (its workgroups fill a CU's LDS: it then always runs beside the other stream's smaller
+                               levels, never beside itself) and are not joined between steps -- a stream's next pass follows its own previous one; x265hip_ctx_sync and
+                               the upload / read calls join them                                                                            */
     int bandRows;           /* 0: sub-batches are whole pictures.  > 0: band-major -- the phase planes of the whole batch first, then bands of this many CTU rows, each taken
                                through all levels and the TQ stage before its stream takes the next band (bands dealt round-robin to the streams): the planes under a band
                                are re-read while they are still in the last-level cache                                                   */
@@ -74,6 +77,8 @@ void  x265hip_batch_destroy(x265hip_batch* batch);
  * strideElems its row pitch.  The padded plane is assembled on the device. */
 int   x265hip_batch_upload_plane(x265hip_batch* batch, int which, int frame, const void* pixels, intptr_t strideElems);
 int   x265hip_batch_step(x265hip_batch* batch);
+int   x265hip_batch_step_one_stream(x265hip_batch* batch);      /* the same pass as ONE sub-batch on the context's stream, whatever desc.streams says (same results): its stages
+                                                                 * run one after the other, which per-stage timing needs */
 int   x265hip_batch_read_results(x265hip_batch* batch, int level, x265hip_me_result* out /* x265hip_batch_task_count entries */);       /* reference 0, 2Nx2N */
 int   x265hip_batch_read_results_ref(x265hip_batch* batch, int w, int h, int ref, x265hip_me_result* out);      /* any searched shape (square or, with rect, 2NxN / Nx2N), any reference */
 int   x265hip_batch_read_choices(x265hip_batch* batch, int w, int h, struct x265hip_inter_choice* out);         /* refs > 1: the per-PU choice among the references */

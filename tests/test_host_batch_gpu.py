@@ -86,6 +86,29 @@ def test_streams_do_not_change_the_bytes_and_python_plumbing_agrees(depth):
     assert pipe.d_coeff.cpu().numpy().tobytes() == ref_out[-2] and pipe.d_numsig.cpu().numpy().astype(np.uint32).tobytes() == ref_out[-1]
 
 
+def test_two_streams_are_joined_when_something_reads_and_one_stream_steps_give_the_same():
+    """streams = 2 alternates the 64x64 level between its two streams and leaves them unjoined between steps: a read straight behind the steps (no sync call) must see both
+    sub-batches' results; x265hip_batch_step_one_stream on the same batch gives the same bytes, and the two kinds of step may be mixed"""
+    W, H, F = 192, 128, 6
+    pairs = pairs_for(W, H, 10, F, 1)
+    outs = []
+    for streams, plan in ((1, "ss"), (2, "ssss"), (2, "sos"), (2, "o"), (2, "soso")):
+        hb = make(10, W, H, F, qp=30, merange=20, method=3, subme=3, tu_log2=5, streams=streams)
+        try:
+            hb.upload(pairs)
+            for c in plan:
+                hb.step() if c == "s" else hb.step_one_stream()
+            out = [hb.results(lv).tobytes() for lv in LEVELS]                    # no sync in between: the reads join the streams themselves
+            co, ns = hb.coeffs()
+            outs.append(out + [co.tobytes(), ns.tobytes()])
+            hb.upload(pairs)                                                     # an upload behind unjoined passes waits for them too
+            hb.step(); hb.sync()
+            assert [hb.results(lv).tobytes() for lv in LEVELS] == out
+        finally:
+            hb.close()
+    assert all(o == outs[0] for o in outs[1:])
+
+
 def test_stage_timing_and_names():
     hb = make(8, 256, 128, 4, method=3, subme=3, merange=24, rect=True, streams=2)
     try:

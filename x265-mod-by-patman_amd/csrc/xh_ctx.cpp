@@ -10,10 +10,12 @@
 
 using namespace xh;
 
+struct x265hip_batch;
 struct x265hip_ctx
 {
     int device = 0;
     hipStream_t stream = nullptr;
+    std::vector<x265hip_batch*> batches;      // batches of this context (their sub-streams are joined into `stream` before anything waits on it)
 };
 
 namespace {
@@ -51,6 +53,10 @@ struct x265hip_batch
     uint16_t* costRow = nullptr; float* bitsRow = nullptr; uint64_t lambda = 0;
     // sub-batches of whole pictures on their own streams (desc.streams): stream 0 is the context's
     hipStream_t sub[8] = {}; hipEvent_t evFork = nullptr, evJoin[8] = {};
+    // two sub-batches of whole pictures (streams = 2): the 64x64 level (window in LDS, two workgroups fill a CU) of the two streams ALTERNATES -- a stream takes it when
+    // the other has finished its own -- so that it always runs beside the other stream's 32x32 .. 8x8 levels, never beside itself; and the sub-batches are not joined
+    // between steps (a stream's next pass only depends on its own previous one): they are joined when something waits on the context's stream (join_subs)
+    hipEvent_t evTok[2] = {}; bool tokSet[2] = {}; int pingpong = 0; bool unjoined = false;
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
     std::vector<void*> owned;
@@ -62,6 +68,19 @@ struct x265hip_batch
         return X265HIP_OK;
     }
 };
+
+// the sub-batches' streams back into the context's stream (a step of the alternating schedule leaves them running)
+static int join_subs(x265hip_batch* b)
+{
+    if (!b->unjoined) return X265HIP_OK;
+    for (int s = 1; s < b->nsub; s++)
+    {
+        XH_HIP(hipEventRecord(b->evJoin[s], b->sub[s]));
+        XH_HIP(hipStreamWaitEvent(b->sub[0], b->evJoin[s], 0));
+    }
+    b->unjoined = false;
+    return X265HIP_OK;
+}
 
 extern "C" int x265hip_ctx_create(int device, x265hip_ctx** out)
 {
@@ -90,6 +109,8 @@ extern "C" int x265hip_ctx_device(const x265hip_ctx* c) { return c ? c->device :
 extern "C" int x265hip_ctx_sync(x265hip_ctx* c)
 {
     if (!c) { set_error("ctx_sync: null context"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(c->device));
+    for (x265hip_batch* b : c->batches) { const int rc = join_subs(b); if (rc) return rc; }
     XH_HIP(hipStreamSynchronize(c->stream));
     return X265HIP_OK;
 }
@@ -180,7 +201,9 @@ extern "C" void x265hip_batch_destroy(x265hip_batch* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
+    { auto& v = b->ctx->batches; v.erase(std::remove(v.begin(), v.end(), b), v.end()); }
     (void)hipStreamSynchronize(b->ctx->stream);
+    for (int i = 0; i < 2; i++) if (b->evTok[i]) (void)hipEventDestroy(b->evTok[i]);
     for (int i = 1; i < 8; i++) if (b->sub[i]) { (void)hipStreamSynchronize(b->sub[i]); x265hip_tme_release_stream(b->sub[i]); (void)hipStreamDestroy(b->sub[i]); }
     for (int i = 0; i < 8; i++) if (b->evJoin[i]) (void)hipEventDestroy(b->evJoin[i]);
     if (b->evFork) (void)hipEventDestroy(b->evFork);
@@ -205,6 +228,12 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
 #define XB(call) do { rc = (call); if (rc != X265HIP_OK) return fail(rc); } while (0)
 #define XBH(call, what) do { if ((call) != hipSuccess) return fail(hip_fail(hipErrorUnknown, what)); } while (0)
     XBH(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming), "hipEventCreate");
+    ctx->batches.push_back(b);
+    if (b->nsub == 2 && d->bandRows <= 0 && !xh_experiment("X265HIP_NO_PINGPONG"))
+    {
+        b->pingpong = 1;
+        for (int i = 0; i < 2; i++) XBH(hipEventCreateWithFlags(&b->evTok[i], hipEventDisableTiming), "hipEventCreate");
+    }
     for (int i = 0; i < b->nsub; i++)
     {
         if (i) XBH(hipStreamCreateWithFlags(&b->sub[i], hipStreamNonBlocking), "hipStreamCreate");
@@ -286,6 +315,7 @@ extern "C" int x265hip_batch_upload_plane(x265hip_batch* b, int which, int frame
     if (!b || which < 0 || which > b->refs || frame < 0 || frame >= b->d.frames || !pixels || strideElems < b->d.width)
     { set_error("batch_upload_plane: bad arguments"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
+    { const int jrc = join_subs(b); if (jrc) return jrc; }
     const x265hip_batch_desc& d = b->d;
     pixel* plane = (which ? b->ref[which - 1] : b->cur) + (size_t)frame * b->plane;
     pixel* org = plane + (size_t)d.margin * b->stride + d.margin;
@@ -313,7 +343,7 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
 // One sub-batch on stream st: the CTU rows g0 .. g1 - 1 of the batch, counted through the pictures (global row g = picture * ctuRows + row).  Tasks of every
 // shape are laid out picture-major, then raster: a range of global CTU rows is a contiguous range of every task list.  withPlanes: the range is whole pictures and
 // their phase planes are made first; ev != nullptr: events around every stage (2 per stage)
-int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev)
+int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev, int sub = -1)
 {
     const x265hip_batch_desc& d = b->d;
     const int64_t planeElems = b->plane * d.frames;
@@ -356,7 +386,10 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
         x265hip_me_result* res[X265HIP_MAX_REF]; x265hip_me_result* par[X265HIP_MAX_REF];
         for (int r = 0; r < b->refs; r++) { res[r] = b->results[r][i]; par[r] = i ? b->results[r][i - 1] : nullptr; }
         if ((rc = mark(0))) return rc;
+        const bool token = b->pingpong && sub >= 0 && i == 0;
+        if (token && b->tokSet[sub ^ 1]) XH_HIP(hipStreamWaitEvent(st, b->evTok[sub ^ 1], 0));
         if ((rc = search(lv, lv, b->tasks[i], g0 * per, (g1 - g0) * per, res, i ? par : nullptr, b->choice[i]))) return rc;
+        if (token) { XH_HIP(hipEventRecord(b->evTok[sub], st)); b->tokSet[sub] = true; }
         if ((rc = mark(1))) return rc;
         if (d.rect)
         {
@@ -432,14 +465,44 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
         for (int s = 0; s < S; s++)
         {
             if (s) XH_HIP(hipStreamWaitEvent(b->sub[s], b->evFork, 0));
-            if ((rc = step_range(b, (F * s / S) * ctuRows, (F * (s + 1) / S) * ctuRows, true, b->sub[s], s == 0 ? ev : nullptr)) != X265HIP_OK) return rc;
+            if ((rc = step_range(b, (F * s / S) * ctuRows, (F * (s + 1) / S) * ctuRows, true, b->sub[s], s == 0 ? ev : nullptr, s)) != X265HIP_OK) return rc;
         }
+        if (b->pingpong) { b->unjoined = true; return X265HIP_OK; }               // joined by x265hip_batch_sync
     }
     for (int s = 1; s < S; s++)
     {
         XH_HIP(hipEventRecord(b->evJoin[s], b->sub[s]));
         XH_HIP(hipStreamWaitEvent(b->sub[0], b->evJoin[s], 0));
     }
+    return X265HIP_OK;
+}
+
+// the whole batch as ONE sub-batch on the context's stream, whatever desc.streams says: the stages then run one after the other, which is what per-stage times need
+extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
+{
+    if (!b) { set_error("batch_step_one_stream: null batch"); return X265HIP_EARG; }
+    if (b->d.bandRows > 0) { set_error("batch_step_one_stream: not with the band-major schedule"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(b->ctx->device));
+    int rc = join_subs(b);
+    if (rc) return rc;
+    for (int s = 1; s < b->nsub; s++)
+    {   // (a batch without the alternating schedule joins at the end of every step already; this makes the call safe after either)
+        XH_HIP(hipEventRecord(b->evJoin[s], b->sub[s]));
+        XH_HIP(hipStreamWaitEvent(b->sub[0], b->evJoin[s], 0));
+    }
+    hipEvent_t* ev = nullptr;
+    if (b->timing)
+    {
+        const size_t per = 2 * b->stageNames.size(), set = (size_t)(b->timedSteps % kTimingSets);
+        while (b->evStage.size() < (set + 1) * per) { hipEvent_t e; XH_HIP(hipEventCreate(&e)); b->evStage.push_back(e); }
+        ev = b->evStage.data() + set * per;
+        b->timedSteps++;
+    }
+    rc = step_range(b, 0, b->d.frames * (b->d.height / CTU), true, b->sub[0], ev);
+    if (rc) return rc;
+    // the sub-streams' next pass starts behind this one
+    XH_HIP(hipEventRecord(b->evFork, b->sub[0]));
+    for (int s = 1; s < b->nsub; s++) XH_HIP(hipStreamWaitEvent(b->sub[s], b->evFork, 0));
     return X265HIP_OK;
 }
 
@@ -479,6 +542,7 @@ extern "C" int x265hip_batch_read_results_ref(x265hip_batch* b, int w, int h, in
     const int i = b ? shape_slot(b, w, h, rect) : -1;
     if (!b || i < 0 || ref < 0 || ref >= b->refs || !out) { set_error("batch_read_results: bad arguments"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
+    { const int jrc = join_subs(b); if (jrc) return jrc; }
     const x265hip_me_result* src = rect ? b->rresults[ref][i] : b->results[ref][i];
     const int n = rect ? b->nrtasks[i] : b->ntasks[i];
     XH_HIP(hipMemcpyAsync(out, src, (size_t)n * sizeof(x265hip_me_result), hipMemcpyDeviceToHost, b->ctx->stream));
@@ -491,6 +555,7 @@ extern "C" int x265hip_batch_read_choices(x265hip_batch* b, int w, int h, x265hi
     const int i = b ? shape_slot(b, w, h, rect) : -1;
     if (!b || i < 0 || b->refs < 2 || !out) { set_error("batch_read_choices: bad arguments (choices exist with refs > 1)"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
+    { const int jrc = join_subs(b); if (jrc) return jrc; }
     const int n = rect ? b->nrtasks[i] : b->ntasks[i];
     XH_HIP(hipMemcpyAsync(out, rect ? b->rchoice[i] : b->choice[i], (size_t)n * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, b->ctx->stream));
     XH_HIP(hipStreamSynchronize(b->ctx->stream));
@@ -500,6 +565,7 @@ extern "C" int x265hip_batch_read_coeffs(x265hip_batch* b, int16_t* coeff, uint3
 {
     if (!b || (!coeff && !numSig)) { set_error("batch_read_coeffs: bad arguments"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
+    { const int jrc = join_subs(b); if (jrc) return jrc; }
     if (coeff) XH_HIP(hipMemcpyAsync(coeff, b->coeff, ((size_t)b->ntu << (2 * b->d.tuLog2)) * sizeof(int16_t), hipMemcpyDeviceToHost, b->ctx->stream));
     if (numSig) XH_HIP(hipMemcpyAsync(numSig, b->numSig, (size_t)b->ntu * sizeof(uint32_t), hipMemcpyDeviceToHost, b->ctx->stream));
     XH_HIP(hipStreamSynchronize(b->ctx->stream));
@@ -509,6 +575,7 @@ extern "C" int x265hip_batch_read_plane(x265hip_batch* b, int which, int frame, 
 {
     if (!b || which < 0 || which > b->refs || frame < 0 || frame >= b->d.frames || !out) { set_error("batch_read_plane: bad arguments"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
+    { const int jrc = join_subs(b); if (jrc) return jrc; }
     const pixel* plane = (which ? b->ref[which - 1] : b->cur) + (size_t)frame * b->plane;
     XH_HIP(hipMemcpyAsync(out, plane, (size_t)b->plane * sizeof(pixel), hipMemcpyDeviceToHost, b->ctx->stream));
     XH_HIP(hipStreamSynchronize(b->ctx->stream));

@@ -86,6 +86,10 @@ class HostBatch:
     def step(self):
         self._ck(self.lib.x265hip_batch_step(self.batch), "batch_step")
 
+    def step_one_stream(self):
+        """the same pass on the context's stream alone (x265hip_batch_step_one_stream): stages one after the other, for per-stage times"""
+        self._ck(self.lib.x265hip_batch_step_one_stream(self.batch), "batch_step_one_stream")
+
     def sync(self):
         self._ck(self.lib.x265hip_ctx_sync(self.ctx), "ctx_sync")
 
