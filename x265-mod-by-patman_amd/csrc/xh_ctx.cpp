@@ -56,7 +56,7 @@ struct x265hip_batch
     // two sub-batches of whole pictures (streams = 2): the 64x64 level (window in LDS, two workgroups fill a CU) of the two streams ALTERNATES -- a stream takes it when
     // the other has finished its own -- so that it always runs beside the other stream's 32x32 .. 8x8 levels, never beside itself; and the sub-batches are not joined
     // between steps (a stream's next pass only depends on its own previous one): they are joined when something waits on the context's stream (join_subs)
-    hipEvent_t evTok[2] = {}; bool tokSet[2] = {}; int pingpong = 0; bool unjoined = false;
+    hipEvent_t evTok[8] = {}; bool tokSet[8] = {}; int pingpong = 0; bool unjoined = false;
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
     std::vector<void*> owned;
@@ -203,7 +203,7 @@ extern "C" void x265hip_batch_destroy(x265hip_batch* b)
     (void)hipSetDevice(b->ctx->device);
     { auto& v = b->ctx->batches; v.erase(std::remove(v.begin(), v.end(), b), v.end()); }
     (void)hipStreamSynchronize(b->ctx->stream);
-    for (int i = 0; i < 2; i++) if (b->evTok[i]) (void)hipEventDestroy(b->evTok[i]);
+    for (int i = 0; i < 8; i++) if (b->evTok[i]) (void)hipEventDestroy(b->evTok[i]);
     for (int i = 1; i < 8; i++) if (b->sub[i]) { (void)hipStreamSynchronize(b->sub[i]); x265hip_tme_release_stream(b->sub[i]); (void)hipStreamDestroy(b->sub[i]); }
     for (int i = 0; i < 8; i++) if (b->evJoin[i]) (void)hipEventDestroy(b->evJoin[i]);
     if (b->evFork) (void)hipEventDestroy(b->evFork);
@@ -229,10 +229,10 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
 #define XBH(call, what) do { if ((call) != hipSuccess) return fail(hip_fail(hipErrorUnknown, what)); } while (0)
     XBH(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming), "hipEventCreate");
     ctx->batches.push_back(b);
-    if (b->nsub == 2 && d->bandRows <= 0 && !xh_experiment("X265HIP_NO_PINGPONG"))
+    if ((b->nsub == 2 || (b->nsub > 2 && xh_experiment("X265HIP_RING"))) && d->bandRows <= 0 && !xh_experiment("X265HIP_NO_PINGPONG"))
     {
         b->pingpong = 1;
-        for (int i = 0; i < 2; i++) XBH(hipEventCreateWithFlags(&b->evTok[i], hipEventDisableTiming), "hipEventCreate");
+        for (int i = 0; i < b->nsub; i++) XBH(hipEventCreateWithFlags(&b->evTok[i], hipEventDisableTiming), "hipEventCreate");
     }
     for (int i = 0; i < b->nsub; i++)
     {
@@ -387,7 +387,8 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
         for (int r = 0; r < b->refs; r++) { res[r] = b->results[r][i]; par[r] = i ? b->results[r][i - 1] : nullptr; }
         if ((rc = mark(0))) return rc;
         const bool token = b->pingpong && sub >= 0 && i == 0;
-        if (token && b->tokSet[sub ^ 1]) XH_HIP(hipStreamWaitEvent(st, b->evTok[sub ^ 1], 0));
+        const int prev = (sub + b->nsub - 1) % b->nsub;                             // the token goes round the streams
+        if (token && b->tokSet[prev]) XH_HIP(hipStreamWaitEvent(st, b->evTok[prev], 0));
         if ((rc = search(lv, lv, b->tasks[i], g0 * per, (g1 - g0) * per, res, i ? par : nullptr, b->choice[i]))) return rc;
         if (token) { XH_HIP(hipEventRecord(b->evTok[sub], st)); b->tokSet[sub] = true; }
         if ((rc = mark(1))) return rc;
