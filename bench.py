@@ -954,7 +954,7 @@ def main():
         px = pipe.pixels_per_step * args.inner      # pixels of one step
         share = 1.0 if serial_stage_times else pipe.sub_batch_pictures() / args.frames      # the part of the batch one timed launch group covers
         n_tu = 1 << args.tu
-        alg = pipe.algorithmic_bytes()              # each plane byte once per launch + the records it writes
+        alg = pipe.algorithmic_bytes(whole_batch=serial_stage_times)      # each plane byte once per launch + the records it writes
         # dominant kernel = strictly the longest average launch of the step, whatever it is bound by
         dom = max(kms, key=lambda k: kms[k])
         achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9

@@ -137,11 +137,12 @@ class HostBatch:
         S = max(1, min(self.streams, self.F))
         return self.F * 1 // S if S > 1 else self.F
 
-    def algorithmic_bytes(self):
-        """SURVEY 8(d) compulsory bytes per launch group of ONE sub-batch (what the stage events bracket): each plane byte once + the records the stage writes (16 B per PU
-        and reference, 2 B per coefficient + 4 B per TU); the phase-plane stage reads one padded plane stack and writes 16, per reference."""
+    def algorithmic_bytes(self, whole_batch=False):
+        """SURVEY 8(d) compulsory bytes per launch group of ONE sub-batch (what the stage events bracket; whole_batch: of a one-stream pass, step_one_stream): each plane
+        byte once + the records the stage writes (16 B per PU and reference, 2 B per coefficient + 4 B per TU); the phase-plane stage reads one padded plane stack and writes
+        16, per reference."""
         bpp = 1 if self.depth == 8 else 2
-        nf = self.sub_batch_pictures()
+        nf = self.F if whole_batch else self.sub_batch_pictures()
         px = int(nf * self.W * self.H)
         share = nf / self.F
         alg = {"me%d" % lv: px * (1 + self.refs) * bpp + int(len(self.tasks_host[lv]) * share) * 16 * self.refs for lv in LEVELS}
