@@ -59,11 +59,15 @@ def test_both_seams_together(depth, args, tmp_path):
 # --hme: the encoder switches it off below 540 lines (encoder.cpp:4799-4806), and below 720 lines the lookahead has no cooperative slices (slicetype.cpp:1165-1169)
 @pytest.mark.parametrize("depth,args", [(8, ["960", "544", "6", "superfast", "hme=1"]),                                   # hme-search hex,umh,umh; hme-range 16,32,48
                                         (8, ["960", "544", "6", "faster", "hme=1", "hme-search=umh,hex,hex", "hme-range=24,24,32", "bframes=3", "b-adapt=2"]),
-                                        (10, ["960", "544", "5", "superfast", "hme=1", "hme-search=hex"])])
+                                        (10, ["960", "544", "5", "superfast", "hme=1", "hme-search=hex"]),
+                                        (8, ["960", "544", "8", "fast", "hme=1", "weightp=1", "bframes=2"])])       # with a fade: list 0 is searched in the weighted copy on the half-resolution level only
 def test_bitstream_identical_with_gpu_hme_lookahead(depth, args, tmp_path):
     """--hme: the quarter-resolution sweep runs on the GPU too (x265hip_la_enable_hme + x265hip_la_estimate_desc.hme); Lowres::lowerResMvs / lowerResMvCosts come back"""
-    cpu, h_cpu = encode(depth, False, False, False, args, str(tmp_path / "cpu.hevc"))
-    gpu, h_gpu = encode(depth, True, False, False, args, str(tmp_path / "gpu.hevc"))
+    fade = "weightp=1" in args
+    cpu, h_cpu = encode(depth, False, False, False, args, str(tmp_path / "cpu.hevc"), fade)
+    gpu, h_gpu = encode(depth, True, False, False, args, str(tmp_path / "gpu.hevc"), fade)
+    if fade:
+        assert gpu["la_weighted"] > 0, "the fade did not make the lookahead weight a reference: %s" % gpu
     assert gpu["la_estimates"] > 0 and gpu["la_cpu_estimates"] == 0, "the GPU lookahead did not run: %s" % gpu
     assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
 
