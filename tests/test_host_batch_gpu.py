@@ -109,6 +109,25 @@ def test_two_streams_are_joined_when_something_reads_and_one_stream_steps_give_t
     assert all(o == outs[0] for o in outs[1:])
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_fused_lower_levels_give_the_bytes_of_a_launch_per_level(depth):
+    """x265hip_batch_set_fused: the 16x16 / 8x8 levels (mode 2: the 32x32 level too) of a 32x32 quadrant searched by one wavefront in one launch (csrc/kern_me_pyr.hip)"""
+    W, H, F = 320, 192, 3
+    pairs = pairs_for(W, H, depth, F, 1, seed0=520)
+    outs = []
+    for mode, streams in ((0, 1), (1, 1), (2, 1), (2, 2), (4, 1), (4, 2)):      # (mode | 4: the 64x64 level with its start-stage launch, the form of rounds 1-2)
+        hb = make(depth, W, H, F, qp=27, merange=57, method=3, subme=3, tu_log2=5, streams=streams)
+        try:
+            hb.set_fused(mode)
+            hb.upload(pairs)
+            hb.step(); hb.step(); hb.sync()
+            co, ns = hb.coeffs()
+            outs.append([hb.results(lv).tobytes() for lv in LEVELS] + [co.tobytes(), ns.tobytes()])
+        finally:
+            hb.close()
+    assert all(o == outs[0] for o in outs[1:])
+
+
 def test_stage_timing_and_names():
     hb = make(8, 256, 128, 4, method=3, subme=3, merange=24, rect=True, streams=2)
     try:

@@ -2,6 +2,7 @@
 // lists, one step = phase planes -> ME 64 / 32 / 16 / 8 -> TQ.  Plain HIP runtime calls around the batch entry points of x265hip_frame.h.
 #include "xh_common.h"
 #include "../../include/x265hip_ctx.h"
+#include "xh_internal.h"
 #include <algorithm>
 #include <cstring>
 #include <new>
@@ -57,6 +58,10 @@ struct x265hip_batch
     // the other has finished its own -- so that it always runs beside the other stream's 32x32 .. 8x8 levels, never beside itself; and the sub-batches are not joined
     // between steps (a stream's next pass only depends on its own previous one): they are joined when something waits on the context's stream (join_subs)
     hipEvent_t evTok[8] = {}; bool tokSet[8] = {}; int pingpong = 0; bool unjoined = false;
+    // the 16x16 / 8x8 levels (fusedFrom32: the 32x32 level too) of a sub-batch in ONE launch, a wavefront per 32x32 quadrant (kern_me_pyr.hip); x265hip_batch_set_fused.
+    // Off by default: measured slower than a launch per level (profiles/r03_fused_ab.txt)
+    bool fused = false, fusedFrom32 = false;
+    bool ownStart64 = true;                  // STAR: the 64x64 level without its start-stage launch (kern_me_star.hip xh_me_star_own64); x265hip_batch_set_fused(mode | 4) turns it off for A/B
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
     std::vector<void*> owned;
@@ -366,6 +371,9 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
     {
         for (int r = 0; r < b->refs; r++)
         {
+            if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
+                rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.subme, res[r] + first, b->planes[r], planeElems);
+            else
             rc = x265hip_me_batch(st, w, h, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.method, d.subme,
                                   res[r] + first, parent ? parent[r] : nullptr, up ? b->planes[r] : nullptr, up ? planeElems : 0);
             if (rc != X265HIP_OK) return rc;
@@ -380,9 +388,25 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
         }
         return X265HIP_OK;
     };
+    // the lower three levels fused: one reference, squares only, STAR out of phase planes (the stage slots of the 16x16 and 8x8 levels then hold empty intervals,
+    // the 32x32 slot the whole launch)
+    const bool fusedLower = b->fused && b->refs == 1 && !d.rect && up && xh_me_pyr_ok(d.method, planeElems, kHalf);
     for (int i = 0; i < 4; i++)
     {
         const int lv = kLevels[i], per = (d.width / lv) * (CTU / lv);               // PUs of this level per CTU row
+        if (fusedLower && i >= (b->fusedFrom32 ? 1 : 2))
+        {
+            if ((rc = mark(0))) return rc;
+            if (i == (b->fusedFrom32 ? 1 : 2))
+            {
+                const x265hip_me_task* tl[3] = { b->tasks[1], b->tasks[2], b->tasks[3] };
+                x265hip_me_result* rl[3] = { b->results[0][1], b->results[0][2], b->results[0][3] };
+                if ((rc = xh_me_pyr(st, b->cur, b->stride, b->ref[0], b->stride, tl, rl, b->fusedFrom32 ? b->results[0][0] : nullptr, g0, g1 - g0, d.width, b->costRow, kHalf, d.merange, d.method, d.subme,
+                                    b->planes[0], planeElems)) != X265HIP_OK) return rc;
+            }
+            if ((rc = mark(1))) return rc;
+            continue;
+        }
         x265hip_me_result* res[X265HIP_MAX_REF]; x265hip_me_result* par[X265HIP_MAX_REF];
         for (int r = 0; r < b->refs; r++) { res[r] = b->results[r][i]; par[r] = i ? b->results[r][i - 1] : nullptr; }
         if ((rc = mark(0))) return rc;
@@ -507,6 +531,7 @@ extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
     return X265HIP_OK;
 }
 
+extern "C" int x265hip_batch_set_fused(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->fused = (on & 3) != 0; b->fusedFrom32 = (on & 3) == 2; b->ownStart64 = !(on & 4); return X265HIP_OK; }
 extern "C" int x265hip_batch_set_timing(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->timing = on != 0; return X265HIP_OK; }
 extern "C" int x265hip_batch_stage_count(const x265hip_batch* b) { return b ? (int)b->stageNames.size() : 0; }
 extern "C" const char* x265hip_batch_stage_name(const x265hip_batch* b, int i) { return (b && i >= 0 && i < (int)b->stageNames.size()) ? b->stageNames[i].c_str() : nullptr; }
