@@ -45,7 +45,9 @@ __device__ __forceinline__ int quant_one(int coef, int q, int qBits, int add, in
     return clip3(-32768, 32767, level * sign);
 }
 
-template<int N>
+// BI: the launch has bi-directional TUs (a second 14-bit prediction per wavefront in LDS).  Without it a workgroup of the 32x32 form holds 26 KB instead of 34.5 KB of LDS:
+// six wavefronts per SIMD instead of four, for a kernel that spends three quarters of its time waiting on memory
+template<int N, bool BI>
 __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
 {
     constexpr int NN = N * N, LG = Lg<N>::v;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     __shared__ __attribute__((aligned(16))) int16_t s_a[4][NN];
     __shared__ __attribute__((aligned(16))) int16_t s_b[4][(N + 7) * N];
     __shared__ int8_t s_m[NN];
-    __shared__ __attribute__((aligned(16))) int16_t s_c[4][NN];                        // second 14-bit prediction of a bi-directional TU
+    __shared__ __attribute__((aligned(16))) int16_t s_c[BI ? 4 : 1][BI ? NN : 8];      // second 14-bit prediction of a bi-directional TU
 
     if (N < 32)
     {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
 
     // ---- motion compensation into LDS (ends with a wave_sync): the reference's copy_pp | hpp | vpp | hvpp dispatch, or -- with
     //      the phase planes of this reference -- a copy of the block at the integer part of the MV out of plane 4*yFrac + xFrac ----
-    if (a.ref1)
+    if (BI && a.ref1)
     {   // bi-directional TU: Predict::motionCompensation's B-slice branch (predict.cpp:186-196, 211): two 14-bit predictions, addAvg
         build_pred_short(c, plane_view(c), tk.mv[0], tk.mv[1], sa);
         McCtx c1 = c; c1.fref = a.ref1 + tk.refOff;
@@ -311,7 +313,8 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
 
 template<int N> int launch_tq(hipStream_t st, const TqArgs& a)
 {
-    hipLaunchKernelGGL(tq_kernel<N>, dim3((a.n + 3) / 4), dim3(256), 0, st, a);
+    if (a.ref1) hipLaunchKernelGGL((tq_kernel<N, true>), dim3((a.n + 3) / 4), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((tq_kernel<N, false>), dim3((a.n + 3) / 4), dim3(256), 0, st, a);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
