@@ -985,7 +985,11 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": (traffic_all.get(dom) * share if traffic_all.get(dom) is not None else None), "traffic_source": traffic_src if traffic_all.get(dom) is not None else None,
                          "algorithmic_bytes_per_launch": int(alg[dom]), "avg_launch_ms": round(kms[dom], 4),
                          "all_kernels_ms": {k: round(v, 4) for k, v in kms.items()},
-                         "all_kernels_GBps": {k: round(alg[k] / (v * 1e-3) / 1e9, 2) for k, v in kms.items()}},
+                         "all_kernels_GBps": {k: round(alg[k] / (v * 1e-3) / 1e9, 2) for k, v in kms.items()},
+                         # what the launches actually move through the L2's memory side (committed counter pass: 2 x FETCH_SIZE + WRITE_SIZE, profiles/r03_fetch_calib.txt) over their
+                         # live time: the lower levels of the search stream the 16 phase planes at most of the achievable HBM rate
+                         "all_kernels_traffic_GBps": ({k: round(traffic_all[k] * share / (v * 1e-3) / 1e9, 1) for k, v in kms.items() if traffic_all.get(k) is not None and v > 0.02} if traffic_all else None),
+                         "hbm_achievable_GBps": 6300},
             # the search kernels are vector-issue bound, not bandwidth bound: instructions per launch (SQ_INSTS_VALU of the committed counter pass)
             # over the live launch time, against the chip's wave-instruction issue rate
             "roofline_valu": {"bound": "valu issue", "unit": "G wave-instr/s", "peak": round(valu_peak / 1e9, 1),

@@ -4,10 +4,10 @@
 usage: summarize_pmc.py <dir-with-*_counter_collection.csv> [...]   -> one line per (kernel, pass) on stdout
        summarize_pmc.py --traffic <fetch_dir> <write_dir>            -> JSON {bench kernel name: HBM bytes per launch}
 
-FETCH_SIZE / WRITE_SIZE are reported in KiB.  Calibration on this box: kern_planes writes
-exactly 15 planes (WRITE_SIZE x 1024 = 324.5 MB vs 324.4 MB computed) and the 4-byte-per-lane loads of tq_kernel
-give FETCH_SIZE x 1024 = the two planes it reads, so no x2 correction is applied for these access widths (the
-guide's x2 applies to 16-byte-per-lane streaming reads, which these kernels do not issue).
+FETCH_SIZE / WRITE_SIZE are reported in KiB.  Calibration on this box: kern_planes writes exactly 15 planes (WRITE_SIZE x 1024 = 324.5 MB vs 324.4 MB computed): writes
+need no correction.  FETCH_SIZE reports HALF of the bytes of a coalesced streaming read at EVERY access width these kernels use -- profiles/micro/fetch_calib.hip streams
+1 GiB with 4, 8, 12 and 16 bytes per lane: 524,296-524,298 KiB each (profiles/r03_fetch_calib.txt) -- so the read side is doubled (FETCH_CORRECTION), as the MI355X guide
+prescribes for gfx950.  (Rounds 1-2 did not double it: tq_kernel's reading 'equal to its two planes' was its line over-fetch of 2x meeting the counter's 1/2.)
 """
 import csv, glob, json, os, re, sys
 from collections import defaultdict
@@ -59,14 +59,17 @@ def per_step(d):
     return {b: {c: v / max(steps, 1) for c, v in cs.items()} for b, cs in tot.items()}
 
 
+FETCH_CORRECTION = 2.0
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "--traffic":
         fetch, write = per_step(sys.argv[2]), per_step(sys.argv[3])
-        out = {"_source": sys.argv[4] if len(sys.argv) > 4 else "FETCH_SIZE + WRITE_SIZE (KiB) per step"}
+        out = {"_source": (sys.argv[4] if len(sys.argv) > 4 else "FETCH_SIZE + WRITE_SIZE (KiB) per step") + "; read side = 2 x FETCH_SIZE (profiles/r03_fetch_calib.txt)"}
         for b in fetch:
             if "FETCH_SIZE" in fetch[b] and b in write:
-                out[b] = int((fetch[b]["FETCH_SIZE"] + write[b].get("WRITE_SIZE", 0.0)) * 1024)
-                out[b + "_read"] = int(fetch[b]["FETCH_SIZE"] * 1024)
+                out[b] = int((FETCH_CORRECTION * fetch[b]["FETCH_SIZE"] + write[b].get("WRITE_SIZE", 0.0)) * 1024)
+                out[b + "_read"] = int(FETCH_CORRECTION * fetch[b]["FETCH_SIZE"] * 1024)
                 out[b + "_write"] = int(write[b].get("WRITE_SIZE", 0.0) * 1024)
         print(json.dumps(out, indent=1, sort_keys=True))
     elif sys.argv[1] == "--valu":
