@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--inner", type=int, default=5, help="passes over the resident batch per step (a step of the driver's --steps 20 then lasts long enough for the whole timed region to be >= 0.5 s)")
     ap.add_argument("--no-streams-leg", action="store_true", help="skip the extra leg that steps the same batch as 2 and 3 sub-batches of whole pictures on their own streams (x265hip_batch_desc.streams); reported under \"streams\", not part of value")
-    ap.add_argument("--fused", type=int, default=0, help="x265hip_batch_set_fused: 1 = the 16x16 and 8x8 levels in one launch (a wavefront per 32x32 quadrant), 2 = the 32x32 level too; 0 = a launch per level (default; the fused forms are slower: profiles/r03_fused_ab.txt); | 4 = the 64x64 level with its start-stage launch")
+    ap.add_argument("--fused", type=int, default=0, help="x265hip_batch_set_fused: 1 = the 16x16 and 8x8 levels in one launch (a wavefront per 32x32 quadrant), 2 = the 32x32 level too; 0 = a launch per level (default; the fused forms are slower: profiles/r03_fused_ab.txt); | 4 = the 64x64 level with its start-stage launch; | 8 = tiled phase planes (16 bit; fewer bytes, slower: profiles/r03_tiled_ab.txt)")
     ap.add_argument("--splits", type=int, default=2, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
     ap.add_argument("--band-rows", type=int, default=0, help="band-major schedule: bands of this many CTU rows go through all levels + TQ before the stream takes the next band (x265hip_batch_desc.bandRows); 0 = sub-batches of whole pictures")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")

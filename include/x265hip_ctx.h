@@ -91,7 +91,10 @@ int   x265hip_batch_set_timing(x265hip_batch* batch, int on);
  * and 8x8 levels, 2 = the 32x32 level too, 0 = a launch per level (the default: the fused forms give the same results -- tests/test_host_batch_gpu.py -- and were measured
  * 30 % slower at 4K 10 bit, profiles/r03_fused_ab.txt).  The stage slots of the fused levels hold the whole launch in the first and empty intervals in the others.
  * mode | 4: the 64x64 level of a STAR search WITH its start-stage launch (by default the batch's own top-level tasks -- zero predictor, no candidates -- are started inside
- * the full-pel kernel, csrc/star64_body.inc: two launches instead of three, same results). */
+ * the full-pel kernel, csrc/star64_body.inc: two launches instead of three, same results).
+ * mode | 8 (16-bit library, one reference, squares only, STAR): the phase planes of the batch are TILED -- slots 1..15 as 16 x 4-pixel tiles of one 128-byte line -- and read
+ * by the tiled forms of the search kernels and of the TQ stage; same results, 20-30 % fewer bytes moved, 40 % slower (profiles/r03_tiled_ab.txt): off by default.  The
+ * phase planes x265hip_batch_device_ptr(.., 2) hands out are in that layout while the mode is on. */
 int   x265hip_batch_set_fused(x265hip_batch* batch, int mode);
 int   x265hip_batch_stage_count(const x265hip_batch* batch);
 const char* x265hip_batch_stage_name(const x265hip_batch* batch, int i);

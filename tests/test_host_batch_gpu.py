@@ -115,7 +115,8 @@ def test_fused_lower_levels_give_the_bytes_of_a_launch_per_level(depth):
     W, H, F = 320, 192, 3
     pairs = pairs_for(W, H, depth, F, 1, seed0=520)
     outs = []
-    for mode, streams in ((0, 1), (1, 1), (2, 1), (2, 2), (4, 1), (4, 2)):      # (mode | 4: the 64x64 level with its start-stage launch, the form of rounds 1-2)
+    # (mode | 4: the 64x64 level with its start-stage launch, the form of rounds 1-2; mode | 8: at 16 bit TILED phase planes -- slots 1..15 as 16 x 4-pixel tiles -- and the kernels that read them)
+    for mode, streams in ((0, 1), (1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (8, 1), (8, 2), (12, 1)):
         hb = make(depth, W, H, F, qp=27, merange=57, method=3, subme=3, tu_log2=5, streams=streams)
         try:
             hb.set_fused(mode)

@@ -269,6 +269,8 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
     }
 }
 #else
+// TILED: slots 1..15 are written as tiles of 16 x 4 pixels (xh_mc.h tile_off; a wavefront's store then fills four whole 128-byte lines); slot 0 by rows
+template<bool TILED>
 __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restrict__ ref, intptr_t stride, int rows,
                                                             pixel* __restrict__ out, int64_t planeElems)
 {
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                 pk.x = (uint32_t)(uint16_t)im[0] | ((uint32_t)(uint16_t)im[1] << 16);
                 pk.y = (uint32_t)(uint16_t)im[2] | ((uint32_t)(uint16_t)im[3] << 16);
                 *(lu2*)((lshort*)s_im[xf - 1] + rr * TW + x4) = pk;
-                if (inTile) store4g(out + (int64_t)xf * planeElems + (intptr_t)gy * stride + x0 + x4, o);
+                if (inTile) store4g(out + (int64_t)xf * planeElems + (TILED ? (intptr_t)tile_off((uint32_t)(x0 + x4), (uint32_t)gy, (uint32_t)stride) : (intptr_t)gy * stride + x0 + x4), o);
             }
         }
     }
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
     const int gy = y0 + y;
     if (gy >= rows || x0 + x4 >= stride) return;
     pixel* o0 = out + (intptr_t)gy * stride + x0 + x4;
+    pixel* ot = TILED ? out + (intptr_t)tile_off((uint32_t)(x0 + x4), (uint32_t)gy, (uint32_t)stride) : o0;      // slots 1..15
     {
         int col[8][4];
 #pragma unroll
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                 for (int k = 0; k < 8; k++) s += col[k][e] * k_lumaTaps[yf][k];
                 o[e] = clip3(0, XH_PIXEL_MAX, (int)(int16_t)((s + 32) >> 6));
             }
-            store4g(o0 + (int64_t)(yf * 4) * planeElems, o);
+            store4g(ot + (int64_t)(yf * 4) * planeElems, o);
         }
     }
     const int shift2 = XH_IF_FILTER_PREC + headRoom, offset2 = (1 << (shift2 - 1)) + (XH_IF_INTERNAL_OFFS << XH_IF_FILTER_PREC);
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                 for (int k = 0; k < 8; k++) s += col[k][e] * k_lumaTaps[yf][k];
                 o[e] = clip3(0, XH_PIXEL_MAX, (int)(int16_t)((s + offset2) >> shift2));
             }
-            store4g(o0 + (int64_t)(yf * 4 + xf) * planeElems, o);
+            store4g(ot + (int64_t)(yf * 4 + xf) * planeElems, o);
         }
     }
 }
@@ -403,8 +406,29 @@ extern "C" int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_
 #else
     dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
 #endif
+#if X265_DEPTH == 8
     hipLaunchKernelGGL(subpel_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                        (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
+#else
+    hipLaunchKernelGGL(subpel_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                       (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
+#endif
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
+}
+
+// The same planes with slots 1..15 tiled (16-bit library; pitch a multiple of 16, rows a multiple of 4): for readers that take the tiled layout (xh_me_star_tiled, xh_tq_batch_tiled)
+bool xh_subpel_planes_tiled_ok(intptr_t stride, int rows) { return X265_DEPTH != 8 && stride >= 16 && (stride & 15) == 0 && (rows & 3) == 0; }
+int xh_subpel_planes_tiled(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems)
+{
+#if X265_DEPTH == 8
+    set_error("subpel_planes_tiled: 16-bit library only"); return X265HIP_EARG;
+#else
+    if (!refPlane || !outPlanes || !xh_subpel_planes_tiled_ok(stride, rows) || rows < 8 || planeElems < (int64_t)stride * rows || (planeElems & 3) || (((uintptr_t)refPlane | (uintptr_t)outPlanes) & 7))
+    { set_error("subpel_planes_tiled: bad arguments"); return X265HIP_EARG; }
+    dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
+    hipLaunchKernelGGL(subpel_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+#endif
 }

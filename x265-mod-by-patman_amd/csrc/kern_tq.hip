@@ -30,6 +30,7 @@ struct TqArgs
     int chroma;
     const pixel* ref1; int choiceRef1;          // bi-directional launch: list-1 reference plane and index
     int dst4;                                   // 4x4 TUs: DST-VII instead of the DCT (intra luma, quant.cpp:429-432, 585-603)
+    int tiled;                                  // 16 bit: slots 1..15 of `planes` are tiled (xh_mc.h tile_off; xh_tq_batch_tiled)
 };
 
 template<int N> struct Lg { static const int v = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5; };
@@ -114,10 +115,30 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     else if (a.planes)
     {
         const int f = (tk.mv[1] & 3) * 4 + (tk.mv[0] & 3);
+        if (a.tiled && f)
+        {   // the block out of the tiles of slot f: a quad that straddles a tile column pixel by pixel
+            const pixel* slot = a.planes + (int64_t)f * a.planeElems;
+            const uint32_t rs32 = (uint32_t)a.rs, py = (uint32_t)tk.refOff / rs32, px = (uint32_t)tk.refOff - py * rs32;
+            const uint32_t X0 = px + (uint32_t)(tk.mv[0] >> 2), Y0 = py + (uint32_t)(tk.mv[1] >> 2);
+            QUAD_LOOP(c, q, y, x4)
+                int v[4];
+                const uint32_t X = X0 + (uint32_t)x4, Y = Y0 + (uint32_t)y;
+                if ((X & 15u) <= 12u) load4u(slot + tile_off(X, Y, rs32), v);
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = slot[tile_off(X + (uint32_t)e, Y, rs32)];
+                }
+                store4(c.pred + y * N + x4, v);
+            QUAD_END
+        }
+        else
+        {
         const pixel* src = (f ? a.planes + (int64_t)f * a.planeElems : a.ref) + tk.refOff + (intptr_t)(tk.mv[1] >> 2) * a.rs + (tk.mv[0] >> 2);
         QUAD_LOOP(c, q, y, x4)
             int v[4]; load4u(src + (intptr_t)y * a.rs + x4, v); store4(c.pred + y * N + x4, v);
         QUAD_END
+        }
         wave_sync();
     }
     else
@@ -321,10 +342,10 @@ template<int N> int launch_tq(hipStream_t st, const TqArgs& a)
 
 } // namespace
 
-extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
-                                const x265hip_tu_task* tasks, int n, const x265hip_tq_params* params,
-                                int16_t* coeff, uint32_t* numSig, void* reconPlane, intptr_t reconStride, uint64_t* sse,
-                                const x265hip_me_result* mvSource)
+static int tq_batch(void* stream, int log2TrSize, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                    const x265hip_tu_task* tasks, int n, const x265hip_tq_params* params,
+                    int16_t* coeff, uint32_t* numSig, void* reconPlane, intptr_t reconStride, uint64_t* sse,
+                    const x265hip_me_result* mvSource, int tiled)
 {
     if (n <= 0) return X265HIP_OK;
     if (!tasks || !params || !coeff || !numSig || log2TrSize < 2 || log2TrSize > 5 || params->qp < 0 || params->qp > 51 ||
@@ -333,7 +354,7 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
     TqArgs a = { (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride, tasks, n,
                  params->qp, params->add, params->quantCoeff, params->deltaU, coeff, numSig,
                  (pixel*)reconPlane, reconStride, sse, mvSource, (const pixel*)params->subpelPlanes, params->planeElems,
-                 params->choice, params->choiceList, params->choiceRef, params->chroma, (const pixel*)params->refPlane1, params->choiceRef1, params->dst4 };
+                 params->choice, params->choiceList, params->choiceRef, params->chroma, (const pixel*)params->refPlane1, params->choiceRef1, params->dst4, tiled };
     if (params->refPlane1 && (!params->choice || params->chroma || params->choiceRef1 < 0 || params->choiceRef1 >= X265HIP_MAX_REF)) { set_error("tq_batch: a bi-directional launch needs choice records, luma planes and choiceRef1 in 0..15"); return X265HIP_EARG; }
     if (params->choice && (params->choiceList < 0 || params->choiceList > 1 || params->choiceRef < 0 || params->choiceRef >= X265HIP_MAX_REF)) { set_error("tq_batch: bad choiceList / choiceRef"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
@@ -344,4 +365,20 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
     case 4: return launch_tq<16>(st, a);
     default: return launch_tq<32>(st, a);
     }
+}
+
+extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                                const x265hip_tu_task* tasks, int n, const x265hip_tq_params* params,
+                                int16_t* coeff, uint32_t* numSig, void* reconPlane, intptr_t reconStride, uint64_t* sse,
+                                const x265hip_me_result* mvSource)
+{
+    return tq_batch(stream, log2TrSize, curPlane, curStride, refPlane, refStride, tasks, n, params, coeff, numSig, reconPlane, reconStride, sse, mvSource, 0);
+}
+// x265hip_tq_batch for a plane buffer whose slots 1..15 are tiled (xh_subpel_planes_tiled; 16-bit library, luma, uni-directional)
+int xh_tq_batch_tiled(void* stream, int log2TrSize, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                      const x265hip_tu_task* tasks, int n, const x265hip_tq_params* params,
+                      int16_t* coeff, uint32_t* numSig, void* reconPlane, intptr_t reconStride, uint64_t* sse, const x265hip_me_result* mvSource)
+{
+    if (X265_DEPTH == 8 || !params || !params->subpelPlanes || params->chroma || params->refPlane1) { set_error("tq_batch_tiled: 16-bit luma planes, one reference"); return X265HIP_EARG; }
+    return tq_batch(stream, log2TrSize, curPlane, curStride, refPlane, refStride, tasks, n, params, coeff, numSig, reconPlane, reconStride, sse, mvSource, 1);
 }

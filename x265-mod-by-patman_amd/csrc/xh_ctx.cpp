@@ -61,6 +61,10 @@ struct x265hip_batch
     // the 16x16 / 8x8 levels (fusedFrom32: the 32x32 level too) of a sub-batch in ONE launch, a wavefront per 32x32 quadrant (kern_me_pyr.hip); x265hip_batch_set_fused.
     // Off by default: measured slower than a launch per level (profiles/r03_fused_ab.txt)
     bool fused = false, fusedFrom32 = false;
+    // 16-bit library, one reference, squares only, STAR: the phase planes of the batch are TILED (slots 1..15 as 16 x 4-pixel tiles of one 128-byte line, kern_planes.hip) and read
+    // by the tiled forms of the search kernels and of the TQ stage (kern_me_star_tiled.hip, xh_tq_batch_tiled).  OFF by default, x265hip_batch_set_fused(mode | 8) turns it on: it moves
+    // 20-30 % fewer bytes and is 40 % slower (profiles/r03_tiled_ab.txt, r03_tiled_pmc.txt)
+    bool tiled = false, tiledWanted = false;
     bool ownStart64 = true;                  // STAR: the 64x64 level without its start-stage launch (kern_me_star.hip xh_me_star_own64); x265hip_batch_set_fused(mode | 4) turns it off for A/B
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
@@ -339,7 +343,8 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
     const int rowsPerPic = d.height + 2 * d.margin;
     for (int r = 0; r < b->refs; r++)
     {
-        const int rc = x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems);
+        const int rc = b->tiled ? xh_subpel_planes_tiled(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems)
+                                : x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems);
         if (rc != X265HIP_OK) return rc;
     }
     return X265HIP_OK;
@@ -348,6 +353,13 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
 // One sub-batch on stream st: the CTU rows g0 .. g1 - 1 of the batch, counted through the pictures (global row g = picture * ctuRows + row).  Tasks of every
 // shape are laid out picture-major, then raster: a range of global CTU rows is a contiguous range of every task list.  withPlanes: the range is whole pictures and
 // their phase planes are made first; ev != nullptr: events around every stage (2 per stage)
+// can this batch run on tiled phase planes?  (decided per step: the planes are made anew by every step)
+bool tiled_ok(const x265hip_batch* b)
+{
+    const x265hip_batch_desc& d = b->d;
+    return b->tiledWanted && !b->fused && b->refs == 1 && !d.rect && d.usePlanes && d.method == X265HIP_ME_STAR && d.merange <= 57 &&
+           xh_subpel_planes_tiled_ok(b->stride, d.height + 2 * d.margin) && (uint64_t)(b->plane * d.frames) * 16u * sizeof(pixel) < (1ull << 32);
+}
 int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev, int sub = -1)
 {
     const x265hip_batch_desc& d = b->d;
@@ -371,7 +383,10 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
     {
         for (int r = 0; r < b->refs; r++)
         {
-            if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
+            if (b->tiled && w == h)
+                rc = xh_me_star_tiled(st, w, h, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.subme, res[r] + first, parent ? parent[r] : nullptr,
+                                      b->planes[r], planeElems, w == CTU && !parent && b->ownStart64);
+            else if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
                 rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.subme, res[r] + first, b->planes[r], planeElems);
             else
             rc = x265hip_me_batch(st, w, h, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.method, d.subme,
@@ -437,7 +452,7 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
         x265hip_tq_params p{};
         p.qp = d.qp; p.add = 85; p.subpelPlanes = up ? b->planes[r] : nullptr; p.planeElems = up ? planeElems : 0;
         if (b->refs > 1) { p.choice = b->choice[mi]; p.choiceList = 0; p.choiceRef = r; }
-        rc = x265hip_tq_batch(st, d.tuLog2, b->cur, b->stride, b->ref[r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
+        rc = (b->tiled ? xh_tq_batch_tiled : x265hip_tq_batch)(st, d.tuLog2, b->cur, b->stride, b->ref[r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
                               d.recon ? b->recon : nullptr, b->stride, d.recon ? b->sse + t0 : nullptr, b->refs > 1 ? nullptr : b->results[0][mi]);
         if (rc != X265HIP_OK) return rc;
     }
@@ -449,6 +464,7 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
 {
     if (!b) { set_error("batch_step: null batch"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
+    b->tiled = tiled_ok(b);
     const int F = b->d.frames, S = b->nsub, ctuRows = b->d.height / CTU, G = F * ctuRows, band = b->d.bandRows;
     hipEvent_t* ev = nullptr;
     if (b->timing)
@@ -508,6 +524,7 @@ extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
     if (!b) { set_error("batch_step_one_stream: null batch"); return X265HIP_EARG; }
     if (b->d.bandRows > 0) { set_error("batch_step_one_stream: not with the band-major schedule"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
+    b->tiled = tiled_ok(b);
     int rc = join_subs(b);
     if (rc) return rc;
     for (int s = 1; s < b->nsub; s++)
@@ -531,7 +548,7 @@ extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
     return X265HIP_OK;
 }
 
-extern "C" int x265hip_batch_set_fused(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->fused = (on & 3) != 0; b->fusedFrom32 = (on & 3) == 2; b->ownStart64 = !(on & 4); return X265HIP_OK; }
+extern "C" int x265hip_batch_set_fused(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->fused = (on & 3) != 0; b->fusedFrom32 = (on & 3) == 2; b->ownStart64 = !(on & 4); b->tiledWanted = (on & 8) != 0; return X265HIP_OK; }
 extern "C" int x265hip_batch_set_timing(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->timing = on != 0; return X265HIP_OK; }
 extern "C" int x265hip_batch_stage_count(const x265hip_batch* b) { return b ? (int)b->stageNames.size() : 0; }
 extern "C" const char* x265hip_batch_stage_name(const x265hip_batch* b, int i) { return (b && i >= 0 && i < (int)b->stageNames.size()) ? b->stageNames[i].c_str() : nullptr; }

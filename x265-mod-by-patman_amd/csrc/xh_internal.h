@@ -27,3 +27,14 @@ int xh_me_pyr(void* stream, const void* curPlane, intptr_t curStride, const void
 int xh_me_star_own64(void* stream, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
                      const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
                      int merange, int subpelRefine, x265hip_me_result* results, const void* subpelPlanes, int64_t planeElems);
+
+// Tiled phase planes (16-bit library): producer (kern_planes.hip) and the readers that take them (kern_me_star_tiled.hip, kern_tq.hip)
+bool xh_subpel_planes_tiled_ok(intptr_t stride, int rows);
+int xh_subpel_planes_tiled(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems);
+int xh_me_star_tiled(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                     const x265hip_me_task* tasks, int n, const uint16_t* costRow, int costHalfRange,
+                     int merange, int subpelRefine, x265hip_me_result* results, const x265hip_me_result* mvpSource,
+                     const void* tiledPlanes, int64_t planeElems, bool ownStart64);
+int xh_tq_batch_tiled(void* stream, int log2TrSize, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                      const struct x265hip_tu_task* tasks, int n, const struct x265hip_tq_params* params,
+                      int16_t* coeff, uint32_t* numSig, void* reconPlane, intptr_t reconStride, uint64_t* sse, const x265hip_me_result* mvSource);

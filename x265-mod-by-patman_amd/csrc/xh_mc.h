@@ -97,6 +97,9 @@ __device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const 
 // The lane unit of the size-specialised kernels: 8 bytes of one row (8 pixels at 8 bit, 4 pixels at 16 bit) as packed
 // register data.  8-byte units keep row chunks >= 16 bytes for every PU width >= 16, which is what the L1/TA front end
 // needs to stay at 4 lanes per clock (profiles/micro/l1bench.hip: 4-byte lanes on 8-byte rows cost 1 lane per clock).
+// Tiled phase planes (16-bit builds; me_body.inc XH_TILED, kern_planes.hip, kern_tq.hip): slots 1..15 of the plane buffer in tiles of 16 x 4 pixels = one 128-byte line
+// (row pitch rs a multiple of 16, rows a multiple of 4); element offset of pixel (X, Y) inside its slot
+__device__ __forceinline__ uint32_t tile_off(uint32_t X, uint32_t Y, uint32_t rs) { return (Y >> 2) * (4u * rs) + ((X >> 4) << 6) + ((Y & 3u) << 4) + (X & 15u); }
 typedef u32x2 fquad;
 #define XH_UNITPX (8 / (int)sizeof(pixel))
 __device__ __forceinline__ fquad ldq(const pixel* p) { u32x2 a; __builtin_memcpy(&a, p, 8); return a; }              // unaligned, global
