@@ -109,6 +109,10 @@ __device__ __forceinline__ fquad ldf(const lpixel* p) { return *(const lu2*)p; }
 // full 4 lanes per clock whatever their 8/16-byte alignment (profiles/micro/l1bench.hip).  a = address rounded down to 4, m = address & 3.
 __device__ __forceinline__ fquad ldq_a(const char* a, unsigned m)
 {
+#if defined(XH_LDQ_UNALIGNED) && X265_DEPTH != 8
+    // experiment (profiles/r03_ldq_unaligned_ab.txt): the 8 bytes straight from their pixel-aligned address -- no funnel shifts, a misaligned load for half of the lanes
+    fquad u; __builtin_memcpy(&u, __builtin_assume_aligned(a + m, 2), 8); return u;
+#endif
     struct W3 { uint32_t x, y, z; } w;
     __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 12);
     fquad r; r.x = __builtin_amdgcn_alignbyte(w.y, w.x, m); r.y = __builtin_amdgcn_alignbyte(w.z, w.y, m);
