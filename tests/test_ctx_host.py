@@ -46,6 +46,15 @@ def test_bad_descriptors_are_refused():
     assert lib.x265hip_batch_task_count(C.byref(ok), 48) < 0                  # not a pyramid level
 
 
+def test_batch_mode_switches_need_a_batch():
+    """x265hip_batch_set_fused / _set_timing / _step / _step_one_stream on a null batch are argument errors (no GPU needed)"""
+    for depth in (8, 10):
+        lib = x265hip.HipLib(depth, fill_table=False).lib
+        for mode in (0, 1, 2, 4, 8):
+            assert lib.x265hip_batch_set_fused(None, mode) < 0
+        assert lib.x265hip_batch_set_timing(None, 1) < 0 and lib.x265hip_batch_step(None) < 0 and lib.x265hip_batch_step_one_stream(None) < 0
+
+
 def test_context_needs_a_device():
     import torch
     if torch.cuda.is_available():
