@@ -51,7 +51,7 @@ def test_batch_mode_switches_need_a_batch():
     for depth in (8, 10):
         lib = x265hip.HipLib(depth, fill_table=False).lib
         for mode in (0, 1, 2, 4, 8):
-            assert lib.x265hip_batch_set_fused(None, mode) < 0
+            assert lib.x265hip_batch_set_fused(None, mode) < 0 and lib.x265hip_batch_set_mode(None, mode) < 0
         assert lib.x265hip_batch_set_timing(None, 1) < 0 and lib.x265hip_batch_step(None) < 0 and lib.x265hip_batch_step_one_stream(None) < 0
 
 

@@ -58,14 +58,14 @@ struct x265hip_batch
     // the other has finished its own -- so that it always runs beside the other stream's 32x32 .. 8x8 levels, never beside itself; and the sub-batches are not joined
     // between steps (a stream's next pass only depends on its own previous one): they are joined when something waits on the context's stream (join_subs)
     hipEvent_t evTok[8] = {}; bool tokSet[8] = {}; int pingpong = 0; bool unjoined = false;
-    // the 16x16 / 8x8 levels (fusedFrom32: the 32x32 level too) of a sub-batch in ONE launch, a wavefront per 32x32 quadrant (kern_me_pyr.hip); x265hip_batch_set_fused.
+    // the 16x16 / 8x8 levels (fusedFrom32: the 32x32 level too) of a sub-batch in ONE launch, a wavefront per 32x32 quadrant (kern_me_pyr.hip); x265hip_batch_set_mode.
     // Off by default: measured slower than a launch per level (profiles/r03_fused_ab.txt)
     bool fused = false, fusedFrom32 = false;
     // 16-bit library, one reference, squares only, STAR: the phase planes of the batch are TILED (slots 1..15 as 16 x 4-pixel tiles of one 128-byte line, kern_planes.hip) and read
-    // by the tiled forms of the search kernels and of the TQ stage (kern_me_star_tiled.hip, xh_tq_batch_tiled).  OFF by default, x265hip_batch_set_fused(mode | 8) turns it on: it moves
+    // by the tiled forms of the search kernels and of the TQ stage (kern_me_star_tiled.hip, xh_tq_batch_tiled).  OFF by default, x265hip_batch_set_mode(X265HIP_BATCH_TILED_PLANES) turns it on: it moves
     // 20-30 % fewer bytes and is 40 % slower (profiles/r03_tiled_ab.txt, r03_tiled_pmc.txt)
     bool tiled = false, tiledWanted = false;
-    bool ownStart64 = true;                  // STAR: the 64x64 level without its start-stage launch (kern_me_star.hip xh_me_star_own64); x265hip_batch_set_fused(mode | 4) turns it off for A/B
+    bool ownStart64 = true;                  // STAR: the 64x64 level without its start-stage launch (kern_me_star.hip xh_me_star_own64); x265hip_batch_set_mode(X265HIP_BATCH_START64_LAUNCH) turns it off for A/B
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
     std::vector<void*> owned;
@@ -548,7 +548,9 @@ extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
     return X265HIP_OK;
 }
 
-extern "C" int x265hip_batch_set_fused(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->fused = (on & 3) != 0; b->fusedFrom32 = (on & 3) == 2; b->ownStart64 = !(on & 4); b->tiledWanted = (on & 8) != 0; return X265HIP_OK; }
+extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on);
+extern "C" int x265hip_batch_set_fused(x265hip_batch* b, int on) { return x265hip_batch_set_mode(b, on); }
+extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->fused = (on & 3) != 0; b->fusedFrom32 = (on & 3) == 2; b->ownStart64 = !(on & 4); b->tiledWanted = (on & 8) != 0; return X265HIP_OK; }
 extern "C" int x265hip_batch_set_timing(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->timing = on != 0; return X265HIP_OK; }
 extern "C" int x265hip_batch_stage_count(const x265hip_batch* b) { return b ? (int)b->stageNames.size() : 0; }
 extern "C" const char* x265hip_batch_stage_name(const x265hip_batch* b, int i) { return (b && i >= 0 && i < (int)b->stageNames.size()) ? b->stageNames[i].c_str() : nullptr; }

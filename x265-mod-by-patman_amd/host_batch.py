@@ -93,9 +93,11 @@ class HostBatch:
     def sync(self):
         self._ck(self.lib.x265hip_ctx_sync(self.ctx), "ctx_sync")
 
-    def set_fused(self, on):
-        """the 32x32 / 16x16 / 8x8 levels in one launch, a wavefront per 32x32 quadrant (x265hip_batch_set_fused; default on where it applies)"""
-        self._ck(self.lib.x265hip_batch_set_fused(self.batch, int(on)), "batch_set_fused")
+    def set_fused(self, flags):
+        """x265hip_batch_set_mode: X265HIP_BATCH_* flags (1 / 2 fused lower levels, 4 the 64x64 start-stage launch, 8 tiled phase planes); 0 = the default schedule"""
+        self._ck(self.lib.x265hip_batch_set_mode(self.batch, int(flags)), "batch_set_mode")
+
+    set_mode = set_fused
 
     def set_timing(self, on):
         self.lib.x265hip_batch_set_timing(self.batch, int(on))
