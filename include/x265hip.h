@@ -26,6 +26,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* the library is built with -fvisibility=hidden: what these headers declare is its whole exported surface */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -233,5 +237,8 @@ int x265hip_intra_cost_batch(void* stream, int log2Size, const void* srcPlane, i
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* X265HIP_H */

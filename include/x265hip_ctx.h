@@ -20,6 +20,10 @@
 #define X265HIP_CTX_H
 #include "x265hip_frame.h"
 
+/* the library is built with -fvisibility=hidden: what these headers declare is its whole exported surface */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -29,7 +33,7 @@ typedef struct x265hip_batch x265hip_batch;
 
 int   x265hip_ctx_create(int device, x265hip_ctx** ctx);
 void  x265hip_ctx_destroy(x265hip_ctx* ctx);
-void* x265hip_ctx_stream(x265hip_ctx* ctx);          /* hipStream_t: every call on this context is ordered on it */
+void* x265hip_ctx_stream(x265hip_ctx* ctx);          /* hipStream_t: every call on this context is ordered on it (a batch with desc.streams > 1: after x265hip_batch_join) */
 int   x265hip_ctx_sync(x265hip_ctx* ctx);              /* waits for everything queued through the context, the sub-streams of its batches included */
 int   x265hip_ctx_device(const x265hip_ctx* ctx);    /* the device the context was created on; every entry point that takes a context selects it for the calling thread */
 
@@ -110,6 +114,10 @@ int   x265hip_batch_read_coeffs(x265hip_batch* batch, int16_t* coeff /* tu_count
 /* device pointers for consumers that stay on the GPU: what = 0 source planes, 1 reference planes, 2 phase planes, 3 coefficients, 4 numSig,
  * 5 reconstruction, 10 + log2(level) - 3 = results of a pyramid level (10: 8x8 ... 13: 64x64; reference 0), 100 + r = plane stack of reference r, 200 + r = its phase planes */
 void* x265hip_batch_device_ptr(x265hip_batch* batch, int what);
+/* desc.streams = 2 leaves the second sub-batch on its own stream when x265hip_batch_step returns (the read_*, upload and x265hip_ctx_sync calls join it).  A consumer that
+ * stays on the GPU and queues its own work on x265hip_ctx_stream() against the pointers above calls this first: everything every sub-batch queued so far is then
+ * ordered in front of what follows on the context's stream (no host wait). */
+int   x265hip_batch_join(x265hip_batch* batch);
 
 /* ---- ThreadedME producer for a C++ encoder: one picture's MEData table from HOST data ------------------------------------------------------------------
  * What ThreadedME::findJob -> Analysis::deriveMVsForCTU does for every CTU of a picture (threadedme.cpp:207-261, analysis.cpp:248-306): the diamond searches of the
@@ -222,5 +230,8 @@ int  x265hip_ff_picture(x265hip_ff* ff, const x265hip_ff_picture_desc* desc);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif

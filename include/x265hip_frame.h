@@ -17,6 +17,10 @@
 
 #define X265HIP_MAX_REF 16                     /* references per list: MAX_NUM_REF (common/common.h:329; m_areaBestMV[5][2][MAX_NUM_REF], encoder/search.h:297) */
 
+/* the library is built with -fvisibility=hidden: what these headers declare is its whole exported surface */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -452,5 +456,8 @@ int x265hip_ssim_pictures(void* stream, const void* recon, intptr_t stride1, con
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif

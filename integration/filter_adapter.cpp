@@ -104,7 +104,11 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
 void FrameFilter::processRow(int row, int layer)
 {
     const x265_param& p = *m_param;
-    bool mine = g_on && (p.bEnableLoopFilter || m_useSao) && m_parallelFilter && p.maxSlices == 1 && p.internalCsp == X265_CSP_I420 && !p.bLimitSAO;
+    /* the replay state is per THREAD (t_replay): with WPP another worker may run ParallelFilter::processTasks of a neighbouring row during the replay
+       (frameencoder.cpp:2072-2076) and would filter the already deblocked picture with the encoder's own bodies; with several frame threads rows of the next picture
+       wait on this one's.  Both keep the encoder's own filters */
+    bool mine = g_on && (p.bEnableLoopFilter || m_useSao) && m_parallelFilter && p.maxSlices == 1 && p.internalCsp == X265_CSP_I420 && !p.bLimitSAO &&
+                !p.bEnableWavefront && p.frameNumThreads == 1;
     if (mine)
     {
         const PicYuv& rp = *m_frame->m_reconPic[0]; const PicYuv& fp = *m_frame->m_fencPic;

@@ -6,8 +6,10 @@
  * objects, in computeMVForPUs' order -- the qp of every CU (Analysis::calculateQpforCuSize), the collocated neighbour of every PU (CUData::getNeighbourMV), the
  * collocated median of every CTU (CUData::getMedianColMV).
  *
- * Preconditions (checked where they can be): frame threads = 1 or complete reference pictures (the producer takes whole planes; the row-lag
- * clamp of Search::setSearchRange, search.cpp:5017-5018, is not modelled); numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF.
+ * Preconditions (checked): ONE frame thread -- the producer takes whole reference planes and keeps them under the picture's key, so a reference must be completely
+ * reconstructed when it is first handed over; with several frame threads a picture starts while its references are still being coded, and the encoder's own body runs
+ * instead (the producer itself models the row-lag window and selectMVP restrictions of that mode -- desc.frameThreads, csrc/xh_tme.cpp -- for a caller that waits for
+ * reference completion before the call); numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF.
  */
 #include <atomic>
 #include <chrono>
@@ -84,6 +86,14 @@ namespace X265_NS {
 void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
 {
     if (!g_useGpu) { ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame); return; }
+    if (frame.m_param->frameNumThreads > 1)
+    {   /* a reference picture may still be in flight (frameencoder.cpp:1029-1036 releases its rows one by one): whole-plane uploads under a permanent key would cache a
+           half-coded picture.  The encoder's own producer knows how to wait row by row */
+        static std::atomic<int> told{0};
+        if (!told.exchange(1)) fprintf(stderr, "tme_adapter: %d frame threads: reference pictures are not complete when a picture starts -- the encoder's own ThreadedME producer runs\n", frame.m_param->frameNumThreads);
+        ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame);
+        return;
+    }
     /* local classes of a member function have the member's access: calculateQpforCuSize (protected) is reached without touching analysis.h */
     struct Harvest
     {

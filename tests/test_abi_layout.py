@@ -89,6 +89,24 @@ def test_library_exports_every_declared_symbol(depth):
     assert lib.x265hip_abi_check(ctypes.c_size_t(100), depth) != 0
 
 
+@pytest.mark.parametrize("depth", [8, 10])
+def test_library_exports_nothing_but_the_c_abi(depth):
+    """-fvisibility=hidden + csrc/exports.map: every defined dynamic symbol is an x265hip_* C entry point the headers declare -- no mangled C++ (runtime classes,
+    launcher functions, device stubs, template instantiations of the standard library)."""
+    import subprocess
+    x265hip.build_libraries()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", B.lib_path(depth)], text=True)
+    syms = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert len(syms) >= 100
+    declared = set()
+    for hdr in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        declared |= set(re.findall(r"\b(x265hip_\w+)\s*\(", open(os.path.join(ROOT, "include", hdr)).read()))
+    bad = [s_ for s_ in syms if s_.startswith("_Z") or not s_.startswith("x265hip_")]
+    assert not bad, "exported beside the C ABI: %s" % bad[:8]
+    undeclared = sorted(set(syms) - declared)
+    assert not undeclared, "exported but declared in no header of include/: %s" % undeclared[:8]
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a device the table setup must fail loudly (never silently fall back)."""
     import torch

@@ -3,6 +3,7 @@
 // (reference pixel.cpp:385-483, 485-594, 751-854).  One 256-thread workgroup per block; lanes walk
 // the block row-major so global accesses are coalesced along rows.
 #include "xh_common.h"
+#include "../../include/x265hip_frame.h"
 using namespace xh;
 
 namespace {

@@ -1008,7 +1008,7 @@ extern "C" int x265hip_cutree_propagate(void* stream, int widthInCU, int heightI
 
 // Lookahead::cuTreeFinish (slicetype.cpp:4098-4150, default configuration: no hevc-aq, qgSize != 8): qp offset of every block from its propagated cost.
 // Integer part exact; the two log2 of doubles are the device math library's (not guaranteed to round like the host's libm: tests state 1e-12).
-__global__ __launch_bounds__(256) void cutree_finish_kernel(int ncu, const int32_t* __restrict__ intraCost, const int32_t* __restrict__ invQscale, const uint16_t* __restrict__ prop,
+static __global__ __launch_bounds__(256) void cutree_finish_kernel(int ncu, const int32_t* __restrict__ intraCost, const int32_t* __restrict__ invQscale, const uint16_t* __restrict__ prop,
                                                             const double* __restrict__ qpAq, int fpsFactor, double weightdelta, double strength, double* __restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -56,7 +56,9 @@ struct x265hip_batch
     hipStream_t sub[8] = {}; hipEvent_t evFork = nullptr, evJoin[8] = {};
     // two sub-batches of whole pictures (streams = 2): the 64x64 level (window in LDS, two workgroups fill a CU) of the two streams ALTERNATES -- a stream takes it when
     // the other has finished its own -- so that it always runs beside the other stream's 32x32 .. 8x8 levels, never beside itself; and the sub-batches are not joined
-    // between steps (a stream's next pass only depends on its own previous one): they are joined when something waits on the context's stream (join_subs)
+    // between steps: they are joined when something waits on the context's stream (join_subs, x265hip_batch_join).  (A step forks every sub-stream behind what the
+    // context's stream holds at that moment -- its own previous pass included -- so sub-stream 1's pass k + 1 starts behind sub-stream 0's pass k; sub-stream 0 never
+    // waits for sub-stream 1.)
     hipEvent_t evTok[8] = {}; bool tokSet[8] = {}; int pingpong = 0; bool unjoined = false;
     // the 16x16 / 8x8 levels (fusedFrom32: the 32x32 level too) of a sub-batch in ONE launch, a wavefront per 32x32 quadrant (kern_me_pyr.hip); x265hip_batch_set_mode.
     // Off by default: measured slower than a launch per level (profiles/r03_fused_ab.txt)
@@ -546,6 +548,15 @@ extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
     XH_HIP(hipEventRecord(b->evFork, b->sub[0]));
     for (int s = 1; s < b->nsub; s++) XH_HIP(hipStreamWaitEvent(b->sub[s], b->evFork, 0));
     return X265HIP_OK;
+}
+
+// the sub-batches' streams joined into the context's stream: what a GPU-side consumer of x265hip_batch_device_ptr's arrays queues on x265hip_ctx_stream() behind this
+// call sees every sub-batch's results (a step of the alternating schedule returns with sub-stream 1 still on its own)
+extern "C" int x265hip_batch_join(x265hip_batch* b)
+{
+    if (!b) { set_error("batch_join: null batch"); return X265HIP_EARG; }
+    XH_HIP(hipSetDevice(b->ctx->device));
+    return join_subs(b);
 }
 
 extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on);

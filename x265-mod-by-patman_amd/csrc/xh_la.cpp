@@ -27,7 +27,7 @@ struct x265hip_la
     // --hme: the quarter-resolution pictures (Lowres::lowerResBuffer[0]: four planes) at the same places, the level-0 MV / cost slots of a launch
     bool hme = false; int wcu4 = 0, hcu4 = 0, ncu4 = 0; intptr_t stride4 = 0; int64_t planeElems4 = 0, origin4 = 0;
     pixel* low4 = nullptr; int16_t* mvs4 = nullptr; int32_t* mvCosts4 = nullptr;
-    struct Slot { uint64_t key = 0; uint64_t used = 0; bool lower = false; };
+    struct Slot { uint64_t key = 0; uint64_t used = 0; bool lower = false; bool haveIntra = false; };      // haveIntra: the slot's intra costs are THIS picture's (a picture that came up as a reference has none yet)
     std::vector<Slot> slots; uint64_t tick = 0;
     std::mutex mu;                                // the device side: one call at a time on the context's stream
     // estimates that arrive while a launch is in flight are queued and go up together (x265hip_la_estimate)
@@ -111,16 +111,24 @@ int ensure_picture(x265hip_la* a, hipStream_t st, uint64_t key, const void* plan
             for (int k = 0; k < nPinned; k++) pin |= pinned[k] == i;
             if (!pin && (s < 0 || a->slots[i].used < a->slots[s].used)) s = i;
         }
-        a->slots[s].key = 0; a->slots[s].lower = false;
+        if (s < 0) { set_error("la: every one of the %d picture places is in use by this launch (create the producer with maxPictures >= 3 x the estimates that arrive together)", (int)a->slots.size()); return X265HIP_EARG; }
+        a->slots[s].key = 0; a->slots[s].lower = false; a->slots[s].haveIntra = false;
         XH_HIP(hipMemcpyAsync(a->low + (size_t)s * 4 * a->planeElems, planes4, (size_t)4 * a->planeElems * sizeof(pixel), hipMemcpyHostToDevice, st));
         if (invQscale) { XH_HIP(hipMemcpyAsync(a->invq + (size_t)s * a->ncu, invQscale, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st)); a->haveInvq = true; }
         if (intraCost) XH_HIP(hipMemcpyAsync(a->intraCost + (size_t)s * a->ncu, intraCost, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st));
         XH_HIP(hipStreamSynchronize(st));                    // the caller's buffers are free again (and pageable copies are staged anyway)
         a->slots[s].key = key;                               // named once its planes are there
+        a->slots[s].haveIntra = intraCost != nullptr;
     }
-    else if (invQscale)
-    {   // the factors of a resident picture may have moved since (--aq-motion rewrites them during the slice-type analysis): they are small, send them again
-        XH_HIP(hipMemcpyAsync(a->invq + (size_t)s * a->ncu, invQscale, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st)); a->haveInvq = true;
+    else if (invQscale || (intraCost && !a->slots[s].haveIntra))
+    {   // the factors of a resident picture may have moved since (--aq-motion rewrites them during the slice-type analysis): they are small, send them again.
+        // A picture that came up as somebody's REFERENCE (no intra costs given) and is estimated now still holds the costs of the picture its place held before
+        if (invQscale) { XH_HIP(hipMemcpyAsync(a->invq + (size_t)s * a->ncu, invQscale, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st)); a->haveInvq = true; }
+        if (intraCost && !a->slots[s].haveIntra)
+        {
+            XH_HIP(hipMemcpyAsync(a->intraCost + (size_t)s * a->ncu, intraCost, (size_t)a->ncu * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            a->slots[s].haveIntra = true;
+        }
         XH_HIP(hipStreamSynchronize(st));
     }
     if (a->hme && lowerPlanes4 && !a->slots[s].lower)
@@ -164,6 +172,7 @@ extern "C" int x265hip_la_intra(x265hip_la* a, uint64_t key, const void* planes4
     const size_t ncu = (size_t)a->ncu;
     if ((rc = x265hip_lookahead_intra_batch(st, a->low + (size_t)s * 4 * a->planeElems, a->planeElems, a->stride, a->origin, a->wcu, a->hcu, 1, a->haveInvq ? a->invq + (size_t)s * ncu : nullptr,
                                             a->intraCost + (size_t)s * ncu, a->intraMode, a->intraLc, a->intraRows, a->intraSums))) return rc;
+    a->slots[s].haveIntra = true;
     XH_HIP(hipMemcpyAsync(intraCost, a->intraCost + (size_t)s * ncu, ncu * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     XH_HIP(hipMemcpyAsync(intraMode, a->intraMode, ncu, hipMemcpyDeviceToHost, st));
     XH_HIP(hipMemcpyAsync(lowresCosts, a->intraLc, ncu * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
@@ -201,6 +210,7 @@ int run_batch(x265hip_la* a, Req* const* reqs, int n)
             if (d->hme && (!a->hme || !a->slots[slot[k]].lower)) { set_error("la_estimate: --hme estimate without x265hip_la_enable_hme / quarter-resolution planes"); return X265HIP_EARG; }
             pinned.push_back(slot[k]);
         }
+        if (!a->slots[slot[1]].haveIntra) { set_error("la_estimate: picture %llu has no intra costs on the device (x265hip_la_intra it first or hand over desc.intraCost)", (unsigned long long)d->key[1]); return X265HIP_EARG; }
         if (slot[0] == slot[1] || (isB && slot[2] == slot[1])) { set_error("la_estimate: the estimated picture is its own reference"); return X265HIP_EARG; }
         x265hip_la_task& t = tasks[i];
         t = x265hip_la_task{};
@@ -272,7 +282,8 @@ extern "C" int x265hip_la_estimate(x265hip_la* a, const x265hip_la_estimate_desc
         // become the leader: everything that is waiting now (this request among it, unless more than a batch was ahead of it) goes up as one launch
         a->leader = true;
         Req* batch[kLaBatch];
-        const int n = (int)std::min<size_t>(a->queue.size(), (size_t)kLaBatch);
+        // a launch pins up to three pictures per estimate: never more estimates than the producer has places for (the rest goes up with the next launch)
+        const int n = (int)std::min<size_t>(a->queue.size(), (size_t)std::min(kLaBatch, std::max(1, a->maxPics / 3)));
         for (int i = 0; i < n; i++) batch[i] = a->queue[i];
         a->queue.erase(a->queue.begin(), a->queue.begin() + n);
         lk.unlock();
