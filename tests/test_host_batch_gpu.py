@@ -1,5 +1,5 @@
 """The C++ host of the frame-batched path (include/x265hip_ctx.h: x265hip_batch_*, csrc/xh_ctx.cpp) with everything preset slow asks of the motion search in ONE run:
-several list-0 references, the rectangular PUs of every CU, sub-batches of whole pictures on their own streams -- sampled against the oracle, equal to the Python
+several list-0 references, the rectangular PUs of every CU, sub-batches of whole pictures on their own streams -- exhaustively against the oracle at 256x128, sampled at 4K, equal to the Python
 plumbing (FramePipeline) where that can run the same configuration, and independent of how the batch is cut into streams."""
 import ctypes as C
 
@@ -49,8 +49,11 @@ def test_host_batch_matches_oracle(depth, method, subme, refs, rect, streams):
             for which in range(1 + refs):
                 assert np.array_equal(hb.device_plane(which, f), pairs[f][which].reshape(-1)), "plane %d of picture %d" % (which, f)
         hb.step(); hb.sync()
-        n = check_host_batch(hb, Oracle(depth), np.random.default_rng(depth + refs), mvcost_row(depth, qp, 1 << 15), mvbits_row(depth, 1 << 14), rd_lambda(depth, qp))
-        assert n >= (12 if rect else 4) * 8
+        # EXHAUSTIVE at this size: every PU of every shape in every reference, every choice, every TU against the oracle (seconds of CPU)
+        n = check_host_batch(hb, Oracle(depth), np.random.default_rng(depth + refs), mvcost_row(depth, qp, 1 << 15), mvbits_row(depth, 1 << 14), rd_lambda(depth, qp),
+                             per_shape=1 << 30, n_tu=1 << 30)
+        ctus = F * (W // 64) * (H // 64)
+        assert n == ctus * (425 if rect else 85) + F * (W // 16) * (H // 16)
     finally:
         hb.close()
 
@@ -61,7 +64,7 @@ def test_streams_do_not_change_the_bytes_and_python_plumbing_agrees(depth):
     W, H, F, qp, merange, method, subme = 192, 128, 5, 30, 20, 3, 3
     pairs = pairs_for(W, H, depth, F, 2)
     ref_out = None
-    for streams, band in ((1, 0), (2, 0), (3, 0), (5, 0), (1, 1), (2, 3), (4, 1), (3, 2)):        # band > 0: band-major, bands of that many CTU rows (they may span pictures)
+    for streams, band in ((1, 0), (2, 0), (3, 0), (5, 0)):        # (band > 0, the band-major schedule, is a measured loss kept for experiment builds: profiles/r03_band_major_ab.txt)
         hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, refs=2, rect=True, streams=streams, band_rows=band)
         try:
             hb.upload(pairs)
@@ -110,13 +113,24 @@ def test_two_streams_are_joined_when_something_reads_and_one_stream_steps_give_t
 
 
 @pytest.mark.parametrize("depth", [8, 10])
-def test_fused_lower_levels_give_the_bytes_of_a_launch_per_level(depth):
-    """x265hip_batch_set_fused: the 16x16 / 8x8 levels (mode 2: the 32x32 level too) of a 32x32 quadrant searched by one wavefront in one launch (csrc/kern_me_pyr.hip)"""
+def test_launch_forms_give_the_same_bytes_and_a_release_library_refuses_the_experiments(depth):
+    """x265hip_batch_set_mode: the 64x64 level with or without its start-stage launch gives the same bytes; the measured-loss forms (fused lower levels, tiled phase
+    planes, band-major schedule: profiles/r03_fused_ab.txt, r03_tiled_ab.txt, r03_band_major_ab.txt) exist in experiment builds only (make EXPERIMENTS=1) and a release
+    library says so instead of silently running something else"""
     W, H, F = 320, 192, 3
     pairs = pairs_for(W, H, depth, F, 1, seed0=520)
     outs = []
-    # (mode | 4: the 64x64 level with its start-stage launch, the form of rounds 1-2; mode | 8: at 16 bit TILED phase planes -- slots 1..15 as 16 x 4-pixel tiles -- and the kernels that read them)
-    for mode, streams in ((0, 1), (1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (8, 1), (8, 2), (12, 1)):
+    hb = make(depth, W, H, F, qp=27, merange=57, method=3, subme=3, tu_log2=5)
+    try:
+        for flags in (1, 2, 8, 12):
+            with pytest.raises(RuntimeError, match="EXPERIMENTS"):
+                hb.set_fused(flags)
+    finally:
+        hb.close()
+    with pytest.raises(RuntimeError):
+        make(depth, W, H, F, qp=27, merange=57, method=3, subme=3, tu_log2=5, band_rows=2)
+    # (mode 4: the 64x64 level with its start-stage launch, the form of rounds 1-2)
+    for mode, streams in ((0, 1), (0, 2), (4, 1), (4, 2)):
         hb = make(depth, W, H, F, qp=27, merange=57, method=3, subme=3, tu_log2=5, streams=streams)
         try:
             hb.set_fused(mode)

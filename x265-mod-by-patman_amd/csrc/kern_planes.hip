@@ -417,6 +417,8 @@ extern "C" int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_
     return X265HIP_OK;
 }
 
+#ifdef X265HIP_EXPERIMENTS
+// (experiment build, make EXPERIMENTS=1 -- a measured loss, profiles/r03_tiled_ab.txt)
 // The same planes with slots 1..15 tiled (16-bit library; pitch a multiple of 16, rows a multiple of 4): for readers that take the tiled layout (xh_me_star_tiled, xh_tq_batch_tiled)
 bool xh_subpel_planes_tiled_ok(intptr_t stride, int rows) { return X265_DEPTH != 8 && stride >= 16 && (stride & 15) == 0 && (rows & 3) == 0; }
 int xh_subpel_planes_tiled(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems)
@@ -432,3 +434,4 @@ int xh_subpel_planes_tiled(void* stream, const void* refPlane, intptr_t stride, 
     return X265HIP_OK;
 #endif
 }
+#endif   // X265HIP_EXPERIMENTS

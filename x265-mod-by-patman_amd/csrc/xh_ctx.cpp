@@ -30,7 +30,11 @@ bool desc_ok(const x265hip_batch_desc* d)
 {
     return d && d->width >= CTU && d->height >= CTU && d->width <= X265HIP_MAX_PIC_DIM && d->height <= X265HIP_MAX_PIC_DIM && d->width % CTU == 0 && d->height % CTU == 0 && d->frames >= 1 && d->margin >= CTU + 16 + 8 &&
            d->margin % 4 == 0 && d->qp >= 0 && d->qp <= 51 && d->merange >= 1 && d->subme >= 0 && d->subme <= 7 && d->tuLog2 >= 2 && d->tuLog2 <= 5 &&
-           d->refs >= 0 && d->refs <= X265HIP_MAX_REF && d->streams >= 0 && d->streams <= 8 && d->bandRows >= 0 && (d->refs <= 1 || d->usePlanes);
+           d->refs >= 0 && d->refs <= X265HIP_MAX_REF && d->streams >= 0 && d->streams <= 8 && d->bandRows >= 0 && (d->refs <= 1 || d->usePlanes)
+#ifndef X265HIP_EXPERIMENTS
+           && d->bandRows == 0           // the band-major schedule is a measured loss (profiles/r03_band_major_ab.txt): experiment builds only (make EXPERIMENTS=1)
+#endif
+           ;
 }
 int level_index(int level) { for (int i = 0; i < 4; i++) if (kLevels[i] == level) return i; return -1; }
 int64_t stride_of(const x265hip_batch_desc* d) { return d->width + 2 * d->margin; }
@@ -345,8 +349,12 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
     const int rowsPerPic = d.height + 2 * d.margin;
     for (int r = 0; r < b->refs; r++)
     {
+#ifdef X265HIP_EXPERIMENTS
         const int rc = b->tiled ? xh_subpel_planes_tiled(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems)
                                 : x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems);
+#else
+        const int rc = x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems);
+#endif
         if (rc != X265HIP_OK) return rc;
     }
     return X265HIP_OK;
@@ -358,9 +366,13 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
 // can this batch run on tiled phase planes?  (decided per step: the planes are made anew by every step)
 bool tiled_ok(const x265hip_batch* b)
 {
+#ifndef X265HIP_EXPERIMENTS
+    (void)b; return false;
+#else
     const x265hip_batch_desc& d = b->d;
     return b->tiledWanted && !b->fused && b->refs == 1 && !d.rect && d.usePlanes && d.method == X265HIP_ME_STAR && d.merange <= 57 &&
            xh_subpel_planes_tiled_ok(b->stride, d.height + 2 * d.margin) && (uint64_t)(b->plane * d.frames) * 16u * sizeof(pixel) < (1ull << 32);
+#endif
 }
 int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev, int sub = -1)
 {
@@ -385,10 +397,13 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
     {
         for (int r = 0; r < b->refs; r++)
         {
+#ifdef X265HIP_EXPERIMENTS
             if (b->tiled && w == h)
                 rc = xh_me_star_tiled(st, w, h, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.subme, res[r] + first, parent ? parent[r] : nullptr,
                                       b->planes[r], planeElems, w == CTU && !parent && b->ownStart64);
-            else if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
+            else
+#endif
+            if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
                 rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.subme, res[r] + first, b->planes[r], planeElems);
             else
             rc = x265hip_me_batch(st, w, h, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.method, d.subme,
@@ -407,10 +422,15 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
     };
     // the lower three levels fused: one reference, squares only, STAR out of phase planes (the stage slots of the 16x16 and 8x8 levels then hold empty intervals,
     // the 32x32 slot the whole launch)
+#ifdef X265HIP_EXPERIMENTS
     const bool fusedLower = b->fused && b->refs == 1 && !d.rect && up && xh_me_pyr_ok(d.method, planeElems, kHalf);
+#else
+    constexpr bool fusedLower = false;
+#endif
     for (int i = 0; i < 4; i++)
     {
         const int lv = kLevels[i], per = (d.width / lv) * (CTU / lv);               // PUs of this level per CTU row
+#ifdef X265HIP_EXPERIMENTS
         if (fusedLower && i >= (b->fusedFrom32 ? 1 : 2))
         {
             if ((rc = mark(0))) return rc;
@@ -424,6 +444,7 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
             if ((rc = mark(1))) return rc;
             continue;
         }
+#endif
         x265hip_me_result* res[X265HIP_MAX_REF]; x265hip_me_result* par[X265HIP_MAX_REF];
         for (int r = 0; r < b->refs; r++) { res[r] = b->results[r][i]; par[r] = i ? b->results[r][i - 1] : nullptr; }
         if ((rc = mark(0))) return rc;
@@ -454,7 +475,12 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
         x265hip_tq_params p{};
         p.qp = d.qp; p.add = 85; p.subpelPlanes = up ? b->planes[r] : nullptr; p.planeElems = up ? planeElems : 0;
         if (b->refs > 1) { p.choice = b->choice[mi]; p.choiceList = 0; p.choiceRef = r; }
-        rc = (b->tiled ? xh_tq_batch_tiled : x265hip_tq_batch)(st, d.tuLog2, b->cur, b->stride, b->ref[r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
+#ifdef X265HIP_EXPERIMENTS
+        rc = (b->tiled ? xh_tq_batch_tiled : x265hip_tq_batch)
+#else
+        rc = x265hip_tq_batch
+#endif
+                             (st, d.tuLog2, b->cur, b->stride, b->ref[r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
                               d.recon ? b->recon : nullptr, b->stride, d.recon ? b->sse + t0 : nullptr, b->refs > 1 ? nullptr : b->results[0][mi]);
         if (rc != X265HIP_OK) return rc;
     }
@@ -478,6 +504,7 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
     }
     if (S == 1 && band <= 0) return step_range(b, 0, G, true, b->sub[0], ev);
     int rc;
+#ifdef X265HIP_EXPERIMENTS
     if (band > 0)
     {   // Band-major: the phase planes of the whole batch first, then bands of CTU rows, each through ALL levels before the stream takes its next band -- the 16 phase
         // planes under a band (tens of MB) are read by four levels and the TQ stage back to back instead of once per level-wide pass over the whole batch (GBs), so the
@@ -501,6 +528,7 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
         }
     }
     else
+#endif
     {   // Independent pictures: the levels of one picture depend on each other (a level's predictor is its parent CU's MV), pictures do not.  Sub-batch s runs on its
         // own stream, so the LDS-bound 64x64 search of one runs beside the latency-bound 16x16 / 8x8 searches of another.  Everything is ordered after the work already
         // queued on the context's stream and joined back into it.
@@ -561,7 +589,15 @@ extern "C" int x265hip_batch_join(x265hip_batch* b)
 
 extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on);
 extern "C" int x265hip_batch_set_fused(x265hip_batch* b, int on) { return x265hip_batch_set_mode(b, on); }
-extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->fused = (on & 3) != 0; b->fusedFrom32 = (on & 3) == 2; b->ownStart64 = !(on & 4); b->tiledWanted = (on & 8) != 0; return X265HIP_OK; }
+extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on)
+{
+    if (!b) return X265HIP_EARG;
+#ifndef X265HIP_EXPERIMENTS
+    if (on & ~X265HIP_BATCH_START64_LAUNCH) { set_error("batch_set_mode: flags %d are measured-loss experiments (fused lower levels, tiled phase planes): build the library with make EXPERIMENTS=1", on & ~X265HIP_BATCH_START64_LAUNCH); return X265HIP_EARG; }
+#endif
+    b->fused = (on & 3) != 0; b->fusedFrom32 = (on & 3) == 2; b->ownStart64 = !(on & 4); b->tiledWanted = (on & 8) != 0;
+    return X265HIP_OK;
+}
 extern "C" int x265hip_batch_set_timing(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->timing = on != 0; return X265HIP_OK; }
 extern "C" int x265hip_batch_stage_count(const x265hip_batch* b) { return b ? (int)b->stageNames.size() : 0; }
 extern "C" const char* x265hip_batch_stage_name(const x265hip_batch* b, int i) { return (b && i >= 0 && i < (int)b->stageNames.size()) ? b->stageNames[i].c_str() : nullptr; }
