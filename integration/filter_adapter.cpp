@@ -8,6 +8,7 @@
  * last filter row (FrameEncoder::encodeSlice).  So deblocking everything first, then collecting all statistics, then deciding and applying SAO row by row in the
  * reference's order gives the reference's picture and the reference's SAO parameters.
  */
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -48,9 +49,17 @@ std::mutex g_lock;                        /* one picture at a time through the p
 x265hip_ff_adapter_stats g_stats;
 std::mutex g_statLock;
 
-/* the picture whose rows are being replayed on this thread: deblocked already, statistics in the table */
-struct Replay { bool deblocked; const int32_t* stats[3]; long long skipped, served; };
-thread_local Replay* t_replay;
+/* the picture whose rows are being replayed: deblocked already, statistics in the table.  Keyed on the picture's FrameData, not on the replaying thread: with WPP
+   another worker may run ParallelFilter::processTasks of one of the picture's rows while the replay is going on (frameencoder.cpp:2072-2076) and must find the same state.
+   The state stays published until the next picture's replay replaces it (a straggler of this picture still finds it; the staging arrays behind `stats` live as long) */
+struct Replay { const FrameData* data; bool deblocked; const int32_t* stats[3]; std::atomic<long long> skipped, served; };
+Replay g_replayState;
+std::atomic<Replay*> g_replay{nullptr};
+inline Replay* replay_of(const FrameData* data)
+{
+    Replay* r = g_replay.load(std::memory_order_acquire);
+    return (r && r->data == data) ? r : nullptr;
+}
 
 /* staging: CUData's per-partition arrays of all CTUs back to back, the statistics of the three planes */
 struct Staging
@@ -82,13 +91,14 @@ namespace X265_NS {
 
 void Deblock::deblockCTU(const CUData* ctu, const CUGeom& cuGeom, int32_t dir)
 {
-    if (t_replay && t_replay->deblocked) { t_replay->skipped++; return; }
+    if (Replay* rp = replay_of(ctu->m_encData)) if (rp->deblocked) { rp->skipped++; return; }
     ::deblockCTU_cpu(ctu, cuGeom, dir);
 }
 
 void SAO::calcSaoStatsCTU(int addr, int plane)
 {
-    const int32_t* tab = t_replay ? t_replay->stats[plane] : NULL;
+    Replay* rp = replay_of(m_frame->m_encData);
+    const int32_t* tab = rp ? rp->stats[plane] : NULL;
     if (!tab) { ::calcSaoStatsCTU_cpu(this, addr, plane); return; }
     /* per CTU [2][5][32]: m_offsetOrg then m_count of the plane; the body ADDS to what rdoSaoUnitCu left there (zero, or the pre-deblock sums of --sao-non-deblock) */
     const int32_t* s = tab + (size_t)addr * (2 * MAX_NUM_SAO_TYPE * MAX_NUM_SAO_CLASS);
@@ -98,17 +108,15 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
             m_offsetOrg[plane][t][c] += s[t * MAX_NUM_SAO_CLASS + c];
             m_count[plane][t][c] += s[(MAX_NUM_SAO_TYPE + t) * MAX_NUM_SAO_CLASS + c];
         }
-    t_replay->served++;
+    rp->served++;
 }
 
 void FrameFilter::processRow(int row, int layer)
 {
     const x265_param& p = *m_param;
-    /* the replay state is per THREAD (t_replay): with WPP another worker may run ParallelFilter::processTasks of a neighbouring row during the replay
-       (frameencoder.cpp:2072-2076) and would filter the already deblocked picture with the encoder's own bodies; with several frame threads rows of the next picture
-       wait on this one's.  Both keep the encoder's own filters */
-    bool mine = g_on && (p.bEnableLoopFilter || m_useSao) && m_parallelFilter && p.maxSlices == 1 && p.internalCsp == X265_CSP_I420 && !p.bLimitSAO &&
-                !p.bEnableWavefront && p.frameNumThreads == 1;
+    /* one picture at a time goes through the producer and the replay (g_lock) and the replay state of a picture stays published until the next one's: several frame
+       threads (pictures in flight together, FrameData objects changing hands) keep the encoder's own filters */
+    bool mine = g_on && (p.bEnableLoopFilter || m_useSao) && m_parallelFilter && p.maxSlices == 1 && p.internalCsp == X265_CSP_I420 && !p.bLimitSAO && p.frameNumThreads == 1;
     if (mine)
     {
         const PicYuv& rp = *m_frame->m_reconPic[0]; const PicYuv& fp = *m_frame->m_fencPic;
@@ -116,6 +124,7 @@ void FrameFilter::processRow(int row, int layer)
     }
     if (!mine)
     {
+        if (replay_of(m_frame->m_encData)) { std::lock_guard<std::mutex> guard(g_lock); if (replay_of(m_frame->m_encData)) g_replay.store(nullptr, std::memory_order_release); }      /* (a recycled FrameData) */
         if (g_on && row == m_numRows - 1) { std::lock_guard<std::mutex> guard(g_statLock); g_stats.cpuPictures++; }
         ::processRow_cpu(this, row, layer);
         return;
@@ -130,6 +139,7 @@ void FrameFilter::processRow(int row, int layer)
     }
 
     std::lock_guard<std::mutex> guard(g_lock);
+    g_replay.store(nullptr, std::memory_order_release);        /* the previous picture is through (one frame thread): its table is about to be overwritten */
     FrameData& encData = *m_frame->m_encData;
     Slice* slice = encData.m_slice;
     PicYuv* recon = m_frame->m_reconPic[0];
@@ -183,16 +193,15 @@ void FrameFilter::processRow(int row, int layer)
     const int rc = g_api.ff_picture(ff, &d);
     const double t2 = now();
     if (rc) { fprintf(stderr, "filter_adapter: x265hip_ff_picture (POC %d): %d %s\n", slice->m_poc, rc, g_api.last_error()); exit(3); }
-    Replay rp;
-    rp.deblocked = p.bEnableLoopFilter != 0; rp.skipped = rp.served = 0;
+    Replay& rp = g_replayState;
+    rp.data = &encData; rp.deblocked = p.bEnableLoopFilter != 0; rp.skipped = 0; rp.served = 0;
     rp.stats[0] = (d.saoStats & 1) ? S.stats[0].data() : NULL;
     rp.stats[1] = (d.saoStats & 2) ? S.stats[1].data() : NULL; rp.stats[2] = (d.saoStats & 2) ? S.stats[2].data() : NULL;
-    t_replay = &rp;
+    g_replay.store(&rp, std::memory_order_release);
     for (int r = 0; r < m_numRows; r++) ::processRow_cpu(this, r, layer);
-    t_replay = NULL;
     const double t3 = now();
     std::lock_guard<std::mutex> sg(g_statLock);
-    g_stats.pictures++; g_stats.deblockSkipped += rp.skipped; g_stats.statsServed += rp.served;
+    g_stats.pictures++; g_stats.deblockSkipped += rp.skipped.load(); g_stats.statsServed += rp.served.load();
     g_stats.gatherSeconds += t1 - t0; g_stats.producerSeconds += t2 - t1; g_stats.replaySeconds += t3 - t2;
 }
 
