@@ -70,7 +70,8 @@ def parse():
     ap.add_argument("--cpu-ctus", type=int, default=4080, help="CTUs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-dry-run", action="store_true", help="launcher / bookkeeping check without a GPU: gloo ranks, a sleep in place of the step (tests/test_sharding.py); prints a line marked data=dry-run")
     ap.add_argument("--no-tme", action="store_true", help="skip the ThreadedME producer leg (x265hip_tme_picture on synthetic 1080p pictures: medium- and slow-like partition sets); reported under \"tme_producer\", not part of value")
-    ap.add_argument("--no-preset-exact", action="store_true", help="skip the preset-exact leg (the preset's own reference count and, from preset slow on, the rectangular PUs, on 2 pictures of the batch); reported under \"preset_exact\", not part of value")
+    ap.add_argument("--no-preset-exact", action="store_true", help="skip the preset-exact legs (per BASELINE workload the preset's own reference count, from preset slow on the rectangular PUs, from slower on the asymmetric ones, on 8 pictures); reported under \"preset_exact\", not part of value")
+    ap.add_argument("--preset-exact-workloads", default="1080p8_medium,2160p10_slow,4320p10_slower", help="which workloads get a preset-exact leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the live end-to-end leg (reference encoder, 1920x1088 medium, CPU producer vs GPU producer of the MEData tables, ~20 s); reported under \"e2e_fps\"")
     ap.add_argument("--filters", action="store_true", help="also time the in-loop filter chain after reconstruction (deblock, SAO statistics, SAO apply, SSIM, SSD) on 8 coded 1080p pictures; reported under \"filters\", not part of value")
     return ap.parse_args()
@@ -165,7 +166,7 @@ def tme_producer_leg(depth):
     return out
 
 
-def e2e_fps_leg(frames=8):
+def e2e_fps_leg(frames=24, seam_frames=8):
     """BASELINE's M2 measured in THIS run: the reference encoder (oracle/_ref/x265e2e_8 = all of source/common + source/encoder compiled from where they lie, C
     primitives, no asm; it travels with the repository) on BASELINE configs[1] -- 1920x1088 8-bit, preset medium with the preset's own defaults, --threaded-me -- with its
     own CPU producers, with x265hip_tme_picture producing the MEData tables (integration/tme_adapter.cpp), with x265hip_la_intra / x265hip_la_estimate producing the
@@ -181,28 +182,33 @@ def e2e_fps_leg(frames=8):
         if not os.path.exists(exe):
             return None
     runs = {}
-    modes = (("cpu", 0, 0, 0), ("tme_gpu", 1, 0, 0)) + ((("la_gpu", 0, 1, 0), ("ff_gpu", 0, 0, 1), ("cpu_filters_timed", 0, 0, 2), ("all_gpu", 1, 1, 1)) if both else ())
+    # M2 itself -- the encoder's own producers against the GPU on every bound seam -- over `frames` pictures (at ~1 fps a short clip is a noisy clock: +-3 % between runs of
+    # 8 frames); the per-seam attribution runs over `seam_frames`, next to a CPU run of the same length (bitstreams are compared within a length)
+    modes = ((("cpu", 0, 0, 0, frames), ("all_gpu", 1, 1, 1, frames), ("cpu_short", 0, 0, 0, seam_frames), ("tme_gpu", 1, 0, 0, seam_frames), ("la_gpu", 0, 1, 0, seam_frames),
+              ("ff_gpu", 0, 0, 1, seam_frames), ("cpu_filters_timed", 0, 0, 2, seam_frames)) if both else (("cpu", 0, 0, 0, frames), ("tme_gpu", 1, 0, 0, frames)))
     with tempfile.TemporaryDirectory() as td:
-        for name, tme, la, ff in modes:
+        for name, tme, la, ff, nfr in modes:
             outp = os.path.join(td, name + ".hevc")
             env = dict(os.environ, X265TMEGPU=str(tme), X265LAGPU=str(la), X265FFGPU="1" if ff else "0", MALLOC_PERTURB_="85")
             env.pop("X265FF_DEFER_ONLY", None)
             if ff == 2:
                 env["X265FF_DEFER_ONLY"] = "1"             # the binding's deferral with the encoder's own filters: times what the CPU spends on a picture's filters
-            r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(frames), "medium", outp], capture_output=True, text=True, env=env, timeout=600)
+            r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(nfr), "medium", outp], capture_output=True, text=True, env=env, timeout=900)
             if r.returncode != 0:
                 return {"measured": "this run: FAILED", "producer": name, "stderr": r.stderr[-500:]}
             info = json.loads(r.stdout.strip().splitlines()[-1])
             info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
+            info["clip_frames"] = nfr
             runs[name] = info
     g, c = runs["tme_gpu"], runs["cpu"]
     best = runs.get("all_gpu", g)
     out = {"value": best["fps"], "unit": "frames/s", "measured": "this run",
-           "config": "BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults (ref=3, weightp, bframes=4, b-adapt 2), --threaded-me, %d frames" % frames,
+           "config": "BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults (ref=3, weightp, bframes=4, b-adapt 2), --threaded-me, one frame thread, no WPP (the seams' bindings "
+                     "take complete reference pictures: integration/*.cpp), %d frames for cpu / all_gpu, %d for the per-seam runs" % (frames, seam_frames),
            "host": "the reference encoder with C primitives (no asm; no nasm on this box) -- its RDO bounds the encode; value = GPU producers on every seam that is bound (%s)"
                    % ("ThreadedME + lookahead + in-loop filters" if both else "ThreadedME"),
            "fps": {k: v["fps"] for k, v in runs.items()}, "same_encoder_cpu_producer_fps": c["fps"],
-           "bitstream_identical": all(v["md5"] == c["md5"] and v["bytes"] == c["bytes"] for v in runs.values()), "bytes": c["bytes"],
+           "bitstream_identical": all(v["md5"] == w["md5"] and v["bytes"] == w["bytes"] for v in runs.values() for w in runs.values() if v["clip_frames"] == w["clip_frames"]), "bytes": c["bytes"],
            "tme": {"gpu_pictures": g["gpu_pictures"], "producer_ms_per_picture": round(1e3 * g["gpu_seconds"] / max(1, g["gpu_pictures"]), 2),
                    "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"] - g.get("adapter_create_seconds", 0.0)) / max(1, g["gpu_pictures"]), 2),
                    "adapter_note": "host work around the producer call (qps, collocated neighbours, medians, table conversions), spread over the encoder's ThreadedME workers; creating the producer (%.0f ms, once) not included"
@@ -600,37 +606,64 @@ def streams_leg(lib, depth, W, H, wl, args, pairs, headline_s_per_pass):
     return res
 
 
-def preset_exact_leg(lib, depth, W, H, wl, args, pairs, refs, rect, headline_s_per_search):
-    """The search the preset really asks for, in ONE run of the C++ host: every list-0 reference of the preset (each down the pyramid with its own predictor chain), the
-    rectangular PUs of every CU where the preset has them, the per-PU choice among the references, TQ from the chosen reference -- on PRESET_F pictures of the batch.
-    `value` of the line stays the SURVEY 8(d) pipeline (85 PUs per CTU, one reference); this leg says what the preset's own load costs next to it."""
+def preset_exact_leg(name, pairs, args, headline_s_per_search):
+    """The search a preset really asks for, in ONE run of the C++ host, on PRESET_F = 8 pictures: every list-0 reference of the preset (each down the pyramid with its own
+    predictor chain), the rectangular PUs of every CU from preset slow on, the asymmetric ones from preset slower on (param.cpp:567-608), the per-PU choice among the
+    references, TQ from the chosen reference.  `value` of the line stays the SURVEY 8(d) pipeline (85 PUs per CTU, one reference); this leg says what the preset's own
+    load costs next to it.  The size-specialised kernels address a reference's 16 phase planes with 32-bit byte offsets: an 8K batch holds 2 pictures, so the 8 pictures of
+    that workload are FOUR batches (own contexts, own streams) stepped together."""
     import torch
+    import x265hip
     from x265hip_pkg.host_batch import HostBatch
-    F = PRESET_F
-    hb = HostBatch(lib, depth, W, H, F, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, margin=MARGIN,
-                   use_planes=True, refs=refs, rect=rect, streams=min(2, F), device=torch.cuda.current_device())
+    wl, pr = WORKLOADS[name], PRESETS[name]
+    depth, W, H, refs, rect, amp = wl["depth"], wl["width"], wl["height"], pr["refs"], pr["rect"], pr["amp"]
+    lib = x265hip.HipLib(depth, fill_table=False).lib
+    F = len(pairs)
+    per = F
+    while 16 * per * (W + 2 * MARGIN) * (H + 2 * MARGIN) * (1 if depth == 8 else 2) >= (1 << 32):
+        per //= 2
+    hbs = []
     try:
-        hb.upload([p[:1 + refs] for p in pairs[:F]])
-        for _ in range(2):
-            hb.step()
-        hb.sync()
-        reps = 4
-        hb.set_timing(True)
+        for k in range(0, F, per):
+            hb = HostBatch(lib, depth, W, H, per, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, margin=MARGIN,
+                           use_planes=True, refs=refs, rect=rect, amp=amp, streams=min(2, per), device=torch.cuda.current_device())
+            hbs.append(hb)
+            hb.upload([p[:1 + refs] for p in pairs[k:k + per]])
+        def run(n):
+            for _ in range(n):
+                for hb in hbs:
+                    hb.step()
+            for hb in hbs:
+                hb.sync()
+        run(1)
+        reps = 3
+        hbs[0].set_timing(True)
         t0 = time.perf_counter()
-        for _ in range(reps):
-            hb.step()
-        hb.sync()
+        run(reps)
         dt = (time.perf_counter() - t0) / reps
-        kms = hb.read_timing()
-        searches = F * (W // 64) * (H // 64) * (425 if rect else 85) * refs
-        return {"config": {"refs": refs, "rect": bool(rect), "pus_per_ctu": 425 if rect else 85, "pictures": F, "preset_exact": True,
-                           "what": "x265hip_batch_step with desc.refs = %d%s: the preset's own motion-search load" % (refs, ", desc.rect = 1" if rect else "")},
-                "ms_per_pass": round(dt * 1e3, 3), "ms_per_picture": round(dt * 1e3 / F, 3), "Mpixels/s": round(F * W * H / dt / 1e6, 1),
-                "searched_pus_per_pass": searches, "ns_per_searched_pu": round(dt / searches * 1e9, 3),
-                "vs_headline_per_searched_pu": round((dt / searches) / headline_s_per_search, 3),
-                "stage_ms_sub_batch_0": {k: round(v, 4) for k, v in kms.items()}}
+        kms = hbs[0].read_timing()
+        pus = 85 + (340 if rect else 0) + (168 if amp else 0)
+        searches = F * (W // 64) * (H // 64) * pus * refs
+        out = {"config": {"workload": name, "refs": refs, "rect": bool(rect), "amp": bool(amp), "pus_per_ctu": pus, "pictures": F, "batches": len(hbs), "preset_exact": True,
+                          "what": "x265hip_batch_step with desc.refs = %d%s%s: the preset's own motion-search load on P pictures" % (refs, ", desc.rect = 1" if rect else "", ", desc.amp = 1" if amp else "")},
+               "ms_per_pass": round(dt * 1e3, 3), "ms_per_picture": round(dt * 1e3 / F, 3), "Mpixels/s": round(F * W * H / dt / 1e6, 1),
+               "searched_pus_per_pass": searches, "ns_per_searched_pu": round(dt / searches * 1e9, 3),
+               "stage_ms_sub_batch_0": {k: round(v, 4) for k, v in kms.items()}}
+        if headline_s_per_search:
+            out["vs_headline_per_searched_pu"] = round((dt / searches) / headline_s_per_search, 3)
+        # vector instructions per pass (SQ_INSTS_VALU summed over every launch of a pass, committed counter pass) over the live time against the issue peak
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "preset_exact_valu.json")))[name]
+            if prof.get("pictures") == F:
+                out["roofline_valu"] = {"bound": "valu issue, %d SIMDs x %.1f GHz / %d" % (N_SIMD, GPU_CLOCK_HZ / 1e9, VALU_CYCLES), "valu_wave_instr_per_pass": prof["valu_per_pass"],
+                                        "achieved": round(prof["valu_per_pass"] / dt / 1e9, 1), "peak": round(N_SIMD * GPU_CLOCK_HZ / VALU_CYCLES / 1e9, 1), "unit": "G wave-instr/s",
+                                        "frac": round(prof["valu_per_pass"] / dt / (N_SIMD * GPU_CLOCK_HZ / VALU_CYCLES), 4), "counter_source": prof.get("source")}
+        except (OSError, KeyError, ValueError):
+            pass
+        return out
     finally:
-        hb.close()
+        for hb in hbs:
+            hb.close()
 
 
 def python_pipeline(args, wl, depth, W, H, pairs):
@@ -782,9 +815,11 @@ def cpu_baseline(pipe, depth, n_ctus):
 
 MARGIN = 96                  # PicYuv-style padding of the synthetic planes (FramePipeline's default)
 # the preset's own search: references per list-0 (param.cpp:567-608) and the rectangular PUs (preset slow and up); medium has no rect
-PRESET_REFS = {"1080p8_medium": 3, "2160p10_slow": 4, "4320p10_slower": 5}
-PRESET_RECT = {"1080p8_medium": False, "2160p10_slow": True, "4320p10_slower": True}
-PRESET_F = 2                 # pictures of the preset-exact leg
+# what the presets set for the motion search (param.cpp:567-608): medium ref 3; slow ref 4 + rect; slower ref 5 + rect + amp
+PRESETS = {"1080p8_medium": dict(refs=3, rect=False, amp=False), "2160p10_slow": dict(refs=4, rect=True, amp=False), "4320p10_slower": dict(refs=5, rect=True, amp=True)}
+PRESET_REFS = {k: v["refs"] for k, v in PRESETS.items()}
+PRESET_RECT = {k: v["rect"] for k, v in PRESETS.items()}
+PRESET_F = 8                 # pictures of every preset-exact leg
 
 
 def _make_pair(W, H, depth, seed, refs=1):
@@ -885,11 +920,24 @@ def main():
     import multiprocessing
     # close() + join(), not the context manager: its terminate() sends SIGTERM to the workers, and under rocprofv3 (whose signal handler is inherited by the forked
     # workers) a worker then never exits and the run hangs in wait4 (seen in the r02 counter passes)
-    pool = multiprocessing.get_context("fork").Pool(min(len(seeds), max(1, (os.cpu_count() or 1) // max(1, args.gpus))))
-    # (the first PRESET_F pictures get the references of the preset-exact leg as well)
-    exact_refs = PRESET_REFS.get(args.workload, 0) if (not args.no_preset_exact and int(os.environ.get("RANK", "0")) == 0) else 0
-    pairs = pool.starmap(_make_pair, [(W, H, depth, sd, max(args.refs, exact_refs) if i < PRESET_F else args.refs) for i, sd in enumerate(seeds)])
+    # (rank 0 also makes the pictures of the preset-exact legs: PRESET_F pictures per workload, each with the preset's references; the headline workload's come out of its own
+    #  batch when that holds enough pictures)
+    exact = [w for w in args.preset_exact_workloads.split(",") if w in PRESETS] if (not args.no_preset_exact and int(os.environ.get("RANK", "0")) == 0) else []
+    own = args.workload in exact and args.frames >= PRESET_F
+    jobs = [(W, H, depth, sd, max(args.refs, PRESETS[args.workload]["refs"]) if (own and i < PRESET_F) else args.refs) for i, sd in enumerate(seeds)]
+    where = {}
+    for wname in exact:
+        if wname == args.workload and own:
+            continue
+        w_ = WORKLOADS[wname]
+        where[wname] = (len(jobs), len(jobs) + PRESET_F)
+        jobs += [(w_["width"], w_["height"], w_["depth"], 5000 + k, PRESETS[wname]["refs"]) for k in range(PRESET_F)]
+    pool = multiprocessing.get_context("fork").Pool(min(len(jobs), max(1, (os.cpu_count() or 1) // max(1, args.gpus))))
+    made = pool.starmap(_make_pair, jobs)
     pool.close(); pool.join()
+    pairs = made[:len(seeds)]
+    exact_pairs = {wname: (pairs[:PRESET_F] if (wname == args.workload and own) else made[where[wname][0]:where[wname][1]]) for wname in exact}
+    del made
     import torch
     import torch.distributed as dist
     import x265hip  # noqa: F401
@@ -1007,8 +1055,16 @@ def main():
         }
         if not args.no_streams_leg and args.band_rows == 0 and args.frames >= 2:
             out["streams"] = streams_leg(lib, depth, W, H, wl, args, pairs, dt / args.steps / args.inner)
-        if exact_refs and not (args.refs == exact_refs and args.rect == PRESET_RECT[args.workload]):
-            out["preset_exact"] = preset_exact_leg(lib, depth, W, H, wl, args, pairs, exact_refs, PRESET_RECT[args.workload], (dt / args.steps / args.inner) / (args.frames * (W // 64) * (H // 64) * 85 * args.refs))
+        if exact:
+            # one object per BASELINE workload: the preset's own search load on PRESET_F pictures (the headline workload's is measured against the headline's time per search)
+            out["preset_exact"] = {}
+            for wname in exact:
+                per_search = (dt / args.steps / args.inner) / (args.frames * (W // 64) * (H // 64) * 85 * args.refs) if wname == args.workload else None
+                try:
+                    out["preset_exact"][wname] = preset_exact_leg(wname, exact_pairs[wname], args, per_search)
+                except (RuntimeError, MemoryError) as e:
+                    out["preset_exact"][wname] = {"failed": str(e)[:300]}
+                exact_pairs[wname] = None
         e2e_path = os.path.join(ROOT, "profiles", "e2e_fps.json")
         if not args.no_e2e:
             try:

@@ -61,7 +61,14 @@ typedef struct x265hip_batch_desc
                                the upload / read calls join them                                                                            */
     int bandRows;           /* 0: sub-batches are whole pictures.  > 0: band-major -- the phase planes of the whole batch first, then bands of this many CTU rows, each taken
                                through all levels and the TQ stage before its stream takes the next band (bands dealt round-robin to the streams): the planes under a band
-                               are re-read while they are still in the last-level cache                                                   */
+                               are re-read while they are still in the last-level cache.  Experiment builds only (a measured loss)       */
+    int amp;                /* != 0: also the asymmetric PUs (2NxnU, 2NxnD, nLx2N, nRx2N) of every CU of 64, 32 and 16 pixels (param->bEnableAMP: preset slower and up,
+                               param.cpp:592-593; searched at analysis.cpp:2756-2860): 168 more PUs per CTU (593 with rect = the MEData entries of a CTU, threadedme.h:67-92),
+                               each seeded by its own CU's 2Nx2N result in the same reference                                             */
+    int refs1;              /* list-1 reference pictures: 0 = a P picture.  > 0 = a B picture: every list-1 reference is searched down the pyramid like list 0's, the per-PU
+                               choice is among both lists and -- for the PUs of split CUs above 8x8, as in the reference (search.cpp:420-503; 2Nx2N bi-prediction belongs to
+                               the mode decision, 8x8 CUs are bi-prediction restricted) -- the bidirectional candidate; the TQ stage compensates every TU from the list and
+                               reference its 2Nx2N PU chose.  Needs usePlanes                                                              */
 } x265hip_batch_desc;
 
 /* Pure host code (no GPU needed): the task lists x265hip_batch_create uploads.  level = 64, 32, 16 or 8.  Task k of a level is PU
@@ -72,12 +79,16 @@ int   x265hip_batch_build_me_tasks(const x265hip_batch_desc* desc, int level, x2
 /* the rectangular partitions w x h (2NxN: w = 2h = CU size; Nx2N: h = 2w): task k = PU (frame, row, column) in raster order of the w x h grid, mvpFrom = its CU's 2Nx2N task */
 int   x265hip_batch_rect_task_count(const x265hip_batch_desc* desc, int w, int h);
 int   x265hip_batch_build_rect_tasks(const x265hip_batch_desc* desc, int w, int h, x265hip_me_task* out);
+/* the asymmetric partitions (desc.amp) w x h with max(w, h) = the CU size (64, 32, 16) and min(w, h) a quarter or three quarters of it.  A shape occurs twice in every CU (as the
+ * first PU of one mode and as the second of its sibling); task k = PU (frame, CU row, occurrence 0 / 1, CU column), mvpFrom = its CU's 2Nx2N task */
+int   x265hip_batch_amp_task_count(const x265hip_batch_desc* desc, int w, int h);
+int   x265hip_batch_build_amp_tasks(const x265hip_batch_desc* desc, int w, int h, x265hip_me_task* out);
 int   x265hip_batch_tu_count(const x265hip_batch_desc* desc);
 int   x265hip_batch_build_tu_tasks(const x265hip_batch_desc* desc, x265hip_tu_task* out);
 
 int   x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* desc, x265hip_batch** batch);
 void  x265hip_batch_destroy(x265hip_batch* batch);
-/* which: 0 = source, 1 + r = list-0 reference r.  pixels: the unpadded width x height picture in HOST memory (pixel = uint8_t / uint16_t by library),
+/* which: 0 = source, 1 + r = list-0 reference r, 1 + refs + r = list-1 reference r (desc.refs1).  pixels: the unpadded width x height picture in HOST memory (pixel = uint8_t / uint16_t by library),
  * strideElems its row pitch.  The padded plane is assembled on the device. */
 int   x265hip_batch_upload_plane(x265hip_batch* batch, int which, int frame, const void* pixels, intptr_t strideElems);
 int   x265hip_batch_step(x265hip_batch* batch);
@@ -85,10 +96,11 @@ int   x265hip_batch_step_one_stream(x265hip_batch* batch);      /* the same pass
                                                                  * run one after the other, which per-stage timing needs */
 int   x265hip_batch_read_results(x265hip_batch* batch, int level, x265hip_me_result* out /* x265hip_batch_task_count entries */);       /* reference 0, 2Nx2N */
 int   x265hip_batch_read_results_ref(x265hip_batch* batch, int w, int h, int ref, x265hip_me_result* out);      /* any searched shape (square or, with rect, 2NxN / Nx2N), any reference */
-int   x265hip_batch_read_choices(x265hip_batch* batch, int w, int h, struct x265hip_inter_choice* out);         /* refs > 1: the per-PU choice among the references */
+int   x265hip_batch_read_results_list(x265hip_batch* batch, int w, int h, int list, int ref, x265hip_me_result* out);      /* any searched shape (with amp the asymmetric ones too), either list */
+int   x265hip_batch_read_choices(x265hip_batch* batch, int w, int h, struct x265hip_inter_choice* out);         /* refs > 1 or refs1 > 0: the per-PU choice among the references / lists */
 /* per-stage timing of sub-batch 0 (HIP events on the stream the stage runs on): while set_timing is 1 every step records its own event set (the last 64 are kept);
  * read_timing synchronises the batch's streams, returns the number of steps averaged (> 0) and the mean milliseconds of every stage over them, in
- * x265hip_batch_stage_name order ("planes", "me64", ["rect64",] ..., "tq"), and starts a new record */
+ * x265hip_batch_stage_name order ("planes", "me64", ["rect64",] ["amp64",] ..., "tq"), and starts a new record */
 int   x265hip_batch_set_timing(x265hip_batch* batch, int on);
 /* How a step launches its kernels -- every combination gives the same bytes (tests/test_host_batch_gpu.py compares them); the default, 0, is the fastest measured form.
  *   X265HIP_BATCH_FUSE_16_8 / _FUSE_32_16_8: the levels below a 64x64 CU only depend on each other inside a 32x32 quadrant (each 2Nx2N search is seeded with its parent CU's
@@ -112,7 +124,8 @@ int   x265hip_batch_read_timing(x265hip_batch* batch, float* msPerStage);
 int   x265hip_batch_read_plane(x265hip_batch* batch, int which, int frame, void* out /* the padded plane as it sits on the device: (width + 2 margin) x (height + 2 margin) pixels */);
 int   x265hip_batch_read_coeffs(x265hip_batch* batch, int16_t* coeff /* tu_count << (2 * tuLog2) */, uint32_t* numSig /* tu_count */);
 /* device pointers for consumers that stay on the GPU: what = 0 source planes, 1 reference planes, 2 phase planes, 3 coefficients, 4 numSig,
- * 5 reconstruction, 10 + log2(level) - 3 = results of a pyramid level (10: 8x8 ... 13: 64x64; reference 0), 100 + r = plane stack of reference r, 200 + r = its phase planes */
+ * 5 reconstruction, 10 + log2(level) - 3 = results of a pyramid level (10: 8x8 ... 13: 64x64; reference 0), 100 + r = plane stack of list-0 reference r, 200 + r = its phase planes,
+ * 300 + r / 400 + r = the same for list-1 reference r */
 void* x265hip_batch_device_ptr(x265hip_batch* batch, int what);
 /* desc.streams = 2 leaves the second sub-batch on its own stream when x265hip_batch_step returns (the read_*, upload and x265hip_ctx_sync calls join it).  A consumer that
  * stays on the GPU and queues its own work on x265hip_ctx_stream() against the pointers above calls this first: everything every sub-batch queued so far is then

@@ -10,8 +10,7 @@ from x265hip_pkg.frame import ME_TASK, TU_TASK
 from x265hip_pkg.pipeline import pyramid_tasks, LEVELS
 
 
-class Desc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes", "refs", "rect", "streams", "bandRows")]
+from x265hip_pkg.host_batch import BatchDesc as Desc      # the ctypes mirror of x265hip_batch_desc (fields beyond the ones given are zero)
 
 
 @pytest.mark.parametrize("depth", [8, 10])
@@ -32,6 +31,40 @@ def test_task_lists_equal_the_python_pipeline(depth, geom):
     out = np.zeros(n, TU_TASK)
     assert lib.x265hip_batch_build_tu_tasks(C.byref(d), C.c_void_p(out.ctypes.data)) == 0
     assert out.tobytes() == tus.tobytes()
+
+
+def test_amp_task_lists_cover_every_cu_the_way_the_four_modes_split_it():
+    """x265hip_batch_build_amp_tasks: per CU of 64 / 32 / 16 the eight PUs of 2NxnU, 2NxnD, nLx2N, nRx2N (g_puLookup, encoder/threadedme.h:67-92): a shape and its
+    complement tile the CU twice (once per mode of the pair); every PU points at its own CU's 2Nx2N task; a range of CTU rows is a contiguous range of the list"""
+    lib = x265hip.HipLib(8, fill_table=False).lib
+    W, H, F, margin = 192, 128, 2, 96
+    d = Desc(W, H, F, margin, 28, 57, 3, 3, 5, 0, 1, 1, 1, 1, 0, 1, 0)          # ... refs, rect, streams, bandRows, amp, refs1
+    stride, plane = W + 2 * margin, (W + 2 * margin) * (H + 2 * margin)
+    total = 0
+    for lv in (64, 32, 16):
+        sq = np.zeros(lib.x265hip_batch_task_count(C.byref(d), lv), ME_TASK)
+        assert lib.x265hip_batch_build_me_tasks(C.byref(d), lv, C.c_void_p(sq.ctypes.data)) == 0
+        cover = np.zeros((F, H, W), np.int32)
+        for (w, h) in ((lv, lv // 4), (lv, 3 * lv // 4), (lv // 4, lv), (3 * lv // 4, lv)):
+            n = lib.x265hip_batch_amp_task_count(C.byref(d), w, h)
+            assert n == F * (W // lv) * (H // lv) * 2
+            t = np.zeros(n, ME_TASK)
+            assert lib.x265hip_batch_build_amp_tasks(C.byref(d), w, h, C.c_void_p(t.ctypes.data)) == 0
+            total += n
+            rows_of_ctus = []
+            for k in t:
+                off = int(k["curOff"]); f, rem = divmod(off, plane); y, x = divmod(rem, stride); y -= margin; x -= margin
+                assert 0 <= x and x + w <= W and 0 <= y and y + h <= H and k["refOff"] == k["curOff"]
+                cover[f, y:y + h, x:x + w] += 1
+                cu = sq[int(k["mvpFrom"])]
+                coff = int(cu["curOff"]) - f * plane; cy, cx = divmod(coff, stride); cy -= margin; cx -= margin
+                assert cx <= x and x + w <= cx + lv and cy <= y and y + h <= cy + lv, "the PU lies inside the CU whose 2Nx2N MV seeds it"
+                assert list(k["mvmin"]) == list(cu["mvmin"]) and list(k["mvmax"]) == list(cu["mvmax"])
+                rows_of_ctus.append(f * (H // 64) + y // 64)
+            assert rows_of_ctus == sorted(rows_of_ctus)
+        assert (cover == 4).all(), "four modes, each tiling the CU once"
+    assert total == F * (W // 64) * (H // 64) * 168
+    assert lib.x265hip_batch_amp_task_count(C.byref(d), 8, 2) < 0 and lib.x265hip_batch_amp_task_count(C.byref(d), 32, 16) < 0 and lib.x265hip_batch_amp_task_count(C.byref(d), 64, 32) < 0
 
 
 def test_bad_descriptors_are_refused():

@@ -17,7 +17,7 @@ from pipeline_check import check_host_batch
 pytestmark = pytest.mark.gpu
 
 
-def pairs_for(W, H, depth, F, refs, seed0=300):
+def pairs_for(W, H, depth, F, refs, seed0=300, refs1=0):
     out = []
     for s in range(F):
         cur, ref, _, _ = frame_pair(W, H, depth, seed=seed0 + s, margin=96, max_shift=14)
@@ -26,6 +26,11 @@ def pairs_for(W, H, depth, F, refs, seed0=300):
         for r in range(1, refs):
             # an older picture of the same scene: the picture area displaced a little further + its own noise, borders replicated as extendPicBorder does
             inner = np.roll(ref[96:96 + H, 96:96 + W], (2 * r, -3 * r), (0, 1)).astype(np.int32) + rng.integers(-3 * r, 3 * r + 1, (H, W)) * (1 << (depth - 8))
+            inner = np.clip(inner, 0, (1 << depth) - 1).astype(ref.dtype)
+            p.append(np.pad(inner, 96, mode="edge"))
+        for r in range(refs1):
+            # list 1: later pictures of the scene -- displaced the other way
+            inner = np.roll(ref[96:96 + H, 96:96 + W], (-2 * (r + 1), 3 * (r + 1) - 1), (0, 1)).astype(np.int32) + rng.integers(-2 * (r + 1), 2 * (r + 1) + 1, (H, W)) * (1 << (depth - 8))
             inner = np.clip(inner, 0, (1 << depth) - 1).astype(ref.dtype)
             p.append(np.pad(inner, 96, mode="edge"))
         out.append(tuple(p))
@@ -37,23 +42,30 @@ def make(depth, W, H, F, **kw):
     return HostBatch(lib, depth, W, H, F, **kw)
 
 
-@pytest.mark.parametrize("depth,method,subme,refs,rect,streams", [(8, 1, 2, 1, False, 1), (10, 3, 3, 1, True, 1), (8, 3, 3, 3, False, 2), (10, 3, 3, 4, True, 2), (8, 1, 2, 2, True, 3),
-                                                                  (8, 3, 4, 5, True, 1)])
-def test_host_batch_matches_oracle(depth, method, subme, refs, rect, streams):
+# (depth, method, subme, list-0 references, rect, streams, amp, list-1 references): P pictures as the presets medium .. slower define them, then B pictures
+@pytest.mark.parametrize("depth,method,subme,refs,rect,streams,amp,refs1", [(8, 1, 2, 1, False, 1, False, 0), (10, 3, 3, 1, True, 1, False, 0), (8, 3, 3, 3, False, 2, False, 0),
+                                                                            (10, 3, 3, 4, True, 2, False, 0), (8, 1, 2, 2, True, 3, False, 0), (8, 3, 4, 5, True, 1, False, 0),
+                                                                            (10, 3, 4, 2, True, 2, True, 0), (8, 3, 3, 1, False, 1, True, 0),
+                                                                            (8, 1, 2, 1, False, 2, False, 1), (10, 3, 3, 2, True, 1, False, 2), (8, 3, 3, 2, True, 2, True, 1)])
+def test_host_batch_matches_oracle(depth, method, subme, refs, rect, streams, amp, refs1):
     W, H, F, qp, merange = 256, 128, 3, 28, 24
-    hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=4, refs=refs, rect=rect, streams=streams)
+    hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=4, refs=refs, rect=rect, streams=streams, amp=amp, refs1=refs1)
     try:
-        pairs = pairs_for(W, H, depth, F, refs)
+        pairs = pairs_for(W, H, depth, F, refs, refs1=refs1)
         hb.upload(pairs)
         for f in (0, F - 1):        # the device pads the picture the way the host-padded planes are padded
-            for which in range(1 + refs):
+            for which in range(1 + refs + refs1):
                 assert np.array_equal(hb.device_plane(which, f), pairs[f][which].reshape(-1)), "plane %d of picture %d" % (which, f)
         hb.step(); hb.sync()
         # EXHAUSTIVE at this size: every PU of every shape in every reference, every choice, every TU against the oracle (seconds of CPU)
         n = check_host_batch(hb, Oracle(depth), np.random.default_rng(depth + refs), mvcost_row(depth, qp, 1 << 15), mvbits_row(depth, 1 << 14), rd_lambda(depth, qp),
                              per_shape=1 << 30, n_tu=1 << 30)
         ctus = F * (W // 64) * (H // 64)
-        assert n == ctus * (425 if rect else 85) + F * (W // 16) * (H // 16)
+        assert n == ctus * (85 + (340 if rect else 0) + (168 if amp else 0)) + F * (W // 16) * (H // 16)
+        if refs1 and (rect or amp):         # the B picture's split PUs really took the bidirectional candidate somewhere (and a 2Nx2N PU never)
+            both = sum(int(((c["ref"][:, 0] >= 0) & (c["ref"][:, 1] >= 0)).sum()) for c in (hb.choices(w, h) for (w, h) in list(hb.rect_host) + list(hb.amp_host) if max(w, h) > 8))
+            assert both > 0
+            assert all(int(((c["ref"][:, 0] >= 0) & (c["ref"][:, 1] >= 0)).sum()) == 0 for c in (hb.choices(lv) for lv in LEVELS))
     finally:
         hb.close()
 

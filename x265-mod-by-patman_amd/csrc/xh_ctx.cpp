@@ -25,12 +25,14 @@ const int kLevels[4] = { 64, 32, 16, 8 };
 constexpr int kHalf = 1 << 15;                 // MVD cost row: d in [-32768, 32768] quarter-pels
 constexpr int kTimingSets = 64;                // event sets kept between two x265hip_batch_read_timing calls
 constexpr int kBitsHalf = 1 << 14;             // MVD bit-size row of the per-PU choice among references
+constexpr int kRect0 = 4, kAmp0 = 12, kSlots = 24;
 
 bool desc_ok(const x265hip_batch_desc* d)
 {
     return d && d->width >= CTU && d->height >= CTU && d->width <= X265HIP_MAX_PIC_DIM && d->height <= X265HIP_MAX_PIC_DIM && d->width % CTU == 0 && d->height % CTU == 0 && d->frames >= 1 && d->margin >= CTU + 16 + 8 &&
            d->margin % 4 == 0 && d->qp >= 0 && d->qp <= 51 && d->merange >= 1 && d->subme >= 0 && d->subme <= 7 && d->tuLog2 >= 2 && d->tuLog2 <= 5 &&
-           d->refs >= 0 && d->refs <= X265HIP_MAX_REF && d->streams >= 0 && d->streams <= 8 && d->bandRows >= 0 && (d->refs <= 1 || d->usePlanes)
+           d->refs >= 0 && d->refs <= X265HIP_MAX_REF && d->refs1 >= 0 && d->refs1 <= X265HIP_MAX_REF && d->streams >= 0 && d->streams <= 8 && d->bandRows >= 0 &&
+           ((d->refs <= 1 && d->refs1 == 0) || d->usePlanes)
 #ifndef X265HIP_EXPERIMENTS
            && d->bandRows == 0           // the band-major schedule is a measured loss (profiles/r03_band_major_ab.txt): experiment builds only (make EXPERIMENTS=1)
 #endif
@@ -45,14 +47,16 @@ struct x265hip_batch
 {
     x265hip_ctx* ctx = nullptr;
     x265hip_batch_desc d{};
-    int refs = 1, nsub = 1;
+    int refs = 1, nsub = 1;                     // refs = nref[0]
     int64_t stride = 0, plane = 0;
     pixel *cur = nullptr, *recon = nullptr;
-    pixel* ref[X265HIP_MAX_REF] = {}; pixel* planes[X265HIP_MAX_REF] = {};                      // per list-0 reference: the plane stack and its 16-slot phase planes
-    x265hip_me_task* tasks[4] = {}; x265hip_me_result* results[X265HIP_MAX_REF][4] = {}; int ntasks[4] = {};      // results[r][level]: reference r's own chain down the pyramid
-    x265hip_inter_choice* choice[4] = {};                                                      // refs > 1: the per-PU choice among the references
-    // rectangular partitions (desc.rect): shape k = 2 * level + (0: 2NxN, 1: Nx2N)
-    x265hip_me_task* rtasks[8] = {}; x265hip_me_result* rresults[X265HIP_MAX_REF][8] = {}; x265hip_inter_choice* rchoice[8] = {}; int nrtasks[8] = {};
+    int nref[2] = { 1, 0 };                                                                    // references searched per list (list 1: B pictures)
+    pixel* ref[2][X265HIP_MAX_REF] = {}; pixel* planes[2][X265HIP_MAX_REF] = {};              // per (list, reference): the plane stack and its 16-slot phase planes
+    // every searched PU shape has a slot: 0..3 the 2Nx2N PUs of the levels 64 / 32 / 16 / 8; 4..11 the 2NxN / Nx2N PUs (desc.rect: 4 + 2 * level + (0: 2NxN, 1: Nx2N));
+    // 12..23 the AMP PUs of the levels 64 / 32 / 16 (desc.amp: 12 + 4 * level + (0: 2N x N/2, 1: 2N x 3N/2, 2: N/2 x 2N, 3: 3N/2 x 2N)).  res[list][ref][slot]: that
+    // reference's own chain down the pyramid; choice[slot]: the per-PU choice among references / lists (several references or a B picture)
+    x265hip_me_task* tasks[kSlots] = {}; int ntasks[kSlots] = {}; x265hip_me_result* res[2][X265HIP_MAX_REF][kSlots] = {}; x265hip_inter_choice* choice[kSlots] = {};
+    bool needChoice = false;
     x265hip_tu_task* tu = nullptr; int ntu = 0, mvLevel = 0;
     int16_t* coeff = nullptr; uint32_t* numSig = nullptr; uint64_t* sse = nullptr;
     uint16_t* costRow = nullptr; float* bitsRow = nullptr; uint64_t lambda = 0;
@@ -184,7 +188,22 @@ extern "C" int x265hip_batch_build_tu_tasks(const x265hip_batch_desc* d, x265hip
 // ---- rectangular partitions: for every CU of a pyramid level its two 2NxN and its two Nx2N PUs (g_puLookup, encoder/threadedme.h:67-92), each seeded with the MV of
 //      its own CU's 2Nx2N search (mvpFrom indexes that level's results); limits = CUData::clipMv on the CU's position (cudata.cpp:2094-2107) ----
 namespace {
-void rect_shape(int k, int& w, int& h) { const int lv = kLevels[k >> 1]; if (k & 1) { w = lv >> 1; h = lv; } else { w = lv; h = lv >> 1; } }
+// slot -> PU shape; lv = the CU size the shape belongs to.  false: no such shape (AMP splits CUs of 16x16 and up -- maxAMPDepth, slice.h)
+bool slot_shape(int slot, int& w, int& h, int& lv)
+{
+    if (slot < kRect0) { lv = kLevels[slot]; w = h = lv; return true; }
+    if (slot < kAmp0) { const int k = slot - kRect0; lv = kLevels[k >> 1]; if (k & 1) { w = lv >> 1; h = lv; } else { w = lv; h = lv >> 1; } return true; }
+    const int k = slot - kAmp0; lv = kLevels[k >> 2];
+    if (lv < 16) return false;
+    switch (k & 3) { case 0: w = lv; h = lv >> 2; break; case 1: w = lv; h = 3 * (lv >> 2); break; case 2: w = lv >> 2; h = lv; break; default: w = 3 * (lv >> 2); h = lv; }
+    return true;
+}
+int amp_slot(int w, int h)
+{
+    const int lv = w > h ? w : h, li = level_index(lv), s = w > h ? h : w;
+    if (li < 0 || lv < 16 || (4 * s != lv && 4 * s != 3 * lv)) return -1;
+    return kAmp0 + 4 * li + (w > h ? 0 : 2) + (4 * s == lv ? 0 : 1);
+}
 }
 extern "C" int x265hip_batch_rect_task_count(const x265hip_batch_desc* d, int w, int h)
 {
@@ -212,6 +231,39 @@ extern "C" int x265hip_batch_build_rect_tasks(const x265hip_batch_desc* d, int w
     return X265HIP_OK;
 }
 
+// ---- asymmetric partitions (param->bEnableAMP: presets slower and up, param.cpp:592-593; searched at analysis.cpp:2756-2860): every CU of 64, 32 and 16 pixels has the
+//      modes 2NxnU (PUs 2N x N/2 over 2N x 3N/2), 2NxnD (2N x 3N/2 over 2N x N/2), nLx2N and nRx2N (the same, left / right) -- g_puLookup, encoder/threadedme.h:67-92.  A shape
+//      w x h occurs twice per CU: once as the first PU of a mode (at the CU's origin) and once as the second PU of the sibling mode (behind the larger PU).  Task order of a
+//      shape: picture, CU row, occurrence (0: at the CU's origin, 1: the other one), CU column -- a range of CTU rows is a contiguous range of the list.  Each PU is seeded by
+//      its CU's 2Nx2N result (mvpFrom), limits as for the rectangles. ----
+extern "C" int x265hip_batch_amp_task_count(const x265hip_batch_desc* d, int w, int h)
+{
+    if (!desc_ok(d) || amp_slot(w, h) < 0) return X265HIP_EARG;
+    const int lv = w > h ? w : h;
+    return d->frames * (d->width / lv) * (d->height / lv) * 2;
+}
+extern "C" int x265hip_batch_build_amp_tasks(const x265hip_batch_desc* d, int w, int h, x265hip_me_task* out)
+{
+    if (x265hip_batch_amp_task_count(d, w, h) < 0 || !out) { set_error("batch_build_amp_tasks: bad arguments"); return X265HIP_EARG; }
+    const int W = d->width, H = d->height, lv = w > h ? w : h, nx = W / lv, ny = H / lv;
+    const int64_t stride = stride_of(d), plane = plane_of(d);
+    x265hip_me_task* t = out;
+    for (int f = 0; f < d->frames; f++)
+        for (int cy = 0; cy < ny; cy++)
+            for (int k = 0; k < 2; k++)
+                for (int cx = 0; cx < nx; cx++, t++)
+                {   // occurrence 1 starts where the sibling mode's first PU (the complementary size) ends
+                    const int x = cx * lv + (k && w < lv ? lv - w : 0), y = cy * lv + (k && h < lv ? lv - h : 0);
+                    memset(t, 0, sizeof(*t));
+                    t->curOff = t->refOff = (int32_t)(f * plane + (int64_t)(d->margin + y) * stride + d->margin + x);
+                    t->mvmin[0] = (int16_t)(-((CTU + 8 + cx * lv - 1) << 2)); t->mvmin[1] = (int16_t)(-((CTU + 8 + cy * lv - 1) << 2));
+                    t->mvmax[0] = (int16_t)((W + 8 - cx * lv - 1) << 2);      t->mvmax[1] = (int16_t)((H + 8 - cy * lv - 1) << 2);
+                    t->flags = X265HIP_ME_WINDOW;
+                    t->mvpFrom = f * (nx * ny) + cy * nx + cx;
+                }
+    return X265HIP_OK;
+}
+
 extern "C" void x265hip_batch_destroy(x265hip_batch* b)
 {
     if (!b) return;
@@ -234,7 +286,8 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
     x265hip_batch* b = new (std::nothrow) x265hip_batch();
     if (!b) { set_error("batch_create: out of host memory"); return X265HIP_EARG; }
     b->ctx = ctx; b->d = *d; b->stride = stride_of(d); b->plane = plane_of(d);
-    b->refs = d->refs > 1 ? d->refs : 1;
+    b->refs = d->refs > 1 ? d->refs : 1; b->nref[0] = b->refs; b->nref[1] = d->refs1;
+    b->needChoice = b->refs > 1 || b->nref[1] > 0;
     b->nsub = d->streams > 1 ? ((d->bandRows > 0 || d->streams < d->frames) ? d->streams : d->frames) : 1;
     b->sub[0] = ctx->stream;
     const size_t elems = (size_t)b->plane * d->frames;
@@ -255,43 +308,31 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
         XBH(hipEventCreateWithFlags(&b->evJoin[i], hipEventDisableTiming), "hipEventCreate");
     }
     XB(b->alloc(b->cur, elems));
-    for (int r = 0; r < b->refs; r++)
-    {
-        XB(b->alloc(b->ref[r], elems));
-        if (d->usePlanes) XB(b->alloc(b->planes[r], 16 * elems));
-    }
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < b->nref[l]; r++)
+        {
+            XB(b->alloc(b->ref[l][r], elems));
+            if (d->usePlanes) XB(b->alloc(b->planes[l][r], 16 * elems));
+        }
     if (d->recon) { XB(b->alloc(b->recon, elems)); XB(b->alloc(b->sse, (size_t)x265hip_batch_tu_count(d))); }
     std::vector<x265hip_me_task> host;
-    for (int i = 0; i < 4; i++)
+    for (int slot = 0; slot < kSlots; slot++)
     {
-        b->ntasks[i] = x265hip_batch_task_count(d, kLevels[i]);
-        host.resize((size_t)b->ntasks[i]);
-        XB(x265hip_batch_build_me_tasks(d, kLevels[i], host.data()));
-        XB(b->alloc(b->tasks[i], host.size()));
-        XBH(hipMemcpy(b->tasks[i], host.data(), host.size() * sizeof(x265hip_me_task), hipMemcpyHostToDevice), "hipMemcpy(tasks)");
-        for (int r = 0; r < b->refs; r++)
-        {
-            XB(b->alloc(b->results[r][i], host.size()));
-            XBH(hipMemset(b->results[r][i], 0, host.size() * sizeof(x265hip_me_result)), "hipMemset(results)");
-        }
-        if (b->refs > 1) XB(b->alloc(b->choice[i], host.size()));
-    }
-    if (d->rect)
-        for (int k = 0; k < 8; k++)
-        {
-            int w, h; rect_shape(k, w, h);
-            b->nrtasks[k] = x265hip_batch_rect_task_count(d, w, h);
-            host.resize((size_t)b->nrtasks[k]);
-            XB(x265hip_batch_build_rect_tasks(d, w, h, host.data()));
-            XB(b->alloc(b->rtasks[k], host.size()));
-            XBH(hipMemcpy(b->rtasks[k], host.data(), host.size() * sizeof(x265hip_me_task), hipMemcpyHostToDevice), "hipMemcpy(rect tasks)");
-            for (int r = 0; r < b->refs; r++)
+        int w, h, lv;
+        if (!slot_shape(slot, w, h, lv) || (slot >= kRect0 && slot < kAmp0 && !d->rect) || (slot >= kAmp0 && !d->amp)) continue;
+        b->ntasks[slot] = slot < kRect0 ? x265hip_batch_task_count(d, lv) : slot < kAmp0 ? x265hip_batch_rect_task_count(d, w, h) : x265hip_batch_amp_task_count(d, w, h);
+        host.resize((size_t)b->ntasks[slot]);
+        XB(slot < kRect0 ? x265hip_batch_build_me_tasks(d, lv, host.data()) : slot < kAmp0 ? x265hip_batch_build_rect_tasks(d, w, h, host.data()) : x265hip_batch_build_amp_tasks(d, w, h, host.data()));
+        XB(b->alloc(b->tasks[slot], host.size()));
+        XBH(hipMemcpy(b->tasks[slot], host.data(), host.size() * sizeof(x265hip_me_task), hipMemcpyHostToDevice), "hipMemcpy(tasks)");
+        for (int l = 0; l < 2; l++)
+            for (int r = 0; r < b->nref[l]; r++)
             {
-                XB(b->alloc(b->rresults[r][k], host.size()));
-                XBH(hipMemset(b->rresults[r][k], 0, host.size() * sizeof(x265hip_me_result)), "hipMemset(rect results)");
+                XB(b->alloc(b->res[l][r][slot], host.size()));
+                XBH(hipMemset(b->res[l][r][slot], 0, host.size() * sizeof(x265hip_me_result)), "hipMemset(results)");
             }
-            if (b->refs > 1) XB(b->alloc(b->rchoice[k], host.size()));
-        }
+        if (b->needChoice) XB(b->alloc(b->choice[slot], host.size()));
+    }
     b->ntu = x265hip_batch_tu_count(d);
     b->mvLevel = (1 << d->tuLog2) < 8 ? 8 : (1 << d->tuLog2);
     std::vector<x265hip_tu_task> tu((size_t)b->ntu);
@@ -303,7 +344,7 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
     XB(x265hip_mvcost_row(d->qp, kHalf, row.data()));
     XB(b->alloc(b->costRow, row.size()));
     XBH(hipMemcpy(b->costRow, row.data(), row.size() * sizeof(uint16_t), hipMemcpyHostToDevice), "hipMemcpy(cost row)");
-    if (b->refs > 1)
+    if (b->needChoice)
     {   // the per-PU choice among references prices MVDs in bits (BitCost::bitcost) and weighs them with the RD lambda (RDCost::getCost)
         std::vector<float> bits(2 * kBitsHalf + 1);
         XB(x265hip_mvbits_row(kBitsHalf, bits.data()));
@@ -317,6 +358,7 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
     {
         b->stageNames.push_back("me" + std::to_string(kLevels[i]));
         if (d->rect) b->stageNames.push_back("rect" + std::to_string(kLevels[i]));
+        if (d->amp && kLevels[i] >= 16) b->stageNames.push_back("amp" + std::to_string(kLevels[i]));
     }
     b->stageNames.push_back("tq");
 #undef XB
@@ -327,12 +369,12 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
 
 extern "C" int x265hip_batch_upload_plane(x265hip_batch* b, int which, int frame, const void* pixels, intptr_t strideElems)
 {
-    if (!b || which < 0 || which > b->refs || frame < 0 || frame >= b->d.frames || !pixels || strideElems < b->d.width)
+    if (!b || which < 0 || which > b->nref[0] + b->nref[1] || frame < 0 || frame >= b->d.frames || !pixels || strideElems < b->d.width)
     { set_error("batch_upload_plane: bad arguments"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
     { const int jrc = join_subs(b); if (jrc) return jrc; }
     const x265hip_batch_desc& d = b->d;
-    pixel* plane = (which ? b->ref[which - 1] : b->cur) + (size_t)frame * b->plane;
+    pixel* plane = (!which ? b->cur : which <= b->nref[0] ? b->ref[0][which - 1] : b->ref[1][which - 1 - b->nref[0]]) + (size_t)frame * b->plane;
     pixel* org = plane + (size_t)d.margin * b->stride + d.margin;
     hipStream_t st = b->ctx->stream;
     // host rows -> straight into the padded plane, then the borders on the device (extendPicBorder)
@@ -347,16 +389,17 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
     const x265hip_batch_desc& d = b->d;
     const int64_t planeElems = b->plane * d.frames;                  // the 16 phase-plane slots are planeElems apart; a sub-batch addresses its pictures inside them
     const int rowsPerPic = d.height + 2 * d.margin;
-    for (int r = 0; r < b->refs; r++)
-    {
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < b->nref[l]; r++)
+        {
+            const pixel* src = b->ref[l][r] + (size_t)f0 * b->plane; pixel* dst = b->planes[l][r] + (size_t)f0 * b->plane;
 #ifdef X265HIP_EXPERIMENTS
-        const int rc = b->tiled ? xh_subpel_planes_tiled(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems)
-                                : x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems);
+            const int rc = b->tiled ? xh_subpel_planes_tiled(st, src, b->stride, (f1 - f0) * rowsPerPic, dst, planeElems) : x265hip_subpel_planes(st, src, b->stride, (f1 - f0) * rowsPerPic, dst, planeElems);
 #else
-        const int rc = x265hip_subpel_planes(st, b->ref[r] + (size_t)f0 * b->plane, b->stride, (f1 - f0) * rowsPerPic, b->planes[r] + (size_t)f0 * b->plane, planeElems);
+            const int rc = x265hip_subpel_planes(st, src, b->stride, (f1 - f0) * rowsPerPic, dst, planeElems);
 #endif
-        if (rc != X265HIP_OK) return rc;
-    }
+            if (rc != X265HIP_OK) return rc;
+        }
     return X265HIP_OK;
 }
 
@@ -370,7 +413,7 @@ bool tiled_ok(const x265hip_batch* b)
     (void)b; return false;
 #else
     const x265hip_batch_desc& d = b->d;
-    return b->tiledWanted && !b->fused && b->refs == 1 && !d.rect && d.usePlanes && d.method == X265HIP_ME_STAR && d.merange <= 57 &&
+    return b->tiledWanted && !b->fused && b->refs == 1 && !b->nref[1] && !d.rect && !d.amp && d.usePlanes && d.method == X265HIP_ME_STAR && d.merange <= 57 &&
            xh_subpel_planes_tiled_ok(b->stride, d.height + 2 * d.margin) && (uint64_t)(b->plane * d.frames) * 16u * sizeof(pixel) < (1ull << 32);
 #endif
 }
@@ -392,40 +435,50 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
         }
         else stage++;                                    // (band-major: the planes of the whole batch were made, and timed, before the bands)
     }
-    // one task list searched in every reference (each with its own parent chain), then the per-PU choice (Search::puMotionEstimation's tail, search.cpp:258-556)
-    auto search = [&](int w, int h, const x265hip_me_task* tasks, int first, int n, x265hip_me_result* const* res, x265hip_me_result* const* parent, x265hip_inter_choice* choice) -> int
+    // one task list (slot) searched in every reference of every list (each with its own parent chain), then the per-PU choice (Search::puMotionEstimation's tail,
+    // search.cpp:258-556).  parentSlot < 0: the top level
+    auto search = [&](int slot, int parentSlot, int first, int n) -> int
     {
-        for (int r = 0; r < b->refs; r++)
-        {
+        int w, h, lv; slot_shape(slot, w, h, lv);
+        const x265hip_me_task* tasks = b->tasks[slot] + first;
+        for (int l = 0; l < 2; l++)
+            for (int r = 0; r < b->nref[l]; r++)
+            {
+                x265hip_me_result* out = b->res[l][r][slot] + first;
+                const x265hip_me_result* parent = parentSlot >= 0 ? b->res[l][r][parentSlot] : nullptr;
 #ifdef X265HIP_EXPERIMENTS
-            if (b->tiled && w == h)
-                rc = xh_me_star_tiled(st, w, h, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.subme, res[r] + first, parent ? parent[r] : nullptr,
-                                      b->planes[r], planeElems, w == CTU && !parent && b->ownStart64);
-            else
+                if (b->tiled && w == h)
+                    rc = xh_me_star_tiled(st, w, h, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, parent, b->planes[l][r], planeElems, w == CTU && !parent && b->ownStart64);
+                else
 #endif
-            if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
-                rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.subme, res[r] + first, b->planes[r], planeElems);
-            else
-            rc = x265hip_me_batch(st, w, h, b->cur, b->stride, b->ref[r], b->stride, tasks + first, n, b->costRow, kHalf, d.merange, d.method, d.subme,
-                                  res[r] + first, parent ? parent[r] : nullptr, up ? b->planes[r] : nullptr, up ? planeElems : 0);
-            if (rc != X265HIP_OK) return rc;
-        }
-        if (b->refs > 1)
+                if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
+                    rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, b->planes[l][r], planeElems);
+                else
+                    rc = x265hip_me_batch(st, w, h, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.method, d.subme, out, parent,
+                                          up ? b->planes[l][r] : nullptr, up ? planeElems : 0);
+                if (rc != X265HIP_OK) return rc;
+            }
+        if (b->needChoice)
         {
             x265hip_merge_params p{};
-            p.numRef[0] = b->refs; p.numRef[1] = 0;
-            for (int r = 0; r < b->refs; r++) { p.results[0][r] = res[r] + first; p.mvpSource[0][r] = parent ? parent[r] : nullptr; p.subpelPlanes[0][r] = b->planes[r]; }
-            p.planeElems = planeElems; p.bitsRow = b->bitsRow; p.bitsHalfRange = kBitsHalf; p.lambda = b->lambda; p.bidir = 0; p.sourceMaxDim = d.width > d.height ? d.width : d.height;
-            if ((rc = x265hip_inter_merge_batch(st, w, h, b->cur, b->stride, b->stride, tasks + first, n, &p, choice + first)) != X265HIP_OK) return rc;
+            p.numRef[0] = b->nref[0]; p.numRef[1] = b->nref[1];
+            for (int l = 0; l < 2; l++)
+                for (int r = 0; r < b->nref[l]; r++)
+                { p.results[l][r] = b->res[l][r][slot] + first; p.mvpSource[l][r] = parentSlot >= 0 ? b->res[l][r][parentSlot] : nullptr; p.subpelPlanes[l][r] = b->planes[l][r]; }
+            p.planeElems = planeElems; p.bitsRow = b->bitsRow; p.bitsHalfRange = kBitsHalf; p.lambda = b->lambda; p.sourceMaxDim = d.width > d.height ? d.width : d.height;
+            // the bidirectional candidate of a B picture exists for the PUs of a split CU -- not for 2Nx2N ("handled elsewhere": checkBidir2Nx2N belongs to the mode decision)
+            // and not inside an 8x8 CU (CUData::isBipredRestriction): search.cpp:421-422
+            p.bidir = b->nref[1] > 0 && w != h && lv > 8;
+            if ((rc = x265hip_inter_merge_batch(st, w, h, b->cur, b->stride, b->stride, tasks, n, &p, b->choice[slot] + first)) != X265HIP_OK) return rc;
         }
         return X265HIP_OK;
     };
     // the lower three levels fused: one reference, squares only, STAR out of phase planes (the stage slots of the 16x16 and 8x8 levels then hold empty intervals,
     // the 32x32 slot the whole launch)
 #ifdef X265HIP_EXPERIMENTS
-    const bool fusedLower = b->fused && b->refs == 1 && !d.rect && up && xh_me_pyr_ok(d.method, planeElems, kHalf);
+    const bool fusedLower = b->fused && b->refs == 1 && !b->nref[1] && !d.rect && !d.amp && up && xh_me_pyr_ok(d.method, planeElems, kHalf);
 #else
-    constexpr bool fusedLower = false;
+    constexpr bool fusedLower = false; (void)fusedLower;
 #endif
     for (int i = 0; i < 4; i++)
     {
@@ -437,53 +490,60 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
             if (i == (b->fusedFrom32 ? 1 : 2))
             {
                 const x265hip_me_task* tl[3] = { b->tasks[1], b->tasks[2], b->tasks[3] };
-                x265hip_me_result* rl[3] = { b->results[0][1], b->results[0][2], b->results[0][3] };
-                if ((rc = xh_me_pyr(st, b->cur, b->stride, b->ref[0], b->stride, tl, rl, b->fusedFrom32 ? b->results[0][0] : nullptr, g0, g1 - g0, d.width, b->costRow, kHalf, d.merange, d.method, d.subme,
-                                    b->planes[0], planeElems)) != X265HIP_OK) return rc;
+                x265hip_me_result* rl[3] = { b->res[0][0][1], b->res[0][0][2], b->res[0][0][3] };
+                if ((rc = xh_me_pyr(st, b->cur, b->stride, b->ref[0][0], b->stride, tl, rl, b->fusedFrom32 ? b->res[0][0][0] : nullptr, g0, g1 - g0, d.width, b->costRow, kHalf, d.merange, d.method, d.subme,
+                                    b->planes[0][0], planeElems)) != X265HIP_OK) return rc;
             }
             if ((rc = mark(1))) return rc;
             continue;
         }
 #endif
-        x265hip_me_result* res[X265HIP_MAX_REF]; x265hip_me_result* par[X265HIP_MAX_REF];
-        for (int r = 0; r < b->refs; r++) { res[r] = b->results[r][i]; par[r] = i ? b->results[r][i - 1] : nullptr; }
         if ((rc = mark(0))) return rc;
         const bool token = b->pingpong && sub >= 0 && i == 0;
         const int prev = (sub + b->nsub - 1) % b->nsub;                             // the token goes round the streams
         if (token && b->tokSet[prev]) XH_HIP(hipStreamWaitEvent(st, b->evTok[prev], 0));
-        if ((rc = search(lv, lv, b->tasks[i], g0 * per, (g1 - g0) * per, res, i ? par : nullptr, b->choice[i]))) return rc;
+        if ((rc = search(i, i ? i - 1 : -1, g0 * per, (g1 - g0) * per))) return rc;
         if (token) { XH_HIP(hipEventRecord(b->evTok[sub], st)); b->tokSet[sub] = true; }
         if ((rc = mark(1))) return rc;
+        // the PUs of the split forms of this level's CUs: seeded by the CU's own 2Nx2N result in the same reference
         if (d.rect)
         {
             if ((rc = mark(0))) return rc;
-            for (int k = 2 * i; k < 2 * i + 2; k++)
+            for (int slot = kRect0 + 2 * i; slot < kRect0 + 2 * i + 2; slot++)
             {
-                int w, h; rect_shape(k, w, h);
-                const int rper = (d.width / w) * (CTU / h);
-                x265hip_me_result* rres[X265HIP_MAX_REF];
-                for (int r = 0; r < b->refs; r++) rres[r] = b->rresults[r][k];
-                if ((rc = search(w, h, b->rtasks[k], g0 * rper, (g1 - g0) * rper, rres, res, b->rchoice[k]))) return rc;      // seeded by the CU's own 2Nx2N result in the same reference
+                const int k = b->ntasks[slot] / (d.frames * ctuRows);                // PUs of the shape per CTU row
+                if ((rc = search(slot, i, g0 * k, (g1 - g0) * k))) return rc;
+            }
+            if ((rc = mark(1))) return rc;
+        }
+        if (d.amp && lv >= 16)
+        {
+            if ((rc = mark(0))) return rc;
+            for (int slot = kAmp0 + 4 * i; slot < kAmp0 + 4 * i + 4; slot++)
+            {
+                const int k = b->ntasks[slot] / (d.frames * ctuRows);
+                if ((rc = search(slot, i, g0 * k, (g1 - g0) * k))) return rc;
             }
             if ((rc = mark(1))) return rc;
         }
     }
     const int n = 1 << d.tuLog2, tper = (d.width / n) * (CTU / n), t0 = g0 * tper, nt = (g1 - g0) * tper, mi = level_index(b->mvLevel);
     if ((rc = mark(0))) return rc;
-    for (int r = 0; r < b->refs; r++)
-    {   // one launch per reference plane: every TU is compensated from the reference its PU chose
-        x265hip_tq_params p{};
-        p.qp = d.qp; p.add = 85; p.subpelPlanes = up ? b->planes[r] : nullptr; p.planeElems = up ? planeElems : 0;
-        if (b->refs > 1) { p.choice = b->choice[mi]; p.choiceList = 0; p.choiceRef = r; }
+    for (int l = 0; l < 2; l++)
+        for (int r = 0; r < b->nref[l]; r++)
+        {   // one launch per reference plane: every TU is compensated from the reference its (2Nx2N) PU chose -- list 0 or list 1; a 2Nx2N PU has no bidirectional candidate here
+            x265hip_tq_params p{};
+            p.qp = d.qp; p.add = 85; p.subpelPlanes = up ? b->planes[l][r] : nullptr; p.planeElems = up ? planeElems : 0;
+            if (b->needChoice) { p.choice = b->choice[mi]; p.choiceList = l; p.choiceRef = r; }
 #ifdef X265HIP_EXPERIMENTS
-        rc = (b->tiled ? xh_tq_batch_tiled : x265hip_tq_batch)
+            rc = (b->tiled ? xh_tq_batch_tiled : x265hip_tq_batch)
 #else
-        rc = x265hip_tq_batch
+            rc = x265hip_tq_batch
 #endif
-                             (st, d.tuLog2, b->cur, b->stride, b->ref[r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
-                              d.recon ? b->recon : nullptr, b->stride, d.recon ? b->sse + t0 : nullptr, b->refs > 1 ? nullptr : b->results[0][mi]);
-        if (rc != X265HIP_OK) return rc;
-    }
+                                 (st, d.tuLog2, b->cur, b->stride, b->ref[l][r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
+                                  d.recon ? b->recon : nullptr, b->stride, d.recon ? b->sse + t0 : nullptr, b->needChoice ? nullptr : b->res[0][0][mi]);
+            if (rc != X265HIP_OK) return rc;
+        }
     return mark(1);
 }
 }
@@ -619,37 +679,35 @@ extern "C" int x265hip_batch_read_timing(x265hip_batch* b, float* ms)
 }
 
 namespace {
-int shape_slot(const x265hip_batch* b, int w, int h, bool& rect)
+// the slot of a searched shape of THIS batch, or -1
+int shape_slot(const x265hip_batch* b, int w, int h)
 {
-    rect = w != h;
-    if (!rect) return level_index(w);
-    if (!b->d.rect || level_index(w > h ? w : h) < 0 || (w != 2 * h && h != 2 * w)) return -1;
-    return 2 * level_index(w > h ? w : h) + (h > w ? 1 : 0);
+    int slot = -1;
+    if (w == h) slot = level_index(w);
+    else if (level_index(w > h ? w : h) >= 0 && (w == 2 * h || h == 2 * w)) slot = kRect0 + 2 * level_index(w > h ? w : h) + (h > w ? 1 : 0);
+    else slot = amp_slot(w, h);
+    return (slot >= 0 && b->tasks[slot]) ? slot : -1;
 }
 }
-extern "C" int x265hip_batch_read_results(x265hip_batch* b, int level, x265hip_me_result* out) { return x265hip_batch_read_results_ref(b, level, level, 0, out); }
-extern "C" int x265hip_batch_read_results_ref(x265hip_batch* b, int w, int h, int ref, x265hip_me_result* out)
+extern "C" int x265hip_batch_read_results(x265hip_batch* b, int level, x265hip_me_result* out) { return x265hip_batch_read_results_list(b, level, level, 0, 0, out); }
+extern "C" int x265hip_batch_read_results_ref(x265hip_batch* b, int w, int h, int ref, x265hip_me_result* out) { return x265hip_batch_read_results_list(b, w, h, 0, ref, out); }
+extern "C" int x265hip_batch_read_results_list(x265hip_batch* b, int w, int h, int list, int ref, x265hip_me_result* out)
 {
-    bool rect = false;
-    const int i = b ? shape_slot(b, w, h, rect) : -1;
-    if (!b || i < 0 || ref < 0 || ref >= b->refs || !out) { set_error("batch_read_results: bad arguments"); return X265HIP_EARG; }
+    const int i = b ? shape_slot(b, w, h) : -1;
+    if (!b || i < 0 || list < 0 || list > 1 || ref < 0 || ref >= b->nref[list] || !out) { set_error("batch_read_results: bad arguments (shape %dx%d, list %d, reference %d)", w, h, list, ref); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
     { const int jrc = join_subs(b); if (jrc) return jrc; }
-    const x265hip_me_result* src = rect ? b->rresults[ref][i] : b->results[ref][i];
-    const int n = rect ? b->nrtasks[i] : b->ntasks[i];
-    XH_HIP(hipMemcpyAsync(out, src, (size_t)n * sizeof(x265hip_me_result), hipMemcpyDeviceToHost, b->ctx->stream));
+    XH_HIP(hipMemcpyAsync(out, b->res[list][ref][i], (size_t)b->ntasks[i] * sizeof(x265hip_me_result), hipMemcpyDeviceToHost, b->ctx->stream));
     XH_HIP(hipStreamSynchronize(b->ctx->stream));
     return X265HIP_OK;
 }
 extern "C" int x265hip_batch_read_choices(x265hip_batch* b, int w, int h, x265hip_inter_choice* out)
 {
-    bool rect = false;
-    const int i = b ? shape_slot(b, w, h, rect) : -1;
-    if (!b || i < 0 || b->refs < 2 || !out) { set_error("batch_read_choices: bad arguments (choices exist with refs > 1)"); return X265HIP_EARG; }
+    const int i = b ? shape_slot(b, w, h) : -1;
+    if (!b || i < 0 || !b->needChoice || !out) { set_error("batch_read_choices: bad arguments (choices exist with refs > 1 or refs1 > 0)"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
     { const int jrc = join_subs(b); if (jrc) return jrc; }
-    const int n = rect ? b->nrtasks[i] : b->ntasks[i];
-    XH_HIP(hipMemcpyAsync(out, rect ? b->rchoice[i] : b->choice[i], (size_t)n * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, b->ctx->stream));
+    XH_HIP(hipMemcpyAsync(out, b->choice[i], (size_t)b->ntasks[i] * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, b->ctx->stream));
     XH_HIP(hipStreamSynchronize(b->ctx->stream));
     return X265HIP_OK;
 }
@@ -665,10 +723,10 @@ extern "C" int x265hip_batch_read_coeffs(x265hip_batch* b, int16_t* coeff, uint3
 }
 extern "C" int x265hip_batch_read_plane(x265hip_batch* b, int which, int frame, void* out)
 {
-    if (!b || which < 0 || which > b->refs || frame < 0 || frame >= b->d.frames || !out) { set_error("batch_read_plane: bad arguments"); return X265HIP_EARG; }
+    if (!b || which < 0 || which > b->nref[0] + b->nref[1] || frame < 0 || frame >= b->d.frames || !out) { set_error("batch_read_plane: bad arguments"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
     { const int jrc = join_subs(b); if (jrc) return jrc; }
-    const pixel* plane = (which ? b->ref[which - 1] : b->cur) + (size_t)frame * b->plane;
+    const pixel* plane = (!which ? b->cur : which <= b->nref[0] ? b->ref[0][which - 1] : b->ref[1][which - 1 - b->nref[0]]) + (size_t)frame * b->plane;
     XH_HIP(hipMemcpyAsync(out, plane, (size_t)b->plane * sizeof(pixel), hipMemcpyDeviceToHost, b->ctx->stream));
     XH_HIP(hipStreamSynchronize(b->ctx->stream));
     return X265HIP_OK;
@@ -676,12 +734,14 @@ extern "C" int x265hip_batch_read_plane(x265hip_batch* b, int which, int frame, 
 extern "C" void* x265hip_batch_device_ptr(x265hip_batch* b, int what)
 {
     if (!b) return nullptr;
-    if (what >= 100 && what < 100 + b->refs) return b->ref[what - 100];
-    if (what >= 200 && what < 200 + b->refs) return b->planes[what - 200];
+    if (what >= 100 && what < 100 + b->nref[0]) return b->ref[0][what - 100];
+    if (what >= 200 && what < 200 + b->nref[0]) return b->planes[0][what - 200];
+    if (what >= 300 && what < 300 + b->nref[1]) return b->ref[1][what - 300];
+    if (what >= 400 && what < 400 + b->nref[1]) return b->planes[1][what - 400];
     switch (what)
     {
-    case 0: return b->cur; case 1: return b->ref[0]; case 2: return b->planes[0]; case 3: return b->coeff; case 4: return b->numSig; case 5: return b->recon;
-    case 10: return b->results[0][3]; case 11: return b->results[0][2]; case 12: return b->results[0][1]; case 13: return b->results[0][0];
+    case 0: return b->cur; case 1: return b->ref[0][0]; case 2: return b->planes[0][0]; case 3: return b->coeff; case 4: return b->numSig; case 5: return b->recon;
+    case 10: return b->res[0][0][3]; case 11: return b->res[0][0][2]; case 12: return b->res[0][0][1]; case 13: return b->res[0][0][0];
     default: return nullptr;
     }
 }

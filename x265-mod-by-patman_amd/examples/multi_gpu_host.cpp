@@ -170,7 +170,7 @@ void run_device(const Api& api, const Options& o, int worker, Ready ready, Go go
                 for (int q = 0; !r && q < o.refs; q++) r = api.batch_upload_plane(b, 1 + q, k, in.data() + (size_t)(2 * k + 1) * pic, o.width);
                 if (r) return r;
             }
-            return 0;
+            return api.ctx_sync(ctx);                       // the copies are asynchronous: `in` must outlive them
         }
         for (int k = 0; k < o.frames; k++)
         {
@@ -181,12 +181,14 @@ void run_device(const Api& api, const Options& o, int worker, Ready ready, Go go
                 std::vector<uint8_t> c, f; make_pair(o.width, o.height, depth, index, c, f);
                 if ((r = api.batch_upload_plane(b, 0, k, c.data(), o.width))) return r;
                 for (int q = 0; q < o.refs; q++) if ((r = api.batch_upload_plane(b, 1 + q, k, f.data(), o.width))) return r;
+                if ((r = api.ctx_sync(ctx))) return r;      // the copies are asynchronous: the pictures must outlive them
             }
             else
             {
                 std::vector<uint16_t> c, f; make_pair(o.width, o.height, depth, index, c, f);
                 if ((r = api.batch_upload_plane(b, 0, k, c.data(), o.width))) return r;
                 for (int q = 0; q < o.refs; q++) if ((r = api.batch_upload_plane(b, 1 + q, k, f.data(), o.width))) return r;
+                if ((r = api.ctx_sync(ctx))) return r;
             }
         }
         return 0;

@@ -11,22 +11,22 @@ LEVELS = (64, 32, 16, 8)
 
 
 class BatchDesc(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes", "refs", "rect", "streams", "bandRows")]
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "frames", "margin", "qp", "merange", "method", "subme", "tuLog2", "recon", "usePlanes", "refs", "rect", "streams", "bandRows", "amp", "refs1")]
 
 
 class HostBatch:
     def __init__(self, lib, depth, width, height, frames, qp=28, merange=57, method=1, subme=2, tu_log2=5, margin=96, recon=False, use_planes=True, refs=1, rect=False,
-                 streams=1, device=0, band_rows=0):
+                 streams=1, device=0, band_rows=0, amp=False, refs1=0):
         self.lib, self.depth = lib, depth
         self.W, self.H, self.F, self.margin = width, height, frames, margin
         self.qp, self.merange, self.method, self.subme, self.tu_log2, self.recon, self.use_planes = qp, merange, method, subme, tu_log2, recon, use_planes
-        self.refs, self.rect, self.streams, self.band_rows = refs, rect, streams, band_rows
+        self.refs, self.rect, self.streams, self.band_rows, self.amp, self.refs1 = refs, rect, streams, band_rows, amp, refs1
         self.stride = width + 2 * margin
         self.plane = self.stride * (height + 2 * margin)
         self.pixel = np.uint8 if depth == 8 else np.uint16
         lib.x265hip_last_error.restype = C.c_char_p
         lib.x265hip_batch_stage_name.restype = C.c_char_p
-        self.desc = BatchDesc(width, height, frames, margin, qp, merange, method, subme, tu_log2, int(recon), int(use_planes), refs, int(rect), streams, band_rows)
+        self.desc = BatchDesc(width, height, frames, margin, qp, merange, method, subme, tu_log2, int(recon), int(use_planes), refs, int(rect), streams, band_rows, int(amp), refs1)
         self.ctx, self.batch = C.c_void_p(), C.c_void_p()
         self._ck(lib.x265hip_ctx_create(device, C.byref(self.ctx)), "ctx_create")
         self._ck(lib.x265hip_batch_create(self.ctx, C.byref(self.desc), C.byref(self.batch)), "batch_create")
@@ -43,6 +43,13 @@ class HostBatch:
                     t = np.zeros(lib.x265hip_batch_rect_task_count(C.byref(self.desc), w, h), ME_TASK)
                     self._ck(lib.x265hip_batch_build_rect_tasks(C.byref(self.desc), w, h, C.c_void_p(t.ctypes.data)), "build_rect_tasks")
                     self.rect_host[(w, h)] = t
+        self.amp_host = {}
+        if amp:
+            for lv in (64, 32, 16):
+                for (w, h) in ((lv, lv // 4), (lv, 3 * lv // 4), (lv // 4, lv), (3 * lv // 4, lv)):
+                    t = np.zeros(lib.x265hip_batch_amp_task_count(C.byref(self.desc), w, h), ME_TASK)
+                    self._ck(lib.x265hip_batch_build_amp_tasks(C.byref(self.desc), w, h, C.c_void_p(t.ctypes.data)), "build_amp_tasks")
+                    self.amp_host[(w, h)] = t
         self.tu_host = np.zeros(lib.x265hip_batch_tu_count(C.byref(self.desc)), TU_TASK)
         self._ck(lib.x265hip_batch_build_tu_tasks(C.byref(self.desc), C.c_void_p(self.tu_host.ctypes.data)), "build_tu_tasks")
         self.stage_names = [lib.x265hip_batch_stage_name(self.batch, i).decode() for i in range(lib.x265hip_batch_stage_count(self.batch))]
@@ -65,9 +72,9 @@ class HostBatch:
         return self.F * self.W * self.H
 
     def upload(self, pairs):
-        """pairs: F tuples (cur_padded, ref0_padded [, ref1_padded ...]) of shape (H + 2 margin, W + 2 margin) with replicated borders; the pictures inside the padding
+        """pairs: F tuples (cur_padded, list-0 references ..., list-1 references ...) of shape (H + 2 margin, W + 2 margin) with replicated borders; the pictures inside the padding
         are handed to x265hip_batch_upload_plane, which pads on the device (extendPicBorder).  The padded host stacks are kept for the CPU baseline."""
-        assert len(pairs) == self.F and all(len(p) == 1 + self.refs for p in pairs)
+        assert len(pairs) == self.F and all(len(p) == 1 + self.refs + self.refs1 for p in pairs)
         m = self.margin
         for f, p in enumerate(pairs):
             for which, a in enumerate(p):
@@ -76,6 +83,7 @@ class HostBatch:
                 self.sync()                                  # `pic` must outlive the asynchronous copy
         self.cur_host = np.concatenate([p[0].reshape(-1) for p in pairs])
         self.refs_host = [np.concatenate([p[1 + r].reshape(-1) for p in pairs]) for r in range(self.refs)]
+        self.refs1_host = [np.concatenate([p[1 + self.refs + r].reshape(-1) for p in pairs]) for r in range(self.refs1)]
         self.ref_host = self.refs_host[0]
 
     def device_plane(self, which, frame):
@@ -114,10 +122,12 @@ class HostBatch:
     def results(self, lv, ref=0):
         return self.shape_results(lv, lv, ref)
 
-    def shape_results(self, w, h, ref=0):
-        n = len(self.tasks_host[w]) if w == h else len(self.rect_host[(w, h)])
-        out = np.zeros(n, ME_RESULT)
-        self._ck(self.lib.x265hip_batch_read_results_ref(self.batch, w, h, ref, C.c_void_p(out.ctypes.data)), "read_results_ref")
+    def shape_tasks(self, w, h):
+        return self.tasks_host[w] if w == h else self.rect_host[(w, h)] if (w, h) in self.rect_host else self.amp_host[(w, h)]
+
+    def shape_results(self, w, h, ref=0, lst=0):
+        out = np.zeros(len(self.shape_tasks(w, h)), ME_RESULT)
+        self._ck(self.lib.x265hip_batch_read_results_list(self.batch, w, h, lst, ref, C.c_void_p(out.ctypes.data)), "read_results_list")
         return out
 
     def rect_results(self, w, h, ref=0):
@@ -125,8 +135,7 @@ class HostBatch:
 
     def choices(self, w, h=None):
         h = w if h is None else h
-        n = len(self.tasks_host[w]) if w == h else len(self.rect_host[(w, h)])
-        out = np.zeros(n, INTER_CHOICE)
+        out = np.zeros(len(self.shape_tasks(w, h)), INTER_CHOICE)
         self._ck(self.lib.x265hip_batch_read_choices(self.batch, w, h, C.c_void_p(out.ctypes.data)), "read_choices")
         return out
 
@@ -151,12 +160,16 @@ class HostBatch:
         nf = self.F if whole_batch else self.sub_batch_pictures()
         px = int(nf * self.W * self.H)
         share = nf / self.F
-        alg = {"me%d" % lv: px * (1 + self.refs) * bpp + int(len(self.tasks_host[lv]) * share) * 16 * self.refs for lv in LEVELS}
+        R = self.refs + self.refs1
+        alg = {"me%d" % lv: px * (1 + R) * bpp + int(len(self.tasks_host[lv]) * share) * 16 * R for lv in LEVELS}
         if self.rect:
             for lv in LEVELS:
-                alg["rect%d" % lv] = 2 * px * (1 + self.refs) * bpp + int(sum(len(self.rect_host[k]) for k in ((lv, lv // 2), (lv // 2, lv))) * share) * 16 * self.refs
+                alg["rect%d" % lv] = 2 * px * (1 + R) * bpp + int(sum(len(self.rect_host[k]) for k in ((lv, lv // 2), (lv // 2, lv))) * share) * 16 * R
+        if self.amp:
+            for lv in (64, 32, 16):
+                alg["amp%d" % lv] = 4 * px * (1 + R) * bpp + int(sum(len(t) for (w, h), t in self.amp_host.items() if max(w, h) == lv) * share) * 16 * R
         alg["tq"] = px * (2 * bpp + 2) + int(len(self.tu_host) * share) * 4 + (px * bpp if self.recon else 0)
         alg = {k: int(v) for k, v in alg.items()}
         if self.use_planes:
-            alg["planes"] = int((self.F if self.band_rows > 0 else nf) * self.plane * bpp * 17 * self.refs)
+            alg["planes"] = int((self.F if self.band_rows > 0 else nf) * self.plane * bpp * 17 * (self.refs + self.refs1))
         return alg
