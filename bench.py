@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--no-preset-exact", action="store_true", help="skip the preset-exact legs (per BASELINE workload the preset's own reference count, from preset slow on the rectangular PUs, from slower on the asymmetric ones, on 8 pictures); reported under \"preset_exact\", not part of value")
     ap.add_argument("--preset-exact-workloads", default="1080p8_medium,2160p10_slow,4320p10_slower", help="which workloads get a preset-exact leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the live end-to-end leg (reference encoder, 1920x1088 medium, CPU producer vs GPU producer of the MEData tables, ~20 s); reported under \"e2e_fps\"")
+    ap.add_argument("--leg", default=None, help="(internal) run ONE auxiliary leg in this process and print its JSON object: tme_producer | preset_exact:<workload> | streams:<headline s per pass>.  "
+                    "The main run starts its GPU-heavy auxiliary legs this way: a fault in one of them then costs that leg, not the line")
     ap.add_argument("--filters", action="store_true", help="also time the in-loop filter chain after reconstruction (deblock, SAO statistics, SAO apply, SSIM, SSD) on 8 coded 1080p pictures; reported under \"filters\", not part of value")
     return ap.parse_args()
 
@@ -216,7 +218,7 @@ def e2e_fps_leg(frames=24, seam_frames=8):
                    "ctus_harvested_by_helper_workers": int(g["adapter_sections"][2])}}
     if both:
         l = runs["la_gpu"]
-        out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "device_launches": l.get("la_launches"), "estimates_left_to_the_cpu": l["la_cpu_estimates"],
+        out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "device_launches": l.get("la_launches"), "finish_batch_calls_taken_whole": l.get("la_batches"), "estimate_batch_calls": l.get("la_batch_calls"), "estimates_left_to_the_cpu": l["la_cpu_estimates"],
                             "ms_per_estimate": round(1e3 * l["la_estimate_seconds"] / max(1, l["la_estimates"]), 3),
                             "ms_per_intra_picture": round(1e3 * l["la_intra_seconds"] / max(1, l["la_intra_pictures"]), 3),
                             "producer_seconds": l["la_producer_seconds"]}
@@ -897,8 +899,72 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def run_leg_child(name, argv_extra=(), timeout=900):
+    """An auxiliary leg in a process of its own (python bench.py --leg NAME + this run's arguments): returns its JSON object, or {"failed": ...} -- the line survives a leg that dies."""
+    import subprocess
+    keep = []
+    skip = False
+    for a in sys.argv[1:]:          # this run's own arguments, minus what belongs to the launcher
+        if skip:
+            skip = False
+            continue
+        if a in ("--gpus", "--leg"):
+            skip = True
+            continue
+        keep.append(a)
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env["X265HIP_LEG_DEVICE"] = os.environ.get("LOCAL_RANK", "0")
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + keep + ["--leg", name] + list(argv_extra), capture_output=True, text=True, env=env, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"failed": "leg %s: no result within %d s" % (name, timeout)}
+    try:
+        if r.returncode == 0:
+            return json.loads(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        pass
+    return {"failed": "leg %s: exit status %d" % (name, r.returncode), "stderr": r.stderr[-400:]}
+
+
+def leg_main(args):
+    """python bench.py --leg NAME: one auxiliary leg, alone in this process"""
+    import x265hip  # noqa: F401
+    import multiprocessing
+    name, _, arg = args.leg.partition(":")
+    dev = int(os.environ.get("X265HIP_LEG_DEVICE", "0"))
+    if name == "tme_producer":
+        import torch
+        torch.cuda.set_device(dev)
+        print(json.dumps(tme_producer_leg(WORKLOADS[args.workload]["depth"])))
+        return
+    if name == "preset_exact":
+        w_ = WORKLOADS[arg]
+        pool = multiprocessing.get_context("fork").Pool(min(PRESET_F, max(1, os.cpu_count() or 1)))
+        pairs = pool.starmap(_make_pair, [(w_["width"], w_["height"], w_["depth"], 5000 + k, PRESETS[arg]["refs"]) for k in range(PRESET_F)])
+        pool.close(); pool.join()
+        import torch
+        torch.cuda.set_device(dev)
+        print(json.dumps(preset_exact_leg(arg, pairs, args, None)))
+        return
+    if name == "streams":
+        wl = WORKLOADS[args.workload]
+        pool = multiprocessing.get_context("fork").Pool(min(args.frames, max(1, os.cpu_count() or 1)))
+        pairs = pool.starmap(_make_pair, [(wl["width"], wl["height"], wl["depth"], sd, args.refs) for sd in range(args.frames)])
+        pool.close(); pool.join()
+        import torch
+        torch.cuda.set_device(dev)
+        lib = x265hip.HipLib(wl["depth"], fill_table=False).lib
+        print(json.dumps(streams_leg(lib, wl["depth"], wl["width"], wl["height"], wl, args, pairs, float(arg))))
+        return
+    raise SystemExit("bench.py --leg: unknown leg %r" % args.leg)
+
+
 def main():
     args = parse()
+    if args.leg:
+        return leg_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started plainly with --gpus N: become the launcher of N ranks (one per GPU), hand their exit status back
         import x265hip  # noqa: F401  (registers the package under an importable name)
@@ -920,24 +986,10 @@ def main():
     import multiprocessing
     # close() + join(), not the context manager: its terminate() sends SIGTERM to the workers, and under rocprofv3 (whose signal handler is inherited by the forked
     # workers) a worker then never exits and the run hangs in wait4 (seen in the r02 counter passes)
-    # (rank 0 also makes the pictures of the preset-exact legs: PRESET_F pictures per workload, each with the preset's references; the headline workload's come out of its own
-    #  batch when that holds enough pictures)
     exact = [w for w in args.preset_exact_workloads.split(",") if w in PRESETS] if (not args.no_preset_exact and int(os.environ.get("RANK", "0")) == 0) else []
-    own = args.workload in exact and args.frames >= PRESET_F
-    jobs = [(W, H, depth, sd, max(args.refs, PRESETS[args.workload]["refs"]) if (own and i < PRESET_F) else args.refs) for i, sd in enumerate(seeds)]
-    where = {}
-    for wname in exact:
-        if wname == args.workload and own:
-            continue
-        w_ = WORKLOADS[wname]
-        where[wname] = (len(jobs), len(jobs) + PRESET_F)
-        jobs += [(w_["width"], w_["height"], w_["depth"], 5000 + k, PRESETS[wname]["refs"]) for k in range(PRESET_F)]
-    pool = multiprocessing.get_context("fork").Pool(min(len(jobs), max(1, (os.cpu_count() or 1) // max(1, args.gpus))))
-    made = pool.starmap(_make_pair, jobs)
+    pool = multiprocessing.get_context("fork").Pool(min(len(seeds), max(1, (os.cpu_count() or 1) // max(1, args.gpus))))
+    pairs = pool.starmap(_make_pair, [(W, H, depth, sd, args.refs) for sd in seeds])
     pool.close(); pool.join()
-    pairs = made[:len(seeds)]
-    exact_pairs = {wname: (pairs[:PRESET_F] if (wname == args.workload and own) else made[where[wname][0]:where[wname][1]]) for wname in exact}
-    del made
     import torch
     import torch.distributed as dist
     import x265hip  # noqa: F401
@@ -1053,20 +1105,24 @@ def main():
                               "traffic_per_step": (sum(v for k, v in traffic_all.items() if k in kms) * args.inner or None) if traffic_all else None, "traffic_source": traffic_src},
             "e2e_fps": None,
         }
+        def leg(name):      # progress on stderr: a leg that takes the process down is then named in the log
+            print("[bench] leg %s" % name, file=sys.stderr, flush=True)
         if not args.no_streams_leg and args.band_rows == 0 and args.frames >= 2:
-            out["streams"] = streams_leg(lib, depth, W, H, wl, args, pairs, dt / args.steps / args.inner)
+            leg("streams")
+            out["streams"] = run_leg_child("streams:%.9f" % (dt / args.steps / args.inner))
         if exact:
             # one object per BASELINE workload: the preset's own search load on PRESET_F pictures (the headline workload's is measured against the headline's time per search)
             out["preset_exact"] = {}
             for wname in exact:
                 per_search = (dt / args.steps / args.inner) / (args.frames * (W // 64) * (H // 64) * 85 * args.refs) if wname == args.workload else None
-                try:
-                    out["preset_exact"][wname] = preset_exact_leg(wname, exact_pairs[wname], args, per_search)
-                except (RuntimeError, MemoryError) as e:
-                    out["preset_exact"][wname] = {"failed": str(e)[:300]}
-                exact_pairs[wname] = None
+                leg("preset_exact " + wname)
+                r_ = run_leg_child("preset_exact:" + wname, timeout=1200)       # (its own process: own pictures, own contexts)
+                if per_search and "ms_per_pass" in r_:
+                    r_["vs_headline_per_searched_pu"] = round((r_["ms_per_pass"] * 1e-3 / r_["searched_pus_per_pass"]) / per_search, 3)
+                out["preset_exact"][wname] = r_
         e2e_path = os.path.join(ROOT, "profiles", "e2e_fps.json")
         if not args.no_e2e:
+            leg("e2e_fps")
             try:
                 out["e2e_fps"] = e2e_fps_leg()
             except Exception as ex:                  # the leg runs an external binary: a failure there must not lose the line
@@ -1082,7 +1138,8 @@ def main():
             except Exception as ex:
                 out["c1_host_fps"] = {"measured": "this run: FAILED", "error": repr(ex)[:300]}
         if not args.no_tme:
-            out["tme_producer"] = tme_producer_leg(depth)
+            leg("tme_producer")
+            out["tme_producer"] = run_leg_child("tme_producer")
         if args.intra:
             out["intra_scan"] = intra_scan_leg(python_pipeline(args, wl, depth, W, H, pairs), depth, max(2, min(args.steps, 10)))
         if args.lookahead:
@@ -1090,6 +1147,7 @@ def main():
         if args.filters:
             out["filters"] = filters_leg(depth, max(2, min(args.steps, 10)))
         if args.cpu_ctus > 0:
+            leg("cpu_baseline")
             out["cpu_baseline"] = cpu_baseline(pipe, depth, args.cpu_ctus)     # rank 0's host cores, after the timed region (the other ranks wait at the barrier below)
             out["cpu_baseline"]["asm"] = asm_probe()
         else:

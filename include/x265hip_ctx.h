@@ -213,7 +213,12 @@ typedef struct x265hip_la_estimate_desc {
     int16_t* lowerMvs[2]; int32_t* lowerMvCosts[2];      /* optional outputs per searched list: Lowres::lowerResMvs / lowerResMvCosts (m_4x4Width * m_4x4Height entries) */
 } x265hip_la_estimate_desc;
 int  x265hip_la_estimate(x265hip_la* la, const x265hip_la_estimate_desc* desc);
-/* x265hip_la_estimate is synchronous for its caller, but estimates that arrive from other threads while a launch is in flight go up TOGETHER as the next launch (up to 16):
+/* n estimates at once -- what CostEstimateGroup::finishBatch holds (slicetype.cpp:4236-4278: up to 512 queued (p0, b, p1) triples): ceil(n / X265HIP_LA_MAX_BATCH) launches, in the
+ * caller's order, synchronous.  Estimates of one call must not depend on each other's searches (an estimate that reuses a list search another one of the SAME call makes belongs in
+ * the next call -- integration/lookahead_adapter.cpp splits a batch into such waves); two estimates that both search the same (b, list, distance) simply both do. */
+#define X265HIP_LA_MAX_BATCH 32
+int  x265hip_la_estimate_batch(x265hip_la* la, const x265hip_la_estimate_desc* descs, int n);
+/* x265hip_la_estimate is synchronous for its caller, but estimates that arrive from other threads while a launch is in flight go up TOGETHER as the next launch (up to X265HIP_LA_MAX_BATCH):
  * the lookahead's batched frame costs (b-adapt 2 with a thread pool) become batches on the device.  launches / estimates so far: */
 int  x265hip_la_batch_stats(const x265hip_la* la, int64_t* launches, int64_t* estimates);
 

@@ -1,7 +1,8 @@
 /*
  * lookahead_adapter.h -- the binding of libx265hip's lookahead producer into the reference encoder.
  *
- * lookahead_adapter.cpp defines LookaheadTLD::lowresIntraEstimate (encoder/slicetype.cpp:755-864) and CostEstimateGroup::estimateFrameCost (:4366-4463): the intra
+ * lookahead_adapter.cpp defines LookaheadTLD::lowresIntraEstimate (encoder/slicetype.cpp:755-864), CostEstimateGroup::estimateFrameCost (:4366-4463) and
+ * CostEstimateGroup::finishBatch (:4271-4278: the queued estimates of a batch go up together as x265hip_la_estimate_batch calls): the intra
  * estimate of a picture entering the lookahead and every (p0, b, p1) frame-cost estimate become one x265hip_la_intra / x265hip_la_estimate call (include/x265hip_ctx.h);
  * slice-type decision, scene cuts, cuTree, VBV look-ahead -- everything that consumes costEst / lowresCosts / lowresMvs / rowSatds / intraMbs -- is the encoder's own code
  * reading the same arrays.  The encoder's bodies stay available under the names lowresIntraEstimate_cpu / estimateFrameCost_cpu (a maintainer renames the two members;
@@ -20,6 +21,7 @@ typedef struct x265hip_la_adapter_stats
 {
     int intraPictures, estimates, cpuEstimates /* fell through to the encoder's own body */, weighted;
     int launches;                              /* device launches the estimates went up in (concurrent callers share one); filled by x265hip_la_adapter_close */
+    int batches, batchCalls;                   /* CostEstimateGroup::finishBatch calls taken whole; x265hip_la_estimate_batch calls they became (waves) */
     double intraSeconds, estimateSeconds;      /* whole calls, harvest and write-back included */
     double producerSeconds;                    /* inside x265hip_la_intra / x265hip_la_estimate */
 } x265hip_la_adapter_stats;

@@ -113,14 +113,14 @@ int main(int argc, char** argv)
     x265hip_tme_adapter_stats s;
     x265hip_tme_adapter_get_stats(&s);
     x265hip_tme_adapter_close();
-    char la[1024] = "";
+    char la[1400] = "";
 #ifdef WITH_LA_ADAPTER
     {
         x265hip_la_adapter_stats ls;
         x265hip_la_adapter_close();
         x265hip_la_adapter_get_stats(&ls);
-        snprintf(la, sizeof(la), "\"lookahead_producer\": \"%s\", \"la_intra_pictures\": %d, \"la_estimates\": %d, \"la_launches\": %d, \"la_cpu_estimates\": %d, \"la_weighted\": %d, \"la_intra_seconds\": %.3f, \"la_estimate_seconds\": %.3f, \"la_producer_seconds\": %.3f, ",
-                 useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.launches, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds);
+        snprintf(la, sizeof(la), "\"lookahead_producer\": \"%s\", \"la_intra_pictures\": %d, \"la_estimates\": %d, \"la_launches\": %d, \"la_batches\": %d, \"la_batch_calls\": %d, \"la_cpu_estimates\": %d, \"la_weighted\": %d, \"la_intra_seconds\": %.3f, \"la_estimate_seconds\": %.3f, \"la_producer_seconds\": %.3f, ",
+                 useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.launches, ls.batches, ls.batchCalls, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds);
         x265hip_ff_adapter_stats fs;
         x265hip_ff_adapter_close();
         x265hip_ff_adapter_get_stats(&fs);

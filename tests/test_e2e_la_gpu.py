@@ -14,13 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def encode(depth, la, tme, tme_gpu, args, out, fade=False):
+def encode(depth, la, tme, tme_gpu, args, out, fade=False, batch=True):
     exe = os.path.join(ROOT, "oracle", "_ref", "x265e2e_%d" % depth)
     if not os.path.exists(exe):
         pytest.skip("no oracle/_ref/x265e2e_%d (built where the reference is present)" % depth)
     env = dict(os.environ, X265LAGPU="1" if la else "0", X265TME="1" if tme else "0", X265TMEGPU="1" if tme_gpu else "0", MALLOC_PERTURB_="85")
     if fade:
         env["X265TME_FADE"] = "1"
+    env["X265LA_BATCH"] = "1" if batch else "0"
     r = subprocess.run([exe, x265hip.lib_path(depth)] + args[:4] + [out] + args[4:], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1]), hashlib.md5(open(out, "rb").read()).hexdigest()
@@ -45,6 +46,26 @@ def test_bitstream_identical_with_gpu_lookahead(depth, args, fade, tmp_path):
     assert 0 < gpu["la_launches"] <= gpu["la_estimates"]
     print("e2e la", depth, args, "estimates %d in %d launches, %.2f ms each (producer %.2f)" % (gpu["la_estimates"], gpu["la_launches"], 1e3 * gpu["la_estimate_seconds"] / gpu["la_estimates"],
                                                                                   1e3 * gpu["la_producer_seconds"] / (gpu["la_estimates"] + gpu["la_intra_pictures"])))
+
+
+@pytest.mark.parametrize("depth,args,fade", [(8, ["320", "192", "20", "medium"], False), (8, ["256", "128", "16", "medium", "weightp=1", "bframes=3"], True),
+                                             (10, ["256", "192", "14", "slow", "rc-lookahead=15"], False)])
+def test_whole_batches_go_up_at_once(depth, args, fade, tmp_path):
+    """CostEstimateGroup::finishBatch bound as a whole (slicetype.cpp:4271-4278: the motion-search batch and the frame-cost batch of b-adapt 2 with a thread pool): the queued
+    (p0, b, p1) triples go up in x265hip_la_estimate_batch calls -- far fewer launches than estimates -- and the bitstream is the one of the CPU lookahead and of the
+    one-estimate-per-call binding (X265LA_BATCH=0)"""
+    # (--threaded-me with the encoder's own CPU producer: it gives the encoder its thread pool, and the lookahead batches its estimates only when it has one -- slicetype.cpp:1140)
+    cpu, h_cpu = encode(depth, False, True, False, args, str(tmp_path / "cpu.hevc"), fade)
+    one, h_one = encode(depth, True, True, False, args, str(tmp_path / "one.hevc"), fade, batch=False)
+    gpu, h_gpu = encode(depth, True, True, False, args, str(tmp_path / "gpu.hevc"), fade)
+    assert h_cpu == h_one == h_gpu and cpu["bytes"] == gpu["bytes"], "bitstreams differ: cpu %s one %s batch %s" % (cpu, one, gpu)
+    assert one["la_batches"] == 0 and one["la_estimates"] > 0
+    assert gpu["la_batches"] > 0 and gpu["la_batch_calls"] >= gpu["la_batches"] and gpu["la_cpu_estimates"] == 0
+    assert gpu["la_launches"] < one["la_launches"], (gpu, one)
+    assert gpu["la_launches"] * 3 <= gpu["la_estimates"], "batches did not merge: %s" % gpu
+    if fade:
+        assert gpu["la_weighted"] > 0
+    print("e2e la batch", depth, args, "estimates %d: %d launches in %d batches (one per call: %d launches)" % (gpu["la_estimates"], gpu["la_launches"], gpu["la_batches"], one["la_launches"]))
 
 
 @pytest.mark.parametrize("depth,args", [(8, ["256", "192", "10", "medium"]), (10, ["192", "128", "8", "slow"])])

@@ -12,7 +12,7 @@
 #include <vector>
 using namespace xh;
 
-namespace { struct Req; constexpr int kLaBatch = 16; }      // estimates per launch at most
+namespace { struct Req; constexpr int kLaBatch = X265HIP_LA_MAX_BATCH; }      // estimates per launch at most
 
 struct x265hip_la
 {
@@ -187,7 +187,7 @@ namespace {
 // batch of estimates costs the device little more than one (the sweep over a picture's block wavefronts is a serial depth that a batch pays once).
 struct Req { const x265hip_la_estimate_desc* d; int rc; bool done; };
 
-int run_batch(x265hip_la* a, Req* const* reqs, int n)
+int run_batch(x265hip_la* a, const x265hip_la_estimate_desc* const* descs, int n)
 {
     std::lock_guard<std::mutex> g(a->mu);
     XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
@@ -198,7 +198,7 @@ int run_batch(x265hip_la* a, Req* const* reqs, int n)
     int rc;
     for (int i = 0; i < n; i++)
     {
-        const x265hip_la_estimate_desc* d = reqs[i]->d;
+        const x265hip_la_estimate_desc* d = descs[i];
         const bool isB = d->key[2] != d->key[1];
         int slot[3] = { -1, -1, -1 };
         const int order[3] = { 1, 0, 2 };      // b first (its intra costs and AQ factors are read), then the references; a picture this batch uses is not evicted for another
@@ -229,10 +229,10 @@ int run_batch(x265hip_la* a, Req* const* reqs, int n)
             }
     }
     // all estimates of a batch sweep the same way (the caller's workers belong to one lookahead)
-    const int rowsPerSlice = reqs[0]->d->rowsPerSlice;
-    const x265hip_la_estimate_desc* d0 = reqs[0]->d;
+    const int rowsPerSlice = descs[0]->rowsPerSlice;
+    const x265hip_la_estimate_desc* d0 = descs[0];
     for (int i = 1; i < n; i++)
-        if (reqs[i]->d->rowsPerSlice != rowsPerSlice || reqs[i]->d->hme != d0->hme || (d0->hme && (memcmp(reqs[i]->d->hmeMethod, d0->hmeMethod, sizeof(d0->hmeMethod)) || memcmp(reqs[i]->d->hmeRange, d0->hmeRange, sizeof(d0->hmeRange)))))
+        if (descs[i]->rowsPerSlice != rowsPerSlice || descs[i]->hme != d0->hme || (d0->hme && (memcmp(descs[i]->hmeMethod, d0->hmeMethod, sizeof(d0->hmeMethod)) || memcmp(descs[i]->hmeRange, d0->hmeRange, sizeof(d0->hmeRange)))))
         { set_error("la_estimate: concurrent estimates with different sweep parameters"); return X265HIP_EARG; }
     x265hip_la_hme H{};
     if (d0->hme)
@@ -246,7 +246,7 @@ int run_batch(x265hip_la* a, Req* const* reqs, int n)
                                                a->costRow, kLaHalf, rowsPerSlice, a->mvs, a->mvCosts, a->lc, a->rows, a->sums, d0->hme ? &H : nullptr))) return rc;
     for (int i = 0; i < n; i++)
     {
-        const x265hip_la_estimate_desc* d = reqs[i]->d;
+        const x265hip_la_estimate_desc* d = descs[i];
         const bool isB = d->key[2] != d->key[1];
         for (int l = 0; l < (isB ? 2 : 1); l++)
             if (tasks[i].doSearch[l])
@@ -281,19 +281,42 @@ extern "C" int x265hip_la_estimate(x265hip_la* a, const x265hip_la_estimate_desc
         if (a->leader) { a->qcv.wait(lk); continue; }
         // become the leader: everything that is waiting now (this request among it, unless more than a batch was ahead of it) goes up as one launch
         a->leader = true;
-        Req* batch[kLaBatch];
+        Req* batch[kLaBatch]; const x265hip_la_estimate_desc* descs[kLaBatch];
         // a launch pins up to three pictures per estimate: never more estimates than the producer has places for (the rest goes up with the next launch)
         const int n = (int)std::min<size_t>(a->queue.size(), (size_t)std::min(kLaBatch, std::max(1, a->maxPics / 3)));
-        for (int i = 0; i < n; i++) batch[i] = a->queue[i];
+        for (int i = 0; i < n; i++) { batch[i] = a->queue[i]; descs[i] = batch[i]->d; }
         a->queue.erase(a->queue.begin(), a->queue.begin() + n);
         lk.unlock();
-        const int rc = run_batch(a, batch, n);
+        const int rc = run_batch(a, descs, n);
         lk.lock();
         for (int i = 0; i < n; i++) { batch[i]->rc = rc; batch[i]->done = true; }      // (an error text belongs to the thread that ran the batch; the code reaches every caller)
         a->leader = false;
         a->qcv.notify_all();
     }
     return r.rc;
+}
+// A whole batch of the caller at once (CostEstimateGroup::finishBatch, slicetype.cpp:4271-4278: up to 512 queued estimates): launches of up to X265HIP_LA_MAX_BATCH estimates
+// (and never more than the producer has picture places for), in the caller's order.  The caller keeps estimates that depend on each other's searches in different calls
+extern "C" int x265hip_la_estimate_batch(x265hip_la* a, const x265hip_la_estimate_desc* descs, int n)
+{
+    if (!a || !descs || n < 0) { set_error("la_estimate_batch: bad arguments"); return X265HIP_EARG; }
+    for (int i = 0; i < n; i++)
+    {
+        const x265hip_la_estimate_desc* d = descs + i;
+        if (!d->lowresCosts || !d->rowSatds || !d->sums || !d->mvs[0] || !d->mvCosts[0] || (d->key[2] != d->key[1] && (!d->mvs[1] || !d->mvCosts[1])))
+        { set_error("la_estimate_batch: estimate %d lacks an output array", i); return X265HIP_EARG; }
+    }
+    const int per = std::min(kLaBatch, std::max(1, a->maxPics / 3));
+    for (int i0 = 0; i0 < n; i0 += per)
+    {
+        const x265hip_la_estimate_desc* p[kLaBatch];
+        const int m = std::min(per, n - i0);
+        for (int i = 0; i < m; i++) p[i] = descs + i0 + i;
+        // (behind the leader of concurrent single estimates, if there is one: the device side is one call at a time -- run_batch takes a->mu)
+        const int rc = run_batch(a, p, m);
+        if (rc) return rc;
+    }
+    return X265HIP_OK;
 }
 extern "C" int x265hip_la_batch_stats(const x265hip_la* a, int64_t* launches, int64_t* estimates)
 {
