@@ -162,9 +162,11 @@ __device__ __forceinline__ void tme_build(const Slice& s, const x265hip_tme_step
 }
 
 // ---- cost: search.cpp:392-416 ----
+// S: the PU's running best (and lastMode, selBits, lambda); P: the state tme_gather / tme_build left for THIS search (predictors, candidates, lowres MV) -- the same object
+// when the searches of a PU run one after the other, the state of another lane group when its references are searched side by side (tme_chain.inc)
 __device__ __forceinline__ void tme_cost(const Slice& s, const x265hip_tme_step& st, int pi, int l, int r, int ctu, const x265hip_me_result& resA, const x265hip_me_result& resB,
                                          const uint16_t* __restrict__ costTable, int costHalf, const float* __restrict__ bitsCentre, int bitsHalf, TmeState& S,
-                                         const uint8_t* __restrict__ qpIndex, int stepIdx, int nSteps, const Lambdas& lambdas)
+                                         const uint8_t* __restrict__ qpIndex, int stepIdx, int nSteps, const Lambdas& lambdas, const TmeState& P)
 {
     const int q = qpIndex ? qpIndex[(int64_t)ctu * nSteps + stepIdx] : 0;
     const uint16_t* costCentre = costTable + (size_t)q * (size_t)(2 * costHalf + 1) + costHalf;
@@ -173,12 +175,12 @@ __device__ __forceinline__ void tme_cost(const Slice& s, const x265hip_tme_step&
     blk_bits(st.part, s.isP != 0, pi, S.lastMode, S.selBits);
     uint32_t bits = (uint32_t)S.selBits[l] + 1u + (uint32_t)(r + (r < s.numRef[l] - 1));
     x265hip_me_result m = resA;
-    bool bLow = S.hasLowres != 0;
-    int lastMvp[2] = { S.mvpA[0], S.mvpA[1] };
-    if (S.ranB)
+    bool bLow = P.hasLowres != 0;
+    int lastMvp[2] = { P.mvpA[0], P.mvpA[1] };
+    if (P.ranB)
     {
         bLow = false;
-        lastMvp[0] = S.lowres[0]; lastMvp[1] = S.lowres[1];
+        lastMvp[0] = P.lowres[0]; lastMvp[1] = P.lowres[1];
         const x265hip_me_result mb = resB;
         if (mb.cost < m.cost) { m = mb; bLow = true; }
     }
@@ -187,16 +189,16 @@ __device__ __forceinline__ void tme_cost(const Slice& s, const x265hip_tme_step&
     const int dx = min(max(outx - lastMvp[0], -costHalf), costHalf), dy = min(max(outy - lastMvp[1], -costHalf), costHalf);
     const uint32_t mvCost = (uint16_t)(costCentre[dx] + costCentre[dy]);               // m_me.mvcost(outmv): against the LAST predictor the ME object was given (:393)
     uint32_t cost = (uint32_t)(m.cost - (int)mvCost) + getcost(lambda, bits);
-    int idx = S.mvpIdx;
+    int idx = P.mvpIdx;
     if (bLow)
     {   // updateMVP(mvp, outmv, bits, cost, mvp_lowres) (:395-396, 4961-4967)
-        const int diff = (int)bits_of(bitsCentre, bitsHalf, outx, outy, S.mvpA[0], S.mvpA[1]) - (int)bits_of(bitsCentre, bitsHalf, outx, outy, S.lowres[0], S.lowres[1]);
+        const int diff = (int)bits_of(bitsCentre, bitsHalf, outx, outy, P.mvpA[0], P.mvpA[1]) - (int)bits_of(bitsCentre, bitsHalf, outx, outy, P.lowres[0], P.lowres[1]);
         const uint32_t orig = bits;
         bits = orig + diff; cost = (cost - getcost(lambda, orig)) + getcost(lambda, bits);
     }
     {   // checkBestMVP (:398, 4947-4958)
         const int o = !idx;
-        const int diff = (int)bits_of(bitsCentre, bitsHalf, outx, outy, S.amvp[o][0], S.amvp[o][1]) - (int)bits_of(bitsCentre, bitsHalf, outx, outy, S.amvp[idx][0], S.amvp[idx][1]);
+        const int diff = (int)bits_of(bitsCentre, bitsHalf, outx, outy, P.amvp[o][0], P.amvp[o][1]) - (int)bits_of(bitsCentre, bitsHalf, outx, outy, P.amvp[idx][0], P.amvp[idx][1]);
         if (diff < 0)
         {
             const uint32_t orig = bits;
@@ -206,8 +208,15 @@ __device__ __forceinline__ void tme_cost(const Slice& s, const x265hip_tme_step&
     if (cost < S.bestCost[l])
     {
         S.bestCost[l] = cost; S.bestBits[l] = bits; S.bestMvCost[l] = mvCost; S.bestRef[l] = r;
-        S.bestMv[l][0] = outx; S.bestMv[l][1] = outy; S.bestMvp[l][0] = S.amvp[idx][0]; S.bestMvp[l][1] = S.amvp[idx][1];
+        S.bestMv[l][0] = outx; S.bestMv[l][1] = outy; S.bestMvp[l][0] = P.amvp[idx][0]; S.bestMvp[l][1] = P.amvp[idx][1];
     }
+}
+
+__device__ __forceinline__ void tme_cost(const Slice& s, const x265hip_tme_step& st, int pi, int l, int r, int ctu, const x265hip_me_result& resA, const x265hip_me_result& resB,
+                                         const uint16_t* __restrict__ costTable, int costHalf, const float* __restrict__ bitsCentre, int bitsHalf, TmeState& S,
+                                         const uint8_t* __restrict__ qpIndex, int stepIdx, int nSteps, const Lambdas& lambdas)
+{
+    tme_cost(s, st, pi, l, r, ctu, resA, resB, costTable, costHalf, bitsCentre, bitsHalf, S, qpIndex, stepIdx, nSteps, lambdas, S);
 }
 
 // ---- the bidirectional candidate's tasks (search.cpp:418-450) ----
