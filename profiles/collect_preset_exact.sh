@@ -9,7 +9,7 @@ for w in 1080p8_medium 2160p10_slow 4320p10_slower; do
   tail -1 $out/pe_$w.log
 done
 python - $out $P "$tag, code $(cat profiles/.commit 2>/dev/null || echo unknown)" <<'PY'
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 out, P, src = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 res = {}
 for w in ("1080p8_medium", "2160p10_slow", "4320p10_slower"):
@@ -18,7 +18,7 @@ for w in ("1080p8_medium", "2160p10_slow", "4320p10_slower"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == "SQ_INSTS_VALU":
                 v = float(r["Counter_Value"]); tot += v; n += 1
-                k = r["Kernel_Name"].split("(")[0][:60]; per[k] = per.get(k, 0.0) + v
+                k = re.sub(r"\(anonymous namespace\)::|^void ", "", r["Kernel_Name"]).split("(")[0][:70]; per[k] = per.get(k, 0.0) + v
     if n:
         top = sorted(per.items(), key=lambda kv: -kv[1])[:6]
         res[w] = {"valu_per_pass": int(tot / P), "pictures": 8, "dispatches_per_pass": n // P, "source": "rocprofv3 --pmc SQ_INSTS_VALU over profiles/preset_exact_run.py %s %d (%s)" % (w, P, src),

@@ -7,6 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import x265hip  # noqa: E402,F401  (registers the package under an importable name: the pool workers import it)
 import bench  # noqa: E402
 
 
