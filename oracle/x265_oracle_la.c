@@ -210,8 +210,9 @@ static int lowres_umh(const la_t* m, mv_t mvmin, mv_t mvmax, mv_t pmv /* full-pe
 
 /* motionEstimate for a lowres reference: no candidates, subme 1 (slicetype.cpp:4483-4486 setSourcePU); the hexagon search, or -- an --hme level whose
  * hmeSearchMethod says so (motion.cpp:1013) -- the uneven multi-hexagon search in front of it */
-static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, int umh, mv_t* out)
+static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, int method, mv_t* out)
 {
+    const int umh = method == XO_ME_UMH;
     m->mvp = qmvp;
     const mv_t qmin = { mvmin.x * 4, mvmin.y * 4 }, qmax = { mvmax.x * 4, mvmax.y * 4 };
     mv_t pmv = { qmvp.x < qmin.x ? qmin.x : qmvp.x > qmax.x ? qmax.x : qmvp.x, qmvp.y < qmin.y ? qmin.y : qmvp.y > qmax.y ? qmax.y : qmvp.y };
@@ -226,6 +227,43 @@ static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, in
         if (cost < bcost) { bcost = cost; bmv.x = 0; int t = 0 < mvmax.y ? 0 : mvmax.y; bmv.y = t > mvmin.y ? t : mvmin.y; }
     }
     if (bcost == 0) { out->x = bmv.x * 4; out->y = bmv.y * 4; return mvcost(m, out->x, out->y); }
+    if (method == XO_ME_DIA)
+    {   /* diamond search, radius 1 (motion.cpp:1016-1039): the four neighbours costed together (sad_x4: whether or not their row is inside the window), the row test only
+           decides which may win; the step is decoded from the low bits of the packed cost */
+        static const mv_t d4[4] = { {0,-1}, {0,1}, {-1,0}, {1,0} };
+        int i = merange;
+        bcost <<= 4;
+        do
+        {
+            int c4[4];
+            for (int k = 0; k < 4; k++) c4[k] = sad_at(m, bmv.x + d4[k].x, bmv.y + d4[k].y) + mvcost(m, (bmv.x + d4[k].x) * 4, (bmv.y + d4[k].y) * 4);
+            if ((bmv.y - 1 >= mvmin.y) & (bmv.y - 1 <= mvmax.y)) { if ((c4[0] << 4) + 1 < bcost) bcost = (c4[0] << 4) + 1; }
+            if ((bmv.y + 1 >= mvmin.y) & (bmv.y + 1 <= mvmax.y)) { if ((c4[1] << 4) + 3 < bcost) bcost = (c4[1] << 4) + 3; }
+            if ((c4[2] << 4) + 4 < bcost) bcost = (c4[2] << 4) + 4;
+            if ((c4[3] << 4) + 12 < bcost) bcost = (c4[3] << 4) + 12;
+            if (!(bcost & 15)) break;
+            bmv.x -= (int32_t)((uint32_t)bcost << 28) >> 30;
+            bmv.y -= (int32_t)((uint32_t)bcost << 30) >> 30;
+            bcost &= ~15;
+        }
+        while (--i && bmv.x >= mvmin.x && bmv.x <= mvmax.x && bmv.y >= mvmin.y && bmv.y <= mvmax.y);
+        bcost >>= 4;
+        goto refine;
+    }
+    if (method == XO_ME_FULL)
+    {   /* exhaustive search (motion.cpp:1593-1632).  For an --hme reference (ReferencePlanes::isHMELowres, set for every Lowres of an --hme encode: lowres.cpp:96) the
+           window is cut to +-merange around the ZERO vector, not around the predictor (:1598-1605); rows of four placements at a time, then the rest one by one: the order
+           of the strict `<` is plain raster either way */
+        const int r = merange < 0 ? -merange : merange;
+        const int y0 = mvmin.y > -r ? mvmin.y : -r, x0 = mvmin.x > -r ? mvmin.x : -r, y1 = mvmax.y < r ? mvmax.y : r, x1 = mvmax.x < r ? mvmax.x : r;
+        for (int ty = y0; ty <= y1; ty++)
+            for (int tx = x0; tx <= x1; tx++)
+            {
+                const int cost = sad_at(m, tx, ty) + mvcost(m, tx * 4, ty * 4);
+                if (cost < bcost) { bcost = cost; bmv.x = tx; bmv.y = ty; }
+            }
+        goto refine;
+    }
     {
         const mv_t fpmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };                              /* motion.cpp:1005 */
         if (umh && !lowres_umh(m, mvmin, mvmax, fpmv, merange, &bmv, &bcost)) goto refine;
@@ -319,7 +357,7 @@ refine:
 
 /* the motion search of one list of one block (slicetype.cpp:4504-4573): reverse-order MV prediction, the candidate with the lowest SATD as MVP, motionEstimate, the
  * zero-MV skip rule of B estimates.  fencMV / fencCost address the block inside the list's arrays (widthInCU entries per row); extra = the fifth candidate or NULL. */
-static void list_search(la_t* me, int cuX, int wcu, int lastRow, int bBidir, mv_t mvmin, mv_t mvmax, const mv_t* extra, int merange, int umh,
+static void list_search(la_t* me, int cuX, int wcu, int lastRow, int bBidir, mv_t mvmin, mv_t mvmax, const mv_t* extra, int merange, int method,
                         int32_t* fencMV, int32_t* fencCost)
 {
     mv_t mvc[5], mvp = { 0, 0 }; int numc = 0, skipCost = INT_MAX;
@@ -344,7 +382,7 @@ static void list_search(la_t* me, int cuX, int wcu, int lastRow, int bBidir, mv_
         }
     }
     mv_t out;
-    *fencCost = lowres_me(me, mvmin, mvmax, mvp, merange, umh, &out);
+    *fencCost = lowres_me(me, mvmin, mvmax, mvp, merange, method, &out);
     fencMV[0] = out.x; fencMV[1] = out.y;
     if (skipCost < 64 && skipCost < *fencCost && bBidir) { *fencCost = skipCost; fencMV[0] = 0; fencMV[1] = 0; }
 }
@@ -380,7 +418,7 @@ void xo_lowres_frame_cost_hme(const xo_pixel* fencPlane0, const xo_pixel* const*
                     if (!doSearch[i]) continue;
                     for (int k = 0; k < 4; k++) me.plane[k] = refs4[i][k] + pel;
                     me.zero = (i ? ref1 : ref0)[0] + pel; me.zeroStride = stride;
-                    list_search(&me, cuX, hme->wcu, cuY == hme->hcu - 1, bBidir, mvmin, mvmax, NULL, hme->range[0], hme->method[0] == XO_ME_UMH,
+                    list_search(&me, cuX, hme->wcu, cuY == hme->hcu - 1, bBidir, mvmin, mvmax, NULL, hme->range[0], hme->method[0],
                                 &hme->mvs[i][2 * cuXY], &hme->mvCosts[i][cuXY]);
                 }
             }
@@ -416,7 +454,7 @@ void xo_lowres_frame_cost_hme(const xo_pixel* fencPlane0, const xo_pixel* const*
                 mv_t extra; int haveExtra = 0;
                 if (hme && hme->mvCosts[i][cuXY_4x4] > 0)                                        /* :4532-4535: twice the quarter-resolution MV */
                 { extra.x = hme->mvs[i][2 * cuXY_4x4] * 2; extra.y = hme->mvs[i][2 * cuXY_4x4 + 1] * 2; haveExtra = 1; }
-                list_search(&me, cuX, wcu, lastRow, bBidir, mvmin, mvmax, haveExtra ? &extra : NULL, merange, hme && hme->method[1] == XO_ME_UMH, fencMV, fencCost);
+                list_search(&me, cuX, wcu, lastRow, bBidir, mvmin, mvmax, haveExtra ? &extra : NULL, merange, hme ? hme->method[1] : XO_ME_HEX, fencMV, fencCost);
                 if (*fencCost < bcost) { bcost = *fencCost; listused = i + 1; }
             }
             if (bBidir)

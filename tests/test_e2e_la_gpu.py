@@ -81,7 +81,8 @@ def test_both_seams_together(depth, args, tmp_path):
 @pytest.mark.parametrize("depth,args", [(8, ["960", "544", "6", "superfast", "hme=1"]),                                   # hme-search hex,umh,umh; hme-range 16,32,48
                                         (8, ["960", "544", "6", "faster", "hme=1", "hme-search=umh,hex,hex", "hme-range=24,24,32", "bframes=3", "b-adapt=2"]),
                                         (10, ["960", "544", "5", "superfast", "hme=1", "hme-search=hex"]),
-                                        (8, ["960", "544", "8", "fast", "hme=1", "weightp=1", "bframes=2"])])       # with a fade: list 0 is searched in the weighted copy on the half-resolution level only
+                                        (8, ["960", "544", "8", "fast", "hme=1", "weightp=1", "bframes=2"]),
+                                        (8, ["960", "544", "5", "superfast", "hme=1", "hme-search=dia,full,hex", "hme-range=16,6,32"])])     # diamond / exhaustive levels       # with a fade: list 0 is searched in the weighted copy on the half-resolution level only
 def test_bitstream_identical_with_gpu_hme_lookahead(depth, args, tmp_path):
     """--hme: the quarter-resolution sweep runs on the GPU too (x265hip_la_enable_hme + x265hip_la_estimate_desc.hme); Lowres::lowerResMvs / lowerResMvCosts come back"""
     fade = "weightp=1" in args

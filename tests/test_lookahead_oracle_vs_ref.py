@@ -175,13 +175,16 @@ def test_lookahead_cost_with_slices_matches_reference(depth, size, rows, aq):
             assert o["intraMbs"] == rt["intraMbs"]
 
 
-# --hme (slicetype.cpp:4430-4439, 4483-4575): (method of the quarter-resolution level, method of the half-resolution level, their ranges); 1 = hexagon, 2 = uneven multi-hexagon
+# --hme (slicetype.cpp:4430-4439, 4483-4575): (method of the quarter-resolution level, method of the half-resolution level, their ranges); 0 = diamond, 1 = hexagon, 2 = uneven multi-hexagon, 5 = exhaustive
 HME_TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3, 0), (0, 3, 3, 0), (0, 1, 3, 0)]
 
 
 @pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("size,aq,shift,hme", [((192, 144), 0, (3, 2), (1, 2, 16, 32)), ((208, 120), 1, (-6, 4), (2, 2, 16, 32)), ((320, 176), 1, (12, -8), (1, 1, 8, 12)),
-                                               ((136, 72), 0, (-5, 9), (2, 1, 24, 48)), ((64, 48), 1, (1, 0), (1, 2, 16, 32))])
+                                               ((136, 72), 0, (-5, 9), (2, 1, 24, 48)), ((64, 48), 1, (1, 0), (1, 2, 16, 32)),
+                                               # diamond (0) and exhaustive (5) levels: the exhaustive search of an --hme reference is cut to +-range around the ZERO vector (motion.cpp:1598-1605)
+                                               ((192, 144), 1, (3, -2), (0, 5, 16, 6)), ((208, 120), 0, (-6, 4), (5, 0, 5, 32)), ((136, 72), 1, (2, 3), (0, 0, 16, 32)),
+                                               ((320, 176), 0, (9, -4), (5, 2, 4, 24)), ((64, 48), 1, (1, 0), (1, 5, 16, 3))])
 def test_hme_lookahead_cost_matches_reference(depth, size, aq, shift, hme):
     if not la_available(depth):
         pytest.skip("no reference lookahead binary")

@@ -309,8 +309,9 @@ __device__ __forceinline__ bool lowres_umh(Blk& c, int px, int py, int merange, 
 
 // MotionEstimate::motionEstimate for a lowres reference (no candidates, subme 1; the hexagon search, or -- with --hme -- the level's method: hexagon or uneven
 // multi-hexagon, motion.cpp:1013): returns the cost, MV in (ox, oy)
-__device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int mxy, int mvpx, int mvpy, int& ox, int& oy, int merange = LA_MERANGE, bool umh = false)
+__device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int mxy, int mvpx, int mvpy, int& ox, int& oy, int merange = LA_MERANGE, int method = X265HIP_ME_HEX)
 {
+    const bool umh = method == X265HIP_ME_UMH;
     c.mvpx = mvpx; c.mvpy = mvpy;
     const int qmnx = mnx * 4, qmny = mny * 4, qmxx = mxx * 4, qmxy = mxy * 4;
     const int pmx = min(max(mvpx, qmnx), qmxx), pmy = min(max(mvpy, qmny), qmxy);
@@ -330,6 +331,50 @@ __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int 
     if (bcost == 0) { ox = bx * 4; oy = by * 4; return mvcost(c, ox, oy); }
     auto inY = [&](int y) { return (y >= mny) & (y <= mxy); };
     bool hexToo = true;
+    if (method == X265HIP_ME_DIA)
+    {   // diamond search, radius 1 (motion.cpp:1016-1039): the four neighbours costed together; the row test decides which may win; the step sits in the low bits of the cost
+        int i = merange;
+        bcost <<= 4;
+        do
+        {
+            const int X[4] = { bx * 4, bx * 4, (bx - 1) * 4, (bx + 1) * 4 }, Y[4] = { (by - 1) * 4, (by + 1) * 4, by * 4, by * 4 };
+            int C[4];
+            eval<4, false>(c, X, Y, C);
+#pragma unroll
+            for (int k = 0; k < 4; k++) C[k] += mvcost(c, X[k], Y[k]);
+            if (inY(by - 1)) bcost = min(bcost, (C[0] << 4) + 1);
+            if (inY(by + 1)) bcost = min(bcost, (C[1] << 4) + 3);
+            bcost = min(bcost, (C[2] << 4) + 4);
+            bcost = min(bcost, (C[3] << 4) + 12);
+            if (!(bcost & 15)) break;
+            bx -= (int32_t)((uint32_t)bcost << 28) >> 30;
+            by -= (int32_t)((uint32_t)bcost << 30) >> 30;
+            bcost &= ~15;
+        }
+        while (--i && bx >= mnx && bx <= mxx && by >= mny && by <= mxy);
+        bcost >>= 4;
+        hexToo = false;
+    }
+    else if (method == X265HIP_ME_FULL)
+    {   // exhaustive search of an --hme reference (motion.cpp:1593-1632): the window cut to +-merange around the ZERO vector (:1598-1605), raster order, strict `<`
+        const int r = merange < 0 ? -merange : merange;
+        const int y0 = max(mny, -r), x0 = max(mnx, -r), y1 = min(mxy, r), x1 = min(mxx, r);
+        for (int ty = y0; ty <= y1; ty++)
+            for (int tx = x0; tx <= x1; tx += 4)
+            {
+                int X[4], Y[4], C[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { X[k] = min(tx + k, x1) * 4; Y[k] = ty * 4; }
+                eval<4, false>(c, X, Y, C);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int cost = C[k] + mvcost(c, X[k], Y[k]);
+                    if (tx + k <= x1 && cost < bcost) { bcost = cost; bx = tx + k; by = ty; }
+                }
+            }
+        hexToo = false;
+    }
     if (umh) hexToo = lowres_umh(c, (pmx + 2) >> 2, (pmy + 2) >> 2, merange, mnx, mny, mxx, mxy, bx, by, bcost);
     if (hexToo)
     {
@@ -472,7 +517,7 @@ __device__ __forceinline__ bool la_task_ok(const x265hip_la_task* tp, int nFrame
 // level-0 MV of the block above it as a fifth predictor candidate.  hme5Mvs == NULL: no such candidate (no HME, or level 0 itself).  gz.lowres != NULL on level 0 only: the
 // half-resolution pictures, for the zero-MV check (Blk::zbase).
 __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip_la_task* __restrict__ tasks, int nFrames, const uint16_t* __restrict__ costCentre, int costR, int rowsPerSlice,
-                                                         uint32_t* mvs, int32_t* mvCosts, int merange, int umh, int useWeighted,
+                                                         uint32_t* mvs, int32_t* mvCosts, int merange, int umh /* the level's search method (X265HIP_ME_*) */, int useWeighted,
                                                          const uint32_t* __restrict__ hme5Mvs, const int32_t* __restrict__ hme5Costs, int hme5N, LaGeom gz)
 {
     const x265hip_la_task* tp = tasks + (blockIdx.x >> 1);
@@ -566,7 +611,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
                 }
             }
             int ox, oy;
-            int fencCost = lowres_me(c, mnx, mny, mxx, mxy, mvpx, mvpy, ox, oy, merange, umh != 0);
+            int fencCost = lowres_me(c, mnx, mny, mxx, mxy, mvpx, mvpy, ox, oy, merange, umh);
             if (skipCost < 64 && skipCost < fencCost && bidir) { fencCost = skipCost; ox = 0; oy = 0; }
             if (lane == 0)
             {
@@ -931,8 +976,8 @@ extern "C" int x265hip_lookahead_cost_batch_hme(void* stream, const void* lowres
         if (bad_geom(hme->lowerRes, hme->planeElems, hme->stride, hme->origin, hme->widthInCU, hme->heightInCU) || !hme->mvs || !hme->mvCosts || ((uintptr_t)hme->mvs & 3))
         { set_error("lookahead_cost_batch_hme: bad quarter-resolution arguments"); return X265HIP_EARG; }
         for (int l = 0; l < 2; l++)
-            if ((hme->method[l] != X265HIP_ME_HEX && hme->method[l] != X265HIP_ME_UMH) || hme->range[l] < 1 || hme->range[l] > 64)
-            { set_error("lookahead_cost_batch_hme: level %d: hexagon or uneven multi-hexagon search, range 1..64", l); return X265HIP_EARG; }
+            if ((hme->method[l] != X265HIP_ME_DIA && hme->method[l] != X265HIP_ME_HEX && hme->method[l] != X265HIP_ME_UMH && hme->method[l] != X265HIP_ME_FULL) || hme->range[l] < 1 || hme->range[l] > 64)
+            { set_error("lookahead_cost_batch_hme: level %d: diamond, hexagon, uneven multi-hexagon or exhaustive search, range 1..64", l); return X265HIP_EARG; }
         if (rowsPerSlice > 0 && rowsPerSlice < heightInCU) { set_error("lookahead_cost_batch_hme: the cooperative sweep is not offered with HME"); return X265HIP_EARG; }
         if (((int64_t)nFrames) * 4 * hme->planeElems >= ((int64_t)1 << 31)) { set_error("lookahead_cost_batch_hme: quarter-resolution buffer beyond 2^31 elements"); return X265HIP_EARG; }
     }
@@ -970,14 +1015,14 @@ extern "C" int x265hip_lookahead_cost_batch_hme(void* stream, const void* lowres
         const LaGeom g0 = { (const pixel*)hme->lowerRes, hme->planeElems, hme->stride, hme->origin, hme->widthInCU, hme->heightInCU };
         const int widest0 = min(hme->heightInCU, (hme->widthInCU + 1) / 2), threads0 = min(1024, max(64, (widest0 * 8 + 63) / 64 * 64));
         hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, 1), dim3(threads0), lds, st, g0, tasks, nFrames, costRow + costHalfRange, costR, hme->heightInCU, (uint32_t*)hme->mvs, hme->mvCosts,
-                           hme->range[0], hme->method[0] == X265HIP_ME_UMH, 0, (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, g);
+                           hme->range[0], hme->method[0], 0, (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, g);
         XH_LAUNCH_CHECK();
         hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts,
-                           hme->range[1], hme->method[1] == X265HIP_ME_UMH, 1, (const uint32_t*)hme->mvs, (const int32_t*)hme->mvCosts, hme->widthInCU * hme->heightInCU, LaGeom{});
+                           hme->range[1], hme->method[1], 1, (const uint32_t*)hme->mvs, (const int32_t*)hme->mvCosts, hme->widthInCU * hme->heightInCU, LaGeom{});
     }
     else
         hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts,
-                           LA_MERANGE, 0, 1, (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, LaGeom{});
+                           LA_MERANGE, X265HIP_ME_HEX, 1, (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, LaGeom{});
     XH_LAUNCH_CHECK();
     hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, nFrames, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
