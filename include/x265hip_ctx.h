@@ -209,7 +209,7 @@ typedef struct x265hip_la_estimate_desc {
     /* --hme (after x265hip_la_enable_hme): the quarter-resolution sweep runs first and seeds the half-resolution one (x265hip_lookahead_cost_batch_hme) */
     int hme;                         /* != 0: param->bEnableHME                                                                                       */
     const void* lowerPlanes[3];      /* Lowres::lowerResBuffer[0] of p0, b, p1 (uploaded once per picture)                                            */
-    int hmeMethod[2], hmeRange[2];   /* param->hmeSearchMethod[0..1] (X265HIP_ME_DIA / _HEX / _UMH / _FULL), param->hmeRange[0..1]                  */
+    int hmeMethod[2], hmeRange[2];   /* param->hmeSearchMethod[0..1] (X265HIP_ME_DIA / _HEX / _UMH / _STAR / _FULL), param->hmeRange[0..1]                  */
     int16_t* lowerMvs[2]; int32_t* lowerMvCosts[2];      /* optional outputs per searched list: Lowres::lowerResMvs / lowerResMvCosts (m_4x4Width * m_4x4Height entries) */
 } x265hip_la_estimate_desc;
 int  x265hip_la_estimate(x265hip_la* la, const x265hip_la_estimate_desc* desc);

@@ -357,8 +357,11 @@ int x265hip_lookahead_cost_batch(void* stream, const void* lowres, int64_t plane
 /* --hme (param->bEnableHME, slicetype.cpp:4430-4437, 4483-4575): the sweep runs first on the QUARTER-resolution pictures (Lowres::lowerResPlane[0..3], four planes per
  * picture at the same picture indices as the lowres buffer; blocks of 8x8 on the Lookahead::m_4x4Width x m_4x4Height grid) with hmeRange[0] / hmeSearchMethod[0] into its own
  * MV / cost slots (mvs / mvCosts below: the device form of Lowres::lowerResMvs / lowerResMvCosts, same slot numbers as the call's mvSlot), then on the half-resolution pictures
- * with hmeRange[1] / hmeSearchMethod[1], where twice the quarter-resolution MV of the block above a block joins its predictor candidates.  Methods: X265HIP_ME_HEX or
- * X265HIP_ME_UMH (the reference's default is hex, umh).  The serial sweep only (rowsPerSlice 0). */
+ * with hmeRange[1] / hmeSearchMethod[1], where twice the quarter-resolution MV of the block above a block joins its predictor candidates.  Methods: X265HIP_ME_DIA, _HEX, _UMH, _STAR
+ * or _FULL (the reference's default is hex, umh; an exhaustive level is cut to +-range around the zero vector, motion.cpp:1598-1605; a star level's raster covers the picture
+ * and costs one placement in four at the doubled vector, :1392 -- costHalfRange >= 12 * the larger picture side + 192 then; a sea level does not exist: the reference's
+ * lookahead has no integral planes and dies there).  The serial sweep only (rowsPerSlice 0): the reference's cooperative slices read each other's quarter-resolution results
+ * while they are being written (slicetype.cpp:4332-4358, 4532). */
 typedef struct x265hip_la_hme {
     const void* lowerRes; int64_t planeElems; intptr_t stride; int64_t origin; int widthInCU, heightInCU;
     int method[2], range[2];

@@ -72,11 +72,12 @@ x265hip_la* producer(const Lowres& f, int widthInCU, int heightInCU)
     return g_la;
 }
 /* --hme: the quarter-resolution level on the producer too (Lookahead::m_4x4Width x m_4x4Height blocks of Lowres::lowerResPlane, rows lumaStride / 2 apart, lowres.cpp:170-188).
-   Diamond, hexagon, uneven multi-hexagon and exhaustive levels are offered (the default is --hme-search hex,umh,umh); a star or sea level keeps the encoder's own estimate. */
+   Diamond, hexagon, uneven multi-hexagon, star and exhaustive levels are offered (the default is --hme-search hex,umh,umh).  A sea level keeps the encoder's own estimate:
+   the lookahead's MotionEstimate has no integral planes (MotionEstimate::integral[] stays NULL, motion.cpp:115, 1509-1541), the reference itself cannot run it. */
 bool hme_ready(x265hip_la* la, const Lowres& f, const x265_param& p, int w4, int h4)
 {
     for (int l = 0; l < 2; l++)
-        if ((p.hmeSearchMethod[l] != X265_DIA_SEARCH && p.hmeSearchMethod[l] != X265_HEX_SEARCH && p.hmeSearchMethod[l] != X265_UMH_SEARCH && p.hmeSearchMethod[l] != X265_FULL_SEARCH) ||
+        if ((p.hmeSearchMethod[l] != X265_DIA_SEARCH && p.hmeSearchMethod[l] != X265_HEX_SEARCH && p.hmeSearchMethod[l] != X265_UMH_SEARCH && p.hmeSearchMethod[l] != X265_STAR_SEARCH && p.hmeSearchMethod[l] != X265_FULL_SEARCH) ||
             p.hmeRange[l] < 1 || p.hmeRange[l] > 64) return false;
     std::lock_guard<std::mutex> guard(g_lock);
     if (!g_hme)

@@ -208,6 +208,151 @@ static int lowres_umh(const la_t* m, mv_t mvmin, mv_t mvmax, mv_t pmv /* full-pe
     return hexToo;
 }
 
+/* X265_STAR_SEARCH (motion.cpp:1328-1436) with StarPatternSearch (:387-629) on an 8x8 lowres block: the point order, the strict `<`, the per-point window tests of the
+ * guarded form (the x4 form visits the same points in the same order), the rounds counter and the raster's fourth mv cost taken at tmv << 3 (:1392) follow
+ * x265_oracle_me.c's restatement of the same code; what differs is where the pixels come from (the level's own full-pel plane: `hme ? fpelLowerResPlane : fpelPlane`,
+ * :400-401, 940-941). */
+typedef struct { mv_t bmv; int bcost, bPointNr, bDistance; } la_star_t;
+long xo_la_star_rasters;       /* how many blocks went through the raster refinement (the tests ask that their clips reach it) */
+#define PT_DIST(mx_, my_, point, dist) do { const int c_ = sad_at(m, (mx_), (my_)) + mvcost(m, (mx_) * 4, (my_) * 4); \
+    if (c_ < s->bcost) { s->bcost = c_; s->bmv.x = (mx_); s->bmv.y = (my_); s->bPointNr = (point); s->bDistance = (dist); } } while (0)
+static void lowres_star_pattern(const la_t* m, mv_t mvmin, mv_t mvmax, la_star_t* s, int earlyExitIters, int merange)
+{
+    const mv_t omv = s->bmv;
+    int saved = s->bcost, rounds = 0;
+    {
+        const int top = omv.y - 1, bottom = omv.y + 1, left = omv.x - 1, right = omv.x + 1;
+        if (top >= mvmin.y) PT_DIST(omv.x, top, 2, 1);
+        if (left >= mvmin.x) PT_DIST(left, omv.y, 4, 1);
+        if (right <= mvmax.x) PT_DIST(right, omv.y, 5, 1);
+        if (bottom <= mvmax.y) PT_DIST(omv.x, bottom, 7, 1);
+        if (s->bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 2; dist <= 8; dist <<= 1)
+    {
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        const int top2 = omv.y - (dist >> 1), bottom2 = omv.y + (dist >> 1), left2 = omv.x - (dist >> 1), right2 = omv.x + (dist >> 1);
+        saved = s->bcost;
+        if (top >= mvmin.y && left >= mvmin.x && right <= mvmax.x && bottom <= mvmax.y)
+        {   /* x4 order: (2, 1, 3, 4) then (5, 6, 8, 7) */
+            PT_DIST(omv.x, top, 2, dist); PT_DIST(left2, top2, 1, dist >> 1); PT_DIST(right2, top2, 3, dist >> 1); PT_DIST(left, omv.y, 4, dist);
+            PT_DIST(right, omv.y, 5, dist); PT_DIST(left2, bottom2, 6, dist >> 1); PT_DIST(right2, bottom2, 8, dist >> 1); PT_DIST(omv.x, bottom, 7, dist);
+        }
+        else
+        {
+            if (top >= mvmin.y) PT_DIST(omv.x, top, 2, dist);
+            if (top2 >= mvmin.y)
+            {
+                if (left2 >= mvmin.x) PT_DIST(left2, top2, 1, dist >> 1);
+                if (right2 <= mvmax.x) PT_DIST(right2, top2, 3, dist >> 1);
+            }
+            if (left >= mvmin.x) PT_DIST(left, omv.y, 4, dist);
+            if (right <= mvmax.x) PT_DIST(right, omv.y, 5, dist);
+            if (bottom2 <= mvmax.y)
+            {
+                if (left2 >= mvmin.x) PT_DIST(left2, bottom2, 6, dist >> 1);
+                if (right2 <= mvmax.x) PT_DIST(right2, bottom2, 8, dist >> 1);
+            }
+            if (bottom <= mvmax.y) PT_DIST(omv.x, bottom, 7, dist);
+        }
+        if (s->bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 16; dist <= (int16_t)merange; dist <<= 1)
+    {
+        const int top = omv.y - dist, bottom = omv.y + dist, left = omv.x - dist, right = omv.x + dist;
+        saved = s->bcost;
+        const int all = top >= mvmin.y && left >= mvmin.x && right <= mvmax.x && bottom <= mvmax.y;
+        if (all || top >= mvmin.y) PT_DIST(omv.x, top, 0, dist);
+        if (all || left >= mvmin.x) PT_DIST(left, omv.y, 0, dist);
+        if (all || right <= mvmax.x) PT_DIST(right, omv.y, 0, dist);
+        if (all || bottom <= mvmax.y) PT_DIST(omv.x, bottom, 0, dist);
+        for (int index = 1; index < 4; index++)
+        {
+            const int posYT = top + ((dist >> 2) * index), posYB = bottom - ((dist >> 2) * index);
+            const int posXL = omv.x - ((dist >> 2) * index), posXR = omv.x + ((dist >> 2) * index);
+            if (all || posYT >= mvmin.y)
+            {
+                if (all || posXL >= mvmin.x) PT_DIST(posXL, posYT, 0, dist);
+                if (all || posXR <= mvmax.x) PT_DIST(posXR, posYT, 0, dist);
+            }
+            if (all || posYB <= mvmax.y)
+            {
+                if (all || posXL >= mvmin.x) PT_DIST(posXL, posYB, 0, dist);
+                if (all || posXR <= mvmax.x) PT_DIST(posXR, posYB, 0, dist);
+            }
+        }
+        if (s->bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+}
+#undef PT_DIST
+static void lowres_star(const la_t* m, mv_t mvmin, mv_t mvmax, int merange, mv_t* bmvIO, int* bcostIO)
+{
+    static const mv_t offsets[16] = { {-1,0}, {0,-1}, {-1,-1}, {1,-1}, {-1,0}, {1,0}, {-1,1}, {-1,-1},
+                                      {1,-1}, {1,1}, {-1,0}, {0,1}, {-1,1}, {1,1}, {1,0}, {0,1} };       /* motion.cpp:75-85 */
+    mv_t bmv = *bmvIO; int bcost = *bcostIO;
+#define COST_MV(mx_, my_) do { const int c_ = sad_at(m, (mx_), (my_)) + mvcost(m, (mx_) * 4, (my_) * 4); if (c_ < bcost) { bcost = c_; bmv.x = (mx_); bmv.y = (my_); } } while (0)
+#define TWO_POINTS(nr) do { const mv_t a_ = { bmv.x + offsets[((nr) - 1) * 2].x, bmv.y + offsets[((nr) - 1) * 2].y }, b_ = { bmv.x + offsets[((nr) - 1) * 2 + 1].x, bmv.y + offsets[((nr) - 1) * 2 + 1].y }; \
+        if (in_range(a_, mvmin, mvmax)) COST_MV(a_.x, a_.y); if (in_range(b_, mvmin, mvmax)) COST_MV(b_.x, b_.y); } while (0)
+    la_star_t st = { bmv, bcost, 0, 0 };
+    lowres_star_pattern(m, mvmin, mvmax, &st, 3, merange);
+    bmv = st.bmv; bcost = st.bcost;
+    int done = 0;
+    if (st.bDistance == 1)
+    {
+        if (st.bPointNr)
+        {
+            const int saved = bcost;
+            TWO_POINTS(st.bPointNr);
+            if (bcost == saved) done = 1;
+        }
+        else done = 1;
+    }
+    if (!done)
+    {
+        const int RasterDistance = 5;
+        if (st.bDistance > RasterDistance)
+        {
+            mv_t t;
+            xo_la_star_rasters++;
+            for (t.y = mvmin.y; t.y <= mvmax.y; t.y += RasterDistance)
+                for (t.x = mvmin.x; t.x <= mvmax.x; t.x += RasterDistance)
+                {
+                    if (t.x + RasterDistance * 3 <= mvmax.x)
+                    {
+                        int c4[4];
+                        for (int k = 0; k < 4; k++) c4[k] = sad_at(m, t.x + RasterDistance * k, t.y);
+                        for (int k = 0; k < 4; k++)
+                        {
+                            if (k) t.x += RasterDistance;
+                            const int c = c4[k] + (k == 3 ? mvcost(m, t.x * 8, t.y * 8) : mvcost(m, t.x * 4, t.y * 4));     /* :1392: tmv << 3 */
+                            if (c < bcost) { bcost = c; bmv = t; }
+                        }
+                    }
+                    else
+                        COST_MV(t.x, t.y);
+                }
+        }
+        int bDistance = st.bDistance;
+        while (bDistance > 0)
+        {
+            st.bmv = bmv; st.bcost = bcost; st.bPointNr = 0; st.bDistance = 0;
+            lowres_star_pattern(m, mvmin, mvmax, &st, 32, merange);
+            bmv = st.bmv; bcost = st.bcost; bDistance = st.bDistance;
+            if (bDistance == 1)
+            {
+                if (st.bPointNr) TWO_POINTS(st.bPointNr);
+                break;
+            }
+        }
+    }
+#undef COST_MV
+#undef TWO_POINTS
+    *bmvIO = bmv; *bcostIO = bcost;
+}
+
 /* motionEstimate for a lowres reference: no candidates, subme 1 (slicetype.cpp:4483-4486 setSourcePU); the hexagon search, or -- an --hme level whose
  * hmeSearchMethod says so (motion.cpp:1013) -- the uneven multi-hexagon search in front of it */
 static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, int method, mv_t* out)
@@ -264,6 +409,7 @@ static int lowres_me(la_t* m, mv_t mvmin, mv_t mvmax, mv_t qmvp, int merange, in
             }
         goto refine;
     }
+    if (method == XO_ME_STAR) { lowres_star(m, mvmin, mvmax, merange, &bmv, &bcost); goto refine; }
     {
         const mv_t fpmv = { (pmv.x + 2) >> 2, (pmv.y + 2) >> 2 };                              /* motion.cpp:1005 */
         if (umh && !lowres_umh(m, mvmin, mvmax, fpmv, merange, &bmv, &bcost)) goto refine;

@@ -82,7 +82,9 @@ def test_both_seams_together(depth, args, tmp_path):
                                         (8, ["960", "544", "6", "faster", "hme=1", "hme-search=umh,hex,hex", "hme-range=24,24,32", "bframes=3", "b-adapt=2"]),
                                         (10, ["960", "544", "5", "superfast", "hme=1", "hme-search=hex"]),
                                         (8, ["960", "544", "8", "fast", "hme=1", "weightp=1", "bframes=2"]),
-                                        (8, ["960", "544", "5", "superfast", "hme=1", "hme-search=dia,full,hex", "hme-range=16,6,32"])])     # diamond / exhaustive levels       # with a fade: list 0 is searched in the weighted copy on the half-resolution level only
+                                        (8, ["960", "544", "5", "superfast", "hme=1", "hme-search=dia,full,hex", "hme-range=16,6,32"]),      # diamond / exhaustive levels
+                                        (8, ["960", "544", "4", "superfast", "hme=1", "hme-search=star,hex,hex"]),                           # star levels (the raster's window is the picture)
+                                        (10, ["960", "544", "4", "superfast", "hme=1", "hme-search=umh,star,hex", "hme-range=16,24,32", "bframes=2"])])       # with a fade: list 0 is searched in the weighted copy on the half-resolution level only
 def test_bitstream_identical_with_gpu_hme_lookahead(depth, args, tmp_path):
     """--hme: the quarter-resolution sweep runs on the GPU too (x265hip_la_enable_hme + x265hip_la_estimate_desc.hme); Lowres::lowerResMvs / lowerResMvCosts come back"""
     fade = "weightp=1" in args
@@ -95,9 +97,10 @@ def test_bitstream_identical_with_gpu_hme_lookahead(depth, args, tmp_path):
 
 
 def test_hme_levels_the_producer_lacks_stay_with_the_encoder(tmp_path):
-    """an --hme level searched with a method the producer does not offer (star, sea, full, dia): the adapter forwards those estimates to the encoder's own body (counted), the
-    intra estimates still come from the GPU"""
-    args = ["960", "544", "4", "superfast", "hme=1", "hme-search=star,hex,hex"]
+    """an --hme level the producer does not offer (a range beyond 64; a sea level is not a case: the reference itself dereferences MotionEstimate::integral[] == NULL there,
+    tests/test_lookahead_oracle_vs_ref.py::test_reference_cannot_run_a_sea_level_of_hme): the adapter forwards those estimates to the encoder's own body (counted), the intra
+    estimates still come from the GPU"""
+    args = ["960", "544", "4", "superfast", "hme=1", "hme-search=hex,umh,hex", "hme-range=16,80,96"]
     cpu, h_cpu = encode(8, False, False, False, args, str(tmp_path / "cpu.hevc"))
     gpu, h_gpu = encode(8, True, False, False, args, str(tmp_path / "gpu.hevc"))
     assert gpu["la_estimates"] == 0 and gpu["la_cpu_estimates"] > 0

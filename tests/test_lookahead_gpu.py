@@ -244,12 +244,15 @@ def test_cutree_finish_matches_oracle(depth):
         assert np.max(np.abs(got - exp)) <= 1e-12, np.max(np.abs(got - exp))
 
 
-# --hme: (method of the quarter-resolution level, method of the half-resolution level, their ranges); 1 = hexagon, 2 = uneven multi-hexagon (the reference's default: hex, umh, 16, 32)
+# --hme: (method of the quarter-resolution level, method of the half-resolution level, their ranges); 0 = diamond, 1 = hexagon, 2 = uneven multi-hexagon, 3 = star, 5 = exhaustive (the reference's default: hex, umh, 16, 32)
 @pytest.mark.parametrize("depth", [8, 10])
 @pytest.mark.parametrize("size,aq,shift,hme", [((192, 144), 0, (3, 2), (1, 2, 16, 32)), ((208, 120), 1, (-6, 4), (2, 2, 16, 32)), ((320, 176), 1, (12, -8), (1, 1, 8, 12)),
                                                ((136, 72), 0, (-5, 9), (2, 1, 24, 48)), ((64, 48), 1, (1, 0), (1, 2, 16, 32)), ((960, 544), 1, (14, -6), (1, 2, 16, 32)),
                                                # diamond (0) and exhaustive (5) levels
-                                               ((192, 144), 1, (3, -2), (0, 5, 16, 6)), ((208, 120), 0, (-6, 4), (5, 0, 5, 32)), ((136, 72), 1, (2, 3), (0, 0, 16, 32)), ((320, 176), 0, (9, -4), (5, 2, 4, 24))])
+                                               ((192, 144), 1, (3, -2), (0, 5, 16, 6)), ((208, 120), 0, (-6, 4), (5, 0, 5, 32)), ((136, 72), 1, (2, 3), (0, 0, 16, 32)), ((320, 176), 0, (9, -4), (5, 2, 4, 24)),
+                                               # star (3) levels; the large shifts send blocks through the raster refinement (whole-picture window, one mv cost in four at the doubled vector)
+                                               ((192, 144), 1, (3, -2), (3, 1, 16, 32)), ((208, 120), 0, (-6, 4), (1, 3, 16, 32)), ((320, 176), 1, (44, -28), (3, 3, 8, 12)),
+                                               ((136, 72), 0, (-25, 19), (3, 2, 24, 48)), ((256, 160), 0, (36, 30), (0, 3, 16, 32)), ((960, 544), 1, (50, -38), (3, 3, 16, 32))])
 def test_hme_lookahead_batch_matches_oracle(depth, size, aq, shift, hme):
     """x265hip_lookahead_cost_batch_hme against the restated --hme sweep (oracle xo_lowres_frame_cost_hme, pinned to the reference by test_lookahead_oracle_vs_ref.py): the
     quarter-resolution MVs / costs (Lowres::lowerResMvs / lowerResMvCosts) and everything the half-resolution sweep leaves, identical"""

@@ -175,7 +175,7 @@ def test_lookahead_cost_with_slices_matches_reference(depth, size, rows, aq):
             assert o["intraMbs"] == rt["intraMbs"]
 
 
-# --hme (slicetype.cpp:4430-4439, 4483-4575): (method of the quarter-resolution level, method of the half-resolution level, their ranges); 0 = diamond, 1 = hexagon, 2 = uneven multi-hexagon, 5 = exhaustive
+# --hme (slicetype.cpp:4430-4439, 4483-4575): (method of the quarter-resolution level, method of the half-resolution level, their ranges); 0 = diamond, 1 = hexagon, 2 = uneven multi-hexagon, 3 = star, 5 = exhaustive
 HME_TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3, 0), (0, 3, 3, 0), (0, 1, 3, 0)]
 
 
@@ -184,7 +184,10 @@ HME_TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3,
                                                ((136, 72), 0, (-5, 9), (2, 1, 24, 48)), ((64, 48), 1, (1, 0), (1, 2, 16, 32)),
                                                # diamond (0) and exhaustive (5) levels: the exhaustive search of an --hme reference is cut to +-range around the ZERO vector (motion.cpp:1598-1605)
                                                ((192, 144), 1, (3, -2), (0, 5, 16, 6)), ((208, 120), 0, (-6, 4), (5, 0, 5, 32)), ((136, 72), 1, (2, 3), (0, 0, 16, 32)),
-                                               ((320, 176), 0, (9, -4), (5, 2, 4, 24)), ((64, 48), 1, (1, 0), (1, 5, 16, 3))])
+                                               ((320, 176), 0, (9, -4), (5, 2, 4, 24)), ((64, 48), 1, (1, 0), (1, 5, 16, 3)),
+                                               # star (3) levels (motion.cpp:1328-1436, 387-629): the large shifts send blocks through the raster (best distance > 5), whose window is the picture
+                                               ((192, 144), 1, (3, -2), (3, 1, 16, 32)), ((208, 120), 0, (-6, 4), (1, 3, 16, 32)), ((320, 176), 1, (44, -28), (3, 3, 8, 12)),
+                                               ((136, 72), 0, (-25, 19), (3, 2, 24, 48)), ((256, 160), 0, (36, 30), (0, 3, 16, 32))])
 def test_hme_lookahead_cost_matches_reference(depth, size, aq, shift, hme):
     if not la_available(depth):
         pytest.skip("no reference lookahead binary")
@@ -203,6 +206,8 @@ def test_hme_lookahead_cost_matches_reference(depth, size, aq, shift, hme):
         planes.append(pl); lower.append(lo)
         intra.append(oracle_intra(ora, pl, g, ref_frames[f]["invQ"] if aq else None))
     cache = {}
+    rasters = C.c_long.in_dll(ora.me_lib, "xo_la_star_rasters")
+    rasters.value = 0
     for t, rt in zip(HME_TRIPLES, ref_triples):
         p0, b, p1, keep = t
         if not keep:
@@ -225,3 +230,18 @@ def test_hme_lookahead_cost_matches_reference(depth, size, aq, shift, hme):
         cache[(b, 0, b - p0)] = (o["mvs0"], o["mvc0"])
         if p1 > b:
             cache[(b, 1, p1 - b)] = (o["mvs1"], o["mvc1"])
+    if 3 in hme[:2] and max(abs(shift[0]), abs(shift[1])) >= 19:
+        assert rasters.value > 0, "no block of this clip reached the raster refinement of the star search"
+
+
+def test_reference_cannot_run_a_sea_level_of_hme(tmp_path):
+    """--hme-search sea: the lookahead's MotionEstimate never gets integral planes (MotionEstimate::integral[] = NULL, motion.cpp:115; set only by Search::predInterSearch,
+    search.cpp), and the SEA search reads them (motion.cpp:1509-1541, 1564) -- the reference encoder dies on its first P estimate.  That is why neither the oracle nor the
+    producer has a sea level for --hme: there is no reference behaviour to match."""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "x265e2e_8")
+    if not os.path.exists(exe):
+        pytest.skip("no oracle/_ref/x265e2e_8 (built where the reference is present)")
+    env = dict(os.environ, X265LAGPU="0", X265TME="0", X265TMEGPU="0")
+    r = subprocess.run([exe, "none", "960", "544", "3", "superfast", str(tmp_path / "sea.hevc"), "hme=1", "hme-search=sea,hex,hex"], capture_output=True, env=env, timeout=600)
+    assert r.returncode < 0, "the reference survived an SEA level of --hme (return code %d): the producer should offer it then" % r.returncode

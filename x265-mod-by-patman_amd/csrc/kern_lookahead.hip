@@ -171,6 +171,7 @@ struct Blk
     // the final zero-MV check of motionEstimate (motion.cpp:1763-1768) goes through subpelCompare, which always reads ReferencePlanes::fpelPlane[0] with lumaStride: on the
     // quarter-resolution level of --hme that is the HALF-resolution plane, at the quarter-resolution block offset.  zbase != NULL: the lane's row of that block (element offset zref).
     const pixel* zbase; uint32_t zref;
+    const uint16_t* gcost;                   // centre of the whole MVD cost row in memory: the star search's raster takes one cost at twice the quarter-pel vector (motion.cpp:1392), beyond the LDS copy
 };
 __device__ __forceinline__ int mvcost(const Blk& c, int qx, int qy) { return (uint16_t)((int)c.lcost[qx - c.mvpx] + (int)c.lcost[qy - c.mvpy]); }   // bitcost.h:57
 // ReferencePlanes::lowresMC: half-pel positions are planes, quarter-pel positions the rounded average of two of them
@@ -307,6 +308,129 @@ __device__ __forceinline__ bool lowres_umh(Blk& c, int px, int py, int merange, 
     return bx >= mnx && bx <= mxx && by >= mny && by <= mxy;               // `goto me_hex2` (:1323-1324)
 }
 
+// X265_STAR_SEARCH (motion.cpp:1328-1436) with StarPatternSearch (:387-629) for an 8x8 lowres block.  A round's points are costed together (4, 8 or 2 x 8 at a time) and
+// compared in the reference's order; a point the reference's window tests leave out is measured at the round's centre and ignored.  The x4 form of a round visits the
+// points of the guarded form in the same order, and `all inside` implies every guard, so the guards alone decide.
+struct StarSt { int bx, by, bcost, pointNr, dist; };
+template<int K>
+__device__ __forceinline__ void star_batch(const Blk& c, StarSt& s, int ox, int oy, const int (&X)[K], const int (&Y)[K], const bool (&ok)[K], const int (&nr)[K], const int (&ds)[K])
+{
+    int QX[K], QY[K], C[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { QX[k] = (ok[k] ? X[k] : ox) * 4; QY[k] = (ok[k] ? Y[k] : oy) * 4; }
+    eval<K, false>(c, QX, QY, C);
+#pragma unroll
+    for (int k = 0; k < K; k++)
+    {
+        const int cost = C[k] + mvcost(c, QX[k], QY[k]);
+        if (ok[k] && cost < s.bcost) { s.bcost = cost; s.bx = X[k]; s.by = Y[k]; s.pointNr = nr[k]; s.dist = ds[k]; }
+    }
+}
+__device__ __forceinline__ void lowres_star_pattern(const Blk& c, int mnx, int mny, int mxx, int mxy, StarSt& s, int earlyExitIters, int merange)
+{
+    const int ox = s.bx, oy = s.by;
+    int rounds = 0;
+    {   // distance 1 (:406-448): 2, 4, 5, 7
+        const int saved = s.bcost;
+        const int X[4] = { ox, ox - 1, ox + 1, ox }, Y[4] = { oy - 1, oy, oy, oy + 1 };
+        const bool ok[4] = { oy - 1 >= mny, ox - 1 >= mnx, ox + 1 <= mxx, oy + 1 <= mxy };
+        const int nr[4] = { 2, 4, 5, 7 }, ds[4] = { 1, 1, 1, 1 };
+        star_batch<4>(c, s, ox, oy, X, Y, ok, nr, ds);
+        if (s.bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 2; dist <= 8; dist <<= 1)
+    {   // :450-527: 2, 1, 3, 4, 5, 6, 8, 7 -- the diagonal points at half the distance
+        const int saved = s.bcost, h = dist >> 1;
+        const int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist, top2 = oy - h, bottom2 = oy + h, left2 = ox - h, right2 = ox + h;
+        const int X[8] = { ox, left2, right2, left, right, left2, right2, ox }, Y[8] = { top, top2, top2, oy, oy, bottom2, bottom2, bottom };
+        const bool ok[8] = { top >= mny, top2 >= mny && left2 >= mnx, top2 >= mny && right2 <= mxx, left >= mnx, right <= mxx, bottom2 <= mxy && left2 >= mnx, bottom2 <= mxy && right2 <= mxx, bottom <= mxy };
+        const int nr[8] = { 2, 1, 3, 4, 5, 6, 8, 7 }, ds[8] = { dist, h, h, dist, dist, h, h, dist };
+        star_batch<8>(c, s, ox, oy, X, Y, ok, nr, ds);
+        if (s.bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+    for (int dist = 16; dist <= (int16_t)merange; dist <<= 1)
+    {   // :529-628: top, left, right, bottom, then three rings of four points between them; point number 0
+        const int saved = s.bcost, q = dist >> 2;
+        const int top = oy - dist, bottom = oy + dist, left = ox - dist, right = ox + dist;
+        {
+            const int yt = top + q, yb = bottom - q, xl = ox - q, xr = ox + q;
+            const int X[8] = { ox, left, right, ox, xl, xr, xl, xr }, Y[8] = { top, oy, oy, bottom, yt, yt, yb, yb };
+            const bool ok[8] = { top >= mny, left >= mnx, right <= mxx, bottom <= mxy, yt >= mny && xl >= mnx, yt >= mny && xr <= mxx, yb <= mxy && xl >= mnx, yb <= mxy && xr <= mxx };
+            const int nr[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ds[8] = { dist, dist, dist, dist, dist, dist, dist, dist };
+            star_batch<8>(c, s, ox, oy, X, Y, ok, nr, ds);
+        }
+        {
+            const int yt2 = top + 2 * q, yb2 = bottom - 2 * q, xl2 = ox - 2 * q, xr2 = ox + 2 * q, yt3 = top + 3 * q, yb3 = bottom - 3 * q, xl3 = ox - 3 * q, xr3 = ox + 3 * q;
+            const int X[8] = { xl2, xr2, xl2, xr2, xl3, xr3, xl3, xr3 }, Y[8] = { yt2, yt2, yb2, yb2, yt3, yt3, yb3, yb3 };
+            const bool ok[8] = { yt2 >= mny && xl2 >= mnx, yt2 >= mny && xr2 <= mxx, yb2 <= mxy && xl2 >= mnx, yb2 <= mxy && xr2 <= mxx,
+                                 yt3 >= mny && xl3 >= mnx, yt3 >= mny && xr3 <= mxx, yb3 <= mxy && xl3 >= mnx, yb3 <= mxy && xr3 <= mxx };
+            const int nr[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ds[8] = { dist, dist, dist, dist, dist, dist, dist, dist };
+            star_batch<8>(c, s, ox, oy, X, Y, ok, nr, ds);
+        }
+        if (s.bcost < saved) rounds = 0;
+        else if (++rounds >= earlyExitIters) return;
+    }
+}
+__device__ __forceinline__ void lowres_star(const Blk& c, int mnx, int mny, int mxx, int mxy, int merange, int& bx, int& by, int& bcost)
+{
+    auto twoPoints = [&](int nr) {   // offsets[] (motion.cpp:75-85): the two outer neighbours of direction nr = 1..8, packed (value + 1) in 2 bits, x then y
+        const unsigned px = 0x684a0884u, py = 0x9a982501u;
+        const int i = (nr - 1) * 2;
+        const int ax = bx + (int)((px >> (2 * i)) & 3) - 1, ay = by + (int)((py >> (2 * i)) & 3) - 1, bx2 = bx + (int)((px >> (2 * i + 2)) & 3) - 1, by2 = by + (int)((py >> (2 * i + 2)) & 3) - 1;
+        const bool oka = ax >= mnx && ax <= mxx && ay >= mny && ay <= mxy, okb = bx2 >= mnx && bx2 <= mxx && by2 >= mny && by2 <= mxy;
+        const int QX[2] = { (oka ? ax : bx) * 4, (okb ? bx2 : bx) * 4 }, QY[2] = { (oka ? ay : by) * 4, (okb ? by2 : by) * 4 };
+        int C[2];
+        eval<2, false>(c, QX, QY, C);
+        const int c0 = C[0] + mvcost(c, QX[0], QY[0]), c1 = C[1] + mvcost(c, QX[1], QY[1]);
+        if (oka && c0 < bcost) { bcost = c0; bx = ax; by = ay; }
+        if (okb && c1 < bcost) { bcost = c1; bx = bx2; by = by2; }
+    };
+    StarSt s = { bx, by, bcost, 0, 0 };
+    lowres_star_pattern(c, mnx, mny, mxx, mxy, s, 3, merange);
+    bx = s.bx; by = s.by; bcost = s.bcost;
+    if (s.dist == 1)
+    {   // :1335-1364: the two missing points; no new best ends the search
+        if (!s.pointNr) return;
+        const int saved = bcost;
+        twoPoints(s.pointNr);
+        if (bcost == saved) return;
+    }
+    if (s.dist > 5)
+    {   // raster refinement over the WHOLE window, every fifth position (:1366-1401): four placements of a row at a time while four fit (the fourth one's mv cost at
+        // tmv << 3, :1392), then the rest of the row one by one
+        for (int ty = mny; ty <= mxy; ty += 5)
+            for (int tx = mnx; tx <= mxx; tx += 20)
+            {
+                const bool four = tx + 15 <= mxx;
+                int X[4], Y[4], C[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { X[k] = min(tx + 5 * k, mxx) * 4; Y[k] = ty * 4; }
+                eval<4, false>(c, X, Y, C);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                {
+                    const int mvc = (k == 3 && four) ? (int)(uint16_t)((int)c.gcost[2 * X[k] - c.mvpx] + (int)c.gcost[2 * Y[k] - c.mvpy]) : mvcost(c, X[k], Y[k]);
+                    const int cost = C[k] + mvc;
+                    if (tx + 5 * k <= mxx && cost < bcost) { bcost = cost; bx = tx + 5 * k; by = ty; }
+                }
+            }
+    }
+    int dist = s.dist;
+    while (dist > 0)
+    {   // :1403-1434: a new search centred on the best so far, until the best distance is 0; distance 1 ends it with the two missing points
+        s.bx = bx; s.by = by; s.bcost = bcost; s.pointNr = 0; s.dist = 0;
+        lowres_star_pattern(c, mnx, mny, mxx, mxy, s, 32, merange);
+        bx = s.bx; by = s.by; bcost = s.bcost; dist = s.dist;
+        if (dist == 1)
+        {
+            if (s.pointNr) twoPoints(s.pointNr);
+            break;
+        }
+    }
+}
+
 // MotionEstimate::motionEstimate for a lowres reference (no candidates, subme 1; the hexagon search, or -- with --hme -- the level's method: hexagon or uneven
 // multi-hexagon, motion.cpp:1013): returns the cost, MV in (ox, oy)
 __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int mxy, int mvpx, int mvpy, int& ox, int& oy, int merange = LA_MERANGE, int method = X265HIP_ME_HEX)
@@ -375,6 +499,7 @@ __device__ __forceinline__ int lowres_me(Blk& c, int mnx, int mny, int mxx, int 
             }
         hexToo = false;
     }
+    else if (method == X265HIP_ME_STAR) { lowres_star(c, mnx, mny, mxx, mxy, merange, bx, by, bcost); hexToo = false; }
     if (umh) hexToo = lowres_umh(c, (pmx + 2) >> 2, (pmy + 2) >> 2, merange, mnx, mny, mxx, mxy, bx, by, bcost);
     if (hexToo)
     {
@@ -553,7 +678,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
             const bool lastRow = j == 0;
             const uint32_t pel = (uint32_t)(CU * cuX + __mul24(CU * cuY + lane, stride));
             Blk c;
-            c.lane = lane; c.stride = stride; c.base = g.lowres; c.lcost = s_cost + costR; c.mvpx = 0; c.mvpy = 0;
+            c.lane = lane; c.stride = stride; c.base = g.lowres; c.lcost = s_cost + costR; c.mvpx = 0; c.mvpy = 0; c.gcost = costCentre;
             c.fenc = ld_row(g.lowres, fencPlane + pel);
             c.ref0 = rp + pel; c.pe = (uint32_t)g.planeElems;
             c.zbase = gz.lowres; c.zref = gz.lowres ? plane0_off(gz, list ? tp1 : tp0) + (uint32_t)(CU * cuX + __mul24(CU * cuY, stride) + __mul24(lane, (int)gz.stride)) : 0u;
@@ -976,10 +1101,16 @@ extern "C" int x265hip_lookahead_cost_batch_hme(void* stream, const void* lowres
         if (bad_geom(hme->lowerRes, hme->planeElems, hme->stride, hme->origin, hme->widthInCU, hme->heightInCU) || !hme->mvs || !hme->mvCosts || ((uintptr_t)hme->mvs & 3))
         { set_error("lookahead_cost_batch_hme: bad quarter-resolution arguments"); return X265HIP_EARG; }
         for (int l = 0; l < 2; l++)
-            if ((hme->method[l] != X265HIP_ME_DIA && hme->method[l] != X265HIP_ME_HEX && hme->method[l] != X265HIP_ME_UMH && hme->method[l] != X265HIP_ME_FULL) || hme->range[l] < 1 || hme->range[l] > 64)
-            { set_error("lookahead_cost_batch_hme: level %d: diamond, hexagon, uneven multi-hexagon or exhaustive search, range 1..64", l); return X265HIP_EARG; }
+            if ((hme->method[l] != X265HIP_ME_DIA && hme->method[l] != X265HIP_ME_HEX && hme->method[l] != X265HIP_ME_UMH && hme->method[l] != X265HIP_ME_STAR && hme->method[l] != X265HIP_ME_FULL) || hme->range[l] < 1 || hme->range[l] > 64)
+            { set_error("lookahead_cost_batch_hme: level %d: diamond, hexagon, uneven multi-hexagon, star or exhaustive search, range 1..64", l); return X265HIP_EARG; }
+        // the raster of a star level costs one placement in four at twice its quarter-pel vector (motion.cpp:1392): |8 * mv - mvp| < 8 * (size + 8) + 4 * (size + 32)
+        if ((hme->method[0] == X265HIP_ME_STAR || hme->method[1] == X265HIP_ME_STAR) && costHalfRange < 12 * max(widthInCU, heightInCU) * CU + 192)
+        { set_error("lookahead_cost_batch_hme: cost row too short for a star level at this picture size (need >= %d)", 12 * max(widthInCU, heightInCU) * CU + 192); return X265HIP_EARG; }
         if (rowsPerSlice > 0 && rowsPerSlice < heightInCU) { set_error("lookahead_cost_batch_hme: the cooperative sweep is not offered with HME"); return X265HIP_EARG; }
         if (((int64_t)nFrames) * 4 * hme->planeElems >= ((int64_t)1 << 31)) { set_error("lookahead_cost_batch_hme: quarter-resolution buffer beyond 2^31 elements"); return X265HIP_EARG; }
+        if (costHalfRange < 4 * (2 * max(widthInCU, heightInCU) * CU + 64))
+        { set_error("lookahead_cost_batch_hme: cost row too short for --hme at this picture size (need >= %d)", 4 * (2 * max(widthInCU, heightInCU) * CU + 64)); return X265HIP_EARG; }
+        if (sizeof(uint16_t) * (size_t)(8 * (2 * max(widthInCU, heightInCU) * CU + 64) + 2) > 160 * 1024) { set_error("lookahead_cost_batch_hme: picture too large for the cost row in LDS"); return X265HIP_EARG; }
     }
     if (nFrames <= 0) { set_error("lookahead_cost_batch: nFrames must be the number of pictures in the lowres buffer"); return X265HIP_EARG; }
     if (rowsPerSlice <= 0 || rowsPerSlice > heightInCU) rowsPerSlice = heightInCU;          // one slice
@@ -1004,12 +1135,17 @@ extern "C" int x265hip_lookahead_cost_batch_hme(void* stream, const void* lowres
     // A/B switches of the profiling scripts, clamped to what the kernel can run with (whole wavefronts, 64..1024 threads; LDS within the CU's 160 KB)
     static const int threadCap = [] { const char* e = xh_experiment("X265HIP_LA_THREADS"); int v = e ? atoi(e) : 1024; v = v / 64 * 64; return v < 64 ? 64 : v > 1024 ? 1024 : v; }();
     const int threads = min(min(1024, threadCap), max(64, (widest * 8 + 63) / 64 * 64));
-    const int costR = 4 * (max(widthInCU, heightInCU) * CU + 32);               // the bound checked above; 2 bytes per entry of LDS
+    // the bound checked above; 2 bytes per entry of LDS.  With --hme the half-resolution sweep takes twice a quarter-resolution MV as a predictor candidate, and the block it
+    // takes it from is indexed with the half-resolution width (slicetype.cpp:4482: for an odd width a block of another column, further down the picture, of any column):
+    // that predictor lies anywhere within the doubled quarter-resolution window, |mv - mvp| < 4 * (2 * size + 64)
+    const int costR = hme ? 4 * (2 * max(widthInCU, heightInCU) * CU + 64) : 4 * (max(widthInCU, heightInCU) * CU + 32);
     // Workgroup placement: a CU accepts four of these 8-wavefront workgroups, and the dispatcher fills CUs one after the other, so a
     // batch of ~2 workgroups per CU ends up four deep on some CUs and absent on others -- and four interleaved wavefront sweeps take
     // four times as long as one.  Asking for 56 KB of LDS (of 160 KB per CU) caps the depth at two.
     static const size_t ldsPad = [] { const char* e = xh_experiment("X265HIP_LA_LDS"); long v = e ? atol(e) : 56 * 1024; return (size_t)(v < 0 ? 0 : v > 160 * 1024 ? 160 * 1024 : v); }();
     const size_t lds = std::max(sizeof(uint16_t) * (size_t)(2 * costR + 2), ldsPad);
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)la_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    { set_error("lookahead_cost_batch: %zu bytes of LDS for the cost row refused", lds); return X265HIP_EDEVICE; }
     if (hme)
     {   // level 0: the quarter-resolution sweep into its own slots (same slot numbers), one slice, never the weighted copy
         const LaGeom g0 = { (const pixel*)hme->lowerRes, hme->planeElems, hme->stride, hme->origin, hme->widthInCU, hme->heightInCU };

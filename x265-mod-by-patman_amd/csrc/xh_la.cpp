@@ -17,7 +17,7 @@ namespace { struct Req; constexpr int kLaBatch = X265HIP_LA_MAX_BATCH; }      //
 struct x265hip_la
 {
     x265hip_ctx* ctx = nullptr;
-    int wcu = 0, hcu = 0, ncu = 0, maxPics = 0;
+    int wcu = 0, hcu = 0, ncu = 0, maxPics = 0, costHalf = 0;
     intptr_t stride = 0; int64_t planeElems = 0, origin = 0;
     pixel* low = nullptr;                        // (maxPics + kLaBatch) pictures x 4 planes; the last kLaBatch places hold the weighted copies of the estimates of one launch
     int32_t* intraCost = nullptr; int32_t* invq = nullptr; bool haveInvq = false;      // per picture slot
@@ -45,28 +45,29 @@ struct x265hip_la
     int find(uint64_t key) const { for (int i = 0; i < (int)slots.size(); i++) if (slots[i].key == key) return i; return -1; }
 };
 
-namespace { constexpr int kLaHalf = 1 << 14; }
+namespace { constexpr int kLaHalfMin = 1 << 14; }
 
 extern "C" int x265hip_la_create(x265hip_ctx* ctx, int widthInCU, int heightInCU, intptr_t stride, int64_t planeElems, int64_t origin, int maxPictures, x265hip_la** out)
 {
     if (!ctx || !out || widthInCU < 1 || heightInCU < 1 || stride < widthInCU * 8 || planeElems < stride * heightInCU * 8 || origin < 0 || origin >= planeElems || maxPictures < 3 || maxPictures > 1024)
     { set_error("la_create: bad geometry"); return X265HIP_EARG; }
-    if (kLaHalf < 4 * (8 * (widthInCU > heightInCU ? widthInCU : heightInCU) + 32)) { set_error("la_create: picture too large for the MVD cost row"); return X265HIP_EARG; }
+    // the MVD cost row: every |mv - mvp| of a picture this size, and the doubled vector the raster of a star level of --hme costs one placement in four at (motion.cpp:1392)
+    const int costHalf = std::max(kLaHalfMin, 12 * 8 * (widthInCU > heightInCU ? widthInCU : heightInCU) + 192);
     XH_HIP(hipSetDevice(x265hip_ctx_device(ctx)));
     x265hip_la* a = new (std::nothrow) x265hip_la();
     if (!a) return X265HIP_EARG;
-    a->ctx = ctx; a->wcu = widthInCU; a->hcu = heightInCU; a->ncu = widthInCU * heightInCU; a->stride = stride; a->planeElems = planeElems; a->origin = origin; a->maxPics = maxPictures;
+    a->ctx = ctx; a->wcu = widthInCU; a->hcu = heightInCU; a->ncu = widthInCU * heightInCU; a->stride = stride; a->planeElems = planeElems; a->origin = origin; a->maxPics = maxPictures; a->costHalf = costHalf;
     a->slots.resize((size_t)maxPictures);
     const size_t np = (size_t)maxPictures + kLaBatch, ncu = (size_t)a->ncu;      // + one weighted copy per estimate of a batch
     if ((int64_t)np * 4 * planeElems >= ((int64_t)1 << 31)) { set_error("la_create: %d pictures of this size do not fit the 2^31-element lowres buffer", maxPictures); delete a; return X265HIP_EARG; }
     int rc;
     if ((rc = a->alloc(a->low, np * 4 * (size_t)planeElems)) || (rc = a->alloc(a->intraCost, np * ncu)) || (rc = a->alloc(a->invq, np * ncu)) || (rc = a->alloc(a->intraMode, ncu)) ||
-        (rc = a->alloc(a->intraLc, ncu)) || (rc = a->alloc(a->intraRows, (size_t)heightInCU)) || (rc = a->alloc(a->intraSums, 2)) || (rc = a->alloc(a->costRow, (size_t)2 * kLaHalf + 1)) ||
+        (rc = a->alloc(a->intraLc, ncu)) || (rc = a->alloc(a->intraRows, (size_t)heightInCU)) || (rc = a->alloc(a->intraSums, 2)) || (rc = a->alloc(a->costRow, (size_t)2 * costHalf + 1)) ||
         (rc = a->alloc(a->mvs, (size_t)kLaBatch * 2 * ncu * 2)) || (rc = a->alloc(a->mvCosts, (size_t)kLaBatch * 2 * ncu)) || (rc = a->alloc(a->lc, (size_t)kLaBatch * ncu)) ||
         (rc = a->alloc(a->rows, (size_t)kLaBatch * heightInCU)) || (rc = a->alloc(a->sums, (size_t)kLaBatch * 3)) || (rc = a->alloc(a->task, (size_t)kLaBatch)))
     { x265hip_la_destroy(a); return rc; }
-    std::vector<uint16_t> row((size_t)2 * kLaHalf + 1);
-    if ((rc = x265hip_mvcost_row(x265hip_lookahead_qp(), kLaHalf, row.data()))) { x265hip_la_destroy(a); return rc; }
+    std::vector<uint16_t> row((size_t)2 * costHalf + 1);
+    if ((rc = x265hip_mvcost_row(x265hip_lookahead_qp(), costHalf, row.data()))) { x265hip_la_destroy(a); return rc; }
     if (hipMemcpy(a->costRow, row.data(), row.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { x265hip_la_destroy(a); return X265HIP_EDEVICE; }
     *out = a;
     return X265HIP_OK;
@@ -243,7 +244,7 @@ int run_batch(x265hip_la* a, const x265hip_la_estimate_desc* const* descs, int n
     }
     XH_HIP(hipMemcpyAsync(a->task, tasks, (size_t)n * sizeof(x265hip_la_task), hipMemcpyHostToDevice, st));
     if ((rc = x265hip_lookahead_cost_batch_hme(st, a->low, a->planeElems, a->stride, a->origin, a->wcu, a->hcu, a->task, n, a->maxPics + kLaBatch, a->intraCost, a->haveInvq ? a->invq : nullptr,
-                                               a->costRow, kLaHalf, rowsPerSlice, a->mvs, a->mvCosts, a->lc, a->rows, a->sums, d0->hme ? &H : nullptr))) return rc;
+                                               a->costRow, a->costHalf, rowsPerSlice, a->mvs, a->mvCosts, a->lc, a->rows, a->sums, d0->hme ? &H : nullptr))) return rc;
     for (int i = 0; i < n; i++)
     {
         const x265hip_la_estimate_desc* d = descs[i];
