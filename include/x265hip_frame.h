@@ -397,6 +397,11 @@ int x265hip_cutree_finish(void* stream, int ncu, const int32_t* intraCost, const
  * statistics leave out under sao-non-deblock, with `recon` = the picture BEFORE deblocking (m_offsetOrgPreDblk / m_countPreDblk of each CTU, same layout). */
 int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
                             int planeOffset, int32_t* out);
+/* the same with --slices: sliceFirstRow (device, ceil(picHeight / ctuSize) + 1 bytes, the last one 0) is non-zero for every CTU row that begins a slice -- its CTUs have no
+ * row above (m_bFirstRowInSlice, sao.cpp:744-746), and the CTUs of the row before it count down to their bottom line like the picture's last row (m_bLastRowInSlice,
+ * :763-766).  NULL = x265hip_sao_stats_frame. */
+int x265hip_sao_stats_frame_slices(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                                   int planeOffset, int32_t* out, const uint8_t* sliceFirstRow);
 
 /* SAO of a whole luma plane, OUT OF PLACE (in != out): SAO::generateLumaOffsets + applyPixelOffsets (encoder/sao.cpp:268-623) for every CTU.  The
  * reference filters in place and classifies against saved unmodified neighbours (m_tmpU, m_tmpL); reading the input plane is the same thing.
@@ -428,7 +433,7 @@ int x265hip_ssim_frame(void* stream, const void* recon, intptr_t stride1, const 
  * m_predMode (0 = not coded / outside the picture), m_cbf[0], m_tqBypass (may be NULL when !tqBypassEnabled), m_qp, m_refIdx[0], m_refIdx[1] (B slices),
  * m_mv[0], m_mv[1] (int32 x, y pairs).  refPic[list][refIdx] = any integer identifying the picture behind slice->m_refFrameList[list][refIdx] (the reference
  * compares Frame pointers; POCs do).  betaOffsetDiv2 / tcOffsetDiv2 / cb / crQpOffset / tqBypassEnabled are the PPS fields.  width and height are
- * multiples of 8 (the minimum CU size); one slice (no slice / tile boundaries inside the picture).
+ * multiples of 8 (the minimum CU size); slices are whole CTU rows (sliceFirstRow), no tiles.
  * bsOut (optional, device, 2 * (height/4) * (width/4) bytes): the boundary strength of every examined edge segment, [dir][unitY][unitX].
  * --------------------------------------------------------------------------------------------------------------------------------------------- */
 typedef struct x265hip_deblock_pic
@@ -438,6 +443,8 @@ typedef struct x265hip_deblock_pic
     const int8_t *qp, *refIdx0, *refIdx1;
     const int32_t *mv0, *mv1;
     int32_t refPic[2][16];
+    const uint8_t* sliceFirstRow;   /* --slices: per CTU row, non-zero where the row begins a slice (CUData::m_bFirstRowInSlice: the CTU above is no neighbour, cudata.cpp:323 -- the
+                                       row's top edge is not filtered); NULL = one slice.  ceil(height / ctuSize) + 1 entries, the last one 0 */
 } x265hip_deblock_pic;
 int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut);
 

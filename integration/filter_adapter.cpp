@@ -102,9 +102,15 @@ void SAO::calcSaoStatsCTU(int addr, int plane)
     if (!tab) { ::calcSaoStatsCTU_cpu(this, addr, plane); return; }
     /* per CTU [2][5][32]: m_offsetOrg then m_count of the plane; the body ADDS to what rdoSaoUnitCu left there (zero, or the pre-deblock sums of --sao-non-deblock) */
     const int32_t* s = tab + (size_t)addr * (2 * MAX_NUM_SAO_TYPE * MAX_NUM_SAO_CLASS);
+    /* --limit-sao (sao.cpp:854-855): the two diagonal classes are only collected where the reference collects them -- never in B slices (and, as the reference writes
+       the test, in every P or I slice).  The producer has them for every CTU; the ones the reference leaves at zero are not added */
+    const Slice* slice = m_frame->m_encData->m_slice;
+    const CUData* cu = m_frame->m_encData->getPicCTU(addr);
+    const bool diagonals = !m_param->bLimitSAO || ((slice->m_sliceType == P_SLICE && !cu->isSkipped(0)) || (slice->m_sliceType != B_SLICE));
     for (int t = 0; t < MAX_NUM_SAO_TYPE; t++)
         for (int c = 0; c < MAX_NUM_SAO_CLASS; c++)
         {
+            if (!diagonals && (t == SAO_EO_2 || t == SAO_EO_3)) continue;
             m_offsetOrg[plane][t][c] += s[t * MAX_NUM_SAO_CLASS + c];
             m_count[plane][t][c] += s[(MAX_NUM_SAO_TYPE + t) * MAX_NUM_SAO_CLASS + c];
         }
@@ -116,7 +122,7 @@ void FrameFilter::processRow(int row, int layer)
     const x265_param& p = *m_param;
     /* one picture at a time goes through the producer and the replay (g_lock) and the replay state of a picture stays published until the next one's: several frame
        threads (pictures in flight together, FrameData objects changing hands) keep the encoder's own filters */
-    bool mine = g_on && (p.bEnableLoopFilter || m_useSao) && m_parallelFilter && p.maxSlices == 1 && p.internalCsp == X265_CSP_I420 && !p.bLimitSAO && p.frameNumThreads == 1;
+    bool mine = g_on && (p.bEnableLoopFilter || m_useSao) && m_parallelFilter && p.internalCsp == X265_CSP_I420 && p.frameNumThreads == 1;
     if (mine)
     {
         const PicYuv& rp = *m_frame->m_reconPic[0]; const PicYuv& fp = *m_frame->m_fencPic;
@@ -129,7 +135,11 @@ void FrameFilter::processRow(int row, int layer)
         ::processRow_cpu(this, row, layer);
         return;
     }
-    if (row != m_numRows - 1) return;                  /* the rows wait for the picture */
+    /* the rows wait for the picture.  One slice: a row's filter runs behind the row above it, the last row's call is the last one.  --slices (WPP, param.cpp:1760): the slices'
+       rows finish in any order (framefilter.cpp:633), the picture is complete when every row has called -- one picture at a time (one frame thread), so a counter tells */
+    static std::atomic<int> rowsIn{0};
+    if (p.maxSlices > 1) { if (rowsIn.fetch_add(1) + 1 != m_numRows) return; rowsIn.store(0); }
+    else if (row != m_numRows - 1) return;
     if (g_deferOnly)
     {   /* X265FF_DEFER_ONLY: the deferral alone, filters by the encoder's own bodies (separates the two things the binding changes; needs no GPU) */
         const double t0 = now();
@@ -184,6 +194,15 @@ void FrameFilter::processRow(int row, int layer)
     for (int l = 0; l < 2; l++) for (int i = 0; i < 16; i++) d.pic.refPic[l][i] = i < slice->m_numRefIdx[l] ? slice->m_refPOCList[l][i] : -1 - i - 16 * l;
     d.reconY = recon->m_picOrg[0]; d.reconCb = recon->m_picOrg[1]; d.reconCr = recon->m_picOrg[2];
     d.fencY = fenc->m_picOrg[0]; d.fencCb = fenc->m_picOrg[1]; d.fencCr = fenc->m_picOrg[2];
+    /* --slices: the CTU rows that begin a slice, as the encoder flagged their CTUs (CUData::initCTU, frameencoder.cpp:1669) */
+    std::vector<uint8_t> sliceFirstRow;
+    if (p.maxSlices > 1)
+    {
+        const uint32_t ncols = slice->m_sps->numCuInWidth;
+        sliceFirstRow.assign((size_t)m_numRows + 1, 0);
+        for (int r = 1; r < m_numRows; r++) sliceFirstRow[r] = encData.getPicCTU(r * ncols)->m_bFirstRowInSlice;
+        d.pic.sliceFirstRow = sliceFirstRow.data();
+    }
     d.deblock = p.bEnableLoopFilter;
     const SAOParam* sp = encData.m_saoParam;
     d.saoStats = (m_useSao && sp) ? (sp->bSaoFlag[0] ? 1 : 0) | (sp->bSaoFlag[1] ? 2 : 0) : 0;

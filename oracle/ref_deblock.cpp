@@ -67,10 +67,16 @@ int main(int argc, char** argv)
     Slice* slice = fd->m_slice;
     slice->m_sps = &sps; slice->m_pps = &pps; slice->m_param = p; slice->m_sliceType = atoi(argv[6]) ? P_SLICE : B_SLICE;
     const uint32_t np = p->num4x4Partitions;
+    std::vector<char> sliceStart(sps.numCuInHeight + 1, 0);
+    if (const char* e = getenv("X265REF_SLICE_ROWS"))
+        for (const char* q = e; *q; ) { char* end; long r = strtol(q, &end, 10); if (end == q) break; if (r > 0 && r < (long)sps.numCuInHeight) sliceStart[r] = 1; q = *end ? end + 1 : end; }
     for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
     {
         CUData& c = fd->m_picCTU[a];
-        c.initCTU(frame, a, 30, a < sps.numCuInWidth, a >= sps.numCUsInFrame - sps.numCuInWidth, a == sps.numCUsInFrame - 1);
+        /* X265REF_SLICE_ROWS=r1,r2,...: CTU rows that begin a slice (--slices: FrameEncoder::processRowEncoder hands the same three flags to CUData::initCTU) */
+        const uint32_t row = a / sps.numCuInWidth, col = a % sps.numCuInWidth;
+        const bool first = row == 0 || sliceStart[row], last = row == sps.numCuInHeight - 1 || sliceStart[row + 1];
+        c.initCTU(frame, a, 30, first, last, last && col == sps.numCuInWidth - 1);
         std::vector<int32_t> mv(2 * np);
         bool ok = rd(in, c.m_log2CUSize, np) && rd(in, c.m_cuDepth, np) && rd(in, c.m_partSize, np) && rd(in, c.m_tuDepth, np) && rd(in, c.m_predMode, np) &&
                   rd(in, c.m_cbf[0], np) && rd(in, c.m_tqBypass, np) && rd(in, c.m_qp, np) && rd(in, c.m_refIdx[0], np) && rd(in, c.m_refIdx[1], np);

@@ -83,11 +83,16 @@ int main(int argc, char** argv)
     FrameData* fd = frame.m_encData = new FrameData;
     fd->m_slice = new Slice; fd->m_slice->m_sliceType = P_SLICE;
     fd->m_picCTU = new CUData[sps.numCUsInFrame];
+    /* X265REF_SLICE_ROWS=r1,r2,...: CTU rows that begin a slice (--slices; CUData::initCTU's firstRowInSlice / lastRowInSlice, cudata.cpp:290-291) */
+    std::vector<char> sliceStart(sps.numCuInHeight + 1, 0);
+    if (const char* e = getenv("X265REF_SLICE_ROWS"))
+        for (const char* q = e; *q; ) { char* end; long r = strtol(q, &end, 10); if (end == q) break; if (r > 0 && r < (long)sps.numCuInHeight) sliceStart[r] = 1; q = *end ? end + 1 : end; }
     for (uint32_t a = 0; a < sps.numCUsInFrame; a++)
     {
         CUData& c = fd->m_picCTU[a];
         c.m_cuPelX = (a % sps.numCuInWidth) * ctu; c.m_cuPelY = (a / sps.numCuInWidth) * ctu;
-        c.m_bFirstRowInSlice = a < sps.numCuInWidth; c.m_bLastRowInSlice = a >= sps.numCUsInFrame - sps.numCuInWidth;
+        const uint32_t row = a / sps.numCuInWidth;
+        c.m_bFirstRowInSlice = row == 0 || sliceStart[row]; c.m_bLastRowInSlice = row == sps.numCuInHeight - 1 || sliceStart[row + 1];
     }
     SaoX sao;
     if (!sao.create(p, 1)) { fprintf(stderr, "SAO::create failed\n"); return 2; }

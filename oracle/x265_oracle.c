@@ -890,13 +890,20 @@ void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t s
  * of a CTU each offset class counts (the rows / columns the deblocking of the neighbours has not finalised are skipped: skipB / skipR),
  * composed from the primitives above.  out: per CTU [2][5][32] = offsetOrg then count, types in the order SAO_EO_0..3, SAO_BO. */
 void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out)
+{
+    xo_sao_stats_frame_slices(fenc, recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out, NULL);
+}
+/* --slices: sliceFirstRow[r] != 0 where CTU row r begins a slice (CUData::m_bFirstRowInSlice of its CTUs; m_bLastRowInSlice of the row before it): sao.cpp:744-746, 763-766 */
+void xo_sao_stats_frame_slices(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
+                               const uint8_t* sliceFirstRow)
 {   /* chroma planes: pass the PLANE's width / height / CTU size (already shifted, :748-756) and planeOffset = 2 (:773) */
     const int po = planeOffset;
     const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
     for (int addr = 0; addr < nx * ny; addr++)
     {
         const int lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;
-        const int firstRow = addr < nx, lastRow = addr >= nx * ny - nx;
+        const int row = addr / nx;
+        const int firstRow = row == 0 || (sliceFirstRow && sliceFirstRow[row]), lastRow = row == ny - 1 || (sliceFirstRow && sliceFirstRow[row + 1]);
         const int bAboveUnavail = (!tpely) | firstRow;
         const int rpelx = lpelx + ctuSize < picWidth ? lpelx + ctuSize : picWidth, bpely = tpely + ctuSize < picHeight ? tpely + ctuSize : picHeight;
         const int ctuWidth = rpelx - lpelx, ctuHeight = bpely - tpely;
@@ -1215,7 +1222,9 @@ void xo_deblock_frame(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo
         for (int uy = 0; uy < uh; uy++)
             for (int ux = 0; ux < uw; ux++)
             {
-                const int bs = xo_deblock_bs(d, ux, uy, dir);
+                int bs = xo_deblock_bs(d, ux, uy, dir);
+                /* --slices: the CTU above the first row of a slice is no neighbour (m_cuAbove = NULL, cudata.cpp:323; CUData::getPUAbove returns NULL and Deblock::setLoopfilterParam leaves the top edge out, deblock.cpp:59-66) */
+                if (dir && d->sliceFirstRow && !(uy % (d->ctuSize / 4)) && d->sliceFirstRow[uy / (d->ctuSize / 4)]) bs = 0;
                 if (bsOut) bsOut[((size_t)dir * uh + uy) * uw + ux] = (uint8_t)bs;
                 if (!bs || ((dir ? uy : ux) & 1)) continue;                             /* edges on the 8x8 grid only (DEBLOCK_SMALLEST_BLOCK) */
                 const uint32_t q = dbk_part(d, ux, uy), p = dir ? dbk_part(d, ux, uy - 1) : dbk_part(d, ux - 1, uy);

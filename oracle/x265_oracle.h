@@ -93,6 +93,8 @@ void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t s
 
 /* SAO::calcSaoStatsCTU, every CTU of one plane of a picture (sao.cpp:729-905; chroma: the plane's own sizes + planeOffset 2); out: per CTU [2][5][32] int32 (offsetOrg, count; EO_0..3, BO) */
 void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out);
+void xo_sao_stats_frame_slices(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
+                               const uint8_t* sliceFirstRow);
 void xo_sao_stats_frame_predeblock(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int planeOffset, int32_t* out);
 
 /* SAO of a luma plane, out of place (sao.cpp:268-623); params: per CTU { typeIdx, bandPos, offset[4] } */
@@ -108,6 +110,7 @@ typedef struct xo_deblock_pic
     const int8_t *qp, *refIdx0, *refIdx1;
     const int32_t *mv0, *mv1;
     int32_t refPic[2][16];
+    const uint8_t* sliceFirstRow;     /* --slices: per CTU row (+ one 0 entry), non-zero where a slice begins; NULL = one slice */
 } xo_deblock_pic;
 int xo_deblock_bs(const xo_deblock_pic* d, int ux, int uy, int dir);
 void xo_deblock_frame(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_pixel* Cb, xo_pixel* Cr, intptr_t strideC, uint8_t* bsOut);

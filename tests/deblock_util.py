@@ -141,7 +141,8 @@ def run_reference(pic):
                 f.write(pic["mv0"][s].tobytes()); f.write(pic["mv1"][s].tobytes())
             f.write(pic["refPic"].tobytes())
         r = subprocess.run([dbk_bin(pic["depth"]), str(pic["W"]), str(pic["H"]), str(pic["ctu"]), inp, out, str(pic["slice_p"]), str(pic["beta_div2"]), str(pic["tc_div2"]),
-                            str(pic["cb_off"]), str(pic["cr_off"]), str(pic["bypass"])], capture_output=True, text=True, timeout=600)
+                            str(pic["cb_off"]), str(pic["cr_off"]), str(pic["bypass"])], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, X265REF_SLICE_ROWS=",".join(str(r) for r in pic.get("slice_rows", ()))))
         assert r.returncode == 0, r.stderr[-2000:]
         d = np.fromfile(out, np.uint16)
     W, H = pic["W"], pic["H"]
@@ -151,7 +152,20 @@ def run_reference(pic):
 class DeblockPic(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("width", "height", "ctuSize", "sliceIsP", "betaOffsetDiv2", "tcOffsetDiv2", "cbQpOffset", "crQpOffset", "tqBypassEnabled")] + \
                [(k, C.c_void_p) for k in ("log2CUSize", "partSize", "tuDepth", "predMode", "cbfLuma", "tqBypass", "qp", "refIdx0", "refIdx1", "mv0", "mv1")] + \
-               [("refPic", C.c_int32 * 32)]
+               [("refPic", C.c_int32 * 32), ("sliceFirstRow", C.c_void_p)]
+
+
+def slice_first_row(pic):
+    """--slices: one byte per CTU row (+ a 0), non-zero where pic["slice_rows"] says a slice begins; None for one slice"""
+    rows = pic.get("slice_rows", ())
+    if not rows:
+        return None
+    n = (pic["H"] + pic["ctu"] - 1) // pic["ctu"]
+    a = np.zeros(n + 1, np.uint8)
+    for r in rows:
+        if 0 < r < n:
+            a[r] = 1
+    return a
 
 
 def descriptor(pic, ptr):
@@ -167,6 +181,9 @@ def run_oracle(ora, pic, want_bs=False):
     planes = [np.ascontiguousarray(p.copy()) for p in pic["planes"]]
     keep = {k: np.ascontiguousarray(pic[k]) for k in U8 + I8 + ("mv0", "mv1")}
     d = descriptor(pic, lambda k: keep[k].ctypes.data)
+    sfr = slice_first_row(pic)
+    if sfr is not None:
+        d.sliceFirstRow = sfr.ctypes.data
     W, H = pic["W"], pic["H"]
     bs = np.zeros((2, H // 4, W // 4), np.uint8)
     P = lambda x: C.c_void_p(x.ctypes.data)

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
 sys.path.insert(0, HERE)
 import x265hip  # noqa: E402,F401  (makes the package importable as x265hip_pkg)
 from oracle_py import Oracle  # noqa: E402
-from deblock_util import I8, U8, coded_picture, descriptor, run_oracle  # noqa: E402
+from deblock_util import slice_first_row, I8, U8, coded_picture, descriptor, run_oracle  # noqa: E402
 from test_deblock_oracle_vs_ref import CASES  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -29,6 +29,10 @@ def hip_deblock(api, pic, pad=(0, 0), time_it=False):
     dev = [api.to_device(b.reshape(-1)) for b in host]
     arrs = {k: api.to_device(np.ascontiguousarray(pic[k]).reshape(-1)) for k in U8 + I8 + ("mv0", "mv1")}
     d = descriptor(pic, lambda k: arrs[k].data_ptr())
+    sfr = slice_first_row(pic)
+    if sfr is not None:
+        d_sfr = api.to_device(sfr)
+        d.sliceFirstRow = d_sfr.data_ptr()
     bs = t.full((2 * (H // 4) * (W // 4),), 7, dtype=t.uint8, device="cuda")
     P = lambda x: C.c_void_p(x.data_ptr())
     call = lambda planes, b: api.lib.x265hip_deblock_frame(api.stream(), C.byref(d), P(planes[0]), C.c_ssize_t(sY), P(planes[1]), P(planes[2]), C.c_ssize_t(sC), b)
@@ -62,6 +66,27 @@ def test_deblock_frame_matches_oracle(depth, W, H, ctu, seed, slice_p, bypass):
     for c in range(3):
         bad = np.argwhere(got[c] != exp[c])
         assert bad.size == 0, "plane %d: %d samples differ, first at (y, x) %s: hip %d oracle %d" % (c, len(bad), bad[0], got[c][tuple(bad[0])], exp[c][tuple(bad[0])])
+
+
+@pytest.mark.parametrize("depth,W,H,ctu,seed,slice_p,bypass,rows", [(8, 136, 200, 64, 11, True, False, (2,)), (8, 200, 152, 32, 12, False, False, (1, 3)), (10, 96, 112, 16, 13, False, True, (2, 3, 6)),
+                                                                     (10, 1920, 1080, 64, 14, True, False, (4, 8, 13))])
+def test_deblock_frame_with_slices_matches_oracle(depth, W, H, ctu, seed, slice_p, bypass, rows):
+    """--slices (x265hip_deblock_pic::sliceFirstRow): the top edge of a slice's first CTU row is left alone; the oracle's form is pinned to the reference's Deblock on CUData
+    objects initialised with the same slice flags (test_deblock_oracle_vs_ref.py)"""
+    from x265hip_pkg.frame import FrameApi
+    api, ora = FrameApi(depth), Oracle(depth)
+    H -= H % 8
+    pic = coded_picture(depth, W, H, ctu, seed, slice_p, bypass)
+    one = run_oracle(ora, pic)
+    pic["slice_rows"] = rows
+    exp, ebs = run_oracle(ora, pic, want_bs=True)
+    assert any(not np.array_equal(a, b) for a, b in zip(one, exp))
+    got, bs = hip_deblock(api, pic, pad=(4, 10))
+    for r in rows:
+        assert not ebs[1][r * ctu // 4].any()
+    for c in range(3):
+        bad = np.argwhere(got[c] != exp[c])
+        assert bad.size == 0, "plane %d: %d samples differ, first at (y, x) %s" % (c, len(bad), bad[0])
 
 
 def test_deblock_frame_refuses_bad_descriptions():

@@ -28,3 +28,20 @@ def test_deblock_frame_matches_reference(depth, W, H, ctu, seed, slice_p, bypass
     for c in range(3):
         bad = np.argwhere(got[c] != ref[c])
         assert bad.size == 0, "plane %d: %d samples differ, first at (y, x) %s: oracle %d reference %d" % (c, len(bad), bad[0], got[c][tuple(bad[0])], ref[c][tuple(bad[0])])
+
+
+@pytest.mark.parametrize("depth,W,H,ctu,seed,slice_p,bypass,rows", [(8, 136, 200, 64, 11, True, False, (2,)), (8, 200, 152, 32, 12, False, False, (1, 3)), (10, 96, 112, 16, 13, False, True, (2, 3, 6)),
+                                                                     (10, 320, 192, 64, 14, True, False, (1, 2))])
+def test_deblock_frame_with_slices_matches_reference(depth, W, H, ctu, seed, slice_p, bypass, rows):
+    """--slices: the CTUs of a slice's first row have no CTU above (CUData::initCTU, cudata.cpp:323): the row's top edge is left alone, luma and chroma"""
+    if not os.path.exists(dbk_bin(depth)):
+        pytest.skip("oracle/_ref/x265deblock_%d not built (needs /root/reference at build time)" % depth)
+    pic = coded_picture(depth, W, H, ctu, seed, slice_p, bypass)
+    one = run_reference(pic)
+    pic["slice_rows"] = rows
+    ref = run_reference(pic)
+    assert any(not np.array_equal(a, b) for a, b in zip(one, ref)), "the slice boundaries changed nothing"
+    got = run_oracle(Oracle(depth), pic)
+    for c in range(3):
+        bad = np.argwhere(got[c] != ref[c])
+        assert bad.size == 0, "plane %d: %d samples differ, first at (y, x) %s" % (c, len(bad), bad[0])

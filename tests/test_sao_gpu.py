@@ -45,6 +45,31 @@ def test_sao_frame_stats_match_oracle(depth, size, ctu, nd, po):
 
 
 @pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu,nd,po,rows", [((200, 200), 64, 0, 0, (2,)), ((192, 128), 32, 0, 0, (1, 3)), ((136, 120), 16, 1, 0, (2, 3, 6)), ((100, 132), 32, 1, 2, (1, 2, 4)),
+                                                 ((1920, 1080), 64, 0, 0, (4, 8, 13)), ((960, 540), 32, 0, 2, (4, 8, 13))])
+def test_sao_frame_stats_with_slices_match_oracle(depth, size, ctu, nd, po, rows):
+    """x265hip_sao_stats_frame_slices: CTU rows that begin a slice (no row above them; the row before counts down to its bottom line) -- the oracle's form is pinned to the
+    reference's SAO class on CTUs carrying the same slice flags (test_sao_oracle_vs_ref.py)"""
+    import ctypes as C
+    from x265hip_pkg.frame import FrameApi
+    from test_sao_oracle_vs_ref import sao_frame_oracle, sao_frame_pair, slice_first_row
+    api = FrameApi(depth)
+    t = api.torch
+    W, H = size
+    fenc, rec = sao_frame_pair(depth, W, H, 270 + depth + W)
+    exp = sao_frame_oracle(Oracle(depth), fenc, rec, ctu, nd, po, rows)
+    assert not np.array_equal(exp, sao_frame_oracle(Oracle(depth), fenc, rec, ctu, nd, po))
+    d_f, d_r, d_s = api.to_device(fenc.reshape(-1)), api.to_device(rec.reshape(-1)), api.to_device(slice_first_row(H, ctu, rows))
+    d_out = t.full((exp.size,), -7, dtype=t.int32, device="cuda")
+    P = lambda x: C.c_void_p(x.data_ptr())  # noqa: E731
+    api.h.check(api.lib.x265hip_sao_stats_frame_slices(api.stream(), P(d_f), P(d_r), C.c_ssize_t(W), W, H, ctu, nd, po, P(d_out), P(d_s)))
+    t.cuda.synchronize()
+    got = d_out.cpu().numpy().reshape(exp.shape)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, "first mismatch (ctu, which, type, class) %s: hip %d oracle %d" % (bad[0], got[tuple(bad[0])], exp[tuple(bad[0])])
+
+
+@pytest.mark.parametrize("depth", [8, 10])
 def test_plane_ssd_matches_oracle(depth):
     """x265hip_plane_ssd = Encoder::computeSSD (the PSNR numerator): exact 64-bit sums, incl. all-extreme planes"""
     import ctypes as C

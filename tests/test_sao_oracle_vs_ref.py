@@ -1,4 +1,6 @@
 """SAO statistics: the oracle restatement against the reference's own primitives (oracle/_ref, op sao_stats)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -20,7 +22,7 @@ def test_sao_stats_match_reference(depth):
         ref.close()
 
 
-def sao_frame_reference(depth, fenc, rec, ctu, non_deblock=0, chroma=None):
+def sao_frame_reference(depth, fenc, rec, ctu, non_deblock=0, chroma=None, slice_rows=()):
     """chroma = [(fencCb, recCb), (fencCr, recCr)] of a 4:2:0 picture -> array [planes, ctus, 2, 5, 32]; luma only -> [ctus, 2, 5, 32]"""
     import os, subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,20 +32,33 @@ def sao_frame_reference(depth, fenc, rec, ctu, non_deblock=0, chroma=None):
         parts = [fenc.reshape(-1), rec.reshape(-1)] + ([a.reshape(-1) for pr in chroma for a in pr] if chroma else [])
         np.concatenate(parts).tofile(inp)
         r = subprocess.run([os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth), str(W), str(H), str(ctu), inp, out, str(non_deblock), "3" if chroma else "1"],
-                           capture_output=True, text=True)
+                           capture_output=True, text=True, env=dict(os.environ, X265REF_SLICE_ROWS=",".join(str(r) for r in slice_rows)))
         assert r.returncode == 0, r.stderr[-1000:]
         o = np.fromfile(out, np.int32)
         return o.reshape(3, -1, 2, 5, 32) if chroma else o.reshape(-1, 2, 5, 32)
 
 
-def sao_frame_oracle(ora, fenc, rec, ctu, non_deblock=0, plane_offset=0):
+def slice_first_row(H, ctu, rows):
+    n = (H + ctu - 1) // ctu
+    a = np.zeros(n + 1, np.uint8)
+    for r in rows:
+        if 0 < r < n:
+            a[r] = 1
+    return a
+
+
+def sao_frame_oracle(ora, fenc, rec, ctu, non_deblock=0, plane_offset=0, slice_rows=()):
     import ctypes as C
     H, W = fenc.shape
     n = ((W + ctu - 1) // ctu) * ((H + ctu - 1) // ctu)
     out = np.zeros((n, 2, 5, 32), np.int32)
     P = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
     f, r = np.ascontiguousarray(fenc), np.ascontiguousarray(rec)
-    ora.lib.xo_sao_stats_frame(P(f), P(r), C.c_ssize_t(W), W, H, ctu, non_deblock, plane_offset, P(out))
+    if slice_rows:
+        sfr = slice_first_row(H, ctu, slice_rows)
+        ora.lib.xo_sao_stats_frame_slices(P(f), P(r), C.c_ssize_t(W), W, H, ctu, non_deblock, plane_offset, P(out), P(sfr))
+    else:
+        ora.lib.xo_sao_stats_frame(P(f), P(r), C.c_ssize_t(W), W, H, ctu, non_deblock, plane_offset, P(out))
     return out
 
 
@@ -86,6 +101,26 @@ def test_sao_frame_stats_chroma_match_reference(depth, size, ctu, nd):
     a = sao_frame_reference(depth, y[0], y[1], ctu, nd, chroma=[cb, cr])
     ora = Oracle(depth)
     exp = [sao_frame_oracle(ora, y[0], y[1], ctu, nd, 0), sao_frame_oracle(ora, cb[0], cb[1], ctu // 2, nd, 2), sao_frame_oracle(ora, cr[0], cr[1], ctu // 2, nd, 2)]
+    for plane in range(3):
+        assert np.array_equal(a[plane], exp[plane]), "plane %d" % plane
+
+
+@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("size,ctu,nd,rows", [((200, 200), 64, 0, (2,)), ((192, 128), 32, 0, (1, 3)), ((136, 120), 16, 1, (2, 3, 6)), ((200, 264), 64, 1, (1, 2, 4))])
+def test_sao_frame_stats_with_slices_match_reference(depth, size, ctu, nd, rows):
+    """--slices: no row above the first CTU row of a slice, the last one counts down to its bottom line (m_bFirstRowInSlice / m_bLastRowInSlice, sao.cpp:744-746, 763-766);
+    luma and the two chroma planes"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth)):
+        pytest.skip("no reference SAO binary")
+    W, H = size
+    y = sao_frame_pair(depth, W, H, 17 + depth + W)
+    cb, cr = sao_frame_pair(depth, W // 2, H // 2, 18 + depth + W), sao_frame_pair(depth, W // 2, H // 2, 19 + depth + W)
+    one = sao_frame_reference(depth, y[0], y[1], ctu, nd, chroma=[cb, cr])
+    a = sao_frame_reference(depth, y[0], y[1], ctu, nd, chroma=[cb, cr], slice_rows=rows)
+    assert not np.array_equal(one, a), "the slice boundaries changed nothing"
+    ora = Oracle(depth)
+    exp = [sao_frame_oracle(ora, y[0], y[1], ctu, nd, 0, rows), sao_frame_oracle(ora, cb[0], cb[1], ctu // 2, nd, 2, rows), sao_frame_oracle(ora, cr[0], cr[1], ctu // 2, nd, 2, rows)]
     for plane in range(3):
         assert np.array_equal(a[plane], exp[plane]), "plane %d" % plane
 

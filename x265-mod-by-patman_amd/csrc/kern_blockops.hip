@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(int type, const int16_t*
 // each class counts is a rectangle per type (skipB / skipR keep away from rows / columns the neighbours' deblocking has not finalised).
 // Edge classes accumulate in registers (5 classes x 4 types, compile-time indexed), the 32 bands through LDS atomics (one copy per wavefront).
 __global__ __launch_bounds__(1024) void sao_frame_kernel(const pixel* __restrict__ fenc, const pixel* __restrict__ recon, intptr_t stride, int picWidth, int picHeight,
-                                                        int ctuSize, int nonDeblocked, int po, int32_t* __restrict__ out, int64_t picElems, int64_t outPicInts)
+                                                        int ctuSize, int nonDeblocked, int po, int32_t* __restrict__ out, int64_t picElems, int64_t outPicInts,
+                                                        const uint8_t* __restrict__ sliceFirstRow)
 {
     fenc += blockIdx.z * picElems; recon += blockIdx.z * picElems; out += blockIdx.z * outPicInts;      // picture of a batch (grid z)
     constexpr int NW = 16;                                         // wavefronts of the workgroup: a 64x64 CTU is 4 pixels per thread
@@ -179,8 +180,11 @@ __global__ __launch_bounds__(1024) void sao_frame_kernel(const pixel* __restrict
     __syncthreads();
     const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
     const int addr = blockIdx.x, lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;
-    const bool lastRow = addr >= nx * ny - nx;
-    const int above = (!tpely) | (addr < nx);
+    // --slices: CTU rows that begin a slice (CUData::m_bFirstRowInSlice / m_bLastRowInSlice, sao.cpp:744-746, 763-766): no neighbours above the slice's first row,
+    // the slice's last row counts down to its bottom line like the picture's last row
+    const int row = addr / nx;
+    const bool lastRow = row == ny - 1 || (sliceFirstRow && sliceFirstRow[row + 1]);
+    const int above = (!tpely) | (sliceFirstRow ? (int)(sliceFirstRow[row] != 0) : 0);
     const int rpelx = min(lpelx + ctuSize, picWidth), bpely = min(tpely + ctuSize, picHeight);
     const int cw = rpelx - lpelx, ch = bpely - tpely;
     const int picH = lastRow ? bpely : picHeight;
@@ -528,17 +532,27 @@ extern "C" int x265hip_sao_stats(void* stream, int type, const int16_t* diff, co
     return X265HIP_OK;
 }
 
-extern "C" int x265hip_sao_stats_pictures(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
-                                          int planeOffset, int32_t* out, int nPictures, int64_t pictureElems)
+static int sao_stats_launch(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                            int planeOffset, int32_t* out, int nPictures, int64_t pictureElems, const uint8_t* sliceFirstRow)
 {
     if (!fenc || !recon || !out || picWidth < 1 || picHeight < 1 || (ctuSize != 8 && ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth ||
         (planeOffset != 0 && planeOffset != 2) || nPictures < 1 || nPictures > 65535 || (nPictures > 1 && pictureElems < stride * (intptr_t)picHeight))
     { set_error("sao_stats: bad arguments"); return X265HIP_EARG; }
     const int n = ((picWidth + ctuSize - 1) / ctuSize) * ((picHeight + ctuSize - 1) / ctuSize);
     hipLaunchKernelGGL(sao_frame_kernel, dim3(n, 1, nPictures), dim3(1024), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize,
-                       nonDeblocked, planeOffset, out, pictureElems, (int64_t)n * 320);
+                       nonDeblocked, planeOffset, out, pictureElems, (int64_t)n * 320, sliceFirstRow);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
+}
+extern "C" int x265hip_sao_stats_pictures(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                                          int planeOffset, int32_t* out, int nPictures, int64_t pictureElems)
+{
+    return sao_stats_launch(stream, fenc, recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out, nPictures, pictureElems, nullptr);
+}
+extern "C" int x265hip_sao_stats_frame_slices(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                                              int planeOffset, int32_t* out, const uint8_t* sliceFirstRow)
+{
+    return sao_stats_launch(stream, fenc, recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out, 1, 0, sliceFirstRow);
 }
 extern "C" int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
                                        int planeOffset, int32_t* out)

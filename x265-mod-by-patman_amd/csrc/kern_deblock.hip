@@ -86,6 +86,8 @@ __device__ __forceinline__ void deblock_body(const x265hip_deblock_pic& d, pixel
     const int a = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int ux = DIR ? a : 2 * a, uy = DIR ? 2 * b : b;                               // the 8x8 grid: even units across the edge
     if (ux >= uw || uy >= uh || !(DIR ? uy : ux)) return;
+    // --slices: the CTU above the first row of a slice is not a neighbour (CUData::initCTU: m_cuAbove = NULL, cudata.cpp:323), its top edge is not filtered
+    if (DIR && d.sliceFirstRow && !(uy & ((1 << lgUpc) - 1)) && d.sliceFirstRow[uy >> lgUpc]) return;
     // one round of independent loads: the two units' records and the segment's 4 lines x 8 luma samples (wasted where the strength turns out 0, but a
     // segment that is filtered no longer waits for the records, then the strength inputs, then the samples one round trip after the other)
     const uint32_t q = part_index(ux, uy, lgUpc, nx);

@@ -20,6 +20,7 @@ struct x265hip_ff
     int8_t *qp = nullptr, *refIdx0 = nullptr, *refIdx1 = nullptr;
     int32_t *mv0 = nullptr, *mv1 = nullptr;
     int32_t* stats[3] = {};
+    uint8_t* sliceFirstRow = nullptr; int nrows = 0;   // --slices: device copy of desc.pic.sliceFirstRow (nrows + 1 bytes)
     std::mutex mu;
     std::vector<void*> owned;
     template<class T> int alloc(T*& p, size_t n)
@@ -48,6 +49,8 @@ extern "C" int x265hip_ff_create(x265hip_ctx* ctx, int width, int height, int ct
     if (!rc) rc = f->alloc(f->log2CUSize, n); if (!rc) rc = f->alloc(f->partSize, n); if (!rc) rc = f->alloc(f->tuDepth, n); if (!rc) rc = f->alloc(f->predMode, n);
     if (!rc) rc = f->alloc(f->cbfLuma, n); if (!rc) rc = f->alloc(f->tqBypass, n); if (!rc) rc = f->alloc(f->qp, n); if (!rc) rc = f->alloc(f->refIdx0, n);
     if (!rc) rc = f->alloc(f->refIdx1, n); if (!rc) rc = f->alloc(f->mv0, 2 * n); if (!rc) rc = f->alloc(f->mv1, 2 * n);
+    f->nrows = (height + ctuSize - 1) / ctuSize;
+    if (!rc) rc = f->alloc(f->sliceFirstRow, (size_t)f->nrows + 1);
     if (rc) { x265hip_ff_destroy(f); return rc; }
     *out = f;
     return X265HIP_OK;
@@ -82,6 +85,14 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     auto pitch = [&](int p) { return (size_t)(p ? f->strideC : f->strideY) * sizeof(pixel); };
     auto wbytes = [&](int p) { return (size_t)(p ? f->width / 2 : f->width) * sizeof(pixel); };
     auto rows = [&](int p) { return (size_t)(p ? f->height / 2 : f->height); };
+    // --slices: the rows that begin a slice (a host array like the rest of the description); the entry behind the last row is always 0
+    const uint8_t* sfr = nullptr;
+    if (P.sliceFirstRow)
+    {
+        XH_HIP(hipMemcpyAsync(f->sliceFirstRow, P.sliceFirstRow, (size_t)f->nrows, hipMemcpyHostToDevice, st));
+        XH_HIP(hipMemsetAsync(f->sliceFirstRow + f->nrows, 0, 1, st));
+        sfr = f->sliceFirstRow;
+    }
     for (int p = 0; p < 3; p++)
     {
         XH_HIP(hipMemcpy2DAsync(f->recon[p], pitch(p), hostRecon[p], pitch(p), wbytes(p), rows(p), hipMemcpyHostToDevice, st));
@@ -91,6 +102,7 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     if (d->deblock)
     {
         x265hip_deblock_pic D = P;
+        D.sliceFirstRow = sfr;
 #define XF_UP(field, count) XH_HIP(hipMemcpyAsync(f->field, P.field, (count) * sizeof(*P.field), hipMemcpyHostToDevice, st)); D.field = f->field
         XF_UP(log2CUSize, n); XF_UP(partSize, n); XF_UP(tuDepth, n); XF_UP(predMode, n); XF_UP(cbfLuma, n); XF_UP(qp, n); XF_UP(refIdx0, n); XF_UP(mv0, 2 * n);
         if (P.tqBypassEnabled) { XF_UP(tqBypass, n); } else D.tqBypass = nullptr;
@@ -104,8 +116,8 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     {
         if (!((p == 0 && (d->saoStats & 1)) || (p > 0 && (d->saoStats & 2)))) continue;
         // a 4:2:0 chroma plane: its own width / height / CTU size and planeOffset 2 (sao.cpp:748-756, :773)
-        int rc = x265hip_sao_stats_frame(st, f->fenc[p], f->recon[p], p ? f->strideC : f->strideY, p ? f->width / 2 : f->width, p ? f->height / 2 : f->height,
-                                         p ? f->ctu / 2 : f->ctu, d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, f->stats[p]);
+        int rc = x265hip_sao_stats_frame_slices(st, f->fenc[p], f->recon[p], p ? f->strideC : f->strideY, p ? f->width / 2 : f->width, p ? f->height / 2 : f->height,
+                                                p ? f->ctu / 2 : f->ctu, d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, f->stats[p], sfr);
         if (rc) return rc;
         XH_HIP(hipMemcpyAsync(d->stats[p], f->stats[p], (size_t)f->nctu * 320 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     }
