@@ -127,6 +127,6 @@ int main(int argc, char** argv)
         list += item;
     }
     if (failed) return 1;
-    printf("{\"streams\": %zu, \"frames\": %.0f, \"wall_seconds\": %.3f, \"aggregate_fps\": %.3f, \"per_stream\": [%s]}\n", st.size(), frames, wall, frames / wall, list.c_str());
+    printf("{\"streams\": %zu, \"frames\": %.0f, \"wall_seconds\": %.6f, \"aggregate_fps\": %.3f, \"per_stream\": [%s]}\n", st.size(), frames, wall, frames / wall, list.c_str());
     return 0;
 }
