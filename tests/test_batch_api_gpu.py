@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.frame import FrameApi
 from backends import Oracle
@@ -150,7 +152,7 @@ def test_argument_validation_and_empty_batches(env):
     assert lib.x265hip_abi_check(C.c_size_t(18240), depth) == 0 and lib.x265hip_abi_check(C.c_size_t(18240), 12) == -1
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_intra_cost_batch_matches_oracle(depth):
     """x265hip_intra_cost_batch over many CUs of one plane (offset addressing, 64x64 workspace path)."""
     from x265hip_pkg.frame import FrameApi

@@ -5,6 +5,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.frame import ME_TASK, TU_TASK
 from x265hip_pkg.pipeline import pyramid_tasks, LEVELS
@@ -13,7 +15,7 @@ from x265hip_pkg.pipeline import pyramid_tasks, LEVELS
 from x265hip_pkg.host_batch import BatchDesc as Desc      # the ctypes mirror of x265hip_batch_desc (fields beyond the ones given are zero)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("geom", [(128, 64, 2, 96, 5), (256, 192, 3, 96, 4), (1920, 1088, 1, 96, 3), (64, 64, 1, 88, 2)])
 def test_task_lists_equal_the_python_pipeline(depth, geom):
     W, H, F, margin, tu = geom

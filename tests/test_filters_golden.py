@@ -7,6 +7,8 @@ import sys
 import numpy as np
 import pytest
 
+from depths import GOLDEN_DEPTHS
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle")); sys.path.insert(0, HERE)
 from oracle_py import Oracle  # noqa: E402
@@ -25,7 +27,7 @@ def deblock_picture(g):
     return pic
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_oracle_matches_golden_filter_outputs(depth):
     g, ora = golden(depth), Oracle(depth)
     pic = deblock_picture(g); pic["depth"] = depth
@@ -40,7 +42,7 @@ def test_oracle_matches_golden_filter_outputs(depth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_hip_matches_golden_filter_outputs(depth):
     import x265hip  # noqa: F401
     from x265hip_pkg.frame import FrameApi

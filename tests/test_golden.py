@@ -2,12 +2,14 @@
 the oracle (CPU) -- the same fixtures are replayed through the HIP library in test_hip_parity.py."""
 import pytest
 
+from depths import GOLDEN_DEPTHS
+
 from backends import Oracle
 from cases import FAMILIES, run_case, same
 from golden_io import load
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 @pytest.mark.parametrize("family", sorted(FAMILIES))
 def test_oracle_reproduces_golden(depth, family):
     ora = Oracle(depth)

@@ -4,6 +4,8 @@ Bit-exact (integer path): any difference is a failure."""
 import numpy as np
 import pytest
 
+from depths import DEPTHS, GOLDEN_DEPTHS
+
 from backends import Hip, Oracle
 from cases import FAMILIES, run_case, same
 from golden_io import load
@@ -11,7 +13,7 @@ from golden_io import load
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("family", sorted(FAMILIES))
 def test_hip_matches_oracle(depth, family):
     rng = np.random.default_rng(0xBADC0DE + depth)
@@ -25,7 +27,7 @@ def test_hip_matches_oracle(depth, family):
     assert n > 20
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 @pytest.mark.parametrize("family", sorted(FAMILIES))
 def test_hip_reproduces_golden(depth, family):
     hip = Hip(depth)

@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip
 from x265hip_pkg.frame import mvcost_row, mvbits_row, rd_lambda
 from x265hip_pkg.host_batch import HostBatch, LEVELS
@@ -70,7 +72,7 @@ def test_host_batch_matches_oracle(depth, method, subme, refs, rect, streams, am
         hb.close()
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_streams_do_not_change_the_bytes_and_python_plumbing_agrees(depth):
     """pictures are independent: 1, 2, 3 and 5 sub-batches of a 5-picture batch give the same records and coefficients; so does the Python pipeline (torch tensors, one stream)"""
     W, H, F, qp, merange, method, subme = 192, 128, 5, 30, 20, 3, 3
@@ -124,7 +126,7 @@ def test_two_streams_are_joined_when_something_reads_and_one_stream_steps_give_t
     assert all(o == outs[0] for o in outs[1:])
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_launch_forms_give_the_same_bytes_and_a_release_library_refuses_the_experiments(depth):
     """x265hip_batch_set_mode: the 64x64 level with or without its start-stage launch gives the same bytes; the measured-loss forms (fused lower levels, tiled phase
     planes, band-major schedule: profiles/r03_fused_ab.txt, r03_tiled_ab.txt, r03_band_major_ab.txt) exist in experiment builds only (make EXPERIMENTS=1) and a release

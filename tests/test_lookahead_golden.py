@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from depths import GOLDEN_DEPTHS
+
 from backends import Oracle
 from lookahead_util import Geometry, lowres_planes_oracle, oracle_frame_cost, oracle_intra
 
@@ -44,7 +46,7 @@ def replay(z, pre, triples, estimate):
             cache[(b, 1, p1 - b)] = (o["mvs1"], o["mvc1"])
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_oracle_matches_golden(depth):
     ora = Oracle(depth)
     for z, pre, frames, aq, triples in clips(depth):
@@ -60,7 +62,7 @@ def test_oracle_matches_golden(depth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_hip_matches_golden(depth):
     import x265hip  # noqa: F401
     from x265hip_pkg.frame import LA_TASK

@@ -4,6 +4,8 @@ on the device by x265hip_frame_init_lowres + x265hip_extend_pic_border) against 
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.frame import FrameApi, LA_TASK
 from backends import Oracle
@@ -31,7 +33,7 @@ def device_lowres(api, ora, frames, g):
     return d_low
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,aq,shift", [((192, 144), 0, (3, 2)), ((208, 120), 1, (-6, 4)), ((64, 48), 1, (1, 0)), ((32, 16), 0, (1, 1)), ((16, 48), 1, (0, 1)), ((640, 368), 1, (5, -3))])
 def test_lookahead_batch_matches_oracle(depth, size, aq, shift):
     api, ora = FrameApi(depth), Oracle(depth)
@@ -109,7 +111,7 @@ def test_lookahead_batch_matches_oracle(depth, size, aq, shift):
         assert [int(v) for v in sm2[out]] == [o["costEst"], o["costEstAq"], o["intraMbs"]], "totals of " + what
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_cutree_propagate_matches_oracle(depth):
     """x265hip_cutree_propagate on the arrays the lookahead batch left in HBM against the oracle's estimateCUPropagate (pinned to the reference)"""
     from x265hip_pkg.lookahead import LookaheadBatch
@@ -148,7 +150,47 @@ def test_cutree_propagate_matches_oracle(depth):
             assert all(np.array_equal(got[f], prop[f]) for f in untouched)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_lookahead_on_extreme_pictures(depth):
+    """lowres pictures of 0 / PIXEL_MAX blocks (every 8x8 difference 0 or the largest of the depth): the packed SATD of the search and of the finish stage at the limit of
+    its 16-bit lanes (a 4x4 coefficient of 16 * PIXEL_MAX)"""
+    api, ora = FrameApi(depth), Oracle(depth)
+    t = api.torch
+    W, H, N = 208, 136, 3
+    rng = np.random.default_rng(1234 + depth)
+    pm = (1 << depth) - 1
+    dt = np.uint8 if depth == 8 else np.uint16
+    frames = [(np.kron(rng.integers(0, 2, (H // 16 + 1, W // 16 + 1)), np.ones((16, 16), np.int64))[:H, :W] * pm).astype(dt) for _ in range(N)]
+    frames[2] = (pm - frames[1]).astype(dt)                                       # the inverse of its reference
+    g = Geometry(W, H)
+    planes = [lowres_planes_oracle(ora, f, g) for f in frames]
+    d_low = api.to_device(np.stack(planes).reshape(-1))
+    intra = [oracle_intra(ora, planes[f], g, None) for f in range(N)]
+    d_ic = api.to_device(np.stack([i["intraCost"] for i in intra]).reshape(-1))
+    row, half = lookahead_cost_row(ora)
+    d_row = api.to_device(row.view(np.int16))
+    est = [(0, 1, 1), (0, 1, 2), (1, 2, 2)]
+    tasks = np.zeros(len(est), LA_TASK)
+    for i, (p0, b, p1) in enumerate(est):
+        tasks[i]["p0"], tasks[i]["b"], tasks[i]["p1"] = p0, b, p1
+        tasks[i]["doSearch"] = (1, 1 if p1 > b else 0); tasks[i]["mvSlot"] = (2 * i, 2 * i + 1); tasks[i]["outSlot"] = i
+    d_tasks = api.to_device(tasks)
+    d_mvs = t.zeros(2 * len(est) * g.ncu * 2, dtype=t.int16, device="cuda"); d_mvc = t.zeros(2 * len(est) * g.ncu, dtype=t.int32, device="cuda")
+    d_lc = t.zeros(len(est) * g.ncu, dtype=t.int16, device="cuda"); d_rs = t.zeros(len(est) * g.hcu, dtype=t.int32, device="cuda")
+    d_sm = t.zeros(len(est) * 3, dtype=t.int64, device="cuda")
+    api.lookahead_cost_batch(d_low, g.plane_elems, g.stride, g.origin, g.wcu, g.hcu, d_tasks, len(est), d_ic, None, d_row, half, d_mvs, d_mvc, d_lc, d_rs, d_sm)
+    t.cuda.synchronize()
+    mvs = d_mvs.cpu().numpy().reshape(-1, g.ncu * 2).astype(np.int32); mvc = d_mvc.cpu().numpy().reshape(-1, g.ncu)
+    lc = d_lc.cpu().numpy().view(np.uint16).reshape(-1, g.ncu); sm = d_sm.cpu().numpy().reshape(-1, 3)
+    for i, (p0, b, p1) in enumerate(est):
+        o = oracle_frame_cost(ora, planes[b], planes[p0], planes[p1] if p1 > b else None, g, intra[b]["intraCost"], None, {}, (1, 1))
+        assert np.array_equal(mvs[2 * i], o["mvs0"]) and np.array_equal(mvc[2 * i], o["mvc0"]) and np.array_equal(lc[i], o["lowresCosts"]), "estimate %s" % (est[i],)
+        if p1 > b:
+            assert np.array_equal(mvs[2 * i + 1], o["mvs1"]) and np.array_equal(mvc[2 * i + 1], o["mvc1"])
+        assert [int(v) for v in sm[i]] == [o["costEst"], o["costEstAq"], o["intraMbs"]]
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_lookahead_weighted_list0_reference(depth):
     """x265hip_la_task.weighted0: list 0 searched in a weighted copy of p0 (an extra picture of the lowres buffer), the bidirectional average in p0 itself"""
     api, ora = FrameApi(depth), Oracle(depth)
@@ -189,7 +231,7 @@ def test_lookahead_weighted_list0_reference(depth):
         assert [int(v) for v in sm[i]] == [o["costEst"], o["costEstAq"], o["intraMbs"]]
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,rows", [((208, 184), 5), ((320, 256), 10), ((192, 144), 3), ((192, 144), 9)])
 def test_lookahead_slices_match_oracle(depth, size, rows):
     """cooperative lookahead slices (rowsPerSlice): every slice swept by its own workgroup"""
@@ -215,7 +257,7 @@ def test_lookahead_slices_match_oracle(depth, size, rows):
         assert [int(v) for v in sm[i]] == [o["costEst"], o["costEstAq"], o["intraMbs"]]
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_cutree_finish_matches_oracle(depth):
     """x265hip_cutree_finish (Lookahead::cuTreeFinish) against the oracle, which equals the reference's doubles exactly on the CPU (test_lookahead_oracle_vs_ref.py).
     The integer part is exact; the device's log2 is allowed 1e-12 against the host's (stated tolerance: float accounting, the one place it applies in this path)."""
@@ -245,7 +287,7 @@ def test_cutree_finish_matches_oracle(depth):
 
 
 # --hme: (method of the quarter-resolution level, method of the half-resolution level, their ranges); 0 = diamond, 1 = hexagon, 2 = uneven multi-hexagon, 3 = star, 5 = exhaustive (the reference's default: hex, umh, 16, 32)
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,aq,shift,hme", [((192, 144), 0, (3, 2), (1, 2, 16, 32)), ((208, 120), 1, (-6, 4), (2, 2, 16, 32)), ((320, 176), 1, (12, -8), (1, 1, 8, 12)),
                                                ((136, 72), 0, (-5, 9), (2, 1, 24, 48)), ((64, 48), 1, (1, 0), (1, 2, 16, 32)), ((960, 544), 1, (14, -6), (1, 2, 16, 32)),
                                                # diamond (0) and exhaustive (5) levels

@@ -5,6 +5,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 from backends import Oracle
 from lookahead_util import (Geometry, la_available, lowerres_planes_oracle, lowres_planes_oracle, oracle_frame_cost, oracle_intra, oracle_propagate, run_reference, synth_clip)
 
@@ -12,7 +14,7 @@ from lookahead_util import (Geometry, la_available, lowerres_planes_oracle, lowr
 TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3, 0), (0, 2, 3, 1), (0, 3, 3, 0), (0, 1, 3, 0)]
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,aq,shift", [((192, 144), 0, (3, 2)), ((208, 120), 1, (-6, 4)), ((64, 48), 1, (1, 0)), ((32, 16), 0, (1, 1)), ((16, 48), 1, (0, 1))])
 def test_lookahead_cost_matches_reference(depth, size, aq, shift):
     if not la_available(depth):
@@ -71,7 +73,7 @@ def _PD(a):
     return C.c_void_p(a.ctypes.data)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,shift", [((192, 144), (3, 2)), ((208, 120), (-9, 7)), ((64, 48), (1, 0))])
 def test_cutree_propagate_matches_reference(depth, size, shift):
     if not la_available(depth):
@@ -120,7 +122,7 @@ def fade_clip(W, H, n, depth, seed):
 WP_TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 1, 2, 0), (1, 2, 3, 0), (0, 3, 3, 0), (1, 3, 3, 0)]
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size", [(192, 144), (208, 120)])
 def test_lookahead_cost_with_weighted_reference_matches_reference(depth, size):
     """--weightp (on by default): P and B estimates whose list-0 search runs in the weighted copy of p0 the reference built"""
@@ -146,7 +148,7 @@ def test_lookahead_cost_with_weighted_reference_matches_reference(depth, size):
         assert (norm, o["costEstAq"]) == (rt["costEstNorm"], rt["costEstAq"])
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,rows,aq", [((192, 144), 3, 0), ((208, 184), 5, 1), ((320, 256), 10, 1), ((192, 144), 9, 0)])
 def test_lookahead_cost_with_slices_matches_reference(depth, size, rows, aq):
     """--lookahead-slices: every slice of `rows` block rows is its own reverse sweep (no predictor crosses its lower edge)"""
@@ -179,7 +181,7 @@ def test_lookahead_cost_with_slices_matches_reference(depth, size, rows, aq):
 HME_TRIPLES = [(0, 1, 1, 0), (0, 2, 2, 0), (0, 2, 3, 1), (0, 1, 2, 0), (1, 2, 3, 0), (0, 3, 3, 0), (0, 1, 3, 0)]
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,aq,shift,hme", [((192, 144), 0, (3, 2), (1, 2, 16, 32)), ((208, 120), 1, (-6, 4), (2, 2, 16, 32)), ((320, 176), 1, (12, -8), (1, 1, 8, 12)),
                                                ((136, 72), 0, (-5, 9), (2, 1, 24, 48)), ((64, 48), 1, (1, 0), (1, 2, 16, 32)),
                                                # diamond (0) and exhaustive (5) levels: the exhaustive search of an --hme reference is cut to +-range around the ZERO vector (motion.cpp:1598-1605)

@@ -3,6 +3,8 @@
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.synth import frame_pair
 from x265hip_pkg.frame import FrameApi, ME_TASK, ME_RESULT
@@ -40,7 +42,7 @@ def make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange):
 
 
 @pytest.mark.parametrize("planes", [False, True])
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method", [0, 1, 2, 3, 5])      # DIA, HEX, UMH, STAR, FULL
 def test_me_batch_matches_oracle(depth, method, planes):
     api, ora = FrameApi(depth), Oracle(depth)
@@ -79,11 +81,92 @@ def test_me_batch_matches_oracle(depth, method, planes):
                     w, h, i, method, subme, merange, got, exp, tk["qmvp"])
 
 
+@pytest.mark.parametrize("depth", DEPTHS)
+@pytest.mark.parametrize("method", [1, 3])      # HEX, STAR
+def test_me_batch_on_extreme_pictures(depth, method):
+    """Pictures of 0 / PIXEL_MAX blocks: every difference is 0 or the largest the depth has -- the 16-bit lanes of the packed Hadamard transforms, the cost keys of the
+    64x64 search and the sums of the sub-pel stage at their limits (a 64x64 SAD of 4096 * PIXEL_MAX, 4x4 coefficients of 16 * PIXEL_MAX)"""
+    api, ora = FrameApi(depth), Oracle(depth)
+    rng = np.random.default_rng(990 + depth + method)
+    W, H, margin = 320, 192, 96
+    half = 1 << 13
+    pm = (1 << depth) - 1
+    cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 31, margin=margin, max_shift=6)
+    blocks = lambda b: np.kron(rng.integers(0, 2, (cur.shape[0] // b + 1, cur.shape[1] // b + 1)), np.ones((b, b), np.int64))[:cur.shape[0], :cur.shape[1]] * pm  # noqa: E731
+    cur = blocks(8).astype(cur.dtype); ref = (pm - blocks(4)).astype(ref.dtype)
+    ref[margin + 40:margin + 150, margin + 30:margin + 290] = pm - cur[margin + 40:margin + 150, margin + 30:margin + 290]      # a region where every pixel differs by PIXEL_MAX
+    cur_f, ref_f = np.ascontiguousarray(cur).reshape(-1), np.ascontiguousarray(ref).reshape(-1)
+    d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+    pe = cur_f.size
+    d_pl = api.torch.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
+    api.subpel_planes(d_ref, stride, cur.shape[0], d_pl, pe)
+    for (w, h) in [(64, 64), (32, 32), (16, 16), (8, 8), (64, 32), (16, 32), (8, 4), (12, 16)]:
+        for subme in (2, 4):
+            merange, qp = 16, 51
+            n = 12
+            tasks = make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange)
+            row = ora.mvcost_row(qp, half)
+            d_tasks, d_row = api.to_device(tasks), api.to_device(row.view(np.int16))
+            d_res = api.torch.zeros(n * ME_RESULT.itemsize, dtype=api.torch.uint8, device="cuda")
+            api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, merange, method, subme, d_res, planes=d_pl, plane_elems=pe)
+            api.torch.cuda.synchronize()
+            res = d_res.cpu().numpy().view(ME_RESULT)
+            for i in range(n):
+                tk = tasks[i]
+                bounds = [int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])]
+                mvc = [int(v) for v in tk["mvc"][:2 * int(tk["numCand"])]]
+                exp = ora.me(w, h, cur_f, stride, int(tk["curOff"]), ref_f, stride, int(tk["refOff"]), bounds, (int(tk["qmvp"][0]), int(tk["qmvp"][1])), mvc, merange, method, subme, row)
+                got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
+                assert got == exp, "PU %dx%d task %d method %d subme %d: hip %s oracle %s" % (w, h, i, method, subme, got, exp)
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_star_search_from_a_start_outside_the_window(depth):
+    """The zero MV that wins the start stage is clipped in y only (motion.cpp:1000-1003): with a predictor far from zero and a small range the search starts OUTSIDE its
+    window, and the star rounds -- each point tested against the window side it moves towards only (:406-448) -- cost points outside it.  The 64x64 level keeps its window
+    in LDS: such a PU must take the general path (star64_body.inc: startInside).  Pictures that hardly move, predictors 10-18 pixels off, range 8."""
+    api, ora = FrameApi(depth), Oracle(depth)
+    rng = np.random.default_rng(4242 + depth)
+    W, H, margin = 320, 192, 96
+    half = 1 << 13
+    cur, ref, stride, (dx, dy) = frame_pair(W, H, depth, 55, margin=margin, max_shift=1)
+    cur_f, ref_f = cur.reshape(-1), ref.reshape(-1)
+    d_cur, d_ref = api.to_device(cur_f), api.to_device(ref_f)
+    pe = cur_f.size
+    d_pl = api.torch.zeros(16 * pe, dtype=d_ref.dtype, device="cuda")
+    api.subpel_planes(d_ref, stride, cur.shape[0], d_pl, pe)
+    outside = 0
+    for (w, h) in [(64, 64), (32, 32), (16, 16), (64, 32)]:
+        merange, n = 8, 16
+        tasks = make_tasks(rng, W, H, margin, stride, w, h, n, dx, dy, merange)
+        for i in range(n):
+            qmvp = (int(rng.choice([-1, 1])) * int(rng.integers(40, 72)), int(rng.choice([-1, 1])) * int(rng.integers(40, 72)))
+            px = (int(tasks[i]["curOff"]) % stride) - margin; py = int(tasks[i]["curOff"]) // stride - margin
+            fx, fy, lim = qmvp[0] >> 2, qmvp[1] >> 2, margin - 16
+            tasks[i]["qmvp"] = qmvp; tasks[i]["numCand"] = 0
+            tasks[i]["mvmin"] = (max(fx - merange, -px - lim), max(fy - merange, -py - lim))
+            tasks[i]["mvmax"] = (min(fx + merange, W - px - w + lim), min(fy + merange, H - py - h + lim))
+        row = ora.mvcost_row(28, half)
+        d_tasks, d_row = api.to_device(tasks), api.to_device(row.view(np.int16))
+        d_res = api.torch.zeros(n * ME_RESULT.itemsize, dtype=api.torch.uint8, device="cuda")
+        api.me_batch(w, h, d_cur, stride, d_ref, stride, d_tasks, n, d_row, half, merange, 3, 2, d_res, planes=d_pl, plane_elems=pe)
+        api.torch.cuda.synchronize()
+        res = d_res.cpu().numpy().view(ME_RESULT)
+        for i in range(n):
+            tk = tasks[i]
+            bounds = [int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])]
+            exp = ora.me(w, h, cur_f, stride, int(tk["curOff"]), ref_f, stride, int(tk["refOff"]), bounds, (int(tk["qmvp"][0]), int(tk["qmvp"][1])), [], merange, 3, 2, row)
+            got = (int(res[i]["mv"][0]), int(res[i]["mv"][1]), int(res[i]["cost"]))
+            assert got == exp, "PU %dx%d task %d: hip %s oracle %s (mvp %s window %s)" % (w, h, i, got, exp, tk["qmvp"], bounds)
+            outside += not (bounds[0] <= 0 <= bounds[2])
+    assert outside > 40
+
+
 SEA_UNDEFINED = {(8, 4), (4, 8), (8, 32), (32, 8)}      # the reference's own result is not a function of the inputs (see test_me_oracle_vs_ref.py)
 
 
 @pytest.mark.parametrize("planes", [False, True])
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_me_batch_sea_matches_oracle(depth, planes):
     """SEA: integral planes built on the device (x265hip_sea_integral_planes) + x265hip_me_batch_sea against the oracle"""
     api, ora = FrameApi(depth), Oracle(depth)
@@ -132,7 +215,7 @@ def test_me_batch_sea_matches_oracle(depth, planes):
             assert got_i == exp, "SEA PU %dx%d task %d subme %d merange %d: hip %s oracle %s (mvp %s)" % (w, h, i, subme, merange, got_i, exp, tk["qmvp"])
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method", [1, 3])               # HEX, STAR (with its raster over the whole +-128 window)
 def test_me_batch_merange_128(depth, method):
     """BASELINE configs[4] searches with --merange 128: MVDs reach the edge of (and leave) the +-512 quarter-pel cost slice the kernels keep
@@ -225,7 +308,7 @@ def test_me_batch_plane_buffer_beyond_4gb():
             assert got == exp, ">4GB planes: PU %dx%d task %d: hip %s oracle %s" % (w, h, i, got, exp)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method", [0, 1, 3, 5])        # DIA, HEX, STAR, FULL
 def test_me_batch_chroma_matches_oracle(depth, method):
     """x265hip_me_batch_chroma (the predInterSearch call form: chroma SATD terms in every sub-pel cost, motion.cpp:1805-1865) against the oracle, which
@@ -275,7 +358,7 @@ def test_me_batch_chroma_matches_oracle(depth, method):
             assert got == exp, "chroma: PU %dx%d task %d method %d subme %d merange %d: hip %s oracle %s (mvp %s)" % (w, h, i, method, subme, merange, got, exp, tk["qmvp"])
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method", [1, 3])
 def test_me_batch_cost_row_per_task(depth, method):
     """X265HIP_ME_ROWS: PUs of CUs with different qps in one launch -- every task names its row of a cost table; the results must be those of the oracle searching

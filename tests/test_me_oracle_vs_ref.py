@@ -3,6 +3,8 @@ MotionEstimate::motionEstimate + BitCost (encoder/motion.cpp, bitcost.cpp, compi
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401  (makes the package importable as x265hip_pkg)
 from x265hip_pkg.synth import frame_pair
 from backends import Oracle, Ref, ref_available
@@ -11,7 +13,7 @@ PUS = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 16), (16, 32
        (16, 4), (4, 16), (32, 24), (24, 32), (32, 8), (8, 32), (64, 48), (48, 64), (64, 16), (16, 64), (8, 4), (4, 8)]
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_lambda_and_mvcost_tables(depth):
     if not ref_available(depth):
         pytest.skip("no reference binary")
@@ -30,7 +32,7 @@ def test_lambda_and_mvcost_tables(depth):
 SEA_UNDEFINED = {(8, 4), (4, 8), (8, 32), (32, 8)}
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method", [0, 1, 2, 3, 4, 5])      # DIA, HEX, UMH, STAR, SEA, FULL
 def test_motion_estimate_matches_reference(depth, method):
     if not ref_available(depth):
@@ -85,7 +87,7 @@ def test_motion_estimate_matches_reference(depth, method):
     assert n >= 70
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_library_cost_row_matches_oracle_and_reference(depth):
     """x265hip_mvcost_row is host code of the PRODUCT (no GPU needed): it must reproduce BitCost::setQP."""
     from x265hip_pkg.frame import mvcost_row

@@ -4,6 +4,8 @@ predictions at SATD, and its zero-MV form) and the final choice."""
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.frame import FrameApi, ME_TASK, ME_RESULT, INTER_CHOICE, mvcost_row, mvbits_row, rd_lambda
 from x265hip_pkg.synth import frame_pair
@@ -12,7 +14,7 @@ from backends import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("nref", [(3, 0), (2, 2), (1, 1), (4, 3)])
 def test_merge_matches_oracle(depth, nref):
     api, ora = FrameApi(depth), Oracle(depth)

@@ -3,13 +3,15 @@ RDCost::getCost of the oracle and of the library's host helpers against the refe
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.frame import mvbits_row, rd_lambda
 from backends import Oracle
 from refproc import RefProc, ref_available
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_bit_sizes_and_rd_lambda_match_the_reference(depth):
     ora = Oracle(depth)
     half = 1 << 12

@@ -3,11 +3,13 @@
 import numpy as np
 import pytest
 
+from depths import DEPTHS, GOLDEN_DEPTHS
+
 from backends import Oracle, Ref, ref_available
 from cases import FAMILIES, run_case, same
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("family", sorted(FAMILIES))
 def test_oracle_matches_reference(depth, family):
     if not ref_available(depth):
@@ -26,7 +28,7 @@ def test_oracle_matches_reference(depth, family):
     assert n > 20
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_dct_matrices_are_the_reference_tables(depth):
     if not ref_available(depth):
         pytest.skip("no reference binary")
@@ -38,7 +40,7 @@ def test_dct_matrices_are_the_reference_tables(depth):
         ref.close()
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_known_answers_from_survey(depth):
     """values captured from the real reference build during the survey."""
     ora = Oracle(depth)

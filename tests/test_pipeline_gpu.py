@@ -3,6 +3,8 @@ bench's full 1080p size -- size-independent properties plus a random sample agai
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.frame import mvcost_row
 from x265hip_pkg.pipeline import FramePipeline, LEVELS
@@ -14,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("planes", [True, False])
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method,subme,tu", [(1, 2, 5), (3, 3, 4), (0, 0, 3), (1, 7, 2)])
 def test_small_frames_match_oracle(depth, method, subme, tu, planes):
     row = mvcost_row(depth, 28, 1 << 15)
@@ -112,7 +114,7 @@ def test_full_size_8k_10bit_slower_merange_128():
     _full_size(10, 7680, 4352, 3, 4, 128, pair0, 0.7)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_phase_planes_equal_the_interpolation_primitives(depth):
     """x265hip_subpel_planes: every phase plane equals luma_hpp / luma_vpp / luma_hvpp of the oracle, block by block."""
     from x265hip_pkg.frame import FrameApi
@@ -140,7 +142,7 @@ def test_phase_planes_equal_the_interpolation_primitives(depth):
             assert np.array_equal(pl[f, y:y + h, x:x + w], exp), "phase (%d,%d) block %dx%d at (%d,%d)" % (xf, yf, w, h, x, y)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_reconstruction_becomes_the_next_reference_on_device(depth):
     """TQ recon -> extendPicBorder -> phase planes, all in HBM, equals the oracle's chain on the host copy."""
     from x265hip_pkg.frame import FrameApi
@@ -208,7 +210,7 @@ def test_several_references_match_oracle(depth, method, subme, refs):
     assert len(chosen) >= 2, "the clip should make more than one reference win: %s" % chosen
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("method,subme", [(1, 2), (3, 3)])
 def test_rectangular_partitions_match_oracle(depth, method, subme):
     """param bEnableRectInter (preset slow and up): the 2NxN / Nx2N PUs of every CU of the pyramid (64x32 ... 4x8, 425 PUs per CTU with the squares), each

@@ -7,6 +7,8 @@ import sys
 import numpy as np
 import pytest
 
+from depths import DEPTHS, GOLDEN_DEPTHS
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -61,7 +63,7 @@ def picture_pair(depth, W, H, seed, kind):
     return np.clip((src + step // 2) // step * step + rng.integers(-2, 3, (H, W)), 0, pm), src          # a coarsely quantised reconstruction
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("W,H,ctu,kind", [(1920, 1080, 64, "coded"), (136, 72, 64, "coded"), (200, 152, 32, "random"), (136, 104, 16, "coded"), (64, 64, 64, "extreme"),
                                           (10, 10, 16, "random"), (4096, 40, 32, "random"), (333, 259, 64, "coded")])
 def test_ssim_frame_matches_oracle(depth, W, H, ctu, kind):
@@ -75,7 +77,7 @@ def test_ssim_frame_matches_oracle(depth, W, H, ctu, kind):
     assert tot == etot
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_ssim_frame_matches_the_encoders_reported_ssim(depth):
     """committed fixtures: pictures the reference encoder reconstructed, with the SSIM it reported"""
     from x265hip_pkg.frame import FrameApi

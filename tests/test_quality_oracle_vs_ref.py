@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import pytest
 
+from depths import DEPTHS, GOLDEN_DEPTHS
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -83,7 +85,7 @@ def golden_pictures(depth):
                                 rec=[g["rec%d_%d" % (i, c)] for c in range(3)]) for i in range(n)]
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_ssim_oracle_matches_golden_encoder_statistics(depth):
     """the same check on the committed fixtures (tests/make_golden_quality.py): runs where /root/reference is absent"""
     ora = Oracle(depth)

@@ -3,6 +3,8 @@ primitives by test_sao_oracle_vs_ref.py): class sums, counts and the sign buffer
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip
 from backends import Oracle
 from sao_util import cases, run_hip, run_oracle
@@ -10,7 +12,7 @@ from sao_util import cases, run_hip, run_oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_sao_stats_slots_match_oracle(depth):
     lib, ora = x265hip.HipLib(depth), Oracle(depth)
     for i, c in enumerate(cases(depth, 900 + depth, n=100)):
@@ -19,7 +21,7 @@ def test_sao_stats_slots_match_oracle(depth):
             assert np.array_equal(x, y), "case %d type %d endX %d endY %d: %s" % (i, c[0], c[5], c[6], what)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu,nd,po", [((200, 136), 64, 0, 0), ((192, 128), 64, 0, 0), ((72, 40), 32, 0, 0), ((130, 70), 16, 0, 0), ((200, 136), 64, 1, 0),
                                             ((64, 64), 64, 0, 0), ((1920, 1080), 64, 0, 0), ((100, 68), 32, 0, 2), ((960, 540), 32, 1, 2), ((36, 20), 8, 0, 2),
                                             ((200, 136), 64, 2, 0), ((1920, 1080), 64, 2, 0), ((130, 70), 16, 2, 0), ((960, 540), 32, 2, 2), ((100, 68), 32, 2, 2), ((64, 64), 64, 2, 0)])
@@ -44,7 +46,7 @@ def test_sao_frame_stats_match_oracle(depth, size, ctu, nd, po):
     assert bad.size == 0, "first mismatch (ctu, which, type, class) %s: hip %d oracle %d" % (bad[0], got[tuple(bad[0])], exp[tuple(bad[0])])
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu,nd,po,rows", [((200, 200), 64, 0, 0, (2,)), ((192, 128), 32, 0, 0, (1, 3)), ((136, 120), 16, 1, 0, (2, 3, 6)), ((100, 132), 32, 1, 2, (1, 2, 4)),
                                                  ((1920, 1080), 64, 0, 0, (4, 8, 13)), ((960, 540), 32, 0, 2, (4, 8, 13))])
 def test_sao_frame_stats_with_slices_match_oracle(depth, size, ctu, nd, po, rows):
@@ -69,7 +71,7 @@ def test_sao_frame_stats_with_slices_match_oracle(depth, size, ctu, nd, po, rows
     assert bad.size == 0, "first mismatch (ctu, which, type, class) %s: hip %d oracle %d" % (bad[0], got[tuple(bad[0])], exp[tuple(bad[0])])
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_plane_ssd_matches_oracle(depth):
     """x265hip_plane_ssd = Encoder::computeSSD (the PSNR numerator): exact 64-bit sums, incl. all-extreme planes"""
     import ctypes as C
@@ -92,7 +94,7 @@ def test_plane_ssd_matches_oracle(depth):
         assert int(d_o.cpu().numpy().view(np.uint64)[0]) == exp, (W, H)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((72, 40), 32), ((130, 70), 16), ((64, 64), 64), ((1920, 1080), 64), ((3, 5), 16)])
 def test_sao_apply_frame_matches_oracle(depth, size, ctu):
     """x265hip_sao_apply_frame against the oracle (pinned to the reference's in-place SAO::generateLumaOffsets sequence)"""
@@ -126,7 +128,7 @@ def test_sao_apply_frame_matches_oracle(depth, size, ctu):
         print("sao_apply %d bit %dx%d: %.4f ms, %.0f GB/s algorithmic (plane read + written)" % (depth, W, H, ms, 2 * W * H * rec.itemsize / ms / 1e6))
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((72, 40), 32), ((136, 72), 16), ((1920, 1080), 64)])
 def test_sao_apply_chroma_planes_match_oracle(depth, size, ctu):
     """Cb / Cr of a 4:2:0 picture = x265hip_sao_apply_frame on the chroma plane with its dimensions and CTU size (oracle pinned to generateChromaOffsets)"""

@@ -4,11 +4,13 @@ import os
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 from backends import Oracle, Ref, ref_available
 from sao_util import cases, run_oracle, run_ref
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_sao_stats_match_reference(depth):
     if not ref_available(depth):
         pytest.skip("no reference binary")
@@ -72,7 +74,7 @@ def sao_frame_pair(depth, W, H, seed):
     return np.clip(fenc, 0, pm).astype(dt), np.clip(rec, 0, pm).astype(dt)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu,nd", [((200, 136), 64, 0), ((192, 128), 64, 0), ((72, 40), 32, 0), ((130, 70), 16, 0), ((200, 136), 64, 1), ((64, 64), 64, 0)])
 def test_sao_frame_stats_match_reference(depth, size, ctu, nd):
     import os
@@ -88,7 +90,7 @@ def test_sao_frame_stats_match_reference(depth, size, ctu, nd):
             assert np.array_equal(a[addr, :, t], b[addr, :, t]), "CTU %d type %d" % (addr, t)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu,nd", [((200, 136), 64, 0), ((192, 128), 64, 1), ((72, 40), 32, 0), ((136, 72), 16, 0)])
 def test_sao_frame_stats_chroma_match_reference(depth, size, ctu, nd):
     import os
@@ -105,7 +107,7 @@ def test_sao_frame_stats_chroma_match_reference(depth, size, ctu, nd):
         assert np.array_equal(a[plane], exp[plane]), "plane %d" % plane
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu,nd,rows", [((200, 200), 64, 0, (2,)), ((192, 128), 32, 0, (1, 3)), ((136, 120), 16, 1, (2, 3, 6)), ((200, 264), 64, 1, (1, 2, 4))])
 def test_sao_frame_stats_with_slices_match_reference(depth, size, ctu, nd, rows):
     """--slices: no row above the first CTU row of a slice, the last one counts down to its bottom line (m_bFirstRowInSlice / m_bLastRowInSlice, sao.cpp:744-746, 763-766);
@@ -159,7 +161,7 @@ def sao_apply_oracle(ora, rec, ctu, params):
     return dst
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((192, 128), 64), ((72, 40), 32), ((130, 70), 16), ((64, 64), 64), ((256, 64), 32)])
 def test_sao_apply_frame_matches_reference(depth, size, ctu):
     import os
@@ -191,7 +193,7 @@ def sao_apply_reference_420(depth, planes, ctu, params3):
     return [d[:W * H].reshape(H, W), d[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), d[W * H + W * H // 4:].reshape(H // 2, W // 2)]
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((192, 128), 64), ((72, 40), 32), ((136, 72), 16)])
 def test_sao_apply_chroma_matches_reference(depth, size, ctu):
     """Cb / Cr through SAO::generateChromaOffsets (sao.cpp:626-730) = the plane-level restatement called with the chroma plane's dimensions and CTU size"""
@@ -232,7 +234,7 @@ def sao_frame_oracle_pre(ora, fenc, rec, ctu, plane_offset=0):
     return out
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("size,ctu", [((200, 136), 64), ((192, 128), 64), ((72, 40), 32), ((136, 72), 16), ((64, 64), 64)])
 def test_sao_predeblock_stats_match_reference(depth, size, ctu):
     """SAO::calcSaoStatsCu_BeforeDblk (sao.cpp:908-1207): the border statistics on the not yet deblocked picture, luma and 4:2:0 chroma, against the

@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip
 from backends import Oracle
 
@@ -17,7 +19,7 @@ def ptr(a, off=0):
     return C.c_void_p(a.ctypes.data + off * a.itemsize)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_cutree_row_slots(depth):
     lib, ora = x265hip.HipLib(depth), Oracle(depth)
     rng = np.random.default_rng(depth)
@@ -42,7 +44,7 @@ def test_cutree_row_slots(depth):
     assert np.array_equal(back, q.view(np.int16).astype(np.float64) / 256.0)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_integral_row_slots_build_the_oracle_planes(depth):
     """drive the 12 slots the way FrameFilter::processPostRow does (framefilter.cpp:757-833) on a small padded picture"""
     lib, ora = x265hip.HipLib(depth), Oracle(depth)

@@ -3,11 +3,13 @@ made (Search::puMotionEstimation's window, predictor and candidate lists; fixtur
 import numpy as np
 import pytest
 
+from depths import GOLDEN_DEPTHS
+
 from backends import Oracle
 from tme_util import TmeFixture
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_oracle_replays_the_threaded_me_calls_of_a_reference_encode(depth):
     fx, ora = TmeFixture(depth), Oracle(depth)
     assert len(fx) > 1500
@@ -31,7 +33,7 @@ def test_oracle_replays_the_threaded_me_calls_of_a_reference_encode(depth):
     assert n == len(fx)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_oracle_replays_the_chroma_satd_searches_of_a_reference_encode(depth):
     """Search::predInterSearch's call form (the Yuv overload of setSourcePU with bChroma, search.cpp:2582): at subme 3 / 4 every sub-pel cost carries
     the SATD of the Cb and Cr predictions (motion.cpp:1805-1865).  Fixtures: a regular (not threaded-me) encode, P and B pictures, up to 12 candidates."""
@@ -55,7 +57,7 @@ def test_oracle_replays_the_chroma_satd_searches_of_a_reference_encode(depth):
         assert got == exp, "call %d (%dx%d, subme %d): oracle %s reference %s" % (i, w, h, int(c["subme"][i]), got, exp)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_oracle_replays_the_diamond_searches_of_a_reference_encode(depth):
     """MotionEstimate::diamondSearch (motion.cpp:631-773), the predictor stage of ThreadedME (search.cpp:355-363): every recorded call, including the
     second loop's positions that COST_MV_X4 offsets twice (xo_diamond_search's header)."""
@@ -96,7 +98,7 @@ def test_oracle_replays_the_get_pmv_calls_of_reference_encodes():
     assert scaled > 1000
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_oracle_replays_select_check_update_mvp(depth):
     """Search::selectMVP, checkBestMVP, updateMVP (search.cpp:2347-2382, 4947-4967) on the records of a --threaded-me encode"""
     from tme_util import MvpSelFixture, u32, lam64
@@ -114,7 +116,7 @@ def test_oracle_replays_select_check_update_mvp(depth):
         assert got == (u32(r[10]), u32(r[11]))
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_whole_pu_motion_estimation_calls_replay_to_the_references_medata(depth):
     """SURVEY 8(f1), one level up from the single functions: whole Search::puMotionEstimation calls of ThreadedME's PU stage (search.cpp:226-556; 2Nx2N, 2NxN and
     Nx2N partitions, P and B pictures, two references per list) -- the neighbour records of the CTU's table, AMVP, the choice of the predictor, the lookahead's MV as

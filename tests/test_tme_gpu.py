@@ -4,6 +4,8 @@ through x265hip_me_batch: the MV, the cost and the MV cost must be the reference
 import numpy as np
 import pytest
 
+from depths import DEPTHS, GOLDEN_DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.frame import FrameApi, ME_TASK, ME_RESULT, mvcost_row
 from tme_util import TmeFixture
@@ -12,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("planes", [True, False])
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_me_batch_replays_the_threaded_me_task_list(depth, planes):
     fx, api = TmeFixture(depth), FrameApi(depth)
     T = api.torch
@@ -52,7 +54,7 @@ def test_me_batch_replays_the_threaded_me_task_list(depth, planes):
     assert checked > 600
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_me_batch_chroma_replays_the_searches_of_pred_inter_search(depth):
     """The predInterSearch call form: chroma SATD terms in every sub-pel cost (subme 3 / 4, 4:2:0).  Fixtures from a regular reference encode
     (P and B pictures, several references, up to 12 candidates): x265hip_me_batch_chroma must return the reference's MV, cost and MV cost."""
@@ -100,7 +102,7 @@ def test_me_batch_chroma_replays_the_searches_of_pred_inter_search(depth):
     assert checked == len(fx)
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_diamond_batch_replays_the_predictor_searches_of_threaded_me(depth):
     """MotionEstimate::diamondSearch (motion.cpp:631-773): the recorded calls of ThreadedME's first stage (the CTU and its four sub-CUs, range 32)
     through x265hip_diamond_batch -- full-pel MV and cost must be the reference's; plus synthetic windows cut by the picture edge (the per-point
@@ -190,7 +192,7 @@ def test_amvp_batch_replays_the_get_pmv_calls_of_reference_encodes():
     assert checked == len(rows) >= 20000
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_select_mvp_and_mvp_bits_replay_the_reference_records(depth):
     """x265hip_select_mvp_batch against the recorded Search::selectMVP calls (index; the two SADs against the oracle's), x265hip_mvp_bits_batch against the
     recorded checkBestMVP and updateMVP calls."""
@@ -255,7 +257,7 @@ def test_select_mvp_and_mvp_bits_replay_the_reference_records(depth):
                 assert np.array_equal(o["mvpIdx"], R[:, 11]) and np.array_equal(o["bits"], R[:, 12].astype(np.uint32)) and np.array_equal(o["cost"], R[:, 13].astype(np.uint32))
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_whole_pu_motion_estimation_calls_through_the_hip_entry_points(depth):
     """The recorded Search::puMotionEstimation calls (tests/golden/pu_*.npz) with every piece of the PU's chain on the GPU -- x265hip_amvp_batch,
     x265hip_select_mvp_batch, x265hip_me_batch (both searches), x265hip_mvp_bits_batch, x265hip_bidir_satd_batch -- each as one batch over all calls that wait for
@@ -276,7 +278,7 @@ def test_whole_pu_motion_estimation_calls_through_the_hip_entry_points(depth):
     assert ex.launches["me"] < 40 and ex.launches["get_pmv"] < 20, "the requests were not batched: %s" % ex.launches
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
 def test_tme_frame_steps_whole_pictures_to_the_references_tables(depth):
     """x265hip_tme_frame: every puMotionEstimation call of every CTU of a P and a B picture (tests/golden/tmectu_*.npz: 4 CTUs x 255 schedule entries x 2 pictures),
     stepped on the device through x265hip_tme_schedule -- the MEData table after the run must hold, at every slot the reference wrote, what the reference wrote.

@@ -3,6 +3,8 @@ quantised coefficients, numSig, deltaU, reconstruction and SSE must be bit-ident
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.synth import frame_pair
 from x265hip_pkg.frame import FrameApi, TU_TASK
@@ -11,7 +13,7 @@ from backends import Oracle
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("log2n", [2, 3, 4, 5])
 def test_tq_batch_matches_oracle(depth, log2n):
     api, ora = FrameApi(depth), Oracle(depth)
@@ -61,7 +63,7 @@ def test_tq_batch_matches_oracle(depth, log2n):
             kinds.add(0 if e_ns == 0 else (1 if e_ns == 1 else 2))
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("log2n", [2, 3, 4, 5])
 def test_tq_batch_chroma_matches_oracle(depth, log2n):
     """Chroma TUs of a 4:2:0 picture: motion compensation = predInterChromaPixel (predict.cpp:340-380) with the luma MV
@@ -113,7 +115,7 @@ def test_tq_batch_chroma_matches_oracle(depth, log2n):
         assert coded or qp > 35
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 @pytest.mark.parametrize("log2n", [2, 3, 4, 5])
 def test_tq_batch_bidirectional_matches_oracle(depth, log2n):
     """Bi-directionally predicted TUs: two 14-bit predictions (Predict::predInterLumaShort: p2s | hps | vps | hps + vss) -> addAvg (predict.cpp:186-211).
@@ -170,7 +172,7 @@ def test_tq_batch_bidirectional_matches_oracle(depth, log2n):
         assert done >= 36
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_tq_batch_intra_4x4_dst_matches_oracle(depth):
     """The chain of an intra luma 4x4 TU (quant.cpp:429-432, 585-603): prediction from a plane the caller filled (MV 0), rounding 171, the DST-VII
     pair instead of the DCT, no DC-only shortcut in the inverse."""

@@ -4,6 +4,8 @@ primitives (oracle/_ref)."""
 import numpy as np
 import pytest
 
+from depths import DEPTHS
+
 import x265hip  # noqa: F401
 from x265hip_pkg.synth import frame_pair
 from backends import Oracle, Ref, ref_available
@@ -47,7 +49,7 @@ def ref_chain(ref, depth, log2n, cur, stride, off, rf, roff, mv, qp, add_num):
     return ns, q, du, recon, sse
 
 
-@pytest.mark.parametrize("depth", [8, 10])
+@pytest.mark.parametrize("depth", DEPTHS)
 def test_tq_pipeline_matches_reference_primitives(depth):
     if not ref_available(depth):
         pytest.skip("no reference binary")

@@ -125,6 +125,14 @@ __device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, 
 __device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ int satd_rows_pk(const Row& a, const Row& b, int lane)
 {
+#if X265_DEPTH > 10
+    {   // 12 bit: a coefficient reaches 16 * 4095, beyond int16 -- the 32-bit form
+        int d[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) d[k] = (int)((a.w[k >> 1] >> (16 * (k & 1))) & 0xffffu) - (int)((b.w[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        return satd_rows(d, lane);
+    }
+#endif
     s2 r[4];                                          // r[k] = (d[k], d[k + 4]): column k of the left block, column k of the right block
 #if X265_DEPTH == 8
 #pragma unroll

@@ -5,10 +5,15 @@
 namespace {
 
 // One thread per position of the padded picture: the six horizontal box widths by successive extension, stored as uint16 (32 pixels
-// of at most 10 bits), then per position the twelve (W, H) boxes as running vertical sums of those rows.
+// of at most 11 bits; uint32 in the 12-bit build), then per position the twelve (W, H) boxes as running vertical sums of those rows.
 constexpr int SEA_NW = 6;
+#if X265_DEPTH <= 11
+typedef uint16_t rowsum_t;
+#else
+typedef uint32_t rowsum_t;
+#endif
 __device__ const int8_t k_seaWidths[SEA_NW] = { 4, 8, 12, 16, 24, 32 };
-__global__ __launch_bounds__(256) void sea_rowsum_kernel(const pixel* __restrict__ pic, intptr_t stride, int rows, int cols, uint16_t* __restrict__ rs, int64_t rsElems)
+__global__ __launch_bounds__(256) void sea_rowsum_kernel(const pixel* __restrict__ pic, intptr_t stride, int rows, int cols, rowsum_t* __restrict__ rs, int64_t rsElems)
 {   // pic / rs point at the first padded row and column; cols = stride (row sums near the right end run into the next row exactly like
     // integral_initNh_c's `x < stride - N` bound leaves them undefined -- those columns are never read)
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -21,19 +26,19 @@ __global__ __launch_bounds__(256) void sea_rowsum_kernel(const pixel* __restrict
     {
         const int W = k_seaWidths[k];
         for (; i < W; i++) s += (!last || x + i < cols) ? (int)p[i] : 0;       // stay inside the allocation on the last row
-        rs[k * rsElems + o] = (uint16_t)s;
+        rs[k * rsElems + o] = (rowsum_t)s;
     }
 }
 __device__ const int8_t k_seaW[12] = { 5, 5, 5, 4, 3, 3, 3, 2, 1, 1, 0, 0 };      // index into k_seaWidths: 32 32 32 24 16 16 16 12 8 8 4 4
 __device__ const int8_t k_seaH[12] = { 32, 24, 8, 32, 16, 12, 4, 16, 32, 8, 16, 4 };
 constexpr int SEA_STRIP = 32;          // rows per thread: a vertical sliding window costs (H + 2 * 31) reads per 32 outputs instead of 32 * H
-__global__ __launch_bounds__(256) void sea_box_kernel(const uint16_t* __restrict__ rs, int64_t rsElems, intptr_t stride, int rows, int cols,
+__global__ __launch_bounds__(256) void sea_box_kernel(const rowsum_t* __restrict__ rs, int64_t rsElems, intptr_t stride, int rows, int cols,
                                                       uint32_t* __restrict__ out, int64_t outElems)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * SEA_STRIP, k = blockIdx.z;
     const int H = k_seaH[k];
     if (x >= cols || y0 + H > rows) return;                                        // boxes that leave the padded picture stay undefined
-    const uint16_t* r = rs + k_seaW[k] * rsElems + (int64_t)y0 * stride + x;
+    const rowsum_t* r = rs + k_seaW[k] * rsElems + (int64_t)y0 * stride + x;
     uint32_t* o = out + k * outElems + (int64_t)y0 * stride + x;
     uint32_t s = 0;
     for (int j = 0; j < H; j++) s += r[(intptr_t)j * stride];
@@ -78,7 +83,7 @@ extern "C" int x265hip_integral_init_v(void* stream, uint32_t* top, const uint32
     return X265HIP_OK;
 }
 
-extern "C" size_t x265hip_sea_integral_workspace(intptr_t stride, int rows) { return sizeof(uint16_t) * (size_t)SEA_NW * (size_t)stride * (size_t)rows; }
+extern "C" size_t x265hip_sea_integral_workspace(intptr_t stride, int rows) { return sizeof(rowsum_t) * (size_t)SEA_NW * (size_t)stride * (size_t)rows; }
 
 extern "C" int x265hip_sea_integral_planes(void* stream, const void* picPadded, intptr_t stride, int rows, uint32_t* planes, int64_t planeElems,
                                            void* workspace, size_t workspaceBytes)
@@ -89,9 +94,9 @@ extern "C" int x265hip_sea_integral_planes(void* stream, const void* picPadded, 
     hipStream_t st = (hipStream_t)stream;
     const int64_t rsElems = (int64_t)stride * rows;
     hipLaunchKernelGGL(sea_rowsum_kernel, dim3((unsigned)((stride + 255) / 256), rows), dim3(256), 0, st, (const pixel*)picPadded, stride, rows, (int)stride,
-                       (uint16_t*)workspace, rsElems);
+                       (rowsum_t*)workspace, rsElems);
     XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sea_box_kernel, dim3((unsigned)((stride + 255) / 256), (rows + SEA_STRIP - 1) / SEA_STRIP, 12), dim3(256), 0, st, (const uint16_t*)workspace, rsElems, stride, rows, (int)stride,
+    hipLaunchKernelGGL(sea_box_kernel, dim3((unsigned)((stride + 255) / 256), (rows + SEA_STRIP - 1) / SEA_STRIP, 12), dim3(256), 0, st, (const rowsum_t*)workspace, rsElems, stride, rows, (int)stride,
                        planes, planeElems);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

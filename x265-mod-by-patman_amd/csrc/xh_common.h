@@ -6,7 +6,7 @@
 #include "../../include/x265hip.h"
 
 #ifndef X265_DEPTH
-#error "build with -DX265_DEPTH=8 or 10"
+#error "build with -DX265_DEPTH=8, 10 or 12"
 #endif
 #if X265_DEPTH > 8
 typedef uint16_t pixel;

@@ -178,7 +178,8 @@ __device__ __forceinline__ void load4u(const lpixel* p, int* v)
 // Four pixels of a row travel as packed data (px4); their differences are two registers of two int16 (U, V).  Every butterfly
 // between rows and the first butterfly along the row are whole-register v_pk_add/sub_i16; the last butterfly along the row pairs the
 // halves of one register, and only sum |coef| is wanted, so it is |a + b| + |a - b| = 2 max(|a|, |b|).  10 bit: |difference| <= 1023,
-// three butterfly stages <= 8184 < 2^15; the eight maxima of a 4x4 add up to <= 65472 < 2^16.
+// three butterfly stages <= 8184 < 2^15; the eight maxima of a 4x4 add up to <= 65472 < 2^16.  12 bit: |difference| <= 4095, three stages <= 32760 still fit int16,
+// the eight maxima (<= 262080) do not fit 16 bits: they are added up as 32-bit integers there.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pk16(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
@@ -222,10 +223,17 @@ __device__ __forceinline__ int had4x4_pk(const px4 (&a)[4], const px4 (&b)[4])
 #pragma unroll
     for (int y = 0; y < 4; y++) px4_diff(a[y], b[y], u[y], v[y]);
     had4p(u[0], u[1], u[2], u[3]); had4p(v[0], v[1], v[2], v[3]);
+#if X265_DEPTH <= 10
     u16x2 acc = 0;
 #pragma unroll
     for (int y = 0; y < 4; y++) { acc += pk_absmax(u[y] + v[y]); acc += pk_absmax(u[y] - v[y]); }
     return 2 * (int)acc.x;
+#else
+    int acc = 0;
+#pragma unroll
+    for (int y = 0; y < 4; y++) { acc += (int)pk_absmax(u[y] + v[y]).x; acc += (int)pk_absmax(u[y] - v[y]).x; }
+    return 2 * acc;
+#endif
 }
 __device__ __forceinline__ unsigned sad4(const lpixel* f /*LDS aligned*/, const lpixel* r /*LDS window, unaligned*/, unsigned acc)
 {
