@@ -1,5 +1,5 @@
 """The C++ host of the frame-batched path (include/x265hip_ctx.h: x265hip_batch_*, csrc/xh_ctx.cpp) with everything preset slow asks of the motion search in ONE run:
-several list-0 references, the rectangular PUs of every CU, sub-batches of whole pictures on their own streams -- exhaustively against the oracle at 256x128, sampled at 4K, equal to the Python
+several list-0 references, the rectangular PUs of every CU, sub-batches of whole pictures on their own streams -- exhaustively against the oracle at 256x128 AND at the full size of the three BASELINE workloads (one reference, square PUs: every search and every TU of whole 1080p / 4K / 8K pictures), sampled at 4K with the preset's four references + rectangles, equal to the Python
 plumbing (FramePipeline) where that can run the same configuration, and independent of how the batch is cut into streams."""
 import ctypes as C
 
@@ -193,3 +193,78 @@ def test_preset_slow_search_at_4k_10bit_full_size():
         assert n >= 12 * 5 + 10
     finally:
         hb.close()
+
+
+# ---- the headline configuration, EVERY PU and EVERY TU of whole 4K pictures against the oracle (the oracle on all host cores: forked workers over slices of the task lists) ----
+_FULL = {}
+
+
+def _full_pus(arg):
+    lv, lo, hi = arg
+    hb, res, parent, row = _FULL["hb"], _FULL["res"][lv], _FULL["res"].get(2 * lv), _FULL["row"]
+    ora = _FULL["ora"]
+    t, d = hb["tasks"][lv], hb["merange"] << 2
+    bad = []
+    for i in range(lo, hi):
+        tk = t[i]
+        qmvp = (0, 0) if tk["mvpFrom"] < 0 else (int(parent[tk["mvpFrom"]]["mv"][0]), int(parent[tk["mvpFrom"]]["mv"][1]))
+        lx0, ly0, lx1, ly1 = int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])
+        b = [min(lx1, max(lx0, qmvp[0] - d)) >> 2, min(ly1, max(ly0, qmvp[1] - d)) >> 2, min(lx1, max(lx0, qmvp[0] + d)) >> 2, min(ly1, max(ly0, qmvp[1] + d)) >> 2]
+        b[3] = max(b[3], b[1])
+        exp = ora.me(lv, lv, hb["cur"], hb["stride"], int(tk["curOff"]), hb["ref"], hb["stride"], int(tk["refOff"]), b, qmvp, [], hb["merange"], hb["method"], hb["subme"], row)
+        g = res[i]
+        if (int(g["mv"][0]), int(g["mv"][1]), int(g["cost"])) != exp:
+            bad.append((lv, i, (int(g["mv"][0]), int(g["mv"][1]), int(g["cost"])), exp))
+    return hi - lo, bad
+
+
+def _full_tus(arg):
+    lo, hi = arg
+    hb, ora = _FULL["hb"], _FULL["ora"]
+    mvs, coeff, numsig = _FULL["res"][hb["mv_level"]], _FULL["coeff"], _FULL["numsig"]
+    bad = []
+    for i in range(lo, hi):
+        tk = hb["tu"][i]
+        mv = (int(mvs[tk["mvFrom"]]["mv"][0]), int(mvs[tk["mvFrom"]]["mv"][1]))
+        e_ns, e_coeff, _, _, _ = ora.tq_tu(hb["tu_log2"], hb["cur"], hb["stride"], int(tk["curOff"]), hb["ref"], hb["stride"], int(tk["refOff"]), mv, hb["qp"], 85)
+        if int(numsig[i]) != e_ns or not np.array_equal(coeff[i], e_coeff):
+            bad.append(i)
+    return hi - lo, bad
+
+
+# BASELINE configs[1], [2] (= [3] per GPU) and [4] as bench.py's workloads define them: (depth, W, H, pictures, method, subme, merange)
+@pytest.mark.parametrize("depth,W,H,F,method,subme,merange", [(8, 1920, 1088, 4, 1, 2, 57), (10, 3840, 2176, 2, 3, 3, 57), (10, 7680, 4352, 1, 3, 4, 128)])
+def test_baseline_workloads_every_pu_and_tu_of_whole_pictures(depth, W, H, F, method, subme, merange):
+    """The three BASELINE workloads at FULL size as bench.py runs them (one reference, the 85 square PUs of every CTU, 32x32 TUs; the headline: 3840x2176 10-bit, STAR, subme 3,
+    merange 57, 2 pictures on 2 streams): ALL motion searches -- MV and cost; 346,800 at 4K, 693,600 at 8K -- and ALL TUs -- every quantised coefficient and numSig -- equal the
+    oracle's (north_star: bit-identical quantised-coefficient output on 4K pictures).  The oracle runs on the host's cores (forked workers; a few CPU-minutes in all at 8K)."""
+    import multiprocessing as mp
+    import os
+    qp = 28
+    hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, refs=1, rect=False, streams=min(F, 2))
+    try:
+        hb.upload(pairs_for(W, H, depth, F, 1, seed0=820))
+        hb.step(); hb.sync()
+        n = 32
+        coeff, numsig = hb.coeffs()
+        _FULL.update(hb=dict(tasks={lv: hb.tasks_host[lv] for lv in LEVELS}, tu=hb.tu_host, cur=hb.cur_host, ref=hb.refs_host[0], stride=hb.stride, merange=hb.merange,
+                             method=hb.method, subme=hb.subme, mv_level=hb.mv_level, tu_log2=hb.tu_log2, qp=hb.qp),
+                     res={lv: hb.shape_results(lv, lv, 0, 0) for lv in LEVELS}, coeff=coeff.reshape(-1, n * n), numsig=numsig, row=mvcost_row(depth, qp, 1 << 15), ora=Oracle(depth))
+    finally:
+        hb.close()
+    jobs = []
+    for lv in LEVELS:
+        nt, step = len(_FULL["hb"]["tasks"][lv]), {64: 24, 32: 128, 16: 1024, 8: 4096}[lv]
+        jobs += [(lv, lo, min(nt, lo + step)) for lo in range(0, nt, step)]
+    ntu = len(_FULL["hb"]["tu"])
+    tjobs = [(lo, min(ntu, lo + 256)) for lo in range(0, ntu, 256)]
+    workers = max(2, min(64, (os.cpu_count() or 4) - 2))
+    with mp.get_context("fork").Pool(workers) as pool:
+        pus = pool.map(_full_pus, jobs, chunksize=1)
+        tus = pool.map(_full_tus, tjobs, chunksize=1)
+    _FULL.clear()
+    bad = [b for _, bl in pus for b in bl]
+    assert not bad, "%d of %d searches differ from the oracle, first (level, task, hip, oracle): %s" % (len(bad), sum(c for c, _ in pus), bad[0])
+    badt = [b for _, bl in tus for b in bl]
+    assert not badt, "%d of %d TUs differ from the oracle, first: TU %d" % (len(badt), ntu, badt[0])
+    assert sum(c for c, _ in pus) == F * (W // 64) * (H // 64) * 85 and sum(c for c, _ in tus) == F * (W // 32) * (H // 32)
