@@ -15,6 +15,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "x265.h"
 #include "common.h"
@@ -137,8 +138,14 @@ void FrameFilter::processRow(int row, int layer)
     }
     /* the rows wait for the picture.  One slice: a row's filter runs behind the row above it, the last row's call is the last one.  --slices (WPP, param.cpp:1760): the slices'
        rows finish in any order (framefilter.cpp:633), the picture is complete when every row has called -- one picture at a time (one frame thread), so a counter tells */
-    static std::atomic<int> rowsIn{0};
-    if (p.maxSlices > 1) { if (rowsIn.fetch_add(1) + 1 != m_numRows) return; rowsIn.store(0); }
+    if (p.maxSlices > 1)
+    {   /* counted per FrameFilter (= per frame encoder of an encoder instance): several encoders may live in one process */
+        static std::mutex rowLock; static std::unordered_map<const FrameFilter*, int> rowsIn;
+        std::lock_guard<std::mutex> rg(rowLock);
+        int& n = rowsIn[this];
+        if (++n != m_numRows) return;
+        n = 0;
+    }
     else if (row != m_numRows - 1) return;
     if (g_deferOnly)
     {   /* X265FF_DEFER_ONLY: the deferral alone, filters by the encoder's own bodies (separates the two things the binding changes; needs no GPU) */
