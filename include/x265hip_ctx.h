@@ -221,6 +221,16 @@ int  x265hip_la_estimate_batch(x265hip_la* la, const x265hip_la_estimate_desc* d
 /* x265hip_la_estimate is synchronous for its caller, but estimates that arrive from other threads while a launch is in flight go up TOGETHER as the next launch (up to X265HIP_LA_MAX_BATCH):
  * the lookahead's batched frame costs (b-adapt 2 with a thread pool) become batches on the device.  launches / estimates so far: */
 int  x265hip_la_batch_stats(const x265hip_la* la, int64_t* launches, int64_t* estimates);
+/* cuTree, one propagation step for a host caller: Lookahead::estimateCUPropagate (slicetype.cpp:3850-3953; primitives.propagateCost, pixel.cpp:906-931) on the caller's
+ * arrays of picture b and its two references -- x265hip_cutree_propagate (include/x265hip_frame.h) with the staging around it.  All arrays have ncu = widthInCU * heightInCU
+ * entries (the producer's geometry); mvs are int16 x, y pairs (4-byte aligned); propB is read (the reference memsets its first row itself when !referenced, :3870-3871) and
+ * prop0 / prop1 are updated in place (prop1 / mvs1 may be NULL for a P picture: distP1 == 0).  Integer results, the reference's double arithmetic: identical.  Synchronous. */
+typedef struct x265hip_la_cutree_desc {
+    int distP0, distP1, weightedBiPred, referenced; double fpsFactor;
+    const int32_t* intraCost; const uint16_t* lowresCosts; const int32_t* invQscale; const int16_t* mvs0; const int16_t* mvs1;
+    const uint16_t* propB; uint16_t* prop0; uint16_t* prop1;
+} x265hip_la_cutree_desc;
+int  x265hip_la_cutree_propagate(x265hip_la* la, const x265hip_la_cutree_desc* desc);
 
 /* ---------------------------------------------------------------------------------------------------------------------------------------------
  * In-loop filter producer for a host caller: what FrameFilter does to one reconstructed 4:2:0 picture between its reconstruction and the SAO decision
@@ -229,7 +239,8 @@ int  x265hip_la_batch_stats(const x265hip_la* la, int64_t* launches, int64_t* es
  * x265hip_deblock_frame / x265hip_sao_stats_frame (include/x265hip_frame.h).  The SAO decision (rate-distortion search with the encoder's entropy coder) and what
  * follows stay with the caller.  What integration/filter_adapter.cpp binds inside the reference encoder.
  * The picture is described as for x265hip_deblock_frame (CUData's per-partition arrays, CTU after CTU -- here HOST arrays); planes are host pointers to pixel (0,0),
- * rows strideY / strideC (given at creation) apart; the source planes have the same strides (PicYuv of one encoder).  One slice, 4:2:0, bLimitSAO off.
+ * rows strideY / strideC (given at creation) apart; the source planes have the same strides (PicYuv of one encoder).  4:2:0; --slices through pic.sliceFirstRow (a HOST array
+ * here); every class of every CTU is returned (--limit-sao is the caller's choice of which to use, integration/filter_adapter.cpp).
  * --------------------------------------------------------------------------------------------------------------------------------------------- */
 typedef struct x265hip_ff x265hip_ff;
 int  x265hip_ff_create(x265hip_ctx* ctx, int width, int height, int ctuSize, intptr_t strideY, intptr_t strideC, x265hip_ff** out);

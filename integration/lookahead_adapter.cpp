@@ -23,6 +23,7 @@
 #include "lowres.h"
 #include "mv.h"
 #include "slicetype.h"
+#include "ratecontrol.h"                     /* CLIP_DURATION */
 #include "../include/x265hip_ctx.h"
 #include "lookahead_adapter.h"
 
@@ -40,6 +41,7 @@ struct Api
     int (*la_estimate)(x265hip_la*, const x265hip_la_estimate_desc*);
     int (*la_estimate_batch)(x265hip_la*, const x265hip_la_estimate_desc*, int);
     int (*la_batch_stats)(const x265hip_la*, int64_t*, int64_t*);
+    int (*la_cutree_propagate)(x265hip_la*, const x265hip_la_cutree_desc*);
     const char* (*last_error)();
 } g_api;
 void* g_lib;
@@ -93,6 +95,7 @@ bool hme_ready(x265hip_la* la, const Lowres& f, const x265_param& p, int w4, int
 int64_t estimateFrameCost_cpu(CostEstimateGroup* self, LookaheadTLD& tld, int p0, int p1, int b, bool bIntraPenalty) __asm__("xla_estimateFrameCost_cpu");
 void finishBatch_cpu(CostEstimateGroup* self) __asm__("xla_finishBatch_cpu");
 void lowresIntraEstimate_cpu(LookaheadTLD* self, Lowres& fenc, uint32_t qgSize) __asm__("xla_lowresIntraEstimate_cpu");
+void estimateCUPropagate_cpu(Lookahead* self, Lowres** frames, double averageDuration, int p0, int p1, int b, int referenced) __asm__("xla_estimateCUPropagate_cpu");
 
 namespace X265_NS {
 
@@ -302,6 +305,40 @@ void CostEstimateGroup::finishBatch()
     m_jobTotal = m_jobAcquired = 0;
 }
 
+/* cuTree, one propagation step (slicetype.cpp:3850-3956): the arrays of picture b and of its two references go through x265hip_la_cutree_propagate; what the reference does
+   around the loop -- the zeroed first row of an unreferenced picture's costs, cuTreeFinish under VBV -- stays here.  (cuTreeFinish itself is left to the encoder: its two
+   log2 of doubles are libm's, and a device library's last bit is not guaranteed to be the same.) */
+void Lookahead::estimateCUPropagate(Lowres** frames, double averageDuration, int p0, int p1, int b, int referenced)
+{
+    x265hip_la* la = g_on ? producer(*frames[b], m_8x8Width, m_8x8Height) : nullptr;
+    if (!la || b <= p0 || p1 < b) { ::estimateCUPropagate_cpu(this, frames, averageDuration, p0, p1, b, referenced); return; }
+    const double t0 = now();
+    Lowres* fb = frames[b];
+    const int ncu = m_8x8Width * m_8x8Height;
+    static thread_local std::vector<int16_t> mv16[2];
+    x265hip_la_cutree_desc d;
+    memset(&d, 0, sizeof(d));
+    d.distP0 = b - p0; d.distP1 = p1 - b; d.weightedBiPred = m_param->bEnableWeightedBiPred; d.referenced = referenced;
+    x265_emms();
+    d.fpsFactor = CLIP_DURATION((double)m_param->fpsDenom / m_param->fpsNum) / CLIP_DURATION(averageDuration);
+    if (!referenced) memset(fb->propagateCost, 0, m_8x8Width * sizeof(uint16_t));                      /* :3866-3867 */
+    d.intraCost = fb->intraCost; d.lowresCosts = fb->lowresCosts[b - p0][p1 - b];
+    d.invQscale = m_param->rc.qgSize == 8 ? fb->invQscaleFactor8x8 : fb->invQscaleFactor;
+    for (int l = 0; l < (p1 > b ? 2 : 1); l++)
+    {
+        const MV* m = fb->lowresMvs[l][l ? p1 - b : b - p0];
+        mv16[l].resize(2 * (size_t)ncu);
+        for (int i = 0; i < ncu; i++) { mv16[l][2 * i] = (int16_t)m[i].x; mv16[l][2 * i + 1] = (int16_t)m[i].y; }
+    }
+    d.mvs0 = mv16[0].data(); d.mvs1 = p1 > b ? mv16[1].data() : NULL;
+    d.propB = fb->propagateCost; d.prop0 = frames[p0]->propagateCost; d.prop1 = p1 > b ? frames[p1]->propagateCost : NULL;
+    const int rc = g_api.la_cutree_propagate(la, &d);
+    if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_cutree_propagate: %d %s\n", rc, g_api.last_error()); exit(3); }
+    { std::lock_guard<std::mutex> sg(g_statLock); g_stats.cutreeSteps++; g_stats.cutreeSeconds += now() - t0; }
+    if (m_param->rc.vbvBufferSize && m_param->lookaheadDepth && referenced)
+        cuTreeFinish(fb, averageDuration, b == p1 ? b - p0 : 0);
+}
+
 }
 
 extern "C" int x265hip_la_adapter_load(const char* libraryPath, int device)
@@ -310,7 +347,7 @@ extern "C" int x265hip_la_adapter_load(const char* libraryPath, int device)
     if (!g_lib) { fprintf(stderr, "lookahead_adapter: dlopen: %s\n", dlerror()); return -1; }
 #define SYM(field, name) *(void**)&g_api.field = dlsym(g_lib, name); if (!g_api.field) { fprintf(stderr, "lookahead_adapter: %s lacks %s\n", libraryPath, name); return -1; }
     SYM(ctx_create, "x265hip_ctx_create") SYM(ctx_destroy, "x265hip_ctx_destroy") SYM(la_create, "x265hip_la_create") SYM(la_destroy, "x265hip_la_destroy") SYM(la_enable_hme, "x265hip_la_enable_hme")
-    SYM(la_intra, "x265hip_la_intra") SYM(la_estimate, "x265hip_la_estimate") SYM(la_estimate_batch, "x265hip_la_estimate_batch") SYM(la_batch_stats, "x265hip_la_batch_stats") SYM(last_error, "x265hip_last_error")
+    SYM(la_intra, "x265hip_la_intra") SYM(la_estimate, "x265hip_la_estimate") SYM(la_estimate_batch, "x265hip_la_estimate_batch") SYM(la_batch_stats, "x265hip_la_batch_stats") SYM(la_cutree_propagate, "x265hip_la_cutree_propagate") SYM(last_error, "x265hip_last_error")
 #undef SYM
     g_device = device; g_on = 1;
     g_batchBinding = !(getenv("X265LA_BATCH") && !atoi(getenv("X265LA_BATCH")));

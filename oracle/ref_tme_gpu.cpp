@@ -119,8 +119,9 @@ int main(int argc, char** argv)
         x265hip_la_adapter_stats ls;
         x265hip_la_adapter_close();
         x265hip_la_adapter_get_stats(&ls);
-        snprintf(la, sizeof(la), "\"lookahead_producer\": \"%s\", \"la_intra_pictures\": %d, \"la_estimates\": %d, \"la_launches\": %d, \"la_batches\": %d, \"la_batch_calls\": %d, \"la_cpu_estimates\": %d, \"la_weighted\": %d, \"la_intra_seconds\": %.3f, \"la_estimate_seconds\": %.3f, \"la_producer_seconds\": %.3f, ",
-                 useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.launches, ls.batches, ls.batchCalls, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds);
+        snprintf(la, sizeof(la), "\"lookahead_producer\": \"%s\", \"la_intra_pictures\": %d, \"la_estimates\": %d, \"la_launches\": %d, \"la_batches\": %d, \"la_batch_calls\": %d, \"la_cpu_estimates\": %d, \"la_weighted\": %d, \"la_intra_seconds\": %.3f, \"la_estimate_seconds\": %.3f, \"la_producer_seconds\": %.3f, \"la_cutree_steps\": %d, \"la_cutree_seconds\": %.3f, ",
+                 useLa ? "gpu" : "cpu", ls.intraPictures, ls.estimates, ls.launches, ls.batches, ls.batchCalls, ls.cpuEstimates, ls.weighted, ls.intraSeconds, ls.estimateSeconds, ls.producerSeconds,
+                 ls.cutreeSteps, ls.cutreeSeconds);
         x265hip_ff_adapter_stats fs;
         x265hip_ff_adapter_close();
         x265hip_ff_adapter_get_stats(&fs);

@@ -41,6 +41,8 @@ def test_bitstream_identical_with_gpu_lookahead(depth, args, fade, tmp_path):
     assert gpu["lookahead_producer"] == "gpu" and gpu["la_intra_pictures"] == int(args[2]) and gpu["la_estimates"] > 0, "the GPU lookahead did not run: %s" % gpu
     assert gpu["la_cpu_estimates"] == 0
     assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
+    if "cutree=0" not in args:
+        assert gpu["la_cutree_steps"] > 0 and cpu["la_cutree_steps"] == 0, "cuTree's propagation steps did not go through the producer: %s" % gpu
     if fade:
         assert gpu["la_weighted"] > 0, "the fade did not make the lookahead weight a reference: %s" % gpu
     assert 0 < gpu["la_launches"] <= gpu["la_estimates"]

@@ -361,3 +361,55 @@ def test_hme_lookahead_batch_matches_oracle(depth, size, aq, shift, hme):
         out = int(tk["outSlot"])
         assert np.array_equal(lc[out], o["lowresCosts"]) and np.array_equal(rs[out], o["rowSatds"]), "lowresCosts / rowSatds of " + what
         assert [int(v) for v in sm[out]] == [o["costEst"], o["costEstAq"], o["intraMbs"]], "totals of " + what
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+def test_la_host_cutree_step_matches_oracle(depth):
+    """x265hip_la_cutree_propagate (the host form integration/lookahead_adapter.cpp binds as Lookahead::estimateCUPropagate): host arrays in, the two references' accumulated
+    costs back -- P and B steps, referenced or not, saturating cells, MVs that leave the picture -- against the oracle's estimateCUPropagate (pinned to the reference)."""
+    import ctypes as C
+    import x265hip
+    from lookahead_util import oracle_propagate
+
+    class Desc(C.Structure):
+        _fields_ = [("distP0", C.c_int), ("distP1", C.c_int), ("weightedBiPred", C.c_int), ("referenced", C.c_int), ("fpsFactor", C.c_double)] + \
+                   [(k, C.c_void_p) for k in ("intraCost", "lowresCosts", "invQscale", "mvs0", "mvs1", "propB", "prop0", "prop1")]
+
+    lib = x265hip.HipLib(depth, fill_table=False).lib
+    ora = Oracle(depth)
+    g = Geometry(208, 136)
+    ctx, la = C.c_void_p(), C.c_void_p()
+    assert lib.x265hip_ctx_create(0, C.byref(ctx)) == 0
+    lib.x265hip_la_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+    assert lib.x265hip_la_create(ctx, g.wcu, g.hcu, g.stride, g.plane_elems, g.origin, 4, C.byref(la)) == 0
+    lib.x265hip_la_cutree_propagate.argtypes = [C.c_void_p, C.c_void_p]
+    lib.x265hip_la_destroy.argtypes = [C.c_void_p]; lib.x265hip_ctx_destroy.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(31 + depth)
+    P = lambda a: a.ctypes.data  # noqa: E731
+    try:
+        for (d0, d1, referenced, wb, fps) in [(1, 0, 1, 0, 1.0), (2, 1, 0, 1, 0.8), (1, 2, 1, 1, 1.25), (3, 0, 1, 1, 0.5), (1, 1, 0, 0, 1.0)]:
+            intra = rng.integers(0, 4000, g.ncu).astype(np.int32); intra[rng.random(g.ncu) < 0.05] = 0
+            lists = rng.integers(1, 4, g.ncu) if d1 else np.ones(g.ncu, np.int64)
+            lc = (np.minimum(rng.integers(0, 5000, g.ncu), 16383) | (lists << 14)).astype(np.uint16)
+            invq = rng.integers(160, 360, g.ncu).astype(np.int32)
+            mv = [np.where(rng.random((g.ncu, 2)) < 0.3, 0, rng.integers(-300, 301, (g.ncu, 2))).astype(np.int16) for _ in range(2)]
+            prop = [np.where(rng.random(g.ncu) < 0.05, rng.integers(65000, 65536, g.ncu), rng.integers(0, 6000, g.ncu)).astype(np.uint16) for _ in range(3)]
+            if not referenced:
+                prop[0][:g.wcu] = 0                                  # the caller's memset of the first row (slicetype.cpp:3866-3867)
+            exp = oracle_propagate(ora, g, d0, d1, wb, fps, referenced, intra, lc.astype(np.int32), invq, mv[0].reshape(-1).astype(np.int32),
+                                   mv[1].reshape(-1).astype(np.int32) if d1 else None, prop[0], prop[1].copy(), prop[2].copy() if d1 else prop[0])
+            got = [a.copy() for a in prop]
+            d = Desc(d0, d1, wb, referenced, fps, P(intra), P(lc), P(invq), P(mv[0]), P(mv[1]) if d1 else None, P(got[0]), P(got[1]), P(got[2]) if d1 else None)
+            rc = lib.x265hip_la_cutree_propagate(la, C.byref(d))
+            assert rc == 0, lib.x265hip_last_error()
+            assert np.array_equal(got[0], prop[0]), "picture b's own costs are read, not written"
+            assert np.array_equal(got[1], exp[1]), "list-0 reference of step %s" % ((d0, d1, referenced),)
+            if d1:
+                assert np.array_equal(got[2], exp[2]), "list-1 reference of step %s" % ((d0, d1, referenced),)
+            else:
+                assert np.array_equal(got[2], prop[2])
+            assert not np.array_equal(got[1], prop[1])
+        bad = Desc(0, 0, 0, 1, 1.0, P(intra), P(lc), P(invq), P(mv[0]), None, P(got[0]), P(got[1]), None)
+        assert lib.x265hip_la_cutree_propagate(la, C.byref(bad)) != 0                       # distP0 < 1
+    finally:
+        lib.x265hip_la_destroy(la); lib.x265hip_ctx_destroy(ctx)

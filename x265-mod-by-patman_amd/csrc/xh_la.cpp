@@ -29,6 +29,8 @@ struct x265hip_la
     pixel* low4 = nullptr; int16_t* mvs4 = nullptr; int32_t* mvCosts4 = nullptr;
     struct Slot { uint64_t key = 0; uint64_t used = 0; bool lower = false; bool haveIntra = false; };      // haveIntra: the slot's intra costs are THIS picture's (a picture that came up as a reference has none yet)
     std::vector<Slot> slots; uint64_t tick = 0;
+    // cuTree (x265hip_la_cutree_propagate): staging of one propagation step, allocated at its first call
+    int32_t *ctIntra = nullptr, *ctInvq = nullptr; uint16_t *ctLc = nullptr, *ctProp[3] = {}; int16_t *ctMv[2] = {}; void* ctWork = nullptr;
     std::mutex mu;                                // the device side: one call at a time on the context's stream
     // estimates that arrive while a launch is in flight are queued and go up together (x265hip_la_estimate)
     std::mutex qmu; std::condition_variable qcv; bool leader = false;
@@ -324,5 +326,43 @@ extern "C" int x265hip_la_batch_stats(const x265hip_la* a, int64_t* launches, in
     if (!a) return X265HIP_EARG;
     if (launches) *launches = a->batches;
     if (estimates) *estimates = a->batched;
+    return X265HIP_OK;
+}
+
+
+// Lookahead::estimateCUPropagate (slicetype.cpp:3850-3953) for a host caller: the step's arrays up, x265hip_cutree_propagate, the two references' accumulated costs back
+extern "C" int x265hip_la_cutree_propagate(x265hip_la* a, const x265hip_la_cutree_desc* d)
+{
+    if (!a || !d) { set_error("la_cutree_propagate: null argument"); return X265HIP_EARG; }
+    const bool bidir = d->distP1 > 0;
+    if (d->distP0 < 1 || d->distP1 < 0 || !d->intraCost || !d->lowresCosts || !d->invQscale || !d->mvs0 || !d->propB || !d->prop0 || (bidir && (!d->mvs1 || !d->prop1)))
+    { set_error("la_cutree_propagate: incomplete description"); return X265HIP_EARG; }
+    std::lock_guard<std::mutex> g(a->mu);
+    XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
+    hipStream_t st = (hipStream_t)x265hip_ctx_stream(a->ctx);
+    const size_t n = (size_t)a->ncu;
+    if (!a->ctWork)
+    {
+        int rc;
+        if ((rc = a->alloc(a->ctIntra, n)) || (rc = a->alloc(a->ctInvq, n)) || (rc = a->alloc(a->ctLc, n)) || (rc = a->alloc(a->ctProp[0], n)) || (rc = a->alloc(a->ctProp[1], n)) ||
+            (rc = a->alloc(a->ctProp[2], n)) || (rc = a->alloc(a->ctMv[0], 2 * n)) || (rc = a->alloc(a->ctMv[1], 2 * n))) return rc;
+        uint64_t* w = nullptr;
+        if ((rc = a->alloc(w, 2 * n))) return rc;
+        a->ctWork = w;
+    }
+    XH_HIP(hipMemcpyAsync(a->ctIntra, d->intraCost, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(a->ctInvq, d->invQscale, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(a->ctLc, d->lowresCosts, n * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(a->ctMv[0], d->mvs0, 2 * n * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    if (bidir) XH_HIP(hipMemcpyAsync(a->ctMv[1], d->mvs1, 2 * n * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(a->ctProp[0], d->propB, n * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(a->ctProp[1], d->prop0, n * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    if (bidir) XH_HIP(hipMemcpyAsync(a->ctProp[2], d->prop1, n * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    int rc = x265hip_cutree_propagate(st, a->wcu, a->hcu, d->distP0, d->distP1, d->weightedBiPred, d->fpsFactor, d->referenced, a->ctIntra, a->ctLc, a->ctInvq, a->ctMv[0],
+                                      bidir ? a->ctMv[1] : nullptr, a->ctProp[0], a->ctProp[1], bidir ? a->ctProp[2] : nullptr, a->ctWork, 2 * n * sizeof(uint64_t));
+    if (rc) return rc;
+    XH_HIP(hipMemcpyAsync(d->prop0, a->ctProp[1], n * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+    if (bidir) XH_HIP(hipMemcpyAsync(d->prop1, a->ctProp[2], n * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+    XH_HIP(hipStreamSynchronize(st));
     return X265HIP_OK;
 }
