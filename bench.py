@@ -218,7 +218,7 @@ def e2e_fps_leg(frames=24, seam_frames=8):
                    "ctus_harvested_by_helper_workers": int(g["adapter_sections"][2])}}
     if both:
         l = runs["la_gpu"]
-        out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "device_launches": l.get("la_launches"), "finish_batch_calls_taken_whole": l.get("la_batches"), "estimate_batch_calls": l.get("la_batch_calls"), "estimates_left_to_the_cpu": l["la_cpu_estimates"],
+        out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "device_launches": l.get("la_launches"), "finish_batch_calls_taken_whole": l.get("la_batches"), "estimate_batch_calls": l.get("la_batch_calls"), "estimates_left_to_the_cpu": l["la_cpu_estimates"], "cutree_steps": l.get("la_cutree_steps"), "ms_per_cutree_step": round(1e3 * l["la_cutree_seconds"] / l["la_cutree_steps"], 3) if l.get("la_cutree_steps") else None,
                             "ms_per_estimate": round(1e3 * l["la_estimate_seconds"] / max(1, l["la_estimates"]), 3),
                             "ms_per_intra_picture": round(1e3 * l["la_intra_seconds"] / max(1, l["la_intra_pictures"]), 3),
                             "producer_seconds": l["la_producer_seconds"]}
