@@ -17,6 +17,9 @@
 #include "../../include/x265hip_frame.h"
 using namespace xh;
 
+#ifndef XP_NT_STORES
+#define XP_NT_STORES 1      // the phase planes are written once and read milliseconds later: streaming stores (profiles/r04_nt_ab.txt: planes 0.586 -> 0.563 ms at 4K 10 bit)
+#endif
 namespace {
 
 constexpr int TW = 64, TH = 16, SROWS = TH + 7, SCOLS = 76;          // source tile: rows y0-3 .. y0+TH+3, cols x0-4 .. x0+71
@@ -27,10 +30,20 @@ __device__ __forceinline__ void store4g(pixel* p, const int* v)      // 4 pixels
 #if X265_DEPTH == 8
     int v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
     asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));      // see xh_mc.h store4(): v_ashr_pk_u8_i32 miscompile
+#if XP_NT_STORES
+    __builtin_nontemporal_store((uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24), (uint32_t*)p);
+#else
     *(uint32_t*)p = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+#endif
 #else
     uint2 a; a.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); a.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
+#if XP_NT_STORES
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    u2v b = { a.x, a.y };
+    __builtin_nontemporal_store(b, (u2v*)p);
+#else
     *(uint2*)p = a;
+#endif
 #endif
 }
 
@@ -69,7 +82,11 @@ template<int SH> __device__ __forceinline__ uint32_t sat_pack4(int a, int b, int
 // Plane stores: the plane / row part of the address is wave-uniform (an SGPR base), the thread part a 32-bit offset.
 __device__ __forceinline__ void store_px4(pixel* uniformBase, uint32_t threadOff, uint32_t v)
 {
+#if XP_NT_STORES
+    __builtin_nontemporal_store(v, (uint32_t*)((char*)uniformBase + (size_t)threadOff));
+#else
     *(uint32_t*)((char*)uniformBase + (size_t)threadOff) = v;
+#endif
 }
 __device__ __forceinline__ uint32_t pack_u8(int a, int b, int c, int d)
 {
