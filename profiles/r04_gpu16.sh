@@ -1,5 +1,5 @@
 # r04: non-temporal stores of the phase planes (xp_nt) against the release library, two runs each
-for v in release xp_nt release xp_nt; do
+for v in ${VARIANTS:-release xp_nt release xp_nt}; do
   if [ $v = release ]; then unset X265HIP_LIBDIR; else export X265HIP_LIBDIR=$GRAFT_REPO_ROOT/x265-mod-by-patman_amd/$v; fi
   python bench.py --steps 10 --warmup 3 --cpu-ctus 0 --no-tme --no-e2e --no-preset-exact --no-streams-leg > gpurun_out/r04_nt_$v.json 2> gpurun_out/r04_nt_$v.err
   python - $v <<'PY'

@@ -114,7 +114,12 @@ __device__ __forceinline__ fquad ldq_a(const char* a, unsigned m)
     fquad u; __builtin_memcpy(&u, __builtin_assume_aligned(a + m, 2), 8); return u;
 #endif
     struct W3 { uint32_t x, y, z; } w;
+#ifdef XH_LDQ_NT      // experiment (profiles/r04_nt_ab.txt): candidate loads as streaming loads
+    const uint32_t* pa = (const uint32_t*)__builtin_assume_aligned(a, 4);
+    w.x = __builtin_nontemporal_load(pa); w.y = __builtin_nontemporal_load(pa + 1); w.z = __builtin_nontemporal_load(pa + 2);
+#else
     __builtin_memcpy(&w, __builtin_assume_aligned(a, 4), 12);
+#endif
     fquad r; r.x = __builtin_amdgcn_alignbyte(w.y, w.x, m); r.y = __builtin_amdgcn_alignbyte(w.z, w.y, m);
     return r;
 }
