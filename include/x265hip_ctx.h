@@ -121,6 +121,9 @@ int   x265hip_batch_set_fused(x265hip_batch* batch, int flags);      /* the same
 int   x265hip_batch_stage_count(const x265hip_batch* batch);
 const char* x265hip_batch_stage_name(const x265hip_batch* batch, int i);
 int   x265hip_batch_read_timing(x265hip_batch* batch, float* msPerStage);
+/* the longest single kernel of a pass on its own -- star64_kernel of the first reference (STAR search with the phase planes; batches stepped on ONE stream) -- bracketed by its
+ * own events while set_timing is 1: mean milliseconds over the timed steps since the last call; returns the number of steps averaged, 0 when no such launch was timed */
+int   x265hip_batch_read_kernel_timing(x265hip_batch* batch, float* msStar64Kernel);
 int   x265hip_batch_read_plane(x265hip_batch* batch, int which, int frame, void* out /* the padded plane as it sits on the device: (width + 2 margin) x (height + 2 margin) pixels */);
 int   x265hip_batch_read_coeffs(x265hip_batch* batch, int16_t* coeff /* tu_count << (2 * tuLog2) */, uint32_t* numSig /* tu_count */);
 /* device pointers for consumers that stay on the GPU: what = 0 source planes, 1 reference planes, 2 phase planes, 3 coefficients, 4 numSig,

@@ -165,11 +165,14 @@ def test_stage_timing_and_names():
         hb.set_timing(True)
         for _ in range(3):
             hb.step()
+        k = hb.read_kernel_timing()                              # star64_kernel alone: inside its stage
         t = hb.read_timing()
         assert set(t) == set(hb.kernel_names()) and all(0 < v < 50 for v in t.values()), t
+        assert k is not None and 0 < k <= t["me64"] * 1.05, (k, t)
         hb.set_timing(False); hb.step(); hb.sync()
         with pytest.raises(RuntimeError):
             hb.read_timing()                                     # nothing was timed since the last read
+        assert hb.read_kernel_timing() is None
     finally:
         hb.close()
 

@@ -34,6 +34,11 @@ inline const char* xh_experiment(const char*) { return nullptr; }
 
 namespace xh {
 
+// A pair of events the NEXT star64_kernel launch of this thread is bracketed with (x265hip_batch_set_timing: the batch host's figure for the longest single kernel of a pass,
+// next to its per-stage times); NULL = none.  Cleared by the launch that used it.
+struct KernelEvents { hipEvent_t before, after; };
+extern thread_local const KernelEvents* tl_star64Events;
+
 // ---- error plumbing ----
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);          // records + returns X265HIP_EDEVICE

@@ -78,6 +78,7 @@ struct x265hip_batch
     bool ownStart64 = true;                  // STAR: the 64x64 level without its start-stage launch (kern_me_star.hip xh_me_star_own64); x265hip_batch_set_mode(X265HIP_BATCH_START64_LAUNCH) turns it off for A/B
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
+    std::vector<xh::KernelEvents> evStar; int starSteps = 0; const xh::KernelEvents* starNow = nullptr;                // star64_kernel alone, first reference of sub-batch 0 (x265hip_batch_read_kernel_timing)
     std::vector<void*> owned;
     template<class T> int alloc(T*& p, size_t n)
     {
@@ -275,6 +276,7 @@ extern "C" void x265hip_batch_destroy(x265hip_batch* b)
     for (int i = 0; i < 8; i++) if (b->evJoin[i]) (void)hipEventDestroy(b->evJoin[i]);
     if (b->evFork) (void)hipEventDestroy(b->evFork);
     for (hipEvent_t e : b->evStage) (void)hipEventDestroy(e);
+    for (auto& k : b->evStar) { (void)hipEventDestroy(k.before); (void)hipEventDestroy(k.after); }
     for (void* p : b->owned) (void)hipFree(p);
     delete b;
 }
@@ -451,6 +453,7 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
                     rc = xh_me_star_tiled(st, w, h, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, parent, b->planes[l][r], planeElems, w == CTU && !parent && b->ownStart64);
                 else
 #endif
+                if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && l == 0 && r == 0 && ev && b->starNow) { xh::tl_star64Events = b->starNow; b->starNow = nullptr; b->starSteps++; }
                 if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
                     rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, b->planes[l][r], planeElems);
                 else
@@ -548,8 +551,21 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
 }
 }
 
+// the event pair of this step's star64_kernel launch (first reference of the timed sub-batch)
+static int arm_star_events(x265hip_batch* b)
+{
+    if (b->evStar.size() < (size_t)kTimingSets)
+    {
+        b->evStar.resize(kTimingSets);
+        for (auto& k : b->evStar) { XH_HIP(hipEventCreate(&k.before)); XH_HIP(hipEventCreate(&k.after)); }
+    }
+    b->starNow = &b->evStar[b->starSteps % kTimingSets];
+    return X265HIP_OK;
+}
+
 extern "C" int x265hip_batch_step(x265hip_batch* b)
 {
+    int rc0;
     if (!b) { set_error("batch_step: null batch"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
     b->tiled = tiled_ok(b);
@@ -561,6 +577,7 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
         while (b->evStage.size() < (set + 1) * per) { hipEvent_t e; XH_HIP(hipEventCreate(&e)); b->evStage.push_back(e); }
         ev = b->evStage.data() + set * per;
         b->timedSteps++;
+        if ((rc0 = arm_star_events(b))) return rc0;
     }
     if (S == 1 && band <= 0) return step_range(b, 0, G, true, b->sub[0], ev);
     int rc;
@@ -629,6 +646,7 @@ extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
         while (b->evStage.size() < (set + 1) * per) { hipEvent_t e; XH_HIP(hipEventCreate(&e)); b->evStage.push_back(e); }
         ev = b->evStage.data() + set * per;
         b->timedSteps++;
+        if ((rc = arm_star_events(b))) return rc;
     }
     rc = step_range(b, 0, b->d.frames * (b->d.height / CTU), true, b->sub[0], ev);
     if (rc) return rc;
@@ -659,6 +677,22 @@ extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on)
     return X265HIP_OK;
 }
 extern "C" int x265hip_batch_set_timing(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->timing = on != 0; return X265HIP_OK; }
+// the longest single kernel of a pass on its own: star64_kernel of the first reference (STAR search with the phase planes, one stream), mean milliseconds over the timed steps
+// since the last call; returns the number of steps averaged, 0 when no such launch was timed
+extern "C" int x265hip_batch_read_kernel_timing(x265hip_batch* b, float* ms)
+{
+    if (!b || !ms) { set_error("batch_read_kernel_timing: null argument"); return X265HIP_EARG; }
+    *ms = 0;
+    if (b->starSteps < 1) return 0;
+    XH_HIP(hipSetDevice(b->ctx->device));
+    for (int s = 0; s < b->nsub; s++) XH_HIP(hipStreamSynchronize(b->sub[s]));
+    const int sets = b->starSteps < kTimingSets ? b->starSteps : kTimingSets;
+    double sum = 0;
+    for (int k = 0; k < sets; k++) { float t = 0; XH_HIP(hipEventElapsedTime(&t, b->evStar[k].before, b->evStar[k].after)); sum += t; }
+    *ms = (float)(sum / sets);
+    b->starSteps = 0;
+    return sets;
+}
 extern "C" int x265hip_batch_stage_count(const x265hip_batch* b) { return b ? (int)b->stageNames.size() : 0; }
 extern "C" const char* x265hip_batch_stage_name(const x265hip_batch* b, int i) { return (b && i >= 0 && i < (int)b->stageNames.size()) ? b->stageNames[i].c_str() : nullptr; }
 extern "C" int x265hip_batch_read_timing(x265hip_batch* b, float* ms)

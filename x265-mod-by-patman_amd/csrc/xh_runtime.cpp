@@ -9,6 +9,7 @@
 #include "../../include/x265hip_frame.h"
 
 namespace xh {
+thread_local const KernelEvents* tl_star64Events = nullptr;
 
 static thread_local char g_err[512];
 

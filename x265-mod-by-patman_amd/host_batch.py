@@ -116,6 +116,12 @@ class HostBatch:
         self._ck(self.lib.x265hip_batch_read_timing(self.batch, ms), "read_timing")
         return {n: float(ms[i]) for i, n in enumerate(self.stage_names)}
 
+    def read_kernel_timing(self):
+        """mean ms of star64_kernel alone (the longest single kernel of a STAR pass) over the timed steps since the last call, or None when no such launch was timed"""
+        ms = C.c_float(0)
+        n = self.lib.x265hip_batch_read_kernel_timing(self.batch, C.byref(ms))
+        return float(ms.value) if n > 0 else None
+
     def kernel_names(self):
         return list(self.stage_names)
 
