@@ -444,7 +444,8 @@ typedef struct x265hip_deblock_pic
     const int32_t *mv0, *mv1;
     int32_t refPic[2][16];
     const uint8_t* sliceFirstRow;   /* --slices: per CTU row, non-zero where the row begins a slice (CUData::m_bFirstRowInSlice: the CTU above is no neighbour, cudata.cpp:323 -- the
-                                       row's top edge is not filtered); NULL = one slice.  ceil(height / ctuSize) + 1 entries, the last one 0 */
+                                       row's top edge is not filtered); NULL = one slice.  ceil(height / ctuSize) + 1 entries, the last one 0.  Like the other arrays: device memory for
+                                       x265hip_deblock_frame / _pictures, host memory inside x265hip_ff_picture_desc */
 } x265hip_deblock_pic;
 int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut);
 
