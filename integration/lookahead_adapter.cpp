@@ -221,7 +221,7 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
             wave.clear();
             std::vector<int> claimed;          /* (b, list, distance) keys of this wave's searches */
             std::vector<int> members;
-            for (int i = 0; i < m_jobTotal; i++)
+            for (int i = 0; i < m_jobTotal && (int)members.size() < X265HIP_LA_MAX_BATCH; i++)      /* a launch takes X265HIP_LA_MAX_BATCH estimates: a wave holds no more (bounds the weighted-plane copies) */
             {
                 if (done[(size_t)i]) continue;
                 const Estimate& q = m_estimates[i];

@@ -11,6 +11,11 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # tools/fence_run.sh: the tests' own device tensors through the fence allocator too (every block ends at an unmapped page; csrc/xh_fence.h)
+    fence = os.environ.get("X265HIP_FENCE_TORCH")
+    if fence:
+        import torch
+        torch.cuda.memory.change_current_allocator(torch.cuda.memory.CUDAPluggableAllocator(fence, "xh_fence_torch_malloc", "xh_fence_torch_free"))
 
 
 @pytest.fixture(scope="session", autouse=True)

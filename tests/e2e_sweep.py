@@ -29,7 +29,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         for (depth, w, h, frames, preset, extra) in CONFIGS:
             enc = os.path.join(ROOT, "oracle", "_ref", "x265enc_%d" % depth)
-            lib = os.path.join(ROOT, "x265-mod-by-patman_amd", "libx265hip_%d.so" % depth)
+            lib = os.path.join(os.environ.get("X265HIP_LIBDIR", os.path.join(ROOT, "x265-mod-by-patman_amd")), "libx265hip_%d.so" % depth)
             outs = {}
             for mode in ("c", "hip"):
                 out = os.path.join(td, mode + ".hevc")

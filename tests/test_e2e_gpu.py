@@ -35,7 +35,7 @@ def _env():
 ])
 def test_reference_encoder_emits_identical_bitstream_with_the_hip_table(tmp_path, depth, w, h, frames, preset, extra):
     enc = os.path.join(ROOT, "oracle", "_ref", "x265enc_%d" % depth)
-    lib = os.path.join(ROOT, "x265-mod-by-patman_amd", "libx265hip_%d.so" % depth)
+    lib = os.path.join(os.environ.get("X265HIP_LIBDIR", os.path.join(ROOT, "x265-mod-by-patman_amd")), "libx265hip_%d.so" % depth)
     if not os.path.exists(enc):
         pytest.skip("oracle/_ref/x265enc_%d not built (needs /root/reference at build time)" % depth)
     outs = {}

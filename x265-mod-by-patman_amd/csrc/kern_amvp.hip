@@ -21,7 +21,7 @@ extern "C" int x265hip_amvp_batch(void* stream, const x265hip_amvp_task* tasks, 
 {
     if (n <= 0) return X265HIP_OK;
     if (!tasks || !params || !out) return X265HIP_EARG;
-    hipLaunchKernelGGL(amvp_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tasks, n, *params, out);
+    XH_KLAUNCH(amvp_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tasks, n, *params, out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -99,7 +99,7 @@ extern "C" int x265hip_select_mvp_batch(void* stream, int w, int h, const void* 
 {
     if (n <= 0) return X265HIP_OK;
     if (!curPlane || !subpelPlanes || !tasks || !out || w < 4 || h < 4 || w > 64 || h > 64 || (w & 3)) { set_error("select_mvp_batch: bad arguments (%dx%d)", w, h); return X265HIP_EARG; }
-    hipLaunchKernelGGL(select_mvp_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, h, (const pixel*)curPlane, curStride, (const pixel*)subpelPlanes, planeElems, refStride, tasks, n, out);
+    XH_KLAUNCH(select_mvp_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, w, h, (const pixel*)curPlane, curStride, (const pixel*)subpelPlanes, planeElems, refStride, tasks, n, out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -107,7 +107,7 @@ extern "C" int x265hip_mvp_bits_batch(void* stream, x265hip_mvp_bits* records, i
 {
     if (n <= 0) return X265HIP_OK;
     if (!records || !bitsRow || bitsHalfRange < 1) return X265HIP_EARG;
-    hipLaunchKernelGGL(mvp_bits_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, records, n, bitsRow + bitsHalfRange, bitsHalfRange, (unsigned long long)lambda);
+    XH_KLAUNCH(mvp_bits_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, records, n, bitsRow + bitsHalfRange, bitsHalfRange, (unsigned long long)lambda);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -98,7 +98,7 @@ template<int OP> int launch(hipStream_t st, int w, int h, const BlkArgs& a, int 
 {
     const long long elems = (long long)w * h;
     const unsigned gy = (unsigned)(elems <= 4096 ? 1 : (elems + 4095) / 4096 > 2048 ? 2048 : (elems + 4095) / 4096);
-    hipLaunchKernelGGL(blockop_kernel<OP>, dim3(n, gy), dim3(256), 0, st, w, h, a, n);
+    XH_KLAUNCH(blockop_kernel<OP>, dim3(n, gy), dim3(256), 0, st, w, h, a, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -457,7 +457,7 @@ extern "C" int x265hip_frame_init_lowres(void* stream, const void* src, intptr_t
 {
     if (width <= 0 || height <= 0) return X265HIP_OK;
     if (!src || !dst0 || !dsth || !dstv || !dstc) { set_error("frame_init_lowres: NULL plane"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(lowres_kernel, dim3((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    XH_KLAUNCH(lowres_kernel, dim3((unsigned)((width + 63) / 64), (unsigned)((height + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const pixel*)src, srcStride, (pixel*)dst0, (pixel*)dsth, (pixel*)dstv, (pixel*)dstc, dstStride, width, height);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -495,7 +495,7 @@ extern "C" int x265hip_extend_pic_border(void* stream, void* picOrg, intptr_t st
     if (nPictures <= 0) return X265HIP_OK;
     if (!picOrg || width <= 0 || height <= 0 || marginX < 0 || marginY < 0 || stride < width + 2 * marginX)
     { set_error("extend_pic_border: bad arguments"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(extend_border_kernel, dim3((unsigned)(height + 2 * marginY), (unsigned)nPictures), dim3(256), 0, (hipStream_t)stream,
+    XH_KLAUNCH(extend_border_kernel, dim3((unsigned)(height + 2 * marginY), (unsigned)nPictures), dim3(256), 0, (hipStream_t)stream,
                        (pixel*)picOrg, stride, width, height, marginX, marginY, pictureElems);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -527,7 +527,7 @@ extern "C" int x265hip_sao_stats(void* stream, int type, const int16_t* diff, co
     if (endX <= 0 || endY <= 0) return X265HIP_OK;
     if (type < 0 || type > 4 || endX > 64 || endY > 64 || !diff || !rec || !out || (type >= 1 && type <= 3 && (!upIn || !upOutA)) || (type == 2 && !upOutB))
     { set_error("sao_stats: bad arguments"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(sao_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, type, diff, (const pixel*)rec, stride, upIn, endX, endY, out, upOutA, upOutB);
+    XH_KLAUNCH(sao_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, type, diff, (const pixel*)rec, stride, upIn, endX, endY, out, upOutA, upOutB);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -539,7 +539,7 @@ static int sao_stats_launch(void* stream, const void* fenc, const void* recon, i
         (planeOffset != 0 && planeOffset != 2) || nPictures < 1 || nPictures > 65535 || (nPictures > 1 && pictureElems < stride * (intptr_t)picHeight))
     { set_error("sao_stats: bad arguments"); return X265HIP_EARG; }
     const int n = ((picWidth + ctuSize - 1) / ctuSize) * ((picHeight + ctuSize - 1) / ctuSize);
-    hipLaunchKernelGGL(sao_frame_kernel, dim3(n, 1, nPictures), dim3(1024), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize,
+    XH_KLAUNCH(sao_frame_kernel, dim3(n, 1, nPictures), dim3(1024), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize,
                        nonDeblocked, planeOffset, out, pictureElems, (int64_t)n * 320, sliceFirstRow);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -566,7 +566,7 @@ extern "C" int x265hip_plane_ssd_pictures(void* stream, const void* fenc, const 
     if (!fenc || !recon || !out || width < 1 || height < 1 || stride < width || width > 16384 || nPictures < 1 || nPictures > 65535) { set_error("plane_ssd: bad arguments"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     XH_HIP(hipMemsetAsync(out, 0, sizeof(uint64_t) * nPictures, st));
-    hipLaunchKernelGGL(plane_ssd_kernel, dim3((width + 255) / 256, (height + 7) / 8, nPictures), dim3(256), 0, st, (const pixel*)fenc, (const pixel*)recon, stride, width, height,
+    XH_KLAUNCH(plane_ssd_kernel, dim3((width + 255) / 256, (height + 7) / 8, nPictures), dim3(256), 0, st, (const pixel*)fenc, (const pixel*)recon, stride, width, height,
                        (unsigned long long*)out, fencPictureElems, reconPictureElems, 1);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -602,10 +602,10 @@ extern "C" int x265hip_ssim_pictures(void* stream, const void* recon, intptr_t s
         return X265HIP_OK;
     }
     const int64_t ePic = (int64_t)(x265hip_ssim_workspace(width, height) / sizeof(float));
-    hipLaunchKernelGGL(ssim_window_kernel, dim3((nwx + 31) / 32, (nwy + 7) / 8, nPictures), dim3(256), 0, st, (const pixel*)recon, stride1, (const pixel*)fenc, stride2, nwx, nwy,
+    XH_KLAUNCH(ssim_window_kernel, dim3((nwx + 31) / 32, (nwy + 7) / 8, nPictures), dim3(256), 0, st, (const pixel*)recon, stride1, (const pixel*)fenc, stride2, nwx, nwy,
                        (float*)workspace, reconPictureElems, fencPictureElems, ePic);
-    hipLaunchKernelGGL(ssim_rows_kernel, dim3(numRows, nPictures), dim3(1024), 0, st, (const float*)workspace, nwx, width, height, ctuSize, numRows, rowSsim, rowCnt, ePic);
-    hipLaunchKernelGGL(ssim_total_kernel, dim3(nPictures), dim3(1), 0, st, (const float*)rowSsim, (const uint32_t*)rowCnt, numRows, frame);
+    XH_KLAUNCH(ssim_rows_kernel, dim3(numRows, nPictures), dim3(1024), 0, st, (const float*)workspace, nwx, width, height, ctuSize, numRows, rowSsim, rowCnt, ePic);
+    XH_KLAUNCH(ssim_total_kernel, dim3(nPictures), dim3(1), 0, st, (const float*)rowSsim, (const uint32_t*)rowCnt, numRows, frame);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -623,7 +623,7 @@ extern "C" int x265hip_sao_apply_pictures(void* stream, const void* in, void* ou
     { set_error("sao_apply: bad arguments (out of place only)"); return X265HIP_EARG; }
     const int lg = ctuSize == 64 ? 6 : ctuSize == 32 ? 5 : ctuSize == 16 ? 4 : 3;        // 8: the chroma plane of a 4:2:0 picture with 16x16 CTUs
     const int n = ((picWidth + ctuSize - 1) / ctuSize) * ((picHeight + ctuSize - 1) / ctuSize);
-    hipLaunchKernelGGL(sao_apply_kernel, dim3((picWidth + 255) / 256, (picHeight + 3) / 4, nPictures), dim3(256), 0, (hipStream_t)stream, (const pixel*)in, (pixel*)out, stride,
+    XH_KLAUNCH(sao_apply_kernel, dim3((picWidth + 255) / 256, (picHeight + 3) / 4, nPictures), dim3(256), 0, (hipStream_t)stream, (const pixel*)in, (pixel*)out, stride,
                        picWidth, picHeight, ctuSize, lg, params, pictureElems, pictureElems, (int64_t)n * 6);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

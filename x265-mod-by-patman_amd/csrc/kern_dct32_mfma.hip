@@ -231,7 +231,7 @@ int xh_dct32_mfma(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t
 {
     int blocks = (n + 3) / 4;
     if (blocks > 4096) blocks = 4096;       // grid-stride: constant operands are amortised over many TUs
-    hipLaunchKernelGGL(dct32_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, ss, sOff, dst, dOff, n);
+    XH_KLAUNCH(dct32_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, ss, sOff, dst, dOff, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -240,7 +240,7 @@ int xh_idct32_mfma(hipStream_t st, const int16_t* src, const int32_t* sOff, int1
 {
     int blocks = (n + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(idct32_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, sOff, dst, ds, dOff, n);
+    XH_KLAUNCH(idct32_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, sOff, dst, ds, dOff, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -249,7 +249,7 @@ int xh_dct16_mfma(hipStream_t st, const int16_t* src, intptr_t ss, const int32_t
 {
     int blocks = ((n + 1) / 2 + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(dct16_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, ss, sOff, dst, dOff, n);
+    XH_KLAUNCH(dct16_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, ss, sOff, dst, dOff, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -257,7 +257,7 @@ int xh_idct16_mfma(hipStream_t st, const int16_t* src, const int32_t* sOff, int1
 {
     int blocks = ((n + 1) / 2 + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(idct16_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, sOff, dst, ds, dOff, n);
+    XH_KLAUNCH(idct16_mfma_kernel, dim3(blocks), dim3(256), 0, st, src, sOff, dst, ds, dOff, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -217,8 +217,8 @@ extern "C" int x265hip_deblock_pictures(void* stream, const x265hip_deblock_job*
     const int lgUpc = d0.ctuSize == 64 ? 4 : d0.ctuSize == 32 ? 3 : 2, nx = (d0.width + d0.ctuSize - 1) / d0.ctuSize, uw = d0.width >> 2, uh = d0.height >> 2;
     for (int i = 0; i < nPictures; i++)
         if (jobsHost[i].bsOut) XH_HIP(hipMemsetAsync(jobsHost[i].bsOut, 0, (size_t)2 * uw * uh, st));
-    hipLaunchKernelGGL(deblock_pictures_kernel<0>, dim3((uw / 2 + 63) / 64, (uh + 3) / 4, nPictures), dim3(256), 0, st, jobsDevice, strideY, strideC, lgUpc, nx);
-    hipLaunchKernelGGL(deblock_pictures_kernel<1>, dim3((uw + 63) / 64, (uh / 2 + 3) / 4, nPictures), dim3(256), 0, st, jobsDevice, strideY, strideC, lgUpc, nx);
+    XH_KLAUNCH(deblock_pictures_kernel<0>, dim3((uw / 2 + 63) / 64, (uh + 3) / 4, nPictures), dim3(256), 0, st, jobsDevice, strideY, strideC, lgUpc, nx);
+    XH_KLAUNCH(deblock_pictures_kernel<1>, dim3((uw + 63) / 64, (uh / 2 + 3) / 4, nPictures), dim3(256), 0, st, jobsDevice, strideY, strideC, lgUpc, nx);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -234,8 +234,8 @@ extern "C" int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* de
     hipStream_t st = (hipStream_t)stream;
     const int lgUpc = d.ctuSize == 64 ? 4 : d.ctuSize == 32 ? 3 : 2, nx = (d.width + d.ctuSize - 1) / d.ctuSize, uw = d.width >> 2, uh = d.height >> 2;
     if (bsOut) XH_HIP(hipMemsetAsync(bsOut, 0, (size_t)2 * uw * uh, st));
-    hipLaunchKernelGGL(deblock_kernel<0>, dim3((uw / 2 + 63) / 64, (uh + 3) / 4), dim3(256), 0, st, d, (pixel*)Y, strideY, (pixel*)Cb, (pixel*)Cr, strideC, lgUpc, nx, bsOut);
-    hipLaunchKernelGGL(deblock_kernel<1>, dim3((uw + 63) / 64, (uh / 2 + 3) / 4), dim3(256), 0, st, d, (pixel*)Y, strideY, (pixel*)Cb, (pixel*)Cr, strideC, lgUpc, nx, bsOut);
+    XH_KLAUNCH(deblock_kernel<0>, dim3((uw / 2 + 63) / 64, (uh + 3) / 4), dim3(256), 0, st, d, (pixel*)Y, strideY, (pixel*)Cb, (pixel*)Cr, strideC, lgUpc, nx, bsOut);
+    XH_KLAUNCH(deblock_kernel<1>, dim3((uw + 63) / 64, (uh / 2 + 3) / 4), dim3(256), 0, st, d, (pixel*)Y, strideY, (pixel*)Cb, (pixel*)Cr, strideC, lgUpc, nx, bsOut);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

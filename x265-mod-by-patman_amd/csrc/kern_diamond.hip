@@ -155,7 +155,7 @@ extern "C" int x265hip_diamond_batch(void* stream, int w, int h, const void* cur
     if (n <= 0) return X265HIP_OK;
     if (!curPlane || !refPlane || !tasks || !costRow || !results || w < 4 || h < 4 || w > 64 || h > 64 || (w & 3) || costHalfRange < 1) return X265HIP_EARG;
     const size_t lds = 4 * (size_t)w * h * sizeof(pixel);
-    hipLaunchKernelGGL(diamond_kernel, dim3((n + 3) / 4), dim3(256), lds, (hipStream_t)stream, w, h, (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride,
+    XH_KLAUNCH(diamond_kernel, dim3((n + 3) / 4), dim3(256), lds, (hipStream_t)stream, w, h, (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride,
                        tasks, n, costRow + costHalfRange, costHalfRange, results);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

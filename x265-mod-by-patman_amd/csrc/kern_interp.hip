@@ -124,8 +124,8 @@ extern "C" int x265hip_interp_batch(void* stream, int op, int taps, int w, int h
     if (op < X265HIP_IP_HPP || op > X265HIP_IP_P2S || (taps != 8 && taps != 4) || w < 2 || h < 2 || w > 64 || h > 64)
     { set_error("interp_batch: bad op/taps/size"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
-    if (taps == 8) hipLaunchKernelGGL(interp_kernel<8>, dim3(n), dim3(256), 0, st, op, w, h, src, srcStride, srcOff, dst, dstStride, dstOff, coeffIdx, n);
-    else hipLaunchKernelGGL(interp_kernel<4>, dim3(n), dim3(256), 0, st, op, w, h, src, srcStride, srcOff, dst, dstStride, dstOff, coeffIdx, n);
+    if (taps == 8) XH_KLAUNCH(interp_kernel<8>, dim3(n), dim3(256), 0, st, op, w, h, src, srcStride, srcOff, dst, dstStride, dstOff, coeffIdx, n);
+    else XH_KLAUNCH(interp_kernel<4>, dim3(n), dim3(256), 0, st, op, w, h, src, srcStride, srcOff, dst, dstStride, dstOff, coeffIdx, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

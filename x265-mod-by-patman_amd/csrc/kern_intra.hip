@@ -386,7 +386,7 @@ extern "C" int x265hip_intra_filter_batch(void* stream, int N, const void* nb, c
 {
     if (n <= 0) return X265HIP_OK;
     if (bad_n(N)) { set_error("intra_filter_batch: N must be 4/8/16/32"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(intra_filter_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, (const pixel*)nb, nbOff, (pixel*)filt, filtOff, n);
+    XH_KLAUNCH(intra_filter_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, (const pixel*)nb, nbOff, (pixel*)filt, filtOff, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -395,7 +395,7 @@ extern "C" int x265hip_intra_pred_batch(void* stream, int N, const void* nb, con
 {
     if (n <= 0) return X265HIP_OK;
     if (bad_n(N) || !modeFilter) { set_error("intra_pred_batch: bad arguments"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(intra_pred_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, N, (const pixel*)nb, nbOff, (pixel*)dst, dstStride, dstOff, modeFilter, n);
+    XH_KLAUNCH(intra_pred_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, N, (const pixel*)nb, nbOff, (pixel*)dst, dstStride, dstOff, modeFilter, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -404,7 +404,7 @@ extern "C" int x265hip_intra_allangs_batch(void* stream, int N, const void* ref,
 {
     if (n <= 0) return X265HIP_OK;
     if (bad_n(N)) { set_error("intra_allangs_batch: N must be 4/8/16/32"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(intra_allangs_kernel, dim3(33, n), dim3(256), 0, (hipStream_t)stream, N, (const pixel*)ref, refOff, (const pixel*)filt, filtOff, (pixel*)dst, bLuma, n);
+    XH_KLAUNCH(intra_allangs_kernel, dim3(33, n), dim3(256), 0, (hipStream_t)stream, N, (const pixel*)ref, refOff, (const pixel*)filt, filtOff, (pixel*)dst, bLuma, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -426,23 +426,23 @@ extern "C" int x265hip_intra_cost_batch(void* stream, int log2Size, const void* 
     {
         if (!workspace || workspaceBytes < x265hip_intra_cost_workspace(6, n)) { set_error("intra_cost_batch: workspace too small for 64x64 CUs"); return X265HIP_EARG; }
         pixel* fencS = (pixel*)workspace; pixel* nbS = fencS + (size_t)n * 1024;
-        hipLaunchKernelGGL(intra_scale64_kernel, dim3(n), dim3(256), 0, st, (const pixel*)srcPlane, srcStride, srcOff, (const pixel*)nbRef, nbPitch, fencS, nbS, n);
+        XH_KLAUNCH(intra_scale64_kernel, dim3(n), dim3(256), 0, st, (const pixel*)srcPlane, srcStride, srcOff, (const pixel*)nbRef, nbPitch, fencS, nbS, n);
         XH_LAUNCH_CHECK();
         // "we do not estimate filtering for downscaled samples": both neighbour arrays are the scaled unfiltered one
-        hipLaunchKernelGGL((intra_scan_kernel<32, 1>), dim3(n), dim3(256), 0, st, 64, (const pixel*)fencS, (intptr_t)32, (const int32_t*)nullptr, (intptr_t)1024,
+        XH_KLAUNCH((intra_scan_kernel<32, 1>), dim3(n), dim3(256), 0, st, 64, (const pixel*)fencS, (intptr_t)32, (const int32_t*)nullptr, (intptr_t)1024,
                            (const pixel*)nbS, (const pixel*)nbS, 129, 2, costs, n);
     }
     else if (size == 4)     // 16 pixels: the workgroup-per-(mode, CU) form
-        hipLaunchKernelGGL(intra_cost_kernel, dim3(35, n), dim3(256), 0, st, size, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+        XH_KLAUNCH(intra_cost_kernel, dim3(35, n), dim3(256), 0, st, size, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     else if (size == 8)
-        hipLaunchKernelGGL((intra_scan_kernel<8, 4>), dim3((n + 3) / 4), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+        XH_KLAUNCH((intra_scan_kernel<8, 4>), dim3((n + 3) / 4), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     else if (size == 16)
-        hipLaunchKernelGGL((intra_scan_kernel<16, 4>), dim3((n + 3) / 4), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+        XH_KLAUNCH((intra_scan_kernel<16, 4>), dim3((n + 3) / 4), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     else
-        hipLaunchKernelGGL((intra_scan_kernel<32, 1>), dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
+        XH_KLAUNCH((intra_scan_kernel<32, 1>), dim3(n), dim3(256), 0, st, size, (const pixel*)srcPlane, srcStride, srcOff, (intptr_t)0,
                            (const pixel*)nbRef, (const pixel*)nbFilt, nbPitch, 0, costs, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

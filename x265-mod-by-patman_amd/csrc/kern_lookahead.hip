@@ -1083,7 +1083,7 @@ extern "C" int x265hip_lookahead_intra_batch(void* stream, const void* lowres, i
     const int penalty = 5 * (int)lambda + 4;                                           // intraPenalty + lowresPenalty (:762-764)
     XH_HIP(hipMemsetAsync(sums, 0, sizeof(int64_t) * 2 * (size_t)nFrames, st));
     const LaGeom g = { (const pixel*)lowres, planeElems, stride, origin, widthInCU, heightInCU };
-    hipLaunchKernelGGL(la_intra_kernel, dim3(heightInCU, nFrames), dim3(256), 0, st, g, invQscale, penalty, intraCost, intraMode, lowresCosts, rowSatds,
+    XH_KLAUNCH(la_intra_kernel, dim3(heightInCU, nFrames), dim3(256), 0, st, g, invQscale, penalty, intraCost, intraMode, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -1135,7 +1135,7 @@ extern "C" int x265hip_lookahead_cost_batch_hme(void* stream, const void* lowres
     if (((int64_t)maxFrame + 1) * 4 * planeElems >= ((int64_t)1 << 31)) { set_error("lookahead_cost_batch: lowres buffer beyond 2^31 elements"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     const LaGeom g = { (const pixel*)lowres, planeElems, stride, origin, widthInCU, heightInCU };
-    hipLaunchKernelGGL(la_zero_kernel, dim3((unsigned)((nTasks * 3 + 255) / 256)), dim3(256), 0, st, tasks, nTasks, (unsigned long long*)sums);
+    XH_KLAUNCH(la_zero_kernel, dim3((unsigned)((nTasks * 3 + 255) / 256)), dim3(256), 0, st, tasks, nTasks, (unsigned long long*)sums);
     XH_LAUNCH_CHECK();
     // one 8-lane group per block of the widest wavefront step, in whole wavefronts, at most 1024 threads
     const int nslices = heightInCU / rowsPerSlice;
@@ -1158,17 +1158,17 @@ extern "C" int x265hip_lookahead_cost_batch_hme(void* stream, const void* lowres
     {   // level 0: the quarter-resolution sweep into its own slots (same slot numbers), one slice, never the weighted copy
         const LaGeom g0 = { (const pixel*)hme->lowerRes, hme->planeElems, hme->stride, hme->origin, hme->widthInCU, hme->heightInCU };
         const int widest0 = min(hme->heightInCU, (hme->widthInCU + 1) / 2), threads0 = min(1024, max(64, (widest0 * 8 + 63) / 64 * 64));
-        hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, 1), dim3(threads0), lds, st, g0, tasks, nFrames, costRow + costHalfRange, costR, hme->heightInCU, (uint32_t*)hme->mvs, hme->mvCosts,
+        XH_KLAUNCH(la_search_kernel, dim3(2 * nTasks, 1), dim3(threads0), lds, st, g0, tasks, nFrames, costRow + costHalfRange, costR, hme->heightInCU, (uint32_t*)hme->mvs, hme->mvCosts,
                            hme->range[0], hme->method[0], 0, (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, g);
         XH_LAUNCH_CHECK();
-        hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts,
+        XH_KLAUNCH(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts,
                            hme->range[1], hme->method[1], 1, (const uint32_t*)hme->mvs, (const int32_t*)hme->mvCosts, hme->widthInCU * hme->heightInCU, LaGeom{});
     }
     else
-        hipLaunchKernelGGL(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts,
+        XH_KLAUNCH(la_search_kernel, dim3(2 * nTasks, nslices), dim3(threads), lds, st, g, tasks, nFrames, costRow + costHalfRange, costR, rowsPerSlice, (uint32_t*)mvs, mvCosts,
                            LA_MERANGE, X265HIP_ME_HEX, 1, (const uint32_t*)nullptr, (const int32_t*)nullptr, 0, LaGeom{});
     XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, nFrames, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
+    XH_KLAUNCH(la_finish_kernel, dim3(heightInCU, nTasks), dim3(256), 0, st, g, tasks, nFrames, (const uint32_t*)mvs, mvCosts, intraCost, invQscale, lowresCosts, rowSatds,
                        (unsigned long long*)sums);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -1187,10 +1187,10 @@ extern "C" int x265hip_cutree_propagate(void* stream, int widthInCU, int heightI
     const int distScaleFactor = ((distP0 << 8) + (span >> 1)) / span;                    // slicetype.cpp:3853-3855
     const int bipredWeight = weightedBiPred ? 64 - (distScaleFactor >> 2) : 32;
     XH_HIP(hipMemsetAsync(workspace, 0, sizeof(uint64_t) * 2 * (size_t)ncu, st));
-    hipLaunchKernelGGL(cutree_scatter_kernel, dim3((ncu + 255) / 256), dim3(256), 0, st, widthInCU, heightInCU, bipredWeight, fpsFactor / 256, referenced,
+    XH_KLAUNCH(cutree_scatter_kernel, dim3((ncu + 255) / 256), dim3(256), 0, st, widthInCU, heightInCU, bipredWeight, fpsFactor / 256, referenced,
                        intraCost, lowresCosts, invQscale, (const uint32_t*)mvs0, (const uint32_t*)(mvs1 ? mvs1 : mvs0), propB, (unsigned long long*)workspace);
     XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cutree_fold_kernel, dim3((ncu + 255) / 256), dim3(256), 0, st, ncu, (const unsigned long long*)workspace, prop0, prop1 ? prop1 : prop0);
+    XH_KLAUNCH(cutree_fold_kernel, dim3((ncu + 255) / 256), dim3(256), 0, st, ncu, (const unsigned long long*)workspace, prop0, prop1 ? prop1 : prop0);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -1214,7 +1214,7 @@ extern "C" int x265hip_cutree_finish(void* stream, int ncu, const int32_t* intra
     if (ncu <= 0) return X265HIP_OK;
     if (!intraCost || !invQscale || !propagateCost || !qpAqOffset || !qpCuTreeOffset) { set_error("cutree_finish: bad arguments"); return X265HIP_EARG; }
     const double weightdelta = ref0Distance && weightedCostDelta > 0 ? 1.0 - weightedCostDelta : 0.0;          // slicetype.cpp:4107-4110
-    hipLaunchKernelGGL(cutree_finish_kernel, dim3((ncu + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncu, intraCost, invQscale, propagateCost, qpAqOffset, fpsFactor, weightdelta,
+    XH_KLAUNCH(cutree_finish_kernel, dim3((ncu + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncu, intraCost, invQscale, propagateCost, qpAqOffset, fpsFactor, weightdelta,
                        cuTreeStrength, qpCuTreeOffset);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -1225,7 +1225,7 @@ extern "C" int x265hip_propagate_cost_row(void* stream, int32_t* dst, const uint
 {
     if (len <= 0) return X265HIP_OK;
     if (!dst || !propagateIn || !intraCosts || !interCosts || !invQscales) { set_error("propagate_cost_row: bad arguments"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(propagate_row_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream, dst, propagateIn, intraCosts, interCosts, invQscales, fpsFactor / 256, len);
+    XH_KLAUNCH(propagate_row_kernel, dim3((len + 255) / 256), dim3(256), 0, (hipStream_t)stream, dst, propagateIn, intraCosts, interCosts, invQscales, fpsFactor / 256, len);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -1233,8 +1233,8 @@ extern "C" int x265hip_fix8_convert(void* stream, int pack, void* dst, const voi
 {
     if (count <= 0) return X265HIP_OK;
     if (!dst || !src) { set_error("fix8_convert: bad arguments"); return X265HIP_EARG; }
-    if (pack) hipLaunchKernelGGL(fix8_pack_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dst, (const double*)src, count);
-    else hipLaunchKernelGGL(fix8_unpack_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double*)dst, (const uint16_t*)src, count);
+    if (pack) XH_KLAUNCH(fix8_pack_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (uint16_t*)dst, (const double*)src, count);
+    else XH_KLAUNCH(fix8_unpack_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double*)dst, (const uint16_t*)src, count);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

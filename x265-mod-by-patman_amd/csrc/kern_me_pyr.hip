@@ -98,8 +98,8 @@ int xh_me_pyr(void* stream, const void* curPlane, intptr_t curStride, const void
     A.planes = (const pixel*)subpelPlanes; A.planeElems = planeElems;
     const int n = ctuRows * A.ctuPerRow;
     if (n <= 0) return X265HIP_OK;
-    if (parent64) hipLaunchKernelGGL((me_pyr_kernel<1, true>), dim3(n), dim3(256), 0, (hipStream_t)stream, A);
-    else hipLaunchKernelGGL((me_pyr_kernel<1, false>), dim3(n), dim3(256), 0, (hipStream_t)stream, A);        // the 32x32 level was searched by its own launch: results[0] seeds the 16x16 PUs
+    if (parent64) XH_KLAUNCH((me_pyr_kernel<1, true>), dim3(n), dim3(256), 0, (hipStream_t)stream, A);
+    else XH_KLAUNCH((me_pyr_kernel<1, false>), dim3(n), dim3(256), 0, (hipStream_t)stream, A);        // the 32x32 level was searched by its own launch: results[0] seeds the 16x16 PUs
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

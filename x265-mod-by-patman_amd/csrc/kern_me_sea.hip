@@ -71,14 +71,14 @@ __global__ __launch_bounds__(256) void integral_v_kernel(uint32_t* __restrict__ 
 extern "C" int x265hip_integral_init_h(void* stream, uint32_t* sum, const uint32_t* above, const void* pix, int boxWidth, int positions)
 {
     if (positions <= 0) return X265HIP_OK;
-    hipLaunchKernelGGL(integral_h_kernel, dim3((positions + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, above, (const pixel*)pix, boxWidth, positions);
+    XH_KLAUNCH(integral_h_kernel, dim3((positions + 255) / 256), dim3(256), 0, (hipStream_t)stream, sum, above, (const pixel*)pix, boxWidth, positions);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
 extern "C" int x265hip_integral_init_v(void* stream, uint32_t* top, const uint32_t* below, int positions)
 {
     if (positions <= 0) return X265HIP_OK;
-    hipLaunchKernelGGL(integral_v_kernel, dim3((positions + 255) / 256), dim3(256), 0, (hipStream_t)stream, top, below, positions);
+    XH_KLAUNCH(integral_v_kernel, dim3((positions + 255) / 256), dim3(256), 0, (hipStream_t)stream, top, below, positions);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -93,10 +93,10 @@ extern "C" int x265hip_sea_integral_planes(void* stream, const void* picPadded, 
     { set_error("sea_integral_planes: bad arguments"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     const int64_t rsElems = (int64_t)stride * rows;
-    hipLaunchKernelGGL(sea_rowsum_kernel, dim3((unsigned)((stride + 255) / 256), rows), dim3(256), 0, st, (const pixel*)picPadded, stride, rows, (int)stride,
+    XH_KLAUNCH(sea_rowsum_kernel, dim3((unsigned)((stride + 255) / 256), rows), dim3(256), 0, st, (const pixel*)picPadded, stride, rows, (int)stride,
                        (rowsum_t*)workspace, rsElems);
     XH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sea_box_kernel, dim3((unsigned)((stride + 255) / 256), (rows + SEA_STRIP - 1) / SEA_STRIP, 12), dim3(256), 0, st, (const rowsum_t*)workspace, rsElems, stride, rows, (int)stride,
+    XH_KLAUNCH(sea_box_kernel, dim3((unsigned)((stride + 255) / 256), (rows + SEA_STRIP - 1) / SEA_STRIP, 12), dim3(256), 0, st, (const rowsum_t*)workspace, rsElems, stride, rows, (int)stride,
                        planes, planeElems);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

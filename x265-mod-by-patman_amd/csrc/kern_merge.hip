@@ -204,8 +204,8 @@ extern "C" int x265hip_inter_merge_batch(void* stream, int w, int h, const void*
             a.res[l * X265HIP_MAX_REF + r] = p->results[l][r]; a.mvpSrc[l * X265HIP_MAX_REF + r] = p->mvpSource[l][r]; a.planes[l * X265HIP_MAX_REF + r] = (const pixel*)p->subpelPlanes[l][r];
         }
     a.bitsCentre = p->bitsRow + p->bitsHalfRange; a.bitsHalf = p->bitsHalfRange; a.lambda = p->lambda; a.out = out;
-    if (a.isP || !a.bidir) hipLaunchKernelGGL(inter_merge_uni_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(inter_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    if (a.isP || !a.bidir) XH_KLAUNCH(inter_merge_uni_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    else XH_KLAUNCH(inter_merge_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -218,7 +218,7 @@ extern "C" int x265hip_bidir_satd_batch(void* stream, int w, int h, const void* 
     MergeArgs a{};
     a.w = w; a.h = h; a.n = n; a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.planeElems = planeElems;
     a.planes[0] = (const pixel*)subpelPlanes0; a.planes[X265HIP_MAX_REF] = (const pixel*)subpelPlanes1;
-    hipLaunchKernelGGL(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd, (const int8_t*)nullptr, (const int8_t*)nullptr);
+    XH_KLAUNCH(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd, (const int8_t*)nullptr, (const int8_t*)nullptr);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -232,7 +232,7 @@ extern "C" int x265hip_bidir_satd_batch_refs(void* stream, int w, int h, const v
     MergeArgs a{};
     a.w = w; a.h = h; a.n = n; a.cur = (const pixel*)curPlane; a.cs = curStride; a.rs = refStride; a.planeElems = planeElems;
     for (int r = 0; r < X265HIP_MAX_REF; r++) { a.planes[r] = (const pixel*)(subpelPlanes0[r] ? subpelPlanes0[r] : subpelPlanes0[0]); a.planes[X265HIP_MAX_REF + r] = (const pixel*)(subpelPlanes1[r] ? subpelPlanes1[r] : subpelPlanes1[0]); }
-    hipLaunchKernelGGL(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd, ref0, ref1);
+    XH_KLAUNCH(bidir_satd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, tasks, satd, ref0, ref1);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -241,7 +241,7 @@ extern "C" int x265hip_ads(void* stream, int parts, int lx, const int32_t* encDC
                            const uint16_t* costMvX, int16_t* mvs, int width, int thresh, int32_t* nmv)
 {
     if ((parts != 1 && parts != 2 && parts != 4) || width < 0 || !encDC || !sums || !costMvX || !mvs || !nmv) { set_error("ads: bad arguments"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(ads_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, parts, lx >> 1, encDC, sums, delta, costMvX, mvs, width, thresh, nmv);
+    XH_KLAUNCH(ads_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, parts, lx >> 1, encDC, sums, delta, costMvX, mvs, width, thresh, nmv);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -255,7 +255,7 @@ extern "C" int x265hip_pixelcmp_batch(void* stream, int op, int w, int h,
     { set_error("pixelcmp_batch: bad op/size %d %dx%d", op, w, h); return X265HIP_EARG; }
     if ((op == X265HIP_CMP_SA8D || op == X265HIP_CMP_PSY_COST) && (w != h || (w & (w - 1))))
     { set_error("pixelcmp_batch: sa8d/psy need square power-of-two blocks"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(pixelcmp_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+    XH_KLAUNCH(pixelcmp_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        op, w, h, a, strideA, offA, b, strideB, offB, n, out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;

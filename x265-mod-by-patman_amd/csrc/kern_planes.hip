@@ -424,10 +424,10 @@ extern "C" int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_
     dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
 #endif
 #if X265_DEPTH == 8
-    hipLaunchKernelGGL(subpel_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+    XH_KLAUNCH(subpel_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                        (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
 #else
-    hipLaunchKernelGGL(subpel_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+    XH_KLAUNCH(subpel_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
                        (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
 #endif
     XH_LAUNCH_CHECK();
@@ -446,7 +446,7 @@ int xh_subpel_planes_tiled(void* stream, const void* refPlane, intptr_t stride, 
     if (!refPlane || !outPlanes || !xh_subpel_planes_tiled_ok(stride, rows) || rows < 8 || planeElems < (int64_t)stride * rows || (planeElems & 3) || (((uintptr_t)refPlane | (uintptr_t)outPlanes) & 7))
     { set_error("subpel_planes_tiled: bad arguments"); return X265HIP_EARG; }
     dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
-    hipLaunchKernelGGL(subpel_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
+    XH_KLAUNCH(subpel_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 #endif

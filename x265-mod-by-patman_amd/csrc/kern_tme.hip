@@ -308,20 +308,20 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
                 for (int r = 0; r < a->numRef[l]; r++)
                 {
                     const x265hip_tme_ref& R = a->refs[l][r];
-                    hipLaunchKernelGGL(tme_gather_kernel, grid, block, 0, st, s, e, k, a->nSteps, pi, l, r, nCtu, a->table, a->areaBest, a->temporal, R.refTable, R.lowresMv, state, sel);
+                    XH_KLAUNCH(tme_gather_kernel, grid, block, 0, st, s, e, k, a->nSteps, pi, l, r, nCtu, a->table, a->areaBest, a->temporal, R.refTable, R.lowresMv, state, sel);
                     int rc = x265hip_select_mvp_batch(stream, pw, ph, a->curPlane, a->stride, R.reconPhase, a->planeElems, a->stride, sel, nCtu, selRes);
                     if (rc) { set_error("tme_frame: select_mvp_batch %dx%d failed", pw, ph); return rc; }
-                    hipLaunchKernelGGL(tme_build_kernel, grid, block, 0, st, s, e, pi, nCtu, selRes, state, tA, tB, a->qpIndex, k, a->nSteps);
+                    XH_KLAUNCH(tme_build_kernel, grid, block, 0, st, s, e, pi, nCtu, selRes, state, tA, tB, a->qpIndex, k, a->nSteps);
                     rc = x265hip_me_batch_rows(stream, pw, ph, a->curPlane, a->stride, R.mePlane, a->stride, tA, nCtu, a->costRows, a->costHalfRange, a->searchRange, a->searchMethod,
                                           a->subpelRefine, rA, nullptr, R.mePhase, a->planeElems);
                     if (rc) return rc;
                     rc = x265hip_me_batch_rows(stream, pw, ph, a->curPlane, a->stride, R.mePlane, a->stride, tB, nCtu, a->costRows, a->costHalfRange, a->searchRange, a->searchMethod,
                                           a->subpelRefine, rB, nullptr, R.mePhase, a->planeElems);
                     if (rc) return rc;
-                    hipLaunchKernelGGL(tme_cost_kernel, grid, block, 0, st, s, e, pi, l, r, nCtu, rA, rB, a->costRows, a->costHalfRange, bitsCentre, a->bitsHalfRange, state,
+                    XH_KLAUNCH(tme_cost_kernel, grid, block, 0, st, s, e, pi, l, r, nCtu, rA, rB, a->costRows, a->costHalfRange, bitsCentre, a->bitsHalfRange, state,
                                        a->qpIndex, k, a->nSteps, lambdas);
                 }
-            hipLaunchKernelGGL(tme_bidir_kernel, grid, block, 0, st, s, e, pi, nCtu, state, b0, b1, br0, br1);
+            XH_KLAUNCH(tme_bidir_kernel, grid, block, 0, st, s, e, pi, nCtu, state, b0, b1, br0, br1);
             if (!a->isP && e.part != 0 && e.cuSize != 8)
             {   // the bidirectional candidate exists for this shape: its two distortions, each PU against the references it chose per list
                 int rc = x265hip_bidir_satd_batch_refs(stream, pw, ph, a->curPlane, a->stride, ph0, ph1, a->planeElems, a->stride, b0, br0, br1, nCtu, s0);
@@ -329,7 +329,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
                 rc = x265hip_bidir_satd_batch_refs(stream, pw, ph, a->curPlane, a->stride, ph0, ph1, a->planeElems, a->stride, b1, br0, br1, nCtu, s1);
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL(tme_finish_kernel, grid, block, 0, st, s, e, pi, nCtu, s0, s1, bitsCentre, a->bitsHalfRange, state, a->table);
+            XH_KLAUNCH(tme_finish_kernel, grid, block, 0, st, s, e, pi, nCtu, s0, s1, bitsCentre, a->bitsHalfRange, state, a->table);
         }
     }
     XH_HIP(hipEventRecord(evJoin[chain], st));
@@ -354,7 +354,7 @@ int xh_tme_slots(void* stream, x265hip_inter_choice* table, x265hip_inter_choice
 {
     const int total = nUsed * nCtu;
     if (total <= 0) return X265HIP_OK;
-    hipLaunchKernelGGL(tme_slots_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, packed, slots, nUsed, total, toTable);
+    XH_KLAUNCH(tme_slots_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, table, packed, slots, nUsed, total, toTable);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void tme_area_kernel(const x265hip_me_result* 
 int xh_tme_area(void* stream, const x265hip_me_result* res, const int32_t* where, int nTasks, int nl, int numRef0, int numRef1, const int16_t* median, int16_t* areaBest)
 {
     if (nTasks <= 0) return X265HIP_OK;
-    hipLaunchKernelGGL(tme_area_kernel, dim3((nTasks + 255) / 256, 2 * X265HIP_MAX_REF), dim3(256), 0, (hipStream_t)stream, res, where, nTasks, nl, numRef0, numRef1, median, areaBest);
+    XH_KLAUNCH(tme_area_kernel, dim3((nTasks + 255) / 256, 2 * X265HIP_MAX_REF), dim3(256), 0, (hipStream_t)stream, res, where, nTasks, nl, numRef0, numRef1, median, areaBest);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
 
 template<int N> int launch_tq(hipStream_t st, const TqArgs& a)
 {
-    if (a.ref1) hipLaunchKernelGGL((tq_kernel<N, true>), dim3((a.n + 3) / 4), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((tq_kernel<N, false>), dim3((a.n + 3) / 4), dim3(256), 0, st, a);
+    if (a.ref1) XH_KLAUNCH((tq_kernel<N, true>), dim3((a.n + 3) / 4), dim3(256), 0, st, a);
+    else XH_KLAUNCH((tq_kernel<N, false>), dim3((a.n + 3) / 4), dim3(256), 0, st, a);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

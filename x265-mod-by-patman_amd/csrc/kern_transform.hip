@@ -155,7 +155,7 @@ template<int N, int OP> int launch_tr(hipStream_t st, const int16_t* src, intptr
                                       int16_t* dst, intptr_t ds, const int32_t* dOff, int n)
 {
     constexpr int TPB = N * N >= 256 ? 1 : 256 / (N * N);
-    hipLaunchKernelGGL((transform_kernel<N, OP>), dim3((n + TPB - 1) / TPB), dim3(256), 0, st, src, ss, sOff, dst, ds, dOff, n);
+    XH_KLAUNCH((transform_kernel<N, OP>), dim3((n + TPB - 1) / TPB), dim3(256), 0, st, src, ss, sOff, dst, ds, dOff, n);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -269,9 +269,9 @@ extern "C" int x265hip_transform_batch(void* stream, int op, int N, const int16_
     }
     if (op == X265HIP_TR_LOWPASS)
     {
-        if (N == 8) hipLaunchKernelGGL(lowpass_kernel<4>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
-        else if (N == 16) hipLaunchKernelGGL(lowpass_kernel<8>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
-        else if (N == 32) hipLaunchKernelGGL(lowpass_kernel<16>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
+        if (N == 8) XH_KLAUNCH(lowpass_kernel<4>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
+        else if (N == 16) XH_KLAUNCH(lowpass_kernel<8>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
+        else if (N == 32) XH_KLAUNCH(lowpass_kernel<16>, dim3(n), dim3(256), 0, st, src, srcStride, srcOff, dst, dstOff, n);
         else { set_error("lowpass dct exists for 8, 16 and 32"); return X265HIP_EARG; }
         XH_LAUNCH_CHECK();
         return X265HIP_OK;
@@ -306,8 +306,8 @@ static int quant_common(bool nq, void* stream, const int16_t* coef, const int32_
     hipStream_t st = (hipStream_t)stream;
     const int total = numCoeff * n;
     if (numSig && numCoeff >= 64) XH_HIP(hipMemsetAsync(numSig, 0, sizeof(uint32_t) * n, st));
-    if (nq) hipLaunchKernelGGL((quant_kernel<false, true>), dim3((total + 255) / 256), dim3(256), 0, st, coef, qc, deltaU, qCoef, qBits, add, numCoeff, total, numSig);
-    else hipLaunchKernelGGL((quant_kernel<true, false>), dim3((total + 255) / 256), dim3(256), 0, st, coef, qc, deltaU, qCoef, qBits, add, numCoeff, total, numSig);
+    if (nq) XH_KLAUNCH((quant_kernel<false, true>), dim3((total + 255) / 256), dim3(256), 0, st, coef, qc, deltaU, qCoef, qBits, add, numCoeff, total, numSig);
+    else XH_KLAUNCH((quant_kernel<true, false>), dim3((total + 255) / 256), dim3(256), 0, st, coef, qc, deltaU, qCoef, qBits, add, numCoeff, total, numSig);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -321,7 +321,7 @@ extern "C" int x265hip_dequant_normal_batch(void* stream, const int16_t* q, int1
 {
     if (num <= 0) return X265HIP_OK;
     if (shift < 1) { set_error("dequant_normal: shift must be >= 1"); return X265HIP_EARG; }
-    hipLaunchKernelGGL(dequant_kernel, dim3((num + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, (const int32_t*)nullptr, coef, num, num, scale, shift);
+    XH_KLAUNCH(dequant_kernel, dim3((num + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, (const int32_t*)nullptr, coef, num, num, scale, shift);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -330,25 +330,25 @@ extern "C" int x265hip_dequant_scaling_batch(void* stream, const int16_t* q, con
     if (n <= 0) return X265HIP_OK;
     if (!deq) { set_error("dequant_scaling: NULL table"); return X265HIP_EARG; }
     const int total = numCoeff * n;
-    hipLaunchKernelGGL(dequant_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, deq, coef, numCoeff, total, per, shift);
+    XH_KLAUNCH(dequant_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, deq, coef, numCoeff, total, per, shift);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
 int xh_count_nonzero(hipStream_t st, int N, const int16_t* q, int n, uint32_t* out)
 {
-    hipLaunchKernelGGL(count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, N, q, (intptr_t)N, (int16_t*)nullptr, n, out);
+    XH_KLAUNCH(count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, N, q, (intptr_t)N, (int16_t*)nullptr, n, out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
 int xh_copy_count(hipStream_t st, int N, const int16_t* resi, intptr_t rs, int16_t* coef, uint32_t* out)
 {
-    hipLaunchKernelGGL(count_kernel, dim3(1), dim3(256), 0, st, N, resi, rs, coef, 1, out);
+    XH_KLAUNCH(count_kernel, dim3(1), dim3(256), 0, st, N, resi, rs, coef, 1, out);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
 int xh_denoise(hipStream_t st, int16_t* coef, uint32_t* resSum, const uint16_t* offset, int num)
 {
-    hipLaunchKernelGGL(denoise_kernel, dim3((num + 255) / 256), dim3(256), 0, st, coef, resSum, offset, num);
+    XH_KLAUNCH(denoise_kernel, dim3((num + 255) / 256), dim3(256), 0, st, coef, resSum, offset, num);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

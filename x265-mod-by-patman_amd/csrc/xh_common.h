@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/x265hip.h"
+#include "xh_fence.h"
 
 #ifndef X265_DEPTH
 #error "build with -DX265_DEPTH=8, 10 or 12"
@@ -45,6 +46,12 @@ int hip_fail(hipError_t e, const char* what);          // records + returns X265
 [[noreturn]] void fatal(const char* what);             // slot functions cannot return errors
 
 #define XH_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return xh::hip_fail(e_, #call); } while (0)
+// every kernel launch of the library: a fence build (xh_fence.h) notes it and waits for it, so that a page fault names its kernel
+#ifdef X265HIP_FENCE
+#define XH_KLAUNCH(k, ...) do { hipLaunchKernelGGL(k, __VA_ARGS__); xh::launch_note(__FILE__ " " #k, __LINE__); } while (0)
+#else
+#define XH_KLAUNCH(...) hipLaunchKernelGGL(__VA_ARGS__)
+#endif
 #define XH_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return xh::hip_fail(e_, "kernel launch"); } while (0)
 
 // ---- device helpers ----

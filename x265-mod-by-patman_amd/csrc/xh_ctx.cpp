@@ -78,12 +78,12 @@ struct x265hip_batch
     bool ownStart64 = true;                  // STAR: the 64x64 level without its start-stage launch (kern_me_star.hip xh_me_star_own64); x265hip_batch_set_mode(X265HIP_BATCH_START64_LAUNCH) turns it off for A/B
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
-    std::vector<xh::KernelEvents> evStar; int starSteps = 0; const xh::KernelEvents* starNow = nullptr;                // star64_kernel alone, first reference of sub-batch 0 (x265hip_batch_read_kernel_timing)
+    std::vector<xh::KernelEvents> evStar; bool starValid[kTimingSets] = {}; int starSteps = 0; const xh::KernelEvents* starNow = nullptr;                // star64_kernel alone, first reference of sub-batch 0 (x265hip_batch_read_kernel_timing)
     std::vector<void*> owned;
     template<class T> int alloc(T*& p, size_t n)
     {
         void* v = nullptr;
-        XH_HIP(hipMalloc(&v, n * sizeof(T)));
+        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), XH_ALLOC_TAG));
         owned.push_back(v); p = (T*)v;
         return X265HIP_OK;
     }
@@ -277,7 +277,7 @@ extern "C" void x265hip_batch_destroy(x265hip_batch* b)
     if (b->evFork) (void)hipEventDestroy(b->evFork);
     for (hipEvent_t e : b->evStage) (void)hipEventDestroy(e);
     for (auto& k : b->evStar) { (void)hipEventDestroy(k.before); (void)hipEventDestroy(k.after); }
-    for (void* p : b->owned) (void)hipFree(p);
+    for (void* p : b->owned) (void)xh::dev_free(p);
     delete b;
 }
 
@@ -450,15 +450,26 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
                 const x265hip_me_result* parent = parentSlot >= 0 ? b->res[l][r][parentSlot] : nullptr;
 #ifdef X265HIP_EXPERIMENTS
                 if (b->tiled && w == h)
+                {
                     rc = xh_me_star_tiled(st, w, h, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, parent, b->planes[l][r], planeElems, w == CTU && !parent && b->ownStart64);
-                else
+                    if (rc != X265HIP_OK) return rc;
+                    continue;
+                }
 #endif
-                if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && l == 0 && r == 0 && ev && b->starNow) { xh::tl_star64Events = b->starNow; b->starNow = nullptr; b->starSteps++; }
+                // star64_kernel alone: its event pair is armed only around a call that can launch it, and never outlives the call (the kernel's launcher clears the pointer
+                // when it records the events; a call that took another kernel -- merange beyond the band, an odd stride -- leaves it, and the step is then not counted)
+                const xh::KernelEvents* armed = nullptr;
+                if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && l == 0 && r == 0 && ev && b->starNow) { armed = b->starNow; b->starNow = nullptr; xh::tl_star64Events = armed; }
                 if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
                     rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, b->planes[l][r], planeElems);
                 else
                     rc = x265hip_me_batch(st, w, h, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.method, d.subme, out, parent,
                                           up ? b->planes[l][r] : nullptr, up ? planeElems : 0);
+                if (armed)
+                {
+                    if (!xh::tl_star64Events && rc == X265HIP_OK) { b->starValid[armed - b->evStar.data()] = true; b->starSteps++; }
+                    xh::tl_star64Events = nullptr;
+                }
                 if (rc != X265HIP_OK) return rc;
             }
         if (b->needChoice)
@@ -688,10 +699,17 @@ extern "C" int x265hip_batch_read_kernel_timing(x265hip_batch* b, float* ms)
     for (int s = 0; s < b->nsub; s++) XH_HIP(hipStreamSynchronize(b->sub[s]));
     const int sets = b->starSteps < kTimingSets ? b->starSteps : kTimingSets;
     double sum = 0;
-    for (int k = 0; k < sets; k++) { float t = 0; XH_HIP(hipEventElapsedTime(&t, b->evStar[k].before, b->evStar[k].after)); sum += t; }
-    *ms = (float)(sum / sets);
+    int used = 0;
+    for (int k = 0; k < sets; k++)
+    {
+        if (!b->starValid[k]) continue;
+        float t = 0; XH_HIP(hipEventElapsedTime(&t, b->evStar[k].before, b->evStar[k].after)); sum += t; used++;
+    }
     b->starSteps = 0;
-    return sets;
+    for (bool& v : b->starValid) v = false;
+    if (!used) return 0;
+    *ms = (float)(sum / used);
+    return used;
 }
 extern "C" int x265hip_batch_stage_count(const x265hip_batch* b) { return b ? (int)b->stageNames.size() : 0; }
 extern "C" const char* x265hip_batch_stage_name(const x265hip_batch* b, int i) { return (b && i >= 0 && i < (int)b->stageNames.size()) ? b->stageNames[i].c_str() : nullptr; }

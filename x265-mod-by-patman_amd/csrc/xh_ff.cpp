@@ -26,7 +26,7 @@ struct x265hip_ff
     template<class T> int alloc(T*& p, size_t n)
     {
         void* v = nullptr;
-        XH_HIP(hipMalloc(&v, n * sizeof(T)));
+        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), XH_ALLOC_TAG));
         owned.push_back(v); p = (T*)v;
         return X265HIP_OK;
     }
@@ -61,7 +61,7 @@ extern "C" void x265hip_ff_destroy(x265hip_ff* f)
     if (!f) return;
     (void)hipSetDevice(x265hip_ctx_device(f->ctx));
     (void)hipStreamSynchronize((hipStream_t)x265hip_ctx_stream(f->ctx));
-    for (void* p : f->owned) (void)hipFree(p);
+    for (void* p : f->owned) (void)xh::dev_free(p);
     delete f;
 }
 

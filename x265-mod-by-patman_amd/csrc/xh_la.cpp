@@ -30,7 +30,7 @@ struct x265hip_la
     struct Slot { uint64_t key = 0; uint64_t used = 0; bool lower = false; bool haveIntra = false; };      // haveIntra: the slot's intra costs are THIS picture's (a picture that came up as a reference has none yet)
     std::vector<Slot> slots; uint64_t tick = 0;
     // cuTree (x265hip_la_cutree_propagate): staging of one propagation step, allocated at its first call
-    int32_t *ctIntra = nullptr, *ctInvq = nullptr; uint16_t *ctLc = nullptr, *ctProp[3] = {}; int16_t *ctMv[2] = {}; void* ctWork = nullptr;
+    int32_t *ctIntra = nullptr, *ctInvq = nullptr; uint16_t *ctLc = nullptr, *ctProp[3] = {}; int16_t *ctMv[2] = {}; uint64_t* ctWork = nullptr;
     std::mutex mu;                                // the device side: one call at a time on the context's stream
     // estimates that arrive while a launch is in flight are queued and go up together (x265hip_la_estimate)
     std::mutex qmu; std::condition_variable qcv; bool leader = false;
@@ -40,7 +40,7 @@ struct x265hip_la
     template<class T> int alloc(T*& p, size_t n)
     {
         void* v = nullptr;
-        XH_HIP(hipMalloc(&v, n * sizeof(T)));
+        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), XH_ALLOC_TAG));
         owned.push_back(v); p = (T*)v;
         return X265HIP_OK;
     }
@@ -94,7 +94,7 @@ extern "C" void x265hip_la_destroy(x265hip_la* a)
     if (!a) return;
     (void)hipSetDevice(x265hip_ctx_device(a->ctx));
     (void)hipStreamSynchronize((hipStream_t)x265hip_ctx_stream(a->ctx));
-    for (void* p : a->owned) (void)hipFree(p);
+    for (void* p : a->owned) (void)xh::dev_free(p);
     delete a;
 }
 
@@ -341,14 +341,11 @@ extern "C" int x265hip_la_cutree_propagate(x265hip_la* a, const x265hip_la_cutre
     XH_HIP(hipSetDevice(x265hip_ctx_device(a->ctx)));
     hipStream_t st = (hipStream_t)x265hip_ctx_stream(a->ctx);
     const size_t n = (size_t)a->ncu;
-    if (!a->ctWork)
-    {
+    {   // staging buffers: each allocated once (a failure half way leaves the earlier ones in place for the next call)
         int rc;
-        if ((rc = a->alloc(a->ctIntra, n)) || (rc = a->alloc(a->ctInvq, n)) || (rc = a->alloc(a->ctLc, n)) || (rc = a->alloc(a->ctProp[0], n)) || (rc = a->alloc(a->ctProp[1], n)) ||
-            (rc = a->alloc(a->ctProp[2], n)) || (rc = a->alloc(a->ctMv[0], 2 * n)) || (rc = a->alloc(a->ctMv[1], 2 * n))) return rc;
-        uint64_t* w = nullptr;
-        if ((rc = a->alloc(w, 2 * n))) return rc;
-        a->ctWork = w;
+        auto once = [&](auto*& p, size_t count) -> int { return p ? X265HIP_OK : a->alloc(p, count); };
+        if ((rc = once(a->ctIntra, n)) || (rc = once(a->ctInvq, n)) || (rc = once(a->ctLc, n)) || (rc = once(a->ctProp[0], n)) || (rc = once(a->ctProp[1], n)) ||
+            (rc = once(a->ctProp[2], n)) || (rc = once(a->ctMv[0], 2 * n)) || (rc = once(a->ctMv[1], 2 * n)) || (rc = once(a->ctWork, 2 * n))) return rc;
     }
     XH_HIP(hipMemcpyAsync(a->ctIntra, d->intraCost, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     XH_HIP(hipMemcpyAsync(a->ctInvq, d->invQscale, n * sizeof(int32_t), hipMemcpyHostToDevice, st));

@@ -39,8 +39,8 @@ struct CtxHolder
     {
         if (!c) return;
         (void)hipStreamSynchronize(c->stream);
-        for (char* p : c->retired) (void)hipFree(p);
-        (void)hipFree(c->arena); (void)hipFree(c->zeros); (void)hipHostFree(c->pinned); (void)hipStreamDestroy(c->stream);
+        for (char* p : c->retired) (void)xh::dev_free(p);
+        (void)xh::dev_free(c->arena); (void)xh::dev_free(c->zeros); (void)hipHostFree(c->pinned); (void)hipStreamDestroy(c->stream);
         delete c;
     }
 };
@@ -56,9 +56,9 @@ ThreadCtx& ThreadCtx::get()
     if (dev >= 0 && hipSetDevice(dev) != hipSuccess) fatal("hipSetDevice failed");     // a new host thread starts on device 0 otherwise
     ThreadCtx* c = new ThreadCtx();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) fatal("hipStreamCreate failed");
-    if (hipMalloc((void**)&c->arena, kArena) != hipSuccess) fatal("hipMalloc(arena) failed");
+    if (xh::dev_alloc((void**)&c->arena, kArena, "slot arena") != hipSuccess) fatal("hipMalloc(arena) failed");
     c->arenaSize = kArena;
-    if (hipMalloc((void**)&c->zeros, 256) != hipSuccess) fatal("hipMalloc(zeros) failed");
+    if (xh::dev_alloc((void**)&c->zeros, 256, "zero offsets") != hipSuccess) fatal("hipMalloc(zeros) failed");
     if (hipHostMalloc((void**)&c->pinned, 4096, hipHostMallocDefault) != hipSuccess) fatal("hipHostMalloc failed");
     t_ctx.c = c;
     if (hipMemsetAsync(c->zeros, 0, 256, c->stream) != hipSuccess) fatal("hipMemset failed");
@@ -69,13 +69,20 @@ ThreadCtx& ThreadCtx::get()
 // (their chunk is retired, not freed) until the next call's reset(), which runs after that call's sync().
 void* ThreadCtx::dalloc(size_t bytes)
 {
+    if (xh::kFence)
+    {   // fence build: every block of a slot call is its own fenced allocation (freed by the next reset())
+        void* p = nullptr;
+        if (xh::dev_alloc(&p, bytes, "slot block") != hipSuccess) { set_error("device memory exhausted (fence build, %zu bytes)", bytes); fatal("arena"); }
+        retired.push_back((char*)p);
+        return p;
+    }
     size_t off = (arenaUsed + 255) & ~(size_t)255;
     if (off + bytes > arenaSize)
     {
         size_t want = arenaSize * 2;
         while (want < bytes + 256) want *= 2;
         char* bigger = nullptr;
-        if (hipMalloc((void**)&bigger, want) != hipSuccess) { set_error("device memory exhausted growing the slot arena to %zu bytes", want); fatal("arena"); }
+        if (xh::dev_alloc((void**)&bigger, want, "slot arena") != hipSuccess) { set_error("device memory exhausted growing the slot arena to %zu bytes", want); fatal("arena"); }
         retired.push_back(arena);
         arena = bigger; arenaSize = want; off = 0;
     }
@@ -88,7 +95,7 @@ void ThreadCtx::reset()
     if (!retired.empty())
     {   // every slot call ends with sync(), so nothing queued on the stream still reads the retired chunks
         (void)hipStreamSynchronize(stream);
-        for (char* p : retired) (void)hipFree(p);
+        for (char* p : retired) (void)xh::dev_free(p);
         retired.clear();
     }
 }

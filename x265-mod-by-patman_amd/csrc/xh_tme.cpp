@@ -133,7 +133,7 @@ struct x265hip_tme
     template<class T> int alloc(T*& p, size_t n)
     {
         void* v = nullptr;
-        XH_HIP(hipMalloc(&v, n * sizeof(T)));
+        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), XH_ALLOC_TAG));
         owned.push_back(v); p = (T*)v;
         return X265HIP_OK;
     }
@@ -193,8 +193,8 @@ extern "C" void x265hip_tme_destroy(x265hip_tme* t)
         fprintf(stderr, "x265hip_tme: %d pictures, per picture: upload + phase planes %.2f ms, diamond stage %.2f ms, submit %.2f ms, drain + table down %.2f ms\n", t->pictures,
                 1e3 * t->sec[0] / t->pictures, 1e3 * t->sec[1] / t->pictures, 1e3 * t->sec[2] / t->pictures, 1e3 * t->sec[3] / t->pictures);
     if (t->hPacked) (void)hipHostFree(t->hPacked);
-    for (void* p : t->owned) (void)hipFree(p);
-    for (auto& kv : t->costRows) (void)hipFree(kv.second);
+    for (void* p : t->owned) (void)xh::dev_free(p);
+    for (auto& kv : t->costRows) (void)xh::dev_free(kv.second);
     delete t;
 }
 extern "C" int x265hip_tme_entries(const x265hip_tme* t, const x265hip_tme_step** steps) { if (!t) return 0; if (steps) *steps = t->steps.data(); return (int)t->steps.size(); }
@@ -295,7 +295,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
             std::vector<uint16_t> row(2 * kHalf + 1);
             if ((rc = x265hip_mvcost_row(d->qps[q], kHalf, row.data()))) return rc;
             void* v = nullptr;
-            XH_HIP(hipMalloc(&v, row.size() * sizeof(uint16_t)));
+            XH_HIP(xh::dev_alloc(&v, row.size() * sizeof(uint16_t), XH_ALLOC_TAG));
             XH_HIP(hipMemcpy(v, row.data(), row.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             t->costRows[d->qps[q]] = (uint16_t*)v;
             t->hostRows[d->qps[q]] = row;

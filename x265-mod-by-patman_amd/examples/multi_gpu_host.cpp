@@ -291,7 +291,9 @@ int run_procs(const Options& o)
             if (!r.rc) run_device(api, o, k, ready, go, r);
             else { ready(); go(); ready(); }
             char msg[512];
-            const int len = snprintf(msg, sizeof(msg), "%d %.9f %.9f %llu %s", r.rc, r.msPerStep, r.seconds, (unsigned long long)r.digest, r.error.c_str());
+            int len = snprintf(msg, sizeof(msg), "%d %.9f %.9f %llu %s", r.rc, r.msPerStep, r.seconds, (unsigned long long)r.digest, r.error.c_str());
+            if (len < 0) len = 0;
+            if (len > (int)sizeof(msg) - 1) len = (int)sizeof(msg) - 1;           // snprintf returns the untruncated length: a long error text is cut, not read past
             if (write(outfd, msg, (size_t)len + 1) != len + 1) _exit(1);
             _exit(0);
         }
