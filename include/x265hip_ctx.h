@@ -149,8 +149,15 @@ typedef struct x265hip_tme_host_ref {
     const struct x265hip_inter_choice* refTable;   /* that picture's own table or NULL (intra picture)                                           */
     const int16_t* lowresMv;                   /* Lowres::lowresMvs[l][dist] as x, y per 16x16 block, or NULL (not estimated / distance out of range) */
     uint64_t reconKey;                         /* identity of the reconstructed picture (e.g. Frame::m_encodeOrder + 1): the producer keeps the planes of the last
-                                                  pictures it saw on the device and uploads / phase-interpolates a picture once; 0 = no identity, upload every time.  Precondition: a keyed picture is
-                                                  COMPLETE (fully reconstructed, borders extended) when first seen -- it is never uploaded again */
+                                                  pictures it saw on the device and uploads / phase-interpolates a picture once; 0 = no identity, upload every time.  A keyed picture is
+                                                  either COMPLETE when first seen (reconRowsValid = 0) or grows: see reconRowsValid */
+    uint64_t meKey;                            /* identity of mePlane when it is not the reconstruction (the weighted plane MotionReference::applyWeight fills for the CURRENT picture, e.g.
+                                                  (picture's encode order + 1) << 8 | list << 5 | ref ... any value unique among live planes); 0 = uploaded with every call                */
+    int reconRowsValid, meRowsValid;           /* frame threads: rows of the plane allocation (counted from its first row, the top margin included) that are final NOW -- the reference is
+                                                  still being reconstructed (Frame::m_reconRowFlag, frameencoder.cpp:1029-1036) / weighted (MotionReference::numSliceWeightedRows).  0 = the
+                                                  whole plane.  A keyed plane is uploaded and phase-interpolated incrementally: each call adds the rows the producer has not seen yet; the
+                                                  count of a key never shrinks.  The caller hands over what the searches of desc.ctuRowFirst .. + ctuRowCount may read (the encoder's own
+                                                  row-lag rule: every reference row up to CTU row + FrameEncoder::m_refLagRows, the window clamped by Search::m_refLagPixels)                */
 } x265hip_tme_host_ref;
 typedef struct x265hip_tme_picture_desc {
     int isP, numRef[2], curPOC, temporalMvp, refPOC[2][16];
@@ -169,6 +176,10 @@ typedef struct x265hip_tme_picture_desc {
                                                   (m_refLagPixels = searchRange, m_bFrameParallel); the caller must still hand over finished reference rows only            */
     int flags;                                 /* X265HIP_TME_LAUNCH_PER_STAGE / X265HIP_TME_PACKED_GROUPS (x265hip_frame.h); 0 for production   */
     int16_t* areaBestOut;                      /* optional [numCtu][5][2][X265HIP_MAX_REF][2]: m_areaBestMV as computed                         */
+    int ctuRowFirst, ctuRowCount;              /* a band of CTU rows of the picture (ThreadedME under frame threads queues a picture's rows as their reference rows become
+                                                  final, threadedme.cpp:121-150): only these rows' CTUs are searched, only their entries of table / median / temporal / qpIndex /
+                                                  areaQpIndex / areaBestOut are read and written (the arrays keep the picture's CTU addressing).  0, 0 = the whole picture.
+                                                  CTUs of a picture do not depend on each other (findJob takes them in any order), so bands in any order give the picture's table */
 } x265hip_tme_picture_desc;
 int  x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** tme);
 void x265hip_tme_destroy(x265hip_tme* tme);
@@ -176,7 +187,7 @@ int  x265hip_tme_entries(const x265hip_tme* tme, const x265hip_tme_step** steps)
 /* optional: page-lock a long-lived host buffer of the caller (a PicYuv plane allocation, a FrameData table) once; copies from / to it are then DMA transfers */
 int  x265hip_host_register(void* p, size_t bytes);
 int  x265hip_host_unregister(void* p);
-int  x265hip_tme_picture(x265hip_tme* tme, const x265hip_tme_picture_desc* desc);     /* synchronous: desc->table holds the picture's records on return   */
+int  x265hip_tme_picture(x265hip_tme* tme, const x265hip_tme_picture_desc* desc);     /* synchronous: desc->table holds the picture's (band's) records on return; one call at a time per producer */
 
 /* ---- lookahead producer for a C++ encoder: lowres intra costs and frame-cost estimates from HOST data ------------------------------------------------------------
  * What the lookahead's workers do per picture and per (p0, b, p1) choice: LookaheadTLD::lowresIntraEstimate (slicetype.cpp:755-864) and CostEstimateGroup::estimateFrameCost

@@ -197,6 +197,8 @@ typedef struct x265hip_tme_args {
                                                   bound of both ends of every search window (search.cpp:5017-5018).  0 = picHeight                                                 */
     int flags;                                 /* X265HIP_TME_* below; 0 = the chain kernels                                                     */
     int frameParallel;                         /* != 0: m_bFrameParallel -- selectMVP does not cost a candidate with y >= (searchRange + 1) * 4 (search.cpp:2360-2365)           */
+    int ctuFirst, ctuCount;                    /* only the CTUs ctuFirst .. ctuFirst + ctuCount - 1 (a band of whole CTU rows: ThreadedME under frame threads, threadedme.cpp:121-150);
+                                                  every per-CTU array keeps the picture's addressing.  ctuCount 0 = the whole picture.  Chain kernels only               */
 } x265hip_tme_args;
 size_t x265hip_tme_workspace(int nCtu);
 int x265hip_tme_frame(void* stream, const x265hip_tme_args* args);
@@ -253,6 +255,11 @@ int x265hip_inter_merge_batch(void* stream, int w, int h, const void* curPlane, 
  * computed from clamped coordinates and must not be used (they lie in the picture margins).
  * stride and planeElems must be multiples of 4 pixels, planeElems >= stride*rows, 16 planes of planeElems allocated. */
 int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems);
+/* The rows rowFirst .. rowEnd - 1 of the same 16 planes: a reference picture that is still being reconstructed becomes valid CTU row by CTU row (frame threads:
+ * Frame::m_reconRowFlag, encoder/frameencoder.cpp:1029-1036, framefilter.cpp:676).  A row's vertical taps read the source rows y - 3 .. y + 4 of the whole plane (clamped at 0
+ * and rows - 1 exactly as the whole-plane call clamps them), so the last 4 rows of a range whose successor rows are not filled yet mean nothing until a later call covers them
+ * again: the caller re-submits them with the next range (x265hip_tme_picture does).  The planes of rowFirst = 0, rowEnd = rows are those of x265hip_subpel_planes. */
+int x265hip_subpel_planes_rows(void* stream, const void* refPlane, intptr_t stride, int rows, int rowFirst, int rowEnd, void* outPlanes, int64_t planeElems);
 
 /* one transform unit of the inter residual path; all TUs of one call share log2 size.
  * replaces the chain Predict::predInterLumaPixel (predict.cpp:279-300: copy_pp | luma_hpp | luma_vpp |

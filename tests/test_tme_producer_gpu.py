@@ -40,3 +40,17 @@ def test_other_search_methods_through_the_producer(depth, preset, kind, method, 
     chains = run(depth, preset, kind, extra=(method, merange))
     launches = run(depth, preset, kind, extra=(method, merange), TME_RUN_FLAGS="1")
     assert chains[1] > 1000 and chains == launches, "method %d: %s != %s" % (method, chains, launches)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth,preset,kind,method,merange,step", [(8, "medium", "P", 1, 16, 1), (10, "slow", "B", 3, 24, 2), (8, "slower", "B", 3, 57, 1), (10, "medium", "P", 2, 16, 3)])
+def test_bands_of_ctu_rows_on_growing_references_give_the_pictures_table(depth, preset, kind, method, merange, step):
+    """ThreadedME under frame threads (threadedme.cpp:121-150): a picture goes through the producer in bands of CTU rows while its references are still being reconstructed --
+    each band sees only the reference rows FrameEncoder::m_refLagRows releases for it (the rest of the host planes is garbage), planes are uploaded and phase-interpolated
+    incrementally under their keys.  The table must be the one a single call on complete references writes (both with the window of m_refLagPixels, desc.frameThreads = 3)."""
+    whole = run(depth, preset, kind, extra=(method, merange), TME_RUN_BANDS="whole", TME_RUN_HEIGHT="616")
+    banded = run(depth, preset, kind, extra=(method, merange), TME_RUN_BANDS=str(step), TME_RUN_HEIGHT="616")
+    one_thread = run(depth, preset, kind, extra=(method, merange), TME_RUN_HEIGHT="616")
+    assert whole[1] > 1000 and banded == whole, "bands of %d rows: %s != %s" % (step, banded, whole)
+    if merange > 24:
+        assert whole != one_thread, "the frame-parallel window did not change a single record: is it modelled?"

@@ -101,7 +101,7 @@ template<int SH> __device__ __forceinline__ void window8(uint32_t w0, uint32_t w
 }
 
 __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restrict__ ref, intptr_t stride, int rows,
-                                                            pixel* __restrict__ out, int64_t planeElems)
+                                                            pixel* __restrict__ out, int64_t planeElems, int by0, int rowsEnd)
 {
     __shared__ uint32_t s_src[TROWS8 * SROW];        // rows y0-3 .. y0+12, bytes x0-4 .. x0+135, as q = p - 128
     // vertically packed copies, [row group][column]: a thread's four adjacent columns are one 16-byte LDS access
@@ -132,11 +132,11 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
         }
     };
     uint32_t nxt[4] = { 0, 0, 0, 0 };
-    if (t < 4 * DW8 && (int)blockIdx.y * NT * TH8 < rows) fetch(blockIdx.y * NT * TH8, nxt);
+    if (t < 4 * DW8 && (by0 + (int)blockIdx.y) * NT * TH8 < rowsEnd) fetch((by0 + (int)blockIdx.y) * NT * TH8, nxt);
     for (int it = 0; it < NT; it++)
     {
-    const int y0 = (blockIdx.y * NT + it) * TH8;
-    if (y0 >= rows) break;                                                          // uniform
+    const int y0 = ((by0 + (int)blockIdx.y) * NT + it) * TH8;
+    if (y0 >= rowsEnd) break;                                                          // uniform
     // ---- A: slot-0 copy, signed bytes, transposed copy (coordinates were clamped into the allocation by fetch) ----
     if (t < 4 * DW8)
     {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
         {
             const int gyu = y0 - 3 + 4 * rb + r;
             v[r] = nxt[r];
-            if (dc >= 1 && dc <= TW8 / 4 && 4 * rb + r >= 3 && 4 * rb + r < 3 + TH8 && gyu < rows && gx < (int)stride)
+            if (dc >= 1 && dc <= TW8 / 4 && 4 * rb + r >= 3 && 4 * rb + r < 3 + TH8 && gyu < rowsEnd && gx < (int)stride)
                 *(uint32_t*)(out + (intptr_t)gyu * stride + gx) = v[r];            // slot 0: the reference plane itself
             v[r] ^= 0x80808080u;
             s_src[(4 * rb + r) * SROW + dc] = v[r];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
             cols.z = __builtin_amdgcn_perm(t3, t1, 0x05040100); cols.w = __builtin_amdgcn_perm(t3, t1, 0x07060302);
             *(uint4*)(s_srcT + rb * TW8 + col) = cols;
         }
-        if (it + 1 < NT && y0 + TH8 < rows) fetch(y0 + TH8, nxt);                     // in flight during H / V / HV
+        if (it + 1 < NT && y0 + TH8 < rowsEnd) fetch(y0 + TH8, nxt);                     // in flight during H / V / HV
     }
     __syncthreads();
 
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                 for (int r = 0; r < 2; r++)
                 {
                     const int tr = 4 * rb + 2 * pb + r, gy = y0 + tr - 3;
-                    if (tr >= 3 && tr < 3 + TH8 && gy < rows && gx < (int)stride)
+                    if (tr >= 3 && tr < 3 + TH8 && gy < rowsEnd && gx < (int)stride)
                         store_px4(out + (int64_t)xf * planeElems, (uint32_t)((y0 - 3 + 2 * pb + r) * (int)stride + x0) + hoff, sat_pack4<6>(d[r][0], d[r][1], d[r][2], d[r][3]));
                 }
             }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                     for (int k = 0; k < 4; k++) sum = dot2(a[k], TP[yf][k], sum);
                     o[c] = sum;
                 }
-                if (gy < rows && gx < (int)stride)
+                if (gy < rowsEnd && gx < (int)stride)
                     store_px4(xbase + (int64_t)(yf * 4) * planeElems, (uint32_t)((y0 + e) * (int)stride + x0) + voff, sat_pack4<12>(o[0], o[1], o[2], o[3]));
             }
     }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
                 int o[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) o[c] = dot8(lo[c][e], hi[c][e], TLO[yf], THI[yf], 8192 + 32);
-                if (gy < rows && gx < (int)stride)
+                if (gy < rowsEnd && gx < (int)stride)
                     store_px4(out + (int64_t)(yf * 4) * planeElems, (uint32_t)((y0 + e) * (int)stride + x0) + voff, sat_pack4<6>(o[0], o[1], o[2], o[3]));
             }
     }
@@ -289,11 +289,11 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
 // TILED: slots 1..15 are written as tiles of 16 x 4 pixels (xh_mc.h tile_off; a wavefront's store then fills four whole 128-byte lines); slot 0 by rows
 template<bool TILED>
 __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restrict__ ref, intptr_t stride, int rows,
-                                                            pixel* __restrict__ out, int64_t planeElems)
+                                                            pixel* __restrict__ out, int64_t planeElems, int by0, int rowsEnd)
 {
     __shared__ __attribute__((aligned(16))) pixel s_src[SROWS * SSTRIDE];
     __shared__ __attribute__((aligned(16))) int16_t s_im[3][SROWS * TW];
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, t = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = (by0 + (int)blockIdx.y) * TH, t = threadIdx.x;
     const lpixel* src = (const lpixel*)s_src;
     const int headRoom = XH_IF_INTERNAL_PREC - X265_DEPTH;
 
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
             px[0] = a[1]; px[1] = a[2]; px[2] = a[3]; px[3] = b[0]; px[4] = b[1]; px[5] = b[2]; px[6] = b[3];
             px[7] = c4[0]; px[8] = c4[1]; px[9] = c4[2]; px[10] = c4[3];
             const int gy = y0 - 3 + rr;
-            const bool inTile = rr >= 3 && rr < 3 + TH && gy < rows && x0 + x4 < stride;
+            const bool inTile = rr >= 3 && rr < 3 + TH && gy < rowsEnd && x0 + x4 < stride;
 #pragma unroll
             for (int xf = 1; xf < 4; xf++)
             {
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
     // ---- stage 2: vertical 8-tap: xFrac == 0 from the pixels, xFrac != 0 from the intermediates ----
     const int y = t >> 4, x4 = (t & 15) * 4;
     const int gy = y0 + y;
-    if (gy >= rows || x0 + x4 >= stride) return;
+    if (gy >= rowsEnd || x0 + x4 >= stride) return;
     pixel* o0 = out + (intptr_t)gy * stride + x0 + x4;
     pixel* ot = TILED ? out + (intptr_t)tile_off((uint32_t)(x0 + x4), (uint32_t)gy, (uint32_t)stride) : o0;      // slots 1..15
     {
@@ -415,20 +415,32 @@ __global__ __launch_bounds__(256) void subpel_planes_kernel(const pixel* __restr
 
 extern "C" int x265hip_subpel_planes(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems)
 {
-    if (!refPlane || !outPlanes || stride < 16 || rows < 8 || (stride & 3) || planeElems < (int64_t)stride * rows || (planeElems & 3))
-    { set_error("subpel_planes: bad arguments (stride and planeElems must be multiples of 4)"); return X265HIP_EARG; }
+    return x265hip_subpel_planes_rows(stream, refPlane, stride, rows, 0, rows, outPlanes, planeElems);
+}
+
+// the rows rowFirst .. rowEnd - 1 of the 16 planes (a reference picture that is still being reconstructed grows by CTU rows: frame threads, encoder/frameencoder.cpp:1029-1036).
+// The vertical taps of a row read the source rows y - 3 .. y + 4 of the WHOLE plane (clamped at 0 and rows - 1 as the whole-plane call clamps them): a row whose taps reach
+// source rows the caller has not filled yet holds no meaning until a later call covers it again -- the caller re-submits the last rows of the previous range
+extern "C" int x265hip_subpel_planes_rows(void* stream, const void* refPlane, intptr_t stride, int rows, int rowFirst, int rowEnd, void* outPlanes, int64_t planeElems)
+{
+    if (!refPlane || !outPlanes || stride < 16 || rows < 8 || (stride & 3) || planeElems < (int64_t)stride * rows || (planeElems & 3) || rowFirst < 0 || rowEnd > rows || rowFirst >= rowEnd)
+    { set_error("subpel_planes: bad arguments (stride and planeElems must be multiples of 4; 0 <= rowFirst < rowEnd <= rows)"); return X265HIP_EARG; }
     if (((uintptr_t)refPlane | (uintptr_t)outPlanes) & 7) { set_error("subpel_planes: planes must be 8-byte aligned"); return X265HIP_EARG; }
 #if X265_DEPTH == 8
-    dim3 grid((unsigned)((stride + TW8 - 1) / TW8), (unsigned)((rows + TH8 * NT - 1) / (TH8 * NT)));
+    constexpr int TILE_ROWS = TH8 * NT;
+    constexpr int TILE_COLS = TW8;
 #else
-    dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
+    constexpr int TILE_ROWS = TH;
+    constexpr int TILE_COLS = TW;
 #endif
+    const int by0 = rowFirst / TILE_ROWS;                 // whole tiles: the rows of the first tile above rowFirst are simply written again (same values)
+    dim3 grid((unsigned)((stride + TILE_COLS - 1) / TILE_COLS), (unsigned)((rowEnd - by0 * TILE_ROWS + TILE_ROWS - 1) / TILE_ROWS));
 #if X265_DEPTH == 8
     XH_KLAUNCH(subpel_planes_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                       (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
+                       (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems, by0, rowEnd);
 #else
     XH_KLAUNCH(subpel_planes_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
-                       (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
+                       (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems, by0, rowEnd);
 #endif
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
@@ -446,7 +458,7 @@ int xh_subpel_planes_tiled(void* stream, const void* refPlane, intptr_t stride, 
     if (!refPlane || !outPlanes || !xh_subpel_planes_tiled_ok(stride, rows) || rows < 8 || planeElems < (int64_t)stride * rows || (planeElems & 3) || (((uintptr_t)refPlane | (uintptr_t)outPlanes) & 7))
     { set_error("subpel_planes_tiled: bad arguments"); return X265HIP_EARG; }
     dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
-    XH_KLAUNCH(subpel_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems);
+    XH_KLAUNCH(subpel_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems, 0, rows);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 #endif

@@ -185,6 +185,8 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
     // CTUs cut by the picture edge run the whole schedule like the others -- computeMVForPUs does not look at the picture size; PUs beyond the edge read the planes' padding
     const int nCtuX = (a->picWidth + a->ctuSize - 1) / a->ctuSize, nCtuY = (a->picHeight + a->ctuSize - 1) / a->ctuSize, nCtu = nCtuX * nCtuY;
     if (a->workspaceBytes < x265hip_tme_workspace(nCtu)) { set_error("tme_frame: workspace too small"); return X265HIP_EARG; }
+    if (a->ctuFirst < 0 || a->ctuCount < 0 || a->ctuFirst + a->ctuCount > nCtu || (a->ctuFirst && !a->ctuCount)) { set_error("tme_frame: CTUs %d + %d of %d", a->ctuFirst, a->ctuCount, nCtu); return X265HIP_EARG; }
+    const int c0 = a->ctuFirst, nBand = a->ctuCount ? a->ctuCount : nCtu;                 // the CTUs of this call (per-CTU arrays keep the picture's addressing)
     const int nl = a->isP ? 1 : 2;
     for (int l = 0; l < nl; l++)
     {
@@ -216,7 +218,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
         XH_HIP(hipMemcpyAsync(dSteps, a->steps, (size_t)a->nSteps * sizeof(x265hip_tme_step), hipMemcpyHostToDevice, mainStream));
         XH_HIP(hipMemcpyAsync(dSched, sched.data(), sched.size() * sizeof(int16_t), hipMemcpyHostToDevice, mainStream));
         XH_HIP(hipMemcpyAsync(dLater, later.data(), later.size(), hipMemcpyHostToDevice, mainStream));
-        XH_HIP(hipMemcpyAsync(dInit, a->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToDevice, mainStream));
+        XH_HIP(hipMemcpyAsync(dInit + (size_t)c0 * 593, a->table + (size_t)c0 * 593, (size_t)nBand * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToDevice, mainStream));
         xh_chain_args A{};
         A.s.isP = a->isP; A.s.numRef[0] = a->numRef[0]; A.s.numRef[1] = a->isP ? 0 : a->numRef[1]; A.s.searchRange = a->searchRange; A.s.picW = a->picWidth; A.s.picH = a->picHeight;
         A.s.ctuSize = a->ctuSize; A.s.numCtuX = nCtuX; A.s.lowresBlocksX = a->lowresBlocksX; A.s.stride = a->stride; A.s.origin = a->origin;
@@ -225,7 +227,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
         for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) A.s.amvp.refPOC[l][r] = a->refPOC[l][r];
         for (int q = 0; q < a->nQp; q++) A.lambdas.v[q] = a->lambdas[q];
         A.sched = dSched; A.later = dLater; A.tableInit = dInit;
-        A.steps = dSteps; A.nSteps = a->nSteps; A.nCtu = nCtu; A.cur = (const pixel*)a->curPlane; A.planeElems = a->planeElems;
+        A.steps = dSteps; A.nSteps = a->nSteps; A.nCtu = nBand; A.ctuFirst = c0; A.cur = (const pixel*)a->curPlane; A.planeElems = a->planeElems;
         for (int l = 0; l < nl; l++)
             for (int r = 0; r < a->numRef[l]; r++)
             {
@@ -256,6 +258,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
         }
         return X265HIP_OK;
     }
+    if (a->ctuCount) { set_error("tme_frame: a band of CTUs is offered by the chain kernels only (not with X265HIP_TME_LAUNCH_PER_STAGE / SEA)"); return X265HIP_EARG; }
     // the chains: entries grouped by shape (CU size, partition type), order kept
     int chainOf[24 * 4]; int nChains = 0; int key[XH_TME_CHAINS];
     (void)chainOf;

@@ -126,7 +126,7 @@ struct x265hip_tme
     // the slots of a CTU's table the schedule writes (and reads: neighbours are PUs of the same shape); sparse schedules move only these (pinned staging, packed [ctu][slot])
     std::vector<int32_t> slots; int32_t* dSlots = nullptr; x265hip_inter_choice* dPacked = nullptr; x265hip_inter_choice* hPacked = nullptr; bool sparse = false;
     // reconstructed reference pictures stay on the device (plane + its 16 phase planes) under the caller's key; the least recently used of kKeep makes room
-    struct Kept { uint64_t key = 0; pixel* plane = nullptr; pixel* phase = nullptr; uint64_t used = 0; };
+    struct Kept { uint64_t key = 0; pixel* plane = nullptr; pixel* phase = nullptr; uint64_t used = 0; int rowsSeen = 0; };      // rowsSeen: plane rows on the device so far (a reference that is still being reconstructed grows)
     std::vector<Kept> kept; uint64_t tick = 0;
     int rowQp[64];                                                // the qp whose MVD cost row sits in row q of costTable (rows are kept across pictures)
     bool prof = false, first = false; double sec[5] = {}; int pictures = 0;      // X265HIP_TME_PROF: upload, diamond stage, submit, drain, (total)
@@ -141,7 +141,7 @@ struct x265hip_tme
 
 namespace {
 constexpr int kHalf = 1 << 15, kBitsHalf = 1 << 15;
-constexpr int kKeep = 20;                  // reconstructed pictures kept on the device (16 references + the ones just replaced); 17 planes each
+constexpr int kKeep = 40;                  // planes kept on the device under a key (16 references + the ones just replaced; with frame threads the references and weighted planes of every picture in flight); 17 planes each
 }
 
 extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** out)
@@ -202,7 +202,13 @@ extern "C" int x265hip_tme_entries(const x265hip_tme* t, const x265hip_tme_step*
 extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_desc* d)
 {
     if (!t || !d || !d->curPlane || !d->table || !d->temporal || d->nQp < 1 || d->nQp > 64 || !d->qpIndex || !d->areaQpIndex) { set_error("tme_picture: bad arguments"); return X265HIP_EARG; }
-    const int nl = d->isP ? 1 : 2, nS = (int)t->steps.size(), nCtu = t->nCtu;
+    const int nl = d->isP ? 1 : 2, nS = (int)t->steps.size();
+    const int nCtuY = t->nCtu / t->nCtuX;
+    if (d->ctuRowFirst < 0 || d->ctuRowCount < 0 || d->ctuRowFirst + d->ctuRowCount > nCtuY || (d->ctuRowFirst && !d->ctuRowCount))
+    { set_error("tme_picture: CTU rows %d + %d of %d", d->ctuRowFirst, d->ctuRowCount, nCtuY); return X265HIP_EARG; }
+    // the band: CTUs c0 .. c0 + nCtu - 1 of the picture (the whole picture without one).  Per-CTU arrays keep the picture's addressing: everything below moves and computes
+    // the band's part of them only
+    const int c0 = d->ctuRowFirst * t->nCtuX, nCtu = (d->ctuRowCount ? d->ctuRowCount : nCtuY) * t->nCtuX;
     for (int l = 0; l < nl; l++)      // before anything is indexed by it: refs[][] and every per-reference array here hold X265HIP_MAX_REF entries
         if (d->numRef[l] < 1 || d->numRef[l] > X265HIP_MAX_REF) { set_error("tme_picture: %d references in list %d (1..%d)", d->numRef[l], l, X265HIP_MAX_REF); return X265HIP_EARG; }
     if (d->width != t->width || d->height != t->height) { set_error("tme_picture: %dx%d picture on a %dx%d producer", d->width, d->height, t->width, t->height); return X265HIP_EARG; }
@@ -218,12 +224,12 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     // host table -> device table: whole, or the schedule's slots through the pinned buffer (the stream is drained before the buffer is reused)
     auto table_up = [&](x265hip_inter_choice* dev, const x265hip_inter_choice* host) -> int
     {
-        if (!t->sparse) { XH_HIP(hipMemcpyAsync(dev, host, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st)); return X265HIP_OK; }
+        if (!t->sparse) { XH_HIP(hipMemcpyAsync(dev + (size_t)c0 * 593, host + (size_t)c0 * 593, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st)); return X265HIP_OK; }
         const int nU = (int)t->slots.size();
         XH_HIP(hipStreamSynchronize(st));
-        for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) t->hPacked[(size_t)c * nU + k] = host[(size_t)c * 593 + t->slots[k]];
+        for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) t->hPacked[(size_t)c * nU + k] = host[(size_t)(c0 + c) * 593 + t->slots[k]];
         XH_HIP(hipMemcpyAsync(t->dPacked, t->hPacked, (size_t)nCtu * nU * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
-        return xh_tme_slots(st, dev, t->dPacked, t->dSlots, nU, nCtu, 1);
+        return xh_tme_slots(st, dev + (size_t)c0 * 593, t->dPacked, t->dSlots, nU, nCtu, 1);
     };
     if (t->planeElems != elems)
     {   // first picture (or another plane geometry): the device planes
@@ -231,8 +237,12 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
         t->planeElems = elems;
         if ((rc = t->alloc(t->cur, (size_t)elems))) return rc;
     }
-    XH_HIP(hipMemcpyAsync(t->cur, d->curPlane, (size_t)elems * sizeof(pixel), hipMemcpyHostToDevice, st));
     const int rows = (int)(elems / d->stride);
+    {   // the source picture: the rows the band's PUs lie in (CTUs cut by the picture edge reach into the bottom margin)
+        const int top = (int)(d->origin / d->stride);
+        const int y0 = d->ctuRowCount ? top + d->ctuRowFirst * t->ctu : 0, y1 = d->ctuRowCount ? std::min(rows, top + (d->ctuRowFirst + d->ctuRowCount) * t->ctu) : rows;
+        XH_HIP(hipMemcpyAsync(t->cur + (size_t)y0 * d->stride, (const pixel*)d->curPlane + (size_t)y0 * d->stride, (size_t)(y1 - y0) * d->stride * sizeof(pixel), hipMemcpyHostToDevice, st));
+    }
     for (int l = 0; l < nl; l++)
         for (int r = 0; r < d->numRef[l]; r++)
         {
@@ -241,13 +251,17 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
             for (int k = 0; k < 2; k++)
             {
                 if (k == 1 && R.reconPlane == R.mePlane) { t->plane[l][r][1] = t->plane[l][r][0]; t->phase[l][r][1] = t->phase[l][r][0]; continue; }
-                const bool recon = k == 1 || R.reconPlane == R.mePlane;                      // a weighted plane belongs to the current picture: never kept
+                const bool recon = k == 1 || R.reconPlane == R.mePlane;                      // else: the weighted plane, which belongs to the current picture
+                const uint64_t key = recon ? R.reconKey : R.meKey;
+                const int valid0 = recon ? R.reconRowsValid : R.meRowsValid;
+                if (valid0 < 0 || valid0 > rows) { set_error("tme_picture: %d valid rows of a %d-row plane (list %d reference %d)", valid0, rows, l, r); return X265HIP_EARG; }
+                const int valid = valid0 ? valid0 : rows;                                  // plane rows that are final now
+                int seen = 0;                                                              // ... and how many of them the device holds already
+                x265hip_tme::Kept* slot = nullptr;
                 uint64_t* pendingKey = nullptr;
-                if (recon && R.reconKey)
+                if (key)
                 {
-                    x265hip_tme::Kept* slot = nullptr;
-                    for (auto& kp : t->kept) if (kp.key == R.reconKey) slot = &kp;
-                    const bool hit = slot != nullptr;
+                    for (auto& kp : t->kept) if (kp.key == key) slot = &kp;
                     if (!slot)
                     {
                         if ((int)t->kept.size() < kKeep)
@@ -261,21 +275,29 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                             if (!slot) { set_error("tme_picture: more distinct reference pictures than kept planes"); return X265HIP_EARG; }
                         }
                         slot->key = 0;                      // named only once its planes are on their way (below): a failed call must not leave a keyed slot with stale planes
+                        slot->rowsSeen = 0;
                         pendingKey = &slot->key;
                     }
                     slot->used = t->tick + 1;
                     t->plane[l][r][k] = slot->plane; t->phase[l][r][k] = slot->phase;
-                    if (hit) continue;
+                    seen = slot->rowsSeen;
+                    if (valid <= seen) continue;
                 }
-                else if (!t->own[l][r][k])
+                else
                 {
-                    if ((rc = t->alloc(t->ownPlane[l][r][k], (size_t)elems)) || (rc = t->alloc(t->ownPhase[l][r][k], (size_t)elems * 16))) return rc;
-                    t->own[l][r][k] = true;
+                    if (!t->own[l][r][k])
+                    {
+                        if ((rc = t->alloc(t->ownPlane[l][r][k], (size_t)elems)) || (rc = t->alloc(t->ownPhase[l][r][k], (size_t)elems * 16))) return rc;
+                        t->own[l][r][k] = true;
+                    }
+                    t->plane[l][r][k] = t->ownPlane[l][r][k]; t->phase[l][r][k] = t->ownPhase[l][r][k];
                 }
-                if (!(recon && R.reconKey)) { t->plane[l][r][k] = t->ownPlane[l][r][k]; t->phase[l][r][k] = t->ownPhase[l][r][k]; }
-                XH_HIP(hipMemcpyAsync(t->plane[l][r][k], k ? R.reconPlane : R.mePlane, (size_t)elems * sizeof(pixel), hipMemcpyHostToDevice, st));
-                if ((rc = x265hip_subpel_planes(st, t->plane[l][r][k], d->stride, rows, t->phase[l][r][k], elems))) return rc;
-                if (pendingKey) *pendingKey = R.reconKey;
+                // rows seen .. valid - 1 go up; the phase rows whose vertical taps reached past `seen` last time (the last 4; 8 taken) are made again with the new ones
+                const pixel* src = (const pixel*)(k ? R.reconPlane : R.mePlane);
+                XH_HIP(hipMemcpyAsync(t->plane[l][r][k] + (size_t)seen * d->stride, src + (size_t)seen * d->stride, (size_t)(valid - seen) * d->stride * sizeof(pixel), hipMemcpyHostToDevice, st));
+                if ((rc = x265hip_subpel_planes_rows(st, t->plane[l][r][k], d->stride, rows, std::max(0, seen - 8), valid, t->phase[l][r][k], elems))) return rc;
+                if (slot) slot->rowsSeen = valid;
+                if (pendingKey) *pendingKey = key;
             }
             if (R.refTable)
             {
@@ -319,7 +341,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
         for (int q = 0; q < d->nQp; q++)
         {
             const int first = (int)tasks.size();
-            for (int c = 0; c < nCtu; c++)
+            for (int c = c0; c < c0 + nCtu; c++)
                 for (int a = (size == t->ctu ? 0 : 1); a < (size == t->ctu ? 1 : 5); a++)
                 {
                     if (d->areaQpIndex[c * 5 + a] != q) continue;
@@ -340,8 +362,9 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     const int nTasks = (int)tasks.size();                                                 // nCtu * 5
     XH_HIP(hipMemcpyAsync(t->dTasks, tasks.data(), (size_t)nTasks * sizeof(x265hip_me_task), hipMemcpyHostToDevice, st));
     XH_HIP(hipMemcpyAsync(t->dWhere, where.data(), (size_t)nTasks * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (d->median) XH_HIP(hipMemcpyAsync(t->dMedian, d->median, (size_t)nCtu * 2 * X265HIP_MAX_REF * 3 * sizeof(int16_t), hipMemcpyHostToDevice, st));
-    XH_HIP(hipMemsetAsync(t->areaBest, 0, (size_t)nCtu * 5 * 2 * X265HIP_MAX_REF * 2 * sizeof(int16_t), st));
+    constexpr size_t kMedianPer = 2 * X265HIP_MAX_REF * 3, kAreaPer = 5 * 2 * X265HIP_MAX_REF * 2;       // int16 per CTU
+    if (d->median) XH_HIP(hipMemcpyAsync(t->dMedian + c0 * kMedianPer, d->median + c0 * kMedianPer, (size_t)nCtu * kMedianPer * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemsetAsync(t->areaBest + c0 * kAreaPer, 0, (size_t)nCtu * kAreaPer * sizeof(int16_t), st));
     for (int l = 0; l < nl; l++)
         for (int r = 0; r < d->numRef[l]; r++)
             for (const Group& g : groups)
@@ -349,8 +372,8 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                                                 t->dResults + (size_t)(l * X265HIP_MAX_REF + r) * nTasks + g.first))) return rc;
     if ((rc = xh_tme_area(st, t->dResults, t->dWhere, nTasks, nl, d->numRef[0], d->isP ? 0 : d->numRef[1], d->median ? t->dMedian : nullptr, t->areaBest))) return rc;
     if ((rc = table_up(t->table, d->table))) return rc;
-    XH_HIP(hipMemcpyAsync(t->temporal, d->temporal, (size_t)nCtu * nS * 2 * sizeof(x265hip_tme_temporal), hipMemcpyHostToDevice, st));
-    XH_HIP(hipMemcpyAsync(t->qpIndex, d->qpIndex, (size_t)nCtu * nS, hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(t->temporal + (size_t)c0 * nS * 2, d->temporal + (size_t)c0 * nS * 2, (size_t)nCtu * nS * 2 * sizeof(x265hip_tme_temporal), hipMemcpyHostToDevice, st));
+    XH_HIP(hipMemcpyAsync(t->qpIndex + (size_t)c0 * nS, d->qpIndex + (size_t)c0 * nS, (size_t)nCtu * nS, hipMemcpyHostToDevice, st));
     lap(1, true);
     x265hip_tme_args a{};
     a.isP = d->isP; a.numRef[0] = d->numRef[0]; a.numRef[1] = d->numRef[1]; a.curPOC = d->curPOC; a.temporalMvp = d->temporalMvp;
@@ -370,21 +393,22 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     a.costRows = t->costTable;
     for (int q = 0; q < d->nQp; q++) a.lambdas[q] = x265hip_rd_lambda(d->qps[q]);
     a.bitsRow = t->bitsRow; a.bitsHalfRange = kBitsHalf; a.steps = t->steps.data(); a.nSteps = nS; a.workspace = t->workspace; a.workspaceBytes = t->workspaceBytes;
+    a.ctuFirst = c0; a.ctuCount = d->ctuRowCount ? nCtu : 0;
     if ((rc = x265hip_tme_frame(st, &a))) return rc;
     lap(2, false);
-    if (!t->sparse) XH_HIP(hipMemcpyAsync(d->table, t->table, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
+    if (!t->sparse) XH_HIP(hipMemcpyAsync(d->table + (size_t)c0 * 593, t->table + (size_t)c0 * 593, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
     else
     {
         const int nU = (int)t->slots.size();
-        if ((rc = xh_tme_slots(st, t->table, t->dPacked, t->dSlots, nU, nCtu, 0))) return rc;
+        if ((rc = xh_tme_slots(st, t->table + (size_t)c0 * 593, t->dPacked, t->dSlots, nU, nCtu, 0))) return rc;
         XH_HIP(hipMemcpyAsync(t->hPacked, t->dPacked, (size_t)nCtu * nU * sizeof(x265hip_inter_choice), hipMemcpyDeviceToHost, st));
     }
-    if (d->areaBestOut) XH_HIP(hipMemcpyAsync(d->areaBestOut, t->areaBest, (size_t)nCtu * 5 * 2 * X265HIP_MAX_REF * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
+    if (d->areaBestOut) XH_HIP(hipMemcpyAsync(d->areaBestOut + c0 * kAreaPer, t->areaBest + c0 * kAreaPer, (size_t)nCtu * kAreaPer * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     XH_HIP(hipStreamSynchronize(st));
     if (t->sparse)
     {
         const int nU = (int)t->slots.size();
-        for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) d->table[(size_t)c * 593 + t->slots[k]] = t->hPacked[(size_t)c * nU + k];
+        for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) d->table[(size_t)(c0 + c) * 593 + t->slots[k]] = t->hPacked[(size_t)c * nU + k];
     }
     t->tick++;
     lap(3, false); if (t->first) t->pictures++; t->first = true;

@@ -12,7 +12,8 @@ struct xh_chain_args
 {
     xh::tme::Slice s;
     xh::tme::Lambdas lambdas;
-    const x265hip_tme_step* steps; int nSteps, nCtu;      // the schedule (device copy)
+    const x265hip_tme_step* steps; int nSteps, nCtu;      // the schedule (device copy); the CTUs of this launch: ctuFirst .. ctuFirst + nCtu - 1 of the picture
+    int ctuFirst;
     int keys[8];                                           // cuSize * 8 + part of the shapes of this launch (blockIdx.y)
     int keyRow[8], nLevels[8], firstStep[8];               // per shape: its row of `sched`, its number of levels, one of its entries (the shape's PU sizes)
     const int16_t* sched;                                  // [shape row][XH_CHAIN_LEVELS][XH_CHAIN_WIDTH]: the entries of a shape by level (-1: none) -- entries of one level

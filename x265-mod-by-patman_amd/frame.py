@@ -189,7 +189,7 @@ class FrameApi:
                         ("refs", (Ref * MAX_REF) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
                         ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 64), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
                         ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t),
-                        ("refLagPixels", C.c_int), ("flags", C.c_int), ("frameParallel", C.c_int)]
+                        ("refLagPixels", C.c_int), ("flags", C.c_int), ("frameParallel", C.c_int), ("ctuFirst", C.c_int), ("ctuCount", C.c_int)]
         a = Args()
         a.isP = int(is_p); a.numRef[0], a.numRef[1] = int(num_ref[0]), int(num_ref[1]); a.curPOC = int(cur_poc); a.temporalMvp = int(temporal_mvp)
         for l in range(2):

@@ -8,7 +8,8 @@ from .frame import INTER_CHOICE, TME_TEMPORAL
 
 
 class HostRef(C.Structure):
-    _fields_ = [("mePlane", C.c_void_p), ("reconPlane", C.c_void_p), ("refTable", C.c_void_p), ("lowresMv", C.c_void_p), ("reconKey", C.c_uint64)]
+    _fields_ = [("mePlane", C.c_void_p), ("reconPlane", C.c_void_p), ("refTable", C.c_void_p), ("lowresMv", C.c_void_p), ("reconKey", C.c_uint64), ("meKey", C.c_uint64),
+                ("reconRowsValid", C.c_int), ("meRowsValid", C.c_int)]
 
 
 class PictureDesc(C.Structure):
@@ -19,7 +20,7 @@ class PictureDesc(C.Structure):
                 ("refs", (HostRef * 16) * 2),
                 ("table", C.c_void_p), ("median", C.c_void_p), ("temporal", C.c_void_p),
                 ("nQp", C.c_int), ("qps", C.c_int * 64), ("qpIndex", C.c_void_p), ("areaQpIndex", C.c_void_p),
-                ("sourceHeight", C.c_int), ("frameThreads", C.c_int), ("flags", C.c_int), ("areaBestOut", C.c_void_p)]
+                ("sourceHeight", C.c_int), ("frameThreads", C.c_int), ("flags", C.c_int), ("areaBestOut", C.c_void_p), ("ctuRowFirst", C.c_int), ("ctuRowCount", C.c_int)]
 
 
 class TmeProducer:
@@ -68,9 +69,11 @@ class TmeProducer:
         t["ref"] = -1
         return t
 
-    def picture(self, cur, refs, stride, origin, table, qp=28, is_p=True, merange=57, method=1, subme=2, cur_poc=1, ref_pocs=((0,), ()), ref_keys=None, flags=0, frame_threads=1):
+    def picture(self, cur, refs, stride, origin, table, qp=28, is_p=True, merange=57, method=1, subme=2, cur_poc=1, ref_pocs=((0,), ()), ref_keys=None, flags=0, frame_threads=1,
+                rows=None, rows_valid=None):
         """cur: padded plane (numpy, pixel dtype); refs: [[plane, ...] of list 0, [...] of list 1]; table: INTER_CHOICE[n_ctu * 593] in / out.
-        No temporal neighbours, no lookahead MVs, one qp: what a first P picture after an intra picture looks like."""
+        No temporal neighbours, no lookahead MVs, one qp: what a first P picture after an intra picture looks like.
+        rows = (first CTU row, count): a band of the picture (desc.ctuRowFirst / ctuRowCount); rows_valid = plane rows of every reference that are final now (frame threads)."""
         d = PictureDesc()
         d.isP = int(is_p); d.numRef[0] = len(refs[0]); d.numRef[1] = len(refs[1]) if not is_p else 0
         d.curPOC = cur_poc; d.temporalMvp = 0
@@ -84,6 +87,9 @@ class TmeProducer:
             for r, p in enumerate(refs[l]):
                 d.refs[l][r].mePlane = p.ctypes.data; d.refs[l][r].reconPlane = p.ctypes.data
                 d.refs[l][r].reconKey = int(ref_keys[l][r]) if ref_keys else 0          # 0: uploaded and phase-interpolated with every picture
+                d.refs[l][r].reconRowsValid = int(rows_valid) if rows_valid else 0
+        if rows:
+            d.ctuRowFirst, d.ctuRowCount = int(rows[0]), int(rows[1])
         if self._keep is None:                                  # no temporal neighbour anywhere, one qp: the same arrays for every picture
             temporal = np.zeros(self.n_ctu * self.entries * 2, dtype=TME_TEMPORAL)
             temporal["nb"]["refIdx"] = -1
