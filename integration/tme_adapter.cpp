@@ -6,10 +6,14 @@
  * objects, in computeMVForPUs' order -- the qp of every CU (Analysis::calculateQpforCuSize), the collocated neighbour of every PU (CUData::getNeighbourMV), the
  * collocated median of every CTU (CUData::getMedianColMV).
  *
- * Preconditions (checked): ONE frame thread -- the producer takes whole reference planes and keeps them under the picture's key, so a reference must be completely
- * reconstructed when it is first handed over; with several frame threads a picture starts while its references are still being coded, and the encoder's own body runs
- * instead (the producer itself models the row-lag window and selectMVP restrictions of that mode -- desc.frameThreads, csrc/xh_tme.cpp -- for a caller that waits for
- * reference completion before the call); numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF.
+ * Frame threads (the encoder's default, encoder.cpp:285): a picture starts while its references are still being coded.  The frame encoder releases a picture's CTU rows to
+ * ThreadedME one by one, row r once every reference has reconstructed (and weighted) its rows up to r + m_refLagRows (frameencoder.cpp:166-171, 975-990, 1029-1043;
+ * threadedme.cpp:121-150).  The adapter follows that protocol: a JOB is a band of CTU rows of one picture -- from the first row the picture has no records for up to the last row
+ * whose reference rows are final now (Frame::m_reconRowFlag, MotionReference::numSliceWeightedRows) -- and the producer gets every reference with the count of rows that are
+ * final (x265hip_tme_host_ref::reconRowsValid / meRowsValid): it uploads and phase-interpolates a keyed plane incrementally.  The window and selectMVP restrictions of
+ * m_bFrameParallel / m_refLagPixels are the producer's (desc.frameThreads).  With one frame thread every reference is complete and the band is the whole picture.
+ *
+ * Preconditions (checked): numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF; --slices only with one frame thread (the slice MV bounds of search.cpp:4999-5003 are not modelled).
  */
 #include <atomic>
 #include <chrono>
@@ -59,7 +63,9 @@ double g_sec[4];      /* per encode: [0] job set-up seconds (incl. creating the 
 double g_createSeconds;                     /* creating the producer (context, streams, device buffers) on the first picture */
 double g_gpuSeconds, g_pictureSeconds;      /* inside x265hip_tme_picture; the whole producer call incl. the adapter's harvest and write-back */
 std::mutex g_lock;
-std::map<const Frame*, int> g_done;          /* picture -> POC + 1 whose table is complete */
+struct PicState { int poc1 = 0, rowsDone = 0; };      /* POC + 1 of the picture the Frame object holds now; its CTU rows [0, rowsDone) have their records */
+std::map<const Frame*, PicState> g_pics;
+int g_bands;                                 /* jobs (bands of CTU rows) run; == g_pictures with one frame thread */
 
 void to_choice(const MEData& m, x265hip_inter_choice& o)
 {
@@ -86,14 +92,6 @@ namespace X265_NS {
 void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
 {
     if (!g_useGpu) { ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame); return; }
-    if (frame.m_param->frameNumThreads > 1)
-    {   /* a reference picture may still be in flight (frameencoder.cpp:1029-1036 releases its rows one by one): whole-plane uploads under a permanent key would cache a
-           half-coded picture.  The encoder's own producer knows how to wait row by row */
-        static std::atomic<int> told{0};
-        if (!told.exchange(1)) fprintf(stderr, "tme_adapter: %d frame threads: reference pictures are not complete when a picture starts -- the encoder's own ThreadedME producer runs\n", frame.m_param->frameNumThreads);
-        ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame);
-        return;
-    }
     /* local classes of a member function have the member's access: calculateQpforCuSize (protected) is reached without touching analysis.h */
     struct Harvest
     {
@@ -159,6 +157,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     struct Job
     {
         Frame* frame; int poc, nCtu, nCtuX, nCtuY, nS, nl;
+        int row0 = 0, row1 = 0, c0 = 0, c1 = 0;                    /* the band: CTU rows [row0, row1) = CTUs [c0, c1) of the picture */
         const x265hip_tme_step* steps;
         std::vector<int> used;                                     /* the MEData slots of a CTU the schedule writes (and reads) */
         std::vector<int> sliceOfRow;
@@ -170,7 +169,41 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         std::atomic<int> nextA{0}, doneA{0}, nextB{0}, doneB{0}, failed{0}, helped{0};
         int phase = 0, users = 0;                                  /* 0 harvest, 1 producer call, 2 write-back, 3 done; workers inside the job (both under g_lock) */
 
-        static Job* create(Analysis& an, Frame& frame)
+        /* FrameEncoder::m_refLagRows (frameencoder.cpp:166-171): how many CTU rows of its references a row waits for */
+        static int ref_lag_rows(const x265_param* p)
+        {
+            int range = p->searchRange;
+            range += !!(p->searchMethod < 2);
+            range += NTAPS_LUMA / 2;
+            range += 2 + (MotionEstimate::hpelIterationCount(p->subpelRefine) + 1) / 2;
+            return 1 + ((range + p->maxCUSize - 1) / p->maxCUSize);
+        }
+        /* CTU rows of the picture, from `from` on, whose reference rows are final now (the frame encoder's own test per row, frameencoder.cpp:1029-1036); `from` itself was
+           released by the frame encoder, or this call would not have come */
+        static int ready_rows(const Analysis& an, int from, int nCtuY)
+        {
+            const Slice* slice = an.m_slice;
+            const x265_param* p = an.m_param;
+            if (p->frameNumThreads <= 1) return nCtuY;
+            const int lag = ref_lag_rows(p);
+            int r = from + 1;                                        /* rows [from, r) are ready */
+            for (; r < nCtuY; r++)
+            {
+                const int idx = X265_MIN(nCtuY - 1, r + lag);
+                bool ok = true;
+                for (int l = 0; ok && l < (slice->isInterP() ? 1 : 2); l++)
+                    for (int ref = 0; ok && ref < slice->m_numRefIdx[l]; ref++)
+                    {
+                        ok = slice->m_refFrameList[l][ref]->m_reconRowFlag[idx].get() != 0;
+                        const MotionReference& mr = slice->m_mref[l][ref];
+                        if (ok && mr.isWeighted) ok = (int)mr.numSliceWeightedRows[0] >= idx;      /* applyWeight(idx, ...) has run (:1035-1036) */
+                    }
+                if (!ok) break;
+            }
+            return r;
+        }
+
+        static Job* create(Analysis& an, Frame& frame, int row0, int row1)
         {
             const Slice* slice = an.m_slice;
             const x265_param* p = an.m_param;
@@ -191,6 +224,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             j->nCtuX = slice->m_sps->numCuInWidth; j->nCtuY = slice->m_sps->numCuInHeight; j->nCtu = j->nCtuX * j->nCtuY;
             j->nS = g_api.tme_entries(g_tme, &j->steps);
             j->nl = slice->isInterP() ? 1 : 2;
+            j->row0 = row0; j->row1 = row1; j->c0 = row0 * j->nCtuX; j->c1 = row1 * j->nCtuX;
             const int nCtu = j->nCtu, nS = j->nS, nl = j->nl;
             for (int l = 0; l < nl; l++)
                 if (slice->m_numRefIdx[l] < 1 || slice->m_numRefIdx[l] > X265HIP_MAX_REF) { fprintf(stderr, "tme_adapter: %d references in list %d (1..%d)\n", slice->m_numRefIdx[l], l, X265HIP_MAX_REF); return nullptr; }
@@ -234,15 +268,29 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
                 {
                     x265hip_tme_host_ref& R = d.refs[l][r];
                     const MotionReference& mr = slice->m_mref[l][r];
-                    if (mr.isWeighted)
-                    {   /* the frame encoder weights the reference's rows as it releases them to the row encoders (frameencoder.cpp:1029-1036); the producer takes the whole
-                           picture at once: finish the plane now (same values, the later calls find nothing left to do) */
+                    const bool parallel = p->frameNumThreads > 1;
+                    if (mr.isWeighted && !parallel)
+                    {   /* the frame encoder weights the reference's rows as it releases them to the row encoders (frameencoder.cpp:1029-1036); with one frame thread the
+                           picture is complete and the producer takes it at once: finish the plane now (same values, the later calls find nothing left to do) */
                         const_cast<MotionReference&>(mr).applyWeight(j->nCtuY - 1, j->nCtuY, j->nCtuY, 0);
-                        g_weighted++;
                     }
+                    if (mr.isWeighted) g_weighted++;
                     const PicYuv* rec = slice->m_refReconPicList[l][r];
                     R.mePlane = mr.fpelPlane[0] - d.origin;
                     R.reconPlane = rec->m_picBuf[0];
+                    if (parallel)
+                    {   /* what is final for the band's last row: reconstruction rows up to CTU row idx (its flag is set: ready_rows), weighted rows below idx (applyWeight(idx)
+                           weights [0, idx), everything when idx is the last row, reference.cpp:119-185) */
+                        const int idx = X265_MIN(j->nCtuY - 1, row1 - 1 + ref_lag_rows(p));
+                        const int allRows = (int)(d.planeElems / d.stride), top = (int)(d.origin / d.stride);
+                        const bool last = idx == j->nCtuY - 1;
+                        R.reconRowsValid = last ? 0 : top + (idx + 1) * ctuSize;
+                        R.meRowsValid = !mr.isWeighted ? R.reconRowsValid : (last ? 0 : top + idx * ctuSize);
+                        if (R.reconRowsValid > allRows) R.reconRowsValid = 0;
+                        if (R.meRowsValid > allRows) R.meRowsValid = 0;
+                        /* the weighted plane belongs to (this picture, list, reference): keyed so that its rows go up once */
+                        if (mr.isWeighted) R.meKey = ((uint64_t)1 << 62) | (((uint64_t)frame.m_encodeOrder + 1) << 8) | ((uint64_t)l << 5) | (uint64_t)r;
+                    }
                     const Frame* rf = slice->m_refFrameList[l][r];
                     R.reconKey = g_keepPlanes ? (uint64_t)rf->m_encodeOrder + 1 : 0;      /* a finished picture: its planes stay on the device for the pictures that reference it */
                     if (rf->m_encData->m_slice->m_sliceType != I_SLICE)
@@ -317,12 +365,13 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             auto qidx = [&](int qp) { if (qp > QP_MAX_SPEC) { fprintf(stderr, "qp %d above 51: not handled\n", qp); exit(3); }
                                       for (size_t i = 0; i < qps.size(); i++) if (qps[i] == qp) return (int)i; qps.push_back(qp); return (int)qps.size() - 1; };
             qpIndex.resize(entryQp.size()); areaQpIndex.resize(areaQp.size());
-            for (size_t i = 0; i < entryQp.size(); i++) qpIndex[i] = (uint8_t)qidx(entryQp[i]);
-            for (size_t i = 0; i < areaQp.size(); i++) areaQpIndex[i] = (uint8_t)qidx(areaQp[i]);
+            for (size_t i = (size_t)c0 * nS; i < (size_t)c1 * nS; i++) qpIndex[i] = (uint8_t)qidx(entryQp[i]);
+            for (size_t i = (size_t)c0 * 5; i < (size_t)c1 * 5; i++) areaQpIndex[i] = (uint8_t)qidx(areaQp[i]);
             if (qps.size() > 64) { fprintf(stderr, "more than 64 distinct qps\n"); return -1; }
             d.nQp = (int)qps.size();
             for (int i = 0; i < d.nQp; i++) d.qps[i] = qps[i];
             d.qpIndex = qpIndex.data(); d.areaQpIndex = areaQpIndex.data(); d.temporal = temporal.data(); d.median = median.data(); d.table = table.data();
+            if (row0 > 0 || row1 < nCtuY) { d.ctuRowFirst = row0; d.ctuRowCount = row1 - row0; }
             const auto t0 = std::chrono::steady_clock::now();
             const int rc = g_api.tme_picture(g_tme, &d);
             if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; }
@@ -343,37 +392,41 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     std::unique_lock<std::mutex> lk(g_lock);
     const int poc = ctu.m_slice->m_poc;
     m_slice = ctu.m_slice; m_frame = &frame; m_param = m_frame->m_param;      /* as the encoder's body starts (analysis.cpp:250-252) */
+    const int nCtuX = m_slice->m_sps->numCuInWidth, nCtuY = m_slice->m_sps->numCuInHeight, row = (int)ctu.m_cuAddr / nCtuX;
     bool leader = false;
     const double tStart = now();
     for (;;)
     {
-        auto it = g_done.find(&frame);
-        if (it != g_done.end() && it->second == poc + 1) return;              /* this picture's table is there already */
-        if (s_job && s_job->frame == &frame && s_job->poc == poc) break;      /* the picture's job is running: help */
+        PicState& ps = g_pics[&frame];
+        if (ps.poc1 != poc + 1) { ps.poc1 = poc + 1; ps.rowsDone = 0; }       /* the Frame object holds a new picture */
+        if (row < ps.rowsDone) return;                                        /* this CTU's records are there already */
+        if (s_job && s_job->frame == &frame && s_job->poc == poc && row >= s_job->row0 && row < s_job->row1) break;      /* the band's job is running: help */
         if (!s_job)
-        {
-            s_job = Job::create(*this, frame);
+        {   /* a new band: from the first row without records to the last one whose reference rows are final (one frame thread: the whole picture) */
+            const int row1 = Job::ready_rows(*this, row, nCtuY);
+            s_job = Job::create(*this, frame, ps.rowsDone, row1);
             if (!s_job) exit(3);
             g_sec[0] += now() - tStart;                                       /* job set-up (the first picture also creates the producer: context, streams, code objects) */
             leader = true;
             break;
         }
-        s_cv.wait(lk);                                                        /* another picture's job is still running (frame threads) */
+        s_cv.wait(lk);                                                        /* another job is running: another picture's, or an earlier band of this one */
     }
     Job* job = s_job;
     job->users++;
     lk.unlock();
+    const int nBand = job->c1 - job->c0;
     for (;;)
     {   /* pass A */
-        const int c = job->nextA.fetch_add(1);
-        if (c >= job->nCtu) break;
+        const int c = job->c0 + job->nextA.fetch_add(1);
+        if (c >= job->c1) break;
         job->harvest(*this, cuGeom, c);
         job->doneA.fetch_add(1);
         if (!leader) job->helped.fetch_add(1);
     }
     if (leader)
     {
-        while (job->doneA.load() < job->nCtu) std::this_thread::yield();      /* the helpers' last CTUs */
+        while (job->doneA.load() < nBand) std::this_thread::yield();          /* the helpers' last CTUs */
         const double tCall = now();
         g_sec[1] += tCall - tStart;                                           /* wall time up to the producer call: set-up + harvest (qps, collocated neighbours, medians, table conversions) */
         g_sec[2] += job->helped.load();                                       /* CTUs other workers harvested */
@@ -390,18 +443,19 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     }
     for (;;)
     {   /* pass B */
-        const int c = job->nextB.fetch_add(1);
-        if (c >= job->nCtu) break;
+        const int c = job->c0 + job->nextB.fetch_add(1);
+        if (c >= job->c1) break;
         job->writeback(c);
         job->doneB.fetch_add(1);
     }
     lk.lock();
     if (leader)
     {
-        while (job->doneB.load() < job->nCtu) { lk.unlock(); std::this_thread::yield(); lk.lock(); }
+        while (job->doneB.load() < nBand) { lk.unlock(); std::this_thread::yield(); lk.lock(); }
         g_sec[3] += now();
-        g_done[&frame] = poc + 1;
-        g_pictures++;
+        g_pics[&frame].rowsDone = job->row1;
+        g_bands++;
+        if (job->row1 == nCtuY) g_pictures++;
         g_pictureSeconds += now() - tStart;
         job->phase = 3;
         s_cv.notify_all();
@@ -441,10 +495,10 @@ extern "C" void x265hip_tme_adapter_close(void)
     std::lock_guard<std::mutex> guard(g_lock);
     if (g_tme) { g_api.tme_destroy(g_tme); g_tme = nullptr; }
     if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
-    g_done.clear(); g_useGpu = 0;
+    g_pics.clear(); g_useGpu = 0;
 }
 extern "C" void x265hip_tme_adapter_get_stats(x265hip_tme_adapter_stats* o)
 {
-    o->pictures = g_pictures; o->weightedRefs = g_weighted; o->producerSeconds = g_gpuSeconds; o->adapterSeconds = g_pictureSeconds; o->createSeconds = g_createSeconds;
+    o->pictures = g_pictures; o->bands = g_bands; o->weightedRefs = g_weighted; o->producerSeconds = g_gpuSeconds; o->adapterSeconds = g_pictureSeconds; o->createSeconds = g_createSeconds;
     for (int i = 0; i < 4; i++) o->sections[i] = g_sec[i];
 }

@@ -25,6 +25,7 @@ void x265hip_tme_adapter_close(void);          /* after x265_encoder_close: dest
 typedef struct x265hip_tme_adapter_stats
 {
     int pictures, weightedRefs;
+    int bands;                     /* producer calls: bands of CTU rows (== pictures with one frame thread; more with frame threads, where a picture's rows become ready as its references' rows are final) */
     double producerSeconds;        /* inside x265hip_tme_picture                                                        */
     double adapterSeconds;         /* the whole per-picture call: harvest + producer + write-back                       */
     double createSeconds;          /* creating the producer, once (inside adapterSeconds and sections[0..1])                */

@@ -106,7 +106,7 @@ int main(int argc, char** argv)
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     x265_param* live = x265_param_alloc();
     x265_encoder_parameters(enc, live);
-    const int tme = live->bThreadedME;
+    const int tme = live->bThreadedME, frameThreads = live->frameNumThreads, wpp = live->bEnableWavefront;
     x265_param_free(live);
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(out);
@@ -130,7 +130,7 @@ int main(int argc, char** argv)
                  useFf ? "gpu" : "cpu", fs.pictures, fs.cpuPictures, fs.deblockSkipped, fs.statsServed, fs.gatherSeconds, fs.producerSeconds, fs.replaySeconds);
     }
 #endif
-    printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
-           la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.producerSeconds, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
+    printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_bands\": %d, \"frame_threads\": %d, \"wpp\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
+           la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.bands, frameThreads, wpp, s.producerSeconds, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
     return 0;
 }

@@ -51,6 +51,27 @@ def test_bitstream_identical_with_gpu_producer(depth, args, tmp_path):
     print("e2e", depth, args, "weighted refs %d" % gpu["weighted_refs"], "cpu fps %.2f gpu fps %.2f (gpu producer %.3f s for %d pictures)" % (cpu["fps"], gpu["fps"], gpu["gpu_seconds"], gpu["gpu_pictures"]))
 
 
+@pytest.mark.parametrize("depth,args", [(8, ["192", "640", "8", "medium", "frame-threads=3", "wpp=1"]),                              # ten CTU rows, the preset as it is (weightp on)
+                                        (8, ["256", "512", "8", "medium", "frame-threads=4", "wpp=0", "ref=2", "bframes=0"]),
+                                        (10, ["192", "576", "7", "slow", "frame-threads=3", "wpp=1"]),
+                                        (8, ["256", "640", "10", "medium", "frame-threads=3", "wpp=1", "ref=2", "weightp=1", "bframes=0", "fades=1"]),   # weighted planes grow row by row
+                                        (8, ["320", "704", "8", "slower", "frame-threads=2", "wpp=1", "merange=25"]),                 # a smaller window: fewer lag rows, more bands
+                                        (8, ["1920", "1080", "6", "medium", "frame-threads=4", "wpp=1"])])                             # BASELINE configs[1] at its own size, threaded as the CLI threads it
+def test_bitstream_identical_with_gpu_producer_under_frame_threads(depth, args, tmp_path):
+    """The encoder's default threading (frame threads + WPP, encoder.cpp:285): a picture starts while its references are still being coded; ThreadedME gets its CTU rows as the
+    reference rows they may read become final (frameencoder.cpp:975-990, threadedme.cpp:121-150).  The binding runs them as bands through the same producer
+    (x265hip_tme_picture_desc.ctuRowFirst / ctuRowCount, refs[].reconRowsValid): same bitstream as the encoder's own producer under the same threading."""
+    cpu, h_cpu = encode(depth, "cpu", args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(depth, "gpu", args, str(tmp_path / "gpu.hevc"))
+    want = int([a for a in args if a.startswith("frame-threads=")][0].split("=")[1])
+    assert gpu["frame_threads"] == want and cpu["frame_threads"] == want, "the encoder did not take the frame threads: %s" % gpu
+    assert gpu["gpu_pictures"] >= min(3, int(args[2]) - 1), "the GPU producer did not run: %s" % gpu
+    assert gpu["gpu_bands"] >= gpu["gpu_pictures"]
+    assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
+    print("e2e frame threads", depth, args, "bands %d for %d pictures, weighted refs %d" % (gpu["gpu_bands"], gpu["gpu_pictures"], gpu["weighted_refs"]),
+          "cpu fps %.2f gpu fps %.2f" % (cpu["fps"], gpu["fps"]))
+
+
 def test_more_references_than_the_tables_hold_is_an_argument_error():
     """x265hip_tme_picture indexes per-reference arrays of X265HIP_MAX_REF = 16 entries (MAX_NUM_REF): 17 must come back as X265HIP_EARG before anything is touched"""
     import ctypes as C

@@ -90,6 +90,7 @@ hipError_t dev_alloc(void** p, size_t bytes, const char* tag)
     char* user = g_startMode ? b.mapAt : b.mapAt + b.mapped - padded;
     // the rest of the mapped range holds a pattern no search result, pixel or coefficient looks like; a kernel that reads it produces loud garbage instead of plausible zeros
     (void)hipMemset(b.mapAt, 0xA5, b.mapped);
+    (void)hipDeviceSynchronize();           // the fill runs on the null stream: it must not land behind a copy the caller queues on its own (non-blocking) stream
     g_blocks[user] = b;
     fprintf(log, "[fence] alloc #%lu %p..%p (%zu B) mapped %p..%p tag %s\n", g_serial++, (void*)user, (void*)(user + bytes), bytes, (void*)b.mapAt, (void*)(b.mapAt + b.mapped), tag);
     *p = user;
