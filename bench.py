@@ -168,7 +168,7 @@ def tme_producer_leg(depth):
     return out
 
 
-def e2e_fps_leg(frames=24, seam_frames=8):
+def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
     """BASELINE's M2 measured in THIS run: the reference encoder (oracle/_ref/x265e2e_8 = all of source/common + source/encoder compiled from where they lie, C
     primitives, no asm; it travels with the repository) on BASELINE configs[1] -- 1920x1088 8-bit, preset medium with the preset's own defaults, --threaded-me -- with its
     own CPU producers, with x265hip_tme_picture producing the MEData tables (integration/tme_adapter.cpp), with x265hip_la_intra / x265hip_la_estimate producing the
@@ -202,6 +202,23 @@ def e2e_fps_leg(frames=24, seam_frames=8):
             info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
             info["clip_frames"] = nfr
             runs[name] = info
+        # the same encode threaded as the x265 CLI threads it by default (frame threads picked from the core count, WPP, every core: encoder.cpp:285): the encoder alone
+        # (no --threaded-me: what anyone runs), with --threaded-me and its own producers, and with the GPU producers.  ThreadedME's binding hands a picture's CTU rows to
+        # the producer as bands while the references are still being coded (integration/tme_adapter.cpp); the filter binding keeps the encoder's own filters there
+        # (one picture in flight per FrameFilter is what it replays), the lookahead binding is thread-safe as it is
+        default_runs = {}
+        if both:
+            for name, tme_on, tme, la, ff in (("cpu_default_threading", 0, 0, 0, 0), ("cpu_default_threading_tme", 1, 0, 0, 0), ("all_gpu_default_threading", 1, 1, 1, 1)):
+                outp = os.path.join(td, name + ".hevc")
+                env = dict(os.environ, X265TME=str(tme_on), X265TMEGPU=str(tme), X265LAGPU=str(la), X265FFGPU=str(ff), X265_CLI_THREADING="1")
+                env.pop("X265FF_DEFER_ONLY", None)
+                r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(default_frames), "medium", outp], capture_output=True, text=True, env=env, timeout=900)
+                if r.returncode != 0:
+                    default_runs[name] = {"failed": r.stderr[-300:]}
+                    continue
+                info = json.loads(r.stdout.strip().splitlines()[-1])
+                info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
+                default_runs[name] = info
     g, c = runs["tme_gpu"], runs["cpu"]
     best = runs.get("all_gpu", g)
     out = {"value": best["fps"], "unit": "frames/s", "measured": "this run",
@@ -216,6 +233,23 @@ def e2e_fps_leg(frames=24, seam_frames=8):
                    "adapter_note": "host work around the producer call (qps, collocated neighbours, medians, table conversions), spread over the encoder's ThreadedME workers; creating the producer (%.0f ms, once) not included"
                                    % (1e3 * g.get("adapter_create_seconds", 0.0)),
                    "ctus_harvested_by_helper_workers": int(g["adapter_sections"][2])}}
+    if default_runs:
+        ok = {k: v for k, v in default_runs.items() if "fps" in v}
+        a, b = ok.get("cpu_default_threading_tme"), ok.get("all_gpu_default_threading")
+        dt = {"config": "the same clip and preset, %d frames, threaded as the CLI threads it (frame threads from the core count, WPP, %d cores)" % (default_frames, os.cpu_count() or 0),
+              "fps": {k: v["fps"] for k, v in ok.items()}, "failed": {k: v["failed"] for k, v in default_runs.items() if "failed" in v} or None,
+              "frame_threads": b.get("frame_threads") if b else None, "wpp": b.get("wpp") if b else None,
+              "bitstream_identical_gpu_vs_cpu_producers": bool(a and b and a["md5"] == b["md5"] and a["bytes"] == b["bytes"])}
+        if b:
+            dt["gpu_run"] = {"tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
+                             "tme_adapter_seconds": b["adapter_seconds"], "la_estimates": b.get("la_estimates"), "la_producer_seconds": b.get("la_producer_seconds"),
+                             "filter_pictures_gpu": b.get("ff_pictures"), "filter_pictures_left_to_the_cpu": b.get("ff_cpu_pictures"), "seconds": b["seconds"]}
+        if a and b and "cpu_default_threading" in ok:
+            d0 = ok["cpu_default_threading"]["fps"]
+            dt["verdict"] = ("GPU producers %.2f fps vs the encoder's own producers %.2f fps under the same threading (%.2fx); the encoder without --threaded-me does %.2f fps -- "
+                             "the RDO / entropy-coding host work, not the seams, bounds the encode, and a host with this many cores does the seams' work in parallel with it"
+                             % (b["fps"], a["fps"], b["fps"] / a["fps"], d0))
+        out["default_threading"] = dt
     if both:
         l = runs["la_gpu"]
         out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "device_launches": l.get("la_launches"), "finish_batch_calls_taken_whole": l.get("la_batches"), "estimate_batch_calls": l.get("la_batch_calls"), "estimates_left_to_the_cpu": l["la_cpu_estimates"], "cutree_steps": l.get("la_cutree_steps"), "ms_per_cutree_step": round(1e3 * l["la_cutree_seconds"] / l["la_cutree_steps"], 3) if l.get("la_cutree_steps") else None,
@@ -684,7 +718,7 @@ def cpu_baseline(pipe, depth, n_ctus):
     missing.  Also cross-checks the sample's results against the GPU's (parity in the same run)."""
     from refproc import RefProc, ref_available
     from x265hip_pkg.host_batch import LEVELS
-    cores = min(os.cpu_count() or 1, 64)
+    cores = os.cpu_count() or 1                # T = all host cores (SURVEY 8d); the figure per core is reported beside it
     ctus_per_frame = (pipe.W // 64) * (pipe.H // 64)
     n_ctus = min(n_ctus, ctus_per_frame * pipe.F)
     n_frames = (n_ctus + ctus_per_frame - 1) // ctus_per_frame
@@ -721,8 +755,21 @@ def cpu_baseline(pipe, depth, n_ctus):
 
     if ref_available(depth):
         kind = "reference"
+        import tempfile
         procs = [RefProc(depth) for _ in range(cores)]
         t0 = time.time()
+        # the sample's two planes go to the processes once, through a file in memory (one process per core: 256 pipes would carry them 5 times each otherwise)
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+        with tempfile.NamedTemporaryFile(dir=shm, suffix=".planes") as pf:
+            pf.write(cur.tobytes()); pf.write(ref.tobytes()); pf.flush()
+            import threading as _th
+            def _load(p_):
+                assert RefProc.i32(p_.call("bench_planes", [cur.nbytes, ref.nbytes], [pf.name.encode()])[0]) == 1, "x265ref could not read the sample planes"
+            ths = [_th.Thread(target=_load, args=(p_,)) for p_ in procs]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
 
         def build(reps):
             pend = []
@@ -748,7 +795,7 @@ def cpu_baseline(pipe, depth, n_ctus):
 
         def worker(i):
             for op, ints, tag in pending[i]:
-                out = procs[i].call(op, ints, [cur, ref])
+                out = procs[i].call(op, ints, [])              # planes: bench_planes above
                 ns_per_proc[i] += int(np.frombuffer(out[0], np.int64)[0])
                 if op == "bench_me":
                     lv, idx = tag
@@ -772,7 +819,7 @@ def cpu_baseline(pipe, depth, n_ctus):
                 th.join()
         run_all()                                   # pass 1: parity cross-check + calibration
         total = sum(ns_per_proc) / 1e9
-        reps = int(max(1, min(200, round(12.0 / max(total, 1e-3)))))   # aim at ~12 CPU-seconds of reference work
+        reps = int(max(1, min(400, round(max(12.0, 0.25 * cores) / max(total, 1e-3)))))   # aim at ~12 CPU-seconds of reference work, and a quarter second per core at least
         if reps > 1:
             pending = build(reps)
             ns_per_proc = [0] * cores
@@ -808,7 +855,7 @@ def cpu_baseline(pipe, depth, n_ctus):
         parity = "not cross-checked"
     if pipe.refs > 1:
         busy *= pipe.refs             # one of the references was searched on the CPU (its chain is cross-checked); the others cost the same
-    return {"value": round(sample_px / busy / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": kind,
+    return {"value": round(sample_px / busy / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": kind, "per_core": round(sample_px * (reps if kind == "reference" else 1) / max(total_cpu, 1e-9) / 1e6 / max(1, pipe.refs), 4),
             "sample": "%d CTU64 (%d luma px) of the same batch: ME pyramid (85 PUs/CTU) + %dx%d DCT+quant, %s; %d repetition(s), %.1f CPU-seconds in total, busiest core %.3f s per repetition; "
                       "results vs GPU: %s" % (n_ctus, sample_px, n_tu, n_tu,
                                                "reference C primitives + motionEstimate (no asm), one process per core" if kind == "reference"

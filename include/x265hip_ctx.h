@@ -103,19 +103,11 @@ int   x265hip_batch_read_choices(x265hip_batch* batch, int w, int h, struct x265
  * x265hip_batch_stage_name order ("planes", "me64", ["rect64",] ["amp64",] ..., "tq"), and starts a new record */
 int   x265hip_batch_set_timing(x265hip_batch* batch, int on);
 /* How a step launches its kernels -- every combination gives the same bytes (tests/test_host_batch_gpu.py compares them); the default, 0, is the fastest measured form.
- *   X265HIP_BATCH_FUSE_16_8 / _FUSE_32_16_8: the levels below a 64x64 CU only depend on each other inside a 32x32 quadrant (each 2Nx2N search is seeded with its parent CU's
- *     MV, analysis.cpp:248-306); with one reference, squares only and the STAR search out of phase planes the batch can run the 16x16 and 8x8 levels (or the 32x32 level too) in
- *     ONE launch, a wavefront per quadrant (csrc/kern_me_pyr.hip).  Measured 30 % slower at 4K 10 bit (profiles/r03_fused_ab.txt).  The stage slots of the fused levels hold
- *     the whole launch in the first and empty intervals in the others.
  *   X265HIP_BATCH_START64_LAUNCH: the 64x64 level of a STAR search WITH its start-stage launch (by default the batch's own top-level tasks -- zero predictor, no candidates --
  *     are started inside the full-pel kernel, csrc/star64_body.inc: two launches instead of three).
- *   X265HIP_BATCH_TILED_PLANES (16-bit library, one reference, squares only, STAR): the phase planes of the batch are TILED -- slots 1..15 as 16 x 4-pixel tiles of one 128-byte
- *     line -- and read by the tiled forms of the search kernels and of the TQ stage: 14-30 % fewer bytes moved, 40 % slower (profiles/r03_tiled_ab.txt).  The phase planes
- *     x265hip_batch_device_ptr(.., 2) hands out are in that layout while the flag is set. */
-#define X265HIP_BATCH_FUSE_16_8      1
-#define X265HIP_BATCH_FUSE_32_16_8   2
+ *   (Flags 1, 2 and 8 -- the 16x16 / 8x8 [/ 32x32] levels fused into one launch, tiled phase planes -- were measured losses, profiles/r03_fused_ab.txt and r03_tiled_ab.txt,
+ *   and are refused since round 5.) */
 #define X265HIP_BATCH_START64_LAUNCH 4
-#define X265HIP_BATCH_TILED_PLANES   8
 int   x265hip_batch_set_mode(x265hip_batch* batch, int flags);
 int   x265hip_batch_set_fused(x265hip_batch* batch, int flags);      /* the same call under its first name */
 int   x265hip_batch_stage_count(const x265hip_batch* batch);

@@ -96,6 +96,7 @@ static int cuIndex(int n) { int i = 0; while ((4 << i) < n) i++; return i; }
 #define S16(b, off) (reinterpret_cast<int16_t*>((b).data()) + (off))
 #define I32(b) (reinterpret_cast<int32_t*>((b).data()))
 
+static Buf g_benchPlanes[2];
 static bool dispatch(Req& r, std::vector<Buf>& out)
 {
     const std::string& op = r.op;
@@ -479,6 +480,18 @@ static bool dispatch(Req& r, std::vector<Buf>& out)
         int32_t r[3] = { outmv.x, outmv.y, cost };
         Buf b(12); memcpy(b.data(), r, 12); out.push_back(b); return true;
     }
+    if (op == "bench_planes")
+    {   /* the two planes of the bench_me / bench_tq requests that follow, read once from a file (bufs = path; ints = bytes of the cur plane, bytes of the ref plane, back to
+           back in the file): bench.py starts one process per host core, and the planes do not travel through every process's pipe */
+        std::string path((const char*)B[0].data(), B[0].size());
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) return false;
+        g_benchPlanes[0].resize((size_t)I[0]); g_benchPlanes[1].resize((size_t)I[1]);
+        const bool ok = fread(g_benchPlanes[0].data(), 1, g_benchPlanes[0].size(), f) == g_benchPlanes[0].size() && fread(g_benchPlanes[1].data(), 1, g_benchPlanes[1].size(), f) == g_benchPlanes[1].size();
+        fclose(f);
+        out.push_back(scalar<int32_t>(ok ? 1 : 0)); return true;
+    }
+    if ((op == "bench_me" || op == "bench_tq") && B.size() < 2) { B.resize(2); B[0].swap(g_benchPlanes[0]); B[1].swap(g_benchPlanes[1]); const bool r2 = dispatch(r, out); B[0].swap(g_benchPlanes[0]); B[1].swap(g_benchPlanes[1]); return r2; }
     if (op == "bench_me")
     {   /* many PUs of one size through the reference's motionEstimate, timed inside the process (no IPC in the
            timed region).  ints = w,h,stride,merange,method,subme,qp,n,reps, then n x (off, mvmin.x,mvmin.y,mvmax.x,mvmax.y,

@@ -127,17 +127,17 @@ def test_two_streams_are_joined_when_something_reads_and_one_stream_steps_give_t
 
 
 @pytest.mark.parametrize("depth", DEPTHS)
-def test_launch_forms_give_the_same_bytes_and_a_release_library_refuses_the_experiments(depth):
-    """x265hip_batch_set_mode: the 64x64 level with or without its start-stage launch gives the same bytes; the measured-loss forms (fused lower levels, tiled phase
-    planes, band-major schedule: profiles/r03_fused_ab.txt, r03_tiled_ab.txt, r03_band_major_ab.txt) exist in experiment builds only (make EXPERIMENTS=1) and a release
-    library says so instead of silently running something else"""
+def test_launch_forms_give_the_same_bytes_and_the_library_refuses_the_dropped_experiments(depth):
+    """x265hip_batch_set_mode: the 64x64 level with or without its start-stage launch gives the same bytes; the measured-loss forms of earlier rounds (fused lower levels,
+    tiled phase planes, band-major schedule: profiles/r03_fused_ab.txt, r03_tiled_ab.txt, r03_band_major_ab.txt) are gone and the library says so instead of silently
+    running something else"""
     W, H, F = 320, 192, 3
     pairs = pairs_for(W, H, depth, F, 1, seed0=520)
     outs = []
     hb = make(depth, W, H, F, qp=27, merange=57, method=3, subme=3, tu_log2=5)
     try:
         for flags in (1, 2, 8, 12):
-            with pytest.raises(RuntimeError, match="EXPERIMENTS"):
+            with pytest.raises(RuntimeError, match="measured losses"):
                 hb.set_fused(flags)
     finally:
         hb.close()
@@ -261,7 +261,7 @@ def test_baseline_workloads_every_pu_and_tu_of_whole_pictures(depth, W, H, F, me
         jobs += [(lv, lo, min(nt, lo + step)) for lo in range(0, nt, step)]
     ntu = len(_FULL["hb"]["tu"])
     tjobs = [(lo, min(ntu, lo + 256)) for lo in range(0, ntu, 256)]
-    workers = max(2, min(64, (os.cpu_count() or 4) - 2))
+    workers = max(2, (os.cpu_count() or 4) - 2)
     with mp.get_context("fork").Pool(workers) as pool:
         pus = pool.map(_full_pus, jobs, chunksize=1)
         tus = pool.map(_full_tus, tjobs, chunksize=1)
@@ -271,3 +271,68 @@ def test_baseline_workloads_every_pu_and_tu_of_whole_pictures(depth, W, H, F, me
     badt = [b for _, bl in tus for b in bl]
     assert not badt, "%d of %d TUs differ from the oracle, first: TU %d" % (len(badt), ntu, badt[0])
     assert sum(c for c, _ in pus) == F * (W // 64) * (H // 64) * 85 and sum(c for c, _ in tus) == F * (W // 32) * (H // 32)
+
+
+def _preset_pus(arg):
+    """one slice of one PU shape: the search in every reference (seeded by that reference's own chain) and the choice among the references"""
+    (w, h), lo, hi = arg
+    F_ = _FULL
+    hb, ora, R = F_["hb"], F_["ora"], F_["refs"]
+    t, res, parent, ch = F_["tasks"][(w, h)], F_["res"][(w, h)], F_["res"][(max(w, h), max(w, h))] if w != h else F_["res"].get((2 * w, 2 * h)), F_["choice"][(w, h)]
+    d = hb["merange"] << 2
+    bad = []
+    for i in range(lo, hi):
+        tk = t[i]
+        mv = np.zeros((8, 2), np.int32); mvp = np.zeros((8, 2), np.int32); cost = np.zeros(8, np.int32); mvc = np.zeros(8, np.int32)
+        for r in range(R):
+            qmvp = (0, 0) if tk["mvpFrom"] < 0 else (int(parent[r][tk["mvpFrom"]]["mv"][0]), int(parent[r][tk["mvpFrom"]]["mv"][1]))
+            lx0, ly0, lx1, ly1 = int(tk["mvmin"][0]), int(tk["mvmin"][1]), int(tk["mvmax"][0]), int(tk["mvmax"][1])
+            b = [min(lx1, max(lx0, qmvp[0] - d)) >> 2, min(ly1, max(ly0, qmvp[1] - d)) >> 2, min(lx1, max(lx0, qmvp[0] + d)) >> 2, min(ly1, max(ly0, qmvp[1] + d)) >> 2]
+            b[3] = max(b[3], b[1])
+            exp = ora.me(w, h, hb["cur"], hb["stride"], int(tk["curOff"]), hb["planes"][r], hb["stride"], int(tk["refOff"]), b, qmvp, [], hb["merange"], hb["method"], hb["subme"], F_["row"])
+            g = res[r][i]
+            if (int(g["mv"][0]), int(g["mv"][1]), int(g["cost"])) != exp:
+                bad.append(("search", w, h, i, r, (int(g["mv"][0]), int(g["mv"][1]), int(g["cost"])), exp))
+            mv[r] = g["mv"]; mvp[r] = qmvp; cost[r] = g["cost"]; mvc[r] = g["mvcost"]
+        rp = [hb["planes"][k] if k < R else None for k in range(8)]
+        o, _ = ora.inter_merge(w, h, (R, 0), mv, mvp, cost, mvc, F_["bits"], F_["lam"], False, max(hb["W"], hb["H"]), list(tk["mvmin"]) + list(tk["mvmax"]),
+                               hb["cur"], hb["stride"], int(tk["curOff"]), rp, hb["stride"], int(tk["refOff"]))
+        g = ch[i]
+        mine = [int(g["mv"][0][0]), int(g["mv"][0][1]), int(g["mv"][1][0]), int(g["mv"][1][1]), int(g["mvp"][0][0]), int(g["mvp"][0][1]), int(g["mvp"][1][0]), int(g["mvp"][1][1]),
+                int(g["ref"][0]), int(g["ref"][1]), int(g["bits"]), int(g["cost"])]
+        if mine != [int(v) for v in o]:
+            bad.append(("choice", w, h, i, mine, [int(v) for v in o]))
+    return (hi - lo), bad
+
+
+def test_preset_slow_every_pu_of_a_whole_4k_picture_in_every_reference():
+    """BASELINE configs[2] with the preset's own load, EXHAUSTIVELY once: one 3840x2176 10-bit picture, STAR, subme 3, merange 57, 4 list-0 references, the 425 PUs of every CTU
+    (squares + 2NxN / Nx2N of every CU): all 2040 x 425 x 4 searches -- MV and cost, each seeded by its own reference's chain -- and all 2040 x 425 choices among the references
+    (MV, MVP, reference, bits, cost) equal the oracle's.  The oracle runs on every host core (forked workers over slices of the task lists)."""
+    import multiprocessing as mp
+    import os
+    depth, W, H, F, refs, qp = 10, 3840, 2176, 1, 4, 28
+    hb = make(depth, W, H, F, qp=qp, merange=57, method=3, subme=3, tu_log2=5, refs=refs, rect=True, streams=1)
+    try:
+        hb.upload(pairs_for(W, H, depth, F, refs, seed0=910))
+        hb.step(); hb.sync()
+        shapes = [(lv, lv) for lv in LEVELS] + sorted(hb.rect_host)
+        tasks = {(lv, lv): hb.tasks_host[lv] for lv in LEVELS}
+        tasks.update(hb.rect_host)
+        _FULL.update(hb=dict(cur=hb.cur_host, planes=[hb.refs_host[r] for r in range(refs)], stride=hb.stride, merange=hb.merange, method=hb.method, subme=hb.subme, W=hb.W, H=hb.H),
+                     refs=refs, tasks=tasks, res={sh: [hb.shape_results(sh[0], sh[1], r, 0) for r in range(refs)] for sh in shapes}, choice={sh: hb.choices(sh[0], sh[1]) for sh in shapes},
+                     row=mvcost_row(depth, qp, 1 << 15), bits=mvbits_row(depth, 1 << 14), lam=rd_lambda(depth, qp), ora=Oracle(depth))
+    finally:
+        hb.close()
+    jobs = []
+    for sh in shapes:
+        nt = len(tasks[sh])
+        step = max(16, min(2048, (24 * 64 * 64) // (sh[0] * sh[1])))           # slices of about equal pixel count
+        jobs += [(sh, lo, min(nt, lo + step)) for lo in range(0, nt, step)]
+    jobs.sort(key=lambda j: -(j[0][0] * j[0][1] * (j[2] - j[1])))
+    with mp.get_context("fork").Pool(max(2, (os.cpu_count() or 4) - 2)) as pool:
+        out = pool.map(_preset_pus, jobs, chunksize=1)
+    _FULL.clear()
+    bad = [b for _, bl in out for b in bl]
+    assert not bad, "%d PUs differ from the oracle, first: %s" % (len(bad), bad[0])
+    assert sum(c for c, _ in out) == (W // 64) * (H // 64) * 425

@@ -446,21 +446,3 @@ extern "C" int x265hip_subpel_planes_rows(void* stream, const void* refPlane, in
     return X265HIP_OK;
 }
 
-#ifdef X265HIP_EXPERIMENTS
-// (experiment build, make EXPERIMENTS=1 -- a measured loss, profiles/r03_tiled_ab.txt)
-// The same planes with slots 1..15 tiled (16-bit library; pitch a multiple of 16, rows a multiple of 4): for readers that take the tiled layout (xh_me_star_tiled, xh_tq_batch_tiled)
-bool xh_subpel_planes_tiled_ok(intptr_t stride, int rows) { return X265_DEPTH != 8 && stride >= 16 && (stride & 15) == 0 && (rows & 3) == 0; }
-int xh_subpel_planes_tiled(void* stream, const void* refPlane, intptr_t stride, int rows, void* outPlanes, int64_t planeElems)
-{
-#if X265_DEPTH == 8
-    set_error("subpel_planes_tiled: 16-bit library only"); return X265HIP_EARG;
-#else
-    if (!refPlane || !outPlanes || !xh_subpel_planes_tiled_ok(stride, rows) || rows < 8 || planeElems < (int64_t)stride * rows || (planeElems & 3) || (((uintptr_t)refPlane | (uintptr_t)outPlanes) & 7))
-    { set_error("subpel_planes_tiled: bad arguments"); return X265HIP_EARG; }
-    dim3 grid((unsigned)((stride + TW - 1) / TW), (unsigned)((rows + TH - 1) / TH));
-    XH_KLAUNCH(subpel_planes_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const pixel*)refPlane, stride, rows, (pixel*)outPlanes, planeElems, 0, rows);
-    XH_LAUNCH_CHECK();
-    return X265HIP_OK;
-#endif
-}
-#endif   // X265HIP_EXPERIMENTS

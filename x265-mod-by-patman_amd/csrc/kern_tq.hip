@@ -115,11 +115,7 @@ __global__ __launch_bounds__(256) void tq_kernel(TqArgs a)
     else if (a.planes)
     {
         const int f = (tk.mv[1] & 3) * 4 + (tk.mv[0] & 3);
-#ifdef X265HIP_EXPERIMENTS
-        if (a.tiled && f)
-#else
         if (false)
-#endif
         {   // the block out of the tiles of slot f: a quad that straddles a tile column pixel by pixel
             const pixel* slot = a.planes + (int64_t)f * a.planeElems;
             const uint32_t rs32 = (uint32_t)a.rs, py = (uint32_t)tk.refOff / rs32, px = (uint32_t)tk.refOff - py * rs32;
@@ -378,13 +374,3 @@ extern "C" int x265hip_tq_batch(void* stream, int log2TrSize, const void* curPla
 {
     return tq_batch(stream, log2TrSize, curPlane, curStride, refPlane, refStride, tasks, n, params, coeff, numSig, reconPlane, reconStride, sse, mvSource, 0);
 }
-#ifdef X265HIP_EXPERIMENTS
-// x265hip_tq_batch for a plane buffer whose slots 1..15 are tiled (xh_subpel_planes_tiled; 16-bit library, luma, uni-directional)
-int xh_tq_batch_tiled(void* stream, int log2TrSize, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
-                      const x265hip_tu_task* tasks, int n, const x265hip_tq_params* params,
-                      int16_t* coeff, uint32_t* numSig, void* reconPlane, intptr_t reconStride, uint64_t* sse, const x265hip_me_result* mvSource)
-{
-    if (X265_DEPTH == 8 || !params || !params->subpelPlanes || params->chroma || params->refPlane1) { set_error("tq_batch_tiled: 16-bit luma planes, one reference"); return X265HIP_EARG; }
-    return tq_batch(stream, log2TrSize, curPlane, curStride, refPlane, refStride, tasks, n, params, coeff, numSig, reconPlane, reconStride, sse, mvSource, 1);
-}
-#endif

@@ -33,9 +33,7 @@ bool desc_ok(const x265hip_batch_desc* d)
            d->margin % 4 == 0 && d->qp >= 0 && d->qp <= 51 && d->merange >= 1 && d->subme >= 0 && d->subme <= 7 && d->tuLog2 >= 2 && d->tuLog2 <= 5 &&
            d->refs >= 0 && d->refs <= X265HIP_MAX_REF && d->refs1 >= 0 && d->refs1 <= X265HIP_MAX_REF && d->streams >= 0 && d->streams <= 8 && d->bandRows >= 0 &&
            ((d->refs <= 1 && d->refs1 == 0) || d->usePlanes)
-#ifndef X265HIP_EXPERIMENTS
-           && d->bandRows == 0           // the band-major schedule is a measured loss (profiles/r03_band_major_ab.txt): experiment builds only (make EXPERIMENTS=1)
-#endif
+           && d->bandRows == 0           // the band-major schedule was a measured loss (profiles/r03_band_major_ab.txt) and left the library in round 5
            ;
 }
 int level_index(int level) { for (int i = 0; i < 4; i++) if (kLevels[i] == level) return i; return -1; }
@@ -68,13 +66,6 @@ struct x265hip_batch
     // context's stream holds at that moment -- its own previous pass included -- so sub-stream 1's pass k + 1 starts behind sub-stream 0's pass k; sub-stream 0 never
     // waits for sub-stream 1.)
     hipEvent_t evTok[8] = {}; bool tokSet[8] = {}; int pingpong = 0; bool unjoined = false;
-    // the 16x16 / 8x8 levels (fusedFrom32: the 32x32 level too) of a sub-batch in ONE launch, a wavefront per 32x32 quadrant (kern_me_pyr.hip); x265hip_batch_set_mode.
-    // Off by default: measured slower than a launch per level (profiles/r03_fused_ab.txt)
-    bool fused = false, fusedFrom32 = false;
-    // 16-bit library, one reference, squares only, STAR: the phase planes of the batch are TILED (slots 1..15 as 16 x 4-pixel tiles of one 128-byte line, kern_planes.hip) and read
-    // by the tiled forms of the search kernels and of the TQ stage (kern_me_star_tiled.hip, xh_tq_batch_tiled).  OFF by default, x265hip_batch_set_mode(X265HIP_BATCH_TILED_PLANES) turns it on: it moves
-    // 20-30 % fewer bytes and is 40 % slower (profiles/r03_tiled_ab.txt, r03_tiled_pmc.txt)
-    bool tiled = false, tiledWanted = false;
     bool ownStart64 = true;                  // STAR: the 64x64 level without its start-stage launch (kern_me_star.hip xh_me_star_own64); x265hip_batch_set_mode(X265HIP_BATCH_START64_LAUNCH) turns it off for A/B
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
@@ -395,11 +386,7 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
         for (int r = 0; r < b->nref[l]; r++)
         {
             const pixel* src = b->ref[l][r] + (size_t)f0 * b->plane; pixel* dst = b->planes[l][r] + (size_t)f0 * b->plane;
-#ifdef X265HIP_EXPERIMENTS
-            const int rc = b->tiled ? xh_subpel_planes_tiled(st, src, b->stride, (f1 - f0) * rowsPerPic, dst, planeElems) : x265hip_subpel_planes(st, src, b->stride, (f1 - f0) * rowsPerPic, dst, planeElems);
-#else
             const int rc = x265hip_subpel_planes(st, src, b->stride, (f1 - f0) * rowsPerPic, dst, planeElems);
-#endif
             if (rc != X265HIP_OK) return rc;
         }
     return X265HIP_OK;
@@ -408,17 +395,6 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
 // One sub-batch on stream st: the CTU rows g0 .. g1 - 1 of the batch, counted through the pictures (global row g = picture * ctuRows + row).  Tasks of every
 // shape are laid out picture-major, then raster: a range of global CTU rows is a contiguous range of every task list.  withPlanes: the range is whole pictures and
 // their phase planes are made first; ev != nullptr: events around every stage (2 per stage)
-// can this batch run on tiled phase planes?  (decided per step: the planes are made anew by every step)
-bool tiled_ok(const x265hip_batch* b)
-{
-#ifndef X265HIP_EXPERIMENTS
-    (void)b; return false;
-#else
-    const x265hip_batch_desc& d = b->d;
-    return b->tiledWanted && !b->fused && b->refs == 1 && !b->nref[1] && !d.rect && !d.amp && d.usePlanes && d.method == X265HIP_ME_STAR && d.merange <= 57 &&
-           xh_subpel_planes_tiled_ok(b->stride, d.height + 2 * d.margin) && (uint64_t)(b->plane * d.frames) * 16u * sizeof(pixel) < (1ull << 32);
-#endif
-}
 int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev, int sub = -1)
 {
     const x265hip_batch_desc& d = b->d;
@@ -448,14 +424,6 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
             {
                 x265hip_me_result* out = b->res[l][r][slot] + first;
                 const x265hip_me_result* parent = parentSlot >= 0 ? b->res[l][r][parentSlot] : nullptr;
-#ifdef X265HIP_EXPERIMENTS
-                if (b->tiled && w == h)
-                {
-                    rc = xh_me_star_tiled(st, w, h, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, parent, b->planes[l][r], planeElems, w == CTU && !parent && b->ownStart64);
-                    if (rc != X265HIP_OK) return rc;
-                    continue;
-                }
-#endif
                 // star64_kernel alone: its event pair is armed only around a call that can launch it, and never outlives the call (the kernel's launcher clears the pointer
                 // when it records the events; a call that took another kernel -- merange beyond the band, an odd stride -- leaves it, and the step is then not counted)
                 const xh::KernelEvents* armed = nullptr;
@@ -487,31 +455,9 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
         }
         return X265HIP_OK;
     };
-    // the lower three levels fused: one reference, squares only, STAR out of phase planes (the stage slots of the 16x16 and 8x8 levels then hold empty intervals,
-    // the 32x32 slot the whole launch)
-#ifdef X265HIP_EXPERIMENTS
-    const bool fusedLower = b->fused && b->refs == 1 && !b->nref[1] && !d.rect && !d.amp && up && xh_me_pyr_ok(d.method, planeElems, kHalf);
-#else
-    constexpr bool fusedLower = false; (void)fusedLower;
-#endif
     for (int i = 0; i < 4; i++)
     {
         const int lv = kLevels[i], per = (d.width / lv) * (CTU / lv);               // PUs of this level per CTU row
-#ifdef X265HIP_EXPERIMENTS
-        if (fusedLower && i >= (b->fusedFrom32 ? 1 : 2))
-        {
-            if ((rc = mark(0))) return rc;
-            if (i == (b->fusedFrom32 ? 1 : 2))
-            {
-                const x265hip_me_task* tl[3] = { b->tasks[1], b->tasks[2], b->tasks[3] };
-                x265hip_me_result* rl[3] = { b->res[0][0][1], b->res[0][0][2], b->res[0][0][3] };
-                if ((rc = xh_me_pyr(st, b->cur, b->stride, b->ref[0][0], b->stride, tl, rl, b->fusedFrom32 ? b->res[0][0][0] : nullptr, g0, g1 - g0, d.width, b->costRow, kHalf, d.merange, d.method, d.subme,
-                                    b->planes[0][0], planeElems)) != X265HIP_OK) return rc;
-            }
-            if ((rc = mark(1))) return rc;
-            continue;
-        }
-#endif
         if ((rc = mark(0))) return rc;
         const bool token = b->pingpong && sub >= 0 && i == 0;
         const int prev = (sub + b->nsub - 1) % b->nsub;                             // the token goes round the streams
@@ -549,11 +495,7 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
             x265hip_tq_params p{};
             p.qp = d.qp; p.add = 85; p.subpelPlanes = up ? b->planes[l][r] : nullptr; p.planeElems = up ? planeElems : 0;
             if (b->needChoice) { p.choice = b->choice[mi]; p.choiceList = l; p.choiceRef = r; }
-#ifdef X265HIP_EXPERIMENTS
-            rc = (b->tiled ? xh_tq_batch_tiled : x265hip_tq_batch)
-#else
             rc = x265hip_tq_batch
-#endif
                                  (st, d.tuLog2, b->cur, b->stride, b->ref[l][r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
                                   d.recon ? b->recon : nullptr, b->stride, d.recon ? b->sse + t0 : nullptr, b->needChoice ? nullptr : b->res[0][0][mi]);
             if (rc != X265HIP_OK) return rc;
@@ -579,7 +521,6 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
     int rc0;
     if (!b) { set_error("batch_step: null batch"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
-    b->tiled = tiled_ok(b);
     const int F = b->d.frames, S = b->nsub, ctuRows = b->d.height / CTU, G = F * ctuRows, band = b->d.bandRows;
     hipEvent_t* ev = nullptr;
     if (b->timing)
@@ -592,31 +533,6 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
     }
     if (S == 1 && band <= 0) return step_range(b, 0, G, true, b->sub[0], ev);
     int rc;
-#ifdef X265HIP_EXPERIMENTS
-    if (band > 0)
-    {   // Band-major: the phase planes of the whole batch first, then bands of CTU rows, each through ALL levels before the stream takes its next band -- the 16 phase
-        // planes under a band (tens of MB) are read by four levels and the TQ stage back to back instead of once per level-wide pass over the whole batch (GBs), so the
-        // re-reads find them in the last-level cache.  Bands are independent of each other (a level's predictor is its parent CU's MV, inside the band); they are dealt
-        // round-robin to the streams.
-        if (b->d.usePlanes)
-        {
-            if (ev) XH_HIP(hipEventRecord(ev[0], b->sub[0]));
-            if ((rc = planes_range(b, 0, F, b->sub[0])) != X265HIP_OK) return rc;
-            if (ev) XH_HIP(hipEventRecord(ev[1], b->sub[0]));
-        }
-        XH_HIP(hipEventRecord(b->evFork, b->sub[0]));
-        for (int s = 1; s < S; s++) XH_HIP(hipStreamWaitEvent(b->sub[s], b->evFork, 0));
-        int k = 0;
-        for (int g0 = 0; g0 < G; g0 += band, k++)
-        {
-            const int s = k % S;
-            // (the stage events bracket the first band of stream 0; its planes slot holds the whole-batch launch above)
-            // the stage events bracket the first band (stream 0); its "planes" pair was recorded around the whole-batch launch above, so the band records from stage 1 on
-            if ((rc = step_range(b, g0, std::min(G, g0 + band), false, b->sub[s], (ev && k == 0) ? ev : nullptr)) != X265HIP_OK) return rc;
-        }
-    }
-    else
-#endif
     {   // Independent pictures: the levels of one picture depend on each other (a level's predictor is its parent CU's MV), pictures do not.  Sub-batch s runs on its
         // own stream, so the LDS-bound 64x64 search of one runs beside the latency-bound 16x16 / 8x8 searches of another.  Everything is ordered after the work already
         // queued on the context's stream and joined back into it.
@@ -642,7 +558,6 @@ extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
     if (!b) { set_error("batch_step_one_stream: null batch"); return X265HIP_EARG; }
     if (b->d.bandRows > 0) { set_error("batch_step_one_stream: not with the band-major schedule"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
-    b->tiled = tiled_ok(b);
     int rc = join_subs(b);
     if (rc) return rc;
     for (int s = 1; s < b->nsub; s++)
@@ -681,10 +596,8 @@ extern "C" int x265hip_batch_set_fused(x265hip_batch* b, int on) { return x265hi
 extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on)
 {
     if (!b) return X265HIP_EARG;
-#ifndef X265HIP_EXPERIMENTS
-    if (on & ~X265HIP_BATCH_START64_LAUNCH) { set_error("batch_set_mode: flags %d are measured-loss experiments (fused lower levels, tiled phase planes): build the library with make EXPERIMENTS=1", on & ~X265HIP_BATCH_START64_LAUNCH); return X265HIP_EARG; }
-#endif
-    b->fused = (on & 3) != 0; b->fusedFrom32 = (on & 3) == 2; b->ownStart64 = !(on & 4); b->tiledWanted = (on & 8) != 0;
+    if (on & ~X265HIP_BATCH_START64_LAUNCH) { set_error("batch_set_mode: flags %d: the fused lower levels and the tiled phase planes were measured losses (profiles/r03_fused_ab.txt, r03_tiled_ab.txt) and left the library in round 5", on & ~X265HIP_BATCH_START64_LAUNCH); return X265HIP_EARG; }
+    b->ownStart64 = !(on & 4);
     return X265HIP_OK;
 }
 extern "C" int x265hip_batch_set_timing(x265hip_batch* b, int on) { if (!b) return X265HIP_EARG; b->timing = on != 0; return X265HIP_OK; }
