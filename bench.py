@@ -1079,6 +1079,17 @@ def main():
             pipe.step()
     barrier()
     dt = time.perf_counter() - t0
+    # NOT part of the reported value: the same region (K steps between barriers) four more times -- the spread of the headline's clock over repetitions of 0.5 s each
+    repeats = [dt]
+    for _ in range(4):
+        pipe.set_timing(False)
+        barrier()
+        tr0 = time.perf_counter()
+        for k in range(args.steps * args.inner):
+            pipe.step()
+        barrier()
+        repeats.append(time.perf_counter() - tr0)
+    repeats = [max_over_ranks(x, dist if world > 1 else None, device="cuda") for x in repeats]
     t_serial = None
     if serial_stage_times and rank == 0:
         # NOT part of the timed region: the same batch stepped as one sub-batch on one stream (x265hip_batch_step_one_stream, same results), every pass with per-stage events
@@ -1124,7 +1135,10 @@ def main():
             "metric": "Mpixels/s ME+DCT+quant on 4K CTU batches (luma source pixels through ME pyramid + MC/DCT/quant)",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": dist.get_world_size() if world > 1 else 1, "rccl_ranks": world, "devices": devices,
             "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step_spread": {"note": "the timed region and four repetitions of it behind it (same K steps between barriers); value is the FIRST, timed, one", "min": round(min(repeats) / args.steps * 1e3, 4),
+                                   "max": round(max(repeats) / args.steps * 1e3, 4), "mean": round(sum(repeats) / len(repeats) / args.steps * 1e3, 4), "regions": len(repeats)},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8" if depth == 8 else "u16", "data": "synthetic",
             "config": {"workload": args.workload, "preset_exact": bool(args.refs == PRESET_REFS.get(args.workload) and args.rect == PRESET_RECT.get(args.workload)),
                        "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames * args.inner,

@@ -66,6 +66,9 @@ std::mutex g_lock;
 struct PicState { int poc1 = 0, rowsDone = 0; };      /* POC + 1 of the picture the Frame object holds now; its CTU rows [0, rowsDone) have their records */
 std::map<const Frame*, PicState> g_pics;
 int g_bands;                                 /* jobs (bands of CTU rows) run; == g_pictures with one frame thread */
+int g_trace;                                 /* X265TME_TRACE=1: a line per job on stderr (where a stalled encode stands) */
+int g_waitRefs;                              /* X265TME_WAIT_REFS=1 (diagnosis; unweighted references only): a picture waits for its references to be complete and goes through the
+                                                producer whole -- separates the frame-parallel window rules from the band protocol */
 
 void to_choice(const MEData& m, x265hip_inter_choice& o)
 {
@@ -403,7 +406,20 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         if (s_job && s_job->frame == &frame && s_job->poc == poc && row >= s_job->row0 && row < s_job->row1) break;      /* the band's job is running: help */
         if (!s_job)
         {   /* a new band: from the first row without records to the last one whose reference rows are final (one frame thread: the whole picture) */
-            const int row1 = Job::ready_rows(*this, row, nCtuY);
+            int row1 = Job::ready_rows(*this, row, nCtuY);
+            if (g_waitRefs && row1 < nCtuY)
+            {
+                lk.unlock();
+                for (int l = 0; l < (m_slice->isInterP() ? 1 : 2); l++)
+                    for (int ref = 0; ref < m_slice->m_numRefIdx[l]; ref++)
+                    {
+                        Frame* rf = m_slice->m_refFrameList[l][ref];
+                        while (rf->m_reconRowFlag[nCtuY - 1].get() == 0) rf->m_reconRowFlag[nCtuY - 1].waitForChange(0);
+                    }
+                lk.lock();
+                continue;                                                     /* (the world may have changed while the lock was open: look again -- the rows are all ready now) */
+            }
+            if (g_trace) fprintf(stderr, "tme_adapter: POC %d rows %d..%d (asked for row %d of %d)\n", poc, ps.rowsDone, row1 - 1, row, nCtuY);
             s_job = Job::create(*this, frame, ps.rowsDone, row1);
             if (!s_job) exit(3);
             g_sec[0] += now() - tStart;                                       /* job set-up (the first picture also creates the producer: context, streams, code objects) */
@@ -455,6 +471,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         g_sec[3] += now();
         g_pics[&frame].rowsDone = job->row1;
         g_bands++;
+        if (g_trace) fprintf(stderr, "tme_adapter: POC %d rows %d..%d done (%.1f ms, %d helpers' CTUs)\n", poc, job->row0, job->row1 - 1, 1e3 * (now() - tStart), job->helped.load());
         if (job->row1 == nCtuY) g_pictures++;
         g_pictureSeconds += now() - tStart;
         job->phase = 3;
@@ -475,6 +492,8 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
 extern "C" int x265hip_tme_adapter_load(const char* libraryPath, int device)
 {
     if (getenv("X265TME_NOKEEP")) g_keepPlanes = 0;
+    g_trace = getenv("X265TME_TRACE") && atoi(getenv("X265TME_TRACE"));
+    g_waitRefs = getenv("X265TME_WAIT_REFS") && atoi(getenv("X265TME_WAIT_REFS"));
     g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
     if (!g_lib) { fprintf(stderr, "tme_adapter: dlopen: %s\n", dlerror()); return -1; }
     g_api.ctx_create = (int (*)(int, x265hip_ctx**))dlsym(g_lib, "x265hip_ctx_create");

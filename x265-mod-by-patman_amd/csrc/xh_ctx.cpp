@@ -71,10 +71,10 @@ struct x265hip_batch
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
     std::vector<xh::KernelEvents> evStar; bool starValid[kTimingSets] = {}; int starSteps = 0; const xh::KernelEvents* starNow = nullptr;                // star64_kernel alone, first reference of sub-batch 0 (x265hip_batch_read_kernel_timing)
     std::vector<void*> owned;
-    template<class T> int alloc(T*& p, size_t n)
+    template<class T> int alloc(T*& p, size_t n, const char* file = __builtin_FILE(), int line = __builtin_LINE())
     {
         void* v = nullptr;
-        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), XH_ALLOC_TAG));
+        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line)));
         owned.push_back(v); p = (T*)v;
         return X265HIP_OK;
     }

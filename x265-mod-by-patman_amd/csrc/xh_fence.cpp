@@ -113,6 +113,14 @@ hipError_t dev_free(void* p)
     return hipSuccess;
 }
 
+const char* alloc_tag(const char* file, int line)
+{
+    static thread_local char buf[160];
+    const char* s = strrchr(file, '/');
+    snprintf(buf, sizeof(buf), "%s:%d", s ? s + 1 : file, line);
+    return buf;
+}
+
 void launch_note(const char* file, int line)
 {
     { std::lock_guard<std::mutex> lock(g_mu); (void)log_file(); }

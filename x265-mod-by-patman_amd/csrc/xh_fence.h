@@ -19,11 +19,13 @@ namespace xh {
 inline hipError_t dev_alloc(void** p, size_t bytes, const char* /*tag*/) { return hipMalloc(p, bytes); }
 inline hipError_t dev_free(void* p) { return hipFree(p); }
 inline void launch_note(const char*, int) {}
+inline const char* alloc_tag(const char*, int) { return ""; }
 constexpr bool kFence = false;
 #else
 hipError_t dev_alloc(void** p, size_t bytes, const char* tag);
 hipError_t dev_free(void* p);
 void launch_note(const char* file, int line);     // log the launch, then wait for it (a fault is then this launch's)
+const char* alloc_tag(const char* file, int line);      // "file:line" of an allocation's CALLER (the per-object alloc() helpers pass __builtin_FILE / __builtin_LINE)
 constexpr bool kFence = true;
 #endif
 

@@ -23,10 +23,10 @@ struct x265hip_ff
     uint8_t* sliceFirstRow = nullptr; int nrows = 0;   // --slices: device copy of desc.pic.sliceFirstRow (nrows + 1 bytes)
     std::mutex mu;
     std::vector<void*> owned;
-    template<class T> int alloc(T*& p, size_t n)
+    template<class T> int alloc(T*& p, size_t n, const char* file = __builtin_FILE(), int line = __builtin_LINE())
     {
         void* v = nullptr;
-        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), XH_ALLOC_TAG));
+        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line)));
         owned.push_back(v); p = (T*)v;
         return X265HIP_OK;
     }

@@ -37,10 +37,10 @@ struct x265hip_la
     std::vector<Req*> queue;
     int64_t batches = 0, batched = 0;
     std::vector<void*> owned;
-    template<class T> int alloc(T*& p, size_t n)
+    template<class T> int alloc(T*& p, size_t n, const char* file = __builtin_FILE(), int line = __builtin_LINE())
     {
         void* v = nullptr;
-        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), XH_ALLOC_TAG));
+        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line)));
         owned.push_back(v); p = (T*)v;
         return X265HIP_OK;
     }

@@ -130,10 +130,10 @@ struct x265hip_tme
     std::vector<Kept> kept; uint64_t tick = 0;
     int rowQp[64];                                                // the qp whose MVD cost row sits in row q of costTable (rows are kept across pictures)
     bool prof = false, first = false; double sec[5] = {}; int pictures = 0;      // X265HIP_TME_PROF: upload, diamond stage, submit, drain, (total)
-    template<class T> int alloc(T*& p, size_t n)
+    template<class T> int alloc(T*& p, size_t n, const char* file = __builtin_FILE(), int line = __builtin_LINE())
     {
         void* v = nullptr;
-        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), XH_ALLOC_TAG));
+        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line)));
         owned.push_back(v); p = (T*)v;
         return X265HIP_OK;
     }
@@ -301,7 +301,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
             }
             if (R.refTable)
             {
-                if (!t->refTable[l][r] && (rc = t->alloc(t->refTable[l][r], (size_t)nCtu * 593))) return rc;
+                if (!t->refTable[l][r] && (rc = t->alloc(t->refTable[l][r], (size_t)t->nCtu * 593))) return rc;      // the whole picture's table, whatever band comes first
                 if ((rc = table_up(t->refTable[l][r], R.refTable))) return rc;
             }
             if (R.lowresMv)
