@@ -229,6 +229,8 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
            "fps": {k: v["fps"] for k, v in runs.items()}, "same_encoder_cpu_producer_fps": c["fps"],
            "bitstream_identical": all(v["md5"] == w["md5"] and v["bytes"] == w["bytes"] for v in runs.values() for w in runs.values() if v["clip_frames"] == w["clip_frames"]), "bytes": c["bytes"],
            "tme": {"gpu_pictures": g["gpu_pictures"], "producer_ms_per_picture": round(1e3 * g["gpu_seconds"] / max(1, g["gpu_pictures"]), 2),
+                   "producer_ms_per_picture_warm": (round(1e3 * best["gpu_seconds_warm"] / best["gpu_calls_warm"], 2) if best.get("gpu_calls_warm") else None),
+                   "producer_note": "producer_ms_per_picture: the %d-picture per-seam run, first launches (code objects) included; _warm: the %d-frame all-GPU run without its first four calls" % (g["clip_frames"], best["clip_frames"]),
                    "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"] - g.get("adapter_create_seconds", 0.0)) / max(1, g["gpu_pictures"]), 2),
                    "adapter_note": "host work around the producer call (qps, collocated neighbours, medians, table conversions), spread over the encoder's ThreadedME workers; creating the producer (%.0f ms, once) not included"
                                    % (1e3 * g.get("adapter_create_seconds", 0.0)),

@@ -62,6 +62,8 @@ double g_sec[4];      /* per encode: [0] job set-up seconds (incl. creating the 
                          collocated neighbours, medians, table conversions -- spread over the workers), [2] CTUs harvested by workers other than the leader, [3] write-back seconds */
 double g_createSeconds;                     /* creating the producer (context, streams, device buffers) on the first picture */
 double g_gpuSeconds, g_pictureSeconds;      /* inside x265hip_tme_picture; the whole producer call incl. the adapter's harvest and write-back */
+double g_gpuSecondsWarm; int g_callsWarm;   /* the same without the first four calls (code objects are loaded by the first launch of each kernel) */
+int g_calls;
 std::mutex g_lock;
 struct PicState { int poc1 = 0, rowsDone = 0; };      /* POC + 1 of the picture the Frame object holds now; its CTU rows [0, rowsDone) have their records */
 std::map<const Frame*, PicState> g_pics;
@@ -378,7 +380,9 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             const auto t0 = std::chrono::steady_clock::now();
             const int rc = g_api.tme_picture(g_tme, &d);
             if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; }
-            g_gpuSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            const double dtCall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            g_gpuSeconds += dtCall;
+            if (++g_calls > 4) { g_gpuSecondsWarm += dtCall; g_callsWarm++; }
             return 0;
         }
 
@@ -518,6 +522,6 @@ extern "C" void x265hip_tme_adapter_close(void)
 }
 extern "C" void x265hip_tme_adapter_get_stats(x265hip_tme_adapter_stats* o)
 {
-    o->pictures = g_pictures; o->bands = g_bands; o->weightedRefs = g_weighted; o->producerSeconds = g_gpuSeconds; o->adapterSeconds = g_pictureSeconds; o->createSeconds = g_createSeconds;
+    o->pictures = g_pictures; o->bands = g_bands; o->producerSecondsWarm = g_gpuSecondsWarm; o->callsWarm = g_callsWarm; o->weightedRefs = g_weighted; o->producerSeconds = g_gpuSeconds; o->adapterSeconds = g_pictureSeconds; o->createSeconds = g_createSeconds;
     for (int i = 0; i < 4; i++) o->sections[i] = g_sec[i];
 }

@@ -27,6 +27,7 @@ typedef struct x265hip_tme_adapter_stats
     int pictures, weightedRefs;
     int bands;                     /* producer calls: bands of CTU rows (== pictures with one frame thread; more with frame threads, where a picture's rows become ready as its references' rows are final) */
     double producerSeconds;        /* inside x265hip_tme_picture                                                        */
+    double producerSecondsWarm; int callsWarm;      /* the same without the first four calls (every kernel's first launch loads its code object) */
     double adapterSeconds;         /* the whole per-picture call: harvest + producer + write-back                       */
     double createSeconds;          /* creating the producer, once (inside adapterSeconds and sections[0..1])                */
     double sections[4];            /* [0] job set-up, [1] wall time up to the producer call (set-up + harvest, spread over the ThreadedME workers), [2] CTUs harvested by workers

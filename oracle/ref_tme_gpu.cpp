@@ -130,7 +130,7 @@ int main(int argc, char** argv)
                  useFf ? "gpu" : "cpu", fs.pictures, fs.cpuPictures, fs.deblockSkipped, fs.statsServed, fs.gatherSeconds, fs.producerSeconds, fs.replaySeconds);
     }
 #endif
-    printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_bands\": %d, \"frame_threads\": %d, \"wpp\": %d, \"gpu_seconds\": %.3f, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
-           la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.bands, frameThreads, wpp, s.producerSeconds, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
+    printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_bands\": %d, \"frame_threads\": %d, \"wpp\": %d, \"gpu_seconds\": %.3f, \"gpu_seconds_warm\": %.4f, \"gpu_calls_warm\": %d, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
+           la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.bands, frameThreads, wpp, s.producerSeconds, s.producerSecondsWarm, s.callsWarm, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
     return 0;
 }

@@ -9,6 +9,7 @@
 #include <csignal>
 #include <mutex>
 #include <unordered_map>
+#include <utility>
 #include <unistd.h>
 
 namespace xh {
@@ -25,6 +26,7 @@ bool g_sync = true;
 // the last launches of the process: written by the SIGABRT handler (the HSA runtime reports a memory fault and calls abort())
 struct Note { const char* file; int line; };
 constexpr int kRing = 32;
+constexpr size_t kQuarantine = 4096;
 Note g_ring[kRing];
 std::atomic<unsigned> g_ringAt{0};
 
@@ -108,7 +110,12 @@ hipError_t dev_free(void* p)
     (void)hipDeviceSynchronize();
     (void)hipMemUnmap(b.mapAt, b.mapped);
     (void)hipMemRelease(b.handle);
-    // the reservation is NOT returned: a later block must never land where a stale pointer still points (use after free = page fault as well)
+    // the reservation is not returned at once: a later block must not land where a stale pointer still points (use after free = page fault as well).  The last kQuarantine
+    // reservations are held back, older ones go back to the driver (a slot-path encode allocates hundreds of thousands of blocks: the address space is not endless)
+    static std::pair<void*, size_t> held[kQuarantine]; static size_t at = 0;
+    std::pair<void*, size_t>& slot = held[at++ % kQuarantine];
+    if (slot.first) (void)hipMemAddressFree(slot.first, slot.second);
+    slot = { (void*)b.base, b.reserved };
     fprintf(log_file(), "[fence] free %p\n", p);
     return hipSuccess;
 }
