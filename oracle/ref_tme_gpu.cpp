@@ -80,6 +80,8 @@ int main(int argc, char** argv)
         if (eq) *eq = 0;
         if (x265_param_parse(p, argv[i], eq ? eq + 1 : NULL) < 0) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
     }
+    const bool frameStats = getenv("X265_FRAME_STATS") && atoi(getenv("X265_FRAME_STATS"));      /* diagnosis: the encoder's own per-frame clocks (x265_frame_stats, csv-log-level 2) summed over the clip */
+    if (frameStats) p->csvLogLevel = 2;
     FILE* out = fopen(argv[6], "wb");
     if (!out) { fprintf(stderr, "cannot write %s\n", argv[6]); return 2; }
     x265_encoder* enc = x265_encoder_open(p);
@@ -92,17 +94,26 @@ int main(int argc, char** argv)
     pic->bitDepth = X265_DEPTH; pic->colorSpace = X265_CSP_I420;
     x265_nal* nal; uint32_t nnal;
     size_t bytes = 0;
+    x265_picture* picOut = frameStats ? x265_picture_alloc() : NULL;
+    double fsTmeWaitMs = 0, fsTmeMs = 0, fsCtuMs = 0, fsStallMs = 0, fsWallMs = 0, fsWpp = 0, fsRefWaitMs = 0; int fsN = 0;
+    auto take = [&](int got) { if (got > 0 && picOut) { const x265_frame_stats& f = picOut->frameData; fsTmeWaitMs += f.tmeWaitTime / 1000.0; fsTmeMs += f.tmeTime / 1000.0; fsCtuMs += f.totalCTUTime; fsStallMs += f.stallTime; fsWallMs += f.wallTime; fsRefWaitMs += f.refWaitWallTime; fsWpp += f.avgWPP; fsN++; } };
     const auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; f++)
     {
         synth(Y, U, V, w, h, f);
         pic->pts = f;
-        const int r = x265_encoder_encode(enc, &nal, &nnal, pic, NULL);
+        const int r = x265_encoder_encode(enc, &nal, &nnal, pic, picOut);
         if (r < 0) { fprintf(stderr, "encode failed\n"); return 2; }
+        take(r);
         for (uint32_t i = 0; i < nnal; i++) { fwrite(nal[i].payload, 1, nal[i].sizeBytes, out); bytes += nal[i].sizeBytes; }
     }
-    while (x265_encoder_encode(enc, &nal, &nnal, NULL, NULL) > 0)
+    for (;;)
+    {
+        const int r = x265_encoder_encode(enc, &nal, &nnal, NULL, picOut);
+        if (r <= 0) break;
+        take(r);
         for (uint32_t i = 0; i < nnal; i++) { fwrite(nal[i].payload, 1, nal[i].sizeBytes, out); bytes += nal[i].sizeBytes; }
+    }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     x265_param* live = x265_param_alloc();
     x265_encoder_parameters(enc, live);
@@ -130,6 +141,9 @@ int main(int argc, char** argv)
                  useFf ? "gpu" : "cpu", fs.pictures, fs.cpuPictures, fs.deblockSkipped, fs.statsServed, fs.gatherSeconds, fs.producerSeconds, fs.replaySeconds);
     }
 #endif
+    if (frameStats && fsN)
+        fprintf(stderr, "frame stats over %d pictures (ms per picture): wall %.1f, all rows' reference wait %.1f, CTU worker time %.1f, stall (no worker) %.1f, ThreadedME tasks %.1f, rows blocked on ThreadedME %.1f, avg WPP %.1f\n",
+                fsN, fsWallMs / fsN, fsRefWaitMs / fsN, fsCtuMs / fsN, fsStallMs / fsN, fsTmeMs / fsN, fsTmeWaitMs / fsN, fsWpp / fsN);
     printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_bands\": %d, \"frame_threads\": %d, \"wpp\": %d, \"gpu_seconds\": %.3f, \"gpu_seconds_warm\": %.4f, \"gpu_calls_warm\": %d, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
            la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.bands, frameThreads, wpp, s.producerSeconds, s.producerSecondsWarm, s.callsWarm, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
     return 0;

@@ -20,11 +20,15 @@ inline hipError_t dev_alloc(void** p, size_t bytes, const char* /*tag*/) { retur
 inline hipError_t dev_free(void* p) { return hipFree(p); }
 inline void launch_note(const char*, int) {}
 inline const char* alloc_tag(const char*, int) { return ""; }
+inline hipError_t dev_alloc_pooled(void** p, size_t bytes, const char*) { return hipMalloc(p, bytes); }
+inline void dev_free_pooled(void* p) { (void)hipFree(p); }
 constexpr bool kFence = false;
 #else
 hipError_t dev_alloc(void** p, size_t bytes, const char* tag);
 hipError_t dev_free(void* p);
 void launch_note(const char* file, int line);     // log the launch, then wait for it (a fault is then this launch's)
+hipError_t dev_alloc_pooled(void** p, size_t bytes, const char* tag);      // blocks that come and go by the hundred thousand (the slot path's staging blocks): kept mapped per size
+void dev_free_pooled(void* p);
 const char* alloc_tag(const char* file, int line);      // "file:line" of an allocation's CALLER (the per-object alloc() helpers pass __builtin_FILE / __builtin_LINE)
 constexpr bool kFence = true;
 #endif

@@ -39,7 +39,7 @@ struct CtxHolder
     {
         if (!c) return;
         (void)hipStreamSynchronize(c->stream);
-        for (char* p : c->retired) (void)xh::dev_free(p);
+        for (char* p : c->retired) { if (xh::kFence) xh::dev_free_pooled(p); else (void)xh::dev_free(p); }
         (void)xh::dev_free(c->arena); (void)xh::dev_free(c->zeros); (void)hipHostFree(c->pinned); (void)hipStreamDestroy(c->stream);
         delete c;
     }
@@ -72,7 +72,7 @@ void* ThreadCtx::dalloc(size_t bytes)
     if (xh::kFence)
     {   // fence build: every block of a slot call is its own fenced allocation (freed by the next reset())
         void* p = nullptr;
-        if (xh::dev_alloc(&p, bytes, "slot block") != hipSuccess) { set_error("device memory exhausted (fence build, %zu bytes)", bytes); fatal("arena"); }
+        if (xh::dev_alloc_pooled(&p, bytes, "slot block") != hipSuccess) { set_error("device memory exhausted (fence build, %zu bytes)", bytes); fatal("arena"); }
         retired.push_back((char*)p);
         return p;
     }
@@ -95,7 +95,7 @@ void ThreadCtx::reset()
     if (!retired.empty())
     {   // every slot call ends with sync(), so nothing queued on the stream still reads the retired chunks
         (void)hipStreamSynchronize(stream);
-        for (char* p : retired) (void)xh::dev_free(p);
+        for (char* p : retired) { if (xh::kFence) xh::dev_free_pooled(p); else (void)xh::dev_free(p); }
         retired.clear();
     }
 }
