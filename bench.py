@@ -208,17 +208,27 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
         # (one picture in flight per FrameFilter is what it replays), the lookahead binding is thread-safe as it is
         default_runs = {}
         if both:
-            for name, tme_on, tme, la, ff in (("cpu_default_threading", 0, 0, 0, 0), ("cpu_default_threading_tme", 1, 0, 0, 0), ("all_gpu_default_threading", 1, 1, 1, 1)):
-                outp = os.path.join(td, name + ".hevc")
-                env = dict(os.environ, X265TME=str(tme_on), X265TMEGPU=str(tme), X265LAGPU=str(la), X265FFGPU=str(ff), X265_CLI_THREADING="1")
-                env.pop("X265FF_DEFER_ONLY", None)
-                r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(default_frames), "medium", outp], capture_output=True, text=True, env=env, timeout=900)
-                if r.returncode != 0:
-                    default_runs[name] = {"failed": r.stderr[-300:]}
-                    continue
-                info = json.loads(r.stdout.strip().splitlines()[-1])
-                info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
-                default_runs[name] = info
+            # (256 pool threads under whatever CPU quota the box gives them: the clock of one run moves by +-10 %, so the GPU run is taken three times, the plain CPU run twice)
+            for name, tme_on, tme, la, ff, reps in (("cpu_default_threading", 0, 0, 0, 0, 3), ("cpu_default_threading_tme", 1, 0, 0, 0, 1), ("all_gpu_default_threading", 1, 1, 1, 1, 3),
+                                                    ("gpu_lookahead_default_threading", 0, 0, 1, 0, 3)):
+                got = []
+                for rep in range(reps):
+                    outp = os.path.join(td, "%s_%d.hevc" % (name, rep))
+                    env = dict(os.environ, X265TME=str(tme_on), X265TMEGPU=str(tme), X265LAGPU=str(la), X265FFGPU=str(ff), X265_CLI_THREADING="1", MALLOC_PERTURB_="85")
+                    env.pop("X265FF_DEFER_ONLY", None)
+                    r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(default_frames), "medium", outp], capture_output=True, text=True, env=env, timeout=900)
+                    if r.returncode != 0:
+                        default_runs[name] = {"failed": r.stderr[-300:]}
+                        break
+                    info = json.loads(r.stdout.strip().splitlines()[-1])
+                    info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
+                    got.append(info)
+                else:
+                    got.sort(key=lambda i: i["fps"])
+                    med = dict(got[len(got) // 2])
+                    med["fps_runs"] = [i["fps"] for i in got]
+                    med["md5_all_equal"] = all(i["md5"] == got[0]["md5"] for i in got)
+                    default_runs[name] = med
     g, c = runs["tme_gpu"], runs["cpu"]
     best = runs.get("all_gpu", g)
     out = {"value": best["fps"], "unit": "frames/s", "measured": "this run",
@@ -239,18 +249,23 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
         ok = {k: v for k, v in default_runs.items() if "fps" in v}
         a, b = ok.get("cpu_default_threading_tme"), ok.get("all_gpu_default_threading")
         dt = {"config": "the same clip and preset, %d frames, threaded as the CLI threads it (frame threads from the core count, WPP, %d cores)" % (default_frames, os.cpu_count() or 0),
-              "fps": {k: v["fps"] for k, v in ok.items()}, "failed": {k: v["failed"] for k, v in default_runs.items() if "failed" in v} or None,
+              "fps": {k: v["fps"] for k, v in ok.items()}, "fps_runs": {k: v["fps_runs"] for k, v in ok.items()}, "fps_rule": "median of the runs listed in fps_runs",
+              "failed": {k: v["failed"] for k, v in default_runs.items() if "failed" in v} or None,
               "frame_threads": b.get("frame_threads") if b else None, "wpp": b.get("wpp") if b else None,
-              "bitstream_identical_gpu_vs_cpu_producers": bool(a and b and a["md5"] == b["md5"] and a["bytes"] == b["bytes"])}
+              "bitstream_identical_gpu_vs_cpu_producers": bool(a and b and a["md5"] == b["md5"] and a["bytes"] == b["bytes"] and b["md5_all_equal"]), "host": usable_cores()[1]}
         if b:
-            dt["gpu_run"] = {"tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
+            dt["gpu_run"] = {"tme_lanes": int(os.environ.get("X265TME_LANES", "4")), "tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
                              "tme_adapter_seconds": b["adapter_seconds"], "la_estimates": b.get("la_estimates"), "la_producer_seconds": b.get("la_producer_seconds"),
                              "filter_pictures_gpu": b.get("ff_pictures"), "filter_pictures_left_to_the_cpu": b.get("ff_cpu_pictures"), "seconds": b["seconds"]}
-        if a and b and "cpu_default_threading" in ok:
-            d0 = ok["cpu_default_threading"]["fps"]
-            dt["verdict"] = ("GPU producers %.2f fps vs the encoder's own producers %.2f fps under the same threading (%.2fx); the encoder without --threaded-me does %.2f fps -- "
-                             "the RDO / entropy-coding host work, not the seams, bounds the encode, and a host with this many cores does the seams' work in parallel with it"
-                             % (b["fps"], a["fps"], b["fps"] / a["fps"], d0))
+        p0, l0 = ok.get("cpu_default_threading"), ok.get("gpu_lookahead_default_threading")
+        if p0 and l0:
+            dt["bitstream_identical_gpu_lookahead_vs_plain_encoder"] = bool(p0["md5"] == l0["md5"] and l0["md5_all_equal"] and p0["md5_all_equal"])
+        if a and b and p0:
+            dt["verdict"] = ("with --threaded-me: GPU producers %.2f fps vs the encoder's own producers %.2f fps (%.2fx), same bitstream.  The encoder WITHOUT --threaded-me does %.2f fps: "
+                             "on this host the ThreadedME seam is %s than not using ThreadedME at all -- a row's records arrive a band call (~6 ms: the depth of one CTU's chain of searches, "
+                             "whatever the band holds) after its reference rows are final, which is when the row could have started (profiles/r05_m2_lanes.txt: rows blocked on ThreadedME "
+                             "110-140 ms per picture).  The lookahead seam alone (no --threaded-me, the plain encoder's bitstream) does %s fps.  RDO and entropy coding on the host bound the encode"
+                             % (b["fps"], a["fps"], b["fps"] / a["fps"], p0["fps"], "FASTER" if b["fps"] > p0["fps"] else "SLOWER", ("%.2f" % l0["fps"]) if l0 else "n/a"))
         out["default_threading"] = dt
     if both:
         l = runs["la_gpu"]

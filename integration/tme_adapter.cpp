@@ -55,8 +55,14 @@ struct Api
     const char* (*last_error)();
 } g_api;
 void* g_lib;
-x265hip_ctx* g_ctx;
-x265hip_tme* g_tme;
+/* Producers ("lanes"): a job -- a band of CTU rows of one picture -- runs on the lane of its picture (encode order modulo the lane count), one job per lane at a time.
+   ONE lane by default.  X265TME_LANES=2..8 gives the pictures in flight their own producers (context, stream, kept planes), so that a band does not queue behind the bands
+   of other pictures -- measured at 1080p medium with five frame threads: no faster (profiles/r05_m2_lanes.txt: the producer calls of different threads slow each other down in
+   the HIP runtime, 2.0 -> 4.3 s of producer time per 48 frames, what DESIGN 8.1 found for four producer threads in round 2).  Bitstreams are the same with any count. */
+constexpr int kMaxLanes = 8;
+int g_lanes = 1;
+x265hip_ctx* g_ctx[kMaxLanes];
+x265hip_tme* g_tme[kMaxLanes];
 int g_useGpu, g_device, g_pictures, g_weighted, g_keepPlanes = 1;
 double g_sec[4];      /* per encode: [0] job set-up seconds (incl. creating the producer on the first picture), [1] wall seconds up to the producer call (set-up + harvest: qps,
                          collocated neighbours, medians, table conversions -- spread over the workers), [2] CTUs harvested by workers other than the leader, [3] write-back seconds */
@@ -64,7 +70,7 @@ double g_createSeconds;                     /* creating the producer (context, s
 double g_gpuSeconds, g_pictureSeconds;      /* inside x265hip_tme_picture; the whole producer call incl. the adapter's harvest and write-back */
 double g_gpuSecondsWarm; int g_callsWarm;   /* the same without the first four calls (code objects are loaded by the first launch of each kernel) */
 int g_calls;
-std::mutex g_lock;
+std::mutex g_lock, g_statLock;
 struct PicState { int poc1 = 0, rowsDone = 0; };      /* POC + 1 of the picture the Frame object holds now; its CTU rows [0, rowsDone) have their records */
 std::map<const Frame*, PicState> g_pics;
 int g_bands;                                 /* jobs (bands of CTU rows) run; == g_pictures with one frame thread */
@@ -163,6 +169,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     {
         Frame* frame; int poc, nCtu, nCtuX, nCtuY, nS, nl;
         int row0 = 0, row1 = 0, c0 = 0, c1 = 0;                    /* the band: CTU rows [row0, row1) = CTUs [c0, c1) of the picture */
+        int lane = 0;
         const x265hip_tme_step* steps;
         std::vector<int> used;                                     /* the MEData slots of a CTU the schedule writes (and reads) */
         std::vector<int> sliceOfRow;
@@ -208,26 +215,27 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             return r;
         }
 
-        static Job* create(Analysis& an, Frame& frame, int row0, int row1)
+        static Job* create(Analysis& an, Frame& frame, int row0, int row1, int lane)
         {
             const Slice* slice = an.m_slice;
             const x265_param* p = an.m_param;
             const int W = slice->m_sps->picWidthInLumaSamples, H = slice->m_sps->picHeightInLumaSamples, ctuSize = p->maxCUSize;
-            if (!g_tme)
+            if (!g_tme[lane])
             {
                 const auto t0 = std::chrono::steady_clock::now();
-                if (g_api.ctx_create(g_device, &g_ctx) || g_api.tme_create(g_ctx, W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme))
+                if (g_api.ctx_create(g_device, &g_ctx[lane]) || g_api.tme_create(g_ctx[lane], W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme[lane]))
                 { fprintf(stderr, "x265hip_tme_create: %s\n", g_api.last_error()); return nullptr; }
                 g_createSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             }
             /* the job's arrays are kept from picture to picture: fresh 10 MB vectors per picture cost more in page faults than the work on them */
-            static Job storage;
-            Job* j = &storage;
+            static Job storage[kMaxLanes];
+            Job* j = &storage[lane];
+            j->lane = lane;
             j->nextA = 0; j->doneA = 0; j->nextB = 0; j->doneB = 0; j->failed = 0; j->helped = 0; j->phase = 0; j->users = 0;
             j->used.clear(); j->refSrc.clear(); j->nRefTables = 0; j->nLowres = 0;
             j->frame = &frame; j->poc = slice->m_poc;
             j->nCtuX = slice->m_sps->numCuInWidth; j->nCtuY = slice->m_sps->numCuInHeight; j->nCtu = j->nCtuX * j->nCtuY;
-            j->nS = g_api.tme_entries(g_tme, &j->steps);
+            j->nS = g_api.tme_entries(g_tme[lane], &j->steps);
             j->nl = slice->isInterP() ? 1 : 2;
             j->row0 = row0; j->row1 = row1; j->c0 = row0 * j->nCtuX; j->c1 = row1 * j->nCtuX;
             const int nCtu = j->nCtu, nS = j->nS, nl = j->nl;
@@ -378,11 +386,12 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             d.qpIndex = qpIndex.data(); d.areaQpIndex = areaQpIndex.data(); d.temporal = temporal.data(); d.median = median.data(); d.table = table.data();
             if (row0 > 0 || row1 < nCtuY) { d.ctuRowFirst = row0; d.ctuRowCount = row1 - row0; }
             const auto t0 = std::chrono::steady_clock::now();
-            const int rc = g_api.tme_picture(g_tme, &d);
+            const int rc = g_api.tme_picture(g_tme[lane], &d);
             if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; }
             const double dtCall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::lock_guard<std::mutex> sg(g_statLock);
             g_gpuSeconds += dtCall;
-            if (++g_calls > 4) { g_gpuSecondsWarm += dtCall; g_callsWarm++; }
+            if (++g_calls > 4 * g_lanes) { g_gpuSecondsWarm += dtCall; g_callsWarm++; }
             return 0;
         }
 
@@ -392,7 +401,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             for (int sl : used) from_choice(table[(size_t)c * 593 + sl], dst[(size_t)c * 593 + sl]);
         }
     };
-    static Job* s_job = nullptr;
+    static Job* s_jobs[kMaxLanes] = {};
     static std::condition_variable s_cv;
 
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -402,6 +411,9 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     const int nCtuX = m_slice->m_sps->numCuInWidth, nCtuY = m_slice->m_sps->numCuInHeight, row = (int)ctu.m_cuAddr / nCtuX;
     bool leader = false;
     const double tStart = now();
+    if (m_param->frameNumThreads <= 1) g_lanes = 1;
+    const int lane = (int)((unsigned)frame.m_encodeOrder % (unsigned)g_lanes);
+    Job*& s_job = s_jobs[lane];
     for (;;)
     {
         PicState& ps = g_pics[&frame];
@@ -424,7 +436,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
                 continue;                                                     /* (the world may have changed while the lock was open: look again -- the rows are all ready now) */
             }
             if (g_trace) fprintf(stderr, "tme_adapter: POC %d rows %d..%d (asked for row %d of %d)\n", poc, ps.rowsDone, row1 - 1, row, nCtuY);
-            s_job = Job::create(*this, frame, ps.rowsDone, row1);
+            s_job = Job::create(*this, frame, ps.rowsDone, row1, lane);
             if (!s_job) exit(3);
             g_sec[0] += now() - tStart;                                       /* job set-up (the first picture also creates the producer: context, streams, code objects) */
             leader = true;
@@ -444,14 +456,14 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         job->doneA.fetch_add(1);
         if (!leader) job->helped.fetch_add(1);
     }
+    double tBack = 0;
     if (leader)
     {
         while (job->doneA.load() < nBand) std::this_thread::yield();          /* the helpers' last CTUs */
         const double tCall = now();
-        g_sec[1] += tCall - tStart;                                           /* wall time up to the producer call: set-up + harvest (qps, collocated neighbours, medians, table conversions) */
-        g_sec[2] += job->helped.load();                                       /* CTUs other workers harvested */
+        { std::lock_guard<std::mutex> sg(g_statLock); g_sec[2] += job->helped.load(); g_sec[1] += tCall - tStart; }      /* [2] CTUs other workers harvested; [1] wall time up to the producer call: set-up + harvest (qps, collocated neighbours, medians, table conversions) */
         if (job->failed.load() || job->call()) exit(3);
-        g_sec[3] -= now();                                                    /* write-back wall time, closed below */
+        tBack = now();                                                        /* write-back wall time, closed below */
         lk.lock(); job->phase = 2; lk.unlock();
         s_cv.notify_all();
     }
@@ -472,7 +484,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     if (leader)
     {
         while (job->doneB.load() < nBand) { lk.unlock(); std::this_thread::yield(); lk.lock(); }
-        g_sec[3] += now();
+        g_sec[3] += now() - tBack;
         g_pics[&frame].rowsDone = job->row1;
         g_bands++;
         if (g_trace) fprintf(stderr, "tme_adapter: POC %d rows %d..%d done (%.1f ms, %d helpers' CTUs)\n", poc, job->row0, job->row1 - 1, 1e3 * (now() - tStart), job->helped.load());
@@ -498,6 +510,9 @@ extern "C" int x265hip_tme_adapter_load(const char* libraryPath, int device)
     if (getenv("X265TME_NOKEEP")) g_keepPlanes = 0;
     g_trace = getenv("X265TME_TRACE") && atoi(getenv("X265TME_TRACE"));
     g_waitRefs = getenv("X265TME_WAIT_REFS") && atoi(getenv("X265TME_WAIT_REFS"));
+    g_lanes = getenv("X265TME_LANES") ? atoi(getenv("X265TME_LANES")) : 1;      /* measured: 2, 4, 8 lanes are no faster than 1 (profiles/r05_m2_lanes.txt) */
+    if (g_lanes < 1) g_lanes = 1;
+    if (g_lanes > kMaxLanes) g_lanes = kMaxLanes;
     g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
     if (!g_lib) { fprintf(stderr, "tme_adapter: dlopen: %s\n", dlerror()); return -1; }
     g_api.ctx_create = (int (*)(int, x265hip_ctx**))dlsym(g_lib, "x265hip_ctx_create");
@@ -516,8 +531,11 @@ extern "C" void x265hip_tme_adapter_enable(int on) { g_useGpu = on && g_lib; }
 extern "C" void x265hip_tme_adapter_close(void)
 {
     std::lock_guard<std::mutex> guard(g_lock);
-    if (g_tme) { g_api.tme_destroy(g_tme); g_tme = nullptr; }
-    if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
+    for (int k = 0; k < kMaxLanes; k++)
+    {
+        if (g_tme[k]) { g_api.tme_destroy(g_tme[k]); g_tme[k] = nullptr; }
+        if (g_ctx[k]) { g_api.ctx_destroy(g_ctx[k]); g_ctx[k] = nullptr; }
+    }
     g_pics.clear(); g_useGpu = 0;
 }
 extern "C" void x265hip_tme_adapter_get_stats(x265hip_tme_adapter_stats* o)

@@ -8,7 +8,7 @@ run() { name=$1; shift; ( env "$@" X265_FRAME_STATS=1 X265_CLI_THREADING=1 MALLO
   echo "== $name: $(tail -1 /tmp/$name.out | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d.get(k) for k in ('fps','frame_threads','gpu_pictures','gpu_bands','gpu_seconds','adapter_seconds','la_producer_seconds','ff_pictures')})" 2>&1)" >> $OUT
   grep "frame stats" /tmp/$name.err >> $OUT; md5sum /tmp/$name.hevc >> $OUT; }
 run cpu_plain X265TME=0 X265TMEGPU=0 X265LAGPU=0 X265FFGPU=0
-run cpu_tme X265TME=1 X265TMEGPU=0 X265LAGPU=0 X265FFGPU=0
-run gpu_tme X265TME=1 X265TMEGPU=1 X265LAGPU=0 X265FFGPU=0
-run gpu_tme_la X265TME=1 X265TMEGPU=1 X265LAGPU=1 X265FFGPU=0
+
+
+for L in 1 2 4 8; do for rep in 1 2 3; do run gpu_tme_la_lanes${L}_$rep X265TME=1 X265TMEGPU=1 X265LAGPU=1 X265FFGPU=0 X265TME_LANES=$L; done; done
 cat $OUT
