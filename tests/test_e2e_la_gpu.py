@@ -50,6 +50,21 @@ def test_bitstream_identical_with_gpu_lookahead(depth, args, fade, tmp_path):
                                                                                   1e3 * gpu["la_producer_seconds"] / (gpu["la_estimates"] + gpu["la_intra_pictures"])))
 
 
+@pytest.mark.parametrize("depth,args", [(8, ["320", "640", "16", "medium", "frame-threads=3", "wpp=1", "lookahead-slices=4"]),
+                                        (10, ["256", "576", "12", "slow", "frame-threads=4", "wpp=1"])])
+def test_both_seams_under_frame_threads(depth, args, tmp_path):
+    """The encoder threaded the way its CLI threads it (frame threads, WPP, cooperative lookahead slices): the lookahead's workers call the binding concurrently and
+    ThreadedME's rows arrive as bands (test_e2e_tme_gpu.py) -- lookahead alone and both seams together write the bitstreams of the CPU producers under the same threading."""
+    cpu, h_cpu = encode(depth, False, False, False, args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(depth, True, False, False, args, str(tmp_path / "gpu.hevc"))
+    assert gpu["lookahead_producer"] == "gpu" and gpu["la_estimates"] > 0 and gpu["frame_threads"] == int(args[4].split("=")[1])
+    assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "lookahead alone: bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
+    cpu2, h_cpu2 = encode(depth, False, True, False, args, str(tmp_path / "cpu2.hevc"))
+    gpu2, h_gpu2 = encode(depth, True, True, True, args, str(tmp_path / "gpu2.hevc"))
+    assert gpu2["gpu_bands"] >= gpu2["gpu_pictures"] > 0 and gpu2["la_estimates"] > 0
+    assert cpu2["bytes"] == gpu2["bytes"] and h_cpu2 == h_gpu2, "both seams: bitstreams differ: cpu %s gpu %s" % (cpu2, gpu2)
+
+
 @pytest.mark.parametrize("depth,args,fade", [(8, ["320", "192", "20", "medium"], False), (8, ["256", "128", "16", "medium", "weightp=1", "bframes=3"], True),
                                              (10, ["256", "192", "14", "slow", "rc-lookahead=15"], False)])
 def test_whole_batches_go_up_at_once(depth, args, fade, tmp_path):
