@@ -195,6 +195,8 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
             env.pop("X265FF_DEFER_ONLY", None)
             if ff == 2:
                 env["X265FF_DEFER_ONLY"] = "1"             # the binding's deferral with the encoder's own filters: times what the CPU spends on a picture's filters
+            if name in ("cpu_short", "tme_gpu"):
+                env["X265_FRAME_STATS"] = "1"              # the encoder's own per-frame clocks (csv-log-level 2; same bitstream): what ThreadedME costs and how long rows wait for it
             r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(nfr), "medium", outp], capture_output=True, text=True, env=env, timeout=900)
             if r.returncode != 0:
                 return {"measured": "this run: FAILED", "producer": name, "stderr": r.stderr[-500:]}
@@ -229,6 +231,12 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
                     med["fps_runs"] = [i["fps"] for i in got]
                     med["md5_all_equal"] = all(i["md5"] == got[0]["md5"] for i in got)
                     default_runs[name] = med
+            # the encoder's own per-frame clocks for the plain and the GPU run (a run each, not part of the fps figures: the statistics cost the ThreadedME runs some speed)
+            for name, tme_on, tme, la in (("cpu_default_threading", 0, 0, 0), ("all_gpu_default_threading", 1, 1, 1)):
+                env = dict(os.environ, X265TME=str(tme_on), X265TMEGPU=str(tme), X265LAGPU=str(la), X265FFGPU="0", X265_CLI_THREADING="1", MALLOC_PERTURB_="85", X265_FRAME_STATS="1")
+                r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(default_frames), "medium", os.path.join(td, "stats.hevc")], capture_output=True, text=True, env=env, timeout=900)
+                if r.returncode == 0 and name in default_runs and "fps" in default_runs[name]:
+                    default_runs[name]["frame_stats_ms_per_picture"] = json.loads(r.stdout.strip().splitlines()[-1]).get("frame_stats_ms_per_picture")
     g, c = runs["tme_gpu"], runs["cpu"]
     best = runs.get("all_gpu", g)
     out = {"value": best["fps"], "unit": "frames/s", "measured": "this run",
@@ -244,7 +252,11 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
                    "adapter_host_ms_per_picture": round(1e3 * (g["adapter_seconds"] - g["gpu_seconds"] - g.get("adapter_create_seconds", 0.0)) / max(1, g["gpu_pictures"]), 2),
                    "adapter_note": "host work around the producer call (qps, collocated neighbours, medians, table conversions), spread over the encoder's ThreadedME workers; creating the producer (%.0f ms, once) not included"
                                    % (1e3 * g.get("adapter_create_seconds", 0.0)),
-                   "ctus_harvested_by_helper_workers": int(g["adapter_sections"][2])}}
+                   "ctus_harvested_by_helper_workers": int(g["adapter_sections"][2])},
+           "encoder_clocks_ms_per_picture": {"one frame thread, its own ThreadedME": runs.get("cpu_short", {}).get("frame_stats_ms_per_picture"), "one frame thread, GPU ThreadedME": g.get("frame_stats_ms_per_picture"),
+                                             "note": "threaded_me_tasks = time the ThreadedME workers spend in their tasks, summed over workers (with the GPU producer: mostly waiting for the picture's call); "
+                                                     "rows_blocked_on_threaded_me = time the row encoder waits for a CTU's records.  wall - blocked is the frame thread's own work: mode decision, RDO, entropy coding -- "
+                                                     "what bounds M2; no encoder-side consumer of the batched TQ / intra arithmetic exists (Quant::transformNxN and estIntraPredQT run per CU inside the RDO loop)"}}
     if default_runs:
         ok = {k: v for k, v in default_runs.items() if "fps" in v}
         a, b = ok.get("cpu_default_threading_tme"), ok.get("all_gpu_default_threading")
@@ -253,6 +265,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
               "failed": {k: v["failed"] for k, v in default_runs.items() if "failed" in v} or None,
               "frame_threads": b.get("frame_threads") if b else None, "wpp": b.get("wpp") if b else None,
               "bitstream_identical_gpu_vs_cpu_producers": bool(a and b and a["md5"] == b["md5"] and a["bytes"] == b["bytes"] and b["md5_all_equal"]), "host": usable_cores()[1]}
+        dt["encoder_clocks_ms_per_picture"] = {k: v.get("frame_stats_ms_per_picture") for k, v in ok.items() if v.get("frame_stats_ms_per_picture")}
         if b:
             dt["gpu_run"] = {"tme_lanes": int(os.environ.get("X265TME_LANES", "4")), "tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
                              "tme_adapter_seconds": b["adapter_seconds"], "la_estimates": b.get("la_estimates"), "la_producer_seconds": b.get("la_producer_seconds"),

@@ -103,6 +103,13 @@ namespace X265_NS {
 void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
 {
     if (!g_useGpu) { ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame); return; }
+    if (frame.m_param->bIntraRefresh)
+    {   /* --intra-refresh narrows the search windows of the columns left of the refresh column (search.cpp:4988-4997): not modelled by the producer -- the encoder's own body runs */
+        static std::atomic<int> told{0};
+        if (!told.exchange(1)) fprintf(stderr, "tme_adapter: --intra-refresh: the encoder's own ThreadedME producer runs\n");
+        ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame);
+        return;
+    }
     /* local classes of a member function have the member's access: calculateQpforCuSize (protected) is reached without touching analysis.h */
     struct Harvest
     {

@@ -144,7 +144,11 @@ int main(int argc, char** argv)
     if (frameStats && fsN)
         fprintf(stderr, "frame stats over %d pictures (ms per picture): wall %.1f, all rows' reference wait %.1f, CTU worker time %.1f, stall (no worker) %.1f, ThreadedME tasks %.1f, rows blocked on ThreadedME %.1f, avg WPP %.1f\n",
                 fsN, fsWallMs / fsN, fsRefWaitMs / fsN, fsCtuMs / fsN, fsStallMs / fsN, fsTmeMs / fsN, fsTmeWaitMs / fsN, fsWpp / fsN);
-    printf("{%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_bands\": %d, \"frame_threads\": %d, \"wpp\": %d, \"gpu_seconds\": %.3f, \"gpu_seconds_warm\": %.4f, \"gpu_calls_warm\": %d, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
-           la, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.bands, frameThreads, wpp, s.producerSeconds, s.producerSecondsWarm, s.callsWarm, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
+    char fs[400] = "";
+    if (frameStats && fsN)
+        snprintf(fs, sizeof(fs), "\"frame_stats_ms_per_picture\": {\"pictures\": %d, \"wall\": %.1f, \"ctu_worker_time\": %.1f, \"threaded_me_tasks\": %.1f, \"rows_blocked_on_threaded_me\": %.1f, \"reference_wait\": %.1f, \"avg_wpp\": %.2f}, ",
+                 fsN, fsWallMs / fsN, fsCtuMs / fsN, fsTmeMs / fsN, fsTmeWaitMs / fsN, fsRefWaitMs / fsN, fsWpp / fsN);
+    printf("{%s%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_bands\": %d, \"frame_threads\": %d, \"wpp\": %d, \"gpu_seconds\": %.3f, \"gpu_seconds_warm\": %.4f, \"gpu_calls_warm\": %d, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
+           la, fs, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.bands, frameThreads, wpp, s.producerSeconds, s.producerSecondsWarm, s.callsWarm, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
     return 0;
 }
