@@ -676,8 +676,8 @@ def preset_exact_leg(name, pairs, args, headline_s_per_search):
     """The search a preset really asks for, in ONE run of the C++ host, on PRESET_F = 8 pictures: every list-0 reference of the preset (each down the pyramid with its own
     predictor chain), the rectangular PUs of every CU from preset slow on, the asymmetric ones from preset slower on (param.cpp:567-608), the per-PU choice among the
     references, TQ from the chosen reference.  `value` of the line stays the SURVEY 8(d) pipeline (85 PUs per CTU, one reference); this leg says what the preset's own
-    load costs next to it.  The size-specialised kernels address a reference's 16 phase planes with 32-bit byte offsets: an 8K batch holds 2 pictures, so the 8 pictures of
-    that workload are FOUR batches (own contexts, own streams) stepped together."""
+    load costs next to it.  The size-specialised kernels address a reference's 16 phase planes with 32-bit byte offsets; an 8K batch keeps its planes in groups of two
+    pictures for them (one batch, one context: `config.batches`)."""
     import torch
     import x265hip
     from x265hip_pkg.host_batch import HostBatch
@@ -686,7 +686,9 @@ def preset_exact_leg(name, pairs, args, headline_s_per_search):
     lib = x265hip.HipLib(depth, fill_table=False).lib
     F = len(pairs)
     per = F
-    while 16 * per * (W + 2 * MARGIN) * (H + 2 * MARGIN) * (1 if depth == 8 else 2) >= (1 << 32):
+    # r05: a batch whose 16-slot plane buffer outgrows the kernels' 32-bit byte offsets keeps its planes in groups of pictures by itself (csrc/xh_ctx.cpp, plane groups): ONE batch of
+    # 8 pictures also at 8K.  X265HIP_PE_SPLIT_BATCHES=1: round 4's form, separate batches of what fits (for A/B)
+    while os.environ.get("X265HIP_PE_SPLIT_BATCHES") == "1" and 16 * per * (W + 2 * MARGIN) * (H + 2 * MARGIN) * (1 if depth == 8 else 2) >= (1 << 32):
         per //= 2
     hbs = []
     try:

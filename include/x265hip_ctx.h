@@ -108,6 +108,10 @@ int   x265hip_batch_set_timing(x265hip_batch* batch, int on);
  *   (Flags 1, 2 and 8 -- the 16x16 / 8x8 [/ 32x32] levels fused into one launch, tiled phase planes -- were measured losses, profiles/r03_fused_ab.txt and r03_tiled_ab.txt,
  *   and are refused since round 5.) */
 #define X265HIP_BATCH_START64_LAUNCH 4
+#define X265HIP_BATCH_PLANE_GROUPS_OF_2 16      /* the phase planes in groups of two pictures (what a batch does by itself when its 16-slot plane buffer outgrows the kernels' 32-bit
+                                                   byte offsets -- 8K 10 bit beyond two pictures: each group keeps its 16 slots back to back, the kernels get a pointer biased by the
+                                                   group's first picture); same bytes: for tests of the grouping at small sizes.  x265hip_batch_device_ptr(.., 2 / 200 + r / 400 + r) hands
+                                                   out the allocation, whose layout is then per group */
 int   x265hip_batch_set_mode(x265hip_batch* batch, int flags);
 int   x265hip_batch_set_fused(x265hip_batch* batch, int flags);      /* the same call under its first name */
 int   x265hip_batch_stage_count(const x265hip_batch* batch);

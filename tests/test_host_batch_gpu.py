@@ -78,9 +78,11 @@ def test_streams_do_not_change_the_bytes_and_python_plumbing_agrees(depth):
     W, H, F, qp, merange, method, subme = 192, 128, 5, 30, 20, 3, 3
     pairs = pairs_for(W, H, depth, F, 2)
     ref_out = None
-    for streams, band in ((1, 0), (2, 0), (3, 0), (5, 0)):        # (band > 0, the band-major schedule, is a measured loss kept for experiment builds: profiles/r03_band_major_ab.txt)
+    # (mode 16: the phase planes in groups of two pictures -- 2 + 2 + 1 -- with two references, the rectangles, the choice among references and the TQ stage behind them)
+    for streams, band, mode in ((1, 0, 0), (2, 0, 0), (3, 0, 0), (5, 0, 0), (1, 0, 16), (2, 0, 16), (3, 0, 16)):
         hb = make(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, refs=2, rect=True, streams=streams, band_rows=band)
         try:
+            hb.set_fused(mode)
             hb.upload(pairs)
             hb.step(); hb.step(); hb.sync()                     # twice: a second pass over the resident planes gives the same bytes
             out = [hb.results(lv, r).tobytes() for lv in LEVELS for r in range(2)] + [hb.rect_results(w, h, r).tobytes() for (w, h) in sorted(hb.rect_host) for r in range(2)]
@@ -92,7 +94,7 @@ def test_streams_do_not_change_the_bytes_and_python_plumbing_agrees(depth):
         if ref_out is None:
             ref_out = out
         else:
-            assert out == ref_out, "%d streams / bands of %d rows change the results" % (streams, band)
+            assert out == ref_out, "%d streams / mode %d change the results" % (streams, mode)
     pipe = FramePipeline(depth, W, H, F, qp=qp, merange=merange, method=method, subme=subme, tu_log2=5, cost_row=mvcost_row(depth, qp, 1 << 15), refs=2)
     pipe.upload(pairs); pipe.step(); pipe.torch.cuda.synchronize()
     k = 0
@@ -143,8 +145,9 @@ def test_launch_forms_give_the_same_bytes_and_the_library_refuses_the_dropped_ex
         hb.close()
     with pytest.raises(RuntimeError):
         make(depth, W, H, F, qp=27, merange=57, method=3, subme=3, tu_log2=5, band_rows=2)
-    # (mode 4: the 64x64 level with its start-stage launch, the form of rounds 1-2)
-    for mode, streams in ((0, 1), (0, 2), (4, 1), (4, 2)):
+    # (mode 4: the 64x64 level with its start-stage launch, the form of rounds 1-2; mode 16: the phase planes in groups of two pictures -- what a batch does by itself when its
+    #  plane buffer outgrows the kernels' 32-bit offsets, 8K 10 bit beyond two pictures -- here 2 + 1 pictures)
+    for mode, streams in ((0, 1), (0, 2), (4, 1), (4, 2), (16, 1), (16, 2), (20, 2)):
         hb = make(depth, W, H, F, qp=27, merange=57, method=3, subme=3, tu_log2=5, streams=streams)
         try:
             hb.set_fused(mode)

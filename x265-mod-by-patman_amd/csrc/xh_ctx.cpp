@@ -66,6 +66,10 @@ struct x265hip_batch
     // context's stream holds at that moment -- its own previous pass included -- so sub-stream 1's pass k + 1 starts behind sub-stream 0's pass k; sub-stream 0 never
     // waits for sub-stream 1.)
     hipEvent_t evTok[8] = {}; bool tokSet[8] = {}; int pingpong = 0; bool unjoined = false;
+    // The size-specialised kernels address a 16-slot plane buffer with 32-bit byte offsets.  A batch whose buffer is larger than that (8K 10 bit: 1.14 GB per picture) is
+    // cut into GROUPS of groupFrames pictures: group g keeps its 16 slots back to back inside the one allocation (slots groupFrames * plane apart), and the pointer the
+    // kernels get is biased by the group's first picture, so that the tasks' absolute offsets (picture * plane + ...) address it unchanged.  0 = one group
+    int groupFrames = 0; bool groupsForced = false;
     bool ownStart64 = true;                  // STAR: the 64x64 level without its start-stage launch (kern_me_star.hip xh_me_star_own64); x265hip_batch_set_mode(X265HIP_BATCH_START64_LAUNCH) turns it off for A/B
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
@@ -272,6 +276,7 @@ extern "C" void x265hip_batch_destroy(x265hip_batch* b)
     delete b;
 }
 
+namespace { int choose_group_frames(const x265hip_batch* b, int forced); }
 extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* d, x265hip_batch** out)
 {
     if (!ctx || !out || !desc_ok(d)) { set_error("batch_create: bad arguments"); return X265HIP_EARG; }
@@ -290,9 +295,10 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
 #define XBH(call, what) do { if ((call) != hipSuccess) return fail(hip_fail(hipErrorUnknown, what)); } while (0)
     XBH(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming), "hipEventCreate");
     ctx->batches.push_back(b);
+    b->groupFrames = choose_group_frames(b, 0);
     if ((b->nsub == 2 || (b->nsub > 2 && xh_experiment("X265HIP_RING"))) && d->bandRows <= 0 && !xh_experiment("X265HIP_NO_PINGPONG"))
     {
-        b->pingpong = 1;
+        b->pingpong = 1;                                         // (a batch in plane groups steps every group as a sub-batch of its own and does not pass the token: step_group)
         for (int i = 0; i < b->nsub; i++) XBH(hipEventCreateWithFlags(&b->evTok[i], hipEventDisableTiming), "hipEventCreate");
     }
     for (int i = 0; i < b->nsub; i++)
@@ -376,16 +382,43 @@ extern "C" int x265hip_batch_upload_plane(x265hip_batch* b, int which, int frame
 }
 
 namespace {
-// the phase planes of pictures f0 .. f1 - 1 (every reference)
+inline int group_frames(const x265hip_batch* b) { return b->groupFrames > 0 ? b->groupFrames : b->d.frames; }
+// the end of the group that holds picture f (a range of pictures is cut at these)
+inline int group_end(const x265hip_batch* b, int f) { const int G = group_frames(b); return std::min(b->d.frames, (f / G + 1) * G); }
+// the 16-slot buffer of the group that holds picture f, as the kernels take it: planeElems = the distance of its slots; the pointer is biased by the group's first picture
+// (groups before it fill 16 * f0 * plane elements of the allocation; the tasks' offsets count pictures from the batch's first: - f0 * plane)
+inline pixel* group_planes(const x265hip_batch* b, int l, int r, int f, int64_t& planeElems)
+{
+    const int G = group_frames(b), f0 = f / G * G, n = std::min(G, b->d.frames - f0);
+    planeElems = (int64_t)n * b->plane;
+    return b->planes[l][r] ? b->planes[l][r] + (size_t)15 * f0 * b->plane : nullptr;
+}
+// largest group the 32-bit byte offsets reach: the last slot of a group ends at (16 * n + f0) * plane elements from the biased pointer
+int choose_group_frames(const x265hip_batch* b, int forced)
+{
+    const int F = b->d.frames;
+    auto fits = [&](int G) { return ((uint64_t)(16 * G + F) * (uint64_t)b->plane + 4096) * sizeof(pixel) < (1ull << 32); };
+    if (forced > 0) return forced < F ? forced : 0;
+    if (!b->d.usePlanes || fits(F)) return 0;
+    int G = F;
+    while (G > 1 && !fits(G)) G--;
+    if (!fits(G)) return 0;                                      // not even one picture: the generic kernels take the batch, as before
+    for (int g = G; g >= 1; g--)                                 // prefer a count of groups the sub-batches share evenly
+        if (((F + g - 1) / g) % b->nsub == 0 && F % g == 0) return g;
+    return G;
+}
+
+// the phase planes of pictures f0 .. f1 - 1 (every reference); the range lies inside one group
 int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
 {
     const x265hip_batch_desc& d = b->d;
-    const int64_t planeElems = b->plane * d.frames;                  // the 16 phase-plane slots are planeElems apart; a sub-batch addresses its pictures inside them
     const int rowsPerPic = d.height + 2 * d.margin;
     for (int l = 0; l < 2; l++)
         for (int r = 0; r < b->nref[l]; r++)
         {
-            const pixel* src = b->ref[l][r] + (size_t)f0 * b->plane; pixel* dst = b->planes[l][r] + (size_t)f0 * b->plane;
+            int64_t planeElems;                                          // the 16 phase-plane slots of the group are planeElems apart; a sub-batch addresses its pictures inside them
+            pixel* planes = group_planes(b, l, r, f0, planeElems);
+            const pixel* src = b->ref[l][r] + (size_t)f0 * b->plane; pixel* dst = planes + (size_t)f0 * b->plane;
             const int rc = x265hip_subpel_planes(st, src, b->stride, (f1 - f0) * rowsPerPic, dst, planeElems);
             if (rc != X265HIP_OK) return rc;
         }
@@ -395,11 +428,28 @@ int planes_range(x265hip_batch* b, int f0, int f1, hipStream_t st)
 // One sub-batch on stream st: the CTU rows g0 .. g1 - 1 of the batch, counted through the pictures (global row g = picture * ctuRows + row).  Tasks of every
 // shape are laid out picture-major, then raster: a range of global CTU rows is a contiguous range of every task list.  withPlanes: the range is whole pictures and
 // their phase planes are made first; ev != nullptr: events around every stage (2 per stage)
+int step_group(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev, int sub);
+// (whole pictures: cut at the plane groups; every piece is a sub-batch of its own on the same stream)
 int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev, int sub = -1)
 {
+    const int ctuRows = b->d.height / CTU;
+    if (group_frames(b) >= b->d.frames) return step_group(b, g0, g1, withPlanes, st, ev, sub);
+    for (int f = g0 / ctuRows; f < g1 / ctuRows;)
+    {
+        const int e = std::min(g1 / ctuRows, group_end(b, f));
+        const int rc = step_group(b, f * ctuRows, e * ctuRows, withPlanes, st, ev, sub);      // (per-stage events: the last piece's)
+        if (rc != X265HIP_OK) return rc;
+        f = e;
+    }
+    return X265HIP_OK;
+}
+int step_group(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st, hipEvent_t* ev, int sub)
+{
     const x265hip_batch_desc& d = b->d;
-    const int64_t planeElems = b->plane * d.frames;
     const int ctuRows = d.height / CTU;
+    int64_t planeElems = 0;
+    pixel* grpPlanes[2][X265HIP_MAX_REF] = {};                          // this group's plane buffers (biased pointers)
+    for (int l = 0; l < 2; l++) for (int r = 0; r < b->nref[l]; r++) grpPlanes[l][r] = group_planes(b, l, r, g0 / ctuRows, planeElems);
     const bool up = d.usePlanes != 0;
     int rc, stage = 0;
     auto mark = [&](int end) -> int { if (ev) XH_HIP(hipEventRecord(ev[2 * stage + end], st)); if (end) stage++; return X265HIP_OK; };
@@ -429,10 +479,10 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
                 const xh::KernelEvents* armed = nullptr;
                 if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && l == 0 && r == 0 && ev && b->starNow) { armed = b->starNow; b->starNow = nullptr; xh::tl_star64Events = armed; }
                 if (w == CTU && h == CTU && !parent && up && d.method == X265HIP_ME_STAR && b->ownStart64)       // the top level's own tasks: zero predictor, no candidates
-                    rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, b->planes[l][r], planeElems);
+                    rc = xh_me_star_own64(st, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.subme, out, grpPlanes[l][r], planeElems);
                 else
                     rc = x265hip_me_batch(st, w, h, b->cur, b->stride, b->ref[l][r], b->stride, tasks, n, b->costRow, kHalf, d.merange, d.method, d.subme, out, parent,
-                                          up ? b->planes[l][r] : nullptr, up ? planeElems : 0);
+                                          up ? grpPlanes[l][r] : nullptr, up ? planeElems : 0);
                 if (armed)
                 {
                     if (!xh::tl_star64Events && rc == X265HIP_OK) { b->starValid[armed - b->evStar.data()] = true; b->starSteps++; }
@@ -446,7 +496,7 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
             p.numRef[0] = b->nref[0]; p.numRef[1] = b->nref[1];
             for (int l = 0; l < 2; l++)
                 for (int r = 0; r < b->nref[l]; r++)
-                { p.results[l][r] = b->res[l][r][slot] + first; p.mvpSource[l][r] = parentSlot >= 0 ? b->res[l][r][parentSlot] : nullptr; p.subpelPlanes[l][r] = b->planes[l][r]; }
+                { p.results[l][r] = b->res[l][r][slot] + first; p.mvpSource[l][r] = parentSlot >= 0 ? b->res[l][r][parentSlot] : nullptr; p.subpelPlanes[l][r] = grpPlanes[l][r]; }
             p.planeElems = planeElems; p.bitsRow = b->bitsRow; p.bitsHalfRange = kBitsHalf; p.lambda = b->lambda; p.sourceMaxDim = d.width > d.height ? d.width : d.height;
             // the bidirectional candidate of a B picture exists for the PUs of a split CU -- not for 2Nx2N ("handled elsewhere": checkBidir2Nx2N belongs to the mode decision)
             // and not inside an 8x8 CU (CUData::isBipredRestriction): search.cpp:421-422
@@ -459,7 +509,7 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
     {
         const int lv = kLevels[i], per = (d.width / lv) * (CTU / lv);               // PUs of this level per CTU row
         if ((rc = mark(0))) return rc;
-        const bool token = b->pingpong && sub >= 0 && i == 0;
+        const bool token = b->pingpong && sub >= 0 && i == 0 && group_frames(b) >= d.frames;
         const int prev = (sub + b->nsub - 1) % b->nsub;                             // the token goes round the streams
         if (token && b->tokSet[prev]) XH_HIP(hipStreamWaitEvent(st, b->evTok[prev], 0));
         if ((rc = search(i, i ? i - 1 : -1, g0 * per, (g1 - g0) * per))) return rc;
@@ -493,7 +543,7 @@ int step_range(x265hip_batch* b, int g0, int g1, bool withPlanes, hipStream_t st
         for (int r = 0; r < b->nref[l]; r++)
         {   // one launch per reference plane: every TU is compensated from the reference its (2Nx2N) PU chose -- list 0 or list 1; a 2Nx2N PU has no bidirectional candidate here
             x265hip_tq_params p{};
-            p.qp = d.qp; p.add = 85; p.subpelPlanes = up ? b->planes[l][r] : nullptr; p.planeElems = up ? planeElems : 0;
+            p.qp = d.qp; p.add = 85; p.subpelPlanes = up ? grpPlanes[l][r] : nullptr; p.planeElems = up ? planeElems : 0;
             if (b->needChoice) { p.choice = b->choice[mi]; p.choiceList = l; p.choiceRef = r; }
             rc = x265hip_tq_batch
                                  (st, d.tuLog2, b->cur, b->stride, b->ref[l][r], b->stride, b->tu + t0, nt, &p, b->coeff + ((size_t)t0 << (2 * d.tuLog2)), b->numSig + t0,
@@ -596,6 +646,8 @@ extern "C" int x265hip_batch_set_fused(x265hip_batch* b, int on) { return x265hi
 extern "C" int x265hip_batch_set_mode(x265hip_batch* b, int on)
 {
     if (!b) return X265HIP_EARG;
+    if (on & X265HIP_BATCH_PLANE_GROUPS_OF_2) { b->groupFrames = choose_group_frames(b, 2); b->groupsForced = true; on &= ~X265HIP_BATCH_PLANE_GROUPS_OF_2; }
+    else if (b->groupsForced) { b->groupFrames = choose_group_frames(b, 0); b->groupsForced = false; }
     if (on & ~X265HIP_BATCH_START64_LAUNCH) { set_error("batch_set_mode: flags %d: the fused lower levels and the tiled phase planes were measured losses (profiles/r03_fused_ab.txt, r03_tiled_ab.txt) and left the library in round 5", on & ~X265HIP_BATCH_START64_LAUNCH); return X265HIP_EARG; }
     b->ownStart64 = !(on & 4);
     return X265HIP_OK;
