@@ -201,6 +201,30 @@ def test_preset_slow_search_at_4k_10bit_full_size():
         hb.close()
 
 
+def test_8k_batch_keeps_its_planes_in_groups_of_pictures():
+    """BASELINE configs[4]'s picture size with FOUR pictures in one batch: the 16-slot plane buffer (4.6 GB per reference) outgrows the 32-bit byte offsets of the size-specialised
+    kernels, so the batch keeps its planes in groups of two pictures (csrc/xh_ctx.cpp, plane groups) instead of falling back to the generic kernels.  PUs of every level and TUs
+    sampled over all four pictures equal the oracle's, and a second pass gives the same bytes."""
+    depth, W, H, F = 10, 7680, 4352, 4
+    hb = make(depth, W, H, F, qp=28, merange=128, method=3, subme=4, tu_log2=5, refs=1, rect=False, streams=2)
+    try:
+        hb.upload(pairs_for(W, H, depth, F, 1, seed0=1300))
+        hb.step(); hb.sync()
+        first = [hb.results(lv).tobytes() for lv in LEVELS]
+        co1, ns1 = hb.coeffs()
+        hb.step(); hb.sync()
+        assert first == [hb.results(lv).tobytes() for lv in LEVELS]
+        co2, ns2 = hb.coeffs()
+        assert np.array_equal(co1, co2) and np.array_equal(ns1, ns2)
+        n = check_host_batch(hb, Oracle(depth), np.random.default_rng(23), mvcost_row(depth, 28, 1 << 15), per_shape=24, n_tu=24)
+        assert n >= 4 * 24 + 24
+        # the samples must reach the second group (pictures 2 and 3)
+        per64 = (W // 64) * (H // 64)
+        assert len(hb.tasks_host[64]) == F * per64
+    finally:
+        hb.close()
+
+
 # ---- the headline configuration, EVERY PU and EVERY TU of whole 4K pictures against the oracle (the oracle on all host cores: forked workers over slices of the task lists) ----
 _FULL = {}
 

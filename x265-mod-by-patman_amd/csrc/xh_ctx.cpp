@@ -397,7 +397,8 @@ inline pixel* group_planes(const x265hip_batch* b, int l, int r, int f, int64_t&
 int choose_group_frames(const x265hip_batch* b, int forced)
 {
     const int F = b->d.frames;
-    auto fits = [&](int G) { return ((uint64_t)(16 * G + F) * (uint64_t)b->plane + 4096) * sizeof(pixel) < (1ull << 32); };
+    // (and a group's offsets -- its first picture's bias included -- stay below 16 x its slot distance, the bound the LDS-window load of the 32x32 kernel clamps to: f0 <= 15 n)
+    auto fits = [&](int G) { const int nLast = F % G ? F % G : G; return ((uint64_t)(16 * G + F) * (uint64_t)b->plane + 4096) * sizeof(pixel) < (1ull << 32) && F - nLast <= 15 * nLast; };
     if (forced > 0) return forced < F ? forced : 0;
     if (!b->d.usePlanes || fits(F)) return 0;
     int G = F;
