@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out; rm -f gpurun_out/fence_*.log
-tools/r05_ft_debug.sh > /dev/null 2>&1
+profiles/r05_ft_debug.sh > /dev/null 2>&1
 grep -E "^####|^==|hevc" gpurun_out/r05_ft_debug.txt | cut -c1-150
 ( time timeout 900 python -m pytest tests/test_tme_producer_gpu.py tests/test_e2e_tme_gpu.py -m gpu -q -s -p no:cacheprovider --timeout=240 -k "frame_threads or bands" ) > gpurun_out/r05_tme_bands.txt 2>&1
 tail -n 25 gpurun_out/r05_tme_bands.txt | cut -c1-300
