@@ -29,6 +29,12 @@ def main():
               (best[0], best[1], best[2], best[3], best[5], best[4], best[6], "end" if best[6] >= 0 else "start"))
     else:
         print("address is in no fenced block's guard (a wild pointer)")
+        near = []
+        for a in re.finditer(r"\[fence\] alloc #(\d+) (0x[0-9a-f]+)\.\.(0x[0-9a-f]+) \((\d+) B\) mapped (0x[0-9a-f]+)\.\.(0x[0-9a-f]+) tag (.*)", log):
+            lo, hi = int(a.group(2), 16), int(a.group(3), 16)
+            near.append((min(abs(addr - lo), abs(addr - hi)), a.group(1), lo, hi, int(a.group(4)), a.group(7)))
+        for dist, idx, lo, hi, size, tag in sorted(near)[:4]:
+            print("  nearest: block #%s %#x..%#x (%d bytes, %s): %+d bytes from its %s" % (idx, lo, hi, size, tag, addr - hi if addr >= hi else addr - lo, "end" if addr >= hi else "start"))
     for line in (err + log).splitlines():
         if line.startswith("[fence] launch #"):
             print(line)

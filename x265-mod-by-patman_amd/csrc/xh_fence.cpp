@@ -31,6 +31,7 @@ constexpr int kRing = 32;
 Note g_ring[kRing];
 std::atomic<unsigned> g_ringAt{0};
 
+void (*g_prevAbort)(int) = nullptr;
 void on_abort(int)
 {
     char buf[256];
@@ -41,8 +42,9 @@ void on_abort(int)
         const int len = snprintf(buf, sizeof(buf), "[fence] launch #%u %s:%d%s\n", i, n.file ? n.file : "?", n.line, i + 1 == at ? "   <-- last" : "");
         if (len > 0) { (void)!write(2, buf, (size_t)len); if (g_log && g_log != stderr) (void)!write(fileno(g_log), buf, (size_t)len); }
     }
-    signal(SIGABRT, SIG_DFL);
-    abort();
+    // (several copies of this file may live in one process -- the 8-bit and the 16-bit library, the tests' torch allocator shim: each prints its own launches, then hands on)
+    signal(SIGABRT, (g_prevAbort && g_prevAbort != SIG_IGN) ? g_prevAbort : SIG_DFL);
+    raise(SIGABRT);
 }
 
 FILE* log_file()
@@ -56,7 +58,7 @@ FILE* log_file()
     g_startMode = m && !strcmp(m, "start");
     if (const char* a = getenv("X265HIP_FENCE_ALIGN")) { const long v = atol(a); if (v >= 1 && v <= 4096 && !(v & (v - 1))) g_align = (size_t)v; }
     if (const char* y = getenv("X265HIP_FENCE_SYNC")) g_sync = atoi(y) != 0;
-    signal(SIGABRT, on_abort);
+    g_prevAbort = signal(SIGABRT, on_abort);
     fprintf(g_log, "[fence] pid %d mode %s align %zu sync %d\n", (int)getpid(), g_startMode ? "start" : "end", g_align, (int)g_sync);
     return g_log;
 }
