@@ -40,7 +40,7 @@ template<int K> __device__ __forceinline__ void cost_points(const DCtx& c, const
 
 __global__ __launch_bounds__(256) void diamond_kernel(int w, int h, const pixel* __restrict__ cur, intptr_t cs, const pixel* __restrict__ ref, intptr_t rs,
                                                       const x265hip_me_task* __restrict__ tasks, int n, const uint16_t* __restrict__ costCentre, int chr,
-                                                      x265hip_me_result* __restrict__ results)
+                                                      x265hip_me_result* __restrict__ results, int64_t rowStride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, item = blockIdx.x * 4 + wave;
@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void diamond_kernel(int w, int h, const pixel*
     lpixel* fenc = (lpixel*)smem + wave * w * h;
     const x265hip_me_task tk = tasks[item];
     DCtx c; c.fenc = fenc; c.ref = ref + tk.refOff; c.rs = rs; c.w = w; c.h = h; c.qpr = w >> 2; c.nquads = (w >> 2) * h; c.lane = lane;
-    c.centre = costCentre; c.chr = chr; c.mvpx = tk.qmvp[0]; c.mvpy = tk.qmvp[1];
+    // rowStride != 0: costCentre is row 0 of a table of MVD cost rows, rowStride entries apart, and the task names its row in mvpFrom (PUs of different qp in one launch:
+    // the ThreadedME producer's first stage, xh_tme.cpp)
+    c.centre = costCentre + (rowStride ? (int64_t)tk.mvpFrom * rowStride : 0); c.chr = chr; c.mvpx = tk.qmvp[0]; c.mvpy = tk.qmvp[1];
     for (int q = lane; q < c.nquads; q += 64)
     {
         const int y = q / c.qpr, x4 = (q - y * c.qpr) * 4;
@@ -156,7 +158,20 @@ extern "C" int x265hip_diamond_batch(void* stream, int w, int h, const void* cur
     if (!curPlane || !refPlane || !tasks || !costRow || !results || w < 4 || h < 4 || w > 64 || h > 64 || (w & 3) || costHalfRange < 1) return X265HIP_EARG;
     const size_t lds = 4 * (size_t)w * h * sizeof(pixel);
     XH_KLAUNCH(diamond_kernel, dim3((n + 3) / 4), dim3(256), lds, (hipStream_t)stream, w, h, (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride,
-                       tasks, n, costRow + costHalfRange, costHalfRange, results);
+                       tasks, n, costRow + costHalfRange, costHalfRange, results, (int64_t)0);
+    XH_LAUNCH_CHECK();
+    return X265HIP_OK;
+}
+
+// the same with an MVD cost row PER TASK: costTable = rows of 2 * costHalfRange + 1 entries, tasks[i].mvpFrom = the row of task i (internal: x265hip_tme_picture)
+int xh_diamond_rows(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                    const x265hip_me_task* tasks, int n, const uint16_t* costTable, int costHalfRange, x265hip_me_result* results)
+{
+    if (n <= 0) return X265HIP_OK;
+    if (!curPlane || !refPlane || !tasks || !costTable || !results || w < 4 || h < 4 || w > 64 || h > 64 || (w & 3) || costHalfRange < 1) return X265HIP_EARG;
+    const size_t lds = 4 * (size_t)w * h * sizeof(pixel);
+    XH_KLAUNCH(diamond_kernel, dim3((n + 3) / 4), dim3(256), lds, (hipStream_t)stream, w, h, (const pixel*)curPlane, curStride, (const pixel*)refPlane, refStride,
+                       tasks, n, costTable + costHalfRange, costHalfRange, results, (int64_t)(2 * costHalfRange + 1));
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

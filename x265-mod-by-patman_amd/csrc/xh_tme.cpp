@@ -103,6 +103,8 @@ extern "C" int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int am
 #include <cstdlib>
 using namespace xh;
 
+int xh_diamond_rows(void* stream, int w, int h, const void* curPlane, intptr_t curStride, const void* refPlane, intptr_t refStride,
+                    const x265hip_me_task* tasks, int n, const uint16_t* costTable, int costHalfRange, x265hip_me_result* results);      // kern_diamond.hip
 int xh_tme_area(void* stream, const x265hip_me_result* res, const int32_t* where, int nTasks, int nl, int numRef0, int numRef1, const int16_t* median, int16_t* areaBest);      // kern_tme.hip
 int xh_tme_slots(void* stream, x265hip_inter_choice* table, x265hip_inter_choice* packed, const int32_t* slots, int nUsed, int nCtu, int toTable);      // kern_tme.hip
 
@@ -335,30 +337,30 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     // (reference, group) is a launch into its own part of the result array, and m_areaBestMV is assembled on the device -- no round trip inside the picture.
     std::vector<x265hip_me_task>& tasks = t->hTasks; std::vector<int32_t>& where = t->hWhere;
     tasks.clear(); where.clear();
-    struct Group { int size, q, first, n; };
+    // (r05: a launch per CU size and reference -- the task names its qp's row of the cost table, xh_diamond_rows -- instead of one per (size, qp, reference): AQ / cuTree
+    //  give a picture a dozen qps and more, and the launches were a millisecond of every call)
+    struct Group { int size, first, n; };
     std::vector<Group> groups;
     for (int size = t->ctu; size >= t->ctu / 2; size >>= 1)
-        for (int q = 0; q < d->nQp; q++)
-        {
-            const int first = (int)tasks.size();
-            for (int c = c0; c < c0 + nCtu; c++)
-                for (int a = (size == t->ctu ? 0 : 1); a < (size == t->ctu ? 1 : 5); a++)
-                {
-                    if (d->areaQpIndex[c * 5 + a] != q) continue;
-                    const int cx = (c % t->nCtuX) * t->ctu + (a ? ((a - 1) & 1) * size : 0), cy = (c / t->nCtuX) * t->ctu + (a ? ((a - 1) >> 1) * size : 0);
-                    x265hip_me_task k{};
-                    k.curOff = k.refOff = (int32_t)(d->origin + (int64_t)cy * d->stride + cx);
-                    // Search::setSearchRange(cu, MV(0,0), 32) >> 2 (search.cpp:4969-5021) with CUData::clipMv's limits of this CU
-                    const int xmin = -((t->ctu + 8 + cx - 1) << 2), ymin = -((t->ctu + 8 + cy - 1) << 2), xmax = (d->width + 8 - cx - 1) << 2, ymax = (d->height + 8 - cy - 1) << 2;
-                    const int dd = 32 << 2;
-                    k.mvmin[0] = (int16_t)(std::min(xmax, std::max(xmin, -dd)) >> 2); k.mvmin[1] = (int16_t)(std::min(ymax, std::max(ymin, -dd)) >> 2);
-                    k.mvmin[1] = (int16_t)std::min((int)k.mvmin[1], refLag);                                  // m_refLagPixels on both ends (search.cpp:5017-5018)
-                    k.mvmax[0] = (int16_t)(std::min(xmax, std::max(xmin, dd)) >> 2); k.mvmax[1] = (int16_t)(std::max(std::min(std::min(ymax, std::max(ymin, dd)) >> 2, refLag), (int)k.mvmin[1]));
-                    k.mvpFrom = -1;
-                    tasks.push_back(k); where.push_back(c * 5 + a);
-                }
-            if ((int)tasks.size() > first) groups.push_back(Group{ size, q, first, (int)tasks.size() - first });
-        }
+    {
+        const int first = (int)tasks.size();
+        for (int c = c0; c < c0 + nCtu; c++)
+            for (int a = (size == t->ctu ? 0 : 1); a < (size == t->ctu ? 1 : 5); a++)
+            {
+                const int cx = (c % t->nCtuX) * t->ctu + (a ? ((a - 1) & 1) * size : 0), cy = (c / t->nCtuX) * t->ctu + (a ? ((a - 1) >> 1) * size : 0);
+                x265hip_me_task k{};
+                k.curOff = k.refOff = (int32_t)(d->origin + (int64_t)cy * d->stride + cx);
+                // Search::setSearchRange(cu, MV(0,0), 32) >> 2 (search.cpp:4969-5021) with CUData::clipMv's limits of this CU
+                const int xmin = -((t->ctu + 8 + cx - 1) << 2), ymin = -((t->ctu + 8 + cy - 1) << 2), xmax = (d->width + 8 - cx - 1) << 2, ymax = (d->height + 8 - cy - 1) << 2;
+                const int dd = 32 << 2;
+                k.mvmin[0] = (int16_t)(std::min(xmax, std::max(xmin, -dd)) >> 2); k.mvmin[1] = (int16_t)(std::min(ymax, std::max(ymin, -dd)) >> 2);
+                k.mvmin[1] = (int16_t)std::min((int)k.mvmin[1], refLag);                                  // m_refLagPixels on both ends (search.cpp:5017-5018)
+                k.mvmax[0] = (int16_t)(std::min(xmax, std::max(xmin, dd)) >> 2); k.mvmax[1] = (int16_t)(std::max(std::min(std::min(ymax, std::max(ymin, dd)) >> 2, refLag), (int)k.mvmin[1]));
+                k.mvpFrom = d->areaQpIndex[c * 5 + a];                                                    // the row of costTable (the order of desc->qps)
+                tasks.push_back(k); where.push_back(c * 5 + a);
+            }
+        if ((int)tasks.size() > first) groups.push_back(Group{ size, first, (int)tasks.size() - first });
+    }
     const int nTasks = (int)tasks.size();                                                 // nCtu * 5
     XH_HIP(hipMemcpyAsync(t->dTasks, tasks.data(), (size_t)nTasks * sizeof(x265hip_me_task), hipMemcpyHostToDevice, st));
     XH_HIP(hipMemcpyAsync(t->dWhere, where.data(), (size_t)nTasks * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -368,8 +370,8 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     for (int l = 0; l < nl; l++)
         for (int r = 0; r < d->numRef[l]; r++)
             for (const Group& g : groups)
-                if ((rc = x265hip_diamond_batch(st, g.size, g.size, t->cur, d->stride, t->plane[l][r][0], d->stride, t->dTasks + g.first, g.n, t->costRows[d->qps[g.q]], kHalf,
-                                                t->dResults + (size_t)(l * X265HIP_MAX_REF + r) * nTasks + g.first))) return rc;
+                if ((rc = xh_diamond_rows(st, g.size, g.size, t->cur, d->stride, t->plane[l][r][0], d->stride, t->dTasks + g.first, g.n, t->costTable, kHalf,
+                                          t->dResults + (size_t)(l * X265HIP_MAX_REF + r) * nTasks + g.first))) return rc;
     if ((rc = xh_tme_area(st, t->dResults, t->dWhere, nTasks, nl, d->numRef[0], d->isP ? 0 : d->numRef[1], d->median ? t->dMedian : nullptr, t->areaBest))) return rc;
     if ((rc = table_up(t->table, d->table))) return rc;
     XH_HIP(hipMemcpyAsync(t->temporal + (size_t)c0 * nS * 2, d->temporal + (size_t)c0 * nS * 2, (size_t)nCtu * nS * 2 * sizeof(x265hip_tme_temporal), hipMemcpyHostToDevice, st));
