@@ -75,6 +75,11 @@ struct PicState { int poc1 = 0, rowsDone = 0; };      /* POC + 1 of the picture 
 std::map<const Frame*, PicState> g_pics;
 int g_bands;                                 /* jobs (bands of CTU rows) run; == g_pictures with one frame thread */
 int g_trace;                                 /* X265TME_TRACE=1: a line per job on stderr (where a stalled encode stands) */
+/* Frame threads: a band that would hold fewer than g_minRows rows (0 = half the picture's CTU rows) waits up to g_waitUs for the references to release another row.  A producer call costs the host a job set-up, a harvest and three
+   rounds of wake-ups whatever it holds, and the row that asked cannot start before the rows above it have anyway: fewer, larger calls.  Measured at 1080p medium, five frame
+   threads, WPP (profiles/r05_min_rows_ab.txt, five runs each): no wait 7.0 fps, 4 rows / 6 ms 7.9, 6 / 10 8.25, 8 / 16 8.4, 12 / 30 8.3 -- the encoder without --threaded-me 8.0.
+   X265TME_MIN_ROWS / X265TME_WAIT_US override (1 / 0: every ready row at once, the first form) */
+int g_minRows = 0, g_waitUs = 16000;
 int g_waitRefs;                              /* X265TME_WAIT_REFS=1 (diagnosis; unweighted references only): a picture waits for its references to be complete and goes through the
                                                 producer whole -- separates the frame-parallel window rules from the band protocol */
 
@@ -430,6 +435,18 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         if (!s_job)
         {   /* a new band: from the first row without records to the last one whose reference rows are final (one frame thread: the whole picture) */
             int row1 = Job::ready_rows(*this, row, nCtuY);
+            const int minRows = g_minRows > 0 ? g_minRows : (nCtuY + 1) / 2;
+            if (minRows > 1 && g_waitUs > 0 && m_param->frameNumThreads > 1 && row1 < nCtuY && row1 - ps.rowsDone < minRows)
+            {   /* few rows are ready: give the references a moment to release more (the lock is open meanwhile; whoever comes back first opens the job) */
+                const int have = row1;
+                lk.unlock();
+                const double tw = now();
+                while ((now() - tw) * 1e6 < g_waitUs && Job::ready_rows(*this, row, nCtuY) == have) std::this_thread::sleep_for(std::chrono::microseconds(150));
+                lk.lock();
+                PicState& ps2 = g_pics[&frame];
+                if (ps2.poc1 != poc + 1 || row < ps2.rowsDone || s_job) continue;       /* somebody else got there: look again */
+                row1 = Job::ready_rows(*this, row, nCtuY);
+            }
             if (g_waitRefs && row1 < nCtuY)
             {
                 lk.unlock();
@@ -517,6 +534,8 @@ extern "C" int x265hip_tme_adapter_load(const char* libraryPath, int device)
     if (getenv("X265TME_NOKEEP")) g_keepPlanes = 0;
     g_trace = getenv("X265TME_TRACE") && atoi(getenv("X265TME_TRACE"));
     g_waitRefs = getenv("X265TME_WAIT_REFS") && atoi(getenv("X265TME_WAIT_REFS"));
+    if (getenv("X265TME_MIN_ROWS")) g_minRows = atoi(getenv("X265TME_MIN_ROWS"));
+    if (getenv("X265TME_WAIT_US")) g_waitUs = atoi(getenv("X265TME_WAIT_US"));
     g_lanes = getenv("X265TME_LANES") ? atoi(getenv("X265TME_LANES")) : 1;      /* measured: 2, 4, 8 lanes are no faster than 1 (profiles/r05_m2_lanes.txt) */
     if (g_lanes < 1) g_lanes = 1;
     if (g_lanes > kMaxLanes) g_lanes = kMaxLanes;
