@@ -80,6 +80,10 @@ int g_trace;                                 /* X265TME_TRACE=1: a line per job 
    threads, WPP (profiles/r05_min_rows_ab.txt, five runs each): no wait 7.0 fps, 4 rows / 6 ms 7.9, 6 / 10 8.25, 8 / 16 8.4, 12 / 30 8.3 -- the encoder without --threaded-me 8.0.
    X265TME_MIN_ROWS / X265TME_WAIT_US override (1 / 0: every ready row at once, the first form) */
 int g_minRows = 0, g_waitUs = 16000;
+int g_oneQueue;
+int g_help = -1;                             /* workers that arrive for a running band take CTUs of its host passes: -1 = with one frame thread only (there the ThreadedME workers have
+                                                nothing else to do and the picture's harvest is 8 ms on one of them); with frame threads they sleep until the job ends -- waking them
+                                                for a band's millisecond of host work costs more than it gives (profiles/r05_queues_ab.txt: 9.40 -> 9.74 fps).  X265TME_HELP=0 / 1 override */
 int g_waitRefs;                              /* X265TME_WAIT_REFS=1 (diagnosis; unweighted references only): a picture waits for its references to be complete and goes through the
                                                 producer whole -- separates the frame-parallel window rules from the band protocol */
 
@@ -414,7 +418,11 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         }
     };
     static Job* s_jobs[kMaxLanes] = {};
-    static std::condition_variable s_cv;
+    /* two queues: s_cv -- workers whose band is not the running job's (another picture, a later band) sleep until a job ENDS; s_cvJob -- the running job's own helpers and its
+       leader follow its phases.  (One queue for both woke every waiting ThreadedME worker three times per band: with a hundred pool threads on a host that grants them 16 CPUs
+       that is scheduling work of its own) */
+    static std::condition_variable s_cv, s_cvJobOwn;
+    std::condition_variable& s_cvJob = g_oneQueue ? s_cv : s_cvJobOwn;      /* X265TME_ONE_QUEUE=1: the first form, for A/B */
 
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::unique_lock<std::mutex> lk(g_lock);
@@ -431,7 +439,12 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         PicState& ps = g_pics[&frame];
         if (ps.poc1 != poc + 1) { ps.poc1 = poc + 1; ps.rowsDone = 0; }       /* the Frame object holds a new picture */
         if (row < ps.rowsDone) return;                                        /* this CTU's records are there already */
-        if (s_job && s_job->frame == &frame && s_job->poc == poc && row >= s_job->row0 && row < s_job->row1) break;      /* the band's job is running: help */
+        if (s_job && s_job->frame == &frame && s_job->poc == poc && row >= s_job->row0 && row < s_job->row1)
+        {
+            if (g_help > 0 || (g_help < 0 && m_param->frameNumThreads <= 1)) break;      /* the band's job is running: help */
+            s_cv.wait(lk);                                                    /* sleep until it ends */
+            continue;
+        }
         if (!s_job)
         {   /* a new band: from the first row without records to the last one whose reference rows are final (one frame thread: the whole picture) */
             int row1 = Job::ready_rows(*this, row, nCtuY);
@@ -489,12 +502,12 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         if (job->failed.load() || job->call()) exit(3);
         tBack = now();                                                        /* write-back wall time, closed below */
         lk.lock(); job->phase = 2; lk.unlock();
-        s_cv.notify_all();
+        s_cvJob.notify_all();
     }
     else
     {
         lk.lock();
-        while (job->phase < 2) s_cv.wait(lk);
+        while (job->phase < 2) s_cvJob.wait(lk);
         lk.unlock();
     }
     for (;;)
@@ -515,16 +528,16 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         if (job->row1 == nCtuY) g_pictures++;
         g_pictureSeconds += now() - tStart;
         job->phase = 3;
-        s_cv.notify_all();
-        while (job->users > 1) s_cv.wait(lk);                                 /* every helper has left the job */
+        s_cvJob.notify_all();
+        while (job->users > 1) s_cvJob.wait(lk);                              /* every helper has left the job */
         s_job = nullptr;
         s_cv.notify_all();
     }
     else
     {
-        while (job->phase < 3) s_cv.wait(lk);
+        while (job->phase < 3) s_cvJob.wait(lk);
         job->users--;
-        s_cv.notify_all();
+        s_cvJob.notify_all();
     }
 }
 }
@@ -534,6 +547,8 @@ extern "C" int x265hip_tme_adapter_load(const char* libraryPath, int device)
     if (getenv("X265TME_NOKEEP")) g_keepPlanes = 0;
     g_trace = getenv("X265TME_TRACE") && atoi(getenv("X265TME_TRACE"));
     g_waitRefs = getenv("X265TME_WAIT_REFS") && atoi(getenv("X265TME_WAIT_REFS"));
+    if (getenv("X265TME_HELP")) g_help = atoi(getenv("X265TME_HELP"));
+    g_oneQueue = getenv("X265TME_ONE_QUEUE") && atoi(getenv("X265TME_ONE_QUEUE"));
     if (getenv("X265TME_MIN_ROWS")) g_minRows = atoi(getenv("X265TME_MIN_ROWS"));
     if (getenv("X265TME_WAIT_US")) g_waitUs = atoi(getenv("X265TME_WAIT_US"));
     g_lanes = getenv("X265TME_LANES") ? atoi(getenv("X265TME_LANES")) : 1;      /* measured: 2, 4, 8 lanes are no faster than 1 (profiles/r05_m2_lanes.txt) */
