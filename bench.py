@@ -277,7 +277,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
             dt["verdict"] = ("with --threaded-me: GPU producers %.2f fps vs the encoder's own producers %.2f fps (%.2fx), same bitstream.  The encoder WITHOUT --threaded-me does %.2f fps: "
                              "the GPU producers are %s than not using ThreadedME at all (%.2fx).  A picture's CTU rows reach the producer in bands as its references' rows become final; a band that "
                              "would hold fewer than half the picture's rows waits up to 16 ms for another row -- a producer call is as long as one CTU's chain of searches whatever it holds and "
-                             "costs the host a job set-up and three rounds of wake-ups (profiles/r05_min_rows_ab.txt: 7.0 fps without the wait, 8.4 with it).  The lookahead seam alone (no "
+                             "costs the host a job set-up and its wake-ups (profiles/r05_min_rows_ab.txt: 7.0 fps without the wait, 8.4 with it; r05_queues_ab.txt: the waiting workers on two queues, no helpers under frame threads: ~9.8).  The lookahead seam alone (no "
                              "--threaded-me, the plain encoder's bitstream) does %s fps; the in-loop filters stay the encoder's own under frame threads.  RDO and entropy coding on the host bound the encode"
                              % (b["fps"], a["fps"], b["fps"] / a["fps"], p0["fps"], "FASTER" if b["fps"] > p0["fps"] else "SLOWER", b["fps"] / p0["fps"], ("%.2f" % l0["fps"]) if l0 else "n/a"))
         out["default_threading"] = dt
