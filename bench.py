@@ -267,7 +267,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
               "bitstream_identical_gpu_vs_cpu_producers": bool(a and b and a["md5"] == b["md5"] and a["bytes"] == b["bytes"] and b["md5_all_equal"]), "host": usable_cores()[1]}
         dt["encoder_clocks_ms_per_picture"] = {k: v.get("frame_stats_ms_per_picture") for k, v in ok.items() if v.get("frame_stats_ms_per_picture")}
         if b:
-            dt["gpu_run"] = {"tme_lanes": int(os.environ.get("X265TME_LANES", "1")), "tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
+            dt["gpu_run"] = {"tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
                              "tme_adapter_seconds": b["adapter_seconds"], "la_estimates": b.get("la_estimates"), "la_producer_seconds": b.get("la_producer_seconds"),
                              "filter_pictures_gpu": b.get("ff_pictures"), "filter_pictures_left_to_the_cpu": b.get("ff_cpu_pictures"), "seconds": b["seconds"]}
         p0, l0 = ok.get("cpu_default_threading"), ok.get("gpu_lookahead_default_threading")

@@ -55,14 +55,10 @@ struct Api
     const char* (*last_error)();
 } g_api;
 void* g_lib;
-/* Producers ("lanes"): a job -- a band of CTU rows of one picture -- runs on the lane of its picture (encode order modulo the lane count), one job per lane at a time.
-   ONE lane by default.  X265TME_LANES=2..8 gives the pictures in flight their own producers (context, stream, kept planes), so that a band does not queue behind the bands
-   of other pictures -- measured at 1080p medium with five frame threads: no faster (profiles/r05_m2_lanes.txt: the producer calls of different threads slow each other down in
-   the HIP runtime, 2.0 -> 4.3 s of producer time per 48 frames, what DESIGN 8.1 found for four producer threads in round 2).  Bitstreams are the same with any count. */
-constexpr int kMaxLanes = 8;
-int g_lanes = 1;
-x265hip_ctx* g_ctx[kMaxLanes];
-x265hip_tme* g_tme[kMaxLanes];
+/* ONE producer: jobs -- bands of CTU rows, of whatever picture -- take turns on it.  (A producer per picture in flight was built and measured in round 5: no faster, the
+   producer calls of different host threads slow each other down in the HIP runtime -- profiles/r05_m2_lanes.txt.) */
+x265hip_ctx* g_ctx;
+x265hip_tme* g_tme;
 int g_useGpu, g_device, g_pictures, g_weighted, g_keepPlanes = 1;
 double g_sec[4];      /* per encode: [0] job set-up seconds (incl. creating the producer on the first picture), [1] wall seconds up to the producer call (set-up + harvest: qps,
                          collocated neighbours, medians, table conversions -- spread over the workers), [2] CTUs harvested by workers other than the leader, [3] write-back seconds */
@@ -80,7 +76,6 @@ int g_trace;                                 /* X265TME_TRACE=1: a line per job 
    threads, WPP (profiles/r05_min_rows_ab.txt, five runs each): no wait 7.0 fps, 4 rows / 6 ms 7.9, 6 / 10 8.25, 8 / 16 8.4, 12 / 30 8.3 -- the encoder without --threaded-me 8.0.
    X265TME_MIN_ROWS / X265TME_WAIT_US override (1 / 0: every ready row at once, the first form) */
 int g_minRows = 0, g_waitUs = 16000;
-int g_oneQueue;
 int g_help = -1;                             /* workers that arrive for a running band take CTUs of its host passes: -1 = with one frame thread only (there the ThreadedME workers have
                                                 nothing else to do and the picture's harvest is 8 ms on one of them); with frame threads they sleep until the job ends -- waking them
                                                 for a band's millisecond of host work costs more than it gives (profiles/r05_queues_ab.txt: 9.40 -> 9.74 fps).  X265TME_HELP=0 / 1 override */
@@ -185,7 +180,6 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     {
         Frame* frame; int poc, nCtu, nCtuX, nCtuY, nS, nl;
         int row0 = 0, row1 = 0, c0 = 0, c1 = 0;                    /* the band: CTU rows [row0, row1) = CTUs [c0, c1) of the picture */
-        int lane = 0;
         const x265hip_tme_step* steps;
         std::vector<int> used;                                     /* the MEData slots of a CTU the schedule writes (and reads) */
         std::vector<int> sliceOfRow;
@@ -231,27 +225,26 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             return r;
         }
 
-        static Job* create(Analysis& an, Frame& frame, int row0, int row1, int lane)
+        static Job* create(Analysis& an, Frame& frame, int row0, int row1)
         {
             const Slice* slice = an.m_slice;
             const x265_param* p = an.m_param;
             const int W = slice->m_sps->picWidthInLumaSamples, H = slice->m_sps->picHeightInLumaSamples, ctuSize = p->maxCUSize;
-            if (!g_tme[lane])
+            if (!g_tme)
             {
                 const auto t0 = std::chrono::steady_clock::now();
-                if (g_api.ctx_create(g_device, &g_ctx[lane]) || g_api.tme_create(g_ctx[lane], W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme[lane]))
+                if (g_api.ctx_create(g_device, &g_ctx) || g_api.tme_create(g_ctx, W, H, ctuSize, p->minCUSize, p->bEnableRectInter, p->bEnableAMP, &g_tme))
                 { fprintf(stderr, "x265hip_tme_create: %s\n", g_api.last_error()); return nullptr; }
                 g_createSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             }
             /* the job's arrays are kept from picture to picture: fresh 10 MB vectors per picture cost more in page faults than the work on them */
-            static Job storage[kMaxLanes];
-            Job* j = &storage[lane];
-            j->lane = lane;
+            static Job storage;
+            Job* j = &storage;
             j->nextA = 0; j->doneA = 0; j->nextB = 0; j->doneB = 0; j->failed = 0; j->helped = 0; j->phase = 0; j->users = 0;
             j->used.clear(); j->refSrc.clear(); j->nRefTables = 0; j->nLowres = 0;
             j->frame = &frame; j->poc = slice->m_poc;
             j->nCtuX = slice->m_sps->numCuInWidth; j->nCtuY = slice->m_sps->numCuInHeight; j->nCtu = j->nCtuX * j->nCtuY;
-            j->nS = g_api.tme_entries(g_tme[lane], &j->steps);
+            j->nS = g_api.tme_entries(g_tme, &j->steps);
             j->nl = slice->isInterP() ? 1 : 2;
             j->row0 = row0; j->row1 = row1; j->c0 = row0 * j->nCtuX; j->c1 = row1 * j->nCtuX;
             const int nCtu = j->nCtu, nS = j->nS, nl = j->nl;
@@ -402,12 +395,12 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             d.qpIndex = qpIndex.data(); d.areaQpIndex = areaQpIndex.data(); d.temporal = temporal.data(); d.median = median.data(); d.table = table.data();
             if (row0 > 0 || row1 < nCtuY) { d.ctuRowFirst = row0; d.ctuRowCount = row1 - row0; }
             const auto t0 = std::chrono::steady_clock::now();
-            const int rc = g_api.tme_picture(g_tme[lane], &d);
+            const int rc = g_api.tme_picture(g_tme, &d);
             if (rc) { fprintf(stderr, "x265hip_tme_picture (POC %d, %s slice, refs %d / %d): %d %s\n", poc, d.isP ? "P" : "B", d.numRef[0], d.numRef[1], rc, g_api.last_error()); return -1; }
             const double dtCall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::lock_guard<std::mutex> sg(g_statLock);
             g_gpuSeconds += dtCall;
-            if (++g_calls > 4 * g_lanes) { g_gpuSecondsWarm += dtCall; g_callsWarm++; }
+            if (++g_calls > 4) { g_gpuSecondsWarm += dtCall; g_callsWarm++; }
             return 0;
         }
 
@@ -417,12 +410,11 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             for (int sl : used) from_choice(table[(size_t)c * 593 + sl], dst[(size_t)c * 593 + sl]);
         }
     };
-    static Job* s_jobs[kMaxLanes] = {};
+    static Job* s_job = nullptr;
     /* two queues: s_cv -- workers whose band is not the running job's (another picture, a later band) sleep until a job ENDS; s_cvJob -- the running job's own helpers and its
        leader follow its phases.  (One queue for both woke every waiting ThreadedME worker three times per band: with a hundred pool threads on a host that grants them 16 CPUs
        that is scheduling work of its own) */
-    static std::condition_variable s_cv, s_cvJobOwn;
-    std::condition_variable& s_cvJob = g_oneQueue ? s_cv : s_cvJobOwn;      /* X265TME_ONE_QUEUE=1: the first form, for A/B */
+    static std::condition_variable s_cv, s_cvJob;
 
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::unique_lock<std::mutex> lk(g_lock);
@@ -431,9 +423,6 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     const int nCtuX = m_slice->m_sps->numCuInWidth, nCtuY = m_slice->m_sps->numCuInHeight, row = (int)ctu.m_cuAddr / nCtuX;
     bool leader = false;
     const double tStart = now();
-    if (m_param->frameNumThreads <= 1) g_lanes = 1;
-    const int lane = (int)((unsigned)frame.m_encodeOrder % (unsigned)g_lanes);
-    Job*& s_job = s_jobs[lane];
     for (;;)
     {
         PicState& ps = g_pics[&frame];
@@ -473,7 +462,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
                 continue;                                                     /* (the world may have changed while the lock was open: look again -- the rows are all ready now) */
             }
             if (g_trace) fprintf(stderr, "tme_adapter: POC %d rows %d..%d (asked for row %d of %d)\n", poc, ps.rowsDone, row1 - 1, row, nCtuY);
-            s_job = Job::create(*this, frame, ps.rowsDone, row1, lane);
+            s_job = Job::create(*this, frame, ps.rowsDone, row1);
             if (!s_job) exit(3);
             g_sec[0] += now() - tStart;                                       /* job set-up (the first picture also creates the producer: context, streams, code objects) */
             leader = true;
@@ -548,12 +537,8 @@ extern "C" int x265hip_tme_adapter_load(const char* libraryPath, int device)
     g_trace = getenv("X265TME_TRACE") && atoi(getenv("X265TME_TRACE"));
     g_waitRefs = getenv("X265TME_WAIT_REFS") && atoi(getenv("X265TME_WAIT_REFS"));
     if (getenv("X265TME_HELP")) g_help = atoi(getenv("X265TME_HELP"));
-    g_oneQueue = getenv("X265TME_ONE_QUEUE") && atoi(getenv("X265TME_ONE_QUEUE"));
     if (getenv("X265TME_MIN_ROWS")) g_minRows = atoi(getenv("X265TME_MIN_ROWS"));
     if (getenv("X265TME_WAIT_US")) g_waitUs = atoi(getenv("X265TME_WAIT_US"));
-    g_lanes = getenv("X265TME_LANES") ? atoi(getenv("X265TME_LANES")) : 1;      /* measured: 2, 4, 8 lanes are no faster than 1 (profiles/r05_m2_lanes.txt) */
-    if (g_lanes < 1) g_lanes = 1;
-    if (g_lanes > kMaxLanes) g_lanes = kMaxLanes;
     g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
     if (!g_lib) { fprintf(stderr, "tme_adapter: dlopen: %s\n", dlerror()); return -1; }
     g_api.ctx_create = (int (*)(int, x265hip_ctx**))dlsym(g_lib, "x265hip_ctx_create");
@@ -572,11 +557,8 @@ extern "C" void x265hip_tme_adapter_enable(int on) { g_useGpu = on && g_lib; }
 extern "C" void x265hip_tme_adapter_close(void)
 {
     std::lock_guard<std::mutex> guard(g_lock);
-    for (int k = 0; k < kMaxLanes; k++)
-    {
-        if (g_tme[k]) { g_api.tme_destroy(g_tme[k]); g_tme[k] = nullptr; }
-        if (g_ctx[k]) { g_api.ctx_destroy(g_ctx[k]); g_ctx[k] = nullptr; }
-    }
+    if (g_tme) { g_api.tme_destroy(g_tme); g_tme = nullptr; }
+    if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
     g_pics.clear(); g_useGpu = 0;
 }
 extern "C" void x265hip_tme_adapter_get_stats(x265hip_tme_adapter_stats* o)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (X265TME_ONE_QUEUE and X265TME_LANES were switches of integration/tme_adapter.cpp at commit e8e30fb; the measured losers left the binding afterwards)
 # M2 under default threading: the encoder's own per-frame clocks for the three runs of bench.py's default_threading object
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out

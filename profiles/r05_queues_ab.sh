@@ -1,4 +1,5 @@
 #!/bin/bash
+# (X265TME_ONE_QUEUE and X265TME_LANES were switches of integration/tme_adapter.cpp at commit e8e30fb; the measured losers left the binding afterwards)
 # the adapter's wake-ups: one condition variable for everybody (first form) against one for the running job's helpers and one for the workers of other bands
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
