@@ -240,9 +240,9 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
     g, c = runs["tme_gpu"], runs["cpu"]
     best = runs.get("all_gpu", g)
     out = {"value": best["fps"], "unit": "frames/s", "measured": "this run",
-           "config": "BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults (ref=3, weightp, bframes=4, b-adapt 2), --threaded-me, one frame thread, no WPP (the seams' bindings "
-                     "take complete reference pictures: integration/*.cpp), %d frames for cpu / all_gpu, %d for the per-seam runs" % (frames, seam_frames),
-           "host": "the reference encoder with C primitives (no asm; no nasm on this box) -- its RDO bounds the encode; value = GPU producers on every seam that is bound (%s)"
+           "config": "BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults (ref=3, weightp, bframes=4, b-adapt 2), --threaded-me, one frame thread, no WPP (how the three seams were first bound: "
+                     "all of them on the GPU, the filter binding needs this threading), %d frames for cpu / all_gpu, %d for the per-seam runs" % (frames, seam_frames),
+           "host": "the reference encoder with C primitives (no asm; no nasm on this box) -- its RDO bounds the encode; one frame thread: GPU producers on every seam that is bound (%s)"
                    % ("ThreadedME + lookahead + in-loop filters" if both else "ThreadedME"),
            "fps": {k: v["fps"] for k, v in runs.items()}, "same_encoder_cpu_producer_fps": c["fps"],
            "bitstream_identical": all(v["md5"] == w["md5"] and v["bytes"] == w["bytes"] for v in runs.values() for w in runs.values() if v["clip_frames"] == w["clip_frames"]), "bytes": c["bytes"],
@@ -281,6 +281,15 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
                              "--threaded-me, the plain encoder's bitstream) does %s fps; the in-loop filters stay the encoder's own under frame threads.  RDO and entropy coding on the host bound the encode"
                              % (b["fps"], a["fps"], b["fps"] / a["fps"], p0["fps"], "FASTER" if b["fps"] > p0["fps"] else "SLOWER", b["fps"] / p0["fps"], ("%.2f" % l0["fps"]) if l0 else "n/a"))
         out["default_threading"] = dt
+        if b and p0 and dt.get("bitstream_identical_gpu_vs_cpu_producers"):
+            # M2 as anyone runs x265: the headline of this object is the default-threaded encode; the one-frame-thread pair (how the seams were first bound) stays beside it
+            out["one_frame_thread"] = {"value": out["value"], "same_encoder_cpu_producer_fps": out["same_encoder_cpu_producer_fps"], "config": out["config"]}
+            out["value"] = b["fps"]
+            out["same_encoder_cpu_producer_fps"] = a["fps"]
+            out["encoder_alone_fps"] = p0["fps"]
+            out["config"] = ("BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults, the CLI's default threading (%s frame threads, WPP, every core the host grants), %d frames, medians of "
+                             "repeated runs: value = --threaded-me with the GPU ThreadedME + GPU lookahead (the in-loop filters are the encoder's own under frame threads); same_encoder_cpu_producer_fps = the same "
+                             "with the encoder's own producers (same bitstream); encoder_alone_fps = no --threaded-me" % (b.get("frame_threads"), default_frames))
     if both:
         l = runs["la_gpu"]
         out["lookahead"] = {"intra_pictures": l["la_intra_pictures"], "estimates": l["la_estimates"], "device_launches": l.get("la_launches"), "finish_batch_calls_taken_whole": l.get("la_batches"), "estimate_batch_calls": l.get("la_batch_calls"), "estimates_left_to_the_cpu": l["la_cpu_estimates"], "cutree_steps": l.get("la_cutree_steps"), "ms_per_cutree_step": round(1e3 * l["la_cutree_seconds"] / l["la_cutree_steps"], 3) if l.get("la_cutree_steps") else None,
