@@ -23,7 +23,8 @@ def main():
     torch.cuda.set_device(0)
     lib = x265hip.HipLib(wl["depth"], fill_table=False).lib
     F, per = len(pairs), len(pairs)
-    while 16 * per * (wl["width"] + 2 * bench.MARGIN) * (wl["height"] + 2 * bench.MARGIN) * (1 if wl["depth"] == 8 else 2) >= (1 << 32):
+    # (one batch, as bench.preset_exact_leg runs it since round 5: a batch too large for the kernels' 32-bit offsets keeps its planes in groups of pictures by itself)
+    while os.environ.get("X265HIP_PE_SPLIT_BATCHES") == "1" and 16 * per * (wl["width"] + 2 * bench.MARGIN) * (wl["height"] + 2 * bench.MARGIN) * (1 if wl["depth"] == 8 else 2) >= (1 << 32):
         per //= 2
     hbs = []
     for k in range(0, F, per):
