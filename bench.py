@@ -271,6 +271,15 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
                              "tme_adapter_seconds": b["adapter_seconds"], "la_estimates": b.get("la_estimates"), "la_producer_seconds": b.get("la_producer_seconds"),
                              "filter_pictures_gpu": b.get("ff_pictures"), "filter_pictures_left_to_the_cpu": b.get("ff_cpu_pictures"), "seconds": b["seconds"]}
         p0, l0 = ok.get("cpu_default_threading"), ok.get("gpu_lookahead_default_threading")
+        ck = dt["encoder_clocks_ms_per_picture"]
+        if ck.get("cpu_default_threading") and ck.get("all_gpu_default_threading") and ck["cpu_default_threading"].get("ctu_worker_time"):
+            # what fraction of the encode the bound seams cover, by the encoder's own clocks (x265 --csv-log-level 2: time its CTU workers spend in compressCTU / encodeCTU per picture, summed
+            # over the workers): the plain encoder's figure holds motion search + mode decision + RDO + entropy coding; with the GPU ThreadedME the searches (and AMVP) are gone from it.
+            # The transforms and intra prediction of RDO stay on the host (x265hip_tq_batch / x265hip_intra_cost_batch have no caller inside an encode: RDO is serial per CU)
+            w0, w1 = ck["cpu_default_threading"]["ctu_worker_time"], ck["all_gpu_default_threading"]["ctu_worker_time"]
+            dt["seam_coverage"] = {"ctu_worker_ms_per_picture_encoder_alone": w0, "ctu_worker_ms_per_picture_gpu_seams": w1, "share_of_ctu_worker_time_moved_to_the_gpu": round(1.0 - w1 / w0, 3),
+                                   "left_on_the_host": "mode decision, RDO (transform / quant / intra prediction through the host table), entropy coding, in-loop filters",
+                                   "batched_tq_and_intra_inside_the_encode": "none: x265hip_tq_batch / x265hip_intra_cost_batch are reached by bench and tests only (RDO decides CU by CU)"}
         if p0 and l0:
             dt["bitstream_identical_gpu_lookahead_vs_plain_encoder"] = bool(p0["md5"] == l0["md5"] and l0["md5_all_equal"] and p0["md5_all_equal"])
         if a and b and p0:
