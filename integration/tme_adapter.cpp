@@ -173,9 +173,10 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             }
         }
     };
-    /* One picture = one job.  The first worker that arrives for a picture sets the job up; every worker that arrives while it runs (ThreadedME's workers are waiting for
-       this picture's records anyway) takes CTUs of the host-side passes -- the harvest before the producer call, the write-back after it -- with its OWN Analysis object,
-       so the per-picture host work is spread over the encoder's ThreadedME workers instead of sitting on one of them. */
+    /* One band of CTU rows (one frame thread: the whole picture) = one job.  The first worker that arrives for a row without records sets the job up; with one frame thread every
+       worker that arrives while it runs (ThreadedME's workers are waiting for this picture's records anyway) takes CTUs of the host-side passes -- the harvest before the producer
+       call, the write-back after it -- with its OWN Analysis object, so the per-picture host work is spread over the encoder's ThreadedME workers instead of sitting on one of
+       them; under frame threads they sleep until the job ends (g_help). */
     struct Job
     {
         Frame* frame; int poc, nCtu, nCtuX, nCtuY, nS, nl;
