@@ -276,7 +276,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
             # what fraction of the encode the bound seams cover, by the encoder's own clocks (x265 --csv-log-level 2: time its CTU workers spend in compressCTU / encodeCTU per picture, summed
             # over the workers): the plain encoder's figure holds motion search + mode decision + RDO + entropy coding; with the GPU ThreadedME the searches (and AMVP) are gone from it.
             # The transforms and intra prediction of RDO stay on the host (x265hip_tq_batch / x265hip_intra_cost_batch have no caller inside an encode: RDO is serial per CU)
-            w0, w1 = ck["cpu_default_threading"]["ctu_worker_time"], ck["all_gpu_default_threading"]["ctu_worker_time"]
+            w0, w1 = ck["cpu_default_threading"]["ctu_worker_time"], ck["all_gpu_default_threading"].get("ctu_worker_time") or 0.0
             dt["seam_coverage"] = {"ctu_worker_ms_per_picture_encoder_alone": w0, "ctu_worker_ms_per_picture_gpu_seams": w1, "share_of_ctu_worker_time_moved_to_the_gpu": round(1.0 - w1 / w0, 3),
                                    "left_on_the_host": "mode decision, RDO (transform / quant / intra prediction through the host table), entropy coding, in-loop filters",
                                    "batched_tq_and_intra_inside_the_encode": "none: x265hip_tq_batch / x265hip_intra_cost_batch are reached by bench and tests only (RDO decides CU by CU)"}
