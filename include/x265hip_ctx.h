@@ -151,8 +151,8 @@ typedef struct x265hip_tme_host_ref {
                                                   (picture's encode order + 1) << 8 | list << 5 | ref ... any value unique among live planes); 0 = uploaded with every call                */
     int reconRowsValid, meRowsValid;           /* frame threads: rows of the plane allocation (counted from its first row, the top margin included) that are final NOW -- the reference is
                                                   still being reconstructed (Frame::m_reconRowFlag, frameencoder.cpp:1029-1036) / weighted (MotionReference::numSliceWeightedRows).  0 = the
-                                                  whole plane.  A keyed plane is uploaded and phase-interpolated incrementally: each call adds the rows the producer has not seen yet; the
-                                                  count of a key never shrinks.  The caller hands over what the searches of desc.ctuRowFirst .. + ctuRowCount may read (the encoder's own
+                                                  whole plane.  A keyed plane is uploaded and phase-interpolated incrementally: each call adds the rows the producer has not seen yet (a call
+                                                  may declare FEWER rows than an earlier one -- each band declares what its own searches need: the producer keeps what it has).  The caller hands over what the searches of desc.ctuRowFirst .. + ctuRowCount may read (the encoder's own
                                                   row-lag rule: every reference row up to CTU row + FrameEncoder::m_refLagRows, the window clamped by Search::m_refLagPixels)                */
 } x265hip_tme_host_ref;
 typedef struct x265hip_tme_picture_desc {

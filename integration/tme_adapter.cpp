@@ -82,6 +82,10 @@ int g_help = -1;                             /* workers that arrive for a runnin
 int g_waitRefs;                              /* X265TME_WAIT_REFS=1 (diagnosis; unweighted references only): a picture waits for its references to be complete and goes through the
                                                 producer whole -- separates the frame-parallel window rules from the band protocol */
 
+/* a producer call failed (or the schedule does not match): the encode cannot go on and must not go on quietly.  The encoder's pool threads are running: exit() would run the
+   static destructors under them (seen: a hang until the caller's timeout) -- leave at once, the message is on stderr */
+[[noreturn]] void die() { fflush(stdout); fflush(stderr); _Exit(3); }
+
 void to_choice(const MEData& m, x265hip_inter_choice& o)
 {
     for (int l = 0; l < 2; l++)
@@ -385,7 +389,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         int call()
         {   /* the distinct qps, then the producer */
             std::vector<int> qps;
-            auto qidx = [&](int qp) { if (qp > QP_MAX_SPEC) { fprintf(stderr, "qp %d above 51: not handled\n", qp); exit(3); }
+            auto qidx = [&](int qp) { if (qp > QP_MAX_SPEC) { fprintf(stderr, "qp %d above 51: not handled\n", qp); die(); }
                                       for (size_t i = 0; i < qps.size(); i++) if (qps[i] == qp) return (int)i; qps.push_back(qp); return (int)qps.size() - 1; };
             qpIndex.resize(entryQp.size()); areaQpIndex.resize(areaQp.size());
             for (size_t i = (size_t)c0 * nS; i < (size_t)c1 * nS; i++) qpIndex[i] = (uint8_t)qidx(entryQp[i]);
@@ -464,7 +468,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             }
             if (g_trace) fprintf(stderr, "tme_adapter: POC %d rows %d..%d (asked for row %d of %d)\n", poc, ps.rowsDone, row1 - 1, row, nCtuY);
             s_job = Job::create(*this, frame, ps.rowsDone, row1);
-            if (!s_job) exit(3);
+            if (!s_job) die();
             g_sec[0] += now() - tStart;                                       /* job set-up (the first picture also creates the producer: context, streams, code objects) */
             leader = true;
             break;
@@ -489,7 +493,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         while (job->doneA.load() < nBand) std::this_thread::yield();          /* the helpers' last CTUs */
         const double tCall = now();
         { std::lock_guard<std::mutex> sg(g_statLock); g_sec[2] += job->helped.load(); g_sec[1] += tCall - tStart; }      /* [2] CTUs other workers harvested; [1] wall time up to the producer call: set-up + harvest (qps, collocated neighbours, medians, table conversions) */
-        if (job->failed.load() || job->call()) exit(3);
+        if (job->failed.load() || job->call()) die();
         tBack = now();                                                        /* write-back wall time, closed below */
         lk.lock(); job->phase = 2; lk.unlock();
         s_cvJob.notify_all();

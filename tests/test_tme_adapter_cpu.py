@@ -1,0 +1,72 @@
+"""The host half of the ThreadedME seam without a GPU: integration/tme_adapter.cpp inside the compiled reference encoder (oracle/_ref/x265tmegpu_8), with tests/mock_tme_producer.cpp
+standing in for the library's producer.  The mock checks the protocol of include/x265hip_ctx.h on every call (one call at a time, a picture's bands in order / contiguous / once,
+the declared final rows of every reference cover what the band's searches reach) and answers with records that are a pure function of what the adapter handed over for each CTU --
+the harvested qps, collocated neighbours and medians, the reference tables, the reference planes' rows inside the CTU's window.  So the bitstream must not depend on how a picture
+was cut into bands or how the threads interleaved; state handed over before it was final would move it.
+(The searches themselves -- x265hip_tme_picture against the encoder's own producers, same bitstream -- are tests/test_e2e_tme_gpu.py, on the GPU.)"""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "x265tmegpu_8")
+REAL = os.path.join(ROOT, "x265-mod-by-patman_amd", "libx265hip_8.so")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(REAL)), reason="oracle/_ref/x265tmegpu_8 or libx265hip_8.so not built")
+
+
+@pytest.fixture(scope="module")
+def mock(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("mock") / "libmock_tme.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "mock_tme_producer.cpp"), "-ldl"], check=True)
+    return out
+
+
+def encode(mock, tmp_path, name, frames=10, size=(1280, 720), env=None, options=(), timeout=240):
+    outp = str(tmp_path / (name + ".hevc"))
+    e = dict(os.environ, X265MOCK_REAL_LIB=REAL, **(env or {}))
+    r = subprocess.run([EXE, mock, str(size[0]), str(size[1]), str(frames), "medium", outp] + list(options), capture_output=True, text=True, env=e, timeout=timeout)
+    info = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {}
+    info["rc"], info["stderr"] = r.returncode, r.stderr
+    if r.returncode == 0:
+        info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
+    return info
+
+
+THREADS = ("pools=48", "frame-threads=5")     # (the encoder switches --threaded-me off below 32 pool threads)
+
+
+def test_bands_under_frame_threads_follow_the_protocol_and_do_not_move_the_bitstream(mock, tmp_path):
+    """Five frame threads + WPP: every ready row at once, the default (a band waits for half the picture's rows), large bands with a long wait, and helpers on the band's
+    host passes: the mock sees no violation, every picture goes through it, and the four bitstreams are one."""
+    runs = {}
+    for name, env in (("every_row", {"X265TME_MIN_ROWS": "1", "X265TME_WAIT_US": "0"}), ("default", {}), ("large", {"X265TME_MIN_ROWS": "100", "X265TME_WAIT_US": "30000"}),
+                      ("helpers", {"X265TME_HELP": "1"})):
+        r = encode(mock, tmp_path, name, env=dict(env, X265_CLI_THREADING="1"), options=THREADS)
+        assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+        assert r["frame_threads"] == 5 and r["wpp"] == 1 and r["threaded_me"] == 1
+        assert r["gpu_pictures"] == 9 and r["gpu_bands"] >= r["gpu_pictures"]          # 10 frames, the first is intra
+        runs[name] = r
+    assert len({r["md5"] for r in runs.values()}) == 1, {k: (v["md5"], v["gpu_bands"]) for k, v in runs.items()}
+    assert runs["every_row"]["gpu_bands"] > runs["large"]["gpu_bands"]               # the policies really cut the pictures differently
+
+
+def test_one_frame_thread_hands_over_whole_pictures(mock, tmp_path):
+    """One frame thread, no WPP (the driver's default threading): a call per picture, complete references (no valid-row counts), the waiting workers help with the host passes."""
+    a = encode(mock, tmp_path, "a", frames=6)
+    b = encode(mock, tmp_path, "b", frames=6, env={"X265TME_HELP": "0"})
+    for r in (a, b):
+        assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+        assert r["frame_threads"] == 1 and r["gpu_pictures"] == 5 and r["gpu_bands"] == 5
+        assert "5 calls, 0 of them bands" in r["stderr"]
+    assert a["md5"] == b["md5"]
+
+
+def test_a_failing_producer_call_ends_the_encode_at_once(mock, tmp_path):
+    """The third call fails: the adapter prints the producer's message and leaves with status 3 -- with a pool of running threads, without hanging in exit handlers."""
+    r = encode(mock, tmp_path, "f", env={"X265_CLI_THREADING": "1", "X265MOCK_FAIL_AT": "3"}, options=THREADS, timeout=60)
+    assert r["rc"] == 3
+    assert "fails on request" in r["stderr"] and "x265hip_tme_picture" in r["stderr"]
