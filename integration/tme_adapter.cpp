@@ -67,7 +67,7 @@ double g_gpuSeconds, g_pictureSeconds;      /* inside x265hip_tme_picture; the w
 double g_gpuSecondsWarm; int g_callsWarm;   /* the same without the first four calls (code objects are loaded by the first launch of each kernel) */
 int g_calls;
 std::mutex g_lock, g_statLock;
-struct PicState { int poc1 = 0, rowsDone = 0; };      /* POC + 1 of the picture the Frame object holds now; its CTU rows [0, rowsDone) have their records */
+struct PicState { int poc1 = 0, rowsDone = 0, claimed = 0; };      /* POC + 1 of the picture the Frame object holds now; its CTU rows [0, rowsDone) have their records, [rowsDone, claimed) belong to jobs in flight */
 std::map<const Frame*, PicState> g_pics;
 int g_bands;                                 /* jobs (bands of CTU rows) run; == g_pictures with one frame thread */
 int g_trace;                                 /* X265TME_TRACE=1: a line per job on stderr (where a stalled encode stands) */
@@ -79,6 +79,9 @@ int g_minRows = 0, g_waitUs = 16000;
 int g_help = -1;                             /* workers that arrive for a running band take CTUs of its host passes: -1 = with one frame thread only (there the ThreadedME workers have
                                                 nothing else to do and the picture's harvest is 8 ms on one of them); with frame threads they sleep until the job ends -- waking them
                                                 for a band's millisecond of host work costs more than it gives (profiles/r05_queues_ab.txt: 9.40 -> 9.74 fps).  X265TME_HELP=0 / 1 override */
+int g_ahead;                                 /* X265TME_AHEAD=1: a band may be set up and harvested while the band before it is in its producer call (two jobs in flight; the producer still
+                                                sees one call at a time, in the jobs' order).  Off: one job at a time, the form every figure of round 5 was measured with.  The host half
+                                                is checked in both forms on the CPU (tests/test_tme_adapter_cpu.py); what it does to the encode's speed is for the GPU box to say */
 int g_waitRefs;                              /* X265TME_WAIT_REFS=1 (diagnosis; unweighted references only): a picture waits for its references to be complete and goes through the
                                                 producer whole -- separates the frame-parallel window rules from the band protocol */
 
@@ -230,7 +233,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             return r;
         }
 
-        static Job* create(Analysis& an, Frame& frame, int row0, int row1)
+        static Job* create(Job* j, Analysis& an, Frame& frame, int row0, int row1)
         {
             const Slice* slice = an.m_slice;
             const x265_param* p = an.m_param;
@@ -242,9 +245,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
                 { fprintf(stderr, "x265hip_tme_create: %s\n", g_api.last_error()); return nullptr; }
                 g_createSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             }
-            /* the job's arrays are kept from picture to picture: fresh 10 MB vectors per picture cost more in page faults than the work on them */
-            static Job storage;
-            Job* j = &storage;
+            /* (the job's arrays are kept from job to job -- j is one of two static objects: fresh 10 MB vectors per picture cost more in page faults than the work on them) */
             j->nextA = 0; j->doneA = 0; j->nextB = 0; j->doneB = 0; j->failed = 0; j->helped = 0; j->phase = 0; j->users = 0;
             j->used.clear(); j->refSrc.clear(); j->nRefTables = 0; j->nLowres = 0;
             j->frame = &frame; j->poc = slice->m_poc;
@@ -415,11 +416,16 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             for (int sl : used) from_choice(table[(size_t)c * 593 + sl], dst[(size_t)c * 593 + sl]);
         }
     };
-    static Job* s_job = nullptr;
-    /* two queues: s_cv -- workers whose band is not the running job's (another picture, a later band) sleep until a job ENDS; s_cvJob -- the running job's own helpers and its
-       leader follow its phases.  (One queue for both woke every waiting ThreadedME worker three times per band: with a hundred pool threads on a host that grants them 16 CPUs
-       that is scheduling work of its own) */
-    static std::condition_variable s_cv, s_cvJob;
+    /* A job is first set up and harvested (s_prep), then in its producer call and write-back (s_call).  With X265TME_AHEAD the next band may enter the first stage while a job
+       is in the second -- the host work of a band in the shadow of the previous band's call instead of queueing behind it; the producer still sees one call at a time, in the
+       order the jobs were created.  Without it a band starts when no job is in flight. */
+    static Job s_store[2];
+    static Job* s_prep = nullptr;
+    static Job* s_call = nullptr;
+    /* queues: s_cv -- workers whose row belongs to a job in flight sleep until a job ENDS; s_cvSlot -- workers that want to open a job while another is being set up;
+       s_cvCall -- the leader of the harvested job, until the producer is free; s_cvJob -- a job's own helpers and its leader follow its phases.  (One queue for all woke every
+       waiting ThreadedME worker several times per band: with a hundred pool threads on a host that grants them 16 CPUs that is scheduling work of its own) */
+    static std::condition_variable s_cv, s_cvJob, s_cvSlot, s_cvCall;
 
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::unique_lock<std::mutex> lk(g_lock);
@@ -428,22 +434,26 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
     const int nCtuX = m_slice->m_sps->numCuInWidth, nCtuY = m_slice->m_sps->numCuInHeight, row = (int)ctu.m_cuAddr / nCtuX;
     bool leader = false;
     const double tStart = now();
+    Job* job = nullptr;
     for (;;)
     {
         PicState& ps = g_pics[&frame];
-        if (ps.poc1 != poc + 1) { ps.poc1 = poc + 1; ps.rowsDone = 0; }       /* the Frame object holds a new picture */
+        if (ps.poc1 != poc + 1) { ps.poc1 = poc + 1; ps.rowsDone = 0; ps.claimed = 0; }       /* the Frame object holds a new picture */
         if (row < ps.rowsDone) return;                                        /* this CTU's records are there already */
-        if (s_job && s_job->frame == &frame && s_job->poc == poc && row >= s_job->row0 && row < s_job->row1)
-        {
-            if (g_help > 0 || (g_help < 0 && m_param->frameNumThreads <= 1)) break;      /* the band's job is running: help */
-            s_cv.wait(lk);                                                    /* sleep until it ends */
+        if (row < ps.claimed)
+        {   /* the row belongs to a job in flight */
+            if (g_help > 0 || (g_help < 0 && m_param->frameNumThreads <= 1))
+                for (Job* j : { s_prep, s_call })
+                    if (j && j->frame == &frame && j->poc == poc && row >= j->row0 && row < j->row1) job = j;
+            if (job) break;                                                   /* help with its host passes */
+            s_cv.wait(lk);                                                    /* sleep until a job ends */
             continue;
         }
-        if (!s_job)
-        {   /* a new band: from the first row without records to the last one whose reference rows are final (one frame thread: the whole picture) */
+        if (!s_prep && (g_ahead || !s_call))
+        {   /* a new band: from the first row no job has claimed to the last one whose reference rows are final (one frame thread: the whole picture) */
             int row1 = Job::ready_rows(*this, row, nCtuY);
             const int minRows = g_minRows > 0 ? g_minRows : (nCtuY + 1) / 2;
-            if (minRows > 1 && g_waitUs > 0 && m_param->frameNumThreads > 1 && row1 < nCtuY && row1 - ps.rowsDone < minRows)
+            if (minRows > 1 && g_waitUs > 0 && m_param->frameNumThreads > 1 && row1 < nCtuY && row1 - ps.claimed < minRows)
             {   /* few rows are ready: give the references a moment to release more (the lock is open meanwhile; whoever comes back first opens the job) */
                 const int have = row1;
                 lk.unlock();
@@ -451,7 +461,7 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
                 while ((now() - tw) * 1e6 < g_waitUs && Job::ready_rows(*this, row, nCtuY) == have) std::this_thread::sleep_for(std::chrono::microseconds(150));
                 lk.lock();
                 PicState& ps2 = g_pics[&frame];
-                if (ps2.poc1 != poc + 1 || row < ps2.rowsDone || s_job) continue;       /* somebody else got there: look again */
+                if (ps2.poc1 != poc + 1 || row < ps2.claimed || s_prep || (!g_ahead && s_call)) continue;       /* somebody else got there: look again */
                 row1 = Job::ready_rows(*this, row, nCtuY);
             }
             if (g_waitRefs && row1 < nCtuY)
@@ -466,16 +476,17 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
                 lk.lock();
                 continue;                                                     /* (the world may have changed while the lock was open: look again -- the rows are all ready now) */
             }
-            if (g_trace) fprintf(stderr, "tme_adapter: POC %d rows %d..%d (asked for row %d of %d)\n", poc, ps.rowsDone, row1 - 1, row, nCtuY);
-            s_job = Job::create(*this, frame, ps.rowsDone, row1);
-            if (!s_job) die();
+            if (g_trace) fprintf(stderr, "tme_adapter: POC %d rows %d..%d (asked for row %d of %d)\n", poc, ps.claimed, row1 - 1, row, nCtuY);
+            s_prep = Job::create(s_call == &s_store[0] ? &s_store[1] : &s_store[0], *this, frame, ps.claimed, row1);
+            if (!s_prep) die();
+            ps.claimed = row1;
             g_sec[0] += now() - tStart;                                       /* job set-up (the first picture also creates the producer: context, streams, code objects) */
             leader = true;
+            job = s_prep;
             break;
         }
-        s_cv.wait(lk);                                                        /* another job is running: another picture's, or an earlier band of this one */
+        s_cvSlot.wait(lk);                                                    /* another job is being set up (or, without X265TME_AHEAD, running): wait for the slot */
     }
-    Job* job = s_job;
     job->users++;
     lk.unlock();
     const int nBand = job->c1 - job->c0;
@@ -493,6 +504,12 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         while (job->doneA.load() < nBand) std::this_thread::yield();          /* the helpers' last CTUs */
         const double tCall = now();
         { std::lock_guard<std::mutex> sg(g_statLock); g_sec[2] += job->helped.load(); g_sec[1] += tCall - tStart; }      /* [2] CTUs other workers harvested; [1] wall time up to the producer call: set-up + harvest (qps, collocated neighbours, medians, table conversions) */
+        /* the producer takes one call at a time: wait for the job before this one (its call and its write-back), then hand the set-up slot to the next band */
+        lk.lock();
+        while (s_call) s_cvCall.wait(lk);
+        s_call = job; s_prep = nullptr;
+        lk.unlock();
+        if (g_ahead) s_cvSlot.notify_all();
         if (job->failed.load() || job->call()) die();
         tBack = now();                                                        /* write-back wall time, closed below */
         lk.lock(); job->phase = 2; lk.unlock();
@@ -524,7 +541,9 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         job->phase = 3;
         s_cvJob.notify_all();
         while (job->users > 1) s_cvJob.wait(lk);                              /* every helper has left the job */
-        s_job = nullptr;
+        s_call = nullptr;
+        s_cvCall.notify_all();
+        s_cvSlot.notify_all();
         s_cv.notify_all();
     }
     else
@@ -542,6 +561,7 @@ extern "C" int x265hip_tme_adapter_load(const char* libraryPath, int device)
     g_trace = getenv("X265TME_TRACE") && atoi(getenv("X265TME_TRACE"));
     g_waitRefs = getenv("X265TME_WAIT_REFS") && atoi(getenv("X265TME_WAIT_REFS"));
     if (getenv("X265TME_HELP")) g_help = atoi(getenv("X265TME_HELP"));
+    g_ahead = getenv("X265TME_AHEAD") && atoi(getenv("X265TME_AHEAD"));
     if (getenv("X265TME_MIN_ROWS")) g_minRows = atoi(getenv("X265TME_MIN_ROWS"));
     if (getenv("X265TME_WAIT_US")) g_waitUs = atoi(getenv("X265TME_WAIT_US"));
     g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);

@@ -40,11 +40,11 @@ THREADS = ("pools=48", "frame-threads=5")     # (the encoder switches --threaded
 
 
 def test_bands_under_frame_threads_follow_the_protocol_and_do_not_move_the_bitstream(mock, tmp_path):
-    """Five frame threads + WPP: every ready row at once, the default (a band waits for half the picture's rows), large bands with a long wait, and helpers on the band's
-    host passes: the mock sees no violation, every picture goes through it, and the four bitstreams are one."""
+    """Five frame threads + WPP: every ready row at once, the default (a band waits for half the picture's rows), large bands with a long wait, helpers on the band's
+    host passes, and a band harvested while the one before it is in its call (X265TME_AHEAD): the mock sees no violation, every picture goes through it, and the bitstreams are one."""
     runs = {}
     for name, env in (("every_row", {"X265TME_MIN_ROWS": "1", "X265TME_WAIT_US": "0"}), ("default", {}), ("large", {"X265TME_MIN_ROWS": "100", "X265TME_WAIT_US": "30000"}),
-                      ("helpers", {"X265TME_HELP": "1"})):
+                      ("helpers", {"X265TME_HELP": "1"}), ("ahead", {"X265TME_AHEAD": "1"}), ("ahead_every_row_helpers", {"X265TME_AHEAD": "1", "X265TME_MIN_ROWS": "1", "X265TME_WAIT_US": "0", "X265TME_HELP": "1"})):
         r = encode(mock, tmp_path, name, env=dict(env, X265_CLI_THREADING="1"), options=THREADS)
         assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
         assert r["frame_threads"] == 5 and r["wpp"] == 1 and r["threaded_me"] == 1
