@@ -25,10 +25,10 @@ def mock(tmp_path_factory):
     return out
 
 
-def encode(mock, tmp_path, name, frames=10, size=(1280, 720), env=None, options=(), timeout=240):
+def encode(mock, tmp_path, name, frames=10, size=(1280, 720), env=None, options=(), timeout=240, preset="medium"):
     outp = str(tmp_path / (name + ".hevc"))
     e = dict(os.environ, X265MOCK_REAL_LIB=REAL, **(env or {}))
-    r = subprocess.run([EXE, mock, str(size[0]), str(size[1]), str(frames), "medium", outp] + list(options), capture_output=True, text=True, env=e, timeout=timeout)
+    r = subprocess.run([EXE, mock, str(size[0]), str(size[1]), str(frames), preset, outp] + list(options), capture_output=True, text=True, env=e, timeout=timeout)
     info = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {}
     info["rc"], info["stderr"] = r.returncode, r.stderr
     if r.returncode == 0:
@@ -70,3 +70,25 @@ def test_a_failing_producer_call_ends_the_encode_at_once(mock, tmp_path):
     r = encode(mock, tmp_path, "f", env={"X265_CLI_THREADING": "1", "X265MOCK_FAIL_AT": "3"}, options=THREADS, timeout=60)
     assert r["rc"] == 3
     assert "fails on request" in r["stderr"] and "x265hip_tme_picture" in r["stderr"]
+
+
+def test_weighted_references_and_the_rectangular_schedule_under_frame_threads(mock, tmp_path):
+    """A fade (weighted prediction: the weighted plane of (picture, list, reference) goes over with the rows MotionReference::applyWeight has finished) and preset slow's
+    schedule (255 entries per CTU) under frame threads, each cut into bands two ways -- one of them with a band harvested while the one before it is in its call."""
+    fade = [encode(mock, tmp_path, "fade%d" % i, env=dict(e, X265_CLI_THREADING="1", X265TME_FADE="1"), options=("pools=48", "frame-threads=4"))
+            for i, e in enumerate(({}, {"X265TME_MIN_ROWS": "1", "X265TME_WAIT_US": "0", "X265TME_AHEAD": "1"}))]
+    for r in fade:
+        assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+        assert r["weighted_refs"] > 0 and r["gpu_pictures"] == 9
+    assert fade[0]["md5"] == fade[1]["md5"]
+    slow = [encode(mock, tmp_path, "slow%d" % i, frames=8, size=(832, 480), env=dict(e, X265_CLI_THREADING="1"), options=("pools=48", "frame-threads=3"), preset="slow")
+            for i, e in enumerate(({}, {"X265TME_MIN_ROWS": "1", "X265TME_AHEAD": "1"}))]
+    for r in slow:
+        assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+    assert slow[0]["md5"] == slow[1]["md5"]
+
+
+def test_slices_with_frame_threads_are_refused_loudly(mock, tmp_path):
+    """--slices with several frame threads: the slice MV bounds of search.cpp:4999-5003 are not modelled -- the binding says so and ends the encode (no silent CPU fallback)."""
+    r = encode(mock, tmp_path, "s", frames=6, env={"X265_CLI_THREADING": "1"}, options=THREADS + ("slices=2",), timeout=60)
+    assert r["rc"] == 3 and "slice MV bounds are not modelled" in r["stderr"]
