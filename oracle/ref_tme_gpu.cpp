@@ -31,6 +31,9 @@ static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixe
 {   /* the clip of ref_tme.cpp: textured picture in (not purely translational) motion + deterministic noise */
     uint32_t s = 4242u + 733u * (uint32_t)f;
     const int pm = (1 << X265_DEPTH) - 1;
+    /* read ONCE: the loop below used to ask per pixel -- 68 ms of the main thread per 1080p picture inside the timed encode, and a getenv that runs while a pool thread loads the
+       HIP libraries (their initialisers call setenv) can fault (seen with the CPU mock producer, which loads libx265hip on the first picture) */
+    static const bool fade = getenv("X265TME_FADE") != NULL;
     for (int j = 0; j < h; j++)
         for (int i = 0; i < w; i++)
         {
@@ -38,7 +41,7 @@ static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixe
             const int t = (((x * x) / 9 + yy * 7 + (x * yy) / 13 + ((x >> 3) ^ (yy >> 3)) * 11) & 255) * (pm + 1) / 256;
             s = s * 1664525u + 1013904223u;
             int val = t + (int)((s >> 24) & 7) - 3;
-            if (getenv("X265TME_FADE")) val = val * (16 - 2 * (f < 6 ? f : 6)) / 16 + 4 * f * (pm + 1) / 256;      /* a fade: weighted prediction gets something to do */
+            if (fade) val = val * (16 - 2 * (f < 6 ? f : 6)) / 16 + 4 * f * (pm + 1) / 256;      /* a fade: weighted prediction gets something to do */
             y[(size_t)j * w + i] = (pixel)(val < 0 ? 0 : val > pm ? pm : val);
         }
     for (int j = 0; j < h / 2; j++)
