@@ -92,3 +92,16 @@ def test_slices_with_frame_threads_are_refused_loudly(mock, tmp_path):
     """--slices with several frame threads: the slice MV bounds of search.cpp:4999-5003 are not modelled -- the binding says so and ends the encode (no silent CPU fallback)."""
     r = encode(mock, tmp_path, "s", frames=6, env={"X265_CLI_THREADING": "1"}, options=THREADS + ("slices=2",), timeout=60)
     assert r["rc"] == 3 and "slice MV bounds are not modelled" in r["stderr"]
+
+
+@pytest.mark.parametrize("options", [("bframes=0",), ("ref=5", "weightb=1"), ("ctu=32",), ("merange=24",), ("merange=120",), ("rect=1", "amp=1"), ("keyint=5", "min-keyint=5", "b-pyramid=0")],
+                         ids=lambda o: "+".join(o))
+def test_encoder_options_that_change_the_row_lag_the_schedule_or_the_reference_lists(mock, tmp_path, options):
+    """Four frame threads; the search range sets how many reference rows a band waits for (FrameEncoder::m_refLagRows), the CTU size the rows themselves, rect / amp the schedule,
+    the GOP options which pictures reference which: every ready row at once against bands harvested ahead -- no violation, one bitstream."""
+    runs = [encode(mock, tmp_path, "o%d" % i, frames=8, size=(832, 480), env=dict(e, X265_CLI_THREADING="1"), options=("pools=48", "frame-threads=4") + tuple(options))
+            for i, e in enumerate(({"X265TME_MIN_ROWS": "1", "X265TME_WAIT_US": "0"}, {"X265TME_AHEAD": "1"}))]
+    for r in runs:
+        assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+        assert r["gpu_pictures"] > 0 and r["gpu_bands"] >= r["gpu_pictures"]
+    assert runs[0]["md5"] == runs[1]["md5"]
