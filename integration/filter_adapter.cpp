@@ -33,6 +33,9 @@
 using namespace X265_NS;
 
 namespace {
+/* a producer call failed: the encode must not go on quietly.  The encoder's pool threads are running -- exit() would run the static destructors under them (a hang, seen in
+   the ThreadedME binding): leave at once, the message is on stderr */
+[[noreturn]] void die() { fflush(stdout); fflush(stderr); _Exit(3); }
 struct Api
 {
     int (*ctx_create)(int, x265hip_ctx**);
@@ -218,7 +221,7 @@ void FrameFilter::processRow(int row, int layer)
     const double t1 = now();
     const int rc = g_api.ff_picture(ff, &d);
     const double t2 = now();
-    if (rc) { fprintf(stderr, "filter_adapter: x265hip_ff_picture (POC %d): %d %s\n", slice->m_poc, rc, g_api.last_error()); exit(3); }
+    if (rc) { fprintf(stderr, "filter_adapter: x265hip_ff_picture (POC %d): %d %s\n", slice->m_poc, rc, g_api.last_error()); die(); }
     Replay& rp = g_replayState;
     rp.data = &encData; rp.deblocked = p.bEnableLoopFilter != 0; rp.skipped = 0; rp.served = 0;
     rp.stats[0] = (d.saoStats & 1) ? S.stats[0].data() : NULL;

@@ -53,6 +53,9 @@ std::mutex g_lock;                       /* creation of the producer; the produc
 x265hip_la_adapter_stats g_stats;
 std::mutex g_statLock;
 
+/* a producer call failed: the encode must not go on quietly.  The encoder's pool threads are running -- exit() would run the static destructors under them (a hang, seen in
+   the ThreadedME binding): leave at once, the message is on stderr */
+[[noreturn]] void die() { fflush(stdout); fflush(stderr); _Exit(3); }
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 uint64_t key_of(const Lowres& f) { return (uint64_t)(int64_t)f.frameNum + 2; }      /* frameNum starts at 0; 0 is "no key" */
 
@@ -111,7 +114,7 @@ void LookaheadTLD::lowresIntraEstimate(Lowres& fenc, uint32_t qgSize)
     const double t1 = now();
     const int rc = g_api.la_intra(la, key_of(fenc), fenc.buffer[0], invq, fenc.intraCost, fenc.intraMode, fenc.lowresCosts[0][0], fenc.rowSatds[0][0], sums);
     const double t2 = now();
-    if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_intra (frame %d): %d %s\n", fenc.frameNum, rc, g_api.last_error()); exit(3); }
+    if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_intra (frame %d): %d %s\n", fenc.frameNum, rc, g_api.last_error()); die(); }
     fenc.costEst[0][0] = sums[0];
     fenc.costEstAq[0][0] = sums[1];
     std::lock_guard<std::mutex> guard(g_statLock);
@@ -251,7 +254,7 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
             const double t1 = now();
             const int rc = g_api.la_estimate_batch(la, descs.data(), (int)descs.size());
             const double t2 = now();
-            if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_estimate_batch (%d estimates): %d %s\n", (int)descs.size(), rc, g_api.last_error()); exit(3); }
+            if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_estimate_batch (%d estimates): %d %s\n", (int)descs.size(), rc, g_api.last_error()); die(); }
             for (XlaEstimate& e : wave) (void)finish(e);
             for (int i : members) { done[(size_t)i] = 1; left--; }
             launches++;
@@ -274,7 +277,7 @@ int64_t CostEstimateGroup::estimateFrameCost(LookaheadTLD& tld, int p0, int p1, 
         const double t1 = now();
         const int rc = g_api.la_estimate(la, &e.d);
         const double t2 = now();
-        if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_estimate (%d, %d, %d): %d %s\n", p0, b, p1, rc, g_api.last_error()); exit(3); }
+        if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_estimate (%d, %d, %d): %d %s\n", p0, b, p1, rc, g_api.last_error()); die(); }
         score = finish(e);
         std::lock_guard<std::mutex> guard(g_statLock);
         g_stats.estimates++; g_stats.estimateSeconds += now() - t0; g_stats.producerSeconds += t2 - t1; g_stats.weighted += e.d.weightedPlanes != nullptr;
@@ -333,7 +336,7 @@ void Lookahead::estimateCUPropagate(Lowres** frames, double averageDuration, int
     d.mvs0 = mv16[0].data(); d.mvs1 = p1 > b ? mv16[1].data() : NULL;
     d.propB = fb->propagateCost; d.prop0 = frames[p0]->propagateCost; d.prop1 = p1 > b ? frames[p1]->propagateCost : NULL;
     const int rc = g_api.la_cutree_propagate(la, &d);
-    if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_cutree_propagate: %d %s\n", rc, g_api.last_error()); exit(3); }
+    if (rc) { fprintf(stderr, "lookahead_adapter: x265hip_la_cutree_propagate: %d %s\n", rc, g_api.last_error()); die(); }
     { std::lock_guard<std::mutex> sg(g_statLock); g_stats.cutreeSteps++; g_stats.cutreeSeconds += now() - t0; }
     if (m_param->rc.vbvBufferSize && m_param->lookaheadDepth && referenced)
         cuTreeFinish(fb, averageDuration, b == p1 ? b - p0 : 0);
