@@ -1,0 +1,58 @@
+"""The host half of the in-loop filter seam without a GPU: integration/filter_adapter.cpp inside the compiled reference encoder (oracle/_ref/x265e2e_8), with
+tests/mock_ff_producer.cpp standing in for x265hip_ff_picture -- answered by the oracle's plain-C deblocking filter and SAO statistics (oracle/x265_oracle.c, pinned to the
+reference's Deblock / SAO classes in tests/test_filters_oracle_vs_ref.py).  The gather of CUData's arrays, the deferral of a picture's filters to its last row and the replay of
+the encoder's row loop behind the call are then all that stands between the plain encoder's bitstream and this one: they must be the same bitstream.
+(The device kernels against the same oracle: tests/test_filters_gpu.py; the GPU producer inside the encoder: tests/test_e2e_ff_gpu.py.)"""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "x265e2e_8")
+ORACLE = os.path.join(ROOT, "oracle", "libx265oracle_me_8.so")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(ORACLE)), reason="oracle/_ref/x265e2e_8 or the oracle library not built")
+
+
+@pytest.fixture(scope="module")
+def mock(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("mockff") / "libmock_ff.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "mock_ff_producer.cpp"), "-ldl"], check=True)
+    return out
+
+
+def encode(mock, tmp_path, name, ff, frames=8, size=(640, 368), env=None, options=(), timeout=240):
+    outp = str(tmp_path / (name + ".hevc"))
+    e = dict(os.environ, X265MOCK_ORACLE_LIB=ORACLE, X265TME="0", X265TMEGPU="0", X265LAGPU="0", X265FFGPU=str(ff), **(env or {}))
+    r = subprocess.run([EXE, mock, str(size[0]), str(size[1]), str(frames), "medium", outp] + list(options), capture_output=True, text=True, env=e, timeout=timeout)
+    info = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {}
+    info["rc"], info["stderr"] = r.returncode, r.stderr
+    if r.returncode == 0:
+        info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()
+    return info
+
+
+@pytest.mark.parametrize("size,options", [((640, 368), ()), ((640, 368), ("limit-sao=1",)), ((640, 368), ("sao-non-deblock=1",)), ((640, 368), ("sao=0",)), ((640, 368), ("deblock=2:-2", "bframes=0")),
+                                          ((640, 368), ("cu-lossless=1",)), ((640, 368), ("ctu=32",)), ((256, 320), ("slices=4", "wpp=1")), ((320, 384), ("slices=3", "wpp=1", "limit-sao=1"))],
+                         ids=lambda v: "+".join(str(x) for x in v) if isinstance(v, tuple) else str(v))
+def test_filters_through_the_binding_give_the_plain_encoders_bitstream(mock, tmp_path, size, options):
+    plain = encode(mock, tmp_path, "plain", 0, size=size, options=options)
+    bound = encode(mock, tmp_path, "bound", 1, size=size, options=options)
+    assert plain["rc"] == 0 and bound["rc"] == 0 and "PROTOCOL VIOLATION" not in bound["stderr"], bound["stderr"][-600:]
+    assert bound["ff_pictures"] == 8 and bound["ff_cpu_pictures"] == 0 and plain["ff_pictures"] == 0
+    assert bound["md5"] == plain["md5"] and bound["bytes"] == plain["bytes"]
+
+
+def test_frame_threads_keep_the_encoders_own_filters(mock, tmp_path):
+    """Several frame threads: the binding leaves every picture to the encoder's own filters -- and says how many."""
+    r = encode(mock, tmp_path, "ft", 1, env={"X265_CLI_THREADING": "1"}, options=("pools=16", "frame-threads=3"))
+    p = encode(mock, tmp_path, "ftp", 0, env={"X265_CLI_THREADING": "1"}, options=("pools=16", "frame-threads=3"))
+    assert r["rc"] == 0 and p["rc"] == 0 and r["ff_pictures"] == 0 and r["ff_cpu_pictures"] == 8 and r["md5"] == p["md5"]
+
+
+def test_a_failing_filter_call_ends_the_encode_at_once(mock, tmp_path):
+    r = encode(mock, tmp_path, "f", 1, env={"X265MOCK_FAIL_AT": "2"}, timeout=60)
+    assert r["rc"] == 3 and "fails on request" in r["stderr"] and "filter_adapter" in r["stderr"]

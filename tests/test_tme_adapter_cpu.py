@@ -105,3 +105,13 @@ def test_encoder_options_that_change_the_row_lag_the_schedule_or_the_reference_l
         assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
         assert r["gpu_pictures"] > 0 and r["gpu_bands"] >= r["gpu_pictures"]
     assert runs[0]["md5"] == runs[1]["md5"]
+
+
+def test_slices_with_one_frame_thread(mock, tmp_path):
+    """--slices with one frame thread (the first / last-row flags initCTU gets per slice, threadedme.cpp:298-308): whole pictures, helpers on and off, one bitstream."""
+    a = encode(mock, tmp_path, "sa", frames=6, size=(256, 256), options=("slices=2", "wpp=1"))
+    b = encode(mock, tmp_path, "sb", frames=6, size=(256, 256), options=("slices=2", "wpp=1"), env={"X265TME_HELP": "0"})
+    for r in (a, b):
+        assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+        assert r["gpu_pictures"] == 5
+    assert a["md5"] == b["md5"]
