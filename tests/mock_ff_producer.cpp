@@ -16,7 +16,11 @@
 #include <vector>
 #include "../include/x265hip_ctx.h"
 
+#if defined(MOCK_DEPTH) && MOCK_DEPTH > 8
+typedef uint16_t xo_pixel;     /* -DMOCK_DEPTH=10: the 10-bit encoder with the 10-bit oracle */
+#else
 typedef uint8_t xo_pixel;      /* the 8-bit encoder */
+#endif
 struct x265hip_ctx { int device; };
 struct x265hip_ff { int width, height, ctu; intptr_t strideY, strideC; long calls = 0; std::mutex mu; };
 

@@ -21,7 +21,11 @@
 #include <vector>
 #include "../include/x265hip_ctx.h"
 
+#if defined(MOCK_DEPTH) && MOCK_DEPTH > 8
+typedef uint16_t xo_pixel;     /* -DMOCK_DEPTH=10: the 10-bit encoder with the 10-bit oracle */
+#else
 typedef uint8_t xo_pixel;      /* the 8-bit encoder */
+#endif
 struct xo_la_hme { const xo_pixel* fenc; const xo_pixel* const* ref0; const xo_pixel* const* ref1; intptr_t stride; int wcu, hcu; int method[2], range[2]; int32_t* mvs[2]; int32_t* mvCosts[2]; };
 
 struct x265hip_ctx { int device; };

@@ -19,15 +19,21 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(ORAC
 
 @pytest.fixture(scope="module")
 def mock(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("mockff") / "libmock_ff.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out, os.path.join(ROOT, "tests", "mock_ff_producer.cpp"), "-ldl"], check=True)
-    return out
+    """mock(depth) -> the mock library for the encoder of that bit depth (built on first use)"""
+    d, built = tmp_path_factory.mktemp("mock_ff"), {}
+
+    def for_depth(depth=8):
+        if depth not in built:
+            built[depth] = str(d / ("libmock_%d.so" % depth))
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DMOCK_DEPTH=%d" % depth, "-o", built[depth], os.path.join(ROOT, "tests", "mock_ff_producer.cpp"), "-ldl"], check=True)
+        return built[depth]
+    return for_depth
 
 
-def encode(mock, tmp_path, name, ff, frames=8, size=(640, 368), env=None, options=(), timeout=240):
+def encode(mock, tmp_path, name, ff, frames=8, size=(640, 368), env=None, options=(), timeout=240, depth=8):
     outp = str(tmp_path / (name + ".hevc"))
-    e = dict(os.environ, X265MOCK_ORACLE_LIB=ORACLE, X265TME="0", X265TMEGPU="0", X265LAGPU="0", X265FFGPU=str(ff), **(env or {}))
-    r = subprocess.run([EXE, mock, str(size[0]), str(size[1]), str(frames), "medium", outp] + list(options), capture_output=True, text=True, env=e, timeout=timeout)
+    e = dict(os.environ, X265MOCK_ORACLE_LIB=ORACLE.replace("_8.so", "_%d.so" % depth), X265TME="0", X265TMEGPU="0", X265LAGPU="0", X265FFGPU=str(ff), **(env or {}))
+    r = subprocess.run([EXE.replace("_8", "_%d" % depth), mock(depth), str(size[0]), str(size[1]), str(frames), "medium", outp] + list(options), capture_output=True, text=True, env=e, timeout=timeout)
     info = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {}
     info["rc"], info["stderr"] = r.returncode, r.stderr
     if r.returncode == 0:
@@ -56,3 +62,11 @@ def test_frame_threads_keep_the_encoders_own_filters(mock, tmp_path):
 def test_a_failing_filter_call_ends_the_encode_at_once(mock, tmp_path):
     r = encode(mock, tmp_path, "f", 1, env={"X265MOCK_FAIL_AT": "2"}, timeout=60)
     assert r["rc"] == 3 and "fails on request" in r["stderr"] and "filter_adapter" in r["stderr"]
+
+
+@pytest.mark.skipif(not os.path.exists(EXE.replace("_8", "_10")), reason="the 10-bit encoder is not built")
+def test_ten_bit_encoder(mock, tmp_path):
+    plain = encode(mock, tmp_path, "plain10", 0, options=("limit-sao=1",), depth=10)
+    bound = encode(mock, tmp_path, "bound10", 1, options=("limit-sao=1",), depth=10)
+    assert plain["rc"] == 0 and bound["rc"] == 0 and "PROTOCOL VIOLATION" not in bound["stderr"], bound["stderr"][-600:]
+    assert bound["ff_pictures"] == 8 and bound["md5"] == plain["md5"]
