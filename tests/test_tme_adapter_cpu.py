@@ -115,3 +115,20 @@ def test_slices_with_one_frame_thread(mock, tmp_path):
         assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
         assert r["gpu_pictures"] == 5
     assert a["md5"] == b["md5"]
+
+
+@pytest.mark.skipif(not (os.path.exists(EXE.replace("_8", "_10")) and os.path.exists(REAL.replace("_8.so", "_10.so"))), reason="the 10-bit encoder / library is not built")
+def test_ten_bit_encoder_under_frame_threads(tmp_path):
+    """The 10-bit encoder (two-byte pixels in every plane the binding hands over) with the mock built for it: two band policies, one bitstream."""
+    mock10 = str(tmp_path / "libmock_tme_10.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DMOCK_PIXEL_BYTES=2", "-o", mock10, os.path.join(ROOT, "tests", "mock_tme_producer.cpp"), "-ldl"], check=True)
+    runs = []
+    for i, e in enumerate(({"X265TME_MIN_ROWS": "1", "X265TME_WAIT_US": "0"}, {"X265TME_AHEAD": "1"})):
+        outp = str(tmp_path / ("t%d.hevc" % i))
+        env = dict(os.environ, X265MOCK_REAL_LIB=REAL.replace("_8.so", "_10.so"), X265_CLI_THREADING="1", X265TME_FADE="1", **e)
+        r = subprocess.run([EXE.replace("_8", "_10"), mock10, "832", "480", "8", "medium", outp, "pools=48", "frame-threads=4"], capture_output=True, text=True, env=env, timeout=240)
+        assert r.returncode == 0 and "PROTOCOL VIOLATION" not in r.stderr, r.stderr[-600:]
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        assert info["gpu_pictures"] == 7 and info["frame_threads"] == 4
+        runs.append(hashlib.md5(open(outp, "rb").read()).hexdigest())
+    assert runs[0] == runs[1]
