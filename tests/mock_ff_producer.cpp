@@ -38,9 +38,11 @@ void (*g_stats)(const xo_pixel*, const xo_pixel*, intptr_t, int, int, int, int, 
 } // namespace
 
 extern "C" {
+#ifndef MOCK_NO_COMMON      /* (the three mocks in one library -- tests/test_all_adapters_cpu.py -- keep one copy of the context functions: the ThreadedME mock's) */
 const char* x265hip_last_error(void) { return g_err; }
 int x265hip_ctx_create(int device, x265hip_ctx** out) { *out = new x265hip_ctx{ device }; return X265HIP_OK; }
 void x265hip_ctx_destroy(x265hip_ctx* c) { delete c; }
+#endif
 
 int x265hip_ff_create(x265hip_ctx* ctx, int width, int height, int ctuSize, intptr_t strideY, intptr_t strideC, x265hip_ff** out)
 {

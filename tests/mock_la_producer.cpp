@@ -126,9 +126,11 @@ int one_estimate(x265hip_la* la, const x265hip_la_estimate_desc* d)
 } // namespace
 
 extern "C" {
+#ifndef MOCK_NO_COMMON      /* (the three mocks in one library -- tests/test_all_adapters_cpu.py -- keep one copy of the context functions: the ThreadedME mock's) */
 const char* x265hip_last_error(void) { return g_err; }
 int x265hip_ctx_create(int device, x265hip_ctx** out) { *out = new x265hip_ctx{ device }; return X265HIP_OK; }
 void x265hip_ctx_destroy(x265hip_ctx* c) { delete c; }
+#endif
 
 int x265hip_la_create(x265hip_ctx* ctx, int widthInCU, int heightInCU, intptr_t stride, int64_t planeElems, int64_t origin, int maxPictures, x265hip_la** out)
 {
