@@ -7,7 +7,7 @@
  *     cover what the band's searches may read (the encoder's row-lag rule; a band declares what ITS searches need, a later band of another picture may declare fewer rows of
  *     the same plane); array pointers there.  A violation is printed and the call fails.
  *   - Writes, for every CTU of the band and every slot of the schedule, a record that is a pure function of WHAT THE ADAPTER HANDED OVER FOR THAT CTU: the qps of its entries,
- *     its collocated neighbours and medians, the reference tables' records, and the reference planes' rows the CTU's searches could read (rows the caller declared final).
+ *     its own pixels, its collocated neighbours and medians, the reference tables' records, the lookahead's MVs of its blocks, and the reference planes' rows the CTU's searches could read (rows the caller declared final).
  *     Two encodes of the same clip therefore write the same bitstream whatever the bands were and however the threads interleaved -- unless the adapter handed over state that
  *     was not final yet (a row still being reconstructed, a table still being written): then the hash, the record's MV and the bitstream move.  The records are legal for the
  *     encoder (list 0, reference 0, a quarter-pel MV within +-3).
@@ -147,11 +147,22 @@ int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_desc* d)
         h = hash_bytes(h, d->temporal + (size_t)c * nS * 2, (size_t)nS * 2 * sizeof(x265hip_tme_temporal));
         if (d->median) h = hash_bytes(h, d->median + (size_t)c * 2 * X265HIP_MAX_REF * 3, (size_t)2 * X265HIP_MAX_REF * 3 * sizeof(int16_t));
         for (int sl : t->slots) h = hash_bytes(h, &d->table[(size_t)c * 593 + sl], sizeof(x265hip_inter_choice));
+        {   /* the CTU's own pixels */
+            const uint8_t* cur = (const uint8_t*)d->curPlane;
+            const int ox = (int)(d->origin % d->stride);
+            for (int y = top + cy * t->ctu; y < top + std::min((cy + 1) * t->ctu, d->height); y++)
+                h = hash_bytes(h, cur + ((size_t)y * d->stride + ox + cx * t->ctu) * px, (size_t)std::min(t->ctu, d->width - cx * t->ctu) * px);
+        }
         for (int l = 0; l < nl; l++)
             for (int r = 0; r < d->numRef[l]; r++)
             {
                 const x265hip_tme_host_ref& R = d->refs[l][r];
                 if (R.refTable) for (int sl : t->slots) h = hash_bytes(h, &R.refTable[(size_t)c * 593 + sl], sizeof(x265hip_inter_choice));
+                if (R.lowresMv)      /* the lookahead's MVs of the CTU's 16x16 blocks */
+                    for (int by = cy * t->ctu / 16; by < std::min((cy + 1) * t->ctu, d->height + 15) / 16; by++)
+                        for (int bx = cx * t->ctu / 16; bx < std::min((cx + 1) * t->ctu / 16, d->lowresBlocksX); bx++)
+                            h = hash_bytes(h, R.lowresMv + 2 * ((size_t)by * d->lowresBlocksX + bx), 2 * sizeof(int16_t));
+                h = mix(h, (uint64_t)(R.lowresMv != nullptr) * 2 + (R.refTable != nullptr));
                 for (int k = 0; k < 2; k++)
                 {
                     if (k && R.reconPlane == R.mePlane) break;
