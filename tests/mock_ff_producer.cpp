@@ -1,7 +1,7 @@
 /*
  * mock_ff_producer.cpp -- TEST INFRASTRUCTURE ONLY (tests/test_ff_adapter_cpu.py builds it with g++): the in-loop filter producer's entry points (include/x265hip_ctx.h:
  * x265hip_ff_create / _picture) answered WITHOUT a GPU by the oracle's plain-C deblocking filter and SAO statistics (oracle/x265_oracle.c in oracle/libx265oracle_me_8.so, named
- * by X265MOCK_ORACLE_LIB; pinned to the reference's Deblock / SAO classes by tests/test_filters_oracle_vs_ref.py), so that the host half of the seam --
+ * by X265MOCK_ORACLE_LIB; pinned to the reference's Deblock / SAO classes by tests/test_deblock_oracle_vs_ref.py, tests/test_sao_oracle_vs_ref.py), so that the host half of the seam --
  * integration/filter_adapter.cpp: the gather of CUData's arrays, the deferral of a picture's filters to its last row, the replay of the encoder's row loop behind the call -- can be
  * driven by the compiled reference encoder (oracle/_ref/x265e2e_8) on the CPU: the encode must write the plain encoder's bitstream.
  * It checks what x265hip_ff_picture checks (the description complete for what is asked) and X265MOCK_FAIL_AT=n makes the n-th call fail.

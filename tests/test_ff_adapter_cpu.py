@@ -1,8 +1,8 @@
 """The host half of the in-loop filter seam without a GPU: integration/filter_adapter.cpp inside the compiled reference encoder (oracle/_ref/x265e2e_8), with
 tests/mock_ff_producer.cpp standing in for x265hip_ff_picture -- answered by the oracle's plain-C deblocking filter and SAO statistics (oracle/x265_oracle.c, pinned to the
-reference's Deblock / SAO classes in tests/test_filters_oracle_vs_ref.py).  The gather of CUData's arrays, the deferral of a picture's filters to its last row and the replay of
+reference's Deblock / SAO classes in tests/test_deblock_oracle_vs_ref.py, tests/test_sao_oracle_vs_ref.py).  The gather of CUData's arrays, the deferral of a picture's filters to its last row and the replay of
 the encoder's row loop behind the call are then all that stands between the plain encoder's bitstream and this one: they must be the same bitstream.
-(The device kernels against the same oracle: tests/test_filters_gpu.py; the GPU producer inside the encoder: tests/test_e2e_ff_gpu.py.)"""
+(The device kernels against the same oracle: tests/test_deblock_gpu.py, tests/test_sao_gpu.py, tests/test_ff_host_gpu.py; the GPU producer inside the encoder: tests/test_e2e_ff_gpu.py.)"""
 import hashlib
 import json
 import os
