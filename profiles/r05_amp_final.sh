@@ -3,6 +3,8 @@
 # masked kernels under the fence (end mode: the masked lanes read up to 16 pixels right of the PU -- inside the plane's margin; a read past the plane buffer would fault here)
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
+# (0) first what only this session can do: X265TME_AHEAD on the real producer (bitstream tests + A/B), a few minutes
+timeout 500 bash profiles/r05_ahead_ab.sh > gpurun_out/r05_ahead_ab.log 2>&1; tail -15 gpurun_out/r05_ahead_ab.log
 timeout 420 bash profiles/collect_preset_exact.sh r05_pe 4320p10_slower > gpurun_out/r05_pe.log 2>&1
 if python -c "import json,sys; d=json.load(open('gpurun_out/r05_pe/preset_exact_valu.json')); sys.exit(0 if 'r05_pe' in d['4320p10_slower']['source'] else 1)"; then cp gpurun_out/r05_pe/preset_exact_valu.json profiles/preset_exact_valu.json; fi
 tail -12 gpurun_out/r05_pe.log
