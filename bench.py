@@ -211,7 +211,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
         default_runs = {}
         if both:
             # (256 pool threads under whatever CPU quota the box gives them: the clock of one run moves by +-10 %, so the GPU run is taken three times, the plain CPU run twice)
-            for name, tme_on, tme, la, ff, reps in (("cpu_default_threading", 0, 0, 0, 0, 3), ("cpu_default_threading_tme", 1, 0, 0, 0, 1), ("all_gpu_default_threading", 1, 1, 1, 1, 3),
+            for name, tme_on, tme, la, ff, reps in (("cpu_default_threading", 0, 0, 0, 0, 3), ("cpu_default_threading_tme", 1, 0, 0, 0, 3), ("all_gpu_default_threading", 1, 1, 1, 1, 3),
                                                     ("gpu_lookahead_default_threading", 0, 0, 1, 0, 3)):
                 got = []
                 for rep in range(reps):
@@ -233,10 +233,19 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
                     default_runs[name] = med
             # the encoder's own per-frame clocks for the plain and the GPU run (a run each, not part of the fps figures: the statistics cost the ThreadedME runs some speed)
             for name, tme_on, tme, la in (("cpu_default_threading", 0, 0, 0), ("all_gpu_default_threading", 1, 1, 1)):
-                env = dict(os.environ, X265TME=str(tme_on), X265TMEGPU=str(tme), X265LAGPU=str(la), X265FFGPU="0", X265_CLI_THREADING="1", MALLOC_PERTURB_="85", X265_FRAME_STATS="1")
+                # ... and the encoder's own quality accounting of the same run (x265_stats: bitrate, global PSNR / SSIM): the bitstream is the fps runs' (checked), and a run with
+                # --threaded-me does not write the plain encoder's bitstream -- their speeds mean something only next to what each spent and kept
+                env = dict(os.environ, X265TME=str(tme_on), X265TMEGPU=str(tme), X265LAGPU=str(la), X265FFGPU="0", X265_CLI_THREADING="1", MALLOC_PERTURB_="85", X265_FRAME_STATS="1", X265_QUALITY="1")
                 r = subprocess.run([exe, x265hip.lib_path(8), "1920", "1088", str(default_frames), "medium", os.path.join(td, "stats.hevc")], capture_output=True, text=True, env=env, timeout=900)
                 if r.returncode == 0 and name in default_runs and "fps" in default_runs[name]:
-                    default_runs[name]["frame_stats_ms_per_picture"] = json.loads(r.stdout.strip().splitlines()[-1]).get("frame_stats_ms_per_picture")
+                    si = json.loads(r.stdout.strip().splitlines()[-1])
+                    default_runs[name]["frame_stats_ms_per_picture"] = si.get("frame_stats_ms_per_picture")
+                    if si.get("quality"):
+                        q = dict(si["quality"])
+                        q["bytes"] = si["bytes"]
+                        # (the encoder measures PSNR / SSIM only at log level info, and its option-string SEI then spells "psnr ssim" instead of "no-psnr no-ssim": 6 bytes per SEI)
+                        q["bytes_more_than_the_fps_runs"] = si["bytes"] - default_runs[name]["bytes"]
+                        default_runs[name]["quality"] = q
     g, c = runs["tme_gpu"], runs["cpu"]
     best = runs.get("all_gpu", g)
     out = {"value": best["fps"], "unit": "frames/s", "measured": "this run",
@@ -266,7 +275,21 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
               "frame_threads": b.get("frame_threads") if b else None, "wpp": b.get("wpp") if b else None,
               "bitstream_identical_gpu_vs_cpu_producers": bool(a and b and a["md5"] == b["md5"] and a["bytes"] == b["bytes"] and b["md5_all_equal"]), "host": usable_cores()[1]}
         dt["encoder_clocks_ms_per_picture"] = {k: v.get("frame_stats_ms_per_picture") for k, v in ok.items() if v.get("frame_stats_ms_per_picture")}
+        # equal-quality reading of the two bitstreams (the plain encoder's; --threaded-me's, which the GPU producers write too) + the speed per CPU the host grants
+        qa, qb = (ok.get("cpu_default_threading") or {}).get("quality"), (b or {}).get("quality")
+        if qa and qb:
+            dt["quality"] = {"encoder_alone": qa, "threaded_me_gpu_producers": qb,
+                             "threaded_me_vs_encoder_alone": {"kbps_ratio": round(qb["kbps"] / qa["kbps"], 4) if qa["kbps"] else None, "psnr_y_db": round(qb["psnr_y"] - qa["psnr_y"], 4),
+                                                              "psnr_global_db": round(qb["psnr_global"] - qa["psnr_global"], 4), "ssim": round(qb["ssim"] - qa["ssim"], 6)},
+                             "note": "x265_encoder_get_stats of one extra run per bitstream (PSNR / SSIM accounting on; it reads the reconstruction and changes no decision; the option-string SEI differs by the two words, bytes_more_than_the_fps_runs). "
+                                     "--threaded-me replaces the per-CU motion search inside mode decision by searches made ahead of it per CTU: another bitstream than the plain encoder's, compared here at the same rate control"}
+        n_cpu = usable_cores()[0]
+        dt["fps_per_granted_cpu"] = {k: round(v["fps"] / max(1, n_cpu), 4) for k, v in ok.items()}
+        dt["granted_cpus"] = n_cpu
         if b:
+            ms = 1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"])
+            dt["producer_ceiling"] = {"tme_producer_ms_per_picture": round(ms, 2), "pictures_per_second_of_the_one_producer": round(1e3 / ms, 1) if ms > 0 else None,
+                                      "note": "one ThreadedME producer serves the encode (bands of every picture in flight take turns on it): whatever the host's core count, the encode cannot go faster than this"}
             dt["gpu_run"] = {"tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
                              "tme_adapter_seconds": b["adapter_seconds"], "la_estimates": b.get("la_estimates"), "la_producer_seconds": b.get("la_producer_seconds"),
                              "filter_pictures_gpu": b.get("ff_pictures"), "filter_pictures_left_to_the_cpu": b.get("ff_cpu_pictures"), "seconds": b["seconds"]}
@@ -790,14 +813,32 @@ def cpu_baseline(pipe, depth, n_ctus):
     tried = {}
     for c in sorted({n, min(n, 64)}, reverse=True):
         tried[c] = cpu_baseline_on(pipe, depth, n_ctus, c)
-    best = max(tried.values(), key=lambda r: r["value"])
-    best = dict(best)
+    best_c = max(tried, key=lambda c: tried[c]["value"])
+    best = dict(tried[best_c])
     best["host"] = info
     best["tried"] = {str(c): {"value": r["value"], "per_core": r["per_core"]} for c, r in tried.items()}
+    # the same C table at -O3 for the widest vector ISA of this host (BASELINE.md section 4's stand-in for the asm table: no assembler here or on the GPU box), at the better core
+    # count; `value` is the FASTER of the builds, `builds` lists both with their per-core figures
+    from refproc import widest_variant
+    builds = {"O2": {"value": best["value"], "per_core": best["per_core"], "cores": best["cores"], "flags": "-O2 (no asm)"}}
+    var = widest_variant(depth)
+    if var:
+        r = cpu_baseline_on(pipe, depth, n_ctus, best_c, variant=var)
+        name = "O3_x86-64-%s" % var
+        builds[name] = {"value": r["value"], "per_core": r["per_core"], "cores": r["cores"], "flags": "-O3 -march=x86-64-%s (no asm; auto-vectorised C, %s)" % (var, "AVX-512" if var == "v4" else "AVX2"),
+                        "sample": r["sample"]}
+        if r["value"] > best["value"]:
+            keep = {k: best[k] for k in ("host", "tried")}
+            best = dict(r)
+            best.update(keep)
+            best["build"] = name
+    best.setdefault("build", "O2")
+    best["builds"] = builds
+    best["builds_note"] = "asm not built: no nasm / yasm and no system libx265 on this host (asm_probe); the reference's TestBench asserts asm == C bit-exactly, so the C table is the specification and its -O3 vector build the nearest timed stand-in"
     return best
 
 
-def cpu_baseline_on(pipe, depth, n_ctus, cores):
+def cpu_baseline_on(pipe, depth, n_ctus, cores, variant=""):
     """The reference's own C primitives + motionEstimate (oracle/_ref, built from /root/reference sources) on the same
     tasks the GPU just processed, one process per core of `cores`; falls back to the restated oracle when the binary is
     missing.  Also cross-checks the sample's results against the GPU's (parity in the same run)."""
@@ -840,7 +881,7 @@ def cpu_baseline_on(pipe, depth, n_ctus, cores):
     if ref_available(depth):
         kind = "reference"
         import tempfile
-        procs = [RefProc(depth) for _ in range(cores)]
+        procs = [RefProc(depth, variant) for _ in range(cores)]
         t0 = time.time()
         # the sample's two planes go to the processes once, through a file in memory (one process per core: 256 pipes would carry them 5 times each otherwise)
         shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
@@ -942,7 +983,7 @@ def cpu_baseline_on(pipe, depth, n_ctus, cores):
     return {"value": round(sample_px / busy / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": kind, "per_core": round(sample_px * (reps if kind == "reference" else 1) / max(total_cpu, 1e-9) / 1e6 / max(1, pipe.refs), 4),
             "sample": "%d CTU64 (%d luma px) of the same batch: ME pyramid (85 PUs/CTU) + %dx%d DCT+quant, %s; %d repetition(s), %.1f CPU-seconds in total, busiest core %.3f s per repetition; "
                       "results vs GPU: %s" % (n_ctus, sample_px, n_tu, n_tu,
-                                               "reference C primitives + motionEstimate (no asm), one process per core" if kind == "reference"
+                                               "reference C primitives + motionEstimate (no asm%s), one process per core" % (", -O3 -march=x86-64-" + variant if variant else "") if kind == "reference"
                                                else "restated oracle, single thread", reps, total_cpu, busy, parity)}
 
 

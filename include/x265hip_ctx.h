@@ -176,6 +176,10 @@ typedef struct x265hip_tme_picture_desc {
                                                   final, threadedme.cpp:121-150): only these rows' CTUs are searched, only their entries of table / median / temporal / qpIndex /
                                                   areaQpIndex / areaBestOut are read and written (the arrays keep the picture's CTU addressing).  0, 0 = the whole picture.
                                                   CTUs of a picture do not depend on each other (findJob takes them in any order), so bands in any order give the picture's table */
+    int pirStartCol, pirSafeX;                 /* --intra-refresh (Search::setSearchRange, search.cpp:4987-4996): in a P picture whose first reference has not finished its refresh sweep
+                                                  (its pirEndCol < numCuInWidth) the CUs of CTU columns left of the picture's own pirStartCol search no further right than
+                                                  4 * (pirSafeX - cuX) quarter-pels, pirSafeX = the reference's pirEndCol * ctuSize - 3.  pirStartCol = 0: no restriction
+                                                  (B pictures, intra refresh off, sweep finished)                                                     */
 } x265hip_tme_picture_desc;
 int  x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** tme);
 void x265hip_tme_destroy(x265hip_tme* tme);

@@ -199,6 +199,7 @@ typedef struct x265hip_tme_args {
     int frameParallel;                         /* != 0: m_bFrameParallel -- selectMVP does not cost a candidate with y >= (searchRange + 1) * 4 (search.cpp:2360-2365)           */
     int ctuFirst, ctuCount;                    /* only the CTUs ctuFirst .. ctuFirst + ctuCount - 1 (a band of whole CTU rows: ThreadedME under frame threads, threadedme.cpp:121-150);
                                                   every per-CTU array keeps the picture's addressing.  ctuCount 0 = the whole picture.  Chain kernels only               */
+    int pirStartCol, pirSafeX;                 /* x265hip_tme_picture_desc's (x265hip_ctx.h): the intra-refresh limit of the windows' right edge; 0 = none */
 } x265hip_tme_args;
 size_t x265hip_tme_workspace(int nCtu);
 int x265hip_tme_frame(void* stream, const x265hip_tme_args* args);

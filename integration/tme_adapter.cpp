@@ -13,7 +13,8 @@
  * final (x265hip_tme_host_ref::reconRowsValid / meRowsValid): it uploads and phase-interpolates a keyed plane incrementally.  The window and selectMVP restrictions of
  * m_bFrameParallel / m_refLagPixels are the producer's (desc.frameThreads).  With one frame thread every reference is complete and the band is the whole picture.
  *
- * Preconditions (checked): numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF; --slices only with one frame thread (the slice MV bounds of search.cpp:4999-5003 are not modelled).
+ * Preconditions (checked): numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF.  Handed back to the encoder's own body (with a line on stderr): --slices with several frame threads (the
+ * reference's ThreadedME reads uninitialised slice MV bounds there: nothing defined to reproduce) and --me sea with several frame threads (bands go through the chain kernels).
  */
 #include <atomic>
 #include <chrono>
@@ -114,10 +115,21 @@ namespace X265_NS {
 void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
 {
     if (!g_useGpu) { ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame); return; }
-    if (frame.m_param->bIntraRefresh)
-    {   /* --intra-refresh narrows the search windows of the columns left of the refresh column (search.cpp:4988-4997): not modelled by the producer -- the encoder's own body runs */
+    if (frame.m_param->frameNumThreads > 1 && frame.m_param->maxSlices > 1)
+    {   /* --slices with several frame threads: setSearchRange and selectMVP then read Search::m_sliceMinY / m_sliceMaxY (search.cpp:2367-2369, 4999-5003), which only
+           FrameEncoder::processRowEncoder ever sets, and only on the FRAME ENCODER's Analysis objects (frameencoder.cpp:1624-1629).  ThreadedME's workers have their own
+           (threadedme.cpp:69-73), whose two members no constructor and no caller initialises: the reference's own producer searches with whatever the allocation held.  There is
+           no defined behaviour to reproduce, so the encoder's own body runs (with this worker's members, exactly as without the binding) and the binding says so */
         static std::atomic<int> told{0};
-        if (!told.exchange(1)) fprintf(stderr, "tme_adapter: --intra-refresh: the encoder's own ThreadedME producer runs\n");
+        if (!told.exchange(1)) fprintf(stderr, "tme_adapter: --slices with several frame threads: the encoder's own ThreadedME producer runs (its slice MV bounds are uninitialised members)\n");
+        ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame);
+        return;
+    }
+    if (frame.m_param->frameNumThreads > 1 && frame.m_param->searchMethod == X265_SEA)
+    {   /* bands of CTU rows are served by the producer's chain kernels (DIA / HEX / UMH / STAR / FULL); its SEA path takes whole pictures only (kern_tme.hip: "a band of
+           CTUs is offered by the chain kernels only") -- with several frame threads the encoder's own body runs, as it did before the band protocol */
+        static std::atomic<int> told{0};
+        if (!told.exchange(1)) fprintf(stderr, "tme_adapter: --me sea with several frame threads: the encoder's own ThreadedME producer runs\n");
         ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame);
         return;
     }
@@ -226,7 +238,10 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
                     {
                         ok = slice->m_refFrameList[l][ref]->m_reconRowFlag[idx].get() != 0;
                         const MotionReference& mr = slice->m_mref[l][ref];
-                        if (ok && mr.isWeighted) ok = (int)mr.numSliceWeightedRows[0] >= idx;      /* applyWeight(idx, ...) has run (:1035-1036) */
+                        /* applyWeight(idx, ...) has run (:1035-1036).  The frame encoder writes the counter with a plain store after the plane's rows (reference.cpp:119-185): an
+                           acquire load keeps the compiler and this core from reading plane rows ahead of it; the WRITER's ordering is what x86's store order gives (the reference
+                           has no release there, and the file is not ours to change) -- on a weakly ordered host take weighted readiness from m_reconRowFlag alone */
+                        if (ok && mr.isWeighted) ok = (int)__atomic_load_n(&mr.numSliceWeightedRows[0], __ATOMIC_ACQUIRE) >= idx;
                     }
                 if (!ok) break;
             }
@@ -262,7 +277,6 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             j->sliceOfRow.assign((size_t)j->nCtuY, 0);
             if (p->maxSlices > 1)
             {
-                if (p->frameNumThreads > 1) { fprintf(stderr, "tme_adapter: --slices with several frame threads: the slice MV bounds are not modelled\n"); return nullptr; }
                 const uint32_t accu = ((uint32_t)j->nCtuY << 8) / p->maxSlices;
                 uint32_t rowSum = accu, sidx = 0;
                 for (uint32_t i = 0; i < (uint32_t)j->nCtuY; i++)
@@ -284,6 +298,13 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
             d.searchRange = p->searchRange; d.searchMethod = p->searchMethod; d.subpelRefine = p->subpelRefine;
             d.flags = getenv("X265TME_PROF") ? X265HIP_TME_PROFILE : 0;
             d.width = W; d.height = H; d.sourceHeight = p->sourceHeight; d.frameThreads = p->frameNumThreads;
+            /* --intra-refresh: Search::setSearchRange's test (search.cpp:4987-4996) -- a P picture whose first reference has not finished its sweep keeps the windows of the
+               CTU columns left of its own refresh column out of the reference's not yet refreshed columns; the per-CU part of the test (cuPelX) is the producer's */
+            if (p->bIntraRefresh && slice->m_sliceType == P_SLICE && slice->m_refFrameList[0][0]->m_encData->m_pir.pirEndCol < slice->m_sps->numCuInWidth)
+            {
+                d.pirStartCol = (int)frame.m_encData->m_pir.pirStartCol;
+                d.pirSafeX = (int)(slice->m_refFrameList[0][0]->m_encData->m_pir.pirEndCol * p->maxCUSize) - 3;
+            }
             const PicYuv* fenc = frame.m_fencPic;
             d.curPlane = fenc->m_picBuf[0]; d.stride = fenc->m_stride; d.origin = fenc->m_picOrg[0] - fenc->m_picBuf[0];
             d.planeElems = (int64_t)fenc->m_stride * (fenc->m_picHeight + 2 * fenc->m_lumaMarginY);

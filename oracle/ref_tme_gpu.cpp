@@ -83,6 +83,11 @@ int main(int argc, char** argv)
         if (eq) *eq = 0;
         if (x265_param_parse(p, argv[i], eq ? eq + 1 : NULL) < 0) { fprintf(stderr, "bad option %s\n", argv[i]); return 2; }
     }
+    /* X265_QUALITY=1: the encoder's own quality accounting (x265_stats: global PSNR / SSIM, bitrate) printed beside the fps -- a run with --threaded-me and a run without it write
+       different bitstreams, so their speeds are only comparable next to what each spent and what each kept.  The accounting reads the reconstructed pictures, it does not change
+       a decision: the bitstream is the one written without it */
+    const bool quality = getenv("X265_QUALITY") && atoi(getenv("X265_QUALITY"));
+    if (quality) { p->bEnablePsnr = 1; p->bEnableSsim = 1; p->logLevel = X265_LOG_INFO; }      /* (below log level info the encoder switches both off again: encoder.cpp:4349-4354) */
     const bool frameStats = getenv("X265_FRAME_STATS") && atoi(getenv("X265_FRAME_STATS"));      /* diagnosis: the encoder's own per-frame clocks (x265_frame_stats, csv-log-level 2) summed over the clip */
     if (frameStats) p->csvLogLevel = 2;
     FILE* out = fopen(argv[6], "wb");
@@ -122,6 +127,15 @@ int main(int argc, char** argv)
     x265_encoder_parameters(enc, live);
     const int tme = live->bThreadedME, frameThreads = live->frameNumThreads, wpp = live->bEnableWavefront;
     x265_param_free(live);
+    char qual[300] = "";
+    if (quality)
+    {
+        x265_stats st;
+        x265_encoder_get_stats(enc, &st, sizeof(st));
+        const double n = st.encodedPictureCount ? st.encodedPictureCount : 1;      /* (x265_stats::globalPsnrY / U / V are sums over the pictures: encoder.cpp:3101-3103) */
+        snprintf(qual, sizeof(qual), "\"quality\": {\"kbps\": %.2f, \"psnr_y\": %.4f, \"psnr_u\": %.4f, \"psnr_v\": %.4f, \"psnr_global\": %.4f, \"ssim\": %.6f, \"pictures\": %u}, ",
+                 st.bitrate, st.globalPsnrY / n, st.globalPsnrU / n, st.globalPsnrV / n, st.globalPsnr, st.globalSsim, st.encodedPictureCount);
+    }
     x265_encoder_close(enc); x265_picture_free(pic); x265_param_free(p);
     fclose(out);
     x265hip_tme_adapter_stats s;
@@ -151,7 +165,7 @@ int main(int argc, char** argv)
     if (frameStats && fsN)
         snprintf(fs, sizeof(fs), "\"frame_stats_ms_per_picture\": {\"pictures\": %d, \"wall\": %.1f, \"ctu_worker_time\": %.1f, \"threaded_me_tasks\": %.1f, \"rows_blocked_on_threaded_me\": %.1f, \"reference_wait\": %.1f, \"avg_wpp\": %.2f}, ",
                  fsN, fsWallMs / fsN, fsCtuMs / fsN, fsTmeMs / fsN, fsTmeWaitMs / fsN, fsRefWaitMs / fsN, fsWpp / fsN);
-    printf("{%s%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_bands\": %d, \"frame_threads\": %d, \"wpp\": %d, \"gpu_seconds\": %.3f, \"gpu_seconds_warm\": %.4f, \"gpu_calls_warm\": %d, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
-           la, fs, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.bands, frameThreads, wpp, s.producerSeconds, s.producerSecondsWarm, s.callsWarm, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
+    printf("{%s%s%s\"producer\": \"%s\", \"weighted_refs\": %d, \"frames\": %d, \"seconds\": %.3f, \"fps\": %.3f, \"bytes\": %zu, \"threaded_me\": %d, \"gpu_pictures\": %d, \"gpu_bands\": %d, \"frame_threads\": %d, \"wpp\": %d, \"gpu_seconds\": %.3f, \"gpu_seconds_warm\": %.4f, \"gpu_calls_warm\": %d, \"adapter_seconds\": %.3f, \"adapter_create_seconds\": %.3f, \"adapter_sections\": [%.3f, %.3f, %.3f, %.3f]}\n",
+           la, fs, qual, useGpu ? "gpu" : "cpu", s.weightedRefs, frames, secs, frames / secs, bytes, tme, s.pictures, s.bands, frameThreads, wpp, s.producerSeconds, s.producerSecondsWarm, s.callsWarm, s.adapterSeconds, s.createSeconds, s.sections[0], s.sections[1], s.sections[2], s.sections[3]);
     return 0;
 }

@@ -13,19 +13,39 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def ref_binary(depth):
-    return os.path.join(HERE, "_ref", "x265ref_%d" % depth)
+def ref_binary(depth, variant=""):
+    """variant "" = the -O2 build; "v3" / "v4" = the same sources at -O3 -march=x86-64-v3 / -v4 (oracle/Makefile)"""
+    return os.path.join(HERE, "_ref", "x265ref_%d%s" % (depth, "_" + variant if variant else ""))
 
 
-def ref_available(depth):
-    return os.access(ref_binary(depth), os.X_OK)
+def ref_available(depth, variant=""):
+    return os.access(ref_binary(depth, variant), os.X_OK)
+
+
+def widest_variant(depth):
+    """The widest -O3 build of the reference table this host can run (by /proc/cpuinfo), or None"""
+    try:
+        flags = set()
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = set(line.split(":", 1)[1].split())
+                break
+    except OSError:
+        return None
+    v4 = {"avx512f", "avx512bw", "avx512cd", "avx512dq", "avx512vl"}
+    v3 = {"avx2", "bmi1", "bmi2", "fma", "movbe", "f16c", "abm"}
+    if v4 <= flags and v3 <= flags and ref_available(depth, "v4"):
+        return "v4"
+    if v3 <= flags and ref_available(depth, "v3"):
+        return "v3"
+    return None
 
 
 class RefProc:
-    def __init__(self, depth):
+    def __init__(self, depth, variant=""):
         self.depth = depth
         self.pixel = np.uint8 if depth == 8 else np.uint16
-        self.p = subprocess.Popen([ref_binary(depth)], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+        self.p = subprocess.Popen([ref_binary(depth, variant)], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
 
     def close(self):
         if self.p:

@@ -20,10 +20,10 @@ from refproc import RefProc, ref_available  # noqa: E402
 class Ref:
     """Reference process with the Oracle's vocabulary."""
 
-    def __init__(self, depth):
+    def __init__(self, depth, variant=""):
         self.depth = depth
         self.pixel = np.uint8 if depth == 8 else np.uint16
-        self.r = RefProc(depth)
+        self.r = RefProc(depth, variant)
 
     def close(self):
         self.r.close()

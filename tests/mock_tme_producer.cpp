@@ -41,7 +41,7 @@ struct x265hip_tme
     std::vector<x265hip_tme_step> steps;
     std::vector<int> slots;
     std::map<int, int> rowsDone;                 /* per POC: CTU rows that have their records */
-    long calls = 0, bands = 0;
+    long calls = 0, bands = 0, pirPictures = 0;
 };
 
 namespace {
@@ -97,6 +97,7 @@ void x265hip_tme_destroy(x265hip_tme* t)
 {
     if (!t) return;
     fprintf(stderr, "mock_tme_producer: %ld calls, %ld of them bands of a picture\n", t->calls, t->bands);
+    if (t->pirPictures) fprintf(stderr, "mock_tme_producer: %ld pictures with an intra-refresh window limit\n", t->pirPictures);
     delete t;
 }
 int x265hip_tme_entries(const x265hip_tme* t, const x265hip_tme_step** steps) { if (!t) return 0; if (steps) *steps = t->steps.data(); return (int)t->steps.size(); }
@@ -111,6 +112,10 @@ int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_desc* d)
     for (int l = 0; l < nl; l++) if (d->numRef[l] < 1 || d->numRef[l] > X265HIP_MAX_REF) return fail("tme_picture: %d references in list %d", d->numRef[l], l);
     if (d->ctuRowFirst < 0 || d->ctuRowCount < 0 || d->ctuRowFirst + d->ctuRowCount > t->nCtuY || (d->ctuRowFirst && !d->ctuRowCount)) return fail("tme_picture: CTU rows %d + %d of %d", d->ctuRowFirst, d->ctuRowCount, t->nCtuY);
     const int row0 = d->ctuRowFirst, row1 = d->ctuRowCount ? row0 + d->ctuRowCount : t->nCtuY;
+    /* --intra-refresh (search.cpp:4987-4996): only P pictures carry the limit; the safe column lies at or right of the picture's own refresh column (encoder.cpp:1095-1106) */
+    if (d->pirStartCol < 0 || d->pirStartCol > t->nCtuX || (d->pirStartCol && (!d->isP || d->pirSafeX < d->pirStartCol * t->ctu - 3 || d->pirSafeX >= (t->nCtuX + 1) * t->ctu)))
+        return fail("POC %d: intra-refresh fields: start column %d, safe x %d (%s picture, %d CTU columns)", d->curPOC, d->pirStartCol, d->pirSafeX, d->isP ? "P" : "B", t->nCtuX);
+    if (d->pirStartCol) t->pirPictures += row0 == 0;
     t->calls++; if (d->ctuRowCount) t->bands++;
     if (getenv("X265MOCK_FAIL_AT") && t->calls == atol(getenv("X265MOCK_FAIL_AT"))) return fail("call %ld fails on request (X265MOCK_FAIL_AT)", t->calls);
     /* bands of a picture: in order, contiguous, once */
@@ -142,6 +147,7 @@ int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_desc* d)
     {
         const int cy = c / t->nCtuX, cx = c % t->nCtuX;
         uint64_t h = mix(0x1234, (uint64_t)d->curPOC * 4099 + (uint64_t)c);
+        if (cx < d->pirStartCol) h = mix(h, (uint64_t)d->pirSafeX + 77);       /* the window limit of this CTU's CUs is an input of its records */
         for (int k = 0; k < nS; k++) h = mix(h, (uint64_t)d->qps[d->qpIndex[(size_t)c * nS + k]]);
         for (int a = 0; a < 5; a++) h = mix(h, (uint64_t)d->qps[d->areaQpIndex[(size_t)c * 5 + a]]);
         h = hash_bytes(h, d->temporal + (size_t)c * nS * 2, (size_t)nS * 2 * sizeof(x265hip_tme_temporal));

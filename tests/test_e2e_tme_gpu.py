@@ -40,6 +40,8 @@ def encode(depth, producer, args, out):
                                         (10, ["192", "128", "7", "veryslow", "ref=6"]),
                                         (8, ["256", "256", "6", "medium", "slices=2", "wpp=1"]),                                         # two slices of two CTU rows
                                         (10, ["192", "320", "5", "slow", "slices=3", "wpp=1"]),
+                                        (8, ["320", "192", "9", "medium", "intra-refresh=1", "keyint=5", "bframes=0"]),              # a refresh column sweeps the picture: windows left of it stop at the reference's refreshed part
+                                        (10, ["448", "128", "9", "slow", "intra-refresh=1", "keyint=6", "bframes=0", "ref=2"]),
                                         (8, ["1920", "1080", "3", "medium"])])                                                  # BASELINE configs[1] at its own size
 def test_bitstream_identical_with_gpu_producer(depth, args, tmp_path):
     cpu, h_cpu = encode(depth, "cpu", args, str(tmp_path / "cpu.hevc"))
@@ -56,6 +58,7 @@ def test_bitstream_identical_with_gpu_producer(depth, args, tmp_path):
                                         (10, ["192", "576", "7", "slow", "frame-threads=3", "wpp=1"]),
                                         (8, ["256", "640", "10", "medium", "frame-threads=3", "wpp=1", "ref=2", "weightp=1", "bframes=0", "fades=1"]),   # weighted planes grow row by row
                                         (8, ["320", "704", "8", "slower", "frame-threads=2", "wpp=1", "merange=25"]),                 # a smaller window: fewer lag rows, more bands
+                                        (8, ["384", "512", "9", "medium", "frame-threads=3", "wpp=1", "intra-refresh=1", "keyint=5", "bframes=0"]),   # --intra-refresh under frame threads
                                         (8, ["1920", "1080", "6", "medium", "frame-threads=4", "wpp=1"])])                             # BASELINE configs[1] at its own size, threaded as the CLI threads it
 def test_bitstream_identical_with_gpu_producer_under_frame_threads(depth, args, tmp_path):
     """The encoder's default threading (frame threads + WPP, encoder.cpp:285): a picture starts while its references are still being coded; ThreadedME gets its CTU rows as the
@@ -70,6 +73,16 @@ def test_bitstream_identical_with_gpu_producer_under_frame_threads(depth, args, 
     assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
     print("e2e frame threads", depth, args, "bands %d for %d pictures, weighted refs %d" % (gpu["gpu_bands"], gpu["gpu_pictures"], gpu["weighted_refs"]),
           "cpu fps %.2f gpu fps %.2f" % (cpu["fps"], gpu["fps"]))
+
+
+@pytest.mark.parametrize("args,why", [(["192", "640", "6", "medium", "frame-threads=3", "wpp=1", "me=sea"], "sea"), (["256", "512", "6", "medium", "frame-threads=3", "wpp=1", "slices=2"], "slices")])
+def test_what_goes_back_to_the_encoders_own_producer_under_frame_threads(args, why, tmp_path):
+    """--me sea with frame threads (bands are served by the chain kernels; SEA takes whole pictures) and --slices with frame threads (the reference's ThreadedME reads
+    uninitialised slice MV bounds: nothing defined to reproduce): the binding hands the CTUs back to the encoder's own body and the encode writes the reference's bitstream."""
+    cpu, h_cpu = encode(8, "cpu", args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(8, "gpu", args, str(tmp_path / "gpu.hevc"))
+    assert gpu["gpu_pictures"] == 0 and gpu["frame_threads"] == 3
+    assert h_cpu == h_gpu
 
 
 def test_more_references_than_the_tables_hold_is_an_argument_error():

@@ -56,3 +56,26 @@ def test_known_answers_from_survey(depth):
     assert ora.sa8d(32, a, 64, 0, b, 64, 0) == exp[2]
     c = ora.dct(32, r, 32)  # the survey driver used a dense 32-wide residual
     assert (int(c[0]), int(c[1]), int(c[32])) == exp[3]
+
+
+@pytest.mark.parametrize("depth", GOLDEN_DEPTHS)
+def test_vector_builds_of_the_reference_table_return_what_the_O2_build_returns(depth):
+    """bench.py's cpu_baseline also times the reference's C table at -O3 -march=x86-64-v3 / -v4 (oracle/Makefile: the stand-in for the asm table, which cannot be
+    assembled here).  A faster build that computed something else would be no baseline: every case family through the widest build this host runs against the -O2 build."""
+    from refproc import widest_variant
+    var = widest_variant(depth)
+    if not ref_available(depth) or var is None:
+        pytest.skip("no -O3 vector build of the reference table for this host")
+    rng = np.random.default_rng(0xBEEF + depth)
+    a, b = Ref(depth), Ref(depth, var)
+    n = 0
+    try:
+        for family in sorted(FAMILIES):
+            for label, method, args in FAMILIES[family](depth, rng):
+                if n % 3 == 0:          # a third of the cases: the families are large and this is the same source twice
+                    assert same(run_case(a, method, args), run_case(b, method, args)), "%s (depth %d): -O3 %s build != -O2 build" % (label, depth, var)
+                n += 1
+    finally:
+        a.close()
+        b.close()
+    assert n > 200

@@ -88,10 +88,33 @@ def test_weighted_references_and_the_rectangular_schedule_under_frame_threads(mo
     assert slow[0]["md5"] == slow[1]["md5"]
 
 
-def test_slices_with_frame_threads_are_refused_loudly(mock, tmp_path):
-    """--slices with several frame threads: the slice MV bounds of search.cpp:4999-5003 are not modelled -- the binding says so and ends the encode (no silent CPU fallback)."""
-    r = encode(mock, tmp_path, "s", frames=6, env={"X265_CLI_THREADING": "1"}, options=THREADS + ("slices=2",), timeout=60)
-    assert r["rc"] == 3 and "slice MV bounds are not modelled" in r["stderr"]
+def test_what_the_producer_does_not_take_under_frame_threads_goes_back_to_the_encoders_own_body(mock, tmp_path):
+    """--slices with several frame threads (the reference's ThreadedME workers read Search::m_sliceMinY / m_sliceMaxY, which nothing initialises on THEIR Analysis objects:
+    frameencoder.cpp:1624 sets the frame encoder's only -- no defined behaviour to reproduce) and --me sea with several frame threads (bands are served by the chain kernels): the
+    binding hands every CTU to the encoder's own body, says so once on stderr, and the encode writes what it writes without the binding."""
+    for name, opts in (("slices", ("slices=2",)), ("sea", ("me=sea",))):
+        with_binding = encode(mock, tmp_path, name + "_b", frames=6, env={"X265_CLI_THREADING": "1"}, options=THREADS + opts)
+        without = encode(mock, tmp_path, name + "_c", frames=6, env={"X265_CLI_THREADING": "1", "X265TMEGPU": "0"}, options=THREADS + opts)
+        assert with_binding["rc"] == 0 and without["rc"] == 0, with_binding["stderr"][-400:]
+        assert "the encoder's own ThreadedME producer runs" in with_binding["stderr"] and with_binding["gpu_pictures"] == 0
+        assert with_binding["threaded_me"] == 1 and with_binding["frame_threads"] == 5
+        assert with_binding["md5"] == without["md5"]
+
+
+def test_intra_refresh_hands_the_window_limit_over(mock, tmp_path):
+    """--intra-refresh: P pictures whose first reference has not finished its sweep carry pirStartCol / pirSafeX (Search::setSearchRange, search.cpp:4987-4996); the mock checks
+    their range on every call and folds the limit into the records of the CTU columns it applies to.  One and five frame threads, two band policies: no violation, the pictures
+    go through the producer (no fallback), one bitstream per threading."""
+    one = encode(mock, tmp_path, "ir1", frames=8, size=(832, 480), options=("intra-refresh=1", "keyint=6", "bframes=0"))
+    assert one["rc"] == 0 and "PROTOCOL VIOLATION" not in one["stderr"], one["stderr"][-600:]
+    assert one["gpu_pictures"] == 7 and "own ThreadedME producer" not in one["stderr"]
+    assert "pictures with an intra-refresh window limit" in one["stderr"]
+    runs = [encode(mock, tmp_path, "ir5_%d" % i, frames=8, size=(832, 480), env=dict(e, X265_CLI_THREADING="1"), options=("pools=48", "frame-threads=4", "intra-refresh=1", "keyint=6", "bframes=0"))
+            for i, e in enumerate(({"X265TME_MIN_ROWS": "1", "X265TME_WAIT_US": "0"}, {"X265TME_AHEAD": "1"}))]
+    for r in runs:
+        assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+        assert r["gpu_pictures"] == 7 and "pictures with an intra-refresh window limit" in r["stderr"]
+    assert runs[0]["md5"] == runs[1]["md5"]
 
 
 @pytest.mark.parametrize("options", [("bframes=0",), ("ref=5", "weightb=1"), ("ctu=32",), ("merange=24",), ("merange=120",), ("rect=1", "amp=1"), ("keyint=5", "min-keyint=5", "b-pyramid=0")],

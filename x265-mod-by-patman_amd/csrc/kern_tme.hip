@@ -223,6 +223,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
         A.s.isP = a->isP; A.s.numRef[0] = a->numRef[0]; A.s.numRef[1] = a->isP ? 0 : a->numRef[1]; A.s.searchRange = a->searchRange; A.s.picW = a->picWidth; A.s.picH = a->picHeight;
         A.s.ctuSize = a->ctuSize; A.s.numCtuX = nCtuX; A.s.lowresBlocksX = a->lowresBlocksX; A.s.stride = a->stride; A.s.origin = a->origin;
         A.s.frameParallel = a->frameParallel != 0; A.s.refLag = a->refLagPixels > 0 ? a->refLagPixels : a->picHeight;
+        A.s.pirStartCol = a->pirStartCol; A.s.pirSafeX = a->pirSafeX;
         A.s.amvp.curPOC = a->curPOC; A.s.amvp.temporalMvp = a->temporalMvp;
         for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) A.s.amvp.refPOC[l][r] = a->refPOC[l][r];
         for (int q = 0; q < a->nQp; q++) A.lambdas.v[q] = a->lambdas[q];
@@ -294,6 +295,7 @@ extern "C" int x265hip_tme_frame(void* stream, const x265hip_tme_args* a)
     s.isP = a->isP; s.numRef[0] = a->numRef[0]; s.numRef[1] = a->isP ? 0 : a->numRef[1]; s.searchRange = a->searchRange; s.picW = a->picWidth; s.picH = a->picHeight;
     s.ctuSize = a->ctuSize; s.numCtuX = nCtuX; s.lowresBlocksX = a->lowresBlocksX; s.stride = a->stride; s.origin = a->origin;
     s.frameParallel = a->frameParallel != 0; s.refLag = a->refLagPixels > 0 ? a->refLagPixels : a->picHeight;
+    s.pirStartCol = a->pirStartCol; s.pirSafeX = a->pirSafeX;
     s.amvp.curPOC = a->curPOC; s.amvp.temporalMvp = a->temporalMvp;
     for (int l = 0; l < 2; l++) for (int r = 0; r < 16; r++) s.amvp.refPOC[l][r] = a->refPOC[l][r];
     const dim3 grid((nCtu + 255) / 256), block(256);

@@ -129,7 +129,7 @@ struct x265hip_tme
     std::vector<int32_t> slots; int32_t* dSlots = nullptr; x265hip_inter_choice* dPacked = nullptr; x265hip_inter_choice* hPacked = nullptr; bool sparse = false;
     // reconstructed reference pictures stay on the device (plane + its 16 phase planes) under the caller's key; the least recently used of kKeep makes room
     struct Kept { uint64_t key = 0; pixel* plane = nullptr; pixel* phase = nullptr; uint64_t used = 0; int rowsSeen = 0; };      // rowsSeen: plane rows on the device so far (a reference that is still being reconstructed grows)
-    std::vector<Kept> kept; uint64_t tick = 0;
+    std::vector<Kept> kept; uint64_t tick = 0; int evictions = 0;
     int rowQp[64];                                                // the qp whose MVD cost row sits in row q of costTable (rows are kept across pictures)
     bool prof = false, first = false; double sec[5] = {}; int pictures = 0;      // X265HIP_TME_PROF: upload, diamond stage, submit, drain, (total)
     template<class T> int alloc(T*& p, size_t n, const char* file = __builtin_FILE(), int line = __builtin_LINE())
@@ -143,7 +143,15 @@ struct x265hip_tme
 
 namespace {
 constexpr int kHalf = 1 << 15, kBitsHalf = 1 << 15;
-constexpr int kKeep = 40;                  // planes kept on the device under a key (16 references + the ones just replaced; with frame threads the references and weighted planes of every picture in flight); 17 planes each
+constexpr int kKeepMax = 40, kKeepMin = 12;   // planes kept on the device under a key (16 references + the ones just replaced; with frame threads the references and weighted planes of every picture in flight); 17 planes each
+constexpr size_t kKeepBytes = (size_t)32 << 30;   // ... within a byte budget: 40 slots of 4K 10 bit are 12.9 GB, of 8K they would be 50 GB -- 8K keeps 25 (X265HIP_TME_KEEP_BYTES overrides the budget)
+int keep_slots(size_t elems)
+{
+    size_t budget = kKeepBytes;
+    if (const char* e = getenv("X265HIP_TME_KEEP_BYTES")) { const long long v = atoll(e); if (v > 0) budget = (size_t)v; }
+    const size_t perSlot = elems * 17 * sizeof(pixel);
+    return (int)std::max<size_t>(kKeepMin, std::min<size_t>(kKeepMax, perSlot ? budget / perSlot : kKeepMax));
+}
 }
 
 extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int ctuSize, int minCuSize, int rect, int amp, x265hip_tme** out)
@@ -194,6 +202,7 @@ extern "C" void x265hip_tme_destroy(x265hip_tme* t)
     if (t->prof && t->pictures)
         fprintf(stderr, "x265hip_tme: %d pictures, per picture: upload + phase planes %.2f ms, diamond stage %.2f ms, submit %.2f ms, drain + table down %.2f ms\n", t->pictures,
                 1e3 * t->sec[0] / t->pictures, 1e3 * t->sec[1] / t->pictures, 1e3 * t->sec[2] / t->pictures, 1e3 * t->sec[3] / t->pictures);
+    if (t->prof && t->evictions) fprintf(stderr, "x265hip_tme: %d kept planes were replaced while they held rows (%d slots)\n", t->evictions, (int)t->kept.size());
     if (t->hPacked) (void)hipHostFree(t->hPacked);
     for (void* p : t->owned) (void)xh::dev_free(p);
     for (auto& kv : t->costRows) (void)xh::dev_free(kv.second);
@@ -214,6 +223,13 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     for (int l = 0; l < nl; l++)      // before anything is indexed by it: refs[][] and every per-reference array here hold X265HIP_MAX_REF entries
         if (d->numRef[l] < 1 || d->numRef[l] > X265HIP_MAX_REF) { set_error("tme_picture: %d references in list %d (1..%d)", d->numRef[l], l, X265HIP_MAX_REF); return X265HIP_EARG; }
     if (d->width != t->width || d->height != t->height) { set_error("tme_picture: %dx%d picture on a %dx%d producer", d->width, d->height, t->width, t->height); return X265HIP_EARG; }
+    if (d->pirStartCol < 0 || d->pirStartCol > t->nCtuX || (d->pirStartCol && (!d->isP || d->pirSafeX < -3 || d->pirSafeX > X265HIP_MAX_PIC_DIM)))
+    { set_error("tme_picture: intra-refresh fields: start column %d of %d, safe x %d (%s picture)", d->pirStartCol, t->nCtuX, d->pirSafeX, d->isP ? "P" : "B"); return X265HIP_EARG; }
+    // the band's qp indices name rows of the cost table and entries of `lambdas` on the device (nQp of them): an index beyond them would be an out-of-range device read
+    for (size_t i = (size_t)c0 * 5; i < (size_t)(c0 + nCtu) * 5; i++)
+        if (d->areaQpIndex[i] >= d->nQp) { set_error("tme_picture: areaQpIndex[%zu] = %d with %d qps", i, (int)d->areaQpIndex[i], d->nQp); return X265HIP_EARG; }
+    for (size_t i = (size_t)c0 * nS; i < (size_t)(c0 + nCtu) * nS; i++)
+        if (d->qpIndex[i] >= d->nQp) { set_error("tme_picture: qpIndex[%zu] = %d with %d qps", i, (int)d->qpIndex[i], d->nQp); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(x265hip_ctx_device(t->ctx)));      // the caller may be any thread of the encoder's pool (a new thread starts on device 0)
     hipStream_t st = (hipStream_t)x265hip_ctx_stream(t->ctx);
     t->prof = (d->flags & X265HIP_TME_PROFILE) != 0;
@@ -266,7 +282,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                     for (auto& kp : t->kept) if (kp.key == key) slot = &kp;
                     if (!slot)
                     {
-                        if ((int)t->kept.size() < kKeep)
+                        if ((int)t->kept.size() < keep_slots((size_t)elems))
                         {
                             t->kept.emplace_back(); slot = &t->kept.back();
                             if ((rc = t->alloc(slot->plane, (size_t)elems)) || (rc = t->alloc(slot->phase, (size_t)elems * 16))) { t->kept.pop_back(); return rc; }
@@ -275,6 +291,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                         {   // least recently used, not one this picture already took
                             for (auto& kp : t->kept) if (kp.used != t->tick + 1 && (!slot || kp.used < slot->used)) slot = &kp;
                             if (!slot) { set_error("tme_picture: more distinct reference pictures than kept planes"); return X265HIP_EARG; }
+                            if (slot->rowsSeen) t->evictions++;      // a plane that was on the device goes: if its picture is asked for again it is uploaded whole (reported by x265hip_tme_destroy under X265HIP_TME_PROFILE)
                         }
                         slot->key = 0;                      // named only once its planes are on their way (below): a failed call must not leave a keyed slot with stale planes
                         slot->rowsSeen = 0;
@@ -351,7 +368,9 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
                 x265hip_me_task k{};
                 k.curOff = k.refOff = (int32_t)(d->origin + (int64_t)cy * d->stride + cx);
                 // Search::setSearchRange(cu, MV(0,0), 32) >> 2 (search.cpp:4969-5021) with CUData::clipMv's limits of this CU
-                const int xmin = -((t->ctu + 8 + cx - 1) << 2), ymin = -((t->ctu + 8 + cy - 1) << 2), xmax = (d->width + 8 - cx - 1) << 2, ymax = (d->height + 8 - cy - 1) << 2;
+                const int xmin = -((t->ctu + 8 + cx - 1) << 2), ymin = -((t->ctu + 8 + cy - 1) << 2), ymax = (d->height + 8 - cy - 1) << 2;
+                int xmax = (d->width + 8 - cx - 1) << 2;
+                if (cx / t->ctu < d->pirStartCol) xmax = std::min(xmax, (d->pirSafeX - cx) * 4);       // --intra-refresh (search.cpp:4987-4996): the min is outermost below as it is there
                 const int dd = 32 << 2;
                 k.mvmin[0] = (int16_t)(std::min(xmax, std::max(xmin, -dd)) >> 2); k.mvmin[1] = (int16_t)(std::min(ymax, std::max(ymin, -dd)) >> 2);
                 k.mvmin[1] = (int16_t)std::min((int)k.mvmin[1], refLag);                                  // m_refLagPixels on both ends (search.cpp:5017-5018)
@@ -383,6 +402,7 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     a.searchRange = d->searchRange; a.searchMethod = d->searchMethod; a.subpelRefine = d->subpelRefine;
     a.picWidth = d->width; a.picHeight = d->height; a.ctuSize = t->ctu; a.lowresBlocksX = d->lowresBlocksX;
     a.refLagPixels = refLag; a.frameParallel = d->frameThreads > 1; a.flags = d->flags;
+    a.pirStartCol = d->pirStartCol; a.pirSafeX = d->pirSafeX;
     a.curPlane = t->cur; a.stride = d->stride; a.origin = d->origin; a.planeElems = elems;
     for (int l = 0; l < nl; l++)
         for (int r = 0; r < d->numRef[l]; r++)

@@ -24,6 +24,7 @@ struct Slice
 {
     int isP, numRef[2], searchRange, picW, picH, ctuSize, numCtuX, lowresBlocksX;
     int refLag, frameParallel;               // Search::m_refLagPixels (full pel; search.cpp:96) and m_bFrameParallel
+    int pirStartCol, pirSafeX;               // --intra-refresh: CUs of CTU columns < pirStartCol keep their windows left of 4 * (pirSafeX - cuX) (search.cpp:4987-4996); 0 = off
     x265hip_amvp_params amvp;
     intptr_t stride; int64_t origin;
 };
@@ -146,6 +147,9 @@ __device__ __forceinline__ void tme_build(const Slice& s, const x265hip_tme_step
     // the window is derived on the device as clamp(mvp -+ range, limits) >> 2; setSearchRange's last clamp, min(full-pel y, m_refLagPixels) on both ends
     // (search.cpp:5017-5018), is the same as an upper quarter-pel limit of 4 * lag + 3
     c[3] = min(c[3], (s.refLag << 2) + 3);
+    // --intra-refresh: mvmax.x = min(mvmax.x, safe), mvmin.x = min(mvmin.x, safe) after clipMv (search.cpp:4993-4995) -- the window's clamp has its min outermost, so
+    // that is an upper quarter-pel limit as well (clip_limits itself stays CUData::clipMv: selectMVP's candidates are not touched by the refresh)
+    if ((ctuX + st.cuX) / s.ctuSize < s.pirStartCol) c[2] = min(c[2], (s.pirSafeX - (ctuX + st.cuX)) * 4);
     a.mvmin[0] = (int16_t)c[0]; a.mvmin[1] = (int16_t)c[1]; a.mvmax[0] = (int16_t)c[2]; a.mvmax[1] = (int16_t)c[3];
     a.qmvp[0] = (int16_t)mvp[0]; a.qmvp[1] = (int16_t)mvp[1];
 #pragma unroll

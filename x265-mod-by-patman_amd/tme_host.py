@@ -20,7 +20,8 @@ class PictureDesc(C.Structure):
                 ("refs", (HostRef * 16) * 2),
                 ("table", C.c_void_p), ("median", C.c_void_p), ("temporal", C.c_void_p),
                 ("nQp", C.c_int), ("qps", C.c_int * 64), ("qpIndex", C.c_void_p), ("areaQpIndex", C.c_void_p),
-                ("sourceHeight", C.c_int), ("frameThreads", C.c_int), ("flags", C.c_int), ("areaBestOut", C.c_void_p), ("ctuRowFirst", C.c_int), ("ctuRowCount", C.c_int)]
+                ("sourceHeight", C.c_int), ("frameThreads", C.c_int), ("flags", C.c_int), ("areaBestOut", C.c_void_p), ("ctuRowFirst", C.c_int), ("ctuRowCount", C.c_int),
+                ("pirStartCol", C.c_int), ("pirSafeX", C.c_int)]
 
 
 class TmeProducer:
@@ -70,7 +71,7 @@ class TmeProducer:
         return t
 
     def picture(self, cur, refs, stride, origin, table, qp=28, is_p=True, merange=57, method=1, subme=2, cur_poc=1, ref_pocs=((0,), ()), ref_keys=None, flags=0, frame_threads=1,
-                rows=None, rows_valid=None):
+                rows=None, rows_valid=None, pir=None):
         """cur: padded plane (numpy, pixel dtype); refs: [[plane, ...] of list 0, [...] of list 1]; table: INTER_CHOICE[n_ctu * 593] in / out.
         No temporal neighbours, no lookahead MVs, one qp: what a first P picture after an intra picture looks like.
         rows = (first CTU row, count): a band of the picture (desc.ctuRowFirst / ctuRowCount); rows_valid = plane rows of every reference that are final now (frame threads)."""
@@ -90,6 +91,8 @@ class TmeProducer:
                 d.refs[l][r].reconRowsValid = int(rows_valid) if rows_valid else 0
         if rows:
             d.ctuRowFirst, d.ctuRowCount = int(rows[0]), int(rows[1])
+        if pir:                                                 # --intra-refresh: (the picture's pirStartCol, the reference's pirEndCol * ctu - 3)
+            d.pirStartCol, d.pirSafeX = int(pir[0]), int(pir[1])
         if self._keep is None:                                  # no temporal neighbour anywhere, one qp: the same arrays for every picture
             temporal = np.zeros(self.n_ctu * self.entries * 2, dtype=TME_TEMPORAL)
             temporal["nb"]["refIdx"] = -1
