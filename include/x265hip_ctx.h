@@ -268,6 +268,12 @@ typedef struct x265hip_ff_picture_desc
     int saoStats;                              /* bit 0: luma statistics, bit 1: the two chroma planes' (SAOParam::bSaoFlag[0] / [1])                                           */
     int saoNonDeblocked;                       /* param->bSaoNonDeblocked (the skipped border widths of calcSaoStatsCTU)                                                         */
     int32_t* stats[3];                         /* out, per plane: per CTU in raster order [2][5][32] int32 = m_offsetOrg then m_count of that plane (x265hip_sao_stats_frame) */
+    int ctuRowFirst, ctuRowCount;              /* a band of CTU rows (FrameFilter::processRow runs a picture's filters row by row behind the row encoders, framefilter.cpp:576-676, and
+                                                  under frame threads the next pictures wait for the rows it finishes): only these rows' CTUs are deblocked -- the band's top edge
+                                                  included, which changes the last 3 luma / 1 chroma lines of the row above -- and only their statistics are written.  The arrays and
+                                                  planes keep the picture's addressing; read: the CU arrays of the band's rows and of the row above, the reconstruction from 8 luma lines
+                                                  above the band (the row above as the previous band left it: deblocked, SAO not yet applied) to the band's last line; written back: the
+                                                  same lines.  Bands of a picture must come in increasing order; bands of different pictures may interleave.  0, 0 = the whole picture */
 } x265hip_ff_picture_desc;
 int  x265hip_ff_picture(x265hip_ff* ff, const x265hip_ff_picture_desc* desc);
 

@@ -410,6 +410,11 @@ int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, i
  * :763-766).  NULL = x265hip_sao_stats_frame. */
 int x265hip_sao_stats_frame_slices(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
                                    int planeOffset, int32_t* out, const uint8_t* sliceFirstRow);
+/* the CTUs of the rows [ctuRow0, ctuRow1) only -- their entries of `out`, the others are not touched.  A band of FrameFilter::processRow's pipeline (framefilter.cpp:490-500:
+ * rdoSaoUnitCu of row r runs before row r + 1 is deblocked): the rows below need not be deblocked yet, a CTU's statistics leave out the lines the next row's deblocking changes
+ * (skipB) and read one line beyond them, which it does not change. */
+int x265hip_sao_stats_rows(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+                           int planeOffset, int32_t* out, const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1);
 
 /* SAO of a whole luma plane, OUT OF PLACE (in != out): SAO::generateLumaOffsets + applyPixelOffsets (encoder/sao.cpp:268-623) for every CTU.  The
  * reference filters in place and classifies against saved unmodified neighbours (m_tmpU, m_tmpL); reading the input plane is the same thing.
@@ -456,6 +461,10 @@ typedef struct x265hip_deblock_pic
                                        x265hip_deblock_frame / _pictures, host memory inside x265hip_ff_picture_desc */
 } x265hip_deblock_pic;
 int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut);
+/* A band of CTU rows [ctuRow0, ctuRow1) (FrameFilter::processRow's order, encoder/framefilter.cpp:576-676): the edges of those rows' CTUs, the band's top edge included -- it changes
+ * the last 3 luma / 1 chroma lines of the row above, which must hold that row's own deblocking.  Bands in increasing order give x265hip_deblock_frame's picture.  bsOut: the band's
+ * unit rows only, not cleared. */
+int x265hip_deblock_rows(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut, int ctuRow0, int ctuRow1);
 
 /* ---- the same stages for a BATCH of pictures of one size in one launch per stage (a 1080p plane does not fill 256 CUs: per-picture launches of 7-20 us
  * on <= 17 workgroups are launch-latency bound; a batch is not).  Pictures are `pictureElems` elements apart in their buffers; per-picture outputs are

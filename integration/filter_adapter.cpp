@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -75,6 +76,38 @@ struct Staging
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+/* ---- band mode (several frame threads): a picture in flight per FrameFilter (= per frame encoder), its rows filtered in bands as they arrive ---- */
+int g_bandRows;                              /* X265FF_BAND_ROWS: rows a band waits for (0 = default 4); with one frame thread 0 = the whole picture at its last row, > 0 forces bands */
+struct Band
+{
+    const FrameData* data = nullptr;
+    int done = 0;                            /* CTU rows [0, done) of the picture are filtered and replayed */
+    Staging st;                              /* picture-addressed; a band fills its rows (+ the row above) */
+    Replay replay;
+};
+std::mutex g_bandLock;
+std::unordered_map<const FrameFilter*, std::unique_ptr<Band>> g_bands;
+Band& band_of(const FrameFilter* ff)
+{
+    std::lock_guard<std::mutex> g(g_bandLock);
+    std::unique_ptr<Band>& b = g_bands[ff];
+    if (!b) b.reset(new Band());
+    return *b;
+}
+/* the band being replayed by THIS thread: the encoder's row loop runs on the thread that made the producer call, and nobody else touches the picture's filter rows meanwhile
+   (a picture's filter rows follow each other, frameencoder.cpp:1504-1508; the row encoders' early start is switched off in band mode, see processTasks below) */
+thread_local Replay* t_replay = nullptr;
+
+/* does the binding filter this FrameFilter's pictures (a function of the encoder's parameters and the picture format only: the same answer for every picture of an encode) */
+bool takes(const FrameFilter& ff, const x265_param& p, const Frame* frame, bool useSao)
+{
+    if (!(g_on && (p.bEnableLoopFilter || useSao) && ff.m_parallelFilter && p.internalCsp == X265_CSP_I420 && frame)) return false;
+    if (p.frameNumThreads > 1 && p.maxSlices > 1) return false;             /* slices finish in any order and pictures overlap: the encoder's own filters */
+    const PicYuv& rp = *frame->m_reconPic[0]; const PicYuv& fp = *frame->m_fencPic;
+    return fp.m_picCsp == X265_CSP_I420 && rp.m_stride == fp.m_stride && rp.m_strideC == fp.m_strideC && !(p.sourceWidth & 7) && !(p.sourceHeight & 7);
+}
+inline bool band_mode(const x265_param& p) { return p.frameNumThreads > 1 || g_bandRows > 0; }
+
 x265hip_ff* producer(const x265_param& p, const PicYuv& recon)
 {
     if (g_ff) return g_ff;
@@ -85,23 +118,135 @@ x265hip_ff* producer(const x265_param& p, const PicYuv& recon)
     }
     return g_ff;
 }
+void processBand(FrameFilter* ff, int row, int layer);
 }
 
 void processRow_cpu(FrameFilter* self, int row, int layer) __asm__("xff_processRow_cpu");
 void deblockCTU_cpu(const CUData* ctu, const CUGeom& cuGeom, int32_t dir) __asm__("xff_deblockCTU_cpu");
 void calcSaoStatsCTU_cpu(SAO* self, int addr, int plane) __asm__("xff_calcSaoStatsCTU_cpu");
+void processTasks_cpu(FrameFilter::ParallelFilter* self, int workerThreadId) __asm__("xff_processTasks_cpu");
+
+namespace {
+/* CUData's per-partition arrays of the CTU rows [rowA, row1) into the picture-addressed staging arrays, and the description of the call (the whole picture: rowA = 0,
+   row1 = the picture's rows; a band: the row above it included -- its CUs are the P side of the band's top edge) */
+void describe(FrameFilter& ff, Staging& S, int rowA, int row1, x265hip_ff_picture_desc& d, std::vector<uint8_t>& sliceFirstRow)
+{
+    const x265_param& p = *ff.m_param;
+    FrameData& encData = *ff.m_frame->m_encData;
+    Slice* slice = encData.m_slice;
+    PicYuv* recon = ff.m_frame->m_reconPic[0];
+    PicYuv* fenc = ff.m_frame->m_fencPic;
+    const uint32_t nctu = slice->m_sps->numCUsInFrame, np = encData.getPicCTU(0)->m_numPartitions, ncols = slice->m_sps->numCuInWidth;
+    const size_t n = (size_t)nctu * np;
+    const bool isB = slice->m_sliceType == B_SLICE, bypass = slice->m_pps->bTransquantBypassEnabled;
+    S.log2CUSize.resize(n); S.partSize.resize(n); S.tuDepth.resize(n); S.predMode.resize(n); S.cbf.resize(n); S.tqBypass.resize(n); S.qp.resize(n);
+    for (int l = 0; l < 2; l++) { S.refIdx[l].resize(n); S.mv[l].resize(2 * n); }
+    if (p.bEnableLoopFilter)
+        for (uint32_t a = (uint32_t)rowA * ncols; a < (uint32_t)row1 * ncols; a++)
+        {
+            const CUData* c = encData.getPicCTU(a);
+            const size_t o = (size_t)a * np;
+            memcpy(&S.log2CUSize[o], c->m_log2CUSize, np); memcpy(&S.partSize[o], c->m_partSize, np); memcpy(&S.tuDepth[o], c->m_tuDepth, np);
+            memcpy(&S.predMode[o], c->m_predMode, np); memcpy(&S.cbf[o], c->m_cbf[0], np); memcpy(&S.qp[o], c->m_qp, np);
+            if (bypass) memcpy(&S.tqBypass[o], c->m_tqBypass, np);
+            for (int l = 0; l < (isB ? 2 : 1); l++)
+            {
+                memcpy(&S.refIdx[l][o], c->m_refIdx[l], np);
+                static_assert(sizeof(MV) == 2 * sizeof(int32_t), "MV is a pair of 32-bit components");
+                memcpy(&S.mv[l][2 * o], c->m_mv[l], np * sizeof(MV));
+            }
+        }
+    memset(&d, 0, sizeof(d));
+    d.pic.width = p.sourceWidth; d.pic.height = p.sourceHeight; d.pic.ctuSize = (int)p.maxCUSize; d.pic.sliceIsP = !isB;
+    d.pic.betaOffsetDiv2 = slice->m_pps->deblockingFilterBetaOffsetDiv2; d.pic.tcOffsetDiv2 = slice->m_pps->deblockingFilterTcOffsetDiv2;
+    d.pic.cbQpOffset = slice->m_pps->chromaQpOffset[0]; d.pic.crQpOffset = slice->m_pps->chromaQpOffset[1]; d.pic.tqBypassEnabled = bypass;
+    d.pic.log2CUSize = S.log2CUSize.data(); d.pic.partSize = S.partSize.data(); d.pic.tuDepth = S.tuDepth.data(); d.pic.predMode = S.predMode.data();
+    d.pic.cbfLuma = S.cbf.data(); d.pic.tqBypass = bypass ? S.tqBypass.data() : NULL; d.pic.qp = S.qp.data();
+    d.pic.refIdx0 = S.refIdx[0].data(); d.pic.mv0 = S.mv[0].data(); d.pic.refIdx1 = isB ? S.refIdx[1].data() : NULL; d.pic.mv1 = isB ? S.mv[1].data() : NULL;
+    /* the reference compares the Frame behind (list, refIdx) (deblock.cpp:getBoundaryStrength); the POC identifies it */
+    for (int l = 0; l < 2; l++) for (int i = 0; i < 16; i++) d.pic.refPic[l][i] = i < slice->m_numRefIdx[l] ? slice->m_refPOCList[l][i] : -1 - i - 16 * l;
+    d.reconY = recon->m_picOrg[0]; d.reconCb = recon->m_picOrg[1]; d.reconCr = recon->m_picOrg[2];
+    d.fencY = fenc->m_picOrg[0]; d.fencCb = fenc->m_picOrg[1]; d.fencCr = fenc->m_picOrg[2];
+    /* --slices: the CTU rows that begin a slice, as the encoder flagged their CTUs (CUData::initCTU, frameencoder.cpp:1669) */
+    if (p.maxSlices > 1)
+    {
+        sliceFirstRow.assign((size_t)ff.m_numRows + 1, 0);
+        for (int r = 1; r < ff.m_numRows; r++) sliceFirstRow[r] = encData.getPicCTU(r * ncols)->m_bFirstRowInSlice;
+        d.pic.sliceFirstRow = sliceFirstRow.data();
+    }
+    d.deblock = p.bEnableLoopFilter;
+    const SAOParam* sp = encData.m_saoParam;
+    d.saoStats = (ff.m_useSao && sp) ? (sp->bSaoFlag[0] ? 1 : 0) | (sp->bSaoFlag[1] ? 2 : 0) : 0;
+    d.saoNonDeblocked = p.bSaoNonDeblocked;
+    for (int k = 0; k < 3; k++) { S.stats[k].resize((size_t)nctu * 320); d.stats[k] = S.stats[k].data(); }
+}
+
+/* Band mode: rows arrive in order (one slice); they pass until a band is due -- g_bandRows rows waiting, or the picture's last row -- then the band goes through the producer and
+   the encoder's own row loop runs over its rows (SAO decision and SAO of the row above each, border extension, PSNR / SSIM, Frame::m_reconRowFlag: what the next pictures wait for) */
+void processBand(FrameFilter* ff, int row, int layer)
+{
+    const x265_param& p = *ff->m_param;
+    Band& B = band_of(ff);
+    FrameData& encData = *ff->m_frame->m_encData;
+    if (row == 0 || B.data != &encData) { B.data = &encData; B.done = 0; }          /* the FrameFilter holds a new picture */
+    if (row < B.done) return;                                                       /* (cannot happen with one slice: rows come once, in order) */
+    const int numRows = ff->m_numRows, wait = g_bandRows > 0 ? g_bandRows : 4;
+    if (row != numRows - 1 && row + 1 - B.done < wait) return;                      /* the row waits for its band */
+    const int r0 = B.done, r1 = row + 1;
+    const double t0 = now();
+    x265hip_ff_picture_desc d;
+    std::vector<uint8_t> sliceFirstRow;
+    describe(*ff, B.st, r0 > 0 ? r0 - 1 : 0, r1, d, sliceFirstRow);
+    if (r0 > 0 || r1 < numRows) { d.ctuRowFirst = r0; d.ctuRowCount = r1 - r0; }
+    const double t1 = now();
+    double t2;
+    {
+        std::lock_guard<std::mutex> guard(g_lock);                                  /* one call at a time on the one producer; bands of the pictures in flight take turns */
+        x265hip_ff* prod = producer(p, *ff->m_frame->m_reconPic[0]);
+        if (!prod) { fprintf(stderr, "filter_adapter: no producer under frame threads\n"); die(); }      /* (rows of this picture may have passed already: there is no way back to the encoder's own filters) */
+        const int rc = g_api.ff_picture(prod, &d);
+        t2 = now();
+        if (rc) { fprintf(stderr, "filter_adapter: x265hip_ff_picture (POC %d, CTU rows %d..%d): %d %s\n", encData.m_slice->m_poc, r0, r1 - 1, rc, g_api.last_error()); die(); }
+    }
+    Replay& rp = B.replay;
+    rp.data = &encData; rp.deblocked = p.bEnableLoopFilter != 0;
+    if (r0 == 0) { rp.skipped = 0; rp.served = 0; }
+    rp.stats[0] = (d.saoStats & 1) ? B.st.stats[0].data() : NULL;
+    rp.stats[1] = (d.saoStats & 2) ? B.st.stats[1].data() : NULL; rp.stats[2] = (d.saoStats & 2) ? B.st.stats[2].data() : NULL;
+    t_replay = &rp;
+    for (int r = r0; r < r1; r++) ::processRow_cpu(ff, r, layer);
+    t_replay = nullptr;
+    B.done = r1;
+    const double t3 = now();
+    std::lock_guard<std::mutex> sg(g_statLock);
+    g_stats.bands++;
+    if (r1 == numRows) { g_stats.pictures++; g_stats.deblockSkipped += rp.skipped.load(); g_stats.statsServed += rp.served.load(); }
+    g_stats.gatherSeconds += t1 - t0; g_stats.producerSeconds += t2 - t1; g_stats.replaySeconds += t3 - t2;
+}
+} // namespace
 
 namespace X265_NS {
 
 void Deblock::deblockCTU(const CUData* ctu, const CUGeom& cuGeom, int32_t dir)
 {
-    if (Replay* rp = replay_of(ctu->m_encData)) if (rp->deblocked) { rp->skipped++; return; }
+    if (t_replay) { if (t_replay->data == ctu->m_encData && t_replay->deblocked) { t_replay->skipped++; return; } }
+    else if (Replay* rp = replay_of(ctu->m_encData)) if (rp->deblocked) { rp->skipped++; return; }
     ::deblockCTU_cpu(ctu, cuGeom, dir);
+}
+
+/* The row encoders' early start of the row above (frameencoder.cpp:2067-2076: "Processing left Deblock block with current threading") -- the only caller of this member outside
+   framefilter.cpp; processRow's own call is bound to the encoder's body inside its object.  In band mode the row is deblocked with its band: the early start would deblock it on
+   the CPU ahead of that.  It is an early start of work processRow does in any case (m_allowedCol = all columns, then processTasks), so leaving it out changes no result. */
+void FrameFilter::ParallelFilter::processTasks(int workerThreadId)
+{
+    const FrameFilter* ff = m_frameFilter;
+    if (ff && ff->m_param && band_mode(*ff->m_param) && takes(*ff, *ff->m_param, ff->m_frame, ff->m_useSao)) return;
+    ::processTasks_cpu(this, workerThreadId);
 }
 
 void SAO::calcSaoStatsCTU(int addr, int plane)
 {
-    Replay* rp = replay_of(m_frame->m_encData);
+    Replay* rp = (t_replay && t_replay->data == m_frame->m_encData) ? t_replay : replay_of(m_frame->m_encData);
     const int32_t* tab = rp ? rp->stats[plane] : NULL;
     if (!tab) { ::calcSaoStatsCTU_cpu(this, addr, plane); return; }
     /* per CTU [2][5][32]: m_offsetOrg then m_count of the plane; the body ADDS to what rdoSaoUnitCu left there (zero, or the pre-deblock sums of --sao-non-deblock) */
@@ -126,12 +271,8 @@ void FrameFilter::processRow(int row, int layer)
     const x265_param& p = *m_param;
     /* one picture at a time goes through the producer and the replay (g_lock) and the replay state of a picture stays published until the next one's: several frame
        threads (pictures in flight together, FrameData objects changing hands) keep the encoder's own filters */
-    bool mine = g_on && (p.bEnableLoopFilter || m_useSao) && m_parallelFilter && p.internalCsp == X265_CSP_I420 && p.frameNumThreads == 1;
-    if (mine)
-    {
-        const PicYuv& rp = *m_frame->m_reconPic[0]; const PicYuv& fp = *m_frame->m_fencPic;
-        mine = fp.m_picCsp == X265_CSP_I420 && rp.m_stride == fp.m_stride && rp.m_strideC == fp.m_strideC && !(p.sourceWidth & 7) && !(p.sourceHeight & 7);
-    }
+    const bool mine = takes(*this, p, m_frame, m_useSao);
+    if (mine && band_mode(p) && !g_deferOnly) { processBand(this, row, layer); return; }
     if (!mine)
     {
         if (replay_of(m_frame->m_encData)) { std::lock_guard<std::mutex> guard(g_lock); if (replay_of(m_frame->m_encData)) g_replay.store(nullptr, std::memory_order_release); }      /* (a recycled FrameData) */
@@ -171,53 +312,10 @@ void FrameFilter::processRow(int row, int layer)
         return;
     }
     const double t0 = now();
-    const uint32_t nctu = slice->m_sps->numCUsInFrame, np = encData.getPicCTU(0)->m_numPartitions;
-    const size_t n = (size_t)nctu * np;
-    const bool isB = slice->m_sliceType == B_SLICE, bypass = slice->m_pps->bTransquantBypassEnabled;
     Staging& S = g_st;
-    S.log2CUSize.resize(n); S.partSize.resize(n); S.tuDepth.resize(n); S.predMode.resize(n); S.cbf.resize(n); S.tqBypass.resize(n); S.qp.resize(n);
-    for (int l = 0; l < 2; l++) { S.refIdx[l].resize(n); S.mv[l].resize(2 * n); }
-    if (p.bEnableLoopFilter)
-        for (uint32_t a = 0; a < nctu; a++)
-        {
-            const CUData* c = encData.getPicCTU(a);
-            const size_t o = (size_t)a * np;
-            memcpy(&S.log2CUSize[o], c->m_log2CUSize, np); memcpy(&S.partSize[o], c->m_partSize, np); memcpy(&S.tuDepth[o], c->m_tuDepth, np);
-            memcpy(&S.predMode[o], c->m_predMode, np); memcpy(&S.cbf[o], c->m_cbf[0], np); memcpy(&S.qp[o], c->m_qp, np);
-            if (bypass) memcpy(&S.tqBypass[o], c->m_tqBypass, np);
-            for (int l = 0; l < (isB ? 2 : 1); l++)
-            {
-                memcpy(&S.refIdx[l][o], c->m_refIdx[l], np);
-                static_assert(sizeof(MV) == 2 * sizeof(int32_t), "MV is a pair of 32-bit components");
-                memcpy(&S.mv[l][2 * o], c->m_mv[l], np * sizeof(MV));
-            }
-        }
     x265hip_ff_picture_desc d;
-    memset(&d, 0, sizeof(d));
-    d.pic.width = p.sourceWidth; d.pic.height = p.sourceHeight; d.pic.ctuSize = (int)p.maxCUSize; d.pic.sliceIsP = !isB;
-    d.pic.betaOffsetDiv2 = slice->m_pps->deblockingFilterBetaOffsetDiv2; d.pic.tcOffsetDiv2 = slice->m_pps->deblockingFilterTcOffsetDiv2;
-    d.pic.cbQpOffset = slice->m_pps->chromaQpOffset[0]; d.pic.crQpOffset = slice->m_pps->chromaQpOffset[1]; d.pic.tqBypassEnabled = bypass;
-    d.pic.log2CUSize = S.log2CUSize.data(); d.pic.partSize = S.partSize.data(); d.pic.tuDepth = S.tuDepth.data(); d.pic.predMode = S.predMode.data();
-    d.pic.cbfLuma = S.cbf.data(); d.pic.tqBypass = bypass ? S.tqBypass.data() : NULL; d.pic.qp = S.qp.data();
-    d.pic.refIdx0 = S.refIdx[0].data(); d.pic.mv0 = S.mv[0].data(); d.pic.refIdx1 = isB ? S.refIdx[1].data() : NULL; d.pic.mv1 = isB ? S.mv[1].data() : NULL;
-    /* the reference compares the Frame behind (list, refIdx) (deblock.cpp:getBoundaryStrength); the POC identifies it */
-    for (int l = 0; l < 2; l++) for (int i = 0; i < 16; i++) d.pic.refPic[l][i] = i < slice->m_numRefIdx[l] ? slice->m_refPOCList[l][i] : -1 - i - 16 * l;
-    d.reconY = recon->m_picOrg[0]; d.reconCb = recon->m_picOrg[1]; d.reconCr = recon->m_picOrg[2];
-    d.fencY = fenc->m_picOrg[0]; d.fencCb = fenc->m_picOrg[1]; d.fencCr = fenc->m_picOrg[2];
-    /* --slices: the CTU rows that begin a slice, as the encoder flagged their CTUs (CUData::initCTU, frameencoder.cpp:1669) */
     std::vector<uint8_t> sliceFirstRow;
-    if (p.maxSlices > 1)
-    {
-        const uint32_t ncols = slice->m_sps->numCuInWidth;
-        sliceFirstRow.assign((size_t)m_numRows + 1, 0);
-        for (int r = 1; r < m_numRows; r++) sliceFirstRow[r] = encData.getPicCTU(r * ncols)->m_bFirstRowInSlice;
-        d.pic.sliceFirstRow = sliceFirstRow.data();
-    }
-    d.deblock = p.bEnableLoopFilter;
-    const SAOParam* sp = encData.m_saoParam;
-    d.saoStats = (m_useSao && sp) ? (sp->bSaoFlag[0] ? 1 : 0) | (sp->bSaoFlag[1] ? 2 : 0) : 0;
-    d.saoNonDeblocked = p.bSaoNonDeblocked;
-    for (int k = 0; k < 3; k++) { S.stats[k].resize((size_t)nctu * 320); d.stats[k] = S.stats[k].data(); }
+    describe(*this, S, 0, m_numRows, d, sliceFirstRow);
     const double t1 = now();
     const int rc = g_api.ff_picture(ff, &d);
     const double t2 = now();
@@ -230,7 +328,7 @@ void FrameFilter::processRow(int row, int layer)
     for (int r = 0; r < m_numRows; r++) ::processRow_cpu(this, r, layer);
     const double t3 = now();
     std::lock_guard<std::mutex> sg(g_statLock);
-    g_stats.pictures++; g_stats.deblockSkipped += rp.skipped.load(); g_stats.statsServed += rp.served.load();
+    g_stats.pictures++; g_stats.bands++; g_stats.deblockSkipped += rp.skipped.load(); g_stats.statsServed += rp.served.load();
     g_stats.gatherSeconds += t1 - t0; g_stats.producerSeconds += t2 - t1; g_stats.replaySeconds += t3 - t2;
 }
 
@@ -239,6 +337,7 @@ void FrameFilter::processRow(int row, int layer)
 extern "C" int x265hip_ff_adapter_load(const char* libraryPath, int device)
 {
     g_deferOnly = getenv("X265FF_DEFER_ONLY") && atoi(getenv("X265FF_DEFER_ONLY"));
+    g_bandRows = getenv("X265FF_BAND_ROWS") ? atoi(getenv("X265FF_BAND_ROWS")) : 0;
     g_lib = dlopen(libraryPath, RTLD_NOW | RTLD_LOCAL);
     if (!g_lib) { fprintf(stderr, "filter_adapter: dlopen: %s\n", dlerror()); return -1; }
 #define SYM(field, name) *(void**)&g_api.field = dlsym(g_lib, name); if (!g_api.field) { fprintf(stderr, "filter_adapter: %s lacks %s\n", libraryPath, name); return -1; }

@@ -154,8 +154,8 @@ int main(int argc, char** argv)
         x265hip_ff_adapter_close();
         x265hip_ff_adapter_get_stats(&fs);
         const size_t at = strlen(la);
-        snprintf(la + at, sizeof(la) - at, "\"filter_producer\": \"%s\", \"ff_pictures\": %d, \"ff_cpu_pictures\": %d, \"ff_deblock_calls_skipped\": %lld, \"ff_stats_served\": %lld, \"ff_gather_seconds\": %.3f, \"ff_producer_seconds\": %.3f, \"ff_replay_seconds\": %.3f, ",
-                 useFf ? "gpu" : "cpu", fs.pictures, fs.cpuPictures, fs.deblockSkipped, fs.statsServed, fs.gatherSeconds, fs.producerSeconds, fs.replaySeconds);
+        snprintf(la + at, sizeof(la) - at, "\"filter_producer\": \"%s\", \"ff_pictures\": %d, \"ff_bands\": %d, \"ff_cpu_pictures\": %d, \"ff_deblock_calls_skipped\": %lld, \"ff_stats_served\": %lld, \"ff_gather_seconds\": %.3f, \"ff_producer_seconds\": %.3f, \"ff_replay_seconds\": %.3f, ",
+                 useFf ? "gpu" : "cpu", fs.pictures, fs.bands, fs.cpuPictures, fs.deblockSkipped, fs.statsServed, fs.gatherSeconds, fs.producerSeconds, fs.replaySeconds);
     }
 #endif
     if (frameStats && fsN)

@@ -896,10 +896,19 @@ void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t st
 /* --slices: sliceFirstRow[r] != 0 where CTU row r begins a slice (CUData::m_bFirstRowInSlice of its CTUs; m_bLastRowInSlice of the row before it): sao.cpp:744-746, 763-766 */
 void xo_sao_stats_frame_slices(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
                                const uint8_t* sliceFirstRow)
+{
+    xo_sao_stats_rows(fenc, recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out, sliceFirstRow, 0, (picHeight + ctuSize - 1) / ctuSize);
+}
+/* The CTUs of the rows [ctuRow0, ctuRow1) only (their entries of `out`; the others are not touched).  The rows below need not be deblocked yet: a CTU's statistics leave out the
+ * lines the deblocking of the row below still changes (skipB) and read one line beyond them, which it does not change -- the order the reference works in (rdoSaoUnitCu of row r
+ * runs before row r + 1 is deblocked, framefilter.cpp:490-500). */
+void xo_sao_stats_rows(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
+                       const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1)
 {   /* chroma planes: pass the PLANE's width / height / CTU size (already shifted, :748-756) and planeOffset = 2 (:773) */
     const int po = planeOffset;
     const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
-    for (int addr = 0; addr < nx * ny; addr++)
+    if (ctuRow1 > ny) ctuRow1 = ny;
+    for (int addr = ctuRow0 * nx; addr < ctuRow1 * nx; addr++)
     {
         const int lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;
         const int row = addr / nx;
@@ -1217,9 +1226,18 @@ static const uint8_t k_dbkChromaScale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 
 
 void xo_deblock_frame(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_pixel* Cb, xo_pixel* Cr, intptr_t strideC, uint8_t* bsOut)
 {
-    const int uw = d->width >> 2, uh = d->height >> 2;
+    xo_deblock_rows(d, Y, strideY, Cb, Cr, strideC, bsOut, 0, (d->height + d->ctuSize - 1) / d->ctuSize);
+}
+/* A band of CTU rows [ctuRow0, ctuRow1): the edges of those rows' CTUs, the band's top edge included -- it changes the last lines of the row above, which must hold that row's
+ * own deblocking already.  What FrameFilter::processRow does for each row in turn (framefilter.cpp:576-676: ParallelFilter::processTasks deblocks row r when the row encoders are
+ * `m_filterRowDelay` rows ahead).  Bands in increasing order over a picture give xo_deblock_frame's picture (tests/test_filters_bands.py): the vertical edges of a row read and
+ * write that row's samples only; a horizontal edge reads 4 and writes 3 lines either side, and edges lie 8 lines apart. */
+void xo_deblock_rows(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_pixel* Cb, xo_pixel* Cr, intptr_t strideC, uint8_t* bsOut, int ctuRow0, int ctuRow1)
+{
+    const int uw = d->width >> 2, uh = d->height >> 2, upc = d->ctuSize / 4;
+    const int uy0 = ctuRow0 * upc, uy1 = ctuRow1 * upc < uh ? ctuRow1 * upc : uh;
     for (int dir = 0; dir < 2; dir++)
-        for (int uy = 0; uy < uh; uy++)
+        for (int uy = uy0; uy < uy1; uy++)
             for (int ux = 0; ux < uw; ux++)
             {
                 int bs = xo_deblock_bs(d, ux, uy, dir);

@@ -95,6 +95,8 @@ void xo_sao_stats(int type, const int16_t* diff, const xo_pixel* rec, intptr_t s
 void xo_sao_stats_frame(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out);
 void xo_sao_stats_frame_slices(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
                                const uint8_t* sliceFirstRow);
+void xo_sao_stats_rows(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
+                       const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1);   /* the CTUs of those rows only */
 void xo_sao_stats_frame_predeblock(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int planeOffset, int32_t* out);
 
 /* SAO of a luma plane, out of place (sao.cpp:268-623); params: per CTU { typeIdx, bandPos, offset[4] } */
@@ -114,6 +116,7 @@ typedef struct xo_deblock_pic
 } xo_deblock_pic;
 int xo_deblock_bs(const xo_deblock_pic* d, int ux, int uy, int dir);
 void xo_deblock_frame(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_pixel* Cb, xo_pixel* Cr, intptr_t strideC, uint8_t* bsOut);
+void xo_deblock_rows(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_pixel* Cb, xo_pixel* Cr, intptr_t strideC, uint8_t* bsOut, int ctuRow0, int ctuRow1);   /* a band of CTU rows (the rows above already deblocked) */
 /* framefilter.cpp:704-722, 839-865 + pixel.cpp:623-693: per CTU row float sums and window counts, frame total in double */
 void xo_ssim_frame(const xo_pixel* rec, intptr_t stride1, const xo_pixel* fenc, intptr_t stride2, int width, int height, int ctuSize,
                    float* rowSsim, uint32_t* rowCnt, double* total, uint32_t* cnt);

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <map>
 #include <mutex>
 #include <vector>
 #include "../include/x265hip_ctx.h"
@@ -22,7 +23,7 @@ typedef uint16_t xo_pixel;     /* -DMOCK_DEPTH=10: the 10-bit encoder with the 1
 typedef uint8_t xo_pixel;      /* the 8-bit encoder */
 #endif
 struct x265hip_ctx { int device; };
-struct x265hip_ff { int width, height, ctu; intptr_t strideY, strideC; long calls = 0; std::mutex mu; };
+struct x265hip_ff { int width, height, ctu; intptr_t strideY, strideC; long calls = 0, bands = 0, pictures = 0; std::mutex mu; std::map<const void*, int> rowsDone; /* per picture in flight (keyed by its luma plane): CTU rows filtered so far */ };
 
 namespace {
 char g_err[512] = "";
@@ -33,8 +34,8 @@ int fail(const char* fmt, ...)
     return X265HIP_EARG;
 }
 /* (x265hip_deblock_pic and the oracle's xo_deblock_pic are the same record: the library's description was modelled on it) */
-void (*g_deblock)(const x265hip_deblock_pic*, xo_pixel*, intptr_t, xo_pixel*, xo_pixel*, intptr_t, uint8_t*);
-void (*g_stats)(const xo_pixel*, const xo_pixel*, intptr_t, int, int, int, int, int, int32_t*, const uint8_t*);
+void (*g_deblock)(const x265hip_deblock_pic*, xo_pixel*, intptr_t, xo_pixel*, xo_pixel*, intptr_t, uint8_t*, int, int);
+void (*g_stats)(const xo_pixel*, const xo_pixel*, intptr_t, int, int, int, int, int, int32_t*, const uint8_t*, int, int);
 } // namespace
 
 extern "C" {
@@ -50,14 +51,20 @@ int x265hip_ff_create(x265hip_ctx* ctx, int width, int height, int ctuSize, intp
     const char* path = getenv("X265MOCK_ORACLE_LIB");
     void* lib = path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : nullptr;
     if (!lib) return fail("X265MOCK_ORACLE_LIB (%s) does not load: %s", path ? path : "unset", dlerror());
-    *(void**)&g_deblock = dlsym(lib, "xo_deblock_frame"); *(void**)&g_stats = dlsym(lib, "xo_sao_stats_frame_slices");
-    if (!g_deblock || !g_stats) return fail("%s lacks xo_deblock_frame / xo_sao_stats_frame_slices", path);
+    *(void**)&g_deblock = dlsym(lib, "xo_deblock_rows"); *(void**)&g_stats = dlsym(lib, "xo_sao_stats_rows");      /* (the whole picture is the band of all its rows) */
+    if (!g_deblock || !g_stats) return fail("%s lacks xo_deblock_rows / xo_sao_stats_rows", path);
     x265hip_ff* f = new x265hip_ff();
     f->width = width; f->height = height; f->ctu = ctuSize; f->strideY = strideY; f->strideC = strideC;
     *out = f;
     return X265HIP_OK;
 }
-void x265hip_ff_destroy(x265hip_ff* f) { if (!f) return; fprintf(stderr, "mock_ff_producer: %ld pictures\n", f->calls); delete f; }
+void x265hip_ff_destroy(x265hip_ff* f)
+{
+    if (!f) return;
+    fprintf(stderr, "mock_ff_producer: %ld pictures in %ld calls, %ld of them bands of a picture\n", f->pictures, f->calls, f->bands);
+    if (!f->rowsDone.empty()) fprintf(stderr, "mock_ff_producer: PROTOCOL VIOLATION: %zu pictures were left unfinished\n", f->rowsDone.size());
+    delete f;
+}
 
 int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* d)
 {
@@ -72,15 +79,25 @@ int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* d)
     f->calls++;
     if (getenv("X265MOCK_FAIL_AT") && f->calls == atol(getenv("X265MOCK_FAIL_AT"))) return fail("call %ld fails on request (X265MOCK_FAIL_AT)", f->calls);
     const int nrows = (f->height + f->ctu - 1) / f->ctu;
+    /* bands of a picture (include/x265hip_ctx.h: desc.ctuRowFirst / ctuRowCount): in increasing order, contiguous, each row once; bands of different pictures may interleave */
+    if (d->ctuRowFirst < 0 || d->ctuRowCount < 0 || d->ctuRowFirst + d->ctuRowCount > nrows || (d->ctuRowFirst && !d->ctuRowCount)) return fail("ff_picture: CTU rows %d + %d of %d", d->ctuRowFirst, d->ctuRowCount, nrows);
+    const int r0 = d->ctuRowFirst, r1 = d->ctuRowCount ? r0 + d->ctuRowCount : nrows;
+    {
+        int& done = f->rowsDone[d->reconY];
+        if (r0 != done) return fail("ff_picture: band starts at CTU row %d, the picture's rows done are %d", r0, done);
+        done = r1;
+        if (r1 == nrows) { f->rowsDone.erase(d->reconY); f->pictures++; }
+    }
+    if (d->ctuRowCount) f->bands++;
     std::vector<uint8_t> sfr;
     x265hip_deblock_pic D = P;
     if (P.sliceFirstRow) { sfr.assign(P.sliceFirstRow, P.sliceFirstRow + nrows); sfr.push_back(0); D.sliceFirstRow = sfr.data(); }
-    if (d->deblock) g_deblock(&D, (xo_pixel*)d->reconY, f->strideY, (xo_pixel*)d->reconCb, (xo_pixel*)d->reconCr, f->strideC, nullptr);
+    if (d->deblock) g_deblock(&D, (xo_pixel*)d->reconY, f->strideY, (xo_pixel*)d->reconCb, (xo_pixel*)d->reconCr, f->strideC, nullptr, r0, r1);
     const void* fenc[3] = { d->fencY, d->fencCb, d->fencCr }; void* rec[3] = { d->reconY, d->reconCb, d->reconCr };
     for (int p = 0; p < 3; p++)
         if ((p == 0 && (d->saoStats & 1)) || (p > 0 && (d->saoStats & 2)))
             g_stats((const xo_pixel*)fenc[p], (const xo_pixel*)rec[p], p ? f->strideC : f->strideY, p ? f->width / 2 : f->width, p ? f->height / 2 : f->height, p ? f->ctu / 2 : f->ctu,
-                    d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, d->stats[p], P.sliceFirstRow ? sfr.data() : nullptr);
+                    d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, d->stats[p], P.sliceFirstRow ? sfr.data() : nullptr, r0, r1);
     return X265HIP_OK;
 }
 } // extern "C"

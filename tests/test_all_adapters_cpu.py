@@ -1,7 +1,7 @@
 """The three bindings together inside the compiled reference encoder (oracle/_ref/x265e2e_8), no GPU: one library made of the three mocks (tests/mock_{tme,la,ff}_producer.cpp).
 The lookahead and filter mocks answer through the oracle (exact), the ThreadedME mock with a pure function of its inputs: switching the lookahead and filter bindings ON beside
-the ThreadedME binding must therefore not move the bitstream -- under four frame threads + WPP (where the filters stay the encoder's own) and with one frame thread (where all
-three producers run).  What this adds to the per-binding tests: three contexts in one process, the bindings' locks and thread pools side by side."""
+the ThreadedME binding must therefore not move the bitstream -- under four frame threads + WPP (ThreadedME and the filters both in bands of CTU rows) and with one frame thread
+(whole pictures).  What this adds to the per-binding tests: three contexts in one process, the bindings' locks and thread pools side by side."""
 import hashlib
 import json
 import os
@@ -46,5 +46,6 @@ def test_lookahead_and_filter_bindings_beside_the_threaded_me_binding(mock, tmp_
     allof = encode(mock, tmp_path, "all", 1, env, options)
     assert alone["frame_threads"] == frame_threads and alone["gpu_pictures"] == 11 and alone["la_estimates"] == 0 and alone["ff_pictures"] == 0
     assert allof["gpu_pictures"] == 11 and allof["la_estimates"] > 0 and allof["la_cpu_estimates"] == 0
-    assert (allof["ff_pictures"], allof["ff_cpu_pictures"]) == ((12, 0) if frame_threads == 1 else (0, 12))
+    assert (allof["ff_pictures"], allof["ff_cpu_pictures"]) == (12, 0)
+    assert allof["ff_bands"] == 12 if frame_threads == 1 else allof["ff_bands"] > 12      # frame threads: the filters go through their producer in bands of CTU rows
     assert allof["md5"] == alone["md5"]

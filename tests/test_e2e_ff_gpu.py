@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def encode(depth, ff, args, out, la=False, tme=False, defer_only=False, tme_gpu=None):
+def encode(depth, ff, args, out, la=False, tme=False, defer_only=False, tme_gpu=None, extra_env=None):
     exe = os.path.join(ROOT, "oracle", "_ref", "x265e2e_%d" % depth)
     if not os.path.exists(exe):
         pytest.skip("no oracle/_ref/x265e2e_%d (built where the reference is present)" % depth)
@@ -23,6 +23,7 @@ def encode(depth, ff, args, out, la=False, tme=False, defer_only=False, tme_gpu=
     env.pop("X265FF_DEFER_ONLY", None)
     if defer_only:
         env["X265FF_DEFER_ONLY"] = "1"
+    env.update(extra_env or {})
     r = subprocess.run([exe, x265hip.lib_path(depth)] + args[:4] + [out] + args[4:], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1]), hashlib.md5(open(out, "rb").read()).hexdigest()
@@ -71,11 +72,50 @@ def test_the_deferral_alone_keeps_the_bitstream(tmp_path):
     assert dfr["ff_pictures"] == 0 and dfr["ff_cpu_pictures"] == 8 and h_cpu == h_dfr
 
 
-@pytest.mark.parametrize("args", [["256", "192", "6", "medium", "frame-threads=2", "wpp=1"]])      # several pictures in flight: the replay state is one picture's (filter_adapter.cpp)
+@pytest.mark.parametrize("depth,args,band_rows", [(8, ["256", "640", "8", "medium", "frame-threads=3", "wpp=1"], None),                 # ten CTU rows, bands of four (the default)
+                                                  (8, ["256", "512", "8", "medium", "frame-threads=4", "wpp=0", "bframes=0"], "1"),      # every row its own band
+                                                  (10, ["192", "576", "7", "slow", "frame-threads=3", "wpp=1"], "2"),
+                                                  (8, ["320", "704", "8", "medium", "frame-threads=2", "wpp=1", "sao-non-deblock=1"], "3"),
+                                                  (8, ["256", "640", "8", "medium", "frame-threads=3", "wpp=1", "sao=0"], "2"),           # deblocking alone: the rows' counters come from processPostCu
+                                                  (8, ["256", "640", "8", "medium", "frame-threads=3", "wpp=1", "limit-sao=1", "ctu=32"], None),
+                                                  (8, ["1920", "1080", "6", "medium", "frame-threads=4", "wpp=1"], None)])                 # BASELINE configs[1], threaded as the CLI threads it
+def test_bitstream_identical_with_gpu_filters_under_frame_threads(depth, args, band_rows, tmp_path):
+    """The encoder's default threading: the next pictures wait for the rows a picture's filters finish (Frame::m_reconRowFlag).  The binding filters in bands of CTU rows as they
+    arrive (x265hip_ff_picture_desc.ctuRowFirst / ctuRowCount; the band's top edge changes the last lines of the row above; a band's statistics are taken before the rows below it
+    are deblocked) and runs the encoder's row loop over each band: same bitstream as the encoder's own filters under the same threading, every picture through the producer."""
+    env = {"X265FF_BAND_ROWS": band_rows} if band_rows else {}
+    cpu, h_cpu = encode(depth, False, args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(depth, True, args, str(tmp_path / "gpu.hevc"), extra_env=env)
+    n = int(args[2])
+    want = int([a for a in args if a.startswith("frame-threads=")][0].split("=")[1])
+    assert gpu["frame_threads"] == want and cpu["frame_threads"] == want
+    assert gpu["ff_pictures"] == n and gpu["ff_cpu_pictures"] == 0 and gpu["ff_bands"] > n, "the pictures did not go through the producer in bands: %s" % gpu
+    assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
+    print("e2e ff frame threads", depth, args, "bands %d for %d pictures; per picture: gather %.2f ms, producer %.2f ms, row loop %.2f ms; fps cpu %.2f gpu %.2f" % (
+        gpu["ff_bands"], n, 1e3 * gpu["ff_gather_seconds"] / n, 1e3 * gpu["ff_producer_seconds"] / n, 1e3 * gpu["ff_replay_seconds"] / n, cpu["fps"], gpu["fps"]))
+
+
+def test_bands_on_request_with_one_frame_thread(tmp_path):
+    args = ["256", "320", "8", "medium"]
+    cpu, h_cpu = encode(8, False, args, str(tmp_path / "cpu.hevc"))
+    gpu, h_gpu = encode(8, True, args, str(tmp_path / "gpu.hevc"), extra_env={"X265FF_BAND_ROWS": "2"})
+    assert gpu["ff_pictures"] == 8 and gpu["ff_bands"] == 8 * 3 and h_cpu == h_gpu
+
+
+@pytest.mark.parametrize("args", [["256", "320", "6", "medium", "frame-threads=2", "wpp=1", "slices=2"]])      # slices finish in any order while pictures overlap
 def test_what_the_producer_lacks_stays_with_the_encoder(args, tmp_path):
     cpu, h_cpu = encode(8, False, args, str(tmp_path / "cpu.hevc"))
     gpu, h_gpu = encode(8, True, args, str(tmp_path / "gpu.hevc"))
     assert gpu["ff_pictures"] == 0 and gpu["ff_cpu_pictures"] == 6 and h_cpu == h_gpu
+
+
+def test_all_three_seams_together_under_frame_threads(tmp_path):
+    """--threaded-me (bands of CTU rows through x265hip_tme_picture), the lookahead and the filters (bands through x265hip_ff_picture) on the GPU with three frame threads + WPP"""
+    args = ["256", "640", "9", "medium", "frame-threads=3", "wpp=1"]
+    cpu, h_cpu = encode(8, False, args, str(tmp_path / "cpu.hevc"), la=False, tme=True, tme_gpu=False)
+    gpu, h_gpu = encode(8, True, args, str(tmp_path / "gpu.hevc"), la=True, tme=True)
+    assert gpu["gpu_pictures"] >= 3 and gpu["la_estimates"] > 0 and gpu["ff_pictures"] == 9 and gpu["ff_bands"] > 9
+    assert cpu["bytes"] == gpu["bytes"] and h_cpu == h_gpu, "bitstreams differ: cpu %s gpu %s" % (cpu, gpu)
 
 
 @pytest.mark.parametrize("depth,args", [(8, ["256", "192", "10", "medium"]), (10, ["192", "128", "8", "slow"])])

@@ -52,10 +52,48 @@ def test_filters_through_the_binding_give_the_plain_encoders_bitstream(mock, tmp
     assert bound["md5"] == plain["md5"] and bound["bytes"] == plain["bytes"]
 
 
-def test_frame_threads_keep_the_encoders_own_filters(mock, tmp_path):
-    """Several frame threads: the binding leaves every picture to the encoder's own filters -- and says how many."""
-    r = encode(mock, tmp_path, "ft", 1, env={"X265_CLI_THREADING": "1"}, options=("pools=16", "frame-threads=3"))
-    p = encode(mock, tmp_path, "ftp", 0, env={"X265_CLI_THREADING": "1"}, options=("pools=16", "frame-threads=3"))
+@pytest.mark.parametrize("options,band_rows", [(("pools=16", "frame-threads=3"), None), (("pools=16", "frame-threads=4", "wpp=0"), "1"), (("pools=16", "frame-threads=3", "sao=0"), "2"),
+                                               (("pools=16", "frame-threads=2", "sao-non-deblock=1"), "3"), (("pools=16", "frame-threads=3", "limit-sao=1", "ctu=32"), None),
+                                               (("pools=16", "frame-threads=5", "deblock=0"), "100")],
+                         ids=lambda v: "+".join(v) if isinstance(v, tuple) else "rows" + str(v))
+def test_frame_threads_filter_in_bands_and_write_the_plain_encoders_bitstream(mock, tmp_path, options, band_rows):
+    """Several frame threads (the encoder's default): the next pictures wait for the rows a picture's filters finish (Frame::m_reconRowFlag), so the binding filters in BANDS of CTU
+    rows as they arrive (desc.ctuRowFirst / ctuRowCount; the row encoders' early start of a row's deblocking is switched off: FrameFilter::ParallelFilter::processTasks).  The mock
+    checks the band protocol (a picture's bands in order, contiguous, every row once; pictures interleave); every picture goes through the binding; the bitstream is the plain
+    encoder's under the same threading."""
+    env = {"X265_CLI_THREADING": "1"}
+    if band_rows:
+        env["X265FF_BAND_ROWS"] = band_rows
+    size = (640, 704)                                  # eleven CTU rows of 64
+    r = encode(mock, tmp_path, "ft", 1, size=size, env=env, options=options)
+    p = encode(mock, tmp_path, "ftp", 0, size=size, env={"X265_CLI_THREADING": "1"}, options=options)
+    assert r["rc"] == 0 and p["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+    assert r["frame_threads"] == int([o for o in options if o.startswith("frame-threads=")][0].split("=")[1])
+    assert r["ff_pictures"] == 8 and r["ff_cpu_pictures"] == 0
+    if band_rows != "100":
+        assert r["ff_bands"] > r["ff_pictures"], "the pictures were not cut into bands: %s" % r["ff_bands"]
+    else:
+        assert r["ff_bands"] == r["ff_pictures"]
+    assert r["md5"] == p["md5"] and r["bytes"] == p["bytes"]
+
+
+def test_bands_with_one_frame_thread_on_request(mock, tmp_path):
+    """X265FF_BAND_ROWS with one frame thread forces the band form (default there: the whole picture at its last row): same bitstream, more calls."""
+    whole = encode(mock, tmp_path, "w", 1)
+    bands = encode(mock, tmp_path, "b", 1, env={"X265FF_BAND_ROWS": "2"})
+    wpp = encode(mock, tmp_path, "bw", 1, env={"X265FF_BAND_ROWS": "1"}, options=("wpp=1", "pools=8"))
+    plain_wpp = encode(mock, tmp_path, "pw", 0, options=("wpp=1", "pools=8"))
+    for r in (whole, bands, wpp):
+        assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+        assert r["ff_pictures"] == 8
+    assert whole["ff_bands"] == 8 and bands["ff_bands"] == 8 * 3 and whole["md5"] == bands["md5"]      # 368 lines = six CTU rows: three bands of two
+    assert wpp["ff_bands"] == 8 * 6 and wpp["md5"] == plain_wpp["md5"]
+
+
+def test_slices_with_frame_threads_keep_the_encoders_own_filters(mock, tmp_path):
+    """--slices together with frame threads: slices finish in any order while pictures overlap -- the binding leaves those pictures to the encoder's own filters and says how many."""
+    r = encode(mock, tmp_path, "sl", 1, size=(256, 320), env={"X265_CLI_THREADING": "1"}, options=("pools=16", "frame-threads=3", "slices=2"))
+    p = encode(mock, tmp_path, "slp", 0, size=(256, 320), env={"X265_CLI_THREADING": "1"}, options=("pools=16", "frame-threads=3", "slices=2"))
     assert r["rc"] == 0 and p["rc"] == 0 and r["ff_pictures"] == 0 and r["ff_cpu_pictures"] == 8 and r["md5"] == p["md5"]
 
 

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 class FfDesc(C.Structure):
     _fields_ = [("pic", DeblockPic), ("recon", C.c_void_p * 3), ("fenc", C.c_void_p * 3), ("deblock", C.c_int), ("saoStats", C.c_int), ("saoNonDeblocked", C.c_int),
-                ("stats", C.c_void_p * 3)]
+                ("stats", C.c_void_p * 3), ("ctuRowFirst", C.c_int), ("ctuRowCount", C.c_int)]
 
 
 @pytest.mark.parametrize("depth,W,H,ctu,slice_p,bypass,deblock,sao,nd", [(8, 256, 192, 64, False, False, 1, 3, 0), (10, 200, 120, 64, True, True, 1, 3, 0), (8, 192, 128, 32, False, False, 1, 1, 1),
@@ -70,4 +70,79 @@ def test_ff_picture_matches_oracle(depth, W, H, ctu, slice_p, bypass, deblock, s
                 assert np.array_equal(stats[c], want), "SAO statistics of plane %d" % c
             else:
                 assert (stats[c] == -9).all()
+    lib.x265hip_ff_destroy(ff); lib.x265hip_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("depth,W,H,ctu,cut,sao,nd", [(8, 256, 320, 64, [1], 3, 0), (10, 320, 328, 64, [2, 1], 3, 0), (8, 200, 168, 32, [3, 1], 3, 1), (8, 128, 136, 16, [4, 1, 2], 1, 0),
+                                                      (10, 1920, 1080, 64, [4], 3, 0), (8, 256, 256, 64, [2], 0, 0)])
+def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd):
+    """desc.ctuRowFirst / ctuRowCount (FrameFilter::processRow's order under frame threads): TWO pictures go through one producer band by band, their bands interleaved -- each
+    band reads the CU arrays of its rows and the row above, the planes from 8 lines above it, and writes those lines and its rows' statistics back.  After the last band each
+    picture equals the whole-picture result of the oracle; the statistics of a band are taken before the rows below it are deblocked (xo_sao_stats_rows on the oracle's band state)."""
+    H -= H % 8
+    ora = Oracle(depth)
+    ora.lib.xo_deblock_rows.restype = None
+    ora.lib.xo_sao_stats_rows.restype = None
+    lib = x265hip.HipLib(depth, fill_table=False).lib
+    lib.x265hip_last_error.restype = C.c_char_p
+    sY, sC = W + 40, W // 2 + 24
+    nx, ny = (W + ctu - 1) // ctu, (H + ctu - 1) // ctu
+    nctu = nx * ny
+    ctx, ff = C.c_void_p(), C.c_void_p()
+    assert lib.x265hip_ctx_create(0, C.byref(ctx)) == 0, lib.x265hip_last_error()
+    assert lib.x265hip_ff_create(ctx, W, H, ctu, C.c_ssize_t(sY), C.c_ssize_t(sC), C.byref(ff)) == 0, lib.x265hip_last_error()
+    P = lambda a: C.c_void_p(a.ctypes.data)
+    pics = []
+    for k in range(2):
+        pic = coded_picture(depth, W, H, ctu, 900 + 13 * k + W + depth, bool(k), False)
+        rng = np.random.default_rng(50 + k + W)
+        dt = pic["planes"][0].dtype
+        src = [np.clip(p.astype(np.int32) + rng.integers(-6, 7, p.shape), 0, (1 << depth) - 1).astype(dt) for p in pic["planes"]]
+        def padded(p, s_):
+            b = np.full((p.shape[0], s_), 3, dt); b[:, :p.shape[1]] = p
+            return b
+        recon = [padded(p, sC if c else sY) for c, p in enumerate(pic["planes"])]
+        fenc = [padded(p, sC if c else sY) for c, p in enumerate(src)]
+        keep = {n: np.ascontiguousarray(pic[n]) for n in U8 + I8 + ("mv0", "mv1")}
+        stats = [np.full(nctu * 320, -9, np.int32) for _ in range(3)]
+        d = FfDesc()
+        d.pic = descriptor(pic, lambda n, keep=keep: keep[n].ctypes.data)
+        d.recon[:] = [r.ctypes.data for r in recon]; d.fenc[:] = [f.ctypes.data for f in fenc]
+        d.deblock, d.saoStats, d.saoNonDeblocked = 1, sao, nd
+        d.stats[:] = [s_.ctypes.data for s_ in stats]
+        # the oracle's band state of the same picture (contiguous planes)
+        oplanes = [np.ascontiguousarray(p.copy()) for p in pic["planes"]]
+        od = descriptor(pic, lambda n, keep=keep: keep[n].ctypes.data)
+        pics.append(dict(pic=pic, src=src, recon=recon, fenc=fenc, keep=keep, stats=stats, d=d, oplanes=oplanes, od=od, want=[np.full(nctu * 320, -9, np.int32) for _ in range(3)]))
+    bands, r, i = [], 0, 0
+    while r < ny:
+        h = min(cut[i % len(cut)], ny - r); bands.append((r, r + h)); r += h; i += 1
+    # picture 0 runs one band ahead of picture 1
+    order = []
+    for b in range(len(bands) + 1):
+        if b < len(bands): order.append((0, bands[b]))
+        if b > 0: order.append((1, bands[b - 1]))
+    for k, (r0, r1) in order:
+        S = pics[k]
+        S["d"].ctuRowFirst, S["d"].ctuRowCount = (r0, r1 - r0) if (r0 > 0 or r1 < ny) else (0, 0)
+        assert lib.x265hip_ff_picture(ff, C.byref(S["d"])) == 0, lib.x265hip_last_error()
+        ora.lib.xo_deblock_rows(C.byref(S["od"]), P(S["oplanes"][0]), C.c_ssize_t(W), P(S["oplanes"][1]), P(S["oplanes"][2]), C.c_ssize_t(W // 2), None, r0, r1)
+        for c in range(3):
+            w = W if c == 0 else W // 2
+            assert np.array_equal(S["recon"][c][:, :w], S["oplanes"][c]), "picture %d plane %d after the band of rows %d..%d" % (k, c, r0, r1 - 1)
+            assert (S["recon"][c][:, w:] == 3).all(), "the padding of plane %d was touched" % c
+            if (c == 0 and sao & 1) or (c > 0 and sao & 2):
+                h, cs = (H, ctu) if c == 0 else (H // 2, ctu // 2)
+                ora.lib.xo_sao_stats_rows(P(np.ascontiguousarray(S["src"][c])), P(S["oplanes"][c]), C.c_ssize_t(w), w, h, cs, nd, 0 if c == 0 else 2, P(S["want"][c]), None, r0, r1)
+            assert np.array_equal(S["stats"][c], S["want"][c]), "picture %d: statistics of plane %d after rows %d..%d (entries outside the bands so far must be untouched)" % (k, c, r0, r1 - 1)
+    for S in pics:
+        whole = run_oracle(ora, S["pic"])
+        for c in range(3):
+            assert np.array_equal(S["oplanes"][c], whole[c])
+    # argument errors: a band beyond the picture, a band without a count
+    bad = pics[0]["d"]
+    bad.ctuRowFirst, bad.ctuRowCount = ny - 1, 2
+    assert lib.x265hip_ff_picture(ff, C.byref(bad)) == -3 and b"CTU rows" in lib.x265hip_last_error()
+    bad.ctuRowFirst, bad.ctuRowCount = 1, 0
+    assert lib.x265hip_ff_picture(ff, C.byref(bad)) == -3
     lib.x265hip_ff_destroy(ff); lib.x265hip_ctx_destroy(ctx)

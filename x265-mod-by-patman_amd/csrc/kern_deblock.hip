@@ -80,12 +80,12 @@ __device__ __forceinline__ int boundary_strength(const x265hip_deblock_pic& d, i
 
 template<int DIR>
 __device__ __forceinline__ void deblock_body(const x265hip_deblock_pic& d, pixel* __restrict__ Y, intptr_t strideY, pixel* __restrict__ Cb, pixel* __restrict__ Cr,
-                                             intptr_t strideC, int lgUpc, int nx, uint8_t* __restrict__ bsOut)
-{
+                                             intptr_t strideC, int lgUpc, int nx, uint8_t* __restrict__ bsOut, int uy0, int uy1)
+{   // unit rows [uy0, uy1): the whole picture, or a band of CTU rows (x265hip_deblock_rows; uy0 is a multiple of the CTU's units, so even)
     const int uw = d.width >> 2, uh = d.height >> 2;
     const int a = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int ux = DIR ? a : 2 * a, uy = DIR ? 2 * b : b;                               // the 8x8 grid: even units across the edge
-    if (ux >= uw || uy >= uh || !(DIR ? uy : ux)) return;
+    const int ux = DIR ? a : 2 * a, uy = uy0 + (DIR ? 2 * b : b);                       // the 8x8 grid: even units across the edge
+    if (ux >= uw || uy >= uy1 || !(DIR ? uy : ux)) return;
     // --slices: the CTU above the first row of a slice is not a neighbour (CUData::initCTU: m_cuAbove = NULL, cudata.cpp:323), its top edge is not filtered
     if (DIR && d.sliceFirstRow && !(uy & ((1 << lgUpc) - 1)) && d.sliceFirstRow[uy >> lgUpc]) return;
     // one round of independent loads: the two units' records and the segment's 4 lines x 8 luma samples (wasted where the strength turns out 0, but a
@@ -182,16 +182,16 @@ __device__ __forceinline__ void deblock_body(const x265hip_deblock_pic& d, pixel
 
 template<int DIR>
 __global__ __launch_bounds__(256) void deblock_kernel(x265hip_deblock_pic d, pixel* __restrict__ Y, intptr_t strideY, pixel* __restrict__ Cb, pixel* __restrict__ Cr,
-                                                      intptr_t strideC, int lgUpc, int nx, uint8_t* __restrict__ bsOut)
+                                                      intptr_t strideC, int lgUpc, int nx, uint8_t* __restrict__ bsOut, int uy0, int uy1)
 {
-    deblock_body<DIR>(d, Y, strideY, Cb, Cr, strideC, lgUpc, nx, bsOut);
+    deblock_body<DIR>(d, Y, strideY, Cb, Cr, strideC, lgUpc, nx, bsOut, uy0, uy1);
 }
 // a batch of pictures of one size: picture = grid z, its description and planes from the device copy of the job list
 template<int DIR>
 __global__ __launch_bounds__(256) void deblock_pictures_kernel(const x265hip_deblock_job* __restrict__ jobs, intptr_t strideY, intptr_t strideC, int lgUpc, int nx)
 {
     const x265hip_deblock_job& j = jobs[blockIdx.z];              // left in memory (uniform address: scalar loads); a local copy would put refPic[][] in scratch
-    deblock_body<DIR>(j.pic, (pixel*)j.Y, strideY, (pixel*)j.Cb, (pixel*)j.Cr, strideC, lgUpc, nx, j.bsOut);
+    deblock_body<DIR>(j.pic, (pixel*)j.Y, strideY, (pixel*)j.Cb, (pixel*)j.Cr, strideC, lgUpc, nx, j.bsOut, 0, j.pic.height >> 2);
 }
 
 } // namespace
@@ -225,6 +225,15 @@ extern "C" int x265hip_deblock_pictures(void* stream, const x265hip_deblock_job*
 
 extern "C" int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut)
 {
+    if (!desc) { set_error("deblock_frame: null argument"); return X265HIP_EARG; }
+    return x265hip_deblock_rows(stream, desc, Y, strideY, Cb, Cr, strideC, bsOut, 0, (desc->height + (desc->ctuSize > 0 ? desc->ctuSize : 64) - 1) / (desc->ctuSize > 0 ? desc->ctuSize : 64));
+}
+
+// A band of CTU rows [ctuRow0, ctuRow1) of the picture: the edges of those rows' CTUs, the band's top edge included (it changes the last 3 luma / 1 chroma lines of the row above,
+// which must hold that row's own deblocking already) -- FrameFilter::processRow's order (framefilter.cpp:576-676).  Bands in increasing order over a picture give the whole
+// picture's result (oracle: xo_deblock_rows, tests/test_filters_bands.py).  bsOut (optional) is written for the band's unit rows only and is NOT cleared here.
+extern "C" int x265hip_deblock_rows(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut, int ctuRow0, int ctuRow1)
+{
     if (!desc || !Y || !Cb || !Cr) { set_error("deblock_frame: null argument"); return X265HIP_EARG; }
     const x265hip_deblock_pic& d = *desc;
     if (d.width < 8 || d.height < 8 || (d.width & 7) || (d.height & 7) || (d.ctuSize != 16 && d.ctuSize != 32 && d.ctuSize != 64) || strideY < d.width || strideC < d.width / 2 ||
@@ -233,9 +242,12 @@ extern "C" int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* de
     { set_error("deblock_frame: bad picture description (dimensions are multiples of 8, CTU 16/32/64, 4:2:0)"); return X265HIP_EARG; }
     hipStream_t st = (hipStream_t)stream;
     const int lgUpc = d.ctuSize == 64 ? 4 : d.ctuSize == 32 ? 3 : 2, nx = (d.width + d.ctuSize - 1) / d.ctuSize, uw = d.width >> 2, uh = d.height >> 2;
-    if (bsOut) XH_HIP(hipMemsetAsync(bsOut, 0, (size_t)2 * uw * uh, st));
-    XH_KLAUNCH(deblock_kernel<0>, dim3((uw / 2 + 63) / 64, (uh + 3) / 4), dim3(256), 0, st, d, (pixel*)Y, strideY, (pixel*)Cb, (pixel*)Cr, strideC, lgUpc, nx, bsOut);
-    XH_KLAUNCH(deblock_kernel<1>, dim3((uw + 63) / 64, (uh / 2 + 3) / 4), dim3(256), 0, st, d, (pixel*)Y, strideY, (pixel*)Cb, (pixel*)Cr, strideC, lgUpc, nx, bsOut);
+    const int nRows = (d.height + d.ctuSize - 1) / d.ctuSize;
+    if (ctuRow0 < 0 || ctuRow1 <= ctuRow0 || ctuRow1 > nRows) { set_error("deblock_rows: CTU rows %d..%d of %d", ctuRow0, ctuRow1, nRows); return X265HIP_EARG; }
+    const int uy0 = ctuRow0 << lgUpc, uy1 = min(ctuRow1 << lgUpc, uh), nUy = uy1 - uy0;
+    if (bsOut && ctuRow0 == 0 && ctuRow1 == nRows) XH_HIP(hipMemsetAsync(bsOut, 0, (size_t)2 * uw * uh, st));
+    XH_KLAUNCH(deblock_kernel<0>, dim3((uw / 2 + 63) / 64, (nUy + 3) / 4), dim3(256), 0, st, d, (pixel*)Y, strideY, (pixel*)Cb, (pixel*)Cr, strideC, lgUpc, nx, bsOut, uy0, uy1);
+    XH_KLAUNCH(deblock_kernel<1>, dim3((uw + 63) / 64, ((nUy + 1) / 2 + 3) / 4), dim3(256), 0, st, d, (pixel*)Y, strideY, (pixel*)Cb, (pixel*)Cr, strideC, lgUpc, nx, bsOut, uy0, uy1);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }

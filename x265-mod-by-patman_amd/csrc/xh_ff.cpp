@@ -4,6 +4,7 @@
 // back.  What integration/filter_adapter.cpp binds inside the reference encoder (FrameFilter::processRow / ParallelFilter::processTasks, encoder/framefilter.cpp:451-664).
 #include "xh_common.h"
 #include "../../include/x265hip_ctx.h"
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -76,15 +77,23 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     { set_error("ff_picture: incomplete picture description"); return X265HIP_EARG; }
     if ((d->saoStats & 1) && (!d->fencY || !d->stats[0])) { set_error("ff_picture: luma statistics without the source plane / the output"); return X265HIP_EARG; }
     if ((d->saoStats & 2) && (!d->fencCb || !d->fencCr || !d->stats[1] || !d->stats[2])) { set_error("ff_picture: chroma statistics without the source planes / the outputs"); return X265HIP_EARG; }
+    const int nRows = f->nrows, nx = (f->width + f->ctu - 1) / f->ctu;
+    if (d->ctuRowFirst < 0 || d->ctuRowCount < 0 || d->ctuRowFirst + d->ctuRowCount > nRows || (d->ctuRowFirst && !d->ctuRowCount))
+    { set_error("ff_picture: CTU rows %d + %d of %d", d->ctuRowFirst, d->ctuRowCount, nRows); return X265HIP_EARG; }
+    // the band (the whole picture without one): CTU rows [r0, r1); moved and computed: the CU arrays from the row above the band, the planes from 8 luma lines above it
+    const int r0 = d->ctuRowFirst, r1 = d->ctuRowCount ? r0 + d->ctuRowCount : nRows;
+    const int rA = std::max(r0 - 1, 0);                                              // the row whose CUs are the P side of the band's top edge
+    const int y0 = std::max(r0 * f->ctu - 8, 0), y1 = std::min(r1 * f->ctu, f->height), ys = r0 * f->ctu;      // luma lines moved; first line of the band
     std::lock_guard<std::mutex> g(f->mu);
     XH_HIP(hipSetDevice(x265hip_ctx_device(f->ctx)));
     hipStream_t st = (hipStream_t)x265hip_ctx_stream(f->ctx);
-    const size_t n = (size_t)f->nctu * f->npart;
+    const size_t a0 = (size_t)rA * nx * f->npart, n = (size_t)(r1 - rA) * nx * f->npart;      // partitions of the CTU rows [rA, r1)
     void* const hostRecon[3] = { d->reconY, d->reconCb, d->reconCr };
     const void* const hostFenc[3] = { d->fencY, d->fencCb, d->fencCr };
     auto pitch = [&](int p) { return (size_t)(p ? f->strideC : f->strideY) * sizeof(pixel); };
     auto wbytes = [&](int p) { return (size_t)(p ? f->width / 2 : f->width) * sizeof(pixel); };
-    auto rows = [&](int p) { return (size_t)(p ? f->height / 2 : f->height); };
+    auto line = [&](int p, int y) { return (size_t)(p ? y / 2 : y); };                        // a luma line's line of plane p (4:2:0; y0 / ys / y1 are even)
+    auto at = [&](const void* base, int p, int y) { return (void*)((char*)base + line(p, y) * pitch(p)); };
     // --slices: the rows that begin a slice (a host array like the rest of the description); the entry behind the last row is always 0
     const uint8_t* sfr = nullptr;
     if (P.sliceFirstRow)
@@ -95,31 +104,33 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     }
     for (int p = 0; p < 3; p++)
     {
-        XH_HIP(hipMemcpy2DAsync(f->recon[p], pitch(p), hostRecon[p], pitch(p), wbytes(p), rows(p), hipMemcpyHostToDevice, st));
+        XH_HIP(hipMemcpy2DAsync(at(f->recon[p], p, y0), pitch(p), at(hostRecon[p], p, y0), pitch(p), wbytes(p), line(p, y1) - line(p, y0), hipMemcpyHostToDevice, st));
         if ((p == 0 && (d->saoStats & 1)) || (p > 0 && (d->saoStats & 2)))
-            XH_HIP(hipMemcpy2DAsync(f->fenc[p], pitch(p), hostFenc[p], pitch(p), wbytes(p), rows(p), hipMemcpyHostToDevice, st));
+            XH_HIP(hipMemcpy2DAsync(at(f->fenc[p], p, ys), pitch(p), at(hostFenc[p], p, ys), pitch(p), wbytes(p), line(p, y1) - line(p, ys), hipMemcpyHostToDevice, st));
     }
     if (d->deblock)
     {
         x265hip_deblock_pic D = P;
         D.sliceFirstRow = sfr;
-#define XF_UP(field, count) XH_HIP(hipMemcpyAsync(f->field, P.field, (count) * sizeof(*P.field), hipMemcpyHostToDevice, st)); D.field = f->field
-        XF_UP(log2CUSize, n); XF_UP(partSize, n); XF_UP(tuDepth, n); XF_UP(predMode, n); XF_UP(cbfLuma, n); XF_UP(qp, n); XF_UP(refIdx0, n); XF_UP(mv0, 2 * n);
-        if (P.tqBypassEnabled) { XF_UP(tqBypass, n); } else D.tqBypass = nullptr;
-        if (!P.sliceIsP) { XF_UP(refIdx1, n); XF_UP(mv1, 2 * n); } else { D.refIdx1 = nullptr; D.mv1 = nullptr; }
+#define XF_UP(field, per) XH_HIP(hipMemcpyAsync(f->field + a0 * (per), P.field + a0 * (per), n * (per) * sizeof(*P.field), hipMemcpyHostToDevice, st)); D.field = f->field
+        XF_UP(log2CUSize, 1); XF_UP(partSize, 1); XF_UP(tuDepth, 1); XF_UP(predMode, 1); XF_UP(cbfLuma, 1); XF_UP(qp, 1); XF_UP(refIdx0, 1); XF_UP(mv0, 2);
+        if (P.tqBypassEnabled) { XF_UP(tqBypass, 1); } else D.tqBypass = nullptr;
+        if (!P.sliceIsP) { XF_UP(refIdx1, 1); XF_UP(mv1, 2); } else { D.refIdx1 = nullptr; D.mv1 = nullptr; }
 #undef XF_UP
-        int rc = x265hip_deblock_frame(st, &D, f->recon[0], f->strideY, f->recon[1], f->recon[2], f->strideC, nullptr);
+        int rc = x265hip_deblock_rows(st, &D, f->recon[0], f->strideY, f->recon[1], f->recon[2], f->strideC, nullptr, r0, r1);
         if (rc) return rc;
-        for (int p = 0; p < 3; p++) XH_HIP(hipMemcpy2DAsync(hostRecon[p], pitch(p), f->recon[p], pitch(p), wbytes(p), rows(p), hipMemcpyDeviceToHost, st));
+        for (int p = 0; p < 3; p++)
+            XH_HIP(hipMemcpy2DAsync(at(hostRecon[p], p, y0), pitch(p), at(f->recon[p], p, y0), pitch(p), wbytes(p), line(p, y1) - line(p, y0), hipMemcpyDeviceToHost, st));
     }
     for (int p = 0; p < 3; p++)
     {
         if (!((p == 0 && (d->saoStats & 1)) || (p > 0 && (d->saoStats & 2)))) continue;
         // a 4:2:0 chroma plane: its own width / height / CTU size and planeOffset 2 (sao.cpp:748-756, :773)
-        int rc = x265hip_sao_stats_frame_slices(st, f->fenc[p], f->recon[p], p ? f->strideC : f->strideY, p ? f->width / 2 : f->width, p ? f->height / 2 : f->height,
-                                                p ? f->ctu / 2 : f->ctu, d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, f->stats[p], sfr);
+        int rc = x265hip_sao_stats_rows(st, f->fenc[p], f->recon[p], p ? f->strideC : f->strideY, p ? f->width / 2 : f->width, p ? f->height / 2 : f->height,
+                                        p ? f->ctu / 2 : f->ctu, d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, f->stats[p], sfr, r0, r1);
         if (rc) return rc;
-        XH_HIP(hipMemcpyAsync(d->stats[p], f->stats[p], (size_t)f->nctu * 320 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        const size_t s0 = (size_t)r0 * nx * 320;
+        XH_HIP(hipMemcpyAsync(d->stats[p] + s0, f->stats[p] + s0, (size_t)(r1 - r0) * nx * 320 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     }
     XH_HIP(hipStreamSynchronize(st));
     return X265HIP_OK;
