@@ -60,9 +60,8 @@ def parse():
     ap.add_argument("--tu", type=int, default=5, help="log2 TU size of the DCT+quant stage")
     ap.add_argument("--inner", type=int, default=5, help="passes over the resident batch per step (a step of the driver's --steps 20 then lasts long enough for the whole timed region to be >= 0.5 s)")
     ap.add_argument("--no-streams-leg", action="store_true", help="skip the extra leg that steps the same batch as 2 and 3 sub-batches of whole pictures on their own streams (x265hip_batch_desc.streams); reported under \"streams\", not part of value")
-    ap.add_argument("--fused", type=int, default=0, help="x265hip_batch_set_fused: 1 = the 16x16 and 8x8 levels in one launch (a wavefront per 32x32 quadrant), 2 = the 32x32 level too; 0 = a launch per level (default; the fused forms are slower: profiles/r03_fused_ab.txt); | 4 = the 64x64 level with its start-stage launch; | 8 = tiled phase planes (16 bit; fewer bytes, slower: profiles/r03_tiled_ab.txt)")
+    ap.add_argument("--fused", type=int, default=0, help="x265hip_batch_set_mode flags: 0 = the default schedule; 4 = the 64x64 level with its start-stage launch (the form of rounds 1-2); 16 = the phase planes in groups of two pictures (what an 8K batch does by itself).  The fused lower levels (1, 2) and the tiled phase planes (8) were measured losses and left the library in round 5: the library refuses them")
     ap.add_argument("--splits", type=int, default=2, help="cut the batch into this many sub-batches of whole pictures, each on its own HIP stream (independent pictures; the levels of one picture stay in order)")
-    ap.add_argument("--band-rows", type=int, default=0, help="band-major schedule: bands of this many CTU rows go through all levels + TQ before the stream takes the next band (x265hip_batch_desc.bandRows); 0 = sub-batches of whole pictures")
     ap.add_argument("--no-planes", action="store_true", help="interpolate sub-pel candidates inside the ME kernel instead of using phase planes")
     ap.add_argument("--recon", action="store_true", help="also run S4 (dequant -> IDCT -> recon -> SSE)")
     ap.add_argument("--lookahead", action="store_true", help="also time the lookahead frame-cost batch (lowres init, intra estimate, estimateFrameCost of a 32-picture window); reported under \"lookahead\", not part of value")
@@ -1178,7 +1177,7 @@ def main():
     # torch is here for the process group (barrier, max over ranks) and the device-wide synchronisation around the timed region.
     lib = x265hip.HipLib(depth, fill_table=False).lib
     pipe = HostBatch(lib, depth, W, H, args.frames, qp=args.qp, merange=wl["merange"], method=METHODS[wl["method"]], subme=wl["subme"], tu_log2=args.tu, margin=MARGIN,
-                     recon=args.recon, use_planes=not args.no_planes, refs=args.refs, rect=args.rect, streams=args.splits, device=local_rank, band_rows=args.band_rows)
+                     recon=args.recon, use_planes=not args.no_planes, refs=args.refs, rect=args.rect, streams=args.splits, device=local_rank)
     pipe.cost_row_host = mvcost_row(depth, args.qp, 1 << 15)
     pipe.set_fused(args.fused)
     pipe.upload([p[:1 + args.refs] for p in pairs])                      # inputs are resident in HBM before the timed region
@@ -1197,7 +1196,7 @@ def main():
     # per-stage HIP events (recorded by the host on the stream each stage runs on, x265hip_batch_set_timing) on every 4th step only: an event between two launches
     # keeps the tail of one kernel from overlapping the head of the next (measured: ~5 % of the step time when every launch is bracketed)
     t0 = time.perf_counter()
-    serial_stage_times = args.splits > 1 and args.band_rows == 0       # sub-batches on their own streams overlap: the per-stage times then come from one-stream passes behind the timed region
+    serial_stage_times = args.splits > 1       # sub-batches on their own streams overlap: the per-stage times then come from one-stream passes behind the timed region
     for k in range(args.steps):
         pipe.set_timing(k % 4 == 0 and not serial_stage_times)
         for _ in range(args.inner):                 # one step = `inner` passes of the hot path over the resident batch (the timed region of the driver's 20 steps is >= 0.5 s)
@@ -1268,7 +1267,7 @@ def main():
             "config": {"workload": args.workload, "preset_exact": bool(args.refs == PRESET_REFS.get(args.workload) and args.rect == PRESET_RECT.get(args.workload)),
                        "frame": "%dx%d (CTU-aligned)" % (W, H), "frames_per_step_per_gpu": args.frames * args.inner,
                        "step": "%d passes of the hot path over a resident batch of %d frame pairs" % (args.inner, args.frames), "host": "C++ (x265hip_batch_step, csrc/xh_ctx.cpp)",
-                       "streams": ("bands of %d CTU rows through all levels, round-robin on %d streams" % (args.band_rows, args.splits)) if args.band_rows > 0 else
+                       "streams":
                                   ("2 sub-batches of whole pictures on their own streams, alternating on the 64x64 level, joined at the end of the timed region (x265hip_batch_desc.streams = 2)" if args.splits == 2 else
                                    "%d sub-batches of whole pictures on their own streams" % args.splits if args.splits > 1 else "one stream"),
                        "ctu": 64, "pus_per_ctu": 425 if args.rect else 85, "me": wl["method"], "subme": wl["subme"], "merange": wl["merange"], "refs": args.refs, "qp": args.qp,
@@ -1301,7 +1300,7 @@ def main():
         }
         def leg(name):      # progress on stderr: a leg that takes the process down is then named in the log
             print("[bench] leg %s" % name, file=sys.stderr, flush=True)
-        if not args.no_streams_leg and args.band_rows == 0 and args.frames >= 2:
+        if not args.no_streams_leg and args.frames >= 2:
             leg("streams")
             out["streams"] = run_leg_child("streams:%.9f" % (dt / args.steps / args.inner))
         if exact:

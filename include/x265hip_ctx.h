@@ -33,6 +33,8 @@ typedef struct x265hip_batch x265hip_batch;
 
 int   x265hip_ctx_create(int device, x265hip_ctx** ctx);
 void  x265hip_ctx_destroy(x265hip_ctx* ctx);
+size_t x265hip_ctx_trim(x265hip_ctx* ctx);           /* a context keeps the large device blocks (>= 64 MiB, up to 96 GiB in all) of its destroyed batches for its next ones (a host that creates and
+                                                         destroys 8K batches does not unmap and map multi-GB ranges each time); this gives them back to the driver now.  Returns the bytes released */
 void* x265hip_ctx_stream(x265hip_ctx* ctx);          /* hipStream_t: every call on this context is ordered on it (a batch with desc.streams > 1: after x265hip_batch_join) */
 int   x265hip_ctx_sync(x265hip_ctx* ctx);              /* waits for everything queued through the context, the sub-streams of its batches included */
 int   x265hip_ctx_device(const x265hip_ctx* ctx);    /* the device the context was created on; every entry point that takes a context selects it for the calling thread */
@@ -59,9 +61,8 @@ typedef struct x265hip_batch_desc
                                2: the two streams ALTERNATE on the 64x64 level (its workgroups fill a CU's LDS: it then always runs beside the other stream's smaller
                                levels, never beside itself) and are not joined between steps -- a stream's next pass follows its own previous one; x265hip_ctx_sync and
                                the upload / read calls join them                                                                            */
-    int bandRows;           /* 0: sub-batches are whole pictures.  > 0: band-major -- the phase planes of the whole batch first, then bands of this many CTU rows, each taken
-                               through all levels and the TQ stage before its stream takes the next band (bands dealt round-robin to the streams): the planes under a band
-                               are re-read while they are still in the last-level cache.  Experiment builds only (a measured loss)       */
+    int bandRows;           /* must be 0 (kept for the record's layout): the band-major schedule of round 3 was a measured loss (profiles/r03_band_major_ab.txt) and left the
+                               library in round 5; x265hip_batch_create refuses any other value                                                      */
     int amp;                /* != 0: also the asymmetric PUs (2NxnU, 2NxnD, nLx2N, nRx2N) of every CU of 64, 32 and 16 pixels (param->bEnableAMP: preset slower and up,
                                param.cpp:592-593; searched at analysis.cpp:2756-2860): 168 more PUs per CTU (593 with rect = the MEData entries of a CTU, threadedme.h:67-92),
                                each seeded by its own CU's 2Nx2N result in the same reference                                             */

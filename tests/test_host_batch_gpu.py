@@ -363,3 +363,33 @@ def test_preset_slow_every_pu_of_a_whole_4k_picture_in_every_reference():
     bad = [b for _, bl in out for b in bl]
     assert not bad, "%d PUs differ from the oracle, first: %s" % (len(bad), bad[0])
     assert sum(c for c, _ in out) == (W // 64) * (H // 64) * 425
+
+
+def test_a_context_hands_the_large_blocks_of_a_destroyed_batch_to_its_next_one():
+    """x265hip_batch_destroy keeps the batch's large device blocks (>= 64 MiB: the phase planes) with the context, the next x265hip_batch_create of the same context takes them
+    again (a long-lived host that creates and destroys batches does not unmap and map multi-GB ranges each time -- the pattern behind round 5's runtime fault); a smaller batch
+    does not get a block more than a quarter too large; x265hip_ctx_trim gives the kept blocks back.  The bytes computed on a reused block are the first batch's."""
+    import ctypes as C
+    depth, W, H, F = 8, 1920, 1088, 2                      # phase planes: 16 x 2 x 2112 x 1280 bytes = 86 MB
+    lib = x265hip.HipLib(depth, fill_table=False).lib
+    lib.x265hip_ctx_trim.restype = C.c_size_t
+    lib.x265hip_batch_device_ptr.restype = C.c_void_p
+    hb = HostBatch(lib, depth, W, H, F, qp=30, merange=16, method=1, subme=2, tu_log2=5)
+    pairs = pairs_for(W, H, depth, F, 1)
+    try:
+        hb.upload(pairs); hb.step(); hb.sync()
+        first = [hb.results(lv).tobytes() for lv in LEVELS]
+        p_first = lib.x265hip_batch_device_ptr(hb.batch, 200)
+        assert p_first
+        lib.x265hip_batch_destroy.restype = None
+        lib.x265hip_batch_destroy(hb.batch); hb.batch = C.c_void_p()
+        # the same geometry again on the same context: the phase planes' block comes back
+        assert lib.x265hip_batch_create(hb.ctx, C.byref(hb.desc), C.byref(hb.batch)) == 0, lib.x265hip_last_error()
+        assert lib.x265hip_batch_device_ptr(hb.batch, 200) == p_first, "the kept block was not reused"
+        hb.upload(pairs); hb.step(); hb.sync()
+        assert [hb.results(lv).tobytes() for lv in LEVELS] == first
+        lib.x265hip_batch_destroy(hb.batch); hb.batch = C.c_void_p()
+        kept = lib.x265hip_ctx_trim(hb.ctx)
+        assert kept >= 16 * F * (W + 192) * (H + 192) and lib.x265hip_ctx_trim(hb.ctx) == 0
+    finally:
+        hb.close()

@@ -17,6 +17,31 @@ struct x265hip_ctx
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<x265hip_batch*> batches;      // batches of this context (their sub-streams are joined into `stream` before anything waits on it)
+    // The large device blocks (plane stacks, phase planes: hundreds of MB to tens of GB) of a destroyed batch stay with the context and are handed to its next batch instead of
+    // going back to the driver: a long-lived host that creates and destroys 8K batches would otherwise unmap and map multi-GB ranges all the time -- slow, and the pattern the
+    // runtime's virtual-memory fault of round 5 needs (profiles/r05_fence_flake.txt: hipMemset on a freshly mapped 4.6 GB block after other multi-GB blocks were unmapped).
+    // Best fit within +25 %; at most kSpareMax bytes are kept; x265hip_ctx_trim / x265hip_ctx_destroy give them back.  (The fence build keeps every block its own reservation.)
+    struct Spare { void* p; size_t bytes; };
+    std::vector<Spare> spare; size_t spareBytes = 0;
+    static constexpr size_t kSpareMin = (size_t)64 << 20, kSpareMax = (size_t)96 << 30;
+    void* take(size_t bytes)
+    {
+        if (xh::kFence || bytes < kSpareMin) return nullptr;
+        int best = -1;
+        for (int i = 0; i < (int)spare.size(); i++)
+            if (spare[i].bytes >= bytes && spare[i].bytes <= bytes + bytes / 4 && (best < 0 || spare[i].bytes < spare[best].bytes)) best = i;
+        if (best < 0) return nullptr;
+        void* p = spare[best].p; spareBytes -= spare[best].bytes;
+        spare.erase(spare.begin() + best);
+        return p;
+    }
+    bool keep(void* p, size_t bytes)
+    {
+        if (xh::kFence || bytes < kSpareMin || spareBytes + bytes > kSpareMax) return false;
+        spare.push_back(Spare{ p, bytes }); spareBytes += bytes;
+        return true;
+    }
+    void trim() { for (const Spare& s : spare) (void)xh::dev_free(s.p); spare.clear(); spareBytes = 0; }
 };
 
 namespace {
@@ -74,12 +99,17 @@ struct x265hip_batch
     // per-stage events of sub-batch 0 (x265hip_batch_set_timing)
     bool timing = false; std::vector<std::string> stageNames; std::vector<hipEvent_t> evStage; int timedSteps = 0;      // evStage: kTimingSets sets of 2 events per stage
     std::vector<xh::KernelEvents> evStar; bool starValid[kTimingSets] = {}; int starSteps = 0; const xh::KernelEvents* starNow = nullptr;                // star64_kernel alone, first reference of sub-batch 0 (x265hip_batch_read_kernel_timing)
-    std::vector<void*> owned;
+    std::vector<void*> owned; std::vector<size_t> ownedBytes;
     template<class T> int alloc(T*& p, size_t n, const char* file = __builtin_FILE(), int line = __builtin_LINE())
     {
-        void* v = nullptr;
-        XH_HIP(xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line)));
-        owned.push_back(v); p = (T*)v;
+        void* v = ctx->take(n * sizeof(T));                      // a large block of an earlier batch of this context, or a fresh one
+        if (!v)
+        {
+            hipError_t e = xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line));
+            if (e == hipErrorOutOfMemory && ctx->spareBytes) { (void)hipGetLastError(); ctx->trim(); e = xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line)); }      // the kept blocks did not fit this batch: give them back and ask again
+            XH_HIP(e);
+        }
+        owned.push_back(v); ownedBytes.push_back(n * sizeof(T)); p = (T*)v;
         return X265HIP_OK;
     }
 };
@@ -117,7 +147,17 @@ extern "C" void x265hip_ctx_destroy(x265hip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream); x265hip_tme_release_stream(c->stream); (void)hipStreamDestroy(c->stream);
+    c->trim();
     delete c;
+}
+// the device blocks the context keeps from destroyed batches go back to the driver now; returns the bytes released
+extern "C" size_t x265hip_ctx_trim(x265hip_ctx* c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    const size_t n = c->spareBytes;
+    c->trim();
+    return n;
 }
 extern "C" void* x265hip_ctx_stream(x265hip_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int x265hip_ctx_device(const x265hip_ctx* c) { return c ? c->device : -1; }
@@ -272,7 +312,7 @@ extern "C" void x265hip_batch_destroy(x265hip_batch* b)
     if (b->evFork) (void)hipEventDestroy(b->evFork);
     for (hipEvent_t e : b->evStage) (void)hipEventDestroy(e);
     for (auto& k : b->evStar) { (void)hipEventDestroy(k.before); (void)hipEventDestroy(k.after); }
-    for (void* p : b->owned) (void)xh::dev_free(p);
+    for (size_t i = 0; i < b->owned.size(); i++) if (!b->ctx->keep(b->owned[i], b->ownedBytes[i])) (void)xh::dev_free(b->owned[i]);      // (everything queued on the blocks has finished: the streams were drained above)
     delete b;
 }
 
@@ -286,7 +326,7 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
     b->ctx = ctx; b->d = *d; b->stride = stride_of(d); b->plane = plane_of(d);
     b->refs = d->refs > 1 ? d->refs : 1; b->nref[0] = b->refs; b->nref[1] = d->refs1;
     b->needChoice = b->refs > 1 || b->nref[1] > 0;
-    b->nsub = d->streams > 1 ? ((d->bandRows > 0 || d->streams < d->frames) ? d->streams : d->frames) : 1;
+    b->nsub = d->streams > 1 ? (d->streams < d->frames ? d->streams : d->frames) : 1;
     b->sub[0] = ctx->stream;
     const size_t elems = (size_t)b->plane * d->frames;
     int rc = X265HIP_OK;
@@ -296,7 +336,7 @@ extern "C" int x265hip_batch_create(x265hip_ctx* ctx, const x265hip_batch_desc* 
     XBH(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming), "hipEventCreate");
     ctx->batches.push_back(b);
     b->groupFrames = choose_group_frames(b, 0);
-    if ((b->nsub == 2 || (b->nsub > 2 && xh_experiment("X265HIP_RING"))) && d->bandRows <= 0 && !xh_experiment("X265HIP_NO_PINGPONG"))
+    if ((b->nsub == 2 || (b->nsub > 2 && xh_experiment("X265HIP_RING"))) && !xh_experiment("X265HIP_NO_PINGPONG"))
     {
         b->pingpong = 1;                                         // (a batch in plane groups steps every group as a sub-batch of its own and does not pass the token: step_group)
         for (int i = 0; i < b->nsub; i++) XBH(hipEventCreateWithFlags(&b->evTok[i], hipEventDisableTiming), "hipEventCreate");
@@ -572,7 +612,7 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
     int rc0;
     if (!b) { set_error("batch_step: null batch"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
-    const int F = b->d.frames, S = b->nsub, ctuRows = b->d.height / CTU, G = F * ctuRows, band = b->d.bandRows;
+    const int F = b->d.frames, S = b->nsub, ctuRows = b->d.height / CTU, G = F * ctuRows;
     hipEvent_t* ev = nullptr;
     if (b->timing)
     {   // the next event set (the sets of the steps since the last read_timing; beyond kTimingSets the oldest are overwritten)
@@ -582,7 +622,7 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
         b->timedSteps++;
         if ((rc0 = arm_star_events(b))) return rc0;
     }
-    if (S == 1 && band <= 0) return step_range(b, 0, G, true, b->sub[0], ev);
+    if (S == 1) return step_range(b, 0, G, true, b->sub[0], ev);
     int rc;
     {   // Independent pictures: the levels of one picture depend on each other (a level's predictor is its parent CU's MV), pictures do not.  Sub-batch s runs on its
         // own stream, so the LDS-bound 64x64 search of one runs beside the latency-bound 16x16 / 8x8 searches of another.  Everything is ordered after the work already
@@ -607,7 +647,6 @@ extern "C" int x265hip_batch_step(x265hip_batch* b)
 extern "C" int x265hip_batch_step_one_stream(x265hip_batch* b)
 {
     if (!b) { set_error("batch_step_one_stream: null batch"); return X265HIP_EARG; }
-    if (b->d.bandRows > 0) { set_error("batch_step_one_stream: not with the band-major schedule"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(b->ctx->device));
     int rc = join_subs(b);
     if (rc) return rc;

@@ -102,7 +102,8 @@ class HostBatch:
         self._ck(self.lib.x265hip_ctx_sync(self.ctx), "ctx_sync")
 
     def set_fused(self, flags):
-        """x265hip_batch_set_mode: X265HIP_BATCH_* flags (1 / 2 fused lower levels, 4 the 64x64 start-stage launch, 8 tiled phase planes); 0 = the default schedule"""
+        """x265hip_batch_set_mode: X265HIP_BATCH_* flags -- 4 = the 64x64 level with its start-stage launch, 16 = phase planes in groups of two pictures; 0 = the default schedule.
+        (1 / 2, the fused lower levels, and 8, the tiled phase planes, were measured losses and left the library in round 5: it refuses them.)"""
         self._ck(self.lib.x265hip_batch_set_mode(self.batch, int(flags)), "batch_set_mode")
 
     set_mode = set_fused
