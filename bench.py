@@ -210,7 +210,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
         default_runs = {}
         if both:
             # (256 pool threads under whatever CPU quota the box gives them: the clock of one run moves by +-10 %, so the GPU run is taken three times, the plain CPU run twice)
-            for name, tme_on, tme, la, ff, reps in (("cpu_default_threading", 0, 0, 0, 0, 3), ("cpu_default_threading_tme", 1, 0, 0, 0, 3), ("all_gpu_default_threading", 1, 1, 1, 1, 3),
+            for name, tme_on, tme, la, ff, reps in (("cpu_default_threading", 0, 0, 0, 0, 3), ("cpu_default_threading_tme", 1, 0, 0, 0, 3), ("all_gpu_default_threading", 1, 1, 1, 1, 3), ("gpu_tme_lookahead_default_threading", 1, 1, 1, 0, 3),
                                                     ("gpu_lookahead_default_threading", 0, 0, 1, 0, 3)):
                 got = []
                 for rep in range(reps):
@@ -267,7 +267,12 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
                                                      "what bounds M2; no encoder-side consumer of the batched TQ / intra arithmetic exists (Quant::transformNxN and estIntraPredQT run per CU inside the RDO loop)"}}
     if default_runs:
         ok = {k: v for k, v in default_runs.items() if "fps" in v}
-        a, b = ok.get("cpu_default_threading_tme"), ok.get("all_gpu_default_threading")
+        # the GPU run of the headline: ThreadedME + lookahead + filters (r06: the filter seam works in bands of CTU rows under frame threads), or the same with the encoder's own
+        # filters -- whichever is faster on this host; both are listed, `gpu_run.seams` says which one `value` is
+        a = ok.get("cpu_default_threading_tme")
+        b3, b2 = ok.get("all_gpu_default_threading"), ok.get("gpu_tme_lookahead_default_threading")
+        b = b3 if (b3 and (not b2 or b3["fps"] >= b2["fps"])) else b2
+        seams = "ThreadedME + lookahead + in-loop filters" if b is b3 else "ThreadedME + lookahead (the encoder's own filters: faster on this host than the filter seam's bands)"
         dt = {"config": "the same clip and preset, %d frames, threaded as the CLI threads it (frame threads from the core count, WPP, %d cores)" % (default_frames, os.cpu_count() or 0),
               "fps": {k: v["fps"] for k, v in ok.items()}, "fps_runs": {k: v["fps_runs"] for k, v in ok.items()}, "fps_rule": "median of the runs listed in fps_runs",
               "failed": {k: v["failed"] for k, v in default_runs.items() if "failed" in v} or None,
@@ -275,7 +280,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
               "bitstream_identical_gpu_vs_cpu_producers": bool(a and b and a["md5"] == b["md5"] and a["bytes"] == b["bytes"] and b["md5_all_equal"]), "host": usable_cores()[1]}
         dt["encoder_clocks_ms_per_picture"] = {k: v.get("frame_stats_ms_per_picture") for k, v in ok.items() if v.get("frame_stats_ms_per_picture")}
         # equal-quality reading of the two bitstreams (the plain encoder's; --threaded-me's, which the GPU producers write too) + the speed per CPU the host grants
-        qa, qb = (ok.get("cpu_default_threading") or {}).get("quality"), (b or {}).get("quality")
+        qa, qb = (ok.get("cpu_default_threading") or {}).get("quality"), (b3 or {}).get("quality") or (b2 or {}).get("quality")
         if qa and qb:
             dt["quality"] = {"encoder_alone": qa, "threaded_me_gpu_producers": qb,
                              "threaded_me_vs_encoder_alone": {"kbps_ratio": round(qb["kbps"] / qa["kbps"], 4) if qa["kbps"] else None, "psnr_y_db": round(qb["psnr_y"] - qa["psnr_y"], 4),
@@ -289,9 +294,11 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
             ms = 1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"])
             dt["producer_ceiling"] = {"tme_producer_ms_per_picture": round(ms, 2), "pictures_per_second_of_the_one_producer": round(1e3 / ms, 1) if ms > 0 else None,
                                       "note": "one ThreadedME producer serves the encode (bands of every picture in flight take turns on it): whatever the host's core count, the encode cannot go faster than this"}
-            dt["gpu_run"] = {"tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
+            dt["gpu_run"] = {"seams": seams, "tme_pictures": b["gpu_pictures"], "tme_bands": b.get("gpu_bands"), "tme_producer_ms_per_picture": round(1e3 * b["gpu_seconds"] / max(1, b["gpu_pictures"]), 2),
                              "tme_adapter_seconds": b["adapter_seconds"], "la_estimates": b.get("la_estimates"), "la_producer_seconds": b.get("la_producer_seconds"),
-                             "filter_pictures_gpu": b.get("ff_pictures"), "filter_pictures_left_to_the_cpu": b.get("ff_cpu_pictures"), "seconds": b["seconds"]}
+                             "filter_pictures_gpu": b.get("ff_pictures"), "filter_bands": b.get("ff_bands"), "filter_pictures_left_to_the_cpu": b.get("ff_cpu_pictures"),
+                             "filter_ms_per_picture": ({"gather": round(1e3 * b["ff_gather_seconds"] / b["ff_pictures"], 2), "x265hip_ff_picture": round(1e3 * b["ff_producer_seconds"] / b["ff_pictures"], 2),
+                                                        "row_loop": round(1e3 * b["ff_replay_seconds"] / b["ff_pictures"], 2)} if b.get("ff_pictures") else None), "seconds": b["seconds"]}
         p0, l0 = ok.get("cpu_default_threading"), ok.get("gpu_lookahead_default_threading")
         ck = dt["encoder_clocks_ms_per_picture"]
         if ck.get("cpu_default_threading") and ck.get("all_gpu_default_threading") and ck["cpu_default_threading"].get("ctu_worker_time"):
@@ -309,7 +316,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
                              "the GPU producers are %s than not using ThreadedME at all (%.2fx).  A picture's CTU rows reach the producer in bands as its references' rows become final; a band that "
                              "would hold fewer than half the picture's rows waits up to 16 ms for another row -- a producer call is as long as one CTU's chain of searches whatever it holds and "
                              "costs the host a job set-up and its wake-ups (profiles/r05_min_rows_ab.txt: 7.0 fps without the wait, 8.4 with it; r05_queues_ab.txt: the waiting workers on two queues, no helpers under frame threads: ~9.8).  The lookahead seam alone (no "
-                             "--threaded-me, the plain encoder's bitstream) does %s fps; the in-loop filters stay the encoder's own under frame threads.  RDO and entropy coding on the host bound the encode"
+                             "--threaded-me, the plain encoder's bitstream) does %s fps; gpu_run.seams says whether the filter seam (bands of CTU rows under frame threads, r06) is part of the value.  RDO and entropy coding on the host bound the encode"
                              % (b["fps"], a["fps"], b["fps"] / a["fps"], p0["fps"], "FASTER" if b["fps"] > p0["fps"] else "SLOWER", b["fps"] / p0["fps"], ("%.2f" % l0["fps"]) if l0 else "n/a"))
         out["default_threading"] = dt
         if b and p0 and dt.get("bitstream_identical_gpu_vs_cpu_producers"):
@@ -319,7 +326,7 @@ def e2e_fps_leg(frames=24, seam_frames=8, default_frames=48):
             out["same_encoder_cpu_producer_fps"] = a["fps"]
             out["encoder_alone_fps"] = p0["fps"]
             out["config"] = ("BASELINE configs[1]: 1920x1088 8-bit, preset medium with its own defaults, the CLI's default threading (%s frame threads, WPP, every core the host grants), %d frames, medians of "
-                             "repeated runs: value = --threaded-me with the GPU ThreadedME + GPU lookahead (the in-loop filters are the encoder's own under frame threads); same_encoder_cpu_producer_fps = the same "
+                             "repeated runs: value = --threaded-me with the GPU producers on the seams gpu_run.seams names; same_encoder_cpu_producer_fps = the same "
                              "with the encoder's own producers (same bitstream); encoder_alone_fps = no --threaded-me" % (b.get("frame_threads"), default_frames))
     if both:
         l = runs["la_gpu"]

@@ -93,8 +93,9 @@ def test_what_the_producer_does_not_take_under_frame_threads_goes_back_to_the_en
     frameencoder.cpp:1624 sets the frame encoder's only -- no defined behaviour to reproduce) and --me sea with several frame threads (bands are served by the chain kernels): the
     binding hands every CTU to the encoder's own body, says so once on stderr, and the encode writes what it writes without the binding."""
     for name, opts in (("slices", ("slices=2",)), ("sea", ("me=sea",))):
-        with_binding = encode(mock, tmp_path, name + "_b", frames=6, env={"X265_CLI_THREADING": "1"}, options=THREADS + opts)
-        without = encode(mock, tmp_path, name + "_c", frames=6, env={"X265_CLI_THREADING": "1", "X265TMEGPU": "0"}, options=THREADS + opts)
+        size = (416, 240) if name == "sea" else (640, 368)          # (the exhaustive-style SEA search is slow on the CPU)
+        with_binding = encode(mock, tmp_path, name + "_b", frames=5, size=size, env={"X265_CLI_THREADING": "1"}, options=THREADS + opts)
+        without = encode(mock, tmp_path, name + "_c", frames=5, size=size, env={"X265_CLI_THREADING": "1", "X265TMEGPU": "0"}, options=THREADS + opts)
         assert with_binding["rc"] == 0 and without["rc"] == 0, with_binding["stderr"][-400:]
         assert "the encoder's own ThreadedME producer runs" in with_binding["stderr"] and with_binding["gpu_pictures"] == 0
         assert with_binding["threaded_me"] == 1 and with_binding["frame_threads"] == 5

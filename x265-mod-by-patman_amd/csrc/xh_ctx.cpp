@@ -24,14 +24,14 @@ struct x265hip_ctx
     struct Spare { void* p; size_t bytes; };
     std::vector<Spare> spare; size_t spareBytes = 0;
     static constexpr size_t kSpareMin = (size_t)64 << 20, kSpareMax = (size_t)96 << 30;
-    void* take(size_t bytes)
+    void* take(size_t bytes, size_t* actual)
     {
         if (xh::kFence || bytes < kSpareMin) return nullptr;
         int best = -1;
         for (int i = 0; i < (int)spare.size(); i++)
             if (spare[i].bytes >= bytes && spare[i].bytes <= bytes + bytes / 4 && (best < 0 || spare[i].bytes < spare[best].bytes)) best = i;
         if (best < 0) return nullptr;
-        void* p = spare[best].p; spareBytes -= spare[best].bytes;
+        void* p = spare[best].p; spareBytes -= spare[best].bytes; *actual = spare[best].bytes;
         spare.erase(spare.begin() + best);
         return p;
     }
@@ -102,14 +102,15 @@ struct x265hip_batch
     std::vector<void*> owned; std::vector<size_t> ownedBytes;
     template<class T> int alloc(T*& p, size_t n, const char* file = __builtin_FILE(), int line = __builtin_LINE())
     {
-        void* v = ctx->take(n * sizeof(T));                      // a large block of an earlier batch of this context, or a fresh one
+        size_t got = n * sizeof(T);                              // (a kept block may be up to a quarter larger than asked for: it goes back with its own size)
+        void* v = ctx->take(n * sizeof(T), &got);                // a large block of an earlier batch of this context, or a fresh one
         if (!v)
         {
             hipError_t e = xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line));
             if (e == hipErrorOutOfMemory && ctx->spareBytes) { (void)hipGetLastError(); ctx->trim(); e = xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line)); }      // the kept blocks did not fit this batch: give them back and ask again
             XH_HIP(e);
         }
-        owned.push_back(v); ownedBytes.push_back(n * sizeof(T)); p = (T*)v;
+        owned.push_back(v); ownedBytes.push_back(got); p = (T*)v;
         return X265HIP_OK;
     }
 };
