@@ -11,6 +11,12 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # X265HIP_EMU=1 (tests/emu/run_gpu_suite.sh, tests/test_emu_kernels.py): the `-m gpu` tests against the library's sources compiled for the host (tests/emu: a workgroup as
+    # fibers, the cross-lane operations modelled) -- the tests' "device" tensors are CPU tensors then.  Test infrastructure; nothing of the product reads the variable
+    if os.environ.get("X265HIP_EMU"):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import torch_on_host
+        torch_on_host.install()
     # tools/fence_run.sh: the tests' own device tensors through the fence allocator too (every block ends at an unmapped page; csrc/xh_fence.h)
     fence = os.environ.get("X265HIP_FENCE_TORCH")
     if fence:

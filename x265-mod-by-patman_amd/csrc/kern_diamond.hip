@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void diamond_kernel(int w, int h, const pixel*
                                                       const x265hip_me_task* __restrict__ tasks, int n, const uint16_t* __restrict__ costCentre, int chr,
                                                       x265hip_me_result* __restrict__ results, int64_t rowStride)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) char, smem)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, item = blockIdx.x * 4 + wave;
     if (item >= n) return;
     lpixel* fenc = (lpixel*)smem + wave * w * h;

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(1024) void la_search_kernel(LaGeom g, const x265hip
     int32_t* mvCost = mvCosts + (int64_t)slot * ncu;
     const int w0 = tp->weighted0;
     const int refFrame = list ? tp1 : ((w0 > 0 && useWeighted) ? w0 - 1 : tp0);
-    extern __shared__ uint16_t s_cost[];                       // 2 * costR + 1 entries of the cost row
+    HIP_DYNAMIC_SHARED(uint16_t, s_cost)                       // 2 * costR + 1 entries of the cost row
     for (int i = threadIdx.x; i <= 2 * costR; i += blockDim.x) s_cost[i] = costCentre[i - costR];
     __syncthreads();
     const uint32_t fencPlane = plane0_off(g, tb), rp = plane0_off(g, refFrame);

@@ -29,7 +29,7 @@ __device__ __forceinline__ void store4g(pixel* p, const int* v)      // 4 pixels
 {
 #if X265_DEPTH == 8
     int v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));      // see xh_mc.h store4(): v_ashr_pk_u8_i32 miscompile
+    XH_PIN_VGPRS("+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));      // see xh_mc.h store4(): v_ashr_pk_u8_i32 miscompile
 #if XP_NT_STORES
     __builtin_nontemporal_store((uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24), (uint32_t*)p);
 #else
@@ -90,7 +90,7 @@ __device__ __forceinline__ void store_px4(pixel* uniformBase, uint32_t threadOff
 }
 __device__ __forceinline__ uint32_t pack_u8(int a, int b, int c, int d)
 {
-    asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));          // see xh_mc.h store4(): v_ashr_pk_u8_i32 miscompile
+    XH_PIN_VGPRS("+v"(a), "+v"(b), "+v"(c), "+v"(d));          // see xh_mc.h store4(): v_ashr_pk_u8_i32 miscompile
     return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
 }
 // the 8 bytes starting `sh` bytes into the 12-byte window (w0, w1, w2), sh = 0..3 (compile-time)

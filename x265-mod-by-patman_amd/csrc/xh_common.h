@@ -54,6 +54,14 @@ int hip_fail(hipError_t e, const char* what);          // records + returns X265
 #endif
 #define XH_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return xh::hip_fail(e_, "kernel launch"); } while (0)
 
+// An empty volatile asm with "+v" operands pins values to VGPRs at a program point: an ordering barrier for the compiler's scheduler (xh_mc.h store4, star64_body.inc pin).
+// XH_EMU is defined by tests/emu/hip/hip_runtime.h, the host emulation the CPU tests compile these sources with: it has no VGPRs (and no scheduler to hold back).
+#ifdef XH_EMU
+#define XH_PIN_VGPRS(...) ((void)0)
+#else
+#define XH_PIN_VGPRS(...) asm volatile("" : __VA_ARGS__)
+#endif
+
 // ---- device helpers ----
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ pixel clip_pixel(int v) { return (pixel)clip3(0, XH_PIXEL_MAX, v); }

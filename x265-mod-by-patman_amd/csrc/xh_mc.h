@@ -76,7 +76,7 @@ __device__ __forceinline__ void store4(lpixel* p, const int* v)     // aligned (
     // result the compiler then ORs with bytes 2-3 as if its upper 16 bits were zero -- they keep the old register
     // contents (observed: bytes 2/3 of every packed quad corrupted).  Materialise the four values first.
     int v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+    XH_PIN_VGPRS("+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
     *(lu32*)p = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
 #else
     u32x2 a; a.x = (uint32_t)v[0] | ((uint32_t)v[1] << 16); a.y = (uint32_t)v[2] | ((uint32_t)v[3] << 16);
