@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 /* ---- qualifiers ---- */
@@ -99,7 +100,7 @@ inline void* dyn_lds() { return g->dyn.data(); }
 
 /* Release the cross-lane operations of one wavefront that can go: a lane's operation is COMPLETE when every live lane of its scope (the lanes its result can depend on: its
    quad / row of 16 / 32 lanes / the wavefront) waits at the same operation -- lane groups of one wavefront that run different control flow (several PUs per wavefront, each with
-   its own search) then proceed independently, as they do under EXEC masks.  `force`: nothing else in the workgroup can run -- the lanes of the most recently reached operation
+   its own search) then proceed independently, as they do under EXEC masks.  `force`: nothing else in the workgroup can run -- the lanes of ONE pending operation (chosen below)
    go with the lanes that are there (the others count as inactive: they returned, or sit in a branch that never comes here). */
 inline bool release_wave(Group& G, int w0, bool force)
 {
@@ -112,9 +113,15 @@ inline bool release_wave(Group& G, int w0, bool force)
         if (G.f[i].st == AT_WAVE) { bool seen = false; for (int k = 0; k < ns; k++) seen |= sites[k] == G.f[i].site; if (!seen) sites[ns++] = G.f[i].site; }
     int forcedSite = -1;
     if (force)
-    {
-        uint64_t best = 0;
-        for (int i = w0; i < w1; i++) if (G.f[i].st == AT_WAVE && G.f[i].stamp >= best) { best = G.f[i].stamp; forcedSite = G.f[i].site; }
+    {   /* the most LOCAL pending operation first (a quad / row operation inside divergent code comes before the wavefront-wide one at the point where the lanes meet again);
+           among equals the one reached last (lanes still inside a loop come back to their operation, the lanes that left it wait behind it) */
+        int bestScope = 65; uint64_t bestStamp = 0;
+        for (int i = w0; i < w1; i++)
+            if (G.f[i].st == AT_WAVE)
+            {
+                const int sc = __builtin_popcountll(G.f[i].scope);
+                if (sc < bestScope || (sc == bestScope && G.f[i].stamp >= bestStamp)) { bestScope = sc; bestStamp = G.f[i].stamp; forcedSite = G.f[i].site; }
+            }
     }
     for (int k = 0; k < ns; k++)
     {
@@ -192,8 +199,10 @@ inline Snapshot* wave_exchange(int site, uint64_t v, uint64_t scope)
 }
 inline void done(Snapshot* s) { if (--s->users == 0) delete s; }
 
+inline std::recursive_mutex& launch_mutex() { static std::recursive_mutex m; return m; }
 template<class F> void launch(dim3 grid, dim3 block, size_t dynBytes, F&& body)
 {
+    std::lock_guard<std::recursive_mutex> guard(launch_mutex());      /* the scheduler's state and the kernels' __shared__ statics are the process's: one launch at a time, whichever host thread asks */
     std::function<void()> fn = body;
     gridDim = grid; blockDim = block; g_dynBytes = dynBytes;
     for (unsigned z = 0; z < grid.z; z++) for (unsigned y = 0; y < grid.y; y++) for (unsigned x = 0; x < grid.x; x++) { blockIdx = uint3{ x, y, z }; run_group(block, fn); }
@@ -490,7 +499,7 @@ inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; return hipSuccess; }      /* (no clock here: a millisecond, so that callers' rates are finite) */
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : e == hipErrorOutOfMemory ? "hipErrorOutOfMemory" : "hip error (emulation)"; }

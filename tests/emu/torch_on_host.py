@@ -31,7 +31,7 @@ class _Event:
         pass
 
     def elapsed_time(self, other):
-        return 0.0
+        return 1.0          # (a millisecond: the tests print rates from it)
 
 
 class _Stream:
@@ -62,7 +62,9 @@ class _Stream:
 def install():
     for name in ("zeros", "empty", "ones", "full", "tensor", "arange", "zeros_like", "empty_like", "as_tensor", "randint", "rand", "randn"):
         setattr(torch, name, _wrap(getattr(torch, name)))
-    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.cuda = lambda self, *a, **k: self.clone()          # a copy, as a transfer to the device is (the source array must not alias the "device" tensor)
+    real_cpu = torch.Tensor.cpu
+    torch.Tensor.cpu = lambda self, *a, **k: real_cpu(self, *a, **k).clone()
     real_to = torch.Tensor.to
 
     def to(self, *a, **k):

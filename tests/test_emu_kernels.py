@@ -1,0 +1,78 @@
+"""The kernel SOURCES on the CPU: a fixed selection of the `-m gpu` tests against the emulated library of tests/emu (x265-mod-by-patman_amd/csrc compiled for the host against
+tests/emu/hip/hip_runtime.h: a workgroup as fibers, the cross-lane operations, MFMA, LDS and atomics modelled -- tests/emu/README.md).  What runs here is the library's own code
+(every table slot, the batched entry points, the ME / TQ batch pipeline, the lookahead, the filter producer in bands, the ThreadedME producer inside the compiled reference encoder)
+against the oracle, the reference's golden vectors and the reference encoder's bitstream -- without a GPU.  It says nothing about speed, about races between wavefronts or about
+the compiler's gfx950 code: the GPU tests proper stay the `-m gpu` run.  tests/emu/run_gpu_suite.sh runs everything that is not full-size (profiles/r06_emu_gpu_suite.txt)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CLANG), reason="no host clang++ to compile the sources with")
+
+
+@pytest.fixture(scope="module")
+def emulated_library():
+    subprocess.check_call(["make", "-s", "-j%d" % (os.cpu_count() or 2), "-C", EMU, "all"])
+    for d in (8, 10):
+        assert os.path.exists(os.path.join(EMU, "_build", "libx265hip_%d.so" % d))
+    return os.path.join(EMU, "_build")
+
+
+def run_gpu_tests(libdir, node_ids, jobs=4, timeout=900):
+    env = dict(os.environ, X265HIP_EMU="1", X265HIP_LIBDIR=libdir)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", "-n", str(jobs)] + list(node_ids), cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    tail = r.stdout[-3000:] + r.stderr[-1000:]
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], tail
+    return r.stdout.splitlines()[-1]
+
+
+def test_the_emulated_library_is_the_librarys_own_sources(emulated_library):
+    """the emulated library exports the C ABI of include/*.h like the real one (same export map), and nothing in the package or the bench can reach it"""
+    import ctypes as C
+    import re
+    lib = C.CDLL(os.path.join(emulated_library, "libx265hip_8.so"))
+    declared = set()
+    for hdr in os.listdir(os.path.join(ROOT, "include")):
+        declared |= set(re.findall(r"\b(x265hip_\w+)\s*\(", open(os.path.join(ROOT, "include", hdr)).read()))
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing[:5]
+    pkg = os.path.join(ROOT, "x265-mod-by-patman_amd")
+    for path in [os.path.join(ROOT, "bench.py")] + [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py")] + [os.path.join(ROOT, "integration", f) for f in os.listdir(os.path.join(ROOT, "integration"))]:
+        src = open(path).read()
+        assert "X265HIP_EMU" not in src and "tests/emu" not in src, path + " must not know the emulation"
+
+
+def test_every_table_slot_and_batched_entry_point(emulated_library):
+    """the table's slots against the oracle (test_hip_parity.py), the reference's golden vectors (test_golden.py, test_filters_golden.py,
+    test_lookahead_golden.py), the batched entry points (test_batch_api_gpu.py), deblocking and SAO statistics (small pictures)"""
+    print(run_gpu_tests(emulated_library, ["tests/test_hip_parity.py", "tests/test_golden.py", "tests/test_filters_golden.py", "tests/test_batch_api_gpu.py",
+                                           "tests/test_sao_gpu.py", "tests/test_deblock_gpu.py", "-k", "not 1920"]))
+
+
+def test_motion_search_and_the_batch_pipeline(emulated_library):
+    """a9 / a21: motionEstimate in every method on the kernels' lane groups, and the C++ host's batch (phase planes, the ME pyramid, the choice among references, TQ) against the
+    oracle -- P and B pictures, rect, AMP, streams"""
+    print(run_gpu_tests(emulated_library, ["tests/test_me_gpu.py::test_me_batch_matches_oracle", "tests/test_me_gpu.py::test_star_search_from_a_start_outside_the_window",
+                                           "tests/test_host_batch_gpu.py::test_host_batch_matches_oracle", "tests/test_tq_gpu.py", "-k", "not whole and not 1080 and not 2160 and not 4320 and not full_size"]))
+
+
+def test_the_filter_producer_in_bands_and_the_lookahead(emulated_library):
+    """f4 (this round's band form of x265hip_ff_picture: two pictures interleaved through one producer, against the oracle's row forms) and f2 (lowres costs, --hme, cuTree)"""
+    print(run_gpu_tests(emulated_library, ["tests/test_ff_host_gpu.py", "tests/test_lookahead_gpu.py", "-k", "not 1920 and not 640"]))
+
+
+def test_the_producers_inside_the_reference_encoder(emulated_library):
+    """f1 / f4 end to end on the CPU: the compiled reference encoder with the EMULATED library as its ThreadedME producer (incl. this round's --intra-refresh windows, 8 and 10 bit,
+    and bands under frame threads) and as its filter producer in bands under frame threads -- the bitstream of the encoder's own producers / filters"""
+    print(run_gpu_tests(emulated_library, ["tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer[8-args0]", "tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer[8-args12]",
+                                           "tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer[10-args13]",
+                                           "tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer_under_frame_threads[8-args1]",
+                                           "tests/test_e2e_ff_gpu.py::test_bitstream_identical_with_gpu_filters_under_frame_threads[8-args1-1]",
+                                           "tests/test_e2e_ff_gpu.py::test_bands_on_request_with_one_frame_thread"], jobs=6))
