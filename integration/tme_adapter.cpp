@@ -14,7 +14,7 @@
  * m_bFrameParallel / m_refLagPixels are the producer's (desc.frameThreads).  With one frame thread every reference is complete and the band is the whole picture.
  *
  * Preconditions (checked): numRefIdx <= X265HIP_MAX_REF = MAX_NUM_REF.  Handed back to the encoder's own body (with a line on stderr): --slices with several frame threads (the
- * reference's ThreadedME reads uninitialised slice MV bounds there: nothing defined to reproduce) and --me sea with several frame threads (bands go through the chain kernels).
+ * reference's ThreadedME reads uninitialised slice MV bounds there: nothing defined to reproduce) and --me sea (the producer keeps no integral planes).
  */
 #include <atomic>
 #include <chrono>
@@ -125,11 +125,12 @@ void Analysis::deriveMVsForCTU(CUData& ctu, const CUGeom& cuGeom, Frame& frame)
         ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame);
         return;
     }
-    if (frame.m_param->frameNumThreads > 1 && frame.m_param->searchMethod == X265_SEA)
-    {   /* bands of CTU rows are served by the producer's chain kernels (DIA / HEX / UMH / STAR / FULL); its SEA path takes whole pictures only (kern_tme.hip: "a band of
-           CTUs is offered by the chain kernels only") -- with several frame threads the encoder's own body runs, as it did before the band protocol */
+    if (frame.m_param->searchMethod == X265_SEA)
+    {   /* the producer searches DIA / HEX / UMH / STAR / FULL (x265hip_me_batch_rows; the chain kernels).  SEA needs the reference's twelve integral planes, which the encoder
+           builds row by row in its filter pipeline (FrameFilter::computeMEIntegral, framefilter.cpp:793-833) and the producer does not keep (the batched SEA search itself
+           exists: x265hip_me_batch_sea, csrc/kern_me_sea.hip) -- the encoder's own body runs, under any threading */
         static std::atomic<int> told{0};
-        if (!told.exchange(1)) fprintf(stderr, "tme_adapter: --me sea with several frame threads: the encoder's own ThreadedME producer runs\n");
+        if (!told.exchange(1)) fprintf(stderr, "tme_adapter: --me sea: the encoder's own ThreadedME producer runs\n");
         ::deriveMVsForCTU_cpu(this, ctu, cuGeom, frame);
         return;
     }

@@ -77,7 +77,7 @@ def test_bitstream_identical_with_gpu_producer_under_frame_threads(depth, args, 
 
 @pytest.mark.parametrize("args,why", [(["192", "640", "6", "medium", "frame-threads=3", "wpp=1", "me=sea"], "sea"), (["256", "512", "6", "medium", "frame-threads=3", "wpp=1", "slices=2"], "slices")])
 def test_what_goes_back_to_the_encoders_own_producer_under_frame_threads(args, why, tmp_path):
-    """--me sea with frame threads (bands are served by the chain kernels; SEA takes whole pictures) and --slices with frame threads (the reference's ThreadedME reads
+    """--me sea (the producer keeps no SEA integral planes) and --slices with frame threads (the reference's ThreadedME reads
     uninitialised slice MV bounds: nothing defined to reproduce): the binding hands the CTUs back to the encoder's own body and the encode writes the reference's bitstream."""
     cpu, h_cpu = encode(8, "cpu", args, str(tmp_path / "cpu.hevc"))
     gpu, h_gpu = encode(8, "gpu", args, str(tmp_path / "gpu.hevc"))

@@ -90,7 +90,7 @@ def test_weighted_references_and_the_rectangular_schedule_under_frame_threads(mo
 
 def test_what_the_producer_does_not_take_under_frame_threads_goes_back_to_the_encoders_own_body(mock, tmp_path):
     """--slices with several frame threads (the reference's ThreadedME workers read Search::m_sliceMinY / m_sliceMaxY, which nothing initialises on THEIR Analysis objects:
-    frameencoder.cpp:1624 sets the frame encoder's only -- no defined behaviour to reproduce) and --me sea with several frame threads (bands are served by the chain kernels): the
+    frameencoder.cpp:1624 sets the frame encoder's only -- no defined behaviour to reproduce) and --me sea (the producer keeps no SEA integral planes; under any threading): the
     binding hands every CTU to the encoder's own body, says so once on stderr, and the encode writes what it writes without the binding."""
     for name, opts in (("slices", ("slices=2",)), ("sea", ("me=sea",))):
         size = (416, 240) if name == "sea" else (640, 368)          # (the exhaustive-style SEA search is slow on the CPU)
@@ -100,6 +100,9 @@ def test_what_the_producer_does_not_take_under_frame_threads_goes_back_to_the_en
         assert "the encoder's own ThreadedME producer runs" in with_binding["stderr"] and with_binding["gpu_pictures"] == 0
         assert with_binding["threaded_me"] == 1 and with_binding["frame_threads"] == 5
         assert with_binding["md5"] == without["md5"]
+    one = encode(mock, tmp_path, "sea1_b", frames=4, size=(256, 192), options=("me=sea",))
+    one_cpu = encode(mock, tmp_path, "sea1_c", frames=4, size=(256, 192), env={"X265TMEGPU": "0"}, options=("me=sea",))
+    assert one["rc"] == 0 and one["gpu_pictures"] == 0 and one["frame_threads"] == 1 and "the encoder's own ThreadedME producer runs" in one["stderr"] and one["md5"] == one_cpu["md5"]
 
 
 def test_intra_refresh_hands_the_window_limit_over(mock, tmp_path):

@@ -94,6 +94,7 @@ extern "C" int x265hip_tme_schedule(int ctuSize, int minCuSize, int rect, int am
 // Uploads the picture's planes, builds the phase planes, runs deriveMVsForCTU's first stage (x265hip_diamond_batch for the CTU and its four sub-CUs per reference,
 // then the caller's collocated-median override), steps x265hip_tme_frame through the schedule and copies the table back.
 #include "../../include/x265hip_ctx.h"
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <new>
@@ -127,6 +128,9 @@ struct x265hip_tme
     std::vector<x265hip_me_task> hTasks; std::vector<int32_t> hWhere;      // kept: the copies read them after the call that filled them returned
     // the slots of a CTU's table the schedule writes (and reads: neighbours are PUs of the same shape); sparse schedules move only these (pinned staging, packed [ctu][slot])
     std::vector<int32_t> slots; int32_t* dSlots = nullptr; x265hip_inter_choice* dPacked = nullptr; x265hip_inter_choice* hPacked = nullptr; bool sparse = false;
+    // the staging pair holds one REGION (nCtu x slots records) per table a call moves -- the picture's and its references' own: every table of a call packs into its own region,
+    // so no copy has to be waited for before the next table is packed (r05 drained the stream once per table: up to 1 + 2 x 16 times per call); regions grow on demand
+    int packRegions = 0, packNext = 0; size_t regionRecs = 0;
     // reconstructed reference pictures stay on the device (plane + its 16 phase planes) under the caller's key; the least recently used of kKeep makes room
     struct Kept { uint64_t key = 0; pixel* plane = nullptr; pixel* phase = nullptr; uint64_t used = 0; int rowsSeen = 0; };      // rowsSeen: plane rows on the device so far (a reference that is still being reconstructed grows)
     std::vector<Kept> kept; uint64_t tick = 0; int evictions = 0;
@@ -137,6 +141,19 @@ struct x265hip_tme
         void* v = nullptr;
         XH_HIP(xh::dev_alloc(&v, n * sizeof(T), xh::alloc_tag(file, line)));
         owned.push_back(v); p = (T*)v;
+        return X265HIP_OK;
+    }
+    // at least `n` regions in the staging pair (called with the stream idle: at creation, and at the start of a call that moves more tables than any before it)
+    int pack_regions(int n)
+    {
+        if (n <= packRegions) return X265HIP_OK;
+        if (hPacked) { XH_HIP(hipHostFree(hPacked)); hPacked = nullptr; }
+        if (dPacked) { owned.erase(std::remove(owned.begin(), owned.end(), (void*)dPacked), owned.end()); XH_HIP(xh::dev_free(dPacked)); dPacked = nullptr; }
+        packRegions = 0;
+        int rc = alloc(dPacked, regionRecs * n);
+        if (rc) return rc;
+        XH_HIP(hipHostMalloc((void**)&hPacked, regionRecs * n * sizeof(x265hip_inter_choice), hipHostMallocDefault));
+        packRegions = n;
         return X265HIP_OK;
     }
 };
@@ -176,10 +193,10 @@ extern "C" int x265hip_tme_create(x265hip_ctx* ctx, int width, int height, int c
         t->sparse = t->slots.size() * 2 < 593;
         if (t->sparse)
         {
-            const size_t nrec = (size_t)t->nCtu * t->slots.size();
-            if ((rc = t->alloc(t->dSlots, t->slots.size())) || (rc = t->alloc(t->dPacked, nrec))) { x265hip_tme_destroy(t); return rc; }
-            if (hipMemcpy(t->dSlots, t->slots.data(), t->slots.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
-                hipHostMalloc((void**)&t->hPacked, nrec * sizeof(x265hip_inter_choice), hipHostMallocDefault) != hipSuccess) { x265hip_tme_destroy(t); return X265HIP_EDEVICE; }
+            t->regionRecs = (size_t)t->nCtu * t->slots.size();
+            if ((rc = t->alloc(t->dSlots, t->slots.size()))) { x265hip_tme_destroy(t); return rc; }
+            if (hipMemcpy(t->dSlots, t->slots.data(), t->slots.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { x265hip_tme_destroy(t); return X265HIP_EDEVICE; }
+            if ((rc = t->pack_regions(4))) { x265hip_tme_destroy(t); return rc; }          // the picture's table + three references' (preset medium); more when a picture brings more
         }
     }
     std::vector<float> bits(2 * kBitsHalf + 1);
@@ -239,15 +256,24 @@ extern "C" int x265hip_tme_picture(x265hip_tme* t, const x265hip_tme_picture_des
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     auto lap = [&](int k, bool sync) { if (!t->prof) return; if (sync) (void)hipStreamSynchronize(st); const double t1 = now(); if (t->first) t->sec[k] += t1 - t0; t0 = t1; };      // the first picture (streams, code objects) is not counted
-    // host table -> device table: whole, or the schedule's slots through the pinned buffer (the stream is drained before the buffer is reused)
+    if (t->sparse)
+    {   // a staging region per table this call moves (the picture's + its references' own); the stream is idle here -- the call before ended with a synchronisation
+        int nTables = 1;
+        for (int l = 0; l < nl; l++) for (int r = 0; r < d->numRef[l]; r++) nTables += d->refs[l][r].refTable != nullptr;
+        if ((rc = t->pack_regions(nTables))) return rc;
+        t->packNext = 0;
+    }
+    // host table -> device table: whole, or the schedule's slots through the pinned staging pair (a region of its own per table: nothing is waited for in between)
     auto table_up = [&](x265hip_inter_choice* dev, const x265hip_inter_choice* host) -> int
     {
         if (!t->sparse) { XH_HIP(hipMemcpyAsync(dev + (size_t)c0 * 593, host + (size_t)c0 * 593, (size_t)nCtu * 593 * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st)); return X265HIP_OK; }
         const int nU = (int)t->slots.size();
-        XH_HIP(hipStreamSynchronize(st));
-        for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) t->hPacked[(size_t)c * nU + k] = host[(size_t)(c0 + c) * 593 + t->slots[k]];
-        XH_HIP(hipMemcpyAsync(t->dPacked, t->hPacked, (size_t)nCtu * nU * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
-        return xh_tme_slots(st, dev + (size_t)c0 * 593, t->dPacked, t->dSlots, nU, nCtu, 1);
+        if (t->packNext >= t->packRegions) { set_error("tme_picture: more tables than staging regions"); return X265HIP_EARG; }      // (sized at the start of the call)
+        x265hip_inter_choice* h = t->hPacked + (size_t)t->packNext * t->regionRecs; x265hip_inter_choice* dv = t->dPacked + (size_t)t->packNext * t->regionRecs;
+        t->packNext++;
+        for (int c = 0; c < nCtu; c++) for (int k = 0; k < nU; k++) h[(size_t)c * nU + k] = host[(size_t)(c0 + c) * 593 + t->slots[k]];
+        XH_HIP(hipMemcpyAsync(dv, h, (size_t)nCtu * nU * sizeof(x265hip_inter_choice), hipMemcpyHostToDevice, st));
+        return xh_tme_slots(st, dev + (size_t)c0 * 593, dv, t->dSlots, nU, nCtu, 1);
     };
     if (t->planeElems != elems)
     {   // first picture (or another plane geometry): the device planes
