@@ -413,8 +413,8 @@ int x265hip_sao_stats_frame_slices(void* stream, const void* fenc, const void* r
 /* the CTUs of the rows [ctuRow0, ctuRow1) only -- their entries of `out`, the others are not touched.  A band of FrameFilter::processRow's pipeline (framefilter.cpp:490-500:
  * rdoSaoUnitCu of row r runs before row r + 1 is deblocked): the rows below need not be deblocked yet, a CTU's statistics leave out the lines the next row's deblocking changes
  * (skipB) and read one line beyond them, which it does not change. */
-int x265hip_sao_stats_rows(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
-                           int planeOffset, int32_t* out, const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1);
+int x265hip_sao_stats_rows(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuWidth, int ctuHeight, int nonDeblocked,
+                           int planeOffset, int32_t* out, const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1);      /* ctuWidth x ctuHeight: the CTU in this plane (4:2:2 chroma: w = h / 2) */
 
 /* SAO of a whole luma plane, OUT OF PLACE (in != out): SAO::generateLumaOffsets + applyPixelOffsets (encoder/sao.cpp:268-623) for every CTU.  The
  * reference filters in place and classifies against saved unmodified neighbours (m_tmpU, m_tmpL); reading the input plane is the same thing.
@@ -459,6 +459,8 @@ typedef struct x265hip_deblock_pic
     const uint8_t* sliceFirstRow;   /* --slices: per CTU row, non-zero where the row begins a slice (CUData::m_bFirstRowInSlice: the CTU above is no neighbour, cudata.cpp:323 -- the
                                        row's top edge is not filtered); NULL = one slice.  ceil(height / ctuSize) + 1 entries, the last one 0.  Like the other arrays: device memory for
                                        x265hip_deblock_frame / _pictures, host memory inside x265hip_ff_picture_desc */
+    int chromaFormat;               /* X265_CSP_*: 0 or 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 -- the subsampling of Cb / Cr (their size in samples, the grid their edges lie on, the QP rule:
+                                       deblock.cpp:104-113, 417-497) */
 } x265hip_deblock_pic;
 int x265hip_deblock_frame(void* stream, const x265hip_deblock_pic* desc, void* Y, intptr_t strideY, void* Cb, void* Cr, intptr_t strideC, uint8_t* bsOut);
 /* A band of CTU rows [ctuRow0, ctuRow1) (FrameFilter::processRow's order, encoder/framefilter.cpp:576-676): the edges of those rows' CTUs, the band's top edge included -- it changes

@@ -101,10 +101,10 @@ thread_local Replay* t_replay = nullptr;
 /* does the binding filter this FrameFilter's pictures (a function of the encoder's parameters and the picture format only: the same answer for every picture of an encode) */
 bool takes(const FrameFilter& ff, const x265_param& p, const Frame* frame, bool useSao)
 {
-    if (!(g_on && (p.bEnableLoopFilter || useSao) && ff.m_parallelFilter && p.internalCsp == X265_CSP_I420 && frame)) return false;
+    if (!(g_on && (p.bEnableLoopFilter || useSao) && ff.m_parallelFilter && p.internalCsp != X265_CSP_I400 && frame)) return false;
     if (p.frameNumThreads > 1 && p.maxSlices > 1) return false;             /* slices finish in any order and pictures overlap: the encoder's own filters */
     const PicYuv& rp = *frame->m_reconPic[0]; const PicYuv& fp = *frame->m_fencPic;
-    return fp.m_picCsp == X265_CSP_I420 && rp.m_stride == fp.m_stride && rp.m_strideC == fp.m_strideC && !(p.sourceWidth & 7) && !(p.sourceHeight & 7);
+    return fp.m_picCsp == p.internalCsp && rp.m_stride == fp.m_stride && rp.m_strideC == fp.m_strideC && !(p.sourceWidth & 7) && !(p.sourceHeight & 7);
 }
 inline bool band_mode(const x265_param& p) { return p.frameNumThreads > 1 || g_bandRows > 0; }
 
@@ -160,6 +160,7 @@ void describe(FrameFilter& ff, Staging& S, int rowA, int row1, x265hip_ff_pictur
     d.pic.width = p.sourceWidth; d.pic.height = p.sourceHeight; d.pic.ctuSize = (int)p.maxCUSize; d.pic.sliceIsP = !isB;
     d.pic.betaOffsetDiv2 = slice->m_pps->deblockingFilterBetaOffsetDiv2; d.pic.tcOffsetDiv2 = slice->m_pps->deblockingFilterTcOffsetDiv2;
     d.pic.cbQpOffset = slice->m_pps->chromaQpOffset[0]; d.pic.crQpOffset = slice->m_pps->chromaQpOffset[1]; d.pic.tqBypassEnabled = bypass;
+    d.pic.chromaFormat = p.internalCsp;                       /* X265_CSP_I420 / I422 / I444: the chroma planes' subsampling */
     d.pic.log2CUSize = S.log2CUSize.data(); d.pic.partSize = S.partSize.data(); d.pic.tuDepth = S.tuDepth.data(); d.pic.predMode = S.predMode.data();
     d.pic.cbfLuma = S.cbf.data(); d.pic.tqBypass = bypass ? S.tqBypass.data() : NULL; d.pic.qp = S.qp.data();
     d.pic.refIdx0 = S.refIdx[0].data(); d.pic.mv0 = S.mv[0].data(); d.pic.refIdx1 = isB ? S.refIdx[1].data() : NULL; d.pic.mv1 = isB ? S.mv[1].data() : NULL;

@@ -36,14 +36,16 @@ int main(int argc, char** argv)
     const int W = atoi(argv[1]), H = atoi(argv[2]), ctu = atoi(argv[3]);
     x265_param* p = x265_param_alloc();
     x265_param_default_preset(p, "medium", NULL);
-    p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = X265_CSP_I420; p->maxCUSize = ctu; p->minCUSize = 8;
+    const int csp = getenv("X265REF_CSP") ? atoi(getenv("X265REF_CSP")) : X265_CSP_I420;      /* 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 */
+    const int hs = csp == X265_CSP_I444 ? 0 : 1, vs = csp == X265_CSP_I420 ? 1 : 0;
+    p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = csp; p->maxCUSize = ctu; p->minCUSize = 8;
     p->maxLog2CUSize = ctu == 64 ? 6 : ctu == 32 ? 5 : 4; p->unitSizeDepth = p->maxLog2CUSize - 2;       /* Encoder::configure */
     p->num4x4Partitions = (ctu >> 2) * (ctu >> 2);
     x265_setup_primitives(p);
     static SPS sps; static PPS pps;
     memset(&sps, 0, sizeof(sps)); memset(&pps, 0, sizeof(pps));
     sps.numCuInWidth = (W + ctu - 1) / ctu; sps.numCuInHeight = (H + ctu - 1) / ctu; sps.numCUsInFrame = sps.numCuInWidth * sps.numCuInHeight;
-    sps.numPartitions = p->num4x4Partitions; sps.numPartInCUSize = ctu >> 2; sps.chromaFormatIdc = X265_CSP_I420;
+    sps.numPartitions = p->num4x4Partitions; sps.numPartInCUSize = ctu >> 2; sps.chromaFormatIdc = csp;
     pps.deblockingFilterBetaOffsetDiv2 = atoi(argv[7]); pps.deblockingFilterTcOffsetDiv2 = atoi(argv[8]);
     pps.chromaQpOffset[0] = atoi(argv[9]); pps.chromaQpOffset[1] = atoi(argv[10]); pps.bTransquantBypassEnabled = atoi(argv[11]) != 0;
 
@@ -56,7 +58,7 @@ int main(int argc, char** argv)
     PicYuv* pic = frame.m_reconPic[0];
     for (int c = 0; c < 3; c++)
     {
-        const int w = c ? W >> 1 : W, h = c ? H >> 1 : H;
+        const int w = c ? W >> hs : W, h = c ? H >> vs : H;
         const intptr_t st = c ? pic->m_strideC : pic->m_stride;
         for (int y = 0; y < h; y++)
             if (!rd(in, pic->m_picOrg[c] + (intptr_t)y * st, w)) { fprintf(stderr, "short input (planes)\n"); return 2; }
@@ -105,7 +107,7 @@ int main(int argc, char** argv)
     std::vector<uint16_t> line;
     for (int c = 0; c < 3; c++)
     {
-        const int w = c ? W >> 1 : W, h = c ? H >> 1 : H;
+        const int w = c ? W >> hs : W, h = c ? H >> vs : H;
         const intptr_t st = c ? pic->m_strideC : pic->m_stride;
         line.resize(w);
         for (int y = 0; y < h; y++) { for (int x = 0; x < w; x++) line[x] = pic->m_picOrg[c][(intptr_t)y * st + x]; fwrite(line.data(), 2, w, out); }

@@ -48,7 +48,7 @@ int main(int argc, char** argv)
     x265_param* p = x265_param_alloc();
     x265_param_default_preset(p, "medium", NULL);
     const int nplanes = argc > 7 ? atoi(argv[7]) : 1;
-    p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = nplanes == 3 ? X265_CSP_I420 : X265_CSP_I400; p->maxCUSize = ctu;
+    p->sourceWidth = W; p->sourceHeight = H; p->internalCsp = nplanes == 3 ? (getenv("X265REF_CSP") ? atoi(getenv("X265REF_CSP")) : X265_CSP_I420) : X265_CSP_I400;      /* X265REF_CSP: 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 */ p->maxCUSize = ctu;
     p->maxLog2CUSize = ctu == 64 ? 6 : ctu == 32 ? 5 : 4; p->unitSizeDepth = p->maxLog2CUSize - 2;       /* Encoder::configure */
     const int statMode = argc > 6 ? atoi(argv[6]) : 0;
     p->bSaoNonDeblocked = statMode ? 1 : 0; p->bLimitSAO = 0;
@@ -75,7 +75,7 @@ int main(int argc, char** argv)
         for (int k = 0; k < 2; k++)
         {
             PicYuv* pic = pics[k];
-            const int w = plane ? W >> 1 : W, h = plane ? H >> 1 : H;
+            const int w = plane ? W >> pic->m_hChromaShift : W, h = plane ? H >> pic->m_vChromaShift : H;
             const intptr_t st = plane ? pic->m_strideC : pic->m_stride;
             for (int y = 0; y < h; y++)
                 if (fread(pic->m_picOrg[plane] + (intptr_t)y * st, sizeof(pixel), w, in) != (size_t)w) { fprintf(stderr, "short input\n"); return 2; }
@@ -118,7 +118,7 @@ int main(int argc, char** argv)
         std::vector<pixel> pristine[3];
         for (int c = 0; c < nplanes; c++)
         {
-            const int w = c ? W >> 1 : W, h = c ? H >> 1 : H;
+            const int w = c ? W >> rp->m_hChromaShift : W, h = c ? H >> rp->m_vChromaShift : H;
             const intptr_t st = c ? rp->m_strideC : rp->m_stride;
             pristine[c].resize((size_t)st * h);
             for (int y = 0; y < h; y++) memcpy(&pristine[c][(size_t)y * st], rp->m_picOrg[c] + (intptr_t)y * st, w * sizeof(pixel));
@@ -129,7 +129,7 @@ int main(int argc, char** argv)
             /* copySaoAboveRef: the unmodified row above the CTU row -- for the first CTU row its own first row (framefilter.cpp:303-325) */
             for (int c = 0; c < nplanes; c++)
             {
-                const int w = c ? W >> 1 : W, ch = c ? ctu >> 1 : ctu;
+                const int w = c ? W >> rp->m_hChromaShift : W, ch = c ? ctu >> rp->m_vChromaShift : ctu;
                 const intptr_t st = c ? rp->m_strideC : rp->m_stride;
                 memcpy(sao.aboveRow(c), &pristine[c][(size_t)(row ? row * ch - 1 : 0) * st], w * sizeof(pixel));
             }
@@ -141,7 +141,7 @@ int main(int argc, char** argv)
         }
         for (int c = 0; c < nplanes; c++)
         {
-            const int w = c ? W >> 1 : W, h = c ? H >> 1 : H;
+            const int w = c ? W >> rp->m_hChromaShift : W, h = c ? H >> rp->m_vChromaShift : H;
             const intptr_t st = c ? rp->m_strideC : rp->m_stride;
             std::vector<int32_t> o((size_t)w * h);
             for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) o[(size_t)y * w + x] = rp->m_picOrg[c][(intptr_t)y * st + x];

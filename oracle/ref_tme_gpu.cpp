@@ -27,7 +27,7 @@
 
 using namespace X265_NS;
 
-static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixel>& v, int w, int h, int f)
+static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixel>& v, int w, int h, int f, int cw, int ch)      /* cw x ch: the chroma planes (the clip's format) */
 {   /* the clip of ref_tme.cpp: textured picture in (not purely translational) motion + deterministic noise */
     uint32_t s = 4242u + 733u * (uint32_t)f;
     const int pm = (1 << X265_DEPTH) - 1;
@@ -44,11 +44,11 @@ static void synth(std::vector<pixel>& y, std::vector<pixel>& u, std::vector<pixe
             if (fade) val = val * (16 - 2 * (f < 6 ? f : 6)) / 16 + 4 * f * (pm + 1) / 256;      /* a fade: weighted prediction gets something to do */
             y[(size_t)j * w + i] = (pixel)(val < 0 ? 0 : val > pm ? pm : val);
         }
-    for (int j = 0; j < h / 2; j++)
-        for (int i = 0; i < w / 2; i++)
+    for (int j = 0; j < ch; j++)
+        for (int i = 0; i < cw; i++)
         {
-            u[(size_t)j * (w / 2) + i] = (pixel)((((i + f) * 3 + j) & 127) * (pm + 1) / 256 + (pm + 1) / 4);
-            v[(size_t)j * (w / 2) + i] = (pixel)((((j + 2 * f) * 5 + i) & 127) * (pm + 1) / 256 + (pm + 1) / 4);
+            u[(size_t)j * cw + i] = (pixel)((((i + f) * 3 + j) & 127) * (pm + 1) / 256 + (pm + 1) / 4);
+            v[(size_t)j * cw + i] = (pixel)((((j + 2 * f) * 5 + i) & 127) * (pm + 1) / 256 + (pm + 1) / 4);
         }
 }
 
@@ -67,7 +67,10 @@ int main(int argc, char** argv)
     const int w = atoi(argv[2]), h = atoi(argv[3]), frames = atoi(argv[4]);
     x265_param* p = x265_param_alloc();
     if (x265_param_default_preset(p, argv[5], NULL) < 0) { fprintf(stderr, "bad preset\n"); return 2; }
-    p->sourceWidth = w; p->sourceHeight = h; p->fpsNum = 25; p->fpsDenom = 1; p->internalCsp = X265_CSP_I420;
+    /* X265_CSP=i422 / i444: the clip's (and the encode's) chroma format; default 4:2:0 */
+    const int csp = getenv("X265_CSP") ? (!strcmp(getenv("X265_CSP"), "i422") ? X265_CSP_I422 : !strcmp(getenv("X265_CSP"), "i444") ? X265_CSP_I444 : X265_CSP_I420) : X265_CSP_I420;
+    const int cw = csp == X265_CSP_I444 ? w : w / 2, ch = csp == X265_CSP_I420 ? h / 2 : h;
+    p->sourceWidth = w; p->sourceHeight = h; p->fpsNum = 25; p->fpsDenom = 1; p->internalCsp = csp;
     p->totalFrames = frames; p->logLevel = X265_LOG_WARNING; p->bRepeatHeaders = 1;
     if (!getenv("X265_CLI_THREADING"))
     {   /* the seams are checked with one frame thread and no WPP (complete reference pictures); X265_CLI_THREADING=1 leaves the threading the x265 CLI would use by
@@ -96,10 +99,10 @@ int main(int argc, char** argv)
     if (!enc) { fprintf(stderr, "encoder_open failed\n"); return 2; }
     x265_picture* pic = x265_picture_alloc();
     x265_picture_init(p, pic);
-    std::vector<pixel> Y((size_t)w * h), U((size_t)w * h / 4), V((size_t)w * h / 4);
+    std::vector<pixel> Y((size_t)w * h), U((size_t)cw * ch), V((size_t)cw * ch);
     pic->planes[0] = Y.data(); pic->planes[1] = U.data(); pic->planes[2] = V.data();
-    pic->stride[0] = w * (int)sizeof(pixel); pic->stride[1] = pic->stride[2] = (w / 2) * (int)sizeof(pixel);
-    pic->bitDepth = X265_DEPTH; pic->colorSpace = X265_CSP_I420;
+    pic->stride[0] = w * (int)sizeof(pixel); pic->stride[1] = pic->stride[2] = cw * (int)sizeof(pixel);
+    pic->bitDepth = X265_DEPTH; pic->colorSpace = csp;
     x265_nal* nal; uint32_t nnal;
     size_t bytes = 0;
     x265_picture* picOut = frameStats ? x265_picture_alloc() : NULL;
@@ -108,7 +111,7 @@ int main(int argc, char** argv)
     const auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < frames; f++)
     {
-        synth(Y, U, V, w, h, f);
+        synth(Y, U, V, w, h, f, cw, ch);
         pic->pts = f;
         const int r = x265_encoder_encode(enc, &nal, &nnal, pic, picOut);
         if (r < 0) { fprintf(stderr, "encode failed\n"); return 2; }

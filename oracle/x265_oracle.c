@@ -899,22 +899,29 @@ void xo_sao_stats_frame_slices(const xo_pixel* fenc, const xo_pixel* recon, intp
 {
     xo_sao_stats_rows(fenc, recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out, sliceFirstRow, 0, (picHeight + ctuSize - 1) / ctuSize);
 }
+void xo_sao_stats_rows(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
+                       const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1)
+{
+    xo_sao_stats_rows_wh(fenc, recon, stride, picWidth, picHeight, ctuSize, ctuSize, nonDeblocked, planeOffset, out, sliceFirstRow, ctuRow0, ctuRow1);
+}
 /* The CTUs of the rows [ctuRow0, ctuRow1) only (their entries of `out`; the others are not touched).  The rows below need not be deblocked yet: a CTU's statistics leave out the
  * lines the deblocking of the row below still changes (skipB) and read one line beyond them, which it does not change -- the order the reference works in (rdoSaoUnitCu of row r
  * runs before row r + 1 is deblocked, framefilter.cpp:490-500). */
-void xo_sao_stats_rows(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
-                       const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1)
+/* ... with the CTU's width and height in the plane given apart: the chroma planes of 4:2:2 have CTUs half as wide as high (ctuWidth >>= m_hChromaShift, ctuHeight >>=
+ * m_vChromaShift, sao.cpp:748-756) */
+void xo_sao_stats_rows_wh(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuW, int ctuH, int nonDeblocked, int planeOffset, int32_t* out,
+                          const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1)
 {   /* chroma planes: pass the PLANE's width / height / CTU size (already shifted, :748-756) and planeOffset = 2 (:773) */
     const int po = planeOffset;
-    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
+    const int nx = (picWidth + ctuW - 1) / ctuW, ny = (picHeight + ctuH - 1) / ctuH;
     if (ctuRow1 > ny) ctuRow1 = ny;
     for (int addr = ctuRow0 * nx; addr < ctuRow1 * nx; addr++)
     {
-        const int lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;
+        const int lpelx = (addr % nx) * ctuW, tpely = (addr / nx) * ctuH;
         const int row = addr / nx;
         const int firstRow = row == 0 || (sliceFirstRow && sliceFirstRow[row]), lastRow = row == ny - 1 || (sliceFirstRow && sliceFirstRow[row + 1]);
         const int bAboveUnavail = (!tpely) | firstRow;
-        const int rpelx = lpelx + ctuSize < picWidth ? lpelx + ctuSize : picWidth, bpely = tpely + ctuSize < picHeight ? tpely + ctuSize : picHeight;
+        const int rpelx = lpelx + ctuW < picWidth ? lpelx + ctuW : picWidth, bpely = tpely + ctuH < picHeight ? tpely + ctuH : picHeight;
         const int ctuWidth = rpelx - lpelx, ctuHeight = bpely - tpely;
         const int picH = lastRow ? bpely : picHeight;
         const xo_pixel* fenc0 = fenc + tpely * stride + lpelx; const xo_pixel* rec0 = recon + tpely * stride + lpelx;
@@ -1254,14 +1261,19 @@ void xo_deblock_rows(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_
                 }
                 const int qp = (d->qp[p] + d->qp[q] + 1) >> 1;
                 dbk_luma_segment(Y + (intptr_t)uy * 4 * strideY + ux * 4, dir ? 1 : strideY, dir ? strideY : 1, bs, qp, 2 * d->betaOffsetDiv2, 2 * d->tcOffsetDiv2, maskP, maskQ);
-                /* chroma (4:2:0): edges on the 16-sample luma grid, intra strength only, one 4-sample chroma segment per TWO luma units along the edge */
-                if (bs < 2 || ((dir ? uy : ux) & 3) || ((dir ? ux : uy) & 1)) continue;
+                /* chroma: edges on the 8-sample CHROMA grid across the edge (deblock.cpp:104-113: luma position a multiple of 8 << the chroma shift in that direction), intra
+                   strength only, one 4-sample chroma segment per (1 << the chroma shift ALONG the edge) luma units, its strength and QPs those of the first of them (:457-459).
+                   4:2:0: the 16-sample luma grid, a segment per two luma units; 4:2:2: 16 across vertical edges / 8 across horizontal ones, a segment per unit along vertical
+                   edges / per two along horizontal ones; 4:4:4: the luma grid */
+                const int hs = d->chromaFormat == 3 ? 0 : 1, vs = (d->chromaFormat == 2 || d->chromaFormat == 3) ? 0 : 1;
+                const int across = dir ? vs : hs, along = dir ? hs : vs;
+                if (bs < 2 || ((dir ? uy : ux) & ((2 << across) - 1)) || ((dir ? ux : uy) & ((1 << along) - 1))) continue;
                 for (int c = 0; c < 2; c++)
                 {
                     int cqp = qp + (c ? d->crQpOffset : d->cbQpOffset);
-                    if (cqp >= 30) cqp = k_dbkChromaScale[cqp > 57 ? 57 : cqp];
+                    if (cqp >= 30) cqp = d->chromaFormat <= 1 ? k_dbkChromaScale[cqp > 57 ? 57 : cqp] : (cqp < 51 ? cqp : 51);      /* :483-484: the table for 4:2:0 only */
                     const int tc = k_dbkTc[dbk_clip3(0, 53, cqp + 2 + 2 * d->tcOffsetDiv2)] << (X265_DEPTH - 8);
-                    xo_pixel* s = (c ? Cr : Cb) + (intptr_t)uy * 2 * strideC + ux * 2;
+                    xo_pixel* s = (c ? Cr : Cb) + (intptr_t)((uy * 4) >> vs) * strideC + ((ux * 4) >> hs);
                     const intptr_t step = dir ? 1 : strideC, off = dir ? strideC : 1;
                     for (int i = 0; i < 4; i++, s += step)
                     {

@@ -97,6 +97,8 @@ void xo_sao_stats_frame_slices(const xo_pixel* fenc, const xo_pixel* recon, intp
                                const uint8_t* sliceFirstRow);
 void xo_sao_stats_rows(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked, int planeOffset, int32_t* out,
                        const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1);   /* the CTUs of those rows only */
+void xo_sao_stats_rows_wh(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuW, int ctuH, int nonDeblocked, int planeOffset, int32_t* out,
+                          const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1);   /* CTU width and height apart (4:2:2 chroma planes) */
 void xo_sao_stats_frame_predeblock(const xo_pixel* fenc, const xo_pixel* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int planeOffset, int32_t* out);
 
 /* SAO of a luma plane, out of place (sao.cpp:268-623); params: per CTU { typeIdx, bandPos, offset[4] } */
@@ -113,6 +115,7 @@ typedef struct xo_deblock_pic
     const int32_t *mv0, *mv1;
     int32_t refPic[2][16];
     const uint8_t* sliceFirstRow;     /* --slices: per CTU row (+ one 0 entry), non-zero where a slice begins; NULL = one slice */
+    int chromaFormat;                 /* X265_CSP_*: 0 or 1 = 4:2:0, 2 = 4:2:2, 3 = 4:4:4 (the chroma planes' subsampling; deblock.cpp:104-113, 417-497) */
 } xo_deblock_pic;
 int xo_deblock_bs(const xo_deblock_pic* d, int ux, int uy, int dir);
 void xo_deblock_frame(const xo_deblock_pic* d, xo_pixel* Y, intptr_t strideY, xo_pixel* Cb, xo_pixel* Cr, intptr_t strideC, uint8_t* bsOut);

@@ -25,7 +25,12 @@ def morton(lx, ly):
     return z
 
 
-def coded_picture(depth, W, H, ctu, seed, slice_p=False, bypass=False, qp_range=(18, 46)):
+def chroma_shifts(csp):
+    """(horizontal, vertical) subsampling shifts of X265_CSP_I420 = 1 / I422 = 2 / I444 = 3"""
+    return (0 if csp == 3 else 1), (1 if csp in (0, 1) else 0)
+
+
+def coded_picture(depth, W, H, ctu, seed, slice_p=False, bypass=False, qp_range=(18, 46), csp=1):
     """W, H multiples of 8.  Returns dict(planes=[Y, Cb, Cr], arrays..., refPic, params)"""
     rng = np.random.default_rng(seed)
     nx, ny, upc = (W + ctu - 1) // ctu, (H + ctu - 1) // ctu, ctu // 4
@@ -117,12 +122,14 @@ def coded_picture(depth, W, H, ctu, seed, slice_p=False, bypass=False, qp_range=
     big = rng.random((H // 8, W // 8)) < 0.05                               # a few strong edges that must stay unfiltered
     Yf = np.clip(Y // 3 + pm // 3 + step + noise + big.repeat(8, 0).repeat(8, 1) * (pm // 3), 0, pm)
     k = np.random.default_rng(seed + 1)
-    Cb = np.clip(Yf[::2, ::2] // 2 + pm // 4 + k.integers(-3, 4, (H // 2, W // 2)) * (1 << (depth - 8)), 0, pm)
-    Cr = np.clip(pm - Yf[::2, ::2] // 2 - pm // 4 + k.integers(-3, 4, (H // 2, W // 2)) * (1 << (depth - 8)), 0, pm)
+    hs, vs = chroma_shifts(csp)
+    sub = Yf[::1 << vs, ::1 << hs]
+    Cb = np.clip(sub // 2 + pm // 4 + k.integers(-3, 4, sub.shape) * (1 << (depth - 8)), 0, pm)
+    Cr = np.clip(pm - sub // 2 - pm // 4 + k.integers(-3, 4, sub.shape) * (1 << (depth - 8)), 0, pm)
     if depth == 8 and seed % 3 == 0:                                        # extremes: saturated neighbours
         Yf[: H // 4] = np.where(k.random((H // 4, W)) < 0.5, pm, pm - 2)
     dt = np.uint8 if depth == 8 else np.uint16
-    return dict(a, planes=[Yf.astype(dt), Cb.astype(dt), Cr.astype(dt)], refPic=ref_pic, W=W, H=H, ctu=ctu, depth=depth, slice_p=int(slice_p), bypass=int(bypass),
+    return dict(a, planes=[Yf.astype(dt), Cb.astype(dt), Cr.astype(dt)], refPic=ref_pic, W=W, H=H, ctu=ctu, depth=depth, csp=csp, slice_p=int(slice_p), bypass=int(bypass),
                 beta_div2=int(rng.integers(-3, 4)), tc_div2=int(rng.integers(-3, 4)), cb_off=int(rng.integers(-6, 7)), cr_off=int(rng.integers(-6, 7)))
 
 
@@ -142,17 +149,19 @@ def run_reference(pic):
             f.write(pic["refPic"].tobytes())
         r = subprocess.run([dbk_bin(pic["depth"]), str(pic["W"]), str(pic["H"]), str(pic["ctu"]), inp, out, str(pic["slice_p"]), str(pic["beta_div2"]), str(pic["tc_div2"]),
                             str(pic["cb_off"]), str(pic["cr_off"]), str(pic["bypass"])], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, X265REF_SLICE_ROWS=",".join(str(r) for r in pic.get("slice_rows", ()))))
+                           env=dict(os.environ, X265REF_SLICE_ROWS=",".join(str(r) for r in pic.get("slice_rows", ())), X265REF_CSP=str(pic.get("csp", 1))))
         assert r.returncode == 0, r.stderr[-2000:]
         d = np.fromfile(out, np.uint16)
     W, H = pic["W"], pic["H"]
-    return [d[:W * H].reshape(H, W), d[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), d[W * H + W * H // 4:].reshape(H // 2, W // 2)]
+    hs, vs = chroma_shifts(pic.get("csp", 1))
+    cw, ch = W >> hs, H >> vs
+    return [d[:W * H].reshape(H, W), d[W * H:W * H + cw * ch].reshape(ch, cw), d[W * H + cw * ch:].reshape(ch, cw)]
 
 
 class DeblockPic(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("width", "height", "ctuSize", "sliceIsP", "betaOffsetDiv2", "tcOffsetDiv2", "cbQpOffset", "crQpOffset", "tqBypassEnabled")] + \
                [(k, C.c_void_p) for k in ("log2CUSize", "partSize", "tuDepth", "predMode", "cbfLuma", "tqBypass", "qp", "refIdx0", "refIdx1", "mv0", "mv1")] + \
-               [("refPic", C.c_int32 * 32), ("sliceFirstRow", C.c_void_p)]
+               [("refPic", C.c_int32 * 32), ("sliceFirstRow", C.c_void_p), ("chromaFormat", C.c_int)]
 
 
 def slice_first_row(pic):
@@ -174,6 +183,7 @@ def descriptor(pic, ptr):
     for k in ("log2CUSize", "partSize", "tuDepth", "predMode", "cbfLuma", "tqBypass", "qp", "refIdx0", "refIdx1", "mv0", "mv1"):
         setattr(d, k, ptr(k))
     d.refPic[:] = [int(v) for v in pic["refPic"].reshape(-1)]
+    d.chromaFormat = int(pic.get("csp", 1))
     return d
 
 
@@ -187,5 +197,5 @@ def run_oracle(ora, pic, want_bs=False):
     W, H = pic["W"], pic["H"]
     bs = np.zeros((2, H // 4, W // 4), np.uint8)
     P = lambda x: C.c_void_p(x.ctypes.data)
-    ora.lib.xo_deblock_frame(C.byref(d), P(planes[0]), C.c_ssize_t(W), P(planes[1]), P(planes[2]), C.c_ssize_t(W // 2), P(bs))
+    ora.lib.xo_deblock_frame(C.byref(d), P(planes[0]), C.c_ssize_t(W), P(planes[1]), P(planes[2]), C.c_ssize_t(planes[1].shape[1]), P(bs))
     return (planes, bs) if want_bs else planes

@@ -35,7 +35,7 @@ int fail(const char* fmt, ...)
 }
 /* (x265hip_deblock_pic and the oracle's xo_deblock_pic are the same record: the library's description was modelled on it) */
 void (*g_deblock)(const x265hip_deblock_pic*, xo_pixel*, intptr_t, xo_pixel*, xo_pixel*, intptr_t, uint8_t*, int, int);
-void (*g_stats)(const xo_pixel*, const xo_pixel*, intptr_t, int, int, int, int, int, int32_t*, const uint8_t*, int, int);
+void (*g_stats)(const xo_pixel*, const xo_pixel*, intptr_t, int, int, int, int, int, int, int32_t*, const uint8_t*, int, int);      /* xo_sao_stats_rows_wh */
 } // namespace
 
 extern "C" {
@@ -51,8 +51,8 @@ int x265hip_ff_create(x265hip_ctx* ctx, int width, int height, int ctuSize, intp
     const char* path = getenv("X265MOCK_ORACLE_LIB");
     void* lib = path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : nullptr;
     if (!lib) return fail("X265MOCK_ORACLE_LIB (%s) does not load: %s", path ? path : "unset", dlerror());
-    *(void**)&g_deblock = dlsym(lib, "xo_deblock_rows"); *(void**)&g_stats = dlsym(lib, "xo_sao_stats_rows");      /* (the whole picture is the band of all its rows) */
-    if (!g_deblock || !g_stats) return fail("%s lacks xo_deblock_rows / xo_sao_stats_rows", path);
+    *(void**)&g_deblock = dlsym(lib, "xo_deblock_rows"); *(void**)&g_stats = dlsym(lib, "xo_sao_stats_rows_wh");      /* (the whole picture is the band of all its rows) */
+    if (!g_deblock || !g_stats) return fail("%s lacks xo_deblock_rows / xo_sao_stats_rows_wh", path);
     x265hip_ff* f = new x265hip_ff();
     f->width = width; f->height = height; f->ctu = ctuSize; f->strideY = strideY; f->strideC = strideC;
     *out = f;
@@ -89,6 +89,8 @@ int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* d)
         if (r1 == nrows) { f->rowsDone.erase(d->reconY); f->pictures++; }
     }
     if (d->ctuRowCount) f->bands++;
+    if (P.chromaFormat < 0 || P.chromaFormat > 3) return fail("ff_picture: chroma format %d", P.chromaFormat);
+    const int hs = P.chromaFormat == 3 ? 0 : 1, vs = (P.chromaFormat == 2 || P.chromaFormat == 3) ? 0 : 1;      /* the chroma planes' subsampling */
     std::vector<uint8_t> sfr;
     x265hip_deblock_pic D = P;
     if (P.sliceFirstRow) { sfr.assign(P.sliceFirstRow, P.sliceFirstRow + nrows); sfr.push_back(0); D.sliceFirstRow = sfr.data(); }
@@ -96,8 +98,8 @@ int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* d)
     const void* fenc[3] = { d->fencY, d->fencCb, d->fencCr }; void* rec[3] = { d->reconY, d->reconCb, d->reconCr };
     for (int p = 0; p < 3; p++)
         if ((p == 0 && (d->saoStats & 1)) || (p > 0 && (d->saoStats & 2)))
-            g_stats((const xo_pixel*)fenc[p], (const xo_pixel*)rec[p], p ? f->strideC : f->strideY, p ? f->width / 2 : f->width, p ? f->height / 2 : f->height, p ? f->ctu / 2 : f->ctu,
-                    d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, d->stats[p], P.sliceFirstRow ? sfr.data() : nullptr, r0, r1);
+            g_stats((const xo_pixel*)fenc[p], (const xo_pixel*)rec[p], p ? f->strideC : f->strideY, p ? f->width >> hs : f->width, p ? f->height >> vs : f->height, p ? f->ctu >> hs : f->ctu,
+                    p ? f->ctu >> vs : f->ctu, d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, d->stats[p], P.sliceFirstRow ? sfr.data() : nullptr, r0, r1);
     return X265HIP_OK;
 }
 } // extern "C"

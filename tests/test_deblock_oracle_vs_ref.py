@@ -45,3 +45,21 @@ def test_deblock_frame_with_slices_matches_reference(depth, W, H, ctu, seed, sli
     for c in range(3):
         bad = np.argwhere(got[c] != ref[c])
         assert bad.size == 0, "plane %d: %d samples differ, first at (y, x) %s" % (c, len(bad), bad[0])
+
+
+@pytest.mark.parametrize("depth,W,H,ctu,seed,slice_p,bypass,csp", [(8, 136, 72, 64, 21, True, False, 2), (8, 200, 152, 32, 22, False, True, 2), (10, 96, 80, 16, 23, False, False, 2),
+                                                                   (8, 136, 104, 64, 24, False, False, 3), (10, 64, 64, 32, 25, True, True, 3), (8, 264, 136, 16, 26, False, False, 3)])
+def test_deblock_frame_in_other_chroma_formats_matches_reference(depth, W, H, ctu, seed, slice_p, bypass, csp):
+    """4:2:2 (csp 2) and 4:4:4 (csp 3): the chroma edges lie on the 8-sample CHROMA grid in each direction, a chroma segment takes the strength of the first luma unit it covers,
+    and the chroma QP is clipped instead of mapped (deblock.cpp:104-113, 417-497) -- the reference's Deblock on a PicYuv / CUData of that format"""
+    if not os.path.exists(dbk_bin(depth)):
+        pytest.skip("oracle/_ref/x265deblock_%d not built (needs /root/reference at build time)" % depth)
+    pic = coded_picture(depth, W, H, ctu, seed, slice_p, bypass, csp=csp)
+    assert pic["planes"][1].shape == (H >> (csp == 1), W >> (csp != 3))
+    ref = run_reference(pic)
+    got = run_oracle(Oracle(depth), pic)
+    as420 = run_oracle(Oracle(depth), dict(pic, csp=1, planes=[pic["planes"][0], pic["planes"][1][: H // 2, : W // 2].copy(), pic["planes"][2][: H // 2, : W // 2].copy()]))
+    assert not np.array_equal(as420[1], got[1][: H // 2, : W // 2]), "the format changed nothing in the chroma planes"
+    for c in range(3):
+        bad = np.argwhere(got[c] != ref[c])
+        assert bad.size == 0, "plane %d: %d samples differ, first at (y, x) %s: oracle %d reference %d" % (c, len(bad), bad[0], got[c][tuple(bad[0])], ref[c][tuple(bad[0])])

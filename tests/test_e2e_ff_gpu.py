@@ -24,6 +24,9 @@ def encode(depth, ff, args, out, la=False, tme=False, defer_only=False, tme_gpu=
     if defer_only:
         env["X265FF_DEFER_ONLY"] = "1"
     env.update(extra_env or {})
+    for a in [a for a in args if a.startswith("csp=")]:          # (the driver takes the clip's chroma format from the environment)
+        env["X265_CSP"] = a.split("=")[1]
+    args = [a for a in args if not a.startswith("csp=")]
     r = subprocess.run([exe, x265hip.lib_path(depth)] + args[:4] + [out] + args[4:], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1]), hashlib.md5(open(out, "rb").read()).hexdigest()
@@ -46,7 +49,10 @@ CONFIGS = [(8, ["256", "192", "10", "medium"]),                                 
            (10, ["320", "384", "6", "fast", "slices=3", "wpp=1", "bframes=2"]),
            (8, ["256", "320", "6", "medium", "slices=4", "wpp=1"]),                       # (with sao-non-deblock=1 on top the reference's own CPU encode never finishes)
            (8, ["256", "192", "8", "medium", "limit-sao=1"]),                              # --limit-sao: the diagonal classes only where the reference collects them
-           (10, ["256", "192", "8", "slow", "limit-sao=1", "bframes=3"])]
+           (10, ["256", "192", "8", "slow", "limit-sao=1", "bframes=3"]),
+           (8, ["256", "192", "8", "medium", "csp=i422"]),                                # 4:2:2: chroma planes half as wide, chroma CTUs 32 x 64
+           (10, ["256", "192", "6", "medium", "csp=i444", "bframes=2"]),                  # 4:4:4
+           (8, ["200", "120", "6", "fast", "csp=i422", "ctu=32"])]
 
 
 @pytest.mark.parametrize("depth,args", CONFIGS)
@@ -78,6 +84,8 @@ def test_the_deferral_alone_keeps_the_bitstream(tmp_path):
                                                   (8, ["320", "704", "8", "medium", "frame-threads=2", "wpp=1", "sao-non-deblock=1"], "3"),
                                                   (8, ["256", "640", "8", "medium", "frame-threads=3", "wpp=1", "sao=0"], "2"),           # deblocking alone: the rows' counters come from processPostCu
                                                   (8, ["256", "640", "8", "medium", "frame-threads=3", "wpp=1", "limit-sao=1", "ctu=32"], None),
+                                                  (8, ["256", "512", "8", "medium", "frame-threads=3", "wpp=1", "csp=i422"], "2"),          # 4:2:2 in bands
+                                                  (10, ["256", "512", "7", "medium", "frame-threads=3", "wpp=1", "csp=i444"], None),
                                                   (8, ["1920", "1080", "6", "medium", "frame-threads=4", "wpp=1"], None)])                 # BASELINE configs[1], threaded as the CLI threads it
 def test_bitstream_identical_with_gpu_filters_under_frame_threads(depth, args, band_rows, tmp_path):
     """The encoder's default threading: the next pictures wait for the rows a picture's filters finish (Frame::m_reconRowFlag).  The binding filters in bands of CTU rows as they

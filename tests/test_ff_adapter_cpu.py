@@ -108,3 +108,19 @@ def test_ten_bit_encoder(mock, tmp_path):
     bound = encode(mock, tmp_path, "bound10", 1, options=("limit-sao=1",), depth=10)
     assert plain["rc"] == 0 and bound["rc"] == 0 and "PROTOCOL VIOLATION" not in bound["stderr"], bound["stderr"][-600:]
     assert bound["ff_pictures"] == 8 and bound["md5"] == plain["md5"]
+
+
+@pytest.mark.parametrize("csp,options,env", [("i422", (), {}), ("i444", (), {}), ("i422", ("pools=16", "frame-threads=3"), {"X265_CLI_THREADING": "1"}),
+                                              ("i444", ("pools=16", "frame-threads=3", "limit-sao=1"), {"X265_CLI_THREADING": "1", "X265FF_BAND_ROWS": "2"})],
+                         ids=lambda v: v if isinstance(v, str) else "+".join(v) if isinstance(v, tuple) else "env%d" % len(v))
+def test_other_chroma_formats_through_the_binding(mock, tmp_path, csp, options, env):
+    """4:2:2 and 4:4:4 encodes (Cb / Cr half as wide and as high as luma / full size; chroma edges on their own 8-sample grid, chroma CTUs 32 x 64 / 64 x 64): whole pictures with
+    one frame thread, bands under frame threads -- the plain encoder's bitstream, every picture through the producer"""
+    e = dict(env, X265_CSP=csp)
+    plain = encode(mock, tmp_path, "plain", 0, size=(640, 704), env=e, options=options)
+    bound = encode(mock, tmp_path, "bound", 1, size=(640, 704), env=e, options=options)
+    assert plain["rc"] == 0 and bound["rc"] == 0 and "PROTOCOL VIOLATION" not in bound["stderr"], bound["stderr"][-600:]
+    assert bound["ff_pictures"] == 8 and bound["ff_cpu_pictures"] == 0
+    assert bound["md5"] == plain["md5"] and bound["bytes"] == plain["bytes"]
+    other = encode(mock, tmp_path, "other", 0, size=(640, 704), options=options, env=env)      # (the format really is another encode)
+    assert other["md5"] != plain["md5"]

@@ -73,19 +73,23 @@ def test_ff_picture_matches_oracle(depth, W, H, ctu, slice_p, bypass, deblock, s
     lib.x265hip_ff_destroy(ff); lib.x265hip_ctx_destroy(ctx)
 
 
-@pytest.mark.parametrize("depth,W,H,ctu,cut,sao,nd", [(8, 256, 320, 64, [1], 3, 0), (10, 320, 328, 64, [2, 1], 3, 0), (8, 200, 168, 32, [3, 1], 3, 1), (8, 128, 136, 16, [4, 1, 2], 1, 0),
-                                                      (10, 1920, 1080, 64, [4], 3, 0), (8, 256, 256, 64, [2], 0, 0)])
-def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd):
+@pytest.mark.parametrize("depth,W,H,ctu,cut,sao,nd,csp", [(8, 256, 320, 64, [1], 3, 0, 1), (10, 320, 328, 64, [2, 1], 3, 0, 1), (8, 200, 168, 32, [3, 1], 3, 1, 1), (8, 128, 136, 16, [4, 1, 2], 1, 0, 1),
+                                                          (10, 1920, 1080, 64, [4], 3, 0, 1), (8, 256, 256, 64, [2], 0, 0, 1),
+                                                          (8, 256, 320, 64, [2, 1], 3, 0, 2), (10, 200, 168, 32, [5], 3, 0, 2), (8, 256, 192, 64, [1, 2], 3, 1, 3), (10, 136, 128, 16, [8], 3, 0, 3)])
+def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd, csp):
     """desc.ctuRowFirst / ctuRowCount (FrameFilter::processRow's order under frame threads): TWO pictures go through one producer band by band, their bands interleaved -- each
     band reads the CU arrays of its rows and the row above, the planes from 8 lines above it, and writes those lines and its rows' statistics back.  After the last band each
-    picture equals the whole-picture result of the oracle; the statistics of a band are taken before the rows below it are deblocked (xo_sao_stats_rows on the oracle's band state)."""
+    picture equals the whole-picture result of the oracle; the statistics of a band are taken before the rows below it are deblocked (xo_sao_stats_rows on the oracle's band state).
+    csp 2 / 3: 4:2:2 / 4:4:4 pictures (desc.pic.chromaFormat: chroma planes half as wide and as high as luma / full size, chroma CTUs ctu / 2 x ctu / ctu x ctu); [n] as the cut =
+    the whole picture in one call."""
     H -= H % 8
     ora = Oracle(depth)
     ora.lib.xo_deblock_rows.restype = None
-    ora.lib.xo_sao_stats_rows.restype = None
+    ora.lib.xo_sao_stats_rows_wh.restype = None
+    hs, vs = (0 if csp == 3 else 1), (1 if csp == 1 else 0)
     lib = x265hip.HipLib(depth, fill_table=False).lib
     lib.x265hip_last_error.restype = C.c_char_p
-    sY, sC = W + 40, W // 2 + 24
+    sY, sC = W + 40, (W >> hs) + 24
     nx, ny = (W + ctu - 1) // ctu, (H + ctu - 1) // ctu
     nctu = nx * ny
     ctx, ff = C.c_void_p(), C.c_void_p()
@@ -94,7 +98,7 @@ def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd):
     P = lambda a: C.c_void_p(a.ctypes.data)
     pics = []
     for k in range(2):
-        pic = coded_picture(depth, W, H, ctu, 900 + 13 * k + W + depth, bool(k), False)
+        pic = coded_picture(depth, W, H, ctu, 900 + 13 * k + W + depth, bool(k), False, csp=csp)
         rng = np.random.default_rng(50 + k + W)
         dt = pic["planes"][0].dtype
         src = [np.clip(p.astype(np.int32) + rng.integers(-6, 7, p.shape), 0, (1 << depth) - 1).astype(dt) for p in pic["planes"]]
@@ -126,14 +130,14 @@ def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd):
         S = pics[k]
         S["d"].ctuRowFirst, S["d"].ctuRowCount = (r0, r1 - r0) if (r0 > 0 or r1 < ny) else (0, 0)
         assert lib.x265hip_ff_picture(ff, C.byref(S["d"])) == 0, lib.x265hip_last_error()
-        ora.lib.xo_deblock_rows(C.byref(S["od"]), P(S["oplanes"][0]), C.c_ssize_t(W), P(S["oplanes"][1]), P(S["oplanes"][2]), C.c_ssize_t(W // 2), None, r0, r1)
+        ora.lib.xo_deblock_rows(C.byref(S["od"]), P(S["oplanes"][0]), C.c_ssize_t(W), P(S["oplanes"][1]), P(S["oplanes"][2]), C.c_ssize_t(W >> hs), None, r0, r1)
         for c in range(3):
-            w = W if c == 0 else W // 2
+            w = W if c == 0 else W >> hs
             assert np.array_equal(S["recon"][c][:, :w], S["oplanes"][c]), "picture %d plane %d after the band of rows %d..%d" % (k, c, r0, r1 - 1)
             assert (S["recon"][c][:, w:] == 3).all(), "the padding of plane %d was touched" % c
             if (c == 0 and sao & 1) or (c > 0 and sao & 2):
-                h, cs = (H, ctu) if c == 0 else (H // 2, ctu // 2)
-                ora.lib.xo_sao_stats_rows(P(np.ascontiguousarray(S["src"][c])), P(S["oplanes"][c]), C.c_ssize_t(w), w, h, cs, nd, 0 if c == 0 else 2, P(S["want"][c]), None, r0, r1)
+                h, cw_, ch_ = (H, ctu, ctu) if c == 0 else (H >> vs, ctu >> hs, ctu >> vs)
+                ora.lib.xo_sao_stats_rows_wh(P(np.ascontiguousarray(S["src"][c])), P(S["oplanes"][c]), C.c_ssize_t(w), w, h, cw_, ch_, nd, 0 if c == 0 else 2, P(S["want"][c]), None, r0, r1)
             assert np.array_equal(S["stats"][c], S["want"][c]), "picture %d: statistics of plane %d after rows %d..%d (entries outside the bands so far must be untouched)" % (k, c, r0, r1 - 1)
     for S in pics:
         whole = run_oracle(ora, S["pic"])

@@ -24,7 +24,7 @@ def test_sao_stats_match_reference(depth):
         ref.close()
 
 
-def sao_frame_reference(depth, fenc, rec, ctu, non_deblock=0, chroma=None, slice_rows=()):
+def sao_frame_reference(depth, fenc, rec, ctu, non_deblock=0, chroma=None, slice_rows=(), csp=1):
     """chroma = [(fencCb, recCb), (fencCr, recCr)] of a 4:2:0 picture -> array [planes, ctus, 2, 5, 32]; luma only -> [ctus, 2, 5, 32]"""
     import os, subprocess, tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,7 +34,7 @@ def sao_frame_reference(depth, fenc, rec, ctu, non_deblock=0, chroma=None, slice
         parts = [fenc.reshape(-1), rec.reshape(-1)] + ([a.reshape(-1) for pr in chroma for a in pr] if chroma else [])
         np.concatenate(parts).tofile(inp)
         r = subprocess.run([os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth), str(W), str(H), str(ctu), inp, out, str(non_deblock), "3" if chroma else "1"],
-                           capture_output=True, text=True, env=dict(os.environ, X265REF_SLICE_ROWS=",".join(str(r) for r in slice_rows)))
+                           capture_output=True, text=True, env=dict(os.environ, X265REF_SLICE_ROWS=",".join(str(r) for r in slice_rows), X265REF_CSP=str(csp)))
         assert r.returncode == 0, r.stderr[-1000:]
         o = np.fromfile(out, np.int32)
         return o.reshape(3, -1, 2, 5, 32) if chroma else o.reshape(-1, 2, 5, 32)
@@ -254,3 +254,32 @@ def test_sao_predeblock_stats_match_reference(depth, size, ctu):
             for t in range(5):
                 assert np.array_equal(a[plane, addr, :, t], exp[plane][addr, :, t]), "plane %d CTU %d type %d" % (plane, addr, t)
     assert a[0, :, 1].sum() > 0 or (W <= ctu and H <= ctu)            # a picture of one CTU has no border left out
+
+
+@pytest.mark.parametrize("depth", DEPTHS)
+@pytest.mark.parametrize("size,ctu,nd,csp", [((200, 136), 64, 0, 2), ((192, 128), 64, 1, 2), ((72, 40), 32, 0, 2), ((136, 72), 16, 0, 2), ((200, 136), 64, 0, 3), ((72, 40), 32, 1, 3), ((136, 72), 16, 0, 3)])
+def test_sao_frame_stats_in_other_chroma_formats_match_reference(depth, size, ctu, nd, csp):
+    """4:2:2 (csp 2): the chroma planes are half as wide and as high as luma, their CTUs ctu / 2 x ctu; 4:4:4 (csp 3): full size.  SAO::calcSaoStatsCTU shifts the picture and
+    CTU sizes by the format's shifts and keeps plane_offset 2 for every chroma plane (sao.cpp:748-756, 773): the oracle's plane-level function with the CTU's width and height
+    given apart (xo_sao_stats_rows_wh) against the reference's SAO on a PicYuv of that format"""
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "x265sao_%d" % depth)):
+        pytest.skip("no reference SAO binary")
+    W, H = size
+    hs, vs = (0 if csp == 3 else 1), 0
+    y = sao_frame_pair(depth, W, H, 7 + depth + W)
+    cb, cr = sao_frame_pair(depth, W >> hs, H >> vs, 8 + depth + W), sao_frame_pair(depth, W >> hs, H >> vs, 9 + depth + W)
+    a = sao_frame_reference(depth, y[0], y[1], ctu, nd, chroma=[cb, cr], csp=csp)
+    ora = Oracle(depth)
+    ora.lib.xo_sao_stats_rows_wh.restype = None
+    P = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
+    assert np.array_equal(a[0], sao_frame_oracle(ora, y[0], y[1], ctu, nd, 0)), "luma"
+    for plane, (f, r) in ((1, cb), (2, cr)):
+        cw, ch = ctu >> hs, ctu >> vs
+        n = (((W >> hs) + cw - 1) // cw) * (((H >> vs) + ch - 1) // ch)
+        out = np.zeros((n, 2, 5, 32), np.int32)
+        f, r = np.ascontiguousarray(f), np.ascontiguousarray(r)
+        ora.lib.xo_sao_stats_rows_wh(P(f), P(r), C.c_ssize_t(W >> hs), W >> hs, H >> vs, cw, ch, nd, 2, P(out), None, 0, ((H >> vs) + ch - 1) // ch)
+        assert out.shape == a[plane].shape and np.array_equal(a[plane], out), "plane %d" % plane

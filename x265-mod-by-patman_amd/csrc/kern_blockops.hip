@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(int type, const int16_t*
 // Edge classes accumulate in registers (5 classes x 4 types, compile-time indexed), the 32 bands through LDS atomics (one copy per wavefront).
 __global__ __launch_bounds__(1024) void sao_frame_kernel(const pixel* __restrict__ fenc, const pixel* __restrict__ recon, intptr_t stride, int picWidth, int picHeight,
                                                         int ctuSize, int nonDeblocked, int po, int32_t* __restrict__ out, int64_t picElems, int64_t outPicInts,
-                                                        const uint8_t* __restrict__ sliceFirstRow, int ctuFirst)
+                                                        const uint8_t* __restrict__ sliceFirstRow, int ctuFirst, int ctuH)
 {
     fenc += blockIdx.z * picElems; recon += blockIdx.z * picElems; out += blockIdx.z * outPicInts;      // picture of a batch (grid z)
     constexpr int NW = 16;                                         // wavefronts of the workgroup: a 64x64 CTU is 4 pixels per thread
@@ -178,14 +178,15 @@ __global__ __launch_bounds__(1024) void sao_frame_kernel(const pixel* __restrict
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     for (int i = t; i < NW * 2 * 32; i += 1024) (&s_bo[0][0][0])[i] = 0;
     __syncthreads();
-    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize;
-    const int addr = ctuFirst + blockIdx.x, lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuSize;      // (ctuFirst: a band of CTU rows, x265hip_sao_stats_rows)
+    // (ctuSize = the CTU's width in this plane, ctuH its height: they differ in the chroma planes of 4:2:2 -- ctuWidth >>= m_hChromaShift, ctuHeight >>= m_vChromaShift, sao.cpp:748-756)
+    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuH - 1) / ctuH;
+    const int addr = ctuFirst + blockIdx.x, lpelx = (addr % nx) * ctuSize, tpely = (addr / nx) * ctuH;      // (ctuFirst: a band of CTU rows, x265hip_sao_stats_rows)
     // --slices: CTU rows that begin a slice (CUData::m_bFirstRowInSlice / m_bLastRowInSlice, sao.cpp:744-746, 763-766): no neighbours above the slice's first row,
     // the slice's last row counts down to its bottom line like the picture's last row
     const int row = addr / nx;
     const bool lastRow = row == ny - 1 || (sliceFirstRow && sliceFirstRow[row + 1]);
     const int above = (!tpely) | (sliceFirstRow ? (int)(sliceFirstRow[row] != 0) : 0);
-    const int rpelx = min(lpelx + ctuSize, picWidth), bpely = min(tpely + ctuSize, picHeight);
+    const int rpelx = min(lpelx + ctuSize, picWidth), bpely = min(tpely + ctuH, picHeight);
     const int cw = rpelx - lpelx, ch = bpely - tpely;
     const int picH = lastRow ? bpely : picHeight;
     const bool atRight = rpelx == picWidth, atBottom = bpely == picH;
@@ -533,16 +534,17 @@ extern "C" int x265hip_sao_stats(void* stream, int type, const int16_t* diff, co
 }
 
 static int sao_stats_launch(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
-                            int planeOffset, int32_t* out, int nPictures, int64_t pictureElems, const uint8_t* sliceFirstRow, int ctuRow0 = 0, int ctuRow1 = -1)
+                            int planeOffset, int32_t* out, int nPictures, int64_t pictureElems, const uint8_t* sliceFirstRow, int ctuRow0 = 0, int ctuRow1 = -1, int ctuH = 0)
 {
-    if (!fenc || !recon || !out || picWidth < 1 || picHeight < 1 || (ctuSize != 8 && ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || stride < picWidth ||
+    if (ctuH == 0) ctuH = ctuSize;
+    if (!fenc || !recon || !out || picWidth < 1 || picHeight < 1 || (ctuSize != 8 && ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || (ctuH != ctuSize && ctuH != 2 * ctuSize) || ctuH > 64 || stride < picWidth ||
         (planeOffset != 0 && planeOffset != 2) || nPictures < 1 || nPictures > 65535 || (nPictures > 1 && pictureElems < stride * (intptr_t)picHeight))
     { set_error("sao_stats: bad arguments"); return X265HIP_EARG; }
-    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuSize - 1) / ctuSize, n = nx * ny;
+    const int nx = (picWidth + ctuSize - 1) / ctuSize, ny = (picHeight + ctuH - 1) / ctuH, n = nx * ny;
     if (ctuRow1 < 0) ctuRow1 = ny;
     if (ctuRow0 < 0 || ctuRow1 <= ctuRow0 || ctuRow1 > ny) { set_error("sao_stats: CTU rows %d..%d of %d", ctuRow0, ctuRow1, ny); return X265HIP_EARG; }
     XH_KLAUNCH(sao_frame_kernel, dim3((ctuRow1 - ctuRow0) * nx, 1, nPictures), dim3(1024), 0, (hipStream_t)stream, (const pixel*)fenc, (const pixel*)recon, stride, picWidth, picHeight, ctuSize,
-                       nonDeblocked, planeOffset, out, pictureElems, (int64_t)n * 320, sliceFirstRow, ctuRow0 * nx);
+                       nonDeblocked, planeOffset, out, pictureElems, (int64_t)n * 320, sliceFirstRow, ctuRow0 * nx, ctuH);
     XH_LAUNCH_CHECK();
     return X265HIP_OK;
 }
@@ -558,10 +560,10 @@ extern "C" int x265hip_sao_stats_frame_slices(void* stream, const void* fenc, co
 }
 // the CTUs of the rows [ctuRow0, ctuRow1) only (their entries of `out`): a band of FrameFilter::processRow's pipeline -- the rows below need not be deblocked yet (a CTU's
 // statistics leave out what the next row's deblocking changes: skipB, sao.cpp:729-905; oracle: xo_sao_stats_rows)
-extern "C" int x265hip_sao_stats_rows(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
+extern "C" int x265hip_sao_stats_rows(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuWidth, int ctuHeight, int nonDeblocked,
                                       int planeOffset, int32_t* out, const uint8_t* sliceFirstRow, int ctuRow0, int ctuRow1)
-{
-    return sao_stats_launch(stream, fenc, recon, stride, picWidth, picHeight, ctuSize, nonDeblocked, planeOffset, out, 1, 0, sliceFirstRow, ctuRow0, ctuRow1);
+{   // ctuWidth x ctuHeight: the CTU in THIS plane (square but for the chroma planes of 4:2:2, where it is half as wide as high)
+    return sao_stats_launch(stream, fenc, recon, stride, picWidth, picHeight, ctuWidth, nonDeblocked, planeOffset, out, 1, 0, sliceFirstRow, ctuRow0, ctuRow1, ctuHeight);
 }
 extern "C" int x265hip_sao_stats_frame(void* stream, const void* fenc, const void* recon, intptr_t stride, int picWidth, int picHeight, int ctuSize, int nonDeblocked,
                                        int planeOffset, int32_t* out)

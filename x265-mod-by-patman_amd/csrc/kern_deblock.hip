@@ -114,17 +114,21 @@ __device__ __forceinline__ void deblock_body(const x265hip_deblock_pic& d, pixel
     constexpr int sh = X265_DEPTH - 8;
     const int tcOffset = 2 * d.tcOffsetDiv2;
 
-    // chroma first (independent planes): edges on the 16-sample luma grid, one 4-sample chroma segment per two luma units along the edge
-    if (bs == 2 && !((DIR ? uy : ux) & 3) && !((DIR ? ux : uy) & 1))
+    // chroma first (independent planes): edges on the 8-sample CHROMA grid across the edge, one 4-sample chroma segment per (1 << the chroma shift along the edge) luma units,
+    // with the strength and QPs of the first of them (deblock.cpp:104-113, 457-459).  4:2:0: the 16-sample luma grid, a segment per two units; 4:2:2: 16 across vertical /
+    // 8 across horizontal edges; 4:4:4: the luma grid.  The QP goes through the table for 4:2:0 only (:483-484)
+    const int hs = d.chromaFormat == 3 ? 0 : 1, vs = (d.chromaFormat == 2 || d.chromaFormat == 3) ? 0 : 1;
+    const int across = DIR ? vs : hs, along = DIR ? hs : vs;
+    if (bs == 2 && !((DIR ? uy : ux) & ((2 << across) - 1)) && !((DIR ? ux : uy) & ((1 << along) - 1)))
     {
         const intptr_t step = DIR ? 1 : strideC, off = DIR ? strideC : 1;
 #pragma unroll
         for (int c = 0; c < 2; c++)
         {
             int cqp = qp + (c ? d.crQpOffset : d.cbQpOffset);
-            if (cqp >= 30) cqp = c_chromaScale[min(cqp, 57)];
+            if (cqp >= 30) cqp = d.chromaFormat <= 1 ? (int)c_chromaScale[min(cqp, 57)] : min(cqp, 51);
             const int tc = c_tc[clip3(0, 53, cqp + 2 + tcOffset)] << sh;
-            pixel* s = (c ? Cr : Cb) + (intptr_t)uy * 2 * strideC + ux * 2;
+            pixel* s = (c ? Cr : Cb) + (intptr_t)((uy * 4) >> vs) * strideC + ((ux * 4) >> hs);
 #pragma unroll
             for (int i = 0; i < 4; i++, s += step)
             {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void deblock_pictures_kernel(const x265hip_deb
 
 static bool deblock_desc_ok(const x265hip_deblock_pic& d, intptr_t strideY, intptr_t strideC)
 {
-    return !(d.width < 8 || d.height < 8 || (d.width & 7) || (d.height & 7) || (d.ctuSize != 16 && d.ctuSize != 32 && d.ctuSize != 64) || strideY < d.width || strideC < d.width / 2 ||
+    return !(d.width < 8 || d.height < 8 || (d.width & 7) || (d.height & 7) || (d.ctuSize != 16 && d.ctuSize != 32 && d.ctuSize != 64) || strideY < d.width || strideC < (d.chromaFormat == 3 ? d.width : d.width / 2) || d.chromaFormat < 0 || d.chromaFormat > 3 ||
              !d.log2CUSize || !d.partSize || !d.tuDepth || !d.predMode || !d.cbfLuma || !d.qp || !d.refIdx0 || !d.mv0 || (!d.sliceIsP && (!d.refIdx1 || !d.mv1)) ||
              (d.tqBypassEnabled && !d.tqBypass));
 }
@@ -236,7 +240,7 @@ extern "C" int x265hip_deblock_rows(void* stream, const x265hip_deblock_pic* des
 {
     if (!desc || !Y || !Cb || !Cr) { set_error("deblock_frame: null argument"); return X265HIP_EARG; }
     const x265hip_deblock_pic& d = *desc;
-    if (d.width < 8 || d.height < 8 || (d.width & 7) || (d.height & 7) || (d.ctuSize != 16 && d.ctuSize != 32 && d.ctuSize != 64) || strideY < d.width || strideC < d.width / 2 ||
+    if (d.width < 8 || d.height < 8 || (d.width & 7) || (d.height & 7) || (d.ctuSize != 16 && d.ctuSize != 32 && d.ctuSize != 64) || strideY < d.width || strideC < (d.chromaFormat == 3 ? d.width : d.width / 2) || d.chromaFormat < 0 || d.chromaFormat > 3 ||
         !d.log2CUSize || !d.partSize || !d.tuDepth || !d.predMode || !d.cbfLuma || !d.qp || !d.refIdx0 || !d.mv0 || (!d.sliceIsP && (!d.refIdx1 || !d.mv1)) ||
         (d.tqBypassEnabled && !d.tqBypass))
     { set_error("deblock_frame: bad picture description (dimensions are multiples of 8, CTU 16/32/64, 4:2:0)"); return X265HIP_EARG; }

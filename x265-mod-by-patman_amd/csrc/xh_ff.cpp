@@ -37,13 +37,13 @@ extern "C" int x265hip_ff_create(x265hip_ctx* ctx, int width, int height, int ct
 {
     if (!ctx || !out || width < 8 || height < 8 || (width & 7) || (height & 7) || width > X265HIP_MAX_PIC_DIM || height > X265HIP_MAX_PIC_DIM ||
         (ctuSize != 16 && ctuSize != 32 && ctuSize != 64) || strideY < width || strideC < width / 2)
-    { set_error("ff_create: bad geometry (dimensions are multiples of 8, CTU 16/32/64, 4:2:0)"); return X265HIP_EARG; }
+    { set_error("ff_create: bad geometry (dimensions are multiples of 8, CTU 16/32/64)"); return X265HIP_EARG; }
     XH_HIP(hipSetDevice(x265hip_ctx_device(ctx)));
     x265hip_ff* f = new (std::nothrow) x265hip_ff();
     if (!f) return X265HIP_EARG;
     f->ctx = ctx; f->width = width; f->height = height; f->ctu = ctuSize; f->strideY = strideY; f->strideC = strideC;
     f->nctu = ((width + ctuSize - 1) / ctuSize) * ((height + ctuSize - 1) / ctuSize); f->npart = (ctuSize / 4) * (ctuSize / 4);
-    const size_t n = (size_t)f->nctu * f->npart, ly = (size_t)strideY * height, lc = (size_t)strideC * (height / 2);
+    const size_t n = (size_t)f->nctu * f->npart, ly = (size_t)strideY * height, lc = (size_t)strideC * height;      // chroma planes: up to the luma's height (4:2:2 / 4:4:4)
     int rc = 0;
     for (int p = 0; p < 3 && !rc; p++)
         if (!(rc = f->alloc(f->recon[p], p ? lc : ly)) && !(rc = f->alloc(f->fenc[p], p ? lc : ly))) rc = f->alloc(f->stats[p], (size_t)f->nctu * 320);
@@ -72,6 +72,10 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     const x265hip_deblock_pic& P = d->pic;
     if (P.width != f->width || P.height != f->height || P.ctuSize != f->ctu || !d->reconY || !d->reconCb || !d->reconCr)
     { set_error("ff_picture: the picture is not the one the producer was created for"); return X265HIP_EARG; }
+    // the chroma planes' subsampling (desc.pic.chromaFormat: X265_CSP_I420 = 1 (or 0), I422 = 2, I444 = 3)
+    if (P.chromaFormat < 0 || P.chromaFormat > 3) { set_error("ff_picture: chroma format %d", P.chromaFormat); return X265HIP_EARG; }
+    const int hs = P.chromaFormat == 3 ? 0 : 1, vs = (P.chromaFormat == 2 || P.chromaFormat == 3) ? 0 : 1;
+    if (f->strideC < (f->width >> hs)) { set_error("ff_picture: chroma pitch %ld for %d samples", (long)f->strideC, f->width >> hs); return X265HIP_EARG; }
     if (d->deblock && (!P.log2CUSize || !P.partSize || !P.tuDepth || !P.predMode || !P.cbfLuma || !P.qp || !P.refIdx0 || !P.mv0 || (!P.sliceIsP && (!P.refIdx1 || !P.mv1)) ||
                        (P.tqBypassEnabled && !P.tqBypass)))
     { set_error("ff_picture: incomplete picture description"); return X265HIP_EARG; }
@@ -91,8 +95,8 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     void* const hostRecon[3] = { d->reconY, d->reconCb, d->reconCr };
     const void* const hostFenc[3] = { d->fencY, d->fencCb, d->fencCr };
     auto pitch = [&](int p) { return (size_t)(p ? f->strideC : f->strideY) * sizeof(pixel); };
-    auto wbytes = [&](int p) { return (size_t)(p ? f->width / 2 : f->width) * sizeof(pixel); };
-    auto line = [&](int p, int y) { return (size_t)(p ? y / 2 : y); };                        // a luma line's line of plane p (4:2:0; y0 / ys / y1 are even)
+    auto wbytes = [&](int p) { return (size_t)(p ? f->width >> hs : f->width) * sizeof(pixel); };
+    auto line = [&](int p, int y) { return (size_t)(p ? y >> vs : y); };                      // a luma line's line of plane p (y0 / ys / y1 are even)
     auto at = [&](const void* base, int p, int y) { return (void*)((char*)base + line(p, y) * pitch(p)); };
     // --slices: the rows that begin a slice (a host array like the rest of the description); the entry behind the last row is always 0
     const uint8_t* sfr = nullptr;
@@ -125,9 +129,9 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     for (int p = 0; p < 3; p++)
     {
         if (!((p == 0 && (d->saoStats & 1)) || (p > 0 && (d->saoStats & 2)))) continue;
-        // a 4:2:0 chroma plane: its own width / height / CTU size and planeOffset 2 (sao.cpp:748-756, :773)
-        int rc = x265hip_sao_stats_rows(st, f->fenc[p], f->recon[p], p ? f->strideC : f->strideY, p ? f->width / 2 : f->width, p ? f->height / 2 : f->height,
-                                        p ? f->ctu / 2 : f->ctu, d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, f->stats[p], sfr, r0, r1);
+        // a chroma plane: its own width / height / CTU width and height (the format's shifts) and planeOffset 2 (sao.cpp:748-756, :773)
+        int rc = x265hip_sao_stats_rows(st, f->fenc[p], f->recon[p], p ? f->strideC : f->strideY, p ? f->width >> hs : f->width, p ? f->height >> vs : f->height,
+                                        p ? f->ctu >> hs : f->ctu, p ? f->ctu >> vs : f->ctu, d->saoNonDeblocked ? 1 : 0, p ? 2 : 0, f->stats[p], sfr, r0, r1);
         if (rc) return rc;
         const size_t s0 = (size_t)r0 * nx * 320;
         XH_HIP(hipMemcpyAsync(d->stats[p] + s0, f->stats[p] + s0, (size_t)(r1 - r0) * nx * 320 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
