@@ -727,7 +727,7 @@ int xo_motion_estimate_sea(const xo_pixel* fencPlane, intptr_t fencStride, int w
         const uint16_t* p_cost_mvy = m->cost - 2 * qmvpy;
         const int meRangeWidth = (maxX - minX + 3) & ~3;
         int16_t* scratch = (int16_t*)calloc((size_t)(merange * 2 + 4 > meRangeWidth ? merange * 2 + 4 : meRangeWidth) + 4, sizeof(int16_t));
-        uint16_t* costMvX = (uint16_t*)malloc((size_t)(meRangeWidth + 4) * sizeof(uint16_t));
+        uint16_t* costMvX = (uint16_t*)malloc((size_t)((meRangeWidth > 0 ? meRangeWidth : 0) + 4) * sizeof(uint16_t));      /* (an empty window -- maxX < minX -- makes the width negative: no position is costed then) */
         for (int i = 0; i < meRangeWidth; i++) costMvX[i] = m->cost[4 * (minX + i) - qmvpx];     /* m_fpelMvCosts[-qmvp.x & 3] + (-qmvp.x >> 2) + minX (bitcost.cpp:57-80) */
         int deltaX = w <= 8 ? w : w >> 1, deltaY = h <= 8 ? h : h >> 1;
         static const int smallRect[5][2] = { {4,4}, {16,12}, {12,16}, {16,4}, {4,16} };

@@ -70,14 +70,24 @@ __attribute__((naked, noinline)) inline void switch_stack(void** /*saveSp: rdi*/
                  "movq %rsp, (%rdi)\n movq %rsi, %rsp\n"
                  "popq %r15\n popq %r14\n popq %r13\n popq %r12\n popq %rbx\n popq %rbp\n ret\n");
 }
+/* AddressSanitizer (make ASAN=1) has to be told about stack switches it did not make */
+#ifdef XH_EMU_ASAN
+extern "C" void __sanitizer_start_switch_fiber(void** fakeStackSave, const void* bottom, size_t size);
+extern "C" void __sanitizer_finish_switch_fiber(void* fakeStackSave, const void** bottomOld, size_t* sizeOld);
+#define EMU_ASAN_START(save, bottom, size) __sanitizer_start_switch_fiber(save, bottom, size)
+#define EMU_ASAN_FINISH(save, bottomOld, sizeOld) __sanitizer_finish_switch_fiber(save, bottomOld, sizeOld)
+#else
+#define EMU_ASAN_START(save, bottom, size) ((void)0)
+#define EMU_ASAN_FINISH(save, bottomOld, sizeOld) ((void)0)
+#endif
 struct Fiber
 {
-    void* sp = nullptr; char* stack = nullptr; State st = READY; uint3 tid; int lin = 0;
+    void* sp = nullptr; char* stack = nullptr; void* fake = nullptr; State st = READY; uint3 tid; int lin = 0;
     int site = -1; uint64_t pub = 0, scope = 0, stamp = 0; Snapshot* snap = nullptr;      /* the cross-lane operation the lane waits at */
 };
 struct Group
 {
-    std::vector<Fiber> f; void* mainSp = nullptr; int cur = -1, live = 0, atBarrier = 0, n = 0; const std::function<void()>* body = nullptr;
+    std::vector<Fiber> f; void* mainSp = nullptr; void* mainFake = nullptr; const void* mainBottom = nullptr; size_t mainSize = 0; int cur = -1, live = 0, atBarrier = 0, n = 0; const std::function<void()>* body = nullptr;
     std::vector<char> dyn;                       /* dynamic LDS of the launch (HIP_DYNAMIC_SHARED) */
 };
 inline Group* g = nullptr;
@@ -87,12 +97,20 @@ constexpr size_t kStack = 192 << 10;
 inline std::vector<char*>& stack_pool() { static std::vector<char*> p; return p; }
 inline void die(const char* what) { fprintf(stderr, "hip emulation: %s\n", what); abort(); }
 
-inline void yield() { switch_stack(&g->f[g->cur].sp, g->mainSp); }
+inline void yield()
+{
+    Fiber& me = g->f[g->cur];
+    EMU_ASAN_START(&me.fake, g->mainBottom, g->mainSize);
+    switch_stack(&me.sp, g->mainSp);
+    EMU_ASAN_FINISH(g->f[g->cur].fake, nullptr, nullptr);
+}
 inline void trampoline()
 {
+    EMU_ASAN_FINISH(nullptr, &g->mainBottom, &g->mainSize);
     (*g->body)();
     Fiber& me = g->f[g->cur];
     me.st = DONE; g->live--;
+    EMU_ASAN_START(nullptr, g->mainBottom, g->mainSize);
     switch_stack(&me.sp, g->mainSp);
     die("a finished work-item was resumed");
 }
@@ -163,7 +181,9 @@ inline void run_group(dim3 block, const std::function<void()>& body)
             Fiber& f = G.f[i];
             if (f.st != READY) continue;
             G.cur = i; threadIdx = f.tid; progressed = true;
+            EMU_ASAN_START(&G.mainFake, f.stack, kStack);
             switch_stack(&G.mainSp, f.sp);
+            EMU_ASAN_FINISH(G.mainFake, nullptr, nullptr);
         }
         if (G.live == 0) break;
         if (G.atBarrier == G.live) { for (auto& f : G.f) if (f.st == AT_BARRIER) f.st = READY; G.atBarrier = 0; progressed = true; }

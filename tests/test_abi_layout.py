@@ -118,3 +118,27 @@ def test_no_cpu_fallback_without_gpu():
     table = (ctypes.c_void_p * (B.SIZEOF_TABLE // 8))()
     assert lib.x265hip_setup_primitives(table, 8, 0) == -2      # X265HIP_EDEVICE
     assert all(not p for p in table)
+
+
+def test_python_mirrors_of_the_c_records_have_the_c_size(tmp_path):
+    """The tests and the Python plumbing describe the C ABI's records with ctypes.  A field added to a header and not to its mirror makes the library read past the caller's
+    record (found in round 6 by AddressSanitizer on the emulated library: x265hip_tme_args had grown by two ints).  sizeof of every mirrored record, from the headers through gcc,
+    against ctypes.sizeof of the mirror."""
+    import ctypes as C
+    import subprocess
+    import x265hip  # noqa: F401
+    from x265hip_pkg import frame, host_batch, tme_host
+    import deblock_util
+    import test_ff_host_gpu
+    import test_filters_batch_gpu
+    pairs = [("x265hip_tme_args", frame.TmeArgs), ("x265hip_tme_ref", frame.TmeRef), ("x265hip_la_hme", frame.LaHme), ("x265hip_batch_desc", host_batch.BatchDesc),
+             ("x265hip_tme_host_ref", tme_host.HostRef), ("x265hip_tme_picture_desc", tme_host.PictureDesc), ("x265hip_deblock_pic", deblock_util.DeblockPic),
+             ("x265hip_ff_picture_desc", test_ff_host_gpu.FfDesc), ("x265hip_deblock_job", test_filters_batch_gpu.Job)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "x265hip.h"\n#include "x265hip_frame.h"\n#include "x265hip_ctx.h"\nint main(void) {\n' +
+                   "".join('    printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n, _ in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    c_sizes = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    wrong = {n: (int(c_sizes[n]), C.sizeof(m)) for n, m in pairs if int(c_sizes[n]) != C.sizeof(m)}
+    assert not wrong, "record: (C size, ctypes mirror's size) %s" % wrong

@@ -118,7 +118,8 @@ def test_reference_count_and_picture_size_limits_are_argument_errors():
                     ("refs", (Ref * MAX_REF) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
                     ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 64), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
                     ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t),
-                    ("refLagPixels", C.c_int), ("flags", C.c_int), ("frameParallel", C.c_int), ("ctuFirst", C.c_int), ("ctuCount", C.c_int)]
+                    ("refLagPixels", C.c_int), ("flags", C.c_int), ("frameParallel", C.c_int), ("ctuFirst", C.c_int), ("ctuCount", C.c_int),
+                    ("pirStartCol", C.c_int), ("pirSafeX", C.c_int)]
     lib.x265hip_tme_workspace.restype = C.c_size_t
     buf = np.zeros(4096, np.uint8)
     a = Args()

@@ -35,6 +35,21 @@ assert ME_TASK.itemsize == 76 and ME_RESULT.itemsize == 16 and TU_TASK.itemsize 
 MAX_REF = 16                   # X265HIP_MAX_REF (include/x265hip_frame.h)
 
 
+class TmeRef(C.Structure):                  # x265hip_tme_ref (include/x265hip_frame.h)
+    _fields_ = [("mePlane", C.c_void_p), ("mePhase", C.c_void_p), ("reconPhase", C.c_void_p), ("refTable", C.c_void_p), ("lowresMv", C.c_void_p)]
+
+class TmeArgs(C.Structure):                 # x265hip_tme_args
+    _fields_ = [("isP", C.c_int), ("numRef", C.c_int * 2), ("curPOC", C.c_int), ("temporalMvp", C.c_int), ("refPOC", (C.c_int * 16) * 2),
+                ("searchRange", C.c_int), ("searchMethod", C.c_int), ("subpelRefine", C.c_int),
+                ("picWidth", C.c_int), ("picHeight", C.c_int), ("ctuSize", C.c_int), ("lowresBlocksX", C.c_int),
+                ("curPlane", C.c_void_p), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("planeElems", C.c_int64),
+                ("refs", (TmeRef * MAX_REF) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
+                ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 64), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
+                ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t),
+                ("refLagPixels", C.c_int), ("flags", C.c_int), ("frameParallel", C.c_int), ("ctuFirst", C.c_int), ("ctuCount", C.c_int),
+                ("pirStartCol", C.c_int), ("pirSafeX", C.c_int)]
+
+
 class LaHme(C.Structure):                   # x265hip_la_hme (include/x265hip_frame.h)
     _fields_ = [("lowerRes", C.c_void_p), ("planeElems", C.c_int64), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("widthInCU", C.c_int), ("heightInCU", C.c_int),
                 ("method", C.c_int * 2), ("range", C.c_int * 2), ("mvs", C.c_void_p), ("mvCosts", C.c_void_p)]
@@ -179,18 +194,7 @@ class FrameApi:
     def tme_frame(self, *, is_p, num_ref, cur_poc, temporal_mvp, ref_poc, merange, method, subme, lams, qp_index, width, height, ctu, lowres_blocks_x, cur, stride, origin, plane_elems,
                   refs, table, area_best, temporal, cost_rows, cost_half, bits_row, bits_half, steps, flags=0, ref_lag=0, frame_parallel=False):
         """x265hip_tme_frame; refs[l][r] = dict(me_plane, me_phase, recon_phase, ref_table or None, lowres_mv or None) of device tensors; steps: host TME_STEP array"""
-        class Ref(C.Structure):
-            _fields_ = [("mePlane", C.c_void_p), ("mePhase", C.c_void_p), ("reconPhase", C.c_void_p), ("refTable", C.c_void_p), ("lowresMv", C.c_void_p)]
-        class Args(C.Structure):
-            _fields_ = [("isP", C.c_int), ("numRef", C.c_int * 2), ("curPOC", C.c_int), ("temporalMvp", C.c_int), ("refPOC", (C.c_int * 16) * 2),
-                        ("searchRange", C.c_int), ("searchMethod", C.c_int), ("subpelRefine", C.c_int),
-                        ("picWidth", C.c_int), ("picHeight", C.c_int), ("ctuSize", C.c_int), ("lowresBlocksX", C.c_int),
-                        ("curPlane", C.c_void_p), ("stride", C.c_ssize_t), ("origin", C.c_int64), ("planeElems", C.c_int64),
-                        ("refs", (Ref * MAX_REF) * 2), ("table", C.c_void_p), ("areaBest", C.c_void_p), ("temporal", C.c_void_p),
-                        ("nQp", C.c_int), ("qpIndex", C.c_void_p), ("costRows", C.c_void_p), ("costHalfRange", C.c_int), ("lambdas", C.c_uint64 * 64), ("bitsRow", C.c_void_p), ("bitsHalfRange", C.c_int),
-                        ("steps", C.c_void_p), ("nSteps", C.c_int), ("workspace", C.c_void_p), ("workspaceBytes", C.c_size_t),
-                        ("refLagPixels", C.c_int), ("flags", C.c_int), ("frameParallel", C.c_int), ("ctuFirst", C.c_int), ("ctuCount", C.c_int)]
-        a = Args()
+        a = TmeArgs()
         a.isP = int(is_p); a.numRef[0], a.numRef[1] = int(num_ref[0]), int(num_ref[1]); a.curPOC = int(cur_poc); a.temporalMvp = int(temporal_mvp)
         for l in range(2):
             for r in range(16): a.refPOC[l][r] = int(ref_poc[l][r])
