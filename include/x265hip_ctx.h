@@ -273,8 +273,8 @@ typedef struct x265hip_ff_picture_desc
                                                   under frame threads the next pictures wait for the rows it finishes): only these rows' CTUs are deblocked -- the band's top edge
                                                   included, which changes the last 3 luma / 1 chroma lines of the row above -- and only their statistics are written.  The arrays and
                                                   planes keep the picture's addressing; read: the CU arrays of the band's rows and of the row above, the reconstruction from 8 luma lines
-                                                  above the band (the row above as the previous band left it: deblocked, SAO not yet applied) to the band's last line; written back: the
-                                                  same lines.  Bands of a picture must come in increasing order; bands of different pictures may interleave.  0, 0 = the whole picture */
+                                                  above the band (the row above as the previous band left it: deblocked, SAO not yet applied) to the band's last line; written back: from
+                                                  4 luma lines above the band.  A band that begins the picture or a slice (pic.sliceFirstRow) reads and writes nothing above itself.  Bands of a picture must come in increasing order; bands of different pictures may interleave.  0, 0 = the whole picture */
 } x265hip_ff_picture_desc;
 int  x265hip_ff_picture(x265hip_ff* ff, const x265hip_ff_picture_desc* desc);
 

@@ -81,7 +81,9 @@ int g_bandRows;                              /* X265FF_BAND_ROWS: rows a band wa
 struct Band
 {
     const FrameData* data = nullptr;
-    int done = 0;                            /* CTU rows [0, done) of the picture are filtered and replayed */
+    std::mutex mu;                           /* the slices of a picture finish their rows side by side (WPP): the state below and the staging arrays' sizes change under it */
+    std::vector<int> sliceOfRow, sliceFirst, sliceDone;      /* --slices: the slice of every CTU row, its first row, and how far its rows are filtered and replayed (one slice: [0 ...], [0], [done]) */
+    int rowsThrough = 0;                     /* rows of the picture filtered and replayed so far (all slices) */
     Staging st;                              /* picture-addressed; a band fills its rows (+ the row above) */
     Replay replay;
 };
@@ -102,7 +104,6 @@ thread_local Replay* t_replay = nullptr;
 bool takes(const FrameFilter& ff, const x265_param& p, const Frame* frame, bool useSao)
 {
     if (!(g_on && (p.bEnableLoopFilter || useSao) && ff.m_parallelFilter && p.internalCsp != X265_CSP_I400 && frame)) return false;
-    if (p.frameNumThreads > 1 && p.maxSlices > 1) return false;             /* slices finish in any order and pictures overlap: the encoder's own filters */
     const PicYuv& rp = *frame->m_reconPic[0]; const PicYuv& fp = *frame->m_fencPic;
     return fp.m_picCsp == p.internalCsp && rp.m_stride == fp.m_stride && rp.m_strideC == fp.m_strideC && !(p.sourceWidth & 7) && !(p.sourceHeight & 7);
 }
@@ -127,6 +128,20 @@ void calcSaoStatsCTU_cpu(SAO* self, int addr, int plane) __asm__("xff_calcSaoSta
 void processTasks_cpu(FrameFilter::ParallelFilter* self, int workerThreadId) __asm__("xff_processTasks_cpu");
 
 namespace {
+/* --slices: the slice of every CTU row and every slice's first row (FrameEncoder::init, frameencoder.cpp:131-146) */
+void slice_rows(const x265_param& p, int numRows, std::vector<int>& of, std::vector<int>& first)
+{
+    of.assign((size_t)numRows, 0); first.assign(1, 0);
+    if (p.maxSlices <= 1) return;
+    const uint32_t accu = ((uint32_t)numRows << 8) / p.maxSlices;
+    uint32_t rowSum = accu, sidx = 0;
+    for (uint32_t i = 0; i < (uint32_t)numRows; i++)
+    {
+        if ((i >= (rowSum >> 8)) & (sidx != (uint32_t)p.maxSlices - 1)) { rowSum += accu; ++sidx; first.push_back((int)i); }
+        of[i] = (int)sidx;
+    }
+}
+
 /* CUData's per-partition arrays of the CTU rows [rowA, row1) into the picture-addressed staging arrays, and the description of the call (the whole picture: rowA = 0,
    row1 = the picture's rows; a band: the row above it included -- its CUs are the P side of the band's top edge) */
 void describe(FrameFilter& ff, Staging& S, int rowA, int row1, x265hip_ff_picture_desc& d, std::vector<uint8_t>& sliceFirstRow)
@@ -170,9 +185,11 @@ void describe(FrameFilter& ff, Staging& S, int rowA, int row1, x265hip_ff_pictur
     d.fencY = fenc->m_picOrg[0]; d.fencCb = fenc->m_picOrg[1]; d.fencCr = fenc->m_picOrg[2];
     /* --slices: the CTU rows that begin a slice, as the encoder flagged their CTUs (CUData::initCTU, frameencoder.cpp:1669) */
     if (p.maxSlices > 1)
-    {
+    {   /* (the rows of a slice as FrameEncoder::init deals them, frameencoder.cpp:131-146 -- the flags of CTUs whose rows have not started yet are not looked at) */
+        std::vector<int> of, first;
+        slice_rows(p, ff.m_numRows, of, first);
         sliceFirstRow.assign((size_t)ff.m_numRows + 1, 0);
-        for (int r = 1; r < ff.m_numRows; r++) sliceFirstRow[r] = encData.getPicCTU(r * ncols)->m_bFirstRowInSlice;
+        for (int r = 1; r < ff.m_numRows; r++) sliceFirstRow[r] = of[r] != of[r - 1];
         d.pic.sliceFirstRow = sliceFirstRow.data();
     }
     d.deblock = p.bEnableLoopFilter;
@@ -189,16 +206,28 @@ void processBand(FrameFilter* ff, int row, int layer)
     const x265_param& p = *ff->m_param;
     Band& B = band_of(ff);
     FrameData& encData = *ff->m_frame->m_encData;
-    if (row == 0 || B.data != &encData) { B.data = &encData; B.done = 0; }          /* the FrameFilter holds a new picture */
-    if (row < B.done) return;                                                       /* (cannot happen with one slice: rows come once, in order) */
     const int numRows = ff->m_numRows, wait = g_bandRows > 0 ? g_bandRows : 4;
-    if (row != numRows - 1 && row + 1 - B.done < wait) return;                      /* the row waits for its band */
-    const int r0 = B.done, r1 = row + 1;
-    const double t0 = now();
+    int r0, r1;
     x265hip_ff_picture_desc d;
     std::vector<uint8_t> sliceFirstRow;
-    describe(*ff, B.st, r0 > 0 ? r0 - 1 : 0, r1, d, sliceFirstRow);
-    if (r0 > 0 || r1 < numRows) { d.ctuRowFirst = r0; d.ctuRowCount = r1 - r0; }
+    const double t0 = now();
+    {
+        std::lock_guard<std::mutex> bg(B.mu);
+        if (B.data != &encData || (int)B.sliceOfRow.size() != numRows)
+        {   /* another picture geometry / FrameData behind this FrameFilter */
+            B.data = &encData; B.rowsThrough = 0;
+            slice_rows(p, numRows, B.sliceOfRow, B.sliceFirst);
+            B.sliceDone = B.sliceFirst;
+        }
+        const int s = B.sliceOfRow[row], sFirst = B.sliceFirst[s], sEnd = s + 1 < (int)B.sliceFirst.size() ? B.sliceFirst[s + 1] : numRows;
+        if (row == sFirst) B.sliceDone[s] = sFirst;                                  /* the slice's first row: a new picture's rows begin (a slice's rows come once, in order) */
+        if (row < B.sliceDone[s]) return;
+        if (row != sEnd - 1 && row + 1 - B.sliceDone[s] < wait) return;              /* the row waits for its band (a band stays inside its slice) */
+        r0 = B.sliceDone[s]; r1 = row + 1;
+        B.sliceDone[s] = r1;                                                         /* claimed: the rows above it in this slice cannot call again */
+        describe(*ff, B.st, (r0 > sFirst) ? r0 - 1 : r0, r1, d, sliceFirstRow);      /* (the row above the band is the P side of its top edge -- not across a slice's first row) */
+        if (r0 > 0 || r1 < numRows) { d.ctuRowFirst = r0; d.ctuRowCount = r1 - r0; }
+    }
     const double t1 = now();
     double t2;
     {
@@ -209,19 +238,19 @@ void processBand(FrameFilter* ff, int row, int layer)
         t2 = now();
         if (rc) { fprintf(stderr, "filter_adapter: x265hip_ff_picture (POC %d, CTU rows %d..%d): %d %s\n", encData.m_slice->m_poc, r0, r1 - 1, rc, g_api.last_error()); die(); }
     }
-    Replay& rp = B.replay;
+    Replay& rp = B.replay;                                                           /* (the same values whichever slice's band writes them) */
     rp.data = &encData; rp.deblocked = p.bEnableLoopFilter != 0;
-    if (r0 == 0) { rp.skipped = 0; rp.served = 0; }
     rp.stats[0] = (d.saoStats & 1) ? B.st.stats[0].data() : NULL;
     rp.stats[1] = (d.saoStats & 2) ? B.st.stats[1].data() : NULL; rp.stats[2] = (d.saoStats & 2) ? B.st.stats[2].data() : NULL;
     t_replay = &rp;
     for (int r = r0; r < r1; r++) ::processRow_cpu(ff, r, layer);
     t_replay = nullptr;
-    B.done = r1;
     const double t3 = now();
+    bool whole;
+    { std::lock_guard<std::mutex> bg(B.mu); B.rowsThrough += r1 - r0; whole = B.rowsThrough == numRows; if (whole) B.rowsThrough = 0; }
     std::lock_guard<std::mutex> sg(g_statLock);
     g_stats.bands++;
-    if (r1 == numRows) { g_stats.pictures++; g_stats.deblockSkipped += rp.skipped.load(); g_stats.statsServed += rp.served.load(); }
+    if (whole) { g_stats.pictures++; g_stats.deblockSkipped += rp.skipped.exchange(0); g_stats.statsServed += rp.served.exchange(0); }
     g_stats.gatherSeconds += t1 - t0; g_stats.producerSeconds += t2 - t1; g_stats.replaySeconds += t3 - t2;
 }
 } // namespace

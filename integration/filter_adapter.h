@@ -7,13 +7,14 @@
  * statistics of every CTU, then the encoder's own row loop runs over all rows with deblockCTU a no-op and calcSaoStatsCTU a table look-up -- the SAO decision (rdoSaoUnitCu
  * with the encoder's entropy coder), the SAO itself, border extension, PSNR / SSIM / hashes and the row flags are the encoder's own code.  The encoder's bodies stay
  * available under the names processRow_cpu / deblockCTU_cpu / calcSaoStatsCTU_cpu (a maintainer renames the three members; oracle/Makefile target e2e2 does it at the
- * object level without touching a source file) and run when the adapter is not loaded, and for what the producer does not offer: 4:0:0, picture sizes that are not multiples
- * of 8, --slices together with frame threads.
+ * object level without touching a source file) and run when the adapter is not loaded, and for what the producer does not offer: 4:0:0 and picture sizes that are not
+ * multiples of 8.
  *
  * Frame threads (the encoder's default): the next pictures wait for the rows this picture's filters finish (Frame::m_reconRowFlag, set by processPostRow), so a picture cannot
  * wait for its last row.  There the binding works in BANDS of CTU rows: the rows pass until X265FF_BAND_ROWS of them (default 4) are waiting or the picture's last row arrives,
  * then one x265hip_ff_picture call with desc.ctuRowFirst / ctuRowCount deblocks those rows (their top edge changes the last lines of the row above) and takes their statistics,
- * and the encoder's own row loop runs over the band's rows.  The fourth member the binding defines for that, FrameFilter::ParallelFilter::processTasks, is the entry the ROW
+ * and the encoder's own row loop runs over the band's rows.  With --slices a band stays inside its slice (a slice's rows are a chain of their own; the slices of a picture and the
+ * pictures in flight interleave on the one producer).  The fourth member the binding defines for that, FrameFilter::ParallelFilter::processTasks, is the entry the ROW
  * ENCODERS use to start a row's deblocking early (frameencoder.cpp:2067-2076): in band mode that call returns at once -- the row is filtered with its band (the call from
  * processRow itself keeps the encoder's body, xff_processTasks_cpu).
  */

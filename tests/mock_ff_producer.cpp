@@ -23,7 +23,7 @@ typedef uint16_t xo_pixel;     /* -DMOCK_DEPTH=10: the 10-bit encoder with the 1
 typedef uint8_t xo_pixel;      /* the 8-bit encoder */
 #endif
 struct x265hip_ctx { int device; };
-struct x265hip_ff { int width, height, ctu; intptr_t strideY, strideC; long calls = 0, bands = 0, pictures = 0; std::mutex mu; std::map<const void*, int> rowsDone; /* per picture in flight (keyed by its luma plane): CTU rows filtered so far */ };
+struct x265hip_ff { int width, height, ctu; intptr_t strideY, strideC; long calls = 0, bands = 0, pictures = 0; std::mutex mu; std::map<const void*, std::map<int, int>> rowsDone; std::map<const void*, int> rowsTotal; /* per picture in flight (keyed by its luma plane): per slice (its first row) the rows filtered so far; rows in all */ };
 
 namespace {
 char g_err[512] = "";
@@ -82,11 +82,22 @@ int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* d)
     /* bands of a picture (include/x265hip_ctx.h: desc.ctuRowFirst / ctuRowCount): in increasing order, contiguous, each row once; bands of different pictures may interleave */
     if (d->ctuRowFirst < 0 || d->ctuRowCount < 0 || d->ctuRowFirst + d->ctuRowCount > nrows || (d->ctuRowFirst && !d->ctuRowCount)) return fail("ff_picture: CTU rows %d + %d of %d", d->ctuRowFirst, d->ctuRowCount, nrows);
     const int r0 = d->ctuRowFirst, r1 = d->ctuRowCount ? r0 + d->ctuRowCount : nrows;
-    {
-        int& done = f->rowsDone[d->reconY];
-        if (r0 != done) return fail("ff_picture: band starts at CTU row %d, the picture's rows done are %d", r0, done);
-        done = r1;
-        if (r1 == nrows) { f->rowsDone.erase(d->reconY); f->pictures++; }
+    {   /* a picture's bands: inside one slice each, a slice's bands in increasing order and contiguous, every row once; the slices of a picture (and pictures) may interleave */
+        int s0 = r0;
+        while (s0 > 0 && !(P.sliceFirstRow && P.sliceFirstRow[s0])) s0--;
+        for (int r = r0 + 1; r < r1; r++) if (P.sliceFirstRow && P.sliceFirstRow[r] && (r0 > 0 || r1 < nrows)) return fail("ff_picture: the band of CTU rows %d..%d crosses the slice that begins at row %d", r0, r1 - 1, r);
+        std::map<int, int>& slices = f->rowsDone[d->reconY];
+        const bool whole = r0 == 0 && r1 == nrows;
+        if (!whole)
+        {
+            if (!slices.count(s0)) slices[s0] = s0;
+            if (r0 != slices[s0]) return fail("ff_picture: band starts at CTU row %d, the rows done of its slice (first row %d) are %d", r0, s0, slices[s0]);
+            slices[s0] = r1;
+        }
+        int& total = f->rowsTotal[d->reconY];
+        total += r1 - r0;
+        if (total > nrows) return fail("ff_picture: %d rows of a picture of %d", total, nrows);
+        if (total == nrows) { f->rowsDone.erase(d->reconY); f->rowsTotal.erase(d->reconY); f->pictures++; }
     }
     if (d->ctuRowCount) f->bands++;
     if (P.chromaFormat < 0 || P.chromaFormat > 3) return fail("ff_picture: chroma format %d", P.chromaFormat);

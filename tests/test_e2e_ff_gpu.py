@@ -110,11 +110,13 @@ def test_bands_on_request_with_one_frame_thread(tmp_path):
     assert gpu["ff_pictures"] == 8 and gpu["ff_bands"] == 8 * 3 and h_cpu == h_gpu
 
 
-@pytest.mark.parametrize("args", [["256", "320", "6", "medium", "frame-threads=2", "wpp=1", "slices=2"]])      # slices finish in any order while pictures overlap
-def test_what_the_producer_lacks_stays_with_the_encoder(args, tmp_path):
+@pytest.mark.parametrize("args,band_rows", [(["256", "320", "6", "medium", "frame-threads=2", "wpp=1", "slices=2"], None), (["320", "704", "7", "medium", "frame-threads=3", "wpp=1", "slices=3"], "2")])
+def test_slices_under_frame_threads_go_through_the_producer_in_bands_of_their_own(args, band_rows, tmp_path):
+    """--slices with frame threads: the slices of a picture finish their rows side by side while pictures overlap -- a band stays inside its slice, the slices' bands interleave"""
     cpu, h_cpu = encode(8, False, args, str(tmp_path / "cpu.hevc"))
-    gpu, h_gpu = encode(8, True, args, str(tmp_path / "gpu.hevc"))
-    assert gpu["ff_pictures"] == 0 and gpu["ff_cpu_pictures"] == 6 and h_cpu == h_gpu
+    gpu, h_gpu = encode(8, True, args, str(tmp_path / "gpu.hevc"), extra_env={"X265FF_BAND_ROWS": band_rows} if band_rows else None)
+    n = int(args[2])
+    assert gpu["ff_pictures"] == n and gpu["ff_cpu_pictures"] == 0 and gpu["ff_bands"] >= 2 * n and h_cpu == h_gpu
 
 
 def test_all_three_seams_together_under_frame_threads(tmp_path):

@@ -90,11 +90,21 @@ def test_bands_with_one_frame_thread_on_request(mock, tmp_path):
     assert wpp["ff_bands"] == 8 * 6 and wpp["md5"] == plain_wpp["md5"]
 
 
-def test_slices_with_frame_threads_keep_the_encoders_own_filters(mock, tmp_path):
-    """--slices together with frame threads: slices finish in any order while pictures overlap -- the binding leaves those pictures to the encoder's own filters and says how many."""
-    r = encode(mock, tmp_path, "sl", 1, size=(256, 320), env={"X265_CLI_THREADING": "1"}, options=("pools=16", "frame-threads=3", "slices=2"))
-    p = encode(mock, tmp_path, "slp", 0, size=(256, 320), env={"X265_CLI_THREADING": "1"}, options=("pools=16", "frame-threads=3", "slices=2"))
-    assert r["rc"] == 0 and p["rc"] == 0 and r["ff_pictures"] == 0 and r["ff_cpu_pictures"] == 8 and r["md5"] == p["md5"]
+@pytest.mark.parametrize("size,options,band_rows", [((256, 320), ("pools=16", "frame-threads=3", "slices=2"), None), ((320, 704), ("pools=24", "frame-threads=4", "slices=3"), "2"),
+                                                    ((256, 512), ("pools=16", "frame-threads=2", "slices=4", "limit-sao=1"), "1")],
+                         ids=lambda v: "+".join(v) if isinstance(v, tuple) and isinstance(v[0], str) else str(v))
+def test_slices_with_frame_threads_filter_in_bands_inside_each_slice(mock, tmp_path, size, options, band_rows):
+    """--slices together with frame threads: the slices of a picture finish their rows side by side (each slice a chain of filter rows of its own) while pictures overlap.  A band
+    stays inside its slice (a slice's top edge is not filtered: m_cuAbove == NULL), the slices' bands of a picture interleave; the mock checks that order, and the bitstream is the
+    plain encoder's"""
+    env = {"X265_CLI_THREADING": "1"}
+    if band_rows:
+        env["X265FF_BAND_ROWS"] = band_rows
+    r = encode(mock, tmp_path, "sl", 1, size=size, env=env, options=options)
+    p = encode(mock, tmp_path, "slp", 0, size=size, env={"X265_CLI_THREADING": "1"}, options=options)
+    assert r["rc"] == 0 and p["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
+    assert r["ff_pictures"] == 8 and r["ff_cpu_pictures"] == 0 and r["ff_bands"] >= 8 * int([o for o in options if o.startswith("slices=")][0].split("=")[1])
+    assert r["md5"] == p["md5"] and r["bytes"] == p["bytes"]
 
 
 def test_a_failing_filter_call_ends_the_encode_at_once(mock, tmp_path):

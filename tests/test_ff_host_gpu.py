@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
 sys.path.insert(0, HERE)
 import x265hip  # noqa: E402
 from oracle_py import Oracle  # noqa: E402
-from deblock_util import I8, U8, DeblockPic, coded_picture, descriptor, run_oracle  # noqa: E402
+from deblock_util import I8, U8, DeblockPic, coded_picture, descriptor, run_oracle, slice_first_row  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -73,10 +73,12 @@ def test_ff_picture_matches_oracle(depth, W, H, ctu, slice_p, bypass, deblock, s
     lib.x265hip_ff_destroy(ff); lib.x265hip_ctx_destroy(ctx)
 
 
-@pytest.mark.parametrize("depth,W,H,ctu,cut,sao,nd,csp", [(8, 256, 320, 64, [1], 3, 0, 1), (10, 320, 328, 64, [2, 1], 3, 0, 1), (8, 200, 168, 32, [3, 1], 3, 1, 1), (8, 128, 136, 16, [4, 1, 2], 1, 0, 1),
-                                                          (10, 1920, 1080, 64, [4], 3, 0, 1), (8, 256, 256, 64, [2], 0, 0, 1),
-                                                          (8, 256, 320, 64, [2, 1], 3, 0, 2), (10, 200, 168, 32, [5], 3, 0, 2), (8, 256, 192, 64, [1, 2], 3, 1, 3), (10, 136, 128, 16, [8], 3, 0, 3)])
-def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd, csp):
+@pytest.mark.parametrize("depth,W,H,ctu,cut,sao,nd,csp,slices", [(8, 256, 320, 64, [1], 3, 0, 1, ()), (10, 320, 328, 64, [2, 1], 3, 0, 1, ()), (8, 200, 168, 32, [3, 1], 3, 1, 1, ()), (8, 128, 136, 16, [4, 1, 2], 1, 0, 1, ()),
+                                                          (10, 1920, 1080, 64, [4], 3, 0, 1, ()), (8, 256, 256, 64, [2], 0, 0, 1, ()),
+                                                          (8, 256, 320, 64, [2, 1], 3, 0, 2, ()), (10, 200, 168, 32, [5], 3, 0, 2, ()), (8, 256, 192, 64, [1, 2], 3, 1, 3, ()), (10, 136, 128, 16, [8], 3, 0, 3, ()),
+                                                          (8, 256, 320, 64, [2, 1, 2], 3, 0, 1, (2,)), (10, 192, 328, 32, [3, 2, 2, 4], 3, 0, 2, (3, 7))])       # --slices: a band stays inside its slice
+
+def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd, csp, slices):
     """desc.ctuRowFirst / ctuRowCount (FrameFilter::processRow's order under frame threads): TWO pictures go through one producer band by band, their bands interleaved -- each
     band reads the CU arrays of its rows and the row above, the planes from 8 lines above it, and writes those lines and its rows' statistics back.  After the last band each
     picture equals the whole-picture result of the oracle; the statistics of a band are taken before the rows below it are deblocked (xo_sao_stats_rows on the oracle's band state).
@@ -99,6 +101,9 @@ def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd, csp):
     pics = []
     for k in range(2):
         pic = coded_picture(depth, W, H, ctu, 900 + 13 * k + W + depth, bool(k), False, csp=csp)
+        if slices:
+            pic["slice_rows"] = slices
+        sfr = slice_first_row(pic)
         rng = np.random.default_rng(50 + k + W)
         dt = pic["planes"][0].dtype
         src = [np.clip(p.astype(np.int32) + rng.integers(-6, 7, p.shape), 0, (1 << depth) - 1).astype(dt) for p in pic["planes"]]
@@ -111,13 +116,17 @@ def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd, csp):
         stats = [np.full(nctu * 320, -9, np.int32) for _ in range(3)]
         d = FfDesc()
         d.pic = descriptor(pic, lambda n, keep=keep: keep[n].ctypes.data)
+        if sfr is not None:
+            d.pic.sliceFirstRow = sfr.ctypes.data
         d.recon[:] = [r.ctypes.data for r in recon]; d.fenc[:] = [f.ctypes.data for f in fenc]
         d.deblock, d.saoStats, d.saoNonDeblocked = 1, sao, nd
         d.stats[:] = [s_.ctypes.data for s_ in stats]
         # the oracle's band state of the same picture (contiguous planes)
         oplanes = [np.ascontiguousarray(p.copy()) for p in pic["planes"]]
         od = descriptor(pic, lambda n, keep=keep: keep[n].ctypes.data)
-        pics.append(dict(pic=pic, src=src, recon=recon, fenc=fenc, keep=keep, stats=stats, d=d, oplanes=oplanes, od=od, want=[np.full(nctu * 320, -9, np.int32) for _ in range(3)]))
+        if sfr is not None:
+            od.sliceFirstRow = sfr.ctypes.data
+        pics.append(dict(pic=pic, sfr=sfr, src=src, recon=recon, fenc=fenc, keep=keep, stats=stats, d=d, oplanes=oplanes, od=od, want=[np.full(nctu * 320, -9, np.int32) for _ in range(3)]))
     bands, r, i = [], 0, 0
     while r < ny:
         h = min(cut[i % len(cut)], ny - r); bands.append((r, r + h)); r += h; i += 1
@@ -137,7 +146,7 @@ def test_ff_picture_in_bands_of_ctu_rows(depth, W, H, ctu, cut, sao, nd, csp):
             assert (S["recon"][c][:, w:] == 3).all(), "the padding of plane %d was touched" % c
             if (c == 0 and sao & 1) or (c > 0 and sao & 2):
                 h, cw_, ch_ = (H, ctu, ctu) if c == 0 else (H >> vs, ctu >> hs, ctu >> vs)
-                ora.lib.xo_sao_stats_rows_wh(P(np.ascontiguousarray(S["src"][c])), P(S["oplanes"][c]), C.c_ssize_t(w), w, h, cw_, ch_, nd, 0 if c == 0 else 2, P(S["want"][c]), None, r0, r1)
+                ora.lib.xo_sao_stats_rows_wh(P(np.ascontiguousarray(S["src"][c])), P(S["oplanes"][c]), C.c_ssize_t(w), w, h, cw_, ch_, nd, 0 if c == 0 else 2, P(S["want"][c]), P(S["sfr"]) if S["sfr"] is not None else None, r0, r1)
             assert np.array_equal(S["stats"][c], S["want"][c]), "picture %d: statistics of plane %d after rows %d..%d (entries outside the bands so far must be untouched)" % (k, c, r0, r1 - 1)
     for S in pics:
         whole = run_oracle(ora, S["pic"])

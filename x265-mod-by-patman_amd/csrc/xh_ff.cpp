@@ -86,8 +86,12 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
     { set_error("ff_picture: CTU rows %d + %d of %d", d->ctuRowFirst, d->ctuRowCount, nRows); return X265HIP_EARG; }
     // the band (the whole picture without one): CTU rows [r0, r1); moved and computed: the CU arrays from the row above the band, the planes from 8 luma lines above it
     const int r0 = d->ctuRowFirst, r1 = d->ctuRowCount ? r0 + d->ctuRowCount : nRows;
-    const int rA = std::max(r0 - 1, 0);                                              // the row whose CUs are the P side of the band's top edge
-    const int y0 = std::max(r0 * f->ctu - 8, 0), y1 = std::min(r1 * f->ctu, f->height), ys = r0 * f->ctu;      // luma lines moved; first line of the band
+    // the band's top edge is filtered unless the band begins the picture or a slice (desc.pic.sliceFirstRow: the CTUs above are no neighbours).  Only then the row above takes
+    // part: its CUs are the P side of the edge, 4 of its luma lines are read and 3 written (8 are moved up, 4 down).  Otherwise NOTHING above the band is touched -- with --slices
+    // under frame threads the rows above belong to another slice, whose own bands (and the encoder's SAO behind them) may be working on them at this very moment
+    const bool topEdge = r0 > 0 && !(P.sliceFirstRow && P.sliceFirstRow[r0]);
+    const int rA = topEdge ? r0 - 1 : r0;
+    const int ys = r0 * f->ctu, y0 = topEdge ? ys - 8 : ys, yBack = topEdge ? ys - 4 : ys, y1 = std::min(r1 * f->ctu, f->height);      // luma lines: first of the band, first moved up, first moved back down
     std::lock_guard<std::mutex> g(f->mu);
     XH_HIP(hipSetDevice(x265hip_ctx_device(f->ctx)));
     hipStream_t st = (hipStream_t)x265hip_ctx_stream(f->ctx);
@@ -124,7 +128,7 @@ extern "C" int x265hip_ff_picture(x265hip_ff* f, const x265hip_ff_picture_desc* 
         int rc = x265hip_deblock_rows(st, &D, f->recon[0], f->strideY, f->recon[1], f->recon[2], f->strideC, nullptr, r0, r1);
         if (rc) return rc;
         for (int p = 0; p < 3; p++)
-            XH_HIP(hipMemcpy2DAsync(at(hostRecon[p], p, y0), pitch(p), at(f->recon[p], p, y0), pitch(p), wbytes(p), line(p, y1) - line(p, y0), hipMemcpyDeviceToHost, st));
+            XH_HIP(hipMemcpy2DAsync(at(hostRecon[p], p, yBack), pitch(p), at(f->recon[p], p, yBack), pitch(p), wbytes(p), line(p, y1) - line(p, yBack), hipMemcpyDeviceToHost, st));
     }
     for (int p = 0; p < 3; p++)
     {
