@@ -33,7 +33,7 @@ def mock(tmp_path_factory):
 def encode(mock, tmp_path, name, la_ff, env, options):
     outp = str(tmp_path / (name + ".hevc"))
     e = dict(os.environ, X265MOCK_REAL_LIB=REAL, X265MOCK_ORACLE_LIB=ORACLE, X265TMEGPU="1", X265LAGPU=str(la_ff), X265FFGPU=str(la_ff), **env)
-    r = subprocess.run([EXE, mock, "832", "480", "12", "medium", outp] + list(options), capture_output=True, text=True, env=e, timeout=300)
+    r = subprocess.run([EXE, mock, "640", "368", "12", "medium", outp] + list(options), capture_output=True, text=True, env=e, timeout=300)
     assert r.returncode == 0 and "PROTOCOL VIOLATION" not in r.stderr, r.stderr[-600:]
     info = json.loads(r.stdout.strip().splitlines()[-1])
     info["md5"] = hashlib.md5(open(outp, "rb").read()).hexdigest()

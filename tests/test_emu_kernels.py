@@ -49,30 +49,25 @@ def test_the_emulated_library_is_the_librarys_own_sources(emulated_library):
         assert "X265HIP_EMU" not in src and "tests/emu" not in src, path + " must not know the emulation"
 
 
-def test_every_table_slot_and_batched_entry_point(emulated_library):
-    """the table's slots against the oracle (test_hip_parity.py), the reference's golden vectors (test_golden.py, test_filters_golden.py,
-    test_lookahead_golden.py), the batched entry points (test_batch_api_gpu.py), deblocking and SAO statistics (small pictures)"""
-    print(run_gpu_tests(emulated_library, ["tests/test_hip_parity.py", "tests/test_golden.py", "tests/test_filters_golden.py", "tests/test_batch_api_gpu.py",
-                                           "tests/test_sao_gpu.py", "tests/test_deblock_gpu.py", "-k", "not 1920"]))
-
-
-def test_motion_search_and_the_batch_pipeline(emulated_library):
-    """a9 / a21: motionEstimate in every method on the kernels' lane groups, and the C++ host's batch (phase planes, the ME pyramid, the choice among references, TQ) against the
-    oracle -- P and B pictures, rect, AMP, streams"""
-    print(run_gpu_tests(emulated_library, ["tests/test_me_gpu.py::test_me_batch_matches_oracle", "tests/test_me_gpu.py::test_star_search_from_a_start_outside_the_window",
-                                           "tests/test_host_batch_gpu.py::test_host_batch_matches_oracle", "tests/test_tq_gpu.py", "-k", "not whole and not 1080 and not 2160 and not 4320 and not full_size"]))
-
-
-def test_the_filter_producer_in_bands_and_the_lookahead(emulated_library):
-    """f4 (this round's band form of x265hip_ff_picture: two pictures interleaved through one producer, against the oracle's row forms) and f2 (lowres costs, --hme, cuTree)"""
-    print(run_gpu_tests(emulated_library, ["tests/test_ff_host_gpu.py", "tests/test_lookahead_gpu.py", "-k", "not 1920 and not 640"]))
+def test_kernels_against_the_oracle_and_the_golden_vectors(emulated_library):
+    """SURVEY 8(a) a2-a25 and f2 / f4 on the CPU: every table slot against the oracle (test_hip_parity.py) and the reference's golden vectors (test_golden.py), the batched entry
+    points (test_batch_api_gpu.py), the C++ host's batch -- phase planes, the ME pyramid in HEX and STAR, rect / AMP, P and B pictures, the choice among references, TQ -- against
+    the oracle (three of test_host_batch_gpu.py's configurations), a lowres frame-cost batch, and this round's band form of the filter producer (two pictures interleaved through
+    one producer; 4:2:0 with slices, 4:2:2, 4:4:4) against the oracle's row forms.  (Everything that is not full-size: tests/emu/run_gpu_suite.sh.)"""
+    print(run_gpu_tests(emulated_library, ["tests/test_hip_parity.py", "tests/test_golden.py", "tests/test_batch_api_gpu.py",
+                                           "tests/test_host_batch_gpu.py::test_host_batch_matches_oracle[8-1-2-1-False-1-False-0]",
+                                           "tests/test_host_batch_gpu.py::test_host_batch_matches_oracle[10-3-3-1-True-1-False-0]",
+                                           "tests/test_host_batch_gpu.py::test_host_batch_matches_oracle[8-3-3-2-True-2-True-1]",
+                                           "tests/test_lookahead_gpu.py::test_lookahead_batch_matches_oracle[size2-1-shift2-8]",
+                                           "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[8-256-320-64-cut0-3-0-1-slices0]",
+                                           "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[8-256-320-64-cut10-3-0-1-slices10]",
+                                           "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[10-200-168-32-cut7-3-0-2-slices7]",
+                                           "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[8-256-192-64-cut8-3-1-3-slices8]"], jobs=6))
 
 
 def test_the_producers_inside_the_reference_encoder(emulated_library):
-    """f1 / f4 end to end on the CPU: the compiled reference encoder with the EMULATED library as its ThreadedME producer (incl. this round's --intra-refresh windows, 8 and 10 bit,
-    and bands under frame threads) and as its filter producer in bands under frame threads -- the bitstream of the encoder's own producers / filters"""
+    """f1 / f4 end to end on the CPU: the compiled reference encoder with the EMULATED library as its ThreadedME producer (one frame thread; this round's --intra-refresh windows;
+    bands under frame threads) and as its filter producer (bands inside slices under frame threads) -- the bitstream of the encoder's own producers / filters"""
     print(run_gpu_tests(emulated_library, ["tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer[8-args0]", "tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer[8-args12]",
-                                           "tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer[10-args13]",
                                            "tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer_under_frame_threads[8-args1]",
-                                           "tests/test_e2e_ff_gpu.py::test_bitstream_identical_with_gpu_filters_under_frame_threads[8-args1-1]",
-                                           "tests/test_e2e_ff_gpu.py::test_bands_on_request_with_one_frame_thread"], jobs=6))
+                                           "tests/test_e2e_ff_gpu.py::test_slices_under_frame_threads_go_through_the_producer_in_bands_of_their_own[args0-None]"], jobs=5))

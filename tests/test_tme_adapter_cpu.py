@@ -56,8 +56,8 @@ def test_bands_under_frame_threads_follow_the_protocol_and_do_not_move_the_bitst
 
 def test_one_frame_thread_hands_over_whole_pictures(mock, tmp_path):
     """One frame thread, no WPP (the driver's default threading): a call per picture, complete references (no valid-row counts), the waiting workers help with the host passes."""
-    a = encode(mock, tmp_path, "a", frames=6)
-    b = encode(mock, tmp_path, "b", frames=6, env={"X265TME_HELP": "0"})
+    a = encode(mock, tmp_path, "a", frames=6, size=(832, 480))
+    b = encode(mock, tmp_path, "b", frames=6, size=(832, 480), env={"X265TME_HELP": "0"})
     for r in (a, b):
         assert r["rc"] == 0 and "PROTOCOL VIOLATION" not in r["stderr"], r["stderr"][-600:]
         assert r["frame_threads"] == 1 and r["gpu_pictures"] == 5 and r["gpu_bands"] == 5
