@@ -71,3 +71,32 @@ def test_the_producers_inside_the_reference_encoder(emulated_library):
     print(run_gpu_tests(emulated_library, ["tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer[8-args0]", "tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer[8-args12]",
                                            "tests/test_e2e_tme_gpu.py::test_bitstream_identical_with_gpu_producer_under_frame_threads[8-args1]",
                                            "tests/test_e2e_ff_gpu.py::test_slices_under_frame_threads_go_through_the_producer_in_bands_of_their_own[args0-None]"], jobs=5))
+
+
+def test_the_bench_line_on_a_few_ctus(emulated_library, tmp_path):
+    """bench.py itself (the driver's contract: ONE JSON line with metric / value / roofline / cpu_baseline) on a 256x128 plumbing workload against the emulated library -- the
+    script's plumbing and the CPU-baseline leg (the reference's C table at -O2 and at -O3 for the host's vector ISA, its results cross-checked against the library's) run without
+    a GPU.  The numbers mean nothing (the emulation has no clock worth reading); the line's shape and the cross-check do."""
+    import json
+    env = dict(os.environ, X265HIP_EMU="1", X265HIP_LIBDIR=emulated_library, PYTHONPATH=EMU + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "plumbing_256x128", "--frames", "2", "--inner", "1", "--steps", "2", "--warmup", "1", "--no-streams-leg",
+                        "--no-tme", "--no-preset-exact", "--no-e2e", "--cpu-ctus", "16"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "bench.py prints ONE JSON line"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "Mpixels/s" and d["dtype"] == "u8" and d["config"]["workload"] == "plumbing_256x128"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    cb = d["cpu_baseline"]
+    if cb["kind"] == "reference":
+        assert "identical" in cb["sample"] and "O2" in cb["builds"] and cb["cores"] >= 1
+        assert all("failed" not in b for b in cb["builds"].values()), cb["builds"]
+
+
+def test_the_drivers_smoke_entry_point(emulated_library):
+    """__graft_entry__.smoke() -- what the driver runs on the GPU box before the bench: the table slots and the frame-level ME + TQ path against the oracle -- on the emulated library"""
+    env = dict(os.environ, X265HIP_EMU="1", X265HIP_LIBDIR=emulated_library, PYTHONPATH=EMU + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stderr[-1500:]
