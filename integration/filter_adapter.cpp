@@ -384,5 +384,6 @@ extern "C" void x265hip_ff_adapter_close(void)
     if (g_ff) { g_api.ff_destroy(g_ff); g_ff = nullptr; }
     if (g_ctx) { g_api.ctx_destroy(g_ctx); g_ctx = nullptr; }
     g_on = 0;
+    { std::lock_guard<std::mutex> bg(g_bandLock); g_bands.clear(); }        /* the FrameFilter objects the band states were keyed on go with their encoder */
 }
 extern "C" void x265hip_ff_adapter_get_stats(x265hip_ff_adapter_stats* o) { std::lock_guard<std::mutex> guard(g_statLock); *o = g_stats; }
