@@ -173,11 +173,20 @@ inline void run_group(dim3 block, const std::function<void()>& body)
         for (int k = 1; k <= 6; k++) top[-k] = nullptr;
         f.sp = (void*)(top - 6);
     }
+    /* The order in which ready work-items get their turn is the emulation's choice, not the program's: a kernel whose result depends on it has a race (an LDS exchange without
+       its __syncthreads() / wave_sync()).  X265HIP_EMU_ORDER = reverse | random[:seed] picks another order (tests/test_emu_kernels.py runs a selection under all three) */
+    static const int orderMode = [] { const char* e = getenv("X265HIP_EMU_ORDER"); return !e ? 0 : !strncmp(e, "reverse", 7) ? 1 : !strncmp(e, "random", 6) ? 2 : 0; }();
+    static uint32_t rnd = [] { const char* e = getenv("X265HIP_EMU_ORDER"); const char* c = e ? strchr(e, ':') : nullptr; return c ? (uint32_t)atoi(c + 1) * 2654435761u + 1u : 12345u; }();
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = orderMode == 1 ? n - 1 - i : i;
     while (G.live > 0)
     {
         bool progressed = false;
-        for (int i = 0; i < n; i++)
+        if (orderMode == 2)
+            for (int i = n - 1; i > 0; i--) { rnd = rnd * 1664525u + 1013904223u; const int j = (int)((rnd >> 8) % (uint32_t)(i + 1)); std::swap(order[i], order[j]); }
+        for (int oi = 0; oi < n; oi++)
         {
+            const int i = order[oi];
             Fiber& f = G.f[i];
             if (f.st != READY) continue;
             G.cur = i; threadIdx = f.tid; progressed = true;

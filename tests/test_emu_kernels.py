@@ -24,8 +24,10 @@ def emulated_library():
     return os.path.join(EMU, "_build")
 
 
-def run_gpu_tests(libdir, node_ids, jobs=4, timeout=900):
+def run_gpu_tests(libdir, node_ids, jobs=4, timeout=900, order=None):
     env = dict(os.environ, X265HIP_EMU="1", X265HIP_LIBDIR=libdir)
+    if order:                                   # the order in which the emulation gives ready work-items their turn: a result that depends on it is a race
+        env["X265HIP_EMU_ORDER"] = order
     r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-p", "no:cacheprovider", "-n", str(jobs)] + list(node_ids), cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=timeout)
     tail = r.stdout[-3000:] + r.stderr[-1000:]
@@ -53,7 +55,8 @@ def test_kernels_against_the_oracle_and_the_golden_vectors(emulated_library):
     """SURVEY 8(a) a2-a25 and f2 / f4 on the CPU: every table slot against the oracle (test_hip_parity.py) and the reference's golden vectors (test_golden.py), the batched entry
     points (test_batch_api_gpu.py), the C++ host's batch -- phase planes, the ME pyramid in HEX and STAR, rect / AMP, P and B pictures, the choice among references, TQ -- against
     the oracle (three of test_host_batch_gpu.py's configurations), a lowres frame-cost batch, and this round's band form of the filter producer (two pictures interleaved through
-    one producer; 4:2:0 with slices, 4:2:2, 4:4:4) against the oracle's row forms.  (Everything that is not full-size: tests/emu/run_gpu_suite.sh.)"""
+    one producer; 4:2:0 with slices, 4:2:2, 4:4:4) against the oracle's row forms -- with the work-items of a workgroup taking their turns in a RANDOM order (a kernel whose
+    result depended on the order would have an LDS exchange without its barrier).  (Everything that is not full-size: tests/emu/run_gpu_suite.sh.)"""
     print(run_gpu_tests(emulated_library, ["tests/test_hip_parity.py", "tests/test_golden.py", "tests/test_batch_api_gpu.py",
                                            "tests/test_host_batch_gpu.py::test_host_batch_matches_oracle[8-1-2-1-False-1-False-0]",
                                            "tests/test_host_batch_gpu.py::test_host_batch_matches_oracle[10-3-3-1-True-1-False-0]",
@@ -62,7 +65,7 @@ def test_kernels_against_the_oracle_and_the_golden_vectors(emulated_library):
                                            "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[8-256-320-64-cut0-3-0-1-slices0]",
                                            "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[8-256-320-64-cut10-3-0-1-slices10]",
                                            "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[10-200-168-32-cut7-3-0-2-slices7]",
-                                           "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[8-256-192-64-cut8-3-1-3-slices8]"], jobs=6))
+                                           "tests/test_ff_host_gpu.py::test_ff_picture_in_bands_of_ctu_rows[8-256-192-64-cut8-3-1-3-slices8]"], jobs=6, order="random:5"))
 
 
 def test_the_producers_inside_the_reference_encoder(emulated_library):
